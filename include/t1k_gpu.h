@@ -1,0 +1,175 @@
+/* include/t1k_gpu.h -- C ABI of libt1k_gpu.so: the MI355X (gfx950) genotyper hot path of T1K.
+ *
+ * The reference (mourisl/T1K) has no library/FFI seam for this path: its seam is the `genotyper` process
+ * (run-t1k:430,434) and, inside it, the C++ methods listed below.  Each entry point names the reference routine it
+ * replaces (paths relative to the reference repository root).  All functions are extern "C", take plain pointers
+ * and sizes, return 0 on success or a negative t1k_status, never throw and never exit().  A t1k_ctx owns one GPU
+ * (one HIP stream); it is driven by one host thread at a time; different contexts are independent.
+ *
+ * Layers:
+ *   (1) device stage API      t1k_ctx_* / t1k_ref_upload / t1k_reads_upload / t1k_assign_batch / t1k_pair_batch /
+ *                             t1k_align_batch / t1k_em_*          -- what a cgo/JNI/ctypes binding would call
+ *   (2) whole-stage job API   t1k_job_*  (host C++ around (1): FASTA/FASTQ parsing, packing, group coalescing,
+ *                             equivalence classes, allele selection, TSV writers) and t1k_genotyper_main(), the
+ *                             argv-compatible replacement of the reference's genotyper main() (Genotyper.cpp:194-738).
+ */
+#ifndef T1K_GPU_H
+#define T1K_GPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  T1K_OK = 0,
+  T1K_ERR_ARG = -1,       /* bad argument */
+  T1K_ERR_DEVICE = -2,    /* HIP error (message in t1k_last_error) */
+  T1K_ERR_CAPACITY = -3,  /* a device arena overflowed; raise the matching t1k_params cap and retry */
+  T1K_ERR_IO = -4,        /* file could not be opened / parsed */
+  T1K_ERR_STATE = -5      /* call made in the wrong order */
+} t1k_status;
+
+typedef struct t1k_ctx t1k_ctx;
+typedef struct t1k_job t1k_job;
+
+/* Genotyper.cpp:218-229 defaults; SeqSet.hpp:760-772 constants */
+typedef struct {
+  int32_t kmer_length;          /* 11 (Genotyper.cpp:207) */
+  int32_t radius;               /* 10 (SeqSet.hpp:763) */
+  int32_t hit_len_required;     /* 31 (SeqSet.hpp:764) */
+  double ref_seq_similarity;    /* -s, default 0.8 */
+  int32_t relax_intron_align;   /* --relaxIntronAlign */
+  int32_t max_assign_cnt;       /* -n, default 2000 */
+  /* device arena sizing (0 = defaults) */
+  int32_t max_read_len;         /* longest read accepted, default 320 */
+  int32_t workgroups;           /* persistent workgroups of the seeding/chaining kernel, default 1024 */
+  int64_t hit_cap_per_wg;       /* u32 hit slots per workgroup */
+  int64_t cand_cap;             /* candidate records per batch */
+  int64_t ovl_cap;              /* overlap records per batch */
+  int64_t row_cap;              /* fragment-row entries per batch */
+} t1k_params;
+
+void t1k_params_default(t1k_params *p);
+
+/* ---- context ------------------------------------------------------------------------------------------------ */
+int t1k_ctx_create(int device, const t1k_params *params, t1k_ctx **out);
+void t1k_ctx_destroy(t1k_ctx *ctx);
+const char *t1k_last_error(const t1k_ctx *ctx);
+int t1k_device_count(void);
+
+/* ---- reference: SeqSet::InputRefSeq + KmerIndex::BuildIndexFromRead (SeqSet.hpp:906-982, KmerIndex.hpp:107-130) --
+ * seqs: nAlleles sequences concatenated as ASCII (ACGT, anything else is treated as N); offsets[nAlleles+1] byte offsets;
+ * exon: one byte per base, non-zero = exon position (_validDiff::exon, SeqSet.hpp:638-723).  Packs to 2-bit + masks,
+ * builds the direct-address 4^k index (postings in (allele, offset) order with the reference's insert rule). */
+int t1k_ref_upload(t1k_ctx *ctx, const char *seqs, const uint64_t *offsets, const uint8_t *exon, uint32_t nAlleles);
+
+/* ---- reads: one batch of read-ends resident in HBM -------------------------------------------------------------
+ * seqs: nReadEnds ASCII reads concatenated; offsets[nReadEnds+1]; weights[nReadEnds] = multiplicity of the read-end
+ * (the run length of identical sequences, Genotyper.cpp:463-480), NULL = all 1. */
+int t1k_reads_upload(t1k_ctx *ctx, const char *seqs, const uint64_t *offsets, const uint32_t *weights, uint32_t nReadEnds);
+
+/* One overlap of a read-end on an allele: SeqSet::_overlap (SeqSet.hpp:89-144) after AssignRead. 48 bytes. */
+typedef struct {
+  int32_t seq_idx, read_start, read_end, seq_start, seq_end, strand;
+  int32_t match_cnt, left_clip, right_clip, relaxed_match_cnt;
+  double similarity;
+} t1k_overlap;
+
+/* SeqSet::AssignRead for every read-end of the uploaded batch (SeqSet.hpp:2119-2303: GetHitsFromRead 1071,
+ * GetOverlapsFromHits 1232, GetOverlapsFromRead 1594, ExtendOverlap 1994, near-best GlobalAlignment + base coverage
+ * 2188-2285).  Results stay on the device; per-base coverage accumulates in the context. */
+int t1k_assign_batch(t1k_ctx *ctx);
+/* copy the overlap lists out (tests / --outputReadAssignment): counts[nReadEnds]; ovl may be NULL to query the total */
+int t1k_overlaps_download(t1k_ctx *ctx, uint32_t *counts, t1k_overlap *ovl, uint64_t cap, uint64_t *total);
+
+/* One kept (fragment, allele) assignment: Genotyper::_readAssignment (Genotyper.hpp:44-56). 24 bytes. */
+typedef struct {
+  int32_t allele_idx, start, end;
+  float weight, qual, adjust_weight;
+} t1k_row_entry;
+
+/* SeqSet::ReadAssignmentToFragmentAssignment + Genotyper::SetReadAssignments for nFragments fragments
+ * (SeqSet.hpp:2310-2655, Genotyper.hpp:778-832).  end1[i]/end2[i] index the uploaded read-ends (end2 NULL = single-end
+ * run, "-u"); hasN[i] != 0 if either mate contains an N (Genotyper.cpp:537-539).  Rows stay on the device. */
+int t1k_pair_batch(t1k_ctx *ctx, const uint32_t *end1, const uint32_t *end2, const uint8_t *hasN, uint32_t nFragments);
+/* rowCounts[nFragments]; fragAssigned[nFragments] = fragmentAssigned flag (Genotyper.cpp:564-565) */
+int t1k_rows_download(t1k_ctx *ctx, uint32_t *rowCounts, uint8_t *fragAssigned, t1k_row_entry *rows, uint64_t cap, uint64_t *total);
+
+/* per-base coverage of each allele's own base (posWeight[pos].count[base], SeqSet.hpp:2253-2274, read back by
+ * GetSeqMissingBaseCoverage 2717-2755).  out[sum of allele lengths], alleles concatenated in upload order. */
+int t1k_coverage_get(t1k_ctx *ctx, int32_t *out, uint64_t cap);
+int t1k_coverage_reset(t1k_ctx *ctx);
+
+/* ---- AlignAlgo::GlobalAlignment (AlignAlgo.hpp:215-421) as a batch --------------------------------------------
+ * job i aligns t = text[tOff[i] .. tOff[i]+tLen[i]) against p = pat[pOff[i] .. +pLen[i]) (ASCII, N = wildcard).
+ * Outputs per job: score, number of MATCH / MISMATCH / indel columns (SeqSet::GetAlignStats, SeqSet.hpp:438-455) and,
+ * if ops != NULL, the edit string (0 match,1 mismatch,2 insert,3 delete) at ops[opsOff[i]..], length in nOps[i]. */
+/* production match-count routine (exact <=3-mismatch fast path + banded forward sweep) on equal-length jobs: nMatch only */
+int t1k_align_count_batch(t1k_ctx *ctx, const char *text, const uint32_t *tOff, const char *pat, const uint32_t *pOff, const uint32_t *len, uint32_t nJobs,
+                          int32_t *nMatch);
+int t1k_align_batch(t1k_ctx *ctx, const char *text, const uint32_t *tOff, const uint32_t *tLen, const char *pat, const uint32_t *pOff,
+                    const uint32_t *pLen, uint32_t nJobs, int32_t *score, int32_t *nMatch, int32_t *nMismatch, int32_t *nIndel, int8_t *ops,
+                    const uint32_t *opsOff, uint32_t *nOps);
+
+/* ---- EM: Genotyper::EMupdate / QuantifyAlleleEquivalentClass inner loop (Genotyper.hpp:372-421, 1234-1314) -------
+ * CSR over read groups: rowPtr[nGroups+1], ecIdx[nnz] (distinct classes of each group in first-appearance order),
+ * count[nGroups] (group read count), ecLen[nEc] (class effective length).  t1k_em_update performs one EMupdate:
+ * x1 = EM(x0); returns sum|x1-x0| in *diff and the expected read counts in ecReadCount (all host pointers).
+ * The summation order is the reference's (bit-identical doubles).  allreduce (may be NULL) is called on the
+ * device-resident partial read-count vector between the E and M steps when the groups are sharded over GPUs. */
+typedef void (*t1k_allreduce_fn)(void *dev_f64, uint64_t n, void *user);
+int t1k_em_setup(t1k_ctx *ctx, const uint64_t *rowPtr, const uint32_t *ecIdx, const double *count, const int32_t *ecLen, uint32_t nGroups,
+                 uint32_t nEc, t1k_allreduce_fn allreduce, void *user);
+int t1k_em_update(t1k_ctx *ctx, const double *x0, double *x1, double *ecReadCount, double *diff);
+
+/* ---- profiling counters of the last t1k_assign_batch (algorithmic-traffic terms of SURVEY.md 8d) --------------- */
+typedef struct {
+  uint64_t read_ends, lookups, postings, hits, groups, candidates, extended, near_best, dp_calls;
+  double ms_seed, ms_chain, ms_extend, ms_select, ms_fullalign, ms_pair, ms_total;
+} t1k_stats;
+int t1k_stats_get(t1k_ctx *ctx, t1k_stats *out);
+
+/* ---- whole-stage job API (host C++ + the device stages above) ------------------------------------------------- */
+/* argv-compatible replacement of the reference's genotyper executable (Genotyper.cpp:194-738). Returns the exit code. */
+int t1k_genotyper_main(int argc, char **argv);
+
+typedef struct {
+  t1k_params dev;
+  double filter_frac, filter_cov, cross_gene_rate, squarem_min_alpha; /* --frac --cov --crossGeneRate --squaremMinAlpha */
+  int32_t allele_digit_units;                                         /* --alleleDigitUnits, -1 = automatic */
+  char allele_delimiter;                                              /* --alleleDelimiter, 0 = automatic */
+  int32_t threads;                                                    /* -t: host parser/packer threads */
+  int32_t device;                                                     /* GPU ordinal */
+  int32_t output_read_assignment;                                     /* --outputReadAssignment */
+  int32_t batch_fragments;                                            /* fragments per device batch (0 = default) */
+} t1k_job_params;
+void t1k_job_params_default(t1k_job_params *p);
+
+int t1k_job_create(const t1k_job_params *p, const char *refFasta, t1k_job **out);
+void t1k_job_destroy(t1k_job *job);
+const char *t1k_job_last_error(const t1k_job *job);
+/* load + keep reads on the host (FASTA/FASTQ, optionally gz); file2 NULL = single-end; barcodeFile may be NULL */
+int t1k_job_load_reads(t1k_job *job, const char *file1, const char *file2, const char *barcodeFile);
+/* or hand reads over from memory: concatenated ASCII + offsets, mates parallel; ids may be NULL ("r<i>") */
+int t1k_job_set_reads(t1k_job *job, const char *seq1, const uint64_t *off1, const char *seq2, const uint64_t *off2, uint32_t nFragments);
+/* move the read batch(es) into HBM ahead of the timed region (bench) */
+int t1k_job_stage_reads(t1k_job *job);
+/* read-end assignment, pairing, coalescing, EC build, EM, allele selection (Genotyper.cpp:451-650) */
+int t1k_job_run(t1k_job *job);
+/* <prefix>_genotype.tsv, _allele.tsv, _aligned*.fa, (_assign.tsv) (Genotyper.cpp:653-718) */
+int t1k_job_write_outputs(t1k_job *job, const char *prefix);
+/* results in memory: one line per gene, same text as _genotype.tsv */
+int t1k_job_genotype_text(t1k_job *job, char *buf, uint64_t cap, uint64_t *needed);
+int t1k_job_counts(t1k_job *job, uint64_t *fragments, uint64_t *assignedFragments, uint64_t *groups, uint64_t *ecs, int32_t *emIterations);
+int t1k_job_stats(t1k_job *job, t1k_stats *out);
+t1k_ctx *t1k_job_ctx(t1k_job *job);
+/* multi-GPU: reads are sharded by the caller (one job per rank); the EM read-count vector is all-reduced through cb */
+int t1k_job_set_allreduce(t1k_job *job, t1k_allreduce_fn cb, void *user);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* T1K_GPU_H */

@@ -1,0 +1,404 @@
+"""ctypes binding of include/t1k_gpu.h (libt1k_gpu.so, built in-tree by __graft_entry__.build()).
+
+There is deliberately no fallback: if the HIP library is missing, or no GPU is visible when a context is created,
+an exception is raised.  Nothing here touches oracle/.
+"""
+import ctypes as C
+import gzip
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def lib_path():
+    return os.path.join(_HERE, "lib", "libt1k_gpu.so")
+
+
+class T1kError(RuntimeError):
+    pass
+
+
+class Params(C.Structure):
+    _fields_ = [("kmer_length", C.c_int32), ("radius", C.c_int32), ("hit_len_required", C.c_int32),
+                ("ref_seq_similarity", C.c_double), ("relax_intron_align", C.c_int32), ("max_assign_cnt", C.c_int32),
+                ("max_read_len", C.c_int32), ("workgroups", C.c_int32), ("hit_cap_per_wg", C.c_int64),
+                ("cand_cap", C.c_int64), ("ovl_cap", C.c_int64), ("row_cap", C.c_int64)]
+
+
+class JobParams(C.Structure):
+    _fields_ = [("dev", Params), ("filter_frac", C.c_double), ("filter_cov", C.c_double),
+                ("cross_gene_rate", C.c_double), ("squarem_min_alpha", C.c_double), ("allele_digit_units", C.c_int32),
+                ("allele_delimiter", C.c_char), ("threads", C.c_int32), ("device", C.c_int32),
+                ("output_read_assignment", C.c_int32), ("batch_fragments", C.c_int32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("read_ends", "lookups", "postings", "hits", "groups", "candidates", "extended",
+                                          "near_best", "dp_calls")] + \
+               [(n, C.c_double) for n in ("ms_seed", "ms_chain", "ms_extend", "ms_select", "ms_fullalign", "ms_pair", "ms_total")]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+OVERLAP_DTYPE = np.dtype([("seq_idx", "<i4"), ("read_start", "<i4"), ("read_end", "<i4"), ("seq_start", "<i4"),
+                          ("seq_end", "<i4"), ("strand", "<i4"), ("match_cnt", "<i4"), ("left_clip", "<i4"),
+                          ("right_clip", "<i4"), ("relaxed_match_cnt", "<i4"), ("similarity", "<f8")])
+ROW_DTYPE = np.dtype([("allele_idx", "<i4"), ("start", "<i4"), ("end", "<i4"), ("weight", "<f4"), ("qual", "<f4"),
+                      ("adjust_weight", "<f4")])
+assert OVERLAP_DTYPE.itemsize == 48 and ROW_DTYPE.itemsize == 24
+
+ALLREDUCE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_uint64, C.c_void_p)
+
+_lib = None
+
+
+def lib():
+    """Load libt1k_gpu.so (fails loudly if it has not been built)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    p = lib_path()
+    if not os.path.exists(p):
+        raise T1kError("%s not found: run `python -c 'import __graft_entry__ as g; g.build()'` first" % p)
+    L = C.CDLL(p)
+    vp, u64p, u32p, u8p, i32p = C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_uint8), C.POINTER(C.c_int32)
+    L.t1k_params_default.argtypes = [C.POINTER(Params)]
+    L.t1k_ctx_create.argtypes = [C.c_int, C.POINTER(Params), C.POINTER(vp)]
+    L.t1k_ctx_destroy.argtypes = [vp]
+    L.t1k_last_error.argtypes = [vp]
+    L.t1k_last_error.restype = C.c_char_p
+    L.t1k_device_count.restype = C.c_int
+    L.t1k_ref_upload.argtypes = [vp, C.c_char_p, vp, vp, C.c_uint32]
+    L.t1k_reads_upload.argtypes = [vp, C.c_char_p, vp, vp, C.c_uint32]
+    L.t1k_assign_batch.argtypes = [vp]
+    L.t1k_overlaps_download.argtypes = [vp, vp, vp, C.c_uint64, u64p]
+    L.t1k_pair_batch.argtypes = [vp, vp, vp, vp, C.c_uint32]
+    L.t1k_rows_download.argtypes = [vp, vp, vp, vp, C.c_uint64, u64p]
+    L.t1k_coverage_get.argtypes = [vp, vp, C.c_uint64]
+    L.t1k_coverage_reset.argtypes = [vp]
+    L.t1k_align_batch.argtypes = [vp, C.c_char_p, vp, vp, C.c_char_p, vp, vp, C.c_uint32, vp, vp, vp, vp, vp, vp, vp]
+    L.t1k_align_count_batch.argtypes = [vp, C.c_char_p, vp, C.c_char_p, vp, vp, C.c_uint32, vp]
+    L.t1k_em_setup.argtypes = [vp, vp, vp, vp, vp, C.c_uint32, C.c_uint32, ALLREDUCE_FN, vp]
+    L.t1k_em_update.argtypes = [vp, vp, vp, vp, vp]
+    L.t1k_stats_get.argtypes = [vp, C.POINTER(Stats)]
+    L.t1k_genotyper_main.argtypes = [C.c_int, C.POINTER(C.c_char_p)]
+    L.t1k_job_params_default.argtypes = [C.POINTER(JobParams)]
+    L.t1k_job_create.argtypes = [C.POINTER(JobParams), C.c_char_p, C.POINTER(vp)]
+    L.t1k_job_destroy.argtypes = [vp]
+    L.t1k_job_last_error.argtypes = [vp]
+    L.t1k_job_last_error.restype = C.c_char_p
+    L.t1k_job_load_reads.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_char_p]
+    L.t1k_job_set_reads.argtypes = [vp, C.c_char_p, vp, C.c_char_p, vp, C.c_uint32]
+    L.t1k_job_stage_reads.argtypes = [vp]
+    L.t1k_job_run.argtypes = [vp]
+    L.t1k_job_write_outputs.argtypes = [vp, C.c_char_p]
+    L.t1k_job_genotype_text.argtypes = [vp, C.c_char_p, C.c_uint64, u64p]
+    L.t1k_job_counts.argtypes = [vp, u64p, u64p, u64p, u64p, i32p]
+    L.t1k_job_stats.argtypes = [vp, C.POINTER(Stats)]
+    L.t1k_job_ctx.argtypes = [vp]
+    L.t1k_job_ctx.restype = vp
+    L.t1k_job_set_allreduce.argtypes = [vp, ALLREDUCE_FN, vp]
+    _lib = L
+    return L
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def _concat(seqs):
+    offs = np.zeros(len(seqs) + 1, dtype=np.uint64)
+    if len(seqs):
+        offs[1:] = np.cumsum([len(s) for s in seqs], dtype=np.uint64)
+    blob = "".join(seqs).encode("ascii")
+    return blob, offs
+
+
+class Context:
+    """One GPU context (t1k_ctx)."""
+
+    def __init__(self, device=0, **kw):
+        L = lib()
+        p = Params()
+        L.t1k_params_default(C.byref(p))
+        for k, v in kw.items():
+            setattr(p, k, v)
+        self.params = p
+        h = C.c_void_p()
+        rc = L.t1k_ctx_create(device, C.byref(p), C.byref(h))
+        if rc != 0:
+            raise T1kError("t1k_ctx_create failed (%d): no usable GPU / bad parameters" % rc)
+        self.h = h
+        self.n_read_ends = 0
+        self.allele_len = None
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise T1kError("%s failed (%d): %s" % (what, rc, lib().t1k_last_error(self.h).decode()))
+
+    def close(self):
+        if self.h:
+            lib().t1k_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def ref_upload(self, seqs, exon_masks=None):
+        blob, offs = _concat(seqs)
+        ex = None
+        if exon_masks is not None:
+            ex = np.concatenate([np.asarray(m, dtype=np.uint8) for m in exon_masks]) if len(seqs) else np.zeros(0, np.uint8)
+        self.allele_len = np.array([len(s) for s in seqs], dtype=np.int64)
+        self._check(lib().t1k_ref_upload(self.h, blob, _ptr(offs), _ptr(ex), len(seqs)), "t1k_ref_upload")
+
+    def reads_upload(self, seqs, weights=None):
+        blob, offs = _concat(seqs)
+        w = None if weights is None else np.asarray(weights, dtype=np.uint32)
+        self.n_read_ends = len(seqs)
+        self._check(lib().t1k_reads_upload(self.h, blob, _ptr(offs), _ptr(w), len(seqs)), "t1k_reads_upload")
+
+    def assign(self):
+        self._check(lib().t1k_assign_batch(self.h), "t1k_assign_batch")
+
+    def overlaps(self):
+        n = self.n_read_ends
+        counts = np.zeros(n, dtype=np.uint32)
+        tot = C.c_uint64()
+        self._check(lib().t1k_overlaps_download(self.h, _ptr(counts), None, 0, C.byref(tot)), "t1k_overlaps_download")
+        out = np.zeros(tot.value, dtype=OVERLAP_DTYPE)
+        self._check(lib().t1k_overlaps_download(self.h, _ptr(counts), _ptr(out), tot.value, C.byref(tot)), "t1k_overlaps_download")
+        return counts, out
+
+    def pair(self, end1, end2, has_n):
+        e1 = np.asarray(end1, dtype=np.uint32)
+        e2 = None if end2 is None else np.asarray(end2, dtype=np.uint32)
+        hn = np.asarray(has_n, dtype=np.uint8)
+        self.n_fragments = len(e1)
+        self._check(lib().t1k_pair_batch(self.h, _ptr(e1), _ptr(e2), _ptr(hn), len(e1)), "t1k_pair_batch")
+
+    def rows(self):
+        n = self.n_fragments
+        counts = np.zeros(n, dtype=np.uint32)
+        assigned = np.zeros(n, dtype=np.uint8)
+        tot = C.c_uint64()
+        self._check(lib().t1k_rows_download(self.h, _ptr(counts), _ptr(assigned), None, 0, C.byref(tot)), "t1k_rows_download")
+        out = np.zeros(tot.value, dtype=ROW_DTYPE)
+        self._check(lib().t1k_rows_download(self.h, _ptr(counts), _ptr(assigned), _ptr(out), tot.value, C.byref(tot)), "t1k_rows_download")
+        return counts, assigned, out
+
+    def coverage(self):
+        tot = int(self.allele_len.sum())
+        out = np.zeros(tot, dtype=np.int32)
+        self._check(lib().t1k_coverage_get(self.h, _ptr(out), tot), "t1k_coverage_get")
+        return out
+
+    def coverage_reset(self):
+        self._check(lib().t1k_coverage_reset(self.h), "t1k_coverage_reset")
+
+    def stats(self):
+        s = Stats()
+        lib().t1k_stats_get(self.h, C.byref(s))
+        return s.as_dict()
+
+    def align_batch(self, texts, pats, want_ops=True):
+        n = len(texts)
+        tb, toff = _concat(texts)
+        pb, poff = _concat(pats)
+        tlen = np.array([len(t) for t in texts], dtype=np.uint32)
+        plen = np.array([len(p) for p in pats], dtype=np.uint32)
+        toff32, poff32 = toff[:-1].astype(np.uint32), poff[:-1].astype(np.uint32)
+        score = np.zeros(n, np.int32); nm = np.zeros(n, np.int32); nx = np.zeros(n, np.int32); ni = np.zeros(n, np.int32)
+        ops_off = np.zeros(n, np.uint32)
+        if n:
+            ops_off[1:] = np.cumsum((tlen + plen + 2)[:-1], dtype=np.uint64).astype(np.uint32)
+        ops = np.zeros(int((tlen + plen + 2).sum()) + 8, np.int8)
+        nops = np.zeros(n, np.uint32)
+        self._check(lib().t1k_align_batch(self.h, tb, _ptr(toff32), _ptr(tlen), pb, _ptr(poff32), _ptr(plen), n, _ptr(score), _ptr(nm),
+                                          _ptr(nx), _ptr(ni), _ptr(ops) if want_ops else None, _ptr(ops_off), _ptr(nops)), "t1k_align_batch")
+        op_list = [ops[ops_off[i]:ops_off[i] + nops[i]].copy() for i in range(n)] if want_ops else None
+        return score, nm, nx, ni, op_list
+
+    def align_count_batch(self, texts, pats):
+        """production match-count routine (exact fast path + banded forward sweep), equal-length jobs"""
+        n = len(texts)
+        tb, toff = _concat(texts)
+        pb, poff = _concat(pats)
+        ln = np.array([len(t) for t in texts], dtype=np.uint32)
+        out = np.zeros(n, np.int32)
+        self._check(lib().t1k_align_count_batch(self.h, tb, _ptr(toff[:-1].astype(np.uint32)), pb, _ptr(poff[:-1].astype(np.uint32)), _ptr(ln), n,
+                                                _ptr(out)), "t1k_align_count_batch")
+        return out
+
+    def em_setup(self, row_ptr, ec_idx, count, ec_len, allreduce=None):
+        self._em_keep = (np.asarray(row_ptr, np.uint64), np.asarray(ec_idx, np.uint32), np.asarray(count, np.float64), np.asarray(ec_len, np.int32))
+        rp, ei, ct, el = self._em_keep
+        self._em_cb = ALLREDUCE_FN(allreduce) if allreduce else C.cast(None, ALLREDUCE_FN)
+        self._em_nec = len(el)
+        self._check(lib().t1k_em_setup(self.h, _ptr(rp), _ptr(ei), _ptr(ct), _ptr(el), len(ct), len(el), self._em_cb, None), "t1k_em_setup")
+
+    def em_update(self, x0):
+        x0 = np.ascontiguousarray(x0, dtype=np.float64)
+        x1 = np.zeros(self._em_nec, np.float64)
+        n = np.zeros(self._em_nec, np.float64)
+        diff = C.c_double()
+        self._check(lib().t1k_em_update(self.h, _ptr(x0), _ptr(x1), _ptr(n), C.byref(diff)), "t1k_em_update")
+        return x1, n, diff.value
+
+
+class Job:
+    """Whole-stage job (t1k_job): host C++ around the device stages; same behaviour as the `genotyper` executable."""
+
+    def __init__(self, ref_fasta, **kw):
+        L = lib()
+        p = JobParams()
+        L.t1k_job_params_default(C.byref(p))
+        for k, v in kw.items():
+            if hasattr(p.dev, k):
+                setattr(p.dev, k, v)
+            elif k == "allele_delimiter":
+                p.allele_delimiter = v.encode() if isinstance(v, str) else v
+            else:
+                setattr(p, k, v)
+        self.params = p
+        h = C.c_void_p()
+        rc = L.t1k_job_create(C.byref(p), ref_fasta.encode(), C.byref(h))
+        if rc != 0:
+            msg = L.t1k_job_last_error(h).decode() if h else "no GPU / cannot read reference"
+            raise T1kError("t1k_job_create failed (%d): %s" % (rc, msg))
+        self.h = h
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise T1kError("%s failed (%d): %s" % (what, rc, lib().t1k_job_last_error(self.h).decode()))
+
+    def close(self):
+        if self.h:
+            lib().t1k_job_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def load_reads(self, f1, f2=None, barcode=None):
+        self._check(lib().t1k_job_load_reads(self.h, f1.encode(), f2.encode() if f2 else None, barcode.encode() if barcode else None), "t1k_job_load_reads")
+
+    def set_reads(self, seqs1, seqs2=None):
+        b1, o1 = _concat(seqs1)
+        b2, o2 = _concat(seqs2) if seqs2 is not None else (None, None)
+        self._check(lib().t1k_job_set_reads(self.h, b1, _ptr(o1), b2, _ptr(o2), len(seqs1)), "t1k_job_set_reads")
+
+    def stage_reads(self):
+        self._check(lib().t1k_job_stage_reads(self.h), "t1k_job_stage_reads")
+
+    def run(self):
+        self._check(lib().t1k_job_run(self.h), "t1k_job_run")
+
+    def write_outputs(self, prefix):
+        self._check(lib().t1k_job_write_outputs(self.h, prefix.encode()), "t1k_job_write_outputs")
+
+    def genotype_text(self):
+        need = C.c_uint64()
+        lib().t1k_job_genotype_text(self.h, None, 0, C.byref(need))
+        buf = C.create_string_buffer(need.value + 1)
+        self._check(lib().t1k_job_genotype_text(self.h, buf, need.value + 1, C.byref(need)), "t1k_job_genotype_text")
+        return buf.value.decode()
+
+    def counts(self):
+        a, b, c, d = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint64()
+        e = C.c_int32()
+        self._check(lib().t1k_job_counts(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(d), C.byref(e)), "t1k_job_counts")
+        return dict(fragments=a.value, assigned_fragments=b.value, groups=c.value, ecs=d.value, em_iterations=e.value)
+
+    def stats(self):
+        s = Stats()
+        lib().t1k_job_stats(self.h, C.byref(s))
+        return s.as_dict()
+
+    def set_allreduce(self, fn):
+        self._cb = ALLREDUCE_FN(fn)
+        self._check(lib().t1k_job_set_allreduce(self.h, self._cb, None), "t1k_job_set_allreduce")
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# small host-side helpers for tests / bench (format conventions of the reference's ReadFiles.hpp / SeqSet::InputRefSeq)
+# ---------------------------------------------------------------------------------------------------------------------
+def _open(path):
+    return gzip.open(path, "rt") if path.endswith(".gz") else open(path, "rt")
+
+
+def read_fastx(path):
+    """-> list of (id, comment, seq).  id loses a trailing /1 or /2 (ReadFiles.hpp:185-189)."""
+    out = []
+    with _open(path) as f:
+        lines = [l.rstrip("\r\n") for l in f]
+    i = 0
+    while i < len(lines):
+        l = lines[i]
+        if not l or l[0] not in ">@":
+            i += 1
+            continue
+        fq = l[0] == "@"
+        head = l[1:].split(None, 1)
+        rid = head[0] if head else ""
+        comment = head[1] if len(head) > 1 else ""
+        if len(rid) >= 2 and rid[-2] == "/" and rid[-1] in "12":
+            rid = rid[:-2]
+        i += 1
+        seq = []
+        while i < len(lines) and not (lines[i][:1] in (">", "@", "+") and lines[i][:1] != ""):
+            seq.append(lines[i])
+            i += 1
+        seq = "".join(seq)
+        if fq and i < len(lines) and lines[i][:1] == "+":
+            i += 1
+            q = 0
+            while i < len(lines) and q < len(seq):
+                q += len(lines[i])
+                i += 1
+        out.append((rid, comment, seq))
+    return out
+
+
+def load_reference_fasta(path):
+    """Reference loading as Genotyper::InitRefSet does it (Genotyper.hpp:707-730): identical sequences collapse onto the
+    first name; exon mask from the header comment (SeqSet.hpp:933-976).  -> names, seqs, exon masks (uint8 arrays), weights"""
+    names, seqs, masks, weights, seen = [], [], [], [], {}
+    for rid, comment, seq in read_fastx(path):
+        if seq in seen:
+            weights[seen[seq]] += 1
+            continue
+        seen[seq] = len(seqs)
+        L = len(seq)
+        exons = []
+        if comment:
+            nums, n = [], 0
+            for ch in comment:
+                if ch.isdigit():
+                    n = n * 10 + int(ch)
+                else:
+                    nums.append(n)
+                    n = 0
+            if n:
+                nums.append(n)
+            if nums:
+                for i in range(1, len(nums), 2):
+                    exons.append((nums[i], nums[i + 1] if i + 1 < len(nums) else 0))
+            else:
+                exons.append((0, L - 1))
+        else:
+            exons.append((0, L - 1))
+        m = np.zeros(L, dtype=np.uint8)
+        for a, b in exons:
+            m[max(a, 0):min(b, L - 1) + 1] = 1
+        names.append(rid); seqs.append(seq); masks.append(m); weights.append(1)
+    return names, seqs, masks, weights

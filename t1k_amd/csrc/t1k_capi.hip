@@ -1,0 +1,435 @@
+// t1k_amd/csrc/t1k_capi.hip -- C ABI (include/t1k_gpu.h), device stage layer: context, reference upload + index build,
+// read upload, the AssignRead batch pipeline, downloads.  Kernels live in t1k_assign.hip / t1k_pair.hip / t1k_em.hip.
+#include <algorithm>
+#include <chrono>
+#include <cstring>
+#include "t1k_dev.h"
+#include "t1k_launch.h"
+
+int t1k_fail(t1k_ctx *ctx, int code, const std::string &msg) {
+  if (ctx) ctx->err = msg;
+  return code;
+}
+
+int t1k_ensure(t1k_ctx *ctx, T1kDevBuf &b, size_t bytes) {
+  if (bytes == 0) bytes = 16;
+  if (b.bytes >= bytes) return 0;
+  if (b.p) { (void)hipFree(b.p); b.p = nullptr; b.bytes = 0; }
+  size_t want = bytes + bytes / 8 + 256;
+  hipError_t e = hipMalloc(&b.p, want);
+  if (e != hipSuccess) { b.p = nullptr; return t1k_fail(ctx, T1K_ERR_DEVICE, std::string("hipMalloc(") + std::to_string(want) + "): " + hipGetErrorString(e)); }
+  b.bytes = want;
+  return 0;
+}
+
+static double nowMs() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+static inline int asciiCode(char c) { return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : 4; }
+
+template <typename T>
+static int uploadVec(t1k_ctx *ctx, const std::vector<T> &v, const void **dst) {
+  T1kDevBuf b;
+  int rc = t1k_ensure(ctx, b, v.size() * sizeof(T));
+  if (rc) return rc;
+  if (!v.empty()) T1K_HIP(ctx, hipMemcpyAsync(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+  T1K_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->refBufs.push_back(b);
+  *dst = b.p;
+  return 0;
+}
+
+
+extern "C" {
+
+void t1k_params_default(t1k_params *p) {
+  memset(p, 0, sizeof(*p));
+  p->kmer_length = 11;
+  p->radius = 10;
+  p->hit_len_required = 31;
+  p->ref_seq_similarity = 0.8;
+  p->relax_intron_align = 0;
+  p->max_assign_cnt = 2000;
+  p->max_read_len = 320;
+  p->workgroups = 512;
+  p->hit_cap_per_wg = 1 << 20;
+  p->cand_cap = 96ll << 20;
+  p->ovl_cap = 64ll << 20;
+  p->row_cap = 64ll << 20;
+}
+
+int t1k_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int t1k_ctx_create(int device, const t1k_params *params, t1k_ctx **out) {
+  if (!out) return T1K_ERR_ARG;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return T1K_ERR_DEVICE;  // no GPU: fail loudly, there is no CPU path
+  if (hipSetDevice(device) != hipSuccess) return T1K_ERR_DEVICE;
+  t1k_ctx *ctx = new t1k_ctx();
+  ctx->device = device;
+  if (params) ctx->prm = *params; else t1k_params_default(&ctx->prm);
+  t1k_params d;
+  t1k_params_default(&d);
+  if (ctx->prm.kmer_length <= 0) ctx->prm.kmer_length = d.kmer_length;
+  if (ctx->prm.radius <= 0) ctx->prm.radius = d.radius;
+  if (ctx->prm.hit_len_required <= 0) ctx->prm.hit_len_required = d.hit_len_required;
+  if (ctx->prm.max_assign_cnt == 0) ctx->prm.max_assign_cnt = d.max_assign_cnt;
+  if (ctx->prm.max_read_len <= 0) ctx->prm.max_read_len = d.max_read_len;
+  if (ctx->prm.workgroups <= 0) ctx->prm.workgroups = d.workgroups;
+  if (ctx->prm.hit_cap_per_wg <= 0) ctx->prm.hit_cap_per_wg = d.hit_cap_per_wg;
+  if (ctx->prm.cand_cap <= 0) ctx->prm.cand_cap = d.cand_cap;
+  if (ctx->prm.ovl_cap <= 0) ctx->prm.ovl_cap = d.ovl_cap;
+  if (ctx->prm.row_cap <= 0) ctx->prm.row_cap = d.row_cap;
+  if (ctx->prm.kmer_length > 14 || ctx->prm.max_read_len > 2000) { delete ctx; return T1K_ERR_ARG; }
+  if (hipStreamCreate(&ctx->stream) != hipSuccess) { delete ctx; return T1K_ERR_DEVICE; }
+  *out = ctx;
+  return T1K_OK;
+}
+
+static void freeBuf(T1kDevBuf &b) {
+  if (b.p) (void)hipFree(b.p);
+  b.p = nullptr; b.bytes = 0;
+}
+
+void t1k_ctx_destroy(t1k_ctx *ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  for (auto &b : ctx->refBufs) freeBuf(b);
+  T1kDevBuf *all[] = {&ctx->bReadAscii, &ctx->bReadOffs, &ctx->bReadBases, &ctx->bReadN, &ctx->bReadLen, &ctx->bReadWeight, &ctx->bWgHits, &ctx->bWgGroups,
+                      &ctx->bWgStage, &ctx->bWgThreadScratch, &ctx->bWgBig, &ctx->bCand, &ctx->bExt, &ctx->bCandStart, &ctx->bCandCount, &ctx->bOvl,
+                      &ctx->bOvlStart, &ctx->bOvlCount, &ctx->bCounters, &ctx->bSlowQueue, &ctx->bSlowScratch, &ctx->bSortScratch, &ctx->bEnd1, &ctx->bEnd2,
+                      &ctx->bHasN, &ctx->bRows, &ctx->bRowStart, &ctx->bRowCount, &ctx->bFragAssigned, &ctx->bPairScratch, &ctx->bEmRowPtr, &ctx->bEmEc,
+                      &ctx->bEmCount, &ctx->bEmLen, &ctx->bEmX0, &ctx->bEmX1, &ctx->bEmN, &ctx->bEmContrib, &ctx->bEmColPtr, &ctx->bEmColIdx, &ctx->bEmScalars};
+  for (auto *b : all) freeBuf(*b);
+  for (auto &b : ctx->bAlign) freeBuf(b);
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+const char *t1k_last_error(const t1k_ctx *ctx) { return ctx ? ctx->err.c_str() : "no context"; }
+
+// ------------------------------------------------------------------------------------------------------------------
+// reference
+// ------------------------------------------------------------------------------------------------------------------
+int t1k_ref_upload(t1k_ctx *ctx, const char *seqs, const uint64_t *offsets, const uint8_t *exon, uint32_t nAlleles) {
+  if (!ctx || !seqs || !offsets || nAlleles == 0 || nAlleles >= (1u << 24)) return t1k_fail(ctx, T1K_ERR_ARG, "t1k_ref_upload: bad arguments");
+  T1K_HIP(ctx, hipSetDevice(ctx->device));
+  for (auto &b : ctx->refBufs) freeBuf(b);
+  ctx->refBufs.clear();
+  const int k = ctx->prm.kmer_length;
+  std::vector<uint64_t> alleleOff(nAlleles);
+  std::vector<uint32_t> alleleLen(nAlleles);
+  uint64_t total = 0;
+  for (uint32_t a = 0; a < nAlleles; ++a) {
+    uint64_t len = offsets[a + 1] - offsets[a];
+    if (len >= (1u << 20)) return t1k_fail(ctx, T1K_ERR_ARG, "allele longer than 2^20 bases");
+    alleleOff[a] = total;
+    alleleLen[a] = (uint32_t)len;
+    total += (len + 31) / 32 * 32;
+  }
+  total += 64;
+  size_t words = total / 32 + 2;
+  std::vector<uint64_t> bases(words, 0), nmask(words, 0), exonm(words, 0);
+  std::vector<uint32_t> sepStart(nAlleles + 1, 0);
+  std::vector<int32_t> sepPos;
+  // index, pass 1: count (KmerIndex::BuildIndexFromRead, KmerIndex.hpp:107-130).  k-mer codes are
+  // little-endian here (first base in the low bits); only equality and "== 0" are ever tested, both convention-free.
+  const size_t nKeys = (size_t)1 << (2 * k);
+  const uint32_t kmask = (uint32_t)(nKeys - 1);
+  std::vector<uint32_t> kStart(nKeys + 1, 0);
+  std::vector<uint32_t> codes;  // per base position, the k-mer code ending there, or ~0u if not inserted
+  std::vector<std::pair<uint32_t, uint32_t>> ins;
+  for (uint32_t a = 0; a < nAlleles; ++a) {
+    const char *s = seqs + offsets[a];
+    const uint32_t len = alleleLen[a];
+    const uint64_t g = alleleOff[a];
+    sepStart[a] = (uint32_t)sepPos.size();
+    uint32_t code = 0, prev = 0;
+    int invalid = -1;
+    for (uint32_t i = 0; i < len; ++i) {
+      int c = asciiCode(s[i]);
+      uint64_t pos = g + i;
+      if (c == 4) { nmask[pos >> 5] |= 1ull << ((pos & 31) * 2); sepPos.push_back((int32_t)i); }
+      else bases[pos >> 5] |= (uint64_t)c << ((pos & 31) * 2);
+      if (exon && exon[offsets[a] + i]) exonm[pos >> 5] |= 1ull << ((pos & 31) * 2);
+      if (invalid != -1) ++invalid;
+      code = (code >> 2) | ((uint32_t)(c == 4 ? 3 : c) << (2 * (k - 1)));
+      code &= kmask;
+      if (c == 4) invalid = 0;
+      if (invalid >= k) invalid = -1;
+      if ((int)i < k - 1) continue;
+      if (invalid == -1 && ((int)i == k || code != prev)) { ins.push_back({code, i - k + 1}); ++kStart[code + 1]; }
+      prev = code;
+    }
+    // remember where this allele's postings end
+    ins.push_back({0xFFFFFFFFu, a});
+  }
+  sepStart[nAlleles] = (uint32_t)sepPos.size();
+  for (size_t i = 0; i < nKeys; ++i) kStart[i + 1] += kStart[i];
+  std::vector<T1kPosting> post(kStart[nKeys]);
+  {
+    std::vector<uint32_t> cur(kStart.begin(), kStart.end() - 1);
+    uint32_t a = 0;
+    for (auto &e : ins) {
+      if (e.first == 0xFFFFFFFFu) { a = e.second + 1; continue; }
+      post[cur[e.first]++] = T1kPosting{a, e.second};
+    }
+  }
+  ctx->hAlleleOff = alleleOff;
+  ctx->hAlleleLen = alleleLen;
+  T1kRefDev r{};
+  r.nAlleles = nAlleles;
+  r.totalBases = total;
+  int rc;
+  if ((rc = uploadVec(ctx, bases, (const void **)&r.bases))) return rc;
+  if ((rc = uploadVec(ctx, nmask, (const void **)&r.nmask))) return rc;
+  if ((rc = uploadVec(ctx, exonm, (const void **)&r.exon))) return rc;
+  if ((rc = uploadVec(ctx, alleleOff, (const void **)&r.alleleOff))) return rc;
+  if ((rc = uploadVec(ctx, alleleLen, (const void **)&r.alleleLen))) return rc;
+  if ((rc = uploadVec(ctx, sepStart, (const void **)&r.sepStart))) return rc;
+  if (sepPos.empty()) sepPos.push_back(0);
+  if ((rc = uploadVec(ctx, sepPos, (const void **)&r.sepPos))) return rc;
+  if ((rc = uploadVec(ctx, kStart, (const void **)&r.kStart))) return rc;
+  if (post.empty()) post.push_back(T1kPosting{0, 0});
+  if ((rc = uploadVec(ctx, post, (const void **)&r.kPost))) return rc;
+  T1kDevBuf cov;
+  if ((rc = t1k_ensure(ctx, cov, (total + 2) * sizeof(int32_t)))) return rc;
+  T1K_HIP(ctx, hipMemsetAsync(cov.p, 0, (total + 2) * sizeof(int32_t), ctx->stream));
+  ctx->refBufs.push_back(cov);
+  r.covDiff = (int32_t *)cov.p;
+  ctx->ref = r;
+  T1K_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return T1K_OK;
+}
+
+int t1k_coverage_reset(t1k_ctx *ctx) {
+  if (!ctx || !ctx->ref.covDiff) return t1k_fail(ctx, T1K_ERR_STATE, "no reference");
+  T1K_HIP(ctx, hipSetDevice(ctx->device));
+  T1K_HIP(ctx, hipMemsetAsync(ctx->ref.covDiff, 0, (ctx->ref.totalBases + 2) * sizeof(int32_t), ctx->stream));
+  T1K_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return T1K_OK;
+}
+
+int t1k_coverage_get(t1k_ctx *ctx, int32_t *out, uint64_t cap) {
+  if (!ctx || !ctx->ref.covDiff || !out) return t1k_fail(ctx, T1K_ERR_STATE, "no reference");
+  T1K_HIP(ctx, hipSetDevice(ctx->device));
+  uint32_t A = ctx->ref.nAlleles;
+  std::vector<uint64_t> outOff(A);
+  uint64_t tot = 0;
+  for (uint32_t a = 0; a < A; ++a) { outOff[a] = tot; tot += ctx->hAlleleLen[a]; }
+  if (cap < tot) return t1k_fail(ctx, T1K_ERR_ARG, "coverage buffer too small");
+  T1kDevBuf dOut, dOff;
+  int rc;
+  if ((rc = t1k_ensure(ctx, dOut, tot * 4))) return rc;
+  if ((rc = t1k_ensure(ctx, dOff, A * 8))) { freeBuf(dOut); return rc; }
+  hipMemcpyAsync(dOff.p, outOff.data(), A * 8, hipMemcpyHostToDevice, ctx->stream);
+  t1k_launch_coverage_scan(ctx, ctx->ref, (int32_t *)dOut.p, (const uint64_t *)dOff.p);
+  hipMemcpyAsync(out, dOut.p, tot * 4, hipMemcpyDeviceToHost, ctx->stream);
+  hipError_t e = hipStreamSynchronize(ctx->stream);
+  freeBuf(dOut); freeBuf(dOff);
+  if (e != hipSuccess) return t1k_fail(ctx, T1K_ERR_DEVICE, hipGetErrorString(e));
+  return T1K_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// reads
+// ------------------------------------------------------------------------------------------------------------------
+int t1k_reads_upload(t1k_ctx *ctx, const char *seqs, const uint64_t *offsets, const uint32_t *weights, uint32_t n) {
+  if (!ctx || (!seqs && n) || !offsets) return t1k_fail(ctx, T1K_ERR_ARG, "t1k_reads_upload: bad arguments");
+  T1K_HIP(ctx, hipSetDevice(ctx->device));
+  int maxLen = 0;
+  for (uint32_t i = 0; i < n; ++i) maxLen = std::max<int>(maxLen, (int)(offsets[i + 1] - offsets[i]));
+  if (maxLen > ctx->prm.max_read_len) return t1k_fail(ctx, T1K_ERR_ARG, "read longer than max_read_len");
+  int S = (maxLen + 31) / 32 + 1;
+  if (S < 2) S = 2;
+  uint64_t bytes = n ? offsets[n] : 0;
+  int rc;
+  if ((rc = t1k_ensure(ctx, ctx->bReadAscii, bytes + 16))) return rc;
+  if ((rc = t1k_ensure(ctx, ctx->bReadOffs, (size_t)(n + 1) * 8))) return rc;
+  if ((rc = t1k_ensure(ctx, ctx->bReadBases, (size_t)n * 2 * S * 8 + 64))) return rc;
+  if ((rc = t1k_ensure(ctx, ctx->bReadN, (size_t)n * 2 * S * 8 + 64))) return rc;
+  if ((rc = t1k_ensure(ctx, ctx->bReadLen, (size_t)n * 2 + 16))) return rc;
+  if ((rc = t1k_ensure(ctx, ctx->bReadWeight, (size_t)n * 4 + 16))) return rc;
+  if (n) {
+    T1K_HIP(ctx, hipMemcpyAsync(ctx->bReadAscii.p, seqs, bytes, hipMemcpyHostToDevice, ctx->stream));
+    T1K_HIP(ctx, hipMemcpyAsync(ctx->bReadOffs.p, offsets, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    if (weights) T1K_HIP(ctx, hipMemcpyAsync(ctx->bReadWeight.p, weights, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+    else {
+      std::vector<uint32_t> ones(n, 1);
+      T1K_HIP(ctx, hipMemcpyAsync(ctx->bReadWeight.p, ones.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+      T1K_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    // the spare word after each strand must be defined (funnel shifts read it)
+    T1K_HIP(ctx, hipMemsetAsync(ctx->bReadBases.p, 0, (size_t)n * 2 * S * 8 + 64, ctx->stream));
+    T1K_HIP(ctx, hipMemsetAsync(ctx->bReadN.p, 0, (size_t)n * 2 * S * 8 + 64, ctx->stream));
+    t1k_launch_pack(ctx, (const char *)ctx->bReadAscii.p, (const uint64_t *)ctx->bReadOffs.p, n, S, (uint64_t *)ctx->bReadBases.p, (uint64_t *)ctx->bReadN.p,
+                    (uint16_t *)ctx->bReadLen.p);
+  }
+  T1K_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->reads.nReadEnds = n;
+  ctx->reads.S = S;
+  ctx->reads.bases = (const uint64_t *)ctx->bReadBases.p;
+  ctx->reads.nmask = (const uint64_t *)ctx->bReadN.p;
+  ctx->reads.len = (const uint16_t *)ctx->bReadLen.p;
+  ctx->reads.weight = (const uint32_t *)ctx->bReadWeight.p;
+  ctx->batchMaxLen = maxLen;
+  ctx->nCand = ctx->nOvl = 0;
+  return T1K_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// AssignRead over the batch
+// ------------------------------------------------------------------------------------------------------------------
+static int fetchCounters(t1k_ctx *ctx, unsigned long long *h) {
+  T1K_HIP(ctx, hipMemcpyAsync(h, ctx->bCounters.p, 16 * 8, hipMemcpyDeviceToHost, ctx->stream));
+  T1K_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+static int capacityError(t1k_ctx *ctx, unsigned long long flags) {
+  std::string m = "device arena overflow:";
+  if (flags & 1) m += " hit_cap_per_wg";
+  if (flags & 2) m += " candidate staging";
+  if (flags & 4) m += " cand_cap";
+  if (flags & 8) m += " group too large";
+  if (flags & 16) m += " ovl_cap";
+  if (flags & 32) m += " sort capacity";
+  if (flags & 64) m += " slow-alignment queue";
+  if (flags & 128) m += " row_cap";
+  return t1k_fail(ctx, T1K_ERR_CAPACITY, m);
+}
+
+int t1k_assign_batch(t1k_ctx *ctx) {
+  if (!ctx || !ctx->ref.bases) return t1k_fail(ctx, T1K_ERR_STATE, "t1k_assign_batch: no reference uploaded");
+  T1K_HIP(ctx, hipSetDevice(ctx->device));
+  const uint32_t n = ctx->reads.nReadEnds;
+  int rc;
+  const int nWg = (int)std::min<uint32_t>((uint32_t)ctx->prm.workgroups, std::max<uint32_t>(n, 1));
+  const uint32_t stageCap = 1u << 16;
+  const uint32_t sortCap = 1u << 15;
+  if ((rc = t1k_ensure(ctx, ctx->bCounters, 16 * 8))) return rc;
+  if ((rc = t1k_ensure(ctx, ctx->bWgHits, (size_t)nWg * ctx->prm.hit_cap_per_wg * 4))) return rc;
+  if ((rc = t1k_ensure(ctx, ctx->bWgGroups, (size_t)nWg * t1k_wg_groups_u32() * 4))) return rc;
+  if ((rc = t1k_ensure(ctx, ctx->bWgStage, (size_t)nWg * stageCap * sizeof(T1kCand)))) return rc;
+  if ((rc = t1k_ensure(ctx, ctx->bWgThreadScratch, (size_t)nWg * t1k_wg_thread_u32() * 4))) return rc;
+  if ((rc = t1k_ensure(ctx, ctx->bWgBig, (size_t)nWg * t1k_wg_big_u32() * 4))) return rc;
+  if ((rc = t1k_ensure(ctx, ctx->bCand, (size_t)ctx->prm.cand_cap * sizeof(T1kCand)))) return rc;
+  if ((rc = t1k_ensure(ctx, ctx->bExt, (size_t)ctx->prm.cand_cap * sizeof(T1kExt)))) return rc;
+  if ((rc = t1k_ensure(ctx, ctx->bOvl, (size_t)ctx->prm.ovl_cap * sizeof(T1kOvl)))) return rc;
+  if ((rc = t1k_ensure(ctx, ctx->bCandStart, (size_t)n * 4))) return rc;
+  if ((rc = t1k_ensure(ctx, ctx->bCandCount, (size_t)n * 4))) return rc;
+  if ((rc = t1k_ensure(ctx, ctx->bOvlStart, (size_t)n * 4))) return rc;
+  if ((rc = t1k_ensure(ctx, ctx->bOvlCount, (size_t)n * 4))) return rc;
+  if ((rc = t1k_ensure(ctx, ctx->bSortScratch, (size_t)nWg * sortCap * 48))) return rc;
+  T1K_HIP(ctx, hipMemsetAsync(ctx->bCounters.p, 0, 16 * 8, ctx->stream));
+  T1K_HIP(ctx, hipMemsetAsync(ctx->bOvlCount.p, 0, (size_t)n * 4 + 4, ctx->stream));
+  ctx->nCand = ctx->nOvl = 0;
+  memset(&ctx->stats, 0, sizeof(ctx->stats));
+  if (n == 0) return T1K_OK;
+  unsigned long long hc[16];
+  double t0 = nowMs();
+  AssignArgs a{};
+  a.ref = ctx->ref; a.reads = ctx->reads;
+  a.k = ctx->prm.kmer_length; a.radius = ctx->prm.radius; a.hitLenRequired = ctx->prm.hit_len_required;
+  a.sim = ctx->prm.ref_seq_similarity; a.relax = ctx->prm.relax_intron_align;
+  a.wgHits = (uint32_t *)ctx->bWgHits.p; a.hitCap = (uint64_t)ctx->prm.hit_cap_per_wg;
+  a.wgGroups = (uint32_t *)ctx->bWgGroups.p;
+  a.wgStage = (T1kCand *)ctx->bWgStage.p; a.stageCap = stageCap;
+  a.wgThread = (uint32_t *)ctx->bWgThreadScratch.p;
+  a.wgBig = (uint32_t *)ctx->bWgBig.p;
+  a.cand = (T1kCand *)ctx->bCand.p; a.candCap = (uint64_t)ctx->prm.cand_cap;
+  a.candStart = (uint32_t *)ctx->bCandStart.p; a.candCount = (uint32_t *)ctx->bCandCount.p;
+  a.counters = (unsigned long long *)ctx->bCounters.p;
+  t1k_launch_seed_chain(ctx, a, nWg);
+  if ((rc = fetchCounters(ctx, hc))) return rc;
+  double t1 = nowMs();
+  if (hc[2]) return capacityError(ctx, hc[2]);
+  ctx->nCand = hc[0];
+  ExtendArgs e{};
+  e.ref = ctx->ref; e.reads = ctx->reads; e.k = a.k; e.sim = a.sim;
+  e.cand = a.cand; e.ext = (T1kExt *)ctx->bExt.p; e.nCand = ctx->nCand; e.counters = a.counters;
+  t1k_launch_extend(ctx, e);
+  T1K_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  double t2 = nowMs();
+  SelectArgs s{};
+  s.reads = ctx->reads; s.cand = a.cand; s.ext = e.ext; s.candStart = a.candStart; s.candCount = a.candCount;
+  s.ovl = (T1kOvl *)ctx->bOvl.p; s.ovlCap = (uint64_t)ctx->prm.ovl_cap;
+  s.ovlStart = (uint32_t *)ctx->bOvlStart.p; s.ovlCount = (uint32_t *)ctx->bOvlCount.p;
+  s.sortScratch = (uint64_t *)ctx->bSortScratch.p; s.sortCap = sortCap; s.counters = a.counters;
+  t1k_launch_select(ctx, s, nWg);
+  if ((rc = fetchCounters(ctx, hc))) return rc;
+  double t3 = nowMs();
+  if (hc[2]) return capacityError(ctx, hc[2]);
+  ctx->nOvl = hc[1];
+  const int maxCells = 340 * 340;
+  const int slowBlocks = 64;
+  if ((rc = t1k_ensure(ctx, ctx->bSlowQueue, (size_t)(ctx->nOvl + 1) * 4))) return rc;
+  if ((rc = t1k_ensure(ctx, ctx->bSlowScratch, (size_t)slowBlocks * 64 * t1k_slow_per_thread(maxCells)))) return rc;
+  FullArgs f{};
+  f.ref = ctx->ref; f.reads = ctx->reads; f.relax = a.relax; f.ovl = s.ovl; f.nOvl = ctx->nOvl;
+  f.slowQueue = (uint32_t *)ctx->bSlowQueue.p; f.slowCap = (uint32_t)std::min<uint64_t>(ctx->nOvl + 1, 0xFFFFFFFFull); f.counters = a.counters;
+  t1k_launch_fullalign(ctx, f);
+  if ((rc = fetchCounters(ctx, hc))) return rc;
+  if (hc[2]) return capacityError(ctx, hc[2]);
+  if (hc[8]) {
+    SlowArgs sl{};
+    sl.ref = ctx->ref; sl.reads = ctx->reads; sl.relax = a.relax; sl.ovl = s.ovl; sl.slowQueue = f.slowQueue; sl.nSlow = (uint32_t)hc[8];
+    sl.scratch = (uint8_t *)ctx->bSlowScratch.p; sl.perThread = t1k_slow_per_thread(maxCells); sl.maxCells = maxCells; sl.counters = a.counters;
+    t1k_launch_fullalign_slow(ctx, sl, slowBlocks);
+  }
+  TruncArgs tr{};
+  tr.reads = ctx->reads; tr.ovl = s.ovl; tr.ovlStart = s.ovlStart; tr.ovlCount = s.ovlCount; tr.sortScratch = s.sortScratch; tr.sortCap = sortCap;
+  tr.counters = a.counters;
+  t1k_launch_truncate(ctx, tr, nWg);
+  if ((rc = fetchCounters(ctx, hc))) return rc;
+  double t4 = nowMs();
+  if (hc[2]) return capacityError(ctx, hc[2]);
+  t1k_stats &st = ctx->stats;
+  st.read_ends = n; st.lookups = hc[3]; st.postings = hc[4]; st.hits = hc[5]; st.groups = hc[6]; st.candidates = hc[0]; st.extended = hc[1];
+  st.dp_calls = hc[7]; st.near_best = hc[8];
+  st.ms_seed = 0; st.ms_chain = t1 - t0; st.ms_extend = t2 - t1; st.ms_select = t3 - t2; st.ms_fullalign = t4 - t3; st.ms_total = t4 - t0;
+  return T1K_OK;
+}
+
+int t1k_overlaps_download(t1k_ctx *ctx, uint32_t *counts, t1k_overlap *out, uint64_t cap, uint64_t *total) {
+  if (!ctx) return T1K_ERR_ARG;
+  T1K_HIP(ctx, hipSetDevice(ctx->device));
+  const uint32_t n = ctx->reads.nReadEnds;
+  std::vector<uint32_t> start(n), cnt(n);
+  if (n) {
+    T1K_HIP(ctx, hipMemcpy(start.data(), ctx->bOvlStart.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    T1K_HIP(ctx, hipMemcpy(cnt.data(), ctx->bOvlCount.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+  }
+  uint64_t tot = 0;
+  for (uint32_t i = 0; i < n; ++i) tot += cnt[i];
+  if (total) *total = tot;
+  if (counts) memcpy(counts, cnt.data(), (size_t)n * 4);
+  if (!out) return T1K_OK;
+  if (cap < tot) return t1k_fail(ctx, T1K_ERR_ARG, "overlap buffer too small");
+  std::vector<T1kOvl> h(ctx->nOvl);
+  if (ctx->nOvl) T1K_HIP(ctx, hipMemcpy(h.data(), ctx->bOvl.p, ctx->nOvl * sizeof(T1kOvl), hipMemcpyDeviceToHost));
+  uint64_t w = 0;
+  for (uint32_t i = 0; i < n; ++i) {
+    for (uint32_t j = 0; j < cnt[i]; ++j) {
+      const T1kOvl &o = h[(uint64_t)start[i] + j];
+      t1k_overlap &r = out[w++];
+      r.seq_idx = (int32_t)o.allele; r.read_start = o.readStart; r.read_end = o.readEnd; r.seq_start = o.seqStart; r.seq_end = o.seqEnd;
+      r.strand = (o.flags & 2) ? -1 : 1;
+      r.match_cnt = o.matchCnt; r.left_clip = o.leftClip; r.right_clip = o.rightClip; r.relaxed_match_cnt = o.relaxed;
+      r.similarity = (double)o.matchCnt / (double)(o.readEnd - o.readStart + 1 + o.seqEnd - o.seqStart + 1 + 2 * o.leftClip + 2 * o.rightClip);
+    }
+  }
+  return T1K_OK;
+}
+
+int t1k_stats_get(t1k_ctx *ctx, t1k_stats *out) {
+  if (!ctx || !out) return T1K_ERR_ARG;
+  *out = ctx->stats;
+  return T1K_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,369 @@
+// t1k_amd/csrc/t1k_dev.h -- internal: device context, HBM layouts, bit helpers and the banded-alignment device
+// routines shared by the gfx950 kernels.  wave64 / CDNA4 only; no CUDA-compat paths.
+//
+// HBM layouts (all little-endian within a word):
+//   bases : uint64 words, 32 bases per word, base i of a sequence at bits [2*(i&31), +2) of word i>>5 (A0 C1 G2 T3)
+//   masks : uint64 words with the SAME geometry, bit 2*(i&31) set if the property holds at base i (N mask, exon mask);
+//           sharing the geometry lets one funnel shift serve bases and masks, and mask & mismatch-bits is a plain AND.
+//   reference: all alleles concatenated, every allele starts on a 32-base boundary; alleleOff[a] = global base offset.
+//   reads: per read-end a fixed stride of S words: [fwd bases | rc bases] and [fwd N | rc N].
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include "../../include/t1k_gpu.h"
+
+#define T1K_EVEN 0x5555555555555555ull
+#define T1K_NEG_BIG (-(1 << 28))
+
+// ------------------------------------------------------------------------------------------------------------------
+// records living in HBM
+// ------------------------------------------------------------------------------------------------------------------
+struct T1kPosting { uint32_t allele, offset; };  // KmerIndex.hpp:12-17
+
+// candidate overlap after chaining + seed-chain match counting (SeqSet.hpp:1524-1548, 1697-1848); 24 bytes
+struct T1kCand {
+  uint32_t allele;     // seqIdx
+  uint32_t readSE;     // readStart | readEnd << 16
+  int32_t seqStart, seqEnd;
+  uint32_t match;      // matchCnt0 (= 2*hitLen, used for the strand vote) | matchCnt << 16
+  uint32_t re;         // read-end id within the batch
+};
+
+// extension result per candidate (SeqSet::ExtendOverlap, SeqSet.hpp:1994-2100); 24 bytes
+struct T1kExt {
+  int32_t seqStart, seqEnd;
+  uint16_t readStart, readEnd;
+  uint16_t matchCnt;   // after extension, including clip credit
+  uint16_t leftClip, rightClip;
+  uint16_t flags;      // T1K_F_*
+  uint32_t pad;
+};
+enum { T1K_F_DROP = 1, T1K_F_SEPSEED = 2, T1K_F_NEEDCLIP = 4, T1K_F_EXTOK = 8 };
+
+// final overlap record kept per read-end (what SeqSet::AssignRead returns); 32 bytes
+struct T1kOvl {
+  uint32_t allele;
+  int32_t seqStart, seqEnd;
+  uint16_t readStart, readEnd;
+  uint16_t matchCnt, relaxed;
+  uint16_t leftClip, rightClip;
+  uint32_t re;
+  uint32_t flags;      // bit0 near-best, bit1 strand is '-', bit2 duplicate-allele list marker
+};
+
+struct T1kRefDev {
+  uint32_t nAlleles;
+  uint64_t totalBases;          // padded global base count
+  const uint64_t *bases, *nmask, *exon;
+  const uint64_t *alleleOff;    // [A]
+  const uint32_t *alleleLen;    // [A]
+  const uint32_t *sepStart;     // [A+1] into sepPos: interior N positions only (the -1 / len sentinels are implicit)
+  const int32_t *sepPos;
+  const uint32_t *kStart;       // [4^k + 1]
+  const T1kPosting *kPost;
+  int32_t *covDiff;             // [totalBases + 1] difference array of per-base coverage
+};
+
+struct T1kReadsDev {
+  uint32_t nReadEnds;
+  int S;                        // words per strand per read-end
+  const uint64_t *bases;        // [re][2][S]  (0 = forward, 1 = reverse complement)
+  const uint64_t *nmask;        // [re][2][S]
+  const uint16_t *len;
+  const uint32_t *weight;
+};
+
+// ------------------------------------------------------------------------------------------------------------------
+// bit helpers
+// ------------------------------------------------------------------------------------------------------------------
+// 32 consecutive positions starting at position pos (pos >= 0) of a 2-bit-per-position stream; the arrays carry
+// one spare word so w[wi+1] is always addressable.
+__device__ __forceinline__ uint64_t t1k_get32(const uint64_t *w, int64_t pos) {
+  int64_t wi = pos >> 5;
+  int sh = (int)(pos & 31) * 2;
+  uint64_t lo = w[wi];
+  if (sh == 0) return lo;
+  return (lo >> sh) | (w[wi + 1] << (64 - sh));
+}
+__device__ __forceinline__ uint64_t t1k_lowmask(int nPos) {  // mask of the first nPos positions (0..32)
+  return nPos >= 32 ? ~0ull : ((1ull << (2 * nPos)) - 1);
+}
+__device__ __forceinline__ int t1k_base(const uint64_t *w, int64_t pos) { return (int)((w[pos >> 5] >> ((pos & 31) * 2)) & 3); }
+__device__ __forceinline__ int t1k_bit(const uint64_t *w, int64_t pos) { return (int)((w[pos >> 5] >> ((pos & 31) * 2)) & 1); }
+
+// mismatch bits (even positions) between 32 read positions and 32 reference positions; an N on either side matches
+// (AlignAlgo.hpp:304-305)
+__device__ __forceinline__ uint64_t t1k_mm32(const uint64_t *rb, const uint64_t *rn, int64_t rpos, const uint64_t *gb, const uint64_t *gn,
+                                               int64_t gpos) {
+  uint64_t x = t1k_get32(rb, rpos) ^ t1k_get32(gb, gpos);
+  uint64_t m = (x | (x >> 1)) & T1K_EVEN;
+  return m & ~(t1k_get32(rn, rpos) | t1k_get32(gn, gpos));
+}
+
+// number of mismatching columns of the ungapped comparison of L positions
+__device__ __forceinline__ int t1k_hamming(const uint64_t *rb, const uint64_t *rn, int64_t rpos, const uint64_t *gb, const uint64_t *gn,
+                                            int64_t gpos, int L) {
+  int x = 0;
+  for (int o = 0; o < L; o += 32) {
+    uint64_t m = t1k_mm32(rb, rn, rpos + o, gb, gn, gpos + o) & t1k_lowmask(L - o);
+    x += __popcll(m);
+  }
+  return x;
+}
+
+// accessor for one sequence operand of the alignment routines
+struct T1kSeqView {
+  const uint64_t *b, *n;
+  int64_t pos;
+  __device__ __forceinline__ int code(int i) const {  // 0..3, or 4 for N
+    int64_t p = pos + i;
+    return t1k_bit(n, p) ? 4 : t1k_base(b, p);
+  }
+};
+__device__ __forceinline__ bool t1k_eq(int a, int b) { return a == b || a == 4 || b == 4; }
+
+// ------------------------------------------------------------------------------------------------------------------
+// AlignAlgo::GlobalAlignment (AlignAlgo.hpp:215-421), equal lengths L >= 2, band +-5: number of MATCH columns on the
+// reference's traceback path, computed in one forward sweep.  cnt*[cell] = matches on the traceback path from
+// (cell, state) to the origin; the traceback's choice at a cell is local (diagonal if it reproduces m, else delete
+// if f >= e, else insert; "gap opened here" iff m(prev)-5 == e/f), so the counts obey the same recurrences as the
+// scores.  Band columns live in registers (d = j - i in [-6, 6], the outer two being the negInf fence cells).
+// ------------------------------------------------------------------------------------------------------------------
+__device__ inline int t1k_ga_matches_equal(const T1kSeqView &T, const T1kSeqView &P, int L, int *scoreOut) {
+  const int negInf = (L + 1) * (L + 1) * -4;
+  int m[13], e[13], cm[13], ce[13];
+  // row 0: boundary values for every column (AlignAlgo.hpp:255-270); e[0][j] uses the stale i == lenp+1
+#pragma unroll
+  for (int s = 0; s < 13; ++s) {
+    int j = s - 6;
+    if (j == 0) { m[s] = 0; e[s] = 0; }
+    else { m[s] = -4 - 4 * j; e[s] = -4 - 4 * (L + 1); }
+    cm[s] = 0; ce[s] = 0;
+  }
+  for (int i = 1; i <= L; ++i) {
+    int pc = P.code(i - 1);
+    int fLeft = 0, mLeft = 0, cfLeft = 0, cmLeft = 0;  // cell (i, j-1) of the current row
+#pragma unroll
+    for (int s = 0; s < 13; ++s) {
+      int j = i + s - 6;
+      int nm, ne, nf, ncm, nce, ncf;
+      if (j < 0) { nm = ne = nf = negInf; ncm = nce = ncf = 0; }
+      else if (j == 0) { nm = -4 - 4 * i; ne = -4 - i; nf = -4 - 4 * i; ncm = nce = ncf = 0; }
+      else if (j > L || s == 0 || s == 12) { nm = ne = nf = negInf; ncm = nce = ncf = 0; }
+      else {
+        // e: from (i-1, j) = previous row at slot s+1
+        int eu = e[s + 1] - 1, mu = m[s + 1] - 5;
+        ne = eu > mu ? eu : mu;
+        nce = (mu == ne) ? cm[s + 1] : ce[s + 1];
+        // f: from (i, j-1)
+        int fl = fLeft - 1, ml = mLeft - 5;
+        nf = fl > ml ? fl : ml;
+        ncf = (ml == nf) ? cmLeft : cfLeft;
+        // m: diagonal (i-1, j-1) = previous row at slot s
+        bool eq = t1k_eq(T.code(j - 1), pc);
+        int dg = m[s] + (eq ? 2 : -2);
+        nm = dg;
+        if (ne > nm) nm = ne;
+        if (nf > nm) nm = nf;
+        if (dg == nm) ncm = cm[s] + (eq ? 1 : 0);
+        else if (nf >= ne) ncm = ncf;
+        else ncm = nce;
+      }
+      // slot s of the previous row is dead now (slot s+1 is still needed by the next iteration)
+      m[s] = nm; e[s] = ne; cm[s] = ncm; ce[s] = nce;
+      fLeft = nf; mLeft = nm; cfLeft = ncf; cmLeft = ncm;
+    }
+  }
+  if (scoreOut) *scoreOut = m[6];
+  return cm[6];
+}
+
+// Exact fast path for equal lengths: with x <= 3 mismatches the ungapped alignment is optimal and is the one the
+// traceback returns (any gapped alignment of equal-length strings scores <= 2L-12 <= 2L-4x, ties go to the diagonal).
+__device__ __forceinline__ int t1k_ga_matches_window(const uint64_t *rb, const uint64_t *rn, int64_t rpos, const uint64_t *gb, const uint64_t *gn,
+                                                      int64_t gpos, int L, unsigned long long *dpCounter) {
+  if (L <= 0) return 0;
+  int x = t1k_hamming(rb, rn, rpos, gb, gn, gpos, L);
+  if (x <= 3) return L - x;
+  if (dpCounter) atomicAdd(dpCounter, 1ull);
+  T1kSeqView T{gb, gn, gpos}, P{rb, rn, rpos};
+  return t1k_ga_matches_equal(T, P, L, nullptr);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// General GlobalAlignment (any lent, lenp) with row arrays in caller-provided scratch (6 * (lent + 2) ints).
+// Returns the score; *nMatch etc. the column counts of the traceback path.  If trace != NULL, one decision byte per
+// cell is stored at trace[i * (lent + 1) + j] (bit0 diagonal reproduces m, bit1 f >= e, bit2 e opened from m,
+// bit3 f opened from m, bit4 columns compare equal) for t1k_ga_traceback().
+// ------------------------------------------------------------------------------------------------------------------
+__device__ inline int t1k_ga_general(const T1kSeqView &T, int lent, const T1kSeqView &P, int lenp, int *scratch, uint8_t *trace, int *nMatch) {
+  if (lent == 0 || lenp == 0) { if (nMatch) *nMatch = 0; return 0; }
+  if (lent == 1 && lenp == 1) {
+    bool eq = t1k_eq(T.code(0), P.code(0));
+    if (nMatch) *nMatch = eq ? 1 : 0;
+    if (trace) { trace[0] = 0; trace[1 * 2 + 1] = (uint8_t)(1 | (eq ? 16 : 0)); }
+    return eq ? 2 : -2;
+  }
+  int leftBand = 5, rightBand = 5;
+  if (lent > lenp) rightBand += lent - lenp; else if (lent < lenp) leftBand += lenp - lent;
+  const int W = lent + 1;
+  const int negInf = (lent + 1) * (lenp + 1) * -4;
+  int *m = scratch, *e = scratch + (W + 1), *f = scratch + 2 * (W + 1);
+  int *cm = scratch + 3 * (W + 1), *ce = scratch + 4 * (W + 1), *cf = scratch + 5 * (W + 1);
+  m[0] = e[0] = f[0] = 0; cm[0] = ce[0] = cf[0] = 0;
+  for (int j = 1; j <= lent; ++j) { f[j] = -4 - j; e[j] = -4 - 4 * (lenp + 1); m[j] = -4 - 4 * j; cm[j] = ce[j] = cf[j] = 0; }
+  if (trace) {
+    for (int j = 0; j <= lent; ++j) {
+      // row 0: no diagonal; bit1 = f >= e; bit3 = m[0][j-1]-5 == f[0][j]
+      uint8_t t = 0;
+      if (j > 0) {
+        if (f[j] >= e[j]) t |= 2;
+        int mprev = (j - 1 == 0) ? 0 : -4 - 4 * (j - 1);
+        if (mprev - 5 == f[j]) t |= 8;
+      }
+      trace[j] = t;
+    }
+  }
+  for (int i = 1; i <= lenp; ++i) {
+    int start = (i - leftBand < 1) ? 1 : (i - leftBand);
+    int end = (i + rightBand > lent) ? lent : (i + rightBand);
+    int pc = P.code(i - 1);
+    // previous-row values are consumed left to right; keep the diagonal predecessor before overwriting
+    int mDiag, cmDiag;      // (i-1, j-1)
+    int mL, fL, cmL, cfL;   // (i, j-1)
+    if (start == 1) {
+      mDiag = (i - 1 == 0) ? 0 : -4 - 4 * (i - 1);  // m[i-1][0]
+      cmDiag = 0;
+      mL = -4 - 4 * i; fL = -4 - 4 * i; cmL = 0; cfL = 0;  // (i, 0)
+      // column 0 of this row also becomes visible to row i+1 as (i, 0): write it
+    } else {
+      mDiag = m[start - 1]; cmDiag = cm[start - 1];
+      mL = negInf; fL = negInf; cmL = 0; cfL = 0;  // the fence cell (i, start-1)
+    }
+    int saveM0 = m[0], saveE0 = e[0];
+    (void)saveM0; (void)saveE0;
+    // column 0 / fence bookkeeping for the next row
+    if (start == 1) { /* (i,0) written after the sweep */ }
+    for (int j = start; j <= end; ++j) {
+      int eu = e[j] - 1, mu = m[j] - 5;  // (i-1, j): still the previous row
+      int ne = eu > mu ? eu : mu;
+      int nce = (mu == ne) ? cm[j] : ce[j];
+      int fl = fL - 1, ml = mL - 5;
+      int nf = fl > ml ? fl : ml;
+      int ncf = (ml == nf) ? cmL : cfL;
+      bool eq = t1k_eq(T.code(j - 1), pc);
+      int dg = mDiag + (eq ? 2 : -2);
+      int nm = dg;
+      if (ne > nm) nm = ne;
+      if (nf > nm) nm = nf;
+      int ncm;
+      if (dg == nm) ncm = cmDiag + (eq ? 1 : 0);
+      else if (nf >= ne) ncm = ncf;
+      else ncm = nce;
+      if (trace) {
+        uint8_t t = 0;
+        if (dg == nm) t |= 1;
+        if (nf >= ne) t |= 2;
+        if (mu == ne) t |= 4;
+        if (ml == nf) t |= 8;
+        if (eq) t |= 16;
+        trace[i * W + j] = t;
+      }
+      mDiag = m[j]; cmDiag = cm[j];  // becomes (i-1, j) -> diagonal for j+1
+      m[j] = nm; e[j] = ne; f[j] = nf; cm[j] = ncm; ce[j] = nce; cf[j] = ncf;
+      mL = nm; fL = nf; cmL = ncm; cfL = ncf;
+    }
+    if (end < lent) { m[end + 1] = e[end + 1] = f[end + 1] = negInf; cm[end + 1] = ce[end + 1] = cf[end + 1] = 0; }
+    if (start > 1) { m[start - 1] = e[start - 1] = f[start - 1] = negInf; cm[start - 1] = ce[start - 1] = cf[start - 1] = 0; }
+    // column 0 of row i (boundary values, AlignAlgo.hpp:256-262) for the next row's j == 1
+    m[0] = -4 - 4 * i; e[0] = -4 - i; f[0] = -4 - 4 * i; cm[0] = ce[0] = cf[0] = 0;
+    if (trace) {
+      // (i, 0): no diagonal; f >= e only when i <= 0; bit2 = m[i-1][0]-5 == e[i][0]
+      uint8_t t = 0;
+      if (f[0] >= e[0]) t |= 2;
+      int mprev = (i - 1 == 0) ? 0 : -4 - 4 * (i - 1);
+      if (mprev - 5 == e[0]) t |= 4;
+      trace[i * W] = t;
+    }
+  }
+  if (nMatch) *nMatch = cm[lent];
+  return m[lent];
+}
+
+// Replays AlignAlgo.hpp:323-415 on the decision bytes written by t1k_ga_general.  ops (capacity lent+lenp+2) receives
+// the edit string in forward order; returns its length.
+__device__ inline int t1k_ga_traceback(const uint8_t *trace, int lent, int lenp, int8_t *ops) {
+  if (lent == 0 || lenp == 0) return 0;
+  const int W = lent + 1;
+  int ti = lenp, tj = lent, mat = 0, n = 0;
+  if (lent == 1 && lenp == 1) { ops[0] = (trace[1 * 2 + 1] & 16) ? 0 : 1; return 1; }
+  while (ti > 0 || tj > 0) {
+    uint8_t t = trace[ti * W + tj];
+    if (mat == 0) {
+      if (ti > 0 && tj > 0 && (t & 1)) { ops[n++] = (t & 16) ? 0 : 1; --ti; --tj; }
+      else if (t & 2) mat = 2;
+      else mat = 1;
+    } else if (mat == 1) {
+      ops[n++] = 2;
+      if (ti > 0) { if (t & 4) mat = 0; --ti; }
+      else mat = 2;
+    } else {
+      ops[n++] = 3;
+      if (tj > 0) { if (t & 8) mat = 0; --tj; }
+      else mat = 1;
+    }
+  }
+  for (int a = 0, b = n - 1; a < b; ++a, --b) { int8_t x = ops[a]; ops[a] = ops[b]; ops[b] = x; }
+  return n;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// host-side context
+// ------------------------------------------------------------------------------------------------------------------
+struct T1kDevBuf {
+  void *p = nullptr;
+  size_t bytes = 0;
+};
+
+struct t1k_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  t1k_params prm;
+  std::string err;
+  // reference
+  T1kRefDev ref{};
+  std::vector<uint64_t> hAlleleOff;
+  std::vector<uint32_t> hAlleleLen;
+  std::vector<T1kDevBuf> refBufs;
+  // reads
+  T1kReadsDev reads{};
+  T1kDevBuf bReadAscii, bReadOffs, bReadBases, bReadN, bReadLen, bReadWeight;
+  int batchMaxLen = 0;
+  // assignment arenas
+  T1kDevBuf bWgHits, bWgGroups, bWgStage, bWgThreadScratch, bWgBig;
+  T1kDevBuf bCand, bExt, bCandStart, bCandCount, bOvl, bOvlStart, bOvlCount, bCounters, bSlowQueue, bSlowScratch, bSortScratch;
+  uint64_t nCand = 0, nOvl = 0;
+  // pairing
+  T1kDevBuf bEnd1, bEnd2, bHasN, bRows, bRowStart, bRowCount, bFragAssigned, bPairScratch;
+  uint32_t nFragments = 0;
+  uint64_t nRows = 0;
+  // EM
+  T1kDevBuf bEmRowPtr, bEmEc, bEmCount, bEmLen, bEmX0, bEmX1, bEmN, bEmContrib, bEmColPtr, bEmColIdx, bEmScalars;
+  uint32_t emGroups = 0, emEc = 0;
+  uint64_t emNnz = 0;
+  t1k_allreduce_fn emAllreduce = nullptr;
+  void *emUser = nullptr;
+  // align batch scratch
+  T1kDevBuf bAlign[12];
+  t1k_stats stats{};
+};
+
+int t1k_fail(t1k_ctx *ctx, int code, const std::string &msg);
+int t1k_ensure(t1k_ctx *ctx, T1kDevBuf &b, size_t bytes);
+#define T1K_HIP(ctx, call)                                                                              \
+  do {                                                                                                  \
+    hipError_t e_ = (call);                                                                             \
+    if (e_ != hipSuccess) return t1k_fail(ctx, T1K_ERR_DEVICE, std::string(#call) + ": " + hipGetErrorString(e_)); \
+  } while (0)

@@ -1,0 +1,87 @@
+"""Shared helpers for the test-suite (test infrastructure: the only place, with bench.py's cpu_baseline leg and
+__graft_entry__.smoke(), that touches oracle/)."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+SYNTH = os.path.join(ROOT, "tools", "t1k_synth")
+ORACLE_SO = os.path.join(ROOT, "oracle", "libt1k_oracle.so")
+ORACLE_CLI = os.path.join(ROOT, "oracle", "t1k_oracle_cli")
+REF_BIN = os.path.join(ROOT, "oracle", "_ref", "genotyper")
+CYP_RNA = os.path.join(GOLDEN, "cyp2d6_rna_seq.fa.gz")
+CYP_DNA = os.path.join(GOLDEN, "cyp2d6_dna_seq.fa.gz")
+CYP_FLAGS = ["--alleleDigitUnits", "1", "--alleleDelimiter", "."]
+
+
+def synth(*args):
+    subprocess.run([SYNTH] + [str(a) for a in args], check=True)
+
+
+def synth_ref(kind, path, **kw):
+    args = [SYNTH, kind]
+    for k, v in kw.items():
+        args += ["--" + k, str(v)]
+    with open(path, "w") as f:
+        subprocess.run(args, check=True, stdout=f)
+
+
+def synth_reads(ref, prefix, **kw):
+    args = [SYNTH, "reads", "--ref", ref, "--out", prefix]
+    for k, v in kw.items():
+        args += ["--" + k, str(v)]
+    subprocess.run(args, check=True)
+
+
+def gunzip_to(src, dst):
+    import gzip
+    import shutil
+    with gzip.open(src, "rb") as a, open(dst, "wb") as b:
+        shutil.copyfileobj(a, b)
+    return dst
+
+
+class Oracle:
+    """ctypes view of oracle/libt1k_oracle.so (CPU restatement) -- the checker, never the thing under test."""
+
+    def __init__(self, fasta, similarity=0.8, relax=False, max_assign=2000, digit_units=-1, delimiter=b"\0"):
+        L = C.CDLL(ORACLE_SO)
+        L.orc_create.restype = C.c_void_p
+        L.orc_create.argtypes = [C.c_double, C.c_int, C.c_int, C.c_int, C.c_char]
+        L.orc_load_reference.argtypes = [C.c_void_p, C.c_char_p]
+        L.orc_assign_read.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+        L.orc_coverage.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        L.orc_allele_count.argtypes = [C.c_void_p]
+        L.orc_allele_name.argtypes = [C.c_void_p, C.c_int]
+        L.orc_allele_name.restype = C.c_char_p
+        L.orc_destroy.argtypes = [C.c_void_p]
+        L.orc_global_alignment.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_void_p, C.c_void_p]
+        self.L = L
+        self.h = L.orc_create(similarity, 1 if relax else 0, max_assign, digit_units, delimiter)
+        if fasta is not None:
+            n = L.orc_load_reference(self.h, fasta.encode())
+            assert n > 0, "oracle could not load %s" % fasta
+            self.n_alleles = n
+
+    def assign_read(self, seq, weight=1, cap=65536):
+        out = np.zeros((cap, 12), dtype=np.int32)
+        sim = np.zeros(cap, dtype=np.float64)
+        n = self.L.orc_assign_read(self.h, seq.encode(), weight, out.ctypes.data, sim.ctypes.data, cap)
+        assert n <= cap
+        return out[:n], sim[:n]
+
+    def coverage(self, allele, length):
+        out = np.zeros(length, dtype=np.int32)
+        self.L.orc_coverage(self.h, allele, out.ctypes.data, length)
+        return out
+
+    def global_alignment(self, t, p):
+        ops = np.zeros(len(t) + len(p) + 2, dtype=np.int8)
+        n = C.c_int()
+        s = self.L.orc_global_alignment(t.encode(), len(t), p.encode(), len(p), ops.ctypes.data, C.byref(n))
+        return s, ops[:n.value].copy()
