@@ -82,6 +82,9 @@ typedef struct {
  * GetOverlapsFromHits 1232, GetOverlapsFromRead 1594, ExtendOverlap 1994, near-best GlobalAlignment + base coverage
  * 2188-2285).  Results stay on the device; per-base coverage accumulates in the context. */
 int t1k_assign_batch(t1k_ctx *ctx);
+/* the same for the sub-range [first, first+count) of the uploaded read-ends; read-end indices of later calls
+ * (t1k_overlaps_download, t1k_pair_batch) are relative to `first` */
+int t1k_assign_range(t1k_ctx *ctx, uint64_t first, uint32_t count);
 /* copy the overlap lists out (tests / --outputReadAssignment): counts[nReadEnds]; ovl may be NULL to query the total */
 int t1k_overlaps_download(t1k_ctx *ctx, uint32_t *counts, t1k_overlap *ovl, uint64_t cap, uint64_t *total);
 

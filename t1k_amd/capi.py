@@ -74,6 +74,7 @@ def lib():
     L.t1k_ref_upload.argtypes = [vp, C.c_char_p, vp, vp, C.c_uint32]
     L.t1k_reads_upload.argtypes = [vp, C.c_char_p, vp, vp, C.c_uint32]
     L.t1k_assign_batch.argtypes = [vp]
+    L.t1k_assign_range.argtypes = [vp, C.c_uint64, C.c_uint32]
     L.t1k_overlaps_download.argtypes = [vp, vp, vp, C.c_uint64, u64p]
     L.t1k_pair_batch.argtypes = [vp, vp, vp, vp, C.c_uint32]
     L.t1k_rows_download.argtypes = [vp, vp, vp, vp, C.c_uint64, u64p]

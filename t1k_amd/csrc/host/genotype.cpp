@@ -1,0 +1,528 @@
+// t1k_amd/csrc/host/genotype.cpp -- read-group coalescing, equivalence classes, the SQUAREM control loop around the
+// device E-step, likelihood pruning, allele selection and the TSV text of the genotyper stage.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <set>
+#include "t1k_host.h"
+
+namespace t1k {
+
+// ------------------------------------------------------------------------------------------------------------------
+// coalescing (Genotyper::CoalesceReadAssignments, Genotyper.hpp:841-908): fragments with the same allele set share one
+// read group; group ids follow first appearance; weights are floats accumulated in fragment order
+// ------------------------------------------------------------------------------------------------------------------
+void Genotyper::coalesce(t1k_row_entry *row, uint32_t n) {
+  if (n == 0) return;
+  ++assignedFragments;
+  std::sort(row, row + n, [](const t1k_row_entry &a, const t1k_row_entry &b) { return a.allele_idx < b.allele_idx; });
+  uint64_t h = 1469598103934665603ull ^ n;
+  for (uint32_t j = 0; j < n; ++j) { h ^= (uint64_t)(uint32_t)row[j].allele_idx; h *= 1099511628211ull; h ^= h >> 29; }
+  std::vector<uint32_t> &bucket = groupOfHash[h];
+  for (uint32_t gid : bucket) {
+    uint64_t b = groupPtr[gid];
+    if (groupPtr[gid + 1] - b != n) continue;
+    bool same = true;
+    for (uint32_t j = 0; j < n && same; ++j) same = groupEnt[b + j].allele == row[j].allele_idx;
+    if (!same) continue;
+    for (uint32_t j = 0; j < n; ++j) {
+      GroupEntry &g = groupEnt[b + j];
+      if (row[j].qual == 1) {
+        if (row[j].start < g.start) g.start = row[j].start;
+        if (row[j].end < g.end) g.end = row[j].start;  // sic: Genotyper.hpp:893-894
+      }
+      g.weight += row[j].weight;
+      g.adjustWeight += row[j].adjust_weight;
+    }
+    return;
+  }
+  bucket.push_back((uint32_t)nGroups());
+  for (uint32_t j = 0; j < n; ++j) groupEnt.push_back(GroupEntry{row[j].allele_idx, row[j].start, row[j].end, row[j].weight, row[j].adjust_weight});
+  groupPtr.push_back(groupEnt.size());
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// FinalizeReadAssignments -> BuildAlleleEquivalentClass + missing coverage (Genotyper.hpp:912-939, 1072-1139;
+// SeqSet::GetSeqMissingBaseCoverage SeqSet.hpp:2717-2755)
+// ------------------------------------------------------------------------------------------------------------------
+void Genotyper::finalize(const std::vector<int32_t> &coverage) {
+  RefSet &R = *ref;
+  const int A = (int)R.al.size();
+  const int G = (int)nGroups();
+  inAllele.assign(A, {});
+  sumAssign = 0;
+  for (int g = 0; g < G; ++g) {
+    sumAssign += (double)(groupPtr[g + 1] - groupPtr[g]);
+    for (uint64_t p = groupPtr[g]; p < groupPtr[g + 1]; ++p) inAllele[groupEnt[p].allele].push_back({g, (int)(p - groupPtr[g])});
+  }
+  struct Key { int allele, fp; };
+  std::vector<Key> keys(A);
+  for (int a = 0; a < A; ++a) {
+    R.al[a].ec = -1;
+    int fp = -1;
+    if (!inAllele[a].empty()) {
+      fp = 0;
+      for (auto &gs : inAllele[a]) fp = (int)(((uint32_t)fp * (uint32_t)G + (uint32_t)gs.first) % 1000003u);  // uint32 wrap-around is part of the order
+    }
+    keys[a] = Key{a, fp};
+  }
+  std::sort(keys.begin(), keys.end(), [](const Key &x, const Key &y) { return x.fp != y.fp ? y.fp < x.fp : x.allele < y.allele; });
+  ecAlleles.clear();
+  auto sameGroups = [&](int a, int b) {
+    if (inAllele[a].size() != inAllele[b].size()) return false;
+    for (size_t i = 0; i < inAllele[a].size(); ++i)
+      if (inAllele[a][i].first != inAllele[b][i].first) return false;
+    return true;
+  };
+  for (int i = 0; i < A && keys[i].fp != -1; ++i) {
+    int joined = -1;
+    for (int j = i - 1; j >= 0 && keys[j].fp == keys[i].fp; --j)
+      if (sameGroups(keys[i].allele, keys[j].allele)) { joined = R.al[keys[j].allele].ec; break; }
+    if (joined < 0) { R.al[keys[i].allele].ec = (int)ecAlleles.size(); ecAlleles.push_back({keys[i].allele}); }
+    else { R.al[keys[i].allele].ec = joined; ecAlleles[joined].push_back(keys[i].allele); }
+  }
+  // RemoveLowMAPQAlleleInEquivalentClass (1330-1368) keeps everything: all assignment qualities are 1 and class members
+  // share their group lists.
+  uint64_t off = 0;
+  std::vector<int> ex;
+  for (int a = 0; a < A; ++a) {
+    ex.clear();
+    const int L = R.al[a].seqLen;
+    for (int p = 0; p < L; ++p)
+      if (R.exon[a][p]) ex.push_back(coverage[off + p]);
+    off += L;
+    int miss = 0;
+    if (!ex.empty()) {
+      std::sort(ex.begin(), ex.end());
+      double cutoff = ex[ex.size() / 2] * 0.01;
+      if (cutoff < 1) cutoff = 1;
+      while (miss < (int)ex.size() && !(ex[miss] >= cutoff)) ++miss;
+    }
+    R.al[a].missingCov = miss;
+  }
+}
+
+void Genotyper::setAbundance(const double *n, const std::vector<int> &ecLen) {
+  RefSet &R = *ref;
+  if (n) {
+    for (auto &a : R.al) a.abundance = a.ecAbundance = 0;
+    for (size_t e = 0; e < ecAlleles.size(); ++e) {
+      double fpk = 0;
+      fpk += n[e];
+      fpk = fpk / ecLen[e] * 1000.0;
+      const int size = (int)ecAlleles[e].size();
+      for (int a : ecAlleles[e]) { R.al[a].abundance = fpk / size; R.al[a].ecAbundance = fpk; }
+    }
+  }
+  geneAbund.assign(R.geneName.size(), 0);
+  majorAbund.assign(R.majorName.size(), 0);
+  geneMaxMajor.assign(R.geneName.size(), 0);
+  for (auto &a : R.al) { majorAbund[a.major] += a.abundance; geneAbund[a.gene] += a.abundance; }
+  for (auto &a : R.al)
+    if (majorAbund[a.major] > geneMaxMajor[a.gene]) geneMaxMajor[a.gene] = majorAbund[a.major];
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// QuantifyAlleleEquivalentClass (Genotyper.hpp:1142-1328): SQUAREM-accelerated EM; every EMupdate is t1k_em_update
+// ------------------------------------------------------------------------------------------------------------------
+int Genotyper::quantify(t1k_ctx *ctx, t1k_allreduce_fn cb, void *user, std::string &err) {
+  RefSet &R = *ref;
+  const size_t E = ecAlleles.size(), G = nGroups();
+  std::vector<uint64_t> rowPtr(G + 1, 0);
+  std::vector<uint32_t> ecIdx;
+  std::vector<double> count(G);
+  std::vector<int> seen;
+  for (size_t g = 0; g < G; ++g) {
+    float c = groupEnt[groupPtr[g]].weight;
+    for (uint64_t p = groupPtr[g] + 1; p < groupPtr[g + 1]; ++p)
+      if (groupEnt[p].weight > c) c = groupEnt[p].weight;
+    count[g] = c;
+    size_t b = ecIdx.size();
+    for (uint64_t p = groupPtr[g]; p < groupPtr[g + 1]; ++p) {
+      uint32_t ec = (uint32_t)R.al[groupEnt[p].allele].ec;
+      bool dup = false;
+      for (size_t q = b; q < ecIdx.size() && !dup; ++q) dup = ecIdx[q] == ec;
+      if (!dup) ecIdx.push_back(ec);
+    }
+    rowPtr[g + 1] = ecIdx.size();
+  }
+  std::vector<int> ecLen(E);
+  for (size_t e = 0; e < E; ++e) {
+    int len = R.al[ecAlleles[e][0]].effLen;
+    for (int a : ecAlleles[e]) len = std::min(len, R.al[a].effLen);
+    ecLen[e] = len;
+  }
+  if (t1k_em_setup(ctx, rowPtr.data(), ecIdx.data(), count.data(), ecLen.data(), (uint32_t)G, (uint32_t)E, cb, user) != T1K_OK) {
+    err = t1k_last_error(ctx);
+    return -1;
+  }
+  std::vector<double> x0(E), x1(E), x2(E), x3(E), n(E);
+  for (size_t e = 0; e < E; ++e) {
+    x0[e] = 0;
+    for (int a : ecAlleles[e]) x0[e] += R.al[a].weight;
+  }
+  const int maxIterations = 1000, maskEvery = 10;
+  int rounds = 0;
+  double diff = 0;
+  auto em = [&](std::vector<double> &from, std::vector<double> &to) {
+    if (E == 0) return true;
+    if (t1k_em_update(ctx, from.data(), to.data(), n.data(), &diff) != T1K_OK) { err = t1k_last_error(ctx); return false; }
+    return true;
+  };
+  for (int t = 0; t < maxIterations; ++t) {
+    ++rounds;
+    if (!em(x0, x1) || !em(x1, x2)) return -1;
+    double r2 = 0, v2 = 0;  // SQUAREMalpha (424-437)
+    for (size_t e = 0; e < E; ++e) {
+      r2 += (x1[e] - x0[e]) * (x1[e] - x0[e]);
+      v2 += (x2[e] - 2 * x1[e] + x0[e]) * (x2[e] - 2 * x1[e] + x0[e]);
+    }
+    double alpha = v2 == 0 ? -1 : -sqrt(r2) / sqrt(v2);
+    if (prm.squarem_min_alpha < 0 && alpha < prm.squarem_min_alpha) alpha = prm.squarem_min_alpha;
+    for (size_t e = 0; e < E; ++e) x3[e] = x0[e] - 2 * alpha * (x1[e] - x0[e]) + alpha * alpha * (x2[e] - 2 * x1[e] + x0[e]);
+    if (!em(x3, x1)) return -1;
+    double moved = 0;
+    for (size_t e = 0; e < E; ++e) { moved += fabs(x1[e] - x0[e]); x0[e] = x1[e]; }
+    if (moved < 1e-5 && t < maxIterations - 2) t = maxIterations - 2;  // one forced extra round
+    if (t > 0 && t % maskEvery == 0) {
+      setAbundance(n.data(), ecLen);
+      for (auto &a : R.al)
+        if (majorAbund[a.major] < prm.filter_frac * 0.5 * geneMaxMajor[a.gene]) { a.abundance = 0; a.ecAbundance = 0; }
+      for (size_t e = 0; e < E; ++e) x0[e] = R.al[ecAlleles[e][0]].ecAbundance;
+    }
+  }
+  setAbundance(n.data(), ecLen);
+  emIterations = rounds;
+  return rounds;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// RemoveLowLikelihoodAlleleInEquivalentClass (Genotyper.hpp:1371-1460)
+// ------------------------------------------------------------------------------------------------------------------
+void Genotyper::dropUnlikely() {
+  RefSet &R = *ref;
+  for (auto &members : ecAlleles) {
+    const int size = (int)members.size();
+    std::vector<int> lo(size), hi(size, -1);
+    std::map<int, int> where;
+    for (int j = 0; j < size; ++j) { lo[j] = R.al[members[j]].seqLen; where[members[j]] = j; }
+    for (auto &gs : inAllele[members[0]]) {
+      for (uint64_t p = groupPtr[gs.first]; p < groupPtr[gs.first + 1]; ++p) {
+        auto it = where.find(groupEnt[p].allele);
+        if (it == where.end()) continue;
+        if (groupEnt[p].start < lo[it->second]) lo[it->second] = groupEnt[p].start;
+        if (groupEnt[p].end > hi[it->second]) hi[it->second] = groupEnt[p].end;
+      }
+    }
+    std::vector<double> ll(size);
+    double best = -1;
+    for (int j = 0; j < size; ++j) {
+      const int len = R.al[members[j]].seqLen;
+      int span = hi[j] - lo[j] + 1;
+      if (span > len) span = len;
+      ll[j] = pow(double(span) / len, R.al[members[j]].ecAbundance);
+      if (ll[j] > best) best = ll[j];
+    }
+    std::vector<int> kept;
+    for (int j = 0; j < size; ++j)
+      if (ll[j] / best >= 0.05 || ll[j] == best) kept.push_back(members[j]);
+    members = kept;
+  }
+}
+
+int Genotyper::geneTypes(int gene) const {
+  if (selected[gene].empty()) return 0;
+  int top = 0;
+  for (auto &s : selected[gene]) top = std::max(top, s.second);
+  return top + 1;
+}
+
+// upper/lower tail of the standard normal, Hill's algorithm AS 66 (Applied Statistics 22(3), 1973) as used by
+// Genotyper.hpp:252-370
+static double normalTail(double x, bool upper) {
+  const double ltone = 7.0, utzero = 18.66, con = 1.28;
+  bool up = upper;
+  double z = x;
+  if (z < 0) { up = !up; z = -z; }
+  if (ltone < z && (!up || utzero < z)) return up ? 0.0 : 1.0;
+  double y = 0.5 * z * z, v;
+  if (z <= con)
+    v = 0.5 - z * (0.398942280444 - 0.39990348504 * y / (y + 5.75885480458 + -29.8213557807 / (y + 2.62433121679 + 48.6959930692 / (y + 5.92885724438))));
+  else
+    v = 0.398942280385 * exp(-y) /
+        (z + -0.000000038052 + 1.00000615302 / (z + 0.000398064794 + 1.98615381364 / (z + -0.151679116635 + 5.29330324926 / (z + 4.8385912808 + -15.1508972451 / (z + 0.742380924027 + 30.789933034 / (z + 3.99019417011))))));
+  return up ? v : 1.0 - v;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// SelectAllelesForGenes (Genotyper.hpp:1462-2090)
+// ------------------------------------------------------------------------------------------------------------------
+void Genotyper::select() {
+  RefSet &R = *ref;
+  const int G = (int)nGroups(), nGenes = (int)R.geneName.size(), E = (int)ecAlleles.size();
+  const double frac = prm.filter_frac;
+  std::vector<char> groupCovered(G, 0);
+  selected.assign(nGenes, {});
+  auto firstWeight = [&](int g) { return (double)groupEnt[groupPtr[g]].weight; };
+  auto lowAbundance = [&](int a) {  // 1568-1570 == 1656-1658
+    const AlleleMeta &m = R.al[a];
+    return m.ecAbundance < frac * geneMaxMajor[m.gene] &&
+           (m.ecAbundance * 3 >= majorAbund[m.major] || majorAbund[m.major] < 3 * frac * geneMaxMajor[m.gene]);
+  };
+  // classes by abundance (desc), class id (asc)
+  std::vector<std::pair<int, double>> order;
+  for (int e = 0; e < E; ++e) order.push_back({e, ecAlleles[e].empty() ? 0.0 : R.al[ecAlleles[e][0]].ecAbundance});
+  std::sort(order.begin(), order.end(), [](const std::pair<int, double> &x, const std::pair<int, double> &y) { return x.second != y.second ? y.second < x.second : x.first < y.first; });
+  std::vector<int> rejected;
+  for (auto &oe : order) {
+    const std::vector<int> &members = ecAlleles[oe.first];
+    if (members.empty()) break;  // cannot happen: dropUnlikely always keeps the maximum
+    const int lead = members[0];
+    if (R.al[lead].ecAbundance <= 1e-6) break;
+    double covered = 0, total = 0;
+    for (auto &gs : inAllele[lead]) {
+      double w = firstWeight(gs.first);
+      if (groupCovered[gs.first]) covered += w;
+      total += w;
+    }
+    std::vector<int> genesHere, toAdd;
+    for (int a : members) {
+      const AlleleMeta &m = R.al[a];
+      bool reject = lowAbundance(a);
+      if (covered == total &&
+          (m.ecAbundance < 0.25 * geneMaxMajor[m.gene] || selected[m.gene].empty() || m.ecAbundance < 0.5 * R.al[selected[m.gene].back().first].ecAbundance))
+        reject = true;
+      if (reject) { rejected.push_back(a); continue; }
+      if (std::find(genesHere.begin(), genesHere.end(), m.gene) == genesHere.end()) genesHere.push_back(m.gene);
+      toAdd.push_back(a);
+    }
+    const int quality = genesHere.size() > 1 ? 0 : 60;
+    if (!genesHere.empty())
+      for (auto &gs : inAllele[lead]) groupCovered[gs.first] = 1;
+    std::map<int, int> freshRank;
+    for (int a : toAdd) {
+      AlleleMeta &m = R.al[a];
+      int rank = -1;
+      for (auto &s : selected[m.gene])
+        if (R.al[s.first].major == m.major) { rank = s.second; break; }
+      if (rank == -1) {
+        auto it = freshRank.find(m.gene);
+        if (it != freshRank.end()) rank = it->second;
+        else { rank = geneTypes(m.gene); freshRank[m.gene] = rank; }
+      }
+      m.quality = quality;
+      m.rank = rank;
+      if (lowAbundance(a)) m.quality = 0;
+      selected[m.gene].push_back({a, rank});
+    }
+  }
+  // rescue rejected alleles whose major allele did get selected (1669-1695)
+  for (int a : rejected) {
+    const AlleleMeta &m = R.al[a];
+    int rank = -1;
+    for (auto &s : selected[m.gene])
+      if (R.al[s.first].major == m.major) { rank = s.second; break; }
+    if (rank != -1) selected[m.gene].push_back({a, rank});
+  }
+  // genes with more than two allele types: pick the pair of types explaining the most reads (1697-1996)
+  std::vector<int> groupUse(G, 0);
+  auto forTopTwo = [&](int gene, std::set<int> &usedEc, int delta) {
+    for (auto &s : selected[gene]) {
+      if (s.second > 1) continue;
+      if (!usedEc.insert(R.al[s.first].ec).second) continue;
+      for (auto &gs : inAllele[s.first]) groupUse[gs.first] += delta;
+    }
+  };
+  {
+    std::set<int> usedEc;  // shared across genes here (1705-1729)
+    for (int g = 0; g < nGenes; ++g) forTopTwo(g, usedEc, +1);
+  }
+  std::vector<std::map<int, double>> typeWeight(nGenes);  // missing coverage -> abundance of the best type carrying it (1733-1770)
+  for (int g = 0; g < nGenes; ++g) {
+    const int T = geneTypes(g);
+    std::vector<int> miss(T, -1);
+    std::vector<double> ab(T, 0);
+    for (auto &s : selected[g]) {
+      ab[s.second] += R.al[s.first].abundance;
+      if (miss[s.second] == -1 || R.al[s.first].missingCov < miss[s.second]) miss[s.second] = R.al[s.first].missingCov;
+    }
+    for (int t = 0; t < T; ++t) {
+      auto it = typeWeight[g].find(miss[t]);
+      if (it == typeWeight[g].end() || it->second < ab[t]) typeWeight[g][miss[t]] = ab[t];
+    }
+  }
+  for (int iter = 0; iter < 1000; ++iter) {
+    int changed = 0;
+    for (int g = 0; g < nGenes; ++g) {
+      const int T = geneTypes(g);
+      if (T <= 2) continue;
+      std::vector<std::pair<int, int>> &sel = selected[g];
+      const int S = (int)sel.size();
+      std::set<int> usedEc;
+      forTopTwo(g, usedEc, -1);
+      double bestCover = 0, bestProduct = 0;
+      std::vector<std::pair<int, int>> bestPairs;
+      int lastJ = 0, lastK = 0;
+      (void)lastK;
+      for (int j = 0; j < T - 1 && j <= 1; ++j) {
+        usedEc.clear();
+        std::map<int, int> fromJ;
+        for (int l = 0; l < S; ++l) {
+          if (sel[l].second != j) continue;
+          if (!usedEc.insert(R.al[sel[l].first].ec).second) continue;
+          for (auto &gs : inAllele[sel[l].first])
+            if (groupUse[gs.first] == 0) fromJ[gs.first] |= 1;
+          lastJ = l;
+        }
+        for (int k = j + 1; k < T; ++k) {
+          std::map<int, int> cover = fromJ;
+          for (int l = 0; l < S; ++l) {  // usedEc deliberately survives from one k to the next
+            if (sel[l].second != k) continue;
+            if (!usedEc.insert(R.al[sel[l].first].ec).second) continue;
+            for (auto &gs : inAllele[sel[l].first])
+              if (groupUse[gs.first] == 0) cover[gs.first] |= 2;
+            lastK = l;
+          }
+          double abJ = 0, abK = 0;
+          int missJ = -1, missK = -1;
+          for (int l = 0; l < S; ++l) {
+            const AlleleMeta &m = R.al[sel[l].first];
+            if (sel[l].second == j) { abJ += m.abundance; if (missJ == -1 || m.missingCov < missJ) missJ = m.missingCov; }
+            else if (sel[l].second == k) { abK += m.abundance; if (missK == -1 || m.missingCov < missK) missK = m.missingCov; }
+          }
+          const double product = abJ * abK;
+          double score = 0;
+          for (auto &kv : cover) score += groupEnt[groupPtr[kv.first]].adjustWeight;
+          if (T > 3 || missJ >= 10 || missK >= 10) {
+            double wJ = typeWeight[g][missJ], wK = typeWeight[g][missK];
+            if (T <= 3) {
+              if (wJ >= 1) wJ = log(wJ) / log(10.0);
+              if (wK >= 1) wK = log(wK) / log(10.0);
+            }
+            score = score - missJ * wJ * readLength / 150.0 - missK * wK * readLength / 150.0 + (R.al[sel[lastJ].first].weight);
+          }
+          if (bestPairs.empty() || score > bestCover || (score == bestCover && product > bestProduct)) {
+            bestCover = score; bestProduct = product;
+            bestPairs.clear();
+            bestPairs.push_back({j, k});
+          } else if (score == bestCover) bestPairs.push_back({j, k});
+        }
+      }
+      const std::pair<int, int> win = bestPairs[0];
+      if (win.first != 0 || win.second != 1) {
+        ++changed;
+        for (auto &s : sel) {
+          int r;
+          if (s.second == win.first) r = 0;
+          else if (s.second == win.second) r = 1;
+          else if (s.second < win.first) r = s.second + 2;
+          else if (s.second < win.second) r = s.second + 1;
+          else continue;
+          s.second = r;
+          R.al[s.first].rank = r;
+        }
+      }
+      usedEc.clear();
+      forTopTwo(g, usedEc, +1);
+    }
+    if (!changed) break;
+  }
+  // genotype quality (2010-2085)
+  std::vector<double> selAbund(nGenes, 0);
+  for (int g = 0; g < nGenes; ++g)
+    for (auto &s : selected[g]) selAbund[g] += R.al[s.first].abundance;
+  const double crossAllele = 0.01;
+  for (int g = 0; g < nGenes; ++g) {
+    const int T = geneTypes(g);
+    std::vector<double> ab(T, 0);
+    for (auto &s : selected[g]) ab[s.second] += R.al[s.first].abundance;
+    double noise = 0;
+    for (int o = 0; o < nGenes; ++o)
+      if (o != g) noise += prm.cross_gene_rate * R.geneSim[o][g] * selAbund[o];
+    for (int t = 0; t < T; ++t) {
+      double nullMean = (selAbund[g] - ab[t]) * crossAllele + noise;
+      double score = 0;
+      if (ab[t]) score = -log(normalTail(2 * (sqrt(ab[t]) - sqrt(nullMean)), true)) / log(double(10.0));
+      if (score > 60) score = 60;
+      if (score < 0) score = 0;
+      if (ab[t] < prm.filter_cov) score = 0;
+      for (auto &s : selected[g])
+        if (s.second == t && R.al[s.first].quality > 0) R.al[s.first].quality = (int)score;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// text output (Genotyper::GetAlleleDescription 2103-2178 + Genotyper.cpp:660-670; OutputRepresentativeAlleles 2180-2229)
+// ------------------------------------------------------------------------------------------------------------------
+std::string Genotyper::geneLine(int gene) const {
+  const RefSet &R = *ref;
+  std::vector<char> shown(R.majorName.size(), 0);
+  int firstTwoQual[2] = {-1, -1};
+  int called = 0;
+  int T = std::max(2, geneTypes(gene));
+  std::string field[3];
+  char sep = '\t';
+  char num[64];
+  for (int type = 0; type < T; ++type) {
+    std::string &buf = field[type < 2 ? type : 2];
+    if (type > 1) sep = ';';
+    buf.clear();  // the reference resets the buffer for every type, so only the last secondary type survives
+    double abundance = 0;
+    bool any = false;
+    int qual = -1;
+    if (type == 1 && firstTwoQual[0] == 0) std::fill(shown.begin(), shown.end(), 0);
+    for (auto &s : selected[gene]) {
+      if (s.second != type) continue;
+      const AlleleMeta &m = R.al[s.first];
+      abundance += m.abundance;
+      if (shown[m.major]) continue;
+      qual = m.quality;
+      if (type <= 1) called = type + 1;
+      if (any) buf += ",";
+      buf += R.majorName[m.major];
+      any = true;
+      shown[m.major] = 1;
+    }
+    if (qual >= 0) { snprintf(num, sizeof(num), "%c%lf%c%d", sep, abundance, sep, qual); buf += num; }
+    else if (type <= 1) buf += ".\t0\t-1";
+    if (type <= 1) firstTwoQual[type] = qual;
+  }
+  std::string line = R.geneName[gene] + "\t" + std::to_string(called);
+  for (int j = 0; j < 3; ++j) line += "\t" + field[j];
+  line += "\n";
+  return line;
+}
+
+std::string Genotyper::alleleLines() const {
+  const RefSet &R = *ref;
+  std::string out;
+  for (size_t g = 0; g < R.geneName.size(); ++g) {
+    int rep[2] = {-1, -1};
+    for (auto &s : selected[g]) {
+      const int t = s.second, a = s.first;
+      if (t > 1 || R.al[a].quality < 1) continue;
+      if (rep[t] == -1 || R.al[rep[t]].ecAbundance < R.al[a].ecAbundance || (R.al[rep[t]].ecAbundance == R.al[a].ecAbundance && rep[t] > a)) rep[t] = a;
+    }
+    if (rep[1] == -1 && rep[0] != -1) {  // two alleles of one major allele (2201-2221)
+      double top = -1;
+      int pick = -1;
+      for (auto &s : selected[g]) {
+        const int a = s.first;
+        if (s.second != 0 || R.al[a].ec == R.al[rep[0]].ec) continue;
+        std::string g1, m1, g2, m2;
+        R.splitName(R.al[a].name, g1, m1, 1);
+        R.splitName(R.al[rep[0]].name, g2, m2, 1);
+        if (m1 == m2) continue;
+        if (R.al[a].ecAbundance > top || (R.al[a].ecAbundance == top && a < pick)) { top = R.al[a].ecAbundance; pick = a; }
+      }
+      if (top != -1) rep[1] = pick;
+    }
+    for (int j = 0; j < 2; ++j)
+      if (rep[j] != -1) out += R.al[rep[j]].name + " " + std::to_string(R.al[rep[j]].quality) + "\n";
+  }
+  return out;
+}
+
+}  // namespace t1k

@@ -1,0 +1,223 @@
+// t1k_amd/csrc/host/refset.cpp -- sequence-file input and the allele reference set of the genotyper stage.
+#include <zlib.h>
+#include <algorithm>
+#include <cstring>
+#include "t1k_host.h"
+
+namespace t1k {
+
+namespace {
+// buffered line source over zlib (reads plain and gz files alike)
+class LineSource {
+ public:
+  explicit LineSource(const std::string &path) : buf_(1 << 20) { fp_ = gzopen(path.c_str(), "rb"); }
+  ~LineSource() { if (fp_) gzclose(fp_); }
+  bool ok() const { return fp_ != nullptr; }
+  bool next(std::string &line) {
+    line.clear();
+    bool any = false;
+    while (true) {
+      if (pos_ == len_) {
+        int n = gzread(fp_, buf_.data(), (unsigned)buf_.size());
+        if (n <= 0) break;
+        len_ = (size_t)n; pos_ = 0;
+      }
+      any = true;
+      const char *s = buf_.data() + pos_;
+      const char *nl = (const char *)memchr(s, '\n', len_ - pos_);
+      if (nl) { line.append(s, nl - s); pos_ = (size_t)(nl - buf_.data()) + 1; goto done; }
+      line.append(s, len_ - pos_);
+      pos_ = len_;
+    }
+    if (!any) return false;
+  done:
+    if (!line.empty() && line.back() == '\r') line.pop_back();
+    return true;
+  }
+
+ private:
+  gzFile fp_ = nullptr;
+  std::vector<char> buf_;
+  size_t pos_ = 0, len_ = 0;
+};
+}  // namespace
+
+bool readSeqFile(const std::string &path, std::vector<SeqRec> &out, std::string &err) {
+  LineSource in(path);
+  if (!in.ok()) { err = "cannot open " + path; return false; }
+  std::string line;
+  bool have = in.next(line);
+  while (have) {
+    if (line.empty() || (line[0] != '>' && line[0] != '@')) { have = in.next(line); continue; }
+    const bool fastq = line[0] == '@';
+    SeqRec r;
+    size_t sp = line.find_first_of(" \t");
+    r.id = sp == std::string::npos ? line.substr(1) : line.substr(1, sp - 1);
+    if (sp != std::string::npos && sp + 1 < line.size()) { r.comment = line.substr(sp + 1); r.hasComment = !r.comment.empty(); }
+    size_t n = r.id.size();
+    if (n >= 2 && r.id[n - 2] == '/' && (r.id[n - 1] == '1' || r.id[n - 1] == '2')) r.id.resize(n - 2);
+    have = in.next(line);
+    while (have && !(!line.empty() && (line[0] == '>' || line[0] == '@' || line[0] == '+'))) { r.seq += line; have = in.next(line); }
+    if (fastq && have && !line.empty() && line[0] == '+') {
+      size_t q = 0;
+      have = in.next(line);
+      while (have && q < r.seq.size()) { q += line.size(); have = in.next(line); }
+    }
+    out.push_back(std::move(r));
+  }
+  return true;
+}
+
+// Genotyper::ParseAlleleName (Genotyper.hpp:63-131)
+void RefSet::splitName(const std::string &allele, std::string &gene, std::string &major, int fieldsType) const {
+  int mode = 1, fields = digitUnits;
+  char delim = 0;
+  if (fields == -1) {
+    fields = 3;
+    if (allele.find(':') != std::string::npos) { delim = ':'; mode = 2; }
+    if (fieldsType >= 1) fields = mode == 1 ? 5 : 3;
+  }
+  if (delimiter != 0) { delim = delimiter; mode = 2; }
+  size_t star = allele.find('*');
+  size_t i = star == std::string::npos ? allele.size() : star;
+  gene = allele.substr(0, i);
+  if (mode == 1) {
+    size_t j = 0;
+    while ((int)j <= fields && i + j < allele.size()) ++j;
+    major = allele.substr(0, i + j);
+  } else {
+    int seen = 0;
+    size_t j = i;
+    for (; j < allele.size(); ++j)
+      if (allele[j] == delim && ++seen >= fields) break;
+    major = allele.substr(0, j);
+  }
+}
+
+namespace {
+// canonical 31-mer multiset of one sequence (KmerCount::AddCount, KmerCount.hpp:53-81); which of the two strands
+// represents a pair is irrelevant for the similarity below, only that both map to one key
+void kmerProfile(const std::string &s, std::unordered_map<uint64_t, int> &prof) {
+  const int K = 31;
+  if ((int)s.size() < K) return;
+  const uint64_t mask = (1ull << (2 * K)) - 1;
+  uint64_t fw = 0, rv = 0;
+  int invalid = -1;
+  for (size_t i = 0; i < s.size(); ++i) {
+    int c = s[i] == 'A' ? 0 : s[i] == 'C' ? 1 : s[i] == 'G' ? 2 : s[i] == 'T' ? 3 : -1;
+    if (invalid != -1) ++invalid;
+    int b = c < 0 ? 3 : c;
+    fw = ((fw << 2) | (uint64_t)b) & mask;
+    rv = (rv >> 2) | ((uint64_t)(3 - b) << (2 * (K - 1)));
+    if (s[i] == 'N') invalid = 0;
+    if (invalid >= K) invalid = -1;
+    if ((int)i < K - 1) continue;
+    if (invalid == -1) ++prof[fw < rv ? fw : rv];
+  }
+}
+}  // namespace
+
+bool RefSet::load(const std::string &fasta, int digitUnitsArg, char delimiterArg, std::string &err) {
+  digitUnits = digitUnitsArg;
+  delimiter = delimiterArg;
+  std::vector<SeqRec> recs;
+  if (!readSeqFile(fasta, recs, err)) return false;
+  std::unordered_map<std::string, int> firstWithSeq;
+  for (auto &r : recs) {
+    auto it = firstWithSeq.find(r.seq);
+    if (it != firstWithSeq.end()) { al[it->second].weight += 1; continue; }  // Genotyper.hpp:718-721
+    firstWithSeq.emplace(r.seq, (int)al.size());
+    AlleleMeta m;
+    m.name = r.id;
+    const int L = (int)r.seq.size();
+    m.seqLen = L;
+    for (int i = 0; i < L; ++i)  // SeqSet::ComputeEffectiveLen (747-758)
+      if (r.seq[i] != 'N' || (i > 0 && r.seq[i - 1] != 'N')) ++m.effLen;
+    // exon intervals from the header comment (SeqSet.hpp:933-976): numbers[0] ignored, then (start, end) pairs
+    std::vector<std::pair<int, int>> ex;
+    if (r.hasComment) {
+      std::vector<int> nums;
+      int v = 0;
+      for (char c : r.comment) {
+        if (c >= '0' && c <= '9') v = v * 10 + (c - '0');
+        else { nums.push_back(v); v = 0; }
+      }
+      if (v) nums.push_back(v);
+      if (!nums.empty()) {
+        for (size_t i = 1; i < nums.size(); i += 2) ex.push_back({nums[i], i + 1 < nums.size() ? nums[i + 1] : 0});
+      } else ex.push_back({0, L - 1});
+    } else ex.push_back({0, L - 1});
+    std::vector<uint8_t> mask(L, 0);  // SetSeqExonInfo (638-723)
+    for (auto &e : ex)
+      for (int j = std::max(e.first, 0); j <= e.second && j < L; ++j) mask[j] = 1;
+    for (size_t i = 1; i < ex.size(); ++i)
+      if (ex[i].first > ex[i - 1].second + 1) { rnaData = false; break; }
+    al.push_back(m);
+    seqs.push_back(r.seq);
+    exon.push_back(std::move(mask));
+  }
+  const int A = (int)al.size();
+  if (A == 0) { err = "no sequences in " + fasta; return false; }
+  if (!rnaData) {  // SeqSet::UpdateDnaSeqWeight (1008-1029): weight = multiplicity of the exon-only sequence
+    std::unordered_map<std::string, int> w;
+    std::vector<std::string> exonSeq(A);
+    for (int a = 0; a < A; ++a)
+      for (int p = 0; p < al[a].seqLen; ++p)
+        if (exon[a][p]) exonSeq[a] += seqs[a][p];
+    for (int a = 0; a < A; ++a) w[exonSeq[a]] += al[a].weight;
+    for (int a = 0; a < A; ++a) al[a].weight = w[exonSeq[a]];
+  }
+  // Genotyper::InitAlleleInfo (559-682)
+  std::unordered_map<std::string, int> geneId, majorId;
+  for (int a = 0; a < A; ++a) {
+    std::string g, m;
+    splitName(al[a].name, g, m, 0);
+    auto gi = geneId.find(g);
+    if (gi == geneId.end()) { gi = geneId.emplace(g, (int)geneName.size()).first; geneName.push_back(g); }
+    auto mi = majorId.find(m);
+    if (mi == majorId.end()) { mi = majorId.emplace(m, (int)majorName.size()).first; majorName.push_back(m); }
+    al[a].gene = gi->second;
+    al[a].major = mi->second;
+  }
+  const int Gn = (int)geneName.size();
+  // gene similarity from the lexicographically smallest allele sequence of each gene (598-638)
+  std::vector<std::unordered_map<uint64_t, int>> prof(Gn);
+  {
+    std::vector<int> pick(Gn, -1);
+    for (int a = 0; a < A; ++a) {
+      int g = al[a].gene;
+      if (pick[g] == -1 || strcmp(seqs[a].c_str(), seqs[pick[g]].c_str()) < 0) pick[g] = a;
+    }
+    for (int g = 0; g < Gn; ++g) kmerProfile(seqs[pick[g]], prof[g]);
+  }
+  geneSim.assign(Gn, std::vector<double>(Gn, 0));
+  for (int i = 0; i < Gn; ++i)
+    for (int j = 0; j < Gn; ++j) {
+      if (i == j) { geneSim[i][j] = 1.0; continue; }
+      int total = 0, shared = 0;
+      for (auto &kv : prof[i]) {
+        total += kv.second;
+        if (prof[j].count(kv.first)) shared += kv.second;
+      }
+      geneSim[i][j] = (double)shared / (double)total;
+    }
+  // effective-length repair (641-681): alleles > 500 shorter than their gene's modal length inherit the mode
+  for (int g = 0; g < Gn; ++g) {
+    std::vector<int> lens;
+    for (int a = 0; a < A; ++a)
+      if (al[a].gene == g) lens.push_back(al[a].effLen);
+    std::sort(lens.begin(), lens.end());
+    int mode = 0, run = 0;
+    for (size_t j = 0; j < lens.size();) {
+      size_t k = j;
+      while (k < lens.size() && lens[k] == lens[j]) ++k;
+      if ((int)(k - j) > run) { run = (int)(k - j); mode = lens[j]; }
+      j = k;
+    }
+    for (int a = 0; a < A; ++a)
+      if (al[a].gene == g && al[a].effLen < mode - 500) al[a].effLen = mode;
+  }
+  return true;
+}
+
+}  // namespace t1k

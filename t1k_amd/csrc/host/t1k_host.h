@@ -1,0 +1,78 @@
+// t1k_amd/csrc/host/t1k_host.h -- host C++ around the device stages: the parts of the genotyper stage that stay on
+// the CPU: FASTA/FASTQ input, allele naming, read-group coalescing,
+// equivalence classes, the SQUAREM control loop (the E-step runs on the GPU), allele selection, TSV writers.
+#pragma once
+#include <cstdint>
+#include <map>
+#include <string>
+#include <unordered_map>
+#include <vector>
+#include "../../../include/t1k_gpu.h"
+
+namespace t1k {
+
+struct SeqRec {
+  std::string id, comment, seq;
+  bool hasComment = false;
+};
+// FASTA / FASTQ, plain or gz; id = header up to the first blank with a trailing /1 or /2 removed (ReadFiles.hpp:185-189)
+bool readSeqFile(const std::string &path, std::vector<SeqRec> &out, std::string &err);
+
+struct AlleleMeta {
+  std::string name;
+  int seqLen = 0, effLen = 0, weight = 1;
+  int gene = -1, major = -1;
+  int missingCov = 0, ec = -1;
+  int rank = -1, quality = -1;
+  double abundance = 0, ecAbundance = 0;
+};
+
+struct RefSet {
+  std::vector<AlleleMeta> al;
+  std::vector<std::string> seqs;
+  std::vector<std::vector<uint8_t>> exon;
+  std::vector<std::string> geneName, majorName;
+  std::vector<std::vector<double>> geneSim;  // geneSim[i][j] = how similar gene i's k-mers are to gene j's (KmerCount.hpp:196-216)
+  bool rnaData = true;
+  // load + merge identical sequences + exon masks + weights + naming (Genotyper::InitRefSet, Genotyper.hpp:707-730)
+  bool load(const std::string &fasta, int digitUnits, char delimiter, std::string &err);
+  void splitName(const std::string &allele, std::string &gene, std::string &major, int fieldsType) const;
+  int digitUnits = -1;
+  char delimiter = 0;
+};
+
+struct GroupEntry {
+  int allele, start, end;
+  float weight, adjustWeight;
+};
+
+struct Genotyper {
+  RefSet *ref = nullptr;
+  t1k_job_params prm;
+  // coalesced read groups (Genotyper::readAssignments, Genotyper.hpp:443), CSR
+  std::vector<uint64_t> groupPtr{0};
+  std::vector<GroupEntry> groupEnt;
+  std::unordered_map<uint64_t, std::vector<uint32_t>> groupOfHash;
+  uint64_t assignedFragments = 0;
+  double sumAssign = 0;
+  int readLength = 0;
+  // allele -> (group, slot) lists, equivalence classes
+  std::vector<std::vector<std::pair<int, int>>> inAllele;
+  std::vector<std::vector<int>> ecAlleles;
+  std::vector<std::vector<std::pair<int, int>>> selected;  // per gene: (allele, rank)
+  std::vector<double> geneAbund, majorAbund, geneMaxMajor;
+  int emIterations = 0;
+
+  size_t nGroups() const { return groupPtr.size() - 1; }
+  void coalesce(t1k_row_entry *row, uint32_t n);             // CoalesceReadAssignments (841-908), one fragment
+  void finalize(const std::vector<int32_t> &coverage);       // FinalizeReadAssignments (912-939)
+  int quantify(t1k_ctx *ctx, t1k_allreduce_fn cb, void *user, std::string &err);  // QuantifyAlleleEquivalentClass (1142-1328)
+  void dropUnlikely();                                       // RemoveLowLikelihoodAlleleInEquivalentClass (1371-1460)
+  void select();                                             // SelectAllelesForGenes (1462-2090)
+  std::string geneLine(int gene) const;                      // GetAlleleDescription (2103-2178) + Genotyper.cpp:660-670
+  std::string alleleLines() const;                           // OutputRepresentativeAlleles (2180-2229)
+  void setAbundance(const double *ecReadCount, const std::vector<int> &ecLen);  // SetAlleleAbundance (957-1014)
+  int geneTypes(int gene) const;                             // GetGeneAlleleTypes (1053-1069)
+};
+
+}  // namespace t1k

@@ -278,6 +278,7 @@ int t1k_reads_upload(t1k_ctx *ctx, const char *seqs, const uint64_t *offsets, co
   ctx->reads.weight = (const uint32_t *)ctx->bReadWeight.p;
   ctx->batchMaxLen = maxLen;
   ctx->nCand = ctx->nOvl = 0;
+  ctx->rangeCount = 0;
   return T1K_OK;
 }
 
@@ -304,9 +305,19 @@ static int capacityError(t1k_ctx *ctx, unsigned long long flags) {
 }
 
 int t1k_assign_batch(t1k_ctx *ctx) {
-  if (!ctx || !ctx->ref.bases) return t1k_fail(ctx, T1K_ERR_STATE, "t1k_assign_batch: no reference uploaded");
+  if (!ctx) return T1K_ERR_ARG;
+  return t1k_assign_range(ctx, 0, ctx->reads.nReadEnds);
+}
+
+int t1k_assign_range(t1k_ctx *ctx, uint64_t first, uint32_t count) {
+  if (!ctx || !ctx->ref.bases) return t1k_fail(ctx, T1K_ERR_STATE, "t1k_assign_range: no reference uploaded");
+  if (first + count > ctx->reads.nReadEnds) return t1k_fail(ctx, T1K_ERR_ARG, "t1k_assign_range: range outside the uploaded reads");
   T1K_HIP(ctx, hipSetDevice(ctx->device));
-  const uint32_t n = ctx->reads.nReadEnds;
+  const uint32_t n = count;
+  T1kReadsDev rd = ctx->reads;  // view of the sub-range; read-end ids inside the batch are relative to `first`
+  rd.nReadEnds = count;
+  rd.bases += first * 2 * rd.S; rd.nmask += first * 2 * rd.S; rd.len += first; rd.weight += first;
+  ctx->rangeCount = count;
   int rc;
   const int nWg = (int)std::min<uint32_t>((uint32_t)ctx->prm.workgroups, std::max<uint32_t>(n, 1));
   const uint32_t stageCap = 1u << 16;
@@ -333,7 +344,7 @@ int t1k_assign_batch(t1k_ctx *ctx) {
   unsigned long long hc[16];
   double t0 = nowMs();
   AssignArgs a{};
-  a.ref = ctx->ref; a.reads = ctx->reads;
+  a.ref = ctx->ref; a.reads = rd;
   a.k = ctx->prm.kmer_length; a.radius = ctx->prm.radius; a.hitLenRequired = ctx->prm.hit_len_required;
   a.sim = ctx->prm.ref_seq_similarity; a.relax = ctx->prm.relax_intron_align;
   a.wgHits = (uint32_t *)ctx->bWgHits.p; a.hitCap = (uint64_t)ctx->prm.hit_cap_per_wg;
@@ -350,13 +361,13 @@ int t1k_assign_batch(t1k_ctx *ctx) {
   if (hc[2]) return capacityError(ctx, hc[2]);
   ctx->nCand = hc[0];
   ExtendArgs e{};
-  e.ref = ctx->ref; e.reads = ctx->reads; e.k = a.k; e.sim = a.sim;
+  e.ref = ctx->ref; e.reads = rd; e.k = a.k; e.sim = a.sim;
   e.cand = a.cand; e.ext = (T1kExt *)ctx->bExt.p; e.nCand = ctx->nCand; e.counters = a.counters;
   t1k_launch_extend(ctx, e);
   T1K_HIP(ctx, hipStreamSynchronize(ctx->stream));
   double t2 = nowMs();
   SelectArgs s{};
-  s.reads = ctx->reads; s.cand = a.cand; s.ext = e.ext; s.candStart = a.candStart; s.candCount = a.candCount;
+  s.reads = rd; s.cand = a.cand; s.ext = e.ext; s.candStart = a.candStart; s.candCount = a.candCount;
   s.ovl = (T1kOvl *)ctx->bOvl.p; s.ovlCap = (uint64_t)ctx->prm.ovl_cap;
   s.ovlStart = (uint32_t *)ctx->bOvlStart.p; s.ovlCount = (uint32_t *)ctx->bOvlCount.p;
   s.sortScratch = (uint64_t *)ctx->bSortScratch.p; s.sortCap = sortCap; s.counters = a.counters;
@@ -370,19 +381,19 @@ int t1k_assign_batch(t1k_ctx *ctx) {
   if ((rc = t1k_ensure(ctx, ctx->bSlowQueue, (size_t)(ctx->nOvl + 1) * 4))) return rc;
   if ((rc = t1k_ensure(ctx, ctx->bSlowScratch, (size_t)slowBlocks * 64 * t1k_slow_per_thread(maxCells)))) return rc;
   FullArgs f{};
-  f.ref = ctx->ref; f.reads = ctx->reads; f.relax = a.relax; f.ovl = s.ovl; f.nOvl = ctx->nOvl;
+  f.ref = ctx->ref; f.reads = rd; f.relax = a.relax; f.ovl = s.ovl; f.nOvl = ctx->nOvl;
   f.slowQueue = (uint32_t *)ctx->bSlowQueue.p; f.slowCap = (uint32_t)std::min<uint64_t>(ctx->nOvl + 1, 0xFFFFFFFFull); f.counters = a.counters;
   t1k_launch_fullalign(ctx, f);
   if ((rc = fetchCounters(ctx, hc))) return rc;
   if (hc[2]) return capacityError(ctx, hc[2]);
   if (hc[8]) {
     SlowArgs sl{};
-    sl.ref = ctx->ref; sl.reads = ctx->reads; sl.relax = a.relax; sl.ovl = s.ovl; sl.slowQueue = f.slowQueue; sl.nSlow = (uint32_t)hc[8];
+    sl.ref = ctx->ref; sl.reads = rd; sl.relax = a.relax; sl.ovl = s.ovl; sl.slowQueue = f.slowQueue; sl.nSlow = (uint32_t)hc[8];
     sl.scratch = (uint8_t *)ctx->bSlowScratch.p; sl.perThread = t1k_slow_per_thread(maxCells); sl.maxCells = maxCells; sl.counters = a.counters;
     t1k_launch_fullalign_slow(ctx, sl, slowBlocks);
   }
   TruncArgs tr{};
-  tr.reads = ctx->reads; tr.ovl = s.ovl; tr.ovlStart = s.ovlStart; tr.ovlCount = s.ovlCount; tr.sortScratch = s.sortScratch; tr.sortCap = sortCap;
+  tr.reads = rd; tr.ovl = s.ovl; tr.ovlStart = s.ovlStart; tr.ovlCount = s.ovlCount; tr.sortScratch = s.sortScratch; tr.sortCap = sortCap;
   tr.counters = a.counters;
   t1k_launch_truncate(ctx, tr, nWg);
   if ((rc = fetchCounters(ctx, hc))) return rc;
@@ -398,7 +409,7 @@ int t1k_assign_batch(t1k_ctx *ctx) {
 int t1k_overlaps_download(t1k_ctx *ctx, uint32_t *counts, t1k_overlap *out, uint64_t cap, uint64_t *total) {
   if (!ctx) return T1K_ERR_ARG;
   T1K_HIP(ctx, hipSetDevice(ctx->device));
-  const uint32_t n = ctx->reads.nReadEnds;
+  const uint32_t n = ctx->rangeCount;
   std::vector<uint32_t> start(n), cnt(n);
   if (n) {
     T1K_HIP(ctx, hipMemcpy(start.data(), ctx->bOvlStart.p, (size_t)n * 4, hipMemcpyDeviceToHost));

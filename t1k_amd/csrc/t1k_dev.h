@@ -341,6 +341,7 @@ struct t1k_ctx {
   T1kReadsDev reads{};
   T1kDevBuf bReadAscii, bReadOffs, bReadBases, bReadN, bReadLen, bReadWeight;
   int batchMaxLen = 0;
+  uint32_t rangeCount = 0;       // read-ends of the last t1k_assign_range
   // assignment arenas
   T1kDevBuf bWgHits, bWgGroups, bWgStage, bWgThreadScratch, bWgBig;
   T1kDevBuf bCand, bExt, bCandStart, bCandCount, bOvl, bOvlStart, bOvlCount, bCounters, bSlowQueue, bSlowScratch, bSortScratch;
@@ -353,6 +354,7 @@ struct t1k_ctx {
   T1kDevBuf bEmRowPtr, bEmEc, bEmCount, bEmLen, bEmX0, bEmX1, bEmN, bEmContrib, bEmColPtr, bEmColIdx, bEmScalars;
   uint32_t emGroups = 0, emEc = 0;
   uint64_t emNnz = 0;
+  std::vector<int32_t> hEmLen;
   t1k_allreduce_fn emAllreduce = nullptr;
   void *emUser = nullptr;
   // align batch scratch

@@ -1,0 +1,248 @@
+// t1k_amd/csrc/t1k_em.hip -- EM read-normalise / class-accumulate kernels (Genotyper::EMupdate, Genotyper.hpp:372-421)
+// and the batched AlignAlgo::GlobalAlignment entry points used by the unit tests.
+//
+// E-step, bit-identical to the reference's sequential doubles:
+//   k_em_rows : one lane per read group g: psum = sum_j x[ec_j] in row order (psum == 0 -> 1), then
+//               contrib = count_g * (x[ec] / psum) written at the entry's class-major (CSC) position
+//   k_em_cols : one lane per class: n[ec] = sum of its contributions in group order -- the order the reference's
+//               row-major loop adds them to ecReadCount[ec] -- so every class total is the same rounded double
+// (optional all-reduce of n over GPUs when groups are sharded), then the M-step (normalise by length, sum|diff|) runs on
+// the host in the reference's order: it is O(#classes) and needs the values on the host anyway.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include "t1k_dev.h"
+#include "t1k_launch.h"
+
+__global__ void k_em_rows(const uint64_t *rowPtr, const uint32_t *ecIdx, const uint64_t *cscPos, const double *count, const double *x, double *contrib,
+                          uint32_t nGroups) {
+  uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= nGroups) return;
+  uint64_t b = rowPtr[g], e = rowPtr[g + 1];
+  double psum = 0;
+  for (uint64_t p = b; p < e; ++p) psum += x[ecIdx[p]];
+  if (psum == 0) psum = 1;
+  const double c = count[g];
+  for (uint64_t p = b; p < e; ++p) contrib[cscPos[p]] = c * (x[ecIdx[p]] / psum);
+}
+
+__global__ void k_em_cols(const uint64_t *colPtr, const double *contrib, double *n, uint32_t nEc) {
+  uint32_t ec = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ec >= nEc) return;
+  uint64_t b = colPtr[ec], e = colPtr[ec + 1];
+  double s = 0;
+  for (uint64_t p = b; p < e; ++p) s += contrib[p];
+  n[ec] = s;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// batched GlobalAlignment for tests
+// ------------------------------------------------------------------------------------------------------------------
+struct AlignJobArgs {
+  const uint64_t *tb, *tn, *pb, *pn;   // packed text / pattern streams
+  const uint64_t *tPos, *pPos;         // start position of each job in the packed streams
+  const uint32_t *tLen, *pLen;
+  uint32_t nJobs;
+  int32_t *score, *nMatch, *nMismatch, *nIndel;
+  int8_t *ops; const uint32_t *opsOff; uint32_t *nOps;
+  uint8_t *scratch; uint64_t perThread; int maxCells;
+  unsigned long long *err;
+};
+
+__global__ __launch_bounds__(64) void k_align_batch(AlignJobArgs P) {
+  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, nT = gridDim.x * blockDim.x;
+  uint8_t *mine = P.scratch + (uint64_t)t * P.perThread;
+  int *rows = (int *)mine;
+  int8_t *ops = (int8_t *)(mine + 6 * (2048 + 4) * 4);
+  uint8_t *trace = mine + 6 * (2048 + 4) * 4 + 4224;
+  for (uint32_t q = t; q < P.nJobs; q += nT) {
+    int lt = (int)P.tLen[q], lp = (int)P.pLen[q];
+    if (lt > 2048 || lp > 2048 || (lt + 1) * (lp + 1) > P.maxCells) { atomicOr(P.err, 1ull); continue; }
+    T1kSeqView T{P.tb, P.tn, (int64_t)P.tPos[q]}, Pv{P.pb, P.pn, (int64_t)P.pPos[q]};
+    int nm = 0;
+    int sc = t1k_ga_general(T, lt, Pv, lp, rows, trace, &nm);
+    int n = t1k_ga_traceback(trace, lt, lp, ops);
+    int c0 = 0, c1 = 0, c2 = 0;
+    for (int i = 0; i < n; ++i) { if (ops[i] == 0) ++c0; else if (ops[i] == 1) ++c1; else ++c2; }
+    P.score[q] = sc;
+    P.nMatch[q] = c0; P.nMismatch[q] = c1; P.nIndel[q] = c2;
+    if (nm != c0) atomicOr(P.err, 2ull);  // the forward-sweep count must agree with the traceback
+    P.nOps[q] = (uint32_t)n;
+    if (P.ops) for (int i = 0; i < n; ++i) P.ops[P.opsOff[q] + i] = ops[i];
+  }
+}
+
+__global__ void k_align_count(const uint64_t *tb, const uint64_t *tn, const uint64_t *pb, const uint64_t *pn, const uint64_t *tPos, const uint64_t *pPos,
+                              const uint32_t *len, uint32_t nJobs, int32_t *nMatch) {
+  uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= nJobs) return;
+  nMatch[q] = t1k_ga_matches_window(pb, pn, (int64_t)pPos[q], tb, tn, (int64_t)tPos[q], (int)len[q], nullptr);
+}
+
+static void packStream(const char *s, const uint32_t *off, const uint32_t *len, uint32_t n, std::vector<uint64_t> &b, std::vector<uint64_t> &nm,
+                       std::vector<uint64_t> &pos) {
+  uint64_t total = 0;
+  pos.resize(n);
+  for (uint32_t i = 0; i < n; ++i) { pos[i] = total; total += ((uint64_t)len[i] + 31) / 32 * 32; }
+  b.assign(total / 32 + 4, 0); nm.assign(total / 32 + 4, 0);
+  for (uint32_t i = 0; i < n; ++i)
+    for (uint32_t j = 0; j < len[i]; ++j) {
+      char c = s[off[i] + j];
+      int code = c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : 4;
+      uint64_t p = pos[i] + j;
+      if (code == 4) nm[p >> 5] |= 1ull << ((p & 31) * 2); else b[p >> 5] |= (uint64_t)code << ((p & 31) * 2);
+    }
+}
+
+template <typename T>
+static int up(t1k_ctx *ctx, T1kDevBuf &buf, const std::vector<T> &v) {
+  int rc = t1k_ensure(ctx, buf, v.size() * sizeof(T) + 16);
+  if (rc) return rc;
+  if (!v.empty()) T1K_HIP(ctx, hipMemcpyAsync(buf.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+  return 0;
+}
+
+extern "C" {
+
+int t1k_align_batch(t1k_ctx *ctx, const char *text, const uint32_t *tOff, const uint32_t *tLen, const char *pat, const uint32_t *pOff,
+                    const uint32_t *pLen, uint32_t nJobs, int32_t *score, int32_t *nMatch, int32_t *nMismatch, int32_t *nIndel, int8_t *ops,
+                    const uint32_t *opsOff, uint32_t *nOps) {
+  if (!ctx || !text || !pat || !tOff || !pOff || !tLen || !pLen) return t1k_fail(ctx, T1K_ERR_ARG, "t1k_align_batch: bad arguments");
+  if (nJobs == 0) return T1K_OK;
+  T1K_HIP(ctx, hipSetDevice(ctx->device));
+  std::vector<uint64_t> tb, tn, tp, pb, pn, pp;
+  packStream(text, tOff, tLen, nJobs, tb, tn, tp);
+  packStream(pat, pOff, pLen, nJobs, pb, pn, pp);
+  int maxCells = 0;
+  uint64_t opsTotal = 0;
+  for (uint32_t i = 0; i < nJobs; ++i) {
+    maxCells = std::max<int>(maxCells, (int)((tLen[i] + 1) * (pLen[i] + 1)));
+    if (ops) opsTotal = std::max<uint64_t>(opsTotal, (uint64_t)opsOff[i] + tLen[i] + pLen[i] + 2);
+  }
+  const int blocks = 64;
+  const size_t perThread = (size_t)6 * (2048 + 4) * 4 + 4224 + (size_t)maxCells + 64;
+  T1kDevBuf *B = ctx->bAlign;
+  int rc;
+  if ((rc = up(ctx, B[0], tb)) || (rc = up(ctx, B[1], tn)) || (rc = up(ctx, B[2], pb)) || (rc = up(ctx, B[3], pn)) || (rc = up(ctx, B[4], tp)) ||
+      (rc = up(ctx, B[5], pp)))
+    return rc;
+  std::vector<uint32_t> tl(tLen, tLen + nJobs), pl(pLen, pLen + nJobs), oo;
+  if (ops) oo.assign(opsOff, opsOff + nJobs); else oo.assign(nJobs, 0);
+  if ((rc = up(ctx, B[6], tl)) || (rc = up(ctx, B[7], pl)) || (rc = up(ctx, B[8], oo))) return rc;
+  if ((rc = t1k_ensure(ctx, B[9], (size_t)nJobs * 5 * 4 + 64))) return rc;           // score, nMatch, nMismatch, nIndel, nOps
+  if ((rc = t1k_ensure(ctx, B[10], opsTotal + 64))) return rc;
+  if ((rc = t1k_ensure(ctx, B[11], (size_t)blocks * 64 * perThread + 64))) return rc;
+  if ((rc = t1k_ensure(ctx, ctx->bCounters, 16 * 8))) return rc;
+  T1K_HIP(ctx, hipMemsetAsync(ctx->bCounters.p, 0, 16 * 8, ctx->stream));
+  AlignJobArgs a{};
+  a.tb = (uint64_t *)B[0].p; a.tn = (uint64_t *)B[1].p; a.pb = (uint64_t *)B[2].p; a.pn = (uint64_t *)B[3].p;
+  a.tPos = (uint64_t *)B[4].p; a.pPos = (uint64_t *)B[5].p; a.tLen = (uint32_t *)B[6].p; a.pLen = (uint32_t *)B[7].p; a.nJobs = nJobs;
+  int32_t *res = (int32_t *)B[9].p;
+  a.score = res; a.nMatch = res + nJobs; a.nMismatch = res + 2 * (size_t)nJobs; a.nIndel = res + 3 * (size_t)nJobs; a.nOps = (uint32_t *)(res + 4 * (size_t)nJobs);
+  a.ops = ops ? (int8_t *)B[10].p : nullptr; a.opsOff = (uint32_t *)B[8].p;
+  a.scratch = (uint8_t *)B[11].p; a.perThread = perThread; a.maxCells = maxCells;
+  a.err = (unsigned long long *)ctx->bCounters.p;
+  hipLaunchKernelGGL(k_align_batch, dim3(blocks), dim3(64), 0, ctx->stream, a);
+  std::vector<int32_t> h((size_t)nJobs * 5);
+  unsigned long long err = 0;
+  T1K_HIP(ctx, hipMemcpyAsync(h.data(), res, h.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+  T1K_HIP(ctx, hipMemcpyAsync(&err, ctx->bCounters.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+  if (ops) T1K_HIP(ctx, hipMemcpyAsync(ops, B[10].p, opsTotal, hipMemcpyDeviceToHost, ctx->stream));
+  T1K_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (err & 1) return t1k_fail(ctx, T1K_ERR_ARG, "t1k_align_batch: sequence longer than 2048");
+  if (err & 2) return t1k_fail(ctx, T1K_ERR_DEVICE, "t1k_align_batch: forward-sweep match count disagrees with traceback");
+  if (score) memcpy(score, h.data(), (size_t)nJobs * 4);
+  if (nMatch) memcpy(nMatch, h.data() + nJobs, (size_t)nJobs * 4);
+  if (nMismatch) memcpy(nMismatch, h.data() + 2 * (size_t)nJobs, (size_t)nJobs * 4);
+  if (nIndel) memcpy(nIndel, h.data() + 3 * (size_t)nJobs, (size_t)nJobs * 4);
+  if (nOps) memcpy(nOps, h.data() + 4 * (size_t)nJobs, (size_t)nJobs * 4);
+  return T1K_OK;
+}
+
+int t1k_align_count_batch(t1k_ctx *ctx, const char *text, const uint32_t *tOff, const char *pat, const uint32_t *pOff, const uint32_t *len, uint32_t nJobs,
+                          int32_t *nMatch) {
+  if (!ctx || !text || !pat || !tOff || !pOff || !len || !nMatch) return t1k_fail(ctx, T1K_ERR_ARG, "t1k_align_count_batch: bad arguments");
+  if (nJobs == 0) return T1K_OK;
+  T1K_HIP(ctx, hipSetDevice(ctx->device));
+  std::vector<uint64_t> tb, tn, tp, pb, pn, pp;
+  packStream(text, tOff, len, nJobs, tb, tn, tp);
+  packStream(pat, pOff, len, nJobs, pb, pn, pp);
+  T1kDevBuf *B = ctx->bAlign;
+  int rc;
+  if ((rc = up(ctx, B[0], tb)) || (rc = up(ctx, B[1], tn)) || (rc = up(ctx, B[2], pb)) || (rc = up(ctx, B[3], pn)) || (rc = up(ctx, B[4], tp)) ||
+      (rc = up(ctx, B[5], pp)))
+    return rc;
+  std::vector<uint32_t> l(len, len + nJobs);
+  if ((rc = up(ctx, B[6], l))) return rc;
+  if ((rc = t1k_ensure(ctx, B[9], (size_t)nJobs * 4 + 64))) return rc;
+  hipLaunchKernelGGL(k_align_count, dim3((nJobs + 255) / 256), dim3(256), 0, ctx->stream, (uint64_t *)B[0].p, (uint64_t *)B[1].p, (uint64_t *)B[2].p,
+                     (uint64_t *)B[3].p, (uint64_t *)B[4].p, (uint64_t *)B[5].p, (uint32_t *)B[6].p, nJobs, (int32_t *)B[9].p);
+  T1K_HIP(ctx, hipMemcpyAsync(nMatch, B[9].p, (size_t)nJobs * 4, hipMemcpyDeviceToHost, ctx->stream));
+  T1K_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return T1K_OK;
+}
+
+int t1k_em_setup(t1k_ctx *ctx, const uint64_t *rowPtr, const uint32_t *ecIdx, const double *count, const int32_t *ecLen, uint32_t nGroups, uint32_t nEc,
+                 t1k_allreduce_fn allreduce, void *user) {
+  if (!ctx || !rowPtr || (!ecIdx && nGroups && rowPtr[nGroups]) || !count || !ecLen) return t1k_fail(ctx, T1K_ERR_ARG, "t1k_em_setup: bad arguments");
+  T1K_HIP(ctx, hipSetDevice(ctx->device));
+  const uint64_t nnz = rowPtr[nGroups];
+  // class-major positions: a stable counting sort of the entries by class keeps them in group order within a class
+  std::vector<uint64_t> colPtr(nEc + 1, 0), cscPos(nnz);
+  for (uint64_t p = 0; p < nnz; ++p) {
+    if (ecIdx[p] >= nEc) return t1k_fail(ctx, T1K_ERR_ARG, "t1k_em_setup: class index out of range");
+    ++colPtr[ecIdx[p] + 1];
+  }
+  for (uint32_t i = 0; i < nEc; ++i) colPtr[i + 1] += colPtr[i];
+  {
+    std::vector<uint64_t> cur(colPtr.begin(), colPtr.end() - 1);
+    for (uint64_t p = 0; p < nnz; ++p) cscPos[p] = cur[ecIdx[p]]++;
+  }
+  int rc;
+  if ((rc = t1k_ensure(ctx, ctx->bEmRowPtr, (size_t)(nGroups + 1) * 8)) || (rc = t1k_ensure(ctx, ctx->bEmEc, (size_t)nnz * 4 + 16)) ||
+      (rc = t1k_ensure(ctx, ctx->bEmCount, (size_t)nGroups * 8 + 16)) || (rc = t1k_ensure(ctx, ctx->bEmColPtr, (size_t)(nEc + 1) * 8)) ||
+      (rc = t1k_ensure(ctx, ctx->bEmColIdx, (size_t)nnz * 8 + 16)) || (rc = t1k_ensure(ctx, ctx->bEmContrib, (size_t)nnz * 8 + 16)) ||
+      (rc = t1k_ensure(ctx, ctx->bEmX0, (size_t)nEc * 8 + 16)) || (rc = t1k_ensure(ctx, ctx->bEmN, (size_t)nEc * 8 + 16)))
+    return rc;
+  T1K_HIP(ctx, hipMemcpyAsync(ctx->bEmRowPtr.p, rowPtr, (size_t)(nGroups + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+  if (nnz) T1K_HIP(ctx, hipMemcpyAsync(ctx->bEmEc.p, ecIdx, (size_t)nnz * 4, hipMemcpyHostToDevice, ctx->stream));
+  if (nGroups) T1K_HIP(ctx, hipMemcpyAsync(ctx->bEmCount.p, count, (size_t)nGroups * 8, hipMemcpyHostToDevice, ctx->stream));
+  T1K_HIP(ctx, hipMemcpyAsync(ctx->bEmColPtr.p, colPtr.data(), (size_t)(nEc + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+  if (nnz) T1K_HIP(ctx, hipMemcpyAsync(ctx->bEmColIdx.p, cscPos.data(), (size_t)nnz * 8, hipMemcpyHostToDevice, ctx->stream));
+  T1K_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->emGroups = nGroups; ctx->emEc = nEc; ctx->emNnz = nnz;
+  ctx->emAllreduce = allreduce; ctx->emUser = user;
+  // class lengths stay on the host (M-step)
+  ctx->hEmLen.assign(ecLen, ecLen + nEc);
+  return T1K_OK;
+}
+
+int t1k_em_update(t1k_ctx *ctx, const double *x0, double *x1, double *ecReadCount, double *diff) {
+  if (!ctx || !x0 || !x1 || !ecReadCount) return t1k_fail(ctx, T1K_ERR_ARG, "t1k_em_update: bad arguments");
+  T1K_HIP(ctx, hipSetDevice(ctx->device));
+  const uint32_t E = ctx->emEc, G = ctx->emGroups;
+  if (E == 0) { if (diff) *diff = 0; return T1K_OK; }
+  T1K_HIP(ctx, hipMemcpyAsync(ctx->bEmX0.p, x0, (size_t)E * 8, hipMemcpyHostToDevice, ctx->stream));
+  if (G) hipLaunchKernelGGL(k_em_rows, dim3((G + 255) / 256), dim3(256), 0, ctx->stream, (const uint64_t *)ctx->bEmRowPtr.p, (const uint32_t *)ctx->bEmEc.p,
+                            (const uint64_t *)ctx->bEmColIdx.p, (const double *)ctx->bEmCount.p, (const double *)ctx->bEmX0.p, (double *)ctx->bEmContrib.p, G);
+  hipLaunchKernelGGL(k_em_cols, dim3((E + 63) / 64), dim3(64), 0, ctx->stream, (const uint64_t *)ctx->bEmColPtr.p, (const double *)ctx->bEmContrib.p,
+                     (double *)ctx->bEmN.p, E);
+  if (ctx->emAllreduce) {
+    T1K_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->emAllreduce(ctx->bEmN.p, E, ctx->emUser);  // RCCL all-reduce of the per-class expected read counts
+  }
+  T1K_HIP(ctx, hipMemcpyAsync(ecReadCount, ctx->bEmN.p, (size_t)E * 8, hipMemcpyDeviceToHost, ctx->stream));
+  T1K_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  // M-step (Genotyper.hpp:406-420), same summation order as the reference
+  double norm = 0, d = 0;
+  for (uint32_t i = 0; i < E; ++i) norm += ecReadCount[i] / ctx->hEmLen[i];
+  for (uint32_t i = 0; i < E; ++i) {
+    double t = ecReadCount[i] / ctx->hEmLen[i] / norm;
+    d += std::fabs(t - x0[i]);
+    x1[i] = t;
+  }
+  if (diff) *diff = d;
+  return T1K_OK;
+}
+
+}  // extern "C"

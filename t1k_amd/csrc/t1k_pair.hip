@@ -1,0 +1,472 @@
+// t1k_amd/csrc/t1k_pair.hip -- mate pairing and fragment rows on the GPU.
+//   k_pair: one 256-thread workgroup per fragment restates SeqSet::ReadAssignmentToFragmentAssignment
+//           (SeqSet.hpp:2310-2655) and Genotyper::SetReadAssignments / ReadAssignmentWeight (Genotyper.hpp:778-832,
+//           205-230) on the two overlap lists left in HBM by t1k_assign_batch.
+// Mates are joined through a per-workgroup direct-address table (allele -> index in the mate's list, stamped with a
+// fragment epoch so it never needs clearing).  If an allele occurs twice in a list (several diagonal runs on one
+// allele -- rare) lane 0 replays the reference's sequential algorithm instead.
+#include <algorithm>
+#include <chrono>
+#include <cstring>
+#include "t1k_dev.h"
+#include "t1k_launch.h"
+
+#define WG 256
+
+struct Frag {
+  uint32_t allele;
+  int32_t i, j;            // index in list 1 / list 2 (-1 = none)
+  int32_t matchCnt, relaxed, seqStart, seqEnd;
+  int32_t slot;            // slow path: position in `assign`
+  double sim;
+};
+
+struct PairArgs {
+  T1kRefDev ref;
+  const T1kOvl *ovl;
+  const uint32_t *ovlStart, *ovlCount;
+  const uint32_t *end1, *end2;     // end2 == NULL: single-end run
+  const uint8_t *hasN;
+  uint32_t nFragments;
+  double sim; int relax; int maxAssign; int hitLenRequired;
+  t1k_row_entry *rows; uint64_t rowCap;
+  uint32_t *rowStart, *rowCount; uint8_t *fragAssigned;
+  uint64_t *tab2, *tabSlot;        // [wg][nAlleles]  (epoch << 32 | value)
+  Frag *frags; uint32_t fragCap;   // [wg][fragCap]
+  uint32_t *keep;                  // [wg][fragCap]
+  unsigned long long *counters;    // [2] error flags, [9] row total
+};
+
+__device__ __forceinline__ double ovlSim(const T1kOvl &o) {
+  return (double)o.matchCnt / (double)(o.readEnd - o.readStart + 1 + o.seqEnd - o.seqStart + 1 + 2 * o.leftClip + 2 * o.rightClip);
+}
+__device__ __forceinline__ int ovlStrand(const T1kOvl &o) { return (o.flags & 2) ? -1 : 1; }
+
+__device__ __forceinline__ bool sepInRangeP(const T1kRefDev &ref, uint32_t allele, int s, int e) {  // SeqSet.hpp:487-498
+  int len = (int)ref.alleleLen[allele];
+  if (s <= -1 && e >= -1) return true;
+  if (s <= len && e >= len) return true;
+  uint32_t b = ref.sepStart[allele], en = ref.sepStart[allele + 1];
+  for (uint32_t i = b; i < en; ++i) {
+    int p = ref.sepPos[i];
+    if (p >= s && p <= e) return true;
+  }
+  return false;
+}
+
+__device__ inline void makeFrag(Frag &f, const T1kOvl *o1, int i, const T1kOvl *o2, int j) {
+  // SeqSet.hpp:2391-2440
+  const T1kOvl &o = o1 ? *o1 : *o2;
+  f.allele = o.allele; f.i = o1 ? i : -1; f.j = o2 ? j : -1; f.slot = -1;
+  f.matchCnt = o.matchCnt; f.relaxed = o.relaxed; f.seqStart = o.seqStart; f.seqEnd = o.seqEnd; f.sim = ovlSim(o);
+  if (o1 && o2) {
+    f.matchCnt += o2->matchCnt;
+    f.relaxed += o2->relaxed;
+    if (ovlStrand(o) == 1) f.seqEnd = o2->seqEnd; else f.seqStart = o2->seqStart;
+    f.sim = (double)f.matchCnt / (double)(o.readEnd - o.readStart + 1 + o2->readEnd - o2->readStart + 1 + o.seqEnd - o.seqStart + 1 + o2->seqEnd -
+                                          o2->seqStart + 1 + 2 * o.leftClip + 2 * o.rightClip + 2 * o2->leftClip + 2 * o2->rightClip);
+  }
+}
+
+// _fragmentOverlap::operator< (SeqSet.hpp:164-171) then _overlap::operator< on overlap1 (103-127)
+__device__ inline bool fragBefore(const Frag &a, const T1kOvl &a1, const Frag &b, const T1kOvl &b1) {
+  if (a.matchCnt != b.matchCnt) return a.matchCnt > b.matchCnt;
+  if (a.sim != b.sim) return a.sim > b.sim;
+  if (a1.matchCnt != b1.matchCnt) return a1.matchCnt > b1.matchCnt;
+  double sa = ovlSim(a1), sb = ovlSim(b1);
+  if (sa != sb) return sa > sb;
+  if (a1.readEnd - a1.readStart != b1.readEnd - b1.readStart) return a1.readEnd - a1.readStart > b1.readEnd - b1.readStart;
+  if (a1.allele != b1.allele) return a1.allele < b1.allele;
+  if (ovlStrand(a1) != ovlStrand(b1)) return ovlStrand(a1) < ovlStrand(b1);
+  if (a1.readStart != b1.readStart) return a1.readStart < b1.readStart;
+  if (a1.readEnd != b1.readEnd) return a1.readEnd < b1.readEnd;
+  if (a1.seqStart != b1.seqStart) return a1.seqStart < b1.seqStart;
+  return a1.seqEnd < b1.seqEnd;
+}
+
+__device__ inline bool truncatedMate(const T1kRefDev &ref, const T1kOvl &o, const T1kOvl &c1, const T1kOvl &c2) {  // SeqSet.hpp:502-523
+  if (ovlStrand(o) == 1) {
+    if ((int)ref.alleleLen[o.allele] - 1 < o.seqEnd + c2.seqEnd - c1.seqEnd || sepInRangeP(ref, o.allele, o.seqEnd, o.seqEnd + c2.seqEnd - c1.seqEnd + 1))
+      return true;
+  } else {
+    if (o.seqStart - (c1.seqStart - c2.seqStart) < 0 || sepInRangeP(ref, o.allele, o.seqStart - (c1.seqStart - c2.seqStart) - 1, o.seqStart)) return true;
+  }
+  return false;
+}
+
+__device__ __forceinline__ float rowWeight(double sim, double s, bool hasN) {  // Genotyper::ReadAssignmentWeight (205-230)
+  double ret = 1;
+  double segment = (1 - s) / 4.0;
+  if (segment < 0.01) segment = 0.01;
+  if (sim < 1 - 3 * segment) ret = 0.01;
+  else if (sim < 1 - 2 * segment) ret = 0.1;
+  else if (sim < 1 - segment) ret = 0.5;
+  if (hasN) ret /= 10.0;
+  return (float)ret;
+}
+
+__device__ __forceinline__ uint32_t scanExcl(uint32_t v, uint32_t *warpSums, uint32_t *total) {
+  int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t x = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    uint32_t y = __shfl_up(x, o, 64);
+    if (lane >= o) x += y;
+  }
+  if (lane == 63) warpSums[wave] = x;
+  __syncthreads();
+  uint32_t base = 0;
+  for (int w = 0; w < wave; ++w) base += warpSums[w];
+  uint32_t tot = warpSums[0] + warpSums[1] + warpSums[2] + warpSums[3];
+  __syncthreads();
+  *total = tot;
+  return base + x - v;
+}
+
+__global__ __launch_bounds__(WG) void k_pair(PairArgs P) {
+  __shared__ uint32_t warpSums[4];
+  __shared__ int sDup, sFail, sBestM, sBestIdx, sAnySep, sNotOne;
+  __shared__ double sBestSim;
+  __shared__ uint32_t sN, sBase;
+  const int tid = threadIdx.x;
+  const uint32_t A = P.ref.nAlleles;
+  uint64_t *tab2 = P.tab2 + (uint64_t)blockIdx.x * A;
+  uint64_t *tabSlot = P.tabSlot + (uint64_t)blockIdx.x * A;
+  Frag *frags = P.frags + (uint64_t)blockIdx.x * P.fragCap;
+  uint32_t *keep = P.keep + (uint64_t)blockIdx.x * P.fragCap;
+  for (uint32_t f = blockIdx.x; f < P.nFragments; f += gridDim.x) {
+    const uint64_t epoch = (uint64_t)(f + 1) << 32;
+    const bool paired = P.end2 != nullptr;
+    const uint32_t e1 = P.end1[f];
+    const uint32_t n1 = P.ovlCount[e1];
+    const T1kOvl *L1 = P.ovl + P.ovlStart[e1];
+    uint32_t n2 = 0;
+    const T1kOvl *L2 = nullptr;
+    if (paired) { uint32_t e2 = P.end2[f]; n2 = P.ovlCount[e2]; L2 = P.ovl + P.ovlStart[e2]; }
+    const bool hasN = P.hasN ? P.hasN[f] != 0 : false;
+    if (tid == 0) { sDup = 0; sFail = 0; sBestM = -1; sBestIdx = 0x7FFFFFFF; sAnySep = 0; sNotOne = 0; sN = 0; }
+    __syncthreads();
+    const bool dangling = paired && (n1 == 0 || n2 == 0);
+    const bool both = paired && !dangling;
+    uint32_t nFrag = 0;
+    if (n1 + n2 > P.fragCap) {
+      if (tid == 0) { atomicOr(&P.counters[2], 128ull); P.rowStart[f] = 0; P.rowCount[f] = 0; P.fragAssigned[f] = 0; }
+      __syncthreads();
+      continue;
+    }
+    // ---- duplicate detection + join table --------------------------------------------------------------------------
+    for (uint32_t i = tid; i < n1; i += WG) {
+      unsigned long long old = atomicExch((unsigned long long *)&tabSlot[L1[i].allele], (unsigned long long)(epoch | i));
+      if ((old >> 32) == (epoch >> 32)) sDup = 1;
+    }
+    for (uint32_t j = tid; j < n2; j += WG) {
+      unsigned long long old = atomicExch((unsigned long long *)&tab2[L2[j].allele], (unsigned long long)(epoch | j));
+      if ((old >> 32) == (epoch >> 32)) sDup = 1;
+    }
+    __syncthreads();
+    const bool dup = sDup != 0;
+    if (!dup) {
+      // ---- fast path: every allele at most once per list -> `assign` == fragment list, in list order ----------------
+      if (!both) {
+        nFrag = n1 + n2;
+        for (uint32_t q = tid; q < nFrag; q += WG) {
+          if (q < n1) makeFrag(frags[q], &L1[q], (int)q, nullptr, -1); else makeFrag(frags[q], nullptr, -1, &L2[q - n1], (int)(q - n1));
+        }
+      } else {
+        const int s1 = ovlStrand(L1[0]), s2 = ovlStrand(L2[0]);
+        for (uint32_t i0 = 0; i0 < n1; i0 += WG) {
+          uint32_t i = i0 + tid;
+          int j = -1;
+          if (i < n1 && s1 != s2) {
+            uint64_t e = tab2[L1[i].allele];
+            if ((e >> 32) == (epoch >> 32)) {
+              int jj = (int)(e & 0x7FFFFFFFu);
+              if ((s1 == 1 && L1[i].seqStart < L2[jj].seqStart) || (s1 == -1 && L1[i].seqStart > L2[jj].seqStart)) j = jj;  // 2369-2380
+            }
+          }
+          uint32_t tot;
+          uint32_t off = scanExcl(j >= 0 ? 1u : 0u, warpSums, &tot);
+          if (j >= 0) {
+            makeFrag(frags[nFrag + off], &L1[i], (int)i, &L2[j], j);
+            tab2[L1[i].allele] |= 0x80000000ull;  // the mate's allele has a fragment (seqIdxToOverlapIdx membership)
+          }
+          nFrag += tot;
+        }
+      }
+      __syncthreads();
+    } else {
+      // ---- slow path: lane 0 replays SeqSet.hpp:2320-2455 ----------------------------------------------------------------
+      if (tid == 0) {
+        uint32_t nA = 0;
+        const uint64_t ep2 = epoch | 0x40000000ull;  // second stamp space for the slot table
+        auto add = [&](const Frag &fr, const T1kOvl &o1) {
+          uint64_t e = tabSlot[fr.allele];
+          if ((e >> 32) == (epoch >> 32) && (e & 0x40000000ull)) {
+            uint32_t s = (uint32_t)(e & 0x3FFFFFFFu);
+            const T1kOvl &b1 = frags[s].i >= 0 ? L1[frags[s].i] : L2[frags[s].j];
+            if (fragBefore(fr, o1, frags[s], b1)) frags[s] = fr;
+          } else {
+            tabSlot[fr.allele] = ep2 | nA;
+            frags[nA++] = fr;
+          }
+        };
+        Frag fr;
+        if (!both) {
+          for (uint32_t i = 0; i < n1; ++i) { makeFrag(fr, &L1[i], (int)i, nullptr, -1); add(fr, L1[i]); }
+          for (uint32_t j = 0; j < n2; ++j) { makeFrag(fr, nullptr, -1, &L2[j], (int)j); add(fr, L2[j]); }
+        } else {
+          for (uint32_t i = 0; i < n1; ++i) {
+            uint64_t e = tab2[L1[i].allele];
+            if ((e >> 32) != (epoch >> 32)) continue;
+            for (uint32_t j = 0; j < n2; ++j) {
+              if (L2[j].allele != L1[i].allele) continue;
+              int s1 = ovlStrand(L1[i]), s2 = ovlStrand(L2[j]);
+              if (s1 == s2) continue;
+              if ((s1 == 1 && L1[i].seqStart < L2[j].seqStart) || (s1 == -1 && L1[i].seqStart > L2[j].seqStart)) {
+                makeFrag(fr, &L1[i], (int)i, &L2[j], (int)j);
+                add(fr, L1[i]);
+                tab2[L1[i].allele] |= 0x80000000ull;
+              }
+            }
+          }
+        }
+        sN = nA;
+      }
+      __syncthreads();
+      nFrag = sN;
+    }
+    // ---- best fragment: max matchCnt, then max similarity, first in order (2474-2487) --------------------------------
+    {
+      int bm = -1, bi = 0x7FFFFFFF; double bs = 0;
+      for (uint32_t q = tid; q < nFrag; q += WG) {
+        const Frag &fr = frags[q];
+        if (fr.matchCnt > bm || (fr.matchCnt == bm && fr.sim > bs)) { bm = fr.matchCnt; bs = fr.sim; bi = (int)q; }
+      }
+      atomicMax(&sBestM, bm);
+      __syncthreads();
+      if (tid == 0) sBestSim = -1;
+      __syncthreads();
+      // among the lanes holding the best matchCnt: max similarity (serialised through a CAS-free two-step)
+      __shared__ double sSim[WG];
+      __shared__ int sIdx2[WG];
+      sSim[tid] = (bm == sBestM && bm >= 0) ? bs : -1.0;
+      sIdx2[tid] = (bm == sBestM && bm >= 0) ? bi : 0x7FFFFFFF;
+      __syncthreads();
+      for (int o = WG / 2; o > 0; o >>= 1) {
+        if (tid < o) {
+          double a = sSim[tid], b = sSim[tid + o];
+          int ia = sIdx2[tid], ib = sIdx2[tid + o];
+          if (b > a || (b == a && ib < ia)) { sSim[tid] = b; sIdx2[tid] = ib; }
+        }
+        __syncthreads();
+      }
+      if (tid == 0) { sBestSim = sSim[0]; sBestIdx = sIdx2[0]; }
+      __syncthreads();
+    }
+    // a lane's local best is its first maximal element, but a later element of the same lane could tie the global best
+    // with a smaller index than another lane's: resolve "first in order" exactly
+    {
+      int mine = 0x7FFFFFFF;
+      for (uint32_t q = tid; q < nFrag; q += WG) {
+        const Frag &fr = frags[q];
+        if (fr.matchCnt == sBestM && fr.sim == sBestSim) { mine = (int)q; break; }
+      }
+      if (tid == 0) sBestIdx = 0x7FFFFFFF;
+      __syncthreads();
+      if (mine != 0x7FFFFFFF) atomicMin(&sBestIdx, mine);
+      __syncthreads();
+    }
+    const int bestM = sBestM;
+    const double bestSim = sBestSim;
+    const int bestRelaxed = nFrag ? frags[sBestIdx].relaxed : 0;
+    // ---- keep filter (2488-2545), order-preserving -----------------------------------------------------------------------
+    uint32_t nKept = 0;
+    for (uint32_t q0 = 0; q0 < nFrag; q0 += WG) {
+      uint32_t q = q0 + tid;
+      bool kp = false;
+      if (q < nFrag) {
+        const Frag &fr = frags[q];
+        int relaxBy = 2;
+        if (P.relax && fr.i >= 0 && fr.j >= 0) {
+          const T1kOvl &a = L1[fr.i], &b = L2[fr.j];
+          bool inter = (a.seqStart <= b.seqStart && a.seqEnd >= b.seqStart) || (b.seqStart <= a.seqStart && b.seqEnd >= a.seqStart);  // 317-324
+          if (inter && a.matchCnt < a.relaxed && b.matchCnt < b.relaxed) relaxBy = 4;
+        }
+        kp = (fr.matchCnt == bestM && fr.sim == bestSim) || (P.relax && fr.matchCnt >= bestM - relaxBy && fr.relaxed == bestRelaxed);
+      }
+      uint32_t tot;
+      uint32_t off = scanExcl(kp ? 1u : 0u, warpSums, &tot);
+      if (kp) keep[nKept + off] = q;
+      nKept += tot;
+    }
+    __syncthreads();
+    // ---- dangling-mate rule (2553-2578) ----------------------------------------------------------------------------------
+    bool cleared = false;
+    if (nKept > 0 && paired && !(frags[keep[0]].i >= 0 && frags[keep[0]].j >= 0)) {
+      for (uint32_t q = tid; q < nKept; q += WG) {
+        const Frag &fr = frags[keep[q]];
+        const T1kOvl &o1 = fr.i >= 0 ? L1[fr.i] : L2[fr.j];
+        bool bad = fr.sim < 1 || sepInRangeP(P.ref, fr.allele, fr.seqStart, fr.seqEnd) ||
+                   (fr.seqEnd - fr.seqStart + 1 + o1.readEnd - o1.readStart + 1 < 3 * P.hitLenRequired);
+        if (!bad) {
+          const int spanRange = 100;
+          if ((ovlStrand(o1) == 1 && fr.seqEnd + spanRange < (int)P.ref.alleleLen[fr.allele]) || (ovlStrand(o1) == -1 && fr.seqStart - spanRange >= 0)) bad = true;
+        }
+        if (bad) sFail = 1;
+      }
+      __syncthreads();
+      cleared = sFail != 0;
+    }
+    // ---- truncated-reference rule (2580-2653) -----------------------------------------------------------------------------
+    if (!cleared && nKept > 0 && paired && frags[keep[0]].i >= 0 && frags[keep[0]].j >= 0) {
+      const Frag rep = frags[keep[0]];
+      const T1kOvl r1 = L1[rep.i], r2 = L2[rep.j];
+      const double r1s = ovlSim(r1), r2s = ovlSim(r2);
+      for (uint32_t i = tid; i < n1; i += WG) {
+        const T1kOvl &o = L1[i];
+        double os = ovlSim(o);
+        bool inSlot;
+        if (!dup) { uint64_t e = tab2[o.allele]; inSlot = (e >> 32) == (epoch >> 32) && (e & 0x80000000ull); }
+        else { uint64_t e = tabSlot[o.allele]; inSlot = (e >> 32) == (epoch >> 32) && (e & 0x40000000ull); }
+        if (o.matchCnt > r1.matchCnt || ((o.matchCnt == r1.matchCnt && os > r1s) && !inSlot)) {
+          if (truncatedMate(P.ref, o, r1, r2)) sFail = 1;
+          else if (os > r2s + 0.1) sFail = 1;
+        }
+      }
+      for (uint32_t j = tid; j < n2; j += WG) {
+        const T1kOvl &o = L2[j];
+        double os = ovlSim(o);
+        bool inSlot;
+        if (!dup) { uint64_t e = tab2[o.allele]; inSlot = (e >> 32) == (epoch >> 32) && (e & 0x80000000ull); }
+        else { uint64_t e = tabSlot[o.allele]; inSlot = (e >> 32) == (epoch >> 32) && (e & 0x40000000ull); }
+        if (o.matchCnt > r2.matchCnt || ((o.matchCnt == r2.matchCnt && os > r2s) && !inSlot)) {
+          if (truncatedMate(P.ref, o, r2, r1)) sFail = 1;
+          else if (os > r1s + 0.1) sFail = 1;
+        }
+      }
+      __syncthreads();
+      cleared = sFail != 0;
+    }
+    if (cleared) nKept = 0;
+    // ---- Genotyper::SetReadAssignments (778-832) ------------------------------------------------------------------------------
+    bool emptyRow = nKept == 0 || (P.maxAssign > 0 && (int)nKept > P.maxAssign);
+    if (!emptyRow) {
+      for (uint32_t q = tid; q < nKept; q += WG) {
+        const Frag &fr = frags[keep[q]];
+        if (sepInRangeP(P.ref, fr.allele, fr.seqStart, fr.seqEnd)) sAnySep = 1;
+        if (fr.sim >= 1) sNotOne = 1;  // maxSimilarity >= 1 somewhere
+      }
+      __syncthreads();
+      if (sAnySep) emptyRow = true;
+    }
+    const uint32_t nRow = emptyRow ? 0 : nKept;
+    if (tid == 0) {
+      unsigned long long b = nRow ? atomicAdd(&P.counters[9], (unsigned long long)nRow) : 0ull;
+      if (b + nRow > P.rowCap) { atomicOr(&P.counters[2], 128ull); sBase = 0xFFFFFFFFu; P.rowStart[f] = 0; P.rowCount[f] = 0; }
+      else { sBase = (uint32_t)b; P.rowStart[f] = (uint32_t)b; P.rowCount[f] = nRow; }
+      P.fragAssigned[f] = nKept > 0 ? 1 : 0;
+    }
+    __syncthreads();
+    if (nRow && sBase != 0xFFFFFFFFu) {
+      const double adjust = sNotOne ? 1.0 : 0.25;  // 804-817
+      for (uint32_t q = tid; q < nRow; q += WG) {
+        const Frag &fr = frags[keep[q]];
+        t1k_row_entry r;
+        r.allele_idx = (int32_t)fr.allele; r.start = fr.seqStart; r.end = fr.seqEnd;
+        r.weight = rowWeight(fr.sim, P.sim, hasN);
+        r.qual = 1.0f;
+        r.adjust_weight = (float)(adjust * r.weight);
+        P.rows[(uint64_t)sBase + q] = r;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+extern "C" {
+
+int t1k_pair_batch(t1k_ctx *ctx, const uint32_t *end1, const uint32_t *end2, const uint8_t *hasN, uint32_t nFragments) {
+  if (!ctx || !end1) return t1k_fail(ctx, T1K_ERR_ARG, "t1k_pair_batch: bad arguments");
+  if (!ctx->ref.bases) return t1k_fail(ctx, T1K_ERR_STATE, "t1k_pair_batch: no reference");
+  T1K_HIP(ctx, hipSetDevice(ctx->device));
+  int rc;
+  const uint32_t n = nFragments;
+  const int nWg = (int)std::min<uint32_t>(512, std::max<uint32_t>(n, 1));
+  const uint32_t fragCap = 1u << 16;
+  const uint32_t A = ctx->ref.nAlleles;
+  ctx->nFragments = n;
+  ctx->nRows = 0;
+  if ((rc = t1k_ensure(ctx, ctx->bEnd1, (size_t)n * 4))) return rc;
+  if ((rc = t1k_ensure(ctx, ctx->bEnd2, (size_t)n * 4))) return rc;
+  if ((rc = t1k_ensure(ctx, ctx->bHasN, (size_t)n))) return rc;
+  if ((rc = t1k_ensure(ctx, ctx->bRows, (size_t)ctx->prm.row_cap * sizeof(t1k_row_entry)))) return rc;
+  if ((rc = t1k_ensure(ctx, ctx->bRowStart, (size_t)n * 4))) return rc;
+  if ((rc = t1k_ensure(ctx, ctx->bRowCount, (size_t)n * 4))) return rc;
+  if ((rc = t1k_ensure(ctx, ctx->bFragAssigned, (size_t)n))) return rc;
+  size_t perWg = (size_t)A * 16 + (size_t)fragCap * (sizeof(Frag) + 4);
+  bool fresh = ctx->bPairScratch.bytes < (size_t)nWg * perWg;
+  if ((rc = t1k_ensure(ctx, ctx->bPairScratch, (size_t)nWg * perWg))) return rc;
+  if ((rc = t1k_ensure(ctx, ctx->bCounters, 16 * 8))) return rc;
+  if (fresh) T1K_HIP(ctx, hipMemsetAsync(ctx->bPairScratch.p, 0, (size_t)nWg * perWg, ctx->stream));  // epochs start at 0
+  if (n == 0) return T1K_OK;
+  double t0 = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+  T1K_HIP(ctx, hipMemcpyAsync(ctx->bEnd1.p, end1, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+  if (end2) T1K_HIP(ctx, hipMemcpyAsync(ctx->bEnd2.p, end2, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+  if (hasN) T1K_HIP(ctx, hipMemcpyAsync(ctx->bHasN.p, hasN, (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+  else T1K_HIP(ctx, hipMemsetAsync(ctx->bHasN.p, 0, (size_t)n, ctx->stream));
+  T1K_HIP(ctx, hipMemsetAsync((char *)ctx->bCounters.p + 2 * 8, 0, 8, ctx->stream));
+  T1K_HIP(ctx, hipMemsetAsync((char *)ctx->bCounters.p + 9 * 8, 0, 8, ctx->stream));
+  // the epoch of fragment f is f+1: a new batch reuses small epochs, so the tables are cleared per call
+  T1K_HIP(ctx, hipMemsetAsync(ctx->bPairScratch.p, 0, (size_t)nWg * (size_t)A * 16, ctx->stream));
+  PairArgs p{};
+  p.ref = ctx->ref;
+  p.ovl = (const T1kOvl *)ctx->bOvl.p; p.ovlStart = (const uint32_t *)ctx->bOvlStart.p; p.ovlCount = (const uint32_t *)ctx->bOvlCount.p;
+  p.end1 = (const uint32_t *)ctx->bEnd1.p; p.end2 = end2 ? (const uint32_t *)ctx->bEnd2.p : nullptr; p.hasN = (const uint8_t *)ctx->bHasN.p;
+  p.nFragments = n; p.sim = ctx->prm.ref_seq_similarity; p.relax = ctx->prm.relax_intron_align; p.maxAssign = ctx->prm.max_assign_cnt;
+  p.hitLenRequired = ctx->prm.hit_len_required;
+  p.rows = (t1k_row_entry *)ctx->bRows.p; p.rowCap = (uint64_t)ctx->prm.row_cap;
+  p.rowStart = (uint32_t *)ctx->bRowStart.p; p.rowCount = (uint32_t *)ctx->bRowCount.p; p.fragAssigned = (uint8_t *)ctx->bFragAssigned.p;
+  uint8_t *sc = (uint8_t *)ctx->bPairScratch.p;
+  p.tab2 = (uint64_t *)sc;
+  p.tabSlot = (uint64_t *)(sc + (size_t)nWg * A * 8);
+  p.frags = (Frag *)(sc + (size_t)nWg * A * 16);
+  p.fragCap = fragCap;
+  p.keep = (uint32_t *)(sc + (size_t)nWg * A * 16 + (size_t)nWg * fragCap * sizeof(Frag));
+  p.counters = (unsigned long long *)ctx->bCounters.p;
+  hipLaunchKernelGGL(k_pair, dim3(nWg), dim3(WG), 0, ctx->stream, p);
+  unsigned long long hc[16];
+  T1K_HIP(ctx, hipMemcpyAsync(hc, ctx->bCounters.p, 16 * 8, hipMemcpyDeviceToHost, ctx->stream));
+  T1K_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (hc[2]) return t1k_fail(ctx, T1K_ERR_CAPACITY, "device arena overflow: row_cap / fragment scratch");
+  ctx->nRows = hc[9];
+  ctx->stats.ms_pair = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count() - t0;
+  return T1K_OK;
+}
+
+int t1k_rows_download(t1k_ctx *ctx, uint32_t *rowCounts, uint8_t *fragAssigned, t1k_row_entry *rows, uint64_t cap, uint64_t *total) {
+  if (!ctx) return T1K_ERR_ARG;
+  T1K_HIP(ctx, hipSetDevice(ctx->device));
+  const uint32_t n = ctx->nFragments;
+  std::vector<uint32_t> start(n), cnt(n);
+  if (n) {
+    T1K_HIP(ctx, hipMemcpy(start.data(), ctx->bRowStart.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    T1K_HIP(ctx, hipMemcpy(cnt.data(), ctx->bRowCount.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    if (fragAssigned) T1K_HIP(ctx, hipMemcpy(fragAssigned, ctx->bFragAssigned.p, (size_t)n, hipMemcpyDeviceToHost));
+  }
+  uint64_t tot = 0;
+  for (uint32_t i = 0; i < n; ++i) tot += cnt[i];
+  if (total) *total = tot;
+  if (rowCounts) memcpy(rowCounts, cnt.data(), (size_t)n * 4);
+  if (!rows) return T1K_OK;
+  if (cap < tot) return t1k_fail(ctx, T1K_ERR_ARG, "row buffer too small");
+  std::vector<t1k_row_entry> h(ctx->nRows);
+  if (ctx->nRows) T1K_HIP(ctx, hipMemcpy(h.data(), ctx->bRows.p, ctx->nRows * sizeof(t1k_row_entry), hipMemcpyDeviceToHost));
+  uint64_t w = 0;
+  for (uint32_t i = 0; i < n; ++i) {
+    if (cnt[i]) memcpy(rows + w, h.data() + start[i], (size_t)cnt[i] * sizeof(t1k_row_entry));
+    w += cnt[i];
+  }
+  return T1K_OK;
+}
+
+}  // extern "C"
