@@ -184,7 +184,7 @@ int t1k_align_count_batch(t1k_ctx *ctx, const char *text, const uint32_t *tOff, 
 
 int t1k_em_setup(t1k_ctx *ctx, const uint64_t *rowPtr, const uint32_t *ecIdx, const double *count, const int32_t *ecLen, uint32_t nGroups, uint32_t nEc,
                  t1k_allreduce_fn allreduce, void *user) {
-  if (!ctx || !rowPtr || (!ecIdx && nGroups && rowPtr[nGroups]) || !count || !ecLen) return t1k_fail(ctx, T1K_ERR_ARG, "t1k_em_setup: bad arguments");
+  if (!ctx || !rowPtr || (!ecIdx && nGroups && rowPtr[nGroups]) || (!count && nGroups) || (!ecLen && nEc)) return t1k_fail(ctx, T1K_ERR_ARG, "t1k_em_setup: bad arguments");
   T1K_HIP(ctx, hipSetDevice(ctx->device));
   const uint64_t nnz = rowPtr[nGroups];
   // class-major positions: a stable counting sort of the entries by class keeps them in group order within a class
@@ -213,7 +213,7 @@ int t1k_em_setup(t1k_ctx *ctx, const uint64_t *rowPtr, const uint32_t *ecIdx, co
   ctx->emGroups = nGroups; ctx->emEc = nEc; ctx->emNnz = nnz;
   ctx->emAllreduce = allreduce; ctx->emUser = user;
   // class lengths stay on the host (M-step)
-  ctx->hEmLen.assign(ecLen, ecLen + nEc);
+  if (nEc) ctx->hEmLen.assign(ecLen, ecLen + nEc); else ctx->hEmLen.clear();
   return T1K_OK;
 }
 

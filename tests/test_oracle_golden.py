@@ -1,0 +1,64 @@
+"""CPU tests (no GPU): the oracle (CPU restatement under oracle/) against golden vectors captured from the reference itself."""
+import gzip
+import os
+import re
+import subprocess
+
+import pytest
+
+import goldens
+import util
+
+
+def test_global_alignment_golden_vectors(built):
+    """AlignAlgo::GlobalAlignment restatement vs 1872 input/output vectors produced by the reference's own routine."""
+    orc = util.Oracle(None)
+    n = 0
+    with gzip.open(os.path.join(util.GOLDEN, "ga_vectors.tsv.gz"), "rt") as f:
+        for line in f:
+            t, p, score, ops = line.rstrip("\n").split("\t")
+            s, o = orc.global_alignment(t, p)
+            assert s == int(score), (t, p)
+            assert "".join(str(int(x)) for x in o) == (ops if ops != "-" else ""), (t, p)
+            n += 1
+    assert n > 1800
+
+
+@pytest.mark.parametrize("name", goldens.CASES)
+def test_oracle_pipeline_matches_reference_outputs(built, tmp_path, name):
+    """read-end assignment + pairing + rows (_assign.tsv), fragmentAssigned ids, EM iteration count and the last EM
+    iteration's per-class read counts / abundances must equal what the reference printed for the same inputs."""
+    c = goldens.Case(name, str(tmp_path))
+    out = os.path.join(str(tmp_path), "orc")
+    flags = [f for f in c.flags]
+    r = subprocess.run([util.ORACLE_CLI] + c.args(with_barcode=False)[:2] + (["-1", c.r1, "-2", c.r2] if c.paired else ["-u", c.r1]) + flags + ["-o", out],
+                       stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 0, r.stderr
+    if c.bc is None:  # with barcodes the reference drops missing_barcode fragments first; covered by the GPU end-to-end test
+        assert open(out + "_assign.tsv").read() == c.expected("assign.tsv.gz")
+        assert open(out + "_aligned_ids.txt").read().split() == c.expected("aligned_ids.txt.gz").split()
+        it = int(open(out + "_em.tsv").readline().split()[1])
+        assert it == c.meta["em_iterations"]
+        exp = [l for l in c.expected("em_last_iteration.txt.gz").splitlines() if l.strip()]
+        got = [l.rstrip("\n").split("\t") for l in open(out + "_em.tsv") if not l.startswith("#")]
+        assert len(exp) == len(got)
+        for e, g in zip(exp, got):
+            m = re.match(r"^(\d+) (\S+) (\d+): (\S+) (\d+)\. (\S+)$", e)
+            assert m, e
+            assert int(m.group(1)) == int(g[0]) and m.group(2) == g[1] and int(m.group(3)) == len(g[1].split(","))
+            assert int(m.group(5)) == int(g[2])
+            assert m.group(4) == "%lf" % float(g[3]) if False else m.group(4) == ("%.6f" % float(g[3]))
+            assert m.group(6) == ("%.6f" % float(g[4]))
+
+
+@pytest.mark.skipif(not os.path.exists(util.REF_BIN), reason="reference-built oracle/_ref not present")
+def test_oracle_vs_live_reference_binary(built, tmp_path):
+    """fresh seeded input, oracle CLI vs the reference binary built from /root/reference (oracle/_ref/genotyper)."""
+    tmp = str(tmp_path)
+    ref = os.path.join(tmp, "ref.fa")
+    util.synth_ref("ref-rna", ref, genes=3, scale=0.02, seed=77)
+    util.synth_reads(ref, os.path.join(tmp, "r"), pairs=150, len=150, seed=78)
+    args = ["-f", ref, "-1", os.path.join(tmp, "r_1.fq"), "-2", os.path.join(tmp, "r_2.fq"), "-s", "0.95"]
+    subprocess.run([util.REF_BIN] + args + ["-o", os.path.join(tmp, "a"), "--outputReadAssignment", "-t", "1"], check=True, stderr=subprocess.PIPE)
+    subprocess.run([util.ORACLE_CLI] + args + ["-o", os.path.join(tmp, "b")], check=True, stderr=subprocess.PIPE)
+    assert open(os.path.join(tmp, "a_assign.tsv")).read() == open(os.path.join(tmp, "b_assign.tsv")).read()
