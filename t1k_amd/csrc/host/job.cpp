@@ -207,7 +207,7 @@ int t1k_job_run(t1k_job *job) {
   memset(&job->stats, 0, sizeof(job->stats));
   if ((rc = t1k_coverage_reset(job->ctx)) != T1K_OK) return jobFail(job, rc, t1k_last_error(job->ctx));
   const uint32_t F = job->nFrag;
-  uint32_t batch = job->prm.batch_fragments > 0 ? (uint32_t)job->prm.batch_fragments : 32768u;
+  uint32_t batch = job->prm.batch_fragments > 0 ? (uint32_t)job->prm.batch_fragments : 16384u;
   const uint32_t per = job->paired ? 2 : 1;
   std::vector<uint32_t> e1, e2, rowCounts;
   std::vector<uint8_t> assigned;

@@ -18,6 +18,11 @@
 #include "t1k_launch.h"
 
 #define WG 256
+#ifdef T1K_PHASE_TIMERS
+#define PHASE(k) do { if (threadIdx.x == 0) { long long now_ = wall_clock64(); atomicAdd(&P.counters[((k) >= 9 ? 32 + (k) : 16 + (k))], (unsigned long long)(now_ - tPhase)); tPhase = now_; } } while (0)
+#else
+#define PHASE(k) do {} while (0)
+#endif
 #define TILE_ALLELES 16384          // LDS histogram tile (u32 per allele)
 #define GROUP_FAST_MAXLEN 320       // read-offset bitmask width of the single-diagonal fast path
 #define THREAD_CAP 192              // hits per group handled with per-thread scratch; larger groups go to lane 0
@@ -82,10 +87,10 @@ struct CandOut {  // packed into the group's own hit segment: 3 u32 per candidat
 };
 
 // seed-chain match count of one gap (SeqSet.hpp:1710-1752 / 1794-1824)
-__device__ inline int gapMatches(const ReadCtx &c, int ra, int ga, int lp, int lt, int *gaScratch, int gaMax, unsigned long long *dpCounter, unsigned long long *errFlags) {
+__device__ inline int gapMatches(const ReadCtx &c, int ra, int ga, int lp, int lt, int *gaScratch, int gaMax, unsigned int *dpCounter, unsigned long long *errFlags) {
   if (lp == lt) return t1k_ga_matches_window(c.rb, c.rn, ra, c.gb, c.gn, c.goff + ga, lp, dpCounter);
   if (lt == 0 || lp == 0) return 0;
-  if (dpCounter) atomicAdd(dpCounter, 1ull);
+  if (dpCounter) ++*dpCounter;
   T1kSeqView T{c.gb, c.gn, c.goff + ga}, P{c.rb, c.rn, ra};
   int nm = 0;
   if (lt > gaMax) { atomicOr(errFlags, (unsigned long long)ERR_BIGGROUP); return 0; }
@@ -93,47 +98,301 @@ __device__ inline int gapMatches(const ReadCtx &c, int ra, int ga, int lp, int l
   return nm;
 }
 
-// Single-diagonal group: every hit has the same (readOffset - alleleOffset).  The LIS is the identity, both hit
-// lengths are equal, and the chain's match count is 2*(covered) + 2*sum of per-gap alignment matches.
-__device__ inline bool groupFastPath(const uint32_t *h, int n, const ReadCtx &c, int k, int hitLenRequired, CandOut &out, unsigned long long *dpCounter) {
-  uint64_t M[GROUP_FAST_MAXLEN / 64];
-#pragma unroll
-  for (int i = 0; i < GROUP_FAST_MAXLEN / 64; ++i) M[i] = 0;
-  int diag = 0;
-  for (int i = 0; i < n; ++i) {
-    uint32_t x = h[i];
-    int a = (int)(x & 0xFFF), b = (int)(x >> 12);
-    if (i == 0) diag = a - b; else if (a - b != diag) return false;
-    if (a >= GROUP_FAST_MAXLEN) return false;
-#pragma unroll
-    for (int w = 0; w < GROUP_FAST_MAXLEN / 64; ++w)
-      if ((a >> 6) == w) M[w] |= 1ull << (a & 63);
+// ------------------------------------------------------------------------------------------------------------------
+// Exact memo of gap alignments within one read-end.  Thousands of alleles of a gene carry the same bases under a given
+// read window, so the same banded DP would be recomputed for each of them.  One 64-bit entry identifies a job completely:
+//   [gpos:34 | matches:9 | readPos:11 | len:9 | strand:1]
+// A probe whose (strand, readPos, len) agree verifies that the allele window at the entry's gpos holds exactly the same
+// bases and N-mask as its own window before it reuses the stored match count, so a hit is bit-exact by construction.
+// The table lives in per-workgroup HBM scratch (L2-resident, 32 KB) and is cleared per read-end.
+// ------------------------------------------------------------------------------------------------------------------
+#define GAP_CACHE 4096
+__device__ inline bool sameWindow(const uint64_t *gb, const uint64_t *gn, int64_t a, int64_t b, int L) {
+  for (int o = 0; o < L; o += 32) {
+    uint64_t lm = t1k_lowmask(L - o);
+    if (((t1k_get32(gb, a + o) ^ t1k_get32(gb, b + o)) & lm) | ((t1k_get32(gn, a + o) ^ t1k_get32(gn, b + o)) & lm)) return false;
   }
-  // walk the set bits in ascending read offset
-  int first = -1, prev = -1, cov = 0, gapMatch = 0;
+  return true;
+}
+
+#define GAP_PENDING 0x1FFull
+// DEFER = true : never run a DP here.  A miss claims a memo slot (CAS) with the PENDING marker and appends the slot to the
+//                workgroup's job list; the caller parks its group (return -1) until the dense DP phase has filled the memo.
+// DEFER = false: a miss is computed inline (used after the dense phase; only slot-collision leftovers get here).
+template <bool DEFER>
+__device__ inline int gapMatchesCached(const ReadCtx &c, int readPos, int64_t gpos, int L, int strandBit, unsigned long long *cache, unsigned int *dpCounter,
+                                       uint32_t *jobList, uint32_t *jobCount) {
+  if (L <= 0) return 0;
+  // mismatch count and a content hash of the allele window in one sweep
+  int x = 0;
+  uint64_t hsh = 0x9E3779B97F4A7C15ull ^ ((uint64_t)readPos << 20) ^ ((uint64_t)L << 1) ^ (uint64_t)strandBit;
+  for (int o = 0; o < L; o += 32) {
+    uint64_t lm = t1k_lowmask(L - o);
+    uint64_t gw = t1k_get32(c.gb, gpos + o) & lm, gnw = t1k_get32(c.gn, gpos + o) & lm;
+    uint64_t xo = t1k_get32(c.rb, readPos + o) ^ gw;
+    uint64_t mm = (xo | (xo >> 1)) & T1K_EVEN & ~(t1k_get32(c.rn, readPos + o) | gnw) & lm;
+    x += __popcll(mm);
+    hsh = (hsh ^ gw ^ (gnw << 1)) * 0xD6E8FEB86659FD93ull;
+    hsh ^= hsh >> 32;
+  }
+  if (x <= 3) return L - x;  // exact fast path (see t1k_ga_matches_window)
+  if (L > 510 || readPos > 2047) {
+    if (DEFER) return -2;  // not memoisable: the retry phase computes it inline
+    return t1k_ga_matches_window(c.rb, c.rn, readPos, c.gb, c.gn, gpos, L, dpCounter);
+  }
+  const uint64_t idBits = ((uint64_t)readPos << 10) | ((uint64_t)L << 1) | (uint64_t)strandBit;  // low 21 bits of an entry
+  const uint32_t slot = (uint32_t)hsh & (GAP_CACHE - 1);
+  bool pendingSeen = false;
 #pragma unroll
-  for (int w = 0; w < GROUP_FAST_MAXLEN / 64; ++w) {
-    uint64_t m = M[w];
-    while (m) {
-      int a = w * 64 + __ffsll((long long)m) - 1;
-      m &= m - 1;
-      if (first < 0) { first = a; cov = k; }
-      else {
-        int d = a - prev;
-        if (d < k) cov += d;  // k-mers overlap on the read (SeqSet.hpp:1704-1707)
-        else {
-          cov += k;
-          int g = d - k;
-          if (g > 0) gapMatch += t1k_ga_matches_window(c.rb, c.rn, prev + k, c.gb, c.gn, c.goff + (prev + k - diag), g, dpCounter);
-        }
+  for (int probe = 0; probe < 2; ++probe) {
+    unsigned long long e = __hip_atomic_load(&cache[slot ^ probe], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (e != 0 && (e & 0x1FFFFFull) == idBits) {
+      int64_t eg = (int64_t)(e >> 30);
+      if (eg == gpos || sameWindow(c.gb, c.gn, eg, gpos, L)) {
+        unsigned long long v = (e >> 21) & 0x1FF;
+        if (v != GAP_PENDING) return (int)v;
+        pendingSeen = true;
       }
-      prev = a;
     }
   }
-  if (n * k < hitLenRequired) return true;  // cannot happen for n >= 3, k = 11
-  if (cov < hitLenRequired) return true;    // GetTotalHitLengthOnRead/OnSeq (1512-1522)
-  out.push(first, prev + k - 1, first - diag, prev - diag + k - 1, 2 * cov, 2 * cov + 2 * gapMatch);
-  return true;
+  if (DEFER) {
+    if (pendingSeen) return -1;
+    const unsigned long long pe = ((unsigned long long)gpos << 30) | (GAP_PENDING << 21) | idBits;
+#pragma unroll
+    for (int probe = 0; probe < 2; ++probe) {
+      unsigned long long old = atomicCAS(&cache[slot ^ probe], 0ull, pe);
+      if (old == 0ull) {
+        uint32_t q = atomicAdd(jobCount, 1u);
+        jobList[q] = slot ^ probe;
+        return -1;
+      }
+      if ((old & 0x1FFFFFull) == idBits && ((int64_t)(old >> 30) == gpos || sameWindow(c.gb, c.gn, (int64_t)(old >> 30), gpos, L))) return -1;  // somebody else just claimed it
+    }
+    return -2;  // both slots taken by other jobs: inline in the retry phase
+  }
+  if (dpCounter) ++*dpCounter;
+  T1kSeqView T{c.gb, c.gn, gpos}, P{c.rb, c.rn, (int64_t)readPos};
+  int m = t1k_ga_matches_equal(T, P, L, nullptr);
+  if (!pendingSeen) {
+    unsigned long long ne = ((unsigned long long)gpos << 30) | ((unsigned long long)m << 21) | idBits;
+    unsigned long long cur = __hip_atomic_load(&cache[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (cur == 0) __hip_atomic_store(&cache[slot], ne, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  return m;
+}
+
+// Single-diagonal group (the common case: the read differs from the allele by substitutions only).
+// NW = number of 32-position words covering a read (5: reads <= 160 bp, 10: reads <= 320 bp).
+//   * the group's hits are fetched in one burst of independent loads (<= 32 hits; larger groups loop)
+//   * majority diagonal by Boyer-Moore vote; every other hit must lie more than `radius` diagonals away (it cannot join the
+//     main run, SeqSet.hpp:1360-1392) and there may be at most two such strays (they cannot form a run of >= 3 hits,
+//     1400-1405); anything else goes to the general path
+//   * on one diagonal the LIS is the identity and both hit lengths are equal; with M = bitmask of hit read-offsets,
+//     covered = popcount(dilate(M, k)) and matchCnt = 2*covered + 2*sum over gaps of GlobalAlignment matches (1697-1760)
+//   * a gap with x <= 3 mismatches aligns ungapped (g - x matches, exact, see t1k_ga_matches_window); if the whole span
+//     has <= 3 mismatches every gap does and matchCnt = 2*(span - mismatches) in closed form
+//   * exact prune: a gap with x > 3 yields at most g - 1 matches, so U = 2*(span - sum_{x<=3} x - #{x>3}) bounds matchCnt;
+//     if U / (2*span) < -s the candidate is certain to fail the similarity filter (1838-1840, 1894-1908) and is emitted
+//     with matchCnt = U (it is dropped by k_extend either way, and the strand vote only reads matchCnt0)
+template <int NW, bool DEFER>
+__device__ inline int groupFastPath(const uint32_t *h, int n, const ReadCtx &c, int k, int radius, int hitLenRequired, double simThreshold, CandOut &out,
+                                    unsigned int *dpCounter, int strandBit, unsigned long long *cache, uint32_t *jobList, uint32_t *jobCount) {
+  constexpr int MW = (NW + 1) / 2;  // 64-bit words of the read-offset bitmask
+#ifdef T1K_PHASE_TIMERS
+  long long tq_ = clock64();
+#define SECT(i) do { long long n_ = clock64(); dpCounter[3 + (i)] += (unsigned int)((n_ - tq_) >> 4); tq_ = n_; } while (0)
+#else
+#define SECT(i) do {} while (0)
+#endif
+  uint64_t M[MW];
+#pragma unroll
+  for (int i = 0; i < MW; ++i) M[i] = 0;
+  int diag = 0, votes = 0, strays = 0, onDiag = 0;
+  if (n <= 32) {
+    uint32_t hr[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) hr[i] = i < n ? h[i] : 0u;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      if (i < n) {
+        int d = (int)(hr[i] & 0xFFF) - (int)(hr[i] >> 12);
+        if (votes == 0) { diag = d; votes = 1; }
+        else if (d == diag) ++votes;
+        else --votes;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      if (i < n) {
+        int a = (int)(hr[i] & 0xFFF);
+        int d = a - (int)(hr[i] >> 12) - diag;
+        if (d != 0) {
+          if (d < 0) d = -d;
+          if (d <= radius) return 0;
+          ++strays;
+        } else {
+          if (a >= NW * 32) return 0;
+          ++onDiag;
+#pragma unroll
+          for (int w = 0; w < MW; ++w)
+            if ((a >> 6) == w) M[w] |= 1ull << (a & 63);
+        }
+      }
+    }
+  } else {
+    for (int i = 0; i < n; ++i) {
+      uint32_t x = h[i];
+      int d = (int)(x & 0xFFF) - (int)(x >> 12);
+      if (votes == 0) { diag = d; votes = 1; }
+      else if (d == diag) ++votes;
+      else --votes;
+    }
+    for (int i = 0; i < n; ++i) {
+      uint32_t x = h[i];
+      int a = (int)(x & 0xFFF);
+      int d = a - (int)(x >> 12) - diag;
+      if (d != 0) {
+        if (d < 0) d = -d;
+        if (d <= radius) return 0;
+        ++strays;
+      } else {
+        if (a >= NW * 32) return 0;
+        ++onDiag;
+#pragma unroll
+        for (int w = 0; w < MW; ++w)
+          if ((a >> 6) == w) M[w] |= 1ull << (a & 63);
+      }
+    }
+  }
+  SECT(0);
+  if (strays > 2) return 0;
+  if (onDiag < 3) return 1;  // minHitRequired (1314, 1400)
+  if (onDiag * k < hitLenRequired) return 1;
+  int first = -1, last = -1;
+#pragma unroll
+  for (int w = 0; w < MW; ++w) {
+    if (M[w]) {
+      if (first < 0) first = w * 64 + __ffsll((long long)M[w]) - 1;
+      last = w * 64 + 63 - __clzll((long long)M[w]);
+    }
+  }
+  // covered positions: dilate M by k (bit p set iff some hit offset a has a <= p < a + k)
+  uint64_t C[MW];
+#pragma unroll
+  for (int w = 0; w < MW; ++w) C[w] = M[w];
+  for (int sft = 1; sft < k; ++sft) {
+#pragma unroll
+    for (int w = MW - 1; w >= 0; --w) {
+      uint64_t carry = w > 0 ? (M[w - 1] >> (64 - sft)) : 0ull;
+      C[w] |= (M[w] << sft) | carry;
+    }
+  }
+  int cov = 0;
+#pragma unroll
+  for (int w = 0; w < MW; ++w) cov += __popcll(C[w]);
+  // (the dilation may spill past NW*32 only for offsets that cannot occur: a + k <= len <= NW*32)
+  SECT(1);
+  if (cov < hitLenRequired) return 1;  // GetTotalHitLengthOnRead/OnSeq (1512-1522)
+  const int spanEnd = last + k, span = spanEnd - first;
+  // mismatch bits of the span on this diagonal, one burst of independent loads
+  uint64_t mmw[NW];
+  int mmT = 0;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) {
+    mmw[w] = 0;
+    const int p0 = w * 32;
+    if (p0 < spanEnd && p0 + 32 > first) {
+      const int lo = p0 < first ? first : p0;  // never read the allele before its first base
+      uint64_t xo = t1k_get32(c.rb, lo) ^ t1k_get32(c.gb, c.goff + lo - diag);
+      uint64_t mm = (xo | (xo >> 1)) & T1K_EVEN & ~(t1k_get32(c.rn, lo) | t1k_get32(c.gn, c.goff + lo - diag));
+      mm <<= 2 * (lo - p0);
+      const int hiN = spanEnd - p0;
+      if (hiN < 32) mm &= t1k_lowmask(hiN);
+      mmw[w] = mm;
+      mmT += __popcll(mm);
+    }
+  }
+  SECT(2);
+  int matchCnt;
+  if (mmT <= 3) matchCnt = 2 * (span - mmT);
+  else {
+    // walk the gaps (maximal uncovered runs inside the span)
+    int sumSmall = 0, nBig = 0;
+    // pass 1: per-gap mismatch counts -> upper bound
+    int pos = first;
+    // gap iteration helper: next uncovered position >= pos is the lowest clear bit of C at or above pos
+    auto nextClear = [&](int from) -> int {
+#pragma unroll
+      for (int w = 0; w < MW; ++w) {
+        if (from < (w + 1) * 64) {
+          uint64_t inv = ~C[w];
+          if (from > w * 64) inv &= ~0ull << (from - w * 64);
+          if (inv) return w * 64 + __ffsll((long long)inv) - 1;
+        }
+      }
+      return MW * 64;
+    };
+    auto nextSet = [&](int from) -> int {
+#pragma unroll
+      for (int w = 0; w < MW; ++w) {
+        if (from < (w + 1) * 64) {
+          uint64_t v = C[w];
+          if (from > w * 64) v &= ~0ull << (from - w * 64);
+          if (v) return w * 64 + __ffsll((long long)v) - 1;
+        }
+      }
+      return MW * 64;
+    };
+    auto mmIn = [&](int gs, int ge) -> int {  // mismatches in [gs, ge)
+      int x = 0;
+#pragma unroll
+      for (int q = 0; q < NW; ++q) {
+        const int p0 = q * 32;
+        if (p0 < ge && p0 + 32 > gs) {
+          uint64_t msk = ~0ull;
+          if (gs > p0) msk &= ~t1k_lowmask(gs - p0);
+          if (ge < p0 + 32) msk &= t1k_lowmask(ge - p0);
+          x += __popcll(mmw[q] & msk);
+        }
+      }
+      return x;
+    };
+    while (true) {
+      int gs = nextClear(pos);
+      if (gs >= spanEnd) break;
+      int ge = nextSet(gs);
+      if (ge > spanEnd) ge = spanEnd;
+      int x = mmIn(gs, ge);
+      if (x <= 3) sumSmall += x; else ++nBig;
+      pos = ge;
+    }
+    const int upper = 2 * (span - sumSmall - nBig);
+    if (nBig == 0) matchCnt = upper;  // exact
+    else if ((double)upper / (double)(2 * span) < simThreshold) matchCnt = upper;  // certain to be dropped; no DP needed
+    else {
+      int gapMatch = 0;
+      bool parked = false;
+      pos = first;
+      while (true) {
+        int gs = nextClear(pos);
+        if (gs >= spanEnd) break;
+        int ge = nextSet(gs);
+        if (ge > spanEnd) ge = spanEnd;
+        int x = mmIn(gs, ge);
+        if (x <= 3) gapMatch += (ge - gs) - x;
+        else {
+          int r = gapMatchesCached<DEFER>(c, gs, c.goff + (gs - diag), ge - gs, strandBit, cache, dpCounter, jobList, jobCount);
+          if (r < 0) parked = true; else gapMatch += r;  // keep walking: later gaps register their jobs too
+        }
+        pos = ge;
+      }
+      if (parked) return 2;
+      matchCnt = 2 * cov + 2 * gapMatch;
+    }
+  }
+  SECT(3);
+  out.push(first, last + k - 1, first - diag, last - diag + k - 1, 2 * cov, matchCnt);
+  return 1;
 }
 
 __device__ __forceinline__ bool hitKeyLess(uint32_t x, uint32_t y) {  // (diag, alleleOff, readOff): CompSortHitCoordDiff (266-274)
@@ -145,7 +404,7 @@ __device__ __forceinline__ bool hitKeyLess(uint32_t x, uint32_t y) {  // (diag, 
 // General group (several diagonals): restates GetOverlapsFromHits 1338-1551 and the chain walk 1697-1833.
 // A[n] sorted copy of the hits, B[n] concordant hits, C[n] packs top (low 16) / link (high 16) of the LIS.
 __device__ inline void groupGeneral(const uint32_t *h, int n, const ReadCtx &c, int k, int radius, int hitLenRequired, uint32_t *A, uint32_t *B,
-                                     uint32_t *C, int *gaScratch, int gaMax, CandOut &out, unsigned long long *dpCounter, unsigned long long *errFlags) {
+                                     uint32_t *C, int *gaScratch, int gaMax, CandOut &out, unsigned int *dpCounter, unsigned long long *errFlags) {
   // insertion sort into A
   for (int i = 0; i < n; ++i) {
     uint32_t x = h[i];
@@ -309,24 +568,37 @@ __global__ __launch_bounds__(WG) void k_seed_chain(AssignArgs P) {
   uint16_t *usedQ = (uint16_t *)(ukLen + maxK);     // [maxK]
   __shared__ uint32_t warpSums[4];
   __shared__ uint32_t sUsed[2];      // used k-mers of pass 0 (+) and pass 1 (-)
-  __shared__ uint32_t sStageCount, sBase;
+  __shared__ uint32_t sStageCount, sBase, sAnyDeferred, sGenCount, sRetryCount, sJobCount;
   __shared__ uint64_t sVoteHi[WG], sVoteLo[WG];
 
   const int tid = threadIdx.x;
   const uint32_t kmask = (1u << (2 * k)) - 1;
   uint32_t *myHits = P.wgHits + (uint64_t)blockIdx.x * P.hitCap;
-  uint32_t *myGroups = P.wgGroups + (uint64_t)blockIdx.x * TILE_ALLELES * 3;
+  uint32_t *myGroups = P.wgGroups + (uint64_t)blockIdx.x * TILE_ALLELES * 4;
+  uint32_t *genList = myGroups + TILE_ALLELES * 3;
   T1kCand *myStage = P.wgStage + (uint64_t)blockIdx.x * P.stageCap;
   uint32_t *myThread = P.wgThread + ((uint64_t)blockIdx.x * WG + tid) * THREAD_SCRATCH_U32;
   uint32_t *myBig = P.wgBig + (uint64_t)blockIdx.x * (3 * BIG_CAP + GA_SCRATCH_INTS);
+  unsigned long long *myCache = P.wgCache + (uint64_t)blockIdx.x * (GAP_CACHE + GAP_CACHE / 2);
+  uint32_t *jobList = (uint32_t *)(myCache + GAP_CACHE);
   const int nTiles = (int)((P.ref.nAlleles + TILE_ALLELES - 1) / TILE_ALLELES);
 
+  unsigned int dpLocalArr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned int &dpLocal = dpLocalArr[0];
+  unsigned int fastLocal = 0, generalLocal = 0, deferredLocal = 0;
+  long long tChain = 0;
+  (void)tChain;
+  long long tPhase = 0;
+  (void)tPhase;
+#ifdef T1K_PHASE_TIMERS
+  tPhase = wall_clock64();
+#endif
   for (uint32_t re = blockIdx.x; re < P.reads.nReadEnds; re += gridDim.x) {
     const int len = P.reads.len[re];
     const int S = P.reads.S;
     const uint64_t *rbase = P.reads.bases + (uint64_t)re * 2 * S;
     const uint64_t *rnm = P.reads.nmask + (uint64_t)re * 2 * S;
-    if (tid == 0) { sStageCount = 0; }
+    if (tid == 0) { sStageCount = 0; sAnyDeferred = 0; sGenCount = 0; sRetryCount = 0; sJobCount = 0; }
     __syncthreads();
     if (len < k) {  // GetOverlapsFromRead returns -1 (SeqSet.hpp:1598-1599)
       if (tid == 0) { P.candStart[re] = 0; P.candCount[re] = 0; }
@@ -334,6 +606,7 @@ __global__ __launch_bounds__(WG) void k_seed_chain(AssignArgs P) {
       continue;
     }
     const int nk = len - k + 1;
+    for (int i = tid; i < GAP_CACHE; i += WG) __hip_atomic_store(&myCache[i], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // ---- 1. k-mer codes and posting-list bounds for both strands -------------------------------------------------
     for (int q = tid; q < 2 * nk; q += WG) {
       int pass = q / nk, p = q - pass * nk;
@@ -346,6 +619,7 @@ __global__ __launch_bounds__(WG) void k_seed_chain(AssignArgs P) {
       ukStart[q] = st; ukLen[q] = ln;
     }
     __syncthreads();
+    PHASE(0);
     // ---- 2. the sequential look-up rule (SeqSet.hpp:1098-1153, 1165-1226) -----------------------------
     if (tid == 0) {
       uint32_t prev = 0;  // prevKmerCode starts at code 0 and is carried from the + strand into the - strand
@@ -372,6 +646,7 @@ __global__ __launch_bounds__(WG) void k_seed_chain(AssignArgs P) {
       atomicAdd(&P.counters[4], postings);
     }
     __syncthreads();
+    PHASE(1);
     const uint32_t nUsedPlus = sUsed[0], nUsedMinus = sUsed[1];
     VoteKey best; best.hi = ~0ull; best.lo = ~0ull;
     // ---- 3. per strand ('-' first, SortHits 1577-1583) and allele tile ---------------------------------------------
@@ -395,6 +670,7 @@ __global__ __launch_bounds__(WG) void k_seed_chain(AssignArgs P) {
           }
         }
         __syncthreads();
+        PHASE(2);
         // scan: groups with >= 3 hits (refMinHitRequired, SeqSet.hpp:1253, 1314) get a slice of the hit arena
         const int EPT = TILE_ALLELES / WG;
         uint32_t hSum = 0, gSum = 0;
@@ -423,6 +699,7 @@ __global__ __launch_bounds__(WG) void k_seed_chain(AssignArgs P) {
         }
         if (tid == 0) { atomicAdd(&P.counters[5], (unsigned long long)hTot); atomicAdd(&P.counters[6], (unsigned long long)gTot); }
         __syncthreads();
+        PHASE(3);
         // scatter the hits of surviving groups: packed (alleleOffset << 12 | readOffset)
         for (uint32_t u = 0; u < uCount; ++u) {
           int q = usedQ[uBegin + u];
@@ -438,23 +715,92 @@ __global__ __launch_bounds__(WG) void k_seed_chain(AssignArgs P) {
         }
         __threadfence_block();
         __syncthreads();
+        PHASE(4);
         // chain: one lane per (strand, allele) group; candidates are packed back into the group's hit slice
+#ifdef T1K_PHASE_TIMERS
+        long long tc0 = clock64();
+#endif
         for (uint32_t g = tid; g < gTot; g += WG) {
           uint32_t allele = myGroups[g * 3 + 0], hs = myGroups[g * 3 + 1], n = myGroups[g * 3 + 2];
           ReadCtx c{rbase + pass * S, rnm + pass * S, len, P.ref.bases, P.ref.nmask, (int64_t)P.ref.alleleOff[allele], (int)P.ref.alleleLen[allele]};
           CandOut out{myHits + hs, 0};
-          bool done = false;
-          if (len <= GROUP_FAST_MAXLEN) done = groupFastPath(myHits + hs, (int)n, c, k, P.hitLenRequired, out, &P.counters[7]);
-          if (!done) {
-            if (n <= THREAD_CAP) {
-              groupGeneral(myHits + hs, (int)n, c, k, P.radius, P.hitLenRequired, myThread, myThread + THREAD_CAP, myThread + 2 * THREAD_CAP,
-                           (int *)(myThread + 3 * THREAD_CAP), GA_T_MAX, out, &P.counters[7], &P.counters[2]);
-            } else { myGroups[g * 3 + 2] = n | 0x80000000u; continue; }  // deferred to lane 0 below
+          int done = 0;
+          if (len <= 160) done = groupFastPath<5, true>(myHits + hs, (int)n, c, k, P.radius, P.hitLenRequired, P.sim, out, dpLocalArr, pass, myCache, jobList, &sJobCount);
+          else if (len <= GROUP_FAST_MAXLEN)
+            done = groupFastPath<10, true>(myHits + hs, (int)n, c, k, P.radius, P.hitLenRequired, P.sim, out, dpLocalArr, pass, myCache, jobList, &sJobCount);
+          if (done == 1) { ++fastLocal; myGroups[g * 3 + 2] = (uint32_t)out.n; }
+          else if (done == 2) {  // parked until the dense DP phase has filled the memo
+            uint32_t q = atomicAdd(&sRetryCount, 1u);
+            genList[TILE_ALLELES - 1 - q] = g;
+          } else {
+            // several diagonals: handled after the lock-step loop so that one slow lane does not stall its wavefront
+            uint32_t q = atomicAdd(&sGenCount, 1u);
+            genList[q] = g;
           }
-          myGroups[g * 3 + 2] = (uint32_t)out.n;
+        }
+#ifdef T1K_PHASE_TIMERS
+        tChain += clock64() - tc0;
+#endif
+        __syncthreads();
+        PHASE(9);
+        {
+          // dense DP phase: one lane per distinct (strand, read window, allele window) job registered above
+          const uint32_t nJobs = sJobCount;
+          for (uint32_t q = tid; q < nJobs; q += WG) {
+            const uint32_t slot = jobList[q];
+            const unsigned long long e = __hip_atomic_load(&myCache[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int L = (int)((e >> 1) & 0x1FF), readPos = (int)((e >> 10) & 0x7FF), sb = (int)(e & 1);
+            const int64_t gpos = (int64_t)(e >> 30);
+            T1kSeqView T{P.ref.bases, P.ref.nmask, gpos}, Pv{rbase + sb * S, rnm + sb * S, (int64_t)readPos};
+            const int m = t1k_ga_matches_equal(T, Pv, L, nullptr);
+            ++dpLocal;
+            __hip_atomic_store(&myCache[slot], (e & ~(GAP_PENDING << 21)) | ((unsigned long long)m << 21), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
+        __threadfence_block();
+        __syncthreads();
+        PHASE(10);
+        {
+          const uint32_t nRetry = sRetryCount;
+          for (uint32_t q = tid; q < nRetry; q += WG) {
+            const uint32_t g = genList[TILE_ALLELES - 1 - q];
+            uint32_t allele = myGroups[g * 3 + 0], hs = myGroups[g * 3 + 1], n = myGroups[g * 3 + 2];
+            ReadCtx c{rbase + pass * S, rnm + pass * S, len, P.ref.bases, P.ref.nmask, (int64_t)P.ref.alleleOff[allele], (int)P.ref.alleleLen[allele]};
+            CandOut out{myHits + hs, 0};
+            if (len <= 160) groupFastPath<5, false>(myHits + hs, (int)n, c, k, P.radius, P.hitLenRequired, P.sim, out, dpLocalArr, pass, myCache, jobList, &sJobCount);
+            else groupFastPath<10, false>(myHits + hs, (int)n, c, k, P.radius, P.hitLenRequired, P.sim, out, dpLocalArr, pass, myCache, jobList, &sJobCount);
+            ++fastLocal;
+            myGroups[g * 3 + 2] = (uint32_t)out.n;
+          }
         }
         __syncthreads();
-        if (tid == 0) {
+        PHASE(11);
+        {
+          const uint32_t nGen = sGenCount;
+          for (uint32_t q = tid; q < nGen; q += WG) {
+            const uint32_t g = genList[q];
+            uint32_t allele = myGroups[g * 3 + 0], hs = myGroups[g * 3 + 1], n = myGroups[g * 3 + 2];
+            if (n > THREAD_CAP) { myGroups[g * 3 + 2] = n | 0x80000000u; ++deferredLocal; sAnyDeferred = 1; continue; }  // lane 0, below
+            ReadCtx c{rbase + pass * S, rnm + pass * S, len, P.ref.bases, P.ref.nmask, (int64_t)P.ref.alleleOff[allele], (int)P.ref.alleleLen[allele]};
+            CandOut out{myHits + hs, 0};
+            if (n <= 48) {
+              // small group: work arrays in private (scratch) memory, which is lane-interleaved and therefore coalesced when
+              // the lanes of this dense phase walk their arrays in step
+              uint32_t wa[48], wb[48], wc[48];
+              groupGeneral(myHits + hs, (int)n, c, k, P.radius, P.hitLenRequired, wa, wb, wc, (int *)(myThread + 3 * THREAD_CAP), GA_T_MAX, out, &dpLocal,
+                           &P.counters[2]);
+            } else
+              groupGeneral(myHits + hs, (int)n, c, k, P.radius, P.hitLenRequired, myThread, myThread + THREAD_CAP, myThread + 2 * THREAD_CAP,
+                           (int *)(myThread + 3 * THREAD_CAP), GA_T_MAX, out, &dpLocal, &P.counters[2]);
+            ++generalLocal;
+            myGroups[g * 3 + 2] = (uint32_t)out.n;
+          }
+        }
+        __syncthreads();
+        if (tid == 0) { sGenCount = 0; sRetryCount = 0; sJobCount = 0; }
+        PHASE(5);
+        if (tid == 0 && sAnyDeferred) {
+          sAnyDeferred = 0;
           for (uint32_t g = 0; g < gTot; ++g) {
             uint32_t n = myGroups[g * 3 + 2];
             if (!(n & 0x80000000u)) continue;
@@ -464,11 +810,12 @@ __global__ __launch_bounds__(WG) void k_seed_chain(AssignArgs P) {
             ReadCtx c{rbase + pass * S, rnm + pass * S, len, P.ref.bases, P.ref.nmask, (int64_t)P.ref.alleleOff[allele], (int)P.ref.alleleLen[allele]};
             CandOut out{myHits + hs, 0};
             groupGeneral(myHits + hs, (int)n, c, k, P.radius, P.hitLenRequired, myBig, myBig + BIG_CAP, myBig + 2 * BIG_CAP, (int *)(myBig + 3 * BIG_CAP), GA_BIG_MAX, out,
-                         &P.counters[7], &P.counters[2]);
+                         &dpLocal, &P.counters[2]);
             myGroups[g * 3 + 2] = (uint32_t)out.n;
           }
         }
         __syncthreads();
+        PHASE(6);
         // compact the candidates of this (strand, tile) into the per-read-end staging list, in group order
         for (uint32_t g0 = 0; g0 < gTot; g0 += WG) {
           uint32_t g = g0 + tid;
@@ -503,6 +850,7 @@ __global__ __launch_bounds__(WG) void k_seed_chain(AssignArgs P) {
           __syncthreads();
         }
         __syncthreads();
+        PHASE(7);
       }  // tile
     }    // strand
     // ---- 4. strand vote and copy-out of the winning strand's candidates -------------------------------------------
@@ -542,6 +890,24 @@ __global__ __launch_bounds__(WG) void k_seed_chain(AssignArgs P) {
       }
     }
     __syncthreads();
+    PHASE(8);
+  }
+  // flush the thread-local tallies: one atomic per counter per wavefront
+  {
+#ifdef T1K_PHASE_TIMERS
+    atomicAdd(&P.counters[25], (unsigned long long)(tChain >> 6));
+    atomicAdd(&P.counters[26], (unsigned long long)dpLocalArr[1]);
+    atomicAdd(&P.counters[27], (unsigned long long)dpLocalArr[2]);
+    atomicAdd(&P.counters[28], (unsigned long long)dpLocalArr[3]); atomicAdd(&P.counters[29], (unsigned long long)dpLocalArr[4]);
+    atomicAdd(&P.counters[30], (unsigned long long)dpLocalArr[5]); atomicAdd(&P.counters[31], (unsigned long long)dpLocalArr[6]);
+#endif
+    unsigned int v[4] = {dpLocal, fastLocal, generalLocal, deferredLocal};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      unsigned int x = v[q];
+      for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o, 64);
+      if ((threadIdx.x & 63) == 0 && x) atomicAdd(&P.counters[q == 0 ? 7 : 10 + q], (unsigned long long)x);
+    }
   }
 }
 
@@ -617,7 +983,8 @@ __global__ __launch_bounds__(WG) void k_extend(ExtendArgs P) {
     }
     if (bestP >= 0) { int i = ss - 1 - bestP; leftClip = lo - i; lo = i; }
   }
-  int match = t1k_ga_matches_window(rb, rn, rs - lo, P.ref.bases, P.ref.nmask, goff + ss - lo, lo, &P.counters[7]);
+  unsigned int dpLocal = 0;
+  int match = t1k_ga_matches_window(rb, rn, rs - lo, P.ref.bases, P.ref.nmask, goff + ss - lo, lo, &dpLocal);
   int ro = (len - 1 - re) < (alleleLen - 1 - se) ? (len - 1 - re) : (alleleLen - 1 - se);
   if (len - 1 - re > alleleLen - 1 - se) rightClip = len - 1 - re - (alleleLen - 1 - se);
   {
@@ -629,7 +996,8 @@ __global__ __launch_bounds__(WG) void k_extend(ExtendArgs P) {
     }
     if (bestP != 0x7FFFFFFF) { int i = bestP - se - 1; rightClip = ro - i; ro = i; }
   }
-  match += t1k_ga_matches_window(rb, rn, re + 1, P.ref.bases, P.ref.nmask, goff + se + 1, ro, &P.counters[7]);
+  match += t1k_ga_matches_window(rb, rn, re + 1, P.ref.bases, P.ref.nmask, goff + se + 1, ro, &dpLocal);
+  if (dpLocal) atomicAdd(&P.counters[14], (unsigned long long)dpLocal);
   int eMatch = 2 * match + matchCnt;
   int ers = rs - lo, ere = re + ro, ess = ss - lo, ese = se + ro;
   double esim = (double)eMatch / (double)(ere - ers + 1 + ese - ess + 1);
@@ -686,8 +1054,24 @@ __global__ __launch_bounds__(WG) void k_select(SelectArgs P) {
       if (tid == 0) { P.ovlStart[re] = 0; P.ovlCount[re] = 0; }
       continue;
     }
+    // candidates that failed the similarity filter never reach the sort: count the survivors first
+    __shared__ uint32_t sLive;
+    if (tid == 0) sLive = 0;
+    __syncthreads();
+    {
+      uint32_t mine = 0;
+      for (uint32_t i = tid; i < n; i += WG) mine += (P.ext[c0 + i].flags & T1K_F_DROP) ? 0u : 1u;
+      if (mine) atomicAdd(&sLive, mine);
+    }
+    __syncthreads();
+    const uint32_t live = sLive;
+    __syncthreads();
+    if (live == 0) {
+      if (tid == 0) { P.ovlStart[re] = 0; P.ovlCount[re] = 0; }
+      continue;
+    }
     uint32_t np2 = 1;
-    while (np2 < n) np2 <<= 1;
+    while (np2 < live) np2 <<= 1;
     uint64_t *key; uint32_t *idx;
     if (np2 <= SELECT_LDS_CAP) { key = sKey; idx = sIdx; }
     else if (np2 <= P.sortCap) { key = P.sortScratch + (uint64_t)blockIdx.x * P.sortCap * 2; idx = (uint32_t *)(key + P.sortCap); }
@@ -695,28 +1079,29 @@ __global__ __launch_bounds__(WG) void k_select(SelectArgs P) {
       if (tid == 0) { atomicOr(&P.counters[2], (unsigned long long)ERR_SORTCAP); P.ovlStart[re] = 0; P.ovlCount[re] = 0; }
       continue;
     }
-    // key: matchCnt desc, similarity desc (== readSpan+seqSpan asc at equal matchCnt), readSpan desc, allele asc;
-    // dropped candidates sort last
-    for (uint32_t i = tid; i < np2; i += WG) {
-      uint64_t kk = ~0ull;
-      if (i < n) {
-        const T1kCand c = P.cand[c0 + i];
-        const uint16_t fl = P.ext[c0 + i].flags;
-        if (!(fl & T1K_F_DROP)) {
-          int rs = c.readSE & 0xFFFF, rend = c.readSE >> 16;
-          int m = (int)(c.match >> 16);
-          int rspan = rend - rs, d = rspan + 1 + c.seqEnd - c.seqStart + 1;
-          kk = ((uint64_t)(4095 - m) << 50) | ((uint64_t)(d & 0x1FFF) << 37) | ((uint64_t)(4095 - rspan) << 24) | (uint64_t)(c.allele & 0xFFFFFF);
-        }
-      }
-      key[i] = kk; idx[i] = i;
+    // key: matchCnt desc, similarity desc (== readSpan+seqSpan asc at equal matchCnt), readSpan desc, allele asc
+    if (tid == 0) sLive = 0;
+    for (uint32_t i = tid; i < np2; i += WG) key[i] = ~0ull;
+    __syncthreads();
+    for (uint32_t i = tid; i < n; i += WG) {
+      const uint16_t fl = P.ext[c0 + i].flags;
+      if (fl & T1K_F_DROP) continue;
+      const T1kCand c = P.cand[c0 + i];
+      int rs = c.readSE & 0xFFFF, rend = c.readSE >> 16;
+      int m = (int)(c.match >> 16);
+      int rspan = rend - rs, d = rspan + 1 + c.seqEnd - c.seqStart + 1;
+      uint32_t slot = atomicAdd(&sLive, 1u);  // any order: the sort follows
+      key[slot] = ((uint64_t)(4095 - m) << 50) | ((uint64_t)(d & 0x1FFF) << 37) | ((uint64_t)(4095 - rspan) << 24) | (uint64_t)(c.allele & 0xFFFFFF);
+      idx[slot] = i;
     }
+    for (uint32_t i = live + tid; i < np2; i += WG) idx[i] = 0;
     __syncthreads();
     bitonicSort(key, idx, np2);
     // resolve ties of the packed key with the remaining comparator fields (same allele, same spans)
+    const uint32_t nAll = n;
+    (void)nAll;
     if (tid == 0) {
-      for (uint32_t i = 1; i < n; ++i) {
-        if (key[i] == ~0ull) break;
+      for (uint32_t i = 1; i < live; ++i) {
         if (key[i] != key[i - 1]) continue;
         uint32_t j = i;
         while (j > 0 && key[j - 1] == key[j] && candBeforeFull(P.cand[c0 + idx[j]], P.cand[c0 + idx[j - 1]])) {
@@ -729,7 +1114,7 @@ __global__ __launch_bounds__(WG) void k_select(SelectArgs P) {
     __syncthreads();
     // latch position: first tried candidate whose extension fails (all candidates before the latch are tried)
     int myLatch = 0x7FFFFFFF;
-    for (uint32_t i = tid; i < n; i += WG) {
+    for (uint32_t i = tid; i < live; i += WG) {
       if (key[i] == ~0ull) continue;
       uint16_t fl = P.ext[c0 + idx[i]].flags;
       if (fl & T1K_F_SEPSEED) continue;
@@ -740,7 +1125,7 @@ __global__ __launch_bounds__(WG) void k_select(SelectArgs P) {
     const int latch = sLatch;
     // goodMatchCnt = seed matchCnt of the first emitted candidate before the latch (the list is sorted by it)
     int myGood = 0x7FFFFFFF;
-    for (uint32_t i = tid; i < n && (int)i < latch; i += WG) {
+    for (uint32_t i = tid; i < live && (int)i < latch; i += WG) {
       if (key[i] == ~0ull) continue;
       uint16_t fl = P.ext[c0 + idx[i]].flags;
       if ((fl & T1K_F_SEPSEED) || !(fl & T1K_F_EXTOK)) continue;
@@ -756,10 +1141,11 @@ __global__ __launch_bounds__(WG) void k_select(SelectArgs P) {
     const int good = sGood;
     // emit flags + best extended matchCnt
     uint32_t written = 0;
+    unsigned int nbLocal = 0;
     int myBest = -1;
     // first pass: count and best
     uint32_t mine = 0;
-    for (uint32_t i = tid; i < n; i += WG) {
+    for (uint32_t i = tid; i < live; i += WG) {
       bool emit = false;
       if (key[i] != ~0ull) {
         const T1kExt x = P.ext[c0 + idx[i]];
@@ -789,9 +1175,9 @@ __global__ __launch_bounds__(WG) void k_select(SelectArgs P) {
     __syncthreads();
     const int bestMatch = sBest;
     if (sBase != 0xFFFFFFFFu) {
-      for (uint32_t i0 = 0; i0 < n; i0 += WG) {
+      for (uint32_t i0 = 0; i0 < live; i0 += WG) {
         uint32_t i = i0 + tid;
-        uint32_t flag = (i < n && (idx[i] & 0x80000000u)) ? 1u : 0u;
+        uint32_t flag = (i < live && (idx[i] & 0x80000000u)) ? 1u : 0u;
         uint32_t t2;
         uint32_t off = blockScanExclusive(flag, warpSums, &t2);
         if (flag) {
@@ -803,11 +1189,14 @@ __global__ __launch_bounds__(WG) void k_select(SelectArgs P) {
           o.seqStart = x.seqStart; o.seqEnd = x.seqEnd; o.readStart = x.readStart; o.readEnd = x.readEnd;
           o.matchCnt = x.matchCnt; o.relaxed = 0; o.leftClip = x.leftClip; o.rightClip = x.rightClip; o.re = re;
           o.flags = ((int)x.matchCnt >= bestMatch - 10 ? 1u : 0u) | ((c.allele >> 31) ? 0u : 2u);  // SeqSet.hpp:2200
+          if (o.flags & 1) ++nbLocal;
           P.ovl[(uint64_t)sBase + written + off] = o;
         }
         written += t2;
       }
     }
+    for (int o = 32; o > 0; o >>= 1) nbLocal += __shfl_down(nbLocal, o, 64);
+    if ((tid & 63) == 0 && nbLocal) atomicAdd(&P.counters[10], (unsigned long long)nbLocal);
     __syncthreads();
   }
 }
@@ -835,8 +1224,14 @@ __global__ __launch_bounds__(WG) void k_fullalign(FullArgs P) {
     if (x > 3) slow = true;
   }
   if (slow) {
-    unsigned long long q = atomicAdd(&P.counters[8], 1ull);
-    if (q < P.slowCap) P.slowQueue[q] = (uint32_t)gid; else atomicOr(&P.counters[2], (unsigned long long)ERR_SLOWCAP);
+    // equal spans: register-band traced DP (queue A, from the front); unequal spans: general DP (queue B, from the back)
+    if (L == Ls) {
+      unsigned long long q = atomicAdd(&P.counters[8], 1ull);
+      P.slowQueue[q] = (uint32_t)gid;
+    } else {
+      unsigned long long q = atomicAdd(&P.counters[15], 1ull);
+      P.slowQueue[P.slowCap - 1 - q] = (uint32_t)gid;
+    }
     return;
   }
   // ungapped alignment: columns are MATCH except at the x mismatching positions
@@ -885,7 +1280,6 @@ __global__ __launch_bounds__(64) void k_fullalign_slow(SlowArgs P) {
     const int lp = o.readEnd - o.readStart + 1, lt = o.seqEnd - o.seqStart + 1;
     const int w = (int)P.reads.weight[o.re];
     if ((lp + 1) * (lt + 1) > P.maxCells || lt > GA_BIG_MAX) { atomicOr(&P.counters[2], (unsigned long long)ERR_SLOWCAP); continue; }
-    atomicAdd(&P.counters[7], 1ull);
     T1kSeqView T{P.ref.bases, P.ref.nmask, goff + o.seqStart}, Pv{rb, rn, (int64_t)o.readStart};
     t1k_ga_general(T, lt, Pv, lp, rows, trace, nullptr);
     int n = t1k_ga_traceback(trace, lt, lp, ops);
@@ -903,6 +1297,66 @@ __global__ __launch_bounds__(64) void k_fullalign_slow(SlowArgs P) {
       if (op != 3) ++readPos;
     }
     P.ovl[gid].relaxed = (uint16_t)(P.relax ? 2 * m : (int)o.matchCnt);
+  }
+}
+
+// equal-span near-best alignments with more than 3 mismatches: banded DP with the band in registers, decision words in a
+// coalesced global trace, then the reference's traceback walked backwards (AlignAlgo.hpp:323-408) accumulating the relaxed
+// match count and the coverage runs directly (no edit string is materialised).
+__global__ __launch_bounds__(WG) void k_fullalign_eq(SlowArgs P) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, nThreads = gridDim.x * blockDim.x;
+  uint64_t *trace = (uint64_t *)P.scratch + t;
+  for (uint32_t q = t; q < P.nSlow; q += nThreads) {
+    const uint32_t gid = P.slowQueue[q];
+    const T1kOvl o = P.ovl[gid];
+    const int pass = (o.flags & 2) ? 1 : 0;
+    const int S = P.reads.S;
+    const uint64_t *rb = P.reads.bases + ((uint64_t)o.re * 2 + pass) * S;
+    const uint64_t *rn = P.reads.nmask + ((uint64_t)o.re * 2 + pass) * S;
+    const int64_t goff = (int64_t)P.ref.alleleOff[o.allele];
+    const int L = o.readEnd - o.readStart + 1;
+    const int w = (int)P.reads.weight[o.re];
+    T1kSeqView T{P.ref.bases, P.ref.nmask, goff + o.seqStart}, Pv{rb, rn, (int64_t)o.readStart};
+    t1k_ga_equal_traced(T, Pv, L, trace, nThreads);
+    int32_t *cov = P.ref.covDiff + goff;
+    const int alleleLen = (int)P.ref.alleleLen[o.allele];
+    int relaxed = 0;
+    int runLo = -1, runHi = -1;  // current run of covered reference positions, extended downwards
+    int ti = L, tj = L, mat = 0;
+    while (ti > 0 || tj > 0) {
+      int bits;
+      if (ti > 0 && tj > 0) bits = (int)((trace[(size_t)ti * nThreads] >> (5 * (tj - ti + 5))) & 31);
+      else if (ti == 0) bits = 2 | (tj == 1 ? 8 : 0);   // row 0: f >= e always; f opens from m only at column 1
+      else bits = (ti == 1 ? 4 : 0);                     // column 0: e > f; e opens from m only at row 1
+      int op;  // 0 match 1 mismatch 2 insert 3 delete
+      int refPos;
+      if (mat == 0) {
+        if (ti > 0 && tj > 0 && (bits & 1)) { op = (bits & 16) ? 0 : 1; refPos = o.seqStart + tj - 1; --ti; --tj; }
+        else { mat = (bits & 2) ? 2 : 1; continue; }
+      } else if (mat == 1) {
+        op = 2; refPos = o.seqStart + tj;
+        if (ti > 0) { if (bits & 4) mat = 0; --ti; } else mat = 2;
+      } else {
+        op = 3; refPos = o.seqStart + tj - 1;
+        if (tj > 0) { if (bits & 8) mat = 0; --tj; } else mat = 1;
+      }
+      if (P.relax) {
+        bool ex = refPos < alleleLen ? t1k_bit(P.ref.exon, goff + refPos) != 0 : false;
+        if (!ex || op == 0) ++relaxed;
+      }
+      if (op == 0 && w) {
+        const int readPos = o.readStart + ti;  // ti was already decremented: this column consumed read base ti
+        if (!t1k_bit(rn, readPos) && !t1k_bit(P.ref.nmask, goff + refPos)) {
+          if (refPos == runLo - 1) runLo = refPos;
+          else {
+            if (runLo >= 0) { atomicAdd(&cov[runLo], w); atomicAdd(&cov[runHi + 1], -w); }
+            runLo = runHi = refPos;
+          }
+        }
+      }
+    }
+    if (runLo >= 0) { atomicAdd(&cov[runLo], w); atomicAdd(&cov[runHi + 1], -w); }
+    P.ovl[gid].relaxed = (uint16_t)(P.relax ? 2 * relaxed : (int)o.matchCnt);
   }
 }
 
@@ -1012,9 +1466,10 @@ int t1k_launch_pack(t1k_ctx *ctx, const char *dAscii, const uint64_t *dOffs, uin
 }
 
 size_t t1k_seed_chain_lds(int S) { return (size_t)TILE_ALLELES * 4 + (size_t)(2 * S * 32) * (4 + 4 + 4 + 2); }
-size_t t1k_wg_groups_u32() { return (size_t)TILE_ALLELES * 3; }
+size_t t1k_wg_groups_u32() { return (size_t)TILE_ALLELES * 4; }
 size_t t1k_wg_thread_u32() { return (size_t)WG * THREAD_SCRATCH_U32; }
 size_t t1k_wg_big_u32() { return (size_t)3 * BIG_CAP + GA_SCRATCH_INTS; }
+size_t t1k_wg_cache_u64() { return (size_t)GAP_CACHE + GAP_CACHE / 2; }
 size_t t1k_slow_per_thread(int maxCells) { return (size_t)GA_SCRATCH_INTS * 4 + 4224 + (size_t)maxCells + 64; }
 
 void t1k_launch_seed_chain(t1k_ctx *ctx, const AssignArgs &a, int nWg) {
@@ -1036,6 +1491,7 @@ void t1k_launch_fullalign(t1k_ctx *ctx, const FullArgs &a) {
   hipLaunchKernelGGL(k_fullalign, dim3((unsigned)((a.nOvl + WG - 1) / WG)), dim3(WG), 0, ctx->stream, a);
 }
 void t1k_launch_fullalign_slow(t1k_ctx *ctx, const SlowArgs &a, int nBlocks) { hipLaunchKernelGGL(k_fullalign_slow, dim3(nBlocks), dim3(64), 0, ctx->stream, a); }
+void t1k_launch_fullalign_eq(t1k_ctx *ctx, const SlowArgs &a, int nBlocks) { hipLaunchKernelGGL(k_fullalign_eq, dim3(nBlocks), dim3(WG), 0, ctx->stream, a); }
 void t1k_launch_truncate(t1k_ctx *ctx, const TruncArgs &a, int nWg) {
   hipFuncSetAttribute((const void *)k_truncate, hipFuncAttributeMaxDynamicSharedMemorySize, SELECT_LDS_BYTES);
   hipLaunchKernelGGL(k_truncate, dim3(nWg), dim3(WG), SELECT_LDS_BYTES, ctx->stream, a);

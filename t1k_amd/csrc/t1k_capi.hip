@@ -3,6 +3,8 @@
 #include <algorithm>
 #include <chrono>
 #include <cstring>
+#include <cstdio>
+#include <cstdlib>
 #include "t1k_dev.h"
 #include "t1k_launch.h"
 
@@ -52,9 +54,9 @@ void t1k_params_default(t1k_params *p) {
   p->max_read_len = 320;
   p->workgroups = 512;
   p->hit_cap_per_wg = 1 << 20;
-  p->cand_cap = 96ll << 20;
-  p->ovl_cap = 64ll << 20;
-  p->row_cap = 64ll << 20;
+  p->cand_cap = 256ll << 20;
+  p->ovl_cap = 160ll << 20;
+  p->row_cap = 128ll << 20;
 }
 
 int t1k_device_count(void) {
@@ -86,6 +88,7 @@ int t1k_ctx_create(int device, const t1k_params *params, t1k_ctx **out) {
   if (ctx->prm.row_cap <= 0) ctx->prm.row_cap = d.row_cap;
   if (ctx->prm.kmer_length > 14 || ctx->prm.max_read_len > 2000) { delete ctx; return T1K_ERR_ARG; }
   if (hipStreamCreate(&ctx->stream) != hipSuccess) { delete ctx; return T1K_ERR_DEVICE; }
+  for (auto &e : ctx->ev) if (hipEventCreate(&e) != hipSuccess) { delete ctx; return T1K_ERR_DEVICE; }
   *out = ctx;
   return T1K_OK;
 }
@@ -100,12 +103,13 @@ void t1k_ctx_destroy(t1k_ctx *ctx) {
   (void)hipSetDevice(ctx->device);
   for (auto &b : ctx->refBufs) freeBuf(b);
   T1kDevBuf *all[] = {&ctx->bReadAscii, &ctx->bReadOffs, &ctx->bReadBases, &ctx->bReadN, &ctx->bReadLen, &ctx->bReadWeight, &ctx->bWgHits, &ctx->bWgGroups,
-                      &ctx->bWgStage, &ctx->bWgThreadScratch, &ctx->bWgBig, &ctx->bCand, &ctx->bExt, &ctx->bCandStart, &ctx->bCandCount, &ctx->bOvl,
-                      &ctx->bOvlStart, &ctx->bOvlCount, &ctx->bCounters, &ctx->bSlowQueue, &ctx->bSlowScratch, &ctx->bSortScratch, &ctx->bEnd1, &ctx->bEnd2,
+                      &ctx->bWgStage, &ctx->bWgThreadScratch, &ctx->bWgBig, &ctx->bWgCache, &ctx->bCand, &ctx->bExt, &ctx->bCandStart, &ctx->bCandCount, &ctx->bOvl,
+                      &ctx->bOvlStart, &ctx->bOvlCount, &ctx->bCounters, &ctx->bSlowQueue, &ctx->bSlowScratch, &ctx->bSortScratch, &ctx->bEqTrace, &ctx->bEnd1, &ctx->bEnd2,
                       &ctx->bHasN, &ctx->bRows, &ctx->bRowStart, &ctx->bRowCount, &ctx->bFragAssigned, &ctx->bPairScratch, &ctx->bEmRowPtr, &ctx->bEmEc,
                       &ctx->bEmCount, &ctx->bEmLen, &ctx->bEmX0, &ctx->bEmX1, &ctx->bEmN, &ctx->bEmContrib, &ctx->bEmColPtr, &ctx->bEmColIdx, &ctx->bEmScalars};
   for (auto *b : all) freeBuf(*b);
   for (auto &b : ctx->bAlign) freeBuf(b);
+  for (auto &e : ctx->ev) if (e) (void)hipEventDestroy(e);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -286,7 +290,7 @@ int t1k_reads_upload(t1k_ctx *ctx, const char *seqs, const uint64_t *offsets, co
 // AssignRead over the batch
 // ------------------------------------------------------------------------------------------------------------------
 static int fetchCounters(t1k_ctx *ctx, unsigned long long *h) {
-  T1K_HIP(ctx, hipMemcpyAsync(h, ctx->bCounters.p, 16 * 8, hipMemcpyDeviceToHost, ctx->stream));
+  T1K_HIP(ctx, hipMemcpyAsync(h, ctx->bCounters.p, 64 * 8, hipMemcpyDeviceToHost, ctx->stream));
   T1K_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return 0;
 }
@@ -322,12 +326,13 @@ int t1k_assign_range(t1k_ctx *ctx, uint64_t first, uint32_t count) {
   const int nWg = (int)std::min<uint32_t>((uint32_t)ctx->prm.workgroups, std::max<uint32_t>(n, 1));
   const uint32_t stageCap = 1u << 16;
   const uint32_t sortCap = 1u << 15;
-  if ((rc = t1k_ensure(ctx, ctx->bCounters, 16 * 8))) return rc;
+  if ((rc = t1k_ensure(ctx, ctx->bCounters, 64 * 8))) return rc;
   if ((rc = t1k_ensure(ctx, ctx->bWgHits, (size_t)nWg * ctx->prm.hit_cap_per_wg * 4))) return rc;
   if ((rc = t1k_ensure(ctx, ctx->bWgGroups, (size_t)nWg * t1k_wg_groups_u32() * 4))) return rc;
   if ((rc = t1k_ensure(ctx, ctx->bWgStage, (size_t)nWg * stageCap * sizeof(T1kCand)))) return rc;
   if ((rc = t1k_ensure(ctx, ctx->bWgThreadScratch, (size_t)nWg * t1k_wg_thread_u32() * 4))) return rc;
   if ((rc = t1k_ensure(ctx, ctx->bWgBig, (size_t)nWg * t1k_wg_big_u32() * 4))) return rc;
+  if ((rc = t1k_ensure(ctx, ctx->bWgCache, (size_t)nWg * t1k_wg_cache_u64() * 8))) return rc;
   if ((rc = t1k_ensure(ctx, ctx->bCand, (size_t)ctx->prm.cand_cap * sizeof(T1kCand)))) return rc;
   if ((rc = t1k_ensure(ctx, ctx->bExt, (size_t)ctx->prm.cand_cap * sizeof(T1kExt)))) return rc;
   if ((rc = t1k_ensure(ctx, ctx->bOvl, (size_t)ctx->prm.ovl_cap * sizeof(T1kOvl)))) return rc;
@@ -336,12 +341,12 @@ int t1k_assign_range(t1k_ctx *ctx, uint64_t first, uint32_t count) {
   if ((rc = t1k_ensure(ctx, ctx->bOvlStart, (size_t)n * 4))) return rc;
   if ((rc = t1k_ensure(ctx, ctx->bOvlCount, (size_t)n * 4))) return rc;
   if ((rc = t1k_ensure(ctx, ctx->bSortScratch, (size_t)nWg * sortCap * 48))) return rc;
-  T1K_HIP(ctx, hipMemsetAsync(ctx->bCounters.p, 0, 16 * 8, ctx->stream));
+  T1K_HIP(ctx, hipMemsetAsync(ctx->bCounters.p, 0, 64 * 8, ctx->stream));
   T1K_HIP(ctx, hipMemsetAsync(ctx->bOvlCount.p, 0, (size_t)n * 4 + 4, ctx->stream));
   ctx->nCand = ctx->nOvl = 0;
   memset(&ctx->stats, 0, sizeof(ctx->stats));
   if (n == 0) return T1K_OK;
-  unsigned long long hc[16];
+  unsigned long long hc[64];
   double t0 = nowMs();
   AssignArgs a{};
   a.ref = ctx->ref; a.reads = rd;
@@ -352,10 +357,13 @@ int t1k_assign_range(t1k_ctx *ctx, uint64_t first, uint32_t count) {
   a.wgStage = (T1kCand *)ctx->bWgStage.p; a.stageCap = stageCap;
   a.wgThread = (uint32_t *)ctx->bWgThreadScratch.p;
   a.wgBig = (uint32_t *)ctx->bWgBig.p;
+  a.wgCache = (unsigned long long *)ctx->bWgCache.p;
   a.cand = (T1kCand *)ctx->bCand.p; a.candCap = (uint64_t)ctx->prm.cand_cap;
   a.candStart = (uint32_t *)ctx->bCandStart.p; a.candCount = (uint32_t *)ctx->bCandCount.p;
   a.counters = (unsigned long long *)ctx->bCounters.p;
+  T1K_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
   t1k_launch_seed_chain(ctx, a, nWg);
+  T1K_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
   if ((rc = fetchCounters(ctx, hc))) return rc;
   double t1 = nowMs();
   if (hc[2]) return capacityError(ctx, hc[2]);
@@ -364,6 +372,7 @@ int t1k_assign_range(t1k_ctx *ctx, uint64_t first, uint32_t count) {
   e.ref = ctx->ref; e.reads = rd; e.k = a.k; e.sim = a.sim;
   e.cand = a.cand; e.ext = (T1kExt *)ctx->bExt.p; e.nCand = ctx->nCand; e.counters = a.counters;
   t1k_launch_extend(ctx, e);
+  T1K_HIP(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
   T1K_HIP(ctx, hipStreamSynchronize(ctx->stream));
   double t2 = nowMs();
   SelectArgs s{};
@@ -372,6 +381,7 @@ int t1k_assign_range(t1k_ctx *ctx, uint64_t first, uint32_t count) {
   s.ovlStart = (uint32_t *)ctx->bOvlStart.p; s.ovlCount = (uint32_t *)ctx->bOvlCount.p;
   s.sortScratch = (uint64_t *)ctx->bSortScratch.p; s.sortCap = sortCap; s.counters = a.counters;
   t1k_launch_select(ctx, s, nWg);
+  T1K_HIP(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
   if ((rc = fetchCounters(ctx, hc))) return rc;
   double t3 = nowMs();
   if (hc[2]) return capacityError(ctx, hc[2]);
@@ -384,25 +394,51 @@ int t1k_assign_range(t1k_ctx *ctx, uint64_t first, uint32_t count) {
   f.ref = ctx->ref; f.reads = rd; f.relax = a.relax; f.ovl = s.ovl; f.nOvl = ctx->nOvl;
   f.slowQueue = (uint32_t *)ctx->bSlowQueue.p; f.slowCap = (uint32_t)std::min<uint64_t>(ctx->nOvl + 1, 0xFFFFFFFFull); f.counters = a.counters;
   t1k_launch_fullalign(ctx, f);
+  T1K_HIP(ctx, hipEventRecord(ctx->ev[7], ctx->stream));
   if ((rc = fetchCounters(ctx, hc))) return rc;
   if (hc[2]) return capacityError(ctx, hc[2]);
-  if (hc[8]) {
+  if (hc[8]) {  // equal-span alignments: register-band traced DP, one lane per job
+    const int eqBlocks = 512;
+    const size_t traceBytes = (size_t)eqBlocks * 256 * (size_t)(ctx->batchMaxLen + 2) * 8;
+    if ((rc = t1k_ensure(ctx, ctx->bEqTrace, traceBytes))) return rc;
     SlowArgs sl{};
     sl.ref = ctx->ref; sl.reads = rd; sl.relax = a.relax; sl.ovl = s.ovl; sl.slowQueue = f.slowQueue; sl.nSlow = (uint32_t)hc[8];
+    sl.scratch = (uint8_t *)ctx->bEqTrace.p; sl.perThread = 0; sl.maxCells = 0; sl.counters = a.counters;
+    t1k_launch_fullalign_eq(ctx, sl, eqBlocks);
+  }
+  if (hc[15]) {  // unequal spans (indel chains): general DP with row arrays in HBM
+    SlowArgs sl{};
+    sl.ref = ctx->ref; sl.reads = rd; sl.relax = a.relax; sl.ovl = s.ovl; sl.slowQueue = f.slowQueue + (f.slowCap - hc[15]); sl.nSlow = (uint32_t)hc[15];
     sl.scratch = (uint8_t *)ctx->bSlowScratch.p; sl.perThread = t1k_slow_per_thread(maxCells); sl.maxCells = maxCells; sl.counters = a.counters;
     t1k_launch_fullalign_slow(ctx, sl, slowBlocks);
   }
+  static hipEvent_t evSlow = nullptr;
+  if (!evSlow) (void)hipEventCreate(&evSlow);
+  T1K_HIP(ctx, hipEventRecord(evSlow, ctx->stream));
   TruncArgs tr{};
   tr.reads = rd; tr.ovl = s.ovl; tr.ovlStart = s.ovlStart; tr.ovlCount = s.ovlCount; tr.sortScratch = s.sortScratch; tr.sortCap = sortCap;
   tr.counters = a.counters;
   t1k_launch_truncate(ctx, tr, nWg);
+  T1K_HIP(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
   if ((rc = fetchCounters(ctx, hc))) return rc;
   double t4 = nowMs();
   if (hc[2]) return capacityError(ctx, hc[2]);
+  if (getenv("T1K_DEBUG_PHASES")) {
+    float a1 = 0, a2 = 0, a3 = 0;
+    (void)hipEventElapsedTime(&a1, ctx->ev[3], ctx->ev[7]); (void)hipEventElapsedTime(&a2, ctx->ev[7], evSlow); (void)hipEventElapsedTime(&a3, evSlow, ctx->ev[4]);
+    fprintf(stderr, "[t1k] fullalign %.2f ms, slow (%llu jobs) %.2f ms, truncate %.2f ms; cand %llu ovl %llu dp %llu; groups fast %llu general %llu deferred %llu\n", a1, hc[8], a2, a3, hc[0], hc[1], hc[7], hc[11], hc[12], hc[13]);
+    fprintf(stderr, "[t1k] chain sub-phases (ticks): fast loop %llu, dense DP %llu, retry %llu, general(in chain=%llu)\n", hc[41], hc[42], hc[43], hc[21]);
+    fprintf(stderr, "[t1k] fast-path sections clocks/16: load+vote+M %llu dilate %llu mm %llu gaps %llu\n", hc[28], hc[29], hc[30], hc[31]);
+    fprintf(stderr, "[t1k] per-thread chain-loop clocks/64 = %llu, of which inside DP = %llu (DP rows %llu)\n", hc[25], hc[26], hc[27]);
+    fprintf(stderr, "[t1k] seed_chain phases (wall_clock64 ticks summed over workgroups): kmer %llu rule %llu count %llu scan %llu scatter %llu chain %llu deferred %llu compact %llu copy %llu | ev ms chain %.2f\n", hc[16], hc[17], hc[18], hc[19], hc[20], hc[21], hc[22], hc[23], hc[24], 0.0);
+  }
   t1k_stats &st = ctx->stats;
   st.read_ends = n; st.lookups = hc[3]; st.postings = hc[4]; st.hits = hc[5]; st.groups = hc[6]; st.candidates = hc[0]; st.extended = hc[1];
-  st.dp_calls = hc[7]; st.near_best = hc[8];
-  st.ms_seed = 0; st.ms_chain = t1 - t0; st.ms_extend = t2 - t1; st.ms_select = t3 - t2; st.ms_fullalign = t4 - t3; st.ms_total = t4 - t0;
+  st.dp_calls = hc[7] + hc[14]; st.near_best = hc[10];
+  float ms[4] = {0, 0, 0, 0};  // kernel durations from HIP events on the launch stream
+  for (int i = 0; i < 4; ++i) (void)hipEventElapsedTime(&ms[i], ctx->ev[i], ctx->ev[i + 1]);
+  (void)t1; (void)t2; (void)t3;
+  st.ms_seed = 0; st.ms_chain = ms[0]; st.ms_extend = ms[1]; st.ms_select = ms[2]; st.ms_fullalign = ms[3]; st.ms_total = t4 - t0;
   return T1K_OK;
 }
 

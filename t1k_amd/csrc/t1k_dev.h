@@ -83,9 +83,8 @@ struct T1kReadsDev {
 __device__ __forceinline__ uint64_t t1k_get32(const uint64_t *w, int64_t pos) {
   int64_t wi = pos >> 5;
   int sh = (int)(pos & 31) * 2;
-  uint64_t lo = w[wi];
-  if (sh == 0) return lo;
-  return (lo >> sh) | (w[wi + 1] << (64 - sh));
+  uint64_t lo = w[wi], hi = w[wi + 1];  // both loads issue together; branch-free so callers can keep many windows in flight
+  return (lo >> sh) | ((hi << 1) << (63 - sh));
 }
 __device__ __forceinline__ uint64_t t1k_lowmask(int nPos) {  // mask of the first nPos positions (0..32)
   return nPos >= 32 ? ~0ull : ((1ull << (2 * nPos)) - 1);
@@ -142,8 +141,14 @@ __device__ inline int t1k_ga_matches_equal(const T1kSeqView &T, const T1kSeqView
     else { m[s] = -4 - 4 * j; e[s] = -4 - 4 * (L + 1); }
     cm[s] = 0; ce[s] = 0;
   }
+  uint64_t pwB = 0, pwN = 0;
   for (int i = 1; i <= L; ++i) {
-    int pc = P.code(i - 1);
+    // pattern base i-1: one 32-base window per 32 rows; text bases i-6 .. i+4: one window per row (2 loads, L1-resident)
+    if (((i - 1) & 31) == 0) { pwB = t1k_get32(P.b, P.pos + i - 1); pwN = t1k_get32(P.n, P.pos + i - 1); }
+    const int pq = ((i - 1) & 31) * 2;
+    const int pc = ((pwN >> pq) & 1) ? 4 : (int)((pwB >> pq) & 3);
+    const int t0 = i - 6 > 0 ? i - 6 : 0;  // first text index covered by the window
+    const uint64_t twB = t1k_get32(T.b, T.pos + t0), twN = t1k_get32(T.n, T.pos + t0);
     int fLeft = 0, mLeft = 0, cfLeft = 0, cmLeft = 0;  // cell (i, j-1) of the current row
 #pragma unroll
     for (int s = 0; s < 13; ++s) {
@@ -162,7 +167,9 @@ __device__ inline int t1k_ga_matches_equal(const T1kSeqView &T, const T1kSeqView
         nf = fl > ml ? fl : ml;
         ncf = (ml == nf) ? cmLeft : cfLeft;
         // m: diagonal (i-1, j-1) = previous row at slot s
-        bool eq = t1k_eq(T.code(j - 1), pc);
+        const int tq = (j - 1 - t0) * 2;
+        const int tc = ((twN >> tq) & 1) ? 4 : (int)((twB >> tq) & 3);
+        bool eq = t1k_eq(tc, pc);
         int dg = m[s] + (eq ? 2 : -2);
         nm = dg;
         if (ne > nm) nm = ne;
@@ -180,16 +187,74 @@ __device__ inline int t1k_ga_matches_equal(const T1kSeqView &T, const T1kSeqView
   return cm[6];
 }
 
+// Same sweep as t1k_ga_matches_equal, additionally recording the traceback decisions: one 64-bit word per row, 5 bits per
+// in-band cell (slot s = j - i + 6 in 1..11 at bits 5*(s-1)): b0 diagonal reproduces m, b1 f >= e, b2 e opened from m,
+// b3 f opened from m, b4 the two bases compare equal.  Words go to trace[i * stride] (i = 1..L) so that a wavefront's
+// stores coalesce.  Boundary cells (row 0 / column 0) need no storage: their decisions are closed-form (see the walker).
+__device__ inline void t1k_ga_equal_traced(const T1kSeqView &T, const T1kSeqView &P, int L, uint64_t *trace, size_t stride) {
+  const int negInf = (L + 1) * (L + 1) * -4;
+  int m[13], e[13];
+#pragma unroll
+  for (int s = 0; s < 13; ++s) {
+    int j = s - 6;
+    if (j == 0) { m[s] = 0; e[s] = 0; }
+    else { m[s] = -4 - 4 * j; e[s] = -4 - 4 * (L + 1); }
+  }
+  uint64_t pwB = 0, pwN = 0;
+  for (int i = 1; i <= L; ++i) {
+    if (((i - 1) & 31) == 0) { pwB = t1k_get32(P.b, P.pos + i - 1); pwN = t1k_get32(P.n, P.pos + i - 1); }
+    const int pq = ((i - 1) & 31) * 2;
+    const int pc = ((pwN >> pq) & 1) ? 4 : (int)((pwB >> pq) & 3);
+    const int t0 = i - 6 > 0 ? i - 6 : 0;
+    const uint64_t twB = t1k_get32(T.b, T.pos + t0), twN = t1k_get32(T.n, T.pos + t0);
+    int fLeft = 0, mLeft = 0;
+    uint64_t word = 0;
+#pragma unroll
+    for (int s = 0; s < 13; ++s) {
+      int j = i + s - 6;
+      int nm, ne, nf;
+      if (j < 0) { nm = ne = nf = negInf; }
+      else if (j == 0) { nm = -4 - 4 * i; ne = -4 - i; nf = -4 - 4 * i; }
+      else if (j > L || s == 0 || s == 12) { nm = ne = nf = negInf; }
+      else {
+        int eu = e[s + 1] - 1, mu = m[s + 1] - 5;
+        ne = eu > mu ? eu : mu;
+        int fl = fLeft - 1, ml = mLeft - 5;
+        nf = fl > ml ? fl : ml;
+        const int tq = (j - 1 - t0) * 2;
+        const int tc = ((twN >> tq) & 1) ? 4 : (int)((twB >> tq) & 3);
+        bool eq = t1k_eq(tc, pc);
+        int dg = m[s] + (eq ? 2 : -2);
+        nm = dg;
+        if (ne > nm) nm = ne;
+        if (nf > nm) nm = nf;
+        uint64_t bits = (dg == nm ? 1u : 0u) | (nf >= ne ? 2u : 0u) | (mu == ne ? 4u : 0u) | (ml == nf ? 8u : 0u) | (eq ? 16u : 0u);
+        word |= bits << (5 * (s - 1));
+      }
+      m[s] = nm; e[s] = ne;
+      fLeft = nf; mLeft = nm;
+    }
+    trace[(size_t)i * stride] = word;
+  }
+}
+
 // Exact fast path for equal lengths: with x <= 3 mismatches the ungapped alignment is optimal and is the one the
 // traceback returns (any gapped alignment of equal-length strings scores <= 2L-12 <= 2L-4x, ties go to the diagonal).
 __device__ __forceinline__ int t1k_ga_matches_window(const uint64_t *rb, const uint64_t *rn, int64_t rpos, const uint64_t *gb, const uint64_t *gn,
-                                                      int64_t gpos, int L, unsigned long long *dpCounter) {
+                                                      int64_t gpos, int L, unsigned int *dpCounter) {
   if (L <= 0) return 0;
   int x = t1k_hamming(rb, rn, rpos, gb, gn, gpos, L);
   if (x <= 3) return L - x;
-  if (dpCounter) atomicAdd(dpCounter, 1ull);
+  if (dpCounter) ++*dpCounter;  // thread-local tally, flushed once per workgroup by the caller
   T1kSeqView T{gb, gn, gpos}, P{rb, rn, rpos};
+#ifdef T1K_PHASE_TIMERS
+  long long t0_ = clock64();
+  int r_ = t1k_ga_matches_equal(T, P, L, nullptr);
+  if (dpCounter) { dpCounter[1] += (unsigned int)((clock64() - t0_) >> 6); dpCounter[2] += (unsigned int)L; }
+  return r_;
+#else
   return t1k_ga_matches_equal(T, P, L, nullptr);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -330,6 +395,7 @@ struct T1kDevBuf {
 struct t1k_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
+  hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   t1k_params prm;
   std::string err;
   // reference
@@ -343,8 +409,8 @@ struct t1k_ctx {
   int batchMaxLen = 0;
   uint32_t rangeCount = 0;       // read-ends of the last t1k_assign_range
   // assignment arenas
-  T1kDevBuf bWgHits, bWgGroups, bWgStage, bWgThreadScratch, bWgBig;
-  T1kDevBuf bCand, bExt, bCandStart, bCandCount, bOvl, bOvlStart, bOvlCount, bCounters, bSlowQueue, bSlowScratch, bSortScratch;
+  T1kDevBuf bWgHits, bWgGroups, bWgStage, bWgThreadScratch, bWgBig, bWgCache;
+  T1kDevBuf bCand, bExt, bCandStart, bCandCount, bOvl, bOvlStart, bOvlCount, bCounters, bSlowQueue, bSlowScratch, bSortScratch, bEqTrace;
   uint64_t nCand = 0, nOvl = 0;
   // pairing
   T1kDevBuf bEnd1, bEnd2, bHasN, bRows, bRowStart, bRowCount, bFragAssigned, bPairScratch;

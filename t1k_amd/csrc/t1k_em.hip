@@ -132,8 +132,8 @@ int t1k_align_batch(t1k_ctx *ctx, const char *text, const uint32_t *tOff, const 
   if ((rc = t1k_ensure(ctx, B[9], (size_t)nJobs * 5 * 4 + 64))) return rc;           // score, nMatch, nMismatch, nIndel, nOps
   if ((rc = t1k_ensure(ctx, B[10], opsTotal + 64))) return rc;
   if ((rc = t1k_ensure(ctx, B[11], (size_t)blocks * 64 * perThread + 64))) return rc;
-  if ((rc = t1k_ensure(ctx, ctx->bCounters, 16 * 8))) return rc;
-  T1K_HIP(ctx, hipMemsetAsync(ctx->bCounters.p, 0, 16 * 8, ctx->stream));
+  if ((rc = t1k_ensure(ctx, ctx->bCounters, 64 * 8))) return rc;
+  T1K_HIP(ctx, hipMemsetAsync(ctx->bCounters.p, 0, 64 * 8, ctx->stream));
   AlignJobArgs a{};
   a.tb = (uint64_t *)B[0].p; a.tn = (uint64_t *)B[1].p; a.pb = (uint64_t *)B[2].p; a.pn = (uint64_t *)B[3].p;
   a.tPos = (uint64_t *)B[4].p; a.pPos = (uint64_t *)B[5].p; a.tLen = (uint32_t *)B[6].p; a.pLen = (uint32_t *)B[7].p; a.nJobs = nJobs;

@@ -14,6 +14,7 @@ struct AssignArgs {
   T1kCand *wgStage; uint32_t stageCap;
   uint32_t *wgThread;          // [wg][WG][THREAD_SCRATCH_U32]
   uint32_t *wgBig;             // [wg][3 * BIG_CAP + GA_SCRATCH_INTS]
+  unsigned long long *wgCache; // [wg][GAP_CACHE] memo of gap alignments of the current read-end
   // outputs
   T1kCand *cand; uint64_t candCap;
   uint32_t *candStart, *candCount;
@@ -79,11 +80,13 @@ size_t t1k_seed_chain_lds(int S);
 size_t t1k_wg_groups_u32();
 size_t t1k_wg_thread_u32();
 size_t t1k_wg_big_u32();
+size_t t1k_wg_cache_u64();
 size_t t1k_slow_per_thread(int maxCells);
 void t1k_launch_seed_chain(t1k_ctx *ctx, const AssignArgs &a, int nWg);
 void t1k_launch_extend(t1k_ctx *ctx, const ExtendArgs &a);
 void t1k_launch_select(t1k_ctx *ctx, const SelectArgs &a, int nWg);
 void t1k_launch_fullalign(t1k_ctx *ctx, const FullArgs &a);
 void t1k_launch_fullalign_slow(t1k_ctx *ctx, const SlowArgs &a, int nBlocks);
+void t1k_launch_fullalign_eq(t1k_ctx *ctx, const SlowArgs &a, int nBlocks);
 void t1k_launch_truncate(t1k_ctx *ctx, const TruncArgs &a, int nWg);
 void t1k_launch_coverage_scan(t1k_ctx *ctx, const T1kRefDev &ref, int32_t *out, const uint64_t *outOff);

@@ -406,7 +406,7 @@ int t1k_pair_batch(t1k_ctx *ctx, const uint32_t *end1, const uint32_t *end2, con
   size_t perWg = (size_t)A * 16 + (size_t)fragCap * (sizeof(Frag) + 4);
   bool fresh = ctx->bPairScratch.bytes < (size_t)nWg * perWg;
   if ((rc = t1k_ensure(ctx, ctx->bPairScratch, (size_t)nWg * perWg))) return rc;
-  if ((rc = t1k_ensure(ctx, ctx->bCounters, 16 * 8))) return rc;
+  if ((rc = t1k_ensure(ctx, ctx->bCounters, 64 * 8))) return rc;
   if (fresh) T1K_HIP(ctx, hipMemsetAsync(ctx->bPairScratch.p, 0, (size_t)nWg * perWg, ctx->stream));  // epochs start at 0
   if (n == 0) return T1K_OK;
   double t0 = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
@@ -433,13 +433,15 @@ int t1k_pair_batch(t1k_ctx *ctx, const uint32_t *end1, const uint32_t *end2, con
   p.fragCap = fragCap;
   p.keep = (uint32_t *)(sc + (size_t)nWg * A * 16 + (size_t)nWg * fragCap * sizeof(Frag));
   p.counters = (unsigned long long *)ctx->bCounters.p;
+  T1K_HIP(ctx, hipEventRecord(ctx->ev[5], ctx->stream));
   hipLaunchKernelGGL(k_pair, dim3(nWg), dim3(WG), 0, ctx->stream, p);
-  unsigned long long hc[16];
-  T1K_HIP(ctx, hipMemcpyAsync(hc, ctx->bCounters.p, 16 * 8, hipMemcpyDeviceToHost, ctx->stream));
+  T1K_HIP(ctx, hipEventRecord(ctx->ev[6], ctx->stream));
+  unsigned long long hc[64];
+  T1K_HIP(ctx, hipMemcpyAsync(hc, ctx->bCounters.p, 64 * 8, hipMemcpyDeviceToHost, ctx->stream));
   T1K_HIP(ctx, hipStreamSynchronize(ctx->stream));
   if (hc[2]) return t1k_fail(ctx, T1K_ERR_CAPACITY, "device arena overflow: row_cap / fragment scratch");
   ctx->nRows = hc[9];
-  ctx->stats.ms_pair = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count() - t0;
+  { float ms = 0; (void)hipEventElapsedTime(&ms, ctx->ev[5], ctx->ev[6]); ctx->stats.ms_pair = ms; (void)t0; }
   return T1K_OK;
 }
 
