@@ -45,8 +45,9 @@ typedef struct {
   int32_t max_assign_cnt;       /* -n, default 2000 */
   /* device arena sizing (0 = defaults) */
   int32_t max_read_len;         /* longest read accepted, default 320 */
-  int32_t workgroups;           /* persistent workgroups of the seeding/chaining kernel, default 1024 */
-  int64_t hit_cap_per_wg;       /* u32 hit slots per workgroup */
+  int32_t workgroups;           /* persistent workgroups of the per-read-end kernels, default 1024 */
+  int64_t hit_cap;              /* k-mer hit slots (u32) per batch, < 2^32 */
+  int64_t group_cap;            /* (read-end, strand, allele) hit groups per batch */
   int64_t cand_cap;             /* candidate records per batch */
   int64_t ovl_cap;              /* overlap records per batch */
   int64_t row_cap;              /* fragment-row entries per batch */

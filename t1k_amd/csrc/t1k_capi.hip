@@ -53,7 +53,8 @@ void t1k_params_default(t1k_params *p) {
   p->max_assign_cnt = 2000;
   p->max_read_len = 320;
   p->workgroups = 512;
-  p->hit_cap_per_wg = 1 << 20;
+  p->hit_cap = 3ll << 30;
+  p->group_cap = 160ll << 20;
   p->cand_cap = 256ll << 20;
   p->ovl_cap = 160ll << 20;
   p->row_cap = 128ll << 20;
@@ -82,7 +83,9 @@ int t1k_ctx_create(int device, const t1k_params *params, t1k_ctx **out) {
   if (ctx->prm.max_assign_cnt == 0) ctx->prm.max_assign_cnt = d.max_assign_cnt;
   if (ctx->prm.max_read_len <= 0) ctx->prm.max_read_len = d.max_read_len;
   if (ctx->prm.workgroups <= 0) ctx->prm.workgroups = d.workgroups;
-  if (ctx->prm.hit_cap_per_wg <= 0) ctx->prm.hit_cap_per_wg = d.hit_cap_per_wg;
+  if (ctx->prm.hit_cap <= 0) ctx->prm.hit_cap = d.hit_cap;
+  if (ctx->prm.group_cap <= 0) ctx->prm.group_cap = d.group_cap;
+  if (ctx->prm.hit_cap > 0xFFFFFFF0ll) ctx->prm.hit_cap = 0xFFFFFFF0ll;
   if (ctx->prm.cand_cap <= 0) ctx->prm.cand_cap = d.cand_cap;
   if (ctx->prm.ovl_cap <= 0) ctx->prm.ovl_cap = d.ovl_cap;
   if (ctx->prm.row_cap <= 0) ctx->prm.row_cap = d.row_cap;
@@ -103,7 +106,7 @@ void t1k_ctx_destroy(t1k_ctx *ctx) {
   (void)hipSetDevice(ctx->device);
   for (auto &b : ctx->refBufs) freeBuf(b);
   T1kDevBuf *all[] = {&ctx->bReadAscii, &ctx->bReadOffs, &ctx->bReadBases, &ctx->bReadN, &ctx->bReadLen, &ctx->bReadWeight, &ctx->bWgHits, &ctx->bWgGroups,
-                      &ctx->bWgStage, &ctx->bWgThreadScratch, &ctx->bWgBig, &ctx->bWgCache, &ctx->bCand, &ctx->bExt, &ctx->bCandStart, &ctx->bCandCount, &ctx->bOvl,
+                      &ctx->bWgStage, &ctx->bWgThreadScratch, &ctx->bWgBig, &ctx->bWgCache, &ctx->bLists, &ctx->bCand, &ctx->bExt, &ctx->bCandStart, &ctx->bCandCount, &ctx->bOvl,
                       &ctx->bOvlStart, &ctx->bOvlCount, &ctx->bCounters, &ctx->bSlowQueue, &ctx->bSlowScratch, &ctx->bSortScratch, &ctx->bEqTrace, &ctx->bEnd1, &ctx->bEnd2,
                       &ctx->bHasN, &ctx->bRows, &ctx->bRowStart, &ctx->bRowCount, &ctx->bFragAssigned, &ctx->bPairScratch, &ctx->bEmRowPtr, &ctx->bEmEc,
                       &ctx->bEmCount, &ctx->bEmLen, &ctx->bEmX0, &ctx->bEmX1, &ctx->bEmN, &ctx->bEmContrib, &ctx->bEmColPtr, &ctx->bEmColIdx, &ctx->bEmScalars};
@@ -297,7 +300,7 @@ static int fetchCounters(t1k_ctx *ctx, unsigned long long *h) {
 
 static int capacityError(t1k_ctx *ctx, unsigned long long flags) {
   std::string m = "device arena overflow:";
-  if (flags & 1) m += " hit_cap_per_wg";
+  if (flags & 1) m += " hit_cap";
   if (flags & 2) m += " candidate staging";
   if (flags & 4) m += " cand_cap";
   if (flags & 8) m += " group too large";
@@ -305,6 +308,7 @@ static int capacityError(t1k_ctx *ctx, unsigned long long flags) {
   if (flags & 32) m += " sort capacity";
   if (flags & 64) m += " slow-alignment queue";
   if (flags & 128) m += " row_cap";
+  if (flags & 256) m += " group_cap";
   return t1k_fail(ctx, T1K_ERR_CAPACITY, m);
 }
 
@@ -324,15 +328,19 @@ int t1k_assign_range(t1k_ctx *ctx, uint64_t first, uint32_t count) {
   ctx->rangeCount = count;
   int rc;
   const int nWg = (int)std::min<uint32_t>((uint32_t)ctx->prm.workgroups, std::max<uint32_t>(n, 1));
-  const uint32_t stageCap = 1u << 16;
   const uint32_t sortCap = 1u << 15;
+  const int maxChunks = t1k_chain_max_chunks(), memoN = t1k_chain_memo_entries();
+  const uint64_t hitCap = (uint64_t)ctx->prm.hit_cap, groupCap = (uint64_t)ctx->prm.group_cap;
+  const uint32_t jobCap = 16u << 20;
+  const int generalBlocks = 128, bigBlocks = 2;
   if ((rc = t1k_ensure(ctx, ctx->bCounters, 64 * 8))) return rc;
-  if ((rc = t1k_ensure(ctx, ctx->bWgHits, (size_t)nWg * ctx->prm.hit_cap_per_wg * 4))) return rc;
-  if ((rc = t1k_ensure(ctx, ctx->bWgGroups, (size_t)nWg * t1k_wg_groups_u32() * 4))) return rc;
-  if ((rc = t1k_ensure(ctx, ctx->bWgStage, (size_t)nWg * stageCap * sizeof(T1kCand)))) return rc;
-  if ((rc = t1k_ensure(ctx, ctx->bWgThreadScratch, (size_t)nWg * t1k_wg_thread_u32() * 4))) return rc;
-  if ((rc = t1k_ensure(ctx, ctx->bWgBig, (size_t)nWg * t1k_wg_big_u32() * 4))) return rc;
-  if ((rc = t1k_ensure(ctx, ctx->bWgCache, (size_t)nWg * t1k_wg_cache_u64() * 8))) return rc;
+  if ((rc = t1k_ensure(ctx, ctx->bWgHits, hitCap * 4))) return rc;                                        // batch hit arena
+  if ((rc = t1k_ensure(ctx, ctx->bWgGroups, groupCap * sizeof(T1kGroup)))) return rc;                     // batch group arena
+  if ((rc = t1k_ensure(ctx, ctx->bWgStage, (size_t)n * maxChunks * 8 + 64))) return rc;                   // chunkStart | chunkCount
+  if ((rc = t1k_ensure(ctx, ctx->bWgCache, (size_t)n * memoN * 8 + 64))) return rc;                       // per-read-end memo
+  if ((rc = t1k_ensure(ctx, ctx->bWgThreadScratch, (size_t)generalBlocks * 256 * t1k_chain_thread_scratch_u32() * 4))) return rc;
+  if ((rc = t1k_ensure(ctx, ctx->bWgBig, (size_t)bigBlocks * 64 * t1k_chain_big_scratch_u32() * 4))) return rc;
+  if ((rc = t1k_ensure(ctx, ctx->bLists, (size_t)jobCap * 4 + groupCap * 4 * 3 + 64))) return rc;        // jobList | retry | general | big
   if ((rc = t1k_ensure(ctx, ctx->bCand, (size_t)ctx->prm.cand_cap * sizeof(T1kCand)))) return rc;
   if ((rc = t1k_ensure(ctx, ctx->bExt, (size_t)ctx->prm.cand_cap * sizeof(T1kExt)))) return rc;
   if ((rc = t1k_ensure(ctx, ctx->bOvl, (size_t)ctx->prm.ovl_cap * sizeof(T1kOvl)))) return rc;
@@ -343,28 +351,29 @@ int t1k_assign_range(t1k_ctx *ctx, uint64_t first, uint32_t count) {
   if ((rc = t1k_ensure(ctx, ctx->bSortScratch, (size_t)nWg * sortCap * 48))) return rc;
   T1K_HIP(ctx, hipMemsetAsync(ctx->bCounters.p, 0, 64 * 8, ctx->stream));
   T1K_HIP(ctx, hipMemsetAsync(ctx->bOvlCount.p, 0, (size_t)n * 4 + 4, ctx->stream));
+  T1K_HIP(ctx, hipMemsetAsync(ctx->bCandCount.p, 0, (size_t)n * 4 + 4, ctx->stream));
+  T1K_HIP(ctx, hipMemsetAsync(ctx->bWgCache.p, 0, (size_t)n * memoN * 8, ctx->stream));
   ctx->nCand = ctx->nOvl = 0;
   memset(&ctx->stats, 0, sizeof(ctx->stats));
   if (n == 0) return T1K_OK;
   unsigned long long hc[64];
   double t0 = nowMs();
-  AssignArgs a{};
+  ChainArgs a{};
   a.ref = ctx->ref; a.reads = rd;
   a.k = ctx->prm.kmer_length; a.radius = ctx->prm.radius; a.hitLenRequired = ctx->prm.hit_len_required;
-  a.sim = ctx->prm.ref_seq_similarity; a.relax = ctx->prm.relax_intron_align;
-  a.wgHits = (uint32_t *)ctx->bWgHits.p; a.hitCap = (uint64_t)ctx->prm.hit_cap_per_wg;
-  a.wgGroups = (uint32_t *)ctx->bWgGroups.p;
-  a.wgStage = (T1kCand *)ctx->bWgStage.p; a.stageCap = stageCap;
-  a.wgThread = (uint32_t *)ctx->bWgThreadScratch.p;
-  a.wgBig = (uint32_t *)ctx->bWgBig.p;
-  a.wgCache = (unsigned long long *)ctx->bWgCache.p;
+  a.sim = ctx->prm.ref_seq_similarity;
+  const int relaxFlag = ctx->prm.relax_intron_align;
+  a.hits = (uint32_t *)ctx->bWgHits.p; a.hitCap = hitCap;
+  a.groups = (T1kGroup *)ctx->bWgGroups.p; a.groupCap = groupCap;
+  a.chunkStart = (uint32_t *)ctx->bWgStage.p; a.chunkCount = a.chunkStart + (size_t)n * maxChunks;
+  a.memo = (unsigned long long *)ctx->bWgCache.p;
+  a.jobList = (uint32_t *)ctx->bLists.p; a.jobCap = jobCap;
+  a.retryList = a.jobList + jobCap; a.generalList = a.retryList + groupCap; a.bigList = a.generalList + groupCap;
+  a.threadScratch = (uint32_t *)ctx->bWgThreadScratch.p; a.bigScratch = (uint32_t *)ctx->bWgBig.p;
   a.cand = (T1kCand *)ctx->bCand.p; a.candCap = (uint64_t)ctx->prm.cand_cap;
   a.candStart = (uint32_t *)ctx->bCandStart.p; a.candCount = (uint32_t *)ctx->bCandCount.p;
   a.counters = (unsigned long long *)ctx->bCounters.p;
-  T1K_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
-  t1k_launch_seed_chain(ctx, a, nWg);
-  T1K_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
-  if ((rc = fetchCounters(ctx, hc))) return rc;
+  if ((rc = t1k_run_chain(ctx, a, nWg, generalBlocks, bigBlocks, hc))) return rc;
   double t1 = nowMs();
   if (hc[2]) return capacityError(ctx, hc[2]);
   ctx->nCand = hc[0];
@@ -391,7 +400,7 @@ int t1k_assign_range(t1k_ctx *ctx, uint64_t first, uint32_t count) {
   if ((rc = t1k_ensure(ctx, ctx->bSlowQueue, (size_t)(ctx->nOvl + 1) * 4))) return rc;
   if ((rc = t1k_ensure(ctx, ctx->bSlowScratch, (size_t)slowBlocks * 64 * t1k_slow_per_thread(maxCells)))) return rc;
   FullArgs f{};
-  f.ref = ctx->ref; f.reads = rd; f.relax = a.relax; f.ovl = s.ovl; f.nOvl = ctx->nOvl;
+  f.ref = ctx->ref; f.reads = rd; f.relax = relaxFlag; f.ovl = s.ovl; f.nOvl = ctx->nOvl;
   f.slowQueue = (uint32_t *)ctx->bSlowQueue.p; f.slowCap = (uint32_t)std::min<uint64_t>(ctx->nOvl + 1, 0xFFFFFFFFull); f.counters = a.counters;
   t1k_launch_fullalign(ctx, f);
   T1K_HIP(ctx, hipEventRecord(ctx->ev[7], ctx->stream));
@@ -402,13 +411,13 @@ int t1k_assign_range(t1k_ctx *ctx, uint64_t first, uint32_t count) {
     const size_t traceBytes = (size_t)eqBlocks * 256 * (size_t)(ctx->batchMaxLen + 2) * 8;
     if ((rc = t1k_ensure(ctx, ctx->bEqTrace, traceBytes))) return rc;
     SlowArgs sl{};
-    sl.ref = ctx->ref; sl.reads = rd; sl.relax = a.relax; sl.ovl = s.ovl; sl.slowQueue = f.slowQueue; sl.nSlow = (uint32_t)hc[8];
+    sl.ref = ctx->ref; sl.reads = rd; sl.relax = relaxFlag; sl.ovl = s.ovl; sl.slowQueue = f.slowQueue; sl.nSlow = (uint32_t)hc[8];
     sl.scratch = (uint8_t *)ctx->bEqTrace.p; sl.perThread = 0; sl.maxCells = 0; sl.counters = a.counters;
     t1k_launch_fullalign_eq(ctx, sl, eqBlocks);
   }
   if (hc[15]) {  // unequal spans (indel chains): general DP with row arrays in HBM
     SlowArgs sl{};
-    sl.ref = ctx->ref; sl.reads = rd; sl.relax = a.relax; sl.ovl = s.ovl; sl.slowQueue = f.slowQueue + (f.slowCap - hc[15]); sl.nSlow = (uint32_t)hc[15];
+    sl.ref = ctx->ref; sl.reads = rd; sl.relax = relaxFlag; sl.ovl = s.ovl; sl.slowQueue = f.slowQueue + (f.slowCap - hc[15]); sl.nSlow = (uint32_t)hc[15];
     sl.scratch = (uint8_t *)ctx->bSlowScratch.p; sl.perThread = t1k_slow_per_thread(maxCells); sl.maxCells = maxCells; sl.counters = a.counters;
     t1k_launch_fullalign_slow(ctx, sl, slowBlocks);
   }
@@ -426,11 +435,8 @@ int t1k_assign_range(t1k_ctx *ctx, uint64_t first, uint32_t count) {
   if (getenv("T1K_DEBUG_PHASES")) {
     float a1 = 0, a2 = 0, a3 = 0;
     (void)hipEventElapsedTime(&a1, ctx->ev[3], ctx->ev[7]); (void)hipEventElapsedTime(&a2, ctx->ev[7], evSlow); (void)hipEventElapsedTime(&a3, evSlow, ctx->ev[4]);
-    fprintf(stderr, "[t1k] fullalign %.2f ms, slow (%llu jobs) %.2f ms, truncate %.2f ms; cand %llu ovl %llu dp %llu; groups fast %llu general %llu deferred %llu\n", a1, hc[8], a2, a3, hc[0], hc[1], hc[7], hc[11], hc[12], hc[13]);
-    fprintf(stderr, "[t1k] chain sub-phases (ticks): fast loop %llu, dense DP %llu, retry %llu, general(in chain=%llu)\n", hc[41], hc[42], hc[43], hc[21]);
-    fprintf(stderr, "[t1k] fast-path sections clocks/16: load+vote+M %llu dilate %llu mm %llu gaps %llu\n", hc[28], hc[29], hc[30], hc[31]);
-    fprintf(stderr, "[t1k] per-thread chain-loop clocks/64 = %llu, of which inside DP = %llu (DP rows %llu)\n", hc[25], hc[26], hc[27]);
-    fprintf(stderr, "[t1k] seed_chain phases (wall_clock64 ticks summed over workgroups): kmer %llu rule %llu count %llu scan %llu scatter %llu chain %llu deferred %llu compact %llu copy %llu | ev ms chain %.2f\n", hc[16], hc[17], hc[18], hc[19], hc[20], hc[21], hc[22], hc[23], hc[24], 0.0);
+    fprintf(stderr, "[t1k] fullalign %.2f ms, eq-DP (%llu jobs) + general-DP (%llu jobs) %.2f ms, truncate %.2f ms; cand %llu ovl %llu dp %llu; groups fast %llu general %llu big %llu\n",
+            a1, hc[8], hc[15], a2, a3, hc[0], hc[1], hc[7], hc[11], hc[12], hc[13]);
   }
   t1k_stats &st = ctx->stats;
   st.read_ends = n; st.lookups = hc[3]; st.postings = hc[4]; st.hits = hc[5]; st.groups = hc[6]; st.candidates = hc[0]; st.extended = hc[1];

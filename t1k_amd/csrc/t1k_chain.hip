@@ -1,0 +1,875 @@
+// t1k_amd/csrc/t1k_chain.hip -- seeding, hit grouping and chaining of SeqSet::AssignRead on gfx950, as a sequence of flat,
+// batch-wide kernels (all integer, HBM/LDS-bound; no MFMA):
+//
+//   k_seed_scatter  one 256-thread workgroup per read-end: rolling 11-mers + direct-address look-up with the >=100 skip
+//                   rule (GetHitsFromRead, SeqSet.hpp:1071-1229); per (strand, allele tile) an LDS histogram -> counting
+//                   sort of the hits by (strand, allele) (SortHits 1558-1590) into the batch hit arena; groups with fewer
+//                   than 3 hits are never written (refMinHitRequired, 1253/1314)
+//   k_chain_fast    one lane per (read-end, strand, allele) group over the whole batch: single-diagonal fast path
+//                   (GetOverlapsFromHits 1232-1556 + seed-chain match count 1697-1848); alignments that need a DP are
+//                   registered in the read-end's memo table and the group is parked
+//   k_dp_dense      one lane per distinct registered alignment (banded forward sweep, band in registers)
+//   k_chain_retry   parked groups finish from the memo
+//   k_chain_general groups with hits on several nearby diagonals: the reference's diagonal-run / LIS logic verbatim
+//   k_collect       one workgroup per read-end: strand vote (1619-1648) and copy-out of the winning strand's candidates
+#include <algorithm>
+#include "t1k_dev.h"
+#include "t1k_launch.h"
+
+#define WG 256
+#define TILE_ALLELES 8192           // LDS histogram tile (u32 per allele): 32 KB -> 4 workgroups per CU
+#define GROUP_FAST_MAXLEN 320
+#define THREAD_CAP 192              // hits per group handled by the general kernel's per-lane scratch; larger groups: k_chain_big
+#define BIG_CAP 16384
+#define GA_BIG_MAX 2048
+#define GA_SCRATCH_INTS (6 * (GA_BIG_MAX + 4))
+#define GA_T_MAX 256
+#define GA_THREAD_INTS (6 * (GA_T_MAX + 4))
+#define THREAD_SCRATCH_U32 (3 * THREAD_CAP + GA_THREAD_INTS)
+#define MAX_CHUNKS 16               // (2 strands) x (allele tiles) per read-end
+
+enum { ERR_HITCAP = 1, ERR_STAGECAP = 2, ERR_CANDCAP = 4, ERR_BIGGROUP = 8, ERR_OVLCAP = 16, ERR_SORTCAP = 32, ERR_SLOWCAP = 64, ERR_ROWCAP = 128, ERR_GROUPCAP = 256 };
+
+// ------------------------------------------------------------------------------------------------------------------
+// group -> candidate overlaps
+// ------------------------------------------------------------------------------------------------------------------
+struct ReadCtx {
+  const uint64_t *rb, *rn;   // strand-specific read words
+  int len;
+  const uint64_t *gb, *gn;   // reference words
+  int64_t goff;              // allele global base offset
+  int alleleLen;
+};
+
+struct CandOut {  // packed into the group's own hit segment: 3 u32 per candidate
+  uint32_t *dst;
+  int n;
+  __device__ void push(int rs, int re, int ss, int se, int m0, int m) {
+    dst[3 * n + 0] = (uint32_t)rs | ((uint32_t)re << 12);
+    dst[3 * n + 1] = (uint32_t)ss | ((uint32_t)m0 << 20);
+    dst[3 * n + 2] = (uint32_t)se | ((uint32_t)m << 20);
+    ++n;
+  }
+};
+
+// seed-chain match count of one gap (SeqSet.hpp:1710-1752 / 1794-1824)
+__device__ inline int gapMatches(const ReadCtx &c, int ra, int ga, int lp, int lt, int *gaScratch, int gaMax, unsigned int *dpCounter, unsigned long long *errFlags) {
+  if (lp == lt) return t1k_ga_matches_window(c.rb, c.rn, ra, c.gb, c.gn, c.goff + ga, lp, dpCounter);
+  if (lt == 0 || lp == 0) return 0;
+  if (dpCounter) ++*dpCounter;
+  T1kSeqView T{c.gb, c.gn, c.goff + ga}, P{c.rb, c.rn, ra};
+  int nm = 0;
+  if (lt > gaMax) { atomicOr(errFlags, (unsigned long long)ERR_BIGGROUP); return 0; }
+  t1k_ga_general(T, lt, P, lp, gaScratch, nullptr, &nm);
+  return nm;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Exact memo of gap alignments within one read-end.  Thousands of alleles of a gene carry the same bases under a given
+// read window, so the same banded DP would be recomputed for each of them.  One 64-bit entry identifies a job completely:
+//   [gpos:34 | matches:9 | readPos:11 | len:9 | strand:1]
+// A probe whose (strand, readPos, len) agree verifies that the allele window at the entry's gpos holds exactly the same
+// bases and N-mask as its own window before it reuses the stored match count, so a hit is bit-exact by construction.
+// The table lives in per-workgroup HBM scratch (L2-resident, 32 KB) and is cleared per read-end.
+// ------------------------------------------------------------------------------------------------------------------
+#define GAP_CACHE 1024
+__device__ inline bool sameWindow(const uint64_t *gb, const uint64_t *gn, int64_t a, int64_t b, int L) {
+  for (int o = 0; o < L; o += 32) {
+    uint64_t lm = t1k_lowmask(L - o);
+    if (((t1k_get32(gb, a + o) ^ t1k_get32(gb, b + o)) & lm) | ((t1k_get32(gn, a + o) ^ t1k_get32(gn, b + o)) & lm)) return false;
+  }
+  return true;
+}
+
+#define GAP_PENDING 0x1FFull
+// DEFER = true : never run a DP here.  A miss claims a memo slot (CAS) with the PENDING marker and appends the slot to the
+//                workgroup's job list; the caller parks its group (return -1) until the dense DP phase has filled the memo.
+// DEFER = false: a miss is computed inline (used after the dense phase; only slot-collision leftovers get here).
+template <bool DEFER>
+__device__ inline int gapMatchesCached(const ReadCtx &c, int readPos, int64_t gpos, int L, int strandBit, unsigned long long *cache, unsigned int *dpCounter,
+                                       uint32_t *jobList, uint32_t *jobCount, uint32_t jobTag, uint32_t jobCap) {
+  if (L <= 0) return 0;
+  // mismatch count and a content hash of the allele window in one sweep
+  int x = 0;
+  uint64_t hsh = 0x9E3779B97F4A7C15ull ^ ((uint64_t)readPos << 20) ^ ((uint64_t)L << 1) ^ (uint64_t)strandBit;
+  for (int o = 0; o < L; o += 32) {
+    uint64_t lm = t1k_lowmask(L - o);
+    uint64_t gw = t1k_get32(c.gb, gpos + o) & lm, gnw = t1k_get32(c.gn, gpos + o) & lm;
+    uint64_t xo = t1k_get32(c.rb, readPos + o) ^ gw;
+    uint64_t mm = (xo | (xo >> 1)) & T1K_EVEN & ~(t1k_get32(c.rn, readPos + o) | gnw) & lm;
+    x += __popcll(mm);
+    hsh = (hsh ^ gw ^ (gnw << 1)) * 0xD6E8FEB86659FD93ull;
+    hsh ^= hsh >> 32;
+  }
+  if (x <= 3) return L - x;  // exact fast path (see t1k_ga_matches_window)
+  if (L > 510 || readPos > 2047) {
+    if (DEFER) return -2;  // not memoisable: the retry phase computes it inline
+    return t1k_ga_matches_window(c.rb, c.rn, readPos, c.gb, c.gn, gpos, L, dpCounter);
+  }
+  const uint64_t idBits = ((uint64_t)readPos << 10) | ((uint64_t)L << 1) | (uint64_t)strandBit;  // low 21 bits of an entry
+  const uint32_t slot = (uint32_t)hsh & (GAP_CACHE - 1);
+  bool pendingSeen = false;
+#pragma unroll
+  for (int probe = 0; probe < 2; ++probe) {
+    unsigned long long e = __hip_atomic_load(&cache[slot ^ probe], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (e != 0 && (e & 0x1FFFFFull) == idBits) {
+      int64_t eg = (int64_t)(e >> 30);
+      if (eg == gpos || sameWindow(c.gb, c.gn, eg, gpos, L)) {
+        unsigned long long v = (e >> 21) & 0x1FF;
+        if (v != GAP_PENDING) return (int)v;
+        pendingSeen = true;
+      }
+    }
+  }
+  if (DEFER) {
+    if (pendingSeen) return -1;
+    const unsigned long long pe = ((unsigned long long)gpos << 30) | (GAP_PENDING << 21) | idBits;
+#pragma unroll
+    for (int probe = 0; probe < 2; ++probe) {
+      unsigned long long old = atomicCAS(&cache[slot ^ probe], 0ull, pe);
+      if (old == 0ull) {
+        uint32_t q = atomicAdd(jobCount, 1u);
+        if (q >= jobCap) {  // job list full: release the claim, the retry pass computes this gap inline
+          __hip_atomic_store(&cache[slot ^ probe], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          return -2;
+        }
+        jobList[q] = jobTag + (slot ^ probe);
+        return -1;
+      }
+      if ((old & 0x1FFFFFull) == idBits && ((int64_t)(old >> 30) == gpos || sameWindow(c.gb, c.gn, (int64_t)(old >> 30), gpos, L))) return -1;  // somebody else just claimed it
+    }
+    return -2;  // both slots taken by other jobs: inline in the retry phase
+  }
+  if (dpCounter) ++*dpCounter;
+  T1kSeqView T{c.gb, c.gn, gpos}, P{c.rb, c.rn, (int64_t)readPos};
+  int m = t1k_ga_matches_equal(T, P, L, nullptr);
+  if (!pendingSeen) {
+    unsigned long long ne = ((unsigned long long)gpos << 30) | ((unsigned long long)m << 21) | idBits;
+    unsigned long long cur = __hip_atomic_load(&cache[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (cur == 0) __hip_atomic_store(&cache[slot], ne, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  return m;
+}
+
+// Single-diagonal group (the common case: the read differs from the allele by substitutions only).
+// NW = number of 32-position words covering a read (5: reads <= 160 bp, 10: reads <= 320 bp).
+//   * the group's hits are fetched in one burst of independent loads (<= 32 hits; larger groups loop)
+//   * majority diagonal by Boyer-Moore vote; every other hit must lie more than `radius` diagonals away (it cannot join the
+//     main run, SeqSet.hpp:1360-1392) and there may be at most two such strays (they cannot form a run of >= 3 hits,
+//     1400-1405); anything else goes to the general path
+//   * on one diagonal the LIS is the identity and both hit lengths are equal; with M = bitmask of hit read-offsets,
+//     covered = popcount(dilate(M, k)) and matchCnt = 2*covered + 2*sum over gaps of GlobalAlignment matches (1697-1760)
+//   * a gap with x <= 3 mismatches aligns ungapped (g - x matches, exact, see t1k_ga_matches_window); if the whole span
+//     has <= 3 mismatches every gap does and matchCnt = 2*(span - mismatches) in closed form
+//   * exact prune: a gap with x > 3 yields at most g - 1 matches, so U = 2*(span - sum_{x<=3} x - #{x>3}) bounds matchCnt;
+//     if U / (2*span) < -s the candidate is certain to fail the similarity filter (1838-1840, 1894-1908) and is emitted
+//     with matchCnt = U (it is dropped by k_extend either way, and the strand vote only reads matchCnt0)
+template <int NW, bool DEFER>
+__device__ inline int groupFastPath(const uint32_t *h, int n, const ReadCtx &c, int k, int radius, int hitLenRequired, double simThreshold, CandOut &out,
+                                    unsigned int *dpCounter, int strandBit, unsigned long long *cache, uint32_t *jobList, uint32_t *jobCount, uint32_t jobTag,
+                                    uint32_t jobCap) {
+  constexpr int MW = (NW + 1) / 2;  // 64-bit words of the read-offset bitmask
+  uint64_t M[MW];
+#pragma unroll
+  for (int i = 0; i < MW; ++i) M[i] = 0;
+  int diag = 0, votes = 0, strays = 0, onDiag = 0;
+  if (n <= 32) {
+    uint32_t hr[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) hr[i] = i < n ? h[i] : 0u;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      if (i < n) {
+        int d = (int)(hr[i] & 0xFFF) - (int)(hr[i] >> 12);
+        if (votes == 0) { diag = d; votes = 1; }
+        else if (d == diag) ++votes;
+        else --votes;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      if (i < n) {
+        int a = (int)(hr[i] & 0xFFF);
+        int d = a - (int)(hr[i] >> 12) - diag;
+        if (d != 0) {
+          if (d < 0) d = -d;
+          if (d <= radius) return 0;
+          ++strays;
+        } else {
+          if (a >= NW * 32) return 0;
+          ++onDiag;
+#pragma unroll
+          for (int w = 0; w < MW; ++w)
+            if ((a >> 6) == w) M[w] |= 1ull << (a & 63);
+        }
+      }
+    }
+  } else {
+    for (int i = 0; i < n; ++i) {
+      uint32_t x = h[i];
+      int d = (int)(x & 0xFFF) - (int)(x >> 12);
+      if (votes == 0) { diag = d; votes = 1; }
+      else if (d == diag) ++votes;
+      else --votes;
+    }
+    for (int i = 0; i < n; ++i) {
+      uint32_t x = h[i];
+      int a = (int)(x & 0xFFF);
+      int d = a - (int)(x >> 12) - diag;
+      if (d != 0) {
+        if (d < 0) d = -d;
+        if (d <= radius) return 0;
+        ++strays;
+      } else {
+        if (a >= NW * 32) return 0;
+        ++onDiag;
+#pragma unroll
+        for (int w = 0; w < MW; ++w)
+          if ((a >> 6) == w) M[w] |= 1ull << (a & 63);
+      }
+    }
+  }
+  if (strays > 2) return 0;
+  if (onDiag < 3) return 1;  // minHitRequired (1314, 1400)
+  if (onDiag * k < hitLenRequired) return 1;
+  int first = -1, last = -1;
+#pragma unroll
+  for (int w = 0; w < MW; ++w) {
+    if (M[w]) {
+      if (first < 0) first = w * 64 + __ffsll((long long)M[w]) - 1;
+      last = w * 64 + 63 - __clzll((long long)M[w]);
+    }
+  }
+  // covered positions: dilate M by k (bit p set iff some hit offset a has a <= p < a + k)
+  uint64_t C[MW];
+#pragma unroll
+  for (int w = 0; w < MW; ++w) C[w] = M[w];
+  for (int sft = 1; sft < k; ++sft) {
+#pragma unroll
+    for (int w = MW - 1; w >= 0; --w) {
+      uint64_t carry = w > 0 ? (M[w - 1] >> (64 - sft)) : 0ull;
+      C[w] |= (M[w] << sft) | carry;
+    }
+  }
+  int cov = 0;
+#pragma unroll
+  for (int w = 0; w < MW; ++w) cov += __popcll(C[w]);
+  // (the dilation may spill past NW*32 only for offsets that cannot occur: a + k <= len <= NW*32)
+  if (cov < hitLenRequired) return 1;  // GetTotalHitLengthOnRead/OnSeq (1512-1522)
+  const int spanEnd = last + k, span = spanEnd - first;
+  // mismatch bits of the span on this diagonal, one burst of independent loads
+  uint64_t mmw[NW];
+  int mmT = 0;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) {
+    mmw[w] = 0;
+    const int p0 = w * 32;
+    if (p0 < spanEnd && p0 + 32 > first) {
+      const int lo = p0 < first ? first : p0;  // never read the allele before its first base
+      uint64_t xo = t1k_get32(c.rb, lo) ^ t1k_get32(c.gb, c.goff + lo - diag);
+      uint64_t mm = (xo | (xo >> 1)) & T1K_EVEN & ~(t1k_get32(c.rn, lo) | t1k_get32(c.gn, c.goff + lo - diag));
+      mm <<= 2 * (lo - p0);
+      const int hiN = spanEnd - p0;
+      if (hiN < 32) mm &= t1k_lowmask(hiN);
+      mmw[w] = mm;
+      mmT += __popcll(mm);
+    }
+  }
+  int matchCnt;
+  if (mmT <= 3) matchCnt = 2 * (span - mmT);
+  else {
+    // walk the gaps (maximal uncovered runs inside the span)
+    int sumSmall = 0, nBig = 0;
+    // pass 1: per-gap mismatch counts -> upper bound
+    int pos = first;
+    // gap iteration helper: next uncovered position >= pos is the lowest clear bit of C at or above pos
+    auto nextClear = [&](int from) -> int {
+#pragma unroll
+      for (int w = 0; w < MW; ++w) {
+        if (from < (w + 1) * 64) {
+          uint64_t inv = ~C[w];
+          if (from > w * 64) inv &= ~0ull << (from - w * 64);
+          if (inv) return w * 64 + __ffsll((long long)inv) - 1;
+        }
+      }
+      return MW * 64;
+    };
+    auto nextSet = [&](int from) -> int {
+#pragma unroll
+      for (int w = 0; w < MW; ++w) {
+        if (from < (w + 1) * 64) {
+          uint64_t v = C[w];
+          if (from > w * 64) v &= ~0ull << (from - w * 64);
+          if (v) return w * 64 + __ffsll((long long)v) - 1;
+        }
+      }
+      return MW * 64;
+    };
+    auto mmIn = [&](int gs, int ge) -> int {  // mismatches in [gs, ge)
+      int x = 0;
+#pragma unroll
+      for (int q = 0; q < NW; ++q) {
+        const int p0 = q * 32;
+        if (p0 < ge && p0 + 32 > gs) {
+          uint64_t msk = ~0ull;
+          if (gs > p0) msk &= ~t1k_lowmask(gs - p0);
+          if (ge < p0 + 32) msk &= t1k_lowmask(ge - p0);
+          x += __popcll(mmw[q] & msk);
+        }
+      }
+      return x;
+    };
+    while (true) {
+      int gs = nextClear(pos);
+      if (gs >= spanEnd) break;
+      int ge = nextSet(gs);
+      if (ge > spanEnd) ge = spanEnd;
+      int x = mmIn(gs, ge);
+      if (x <= 3) sumSmall += x; else ++nBig;
+      pos = ge;
+    }
+    const int upper = 2 * (span - sumSmall - nBig);
+    if (nBig == 0) matchCnt = upper;  // exact
+    else if ((double)upper / (double)(2 * span) < simThreshold) matchCnt = upper;  // certain to be dropped; no DP needed
+    else {
+      int gapMatch = 0;
+      bool parked = false;
+      pos = first;
+      while (true) {
+        int gs = nextClear(pos);
+        if (gs >= spanEnd) break;
+        int ge = nextSet(gs);
+        if (ge > spanEnd) ge = spanEnd;
+        int x = mmIn(gs, ge);
+        if (x <= 3) gapMatch += (ge - gs) - x;
+        else {
+          int r = gapMatchesCached<DEFER>(c, gs, c.goff + (gs - diag), ge - gs, strandBit, cache, dpCounter, jobList, jobCount, jobTag, jobCap);
+          if (r < 0) parked = true; else gapMatch += r;  // keep walking: later gaps register their jobs too
+        }
+        pos = ge;
+      }
+      if (parked) return 2;
+      matchCnt = 2 * cov + 2 * gapMatch;
+    }
+  }
+  out.push(first, last + k - 1, first - diag, last - diag + k - 1, 2 * cov, matchCnt);
+  return 1;
+}
+
+__device__ __forceinline__ bool hitKeyLess(uint32_t x, uint32_t y) {  // (diag, alleleOff, readOff): CompSortHitCoordDiff (266-274)
+  int cx = (int)(x & 0xFFF) - (int)(x >> 12), cy = (int)(y & 0xFFF) - (int)(y >> 12);
+  if (cx != cy) return cx < cy;
+  return x < y;
+}
+
+// General group (several diagonals): restates GetOverlapsFromHits 1338-1551 and the chain walk 1697-1833.
+// A[n] sorted copy of the hits, B[n] concordant hits, C[n] packs top (low 16) / link (high 16) of the LIS.
+__device__ inline void groupGeneral(const uint32_t *h, int n, const ReadCtx &c, int k, int radius, int hitLenRequired, uint32_t *A, uint32_t *B,
+                                     uint32_t *C, int *gaScratch, int gaMax, CandOut &out, unsigned int *dpCounter, unsigned long long *errFlags) {
+  // insertion sort into A
+  for (int i = 0; i < n; ++i) {
+    uint32_t x = h[i];
+    int j = i - 1;
+    while (j >= 0 && hitKeyLess(x, A[j])) { A[j + 1] = A[j]; --j; }
+    A[j + 1] = x;
+  }
+  for (int s = 0; s < n;) {
+    auto diagOf = [](uint32_t x) { return (int)(x & 0xFFF) - (int)(x >> 12); };
+    int curDiff = diagOf(A[s]), curCnt = 1, domCnt = 0, dominant = 0;
+    int e = s + 1;
+    for (; e < n; ++e) {
+      int d = diagOf(A[e]) - diagOf(A[e - 1]);
+      if (d < 0) d = -d;
+      if (d > radius) break;
+      if (d == 0) ++curCnt;
+      else {
+        if (curCnt > domCnt) { dominant = curDiff; domCnt = curCnt; }
+        curDiff = diagOf(A[e]); curCnt = 1;
+      }
+    }
+    if (curCnt > domCnt) dominant = curDiff;
+    if (e - s < 3 || (e - s) * k < hitLenRequired) { s = e; continue; }
+    // nearest-to-dominant filter per read offset (1437-1456)
+    int m = 0;
+    for (int q = s; q < e; ++q) {
+      int a = (int)(A[q] & 0xFFF);
+      int dq = diagOf(A[q]) - dominant; if (dq < 0) dq = -dq;
+      bool keep = true;
+      for (int r = s; r < e; ++r) {
+        if ((int)(A[r] & 0xFFF) != a) continue;
+        int dr = diagOf(A[r]) - dominant; if (dr < 0) dr = -dr;
+        if (dr < dq) { keep = false; break; }
+      }
+      if (keep) {  // insertion by (alleleOff, readOff) == packed value order (CompSortPairBInc)
+        uint32_t x = A[q];
+        int j = m - 1;
+        while (j >= 0 && x < B[j]) { B[j + 1] = B[j]; --j; }
+        B[j + 1] = x;
+        ++m;
+      }
+    }
+    // LIS over read offsets (352-436); C[i] = top | link << 16, link 0xFFFF = none
+    int ret = 1;
+    C[0] = 0 | (0xFFFFu << 16);
+    auto topOf = [&](int i) { return (int)(C[i] & 0xFFFF); };
+    auto setTop = [&](int i, int v) { C[i] = (C[i] & 0xFFFF0000u) | (uint32_t)v; };
+    auto setLink = [&](int i, int v) { C[i] = (C[i] & 0xFFFFu) | ((uint32_t)(v & 0xFFFF) << 16); };
+    auto linkOf = [&](int i) { return (int)(C[i] >> 16); };
+    auto aOf = [&](int i) { return (int)(B[i] & 0xFFF); };
+    for (int i = 1; i < m; ++i) C[i] = 0xFFFFu << 16;
+    for (int i = 1; i < m; ++i) {
+      int tag;
+      if (aOf(topOf(ret - 1)) <= aOf(i)) tag = ret - 1;
+      else {
+        int l = 0, r = ret - 1;
+        tag = -2;
+        while (l <= r) {
+          int mid = (l + r) / 2;
+          if (aOf(i) == aOf(topOf(mid))) { tag = mid; break; }
+          if (aOf(i) < aOf(topOf(mid))) r = mid - 1; else l = mid + 1;
+        }
+        if (tag == -2) tag = l - 1;
+      }
+      if (tag == -1) { setTop(0, i); setLink(i, 0xFFFF); }
+      else if (aOf(i) > aOf(topOf(tag))) {
+        if (tag == ret - 1) { setTop(ret, i); ++ret; setLink(i, topOf(tag)); }
+        else if (aOf(i) < aOf(topOf(tag + 1))) { setTop(tag + 1, i); setLink(i, topOf(tag)); }
+      }
+    }
+    // retrieve the chain into A[s .. s+ret) (the run's slice of A is dead now), then drop repeated allele offsets
+    {
+      int kx = topOf(ret - 1);
+      for (int i = ret - 1; i >= 0; --i) { A[s + i] = B[kx]; kx = linkOf(kx); }
+      int w = 1;
+      for (int i = 1; i < ret; ++i) {
+        if ((A[s + i] >> 12) == (A[s + w - 1] >> 12)) continue;
+        A[s + w] = A[s + i];
+        ++w;
+      }
+      ret = w;
+    }
+    if (ret * k < hitLenRequired) { s = e; continue; }
+    // hit lengths on read and on allele (1032-1069)
+    int lenR = 0, lenS = 0;
+    for (int i = 0; i < ret;) {
+      int j = i + 1;
+      for (; j < ret; ++j) if ((int)(A[s + j] & 0xFFF) > (int)(A[s + j - 1] & 0xFFF) + k - 1) break;
+      lenR += (int)(A[s + j - 1] & 0xFFF) - (int)(A[s + i] & 0xFFF) + k;
+      i = j;
+    }
+    for (int i = 0; i < ret;) {
+      int j = i + 1;
+      for (; j < ret; ++j) if ((int)(A[s + j] >> 12) > (int)(A[s + j - 1] >> 12) + k - 1) break;
+      lenS += (int)(A[s + j - 1] >> 12) - (int)(A[s + i] >> 12) + k;
+      i = j;
+    }
+    if (lenR < hitLenRequired || lenS < hitLenRequired) { s = e; continue; }
+    // seed-chain match count (1697-1833)
+    int matchCnt = 2 * k;
+    for (int i = 1; i < ret; ++i) {
+      int pa = (int)(A[s + i - 1] & 0xFFF), pb = (int)(A[s + i - 1] >> 12), qa = (int)(A[s + i] & 0xFFF), qb = (int)(A[s + i] >> 12);
+      bool sameDiag = (pb - pa) == (qb - qa);
+      bool readOv = pa + k - 1 >= qa, seqOv = pb + k - 1 >= qb;
+      if (sameDiag) {
+        if (readOv) matchCnt += 2 * (qa - pa);
+        else matchCnt += 2 * k + 2 * gapMatches(c, pa + k, pb + k, qa - (pa + k), qb - (pb + k), gaScratch, gaMax, dpCounter, errFlags);
+      } else {
+        if (readOv && !seqOv) matchCnt += 2 * (qa - pa);
+        else if (!readOv && seqOv) matchCnt += 2 * (qb - pb);
+        else if (readOv && seqOv) matchCnt += 2 * ((qa - pa) < (qb - pb) ? (qa - pa) : (qb - pb));
+        else matchCnt += 2 * k + 2 * gapMatches(c, pa + k, pb + k, qa - (pa + k), qb - (pb + k), gaScratch, gaMax, dpCounter, errFlags);
+      }
+    }
+    int rs = (int)(A[s] & 0xFFF), ss = (int)(A[s] >> 12);
+    int re = (int)(A[s + ret - 1] & 0xFFF) + k - 1, se = (int)(A[s + ret - 1] >> 12) + k - 1;
+    out.push(rs, re, ss, se, 2 * lenR, matchCnt);
+    s = e;
+  }
+}
+
+// key of the strand vote: _overlap::operator< with similarity == 0 (SeqSet.hpp:103-127, 1623-1627); smaller = better
+struct VoteKey {
+  uint64_t hi, lo;
+  __device__ bool operator<(const VoteKey &o) const { return hi != o.hi ? hi < o.hi : lo < o.lo; }
+};
+__device__ __forceinline__ VoteKey voteKey(int matchCnt0, int rs, int re, uint32_t allele, int strandPlus, int ss, int se) {
+  VoteKey k;
+  k.hi = ((uint64_t)(4095 - matchCnt0) << 40) | ((uint64_t)(4095 - (re - rs)) << 26) | ((uint64_t)allele << 1) | (uint64_t)strandPlus;
+  k.lo = ((uint64_t)rs << 52) | ((uint64_t)re << 40) | ((uint64_t)ss << 20) | (uint64_t)se;
+  return k;
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------
+// K1: seeds -> hits grouped by (strand, allele)
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WG) void k_seed_scatter(ChainArgs P) {
+  extern __shared__ uint32_t lds[];
+  const int k = P.k;
+  const int maxK = 2 * (P.reads.S * 32);
+  uint32_t *hist = lds;                             // [TILE_ALLELES]
+  uint32_t *ukCode = hist + TILE_ALLELES;           // [maxK]  code | valid << 31
+  uint32_t *ukStart = ukCode + maxK;                // [maxK]
+  uint32_t *ukLen = ukStart + maxK;                 // [maxK]
+  uint32_t *tLo = ukLen + maxK;                     // [maxK]  posting sub-range of the current allele tile
+  uint32_t *tHi = tLo + maxK;                       // [maxK]
+  uint16_t *usedQ = (uint16_t *)(tHi + maxK);       // [maxK]
+  __shared__ uint32_t warpSums[4];
+  __shared__ uint32_t sUsed[2], sHitBase, sGroupBase;
+  const int tid = threadIdx.x;
+  const uint32_t kmask = (1u << (2 * k)) - 1;
+  const int nTiles = (int)((P.ref.nAlleles + TILE_ALLELES - 1) / TILE_ALLELES);
+  for (uint32_t re = blockIdx.x; re < P.reads.nReadEnds; re += gridDim.x) {
+    const int len = P.reads.len[re];
+    const int S = P.reads.S;
+    const uint64_t *rbase = P.reads.bases + (uint64_t)re * 2 * S;
+    const uint64_t *rnm = P.reads.nmask + (uint64_t)re * 2 * S;
+    for (int c = tid; c < MAX_CHUNKS; c += WG) P.chunkCount[(uint64_t)re * MAX_CHUNKS + c] = 0;
+    if (len < k) { __syncthreads(); continue; }  // GetOverlapsFromRead returns -1 (SeqSet.hpp:1598-1599)
+    const int nk = len - k + 1;
+    // ---- k-mer codes and posting-list bounds for both strands ----------------------------------------------------
+    for (int q = tid; q < 2 * nk; q += WG) {
+      int pass = q / nk, p = q - pass * nk;
+      const uint64_t *b = rbase + pass * S, *nm = rnm + pass * S;
+      uint32_t code = (uint32_t)t1k_get32(b, p) & kmask;
+      bool valid = ((uint32_t)t1k_get32(nm, p) & kmask) == 0;
+      uint32_t st = 0, ln = 0;
+      if (valid) { st = P.ref.kStart[code]; ln = P.ref.kStart[code + 1] - st; }
+      ukCode[q] = code | (valid ? 0x80000000u : 0);
+      ukStart[q] = st; ukLen[q] = ln;
+    }
+    __syncthreads();
+    // ---- the sequential look-up rule (SeqSet.hpp:1098-1153, 1165-1226) --------------------------------
+    if (tid == 0) {
+      uint32_t prev = 0;  // prevKmerCode starts at code 0 and is carried from the + strand into the - strand
+      uint32_t nUsed = 0;
+      unsigned long long lookups = 0, postings = 0;
+      for (int pass = 0; pass < 2; ++pass) {
+        int skipCnt = 0;
+        uint32_t begin = nUsed;
+        for (int p = 0; p < nk; ++p) {
+          int q = pass * nk + p;
+          uint32_t code = ukCode[q] & 0x7FFFFFFFu;
+          if (p == 0 || code != prev) {
+            uint32_t size = ukLen[q];
+            ++lookups;
+            if (size >= 100 && p != 0 && p != nk - 1 && skipCnt < k / 2) { ++skipCnt; continue; }
+            skipCnt = 0;
+            if (size) { usedQ[nUsed++] = (uint16_t)q; postings += size; }
+          }
+          prev = code;
+        }
+        sUsed[pass] = nUsed - begin;
+      }
+      atomicAdd(&P.counters[3], lookups);
+      atomicAdd(&P.counters[4], postings);
+    }
+    __syncthreads();
+    const uint32_t nUsedPlus = sUsed[0], nUsedMinus = sUsed[1];
+    int chunk = 0;
+    for (int sp = 0; sp < 2; ++sp) {  // '-' strand first (SortHits 1577-1583)
+      const int pass = sp == 0 ? 1 : 0;
+      const uint32_t uBegin = pass == 0 ? 0 : nUsedPlus;
+      const uint32_t uCount = pass == 0 ? nUsedPlus : nUsedMinus;
+      if (uCount == 0) continue;
+      for (int tile = 0; tile < nTiles; ++tile) {
+        const uint32_t a0 = (uint32_t)tile * TILE_ALLELES;
+        const uint32_t a1 = min(a0 + TILE_ALLELES, P.ref.nAlleles);
+        for (uint32_t i = tid; i < TILE_ALLELES; i += WG) hist[i] = 0;
+        // posting lists are sorted by allele: restrict every used list to the tile with two binary searches
+        for (uint32_t u = tid; u < uCount; u += WG) {
+          int q = usedQ[uBegin + u];
+          uint32_t st = ukStart[q], ln = ukLen[q];
+          uint32_t lo = 0, hi = ln;
+          if (nTiles > 1) {
+            uint32_t l = 0, r = ln;
+            while (l < r) { uint32_t m = (l + r) >> 1; if (P.ref.kPost[st + m].allele < a0) l = m + 1; else r = m; }
+            lo = l; r = ln;
+            while (l < r) { uint32_t m = (l + r) >> 1; if (P.ref.kPost[st + m].allele < a1) l = m + 1; else r = m; }
+            hi = l;
+          }
+          tLo[u] = st + lo; tHi[u] = st + hi;
+        }
+        __syncthreads();
+        for (uint32_t u = 0; u < uCount; ++u) {
+          const uint32_t b = tLo[u], e = tHi[u];
+          for (uint32_t x = b + tid; x < e; x += WG) atomicAdd(&hist[P.ref.kPost[x].allele - a0], 1u);
+        }
+        __syncthreads();
+        // scan: groups with >= 3 hits (refMinHitRequired, SeqSet.hpp:1253, 1314) get a slice of the hit arena
+        const int EPT = TILE_ALLELES / WG;
+        uint32_t hSum = 0, gSum = 0;
+        for (int i = 0; i < EPT; ++i) {
+          uint32_t c = hist[tid * EPT + i];
+          if (c >= 3) { hSum += c; ++gSum; }
+        }
+        uint32_t hTot, gTot;
+        uint32_t hOff = t1k_block_scan_exclusive(hSum, warpSums, &hTot);
+        uint32_t gOff = t1k_block_scan_exclusive(gSum, warpSums, &gTot);
+        if (tid == 0) {
+          unsigned long long hb = atomicAdd(&P.counters[5], (unsigned long long)hTot);
+          unsigned long long gb = atomicAdd(&P.counters[6], (unsigned long long)gTot);
+          if (hb + hTot > P.hitCap) { atomicOr(&P.counters[2], (unsigned long long)ERR_HITCAP); hb = ~0ull; }
+          if (gb + gTot > P.groupCap || chunk >= MAX_CHUNKS) { atomicOr(&P.counters[2], (unsigned long long)ERR_GROUPCAP); hb = ~0ull; }
+          sHitBase = hb == ~0ull ? 0xFFFFFFFFu : (uint32_t)hb;
+          sGroupBase = (uint32_t)gb;
+          if (hb != ~0ull) { P.chunkStart[(uint64_t)re * MAX_CHUNKS + chunk] = (uint32_t)gb; P.chunkCount[(uint64_t)re * MAX_CHUNKS + chunk] = gTot; }
+        }
+        __syncthreads();
+        const uint32_t hitBase = sHitBase, groupBase = sGroupBase;
+        if (hitBase == 0xFFFFFFFFu) { __syncthreads(); continue; }
+        ++chunk;
+        for (int i = 0; i < EPT; ++i) {
+          uint32_t idx = tid * EPT + i;
+          uint32_t c = hist[idx];
+          if (c >= 3) {
+            T1kGroup g;
+            g.reStrand = re | (pass == 0 ? 0x80000000u : 0);  // bit31: '+' strand
+            g.allele = a0 + idx; g.hitStart = hitBase + hOff; g.n = c;
+            P.groups[(uint64_t)groupBase + gOff] = g;
+            hist[idx] = hitBase + hOff;
+            hOff += c; ++gOff;
+          } else hist[idx] = 0xFFFFFFFFu;
+        }
+        __syncthreads();
+        // scatter the hits of surviving groups: packed (alleleOffset << 12 | readOffset)
+        for (uint32_t u = 0; u < uCount; ++u) {
+          const uint32_t b = tLo[u], e = tHi[u];
+          const uint32_t rOff = (uint32_t)(usedQ[uBegin + u] - pass * nk);
+          for (uint32_t x = b + tid; x < e; x += WG) {
+            T1kPosting pst = P.ref.kPost[x];
+            if (hist[pst.allele - a0] != 0xFFFFFFFFu) {
+              uint32_t pos = atomicAdd(&hist[pst.allele - a0], 1u);
+              P.hits[pos] = (pst.offset << 12) | rOff;
+            }
+          }
+        }
+        __syncthreads();
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// K2 / K4: single-diagonal chain, one lane per group
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ ReadCtx makeCtx(const ChainArgs &P, uint32_t re, int pass, uint32_t allele) {
+  const int S = P.reads.S;
+  ReadCtx c{P.reads.bases + ((uint64_t)re * 2 + pass) * S, P.reads.nmask + ((uint64_t)re * 2 + pass) * S, (int)P.reads.len[re], P.ref.bases, P.ref.nmask,
+            (int64_t)P.ref.alleleOff[allele], (int)P.ref.alleleLen[allele]};
+  return c;
+}
+
+__device__ __forceinline__ void waveFlush(unsigned long long *counter, unsigned int v) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  if ((threadIdx.x & 63) == 0 && v) atomicAdd(counter, (unsigned long long)v);
+}
+
+template <bool DEFER>
+__global__ __launch_bounds__(WG) void k_chain_fast(ChainArgs P, const uint32_t *list, uint32_t nItems) {
+  const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned int dpLocal = 0, fastLocal = 0;
+  if (gid < nItems) {
+    const uint32_t gi = list ? list[gid] : (uint32_t)gid;
+    const T1kGroup g = P.groups[gi];
+    const uint32_t re = g.reStrand & 0x7FFFFFFFu;
+    const int pass = (g.reStrand >> 31) ? 0 : 1;
+    ReadCtx c = makeCtx(P, re, pass, g.allele);
+    CandOut out{P.hits + g.hitStart, 0};
+    unsigned long long *memo = P.memo + (uint64_t)re * GAP_CACHE;
+    int done = 0;
+    if (c.len <= 160)
+      done = groupFastPath<5, DEFER>(P.hits + g.hitStart, (int)g.n, c, P.k, P.radius, P.hitLenRequired, P.sim, out, &dpLocal, pass, memo, P.jobList,
+                                     (uint32_t *)&P.counters[16], re * GAP_CACHE, P.jobCap);
+    else if (c.len <= GROUP_FAST_MAXLEN)
+      done = groupFastPath<10, DEFER>(P.hits + g.hitStart, (int)g.n, c, P.k, P.radius, P.hitLenRequired, P.sim, out, &dpLocal, pass, memo, P.jobList,
+                                      (uint32_t *)&P.counters[16], re * GAP_CACHE, P.jobCap);
+    if (done == 1) { ++fastLocal; P.groups[gi].n = (uint32_t)out.n | 0x40000000u; }  // bit30: n now holds the candidate count
+    else if (done == 2) { uint32_t q = atomicAdd((uint32_t *)&P.counters[17], 1u); P.retryList[q] = gi; }
+    else if (g.n > THREAD_CAP) { uint32_t q = atomicAdd((uint32_t *)&P.counters[19], 1u); P.bigList[q] = gi; }
+    else { uint32_t q = atomicAdd((uint32_t *)&P.counters[18], 1u); P.generalList[q] = gi; }
+  }
+  waveFlush(&P.counters[7], dpLocal);
+  waveFlush(&P.counters[11], fastLocal);
+}
+
+// K3: one lane per registered alignment
+__global__ __launch_bounds__(WG) void k_dp_dense(ChainArgs P, uint32_t nJobs) {
+  const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned int dpLocal = 0;
+  if (q < nJobs) {
+    const uint32_t tag = P.jobList[q];
+    const uint32_t re = tag / GAP_CACHE;
+    unsigned long long *slot = P.memo + tag;
+    const unsigned long long e = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int L = (int)((e >> 1) & 0x1FF), readPos = (int)((e >> 10) & 0x7FF), sb = (int)(e & 1);
+    const int64_t gpos = (int64_t)(e >> 30);
+    const int S = P.reads.S;
+    T1kSeqView T{P.ref.bases, P.ref.nmask, gpos}, Pv{P.reads.bases + ((uint64_t)re * 2 + sb) * S, P.reads.nmask + ((uint64_t)re * 2 + sb) * S, (int64_t)readPos};
+    const int m = t1k_ga_matches_equal(T, Pv, L, nullptr);
+    ++dpLocal;
+    __hip_atomic_store(slot, (e & ~(GAP_PENDING << 21)) | ((unsigned long long)m << 21), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  waveFlush(&P.counters[7], dpLocal);
+}
+
+// K5: groups with several diagonals; bounded grid, per-lane scratch for the larger ones
+__global__ __launch_bounds__(WG) void k_chain_general(ChainArgs P, uint32_t nItems) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, nT = gridDim.x * blockDim.x;
+  uint32_t *mine = P.threadScratch + (uint64_t)t * THREAD_SCRATCH_U32;
+  unsigned int dpLocal = 0, genLocal = 0;
+  for (uint32_t q = t; q < nItems; q += nT) {
+    const uint32_t gi = P.generalList[q];
+    const T1kGroup g = P.groups[gi];
+    const uint32_t re = g.reStrand & 0x7FFFFFFFu;
+    const int pass = (g.reStrand >> 31) ? 0 : 1;
+    ReadCtx c = makeCtx(P, re, pass, g.allele);
+    CandOut out{P.hits + g.hitStart, 0};
+    if (g.n <= 48) {
+      uint32_t wa[48], wb[48], wc[48];  // private memory: lane-interleaved, coalesced when the lanes walk in step
+      groupGeneral(P.hits + g.hitStart, (int)g.n, c, P.k, P.radius, P.hitLenRequired, wa, wb, wc, (int *)(mine + 3 * THREAD_CAP), GA_T_MAX, out, &dpLocal,
+                   &P.counters[2]);
+    } else
+      groupGeneral(P.hits + g.hitStart, (int)g.n, c, P.k, P.radius, P.hitLenRequired, mine, mine + THREAD_CAP, mine + 2 * THREAD_CAP,
+                   (int *)(mine + 3 * THREAD_CAP), GA_T_MAX, out, &dpLocal, &P.counters[2]);
+    ++genLocal;
+    P.groups[gi].n = (uint32_t)out.n | 0x40000000u;
+  }
+  waveFlush(&P.counters[7], dpLocal);
+  waveFlush(&P.counters[12], genLocal);
+}
+
+// very large groups (repeat-rich alleles): a handful of lanes with big scratch
+__global__ __launch_bounds__(64) void k_chain_big(ChainArgs P, uint32_t nItems) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, nT = gridDim.x * blockDim.x;
+  uint32_t *mine = P.bigScratch + (uint64_t)t * (3 * BIG_CAP + GA_SCRATCH_INTS);
+  unsigned int dpLocal = 0;
+  for (uint32_t q = t; q < nItems; q += nT) {
+    const uint32_t gi = P.bigList[q];
+    const T1kGroup g = P.groups[gi];
+    if (g.n > BIG_CAP) { atomicOr(&P.counters[2], (unsigned long long)ERR_BIGGROUP); P.groups[gi].n = 0x40000000u; continue; }
+    const uint32_t re = g.reStrand & 0x7FFFFFFFu;
+    const int pass = (g.reStrand >> 31) ? 0 : 1;
+    ReadCtx c = makeCtx(P, re, pass, g.allele);
+    CandOut out{P.hits + g.hitStart, 0};
+    groupGeneral(P.hits + g.hitStart, (int)g.n, c, P.k, P.radius, P.hitLenRequired, mine, mine + BIG_CAP, mine + 2 * BIG_CAP, (int *)(mine + 3 * BIG_CAP),
+                 GA_BIG_MAX, out, &dpLocal, &P.counters[2]);
+    P.groups[gi].n = (uint32_t)out.n | 0x40000000u;
+    atomicAdd(&P.counters[13], 1ull);
+  }
+  if (dpLocal) atomicAdd(&P.counters[7], (unsigned long long)dpLocal);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// K6: strand vote + copy-out, one workgroup per read-end
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WG) void k_collect(ChainArgs P) {
+  __shared__ uint32_t warpSums[4];
+  __shared__ uint64_t sVoteHi[WG], sVoteLo[WG];
+  __shared__ uint32_t sBase;
+  const int tid = threadIdx.x;
+  for (uint32_t re = blockIdx.x; re < P.reads.nReadEnds; re += gridDim.x) {
+    const uint32_t *cs = P.chunkStart + (uint64_t)re * MAX_CHUNKS, *cc = P.chunkCount + (uint64_t)re * MAX_CHUNKS;
+    VoteKey best; best.hi = ~0ull; best.lo = ~0ull;
+    uint32_t nCand[2] = {0, 0};
+    for (int ch = 0; ch < MAX_CHUNKS; ++ch) {
+      const uint32_t g0 = cs[ch], gn = cc[ch];
+      for (uint32_t i = tid; i < gn; i += WG) {
+        const T1kGroup g = P.groups[g0 + i];
+        const uint32_t nc = g.n & 0x3FFFFFFFu;
+        const int plus = (int)(g.reStrand >> 31);
+        nCand[plus] += nc;
+        for (uint32_t j = 0; j < nc; ++j) {
+          uint32_t w0 = P.hits[g.hitStart + 3 * j], w1 = P.hits[g.hitStart + 3 * j + 1], w2 = P.hits[g.hitStart + 3 * j + 2];
+          VoteKey vk = voteKey((int)(w1 >> 20), (int)(w0 & 0xFFF), (int)((w0 >> 12) & 0xFFF), g.allele, plus, (int)(w1 & 0xFFFFF), (int)(w2 & 0xFFFFF));
+          if (vk < best) best = vk;
+        }
+      }
+    }
+    sVoteHi[tid] = best.hi; sVoteLo[tid] = best.lo;
+    __syncthreads();
+    for (int o = WG / 2; o > 0; o >>= 1) {
+      if (tid < o) {
+        VoteKey a{sVoteHi[tid], sVoteLo[tid]}, b{sVoteHi[tid + o], sVoteLo[tid + o]};
+        if (b < a) { sVoteHi[tid] = b.hi; sVoteLo[tid] = b.lo; }
+      }
+      __syncthreads();
+    }
+    const uint32_t winPlus = (uint32_t)(sVoteHi[0] & 1);
+    __syncthreads();
+    uint32_t totWin;
+    t1k_block_scan_exclusive(nCand[winPlus], warpSums, &totWin);
+    if (tid == 0) {
+      unsigned long long b = totWin ? atomicAdd(&P.counters[0], (unsigned long long)totWin) : 0ull;
+      if (b + totWin > P.candCap) { atomicOr(&P.counters[2], (unsigned long long)ERR_CANDCAP); sBase = 0xFFFFFFFFu; P.candStart[re] = 0; P.candCount[re] = 0; }
+      else { sBase = (uint32_t)b; P.candStart[re] = (uint32_t)b; P.candCount[re] = totWin; }
+    }
+    __syncthreads();
+    if (sBase != 0xFFFFFFFFu && totWin) {
+      // chunks are in the reference's order ('-' strand first, alleles ascending); copy the winning strand's candidates in order
+      uint32_t written = 0;
+      for (int ch = 0; ch < MAX_CHUNKS; ++ch) {
+        const uint32_t g0 = cs[ch], gn = cc[ch];
+        if (gn == 0) continue;
+        if ((P.groups[g0].reStrand >> 31) != winPlus) continue;  // a chunk holds one strand
+        for (uint32_t i0 = 0; i0 < gn; i0 += WG) {
+          const uint32_t i = i0 + tid;
+          T1kGroup g{};
+          uint32_t nc = 0;
+          if (i < gn) { g = P.groups[g0 + i]; nc = g.n & 0x3FFFFFFFu; }
+          uint32_t tot;
+          uint32_t off = t1k_block_scan_exclusive(nc, warpSums, &tot);
+          for (uint32_t j = 0; j < nc; ++j) {
+            uint32_t w0 = P.hits[g.hitStart + 3 * j], w1 = P.hits[g.hitStart + 3 * j + 1], w2 = P.hits[g.hitStart + 3 * j + 2];
+            T1kCand cd;
+            cd.allele = g.allele | (winPlus ? 0x80000000u : 0);
+            cd.readSE = (w0 & 0xFFF) | (((w0 >> 12) & 0xFFF) << 16);
+            cd.seqStart = (int)(w1 & 0xFFFFF); cd.seqEnd = (int)(w2 & 0xFFFFF);
+            cd.match = (w1 >> 20) | ((w2 >> 20) << 16);
+            cd.re = re;
+            P.cand[(uint64_t)sBase + written + off + j] = cd;
+          }
+          written += tot;
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------------------------
+size_t t1k_chain_thread_scratch_u32() { return (size_t)THREAD_SCRATCH_U32; }
+size_t t1k_chain_big_scratch_u32() { return (size_t)3 * BIG_CAP + GA_SCRATCH_INTS; }
+int t1k_chain_max_chunks() { return MAX_CHUNKS; }
+int t1k_chain_memo_entries() { return GAP_CACHE; }
+
+static int readCounters(t1k_ctx *ctx, unsigned long long *h) {
+  T1K_HIP(ctx, hipMemcpyAsync(h, ctx->bCounters.p, 64 * 8, hipMemcpyDeviceToHost, ctx->stream));
+  T1K_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+// runs K1..K6; on return counters[0] = number of candidates, counters[2] = error flags
+int t1k_run_chain(t1k_ctx *ctx, const ChainArgs &a, int nWg, int generalThreadsBlocks, int bigBlocks, unsigned long long *hc) {
+  const size_t lds = (size_t)TILE_ALLELES * 4 + (size_t)(2 * a.reads.S * 32) * (5 * 4 + 2);
+  T1K_HIP(ctx, hipFuncSetAttribute((const void *)k_seed_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  T1K_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+  hipLaunchKernelGGL(k_seed_scatter, dim3(nWg), dim3(WG), lds, ctx->stream, a);
+  int rc = readCounters(ctx, hc);
+  if (rc) return rc;
+  if (hc[2]) return 0;
+  const uint32_t nGroups = (uint32_t)hc[6];
+  if (nGroups) hipLaunchKernelGGL(k_chain_fast<true>, dim3((nGroups + WG - 1) / WG), dim3(WG), 0, ctx->stream, a, (const uint32_t *)nullptr, nGroups);
+  if ((rc = readCounters(ctx, hc))) return rc;
+  const uint32_t nJobs = (uint32_t)std::min<unsigned long long>(hc[16] & 0xFFFFFFFFull, a.jobCap);
+  const uint32_t nRetry = (uint32_t)(hc[17] & 0xFFFFFFFFull), nGen = (uint32_t)(hc[18] & 0xFFFFFFFFull), nBig = (uint32_t)(hc[19] & 0xFFFFFFFFull);
+  if (nJobs) hipLaunchKernelGGL(k_dp_dense, dim3((nJobs + WG - 1) / WG), dim3(WG), 0, ctx->stream, a, nJobs);
+  if (nRetry) hipLaunchKernelGGL(k_chain_fast<false>, dim3((nRetry + WG - 1) / WG), dim3(WG), 0, ctx->stream, a, (const uint32_t *)a.retryList, nRetry);
+  if (nGen) hipLaunchKernelGGL(k_chain_general, dim3(generalThreadsBlocks), dim3(WG), 0, ctx->stream, a, nGen);
+  if (nBig) hipLaunchKernelGGL(k_chain_big, dim3(bigBlocks), dim3(64), 0, ctx->stream, a, nBig);
+  hipLaunchKernelGGL(k_collect, dim3(nWg), dim3(WG), 0, ctx->stream, a);
+  T1K_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+  return readCounters(ctx, hc);
+}

@@ -384,6 +384,26 @@ __device__ inline int t1k_ga_traceback(const uint8_t *trace, int lent, int lenp,
   return n;
 }
 
+// exclusive prefix sum over a 256-thread workgroup (4 wavefronts); all threads must call it
+__device__ __forceinline__ uint32_t t1k_block_scan_exclusive(uint32_t v, uint32_t *warpSums, uint32_t *total) {
+  // 256 threads = 4 wavefronts of 64
+  int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t x = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    uint32_t y = __shfl_up(x, o, 64);
+    if (lane >= o) x += y;
+  }
+  if (lane == 63) warpSums[wave] = x;
+  __syncthreads();
+  uint32_t base = 0;
+  for (int w = 0; w < wave; ++w) base += warpSums[w];
+  uint32_t tot = warpSums[0] + warpSums[1] + warpSums[2] + warpSums[3];
+  __syncthreads();
+  *total = tot;
+  return base + x - v;
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // host-side context
 // ------------------------------------------------------------------------------------------------------------------
@@ -409,7 +429,7 @@ struct t1k_ctx {
   int batchMaxLen = 0;
   uint32_t rangeCount = 0;       // read-ends of the last t1k_assign_range
   // assignment arenas
-  T1kDevBuf bWgHits, bWgGroups, bWgStage, bWgThreadScratch, bWgBig, bWgCache;
+  T1kDevBuf bWgHits, bWgGroups, bWgStage, bWgThreadScratch, bWgBig, bWgCache, bLists;
   T1kDevBuf bCand, bExt, bCandStart, bCandCount, bOvl, bOvlStart, bOvlCount, bCounters, bSlowQueue, bSlowScratch, bSortScratch, bEqTrace;
   uint64_t nCand = 0, nOvl = 0;
   // pairing

@@ -2,23 +2,29 @@
 #pragma once
 #include "t1k_dev.h"
 
-struct AssignArgs {
+// one (read-end, strand, allele) hit group of the batch; 16 bytes
+struct T1kGroup {
+  uint32_t reStrand;   // read-end id | '+' strand << 31
+  uint32_t allele;
+  uint32_t hitStart;   // index into the batch hit arena; after chaining the slice holds the group's packed candidates
+  uint32_t n;          // hit count; after chaining: candidate count | 1 << 30
+};
+
+struct ChainArgs {
   T1kRefDev ref;
   T1kReadsDev reads;
   int k, radius, hitLenRequired;
   double sim;
-  int relax;
-  // per-workgroup scratch
-  uint32_t *wgHits; uint64_t hitCap;
-  uint32_t *wgGroups;          // [wg][TILE_ALLELES][3]
-  T1kCand *wgStage; uint32_t stageCap;
-  uint32_t *wgThread;          // [wg][WG][THREAD_SCRATCH_U32]
-  uint32_t *wgBig;             // [wg][3 * BIG_CAP + GA_SCRATCH_INTS]
-  unsigned long long *wgCache; // [wg][GAP_CACHE] memo of gap alignments of the current read-end
-  // outputs
+  uint32_t *hits; uint64_t hitCap;
+  T1kGroup *groups; uint64_t groupCap;
+  uint32_t *chunkStart, *chunkCount;          // [re][MAX_CHUNKS] runs of groups per (strand, allele tile), reference order
+  unsigned long long *memo;                   // [re][GAP_CACHE] memo of gap alignments
+  uint32_t *jobList; uint32_t jobCap;
+  uint32_t *retryList, *generalList, *bigList;
+  uint32_t *threadScratch, *bigScratch;
   T1kCand *cand; uint64_t candCap;
   uint32_t *candStart, *candCount;
-  unsigned long long *counters;  // [0] cand total, [1] ovl total, [2] error flags, [3] lookups, [4] postings, [5] hits, [6] groups, [7] dp, [8] slow queue len
+  unsigned long long *counters;
 };
 
 struct ExtendArgs {
@@ -76,13 +82,12 @@ struct TruncArgs {
 };
 
 int t1k_launch_pack(t1k_ctx *ctx, const char *dAscii, const uint64_t *dOffs, uint32_t n, int S, uint64_t *bases, uint64_t *nmask, uint16_t *lens);
-size_t t1k_seed_chain_lds(int S);
-size_t t1k_wg_groups_u32();
-size_t t1k_wg_thread_u32();
-size_t t1k_wg_big_u32();
-size_t t1k_wg_cache_u64();
 size_t t1k_slow_per_thread(int maxCells);
-void t1k_launch_seed_chain(t1k_ctx *ctx, const AssignArgs &a, int nWg);
+size_t t1k_chain_thread_scratch_u32();
+size_t t1k_chain_big_scratch_u32();
+int t1k_chain_max_chunks();
+int t1k_chain_memo_entries();
+int t1k_run_chain(t1k_ctx *ctx, const ChainArgs &a, int nWg, int generalBlocks, int bigBlocks, unsigned long long *hc);
 void t1k_launch_extend(t1k_ctx *ctx, const ExtendArgs &a);
 void t1k_launch_select(t1k_ctx *ctx, const SelectArgs &a, int nWg);
 void t1k_launch_fullalign(t1k_ctx *ctx, const FullArgs &a);
