@@ -94,10 +94,12 @@ void Genotyper::finalize(const std::vector<int32_t> &coverage) {
     off += L;
     int miss = 0;
     if (!ex.empty()) {
-      std::sort(ex.begin(), ex.end());
+      // the reference sorts and scans (SeqSet.hpp:2733-2741); only the median and the number of values below the cutoff
+      // matter, which selection + counting give without the full sort
+      std::nth_element(ex.begin(), ex.begin() + ex.size() / 2, ex.end());
       double cutoff = ex[ex.size() / 2] * 0.01;
       if (cutoff < 1) cutoff = 1;
-      while (miss < (int)ex.size() && !(ex[miss] >= cutoff)) ++miss;
+      for (int v : ex) miss += !(v >= cutoff);
     }
     R.al[a].missingCov = miss;
   }
@@ -132,18 +134,17 @@ int Genotyper::quantify(t1k_ctx *ctx, t1k_allreduce_fn cb, void *user, std::stri
   std::vector<uint64_t> rowPtr(G + 1, 0);
   std::vector<uint32_t> ecIdx;
   std::vector<double> count(G);
-  std::vector<int> seen;
+  std::vector<int> seen(E, 0);
   for (size_t g = 0; g < G; ++g) {
     float c = groupEnt[groupPtr[g]].weight;
     for (uint64_t p = groupPtr[g] + 1; p < groupPtr[g + 1]; ++p)
       if (groupEnt[p].weight > c) c = groupEnt[p].weight;
     count[g] = c;
-    size_t b = ecIdx.size();
-    for (uint64_t p = groupPtr[g]; p < groupPtr[g + 1]; ++p) {
+    for (uint64_t p = groupPtr[g]; p < groupPtr[g + 1]; ++p) {  // distinct classes of the row, first-appearance order (1165-1189)
       uint32_t ec = (uint32_t)R.al[groupEnt[p].allele].ec;
-      bool dup = false;
-      for (size_t q = b; q < ecIdx.size() && !dup; ++q) dup = ecIdx[q] == ec;
-      if (!dup) ecIdx.push_back(ec);
+      if (seen[ec] == (int)g + 1) continue;
+      seen[ec] = (int)g + 1;
+      ecIdx.push_back(ec);
     }
     rowPtr[g + 1] = ecIdx.size();
   }
@@ -205,14 +206,14 @@ void Genotyper::dropUnlikely() {
   for (auto &members : ecAlleles) {
     const int size = (int)members.size();
     std::vector<int> lo(size), hi(size, -1);
-    std::map<int, int> where;
-    for (int j = 0; j < size; ++j) { lo[j] = R.al[members[j]].seqLen; where[members[j]] = j; }
-    for (auto &gs : inAllele[members[0]]) {
-      for (uint64_t p = groupPtr[gs.first]; p < groupPtr[gs.first + 1]; ++p) {
-        auto it = where.find(groupEnt[p].allele);
-        if (it == where.end()) continue;
-        if (groupEnt[p].start < lo[it->second]) lo[it->second] = groupEnt[p].start;
-        if (groupEnt[p].end > hi[it->second]) hi[it->second] = groupEnt[p].end;
+    // The reference walks the groups of the class representative and picks out the members' entries (1398-1416).  Class
+    // members share their group list by construction, so those entries are exactly each member's own (group, slot) list.
+    for (int j = 0; j < size; ++j) {
+      lo[j] = R.al[members[j]].seqLen;
+      for (auto &gs : inAllele[members[j]]) {
+        const GroupEntry &e = groupEnt[groupPtr[gs.first] + gs.second];
+        if (e.start < lo[j]) lo[j] = e.start;
+        if (e.end > hi[j]) hi[j] = e.end;
       }
     }
     std::vector<double> ll(size);

@@ -276,11 +276,14 @@ int t1k_job_run(t1k_job *job) {
   }
   double t4 = nowMs();
   gt.dropUnlikely();
+  double t4b = nowMs();
   gt.select();
   double t5 = nowMs();
   job->msDevice = tDev; job->msHost = tHost + (t3 - t2) + (t5 - t4); job->msEm = t4 - t3;
   job->stats.ms_total = tDev + tHost + (t5 - t2);
   job->stats.ms_seed = job->msEm;  // reported as the EM time of the job
+  if (getenv("T1K_DEBUG_PHASES"))
+    fprintf(stderr, "[t1k job] device+download %.1f ms, host coalesce %.1f ms, coverage+finalize %.1f ms, EM %.1f ms, dropUnlikely %.1f ms, select %.1f ms\n", tDev, tHost, t3 - t2, t4 - t3, t4b - t4, t5 - t4b);
   job->ran = true;
   return T1K_OK;
 }

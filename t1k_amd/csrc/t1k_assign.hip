@@ -361,12 +361,16 @@ __global__ __launch_bounds__(WG) void k_fullalign(FullArgs P) {
   }
   if (slow) {
     // equal spans: register-band traced DP (queue A, from the front); unequal spans: general DP (queue B, from the back)
+    const int dl = L > Ls ? L - Ls : Ls - L;
     if (L == Ls) {
       unsigned long long q = atomicAdd(&P.counters[8], 1ull);
       P.slowQueue[q] = (uint32_t)gid;
-    } else {
+    } else if (dl <= 4) {  // register-band DP (k_fullalign_band), queued from the back
       unsigned long long q = atomicAdd(&P.counters[15], 1ull);
       P.slowQueue[P.slowCap - 1 - q] = (uint32_t)gid;
+    } else {               // wide band: general DP with row arrays in HBM (k_fullalign_slow)
+      unsigned long long q = atomicAdd(&P.counters[20], 1ull);
+      P.slowQueue[P.slowCap + q] = (uint32_t)gid;
     }
     return;
   }
@@ -496,6 +500,64 @@ __global__ __launch_bounds__(WG) void k_fullalign_eq(SlowArgs P) {
   }
 }
 
+// near-best alignments whose spans differ by 1..4 (chains with a small indel): same scheme as k_fullalign_eq with the wider
+// register band of t1k_ga_band
+__global__ __launch_bounds__(WG) void k_fullalign_band(SlowArgs P) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, nThreads = gridDim.x * blockDim.x;
+  uint64_t *trace = (uint64_t *)P.scratch + t;
+  for (uint32_t q = t; q < P.nSlow; q += nThreads) {
+    const uint32_t gid = P.slowQueue[q];
+    const T1kOvl o = P.ovl[gid];
+    const int pass = (o.flags & 2) ? 1 : 0;
+    const int S = P.reads.S;
+    const uint64_t *rb = P.reads.bases + ((uint64_t)o.re * 2 + pass) * S;
+    const uint64_t *rn = P.reads.nmask + ((uint64_t)o.re * 2 + pass) * S;
+    const int64_t goff = (int64_t)P.ref.alleleOff[o.allele];
+    const int lp = o.readEnd - o.readStart + 1, lt = o.seqEnd - o.seqStart + 1;
+    const int LB = 5 + (lp > lt ? lp - lt : 0);
+    const int w = (int)P.reads.weight[o.re];
+    T1kSeqView T{P.ref.bases, P.ref.nmask, goff + o.seqStart}, Pv{rb, rn, (int64_t)o.readStart};
+    t1k_ga_band<4, true>(T, lt, Pv, lp, trace, nThreads);
+    int32_t *cov = P.ref.covDiff + goff;
+    const int alleleLen = (int)P.ref.alleleLen[o.allele];
+    int relaxed = 0, runLo = -1, runHi = -1;
+    int ti = lp, tj = lt, mat = 0;
+    while (ti > 0 || tj > 0) {
+      int bits;
+      if (ti > 0 && tj > 0) bits = (int)((trace[(size_t)ti * nThreads] >> (4 * (tj - ti + LB))) & 15);
+      else if (ti == 0) bits = 2 | (tj == 1 ? 8 : 0);
+      else bits = (ti == 1 ? 4 : 0);
+      int op, refPos;
+      if (mat == 0) {
+        if (ti > 0 && tj > 0 && (bits & 1)) { op = t1k_eq(T.code(tj - 1), Pv.code(ti - 1)) ? 0 : 1; refPos = o.seqStart + tj - 1; --ti; --tj; }
+        else { mat = (bits & 2) ? 2 : 1; continue; }
+      } else if (mat == 1) {
+        op = 2; refPos = o.seqStart + tj;
+        if (ti > 0) { if (bits & 4) mat = 0; --ti; } else mat = 2;
+      } else {
+        op = 3; refPos = o.seqStart + tj - 1;
+        if (tj > 0) { if (bits & 8) mat = 0; --tj; } else mat = 1;
+      }
+      if (P.relax) {
+        bool ex = refPos < alleleLen ? t1k_bit(P.ref.exon, goff + refPos) != 0 : false;
+        if (!ex || op == 0) ++relaxed;
+      }
+      if (op == 0 && w) {
+        const int readPos = o.readStart + ti;
+        if (!t1k_bit(rn, readPos) && !t1k_bit(P.ref.nmask, goff + refPos)) {
+          if (refPos == runLo - 1) runLo = refPos;
+          else {
+            if (runLo >= 0) { atomicAdd(&cov[runLo], w); atomicAdd(&cov[runHi + 1], -w); }
+            runLo = runHi = refPos;
+          }
+        }
+      }
+    }
+    if (runLo >= 0) { atomicAdd(&cov[runLo], w); atomicAdd(&cov[runHi + 1], -w); }
+    P.ovl[gid].relaxed = (uint16_t)(P.relax ? 2 * relaxed : (int)o.matchCnt);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // > 1000 overlaps: sort by _overlap::operator< on the extended records and cut (SeqSet.hpp:2290-2298)
 // ------------------------------------------------------------------------------------------------------------------
@@ -553,11 +615,16 @@ __global__ __launch_bounds__(WG) void k_truncate(TruncArgs P) {
           --j;
         }
       }
-      double s0 = ovlSimilarity(stage[idx[0]]);
-      uint32_t j = 1;
-      for (; j < n; ++j)
-        if (ovlSimilarity(stage[idx[j]]) < s0 - 0.1) break;
-      sCut = j;
+      sCut = n;
+    }
+    __syncthreads();
+    {
+      // first j >= 1 whose similarity falls more than 0.1 below the best one (SeqSet.hpp:2294-2297)
+      const double s0 = ovlSimilarity(stage[idx[0]]);
+      uint32_t mine = n;
+      for (uint32_t j = 1 + tid; j < n; j += WG)
+        if (ovlSimilarity(stage[idx[j]]) < s0 - 0.1) { mine = j; break; }
+      if (mine < n) atomicMin(&sCut, mine);
     }
     __syncthreads();
     const uint32_t cut = sCut;
@@ -618,6 +685,7 @@ void t1k_launch_fullalign(t1k_ctx *ctx, const FullArgs &a) {
 }
 void t1k_launch_fullalign_slow(t1k_ctx *ctx, const SlowArgs &a, int nBlocks) { hipLaunchKernelGGL(k_fullalign_slow, dim3(nBlocks), dim3(64), 0, ctx->stream, a); }
 void t1k_launch_fullalign_eq(t1k_ctx *ctx, const SlowArgs &a, int nBlocks) { hipLaunchKernelGGL(k_fullalign_eq, dim3(nBlocks), dim3(WG), 0, ctx->stream, a); }
+void t1k_launch_fullalign_band(t1k_ctx *ctx, const SlowArgs &a, int nBlocks) { hipLaunchKernelGGL(k_fullalign_band, dim3(nBlocks), dim3(WG), 0, ctx->stream, a); }
 void t1k_launch_truncate(t1k_ctx *ctx, const TruncArgs &a, int nWg) {
   hipFuncSetAttribute((const void *)k_truncate, hipFuncAttributeMaxDynamicSharedMemorySize, SELECT_LDS_BYTES);
   hipLaunchKernelGGL(k_truncate, dim3(nWg), dim3(WG), SELECT_LDS_BYTES, ctx->stream, a);

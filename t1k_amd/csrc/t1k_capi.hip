@@ -332,13 +332,12 @@ int t1k_assign_range(t1k_ctx *ctx, uint64_t first, uint32_t count) {
   const int maxChunks = t1k_chain_max_chunks(), memoN = t1k_chain_memo_entries();
   const uint64_t hitCap = (uint64_t)ctx->prm.hit_cap, groupCap = (uint64_t)ctx->prm.group_cap;
   const uint32_t jobCap = 16u << 20;
-  const int generalBlocks = 128, bigBlocks = 2;
+  const int generalBlocks = 1, bigBlocks = 32;
   if ((rc = t1k_ensure(ctx, ctx->bCounters, 64 * 8))) return rc;
   if ((rc = t1k_ensure(ctx, ctx->bWgHits, hitCap * 4))) return rc;                                        // batch hit arena
   if ((rc = t1k_ensure(ctx, ctx->bWgGroups, groupCap * sizeof(T1kGroup)))) return rc;                     // batch group arena
   if ((rc = t1k_ensure(ctx, ctx->bWgStage, (size_t)n * maxChunks * 8 + 64))) return rc;                   // chunkStart | chunkCount
   if ((rc = t1k_ensure(ctx, ctx->bWgCache, (size_t)n * memoN * 8 + 64))) return rc;                       // per-read-end memo
-  if ((rc = t1k_ensure(ctx, ctx->bWgThreadScratch, (size_t)generalBlocks * 256 * t1k_chain_thread_scratch_u32() * 4))) return rc;
   if ((rc = t1k_ensure(ctx, ctx->bWgBig, (size_t)bigBlocks * 64 * t1k_chain_big_scratch_u32() * 4))) return rc;
   if ((rc = t1k_ensure(ctx, ctx->bLists, (size_t)jobCap * 4 + groupCap * 4 * 3 + 64))) return rc;        // jobList | retry | general | big
   if ((rc = t1k_ensure(ctx, ctx->bCand, (size_t)ctx->prm.cand_cap * sizeof(T1kCand)))) return rc;
@@ -397,7 +396,7 @@ int t1k_assign_range(t1k_ctx *ctx, uint64_t first, uint32_t count) {
   ctx->nOvl = hc[1];
   const int maxCells = 340 * 340;
   const int slowBlocks = 64;
-  if ((rc = t1k_ensure(ctx, ctx->bSlowQueue, (size_t)(ctx->nOvl + 1) * 4))) return rc;
+  if ((rc = t1k_ensure(ctx, ctx->bSlowQueue, (size_t)(ctx->nOvl + 1) * 8))) return rc;  // [equal -> | <- band][wide ->]
   if ((rc = t1k_ensure(ctx, ctx->bSlowScratch, (size_t)slowBlocks * 64 * t1k_slow_per_thread(maxCells)))) return rc;
   FullArgs f{};
   f.ref = ctx->ref; f.reads = rd; f.relax = relaxFlag; f.ovl = s.ovl; f.nOvl = ctx->nOvl;
@@ -415,9 +414,18 @@ int t1k_assign_range(t1k_ctx *ctx, uint64_t first, uint32_t count) {
     sl.scratch = (uint8_t *)ctx->bEqTrace.p; sl.perThread = 0; sl.maxCells = 0; sl.counters = a.counters;
     t1k_launch_fullalign_eq(ctx, sl, eqBlocks);
   }
-  if (hc[15]) {  // unequal spans (indel chains): general DP with row arrays in HBM
+  if (hc[15]) {  // spans differing by 1..4 (small indel in the chain): wider register band
+    const int eqBlocks = 512;
+    const size_t traceBytes = (size_t)eqBlocks * 256 * (size_t)(ctx->batchMaxLen + 2) * 8;
+    if ((rc = t1k_ensure(ctx, ctx->bEqTrace, traceBytes))) return rc;
     SlowArgs sl{};
     sl.ref = ctx->ref; sl.reads = rd; sl.relax = relaxFlag; sl.ovl = s.ovl; sl.slowQueue = f.slowQueue + (f.slowCap - hc[15]); sl.nSlow = (uint32_t)hc[15];
+    sl.scratch = (uint8_t *)ctx->bEqTrace.p; sl.perThread = 0; sl.maxCells = 0; sl.counters = a.counters;
+    t1k_launch_fullalign_band(ctx, sl, eqBlocks);
+  }
+  if (hc[20]) {  // wide length difference: general DP with row arrays in HBM
+    SlowArgs sl{};
+    sl.ref = ctx->ref; sl.reads = rd; sl.relax = relaxFlag; sl.ovl = s.ovl; sl.slowQueue = f.slowQueue + f.slowCap; sl.nSlow = (uint32_t)hc[20];
     sl.scratch = (uint8_t *)ctx->bSlowScratch.p; sl.perThread = t1k_slow_per_thread(maxCells); sl.maxCells = maxCells; sl.counters = a.counters;
     t1k_launch_fullalign_slow(ctx, sl, slowBlocks);
   }

@@ -19,13 +19,10 @@
 #define WG 256
 #define TILE_ALLELES 8192           // LDS histogram tile (u32 per allele): 32 KB -> 4 workgroups per CU
 #define GROUP_FAST_MAXLEN 320
-#define THREAD_CAP 192              // hits per group handled by the general kernel's per-lane scratch; larger groups: k_chain_big
+#define GENERAL_CAP 128             // hits per group handled by k_chain_general in private memory; larger groups: k_chain_big
 #define BIG_CAP 16384
 #define GA_BIG_MAX 2048
 #define GA_SCRATCH_INTS (6 * (GA_BIG_MAX + 4))
-#define GA_T_MAX 256
-#define GA_THREAD_INTS (6 * (GA_T_MAX + 4))
-#define THREAD_SCRATCH_U32 (3 * THREAD_CAP + GA_THREAD_INTS)
 #define MAX_CHUNKS 16               // (2 strands) x (allele tiles) per read-end
 
 enum { ERR_HITCAP = 1, ERR_STAGECAP = 2, ERR_CANDCAP = 4, ERR_BIGGROUP = 8, ERR_OVLCAP = 16, ERR_SORTCAP = 32, ERR_SLOWCAP = 64, ERR_ROWCAP = 128, ERR_GROUPCAP = 256 };
@@ -53,11 +50,15 @@ struct CandOut {  // packed into the group's own hit segment: 3 u32 per candidat
 };
 
 // seed-chain match count of one gap (SeqSet.hpp:1710-1752 / 1794-1824)
-__device__ inline int gapMatches(const ReadCtx &c, int ra, int ga, int lp, int lt, int *gaScratch, int gaMax, unsigned int *dpCounter, unsigned long long *errFlags) {
+__device__ inline int gapMatches(const ReadCtx &c, int ra, int ga, int lp, int lt, int *gaScratch, int gaMax, unsigned int *dpCounter, unsigned long long *errFlags,
+                                 bool *needScratch) {
   if (lp == lt) return t1k_ga_matches_window(c.rb, c.rn, ra, c.gb, c.gn, c.goff + ga, lp, dpCounter);
   if (lt == 0 || lp == 0) return 0;
   if (dpCounter) ++*dpCounter;
   T1kSeqView T{c.gb, c.gn, c.goff + ga}, P{c.rb, c.rn, ra};
+  const int diff = lt > lp ? lt - lp : lp - lt;
+  if (diff <= 4) return t1k_ga_band<4, false>(T, lt, P, lp, nullptr, 0);  // band in registers
+  if (!gaScratch) { *needScratch = true; return 0; }
   int nm = 0;
   if (lt > gaMax) { atomicOr(errFlags, (unsigned long long)ERR_BIGGROUP); return 0; }
   t1k_ga_general(T, lt, P, lp, gaScratch, nullptr, &nm);
@@ -365,7 +366,7 @@ __device__ __forceinline__ bool hitKeyLess(uint32_t x, uint32_t y) {  // (diag, 
 // General group (several diagonals): restates GetOverlapsFromHits 1338-1551 and the chain walk 1697-1833.
 // A[n] sorted copy of the hits, B[n] concordant hits, C[n] packs top (low 16) / link (high 16) of the LIS.
 __device__ inline void groupGeneral(const uint32_t *h, int n, const ReadCtx &c, int k, int radius, int hitLenRequired, uint32_t *A, uint32_t *B,
-                                     uint32_t *C, int *gaScratch, int gaMax, CandOut &out, unsigned int *dpCounter, unsigned long long *errFlags) {
+                                     uint32_t *C, int *gaScratch, int gaMax, CandOut &out, unsigned int *dpCounter, unsigned long long *errFlags, bool *needScratch) {
   // insertion sort into A
   for (int i = 0; i < n; ++i) {
     uint32_t x = h[i];
@@ -472,12 +473,12 @@ __device__ inline void groupGeneral(const uint32_t *h, int n, const ReadCtx &c, 
       bool readOv = pa + k - 1 >= qa, seqOv = pb + k - 1 >= qb;
       if (sameDiag) {
         if (readOv) matchCnt += 2 * (qa - pa);
-        else matchCnt += 2 * k + 2 * gapMatches(c, pa + k, pb + k, qa - (pa + k), qb - (pb + k), gaScratch, gaMax, dpCounter, errFlags);
+        else matchCnt += 2 * k + 2 * gapMatches(c, pa + k, pb + k, qa - (pa + k), qb - (pb + k), gaScratch, gaMax, dpCounter, errFlags, needScratch);
       } else {
         if (readOv && !seqOv) matchCnt += 2 * (qa - pa);
         else if (!readOv && seqOv) matchCnt += 2 * (qb - pb);
         else if (readOv && seqOv) matchCnt += 2 * ((qa - pa) < (qb - pb) ? (qa - pa) : (qb - pb));
-        else matchCnt += 2 * k + 2 * gapMatches(c, pa + k, pb + k, qa - (pa + k), qb - (pb + k), gaScratch, gaMax, dpCounter, errFlags);
+        else matchCnt += 2 * k + 2 * gapMatches(c, pa + k, pb + k, qa - (pa + k), qb - (pb + k), gaScratch, gaMax, dpCounter, errFlags, needScratch);
       }
     }
     int rs = (int)(A[s] & 0xFFF), ss = (int)(A[s] >> 12);
@@ -686,7 +687,7 @@ __global__ __launch_bounds__(WG) void k_chain_fast(ChainArgs P, const uint32_t *
                                       (uint32_t *)&P.counters[16], re * GAP_CACHE, P.jobCap);
     if (done == 1) { ++fastLocal; P.groups[gi].n = (uint32_t)out.n | 0x40000000u; }  // bit30: n now holds the candidate count
     else if (done == 2) { uint32_t q = atomicAdd((uint32_t *)&P.counters[17], 1u); P.retryList[q] = gi; }
-    else if (g.n > THREAD_CAP) { uint32_t q = atomicAdd((uint32_t *)&P.counters[19], 1u); P.bigList[q] = gi; }
+    else if (g.n > GENERAL_CAP) { uint32_t q = atomicAdd((uint32_t *)&P.counters[19], 1u); P.bigList[q] = gi; }
     else { uint32_t q = atomicAdd((uint32_t *)&P.counters[18], 1u); P.generalList[q] = gi; }
   }
   waveFlush(&P.counters[7], dpLocal);
@@ -713,27 +714,29 @@ __global__ __launch_bounds__(WG) void k_dp_dense(ChainArgs P, uint32_t nJobs) {
   waveFlush(&P.counters[7], dpLocal);
 }
 
-// K5: groups with several diagonals; bounded grid, per-lane scratch for the larger ones
+// K5: groups with several diagonals, one lane per group; work arrays in private memory (lane-interleaved, coalesced when
+// the lanes walk in step).  Groups that are too large for that, or that need an alignment wider than the register band, go to
+// k_chain_big.
 __global__ __launch_bounds__(WG) void k_chain_general(ChainArgs P, uint32_t nItems) {
-  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, nT = gridDim.x * blockDim.x;
-  uint32_t *mine = P.threadScratch + (uint64_t)t * THREAD_SCRATCH_U32;
+  const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
   unsigned int dpLocal = 0, genLocal = 0;
-  for (uint32_t q = t; q < nItems; q += nT) {
+  if (q < nItems) {
     const uint32_t gi = P.generalList[q];
     const T1kGroup g = P.groups[gi];
     const uint32_t re = g.reStrand & 0x7FFFFFFFu;
     const int pass = (g.reStrand >> 31) ? 0 : 1;
     ReadCtx c = makeCtx(P, re, pass, g.allele);
-    CandOut out{P.hits + g.hitStart, 0};
-    if (g.n <= 48) {
-      uint32_t wa[48], wb[48], wc[48];  // private memory: lane-interleaved, coalesced when the lanes walk in step
-      groupGeneral(P.hits + g.hitStart, (int)g.n, c, P.k, P.radius, P.hitLenRequired, wa, wb, wc, (int *)(mine + 3 * THREAD_CAP), GA_T_MAX, out, &dpLocal,
-                   &P.counters[2]);
-    } else
-      groupGeneral(P.hits + g.hitStart, (int)g.n, c, P.k, P.radius, P.hitLenRequired, mine, mine + THREAD_CAP, mine + 2 * THREAD_CAP,
-                   (int *)(mine + 3 * THREAD_CAP), GA_T_MAX, out, &dpLocal, &P.counters[2]);
-    ++genLocal;
-    P.groups[gi].n = (uint32_t)out.n | 0x40000000u;
+    uint32_t wa[GENERAL_CAP], wb[GENERAL_CAP], wc[GENERAL_CAP];
+    uint32_t cbuf[GENERAL_CAP + 3];  // candidates are staged here so that the hit slice stays intact if the group is handed over
+    CandOut out{cbuf, 0};
+    bool needScratch = false;
+    groupGeneral(P.hits + g.hitStart, (int)g.n, c, P.k, P.radius, P.hitLenRequired, wa, wb, wc, nullptr, 0, out, &dpLocal, &P.counters[2], &needScratch);
+    if (needScratch) { uint32_t b = atomicAdd((uint32_t *)&P.counters[19], 1u); P.bigList[b] = gi; }
+    else {
+      ++genLocal;
+      for (int i = 0; i < 3 * out.n; ++i) P.hits[g.hitStart + i] = cbuf[i];
+      P.groups[gi].n = (uint32_t)out.n | 0x40000000u;
+    }
   }
   waveFlush(&P.counters[7], dpLocal);
   waveFlush(&P.counters[12], genLocal);
@@ -752,8 +755,9 @@ __global__ __launch_bounds__(64) void k_chain_big(ChainArgs P, uint32_t nItems) 
     const int pass = (g.reStrand >> 31) ? 0 : 1;
     ReadCtx c = makeCtx(P, re, pass, g.allele);
     CandOut out{P.hits + g.hitStart, 0};
+    bool dummy = false;
     groupGeneral(P.hits + g.hitStart, (int)g.n, c, P.k, P.radius, P.hitLenRequired, mine, mine + BIG_CAP, mine + 2 * BIG_CAP, (int *)(mine + 3 * BIG_CAP),
-                 GA_BIG_MAX, out, &dpLocal, &P.counters[2]);
+                 GA_BIG_MAX, out, &dpLocal, &P.counters[2], &dummy);
     P.groups[gi].n = (uint32_t)out.n | 0x40000000u;
     atomicAdd(&P.counters[13], 1ull);
   }
@@ -840,7 +844,7 @@ __global__ __launch_bounds__(WG) void k_collect(ChainArgs P) {
 // ------------------------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------------------------
-size_t t1k_chain_thread_scratch_u32() { return (size_t)THREAD_SCRATCH_U32; }
+size_t t1k_chain_thread_scratch_u32() { return 16; }
 size_t t1k_chain_big_scratch_u32() { return (size_t)3 * BIG_CAP + GA_SCRATCH_INTS; }
 int t1k_chain_max_chunks() { return MAX_CHUNKS; }
 int t1k_chain_memo_entries() { return GAP_CACHE; }
@@ -867,8 +871,14 @@ int t1k_run_chain(t1k_ctx *ctx, const ChainArgs &a, int nWg, int generalThreadsB
   const uint32_t nRetry = (uint32_t)(hc[17] & 0xFFFFFFFFull), nGen = (uint32_t)(hc[18] & 0xFFFFFFFFull), nBig = (uint32_t)(hc[19] & 0xFFFFFFFFull);
   if (nJobs) hipLaunchKernelGGL(k_dp_dense, dim3((nJobs + WG - 1) / WG), dim3(WG), 0, ctx->stream, a, nJobs);
   if (nRetry) hipLaunchKernelGGL(k_chain_fast<false>, dim3((nRetry + WG - 1) / WG), dim3(WG), 0, ctx->stream, a, (const uint32_t *)a.retryList, nRetry);
-  if (nGen) hipLaunchKernelGGL(k_chain_general, dim3(generalThreadsBlocks), dim3(WG), 0, ctx->stream, a, nGen);
-  if (nBig) hipLaunchKernelGGL(k_chain_big, dim3(bigBlocks), dim3(64), 0, ctx->stream, a, nBig);
+  (void)generalThreadsBlocks;
+  if (nGen) {
+    hipLaunchKernelGGL(k_chain_general, dim3((nGen + WG - 1) / WG), dim3(WG), 0, ctx->stream, a, nGen);
+    if ((rc = readCounters(ctx, hc))) return rc;  // the general kernel may hand groups over to the big-scratch kernel
+  }
+  const uint32_t nBig2 = (uint32_t)(hc[19] & 0xFFFFFFFFull);
+  (void)nBig;
+  if (nBig2) hipLaunchKernelGGL(k_chain_big, dim3(bigBlocks), dim3(64), 0, ctx->stream, a, nBig2);
   hipLaunchKernelGGL(k_collect, dim3(nWg), dim3(WG), 0, ctx->stream, a);
   T1K_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
   return readCounters(ctx, hc);

@@ -238,6 +238,80 @@ __device__ inline void t1k_ga_equal_traced(const T1kSeqView &T, const T1kSeqView
   }
 }
 
+// Banded GlobalAlignment for |lent - lenp| <= DMAX with the whole band in registers (generalises the two routines above:
+// leftBand = 5 + max(0, lenp - lent), rightBand = 5 + max(0, lent - lenp), AlignAlgo.hpp:240-245).  Slot s of a row holds
+// column j = i + s - (LB + 1); slots 0 and LB + RB + 2 are the negInf fence cells.
+//   TRACE = false: returns the number of MATCH columns of the reference's traceback (forward-carried counts).
+//   TRACE = true : stores one 64-bit word of 4-bit decisions per row (b0 diagonal reproduces m, b1 f >= e, b2 e opened from
+//                  m, b3 f opened from m) at trace[i * stride]; whether two bases compare equal is re-derived by the walker.
+template <int DMAX, bool TRACE>
+__device__ inline int t1k_ga_band(const T1kSeqView &T, int lent, const T1kSeqView &P, int lenp, uint64_t *trace, size_t stride) {
+  constexpr int NS = 13 + DMAX;
+  const int LB = 5 + (lenp > lent ? lenp - lent : 0), RB = 5 + (lent > lenp ? lent - lenp : 0);
+  const int last = LB + RB + 2;  // right fence slot
+  const int negInf = (lent + 1) * (lenp + 1) * -4;
+  int m[NS], e[NS], cm[NS], ce[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {  // row 0: boundary values for every column (AlignAlgo.hpp:255-270)
+    int j = s - (LB + 1);
+    if (j == 0) { m[s] = 0; e[s] = 0; }
+    else { m[s] = -4 - 4 * j; e[s] = -4 - 4 * (lenp + 1); }
+    cm[s] = 0; ce[s] = 0;
+  }
+  uint64_t pwB = 0, pwN = 0;
+  for (int i = 1; i <= lenp; ++i) {
+    if (((i - 1) & 31) == 0) { pwB = t1k_get32(P.b, P.pos + i - 1); pwN = t1k_get32(P.n, P.pos + i - 1); }
+    const int pq = ((i - 1) & 31) * 2;
+    const int pc = ((pwN >> pq) & 1) ? 4 : (int)((pwB >> pq) & 3);
+    const int t0 = i - LB - 1 > 0 ? i - LB - 1 : 0;
+    const uint64_t twB = t1k_get32(T.b, T.pos + t0), twN = t1k_get32(T.n, T.pos + t0);
+    int fLeft = 0, mLeft = 0, cfLeft = 0, cmLeft = 0;
+    uint64_t word = 0;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      int j = i + s - (LB + 1);
+      int nm, ne, nf, ncm = 0, nce = 0, ncf = 0;
+      if (s > last || j < 0) { nm = ne = nf = negInf; }
+      else if (j == 0) { nm = -4 - 4 * i; ne = -4 - i; nf = -4 - 4 * i; }
+      else if (j > lent || s == 0 || s == last) { nm = ne = nf = negInf; }
+      else {
+        const int up = s + 1 < NS ? s + 1 : s;  // (i-1, j); s + 1 <= last < NS whenever this branch is live
+        int eu = e[up] - 1, mu = m[up] - 5;
+        ne = eu > mu ? eu : mu;
+        int fl = fLeft - 1, ml = mLeft - 5;
+        nf = fl > ml ? fl : ml;
+        const int tq = (j - 1 - t0) * 2;
+        const int tc = ((twN >> tq) & 1) ? 4 : (int)((twB >> tq) & 3);
+        bool eq = t1k_eq(tc, pc);
+        int dg = m[s] + (eq ? 2 : -2);
+        nm = dg;
+        if (ne > nm) nm = ne;
+        if (nf > nm) nm = nf;
+        if (TRACE) {
+          uint64_t bits = (dg == nm ? 1u : 0u) | (nf >= ne ? 2u : 0u) | (mu == ne ? 4u : 0u) | (ml == nf ? 8u : 0u);
+          word |= bits << (4 * (s - 1));
+        } else {
+          nce = (mu == ne) ? cm[up] : ce[up];
+          ncf = (ml == nf) ? cmLeft : cfLeft;
+          if (dg == nm) ncm = cm[s] + (eq ? 1 : 0);
+          else if (nf >= ne) ncm = ncf;
+          else ncm = nce;
+        }
+      }
+      m[s] = nm; e[s] = ne;
+      if (!TRACE) { cm[s] = ncm; ce[s] = nce; }
+      fLeft = nf; mLeft = nm; cfLeft = ncf; cmLeft = ncm;
+    }
+    if (TRACE) trace[(size_t)i * stride] = word;
+  }
+  // final cell (lenp, lent): slot lent - lenp + LB + 1
+  int res = 0;
+#pragma unroll
+  for (int s = 0; s < NS; ++s)
+    if (s == lent - lenp + LB + 1) res = cm[s];
+  return res;
+}
+
 // Exact fast path for equal lengths: with x <= 3 mismatches the ungapped alignment is optimal and is the one the
 // traceback returns (any gapped alignment of equal-length strings scores <= 2L-12 <= 2L-4x, ties go to the diagonal).
 __device__ __forceinline__ int t1k_ga_matches_window(const uint64_t *rb, const uint64_t *rn, int64_t rpos, const uint64_t *gb, const uint64_t *gn,

@@ -93,5 +93,6 @@ void t1k_launch_select(t1k_ctx *ctx, const SelectArgs &a, int nWg);
 void t1k_launch_fullalign(t1k_ctx *ctx, const FullArgs &a);
 void t1k_launch_fullalign_slow(t1k_ctx *ctx, const SlowArgs &a, int nBlocks);
 void t1k_launch_fullalign_eq(t1k_ctx *ctx, const SlowArgs &a, int nBlocks);
+void t1k_launch_fullalign_band(t1k_ctx *ctx, const SlowArgs &a, int nBlocks);
 void t1k_launch_truncate(t1k_ctx *ctx, const TruncArgs &a, int nWg);
 void t1k_launch_coverage_scan(t1k_ctx *ctx, const T1kRefDev &ref, int32_t *out, const uint64_t *outOff);
