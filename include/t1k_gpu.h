@@ -131,8 +131,10 @@ int t1k_em_update(t1k_ctx *ctx, const double *x0, double *x1, double *ecReadCoun
 
 /* ---- profiling counters of the last t1k_assign_batch (algorithmic-traffic terms of SURVEY.md 8d) --------------- */
 typedef struct {
-  uint64_t read_ends, lookups, postings, hits, groups, candidates, extended, near_best, dp_calls;
-  double ms_seed, ms_chain, ms_extend, ms_select, ms_fullalign, ms_pair, ms_total;
+  uint64_t read_ends, lookups, postings, hits, groups, candidates, extended, near_best, dp_calls, rows, batches;
+  /* kernel time (HIP events on the launch stream), summed over the batches of the last run:
+     ms_seed = k_seed_scatter, ms_chain = the remaining chain kernels, ms_fullalign = k_fullalign + DP kernels + k_truncate */
+  double ms_seed, ms_chain, ms_extend, ms_select, ms_fullalign, ms_pair, ms_em, ms_total;
 } t1k_stats;
 int t1k_stats_get(t1k_ctx *ctx, t1k_stats *out);
 
@@ -146,7 +148,7 @@ typedef struct {
   int32_t allele_digit_units;                                         /* --alleleDigitUnits, -1 = automatic */
   char allele_delimiter;                                              /* --alleleDelimiter, 0 = automatic */
   int32_t threads;                                                    /* -t: host parser/packer threads */
-  int32_t device;                                                     /* GPU ordinal */
+  int32_t device;                                                     /* GPU ordinal; -1 = host-only job (group bookkeeping only, cannot run) */
   int32_t output_read_assignment;                                     /* --outputReadAssignment */
   int32_t batch_fragments;                                            /* fragments per device batch (0 = default) */
 } t1k_job_params;
@@ -170,8 +172,24 @@ int t1k_job_genotype_text(t1k_job *job, char *buf, uint64_t cap, uint64_t *neede
 int t1k_job_counts(t1k_job *job, uint64_t *fragments, uint64_t *assignedFragments, uint64_t *groups, uint64_t *ecs, int32_t *emIterations);
 int t1k_job_stats(t1k_job *job, t1k_stats *out);
 t1k_ctx *t1k_job_ctx(t1k_job *job);
-/* multi-GPU: reads are sharded by the caller (one job per rank); the EM read-count vector is all-reduced through cb */
+/* ---- multi-GPU: one job (process) per GPU, each owning a contiguous slice of the fragments in file order -------------
+ * t1k_job_run == t1k_job_run_local + t1k_job_finish(0, all groups).  With N ranks:
+ *   1. every rank: t1k_job_run_local (read-end assignment, pairing, local coalescing; coverage stays on the device)
+ *   2. all-reduce (sum, int32) the coverage difference array returned by t1k_coverage_device over RCCL
+ *   3. all-gather the byte strings of t1k_job_groups_serialize; every rank calls t1k_job_groups_reset and absorbs the
+ *      strings in rank order (fragment order), which reproduces global first-appearance group numbering
+ *   4. every rank: t1k_job_finish(b, e) with its slice [b, e) of the merged groups: local E-step, the callback set by
+ *      t1k_job_set_allreduce sums the per-class read counts over the ranks, identical M-step / selection everywhere */
 int t1k_job_set_allreduce(t1k_job *job, t1k_allreduce_fn cb, void *user);
+int t1k_job_run_local(t1k_job *job);
+int t1k_job_finish(t1k_job *job, uint64_t emGroupBegin, uint64_t emGroupEnd);
+int t1k_job_groups_serialize(t1k_job *job, void *buf, uint64_t cap, uint64_t *needed);
+int t1k_job_groups_reset(t1k_job *job);
+int t1k_job_groups_absorb(t1k_job *job, const void *buf, uint64_t len);
+/* host-side CoalesceReadAssignments (Genotyper.hpp:841-908) on caller-provided fragment rows, in order (tests; device = -1 jobs) */
+int t1k_job_coalesce_rows(t1k_job *job, const t1k_row_entry *rows, const uint32_t *rowCounts, uint32_t nFragments);
+/* device pointer + element count of the int32 coverage difference array (for an in-place all-reduce) */
+int t1k_coverage_device(t1k_ctx *ctx, void **devPtr, uint64_t *count);
 
 #ifdef __cplusplus
 }

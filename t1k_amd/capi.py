@@ -36,8 +36,8 @@ class JobParams(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("read_ends", "lookups", "postings", "hits", "groups", "candidates", "extended",
-                                          "near_best", "dp_calls")] + \
-               [(n, C.c_double) for n in ("ms_seed", "ms_chain", "ms_extend", "ms_select", "ms_fullalign", "ms_pair", "ms_total")]
+                                          "near_best", "dp_calls", "rows", "batches")] + \
+               [(n, C.c_double) for n in ("ms_seed", "ms_chain", "ms_extend", "ms_select", "ms_fullalign", "ms_pair", "ms_em", "ms_total")]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -102,6 +102,13 @@ def lib():
     L.t1k_job_ctx.argtypes = [vp]
     L.t1k_job_ctx.restype = vp
     L.t1k_job_set_allreduce.argtypes = [vp, ALLREDUCE_FN, vp]
+    L.t1k_job_run_local.argtypes = [vp]
+    L.t1k_job_finish.argtypes = [vp, C.c_uint64, C.c_uint64]
+    L.t1k_job_groups_serialize.argtypes = [vp, vp, C.c_uint64, u64p]
+    L.t1k_job_groups_reset.argtypes = [vp]
+    L.t1k_job_groups_absorb.argtypes = [vp, vp, C.c_uint64]
+    L.t1k_job_coalesce_rows.argtypes = [vp, vp, vp, C.c_uint32]
+    L.t1k_coverage_device.argtypes = [vp, C.POINTER(vp), u64p]
     _lib = L
     return L
 
@@ -328,6 +335,40 @@ class Job:
     def set_allreduce(self, fn):
         self._cb = ALLREDUCE_FN(fn)
         self._check(lib().t1k_job_set_allreduce(self.h, self._cb, None), "t1k_job_set_allreduce")
+
+    # ---- multi-GPU building blocks (include/t1k_gpu.h, "multi-GPU") ----
+    def run_local(self):
+        self._check(lib().t1k_job_run_local(self.h), "t1k_job_run_local")
+
+    def finish(self, group_begin=0, group_end=2 ** 64 - 1):
+        self._check(lib().t1k_job_finish(self.h, group_begin, group_end), "t1k_job_finish")
+
+    def groups_serialize(self):
+        need = C.c_uint64()
+        self._check(lib().t1k_job_groups_serialize(self.h, None, 0, C.byref(need)), "t1k_job_groups_serialize")
+        buf = np.zeros(need.value, dtype=np.uint8)
+        self._check(lib().t1k_job_groups_serialize(self.h, _ptr(buf), need.value, C.byref(need)), "t1k_job_groups_serialize")
+        return buf
+
+    def groups_reset(self):
+        self._check(lib().t1k_job_groups_reset(self.h), "t1k_job_groups_reset")
+
+    def groups_absorb(self, buf):
+        buf = np.ascontiguousarray(buf, dtype=np.uint8)
+        self._check(lib().t1k_job_groups_absorb(self.h, _ptr(buf), buf.size), "t1k_job_groups_absorb")
+
+    def coalesce_rows(self, rows, row_counts):
+        rows = np.ascontiguousarray(rows, dtype=ROW_DTYPE)
+        rc = np.ascontiguousarray(row_counts, dtype=np.uint32)
+        self._check(lib().t1k_job_coalesce_rows(self.h, _ptr(rows), _ptr(rc), len(rc)), "t1k_job_coalesce_rows")
+
+    def coverage_device(self):
+        """(device pointer, element count) of the int32 coverage difference array"""
+        p, n = C.c_void_p(), C.c_uint64()
+        ctx = lib().t1k_job_ctx(self.h)
+        if lib().t1k_coverage_device(ctx, C.byref(p), C.byref(n)) != 0:
+            raise T1kError("t1k_coverage_device failed")
+        return p.value, n.value
 
 
 # ---------------------------------------------------------------------------------------------------------------------

@@ -42,6 +42,34 @@ void Genotyper::coalesce(t1k_row_entry *row, uint32_t n) {
   groupPtr.push_back(groupEnt.size());
 }
 
+// merge a group that another shard (a later slice of the fragments) has already coalesced: same pattern -> same group,
+// weights added in shard order, start = min, and the reference's end rule applied with the shard's (start, end) as if it
+// were one fragment (exact when the shard's entry never triggered the rule)
+void Genotyper::absorb(const GroupEntry *ent, uint32_t n) {
+  if (n == 0) return;
+  uint64_t h = 1469598103934665603ull ^ n;
+  for (uint32_t j = 0; j < n; ++j) { h ^= (uint64_t)(uint32_t)ent[j].allele; h *= 1099511628211ull; h ^= h >> 29; }
+  std::vector<uint32_t> &bucket = groupOfHash[h];
+  for (uint32_t gid : bucket) {
+    uint64_t b = groupPtr[gid];
+    if (groupPtr[gid + 1] - b != n) continue;
+    bool same = true;
+    for (uint32_t j = 0; j < n && same; ++j) same = groupEnt[b + j].allele == ent[j].allele;
+    if (!same) continue;
+    for (uint32_t j = 0; j < n; ++j) {
+      GroupEntry &g = groupEnt[b + j];
+      if (ent[j].start < g.start) g.start = ent[j].start;
+      if (ent[j].end < g.end) g.end = ent[j].start;
+      g.weight += ent[j].weight;
+      g.adjustWeight += ent[j].adjustWeight;
+    }
+    return;
+  }
+  bucket.push_back((uint32_t)nGroups());
+  groupEnt.insert(groupEnt.end(), ent, ent + n);
+  groupPtr.push_back(groupEnt.size());
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // FinalizeReadAssignments -> BuildAlleleEquivalentClass + missing coverage (Genotyper.hpp:912-939, 1072-1139;
 // SeqSet::GetSeqMissingBaseCoverage SeqSet.hpp:2717-2755)
@@ -128,25 +156,29 @@ void Genotyper::setAbundance(const double *n, const std::vector<int> &ecLen) {
 // ------------------------------------------------------------------------------------------------------------------
 // QuantifyAlleleEquivalentClass (Genotyper.hpp:1142-1328): SQUAREM-accelerated EM; every EMupdate is t1k_em_update
 // ------------------------------------------------------------------------------------------------------------------
-int Genotyper::quantify(t1k_ctx *ctx, t1k_allreduce_fn cb, void *user, std::string &err) {
+int Genotyper::quantify(t1k_ctx *ctx, t1k_allreduce_fn cb, void *user, std::string &err, uint64_t gBegin, uint64_t gEnd) {
   RefSet &R = *ref;
-  const size_t E = ecAlleles.size(), G = nGroups();
+  const size_t E = ecAlleles.size(), Gall = nGroups();
+  if (gEnd > Gall) gEnd = Gall;
+  if (gBegin > gEnd) gBegin = gEnd;
+  const size_t G = gEnd - gBegin;  // rows of the E-step handled by this GPU
   std::vector<uint64_t> rowPtr(G + 1, 0);
   std::vector<uint32_t> ecIdx;
   std::vector<double> count(G);
   std::vector<int> seen(E, 0);
-  for (size_t g = 0; g < G; ++g) {
+  for (size_t gl = 0; gl < G; ++gl) {
+    const size_t g = gBegin + gl;
     float c = groupEnt[groupPtr[g]].weight;
     for (uint64_t p = groupPtr[g] + 1; p < groupPtr[g + 1]; ++p)
       if (groupEnt[p].weight > c) c = groupEnt[p].weight;
-    count[g] = c;
+    count[gl] = c;
     for (uint64_t p = groupPtr[g]; p < groupPtr[g + 1]; ++p) {  // distinct classes of the row, first-appearance order (1165-1189)
       uint32_t ec = (uint32_t)R.al[groupEnt[p].allele].ec;
-      if (seen[ec] == (int)g + 1) continue;
-      seen[ec] = (int)g + 1;
+      if (seen[ec] == (int)gl + 1) continue;
+      seen[ec] = (int)gl + 1;
       ecIdx.push_back(ec);
     }
-    rowPtr[g + 1] = ecIdx.size();
+    rowPtr[gl + 1] = ecIdx.size();
   }
   std::vector<int> ecLen(E);
   for (size_t e = 0; e < E; ++e) {

@@ -27,7 +27,7 @@ struct t1k_job {
   std::vector<uint8_t> hasN, fragAssigned;
   bool hasBarcode = false;
   int maxReadLen = 0;
-  bool staged = false, ran = false;
+  bool staged = false, ran = false, localDone = false;
   std::vector<char> whitelist;      // per allele, empty = everything allowed
   std::string abundanceFile;
   std::string assignText;           // --outputReadAssignment rows
@@ -68,6 +68,9 @@ int t1k_job_create(const t1k_job_params *p, const char *refFasta, t1k_job **out)
   if (p) job->prm = *p; else t1k_job_params_default(&job->prm);
   *out = job;  // handed back even on failure so the caller can read the message
   if (!job->ref.load(refFasta, job->prm.allele_digit_units, job->prm.allele_delimiter, job->err)) return T1K_ERR_IO;
+  job->gt.ref = &job->ref;
+  job->gt.prm = job->prm;
+  if (job->prm.device < 0) return T1K_OK;  // host-only job: group bookkeeping for tests / merging, no device work possible
   int rc = t1k_ctx_create(job->prm.device, &job->prm.dev, &job->ctx);
   if (rc != T1K_OK) return jobFail(job, rc, "cannot create a GPU context on device " + std::to_string(job->prm.device) + " (this build has no CPU path)");
   // upload the reference
@@ -193,8 +196,8 @@ static bool loadAbundance(t1k_job *job) {
   return true;
 }
 
-int t1k_job_run(t1k_job *job) {
-  if (!job || !job->ctx) return T1K_ERR_STATE;
+int t1k_job_run_local(t1k_job *job) {
+  if (!job || !job->ctx) return jobFail(job, T1K_ERR_STATE, "this job has no GPU context (device = -1): it cannot run");
   int rc;
   if (!job->staged && (rc = t1k_job_stage_reads(job)) != T1K_OK) return rc;
   // fresh state (a job may be run repeatedly, e.g. by the benchmark)
@@ -234,7 +237,8 @@ int t1k_job_run(t1k_job *job) {
     job->stats.read_ends += st.read_ends; job->stats.lookups += st.lookups; job->stats.postings += st.postings; job->stats.hits += st.hits;
     job->stats.groups += st.groups; job->stats.candidates += st.candidates; job->stats.extended += st.extended; job->stats.near_best += st.near_best;
     job->stats.dp_calls += st.dp_calls; job->stats.ms_chain += st.ms_chain; job->stats.ms_extend += st.ms_extend; job->stats.ms_select += st.ms_select;
-    job->stats.ms_fullalign += st.ms_fullalign; job->stats.ms_pair += st.ms_pair;
+    job->stats.ms_fullalign += st.ms_fullalign; job->stats.ms_pair += st.ms_pair; job->stats.ms_seed += st.ms_seed; job->stats.batches += 1;
+    job->stats.rows += total;
     double t1 = nowMs();
     tDev += t1 - t0;
     uint64_t p = 0;
@@ -259,6 +263,15 @@ int t1k_job_run(t1k_job *job) {
     tHost += nowMs() - t1;
     b0 += nb;
   }
+  job->msDevice = tDev; job->msHost = tHost;
+  job->localDone = true;
+  return T1K_OK;
+}
+
+int t1k_job_finish(t1k_job *job, uint64_t emGroupBegin, uint64_t emGroupEnd) {
+  if (!job || !job->ctx || !job->localDone) return jobFail(job, T1K_ERR_STATE, "t1k_job_finish: t1k_job_run_local has not completed");
+  Genotyper &gt = job->gt;
+  int rc;
   double t2 = nowMs();
   std::vector<int32_t> cov;
   {
@@ -272,24 +285,85 @@ int t1k_job_run(t1k_job *job) {
   if (!job->abundanceFile.empty()) {
     if (!loadAbundance(job)) return T1K_ERR_IO;
   } else {
-    if (gt.quantify(job->ctx, job->allreduce, job->allreduceUser, job->err) < 0) return T1K_ERR_DEVICE;
+    if (gt.quantify(job->ctx, job->allreduce, job->allreduceUser, job->err, emGroupBegin, emGroupEnd) < 0) return T1K_ERR_DEVICE;
   }
   double t4 = nowMs();
   gt.dropUnlikely();
   double t4b = nowMs();
   gt.select();
   double t5 = nowMs();
-  job->msDevice = tDev; job->msHost = tHost + (t3 - t2) + (t5 - t4); job->msEm = t4 - t3;
-  job->stats.ms_total = tDev + tHost + (t5 - t2);
-  job->stats.ms_seed = job->msEm;  // reported as the EM time of the job
+  job->msHost += (t3 - t2) + (t5 - t4); job->msEm = t4 - t3;
+  job->stats.ms_total = job->msDevice + job->msHost + job->msEm;
+  job->stats.ms_em = job->msEm;
   if (getenv("T1K_DEBUG_PHASES"))
-    fprintf(stderr, "[t1k job] device+download %.1f ms, host coalesce %.1f ms, coverage+finalize %.1f ms, EM %.1f ms, dropUnlikely %.1f ms, select %.1f ms\n", tDev, tHost, t3 - t2, t4 - t3, t4b - t4, t5 - t4b);
+    fprintf(stderr, "[t1k job] device+download %.1f ms, host coalesce+finalize %.1f ms, EM %.1f ms, dropUnlikely %.1f ms, select %.1f ms\n", job->msDevice,
+            job->msHost, t4 - t3, t4b - t4, t5 - t4b);
   job->ran = true;
   return T1K_OK;
 }
 
+int t1k_job_run(t1k_job *job) {
+  int rc = t1k_job_run_local(job);
+  if (rc != T1K_OK) return rc;
+  return t1k_job_finish(job, 0, ~0ull);
+}
+
+// group table <-> byte string: [u64 nGroups][u64 nEntries][u64 assignedFragments][u64 groupPtr[nGroups+1]][GroupEntry entries[nEntries]]
+int t1k_job_groups_serialize(t1k_job *job, void *buf, uint64_t cap, uint64_t *needed) {
+  if (!job) return T1K_ERR_ARG;
+  const Genotyper &gt = job->gt;
+  const uint64_t G = gt.nGroups(), N = gt.groupEnt.size();
+  const uint64_t bytes = 24 + (G + 1) * 8 + N * sizeof(GroupEntry);
+  if (needed) *needed = bytes;
+  if (!buf) return T1K_OK;
+  if (cap < bytes) return jobFail(job, T1K_ERR_ARG, "group buffer too small");
+  uint8_t *p = (uint8_t *)buf;
+  uint64_t head[3] = {G, N, gt.assignedFragments};
+  memcpy(p, head, 24); p += 24;
+  memcpy(p, gt.groupPtr.data(), (G + 1) * 8); p += (G + 1) * 8;
+  if (N) memcpy(p, gt.groupEnt.data(), N * sizeof(GroupEntry));
+  return T1K_OK;
+}
+
+int t1k_job_groups_reset(t1k_job *job) {
+  if (!job) return T1K_ERR_ARG;
+  Genotyper &gt = job->gt;
+  gt.groupPtr.assign(1, 0); gt.groupEnt.clear(); gt.groupOfHash.clear(); gt.assignedFragments = 0;
+  return T1K_OK;
+}
+
+int t1k_job_groups_absorb(t1k_job *job, const void *buf, uint64_t len) {
+  if (!job || !buf || len < 24) return T1K_ERR_ARG;
+  const uint8_t *p = (const uint8_t *)buf;
+  uint64_t head[3];
+  memcpy(head, p, 24);
+  const uint64_t G = head[0], N = head[1];
+  if (len < 24 + (G + 1) * 8 + N * sizeof(GroupEntry)) return jobFail(job, T1K_ERR_ARG, "truncated group table");
+  const uint64_t *gp = (const uint64_t *)(p + 24);
+  const GroupEntry *ent = (const GroupEntry *)(p + 24 + (G + 1) * 8);
+  std::vector<GroupEntry> row;
+  for (uint64_t g = 0; g < G; ++g) {
+    row.assign(ent + gp[g], ent + gp[g + 1]);  // copy: the source may be unaligned for GroupEntry
+    job->gt.absorb(row.data(), (uint32_t)row.size());
+  }
+  job->gt.assignedFragments += head[2];
+  return T1K_OK;
+}
+
+int t1k_job_coalesce_rows(t1k_job *job, const t1k_row_entry *rows, const uint32_t *rowCounts, uint32_t nFragments) {
+  if (!job || !rowCounts || (!rows && nFragments)) return T1K_ERR_ARG;
+  std::vector<t1k_row_entry> tmp;
+  uint64_t p = 0;
+  for (uint32_t f = 0; f < nFragments; ++f) {
+    tmp.assign(rows + p, rows + p + rowCounts[f]);
+    p += rowCounts[f];
+    job->gt.coalesce(tmp.data(), (uint32_t)tmp.size());
+  }
+  return T1K_OK;
+}
+
 int t1k_job_genotype_text(t1k_job *job, char *buf, uint64_t cap, uint64_t *needed) {
-  if (!job || !job->ran) return T1K_ERR_STATE;
+  if (!job || !job->ran) return jobFail(job, T1K_ERR_STATE, "the job has not run");
   std::string s;
   for (size_t g = 0; g < job->ref.geneName.size(); ++g) s += job->gt.geneLine((int)g);
   if (needed) *needed = s.size();

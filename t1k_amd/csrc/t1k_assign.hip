@@ -181,7 +181,7 @@ __global__ __launch_bounds__(WG) void k_select(SelectArgs P) {
   uint64_t *sKey = dynLds;
   uint32_t *sIdx = (uint32_t *)(dynLds + SELECT_LDS_CAP);
   __shared__ uint32_t warpSums[4];
-  __shared__ int sLatch, sGood, sBest;
+  __shared__ int sLatch, sGood, sBest, sTie;
   __shared__ uint32_t sBase;
   const int tid = threadIdx.x;
   for (uint32_t re = blockIdx.x; re < P.reads.nReadEnds; re += gridDim.x) {
@@ -236,7 +236,13 @@ __global__ __launch_bounds__(WG) void k_select(SelectArgs P) {
     // resolve ties of the packed key with the remaining comparator fields (same allele, same spans)
     const uint32_t nAll = n;
     (void)nAll;
-    if (tid == 0) {
+    // equal packed keys (same allele, same spans and match count; rare) are ordered by the remaining comparator fields
+    if (tid == 0) { sTie = 0; sLatch = 0x7FFFFFFF; sGood = -1; sBest = -1; }
+    __syncthreads();
+    for (uint32_t i = 1 + tid; i < live; i += WG)
+      if (key[i] == key[i - 1]) sTie = 1;
+    __syncthreads();
+    if (sTie && tid == 0) {
       for (uint32_t i = 1; i < live; ++i) {
         if (key[i] != key[i - 1]) continue;
         uint32_t j = i;
@@ -245,7 +251,6 @@ __global__ __launch_bounds__(WG) void k_select(SelectArgs P) {
           --j;
         }
       }
-      sLatch = 0x7FFFFFFF; sGood = -1; sBest = -1;
     }
     __syncthreads();
     // latch position: first tried candidate whose extension fails (all candidates before the latch are tried)
@@ -579,7 +584,7 @@ __global__ __launch_bounds__(WG) void k_truncate(TruncArgs P) {
   extern __shared__ uint64_t dynLds[];
   uint64_t *sKey = dynLds;
   uint32_t *sIdx = (uint32_t *)(dynLds + SELECT_LDS_CAP);
-  __shared__ uint32_t sCut;
+  __shared__ uint32_t sCut, sTie2;
   const int tid = threadIdx.x;
   for (uint32_t re = blockIdx.x; re < P.reads.nReadEnds; re += gridDim.x) {
     const uint32_t n = P.ovlCount[re], o0 = P.ovlStart[re];
@@ -606,7 +611,12 @@ __global__ __launch_bounds__(WG) void k_truncate(TruncArgs P) {
     }
     __syncthreads();
     bitonicSort(key, idx, np2);
-    if (tid == 0) {
+    if (tid == 0) { sCut = n; sTie2 = 0; }
+    __syncthreads();
+    for (uint32_t i = 1 + tid; i < n; i += WG)
+      if (key[i] == key[i - 1]) sTie2 = 1;
+    __syncthreads();
+    if (sTie2 && tid == 0) {
       for (uint32_t i = 1; i < n; ++i) {
         if (key[i] != key[i - 1]) continue;
         uint32_t j = i;
@@ -615,7 +625,6 @@ __global__ __launch_bounds__(WG) void k_truncate(TruncArgs P) {
           --j;
         }
       }
-      sCut = n;
     }
     __syncthreads();
     {

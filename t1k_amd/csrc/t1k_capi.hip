@@ -213,6 +213,13 @@ int t1k_ref_upload(t1k_ctx *ctx, const char *seqs, const uint64_t *offsets, cons
   return T1K_OK;
 }
 
+int t1k_coverage_device(t1k_ctx *ctx, void **devPtr, uint64_t *count) {
+  if (!ctx || !ctx->ref.covDiff || !devPtr || !count) return t1k_fail(ctx, T1K_ERR_STATE, "no reference");
+  *devPtr = ctx->ref.covDiff;
+  *count = ctx->ref.totalBases + 2;
+  return T1K_OK;
+}
+
 int t1k_coverage_reset(t1k_ctx *ctx) {
   if (!ctx || !ctx->ref.covDiff) return t1k_fail(ctx, T1K_ERR_STATE, "no reference");
   T1K_HIP(ctx, hipSetDevice(ctx->device));
@@ -449,10 +456,12 @@ int t1k_assign_range(t1k_ctx *ctx, uint64_t first, uint32_t count) {
   t1k_stats &st = ctx->stats;
   st.read_ends = n; st.lookups = hc[3]; st.postings = hc[4]; st.hits = hc[5]; st.groups = hc[6]; st.candidates = hc[0]; st.extended = hc[1];
   st.dp_calls = hc[7] + hc[14]; st.near_best = hc[10];
-  float ms[4] = {0, 0, 0, 0};  // kernel durations from HIP events on the launch stream
+  float ms[4] = {0, 0, 0, 0}, msSeed = 0;  // kernel durations from HIP events on the launch stream
   for (int i = 0; i < 4; ++i) (void)hipEventElapsedTime(&ms[i], ctx->ev[i], ctx->ev[i + 1]);
+  (void)hipEventElapsedTime(&msSeed, ctx->ev[0], ctx->ev[8]);
   (void)t1; (void)t2; (void)t3;
-  st.ms_seed = 0; st.ms_chain = ms[0]; st.ms_extend = ms[1]; st.ms_select = ms[2]; st.ms_fullalign = ms[3]; st.ms_total = t4 - t0;
+  st.ms_seed = msSeed; st.ms_chain = ms[0] - msSeed; st.ms_extend = ms[1]; st.ms_select = ms[2]; st.ms_fullalign = ms[3]; st.ms_total = t4 - t0;
+  st.batches = 1;
   return T1K_OK;
 }
 

@@ -861,6 +861,7 @@ int t1k_run_chain(t1k_ctx *ctx, const ChainArgs &a, int nWg, int generalThreadsB
   T1K_HIP(ctx, hipFuncSetAttribute((const void *)k_seed_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   T1K_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
   hipLaunchKernelGGL(k_seed_scatter, dim3(nWg), dim3(WG), lds, ctx->stream, a);
+  T1K_HIP(ctx, hipEventRecord(ctx->ev[8], ctx->stream));
   int rc = readCounters(ctx, hc);
   if (rc) return rc;
   if (hc[2]) return 0;

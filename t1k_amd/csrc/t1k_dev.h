@@ -489,7 +489,7 @@ struct T1kDevBuf {
 struct t1k_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
-  hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev[12] = {};
   t1k_params prm;
   std::string err;
   // reference
