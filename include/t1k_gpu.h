@@ -46,7 +46,7 @@ typedef struct {
   /* device arena sizing (0 = defaults) */
   int32_t max_read_len;         /* longest read accepted, default 320 */
   int32_t workgroups;           /* persistent workgroups of the per-read-end kernels, default 1024 */
-  int64_t hit_cap;              /* k-mer hit slots (u32) per batch, < 2^32 */
+  int64_t hit_cap;              /* unused (kept for ABI stability) */
   int64_t group_cap;            /* (read-end, strand, allele) hit groups per batch */
   int64_t cand_cap;             /* candidate records per batch */
   int64_t ovl_cap;              /* overlap records per batch */

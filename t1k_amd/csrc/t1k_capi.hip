@@ -53,7 +53,7 @@ void t1k_params_default(t1k_params *p) {
   p->max_assign_cnt = 2000;
   p->max_read_len = 320;
   p->workgroups = 512;
-  p->hit_cap = 3ll << 30;
+  p->hit_cap = 0;
   p->group_cap = 160ll << 20;
   p->cand_cap = 256ll << 20;
   p->ovl_cap = 160ll << 20;
@@ -83,13 +83,12 @@ int t1k_ctx_create(int device, const t1k_params *params, t1k_ctx **out) {
   if (ctx->prm.max_assign_cnt == 0) ctx->prm.max_assign_cnt = d.max_assign_cnt;
   if (ctx->prm.max_read_len <= 0) ctx->prm.max_read_len = d.max_read_len;
   if (ctx->prm.workgroups <= 0) ctx->prm.workgroups = d.workgroups;
-  if (ctx->prm.hit_cap <= 0) ctx->prm.hit_cap = d.hit_cap;
   if (ctx->prm.group_cap <= 0) ctx->prm.group_cap = d.group_cap;
-  if (ctx->prm.hit_cap > 0xFFFFFFF0ll) ctx->prm.hit_cap = 0xFFFFFFF0ll;
+
   if (ctx->prm.cand_cap <= 0) ctx->prm.cand_cap = d.cand_cap;
   if (ctx->prm.ovl_cap <= 0) ctx->prm.ovl_cap = d.ovl_cap;
   if (ctx->prm.row_cap <= 0) ctx->prm.row_cap = d.row_cap;
-  if (ctx->prm.kmer_length > 14 || ctx->prm.max_read_len > 2000) { delete ctx; return T1K_ERR_ARG; }
+  if (ctx->prm.kmer_length > 14 || ctx->prm.max_read_len > 320) { delete ctx; return T1K_ERR_ARG; }  // the hit-offset bitmask of the chain kernels spans 320 positions
   if (hipStreamCreate(&ctx->stream) != hipSuccess) { delete ctx; return T1K_ERR_DEVICE; }
   for (auto &e : ctx->ev) if (hipEventCreate(&e) != hipSuccess) { delete ctx; return T1K_ERR_DEVICE; }
   *out = ctx;
@@ -336,17 +335,19 @@ int t1k_assign_range(t1k_ctx *ctx, uint64_t first, uint32_t count) {
   int rc;
   const int nWg = (int)std::min<uint32_t>((uint32_t)ctx->prm.workgroups, std::max<uint32_t>(n, 1));
   const uint32_t sortCap = 1u << 15;
-  const int maxChunks = t1k_chain_max_chunks(), memoN = t1k_chain_memo_entries();
-  const uint64_t hitCap = (uint64_t)ctx->prm.hit_cap, groupCap = (uint64_t)ctx->prm.group_cap;
-  const uint32_t jobCap = 16u << 20;
-  const int generalBlocks = 1, bigBlocks = 32;
+  const int maxChunks = t1k_chain_max_chunks(ctx->ref.nAlleles), memoN = t1k_chain_memo_entries();
+  const bool longReads = ctx->batchMaxLen > 160;
+  const int recStride = t1k_chain_rec_stride(ctx->batchMaxLen);
+  const uint64_t groupCap = (uint64_t)ctx->prm.group_cap;
+  const uint32_t jobCap = 16u << 20, genCandCap = 32u << 20;
+  const int bigBlocks = 32;
   if ((rc = t1k_ensure(ctx, ctx->bCounters, 64 * 8))) return rc;
-  if ((rc = t1k_ensure(ctx, ctx->bWgHits, hitCap * 4))) return rc;                                        // batch hit arena
-  if ((rc = t1k_ensure(ctx, ctx->bWgGroups, groupCap * sizeof(T1kGroup)))) return rc;                     // batch group arena
+  if ((rc = t1k_ensure(ctx, ctx->bWgGroups, groupCap * recStride * 4))) return rc;                        // batch group records
   if ((rc = t1k_ensure(ctx, ctx->bWgStage, (size_t)n * maxChunks * 8 + 64))) return rc;                   // chunkStart | chunkCount
+  if ((rc = t1k_ensure(ctx, ctx->bWgHits, (size_t)n * (t1k_chain_used_u32(rd.S) + 2) * 4 + 64))) return rc;  // used k-mer lists | counts
   if ((rc = t1k_ensure(ctx, ctx->bWgCache, (size_t)n * memoN * 8 + 64))) return rc;                       // per-read-end memo
   if ((rc = t1k_ensure(ctx, ctx->bWgBig, (size_t)bigBlocks * 64 * t1k_chain_big_scratch_u32() * 4))) return rc;
-  if ((rc = t1k_ensure(ctx, ctx->bLists, (size_t)jobCap * 4 + groupCap * 4 * 3 + 64))) return rc;        // jobList | retry | general | big
+  if ((rc = t1k_ensure(ctx, ctx->bLists, (size_t)jobCap * 4 + groupCap * 4 * 3 + (size_t)genCandCap * 12 + 64))) return rc;  // jobs | retry | general | big | genCand
   if ((rc = t1k_ensure(ctx, ctx->bCand, (size_t)ctx->prm.cand_cap * sizeof(T1kCand)))) return rc;
   if ((rc = t1k_ensure(ctx, ctx->bExt, (size_t)ctx->prm.cand_cap * sizeof(T1kExt)))) return rc;
   if ((rc = t1k_ensure(ctx, ctx->bOvl, (size_t)ctx->prm.ovl_cap * sizeof(T1kOvl)))) return rc;
@@ -369,17 +370,18 @@ int t1k_assign_range(t1k_ctx *ctx, uint64_t first, uint32_t count) {
   a.k = ctx->prm.kmer_length; a.radius = ctx->prm.radius; a.hitLenRequired = ctx->prm.hit_len_required;
   a.sim = ctx->prm.ref_seq_similarity;
   const int relaxFlag = ctx->prm.relax_intron_align;
-  a.hits = (uint32_t *)ctx->bWgHits.p; a.hitCap = hitCap;
-  a.groups = (T1kGroup *)ctx->bWgGroups.p; a.groupCap = groupCap;
-  a.chunkStart = (uint32_t *)ctx->bWgStage.p; a.chunkCount = a.chunkStart + (size_t)n * maxChunks;
+  a.recs = (uint32_t *)ctx->bWgGroups.p; a.recStride = (uint32_t)recStride; a.groupCap = groupCap;
+  a.chunkStart = (uint32_t *)ctx->bWgStage.p; a.chunkCount = a.chunkStart + (size_t)n * maxChunks; a.maxChunks = maxChunks;
+  a.usedOut = (uint32_t *)ctx->bWgHits.p; a.usedCount = a.usedOut + (size_t)n * t1k_chain_used_u32(rd.S);
   a.memo = (unsigned long long *)ctx->bWgCache.p;
   a.jobList = (uint32_t *)ctx->bLists.p; a.jobCap = jobCap;
   a.retryList = a.jobList + jobCap; a.generalList = a.retryList + groupCap; a.bigList = a.generalList + groupCap;
-  a.threadScratch = (uint32_t *)ctx->bWgThreadScratch.p; a.bigScratch = (uint32_t *)ctx->bWgBig.p;
+  a.genCand = a.bigList + groupCap; a.genCandCap = genCandCap;
+  a.bigScratch = (uint32_t *)ctx->bWgBig.p;
   a.cand = (T1kCand *)ctx->bCand.p; a.candCap = (uint64_t)ctx->prm.cand_cap;
   a.candStart = (uint32_t *)ctx->bCandStart.p; a.candCount = (uint32_t *)ctx->bCandCount.p;
   a.counters = (unsigned long long *)ctx->bCounters.p;
-  if ((rc = t1k_run_chain(ctx, a, nWg, generalBlocks, bigBlocks, hc))) return rc;
+  if ((rc = t1k_run_chain(ctx, a, nWg, bigBlocks, longReads, hc))) return rc;
   double t1 = nowMs();
   if (hc[2]) return capacityError(ctx, hc[2]);
   ctx->nCand = hc[0];

@@ -1,9 +1,10 @@
 // t1k_amd/csrc/t1k_chain.hip -- seeding, hit grouping and chaining of SeqSet::AssignRead on gfx950, as a sequence of flat,
 // batch-wide kernels (all integer, HBM/LDS-bound; no MFMA):
 //
-//   k_seed_scatter  one 256-thread workgroup per read-end: rolling 11-mers + direct-address look-up with the >=100 skip
-//                   rule (GetHitsFromRead, SeqSet.hpp:1071-1229); per (strand, allele tile) an LDS histogram -> counting
-//                   sort of the hits by (strand, allele) (SortHits 1558-1590) into the batch hit arena; groups with fewer
+//   k_seed_groups   one 256-thread workgroup per read-end: rolling 11-mers + direct-address look-up with the >=100 skip
+//                   rule (GetHitsFromRead, SeqSet.hpp:1071-1229); per (strand, 1024-allele chunk) the hits are folded into
+//                   per-allele LDS accumulators (reference diagonal, bitmask of hit offsets, stray counts), i.e. grouped by
+//                   (strand, allele) as SortHits 1558-1590 does, and one record per group leaves the chip; groups with fewer
 //                   than 3 hits are never written (refMinHitRequired, 1253/1314)
 //   k_chain_fast    one lane per (read-end, strand, allele) group over the whole batch: single-diagonal fast path
 //                   (GetOverlapsFromHits 1232-1556 + seed-chain match count 1697-1848); alignments that need a DP are
@@ -17,13 +18,11 @@
 #include "t1k_launch.h"
 
 #define WG 256
-#define TILE_ALLELES 8192           // LDS histogram tile (u32 per allele): 32 KB -> 4 workgroups per CU
 #define GROUP_FAST_MAXLEN 320
 #define GENERAL_CAP 128             // hits per group handled by k_chain_general in private memory; larger groups: k_chain_big
 #define BIG_CAP 16384
 #define GA_BIG_MAX 2048
 #define GA_SCRATCH_INTS (6 * (GA_BIG_MAX + 4))
-#define MAX_CHUNKS 16               // (2 strands) x (allele tiles) per read-end
 
 enum { ERR_HITCAP = 1, ERR_STAGECAP = 2, ERR_CANDCAP = 4, ERR_BIGGROUP = 8, ERR_OVLCAP = 16, ERR_SORTCAP = 32, ERR_SLOWCAP = 64, ERR_ROWCAP = 128, ERR_GROUPCAP = 256 };
 
@@ -154,10 +153,9 @@ __device__ inline int gapMatchesCached(const ReadCtx &c, int readPos, int64_t gp
 
 // Single-diagonal group (the common case: the read differs from the allele by substitutions only).
 // NW = number of 32-position words covering a read (5: reads <= 160 bp, 10: reads <= 320 bp).
-//   * the group's hits are fetched in one burst of independent loads (<= 32 hits; larger groups loop)
-//   * majority diagonal by Boyer-Moore vote; every other hit must lie more than `radius` diagonals away (it cannot join the
-//     main run, SeqSet.hpp:1360-1392) and there may be at most two such strays (they cannot form a run of >= 3 hits,
-//     1400-1405); anything else goes to the general path
+//   * input: the group's reference diagonal and the bitmask M of read offsets hitting it, accumulated by k_seed_groups; the
+//     caller has checked that every other hit lies more than `radius` diagonals away (it cannot join this run,
+//     SeqSet.hpp:1360-1392) and that there are at most two such strays (they cannot form a run of >= 3 hits, 1400-1405)
 //   * on one diagonal the LIS is the identity and both hit lengths are equal; with M = bitmask of hit read-offsets,
 //     covered = popcount(dilate(M, k)) and matchCnt = 2*covered + 2*sum over gaps of GlobalAlignment matches (1697-1760)
 //   * a gap with x <= 3 mismatches aligns ungapped (g - x matches, exact, see t1k_ga_matches_window); if the whole span
@@ -166,71 +164,17 @@ __device__ inline int gapMatchesCached(const ReadCtx &c, int readPos, int64_t gp
 //     if U / (2*span) < -s the candidate is certain to fail the similarity filter (1838-1840, 1894-1908) and is emitted
 //     with matchCnt = U (it is dropped by k_extend either way, and the strand vote only reads matchCnt0)
 template <int NW, bool DEFER>
-__device__ inline int groupFastPath(const uint32_t *h, int n, const ReadCtx &c, int k, int radius, int hitLenRequired, double simThreshold, CandOut &out,
+__device__ inline int groupFastPath(const uint32_t *Mw, int diag, const ReadCtx &c, int k, int hitLenRequired, double simThreshold, CandOut &out,
                                     unsigned int *dpCounter, int strandBit, unsigned long long *cache, uint32_t *jobList, uint32_t *jobCount, uint32_t jobTag,
                                     uint32_t jobCap) {
   constexpr int MW = (NW + 1) / 2;  // 64-bit words of the read-offset bitmask
   uint64_t M[MW];
+  int onDiag = 0;
 #pragma unroll
-  for (int i = 0; i < MW; ++i) M[i] = 0;
-  int diag = 0, votes = 0, strays = 0, onDiag = 0;
-  if (n <= 32) {
-    uint32_t hr[32];
-#pragma unroll
-    for (int i = 0; i < 32; ++i) hr[i] = i < n ? h[i] : 0u;
-#pragma unroll
-    for (int i = 0; i < 32; ++i) {
-      if (i < n) {
-        int d = (int)(hr[i] & 0xFFF) - (int)(hr[i] >> 12);
-        if (votes == 0) { diag = d; votes = 1; }
-        else if (d == diag) ++votes;
-        else --votes;
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < 32; ++i) {
-      if (i < n) {
-        int a = (int)(hr[i] & 0xFFF);
-        int d = a - (int)(hr[i] >> 12) - diag;
-        if (d != 0) {
-          if (d < 0) d = -d;
-          if (d <= radius) return 0;
-          ++strays;
-        } else {
-          if (a >= NW * 32) return 0;
-          ++onDiag;
-#pragma unroll
-          for (int w = 0; w < MW; ++w)
-            if ((a >> 6) == w) M[w] |= 1ull << (a & 63);
-        }
-      }
-    }
-  } else {
-    for (int i = 0; i < n; ++i) {
-      uint32_t x = h[i];
-      int d = (int)(x & 0xFFF) - (int)(x >> 12);
-      if (votes == 0) { diag = d; votes = 1; }
-      else if (d == diag) ++votes;
-      else --votes;
-    }
-    for (int i = 0; i < n; ++i) {
-      uint32_t x = h[i];
-      int a = (int)(x & 0xFFF);
-      int d = a - (int)(x >> 12) - diag;
-      if (d != 0) {
-        if (d < 0) d = -d;
-        if (d <= radius) return 0;
-        ++strays;
-      } else {
-        if (a >= NW * 32) return 0;
-        ++onDiag;
-#pragma unroll
-        for (int w = 0; w < MW; ++w)
-          if ((a >> 6) == w) M[w] |= 1ull << (a & 63);
-      }
-    }
+  for (int i = 0; i < MW; ++i) {
+    M[i] = (uint64_t)Mw[2 * i] | ((2 * i + 1 < NW) ? ((uint64_t)Mw[2 * i + 1] << 32) : 0ull);
+    onDiag += __popcll(M[i]);
   }
-  if (strays > 2) return 0;
   if (onDiag < 3) return 1;  // minHitRequired (1314, 1400)
   if (onDiag * k < hitLenRequired) return 1;
   int first = -1, last = -1;
@@ -502,33 +446,49 @@ __device__ __forceinline__ VoteKey voteKey(int matchCnt0, int rs, int re, uint32
 
 
 // ------------------------------------------------------------------------------------------------------------------
-// K1: seeds -> hits grouped by (strand, allele)
+// K1: seeds -> one record per (strand, allele) group, built in LDS in a single pass over the posting lists
+//
+// Alleles are processed in chunks of CHUNK_A; each allele of the chunk owns an accumulator in LDS:
+//   diag  reference diagonal = diagonal of the first hit that arrived (any choice is valid, see groupFastPath)
+//   M     bitmask of the read offsets whose k-mer hits the allele on that diagonal
+//   meta  number of hits on other diagonals (low 16 bits) and how many of those lie within `radius` (high 16 bits)
+// Posting lists are sorted by allele, so the chunk's slice of every used list is found by binary search from a cursor.
+// A group record leaves the chip once, coalesced; no hit list is ever written.
 // ------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(WG) void k_seed_scatter(ChainArgs P) {
+#define CHUNK_A 1024
+#define DIAG_EMPTY 0x7FFFFFFF
+
+template <int NW>
+__global__ __launch_bounds__(WG) void k_seed_groups(ChainArgs P) {
+  constexpr int AW = NW == 5 ? 8 : 12;  // u32 per accumulator: diag, meta, M[NW] (+ pad)
   extern __shared__ uint32_t lds[];
   const int k = P.k;
   const int maxK = 2 * (P.reads.S * 32);
-  uint32_t *hist = lds;                             // [TILE_ALLELES]
-  uint32_t *ukCode = hist + TILE_ALLELES;           // [maxK]  code | valid << 31
+  uint32_t *acc = lds;                              // [CHUNK_A][AW]
+  uint32_t *ukCode = acc + CHUNK_A * AW;            // [maxK]  code | valid << 31
   uint32_t *ukStart = ukCode + maxK;                // [maxK]
   uint32_t *ukLen = ukStart + maxK;                 // [maxK]
-  uint32_t *tLo = ukLen + maxK;                     // [maxK]  posting sub-range of the current allele tile
-  uint32_t *tHi = tLo + maxK;                       // [maxK]
-  uint16_t *usedQ = (uint16_t *)(tHi + maxK);       // [maxK]
+  uint32_t *cur = ukLen + maxK;                     // [maxK]  per used list: cursor (end of the previous chunk's slice)
+  uint32_t *sLo = cur + maxK;                       // [maxK]  slice of the current chunk
+  uint32_t *pre = sLo + maxK;                       // [maxK + 1] exclusive prefix of the slice lengths
+  uint16_t *usedQ = (uint16_t *)(pre + maxK + 1);   // [maxK]
   __shared__ uint32_t warpSums[4];
-  __shared__ uint32_t sUsed[2], sHitBase, sGroupBase;
+  __shared__ uint32_t sUsed[2], sGroupBase, sTotal;
   const int tid = threadIdx.x;
   const uint32_t kmask = (1u << (2 * k)) - 1;
-  const int nTiles = (int)((P.ref.nAlleles + TILE_ALLELES - 1) / TILE_ALLELES);
+  const uint32_t A = P.ref.nAlleles;
+  const uint32_t stride = P.recStride;
+  for (uint32_t i = tid; i < CHUNK_A * AW; i += WG) acc[i] = (i % AW) == 0 ? (uint32_t)DIAG_EMPTY : 0u;
+  __syncthreads();
   for (uint32_t re = blockIdx.x; re < P.reads.nReadEnds; re += gridDim.x) {
     const int len = P.reads.len[re];
     const int S = P.reads.S;
     const uint64_t *rbase = P.reads.bases + (uint64_t)re * 2 * S;
     const uint64_t *rnm = P.reads.nmask + (uint64_t)re * 2 * S;
-    for (int c = tid; c < MAX_CHUNKS; c += WG) P.chunkCount[(uint64_t)re * MAX_CHUNKS + c] = 0;
+    for (int c = tid; c < P.maxChunks; c += WG) P.chunkCount[(uint64_t)re * P.maxChunks + c] = 0;
+    if (tid == 0) { P.usedCount[2 * re] = 0; P.usedCount[2 * re + 1] = 0; }
     if (len < k) { __syncthreads(); continue; }  // GetOverlapsFromRead returns -1 (SeqSet.hpp:1598-1599)
     const int nk = len - k + 1;
-    // ---- k-mer codes and posting-list bounds for both strands ----------------------------------------------------
     for (int q = tid; q < 2 * nk; q += WG) {
       int pass = q / nk, p = q - pass * nk;
       const uint64_t *b = rbase + pass * S, *nm = rnm + pass * S;
@@ -540,7 +500,7 @@ __global__ __launch_bounds__(WG) void k_seed_scatter(ChainArgs P) {
       ukStart[q] = st; ukLen[q] = ln;
     }
     __syncthreads();
-    // ---- the sequential look-up rule (SeqSet.hpp:1098-1153, 1165-1226) --------------------------------
+    // the sequential look-up rule (SeqSet.hpp:1098-1153, 1165-1226)
     if (tid == 0) {
       uint32_t prev = 0;  // prevKmerCode starts at code 0 and is carried from the + strand into the - strand
       uint32_t nUsed = 0;
@@ -564,96 +524,131 @@ __global__ __launch_bounds__(WG) void k_seed_scatter(ChainArgs P) {
       }
       atomicAdd(&P.counters[3], lookups);
       atomicAdd(&P.counters[4], postings);
+      P.usedCount[2 * re] = sUsed[0]; P.usedCount[2 * re + 1] = sUsed[1];
     }
     __syncthreads();
     const uint32_t nUsedPlus = sUsed[0], nUsedMinus = sUsed[1];
+    // the used lists are kept for k_chain_general, which re-derives the hits of the few multi-diagonal groups
+    {
+      uint32_t *uo = P.usedOut + (uint64_t)re * maxK * 3;
+      for (uint32_t u = tid; u < nUsedPlus + nUsedMinus; u += WG) {
+        int q = usedQ[u];
+        int pass = u < nUsedPlus ? 0 : 1;
+        uo[3 * u] = (uint32_t)(q - pass * nk); uo[3 * u + 1] = ukStart[q]; uo[3 * u + 2] = ukLen[q];
+      }
+    }
     int chunk = 0;
+    unsigned long long hitsLocal = 0;
     for (int sp = 0; sp < 2; ++sp) {  // '-' strand first (SortHits 1577-1583)
       const int pass = sp == 0 ? 1 : 0;
       const uint32_t uBegin = pass == 0 ? 0 : nUsedPlus;
       const uint32_t uCount = pass == 0 ? nUsedPlus : nUsedMinus;
       if (uCount == 0) continue;
-      for (int tile = 0; tile < nTiles; ++tile) {
-        const uint32_t a0 = (uint32_t)tile * TILE_ALLELES;
-        const uint32_t a1 = min(a0 + TILE_ALLELES, P.ref.nAlleles);
-        for (uint32_t i = tid; i < TILE_ALLELES; i += WG) hist[i] = 0;
-        // posting lists are sorted by allele: restrict every used list to the tile with two binary searches
+      for (uint32_t u = tid; u < uCount; u += WG) cur[u] = 0;
+      __syncthreads();
+      for (uint32_t c0 = 0; c0 < A; c0 += CHUNK_A) {
+        const uint32_t c1 = min(c0 + CHUNK_A, A);
+        // slice of every used list inside [c0, c1): lower bound of c1 from the cursor
         for (uint32_t u = tid; u < uCount; u += WG) {
-          int q = usedQ[uBegin + u];
-          uint32_t st = ukStart[q], ln = ukLen[q];
-          uint32_t lo = 0, hi = ln;
-          if (nTiles > 1) {
-            uint32_t l = 0, r = ln;
-            while (l < r) { uint32_t m = (l + r) >> 1; if (P.ref.kPost[st + m].allele < a0) l = m + 1; else r = m; }
-            lo = l; r = ln;
-            while (l < r) { uint32_t m = (l + r) >> 1; if (P.ref.kPost[st + m].allele < a1) l = m + 1; else r = m; }
-            hi = l;
-          }
-          tLo[u] = st + lo; tHi[u] = st + hi;
+          const int q = usedQ[uBegin + u];
+          const uint32_t st = ukStart[q], ln = ukLen[q];
+          uint32_t l = cur[u], r = ln;
+          // gallop a little before the binary search: slices are short compared with the list
+          if (l < ln && P.ref.kPost[st + l].allele >= c1) r = l;
+          while (l < r) { uint32_t m = (l + r) >> 1; if (P.ref.kPost[st + m].allele < c1) l = m + 1; else r = m; }
+          sLo[u] = cur[u];
+          pre[u] = l - cur[u];  // slice length, turned into an exclusive prefix below
+          cur[u] = l;
         }
         __syncthreads();
-        for (uint32_t u = 0; u < uCount; ++u) {
-          const uint32_t b = tLo[u], e = tHi[u];
-          for (uint32_t x = b + tid; x < e; x += WG) atomicAdd(&hist[P.ref.kPost[x].allele - a0], 1u);
-        }
-        __syncthreads();
-        // scan: groups with >= 3 hits (refMinHitRequired, SeqSet.hpp:1253, 1314) get a slice of the hit arena
-        const int EPT = TILE_ALLELES / WG;
-        uint32_t hSum = 0, gSum = 0;
-        for (int i = 0; i < EPT; ++i) {
-          uint32_t c = hist[tid * EPT + i];
-          if (c >= 3) { hSum += c; ++gSum; }
-        }
-        uint32_t hTot, gTot;
-        uint32_t hOff = t1k_block_scan_exclusive(hSum, warpSums, &hTot);
-        uint32_t gOff = t1k_block_scan_exclusive(gSum, warpSums, &gTot);
         if (tid == 0) {
-          unsigned long long hb = atomicAdd(&P.counters[5], (unsigned long long)hTot);
-          unsigned long long gb = atomicAdd(&P.counters[6], (unsigned long long)gTot);
-          if (hb + hTot > P.hitCap) { atomicOr(&P.counters[2], (unsigned long long)ERR_HITCAP); hb = ~0ull; }
-          if (gb + gTot > P.groupCap || chunk >= MAX_CHUNKS) { atomicOr(&P.counters[2], (unsigned long long)ERR_GROUPCAP); hb = ~0ull; }
-          sHitBase = hb == ~0ull ? 0xFFFFFFFFu : (uint32_t)hb;
-          sGroupBase = (uint32_t)gb;
-          if (hb != ~0ull) { P.chunkStart[(uint64_t)re * MAX_CHUNKS + chunk] = (uint32_t)gb; P.chunkCount[(uint64_t)re * MAX_CHUNKS + chunk] = gTot; }
+          uint32_t run = 0;
+          for (uint32_t u = 0; u < uCount; ++u) { uint32_t n = pre[u]; pre[u] = run; run += n; }
+          pre[uCount] = run;
+          sTotal = run;
         }
         __syncthreads();
-        const uint32_t hitBase = sHitBase, groupBase = sGroupBase;
-        if (hitBase == 0xFFFFFFFFu) { __syncthreads(); continue; }
-        ++chunk;
-        for (int i = 0; i < EPT; ++i) {
-          uint32_t idx = tid * EPT + i;
-          uint32_t c = hist[idx];
-          if (c >= 3) {
-            T1kGroup g;
-            g.reStrand = re | (pass == 0 ? 0x80000000u : 0);  // bit31: '+' strand
-            g.allele = a0 + idx; g.hitStart = hitBase + hOff; g.n = c;
-            P.groups[(uint64_t)groupBase + gOff] = g;
-            hist[idx] = hitBase + hOff;
-            hOff += c; ++gOff;
-          } else hist[idx] = 0xFFFFFFFFu;
-        }
-        __syncthreads();
-        // scatter the hits of surviving groups: packed (alleleOffset << 12 | readOffset)
-        for (uint32_t u = 0; u < uCount; ++u) {
-          const uint32_t b = tLo[u], e = tHi[u];
-          const uint32_t rOff = (uint32_t)(usedQ[uBegin + u] - pass * nk);
-          for (uint32_t x = b + tid; x < e; x += WG) {
-            T1kPosting pst = P.ref.kPost[x];
-            if (hist[pst.allele - a0] != 0xFFFFFFFFu) {
-              uint32_t pos = atomicAdd(&hist[pst.allele - a0], 1u);
-              P.hits[pos] = (pst.offset << 12) | rOff;
-            }
+        const uint32_t T = sTotal;
+        if (T == 0) { __syncthreads(); continue; }
+        if (tid == 0) hitsLocal += T;
+        // walk the chunk's postings (flat index -> list by binary search over the prefix)
+        for (uint32_t j = tid; j < T; j += WG) {
+          uint32_t lo = 0, hi = uCount;
+          while (hi - lo > 1) { uint32_t m = (lo + hi) >> 1; if (pre[m] <= j) lo = m; else hi = m; }
+          const uint32_t u = lo;
+          const int q = usedQ[uBegin + u];
+          const T1kPosting pst = P.ref.kPost[ukStart[q] + sLo[u] + (j - pre[u])];
+          const int r = q - pass * nk;
+          const int d = r - (int)pst.offset;
+          uint32_t *a = acc + (pst.allele - c0) * AW;
+          const uint32_t old = atomicCAS(&a[0], (uint32_t)DIAG_EMPTY, (uint32_t)d);
+          if (old == (uint32_t)DIAG_EMPTY || old == (uint32_t)d) atomicOr(&a[2 + (r >> 5)], 1u << (r & 31));
+          else {
+            int dd = d - (int)old; if (dd < 0) dd = -dd;
+            atomicAdd(&a[1], dd <= P.radius ? 0x10001u : 1u);
           }
+        }
+        __syncthreads();
+        // emit the groups that can still produce a candidate: >= 3 hits in total, and either >= 3 on the reference diagonal
+        // or some hit close enough to chain with it, or > 2 strays (which could form their own run)
+        const int EPT = CHUNK_A / WG;
+        uint32_t mine = 0, flags = 0;
+        for (int i = 0; i < EPT; ++i) {
+          const uint32_t idx = tid * EPT + i;
+          const uint32_t *a = acc + idx * AW;
+          if (a[0] == (uint32_t)DIAG_EMPTY) continue;
+          int onDiag = 0;
+#pragma unroll
+          for (int w = 0; w < NW; ++w) onDiag += __popc(a[2 + w]);
+          const uint32_t strays = a[1] & 0xFFFFu, nearCnt = a[1] >> 16;
+          const bool general = nearCnt > 0 || strays > 2;
+          if (onDiag + (int)strays >= 3 && (general || onDiag >= 3)) { ++mine; flags |= 1u << i; }
+        }
+        uint32_t gTot;
+        uint32_t gOff = t1k_block_scan_exclusive(mine, warpSums, &gTot);
+        if (tid == 0) {
+          unsigned long long gb = gTot ? atomicAdd(&P.counters[6], (unsigned long long)gTot) : 0ull;
+          bool ok = gb + gTot <= P.groupCap && chunk < P.maxChunks;
+          if (!ok) atomicOr(&P.counters[2], (unsigned long long)ERR_GROUPCAP);
+          sGroupBase = ok ? (uint32_t)gb : 0xFFFFFFFFu;
+          if (ok && gTot) { P.chunkStart[(uint64_t)re * P.maxChunks + chunk] = (uint32_t)gb; P.chunkCount[(uint64_t)re * P.maxChunks + chunk] = gTot; }
+        }
+        __syncthreads();
+        const uint32_t groupBase = sGroupBase;
+        if (gTot) ++chunk;
+        for (int i = 0; i < EPT; ++i) {
+          const uint32_t idx = tid * EPT + i;
+          uint32_t *a = acc + idx * AW;
+          if (a[0] == (uint32_t)DIAG_EMPTY) continue;
+          if ((flags >> i) & 1u) {
+            if (groupBase != 0xFFFFFFFFu) {
+              uint32_t *rec = P.recs + (uint64_t)(groupBase + gOff) * stride;
+              rec[0] = re | (pass == 0 ? 0x80000000u : 0);  // bit31: '+' strand
+              rec[1] = c0 + idx;
+              rec[2] = a[0];
+              rec[3] = a[1];
+#pragma unroll
+              for (int w = 0; w < NW; ++w) rec[4 + w] = a[2 + w];
+            }
+            ++gOff;
+          }
+          a[0] = (uint32_t)DIAG_EMPTY; a[1] = 0;
+#pragma unroll
+          for (int w = 0; w < NW; ++w) a[2 + w] = 0;
         }
         __syncthreads();
       }
     }
+    if (tid == 0 && hitsLocal) atomicAdd(&P.counters[5], hitsLocal);
   }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// K2 / K4: single-diagonal chain, one lane per group
+// K2 / K4: single-diagonal chain, one lane per group record
+// record words: 0 re|strand, 1 allele, 2 diag, 3 meta, 4.. M   -> after chaining: 3 = state, 4..6 packed candidate / side-arena ref
 // ------------------------------------------------------------------------------------------------------------------
+enum { REC_DONE = 0x80000000u };  // word 3 after chaining: REC_DONE | number of candidates (general groups: candidates in the side arena)
+
 __device__ __forceinline__ ReadCtx makeCtx(const ChainArgs &P, uint32_t re, int pass, uint32_t allele) {
   const int S = P.reads.S;
   ReadCtx c{P.reads.bases + ((uint64_t)re * 2 + pass) * S, P.reads.nmask + ((uint64_t)re * 2 + pass) * S, (int)P.reads.len[re], P.ref.bases, P.ref.nmask,
@@ -666,29 +661,34 @@ __device__ __forceinline__ void waveFlush(unsigned long long *counter, unsigned 
   if ((threadIdx.x & 63) == 0 && v) atomicAdd(counter, (unsigned long long)v);
 }
 
-template <bool DEFER>
+template <int NW, bool DEFER>
 __global__ __launch_bounds__(WG) void k_chain_fast(ChainArgs P, const uint32_t *list, uint32_t nItems) {
   const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   unsigned int dpLocal = 0, fastLocal = 0;
   if (gid < nItems) {
     const uint32_t gi = list ? list[gid] : (uint32_t)gid;
-    const T1kGroup g = P.groups[gi];
-    const uint32_t re = g.reStrand & 0x7FFFFFFFu;
-    const int pass = (g.reStrand >> 31) ? 0 : 1;
-    ReadCtx c = makeCtx(P, re, pass, g.allele);
-    CandOut out{P.hits + g.hitStart, 0};
-    unsigned long long *memo = P.memo + (uint64_t)re * GAP_CACHE;
-    int done = 0;
-    if (c.len <= 160)
-      done = groupFastPath<5, DEFER>(P.hits + g.hitStart, (int)g.n, c, P.k, P.radius, P.hitLenRequired, P.sim, out, &dpLocal, pass, memo, P.jobList,
-                                     (uint32_t *)&P.counters[16], re * GAP_CACHE, P.jobCap);
-    else if (c.len <= GROUP_FAST_MAXLEN)
-      done = groupFastPath<10, DEFER>(P.hits + g.hitStart, (int)g.n, c, P.k, P.radius, P.hitLenRequired, P.sim, out, &dpLocal, pass, memo, P.jobList,
-                                      (uint32_t *)&P.counters[16], re * GAP_CACHE, P.jobCap);
-    if (done == 1) { ++fastLocal; P.groups[gi].n = (uint32_t)out.n | 0x40000000u; }  // bit30: n now holds the candidate count
-    else if (done == 2) { uint32_t q = atomicAdd((uint32_t *)&P.counters[17], 1u); P.retryList[q] = gi; }
-    else if (g.n > GENERAL_CAP) { uint32_t q = atomicAdd((uint32_t *)&P.counters[19], 1u); P.bigList[q] = gi; }
-    else { uint32_t q = atomicAdd((uint32_t *)&P.counters[18], 1u); P.generalList[q] = gi; }
+    uint32_t *rec = P.recs + (uint64_t)gi * P.recStride;
+    const uint32_t re = rec[0] & 0x7FFFFFFFu, allele = rec[1], meta = rec[3];
+    const int pass = (rec[0] >> 31) ? 0 : 1;
+    const bool general = (meta >> 16) > 0 || (meta & 0xFFFFu) > 2;
+    if (general) { uint32_t q = atomicAdd((uint32_t *)&P.counters[18], 1u); P.generalList[q] = gi; }
+    else {
+      uint32_t Mw[NW];
+#pragma unroll
+      for (int w = 0; w < NW; ++w) Mw[w] = rec[4 + w];
+      ReadCtx c = makeCtx(P, re, pass, allele);
+      uint32_t cbuf[3];
+      CandOut out{cbuf, 0};
+      unsigned long long *memo = P.memo + (uint64_t)re * GAP_CACHE;
+      int done = groupFastPath<NW, DEFER>(Mw, (int)rec[2], c, P.k, P.hitLenRequired, P.sim, out, &dpLocal, pass, memo, P.jobList, (uint32_t *)&P.counters[16],
+                                          re * GAP_CACHE, P.jobCap);
+      if (done == 2) { uint32_t q = atomicAdd((uint32_t *)&P.counters[17], 1u); P.retryList[q] = gi; }
+      else {
+        ++fastLocal;
+        if (out.n) { rec[4] = cbuf[0]; rec[5] = cbuf[1]; rec[6] = cbuf[2]; }
+        rec[3] = REC_DONE | (uint32_t)out.n;
+      }
+    }
   }
   waveFlush(&P.counters[7], dpLocal);
   waveFlush(&P.counters[11], fastLocal);
@@ -714,51 +714,90 @@ __global__ __launch_bounds__(WG) void k_dp_dense(ChainArgs P, uint32_t nJobs) {
   waveFlush(&P.counters[7], dpLocal);
 }
 
-// K5: groups with several diagonals, one lane per group; work arrays in private memory (lane-interleaved, coalesced when
-// the lanes walk in step).  Groups that are too large for that, or that need an alignment wider than the register band, go to
-// k_chain_big.
+// re-derive the hit list of one (read-end, strand, allele) group from the used posting lists kept by k_seed_groups:
+// the allele's postings are a contiguous run of each list (lists are sorted by allele, then offset)
+__device__ inline int gatherHits(const ChainArgs &P, uint32_t re, int pass, uint32_t allele, uint32_t *h, int cap) {
+  const int maxK = 2 * (P.reads.S * 32);
+  const uint32_t nPlus = P.usedCount[2 * re], nMinus = P.usedCount[2 * re + 1];
+  const uint32_t b = pass == 0 ? 0 : nPlus, e = pass == 0 ? nPlus : nPlus + nMinus;
+  const uint32_t *uo = P.usedOut + (uint64_t)re * maxK * 3;
+  int n = 0;
+  for (uint32_t u = b; u < e; ++u) {
+    const uint32_t rOff = uo[3 * u], st = uo[3 * u + 1], ln = uo[3 * u + 2];
+    uint32_t l = 0, r = ln;
+    while (l < r) { uint32_t m = (l + r) >> 1; if (P.ref.kPost[st + m].allele < allele) l = m + 1; else r = m; }
+    for (; l < ln; ++l) {
+      const T1kPosting pst = P.ref.kPost[st + l];
+      if (pst.allele != allele) break;
+      if (n < cap) h[n] = (pst.offset << 12) | rOff;
+      ++n;
+    }
+  }
+  return n;
+}
+
+// K5: groups with several diagonals, one lane per group; hit list and work arrays in private memory (lane-interleaved).
+// Groups that are too large for that, or that need an alignment wider than the register band, go to k_chain_big.
 __global__ __launch_bounds__(WG) void k_chain_general(ChainArgs P, uint32_t nItems) {
   const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
   unsigned int dpLocal = 0, genLocal = 0;
   if (q < nItems) {
     const uint32_t gi = P.generalList[q];
-    const T1kGroup g = P.groups[gi];
-    const uint32_t re = g.reStrand & 0x7FFFFFFFu;
-    const int pass = (g.reStrand >> 31) ? 0 : 1;
-    ReadCtx c = makeCtx(P, re, pass, g.allele);
-    uint32_t wa[GENERAL_CAP], wb[GENERAL_CAP], wc[GENERAL_CAP];
-    uint32_t cbuf[GENERAL_CAP + 3];  // candidates are staged here so that the hit slice stays intact if the group is handed over
+    uint32_t *rec = P.recs + (uint64_t)gi * P.recStride;
+    const uint32_t re = rec[0] & 0x7FFFFFFFu, allele = rec[1];
+    const int pass = (rec[0] >> 31) ? 0 : 1;
+    ReadCtx c = makeCtx(P, re, pass, allele);
+    uint32_t hh[GENERAL_CAP], wa[GENERAL_CAP], wb[GENERAL_CAP], wc[GENERAL_CAP];
+    const int n = gatherHits(P, re, pass, allele, hh, GENERAL_CAP);
+    bool needScratch = n > GENERAL_CAP;
+    uint32_t cbuf[GENERAL_CAP + 3];
     CandOut out{cbuf, 0};
-    bool needScratch = false;
-    groupGeneral(P.hits + g.hitStart, (int)g.n, c, P.k, P.radius, P.hitLenRequired, wa, wb, wc, nullptr, 0, out, &dpLocal, &P.counters[2], &needScratch);
+    if (!needScratch) groupGeneral(hh, n, c, P.k, P.radius, P.hitLenRequired, wa, wb, wc, nullptr, 0, out, &dpLocal, &P.counters[2], &needScratch);
     if (needScratch) { uint32_t b = atomicAdd((uint32_t *)&P.counters[19], 1u); P.bigList[b] = gi; }
     else {
       ++genLocal;
-      for (int i = 0; i < 3 * out.n; ++i) P.hits[g.hitStart + i] = cbuf[i];
-      P.groups[gi].n = (uint32_t)out.n | 0x40000000u;
+      uint32_t base = 0;
+      if (out.n) {
+        base = atomicAdd((uint32_t *)&P.counters[21], (uint32_t)out.n);
+        if (base + out.n > P.genCandCap) { atomicOr(&P.counters[2], (unsigned long long)ERR_STAGECAP); out.n = 0; }
+        for (int i = 0; i < 3 * out.n; ++i) P.genCand[(uint64_t)base * 3 + i] = cbuf[i];
+      }
+      rec[4] = base;
+      rec[3] = REC_DONE | 0x40000000u | (uint32_t)out.n;  // bit30: candidates live in the side arena
     }
   }
   waveFlush(&P.counters[7], dpLocal);
   waveFlush(&P.counters[12], genLocal);
 }
 
-// very large groups (repeat-rich alleles): a handful of lanes with big scratch
+// very large groups (repeat-rich alleles) or wide gaps: a handful of lanes with big scratch in HBM
 __global__ __launch_bounds__(64) void k_chain_big(ChainArgs P, uint32_t nItems) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, nT = gridDim.x * blockDim.x;
-  uint32_t *mine = P.bigScratch + (uint64_t)t * (3 * BIG_CAP + GA_SCRATCH_INTS);
+  uint32_t *mine = P.bigScratch + (uint64_t)t * (4 * BIG_CAP + GA_SCRATCH_INTS);
   unsigned int dpLocal = 0;
   for (uint32_t q = t; q < nItems; q += nT) {
     const uint32_t gi = P.bigList[q];
-    const T1kGroup g = P.groups[gi];
-    if (g.n > BIG_CAP) { atomicOr(&P.counters[2], (unsigned long long)ERR_BIGGROUP); P.groups[gi].n = 0x40000000u; continue; }
-    const uint32_t re = g.reStrand & 0x7FFFFFFFu;
-    const int pass = (g.reStrand >> 31) ? 0 : 1;
-    ReadCtx c = makeCtx(P, re, pass, g.allele);
-    CandOut out{P.hits + g.hitStart, 0};
+    uint32_t *rec = P.recs + (uint64_t)gi * P.recStride;
+    const uint32_t re = rec[0] & 0x7FFFFFFFu, allele = rec[1];
+    const int pass = (rec[0] >> 31) ? 0 : 1;
+    ReadCtx c = makeCtx(P, re, pass, allele);
+    uint32_t *hh = mine + 3 * BIG_CAP;
+    const int n = gatherHits(P, re, pass, allele, hh, BIG_CAP);
+    if (n > BIG_CAP) { atomicOr(&P.counters[2], (unsigned long long)ERR_BIGGROUP); rec[3] = REC_DONE; continue; }
     bool dummy = false;
-    groupGeneral(P.hits + g.hitStart, (int)g.n, c, P.k, P.radius, P.hitLenRequired, mine, mine + BIG_CAP, mine + 2 * BIG_CAP, (int *)(mine + 3 * BIG_CAP),
-                 GA_BIG_MAX, out, &dpLocal, &P.counters[2], &dummy);
-    P.groups[gi].n = (uint32_t)out.n | 0x40000000u;
+    uint32_t cbuf[96];  // at most 32 candidates (3 words each) are kept per group
+    CandOut o2{cbuf, 0};
+    groupGeneral(hh, n, c, P.k, P.radius, P.hitLenRequired, mine, mine + BIG_CAP, mine + 2 * BIG_CAP, (int *)(mine + 4 * BIG_CAP), GA_BIG_MAX, o2, &dpLocal,
+                 &P.counters[2], &dummy);
+    if (o2.n > 32) { atomicOr(&P.counters[2], (unsigned long long)ERR_BIGGROUP); o2.n = 32; }
+    uint32_t base = 0;
+    if (o2.n) {
+      base = atomicAdd((uint32_t *)&P.counters[21], (uint32_t)o2.n);
+      if (base + o2.n > P.genCandCap) { atomicOr(&P.counters[2], (unsigned long long)ERR_STAGECAP); o2.n = 0; }
+      for (int i = 0; i < 3 * o2.n; ++i) P.genCand[(uint64_t)base * 3 + i] = cbuf[i];
+    }
+    rec[4] = base;
+    rec[3] = REC_DONE | 0x40000000u | (uint32_t)o2.n;
     atomicAdd(&P.counters[13], 1ull);
   }
   if (dpLocal) atomicAdd(&P.counters[7], (unsigned long long)dpLocal);
@@ -767,25 +806,33 @@ __global__ __launch_bounds__(64) void k_chain_big(ChainArgs P, uint32_t nItems) 
 // ------------------------------------------------------------------------------------------------------------------
 // K6: strand vote + copy-out, one workgroup per read-end
 // ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void loadCand(const ChainArgs &P, const uint32_t *rec, uint32_t j, uint32_t &w0, uint32_t &w1, uint32_t &w2) {
+  if (rec[3] & 0x40000000u) { const uint32_t *g = P.genCand + ((uint64_t)rec[4] + j) * 3; w0 = g[0]; w1 = g[1]; w2 = g[2]; }
+  else { w0 = rec[4]; w1 = rec[5]; w2 = rec[6]; }
+}
+
 __global__ __launch_bounds__(WG) void k_collect(ChainArgs P) {
   __shared__ uint32_t warpSums[4];
   __shared__ uint64_t sVoteHi[WG], sVoteLo[WG];
   __shared__ uint32_t sBase;
   const int tid = threadIdx.x;
+  const uint32_t stride = P.recStride;
   for (uint32_t re = blockIdx.x; re < P.reads.nReadEnds; re += gridDim.x) {
-    const uint32_t *cs = P.chunkStart + (uint64_t)re * MAX_CHUNKS, *cc = P.chunkCount + (uint64_t)re * MAX_CHUNKS;
+    const uint32_t *cs = P.chunkStart + (uint64_t)re * P.maxChunks, *cc = P.chunkCount + (uint64_t)re * P.maxChunks;
     VoteKey best; best.hi = ~0ull; best.lo = ~0ull;
     uint32_t nCand[2] = {0, 0};
-    for (int ch = 0; ch < MAX_CHUNKS; ++ch) {
+    for (int ch = 0; ch < P.maxChunks; ++ch) {
       const uint32_t g0 = cs[ch], gn = cc[ch];
+      if (gn == 0) break;  // chunks are recorded densely
       for (uint32_t i = tid; i < gn; i += WG) {
-        const T1kGroup g = P.groups[g0 + i];
-        const uint32_t nc = g.n & 0x3FFFFFFFu;
-        const int plus = (int)(g.reStrand >> 31);
+        const uint32_t *rec = P.recs + (uint64_t)(g0 + i) * stride;
+        const uint32_t nc = rec[3] & 0x3FFFFFFFu;
+        const int plus = (int)(rec[0] >> 31);
         nCand[plus] += nc;
         for (uint32_t j = 0; j < nc; ++j) {
-          uint32_t w0 = P.hits[g.hitStart + 3 * j], w1 = P.hits[g.hitStart + 3 * j + 1], w2 = P.hits[g.hitStart + 3 * j + 2];
-          VoteKey vk = voteKey((int)(w1 >> 20), (int)(w0 & 0xFFF), (int)((w0 >> 12) & 0xFFF), g.allele, plus, (int)(w1 & 0xFFFFF), (int)(w2 & 0xFFFFF));
+          uint32_t w0, w1, w2;
+          loadCand(P, rec, j, w0, w1, w2);
+          VoteKey vk = voteKey((int)(w1 >> 20), (int)(w0 & 0xFFF), (int)((w0 >> 12) & 0xFFF), rec[1], plus, (int)(w1 & 0xFFFFF), (int)(w2 & 0xFFFFF));
           if (vk < best) best = vk;
         }
       }
@@ -812,21 +859,21 @@ __global__ __launch_bounds__(WG) void k_collect(ChainArgs P) {
     if (sBase != 0xFFFFFFFFu && totWin) {
       // chunks are in the reference's order ('-' strand first, alleles ascending); copy the winning strand's candidates in order
       uint32_t written = 0;
-      for (int ch = 0; ch < MAX_CHUNKS; ++ch) {
+      for (int ch = 0; ch < P.maxChunks; ++ch) {
         const uint32_t g0 = cs[ch], gn = cc[ch];
-        if (gn == 0) continue;
-        if ((P.groups[g0].reStrand >> 31) != winPlus) continue;  // a chunk holds one strand
+        if (gn == 0) break;
+        if ((P.recs[(uint64_t)g0 * stride] >> 31) != winPlus) continue;  // a chunk holds one strand
         for (uint32_t i0 = 0; i0 < gn; i0 += WG) {
           const uint32_t i = i0 + tid;
-          T1kGroup g{};
-          uint32_t nc = 0;
-          if (i < gn) { g = P.groups[g0 + i]; nc = g.n & 0x3FFFFFFFu; }
+          const uint32_t *rec = P.recs + (uint64_t)(g0 + (i < gn ? i : 0)) * stride;
+          uint32_t nc = i < gn ? (rec[3] & 0x3FFFFFFFu) : 0;
           uint32_t tot;
           uint32_t off = t1k_block_scan_exclusive(nc, warpSums, &tot);
           for (uint32_t j = 0; j < nc; ++j) {
-            uint32_t w0 = P.hits[g.hitStart + 3 * j], w1 = P.hits[g.hitStart + 3 * j + 1], w2 = P.hits[g.hitStart + 3 * j + 2];
+            uint32_t w0, w1, w2;
+            loadCand(P, rec, j, w0, w1, w2);
             T1kCand cd;
-            cd.allele = g.allele | (winPlus ? 0x80000000u : 0);
+            cd.allele = rec[1] | (winPlus ? 0x80000000u : 0);
             cd.readSE = (w0 & 0xFFF) | (((w0 >> 12) & 0xFFF) << 16);
             cd.seqStart = (int)(w1 & 0xFFFFF); cd.seqEnd = (int)(w2 & 0xFFFFF);
             cd.match = (w1 >> 20) | ((w2 >> 20) << 16);
@@ -844,10 +891,11 @@ __global__ __launch_bounds__(WG) void k_collect(ChainArgs P) {
 // ------------------------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------------------------
-size_t t1k_chain_thread_scratch_u32() { return 16; }
-size_t t1k_chain_big_scratch_u32() { return (size_t)3 * BIG_CAP + GA_SCRATCH_INTS; }
-int t1k_chain_max_chunks() { return MAX_CHUNKS; }
+size_t t1k_chain_big_scratch_u32() { return (size_t)4 * BIG_CAP + GA_SCRATCH_INTS; }
+int t1k_chain_max_chunks(uint32_t nAlleles) { return 2 * (int)((nAlleles + CHUNK_A - 1) / CHUNK_A) + 2; }
 int t1k_chain_memo_entries() { return GAP_CACHE; }
+int t1k_chain_rec_stride(int maxLen) { return maxLen <= 160 ? 10 : 14; }
+int t1k_chain_used_u32(int S) { return 2 * (S * 32) * 3; }
 
 static int readCounters(t1k_ctx *ctx, unsigned long long *h) {
   T1K_HIP(ctx, hipMemcpyAsync(h, ctx->bCounters.p, 64 * 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -856,30 +904,41 @@ static int readCounters(t1k_ctx *ctx, unsigned long long *h) {
 }
 
 // runs K1..K6; on return counters[0] = number of candidates, counters[2] = error flags
-int t1k_run_chain(t1k_ctx *ctx, const ChainArgs &a, int nWg, int generalThreadsBlocks, int bigBlocks, unsigned long long *hc) {
-  const size_t lds = (size_t)TILE_ALLELES * 4 + (size_t)(2 * a.reads.S * 32) * (5 * 4 + 2);
-  T1K_HIP(ctx, hipFuncSetAttribute((const void *)k_seed_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+int t1k_run_chain(t1k_ctx *ctx, const ChainArgs &a, int nWg, int bigBlocks, bool longReads, unsigned long long *hc) {
+  const int AW = longReads ? 12 : 8;
+  const size_t maxK = (size_t)2 * a.reads.S * 32;
+  const size_t lds = (size_t)CHUNK_A * AW * 4 + maxK * (6 * 4 + 2) + 64;
   T1K_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
-  hipLaunchKernelGGL(k_seed_scatter, dim3(nWg), dim3(WG), lds, ctx->stream, a);
+  if (longReads) {
+    T1K_HIP(ctx, hipFuncSetAttribute((const void *)k_seed_groups<10>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_seed_groups<10>, dim3(nWg), dim3(WG), lds, ctx->stream, a);
+  } else {
+    T1K_HIP(ctx, hipFuncSetAttribute((const void *)k_seed_groups<5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_seed_groups<5>, dim3(nWg), dim3(WG), lds, ctx->stream, a);
+  }
   T1K_HIP(ctx, hipEventRecord(ctx->ev[8], ctx->stream));
   int rc = readCounters(ctx, hc);
   if (rc) return rc;
   if (hc[2]) return 0;
   const uint32_t nGroups = (uint32_t)hc[6];
-  if (nGroups) hipLaunchKernelGGL(k_chain_fast<true>, dim3((nGroups + WG - 1) / WG), dim3(WG), 0, ctx->stream, a, (const uint32_t *)nullptr, nGroups);
+  if (nGroups) {
+    if (longReads) hipLaunchKernelGGL((k_chain_fast<10, true>), dim3((nGroups + WG - 1) / WG), dim3(WG), 0, ctx->stream, a, (const uint32_t *)nullptr, nGroups);
+    else hipLaunchKernelGGL((k_chain_fast<5, true>), dim3((nGroups + WG - 1) / WG), dim3(WG), 0, ctx->stream, a, (const uint32_t *)nullptr, nGroups);
+  }
   if ((rc = readCounters(ctx, hc))) return rc;
   const uint32_t nJobs = (uint32_t)std::min<unsigned long long>(hc[16] & 0xFFFFFFFFull, a.jobCap);
-  const uint32_t nRetry = (uint32_t)(hc[17] & 0xFFFFFFFFull), nGen = (uint32_t)(hc[18] & 0xFFFFFFFFull), nBig = (uint32_t)(hc[19] & 0xFFFFFFFFull);
+  const uint32_t nRetry = (uint32_t)(hc[17] & 0xFFFFFFFFull), nGen = (uint32_t)(hc[18] & 0xFFFFFFFFull);
   if (nJobs) hipLaunchKernelGGL(k_dp_dense, dim3((nJobs + WG - 1) / WG), dim3(WG), 0, ctx->stream, a, nJobs);
-  if (nRetry) hipLaunchKernelGGL(k_chain_fast<false>, dim3((nRetry + WG - 1) / WG), dim3(WG), 0, ctx->stream, a, (const uint32_t *)a.retryList, nRetry);
-  (void)generalThreadsBlocks;
+  if (nRetry) {
+    if (longReads) hipLaunchKernelGGL((k_chain_fast<10, false>), dim3((nRetry + WG - 1) / WG), dim3(WG), 0, ctx->stream, a, (const uint32_t *)a.retryList, nRetry);
+    else hipLaunchKernelGGL((k_chain_fast<5, false>), dim3((nRetry + WG - 1) / WG), dim3(WG), 0, ctx->stream, a, (const uint32_t *)a.retryList, nRetry);
+  }
   if (nGen) {
     hipLaunchKernelGGL(k_chain_general, dim3((nGen + WG - 1) / WG), dim3(WG), 0, ctx->stream, a, nGen);
     if ((rc = readCounters(ctx, hc))) return rc;  // the general kernel may hand groups over to the big-scratch kernel
   }
-  const uint32_t nBig2 = (uint32_t)(hc[19] & 0xFFFFFFFFull);
-  (void)nBig;
-  if (nBig2) hipLaunchKernelGGL(k_chain_big, dim3(bigBlocks), dim3(64), 0, ctx->stream, a, nBig2);
+  const uint32_t nBig = (uint32_t)(hc[19] & 0xFFFFFFFFull);
+  if (nBig) hipLaunchKernelGGL(k_chain_big, dim3(bigBlocks), dim3(64), 0, ctx->stream, a, nBig);
   hipLaunchKernelGGL(k_collect, dim3(nWg), dim3(WG), 0, ctx->stream, a);
   T1K_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
   return readCounters(ctx, hc);

@@ -2,26 +2,19 @@
 #pragma once
 #include "t1k_dev.h"
 
-// one (read-end, strand, allele) hit group of the batch; 16 bytes
-struct T1kGroup {
-  uint32_t reStrand;   // read-end id | '+' strand << 31
-  uint32_t allele;
-  uint32_t hitStart;   // index into the batch hit arena; after chaining the slice holds the group's packed candidates
-  uint32_t n;          // hit count; after chaining: candidate count | 1 << 30
-};
-
 struct ChainArgs {
   T1kRefDev ref;
   T1kReadsDev reads;
   int k, radius, hitLenRequired;
   double sim;
-  uint32_t *hits; uint64_t hitCap;
-  T1kGroup *groups; uint64_t groupCap;
-  uint32_t *chunkStart, *chunkCount;          // [re][MAX_CHUNKS] runs of groups per (strand, allele tile), reference order
-  unsigned long long *memo;                   // [re][GAP_CACHE] memo of gap alignments
+  uint32_t *recs; uint32_t recStride; uint64_t groupCap;   // group records: re|strand, allele, diag, meta, M[...]
+  uint32_t *chunkStart, *chunkCount; int maxChunks;        // [re][maxChunks] runs of groups per (strand, allele chunk), reference order
+  uint32_t *usedOut, *usedCount;                           // [re][maxK][3] used k-mers (readOff, listStart, listLen); [re][2] counts per strand
+  unsigned long long *memo;                                // [re][GAP_CACHE] memo of gap alignments
   uint32_t *jobList; uint32_t jobCap;
   uint32_t *retryList, *generalList, *bigList;
-  uint32_t *threadScratch, *bigScratch;
+  uint32_t *genCand; uint32_t genCandCap;                  // packed candidates of multi-diagonal groups (3 u32 each)
+  uint32_t *bigScratch;
   T1kCand *cand; uint64_t candCap;
   uint32_t *candStart, *candCount;
   unsigned long long *counters;
@@ -83,11 +76,12 @@ struct TruncArgs {
 
 int t1k_launch_pack(t1k_ctx *ctx, const char *dAscii, const uint64_t *dOffs, uint32_t n, int S, uint64_t *bases, uint64_t *nmask, uint16_t *lens);
 size_t t1k_slow_per_thread(int maxCells);
-size_t t1k_chain_thread_scratch_u32();
 size_t t1k_chain_big_scratch_u32();
-int t1k_chain_max_chunks();
+int t1k_chain_max_chunks(uint32_t nAlleles);
 int t1k_chain_memo_entries();
-int t1k_run_chain(t1k_ctx *ctx, const ChainArgs &a, int nWg, int generalBlocks, int bigBlocks, unsigned long long *hc);
+int t1k_chain_rec_stride(int maxLen);
+int t1k_chain_used_u32(int S);
+int t1k_run_chain(t1k_ctx *ctx, const ChainArgs &a, int nWg, int bigBlocks, bool longReads, unsigned long long *hc);
 void t1k_launch_extend(t1k_ctx *ctx, const ExtendArgs &a);
 void t1k_launch_select(t1k_ctx *ctx, const SelectArgs &a, int nWg);
 void t1k_launch_fullalign(t1k_ctx *ctx, const FullArgs &a);
