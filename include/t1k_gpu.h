@@ -29,7 +29,8 @@ typedef enum {
   T1K_ERR_DEVICE = -2,    /* HIP error (message in t1k_last_error) */
   T1K_ERR_CAPACITY = -3,  /* a device arena overflowed; raise the matching t1k_params cap and retry */
   T1K_ERR_IO = -4,        /* file could not be opened / parsed */
-  T1K_ERR_STATE = -5      /* call made in the wrong order */
+  T1K_ERR_STATE = -5,     /* call made in the wrong order */
+  T1K_ERR_INTERNAL = -6   /* an internal invariant did not hold (a bug; results of the call are void) */
 } t1k_status;
 
 typedef struct t1k_ctx t1k_ctx;

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def lib_path():
-    return os.path.join(_HERE, "lib", "libt1k_gpu.so")
+    return os.environ.get("T1K_GPU_LIB") or os.path.join(_HERE, "lib", "libt1k_gpu.so")
 
 
 class T1kError(RuntimeError):

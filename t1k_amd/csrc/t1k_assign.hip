@@ -83,9 +83,7 @@ __device__ inline bool lowComplexity(const uint64_t *rb, const uint64_t *rn, int
   return low >= 2;
 }
 
-__global__ __launch_bounds__(WG) void k_extend(ExtendArgs P) {
-  uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (gid >= P.nCand) return;
+__device__ __forceinline__ void extendOne(const ExtendArgs &P, uint64_t gid, unsigned int &extendDp) {
   T1kCand c = P.cand[gid];
   T1kExt x{};
   const uint32_t allele = c.allele & 0x7FFFFFFFu;
@@ -133,7 +131,7 @@ __global__ __launch_bounds__(WG) void k_extend(ExtendArgs P) {
     if (bestP != 0x7FFFFFFF) { int i = bestP - se - 1; rightClip = ro - i; ro = i; }
   }
   match += t1k_ga_matches_window(rb, rn, re + 1, P.ref.bases, P.ref.nmask, goff + se + 1, ro, &dpLocal);
-  if (dpLocal) atomicAdd(&P.counters[14], (unsigned long long)dpLocal);
+  extendDp = dpLocal;
   int eMatch = 2 * match + matchCnt;
   int ers = rs - lo, ere = re + ro, ess = ss - lo, ese = se + ro;
   double esim = (double)eMatch / (double)(ere - ers + 1 + ese - ess + 1);
@@ -142,6 +140,13 @@ __global__ __launch_bounds__(WG) void k_extend(ExtendArgs P) {
   x.seqStart = ess; x.seqEnd = ese; x.readStart = (uint16_t)ers; x.readEnd = (uint16_t)ere;
   x.matchCnt = (uint16_t)eMatch; x.leftClip = (uint16_t)leftClip; x.rightClip = (uint16_t)rightClip; x.flags = flags;
   P.ext[gid] = x;
+}
+
+__global__ __launch_bounds__(WG) void k_extend(ExtendArgs P) {
+  const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned int dp = 0;
+  if (gid < P.nCand) extendOne(P, gid, dp);
+  t1k_stat_add(P.counters, T1K_STAT_EXTEND_DP, dp);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -368,14 +373,14 @@ __global__ __launch_bounds__(WG) void k_fullalign(FullArgs P) {
     // equal spans: register-band traced DP (queue A, from the front); unequal spans: general DP (queue B, from the back)
     const int dl = L > Ls ? L - Ls : Ls - L;
     if (L == Ls) {
-      unsigned long long q = atomicAdd(&P.counters[8], 1ull);
-      P.slowQueue[q] = (uint32_t)gid;
-    } else if (dl <= 4) {  // register-band DP (k_fullalign_band), queued from the back
-      unsigned long long q = atomicAdd(&P.counters[15], 1ull);
-      P.slowQueue[P.slowCap - 1 - q] = (uint32_t)gid;
+      const uint32_t q = t1k_arena_append(P.counters, T1K_AR_EQ, P.segCap);
+      if (q != T1K_ARENA_FULL) P.eqStr[q] = (uint32_t)gid;
+    } else if (dl <= 4) {  // register-band DP (k_fullalign_band)
+      const uint32_t q = t1k_arena_append(P.counters, T1K_AR_BAND, P.segCap);
+      if (q != T1K_ARENA_FULL) P.bandStr[q] = (uint32_t)gid;
     } else {               // wide band: general DP with row arrays in HBM (k_fullalign_slow)
-      unsigned long long q = atomicAdd(&P.counters[20], 1ull);
-      P.slowQueue[P.slowCap + q] = (uint32_t)gid;
+      const uint32_t q = t1k_arena_append(P.counters, T1K_AR_WIDE, P.segCap);
+      if (q != T1K_ARENA_FULL) P.wideStr[q] = (uint32_t)gid;
     }
     return;
   }

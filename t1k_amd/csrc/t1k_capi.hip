@@ -141,6 +141,7 @@ int t1k_ref_upload(t1k_ctx *ctx, const char *seqs, const uint64_t *offsets, cons
   size_t words = total / 32 + 2;
   std::vector<uint64_t> bases(words, 0), nmask(words, 0), exonm(words, 0);
   std::vector<uint32_t> sepStart(nAlleles + 1, 0);
+  std::vector<uint8_t> alleleHasN(nAlleles, 0);
   std::vector<int32_t> sepPos;
   // index, pass 1: count (KmerIndex::BuildIndexFromRead, KmerIndex.hpp:107-130).  k-mer codes are
   // little-endian here (first base in the low bits); only equality and "== 0" are ever tested, both convention-free.
@@ -159,7 +160,7 @@ int t1k_ref_upload(t1k_ctx *ctx, const char *seqs, const uint64_t *offsets, cons
     for (uint32_t i = 0; i < len; ++i) {
       int c = asciiCode(s[i]);
       uint64_t pos = g + i;
-      if (c == 4) { nmask[pos >> 5] |= 1ull << ((pos & 31) * 2); sepPos.push_back((int32_t)i); }
+      if (c == 4) { nmask[pos >> 5] |= 1ull << ((pos & 31) * 2); sepPos.push_back((int32_t)i); alleleHasN[a] = 1; }
       else bases[pos >> 5] |= (uint64_t)c << ((pos & 31) * 2);
       if (exon && exon[offsets[a] + i]) exonm[pos >> 5] |= 1ull << ((pos & 31) * 2);
       if (invalid != -1) ++invalid;
@@ -196,6 +197,7 @@ int t1k_ref_upload(t1k_ctx *ctx, const char *seqs, const uint64_t *offsets, cons
   if ((rc = uploadVec(ctx, exonm, (const void **)&r.exon))) return rc;
   if ((rc = uploadVec(ctx, alleleOff, (const void **)&r.alleleOff))) return rc;
   if ((rc = uploadVec(ctx, alleleLen, (const void **)&r.alleleLen))) return rc;
+  if ((rc = uploadVec(ctx, alleleHasN, (const void **)&r.alleleHasN))) return rc;
   if ((rc = uploadVec(ctx, sepStart, (const void **)&r.sepStart))) return rc;
   if (sepPos.empty()) sepPos.push_back(0);
   if ((rc = uploadVec(ctx, sepPos, (const void **)&r.sepPos))) return rc;
@@ -298,11 +300,19 @@ int t1k_reads_upload(t1k_ctx *ctx, const char *seqs, const uint64_t *offsets, co
 // ------------------------------------------------------------------------------------------------------------------
 // AssignRead over the batch
 // ------------------------------------------------------------------------------------------------------------------
-static int fetchCounters(t1k_ctx *ctx, unsigned long long *h) {
-  T1K_HIP(ctx, hipMemcpyAsync(h, ctx->bCounters.p, 64 * 8, hipMemcpyDeviceToHost, ctx->stream));
+// control counters + the striped statistics folded into their historical slots (7 dp, 11 fast, 12 general, 14 extend dp, 10 near-best)
+extern "C++" int t1k_fetch_counters(t1k_ctx *ctx, unsigned long long *h) {
+  std::vector<unsigned long long> &raw = ctx->hRaw;
+  raw.resize(T1K_COUNTER_WORDS);
+  T1K_HIP(ctx, hipMemcpyAsync(raw.data(), ctx->bCounters.p, (size_t)T1K_COUNTER_WORDS * 8, hipMemcpyDeviceToHost, ctx->stream));
   T1K_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  memcpy(h, raw.data(), 64 * 8);
+  static const int slot[5] = {7, 11, 12, 14, 10};
+  for (int s = 0; s < T1K_STAT_STRIPES; ++s)
+    for (int k = 0; k < 5; ++k) h[slot[k]] += raw[64 + s * 8 + k];
   return 0;
 }
+static int fetchCounters(t1k_ctx *ctx, unsigned long long *h) { return t1k_fetch_counters(ctx, h); }
 
 static int capacityError(t1k_ctx *ctx, unsigned long long flags) {
   std::string m = "device arena overflow:";
@@ -315,6 +325,7 @@ static int capacityError(t1k_ctx *ctx, unsigned long long flags) {
   if (flags & 64) m += " slow-alignment queue";
   if (flags & 128) m += " row_cap";
   if (flags & 256) m += " group_cap";
+  if (flags & 512) return t1k_fail(ctx, T1K_ERR_INTERNAL, "alignment memo entry left pending");
   return t1k_fail(ctx, T1K_ERR_CAPACITY, m);
 }
 
@@ -341,13 +352,17 @@ int t1k_assign_range(t1k_ctx *ctx, uint64_t first, uint32_t count) {
   const uint64_t groupCap = (uint64_t)ctx->prm.group_cap;
   const uint32_t jobCap = 16u << 20, genCandCap = 32u << 20;
   const int bigBlocks = 32;
-  if ((rc = t1k_ensure(ctx, ctx->bCounters, 64 * 8))) return rc;
+  if ((rc = t1k_ensure(ctx, ctx->bCounters, (size_t)T1K_COUNTER_WORDS * 8))) return rc;
   if ((rc = t1k_ensure(ctx, ctx->bWgGroups, groupCap * recStride * 4))) return rc;                        // batch group records
   if ((rc = t1k_ensure(ctx, ctx->bWgStage, (size_t)n * maxChunks * 8 + 64))) return rc;                   // chunkStart | chunkCount
   if ((rc = t1k_ensure(ctx, ctx->bWgHits, (size_t)n * (t1k_chain_used_u32(rd.S) + 2) * 4 + 64))) return rc;  // used k-mer lists | counts
   if ((rc = t1k_ensure(ctx, ctx->bWgCache, (size_t)n * memoN * 8 + 64))) return rc;                       // per-read-end memo
   if ((rc = t1k_ensure(ctx, ctx->bWgBig, (size_t)bigBlocks * 64 * t1k_chain_big_scratch_u32() * 4))) return rc;
-  if ((rc = t1k_ensure(ctx, ctx->bLists, (size_t)jobCap * 4 + groupCap * 4 * 3 + (size_t)genCandCap * 12 + 64))) return rc;  // jobs | retry | general | big | genCand
+  // work lists: every list exists twice, as a striped arena the kernels append to and as the dense list its consumer reads
+  const uint32_t groupSegCap = (uint32_t)std::min<uint64_t>(groupCap / T1K_NSTRIPE, 0xFFFFFFFFull / T1K_NSTRIPE);
+  const uint32_t listSegCap = std::max<uint32_t>(groupSegCap / 2, 1024u), jobSegCap = jobCap / T1K_NSTRIPE, genCandSegCap = genCandCap / T1K_NSTRIPE;
+  const size_t listWords = (size_t)listSegCap * T1K_NSTRIPE;
+  if ((rc = t1k_ensure(ctx, ctx->bLists, ((size_t)jobCap * 2 + listWords * 8 + (size_t)genCandCap * 3) * 4 + 64))) return rc;
   if ((rc = t1k_ensure(ctx, ctx->bCand, (size_t)ctx->prm.cand_cap * sizeof(T1kCand)))) return rc;
   if ((rc = t1k_ensure(ctx, ctx->bExt, (size_t)ctx->prm.cand_cap * sizeof(T1kExt)))) return rc;
   if ((rc = t1k_ensure(ctx, ctx->bOvl, (size_t)ctx->prm.ovl_cap * sizeof(T1kOvl)))) return rc;
@@ -356,7 +371,7 @@ int t1k_assign_range(t1k_ctx *ctx, uint64_t first, uint32_t count) {
   if ((rc = t1k_ensure(ctx, ctx->bOvlStart, (size_t)n * 4))) return rc;
   if ((rc = t1k_ensure(ctx, ctx->bOvlCount, (size_t)n * 4))) return rc;
   if ((rc = t1k_ensure(ctx, ctx->bSortScratch, (size_t)nWg * sortCap * 48))) return rc;
-  T1K_HIP(ctx, hipMemsetAsync(ctx->bCounters.p, 0, 64 * 8, ctx->stream));
+  T1K_HIP(ctx, hipMemsetAsync(ctx->bCounters.p, 0, (size_t)T1K_COUNTER_WORDS * 8, ctx->stream));
   T1K_HIP(ctx, hipMemsetAsync(ctx->bOvlCount.p, 0, (size_t)n * 4 + 4, ctx->stream));
   T1K_HIP(ctx, hipMemsetAsync(ctx->bCandCount.p, 0, (size_t)n * 4 + 4, ctx->stream));
   T1K_HIP(ctx, hipMemsetAsync(ctx->bWgCache.p, 0, (size_t)n * memoN * 8, ctx->stream));
@@ -375,8 +390,11 @@ int t1k_assign_range(t1k_ctx *ctx, uint64_t first, uint32_t count) {
   a.usedOut = (uint32_t *)ctx->bWgHits.p; a.usedCount = a.usedOut + (size_t)n * t1k_chain_used_u32(rd.S);
   a.memo = (unsigned long long *)ctx->bWgCache.p;
   a.jobList = (uint32_t *)ctx->bLists.p; a.jobCap = jobCap;
-  a.retryList = a.jobList + jobCap; a.generalList = a.retryList + groupCap; a.bigList = a.generalList + groupCap;
-  a.genCand = a.bigList + groupCap; a.genCandCap = genCandCap;
+  a.jobStr = a.jobList + jobCap;
+  a.retryList = a.jobStr + jobCap; a.generalList = a.retryList + listWords; a.bigList = a.generalList + listWords; a.finishList = a.bigList + listWords;
+  a.retryStr = a.finishList + listWords; a.generalStr = a.retryStr + listWords; a.bigStr = a.generalStr + listWords; a.finishStr = a.bigStr + listWords;
+  a.genCand = a.finishStr + listWords; a.genCandCap = genCandCap;
+  a.groupSegCap = groupSegCap; a.jobSegCap = jobSegCap; a.listSegCap = listSegCap; a.genCandSegCap = genCandSegCap;
   a.bigScratch = (uint32_t *)ctx->bWgBig.p;
   a.cand = (T1kCand *)ctx->bCand.p; a.candCap = (uint64_t)ctx->prm.cand_cap;
   a.candStart = (uint32_t *)ctx->bCandStart.p; a.candCount = (uint32_t *)ctx->bCandCount.p;
@@ -405,21 +423,33 @@ int t1k_assign_range(t1k_ctx *ctx, uint64_t first, uint32_t count) {
   ctx->nOvl = hc[1];
   const int maxCells = 340 * 340;
   const int slowBlocks = 64;
-  if ((rc = t1k_ensure(ctx, ctx->bSlowQueue, (size_t)(ctx->nOvl + 1) * 8))) return rc;  // [equal -> | <- band][wide ->]
+  // alignment queues (equal spans | spans differing by <= 4 | wider): striped arenas appended to by k_fullalign, then made dense
+  const uint32_t qSegCap = (uint32_t)(ctx->nOvl / T1K_NSTRIPE * 2 + 1024);
+  const size_t qDense = (size_t)ctx->nOvl + 1, qStr = (size_t)qSegCap * T1K_NSTRIPE;
+  if ((rc = t1k_ensure(ctx, ctx->bSlowQueue, (qDense + qStr) * 3 * 4))) return rc;
   if ((rc = t1k_ensure(ctx, ctx->bSlowScratch, (size_t)slowBlocks * 64 * t1k_slow_per_thread(maxCells)))) return rc;
   FullArgs f{};
   f.ref = ctx->ref; f.reads = rd; f.relax = relaxFlag; f.ovl = s.ovl; f.nOvl = ctx->nOvl;
-  f.slowQueue = (uint32_t *)ctx->bSlowQueue.p; f.slowCap = (uint32_t)std::min<uint64_t>(ctx->nOvl + 1, 0xFFFFFFFFull); f.counters = a.counters;
+  uint32_t *qEq = (uint32_t *)ctx->bSlowQueue.p, *qBand = qEq + qDense, *qWide = qBand + qDense;
+  f.eqStr = qWide + qDense; f.bandStr = f.eqStr + qStr; f.wideStr = f.bandStr + qStr; f.segCap = qSegCap; f.counters = a.counters;
   t1k_launch_fullalign(ctx, f);
   T1K_HIP(ctx, hipEventRecord(ctx->ev[7], ctx->stream));
   if ((rc = fetchCounters(ctx, hc))) return rc;
   if (hc[2]) return capacityError(ctx, hc[2]);
+  {
+    const T1kArenaCounts ce = t1k_arena_counts(ctx, T1K_AR_EQ, qSegCap), cb = t1k_arena_counts(ctx, T1K_AR_BAND, qSegCap), cw = t1k_arena_counts(ctx, T1K_AR_WIDE, qSegCap);
+    if (ce.overflow || cb.overflow || cw.overflow) return capacityError(ctx, 64);
+    t1k_arena_compact(ctx, T1K_AR_EQ, f.eqStr, qSegCap, qEq, ce.maxSeg);
+    t1k_arena_compact(ctx, T1K_AR_BAND, f.bandStr, qSegCap, qBand, cb.maxSeg);
+    t1k_arena_compact(ctx, T1K_AR_WIDE, f.wideStr, qSegCap, qWide, cw.maxSeg);
+    hc[8] = ce.total; hc[15] = cb.total; hc[20] = cw.total;
+  }
   if (hc[8]) {  // equal-span alignments: register-band traced DP, one lane per job
     const int eqBlocks = 512;
     const size_t traceBytes = (size_t)eqBlocks * 256 * (size_t)(ctx->batchMaxLen + 2) * 8;
     if ((rc = t1k_ensure(ctx, ctx->bEqTrace, traceBytes))) return rc;
     SlowArgs sl{};
-    sl.ref = ctx->ref; sl.reads = rd; sl.relax = relaxFlag; sl.ovl = s.ovl; sl.slowQueue = f.slowQueue; sl.nSlow = (uint32_t)hc[8];
+    sl.ref = ctx->ref; sl.reads = rd; sl.relax = relaxFlag; sl.ovl = s.ovl; sl.slowQueue = qEq; sl.nSlow = (uint32_t)hc[8];
     sl.scratch = (uint8_t *)ctx->bEqTrace.p; sl.perThread = 0; sl.maxCells = 0; sl.counters = a.counters;
     t1k_launch_fullalign_eq(ctx, sl, eqBlocks);
   }
@@ -428,13 +458,13 @@ int t1k_assign_range(t1k_ctx *ctx, uint64_t first, uint32_t count) {
     const size_t traceBytes = (size_t)eqBlocks * 256 * (size_t)(ctx->batchMaxLen + 2) * 8;
     if ((rc = t1k_ensure(ctx, ctx->bEqTrace, traceBytes))) return rc;
     SlowArgs sl{};
-    sl.ref = ctx->ref; sl.reads = rd; sl.relax = relaxFlag; sl.ovl = s.ovl; sl.slowQueue = f.slowQueue + (f.slowCap - hc[15]); sl.nSlow = (uint32_t)hc[15];
+    sl.ref = ctx->ref; sl.reads = rd; sl.relax = relaxFlag; sl.ovl = s.ovl; sl.slowQueue = qBand; sl.nSlow = (uint32_t)hc[15];
     sl.scratch = (uint8_t *)ctx->bEqTrace.p; sl.perThread = 0; sl.maxCells = 0; sl.counters = a.counters;
     t1k_launch_fullalign_band(ctx, sl, eqBlocks);
   }
   if (hc[20]) {  // wide length difference: general DP with row arrays in HBM
     SlowArgs sl{};
-    sl.ref = ctx->ref; sl.reads = rd; sl.relax = relaxFlag; sl.ovl = s.ovl; sl.slowQueue = f.slowQueue + f.slowCap; sl.nSlow = (uint32_t)hc[20];
+    sl.ref = ctx->ref; sl.reads = rd; sl.relax = relaxFlag; sl.ovl = s.ovl; sl.slowQueue = qWide; sl.nSlow = (uint32_t)hc[20];
     sl.scratch = (uint8_t *)ctx->bSlowScratch.p; sl.perThread = t1k_slow_per_thread(maxCells); sl.maxCells = maxCells; sl.counters = a.counters;
     t1k_launch_fullalign_slow(ctx, sl, slowBlocks);
   }
@@ -452,8 +482,8 @@ int t1k_assign_range(t1k_ctx *ctx, uint64_t first, uint32_t count) {
   if (getenv("T1K_DEBUG_PHASES")) {
     float a1 = 0, a2 = 0, a3 = 0;
     (void)hipEventElapsedTime(&a1, ctx->ev[3], ctx->ev[7]); (void)hipEventElapsedTime(&a2, ctx->ev[7], evSlow); (void)hipEventElapsedTime(&a3, evSlow, ctx->ev[4]);
-    fprintf(stderr, "[t1k] fullalign %.2f ms, eq-DP (%llu jobs) + general-DP (%llu jobs) %.2f ms, truncate %.2f ms; cand %llu ovl %llu dp %llu; groups fast %llu general %llu big %llu\n",
-            a1, hc[8], hc[15], a2, a3, hc[0], hc[1], hc[7], hc[11], hc[12], hc[13]);
+    fprintf(stderr, "[t1k] fullalign %.2f ms, eq-DP (%llu jobs) + general-DP (%llu jobs) %.2f ms, truncate %.2f ms; cand %llu ovl %llu dp %llu; groups %llu fast %llu general %llu big %llu; memo jobs %llu parked %llu wide-queue %llu\n",
+            a1, hc[8], hc[15], a2, a3, hc[0], hc[1], hc[7], hc[6], hc[11], hc[12], hc[13], hc[16], hc[17], hc[20]);
   }
   t1k_stats &st = ctx->stats;
   st.read_ends = n; st.lookups = hc[3]; st.postings = hc[4]; st.hits = hc[5]; st.groups = hc[6]; st.candidates = hc[0]; st.extended = hc[1];

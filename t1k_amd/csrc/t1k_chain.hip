@@ -24,7 +24,7 @@
 #define GA_BIG_MAX 2048
 #define GA_SCRATCH_INTS (6 * (GA_BIG_MAX + 4))
 
-enum { ERR_HITCAP = 1, ERR_STAGECAP = 2, ERR_CANDCAP = 4, ERR_BIGGROUP = 8, ERR_OVLCAP = 16, ERR_SORTCAP = 32, ERR_SLOWCAP = 64, ERR_ROWCAP = 128, ERR_GROUPCAP = 256 };
+enum { ERR_HITCAP = 1, ERR_STAGECAP = 2, ERR_CANDCAP = 4, ERR_BIGGROUP = 8, ERR_OVLCAP = 16, ERR_SORTCAP = 32, ERR_SLOWCAP = 64, ERR_ROWCAP = 128, ERR_GROUPCAP = 256, ERR_MEMO = 512 };
 
 // ------------------------------------------------------------------------------------------------------------------
 // group -> candidate overlaps
@@ -72,7 +72,8 @@ __device__ inline int gapMatches(const ReadCtx &c, int ra, int ga, int lp, int l
 // bases and N-mask as its own window before it reuses the stored match count, so a hit is bit-exact by construction.
 // The table lives in per-workgroup HBM scratch (L2-resident, 32 KB) and is cleared per read-end.
 // ------------------------------------------------------------------------------------------------------------------
-#define GAP_CACHE 1024
+#define GAP_CACHE 2048
+#define GAP_PROBES 4
 __device__ inline bool sameWindow(const uint64_t *gb, const uint64_t *gn, int64_t a, int64_t b, int L) {
   for (int o = 0; o < L; o += 32) {
     uint64_t lm = t1k_lowmask(L - o);
@@ -87,7 +88,7 @@ __device__ inline bool sameWindow(const uint64_t *gb, const uint64_t *gn, int64_
 // DEFER = false: a miss is computed inline (used after the dense phase; only slot-collision leftovers get here).
 template <bool DEFER>
 __device__ inline int gapMatchesCached(const ReadCtx &c, int readPos, int64_t gpos, int L, int strandBit, unsigned long long *cache, unsigned int *dpCounter,
-                                       uint32_t *jobList, uint32_t *jobCount, uint32_t jobTag, uint32_t jobCap) {
+                                       uint32_t *jobStr, unsigned long long *counters, uint32_t jobTag, uint32_t jobSegCap, uint32_t *slotOut) {
   if (L <= 0) return 0;
   // mismatch count and a content hash of the allele window in one sweep
   int x = 0;
@@ -110,7 +111,7 @@ __device__ inline int gapMatchesCached(const ReadCtx &c, int readPos, int64_t gp
   const uint32_t slot = (uint32_t)hsh & (GAP_CACHE - 1);
   bool pendingSeen = false;
 #pragma unroll
-  for (int probe = 0; probe < 2; ++probe) {
+  for (int probe = 0; probe < GAP_PROBES; ++probe) {
     unsigned long long e = __hip_atomic_load(&cache[slot ^ probe], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (e != 0 && (e & 0x1FFFFFull) == idBits) {
       int64_t eg = (int64_t)(e >> 30);
@@ -118,6 +119,7 @@ __device__ inline int gapMatchesCached(const ReadCtx &c, int readPos, int64_t gp
         unsigned long long v = (e >> 21) & 0x1FF;
         if (v != GAP_PENDING) return (int)v;
         pendingSeen = true;
+        *slotOut = slot ^ probe;
       }
     }
   }
@@ -125,20 +127,24 @@ __device__ inline int gapMatchesCached(const ReadCtx &c, int readPos, int64_t gp
     if (pendingSeen) return -1;
     const unsigned long long pe = ((unsigned long long)gpos << 30) | (GAP_PENDING << 21) | idBits;
 #pragma unroll
-    for (int probe = 0; probe < 2; ++probe) {
+    for (int probe = 0; probe < GAP_PROBES; ++probe) {
       unsigned long long old = atomicCAS(&cache[slot ^ probe], 0ull, pe);
       if (old == 0ull) {
-        uint32_t q = atomicAdd(jobCount, 1u);
-        if (q >= jobCap) {  // job list full: release the claim, the retry pass computes this gap inline
+        const uint32_t q = t1k_arena_append(counters, T1K_AR_JOBS, jobSegCap);
+        if (q == T1K_ARENA_FULL) {  // job list full: release the claim, the retry pass computes this gap inline
           __hip_atomic_store(&cache[slot ^ probe], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           return -2;
         }
-        jobList[q] = jobTag + (slot ^ probe);
+        jobStr[q] = jobTag + (slot ^ probe);
+        *slotOut = slot ^ probe;
         return -1;
       }
-      if ((old & 0x1FFFFFull) == idBits && ((int64_t)(old >> 30) == gpos || sameWindow(c.gb, c.gn, (int64_t)(old >> 30), gpos, L))) return -1;  // somebody else just claimed it
+      if ((old & 0x1FFFFFull) == idBits && ((int64_t)(old >> 30) == gpos || sameWindow(c.gb, c.gn, (int64_t)(old >> 30), gpos, L))) {
+        *slotOut = slot ^ probe;
+        return -1;  // somebody else just claimed it
+      }
     }
-    return -2;  // both slots taken by other jobs: inline in the retry phase
+    return -2;  // all probe slots taken by other jobs: inline in the retry phase
   }
   if (dpCounter) ++*dpCounter;
   T1kSeqView T{c.gb, c.gn, gpos}, P{c.rb, c.rn, (int64_t)readPos};
@@ -163,10 +169,23 @@ __device__ inline int gapMatchesCached(const ReadCtx &c, int readPos, int64_t gp
 //   * exact prune: a gap with x > 3 yields at most g - 1 matches, so U = 2*(span - sum_{x<=3} x - #{x>3}) bounds matchCnt;
 //     if U / (2*span) < -s the candidate is certain to fail the similarity filter (1838-1840, 1894-1908) and is emitted
 //     with matchCnt = U (it is dropped by k_extend either way, and the strand vote only reads matchCnt0)
+// multi-word shift-left-or: C |= C << sft (sft < 64), MW 64-bit words, low word first
+template <int MW>
+__device__ __forceinline__ void shlOr(uint64_t *C, int sft) {
+#pragma unroll
+  for (int w = MW - 1; w >= 0; --w) {
+    uint64_t carry = w > 0 ? (C[w - 1] >> (64 - sft)) : 0ull;
+    C[w] |= (C[w] << sft) | carry;
+  }
+}
+
+// return value: 1 = finished (out holds 0 or 1 candidate), 2 = run again after the dense DP phase, 3 = candidate pushed with a
+// partial matchCnt, refs[] name the memo slots whose match counts are still to be added (DEFER only)
+#define GROUP_MAX_REFS 6
 template <int NW, bool DEFER>
-__device__ inline int groupFastPath(const uint32_t *Mw, int diag, const ReadCtx &c, int k, int hitLenRequired, double simThreshold, CandOut &out,
-                                    unsigned int *dpCounter, int strandBit, unsigned long long *cache, uint32_t *jobList, uint32_t *jobCount, uint32_t jobTag,
-                                    uint32_t jobCap) {
+__device__ inline int groupFastPath(const uint32_t *Mw, int diag, const ReadCtx &c, bool hasN, int k, int hitLenRequired, double simThreshold, CandOut &out,
+                                    unsigned int *dpCounter, int strandBit, unsigned long long *cache, uint32_t *jobStr, unsigned long long *counters, uint32_t jobTag,
+                                    uint32_t jobSegCap, uint32_t *refs, int *nRefs) {
   constexpr int MW = (NW + 1) / 2;  // 64-bit words of the read-offset bitmask
   uint64_t M[MW];
   int onDiag = 0;
@@ -185,16 +204,14 @@ __device__ inline int groupFastPath(const uint32_t *Mw, int diag, const ReadCtx 
       last = w * 64 + 63 - __clzll((long long)M[w]);
     }
   }
-  // covered positions: dilate M by k (bit p set iff some hit offset a has a <= p < a + k)
+  // covered positions: dilate M by k (bit p set iff some hit offset a has a <= p < a + k), by doubling
   uint64_t C[MW];
 #pragma unroll
   for (int w = 0; w < MW; ++w) C[w] = M[w];
-  for (int sft = 1; sft < k; ++sft) {
-#pragma unroll
-    for (int w = MW - 1; w >= 0; --w) {
-      uint64_t carry = w > 0 ? (M[w - 1] >> (64 - sft)) : 0ull;
-      C[w] |= (M[w] << sft) | carry;
-    }
+  {
+    int have = 1;
+    while (2 * have <= k) { shlOr<MW>(C, have); have *= 2; }
+    if (have < k) shlOr<MW>(C, k - have);
   }
   int cov = 0;
 #pragma unroll
@@ -202,32 +219,55 @@ __device__ inline int groupFastPath(const uint32_t *Mw, int diag, const ReadCtx 
   // (the dilation may spill past NW*32 only for offsets that cannot occur: a + k <= len <= NW*32)
   if (cov < hitLenRequired) return 1;  // GetTotalHitLengthOnRead/OnSeq (1512-1522)
   const int spanEnd = last + k, span = spanEnd - first;
-  // mismatch bits of the span on this diagonal, one burst of independent loads
+  // mismatch bits of the span on this diagonal, relative to `first`: bit 2*j of mmw[i] <-> read position first + 32*i + j.
+  // Both windows are fetched as NW + 1 consecutive words and funnel-shifted in registers (one burst of independent loads).
   uint64_t mmw[NW];
   int mmT = 0;
+  {
+    const int64_t g0 = c.goff + (first - diag);
+    const int64_t gw = g0 >> 5;
+    const int gsh = (int)(g0 & 31) * 2, rsh = (first & 31) * 2;
+    const int rw = first >> 5;
+    const int nWin = (span + 31) >> 5;
+    constexpr int NP = (NW + 2) / 2;  // 16-byte pieces covering NW + 1 words
+    uint64_t G[2 * NP], R[2 * NP], GN[2 * NP], RN[2 * NP];
 #pragma unroll
-  for (int w = 0; w < NW; ++w) {
-    mmw[w] = 0;
-    const int p0 = w * 32;
-    if (p0 < spanEnd && p0 + 32 > first) {
-      const int lo = p0 < first ? first : p0;  // never read the allele before its first base
-      uint64_t xo = t1k_get32(c.rb, lo) ^ t1k_get32(c.gb, c.goff + lo - diag);
-      uint64_t mm = (xo | (xo >> 1)) & T1K_EVEN & ~(t1k_get32(c.rn, lo) | t1k_get32(c.gn, c.goff + lo - diag));
-      mm <<= 2 * (lo - p0);
-      const int hiN = spanEnd - p0;
-      if (hiN < 32) mm &= t1k_lowmask(hiN);
-      mmw[w] = mm;
-      mmT += __popcll(mm);
+    for (int j = 0; j < NP; ++j) {
+      const bool need = 2 * j <= nWin;  // the arrays carry spare words, but do not stream what is never used
+      t1k_u64x2 g = {0ull, 0ull}, r = {0ull, 0ull}, rn2 = {0ull, 0ull};
+      if (need) { g = *(const t1k_u64x2 *)(c.gb + gw + 2 * j); r = *(const t1k_u64x2 *)(c.rb + rw + 2 * j); rn2 = *(const t1k_u64x2 *)(c.rn + rw + 2 * j); }
+      G[2 * j] = g.x; G[2 * j + 1] = g.y; R[2 * j] = r.x; R[2 * j + 1] = r.y; RN[2 * j] = rn2.x; RN[2 * j + 1] = rn2.y;
+      GN[2 * j] = GN[2 * j + 1] = 0ull;
+    }
+    if (hasN) {
+#pragma unroll
+      for (int j = 0; j < NP; ++j) {
+        if (2 * j <= nWin) { const t1k_u64x2 g = *(const t1k_u64x2 *)(c.gn + gw + 2 * j); GN[2 * j] = g.x; GN[2 * j + 1] = g.y; }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+      mmw[i] = 0;
+      if (i < nWin) {
+        const uint64_t g = (G[i] >> gsh) | ((G[i + 1] << 1) << (63 - gsh)), r = (R[i] >> rsh) | ((R[i + 1] << 1) << (63 - rsh));
+        const uint64_t nn = ((GN[i] >> gsh) | ((GN[i + 1] << 1) << (63 - gsh))) | ((RN[i] >> rsh) | ((RN[i + 1] << 1) << (63 - rsh)));
+        const uint64_t xo = g ^ r;
+        uint64_t mm = (xo | (xo >> 1)) & T1K_EVEN & ~nn;
+        const int rem = span - 32 * i;
+        if (rem < 32) mm &= t1k_lowmask(rem);
+        mmw[i] = mm;
+        mmT += __popcll(mm);
+      }
     }
   }
   int matchCnt;
+  int result = 1;
   if (mmT <= 3) matchCnt = 2 * (span - mmT);
   else {
     // walk the gaps (maximal uncovered runs inside the span)
     int sumSmall = 0, nBig = 0;
-    // pass 1: per-gap mismatch counts -> upper bound
     int pos = first;
-    // gap iteration helper: next uncovered position >= pos is the lowest clear bit of C at or above pos
+    // next uncovered / covered position >= from (lowest clear / set bit of C at or above it)
     auto nextClear = [&](int from) -> int {
 #pragma unroll
       for (int w = 0; w < MW; ++w) {
@@ -250,7 +290,8 @@ __device__ inline int groupFastPath(const uint32_t *Mw, int diag, const ReadCtx 
       }
       return MW * 64;
     };
-    auto mmIn = [&](int gs, int ge) -> int {  // mismatches in [gs, ge)
+    auto mmIn = [&](int gsAbs, int geAbs) -> int {  // mismatches in read positions [gsAbs, geAbs)
+      const int gs = gsAbs - first, ge = geAbs - first;
       int x = 0;
 #pragma unroll
       for (int q = 0; q < NW; ++q) {
@@ -264,6 +305,7 @@ __device__ inline int groupFastPath(const uint32_t *Mw, int diag, const ReadCtx 
       }
       return x;
     };
+    // pass 1: per-gap mismatch counts -> upper bound
     while (true) {
       int gs = nextClear(pos);
       if (gs >= spanEnd) break;
@@ -277,8 +319,8 @@ __device__ inline int groupFastPath(const uint32_t *Mw, int diag, const ReadCtx 
     if (nBig == 0) matchCnt = upper;  // exact
     else if ((double)upper / (double)(2 * span) < simThreshold) matchCnt = upper;  // certain to be dropped; no DP needed
     else {
-      int gapMatch = 0;
-      bool parked = false;
+      int gapMatch = 0, nref = 0;
+      bool again = false;
       pos = first;
       while (true) {
         int gs = nextClear(pos);
@@ -288,17 +330,21 @@ __device__ inline int groupFastPath(const uint32_t *Mw, int diag, const ReadCtx 
         int x = mmIn(gs, ge);
         if (x <= 3) gapMatch += (ge - gs) - x;
         else {
-          int r = gapMatchesCached<DEFER>(c, gs, c.goff + (gs - diag), ge - gs, strandBit, cache, dpCounter, jobList, jobCount, jobTag, jobCap);
-          if (r < 0) parked = true; else gapMatch += r;  // keep walking: later gaps register their jobs too
+          uint32_t slot = 0;
+          int r = gapMatchesCached<DEFER>(c, gs, c.goff + (gs - diag), ge - gs, strandBit, cache, dpCounter, jobStr, counters, jobTag, jobSegCap, &slot);
+          if (r >= 0) gapMatch += r;
+          else if (r == -1 && nref < GROUP_MAX_REFS) { refs[nref >> 1] |= slot << (16 * (nref & 1)); ++nref; }
+          else again = true;  // keep walking: later gaps register their jobs too
         }
         pos = ge;
       }
-      if (parked) return 2;
+      if (again) return 2;
       matchCnt = 2 * cov + 2 * gapMatch;
+      if (nref) { *nRefs = nref; result = 3; }
     }
   }
   out.push(first, last + k - 1, first - diag, last - diag + k - 1, 2 * cov, matchCnt);
-  return 1;
+  return result;
 }
 
 __device__ __forceinline__ bool hitKeyLess(uint32_t x, uint32_t y) {  // (diag, alleleOff, readOff): CompSortHitCoordDiff (266-274)
@@ -455,12 +501,14 @@ __device__ __forceinline__ VoteKey voteKey(int matchCnt0, int rs, int re, uint32
 // Posting lists are sorted by allele, so the chunk's slice of every used list is found by binary search from a cursor.
 // A group record leaves the chip once, coalesced; no hit list is ever written.
 // ------------------------------------------------------------------------------------------------------------------
-#define CHUNK_A 1024
+#ifndef CHUNK_A
+#define CHUNK_A 512
+#endif
 #define DIAG_EMPTY 0x7FFFFFFF
 
 template <int NW>
 __global__ __launch_bounds__(WG) void k_seed_groups(ChainArgs P) {
-  constexpr int AW = NW == 5 ? 8 : 12;  // u32 per accumulator: diag, meta, M[NW] (+ pad)
+  constexpr int AW = NW == 5 ? 7 : 13;  // u32 per accumulator: diag, meta, M[NW]; odd stride = no LDS bank conflicts
   extern __shared__ uint32_t lds[];
   const int k = P.k;
   const int maxK = 2 * (P.reads.S * 32);
@@ -471,9 +519,11 @@ __global__ __launch_bounds__(WG) void k_seed_groups(ChainArgs P) {
   uint32_t *cur = ukLen + maxK;                     // [maxK]  per used list: cursor (end of the previous chunk's slice)
   uint32_t *sLo = cur + maxK;                       // [maxK]  slice of the current chunk
   uint32_t *pre = sLo + maxK;                       // [maxK + 1] exclusive prefix of the slice lengths
-  uint16_t *usedQ = (uint16_t *)(pre + maxK + 1);   // [maxK]
+  uint32_t *lstStart = pre + maxK + 1;              // [maxK]  posting-list start of the current strand's used lists
+  uint16_t *usedQ = (uint16_t *)(lstStart + maxK);  // [maxK]
+  uint16_t *qOf = usedQ + maxK;                     // [maxK]  read offset of the current strand's used lists
   __shared__ uint32_t warpSums[4];
-  __shared__ uint32_t sUsed[2], sGroupBase, sTotal;
+  __shared__ uint32_t sUsed[2], sGroupBase, sMin;
   const int tid = threadIdx.x;
   const uint32_t kmask = (1u << (2 * k)) - 1;
   const uint32_t A = P.ref.nAlleles;
@@ -500,31 +550,44 @@ __global__ __launch_bounds__(WG) void k_seed_groups(ChainArgs P) {
       ukStart[q] = st; ukLen[q] = ln;
     }
     __syncthreads();
-    // the sequential look-up rule (SeqSet.hpp:1098-1153, 1165-1226)
-    if (tid == 0) {
+    // the sequential look-up rule (SeqSet.hpp:1098-1153, 1165-1226).  The first wavefront runs it as uniform
+    // (scalar) code: each lane holds one k-mer's code and list length, the loop reads them with v_readlane.
+    if (tid < 64) {
       uint32_t prev = 0;  // prevKmerCode starts at code 0 and is carried from the + strand into the - strand
       uint32_t nUsed = 0;
-      unsigned long long lookups = 0, postings = 0;
+      uint32_t lookups = 0, postings = 0;
       for (int pass = 0; pass < 2; ++pass) {
         int skipCnt = 0;
-        uint32_t begin = nUsed;
-        for (int p = 0; p < nk; ++p) {
-          int q = pass * nk + p;
-          uint32_t code = ukCode[q] & 0x7FFFFFFFu;
-          if (p == 0 || code != prev) {
-            uint32_t size = ukLen[q];
-            ++lookups;
-            if (size >= 100 && p != 0 && p != nk - 1 && skipCnt < k / 2) { ++skipCnt; continue; }
-            skipCnt = 0;
-            if (size) { usedQ[nUsed++] = (uint16_t)q; postings += size; }
+        const uint32_t begin = nUsed;
+        for (int seg = 0; seg < nk; seg += 64) {
+          const int pl = seg + tid;
+          const uint32_t vc = pl < nk ? (ukCode[pass * nk + pl] & 0x7FFFFFFFu) : 0u;
+          const uint32_t vl = pl < nk ? ukLen[pass * nk + pl] : 0u;
+          const int cnt = min(64, nk - seg);
+          for (int j = 0; j < cnt; ++j) {
+            const uint32_t code = (uint32_t)__builtin_amdgcn_readlane((int)vc, j);
+            const uint32_t size = (uint32_t)__builtin_amdgcn_readlane((int)vl, j);
+            const int p = seg + j;
+            if (p == 0 || code != prev) {
+              ++lookups;
+              if (size >= 100 && p != 0 && p != nk - 1 && skipCnt < k / 2) { ++skipCnt; continue; }
+              skipCnt = 0;
+              if (size) {
+                if (tid == 0) usedQ[nUsed] = (uint16_t)(pass * nk + p);
+                ++nUsed;
+                postings += size;
+              }
+            }
+            prev = code;
           }
-          prev = code;
         }
-        sUsed[pass] = nUsed - begin;
+        if (tid == 0) sUsed[pass] = nUsed - begin;
       }
-      atomicAdd(&P.counters[3], lookups);
-      atomicAdd(&P.counters[4], postings);
-      P.usedCount[2 * re] = sUsed[0]; P.usedCount[2 * re + 1] = sUsed[1];
+      if (tid == 0) {
+        atomicAdd(&P.counters[3], (unsigned long long)lookups);
+        atomicAdd(&P.counters[4], (unsigned long long)postings);
+        P.usedCount[2 * re] = sUsed[0]; P.usedCount[2 * re + 1] = sUsed[1];
+      }
     }
     __syncthreads();
     const uint32_t nUsedPlus = sUsed[0], nUsedMinus = sUsed[1];
@@ -544,97 +607,138 @@ __global__ __launch_bounds__(WG) void k_seed_groups(ChainArgs P) {
       const uint32_t uBegin = pass == 0 ? 0 : nUsedPlus;
       const uint32_t uCount = pass == 0 ? nUsedPlus : nUsedMinus;
       if (uCount == 0) continue;
-      for (uint32_t u = tid; u < uCount; u += WG) cur[u] = 0;
-      __syncthreads();
-      for (uint32_t c0 = 0; c0 < A; c0 += CHUNK_A) {
+      // thread t owns the lists t and t + WG (uCount <= 2 * WG: reads are at most 320 bp)
+      const bool has0 = (uint32_t)tid < uCount, has1 = (uint32_t)tid + WG < uCount;
+      uint32_t st0 = 0, ln0 = 0, st1 = 0, ln1 = 0, cur0 = 0, cur1 = 0;
+      if (has0) { const int q = usedQ[uBegin + tid]; st0 = ukStart[q]; ln0 = ukLen[q]; }
+      if (has1) { const int q = usedQ[uBegin + tid + WG]; st1 = ukStart[q]; ln1 = ukLen[q]; }
+      for (uint32_t u = tid; u < uCount; u += WG) qOf[u] = (uint16_t)(usedQ[uBegin + u] - pass * nk);
+      for (uint32_t u = tid; u < uCount; u += WG) lstStart[u] = ukStart[usedQ[uBegin + u]];
+      for (;;) {
+        // next chunk = the CHUNK_A alleles from the smallest allele any list still holds (empty stretches are skipped)
+        if (tid == 0) sMin = 0xFFFFFFFFu;
+        __syncthreads();
+        uint32_t nxt = 0xFFFFFFFFu;
+        if (has0 && cur0 < ln0) nxt = P.ref.kPost[st0 + cur0].allele;
+        if (has1 && cur1 < ln1) nxt = min(nxt, P.ref.kPost[st1 + cur1].allele);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) nxt = min(nxt, (uint32_t)__shfl_xor((int)nxt, o, 64));
+        if ((tid & 63) == 0 && nxt != 0xFFFFFFFFu) atomicMin(&sMin, nxt);
+        __syncthreads();
+        const uint32_t c0 = sMin;
+        if (c0 == 0xFFFFFFFFu) break;
         const uint32_t c1 = min(c0 + CHUNK_A, A);
         // slice of every used list inside [c0, c1): lower bound of c1 from the cursor
-        for (uint32_t u = tid; u < uCount; u += WG) {
-          const int q = usedQ[uBegin + u];
-          const uint32_t st = ukStart[q], ln = ukLen[q];
-          uint32_t l = cur[u], r = ln;
-          // gallop a little before the binary search: slices are short compared with the list
-          if (l < ln && P.ref.kPost[st + l].allele >= c1) r = l;
-          while (l < r) { uint32_t m = (l + r) >> 1; if (P.ref.kPost[st + m].allele < c1) l = m + 1; else r = m; }
-          sLo[u] = cur[u];
-          pre[u] = l - cur[u];  // slice length, turned into an exclusive prefix below
-          cur[u] = l;
+        uint32_t n0 = 0, n1 = 0;
+        if (has0) {
+          uint32_t l = cur0, r = ln0;
+          while (l < r) { uint32_t m = (l + r) >> 1; if (P.ref.kPost[st0 + m].allele < c1) l = m + 1; else r = m; }
+          n0 = l - cur0; sLo[tid] = cur0; cur0 = l;
         }
-        __syncthreads();
-        if (tid == 0) {
-          uint32_t run = 0;
-          for (uint32_t u = 0; u < uCount; ++u) { uint32_t n = pre[u]; pre[u] = run; run += n; }
-          pre[uCount] = run;
-          sTotal = run;
+        if (has1) {
+          uint32_t l = cur1, r = ln1;
+          while (l < r) { uint32_t m = (l + r) >> 1; if (P.ref.kPost[st1 + m].allele < c1) l = m + 1; else r = m; }
+          n1 = l - cur1; sLo[tid + WG] = cur1; cur1 = l;
         }
+        uint32_t tot0, tot1 = 0;
+        const uint32_t e0 = t1k_block_scan_exclusive(n0, warpSums, &tot0);
+        if (has0) pre[tid] = e0;
+        if (uCount > WG) {
+          const uint32_t e1 = t1k_block_scan_exclusive(n1, warpSums, &tot1);
+          if (has1) pre[tid + WG] = tot0 + e1;
+        }
+        const uint32_t T = tot0 + tot1;
+        if (tid == 0) { pre[uCount] = T; hitsLocal += T; }
         __syncthreads();
-        const uint32_t T = sTotal;
-        if (T == 0) { __syncthreads(); continue; }
-        if (tid == 0) hitsLocal += T;
-        // walk the chunk's postings (flat index -> list by binary search over the prefix)
-        for (uint32_t j = tid; j < T; j += WG) {
-          uint32_t lo = 0, hi = uCount;
-          while (hi - lo > 1) { uint32_t m = (lo + hi) >> 1; if (pre[m] <= j) lo = m; else hi = m; }
-          const uint32_t u = lo;
-          const int q = usedQ[uBegin + u];
-          const T1kPosting pst = P.ref.kPost[ukStart[q] + sLo[u] + (j - pre[u])];
-          const int r = q - pass * nk;
-          const int d = r - (int)pst.offset;
-          uint32_t *a = acc + (pst.allele - c0) * AW;
-          const uint32_t old = atomicCAS(&a[0], (uint32_t)DIAG_EMPTY, (uint32_t)d);
-          if (old == (uint32_t)DIAG_EMPTY || old == (uint32_t)d) atomicOr(&a[2 + (r >> 5)], 1u << (r & 31));
-          else {
-            int dd = d - (int)old; if (dd < 0) dd = -dd;
-            atomicAdd(&a[1], dd <= P.radius ? 0x10001u : 1u);
+        // walk the chunk's postings (flat index -> list by binary search over the prefix), four in flight per lane
+        for (uint32_t j0 = tid; j0 < T; j0 += 4 * WG) {
+          T1kPosting pst[4];
+          int rr[4];
+#pragma unroll
+          for (int x = 0; x < 4; ++x) {
+            const uint32_t j = j0 + x * WG;
+            if (j < T) {
+              uint32_t lo = 0, hi = uCount;
+              while (hi - lo > 1) { uint32_t m = (lo + hi) >> 1; if (pre[m] <= j) lo = m; else hi = m; }
+              pst[x] = P.ref.kPost[lstStart[lo] + sLo[lo] + (j - pre[lo])];
+              rr[x] = qOf[lo];
+            }
+          }
+#pragma unroll
+          for (int x = 0; x < 4; ++x) {
+            const uint32_t j = j0 + x * WG;
+            if (j < T) {
+              const int r = rr[x];
+              const int d = r - (int)pst[x].offset;
+              uint32_t *a = acc + (pst[x].allele - c0) * AW;
+              const uint32_t old = atomicCAS(&a[0], (uint32_t)DIAG_EMPTY, (uint32_t)d);
+              if (old == (uint32_t)DIAG_EMPTY || old == (uint32_t)d) atomicOr(&a[2 + (r >> 5)], 1u << (r & 31));
+              else {
+                int dd = d - (int)old; if (dd < 0) dd = -dd;
+                atomicAdd(&a[1], dd <= P.radius ? 0x10001u : 1u);
+              }
+            }
           }
         }
         __syncthreads();
         // emit the groups that can still produce a candidate: >= 3 hits in total, and either >= 3 on the reference diagonal
-        // or some hit close enough to chain with it, or > 2 strays (which could form their own run)
-        const int EPT = CHUNK_A / WG;
-        uint32_t mine = 0, flags = 0;
+        // or some hit close enough to chain with it, or > 2 strays (which could form their own run).  Lane t looks at the
+        // accumulators t, t + WG, ... (conflict-free with the odd accumulator stride); the records leave in allele order.
+        constexpr int EPT = CHUNK_A / WG;
+        uint32_t flags = 0;
+        uint64_t packed = 0;  // EPT counters of 16 bits
+#pragma unroll
         for (int i = 0; i < EPT; ++i) {
-          const uint32_t idx = tid * EPT + i;
-          const uint32_t *a = acc + idx * AW;
+          const uint32_t *a = acc + (i * WG + tid) * AW;
           if (a[0] == (uint32_t)DIAG_EMPTY) continue;
           int onDiag = 0;
 #pragma unroll
           for (int w = 0; w < NW; ++w) onDiag += __popc(a[2 + w]);
           const uint32_t strays = a[1] & 0xFFFFu, nearCnt = a[1] >> 16;
           const bool general = nearCnt > 0 || strays > 2;
-          if (onDiag + (int)strays >= 3 && (general || onDiag >= 3)) { ++mine; flags |= 1u << i; }
+          flags |= 2u << (2 * i);  // occupied
+          if (onDiag + (int)strays >= 3 && (general || onDiag >= 3)) { flags |= 1u << (2 * i); packed += 1ull << (16 * i); }
         }
-        uint32_t gTot;
-        uint32_t gOff = t1k_block_scan_exclusive(mine, warpSums, &gTot);
+        uint32_t totLo, totHi;
+        const uint32_t exLo = t1k_block_scan_exclusive((uint32_t)packed, warpSums, &totLo);
+        const uint32_t exHi = t1k_block_scan_exclusive((uint32_t)(packed >> 32), warpSums, &totHi);
+        const uint64_t ex = (uint64_t)exLo | ((uint64_t)exHi << 32), tt = (uint64_t)totLo | ((uint64_t)totHi << 32);
+        const uint32_t gTot = (uint32_t)((tt & 0xFFFF) + ((tt >> 16) & 0xFFFF) + ((tt >> 32) & 0xFFFF) + (tt >> 48));
         if (tid == 0) {
-          unsigned long long gb = gTot ? atomicAdd(&P.counters[6], (unsigned long long)gTot) : 0ull;
-          bool ok = gb + gTot <= P.groupCap && chunk < P.maxChunks;
+          const uint32_t gb = gTot ? t1k_arena_alloc(P.counters, T1K_AR_GROUPS, gTot, P.groupSegCap) : 0u;
+          const bool ok = gb != T1K_ARENA_FULL && chunk < P.maxChunks;
           if (!ok) atomicOr(&P.counters[2], (unsigned long long)ERR_GROUPCAP);
-          sGroupBase = ok ? (uint32_t)gb : 0xFFFFFFFFu;
-          if (ok && gTot) { P.chunkStart[(uint64_t)re * P.maxChunks + chunk] = (uint32_t)gb; P.chunkCount[(uint64_t)re * P.maxChunks + chunk] = gTot; }
+          sGroupBase = ok ? gb : 0xFFFFFFFFu;
+          if (ok && gTot) { P.chunkStart[(uint64_t)re * P.maxChunks + chunk] = gb; P.chunkCount[(uint64_t)re * P.maxChunks + chunk] = gTot; }
         }
         __syncthreads();
         const uint32_t groupBase = sGroupBase;
         if (gTot) ++chunk;
+        uint32_t before = 0;  // records of the lower accumulator rows
+#pragma unroll
         for (int i = 0; i < EPT; ++i) {
-          const uint32_t idx = tid * EPT + i;
-          uint32_t *a = acc + idx * AW;
-          if (a[0] == (uint32_t)DIAG_EMPTY) continue;
-          if ((flags >> i) & 1u) {
-            if (groupBase != 0xFFFFFFFFu) {
-              uint32_t *rec = P.recs + (uint64_t)(groupBase + gOff) * stride;
-              rec[0] = re | (pass == 0 ? 0x80000000u : 0);  // bit31: '+' strand
-              rec[1] = c0 + idx;
-              rec[2] = a[0];
-              rec[3] = a[1];
+          if ((flags >> (2 * i)) & 2u) {
+            uint32_t *a = acc + (i * WG + tid) * AW;
+            if (((flags >> (2 * i)) & 1u) && groupBase != 0xFFFFFFFFu) {
+              const uint32_t slot = before + (uint32_t)((ex >> (16 * i)) & 0xFFFF);
+              uint4 *rec = (uint4 *)(P.recs + (uint64_t)(groupBase + slot) * stride);
+              uint32_t v[NW == 5 ? 12 : 16];
+              v[0] = re | (pass == 0 ? 0x80000000u : 0);  // bit31: '+' strand
+              v[1] = c0 + i * WG + tid;
+              v[2] = a[0];
+              v[3] = a[1];
 #pragma unroll
-              for (int w = 0; w < NW; ++w) rec[4 + w] = a[2 + w];
+              for (int w = 0; w < NW; ++w) v[4 + w] = a[2 + w];
+#pragma unroll
+              for (int w = 4 + NW; w < (NW == 5 ? 12 : 16); ++w) v[w] = 0;
+#pragma unroll
+              for (int w = 0; w < (NW == 5 ? 3 : 4); ++w) rec[w] = make_uint4(v[4 * w], v[4 * w + 1], v[4 * w + 2], v[4 * w + 3]);
             }
-            ++gOff;
-          }
-          a[0] = (uint32_t)DIAG_EMPTY; a[1] = 0;
+            a[0] = (uint32_t)DIAG_EMPTY; a[1] = 0;
 #pragma unroll
-          for (int w = 0; w < NW; ++w) a[2 + w] = 0;
+            for (int w = 0; w < NW; ++w) a[2 + w] = 0;
+          }
+          before += (uint32_t)((tt >> (16 * i)) & 0xFFFF);
         }
         __syncthreads();
       }
@@ -656,42 +760,70 @@ __device__ __forceinline__ ReadCtx makeCtx(const ChainArgs &P, uint32_t re, int 
   return c;
 }
 
-__device__ __forceinline__ void waveFlush(unsigned long long *counter, unsigned int v) {
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-  if ((threadIdx.x & 63) == 0 && v) atomicAdd(counter, (unsigned long long)v);
-}
-
 template <int NW, bool DEFER>
 __global__ __launch_bounds__(WG) void k_chain_fast(ChainArgs P, const uint32_t *list, uint32_t nItems) {
-  const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   unsigned int dpLocal = 0, fastLocal = 0;
-  if (gid < nItems) {
-    const uint32_t gi = list ? list[gid] : (uint32_t)gid;
+  int kind = 0;
+  uint32_t gi = 0;
+  bool valid;
+  if (list) {  // list mode: 1-D grid over a dense list of record indices
+    const uint64_t gid = (uint64_t)blockIdx.x * WG + threadIdx.x;
+    valid = gid < nItems;
+    if (valid) gi = list[gid];
+  } else {     // all records: blockIdx.y = arena segment, blockIdx.x = block within the segment
+    const unsigned long long cnt = *t1k_arena_cursor(P.counters, T1K_AR_GROUPS, blockIdx.y);
+    const uint32_t idx = blockIdx.x * WG + threadIdx.x;
+    valid = idx < cnt;
+    gi = blockIdx.y * P.groupSegCap + idx;
+  }
+  if (valid) {
     uint32_t *rec = P.recs + (uint64_t)gi * P.recStride;
-    const uint32_t re = rec[0] & 0x7FFFFFFFu, allele = rec[1], meta = rec[3];
-    const int pass = (rec[0] >> 31) ? 0 : 1;
+    uint32_t rv[NW == 5 ? 12 : 16];  // the record, fetched as 16-byte pieces
+#pragma unroll
+    for (int w = 0; w < (NW == 5 ? 3 : 4); ++w) {
+      const uint4 q4 = ((const uint4 *)rec)[w];
+      rv[4 * w] = q4.x; rv[4 * w + 1] = q4.y; rv[4 * w + 2] = q4.z; rv[4 * w + 3] = q4.w;
+    }
+    const uint32_t re = rv[0] & 0x7FFFFFFFu, allele = rv[1], meta = rv[3];
+    const int pass = (rv[0] >> 31) ? 0 : 1;
     const bool general = (meta >> 16) > 0 || (meta & 0xFFFFu) > 2;
-    if (general) { uint32_t q = atomicAdd((uint32_t *)&P.counters[18], 1u); P.generalList[q] = gi; }
+    if (general) kind = 4;
     else {
       uint32_t Mw[NW];
 #pragma unroll
-      for (int w = 0; w < NW; ++w) Mw[w] = rec[4 + w];
+      for (int w = 0; w < NW; ++w) Mw[w] = rv[4 + w];
       ReadCtx c = makeCtx(P, re, pass, allele);
       uint32_t cbuf[3];
       CandOut out{cbuf, 0};
       unsigned long long *memo = P.memo + (uint64_t)re * GAP_CACHE;
-      int done = groupFastPath<NW, DEFER>(Mw, (int)rec[2], c, P.k, P.hitLenRequired, P.sim, out, &dpLocal, pass, memo, P.jobList, (uint32_t *)&P.counters[16],
-                                          re * GAP_CACHE, P.jobCap);
-      if (done == 2) { uint32_t q = atomicAdd((uint32_t *)&P.counters[17], 1u); P.retryList[q] = gi; }
-      else {
+      uint32_t refs[3] = {0, 0, 0};
+      int nRefs = 0;
+      kind = groupFastPath<NW, DEFER>(Mw, (int)rv[2], c, P.ref.alleleHasN[allele] != 0, P.k, P.hitLenRequired, P.sim, out, &dpLocal, pass, memo, P.jobStr,
+                                      P.counters, re * GAP_CACHE, P.jobSegCap, refs, &nRefs);
+      if (kind == 3) {  // matchCnt lacks the registered alignments: k_chain_finish adds them from the memo
+        ((uint4 *)rec)[1] = make_uint4(cbuf[0], cbuf[1], cbuf[2], refs[0]);
+        ((uint2 *)rec)[4] = make_uint2(refs[1], refs[2]);
+        rec[3] = (uint32_t)nRefs;
+      } else if (kind == 1) {
         ++fastLocal;
-        if (out.n) { rec[4] = cbuf[0]; rec[5] = cbuf[1]; rec[6] = cbuf[2]; }
+        if (out.n) ((uint4 *)rec)[1] = make_uint4(cbuf[0], cbuf[1], cbuf[2], 0u);
         rec[3] = REC_DONE | (uint32_t)out.n;
       }
     }
   }
-  waveFlush(&P.counters[7], dpLocal);
-  waveFlush(&P.counters[11], fastLocal);
+  // list appends: one atomic per wavefront, list and arena segment
+  if (kind >= 2) {
+    const int arena = kind == 2 ? T1K_AR_RETRY : kind == 3 ? T1K_AR_FINISH : T1K_AR_GENERAL;
+    uint32_t *dst = kind == 2 ? P.retryStr : kind == 3 ? P.finishStr : P.generalStr;
+    uint32_t q;
+    if (kind == 2) q = t1k_arena_append(P.counters, T1K_AR_RETRY, P.listSegCap);
+    else if (kind == 3) q = t1k_arena_append(P.counters, T1K_AR_FINISH, P.listSegCap);
+    else q = t1k_arena_append(P.counters, T1K_AR_GENERAL, P.listSegCap);
+    (void)arena;
+    if (q != T1K_ARENA_FULL) dst[q] = gi;  // a full segment shows in its cursor; the host fails the batch
+  }
+  t1k_stat_add(P.counters, T1K_STAT_DP, dpLocal);
+  t1k_stat_add(P.counters, T1K_STAT_FAST, fastLocal);
 }
 
 // K3: one lane per registered alignment
@@ -711,7 +843,31 @@ __global__ __launch_bounds__(WG) void k_dp_dense(ChainArgs P, uint32_t nJobs) {
     ++dpLocal;
     __hip_atomic_store(slot, (e & ~(GAP_PENDING << 21)) | ((unsigned long long)m << 21), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  waveFlush(&P.counters[7], dpLocal);
+  t1k_stat_add(P.counters, T1K_STAT_DP, dpLocal);
+}
+
+// K3b: groups whose candidate waits for registered alignments: add the memo's match counts (SeqSet.hpp:1736-1741)
+__global__ __launch_bounds__(WG) void k_chain_finish(ChainArgs P, uint32_t nItems) {
+  const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned int fastLocal = 0;
+  if (q < nItems) {
+    uint32_t *rec = P.recs + (uint64_t)P.finishList[q] * P.recStride;
+    const uint32_t re = rec[0] & 0x7FFFFFFFu;
+    const int nRefs = (int)rec[3];
+    const unsigned long long *memo = P.memo + (uint64_t)re * GAP_CACHE;
+    uint32_t sum = 0;
+    for (int i = 0; i < nRefs; ++i) {
+      const uint32_t slot = (rec[7 + (i >> 1)] >> (16 * (i & 1))) & 0xFFFFu;
+      const unsigned long long e = __hip_atomic_load(&memo[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const uint32_t v = (uint32_t)((e >> 21) & 0x1FF);
+      if (v == GAP_PENDING) atomicOr(&P.counters[2], (unsigned long long)ERR_MEMO);  // cannot happen: every registered job is run by k_dp_dense
+      sum += v;
+    }
+    rec[6] += (2u * sum) << 20;
+    rec[3] = REC_DONE | 1u;
+    ++fastLocal;
+  }
+  t1k_stat_add(P.counters, T1K_STAT_FAST, fastLocal);
 }
 
 // re-derive the hit list of one (read-end, strand, allele) group from the used posting lists kept by k_seed_groups:
@@ -753,21 +909,21 @@ __global__ __launch_bounds__(WG) void k_chain_general(ChainArgs P, uint32_t nIte
     uint32_t cbuf[GENERAL_CAP + 3];
     CandOut out{cbuf, 0};
     if (!needScratch) groupGeneral(hh, n, c, P.k, P.radius, P.hitLenRequired, wa, wb, wc, nullptr, 0, out, &dpLocal, &P.counters[2], &needScratch);
-    if (needScratch) { uint32_t b = atomicAdd((uint32_t *)&P.counters[19], 1u); P.bigList[b] = gi; }
+    if (needScratch) { const uint32_t b = t1k_arena_append(P.counters, T1K_AR_BIG, P.listSegCap); if (b != T1K_ARENA_FULL) P.bigStr[b] = gi; }
     else {
       ++genLocal;
       uint32_t base = 0;
       if (out.n) {
-        base = atomicAdd((uint32_t *)&P.counters[21], (uint32_t)out.n);
-        if (base + out.n > P.genCandCap) { atomicOr(&P.counters[2], (unsigned long long)ERR_STAGECAP); out.n = 0; }
+        base = t1k_arena_alloc(P.counters, T1K_AR_GENCAND, (uint32_t)out.n, P.genCandSegCap);
+        if (base == T1K_ARENA_FULL) { atomicOr(&P.counters[2], (unsigned long long)ERR_STAGECAP); out.n = 0; base = 0; }
         for (int i = 0; i < 3 * out.n; ++i) P.genCand[(uint64_t)base * 3 + i] = cbuf[i];
       }
       rec[4] = base;
       rec[3] = REC_DONE | 0x40000000u | (uint32_t)out.n;  // bit30: candidates live in the side arena
     }
   }
-  waveFlush(&P.counters[7], dpLocal);
-  waveFlush(&P.counters[12], genLocal);
+  t1k_stat_add(P.counters, T1K_STAT_DP, dpLocal);
+  t1k_stat_add(P.counters, T1K_STAT_GENERAL, genLocal);
 }
 
 // very large groups (repeat-rich alleles) or wide gaps: a handful of lanes with big scratch in HBM
@@ -792,8 +948,8 @@ __global__ __launch_bounds__(64) void k_chain_big(ChainArgs P, uint32_t nItems) 
     if (o2.n > 32) { atomicOr(&P.counters[2], (unsigned long long)ERR_BIGGROUP); o2.n = 32; }
     uint32_t base = 0;
     if (o2.n) {
-      base = atomicAdd((uint32_t *)&P.counters[21], (uint32_t)o2.n);
-      if (base + o2.n > P.genCandCap) { atomicOr(&P.counters[2], (unsigned long long)ERR_STAGECAP); o2.n = 0; }
+      base = t1k_arena_alloc(P.counters, T1K_AR_GENCAND, (uint32_t)o2.n, P.genCandSegCap);
+      if (base == T1K_ARENA_FULL) { atomicOr(&P.counters[2], (unsigned long long)ERR_STAGECAP); o2.n = 0; base = 0; }
       for (int i = 0; i < 3 * o2.n; ++i) P.genCand[(uint64_t)base * 3 + i] = cbuf[i];
     }
     rec[4] = base;
@@ -894,52 +1050,94 @@ __global__ __launch_bounds__(WG) void k_collect(ChainArgs P) {
 size_t t1k_chain_big_scratch_u32() { return (size_t)4 * BIG_CAP + GA_SCRATCH_INTS; }
 int t1k_chain_max_chunks(uint32_t nAlleles) { return 2 * (int)((nAlleles + CHUNK_A - 1) / CHUNK_A) + 2; }
 int t1k_chain_memo_entries() { return GAP_CACHE; }
-int t1k_chain_rec_stride(int maxLen) { return maxLen <= 160 ? 10 : 14; }
+int t1k_chain_rec_stride(int maxLen) { return maxLen <= 160 ? 12 : 16; }  // u32 per record, 16-byte aligned
 int t1k_chain_used_u32(int S) { return 2 * (S * 32) * 3; }
 
-static int readCounters(t1k_ctx *ctx, unsigned long long *h) {
-  T1K_HIP(ctx, hipMemcpyAsync(h, ctx->bCounters.p, 64 * 8, hipMemcpyDeviceToHost, ctx->stream));
-  T1K_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  return 0;
+static int readCounters(t1k_ctx *ctx, unsigned long long *h) { return t1k_fetch_counters(ctx, h); }
+
+// striped list -> dense list; grid (blocks, T1K_NSTRIPE)
+__global__ __launch_bounds__(WG) void k_arena_compact(const uint32_t *src, uint32_t segCap, const unsigned long long *cursors, uint32_t *dst) {
+  const uint32_t seg = blockIdx.y;
+  uint32_t prefix = 0;
+  for (uint32_t s = 0; s < seg; ++s) prefix += (uint32_t)min(cursors[s * 8], (unsigned long long)segCap);
+  const uint32_t cnt = (uint32_t)min(cursors[seg * 8], (unsigned long long)segCap);
+  for (uint32_t i = blockIdx.x * WG + threadIdx.x; i < cnt; i += gridDim.x * WG) dst[prefix + i] = src[(uint64_t)seg * segCap + i];
+}
+
+T1kArenaCounts t1k_arena_counts(const t1k_ctx *ctx, int arena, uint32_t segCap) {
+  T1kArenaCounts r{0, 0, false};
+  for (int s = 0; s < T1K_NSTRIPE; ++s) {
+    unsigned long long c = ctx->hRaw[T1K_ARENA_BASE + ((size_t)arena * T1K_NSTRIPE + s) * 8];
+    if (c > segCap) { r.overflow = true; c = segCap; }
+    r.total += c;
+    r.maxSeg = std::max<uint32_t>(r.maxSeg, (uint32_t)c);
+  }
+  return r;
+}
+
+void t1k_arena_compact(t1k_ctx *ctx, int arena, const uint32_t *src, uint32_t segCap, uint32_t *dst, uint32_t maxSeg) {
+  if (!maxSeg) return;
+  const unsigned long long *cur = (const unsigned long long *)ctx->bCounters.p + T1K_ARENA_BASE + (size_t)arena * T1K_NSTRIPE * 8;
+  hipLaunchKernelGGL(k_arena_compact, dim3(std::min<uint32_t>((maxSeg + WG - 1) / WG, 256u), T1K_NSTRIPE), dim3(WG), 0, ctx->stream, src, segCap, cur, dst);
 }
 
 // runs K1..K6; on return counters[0] = number of candidates, counters[2] = error flags
 int t1k_run_chain(t1k_ctx *ctx, const ChainArgs &a, int nWg, int bigBlocks, bool longReads, unsigned long long *hc) {
-  const int AW = longReads ? 12 : 8;
+  const int AW = longReads ? 13 : 7;
   const size_t maxK = (size_t)2 * a.reads.S * 32;
-  const size_t lds = (size_t)CHUNK_A * AW * 4 + maxK * (6 * 4 + 2) + 64;
+  const size_t lds = (size_t)CHUNK_A * AW * 4 + maxK * (7 * 4 + 4) + 64;
+  // the seeding kernel keeps no per-workgroup HBM scratch: over-subscribe the CUs so read-ends of uneven cost balance out
+  const int seedWg = (int)std::min<uint32_t>(a.reads.nReadEnds, 4096u);
   T1K_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
   if (longReads) {
     T1K_HIP(ctx, hipFuncSetAttribute((const void *)k_seed_groups<10>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_seed_groups<10>, dim3(nWg), dim3(WG), lds, ctx->stream, a);
+    hipLaunchKernelGGL(k_seed_groups<10>, dim3(seedWg), dim3(WG), lds, ctx->stream, a);
   } else {
     T1K_HIP(ctx, hipFuncSetAttribute((const void *)k_seed_groups<5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_seed_groups<5>, dim3(nWg), dim3(WG), lds, ctx->stream, a);
+    hipLaunchKernelGGL(k_seed_groups<5>, dim3(seedWg), dim3(WG), lds, ctx->stream, a);
   }
   T1K_HIP(ctx, hipEventRecord(ctx->ev[8], ctx->stream));
   int rc = readCounters(ctx, hc);
   if (rc) return rc;
   if (hc[2]) return 0;
-  const uint32_t nGroups = (uint32_t)hc[6];
-  if (nGroups) {
-    if (longReads) hipLaunchKernelGGL((k_chain_fast<10, true>), dim3((nGroups + WG - 1) / WG), dim3(WG), 0, ctx->stream, a, (const uint32_t *)nullptr, nGroups);
-    else hipLaunchKernelGGL((k_chain_fast<5, true>), dim3((nGroups + WG - 1) / WG), dim3(WG), 0, ctx->stream, a, (const uint32_t *)nullptr, nGroups);
+  const T1kArenaCounts groups = t1k_arena_counts(ctx, T1K_AR_GROUPS, a.groupSegCap);
+  hc[6] = groups.total;
+  if (groups.maxSeg) {
+    const dim3 grid((groups.maxSeg + WG - 1) / WG, T1K_NSTRIPE);
+    if (longReads) hipLaunchKernelGGL((k_chain_fast<10, true>), grid, dim3(WG), 0, ctx->stream, a, (const uint32_t *)nullptr, 0u);
+    else hipLaunchKernelGGL((k_chain_fast<5, true>), grid, dim3(WG), 0, ctx->stream, a, (const uint32_t *)nullptr, 0u);
   }
   if ((rc = readCounters(ctx, hc))) return rc;
-  const uint32_t nJobs = (uint32_t)std::min<unsigned long long>(hc[16] & 0xFFFFFFFFull, a.jobCap);
-  const uint32_t nRetry = (uint32_t)(hc[17] & 0xFFFFFFFFull), nGen = (uint32_t)(hc[18] & 0xFFFFFFFFull);
+  hc[6] = groups.total;
+  const T1kArenaCounts jobs = t1k_arena_counts(ctx, T1K_AR_JOBS, a.jobSegCap), retry = t1k_arena_counts(ctx, T1K_AR_RETRY, a.listSegCap),
+                       fin = t1k_arena_counts(ctx, T1K_AR_FINISH, a.listSegCap), gen = t1k_arena_counts(ctx, T1K_AR_GENERAL, a.listSegCap);
+  // (a full job segment is benign: the claim was released and the gap is aligned inline by the retry pass)
+  if (retry.overflow || fin.overflow || gen.overflow) { hc[2] |= ERR_GROUPCAP; return 0; }
+  hc[16] = jobs.total; hc[17] = retry.total; hc[18] = gen.total; hc[22] = fin.total;
+  t1k_arena_compact(ctx, T1K_AR_JOBS, a.jobStr, a.jobSegCap, a.jobList, jobs.maxSeg);
+  t1k_arena_compact(ctx, T1K_AR_FINISH, a.finishStr, a.listSegCap, a.finishList, fin.maxSeg);
+  t1k_arena_compact(ctx, T1K_AR_RETRY, a.retryStr, a.listSegCap, a.retryList, retry.maxSeg);
+  t1k_arena_compact(ctx, T1K_AR_GENERAL, a.generalStr, a.listSegCap, a.generalList, gen.maxSeg);
+  const uint32_t nJobs = (uint32_t)jobs.total, nRetry = (uint32_t)retry.total, nGen = (uint32_t)gen.total, nFinish = (uint32_t)fin.total;
   if (nJobs) hipLaunchKernelGGL(k_dp_dense, dim3((nJobs + WG - 1) / WG), dim3(WG), 0, ctx->stream, a, nJobs);
+  if (nFinish) hipLaunchKernelGGL(k_chain_finish, dim3((nFinish + WG - 1) / WG), dim3(WG), 0, ctx->stream, a, nFinish);
   if (nRetry) {
     if (longReads) hipLaunchKernelGGL((k_chain_fast<10, false>), dim3((nRetry + WG - 1) / WG), dim3(WG), 0, ctx->stream, a, (const uint32_t *)a.retryList, nRetry);
     else hipLaunchKernelGGL((k_chain_fast<5, false>), dim3((nRetry + WG - 1) / WG), dim3(WG), 0, ctx->stream, a, (const uint32_t *)a.retryList, nRetry);
   }
+  uint32_t nBig = 0;
   if (nGen) {
     hipLaunchKernelGGL(k_chain_general, dim3((nGen + WG - 1) / WG), dim3(WG), 0, ctx->stream, a, nGen);
     if ((rc = readCounters(ctx, hc))) return rc;  // the general kernel may hand groups over to the big-scratch kernel
+    const T1kArenaCounts big = t1k_arena_counts(ctx, T1K_AR_BIG, a.listSegCap);
+    if (big.overflow) { hc[2] |= ERR_GROUPCAP; return 0; }
+    t1k_arena_compact(ctx, T1K_AR_BIG, a.bigStr, a.listSegCap, a.bigList, big.maxSeg);
+    nBig = (uint32_t)big.total;
   }
-  const uint32_t nBig = (uint32_t)(hc[19] & 0xFFFFFFFFull);
   if (nBig) hipLaunchKernelGGL(k_chain_big, dim3(bigBlocks), dim3(64), 0, ctx->stream, a, nBig);
   hipLaunchKernelGGL(k_collect, dim3(nWg), dim3(WG), 0, ctx->stream, a);
   T1K_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
-  return readCounters(ctx, hc);
+  rc = readCounters(ctx, hc);
+  hc[6] = groups.total; hc[16] = jobs.total; hc[17] = retry.total; hc[18] = gen.total; hc[19] = nBig; hc[22] = fin.total;
+  return rc;
 }

@@ -59,6 +59,7 @@ struct T1kRefDev {
   const uint64_t *bases, *nmask, *exon;
   const uint64_t *alleleOff;    // [A]
   const uint32_t *alleleLen;    // [A]
+  const uint8_t *alleleHasN;    // [A] 1 if the allele holds an N anywhere (its N-mask words can be skipped otherwise)
   const uint32_t *sepStart;     // [A+1] into sepPos: interior N positions only (the -1 / len sentinels are implicit)
   const int32_t *sepPos;
   const uint32_t *kStart;       // [4^k + 1]
@@ -86,6 +87,8 @@ __device__ __forceinline__ uint64_t t1k_get32(const uint64_t *w, int64_t pos) {
   uint64_t lo = w[wi], hi = w[wi + 1];  // both loads issue together; branch-free so callers can keep many windows in flight
   return (lo >> sh) | ((hi << 1) << (63 - sh));
 }
+// two consecutive stream words in one 16-byte access (the streams are only 8-byte aligned; gfx950 global loads allow that)
+typedef uint64_t t1k_u64x2 __attribute__((ext_vector_type(2), aligned(8)));
 __device__ __forceinline__ uint64_t t1k_lowmask(int nPos) {  // mask of the first nPos positions (0..32)
   return nPos >= 32 ? ~0ull : ((1ull << (2 * nPos)) - 1);
 }
@@ -458,6 +461,62 @@ __device__ inline int t1k_ga_traceback(const uint8_t *trace, int lent, int lenp,
   return n;
 }
 
+// append to a global list from (possibly divergent) code: the active lanes of the wavefront share one atomic
+__device__ __forceinline__ uint32_t t1k_wave_append(uint32_t *counter) {
+  const uint64_t m = __ballot(1);
+  const int lane = threadIdx.x & 63;
+  uint32_t base = 0;
+  if (lane == __ffsll((long long)m) - 1) base = atomicAdd(counter, (uint32_t)__popcll(m));
+  base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+  return base + (uint32_t)__popcll(m & ((1ull << lane) - 1));
+}
+
+// Statistics counters (never read by device code).  Millions of atomics on one address serialise in L2, so every
+// statistic is striped over T1K_STAT_STRIPES cache lines behind the 64 control counters; the host adds the stripes up.
+#define T1K_STAT_STRIPES 256
+enum { T1K_STAT_DP = 0, T1K_STAT_FAST = 1, T1K_STAT_GENERAL = 2, T1K_STAT_EXTEND_DP = 3, T1K_STAT_NEARBEST = 4 };
+// Allocation cursors.  A returning atomic on ONE word tops out near 88 M/s on this part, far below what the chain kernels
+// ask for, so every device arena (group records, work lists, queues) is cut into T1K_NSTRIPE independent segments with
+// their own cursor (64 bytes apart); a workgroup allocates from segment blockIdx.x % T1K_NSTRIPE.  Lists are made dense
+// again by k_arena_compact before their consumer runs; group records are consumed segment by segment.
+#define T1K_NSTRIPE 32
+enum { T1K_AR_GROUPS = 0, T1K_AR_JOBS, T1K_AR_RETRY, T1K_AR_FINISH, T1K_AR_GENERAL, T1K_AR_BIG, T1K_AR_GENCAND, T1K_AR_EQ, T1K_AR_BAND, T1K_AR_WIDE, T1K_NARENA };
+#define T1K_ARENA_BASE (64 + T1K_STAT_STRIPES * 8)
+#define T1K_COUNTER_WORDS (T1K_ARENA_BASE + T1K_NARENA * T1K_NSTRIPE * 8)
+#define T1K_ARENA_FULL 0xFFFFFFFFu
+__device__ __forceinline__ unsigned long long *t1k_arena_cursor(unsigned long long *counters, int arena, uint32_t stripe) {
+  return counters + T1K_ARENA_BASE + ((uint32_t)arena * T1K_NSTRIPE + stripe) * 8;
+}
+// n consecutive slots in this workgroup's segment -> global slot index (segment * segCap + offset), or T1K_ARENA_FULL.
+// The cursor keeps counting past segCap, which is how the host sees the overflow.
+__device__ __forceinline__ uint32_t t1k_arena_alloc(unsigned long long *counters, int arena, uint32_t n, uint32_t segCap) {
+  const uint32_t stripe = blockIdx.x & (T1K_NSTRIPE - 1);
+  const unsigned long long off = atomicAdd(t1k_arena_cursor(counters, arena, stripe), (unsigned long long)n);
+  return off + n <= segCap ? stripe * segCap + (uint32_t)off : T1K_ARENA_FULL;
+}
+// one slot per calling lane; the active lanes of the wavefront share one atomic (works in divergent code)
+__device__ __forceinline__ uint32_t t1k_arena_append(unsigned long long *counters, int arena, uint32_t segCap) {
+  const uint64_t m = __ballot(1);
+  const int lane = threadIdx.x & 63;
+  const uint32_t stripe = blockIdx.x & (T1K_NSTRIPE - 1);
+  uint32_t base = 0;
+  if (lane == __ffsll((long long)m) - 1) {
+    const unsigned long long off = atomicAdd(t1k_arena_cursor(counters, arena, stripe), (unsigned long long)__popcll(m));
+    base = off > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)off;
+  }
+  base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+  const uint64_t off = (uint64_t)base + (uint32_t)__popcll(m & ((1ull << lane) - 1));
+  return off < segCap ? stripe * segCap + (uint32_t)off : T1K_ARENA_FULL;
+}
+__device__ __forceinline__ void t1k_stat_add(unsigned long long *counters, int kind, unsigned int v) {  // call from converged code
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  if ((threadIdx.x & 63) == 0 && v) {
+    const unsigned int stripe = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & (T1K_STAT_STRIPES - 1);
+    atomicAdd(&counters[64 + stripe * 8 + kind], (unsigned long long)v);
+  }
+}
+
 // exclusive prefix sum over a 256-thread workgroup (4 wavefronts); all threads must call it
 __device__ __forceinline__ uint32_t t1k_block_scan_exclusive(uint32_t v, uint32_t *warpSums, uint32_t *total) {
   // 256 threads = 4 wavefronts of 64
@@ -488,6 +547,7 @@ struct T1kDevBuf {
 
 struct t1k_ctx {
   int device = 0;
+  std::vector<unsigned long long> hRaw;  // last fetched counter block (control | statistics stripes | arena cursors)
   hipStream_t stream = nullptr;
   hipEvent_t ev[12] = {};
   t1k_params prm;

@@ -12,7 +12,9 @@ struct ChainArgs {
   uint32_t *usedOut, *usedCount;                           // [re][maxK][3] used k-mers (readOff, listStart, listLen); [re][2] counts per strand
   unsigned long long *memo;                                // [re][GAP_CACHE] memo of gap alignments
   uint32_t *jobList; uint32_t jobCap;
-  uint32_t *retryList, *generalList, *bigList;
+  uint32_t *retryList, *generalList, *bigList, *finishList;  // dense lists (filled by k_arena_compact)
+  uint32_t *jobStr, *retryStr, *generalStr, *bigStr, *finishStr;  // striped arenas the kernels append to
+  uint32_t groupSegCap, jobSegCap, listSegCap, genCandSegCap;
   uint32_t *genCand; uint32_t genCandCap;                  // packed candidates of multi-diagonal groups (3 u32 each)
   uint32_t *bigScratch;
   T1kCand *cand; uint64_t candCap;
@@ -49,7 +51,7 @@ struct FullArgs {
   int relax;
   T1kOvl *ovl;
   uint64_t nOvl;
-  uint32_t *slowQueue; uint32_t slowCap;
+  uint32_t *eqStr, *bandStr, *wideStr; uint32_t segCap;  // striped alignment queues
   unsigned long long *counters;
 };
 
@@ -90,3 +92,7 @@ void t1k_launch_fullalign_eq(t1k_ctx *ctx, const SlowArgs &a, int nBlocks);
 void t1k_launch_fullalign_band(t1k_ctx *ctx, const SlowArgs &a, int nBlocks);
 void t1k_launch_truncate(t1k_ctx *ctx, const TruncArgs &a, int nWg);
 void t1k_launch_coverage_scan(t1k_ctx *ctx, const T1kRefDev &ref, int32_t *out, const uint64_t *outOff);
+int t1k_fetch_counters(t1k_ctx *ctx, unsigned long long *h);
+struct T1kArenaCounts { uint64_t total; uint32_t maxSeg; bool overflow; };
+T1kArenaCounts t1k_arena_counts(const t1k_ctx *ctx, int arena, uint32_t segCap);  // from the last t1k_fetch_counters
+void t1k_arena_compact(t1k_ctx *ctx, int arena, const uint32_t *src, uint32_t segCap, uint32_t *dst, uint32_t maxSeg);
