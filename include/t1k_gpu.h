@@ -46,7 +46,7 @@ typedef struct {
   int32_t max_assign_cnt;       /* -n, default 2000 */
   /* device arena sizing (0 = defaults) */
   int32_t max_read_len;         /* longest read accepted, default 320 */
-  int32_t workgroups;           /* persistent workgroups of the per-read-end kernels, default 1024 */
+  int32_t workgroups;           /* persistent workgroups of the per-read-end kernels, default 2048 */
   int64_t hit_cap;              /* unused (kept for ABI stability) */
   int64_t group_cap;            /* (read-end, strand, allele) hit groups per batch */
   int64_t cand_cap;             /* candidate records per batch */

@@ -179,8 +179,13 @@ __device__ inline bool candBeforeFull(const T1kCand &a, const T1kCand &b) {
   return a.seqEnd < b.seqEnd;
 }
 
-#define SELECT_LDS_CAP 8192
+// The per-read-end sorts run in LDS.  Two instantiations share the read-ends by size so that the common small lists do not
+// pay the occupancy of the rare large ones: CAP 2048 (24 KB of LDS, six workgroups per CU) takes lists of up to 2048
+// entries, CAP 8192 (96 KB, one workgroup per CU) the rest; beyond 8192 the sort falls back to per-workgroup HBM scratch.
+#define SELECT_SMALL 2048
+#define SELECT_LARGE 8192
 
+template <int SELECT_LDS_CAP>
 __global__ __launch_bounds__(WG) void k_select(SelectArgs P) {
   extern __shared__ uint64_t dynLds[];
   uint64_t *sKey = dynLds;
@@ -192,7 +197,7 @@ __global__ __launch_bounds__(WG) void k_select(SelectArgs P) {
   for (uint32_t re = blockIdx.x; re < P.reads.nReadEnds; re += gridDim.x) {
     const uint32_t n = P.candCount[re], c0 = P.candStart[re];
     if (n == 0) {
-      if (tid == 0) { P.ovlStart[re] = 0; P.ovlCount[re] = 0; }
+      if (tid == 0 && SELECT_LDS_CAP == SELECT_SMALL) { P.ovlStart[re] = 0; P.ovlCount[re] = 0; }
       continue;
     }
     // candidates that failed the similarity filter never reach the sort: count the survivors first
@@ -207,6 +212,7 @@ __global__ __launch_bounds__(WG) void k_select(SelectArgs P) {
     __syncthreads();
     const uint32_t live = sLive;
     __syncthreads();
+    if ((live > SELECT_SMALL) != (SELECT_LDS_CAP == SELECT_LARGE)) continue;  // the other instantiation's read-end
     if (live == 0) {
       if (tid == 0) { P.ovlStart[re] = 0; P.ovlCount[re] = 0; }
       continue;
@@ -585,6 +591,7 @@ __device__ inline bool ovlBeforeFull(const T1kOvl &a, const T1kOvl &b) {
   return a.seqEnd < b.seqEnd;
 }
 
+template <int SELECT_LDS_CAP>
 __global__ __launch_bounds__(WG) void k_truncate(TruncArgs P) {
   extern __shared__ uint64_t dynLds[];
   uint64_t *sKey = dynLds;
@@ -594,6 +601,7 @@ __global__ __launch_bounds__(WG) void k_truncate(TruncArgs P) {
   for (uint32_t re = blockIdx.x; re < P.reads.nReadEnds; re += gridDim.x) {
     const uint32_t n = P.ovlCount[re], o0 = P.ovlStart[re];
     if (n <= 1000) continue;
+    if ((n > SELECT_SMALL) != (SELECT_LDS_CAP == SELECT_LARGE)) continue;  // the other instantiation's read-end
     uint32_t np2 = 1;
     while (np2 < n) np2 <<= 1;
     uint64_t *key; uint32_t *idx;
@@ -688,10 +696,10 @@ void t1k_launch_extend(t1k_ctx *ctx, const ExtendArgs &a) {
   if (!a.nCand) return;
   hipLaunchKernelGGL(k_extend, dim3((unsigned)((a.nCand + WG - 1) / WG)), dim3(WG), 0, ctx->stream, a);
 }
-#define SELECT_LDS_BYTES (SELECT_LDS_CAP * 12)
 void t1k_launch_select(t1k_ctx *ctx, const SelectArgs &a, int nWg) {
-  hipFuncSetAttribute((const void *)k_select, hipFuncAttributeMaxDynamicSharedMemorySize, SELECT_LDS_BYTES);
-  hipLaunchKernelGGL(k_select, dim3(nWg), dim3(WG), SELECT_LDS_BYTES, ctx->stream, a);
+  hipFuncSetAttribute((const void *)k_select<SELECT_LARGE>, hipFuncAttributeMaxDynamicSharedMemorySize, SELECT_LARGE * 12);
+  hipLaunchKernelGGL(k_select<SELECT_SMALL>, dim3(nWg), dim3(WG), SELECT_SMALL * 12, ctx->stream, a);
+  hipLaunchKernelGGL(k_select<SELECT_LARGE>, dim3(std::min(nWg, 512)), dim3(WG), SELECT_LARGE * 12, ctx->stream, a);
 }
 void t1k_launch_fullalign(t1k_ctx *ctx, const FullArgs &a) {
   if (!a.nOvl) return;
@@ -701,8 +709,9 @@ void t1k_launch_fullalign_slow(t1k_ctx *ctx, const SlowArgs &a, int nBlocks) { h
 void t1k_launch_fullalign_eq(t1k_ctx *ctx, const SlowArgs &a, int nBlocks) { hipLaunchKernelGGL(k_fullalign_eq, dim3(nBlocks), dim3(WG), 0, ctx->stream, a); }
 void t1k_launch_fullalign_band(t1k_ctx *ctx, const SlowArgs &a, int nBlocks) { hipLaunchKernelGGL(k_fullalign_band, dim3(nBlocks), dim3(WG), 0, ctx->stream, a); }
 void t1k_launch_truncate(t1k_ctx *ctx, const TruncArgs &a, int nWg) {
-  hipFuncSetAttribute((const void *)k_truncate, hipFuncAttributeMaxDynamicSharedMemorySize, SELECT_LDS_BYTES);
-  hipLaunchKernelGGL(k_truncate, dim3(nWg), dim3(WG), SELECT_LDS_BYTES, ctx->stream, a);
+  hipFuncSetAttribute((const void *)k_truncate<SELECT_LARGE>, hipFuncAttributeMaxDynamicSharedMemorySize, SELECT_LARGE * 12);
+  hipLaunchKernelGGL(k_truncate<SELECT_SMALL>, dim3(nWg), dim3(WG), SELECT_SMALL * 12, ctx->stream, a);
+  hipLaunchKernelGGL(k_truncate<SELECT_LARGE>, dim3(std::min(nWg, 512)), dim3(WG), SELECT_LARGE * 12, ctx->stream, a);
 }
 void t1k_launch_coverage_scan(t1k_ctx *ctx, const T1kRefDev &ref, int32_t *out, const uint64_t *outOff) {
   hipLaunchKernelGGL(k_coverage_scan, dim3(ref.nAlleles), dim3(WG), 0, ctx->stream, ref, out, outOff);

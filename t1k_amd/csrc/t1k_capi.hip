@@ -52,7 +52,7 @@ void t1k_params_default(t1k_params *p) {
   p->relax_intron_align = 0;
   p->max_assign_cnt = 2000;
   p->max_read_len = 320;
-  p->workgroups = 512;
+  p->workgroups = 2048;
   p->hit_cap = 0;
   p->group_cap = 160ll << 20;
   p->cand_cap = 256ll << 20;
@@ -123,6 +123,7 @@ const char *t1k_last_error(const t1k_ctx *ctx) { return ctx ? ctx->err.c_str() :
 // ------------------------------------------------------------------------------------------------------------------
 int t1k_ref_upload(t1k_ctx *ctx, const char *seqs, const uint64_t *offsets, const uint8_t *exon, uint32_t nAlleles) {
   if (!ctx || !seqs || !offsets || nAlleles == 0 || nAlleles >= (1u << 24)) return t1k_fail(ctx, T1K_ERR_ARG, "t1k_ref_upload: bad arguments");
+  if (offsets[nAlleles] - offsets[0] >= (1ull << 29)) return t1k_fail(ctx, T1K_ERR_ARG, "t1k_ref_upload: reference larger than 512 Mbases");
   T1K_HIP(ctx, hipSetDevice(ctx->device));
   for (auto &b : ctx->refBufs) freeBuf(b);
   ctx->refBufs.clear();
@@ -310,6 +311,11 @@ extern "C++" int t1k_fetch_counters(t1k_ctx *ctx, unsigned long long *h) {
   static const int slot[5] = {7, 11, 12, 14, 10};
   for (int s = 0; s < T1K_STAT_STRIPES; ++s)
     for (int k = 0; k < 5; ++k) h[slot[k]] += raw[64 + s * 8 + k];
+  if (getenv("T1K_DEBUG_PHASES")) {
+    unsigned long long t[3] = {0, 0, 0};
+    for (int s = 0; s < T1K_STAT_STRIPES; ++s) for (int k = 0; k < 3; ++k) t[k] += raw[64 + s * 8 + 5 + k];
+    if (t[0] + t[1] + t[2]) fprintf(stderr, "[t1k] multi-diagonal groups by hit count: <=32 %llu, <=64 %llu, more %llu\n", t[0], t[1], t[2]);
+  }
   return 0;
 }
 static int fetchCounters(t1k_ctx *ctx, unsigned long long *h) { return t1k_fetch_counters(ctx, h); }
@@ -350,7 +356,7 @@ int t1k_assign_range(t1k_ctx *ctx, uint64_t first, uint32_t count) {
   const bool longReads = ctx->batchMaxLen > 160;
   const int recStride = t1k_chain_rec_stride(ctx->batchMaxLen);
   const uint64_t groupCap = (uint64_t)ctx->prm.group_cap;
-  const uint32_t jobCap = 16u << 20, genCandCap = 32u << 20;
+  const uint32_t jobCap = 16u << 20, genCandCap = 16u << 20, genHitCap = 64u << 20, genJobCap = 4u << 20;
   const int bigBlocks = 32;
   if ((rc = t1k_ensure(ctx, ctx->bCounters, (size_t)T1K_COUNTER_WORDS * 8))) return rc;
   if ((rc = t1k_ensure(ctx, ctx->bWgGroups, groupCap * recStride * 4))) return rc;                        // batch group records
@@ -362,7 +368,7 @@ int t1k_assign_range(t1k_ctx *ctx, uint64_t first, uint32_t count) {
   const uint32_t groupSegCap = (uint32_t)std::min<uint64_t>(groupCap / T1K_NSTRIPE, 0xFFFFFFFFull / T1K_NSTRIPE);
   const uint32_t listSegCap = std::max<uint32_t>(groupSegCap / 2, 1024u), jobSegCap = jobCap / T1K_NSTRIPE, genCandSegCap = genCandCap / T1K_NSTRIPE;
   const size_t listWords = (size_t)listSegCap * T1K_NSTRIPE;
-  if ((rc = t1k_ensure(ctx, ctx->bLists, ((size_t)jobCap * 2 + listWords * 8 + (size_t)genCandCap * 3) * 4 + 64))) return rc;
+  if ((rc = t1k_ensure(ctx, ctx->bLists, ((size_t)jobCap * 2 + listWords * 8 + (size_t)genCandCap * 6 + genHitCap + (size_t)genJobCap * 2) * 4 + 64))) return rc;
   if ((rc = t1k_ensure(ctx, ctx->bCand, (size_t)ctx->prm.cand_cap * sizeof(T1kCand)))) return rc;
   if ((rc = t1k_ensure(ctx, ctx->bExt, (size_t)ctx->prm.cand_cap * sizeof(T1kExt)))) return rc;
   if ((rc = t1k_ensure(ctx, ctx->bOvl, (size_t)ctx->prm.ovl_cap * sizeof(T1kOvl)))) return rc;
@@ -394,6 +400,8 @@ int t1k_assign_range(t1k_ctx *ctx, uint64_t first, uint32_t count) {
   a.retryList = a.jobStr + jobCap; a.generalList = a.retryList + listWords; a.bigList = a.generalList + listWords; a.finishList = a.bigList + listWords;
   a.retryStr = a.finishList + listWords; a.generalStr = a.retryStr + listWords; a.bigStr = a.generalStr + listWords; a.finishStr = a.bigStr + listWords;
   a.genCand = a.finishStr + listWords; a.genCandCap = genCandCap;
+  a.genHits = a.genCand + (size_t)genCandCap * 6; a.genHitSegCap = genHitCap / T1K_NSTRIPE;
+  a.genJobStr = a.genHits + genHitCap; a.genJobList = a.genJobStr + genJobCap; a.genJobSegCap = genJobCap / T1K_NSTRIPE;
   a.groupSegCap = groupSegCap; a.jobSegCap = jobSegCap; a.listSegCap = listSegCap; a.genCandSegCap = genCandSegCap;
   a.bigScratch = (uint32_t *)ctx->bWgBig.p;
   a.cand = (T1kCand *)ctx->bCand.p; a.candCap = (uint64_t)ctx->prm.cand_cap;

@@ -37,14 +37,25 @@ struct ReadCtx {
   int alleleLen;
 };
 
-struct CandOut {  // packed into the group's own hit segment: 3 u32 per candidate
+struct CandOut {  // packed candidates: 3 u32 each (+ 3 u32 of memo references when stride == 6, multi-diagonal groups)
   uint32_t *dst;
   int n;
+  int stride = 3;
+  int cap = 0x7FFFFFFF;
+  bool overflow = false;
   __device__ void push(int rs, int re, int ss, int se, int m0, int m) {
-    dst[3 * n + 0] = (uint32_t)rs | ((uint32_t)re << 12);
-    dst[3 * n + 1] = (uint32_t)ss | ((uint32_t)m0 << 20);
-    dst[3 * n + 2] = (uint32_t)se | ((uint32_t)m << 20);
+    if (n >= cap) { overflow = true; return; }
+    dst[stride * n + 0] = (uint32_t)rs | ((uint32_t)re << 12);
+    dst[stride * n + 1] = (uint32_t)ss | ((uint32_t)m0 << 20);
+    dst[stride * n + 2] = (uint32_t)se | ((uint32_t)m << 20);
+    if (stride == 6) dst[6 * n + 3] = dst[6 * n + 4] = dst[6 * n + 5] = 0;
     ++n;
+  }
+  // memo slots whose match counts are still missing from the last pushed candidate's matchCnt (count in bits 24..27 of word 0)
+  __device__ void setRefs(const uint32_t *refs, int nref) {
+    if (overflow || stride != 6 || n == 0) return;
+    uint32_t *d = dst + 6 * (n - 1);
+    d[0] |= (uint32_t)nref << 24; d[3] = refs[0]; d[4] = refs[1]; d[5] = refs[2];
   }
 };
 
@@ -67,13 +78,17 @@ __device__ inline int gapMatches(const ReadCtx &c, int ra, int ga, int lp, int l
 // ------------------------------------------------------------------------------------------------------------------
 // Exact memo of gap alignments within one read-end.  Thousands of alleles of a gene carry the same bases under a given
 // read window, so the same banded DP would be recomputed for each of them.  One 64-bit entry identifies a job completely:
-//   [gpos:34 | matches:9 | readPos:11 | len:9 | strand:1]
-// A probe whose (strand, readPos, len) agree verifies that the allele window at the entry's gpos holds exactly the same
-// bases and N-mask as its own window before it reuses the stored match count, so a hit is bit-exact by construction.
-// The table lives in per-workgroup HBM scratch (L2-resident, 32 KB) and is cleared per read-end.
+//   [gpos:30 | matches:9 | readPos:11 | readLen:9 | (alleleLen - readLen + 4):4 | strand:1]
+// A probe whose (strand, readPos, lengths) agree verifies that the allele window at the entry's gpos holds exactly the same
+// bases and N-mask as its own window before it reuses the stored match count, so a hit is bit-exact by construction
+// (GlobalAlignment only sees the two windows).  The table lives in HBM (16 KB per read-end) and is cleared per batch.
 // ------------------------------------------------------------------------------------------------------------------
 #define GAP_CACHE 2048
 #define GAP_PROBES 4
+#define GAP_ID_MASK 0x1FFFFFFull
+#define GAP_VAL(e) ((uint32_t)(((e) >> 25) & 0x1FF))
+#define GAP_GPOS(e) ((int64_t)((e) >> 34))
+#define GAP_PENDING 0x1FFull
 __device__ inline bool sameWindow(const uint64_t *gb, const uint64_t *gn, int64_t a, int64_t b, int L) {
   for (int o = 0; o < L; o += 32) {
     uint64_t lm = t1k_lowmask(L - o);
@@ -82,41 +97,61 @@ __device__ inline bool sameWindow(const uint64_t *gb, const uint64_t *gn, int64_
   return true;
 }
 
-#define GAP_PENDING 0x1FFull
+struct GapSink {  // where deferred alignments are registered
+  unsigned long long *cache;     // the read-end's memo table
+  uint32_t *jobStr;              // striped job list
+  unsigned long long *counters;
+  uint32_t jobTag, jobSegCap;
+  int arena;
+};
+
+// the alignment itself: lp read positions from readPos against lt allele positions from gpos, |lt - lp| <= 4
+__device__ __forceinline__ int gapAlign(const ReadCtx &c, int readPos, int64_t gpos, int lp, int lt) {
+  T1kSeqView T{c.gb, c.gn, gpos}, P{c.rb, c.rn, (int64_t)readPos};
+  if (lp == lt) return t1k_ga_matches_equal(T, P, lp, nullptr);
+  return t1k_ga_band<4, false>(T, lt, P, lp, nullptr, 0);
+}
+
 // DEFER = true : never run a DP here.  A miss claims a memo slot (CAS) with the PENDING marker and appends the slot to the
-//                workgroup's job list; the caller parks its group (return -1) until the dense DP phase has filled the memo.
-// DEFER = false: a miss is computed inline (used after the dense phase; only slot-collision leftovers get here).
+//                job list; the caller keeps the slot (return -1) and adds the match count once the dense DP phase has
+//                filled the memo.  -2: not memoisable / table or list full, the caller aligns it inline later.
+// DEFER = false: a miss is computed inline.
 template <bool DEFER>
-__device__ inline int gapMatchesCached(const ReadCtx &c, int readPos, int64_t gpos, int L, int strandBit, unsigned long long *cache, unsigned int *dpCounter,
-                                       uint32_t *jobStr, unsigned long long *counters, uint32_t jobTag, uint32_t jobSegCap, uint32_t *slotOut) {
-  if (L <= 0) return 0;
-  // mismatch count and a content hash of the allele window in one sweep
+__device__ inline int gapMatchesCached(const ReadCtx &c, int readPos, int64_t gpos, int lp, int lt, int strandBit, const GapSink &sink, unsigned int *dpCounter,
+                                       uint32_t *slotOut) {
+  if (lp <= 0 || lt <= 0) return 0;
+  const int d = lt - lp;
+  // content hash of the allele window (and, for equal lengths, the mismatch count) in one sweep
   int x = 0;
-  uint64_t hsh = 0x9E3779B97F4A7C15ull ^ ((uint64_t)readPos << 20) ^ ((uint64_t)L << 1) ^ (uint64_t)strandBit;
-  for (int o = 0; o < L; o += 32) {
-    uint64_t lm = t1k_lowmask(L - o);
+  uint64_t hsh = 0x9E3779B97F4A7C15ull ^ ((uint64_t)readPos << 20) ^ ((uint64_t)lp << 1) ^ ((uint64_t)(d + 4) << 40) ^ (uint64_t)strandBit;
+  for (int o = 0; o < lt; o += 32) {
+    uint64_t lm = t1k_lowmask(lt - o);
     uint64_t gw = t1k_get32(c.gb, gpos + o) & lm, gnw = t1k_get32(c.gn, gpos + o) & lm;
-    uint64_t xo = t1k_get32(c.rb, readPos + o) ^ gw;
-    uint64_t mm = (xo | (xo >> 1)) & T1K_EVEN & ~(t1k_get32(c.rn, readPos + o) | gnw) & lm;
-    x += __popcll(mm);
+    if (d == 0) {
+      uint64_t xo = t1k_get32(c.rb, readPos + o) ^ gw;
+      uint64_t mm = (xo | (xo >> 1)) & T1K_EVEN & ~(t1k_get32(c.rn, readPos + o) | gnw) & lm;
+      x += __popcll(mm);
+    }
     hsh = (hsh ^ gw ^ (gnw << 1)) * 0xD6E8FEB86659FD93ull;
     hsh ^= hsh >> 32;
   }
-  if (x <= 3) return L - x;  // exact fast path (see t1k_ga_matches_window)
-  if (L > 510 || readPos > 2047) {
-    if (DEFER) return -2;  // not memoisable: the retry phase computes it inline
-    return t1k_ga_matches_window(c.rb, c.rn, readPos, c.gb, c.gn, gpos, L, dpCounter);
+  if (d == 0 && x <= 3) return lp - x;  // exact fast path (see t1k_ga_matches_window)
+  if (lp > 510 || lt > 510 || readPos > 2047 || gpos >= (1ll << 30)) {
+    if (DEFER) return -2;  // not memoisable
+    if (dpCounter) ++*dpCounter;
+    return gapAlign(c, readPos, gpos, lp, lt);
   }
-  const uint64_t idBits = ((uint64_t)readPos << 10) | ((uint64_t)L << 1) | (uint64_t)strandBit;  // low 21 bits of an entry
+  const uint64_t idBits = ((uint64_t)readPos << 14) | ((uint64_t)lp << 5) | ((uint64_t)(d + 4) << 1) | (uint64_t)strandBit;  // low 25 bits of an entry
+  unsigned long long *cache = sink.cache;
   const uint32_t slot = (uint32_t)hsh & (GAP_CACHE - 1);
   bool pendingSeen = false;
 #pragma unroll
   for (int probe = 0; probe < GAP_PROBES; ++probe) {
     unsigned long long e = __hip_atomic_load(&cache[slot ^ probe], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (e != 0 && (e & 0x1FFFFFull) == idBits) {
-      int64_t eg = (int64_t)(e >> 30);
-      if (eg == gpos || sameWindow(c.gb, c.gn, eg, gpos, L)) {
-        unsigned long long v = (e >> 21) & 0x1FF;
+    if (e != 0 && (e & GAP_ID_MASK) == idBits) {
+      int64_t eg = GAP_GPOS(e);
+      if (eg == gpos || sameWindow(c.gb, c.gn, eg, gpos, lt)) {
+        const uint32_t v = GAP_VAL(e);
         if (v != GAP_PENDING) return (int)v;
         pendingSeen = true;
         *slotOut = slot ^ probe;
@@ -125,32 +160,31 @@ __device__ inline int gapMatchesCached(const ReadCtx &c, int readPos, int64_t gp
   }
   if (DEFER) {
     if (pendingSeen) return -1;
-    const unsigned long long pe = ((unsigned long long)gpos << 30) | (GAP_PENDING << 21) | idBits;
+    const unsigned long long pe = ((unsigned long long)gpos << 34) | (GAP_PENDING << 25) | idBits;
 #pragma unroll
     for (int probe = 0; probe < GAP_PROBES; ++probe) {
       unsigned long long old = atomicCAS(&cache[slot ^ probe], 0ull, pe);
       if (old == 0ull) {
-        const uint32_t q = t1k_arena_append(counters, T1K_AR_JOBS, jobSegCap);
-        if (q == T1K_ARENA_FULL) {  // job list full: release the claim, the retry pass computes this gap inline
+        const uint32_t q = t1k_arena_append(sink.counters, sink.arena, sink.jobSegCap);
+        if (q == T1K_ARENA_FULL) {  // job list full: release the claim
           __hip_atomic_store(&cache[slot ^ probe], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           return -2;
         }
-        jobStr[q] = jobTag + (slot ^ probe);
+        sink.jobStr[q] = sink.jobTag + (slot ^ probe);
         *slotOut = slot ^ probe;
         return -1;
       }
-      if ((old & 0x1FFFFFull) == idBits && ((int64_t)(old >> 30) == gpos || sameWindow(c.gb, c.gn, (int64_t)(old >> 30), gpos, L))) {
+      if ((old & GAP_ID_MASK) == idBits && (GAP_GPOS(old) == gpos || sameWindow(c.gb, c.gn, GAP_GPOS(old), gpos, lt))) {
         *slotOut = slot ^ probe;
         return -1;  // somebody else just claimed it
       }
     }
-    return -2;  // all probe slots taken by other jobs: inline in the retry phase
+    return -2;  // all probe slots taken by other jobs
   }
   if (dpCounter) ++*dpCounter;
-  T1kSeqView T{c.gb, c.gn, gpos}, P{c.rb, c.rn, (int64_t)readPos};
-  int m = t1k_ga_matches_equal(T, P, L, nullptr);
+  const int m = gapAlign(c, readPos, gpos, lp, lt);
   if (!pendingSeen) {
-    unsigned long long ne = ((unsigned long long)gpos << 30) | ((unsigned long long)m << 21) | idBits;
+    unsigned long long ne = ((unsigned long long)gpos << 34) | ((unsigned long long)m << 25) | idBits;
     unsigned long long cur = __hip_atomic_load(&cache[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (cur == 0) __hip_atomic_store(&cache[slot], ne, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
@@ -184,8 +218,7 @@ __device__ __forceinline__ void shlOr(uint64_t *C, int sft) {
 #define GROUP_MAX_REFS 6
 template <int NW, bool DEFER>
 __device__ inline int groupFastPath(const uint32_t *Mw, int diag, const ReadCtx &c, bool hasN, int k, int hitLenRequired, double simThreshold, CandOut &out,
-                                    unsigned int *dpCounter, int strandBit, unsigned long long *cache, uint32_t *jobStr, unsigned long long *counters, uint32_t jobTag,
-                                    uint32_t jobSegCap, uint32_t *refs, int *nRefs) {
+                                    unsigned int *dpCounter, int strandBit, const GapSink &sink, uint32_t *refs, int *nRefs) {
   constexpr int MW = (NW + 1) / 2;  // 64-bit words of the read-offset bitmask
   uint64_t M[MW];
   int onDiag = 0;
@@ -331,7 +364,7 @@ __device__ inline int groupFastPath(const uint32_t *Mw, int diag, const ReadCtx 
         if (x <= 3) gapMatch += (ge - gs) - x;
         else {
           uint32_t slot = 0;
-          int r = gapMatchesCached<DEFER>(c, gs, c.goff + (gs - diag), ge - gs, strandBit, cache, dpCounter, jobStr, counters, jobTag, jobSegCap, &slot);
+          int r = gapMatchesCached<DEFER>(c, gs, c.goff + (gs - diag), ge - gs, ge - gs, strandBit, sink, dpCounter, &slot);
           if (r >= 0) gapMatch += r;
           else if (r == -1 && nref < GROUP_MAX_REFS) { refs[nref >> 1] |= slot << (16 * (nref & 1)); ++nref; }
           else again = true;  // keep walking: later gaps register their jobs too
@@ -355,8 +388,15 @@ __device__ __forceinline__ bool hitKeyLess(uint32_t x, uint32_t y) {  // (diag, 
 
 // General group (several diagonals): restates GetOverlapsFromHits 1338-1551 and the chain walk 1697-1833.
 // A[n] sorted copy of the hits, B[n] concordant hits, C[n] packs top (low 16) / link (high 16) of the LIS.
-__device__ inline void groupGeneral(const uint32_t *h, int n, const ReadCtx &c, int k, int radius, int hitLenRequired, uint32_t *A, uint32_t *B,
-                                     uint32_t *C, int *gaScratch, int gaMax, CandOut &out, unsigned int *dpCounter, unsigned long long *errFlags, bool *needScratch) {
+// Arr: work-array accessor (plain pointer, or LaneArr = LDS arrays interleaved over the lanes of a wavefront)
+struct LaneArr {
+  uint32_t *p;  // element i of this lane's array lives at p[i * 64]
+  __device__ __forceinline__ uint32_t &operator[](int i) const { return p[i * 64]; }
+};
+template <class Arr>
+__device__ inline void groupGeneral(const uint32_t *h, int n, const ReadCtx &c, int k, int radius, int hitLenRequired, Arr A, Arr B,
+                                     Arr C, int *gaScratch, int gaMax, CandOut &out, unsigned int *dpCounter, unsigned long long *errFlags, bool *needScratch,
+                                     const GapSink *sink = nullptr, int strandBit = 0) {
   // insertion sort into A
   for (int i = 0; i < n; ++i) {
     uint32_t x = h[i];
@@ -455,7 +495,22 @@ __device__ inline void groupGeneral(const uint32_t *h, int n, const ReadCtx &c, 
       i = j;
     }
     if (lenR < hitLenRequired || lenS < hitLenRequired) { s = e; continue; }
-    // seed-chain match count (1697-1833)
+    // seed-chain match count (1697-1833).  With a sink the alignments are registered in the read-end's memo instead of being
+    // run here; the candidate then carries the memo slots (k_general_finish adds their match counts).
+    uint32_t refs[3] = {0, 0, 0};
+    int nref = 0;
+    auto gapM = [&](int ra, int ga, int lp, int lt) -> int {
+      if (!sink) return gapMatches(c, ra, ga, lp, lt, gaScratch, gaMax, dpCounter, errFlags, needScratch);
+      if (lp <= 0 || lt <= 0) return 0;
+      const int diff = lt > lp ? lt - lp : lp - lt;
+      if (diff > 4) { *needScratch = true; return 0; }
+      uint32_t slot = 0;
+      const int r = gapMatchesCached<true>(c, ra, c.goff + ga, lp, lt, strandBit, *sink, dpCounter, &slot);
+      if (r >= 0) return r;
+      if (r == -1 && nref < GROUP_MAX_REFS) { refs[nref >> 1] |= slot << (16 * (nref & 1)); ++nref; return 0; }
+      if (dpCounter) ++*dpCounter;
+      return gapAlign(c, ra, c.goff + ga, lp, lt);
+    };
     int matchCnt = 2 * k;
     for (int i = 1; i < ret; ++i) {
       int pa = (int)(A[s + i - 1] & 0xFFF), pb = (int)(A[s + i - 1] >> 12), qa = (int)(A[s + i] & 0xFFF), qb = (int)(A[s + i] >> 12);
@@ -463,17 +518,18 @@ __device__ inline void groupGeneral(const uint32_t *h, int n, const ReadCtx &c, 
       bool readOv = pa + k - 1 >= qa, seqOv = pb + k - 1 >= qb;
       if (sameDiag) {
         if (readOv) matchCnt += 2 * (qa - pa);
-        else matchCnt += 2 * k + 2 * gapMatches(c, pa + k, pb + k, qa - (pa + k), qb - (pb + k), gaScratch, gaMax, dpCounter, errFlags, needScratch);
+        else matchCnt += 2 * k + 2 * gapM(pa + k, pb + k, qa - (pa + k), qb - (pb + k));
       } else {
         if (readOv && !seqOv) matchCnt += 2 * (qa - pa);
         else if (!readOv && seqOv) matchCnt += 2 * (qb - pb);
         else if (readOv && seqOv) matchCnt += 2 * ((qa - pa) < (qb - pb) ? (qa - pa) : (qb - pb));
-        else matchCnt += 2 * k + 2 * gapMatches(c, pa + k, pb + k, qa - (pa + k), qb - (pb + k), gaScratch, gaMax, dpCounter, errFlags, needScratch);
+        else matchCnt += 2 * k + 2 * gapM(pa + k, pb + k, qa - (pa + k), qb - (pb + k));
       }
     }
     int rs = (int)(A[s] & 0xFFF), ss = (int)(A[s] >> 12);
     int re = (int)(A[s + ret - 1] & 0xFFF) + k - 1, se = (int)(A[s + ret - 1] >> 12) + k - 1;
     out.push(rs, re, ss, se, 2 * lenR, matchCnt);
+    out.setRefs(refs, nref);
     s = e;
   }
 }
@@ -795,11 +851,10 @@ __global__ __launch_bounds__(WG) void k_chain_fast(ChainArgs P, const uint32_t *
       ReadCtx c = makeCtx(P, re, pass, allele);
       uint32_t cbuf[3];
       CandOut out{cbuf, 0};
-      unsigned long long *memo = P.memo + (uint64_t)re * GAP_CACHE;
+      const GapSink sink{P.memo + (uint64_t)re * GAP_CACHE, P.jobStr, P.counters, re * GAP_CACHE, P.jobSegCap, T1K_AR_JOBS};
       uint32_t refs[3] = {0, 0, 0};
       int nRefs = 0;
-      kind = groupFastPath<NW, DEFER>(Mw, (int)rv[2], c, P.ref.alleleHasN[allele] != 0, P.k, P.hitLenRequired, P.sim, out, &dpLocal, pass, memo, P.jobStr,
-                                      P.counters, re * GAP_CACHE, P.jobSegCap, refs, &nRefs);
+      kind = groupFastPath<NW, DEFER>(Mw, (int)rv[2], c, P.ref.alleleHasN[allele] != 0, P.k, P.hitLenRequired, P.sim, out, &dpLocal, pass, sink, refs, &nRefs);
       if (kind == 3) {  // matchCnt lacks the registered alignments: k_chain_finish adds them from the memo
         ((uint4 *)rec)[1] = make_uint4(cbuf[0], cbuf[1], cbuf[2], refs[0]);
         ((uint2 *)rec)[4] = make_uint2(refs[1], refs[2]);
@@ -827,21 +882,20 @@ __global__ __launch_bounds__(WG) void k_chain_fast(ChainArgs P, const uint32_t *
 }
 
 // K3: one lane per registered alignment
-__global__ __launch_bounds__(WG) void k_dp_dense(ChainArgs P, uint32_t nJobs) {
+__global__ __launch_bounds__(WG) void k_dp_dense(ChainArgs P, const uint32_t *jobs, uint32_t nJobs) {
   const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
   unsigned int dpLocal = 0;
   if (q < nJobs) {
-    const uint32_t tag = P.jobList[q];
+    const uint32_t tag = jobs[q];
     const uint32_t re = tag / GAP_CACHE;
     unsigned long long *slot = P.memo + tag;
     const unsigned long long e = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int L = (int)((e >> 1) & 0x1FF), readPos = (int)((e >> 10) & 0x7FF), sb = (int)(e & 1);
-    const int64_t gpos = (int64_t)(e >> 30);
+    const int sb = (int)(e & 1), d = (int)((e >> 1) & 0xF) - 4, lp = (int)((e >> 5) & 0x1FF), readPos = (int)((e >> 14) & 0x7FF);
     const int S = P.reads.S;
-    T1kSeqView T{P.ref.bases, P.ref.nmask, gpos}, Pv{P.reads.bases + ((uint64_t)re * 2 + sb) * S, P.reads.nmask + ((uint64_t)re * 2 + sb) * S, (int64_t)readPos};
-    const int m = t1k_ga_matches_equal(T, Pv, L, nullptr);
+    ReadCtx c{P.reads.bases + ((uint64_t)re * 2 + sb) * S, P.reads.nmask + ((uint64_t)re * 2 + sb) * S, 0, P.ref.bases, P.ref.nmask, 0, 0};
+    const int m = gapAlign(c, readPos, GAP_GPOS(e), lp, lp + d);
     ++dpLocal;
-    __hip_atomic_store(slot, (e & ~(GAP_PENDING << 21)) | ((unsigned long long)m << 21), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(slot, (e & ~(GAP_PENDING << 25)) | ((unsigned long long)m << 25), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   t1k_stat_add(P.counters, T1K_STAT_DP, dpLocal);
 }
@@ -859,7 +913,7 @@ __global__ __launch_bounds__(WG) void k_chain_finish(ChainArgs P, uint32_t nItem
     for (int i = 0; i < nRefs; ++i) {
       const uint32_t slot = (rec[7 + (i >> 1)] >> (16 * (i & 1))) & 0xFFFFu;
       const unsigned long long e = __hip_atomic_load(&memo[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const uint32_t v = (uint32_t)((e >> 21) & 0x1FF);
+      const uint32_t v = GAP_VAL(e);
       if (v == GAP_PENDING) atomicOr(&P.counters[2], (unsigned long long)ERR_MEMO);  // cannot happen: every registered job is run by k_dp_dense
       sum += v;
     }
@@ -892,23 +946,96 @@ __device__ inline int gatherHits(const ChainArgs &P, uint32_t re, int pass, uint
   return n;
 }
 
-// K5: groups with several diagonals, one lane per group; hit list and work arrays in private memory (lane-interleaved).
-// Groups that are too large for that, or that need an alignment wider than the register band, go to k_chain_big.
-__global__ __launch_bounds__(WG) void k_chain_general(ChainArgs P, uint32_t nItems) {
+// K5a: hit lists of the multi-diagonal groups.  One wavefront per group: the lanes share the read-end's used posting lists,
+// each finds the allele's run in its lists (sorted by allele, then offset) and the hits are written to the hit arena;
+// record word 4 = arena offset, word 5 = hit count (0xFFFFFFFF: handed to k_chain_big)
+__global__ __launch_bounds__(WG) void k_gather_general(ChainArgs P, uint32_t nItems) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t wave = (blockIdx.x * WG + threadIdx.x) >> 6, nWaves = gridDim.x * (WG / 64);
+  const int maxK = 2 * (P.reads.S * 32);
+  constexpr int ROUNDS = 2 * GROUP_FAST_MAXLEN / 64 / 2;  // lists of one strand (<= 320) over 64 lanes
+  unsigned int h32 = 0, h64 = 0, hBig = 0;
+  for (uint32_t q = wave; q < nItems; q += nWaves) {
+    const uint32_t gi = P.generalList[q];
+    uint32_t *rec = P.recs + (uint64_t)gi * P.recStride;
+    const uint32_t re = rec[0] & 0x7FFFFFFFu, allele = rec[1];
+    const int pass = (rec[0] >> 31) ? 0 : 1;
+    const uint32_t nPlus = P.usedCount[2 * re], nMinus = P.usedCount[2 * re + 1];
+    const uint32_t b = pass == 0 ? 0 : nPlus, e = pass == 0 ? nPlus : nPlus + nMinus;
+    const uint32_t *uo = P.usedOut + (uint64_t)re * maxK * 3;
+    uint32_t first[ROUNDS], cnt[ROUNDS], mine = 0;
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+      const uint32_t u = b + lane + 64 * r;
+      first[r] = 0; cnt[r] = 0;
+      if (u < e) {
+        const uint32_t st = uo[3 * u + 1], ln = uo[3 * u + 2];
+        uint32_t l = 0, rr = ln;
+        while (l < rr) { uint32_t m = (l + rr) >> 1; if (P.ref.kPost[st + m].allele < allele) l = m + 1; else rr = m; }
+        uint32_t c = 0;
+        while (l + c < ln && P.ref.kPost[st + l + c].allele == allele) ++c;
+        first[r] = st + l; cnt[r] = c; mine += c;
+      }
+    }
+    uint32_t incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { uint32_t y = __shfl_up(incl, o, 64); if (lane >= o) incl += y; }
+    const uint32_t n = __shfl(incl, 63, 64);
+    uint32_t base = 0;
+    if (lane == 0) {
+      if (n <= 32) ++h32; else if (n <= 64) ++h64; else ++hBig;
+      if (n > GENERAL_CAP) {
+        const uint32_t bq = t1k_arena_append(P.counters, T1K_AR_BIG, P.listSegCap);
+        if (bq != T1K_ARENA_FULL) P.bigStr[bq] = gi;
+        rec[5] = 0xFFFFFFFFu;
+      } else {
+        base = n ? t1k_arena_alloc(P.counters, T1K_AR_GENHITS, n, P.genHitSegCap) : 0u;
+        rec[4] = base; rec[5] = n;
+      }
+    }
+    base = __shfl(base, 0, 64);
+    if (n <= GENERAL_CAP && base != T1K_ARENA_FULL) {
+      uint32_t w = base + incl - mine;
+#pragma unroll
+      for (int r = 0; r < ROUNDS; ++r) {
+        const uint32_t u = b + lane + 64 * r;
+        if (cnt[r]) {
+          const uint32_t rOff = uo[3 * u];
+          for (uint32_t j = 0; j < cnt[r]; ++j) P.genHits[w++] = (P.ref.kPost[first[r] + j].offset << 12) | rOff;
+        }
+      }
+    }
+  }
+  t1k_stat_add(P.counters, 5, h32); t1k_stat_add(P.counters, 6, h64); t1k_stat_add(P.counters, 7, hBig);
+}
+
+// K5b: groups with several diagonals, one lane per group, 64-thread workgroups; the three work arrays live in LDS,
+// interleaved over the lanes.  CAP = 32 takes the groups with at most 32 hits (24 KB of LDS), CAP = GENERAL_CAP the few
+// larger ones (96 KB).  Alignments go through the read-end's memo (registered now, run by k_dp_dense, added by
+// k_general_finish); groups that need an alignment wider than the register band go to k_chain_big.
+#define GENERAL_SMALL 32
+template <int CAP>
+__global__ __launch_bounds__(64) void k_chain_general(ChainArgs P, uint32_t nItems) {
+  extern __shared__ uint32_t sArr[];  // [3][CAP][64]
   const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
   unsigned int dpLocal = 0, genLocal = 0;
-  if (q < nItems) {
+  uint32_t nHits = 0xFFFFFFFFu;
+  if (q < nItems) nHits = P.recs[(uint64_t)P.generalList[q] * P.recStride + 5];
+  if (nHits != 0xFFFFFFFFu && (nHits <= GENERAL_SMALL) == (CAP == GENERAL_SMALL)) {
     const uint32_t gi = P.generalList[q];
     uint32_t *rec = P.recs + (uint64_t)gi * P.recStride;
     const uint32_t re = rec[0] & 0x7FFFFFFFu, allele = rec[1];
     const int pass = (rec[0] >> 31) ? 0 : 1;
     ReadCtx c = makeCtx(P, re, pass, allele);
-    uint32_t hh[GENERAL_CAP], wa[GENERAL_CAP], wb[GENERAL_CAP], wc[GENERAL_CAP];
-    const int n = gatherHits(P, re, pass, allele, hh, GENERAL_CAP);
-    bool needScratch = n > GENERAL_CAP;
-    uint32_t cbuf[GENERAL_CAP + 3];
-    CandOut out{cbuf, 0};
-    if (!needScratch) groupGeneral(hh, n, c, P.k, P.radius, P.hitLenRequired, wa, wb, wc, nullptr, 0, out, &dpLocal, &P.counters[2], &needScratch);
+    const int n = (int)nHits;
+    if (rec[4] == T1K_ARENA_FULL) atomicOr(&P.counters[2], (unsigned long long)ERR_STAGECAP);
+    const uint32_t *hh = P.genHits + (rec[4] == T1K_ARENA_FULL ? 0u : rec[4]);
+    bool needScratch = false;
+    uint32_t cbuf[2 * CAP + 6];  // a candidate needs >= 3 hits
+    CandOut out{cbuf, 0, 6, CAP / 3 + 1};
+    const GapSink sink{P.memo + (uint64_t)re * GAP_CACHE, P.genJobStr, P.counters, re * GAP_CACHE, P.genJobSegCap, T1K_AR_GENJOBS};
+    LaneArr A{sArr + threadIdx.x}, B{sArr + CAP * 64 + threadIdx.x}, C{sArr + 2 * CAP * 64 + threadIdx.x};
+    groupGeneral(hh, n, c, P.k, P.radius, P.hitLenRequired, A, B, C, nullptr, 0, out, &dpLocal, &P.counters[2], &needScratch, &sink, pass);
     if (needScratch) { const uint32_t b = t1k_arena_append(P.counters, T1K_AR_BIG, P.listSegCap); if (b != T1K_ARENA_FULL) P.bigStr[b] = gi; }
     else {
       ++genLocal;
@@ -916,7 +1043,7 @@ __global__ __launch_bounds__(WG) void k_chain_general(ChainArgs P, uint32_t nIte
       if (out.n) {
         base = t1k_arena_alloc(P.counters, T1K_AR_GENCAND, (uint32_t)out.n, P.genCandSegCap);
         if (base == T1K_ARENA_FULL) { atomicOr(&P.counters[2], (unsigned long long)ERR_STAGECAP); out.n = 0; base = 0; }
-        for (int i = 0; i < 3 * out.n; ++i) P.genCand[(uint64_t)base * 3 + i] = cbuf[i];
+        for (int i = 0; i < 6 * out.n; ++i) P.genCand[(uint64_t)base * 6 + i] = cbuf[i];
       }
       rec[4] = base;
       rec[3] = REC_DONE | 0x40000000u | (uint32_t)out.n;  // bit30: candidates live in the side arena
@@ -924,6 +1051,31 @@ __global__ __launch_bounds__(WG) void k_chain_general(ChainArgs P, uint32_t nIte
   }
   t1k_stat_add(P.counters, T1K_STAT_DP, dpLocal);
   t1k_stat_add(P.counters, T1K_STAT_GENERAL, genLocal);
+}
+
+// K5c: add the memo's match counts to the candidates of the multi-diagonal groups
+__global__ __launch_bounds__(WG) void k_general_finish(ChainArgs P, uint32_t nItems) {
+  const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= nItems) return;
+  const uint32_t *rec = P.recs + (uint64_t)P.generalList[q] * P.recStride;
+  if ((rec[3] & (REC_DONE | 0x40000000u)) != (REC_DONE | 0x40000000u)) return;  // not chained yet (waits for k_chain_big)
+  const uint32_t re = rec[0] & 0x7FFFFFFFu, nc = rec[3] & 0x3FFFFFFFu;
+  const unsigned long long *memo = P.memo + (uint64_t)re * GAP_CACHE;
+  for (uint32_t j = 0; j < nc; ++j) {
+    uint32_t *g = P.genCand + ((uint64_t)rec[4] + j) * 6;
+    const int nref = (int)((g[0] >> 24) & 0xF);
+    if (!nref) continue;
+    uint32_t sum = 0;
+    for (int i = 0; i < nref; ++i) {
+      const uint32_t slot = (g[3 + (i >> 1)] >> (16 * (i & 1))) & 0xFFFFu;
+      const unsigned long long e = __hip_atomic_load(&memo[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const uint32_t v = GAP_VAL(e);
+      if (v == GAP_PENDING) atomicOr(&P.counters[2], (unsigned long long)ERR_MEMO);
+      sum += v;
+    }
+    g[2] += (2u * sum) << 20;
+    g[0] &= 0x00FFFFFFu;
+  }
 }
 
 // very large groups (repeat-rich alleles) or wide gaps: a handful of lanes with big scratch in HBM
@@ -941,16 +1093,16 @@ __global__ __launch_bounds__(64) void k_chain_big(ChainArgs P, uint32_t nItems) 
     const int n = gatherHits(P, re, pass, allele, hh, BIG_CAP);
     if (n > BIG_CAP) { atomicOr(&P.counters[2], (unsigned long long)ERR_BIGGROUP); rec[3] = REC_DONE; continue; }
     bool dummy = false;
-    uint32_t cbuf[96];  // at most 32 candidates (3 words each) are kept per group
-    CandOut o2{cbuf, 0};
+    uint32_t cbuf[192];  // at most 32 candidates are kept per group
+    CandOut o2{cbuf, 0, 6, 32};
     groupGeneral(hh, n, c, P.k, P.radius, P.hitLenRequired, mine, mine + BIG_CAP, mine + 2 * BIG_CAP, (int *)(mine + 4 * BIG_CAP), GA_BIG_MAX, o2, &dpLocal,
                  &P.counters[2], &dummy);
-    if (o2.n > 32) { atomicOr(&P.counters[2], (unsigned long long)ERR_BIGGROUP); o2.n = 32; }
+    if (o2.overflow) atomicOr(&P.counters[2], (unsigned long long)ERR_BIGGROUP);
     uint32_t base = 0;
     if (o2.n) {
       base = t1k_arena_alloc(P.counters, T1K_AR_GENCAND, (uint32_t)o2.n, P.genCandSegCap);
       if (base == T1K_ARENA_FULL) { atomicOr(&P.counters[2], (unsigned long long)ERR_STAGECAP); o2.n = 0; base = 0; }
-      for (int i = 0; i < 3 * o2.n; ++i) P.genCand[(uint64_t)base * 3 + i] = cbuf[i];
+      for (int i = 0; i < 6 * o2.n; ++i) P.genCand[(uint64_t)base * 6 + i] = cbuf[i];
     }
     rec[4] = base;
     rec[3] = REC_DONE | 0x40000000u | (uint32_t)o2.n;
@@ -963,7 +1115,7 @@ __global__ __launch_bounds__(64) void k_chain_big(ChainArgs P, uint32_t nItems) 
 // K6: strand vote + copy-out, one workgroup per read-end
 // ------------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void loadCand(const ChainArgs &P, const uint32_t *rec, uint32_t j, uint32_t &w0, uint32_t &w1, uint32_t &w2) {
-  if (rec[3] & 0x40000000u) { const uint32_t *g = P.genCand + ((uint64_t)rec[4] + j) * 3; w0 = g[0]; w1 = g[1]; w2 = g[2]; }
+  if (rec[3] & 0x40000000u) { const uint32_t *g = P.genCand + ((uint64_t)rec[4] + j) * 6; w0 = g[0]; w1 = g[1]; w2 = g[2]; }
   else { w0 = rec[4]; w1 = rec[5]; w2 = rec[6]; }
 }
 
@@ -1119,7 +1271,7 @@ int t1k_run_chain(t1k_ctx *ctx, const ChainArgs &a, int nWg, int bigBlocks, bool
   t1k_arena_compact(ctx, T1K_AR_RETRY, a.retryStr, a.listSegCap, a.retryList, retry.maxSeg);
   t1k_arena_compact(ctx, T1K_AR_GENERAL, a.generalStr, a.listSegCap, a.generalList, gen.maxSeg);
   const uint32_t nJobs = (uint32_t)jobs.total, nRetry = (uint32_t)retry.total, nGen = (uint32_t)gen.total, nFinish = (uint32_t)fin.total;
-  if (nJobs) hipLaunchKernelGGL(k_dp_dense, dim3((nJobs + WG - 1) / WG), dim3(WG), 0, ctx->stream, a, nJobs);
+  if (nJobs) hipLaunchKernelGGL(k_dp_dense, dim3((nJobs + WG - 1) / WG), dim3(WG), 0, ctx->stream, a, (const uint32_t *)a.jobList, nJobs);
   if (nFinish) hipLaunchKernelGGL(k_chain_finish, dim3((nFinish + WG - 1) / WG), dim3(WG), 0, ctx->stream, a, nFinish);
   if (nRetry) {
     if (longReads) hipLaunchKernelGGL((k_chain_fast<10, false>), dim3((nRetry + WG - 1) / WG), dim3(WG), 0, ctx->stream, a, (const uint32_t *)a.retryList, nRetry);
@@ -1127,8 +1279,15 @@ int t1k_run_chain(t1k_ctx *ctx, const ChainArgs &a, int nWg, int bigBlocks, bool
   }
   uint32_t nBig = 0;
   if (nGen) {
-    hipLaunchKernelGGL(k_chain_general, dim3((nGen + WG - 1) / WG), dim3(WG), 0, ctx->stream, a, nGen);
-    if ((rc = readCounters(ctx, hc))) return rc;  // the general kernel may hand groups over to the big-scratch kernel
+    hipLaunchKernelGGL(k_gather_general, dim3(std::min<uint32_t>((nGen + 3) / 4, 8192u)), dim3(WG), 0, ctx->stream, a, nGen);
+    T1K_HIP(ctx, hipFuncSetAttribute((const void *)k_chain_general<GENERAL_CAP>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * GENERAL_CAP * 64 * 4));
+    hipLaunchKernelGGL(k_chain_general<GENERAL_SMALL>, dim3((nGen + 63) / 64), dim3(64), 3 * GENERAL_SMALL * 64 * 4, ctx->stream, a, nGen);
+    hipLaunchKernelGGL(k_chain_general<GENERAL_CAP>, dim3((nGen + 63) / 64), dim3(64), 3 * GENERAL_CAP * 64 * 4, ctx->stream, a, nGen);
+    if ((rc = readCounters(ctx, hc))) return rc;  // the general kernels register alignments and may hand groups over to the big-scratch kernel
+    const T1kArenaCounts gj = t1k_arena_counts(ctx, T1K_AR_GENJOBS, a.genJobSegCap);
+    t1k_arena_compact(ctx, T1K_AR_GENJOBS, a.genJobStr, a.genJobSegCap, a.genJobList, gj.maxSeg);
+    if (gj.total) hipLaunchKernelGGL(k_dp_dense, dim3(((uint32_t)gj.total + WG - 1) / WG), dim3(WG), 0, ctx->stream, a, (const uint32_t *)a.genJobList, (uint32_t)gj.total);
+    hipLaunchKernelGGL(k_general_finish, dim3((nGen + WG - 1) / WG), dim3(WG), 0, ctx->stream, a, nGen);
     const T1kArenaCounts big = t1k_arena_counts(ctx, T1K_AR_BIG, a.listSegCap);
     if (big.overflow) { hc[2] |= ERR_GROUPCAP; return 0; }
     t1k_arena_compact(ctx, T1K_AR_BIG, a.bigStr, a.listSegCap, a.bigList, big.maxSeg);

@@ -14,7 +14,9 @@ struct ChainArgs {
   uint32_t *jobList; uint32_t jobCap;
   uint32_t *retryList, *generalList, *bigList, *finishList;  // dense lists (filled by k_arena_compact)
   uint32_t *jobStr, *retryStr, *generalStr, *bigStr, *finishStr;  // striped arenas the kernels append to
-  uint32_t groupSegCap, jobSegCap, listSegCap, genCandSegCap;
+  uint32_t groupSegCap, jobSegCap, listSegCap, genCandSegCap, genHitSegCap;
+  uint32_t *genJobStr, *genJobList; uint32_t genJobSegCap;  // alignments registered by the multi-diagonal groups
+  uint32_t *genHits;  // hit lists of the multi-diagonal groups (k_gather_general)
   uint32_t *genCand; uint32_t genCandCap;                  // packed candidates of multi-diagonal groups (3 u32 each)
   uint32_t *bigScratch;
   T1kCand *cand; uint64_t candCap;
