@@ -7,6 +7,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <ctime>
+#include <future>
+#include <memory>
 #include <set>
 #include "t1k_host.h"
 
@@ -212,40 +214,24 @@ int t1k_job_run_local(t1k_job *job) {
   const uint32_t F = job->nFrag;
   uint32_t batch = job->prm.batch_fragments > 0 ? (uint32_t)job->prm.batch_fragments : 16384u;
   const uint32_t per = job->paired ? 2 : 1;
-  std::vector<uint32_t> e1, e2, rowCounts;
-  std::vector<uint8_t> assigned;
-  std::vector<t1k_row_entry> rows;
+  std::vector<uint32_t> e1, e2;
   double tDev = 0, tHost = 0;
-  for (uint32_t b0 = 0; b0 < F;) {
-    uint32_t nb = std::min(batch, F - b0);
-    double t0 = nowMs();
-    rc = t1k_assign_range(job->ctx, (uint64_t)b0 * per, nb * per);
-    if (rc == T1K_ERR_CAPACITY && nb > 64) { batch = std::max<uint32_t>(64, nb / 2); continue; }  // nothing has been committed yet: retry smaller
-    if (rc != T1K_OK) return jobFail(job, rc, t1k_last_error(job->ctx));
-    e1.resize(nb); e2.resize(nb);
-    for (uint32_t i = 0; i < nb; ++i) { e1[i] = i * per; e2[i] = i * per + 1; }
-    rc = t1k_pair_batch(job->ctx, e1.data(), job->paired ? e2.data() : nullptr, job->hasN.data() + b0, nb);
-    if (rc != T1K_OK) return jobFail(job, rc, t1k_last_error(job->ctx));
-    uint64_t total = 0;
-    rowCounts.resize(nb); assigned.resize(nb);
-    if ((rc = t1k_rows_download(job->ctx, rowCounts.data(), assigned.data(), nullptr, 0, &total)) != T1K_OK) return jobFail(job, rc, t1k_last_error(job->ctx));
-    rows.resize(total);
-    if ((rc = t1k_rows_download(job->ctx, rowCounts.data(), assigned.data(), rows.data(), total, &total)) != T1K_OK)
-      return jobFail(job, rc, t1k_last_error(job->ctx));
-    t1k_stats st;
-    t1k_stats_get(job->ctx, &st);
-    job->stats.read_ends += st.read_ends; job->stats.lookups += st.lookups; job->stats.postings += st.postings; job->stats.hits += st.hits;
-    job->stats.groups += st.groups; job->stats.candidates += st.candidates; job->stats.extended += st.extended; job->stats.near_best += st.near_best;
-    job->stats.dp_calls += st.dp_calls; job->stats.ms_chain += st.ms_chain; job->stats.ms_extend += st.ms_extend; job->stats.ms_select += st.ms_select;
-    job->stats.ms_fullalign += st.ms_fullalign; job->stats.ms_pair += st.ms_pair; job->stats.ms_seed += st.ms_seed; job->stats.batches += 1;
-    job->stats.rows += total;
-    double t1 = nowMs();
-    tDev += t1 - t0;
+  // The host half of a batch (whitelist filter, assignment text, read-group coalescing) runs on a worker thread while the
+  // device works on the next batch; batches are absorbed strictly in order (coalescing is order-dependent).
+  struct HostBatch {
+    uint32_t b0 = 0, nb = 0;
+    std::vector<uint32_t> rowCounts;
+    std::vector<uint8_t> assigned;
+    std::vector<t1k_row_entry> rows;
+  };
+  std::future<void> pending;
+  auto absorb = [job, &gt, &tHost](std::shared_ptr<HostBatch> hb) {
+    const double t1 = nowMs();
     uint64_t p = 0;
-    for (uint32_t i = 0; i < nb; ++i) {
-      job->fragAssigned[b0 + i] = assigned[i];
-      uint32_t n = rowCounts[i];
-      t1k_row_entry *row = rows.data() + p;
+    for (uint32_t i = 0; i < hb->nb; ++i) {
+      job->fragAssigned[hb->b0 + i] = hb->assigned[i];
+      uint32_t n = hb->rowCounts[i];
+      t1k_row_entry *row = hb->rows.data() + p;
       p += n;
       if (!job->whitelist.empty()) {  // SetReadAssignments skips alleles outside the whitelist (Genotyper.hpp:822-823)
         uint32_t w = 0;
@@ -254,15 +240,48 @@ int t1k_job_run_local(t1k_job *job) {
         n = w;
       }
       if (job->prm.output_read_assignment) {
-        const std::string id = job->id1.empty() ? "r" + std::to_string(b0 + i) : job->id1[b0 + i];
+        const std::string id = job->id1.empty() ? "r" + std::to_string(hb->b0 + i) : job->id1[hb->b0 + i];
         for (uint32_t j = 0; j < n; ++j)
           job->assignText += id + "\t" + job->ref.al[row[j].allele_idx].name + "\t" + std::to_string(row[j].start) + "\t" + std::to_string(row[j].end) + "\n";
       }
       gt.coalesce(row, n);
     }
     tHost += nowMs() - t1;
+  };
+  auto drain = [&pending]() { if (pending.valid()) pending.get(); };
+  for (uint32_t b0 = 0; b0 < F;) {
+    uint32_t nb = std::min(batch, F - b0);
+    double t0 = nowMs();
+    rc = t1k_assign_range(job->ctx, (uint64_t)b0 * per, nb * per);
+    if (rc == T1K_ERR_CAPACITY && nb > 64) { batch = std::max<uint32_t>(64, nb / 2); continue; }  // nothing has been committed yet: retry smaller
+    if (rc != T1K_OK) { drain(); return jobFail(job, rc, t1k_last_error(job->ctx)); }
+    e1.resize(nb); e2.resize(nb);
+    for (uint32_t i = 0; i < nb; ++i) { e1[i] = i * per; e2[i] = i * per + 1; }
+    rc = t1k_pair_batch(job->ctx, e1.data(), job->paired ? e2.data() : nullptr, job->hasN.data() + b0, nb);
+    if (rc != T1K_OK) { drain(); return jobFail(job, rc, t1k_last_error(job->ctx)); }
+    uint64_t total = 0;
+    auto hb = std::make_shared<HostBatch>();
+    hb->b0 = b0; hb->nb = nb;
+    hb->rowCounts.resize(nb); hb->assigned.resize(nb);
+    if ((rc = t1k_rows_download(job->ctx, hb->rowCounts.data(), hb->assigned.data(), nullptr, 0, &total)) != T1K_OK) { drain(); return jobFail(job, rc, t1k_last_error(job->ctx)); }
+    hb->rows.resize(total);
+    if ((rc = t1k_rows_download(job->ctx, hb->rowCounts.data(), hb->assigned.data(), hb->rows.data(), total, &total)) != T1K_OK) {
+      drain();
+      return jobFail(job, rc, t1k_last_error(job->ctx));
+    }
+    t1k_stats st;
+    t1k_stats_get(job->ctx, &st);
+    job->stats.read_ends += st.read_ends; job->stats.lookups += st.lookups; job->stats.postings += st.postings; job->stats.hits += st.hits;
+    job->stats.groups += st.groups; job->stats.candidates += st.candidates; job->stats.extended += st.extended; job->stats.near_best += st.near_best;
+    job->stats.dp_calls += st.dp_calls; job->stats.ms_chain += st.ms_chain; job->stats.ms_extend += st.ms_extend; job->stats.ms_select += st.ms_select;
+    job->stats.ms_fullalign += st.ms_fullalign; job->stats.ms_pair += st.ms_pair; job->stats.ms_seed += st.ms_seed; job->stats.batches += 1;
+    job->stats.rows += total;
+    tDev += nowMs() - t0;
+    drain();  // the previous batch must be absorbed before this one
+    pending = std::async(std::launch::async, absorb, hb);
     b0 += nb;
   }
+  drain();
   job->msDevice = tDev; job->msHost = tHost;
   job->localDone = true;
   return T1K_OK;

@@ -185,12 +185,12 @@ __device__ inline bool candBeforeFull(const T1kCand &a, const T1kCand &b) {
 #define SELECT_SMALL 2048
 #define SELECT_LARGE 8192
 
-template <int SELECT_LDS_CAP>
-__global__ __launch_bounds__(WG) void k_select(SelectArgs P) {
+template <int SELECT_LDS_CAP, int NT>
+__global__ __launch_bounds__(NT) void k_select(SelectArgs P) {
   extern __shared__ uint64_t dynLds[];
   uint64_t *sKey = dynLds;
   uint32_t *sIdx = (uint32_t *)(dynLds + SELECT_LDS_CAP);
-  __shared__ uint32_t warpSums[4];
+  __shared__ uint32_t warpSums[NT / 64];
   __shared__ int sLatch, sGood, sBest, sTie;
   __shared__ uint32_t sBase;
   const int tid = threadIdx.x;
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(WG) void k_select(SelectArgs P) {
     __syncthreads();
     {
       uint32_t mine = 0;
-      for (uint32_t i = tid; i < n; i += WG) mine += (P.ext[c0 + i].flags & T1K_F_DROP) ? 0u : 1u;
+      for (uint32_t i = tid; i < n; i += NT) mine += (P.ext[c0 + i].flags & T1K_F_DROP) ? 0u : 1u;
       if (mine) atomicAdd(&sLive, mine);
     }
     __syncthreads();
@@ -228,9 +228,9 @@ __global__ __launch_bounds__(WG) void k_select(SelectArgs P) {
     }
     // key: matchCnt desc, similarity desc (== readSpan+seqSpan asc at equal matchCnt), readSpan desc, allele asc
     if (tid == 0) sLive = 0;
-    for (uint32_t i = tid; i < np2; i += WG) key[i] = ~0ull;
+    for (uint32_t i = tid; i < np2; i += NT) key[i] = ~0ull;
     __syncthreads();
-    for (uint32_t i = tid; i < n; i += WG) {
+    for (uint32_t i = tid; i < n; i += NT) {
       const uint16_t fl = P.ext[c0 + i].flags;
       if (fl & T1K_F_DROP) continue;
       const T1kCand c = P.cand[c0 + i];
@@ -241,7 +241,7 @@ __global__ __launch_bounds__(WG) void k_select(SelectArgs P) {
       key[slot] = ((uint64_t)(4095 - m) << 50) | ((uint64_t)(d & 0x1FFF) << 37) | ((uint64_t)(4095 - rspan) << 24) | (uint64_t)(c.allele & 0xFFFFFF);
       idx[slot] = i;
     }
-    for (uint32_t i = live + tid; i < np2; i += WG) idx[i] = 0;
+    for (uint32_t i = live + tid; i < np2; i += NT) idx[i] = 0;
     __syncthreads();
     bitonicSort(key, idx, np2);
     // resolve ties of the packed key with the remaining comparator fields (same allele, same spans)
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(WG) void k_select(SelectArgs P) {
     // equal packed keys (same allele, same spans and match count; rare) are ordered by the remaining comparator fields
     if (tid == 0) { sTie = 0; sLatch = 0x7FFFFFFF; sGood = -1; sBest = -1; }
     __syncthreads();
-    for (uint32_t i = 1 + tid; i < live; i += WG)
+    for (uint32_t i = 1 + tid; i < live; i += NT)
       if (key[i] == key[i - 1]) sTie = 1;
     __syncthreads();
     if (sTie && tid == 0) {
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(WG) void k_select(SelectArgs P) {
     __syncthreads();
     // latch position: first tried candidate whose extension fails (all candidates before the latch are tried)
     int myLatch = 0x7FFFFFFF;
-    for (uint32_t i = tid; i < live; i += WG) {
+    for (uint32_t i = tid; i < live; i += NT) {
       if (key[i] == ~0ull) continue;
       uint16_t fl = P.ext[c0 + idx[i]].flags;
       if (fl & T1K_F_SEPSEED) continue;
@@ -277,7 +277,7 @@ __global__ __launch_bounds__(WG) void k_select(SelectArgs P) {
     const int latch = sLatch;
     // goodMatchCnt = seed matchCnt of the first emitted candidate before the latch (the list is sorted by it)
     int myGood = 0x7FFFFFFF;
-    for (uint32_t i = tid; i < live && (int)i < latch; i += WG) {
+    for (uint32_t i = tid; i < live && (int)i < latch; i += NT) {
       if (key[i] == ~0ull) continue;
       uint16_t fl = P.ext[c0 + idx[i]].flags;
       if ((fl & T1K_F_SEPSEED) || !(fl & T1K_F_EXTOK)) continue;
@@ -297,7 +297,7 @@ __global__ __launch_bounds__(WG) void k_select(SelectArgs P) {
     int myBest = -1;
     // first pass: count and best
     uint32_t mine = 0;
-    for (uint32_t i = tid; i < live; i += WG) {
+    for (uint32_t i = tid; i < live; i += NT) {
       bool emit = false;
       if (key[i] != ~0ull) {
         const T1kExt x = P.ext[c0 + idx[i]];
@@ -318,7 +318,7 @@ __global__ __launch_bounds__(WG) void k_select(SelectArgs P) {
     }
     atomicMax(&sBest, myBest);
     uint32_t tot;
-    t1k_block_scan_exclusive(mine, warpSums, &tot);
+    t1k_block_scan_exclusive_n<NT / 64>(mine, warpSums, &tot);
     if (tid == 0) {
       unsigned long long b = atomicAdd(&P.counters[1], (unsigned long long)tot);
       if (b + tot > P.ovlCap) { atomicOr(&P.counters[2], (unsigned long long)ERR_OVLCAP); sBase = 0xFFFFFFFFu; P.ovlStart[re] = 0; P.ovlCount[re] = 0; }
@@ -327,11 +327,11 @@ __global__ __launch_bounds__(WG) void k_select(SelectArgs P) {
     __syncthreads();
     const int bestMatch = sBest;
     if (sBase != 0xFFFFFFFFu) {
-      for (uint32_t i0 = 0; i0 < live; i0 += WG) {
+      for (uint32_t i0 = 0; i0 < live; i0 += NT) {
         uint32_t i = i0 + tid;
         uint32_t flag = (i < live && (idx[i] & 0x80000000u)) ? 1u : 0u;
         uint32_t t2;
-        uint32_t off = t1k_block_scan_exclusive(flag, warpSums, &t2);
+        uint32_t off = t1k_block_scan_exclusive_n<NT / 64>(flag, warpSums, &t2);
         if (flag) {
           uint32_t ci = c0 + (idx[i] & 0x7FFFFFFFu);
           const T1kCand c = P.cand[ci];
@@ -591,8 +591,8 @@ __device__ inline bool ovlBeforeFull(const T1kOvl &a, const T1kOvl &b) {
   return a.seqEnd < b.seqEnd;
 }
 
-template <int SELECT_LDS_CAP>
-__global__ __launch_bounds__(WG) void k_truncate(TruncArgs P) {
+template <int SELECT_LDS_CAP, int NT>
+__global__ __launch_bounds__(NT) void k_truncate(TruncArgs P) {
   extern __shared__ uint64_t dynLds[];
   uint64_t *sKey = dynLds;
   uint32_t *sIdx = (uint32_t *)(dynLds + SELECT_LDS_CAP);
@@ -611,7 +611,7 @@ __global__ __launch_bounds__(WG) void k_truncate(TruncArgs P) {
     else { if (tid == 0) atomicOr(&P.counters[2], (unsigned long long)ERR_SORTCAP); continue; }
     T1kOvl *stage = (T1kOvl *)(wgScratch + P.sortCap * 2);
     if (n > P.sortCap) { if (tid == 0) atomicOr(&P.counters[2], (unsigned long long)ERR_SORTCAP); continue; }
-    for (uint32_t i = tid; i < np2; i += WG) {
+    for (uint32_t i = tid; i < np2; i += NT) {
       uint64_t kk = ~0ull;
       if (i < n) {
         const T1kOvl o = P.ovl[o0 + i];
@@ -626,7 +626,7 @@ __global__ __launch_bounds__(WG) void k_truncate(TruncArgs P) {
     bitonicSort(key, idx, np2);
     if (tid == 0) { sCut = n; sTie2 = 0; }
     __syncthreads();
-    for (uint32_t i = 1 + tid; i < n; i += WG)
+    for (uint32_t i = 1 + tid; i < n; i += NT)
       if (key[i] == key[i - 1]) sTie2 = 1;
     __syncthreads();
     if (sTie2 && tid == 0) {
@@ -644,13 +644,13 @@ __global__ __launch_bounds__(WG) void k_truncate(TruncArgs P) {
       // first j >= 1 whose similarity falls more than 0.1 below the best one (SeqSet.hpp:2294-2297)
       const double s0 = ovlSimilarity(stage[idx[0]]);
       uint32_t mine = n;
-      for (uint32_t j = 1 + tid; j < n; j += WG)
+      for (uint32_t j = 1 + tid; j < n; j += NT)
         if (ovlSimilarity(stage[idx[j]]) < s0 - 0.1) { mine = j; break; }
       if (mine < n) atomicMin(&sCut, mine);
     }
     __syncthreads();
     const uint32_t cut = sCut;
-    for (uint32_t i = tid; i < cut; i += WG) P.ovl[o0 + i] = stage[idx[i]];
+    for (uint32_t i = tid; i < cut; i += NT) P.ovl[o0 + i] = stage[idx[i]];
     if (tid == 0) P.ovlCount[re] = cut;
     __syncthreads();
   }
@@ -697,9 +697,9 @@ void t1k_launch_extend(t1k_ctx *ctx, const ExtendArgs &a) {
   hipLaunchKernelGGL(k_extend, dim3((unsigned)((a.nCand + WG - 1) / WG)), dim3(WG), 0, ctx->stream, a);
 }
 void t1k_launch_select(t1k_ctx *ctx, const SelectArgs &a, int nWg) {
-  hipFuncSetAttribute((const void *)k_select<SELECT_LARGE>, hipFuncAttributeMaxDynamicSharedMemorySize, SELECT_LARGE * 12);
-  hipLaunchKernelGGL(k_select<SELECT_SMALL>, dim3(nWg), dim3(WG), SELECT_SMALL * 12, ctx->stream, a);
-  hipLaunchKernelGGL(k_select<SELECT_LARGE>, dim3(std::min(nWg, 512)), dim3(WG), SELECT_LARGE * 12, ctx->stream, a);
+  hipFuncSetAttribute((const void *)k_select<SELECT_LARGE, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, SELECT_LARGE * 12);
+  hipLaunchKernelGGL((k_select<SELECT_SMALL, 256>), dim3(nWg), dim3(256), SELECT_SMALL * 12, ctx->stream, a);
+  hipLaunchKernelGGL((k_select<SELECT_LARGE, 1024>), dim3(std::min(nWg, 512)), dim3(1024), SELECT_LARGE * 12, ctx->stream, a);
 }
 void t1k_launch_fullalign(t1k_ctx *ctx, const FullArgs &a) {
   if (!a.nOvl) return;
@@ -709,9 +709,9 @@ void t1k_launch_fullalign_slow(t1k_ctx *ctx, const SlowArgs &a, int nBlocks) { h
 void t1k_launch_fullalign_eq(t1k_ctx *ctx, const SlowArgs &a, int nBlocks) { hipLaunchKernelGGL(k_fullalign_eq, dim3(nBlocks), dim3(WG), 0, ctx->stream, a); }
 void t1k_launch_fullalign_band(t1k_ctx *ctx, const SlowArgs &a, int nBlocks) { hipLaunchKernelGGL(k_fullalign_band, dim3(nBlocks), dim3(WG), 0, ctx->stream, a); }
 void t1k_launch_truncate(t1k_ctx *ctx, const TruncArgs &a, int nWg) {
-  hipFuncSetAttribute((const void *)k_truncate<SELECT_LARGE>, hipFuncAttributeMaxDynamicSharedMemorySize, SELECT_LARGE * 12);
-  hipLaunchKernelGGL(k_truncate<SELECT_SMALL>, dim3(nWg), dim3(WG), SELECT_SMALL * 12, ctx->stream, a);
-  hipLaunchKernelGGL(k_truncate<SELECT_LARGE>, dim3(std::min(nWg, 512)), dim3(WG), SELECT_LARGE * 12, ctx->stream, a);
+  hipFuncSetAttribute((const void *)k_truncate<SELECT_LARGE, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, SELECT_LARGE * 12);
+  hipLaunchKernelGGL((k_truncate<SELECT_SMALL, 256>), dim3(nWg), dim3(256), SELECT_SMALL * 12, ctx->stream, a);
+  hipLaunchKernelGGL((k_truncate<SELECT_LARGE, 1024>), dim3(std::min(nWg, 512)), dim3(1024), SELECT_LARGE * 12, ctx->stream, a);
 }
 void t1k_launch_coverage_scan(t1k_ctx *ctx, const T1kRefDev &ref, int32_t *out, const uint64_t *outOff) {
   hipLaunchKernelGGL(k_coverage_scan, dim3(ref.nAlleles), dim3(WG), 0, ctx->stream, ref, out, outOff);

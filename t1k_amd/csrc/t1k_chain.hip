@@ -393,6 +393,104 @@ struct LaneArr {
   uint32_t *p;  // element i of this lane's array lives at p[i * 64]
   __device__ __forceinline__ uint32_t &operator[](int i) const { return p[i * 64]; }
 };
+// second half of one diagonal run: B[0..m) = the run's hits nearest to the dominant diagonal, sorted by (allele offset, read offset);
+// LIS over the read offsets, chain -> A[s..), hit lengths, seed-chain match count, candidate (SeqSet.hpp:352-436, 1512-1551, 1697-1833)
+template <class Arr>
+__device__ inline void chainRun(const ReadCtx &c, int k, int hitLenRequired, Arr A, Arr B, Arr C, int s, int m, int *gaScratch, int gaMax, CandOut &out,
+                                unsigned int *dpCounter, unsigned long long *errFlags, bool *needScratch, const GapSink *sink, int strandBit) {
+    // LIS over read offsets (352-436); C[i] = top | link << 16, link 0xFFFF = none
+    int ret = 1;
+    C[0] = 0 | (0xFFFFu << 16);
+    auto topOf = [&](int i) { return (int)(C[i] & 0xFFFF); };
+    auto setTop = [&](int i, int v) { C[i] = (C[i] & 0xFFFF0000u) | (uint32_t)v; };
+    auto setLink = [&](int i, int v) { C[i] = (C[i] & 0xFFFFu) | ((uint32_t)(v & 0xFFFF) << 16); };
+    auto linkOf = [&](int i) { return (int)(C[i] >> 16); };
+    auto aOf = [&](int i) { return (int)(B[i] & 0xFFF); };
+    for (int i = 1; i < m; ++i) C[i] = 0xFFFFu << 16;
+    for (int i = 1; i < m; ++i) {
+      int tag;
+      if (aOf(topOf(ret - 1)) <= aOf(i)) tag = ret - 1;
+      else {
+        int l = 0, r = ret - 1;
+        tag = -2;
+        while (l <= r) {
+          int mid = (l + r) / 2;
+          if (aOf(i) == aOf(topOf(mid))) { tag = mid; break; }
+          if (aOf(i) < aOf(topOf(mid))) r = mid - 1; else l = mid + 1;
+        }
+        if (tag == -2) tag = l - 1;
+      }
+      if (tag == -1) { setTop(0, i); setLink(i, 0xFFFF); }
+      else if (aOf(i) > aOf(topOf(tag))) {
+        if (tag == ret - 1) { setTop(ret, i); ++ret; setLink(i, topOf(tag)); }
+        else if (aOf(i) < aOf(topOf(tag + 1))) { setTop(tag + 1, i); setLink(i, topOf(tag)); }
+      }
+    }
+    // retrieve the chain into A[s .. s+ret) (the run's slice of A is dead now), then drop repeated allele offsets
+    {
+      int kx = topOf(ret - 1);
+      for (int i = ret - 1; i >= 0; --i) { A[s + i] = B[kx]; kx = linkOf(kx); }
+      int w = 1;
+      for (int i = 1; i < ret; ++i) {
+        if ((A[s + i] >> 12) == (A[s + w - 1] >> 12)) continue;
+        A[s + w] = A[s + i];
+        ++w;
+      }
+      ret = w;
+    }
+    if (ret * k < hitLenRequired) return;
+    // hit lengths on read and on allele (1032-1069)
+    int lenR = 0, lenS = 0;
+    for (int i = 0; i < ret;) {
+      int j = i + 1;
+      for (; j < ret; ++j) if ((int)(A[s + j] & 0xFFF) > (int)(A[s + j - 1] & 0xFFF) + k - 1) break;
+      lenR += (int)(A[s + j - 1] & 0xFFF) - (int)(A[s + i] & 0xFFF) + k;
+      i = j;
+    }
+    for (int i = 0; i < ret;) {
+      int j = i + 1;
+      for (; j < ret; ++j) if ((int)(A[s + j] >> 12) > (int)(A[s + j - 1] >> 12) + k - 1) break;
+      lenS += (int)(A[s + j - 1] >> 12) - (int)(A[s + i] >> 12) + k;
+      i = j;
+    }
+    if (lenR < hitLenRequired || lenS < hitLenRequired) return;
+    // seed-chain match count (1697-1833).  With a sink the alignments are registered in the read-end's memo instead of being
+    // run here; the candidate then carries the memo slots (k_general_finish adds their match counts).
+    uint32_t refs[3] = {0, 0, 0};
+    int nref = 0;
+    auto gapM = [&](int ra, int ga, int lp, int lt) -> int {
+      if (!sink) return gapMatches(c, ra, ga, lp, lt, gaScratch, gaMax, dpCounter, errFlags, needScratch);
+      if (lp <= 0 || lt <= 0) return 0;
+      const int diff = lt > lp ? lt - lp : lp - lt;
+      if (diff > 4) { *needScratch = true; return 0; }
+      uint32_t slot = 0;
+      const int r = gapMatchesCached<true>(c, ra, c.goff + ga, lp, lt, strandBit, *sink, dpCounter, &slot);
+      if (r >= 0) return r;
+      if (r == -1 && nref < GROUP_MAX_REFS) { refs[nref >> 1] |= slot << (16 * (nref & 1)); ++nref; return 0; }
+      if (dpCounter) ++*dpCounter;
+      return gapAlign(c, ra, c.goff + ga, lp, lt);
+    };
+    int matchCnt = 2 * k;
+    for (int i = 1; i < ret; ++i) {
+      int pa = (int)(A[s + i - 1] & 0xFFF), pb = (int)(A[s + i - 1] >> 12), qa = (int)(A[s + i] & 0xFFF), qb = (int)(A[s + i] >> 12);
+      bool sameDiag = (pb - pa) == (qb - qa);
+      bool readOv = pa + k - 1 >= qa, seqOv = pb + k - 1 >= qb;
+      if (sameDiag) {
+        if (readOv) matchCnt += 2 * (qa - pa);
+        else matchCnt += 2 * k + 2 * gapM(pa + k, pb + k, qa - (pa + k), qb - (pb + k));
+      } else {
+        if (readOv && !seqOv) matchCnt += 2 * (qa - pa);
+        else if (!readOv && seqOv) matchCnt += 2 * (qb - pb);
+        else if (readOv && seqOv) matchCnt += 2 * ((qa - pa) < (qb - pb) ? (qa - pa) : (qb - pb));
+        else matchCnt += 2 * k + 2 * gapM(pa + k, pb + k, qa - (pa + k), qb - (pb + k));
+      }
+    }
+    int rs = (int)(A[s] & 0xFFF), ss = (int)(A[s] >> 12);
+    int re = (int)(A[s + ret - 1] & 0xFFF) + k - 1, se = (int)(A[s + ret - 1] >> 12) + k - 1;
+    out.push(rs, re, ss, se, 2 * lenR, matchCnt);
+    out.setRefs(refs, nref);
+}
+
 template <class Arr>
 __device__ inline void groupGeneral(const uint32_t *h, int n, const ReadCtx &c, int k, int radius, int hitLenRequired, Arr A, Arr B,
                                      Arr C, int *gaScratch, int gaMax, CandOut &out, unsigned int *dpCounter, unsigned long long *errFlags, bool *needScratch,
@@ -439,97 +537,7 @@ __device__ inline void groupGeneral(const uint32_t *h, int n, const ReadCtx &c, 
         ++m;
       }
     }
-    // LIS over read offsets (352-436); C[i] = top | link << 16, link 0xFFFF = none
-    int ret = 1;
-    C[0] = 0 | (0xFFFFu << 16);
-    auto topOf = [&](int i) { return (int)(C[i] & 0xFFFF); };
-    auto setTop = [&](int i, int v) { C[i] = (C[i] & 0xFFFF0000u) | (uint32_t)v; };
-    auto setLink = [&](int i, int v) { C[i] = (C[i] & 0xFFFFu) | ((uint32_t)(v & 0xFFFF) << 16); };
-    auto linkOf = [&](int i) { return (int)(C[i] >> 16); };
-    auto aOf = [&](int i) { return (int)(B[i] & 0xFFF); };
-    for (int i = 1; i < m; ++i) C[i] = 0xFFFFu << 16;
-    for (int i = 1; i < m; ++i) {
-      int tag;
-      if (aOf(topOf(ret - 1)) <= aOf(i)) tag = ret - 1;
-      else {
-        int l = 0, r = ret - 1;
-        tag = -2;
-        while (l <= r) {
-          int mid = (l + r) / 2;
-          if (aOf(i) == aOf(topOf(mid))) { tag = mid; break; }
-          if (aOf(i) < aOf(topOf(mid))) r = mid - 1; else l = mid + 1;
-        }
-        if (tag == -2) tag = l - 1;
-      }
-      if (tag == -1) { setTop(0, i); setLink(i, 0xFFFF); }
-      else if (aOf(i) > aOf(topOf(tag))) {
-        if (tag == ret - 1) { setTop(ret, i); ++ret; setLink(i, topOf(tag)); }
-        else if (aOf(i) < aOf(topOf(tag + 1))) { setTop(tag + 1, i); setLink(i, topOf(tag)); }
-      }
-    }
-    // retrieve the chain into A[s .. s+ret) (the run's slice of A is dead now), then drop repeated allele offsets
-    {
-      int kx = topOf(ret - 1);
-      for (int i = ret - 1; i >= 0; --i) { A[s + i] = B[kx]; kx = linkOf(kx); }
-      int w = 1;
-      for (int i = 1; i < ret; ++i) {
-        if ((A[s + i] >> 12) == (A[s + w - 1] >> 12)) continue;
-        A[s + w] = A[s + i];
-        ++w;
-      }
-      ret = w;
-    }
-    if (ret * k < hitLenRequired) { s = e; continue; }
-    // hit lengths on read and on allele (1032-1069)
-    int lenR = 0, lenS = 0;
-    for (int i = 0; i < ret;) {
-      int j = i + 1;
-      for (; j < ret; ++j) if ((int)(A[s + j] & 0xFFF) > (int)(A[s + j - 1] & 0xFFF) + k - 1) break;
-      lenR += (int)(A[s + j - 1] & 0xFFF) - (int)(A[s + i] & 0xFFF) + k;
-      i = j;
-    }
-    for (int i = 0; i < ret;) {
-      int j = i + 1;
-      for (; j < ret; ++j) if ((int)(A[s + j] >> 12) > (int)(A[s + j - 1] >> 12) + k - 1) break;
-      lenS += (int)(A[s + j - 1] >> 12) - (int)(A[s + i] >> 12) + k;
-      i = j;
-    }
-    if (lenR < hitLenRequired || lenS < hitLenRequired) { s = e; continue; }
-    // seed-chain match count (1697-1833).  With a sink the alignments are registered in the read-end's memo instead of being
-    // run here; the candidate then carries the memo slots (k_general_finish adds their match counts).
-    uint32_t refs[3] = {0, 0, 0};
-    int nref = 0;
-    auto gapM = [&](int ra, int ga, int lp, int lt) -> int {
-      if (!sink) return gapMatches(c, ra, ga, lp, lt, gaScratch, gaMax, dpCounter, errFlags, needScratch);
-      if (lp <= 0 || lt <= 0) return 0;
-      const int diff = lt > lp ? lt - lp : lp - lt;
-      if (diff > 4) { *needScratch = true; return 0; }
-      uint32_t slot = 0;
-      const int r = gapMatchesCached<true>(c, ra, c.goff + ga, lp, lt, strandBit, *sink, dpCounter, &slot);
-      if (r >= 0) return r;
-      if (r == -1 && nref < GROUP_MAX_REFS) { refs[nref >> 1] |= slot << (16 * (nref & 1)); ++nref; return 0; }
-      if (dpCounter) ++*dpCounter;
-      return gapAlign(c, ra, c.goff + ga, lp, lt);
-    };
-    int matchCnt = 2 * k;
-    for (int i = 1; i < ret; ++i) {
-      int pa = (int)(A[s + i - 1] & 0xFFF), pb = (int)(A[s + i - 1] >> 12), qa = (int)(A[s + i] & 0xFFF), qb = (int)(A[s + i] >> 12);
-      bool sameDiag = (pb - pa) == (qb - qa);
-      bool readOv = pa + k - 1 >= qa, seqOv = pb + k - 1 >= qb;
-      if (sameDiag) {
-        if (readOv) matchCnt += 2 * (qa - pa);
-        else matchCnt += 2 * k + 2 * gapM(pa + k, pb + k, qa - (pa + k), qb - (pb + k));
-      } else {
-        if (readOv && !seqOv) matchCnt += 2 * (qa - pa);
-        else if (!readOv && seqOv) matchCnt += 2 * (qb - pb);
-        else if (readOv && seqOv) matchCnt += 2 * ((qa - pa) < (qb - pb) ? (qa - pa) : (qb - pb));
-        else matchCnt += 2 * k + 2 * gapM(pa + k, pb + k, qa - (pa + k), qb - (pb + k));
-      }
-    }
-    int rs = (int)(A[s] & 0xFFF), ss = (int)(A[s] >> 12);
-    int re = (int)(A[s + ret - 1] & 0xFFF) + k - 1, se = (int)(A[s + ret - 1] >> 12) + k - 1;
-    out.push(rs, re, ss, se, 2 * lenR, matchCnt);
-    out.setRefs(refs, nref);
+    chainRun(c, k, hitLenRequired, A, B, C, s, m, gaScratch, gaMax, out, dpCounter, errFlags, needScratch, sink, strandBit);
     s = e;
   }
 }
@@ -946,6 +954,8 @@ __device__ inline int gatherHits(const ChainArgs &P, uint32_t re, int pass, uint
   return n;
 }
 
+#define GENERAL_SMALL 32   // hits per group handled one lane per group (k_chain_general)
+#define WAVE_CAP 4096      // ... one wavefront per group with the work arrays in LDS (k_chain_wave); beyond: k_chain_big
 // K5a: hit lists of the multi-diagonal groups.  One wavefront per group: the lanes share the read-end's used posting lists,
 // each finds the allele's run in its lists (sorted by allele, then offset) and the hits are written to the hit arena;
 // record word 4 = arena offset, word 5 = hit count (0xFFFFFFFF: handed to k_chain_big)
@@ -984,17 +994,21 @@ __global__ __launch_bounds__(WG) void k_gather_general(ChainArgs P, uint32_t nIt
     uint32_t base = 0;
     if (lane == 0) {
       if (n <= 32) ++h32; else if (n <= 64) ++h64; else ++hBig;
-      if (n > GENERAL_CAP) {
+      if (n > WAVE_CAP) {  // k_chain_big gathers for itself
         const uint32_t bq = t1k_arena_append(P.counters, T1K_AR_BIG, P.listSegCap);
         if (bq != T1K_ARENA_FULL) P.bigStr[bq] = gi;
         rec[5] = 0xFFFFFFFFu;
       } else {
         base = n ? t1k_arena_alloc(P.counters, T1K_AR_GENHITS, n, P.genHitSegCap) : 0u;
         rec[4] = base; rec[5] = n;
+        if (n > GENERAL_SMALL) {  // one wavefront per group (k_chain_wave)
+          const uint32_t wq = t1k_arena_append(P.counters, T1K_AR_WAVE, P.listSegCap);
+          if (wq != T1K_ARENA_FULL) P.waveStr[wq] = gi;
+        }
       }
     }
     base = __shfl(base, 0, 64);
-    if (n <= GENERAL_CAP && base != T1K_ARENA_FULL) {
+    if (n <= WAVE_CAP && base != T1K_ARENA_FULL) {
       uint32_t w = base + incl - mine;
 #pragma unroll
       for (int r = 0; r < ROUNDS; ++r) {
@@ -1009,19 +1023,16 @@ __global__ __launch_bounds__(WG) void k_gather_general(ChainArgs P, uint32_t nIt
   t1k_stat_add(P.counters, 5, h32); t1k_stat_add(P.counters, 6, h64); t1k_stat_add(P.counters, 7, hBig);
 }
 
-// K5b: groups with several diagonals, one lane per group, 64-thread workgroups; the three work arrays live in LDS,
-// interleaved over the lanes.  CAP = 32 takes the groups with at most 32 hits (24 KB of LDS), CAP = GENERAL_CAP the few
-// larger ones (96 KB).  Alignments go through the read-end's memo (registered now, run by k_dp_dense, added by
-// k_general_finish); groups that need an alignment wider than the register band go to k_chain_big.
-#define GENERAL_SMALL 32
-template <int CAP>
+// K5b: multi-diagonal groups with at most GENERAL_SMALL hits, one lane per group, 64-thread workgroups; the three work arrays
+// live in LDS, interleaved over the lanes (24 KB).  Alignments go through the read-end's memo (registered now, run by
+// k_dp_dense, added by k_general_finish); groups that need an alignment wider than the register band go to k_chain_big.
 __global__ __launch_bounds__(64) void k_chain_general(ChainArgs P, uint32_t nItems) {
-  extern __shared__ uint32_t sArr[];  // [3][CAP][64]
+  __shared__ uint32_t sArr[3 * GENERAL_SMALL * 64];
   const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
   unsigned int dpLocal = 0, genLocal = 0;
   uint32_t nHits = 0xFFFFFFFFu;
   if (q < nItems) nHits = P.recs[(uint64_t)P.generalList[q] * P.recStride + 5];
-  if (nHits != 0xFFFFFFFFu && (nHits <= GENERAL_SMALL) == (CAP == GENERAL_SMALL)) {
+  if (nHits <= GENERAL_SMALL) {
     const uint32_t gi = P.generalList[q];
     uint32_t *rec = P.recs + (uint64_t)gi * P.recStride;
     const uint32_t re = rec[0] & 0x7FFFFFFFu, allele = rec[1];
@@ -1031,10 +1042,10 @@ __global__ __launch_bounds__(64) void k_chain_general(ChainArgs P, uint32_t nIte
     if (rec[4] == T1K_ARENA_FULL) atomicOr(&P.counters[2], (unsigned long long)ERR_STAGECAP);
     const uint32_t *hh = P.genHits + (rec[4] == T1K_ARENA_FULL ? 0u : rec[4]);
     bool needScratch = false;
-    uint32_t cbuf[2 * CAP + 6];  // a candidate needs >= 3 hits
-    CandOut out{cbuf, 0, 6, CAP / 3 + 1};
+    uint32_t cbuf[2 * GENERAL_SMALL + 6];  // a candidate needs >= 3 hits
+    CandOut out{cbuf, 0, 6, GENERAL_SMALL / 3 + 1};
     const GapSink sink{P.memo + (uint64_t)re * GAP_CACHE, P.genJobStr, P.counters, re * GAP_CACHE, P.genJobSegCap, T1K_AR_GENJOBS};
-    LaneArr A{sArr + threadIdx.x}, B{sArr + CAP * 64 + threadIdx.x}, C{sArr + 2 * CAP * 64 + threadIdx.x};
+    LaneArr A{sArr + threadIdx.x}, B{sArr + GENERAL_SMALL * 64 + threadIdx.x}, C{sArr + 2 * GENERAL_SMALL * 64 + threadIdx.x};
     groupGeneral(hh, n, c, P.k, P.radius, P.hitLenRequired, A, B, C, nullptr, 0, out, &dpLocal, &P.counters[2], &needScratch, &sink, pass);
     if (needScratch) { const uint32_t b = t1k_arena_append(P.counters, T1K_AR_BIG, P.listSegCap); if (b != T1K_ARENA_FULL) P.bigStr[b] = gi; }
     else {
@@ -1047,6 +1058,104 @@ __global__ __launch_bounds__(64) void k_chain_general(ChainArgs P, uint32_t nIte
       }
       rec[4] = base;
       rec[3] = REC_DONE | 0x40000000u | (uint32_t)out.n;  // bit30: candidates live in the side arena
+    }
+  }
+  t1k_stat_add(P.counters, T1K_STAT_DP, dpLocal);
+  t1k_stat_add(P.counters, T1K_STAT_GENERAL, genLocal);
+}
+
+// K5b': multi-diagonal groups with GENERAL_SMALL < hits <= WAVE_CAP, one wavefront per group.  The quadratic steps of
+// GetOverlapsFromHits (sort by diagonal, nearest-to-dominant filter, sort by allele offset; SeqSet.hpp:1338-1456) are spread
+// over the lanes as rank sorts; the LIS and the chain walk of each diagonal run are done by lane 0 (chainRun).
+__global__ __launch_bounds__(64) void k_chain_wave(ChainArgs P, uint32_t nItems) {
+  extern __shared__ uint32_t sW[];  // A | B | C, WAVE_CAP words each
+  uint32_t *A = sW, *B = sW + WAVE_CAP, *C = sW + 2 * WAVE_CAP;
+  const int lane = threadIdx.x;
+  unsigned int dpLocal = 0, genLocal = 0;
+  auto diagOf = [](uint32_t x) { return (int)(x & 0xFFF) - (int)(x >> 12); };
+  for (uint32_t q = blockIdx.x; q < nItems; q += gridDim.x) {
+    const uint32_t gi = P.waveList[q];
+    uint32_t *rec = P.recs + (uint64_t)gi * P.recStride;
+    const uint32_t re = rec[0] & 0x7FFFFFFFu, allele = rec[1];
+    const int pass = (rec[0] >> 31) ? 0 : 1;
+    const int n = (int)rec[5];
+    const bool lost = rec[4] == T1K_ARENA_FULL;
+    if (lost && lane == 0) atomicOr(&P.counters[2], (unsigned long long)ERR_STAGECAP);
+    const uint32_t *hh = P.genHits + (lost ? 0u : rec[4]);
+    ReadCtx c = makeCtx(P, re, pass, allele);
+    const int k = P.k;
+    __syncthreads();  // the previous group's arrays are dead
+    for (int i = lane; i < n; i += 64) C[i] = hh[i];
+    __syncthreads();
+    for (int i = lane; i < n; i += 64) {  // rank sort by (diagonal, allele offset, read offset): CompSortHitCoordDiff (266-274)
+      const uint32_t x = C[i];
+      int r = 0;
+      for (int j = 0; j < n; ++j) r += hitKeyLess(C[j], x) ? 1 : 0;
+      A[r] = x;
+    }
+    __syncthreads();
+    bool needScratch = false;
+    uint32_t cbuf[192];  // lane 0: at most 32 candidates are kept per group
+    CandOut out{cbuf, 0, 6, 32};
+    const GapSink sink{P.memo + (uint64_t)re * GAP_CACHE, P.genJobStr, P.counters, re * GAP_CACHE, P.genJobSegCap, T1K_AR_GENJOBS};
+    for (int s = 0; s < n;) {  // wave-uniform: every lane tracks the run boundaries
+      int curDiff = diagOf(A[s]), curCnt = 1, domCnt = 0, dominant = 0;
+      int e = s + 1;
+      for (; e < n; ++e) {
+        int d = diagOf(A[e]) - diagOf(A[e - 1]);
+        if (d < 0) d = -d;
+        if (d > P.radius) break;
+        if (d == 0) ++curCnt;
+        else {
+          if (curCnt > domCnt) { dominant = curDiff; domCnt = curCnt; }
+          curDiff = diagOf(A[e]); curCnt = 1;
+        }
+      }
+      if (curCnt > domCnt) dominant = curDiff;
+      if (e - s < 3 || (e - s) * k < P.hitLenRequired) { s = e; continue; }
+      // nearest-to-dominant filter per read offset (1437-1456): keep flags in C
+      int mine = 0;
+      for (int qq = s + lane; qq < e; qq += 64) {
+        const int a = (int)(A[qq] & 0xFFF);
+        int dq = diagOf(A[qq]) - dominant; if (dq < 0) dq = -dq;
+        bool keep = true;
+        for (int r = s; r < e; ++r) {
+          if ((int)(A[r] & 0xFFF) != a) continue;
+          int dr = diagOf(A[r]) - dominant; if (dr < 0) dr = -dr;
+          if (dr < dq) { keep = false; break; }
+        }
+        C[qq] = keep ? 1u : 0u;
+        mine += keep ? 1 : 0;
+      }
+      for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o, 64);
+      const int m = mine;
+      __syncthreads();
+      for (int qq = s + lane; qq < e; qq += 64) {  // kept hits by (allele offset, read offset) == packed value (CompSortPairBInc)
+        if (!C[qq]) continue;
+        const uint32_t x = A[qq];
+        int r = 0;
+        for (int t = s; t < e; ++t) r += (C[t] && A[t] < x) ? 1 : 0;
+        B[r] = x;
+      }
+      __syncthreads();
+      if (lane == 0) chainRun(c, k, P.hitLenRequired, A, B, C, s, m, nullptr, 0, out, &dpLocal, &P.counters[2], &needScratch, &sink, pass);
+      __syncthreads();
+      s = e;
+    }
+    if (lane == 0) {
+      if (out.overflow) atomicOr(&P.counters[2], (unsigned long long)ERR_BIGGROUP);
+      if (needScratch) { const uint32_t b = t1k_arena_append(P.counters, T1K_AR_BIG, P.listSegCap); if (b != T1K_ARENA_FULL) P.bigStr[b] = gi; }
+      else {
+        ++genLocal;
+        uint32_t base = 0;
+        if (out.n) {
+          base = t1k_arena_alloc(P.counters, T1K_AR_GENCAND, (uint32_t)out.n, P.genCandSegCap);
+          if (base == T1K_ARENA_FULL) { atomicOr(&P.counters[2], (unsigned long long)ERR_STAGECAP); out.n = 0; base = 0; }
+          for (int i = 0; i < 6 * out.n; ++i) P.genCand[(uint64_t)base * 6 + i] = cbuf[i];
+        }
+        rec[4] = base;
+        rec[3] = REC_DONE | 0x40000000u | (uint32_t)out.n;
+      }
     }
   }
   t1k_stat_add(P.counters, T1K_STAT_DP, dpLocal);
@@ -1078,10 +1187,13 @@ __global__ __launch_bounds__(WG) void k_general_finish(ChainArgs P, uint32_t nIt
   }
 }
 
-// very large groups (repeat-rich alleles) or wide gaps: a handful of lanes with big scratch in HBM
+// what is left: groups with more than WAVE_CAP hits, or a gap whose two sides differ by more than the register band covers.
+// One working lane per 64-thread workgroup; sort arrays in HBM scratch, the rows of the general alignment in LDS.
 __global__ __launch_bounds__(64) void k_chain_big(ChainArgs P, uint32_t nItems) {
-  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, nT = gridDim.x * blockDim.x;
-  uint32_t *mine = P.bigScratch + (uint64_t)t * (4 * BIG_CAP + GA_SCRATCH_INTS);
+  __shared__ int sGa[GA_SCRATCH_INTS];
+  if (threadIdx.x != 0) return;
+  const uint32_t t = blockIdx.x, nT = gridDim.x;
+  uint32_t *mine = P.bigScratch + (uint64_t)t * (4 * BIG_CAP);
   unsigned int dpLocal = 0;
   for (uint32_t q = t; q < nItems; q += nT) {
     const uint32_t gi = P.bigList[q];
@@ -1095,7 +1207,7 @@ __global__ __launch_bounds__(64) void k_chain_big(ChainArgs P, uint32_t nItems) 
     bool dummy = false;
     uint32_t cbuf[192];  // at most 32 candidates are kept per group
     CandOut o2{cbuf, 0, 6, 32};
-    groupGeneral(hh, n, c, P.k, P.radius, P.hitLenRequired, mine, mine + BIG_CAP, mine + 2 * BIG_CAP, (int *)(mine + 4 * BIG_CAP), GA_BIG_MAX, o2, &dpLocal,
+    groupGeneral(hh, n, c, P.k, P.radius, P.hitLenRequired, mine, mine + BIG_CAP, mine + 2 * BIG_CAP, sGa, GA_BIG_MAX, o2, &dpLocal,
                  &P.counters[2], &dummy);
     if (o2.overflow) atomicOr(&P.counters[2], (unsigned long long)ERR_BIGGROUP);
     uint32_t base = 0;
@@ -1280,9 +1392,15 @@ int t1k_run_chain(t1k_ctx *ctx, const ChainArgs &a, int nWg, int bigBlocks, bool
   uint32_t nBig = 0;
   if (nGen) {
     hipLaunchKernelGGL(k_gather_general, dim3(std::min<uint32_t>((nGen + 3) / 4, 8192u)), dim3(WG), 0, ctx->stream, a, nGen);
-    T1K_HIP(ctx, hipFuncSetAttribute((const void *)k_chain_general<GENERAL_CAP>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * GENERAL_CAP * 64 * 4));
-    hipLaunchKernelGGL(k_chain_general<GENERAL_SMALL>, dim3((nGen + 63) / 64), dim3(64), 3 * GENERAL_SMALL * 64 * 4, ctx->stream, a, nGen);
-    hipLaunchKernelGGL(k_chain_general<GENERAL_CAP>, dim3((nGen + 63) / 64), dim3(64), 3 * GENERAL_CAP * 64 * 4, ctx->stream, a, nGen);
+    hipLaunchKernelGGL(k_chain_general, dim3((nGen + 63) / 64), dim3(64), 0, ctx->stream, a, nGen);
+    if ((rc = readCounters(ctx, hc))) return rc;
+    const T1kArenaCounts wv = t1k_arena_counts(ctx, T1K_AR_WAVE, a.listSegCap);
+    if (wv.overflow) { hc[2] |= ERR_GROUPCAP; return 0; }
+    if (wv.total) {
+      t1k_arena_compact(ctx, T1K_AR_WAVE, a.waveStr, a.listSegCap, a.waveList, wv.maxSeg);
+      T1K_HIP(ctx, hipFuncSetAttribute((const void *)k_chain_wave, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * WAVE_CAP * 4));
+      hipLaunchKernelGGL(k_chain_wave, dim3(std::min<uint32_t>((uint32_t)wv.total, 2048u)), dim3(64), 3 * WAVE_CAP * 4, ctx->stream, a, (uint32_t)wv.total);
+    }
     if ((rc = readCounters(ctx, hc))) return rc;  // the general kernels register alignments and may hand groups over to the big-scratch kernel
     const T1kArenaCounts gj = t1k_arena_counts(ctx, T1K_AR_GENJOBS, a.genJobSegCap);
     t1k_arena_compact(ctx, T1K_AR_GENJOBS, a.genJobStr, a.genJobSegCap, a.genJobList, gj.maxSeg);
@@ -1293,7 +1411,7 @@ int t1k_run_chain(t1k_ctx *ctx, const ChainArgs &a, int nWg, int bigBlocks, bool
     t1k_arena_compact(ctx, T1K_AR_BIG, a.bigStr, a.listSegCap, a.bigList, big.maxSeg);
     nBig = (uint32_t)big.total;
   }
-  if (nBig) hipLaunchKernelGGL(k_chain_big, dim3(bigBlocks), dim3(64), 0, ctx->stream, a, nBig);
+  if (nBig) hipLaunchKernelGGL(k_chain_big, dim3(bigBlocks * 64), dim3(64), 0, ctx->stream, a, nBig);
   hipLaunchKernelGGL(k_collect, dim3(nWg), dim3(WG), 0, ctx->stream, a);
   T1K_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
   rc = readCounters(ctx, hc);

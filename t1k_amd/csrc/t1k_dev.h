@@ -480,7 +480,7 @@ enum { T1K_STAT_DP = 0, T1K_STAT_FAST = 1, T1K_STAT_GENERAL = 2, T1K_STAT_EXTEND
 // their own cursor (64 bytes apart); a workgroup allocates from segment blockIdx.x % T1K_NSTRIPE.  Lists are made dense
 // again by k_arena_compact before their consumer runs; group records are consumed segment by segment.
 #define T1K_NSTRIPE 32
-enum { T1K_AR_GROUPS = 0, T1K_AR_JOBS, T1K_AR_RETRY, T1K_AR_FINISH, T1K_AR_GENERAL, T1K_AR_BIG, T1K_AR_GENCAND, T1K_AR_EQ, T1K_AR_BAND, T1K_AR_WIDE, T1K_AR_GENHITS, T1K_AR_GENJOBS, T1K_NARENA };
+enum { T1K_AR_GROUPS = 0, T1K_AR_JOBS, T1K_AR_RETRY, T1K_AR_FINISH, T1K_AR_GENERAL, T1K_AR_BIG, T1K_AR_GENCAND, T1K_AR_EQ, T1K_AR_BAND, T1K_AR_WIDE, T1K_AR_GENHITS, T1K_AR_GENJOBS, T1K_AR_WAVE, T1K_NARENA };
 #define T1K_ARENA_BASE (64 + T1K_STAT_STRIPES * 8)
 #define T1K_COUNTER_WORDS (T1K_ARENA_BASE + T1K_NARENA * T1K_NSTRIPE * 8)
 #define T1K_ARENA_FULL 0xFFFFFFFFu
@@ -517,9 +517,9 @@ __device__ __forceinline__ void t1k_stat_add(unsigned long long *counters, int k
   }
 }
 
-// exclusive prefix sum over a 256-thread workgroup (4 wavefronts); all threads must call it
-__device__ __forceinline__ uint32_t t1k_block_scan_exclusive(uint32_t v, uint32_t *warpSums, uint32_t *total) {
-  // 256 threads = 4 wavefronts of 64
+// exclusive prefix sum over a workgroup of NWAVES wavefronts; all threads must call it (warpSums: NWAVES words of LDS)
+template <int NWAVES>
+__device__ __forceinline__ uint32_t t1k_block_scan_exclusive_n(uint32_t v, uint32_t *warpSums, uint32_t *total) {
   int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   uint32_t x = v;
 #pragma unroll
@@ -529,12 +529,15 @@ __device__ __forceinline__ uint32_t t1k_block_scan_exclusive(uint32_t v, uint32_
   }
   if (lane == 63) warpSums[wave] = x;
   __syncthreads();
-  uint32_t base = 0;
-  for (int w = 0; w < wave; ++w) base += warpSums[w];
-  uint32_t tot = warpSums[0] + warpSums[1] + warpSums[2] + warpSums[3];
+  uint32_t base = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < NWAVES; ++w) { const uint32_t s = warpSums[w]; if (w < wave) base += s; tot += s; }
   __syncthreads();
   *total = tot;
   return base + x - v;
+}
+__device__ __forceinline__ uint32_t t1k_block_scan_exclusive(uint32_t v, uint32_t *warpSums, uint32_t *total) {  // 256 threads
+  return t1k_block_scan_exclusive_n<4>(v, warpSums, total);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
