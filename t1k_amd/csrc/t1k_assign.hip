@@ -12,6 +12,7 @@
 //   k_truncate     >1000 overlaps: re-sort and cut at similarity < best - 0.1 (2290-2298)
 #include "t1k_dev.h"
 #include "t1k_launch.h"
+#include "t1k_memo.h"
 
 #define WG 256
 #define GA_BIG_MAX 2048
@@ -83,7 +84,11 @@ __device__ inline bool lowComplexity(const uint64_t *rb, const uint64_t *rn, int
   return low >= 2;
 }
 
-__device__ __forceinline__ void extendOne(const ExtendArgs &P, uint64_t gid, unsigned int &extendDp) {
+// DEFER = true: the two extension alignments that need a DP are registered in the read-end's memo (the same table the chain
+// stage filled: thousands of alleles share a window) and the candidate is put on the retry list; returns false.
+// DEFER = false: second pass, after k_dp_dense: the memo answers (or, for the few unregistered ones, the DP runs here).
+template <bool DEFER>
+__device__ __forceinline__ bool extendOne(const ExtendArgs &P, uint64_t gid, unsigned int &extendDp) {
   T1kCand c = P.cand[gid];
   T1kExt x{};
   const uint32_t allele = c.allele & 0x7FFFFFFFu;
@@ -97,11 +102,11 @@ __device__ __forceinline__ void extendOne(const ExtendArgs &P, uint64_t gid, uns
   const int matchCnt = (int)(c.match >> 16);
   double sim = (double)matchCnt / (double)(se - ss + 1 + re - rs + 1);  // SeqSet.hpp:1838-1840
   if (lowComplexity(rb, rn, rs, re)) sim = 0;                           // 1844-1845
-  if (sim < P.sim) { x.flags = T1K_F_DROP; P.ext[gid] = x; return; }    // 1894-1908
+  if (sim < P.sim) { x.flags = T1K_F_DROP; P.ext[gid] = x; return true; }    // 1894-1908
   uint16_t flags = 0;
   if (sepInRange(P.ref, allele, ss, se)) flags |= T1K_F_SEPSEED;                                  // 2163
   if (sepInRange(P.ref, allele, ss - rs, se + (len - re - 1))) flags |= T1K_F_NEEDCLIP;           // 2167-2169
-  if (flags & T1K_F_SEPSEED) { x.flags = flags; P.ext[gid] = x; return; }
+  if (flags & T1K_F_SEPSEED) { x.flags = flags; P.ext[gid] = x; return true; }
   // ExtendOverlap (1994-2100)
   const int alleleLen = (int)P.ref.alleleLen[allele];
   const int64_t goff = (int64_t)P.ref.alleleOff[allele];
@@ -118,7 +123,12 @@ __device__ __forceinline__ void extendOne(const ExtendArgs &P, uint64_t gid, uns
     if (bestP >= 0) { int i = ss - 1 - bestP; leftClip = lo - i; lo = i; }
   }
   unsigned int dpLocal = 0;
-  int match = t1k_ga_matches_window(rb, rn, rs - lo, P.ref.bases, P.ref.nmask, goff + ss - lo, lo, &dpLocal);
+  const ReadCtx rc{rb, rn, len, P.ref.bases, P.ref.nmask, goff, alleleLen};
+  const GapSink sink{P.memo + (uint64_t)c.re * GAP_CACHE, P.jobStr, P.counters, c.re * GAP_CACHE, P.jobSegCap, T1K_AR_EXTJOBS};
+  uint32_t slot = 0;
+  bool pending = false;
+  int match = gapMatchesCached<DEFER>(rc, rs - lo, goff + ss - lo, lo, lo, pass, sink, &dpLocal, &slot);
+  if (match < 0) { pending = true; match = 0; }
   int ro = (len - 1 - re) < (alleleLen - 1 - se) ? (len - 1 - re) : (alleleLen - 1 - se);
   if (len - 1 - re > alleleLen - 1 - se) rightClip = len - 1 - re - (alleleLen - 1 - se);
   {
@@ -130,8 +140,12 @@ __device__ __forceinline__ void extendOne(const ExtendArgs &P, uint64_t gid, uns
     }
     if (bestP != 0x7FFFFFFF) { int i = bestP - se - 1; rightClip = ro - i; ro = i; }
   }
-  match += t1k_ga_matches_window(rb, rn, re + 1, P.ref.bases, P.ref.nmask, goff + se + 1, ro, &dpLocal);
+  {
+    const int mr = gapMatchesCached<DEFER>(rc, re + 1, goff + se + 1, ro, ro, pass, sink, &dpLocal, &slot);
+    if (mr < 0) pending = true; else match += mr;
+  }
   extendDp = dpLocal;
+  if (pending) return false;
   int eMatch = 2 * match + matchCnt;
   int ers = rs - lo, ere = re + ro, ess = ss - lo, ese = se + ro;
   double esim = (double)eMatch / (double)(ere - ers + 1 + ese - ess + 1);
@@ -140,12 +154,26 @@ __device__ __forceinline__ void extendOne(const ExtendArgs &P, uint64_t gid, uns
   x.seqStart = ess; x.seqEnd = ese; x.readStart = (uint16_t)ers; x.readEnd = (uint16_t)ere;
   x.matchCnt = (uint16_t)eMatch; x.leftClip = (uint16_t)leftClip; x.rightClip = (uint16_t)rightClip; x.flags = flags;
   P.ext[gid] = x;
+  return true;
 }
 
 __global__ __launch_bounds__(WG) void k_extend(ExtendArgs P) {
   const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   unsigned int dp = 0;
-  if (gid < P.nCand) extendOne(P, gid, dp);
+  bool done = true;
+  if (gid < P.nCand) done = extendOne<true>(P, gid, dp);
+  if (!done) {
+    const uint32_t q = t1k_arena_append(P.counters, T1K_AR_EXTRETRY, P.retrySegCap);
+    if (q != T1K_ARENA_FULL) P.retryStr[q] = (uint32_t)gid;
+  }
+  t1k_stat_add(P.counters, T1K_STAT_EXTEND_DP, dp);
+}
+
+// second pass over the candidates whose extension waited for registered alignments
+__global__ __launch_bounds__(WG) void k_extend_retry(ExtendArgs P, const uint32_t *list, uint32_t nItems) {
+  const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned int dp = 0;
+  if (q < nItems) extendOne<false>(P, list[q], dp);
   t1k_stat_add(P.counters, T1K_STAT_EXTEND_DP, dp);
 }
 
@@ -378,12 +406,25 @@ __global__ __launch_bounds__(WG) void k_fullalign(FullArgs P) {
   if (slow) {
     // equal spans: register-band traced DP (queue A, from the front); unequal spans: general DP (queue B, from the back)
     const int dl = L > Ls ? L - Ls : Ls - L;
+    // sort key of the queue entry: alignments of one read window against identical allele windows become neighbours, and the
+    // traced kernels fill the DP only once per run of them (content hash; equality is verified there, the hash only orders)
+    unsigned long long key = 0;
+    if (dl <= 4) {
+      uint64_t hsh = 0x9E3779B97F4A7C15ull;
+      for (int off = 0; off < Ls; off += 32) {
+        const uint64_t lm = t1k_lowmask(Ls - off);
+        hsh = (hsh ^ (t1k_get32(P.ref.bases, goff + o.seqStart + off) & lm) ^ ((t1k_get32(P.ref.nmask, goff + o.seqStart + off) & lm) << 1)) * 0xD6E8FEB86659FD93ull;
+        hsh ^= hsh >> 32;
+      }
+      key = ((unsigned long long)o.re << 44) | ((unsigned long long)pass << 43) | ((unsigned long long)o.readStart << 34) | ((unsigned long long)L << 25) |
+            ((unsigned long long)(Ls - L + 4) << 21) | (hsh & 0x1FFFFFull);
+    }
     if (L == Ls) {
       const uint32_t q = t1k_arena_append(P.counters, T1K_AR_EQ, P.segCap);
-      if (q != T1K_ARENA_FULL) P.eqStr[q] = (uint32_t)gid;
+      if (q != T1K_ARENA_FULL) { P.eqStr[q] = (uint32_t)gid; P.eqKeyStr[q] = key; }
     } else if (dl <= 4) {  // register-band DP (k_fullalign_band)
       const uint32_t q = t1k_arena_append(P.counters, T1K_AR_BAND, P.segCap);
-      if (q != T1K_ARENA_FULL) P.bandStr[q] = (uint32_t)gid;
+      if (q != T1K_ARENA_FULL) { P.bandStr[q] = (uint32_t)gid; P.bandKeyStr[q] = key; }
     } else {               // wide band: general DP with row arrays in HBM (k_fullalign_slow)
       const uint32_t q = t1k_arena_append(P.counters, T1K_AR_WIDE, P.segCap);
       if (q != T1K_ARENA_FULL) P.wideStr[q] = (uint32_t)gid;
@@ -459,10 +500,54 @@ __global__ __launch_bounds__(64) void k_fullalign_slow(SlowArgs P) {
 // equal-span near-best alignments with more than 3 mismatches: banded DP with the band in registers, decision words in a
 // coalesced global trace, then the reference's traceback walked backwards (AlignAlgo.hpp:323-408) accumulating the relaxed
 // match count and the coverage runs directly (no edit string is materialised).
-__global__ __launch_bounds__(WG) void k_fullalign_eq(SlowArgs P) {
-  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, nThreads = gridDim.x * blockDim.x;
-  uint64_t *trace = (uint64_t *)P.scratch + t;
-  for (uint32_t q = t; q < P.nSlow; q += nThreads) {
+// The traced alignments run in three steps over the SORTED queue (identical jobs are neighbours):
+//   k_align_flags  marks the first job of every run of identical (read window, allele window) jobs; an inclusive scan numbers the runs
+//   k_align_fill   one lane per run: DP sweep, decision words -> trace[row * stride + run]
+//   k_align_apply  one lane per job: traceback over its run's decision words -> relaxed match count + coverage of its own allele
+// (neighbouring lanes read the same or adjacent trace columns)
+__global__ __launch_bounds__(WG) void k_align_flags(SlowArgs P, uint32_t *flags) {
+  const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= P.nSlow) return;
+  uint32_t fl = 1;
+  if (q > 0) {
+    const T1kOvl o = P.ovl[P.slowQueue[q]], p = P.ovl[P.slowQueue[q - 1]];
+    const int lt = o.seqEnd - o.seqStart + 1;
+    if (o.re == p.re && ((o.flags ^ p.flags) & 2) == 0 && o.readStart == p.readStart && o.readEnd == p.readEnd && lt == p.seqEnd - p.seqStart + 1 &&
+        t1k_same_window(P.ref.bases, P.ref.nmask, (int64_t)P.ref.alleleOff[p.allele] + p.seqStart, (int64_t)P.ref.alleleOff[o.allele] + o.seqStart, lt))
+      fl = 0;
+  }
+  flags[q] = fl;
+}
+__global__ __launch_bounds__(WG) void k_align_reps(const uint32_t *flags, const uint32_t *runOf, uint32_t *rep, uint32_t n) {
+  const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q < n && flags[q]) rep[runOf[q] - 1] = q;
+}
+
+template <bool EQ>
+__global__ __launch_bounds__(WG) void k_align_fill(SlowArgs P) {
+  const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= P.nRuns) return;
+  const uint32_t q = P.rep[u];
+    const uint32_t gid = P.slowQueue[q];
+    const T1kOvl o = P.ovl[gid];
+    const int pass = (o.flags & 2) ? 1 : 0;
+    const int S = P.reads.S;
+    const uint64_t *rb = P.reads.bases + ((uint64_t)o.re * 2 + pass) * S;
+    const uint64_t *rn = P.reads.nmask + ((uint64_t)o.re * 2 + pass) * S;
+    const int64_t goff = (int64_t)P.ref.alleleOff[o.allele];
+    const int lp = o.readEnd - o.readStart + 1, lt = o.seqEnd - o.seqStart + 1;
+    T1kSeqView T{P.ref.bases, P.ref.nmask, goff + o.seqStart}, Pv{rb, rn, (int64_t)o.readStart};
+    uint64_t *trace = (uint64_t *)P.scratch + u;
+    if (EQ) t1k_ga_equal_traced(T, Pv, lp, trace, P.traceStride);
+    else t1k_ga_band<4, true>(T, lt, Pv, lp, trace, P.traceStride);
+}
+
+__global__ __launch_bounds__(WG) void k_align_apply_eq(SlowArgs P) {
+  const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= P.nSlow) return;
+  const size_t nThreads = P.traceStride;
+  const uint64_t *trace = (const uint64_t *)P.scratch + (P.runOf[q] - 1);
+  {
     const uint32_t gid = P.slowQueue[q];
     const T1kOvl o = P.ovl[gid];
     const int pass = (o.flags & 2) ? 1 : 0;
@@ -472,8 +557,6 @@ __global__ __launch_bounds__(WG) void k_fullalign_eq(SlowArgs P) {
     const int64_t goff = (int64_t)P.ref.alleleOff[o.allele];
     const int L = o.readEnd - o.readStart + 1;
     const int w = (int)P.reads.weight[o.re];
-    T1kSeqView T{P.ref.bases, P.ref.nmask, goff + o.seqStart}, Pv{rb, rn, (int64_t)o.readStart};
-    t1k_ga_equal_traced(T, Pv, L, trace, nThreads);
     int32_t *cov = P.ref.covDiff + goff;
     const int alleleLen = (int)P.ref.alleleLen[o.allele];
     int relaxed = 0;
@@ -516,12 +599,12 @@ __global__ __launch_bounds__(WG) void k_fullalign_eq(SlowArgs P) {
   }
 }
 
-// near-best alignments whose spans differ by 1..4 (chains with a small indel): same scheme as k_fullalign_eq with the wider
-// register band of t1k_ga_band
-__global__ __launch_bounds__(WG) void k_fullalign_band(SlowArgs P) {
-  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, nThreads = gridDim.x * blockDim.x;
-  uint64_t *trace = (uint64_t *)P.scratch + t;
-  for (uint32_t q = t; q < P.nSlow; q += nThreads) {
+__global__ __launch_bounds__(WG) void k_align_apply_band(SlowArgs P) {
+  const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= P.nSlow) return;
+  const size_t nThreads = P.traceStride;
+  const uint64_t *trace = (const uint64_t *)P.scratch + (P.runOf[q] - 1);
+  {
     const uint32_t gid = P.slowQueue[q];
     const T1kOvl o = P.ovl[gid];
     const int pass = (o.flags & 2) ? 1 : 0;
@@ -533,7 +616,6 @@ __global__ __launch_bounds__(WG) void k_fullalign_band(SlowArgs P) {
     const int LB = 5 + (lp > lt ? lp - lt : 0);
     const int w = (int)P.reads.weight[o.re];
     T1kSeqView T{P.ref.bases, P.ref.nmask, goff + o.seqStart}, Pv{rb, rn, (int64_t)o.readStart};
-    t1k_ga_band<4, true>(T, lt, Pv, lp, trace, nThreads);
     int32_t *cov = P.ref.covDiff + goff;
     const int alleleLen = (int)P.ref.alleleLen[o.allele];
     int relaxed = 0, runLo = -1, runHi = -1;
@@ -696,6 +778,10 @@ void t1k_launch_extend(t1k_ctx *ctx, const ExtendArgs &a) {
   if (!a.nCand) return;
   hipLaunchKernelGGL(k_extend, dim3((unsigned)((a.nCand + WG - 1) / WG)), dim3(WG), 0, ctx->stream, a);
 }
+void t1k_launch_extend_retry(t1k_ctx *ctx, const ExtendArgs &a, const uint32_t *list, uint32_t n) {
+  if (!n) return;
+  hipLaunchKernelGGL(k_extend_retry, dim3((n + WG - 1) / WG), dim3(WG), 0, ctx->stream, a, list, n);
+}
 void t1k_launch_select(t1k_ctx *ctx, const SelectArgs &a, int nWg) {
   hipFuncSetAttribute((const void *)k_select<SELECT_LARGE, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, SELECT_LARGE * 12);
   hipLaunchKernelGGL((k_select<SELECT_SMALL, 256>), dim3(nWg), dim3(256), SELECT_SMALL * 12, ctx->stream, a);
@@ -706,8 +792,21 @@ void t1k_launch_fullalign(t1k_ctx *ctx, const FullArgs &a) {
   hipLaunchKernelGGL(k_fullalign, dim3((unsigned)((a.nOvl + WG - 1) / WG)), dim3(WG), 0, ctx->stream, a);
 }
 void t1k_launch_fullalign_slow(t1k_ctx *ctx, const SlowArgs &a, int nBlocks) { hipLaunchKernelGGL(k_fullalign_slow, dim3(nBlocks), dim3(64), 0, ctx->stream, a); }
-void t1k_launch_fullalign_eq(t1k_ctx *ctx, const SlowArgs &a, int nBlocks) { hipLaunchKernelGGL(k_fullalign_eq, dim3(nBlocks), dim3(WG), 0, ctx->stream, a); }
-void t1k_launch_fullalign_band(t1k_ctx *ctx, const SlowArgs &a, int nBlocks) { hipLaunchKernelGGL(k_fullalign_band, dim3(nBlocks), dim3(WG), 0, ctx->stream, a); }
+void t1k_launch_align_flags(t1k_ctx *ctx, const SlowArgs &a, uint32_t *flags) {
+  hipLaunchKernelGGL(k_align_flags, dim3((a.nSlow + WG - 1) / WG), dim3(WG), 0, ctx->stream, a, flags);
+}
+void t1k_launch_align_reps(t1k_ctx *ctx, const uint32_t *flags, const uint32_t *runOf, uint32_t *rep, uint32_t n) {
+  hipLaunchKernelGGL(k_align_reps, dim3((n + WG - 1) / WG), dim3(WG), 0, ctx->stream, flags, runOf, rep, n);
+}
+void t1k_launch_align_fill_apply(t1k_ctx *ctx, const SlowArgs &a, bool eq) {
+  if (eq) {
+    hipLaunchKernelGGL(k_align_fill<true>, dim3((a.nRuns + WG - 1) / WG), dim3(WG), 0, ctx->stream, a);
+    hipLaunchKernelGGL(k_align_apply_eq, dim3((a.nSlow + WG - 1) / WG), dim3(WG), 0, ctx->stream, a);
+  } else {
+    hipLaunchKernelGGL(k_align_fill<false>, dim3((a.nRuns + WG - 1) / WG), dim3(WG), 0, ctx->stream, a);
+    hipLaunchKernelGGL(k_align_apply_band, dim3((a.nSlow + WG - 1) / WG), dim3(WG), 0, ctx->stream, a);
+  }
+}
 void t1k_launch_truncate(t1k_ctx *ctx, const TruncArgs &a, int nWg) {
   hipFuncSetAttribute((const void *)k_truncate<SELECT_LARGE, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, SELECT_LARGE * 12);
   hipLaunchKernelGGL((k_truncate<SELECT_SMALL, 256>), dim3(nWg), dim3(256), SELECT_SMALL * 12, ctx->stream, a);

@@ -106,7 +106,7 @@ void t1k_ctx_destroy(t1k_ctx *ctx) {
   for (auto &b : ctx->refBufs) freeBuf(b);
   T1kDevBuf *all[] = {&ctx->bReadAscii, &ctx->bReadOffs, &ctx->bReadBases, &ctx->bReadN, &ctx->bReadLen, &ctx->bReadWeight, &ctx->bWgHits, &ctx->bWgGroups,
                       &ctx->bWgStage, &ctx->bWgThreadScratch, &ctx->bWgBig, &ctx->bWgCache, &ctx->bLists, &ctx->bCand, &ctx->bExt, &ctx->bCandStart, &ctx->bCandCount, &ctx->bOvl,
-                      &ctx->bOvlStart, &ctx->bOvlCount, &ctx->bCounters, &ctx->bSlowQueue, &ctx->bSlowScratch, &ctx->bSortScratch, &ctx->bEqTrace, &ctx->bEnd1, &ctx->bEnd2,
+                      &ctx->bOvlStart, &ctx->bOvlCount, &ctx->bCounters, &ctx->bSlowQueue, &ctx->bSlowScratch, &ctx->bSortScratch, &ctx->bEqTrace, &ctx->bSortTmp, &ctx->bSlowKeys, &ctx->bEnd1, &ctx->bEnd2,
                       &ctx->bHasN, &ctx->bRows, &ctx->bRowStart, &ctx->bRowCount, &ctx->bFragAssigned, &ctx->bPairScratch, &ctx->bEmRowPtr, &ctx->bEmEc,
                       &ctx->bEmCount, &ctx->bEmLen, &ctx->bEmX0, &ctx->bEmX1, &ctx->bEmN, &ctx->bEmContrib, &ctx->bEmColPtr, &ctx->bEmColIdx, &ctx->bEmScalars};
   for (auto *b : all) freeBuf(*b);
@@ -415,7 +415,18 @@ int t1k_assign_range(t1k_ctx *ctx, uint64_t first, uint32_t count) {
   ExtendArgs e{};
   e.ref = ctx->ref; e.reads = rd; e.k = a.k; e.sim = a.sim;
   e.cand = a.cand; e.ext = (T1kExt *)ctx->bExt.p; e.nCand = ctx->nCand; e.counters = a.counters;
+  // the extension alignments go through the memo like the chain's (the chain's work lists are dead by now: reuse their memory)
+  e.memo = a.memo; e.jobStr = a.jobStr; e.jobSegCap = a.jobSegCap; e.retryStr = a.retryStr; e.retrySegCap = a.listSegCap;
   t1k_launch_extend(ctx, e);
+  if ((rc = fetchCounters(ctx, hc))) return rc;
+  {
+    const T1kArenaCounts ej = t1k_arena_counts(ctx, T1K_AR_EXTJOBS, e.jobSegCap), er = t1k_arena_counts(ctx, T1K_AR_EXTRETRY, e.retrySegCap);
+    if (er.overflow) return capacityError(ctx, 256);
+    t1k_arena_compact(ctx, T1K_AR_EXTJOBS, e.jobStr, e.jobSegCap, a.jobList, ej.maxSeg);
+    t1k_arena_compact(ctx, T1K_AR_EXTRETRY, e.retryStr, e.retrySegCap, a.retryList, er.maxSeg);
+    t1k_launch_dp_dense(ctx, a, a.jobList, (uint32_t)ej.total);
+    t1k_launch_extend_retry(ctx, e, a.retryList, (uint32_t)er.total);
+  }
   T1K_HIP(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
   T1K_HIP(ctx, hipStreamSynchronize(ctx->stream));
   double t2 = nowMs();
@@ -441,6 +452,11 @@ int t1k_assign_range(t1k_ctx *ctx, uint64_t first, uint32_t count) {
   f.ref = ctx->ref; f.reads = rd; f.relax = relaxFlag; f.ovl = s.ovl; f.nOvl = ctx->nOvl;
   uint32_t *qEq = (uint32_t *)ctx->bSlowQueue.p, *qBand = qEq + qDense, *qWide = qBand + qDense;
   f.eqStr = qWide + qDense; f.bandStr = f.eqStr + qStr; f.wideStr = f.bandStr + qStr; f.segCap = qSegCap; f.counters = a.counters;
+  // sort keys of the equal / band queues: striped | dense | sorted (scratch of the radix sort), and the unsorted dense gid lists
+  if ((rc = t1k_ensure(ctx, ctx->bSlowKeys, (qStr * 2 + qDense * 2) * 8 + qDense * 4))) return rc;
+  f.eqKeyStr = (unsigned long long *)ctx->bSlowKeys.p; f.bandKeyStr = f.eqKeyStr + qStr;
+  unsigned long long *kDense = f.bandKeyStr + qStr, *kSorted = kDense + qDense;
+  uint32_t *vDense = (uint32_t *)(kSorted + qDense);
   t1k_launch_fullalign(ctx, f);
   T1K_HIP(ctx, hipEventRecord(ctx->ev[7], ctx->stream));
   if ((rc = fetchCounters(ctx, hc))) return rc;
@@ -448,28 +464,35 @@ int t1k_assign_range(t1k_ctx *ctx, uint64_t first, uint32_t count) {
   {
     const T1kArenaCounts ce = t1k_arena_counts(ctx, T1K_AR_EQ, qSegCap), cb = t1k_arena_counts(ctx, T1K_AR_BAND, qSegCap), cw = t1k_arena_counts(ctx, T1K_AR_WIDE, qSegCap);
     if (ce.overflow || cb.overflow || cw.overflow) return capacityError(ctx, 64);
-    t1k_arena_compact(ctx, T1K_AR_EQ, f.eqStr, qSegCap, qEq, ce.maxSeg);
-    t1k_arena_compact(ctx, T1K_AR_BAND, f.bandStr, qSegCap, qBand, cb.maxSeg);
+    // equal / band queues: dense, then ordered by (read-end, strand, read window, allele-window hash)
+    t1k_arena_compact(ctx, T1K_AR_EQ, f.eqStr, qSegCap, vDense, ce.maxSeg);
+    t1k_arena_compact64(ctx, T1K_AR_EQ, f.eqKeyStr, qSegCap, kDense, ce.maxSeg);
+    if ((rc = t1k_sort_pairs(ctx, kDense, kSorted, vDense, qEq, (uint32_t)ce.total))) return rc;
+    t1k_arena_compact(ctx, T1K_AR_BAND, f.bandStr, qSegCap, vDense, cb.maxSeg);
+    t1k_arena_compact64(ctx, T1K_AR_BAND, f.bandKeyStr, qSegCap, kDense, cb.maxSeg);
+    if ((rc = t1k_sort_pairs(ctx, kDense, kSorted, vDense, qBand, (uint32_t)cb.total))) return rc;
     t1k_arena_compact(ctx, T1K_AR_WIDE, f.wideStr, qSegCap, qWide, cw.maxSeg);
     hc[8] = ce.total; hc[15] = cb.total; hc[20] = cw.total;
   }
-  if (hc[8]) {  // equal-span alignments: register-band traced DP, one lane per job
-    const int eqBlocks = 512;
-    const size_t traceBytes = (size_t)eqBlocks * 256 * (size_t)(ctx->batchMaxLen + 2) * 8;
-    if ((rc = t1k_ensure(ctx, ctx->bEqTrace, traceBytes))) return rc;
+  // equal spans (register-band traced DP) and spans differing by 1..4 (wider register band): flags -> runs -> fill -> apply
+  for (int kind = 0; kind < 2; ++kind) {
+    const uint32_t nJobs = (uint32_t)(kind == 0 ? hc[8] : hc[15]);
+    if (!nJobs) continue;
     SlowArgs sl{};
-    sl.ref = ctx->ref; sl.reads = rd; sl.relax = relaxFlag; sl.ovl = s.ovl; sl.slowQueue = qEq; sl.nSlow = (uint32_t)hc[8];
-    sl.scratch = (uint8_t *)ctx->bEqTrace.p; sl.perThread = 0; sl.maxCells = 0; sl.counters = a.counters;
-    t1k_launch_fullalign_eq(ctx, sl, eqBlocks);
-  }
-  if (hc[15]) {  // spans differing by 1..4 (small indel in the chain): wider register band
-    const int eqBlocks = 512;
-    const size_t traceBytes = (size_t)eqBlocks * 256 * (size_t)(ctx->batchMaxLen + 2) * 8;
-    if ((rc = t1k_ensure(ctx, ctx->bEqTrace, traceBytes))) return rc;
-    SlowArgs sl{};
-    sl.ref = ctx->ref; sl.reads = rd; sl.relax = relaxFlag; sl.ovl = s.ovl; sl.slowQueue = qBand; sl.nSlow = (uint32_t)hc[15];
-    sl.scratch = (uint8_t *)ctx->bEqTrace.p; sl.perThread = 0; sl.maxCells = 0; sl.counters = a.counters;
-    t1k_launch_fullalign_band(ctx, sl, eqBlocks);
+    sl.ref = ctx->ref; sl.reads = rd; sl.relax = relaxFlag; sl.ovl = s.ovl; sl.slowQueue = kind == 0 ? qEq : qBand; sl.nSlow = nJobs;
+    sl.perThread = 0; sl.maxCells = 0; sl.counters = a.counters;
+    uint32_t *flags = vDense, *runOf = (uint32_t *)kDense, *rep = (uint32_t *)kSorted;  // the sort's buffers are free again
+    t1k_launch_align_flags(ctx, sl, flags);
+    if ((rc = t1k_inclusive_sum(ctx, flags, runOf, nJobs))) return rc;
+    uint32_t nRuns = 0;
+    T1K_HIP(ctx, hipMemcpyAsync(&nRuns, runOf + (nJobs - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
+    T1K_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    t1k_launch_align_reps(ctx, flags, runOf, rep, nJobs);
+    const uint64_t stride = ((uint64_t)nRuns + 63) / 64 * 64;
+    if ((rc = t1k_ensure(ctx, ctx->bEqTrace, stride * (size_t)(ctx->batchMaxLen + 2) * 8))) return rc;
+    sl.scratch = (uint8_t *)ctx->bEqTrace.p; sl.runOf = runOf; sl.rep = rep; sl.nRuns = nRuns; sl.traceStride = stride;
+    t1k_launch_align_fill_apply(ctx, sl, kind == 0);
+    if (getenv("T1K_DEBUG_PHASES")) fprintf(stderr, "[t1k] %s alignments: %u jobs in %u runs of identical windows\n", kind == 0 ? "equal-span" : "band", nJobs, nRuns);
   }
   if (hc[20]) {  // wide length difference: general DP with row arrays in HBM
     SlowArgs sl{};

@@ -16,6 +16,7 @@
 #include <algorithm>
 #include "t1k_dev.h"
 #include "t1k_launch.h"
+#include "t1k_memo.h"
 
 #define WG 256
 #define GROUP_FAST_MAXLEN 320
@@ -29,14 +30,6 @@ enum { ERR_HITCAP = 1, ERR_STAGECAP = 2, ERR_CANDCAP = 4, ERR_BIGGROUP = 8, ERR_
 // ------------------------------------------------------------------------------------------------------------------
 // group -> candidate overlaps
 // ------------------------------------------------------------------------------------------------------------------
-struct ReadCtx {
-  const uint64_t *rb, *rn;   // strand-specific read words
-  int len;
-  const uint64_t *gb, *gn;   // reference words
-  int64_t goff;              // allele global base offset
-  int alleleLen;
-};
-
 struct CandOut {  // packed candidates: 3 u32 each (+ 3 u32 of memo references when stride == 6, multi-diagonal groups)
   uint32_t *dst;
   int n;
@@ -73,122 +66,6 @@ __device__ inline int gapMatches(const ReadCtx &c, int ra, int ga, int lp, int l
   if (lt > gaMax) { atomicOr(errFlags, (unsigned long long)ERR_BIGGROUP); return 0; }
   t1k_ga_general(T, lt, P, lp, gaScratch, nullptr, &nm);
   return nm;
-}
-
-// ------------------------------------------------------------------------------------------------------------------
-// Exact memo of gap alignments within one read-end.  Thousands of alleles of a gene carry the same bases under a given
-// read window, so the same banded DP would be recomputed for each of them.  One 64-bit entry identifies a job completely:
-//   [gpos:30 | matches:9 | readPos:11 | readLen:9 | (alleleLen - readLen + 4):4 | strand:1]
-// A probe whose (strand, readPos, lengths) agree verifies that the allele window at the entry's gpos holds exactly the same
-// bases and N-mask as its own window before it reuses the stored match count, so a hit is bit-exact by construction
-// (GlobalAlignment only sees the two windows).  The table lives in HBM (16 KB per read-end) and is cleared per batch.
-// ------------------------------------------------------------------------------------------------------------------
-#define GAP_CACHE 2048
-#define GAP_PROBES 4
-#define GAP_ID_MASK 0x1FFFFFFull
-#define GAP_VAL(e) ((uint32_t)(((e) >> 25) & 0x1FF))
-#define GAP_GPOS(e) ((int64_t)((e) >> 34))
-#define GAP_PENDING 0x1FFull
-__device__ inline bool sameWindow(const uint64_t *gb, const uint64_t *gn, int64_t a, int64_t b, int L) {
-  for (int o = 0; o < L; o += 32) {
-    uint64_t lm = t1k_lowmask(L - o);
-    if (((t1k_get32(gb, a + o) ^ t1k_get32(gb, b + o)) & lm) | ((t1k_get32(gn, a + o) ^ t1k_get32(gn, b + o)) & lm)) return false;
-  }
-  return true;
-}
-
-struct GapSink {  // where deferred alignments are registered
-  unsigned long long *cache;     // the read-end's memo table
-  uint32_t *jobStr;              // striped job list
-  unsigned long long *counters;
-  uint32_t jobTag, jobSegCap;
-  int arena;
-};
-
-// the alignment itself: lp read positions from readPos against lt allele positions from gpos, |lt - lp| <= 4
-__device__ __forceinline__ int gapAlign(const ReadCtx &c, int readPos, int64_t gpos, int lp, int lt) {
-  T1kSeqView T{c.gb, c.gn, gpos}, P{c.rb, c.rn, (int64_t)readPos};
-  if (lp == lt) return t1k_ga_matches_equal(T, P, lp, nullptr);
-  return t1k_ga_band<4, false>(T, lt, P, lp, nullptr, 0);
-}
-
-// DEFER = true : never run a DP here.  A miss claims a memo slot (CAS) with the PENDING marker and appends the slot to the
-//                job list; the caller keeps the slot (return -1) and adds the match count once the dense DP phase has
-//                filled the memo.  -2: not memoisable / table or list full, the caller aligns it inline later.
-// DEFER = false: a miss is computed inline.
-template <bool DEFER>
-__device__ inline int gapMatchesCached(const ReadCtx &c, int readPos, int64_t gpos, int lp, int lt, int strandBit, const GapSink &sink, unsigned int *dpCounter,
-                                       uint32_t *slotOut) {
-  if (lp <= 0 || lt <= 0) return 0;
-  const int d = lt - lp;
-  // content hash of the allele window (and, for equal lengths, the mismatch count) in one sweep
-  int x = 0;
-  uint64_t hsh = 0x9E3779B97F4A7C15ull ^ ((uint64_t)readPos << 20) ^ ((uint64_t)lp << 1) ^ ((uint64_t)(d + 4) << 40) ^ (uint64_t)strandBit;
-  for (int o = 0; o < lt; o += 32) {
-    uint64_t lm = t1k_lowmask(lt - o);
-    uint64_t gw = t1k_get32(c.gb, gpos + o) & lm, gnw = t1k_get32(c.gn, gpos + o) & lm;
-    if (d == 0) {
-      uint64_t xo = t1k_get32(c.rb, readPos + o) ^ gw;
-      uint64_t mm = (xo | (xo >> 1)) & T1K_EVEN & ~(t1k_get32(c.rn, readPos + o) | gnw) & lm;
-      x += __popcll(mm);
-    }
-    hsh = (hsh ^ gw ^ (gnw << 1)) * 0xD6E8FEB86659FD93ull;
-    hsh ^= hsh >> 32;
-  }
-  if (d == 0 && x <= 3) return lp - x;  // exact fast path (see t1k_ga_matches_window)
-  if (lp > 510 || lt > 510 || readPos > 2047 || gpos >= (1ll << 30)) {
-    if (DEFER) return -2;  // not memoisable
-    if (dpCounter) ++*dpCounter;
-    return gapAlign(c, readPos, gpos, lp, lt);
-  }
-  const uint64_t idBits = ((uint64_t)readPos << 14) | ((uint64_t)lp << 5) | ((uint64_t)(d + 4) << 1) | (uint64_t)strandBit;  // low 25 bits of an entry
-  unsigned long long *cache = sink.cache;
-  const uint32_t slot = (uint32_t)hsh & (GAP_CACHE - 1);
-  bool pendingSeen = false;
-#pragma unroll
-  for (int probe = 0; probe < GAP_PROBES; ++probe) {
-    unsigned long long e = __hip_atomic_load(&cache[slot ^ probe], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (e != 0 && (e & GAP_ID_MASK) == idBits) {
-      int64_t eg = GAP_GPOS(e);
-      if (eg == gpos || sameWindow(c.gb, c.gn, eg, gpos, lt)) {
-        const uint32_t v = GAP_VAL(e);
-        if (v != GAP_PENDING) return (int)v;
-        pendingSeen = true;
-        *slotOut = slot ^ probe;
-      }
-    }
-  }
-  if (DEFER) {
-    if (pendingSeen) return -1;
-    const unsigned long long pe = ((unsigned long long)gpos << 34) | (GAP_PENDING << 25) | idBits;
-#pragma unroll
-    for (int probe = 0; probe < GAP_PROBES; ++probe) {
-      unsigned long long old = atomicCAS(&cache[slot ^ probe], 0ull, pe);
-      if (old == 0ull) {
-        const uint32_t q = t1k_arena_append(sink.counters, sink.arena, sink.jobSegCap);
-        if (q == T1K_ARENA_FULL) {  // job list full: release the claim
-          __hip_atomic_store(&cache[slot ^ probe], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          return -2;
-        }
-        sink.jobStr[q] = sink.jobTag + (slot ^ probe);
-        *slotOut = slot ^ probe;
-        return -1;
-      }
-      if ((old & GAP_ID_MASK) == idBits && (GAP_GPOS(old) == gpos || sameWindow(c.gb, c.gn, GAP_GPOS(old), gpos, lt))) {
-        *slotOut = slot ^ probe;
-        return -1;  // somebody else just claimed it
-      }
-    }
-    return -2;  // all probe slots taken by other jobs
-  }
-  if (dpCounter) ++*dpCounter;
-  const int m = gapAlign(c, readPos, gpos, lp, lt);
-  if (!pendingSeen) {
-    unsigned long long ne = ((unsigned long long)gpos << 34) | ((unsigned long long)m << 25) | idBits;
-    unsigned long long cur = __hip_atomic_load(&cache[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (cur == 0) __hip_atomic_store(&cache[slot], ne, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  return m;
 }
 
 // Single-diagonal group (the common case: the read differs from the allele by substitutions only).
@@ -1320,7 +1197,8 @@ int t1k_chain_used_u32(int S) { return 2 * (S * 32) * 3; }
 static int readCounters(t1k_ctx *ctx, unsigned long long *h) { return t1k_fetch_counters(ctx, h); }
 
 // striped list -> dense list; grid (blocks, T1K_NSTRIPE)
-__global__ __launch_bounds__(WG) void k_arena_compact(const uint32_t *src, uint32_t segCap, const unsigned long long *cursors, uint32_t *dst) {
+template <class V>
+__global__ __launch_bounds__(WG) void k_arena_compact(const V *src, uint32_t segCap, const unsigned long long *cursors, V *dst) {
   const uint32_t seg = blockIdx.y;
   uint32_t prefix = 0;
   for (uint32_t s = 0; s < seg; ++s) prefix += (uint32_t)min(cursors[s * 8], (unsigned long long)segCap);
@@ -1342,7 +1220,16 @@ T1kArenaCounts t1k_arena_counts(const t1k_ctx *ctx, int arena, uint32_t segCap) 
 void t1k_arena_compact(t1k_ctx *ctx, int arena, const uint32_t *src, uint32_t segCap, uint32_t *dst, uint32_t maxSeg) {
   if (!maxSeg) return;
   const unsigned long long *cur = (const unsigned long long *)ctx->bCounters.p + T1K_ARENA_BASE + (size_t)arena * T1K_NSTRIPE * 8;
-  hipLaunchKernelGGL(k_arena_compact, dim3(std::min<uint32_t>((maxSeg + WG - 1) / WG, 256u), T1K_NSTRIPE), dim3(WG), 0, ctx->stream, src, segCap, cur, dst);
+  hipLaunchKernelGGL(k_arena_compact<uint32_t>, dim3(std::min<uint32_t>((maxSeg + WG - 1) / WG, 256u), T1K_NSTRIPE), dim3(WG), 0, ctx->stream, src, segCap, cur, dst);
+}
+void t1k_arena_compact64(t1k_ctx *ctx, int arena, const unsigned long long *src, uint32_t segCap, unsigned long long *dst, uint32_t maxSeg) {
+  if (!maxSeg) return;
+  const unsigned long long *cur = (const unsigned long long *)ctx->bCounters.p + T1K_ARENA_BASE + (size_t)arena * T1K_NSTRIPE * 8;
+  hipLaunchKernelGGL(k_arena_compact<unsigned long long>, dim3(std::min<uint32_t>((maxSeg + WG - 1) / WG, 256u), T1K_NSTRIPE), dim3(WG), 0, ctx->stream, src, segCap, cur, dst);
+}
+
+void t1k_launch_dp_dense(t1k_ctx *ctx, const ChainArgs &a, const uint32_t *jobs, uint32_t n) {
+  if (n) hipLaunchKernelGGL(k_dp_dense, dim3((n + WG - 1) / WG), dim3(WG), 0, ctx->stream, a, jobs, n);
 }
 
 // runs K1..K6; on return counters[0] = number of candidates, counters[2] = error flags

@@ -115,6 +115,16 @@ __device__ __forceinline__ int t1k_hamming(const uint64_t *rb, const uint64_t *r
   return x;
 }
 
+// do two L-position windows of the reference hold the same bases and N marks?
+__device__ inline bool t1k_same_window(const uint64_t *gb, const uint64_t *gn, int64_t a, int64_t b, int L) {
+  if (a == b) return true;
+  for (int o = 0; o < L; o += 32) {
+    uint64_t lm = t1k_lowmask(L - o);
+    if (((t1k_get32(gb, a + o) ^ t1k_get32(gb, b + o)) & lm) | ((t1k_get32(gn, a + o) ^ t1k_get32(gn, b + o)) & lm)) return false;
+  }
+  return true;
+}
+
 // accessor for one sequence operand of the alignment routines
 struct T1kSeqView {
   const uint64_t *b, *n;
@@ -480,7 +490,7 @@ enum { T1K_STAT_DP = 0, T1K_STAT_FAST = 1, T1K_STAT_GENERAL = 2, T1K_STAT_EXTEND
 // their own cursor (64 bytes apart); a workgroup allocates from segment blockIdx.x % T1K_NSTRIPE.  Lists are made dense
 // again by k_arena_compact before their consumer runs; group records are consumed segment by segment.
 #define T1K_NSTRIPE 32
-enum { T1K_AR_GROUPS = 0, T1K_AR_JOBS, T1K_AR_RETRY, T1K_AR_FINISH, T1K_AR_GENERAL, T1K_AR_BIG, T1K_AR_GENCAND, T1K_AR_EQ, T1K_AR_BAND, T1K_AR_WIDE, T1K_AR_GENHITS, T1K_AR_GENJOBS, T1K_AR_WAVE, T1K_NARENA };
+enum { T1K_AR_GROUPS = 0, T1K_AR_JOBS, T1K_AR_RETRY, T1K_AR_FINISH, T1K_AR_GENERAL, T1K_AR_BIG, T1K_AR_GENCAND, T1K_AR_EQ, T1K_AR_BAND, T1K_AR_WIDE, T1K_AR_GENHITS, T1K_AR_GENJOBS, T1K_AR_WAVE, T1K_AR_EXTJOBS, T1K_AR_EXTRETRY, T1K_NARENA };
 #define T1K_ARENA_BASE (64 + T1K_STAT_STRIPES * 8)
 #define T1K_COUNTER_WORDS (T1K_ARENA_BASE + T1K_NARENA * T1K_NSTRIPE * 8)
 #define T1K_ARENA_FULL 0xFFFFFFFFu
@@ -567,7 +577,7 @@ struct t1k_ctx {
   uint32_t rangeCount = 0;       // read-ends of the last t1k_assign_range
   // assignment arenas
   T1kDevBuf bWgHits, bWgGroups, bWgStage, bWgThreadScratch, bWgBig, bWgCache, bLists;
-  T1kDevBuf bCand, bExt, bCandStart, bCandCount, bOvl, bOvlStart, bOvlCount, bCounters, bSlowQueue, bSlowScratch, bSortScratch, bEqTrace;
+  T1kDevBuf bCand, bExt, bCandStart, bCandCount, bOvl, bOvlStart, bOvlCount, bCounters, bSlowQueue, bSlowScratch, bSortScratch, bEqTrace, bSortTmp, bSlowKeys;
   uint64_t nCand = 0, nOvl = 0;
   // pairing
   T1kDevBuf bEnd1, bEnd2, bHasN, bRows, bRowStart, bRowCount, bFragAssigned, bPairScratch;

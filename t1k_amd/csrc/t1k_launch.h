@@ -33,6 +33,9 @@ struct ExtendArgs {
   T1kExt *ext;
   uint64_t nCand;
   unsigned long long *counters;
+  unsigned long long *memo;                 // per-read-end alignment memo (t1k_memo.h)
+  uint32_t *jobStr; uint32_t jobSegCap;     // striped list of registered alignments
+  uint32_t *retryStr; uint32_t retrySegCap; // striped list of candidates waiting for them
 };
 
 struct SelectArgs {
@@ -54,6 +57,7 @@ struct FullArgs {
   T1kOvl *ovl;
   uint64_t nOvl;
   uint32_t *eqStr, *bandStr, *wideStr; uint32_t segCap;  // striped alignment queues
+  unsigned long long *eqKeyStr, *bandKeyStr;              // their sort keys (see k_fullalign)
   unsigned long long *counters;
 };
 
@@ -62,8 +66,9 @@ struct SlowArgs {
   T1kReadsDev reads;
   int relax;
   T1kOvl *ovl;
-  const uint32_t *slowQueue;
+  const uint32_t *slowQueue;  // (sorted) queue of overlap indices
   uint32_t nSlow;
+  const uint32_t *runOf, *rep; uint32_t nRuns; uint64_t traceStride;  // runs of identical jobs: 1-based run of each job, first job of each run
   uint8_t *scratch; uint64_t perThread;  // per thread: int rows[GA_SCRATCH_INTS] | int8 ops[] | trace bytes
   int maxCells;
   unsigned long long *counters;
@@ -90,11 +95,17 @@ void t1k_launch_extend(t1k_ctx *ctx, const ExtendArgs &a);
 void t1k_launch_select(t1k_ctx *ctx, const SelectArgs &a, int nWg);
 void t1k_launch_fullalign(t1k_ctx *ctx, const FullArgs &a);
 void t1k_launch_fullalign_slow(t1k_ctx *ctx, const SlowArgs &a, int nBlocks);
-void t1k_launch_fullalign_eq(t1k_ctx *ctx, const SlowArgs &a, int nBlocks);
-void t1k_launch_fullalign_band(t1k_ctx *ctx, const SlowArgs &a, int nBlocks);
+void t1k_launch_align_flags(t1k_ctx *ctx, const SlowArgs &a, uint32_t *flags);
+void t1k_launch_align_reps(t1k_ctx *ctx, const uint32_t *flags, const uint32_t *runOf, uint32_t *rep, uint32_t n);
+void t1k_launch_align_fill_apply(t1k_ctx *ctx, const SlowArgs &a, bool eq);
+int t1k_inclusive_sum(t1k_ctx *ctx, const uint32_t *in, uint32_t *out, uint32_t n);
 void t1k_launch_truncate(t1k_ctx *ctx, const TruncArgs &a, int nWg);
 void t1k_launch_coverage_scan(t1k_ctx *ctx, const T1kRefDev &ref, int32_t *out, const uint64_t *outOff);
 int t1k_fetch_counters(t1k_ctx *ctx, unsigned long long *h);
 struct T1kArenaCounts { uint64_t total; uint32_t maxSeg; bool overflow; };
 T1kArenaCounts t1k_arena_counts(const t1k_ctx *ctx, int arena, uint32_t segCap);  // from the last t1k_fetch_counters
+void t1k_launch_extend_retry(t1k_ctx *ctx, const ExtendArgs &a, const uint32_t *list, uint32_t n);
+void t1k_launch_dp_dense(t1k_ctx *ctx, const ChainArgs &a, const uint32_t *jobs, uint32_t n);
+void t1k_arena_compact64(t1k_ctx *ctx, int arena, const unsigned long long *src, uint32_t segCap, unsigned long long *dst, uint32_t maxSeg);
+int t1k_sort_pairs(t1k_ctx *ctx, const unsigned long long *keysIn, unsigned long long *keysOut, const uint32_t *valsIn, uint32_t *valsOut, uint32_t n);
 void t1k_arena_compact(t1k_ctx *ctx, int arena, const uint32_t *src, uint32_t segCap, uint32_t *dst, uint32_t maxSeg);
