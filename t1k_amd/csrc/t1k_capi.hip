@@ -368,7 +368,7 @@ int t1k_assign_range(t1k_ctx *ctx, uint64_t first, uint32_t count) {
   const uint32_t groupSegCap = (uint32_t)std::min<uint64_t>(groupCap / T1K_NSTRIPE, 0xFFFFFFFFull / T1K_NSTRIPE);
   const uint32_t listSegCap = std::max<uint32_t>(groupSegCap / 2, 1024u), jobSegCap = jobCap / T1K_NSTRIPE, genCandSegCap = genCandCap / T1K_NSTRIPE;
   const size_t listWords = (size_t)listSegCap * T1K_NSTRIPE;
-  if ((rc = t1k_ensure(ctx, ctx->bLists, ((size_t)jobCap * 2 + listWords * 10 + (size_t)genCandCap * 6 + genHitCap + (size_t)genJobCap * 2) * 4 + 64))) return rc;
+  if ((rc = t1k_ensure(ctx, ctx->bLists, ((size_t)jobCap * 2 + listWords * 12 + (size_t)genCandCap * 6 + genHitCap + (size_t)genJobCap * 2) * 4 + 64))) return rc;
   if ((rc = t1k_ensure(ctx, ctx->bCand, (size_t)ctx->prm.cand_cap * sizeof(T1kCand)))) return rc;
   if ((rc = t1k_ensure(ctx, ctx->bExt, (size_t)ctx->prm.cand_cap * sizeof(T1kExt)))) return rc;
   if ((rc = t1k_ensure(ctx, ctx->bOvl, (size_t)ctx->prm.ovl_cap * sizeof(T1kOvl)))) return rc;
@@ -400,7 +400,8 @@ int t1k_assign_range(t1k_ctx *ctx, uint64_t first, uint32_t count) {
   a.retryList = a.jobStr + jobCap; a.generalList = a.retryList + listWords; a.bigList = a.generalList + listWords; a.finishList = a.bigList + listWords;
   a.retryStr = a.finishList + listWords; a.generalStr = a.retryStr + listWords; a.bigStr = a.generalStr + listWords; a.finishStr = a.bigStr + listWords;
   a.waveStr = a.finishStr + listWords; a.waveList = a.waveStr + listWords;
-  a.genCand = a.waveList + listWords; a.genCandCap = genCandCap;
+  a.slowStr = a.waveList + listWords; a.slowList = a.slowStr + listWords;
+  a.genCand = a.slowList + listWords; a.genCandCap = genCandCap;
   a.genHits = a.genCand + (size_t)genCandCap * 6; a.genHitSegCap = genHitCap / T1K_NSTRIPE;
   a.genJobStr = a.genHits + genHitCap; a.genJobList = a.genJobStr + genJobCap; a.genJobSegCap = genJobCap / T1K_NSTRIPE;
   a.groupSegCap = groupSegCap; a.jobSegCap = jobSegCap; a.listSegCap = listSegCap; a.genCandSegCap = genCandSegCap;

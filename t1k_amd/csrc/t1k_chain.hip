@@ -90,10 +90,10 @@ __device__ __forceinline__ void shlOr(uint64_t *C, int sft) {
   }
 }
 
-// return value: 1 = finished (out holds 0 or 1 candidate), 2 = run again after the dense DP phase, 3 = candidate pushed with a
+// return value: 5 = needs the gap walk (CLOSED only), 1 = finished (out holds 0 or 1 candidate), 2 = run again after the dense DP phase, 3 = candidate pushed with a
 // partial matchCnt, refs[] name the memo slots whose match counts are still to be added (DEFER only)
 #define GROUP_MAX_REFS 6
-template <int NW, bool DEFER>
+template <int NW, bool DEFER, bool CLOSED>
 __device__ inline int groupFastPath(const uint32_t *Mw, int diag, const ReadCtx &c, bool hasN, int k, int hitLenRequired, double simThreshold, CandOut &out,
                                     unsigned int *dpCounter, int strandBit, const GapSink &sink, uint32_t *refs, int *nRefs) {
   constexpr int MW = (NW + 1) / 2;  // 64-bit words of the read-offset bitmask
@@ -173,6 +173,7 @@ __device__ inline int groupFastPath(const uint32_t *Mw, int diag, const ReadCtx 
   int matchCnt;
   int result = 1;
   if (mmT <= 3) matchCnt = 2 * (span - mmT);
+  else if (CLOSED) return 5;  // first pass: only the closed form; the gap walk runs on the compacted list of the others
   else {
     // walk the gaps (maximal uncovered runs inside the span)
     int sumSmall = 0, nBig = 0;
@@ -555,13 +556,20 @@ __global__ __launch_bounds__(WG) void k_seed_groups(ChainArgs P) {
       if (has1) { const int q = usedQ[uBegin + tid + WG]; st1 = ukStart[q]; ln1 = ukLen[q]; }
       for (uint32_t u = tid; u < uCount; u += WG) qOf[u] = (uint16_t)(usedQ[uBegin + u] - pass * nk);
       for (uint32_t u = tid; u < uCount; u += WG) lstStart[u] = ukStart[usedQ[uBegin + u]];
+      // allele of the posting under each cursor (0xFFFFFFFF: list exhausted); kept up to date by the slice search below
+      uint32_t nx0 = (has0 && ln0) ? P.ref.kPost[st0].allele : 0xFFFFFFFFu, nx1 = (has1 && ln1) ? P.ref.kPost[st1].allele : 0xFFFFFFFFu;
+      // first posting with allele >= c1 at or after cur
+      auto sliceEnd = [&](uint32_t st, uint32_t cur, uint32_t ln, uint32_t c1, uint32_t &nxt) -> uint32_t {
+        uint32_t lo = cur + 1, hi = ln;  // the posting under the cursor is known to be < c1
+        while (lo < hi) { uint32_t m = (lo + hi) >> 1; if (P.ref.kPost[st + m].allele < c1) lo = m + 1; else hi = m; }
+        nxt = lo < ln ? P.ref.kPost[st + lo].allele : 0xFFFFFFFFu;
+        return lo;
+      };
       for (;;) {
         // next chunk = the CHUNK_A alleles from the smallest allele any list still holds (empty stretches are skipped)
         if (tid == 0) sMin = 0xFFFFFFFFu;
         __syncthreads();
-        uint32_t nxt = 0xFFFFFFFFu;
-        if (has0 && cur0 < ln0) nxt = P.ref.kPost[st0 + cur0].allele;
-        if (has1 && cur1 < ln1) nxt = min(nxt, P.ref.kPost[st1 + cur1].allele);
+        uint32_t nxt = min(nx0, nx1);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) nxt = min(nxt, (uint32_t)__shfl_xor((int)nxt, o, 64));
         if ((tid & 63) == 0 && nxt != 0xFFFFFFFFu) atomicMin(&sMin, nxt);
@@ -569,16 +577,16 @@ __global__ __launch_bounds__(WG) void k_seed_groups(ChainArgs P) {
         const uint32_t c0 = sMin;
         if (c0 == 0xFFFFFFFFu) break;
         const uint32_t c1 = min(c0 + CHUNK_A, A);
-        // slice of every used list inside [c0, c1): lower bound of c1 from the cursor
+        // slice of every used list inside [c0, c1)
         uint32_t n0 = 0, n1 = 0;
         if (has0) {
-          uint32_t l = cur0, r = ln0;
-          while (l < r) { uint32_t m = (l + r) >> 1; if (P.ref.kPost[st0 + m].allele < c1) l = m + 1; else r = m; }
+          uint32_t l = cur0;
+          if (nx0 < c1) l = sliceEnd(st0, cur0, ln0, c1, nx0);
           n0 = l - cur0; sLo[tid] = cur0; cur0 = l;
         }
         if (has1) {
-          uint32_t l = cur1, r = ln1;
-          while (l < r) { uint32_t m = (l + r) >> 1; if (P.ref.kPost[st1 + m].allele < c1) l = m + 1; else r = m; }
+          uint32_t l = cur1;
+          if (nx1 < c1) l = sliceEnd(st1, cur1, ln1, c1, nx1);
           n1 = l - cur1; sLo[tid + WG] = cur1; cur1 = l;
         }
         uint32_t tot0, tot1 = 0;
@@ -701,8 +709,12 @@ __device__ __forceinline__ ReadCtx makeCtx(const ChainArgs &P, uint32_t re, int 
   return c;
 }
 
-template <int NW, bool DEFER>
+// MODE 0: all records, closed form only (the rest -> slow list; multi-diagonal groups -> general list)
+// MODE 1: slow list: gap walk, alignments registered in the memo (-> finish list / retry list)
+// MODE 2: retry list after k_dp_dense: alignments from the memo or inline
+template <int NW, int MODE>
 __global__ __launch_bounds__(WG) void k_chain_fast(ChainArgs P, const uint32_t *list, uint32_t nItems) {
+  constexpr bool DEFER = MODE != 2;
   unsigned int dpLocal = 0, fastLocal = 0;
   int kind = 0;
   uint32_t gi = 0;
@@ -739,7 +751,7 @@ __global__ __launch_bounds__(WG) void k_chain_fast(ChainArgs P, const uint32_t *
       const GapSink sink{P.memo + (uint64_t)re * GAP_CACHE, P.jobStr, P.counters, re * GAP_CACHE, P.jobSegCap, T1K_AR_JOBS};
       uint32_t refs[3] = {0, 0, 0};
       int nRefs = 0;
-      kind = groupFastPath<NW, DEFER>(Mw, (int)rv[2], c, P.ref.alleleHasN[allele] != 0, P.k, P.hitLenRequired, P.sim, out, &dpLocal, pass, sink, refs, &nRefs);
+      kind = groupFastPath<NW, DEFER, MODE == 0>(Mw, (int)rv[2], c, P.ref.alleleHasN[allele] != 0, P.k, P.hitLenRequired, P.sim, out, &dpLocal, pass, sink, refs, &nRefs);
       if (kind == 3) {  // matchCnt lacks the registered alignments: k_chain_finish adds them from the memo
         ((uint4 *)rec)[1] = make_uint4(cbuf[0], cbuf[1], cbuf[2], refs[0]);
         ((uint2 *)rec)[4] = make_uint2(refs[1], refs[2]);
@@ -751,17 +763,11 @@ __global__ __launch_bounds__(WG) void k_chain_fast(ChainArgs P, const uint32_t *
       }
     }
   }
-  // list appends: one atomic per wavefront, list and arena segment
-  if (kind >= 2) {
-    const int arena = kind == 2 ? T1K_AR_RETRY : kind == 3 ? T1K_AR_FINISH : T1K_AR_GENERAL;
-    uint32_t *dst = kind == 2 ? P.retryStr : kind == 3 ? P.finishStr : P.generalStr;
-    uint32_t q;
-    if (kind == 2) q = t1k_arena_append(P.counters, T1K_AR_RETRY, P.listSegCap);
-    else if (kind == 3) q = t1k_arena_append(P.counters, T1K_AR_FINISH, P.listSegCap);
-    else q = t1k_arena_append(P.counters, T1K_AR_GENERAL, P.listSegCap);
-    (void)arena;
-    if (q != T1K_ARENA_FULL) dst[q] = gi;  // a full segment shows in its cursor; the host fails the batch
-  }
+  // list appends: one atomic per wavefront, list and arena segment (a full segment shows in its cursor; the host fails the batch)
+  if (kind == 2) { const uint32_t q = t1k_arena_append(P.counters, T1K_AR_RETRY, P.listSegCap); if (q != T1K_ARENA_FULL) P.retryStr[q] = gi; }
+  if (kind == 3) { const uint32_t q = t1k_arena_append(P.counters, T1K_AR_FINISH, P.listSegCap); if (q != T1K_ARENA_FULL) P.finishStr[q] = gi; }
+  if (kind == 4) { const uint32_t q = t1k_arena_append(P.counters, T1K_AR_GENERAL, P.listSegCap); if (q != T1K_ARENA_FULL) P.generalStr[q] = gi; }
+  if (kind == 5) { const uint32_t q = t1k_arena_append(P.counters, T1K_AR_SLOW, P.listSegCap); if (q != T1K_ARENA_FULL) P.slowStr[q] = gi; }
   t1k_stat_add(P.counters, T1K_STAT_DP, dpLocal);
   t1k_stat_add(P.counters, T1K_STAT_FAST, fastLocal);
 }
@@ -1255,8 +1261,17 @@ int t1k_run_chain(t1k_ctx *ctx, const ChainArgs &a, int nWg, int bigBlocks, bool
   hc[6] = groups.total;
   if (groups.maxSeg) {
     const dim3 grid((groups.maxSeg + WG - 1) / WG, T1K_NSTRIPE);
-    if (longReads) hipLaunchKernelGGL((k_chain_fast<10, true>), grid, dim3(WG), 0, ctx->stream, a, (const uint32_t *)nullptr, 0u);
-    else hipLaunchKernelGGL((k_chain_fast<5, true>), grid, dim3(WG), 0, ctx->stream, a, (const uint32_t *)nullptr, 0u);
+    if (longReads) hipLaunchKernelGGL((k_chain_fast<10, 0>), grid, dim3(WG), 0, ctx->stream, a, (const uint32_t *)nullptr, 0u);
+    else hipLaunchKernelGGL((k_chain_fast<5, 0>), grid, dim3(WG), 0, ctx->stream, a, (const uint32_t *)nullptr, 0u);
+  }
+  if ((rc = readCounters(ctx, hc))) return rc;
+  const T1kArenaCounts slow = t1k_arena_counts(ctx, T1K_AR_SLOW, a.listSegCap);
+  if (slow.overflow) { hc[2] |= ERR_GROUPCAP; return 0; }
+  if (slow.total) {
+    t1k_arena_compact(ctx, T1K_AR_SLOW, a.slowStr, a.listSegCap, a.slowList, slow.maxSeg);
+    const uint32_t nSlowGroups = (uint32_t)slow.total;
+    if (longReads) hipLaunchKernelGGL((k_chain_fast<10, 1>), dim3((nSlowGroups + WG - 1) / WG), dim3(WG), 0, ctx->stream, a, (const uint32_t *)a.slowList, nSlowGroups);
+    else hipLaunchKernelGGL((k_chain_fast<5, 1>), dim3((nSlowGroups + WG - 1) / WG), dim3(WG), 0, ctx->stream, a, (const uint32_t *)a.slowList, nSlowGroups);
   }
   if ((rc = readCounters(ctx, hc))) return rc;
   hc[6] = groups.total;
@@ -1273,8 +1288,8 @@ int t1k_run_chain(t1k_ctx *ctx, const ChainArgs &a, int nWg, int bigBlocks, bool
   if (nJobs) hipLaunchKernelGGL(k_dp_dense, dim3((nJobs + WG - 1) / WG), dim3(WG), 0, ctx->stream, a, (const uint32_t *)a.jobList, nJobs);
   if (nFinish) hipLaunchKernelGGL(k_chain_finish, dim3((nFinish + WG - 1) / WG), dim3(WG), 0, ctx->stream, a, nFinish);
   if (nRetry) {
-    if (longReads) hipLaunchKernelGGL((k_chain_fast<10, false>), dim3((nRetry + WG - 1) / WG), dim3(WG), 0, ctx->stream, a, (const uint32_t *)a.retryList, nRetry);
-    else hipLaunchKernelGGL((k_chain_fast<5, false>), dim3((nRetry + WG - 1) / WG), dim3(WG), 0, ctx->stream, a, (const uint32_t *)a.retryList, nRetry);
+    if (longReads) hipLaunchKernelGGL((k_chain_fast<10, 2>), dim3((nRetry + WG - 1) / WG), dim3(WG), 0, ctx->stream, a, (const uint32_t *)a.retryList, nRetry);
+    else hipLaunchKernelGGL((k_chain_fast<5, 2>), dim3((nRetry + WG - 1) / WG), dim3(WG), 0, ctx->stream, a, (const uint32_t *)a.retryList, nRetry);
   }
   uint32_t nBig = 0;
   if (nGen) {
