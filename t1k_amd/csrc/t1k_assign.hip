@@ -181,8 +181,9 @@ __global__ __launch_bounds__(WG) void k_extend_retry(ExtendArgs P, const uint32_
 // selection: sort + latch, one workgroup per read-end
 // ------------------------------------------------------------------------------------------------------------------
 
-// bitonic sort of n (key, idx) pairs, n padded to a power of two by the caller with key = ~0
-__device__ inline void bitonicSort(uint64_t *key, uint32_t *idx, uint32_t np2) {
+// bitonic sort of n packed 64-bit entries (sort key in the high bits, payload index in the low bits), n padded to a power of
+// two by the caller with ~0
+__device__ inline void bitonicSort(uint64_t *key, uint32_t np2) {
   for (uint32_t size = 2; size <= np2; size <<= 1) {
     for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
       for (uint32_t t = threadIdx.x; t < np2 / 2; t += blockDim.x) {
@@ -191,11 +192,18 @@ __device__ inline void bitonicSort(uint64_t *key, uint32_t *idx, uint32_t np2) {
         bool up = (lo & size) == 0;
         uint64_t a = key[lo], b = key[hi];
         bool sw = up ? (a > b) : (a < b);
-        if (sw) { key[lo] = b; key[hi] = a; uint32_t x = idx[lo]; idx[lo] = idx[hi]; idx[hi] = x; }
+        if (sw) { key[lo] = b; key[hi] = a; }
       }
       __syncthreads();
     }
   }
+}
+// entry layout: [0 | 2047 - matchCnt : 11 | span sum : 11 | 511 - read span : 9 | allele : aBits | index : iBits], bit 63 is the
+// emit mark of k_select.  Returns false if a field does not fit.
+__device__ __forceinline__ bool packSortKey(int m, int d, int rspan, uint32_t allele, uint32_t index, int aBits, int iBits, uint64_t *out) {
+  if (m < 0 || m > 2047 || d < 0 || d > 2047 || rspan < 0 || rspan > 511 || 32 + aBits + iBits > 64) return false;
+  *out = (((((uint64_t)(2047 - m) << 11 | (uint64_t)d) << 9 | (uint64_t)(511 - rspan)) << aBits | (uint64_t)allele) << iBits) | (uint64_t)index;
+  return true;
 }
 
 // full comparator on the seed coordinates for the (rare) ties of the 64-bit key
@@ -208,8 +216,8 @@ __device__ inline bool candBeforeFull(const T1kCand &a, const T1kCand &b) {
 }
 
 // The per-read-end sorts run in LDS.  Two instantiations share the read-ends by size so that the common small lists do not
-// pay the occupancy of the rare large ones: CAP 2048 (24 KB of LDS, six workgroups per CU) takes lists of up to 2048
-// entries, CAP 8192 (96 KB, one workgroup per CU) the rest; beyond 8192 the sort falls back to per-workgroup HBM scratch.
+// pay the occupancy of the rare large ones: CAP 2048 (16 KB of LDS) takes lists of up to 2048 entries, CAP 8192 (64 KB,
+// 1024 threads) the rest; beyond 8192 the sort falls back to per-workgroup HBM scratch.
 #define SELECT_SMALL 2048
 #define SELECT_LARGE 8192
 
@@ -217,7 +225,6 @@ template <int SELECT_LDS_CAP, int NT>
 __global__ __launch_bounds__(NT) void k_select(SelectArgs P) {
   extern __shared__ uint64_t dynLds[];
   uint64_t *sKey = dynLds;
-  uint32_t *sIdx = (uint32_t *)(dynLds + SELECT_LDS_CAP);
   __shared__ uint32_t warpSums[NT / 64];
   __shared__ int sLatch, sGood, sBest, sTie;
   __shared__ uint32_t sBase;
@@ -247,14 +254,17 @@ __global__ __launch_bounds__(NT) void k_select(SelectArgs P) {
     }
     uint32_t np2 = 1;
     while (np2 < live) np2 <<= 1;
-    uint64_t *key; uint32_t *idx;
-    if (np2 <= SELECT_LDS_CAP) { key = sKey; idx = sIdx; }
-    else if (np2 <= P.sortCap) { key = P.sortScratch + (uint64_t)blockIdx.x * P.sortCap * 2; idx = (uint32_t *)(key + P.sortCap); }
+    uint64_t *key;
+    if (np2 <= SELECT_LDS_CAP) key = sKey;
+    else if (np2 <= P.sortCap) key = P.sortScratch + (uint64_t)blockIdx.x * P.sortCap * 6;
     else {
       if (tid == 0) { atomicOr(&P.counters[2], (unsigned long long)ERR_SORTCAP); P.ovlStart[re] = 0; P.ovlCount[re] = 0; }
       continue;
     }
-    // key: matchCnt desc, similarity desc (== readSpan+seqSpan asc at equal matchCnt), readSpan desc, allele asc
+    // key: matchCnt desc, similarity desc (== readSpan+seqSpan asc at equal matchCnt), readSpan desc, allele asc; payload: candidate
+    int iBits = 1;
+    while ((1u << iBits) < n) ++iBits;
+    const uint64_t iMask = (1ull << iBits) - 1;
     if (tid == 0) sLive = 0;
     for (uint32_t i = tid; i < np2; i += NT) key[i] = ~0ull;
     __syncthreads();
@@ -266,12 +276,12 @@ __global__ __launch_bounds__(NT) void k_select(SelectArgs P) {
       int m = (int)(c.match >> 16);
       int rspan = rend - rs, d = rspan + 1 + c.seqEnd - c.seqStart + 1;
       uint32_t slot = atomicAdd(&sLive, 1u);  // any order: the sort follows
-      key[slot] = ((uint64_t)(4095 - m) << 50) | ((uint64_t)(d & 0x1FFF) << 37) | ((uint64_t)(4095 - rspan) << 24) | (uint64_t)(c.allele & 0xFFFFFF);
-      idx[slot] = i;
+      uint64_t kk;
+      if (!packSortKey(m, d, rspan, c.allele & 0x7FFFFFFFu, i, P.alleleBits, iBits, &kk)) { atomicOr(&P.counters[2], (unsigned long long)ERR_SORTCAP); kk = i; }
+      key[slot] = kk;
     }
-    for (uint32_t i = live + tid; i < np2; i += NT) idx[i] = 0;
     __syncthreads();
-    bitonicSort(key, idx, np2);
+    bitonicSort(key, np2);
     // resolve ties of the packed key with the remaining comparator fields (same allele, same spans)
     const uint32_t nAll = n;
     (void)nAll;
@@ -279,14 +289,14 @@ __global__ __launch_bounds__(NT) void k_select(SelectArgs P) {
     if (tid == 0) { sTie = 0; sLatch = 0x7FFFFFFF; sGood = -1; sBest = -1; }
     __syncthreads();
     for (uint32_t i = 1 + tid; i < live; i += NT)
-      if (key[i] == key[i - 1]) sTie = 1;
+      if ((key[i] >> iBits) == (key[i - 1] >> iBits)) sTie = 1;
     __syncthreads();
     if (sTie && tid == 0) {
       for (uint32_t i = 1; i < live; ++i) {
-        if (key[i] != key[i - 1]) continue;
+        if ((key[i] >> iBits) != (key[i - 1] >> iBits)) continue;
         uint32_t j = i;
-        while (j > 0 && key[j - 1] == key[j] && candBeforeFull(P.cand[c0 + idx[j]], P.cand[c0 + idx[j - 1]])) {
-          uint32_t t = idx[j]; idx[j] = idx[j - 1]; idx[j - 1] = t;
+        while (j > 0 && (key[j - 1] >> iBits) == (key[j] >> iBits) && candBeforeFull(P.cand[c0 + (key[j] & iMask)], P.cand[c0 + (key[j - 1] & iMask)])) {
+          uint64_t t = key[j]; key[j] = key[j - 1]; key[j - 1] = t;
           --j;
         }
       }
@@ -296,7 +306,7 @@ __global__ __launch_bounds__(NT) void k_select(SelectArgs P) {
     int myLatch = 0x7FFFFFFF;
     for (uint32_t i = tid; i < live; i += NT) {
       if (key[i] == ~0ull) continue;
-      uint16_t fl = P.ext[c0 + idx[i]].flags;
+      uint16_t fl = P.ext[c0 + (uint32_t)(key[i] & iMask)].flags;
       if (fl & T1K_F_SEPSEED) continue;
       if (!(fl & T1K_F_EXTOK)) { if ((int)i < myLatch) myLatch = (int)i; }
     }
@@ -307,7 +317,7 @@ __global__ __launch_bounds__(NT) void k_select(SelectArgs P) {
     int myGood = 0x7FFFFFFF;
     for (uint32_t i = tid; i < live && (int)i < latch; i += NT) {
       if (key[i] == ~0ull) continue;
-      uint16_t fl = P.ext[c0 + idx[i]].flags;
+      uint16_t fl = P.ext[c0 + (uint32_t)(key[i] & iMask)].flags;
       if ((fl & T1K_F_SEPSEED) || !(fl & T1K_F_EXTOK)) continue;
       if ((int)i < myGood) myGood = (int)i;
     }
@@ -316,7 +326,7 @@ __global__ __launch_bounds__(NT) void k_select(SelectArgs P) {
     __syncthreads();
     atomicMin(&sFirst, myGood);
     __syncthreads();
-    if (tid == 0) sGood = sFirst == 0x7FFFFFFF ? -1 : (int)(P.cand[c0 + idx[sFirst]].match >> 16);
+    if (tid == 0) sGood = sFirst == 0x7FFFFFFF ? -1 : (int)(P.cand[c0 + (uint32_t)(key[sFirst] & iMask)].match >> 16);
     __syncthreads();
     const int good = sGood;
     // emit flags + best extended matchCnt
@@ -328,11 +338,11 @@ __global__ __launch_bounds__(NT) void k_select(SelectArgs P) {
     for (uint32_t i = tid; i < live; i += NT) {
       bool emit = false;
       if (key[i] != ~0ull) {
-        const T1kExt x = P.ext[c0 + idx[i]];
+        const T1kExt x = P.ext[c0 + (uint32_t)(key[i] & iMask)];
         if (!(x.flags & T1K_F_SEPSEED)) {
           bool tried = true;
           if ((int)i > latch) {
-            const T1kCand c = P.cand[c0 + idx[i]];
+            const T1kCand c = P.cand[c0 + (uint32_t)(key[i] & iMask)];
             int m = (int)(c.match >> 16);
             int rs = c.readSE & 0xFFFF, rend = c.readSE >> 16;
             double sim = (double)m / (double)(c.seqEnd - c.seqStart + 1 + rend - rs + 1);
@@ -342,7 +352,7 @@ __global__ __launch_bounds__(NT) void k_select(SelectArgs P) {
           if (emit && (int)x.matchCnt > myBest) myBest = x.matchCnt;
         }
       }
-      if (emit) { ++mine; idx[i] |= 0x80000000u; }
+      if (emit) { ++mine; key[i] |= 1ull << 63; }
     }
     atomicMax(&sBest, myBest);
     uint32_t tot;
@@ -357,11 +367,11 @@ __global__ __launch_bounds__(NT) void k_select(SelectArgs P) {
     if (sBase != 0xFFFFFFFFu) {
       for (uint32_t i0 = 0; i0 < live; i0 += NT) {
         uint32_t i = i0 + tid;
-        uint32_t flag = (i < live && (idx[i] & 0x80000000u)) ? 1u : 0u;
+        uint32_t flag = (i < live && (key[i] >> 63)) ? 1u : 0u;
         uint32_t t2;
         uint32_t off = t1k_block_scan_exclusive_n<NT / 64>(flag, warpSums, &t2);
         if (flag) {
-          uint32_t ci = c0 + (idx[i] & 0x7FFFFFFFu);
+          uint32_t ci = c0 + (uint32_t)(key[i] & iMask);
           const T1kCand c = P.cand[ci];
           const T1kExt x = P.ext[ci];
           T1kOvl o;
@@ -677,7 +687,6 @@ template <int SELECT_LDS_CAP, int NT>
 __global__ __launch_bounds__(NT) void k_truncate(TruncArgs P) {
   extern __shared__ uint64_t dynLds[];
   uint64_t *sKey = dynLds;
-  uint32_t *sIdx = (uint32_t *)(dynLds + SELECT_LDS_CAP);
   __shared__ uint32_t sCut, sTie2;
   const int tid = threadIdx.x;
   for (uint32_t re = blockIdx.x; re < P.reads.nReadEnds; re += gridDim.x) {
@@ -686,37 +695,40 @@ __global__ __launch_bounds__(NT) void k_truncate(TruncArgs P) {
     if ((n > SELECT_SMALL) != (SELECT_LDS_CAP == SELECT_LARGE)) continue;  // the other instantiation's read-end
     uint32_t np2 = 1;
     while (np2 < n) np2 <<= 1;
-    uint64_t *key; uint32_t *idx;
-    uint64_t *wgScratch = P.sortScratch + (uint64_t)blockIdx.x * (P.sortCap * 2 + (uint64_t)P.sortCap * 4);
-    if (np2 <= SELECT_LDS_CAP) { key = sKey; idx = sIdx; }
-    else if (np2 <= P.sortCap) { key = wgScratch; idx = (uint32_t *)(key + P.sortCap); }
+    uint64_t *key;
+    uint64_t *wgScratch = P.sortScratch + (uint64_t)blockIdx.x * ((uint64_t)P.sortCap * 6);
+    if (np2 <= SELECT_LDS_CAP) key = sKey;
+    else if (np2 <= P.sortCap) key = wgScratch;
     else { if (tid == 0) atomicOr(&P.counters[2], (unsigned long long)ERR_SORTCAP); continue; }
     T1kOvl *stage = (T1kOvl *)(wgScratch + P.sortCap * 2);
     if (n > P.sortCap) { if (tid == 0) atomicOr(&P.counters[2], (unsigned long long)ERR_SORTCAP); continue; }
+    int iBits = 1;
+    while ((1u << iBits) < n) ++iBits;
+    const uint64_t iMask = (1ull << iBits) - 1;
     for (uint32_t i = tid; i < np2; i += NT) {
       uint64_t kk = ~0ull;
       if (i < n) {
         const T1kOvl o = P.ovl[o0 + i];
         int rspan = o.readEnd - o.readStart;
         int d = rspan + 1 + o.seqEnd - o.seqStart + 1 + 2 * o.leftClip + 2 * o.rightClip;  // similarity desc == d asc at equal matchCnt
-        kk = ((uint64_t)(4095 - o.matchCnt) << 50) | ((uint64_t)(d & 0x1FFF) << 37) | ((uint64_t)(4095 - rspan) << 24) | (uint64_t)(o.allele & 0xFFFFFF);
+        if (!packSortKey((int)o.matchCnt, d, rspan, o.allele, i, P.alleleBits, iBits, &kk)) { atomicOr(&P.counters[2], (unsigned long long)ERR_SORTCAP); kk = i; }
         stage[i] = o;
       }
-      key[i] = kk; idx[i] = i;
+      key[i] = kk;
     }
     __syncthreads();
-    bitonicSort(key, idx, np2);
+    bitonicSort(key, np2);
     if (tid == 0) { sCut = n; sTie2 = 0; }
     __syncthreads();
     for (uint32_t i = 1 + tid; i < n; i += NT)
-      if (key[i] == key[i - 1]) sTie2 = 1;
+      if ((key[i] >> iBits) == (key[i - 1] >> iBits)) sTie2 = 1;
     __syncthreads();
     if (sTie2 && tid == 0) {
       for (uint32_t i = 1; i < n; ++i) {
-        if (key[i] != key[i - 1]) continue;
+        if ((key[i] >> iBits) != (key[i - 1] >> iBits)) continue;
         uint32_t j = i;
-        while (j > 0 && key[j - 1] == key[j] && ovlBeforeFull(stage[idx[j]], stage[idx[j - 1]])) {
-          uint32_t t = idx[j]; idx[j] = idx[j - 1]; idx[j - 1] = t;
+        while (j > 0 && (key[j - 1] >> iBits) == (key[j] >> iBits) && ovlBeforeFull(stage[key[j] & iMask], stage[key[j - 1] & iMask])) {
+          uint64_t t = key[j]; key[j] = key[j - 1]; key[j - 1] = t;
           --j;
         }
       }
@@ -724,15 +736,15 @@ __global__ __launch_bounds__(NT) void k_truncate(TruncArgs P) {
     __syncthreads();
     {
       // first j >= 1 whose similarity falls more than 0.1 below the best one (SeqSet.hpp:2294-2297)
-      const double s0 = ovlSimilarity(stage[idx[0]]);
+      const double s0 = ovlSimilarity(stage[key[0] & iMask]);
       uint32_t mine = n;
       for (uint32_t j = 1 + tid; j < n; j += NT)
-        if (ovlSimilarity(stage[idx[j]]) < s0 - 0.1) { mine = j; break; }
+        if (ovlSimilarity(stage[key[j] & iMask]) < s0 - 0.1) { mine = j; break; }
       if (mine < n) atomicMin(&sCut, mine);
     }
     __syncthreads();
     const uint32_t cut = sCut;
-    for (uint32_t i = tid; i < cut; i += NT) P.ovl[o0 + i] = stage[idx[i]];
+    for (uint32_t i = tid; i < cut; i += NT) P.ovl[o0 + i] = stage[key[i] & iMask];
     if (tid == 0) P.ovlCount[re] = cut;
     __syncthreads();
   }
@@ -783,9 +795,9 @@ void t1k_launch_extend_retry(t1k_ctx *ctx, const ExtendArgs &a, const uint32_t *
   hipLaunchKernelGGL(k_extend_retry, dim3((n + WG - 1) / WG), dim3(WG), 0, ctx->stream, a, list, n);
 }
 void t1k_launch_select(t1k_ctx *ctx, const SelectArgs &a, int nWg) {
-  hipFuncSetAttribute((const void *)k_select<SELECT_LARGE, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, SELECT_LARGE * 12);
-  hipLaunchKernelGGL((k_select<SELECT_SMALL, 256>), dim3(nWg), dim3(256), SELECT_SMALL * 12, ctx->stream, a);
-  hipLaunchKernelGGL((k_select<SELECT_LARGE, 1024>), dim3(std::min(nWg, 512)), dim3(1024), SELECT_LARGE * 12, ctx->stream, a);
+  hipFuncSetAttribute((const void *)k_select<SELECT_LARGE, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, SELECT_LARGE * 8);
+  hipLaunchKernelGGL((k_select<SELECT_SMALL, 256>), dim3(nWg), dim3(256), SELECT_SMALL * 8, ctx->stream, a);
+  hipLaunchKernelGGL((k_select<SELECT_LARGE, 1024>), dim3(std::min(nWg, 512)), dim3(1024), SELECT_LARGE * 8, ctx->stream, a);
 }
 void t1k_launch_fullalign(t1k_ctx *ctx, const FullArgs &a) {
   if (!a.nOvl) return;
@@ -808,9 +820,9 @@ void t1k_launch_align_fill_apply(t1k_ctx *ctx, const SlowArgs &a, bool eq) {
   }
 }
 void t1k_launch_truncate(t1k_ctx *ctx, const TruncArgs &a, int nWg) {
-  hipFuncSetAttribute((const void *)k_truncate<SELECT_LARGE, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, SELECT_LARGE * 12);
-  hipLaunchKernelGGL((k_truncate<SELECT_SMALL, 256>), dim3(nWg), dim3(256), SELECT_SMALL * 12, ctx->stream, a);
-  hipLaunchKernelGGL((k_truncate<SELECT_LARGE, 1024>), dim3(std::min(nWg, 512)), dim3(1024), SELECT_LARGE * 12, ctx->stream, a);
+  hipFuncSetAttribute((const void *)k_truncate<SELECT_LARGE, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, SELECT_LARGE * 8);
+  hipLaunchKernelGGL((k_truncate<SELECT_SMALL, 256>), dim3(nWg), dim3(256), SELECT_SMALL * 8, ctx->stream, a);
+  hipLaunchKernelGGL((k_truncate<SELECT_LARGE, 1024>), dim3(std::min(nWg, 512)), dim3(1024), SELECT_LARGE * 8, ctx->stream, a);
 }
 void t1k_launch_coverage_scan(t1k_ctx *ctx, const T1kRefDev &ref, int32_t *out, const uint64_t *outOff) {
   hipLaunchKernelGGL(k_coverage_scan, dim3(ref.nAlleles), dim3(WG), 0, ctx->stream, ref, out, outOff);

@@ -436,6 +436,8 @@ int t1k_assign_range(t1k_ctx *ctx, uint64_t first, uint32_t count) {
   s.ovl = (T1kOvl *)ctx->bOvl.p; s.ovlCap = (uint64_t)ctx->prm.ovl_cap;
   s.ovlStart = (uint32_t *)ctx->bOvlStart.p; s.ovlCount = (uint32_t *)ctx->bOvlCount.p;
   s.sortScratch = (uint64_t *)ctx->bSortScratch.p; s.sortCap = sortCap; s.counters = a.counters;
+  s.alleleBits = 1;
+  while ((1u << s.alleleBits) < ctx->ref.nAlleles) ++s.alleleBits;
   t1k_launch_select(ctx, s, nWg);
   T1K_HIP(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
   if ((rc = fetchCounters(ctx, hc))) return rc;
@@ -505,7 +507,7 @@ int t1k_assign_range(t1k_ctx *ctx, uint64_t first, uint32_t count) {
   if (!evSlow) (void)hipEventCreate(&evSlow);
   T1K_HIP(ctx, hipEventRecord(evSlow, ctx->stream));
   TruncArgs tr{};
-  tr.reads = rd; tr.ovl = s.ovl; tr.ovlStart = s.ovlStart; tr.ovlCount = s.ovlCount; tr.sortScratch = s.sortScratch; tr.sortCap = sortCap;
+  tr.reads = rd; tr.ovl = s.ovl; tr.ovlStart = s.ovlStart; tr.ovlCount = s.ovlCount; tr.sortScratch = s.sortScratch; tr.sortCap = sortCap; tr.alleleBits = s.alleleBits;
   tr.counters = a.counters;
   t1k_launch_truncate(ctx, tr, nWg);
   T1K_HIP(ctx, hipEventRecord(ctx->ev[4], ctx->stream));

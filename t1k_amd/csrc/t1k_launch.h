@@ -45,8 +45,9 @@ struct SelectArgs {
   const uint32_t *candStart, *candCount;
   T1kOvl *ovl; uint64_t ovlCap;
   uint32_t *ovlStart, *ovlCount;
-  uint64_t *sortScratch;   // [wg][sortCap] keys, then [wg][sortCap] u32 idx
+  uint64_t *sortScratch;   // [wg][sortCap] packed keys (per-workgroup stride: sortCap * 6 words, shared with k_truncate)
   uint32_t sortCap;
+  int alleleBits;          // bits of an allele index
   unsigned long long *counters;
 };
 
@@ -79,7 +80,8 @@ struct TruncArgs {
   T1kOvl *ovl;
   const uint32_t *ovlStart;
   uint32_t *ovlCount;
-  uint64_t *sortScratch; uint32_t sortCap;   // keys + idx, then a T1kOvl staging area of sortCap records
+  uint64_t *sortScratch; uint32_t sortCap;   // keys, then a T1kOvl staging area of sortCap records
+  int alleleBits;
   unsigned long long *counters;
 };
 
