@@ -26,9 +26,9 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 READ_LEN = 150
-# HBM traffic of one full-batch k_seed_scatter launch (16384 fragments) from the rocprofv3 PMC passes of profiles/r01_pmc_hbm.md:
-# FETCH_SIZE 8.65e6 KB (x2: the counter tallies 128-B requests at 64 B on gfx950, MI355X_MICROARCH.md) + WRITE_SIZE 2.20e7 KB
-TRAFFIC_BYTES_PER_LAUNCH = 2 * 8.65e9 + 2.20e10
+# HBM traffic of one full-batch k_seed_groups launch (16384 fragments) from the rocprofv3 PMC passes of profiles/r01_pmc_hbm.md:
+# FETCH_SIZE 4.71e6 KB (x2: the counter tallies 128-B requests at 64 B on gfx950, MI355X_MICROARCH.md) + WRITE_SIZE 3.06e6 KB
+TRAFFIC_BYTES_PER_LAUNCH = 2 * 4.71e9 + 3.06e9
 
 
 def sh(cmd, **kw):
@@ -69,7 +69,7 @@ def cpu_baseline(ref, pfx, workdir, pairs_total):
     kind, binary = "reference", refbin
     if not os.path.exists(refbin):
         kind, binary, threads = "port", os.path.join(ROOT, "oracle", "t1k_oracle_cli"), 1
-    n = min(pairs_total, 120 * threads if kind == "reference" else 400)
+    n = min(pairs_total, 480 * threads if kind == "reference" else 400)  # ~20 s of CPU work on the HLA-like workload
     s1, s2 = os.path.join(workdir, "cpu_1.fq"), os.path.join(workdir, "cpu_2.fq")
     head_fastq(pfx + "_1.fq", s1, n)
     head_fastq(pfx + "_2.fq", s2, n)
@@ -83,13 +83,13 @@ def cpu_baseline(ref, pfx, workdir, pairs_total):
 
 
 def kernel_bytes(st, pairs):
-    """ALGORITHMIC bytes per kernel (group) for one step: DESIGN.md section 5, terms of SURVEY.md 8d, every count measured by the
-    device itself.  k_seed_scatter: packed read (3l/8 B) + one 8 B bucket header per looked-up k-mer + 8 B per posting of the used
-    lists (each posting counted once) + 4 B per grouped hit written + 16 B per group record."""
+    """ALGORITHMIC bytes per kernel (group) for one step: the terms of SURVEY.md 8d, every count measured by
+    the device itself.  k_seed_groups covers the first two terms: the packed read (3l/8 B per read-end) + one 8 B bucket header per
+    looked-up k-mer + 8 B per posting of the used lists (each posting counted once)."""
     re, L = st["read_ends"], READ_LEN
     return {
-        "k_seed_scatter": re * (3 * L / 8.0) + st["lookups"] * 8 + st["postings"] * 8 + st["hits"] * 4 + st["groups"] * 16,
-        "chain kernels": st["hits"] * 4 + st["groups"] * (16 + 60) + st["candidates"] * 24,
+        "k_seed_groups": re * (3 * L / 8.0) + st["lookups"] * 8 + st["postings"] * 8,
+        "chain kernels": st["groups"] * 60 + st["candidates"] * 24,
         "k_extend": st["candidates"] * (24 + 60 + 24),
         "k_select": st["candidates"] * (24 + 24) + st["extended"] * 32,
         "fullalign kernels": st["extended"] * 32 + st["near_best"] * (60 + 12),
@@ -173,10 +173,10 @@ def main():
     import ctypes
     ctypes.CDLL(None).fflush(None)  # RCCL prints its banner through C stdio: get it out before the JSON line
     if rank == 0:
-        ms = {"k_seed_scatter": st["ms_seed"], "chain kernels": st["ms_chain"], "k_extend": st["ms_extend"], "k_select": st["ms_select"],
+        ms = {"k_seed_groups": st["ms_seed"], "chain kernels": st["ms_chain"], "k_extend": st["ms_extend"], "k_select": st["ms_select"],
               "fullalign kernels": st["ms_fullalign"], "k_pair": st["ms_pair"]}
         kb = kernel_bytes(st, a.pairs)
-        dom = "k_seed_scatter"  # the single largest kernel (profiles/): one launch per device batch
+        dom = "k_seed_groups"  # the single largest kernel (profiles/): one launch per device batch
         launches = max(1, st["batches"])
         achieved = kb[dom] / (ms[dom] * 1e-3) / 1e9 if ms[dom] > 0 else 0.0
         out = {

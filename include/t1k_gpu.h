@@ -134,7 +134,7 @@ int t1k_em_update(t1k_ctx *ctx, const double *x0, double *x1, double *ecReadCoun
 typedef struct {
   uint64_t read_ends, lookups, postings, hits, groups, candidates, extended, near_best, dp_calls, rows, batches;
   /* kernel time (HIP events on the launch stream), summed over the batches of the last run:
-     ms_seed = k_seed_scatter, ms_chain = the remaining chain kernels, ms_fullalign = k_fullalign + DP kernels + k_truncate */
+     ms_seed = k_seed_groups, ms_chain = the remaining chain kernels, ms_fullalign = k_fullalign + DP kernels + k_truncate */
   double ms_seed, ms_chain, ms_extend, ms_select, ms_fullalign, ms_pair, ms_em, ms_total;
 } t1k_stats;
 int t1k_stats_get(t1k_ctx *ctx, t1k_stats *out);
