@@ -7,6 +7,26 @@
 #include <set>
 #include "t1k_host.h"
 
+#include <thread>
+
+namespace {
+// static-chunk parallel loop over [0, n) on the host cores (the per-allele / per-class post-processing is embarrassingly parallel)
+template <class F>
+void parallelFor(size_t n, F fn) {
+  unsigned T = std::thread::hardware_concurrency();
+  if (T > 16) T = 16;
+  if (T < 2 || n < 256) { for (size_t i = 0; i < n; ++i) fn(i); return; }
+  std::vector<std::thread> th;
+  const size_t chunk = (n + T - 1) / T;
+  for (unsigned t = 0; t < T; ++t) {
+    const size_t b = t * chunk, e = std::min(n, b + chunk);
+    if (b >= e) break;
+    th.emplace_back([b, e, &fn] { for (size_t i = b; i < e; ++i) fn(i); });
+  }
+  for (auto &x : th) x.join();
+}
+}  // namespace
+
 namespace t1k {
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -112,14 +132,14 @@ void Genotyper::finalize(const std::vector<int32_t> &coverage) {
   }
   // RemoveLowMAPQAlleleInEquivalentClass (1330-1368) keeps everything: all assignment qualities are 1 and class members
   // share their group lists.
-  uint64_t off = 0;
-  std::vector<int> ex;
-  for (int a = 0; a < A; ++a) {
-    ex.clear();
+  std::vector<uint64_t> covOff(A + 1, 0);
+  for (int a = 0; a < A; ++a) covOff[a + 1] = covOff[a] + (uint64_t)R.al[a].seqLen;
+  parallelFor((size_t)A, [&](size_t a) {
+    std::vector<int> ex;
     const int L = R.al[a].seqLen;
+    const uint64_t off = covOff[a];
     for (int p = 0; p < L; ++p)
       if (R.exon[a][p]) ex.push_back(coverage[off + p]);
-    off += L;
     int miss = 0;
     if (!ex.empty()) {
       // the reference sorts and scans (SeqSet.hpp:2733-2741); only the median and the number of values below the cutoff
@@ -130,7 +150,7 @@ void Genotyper::finalize(const std::vector<int32_t> &coverage) {
       for (int v : ex) miss += !(v >= cutoff);
     }
     R.al[a].missingCov = miss;
-  }
+  });
 }
 
 void Genotyper::setAbundance(const double *n, const std::vector<int> &ecLen) {
@@ -235,7 +255,8 @@ int Genotyper::quantify(t1k_ctx *ctx, t1k_allreduce_fn cb, void *user, std::stri
 // ------------------------------------------------------------------------------------------------------------------
 void Genotyper::dropUnlikely() {
   RefSet &R = *ref;
-  for (auto &members : ecAlleles) {
+  parallelFor(ecAlleles.size(), [&](size_t ci) {
+    std::vector<int> &members = ecAlleles[ci];
     const int size = (int)members.size();
     std::vector<int> lo(size), hi(size, -1);
     // The reference walks the groups of the class representative and picks out the members' entries (1398-1416).  Class
@@ -261,7 +282,7 @@ void Genotyper::dropUnlikely() {
     for (int j = 0; j < size; ++j)
       if (ll[j] / best >= 0.05 || ll[j] == best) kept.push_back(members[j]);
     members = kept;
-  }
+  });
 }
 
 int Genotyper::geneTypes(int gene) const {

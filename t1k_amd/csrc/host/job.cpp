@@ -7,8 +7,11 @@
 #include <cstdlib>
 #include <cstring>
 #include <ctime>
-#include <future>
+#include <condition_variable>
+#include <functional>
 #include <memory>
+#include <mutex>
+#include <thread>
 #include <set>
 #include "t1k_host.h"
 
@@ -20,6 +23,7 @@ struct t1k_job {
   RefSet ref;
   Genotyper gt;
   t1k_ctx *ctx = nullptr;
+  std::vector<t1k_ctx *> more;      // further pipelines on the same GPU (own stream and batch arenas): several batches in flight
   // reads: read-end 2f / 2f+1 are the mates of fragment f (single-end: read-end f)
   bool paired = false;
   uint32_t nFrag = 0;
@@ -87,6 +91,17 @@ int t1k_job_create(const t1k_job_params *p, const char *refFasta, t1k_job **out)
   }
   rc = t1k_ref_upload(job->ctx, blob.data(), off.data(), ex.data(), (uint32_t)R.seqs.size());
   if (rc != T1K_OK) return jobFail(job, rc, t1k_last_error(job->ctx));
+  // Most kernels of the path are latency-bound; a second, independent pipeline (context, stream, arenas) on the same GPU lets
+  // the hardware overlap two batches.  T1K_PIPELINES=1 turns it off.
+  const char *pl = getenv("T1K_PIPELINES");
+  const int nPipe = pl ? std::max(1, std::min(8, atoi(pl))) : 3;
+  for (int i = 1; i < nPipe; ++i) {
+    t1k_ctx *c = nullptr;
+    rc = t1k_ctx_create(job->prm.device, &job->prm.dev, &c);
+    if (rc == T1K_OK) rc = t1k_ref_upload(c, blob.data(), off.data(), ex.data(), (uint32_t)R.seqs.size());
+    if (rc != T1K_OK) { if (c) t1k_ctx_destroy(c); break; }  // not enough memory: run with the pipelines we have
+    job->more.push_back(c);
+  }
   job->gt.ref = &job->ref;
   job->gt.prm = job->prm;
   return T1K_OK;
@@ -95,6 +110,7 @@ int t1k_job_create(const t1k_job_params *p, const char *refFasta, t1k_job **out)
 void t1k_job_destroy(t1k_job *job) {
   if (!job) return;
   if (job->ctx) t1k_ctx_destroy(job->ctx);
+  for (t1k_ctx *c : job->more) t1k_ctx_destroy(c);
   delete job;
 }
 
@@ -162,6 +178,8 @@ int t1k_job_stage_reads(t1k_job *job) {
   uint32_t nEnds = (uint32_t)(job->endOff.size() - 1);
   int rc = t1k_reads_upload(job->ctx, job->ends.data(), job->endOff.data(), nullptr, nEnds);
   if (rc != T1K_OK) return jobFail(job, rc, t1k_last_error(job->ctx));
+  for (t1k_ctx *c : job->more)
+    if ((rc = t1k_reads_upload(c, job->ends.data(), job->endOff.data(), nullptr, nEnds)) != T1K_OK) return jobFail(job, rc, t1k_last_error(c));
   job->staged = true;
   job->msUpload = nowMs() - t0;
   return T1K_OK;
@@ -211,27 +229,35 @@ int t1k_job_run_local(t1k_job *job) {
   job->assignText.clear();
   memset(&job->stats, 0, sizeof(job->stats));
   if ((rc = t1k_coverage_reset(job->ctx)) != T1K_OK) return jobFail(job, rc, t1k_last_error(job->ctx));
+  for (t1k_ctx *c : job->more)
+    if ((rc = t1k_coverage_reset(c)) != T1K_OK) return jobFail(job, rc, t1k_last_error(c));
   const uint32_t F = job->nFrag;
-  uint32_t batch = job->prm.batch_fragments > 0 ? (uint32_t)job->prm.batch_fragments : 16384u;
   const uint32_t per = job->paired ? 2 : 1;
-  std::vector<uint32_t> e1, e2;
   double tDev = 0, tHost = 0;
-  // The host half of a batch (whitelist filter, assignment text, read-group coalescing) runs on a worker thread while the
-  // device works on the next batch; batches are absorbed strictly in order (coalescing is order-dependent).
+  // One worker per pipeline.  A worker takes the next contiguous range of fragments, runs the device stages on its context,
+  // downloads the rows, and then -- when every earlier range has been absorbed (coalescing is order-dependent) --
+  // does the host half (whitelist filter, assignment text, read-group coalescing) while the other worker's batch is on the GPU.
   struct HostBatch {
     uint32_t b0 = 0, nb = 0;
     std::vector<uint32_t> rowCounts;
     std::vector<uint8_t> assigned;
     std::vector<t1k_row_entry> rows;
   };
-  std::future<void> pending;
-  auto absorb = [job, &gt, &tHost](std::shared_ptr<HostBatch> hb) {
+  struct Shared {
+    std::mutex m;
+    std::condition_variable cv;
+    uint32_t next = 0, absorbNext = 0, batch = 16384;
+    int err = T1K_OK;
+    std::string errMsg;
+  } sh;
+  sh.batch = job->prm.batch_fragments > 0 ? (uint32_t)job->prm.batch_fragments : 16384u;
+  auto absorb = [job, &gt, &tHost](HostBatch &hb) {
     const double t1 = nowMs();
     uint64_t p = 0;
-    for (uint32_t i = 0; i < hb->nb; ++i) {
-      job->fragAssigned[hb->b0 + i] = hb->assigned[i];
-      uint32_t n = hb->rowCounts[i];
-      t1k_row_entry *row = hb->rows.data() + p;
+    for (uint32_t i = 0; i < hb.nb; ++i) {
+      job->fragAssigned[hb.b0 + i] = hb.assigned[i];
+      uint32_t n = hb.rowCounts[i];
+      t1k_row_entry *row = hb.rows.data() + p;
       p += n;
       if (!job->whitelist.empty()) {  // SetReadAssignments skips alleles outside the whitelist (Genotyper.hpp:822-823)
         uint32_t w = 0;
@@ -240,7 +266,7 @@ int t1k_job_run_local(t1k_job *job) {
         n = w;
       }
       if (job->prm.output_read_assignment) {
-        const std::string id = job->id1.empty() ? "r" + std::to_string(hb->b0 + i) : job->id1[hb->b0 + i];
+        const std::string id = job->id1.empty() ? "r" + std::to_string(hb.b0 + i) : job->id1[hb.b0 + i];
         for (uint32_t j = 0; j < n; ++j)
           job->assignText += id + "\t" + job->ref.al[row[j].allele_idx].name + "\t" + std::to_string(row[j].start) + "\t" + std::to_string(row[j].end) + "\n";
       }
@@ -248,40 +274,71 @@ int t1k_job_run_local(t1k_job *job) {
     }
     tHost += nowMs() - t1;
   };
-  auto drain = [&pending]() { if (pending.valid()) pending.get(); };
-  for (uint32_t b0 = 0; b0 < F;) {
-    uint32_t nb = std::min(batch, F - b0);
-    double t0 = nowMs();
-    rc = t1k_assign_range(job->ctx, (uint64_t)b0 * per, nb * per);
-    if (rc == T1K_ERR_CAPACITY && nb > 64) { batch = std::max<uint32_t>(64, nb / 2); continue; }  // nothing has been committed yet: retry smaller
-    if (rc != T1K_OK) { drain(); return jobFail(job, rc, t1k_last_error(job->ctx)); }
-    e1.resize(nb); e2.resize(nb);
-    for (uint32_t i = 0; i < nb; ++i) { e1[i] = i * per; e2[i] = i * per + 1; }
-    rc = t1k_pair_batch(job->ctx, e1.data(), job->paired ? e2.data() : nullptr, job->hasN.data() + b0, nb);
-    if (rc != T1K_OK) { drain(); return jobFail(job, rc, t1k_last_error(job->ctx)); }
-    uint64_t total = 0;
-    auto hb = std::make_shared<HostBatch>();
-    hb->b0 = b0; hb->nb = nb;
-    hb->rowCounts.resize(nb); hb->assigned.resize(nb);
-    if ((rc = t1k_rows_download(job->ctx, hb->rowCounts.data(), hb->assigned.data(), nullptr, 0, &total)) != T1K_OK) { drain(); return jobFail(job, rc, t1k_last_error(job->ctx)); }
-    hb->rows.resize(total);
-    if ((rc = t1k_rows_download(job->ctx, hb->rowCounts.data(), hb->assigned.data(), hb->rows.data(), total, &total)) != T1K_OK) {
-      drain();
-      return jobFail(job, rc, t1k_last_error(job->ctx));
+  // device stages of fragments [b0, b0 + nb) on one context; on a capacity error nothing has been committed: split the range
+  std::function<int(t1k_ctx *, uint32_t, uint32_t, std::vector<HostBatch> &, std::string &)> runRange =
+      [&](t1k_ctx *ctx, uint32_t b0, uint32_t nb, std::vector<HostBatch> &out, std::string &msg) -> int {
+    int r = t1k_assign_range(ctx, (uint64_t)b0 * per, nb * per);
+    if (r == T1K_ERR_CAPACITY && nb > 64) {
+      { std::lock_guard<std::mutex> g(sh.m); sh.batch = std::max<uint32_t>(64, std::min(sh.batch, nb / 2)); }
+      if ((r = runRange(ctx, b0, nb / 2, out, msg)) != T1K_OK) return r;
+      return runRange(ctx, b0 + nb / 2, nb - nb / 2, out, msg);
     }
+    if (r != T1K_OK) { msg = t1k_last_error(ctx); return r; }
+    std::vector<uint32_t> e1(nb), e2(nb);
+    for (uint32_t i = 0; i < nb; ++i) { e1[i] = i * per; e2[i] = i * per + 1; }
+    if ((r = t1k_pair_batch(ctx, e1.data(), job->paired ? e2.data() : nullptr, job->hasN.data() + b0, nb)) != T1K_OK) { msg = t1k_last_error(ctx); return r; }
+    out.emplace_back();
+    HostBatch &hb = out.back();
+    hb.b0 = b0; hb.nb = nb;
+    hb.rowCounts.resize(nb); hb.assigned.resize(nb);
+    uint64_t total = 0;
+    if ((r = t1k_rows_download(ctx, hb.rowCounts.data(), hb.assigned.data(), nullptr, 0, &total)) != T1K_OK) { msg = t1k_last_error(ctx); return r; }
+    hb.rows.resize(total);
+    if ((r = t1k_rows_download(ctx, hb.rowCounts.data(), hb.assigned.data(), hb.rows.data(), total, &total)) != T1K_OK) { msg = t1k_last_error(ctx); return r; }
     t1k_stats st;
-    t1k_stats_get(job->ctx, &st);
+    t1k_stats_get(ctx, &st);
+    std::lock_guard<std::mutex> g(sh.m);
     job->stats.read_ends += st.read_ends; job->stats.lookups += st.lookups; job->stats.postings += st.postings; job->stats.hits += st.hits;
     job->stats.groups += st.groups; job->stats.candidates += st.candidates; job->stats.extended += st.extended; job->stats.near_best += st.near_best;
     job->stats.dp_calls += st.dp_calls; job->stats.ms_chain += st.ms_chain; job->stats.ms_extend += st.ms_extend; job->stats.ms_select += st.ms_select;
     job->stats.ms_fullalign += st.ms_fullalign; job->stats.ms_pair += st.ms_pair; job->stats.ms_seed += st.ms_seed; job->stats.batches += 1;
     job->stats.rows += total;
-    tDev += nowMs() - t0;
-    drain();  // the previous batch must be absorbed before this one
-    pending = std::async(std::launch::async, absorb, hb);
-    b0 += nb;
+    return T1K_OK;
+  };
+  auto worker = [&](t1k_ctx *ctx) {
+    for (;;) {
+      uint32_t b0, nb;
+      {
+        std::lock_guard<std::mutex> g(sh.m);
+        if (sh.err != T1K_OK || sh.next >= F) return;
+        b0 = sh.next; nb = std::min(sh.batch, F - b0); sh.next += nb;
+      }
+      std::vector<HostBatch> done;
+      std::string msg;
+      const int r = runRange(ctx, b0, nb, done, msg);
+      std::unique_lock<std::mutex> lk(sh.m);
+      sh.cv.wait(lk, [&] { return sh.absorbNext == b0 || sh.err != T1K_OK; });
+      if (r != T1K_OK && sh.err == T1K_OK) { sh.err = r; sh.errMsg = msg; }
+      if (sh.err != T1K_OK) { sh.cv.notify_all(); return; }
+      lk.unlock();
+      for (auto &hb : done) absorb(hb);  // this worker holds the turn: nobody else absorbs until absorbNext moves on
+      lk.lock();
+      sh.absorbNext = b0 + nb;
+      sh.cv.notify_all();
+    }
+  };
+  {
+    const double t0 = nowMs();
+    std::vector<std::thread> others;
+    for (t1k_ctx *c : job->more) others.emplace_back(worker, c);
+    worker(job->ctx);
+    for (auto &t : others) t.join();
+    tDev = nowMs() - t0;  // wall time of the batch loop; the host half of the batches is hidden inside it
+    tHost = 0;
   }
-  drain();
+  if (sh.err != T1K_OK) return jobFail(job, sh.err, sh.errMsg);
+  for (t1k_ctx *c : job->more)
+    if ((rc = t1k_coverage_absorb(job->ctx, c)) != T1K_OK) return jobFail(job, rc, t1k_last_error(job->ctx));
   job->msDevice = tDev; job->msHost = tHost;
   job->localDone = true;
   return T1K_OK;

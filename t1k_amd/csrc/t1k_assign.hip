@@ -824,6 +824,13 @@ void t1k_launch_truncate(t1k_ctx *ctx, const TruncArgs &a, int nWg) {
   hipLaunchKernelGGL((k_truncate<SELECT_SMALL, 256>), dim3(nWg), dim3(256), SELECT_SMALL * 8, ctx->stream, a);
   hipLaunchKernelGGL((k_truncate<SELECT_LARGE, 1024>), dim3(std::min(nWg, 512)), dim3(1024), SELECT_LARGE * 8, ctx->stream, a);
 }
+__global__ __launch_bounds__(WG) void k_coverage_add(int32_t *dst, int32_t *src, uint64_t n) {
+  const uint64_t i = (uint64_t)blockIdx.x * WG + threadIdx.x;
+  if (i < n) { dst[i] += src[i]; src[i] = 0; }
+}
+void t1k_launch_coverage_add(t1k_ctx *ctx, int32_t *dst, int32_t *src, uint64_t n) {
+  hipLaunchKernelGGL(k_coverage_add, dim3((unsigned)((n + WG - 1) / WG)), dim3(WG), 0, ctx->stream, dst, src, n);
+}
 void t1k_launch_coverage_scan(t1k_ctx *ctx, const T1kRefDev &ref, int32_t *out, const uint64_t *outOff) {
   hipLaunchKernelGGL(k_coverage_scan, dim3(ref.nAlleles), dim3(WG), 0, ctx->stream, ref, out, outOff);
 }

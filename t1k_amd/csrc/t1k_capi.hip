@@ -222,6 +222,15 @@ int t1k_coverage_device(t1k_ctx *ctx, void **devPtr, uint64_t *count) {
   return T1K_OK;
 }
 
+int t1k_coverage_absorb(t1k_ctx *dst, t1k_ctx *src) {
+  if (!dst || !src || !dst->ref.covDiff || !src->ref.covDiff || dst->device != src->device || dst->ref.totalBases != src->ref.totalBases)
+    return t1k_fail(dst, T1K_ERR_ARG, "t1k_coverage_absorb: contexts do not match");
+  T1K_HIP(dst, hipSetDevice(dst->device));
+  T1K_HIP(dst, hipStreamSynchronize(src->stream));
+  t1k_launch_coverage_add(dst, dst->ref.covDiff, src->ref.covDiff, dst->ref.totalBases + 2);
+  T1K_HIP(dst, hipStreamSynchronize(dst->stream));
+  return T1K_OK;
+}
 int t1k_coverage_reset(t1k_ctx *ctx) {
   if (!ctx || !ctx->ref.covDiff) return t1k_fail(ctx, T1K_ERR_STATE, "no reference");
   T1K_HIP(ctx, hipSetDevice(ctx->device));
@@ -503,8 +512,7 @@ int t1k_assign_range(t1k_ctx *ctx, uint64_t first, uint32_t count) {
     sl.scratch = (uint8_t *)ctx->bSlowScratch.p; sl.perThread = t1k_slow_per_thread(maxCells); sl.maxCells = maxCells; sl.counters = a.counters;
     t1k_launch_fullalign_slow(ctx, sl, slowBlocks);
   }
-  static hipEvent_t evSlow = nullptr;
-  if (!evSlow) (void)hipEventCreate(&evSlow);
+  hipEvent_t evSlow = ctx->ev[9];
   T1K_HIP(ctx, hipEventRecord(evSlow, ctx->stream));
   TruncArgs tr{};
   tr.reads = rd; tr.ovl = s.ovl; tr.ovlStart = s.ovlStart; tr.ovlCount = s.ovlCount; tr.sortScratch = s.sortScratch; tr.sortCap = sortCap; tr.alleleBits = s.alleleBits;
