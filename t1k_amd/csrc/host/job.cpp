@@ -251,6 +251,7 @@ int t1k_job_run_local(t1k_job *job) {
     std::string errMsg;
   } sh;
   sh.batch = job->prm.batch_fragments > 0 ? (uint32_t)job->prm.batch_fragments : 16384u;
+  if (const char *eb = getenv("T1K_BATCH")) sh.batch = std::max(64, atoi(eb));  // tuning aid
   auto absorb = [job, &gt, &tHost](HostBatch &hb) {
     const double t1 = nowMs();
     uint64_t p = 0;

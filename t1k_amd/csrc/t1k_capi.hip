@@ -317,6 +317,8 @@ extern "C++" int t1k_fetch_counters(t1k_ctx *ctx, unsigned long long *h) {
   T1K_HIP(ctx, hipMemcpyAsync(raw.data(), ctx->bCounters.p, (size_t)T1K_COUNTER_WORDS * 8, hipMemcpyDeviceToHost, ctx->stream));
   T1K_HIP(ctx, hipStreamSynchronize(ctx->stream));
   memcpy(h, raw.data(), 64 * 8);
+  h[6] = 0;  // group records: sum of the arena's segment cursors
+  for (int s = 0; s < T1K_NSTRIPE; ++s) h[6] += raw[T1K_ARENA_BASE + ((size_t)T1K_AR_GROUPS * T1K_NSTRIPE + s) * 8];
   static const int slot[5] = {7, 11, 12, 14, 10};
   for (int s = 0; s < T1K_STAT_STRIPES; ++s)
     for (int k = 0; k < 5; ++k) h[slot[k]] += raw[64 + s * 8 + k];

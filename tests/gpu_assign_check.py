@@ -80,6 +80,14 @@ def main():
     util.synth_reads(hla, os.path.join(tmp, "h1"), pairs=200, len=150, seed=3)
     reads = [s for _, _, s in t1k_amd.read_fastx(os.path.join(tmp, "h1_1.fq"))] + [s for _, _, s in t1k_amd.read_fastx(os.path.join(tmp, "h1_2.fq"))]
     total += compare(hla, reads, 0.97, False, "synthetic_hla")
+    # 4. 2 x 250 bp reads (the 320-position instantiations of the seeding / chaining kernels), more substitutions
+    util.synth_reads(hla, os.path.join(tmp, "h2"), pairs=120, len=250, seed=5, sub=0.01, fragmean=520)
+    reads = [s for _, _, s in t1k_amd.read_fastx(os.path.join(tmp, "h2_1.fq"))] + [s for _, _, s in t1k_amd.read_fastx(os.path.join(tmp, "h2_2.fq"))]
+    total += compare(hla, reads, 0.9, False, "synthetic_hla_250bp")
+    # 5. indel-rich reads: groups with several diagonals (gather / LDS / wave-cooperative chaining, band alignments)
+    util.synth_reads(hla, os.path.join(tmp, "h3"), pairs=150, len=150, seed=9, sub=0.004, indel=0.006)
+    reads = [s for _, _, s in t1k_amd.read_fastx(os.path.join(tmp, "h3_1.fq"))] + [s for _, _, s in t1k_amd.read_fastx(os.path.join(tmp, "h3_2.fq"))]
+    total += compare(hla, reads, 0.9, False, "synthetic_hla_indels")
     print("TOTAL MISMATCHES", total)
     return 1 if total else 0
 
