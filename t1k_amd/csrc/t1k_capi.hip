@@ -203,6 +203,28 @@ int t1k_ref_upload(t1k_ctx *ctx, const char *seqs, const uint64_t *offsets, cons
   if (sepPos.empty()) sepPos.push_back(0);
   if ((rc = uploadVec(ctx, sepPos, (const void **)&r.sepPos))) return rc;
   if ((rc = uploadVec(ctx, kStart, (const void **)&r.kStart))) return rc;
+  {
+    // chunk directory: where each multiple of T1K_SEED_CHUNK alleles begins inside a long posting list, so that the seeding kernel
+    // finds a chunk's slice of a list with one load instead of a bisection
+    const uint32_t stride = (nAlleles + T1K_SEED_CHUNK - 1) / T1K_SEED_CHUNK + 1;
+    std::vector<uint32_t> dirIdx(nKeys, T1K_NO_DIR), dir;
+    uint32_t rows = 0;
+    for (size_t code = 0; code < nKeys; ++code) {
+      const uint32_t st = kStart[code], ln = kStart[code + 1] - st;
+      if (ln <= T1K_DIR_MINLEN) continue;
+      dirIdx[code] = rows++;
+      uint32_t p = 0;
+      for (uint32_t cidx = 0; cidx < stride; ++cidx) {
+        const uint32_t bound = cidx * T1K_SEED_CHUNK;
+        while (p < ln && post[st + p].allele < bound) ++p;
+        dir.push_back(p);
+      }
+    }
+    if (dir.empty()) dir.push_back(0);
+    r.kDirStride = stride;
+    if ((rc = uploadVec(ctx, dirIdx, (const void **)&r.kDirIdx))) return rc;
+    if ((rc = uploadVec(ctx, dir, (const void **)&r.kDir))) return rc;
+  }
   if (post.empty()) post.push_back(T1kPosting{0, 0});
   if ((rc = uploadVec(ctx, post, (const void **)&r.kPost))) return rc;
   T1kDevBuf cov;
@@ -319,14 +341,10 @@ extern "C++" int t1k_fetch_counters(t1k_ctx *ctx, unsigned long long *h) {
   memcpy(h, raw.data(), 64 * 8);
   h[6] = 0;  // group records: sum of the arena's segment cursors
   for (int s = 0; s < T1K_NSTRIPE; ++s) h[6] += raw[T1K_ARENA_BASE + ((size_t)T1K_AR_GROUPS * T1K_NSTRIPE + s) * 8];
-  static const int slot[5] = {7, 11, 12, 14, 10};
+  static const int slot[8] = {7, 11, 12, 14, 10, 3, 4, 5};
   for (int s = 0; s < T1K_STAT_STRIPES; ++s)
-    for (int k = 0; k < 5; ++k) h[slot[k]] += raw[64 + s * 8 + k];
-  if (getenv("T1K_DEBUG_PHASES")) {
-    unsigned long long t[3] = {0, 0, 0};
-    for (int s = 0; s < T1K_STAT_STRIPES; ++s) for (int k = 0; k < 3; ++k) t[k] += raw[64 + s * 8 + 5 + k];
-    if (t[0] + t[1] + t[2]) fprintf(stderr, "[t1k] multi-diagonal groups by hit count: <=32 %llu, <=64 %llu, more %llu\n", t[0], t[1], t[2]);
-  }
+    for (int k = 0; k < 8; ++k) h[slot[k]] += raw[64 + s * 8 + k];
+  if (getenv("T1K_SEED_PROFILE") && raw[48]) fprintf(stderr, "[t1k] seed phases (ticks, thread 0 of every workgroup): lookup %llu rule %llu setup %llu min %llu slice %llu scan %llu walk %llu emit-scan %llu (record writes + reset are charged to min)\n", raw[48], raw[49], raw[50], raw[51], raw[52], raw[53], raw[54], raw[55]);
   return 0;
 }
 static int fetchCounters(t1k_ctx *ctx, unsigned long long *h) { return t1k_fetch_counters(ctx, h); }
@@ -372,7 +390,8 @@ int t1k_assign_range(t1k_ctx *ctx, uint64_t first, uint32_t count) {
   if ((rc = t1k_ensure(ctx, ctx->bCounters, (size_t)T1K_COUNTER_WORDS * 8))) return rc;
   if ((rc = t1k_ensure(ctx, ctx->bWgGroups, groupCap * recStride * 4))) return rc;                        // batch group records
   if ((rc = t1k_ensure(ctx, ctx->bWgStage, (size_t)n * maxChunks * 8 + 64))) return rc;                   // chunkStart | chunkCount
-  if ((rc = t1k_ensure(ctx, ctx->bWgHits, (size_t)n * (t1k_chain_used_u32(rd.S) + 2) * 4 + 64))) return rc;  // used k-mer lists | counts
+  const int maxK = t1k_chain_max_kmers(ctx->batchMaxLen, ctx->prm.kmer_length);
+  if ((rc = t1k_ensure(ctx, ctx->bWgHits, (size_t)n * (t1k_chain_used_u32(maxK) + 2) * 4 + 64))) return rc;  // used k-mer lists | counts
   if ((rc = t1k_ensure(ctx, ctx->bWgCache, (size_t)n * memoN * 8 + 64))) return rc;                       // per-read-end memo
   if ((rc = t1k_ensure(ctx, ctx->bWgBig, (size_t)bigBlocks * 64 * t1k_chain_big_scratch_u32() * 4))) return rc;
   // work lists: every list exists twice, as a striped arena the kernels append to and as the dense list its consumer reads
@@ -404,7 +423,7 @@ int t1k_assign_range(t1k_ctx *ctx, uint64_t first, uint32_t count) {
   const int relaxFlag = ctx->prm.relax_intron_align;
   a.recs = (uint32_t *)ctx->bWgGroups.p; a.recStride = (uint32_t)recStride; a.groupCap = groupCap;
   a.chunkStart = (uint32_t *)ctx->bWgStage.p; a.chunkCount = a.chunkStart + (size_t)n * maxChunks; a.maxChunks = maxChunks;
-  a.usedOut = (uint32_t *)ctx->bWgHits.p; a.usedCount = a.usedOut + (size_t)n * t1k_chain_used_u32(rd.S);
+  a.usedOut = (uint32_t *)ctx->bWgHits.p; a.usedCount = a.usedOut + (size_t)n * t1k_chain_used_u32(maxK); a.maxK = (uint32_t)maxK;
   a.memo = (unsigned long long *)ctx->bWgCache.p;
   a.jobList = (uint32_t *)ctx->bLists.p; a.jobCap = jobCap;
   a.jobStr = a.jobList + jobCap;

@@ -443,9 +443,7 @@ __device__ __forceinline__ VoteKey voteKey(int matchCnt0, int rs, int re, uint32
 // Posting lists are sorted by allele, so the chunk's slice of every used list is found by binary search from a cursor.
 // A group record leaves the chip once, coalesced; no hit list is ever written.
 // ------------------------------------------------------------------------------------------------------------------
-#ifndef CHUNK_A
-#define CHUNK_A 512
-#endif
+#define CHUNK_A T1K_SEED_CHUNK
 #define DIAG_EMPTY 0x7FFFFFFF
 
 template <int NW>
@@ -453,25 +451,34 @@ __global__ __launch_bounds__(WG) void k_seed_groups(ChainArgs P) {
   constexpr int AW = NW == 5 ? 7 : 13;  // u32 per accumulator: diag, meta, M[NW]; odd stride = no LDS bank conflicts
   extern __shared__ uint32_t lds[];
   const int k = P.k;
-  const int maxK = 2 * (P.reads.S * 32);
-  uint32_t *acc = lds;                              // [CHUNK_A][AW]
-  uint32_t *ukCode = acc + CHUNK_A * AW;            // [maxK]  code | valid << 31
+  const int maxK = (int)P.maxK;                     // >= k-mers of a read-end, both strands
+  uint32_t *acc = lds;                              // [CHUNK_A][AW] per-allele accumulators of the current chunk
+  // look-up phase only (overlaid on the accumulators, which are re-initialised afterwards):
+  uint32_t *ukCode = acc;                           // [maxK]  code | valid << 31
   uint32_t *ukStart = ukCode + maxK;                // [maxK]
   uint32_t *ukLen = ukStart + maxK;                 // [maxK]
-  uint32_t *cur = ukLen + maxK;                     // [maxK]  per used list: cursor (end of the previous chunk's slice)
-  uint32_t *sLo = cur + maxK;                       // [maxK]  slice of the current chunk
+  uint32_t *ukDir = ukLen + maxK;                   // [maxK]  chunk-directory row of the list
+  uint16_t *usedQ = (uint16_t *)(ukDir + maxK);     // [maxK]  k-mers whose lists are used, + strand first
+  // chunk loop:
+  uint32_t *sLo = acc + CHUNK_A * AW;               // [maxK]  slice of the current chunk
   uint32_t *pre = sLo + maxK;                       // [maxK + 1] exclusive prefix of the slice lengths
-  uint32_t *lstStart = pre + maxK + 1;              // [maxK]  posting-list start of the current strand's used lists
-  uint16_t *usedQ = (uint16_t *)(lstStart + maxK);  // [maxK]
-  uint16_t *qOf = usedQ + maxK;                     // [maxK]  read offset of the current strand's used lists
+  uint32_t *lstStart = pre + maxK + 1;              // [maxK]  posting-list start / length of the used lists (both strands)
+  uint32_t *lstLen = lstStart + maxK;               // [maxK]
+  uint32_t *lstDir = lstLen + maxK;                 // [maxK]
+  uint16_t *qOf = (uint16_t *)(lstDir + maxK);      // [maxK]  read offset of the used lists
   __shared__ uint32_t warpSums[4];
-  __shared__ uint32_t sUsed[2], sGroupBase, sMin;
+  __shared__ uint32_t sUsed[2], sGroupBase, sMin, sFallback, sPost;
+  __shared__ int sWaveMax[4];
   const int tid = threadIdx.x;
   const uint32_t kmask = (1u << (2 * k)) - 1;
   const uint32_t A = P.ref.nAlleles;
   const uint32_t stride = P.recStride;
   for (uint32_t i = tid; i < CHUNK_A * AW; i += WG) acc[i] = (i % AW) == 0 ? (uint32_t)DIAG_EMPTY : 0u;
   __syncthreads();
+#ifdef T1K_SEED_PROFILE
+  uint64_t tp_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tl_ = __builtin_amdgcn_s_memtime();
+#endif
+  unsigned long long statLookups = 0, statPostings = 0, statHits = 0;  // thread 0 tallies, flushed once per workgroup
   for (uint32_t re = blockIdx.x; re < P.reads.nReadEnds; re += gridDim.x) {
     const int len = P.reads.len[re];
     const int S = P.reads.S;
@@ -486,15 +493,83 @@ __global__ __launch_bounds__(WG) void k_seed_groups(ChainArgs P) {
       const uint64_t *b = rbase + pass * S, *nm = rnm + pass * S;
       uint32_t code = (uint32_t)t1k_get32(b, p) & kmask;
       bool valid = ((uint32_t)t1k_get32(nm, p) & kmask) == 0;
-      uint32_t st = 0, ln = 0;
-      if (valid) { st = P.ref.kStart[code]; ln = P.ref.kStart[code + 1] - st; }
+      uint32_t st = 0, ln = 0, dr = T1K_NO_DIR;
+      if (valid) { st = P.ref.kStart[code]; ln = P.ref.kStart[code + 1] - st; dr = P.ref.kDirIdx[code]; }
       ukCode[q] = code | (valid ? 0x80000000u : 0);
-      ukStart[q] = st; ukLen[q] = ln;
+      ukStart[q] = st; ukLen[q] = ln; ukDir[q] = dr;
     }
     __syncthreads();
-    // the sequential look-up rule (SeqSet.hpp:1098-1153, 1165-1226).  The first wavefront runs it as uniform
-    // (scalar) code: each lane holds one k-mer's code and list length, the loop reads them with v_readlane.
-    if (tid < 64) {
+
+#ifdef T1K_SEED_PROFILE
+    { const uint64_t tn_ = __builtin_amdgcn_s_memtime(); tp_[0] += tn_ - tl_; tl_ = tn_; }
+#endif
+    // The look-up rule (SeqSet.hpp:1098-1153, 1165-1226) is a sequential state machine (prevKmerCode, skipCnt).
+    // Parallel form: if no two k-mers within k/2 + 1 consecutive positions of a strand are equal, `code != prev` holds at every
+    // position (prev is the code of one of the previous k/2 + 1 positions), every position is a look-up, and only skipCnt is
+    // left: in a maximal run of "big" positions (list >= 100, not the first / last k-mer) exactly every (k/2 + 1)-th one is
+    // used, any other position resets the count.  Reads with such short repeats take the sequential replay below.
+    const int W1 = k / 2 + 1;
+    if (tid == 0) { sFallback = 0; sUsed[0] = 0; sUsed[1] = 0; sPost = 0; }
+    __syncthreads();
+    int qv[3], lastNonBig[3];
+    uint32_t szv[3];
+    bool bigv[3];
+    {
+      int localMax = -1;
+#pragma unroll
+      for (int x = 0; x < 3; ++x) {
+        const int q = 3 * tid + x;
+        qv[x] = q; szv[x] = 0; bigv[x] = false; lastNonBig[x] = -1;
+        if (q < 2 * nk) {
+          const int pass = q >= nk ? 1 : 0, p = q - pass * nk;
+          const uint32_t code = ukCode[q] & 0x7FFFFFFFu;
+          for (int d = 1; d <= W1 && d <= p; ++d)
+            if ((ukCode[q - d] & 0x7FFFFFFFu) == code) sFallback = 1;
+          szv[x] = ukLen[q];
+          bigv[x] = szv[x] >= 100 && p != 0 && p != nk - 1;
+          if (!bigv[x]) localMax = q;
+        }
+        lastNonBig[x] = localMax;  // within this lane so far; the lanes before are merged in below
+      }
+      // inclusive max-scan of localMax over the lanes (three consecutive positions per lane, lanes in position order)
+      int incl = localMax;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(incl, o, 64); if ((tid & 63) >= o) incl = max(incl, y); }
+      if ((tid & 63) == 63) sWaveMax[tid >> 6] = incl;
+      __syncthreads();
+      int before = __shfl_up(incl, 1, 64);
+      if ((tid & 63) == 0) before = -1;
+      for (int w = 0; w < (tid >> 6); ++w) before = max(before, sWaveMax[w]);
+#pragma unroll
+      for (int x = 0; x < 3; ++x) lastNonBig[x] = max(lastNonBig[x], before);
+    }
+    const bool fallback = sFallback != 0;  // (sWaveMax's barrier also published sFallback)
+    if (!fallback) {
+      uint32_t mine = 0, minePlus = 0, minePost = 0;
+      bool usedv[3];
+#pragma unroll
+      for (int x = 0; x < 3; ++x) {
+        usedv[x] = false;
+        if (qv[x] < 2 * nk && szv[x]) usedv[x] = !bigv[x] || ((qv[x] - lastNonBig[x]) % W1 == 0);
+        if (usedv[x]) { ++mine; minePost += szv[x]; if (qv[x] < nk) ++minePlus; }
+      }
+      uint32_t tot;
+      uint32_t slot = t1k_block_scan_exclusive(mine, warpSums, &tot);
+#pragma unroll
+      for (int x = 0; x < 3; ++x)
+        if (usedv[x]) usedQ[slot++] = (uint16_t)qv[x];
+      for (int o = 32; o > 0; o >>= 1) { minePlus += __shfl_xor(minePlus, o, 64); minePost += __shfl_xor(minePost, o, 64); }
+      if ((tid & 63) == 0) { atomicAdd(&sUsed[0], minePlus); atomicAdd(&sPost, minePost); }
+      __syncthreads();
+      if (tid == 0) {
+        sUsed[1] = tot - sUsed[0];
+        statLookups += 2 * nk; statPostings += sPost;
+        P.usedCount[2 * re] = sUsed[0]; P.usedCount[2 * re + 1] = sUsed[1];
+      }
+    }
+    // sequential replay (reads with short repeats): the first wavefront runs it as uniform (scalar) code: each lane holds one
+    // k-mer's code and list length, the loop reads them with v_readlane.
+    if (fallback && tid < 64) {
       uint32_t prev = 0;  // prevKmerCode starts at code 0 and is carried from the + strand into the - strand
       uint32_t nUsed = 0;
       uint32_t lookups = 0, postings = 0;
@@ -526,13 +601,16 @@ __global__ __launch_bounds__(WG) void k_seed_groups(ChainArgs P) {
         if (tid == 0) sUsed[pass] = nUsed - begin;
       }
       if (tid == 0) {
-        atomicAdd(&P.counters[3], (unsigned long long)lookups);
-        atomicAdd(&P.counters[4], (unsigned long long)postings);
+        statLookups += lookups; statPostings += postings;
         P.usedCount[2 * re] = sUsed[0]; P.usedCount[2 * re + 1] = sUsed[1];
       }
     }
     __syncthreads();
     const uint32_t nUsedPlus = sUsed[0], nUsedMinus = sUsed[1];
+#ifdef T1K_SEED_PROFILE
+    { const uint64_t tn_ = __builtin_amdgcn_s_memtime(); tp_[1] += tn_ - tl_; tl_ = tn_; }
+#endif
+
     // the used lists are kept for k_chain_general, which re-derives the hits of the few multi-diagonal groups
     {
       uint32_t *uo = P.usedOut + (uint64_t)re * maxK * 3;
@@ -542,6 +620,21 @@ __global__ __launch_bounds__(WG) void k_seed_groups(ChainArgs P) {
         uo[3 * u] = (uint32_t)(q - pass * nk); uo[3 * u + 1] = ukStart[q]; uo[3 * u + 2] = ukLen[q];
       }
     }
+    // what the chunk loop needs of the used lists moves out of the overlay, then the accumulators under it are made clean again
+    __syncthreads();
+    for (uint32_t u = tid; u < nUsedPlus + nUsedMinus; u += WG) {
+      const int q = usedQ[u];
+      const int pass = u < nUsedPlus ? 0 : 1;
+      const uint32_t st = ukStart[q], ln = ukLen[q];
+      lstStart[u] = st; lstLen[u] = ln; lstDir[u] = ukDir[q]; qOf[u] = (uint16_t)(q - pass * nk);
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < (uint32_t)((9 * maxK + 1) / 2); i += WG) acc[i] = (i % AW) == 0 ? (uint32_t)DIAG_EMPTY : 0u;
+    __syncthreads();
+
+#ifdef T1K_SEED_PROFILE
+    { const uint64_t tn_ = __builtin_amdgcn_s_memtime(); tp_[2] += tn_ - tl_; tl_ = tn_; }
+#endif
     int chunk = 0;
     unsigned long long hitsLocal = 0;
     for (int sp = 0; sp < 2; ++sp) {  // '-' strand first (SortHits 1577-1583)
@@ -552,21 +645,25 @@ __global__ __launch_bounds__(WG) void k_seed_groups(ChainArgs P) {
       // thread t owns the lists t and t + WG (uCount <= 2 * WG: reads are at most 320 bp)
       const bool has0 = (uint32_t)tid < uCount, has1 = (uint32_t)tid + WG < uCount;
       uint32_t st0 = 0, ln0 = 0, st1 = 0, ln1 = 0, cur0 = 0, cur1 = 0;
-      if (has0) { const int q = usedQ[uBegin + tid]; st0 = ukStart[q]; ln0 = ukLen[q]; }
-      if (has1) { const int q = usedQ[uBegin + tid + WG]; st1 = ukStart[q]; ln1 = ukLen[q]; }
-      for (uint32_t u = tid; u < uCount; u += WG) qOf[u] = (uint16_t)(usedQ[uBegin + u] - pass * nk);
-      for (uint32_t u = tid; u < uCount; u += WG) lstStart[u] = ukStart[usedQ[uBegin + u]];
+      const uint32_t *dir0 = nullptr, *dir1 = nullptr;  // chunk-directory rows of this lane's lists (long lists only)
+      if (has0) { st0 = lstStart[uBegin + tid]; ln0 = lstLen[uBegin + tid]; const uint32_t d = lstDir[uBegin + tid]; if (d != T1K_NO_DIR) dir0 = P.ref.kDir + (uint64_t)d * P.ref.kDirStride; }
+      if (has1) { st1 = lstStart[uBegin + tid + WG]; ln1 = lstLen[uBegin + tid + WG]; const uint32_t d = lstDir[uBegin + tid + WG]; if (d != T1K_NO_DIR) dir1 = P.ref.kDir + (uint64_t)d * P.ref.kDirStride; }
       // allele of the posting under each cursor (0xFFFFFFFF: list exhausted); kept up to date by the slice search below
       uint32_t nx0 = (has0 && ln0) ? P.ref.kPost[st0].allele : 0xFFFFFFFFu, nx1 = (has1 && ln1) ? P.ref.kPost[st1].allele : 0xFFFFFFFFu;
-      // first posting with allele >= c1 at or after cur
-      auto sliceEnd = [&](uint32_t st, uint32_t cur, uint32_t ln, uint32_t c1, uint32_t &nxt) -> uint32_t {
-        uint32_t lo = cur + 1, hi = ln;  // the posting under the cursor is known to be < c1
-        while (lo < hi) { uint32_t m = (lo + hi) >> 1; if (P.ref.kPost[st + m].allele < c1) lo = m + 1; else hi = m; }
+      // first posting with allele >= the end of chunk ci, at or after cur: one directory load, or a bisection of a short list
+      auto sliceEnd = [&](uint32_t st, uint32_t cur, uint32_t ln, const uint32_t *dir, uint32_t ci, uint32_t c1, uint32_t &nxt) -> uint32_t {
+        uint32_t lo;
+        if (dir) lo = dir[ci + 1];
+        else {
+          lo = cur + 1;  // the posting under the cursor is known to be < c1
+          uint32_t hi = ln;
+          while (lo < hi) { uint32_t m = (lo + hi) >> 1; if (P.ref.kPost[st + m].allele < c1) lo = m + 1; else hi = m; }
+        }
         nxt = lo < ln ? P.ref.kPost[st + lo].allele : 0xFFFFFFFFu;
         return lo;
       };
       for (;;) {
-        // next chunk = the CHUNK_A alleles from the smallest allele any list still holds (empty stretches are skipped)
+        // next chunk = the CHUNK_A-aligned chunk of the smallest allele any list still holds (empty chunks are skipped)
         if (tid == 0) sMin = 0xFFFFFFFFu;
         __syncthreads();
         uint32_t nxt = min(nx0, nx1);
@@ -574,21 +671,29 @@ __global__ __launch_bounds__(WG) void k_seed_groups(ChainArgs P) {
         for (int o = 32; o > 0; o >>= 1) nxt = min(nxt, (uint32_t)__shfl_xor((int)nxt, o, 64));
         if ((tid & 63) == 0 && nxt != 0xFFFFFFFFu) atomicMin(&sMin, nxt);
         __syncthreads();
-        const uint32_t c0 = sMin;
-        if (c0 == 0xFFFFFFFFu) break;
+
+#ifdef T1K_SEED_PROFILE
+    { const uint64_t tn_ = __builtin_amdgcn_s_memtime(); tp_[3] += tn_ - tl_; tl_ = tn_; }
+#endif
+        if (sMin == 0xFFFFFFFFu) break;
+        const uint32_t ci = sMin / CHUNK_A, c0 = ci * CHUNK_A;
         const uint32_t c1 = min(c0 + CHUNK_A, A);
         // slice of every used list inside [c0, c1)
         uint32_t n0 = 0, n1 = 0;
         if (has0) {
           uint32_t l = cur0;
-          if (nx0 < c1) l = sliceEnd(st0, cur0, ln0, c1, nx0);
+          if (nx0 < c1) l = sliceEnd(st0, cur0, ln0, dir0, ci, c1, nx0);
           n0 = l - cur0; sLo[tid] = cur0; cur0 = l;
         }
         if (has1) {
           uint32_t l = cur1;
-          if (nx1 < c1) l = sliceEnd(st1, cur1, ln1, c1, nx1);
+          if (nx1 < c1) l = sliceEnd(st1, cur1, ln1, dir1, ci, c1, nx1);
           n1 = l - cur1; sLo[tid + WG] = cur1; cur1 = l;
         }
+
+#ifdef T1K_SEED_PROFILE
+    { const uint64_t tn_ = __builtin_amdgcn_s_memtime(); tp_[4] += tn_ - tl_; tl_ = tn_; }
+#endif
         uint32_t tot0, tot1 = 0;
         const uint32_t e0 = t1k_block_scan_exclusive(n0, warpSums, &tot0);
         if (has0) pre[tid] = e0;
@@ -599,6 +704,10 @@ __global__ __launch_bounds__(WG) void k_seed_groups(ChainArgs P) {
         const uint32_t T = tot0 + tot1;
         if (tid == 0) { pre[uCount] = T; hitsLocal += T; }
         __syncthreads();
+
+#ifdef T1K_SEED_PROFILE
+    { const uint64_t tn_ = __builtin_amdgcn_s_memtime(); tp_[5] += tn_ - tl_; tl_ = tn_; }
+#endif
         // walk the chunk's postings (flat index -> list by binary search over the prefix), four in flight per lane
         for (uint32_t j0 = tid; j0 < T; j0 += 4 * WG) {
           T1kPosting pst[4];
@@ -609,8 +718,8 @@ __global__ __launch_bounds__(WG) void k_seed_groups(ChainArgs P) {
             if (j < T) {
               uint32_t lo = 0, hi = uCount;
               while (hi - lo > 1) { uint32_t m = (lo + hi) >> 1; if (pre[m] <= j) lo = m; else hi = m; }
-              pst[x] = P.ref.kPost[lstStart[lo] + sLo[lo] + (j - pre[lo])];
-              rr[x] = qOf[lo];
+              pst[x] = P.ref.kPost[lstStart[uBegin + lo] + sLo[lo] + (j - pre[lo])];
+              rr[x] = qOf[uBegin + lo];
             }
           }
 #pragma unroll
@@ -630,6 +739,10 @@ __global__ __launch_bounds__(WG) void k_seed_groups(ChainArgs P) {
           }
         }
         __syncthreads();
+
+#ifdef T1K_SEED_PROFILE
+    { const uint64_t tn_ = __builtin_amdgcn_s_memtime(); tp_[6] += tn_ - tl_; tl_ = tn_; }
+#endif
         // emit the groups that can still produce a candidate: >= 3 hits in total, and either >= 3 on the reference diagonal
         // or some hit close enough to chain with it, or > 2 strays (which could form their own run).  Lane t looks at the
         // accumulators t, t + WG, ... (conflict-free with the odd accumulator stride); the records leave in allele order.
@@ -662,6 +775,10 @@ __global__ __launch_bounds__(WG) void k_seed_groups(ChainArgs P) {
         }
         __syncthreads();
         const uint32_t groupBase = sGroupBase;
+
+#ifdef T1K_SEED_PROFILE
+    { const uint64_t tn_ = __builtin_amdgcn_s_memtime(); tp_[7] += tn_ - tl_; tl_ = tn_; }
+#endif
         if (gTot) ++chunk;
         uint32_t before = 0;  // records of the lower accumulator rows
 #pragma unroll
@@ -692,7 +809,14 @@ __global__ __launch_bounds__(WG) void k_seed_groups(ChainArgs P) {
         __syncthreads();
       }
     }
-    if (tid == 0 && hitsLocal) atomicAdd(&P.counters[5], hitsLocal);
+    if (tid == 0) statHits += hitsLocal;
+  }
+#ifdef T1K_SEED_PROFILE
+  if (tid == 0) for (int i = 0; i < 8; ++i) atomicAdd(&P.counters[48 + i], (unsigned long long)tp_[i]);
+#endif
+  if (tid == 0) {  // statistics: one striped atomic per workgroup and counter
+    unsigned long long *st = P.counters + 64 + (blockIdx.x & (T1K_STAT_STRIPES - 1)) * 8;
+    atomicAdd(&st[T1K_STAT_LOOKUPS], statLookups); atomicAdd(&st[T1K_STAT_POSTINGS], statPostings); atomicAdd(&st[T1K_STAT_HITS], statHits);
   }
 }
 
@@ -818,7 +942,7 @@ __global__ __launch_bounds__(WG) void k_chain_finish(ChainArgs P, uint32_t nItem
 // re-derive the hit list of one (read-end, strand, allele) group from the used posting lists kept by k_seed_groups:
 // the allele's postings are a contiguous run of each list (lists are sorted by allele, then offset)
 __device__ inline int gatherHits(const ChainArgs &P, uint32_t re, int pass, uint32_t allele, uint32_t *h, int cap) {
-  const int maxK = 2 * (P.reads.S * 32);
+  const int maxK = (int)P.maxK;
   const uint32_t nPlus = P.usedCount[2 * re], nMinus = P.usedCount[2 * re + 1];
   const uint32_t b = pass == 0 ? 0 : nPlus, e = pass == 0 ? nPlus : nPlus + nMinus;
   const uint32_t *uo = P.usedOut + (uint64_t)re * maxK * 3;
@@ -845,9 +969,8 @@ __device__ inline int gatherHits(const ChainArgs &P, uint32_t re, int pass, uint
 __global__ __launch_bounds__(WG) void k_gather_general(ChainArgs P, uint32_t nItems) {
   const int lane = threadIdx.x & 63;
   const uint32_t wave = (blockIdx.x * WG + threadIdx.x) >> 6, nWaves = gridDim.x * (WG / 64);
-  const int maxK = 2 * (P.reads.S * 32);
+  const int maxK = (int)P.maxK;
   constexpr int ROUNDS = 2 * GROUP_FAST_MAXLEN / 64 / 2;  // lists of one strand (<= 320) over 64 lanes
-  unsigned int h32 = 0, h64 = 0, hBig = 0;
   for (uint32_t q = wave; q < nItems; q += nWaves) {
     const uint32_t gi = P.generalList[q];
     uint32_t *rec = P.recs + (uint64_t)gi * P.recStride;
@@ -876,7 +999,6 @@ __global__ __launch_bounds__(WG) void k_gather_general(ChainArgs P, uint32_t nIt
     const uint32_t n = __shfl(incl, 63, 64);
     uint32_t base = 0;
     if (lane == 0) {
-      if (n <= 32) ++h32; else if (n <= 64) ++h64; else ++hBig;
       if (n > WAVE_CAP) {  // k_chain_big gathers for itself
         const uint32_t bq = t1k_arena_append(P.counters, T1K_AR_BIG, P.listSegCap);
         if (bq != T1K_ARENA_FULL) P.bigStr[bq] = gi;
@@ -903,7 +1025,6 @@ __global__ __launch_bounds__(WG) void k_gather_general(ChainArgs P, uint32_t nIt
       }
     }
   }
-  t1k_stat_add(P.counters, 5, h32); t1k_stat_add(P.counters, 6, h64); t1k_stat_add(P.counters, 7, hBig);
 }
 
 // K5b: multi-diagonal groups with at most GENERAL_SMALL hits, one lane per group, 64-thread workgroups; the three work arrays
@@ -1198,7 +1319,8 @@ size_t t1k_chain_big_scratch_u32() { return (size_t)4 * BIG_CAP + GA_SCRATCH_INT
 int t1k_chain_max_chunks(uint32_t nAlleles) { return 2 * (int)((nAlleles + CHUNK_A - 1) / CHUNK_A) + 2; }
 int t1k_chain_memo_entries() { return GAP_CACHE; }
 int t1k_chain_rec_stride(int maxLen) { return maxLen <= 160 ? 12 : 16; }  // u32 per record, 16-byte aligned
-int t1k_chain_used_u32(int S) { return 2 * (S * 32) * 3; }
+int t1k_chain_max_kmers(int maxLen, int k) { return (2 * std::max(1, maxLen - k + 1) + 3) / 4 * 4; }
+int t1k_chain_used_u32(int maxK) { return maxK * 3; }
 
 static int readCounters(t1k_ctx *ctx, unsigned long long *h) { return t1k_fetch_counters(ctx, h); }
 
@@ -1241,10 +1363,11 @@ void t1k_launch_dp_dense(t1k_ctx *ctx, const ChainArgs &a, const uint32_t *jobs,
 // runs K1..K6; on return counters[0] = number of candidates, counters[2] = error flags
 int t1k_run_chain(t1k_ctx *ctx, const ChainArgs &a, int nWg, int bigBlocks, bool longReads, unsigned long long *hc) {
   const int AW = longReads ? 13 : 7;
-  const size_t maxK = (size_t)2 * a.reads.S * 32;
-  const size_t lds = (size_t)CHUNK_A * AW * 4 + maxK * (7 * 4 + 4) + 64;
-  // the seeding kernel keeps no per-workgroup HBM scratch: over-subscribe the CUs so read-ends of uneven cost balance out
-  const int seedWg = (int)std::min<uint32_t>(a.reads.nReadEnds, 4096u);
+  const size_t maxK = a.maxK;
+  const size_t lds = (size_t)CHUNK_A * AW * 4 + maxK * (5 * 4 + 2) + 4 + 64;  // accumulators | sLo, pre, lstStart, lstLen, lstDir, qOf
+  // the seeding kernel keeps no per-workgroup HBM scratch: one workgroup per read-end (up to 32768) balances their uneven cost best
+  const char *esw = getenv("T1K_SEED_WG");
+  const int seedWg = (int)std::min<uint32_t>(a.reads.nReadEnds, esw ? (uint32_t)atoi(esw) : 32768u);
   T1K_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
   if (longReads) {
     T1K_HIP(ctx, hipFuncSetAttribute((const void *)k_seed_groups<10>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -53,6 +53,9 @@ struct T1kOvl {
   uint32_t flags;      // bit0 near-best, bit1 strand is '-', bit2 duplicate-allele list marker
 };
 
+#define T1K_SEED_CHUNK 512    // alleles per seeding chunk (k_seed_groups): accumulators of one chunk live in LDS
+#define T1K_DIR_MINLEN 32     // posting lists longer than this get a chunk directory
+#define T1K_NO_DIR 0xFFFFFFFFu
 struct T1kRefDev {
   uint32_t nAlleles;
   uint64_t totalBases;          // padded global base count
@@ -63,6 +66,11 @@ struct T1kRefDev {
   const uint32_t *sepStart;     // [A+1] into sepPos: interior N positions only (the -1 / len sentinels are implicit)
   const int32_t *sepPos;
   const uint32_t *kStart;       // [4^k + 1]
+  // chunk directory of the long posting lists: kDirIdx[code] = row or T1K_NO_DIR; row r, entry c = first posting of the list
+  // whose allele is >= c * T1K_SEED_CHUNK (relative to the list start), c = 0 .. kDirStride - 1
+  const uint32_t *kDirIdx;      // [4^k]
+  const uint32_t *kDir;         // [rows][kDirStride]
+  uint32_t kDirStride;
   const T1kPosting *kPost;
   int32_t *covDiff;             // [totalBases + 1] difference array of per-base coverage
 };
@@ -484,7 +492,7 @@ __device__ __forceinline__ uint32_t t1k_wave_append(uint32_t *counter) {
 // Statistics counters (never read by device code).  Millions of atomics on one address serialise in L2, so every
 // statistic is striped over T1K_STAT_STRIPES cache lines behind the 64 control counters; the host adds the stripes up.
 #define T1K_STAT_STRIPES 256
-enum { T1K_STAT_DP = 0, T1K_STAT_FAST = 1, T1K_STAT_GENERAL = 2, T1K_STAT_EXTEND_DP = 3, T1K_STAT_NEARBEST = 4 };
+enum { T1K_STAT_DP = 0, T1K_STAT_FAST = 1, T1K_STAT_GENERAL = 2, T1K_STAT_EXTEND_DP = 3, T1K_STAT_NEARBEST = 4, T1K_STAT_LOOKUPS = 5, T1K_STAT_POSTINGS = 6, T1K_STAT_HITS = 7 };
 // Allocation cursors.  A returning atomic on ONE word tops out near 88 M/s on this part, far below what the chain kernels
 // ask for, so every device arena (group records, work lists, queues) is cut into T1K_NSTRIPE independent segments with
 // their own cursor (64 bytes apart); a workgroup allocates from segment blockIdx.x % T1K_NSTRIPE.  Lists are made dense

@@ -15,6 +15,7 @@ struct ChainArgs {
   uint32_t *retryList, *generalList, *bigList, *finishList;  // dense lists (filled by k_arena_compact)
   uint32_t *jobStr, *retryStr, *generalStr, *bigStr, *finishStr, *waveStr, *waveList, *slowStr, *slowList;  // striped arenas the kernels append to
   uint32_t groupSegCap, jobSegCap, listSegCap, genCandSegCap, genHitSegCap;
+  uint32_t maxK;  // upper bound of the k-mers of a read-end (both strands): stride of the used-list table
   uint32_t *genJobStr, *genJobList; uint32_t genJobSegCap;  // alignments registered by the multi-diagonal groups
   uint32_t *genHits;  // hit lists of the multi-diagonal groups (k_gather_general)
   uint32_t *genCand; uint32_t genCandCap;                  // packed candidates of multi-diagonal groups (3 u32 each)
@@ -91,7 +92,8 @@ size_t t1k_chain_big_scratch_u32();
 int t1k_chain_max_chunks(uint32_t nAlleles);
 int t1k_chain_memo_entries();
 int t1k_chain_rec_stride(int maxLen);
-int t1k_chain_used_u32(int S);
+int t1k_chain_max_kmers(int maxLen, int k);
+int t1k_chain_used_u32(int maxK);
 int t1k_run_chain(t1k_ctx *ctx, const ChainArgs &a, int nWg, int bigBlocks, bool longReads, unsigned long long *hc);
 void t1k_launch_extend(t1k_ctx *ctx, const ExtendArgs &a);
 void t1k_launch_select(t1k_ctx *ctx, const SelectArgs &a, int nWg);
