@@ -206,6 +206,18 @@ __device__ __forceinline__ bool packSortKey(int m, int d, int rspan, uint32_t al
   return true;
 }
 
+// k_select's entry: [emit mark : 1 | 1023 - seed matchCnt : 10 | span sum : 10 | 511 - read span : 9 | allele : aBits | index : iBits |
+// flags : 3]; the flags (separator in the seed, extension passed, "needs clipping and similarity >= 0.95") are all the later
+// phases need to know about a candidate, so they never go back to HBM for it.  The index is unique, so the flags never order.
+#define SEL_F_SEPSEED 1u
+#define SEL_F_EXTOK 2u
+#define SEL_F_KEEPCLIP 4u
+__device__ __forceinline__ bool packSelectKey(int m, int d, int rspan, uint32_t allele, uint32_t index, uint32_t flags, int aBits, int iBits, uint64_t *out) {
+  if (m < 0 || m > 1023 || d < 0 || d > 1023 || rspan < 0 || rspan > 511 || 33 + aBits + iBits > 64) return false;
+  *out = ((((((uint64_t)(1023 - m) << 10 | (uint64_t)d) << 9 | (uint64_t)(511 - rspan)) << aBits | (uint64_t)allele) << iBits) | (uint64_t)index) << 3 | flags;
+  return true;
+}
+
 // full comparator on the seed coordinates for the (rare) ties of the 64-bit key
 __device__ inline bool candBeforeFull(const T1kCand &a, const T1kCand &b) {
   int ars = a.readSE & 0xFFFF, are = a.readSE >> 16, brs = b.readSE & 0xFFFF, bre = b.readSE >> 16;
@@ -229,6 +241,7 @@ __global__ __launch_bounds__(NT) void k_select(SelectArgs P) {
   __shared__ int sLatch, sGood, sBest, sTie;
   __shared__ uint32_t sBase;
   const int tid = threadIdx.x;
+  unsigned int nbTotal = 0;
   for (uint32_t re = blockIdx.x; re < P.reads.nReadEnds; re += gridDim.x) {
     const uint32_t n = P.candCount[re], c0 = P.candStart[re];
     if (n == 0) {
@@ -265,6 +278,9 @@ __global__ __launch_bounds__(NT) void k_select(SelectArgs P) {
     int iBits = 1;
     while ((1u << iBits) < n) ++iBits;
     const uint64_t iMask = (1ull << iBits) - 1;
+    const int mShift = 19 + P.alleleBits + iBits + 3;  // position of the (1023 - matchCnt) field
+    auto idxOf = [&](uint64_t kk) { return (uint32_t)((kk >> 3) & iMask); };
+    auto seedOf = [&](uint64_t kk) { return 1023 - (int)((kk >> mShift) & 0x3FF); };
     if (tid == 0) sLive = 0;
     for (uint32_t i = tid; i < np2; i += NT) key[i] = ~0ull;
     __syncthreads();
@@ -275,9 +291,12 @@ __global__ __launch_bounds__(NT) void k_select(SelectArgs P) {
       int rs = c.readSE & 0xFFFF, rend = c.readSE >> 16;
       int m = (int)(c.match >> 16);
       int rspan = rend - rs, d = rspan + 1 + c.seqEnd - c.seqStart + 1;
+      const double sim = (double)m / (double)(c.seqEnd - c.seqStart + 1 + rend - rs + 1);
+      const uint32_t kf = ((fl & T1K_F_SEPSEED) ? SEL_F_SEPSEED : 0u) | ((fl & T1K_F_EXTOK) ? SEL_F_EXTOK : 0u) |
+                          (((fl & T1K_F_NEEDCLIP) && !(sim < 0.95)) ? SEL_F_KEEPCLIP : 0u);  // SeqSet.hpp:2170-2172
       uint32_t slot = atomicAdd(&sLive, 1u);  // any order: the sort follows
       uint64_t kk;
-      if (!packSortKey(m, d, rspan, c.allele & 0x7FFFFFFFu, i, P.alleleBits, iBits, &kk)) { atomicOr(&P.counters[2], (unsigned long long)ERR_SORTCAP); kk = i; }
+      if (!packSelectKey(m, d, rspan, c.allele & 0x7FFFFFFFu, i, kf, P.alleleBits, iBits, &kk)) { atomicOr(&P.counters[2], (unsigned long long)ERR_SORTCAP); kk = (uint64_t)i << 3; }
       key[slot] = kk;
     }
     __syncthreads();
@@ -289,13 +308,13 @@ __global__ __launch_bounds__(NT) void k_select(SelectArgs P) {
     if (tid == 0) { sTie = 0; sLatch = 0x7FFFFFFF; sGood = -1; sBest = -1; }
     __syncthreads();
     for (uint32_t i = 1 + tid; i < live; i += NT)
-      if ((key[i] >> iBits) == (key[i - 1] >> iBits)) sTie = 1;
+      if ((key[i] >> (iBits + 3)) == (key[i - 1] >> (iBits + 3))) sTie = 1;
     __syncthreads();
     if (sTie && tid == 0) {
       for (uint32_t i = 1; i < live; ++i) {
-        if ((key[i] >> iBits) != (key[i - 1] >> iBits)) continue;
+        if ((key[i] >> (iBits + 3)) != (key[i - 1] >> (iBits + 3))) continue;
         uint32_t j = i;
-        while (j > 0 && (key[j - 1] >> iBits) == (key[j] >> iBits) && candBeforeFull(P.cand[c0 + (key[j] & iMask)], P.cand[c0 + (key[j - 1] & iMask)])) {
+        while (j > 0 && (key[j - 1] >> (iBits + 3)) == (key[j] >> (iBits + 3)) && candBeforeFull(P.cand[c0 + idxOf(key[j])], P.cand[c0 + idxOf(key[j - 1])])) {
           uint64_t t = key[j]; key[j] = key[j - 1]; key[j - 1] = t;
           --j;
         }
@@ -305,10 +324,9 @@ __global__ __launch_bounds__(NT) void k_select(SelectArgs P) {
     // latch position: first tried candidate whose extension fails (all candidates before the latch are tried)
     int myLatch = 0x7FFFFFFF;
     for (uint32_t i = tid; i < live; i += NT) {
-      if (key[i] == ~0ull) continue;
-      uint16_t fl = P.ext[c0 + (uint32_t)(key[i] & iMask)].flags;
-      if (fl & T1K_F_SEPSEED) continue;
-      if (!(fl & T1K_F_EXTOK)) { if ((int)i < myLatch) myLatch = (int)i; }
+      const uint32_t fl = (uint32_t)key[i] & 7u;
+      if (fl & SEL_F_SEPSEED) continue;
+      if (!(fl & SEL_F_EXTOK)) { if ((int)i < myLatch) myLatch = (int)i; }
     }
     atomicMin(&sLatch, myLatch);
     __syncthreads();
@@ -316,9 +334,8 @@ __global__ __launch_bounds__(NT) void k_select(SelectArgs P) {
     // goodMatchCnt = seed matchCnt of the first emitted candidate before the latch (the list is sorted by it)
     int myGood = 0x7FFFFFFF;
     for (uint32_t i = tid; i < live && (int)i < latch; i += NT) {
-      if (key[i] == ~0ull) continue;
-      uint16_t fl = P.ext[c0 + (uint32_t)(key[i] & iMask)].flags;
-      if ((fl & T1K_F_SEPSEED) || !(fl & T1K_F_EXTOK)) continue;
+      const uint32_t fl = (uint32_t)key[i] & 7u;
+      if ((fl & SEL_F_SEPSEED) || !(fl & SEL_F_EXTOK)) continue;
       if ((int)i < myGood) myGood = (int)i;
     }
     __shared__ int sFirst;
@@ -326,7 +343,7 @@ __global__ __launch_bounds__(NT) void k_select(SelectArgs P) {
     __syncthreads();
     atomicMin(&sFirst, myGood);
     __syncthreads();
-    if (tid == 0) sGood = sFirst == 0x7FFFFFFF ? -1 : (int)(P.cand[c0 + (uint32_t)(key[sFirst] & iMask)].match >> 16);
+    if (tid == 0) sGood = sFirst == 0x7FFFFFFF ? -1 : seedOf(key[sFirst]);
     __syncthreads();
     const int good = sGood;
     // emit flags + best extended matchCnt
@@ -336,23 +353,16 @@ __global__ __launch_bounds__(NT) void k_select(SelectArgs P) {
     // first pass: count and best
     uint32_t mine = 0;
     for (uint32_t i = tid; i < live; i += NT) {
+      const uint64_t kk = key[i];
+      const uint32_t fl = (uint32_t)kk & 7u;
       bool emit = false;
-      if (key[i] != ~0ull) {
-        const T1kExt x = P.ext[c0 + (uint32_t)(key[i] & iMask)];
-        if (!(x.flags & T1K_F_SEPSEED)) {
-          bool tried = true;
-          if ((int)i > latch) {
-            const T1kCand c = P.cand[c0 + (uint32_t)(key[i] & iMask)];
-            int m = (int)(c.match >> 16);
-            int rs = c.readSE & 0xFFFF, rend = c.readSE >> 16;
-            double sim = (double)m / (double)(c.seqEnd - c.seqStart + 1 + rend - rs + 1);
-            if (m < good && (!(x.flags & T1K_F_NEEDCLIP) || sim < 0.95)) tried = false;  // SeqSet.hpp:2170-2172
-          }
-          emit = tried && (x.flags & T1K_F_EXTOK);
-          if (emit && (int)x.matchCnt > myBest) myBest = x.matchCnt;
-        }
+      if (!(fl & SEL_F_SEPSEED)) {
+        bool tried = true;
+        if ((int)i > latch && seedOf(kk) < good && !(fl & SEL_F_KEEPCLIP)) tried = false;  // SeqSet.hpp:2170-2172
+        emit = tried && (fl & SEL_F_EXTOK);
+        if (emit) { const int xm = (int)P.ext[c0 + idxOf(kk)].matchCnt; if (xm > myBest) myBest = xm; }
       }
-      if (emit) { ++mine; key[i] |= 1ull << 63; }
+      if (emit) { ++mine; key[i] = kk | (1ull << 63); }
     }
     atomicMax(&sBest, myBest);
     uint32_t tot;
@@ -371,7 +381,7 @@ __global__ __launch_bounds__(NT) void k_select(SelectArgs P) {
         uint32_t t2;
         uint32_t off = t1k_block_scan_exclusive_n<NT / 64>(flag, warpSums, &t2);
         if (flag) {
-          uint32_t ci = c0 + (uint32_t)(key[i] & iMask);
+          uint32_t ci = c0 + idxOf(key[i]);
           const T1kCand c = P.cand[ci];
           const T1kExt x = P.ext[ci];
           T1kOvl o;
@@ -385,10 +395,10 @@ __global__ __launch_bounds__(NT) void k_select(SelectArgs P) {
         written += t2;
       }
     }
-    for (int o = 32; o > 0; o >>= 1) nbLocal += __shfl_down(nbLocal, o, 64);
-    if ((tid & 63) == 0 && nbLocal) atomicAdd(&P.counters[10], (unsigned long long)nbLocal);
+    nbTotal += nbLocal;
     __syncthreads();
   }
+  t1k_stat_add(P.counters, T1K_STAT_NEARBEST, nbTotal);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
