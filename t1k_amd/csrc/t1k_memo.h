@@ -74,9 +74,12 @@ __device__ inline int gapMatchesCached(const ReadCtx &c, int readPos, int64_t gp
   unsigned long long *cache = sink.cache;
   const uint32_t slot = (uint32_t)hsh & (GAP_CACHE - 1);
   bool pendingSeen = false;
+  unsigned long long probed[GAP_PROBES];  // the probe slots share one 32-byte block: fetch them together, then look
+#pragma unroll
+  for (int probe = 0; probe < GAP_PROBES; ++probe) probed[probe] = __hip_atomic_load(&cache[slot ^ probe], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
   for (int probe = 0; probe < GAP_PROBES; ++probe) {
-    unsigned long long e = __hip_atomic_load(&cache[slot ^ probe], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long e = probed[probe];
     if (e != 0 && (e & GAP_ID_MASK) == idBits) {
       int64_t eg = GAP_GPOS(e);
       if (eg == gpos || t1k_same_window(c.gb, c.gn, eg, gpos, lt)) {
