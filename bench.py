@@ -27,8 +27,8 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 READ_LEN = 150
 # HBM traffic of one full-batch k_seed_groups launch (16384 fragments) from the rocprofv3 PMC passes of profiles/r01_pmc_hbm.md:
-# FETCH_SIZE 4.71e6 KB (x2: the counter tallies 128-B requests at 64 B on gfx950, MI355X_MICROARCH.md) + WRITE_SIZE 3.06e6 KB
-TRAFFIC_BYTES_PER_LAUNCH = 2 * 4.71e9 + 3.06e9
+# FETCH_SIZE 4.79e6 KB (x2: the counter tallies 128-B requests at 64 B on gfx950, MI355X_MICROARCH.md) + WRITE_SIZE 3.06e6 KB
+TRAFFIC_BYTES_PER_LAUNCH = 2 * 4.79e9 + 3.06e9
 
 
 def sh(cmd, **kw):
@@ -201,7 +201,7 @@ def main():
                        "assigned_fragments": counts["assigned_fragments"]},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": TRAFFIC_BYTES_PER_LAUNCH if a.pairs >= 16384 else None,
-                         "launches_per_step": launches, "algorithmic_bytes_per_launch": kb[dom] / launches, "avg_launch_ms": ms[dom] / launches,
+                         "launches_per_step": launches, "pipelines_per_gpu": int(os.environ.get("T1K_PIPELINES", "3")), "algorithmic_bytes_per_launch": kb[dom] / launches, "avg_launch_ms": ms[dom] / launches,
                          "all_kernels_ms_per_step": ms,
                          "all_kernels_algorithmic_GBs": {k: (kb[k] / (ms[k] * 1e-3) / 1e9 if ms[k] > 0 else 0.0) for k in ms},
                          "em_ms": st["ms_em"], "job_ms_total": st["ms_total"]},
