@@ -181,9 +181,18 @@ __global__ __launch_bounds__(WG) void k_extend_retry(ExtendArgs P, const uint32_
 // selection: sort + latch, one workgroup per read-end
 // ------------------------------------------------------------------------------------------------------------------
 
-// bitonic sort of n packed 64-bit entries (sort key in the high bits, payload index in the low bits), n padded to a power of
-// two by the caller with ~0
-__device__ inline void bitonicSort(uint64_t *key, uint32_t np2) {
+// bitonic sort of np2 (a power of two >= 8) packed 64-bit entries (sort key in the high bits, payload index in the low bits), padded
+// by the caller with ~0.  Blocked layout: lane t of the first np2/8 threads keeps entries [8t, 8t + 8) in registers, so the
+// compare-exchange partners are in the same lane for strides < 8, in the same wavefront for strides < 512 (exchanged with
+// ds_bpermute shuffles, no barrier) and only the strides >= 512 go through LDS with workgroup barriers: 10 of the 91 steps at
+// 8192 entries.  All threads of the workgroup must call it.
+__device__ __forceinline__ uint64_t shflXor64(uint64_t v, int laneMask) {
+  const int lo = __shfl_xor((int)(uint32_t)v, laneMask, 64), hi = __shfl_xor((int)(uint32_t)(v >> 32), laneMask, 64);
+  return ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo;
+}
+// plain version (any size, entries in LDS or HBM): one barrier per step
+__device__ inline void bitonicSortSimple(uint64_t *key, uint32_t np2) {
+  __syncthreads();
   for (uint32_t size = 2; size <= np2; size <<= 1) {
     for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
       for (uint32_t t = threadIdx.x; t < np2 / 2; t += blockDim.x) {
@@ -197,6 +206,74 @@ __device__ inline void bitonicSort(uint64_t *key, uint32_t np2) {
       __syncthreads();
     }
   }
+}
+__device__ inline void bitonicSort(uint64_t *key, uint32_t np2) {
+  constexpr int E = 8;
+  if (np2 < E || np2 > blockDim.x * E) { bitonicSortSimple(key, np2); return; }
+  const uint32_t t = threadIdx.x;
+  const bool act = t * E < np2;
+  uint64_t a[E];
+  __syncthreads();
+  if (act) {
+#pragma unroll
+    for (int e = 0; e < E; ++e) a[e] = key[t * E + e];
+  }
+  for (uint32_t size = 2; size <= np2; size <<= 1) {
+    for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+      if (stride >= 64 * E) {  // partner in another wavefront: through LDS
+        if (act) {
+#pragma unroll
+          for (int e = 0; e < E; ++e) key[t * E + e] = a[e];
+        }
+        __syncthreads();
+        if (act) {
+          const uint32_t pt = t ^ (stride / E);
+#pragma unroll
+          for (int e = 0; e < E; ++e) {
+            const uint32_t i = t * E + e;
+            const uint64_t b = key[pt * E + e];
+            const bool up = (i & size) == 0, lower = (i & stride) == 0;
+            const bool keepMin = up == lower;
+            a[e] = keepMin ? (a[e] < b ? a[e] : b) : (a[e] > b ? a[e] : b);
+          }
+        }
+        __syncthreads();
+      } else if (stride >= E) {  // partner lane in the same wavefront
+        if (act) {
+          const int lm = (int)(stride / E);
+#pragma unroll
+          for (int e = 0; e < E; ++e) {
+            const uint32_t i = t * E + e;
+            const uint64_t b = shflXor64(a[e], lm);
+            const bool up = (i & size) == 0, lower = (i & stride) == 0;
+            const bool keepMin = up == lower;
+            a[e] = keepMin ? (a[e] < b ? a[e] : b) : (a[e] > b ? a[e] : b);
+          }
+        }
+      } else if (act) {  // both entries in this lane
+#pragma unroll
+        for (int s = E / 2; s > 0; s >>= 1) {
+          if (stride == (uint32_t)s) {
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+              if ((e & s) == 0) {
+                const uint32_t i = t * E + e;
+                const bool up = (i & size) == 0;
+                const uint64_t x = a[e], y = a[e + s];
+                const bool sw = up ? (x > y) : (x < y);
+                a[e] = sw ? y : x; a[e + s] = sw ? x : y;
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+  if (act) {
+#pragma unroll
+    for (int e = 0; e < E; ++e) key[t * E + e] = a[e];
+  }
+  __syncthreads();
 }
 // entry layout: [0 | 2047 - matchCnt : 11 | span sum : 11 | 511 - read span : 9 | allele : aBits | index : iBits], bit 63 is the
 // emit mark of k_select.  Returns false if a field does not fit.
@@ -265,7 +342,7 @@ __global__ __launch_bounds__(NT) void k_select(SelectArgs P) {
       if (tid == 0) { P.ovlStart[re] = 0; P.ovlCount[re] = 0; }
       continue;
     }
-    uint32_t np2 = 1;
+    uint32_t np2 = 8;
     while (np2 < live) np2 <<= 1;
     uint64_t *key;
     if (np2 <= SELECT_LDS_CAP) key = sKey;
@@ -703,7 +780,7 @@ __global__ __launch_bounds__(NT) void k_truncate(TruncArgs P) {
     const uint32_t n = P.ovlCount[re], o0 = P.ovlStart[re];
     if (n <= 1000) continue;
     if ((n > SELECT_SMALL) != (SELECT_LDS_CAP == SELECT_LARGE)) continue;  // the other instantiation's read-end
-    uint32_t np2 = 1;
+    uint32_t np2 = 8;
     while (np2 < n) np2 <<= 1;
     uint64_t *key;
     uint64_t *wgScratch = P.sortScratch + (uint64_t)blockIdx.x * ((uint64_t)P.sortCap * 6);
