@@ -597,6 +597,19 @@ __global__ __launch_bounds__(64) void k_fullalign_slow(SlowArgs P) {
 // equal-span near-best alignments with more than 3 mismatches: banded DP with the band in registers, decision words in a
 // coalesced global trace, then the reference's traceback walked backwards (AlignAlgo.hpp:323-408) accumulating the relaxed
 // match count and the coverage runs directly (no edit string is materialised).
+// one bit per position of a 2-bit-geometry mask stream, fetched 32 positions at a time (the tracebacks walk downwards)
+struct T1kWinBits {
+  const uint64_t *p;
+  int64_t off;
+  int base;
+  uint64_t w;
+  __device__ T1kWinBits(const uint64_t *p_, int64_t off_) : p(p_), off(off_), base(1 << 30), w(0) {}
+  __device__ __forceinline__ int bit(int pos) {
+    if (pos < base || pos >= base + 32) { base = pos > 31 ? pos - 31 : 0; w = t1k_get32(p, off + base); }
+    return (int)((w >> (2 * (pos - base))) & 1);
+  }
+};
+
 // The traced alignments run in three steps over the SORTED queue (identical jobs are neighbours):
 //   k_align_flags  marks the first job of every run of identical (read window, allele window) jobs; an inclusive scan numbers the runs
 //   k_align_fill   one lane per run: DP sweep, decision words -> trace[row * stride + run]
@@ -655,6 +668,7 @@ __global__ __launch_bounds__(WG) void k_align_apply_eq(SlowArgs P) {
     const int L = o.readEnd - o.readStart + 1;
     const int w = (int)P.reads.weight[o.re];
     int32_t *cov = P.ref.covDiff + goff;
+    T1kWinBits exW(P.ref.exon, goff), gnW(P.ref.nmask, goff), rnW(rn, 0);
     const int alleleLen = (int)P.ref.alleleLen[o.allele];
     int relaxed = 0;
     int runLo = -1, runHi = -1;  // current run of covered reference positions, extended downwards
@@ -677,12 +691,12 @@ __global__ __launch_bounds__(WG) void k_align_apply_eq(SlowArgs P) {
         if (tj > 0) { if (bits & 8) mat = 0; --tj; } else mat = 1;
       }
       if (P.relax) {
-        bool ex = refPos < alleleLen ? t1k_bit(P.ref.exon, goff + refPos) != 0 : false;
+        bool ex = refPos < alleleLen ? exW.bit(refPos) != 0 : false;
         if (!ex || op == 0) ++relaxed;
       }
       if (op == 0 && w) {
         const int readPos = o.readStart + ti;  // ti was already decremented: this column consumed read base ti
-        if (!t1k_bit(rn, readPos) && !t1k_bit(P.ref.nmask, goff + refPos)) {
+        if (!rnW.bit(readPos) && !gnW.bit(refPos)) {
           if (refPos == runLo - 1) runLo = refPos;
           else {
             if (runLo >= 0) { atomicAdd(&cov[runLo], w); atomicAdd(&cov[runHi + 1], -w); }
@@ -714,6 +728,7 @@ __global__ __launch_bounds__(WG) void k_align_apply_band(SlowArgs P) {
     const int w = (int)P.reads.weight[o.re];
     T1kSeqView T{P.ref.bases, P.ref.nmask, goff + o.seqStart}, Pv{rb, rn, (int64_t)o.readStart};
     int32_t *cov = P.ref.covDiff + goff;
+    T1kWinBits exW(P.ref.exon, goff), gnW(P.ref.nmask, goff), rnW(rn, 0);
     const int alleleLen = (int)P.ref.alleleLen[o.allele];
     int relaxed = 0, runLo = -1, runHi = -1;
     int ti = lp, tj = lt, mat = 0;
@@ -734,12 +749,12 @@ __global__ __launch_bounds__(WG) void k_align_apply_band(SlowArgs P) {
         if (tj > 0) { if (bits & 8) mat = 0; --tj; } else mat = 1;
       }
       if (P.relax) {
-        bool ex = refPos < alleleLen ? t1k_bit(P.ref.exon, goff + refPos) != 0 : false;
+        bool ex = refPos < alleleLen ? exW.bit(refPos) != 0 : false;
         if (!ex || op == 0) ++relaxed;
       }
       if (op == 0 && w) {
         const int readPos = o.readStart + ti;
-        if (!t1k_bit(rn, readPos) && !t1k_bit(P.ref.nmask, goff + refPos)) {
+        if (!rnW.bit(readPos) && !gnW.bit(refPos)) {
           if (refPos == runLo - 1) runLo = refPos;
           else {
             if (runLo >= 0) { atomicAdd(&cov[runLo], w); atomicAdd(&cov[runHi + 1], -w); }

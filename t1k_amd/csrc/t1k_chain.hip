@@ -1230,10 +1230,6 @@ __global__ __launch_bounds__(64) void k_chain_big(ChainArgs P, uint32_t nItems) 
 // ------------------------------------------------------------------------------------------------------------------
 // K6: strand vote + copy-out, one workgroup per read-end
 // ------------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void loadCand(const ChainArgs &P, const uint32_t *rec, uint32_t j, uint32_t &w0, uint32_t &w1, uint32_t &w2) {
-  if (rec[3] & 0x40000000u) { const uint32_t *g = P.genCand + ((uint64_t)rec[4] + j) * 6; w0 = g[0]; w1 = g[1]; w2 = g[2]; }
-  else { w0 = rec[4]; w1 = rec[5]; w2 = rec[6]; }
-}
 
 __global__ __launch_bounds__(WG) void k_collect(ChainArgs P) {
   __shared__ uint32_t warpSums[4];
@@ -1250,13 +1246,14 @@ __global__ __launch_bounds__(WG) void k_collect(ChainArgs P) {
       if (gn == 0) break;  // chunks are recorded densely
       for (uint32_t i = tid; i < gn; i += WG) {
         const uint32_t *rec = P.recs + (uint64_t)(g0 + i) * stride;
-        const uint32_t nc = rec[3] & 0x3FFFFFFFu;
-        const int plus = (int)(rec[0] >> 31);
+        const uint4 hd = ((const uint4 *)rec)[0], cw = ((const uint4 *)rec)[1];  // header and inline candidate in two 16-byte loads
+        const uint32_t nc = hd.w & 0x3FFFFFFFu;
+        const int plus = (int)(hd.x >> 31);
         nCand[plus] += nc;
         for (uint32_t j = 0; j < nc; ++j) {
-          uint32_t w0, w1, w2;
-          loadCand(P, rec, j, w0, w1, w2);
-          VoteKey vk = voteKey((int)(w1 >> 20), (int)(w0 & 0xFFF), (int)((w0 >> 12) & 0xFFF), rec[1], plus, (int)(w1 & 0xFFFFF), (int)(w2 & 0xFFFFF));
+          uint32_t w0 = cw.x, w1 = cw.y, w2 = cw.z;
+          if (hd.w & 0x40000000u) { const uint32_t *g = P.genCand + ((uint64_t)cw.x + j) * 6; w0 = g[0]; w1 = g[1]; w2 = g[2]; }
+          VoteKey vk = voteKey((int)(w1 >> 20), (int)(w0 & 0xFFF), (int)((w0 >> 12) & 0xFFF), hd.y, plus, (int)(w1 & 0xFFFFF), (int)(w2 & 0xFFFFF));
           if (vk < best) best = vk;
         }
       }
@@ -1290,14 +1287,15 @@ __global__ __launch_bounds__(WG) void k_collect(ChainArgs P) {
         for (uint32_t i0 = 0; i0 < gn; i0 += WG) {
           const uint32_t i = i0 + tid;
           const uint32_t *rec = P.recs + (uint64_t)(g0 + (i < gn ? i : 0)) * stride;
-          uint32_t nc = i < gn ? (rec[3] & 0x3FFFFFFFu) : 0;
+          const uint4 hd = ((const uint4 *)rec)[0], cw = ((const uint4 *)rec)[1];
+          uint32_t nc = i < gn ? (hd.w & 0x3FFFFFFFu) : 0;
           uint32_t tot;
           uint32_t off = t1k_block_scan_exclusive(nc, warpSums, &tot);
           for (uint32_t j = 0; j < nc; ++j) {
-            uint32_t w0, w1, w2;
-            loadCand(P, rec, j, w0, w1, w2);
+            uint32_t w0 = cw.x, w1 = cw.y, w2 = cw.z;
+            if (hd.w & 0x40000000u) { const uint32_t *g = P.genCand + ((uint64_t)cw.x + j) * 6; w0 = g[0]; w1 = g[1]; w2 = g[2]; }
             T1kCand cd;
-            cd.allele = rec[1] | (winPlus ? 0x80000000u : 0);
+            cd.allele = hd.y | (winPlus ? 0x80000000u : 0);
             cd.readSE = (w0 & 0xFFF) | (((w0 >> 12) & 0xFFF) << 16);
             cd.seqStart = (int)(w1 & 0xFFFFF); cd.seqEnd = (int)(w2 & 0xFFFFF);
             cd.match = (w1 >> 20) | ((w2 >> 20) << 16);
