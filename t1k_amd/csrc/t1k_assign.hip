@@ -495,9 +495,26 @@ __global__ __launch_bounds__(WG) void k_fullalign(FullArgs P) {
   const int L = o.readEnd - o.readStart + 1, Ls = o.seqEnd - o.seqStart + 1;
   const int w = (int)P.reads.weight[o.re];
   bool slow = (L != Ls);
-  int x = 0;
+  int x = 0, exonMis = 0;
+  // one sweep over the windows: mismatch count, and -- kept in registers for the coverage updates below -- the covered-column
+  // words (MATCH column, read base not N (2261-2265); an N allele base never feeds GetSeqMissingBaseCoverage's counter of the
+  // allele's own base, so it is left out)
+  uint64_t covw[10];  // reads are at most 320 bp
   if (!slow) {
-    x = t1k_hamming(rb, rn, o.readStart, P.ref.bases, P.ref.nmask, goff + o.seqStart, L);
+#pragma unroll
+    for (int wi = 0; wi < 10; ++wi) {
+      const int off = wi * 32;
+      covw[wi] = 0;
+      if (off < L) {
+        const uint64_t lm = t1k_lowmask(L - off);
+        const uint64_t rnn = t1k_get32(rn, o.readStart + off), gnn = t1k_get32(P.ref.nmask, goff + o.seqStart + off);
+        const uint64_t xo = t1k_get32(rb, o.readStart + off) ^ t1k_get32(P.ref.bases, goff + o.seqStart + off);
+        const uint64_t mm = (xo | (xo >> 1)) & T1K_EVEN & ~(rnn | gnn) & lm;
+        x += __popcll(mm);
+        if (P.relax) exonMis += __popcll(mm & t1k_get32(P.ref.exon, goff + o.seqStart + off));
+        covw[wi] = T1K_EVEN & lm & ~mm & ~rnn & ~gnn;
+      }
+    }
     if (x > 3) slow = true;
   }
   if (slow) {
@@ -529,26 +546,22 @@ __global__ __launch_bounds__(WG) void k_fullalign(FullArgs P) {
     return;
   }
   // ungapped alignment: columns are MATCH except at the x mismatching positions
-  int exonMis = 0;
   uint64_t carry = 0;  // coverage state of the previous position
   int32_t *diff = P.ref.covDiff + goff + o.seqStart;
-  for (int off = 0; off < L; off += 32) {
-    uint64_t lm = t1k_lowmask(L - off);
-    uint64_t rnn = t1k_get32(rn, o.readStart + off), gnn = t1k_get32(P.ref.nmask, goff + o.seqStart + off);
-    uint64_t xo = t1k_get32(rb, o.readStart + off) ^ t1k_get32(P.ref.bases, goff + o.seqStart + off);
-    uint64_t mm = (xo | (xo >> 1)) & T1K_EVEN & ~(rnn | gnn) & lm;
-    if (P.relax) exonMis += __popcll(mm & t1k_get32(P.ref.exon, goff + o.seqStart + off));
-    // covered: MATCH column, read base not N (2261-2265); an N allele base never feeds GetSeqMissingBaseCoverage's
-    // counter of the allele's own base, so it is left out
-    uint64_t cov = T1K_EVEN & lm & ~mm & ~rnn & ~gnn;
-    uint64_t tr = cov ^ ((cov << 2) | carry);  // positions whose covered state differs from the previous position
-    while (tr) {
-      int b = __ffsll((long long)tr) - 1;
-      tr &= tr - 1;
-      bool on = (cov >> b) & 1;
-      if (w) atomicAdd(&diff[off + (b >> 1)], on ? w : -w);
+#pragma unroll
+  for (int wi = 0; wi < 10; ++wi) {
+    const int off = wi * 32;
+    if (off < L) {
+      const uint64_t cov = covw[wi];
+      uint64_t tr = cov ^ ((cov << 2) | carry);  // positions whose covered state differs from the previous position
+      while (tr) {
+        int b = __ffsll((long long)tr) - 1;
+        tr &= tr - 1;
+        bool on = (cov >> b) & 1;
+        if (w) atomicAdd(&diff[off + (b >> 1)], on ? w : -w);
+      }
+      carry = (cov >> 62) & 1;
     }
-    carry = (cov >> 62) & 1;
   }
   if (carry && w) atomicAdd(&diff[L], -w);  // a run reaching the last position of a full final word closes at L
   int relaxed = P.relax ? 2 * (L - exonMis) : (int)o.matchCnt;  // 2215-2250
