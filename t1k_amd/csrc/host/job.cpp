@@ -94,7 +94,7 @@ int t1k_job_create(const t1k_job_params *p, const char *refFasta, t1k_job **out)
   // Most kernels of the path are latency-bound; a second, independent pipeline (context, stream, arenas) on the same GPU lets
   // the hardware overlap two batches.  T1K_PIPELINES=1 turns it off.
   const char *pl = getenv("T1K_PIPELINES");
-  const int nPipe = pl ? std::max(1, std::min(8, atoi(pl))) : 3;
+  const int nPipe = pl ? std::max(1, std::min(8, atoi(pl))) : 4;
   for (int i = 1; i < nPipe; ++i) {
     t1k_ctx *c = nullptr;
     rc = t1k_ctx_create(job->prm.device, &job->prm.dev, &c);

@@ -101,6 +101,7 @@ static void freeBuf(T1kDevBuf &b) {
 }
 
 void t1k_ctx_destroy(t1k_ctx *ctx) {
+  if (ctx && ctx->emPinned) { (void)hipHostFree(ctx->emPinned); ctx->emPinned = nullptr; }
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   for (auto &b : ctx->refBufs) freeBuf(b);

@@ -222,7 +222,16 @@ int t1k_em_update(t1k_ctx *ctx, const double *x0, double *x1, double *ecReadCoun
   T1K_HIP(ctx, hipSetDevice(ctx->device));
   const uint32_t E = ctx->emEc, G = ctx->emGroups;
   if (E == 0) { if (diff) *diff = 0; return T1K_OK; }
-  T1K_HIP(ctx, hipMemcpyAsync(ctx->bEmX0.p, x0, (size_t)E * 8, hipMemcpyHostToDevice, ctx->stream));
+  // the vectors are small (8 B per class) but there are ~40 updates per job: page-locked staging keeps each copy a plain DMA
+  if (ctx->emPinnedN < E) {
+    if (ctx->emPinned) (void)hipHostFree(ctx->emPinned);
+    ctx->emPinned = nullptr; ctx->emPinnedN = 0;
+    T1K_HIP(ctx, hipHostMalloc((void **)&ctx->emPinned, (size_t)E * 16, hipHostMallocDefault));
+    ctx->emPinnedN = E;
+  }
+  double *px = ctx->emPinned, *pn = ctx->emPinned + ctx->emPinnedN;
+  memcpy(px, x0, (size_t)E * 8);
+  T1K_HIP(ctx, hipMemcpyAsync(ctx->bEmX0.p, px, (size_t)E * 8, hipMemcpyHostToDevice, ctx->stream));
   if (G) hipLaunchKernelGGL(k_em_rows, dim3((G + 255) / 256), dim3(256), 0, ctx->stream, (const uint64_t *)ctx->bEmRowPtr.p, (const uint32_t *)ctx->bEmEc.p,
                             (const uint64_t *)ctx->bEmColIdx.p, (const double *)ctx->bEmCount.p, (const double *)ctx->bEmX0.p, (double *)ctx->bEmContrib.p, G);
   hipLaunchKernelGGL(k_em_cols, dim3((E + 63) / 64), dim3(64), 0, ctx->stream, (const uint64_t *)ctx->bEmColPtr.p, (const double *)ctx->bEmContrib.p,
@@ -231,8 +240,9 @@ int t1k_em_update(t1k_ctx *ctx, const double *x0, double *x1, double *ecReadCoun
     T1K_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->emAllreduce(ctx->bEmN.p, E, ctx->emUser);  // RCCL all-reduce of the per-class expected read counts
   }
-  T1K_HIP(ctx, hipMemcpyAsync(ecReadCount, ctx->bEmN.p, (size_t)E * 8, hipMemcpyDeviceToHost, ctx->stream));
+  T1K_HIP(ctx, hipMemcpyAsync(pn, ctx->bEmN.p, (size_t)E * 8, hipMemcpyDeviceToHost, ctx->stream));
   T1K_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  memcpy(ecReadCount, pn, (size_t)E * 8);
   // M-step (Genotyper.hpp:406-420), same summation order as the reference
   double norm = 0, d = 0;
   for (uint32_t i = 0; i < E; ++i) norm += ecReadCount[i] / ctx->hEmLen[i];
