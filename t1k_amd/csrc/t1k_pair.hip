@@ -32,6 +32,7 @@ struct PairArgs {
   t1k_row_entry *rows; uint64_t rowCap;
   uint32_t *rowStart, *rowCount; uint8_t *fragAssigned;
   uint64_t *tab2, *tabSlot;        // [wg][nAlleles]  (epoch << 32 | value)
+  uint32_t epochBase;              // epoch of fragment f = epochBase + f + 1 (never 0, never reused between clears)
   Frag *frags; uint32_t fragCap;   // [wg][fragCap]
   uint32_t *keep;                  // [wg][fragCap]
   unsigned long long *counters;    // [2] error flags, [9] row total
@@ -135,7 +136,7 @@ __global__ __launch_bounds__(WG) void k_pair(PairArgs P) {
   Frag *frags = P.frags + (uint64_t)blockIdx.x * P.fragCap;
   uint32_t *keep = P.keep + (uint64_t)blockIdx.x * P.fragCap;
   for (uint32_t f = blockIdx.x; f < P.nFragments; f += gridDim.x) {
-    const uint64_t epoch = (uint64_t)(f + 1) << 32;
+    const uint64_t epoch = (uint64_t)(P.epochBase + f + 1) << 32;
     const bool paired = P.end2 != nullptr;
     const uint32_t e1 = P.end1[f];
     const uint32_t n1 = P.ovlCount[e1];
@@ -391,7 +392,7 @@ int t1k_pair_batch(t1k_ctx *ctx, const uint32_t *end1, const uint32_t *end2, con
   T1K_HIP(ctx, hipSetDevice(ctx->device));
   int rc;
   const uint32_t n = nFragments;
-  const int nWg = (int)std::min<uint32_t>(512, std::max<uint32_t>(n, 1));
+  const int nWg = (int)std::min<uint32_t>(2048, std::max<uint32_t>(n, 1));  // the kernel is latency-bound: fill the wave slots
   const uint32_t fragCap = 1u << 16;
   const uint32_t A = ctx->ref.nAlleles;
   ctx->nFragments = n;
@@ -416,12 +417,17 @@ int t1k_pair_batch(t1k_ctx *ctx, const uint32_t *end1, const uint32_t *end2, con
   else T1K_HIP(ctx, hipMemsetAsync(ctx->bHasN.p, 0, (size_t)n, ctx->stream));
   T1K_HIP(ctx, hipMemsetAsync((char *)ctx->bCounters.p + 2 * 8, 0, 8, ctx->stream));
   T1K_HIP(ctx, hipMemsetAsync((char *)ctx->bCounters.p + 9 * 8, 0, 8, ctx->stream));
-  // the epoch of fragment f is f+1: a new batch reuses small epochs, so the tables are cleared per call
-  T1K_HIP(ctx, hipMemsetAsync(ctx->bPairScratch.p, 0, (size_t)nWg * (size_t)A * 16, ctx->stream));
+  // the epoch of fragment f is epochBase + f + 1; the base moves on with every call, so the tables only need clearing when the
+  // 32-bit epoch space is about to wrap (or the scratch was just allocated)
+  if (fresh || ctx->pairEpoch > 0xFFFFFFFFull - 2ull * n - 2) {
+    T1K_HIP(ctx, hipMemsetAsync(ctx->bPairScratch.p, 0, (size_t)nWg * (size_t)A * 16, ctx->stream));
+    ctx->pairEpoch = 0;
+  }
   PairArgs p{};
   p.ref = ctx->ref;
   p.ovl = (const T1kOvl *)ctx->bOvl.p; p.ovlStart = (const uint32_t *)ctx->bOvlStart.p; p.ovlCount = (const uint32_t *)ctx->bOvlCount.p;
   p.end1 = (const uint32_t *)ctx->bEnd1.p; p.end2 = end2 ? (const uint32_t *)ctx->bEnd2.p : nullptr; p.hasN = (const uint8_t *)ctx->bHasN.p;
+  p.epochBase = (uint32_t)ctx->pairEpoch; ctx->pairEpoch += n;
   p.nFragments = n; p.sim = ctx->prm.ref_seq_similarity; p.relax = ctx->prm.relax_intron_align; p.maxAssign = ctx->prm.max_assign_cnt;
   p.hitLenRequired = ctx->prm.hit_len_required;
   p.rows = (t1k_row_entry *)ctx->bRows.p; p.rowCap = (uint64_t)ctx->prm.row_cap;
