@@ -585,7 +585,7 @@ struct t1k_ctx {
   uint32_t rangeCount = 0;       // read-ends of the last t1k_assign_range
   // assignment arenas
   T1kDevBuf bWgHits, bWgGroups, bWgStage, bWgThreadScratch, bWgBig, bWgCache, bLists;
-  T1kDevBuf bCand, bExt, bCandStart, bCandCount, bOvl, bOvlStart, bOvlCount, bCounters, bSlowQueue, bSlowScratch, bSortScratch, bEqTrace, bSortTmp, bSlowKeys;
+  T1kDevBuf bCand, bExt, bCandStart, bCandCount, bOvl, bOvlStart, bOvlCount, bCounters, bSlowQueue, bSlowScratch, bSortScratch, bEqTrace, bSortTmp, bSlowKeys, bJobSort;
   uint64_t nCand = 0, nOvl = 0;
   // pairing
   T1kDevBuf bEnd1, bEnd2, bHasN, bRows, bRowStart, bRowCount, bFragAssigned, bPairScratch;

@@ -112,5 +112,5 @@ void t1k_launch_coverage_add(t1k_ctx *ctx, int32_t *dst, int32_t *src, uint64_t 
 void t1k_launch_extend_retry(t1k_ctx *ctx, const ExtendArgs &a, const uint32_t *list, uint32_t n);
 void t1k_launch_dp_dense(t1k_ctx *ctx, const ChainArgs &a, const uint32_t *jobs, uint32_t n);
 void t1k_arena_compact64(t1k_ctx *ctx, int arena, const unsigned long long *src, uint32_t segCap, unsigned long long *dst, uint32_t maxSeg);
-int t1k_sort_pairs(t1k_ctx *ctx, const unsigned long long *keysIn, unsigned long long *keysOut, const uint32_t *valsIn, uint32_t *valsOut, uint32_t n);
+int t1k_sort_pairs(t1k_ctx *ctx, const unsigned long long *keysIn, unsigned long long *keysOut, const uint32_t *valsIn, uint32_t *valsOut, uint32_t n, int endBit = 64);
 void t1k_arena_compact(t1k_ctx *ctx, int arena, const uint32_t *src, uint32_t segCap, uint32_t *dst, uint32_t maxSeg);

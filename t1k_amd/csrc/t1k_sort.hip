@@ -4,13 +4,13 @@
 #include "t1k_dev.h"
 #include "t1k_launch.h"
 
-int t1k_sort_pairs(t1k_ctx *ctx, const unsigned long long *keysIn, unsigned long long *keysOut, const uint32_t *valsIn, uint32_t *valsOut, uint32_t n) {
+int t1k_sort_pairs(t1k_ctx *ctx, const unsigned long long *keysIn, unsigned long long *keysOut, const uint32_t *valsIn, uint32_t *valsOut, uint32_t n, int endBit) {
   if (!n) return T1K_OK;
   size_t bytes = 0;
-  T1K_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, keysIn, keysOut, valsIn, valsOut, n, 0, 64, ctx->stream));
+  T1K_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, keysIn, keysOut, valsIn, valsOut, n, 0, endBit, ctx->stream));
   int rc = t1k_ensure(ctx, ctx->bSortTmp, bytes + 256);
   if (rc) return rc;
-  T1K_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(ctx->bSortTmp.p, bytes, keysIn, keysOut, valsIn, valsOut, n, 0, 64, ctx->stream));
+  T1K_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(ctx->bSortTmp.p, bytes, keysIn, keysOut, valsIn, valsOut, n, 0, endBit, ctx->stream));
   return T1K_OK;
 }
 
