@@ -7,15 +7,17 @@
 #include <set>
 #include "t1k_host.h"
 
+#include <chrono>
 #include <thread>
 
 namespace {
+double hostNowMs() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 // static-chunk parallel loop over [0, n) on the host cores (the per-allele / per-class post-processing is embarrassingly parallel)
 template <class F>
-void parallelFor(size_t n, F fn) {
+void parallelFor(size_t n, F fn, size_t serialBelow = 256) {
   unsigned T = std::thread::hardware_concurrency();
   if (T > 16) T = 16;
-  if (T < 2 || n < 256) { for (size_t i = 0; i < n; ++i) fn(i); return; }
+  if (T < 2 || n < serialBelow || n < 2) { for (size_t i = 0; i < n; ++i) fn(i); return; }
   std::vector<std::thread> th;
   const size_t chunk = (n + T - 1) / T;
   for (unsigned t = 0; t < T; ++t) {
@@ -95,26 +97,51 @@ void Genotyper::absorb(const GroupEntry *ent, uint32_t n) {
 // SeqSet::GetSeqMissingBaseCoverage SeqSet.hpp:2717-2755)
 // ------------------------------------------------------------------------------------------------------------------
 void Genotyper::finalize(const std::vector<int32_t> &coverage) {
+  const double tf0 = hostNowMs();
   RefSet &R = *ref;
   const int A = (int)R.al.size();
   const int G = (int)nGroups();
-  inAllele.assign(A, {});
   sumAssign = 0;
-  for (int g = 0; g < G; ++g) {
-    sumAssign += (double)(groupPtr[g + 1] - groupPtr[g]);
-    for (uint64_t p = groupPtr[g]; p < groupPtr[g + 1]; ++p) inAllele[groupEnt[p].allele].push_back({g, (int)(p - groupPtr[g])});
+  for (int g = 0; g < G; ++g) sumAssign += (double)(groupPtr[g + 1] - groupPtr[g]);
+  // allele -> (group, slot) lists in group order: the groups are cut into one contiguous piece per thread; per-piece counts give
+  // every piece its own range inside each allele's list, so the pieces fill in parallel and the order stays the sequential one
+  {
+    unsigned T = std::thread::hardware_concurrency();
+    if (T > 16) T = 16;
+    if (T < 1 || G < 4096) T = 1;
+    const size_t piece = ((size_t)G + T - 1) / T;
+    std::vector<std::vector<uint32_t>> cnt(T, std::vector<uint32_t>((size_t)A, 0));
+    parallelFor(T, [&](size_t t) {
+      const size_t g0 = t * piece, g1 = std::min((size_t)G, g0 + piece);
+      for (size_t g = g0; g < g1; ++g)
+        for (uint64_t p = groupPtr[g]; p < groupPtr[g + 1]; ++p) ++cnt[t][groupEnt[p].allele];
+    }, 1);
+    inAllele.assign(A, {});
+    parallelFor((size_t)A, [&](size_t a) {
+      uint32_t run = 0;
+      for (unsigned t = 0; t < T; ++t) { const uint32_t c = cnt[t][a]; cnt[t][a] = run; run += c; }
+      inAllele[a].resize(run);
+    });
+    parallelFor(T, [&](size_t t) {
+      const size_t g0 = t * piece, g1 = std::min((size_t)G, g0 + piece);
+      for (size_t g = g0; g < g1; ++g)
+        for (uint64_t p = groupPtr[g]; p < groupPtr[g + 1]; ++p) {
+          const int a = groupEnt[p].allele;
+          inAllele[a][cnt[t][a]++] = {(int)g, (int)(p - groupPtr[g])};
+        }
+    }, 1);
   }
   struct Key { int allele, fp; };
   std::vector<Key> keys(A);
-  for (int a = 0; a < A; ++a) {
+  parallelFor((size_t)A, [&](size_t a) {
     R.al[a].ec = -1;
     int fp = -1;
     if (!inAllele[a].empty()) {
       fp = 0;
       for (auto &gs : inAllele[a]) fp = (int)(((uint32_t)fp * (uint32_t)G + (uint32_t)gs.first) % 1000003u);  // uint32 wrap-around is part of the order
     }
-    keys[a] = Key{a, fp};
-  }
+    keys[a] = Key{(int)a, fp};
+  });
   std::sort(keys.begin(), keys.end(), [](const Key &x, const Key &y) { return x.fp != y.fp ? y.fp < x.fp : x.allele < y.allele; });
   ecAlleles.clear();
   auto sameGroups = [&](int a, int b) {
@@ -132,6 +159,7 @@ void Genotyper::finalize(const std::vector<int32_t> &coverage) {
   }
   // RemoveLowMAPQAlleleInEquivalentClass (1330-1368) keeps everything: all assignment qualities are 1 and class members
   // share their group lists.
+  const double tf1 = hostNowMs();
   std::vector<uint64_t> covOff(A + 1, 0);
   for (int a = 0; a < A; ++a) covOff[a + 1] = covOff[a] + (uint64_t)R.al[a].seqLen;
   parallelFor((size_t)A, [&](size_t a) {
@@ -151,6 +179,7 @@ void Genotyper::finalize(const std::vector<int32_t> &coverage) {
     }
     R.al[a].missingCov = miss;
   });
+  if (getenv("T1K_DEBUG_PHASES")) fprintf(stderr, "[t1k host] finalize: group lists + classes %.1f ms, coverage medians %.1f ms\n", tf1 - tf0, hostNowMs() - tf1);
 }
 
 void Genotyper::setAbundance(const double *n, const std::vector<int> &ecLen) {
@@ -177,6 +206,7 @@ void Genotyper::setAbundance(const double *n, const std::vector<int> &ecLen) {
 // QuantifyAlleleEquivalentClass (Genotyper.hpp:1142-1328): SQUAREM-accelerated EM; every EMupdate is t1k_em_update
 // ------------------------------------------------------------------------------------------------------------------
 int Genotyper::quantify(t1k_ctx *ctx, t1k_allreduce_fn cb, void *user, std::string &err, uint64_t gBegin, uint64_t gEnd) {
+  const double tq0 = hostNowMs();
   RefSet &R = *ref;
   const size_t E = ecAlleles.size(), Gall = nGroups();
   if (gEnd > Gall) gEnd = Gall;
@@ -206,10 +236,12 @@ int Genotyper::quantify(t1k_ctx *ctx, t1k_allreduce_fn cb, void *user, std::stri
     for (int a : ecAlleles[e]) len = std::min(len, R.al[a].effLen);
     ecLen[e] = len;
   }
+  const double tq1 = hostNowMs();
   if (t1k_em_setup(ctx, rowPtr.data(), ecIdx.data(), count.data(), ecLen.data(), (uint32_t)G, (uint32_t)E, cb, user) != T1K_OK) {
     err = t1k_last_error(ctx);
     return -1;
   }
+  const double tq2 = hostNowMs();
   std::vector<double> x0(E), x1(E), x2(E), x3(E), n(E);
   for (size_t e = 0; e < E; ++e) {
     x0[e] = 0;
@@ -247,6 +279,7 @@ int Genotyper::quantify(t1k_ctx *ctx, t1k_allreduce_fn cb, void *user, std::stri
   }
   setAbundance(n.data(), ecLen);
   emIterations = rounds;
+  if (getenv("T1K_DEBUG_PHASES")) fprintf(stderr, "[t1k host] quantify: rows %.1f ms, setup %.1f ms (nnz %zu), iterations %.1f ms\n", tq1 - tq0, tq2 - tq1, ecIdx.size(), hostNowMs() - tq2);
   return rounds;
 }
 

@@ -14,25 +14,49 @@
 #include "t1k_dev.h"
 #include "t1k_launch.h"
 
-__global__ void k_em_rows(const uint64_t *rowPtr, const uint32_t *ecIdx, const uint64_t *cscPos, const double *count, const double *x, double *contrib,
-                          uint32_t nGroups) {
-  uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= nGroups) return;
-  uint64_t b = rowPtr[g], e = rowPtr[g + 1];
-  double psum = 0;
-  for (uint64_t p = b; p < e; ++p) psum += x[ecIdx[p]];
-  if (psum == 0) psum = 1;
-  const double c = count[g];
-  for (uint64_t p = b; p < e; ++p) contrib[cscPos[p]] = c * (x[ecIdx[p]] / psum);
+// acc + v(lane 0) + v(lane 1) + ... + v(lane cnt-1), added strictly in that order (the floating-point sums of the EM must follow
+// the reference's order); the loop is uniform, the operands come out of the lanes with v_readlane
+__device__ __forceinline__ double waveOrderedSum(double v, int cnt, double acc) {
+  const long long bits = __double_as_longlong(v);
+  const int lo = (int)(uint32_t)bits, hi = (int)(uint32_t)((unsigned long long)bits >> 32);
+  for (int j = 0; j < cnt; ++j) {
+    const uint32_t l = (uint32_t)__builtin_amdgcn_readlane(lo, j), h = (uint32_t)__builtin_amdgcn_readlane(hi, j);
+    acc += __longlong_as_double((long long)(((unsigned long long)h << 32) | l));
+  }
+  return acc;
 }
 
-__global__ void k_em_cols(const uint64_t *colPtr, const double *contrib, double *n, uint32_t nEc) {
-  uint32_t ec = blockIdx.x * blockDim.x + threadIdx.x;
+// one wavefront per read group: the lanes gather the row's class abundances together, the sum is taken in row order
+__global__ __launch_bounds__(256) void k_em_rows(const uint64_t *rowPtr, const uint32_t *ecIdx, const uint64_t *cscPos, const double *count, const double *x, double *contrib,
+                          uint32_t nGroups) {
+  const uint32_t g = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (g >= nGroups) return;
+  const uint64_t b = rowPtr[g], e = rowPtr[g + 1];
+  double psum = 0;
+  for (uint64_t base = b; base < e; base += 64) {
+    const uint64_t p = base + lane;
+    const double v = p < e ? x[ecIdx[p]] : 0.0;
+    psum = waveOrderedSum(v, (int)(e - base < 64 ? e - base : 64), psum);
+  }
+  if (psum == 0) psum = 1;
+  const double c = count[g];
+  for (uint64_t p = b + lane; p < e; p += 64) contrib[cscPos[p]] = c * (x[ecIdx[p]] / psum);
+}
+
+// one wavefront per class: its contributions are added in group order
+__global__ __launch_bounds__(256) void k_em_cols(const uint64_t *colPtr, const double *contrib, double *n, uint32_t nEc) {
+  const uint32_t ec = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
   if (ec >= nEc) return;
-  uint64_t b = colPtr[ec], e = colPtr[ec + 1];
+  const uint64_t b = colPtr[ec], e = colPtr[ec + 1];
   double s = 0;
-  for (uint64_t p = b; p < e; ++p) s += contrib[p];
-  n[ec] = s;
+  for (uint64_t base = b; base < e; base += 64) {
+    const uint64_t p = base + lane;
+    const double v = p < e ? contrib[p] : 0.0;
+    s = waveOrderedSum(v, (int)(e - base < 64 ? e - base : 64), s);
+  }
+  if (lane == 0) n[ec] = s;
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -232,9 +256,9 @@ int t1k_em_update(t1k_ctx *ctx, const double *x0, double *x1, double *ecReadCoun
   double *px = ctx->emPinned, *pn = ctx->emPinned + ctx->emPinnedN;
   memcpy(px, x0, (size_t)E * 8);
   T1K_HIP(ctx, hipMemcpyAsync(ctx->bEmX0.p, px, (size_t)E * 8, hipMemcpyHostToDevice, ctx->stream));
-  if (G) hipLaunchKernelGGL(k_em_rows, dim3((G + 255) / 256), dim3(256), 0, ctx->stream, (const uint64_t *)ctx->bEmRowPtr.p, (const uint32_t *)ctx->bEmEc.p,
+  if (G) hipLaunchKernelGGL(k_em_rows, dim3((G + 3) / 4), dim3(256), 0, ctx->stream, (const uint64_t *)ctx->bEmRowPtr.p, (const uint32_t *)ctx->bEmEc.p,
                             (const uint64_t *)ctx->bEmColIdx.p, (const double *)ctx->bEmCount.p, (const double *)ctx->bEmX0.p, (double *)ctx->bEmContrib.p, G);
-  hipLaunchKernelGGL(k_em_cols, dim3((E + 63) / 64), dim3(64), 0, ctx->stream, (const uint64_t *)ctx->bEmColPtr.p, (const double *)ctx->bEmContrib.p,
+  hipLaunchKernelGGL(k_em_cols, dim3((E + 3) / 4), dim3(256), 0, ctx->stream, (const uint64_t *)ctx->bEmColPtr.p, (const double *)ctx->bEmContrib.p,
                      (double *)ctx->bEmN.p, E);
   if (ctx->emAllreduce) {
     T1K_HIP(ctx, hipStreamSynchronize(ctx->stream));
