@@ -107,6 +107,9 @@ int t1k_rows_download(t1k_ctx *ctx, uint32_t *rowCounts, uint8_t *fragAssigned, 
  * GetSeqMissingBaseCoverage 2717-2755).  out[sum of allele lengths], alleles concatenated in upload order. */
 int t1k_coverage_get(t1k_ctx *ctx, int32_t *out, uint64_t cap);
 int t1k_coverage_reset(t1k_ctx *ctx);
+/* per allele: number of exon positions whose coverage is below max(1, 1 % of the allele's median exon coverage)
+ * (SeqSet::GetSeqMissingBaseCoverage, SeqSet.hpp:2717-2755), computed on the device; missing[nAlleles] */
+int t1k_missing_coverage(t1k_ctx *ctx, int32_t *missing);
 /* adds src's coverage into dst's and clears src's; both contexts must live on the same device and hold the same reference */
 int t1k_coverage_absorb(t1k_ctx *dst, t1k_ctx *src);
 

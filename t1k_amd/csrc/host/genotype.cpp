@@ -96,7 +96,7 @@ void Genotyper::absorb(const GroupEntry *ent, uint32_t n) {
 // FinalizeReadAssignments -> BuildAlleleEquivalentClass + missing coverage (Genotyper.hpp:912-939, 1072-1139;
 // SeqSet::GetSeqMissingBaseCoverage SeqSet.hpp:2717-2755)
 // ------------------------------------------------------------------------------------------------------------------
-void Genotyper::finalize(const std::vector<int32_t> &coverage) {
+void Genotyper::finalize(const std::vector<int32_t> &missing) {
   const double tf0 = hostNowMs();
   RefSet &R = *ref;
   const int A = (int)R.al.size();
@@ -160,26 +160,8 @@ void Genotyper::finalize(const std::vector<int32_t> &coverage) {
   // RemoveLowMAPQAlleleInEquivalentClass (1330-1368) keeps everything: all assignment qualities are 1 and class members
   // share their group lists.
   const double tf1 = hostNowMs();
-  std::vector<uint64_t> covOff(A + 1, 0);
-  for (int a = 0; a < A; ++a) covOff[a + 1] = covOff[a] + (uint64_t)R.al[a].seqLen;
-  parallelFor((size_t)A, [&](size_t a) {
-    std::vector<int> ex;
-    const int L = R.al[a].seqLen;
-    const uint64_t off = covOff[a];
-    for (int p = 0; p < L; ++p)
-      if (R.exon[a][p]) ex.push_back(coverage[off + p]);
-    int miss = 0;
-    if (!ex.empty()) {
-      // the reference sorts and scans (SeqSet.hpp:2733-2741); only the median and the number of values below the cutoff
-      // matter, which selection + counting give without the full sort
-      std::nth_element(ex.begin(), ex.begin() + ex.size() / 2, ex.end());
-      double cutoff = ex[ex.size() / 2] * 0.01;
-      if (cutoff < 1) cutoff = 1;
-      for (int v : ex) miss += !(v >= cutoff);
-    }
-    R.al[a].missingCov = miss;
-  });
-  if (getenv("T1K_DEBUG_PHASES")) fprintf(stderr, "[t1k host] finalize: group lists + classes %.1f ms, coverage medians %.1f ms\n", tf1 - tf0, hostNowMs() - tf1);
+  for (int a = 0; a < A; ++a) R.al[a].missingCov = missing[a];  // GetSeqMissingBaseCoverage, computed on the device
+  if (getenv("T1K_DEBUG_PHASES")) fprintf(stderr, "[t1k host] finalize: group lists + classes %.1f ms, rest %.1f ms\n", tf1 - tf0, hostNowMs() - tf1);
 }
 
 void Genotyper::setAbundance(const double *n, const std::vector<int> &ecLen) {

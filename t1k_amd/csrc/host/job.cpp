@@ -350,13 +350,8 @@ int t1k_job_finish(t1k_job *job, uint64_t emGroupBegin, uint64_t emGroupEnd) {
   Genotyper &gt = job->gt;
   int rc;
   double t2 = nowMs();
-  std::vector<int32_t> cov;
-  {
-    uint64_t tot = 0;
-    for (auto &a : job->ref.al) tot += a.seqLen;
-    cov.resize(tot);
-    if ((rc = t1k_coverage_get(job->ctx, cov.data(), tot)) != T1K_OK) return jobFail(job, rc, t1k_last_error(job->ctx));
-  }
+  std::vector<int32_t> cov(job->ref.al.size());  // per allele: exon positions with too little coverage
+  if ((rc = t1k_missing_coverage(job->ctx, cov.data())) != T1K_OK) return jobFail(job, rc, t1k_last_error(job->ctx));
   gt.finalize(cov);
   double t3 = nowMs();
   if (!job->abundanceFile.empty()) {

@@ -65,7 +65,7 @@ struct Genotyper {
 
   size_t nGroups() const { return groupPtr.size() - 1; }
   void coalesce(t1k_row_entry *row, uint32_t n);             // CoalesceReadAssignments (841-908), one fragment
-  void finalize(const std::vector<int32_t> &coverage);       // FinalizeReadAssignments (912-939)
+  void finalize(const std::vector<int32_t> &missing);        // FinalizeReadAssignments (912-939); missing[a] from t1k_missing_coverage
   // QuantifyAlleleEquivalentClass (1142-1328); the E-step covers groups [gBegin, gEnd) (the whole table on one GPU)
   int quantify(t1k_ctx *ctx, t1k_allreduce_fn cb, void *user, std::string &err, uint64_t gBegin = 0, uint64_t gEnd = ~0ull);
   void absorb(const GroupEntry *ent, uint32_t n);               // merge one already-coalesced group of another shard

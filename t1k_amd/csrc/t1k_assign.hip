@@ -946,6 +946,71 @@ __global__ __launch_bounds__(WG) void k_coverage_add(int32_t *dst, int32_t *src,
 void t1k_launch_coverage_add(t1k_ctx *ctx, int32_t *dst, int32_t *src, uint64_t n) {
   hipLaunchKernelGGL(k_coverage_add, dim3((unsigned)((n + WG - 1) / WG)), dim3(WG), 0, ctx->stream, dst, src, n);
 }
+// GetSeqMissingBaseCoverage on the device (SeqSet.hpp:2717-2755): per allele, the coverage of its exon positions; median by radix
+// selection (the reference sorts and takes element size/2), cutoff = max(1, 1 % of the median), missing = positions below it.
+// scratch: one int per reference position (the prefix-summed coverage of the allele under construction)
+__global__ __launch_bounds__(WG) void k_missing_coverage(T1kRefDev ref, int32_t *scratch, int32_t *missing) {
+  const uint32_t a = blockIdx.x;
+  if (a >= ref.nAlleles) return;
+  __shared__ uint32_t warpSums[4];
+  __shared__ int32_t sCarry;
+  __shared__ uint32_t sCnt;
+  const int tid = threadIdx.x;
+  const int len = (int)ref.alleleLen[a];
+  const int64_t g0 = (int64_t)ref.alleleOff[a];
+  const int32_t *d = ref.covDiff + g0;
+  int32_t *cv = scratch + g0;
+  if (tid == 0) sCarry = 0;
+  __syncthreads();
+  for (int base = 0; base < len; base += WG) {  // coverage = prefix sum of the difference array
+    const int i = base + tid;
+    const int32_t v = i < len ? d[i] : 0;
+    uint32_t tot;
+    const uint32_t ex = t1k_block_scan_exclusive((uint32_t)v, warpSums, &tot);
+    if (i < len) cv[i] = (int32_t)ex + v + sCarry;
+    __syncthreads();
+    if (tid == 0) sCarry += (int32_t)tot;
+    __syncthreads();
+  }
+  auto blockCount = [&](uint32_t mine) -> uint32_t {  // sum over the workgroup, returned to every thread
+    for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o, 64);
+    if (tid == 0) sCnt = 0;
+    __syncthreads();
+    if ((tid & 63) == 0 && mine) atomicAdd(&sCnt, mine);
+    __syncthreads();
+    const uint32_t r = sCnt;
+    __syncthreads();
+    return r;
+  };
+  uint32_t mine = 0;
+  for (int i = tid; i < len; i += WG) mine += (uint32_t)t1k_bit(ref.exon, g0 + i);
+  const uint32_t nEx = blockCount(mine);
+  if (nEx == 0) { if (tid == 0) missing[a] = 0; return; }
+  // element nEx / 2 of the sorted exon coverages: fix the bits from the top (values mapped order-preservingly to unsigned)
+  uint32_t k = nEx / 2, prefix = 0;
+  for (int bit = 31; bit >= 0; --bit) {
+    const uint32_t hiMask = bit == 31 ? 0u : ~0u << (bit + 1);
+    uint32_t zeros = 0;
+    for (int i = tid; i < len; i += WG) {
+      if (!t1k_bit(ref.exon, g0 + i)) continue;
+      const uint32_t u = (uint32_t)cv[i] ^ 0x80000000u;
+      if ((u & hiMask) == (prefix & hiMask) && !((u >> bit) & 1u)) ++zeros;
+    }
+    zeros = blockCount(zeros);
+    if (k >= zeros) { k -= zeros; prefix |= 1u << bit; }
+  }
+  const int32_t median = (int32_t)(prefix ^ 0x80000000u);
+  double cutoff = median * 0.01;
+  if (cutoff < 1) cutoff = 1;
+  mine = 0;
+  for (int i = tid; i < len; i += WG)
+    if (t1k_bit(ref.exon, g0 + i) && !((double)cv[i] >= cutoff)) ++mine;
+  const uint32_t miss = blockCount(mine);
+  if (tid == 0) missing[a] = (int32_t)miss;
+}
+void t1k_launch_missing_coverage(t1k_ctx *ctx, const T1kRefDev &ref, int32_t *scratch, int32_t *missing) {
+  hipLaunchKernelGGL(k_missing_coverage, dim3(ref.nAlleles), dim3(WG), 0, ctx->stream, ref, scratch, missing);
+}
 void t1k_launch_coverage_scan(t1k_ctx *ctx, const T1kRefDev &ref, int32_t *out, const uint64_t *outOff) {
   hipLaunchKernelGGL(k_coverage_scan, dim3(ref.nAlleles), dim3(WG), 0, ctx->stream, ref, out, outOff);
 }

@@ -238,6 +238,21 @@ int t1k_ref_upload(t1k_ctx *ctx, const char *seqs, const uint64_t *offsets, cons
   return T1K_OK;
 }
 
+int t1k_missing_coverage(t1k_ctx *ctx, int32_t *missing) {
+  if (!ctx || !ctx->ref.covDiff || !missing) return t1k_fail(ctx, T1K_ERR_STATE, "no reference");
+  T1K_HIP(ctx, hipSetDevice(ctx->device));
+  const uint32_t A = ctx->ref.nAlleles;
+  T1kDevBuf dScratch, dMiss;
+  int rc;
+  if ((rc = t1k_ensure(ctx, dScratch, (ctx->ref.totalBases + 2) * 4))) return rc;
+  if ((rc = t1k_ensure(ctx, dMiss, (size_t)A * 4))) { freeBuf(dScratch); return rc; }
+  t1k_launch_missing_coverage(ctx, ctx->ref, (int32_t *)dScratch.p, (int32_t *)dMiss.p);
+  hipMemcpyAsync(missing, dMiss.p, (size_t)A * 4, hipMemcpyDeviceToHost, ctx->stream);
+  hipError_t e = hipStreamSynchronize(ctx->stream);
+  freeBuf(dScratch); freeBuf(dMiss);
+  if (e != hipSuccess) return t1k_fail(ctx, T1K_ERR_DEVICE, hipGetErrorString(e));
+  return T1K_OK;
+}
 int t1k_coverage_device(t1k_ctx *ctx, void **devPtr, uint64_t *count) {
   if (!ctx || !ctx->ref.covDiff || !devPtr || !count) return t1k_fail(ctx, T1K_ERR_STATE, "no reference");
   *devPtr = ctx->ref.covDiff;
