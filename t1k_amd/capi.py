@@ -80,6 +80,8 @@ def lib():
     L.t1k_rows_download.argtypes = [vp, vp, vp, vp, C.c_uint64, u64p]
     L.t1k_coverage_get.argtypes = [vp, vp, C.c_uint64]
     L.t1k_coverage_reset.argtypes = [vp]
+    L.t1k_missing_coverage.argtypes = [vp, vp]
+    L.t1k_coverage_absorb.argtypes = [vp, vp]
     L.t1k_align_batch.argtypes = [vp, C.c_char_p, vp, vp, C.c_char_p, vp, vp, C.c_uint32, vp, vp, vp, vp, vp, vp, vp]
     L.t1k_align_count_batch.argtypes = [vp, C.c_char_p, vp, C.c_char_p, vp, vp, C.c_uint32, vp]
     L.t1k_em_setup.argtypes = [vp, vp, vp, vp, vp, C.c_uint32, C.c_uint32, ALLREDUCE_FN, vp]
@@ -209,6 +211,12 @@ class Context:
 
     def coverage_reset(self):
         self._check(lib().t1k_coverage_reset(self.h), "t1k_coverage_reset")
+
+    def missing_coverage(self):
+        """per allele: exon positions with coverage below max(1, 1 % of the allele's median exon coverage)"""
+        out = np.zeros(len(self.allele_len), dtype=np.int32)
+        self._check(lib().t1k_missing_coverage(self.h, _ptr(out)), "t1k_missing_coverage")
+        return out
 
     def stats(self):
         s = Stats()

@@ -174,3 +174,28 @@ def test_ragged_and_degenerate_reads(ctx, tmp_path):
         if len(o):
             assert np.array_equal(o[:, 0], g["seq_idx"]) and np.array_equal(o[:, 6], g["match_cnt"]) and np.array_equal(s, g["similarity"])
     assert counts[0] == 0 and counts[1] == 0 and counts[3] > 0 and counts[4] > 0
+
+
+def test_missing_coverage_kernel_vs_host(ctx, tmp_path):
+    """t1k_missing_coverage (prefix sum + radix-selection median on the device) against the same statistic computed from the
+    downloaded per-base coverage the way SeqSet::GetSeqMissingBaseCoverage does (sort, element size/2, cutoff, count)"""
+    ref = str(tmp_path / "hla.fa")
+    util.synth_ref("ref-dna", ref, genes=3, scale=0.03)
+    names, seqs, masks, _ = t1k_amd.load_reference_fasta(ref)
+    ctx.ref_upload(seqs, masks)
+    util.synth_reads(ref, str(tmp_path / "r"), pairs=400, len=150, seed=4)
+    reads = [s for _, _, s in t1k_amd.read_fastx(str(tmp_path / "r_1.fq"))] + [s for _, _, s in t1k_amd.read_fastx(str(tmp_path / "r_2.fq"))]
+    ctx.reads_upload(reads)
+    ctx.coverage_reset()
+    ctx.assign()
+    cov = ctx.coverage()
+    got = ctx.missing_coverage()
+    off = 0
+    exp = np.zeros(len(seqs), dtype=np.int32)
+    for a, (sq, m) in enumerate(zip(seqs, masks)):
+        ex = np.sort(cov[off:off + len(sq)][np.asarray(m, dtype=bool)])
+        off += len(sq)
+        if len(ex):
+            cutoff = max(1.0, ex[len(ex) // 2] * 0.01)
+            exp[a] = int(np.sum(~(ex >= cutoff)))
+    assert cov.sum() > 0 and np.array_equal(got, exp)
