@@ -65,24 +65,6 @@ __device__ __forceinline__ bool sepInRange(const T1kRefDev &ref, uint32_t allele
   return false;
 }
 
-__device__ inline bool lowComplexity(const uint64_t *rb, const uint64_t *rn, int rs, int re) {  // SeqSet.hpp:458-485
-  int cnt[4] = {0, 0, 0, 0};
-  int L = re - rs + 1;
-  for (int o = 0; o < L; o += 32) {
-    uint64_t x = t1k_get32(rb, rs + o), nn = t1k_get32(rn, rs + o);
-    uint64_t valid = T1K_EVEN & ~nn & t1k_lowmask(L - o);
-    uint64_t lo = x & T1K_EVEN, hi = (x >> 1) & T1K_EVEN;
-    cnt[0] += __popcll(~lo & ~hi & valid);
-    cnt[1] += __popcll(lo & ~hi & valid);
-    cnt[2] += __popcll(~lo & hi & valid);
-    cnt[3] += __popcll(lo & hi & valid);
-  }
-  int low = 0, lowTotal = 0;
-  for (int i = 0; i < 4; ++i)
-    if (cnt[i] <= 2) { ++low; lowTotal += cnt[i]; }
-  if (lowTotal * 7 >= L) return false;
-  return low >= 2;
-}
 
 // DEFER = true: the two extension alignments that need a DP are registered in the read-end's memo (the same table the chain
 // stage filled: thousands of alleles share a window) and the candidate is put on the retry list; returns false.
@@ -100,9 +82,7 @@ __device__ __forceinline__ bool extendOne(const ExtendArgs &P, uint64_t gid, uns
   const int rs = (int)(c.readSE & 0xFFFF), re = (int)(c.readSE >> 16);
   const int ss = c.seqStart, se = c.seqEnd;
   const int matchCnt = (int)(c.match >> 16);
-  double sim = (double)matchCnt / (double)(se - ss + 1 + re - rs + 1);  // SeqSet.hpp:1838-1840
-  if (lowComplexity(rb, rn, rs, re)) sim = 0;                           // 1844-1845
-  if (sim < P.sim) { x.flags = T1K_F_DROP; P.ext[gid] = x; return true; }    // 1894-1908
+  // (the similarity / low-complexity filter of SeqSet.hpp:1838-1845, 1894-1908 has been applied by k_collect: only survivors are here)
   uint16_t flags = 0;
   if (sepInRange(P.ref, allele, ss, se)) flags |= T1K_F_SEPSEED;                                  // 2163
   if (sepInRange(P.ref, allele, ss - rs, se + (len - re - 1))) flags |= T1K_F_NEEDCLIP;           // 2167-2169

@@ -1231,6 +1231,19 @@ __global__ __launch_bounds__(64) void k_chain_big(ChainArgs P, uint32_t nItems) 
 // K6: strand vote + copy-out, one workgroup per read-end
 // ------------------------------------------------------------------------------------------------------------------
 
+// the similarity / low-complexity filter on a seed candidate (SeqSet.hpp:1838-1845, 1894-1908): candidates that fail it take no
+// further part (they only counted for the strand vote), so they are never copied out
+__device__ __forceinline__ bool keepCandidate(const ChainArgs &P, uint32_t re, int plus, uint32_t w0, uint32_t w1, uint32_t w2) {
+  const int rs = (int)(w0 & 0xFFF), rend = (int)((w0 >> 12) & 0xFFF), ss = (int)(w1 & 0xFFFFF), se = (int)(w2 & 0xFFFFF);
+  const int matchCnt = (int)(w2 >> 20);
+  const double sim = (double)matchCnt / (double)(se - ss + 1 + rend - rs + 1);
+  if (sim < P.sim) return false;
+  const int S = P.reads.S, pass = plus ? 0 : 1;
+  const uint64_t *rb = P.reads.bases + ((uint64_t)re * 2 + pass) * S, *rn = P.reads.nmask + ((uint64_t)re * 2 + pass) * S;
+  if (t1k_low_complexity(rb, rn, rs, rend)) return !(0.0 < P.sim);  // similarity becomes 0
+  return true;
+}
+
 __global__ __launch_bounds__(WG) void k_collect(ChainArgs P) {
   __shared__ uint32_t warpSums[4];
   __shared__ uint64_t sVoteHi[WG], sVoteLo[WG];
@@ -1249,12 +1262,12 @@ __global__ __launch_bounds__(WG) void k_collect(ChainArgs P) {
         const uint4 hd = ((const uint4 *)rec)[0], cw = ((const uint4 *)rec)[1];  // header and inline candidate in two 16-byte loads
         const uint32_t nc = hd.w & 0x3FFFFFFFu;
         const int plus = (int)(hd.x >> 31);
-        nCand[plus] += nc;
         for (uint32_t j = 0; j < nc; ++j) {
           uint32_t w0 = cw.x, w1 = cw.y, w2 = cw.z;
           if (hd.w & 0x40000000u) { const uint32_t *g = P.genCand + ((uint64_t)cw.x + j) * 6; w0 = g[0]; w1 = g[1]; w2 = g[2]; }
           VoteKey vk = voteKey((int)(w1 >> 20), (int)(w0 & 0xFFF), (int)((w0 >> 12) & 0xFFF), hd.y, plus, (int)(w1 & 0xFFFFF), (int)(w2 & 0xFFFFF));
           if (vk < best) best = vk;
+          nCand[plus] += keepCandidate(P, re, plus, w0, w1, w2) ? 1u : 0u;
         }
       }
     }
@@ -1288,10 +1301,17 @@ __global__ __launch_bounds__(WG) void k_collect(ChainArgs P) {
           const uint32_t i = i0 + tid;
           const uint32_t *rec = P.recs + (uint64_t)(g0 + (i < gn ? i : 0)) * stride;
           const uint4 hd = ((const uint4 *)rec)[0], cw = ((const uint4 *)rec)[1];
-          uint32_t nc = i < gn ? (hd.w & 0x3FFFFFFFu) : 0;
-          uint32_t tot;
-          uint32_t off = t1k_block_scan_exclusive(nc, warpSums, &tot);
+          const uint32_t nc = i < gn ? (hd.w & 0x3FFFFFFFu) : 0;
+          uint32_t keepMask = 0, nk = 0;  // a group holds at most 32 candidates
           for (uint32_t j = 0; j < nc; ++j) {
+            uint32_t w0 = cw.x, w1 = cw.y, w2 = cw.z;
+            if (hd.w & 0x40000000u) { const uint32_t *g = P.genCand + ((uint64_t)cw.x + j) * 6; w0 = g[0]; w1 = g[1]; w2 = g[2]; }
+            if (keepCandidate(P, re, (int)winPlus, w0, w1, w2)) { keepMask |= 1u << j; ++nk; }
+          }
+          uint32_t tot;
+          uint32_t off = t1k_block_scan_exclusive(nk, warpSums, &tot);
+          for (uint32_t j = 0; j < nc; ++j) {
+            if (!((keepMask >> j) & 1u)) continue;
             uint32_t w0 = cw.x, w1 = cw.y, w2 = cw.z;
             if (hd.w & 0x40000000u) { const uint32_t *g = P.genCand + ((uint64_t)cw.x + j) * 6; w0 = g[0]; w1 = g[1]; w2 = g[2]; }
             T1kCand cd;
@@ -1300,7 +1320,8 @@ __global__ __launch_bounds__(WG) void k_collect(ChainArgs P) {
             cd.seqStart = (int)(w1 & 0xFFFFF); cd.seqEnd = (int)(w2 & 0xFFFFF);
             cd.match = (w1 >> 20) | ((w2 >> 20) << 16);
             cd.re = re;
-            P.cand[(uint64_t)sBase + written + off + j] = cd;
+            P.cand[(uint64_t)sBase + written + off] = cd;
+            ++off;
           }
           written += tot;
         }

@@ -123,6 +123,26 @@ __device__ __forceinline__ int t1k_hamming(const uint64_t *rb, const uint64_t *r
   return x;
 }
 
+// SeqSet::IsLowComplexity over read positions [rs, re] (SeqSet.hpp:458-485)
+__device__ inline bool t1k_low_complexity(const uint64_t *rb, const uint64_t *rn, int rs, int re) {  // SeqSet.hpp:458-485
+  int cnt[4] = {0, 0, 0, 0};
+  int L = re - rs + 1;
+  for (int o = 0; o < L; o += 32) {
+    uint64_t x = t1k_get32(rb, rs + o), nn = t1k_get32(rn, rs + o);
+    uint64_t valid = T1K_EVEN & ~nn & t1k_lowmask(L - o);
+    uint64_t lo = x & T1K_EVEN, hi = (x >> 1) & T1K_EVEN;
+    cnt[0] += __popcll(~lo & ~hi & valid);
+    cnt[1] += __popcll(lo & ~hi & valid);
+    cnt[2] += __popcll(~lo & hi & valid);
+    cnt[3] += __popcll(lo & hi & valid);
+  }
+  int low = 0, lowTotal = 0;
+  for (int i = 0; i < 4; ++i)
+    if (cnt[i] <= 2) { ++low; lowTotal += cnt[i]; }
+  if (lowTotal * 7 >= L) return false;
+  return low >= 2;
+}
+
 // do two L-position windows of the reference hold the same bases and N marks?
 __device__ inline bool t1k_same_window(const uint64_t *gb, const uint64_t *gn, int64_t a, int64_t b, int L) {
   if (a == b) return true;
