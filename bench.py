@@ -201,7 +201,7 @@ def main():
                        "assigned_fragments": counts["assigned_fragments"]},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": TRAFFIC_BYTES_PER_LAUNCH if a.pairs >= 16384 else None,
-                         "launches_per_step": launches, "pipelines_per_gpu": int(os.environ.get("T1K_PIPELINES", "3")), "algorithmic_bytes_per_launch": kb[dom] / launches, "avg_launch_ms": ms[dom] / launches,
+                         "launches_per_step": launches, "pipelines_per_gpu": int(os.environ.get("T1K_PIPELINES", "4")), "algorithmic_bytes_per_launch": kb[dom] / launches, "avg_launch_ms": ms[dom] / launches,
                          "all_kernels_ms_per_step": ms,
                          "all_kernels_algorithmic_GBs": {k: (kb[k] / (ms[k] * 1e-3) / 1e9 if ms[k] > 0 else 0.0) for k in ms},
                          "em_ms": st["ms_em"], "job_ms_total": st["ms_total"]},
