@@ -291,7 +291,7 @@ __device__ inline bool candBeforeFull(const T1kCand &a, const T1kCand &b) {
 #define SELECT_LARGE 8192
 
 template <int SELECT_LDS_CAP, int NT>
-__global__ __launch_bounds__(NT) void k_select(SelectArgs P) {
+__global__ __launch_bounds__(NT) T1K_OCC8 void k_select(SelectArgs P) {
   extern __shared__ uint64_t dynLds[];
   uint64_t *sKey = dynLds;
   __shared__ uint32_t warpSums[NT / 64];

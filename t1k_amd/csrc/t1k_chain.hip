@@ -447,7 +447,7 @@ __device__ __forceinline__ VoteKey voteKey(int matchCnt0, int rs, int re, uint32
 #define DIAG_EMPTY 0x7FFFFFFF
 
 template <int NW>
-__global__ __launch_bounds__(WG) void k_seed_groups(ChainArgs P) {
+__global__ __launch_bounds__(WG) T1K_OCC8 void k_seed_groups(ChainArgs P) {
   constexpr int AW = NW == 5 ? 7 : 13;  // u32 per accumulator: diag, meta, M[NW]; odd stride = no LDS bank conflicts
   extern __shared__ uint32_t lds[];
   const int k = P.k;
