@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string>
+#include <type_traits>
 #include <vector>
 #include "../../include/t1k_gpu.h"
 
@@ -183,21 +184,30 @@ __device__ inline int t1k_ga_matches_equal(const T1kSeqView &T, const T1kSeqView
     cm[s] = 0; ce[s] = 0;
   }
   uint64_t pwB = 0, pwN = 0;
-  for (int i = 1; i <= L; ++i) {
+  // one row of the band.  INTERIOR rows (7 <= i <= L - 5) have all eleven columns inside the matrix: no boundary tests, the
+  // text window starts exactly at column i - 5, and the eleven base comparisons are done at once on the packed window
+  auto row = [&](int i, auto interiorTag) {
+    constexpr bool INTERIOR = decltype(interiorTag)::value;
     // pattern base i-1: one 32-base window per 32 rows; text bases i-6 .. i+4: one window per row (2 loads, L1-resident)
     if (((i - 1) & 31) == 0) { pwB = t1k_get32(P.b, P.pos + i - 1); pwN = t1k_get32(P.n, P.pos + i - 1); }
     const int pq = ((i - 1) & 31) * 2;
-    const int pc = ((pwN >> pq) & 1) ? 4 : (int)((pwB >> pq) & 3);
+    const bool pIsN = (pwN >> pq) & 1;
+    const int pc = pIsN ? 4 : (int)((pwB >> pq) & 3);
     const int t0 = i - 6 > 0 ? i - 6 : 0;  // first text index covered by the window
     const uint64_t twB = t1k_get32(T.b, T.pos + t0), twN = t1k_get32(T.n, T.pos + t0);
-    int fLeft = 0, mLeft = 0, cfLeft = 0, cmLeft = 0;  // cell (i, j-1) of the current row
+    uint64_t eqm = 0;  // INTERIOR: bit 2(s-1) = text base of slot s compares equal to the pattern base (N matches anything)
+    if (INTERIOR) {
+      const uint64_t x = twB ^ ((uint64_t)(pc & 3) * T1K_EVEN);
+      eqm = pIsN ? ~0ull : (~((x | (x >> 1))) | twN);
+    }
+    int fLeft = negInf, mLeft = negInf, cfLeft = 0, cmLeft = 0;  // cell (i, j-1) of the current row
 #pragma unroll
     for (int s = 0; s < 13; ++s) {
       int j = i + s - 6;
       int nm, ne, nf, ncm, nce, ncf;
-      if (j < 0) { nm = ne = nf = negInf; ncm = nce = ncf = 0; }
-      else if (j == 0) { nm = -4 - 4 * i; ne = -4 - i; nf = -4 - 4 * i; ncm = nce = ncf = 0; }
-      else if (j > L || s == 0 || s == 12) { nm = ne = nf = negInf; ncm = nce = ncf = 0; }
+      if (!INTERIOR && j < 0) { nm = ne = nf = negInf; ncm = nce = ncf = 0; }
+      else if (!INTERIOR && j == 0) { nm = -4 - 4 * i; ne = -4 - i; nf = -4 - 4 * i; ncm = nce = ncf = 0; }  // column 0 (also in slot 0, row 6)
+      else if (s == 0 || s == 12 || (!INTERIOR && j > L)) { nm = ne = nf = negInf; ncm = nce = ncf = 0; }
       else {
         // e: from (i-1, j) = previous row at slot s+1
         int eu = e[s + 1] - 1, mu = m[s + 1] - 5;
@@ -208,9 +218,13 @@ __device__ inline int t1k_ga_matches_equal(const T1kSeqView &T, const T1kSeqView
         nf = fl > ml ? fl : ml;
         ncf = (ml == nf) ? cmLeft : cfLeft;
         // m: diagonal (i-1, j-1) = previous row at slot s
-        const int tq = (j - 1 - t0) * 2;
-        const int tc = ((twN >> tq) & 1) ? 4 : (int)((twB >> tq) & 3);
-        bool eq = t1k_eq(tc, pc);
+        bool eq;
+        if (INTERIOR) eq = (eqm >> (2 * (s - 1))) & 1;
+        else {
+          const int tq = (j - 1 - t0) * 2;
+          const int tc = ((twN >> tq) & 1) ? 4 : (int)((twB >> tq) & 3);
+          eq = t1k_eq(tc, pc);
+        }
         int dg = m[s] + (eq ? 2 : -2);
         nm = dg;
         if (ne > nm) nm = ne;
@@ -223,7 +237,11 @@ __device__ inline int t1k_ga_matches_equal(const T1kSeqView &T, const T1kSeqView
       m[s] = nm; e[s] = ne; cm[s] = ncm; ce[s] = nce;
       fLeft = nf; mLeft = nm; cfLeft = ncf; cmLeft = ncm;
     }
-  }
+  };
+  int i = 1;
+  for (; i <= L && i < 7; ++i) row(i, std::false_type{});
+  for (; i <= L - 5; ++i) row(i, std::true_type{});
+  for (; i <= L; ++i) row(i, std::false_type{});
   if (scoreOut) *scoreOut = m[6];
   return cm[6];
 }
@@ -242,29 +260,40 @@ __device__ inline void t1k_ga_equal_traced(const T1kSeqView &T, const T1kSeqView
     else { m[s] = -4 - 4 * j; e[s] = -4 - 4 * (L + 1); }
   }
   uint64_t pwB = 0, pwN = 0;
-  for (int i = 1; i <= L; ++i) {
+  auto row = [&](int i, auto interiorTag) {  // see t1k_ga_matches_equal
+    constexpr bool INTERIOR = decltype(interiorTag)::value;
     if (((i - 1) & 31) == 0) { pwB = t1k_get32(P.b, P.pos + i - 1); pwN = t1k_get32(P.n, P.pos + i - 1); }
     const int pq = ((i - 1) & 31) * 2;
-    const int pc = ((pwN >> pq) & 1) ? 4 : (int)((pwB >> pq) & 3);
+    const bool pIsN = (pwN >> pq) & 1;
+    const int pc = pIsN ? 4 : (int)((pwB >> pq) & 3);
     const int t0 = i - 6 > 0 ? i - 6 : 0;
     const uint64_t twB = t1k_get32(T.b, T.pos + t0), twN = t1k_get32(T.n, T.pos + t0);
-    int fLeft = 0, mLeft = 0;
+    uint64_t eqm = 0;
+    if (INTERIOR) {
+      const uint64_t x = twB ^ ((uint64_t)(pc & 3) * T1K_EVEN);
+      eqm = pIsN ? ~0ull : (~((x | (x >> 1))) | twN);
+    }
+    int fLeft = negInf, mLeft = negInf;
     uint64_t word = 0;
 #pragma unroll
     for (int s = 0; s < 13; ++s) {
       int j = i + s - 6;
       int nm, ne, nf;
-      if (j < 0) { nm = ne = nf = negInf; }
-      else if (j == 0) { nm = -4 - 4 * i; ne = -4 - i; nf = -4 - 4 * i; }
-      else if (j > L || s == 0 || s == 12) { nm = ne = nf = negInf; }
+      if (!INTERIOR && j < 0) { nm = ne = nf = negInf; }
+      else if (!INTERIOR && j == 0) { nm = -4 - 4 * i; ne = -4 - i; nf = -4 - 4 * i; }
+      else if (s == 0 || s == 12 || (!INTERIOR && j > L)) { nm = ne = nf = negInf; }
       else {
         int eu = e[s + 1] - 1, mu = m[s + 1] - 5;
         ne = eu > mu ? eu : mu;
         int fl = fLeft - 1, ml = mLeft - 5;
         nf = fl > ml ? fl : ml;
-        const int tq = (j - 1 - t0) * 2;
-        const int tc = ((twN >> tq) & 1) ? 4 : (int)((twB >> tq) & 3);
-        bool eq = t1k_eq(tc, pc);
+        bool eq;
+        if (INTERIOR) eq = (eqm >> (2 * (s - 1))) & 1;
+        else {
+          const int tq = (j - 1 - t0) * 2;
+          const int tc = ((twN >> tq) & 1) ? 4 : (int)((twB >> tq) & 3);
+          eq = t1k_eq(tc, pc);
+        }
         int dg = m[s] + (eq ? 2 : -2);
         nm = dg;
         if (ne > nm) nm = ne;
@@ -276,7 +305,11 @@ __device__ inline void t1k_ga_equal_traced(const T1kSeqView &T, const T1kSeqView
       fLeft = nf; mLeft = nm;
     }
     trace[(size_t)i * stride] = word;
-  }
+  };
+  int i = 1;
+  for (; i <= L && i < 7; ++i) row(i, std::false_type{});
+  for (; i <= L - 5; ++i) row(i, std::true_type{});
+  for (; i <= L; ++i) row(i, std::false_type{});
 }
 
 // Banded GlobalAlignment for |lent - lenp| <= DMAX with the whole band in registers (generalises the two routines above:
