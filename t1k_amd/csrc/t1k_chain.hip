@@ -92,7 +92,7 @@ __device__ __forceinline__ void shlOr(uint64_t *C, int sft) {
 
 // return value: 5 = needs the gap walk (CLOSED only), 1 = finished (out holds 0 or 1 candidate), 2 = run again after the dense DP phase, 3 = candidate pushed with a
 // partial matchCnt, refs[] name the memo slots whose match counts are still to be added (DEFER only)
-#define GROUP_MAX_REFS 6
+#define GROUP_MAX_REFS 4   // two 32-bit words of 16-bit memo slots in a group record
 template <int NW, bool DEFER, bool CLOSED>
 __device__ inline int groupFastPath(const uint32_t *Mw, int diag, const ReadCtx &c, bool hasN, int k, int hitLenRequired, double simThreshold, CandOut &out,
                                     unsigned int *dpCounter, int strandBit, const GapSink &sink, uint32_t *refs, int *nRefs) {
@@ -444,6 +444,14 @@ __device__ __forceinline__ VoteKey voteKey(int matchCnt0, int rs, int re, uint32
 // A group record leaves the chip once, coalesced; no hit list is ever written.
 // ------------------------------------------------------------------------------------------------------------------
 #define CHUNK_A T1K_SEED_CHUNK
+// record word 2 before chaining: reference diagonal (22 bits, biased; alleles are shorter than 2^20 bases) and the counts of hits off
+// it, far (bits 22..26) and near = within `radius` (bits 27..31), saturating at 31 -- the chain only asks "near > 0" and "far > 2"
+__device__ __forceinline__ uint32_t packDiagMeta(int diag, uint32_t meta) {
+  const uint32_t strays = meta & 0xFFFFu, nearCnt = meta >> 16;
+  return (uint32_t)(diag + (1 << 21)) | (min(strays, 31u) << 22) | (min(nearCnt, 31u) << 27);
+}
+__device__ __forceinline__ int recDiag(uint32_t w2) { return (int)(w2 & 0x3FFFFFu) - (1 << 21); }
+__device__ __forceinline__ bool recIsGeneral(uint32_t w2) { return (w2 >> 27) > 0 || ((w2 >> 22) & 31u) > 2; }
 #define DIAG_EMPTY 0x7FFFFFFF
 
 template <int NW>
@@ -788,17 +796,17 @@ __global__ __launch_bounds__(WG) T1K_OCC8 void k_seed_groups(ChainArgs P) {
             if (((flags >> (2 * i)) & 1u) && groupBase != 0xFFFFFFFFu) {
               const uint32_t slot = before + (uint32_t)((ex >> (16 * i)) & 0xFFFF);
               uint4 *rec = (uint4 *)(P.recs + (uint64_t)(groupBase + slot) * stride);
-              uint32_t v[NW == 5 ? 12 : 16];
+              constexpr int RW = NW == 5 ? 8 : 16;  // record words: re|strand, allele, diagonal + stray counts, M[NW]
+              uint32_t v[RW];
               v[0] = re | (pass == 0 ? 0x80000000u : 0);  // bit31: '+' strand
               v[1] = c0 + i * WG + tid;
-              v[2] = a[0];
-              v[3] = a[1];
+              v[2] = packDiagMeta((int)a[0], a[1]);
 #pragma unroll
-              for (int w = 0; w < NW; ++w) v[4 + w] = a[2 + w];
+              for (int w = 0; w < NW; ++w) v[3 + w] = a[2 + w];
 #pragma unroll
-              for (int w = 4 + NW; w < (NW == 5 ? 12 : 16); ++w) v[w] = 0;
+              for (int w = 3 + NW; w < RW; ++w) v[w] = 0;
 #pragma unroll
-              for (int w = 0; w < (NW == 5 ? 3 : 4); ++w) rec[w] = make_uint4(v[4 * w], v[4 * w + 1], v[4 * w + 2], v[4 * w + 3]);
+              for (int w = 0; w < RW / 4; ++w) rec[w] = make_uint4(v[4 * w], v[4 * w + 1], v[4 * w + 2], v[4 * w + 3]);
             }
             a[0] = (uint32_t)DIAG_EMPTY; a[1] = 0;
 #pragma unroll
@@ -822,7 +830,8 @@ __global__ __launch_bounds__(WG) T1K_OCC8 void k_seed_groups(ChainArgs P) {
 
 // ------------------------------------------------------------------------------------------------------------------
 // K2 / K4: single-diagonal chain, one lane per group record
-// record words: 0 re|strand, 1 allele, 2 diag, 3 meta, 4.. M   -> after chaining: 3 = state, 4..6 packed candidate / side-arena ref
+// record words: 0 re|strand, 1 allele, 2 diagonal + stray counts, 3.. M   -> after chaining: 2 = state, 3..5 packed candidate (3 = side-arena base for
+// multi-diagonal groups), 6..7 memo slots still to be added
 // ------------------------------------------------------------------------------------------------------------------
 enum { REC_DONE = 0x80000000u };  // word 3 after chaining: REC_DONE | number of candidates (general groups: candidates in the side arena)
 
@@ -855,35 +864,37 @@ __global__ __launch_bounds__(WG) void k_chain_fast(ChainArgs P, const uint32_t *
   }
   if (valid) {
     uint32_t *rec = P.recs + (uint64_t)gi * P.recStride;
-    uint32_t rv[NW == 5 ? 12 : 16];  // the record, fetched as 16-byte pieces
+    constexpr int RW = NW == 5 ? 8 : 16;
+    uint32_t rv[RW];  // the record, fetched as 16-byte pieces
 #pragma unroll
-    for (int w = 0; w < (NW == 5 ? 3 : 4); ++w) {
+    for (int w = 0; w < RW / 4; ++w) {
       const uint4 q4 = ((const uint4 *)rec)[w];
       rv[4 * w] = q4.x; rv[4 * w + 1] = q4.y; rv[4 * w + 2] = q4.z; rv[4 * w + 3] = q4.w;
     }
-    const uint32_t re = rv[0] & 0x7FFFFFFFu, allele = rv[1], meta = rv[3];
+    const uint32_t re = rv[0] & 0x7FFFFFFFu, allele = rv[1];
     const int pass = (rv[0] >> 31) ? 0 : 1;
-    const bool general = (meta >> 16) > 0 || (meta & 0xFFFFu) > 2;
+    const bool general = recIsGeneral(rv[2]);
     if (general) kind = 4;
     else {
       uint32_t Mw[NW];
 #pragma unroll
-      for (int w = 0; w < NW; ++w) Mw[w] = rv[4 + w];
+      for (int w = 0; w < NW; ++w) Mw[w] = rv[3 + w];
       ReadCtx c = makeCtx(P, re, pass, allele);
       uint32_t cbuf[3];
       CandOut out{cbuf, 0};
       const GapSink sink{P.memo + (uint64_t)re * GAP_CACHE, P.jobStr, P.counters, re * GAP_CACHE, P.jobSegCap, T1K_AR_JOBS};
-      uint32_t refs[3] = {0, 0, 0};
+      uint32_t refs[2] = {0, 0};
       int nRefs = 0;
-      kind = groupFastPath<NW, DEFER, MODE == 0>(Mw, (int)rv[2], c, P.ref.alleleHasN[allele] != 0, P.k, P.hitLenRequired, P.sim, out, &dpLocal, pass, sink, refs, &nRefs);
+      kind = groupFastPath<NW, DEFER, MODE == 0>(Mw, recDiag(rv[2]), c, P.ref.alleleHasN[allele] != 0, P.k, P.hitLenRequired, P.sim, out, &dpLocal, pass, sink, refs, &nRefs);
       if (kind == 3) {  // matchCnt lacks the registered alignments: k_chain_finish adds them from the memo
-        ((uint4 *)rec)[1] = make_uint4(cbuf[0], cbuf[1], cbuf[2], refs[0]);
-        ((uint2 *)rec)[4] = make_uint2(refs[1], refs[2]);
-        rec[3] = (uint32_t)nRefs;
+        // words 2..7: state (= number of memo slots to add), candidate, slots
+        ((uint2 *)rec)[1] = make_uint2((uint32_t)nRefs, cbuf[0]);
+        ((uint2 *)rec)[2] = make_uint2(cbuf[1], cbuf[2]);
+        ((uint2 *)rec)[3] = make_uint2(refs[0], refs[1]);
       } else if (kind == 1) {
         ++fastLocal;
-        if (out.n) ((uint4 *)rec)[1] = make_uint4(cbuf[0], cbuf[1], cbuf[2], 0u);
-        rec[3] = REC_DONE | (uint32_t)out.n;
+        if (out.n) { ((uint2 *)rec)[1] = make_uint2(REC_DONE | 1u, cbuf[0]); ((uint2 *)rec)[2] = make_uint2(cbuf[1], cbuf[2]); }
+        else rec[2] = REC_DONE;
       }
     }
   }
@@ -922,18 +933,18 @@ __global__ __launch_bounds__(WG) void k_chain_finish(ChainArgs P, uint32_t nItem
   if (q < nItems) {
     uint32_t *rec = P.recs + (uint64_t)P.finishList[q] * P.recStride;
     const uint32_t re = rec[0] & 0x7FFFFFFFu;
-    const int nRefs = (int)rec[3];
+    const int nRefs = (int)rec[2];
     const unsigned long long *memo = P.memo + (uint64_t)re * GAP_CACHE;
     uint32_t sum = 0;
     for (int i = 0; i < nRefs; ++i) {
-      const uint32_t slot = (rec[7 + (i >> 1)] >> (16 * (i & 1))) & 0xFFFFu;
+      const uint32_t slot = (rec[6 + (i >> 1)] >> (16 * (i & 1))) & 0xFFFFu;
       const unsigned long long e = __hip_atomic_load(&memo[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const uint32_t v = GAP_VAL(e);
       if (v == GAP_PENDING) atomicOr(&P.counters[2], (unsigned long long)ERR_MEMO);  // cannot happen: every registered job is run by k_dp_dense
       sum += v;
     }
-    rec[6] += (2u * sum) << 20;
-    rec[3] = REC_DONE | 1u;
+    rec[5] += (2u * sum) << 20;
+    rec[2] = REC_DONE | 1u;
     ++fastLocal;
   }
   t1k_stat_add(P.counters, T1K_STAT_FAST, fastLocal);
@@ -1002,10 +1013,10 @@ __global__ __launch_bounds__(WG) void k_gather_general(ChainArgs P, uint32_t nIt
       if (n > WAVE_CAP) {  // k_chain_big gathers for itself
         const uint32_t bq = t1k_arena_append(P.counters, T1K_AR_BIG, P.listSegCap);
         if (bq != T1K_ARENA_FULL) P.bigStr[bq] = gi;
-        rec[5] = 0xFFFFFFFFu;
+        rec[4] = 0xFFFFFFFFu;
       } else {
         base = n ? t1k_arena_alloc(P.counters, T1K_AR_GENHITS, n, P.genHitSegCap) : 0u;
-        rec[4] = base; rec[5] = n;
+        rec[3] = base; rec[4] = n;
         if (n > GENERAL_SMALL) {  // one wavefront per group (k_chain_wave)
           const uint32_t wq = t1k_arena_append(P.counters, T1K_AR_WAVE, P.listSegCap);
           if (wq != T1K_ARENA_FULL) P.waveStr[wq] = gi;
@@ -1035,7 +1046,7 @@ __global__ __launch_bounds__(64) void k_chain_general(ChainArgs P, uint32_t nIte
   const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
   unsigned int dpLocal = 0, genLocal = 0;
   uint32_t nHits = 0xFFFFFFFFu;
-  if (q < nItems) nHits = P.recs[(uint64_t)P.generalList[q] * P.recStride + 5];
+  if (q < nItems) nHits = P.recs[(uint64_t)P.generalList[q] * P.recStride + 4];
   if (nHits <= GENERAL_SMALL) {
     const uint32_t gi = P.generalList[q];
     uint32_t *rec = P.recs + (uint64_t)gi * P.recStride;
@@ -1043,8 +1054,8 @@ __global__ __launch_bounds__(64) void k_chain_general(ChainArgs P, uint32_t nIte
     const int pass = (rec[0] >> 31) ? 0 : 1;
     ReadCtx c = makeCtx(P, re, pass, allele);
     const int n = (int)nHits;
-    if (rec[4] == T1K_ARENA_FULL) atomicOr(&P.counters[2], (unsigned long long)ERR_STAGECAP);
-    const uint32_t *hh = P.genHits + (rec[4] == T1K_ARENA_FULL ? 0u : rec[4]);
+    if (rec[3] == T1K_ARENA_FULL) atomicOr(&P.counters[2], (unsigned long long)ERR_STAGECAP);
+    const uint32_t *hh = P.genHits + (rec[3] == T1K_ARENA_FULL ? 0u : rec[3]);
     bool needScratch = false;
     uint32_t cbuf[2 * GENERAL_SMALL + 6];  // a candidate needs >= 3 hits
     CandOut out{cbuf, 0, 6, GENERAL_SMALL / 3 + 1};
@@ -1060,8 +1071,8 @@ __global__ __launch_bounds__(64) void k_chain_general(ChainArgs P, uint32_t nIte
         if (base == T1K_ARENA_FULL) { atomicOr(&P.counters[2], (unsigned long long)ERR_STAGECAP); out.n = 0; base = 0; }
         for (int i = 0; i < 6 * out.n; ++i) P.genCand[(uint64_t)base * 6 + i] = cbuf[i];
       }
-      rec[4] = base;
-      rec[3] = REC_DONE | 0x40000000u | (uint32_t)out.n;  // bit30: candidates live in the side arena
+      rec[3] = base;
+      rec[2] = REC_DONE | 0x40000000u | (uint32_t)out.n;  // bit30: candidates live in the side arena
     }
   }
   t1k_stat_add(P.counters, T1K_STAT_DP, dpLocal);
@@ -1082,10 +1093,10 @@ __global__ __launch_bounds__(64) void k_chain_wave(ChainArgs P, uint32_t nItems)
     uint32_t *rec = P.recs + (uint64_t)gi * P.recStride;
     const uint32_t re = rec[0] & 0x7FFFFFFFu, allele = rec[1];
     const int pass = (rec[0] >> 31) ? 0 : 1;
-    const int n = (int)rec[5];
-    const bool lost = rec[4] == T1K_ARENA_FULL;
+    const int n = (int)rec[4];
+    const bool lost = rec[3] == T1K_ARENA_FULL;
     if (lost && lane == 0) atomicOr(&P.counters[2], (unsigned long long)ERR_STAGECAP);
-    const uint32_t *hh = P.genHits + (lost ? 0u : rec[4]);
+    const uint32_t *hh = P.genHits + (lost ? 0u : rec[3]);
     ReadCtx c = makeCtx(P, re, pass, allele);
     const int k = P.k;
     __syncthreads();  // the previous group's arrays are dead
@@ -1157,8 +1168,8 @@ __global__ __launch_bounds__(64) void k_chain_wave(ChainArgs P, uint32_t nItems)
           if (base == T1K_ARENA_FULL) { atomicOr(&P.counters[2], (unsigned long long)ERR_STAGECAP); out.n = 0; base = 0; }
           for (int i = 0; i < 6 * out.n; ++i) P.genCand[(uint64_t)base * 6 + i] = cbuf[i];
         }
-        rec[4] = base;
-        rec[3] = REC_DONE | 0x40000000u | (uint32_t)out.n;
+        rec[3] = base;
+        rec[2] = REC_DONE | 0x40000000u | (uint32_t)out.n;
       }
     }
   }
@@ -1171,11 +1182,11 @@ __global__ __launch_bounds__(WG) void k_general_finish(ChainArgs P, uint32_t nIt
   const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= nItems) return;
   const uint32_t *rec = P.recs + (uint64_t)P.generalList[q] * P.recStride;
-  if ((rec[3] & (REC_DONE | 0x40000000u)) != (REC_DONE | 0x40000000u)) return;  // not chained yet (waits for k_chain_big)
-  const uint32_t re = rec[0] & 0x7FFFFFFFu, nc = rec[3] & 0x3FFFFFFFu;
+  if ((rec[2] & (REC_DONE | 0x40000000u)) != (REC_DONE | 0x40000000u)) return;  // not chained yet (waits for k_chain_big)
+  const uint32_t re = rec[0] & 0x7FFFFFFFu, nc = rec[2] & 0x3FFFFFFFu;
   const unsigned long long *memo = P.memo + (uint64_t)re * GAP_CACHE;
   for (uint32_t j = 0; j < nc; ++j) {
-    uint32_t *g = P.genCand + ((uint64_t)rec[4] + j) * 6;
+    uint32_t *g = P.genCand + ((uint64_t)rec[3] + j) * 6;
     const int nref = (int)((g[0] >> 24) & 0xF);
     if (!nref) continue;
     uint32_t sum = 0;
@@ -1207,7 +1218,7 @@ __global__ __launch_bounds__(64) void k_chain_big(ChainArgs P, uint32_t nItems) 
     ReadCtx c = makeCtx(P, re, pass, allele);
     uint32_t *hh = mine + 3 * BIG_CAP;
     const int n = gatherHits(P, re, pass, allele, hh, BIG_CAP);
-    if (n > BIG_CAP) { atomicOr(&P.counters[2], (unsigned long long)ERR_BIGGROUP); rec[3] = REC_DONE; continue; }
+    if (n > BIG_CAP) { atomicOr(&P.counters[2], (unsigned long long)ERR_BIGGROUP); rec[2] = REC_DONE; continue; }
     bool dummy = false;
     uint32_t cbuf[192];  // at most 32 candidates are kept per group
     CandOut o2{cbuf, 0, 6, 32};
@@ -1220,8 +1231,8 @@ __global__ __launch_bounds__(64) void k_chain_big(ChainArgs P, uint32_t nItems) 
       if (base == T1K_ARENA_FULL) { atomicOr(&P.counters[2], (unsigned long long)ERR_STAGECAP); o2.n = 0; base = 0; }
       for (int i = 0; i < 6 * o2.n; ++i) P.genCand[(uint64_t)base * 6 + i] = cbuf[i];
     }
-    rec[4] = base;
-    rec[3] = REC_DONE | 0x40000000u | (uint32_t)o2.n;
+    rec[3] = base;
+    rec[2] = REC_DONE | 0x40000000u | (uint32_t)o2.n;
     atomicAdd(&P.counters[13], 1ull);
   }
   if (dpLocal) atomicAdd(&P.counters[7], (unsigned long long)dpLocal);
@@ -1259,12 +1270,12 @@ __global__ __launch_bounds__(WG) void k_collect(ChainArgs P) {
       if (gn == 0) break;  // chunks are recorded densely
       for (uint32_t i = tid; i < gn; i += WG) {
         const uint32_t *rec = P.recs + (uint64_t)(g0 + i) * stride;
-        const uint4 hd = ((const uint4 *)rec)[0], cw = ((const uint4 *)rec)[1];  // header and inline candidate in two 16-byte loads
-        const uint32_t nc = hd.w & 0x3FFFFFFFu;
+        const uint4 hd = ((const uint4 *)rec)[0], cw = ((const uint4 *)rec)[1];  // words 0..3: re|strand, allele, state, candidate word 0 (or side-arena base); 4..5: candidate words 1, 2
+        const uint32_t nc = hd.z & 0x3FFFFFFFu;
         const int plus = (int)(hd.x >> 31);
         for (uint32_t j = 0; j < nc; ++j) {
-          uint32_t w0 = cw.x, w1 = cw.y, w2 = cw.z;
-          if (hd.w & 0x40000000u) { const uint32_t *g = P.genCand + ((uint64_t)cw.x + j) * 6; w0 = g[0]; w1 = g[1]; w2 = g[2]; }
+          uint32_t w0 = hd.w, w1 = cw.x, w2 = cw.y;
+          if (hd.z & 0x40000000u) { const uint32_t *g = P.genCand + ((uint64_t)hd.w + j) * 6; w0 = g[0]; w1 = g[1]; w2 = g[2]; }
           VoteKey vk = voteKey((int)(w1 >> 20), (int)(w0 & 0xFFF), (int)((w0 >> 12) & 0xFFF), hd.y, plus, (int)(w1 & 0xFFFFF), (int)(w2 & 0xFFFFF));
           if (vk < best) best = vk;
           nCand[plus] += keepCandidate(P, re, plus, w0, w1, w2) ? 1u : 0u;
@@ -1301,19 +1312,19 @@ __global__ __launch_bounds__(WG) void k_collect(ChainArgs P) {
           const uint32_t i = i0 + tid;
           const uint32_t *rec = P.recs + (uint64_t)(g0 + (i < gn ? i : 0)) * stride;
           const uint4 hd = ((const uint4 *)rec)[0], cw = ((const uint4 *)rec)[1];
-          const uint32_t nc = i < gn ? (hd.w & 0x3FFFFFFFu) : 0;
+          const uint32_t nc = i < gn ? (hd.z & 0x3FFFFFFFu) : 0;
           uint32_t keepMask = 0, nk = 0;  // a group holds at most 32 candidates
           for (uint32_t j = 0; j < nc; ++j) {
-            uint32_t w0 = cw.x, w1 = cw.y, w2 = cw.z;
-            if (hd.w & 0x40000000u) { const uint32_t *g = P.genCand + ((uint64_t)cw.x + j) * 6; w0 = g[0]; w1 = g[1]; w2 = g[2]; }
+            uint32_t w0 = hd.w, w1 = cw.x, w2 = cw.y;
+            if (hd.z & 0x40000000u) { const uint32_t *g = P.genCand + ((uint64_t)hd.w + j) * 6; w0 = g[0]; w1 = g[1]; w2 = g[2]; }
             if (keepCandidate(P, re, (int)winPlus, w0, w1, w2)) { keepMask |= 1u << j; ++nk; }
           }
           uint32_t tot;
           uint32_t off = t1k_block_scan_exclusive(nk, warpSums, &tot);
           for (uint32_t j = 0; j < nc; ++j) {
             if (!((keepMask >> j) & 1u)) continue;
-            uint32_t w0 = cw.x, w1 = cw.y, w2 = cw.z;
-            if (hd.w & 0x40000000u) { const uint32_t *g = P.genCand + ((uint64_t)cw.x + j) * 6; w0 = g[0]; w1 = g[1]; w2 = g[2]; }
+            uint32_t w0 = hd.w, w1 = cw.x, w2 = cw.y;
+            if (hd.z & 0x40000000u) { const uint32_t *g = P.genCand + ((uint64_t)hd.w + j) * 6; w0 = g[0]; w1 = g[1]; w2 = g[2]; }
             T1kCand cd;
             cd.allele = hd.y | (winPlus ? 0x80000000u : 0);
             cd.readSE = (w0 & 0xFFF) | (((w0 >> 12) & 0xFFF) << 16);
@@ -1337,7 +1348,7 @@ __global__ __launch_bounds__(WG) void k_collect(ChainArgs P) {
 size_t t1k_chain_big_scratch_u32() { return (size_t)4 * BIG_CAP + GA_SCRATCH_INTS; }
 int t1k_chain_max_chunks(uint32_t nAlleles) { return 2 * (int)((nAlleles + CHUNK_A - 1) / CHUNK_A) + 2; }
 int t1k_chain_memo_entries() { return GAP_CACHE; }
-int t1k_chain_rec_stride(int maxLen) { return maxLen <= 160 ? 12 : 16; }  // u32 per record, 16-byte aligned
+int t1k_chain_rec_stride(int maxLen) { return maxLen <= 160 ? 8 : 16; }  // u32 per record (32 / 64 bytes)
 int t1k_chain_max_kmers(int maxLen, int k) { return (2 * std::max(1, maxLen - k + 1) + 3) / 4 * 4; }
 int t1k_chain_used_u32(int maxK) { return maxK * 3; }
 
