@@ -549,11 +549,14 @@ __global__ __launch_bounds__(WG) void k_fullalign(FullArgs P) {
 }
 
 
+// (rare: a handful per batch.)  One working lane per 64-thread workgroup: the row arrays of the general DP live in LDS -- with
+// them in HBM every cell paid a memory round trip and the kernel sat on the batch's critical path for a millisecond.
 __global__ __launch_bounds__(64) void k_fullalign_slow(SlowArgs P) {
-  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  uint32_t nThreads = gridDim.x * blockDim.x;
+  __shared__ int rows[GA_SCRATCH_INTS];
+  if (threadIdx.x != 0) return;
+  uint32_t t = blockIdx.x;
+  uint32_t nThreads = gridDim.x;
   uint8_t *mine = P.scratch + (uint64_t)t * P.perThread;
-  int *rows = (int *)mine;
   int8_t *ops = (int8_t *)(mine + GA_SCRATCH_INTS * 4);
   uint8_t *trace = mine + GA_SCRATCH_INTS * 4 + 4224;
   for (uint32_t q = t; q < P.nSlow; q += nThreads) {
@@ -898,7 +901,7 @@ void t1k_launch_fullalign(t1k_ctx *ctx, const FullArgs &a) {
   if (!a.nOvl) return;
   hipLaunchKernelGGL(k_fullalign, dim3((unsigned)((a.nOvl + WG - 1) / WG)), dim3(WG), 0, ctx->stream, a);
 }
-void t1k_launch_fullalign_slow(t1k_ctx *ctx, const SlowArgs &a, int nBlocks) { hipLaunchKernelGGL(k_fullalign_slow, dim3(nBlocks), dim3(64), 0, ctx->stream, a); }
+void t1k_launch_fullalign_slow(t1k_ctx *ctx, const SlowArgs &a, int nBlocks) { hipLaunchKernelGGL(k_fullalign_slow, dim3(nBlocks * 64), dim3(64), 0, ctx->stream, a); }
 void t1k_launch_align_flags(t1k_ctx *ctx, const SlowArgs &a, uint32_t *flags) {
   hipLaunchKernelGGL(k_align_flags, dim3((a.nSlow + WG - 1) / WG), dim3(WG), 0, ctx->stream, a, flags);
 }
