@@ -27,8 +27,8 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 READ_LEN = 150
 # HBM traffic of one full-batch k_seed_groups launch (16384 fragments) from the rocprofv3 PMC passes of profiles/r01_pmc_hbm.md:
-# FETCH_SIZE 5.39e6 KB (x2: the counter tallies 128-B requests at 64 B on gfx950, MI355X_MICROARCH.md) + WRITE_SIZE 4.26e6 KB
-TRAFFIC_BYTES_PER_LAUNCH = 2 * 5.39e9 + 4.26e9
+# FETCH_SIZE 5.37e6 KB (x2: the counter tallies 128-B requests at 64 B on gfx950, MI355X_MICROARCH.md) + WRITE_SIZE 3.12e6 KB
+TRAFFIC_BYTES_PER_LAUNCH = 2 * 5.37e9 + 3.12e9
 
 
 def sh(cmd, **kw):
