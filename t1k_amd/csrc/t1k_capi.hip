@@ -352,6 +352,7 @@ int t1k_reads_upload(t1k_ctx *ctx, const char *seqs, const uint64_t *offsets, co
 extern "C++" int t1k_fetch_counters(t1k_ctx *ctx, unsigned long long *h) {
   std::vector<unsigned long long> &raw = ctx->hRaw;
   raw.resize(T1K_COUNTER_WORDS);
+  if (getenv("T1K_DEBUG_TRACE")) fprintf(stderr, "[t1k trace] counter fetch %d of this batch\n", ++ctx->traceFetch);
   T1K_HIP(ctx, hipMemcpyAsync(raw.data(), ctx->bCounters.p, (size_t)T1K_COUNTER_WORDS * 8, hipMemcpyDeviceToHost, ctx->stream));
   T1K_HIP(ctx, hipStreamSynchronize(ctx->stream));
   memcpy(h, raw.data(), 64 * 8);
@@ -428,6 +429,8 @@ int t1k_assign_range(t1k_ctx *ctx, uint64_t first, uint32_t count) {
   T1K_HIP(ctx, hipMemsetAsync(ctx->bCandCount.p, 0, (size_t)n * 4 + 4, ctx->stream));
   T1K_HIP(ctx, hipMemsetAsync(ctx->bWgCache.p, 0, (size_t)n * memoN * 8, ctx->stream));
   ctx->nCand = ctx->nOvl = 0;
+  ctx->traceFetch = 0;
+  if (getenv("T1K_DEBUG_TRACE")) fprintf(stderr, "[t1k trace] assign_range first %llu count %u\n", (unsigned long long)first, n);
   memset(&ctx->stats, 0, sizeof(ctx->stats));
   if (n == 0) return T1K_OK;
   unsigned long long hc[64];

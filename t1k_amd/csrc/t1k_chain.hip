@@ -445,13 +445,14 @@ __device__ __forceinline__ VoteKey voteKey(int matchCnt0, int rs, int re, uint32
 // ------------------------------------------------------------------------------------------------------------------
 #define CHUNK_A T1K_SEED_CHUNK
 // record word 2 before chaining: reference diagonal (22 bits, biased; alleles are shorter than 2^20 bases) and the counts of hits off
-// it, far (bits 22..26) and near = within `radius` (bits 27..31), saturating at 31 -- the chain only asks "near > 0" and "far > 2"
+// it, far (bits 22..26, saturating at 31) and near = within `radius` (bits 27..29, saturating at 7) -- the chain only asks
+// "near > 0" and "far > 2".  Bits 30 and 31 stay clear: after chaining the word holds the state, whose REC_DONE is bit 31.
 __device__ __forceinline__ uint32_t packDiagMeta(int diag, uint32_t meta) {
   const uint32_t strays = meta & 0xFFFFu, nearCnt = meta >> 16;
-  return (uint32_t)(diag + (1 << 21)) | (min(strays, 31u) << 22) | (min(nearCnt, 31u) << 27);
+  return (uint32_t)(diag + (1 << 21)) | (min(strays, 31u) << 22) | (min(nearCnt, 7u) << 27);
 }
 __device__ __forceinline__ int recDiag(uint32_t w2) { return (int)(w2 & 0x3FFFFFu) - (1 << 21); }
-__device__ __forceinline__ bool recIsGeneral(uint32_t w2) { return (w2 >> 27) > 0 || ((w2 >> 22) & 31u) > 2; }
+__device__ __forceinline__ bool recIsGeneral(uint32_t w2) { return ((w2 >> 27) & 7u) > 0 || ((w2 >> 22) & 31u) > 2; }
 #define DIAG_EMPTY 0x7FFFFFFF
 
 template <int NW>

@@ -652,6 +652,7 @@ struct t1k_ctx {
   uint32_t emGroups = 0, emEc = 0;
   uint64_t emNnz = 0;
   std::vector<int32_t> hEmLen;
+  int traceFetch = 0;          // T1K_DEBUG_TRACE
   uint64_t pairEpoch = 0;      // epochs handed out to k_pair's allele tables since they were last cleared
   double *emPinned = nullptr;  // page-locked staging for the per-update vectors: [x | n], emPinnedN doubles each
   size_t emPinnedN = 0;

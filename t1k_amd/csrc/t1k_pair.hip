@@ -439,6 +439,7 @@ int t1k_pair_batch(t1k_ctx *ctx, const uint32_t *end1, const uint32_t *end2, con
   p.fragCap = fragCap;
   p.keep = (uint32_t *)(sc + (size_t)nWg * A * 16 + (size_t)nWg * fragCap * sizeof(Frag));
   p.counters = (unsigned long long *)ctx->bCounters.p;
+  if (getenv("T1K_DEBUG_TRACE")) fprintf(stderr, "[t1k trace] pair_batch %u fragments\n", n);
   T1K_HIP(ctx, hipEventRecord(ctx->ev[5], ctx->stream));
   hipLaunchKernelGGL(k_pair, dim3(nWg), dim3(WG), 0, ctx->stream, p);
   T1K_HIP(ctx, hipEventRecord(ctx->ev[6], ctx->stream));
