@@ -110,6 +110,10 @@ int t1k_coverage_reset(t1k_ctx *ctx);
 /* per allele: number of exon positions whose coverage is below max(1, 1 % of the allele's median exon coverage)
  * (SeqSet::GetSeqMissingBaseCoverage, SeqSet.hpp:2717-2755), computed on the device; missing[nAlleles] */
 int t1k_missing_coverage(t1k_ctx *ctx, int32_t *missing);
+/* Several contexts on one GPU (pipelines of one job) can share the read-only device data of one of them: dst aliases src's
+ * reference (and gets its own, zeroed coverage array) / src's packed reads.  src must outlive dst. */
+int t1k_ref_share(t1k_ctx *dst, const t1k_ctx *src);
+int t1k_reads_share(t1k_ctx *dst, const t1k_ctx *src);
 /* adds src's coverage into dst's and clears src's; both contexts must live on the same device and hold the same reference */
 int t1k_coverage_absorb(t1k_ctx *dst, t1k_ctx *src);
 

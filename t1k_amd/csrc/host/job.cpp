@@ -98,7 +98,7 @@ int t1k_job_create(const t1k_job_params *p, const char *refFasta, t1k_job **out)
   for (int i = 1; i < nPipe; ++i) {
     t1k_ctx *c = nullptr;
     rc = t1k_ctx_create(job->prm.device, &job->prm.dev, &c);
-    if (rc == T1K_OK) rc = t1k_ref_upload(c, blob.data(), off.data(), ex.data(), (uint32_t)R.seqs.size());
+    if (rc == T1K_OK) rc = t1k_ref_share(c, job->ctx);  // the pipelines read one copy of the reference and index
     if (rc != T1K_OK) { if (c) t1k_ctx_destroy(c); break; }  // not enough memory: run with the pipelines we have
     job->more.push_back(c);
   }
@@ -109,8 +109,8 @@ int t1k_job_create(const t1k_job_params *p, const char *refFasta, t1k_job **out)
 
 void t1k_job_destroy(t1k_job *job) {
   if (!job) return;
+  for (t1k_ctx *c : job->more) t1k_ctx_destroy(c);  // before job->ctx, whose reference and reads they alias
   if (job->ctx) t1k_ctx_destroy(job->ctx);
-  for (t1k_ctx *c : job->more) t1k_ctx_destroy(c);
   delete job;
 }
 
@@ -179,7 +179,7 @@ int t1k_job_stage_reads(t1k_job *job) {
   int rc = t1k_reads_upload(job->ctx, job->ends.data(), job->endOff.data(), nullptr, nEnds);
   if (rc != T1K_OK) return jobFail(job, rc, t1k_last_error(job->ctx));
   for (t1k_ctx *c : job->more)
-    if ((rc = t1k_reads_upload(c, job->ends.data(), job->endOff.data(), nullptr, nEnds)) != T1K_OK) return jobFail(job, rc, t1k_last_error(c));
+    if ((rc = t1k_reads_share(c, job->ctx)) != T1K_OK) return jobFail(job, rc, t1k_last_error(c));  // one packed copy of the reads
   job->staged = true;
   job->msUpload = nowMs() - t0;
   return T1K_OK;

@@ -260,6 +260,32 @@ int t1k_coverage_device(t1k_ctx *ctx, void **devPtr, uint64_t *count) {
   return T1K_OK;
 }
 
+int t1k_ref_share(t1k_ctx *dst, const t1k_ctx *src) {
+  if (!dst || !src || dst == src || !src->ref.bases || dst->device != src->device) return t1k_fail(dst, T1K_ERR_ARG, "t1k_ref_share: contexts do not match");
+  if (dst->prm.kmer_length != src->prm.kmer_length) return t1k_fail(dst, T1K_ERR_ARG, "t1k_ref_share: different k-mer length");
+  T1K_HIP(dst, hipSetDevice(dst->device));
+  for (auto &b : dst->refBufs) freeBuf(b);
+  dst->refBufs.clear();
+  dst->ref = src->ref;  // read-only arrays are aliased; they stay owned by src, which must outlive dst
+  dst->hAlleleOff = src->hAlleleOff;
+  dst->hAlleleLen = src->hAlleleLen;
+  T1kDevBuf cov;  // the coverage difference array is per context
+  int rc;
+  if ((rc = t1k_ensure(dst, cov, (src->ref.totalBases + 2) * sizeof(int32_t)))) return rc;
+  T1K_HIP(dst, hipMemsetAsync(cov.p, 0, (src->ref.totalBases + 2) * sizeof(int32_t), dst->stream));
+  T1K_HIP(dst, hipStreamSynchronize(dst->stream));
+  dst->refBufs.push_back(cov);
+  dst->ref.covDiff = (int32_t *)cov.p;
+  return T1K_OK;
+}
+int t1k_reads_share(t1k_ctx *dst, const t1k_ctx *src) {
+  if (!dst || !src || dst == src || dst->device != src->device) return t1k_fail(dst, T1K_ERR_ARG, "t1k_reads_share: contexts do not match");
+  dst->reads = src->reads;  // packed read-ends are read-only for the stages; owned by src
+  dst->batchMaxLen = src->batchMaxLen;
+  dst->nCand = dst->nOvl = 0;
+  dst->rangeCount = 0;
+  return T1K_OK;
+}
 int t1k_coverage_absorb(t1k_ctx *dst, t1k_ctx *src) {
   if (!dst || !src || !dst->ref.covDiff || !src->ref.covDiff || dst->device != src->device || dst->ref.totalBases != src->ref.totalBases)
     return t1k_fail(dst, T1K_ERR_ARG, "t1k_coverage_absorb: contexts do not match");
