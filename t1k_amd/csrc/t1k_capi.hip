@@ -55,9 +55,9 @@ void t1k_params_default(t1k_params *p) {
   p->workgroups = 2048;
   p->hit_cap = 0;
   p->group_cap = 160ll << 20;
-  p->cand_cap = 256ll << 20;
-  p->ovl_cap = 160ll << 20;
-  p->row_cap = 128ll << 20;
+  p->cand_cap = 128ll << 20;
+  p->ovl_cap = 96ll << 20;
+  p->row_cap = 48ll << 20;
 }
 
 int t1k_device_count(void) {
