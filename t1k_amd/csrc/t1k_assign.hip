@@ -525,25 +525,25 @@ __global__ __launch_bounds__(WG) void k_fullalign(FullArgs P) {
     }
     return;
   }
-  // ungapped alignment: columns are MATCH except at the x mismatching positions
-  uint64_t carry = 0;  // coverage state of the previous position
-  int32_t *diff = P.ref.covDiff + goff + o.seqStart;
+  // ungapped alignment: columns are MATCH except at the x mismatching positions.  Coverage: the whole span as one run in the
+  // difference array (2 atomics) and one "hole" per position of the span that is not covered (mismatch or N)
+  if (w) {
+    int32_t *diff = P.ref.covDiff + goff + o.seqStart, *hole = diff + P.ref.covStride;
+    atomicAdd(&diff[0], w);
+    atomicAdd(&diff[L], -w);
 #pragma unroll
-  for (int wi = 0; wi < 10; ++wi) {
-    const int off = wi * 32;
-    if (off < L) {
-      const uint64_t cov = covw[wi];
-      uint64_t tr = cov ^ ((cov << 2) | carry);  // positions whose covered state differs from the previous position
-      while (tr) {
-        int b = __ffsll((long long)tr) - 1;
-        tr &= tr - 1;
-        bool on = (cov >> b) & 1;
-        if (w) atomicAdd(&diff[off + (b >> 1)], on ? w : -w);
+    for (int wi = 0; wi < 10; ++wi) {
+      const int off = wi * 32;
+      if (off < L) {
+        uint64_t un = T1K_EVEN & t1k_lowmask(L - off) & ~covw[wi];
+        while (un) {
+          const int b = __ffsll((long long)un) - 1;
+          un &= un - 1;
+          atomicAdd(&hole[off + (b >> 1)], w);
+        }
       }
-      carry = (cov >> 62) & 1;
     }
   }
-  if (carry && w) atomicAdd(&diff[L], -w);  // a run reaching the last position of a full final word closes at L
   int relaxed = P.relax ? 2 * (L - exonMis) : (int)o.matchCnt;  // 2215-2250
   P.ovl[gid].relaxed = (uint16_t)relaxed;
 }
@@ -865,7 +865,7 @@ __global__ __launch_bounds__(WG) void k_coverage_scan(T1kRefDev ref, int32_t *ou
     uint32_t tot;
     uint32_t ex = t1k_block_scan_exclusive((uint32_t)v, warpSums, &tot);
     int32_t incl = (int32_t)ex + v + sCarry;
-    if (i < len) o[i] = incl;
+    if (i < len) o[i] = incl - d[ref.covStride + i];  // minus the holes
     __syncthreads();
     if (threadIdx.x == 0) sCarry += (int32_t)tot;
     __syncthreads();
@@ -950,7 +950,7 @@ __global__ __launch_bounds__(WG) void k_missing_coverage(T1kRefDev ref, int32_t 
     const int32_t v = i < len ? d[i] : 0;
     uint32_t tot;
     const uint32_t ex = t1k_block_scan_exclusive((uint32_t)v, warpSums, &tot);
-    if (i < len) cv[i] = (int32_t)ex + v + sCarry;
+    if (i < len) cv[i] = (int32_t)ex + v + sCarry - d[ref.covStride + i];  // minus the holes
     __syncthreads();
     if (tid == 0) sCarry += (int32_t)tot;
     __syncthreads();

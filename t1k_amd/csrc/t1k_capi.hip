@@ -229,8 +229,9 @@ int t1k_ref_upload(t1k_ctx *ctx, const char *seqs, const uint64_t *offsets, cons
   if (post.empty()) post.push_back(T1kPosting{0, 0});
   if ((rc = uploadVec(ctx, post, (const void **)&r.kPost))) return rc;
   T1kDevBuf cov;
-  if ((rc = t1k_ensure(ctx, cov, (total + 2) * sizeof(int32_t)))) return rc;
-  T1K_HIP(ctx, hipMemsetAsync(cov.p, 0, (total + 2) * sizeof(int32_t), ctx->stream));
+  r.covStride = total + 2;
+  if ((rc = t1k_ensure(ctx, cov, 2 * r.covStride * sizeof(int32_t)))) return rc;
+  T1K_HIP(ctx, hipMemsetAsync(cov.p, 0, 2 * r.covStride * sizeof(int32_t), ctx->stream));
   ctx->refBufs.push_back(cov);
   r.covDiff = (int32_t *)cov.p;
   ctx->ref = r;
@@ -256,7 +257,7 @@ int t1k_missing_coverage(t1k_ctx *ctx, int32_t *missing) {
 int t1k_coverage_device(t1k_ctx *ctx, void **devPtr, uint64_t *count) {
   if (!ctx || !ctx->ref.covDiff || !devPtr || !count) return t1k_fail(ctx, T1K_ERR_STATE, "no reference");
   *devPtr = ctx->ref.covDiff;
-  *count = ctx->ref.totalBases + 2;
+  *count = 2 * ctx->ref.covStride;  // difference array and hole array, contiguous: both are additive over GPUs
   return T1K_OK;
 }
 
@@ -271,8 +272,8 @@ int t1k_ref_share(t1k_ctx *dst, const t1k_ctx *src) {
   dst->hAlleleLen = src->hAlleleLen;
   T1kDevBuf cov;  // the coverage difference array is per context
   int rc;
-  if ((rc = t1k_ensure(dst, cov, (src->ref.totalBases + 2) * sizeof(int32_t)))) return rc;
-  T1K_HIP(dst, hipMemsetAsync(cov.p, 0, (src->ref.totalBases + 2) * sizeof(int32_t), dst->stream));
+  if ((rc = t1k_ensure(dst, cov, 2 * src->ref.covStride * sizeof(int32_t)))) return rc;
+  T1K_HIP(dst, hipMemsetAsync(cov.p, 0, 2 * src->ref.covStride * sizeof(int32_t), dst->stream));
   T1K_HIP(dst, hipStreamSynchronize(dst->stream));
   dst->refBufs.push_back(cov);
   dst->ref.covDiff = (int32_t *)cov.p;
@@ -291,14 +292,14 @@ int t1k_coverage_absorb(t1k_ctx *dst, t1k_ctx *src) {
     return t1k_fail(dst, T1K_ERR_ARG, "t1k_coverage_absorb: contexts do not match");
   T1K_HIP(dst, hipSetDevice(dst->device));
   T1K_HIP(dst, hipStreamSynchronize(src->stream));
-  t1k_launch_coverage_add(dst, dst->ref.covDiff, src->ref.covDiff, dst->ref.totalBases + 2);
+  t1k_launch_coverage_add(dst, dst->ref.covDiff, src->ref.covDiff, 2 * dst->ref.covStride);
   T1K_HIP(dst, hipStreamSynchronize(dst->stream));
   return T1K_OK;
 }
 int t1k_coverage_reset(t1k_ctx *ctx) {
   if (!ctx || !ctx->ref.covDiff) return t1k_fail(ctx, T1K_ERR_STATE, "no reference");
   T1K_HIP(ctx, hipSetDevice(ctx->device));
-  T1K_HIP(ctx, hipMemsetAsync(ctx->ref.covDiff, 0, (ctx->ref.totalBases + 2) * sizeof(int32_t), ctx->stream));
+  T1K_HIP(ctx, hipMemsetAsync(ctx->ref.covDiff, 0, 2 * ctx->ref.covStride * sizeof(int32_t), ctx->stream));
   T1K_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return T1K_OK;
 }

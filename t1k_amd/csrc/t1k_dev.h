@@ -73,7 +73,10 @@ struct T1kRefDev {
   const uint32_t *kDir;         // [rows][kDirStride]
   uint32_t kDirStride;
   const T1kPosting *kPost;
-  int32_t *covDiff;             // [totalBases + 1] difference array of per-base coverage
+  // per-base coverage = prefix sum of covDiff (+w where a covered run starts, -w behind its end) minus covHole (w at a position
+  // inside an ungapped alignment's span that is not covered: a mismatch or an N).  covHole = covDiff + covStride.
+  int32_t *covDiff;             // [2][covStride]
+  uint64_t covStride;           // totalBases + 2
 };
 
 struct T1kReadsDev {
