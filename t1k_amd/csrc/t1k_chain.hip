@@ -1392,6 +1392,12 @@ __global__ __launch_bounds__(WG) void k_job_keys(const unsigned long long *memo,
   const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q < n) keys[q] = (memo[jobs[q]] >> 5) & 0x1FF;
 }
+// sort key of a multi-diagonal group: its hit count (record word 4 after k_gather_general), so that the lanes of k_chain_general's
+// wavefronts work on groups of similar size
+__global__ __launch_bounds__(WG) void k_group_size_keys(const uint32_t *recs, uint32_t stride, const uint32_t *list, unsigned long long *keys, uint32_t n) {
+  const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q < n) keys[q] = min(recs[(uint64_t)list[q] * stride + 4], 63u);
+}
 void t1k_launch_dp_dense(t1k_ctx *ctx, const ChainArgs &a, const uint32_t *jobs, uint32_t n) {
   if (!n) return;
   // order the jobs by length first (9-bit radix sort, ~50 us): wavefronts of mixed lengths ran at 40 % lane utilisation
@@ -1461,7 +1467,14 @@ int t1k_run_chain(t1k_ctx *ctx, const ChainArgs &a, int nWg, int bigBlocks, bool
   uint32_t nBig = 0;
   if (nGen) {
     hipLaunchKernelGGL(k_gather_general, dim3(std::min<uint32_t>((nGen + 3) / 4, 8192u)), dim3(WG), 0, ctx->stream, a, nGen);
-    hipLaunchKernelGGL(k_chain_general, dim3((nGen + 63) / 64), dim3(64), 0, ctx->stream, a, nGen);
+    ChainArgs g = a;
+    if (nGen >= 4096 && t1k_ensure(ctx, ctx->bJobSort, (size_t)nGen * 20 + 64) == T1K_OK) {  // groups of similar size side by side
+      unsigned long long *k0 = (unsigned long long *)ctx->bJobSort.p, *k1 = k0 + nGen;
+      uint32_t *sorted = (uint32_t *)(k1 + nGen);
+      hipLaunchKernelGGL(k_group_size_keys, dim3((nGen + WG - 1) / WG), dim3(WG), 0, ctx->stream, (const uint32_t *)a.recs, a.recStride, (const uint32_t *)a.generalList, k0, nGen);
+      if (t1k_sort_pairs(ctx, k0, k1, a.generalList, sorted, nGen, 6) == T1K_OK) g.generalList = sorted;
+    }
+    hipLaunchKernelGGL(k_chain_general, dim3((nGen + 63) / 64), dim3(64), 0, ctx->stream, g, nGen);
     if ((rc = readCounters(ctx, hc))) return rc;
     const T1kArenaCounts wv = t1k_arena_counts(ctx, T1K_AR_WAVE, a.listSegCap);
     if (wv.overflow) { hc[2] |= ERR_GROUPCAP; return 0; }
