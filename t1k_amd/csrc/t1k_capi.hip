@@ -102,6 +102,7 @@ static void freeBuf(T1kDevBuf &b) {
 
 void t1k_ctx_destroy(t1k_ctx *ctx) {
   if (ctx && ctx->emPinned) { (void)hipHostFree(ctx->emPinned); ctx->emPinned = nullptr; }
+  if (ctx && ctx->countersPinned) { (void)hipHostFree(ctx->countersPinned); ctx->countersPinned = nullptr; }
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   for (auto &b : ctx->refBufs) freeBuf(b);
@@ -380,8 +381,11 @@ extern "C++" int t1k_fetch_counters(t1k_ctx *ctx, unsigned long long *h) {
   std::vector<unsigned long long> &raw = ctx->hRaw;
   raw.resize(T1K_COUNTER_WORDS);
   if (getenv("T1K_DEBUG_TRACE")) fprintf(stderr, "[t1k trace] counter fetch %d of this batch\n", ++ctx->traceFetch);
-  T1K_HIP(ctx, hipMemcpyAsync(raw.data(), ctx->bCounters.p, (size_t)T1K_COUNTER_WORDS * 8, hipMemcpyDeviceToHost, ctx->stream));
+  // a dozen of these per batch sit on the pipeline's critical path: page-locked landing buffer (a plain DMA, no staging)
+  if (!ctx->countersPinned) T1K_HIP(ctx, hipHostMalloc((void **)&ctx->countersPinned, (size_t)T1K_COUNTER_WORDS * 8, hipHostMallocDefault));
+  T1K_HIP(ctx, hipMemcpyAsync(ctx->countersPinned, ctx->bCounters.p, (size_t)T1K_COUNTER_WORDS * 8, hipMemcpyDeviceToHost, ctx->stream));
   T1K_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  memcpy(raw.data(), ctx->countersPinned, (size_t)T1K_COUNTER_WORDS * 8);
   memcpy(h, raw.data(), 64 * 8);
   h[6] = 0;  // group records: sum of the arena's segment cursors
   for (int s = 0; s < T1K_NSTRIPE; ++s) h[6] += raw[T1K_ARENA_BASE + ((size_t)T1K_AR_GROUPS * T1K_NSTRIPE + s) * 8];

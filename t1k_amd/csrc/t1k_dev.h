@@ -657,6 +657,7 @@ struct t1k_ctx {
   std::vector<int32_t> hEmLen;
   int traceFetch = 0;          // T1K_DEBUG_TRACE
   uint64_t pairEpoch = 0;      // epochs handed out to k_pair's allele tables since they were last cleared
+  unsigned long long *countersPinned = nullptr;  // page-locked landing buffer of t1k_fetch_counters
   double *emPinned = nullptr;  // page-locked staging for the per-update vectors: [x | n], emPinnedN doubles each
   size_t emPinnedN = 0;
   t1k_allreduce_fn emAllreduce = nullptr;
