@@ -107,10 +107,10 @@ void t1k_ctx_destroy(t1k_ctx *ctx) {
   (void)hipSetDevice(ctx->device);
   for (auto &b : ctx->refBufs) freeBuf(b);
   T1kDevBuf *all[] = {&ctx->bReadAscii, &ctx->bReadOffs, &ctx->bReadBases, &ctx->bReadN, &ctx->bReadLen, &ctx->bReadWeight, &ctx->bWgHits, &ctx->bWgGroups,
-                      &ctx->bWgStage, &ctx->bWgThreadScratch, &ctx->bWgBig, &ctx->bWgCache, &ctx->bLists, &ctx->bCand, &ctx->bExt, &ctx->bCandStart, &ctx->bCandCount, &ctx->bOvl,
+                      &ctx->bWgStage, &ctx->bWgBig, &ctx->bWgCache, &ctx->bLists, &ctx->bCand, &ctx->bExt, &ctx->bCandStart, &ctx->bCandCount, &ctx->bOvl,
                       &ctx->bOvlStart, &ctx->bOvlCount, &ctx->bCounters, &ctx->bSlowQueue, &ctx->bSlowScratch, &ctx->bSortScratch, &ctx->bEqTrace, &ctx->bSortTmp, &ctx->bSlowKeys, &ctx->bJobSort, &ctx->bEnd1, &ctx->bEnd2,
                       &ctx->bHasN, &ctx->bRows, &ctx->bRowStart, &ctx->bRowCount, &ctx->bFragAssigned, &ctx->bPairScratch, &ctx->bEmRowPtr, &ctx->bEmEc,
-                      &ctx->bEmCount, &ctx->bEmLen, &ctx->bEmX0, &ctx->bEmX1, &ctx->bEmN, &ctx->bEmContrib, &ctx->bEmColPtr, &ctx->bEmColIdx, &ctx->bEmScalars};
+                      &ctx->bEmCount, &ctx->bEmLen, &ctx->bEmX0, &ctx->bEmN, &ctx->bEmContrib, &ctx->bEmColPtr, &ctx->bEmColIdx};
   for (auto *b : all) freeBuf(*b);
   for (auto &b : ctx->bAlign) freeBuf(b);
   for (auto &e : ctx->ev) if (e) (void)hipEventDestroy(e);

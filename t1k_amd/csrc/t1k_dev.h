@@ -535,16 +535,6 @@ __device__ inline int t1k_ga_traceback(const uint8_t *trace, int lent, int lenp,
   return n;
 }
 
-// append to a global list from (possibly divergent) code: the active lanes of the wavefront share one atomic
-__device__ __forceinline__ uint32_t t1k_wave_append(uint32_t *counter) {
-  const uint64_t m = __ballot(1);
-  const int lane = threadIdx.x & 63;
-  uint32_t base = 0;
-  if (lane == __ffsll((long long)m) - 1) base = atomicAdd(counter, (uint32_t)__popcll(m));
-  base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-  return base + (uint32_t)__popcll(m & ((1ull << lane) - 1));
-}
-
 // Statistics counters (never read by device code).  Millions of atomics on one address serialise in L2, so every
 // statistic is striped over T1K_STAT_STRIPES cache lines behind the 64 control counters; the host adds the stripes up.
 #define T1K_STAT_STRIPES 256
@@ -643,7 +633,7 @@ struct t1k_ctx {
   int batchMaxLen = 0;
   uint32_t rangeCount = 0;       // read-ends of the last t1k_assign_range
   // assignment arenas
-  T1kDevBuf bWgHits, bWgGroups, bWgStage, bWgThreadScratch, bWgBig, bWgCache, bLists;
+  T1kDevBuf bWgHits, bWgGroups, bWgStage, bWgBig, bWgCache, bLists;
   T1kDevBuf bCand, bExt, bCandStart, bCandCount, bOvl, bOvlStart, bOvlCount, bCounters, bSlowQueue, bSlowScratch, bSortScratch, bEqTrace, bSortTmp, bSlowKeys, bJobSort;
   uint64_t nCand = 0, nOvl = 0;
   // pairing
@@ -651,7 +641,7 @@ struct t1k_ctx {
   uint32_t nFragments = 0;
   uint64_t nRows = 0;
   // EM
-  T1kDevBuf bEmRowPtr, bEmEc, bEmCount, bEmLen, bEmX0, bEmX1, bEmN, bEmContrib, bEmColPtr, bEmColIdx, bEmScalars;
+  T1kDevBuf bEmRowPtr, bEmEc, bEmCount, bEmLen, bEmX0, bEmN, bEmContrib, bEmColPtr, bEmColIdx;
   uint32_t emGroups = 0, emEc = 0;
   uint64_t emNnz = 0;
   std::vector<int32_t> hEmLen;
