@@ -117,6 +117,16 @@ int t1k_reads_share(t1k_ctx *dst, const t1k_ctx *src);
 /* adds src's coverage into dst's and clears src's; both contexts must live on the same device and hold the same reference */
 int t1k_coverage_absorb(t1k_ctx *dst, t1k_ctx *src);
 
+/* ---- candidate extraction: IsGoodCandidate (FastqExtractor.cpp:113-118) = !IsLowComplexity (FastqExtractor.cpp:89-111) &&
+ * SeqSet::HasHitInSet (SeqSet.hpp:1915-1990: GetHitsFromRead 1071, fullest (strand, sequence) bucket 1929-1964, GetOverlapsFromHits 1232
+ * with filter 0, mismatch threshold 1974-1979) for every fragment of the uploaded batch.  The context is created with the
+ * extractor's parameters (kmer_length = SeqSet::InferKmerLength, hit_len_required as FastqExtractor.cpp:383-416 computes it,
+ * ref_seq_similarity = -s) and its reference uploaded with t1k_ref_upload (exon = NULL; SeqSet::InputRefFa 872-904 keeps one
+ * sequence per FASTA record).  Read-ends of a fragment are consecutive in the batch (endsPerFragment 1 or 2); the second end is
+ * only tested when the first fails (FastqExtractor.cpp:459-464).  good[nReadEnds / endsPerFragment] receives 0 / 1.
+ * stats (may be NULL) receives {read-ends tested, index look-ups, postings of the used lists, read-ends with a hit, read-ends chained}. */
+int t1k_extract_batch(t1k_ctx *ctx, uint32_t endsPerFragment, uint8_t *good, uint64_t *stats);
+
 /* ---- AlignAlgo::GlobalAlignment (AlignAlgo.hpp:215-421) as a batch --------------------------------------------
  * job i aligns t = text[tOff[i] .. tOff[i]+tLen[i]) against p = pat[pOff[i] .. +pLen[i]) (ASCII, N = wildcard).
  * Outputs per job: score, number of MATCH / MISMATCH / indel columns (SeqSet::GetAlignStats, SeqSet.hpp:438-455) and,
@@ -151,6 +161,8 @@ int t1k_stats_get(t1k_ctx *ctx, t1k_stats *out);
 /* ---- whole-stage job API (host C++ + the device stages above) ------------------------------------------------- */
 /* argv-compatible replacement of the reference's genotyper executable (Genotyper.cpp:194-738). Returns the exit code. */
 int t1k_genotyper_main(int argc, char **argv);
+/* argv-compatible replacement of the reference's fastq-extractor main() (FastqExtractor.cpp:260-626; run-t1k:377-403) */
+int t1k_extractor_main(int argc, char **argv);
 
 typedef struct {
   t1k_params dev;

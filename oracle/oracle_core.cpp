@@ -176,6 +176,7 @@ bool readAllRecords(const std::string &path, std::vector<SeqRecord> &out) {
     size_t sp = line.find_first_of(" \t");
     r.id = line.substr(1, sp == std::string::npos ? std::string::npos : sp - 1);
     if (sp != std::string::npos && sp + 1 < line.size()) { r.comment = line.substr(sp + 1); r.hasComment = !r.comment.empty(); }
+    r.rawId = r.id;
     int n = (int)r.id.size();  // ReadFiles.hpp:185-189: strip trailing /1 or /2
     if (n >= 2 && (r.id[n - 1] == '1' || r.id[n - 1] == '2') && r.id[n - 2] == '/') r.id.resize(n - 2);
     have = in.getline(line);

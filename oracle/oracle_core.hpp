@@ -104,6 +104,14 @@ class Oracle {
   std::vector<double> ecReadCountFinal, ecAbundanceFinal;
   std::vector<int> ecLength;
 
+  // ---- candidate extraction (oracle_extract.cpp) ----
+  int loadReferenceFa(const std::string &fasta);   // SeqSet::InputRefFa (SeqSet.hpp:872-904): one sequence per record, no merging
+  int inferKmerLength() const;                     // SeqSet::InferKmerLength (SeqSet.hpp:2830-2845)
+  void setKmerLength(int k);                       // SeqSet::UpdateKmerLength (SeqSet.hpp:2847-2858)
+  bool hasHitInSet(const std::string &read);       // SeqSet::HasHitInSet (SeqSet.hpp:1915-1990)
+  static bool isLowComplexityRead(const std::string &read);  // IsLowComplexity (FastqExtractor.cpp:89-111)
+  bool isGoodCandidate(const std::string &read) { return !isLowComplexityRead(read) && hasHitInSet(read); }  // FastqExtractor.cpp:113-118
+
   // helpers exposed for unit tests
   void seedHits(const std::string &read, std::vector<int> &strand, std::vector<int> &readOff, std::vector<Posting> &post);
   bool separatorInRange(int s, int e, int seqIdx) const;  // SeqSet.hpp:487-498
@@ -127,7 +135,7 @@ class Oracle {
 };
 
 // FASTA/FASTQ(+gz) record reader with the reference's id/comment conventions (ReadFiles.hpp:155-204, kseq.h)
-struct SeqRecord { std::string id, comment, seq, qual; bool hasComment = false; };
+struct SeqRecord { std::string id, rawId, comment, seq, qual; bool hasComment = false; };  // rawId: before the /1 /2 strip
 bool readAllRecords(const std::string &path, std::vector<SeqRecord> &out);
 
 std::string reverseComplement(const std::string &s);  // SeqSet.hpp:2103-2114

@@ -1,0 +1,374 @@
+// t1k_amd/csrc/host/extract.cpp -- host side of the candidate-read extractor: the argv-compatible replacement of the reference's
+// fastq-extractor main() (FastqExtractor.cpp:260-626, called by run-t1k:377-403).  Input parsing, parameter inference and the
+// output writers stay on the CPU; the per-read test IsGoodCandidate runs on the GPU (t1k_extract_batch), one chunk of fragments at a
+// time, with the readers running ahead of the GPU on their own threads.  There is no CPU fallback: without a GPU the run fails.
+#include <zlib.h>
+
+#include <algorithm>
+#include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <ctime>
+#include <deque>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "t1k_host.h"
+
+namespace {
+
+// FASTA/FASTQ records with kseq.h's rules (the reader behind ReadFiles.hpp): the name ends at the first blank, sequence lines are
+// joined until a line starting with '+', '>' or '@', quality lines are joined until they are as long as the sequence.
+struct RecordReader {
+  gzFile fp = nullptr;
+  std::vector<char> buf;
+  size_t pos = 0, end = 0;
+  bool eof = false;
+  std::string pending;  // a header line read ahead
+  bool havePending = false;
+  explicit RecordReader(const std::string &path) : buf(1 << 22) {
+    fp = gzopen(path.c_str(), "r");
+    if (fp) gzbuffer(fp, 1 << 20);
+  }
+  ~RecordReader() { if (fp) gzclose(fp); }
+  bool getline(std::string &line) {
+    line.clear();
+    while (true) {
+      if (pos == end) {
+        if (eof) return !line.empty();
+        const int n = gzread(fp, buf.data(), (unsigned)buf.size());
+        if (n <= 0) { eof = true; return !line.empty(); }
+        pos = 0; end = (size_t)n;
+      }
+      const char *nl = (const char *)memchr(buf.data() + pos, '\n', end - pos);
+      if (nl) {
+        line.append(buf.data() + pos, nl - (buf.data() + pos));
+        pos = (size_t)(nl - buf.data()) + 1;
+        if (line.size() > 1 && line.back() == '\r') line.pop_back();
+        return true;
+      }
+      line.append(buf.data() + pos, end - pos);
+      pos = end;
+    }
+  }
+  // name (up to the first blank), sequence, quality ("" for FASTA); false at the end of the file
+  bool next(std::string &name, std::string &seq, std::string &qual) {
+    std::string line;
+    if (havePending) { line.swap(pending); havePending = false; }
+    else {
+      bool got = false;
+      while (getline(line)) if (!line.empty() && (line[0] == '>' || line[0] == '@')) { got = true; break; }
+      if (!got) return false;
+    }
+    size_t sp = 1;
+    while (sp < line.size() && !isspace((unsigned char)line[sp])) ++sp;
+    name.assign(line, 1, sp - 1);
+    seq.clear(); qual.clear();
+    bool plus = false;
+    while (getline(line)) {
+      if (line.empty()) continue;
+      if (line[0] == '>' || line[0] == '@') { pending.swap(line); havePending = true; break; }
+      if (line[0] == '+') { plus = true; break; }
+      seq += line;
+    }
+    if (plus) {
+      while (qual.size() < seq.size() && getline(line)) qual += line;
+      if (qual.size() != seq.size()) return false;  // truncated record: kseq_read returns -2, ReadFiles treats it as the end of the file
+    }
+    return true;
+  }
+};
+
+struct EndChunk {  // one chunk of one input stream
+  std::string arena;  // name \0 seq \0 qual \0 per record
+  std::vector<uint64_t> off;      // start of each record in the arena
+  std::vector<uint32_t> nameLen, seqLen;
+  std::vector<uint8_t> hasQual;
+  size_t n() const { return nameLen.size(); }
+  const char *name(size_t i) const { return arena.data() + off[i]; }
+  const char *seq(size_t i) const { return arena.data() + off[i] + nameLen[i] + 1; }
+  const char *qual(size_t i) const { return hasQual[i] ? seq(i) + seqLen[i] + 1 : nullptr; }
+};
+
+// One input stream = the files given with repeated -1 / -2 / -u / --barcode, read back to back on its own thread.  mod / rem select
+// the records of an interleaved file (-i): record r is kept if r % mod == rem.
+struct Stream {
+  std::vector<std::string> files;
+  int mod = 1, rem = 0;
+  size_t chunkRecords = 1 << 20;
+  std::mutex mu;
+  std::condition_variable cv;
+  std::deque<std::unique_ptr<EndChunk>> q;
+  bool done = false, failed = false;
+  std::thread th;
+  void start() { th = std::thread([this] { run(); }); }
+  void run() {
+    auto cur = std::make_unique<EndChunk>();
+    auto flush = [&](bool last) {
+      std::unique_lock<std::mutex> lk(mu);
+      cv.wait(lk, [&] { return q.size() < 2; });
+      if (cur->n() || last) q.push_back(std::move(cur));
+      if (last) done = true;
+      cv.notify_all();
+      cur = std::make_unique<EndChunk>();
+    };
+    std::string name, seq, qual;
+    for (auto &f : files) {
+      RecordReader rd(f);
+      if (!rd.fp) { failed = true; break; }
+      uint64_t r = 0;
+      while (rd.next(name, seq, qual)) {
+        if ((int)(r++ % mod) != rem) continue;
+        cur->off.push_back(cur->arena.size());
+        cur->nameLen.push_back((uint32_t)name.size());
+        cur->seqLen.push_back((uint32_t)seq.size());
+        cur->hasQual.push_back(qual.empty() ? 0 : 1);
+        cur->arena.append(name); cur->arena.push_back('\0');
+        cur->arena.append(seq); cur->arena.push_back('\0');
+        if (!qual.empty()) { cur->arena.append(qual); cur->arena.push_back('\0'); }
+        if (cur->n() >= chunkRecords) flush(false);
+      }
+    }
+    flush(true);
+  }
+  // next chunk (possibly empty at the very end); nullptr when the stream is exhausted
+  std::unique_ptr<EndChunk> pop() {
+    std::unique_lock<std::mutex> lk(mu);
+    cv.wait(lk, [&] { return !q.empty() || done; });
+    if (q.empty()) return nullptr;
+    auto c = std::move(q.front());
+    q.pop_front();
+    cv.notify_all();
+    return c;
+  }
+  ~Stream() { if (th.joinable()) th.join(); }
+};
+
+void printLog(const char *msg) {  // PrintLog (FastqExtractor.cpp:76-87)
+  time_t t = time(nullptr);
+  char stime[500];
+  strftime(stime, sizeof(stime), "%c", localtime(&t));
+  fprintf(stderr, "[%s] %s\n", stime, msg);
+}
+
+const char kUsage[] =
+    "./fastq-extractor [OPTIONS]:\n"
+    "Required:\n"
+    "\t-f STRING: fasta file containing the reference sequence\n"
+    "\t-u STRING: path to single-end read file\n"
+    "\t\tor\n"
+    "\t-1 STRING -2 STRING: path to paired-end read files\n"
+    "\t\tor\n"
+    "\t-i STRING: path to interleaved read file\n"
+    "Optional:\n"
+    "\t-o STRING: prefix to the output file (default: toassemble)\n"
+    "\t-t INT: number of threads (default: 1)\n"
+    "\t-s FLOAT: filter alignments with alignment similarity less than specified value (defalut: 0.8)\n"
+    "\t--barcode STRING: path to the raw barcode file (default: not used)\n"
+    "\t--barcodeStart INT: the start position of barcode in the barcode sequence (default: 0)\n"
+    "\t--barcodeEnd INT: the end position of barcode in the barcode sequence (default: length-1)\n"
+    "\t--barcodeRevComp: whether the barcode need to be reverse complemented (default: not used)\n"
+    "\t--read1Start INT: the start position of sequence in read 1 (default: 0)\n"
+    "\t--read1End INT: the end position of sequence in read 1 (default: length-1)\n"
+    "\t--read2Start INT: the start position of sequence in read 2 (default: 0)\n"
+    "\t--read2End INT: the end position of sequence in read 2 (default: length-1)\n";
+
+// OutputSeq (FastqExtractor.cpp:120-154)
+void outputSeq(std::string &out, const char *name, size_t nameLen, const char *seq, const char *qual, size_t len, int start, int end) {
+  size_t s = 0, n = len;
+  if (!(start == 0 && end == -1)) {
+    const long e = end == -1 ? (long)len - 1 : end;
+    s = (size_t)start;
+    n = e >= start ? (size_t)(e - start + 1) : 0;
+    if (s > len) { s = len; n = 0; }
+    if (s + n > len) n = len - s;
+  }
+  out.push_back(qual ? '@' : '>');
+  out.append(name, nameLen); out.push_back('\n');
+  out.append(seq + s, n); out.push_back('\n');
+  if (qual) { out.append("+\n"); out.append(qual + s, n); out.push_back('\n'); }
+}
+
+}  // namespace
+
+extern "C" int t1k_extractor_main(int argc, char **argv) {
+  if (argc <= 1) { fprintf(stderr, "%s", kUsage); return 0; }
+  std::string refPath, prefix = "toassemble";
+  Stream reads, mates, barcodes;
+  bool hasMate = false, hasBarcode = false, barcodeRevComp = false;
+  double similarity = 0.8;
+  int threadCnt = 1, barcodeStart = 0, barcodeEnd = -1, r1s = 0, r1e = -1, r2s = 0, r2e = -1;
+  for (int i = 1; i < argc; ++i) {
+    const std::string a = argv[i];
+    auto val = [&]() -> const char * { return i + 1 < argc ? argv[++i] : ""; };
+    if (a == "-f") refPath = val();
+    else if (a == "-o") prefix = val();
+    else if (a == "-1") { reads.files.push_back(val()); hasMate = true; }
+    else if (a == "-2") { mates.files.push_back(val()); hasMate = true; }
+    else if (a == "-u") reads.files.push_back(val());
+    else if (a == "-i") {
+      const char *f = val();
+      if (!reads.files.empty() || !mates.files.empty()) { fprintf(stderr, "-i takes the place of every other read file option.\n"); return EXIT_FAILURE; }
+      reads.files.push_back(f); mates.files.push_back(f);
+      reads.mod = mates.mod = 2; reads.rem = 0; mates.rem = 1;
+      hasMate = true;
+    }
+    else if (a == "-t") threadCnt = atoi(val());
+    else if (a == "-s") similarity = atof(val());
+    else if (a == "--barcode") { hasBarcode = true; barcodes.files.push_back(val()); }
+    else if (a == "--barcodeStart") barcodeStart = atoi(val());
+    else if (a == "--barcodeEnd") barcodeEnd = atoi(val());
+    else if (a == "--barcodeRevComp") barcodeRevComp = true;
+    else if (a == "--barcodeWhitelist") {
+      fprintf(stderr, "--barcodeWhitelist (BarcodeCorrector.hpp) is not part of this build.\n");
+      return EXIT_FAILURE;
+    }
+    else if (a == "--read1Start") r1s = atoi(val());
+    else if (a == "--read1End") r1e = atoi(val());
+    else if (a == "--read2Start") r2s = atoi(val());
+    else if (a == "--read2End") r2e = atoi(val());
+    else { fprintf(stderr, "Unknown parameter %s\n", a.c_str()); return EXIT_FAILURE; }
+  }
+  if (refPath.empty()) { fprintf(stderr, "Need to use -f to specify the reference sequence.\n"); return EXIT_FAILURE; }
+  if (reads.files.empty()) { fprintf(stderr, "Need to use -u/-1/-2/-i to specify the read files.\n"); return EXIT_FAILURE; }
+  printLog("Start to extract candidate reads from read files.");
+
+  // reference: one sequence per FASTA record (SeqSet::InputRefFa, SeqSet.hpp:872-904)
+  std::vector<t1k::SeqRec> ref;
+  std::string err;
+  if (!t1k::readSeqFile(refPath, ref, err) || ref.empty()) { fprintf(stderr, "%s\n", err.empty() ? "empty reference" : err.c_str()); return EXIT_FAILURE; }
+  // hitLenRequired from the first 1000 reads (FastqExtractor.cpp:383-401)
+  int hitLenRequired = hasMate ? 27 : 23;
+  {
+    int len = 0, n = 0;
+    std::string name, seq, qual;
+    uint64_t r = 0;
+    for (auto &f : reads.files) {
+      RecordReader rd(f);
+      if (!rd.fp) { fprintf(stderr, "Cannot open %s\n", f.c_str()); return EXIT_FAILURE; }
+      while (n < 1000 && rd.next(name, seq, qual)) {
+        if ((int)(r++ % reads.mod) != reads.rem) continue;
+        len += (int)seq.size(); ++n;
+      }
+      if (n >= 1000) break;
+    }
+    if (n == 0) { fprintf(stderr, "Read file is empty.\n"); return EXIT_FAILURE; }
+    if (len / (n * 5) > hitLenRequired) hitLenRequired = len / (n * 5);
+  }
+  // k-mer length (SeqSet::InferKmerLength 2830-2845, FastqExtractor.cpp:409-416); the total is an int in the reference as well
+  int kmerLength = 9;
+  {
+    int total = 0;
+    for (auto &r : ref) total += (int)r.seq.size();
+    int ret = 0;
+    while (total) { ++ret; total /= 4; }
+    ++ret;
+    if (ret > kmerLength) { kmerLength = ret; if (kmerLength > hitLenRequired) hitLenRequired = kmerLength; }
+  }
+
+  if (t1k_device_count() <= 0) { fprintf(stderr, "fastq-extractor: no HIP device (this build has no CPU path)\n"); return EXIT_FAILURE; }
+  t1k_params prm;
+  t1k_params_default(&prm);
+  prm.kmer_length = kmerLength;
+  prm.hit_len_required = hitLenRequired;
+  prm.ref_seq_similarity = similarity;
+  t1k_ctx *ctx = nullptr;
+  if (t1k_ctx_create(0, &prm, &ctx) != T1K_OK) { fprintf(stderr, "fastq-extractor: cannot create the device context (k = %d)\n", kmerLength); return EXIT_FAILURE; }
+  {
+    std::string cat;
+    std::vector<uint64_t> off(ref.size() + 1, 0);
+    for (size_t i = 0; i < ref.size(); ++i) { cat += ref[i].seq; off[i + 1] = cat.size(); }
+    if (t1k_ref_upload(ctx, cat.data(), off.data(), nullptr, (uint32_t)ref.size()) != T1K_OK) {
+      fprintf(stderr, "fastq-extractor: %s\n", t1k_last_error(ctx));
+      t1k_ctx_destroy(ctx);
+      return EXIT_FAILURE;
+    }
+  }
+
+  FILE *fp1 = fopen((prefix + (hasMate ? "_1.fq" : ".fq")).c_str(), "w");
+  FILE *fp2 = hasMate ? fopen((prefix + "_2.fq").c_str(), "w") : nullptr;
+  FILE *fpBc = hasBarcode ? fopen((prefix + "_bc.fa").c_str(), "w") : nullptr;
+  if (!fp1 || (hasMate && !fp2) || (hasBarcode && !fpBc)) { fprintf(stderr, "Cannot open the output files.\n"); t1k_ctx_destroy(ctx); return EXIT_FAILURE; }
+
+  if (const char *e = getenv("T1K_EXTRACT_CHUNK")) reads.chunkRecords = mates.chunkRecords = barcodes.chunkRecords = (size_t)std::max(1, atoi(e));
+  reads.start();
+  if (hasMate) mates.start();
+  if (hasBarcode) barcodes.start();
+  int rc = 0;
+  std::string seqCat, out1, out2, outBc;
+  std::vector<uint64_t> offs;
+  std::vector<uint8_t> good;
+  uint64_t nFragments = 0, nGood = 0;
+  while (true) {
+    auto c1 = reads.pop();
+    std::unique_ptr<EndChunk> c2, cb;
+    if (hasMate) c2 = mates.pop();
+    if (hasBarcode) cb = barcodes.pop();
+    const size_t n1 = c1 ? c1->n() : 0;
+    if (hasMate && (c2 ? c2->n() : 0) != n1) { fprintf(stderr, "The two mate-pair read files have different number of reads.\n"); rc = 1; break; }
+    if (hasBarcode && (cb ? cb->n() : 0) != n1) { fprintf(stderr, "Read file and barcode have different number of reads.\n"); rc = 1; break; }
+    if (!c1) break;
+    if (n1 == 0) continue;
+    const uint32_t epf = hasMate ? 2 : 1;
+    seqCat.clear(); offs.clear(); offs.push_back(0);
+    for (size_t i = 0; i < n1; ++i) {
+      seqCat.append(c1->seq(i), c1->seqLen[i]); offs.push_back(seqCat.size());
+      if (hasMate) { seqCat.append(c2->seq(i), c2->seqLen[i]); offs.push_back(seqCat.size()); }
+    }
+    good.assign(n1, 0);
+    if (t1k_reads_upload(ctx, seqCat.data(), offs.data(), nullptr, (uint32_t)(n1 * epf)) != T1K_OK || t1k_extract_batch(ctx, epf, good.data(), nullptr) != T1K_OK) {
+      fprintf(stderr, "fastq-extractor: %s\n", t1k_last_error(ctx));
+      rc = 1;
+      break;
+    }
+    out1.clear(); out2.clear(); outBc.clear();
+    for (size_t i = 0; i < n1; ++i) {
+      if (!good[i]) continue;
+      ++nGood;
+      // the single-thread loop prints ReadFiles::Next()'s id (a trailing /1 or /2 removed, ReadFiles.hpp:185-189), the batch loop of
+      // -t > 1 prints NextWithBuffer()'s raw name (FastqExtractor.cpp:446-476 vs 529-545)
+      size_t nl = c1->nameLen[i];
+      const char *nm = c1->name(i);
+      if (threadCnt == 1 && nl >= 2 && nm[nl - 2] == '/' && (nm[nl - 1] == '1' || nm[nl - 1] == '2')) nl -= 2;
+      outputSeq(out1, nm, nl, c1->seq(i), c1->qual(i), c1->seqLen[i], r1s, r1e);
+      if (hasMate) outputSeq(out2, nm, nl, c2->seq(i), c2->qual(i), c2->seqLen[i], r2s, r2e);
+      if (hasBarcode) {  // OutputBarcode without a whitelist (FastqExtractor.cpp:157-204)
+        outBc.push_back('>'); outBc.append(nm, nl); outBc.push_back('\n');
+        const char *bc = cb->seq(i);
+        const size_t bl = cb->seqLen[i];
+        if (bl == 0) outBc.append("missing_barcode\n");
+        else if (barcodeStart == 0 && barcodeEnd == -1 && !barcodeRevComp) { outBc.append(bc, bl); outBc.push_back('\n'); }
+        else {
+          const long s = barcodeStart, e = barcodeEnd == -1 ? (long)bl - 1 : barcodeEnd;
+          if (!barcodeRevComp) { for (long x = s; x <= e && x < (long)bl; ++x) outBc.push_back(bc[x]); }
+          else {
+            for (long x = std::min(e, (long)bl - 1); x >= s; --x) {  // SeqSet::ReverseComplement (SeqSet.hpp:2103-2114)
+              const char c = bc[x];
+              outBc.push_back(c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'T' ? 'A' : 'N');
+            }
+          }
+          outBc.push_back('\n');
+        }
+      }
+    }
+    fwrite(out1.data(), 1, out1.size(), fp1);
+    if (fp2) fwrite(out2.data(), 1, out2.size(), fp2);
+    if (fpBc) fwrite(outBc.data(), 1, outBc.size(), fpBc);
+    nFragments += n1;
+  }
+  if (reads.failed || mates.failed || barcodes.failed) { fprintf(stderr, "Cannot open a read file.\n"); rc = 1; }
+  // on an error the reader threads may still be blocked on a full queue: drain them
+  if (rc) { while (reads.pop()) {} if (hasMate) while (mates.pop()) {} if (hasBarcode) while (barcodes.pop()) {} }
+  fclose(fp1);
+  if (fp2) fclose(fp2);
+  if (fpBc) fclose(fpBc);
+  t1k_ctx_destroy(ctx);
+  if (rc) return rc;
+  if (getenv("T1K_DEBUG_PHASES")) fprintf(stderr, "[t1k] extractor: k=%d hitLenRequired=%d fragments=%llu kept=%llu\n", kmerLength, hitLenRequired, (unsigned long long)nFragments, (unsigned long long)nGood);
+  printLog("Finish extracting reads.");
+  return 0;
+}

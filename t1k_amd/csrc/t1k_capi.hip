@@ -88,7 +88,7 @@ int t1k_ctx_create(int device, const t1k_params *params, t1k_ctx **out) {
   if (ctx->prm.cand_cap <= 0) ctx->prm.cand_cap = d.cand_cap;
   if (ctx->prm.ovl_cap <= 0) ctx->prm.ovl_cap = d.ovl_cap;
   if (ctx->prm.row_cap <= 0) ctx->prm.row_cap = d.row_cap;
-  if (ctx->prm.kmer_length > 14 || ctx->prm.max_read_len > 320) { delete ctx; return T1K_ERR_ARG; }  // the hit-offset bitmask of the chain kernels spans 320 positions
+  if (ctx->prm.kmer_length > 15 || ctx->prm.max_read_len > 320) { delete ctx; return T1K_ERR_ARG; }  // the hit-offset bitmask of the chain kernels spans 320 positions
   if (hipStreamCreate(&ctx->stream) != hipSuccess) { delete ctx; return T1K_ERR_DEVICE; }
   for (auto &e : ctx->ev) if (hipEventCreate(&e) != hipSuccess) { delete ctx; return T1K_ERR_DEVICE; }
   *out = ctx;
@@ -110,7 +110,7 @@ void t1k_ctx_destroy(t1k_ctx *ctx) {
                       &ctx->bWgStage, &ctx->bWgBig, &ctx->bWgCache, &ctx->bLists, &ctx->bCand, &ctx->bExt, &ctx->bCandStart, &ctx->bCandCount, &ctx->bOvl,
                       &ctx->bOvlStart, &ctx->bOvlCount, &ctx->bCounters, &ctx->bSlowQueue, &ctx->bSlowScratch, &ctx->bSortScratch, &ctx->bEqTrace, &ctx->bSortTmp, &ctx->bSlowKeys, &ctx->bJobSort, &ctx->bEnd1, &ctx->bEnd2,
                       &ctx->bHasN, &ctx->bRows, &ctx->bRowStart, &ctx->bRowCount, &ctx->bFragAssigned, &ctx->bPairScratch, &ctx->bEmRowPtr, &ctx->bEmEc,
-                      &ctx->bEmCount, &ctx->bEmLen, &ctx->bEmX0, &ctx->bEmN, &ctx->bEmContrib, &ctx->bEmColPtr, &ctx->bEmColIdx};
+                      &ctx->bEmCount, &ctx->bEmLen, &ctx->bEmX0, &ctx->bEmN, &ctx->bEmContrib, &ctx->bEmColPtr, &ctx->bEmColIdx, &ctx->bExtract};
   for (auto *b : all) freeBuf(*b);
   for (auto &b : ctx->bAlign) freeBuf(b);
   for (auto &e : ctx->ev) if (e) (void)hipEventDestroy(e);
@@ -370,6 +370,36 @@ int t1k_reads_upload(t1k_ctx *ctx, const char *seqs, const uint64_t *offsets, co
   ctx->batchMaxLen = maxLen;
   ctx->nCand = ctx->nOvl = 0;
   ctx->rangeCount = 0;
+  return T1K_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// candidate extraction over the batch (FastqExtractor.cpp:113-118 IsGoodCandidate, SeqSet.hpp:1915-1990 HasHitInSet)
+// ------------------------------------------------------------------------------------------------------------------
+int t1k_extract_batch(t1k_ctx *ctx, uint32_t endsPerFragment, uint8_t *good, uint64_t *stats) {
+  if (!ctx || !good || (endsPerFragment != 1 && endsPerFragment != 2)) return t1k_fail(ctx, T1K_ERR_ARG, "t1k_extract_batch: bad arguments");
+  if (!ctx->ref.kStart) return t1k_fail(ctx, T1K_ERR_STATE, "t1k_extract_batch: no reference uploaded");
+  const uint32_t nEnds = ctx->reads.nReadEnds;
+  if (nEnds % endsPerFragment) return t1k_fail(ctx, T1K_ERR_ARG, "t1k_extract_batch: odd number of read-ends in a paired batch");
+  const uint32_t nFrag = nEnds / endsPerFragment;
+  if (stats) memset(stats, 0, 5 * sizeof(uint64_t));
+  if (!nFrag) return T1K_OK;
+  T1K_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t flagBytes = ((size_t)nFrag + 63) / 64 * 64;
+  int rc;
+  if ((rc = t1k_ensure(ctx, ctx->bExtract, flagBytes + 64))) return rc;
+  uint8_t *dGood = (uint8_t *)ctx->bExtract.p;
+  unsigned long long *dCtl = (unsigned long long *)(dGood + flagBytes);  // [0] error flags, [1..5] statistics
+  T1K_HIP(ctx, hipMemsetAsync(dCtl, 0, 64, ctx->stream));
+  const uint32_t maxK = (uint32_t)((2 * std::max(1, ctx->batchMaxLen - ctx->prm.kmer_length + 1) + 3) / 4 * 4);
+  t1k_launch_extract(ctx, ctx->ref, ctx->reads, ctx->prm.kmer_length, ctx->prm.radius, ctx->prm.hit_len_required, 1 - ctx->prm.ref_seq_similarity, nFrag,
+                     endsPerFragment, maxK, dGood, dCtl, dCtl + 1, ctx->prm.workgroups * 4);
+  unsigned long long ctl[8];
+  T1K_HIP(ctx, hipMemcpyAsync(good, dGood, nFrag, hipMemcpyDeviceToHost, ctx->stream));
+  T1K_HIP(ctx, hipMemcpyAsync(ctl, dCtl, 64, hipMemcpyDeviceToHost, ctx->stream));
+  T1K_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctl[0]) return t1k_fail(ctx, T1K_ERR_CAPACITY, "t1k_extract_batch: a read has more than 2048 hits on one reference sequence");
+  if (stats) for (int i = 0; i < 5; ++i) stats[i] = ctl[1 + i];
   return T1K_OK;
 }
 

@@ -17,6 +17,7 @@
 #include "t1k_dev.h"
 #include "t1k_launch.h"
 #include "t1k_memo.h"
+#include "t1k_group.h"
 
 #define WG 256
 #define GROUP_FAST_MAXLEN 320
@@ -258,80 +259,16 @@ __device__ inline int groupFastPath(const uint32_t *Mw, int diag, const ReadCtx 
   return result;
 }
 
-__device__ __forceinline__ bool hitKeyLess(uint32_t x, uint32_t y) {  // (diag, alleleOff, readOff): CompSortHitCoordDiff (266-274)
-  int cx = (int)(x & 0xFFF) - (int)(x >> 12), cy = (int)(y & 0xFFF) - (int)(y >> 12);
-  if (cx != cy) return cx < cy;
-  return x < y;
-}
-
 // General group (several diagonals): restates GetOverlapsFromHits 1338-1551 and the chain walk 1697-1833.
 // A[n] sorted copy of the hits, B[n] concordant hits, C[n] packs top (low 16) / link (high 16) of the LIS.
 // Arr: work-array accessor (plain pointer, or LaneArr = LDS arrays interleaved over the lanes of a wavefront)
-struct LaneArr {
-  uint32_t *p;  // element i of this lane's array lives at p[i * 64]
-  __device__ __forceinline__ uint32_t &operator[](int i) const { return p[i * 64]; }
-};
 // second half of one diagonal run: B[0..m) = the run's hits nearest to the dominant diagonal, sorted by (allele offset, read offset);
 // LIS over the read offsets, chain -> A[s..), hit lengths, seed-chain match count, candidate (SeqSet.hpp:352-436, 1512-1551, 1697-1833)
 template <class Arr>
 __device__ inline void chainRun(const ReadCtx &c, int k, int hitLenRequired, Arr A, Arr B, Arr C, int s, int m, int *gaScratch, int gaMax, CandOut &out,
                                 unsigned int *dpCounter, unsigned long long *errFlags, bool *needScratch, const GapSink *sink, int strandBit) {
-    // LIS over read offsets (352-436); C[i] = top | link << 16, link 0xFFFF = none
-    int ret = 1;
-    C[0] = 0 | (0xFFFFu << 16);
-    auto topOf = [&](int i) { return (int)(C[i] & 0xFFFF); };
-    auto setTop = [&](int i, int v) { C[i] = (C[i] & 0xFFFF0000u) | (uint32_t)v; };
-    auto setLink = [&](int i, int v) { C[i] = (C[i] & 0xFFFFu) | ((uint32_t)(v & 0xFFFF) << 16); };
-    auto linkOf = [&](int i) { return (int)(C[i] >> 16); };
-    auto aOf = [&](int i) { return (int)(B[i] & 0xFFF); };
-    for (int i = 1; i < m; ++i) C[i] = 0xFFFFu << 16;
-    for (int i = 1; i < m; ++i) {
-      int tag;
-      if (aOf(topOf(ret - 1)) <= aOf(i)) tag = ret - 1;
-      else {
-        int l = 0, r = ret - 1;
-        tag = -2;
-        while (l <= r) {
-          int mid = (l + r) / 2;
-          if (aOf(i) == aOf(topOf(mid))) { tag = mid; break; }
-          if (aOf(i) < aOf(topOf(mid))) r = mid - 1; else l = mid + 1;
-        }
-        if (tag == -2) tag = l - 1;
-      }
-      if (tag == -1) { setTop(0, i); setLink(i, 0xFFFF); }
-      else if (aOf(i) > aOf(topOf(tag))) {
-        if (tag == ret - 1) { setTop(ret, i); ++ret; setLink(i, topOf(tag)); }
-        else if (aOf(i) < aOf(topOf(tag + 1))) { setTop(tag + 1, i); setLink(i, topOf(tag)); }
-      }
-    }
-    // retrieve the chain into A[s .. s+ret) (the run's slice of A is dead now), then drop repeated allele offsets
-    {
-      int kx = topOf(ret - 1);
-      for (int i = ret - 1; i >= 0; --i) { A[s + i] = B[kx]; kx = linkOf(kx); }
-      int w = 1;
-      for (int i = 1; i < ret; ++i) {
-        if ((A[s + i] >> 12) == (A[s + w - 1] >> 12)) continue;
-        A[s + w] = A[s + i];
-        ++w;
-      }
-      ret = w;
-    }
-    if (ret * k < hitLenRequired) return;
-    // hit lengths on read and on allele (1032-1069)
-    int lenR = 0, lenS = 0;
-    for (int i = 0; i < ret;) {
-      int j = i + 1;
-      for (; j < ret; ++j) if ((int)(A[s + j] & 0xFFF) > (int)(A[s + j - 1] & 0xFFF) + k - 1) break;
-      lenR += (int)(A[s + j - 1] & 0xFFF) - (int)(A[s + i] & 0xFFF) + k;
-      i = j;
-    }
-    for (int i = 0; i < ret;) {
-      int j = i + 1;
-      for (; j < ret; ++j) if ((int)(A[s + j] >> 12) > (int)(A[s + j - 1] >> 12) + k - 1) break;
-      lenS += (int)(A[s + j - 1] >> 12) - (int)(A[s + i] >> 12) + k;
-      i = j;
-    }
-    if (lenR < hitLenRequired || lenS < hitLenRequired) return;
+    int ret, lenR, lenS;
+    if (!t1k_run_lis(A, B, C, s, m, k, hitLenRequired, &ret, &lenR, &lenS)) return;
     // seed-chain match count (1697-1833).  With a sink the alignments are registered in the read-end's memo instead of being
     // run here; the candidate then carries the memo slots (k_general_finish adds their match counts).
     uint32_t refs[3] = {0, 0, 0};

@@ -654,6 +654,8 @@ struct t1k_ctx {
   void *emUser = nullptr;
   // align batch scratch
   T1kDevBuf bAlign[12];
+  // candidate extraction (t1k_extract.hip): bAlign-independent scratch [good flags | error word | statistics]
+  T1kDevBuf bExtract;
   t1k_stats stats{};
 };
 

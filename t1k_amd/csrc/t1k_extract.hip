@@ -1,0 +1,324 @@
+// t1k_amd/csrc/t1k_extract.hip -- the candidate-read test of the reference's fastq-extractor on gfx950:
+// IsGoodCandidate = !IsLowComplexity(read) && SeqSet::HasHitInSet(read) (FastqExtractor.cpp:89-118, SeqSet.hpp:1915-1990), for a batch
+// of fragments resident in HBM.  All integer, HBM/LDS-bound work; no MFMA.
+//
+//   k_extract   one 256-thread workgroup per fragment; the mate is only looked at when the first end fails, as in the reference
+//               (FastqExtractor.cpp:459-464).  Per read-end:
+//     1. base counts from the packed words                                   IsLowComplexity (FastqExtractor.cpp:89-111)
+//     2. every k-mer of both strands is looked up in the direct-address index at once (one load round), then the first wavefront
+//        replays the sequential look-up rule (prevKmerCode / skipCnt) over registers    GetHitsFromRead (SeqSet.hpp:1071-1229)
+//        -- nearly all reads of a sequencing run end here: no strand has a hit
+//     3. hits per (strand, sequence) counted in an LDS histogram, 8192 sequences at a time; minus strand first, first maximum wins
+//        (SeqSet.hpp:1934-1957); k * max < hitLenRequired ends the read (1959)
+//     4. the winning bucket's hits are gathered (bisection in each used posting list), rank-sorted by (diagonal, sequence offset,
+//        read offset) by the whole workgroup, and thread 0 walks the diagonal runs: nearest-to-dominant filter, LIS, hit lengths
+//        (GetOverlapsFromHits with filter 0, SeqSet.hpp:1232-1556); the read is a candidate if some overlap has
+//        len - hitLen <= int(len * (1 - similarity)) * k  (1974-1979)
+#include <algorithm>
+#include "t1k_dev.h"
+#include "t1k_launch.h"
+#include "t1k_group.h"
+
+#define XWG 256
+#define X_RANGE 8192   // sequences per histogram pass (u32 counters: 32 KB of LDS)
+#define X_HCAP 2048    // hits of one (strand, sequence) bucket
+enum { XERR_HITCAP = 1 };
+
+struct ExtractArgs {
+  T1kRefDev ref;
+  T1kReadsDev reads;
+  int k, radius, hitLenRequired;
+  double oneMinusSim;
+  uint32_t nFragments, epf, maxK;
+  uint8_t *good;
+  unsigned long long *err;
+  unsigned long long *stats;  // [0] read-ends looked at, [1] look-ups, [2] postings streamed, [3] read-ends reaching the histogram, [4] reaching the chain
+};
+
+// slice [lo, hi) of a posting list (sorted by sequence) holding the sequences [a0, a1)
+__device__ __forceinline__ uint32_t listLowerBound(const T1kPosting *p, uint32_t n, uint32_t allele) {
+  uint32_t lo = 0, hi = n;
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (p[mid].allele < allele) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+__global__ __launch_bounds__(XWG) void k_extract(ExtractArgs P) {
+  extern __shared__ uint32_t lds[];
+  const int maxK = (int)P.maxK;
+  uint32_t *ukCode = lds;                        // [maxK] code | valid << 31, both strands
+  uint32_t *ukStart = ukCode + maxK;             // [maxK]
+  uint32_t *ukLen = ukStart + maxK;              // [maxK]
+  uint32_t *sliceLo = ukLen + maxK;              // [maxK] slice of the current pass inside each used list (later: minDist of the chain)
+  uint32_t *pre = sliceLo + maxK;                // [maxK + 1] exclusive prefix of the slice lengths
+  uint16_t *usedQ = (uint16_t *)(pre + maxK + 2);  // [maxK] used look-ups, + strand first
+  uint32_t *hist = (uint32_t *)(usedQ + maxK + (maxK & 1));  // [X_RANGE]; after the vote: H | A | B | C, X_HCAP words each
+  __shared__ uint32_t warpSums[4];
+  __shared__ uint32_t sCnt[4];
+  __shared__ uint32_t sUsed[2];
+  __shared__ unsigned long long sKey[4];
+  __shared__ int sRes;
+  const int tid = threadIdx.x;
+  const int k = P.k;
+  const uint32_t kmask = (1u << (2 * k)) - 1;
+  const uint32_t A = P.ref.nAlleles;
+  unsigned long long stEnds = 0, stLook = 0, stPost = 0, stHist = 0, stChain = 0;  // thread 0 tallies
+
+  for (uint32_t f = blockIdx.x; f < P.nFragments; f += gridDim.x) {
+    bool fragGood = false;
+    for (uint32_t j = 0; j < P.epf && !fragGood; ++j) {
+      const uint32_t re = f * P.epf + j;
+      const int len = P.reads.len[re];
+      const int S = P.reads.S;
+      const uint64_t *rbase = P.reads.bases + (uint64_t)re * 2 * S;
+      const uint64_t *rnm = P.reads.nmask + (uint64_t)re * 2 * S;
+      ++stEnds;
+      __syncthreads();  // the previous read-end is done with the shared words
+      if (tid < 4) sCnt[tid] = 0;
+      if (tid == 0) { sUsed[0] = 0; sUsed[1] = 0; sRes = 0; }
+      __syncthreads();
+      if (len < k) continue;  // HasHitInSet 1919-1920 (uniform)
+      // ---- 1. IsLowComplexity
+      if (tid < (len + 31) / 32) {
+        const uint64_t b = rbase[tid], n = rnm[tid];
+        const uint64_t lo = b & T1K_EVEN, hi = (b >> 1) & T1K_EVEN;
+        atomicAdd(&sCnt[0], (uint32_t)__popcll(lo & ~hi));  // C
+        atomicAdd(&sCnt[1], (uint32_t)__popcll(hi & ~lo));  // G
+        atomicAdd(&sCnt[2], (uint32_t)__popcll(lo & hi));   // T
+        atomicAdd(&sCnt[3], (uint32_t)__popcll(n & T1K_EVEN));  // N (packed as base 0 with its mask bit set)
+      }
+      // ---- 2. look-ups of both strands
+      const int nk = len - k + 1;
+      for (int q = tid; q < 2 * nk; q += XWG) {
+        const int pass = q >= nk ? 1 : 0, p = q - pass * nk;
+        const uint64_t *b = rbase + pass * S, *nm = rnm + pass * S;
+        const uint32_t code = (uint32_t)t1k_get32(b, p) & kmask;
+        const bool valid = ((uint32_t)t1k_get32(nm, p) & kmask) == 0;
+        uint32_t st = 0, ln = 0;
+        if (valid) { st = P.ref.kStart[code]; ln = P.ref.kStart[code + 1] - st; }
+        ukCode[q] = code; ukStart[q] = st; ukLen[q] = ln;
+      }
+      __syncthreads();
+      {
+        const int cC = (int)sCnt[0], cG = (int)sCnt[1], cT = (int)sCnt[2], cN = (int)sCnt[3], cA = len - cC - cG - cT - cN;
+        const int half = len / 2;
+        bool low = cA >= half || cC >= half || cG >= half || cT >= half || cN >= len / 10;
+        const int lowCnt = (cA <= 2) + (cC <= 2) + (cG <= 2) + (cT <= 2);
+        if (lowCnt >= 2) low = true;
+        if (low) continue;  // uniform
+      }
+      // sequential replay of the look-up rule by the first wavefront (uniform code over v_readlane)
+      if (tid < 64) {
+        uint32_t prev = 0;  // prevKmerCode starts at code 0 and is carried from the + strand into the - strand
+        uint32_t nUsed = 0, lookups = 0, postings = 0;
+        for (int pass = 0; pass < 2; ++pass) {
+          int skipCnt = 0;
+          const uint32_t begin = nUsed;
+          for (int seg = 0; seg < nk; seg += 64) {
+            const int pl = seg + tid;
+            const uint32_t vc = pl < nk ? ukCode[pass * nk + pl] : 0u;
+            const uint32_t vl = pl < nk ? ukLen[pass * nk + pl] : 0u;
+            const int cnt = min(64, nk - seg);
+            for (int jx = 0; jx < cnt; ++jx) {
+              const uint32_t code = (uint32_t)__builtin_amdgcn_readlane((int)vc, jx);
+              const uint32_t size = (uint32_t)__builtin_amdgcn_readlane((int)vl, jx);
+              const int p = seg + jx;
+              if (p == 0 || code != prev) {
+                ++lookups;
+                if (size >= 100 && p != 0 && p != nk - 1 && skipCnt < k / 2) { ++skipCnt; continue; }
+                skipCnt = 0;
+                if (size) {
+                  if (tid == 0) usedQ[nUsed] = (uint16_t)(pass * nk + p);
+                  ++nUsed;
+                  postings += size;
+                }
+              }
+              prev = code;
+            }
+          }
+          if (tid == 0) sUsed[pass] = nUsed - begin;
+        }
+        stLook += lookups; stPost += postings;
+      }
+      __syncthreads();
+      const uint32_t nUsed0 = sUsed[0], nUsed1 = sUsed[1];
+      if (nUsed0 + nUsed1 == 0) continue;  // no hit (1925-1927)
+      ++stHist;
+      // ---- 3. the fullest (strand, sequence) bucket
+      int bestCnt = -1, bestPass = 0;
+      uint32_t bestAllele = 0;
+      for (int tag = 0; tag < 2; ++tag) {
+        const int pass = tag == 0 ? 1 : 0;  // bucket tag 0 = minus strand
+        const uint32_t uBeg = pass == 0 ? 0 : nUsed0, uCnt = pass == 0 ? nUsed0 : nUsed1;
+        if (!uCnt) continue;
+        for (uint32_t r0 = 0; r0 < A; r0 += X_RANGE) {
+          const uint32_t r1 = min(A, r0 + X_RANGE);
+          for (int i = tid; i < X_RANGE; i += XWG) hist[i] = 0;
+          // slices of the used lists (two consecutive lists per thread keep the prefix in list order)
+          uint32_t myLen[2] = {0, 0};
+#pragma unroll
+          for (int x = 0; x < 2; ++x) {
+            const uint32_t u = 2 * tid + x;
+            if (u < uCnt) {
+              const int q = usedQ[uBeg + u];
+              const uint32_t st = ukStart[q], ln = ukLen[q];
+              uint32_t lo = 0, hi = ln;
+              if (A > X_RANGE) {
+                const uint32_t dr = ln > T1K_DIR_MINLEN ? P.ref.kDirIdx[ukCode[q]] : T1K_NO_DIR;
+                if (dr != T1K_NO_DIR) {
+                  const uint32_t *row = P.ref.kDir + (uint64_t)dr * P.ref.kDirStride;
+                  lo = row[r0 / T1K_SEED_CHUNK];
+                  hi = r1 >= A ? ln : row[r1 / T1K_SEED_CHUNK];
+                } else {
+                  lo = listLowerBound(P.ref.kPost + st, ln, r0);
+                  hi = r1 >= A ? ln : listLowerBound(P.ref.kPost + st, ln, r1);
+                }
+              }
+              sliceLo[u] = lo;
+              myLen[x] = hi - lo;
+            }
+          }
+          uint32_t total;
+          const uint32_t base = t1k_block_scan_exclusive(myLen[0] + myLen[1], warpSums, &total);
+          if (2 * tid < (int)uCnt) pre[2 * tid] = base;
+          if (2 * tid + 1 < (int)uCnt) pre[2 * tid + 1] = base + myLen[0];
+          if (tid == 0) pre[uCnt] = total;
+          __syncthreads();
+          for (uint32_t x = tid; x < total; x += XWG) {
+            uint32_t lo = 0, hi = uCnt;  // last u with pre[u] <= x
+            while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (pre[mid] <= x) lo = mid; else hi = mid; }
+            const int q = usedQ[uBeg + lo];
+            const T1kPosting pp = P.ref.kPost[ukStart[q] + sliceLo[lo] + (x - pre[lo])];
+            atomicAdd(&hist[pp.allele - r0], 1u);
+          }
+          __syncthreads();
+          // first maximum of the range: largest count, then smallest sequence index
+          unsigned long long key = 0;
+          for (int i = tid; i < X_RANGE; i += XWG) {
+            const uint32_t c = hist[i];
+            if (c) { const unsigned long long kx = ((unsigned long long)c << 32) | (0xFFFFFFFFu - (r0 + (uint32_t)i)); if (kx > key) key = kx; }
+          }
+          for (int o = 32; o > 0; o >>= 1) { const unsigned long long y = __shfl_xor(key, o, 64); if (y > key) key = y; }
+          if ((tid & 63) == 0) sKey[tid >> 6] = key;
+          __syncthreads();
+          key = max(max(sKey[0], sKey[1]), max(sKey[2], sKey[3]));
+          const int c = (int)(key >> 32);
+          if (c > 0 && c > bestCnt) { bestCnt = c; bestPass = pass; bestAllele = 0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFu); }
+          __syncthreads();  // hist / pre / sKey are rewritten by the next pass
+        }
+      }
+      if (bestCnt < 0 || k * bestCnt < P.hitLenRequired) continue;  // 1959-1964
+      ++stChain;
+      // ---- 4. the bucket's hits -> H (hist is dead)
+      uint32_t *H = hist, *SA = hist + X_HCAP, *SB = hist + 2 * X_HCAP, *SC = hist + 3 * X_HCAP;
+      const uint32_t uBeg = bestPass == 0 ? 0 : nUsed0, uCnt = bestPass == 0 ? nUsed0 : nUsed1;
+      uint32_t n;
+      {
+        uint32_t myLo[2] = {0, 0}, myLen[2] = {0, 0};
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+          const uint32_t u = 2 * tid + x;
+          if (u < uCnt) {
+            const int q = usedQ[uBeg + u];
+            const T1kPosting *pl = P.ref.kPost + ukStart[q];
+            const uint32_t ln = ukLen[q];
+            const uint32_t lo = listLowerBound(pl, ln, bestAllele);
+            uint32_t hi = lo;
+            while (hi < ln && pl[hi].allele == bestAllele) ++hi;
+            myLo[x] = lo; myLen[x] = hi - lo;
+          }
+        }
+        const uint32_t base = t1k_block_scan_exclusive(myLen[0] + myLen[1], warpSums, &n);
+        if (n <= X_HCAP) {
+          uint32_t w = base;
+#pragma unroll
+          for (int x = 0; x < 2; ++x) {
+            const uint32_t u = 2 * tid + x;
+            if (u < uCnt) {
+              const int q = usedQ[uBeg + u];
+              const uint32_t a = (uint32_t)(q - bestPass * nk);
+              const T1kPosting *pl = P.ref.kPost + ukStart[q] + myLo[x];
+              for (uint32_t i = 0; i < myLen[x]; ++i) H[w++] = a | (pl[i].offset << 12);
+            }
+          }
+        }
+      }
+      if (n > X_HCAP) { if (tid == 0) atomicOr(P.err, (unsigned long long)XERR_HITCAP); continue; }
+      __syncthreads();
+      // rank sort by (diagonal, sequence offset, read offset): the packed words are distinct
+      for (uint32_t i = tid; i < n; i += XWG) {
+        const uint32_t x = H[i];
+        uint32_t r = 0;
+        for (uint32_t jx = 0; jx < n; ++jx) r += hitKeyLess(H[jx], x) ? 1u : 0u;
+        SA[r] = x;
+      }
+      __syncthreads();
+      if (tid == 0) {
+        int *minDist = (int *)sliceLo;  // per read offset (readOffsetUsed, 1246, 1437-1456)
+        const int thr = (int)(len * P.oneMinusSim) * k;  // mismatchThreshold (1974)
+        bool ok = false;
+        auto diagOf = [](uint32_t x) { return (int)(x & 0xFFF) - (int)(x >> 12); };
+        for (int s = 0; s < (int)n && !ok;) {
+          int curDiff = diagOf(SA[s]), curCnt = 1, domCnt = 0, dominant = 0;
+          int e = s + 1;
+          for (; e < (int)n; ++e) {
+            int d = diagOf(SA[e]) - diagOf(SA[e - 1]);
+            if (d < 0) d = -d;
+            if (d > P.radius) break;
+            if (d == 0) ++curCnt;
+            else {
+              if (curCnt > domCnt) { dominant = curDiff; domCnt = curCnt; }
+              curDiff = diagOf(SA[e]); curCnt = 1;
+            }
+          }
+          if (curCnt > domCnt) dominant = curDiff;
+          if (e - s < 3 || (e - s) * k < P.hitLenRequired) { s = e; continue; }
+          for (int q = s; q < e; ++q) minDist[SA[q] & 0xFFF] = 0x7FFFFFFF;
+          for (int q = s; q < e; ++q) {
+            int dq = diagOf(SA[q]) - dominant; if (dq < 0) dq = -dq;
+            int *md = &minDist[SA[q] & 0xFFF];
+            if (dq < *md) *md = dq;
+          }
+          int m = 0;
+          for (int q = s; q < e; ++q) {
+            const uint32_t x = SA[q];
+            int dq = diagOf(x) - dominant; if (dq < 0) dq = -dq;
+            if (dq != minDist[x & 0xFFF]) continue;
+            int jx = m - 1;  // insertion by (sequence offset, read offset) == packed value order (CompSortPairBInc)
+            while (jx >= 0 && x < SB[jx]) { SB[jx + 1] = SB[jx]; --jx; }
+            SB[jx + 1] = x;
+            ++m;
+          }
+          int ret, lenR, lenS;
+          if (t1k_run_lis(SA, SB, SC, s, m, k, P.hitLenRequired, &ret, &lenR, &lenS)) {
+            if (len - lenR <= thr) ok = true;  // matchCnt = 2 * hitLen (1536); len - matchCnt / 2 <= mismatchThreshold (1978)
+          }
+          s = e;
+        }
+        sRes = ok ? 1 : 0;
+      }
+      __syncthreads();
+      fragGood = sRes != 0;
+    }
+    if (tid == 0) P.good[f] = fragGood ? 1 : 0;
+  }
+  if (tid == 0 && P.stats) {
+    atomicAdd(&P.stats[0], stEnds); atomicAdd(&P.stats[1], stLook); atomicAdd(&P.stats[2], stPost);
+    atomicAdd(&P.stats[3], stHist); atomicAdd(&P.stats[4], stChain);
+  }
+}
+
+size_t t1k_extract_lds_bytes(int maxK) { return ((size_t)maxK * 5 + 3) * 4 + ((size_t)maxK + 1) / 2 * 2 * 2 + (size_t)X_RANGE * 4 + 16; }
+
+void t1k_launch_extract(t1k_ctx *ctx, const T1kRefDev &ref, const T1kReadsDev &reads, int k, int radius, int hitLenRequired, double oneMinusSim, uint32_t nFragments,
+                        uint32_t epf, uint32_t maxK, uint8_t *good, unsigned long long *err, unsigned long long *stats, int nWg) {
+  ExtractArgs a{};
+  a.ref = ref; a.reads = reads; a.k = k; a.radius = radius; a.hitLenRequired = hitLenRequired; a.oneMinusSim = oneMinusSim;
+  a.nFragments = nFragments; a.epf = epf; a.maxK = maxK; a.good = good; a.err = err; a.stats = stats;
+  const size_t ldsBytes = t1k_extract_lds_bytes((int)maxK);
+  hipFuncSetAttribute((const void *)k_extract, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes);
+  const unsigned grid = (unsigned)std::min<uint64_t>(nFragments, (uint64_t)nWg);
+  hipLaunchKernelGGL(k_extract, dim3(grid), dim3(XWG), ldsBytes, ctx->stream, a);
+}

@@ -1,0 +1,39 @@
+#!/bin/bash
+# Candidate extraction through the executable (t1k_amd/bin/fastq-extractor) against the reference's own fastq-extractor
+# (oracle/_ref/fastq-extractor, built by oracle/Makefile from the reference's sources): every output file must be identical.
+# Synthetic references / reads from tools/t1k_synth (seeded).  Usage: tools/extract_parity.sh [pairs]
+set -e
+cd "$(dirname "$0")/.."
+W=${W:-/tmp/extract_parity}; mkdir -p $W
+P=${1:-200000}
+fail=0
+run() { # name, args...
+  n=$1; shift
+  timeout 300 t1k_amd/bin/fastq-extractor "$@" -o $W/ours_$n > $W/ours_$n.log 2>&1 || { echo "ours rc=$? ($n)"; tail -2 $W/ours_$n.log; }
+  timeout 300 oracle/_ref/fastq-extractor "$@" -o $W/ref_$n > $W/ref_$n.log 2>&1 || echo "ref rc=$? ($n)"
+  ok=1; cnt=0
+  for f in $W/ref_${n}[._]*; do case $f in *.log) continue;; esac
+    o=$W/ours_${n}${f#$W/ref_${n}}; cnt=$((cnt+1)); cmp -s $o $f || { ok=0; fail=1; echo "DIFF $n ${f##*/}"; }; done
+  if [ $ok = 1 ]; then echo "$n: $cnt files identical, $(grep -c '^[@>]' $(ls $W/ref_${n}[._]*f[qa] | head -1)) reads kept"; fi
+}
+tools/t1k_synth ref-rna --seed 31 --genes 8 --scale 0.3 > $W/rna.fa
+tools/t1k_synth ref-dna --seed 32 --genes 6 --scale 0.2 > $W/dna.fa
+tools/t1k_synth reads --ref $W/rna.fa --out $W/a --seed 33 --pairs $P --len 100 --bg 0.6 --barcodes 500
+tools/t1k_synth reads --ref $W/rna.fa --out $W/b --seed 34 --pairs $P --len 150 --bg 0.3 --sub 0.12 --indel 0.01 --nrate 0.02
+tools/t1k_synth reads --ref $W/dna.fa --out $W/c --seed 35 --pairs $P --len 250 --bg 0.5 --sub 0.03
+tools/t1k_synth reads --ref $W/rna.fa --out $W/d --seed 36 --pairs $((P/4)) --len 75 --bg 0.5 --fasta
+run rna100 -f $W/rna.fa -1 $W/a_1.fq -2 $W/a_2.fq
+run rna100_t8 -f $W/rna.fa -1 $W/a_1.fq -2 $W/a_2.fq -t 8
+run rna100_bc -f $W/rna.fa -1 $W/a_1.fq -2 $W/a_2.fq --barcode $W/a_bc.fa --barcodeStart 2 --barcodeEnd 13 -t 4
+# (reverse-complementing the literal "missing_barcode" indexes the reference's nucToNum out of bounds: only the head of the file, which has none)
+head -400 $W/a_1.fq > $W/h_1.fq; head -400 $W/a_2.fq > $W/h_2.fq; head -200 $W/a_bc.fa > $W/h_bc.fa
+run rna100_bcrc -f $W/rna.fa -1 $W/h_1.fq -2 $W/h_2.fq --barcode $W/h_bc.fa --barcodeStart 1 --barcodeEnd 14 --barcodeRevComp
+run rna150_noisy -f $W/rna.fa -1 $W/b_1.fq -2 $W/b_2.fq -t 4
+run rna150_s95 -f $W/rna.fa -1 $W/b_1.fq -2 $W/b_2.fq -s 0.95
+run rna150_single -f $W/rna.fa -u $W/b_1.fq -s 0.97 --read1Start 5 --read1End 120
+run dna250 -f $W/dna.fa -1 $W/c_1.fq -2 $W/c_2.fq -t 4
+run dna250_single -f $W/dna.fa -u $W/c_2.fq
+run fasta75 -f $W/rna.fa -1 $W/d_1.fa -2 $W/d_2.fa -t 2
+run cross -f $W/dna.fa -1 $W/b_1.fq -2 $W/b_2.fq -t 4
+if [ $fail = 0 ]; then echo "extract parity: all identical"; fi
+exit $fail
