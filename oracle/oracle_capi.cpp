@@ -58,4 +58,16 @@ int orc_coverage(void *h, int allele, int *out, int cap) {
   }
   return L;
 }
+
+// ---- candidate extraction (oracle_extract.cpp) ----
+int orc_load_reference_fa(void *h, const char *fasta) { return ((Oracle *)h)->loadReferenceFa(fasta); }
+int orc_infer_kmer_length(void *h) { return ((Oracle *)h)->inferKmerLength(); }
+void orc_set_extract_params(void *h, int k, int hitLenRequired) {
+  Oracle *o = (Oracle *)h;
+  if (k != o->prm.k) o->setKmerLength(k);
+  o->prm.hitLenRequired = hitLenRequired;
+}
+int orc_is_low_complexity(const char *read) { return Oracle::isLowComplexityRead(read) ? 1 : 0; }
+int orc_has_hit_in_set(void *h, const char *read) { return ((Oracle *)h)->hasHitInSet(read) ? 1 : 0; }
+int orc_is_good_candidate(void *h, const char *read) { return ((Oracle *)h)->isGoodCandidate(read) ? 1 : 0; }
 }

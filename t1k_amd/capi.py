@@ -86,6 +86,8 @@ def lib():
     L.t1k_align_count_batch.argtypes = [vp, C.c_char_p, vp, C.c_char_p, vp, vp, C.c_uint32, vp]
     L.t1k_em_setup.argtypes = [vp, vp, vp, vp, vp, C.c_uint32, C.c_uint32, ALLREDUCE_FN, vp]
     L.t1k_em_update.argtypes = [vp, vp, vp, vp, vp]
+    L.t1k_extract_batch.argtypes = [vp, C.c_uint32, vp, vp]
+    L.t1k_extractor_main.argtypes = [C.c_int, C.POINTER(C.c_char_p)]
     L.t1k_stats_get.argtypes = [vp, C.POINTER(Stats)]
     L.t1k_genotyper_main.argtypes = [C.c_int, C.POINTER(C.c_char_p)]
     L.t1k_job_params_default.argtypes = [C.POINTER(JobParams)]
@@ -176,6 +178,13 @@ class Context:
 
     def assign(self):
         self._check(lib().t1k_assign_batch(self.h), "t1k_assign_batch")
+
+    def extract(self, ends_per_fragment=1):
+        """IsGoodCandidate of every fragment of the uploaded batch (t1k_extract_batch): (good[nFragments] uint8, stats dict)."""
+        good = np.zeros(self.n_read_ends // ends_per_fragment, dtype=np.uint8)
+        st = np.zeros(5, dtype=np.uint64)
+        self._check(lib().t1k_extract_batch(self.h, ends_per_fragment, _ptr(good), _ptr(st)), "t1k_extract_batch")
+        return good, dict(zip(("read_ends", "lookups", "postings", "read_ends_with_hits", "read_ends_chained"), (int(x) for x in st)))
 
     def overlaps(self):
         n = self.n_read_ends

@@ -15,8 +15,8 @@ def pytest_configure(config):
 def built():
     """In-tree build products; build them if a fresh checkout has none."""
     import util
-    need = [os.path.join(util.ROOT, "t1k_amd", "lib", "libt1k_gpu.so"), util.ORACLE_SO, util.ORACLE_CLI, util.SYNTH,
-            os.path.join(util.ROOT, "t1k_amd", "bin", "genotyper")]
+    need = [os.path.join(util.ROOT, "t1k_amd", "lib", "libt1k_gpu.so"), util.ORACLE_SO, util.ORACLE_CLI, util.ORACLE_EXTRACT, util.SYNTH,
+            os.path.join(util.ROOT, "t1k_amd", "bin", "genotyper"), os.path.join(util.ROOT, "t1k_amd", "bin", "fastq-extractor")]
     if not all(os.path.exists(p) for p in need):
         sys.path.insert(0, util.ROOT)
         import __graft_entry__

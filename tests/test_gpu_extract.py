@@ -1,0 +1,130 @@
+"""GPU tests (pytest -m gpu) of the candidate-read extraction row: t1k_extract_batch through the C ABI against the oracle's
+IsGoodCandidate read by read, and the fastq-extractor executable against the golden fixtures of the reference's own binary
+(tests/golden/extract_*).  All results are 0/1 flags and byte strings: bit-exact."""
+import os
+import random
+import subprocess
+
+import numpy as np
+import pytest
+
+import util
+import t1k_amd
+from test_extract_oracle import CASES, XCase, kept_ids
+
+pytestmark = pytest.mark.gpu
+XBIN = os.path.join(util.ROOT, "t1k_amd", "bin", "fastq-extractor")
+
+
+def device_flags(ref, seqs, epf, k, hit_len, sim):
+    c = t1k_amd.Context(kmer_length=k, hit_len_required=hit_len, ref_seq_similarity=sim)
+    try:
+        c.ref_upload(ref)
+        c.reads_upload(seqs)
+        return c.extract(epf)
+    finally:
+        c.close()
+
+
+def ref_seqs(path):
+    out, cur = [], []
+    for l in open(path):
+        if l[0] == ">":
+            if cur:
+                out.append("".join(cur))
+            cur = []
+        else:
+            cur.append(l.strip())
+    if cur:
+        out.append("".join(cur))
+    return out
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_extract_batch_vs_oracle_and_golden(built, tmp_path, name):
+    """every fragment's flag == oracle's IsGoodCandidate (first end, else the mate); the kept set == what the reference kept"""
+    c = XCase(name, str(tmp_path))
+    k, hl, sim = c.meta["kmer_length"], c.meta["hit_len_required"], c.similarity()
+    r1 = util.fastx_records(c.r1)
+    r2 = util.fastx_records(c.r2) if c.paired else None
+    seqs = [s for pair in zip((s for _, s in r1), (s for _, s in r2)) for s in pair] if c.paired else [s for _, s in r1]
+    good, st = device_flags(ref_seqs(c.ref), seqs, 2 if c.paired else 1, k, hl, sim)
+    orc = util.ExtractOracle(c.ref, similarity=sim, k=k, hit_len_required=hl)
+    want = np.array([1 if (orc.good(r1[i][1]) or (c.paired and orc.good(r2[i][1]))) else 0 for i in range(len(r1))], dtype=np.uint8)
+    orc.close()
+    assert np.array_equal(good, want)
+    ids = [n[:-2] if (c.strips_mate_suffix() and n[-2:] in ("/1", "/2")) else n for n, _ in r1]
+    assert [ids[i] for i in range(len(ids)) if good[i]] == c.kept
+    assert st["read_ends"] >= len(r1) and st["read_ends_chained"] <= st["read_ends_with_hits"] <= st["read_ends"]
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_executable_vs_golden(built, tmp_path, name):
+    c = XCase(name, str(tmp_path))
+    o = str(tmp_path / "out")
+    subprocess.run([XBIN] + c.args() + ["-o", o], check=True, stderr=subprocess.PIPE)
+    assert kept_ids(o + ("_1.fq" if c.paired else ".fq")) == c.kept
+    if c.paired:
+        assert kept_ids(o + "_2.fq") == c.kept
+    # chunking of the input must not matter
+    subprocess.run([XBIN] + c.args() + ["-o", o + "_c"], check=True, stderr=subprocess.PIPE, env=dict(os.environ, T1K_EXTRACT_CHUNK="97"))
+    for suffix in (["_1.fq", "_2.fq"] if c.paired else [".fq"]):
+        assert open(o + suffix).read() == open(o + "_c" + suffix).read()
+
+
+def test_edge_reads_vs_oracle(built, tmp_path):
+    """empty / shorter-than-k / all-N / homopolymer / repeat / exact-copy / reverse-complement / boundary-similarity reads"""
+    ref_fa = util.gunzip_to(util.CYP_DNA, str(tmp_path / "ref.fa"))
+    ref = ref_seqs(ref_fa)
+    rng = random.Random(7)
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A", "N": "N"}
+    a0 = ref[0].replace("N", "A")
+    reads = ["", "ACGTACG", "N" * 100, "A" * 100, "AC" * 50, "ACG" * 40, a0[100:250], "".join(comp[c] for c in reversed(a0[300:450])), a0[500:511], a0[500:512]]
+    for _ in range(300):  # windows of alleles with a growing number of substitutions / N / one indel
+        al = rng.choice(ref)
+        L = rng.choice([36, 75, 100, 150, 250, 320])
+        p = rng.randrange(0, max(1, len(al) - L))
+        s = list(al[p:p + L])
+        for _ in range(rng.choice([0, 1, 3, 8, 15, 30, 60])):
+            q = rng.randrange(len(s))
+            s[q] = rng.choice("ACGTN")
+        if rng.random() < 0.3 and len(s) > 20:
+            q = rng.randrange(5, len(s) - 5)
+            s[q:q + rng.choice([1, 2, 7])] = []
+        if rng.random() < 0.5:
+            s = [comp[c] for c in reversed(s)]
+        reads.append("".join(s))
+    for k, hl, sim in ((12, 27, 0.8), (12, 30, 0.97), (9, 23, 0.8), (14, 40, 0.9)):
+        good, _ = device_flags(ref, reads, 1, k, hl, sim)
+        orc = util.ExtractOracle(ref_fa, similarity=sim, k=k, hit_len_required=hl)
+        want = np.array([1 if orc.good(r) else 0 for r in reads], dtype=np.uint8)
+        orc.close()
+        assert np.array_equal(good, want), (k, hl, sim, np.nonzero(good != want)[0][:10])
+        assert 0 < want.sum() < len(reads)
+
+
+def test_full_size_properties(built, tmp_path):
+    """200k synthetic pairs (too many for the pure-CPU oracle in a test): extraction is idempotent (running it on its own output keeps
+    everything), keeps input order, keeps pairs together, and agrees with the oracle on a random sample of fragments."""
+    ref = str(tmp_path / "ref.fa")
+    util.synth_ref("ref-rna", ref, seed=41, genes=8, scale=0.3)
+    pfx = str(tmp_path / "r")
+    util.synth_reads(ref, pfx, seed=42, pairs=200000, len=150, bg=0.6, sub=0.05, indel=0.003, nrate=0.01)
+    o = str(tmp_path / "x")
+    p = subprocess.run([XBIN, "-f", ref, "-1", pfx + "_1.fq", "-2", pfx + "_2.fq", "-o", o], check=True, stderr=subprocess.PIPE, text=True,
+                       env=dict(os.environ, T1K_DEBUG_PHASES="1"))
+    k1, k2 = kept_ids(o + "_1.fq"), kept_ids(o + "_2.fq")
+    assert k1 == k2 and 50000 < len(k1) < 100000
+    order = [int(n[1:]) for n in k1]
+    assert order == sorted(order)
+    subprocess.run([XBIN, "-f", ref, "-1", o + "_1.fq", "-2", o + "_2.fq", "-o", o + "2"], check=True, stderr=subprocess.PIPE)
+    assert open(o + "_1.fq").read() == open(o + "2_1.fq").read() and open(o + "_2.fq").read() == open(o + "2_2.fq").read()
+    import re
+    m = re.search(r"k=(\d+) hitLenRequired=(\d+)", p.stderr)
+    orc = util.ExtractOracle(ref, k=int(m.group(1)), hit_len_required=int(m.group(2)))
+    r1, r2 = util.fastx_records(pfx + "_1.fq"), util.fastx_records(pfx + "_2.fq")
+    kept = set(k1)
+    rng = random.Random(3)
+    for i in rng.sample(range(len(r1)), 600):
+        assert (orc.good(r1[i][1]) or orc.good(r2[i][1])) == (r1[i][0][:-2] in kept)
+    orc.close()

@@ -14,6 +14,8 @@ SYNTH = os.path.join(ROOT, "tools", "t1k_synth")
 ORACLE_SO = os.path.join(ROOT, "oracle", "libt1k_oracle.so")
 ORACLE_CLI = os.path.join(ROOT, "oracle", "t1k_oracle_cli")
 REF_BIN = os.path.join(ROOT, "oracle", "_ref", "genotyper")
+ORACLE_EXTRACT = os.path.join(ROOT, "oracle", "t1k_oracle_extract")
+REF_EXTRACT = os.path.join(ROOT, "oracle", "_ref", "fastq-extractor")
 CYP_RNA = os.path.join(GOLDEN, "cyp2d6_rna_seq.fa.gz")
 CYP_DNA = os.path.join(GOLDEN, "cyp2d6_dna_seq.fa.gz")
 CYP_FLAGS = ["--alleleDigitUnits", "1", "--alleleDelimiter", "."]
@@ -85,3 +87,57 @@ class Oracle:
         n = C.c_int()
         s = self.L.orc_global_alignment(t.encode(), len(t), p.encode(), len(p), ops.ctypes.data, C.byref(n))
         return s, ops[:n.value].copy()
+
+
+class ExtractOracle:
+    """ctypes view of the extraction restatement (oracle/oracle_extract.cpp) -- the checker of t1k_extract_batch."""
+
+    def __init__(self, fasta, similarity=0.8, k=None, hit_len_required=27):
+        L = C.CDLL(ORACLE_SO)
+        L.orc_create.restype = C.c_void_p
+        L.orc_create.argtypes = [C.c_double, C.c_int, C.c_int, C.c_int, C.c_char]
+        for f in ("orc_load_reference_fa", "orc_has_hit_in_set", "orc_is_good_candidate"):
+            getattr(L, f).argtypes = [C.c_void_p, C.c_char_p]
+        L.orc_infer_kmer_length.argtypes = [C.c_void_p]
+        L.orc_set_extract_params.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.orc_is_low_complexity.argtypes = [C.c_char_p]
+        L.orc_destroy.argtypes = [C.c_void_p]
+        self.L = L
+        self.h = L.orc_create(similarity, 0, 2000, -1, b"\0")
+        assert L.orc_load_reference_fa(self.h, fasta.encode()) > 0
+        self.inferred_k = L.orc_infer_kmer_length(self.h)
+        self.k = max(9, self.inferred_k) if k is None else k  # FastqExtractor.cpp:409-416
+        L.orc_set_extract_params(self.h, self.k, max(hit_len_required, self.k) if k is None else hit_len_required)
+
+    def low_complexity(self, read):
+        return bool(self.L.orc_is_low_complexity(read.encode()))
+
+    def has_hit(self, read):
+        return bool(self.L.orc_has_hit_in_set(self.h, read.encode()))
+
+    def good(self, read):
+        return bool(self.L.orc_is_good_candidate(self.h, read.encode()))
+
+    def close(self):
+        if self.h:
+            self.L.orc_destroy(self.h)
+            self.h = None
+
+
+def fastx_records(path):
+    """(name up to the first blank, sequence) of a FASTA/FASTQ file with one-line records."""
+    out = []
+    with open(path) as f:
+        lines = f.read().split("\n")
+    i = 0
+    while i < len(lines):
+        l = lines[i]
+        if l[:1] == "@":
+            out.append((l[1:].split()[0], lines[i + 1]))
+            i += 4
+        elif l[:1] == ">":
+            out.append((l[1:].split()[0], lines[i + 1]))
+            i += 2
+        else:
+            i += 1
+    return out
