@@ -2,18 +2,22 @@
 // IsGoodCandidate = !IsLowComplexity(read) && SeqSet::HasHitInSet(read) (FastqExtractor.cpp:89-118, SeqSet.hpp:1915-1990), for a batch
 // of fragments resident in HBM.  All integer, HBM/LDS-bound work; no MFMA.
 //
-//   k_extract   one 256-thread workgroup per fragment; the mate is only looked at when the first end fails, as in the reference
+//   k_extract_screen  one wavefront per read-end: base counts (IsLowComplexity) and all k-mer look-ups of both strands in one burst of
+//               independent loads; a read-end with no non-empty posting list on either strand cannot have a hit (SeqSet.hpp:1925-1927)
+//               and is finished here -- that is nearly every read of a sequencing run.  No LDS, full occupancy.
+//   k_extract   the remaining read-ends, one 256-thread workgroup per fragment (workgroups walk blocks of 256 fragments and compact
+//               the ones with work left); the mate is only looked at when the first end fails, as in the reference
 //               (FastqExtractor.cpp:459-464).  Per read-end:
-//     1. base counts from the packed words                                   IsLowComplexity (FastqExtractor.cpp:89-111)
 //     2. every k-mer of both strands is looked up in the direct-address index at once (one load round), then the first wavefront
 //        replays the sequential look-up rule (prevKmerCode / skipCnt) over registers    GetHitsFromRead (SeqSet.hpp:1071-1229)
-//        -- nearly all reads of a sequencing run end here: no strand has a hit
 //     3. hits per (strand, sequence) counted in an LDS histogram, 8192 sequences at a time; minus strand first, first maximum wins
 //        (SeqSet.hpp:1934-1957); k * max < hitLenRequired ends the read (1959)
 //     4. the winning bucket's hits are gathered (bisection in each used posting list), rank-sorted by (diagonal, sequence offset,
 //        read offset) by the whole workgroup, and thread 0 walks the diagonal runs: nearest-to-dominant filter, LIS, hit lengths
 //        (GetOverlapsFromHits with filter 0, SeqSet.hpp:1232-1556); the read is a candidate if some overlap has
-//        len - hitLen <= int(len * (1 - similarity)) * k  (1974-1979)
+//        len - hitLen <= int(len * (1 - similarity)) * k  (1974-1979).  A bucket whose hits all lie on one diagonal (the read differs
+//        from the sequence by substitutions only) needs none of that: one run, every hit kept, LIS = all hits, and both hit lengths are
+//        the union of the k-mer intervals -- a parallel sum
 #include <algorithm>
 #include "t1k_dev.h"
 #include "t1k_launch.h"
@@ -31,8 +35,9 @@ struct ExtractArgs {
   double oneMinusSim;
   uint32_t nFragments, epf, maxK;
   uint8_t *good;
+  uint8_t *state;             // [read-end] written by k_extract_screen: 1 = some posting list of the read-end is non-empty
   unsigned long long *err;
-  unsigned long long *stats;  // [0] read-ends looked at, [1] look-ups, [2] postings streamed, [3] read-ends reaching the histogram, [4] reaching the chain
+  unsigned long long *stats;  // [0] read-ends screened, [1] look-ups, [2] postings streamed, [3] read-ends reaching the histogram, [4] reaching the chain
 };
 
 // slice [lo, hi) of a posting list (sorted by sequence) holding the sequences [a0, a1)
@@ -43,6 +48,59 @@ __device__ __forceinline__ uint32_t listLowerBound(const T1kPosting *p, uint32_t
     if (p[mid].allele < allele) lo = mid + 1; else hi = mid;
   }
   return lo;
+}
+
+// popcounts of C, G, T and N in one packed word (A is what is left of the length)
+__device__ __forceinline__ void baseCounts(uint64_t b, uint64_t n, int &c, int &g, int &t, int &nn) {
+  const uint64_t lo = b & T1K_EVEN, hi = (b >> 1) & T1K_EVEN;
+  c = __popcll(lo & ~hi); g = __popcll(hi & ~lo); t = __popcll(lo & hi); nn = __popcll(n & T1K_EVEN);  // N is packed as base 0 with its mask bit set
+}
+__device__ __forceinline__ bool lowComplexity(int len, int cC, int cG, int cT, int cN) {  // IsLowComplexity (FastqExtractor.cpp:89-111)
+  const int cA = len - cC - cG - cT - cN, half = len / 2;
+  if (cA >= half || cC >= half || cG >= half || cT >= half || cN >= len / 10) return true;
+  return (cA <= 2) + (cC <= 2) + (cG <= 2) + (cT <= 2) >= 2;
+}
+
+__global__ __launch_bounds__(XWG) void k_extract_screen(ExtractArgs P) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t wave = blockIdx.x * (XWG / 64) + (threadIdx.x >> 6), nWaves = gridDim.x * (XWG / 64);
+  const int k = P.k;
+  const uint32_t kmask = (1u << (2 * k)) - 1;
+  const int S = P.reads.S;
+  for (uint32_t re = wave; re < P.reads.nReadEnds; re += nWaves) {
+    const int len = P.reads.len[re];
+    const uint64_t *rbase = P.reads.bases + (uint64_t)re * 2 * S;
+    const uint64_t *rnm = P.reads.nmask + (uint64_t)re * 2 * S;
+    bool live = len >= k;  // HasHitInSet 1919-1920
+    if (live) {
+      int cC = 0, cG = 0, cT = 0, cN = 0;
+      if (lane < (len + 31) / 32) baseCounts(rbase[lane], rnm[lane], cC, cG, cT, cN);
+      for (int o = 32; o > 0; o >>= 1) { cC += __shfl_xor(cC, o, 64); cG += __shfl_xor(cG, o, 64); cT += __shfl_xor(cT, o, 64); cN += __shfl_xor(cN, o, 64); }
+      live = !lowComplexity(len, cC, cG, cT, cN);
+    }
+    bool any = false;
+    if (live) {
+      const int nk = len - k + 1;
+      for (int q0 = 0; q0 < 2 * nk; q0 += 64 * 4) {  // four independent look-ups per lane in flight
+        uint32_t st[4], en[4];
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+          const int q = q0 + x * 64 + lane;
+          st[x] = en[x] = 0;
+          if (q < 2 * nk) {
+            const int pass = q >= nk ? 1 : 0, p = q - pass * nk;
+            const uint32_t code = (uint32_t)t1k_get32(rbase + pass * S, p) & kmask;
+            const bool valid = ((uint32_t)t1k_get32(rnm + pass * S, p) & kmask) == 0;
+            if (valid) { st[x] = P.ref.kStart[code]; en[x] = P.ref.kStart[code + 1]; }
+          }
+        }
+#pragma unroll
+        for (int x = 0; x < 4; ++x) any |= en[x] != st[x];
+      }
+    }
+    const bool anyWave = __ballot(any) != 0ull;
+    if (lane == 0) P.state[re] = (live && anyWave) ? 1 : 0;
+  }
 }
 
 __global__ __launch_bounds__(XWG) void k_extract(ExtractArgs P) {
@@ -56,39 +114,47 @@ __global__ __launch_bounds__(XWG) void k_extract(ExtractArgs P) {
   uint16_t *usedQ = (uint16_t *)(pre + maxK + 2);  // [maxK] used look-ups, + strand first
   uint32_t *hist = (uint32_t *)(usedQ + maxK + (maxK & 1));  // [X_RANGE]; after the vote: H | A | B | C, X_HCAP words each
   __shared__ uint32_t warpSums[4];
-  __shared__ uint32_t sCnt[4];
   __shared__ uint32_t sUsed[2];
   __shared__ unsigned long long sKey[4];
-  __shared__ int sRes;
+  __shared__ int sRes, sMulti, sLen;
+  __shared__ uint16_t sList[XWG];
   const int tid = threadIdx.x;
   const int k = P.k;
   const uint32_t kmask = (1u << (2 * k)) - 1;
   const uint32_t A = P.ref.nAlleles;
-  unsigned long long stEnds = 0, stLook = 0, stPost = 0, stHist = 0, stChain = 0;  // thread 0 tallies
+  unsigned long long stLook = 0, stPost = 0, stHist = 0, stChain = 0;  // thread 0 tallies
 
-  for (uint32_t f = blockIdx.x; f < P.nFragments; f += gridDim.x) {
+  for (uint32_t blk = blockIdx.x; (uint64_t)blk * XWG < P.nFragments; blk += gridDim.x) {
+   // fragments of this block with a read-end the screen could not finish, in order
+   const uint32_t f0 = blk * XWG;
+   uint32_t nList;
+   {
+     uint32_t need = 0;
+     if (f0 + tid < P.nFragments) {
+       need = P.state[(uint64_t)(f0 + tid) * P.epf];
+       if (P.epf == 2) need |= (uint32_t)P.state[(uint64_t)(f0 + tid) * 2 + 1] << 1;
+       if (!need) P.good[f0 + tid] = 0;
+     }
+     __syncthreads();  // the previous block is done with sList
+     const uint32_t slot = t1k_block_scan_exclusive(need ? 1u : 0u, warpSums, &nList);
+     if (need) sList[slot] = (uint16_t)(tid | (need << 8));
+     __syncthreads();
+   }
+   for (uint32_t li = 0; li < nList; ++li) {
+    const uint32_t f = f0 + (sList[li] & 255u), need = sList[li] >> 8;
     bool fragGood = false;
     for (uint32_t j = 0; j < P.epf && !fragGood; ++j) {
+      if (!((need >> j) & 1u)) continue;
       const uint32_t re = f * P.epf + j;
       const int len = P.reads.len[re];
       const int S = P.reads.S;
       const uint64_t *rbase = P.reads.bases + (uint64_t)re * 2 * S;
       const uint64_t *rnm = P.reads.nmask + (uint64_t)re * 2 * S;
-      ++stEnds;
       __syncthreads();  // the previous read-end is done with the shared words
-      if (tid < 4) sCnt[tid] = 0;
-      if (tid == 0) { sUsed[0] = 0; sUsed[1] = 0; sRes = 0; }
+      if (tid == 0) { sUsed[0] = 0; sUsed[1] = 0; sRes = 0; sMulti = 0; sLen = 0; }
       __syncthreads();
       if (len < k) continue;  // HasHitInSet 1919-1920 (uniform)
-      // ---- 1. IsLowComplexity
-      if (tid < (len + 31) / 32) {
-        const uint64_t b = rbase[tid], n = rnm[tid];
-        const uint64_t lo = b & T1K_EVEN, hi = (b >> 1) & T1K_EVEN;
-        atomicAdd(&sCnt[0], (uint32_t)__popcll(lo & ~hi));  // C
-        atomicAdd(&sCnt[1], (uint32_t)__popcll(hi & ~lo));  // G
-        atomicAdd(&sCnt[2], (uint32_t)__popcll(lo & hi));   // T
-        atomicAdd(&sCnt[3], (uint32_t)__popcll(n & T1K_EVEN));  // N (packed as base 0 with its mask bit set)
-      }
+      // (1. IsLowComplexity and len < k were decided by the screen: such read-ends never get here)
       // ---- 2. look-ups of both strands
       const int nk = len - k + 1;
       for (int q = tid; q < 2 * nk; q += XWG) {
@@ -101,14 +167,6 @@ __global__ __launch_bounds__(XWG) void k_extract(ExtractArgs P) {
         ukCode[q] = code; ukStart[q] = st; ukLen[q] = ln;
       }
       __syncthreads();
-      {
-        const int cC = (int)sCnt[0], cG = (int)sCnt[1], cT = (int)sCnt[2], cN = (int)sCnt[3], cA = len - cC - cG - cT - cN;
-        const int half = len / 2;
-        bool low = cA >= half || cC >= half || cG >= half || cT >= half || cN >= len / 10;
-        const int lowCnt = (cA <= 2) + (cC <= 2) + (cG <= 2) + (cT <= 2);
-        if (lowCnt >= 2) low = true;
-        if (low) continue;  // uniform
-      }
       // sequential replay of the look-up rule by the first wavefront (uniform code over v_readlane)
       if (tid < 64) {
         uint32_t prev = 0;  // prevKmerCode starts at code 0 and is carried from the + strand into the - strand
@@ -247,6 +305,31 @@ __global__ __launch_bounds__(XWG) void k_extract(ExtractArgs P) {
       }
       if (n > X_HCAP) { if (tid == 0) atomicOr(P.err, (unsigned long long)XERR_HITCAP); continue; }
       __syncthreads();
+      // one diagonal, read offsets ascending (the gather order): one run, nothing filtered, LIS = every hit (see the header)
+      {
+        const int d0 = (int)(H[0] & 0xFFF) - (int)(H[0] >> 12);
+        int part = 0;
+        bool multi = false;
+        for (uint32_t i = tid; i < n; i += XWG) {
+          const uint32_t x = H[i];
+          if ((int)(x & 0xFFF) - (int)(x >> 12) != d0) multi = true;
+          if (i + 1 < n) {
+            const int gap = (int)(H[i + 1] & 0xFFF) - (int)(x & 0xFFF);
+            if (gap <= 0) multi = true;
+            part += gap < k ? gap : k;
+          } else part += k;
+        }
+        if (multi) sMulti = 1;
+        for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+        if ((tid & 63) == 0) atomicAdd(&sLen, part);
+      }
+      __syncthreads();
+      if (!sMulti) {
+        const int hitLen = sLen;  // on the read and on the sequence alike
+        const int thr = (int)(len * P.oneMinusSim) * k;
+        fragGood = n >= 3 && (int)n * k >= P.hitLenRequired && hitLen >= P.hitLenRequired && len - hitLen <= thr;
+        continue;
+      }
       // rank sort by (diagonal, sequence offset, read offset): the packed words are distinct
       for (uint32_t i = tid; i < n; i += XWG) {
         const uint32_t x = H[i];
@@ -303,9 +386,10 @@ __global__ __launch_bounds__(XWG) void k_extract(ExtractArgs P) {
       fragGood = sRes != 0;
     }
     if (tid == 0) P.good[f] = fragGood ? 1 : 0;
+   }
   }
   if (tid == 0 && P.stats) {
-    atomicAdd(&P.stats[0], stEnds); atomicAdd(&P.stats[1], stLook); atomicAdd(&P.stats[2], stPost);
+    atomicAdd(&P.stats[1], stLook); atomicAdd(&P.stats[2], stPost);
     atomicAdd(&P.stats[3], stHist); atomicAdd(&P.stats[4], stChain);
   }
 }
@@ -313,12 +397,14 @@ __global__ __launch_bounds__(XWG) void k_extract(ExtractArgs P) {
 size_t t1k_extract_lds_bytes(int maxK) { return ((size_t)maxK * 5 + 3) * 4 + ((size_t)maxK + 1) / 2 * 2 * 2 + (size_t)X_RANGE * 4 + 16; }
 
 void t1k_launch_extract(t1k_ctx *ctx, const T1kRefDev &ref, const T1kReadsDev &reads, int k, int radius, int hitLenRequired, double oneMinusSim, uint32_t nFragments,
-                        uint32_t epf, uint32_t maxK, uint8_t *good, unsigned long long *err, unsigned long long *stats, int nWg) {
+                        uint32_t epf, uint32_t maxK, uint8_t *good, uint8_t *state, unsigned long long *err, unsigned long long *stats, int nWg) {
   ExtractArgs a{};
   a.ref = ref; a.reads = reads; a.k = k; a.radius = radius; a.hitLenRequired = hitLenRequired; a.oneMinusSim = oneMinusSim;
-  a.nFragments = nFragments; a.epf = epf; a.maxK = maxK; a.good = good; a.err = err; a.stats = stats;
+  a.nFragments = nFragments; a.epf = epf; a.maxK = maxK; a.good = good; a.state = state; a.err = err; a.stats = stats;
   const size_t ldsBytes = t1k_extract_lds_bytes((int)maxK);
   hipFuncSetAttribute((const void *)k_extract, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes);
-  const unsigned grid = (unsigned)std::min<uint64_t>(nFragments, (uint64_t)nWg);
+  const unsigned gridS = (unsigned)std::min<uint64_t>(((uint64_t)reads.nReadEnds + 3) / 4, (uint64_t)nWg);
+  hipLaunchKernelGGL(k_extract_screen, dim3(gridS), dim3(XWG), 0, ctx->stream, a);
+  const unsigned grid = (unsigned)std::min<uint64_t>(((uint64_t)nFragments + XWG - 1) / XWG, (uint64_t)nWg);
   hipLaunchKernelGGL(k_extract, dim3(grid), dim3(XWG), ldsBytes, ctx->stream, a);
 }
