@@ -388,18 +388,23 @@ int t1k_extract_batch(t1k_ctx *ctx, uint32_t endsPerFragment, uint8_t *good, uin
   const size_t flagBytes = ((size_t)nFrag + 63) / 64 * 64;
   int rc;
   const size_t stateBytes = ((size_t)nEnds + 63) / 64 * 64;
-  if ((rc = t1k_ensure(ctx, ctx->bExtract, flagBytes + 64 + stateBytes))) return rc;
+  if ((rc = t1k_ensure(ctx, ctx->bExtract, flagBytes + 128 + stateBytes))) return rc;
   uint8_t *dGood = (uint8_t *)ctx->bExtract.p;
   unsigned long long *dCtl = (unsigned long long *)(dGood + flagBytes);  // [0] error flags, [1..5] statistics
-  uint8_t *dState = dGood + flagBytes + 64;                             // per read-end verdict of the screen
-  T1K_HIP(ctx, hipMemsetAsync(dCtl, 0, 64, ctx->stream));
+  uint8_t *dState = dGood + flagBytes + 128;                            // per read-end verdict of the screen
+  T1K_HIP(ctx, hipMemsetAsync(dCtl, 0, 128, ctx->stream));
   const uint32_t maxK = (uint32_t)((2 * std::max(1, ctx->batchMaxLen - ctx->prm.kmer_length + 1) + 3) / 4 * 4);
   t1k_launch_extract(ctx, ctx->ref, ctx->reads, ctx->prm.kmer_length, ctx->prm.radius, ctx->prm.hit_len_required, 1 - ctx->prm.ref_seq_similarity, nFrag,
                      endsPerFragment, maxK, dGood, dState, dCtl, dCtl + 1, ctx->prm.workgroups * 4);
-  unsigned long long ctl[8];
+  unsigned long long ctl[16];
   T1K_HIP(ctx, hipMemcpyAsync(good, dGood, nFrag, hipMemcpyDeviceToHost, ctx->stream));
-  T1K_HIP(ctx, hipMemcpyAsync(ctl, dCtl, 64, hipMemcpyDeviceToHost, ctx->stream));
+  T1K_HIP(ctx, hipMemcpyAsync(ctl, dCtl, 128, hipMemcpyDeviceToHost, ctx->stream));
   T1K_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (getenv("T1K_XPROF")) {  // phase clocks of k_extract (builds with -DT1K_XPROF only): list, look-ups, replay, vote, gather, diagonal test, chain
+    fprintf(stderr, "[t1k xprof]");
+    for (int i = 0; i < 7; ++i) fprintf(stderr, " %.3g", (double)ctl[8 + i]);
+    fprintf(stderr, "\n");
+  }
   if (ctl[0]) return t1k_fail(ctx, T1K_ERR_CAPACITY, "t1k_extract_batch: a read has more than 2048 hits on one reference sequence");
   if (stats) { for (int i = 0; i < 5; ++i) stats[i] = ctl[1 + i]; stats[0] = nEnds; }
   return T1K_OK;

@@ -27,6 +27,11 @@
 #define X_RANGE 8192   // sequences per histogram pass (u32 counters: 32 KB of LDS)
 #define X_HCAP 2048    // hits of one (strand, sequence) bucket
 enum { XERR_HITCAP = 1 };
+#ifdef T1K_XPROF
+#define XP(i) { const uint64_t tn_ = __builtin_amdgcn_s_memtime(); xp_[i] += tn_ - xl_; xl_ = tn_; }
+#else
+#define XP(i)
+#endif
 
 struct ExtractArgs {
   T1kRefDev ref;
@@ -117,11 +122,16 @@ __global__ __launch_bounds__(XWG) void k_extract(ExtractArgs P) {
   __shared__ uint32_t sUsed[2];
   __shared__ unsigned long long sKey[4];
   __shared__ int sRes, sMulti, sLen;
+  __shared__ int sWaveMax[4];
+  __shared__ uint32_t sPost;
   __shared__ uint16_t sList[XWG];
   const int tid = threadIdx.x;
   const int k = P.k;
   const uint32_t kmask = (1u << (2 * k)) - 1;
   const uint32_t A = P.ref.nAlleles;
+#ifdef T1K_XPROF
+  uint64_t xp_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, xl_ = __builtin_amdgcn_s_memtime();
+#endif
   unsigned long long stLook = 0, stPost = 0, stHist = 0, stChain = 0;  // thread 0 tallies
 
   for (uint32_t blk = blockIdx.x; (uint64_t)blk * XWG < P.nFragments; blk += gridDim.x) {
@@ -140,6 +150,7 @@ __global__ __launch_bounds__(XWG) void k_extract(ExtractArgs P) {
      if (need) sList[slot] = (uint16_t)(tid | (need << 8));
      __syncthreads();
    }
+   XP(0)
    for (uint32_t li = 0; li < nList; ++li) {
     const uint32_t f = f0 + (sList[li] & 255u), need = sList[li] >> 8;
     bool fragGood = false;
@@ -151,7 +162,7 @@ __global__ __launch_bounds__(XWG) void k_extract(ExtractArgs P) {
       const uint64_t *rbase = P.reads.bases + (uint64_t)re * 2 * S;
       const uint64_t *rnm = P.reads.nmask + (uint64_t)re * 2 * S;
       __syncthreads();  // the previous read-end is done with the shared words
-      if (tid == 0) { sUsed[0] = 0; sUsed[1] = 0; sRes = 0; sMulti = 0; sLen = 0; }
+      if (tid == 0) { sUsed[0] = 0; sUsed[1] = 0; sRes = 0; sMulti = 0; sLen = 0; sPost = 0; }
       __syncthreads();
       if (len < k) continue;  // HasHitInSet 1919-1920 (uniform)
       // (1. IsLowComplexity and len < k were decided by the screen: such read-ends never get here)
@@ -167,8 +178,63 @@ __global__ __launch_bounds__(XWG) void k_extract(ExtractArgs P) {
         ukCode[q] = code; ukStart[q] = st; ukLen[q] = ln;
       }
       __syncthreads();
-      // sequential replay of the look-up rule by the first wavefront (uniform code over v_readlane)
-      if (tid < 64) {
+      XP(1)
+      // The look-up rule (SeqSet.hpp:1098-1153, 1165-1226) is a sequential state machine (prevKmerCode, skipCnt).  Parallel form: if no two
+      // k-mers within k/2 + 1 consecutive positions of a strand are equal, `code != prev` holds at every position (prev is the code of one
+      // of the previous k/2 + 1 positions), every position is a look-up, and only skipCnt is left: in a maximal run of "big" positions
+      // (list >= 100, not the first / last k-mer) exactly every (k/2 + 1)-th one is used, any other position resets the count.  Reads
+      // with such short repeats take the sequential replay below.
+      {
+        const int W1 = k / 2 + 1;
+        int lastNonBig[3];
+        uint32_t szv[3];
+        bool bigv[3], dup = false;
+        int localMax = -1;
+#pragma unroll
+        for (int x = 0; x < 3; ++x) {
+          const int q = 3 * tid + x;
+          szv[x] = 0; bigv[x] = false;
+          if (q < 2 * nk) {
+            const int pass = q >= nk ? 1 : 0, p = q - pass * nk;
+            const uint32_t code = ukCode[q];
+            for (int d = 1; d <= W1 && d <= p; ++d) dup |= ukCode[q - d] == code;
+            szv[x] = ukLen[q];
+            bigv[x] = szv[x] >= 100 && p != 0 && p != nk - 1;
+            if (!bigv[x]) localMax = q;
+          }
+          lastNonBig[x] = localMax;  // within this thread so far; the threads before are merged in below
+        }
+        if (dup) sMulti = 1;  // (borrowed as the "needs the replay" flag until the chain)
+        int incl = localMax;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(incl, o, 64); if ((tid & 63) >= o) incl = max(incl, y); }
+        if ((tid & 63) == 63) sWaveMax[tid >> 6] = incl;
+        __syncthreads();
+        int before = __shfl_up(incl, 1, 64);
+        if ((tid & 63) == 0) before = -1;
+        for (int w = 0; w < (tid >> 6); ++w) before = max(before, sWaveMax[w]);
+        const bool fallback = sMulti != 0;
+        uint32_t mine = 0, minePlus = 0, minePost = 0;
+        bool usedv[3];
+#pragma unroll
+        for (int x = 0; x < 3; ++x) {
+          const int q = 3 * tid + x;
+          usedv[x] = false;
+          if (!fallback && q < 2 * nk && szv[x]) usedv[x] = !bigv[x] || ((q - max(lastNonBig[x], before)) % W1 == 0);
+          if (usedv[x]) { ++mine; minePost += szv[x]; if (q < nk) ++minePlus; }
+        }
+        uint32_t tot;
+        uint32_t slot = t1k_block_scan_exclusive(mine, warpSums, &tot);
+#pragma unroll
+        for (int x = 0; x < 3; ++x)
+          if (usedv[x]) usedQ[slot++] = (uint16_t)(3 * tid + x);
+        for (int o = 32; o > 0; o >>= 1) { minePlus += __shfl_xor(minePlus, o, 64); minePost += __shfl_xor(minePost, o, 64); }
+        if ((tid & 63) == 0 && !fallback) { atomicAdd(&sUsed[0], minePlus); atomicAdd(&sPost, minePost); }
+        __syncthreads();
+        if (tid == 0 && !fallback) { sUsed[1] = tot - sUsed[0]; stLook += 2 * nk; stPost += sPost; }
+      }
+      // sequential replay by the first wavefront (uniform code over v_readlane)
+      if (sMulti && tid < 64) {
         uint32_t prev = 0;  // prevKmerCode starts at code 0 and is carried from the + strand into the - strand
         uint32_t nUsed = 0, lookups = 0, postings = 0;
         for (int pass = 0; pass < 2; ++pass) {
@@ -201,19 +267,21 @@ __global__ __launch_bounds__(XWG) void k_extract(ExtractArgs P) {
         stLook += lookups; stPost += postings;
       }
       __syncthreads();
+      if (tid == 0) sMulti = 0;  // back to its own meaning (set again before it is read: a barrier follows in every path)
       const uint32_t nUsed0 = sUsed[0], nUsed1 = sUsed[1];
+      XP(2)
       if (nUsed0 + nUsed1 == 0) continue;  // no hit (1925-1927)
       ++stHist;
       // ---- 3. the fullest (strand, sequence) bucket
       int bestCnt = -1, bestPass = 0;
       uint32_t bestAllele = 0;
+      const int needHits = (P.hitLenRequired + k - 1) / k;
       for (int tag = 0; tag < 2; ++tag) {
         const int pass = tag == 0 ? 1 : 0;  // bucket tag 0 = minus strand
         const uint32_t uBeg = pass == 0 ? 0 : nUsed0, uCnt = pass == 0 ? nUsed0 : nUsed1;
         if (!uCnt) continue;
         for (uint32_t r0 = 0; r0 < A; r0 += X_RANGE) {
           const uint32_t r1 = min(A, r0 + X_RANGE);
-          for (int i = tid; i < X_RANGE; i += XWG) hist[i] = 0;
           // slices of the used lists (two consecutive lists per thread keep the prefix in list order)
           uint32_t myLen[2] = {0, 0};
 #pragma unroll
@@ -243,13 +311,29 @@ __global__ __launch_bounds__(XWG) void k_extract(ExtractArgs P) {
           if (2 * tid < (int)uCnt) pre[2 * tid] = base;
           if (2 * tid + 1 < (int)uCnt) pre[2 * tid + 1] = base + myLen[0];
           if (tid == 0) pre[uCnt] = total;
+          // a bucket holds at most all `total` hits of this range: fewer than ceil(hitLenRequired / k) cannot pass 1959, and cannot outvote
+          // a bucket that does (the vote is by count alone)
+          if ((int)total < needHits) { __syncthreads(); continue; }
+          for (int i = tid; i < X_RANGE; i += XWG) hist[i] = 0;
           __syncthreads();
-          for (uint32_t x = tid; x < total; x += XWG) {
-            uint32_t lo = 0, hi = uCnt;  // last u with pre[u] <= x
-            while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (pre[mid] <= x) lo = mid; else hi = mid; }
-            const int q = usedQ[uBeg + lo];
-            const T1kPosting pp = P.ref.kPost[ukStart[q] + sliceLo[lo] + (x - pre[lo])];
-            atomicAdd(&hist[pp.allele - r0], 1u);
+          {
+            uint32_t cur = 0;  // list holding flattened posting x: pre[cur] <= x < pre[cur + 1]; x only grows, so the cursor only advances
+            for (uint32_t x0 = tid; x0 < total; x0 += 4 * XWG) {
+              uint32_t al[4];
+#pragma unroll
+              for (int v = 0; v < 4; ++v) {  // four independent loads in flight
+                const uint32_t x = x0 + v * XWG;
+                al[v] = 0xFFFFFFFFu;
+                if (x < total) {
+                  while (pre[cur + 1] <= x) ++cur;
+                  const int q = usedQ[uBeg + cur];
+                  al[v] = P.ref.kPost[ukStart[q] + sliceLo[cur] + (x - pre[cur])].allele;
+                }
+              }
+#pragma unroll
+              for (int v = 0; v < 4; ++v)
+                if (al[v] != 0xFFFFFFFFu) atomicAdd(&hist[al[v] - r0], 1u);
+            }
           }
           __syncthreads();
           // first maximum of the range: largest count, then smallest sequence index
@@ -267,6 +351,7 @@ __global__ __launch_bounds__(XWG) void k_extract(ExtractArgs P) {
           __syncthreads();  // hist / pre / sKey are rewritten by the next pass
         }
       }
+      XP(3)
       if (bestCnt < 0 || k * bestCnt < P.hitLenRequired) continue;  // 1959-1964
       ++stChain;
       // ---- 4. the bucket's hits -> H (hist is dead)
@@ -305,6 +390,7 @@ __global__ __launch_bounds__(XWG) void k_extract(ExtractArgs P) {
       }
       if (n > X_HCAP) { if (tid == 0) atomicOr(P.err, (unsigned long long)XERR_HITCAP); continue; }
       __syncthreads();
+      XP(4)
       // one diagonal, read offsets ascending (the gather order): one run, nothing filtered, LIS = every hit (see the header)
       {
         const int d0 = (int)(H[0] & 0xFFF) - (int)(H[0] >> 12);
@@ -324,6 +410,7 @@ __global__ __launch_bounds__(XWG) void k_extract(ExtractArgs P) {
         if ((tid & 63) == 0) atomicAdd(&sLen, part);
       }
       __syncthreads();
+      XP(5)
       if (!sMulti) {
         const int hitLen = sLen;  // on the read and on the sequence alike
         const int thr = (int)(len * P.oneMinusSim) * k;
@@ -383,6 +470,7 @@ __global__ __launch_bounds__(XWG) void k_extract(ExtractArgs P) {
         sRes = ok ? 1 : 0;
       }
       __syncthreads();
+      XP(6)
       fragGood = sRes != 0;
     }
     if (tid == 0) P.good[f] = fragGood ? 1 : 0;
@@ -391,6 +479,9 @@ __global__ __launch_bounds__(XWG) void k_extract(ExtractArgs P) {
   if (tid == 0 && P.stats) {
     atomicAdd(&P.stats[1], stLook); atomicAdd(&P.stats[2], stPost);
     atomicAdd(&P.stats[3], stHist); atomicAdd(&P.stats[4], stChain);
+#ifdef T1K_XPROF
+    for (int i = 0; i < 7; ++i) atomicAdd(&P.stats[7 + i], (unsigned long long)xp_[i]);
+#endif
   }
 }
 
