@@ -206,6 +206,12 @@ int t1k_ref_upload(t1k_ctx *ctx, const char *seqs, const uint64_t *offsets, cons
   if ((rc = uploadVec(ctx, sepPos, (const void **)&r.sepPos))) return rc;
   if ((rc = uploadVec(ctx, kStart, (const void **)&r.kStart))) return rc;
   {
+    std::vector<uint32_t> has((nKeys + 31) / 32, 0);
+    for (size_t code = 0; code < nKeys; ++code)
+      if (kStart[code + 1] != kStart[code]) has[code >> 5] |= 1u << (code & 31);
+    if ((rc = uploadVec(ctx, has, (const void **)&r.kHas))) return rc;
+  }
+  {
     // chunk directory: where each multiple of T1K_SEED_CHUNK alleles begins inside a long posting list, so that the seeding kernel
     // finds a chunk's slice of a list with one load instead of a bisection
     const uint32_t stride = (nAlleles + T1K_SEED_CHUNK - 1) / T1K_SEED_CHUNK + 1;

@@ -87,20 +87,20 @@ __global__ __launch_bounds__(XWG) void k_extract_screen(ExtractArgs P) {
     if (live) {
       const int nk = len - k + 1;
       for (int q0 = 0; q0 < 2 * nk; q0 += 64 * 4) {  // four independent look-ups per lane in flight
-        uint32_t st[4], en[4];
+        uint32_t w[4], bit[4];
 #pragma unroll
         for (int x = 0; x < 4; ++x) {
           const int q = q0 + x * 64 + lane;
-          st[x] = en[x] = 0;
+          w[x] = 0; bit[x] = 0;
           if (q < 2 * nk) {
             const int pass = q >= nk ? 1 : 0, p = q - pass * nk;
             const uint32_t code = (uint32_t)t1k_get32(rbase + pass * S, p) & kmask;
             const bool valid = ((uint32_t)t1k_get32(rnm + pass * S, p) & kmask) == 0;
-            if (valid) { st[x] = P.ref.kStart[code]; en[x] = P.ref.kStart[code + 1]; }
+            if (valid) { w[x] = P.ref.kHas[code >> 5]; bit[x] = code & 31u; }  // the presence bitmap, not the 32x larger bucket table
           }
         }
 #pragma unroll
-        for (int x = 0; x < 4; ++x) any |= en[x] != st[x];
+        for (int x = 0; x < 4; ++x) any |= ((w[x] >> bit[x]) & 1u) != 0;
       }
     }
     const bool anyWave = __ballot(any) != 0ull;
@@ -114,7 +114,8 @@ __global__ __launch_bounds__(XWG) void k_extract(ExtractArgs P) {
   uint32_t *ukCode = lds;                        // [maxK] code | valid << 31, both strands
   uint32_t *ukStart = ukCode + maxK;             // [maxK]
   uint32_t *ukLen = ukStart + maxK;              // [maxK]
-  uint32_t *sliceLo = ukLen + maxK;              // [maxK] slice of the current pass inside each used list (later: minDist of the chain)
+  uint32_t *ukDir = ukLen + maxK;                // [maxK] chunk-directory row of the list (lists longer than T1K_DIR_MINLEN)
+  uint32_t *sliceLo = ukDir + maxK;              // [maxK] slice of the current pass inside each used list (later: minDist of the chain)
   uint32_t *pre = sliceLo + maxK;                // [maxK + 1] exclusive prefix of the slice lengths
   uint16_t *usedQ = (uint16_t *)(pre + maxK + 2);  // [maxK] used look-ups, + strand first
   uint32_t *hist = (uint32_t *)(usedQ + maxK + (maxK & 1));  // [X_RANGE]; after the vote: H | A | B | C, X_HCAP words each
@@ -123,6 +124,7 @@ __global__ __launch_bounds__(XWG) void k_extract(ExtractArgs P) {
   __shared__ unsigned long long sKey[4];
   __shared__ int sRes, sMulti, sLen;
   __shared__ int sWaveMax[4];
+  __shared__ uint32_t sRed[12];
   __shared__ uint32_t sPost;
   __shared__ uint16_t sList[XWG];
   const int tid = threadIdx.x;
@@ -173,9 +175,10 @@ __global__ __launch_bounds__(XWG) void k_extract(ExtractArgs P) {
         const uint64_t *b = rbase + pass * S, *nm = rnm + pass * S;
         const uint32_t code = (uint32_t)t1k_get32(b, p) & kmask;
         const bool valid = ((uint32_t)t1k_get32(nm, p) & kmask) == 0;
-        uint32_t st = 0, ln = 0;
+        uint32_t st = 0, ln = 0, dr = T1K_NO_DIR;
         if (valid) { st = P.ref.kStart[code]; ln = P.ref.kStart[code + 1] - st; }
-        ukCode[q] = code; ukStart[q] = st; ukLen[q] = ln;
+        if (ln > T1K_DIR_MINLEN && A > X_RANGE) dr = P.ref.kDirIdx[code];
+        ukCode[q] = code; ukStart[q] = st; ukLen[q] = ln; ukDir[q] = dr;
       }
       __syncthreads();
       XP(1)
@@ -280,7 +283,31 @@ __global__ __launch_bounds__(XWG) void k_extract(ExtractArgs P) {
         const int pass = tag == 0 ? 1 : 0;  // bucket tag 0 = minus strand
         const uint32_t uBeg = pass == 0 ? 0 : nUsed0, uCnt = pass == 0 ? nUsed0 : nUsed1;
         if (!uCnt) continue;
-        for (uint32_t r0 = 0; r0 < A; r0 += X_RANGE) {
+        // sequences the strand's used lists span, and how many hits they hold: a strand with fewer than needHits hits cannot matter
+        // (see below), and only the histogram ranges inside the span are walked (the sequences of one gene are neighbours)
+        uint32_t rBeg, rEnd;
+        {
+          uint32_t mn = 0xFFFFFFFFu, mx = 0, tsum = 0;
+#pragma unroll
+          for (int x = 0; x < 2; ++x) {
+            const uint32_t u = 2 * tid + x;
+            if (u < uCnt) {
+              const int q = usedQ[uBeg + u];
+              const uint32_t st = ukStart[q], ln = ukLen[q];
+              mn = min(mn, P.ref.kPost[st].allele); mx = max(mx, P.ref.kPost[st + ln - 1].allele); tsum += ln;
+            }
+          }
+          for (int o = 32; o > 0; o >>= 1) { mn = min(mn, (uint32_t)__shfl_xor(mn, o, 64)); mx = max(mx, (uint32_t)__shfl_xor(mx, o, 64)); tsum += __shfl_xor(tsum, o, 64); }
+          if ((tid & 63) == 0) { sRed[tid >> 6] = mn; sRed[4 + (tid >> 6)] = mx; sRed[8 + (tid >> 6)] = tsum; }
+          __syncthreads();
+          mn = min(min(sRed[0], sRed[1]), min(sRed[2], sRed[3])); mx = max(max(sRed[4], sRed[5]), max(sRed[6], sRed[7]));
+          tsum = sRed[8] + sRed[9] + sRed[10] + sRed[11];
+          __syncthreads();
+          if ((int)tsum < needHits) continue;
+          rBeg = A > X_RANGE ? mn / T1K_SEED_CHUNK * T1K_SEED_CHUNK : 0;
+          rEnd = mx + 1;
+        }
+        for (uint32_t r0 = rBeg; r0 < rEnd; r0 += X_RANGE) {
           const uint32_t r1 = min(A, r0 + X_RANGE);
           // slices of the used lists (two consecutive lists per thread keep the prefix in list order)
           uint32_t myLen[2] = {0, 0};
@@ -292,7 +319,7 @@ __global__ __launch_bounds__(XWG) void k_extract(ExtractArgs P) {
               const uint32_t st = ukStart[q], ln = ukLen[q];
               uint32_t lo = 0, hi = ln;
               if (A > X_RANGE) {
-                const uint32_t dr = ln > T1K_DIR_MINLEN ? P.ref.kDirIdx[ukCode[q]] : T1K_NO_DIR;
+                const uint32_t dr = ukDir[q];
                 if (dr != T1K_NO_DIR) {
                   const uint32_t *row = P.ref.kDir + (uint64_t)dr * P.ref.kDirStride;
                   lo = row[r0 / T1K_SEED_CHUNK];
@@ -485,7 +512,7 @@ __global__ __launch_bounds__(XWG) void k_extract(ExtractArgs P) {
   }
 }
 
-size_t t1k_extract_lds_bytes(int maxK) { return ((size_t)maxK * 5 + 3) * 4 + ((size_t)maxK + 1) / 2 * 2 * 2 + (size_t)X_RANGE * 4 + 16; }
+size_t t1k_extract_lds_bytes(int maxK) { return ((size_t)maxK * 6 + 3) * 4 + ((size_t)maxK + 1) / 2 * 2 * 2 + (size_t)X_RANGE * 4 + 16; }
 
 void t1k_launch_extract(t1k_ctx *ctx, const T1kRefDev &ref, const T1kReadsDev &reads, int k, int radius, int hitLenRequired, double oneMinusSim, uint32_t nFragments,
                         uint32_t epf, uint32_t maxK, uint8_t *good, uint8_t *state, unsigned long long *err, unsigned long long *stats, int nWg) {
