@@ -210,6 +210,12 @@ int t1k_ref_upload(t1k_ctx *ctx, const char *seqs, const uint64_t *offsets, cons
     for (size_t code = 0; code < nKeys; ++code)
       if (kStart[code + 1] != kStart[code]) has[code >> 5] |= 1u << (code & 31);
     if ((rc = uploadVec(ctx, has, (const void **)&r.kHas))) return rc;
+    const int kp = std::max(1, k - 2);
+    const size_t nPre = (size_t)1 << (2 * kp);
+    std::vector<uint32_t> hasPre((nPre + 31) / 32, 0);
+    for (size_t code = 0; code < nKeys; ++code)
+      if (kStart[code + 1] != kStart[code]) { const size_t pcode = code & (nPre - 1); hasPre[pcode >> 5] |= 1u << (pcode & 31); }
+    if ((rc = uploadVec(ctx, hasPre, (const void **)&r.kHasPre))) return rc;
   }
   {
     // chunk directory: where each multiple of T1K_SEED_CHUNK alleles begins inside a long posting list, so that the seeding kernel

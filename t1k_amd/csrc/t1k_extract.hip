@@ -86,21 +86,25 @@ __global__ __launch_bounds__(XWG) void k_extract_screen(ExtractArgs P) {
     bool any = false;
     if (live) {
       const int nk = len - k + 1;
+      // two presence bitmaps: the first k - 2 bases of the k-mer (small enough to stay in L2) decide for most positions; only the ones it
+      // lets through ask the full bitmap
+      const uint32_t pmask = k > 2 ? (1u << (2 * (k - 2))) - 1 : kmask;
       for (int q0 = 0; q0 < 2 * nk; q0 += 64 * 4) {  // four independent look-ups per lane in flight
-        uint32_t w[4], bit[4];
+        uint32_t w[4], code[4];
 #pragma unroll
         for (int x = 0; x < 4; ++x) {
           const int q = q0 + x * 64 + lane;
-          w[x] = 0; bit[x] = 0;
+          w[x] = 0; code[x] = 0;
           if (q < 2 * nk) {
             const int pass = q >= nk ? 1 : 0, p = q - pass * nk;
-            const uint32_t code = (uint32_t)t1k_get32(rbase + pass * S, p) & kmask;
+            code[x] = (uint32_t)t1k_get32(rbase + pass * S, p) & kmask;
             const bool valid = ((uint32_t)t1k_get32(rnm + pass * S, p) & kmask) == 0;
-            if (valid) { w[x] = P.ref.kHas[code >> 5]; bit[x] = code & 31u; }  // the presence bitmap, not the 32x larger bucket table
+            if (valid) w[x] = P.ref.kHasPre[(code[x] & pmask) >> 5];
           }
         }
 #pragma unroll
-        for (int x = 0; x < 4; ++x) any |= ((w[x] >> bit[x]) & 1u) != 0;
+        for (int x = 0; x < 4; ++x)
+          if ((w[x] >> (code[x] & 31u)) & 1u) any |= ((P.ref.kHas[code[x] >> 5] >> (code[x] & 31u)) & 1u) != 0;
       }
     }
     const bool anyWave = __ballot(any) != 0ull;
