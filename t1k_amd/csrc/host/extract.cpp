@@ -5,6 +5,7 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <chrono>
 #include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
@@ -236,11 +237,20 @@ extern "C" int t1k_extractor_main(int argc, char **argv) {
   if (refPath.empty()) { fprintf(stderr, "Need to use -f to specify the reference sequence.\n"); return EXIT_FAILURE; }
   if (reads.files.empty()) { fprintf(stderr, "Need to use -u/-1/-2/-i to specify the read files.\n"); return EXIT_FAILURE; }
   printLog("Start to extract candidate reads from read files.");
+  const bool dbg = getenv("T1K_DEBUG_PHASES") != nullptr;
+  auto tStart = std::chrono::steady_clock::now();
+  auto lap = [&](const char *what) {
+    if (!dbg) return;
+    auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "[t1k] extractor %s: %.3f s\n", what, std::chrono::duration<double>(now - tStart).count());
+    tStart = now;
+  };
 
   // reference: one sequence per FASTA record (SeqSet::InputRefFa, SeqSet.hpp:872-904)
   std::vector<t1k::SeqRec> ref;
   std::string err;
   if (!t1k::readSeqFile(refPath, ref, err) || ref.empty()) { fprintf(stderr, "%s\n", err.empty() ? "empty reference" : err.c_str()); return EXIT_FAILURE; }
+  lap("reference read");
   // hitLenRequired from the first 1000 reads (FastqExtractor.cpp:383-401)
   int hitLenRequired = hasMate ? 27 : 23;
   {
@@ -289,6 +299,7 @@ extern "C" int t1k_extractor_main(int argc, char **argv) {
     }
   }
 
+  lap("context + reference index upload");
   FILE *fp1 = fopen((prefix + (hasMate ? "_1.fq" : ".fq")).c_str(), "w");
   FILE *fp2 = hasMate ? fopen((prefix + "_2.fq").c_str(), "w") : nullptr;
   FILE *fpBc = hasBarcode ? fopen((prefix + "_bc.fa").c_str(), "w") : nullptr;
@@ -360,6 +371,7 @@ extern "C" int t1k_extractor_main(int argc, char **argv) {
     if (fpBc) fwrite(outBc.data(), 1, outBc.size(), fpBc);
     nFragments += n1;
   }
+  lap("read loop (parse / upload / test / write)");
   if (reads.failed || mates.failed || barcodes.failed) { fprintf(stderr, "Cannot open a read file.\n"); rc = 1; }
   // on an error the reader threads may still be blocked on a full queue: drain them
   if (rc) { while (reads.pop()) {} if (hasMate) while (mates.pop()) {} if (hasBarcode) while (barcodes.pop()) {} }
@@ -368,7 +380,7 @@ extern "C" int t1k_extractor_main(int argc, char **argv) {
   if (fpBc) fclose(fpBc);
   t1k_ctx_destroy(ctx);
   if (rc) return rc;
-  if (getenv("T1K_DEBUG_PHASES")) fprintf(stderr, "[t1k] extractor: k=%d hitLenRequired=%d fragments=%llu kept=%llu\n", kmerLength, hitLenRequired, (unsigned long long)nFragments, (unsigned long long)nGood);
+  if (dbg) fprintf(stderr, "[t1k] extractor: k=%d hitLenRequired=%d fragments=%llu kept=%llu\n", kmerLength, hitLenRequired, (unsigned long long)nFragments, (unsigned long long)nGood);
   printLog("Finish extracting reads.");
   return 0;
 }

@@ -1,6 +1,8 @@
 // t1k_amd/csrc/t1k_capi.hip -- C ABI (include/t1k_gpu.h), device stage layer: context, reference upload + index build,
 // read upload, the AssignRead batch pipeline, downloads.  Kernels live in t1k_assign.hip / t1k_pair.hip / t1k_em.hip.
 #include <algorithm>
+#include <memory>
+#include <thread>
 #include <chrono>
 #include <cstring>
 #include <cstdio>
@@ -182,12 +184,14 @@ int t1k_ref_upload(t1k_ctx *ctx, const char *seqs, const uint64_t *offsets, cons
   for (size_t i = 0; i < nKeys; ++i) kStart[i + 1] += kStart[i];
   std::vector<T1kPosting> post(kStart[nKeys]);
   {
-    std::vector<uint32_t> cur(kStart.begin(), kStart.end() - 1);
+    // kStart doubles as the placement cursor: afterwards entry c holds the end of list c, i.e. the start of list c + 1
     uint32_t a = 0;
     for (auto &e : ins) {
       if (e.first == 0xFFFFFFFFu) { a = e.second + 1; continue; }
-      post[cur[e.first]++] = T1kPosting{a, e.second};
+      post[kStart[e.first]++] = T1kPosting{a, e.second};
     }
+    memmove(&kStart[1], &kStart[0], nKeys * sizeof(uint32_t));
+    kStart[0] = 0;
   }
   ctx->hAlleleOff = alleleOff;
   ctx->hAlleleLen = alleleLen;
@@ -206,38 +210,63 @@ int t1k_ref_upload(t1k_ctx *ctx, const char *seqs, const uint64_t *offsets, cons
   if ((rc = uploadVec(ctx, sepPos, (const void **)&r.sepPos))) return rc;
   if ((rc = uploadVec(ctx, kStart, (const void **)&r.kStart))) return rc;
   {
-    std::vector<uint32_t> has((nKeys + 31) / 32, 0);
-    for (size_t code = 0; code < nKeys; ++code)
-      if (kStart[code + 1] != kStart[code]) has[code >> 5] |= 1u << (code & 31);
-    if ((rc = uploadVec(ctx, has, (const void **)&r.kHas))) return rc;
+    // Per code, in two parallel sweeps over the bucket table (it has 4^k entries: 1 GB at the extractor's k = 14):
+    //   presence bitmaps (t1k_extract.hip): bit c of kHas = list c is not empty; bit p of kHasPre = some non-empty code starts with the k - 2 bases p
+    //   chunk directory: where each multiple of T1K_SEED_CHUNK alleles begins inside a long posting list, so that the kernels find a
+    //   chunk's slice of a list with one load instead of a bisection
+    const uint32_t stride = (nAlleles + T1K_SEED_CHUNK - 1) / T1K_SEED_CHUNK + 1;
     const int kp = std::max(1, k - 2);
     const size_t nPre = (size_t)1 << (2 * kp);
-    std::vector<uint32_t> hasPre((nPre + 31) / 32, 0);
-    for (size_t code = 0; code < nKeys; ++code)
-      if (kStart[code + 1] != kStart[code]) { const size_t pcode = code & (nPre - 1); hasPre[pcode >> 5] |= 1u << (pcode & 31); }
-    if ((rc = uploadVec(ctx, hasPre, (const void **)&r.kHasPre))) return rc;
-  }
-  {
-    // chunk directory: where each multiple of T1K_SEED_CHUNK alleles begins inside a long posting list, so that the seeding kernel
-    // finds a chunk's slice of a list with one load instead of a bisection
-    const uint32_t stride = (nAlleles + T1K_SEED_CHUNK - 1) / T1K_SEED_CHUNK + 1;
-    std::vector<uint32_t> dirIdx(nKeys, T1K_NO_DIR), dir;
-    uint32_t rows = 0;
-    for (size_t code = 0; code < nKeys; ++code) {
-      const uint32_t st = kStart[code], ln = kStart[code + 1] - st;
-      if (ln <= T1K_DIR_MINLEN) continue;
-      dirIdx[code] = rows++;
-      uint32_t p = 0;
-      for (uint32_t cidx = 0; cidx < stride; ++cidx) {
-        const uint32_t bound = cidx * T1K_SEED_CHUNK;
-        while (p < ln && post[st + p].allele < bound) ++p;
-        dir.push_back(p);
+    std::vector<uint32_t> has((nKeys + 31) / 32, 0), hasPre((nPre + 31) / 32, 0);
+    std::unique_ptr<uint32_t[]> dirIdx(new uint32_t[nKeys]);
+    const unsigned T = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    const size_t per = ((nKeys + T - 1) / T + 31) / 32 * 32;
+    std::vector<uint32_t> rowBase(T + 1, 0);
+    auto sweep = [&](auto fn) {
+      std::vector<std::thread> th;
+      for (unsigned t = 0; t < T; ++t) th.emplace_back([&, t] { fn(t, std::min(nKeys, t * per), std::min(nKeys, (t + 1) * per)); });
+      for (auto &x : th) x.join();
+    };
+    sweep([&](unsigned t, size_t lo, size_t hi) {
+      uint32_t rows = 0;
+      for (size_t code = lo; code < hi; ++code) {
+        const uint32_t ln = kStart[code + 1] - kStart[code];
+        if (!ln) continue;
+        has[code >> 5] |= 1u << (code & 31);  // the ranges are multiples of 32 codes: no word is shared
+        const size_t pcode = code & (nPre - 1);
+        __atomic_fetch_or(&hasPre[pcode >> 5], 1u << (pcode & 31), __ATOMIC_RELAXED);
+        if (ln > T1K_DIR_MINLEN) ++rows;
       }
-    }
-    if (dir.empty()) dir.push_back(0);
+      rowBase[t + 1] = rows;
+    });
+    for (unsigned t = 0; t < T; ++t) rowBase[t + 1] += rowBase[t];
+    std::vector<uint32_t> dir((size_t)std::max<uint32_t>(rowBase[T], 1) * stride, 0);
+    sweep([&](unsigned t, size_t lo, size_t hi) {
+      uint32_t row = rowBase[t];
+      for (size_t code = lo; code < hi; ++code) {
+        const uint32_t st = kStart[code], ln = kStart[code + 1] - st;
+        if (ln <= T1K_DIR_MINLEN) { dirIdx[code] = T1K_NO_DIR; continue; }
+        dirIdx[code] = row;
+        uint32_t *d = &dir[(size_t)row * stride];
+        uint32_t p = 0;
+        for (uint32_t cidx = 0; cidx < stride; ++cidx) {
+          const uint32_t bound = cidx * T1K_SEED_CHUNK;
+          while (p < ln && post[st + p].allele < bound) ++p;
+          d[cidx] = p;
+        }
+        ++row;
+      }
+    });
     r.kDirStride = stride;
-    if ((rc = uploadVec(ctx, dirIdx, (const void **)&r.kDirIdx))) return rc;
+    if ((rc = uploadVec(ctx, has, (const void **)&r.kHas))) return rc;
+    if ((rc = uploadVec(ctx, hasPre, (const void **)&r.kHasPre))) return rc;
     if ((rc = uploadVec(ctx, dir, (const void **)&r.kDir))) return rc;
+    T1kDevBuf b;
+    if ((rc = t1k_ensure(ctx, b, nKeys * sizeof(uint32_t)))) return rc;
+    T1K_HIP(ctx, hipMemcpyAsync(b.p, dirIdx.get(), nKeys * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    T1K_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->refBufs.push_back(b);
+    r.kDirIdx = (const uint32_t *)b.p;
   }
   if (post.empty()) post.push_back(T1kPosting{0, 0});
   if ((rc = uploadVec(ctx, post, (const void **)&r.kPost))) return rc;
@@ -394,7 +423,7 @@ int t1k_extract_batch(t1k_ctx *ctx, uint32_t endsPerFragment, uint8_t *good, uin
   const uint32_t nEnds = ctx->reads.nReadEnds;
   if (nEnds % endsPerFragment) return t1k_fail(ctx, T1K_ERR_ARG, "t1k_extract_batch: odd number of read-ends in a paired batch");
   const uint32_t nFrag = nEnds / endsPerFragment;
-  if (stats) memset(stats, 0, 5 * sizeof(uint64_t));
+  if (stats) memset(stats, 0, 8 * sizeof(uint64_t));
   if (!nFrag) return T1K_OK;
   T1K_HIP(ctx, hipSetDevice(ctx->device));
   const size_t flagBytes = ((size_t)nFrag + 63) / 64 * 64;
@@ -418,7 +447,14 @@ int t1k_extract_batch(t1k_ctx *ctx, uint32_t endsPerFragment, uint8_t *good, uin
     fprintf(stderr, "\n");
   }
   if (ctl[0]) return t1k_fail(ctx, T1K_ERR_CAPACITY, "t1k_extract_batch: a read has more than 2048 hits on one reference sequence");
-  if (stats) { for (int i = 0; i < 5; ++i) stats[i] = ctl[1 + i]; stats[0] = nEnds; }
+  if (stats) {
+    for (int i = 0; i < 5; ++i) stats[i] = ctl[1 + i];
+    stats[0] = nEnds;
+    float msScreen = 0, msMain = 0;  // HIP events on the context's stream around each launch
+    (void)hipEventElapsedTime(&msScreen, ctx->ev[0], ctx->ev[1]);
+    (void)hipEventElapsedTime(&msMain, ctx->ev[1], ctx->ev[2]);
+    stats[5] = (uint64_t)(msScreen * 1e6); stats[6] = (uint64_t)(msMain * 1e6);
+  }
   return T1K_OK;
 }
 

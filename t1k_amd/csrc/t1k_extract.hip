@@ -526,7 +526,10 @@ void t1k_launch_extract(t1k_ctx *ctx, const T1kRefDev &ref, const T1kReadsDev &r
   const size_t ldsBytes = t1k_extract_lds_bytes((int)maxK);
   hipFuncSetAttribute((const void *)k_extract, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes);
   const unsigned gridS = (unsigned)std::min<uint64_t>(((uint64_t)reads.nReadEnds + 3) / 4, (uint64_t)nWg);
+  (void)hipEventRecord(ctx->ev[0], ctx->stream);
   hipLaunchKernelGGL(k_extract_screen, dim3(gridS), dim3(XWG), 0, ctx->stream, a);
+  (void)hipEventRecord(ctx->ev[1], ctx->stream);
   const unsigned grid = (unsigned)std::min<uint64_t>(((uint64_t)nFragments + XWG - 1) / XWG, (uint64_t)nWg);
   hipLaunchKernelGGL(k_extract, dim3(grid), dim3(XWG), ldsBytes, ctx->stream, a);
+  (void)hipEventRecord(ctx->ev[2], ctx->stream);
 }
