@@ -17,6 +17,9 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md
+# HBM traffic of one k_extract launch per read pair of the default workload (profiles/r01_extract_pmc.md: FETCH_SIZE 3.458e7 KB + WRITE_SIZE
+# 3.70e4 KB for 4 M pairs, as reported; FETCH_SIZE is uncalibrated for 4-byte-per-lane loads on gfx950)
+TRAFFIC_BYTES_PER_PAIR = (3.458e10 + 3.70e7) / 4e6
 READ_LEN = 150
 
 
@@ -105,7 +108,8 @@ def main():
         "ms_per_step": dt * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
         "config": {"workload": "%d synthetic 2x150 bp pairs (%.0f %% background) vs synthetic HLA-like rna reference (%d sequences), k=%d, hitLenRequired=%d, -s 0.8; "
                                "reads packed and resident in HBM" % (a.pairs, 100 * a.bg, len(rs), k, hit_len), "kept_pairs": int(good.sum()), "device_stats": st},
-        "roofline": {"bound": "hbm", "achieved": alg / t_dom / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / t_dom / 1e9 / HBM_PEAK_GBS, "traffic": None,
+        "roofline": {"bound": "hbm", "achieved": alg / t_dom / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / t_dom / 1e9 / HBM_PEAK_GBS,
+                     "traffic": TRAFFIC_BYTES_PER_PAIR * a.pairs if (dom == "k_extract" and a.bg == 0.97) else None,
                      "kernel": dom, "algorithmic_bytes_per_launch": alg, "kernel_ms": t_dom * 1e3,
                      "other": {"k_extract_screen" if dom == "k_extract" else "k_extract": {
                          "ms": (t_screen if dom == "k_extract" else t_main) * 1e3,
