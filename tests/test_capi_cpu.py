@@ -48,6 +48,8 @@ def test_no_gpu_fails_loudly(built, tmp_path):
         t1k_amd.Job(ref)
     r = subprocess.run([GENO, "-f", ref, "-u", ref], stderr=subprocess.PIPE, text=True)
     assert r.returncode != 0 and "GPU" in r.stderr
+    x = subprocess.run([os.path.join(util.ROOT, "t1k_amd", "bin", "fastq-extractor"), "-f", ref, "-u", ref, "-o", str(tmp_path / "x")], stderr=subprocess.PIPE, text=True)
+    assert x.returncode != 0 and "no HIP device" in x.stderr
 
 
 def test_executable_exit_codes(built, tmp_path):
