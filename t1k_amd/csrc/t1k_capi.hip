@@ -211,13 +211,14 @@ int t1k_ref_upload(t1k_ctx *ctx, const char *seqs, const uint64_t *offsets, cons
   if ((rc = uploadVec(ctx, kStart, (const void **)&r.kStart))) return rc;
   {
     // Per code, in two parallel sweeps over the bucket table (it has 4^k entries: 1 GB at the extractor's k = 14):
-    //   presence bitmaps (t1k_extract.hip): bit c of kHas = list c is not empty; bit p of kHasPre = some non-empty code starts with the k - 2 bases p
+    //   presence bitmaps (t1k_extract.hip): bit c of kHas = list c is not empty; bit p of kHasPre = some non-empty code starts with the k - 2 bases p;
+    //   bit c of kMulti = list c holds a sequence more than once
     //   chunk directory: where each multiple of T1K_SEED_CHUNK alleles begins inside a long posting list, so that the kernels find a
     //   chunk's slice of a list with one load instead of a bisection
     const uint32_t stride = (nAlleles + T1K_SEED_CHUNK - 1) / T1K_SEED_CHUNK + 1;
     const int kp = std::max(1, k - 2);
     const size_t nPre = (size_t)1 << (2 * kp);
-    std::vector<uint32_t> has((nKeys + 31) / 32, 0), hasPre((nPre + 31) / 32, 0);
+    std::vector<uint32_t> has((nKeys + 31) / 32, 0), multi((nKeys + 31) / 32, 0), hasPre((nPre + 31) / 32, 0);
     std::unique_ptr<uint32_t[]> dirIdx(new uint32_t[nKeys]);
     const unsigned T = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
     const size_t per = ((nKeys + T - 1) / T + 31) / 32 * 32;
@@ -236,6 +237,9 @@ int t1k_ref_upload(t1k_ctx *ctx, const char *seqs, const uint64_t *offsets, cons
         const size_t pcode = code & (nPre - 1);
         __atomic_fetch_or(&hasPre[pcode >> 5], 1u << (pcode & 31), __ATOMIC_RELAXED);
         if (ln > T1K_DIR_MINLEN) ++rows;
+        const T1kPosting *pl = &post[kStart[code]];
+        for (uint32_t i = 1; i < ln; ++i)
+          if (pl[i].allele == pl[i - 1].allele) { multi[code >> 5] |= 1u << (code & 31); break; }
       }
       rowBase[t + 1] = rows;
     });
@@ -260,6 +264,7 @@ int t1k_ref_upload(t1k_ctx *ctx, const char *seqs, const uint64_t *offsets, cons
     r.kDirStride = stride;
     if ((rc = uploadVec(ctx, has, (const void **)&r.kHas))) return rc;
     if ((rc = uploadVec(ctx, hasPre, (const void **)&r.kHasPre))) return rc;
+    if ((rc = uploadVec(ctx, multi, (const void **)&r.kMulti))) return rc;
     if ((rc = uploadVec(ctx, dir, (const void **)&r.kDir))) return rc;
     T1kDevBuf b;
     if ((rc = t1k_ensure(ctx, b, nKeys * sizeof(uint32_t)))) return rc;

@@ -68,6 +68,7 @@ struct T1kRefDev {
   const int32_t *sepPos;
   const uint32_t *kStart;       // [4^k + 1]
   const uint32_t *kHas;         // [4^k / 32] bit c = posting list of code c is not empty (32 MB at k = 14: lives in the Infinity Cache)
+  const uint32_t *kMulti;       // [4^k / 32] bit c = list c names some sequence more than once (the k-mer repeats inside a sequence)
   const uint32_t *kHasPre;      // [4^(k-2) / 32] bit p = some non-empty code has p as its first k - 2 bases (2 MB at k = 14: lives in L2)
   // chunk directory of the long posting lists: kDirIdx[code] = row or T1K_NO_DIR; row r, entry c = first posting of the list
   // whose allele is >= c * T1K_SEED_CHUNK (relative to the list start), c = 0 .. kDirStride - 1

@@ -3,8 +3,8 @@
 // of fragments resident in HBM.  All integer, HBM/LDS-bound work; no MFMA.
 //
 //   k_extract_screen  one wavefront per read-end: base counts (IsLowComplexity) and all k-mer look-ups of both strands in one burst of
-//               independent loads; a read-end with no non-empty posting list on either strand cannot have a hit (SeqSet.hpp:1925-1927)
-//               and is finished here -- that is nearly every read of a sequencing run.  No LDS, full occupancy.
+//               independent loads against presence bitmaps of the index; a read-end whose strands cannot collect hitLenRequired / k hits
+//               in one bucket (SeqSet.hpp:1925-1927, 1959) is finished here -- that is nearly every read of a sequencing run.  No LDS.
 //   k_extract   the remaining read-ends, one 256-thread workgroup per fragment (workgroups walk blocks of 256 fragments and compact
 //               the ones with work left); the mate is only looked at when the first end fails, as in the reference
 //               (FastqExtractor.cpp:459-464).  Per read-end:
@@ -40,7 +40,7 @@ struct ExtractArgs {
   double oneMinusSim;
   uint32_t nFragments, epf, maxK;
   uint8_t *good;
-  uint8_t *state;             // [read-end] written by k_extract_screen: 1 = some posting list of the read-end is non-empty
+  uint8_t *state;             // [read-end] written by k_extract_screen: 1 = the read-end may have a hit (k_extract decides)
   unsigned long long *err;
   unsigned long long *stats;  // [0] read-ends screened, [1] look-ups, [2] postings streamed, [3] read-ends reaching the histogram, [4] reaching the chain
 };
@@ -83,7 +83,11 @@ __global__ __launch_bounds__(XWG) void k_extract_screen(ExtractArgs P) {
       for (int o = 32; o > 0; o >>= 1) { cC += __shfl_xor(cC, o, 64); cG += __shfl_xor(cG, o, 64); cT += __shfl_xor(cT, o, 64); cN += __shfl_xor(cN, o, 64); }
       live = !lowComplexity(len, cC, cG, cT, cN);
     }
-    bool any = false;
+    // Per strand: how many positions have a non-empty list, and whether one of those lists names a sequence twice.  Without such a list
+    // a (strand, sequence) bucket holds at most one hit per position, and a bucket with fewer than ceil(hitLenRequired / k) hits fails
+    // SeqSet.hpp:1959 whichever bucket wins the vote: the read-end is finished here unless some strand can reach that many hits.
+    int nz0 = 0, nz1 = 0;
+    bool multi = false;
     if (live) {
       const int nk = len - k + 1;
       // two presence bitmaps: the first k - 2 bases of the k-mer (small enough to stay in L2) decide for most positions; only the ones it
@@ -103,11 +107,20 @@ __global__ __launch_bounds__(XWG) void k_extract_screen(ExtractArgs P) {
           }
         }
 #pragma unroll
-        for (int x = 0; x < 4; ++x)
-          if ((w[x] >> (code[x] & 31u)) & 1u) any |= ((P.ref.kHas[code[x] >> 5] >> (code[x] & 31u)) & 1u) != 0;
+        for (int x = 0; x < 4; ++x) {
+          bool hit = false;
+          if ((w[x] >> (code[x] & 31u)) & 1u) {
+            hit = ((P.ref.kHas[code[x] >> 5] >> (code[x] & 31u)) & 1u) != 0;
+            if (hit) multi |= ((P.ref.kMulti[code[x] >> 5] >> (code[x] & 31u)) & 1u) != 0;
+          }
+          const bool second = q0 + x * 64 + lane >= nk;
+          nz0 += __popcll(__ballot(hit && !second));
+          nz1 += __popcll(__ballot(hit && second));
+        }
       }
     }
-    const bool anyWave = __ballot(any) != 0ull;
+    const int needHits = (P.hitLenRequired + k - 1) / k;
+    const bool anyWave = __ballot(multi) != 0ull ? (nz0 + nz1 > 0) : (nz0 >= needHits || nz1 >= needHits);
     if (lane == 0) P.state[re] = (live && anyWave) ? 1 : 0;
   }
 }
