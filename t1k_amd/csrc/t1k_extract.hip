@@ -76,12 +76,13 @@ __global__ __launch_bounds__(XWG) void k_extract_screen(ExtractArgs P) {
     const int len = P.reads.len[re];
     const uint64_t *rbase = P.reads.bases + (uint64_t)re * 2 * S;
     const uint64_t *rnm = P.reads.nmask + (uint64_t)re * 2 * S;
-    bool live = len >= k;  // HasHitInSet 1919-1920
+    bool live = len >= k, hasN = false;  // HasHitInSet 1919-1920
     if (live) {
       int cC = 0, cG = 0, cT = 0, cN = 0;
       if (lane < (len + 31) / 32) baseCounts(rbase[lane], rnm[lane], cC, cG, cT, cN);
       for (int o = 32; o > 0; o >>= 1) { cC += __shfl_xor(cC, o, 64); cG += __shfl_xor(cG, o, 64); cT += __shfl_xor(cT, o, 64); cN += __shfl_xor(cN, o, 64); }
       live = !lowComplexity(len, cC, cG, cT, cN);
+      hasN = cN > 0;
     }
     // Per strand: how many positions have a non-empty list, and whether one of those lists names a sequence twice.  Without such a list
     // a (strand, sequence) bucket holds at most one hit per position, and a bucket with fewer than ceil(hitLenRequired / k) hits fails
@@ -91,31 +92,40 @@ __global__ __launch_bounds__(XWG) void k_extract_screen(ExtractArgs P) {
     if (live) {
       const int nk = len - k + 1;
       // two presence bitmaps: the first k - 2 bases of the k-mer (small enough to stay in L2) decide for most positions; only the ones it
-      // lets through ask the full bitmap
+      // lets through ask the full bitmap.  A lane owns `per` consecutive positions of each strand and cuts their codes out of two packed
+      // words it loads once (per + k - 1 <= 32 positions).
       const uint32_t pmask = k > 2 ? (1u << (2 * (k - 2))) - 1 : kmask;
-      for (int q0 = 0; q0 < 2 * nk; q0 += 64 * 4) {  // four independent look-ups per lane in flight
-        uint32_t w[4], code[4];
+      const int per = (nk + 63) / 64;  // <= 5 for reads up to 320 bp
+      const int p0 = lane * per;
+      uint32_t code[2][5], w[2][5];
 #pragma unroll
-        for (int x = 0; x < 4; ++x) {
-          const int q = q0 + x * 64 + lane;
-          w[x] = 0; code[x] = 0;
-          if (q < 2 * nk) {
-            const int pass = q >= nk ? 1 : 0, p = q - pass * nk;
-            code[x] = (uint32_t)t1k_get32(rbase + pass * S, p) & kmask;
-            const bool valid = ((uint32_t)t1k_get32(rnm + pass * S, p) & kmask) == 0;
-            if (valid) w[x] = P.ref.kHasPre[(code[x] & pmask) >> 5];
-          }
+      for (int pass = 0; pass < 2; ++pass) {
+        uint64_t bits = 0, nbits = 0;
+        if (p0 < nk) {
+          bits = t1k_get32(rbase + pass * S, p0);
+          if (hasN) nbits = t1k_get32(rnm + pass * S, p0);
         }
 #pragma unroll
-        for (int x = 0; x < 4; ++x) {
+        for (int j = 0; j < 5; ++j) {
+          code[pass][j] = (uint32_t)(bits >> (2 * j)) & kmask;
+          w[pass][j] = 0;
+          const bool valid = j < per && p0 + j < nk && ((uint32_t)(nbits >> (2 * j)) & kmask) == 0;
+          if (valid) w[pass][j] = P.ref.kHasPre[(code[pass][j] & pmask) >> 5];
+        }
+      }
+#pragma unroll
+      for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+          if (j >= per) break;  // uniform
           bool hit = false;
-          if ((w[x] >> (code[x] & 31u)) & 1u) {
-            hit = ((P.ref.kHas[code[x] >> 5] >> (code[x] & 31u)) & 1u) != 0;
-            if (hit) multi |= ((P.ref.kMulti[code[x] >> 5] >> (code[x] & 31u)) & 1u) != 0;
+          const uint32_t c = code[pass][j];
+          if ((w[pass][j] >> (c & 31u)) & 1u) {
+            hit = ((P.ref.kHas[c >> 5] >> (c & 31u)) & 1u) != 0;
+            if (hit) multi |= ((P.ref.kMulti[c >> 5] >> (c & 31u)) & 1u) != 0;
           }
-          const bool second = q0 + x * 64 + lane >= nk;
-          nz0 += __popcll(__ballot(hit && !second));
-          nz1 += __popcll(__ballot(hit && second));
+          const int n = __popcll(__ballot(hit));
+          if (pass == 0) nz0 += n; else nz1 += n;
         }
       }
     }
