@@ -275,6 +275,11 @@ int t1k_ref_upload(t1k_ctx *ctx, const char *seqs, const uint64_t *offsets, cons
   }
   if (post.empty()) post.push_back(T1kPosting{0, 0});
   if ((rc = uploadVec(ctx, post, (const void **)&r.kPost))) return rc;
+  {
+    std::vector<uint32_t> postAllele(post.size());
+    for (size_t i = 0; i < post.size(); ++i) postAllele[i] = post[i].allele;
+    if ((rc = uploadVec(ctx, postAllele, (const void **)&r.kPostAllele))) return rc;
+  }
   T1kDevBuf cov;
   r.covStride = total + 2;
   if ((rc = t1k_ensure(ctx, cov, 2 * r.covStride * sizeof(int32_t)))) return rc;

@@ -76,6 +76,7 @@ struct T1kRefDev {
   const uint32_t *kDir;         // [rows][kDirStride]
   uint32_t kDirStride;
   const T1kPosting *kPost;
+  const uint32_t *kPostAllele;  // the allele column of kPost on its own: the extractor's vote streams only this
   // per-base coverage = prefix sum of covDiff (+w where a covered run starts, -w behind its end) minus covHole (w at a position
   // inside an ungapped alignment's span that is not covered: a mismatch or an N).  covHole = covDiff + covStride.
   int32_t *covDiff;             // [2][covStride]

@@ -46,11 +46,11 @@ struct ExtractArgs {
 };
 
 // slice [lo, hi) of a posting list (sorted by sequence) holding the sequences [a0, a1)
-__device__ __forceinline__ uint32_t listLowerBound(const T1kPosting *p, uint32_t n, uint32_t allele) {
+__device__ __forceinline__ uint32_t listLowerBound(const uint32_t *p, uint32_t n, uint32_t allele) {
   uint32_t lo = 0, hi = n;
   while (lo < hi) {
     const uint32_t mid = (lo + hi) >> 1;
-    if (p[mid].allele < allele) lo = mid + 1; else hi = mid;
+    if (p[mid] < allele) lo = mid + 1; else hi = mid;
   }
   return lo;
 }
@@ -321,7 +321,7 @@ __global__ __launch_bounds__(XWG) void k_extract(ExtractArgs P) {
             if (u < uCnt) {
               const int q = usedQ[uBeg + u];
               const uint32_t st = ukStart[q], ln = ukLen[q];
-              mn = min(mn, P.ref.kPost[st].allele); mx = max(mx, P.ref.kPost[st + ln - 1].allele); tsum += ln;
+              mn = min(mn, P.ref.kPostAllele[st]); mx = max(mx, P.ref.kPostAllele[st + ln - 1]); tsum += ln;
             }
           }
           for (int o = 32; o > 0; o >>= 1) { mn = min(mn, (uint32_t)__shfl_xor(mn, o, 64)); mx = max(mx, (uint32_t)__shfl_xor(mx, o, 64)); tsum += __shfl_xor(tsum, o, 64); }
@@ -352,8 +352,8 @@ __global__ __launch_bounds__(XWG) void k_extract(ExtractArgs P) {
                   lo = row[r0 / T1K_SEED_CHUNK];
                   hi = r1 >= A ? ln : row[r1 / T1K_SEED_CHUNK];
                 } else {
-                  lo = listLowerBound(P.ref.kPost + st, ln, r0);
-                  hi = r1 >= A ? ln : listLowerBound(P.ref.kPost + st, ln, r1);
+                  lo = listLowerBound(P.ref.kPostAllele + st, ln, r0);
+                  hi = r1 >= A ? ln : listLowerBound(P.ref.kPostAllele + st, ln, r1);
                 }
               }
               sliceLo[u] = lo;
@@ -372,20 +372,20 @@ __global__ __launch_bounds__(XWG) void k_extract(ExtractArgs P) {
           __syncthreads();
           {
             uint32_t cur = 0;  // list holding flattened posting x: pre[cur] <= x < pre[cur + 1]; x only grows, so the cursor only advances
-            for (uint32_t x0 = tid; x0 < total; x0 += 4 * XWG) {
-              uint32_t al[4];
+            for (uint32_t x0 = tid; x0 < total; x0 += 8 * XWG) {
+              uint32_t al[8];
 #pragma unroll
-              for (int v = 0; v < 4; ++v) {  // four independent loads in flight
+              for (int v = 0; v < 8; ++v) {  // eight independent loads in flight
                 const uint32_t x = x0 + v * XWG;
                 al[v] = 0xFFFFFFFFu;
                 if (x < total) {
                   while (pre[cur + 1] <= x) ++cur;
                   const int q = usedQ[uBeg + cur];
-                  al[v] = P.ref.kPost[ukStart[q] + sliceLo[cur] + (x - pre[cur])].allele;
+                  al[v] = P.ref.kPostAllele[ukStart[q] + sliceLo[cur] + (x - pre[cur])];
                 }
               }
 #pragma unroll
-              for (int v = 0; v < 4; ++v)
+              for (int v = 0; v < 8; ++v)
                 if (al[v] != 0xFFFFFFFFu) atomicAdd(&hist[al[v] - r0], 1u);
             }
           }
@@ -419,11 +419,11 @@ __global__ __launch_bounds__(XWG) void k_extract(ExtractArgs P) {
           const uint32_t u = 2 * tid + x;
           if (u < uCnt) {
             const int q = usedQ[uBeg + u];
-            const T1kPosting *pl = P.ref.kPost + ukStart[q];
+            const uint32_t *pl = P.ref.kPostAllele + ukStart[q];
             const uint32_t ln = ukLen[q];
             const uint32_t lo = listLowerBound(pl, ln, bestAllele);
             uint32_t hi = lo;
-            while (hi < ln && pl[hi].allele == bestAllele) ++hi;
+            while (hi < ln && pl[hi] == bestAllele) ++hi;
             myLo[x] = lo; myLen[x] = hi - lo;
           }
         }
