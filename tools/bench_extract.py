@@ -17,10 +17,9 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md
-# HBM traffic of one k_extract launch per read pair of the default workload (profiles/r01_extract_pmc.md: FETCH_SIZE 3.458e7 KB + WRITE_SIZE
-# 3.70e4 KB for 4 M pairs, as reported; FETCH_SIZE is uncalibrated for 4-byte-per-lane loads on gfx950)
-TRAFFIC_BYTES_PER_PAIR = (3.458e10 + 3.70e7) / 4e6
-READ_LEN = 150
+# HBM traffic of one launch per read pair of the default workload (profiles/r01_extract_pmc.md: FETCH_SIZE + WRITE_SIZE for 4 M pairs, as
+# reported; on gfx950 FETCH_SIZE is calibrated only for wide coalesced loads, these kernels issue 4-byte-per-lane loads)
+TRAFFIC_BYTES_PER_PAIR = {"k_extract_screen": (4.726e9 + 4.977e8) / 4e6, "k_extract": (1.178e10 + 1.163e7) / 4e6}
 
 
 def records(path, n=None):
@@ -95,12 +94,12 @@ def main():
     # ALGORITHMIC bytes per launch:
     #   k_extract_screen  every read-end: its packed words (bases + N mask, both strands: 4 * ceil(l/32) * 8 B) + one 4-byte presence word per
     #                     k-mer position of both strands
-    #   k_extract         the read-ends the screen let through: the packed words again + one 8-byte bucket header per k-mer position + 8 B per
-    #                     posting of the used lists (counted once)
+    #   k_extract         the read-ends the screen let through: the packed words again + one 8-byte bucket header per k-mer position + 4 B per
+    #                     posting of the used lists (the sequence index, which is all the vote reads; counted once)
     ends, words, npos = st["read_ends"], (READ_LEN + 31) // 32, 2 * (READ_LEN - k + 1)
     heavy = st["lookups"] // npos  # read-ends that reached k_extract's look-ups
     alg_screen = ends * (4 * words * 8 + npos * 4)
-    alg_main = heavy * (4 * words * 8 + npos * 8) + st["postings"] * 8
+    alg_main = heavy * (4 * words * 8 + npos * 8) + st["postings"] * 4
     t_screen, t_main = st["screen_ns"] * 1e-9, st["main_ns"] * 1e-9
     dom, alg, t_dom = ("k_extract", alg_main, t_main) if t_main >= t_screen else ("k_extract_screen", alg_screen, t_screen)
     out = {
@@ -109,7 +108,7 @@ def main():
         "config": {"workload": "%d synthetic 2x150 bp pairs (%.0f %% background) vs synthetic HLA-like rna reference (%d sequences), k=%d, hitLenRequired=%d, -s 0.8; "
                                "reads packed and resident in HBM" % (a.pairs, 100 * a.bg, len(rs), k, hit_len), "kept_pairs": int(good.sum()), "device_stats": st},
         "roofline": {"bound": "hbm", "achieved": alg / t_dom / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / t_dom / 1e9 / HBM_PEAK_GBS,
-                     "traffic": TRAFFIC_BYTES_PER_PAIR * a.pairs if (dom == "k_extract" and a.bg == 0.97) else None,
+                     "traffic": TRAFFIC_BYTES_PER_PAIR[dom] * a.pairs if a.bg == 0.97 else None,
                      "kernel": dom, "algorithmic_bytes_per_launch": alg, "kernel_ms": t_dom * 1e3,
                      "other": {"k_extract_screen" if dom == "k_extract" else "k_extract": {
                          "ms": (t_screen if dom == "k_extract" else t_main) * 1e3,
