@@ -184,7 +184,7 @@ class Context:
         good = np.zeros(self.n_read_ends // ends_per_fragment, dtype=np.uint8)
         st = np.zeros(8, dtype=np.uint64)
         self._check(lib().t1k_extract_batch(self.h, ends_per_fragment, _ptr(good), _ptr(st)), "t1k_extract_batch")
-        return good, dict(zip(("read_ends", "lookups", "postings", "read_ends_with_hits", "read_ends_chained", "screen_ns", "main_ns"), (int(x) for x in st)))
+        return good, dict(zip(("read_ends", "lookups", "postings", "read_ends_with_hits", "read_ends_chained", "screen_ns", "main_ns", "big_shape"), (int(x) for x in st)))
 
     def overlaps(self):
         n = self.n_read_ends

@@ -448,22 +448,32 @@ int t1k_extract_batch(t1k_ctx *ctx, uint32_t endsPerFragment, uint8_t *good, uin
   t1k_launch_extract(ctx, ctx->ref, ctx->reads, ctx->prm.kmer_length, ctx->prm.radius, ctx->prm.hit_len_required, 1 - ctx->prm.ref_seq_similarity, nFrag,
                      endsPerFragment, maxK, dGood, dState, dCtl, dCtl + 1, ctx->prm.workgroups * 4);
   unsigned long long ctl[16];
-  T1K_HIP(ctx, hipMemcpyAsync(good, dGood, nFrag, hipMemcpyDeviceToHost, ctx->stream));
   T1K_HIP(ctx, hipMemcpyAsync(ctl, dCtl, 128, hipMemcpyDeviceToHost, ctx->stream));
+  T1K_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  bool bigShape = false;
+  if (ctl[0] || getenv("T1K_EXTRACT_FORCE_BIG")) {
+    bigShape = true;
+    // some (strand, sequence) bucket holds more hits than the production kernel keeps in LDS: the whole batch again in the large shape
+    T1K_HIP(ctx, hipMemsetAsync(dCtl, 0, 128, ctx->stream));
+    t1k_launch_extract_big(ctx, ctx->ref, ctx->reads, ctx->prm.kmer_length, ctx->prm.radius, ctx->prm.hit_len_required, 1 - ctx->prm.ref_seq_similarity, nFrag,
+                           endsPerFragment, maxK, dGood, dState, dCtl, dCtl + 1, ctx->prm.workgroups * 4);
+    T1K_HIP(ctx, hipMemcpyAsync(ctl, dCtl, 128, hipMemcpyDeviceToHost, ctx->stream));
+  }
+  T1K_HIP(ctx, hipMemcpyAsync(good, dGood, nFrag, hipMemcpyDeviceToHost, ctx->stream));
   T1K_HIP(ctx, hipStreamSynchronize(ctx->stream));
   if (getenv("T1K_XPROF")) {  // phase clocks of k_extract (builds with -DT1K_XPROF only): list, look-ups, replay, vote, gather, diagonal test, chain
     fprintf(stderr, "[t1k xprof]");
     for (int i = 0; i < 7; ++i) fprintf(stderr, " %.3g", (double)ctl[8 + i]);
     fprintf(stderr, "\n");
   }
-  if (ctl[0]) return t1k_fail(ctx, T1K_ERR_CAPACITY, "t1k_extract_batch: a read has more than 2048 hits on one reference sequence");
+  if (ctl[0]) return t1k_fail(ctx, T1K_ERR_CAPACITY, "t1k_extract_batch: a read has more than 8192 hits on one reference sequence");
   if (stats) {
     for (int i = 0; i < 5; ++i) stats[i] = ctl[1 + i];
     stats[0] = nEnds;
     float msScreen = 0, msMain = 0;  // HIP events on the context's stream around each launch
     (void)hipEventElapsedTime(&msScreen, ctx->ev[0], ctx->ev[1]);
     (void)hipEventElapsedTime(&msMain, ctx->ev[1], ctx->ev[2]);
-    stats[5] = (uint64_t)(msScreen * 1e6); stats[6] = (uint64_t)(msMain * 1e6);
+    stats[5] = (uint64_t)(msScreen * 1e6); stats[6] = (uint64_t)(msMain * 1e6); stats[7] = bigShape ? 1 : 0;
   }
   return T1K_OK;
 }

@@ -24,8 +24,11 @@
 #include "t1k_group.h"
 
 #define XWG 256
-#define X_RANGE 8192   // sequences per histogram pass (u32 counters: 32 KB of LDS)
-#define X_HCAP 2048    // hits of one (strand, sequence) bucket
+// k_extract<X_RANGE>: sequences per histogram pass (u32 counters in LDS); the same words later hold the bucket's hits and the three
+// work arrays of the chain, so a bucket may have X_RANGE / 4 hits.  8192 (32 KB, 2048 hits) is the production shape; a batch in which
+// some bucket is larger is run again with 32768 (128 KB, one workgroup per CU, 8192 hits).
+#define X_RANGE_SMALL 8192
+#define X_RANGE_BIG 32768
 enum { XERR_HITCAP = 1 };
 #ifdef T1K_XPROF
 #define XP(i) { const uint64_t tn_ = __builtin_amdgcn_s_memtime(); xp_[i] += tn_ - xl_; xl_ = tn_; }
@@ -135,7 +138,9 @@ __global__ __launch_bounds__(XWG) void k_extract_screen(ExtractArgs P) {
   }
 }
 
+template <int X_RANGE>
 __global__ __launch_bounds__(XWG) void k_extract(ExtractArgs P) {
+  constexpr int X_HCAP = X_RANGE / 4;
   extern __shared__ uint32_t lds[];
   const int maxK = (int)P.maxK;
   uint32_t *ukCode = lds;                        // [maxK] code | valid << 31, both strands
@@ -539,20 +544,37 @@ __global__ __launch_bounds__(XWG) void k_extract(ExtractArgs P) {
   }
 }
 
-size_t t1k_extract_lds_bytes(int maxK) { return ((size_t)maxK * 6 + 3) * 4 + ((size_t)maxK + 1) / 2 * 2 * 2 + (size_t)X_RANGE * 4 + 16; }
+size_t t1k_extract_lds_bytes(int maxK, int range) { return ((size_t)maxK * 6 + 3) * 4 + ((size_t)maxK + 1) / 2 * 2 * 2 + (size_t)range * 4 + 16; }
 
-void t1k_launch_extract(t1k_ctx *ctx, const T1kRefDev &ref, const T1kReadsDev &reads, int k, int radius, int hitLenRequired, double oneMinusSim, uint32_t nFragments,
-                        uint32_t epf, uint32_t maxK, uint8_t *good, uint8_t *state, unsigned long long *err, unsigned long long *stats, int nWg) {
+static ExtractArgs extractArgs(const T1kRefDev &ref, const T1kReadsDev &reads, int k, int radius, int hitLenRequired, double oneMinusSim, uint32_t nFragments,
+                               uint32_t epf, uint32_t maxK, uint8_t *good, uint8_t *state, unsigned long long *err, unsigned long long *stats) {
   ExtractArgs a{};
   a.ref = ref; a.reads = reads; a.k = k; a.radius = radius; a.hitLenRequired = hitLenRequired; a.oneMinusSim = oneMinusSim;
   a.nFragments = nFragments; a.epf = epf; a.maxK = maxK; a.good = good; a.state = state; a.err = err; a.stats = stats;
-  const size_t ldsBytes = t1k_extract_lds_bytes((int)maxK);
-  hipFuncSetAttribute((const void *)k_extract, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes);
+  return a;
+}
+
+void t1k_launch_extract(t1k_ctx *ctx, const T1kRefDev &ref, const T1kReadsDev &reads, int k, int radius, int hitLenRequired, double oneMinusSim, uint32_t nFragments,
+                        uint32_t epf, uint32_t maxK, uint8_t *good, uint8_t *state, unsigned long long *err, unsigned long long *stats, int nWg) {
+  const ExtractArgs a = extractArgs(ref, reads, k, radius, hitLenRequired, oneMinusSim, nFragments, epf, maxK, good, state, err, stats);
+  const size_t ldsBytes = t1k_extract_lds_bytes((int)maxK, X_RANGE_SMALL);
+  hipFuncSetAttribute((const void *)k_extract<X_RANGE_SMALL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes);
   const unsigned gridS = (unsigned)std::min<uint64_t>(((uint64_t)reads.nReadEnds + 3) / 4, (uint64_t)nWg);
   (void)hipEventRecord(ctx->ev[0], ctx->stream);
   hipLaunchKernelGGL(k_extract_screen, dim3(gridS), dim3(XWG), 0, ctx->stream, a);
   (void)hipEventRecord(ctx->ev[1], ctx->stream);
   const unsigned grid = (unsigned)std::min<uint64_t>(((uint64_t)nFragments + XWG - 1) / XWG, (uint64_t)nWg);
-  hipLaunchKernelGGL(k_extract, dim3(grid), dim3(XWG), ldsBytes, ctx->stream, a);
+  hipLaunchKernelGGL(k_extract<X_RANGE_SMALL>, dim3(grid), dim3(XWG), ldsBytes, ctx->stream, a);
+  (void)hipEventRecord(ctx->ev[2], ctx->stream);
+}
+
+// second attempt of a batch in which a bucket overflowed the production shape (the screen's verdicts are still in `state`)
+void t1k_launch_extract_big(t1k_ctx *ctx, const T1kRefDev &ref, const T1kReadsDev &reads, int k, int radius, int hitLenRequired, double oneMinusSim,
+                            uint32_t nFragments, uint32_t epf, uint32_t maxK, uint8_t *good, uint8_t *state, unsigned long long *err, unsigned long long *stats, int nWg) {
+  const ExtractArgs a = extractArgs(ref, reads, k, radius, hitLenRequired, oneMinusSim, nFragments, epf, maxK, good, state, err, stats);
+  const size_t ldsBytes = t1k_extract_lds_bytes((int)maxK, X_RANGE_BIG);
+  hipFuncSetAttribute((const void *)k_extract<X_RANGE_BIG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes);
+  const unsigned grid = (unsigned)std::min<uint64_t>(((uint64_t)nFragments + XWG - 1) / XWG, (uint64_t)nWg);
+  hipLaunchKernelGGL(k_extract<X_RANGE_BIG>, dim3(grid), dim3(XWG), ldsBytes, ctx->stream, a);
   (void)hipEventRecord(ctx->ev[2], ctx->stream);
 }

@@ -128,3 +128,30 @@ def test_full_size_properties(built, tmp_path):
     for i in rng.sample(range(len(r1)), 600):
         assert (orc.good(r1[i][1]) or orc.good(r2[i][1])) == (r1[i][0][:-2] in kept)
     orc.close()
+
+
+def test_large_bucket_takes_the_big_shape(built, tmp_path):
+    """a trinucleotide repeat puts thousands of hits into one (strand, sequence) bucket: more than the production LDS shape holds (2048),
+    so the batch is run again in the large shape (8192); results still equal the oracle's.  Beyond that the call fails loudly."""
+    rng = random.Random(11)
+    rnd = lambda n: "".join(rng.choice("ACGT") for _ in range(n))
+    ref = [rnd(400) + "CAG" * 300 + rnd(400), rnd(1500), rnd(300) + "CAG" * 40 + rnd(300)]
+    fa = tmp_path / "rep.fa"
+    fa.write_text("".join(">s%d\n%s\n" % (i, s) for i, s in enumerate(ref)))
+    reads = ["CAG" * 50, "AGC" * 50, "CTG" * 50, ref[0][330:480], ref[0][1250:1400], ref[2][280:430], rnd(150), ("CAG" * 50)[:100] + rnd(50)]
+    for k, hl in ((12, 30), (9, 27)):
+        orc = util.ExtractOracle(str(fa), k=k, hit_len_required=hl)
+        want = np.array([1 if orc.good(r) else 0 for r in reads], dtype=np.uint8)
+        orc.close()
+        good, st = device_flags(ref, reads, 1, k, hl, 0.8)
+        assert np.array_equal(good, want), (k, good, want)
+        assert want[0] == 1 and st["big_shape"] == 1
+    os.environ["T1K_EXTRACT_FORCE_BIG"] = "1"
+    try:
+        good2, _ = device_flags(ref, reads, 1, 9, 27, 0.8)
+    finally:
+        del os.environ["T1K_EXTRACT_FORCE_BIG"]
+    assert np.array_equal(good2, want)
+    huge = [rnd(200) + "CAG" * 1500 + rnd(200)]
+    with pytest.raises(t1k_amd.T1kError, match="8192 hits"):
+        device_flags(huge, ["CAG" * 50], 1, 9, 27, 0.8)
