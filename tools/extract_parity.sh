@@ -34,6 +34,12 @@ run rna150_single -f $W/rna.fa -u $W/b_1.fq -s 0.97 --read1Start 5 --read1End 12
 run dna250 -f $W/dna.fa -1 $W/c_1.fq -2 $W/c_2.fq -t 4
 run dna250_single -f $W/dna.fa -u $W/c_2.fq
 run fasta75 -f $W/rna.fa -1 $W/d_1.fa -2 $W/d_2.fa -t 2
+gzip -c $W/b_1.fq > $W/bz_1.fq.gz; gzip -c $W/b_2.fq > $W/bz_2.fq.gz
+run gz -f $W/rna.fa -1 $W/bz_1.fq.gz -2 $W/bz_2.fq.gz -t 4
+paste -d '\n' <(paste - - - - < $W/a_1.fq) <(paste - - - - < $W/a_2.fq) | tr '\t' '\n' > $W/il.fq
+run interleaved -f $W/rna.fa -i $W/il.fq
+run interleaved_t4 -f $W/rna.fa -i $W/il.fq -t 4
+run two_files -f $W/rna.fa -1 $W/a_1.fq -1 $W/b_1.fq -2 $W/a_2.fq -2 $W/b_2.fq -t 2
 run cross -f $W/dna.fa -1 $W/b_1.fq -2 $W/b_2.fq -t 4
 if [ $fail = 0 ]; then echo "extract parity: all identical"; fi
 exit $fail
