@@ -52,6 +52,9 @@ typedef struct {
   int64_t cand_cap;             /* candidate records per batch */
   int64_t ovl_cap;              /* overlap records per batch */
   int64_t row_cap;              /* fragment-row entries per batch */
+  int32_t n_base_code;          /* the two bits a non-ACGT base contributes to a k-mer code (the code of a window holding one still decides
+                                   whether its neighbour repeats the previous k-mer): 3 in the genotyper (nucToNum, Genotyper.cpp:37-40:
+                                   -1 & 3), 0 in fastq-extractor (FastqExtractor.cpp:51-54: 'N' -> 0).  t1k_params_default sets 3. */
 } t1k_params;
 
 void t1k_params_default(t1k_params *p);

@@ -338,7 +338,7 @@ void Oracle::buildIndex() {
     int invalid = -1;
     for (int i = 0; i < len; ++i) {
       if (invalid != -1) ++invalid;
-      code = ((code << 2) & mask) | (uint64_t)(baseCode(s[i]) & 3);
+      code = ((code << 2) & mask) | (uint64_t)(s[i] == 'N' ? prm.nBaseCode : (baseCode(s[i]) & 3));
       if (s[i] == 'N') invalid = 0;
       if (invalid >= k) invalid = -1;
       if (i < k - 1) continue;
@@ -370,7 +370,7 @@ void Oracle::seedHits(const std::string &read, std::vector<int> &strand, std::ve
     int invalid = -1, skipCnt = 0;
     for (int i = 0; i < len; ++i) {
       if (invalid != -1) ++invalid;
-      code = ((code << 2) & mask) | (uint64_t)(baseCode(s[i]) & 3);
+      code = ((code << 2) & mask) | (uint64_t)(s[i] == 'N' ? prm.nBaseCode : (baseCode(s[i]) & 3));
       if (s[i] == 'N') invalid = 0;
       if (invalid >= k) invalid = -1;
       if (i < k - 1) continue;

@@ -67,6 +67,7 @@ struct Params {
   int alleleDigitUnits = -1;
   char alleleDelimiter = 0;
   double minSquaremAlpha = 0;
+  int nBaseCode = 3;  // bits an N contributes to a k-mer code: nucToNum['N'] & 3 = 3 in Genotyper.cpp:37-40, 0 in FastqExtractor.cpp:51-54
 };
 
 struct Stats {  // algorithmic-traffic counters for SURVEY 8d's roofline formula

@@ -14,6 +14,7 @@
 namespace t1k_oracle {
 
 int Oracle::loadReferenceFa(const std::string &fasta) {
+  prm.nBaseCode = 0;  // this program's nucToNum maps 'N' to 0 (FastqExtractor.cpp:51-54)
   std::vector<SeqRecord> recs;
   if (!readAllRecords(fasta, recs)) return -1;
   for (auto &r : recs) {

@@ -286,6 +286,7 @@ extern "C" int t1k_extractor_main(int argc, char **argv) {
   prm.kmer_length = kmerLength;
   prm.hit_len_required = hitLenRequired;
   prm.ref_seq_similarity = similarity;
+  prm.n_base_code = 0;  // this program's nucToNum maps 'N' to 0 (FastqExtractor.cpp:51-54), the genotyper's to -1
   t1k_ctx *ctx = nullptr;
   if (t1k_ctx_create(0, &prm, &ctx) != T1K_OK) { fprintf(stderr, "fastq-extractor: cannot create the device context (k = %d)\n", kmerLength); return EXIT_FAILURE; }
   {

@@ -23,7 +23,8 @@ enum { ERR_HITCAP = 1, ERR_STAGECAP = 2, ERR_CANDCAP = 4, ERR_BIGGROUP = 8, ERR_
 // ------------------------------------------------------------------------------------------------------------------
 // pack
 // ------------------------------------------------------------------------------------------------------------------
-__global__ void k_pack_reads(const char *ascii, const uint64_t *offs, uint32_t n, int S, uint64_t *bases, uint64_t *nmask, uint16_t *lens) {
+// nCode: the base bits stored under an N (t1k_params::n_base_code); every consumer of the bases other than the k-mer codes masks N positions out
+__global__ void k_pack_reads(const char *ascii, const uint64_t *offs, uint32_t n, int S, uint64_t *bases, uint64_t *nmask, uint16_t *lens, int nCode) {
   uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   uint64_t total = (uint64_t)n * S;
   if (gid >= total) return;
@@ -38,10 +39,10 @@ __global__ void k_pack_reads(const char *ascii, const uint64_t *offs, uint32_t n
     if (i >= len) break;
     char c = ascii[o + i];
     int code = c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : 4;
-    if (code == 4) fn |= 1ull << (2 * q); else fb |= (uint64_t)code << (2 * q);
+    if (code == 4) { fn |= 1ull << (2 * q); fb |= (uint64_t)nCode << (2 * q); } else fb |= (uint64_t)code << (2 * q);
     char d = ascii[o + len - 1 - i];
     int dc = d == 'A' ? 3 : d == 'C' ? 2 : d == 'G' ? 1 : d == 'T' ? 0 : 4;
-    if (dc == 4) rn |= 1ull << (2 * q); else rb |= (uint64_t)dc << (2 * q);
+    if (dc == 4) { rn |= 1ull << (2 * q); rb |= (uint64_t)nCode << (2 * q); } else rb |= (uint64_t)dc << (2 * q);
   }
   uint64_t base = (uint64_t)re * 2 * S;
   bases[base + w] = fb; nmask[base + w] = fn;
@@ -875,10 +876,10 @@ __global__ __launch_bounds__(WG) void k_coverage_scan(T1kRefDev ref, int32_t *ou
 // ------------------------------------------------------------------------------------------------------------------
 // host launchers
 // ------------------------------------------------------------------------------------------------------------------
-int t1k_launch_pack(t1k_ctx *ctx, const char *dAscii, const uint64_t *dOffs, uint32_t n, int S, uint64_t *bases, uint64_t *nmask, uint16_t *lens) {
+int t1k_launch_pack(t1k_ctx *ctx, const char *dAscii, const uint64_t *dOffs, uint32_t n, int S, uint64_t *bases, uint64_t *nmask, uint16_t *lens, int nCode) {
   uint64_t total = (uint64_t)n * S;
   if (!total) return 0;
-  hipLaunchKernelGGL(k_pack_reads, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, dAscii, dOffs, n, S, bases, nmask, lens);
+  hipLaunchKernelGGL(k_pack_reads, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, dAscii, dOffs, n, S, bases, nmask, lens, nCode);
   return 0;
 }
 

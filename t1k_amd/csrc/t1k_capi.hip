@@ -55,6 +55,7 @@ void t1k_params_default(t1k_params *p) {
   p->max_assign_cnt = 2000;
   p->max_read_len = 320;
   p->workgroups = 2048;
+  p->n_base_code = 3;
   p->hit_cap = 0;
   p->group_cap = 160ll << 20;
   p->cand_cap = 128ll << 20;
@@ -132,6 +133,7 @@ int t1k_ref_upload(t1k_ctx *ctx, const char *seqs, const uint64_t *offsets, cons
   for (auto &b : ctx->refBufs) freeBuf(b);
   ctx->refBufs.clear();
   const int k = ctx->prm.kmer_length;
+  const uint32_t nCode = (uint32_t)ctx->prm.n_base_code & 3u;
   std::vector<uint64_t> alleleOff(nAlleles);
   std::vector<uint32_t> alleleLen(nAlleles);
   uint64_t total = 0;
@@ -169,7 +171,7 @@ int t1k_ref_upload(t1k_ctx *ctx, const char *seqs, const uint64_t *offsets, cons
       else bases[pos >> 5] |= (uint64_t)c << ((pos & 31) * 2);
       if (exon && exon[offsets[a] + i]) exonm[pos >> 5] |= 1ull << ((pos & 31) * 2);
       if (invalid != -1) ++invalid;
-      code = (code >> 2) | ((uint32_t)(c == 4 ? 3 : c) << (2 * (k - 1)));
+      code = (code >> 2) | ((uint32_t)(c == 4 ? nCode : c) << (2 * (k - 1)));
       code &= kmask;
       if (c == 4) invalid = 0;
       if (invalid >= k) invalid = -1;
@@ -409,7 +411,7 @@ int t1k_reads_upload(t1k_ctx *ctx, const char *seqs, const uint64_t *offsets, co
     T1K_HIP(ctx, hipMemsetAsync(ctx->bReadBases.p, 0, (size_t)n * 2 * S * 8 + 64, ctx->stream));
     T1K_HIP(ctx, hipMemsetAsync(ctx->bReadN.p, 0, (size_t)n * 2 * S * 8 + 64, ctx->stream));
     t1k_launch_pack(ctx, (const char *)ctx->bReadAscii.p, (const uint64_t *)ctx->bReadOffs.p, n, S, (uint64_t *)ctx->bReadBases.p, (uint64_t *)ctx->bReadN.p,
-                    (uint16_t *)ctx->bReadLen.p);
+                    (uint16_t *)ctx->bReadLen.p, ctx->prm.n_base_code & 3);
   }
   T1K_HIP(ctx, hipStreamSynchronize(ctx->stream));
   ctx->reads.nReadEnds = n;

@@ -60,8 +60,8 @@ __device__ __forceinline__ uint32_t listLowerBound(const uint32_t *p, uint32_t n
 
 // popcounts of C, G, T and N in one packed word (A is what is left of the length)
 __device__ __forceinline__ void baseCounts(uint64_t b, uint64_t n, int &c, int &g, int &t, int &nn) {
-  const uint64_t lo = b & T1K_EVEN, hi = (b >> 1) & T1K_EVEN;
-  c = __popcll(lo & ~hi); g = __popcll(hi & ~lo); t = __popcll(lo & hi); nn = __popcll(n & T1K_EVEN);  // N is packed as base 0 with its mask bit set
+  const uint64_t nm = n & T1K_EVEN, lo = b & T1K_EVEN & ~nm, hi = (b >> 1) & T1K_EVEN & ~nm;  // whatever bits sit under an N do not count
+  c = __popcll(lo & ~hi); g = __popcll(hi & ~lo); t = __popcll(lo & hi); nn = __popcll(nm);
 }
 __device__ __forceinline__ bool lowComplexity(int len, int cC, int cG, int cT, int cN) {  // IsLowComplexity (FastqExtractor.cpp:89-111)
   const int cA = len - cC - cG - cT - cN, half = len / 2;

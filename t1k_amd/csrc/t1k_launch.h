@@ -86,7 +86,7 @@ struct TruncArgs {
   unsigned long long *counters;
 };
 
-int t1k_launch_pack(t1k_ctx *ctx, const char *dAscii, const uint64_t *dOffs, uint32_t n, int S, uint64_t *bases, uint64_t *nmask, uint16_t *lens);
+int t1k_launch_pack(t1k_ctx *ctx, const char *dAscii, const uint64_t *dOffs, uint32_t n, int S, uint64_t *bases, uint64_t *nmask, uint16_t *lens, int nCode);
 size_t t1k_slow_per_thread(int maxCells);
 size_t t1k_chain_big_scratch_u32();
 int t1k_chain_max_chunks(uint32_t nAlleles);

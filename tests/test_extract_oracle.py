@@ -90,3 +90,45 @@ def test_restatement_vs_reference_binary_live(built, tmp_path, seed, length, sub
     subprocess.run([util.ORACLE_EXTRACT] + args + ["-o", str(tmp_path / "b")], check=True, stderr=subprocess.DEVNULL)
     for suffix in ([".fq"] if single else ["_1.fq", "_2.fq"]):
         assert open(str(tmp_path / "a") + suffix).read() == open(str(tmp_path / "b") + suffix).read()
+
+
+def homopolymer_reads(tmp_path, k):
+    """reference sequences with A / T runs longer than k next to an N, and reads that put an N before / after / inside such runs: the code of
+    a k-mer holding an N (this program maps N to 0, FastqExtractor.cpp:51-54) decides whether its neighbour repeats the previous k-mer,
+    both when the index is built (KmerIndex.hpp:121) and when the read is looked up (SeqSet.hpp:1104)"""
+    import random
+    rng = random.Random(9)
+    rnd = lambda n: "".join(rng.choice("ACGT") for _ in range(n))
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A", "N": "N"}
+    body = rnd(200) + "N" + "A" * (k + 4) + rnd(150) + "T" * (k + 3) + "N" + rnd(180) + "A" * (k + 6) + rnd(120) + "N" + "T" * (k + 2) + rnd(150)
+    ref = tmp_path / "homo.fa"
+    ref.write_text(">s0\n%s\n>s1\n%s\n" % (body, rnd(900)))
+    reads = []
+    runs = [i for i in range(1, len(body)) if body[i] in "AT" and body[i - 1] != body[i] and body[i:i + k] == body[i] * k]
+    for start in runs:
+        ln = len(body[start:]) - len(body[start:].lstrip(body[start]))
+        for npos in (None, start - 2, start - 1, start, start + 1, start + ln - 1, start + ln, start + ln + 1):
+            for w0 in (start - 60, start - 25, start - 95):
+                w0 = max(0, w0)
+                s = list(body[w0:w0 + 120].replace("N", "G"))
+                if npos is not None and 0 <= npos - w0 < len(s):
+                    s[npos - w0] = "N"
+                reads.append("".join(s))
+                reads.append("".join(comp[c] for c in reversed(s)))
+    return str(ref), reads
+
+
+@pytest.mark.skipif(not os.path.exists(util.REF_EXTRACT), reason="reference binary not built")
+def test_n_next_to_homopolymers_vs_reference_binary(built, tmp_path):
+    ref, reads = homopolymer_reads(tmp_path, 9)
+    fq = tmp_path / "h.fq"
+    fq.write_text("".join("@h%d\n%s\n+\n%s\n" % (i, r, "I" * len(r)) for i, r in enumerate(reads)))
+    split = False
+    for sim in ("0.8", "0.985", "0.992", "0.999"):
+        args = ["-f", ref, "-u", str(fq), "-s", sim]
+        subprocess.run([util.REF_EXTRACT] + args + ["-o", str(tmp_path / "a")], check=True, stderr=subprocess.DEVNULL)
+        subprocess.run([util.ORACLE_EXTRACT] + args + ["-o", str(tmp_path / "b")], check=True, stderr=subprocess.DEVNULL)
+        a, b = open(str(tmp_path / "a.fq")).read(), open(str(tmp_path / "b.fq")).read()
+        assert a == b
+        split |= 0 < a.count("@h") < len(reads)
+    assert split

@@ -10,14 +10,14 @@ import pytest
 
 import util
 import t1k_amd
-from test_extract_oracle import CASES, XCase, kept_ids
+from test_extract_oracle import CASES, XCase, homopolymer_reads, kept_ids
 
 pytestmark = pytest.mark.gpu
 XBIN = os.path.join(util.ROOT, "t1k_amd", "bin", "fastq-extractor")
 
 
 def device_flags(ref, seqs, epf, k, hit_len, sim):
-    c = t1k_amd.Context(kmer_length=k, hit_len_required=hit_len, ref_seq_similarity=sim)
+    c = t1k_amd.Context(kmer_length=k, hit_len_required=hit_len, ref_seq_similarity=sim, n_base_code=0)
     try:
         c.ref_upload(ref)
         c.reads_upload(seqs)
@@ -155,3 +155,15 @@ def test_large_bucket_takes_the_big_shape(built, tmp_path):
     huge = [rnd(200) + "CAG" * 1500 + rnd(200)]
     with pytest.raises(t1k_amd.T1kError, match="8192 hits"):
         device_flags(huge, ["CAG" * 50], 1, 9, 27, 0.8)
+
+
+def test_n_next_to_homopolymers_vs_oracle(built, tmp_path):
+    """k-mer windows holding an N next to A / T runs (see test_extract_oracle.homopolymer_reads): index build and look-up rule with N -> 0"""
+    ref_fa, reads = homopolymer_reads(tmp_path, 9)
+    ref = ref_seqs(ref_fa)
+    for k, hl, sim in ((9, 23, 0.8), (9, 27, 0.985), (9, 23, 0.992), (11, 23, 0.999), (11, 40, 0.8)):
+        orc = util.ExtractOracle(ref_fa, similarity=sim, k=k, hit_len_required=hl)
+        want = np.array([1 if orc.good(r) else 0 for r in reads], dtype=np.uint8)
+        orc.close()
+        good, _ = device_flags(ref, reads, 1, k, hl, sim)
+        assert np.array_equal(good, want), (k, hl, sim, np.nonzero(good != want)[0][:10])

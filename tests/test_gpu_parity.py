@@ -199,3 +199,33 @@ def test_missing_coverage_kernel_vs_host(ctx, tmp_path):
             cutoff = max(1.0, ex[len(ex) // 2] * 0.01)
             exp[a] = int(np.sum(~(ex >= cutoff)))
     assert cov.sum() > 0 and np.array_equal(got, exp)
+
+
+def homopolymer_case(tmp_path, k):
+    """a reference with A / T runs longer than k and reads that put an N right before, right after or inside them, both strands:
+    the k-mer code of a window holding an N decides whether its neighbour counts as a repeat of the previous k-mer"""
+    import random
+    rng = random.Random(5)
+    rnd = lambda n: "".join(rng.choice("ACGT") for _ in range(n))
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A", "N": "N"}
+    body = rnd(260) + "A" * (k + 6) + rnd(240) + "T" * (k + 5) + rnd(260) + "A" * (k + 1) + "C" + "T" * (k + 2) + rnd(200)
+    alt = body[:100] + ("A" if body[100] != "A" else "C") + body[101:]
+    fa = tmp_path / "homo.fa"
+    fa.write_text(">X*01:01 1 0 %d\n%s\n>X*01:02 1 0 %d\n%s\n" % (len(body) - 1, body, len(alt) - 1, alt))
+    reads = []
+    runs = [(260, k + 6), (260 + k + 6 + 240, k + 5), (260 + k + 6 + 240 + k + 5 + 260, k + 1), (260 + k + 6 + 240 + k + 5 + 260 + k + 2, k + 2)]
+    for start, ln in runs:
+        for npos in (start - 2, start - 1, start, start + 1, start + ln - 1, start + ln, start + ln + 1):
+            for w0 in (start - 70, start - 20, start - 120):
+                s = list(body[w0:w0 + 150])
+                if 0 <= npos - w0 < len(s):
+                    s[npos - w0] = "N"
+                reads.append("".join(s))
+                reads.append("".join(comp[c] for c in reversed(s)))
+    return str(fa), reads
+
+
+def test_n_next_to_homopolymer_vs_oracle(built, tmp_path):
+    import gpu_assign_check
+    fa, reads = homopolymer_case(tmp_path, 11)
+    assert gpu_assign_check.compare(fa, reads, 0.8, False, "N next to homopolymers") == 0

@@ -81,7 +81,7 @@ def main():
     hit_len = max(27, READ_LEN // 5, k)
     r1, r2 = records(pfx + "_1.fq"), records(pfx + "_2.fq")
     seqs = [s for pr in zip(r1, r2) for s in pr]
-    ctx = t1k_amd.Context(kmer_length=k, hit_len_required=hit_len, ref_seq_similarity=0.8)
+    ctx = t1k_amd.Context(kmer_length=k, hit_len_required=hit_len, ref_seq_similarity=0.8, n_base_code=0)
     ctx.ref_upload(rs)
     ctx.reads_upload(seqs)  # packed and resident in HBM before the timed region
     del seqs
