@@ -142,7 +142,7 @@ int t1k_ref_upload(t1k_ctx *ctx, const char *seqs, const uint64_t *offsets, cons
     if (len >= (1u << 20)) return t1k_fail(ctx, T1K_ERR_ARG, "allele longer than 2^20 bases");
     alleleOff[a] = total;
     alleleLen[a] = (uint32_t)len;
-    total += (len + 31) / 32 * 32;
+    total += (len + 32) / 32 * 32;  // at least one spare position behind every allele: the coverage difference array writes its end marker at seqEnd + 1
   }
   total += 64;
   size_t words = total / 32 + 2;

@@ -1,6 +1,7 @@
 """GPU fuzz of the AssignRead stage against the oracle (pytest -m gpu): adversarial read-ends built from the reference itself -- the
 shapes seeded synthetic sequencing never produces.  Every overlap list (coordinates, matchCnt, clips, similarity) and the per-base
 coverage must equal the oracle's."""
+import os
 import random
 
 import pytest
@@ -9,6 +10,8 @@ import gpu_assign_check
 import util
 
 pytestmark = pytest.mark.gpu
+SCALE = int(os.environ.get("T1K_FUZZ_SCALE", "1"))      # more reads per case
+SEED0 = int(os.environ.get("T1K_FUZZ_SEED", "0"))        # shifts every seed: a fresh fuzz run
 COMP = {"A": "T", "C": "G", "G": "C", "T": "A", "N": "N"}
 
 
@@ -96,5 +99,14 @@ def adversarial_reads(al, rng, n):
 @pytest.mark.parametrize("ref_gz,sim,relax,seed", [("rna", 0.8, False, 1), ("dna", 0.9, True, 2), ("rna", 0.97, False, 3), ("dna", 0.8, False, 4)])
 def test_adversarial_reads_vs_oracle(built, tmp_path, ref_gz, sim, relax, seed):
     ref = util.gunzip_to(util.CYP_RNA if ref_gz == "rna" else util.CYP_DNA, str(tmp_path / "ref.fa"))
-    reads = adversarial_reads(alleles(ref), random.Random(seed), 1500)
+    reads = adversarial_reads(alleles(ref), random.Random(seed + SEED0), 1500 * SCALE)
     assert gpu_assign_check.compare(ref, reads, sim, relax, "fuzz %s s=%s" % (ref_gz, sim)) == 0
+
+
+@pytest.mark.parametrize("kind,sim,relax,seed", [("ref-rna", 0.8, False, 5), ("ref-dna", 0.8, True, 6)])
+def test_adversarial_reads_many_alleles_vs_oracle(built, tmp_path, kind, sim, relax, seed):
+    """the same on a synthetic reference with hundreds of near-identical alleles per gene (large hit groups, ties, long posting lists)"""
+    ref = str(tmp_path / "ref.fa")
+    util.synth_ref(kind, ref, seed=seed + SEED0, genes=6, scale=0.3)
+    reads = adversarial_reads(alleles(ref), random.Random(seed + SEED0), 800 * SCALE)
+    assert gpu_assign_check.compare(ref, reads, sim, relax, "fuzz %s s=%s" % (kind, sim)) == 0
