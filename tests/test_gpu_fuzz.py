@@ -110,3 +110,74 @@ def test_adversarial_reads_many_alleles_vs_oracle(built, tmp_path, kind, sim, re
     util.synth_ref(kind, ref, seed=seed + SEED0, genes=6, scale=0.3)
     reads = adversarial_reads(alleles(ref), random.Random(seed + SEED0), 800 * SCALE)
     assert gpu_assign_check.compare(ref, reads, sim, relax, "fuzz %s s=%s" % (kind, sim)) == 0
+
+
+def adversarial_pairs(al, rng, n):
+    """fragments whose mates relate in the ways a sequencer rarely produces: same orientation, swapped, overlapping, contained, from
+    different alleles, one mate noise; every mate then goes through one of the read-level distortions"""
+    rnd = lambda m: "".join(rng.choice("ACGT") for _ in range(m))
+    pairs = []
+    while len(pairs) < n:
+        a = rng.choice(al)
+        L = rng.choice([50, 75, 100, 150])
+        F = rng.choice([L, L + 10, 2 * L - 20, 2 * L + 50, 400])
+        if len(a) < F + 2:
+            continue
+        p = rng.randrange(0, len(a) - F)
+        frag = a[p:p + F]
+        m1, m2 = frag[:L], rc(frag)[:L]
+        kind = rng.randrange(9)
+        if kind == 0:
+            m2 = rc(m2)                       # both mates on the same strand
+        elif kind == 1:
+            m1, m2 = rc(m1), rc(m2)           # outward facing
+        elif kind == 2:
+            b = rng.choice(al)
+            q = rng.randrange(0, max(1, len(b) - L))
+            m2 = rc(b[q:q + L])               # mate from another allele (maybe another gene)
+        elif kind == 3:
+            m2 = rnd(L)                       # one mate is noise
+        elif kind == 4:
+            m2 = rc(m1)                       # mates are reverse complements of each other
+        elif kind == 5:
+            m2 = m1                           # identical mates
+        elif kind == 6:
+            m2 = rc(frag[L // 2:L // 2 + L // 3])  # short mate inside the other
+        elif kind == 7:
+            m1 = adversarial_reads([a], rng, 1)[0][:L]
+        # kind 8: a proper pair
+        if rng.random() < 0.3:
+            t = list(m2)
+            for _ in range(rng.choice([1, 3, 8])):
+                t[rng.randrange(len(t))] = rng.choice("ACGTN")
+            m2 = "".join(t)
+        if rng.random() < 0.5:
+            m1, m2 = m2, m1
+        pairs.append((m1, m2))
+    return pairs
+
+
+@pytest.mark.skipif(not os.path.exists(util.REF_BIN), reason="reference binary not built")
+@pytest.mark.parametrize("kind,flags,seed", [("ref-rna", ["-s", "0.8"], 7), ("ref-dna", ["-s", "0.9", "--relaxIntronAlign"], 8), ("ref-rna", ["-s", "0.97", "-n", "40"], 9)])
+def test_adversarial_pairs_executable_vs_reference_binary(built, tmp_path, kind, flags, seed):
+    """mate pairing, row weights, coalescing, EM and selection on adversarial fragments: every output file of the executable (including
+    the per-fragment assignment table) against the reference binary's"""
+    import subprocess
+    ref = str(tmp_path / "ref.fa")
+    util.synth_ref(kind, ref, seed=seed + SEED0, genes=5, scale=0.15)
+    pairs = adversarial_pairs(alleles(ref), random.Random(seed + SEED0), 6000 * SCALE)
+    for i, suffix in enumerate(("_1.fq", "_2.fq")):
+        with open(str(tmp_path / "p") + suffix, "w") as f:
+            for j, pr in enumerate(pairs):
+                f.write("@f%d/%d\n%s\n+\n%s\n" % (j, i + 1, pr[i], "I" * len(pr[i])))
+    args = ["-f", ref, "-1", str(tmp_path / "p_1.fq"), "-2", str(tmp_path / "p_2.fq")] + flags + ["--outputReadAssignment"]
+    exe = os.path.join(util.ROOT, "t1k_amd", "bin", "genotyper")
+    subprocess.run([exe] + args + ["-o", str(tmp_path / "ours")], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    subprocess.run([util.REF_BIN] + args + ["-t", "16", "-o", str(tmp_path / "ref")], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    n = 0
+    for fn in sorted(os.listdir(str(tmp_path))):
+        if fn.startswith("ref_"):
+            a, b = open(str(tmp_path / fn)).read(), open(str(tmp_path / ("ours_" + fn[4:]))).read()
+            assert a == b, fn
+            n += 1
+    assert n >= 5 and open(str(tmp_path / "ref_assign.tsv")).read().count("\n") > 1000
