@@ -56,6 +56,30 @@ struct RecordReader {
       pos = end;
     }
   }
+  // The common case without copies: a four-line FASTQ record that lies entirely in the buffer.  The pointers stay valid until the next
+  // call.  Returns false if the record is anything else (FASTA, wrapped lines, CR line ends, a record cut by the buffer end, a header read
+  // ahead): the caller then takes next().
+  bool nextInPlace(const char *&name, size_t &nameLen, const char *&seq, size_t &seqLen, const char *&qual) {
+    if (havePending || pos >= end) return false;
+    const char *p = buf.data() + pos, *e = buf.data() + end;
+    if (*p != '@') return false;
+    const char *l1 = (const char *)memchr(p, '\n', e - p);
+    if (!l1 || l1 + 1 >= e) return false;
+    const char *l2 = (const char *)memchr(l1 + 1, '\n', e - (l1 + 1));
+    if (!l2 || l2 + 1 >= e || l2[1] != '+') return false;
+    const char *l3 = (const char *)memchr(l2 + 1, '\n', e - (l2 + 1));
+    if (!l3 || l3 + 1 >= e) return false;
+    const char *l4 = (const char *)memchr(l3 + 1, '\n', e - (l3 + 1));
+    if (!l4) return false;
+    if (l2 - l1 != l4 - l3 || l2 - l1 < 2 || l1[-1] == '\r' || l2[-1] == '\r') return false;
+    const char *sp = p + 1;
+    while (sp < l1 && !isspace((unsigned char)*sp)) ++sp;
+    name = p + 1; nameLen = (size_t)(sp - (p + 1));
+    seq = l1 + 1; seqLen = (size_t)(l2 - l1 - 1);
+    qual = l3 + 1;
+    pos = (size_t)(l4 - buf.data()) + 1;
+    return true;
+  }
   // name (up to the first blank), sequence, quality ("" for FASTA); false at the end of the file
   bool next(std::string &name, std::string &seq, std::string &qual) {
     std::string line;
@@ -122,15 +146,29 @@ struct Stream {
       RecordReader rd(f);
       if (!rd.fp) { failed = true; break; }
       uint64_t r = 0;
-      while (rd.next(name, seq, qual)) {
-        if ((int)(r++ % mod) != rem) continue;
-        cur->off.push_back(cur->arena.size());
-        cur->nameLen.push_back((uint32_t)name.size());
-        cur->seqLen.push_back((uint32_t)seq.size());
-        cur->hasQual.push_back(qual.empty() ? 0 : 1);
-        cur->arena.append(name); cur->arena.push_back('\0');
-        cur->arena.append(seq); cur->arena.push_back('\0');
-        if (!qual.empty()) { cur->arena.append(qual); cur->arena.push_back('\0'); }
+      while (true) {
+        const char *pn, *ps, *pq;
+        size_t nl, sl;
+        if (rd.nextInPlace(pn, nl, ps, sl, pq)) {
+          if ((int)(r++ % mod) != rem) continue;
+          cur->off.push_back(cur->arena.size());
+          cur->nameLen.push_back((uint32_t)nl);
+          cur->seqLen.push_back((uint32_t)sl);
+          cur->hasQual.push_back(1);
+          cur->arena.append(pn, nl); cur->arena.push_back('\0');
+          cur->arena.append(ps, sl); cur->arena.push_back('\0');
+          cur->arena.append(pq, sl); cur->arena.push_back('\0');
+        } else {
+          if (!rd.next(name, seq, qual)) break;
+          if ((int)(r++ % mod) != rem) continue;
+          cur->off.push_back(cur->arena.size());
+          cur->nameLen.push_back((uint32_t)name.size());
+          cur->seqLen.push_back((uint32_t)seq.size());
+          cur->hasQual.push_back(qual.empty() ? 0 : 1);
+          cur->arena.append(name); cur->arena.push_back('\0');
+          cur->arena.append(seq); cur->arena.push_back('\0');
+          if (!qual.empty()) { cur->arena.append(qual); cur->arena.push_back('\0'); }
+        }
         if (cur->n() >= chunkRecords) flush(false);
       }
     }
