@@ -213,7 +213,8 @@ int t1k_ref_upload(t1k_ctx *ctx, const char *seqs, const uint64_t *offsets, cons
   if ((rc = uploadVec(ctx, kStart, (const void **)&r.kStart))) return rc;
   {
     // Per code, in two parallel sweeps over the bucket table (it has 4^k entries: 1 GB at the extractor's k = 14):
-    //   presence bitmaps (t1k_extract.hip): bit c of kHas = list c is not empty; bit p of kHasPre = some non-empty code starts with the k - 2 bases p;
+    //   presence bitmaps (t1k_extract.hip): bit c of kHas = list c is not empty; bit p of kHasPre = some non-empty code c has
+    //   p as the first k - 2 bases of min(c, revcomp(c));
     //   bit c of kMulti = list c holds a sequence more than once
     //   chunk directory: where each multiple of T1K_SEED_CHUNK alleles begins inside a long posting list, so that the kernels find a
     //   chunk's slice of a list with one load instead of a bisection
@@ -236,7 +237,8 @@ int t1k_ref_upload(t1k_ctx *ctx, const char *seqs, const uint64_t *offsets, cons
         const uint32_t ln = kStart[code + 1] - kStart[code];
         if (!ln) continue;
         has[code >> 5] |= 1u << (code & 31);  // the ranges are multiples of 32 codes: no word is shared
-        const size_t pcode = code & (nPre - 1);
+        const uint32_t rcode = t1k_code_revcomp((uint32_t)code, k);
+        const size_t pcode = std::min<uint32_t>((uint32_t)code, rcode) & (nPre - 1);
         __atomic_fetch_or(&hasPre[pcode >> 5], 1u << (pcode & 31), __ATOMIC_RELAXED);
         if (ln > T1K_DIR_MINLEN) ++rows;
         const T1kPosting *pl = &post[kStart[code]];

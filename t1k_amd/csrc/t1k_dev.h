@@ -69,7 +69,8 @@ struct T1kRefDev {
   const uint32_t *kStart;       // [4^k + 1]
   const uint32_t *kHas;         // [4^k / 32] bit c = posting list of code c is not empty (32 MB at k = 14: lives in the Infinity Cache)
   const uint32_t *kMulti;       // [4^k / 32] bit c = list c names some sequence more than once (the k-mer repeats inside a sequence)
-  const uint32_t *kHasPre;      // [4^(k-2) / 32] bit p = some non-empty code has p as its first k - 2 bases (2 MB at k = 14: lives in L2)
+  const uint32_t *kHasPre;      // [4^(k-2) / 32] bit p = some non-empty code c has p as the first k - 2 bases of min(c, revcomp(c)): one look-up
+                                // screens a k-mer position for both strands (2 MB at k = 14: lives in L2)
   // chunk directory of the long posting lists: kDirIdx[code] = row or T1K_NO_DIR; row r, entry c = first posting of the list
   // whose allele is >= c * T1K_SEED_CHUNK (relative to the list start), c = 0 .. kDirStride - 1
   const uint32_t *kDirIdx;      // [4^k]
@@ -102,6 +103,15 @@ __device__ __forceinline__ uint64_t t1k_get32(const uint64_t *w, int64_t pos) {
   int sh = (int)(pos & 31) * 2;
   uint64_t lo = w[wi], hi = w[wi + 1];  // both loads issue together; branch-free so callers can keep many windows in flight
   return (lo >> sh) | ((hi << 1) << (63 - sh));
+}
+// reverse complement of a k-mer code (first base in the low bits): the code of the same window read on the other strand
+__host__ __device__ __forceinline__ uint32_t t1k_code_revcomp(uint32_t code, int k) {
+  uint32_t x = code;
+  x = ((x >> 16) | (x << 16));
+  x = ((x & 0xFF00FF00u) >> 8) | ((x & 0x00FF00FFu) << 8);
+  x = ((x & 0xF0F0F0F0u) >> 4) | ((x & 0x0F0F0F0Fu) << 4);
+  x = ((x & 0xCCCCCCCCu) >> 2) | ((x & 0x33333333u) << 2);  // 2-bit groups reversed, bits inside a group kept
+  return (~x) >> (32 - 2 * k);
 }
 // two consecutive stream words in one 16-byte access (the streams are only 8-byte aligned; gfx950 global loads allow that)
 typedef uint64_t t1k_u64x2 __attribute__((ext_vector_type(2), aligned(8)));

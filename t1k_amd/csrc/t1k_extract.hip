@@ -94,42 +94,40 @@ __global__ __launch_bounds__(XWG) void k_extract_screen(ExtractArgs P) {
     bool multi = false;
     if (live) {
       const int nk = len - k + 1;
-      // two presence bitmaps: the first k - 2 bases of the k-mer (small enough to stay in L2) decide for most positions; only the ones it
-      // lets through ask the full bitmap.  A lane owns `per` consecutive positions of each strand and cuts their codes out of two packed
-      // words it loads once (per + k - 1 <= 32 positions).
+      // Two presence bitmaps.  A window and its reverse complement are the same k-mer position seen from the two strands, so the first
+      // one is keyed by the smaller of the two codes (its first k - 2 bases: 2 MB, stays in L2) and one look-up per forward position
+      // screens both strands; only the positions it lets through ask the full bitmap, once per strand.  A lane owns `per` consecutive
+      // positions and cuts their codes out of two packed words it loads once (per + k - 1 <= 32 positions).
       const uint32_t pmask = k > 2 ? (1u << (2 * (k - 2))) - 1 : kmask;
       const int per = (nk + 63) / 64;  // <= 5 for reads up to 320 bp
       const int p0 = lane * per;
-      uint32_t code[2][5], w[2][5];
-#pragma unroll
-      for (int pass = 0; pass < 2; ++pass) {
-        uint64_t bits = 0, nbits = 0;
-        if (p0 < nk) {
-          bits = t1k_get32(rbase + pass * S, p0);
-          if (hasN) nbits = t1k_get32(rnm + pass * S, p0);
-        }
-#pragma unroll
-        for (int j = 0; j < 5; ++j) {
-          code[pass][j] = (uint32_t)(bits >> (2 * j)) & kmask;
-          w[pass][j] = 0;
-          const bool valid = j < per && p0 + j < nk && ((uint32_t)(nbits >> (2 * j)) & kmask) == 0;
-          if (valid) w[pass][j] = P.ref.kHasPre[(code[pass][j] & pmask) >> 5];
-        }
+      uint32_t code[5], rcode[5], w[5];
+      uint64_t bits = 0, nbits = 0;
+      if (p0 < nk) {
+        bits = t1k_get32(rbase, p0);
+        if (hasN) nbits = t1k_get32(rnm, p0);
       }
 #pragma unroll
-      for (int pass = 0; pass < 2; ++pass) {
+      for (int j = 0; j < 5; ++j) {
+        code[j] = (uint32_t)(bits >> (2 * j)) & kmask;
+        rcode[j] = t1k_code_revcomp(code[j], k);
+        w[j] = 0;
+        const bool valid = j < per && p0 + j < nk && ((uint32_t)(nbits >> (2 * j)) & kmask) == 0;
+        if (valid) w[j] = P.ref.kHasPre[(min(code[j], rcode[j]) & pmask) >> 5];
+      }
 #pragma unroll
-        for (int j = 0; j < 5; ++j) {
-          if (j >= per) break;  // uniform
-          bool hit = false;
-          const uint32_t c = code[pass][j];
-          if ((w[pass][j] >> (c & 31u)) & 1u) {
-            hit = ((P.ref.kHas[c >> 5] >> (c & 31u)) & 1u) != 0;
-            if (hit) multi |= ((P.ref.kMulti[c >> 5] >> (c & 31u)) & 1u) != 0;
-          }
-          const int n = __popcll(__ballot(hit));
-          if (pass == 0) nz0 += n; else nz1 += n;
+      for (int j = 0; j < 5; ++j) {
+        if (j >= per) break;  // uniform
+        bool hit0 = false, hit1 = false;
+        if ((w[j] >> (min(code[j], rcode[j]) & 31u)) & 1u) {
+          const uint32_t c = code[j], r = rcode[j];  // r is the code of the minus strand's position nk - 1 - (p0 + j)
+          hit0 = ((P.ref.kHas[c >> 5] >> (c & 31u)) & 1u) != 0;
+          hit1 = ((P.ref.kHas[r >> 5] >> (r & 31u)) & 1u) != 0;
+          if (hit0) multi |= ((P.ref.kMulti[c >> 5] >> (c & 31u)) & 1u) != 0;
+          if (hit1) multi |= ((P.ref.kMulti[r >> 5] >> (r & 31u)) & 1u) != 0;
         }
+        nz0 += __popcll(__ballot(hit0));
+        nz1 += __popcll(__ballot(hit1));
       }
     }
     const int needHits = (P.hitLenRequired + k - 1) / k;

@@ -93,13 +93,13 @@ def main():
         good, st = ctx.extract(2)
     dt = (time.time() - t0) / a.steps
     # ALGORITHMIC bytes per launch:
-    #   k_extract_screen  every read-end: its packed words (bases + N mask, both strands: 4 * ceil(l/32) * 8 B) + one 4-byte presence word per
-    #                     k-mer position of both strands
+    #   k_extract_screen  every read-end: the packed words of its forward strand (bases + N mask: 2 * ceil(l/32) * 8 B) + one 4-byte presence
+    #                     word per k-mer position (one look-up serves both strands)
     #   k_extract         the read-ends the screen let through: the packed words again + one 8-byte bucket header per k-mer position + 4 B per
     #                     posting of the used lists (the sequence index, which is all the vote reads; counted once)
     ends, words, npos = st["read_ends"], (READ_LEN + 31) // 32, 2 * (READ_LEN - k + 1)
     heavy = st["lookups"] // npos  # read-ends that reached k_extract's look-ups
-    alg_screen = ends * (4 * words * 8 + npos * 4)
+    alg_screen = ends * (2 * words * 8 + (npos // 2) * 4)
     alg_main = heavy * (4 * words * 8 + npos * 8) + st["postings"] * 4
     t_screen, t_main = st["screen_ns"] * 1e-9, st["main_ns"] * 1e-9
     dom, alg, t_dom = ("k_extract", alg_main, t_main) if t_main >= t_screen else ("k_extract_screen", alg_screen, t_screen)
