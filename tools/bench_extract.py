@@ -20,7 +20,7 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md
 # HBM traffic of one launch per read pair of the default workload (profiles/r01_extract_pmc.md: FETCH_SIZE + WRITE_SIZE for 4 M pairs, as
 # reported; on gfx950 FETCH_SIZE is calibrated only for wide coalesced loads, these kernels issue 4-byte-per-lane loads)
 READ_LEN = 150
-TRAFFIC_BYTES_PER_PAIR = {"k_extract_screen": (4.726e9 + 4.977e8) / 4e6, "k_extract": (1.178e10 + 1.163e7) / 4e6}
+TRAFFIC_BYTES_PER_PAIR = {"k_extract_screen": (6.861e9 + 3.926e8) / 4e6, "k_extract": (1.177e10 + 1.163e7) / 4e6}
 
 
 def records(path, n=None):
