@@ -181,6 +181,19 @@ def test_adversarial_pairs_executable_vs_reference_binary(built, tmp_path, kind,
             assert a == b, fn
             n += 1
     assert n >= 5 and open(str(tmp_path / "ref_assign.tsv")).read().count("\n") > 1000
+    # the same read-ends as a single-end run (-u) with per-read barcodes: the dangling-mate rules do not apply, the barcode path does
+    with open(str(tmp_path / "bc.fa"), "w") as f:
+        for j in range(len(pairs)):
+            f.write(">f%d\n%s\n" % (j, "missing_barcode" if j % 97 == 0 else "ACGTTGCA"[j % 3:] + "ACGT"[j % 4] * 4))
+    args = ["-f", ref, "-u", str(tmp_path / "p_2.fq"), "--barcode", str(tmp_path / "bc.fa")] + flags + ["--outputReadAssignment"]
+    subprocess.run([exe] + args + ["-o", str(tmp_path / "sours")], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    subprocess.run([util.REF_BIN] + args + ["-t", "16", "-o", str(tmp_path / "sref")], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    m = 0
+    for fn in sorted(os.listdir(str(tmp_path))):
+        if fn.startswith("sref_"):
+            assert open(str(tmp_path / fn)).read() == open(str(tmp_path / ("sours_" + fn[5:]))).read(), fn
+            m += 1
+    assert m >= 4
 
 
 @pytest.mark.skipif(not os.path.exists(util.REF_EXTRACT), reason="reference binary not built")
