@@ -38,7 +38,7 @@ def adversarial_reads(al, rng, n):
     reads = []
     while len(reads) < n:
         a = rng.choice(al)
-        L = rng.choice([11, 12, 20, 31, 36, 50, 75, 100, 150, 151, 200, 250, 320])
+        L = rng.choice([11, 12, 20, 31, 32, 33, 36, 50, 64, 75, 96, 100, 128, 150, 151, 160, 161, 192, 200, 250, 256, 288, 319, 320])
         kind = rng.randrange(12)
         if len(a) < L + 2:
             continue
