@@ -319,6 +319,12 @@ extern "C" int t1k_extractor_main(int argc, char **argv) {
   }
 
   if (t1k_device_count() <= 0) { fprintf(stderr, "fastq-extractor: no HIP device (this build has no CPU path)\n"); return EXIT_FAILURE; }
+  // the readers start now and parse their first chunks while the index is built and uploaded
+  if (const char *e = getenv("T1K_EXTRACT_CHUNK")) reads.chunkRecords = mates.chunkRecords = barcodes.chunkRecords = (size_t)std::max(1, atoi(e));
+  reads.start();
+  if (hasMate) mates.start();
+  if (hasBarcode) barcodes.start();
+  auto drain = [&]() { while (reads.pop()) {} if (hasMate) while (mates.pop()) {} if (hasBarcode) while (barcodes.pop()) {} };  // lets blocked readers finish
   t1k_params prm;
   t1k_params_default(&prm);
   prm.kmer_length = kmerLength;
@@ -326,7 +332,7 @@ extern "C" int t1k_extractor_main(int argc, char **argv) {
   prm.ref_seq_similarity = similarity;
   prm.n_base_code = 0;  // this program's nucToNum maps 'N' to 0 (FastqExtractor.cpp:51-54), the genotyper's to -1
   t1k_ctx *ctx = nullptr;
-  if (t1k_ctx_create(0, &prm, &ctx) != T1K_OK) { fprintf(stderr, "fastq-extractor: cannot create the device context (k = %d)\n", kmerLength); return EXIT_FAILURE; }
+  if (t1k_ctx_create(0, &prm, &ctx) != T1K_OK) { fprintf(stderr, "fastq-extractor: cannot create the device context (k = %d)\n", kmerLength); drain(); return EXIT_FAILURE; }
   {
     std::string cat;
     std::vector<uint64_t> off(ref.size() + 1, 0);
@@ -334,6 +340,7 @@ extern "C" int t1k_extractor_main(int argc, char **argv) {
     if (t1k_ref_upload(ctx, cat.data(), off.data(), nullptr, (uint32_t)ref.size()) != T1K_OK) {
       fprintf(stderr, "fastq-extractor: %s\n", t1k_last_error(ctx));
       t1k_ctx_destroy(ctx);
+      drain();
       return EXIT_FAILURE;
     }
   }
@@ -342,12 +349,8 @@ extern "C" int t1k_extractor_main(int argc, char **argv) {
   FILE *fp1 = fopen((prefix + (hasMate ? "_1.fq" : ".fq")).c_str(), "w");
   FILE *fp2 = hasMate ? fopen((prefix + "_2.fq").c_str(), "w") : nullptr;
   FILE *fpBc = hasBarcode ? fopen((prefix + "_bc.fa").c_str(), "w") : nullptr;
-  if (!fp1 || (hasMate && !fp2) || (hasBarcode && !fpBc)) { fprintf(stderr, "Cannot open the output files.\n"); t1k_ctx_destroy(ctx); return EXIT_FAILURE; }
+  if (!fp1 || (hasMate && !fp2) || (hasBarcode && !fpBc)) { fprintf(stderr, "Cannot open the output files.\n"); t1k_ctx_destroy(ctx); drain(); return EXIT_FAILURE; }
 
-  if (const char *e = getenv("T1K_EXTRACT_CHUNK")) reads.chunkRecords = mates.chunkRecords = barcodes.chunkRecords = (size_t)std::max(1, atoi(e));
-  reads.start();
-  if (hasMate) mates.start();
-  if (hasBarcode) barcodes.start();
   int rc = 0;
   std::string seqCat, out1, out2, outBc;
   std::vector<uint64_t> offs;
@@ -413,7 +416,7 @@ extern "C" int t1k_extractor_main(int argc, char **argv) {
   lap("read loop (parse / upload / test / write)");
   if (reads.failed || mates.failed || barcodes.failed) { fprintf(stderr, "Cannot open a read file.\n"); rc = 1; }
   // on an error the reader threads may still be blocked on a full queue: drain them
-  if (rc) { while (reads.pop()) {} if (hasMate) while (mates.pop()) {} if (hasBarcode) while (barcodes.pop()) {} }
+  if (rc) drain();
   fclose(fp1);
   if (fp2) fclose(fp2);
   if (fpBc) fclose(fpBc);
