@@ -1,5 +1,6 @@
 // t1k_amd/csrc/t1k_capi.hip -- C ABI (include/t1k_gpu.h), device stage layer: context, reference upload + index build,
 // read upload, the AssignRead batch pipeline, downloads.  Kernels live in t1k_assign.hip / t1k_pair.hip / t1k_em.hip.
+#include <sys/mman.h>
 #include <algorithm>
 #include <memory>
 #include <thread>
@@ -134,6 +135,14 @@ int t1k_ref_upload(t1k_ctx *ctx, const char *seqs, const uint64_t *offsets, cons
   ctx->refBufs.clear();
   const int k = ctx->prm.kmer_length;
   const uint32_t nCode = (uint32_t)ctx->prm.n_base_code & 3u;
+  const bool dbgPhases = getenv("T1K_DEBUG_PHASES") != nullptr;
+  auto tLap = std::chrono::steady_clock::now();
+  auto lap = [&](const char *what) {
+    if (!dbgPhases) return;
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "[t1k] ref_upload %s: %.3f s\n", what, std::chrono::duration<double>(now - tLap).count());
+    tLap = now;
+  };
   std::vector<uint64_t> alleleOff(nAlleles);
   std::vector<uint32_t> alleleLen(nAlleles);
   uint64_t total = 0;
@@ -154,47 +163,91 @@ int t1k_ref_upload(t1k_ctx *ctx, const char *seqs, const uint64_t *offsets, cons
   // little-endian here (first base in the low bits); only equality and "== 0" are ever tested, both convention-free.
   const size_t nKeys = (size_t)1 << (2 * k);
   const uint32_t kmask = (uint32_t)(nKeys - 1);
-  std::vector<uint32_t> kStart(nKeys + 1, 0);
-  std::vector<uint32_t> codes;  // per base position, the k-mer code ending there, or ~0u if not inserted
-  std::vector<std::pair<uint32_t, uint32_t>> ins;
-  for (uint32_t a = 0; a < nAlleles; ++a) {
-    const char *s = seqs + offsets[a];
-    const uint32_t len = alleleLen[a];
-    const uint64_t g = alleleOff[a];
-    sepStart[a] = (uint32_t)sepPos.size();
-    uint32_t code = 0, prev = 0;
-    int invalid = -1;
-    for (uint32_t i = 0; i < len; ++i) {
-      int c = asciiCode(s[i]);
-      uint64_t pos = g + i;
-      if (c == 4) { nmask[pos >> 5] |= 1ull << ((pos & 31) * 2); sepPos.push_back((int32_t)i); alleleHasN[a] = 1; }
-      else bases[pos >> 5] |= (uint64_t)c << ((pos & 31) * 2);
-      if (exon && exon[offsets[a] + i]) exonm[pos >> 5] |= 1ull << ((pos & 31) * 2);
-      if (invalid != -1) ++invalid;
-      code = (code >> 2) | ((uint32_t)(c == 4 ? nCode : c) << (2 * (k - 1)));
-      code &= kmask;
-      if (c == 4) invalid = 0;
-      if (invalid >= k) invalid = -1;
-      if ((int)i < k - 1) continue;
-      if (invalid == -1 && ((int)i == k || code != prev)) { ins.push_back({code, i - k + 1}); ++kStart[code + 1]; }
-      prev = code;
-    }
-    // remember where this allele's postings end
-    ins.push_back({0xFFFFFFFFu, a});
+  // the bucket table has 4^k + 1 entries (1 GB at k = 14): transparent huge pages and a first touch by several threads, or the page
+  // faults of a plain zero-initialised vector cost more than the index build itself
+  const size_t kStartBytes = ((nKeys + 1) * sizeof(uint32_t) + (2u << 20) - 1) & ~(size_t)((2u << 20) - 1);
+  std::unique_ptr<uint32_t, void (*)(void *)> kStartBuf((uint32_t *)aligned_alloc(2u << 20, kStartBytes), free);
+  if (!kStartBuf) return t1k_fail(ctx, T1K_ERR_ARG, "t1k_ref_upload: out of host memory");
+  uint32_t *kStart = kStartBuf.get();
+  (void)madvise(kStart, kStartBytes, MADV_HUGEPAGE);
+  {
+    const unsigned nz = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    const size_t per = ((kStartBytes / nz) + 4095) & ~(size_t)4095;
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nz; ++t)
+      th.emplace_back([&, t] { const size_t lo = std::min(kStartBytes, t * per), hi = std::min(kStartBytes, (t + 1) * per); memset((char *)kStart + lo, 0, hi - lo); });
+    for (auto &x : th) x.join();
   }
-  sepStart[nAlleles] = (uint32_t)sepPos.size();
+  // Alleles are independent here (every allele owns whole 32-base words of the packed arrays): contiguous allele ranges go to host
+  // threads, each keeping its insertions in allele order; the only shared writes are the bucket counts.
+  typedef std::vector<std::pair<uint32_t, uint32_t>> InsList;
+  const unsigned nThr = std::max(1u, std::min({16u, std::thread::hardware_concurrency(), nAlleles}));
+  std::vector<InsList> insOf(nThr);
+  std::vector<std::vector<int32_t>> sepOf(nThr);
+  std::vector<uint32_t> sepCount(nAlleles, 0), rangeBegin(nThr + 1, nAlleles);
+  {
+    const uint64_t totalBases = offsets[nAlleles] - offsets[0];
+    uint32_t a = 0;
+    for (unsigned t = 0; t < nThr; ++t) {  // split by bases, not by allele count
+      rangeBegin[t] = a;
+      const uint64_t until = offsets[0] + totalBases * (t + 1) / nThr;
+      while (a < nAlleles && (offsets[a + 1] <= until || a == rangeBegin[t])) ++a;
+    }
+    rangeBegin[nThr] = nAlleles;
+    rangeBegin[0] = 0;
+    for (unsigned t = 1; t <= nThr; ++t) rangeBegin[t] = std::max(rangeBegin[t], rangeBegin[t - 1]);
+  }
+  {
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nThr; ++t)
+      th.emplace_back([&, t] {
+        InsList &ins = insOf[t];
+        std::vector<int32_t> &sep = sepOf[t];
+        for (uint32_t a = rangeBegin[t]; a < rangeBegin[t + 1]; ++a) {
+          const char *s = seqs + offsets[a];
+          const uint32_t len = alleleLen[a];
+          const uint64_t g = alleleOff[a];
+          uint32_t code = 0, prev = 0;
+          int invalid = -1;
+          for (uint32_t i = 0; i < len; ++i) {
+            int c = asciiCode(s[i]);
+            uint64_t pos = g + i;
+            if (c == 4) { nmask[pos >> 5] |= 1ull << ((pos & 31) * 2); sep.push_back((int32_t)i); ++sepCount[a]; alleleHasN[a] = 1; }
+            else bases[pos >> 5] |= (uint64_t)c << ((pos & 31) * 2);
+            if (exon && exon[offsets[a] + i]) exonm[pos >> 5] |= 1ull << ((pos & 31) * 2);
+            if (invalid != -1) ++invalid;
+            code = (code >> 2) | ((uint32_t)(c == 4 ? nCode : c) << (2 * (k - 1)));
+            code &= kmask;
+            if (c == 4) invalid = 0;
+            if (invalid >= k) invalid = -1;
+            if ((int)i < k - 1) continue;
+            if (invalid == -1 && ((int)i == k || code != prev)) { ins.push_back({code, i - k + 1}); __atomic_fetch_add(&kStart[code + 1], 1u, __ATOMIC_RELAXED); }
+            prev = code;
+          }
+          // remember where this allele's postings end
+          ins.push_back({0xFFFFFFFFu, a});
+        }
+      });
+    for (auto &x : th) x.join();
+  }
+  for (uint32_t a = 0; a < nAlleles; ++a) sepStart[a + 1] = sepStart[a] + sepCount[a];
+  for (unsigned t = 0; t < nThr; ++t) sepPos.insert(sepPos.end(), sepOf[t].begin(), sepOf[t].end());
+  lap("pack + k-mer codes");
   for (size_t i = 0; i < nKeys; ++i) kStart[i + 1] += kStart[i];
+  lap("prefix");
   std::vector<T1kPosting> post(kStart[nKeys]);
   {
     // kStart doubles as the placement cursor: afterwards entry c holds the end of list c, i.e. the start of list c + 1
     uint32_t a = 0;
-    for (auto &e : ins) {
-      if (e.first == 0xFFFFFFFFu) { a = e.second + 1; continue; }
-      post[kStart[e.first]++] = T1kPosting{a, e.second};
-    }
+    for (auto &ins : insOf)
+      for (auto &e : ins) {
+        if (e.first == 0xFFFFFFFFu) { a = e.second + 1; continue; }
+        post[kStart[e.first]++] = T1kPosting{a, e.second};
+      }
     memmove(&kStart[1], &kStart[0], nKeys * sizeof(uint32_t));
     kStart[0] = 0;
   }
+  lap("placement");
   ctx->hAlleleOff = alleleOff;
   ctx->hAlleleLen = alleleLen;
   T1kRefDev r{};
@@ -210,7 +263,15 @@ int t1k_ref_upload(t1k_ctx *ctx, const char *seqs, const uint64_t *offsets, cons
   if ((rc = uploadVec(ctx, sepStart, (const void **)&r.sepStart))) return rc;
   if (sepPos.empty()) sepPos.push_back(0);
   if ((rc = uploadVec(ctx, sepPos, (const void **)&r.sepPos))) return rc;
-  if ((rc = uploadVec(ctx, kStart, (const void **)&r.kStart))) return rc;
+  {
+    T1kDevBuf b;
+    if ((rc = t1k_ensure(ctx, b, (nKeys + 1) * sizeof(uint32_t)))) return rc;
+    T1K_HIP(ctx, hipMemcpyAsync(b.p, kStart, (nKeys + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    T1K_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->refBufs.push_back(b);
+    r.kStart = (const uint32_t *)b.p;
+  }
+  lap("small uploads + bucket table upload");
   {
     // Per code, in two parallel sweeps over the bucket table (it has 4^k entries: 1 GB at the extractor's k = 14):
     //   presence bitmaps (t1k_extract.hip): bit c of kHas = list c is not empty; bit p of kHasPre = some non-empty code c has
@@ -266,6 +327,7 @@ int t1k_ref_upload(t1k_ctx *ctx, const char *seqs, const uint64_t *offsets, cons
       }
     });
     r.kDirStride = stride;
+    lap("bitmap + directory sweeps");
     if ((rc = uploadVec(ctx, has, (const void **)&r.kHas))) return rc;
     if ((rc = uploadVec(ctx, hasPre, (const void **)&r.kHasPre))) return rc;
     if ((rc = uploadVec(ctx, multi, (const void **)&r.kMulti))) return rc;
@@ -277,6 +339,7 @@ int t1k_ref_upload(t1k_ctx *ctx, const char *seqs, const uint64_t *offsets, cons
     ctx->refBufs.push_back(b);
     r.kDirIdx = (const uint32_t *)b.p;
   }
+  lap("bitmap + directory uploads");
   if (post.empty()) post.push_back(T1kPosting{0, 0});
   if ((rc = uploadVec(ctx, post, (const void **)&r.kPost))) return rc;
   {
@@ -292,6 +355,7 @@ int t1k_ref_upload(t1k_ctx *ctx, const char *seqs, const uint64_t *offsets, cons
   r.covDiff = (int32_t *)cov.p;
   ctx->ref = r;
   T1K_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  lap("postings + coverage arrays");
   return T1K_OK;
 }
 
