@@ -2,17 +2,19 @@
 // IsGoodCandidate = !IsLowComplexity(read) && SeqSet::HasHitInSet(read) (FastqExtractor.cpp:89-118, SeqSet.hpp:1915-1990), for a batch
 // of fragments resident in HBM.  All integer, HBM/LDS-bound work; no MFMA.
 //
-//   k_extract_screen  one wavefront per read-end: base counts (IsLowComplexity) and all k-mer look-ups of both strands in one burst of
-//               independent loads against presence bitmaps of the index; a read-end whose strands cannot collect hitLenRequired / k hits
-//               in one bucket (SeqSet.hpp:1925-1927, 1959) is finished here -- that is nearly every read of a sequencing run.  No LDS.
+//   k_extract_screen  one wavefront per read-end: base counts (IsLowComplexity, FastqExtractor.cpp:89-111) and one look-up per k-mer
+//               position, in one burst of independent loads, into presence bitmaps of the index (a position and its reverse complement
+//               share the first look-up); a read-end whose strands cannot collect hitLenRequired / k hits in one bucket
+//               (SeqSet.hpp:1925-1927, 1959) is finished here -- that is nearly every read of a sequencing run.  No LDS.
 //   k_extract   the remaining read-ends, one 256-thread workgroup per fragment (workgroups walk blocks of 256 fragments and compact
 //               the ones with work left); the mate is only looked at when the first end fails, as in the reference
 //               (FastqExtractor.cpp:459-464).  Per read-end:
-//     2. every k-mer of both strands is looked up in the direct-address index at once (one load round), then the first wavefront
-//        replays the sequential look-up rule (prevKmerCode / skipCnt) over registers    GetHitsFromRead (SeqSet.hpp:1071-1229)
-//     3. hits per (strand, sequence) counted in an LDS histogram, 8192 sequences at a time; minus strand first, first maximum wins
-//        (SeqSet.hpp:1934-1957); k * max < hitLenRequired ends the read (1959)
-//     4. the winning bucket's hits are gathered (bisection in each used posting list), rank-sorted by (diagonal, sequence offset,
+//     1. every k-mer of both strands is looked up in the direct-address index at once (one load round); the look-up rule
+//        (prevKmerCode / skipCnt, GetHitsFromRead SeqSet.hpp:1071-1229) is applied in its parallel form, reads with short repeats are
+//        replayed sequentially by the first wavefront over registers
+//     2. hits per (strand, sequence) counted in an LDS histogram, 8192 sequences at a time and only over the span of sequences the
+//        strand's lists name; minus strand first, first maximum wins (SeqSet.hpp:1934-1957); k * max < hitLenRequired ends the read (1959)
+//     3. the winning bucket's hits are gathered (bisection in each used posting list), rank-sorted by (diagonal, sequence offset,
 //        read offset) by the whole workgroup, and thread 0 walks the diagonal runs: nearest-to-dominant filter, LIS, hit lengths
 //        (GetOverlapsFromHits with filter 0, SeqSet.hpp:1232-1556); the read is a candidate if some overlap has
 //        len - hitLen <= int(len * (1 - similarity)) * k  (1974-1979).  A bucket whose hits all lie on one diagonal (the read differs
