@@ -332,7 +332,8 @@ extern "C" int t1k_extractor_main(int argc, char **argv) {
   prm.ref_seq_similarity = similarity;
   prm.n_base_code = 0;  // this program's nucToNum maps 'N' to 0 (FastqExtractor.cpp:51-54), the genotyper's to -1
   t1k_ctx *ctx = nullptr;
-  if (t1k_ctx_create(0, &prm, &ctx) != T1K_OK) { fprintf(stderr, "fastq-extractor: cannot create the device context (k = %d)\n", kmerLength); drain(); return EXIT_FAILURE; }
+  const int device = getenv("T1K_DEVICE") ? atoi(getenv("T1K_DEVICE")) : 0;  // as the genotyper executable picks its GPU
+  if (t1k_ctx_create(device, &prm, &ctx) != T1K_OK) { fprintf(stderr, "fastq-extractor: cannot create the device context (k = %d)\n", kmerLength); drain(); return EXIT_FAILURE; }
   {
     std::string cat;
     std::vector<uint64_t> off(ref.size() + 1, 0);
