@@ -16,6 +16,7 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include "t1k_host.h"
@@ -211,6 +212,7 @@ const char kUsage[] =
     "\t--barcodeStart INT: the start position of barcode in the barcode sequence (default: 0)\n"
     "\t--barcodeEnd INT: the end position of barcode in the barcode sequence (default: length-1)\n"
     "\t--barcodeRevComp: whether the barcode need to be reverse complemented (default: not used)\n"
+    "\t--barcodeWhitelist STRING: path to the barcode whitelist (default: not used)\n"
     "\t--read1Start INT: the start position of sequence in read 1 (default: 0)\n"
     "\t--read1End INT: the end position of sequence in read 1 (default: length-1)\n"
     "\t--read2Start INT: the start position of sequence in read 2 (default: 0)\n"
@@ -232,13 +234,87 @@ void outputSeq(std::string &out, const char *name, size_t nameLen, const char *s
   if (qual) { out.append("+\n"); out.append(qual + s, n); out.push_back('\n'); }
 }
 
+// BarcodeCorrector::FormatBarcode (BarcodeCorrector.hpp:119-139) / the sub-range and reverse complement of OutputBarcode
+std::string formatBarcode(const char *bc, size_t bl, int start, int end, bool revcomp) {
+  if (start == 0 && end == -1 && !revcomp) return std::string(bc, bl);
+  std::string out;
+  const long s = start, e = end == -1 ? (long)bl - 1 : end;
+  if (!revcomp) { for (long x = s; x <= e && x < (long)bl; ++x) out.push_back(bc[x]); }
+  else {
+    for (long x = std::min(e, (long)bl - 1); x >= s; --x) {  // SeqSet::ReverseComplement (SeqSet.hpp:2103-2114)
+      const char c = bc[x];
+      out.push_back(c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'T' ? 'A' : 'N');
+    }
+  }
+  return out;
+}
+
+// BarcodeCorrector (BarcodeCorrector.hpp:104-239): whitelist with background counts; a barcode that is not on the list is replaced by
+// the one-substitution neighbour on the list with the highest count (first in (position, base) order on ties, or -- with qualities --
+// the one whose changed position has the lowest quality)
+struct BarcodeCorrector {
+  // the reference's Trie (BarcodeCorrector.hpp:17-102): a look-up succeeds for any path that exists, whole barcode or prefix of one, and
+  // returns (and updates) the count stored at the node it ends on
+  std::vector<int> next{-1, -1, -1, -1}, cnt{0};
+  static int code(char c) { return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : -1; }
+  static bool acgt(const std::string &s) { for (char c : s) if (code(c) < 0) return false; return true; }
+  void insert(const std::string &s, int weight) {
+    if (!acgt(s)) return;
+    int p = 0;
+    for (char c : s) {
+      const int t = code(c);
+      if (next[4 * p + t] < 0) { next[4 * p + t] = (int)cnt.size(); cnt.push_back(0); next.insert(next.end(), 4, -1); }
+      p = next[4 * p + t];
+    }
+    cnt[p] += weight;
+  }
+  int searchAndUpdate(const std::string &s, int weight) {  // the count after the update, -1 if there is no such path
+    if (!acgt(s)) return -1;
+    int p = 0;
+    for (char c : s) { p = next[4 * p + code(c)]; if (p < 0) return -1; }
+    cnt[p] += weight;
+    return cnt[p];
+  }
+  bool load(const std::string &path) {  // SetWhitelist (145-152)
+    FILE *fp = fopen(path.c_str(), "r");
+    if (!fp) return false;
+    char buffer[256];
+    while (fscanf(fp, "%255s", buffer) != EOF) insert(buffer, 1);
+    fclose(fp);
+    return true;
+  }
+  int count(const std::string &b) { return searchAndUpdate(b, 0); }
+  void observe(const std::string &b) { searchAndUpdate(b, 1); }  // CollectBackgroundDistribution (154-168)
+  // Correct (170-237): 0 = on the list, 1 = corrected in place, -1 = no candidate
+  int correct(std::string &barcode, const char *qual) {
+    if (count(barcode) != -1) return 0;
+    static const char testChr[5] = "ACGT";
+    int bestCnt = -1, bestPos = -1, bestBase = -1, bestLowQual = 255;
+    std::string buffer = barcode;
+    for (size_t i = 0; i < barcode.size(); ++i)
+      for (int j = 0; j < 4; ++j) {
+        if (testChr[j] == barcode[i]) continue;
+        buffer[i] = testChr[j];
+        const int cnt = count(buffer);
+        buffer[i] = barcode[i];
+        if (cnt == -1) continue;
+        if (cnt > bestCnt) { bestCnt = cnt; bestPos = (int)i; bestBase = j; if (qual) bestLowQual = qual[i]; }
+        else if (cnt == bestCnt && qual && qual[i] < bestLowQual) { bestLowQual = qual[i]; bestPos = (int)i; bestBase = j; }
+      }
+    if (bestPos < 0) return -1;
+    barcode[bestPos] = testChr[bestBase];
+    return 1;
+  }
+};
+
 }  // namespace
 
 extern "C" int t1k_extractor_main(int argc, char **argv) {
   if (argc <= 1) { fprintf(stderr, "%s", kUsage); return 0; }
   std::string refPath, prefix = "toassemble";
   Stream reads, mates, barcodes;
-  bool hasMate = false, hasBarcode = false, barcodeRevComp = false;
+  bool hasMate = false, hasBarcode = false, barcodeRevComp = false, hasWhitelist = false;
+  BarcodeCorrector corrector;
   double similarity = 0.8;
   int threadCnt = 1, barcodeStart = 0, barcodeEnd = -1, r1s = 0, r1e = -1, r2s = 0, r2e = -1;
   for (int i = 1; i < argc; ++i) {
@@ -263,8 +339,8 @@ extern "C" int t1k_extractor_main(int argc, char **argv) {
     else if (a == "--barcodeEnd") barcodeEnd = atoi(val());
     else if (a == "--barcodeRevComp") barcodeRevComp = true;
     else if (a == "--barcodeWhitelist") {
-      fprintf(stderr, "--barcodeWhitelist (BarcodeCorrector.hpp) is not part of this build.\n");
-      return EXIT_FAILURE;
+      hasWhitelist = true;
+      if (!corrector.load(val())) { fprintf(stderr, "Cannot open the barcode whitelist.\n"); return EXIT_FAILURE; }
     }
     else if (a == "--read1Start") r1s = atoi(val());
     else if (a == "--read1End") r1e = atoi(val());
@@ -318,6 +394,16 @@ extern "C" int t1k_extractor_main(int argc, char **argv) {
     if (ret > kmerLength) { kmerLength = ret; if (kmerLength > hitLenRequired) hitLenRequired = kmerLength; }
   }
 
+  if (hasBarcode && hasWhitelist) {  // CollectBackgroundDistribution over the first 2,000,000 barcodes (FastqExtractor.cpp:420-423)
+    std::string name, seq, qual;
+    int seen = 0;
+    for (auto &f : barcodes.files) {
+      RecordReader rd(f);
+      if (!rd.fp) { fprintf(stderr, "Cannot open %s\n", f.c_str()); return EXIT_FAILURE; }
+      while (seen < 2000000 && rd.next(name, seq, qual)) { corrector.observe(formatBarcode(seq.data(), seq.size(), barcodeStart, barcodeEnd, barcodeRevComp)); ++seen; }
+      if (seen >= 2000000) break;
+    }
+  }
   if (t1k_device_count() <= 0) { fprintf(stderr, "fastq-extractor: no HIP device (this build has no CPU path)\n"); return EXIT_FAILURE; }
   // the readers start now and parse their first chunks while the index is built and uploaded
   if (const char *e = getenv("T1K_EXTRACT_CHUNK")) reads.chunkRecords = mates.chunkRecords = barcodes.chunkRecords = (size_t)std::max(1, atoi(e));
@@ -390,22 +476,15 @@ extern "C" int t1k_extractor_main(int argc, char **argv) {
       if (threadCnt == 1 && nl >= 2 && nm[nl - 2] == '/' && (nm[nl - 1] == '1' || nm[nl - 1] == '2')) nl -= 2;
       outputSeq(out1, nm, nl, c1->seq(i), c1->qual(i), c1->seqLen[i], r1s, r1e);
       if (hasMate) outputSeq(out2, nm, nl, c2->seq(i), c2->qual(i), c2->seqLen[i], r2s, r2e);
-      if (hasBarcode) {  // OutputBarcode without a whitelist (FastqExtractor.cpp:157-204)
+      if (hasBarcode) {  // OutputBarcode (FastqExtractor.cpp:157-204)
         outBc.push_back('>'); outBc.append(nm, nl); outBc.push_back('\n');
-        const char *bc = cb->seq(i);
         const size_t bl = cb->seqLen[i];
         if (bl == 0) outBc.append("missing_barcode\n");
-        else if (barcodeStart == 0 && barcodeEnd == -1 && !barcodeRevComp) { outBc.append(bc, bl); outBc.push_back('\n'); }
         else {
-          const long s = barcodeStart, e = barcodeEnd == -1 ? (long)bl - 1 : barcodeEnd;
-          if (!barcodeRevComp) { for (long x = s; x <= e && x < (long)bl; ++x) outBc.push_back(bc[x]); }
-          else {
-            for (long x = std::min(e, (long)bl - 1); x >= s; --x) {  // SeqSet::ReverseComplement (SeqSet.hpp:2103-2114)
-              const char c = bc[x];
-              outBc.push_back(c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'T' ? 'A' : 'N');
-            }
-          }
-          outBc.push_back('\n');
+          std::string b = formatBarcode(cb->seq(i), bl, barcodeStart, barcodeEnd, barcodeRevComp);
+          // the corrector looks the changed position up in the quality string of the raw barcode read, unshifted and unreversed
+          if (hasWhitelist && corrector.correct(b, cb->qual(i)) < 0) outBc.append("missing_barcode\n");
+          else { outBc.append(b); outBc.push_back('\n'); }
         }
       }
     }

@@ -28,6 +28,36 @@ run rna100_bc -f $W/rna.fa -1 $W/a_1.fq -2 $W/a_2.fq --barcode $W/a_bc.fa --barc
 # (reverse-complementing the literal "missing_barcode" indexes the reference's nucToNum out of bounds: only the head of the file, which has none)
 head -400 $W/a_1.fq > $W/h_1.fq; head -400 $W/a_2.fq > $W/h_2.fq; head -200 $W/a_bc.fa > $W/h_bc.fa
 run rna100_bcrc -f $W/rna.fa -1 $W/h_1.fq -2 $W/h_2.fq --barcode $W/h_bc.fa --barcodeStart 1 --barcodeEnd 14 --barcodeRevComp
+# barcode whitelist correction (BarcodeCorrector.hpp): whitelist = the barcodes in use + decoys one substitution apart; the barcode reads get
+# substitutions, N and varying qualities (records of the synthetic file that say "missing_barcode" are replaced: the reference's trie
+# indexes nucToNum out of bounds on lower-case letters)
+python3 - $W <<'PYEOF'
+import random, sys
+W = sys.argv[1]; rng = random.Random(3)
+recs = [l.strip() for l in open(W + "/a_bc.fa")]
+ids, bcs = recs[0::2], recs[1::2]
+rnd = lambda n: "".join(rng.choice("ACGT") for _ in range(n))
+L = len(next(b for b in bcs if b != "missing_barcode"))
+wl = sorted(set(b for b in bcs if b != "missing_barcode"))
+decoys = []
+for b in wl[:200]:
+    i = rng.randrange(L); decoys.append(b[:i] + rng.choice([c for c in "ACGT" if c != b[i]]) + b[i + 1:])
+comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+open(W + "/wl.txt", "w").write("\n".join(wl + decoys + [rnd(L) for _ in range(300)]) + "\n")
+open(W + "/wl_rc.txt", "w").write("\n".join("".join(comp[c] for c in reversed(b[1:L - 1])) for b in wl + decoys) + "\n")
+with open(W + "/a_bcq.fq", "w") as f:
+    for i, b in zip(ids, bcs):
+        if b == "missing_barcode": b = rnd(L)
+        t = list(b); u = rng.random()
+        for _ in range(1 if u < 0.3 else 2 if u < 0.36 else 0):
+            j = rng.randrange(L); t[j] = rng.choice("ACGTN")
+        q = "".join(chr(rng.randrange(35, 74)) for _ in range(L))
+        f.write("@%s\n%s\n+\n%s\n" % (i[1:], "".join(t), q))
+PYEOF
+run rna100_wl -f $W/rna.fa -1 $W/a_1.fq -2 $W/a_2.fq --barcode $W/a_bcq.fq --barcodeWhitelist $W/wl.txt
+run rna100_wl_t4 -f $W/rna.fa -1 $W/a_1.fq -2 $W/a_2.fq --barcode $W/a_bcq.fq --barcodeWhitelist $W/wl.txt -t 4
+run rna100_wl_rc -f $W/rna.fa -1 $W/a_1.fq -2 $W/a_2.fq --barcode $W/a_bcq.fq --barcodeWhitelist $W/wl_rc.txt --barcodeStart 1 --barcodeEnd 14 --barcodeRevComp -t 2
+run rna100_wl_prefix -f $W/rna.fa -1 $W/a_1.fq -2 $W/a_2.fq --barcode $W/a_bcq.fq --barcodeWhitelist $W/wl.txt --barcodeEnd 11
 run rna150_noisy -f $W/rna.fa -1 $W/b_1.fq -2 $W/b_2.fq -t 4
 run rna150_s95 -f $W/rna.fa -1 $W/b_1.fq -2 $W/b_2.fq -s 0.95
 run rna150_single -f $W/rna.fa -u $W/b_1.fq -s 0.97 --read1Start 5 --read1End 120
