@@ -167,3 +167,34 @@ def test_n_next_to_homopolymers_vs_oracle(built, tmp_path):
         orc.close()
         good, _ = device_flags(ref, reads, 1, k, hl, sim)
         assert np.array_equal(good, want), (k, hl, sim, np.nonzero(good != want)[0][:10])
+
+
+@pytest.mark.skipif(not os.path.exists(util.REF_EXTRACT), reason="reference binary not built")
+def test_barcode_whitelist_vs_reference_binary(built, tmp_path):
+    """--barcode / --barcodeWhitelist (BarcodeCorrector.hpp): exact, corrected, ambiguous (quality tie-break), uncorrectable and N barcodes,
+    plain and with a reverse-complemented sub-range; the _bc.fa files against the reference's own fastq-extractor"""
+    c = XCase("cyp_rna_2x100", str(tmp_path))
+    rng = random.Random(21)
+    rnd = lambda n: "".join(rng.choice("ACGT") for _ in range(n))
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+    L = 16
+    wl = [rnd(L) for _ in range(40)]
+    wl += [b[:5] + ("A" if b[5] != "A" else "C") + b[6:] for b in wl[:15]]          # neighbours: corrections can be ambiguous
+    (tmp_path / "wl.txt").write_text("\n".join(wl) + "\n")
+    (tmp_path / "wl_rc.txt").write_text("\n".join("".join(comp[x] for x in reversed(b[2:14])) for b in wl) + "\n")
+    n = len(util.fastx_records(c.r1))
+    with open(str(tmp_path / "bc.fq"), "w") as f:
+        for i in range(n):
+            b = list(rng.choice(wl)) if rng.random() < 0.9 else list(rnd(L))
+            u = rng.random()
+            for _ in range(1 if u < 0.35 else 2 if u < 0.45 else 0):
+                b[rng.randrange(L)] = rng.choice("ACGTN")
+            f.write("@b%d\n%s\n+\n%s\n" % (i, "".join(b), "".join(chr(rng.randrange(35, 74)) for _ in range(L))))
+    for name, extra in (("plain", ["--barcodeWhitelist", str(tmp_path / "wl.txt")]),
+                        ("rc", ["--barcodeWhitelist", str(tmp_path / "wl_rc.txt"), "--barcodeStart", "2", "--barcodeEnd", "13", "--barcodeRevComp", "-t", "3"])):
+        args = c.args() + ["--barcode", str(tmp_path / "bc.fq")] + extra
+        subprocess.run([XBIN] + args + ["-o", str(tmp_path / ("o_" + name))], check=True, stderr=subprocess.DEVNULL)
+        subprocess.run([util.REF_EXTRACT] + args + ["-o", str(tmp_path / ("r_" + name))], check=True, stderr=subprocess.DEVNULL)
+        a, b = open(str(tmp_path / ("r_" + name)) + "_bc.fa").read(), open(str(tmp_path / ("o_" + name)) + "_bc.fa").read()
+        assert a == b
+        assert 0 < a.count("missing_barcode") < a.count(">")
