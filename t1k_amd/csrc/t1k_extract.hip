@@ -77,7 +77,12 @@ __global__ __launch_bounds__(XWG) void k_extract_screen(ExtractArgs P) {
   const int k = P.k;
   const uint32_t kmask = (1u << (2 * k)) - 1;
   const int S = P.reads.S;
-  for (uint32_t re = wave; re < P.reads.nReadEnds; re += nWaves) {
+  // a wavefront takes 64 consecutive read-ends at a time, lane i keeps the verdict of the i-th: one 64-byte store instead of 64 one-byte ones
+  for (uint32_t base = wave * 64u; base < P.reads.nReadEnds; base += nWaves * 64u) {
+   uint32_t mine = 0;
+   const uint32_t cnt = min(64u, P.reads.nReadEnds - base);
+   for (uint32_t i = 0; i < cnt; ++i) {
+    const uint32_t re = base + i;
     const int len = P.reads.len[re];
     const uint64_t *rbase = P.reads.bases + (uint64_t)re * 2 * S;
     const uint64_t *rnm = P.reads.nmask + (uint64_t)re * 2 * S;
@@ -134,7 +139,9 @@ __global__ __launch_bounds__(XWG) void k_extract_screen(ExtractArgs P) {
     }
     const int needHits = (P.hitLenRequired + k - 1) / k;
     const bool anyWave = __ballot(multi) != 0ull ? (nz0 + nz1 > 0) : (nz0 >= needHits || nz1 >= needHits);
-    if (lane == 0) P.state[re] = (live && anyWave) ? 1 : 0;
+    if (lane == (int)i) mine = (live && anyWave) ? 1u : 0u;
+   }
+   if ((uint32_t)lane < cnt) P.state[base + lane] = (uint8_t)mine;
   }
 }
 
