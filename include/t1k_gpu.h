@@ -129,7 +129,7 @@ int t1k_coverage_absorb(t1k_ctx *dst, t1k_ctx *src);
  * only tested when the first fails (FastqExtractor.cpp:459-464).  good[nReadEnds / endsPerFragment] receives 0 / 1.
  * stats (may be NULL, else 8 words) receives {read-ends screened, index look-ups of the read-ends the screen let through, postings of their
  * used lists, read-ends with a hit, read-ends chained, k_extract_screen ns, k_extract ns (HIP events on the context's stream), 1 if the
- * batch had to be run again in the large LDS shape (a bucket of more than 2048 hits; more than 8192 is T1K_ERR_CAPACITY)}. */
+ * batch had to be run again in the large LDS shape (a bucket of more than 1024 hits; more than 8192 is T1K_ERR_CAPACITY)}. */
 int t1k_extract_batch(t1k_ctx *ctx, uint32_t endsPerFragment, uint8_t *good, uint64_t *stats);
 
 /* ---- AlignAlgo::GlobalAlignment (AlignAlgo.hpp:215-421) as a batch --------------------------------------------

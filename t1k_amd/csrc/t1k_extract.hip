@@ -12,7 +12,7 @@
 //     1. every k-mer of both strands is looked up in the direct-address index at once (one load round); the look-up rule
 //        (prevKmerCode / skipCnt, GetHitsFromRead SeqSet.hpp:1071-1229) is applied in its parallel form, reads with short repeats are
 //        replayed sequentially by the first wavefront over registers
-//     2. hits per (strand, sequence) counted in an LDS histogram, 8192 sequences at a time and only over the span of sequences the
+//     2. hits per (strand, sequence) counted in an LDS histogram, 4096 sequences at a time and only over the span of sequences the
 //        strand's lists name; minus strand first, first maximum wins (SeqSet.hpp:1934-1957); k * max < hitLenRequired ends the read (1959)
 //     3. the winning bucket's hits are gathered (bisection in each used posting list), rank-sorted by (diagonal, sequence offset,
 //        read offset) by the whole workgroup, and thread 0 walks the diagonal runs: nearest-to-dominant filter, LIS, hit lengths
@@ -27,9 +27,10 @@
 
 #define XWG 256
 // k_extract<X_RANGE>: sequences per histogram pass (u32 counters in LDS); the same words later hold the bucket's hits and the three
-// work arrays of the chain, so a bucket may have X_RANGE / 4 hits.  8192 (32 KB, 2048 hits) is the production shape; a batch in which
-// some bucket is larger is run again with 32768 (128 KB, one workgroup per CU, 8192 hits).
-#define X_RANGE_SMALL 8192
+// work arrays of the chain, so a bucket may have X_RANGE / 4 hits.  4096 (16 KB, 1024 hits) is the production shape (measured: 8192 -> 8.5 ms,
+// 4096 -> 7.4 ms, 2048 -> 8.1 ms per 4 M pairs: occupancy against the number of passes); a batch in which some bucket is larger is run
+// again with 32768 (128 KB, one workgroup per CU, 8192 hits).
+#define X_RANGE_SMALL 4096
 #define X_RANGE_BIG 32768
 enum { XERR_HITCAP = 1 };
 #ifdef T1K_XPROF

@@ -131,7 +131,7 @@ def test_full_size_properties(built, tmp_path):
 
 
 def test_large_bucket_takes_the_big_shape(built, tmp_path):
-    """a trinucleotide repeat puts thousands of hits into one (strand, sequence) bucket: more than the production LDS shape holds (2048),
+    """a trinucleotide repeat puts thousands of hits into one (strand, sequence) bucket: more than the production LDS shape holds (1024),
     so the batch is run again in the large shape (8192); results still equal the oracle's.  Beyond that the call fails loudly."""
     rng = random.Random(11)
     rnd = lambda n: "".join(rng.choice("ACGT") for _ in range(n))
