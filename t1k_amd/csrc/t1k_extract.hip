@@ -147,7 +147,7 @@ __global__ __launch_bounds__(XWG) void k_extract_screen(ExtractArgs P) {
 }
 
 template <int X_RANGE>
-__global__ __launch_bounds__(XWG) void k_extract(ExtractArgs P) {
+__global__ __launch_bounds__(XWG) __attribute__((amdgpu_waves_per_eu(6))) void k_extract(ExtractArgs P) {
   constexpr int X_HCAP = X_RANGE / 4;
   extern __shared__ uint32_t lds[];
   const int maxK = (int)P.maxK;
