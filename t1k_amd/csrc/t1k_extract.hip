@@ -28,7 +28,7 @@
 #define XWG 256
 // k_extract<X_RANGE>: sequences per histogram pass (u32 counters in LDS); the same words later hold the bucket's hits and the three
 // work arrays of the chain, so a bucket may have X_RANGE / 4 hits.  4096 (16 KB, 1024 hits) is the production shape (measured: 8192 -> 8.5 ms,
-// 4096 -> 7.4 ms, 2048 -> 8.1 ms per 4 M pairs: occupancy against the number of passes); a batch in which some bucket is larger is run
+// 4096 -> 7.4 ms, 2048 -> 8.1 ms per 4 M pairs: occupancy against the number of passes; 6.6 ms with the kernel held to 80 VGPRs); a batch in which some bucket is larger is run
 // again with 32768 (128 KB, one workgroup per CU, 8192 hits).
 #define X_RANGE_SMALL 4096
 #define X_RANGE_BIG 32768
