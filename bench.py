@@ -1,18 +1,23 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the MI355X genotyper hot path.
 
-Metric (BASELINE.json): genotyped reads/sec, 2x150 bp HLA, at N MI355X.  A "step" is one full pass of the genotyper stage
-over the synthetic read set resident in HBM: read-end assignment (seed/chain/extend/select/full-align kernels), mate
-pairing, read-group coalescing, equivalence classes, SQUAREM EM (E-step on the GPU), allele selection.  The workload at
-N=1 is BASELINE.json configs[1]: 1 M synthetic 2x150 bp pairs against the HLA-like rna reference (the real
-hlaidx_rna_seq.fa cannot be downloaded; tools/t1k_synth generates a reference of the same shape, seed 20250614).
+Metric (BASELINE.json / SURVEY 8d): genotyped reads/sec END TO END -- fragments divided by the wall time of the whole genotyper
+stage, from opening the reference FASTA and the FASTQ files to the closed *_genotype.tsv / *_allele.tsv / *_aligned_{1,2}.fa.
+A "step" is one complete pass of that stage inside this process: reference parse + pack + index build + upload, FASTQ mapping and
+record indexing, the windows of fragments streamed through the GPU (upload, 2-bit pack, identical-read-end collapse, read-end
+assignment, mate pairing), coalescing, equivalence classes, SQUAREM EM, allele selection, and all output files written.  Nothing is
+kept between steps except the HIP runtime itself (the process) and the OS page cache of the input files.
+
+Workload at N=1: 10 M synthetic 2x150 bp pairs against the HLA-like rna reference (north_star's "10M synthetic 2x150 bp HLA reads";
+the real hlaidx_rna_seq.fa cannot be downloaded: tools/t1k_synth generates a reference of the same shape, seed 20250614);
+--pairs 1000000 gives BASELINE.json configs[1].  With N ranks every rank owns --pairs fragments (weak scaling).
 
   python bench.py --gpus 1 --steps 3 --warmup 1            (single GPU)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-Rank 0 prints ONE JSON line with the contract fields plus "roofline" (dominant kernel: algorithmic bytes / HIP-event time
-vs the 8 TB/s HBM peak) and "cpu_baseline" (the reference genotyper built from /root/reference, timed here on a bounded
-sample of the same workload).
+Rank 0 prints ONE JSON line with the contract fields plus "roofline" (dominant kernel: algorithmic bytes / HIP-event time vs the
+8 TB/s HBM peak, and the whole pipeline's algorithmic bytes over the step time) and "cpu_baseline" (the reference genotyper built
+from /root/reference by oracle/Makefile, timed here on a bounded sample of the same workload with -t = all host cores).
 """
 import argparse
 import json
@@ -26,9 +31,6 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 READ_LEN = 150
-# HBM traffic of one full-batch k_seed_groups launch (16384 fragments) from the rocprofv3 PMC passes of profiles/r01_pmc_hbm.md:
-# FETCH_SIZE 5.37e6 KB (x2: the counter tallies 128-B requests at 64 B on gfx950, MI355X_MICROARCH.md) + WRITE_SIZE 3.12e6 KB
-TRAFFIC_BYTES_PER_LAUNCH = 2 * 5.37e9 + 3.12e9
 
 
 def sh(cmd, **kw):
@@ -61,31 +63,38 @@ def head_fastq(src, dst, n):
 
 
 def cpu_baseline(ref, pfx, workdir, pairs_total):
-    """the reference's genotyper (oracle/_ref/genotyper, built by oracle/Makefile from /root/reference) on the host cores of
-    this box, on a bounded sample (first n pairs) of the same workload.  Falls back to the oracle restatement (1 thread)."""
+    """the reference's genotyper (oracle/_ref/genotyper, built by oracle/Makefile from /root/reference) on ALL host cores of this
+    box (-t nproc), on a bounded sample (first n pairs) of the same workload; the reference-load time (the same command on an empty
+    read file) is reported separately.  Falls back to the oracle restatement (1 thread) when the reference binary is absent."""
     cores = os.cpu_count() or 1
-    threads = min(cores, 32)
     refbin = os.path.join(ROOT, "oracle", "_ref", "genotyper")
-    kind, binary = "reference", refbin
+    kind, binary, threads = "reference", refbin, cores
     if not os.path.exists(refbin):
         kind, binary, threads = "port", os.path.join(ROOT, "oracle", "t1k_oracle_cli"), 1
-    n = min(pairs_total, 480 * threads if kind == "reference" else 400)  # ~20 s of CPU work on the HLA-like workload
+    n = min(pairs_total, 100000 if kind == "reference" else 400)
     s1, s2 = os.path.join(workdir, "cpu_1.fq"), os.path.join(workdir, "cpu_2.fq")
-    head_fastq(pfx + "_1.fq", s1, n)
-    head_fastq(pfx + "_2.fq", s2, n)
     out = os.path.join(workdir, "cpu_out")
-    t0 = time.time()
-    sh([binary, "-f", ref, "-1", s1, "-2", s2, "-s", "0.97", "-t", str(threads), "-o", out], stderr=subprocess.DEVNULL, stdout=subprocess.DEVNULL)
-    dt = time.time() - t0
-    geno = out + "_genotype.tsv"
-    return dict(value=n / dt, unit="read pairs/s", cores=threads, kind=kind,
-                sample="first %d of %d pairs, same reference, -s 0.97, wall %.1f s incl. reference load" % (n, pairs_total, dt)), (geno if os.path.exists(geno) else None)
+
+    def run(k):
+        head_fastq(pfx + "_1.fq", s1, k)
+        head_fastq(pfx + "_2.fq", s2, k)
+        t0 = time.time()
+        sh([binary, "-f", ref, "-1", s1, "-2", s2, "-s", "0.97", "-t", str(threads), "-o", out], stderr=subprocess.DEVNULL, stdout=subprocess.DEVNULL)
+        return time.time() - t0
+
+    load = run(0)
+    dt = run(n)
+    return dict(value=n / dt, unit="read pairs/s", cores=threads, kind=kind, wall_s=dt, reference_load_s=load,
+                value_without_reference_load=n / max(dt - load, 1e-9),
+                sample="first %d of %d pairs, same reference, -s 0.97, -t %d; wall %.1f s of which %.1f s is the reference load (same command, no reads)"
+                       % (n, pairs_total, threads, dt, load))
 
 
-def kernel_bytes(st, pairs):
+def kernel_bytes(st):
     """ALGORITHMIC bytes per kernel (group) for one step: the terms of SURVEY.md 8d, every count measured by
     the device itself.  k_seed_groups covers the first two terms: the packed read (3l/8 B per read-end) + one 8 B bucket header per
-    looked-up k-mer + 8 B per posting of the used lists (each posting counted once)."""
+    looked-up k-mer + 8 B per posting of the used lists (each posting counted once).  read_ends counts the DISTINCT read-ends the
+    kernels ran on (identical read-ends are assigned once, as in the reference)."""
     re, L = st["read_ends"], READ_LEN
     return {
         "k_seed_groups": re * (3 * L / 8.0) + st["lookups"] * 8 + st["postings"] * 8,
@@ -93,7 +102,7 @@ def kernel_bytes(st, pairs):
         "k_extend": st["candidates"] * (24 + 60 + 24),
         "k_select": st["candidates"] * (24 + 24) + st["extended"] * 32,
         "fullalign kernels": st["extended"] * 32 + st["near_best"] * (60 + 12),
-        "k_pair": st["extended"] * 32 + st["rows"] * 24,
+        "k_pair": st["pair_overlaps"] * 32 + st["rows"] * 24,
     }
 
 
@@ -102,12 +111,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--pairs", type=int, default=1000000, help="read pairs per GPU (weak scaling)")
+    ap.add_argument("--pairs", type=int, default=10000000, help="read pairs per GPU (weak scaling)")
     ap.add_argument("--genes", type=int, default=24)
     ap.add_argument("--scale", type=float, default=1.0)
     ap.add_argument("--workdir", default=os.environ.get("T1K_BENCH_DIR", "/tmp/t1k_bench"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--force-dist", action="store_true", help="take the sharded (collective) code path even with one rank")
+    ap.add_argument("--executable-check", action="store_true", help="also time one cold run of t1k_amd/bin/genotyper on the same files (stopwatch around the process)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -115,38 +124,32 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
     dist = None
-    if world > 1 or a.force_dist:
+    if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        os.environ.setdefault("RANK", "0")
-        os.environ.setdefault("WORLD_SIZE", "1")
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # RCCL on ROCm
     import t1k_amd
-    import bench_dist
 
-    # inputs: one sample of world*pairs fragments, rank r owns the contiguous slice r (fragments in file order)
-    total_pairs = a.pairs * world
+    # inputs: rank r genotypes its own sample of --pairs fragments against the shared reference (independent samples per GPU)
     if rank == 0:
-        ref, pfx = ensure_inputs(a.workdir, total_pairs, a.genes, a.scale, seed=2)
+        ensure_inputs(a.workdir, a.pairs, a.genes, a.scale, seed=2)
     if dist is not None:
         dist.barrier()
-    ref, pfx = ensure_inputs(a.workdir, total_pairs, a.genes, a.scale, seed=2)
-
-    job = t1k_amd.Job(ref, ref_seq_similarity=0.97, device=local_rank)
-    if dist is None:
-        job.load_reads(pfx + "_1.fq", pfx + "_2.fq")
-    else:
-        bench_dist.load_shard(job, pfx, rank, world, a.pairs)
-        bench_dist.install_allreduce(job, dist, torch)
-    job.stage_reads()  # reads are packed and resident in HBM before the timed region
+    ref, pfx = ensure_inputs(a.workdir, a.pairs, a.genes, a.scale, seed=2)
+    out_prefix = os.path.join(a.workdir, "out_rank%d" % rank)
+    last = {}
 
     def step():
-        if dist is None:
-            job.run()
-        else:
-            bench_dist.sharded_step(job, dist, torch, rank, world)
+        job = t1k_amd.Job(ref, ref_seq_similarity=0.97, device=local_rank)
+        job.load_reads(pfx + "_1.fq", pfx + "_2.fq")
+        job.run()
+        job.write_outputs(out_prefix)
+        last["stats"] = job.stats()
+        last["counts"] = job.counts()
+        last["text"] = job.genotype_text()
+        job.close()
 
     for _ in range(a.warmup):
         step()
@@ -164,21 +167,23 @@ def main():
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    st = job.stats()
-    counts = job.counts()
-    text = job.genotype_text()
-    job.close()
-    if dist is not None:
         dist.destroy_process_group()
+    st, counts, text = last["stats"], last["counts"], last["text"]
     import ctypes
     ctypes.CDLL(None).fflush(None)  # RCCL prints its banner through C stdio: get it out before the JSON line
     if rank == 0:
         ms = {"k_seed_groups": st["ms_seed"], "chain kernels": st["ms_chain"], "k_extend": st["ms_extend"], "k_select": st["ms_select"],
               "fullalign kernels": st["ms_fullalign"], "k_pair": st["ms_pair"]}
-        kb = kernel_bytes(st, a.pairs)
-        dom = "k_seed_groups"  # the single largest kernel (profiles/): one launch per device batch
+        kb = kernel_bytes(st)
+        dom = "k_seed_groups"  # the kernel with the most algorithmic bytes (profiles/): one launch per batch of distinct read-ends
         launches = max(1, st["batches"])
         achieved = kb[dom] / (ms[dom] * 1e-3) / 1e9 if ms[dom] > 0 else 0.0
+        step_s = dt / a.steps
+        total_pairs = a.pairs * world
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r02_seed_traffic.json")  # PMC passes of the same command (profiles/r02_pmc_hbm.md)
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get("bytes_per_launch")
         out = {
             "metric": "genotyped reads/sec (end-to-end genotyper stage, 2x150 bp HLA)",
             "value": total_pairs * a.steps / dt,
@@ -186,29 +191,42 @@ def main():
             "n_gpus": world,
             "steps": a.steps,
             "warmup": a.warmup,
-            "ms_per_step": dt / a.steps * 1e3,
+            "ms_per_step": step_s * 1e3,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "u64",
             "data": "synthetic",
-            "config": {"workload": "%d synthetic 2x150 bp pairs per GPU vs synthetic HLA-like rna reference (%d genes, scale %s: %d alleles), -s 0.97, reads packed and resident in HBM"
+            "config": {"workload": "%d synthetic 2x150 bp pairs per GPU vs synthetic HLA-like rna reference (%d genes, scale %s: %d alleles), -s 0.97; "
+                                   "END TO END per step: reference FASTA -> index -> FASTQ parse -> GPU -> genotype.tsv + allele.tsv + aligned_{1,2}.fa written"
                                    % (a.pairs, a.genes, a.scale, sum(1 for l in open(ref) if l.startswith(">"))),
-                       "parallelism": ("fragments sharded over %d GPUs; RCCL all-reduce of coverage and of the EM read-count vector, all-gather of group tables" % world)
-                       if world > 1 else "1 GPU",
-                       "arithmetic": "2-bit packed bases in u64 words, int32 alignment scores, f64 EM",
+                       "parallelism": ("%d GPUs, one sample of %d pairs per GPU (independent genotyping jobs, no collective)" % (world, a.pairs)) if world > 1 else "1 GPU",
+                       "arithmetic": "2-bit packed bases in u64 words, int32 alignment scores, f32 read-group weights, f64 EM",
+                       "read_ends": st["read_ends_total"], "distinct_read_ends": st["read_ends"],
                        "groups": counts["groups"], "equivalence_classes": counts["ecs"], "em_iterations": counts["em_iterations"],
-                       "assigned_fragments": counts["assigned_fragments"]},
+                       "assigned_fragments": counts["assigned_fragments"],
+                       "phases_ms": {"read_files_map_index": st["ms_load"], "device_loop": st["ms_device"], "coalesce": st["ms_coalesce"], "em": st["ms_em"],
+                                     "write_outputs": st["ms_write"]}},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": TRAFFIC_BYTES_PER_LAUNCH if a.pairs >= 16384 else None,
+                         "traffic": traffic,
                          "launches_per_step": launches, "pipelines_per_gpu": int(os.environ.get("T1K_PIPELINES", "4")), "algorithmic_bytes_per_launch": kb[dom] / launches, "avg_launch_ms": ms[dom] / launches,
                          "all_kernels_ms_per_step": ms,
                          "all_kernels_algorithmic_GBs": {k: (kb[k] / (ms[k] * 1e-3) / 1e9 if ms[k] > 0 else 0.0) for k in ms},
+                         "pipeline_algorithmic_bytes_per_step": sum(kb.values()),
+                         "pipeline_frac": sum(kb.values()) / step_s / 1e9 / HBM_PEAK_GBS,
+                         "pipeline_frac_device_loop": sum(kb.values()) / max(st["ms_device"] * 1e-3, 1e-9) / 1e9 / HBM_PEAK_GBS,
+                         "dp_cell_updates_per_s": st["dp_cells"] / max(st["ms_fullalign"] * 1e-3, 1e-9) if st.get("dp_cells") else None,
                          "em_ms": st["ms_em"], "job_ms_total": st["ms_total"]},
         }
+        if a.executable_check:
+            exe = os.path.join(ROOT, "t1k_amd", "bin", "genotyper")
+            t1 = time.time()
+            sh([exe, "-f", ref, "-1", pfx + "_1.fq", "-2", pfx + "_2.fq", "-s", "0.97", "-o", os.path.join(a.workdir, "exe_out")], stderr=subprocess.DEVNULL)
+            wall = time.time() - t1
+            same = open(os.path.join(a.workdir, "exe_out_genotype.tsv")).read() == text
+            out["config"]["executable_cold_run"] = {"wall_s": wall, "read_pairs_per_s": a.pairs / wall, "genotype_tsv_identical_to_bench": same}
         if world == 1 and not a.no_cpu_baseline:
-            cb, cpu_geno = cpu_baseline(ref, pfx, a.workdir, a.pairs)
-            out["cpu_baseline"] = cb
+            out["cpu_baseline"] = cpu_baseline(ref, pfx, a.workdir, a.pairs)
         else:
             out["cpu_baseline"] = None
         with open(os.path.join(a.workdir, "last_genotype.tsv"), "w") as f:

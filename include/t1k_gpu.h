@@ -35,6 +35,8 @@ typedef enum {
 
 typedef struct t1k_ctx t1k_ctx;
 typedef struct t1k_job t1k_job;
+typedef struct t1k_rowset t1k_rowset;
+typedef struct t1k_comm t1k_comm;
 
 /* Genotyper.cpp:218-229 defaults; SeqSet.hpp:760-772 constants */
 typedef struct {
@@ -47,14 +49,15 @@ typedef struct {
   /* device arena sizing (0 = defaults) */
   int32_t max_read_len;         /* longest read accepted, default 320 */
   int32_t workgroups;           /* persistent workgroups of the per-read-end kernels, default 2048 */
-  int64_t hit_cap;              /* unused (kept for ABI stability) */
   int64_t group_cap;            /* (read-end, strand, allele) hit groups per batch */
   int64_t cand_cap;             /* candidate records per batch */
-  int64_t ovl_cap;              /* overlap records per batch */
+  int64_t ovl_cap;              /* overlap records of one t1k_assign_range */
   int64_t row_cap;              /* fragment-row entries per batch */
   int32_t n_base_code;          /* the two bits a non-ACGT base contributes to a k-mer code (the code of a window holding one still decides
                                    whether its neighbour repeats the previous k-mer): 3 in the genotyper (nucToNum, Genotyper.cpp:37-40:
                                    -1 & 3), 0 in fastq-extractor (FastqExtractor.cpp:51-54: 'N' -> 0).  t1k_params_default sets 3. */
+  int32_t store_chunk_factor;   /* the overlap store (final overlap lists, resident until the next read upload) grows in chunks of
+                                   store_chunk_factor * ovl_cap records; default 4 */
 } t1k_params;
 
 void t1k_params_default(t1k_params *p);
@@ -76,6 +79,13 @@ int t1k_ref_upload(t1k_ctx *ctx, const char *seqs, const uint64_t *offsets, cons
  * (the run length of identical sequences, Genotyper.cpp:463-480), NULL = all 1. */
 int t1k_reads_upload(t1k_ctx *ctx, const char *seqs, const uint64_t *offsets, const uint32_t *weights, uint32_t nReadEnds);
 
+/* Identical read-ends collapse onto one representative whose weight is the sum of theirs: the sort + run-length loop of
+ * Genotyper.cpp:451-480 (AssignRead is called once per distinct sequence with weight = multiplicity; the weight only feeds the
+ * per-base coverage, SeqSet.hpp:2253-2274).  After the call the context's read set is the nDistinct distinct sequences (all
+ * later read-end indices -- t1k_assign_range, t1k_pair_batch, t1k_pair_into -- refer to it) and distinctOf[i] is the index of
+ * uploaded read-end i's sequence in it.  distinctOf: host array of the uploaded size. */
+int t1k_reads_dedupe(t1k_ctx *ctx, uint32_t *distinctOf, uint32_t *nDistinct);
+
 /* One overlap of a read-end on an allele: SeqSet::_overlap (SeqSet.hpp:89-144) after AssignRead. 48 bytes. */
 typedef struct {
   int32_t seq_idx, read_start, read_end, seq_start, seq_end, strand;
@@ -87,8 +97,11 @@ typedef struct {
  * GetOverlapsFromHits 1232, GetOverlapsFromRead 1594, ExtendOverlap 1994, near-best GlobalAlignment + base coverage
  * 2188-2285).  Results stay on the device; per-base coverage accumulates in the context. */
 int t1k_assign_batch(t1k_ctx *ctx);
-/* the same for the sub-range [first, first+count) of the uploaded read-ends; read-end indices of later calls
- * (t1k_overlaps_download, t1k_pair_batch) are relative to `first` */
+/* the same for the sub-range [first, first+count) of the read set.  The final overlap lists of every read-end assigned since
+ * the read set was uploaded stay resident (the "overlap store", grown in chunks of store_chunk_factor * ovl_cap records) and are
+ * published in a table shared by all contexts that alias the read set (t1k_reads_share / t1k_reads_attach): mate pairing finds
+ * both mates' lists whichever call, on whichever context, produced them.  t1k_overlaps_download returns the lists of the last
+ * call only (its read-end indices are relative to `first`). */
 int t1k_assign_range(t1k_ctx *ctx, uint64_t first, uint32_t count);
 /* copy the overlap lists out (tests / --outputReadAssignment): counts[nReadEnds]; ovl may be NULL to query the total */
 int t1k_overlaps_download(t1k_ctx *ctx, uint32_t *counts, t1k_overlap *ovl, uint64_t cap, uint64_t *total);
@@ -100,11 +113,34 @@ typedef struct {
 } t1k_row_entry;
 
 /* SeqSet::ReadAssignmentToFragmentAssignment + Genotyper::SetReadAssignments for nFragments fragments
- * (SeqSet.hpp:2310-2655, Genotyper.hpp:778-832).  end1[i]/end2[i] index the uploaded read-ends (end2 NULL = single-end
- * run, "-u"); hasN[i] != 0 if either mate contains an N (Genotyper.cpp:537-539).  Rows stay on the device. */
+ * (SeqSet.hpp:2310-2655, Genotyper.hpp:778-832).  end1[i]/end2[i] index the context's read set (after t1k_reads_dedupe: the
+ * distinct sequences; end2 NULL = single-end run, "-u"); both read-ends must have been assigned since the upload;
+ * hasN[i] != 0 if either mate contains an N (Genotyper.cpp:537-539).  Rows stay on the device, in the reference's row order. */
 int t1k_pair_batch(t1k_ctx *ctx, const uint32_t *end1, const uint32_t *end2, const uint8_t *hasN, uint32_t nFragments);
 /* rowCounts[nFragments]; fragAssigned[nFragments] = fragmentAssigned flag (Genotyper.cpp:564-565) */
 int t1k_rows_download(t1k_ctx *ctx, uint32_t *rowCounts, uint8_t *fragAssigned, t1k_row_entry *rows, uint64_t cap, uint64_t *total);
+
+/* ---- all fragment rows of a job, resident on one GPU, and Genotyper::CoalesceReadAssignments over them ------------------------
+ * (Genotyper.hpp:841-908).  t1k_pair_into is t1k_pair_batch writing fragment i's row as fragment fragBase + i of the rowset, ordered
+ * by allele index (the order of a coalesced group's entries, 847-853), alleles outside the whitelist left out (822-823); several
+ * contexts of one GPU may append concurrently.  t1k_rowset_coalesce then folds all fragments into read groups in fragment order:
+ * groups numbered by first appearance, start = min, the `end` rule of 893-894 and the float weight sums evaluated in exactly the
+ * reference's order (bit-identical, whatever the batching).  Results: groupPtr[nGroups + 1] into entries[nEntries];
+ * firstFragment[nGroups] = the fragment that opened each group. */
+typedef struct {
+  int32_t allele, start, end;
+  float weight, adjust_weight;
+} t1k_group_entry;
+int t1k_rowset_create(t1k_ctx *owner, uint64_t nFragments, const uint8_t *whitelist /* [nAlleles] or NULL */, t1k_rowset **out);
+void t1k_rowset_destroy(t1k_rowset *rs);
+const char *t1k_rowset_last_error(const t1k_rowset *rs);
+int t1k_pair_into(t1k_ctx *ctx, t1k_rowset *rs, const uint32_t *end1, const uint32_t *end2, const uint8_t *hasN, uint32_t nFragments, uint64_t fragBase);
+int t1k_rowset_coalesce(t1k_rowset *rs, uint64_t *nGroups, uint64_t *nEntries, uint64_t *assignedFragments);
+int t1k_rowset_groups_download(t1k_rowset *rs, uint64_t *groupPtr, t1k_group_entry *entries, uint32_t *firstFragment);
+/* fragAssigned[nFragments]: Genotyper.cpp:564-565 */
+int t1k_rowset_assigned_download(t1k_rowset *rs, uint8_t *fragAssigned);
+/* rows of fragments [first, first + count) in the reference's row order (--outputReadAssignment, tests) */
+int t1k_rowset_rows_download(t1k_rowset *rs, uint64_t first, uint32_t count, uint32_t *rowCounts, t1k_row_entry *rows, uint64_t cap, uint64_t *total);
 
 /* per-base coverage of each allele's own base (posWeight[pos].count[base], SeqSet.hpp:2253-2274, read back by
  * GetSeqMissingBaseCoverage 2717-2755).  out[sum of allele lengths], alleles concatenated in upload order. */
@@ -117,6 +153,9 @@ int t1k_missing_coverage(t1k_ctx *ctx, int32_t *missing);
  * reference (and gets its own, zeroed coverage array) / src's packed reads.  src must outlive dst. */
 int t1k_ref_share(t1k_ctx *dst, const t1k_ctx *src);
 int t1k_reads_share(t1k_ctx *dst, const t1k_ctx *src);
+/* the same with a choice of the overlap-store slot (0 or 1) dst writes its lists to, emptied first if resetStore != 0: a job
+ * keeps two read sets (windows of fragments) in flight, so the lists of one stay valid while the next is being assigned */
+int t1k_reads_attach(t1k_ctx *dst, const t1k_ctx *src, int storeSlot, int resetStore);
 /* adds src's coverage into dst's and clears src's; both contexts must live on the same device and hold the same reference */
 int t1k_coverage_absorb(t1k_ctx *dst, t1k_ctx *src);
 
@@ -160,6 +199,12 @@ typedef struct {
   /* kernel time (HIP events on the launch stream), summed over the batches of the last run:
      ms_seed = k_seed_groups, ms_chain = the remaining chain kernels, ms_fullalign = k_fullalign + DP kernels + k_truncate */
   double ms_seed, ms_chain, ms_extend, ms_select, ms_fullalign, ms_pair, ms_em, ms_total;
+  /* job level (t1k_job_stats): read_ends above counts the DISTINCT read-ends the kernels ran on, read_ends_total all of them;
+     pair_overlaps = overlap records read by mate pairing; dp_cells = cell updates of the traced alignment kernels;
+     wall-clock phases of the last run: mapping + indexing the read files, the window loop on the device, coalescing + download,
+     writing the output files */
+  uint64_t read_ends_total, pair_overlaps, dp_cells;
+  double ms_load, ms_device, ms_coalesce, ms_write;
 } t1k_stats;
 int t1k_stats_get(t1k_ctx *ctx, t1k_stats *out);
 
@@ -186,9 +231,11 @@ void t1k_job_destroy(t1k_job *job);
 const char *t1k_job_last_error(const t1k_job *job);
 /* load + keep reads on the host (FASTA/FASTQ, optionally gz); file2 NULL = single-end; barcodeFile may be NULL */
 int t1k_job_load_reads(t1k_job *job, const char *file1, const char *file2, const char *barcodeFile);
+/* several files per mate, read back to back (ReadFiles::AddReadFile, Genotyper.cpp: every -u / -1 / -2 adds one); files2 NULL = single-end */
+int t1k_job_load_reads_multi(t1k_job *job, const char *const *files1, uint32_t n1, const char *const *files2, uint32_t n2, const char *barcodeFile);
 /* or hand reads over from memory: concatenated ASCII + offsets, mates parallel; ids may be NULL ("r<i>") */
 int t1k_job_set_reads(t1k_job *job, const char *seq1, const uint64_t *off1, const char *seq2, const uint64_t *off2, uint32_t nFragments);
-/* move the read batch(es) into HBM ahead of the timed region (bench) */
+/* no-op kept from round 1 (reads used to be uploaded ahead of t1k_job_run; they now stream through the GPU window by window inside it) */
 int t1k_job_stage_reads(t1k_job *job);
 /* read-end assignment, pairing, coalescing, EC build, EM, allele selection (Genotyper.cpp:451-650) */
 int t1k_job_run(t1k_job *job);

@@ -23,8 +23,8 @@ class T1kError(RuntimeError):
 class Params(C.Structure):
     _fields_ = [("kmer_length", C.c_int32), ("radius", C.c_int32), ("hit_len_required", C.c_int32),
                 ("ref_seq_similarity", C.c_double), ("relax_intron_align", C.c_int32), ("max_assign_cnt", C.c_int32),
-                ("max_read_len", C.c_int32), ("workgroups", C.c_int32), ("hit_cap", C.c_int64), ("group_cap", C.c_int64),
-                ("cand_cap", C.c_int64), ("ovl_cap", C.c_int64), ("row_cap", C.c_int64), ("n_base_code", C.c_int32)]
+                ("max_read_len", C.c_int32), ("workgroups", C.c_int32), ("group_cap", C.c_int64),
+                ("cand_cap", C.c_int64), ("ovl_cap", C.c_int64), ("row_cap", C.c_int64), ("n_base_code", C.c_int32), ("store_chunk_factor", C.c_int32)]
 
 
 class JobParams(C.Structure):
@@ -37,7 +37,9 @@ class JobParams(C.Structure):
 class Stats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("read_ends", "lookups", "postings", "hits", "groups", "candidates", "extended",
                                           "near_best", "dp_calls", "rows", "batches")] + \
-               [(n, C.c_double) for n in ("ms_seed", "ms_chain", "ms_extend", "ms_select", "ms_fullalign", "ms_pair", "ms_em", "ms_total")]
+               [(n, C.c_double) for n in ("ms_seed", "ms_chain", "ms_extend", "ms_select", "ms_fullalign", "ms_pair", "ms_em", "ms_total")] + \
+               [(n, C.c_uint64) for n in ("read_ends_total", "pair_overlaps", "dp_cells")] + \
+               [(n, C.c_double) for n in ("ms_load", "ms_device", "ms_coalesce", "ms_write")]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

@@ -1,6 +1,8 @@
 // t1k_amd/csrc/host/job.cpp -- the whole genotyper stage as a job: the t1k_job_* C ABI and t1k_genotyper_main(), the
 // argv-compatible replacement of the reference's genotyper executable (Genotyper.cpp:194-738, invoked by run-t1k:430,434).
 #include <getopt.h>
+#include <unistd.h>
+#include <atomic>
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
@@ -22,25 +24,21 @@ struct t1k_job {
   std::string err;
   RefSet ref;
   Genotyper gt;
-  t1k_ctx *ctx = nullptr;
+  t1k_ctx *ctx = nullptr;           // owns the reference, pipeline 0, final stages (missing coverage, coalescing, EM)
   std::vector<t1k_ctx *> more;      // further pipelines on the same GPU (own stream and batch arenas): several batches in flight
-  // reads: read-end 2f / 2f+1 are the mates of fragment f (single-end: read-end f)
-  bool paired = false;
-  uint32_t nFrag = 0;
-  std::string ends;                 // concatenated ASCII of all read-ends, interleaved
-  std::vector<uint64_t> endOff;     // [nEnds + 1]
-  std::vector<std::string> id1, id2, barcode;
-  std::vector<uint8_t> hasN, fragAssigned;
-  bool hasBarcode = false;
-  int maxReadLen = 0;
-  bool staged = false, ran = false, localDone = false;
+  t1k_ctx *reader[2] = {nullptr, nullptr};  // the read sets of two consecutive windows of fragments (upload, pack, identical-read-end collapse)
+  std::unique_ptr<ReadInput> in;    // the read files, mapped and indexed
+  t1k_rowset *rows = nullptr;       // every fragment's row, resident on the GPU until the job is coalesced
+  std::vector<uint8_t> fragAssigned;
+  bool ran = false, localDone = false;
   std::vector<char> whitelist;      // per allele, empty = everything allowed
   std::string abundanceFile;
   std::string assignText;           // --outputReadAssignment rows
   t1k_stats stats{};
+  uint64_t distinctReadEnds = 0, readEnds = 0;
   t1k_allreduce_fn allreduce = nullptr;
   void *allreduceUser = nullptr;
-  double msUpload = 0, msDevice = 0, msHost = 0, msEm = 0;
+  double msLoad = 0, msDevice = 0, msHost = 0, msEm = 0, msCoalesce = 0, msWrite = 0;
 };
 
 static double nowMs() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
@@ -48,6 +46,24 @@ static double nowMs() { return std::chrono::duration<double, std::milli>(std::ch
 static int jobFail(t1k_job *job, int code, const std::string &msg) {
   if (job) job->err = msg;
   return code;
+}
+
+// host threads for parsing, window assembly and the output writers: -t, but never fewer than the machine offers (up to 32) --
+// the GPU path is fed by the host, and the reference's -t default of 1 would starve it
+static int hostThreads(const t1k_job *job) {
+  if (const char *e = getenv("T1K_HOST_THREADS")) return std::max(1, atoi(e));
+  const int hw = (int)std::thread::hardware_concurrency();
+  return std::max(1, std::max(job->prm.threads, std::min(hw, 32)));
+}
+
+template <class F>
+static void parallelRanges(size_t n, int T, F fn) {  // fn(t, begin, end) over contiguous pieces of [0, n)
+  T = (int)std::max<size_t>(1, std::min<size_t>((size_t)T, n / 4096 + 1));
+  if (T == 1) { fn(0, (size_t)0, n); return; }
+  std::vector<std::thread> th;
+  const size_t per = (n + T - 1) / T;
+  for (int t = 0; t < T; ++t) th.emplace_back([=] { fn(t, std::min(n, t * per), std::min(n, (t + 1) * per)); });
+  for (auto &x : th) x.join();
 }
 
 extern "C" {
@@ -73,10 +89,12 @@ int t1k_job_create(const t1k_job_params *p, const char *refFasta, t1k_job **out)
   t1k_job *job = new t1k_job();
   if (p) job->prm = *p; else t1k_job_params_default(&job->prm);
   *out = job;  // handed back even on failure so the caller can read the message
+  const double t0 = nowMs();
   if (!job->ref.load(refFasta, job->prm.allele_digit_units, job->prm.allele_delimiter, job->err)) return T1K_ERR_IO;
   job->gt.ref = &job->ref;
   job->gt.prm = job->prm;
   if (job->prm.device < 0) return T1K_OK;  // host-only job: group bookkeeping for tests / merging, no device work possible
+  const double t1 = nowMs();
   int rc = t1k_ctx_create(job->prm.device, &job->prm.dev, &job->ctx);
   if (rc != T1K_OK) return jobFail(job, rc, "cannot create a GPU context on device " + std::to_string(job->prm.device) + " (this build has no CPU path)");
   // upload the reference
@@ -91,8 +109,8 @@ int t1k_job_create(const t1k_job_params *p, const char *refFasta, t1k_job **out)
   }
   rc = t1k_ref_upload(job->ctx, blob.data(), off.data(), ex.data(), (uint32_t)R.seqs.size());
   if (rc != T1K_OK) return jobFail(job, rc, t1k_last_error(job->ctx));
-  // Most kernels of the path are latency-bound; a second, independent pipeline (context, stream, arenas) on the same GPU lets
-  // the hardware overlap two batches.  T1K_PIPELINES=1 turns it off.
+  // Most kernels of the path are latency-bound; further independent pipelines (context, stream, arenas) on the same GPU let
+  // the hardware overlap several batches.  T1K_PIPELINES=1 turns it off.
   const char *pl = getenv("T1K_PIPELINES");
   const int nPipe = pl ? std::max(1, std::min(8, atoi(pl))) : 4;
   for (int i = 1; i < nPipe; ++i) {
@@ -102,14 +120,17 @@ int t1k_job_create(const t1k_job_params *p, const char *refFasta, t1k_job **out)
     if (rc != T1K_OK) { if (c) t1k_ctx_destroy(c); break; }  // not enough memory: run with the pipelines we have
     job->more.push_back(c);
   }
-  job->gt.ref = &job->ref;
-  job->gt.prm = job->prm;
+  for (int i = 0; i < 2; ++i)
+    if ((rc = t1k_ctx_create(job->prm.device, &job->prm.dev, &job->reader[i])) != T1K_OK) return jobFail(job, rc, "cannot create a read-set context");
+  if (getenv("T1K_DEBUG_PHASES")) fprintf(stderr, "[t1k job] reference: parse + naming + gene similarity %.1f ms, pack + index + upload + contexts %.1f ms\n", t1 - t0, nowMs() - t1);
   return T1K_OK;
 }
 
 void t1k_job_destroy(t1k_job *job) {
   if (!job) return;
-  for (t1k_ctx *c : job->more) t1k_ctx_destroy(c);  // before job->ctx, whose reference and reads they alias
+  if (job->rows) t1k_rowset_destroy(job->rows);
+  for (t1k_ctx *c : job->more) t1k_ctx_destroy(c);  // before job->ctx, whose reference they alias
+  for (t1k_ctx *c : job->reader) if (c) t1k_ctx_destroy(c);
   if (job->ctx) t1k_ctx_destroy(job->ctx);
   delete job;
 }
@@ -117,71 +138,34 @@ void t1k_job_destroy(t1k_job *job) {
 const char *t1k_job_last_error(const t1k_job *job) { return job ? job->err.c_str() : "no job"; }
 t1k_ctx *t1k_job_ctx(t1k_job *job) { return job ? job->ctx : nullptr; }
 
-static void addFragment(t1k_job *job, const std::string &s1, const std::string *s2) {
-  job->ends += s1;
-  job->endOff.push_back(job->ends.size());
-  bool n = s1.find('N') != std::string::npos;
-  job->maxReadLen = std::max<int>(job->maxReadLen, (int)s1.size());
-  if (s2) {
-    job->ends += *s2;
-    job->endOff.push_back(job->ends.size());
-    n = n || s2->find('N') != std::string::npos;
-    job->maxReadLen = std::max<int>(job->maxReadLen, (int)s2->size());
-  }
-  job->hasN.push_back(n ? 1 : 0);
-  ++job->nFrag;
-}
-
-static void clearReads(t1k_job *job) {
-  job->ends.clear(); job->endOff.assign(1, 0); job->id1.clear(); job->id2.clear(); job->barcode.clear(); job->hasN.clear();
-  job->nFrag = 0; job->maxReadLen = 0; job->staged = false; job->ran = false; job->hasBarcode = false;
+int t1k_job_load_reads_multi(t1k_job *job, const char *const *files1, uint32_t n1, const char *const *files2, uint32_t n2, const char *barcodeFile) {
+  if (!job || !files1 || n1 == 0) return T1K_ERR_ARG;
+  const double t0 = nowMs();
+  job->in.reset(new ReadInput());
+  job->ran = false; job->localDone = false;
+  std::vector<std::string> f1(files1, files1 + n1), f2;
+  if (files2) f2.assign(files2, files2 + n2);
+  if (!job->in->open(f1, f2, barcodeFile ? barcodeFile : "", hostThreads(job), job->err)) { job->in.reset(); return T1K_ERR_IO; }
+  job->msLoad = nowMs() - t0;
+  if (getenv("T1K_DEBUG_PHASES")) fprintf(stderr, "[t1k job] read files mapped + indexed: %zu fragments, %.1f ms\n", job->in->nFrag(), job->msLoad);
+  return T1K_OK;
 }
 
 int t1k_job_load_reads(t1k_job *job, const char *file1, const char *file2, const char *barcodeFile) {
   if (!job || !file1) return T1K_ERR_ARG;
-  clearReads(job);
-  std::vector<SeqRec> r1, r2, bc;
-  if (!readSeqFile(file1, r1, job->err)) return T1K_ERR_IO;
-  job->paired = file2 != nullptr;
-  if (file2 && !readSeqFile(file2, r2, job->err)) return T1K_ERR_IO;
-  if (file2 && r2.size() != r1.size()) return jobFail(job, T1K_ERR_IO, "mate files hold different numbers of reads");
-  if (barcodeFile) {
-    if (!readSeqFile(barcodeFile, bc, job->err)) return T1K_ERR_IO;
-    if (bc.size() != r1.size()) return jobFail(job, T1K_ERR_IO, "barcode file and read file hold different numbers of records");
-    job->hasBarcode = true;
-  }
-  for (size_t i = 0; i < r1.size(); ++i) {
-    if (barcodeFile && bc[i].seq == "missing_barcode") continue;  // dropped with its mate (Genotyper.cpp:376-381)
-    addFragment(job, r1[i].seq, file2 ? &r2[i].seq : nullptr);
-    job->id1.push_back(r1[i].id);
-    if (file2) job->id2.push_back(r2[i].id);
-    if (barcodeFile) job->barcode.push_back(bc[i].seq);
-  }
-  return T1K_OK;
+  return t1k_job_load_reads_multi(job, &file1, 1, file2 ? &file2 : nullptr, file2 ? 1 : 0, barcodeFile);
 }
 
 int t1k_job_set_reads(t1k_job *job, const char *seq1, const uint64_t *off1, const char *seq2, const uint64_t *off2, uint32_t nFragments) {
   if (!job || !seq1 || !off1 || (seq2 && !off2)) return T1K_ERR_ARG;
-  clearReads(job);
-  job->paired = seq2 != nullptr;
-  for (uint32_t i = 0; i < nFragments; ++i) {
-    std::string a(seq1 + off1[i], seq1 + off1[i + 1]);
-    if (seq2) { std::string b(seq2 + off2[i], seq2 + off2[i + 1]); addFragment(job, a, &b); }
-    else addFragment(job, a, nullptr);
-  }
+  job->in.reset(new ReadInput());
+  job->ran = false; job->localDone = false;
+  job->in->setMemory(seq1, off1, seq2, off2, nFragments);
   return T1K_OK;
 }
 
-int t1k_job_stage_reads(t1k_job *job) {
+int t1k_job_stage_reads(t1k_job *job) {  // kept for callers of round 1: reads now stream through the GPU window by window inside t1k_job_run
   if (!job || !job->ctx) return T1K_ERR_STATE;
-  double t0 = nowMs();
-  uint32_t nEnds = (uint32_t)(job->endOff.size() - 1);
-  int rc = t1k_reads_upload(job->ctx, job->ends.data(), job->endOff.data(), nullptr, nEnds);
-  if (rc != T1K_OK) return jobFail(job, rc, t1k_last_error(job->ctx));
-  for (t1k_ctx *c : job->more)
-    if ((rc = t1k_reads_share(c, job->ctx)) != T1K_OK) return jobFail(job, rc, t1k_last_error(c));  // one packed copy of the reads
-  job->staged = true;
-  job->msUpload = nowMs() - t0;
   return T1K_OK;
 }
 
@@ -216,131 +200,282 @@ static bool loadAbundance(t1k_job *job) {
   return true;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The device half of the stage (Genotyper.cpp:443-650 up to the coalesced read groups).
+//
+// Fragments stream through the GPU in windows of T1K_WINDOW fragments (file order).  A window is prepared by its own thread
+// on one of two read-set contexts -- the read-ends' text gathered from the mapped files by the host threads, uploaded, packed,
+// identical read-ends collapsed (t1k_reads_dedupe: the reference's sort + run-length loop, Genotyper.cpp:451-480) -- while the
+// pipelines work on the window before it.  Work items of a window: AssignRead over ranges of its distinct read-ends, then -- once
+// all of those are done, because a fragment's mates are scattered over the ranges -- mate pairing over ranges of its fragments
+// straight into the job's rowset.  A pipeline that finds no item left in the oldest window starts on the next one (its lists go
+// to the other slot of the pipeline's overlap store), so the GPU does not drain at window boundaries.
+// ------------------------------------------------------------------------------------------------------------------
+namespace {
+struct Window {
+  uint32_t f0 = 0, f1 = 0;          // fragments [f0, f1)
+  int slot = 0;                     // read-set context and overlap-store slot
+  uint32_t nDistinct = 0;
+  std::vector<uint32_t> distinctOf; // per read-end of the window: index in the distinct set
+  std::vector<uint8_t> hasN;        // per fragment
+  uint32_t assignBatch = 0, nAssign = 0, nextAssign = 0, doneAssign = 0;
+  uint32_t pairBatch = 0, nPair = 0, nextPair = 0, donePair = 0;
+  bool ready = false, done = false;
+  std::vector<char> touched;        // per pipeline: has it attached to this window yet (first touch empties its store slot)
+};
+}  // namespace
+
 int t1k_job_run_local(t1k_job *job) {
   if (!job || !job->ctx) return jobFail(job, T1K_ERR_STATE, "this job has no GPU context (device = -1): it cannot run");
+  if (!job->in) return jobFail(job, T1K_ERR_STATE, "no reads loaded");
   int rc;
-  if (!job->staged && (rc = t1k_job_stage_reads(job)) != T1K_OK) return rc;
   // fresh state (a job may be run repeatedly, e.g. by the benchmark)
   Genotyper &gt = job->gt;
+  const ReadInput &in = *job->in;
   gt.groupPtr.assign(1, 0); gt.groupEnt.clear(); gt.groupOfHash.clear(); gt.assignedFragments = 0; gt.emIterations = 0;
-  gt.readLength = job->maxReadLen;  // Genotyper.cpp:443
+  gt.readLength = in.maxLen;  // Genotyper.cpp:443
   for (auto &a : job->ref.al) { a.rank = -1; a.quality = -1; a.abundance = a.ecAbundance = 0; a.ec = -1; a.missingCov = 0; }
-  job->fragAssigned.assign(job->nFrag, 0);
+  const uint32_t F = (uint32_t)in.nFrag();
+  const uint32_t per = in.paired ? 2 : 1;
+  job->fragAssigned.assign(F, 0);
   job->assignText.clear();
   memset(&job->stats, 0, sizeof(job->stats));
+  job->distinctReadEnds = 0; job->readEnds = (uint64_t)F * per;
+  if (in.maxLen > job->prm.dev.max_read_len && job->prm.dev.max_read_len > 0)
+    return jobFail(job, T1K_ERR_ARG, "a read of " + std::to_string(in.maxLen) + " bases is longer than this build handles (" + std::to_string(job->prm.dev.max_read_len) + ")");
   if ((rc = t1k_coverage_reset(job->ctx)) != T1K_OK) return jobFail(job, rc, t1k_last_error(job->ctx));
   for (t1k_ctx *c : job->more)
     if ((rc = t1k_coverage_reset(c)) != T1K_OK) return jobFail(job, rc, t1k_last_error(c));
-  const uint32_t F = job->nFrag;
-  const uint32_t per = job->paired ? 2 : 1;
-  double tDev = 0, tHost = 0;
-  // One worker per pipeline.  A worker takes the next contiguous range of fragments, runs the device stages on its context,
-  // downloads the rows, and then -- when every earlier range has been absorbed (coalescing is order-dependent) --
-  // does the host half (whitelist filter, assignment text, read-group coalescing) while the other worker's batch is on the GPU.
-  struct HostBatch {
-    uint32_t b0 = 0, nb = 0;
-    std::vector<uint32_t> rowCounts;
-    std::vector<uint8_t> assigned;
-    std::vector<t1k_row_entry> rows;
-  };
+  if (job->rows) { t1k_rowset_destroy(job->rows); job->rows = nullptr; }
+  {
+    std::vector<uint8_t> wl(job->whitelist.begin(), job->whitelist.end());
+    if ((rc = t1k_rowset_create(job->ctx, F, wl.empty() ? nullptr : wl.data(), &job->rows)) != T1K_OK) return jobFail(job, rc, t1k_last_error(job->ctx));
+  }
+  const double tStart = nowMs();
+  const int T = hostThreads(job);
+  std::vector<t1k_ctx *> pipes{job->ctx};
+  pipes.insert(pipes.end(), job->more.begin(), job->more.end());
+  const int P = (int)pipes.size();
+  uint32_t windowFrags = 1u << 21;
+  if (const char *e = getenv("T1K_WINDOW")) windowFrags = (uint32_t)std::max(64, atoi(e));
+  uint32_t assignBatch = job->prm.batch_fragments > 0 ? (uint32_t)job->prm.batch_fragments * per : 32768u;
+  if (const char *eb = getenv("T1K_BATCH")) assignBatch = (uint32_t)std::max(64, atoi(eb)) * per;  // tuning aid (in fragments, as in round 1)
+  const uint32_t pairBatch = 1u << 16;
+  const uint32_t nWin = F ? (F + windowFrags - 1) / windowFrags : 0;
+  std::vector<Window> win(nWin);
+  for (uint32_t w = 0; w < nWin; ++w) {
+    win[w].f0 = w * windowFrags; win[w].f1 = (uint32_t)std::min<uint64_t>(F, (uint64_t)(w + 1) * windowFrags);
+    win[w].slot = (int)(w & 1);
+    win[w].touched.assign(P, 0);
+  }
   struct Shared {
     std::mutex m;
     std::condition_variable cv;
-    uint32_t next = 0, absorbNext = 0, batch = 16384;
     int err = T1K_OK;
     std::string errMsg;
+    uint32_t oldest = 0;  // first window that is not done
   } sh;
-  sh.batch = job->prm.batch_fragments > 0 ? (uint32_t)job->prm.batch_fragments : 16384u;
-  if (const char *eb = getenv("T1K_BATCH")) sh.batch = std::max(64, atoi(eb));  // tuning aid
-  auto absorb = [job, &gt, &tHost](HostBatch &hb) {
-    const double t1 = nowMs();
-    uint64_t p = 0;
-    for (uint32_t i = 0; i < hb.nb; ++i) {
-      job->fragAssigned[hb.b0 + i] = hb.assigned[i];
-      uint32_t n = hb.rowCounts[i];
-      t1k_row_entry *row = hb.rows.data() + p;
-      p += n;
-      if (!job->whitelist.empty()) {  // SetReadAssignments skips alleles outside the whitelist (Genotyper.hpp:822-823)
-        uint32_t w = 0;
-        for (uint32_t j = 0; j < n; ++j)
-          if (job->whitelist[row[j].allele_idx]) row[w++] = row[j];
-        n = w;
-      }
-      if (job->prm.output_read_assignment) {
-        const std::string id = job->id1.empty() ? "r" + std::to_string(hb.b0 + i) : job->id1[hb.b0 + i];
-        for (uint32_t j = 0; j < n; ++j)
-          job->assignText += id + "\t" + job->ref.al[row[j].allele_idx].name + "\t" + std::to_string(row[j].start) + "\t" + std::to_string(row[j].end) + "\n";
-      }
-      gt.coalesce(row, n);
-    }
-    tHost += nowMs() - t1;
+  auto fail = [&](int code, const std::string &msg) {
+    std::lock_guard<std::mutex> g(sh.m);
+    if (sh.err == T1K_OK) { sh.err = code; sh.errMsg = msg; }
+    sh.cv.notify_all();
   };
-  // device stages of fragments [b0, b0 + nb) on one context; on a capacity error nothing has been committed: split the range
-  std::function<int(t1k_ctx *, uint32_t, uint32_t, std::vector<HostBatch> &, std::string &)> runRange =
-      [&](t1k_ctx *ctx, uint32_t b0, uint32_t nb, std::vector<HostBatch> &out, std::string &msg) -> int {
-    int r = t1k_assign_range(ctx, (uint64_t)b0 * per, nb * per);
+  double msPrep = 0;
+  // ---- window preparation ------------------------------------------------------------------------------------------
+  auto prepare = [&] {
+    std::vector<char> text[2];
+    std::vector<uint64_t> offs[2];
+    for (uint32_t w = 0; w < nWin; ++w) {
+      Window &W = win[w];
+      {
+        std::unique_lock<std::mutex> lk(sh.m);
+        sh.cv.wait(lk, [&] { return sh.err != T1K_OK || w < 2 || win[w - 2].done; });  // the read-set context of window w - 2 is free again
+        if (sh.err != T1K_OK) return;
+      }
+      const double t0 = nowMs();
+      const uint32_t nf = W.f1 - W.f0, ne = nf * per;
+      std::vector<uint64_t> &off = offs[W.slot];
+      std::vector<char> &tx = text[W.slot];
+      off.resize((size_t)ne + 1);
+      W.hasN.resize(nf);
+      // lengths -> offsets (pieces, then a carry per piece), then the text itself
+      std::vector<uint64_t> pieceBytes(T + 2, 0);
+      parallelRanges(nf, T, [&](int t, size_t b, size_t e) {
+        uint64_t run = 0;
+        for (size_t i = b; i < e; ++i) {
+          const uint32_t r = in.frag[W.f0 + i];
+          for (uint32_t m = 0; m < per; ++m) { off[i * per + m] = run; run += in.side[m].seqL[r]; }
+        }
+        pieceBytes[t + 1] = run;
+      });
+      for (int t = 0; t < T; ++t) pieceBytes[t + 1] += pieceBytes[t];  // pieces the loop did not use hold 0
+      const uint64_t total = pieceBytes[T];
+      tx.resize(total + 16);
+      parallelRanges(nf, T, [&](int t, size_t b, size_t e) {
+        const uint64_t carry = pieceBytes[t];
+        for (size_t i = b; i < e; ++i) {
+          const uint32_t r = in.frag[W.f0 + i];
+          bool n = false;
+          for (uint32_t m = 0; m < per; ++m) {
+            const uint32_t len = in.side[m].seqL[r];
+            const uint64_t at = (off[i * per + m] += carry);
+            memcpy(tx.data() + at, in.side[m].seqP[r], len);
+            n = n || memchr(in.side[m].seqP[r], 'N', len) != nullptr;  // Genotyper.cpp: hasN = strchr(seq, 'N')
+          }
+          W.hasN[i] = n ? 1 : 0;
+        }
+      });
+      off[ne] = total;
+      t1k_ctx *rd = job->reader[W.slot];
+      int r = t1k_reads_upload(rd, tx.data(), off.data(), nullptr, ne);
+      W.distinctOf.resize(ne);
+      if (r == T1K_OK) r = t1k_reads_dedupe(rd, W.distinctOf.data(), &W.nDistinct);
+      if (r != T1K_OK) { fail(r, t1k_last_error(rd)); return; }
+      W.assignBatch = assignBatch; W.nAssign = (W.nDistinct + assignBatch - 1) / assignBatch;
+      W.pairBatch = pairBatch; W.nPair = (nf + pairBatch - 1) / pairBatch;
+      {
+        std::lock_guard<std::mutex> g(sh.m);
+        job->distinctReadEnds += W.nDistinct;
+        msPrep += nowMs() - t0;
+        W.ready = true;
+      }
+      sh.cv.notify_all();
+    }
+  };
+  // ---- pipelines -------------------------------------------------------------------------------------------------------
+  // AssignRead over distinct read-ends [b0, b0 + nb) of a window; on a capacity error of a stage before anything is committed the range is split
+  std::function<int(t1k_ctx *, uint32_t, uint32_t, std::string &)> assignRange = [&](t1k_ctx *ctx, uint32_t b0, uint32_t nb, std::string &msg) -> int {
+    int r = t1k_assign_range(ctx, b0, nb);
     if (r == T1K_ERR_CAPACITY && nb > 64) {
-      { std::lock_guard<std::mutex> g(sh.m); sh.batch = std::max<uint32_t>(64, std::min(sh.batch, nb / 2)); }
-      if ((r = runRange(ctx, b0, nb / 2, out, msg)) != T1K_OK) return r;
-      return runRange(ctx, b0 + nb / 2, nb - nb / 2, out, msg);
+      if ((r = assignRange(ctx, b0, nb / 2, msg)) != T1K_OK) return r;
+      return assignRange(ctx, b0 + nb / 2, nb - nb / 2, msg);
     }
     if (r != T1K_OK) { msg = t1k_last_error(ctx); return r; }
-    std::vector<uint32_t> e1(nb), e2(nb);
-    for (uint32_t i = 0; i < nb; ++i) { e1[i] = i * per; e2[i] = i * per + 1; }
-    if ((r = t1k_pair_batch(ctx, e1.data(), job->paired ? e2.data() : nullptr, job->hasN.data() + b0, nb)) != T1K_OK) { msg = t1k_last_error(ctx); return r; }
-    out.emplace_back();
-    HostBatch &hb = out.back();
-    hb.b0 = b0; hb.nb = nb;
-    hb.rowCounts.resize(nb); hb.assigned.resize(nb);
-    uint64_t total = 0;
-    if ((r = t1k_rows_download(ctx, hb.rowCounts.data(), hb.assigned.data(), nullptr, 0, &total)) != T1K_OK) { msg = t1k_last_error(ctx); return r; }
-    hb.rows.resize(total);
-    if ((r = t1k_rows_download(ctx, hb.rowCounts.data(), hb.assigned.data(), hb.rows.data(), total, &total)) != T1K_OK) { msg = t1k_last_error(ctx); return r; }
     t1k_stats st;
     t1k_stats_get(ctx, &st);
     std::lock_guard<std::mutex> g(sh.m);
     job->stats.read_ends += st.read_ends; job->stats.lookups += st.lookups; job->stats.postings += st.postings; job->stats.hits += st.hits;
     job->stats.groups += st.groups; job->stats.candidates += st.candidates; job->stats.extended += st.extended; job->stats.near_best += st.near_best;
     job->stats.dp_calls += st.dp_calls; job->stats.ms_chain += st.ms_chain; job->stats.ms_extend += st.ms_extend; job->stats.ms_select += st.ms_select;
-    job->stats.ms_fullalign += st.ms_fullalign; job->stats.ms_pair += st.ms_pair; job->stats.ms_seed += st.ms_seed; job->stats.batches += 1;
-    job->stats.rows += total;
+    job->stats.ms_fullalign += st.ms_fullalign; job->stats.ms_seed += st.ms_seed; job->stats.batches += 1; job->stats.dp_cells += st.dp_cells;
     return T1K_OK;
   };
-  auto worker = [&](t1k_ctx *ctx) {
+  auto worker = [&](int pi) {
+    t1k_ctx *ctx = pipes[pi];
+    int attached = -1;
+    std::vector<uint32_t> e1, e2;
     for (;;) {
-      uint32_t b0, nb;
+      uint32_t w = 0, item = 0;
+      int kind = -1;  // 0 assign, 1 pair
+      {
+        std::unique_lock<std::mutex> lk(sh.m);
+        for (;;) {
+          if (sh.err != T1K_OK) return;
+          if (sh.oldest >= nWin) return;
+          for (w = sh.oldest; w < nWin && w < sh.oldest + 2 && win[w].ready && kind < 0; ++w) {
+            Window &W = win[w];
+            if (W.doneAssign == W.nAssign && W.nextPair < W.nPair) { kind = 1; item = W.nextPair++; }
+            else if (W.nextAssign < W.nAssign) { kind = 0; item = W.nextAssign++; }
+            if (kind >= 0) break;
+          }
+          if (kind >= 0) break;
+          sh.cv.wait(lk);
+        }
+      }
+      Window &W = win[w];
+      int r = T1K_OK;
+      std::string msg;
+      if (attached != (int)w) {
+        r = t1k_reads_attach(ctx, job->reader[W.slot], W.slot, W.touched[pi] ? 0 : 1);
+        if (r != T1K_OK) msg = t1k_last_error(ctx);
+        W.touched[pi] = 1;
+        attached = (int)w;
+      }
+      if (r == T1K_OK && kind == 0) {
+        const uint32_t b0 = item * W.assignBatch, nb = std::min(W.assignBatch, W.nDistinct - b0);
+        r = assignRange(ctx, b0, nb, msg);
+      } else if (r == T1K_OK) {
+        const uint32_t q0 = item * W.pairBatch, nq = std::min(W.pairBatch, (W.f1 - W.f0) - q0);
+        e1.resize(nq); e2.resize(nq);
+        for (uint32_t i = 0; i < nq; ++i) { e1[i] = W.distinctOf[(size_t)(q0 + i) * per]; if (per == 2) e2[i] = W.distinctOf[(size_t)(q0 + i) * per + 1]; }
+        r = t1k_pair_into(ctx, job->rows, e1.data(), per == 2 ? e2.data() : nullptr, W.hasN.data() + q0, nq, (uint64_t)W.f0 + q0);
+        if (r != T1K_OK) msg = t1k_last_error(ctx);
+        else {
+          t1k_stats st;
+          t1k_stats_get(ctx, &st);
+          std::lock_guard<std::mutex> g(sh.m);
+          job->stats.ms_pair += st.ms_pair; job->stats.pair_overlaps += st.pair_overlaps; job->stats.rows += st.rows;
+        }
+      }
+      if (r != T1K_OK) { fail(r, msg); return; }
       {
         std::lock_guard<std::mutex> g(sh.m);
-        if (sh.err != T1K_OK || sh.next >= F) return;
-        b0 = sh.next; nb = std::min(sh.batch, F - b0); sh.next += nb;
+        if (kind == 0) ++W.doneAssign; else ++W.donePair;
+        if (W.doneAssign == W.nAssign && W.donePair == W.nPair) {
+          W.done = true;
+          std::vector<uint32_t>().swap(W.distinctOf);
+          while (sh.oldest < nWin && win[sh.oldest].done) ++sh.oldest;
+        }
       }
-      std::vector<HostBatch> done;
-      std::string msg;
-      const int r = runRange(ctx, b0, nb, done, msg);
-      std::unique_lock<std::mutex> lk(sh.m);
-      sh.cv.wait(lk, [&] { return sh.absorbNext == b0 || sh.err != T1K_OK; });
-      if (r != T1K_OK && sh.err == T1K_OK) { sh.err = r; sh.errMsg = msg; }
-      if (sh.err != T1K_OK) { sh.cv.notify_all(); return; }
-      lk.unlock();
-      for (auto &hb : done) absorb(hb);  // this worker holds the turn: nobody else absorbs until absorbNext moves on
-      lk.lock();
-      sh.absorbNext = b0 + nb;
       sh.cv.notify_all();
     }
   };
   {
-    const double t0 = nowMs();
+    std::thread prep(prepare);
     std::vector<std::thread> others;
-    for (t1k_ctx *c : job->more) others.emplace_back(worker, c);
-    worker(job->ctx);
+    for (int i = 1; i < P; ++i) others.emplace_back(worker, i);
+    worker(0);
     for (auto &t : others) t.join();
-    tDev = nowMs() - t0;  // wall time of the batch loop; the host half of the batches is hidden inside it
-    tHost = 0;
+    { std::lock_guard<std::mutex> g(sh.m); if (sh.err == T1K_OK && sh.oldest < nWin) { sh.err = T1K_ERR_INTERNAL; sh.errMsg = "window loop ended early"; } }
+    sh.cv.notify_all();
+    prep.join();
   }
   if (sh.err != T1K_OK) return jobFail(job, sh.err, sh.errMsg);
+  const double tDev = nowMs();
   for (t1k_ctx *c : job->more)
     if ((rc = t1k_coverage_absorb(job->ctx, c)) != T1K_OK) return jobFail(job, rc, t1k_last_error(job->ctx));
-  job->msDevice = tDev; job->msHost = tHost;
+  // ---- CoalesceReadAssignments over all fragments (t1k_coalesce.hip), groups back to the host ---------------------------
+  uint64_t G = 0, N = 0, assigned = 0;
+  if ((rc = t1k_rowset_coalesce(job->rows, &G, &N, &assigned)) != T1K_OK) return jobFail(job, rc, t1k_rowset_last_error(job->rows));
+  gt.groupPtr.assign(G + 1, 0);
+  gt.groupEnt.resize(N);
+  static_assert(sizeof(GroupEntry) == sizeof(t1k_group_entry), "group entry layouts differ");
+  if ((rc = t1k_rowset_groups_download(job->rows, gt.groupPtr.data(), (t1k_group_entry *)gt.groupEnt.data(), nullptr)) != T1K_OK)
+    return jobFail(job, rc, t1k_rowset_last_error(job->rows));
+  gt.assignedFragments = assigned;
+  if ((rc = t1k_rowset_assigned_download(job->rows, job->fragAssigned.data())) != T1K_OK) return jobFail(job, rc, t1k_rowset_last_error(job->rows));
+  job->stats.read_ends_total = job->readEnds;
+  if (job->prm.output_read_assignment) {  // Genotyper.cpp:553-560: the rows in the reference's order, before coalescing
+    const uint32_t step = 1u << 18;
+    std::vector<uint32_t> cnt;
+    std::vector<t1k_row_entry> rows;
+    char num[64];
+    for (uint32_t f0 = 0; f0 < F; f0 += step) {
+      const uint32_t n = std::min(step, F - f0);
+      cnt.resize(n);
+      uint64_t total = 0;
+      if ((rc = t1k_rowset_rows_download(job->rows, f0, n, cnt.data(), nullptr, 0, &total)) != T1K_OK) return jobFail(job, rc, t1k_rowset_last_error(job->rows));
+      rows.resize(total);
+      if (total && (rc = t1k_rowset_rows_download(job->rows, f0, n, cnt.data(), rows.data(), total, &total)) != T1K_OK) return jobFail(job, rc, t1k_rowset_last_error(job->rows));
+      uint64_t p = 0;
+      for (uint32_t i = 0; i < n; ++i) {
+        const uint32_t r = in.frag[f0 + i];
+        const std::string id = in.noIds ? "r" + std::to_string(f0 + i) : std::string(in.side[0].idP[r], in.side[0].idL[r]);
+        for (uint32_t j = 0; j < cnt[i]; ++j, ++p) {
+          job->assignText += id; job->assignText += '\t'; job->assignText += job->ref.al[rows[p].allele_idx].name;
+          snprintf(num, sizeof(num), "\t%d\t%d\n", rows[p].start, rows[p].end);
+          job->assignText += num;
+        }
+      }
+    }
+  }
+  t1k_rowset_destroy(job->rows);
+  job->rows = nullptr;
+  job->msDevice = tDev - tStart; job->msCoalesce = nowMs() - tDev; job->msHost = 0;
+  job->stats.ms_load = job->msLoad; job->stats.ms_device = job->msDevice; job->stats.ms_coalesce = job->msCoalesce;
+  if (getenv("T1K_DEBUG_PHASES"))
+    fprintf(stderr, "[t1k job] %u windows, %llu read-ends -> %llu distinct; window preparation %.1f ms (overlapped), device loop %.1f ms, coalesce + download %.1f ms (%llu groups, %llu entries)\n",
+            nWin, (unsigned long long)job->readEnds, (unsigned long long)job->distinctReadEnds, msPrep, job->msDevice, job->msCoalesce, (unsigned long long)G, (unsigned long long)N);
   job->localDone = true;
   return T1K_OK;
 }
@@ -365,7 +500,7 @@ int t1k_job_finish(t1k_job *job, uint64_t emGroupBegin, uint64_t emGroupEnd) {
   gt.select();
   double t5 = nowMs();
   job->msHost += (t3 - t2) + (t5 - t4); job->msEm = t4 - t3;
-  job->stats.ms_total = job->msDevice + job->msHost + job->msEm;
+  job->stats.ms_total = job->msLoad + job->msDevice + job->msCoalesce + job->msHost + job->msEm;
   job->stats.ms_em = job->msEm;
   if (getenv("T1K_DEBUG_PHASES"))
     fprintf(stderr, "[t1k job] device+download %.1f ms, host coalesce+finalize %.1f ms, EM %.1f ms, dropUnlikely %.1f ms, select %.1f ms\n", job->msDevice,
@@ -446,7 +581,7 @@ int t1k_job_genotype_text(t1k_job *job, char *buf, uint64_t cap, uint64_t *neede
 
 int t1k_job_counts(t1k_job *job, uint64_t *fragments, uint64_t *assignedFragments, uint64_t *groups, uint64_t *ecs, int32_t *emIterations) {
   if (!job) return T1K_ERR_ARG;
-  if (fragments) *fragments = job->nFrag;
+  if (fragments) *fragments = job->in ? job->in->nFrag() : 0;
   if (assignedFragments) *assignedFragments = job->gt.assignedFragments;
   if (groups) *groups = job->gt.nGroups();
   if (ecs) *ecs = job->gt.ecAlleles.size();
@@ -468,8 +603,64 @@ static bool writeText(const std::string &path, const std::string &text, std::str
   return true;
 }
 
+// ">id\nSEQ\n" of every assigned fragment (Genotyper.cpp:680-718), formatted by the host threads straight from the mapped input and
+// written with pwrite at precomputed offsets; what = 0 / 1: the mate's sequence, 2: the barcode
+static bool writeAligned(t1k_job *job, const std::string &path, int what, int T) {
+  const ReadInput &in = *job->in;
+  const uint32_t F = (uint32_t)in.nFrag();
+  FILE *fp = fopen(path.c_str(), "w");
+  if (!fp) { job->err = "cannot write " + path; return false; }
+  const int fd = fileno(fp);
+  const ReadInput::Side &seqSide = what == 2 ? in.bc : in.side[what];
+  const ReadInput::Side &idSide = what == 1 ? in.side[1] : in.side[0];  // the barcode file carries mate 1's name (Genotyper.cpp:709-718)
+  auto idOf = [&](uint32_t f, char *tmp) -> std::pair<const char *, size_t> {
+    if (in.noIds) { int n = snprintf(tmp, 32, "r%u", f); return {tmp, (size_t)n}; }
+    const uint32_t r = in.frag[f];
+    return {idSide.idP[r], idSide.idL[r]};
+  };
+  std::vector<uint64_t> pieceBytes(T + 2, 0);
+  parallelRanges(F, T, [&](int t, size_t b, size_t e) {
+    uint64_t run = 0;
+    char tmp[32];
+    for (size_t f = b; f < e; ++f)
+      if (job->fragAssigned[f]) run += 3 + idOf((uint32_t)f, tmp).second + seqSide.seqL[in.frag[f]];
+    pieceBytes[t + 1] = run;
+  });
+  for (int t = 0; t < T + 1; ++t) pieceBytes[t + 1] += pieceBytes[t];
+  std::atomic<bool> ok{true};
+  parallelRanges(F, T, [&](int t, size_t b, size_t e) {
+    uint64_t at = pieceBytes[t];
+    std::vector<char> buf;
+    buf.reserve(8u << 20);
+    char tmp[32];
+    auto flush = [&] {
+      size_t done = 0;
+      while (done < buf.size()) {
+        ssize_t w = pwrite(fd, buf.data() + done, buf.size() - done, (off_t)(at + done));
+        if (w <= 0) { ok = false; break; }
+        done += (size_t)w;
+      }
+      at += buf.size();
+      buf.clear();
+    };
+    for (size_t f = b; f < e; ++f) {
+      if (!job->fragAssigned[f]) continue;
+      const auto id = idOf((uint32_t)f, tmp);
+      const uint32_t r = in.frag[f];
+      buf.push_back('>'); buf.insert(buf.end(), id.first, id.first + id.second); buf.push_back('\n');
+      buf.insert(buf.end(), seqSide.seqP[r], seqSide.seqP[r] + seqSide.seqL[r]); buf.push_back('\n');
+      if (buf.size() > (7u << 20)) flush();
+    }
+    flush();
+  });
+  fclose(fp);
+  if (!ok) { job->err = "cannot write " + path; return false; }
+  return true;
+}
+
 int t1k_job_write_outputs(t1k_job *job, const char *prefix) {
-  if (!job || !prefix || !job->ran) return T1K_ERR_STATE;
+  if (!job || !prefix || !job->ran || !job->in) return T1K_ERR_STATE;
+  const double t0 = nowMs();
   const std::string pfx = prefix;
   std::string s;
   for (size_t g = 0; g < job->ref.geneName.size(); ++g) s += job->gt.geneLine((int)g);
@@ -477,27 +668,22 @@ int t1k_job_write_outputs(t1k_job *job, const char *prefix) {
   if (!writeText(pfx + "_allele.tsv", job->gt.alleleLines(), job->err)) return T1K_ERR_IO;
   if (job->prm.output_read_assignment && !writeText(pfx + "_assign.tsv", job->assignText, job->err)) return T1K_ERR_IO;
   // reads with at least one fragment assignment (Genotyper.cpp:680-718)
-  const uint32_t per = job->paired ? 2 : 1;
-  for (uint32_t m = 0; m < per; ++m) {
-    std::string path = job->paired ? pfx + (m == 0 ? "_aligned_1.fa" : "_aligned_2.fa") : pfx + "_aligned.fa";
-    FILE *fp = fopen(path.c_str(), "w");
-    if (!fp) return jobFail(job, T1K_ERR_IO, "cannot write " + path);
-    for (uint32_t f = 0; f < job->nFrag; ++f) {
-      if (!job->fragAssigned[f]) continue;
-      const std::vector<std::string> &ids = m == 0 ? job->id1 : job->id2;
-      uint64_t e = (uint64_t)f * per + m;
-      std::string id = ids.empty() ? "r" + std::to_string(f) : ids[f];
-      fprintf(fp, ">%s\n%.*s\n", id.c_str(), (int)(job->endOff[e + 1] - job->endOff[e]), job->ends.data() + job->endOff[e]);
-    }
-    fclose(fp);
+  const int T = hostThreads(job);
+  const bool paired = job->in->paired;
+  bool ok1 = true, ok2 = true, ok3 = true;
+  {
+    std::thread t2, t3;
+    const int per = std::max(1, T / (1 + (paired ? 1 : 0) + (job->in->hasBarcode ? 1 : 0)));
+    if (paired) t2 = std::thread([&] { ok2 = writeAligned(job, pfx + "_aligned_2.fa", 1, per); });
+    if (job->in->hasBarcode) t3 = std::thread([&] { ok3 = writeAligned(job, pfx + "_aligned_bc.fa", 2, per); });
+    ok1 = writeAligned(job, paired ? pfx + "_aligned_1.fa" : pfx + "_aligned.fa", 0, per);
+    if (t2.joinable()) t2.join();
+    if (t3.joinable()) t3.join();
   }
-  if (job->hasBarcode) {
-    FILE *fp = fopen((pfx + "_aligned_bc.fa").c_str(), "w");
-    if (!fp) return jobFail(job, T1K_ERR_IO, "cannot write " + pfx + "_aligned_bc.fa");
-    for (uint32_t f = 0; f < job->nFrag; ++f)
-      if (job->fragAssigned[f]) fprintf(fp, ">%s\n%s\n", job->id1[f].c_str(), job->barcode[f].c_str());
-    fclose(fp);
-  }
+  if (!ok1 || !ok2 || !ok3) return T1K_ERR_IO;
+  job->msWrite = nowMs() - t0;
+  job->stats.ms_write = job->msWrite;
+  if (getenv("T1K_DEBUG_PHASES")) fprintf(stderr, "[t1k job] outputs written in %.1f ms\n", job->msWrite);
   return T1K_OK;
 }
 
@@ -550,16 +736,17 @@ int t1k_genotyper_main(int argc, char **argv) {
   t1k_job_params p;
   t1k_job_params_default(&p);
   if (const char *d = getenv("T1K_DEVICE")) p.device = atoi(d);
-  std::string refFile, f1, f2, single, prefix = "t1k", barcode, whitelistFile, abundance;
+  std::string refFile, prefix = "t1k", barcode, whitelistFile, abundance;
+  std::vector<const char *> f1, f2, single;  // every -u / -1 / -2 counts: the files are read back to back (ReadFiles::AddReadFile)
   optind = 1;
   int c, idx = 0;
   while ((c = getopt_long(argc, argv, "f:a:u:1:2:o:t:n:s:b:", longOpts, &idx)) != -1) {
     switch (c) {
       case 'f': refFile = optarg; break;
       case 'a': abundance = optarg; break;
-      case 'u': single = optarg; break;
-      case '1': f1 = optarg; break;
-      case '2': f2 = optarg; break;
+      case 'u': single.push_back(optarg); break;
+      case '1': f1.push_back(optarg); break;
+      case '2': f2.push_back(optarg); break;
       case 'o': prefix = optarg; break;
       case 't': p.threads = atoi(optarg); break;
       case 'n': p.dev.max_assign_cnt = atoi(optarg); break;
@@ -608,11 +795,11 @@ int t1k_genotyper_main(int argc, char **argv) {
   }
   job->abundanceFile = abundance;
   const bool paired = !f2.empty();
-  const std::string &first = !f1.empty() ? f1 : single;
+  const std::vector<const char *> &first = !f1.empty() ? f1 : single;
   if (first.empty()) { fprintf(stderr, "genotyper: no read file given (-u, or -1 and -2)\n"); t1k_job_destroy(job); return EXIT_FAILURE; }
-  rc = t1k_job_load_reads(job, first.c_str(), paired ? f2.c_str() : nullptr, barcode.empty() ? nullptr : barcode.c_str());
+  rc = t1k_job_load_reads_multi(job, first.data(), (uint32_t)first.size(), paired ? f2.data() : nullptr, (uint32_t)f2.size(), barcode.empty() ? nullptr : barcode.c_str());
   if (rc != T1K_OK) { fprintf(stderr, "genotyper: %s\n", t1k_job_last_error(job)); t1k_job_destroy(job); return EXIT_FAILURE; }
-  logLine("Found %d read fragments. Start read assignment.", (int)job->nFrag);
+  logLine("Found %d read fragments. Start read assignment.", (int)job->in->nFrag());
   rc = t1k_job_run(job);
   if (rc != T1K_OK) { fprintf(stderr, "genotyper: %s\n", t1k_job_last_error(job)); t1k_job_destroy(job); return EXIT_FAILURE; }
   logLine("Finish read end assignments.");

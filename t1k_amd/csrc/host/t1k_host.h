@@ -4,6 +4,7 @@
 #pragma once
 #include <cstdint>
 #include <map>
+#include <memory>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -17,6 +18,39 @@ struct SeqRec {
 };
 // FASTA / FASTQ, plain or gz; id = header up to the first blank with a trailing /1 or /2 removed (ReadFiles.hpp:185-189)
 bool readSeqFile(const std::string &path, std::vector<SeqRec> &out, std::string &err);
+
+// The read files of a job, whole in memory (mmap / inflated once) with a record index built in place by the host threads
+// (host/reads.cpp).  Record i of mate m is side[m].seqP[i][0 .. seqL[i]) with name idP[i][0 .. idL[i]); nothing is copied.
+struct ReadInput {
+  struct Side {
+    std::vector<const char *> seqP, idP;
+    std::vector<uint32_t> seqL;
+    std::vector<uint16_t> idL;
+  };
+  Side side[2], bc;            // mates; barcode records (sequence = the barcode)
+  bool paired = false, hasBarcode = false, noIds = false;
+  std::vector<uint32_t> frag;  // fragment f = record frag[f] (records with a missing barcode are dropped with their mates)
+  int maxLen = 0;
+  ReadInput() = default;
+  ReadInput(const ReadInput &) = delete;
+  ReadInput &operator=(const ReadInput &) = delete;
+  ~ReadInput();
+  bool open(const std::vector<std::string> &files1, const std::vector<std::string> &files2, const std::string &barcodeFile, int threads, std::string &err);
+  void setMemory(const char *seq1, const uint64_t *off1, const char *seq2, const uint64_t *off2, uint32_t n);
+  size_t nFrag() const { return frag.size(); }
+
+ private:
+  struct Blob {
+    void *map = nullptr;
+    size_t len = 0;
+    std::unique_ptr<std::vector<char>> owned;
+  };
+  std::vector<Blob> blobs_;
+  bool addFile(const std::string &path, int threads, Side &dst, std::string &err);
+  bool addBuffer(const char *p, size_t n, int threads, Side &dst, std::string &err, const std::string &what);
+  bool addGeneral(const std::string &path, Side &dst, std::string &err);
+  void finish();
+};
 
 struct AlleleMeta {
   std::string name;

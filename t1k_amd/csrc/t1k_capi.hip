@@ -31,6 +31,18 @@ static double nowMs() { return std::chrono::duration<double, std::milli>(std::ch
 
 static inline int asciiCode(char c) { return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : 4; }
 
+// listPtr[i] = device address of read-end i's first overlap record, listCount[i] = its length (after k_truncate)
+__global__ void k_publish_lists(unsigned long long *listPtr, uint32_t *listCount, const T1kOvl *base, const uint32_t *ovlStart, const uint32_t *ovlCount, uint32_t n) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  listPtr[i] = (unsigned long long)(base + ovlStart[i]);
+  listCount[i] = ovlCount[i];
+}
+static void t1k_launch_publish_lists(t1k_ctx *ctx, unsigned long long *listPtr, uint32_t *listCount, const T1kOvl *base, const uint32_t *ovlStart, const uint32_t *ovlCount,
+                                     uint32_t n) {
+  if (n) hipLaunchKernelGGL(k_publish_lists, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, listPtr, listCount, base, ovlStart, ovlCount, n);
+}
+
 template <typename T>
 static int uploadVec(t1k_ctx *ctx, const std::vector<T> &v, const void **dst) {
   T1kDevBuf b;
@@ -57,7 +69,7 @@ void t1k_params_default(t1k_params *p) {
   p->max_read_len = 320;
   p->workgroups = 2048;
   p->n_base_code = 3;
-  p->hit_cap = 0;
+  p->store_chunk_factor = 4;
   p->group_cap = 160ll << 20;
   p->cand_cap = 128ll << 20;
   p->ovl_cap = 96ll << 20;
@@ -92,6 +104,7 @@ int t1k_ctx_create(int device, const t1k_params *params, t1k_ctx **out) {
   if (ctx->prm.cand_cap <= 0) ctx->prm.cand_cap = d.cand_cap;
   if (ctx->prm.ovl_cap <= 0) ctx->prm.ovl_cap = d.ovl_cap;
   if (ctx->prm.row_cap <= 0) ctx->prm.row_cap = d.row_cap;
+  if (ctx->prm.store_chunk_factor <= 0) ctx->prm.store_chunk_factor = d.store_chunk_factor;
   if (ctx->prm.kmer_length > 15 || ctx->prm.max_read_len > 320) { delete ctx; return T1K_ERR_ARG; }  // the hit-offset bitmask of the chain kernels spans 320 positions
   if (hipStreamCreate(&ctx->stream) != hipSuccess) { delete ctx; return T1K_ERR_DEVICE; }
   for (auto &e : ctx->ev) if (hipEventCreate(&e) != hipSuccess) { delete ctx; return T1K_ERR_DEVICE; }
@@ -111,11 +124,13 @@ void t1k_ctx_destroy(t1k_ctx *ctx) {
   (void)hipSetDevice(ctx->device);
   for (auto &b : ctx->refBufs) freeBuf(b);
   T1kDevBuf *all[] = {&ctx->bReadAscii, &ctx->bReadOffs, &ctx->bReadBases, &ctx->bReadN, &ctx->bReadLen, &ctx->bReadWeight, &ctx->bWgHits, &ctx->bWgGroups,
-                      &ctx->bWgStage, &ctx->bWgBig, &ctx->bWgCache, &ctx->bLists, &ctx->bCand, &ctx->bExt, &ctx->bCandStart, &ctx->bCandCount, &ctx->bOvl,
-                      &ctx->bOvlStart, &ctx->bOvlCount, &ctx->bCounters, &ctx->bSlowQueue, &ctx->bSlowScratch, &ctx->bSortScratch, &ctx->bEqTrace, &ctx->bSortTmp, &ctx->bSlowKeys, &ctx->bJobSort, &ctx->bEnd1, &ctx->bEnd2,
+                      &ctx->bWgStage, &ctx->bWgBig, &ctx->bWgCache, &ctx->bLists, &ctx->bCand, &ctx->bExt, &ctx->bCandStart, &ctx->bCandCount, &ctx->bListPtr, &ctx->bListCount,
+                      &ctx->bDedupScratch, &ctx->bDedupBases, &ctx->bDedupN, &ctx->bDedupLen, &ctx->bDedupWeight, &ctx->bOvlStart, &ctx->bOvlCount, &ctx->bCounters, &ctx->bSlowQueue, &ctx->bSlowScratch, &ctx->bSortScratch, &ctx->bEqTrace, &ctx->bSortTmp, &ctx->bSlowKeys, &ctx->bJobSort, &ctx->bEnd1, &ctx->bEnd2,
                       &ctx->bHasN, &ctx->bRows, &ctx->bRowStart, &ctx->bRowCount, &ctx->bFragAssigned, &ctx->bPairScratch, &ctx->bEmRowPtr, &ctx->bEmEc,
                       &ctx->bEmCount, &ctx->bEmLen, &ctx->bEmX0, &ctx->bEmN, &ctx->bEmContrib, &ctx->bEmColPtr, &ctx->bEmColIdx, &ctx->bExtract};
   for (auto *b : all) freeBuf(*b);
+  for (auto &slot : ctx->storeChunks)
+    for (auto &b : slot) freeBuf(b);
   for (auto &b : ctx->bAlign) freeBuf(b);
   for (auto &e : ctx->ev) if (e) (void)hipEventDestroy(e);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -399,14 +414,18 @@ int t1k_ref_share(t1k_ctx *dst, const t1k_ctx *src) {
   dst->ref.covDiff = (int32_t *)cov.p;
   return T1K_OK;
 }
-int t1k_reads_share(t1k_ctx *dst, const t1k_ctx *src) {
-  if (!dst || !src || dst == src || dst->device != src->device) return t1k_fail(dst, T1K_ERR_ARG, "t1k_reads_share: contexts do not match");
-  dst->reads = src->reads;  // packed read-ends are read-only for the stages; owned by src
+int t1k_reads_attach(t1k_ctx *dst, const t1k_ctx *src, int storeSlot, int resetStore) {
+  if (!dst || !src || dst == src || dst->device != src->device || storeSlot < 0 || storeSlot > 1) return t1k_fail(dst, T1K_ERR_ARG, "t1k_reads_attach: contexts do not match");
+  dst->reads = src->reads;  // packed read-ends are read-only for the stages and the list table is shared; both are owned by src
+  dst->readsShared = true;
   dst->batchMaxLen = src->batchMaxLen;
   dst->nCand = dst->nOvl = 0;
   dst->rangeCount = 0;
+  dst->storeSlot = storeSlot;
+  if (resetStore) { dst->storeChunk[storeSlot] = 0; dst->storeUsed[storeSlot] = 0; }
   return T1K_OK;
 }
+int t1k_reads_share(t1k_ctx *dst, const t1k_ctx *src) { return t1k_reads_attach(dst, src, 0, 1); }
 int t1k_coverage_absorb(t1k_ctx *dst, t1k_ctx *src) {
   if (!dst || !src || !dst->ref.covDiff || !src->ref.covDiff || dst->device != src->device || dst->ref.totalBases != src->ref.totalBases)
     return t1k_fail(dst, T1K_ERR_ARG, "t1k_coverage_absorb: contexts do not match");
@@ -464,6 +483,10 @@ int t1k_reads_upload(t1k_ctx *ctx, const char *seqs, const uint64_t *offsets, co
   if ((rc = t1k_ensure(ctx, ctx->bReadN, (size_t)n * 2 * S * 8 + 64))) return rc;
   if ((rc = t1k_ensure(ctx, ctx->bReadLen, (size_t)n * 2 + 16))) return rc;
   if ((rc = t1k_ensure(ctx, ctx->bReadWeight, (size_t)n * 4 + 16))) return rc;
+  if ((rc = t1k_ensure(ctx, ctx->bListPtr, (size_t)n * 8 + 16))) return rc;
+  if ((rc = t1k_ensure(ctx, ctx->bListCount, (size_t)n * 4 + 16))) return rc;
+  T1K_HIP(ctx, hipMemsetAsync(ctx->bListCount.p, 0, (size_t)n * 4 + 16, ctx->stream));  // a read-end that was never assigned has an empty list
+  T1K_HIP(ctx, hipMemsetAsync(ctx->bListPtr.p, 0, (size_t)n * 8 + 16, ctx->stream));
   if (n) {
     T1K_HIP(ctx, hipMemcpyAsync(ctx->bReadAscii.p, seqs, bytes, hipMemcpyHostToDevice, ctx->stream));
     T1K_HIP(ctx, hipMemcpyAsync(ctx->bReadOffs.p, offsets, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
@@ -486,6 +509,10 @@ int t1k_reads_upload(t1k_ctx *ctx, const char *seqs, const uint64_t *offsets, co
   ctx->reads.nmask = (const uint64_t *)ctx->bReadN.p;
   ctx->reads.len = (const uint16_t *)ctx->bReadLen.p;
   ctx->reads.weight = (const uint32_t *)ctx->bReadWeight.p;
+  ctx->reads.listPtr = (unsigned long long *)ctx->bListPtr.p;
+  ctx->reads.listCount = (uint32_t *)ctx->bListCount.p;
+  ctx->readsShared = false;
+  ctx->storeSlot = 0; ctx->storeChunk[0] = 0; ctx->storeUsed[0] = 0;  // the lists of the previous read set are dead
   ctx->batchMaxLen = maxLen;
   ctx->nCand = ctx->nOvl = 0;
   ctx->rangeCount = 0;
@@ -587,6 +614,7 @@ static int capacityError(t1k_ctx *ctx, unsigned long long flags) {
 
 int t1k_assign_batch(t1k_ctx *ctx) {
   if (!ctx) return T1K_ERR_ARG;
+  ctx->storeChunk[ctx->storeSlot] = 0; ctx->storeUsed[ctx->storeSlot] = 0;  // every list is recomputed
   return t1k_assign_range(ctx, 0, ctx->reads.nReadEnds);
 }
 
@@ -622,7 +650,21 @@ int t1k_assign_range(t1k_ctx *ctx, uint64_t first, uint32_t count) {
   if ((rc = t1k_ensure(ctx, ctx->bLists, ((size_t)jobCap * 2 + listWords * 12 + (size_t)genCandCap * 6 + genHitCap + (size_t)genJobCap * 2) * 4 + 64))) return rc;
   if ((rc = t1k_ensure(ctx, ctx->bCand, (size_t)ctx->prm.cand_cap * sizeof(T1kCand)))) return rc;
   if ((rc = t1k_ensure(ctx, ctx->bExt, (size_t)ctx->prm.cand_cap * sizeof(T1kExt)))) return rc;
-  if ((rc = t1k_ensure(ctx, ctx->bOvl, (size_t)ctx->prm.ovl_cap * sizeof(T1kOvl)))) return rc;
+  // this range's lists go to the end of the overlap store: the current chunk if a full ovl_cap still fits, else the next one
+  const uint64_t chunkEntries = (uint64_t)ctx->prm.ovl_cap * (uint64_t)std::max(1, ctx->prm.store_chunk_factor);
+  {
+    const int sl = ctx->storeSlot;
+    if (ctx->storeUsed[sl] + (uint64_t)ctx->prm.ovl_cap > chunkEntries) { ++ctx->storeChunk[sl]; ctx->storeUsed[sl] = 0; }
+    if (ctx->storeChunk[sl] >= ctx->storeChunks[sl].size()) ctx->storeChunks[sl].resize(ctx->storeChunk[sl] + 1);
+    T1kDevBuf &ch = ctx->storeChunks[sl][ctx->storeChunk[sl]];
+    if (ch.bytes < chunkEntries * sizeof(T1kOvl)) {
+      if (ch.p) { (void)hipFree(ch.p); ch.p = nullptr; ch.bytes = 0; }
+      hipError_t e = hipMalloc(&ch.p, chunkEntries * sizeof(T1kOvl));
+      if (e != hipSuccess) { ch.p = nullptr; return t1k_fail(ctx, T1K_ERR_DEVICE, std::string("overlap store: hipMalloc of another ") + std::to_string(chunkEntries * sizeof(T1kOvl) >> 20) + " MB chunk failed (" + hipGetErrorString(e) + "); fewer read-ends per window (T1K_WINDOW) need less"); }
+      ch.bytes = chunkEntries * sizeof(T1kOvl);
+    }
+    ctx->ovlBase = (T1kOvl *)ch.p + ctx->storeUsed[sl];
+  }
   if ((rc = t1k_ensure(ctx, ctx->bCandStart, (size_t)n * 4))) return rc;
   if ((rc = t1k_ensure(ctx, ctx->bCandCount, (size_t)n * 4))) return rc;
   if ((rc = t1k_ensure(ctx, ctx->bOvlStart, (size_t)n * 4))) return rc;
@@ -686,7 +728,7 @@ int t1k_assign_range(t1k_ctx *ctx, uint64_t first, uint32_t count) {
   double t2 = nowMs();
   SelectArgs s{};
   s.reads = rd; s.cand = a.cand; s.ext = e.ext; s.candStart = a.candStart; s.candCount = a.candCount;
-  s.ovl = (T1kOvl *)ctx->bOvl.p; s.ovlCap = (uint64_t)ctx->prm.ovl_cap;
+  s.ovl = ctx->ovlBase; s.ovlCap = (uint64_t)ctx->prm.ovl_cap;
   s.ovlStart = (uint32_t *)ctx->bOvlStart.p; s.ovlCount = (uint32_t *)ctx->bOvlCount.p;
   s.sortScratch = (uint64_t *)ctx->bSortScratch.p; s.sortCap = sortCap; s.counters = a.counters;
   s.alleleBits = 1;
@@ -763,9 +805,12 @@ int t1k_assign_range(t1k_ctx *ctx, uint64_t first, uint32_t count) {
   tr.counters = a.counters;
   t1k_launch_truncate(ctx, tr, nWg);
   T1K_HIP(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
+  // the lists are final: publish them in the read set's table (absolute read-end index) and keep their records in the store
+  t1k_launch_publish_lists(ctx, rd.listPtr + first, rd.listCount + first, ctx->ovlBase, s.ovlStart, s.ovlCount, n);
   if ((rc = fetchCounters(ctx, hc))) return rc;
   double t4 = nowMs();
   if (hc[2]) return capacityError(ctx, hc[2]);
+  ctx->storeUsed[ctx->storeSlot] += ctx->nOvl;
   if (getenv("T1K_DEBUG_PHASES")) {
     float a1 = 0, a2 = 0, a3 = 0;
     (void)hipEventElapsedTime(&a1, ctx->ev[3], ctx->ev[7]); (void)hipEventElapsedTime(&a2, ctx->ev[7], evSlow); (void)hipEventElapsedTime(&a3, evSlow, ctx->ev[4]);
@@ -800,7 +845,7 @@ int t1k_overlaps_download(t1k_ctx *ctx, uint32_t *counts, t1k_overlap *out, uint
   if (!out) return T1K_OK;
   if (cap < tot) return t1k_fail(ctx, T1K_ERR_ARG, "overlap buffer too small");
   std::vector<T1kOvl> h(ctx->nOvl);
-  if (ctx->nOvl) T1K_HIP(ctx, hipMemcpy(h.data(), ctx->bOvl.p, ctx->nOvl * sizeof(T1kOvl), hipMemcpyDeviceToHost));
+  if (ctx->nOvl) T1K_HIP(ctx, hipMemcpy(h.data(), ctx->ovlBase, ctx->nOvl * sizeof(T1kOvl), hipMemcpyDeviceToHost));
   uint64_t w = 0;
   for (uint32_t i = 0; i < n; ++i) {
     for (uint32_t j = 0; j < cnt[i]; ++j) {

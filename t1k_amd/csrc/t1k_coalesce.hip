@@ -1,0 +1,311 @@
+// t1k_amd/csrc/t1k_coalesce.hip -- Genotyper::CoalesceReadAssignments (Genotyper.hpp:841-908) on the GPU, over all fragment
+// rows of a job at once.
+//
+// The reference walks the fragments in file order: a fragment whose (allele-sorted) row pattern was seen before is folded into
+// that read group -- per entry start = min, the `end` rule of 893-894 (sic: `if (new.end < end) end = new.start`), float weights
+// added in fragment order -- otherwise it opens the next group (group ids = first-appearance order, H10).
+// Here every fragment's row stays in HBM (t1k_pair_into: ordered by allele, with a 128-bit pattern hash), and one pass at the
+// end of the job does the same thing data-parallel:
+//   1. the fragments with a non-empty row, in fragment order (scan + compaction);
+//   2. two stable 64-bit radix sorts (hash word 2, then hash word 1): equal patterns become neighbours, still in fragment order;
+//   3. a run of equal hashes is split wherever two neighbours differ in length or in any allele (a hash collision costs
+//      nothing but that comparison);
+//   4. runs are numbered by their first fragment (radix sort of the run heads) = the reference's group ids;
+//   5. one wavefront per (group, 64 slots): lane q folds slot q of the group's fragments in fragment order -- the same sequence
+//      of float additions and of the order-dependent `end` updates as the reference's loop, so the result is bit-identical and
+//      does not depend on how the fragments were batched, on the number of pipelines or (with the exchange of t1k_comm.hip) of GPUs.
+// Integer / float-add work bound by HBM latency; no MFMA.
+#include <algorithm>
+#include <cstring>
+#include "t1k_dev.h"
+#include "t1k_launch.h"
+
+struct T1kGroupEnt { int32_t allele, start, end; float weight, adjustWeight; };  // == t1k_group_entry == host GroupEntry, 20 bytes
+
+__global__ void k_co_flag(const uint32_t *rowCount, uint32_t *flag, uint32_t n) {
+  const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f < n) flag[f] = rowCount[f] ? 1u : 0u;
+}
+__global__ void k_co_compact(const uint32_t *flag, const uint32_t *pos, const unsigned long long *h2, uint32_t *idx, unsigned long long *key, uint32_t n) {
+  const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f < n && flag[f]) { idx[pos[f] - 1] = f; key[pos[f] - 1] = h2[f]; }
+}
+__global__ void k_co_gather_key(const uint32_t *idx, const unsigned long long *h, unsigned long long *key, uint32_t m) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < m) key[j] = h[idx[j]];
+}
+__global__ void k_co_mark(const uint32_t *idx, const unsigned long long *k1, const unsigned long long *h2, const unsigned long long *rowPtr, const uint32_t *rowCount,
+                          uint32_t *flag, uint32_t m) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= m) return;
+  uint32_t fl = 1;
+  if (j > 0 && k1[j] == k1[j - 1]) {
+    const uint32_t a = idx[j], b = idx[j - 1];
+    if (h2[a] == h2[b] && rowCount[a] == rowCount[b]) {
+      const t1k_row_entry *ra = (const t1k_row_entry *)rowPtr[a], *rb = (const t1k_row_entry *)rowPtr[b];
+      const uint32_t n = rowCount[a];
+      bool same = true;
+      for (uint32_t q = 0; q < n && same; ++q) same = ra[q].allele_idx == rb[q].allele_idx;
+      if (same) fl = 0;
+    }
+  }
+  flag[j] = fl;
+}
+__global__ void k_co_heads(const uint32_t *idx, const uint32_t *flag, const uint32_t *runOf, uint32_t *runStart, unsigned long long *headKey, uint32_t *headVal, uint32_t m) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= m) return;
+  if (flag[j]) { const uint32_t r = runOf[j] - 1; runStart[r] = j; headKey[r] = idx[j]; headVal[r] = r; }
+  if (j == m - 1) runStart[runOf[j]] = m;
+}
+// group g (first-appearance order) is run order[g]; its size, its 64-slot tiles
+__global__ void k_co_sizes(const uint32_t *order, const uint32_t *runStart, const uint32_t *idx, const uint32_t *rowCount, uint32_t *gSize, uint32_t *gTiles, uint32_t *gFirst,
+                           uint32_t G) {
+  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= G) return;
+  const uint32_t f = idx[runStart[order[g]]];
+  const uint32_t n = rowCount[f];
+  gSize[g] = n; gTiles[g] = (n + 63) / 64; gFirst[g] = f;
+}
+__global__ void k_co_tilemap(const unsigned long long *tilePtr, const uint32_t *gTiles, uint32_t *tileGroup, uint32_t G) {
+  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= G) return;
+  const unsigned long long b = tilePtr[g];
+  for (uint32_t t = 0; t < gTiles[g]; ++t) tileGroup[b + t] = g;
+}
+
+__device__ __forceinline__ void foldEntry(T1kGroupEnt &g, const t1k_row_entry &e) {  // Genotyper.hpp:887-897 (qual == 1 always)
+  if (e.start < g.start) g.start = e.start;
+  if (e.end < g.end) g.end = e.start;  // sic
+  g.weight += e.weight;
+  g.adjustWeight += e.adjust_weight;
+}
+
+__global__ __launch_bounds__(256) void k_co_reduce(const uint32_t *tileGroup, const unsigned long long *tilePtr, const uint32_t *order, const uint32_t *runStart,
+                                                   const uint32_t *idx, const unsigned long long *rowPtr, const uint32_t *gSize, const unsigned long long *groupPtr,
+                                                   T1kGroupEnt *out, uint64_t nTiles) {
+  const uint64_t tile = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (tile >= nTiles) return;
+  const int lane = threadIdx.x & 63;
+  const uint32_t g = tileGroup[tile];
+  const uint32_t q = (uint32_t)(tile - tilePtr[g]) * 64 + lane;
+  const uint32_t n = gSize[g];
+  const uint32_t run = order[g];
+  const uint32_t j0 = runStart[run], j1 = runStart[run + 1];
+  if (q >= n) return;
+  const t1k_row_entry first = ((const t1k_row_entry *)rowPtr[idx[j0]])[q];
+  T1kGroupEnt acc{first.allele_idx, first.start, first.end, first.weight, first.adjust_weight};
+  uint32_t j = j0 + 1;
+  for (; j + 4 <= j1; j += 4) {  // four independent loads in flight, folded in fragment order
+    const t1k_row_entry *r0 = (const t1k_row_entry *)rowPtr[idx[j]], *r1 = (const t1k_row_entry *)rowPtr[idx[j + 1]],
+                        *r2 = (const t1k_row_entry *)rowPtr[idx[j + 2]], *r3 = (const t1k_row_entry *)rowPtr[idx[j + 3]];
+    const t1k_row_entry e0 = r0[q], e1 = r1[q], e2 = r2[q], e3 = r3[q];
+    foldEntry(acc, e0); foldEntry(acc, e1); foldEntry(acc, e2); foldEntry(acc, e3);
+  }
+  for (; j < j1; ++j) { const t1k_row_entry e = ((const t1k_row_entry *)rowPtr[idx[j]])[q]; foldEntry(acc, e); }
+  out[groupPtr[g] + q] = acc;
+}
+
+// rows of fragments [f0, f0 + n) back in the reference's row order (the `qual` slot holds the position), one wave per fragment
+__global__ void k_co_unsort(const unsigned long long *rowPtr, const uint32_t *rowCount, const unsigned long long *outOff, t1k_row_entry *out, uint64_t f0, uint32_t n) {
+  const uint32_t i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n) return;
+  const int lane = threadIdx.x & 63;
+  const t1k_row_entry *r = (const t1k_row_entry *)rowPtr[f0 + i];
+  const uint32_t c = rowCount[f0 + i];
+  for (uint32_t q = lane; q < c; q += 64) {
+    t1k_row_entry e = r[q];
+    const uint32_t at = __float_as_uint(e.qual);
+    e.qual = 1.0f;
+    out[outOff[i] + at] = e;
+  }
+}
+
+static int rsFail(t1k_rowset *rs, int code, const std::string &m) { if (rs) rs->err = m; return code; }
+#define RS_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return rsFail(rs, T1K_ERR_DEVICE, std::string(#call) + ": " + hipGetErrorString(e_)); } while (0)
+
+int t1k_rowset_chunk(t1k_rowset *rs, t1k_ctx *ctx, size_t *chunk, t1k_row_entry **rows, uint64_t *cap, unsigned long long **cursor) {
+  std::lock_guard<std::mutex> g(rs->m);
+  if (rs->cur >= 1024) return t1k_fail(ctx, T1K_ERR_CAPACITY, "rowset: more than 1024 row chunks");
+  if (rs->cur >= rs->chunks.size()) rs->chunks.resize(rs->cur + 1);
+  T1kDevBuf &b = rs->chunks[rs->cur];
+  if (!b.p) {
+    hipError_t e = hipMalloc(&b.p, rs->chunkEntries * sizeof(t1k_row_entry));
+    if (e != hipSuccess) { b.p = nullptr; return t1k_fail(ctx, T1K_ERR_DEVICE, std::string("rowset: hipMalloc of a row chunk failed: ") + hipGetErrorString(e)); }
+    b.bytes = rs->chunkEntries * sizeof(t1k_row_entry);
+  }
+  *chunk = rs->cur; *rows = (t1k_row_entry *)b.p; *cap = rs->chunkEntries; *cursor = (unsigned long long *)rs->bCursors.p + rs->cur;
+  return T1K_OK;
+}
+int t1k_rowset_chunk_full(t1k_rowset *rs, t1k_ctx *, size_t chunk) {
+  std::lock_guard<std::mutex> g(rs->m);
+  if (rs->cur == chunk) ++rs->cur;
+  return T1K_OK;
+}
+
+extern "C" {
+
+int t1k_rowset_create(t1k_ctx *owner, uint64_t nFragments, const uint8_t *whitelist, t1k_rowset **out) {
+  if (!owner || !out) return T1K_ERR_ARG;
+  *out = nullptr;
+  if (nFragments >= 0xFFFFFFF0ull) return t1k_fail(owner, T1K_ERR_ARG, "t1k_rowset_create: more than 2^32 fragments on one GPU");
+  T1K_HIP(owner, hipSetDevice(owner->device));
+  t1k_rowset *rs = new t1k_rowset();
+  rs->device = owner->device; rs->owner = owner; rs->nFrag = nFragments;
+  const uint64_t F = std::max<uint64_t>(nFragments, 1);
+  int rc;
+  if ((rc = t1k_ensure(owner, rs->bFrag, F * (8 * 3 + 4 + 1) + 256)) || (rc = t1k_ensure(owner, rs->bCursors, 1024 * 8))) { delete rs; return rc; }
+  rs->rowPtr = (unsigned long long *)rs->bFrag.p; rs->h1 = rs->rowPtr + F; rs->h2 = rs->h1 + F;
+  rs->rowCount = (uint32_t *)(rs->h2 + F); rs->assigned = (uint8_t *)(rs->rowCount + F);
+  T1K_HIP(owner, hipMemsetAsync(rs->bFrag.p, 0, rs->bFrag.bytes, owner->stream));  // a fragment that is never paired has an empty row
+  T1K_HIP(owner, hipMemsetAsync(rs->bCursors.p, 0, 1024 * 8, owner->stream));
+  const char *ce = getenv("T1K_ROW_CHUNK");
+  rs->chunkEntries = ce ? std::max<uint64_t>(1u << 16, strtoull(ce, nullptr, 10)) : std::max<uint64_t>((uint64_t)owner->prm.row_cap, 64ull << 20);
+  if (whitelist) {
+    const uint32_t A = owner->ref.nAlleles;
+    if ((rc = t1k_ensure(owner, rs->bWhitelist, A))) { delete rs; return rc; }
+    T1K_HIP(owner, hipMemcpyAsync(rs->bWhitelist.p, whitelist, A, hipMemcpyHostToDevice, owner->stream));
+    rs->whitelist = (const uint8_t *)rs->bWhitelist.p;
+  }
+  T1K_HIP(owner, hipStreamSynchronize(owner->stream));
+  *out = rs;
+  return T1K_OK;
+}
+
+void t1k_rowset_destroy(t1k_rowset *rs) {
+  if (!rs) return;
+  (void)hipSetDevice(rs->device);
+  T1kDevBuf *all[] = {&rs->bFrag, &rs->bCursors, &rs->bWhitelist, &rs->bWork, &rs->bGroupPtr, &rs->bGroupEnt, &rs->bGroupFirst};
+  for (auto *b : all) if (b->p) (void)hipFree(b->p);
+  for (auto &b : rs->chunks) if (b.p) (void)hipFree(b.p);
+  delete rs;
+}
+
+const char *t1k_rowset_last_error(const t1k_rowset *rs) { return rs ? rs->err.c_str() : "no rowset"; }
+
+int t1k_rowset_coalesce(t1k_rowset *rs, uint64_t *nGroups, uint64_t *nEntries, uint64_t *assignedFragments) {
+  if (!rs) return T1K_ERR_ARG;
+  t1k_ctx *ctx = rs->owner;
+  RS_HIP(hipSetDevice(rs->device));
+  hipStream_t st = ctx->stream;
+  const uint32_t F = (uint32_t)rs->nFrag;
+  rs->nGroups = rs->nEntries = rs->nAssigned = 0;
+  rs->coalesced = true;
+  if (nGroups) *nGroups = 0;
+  if (nEntries) *nEntries = 0;
+  if (assignedFragments) *assignedFragments = 0;
+  if (F == 0) return T1K_OK;
+  int rc;
+  auto fail = [&](int code) { rs->err = ctx->err; return code; };
+  // work area: u32 arrays a0..a5 [F+2], u64 arrays k0, k1 [F+1]
+  const size_t n4 = ((size_t)(F + 2) * 4 + 255) & ~(size_t)255, n8 = ((size_t)(F + 2) * 8 + 255) & ~(size_t)255;
+  if ((rc = t1k_ensure(ctx, rs->bWork, 8 * n4 + 3 * n8))) return fail(rc);
+  char *wp = (char *)rs->bWork.p;
+  uint32_t *a0 = (uint32_t *)wp, *a1 = (uint32_t *)(wp + n4), *a2 = (uint32_t *)(wp + 2 * n4), *a3 = (uint32_t *)(wp + 3 * n4), *a4 = (uint32_t *)(wp + 4 * n4),
+           *a5 = (uint32_t *)(wp + 5 * n4), *a6 = (uint32_t *)(wp + 6 * n4), *a7 = (uint32_t *)(wp + 7 * n4);
+  unsigned long long *k0 = (unsigned long long *)(wp + 8 * n4), *k1 = (unsigned long long *)(wp + 8 * n4 + n8), *k2 = (unsigned long long *)(wp + 8 * n4 + 2 * n8);
+  const unsigned nbF = (F + 255) / 256;
+  // 1. fragments with a row, in fragment order
+  hipLaunchKernelGGL(k_co_flag, dim3(nbF), dim3(256), 0, st, rs->rowCount, a0, F);
+  if ((rc = t1k_inclusive_sum(ctx, a0, a1, F))) return fail(rc);
+  uint32_t M = 0;
+  RS_HIP(hipMemcpyAsync(&M, a1 + (F - 1), 4, hipMemcpyDeviceToHost, st));
+  RS_HIP(hipStreamSynchronize(st));
+  rs->nAssigned = M;
+  if (assignedFragments) *assignedFragments = M;
+  if (M == 0) return T1K_OK;
+  hipLaunchKernelGGL(k_co_compact, dim3(nbF), dim3(256), 0, st, a0, a1, rs->h2, a2, k0, F);  // a2 = fragment ids, k0 = hash word 2
+  const unsigned nbM = (M + 255) / 256;
+  // 2. stable sorts: by hash word 2, then by hash word 1
+  if ((rc = t1k_sort_pairs(ctx, k0, k1, a2, a3, M))) return fail(rc);                       // a3 = ids ordered by h2
+  hipLaunchKernelGGL(k_co_gather_key, dim3(nbM), dim3(256), 0, st, a3, rs->h1, k0, M);
+  if ((rc = t1k_sort_pairs(ctx, k0, k1, a3, a2, M))) return fail(rc);                       // a2 = ids ordered by (h1, h2, fragment), k1 = sorted h1
+  uint32_t *idx = a2;
+  // 3. run heads
+  hipLaunchKernelGGL(k_co_mark, dim3(nbM), dim3(256), 0, st, idx, k1, rs->h2, rs->rowPtr, rs->rowCount, a0, M);
+  if ((rc = t1k_inclusive_sum(ctx, a0, a1, M))) return fail(rc);                            // a0 = head flags, a1 = 1-based run of each position
+  uint32_t G = 0;
+  RS_HIP(hipMemcpyAsync(&G, a1 + (M - 1), 4, hipMemcpyDeviceToHost, st));
+  RS_HIP(hipStreamSynchronize(st));
+  // 4. runs numbered by their first fragment
+  uint32_t *runStart = a3, *headVal = a4, *order = a5;
+  hipLaunchKernelGGL(k_co_heads, dim3(nbM), dim3(256), 0, st, idx, a0, a1, runStart, k0, headVal, M);
+  if ((rc = t1k_sort_pairs(ctx, k0, k2, headVal, order, G, 32))) return fail(rc);
+  uint32_t *gSize = a0, *gTiles = a1, *gFirst = a6;
+  const unsigned nbG = (G + 255) / 256;
+  hipLaunchKernelGGL(k_co_sizes, dim3(nbG), dim3(256), 0, st, order, runStart, idx, rs->rowCount, gSize, gTiles, gFirst, G);
+  if ((rc = t1k_ensure(ctx, rs->bGroupPtr, ((size_t)G + 2) * 8 * 2))) return fail(rc);
+  unsigned long long *groupPtr = (unsigned long long *)rs->bGroupPtr.p, *tilePtr = groupPtr + (G + 2);
+  // exclusive sums over G + 1 elements (the element behind the last group is read but never used: make it defined)
+  RS_HIP(hipMemsetAsync(gSize + G, 0, 4, st));
+  RS_HIP(hipMemsetAsync(gTiles + G, 0, 4, st));
+  if ((rc = t1k_exclusive_sum64(ctx, gSize, groupPtr, G + 1))) return fail(rc);
+  if ((rc = t1k_exclusive_sum64(ctx, gTiles, tilePtr, G + 1))) return fail(rc);
+  unsigned long long tot[2] = {0, 0};
+  RS_HIP(hipMemcpyAsync(&tot[0], groupPtr + G, 8, hipMemcpyDeviceToHost, st));
+  RS_HIP(hipMemcpyAsync(&tot[1], tilePtr + G, 8, hipMemcpyDeviceToHost, st));
+  RS_HIP(hipStreamSynchronize(st));
+  const uint64_t N = tot[0], nTiles = tot[1];
+  if (nTiles >= 0xFFFFFFFFull) return rsFail(rs, T1K_ERR_CAPACITY, "t1k_rowset_coalesce: too many group tiles");
+  if ((rc = t1k_ensure(ctx, rs->bGroupEnt, N * sizeof(T1kGroupEnt) + 64))) return fail(rc);
+  if ((rc = t1k_ensure(ctx, rs->bGroupFirst, ((size_t)G + 1) * 4 + nTiles * 4 + 64))) return fail(rc);
+  uint32_t *tileGroup = (uint32_t *)rs->bGroupFirst.p + (G + 1);
+  RS_HIP(hipMemcpyAsync(rs->bGroupFirst.p, gFirst, (size_t)G * 4, hipMemcpyDeviceToDevice, st));
+  hipLaunchKernelGGL(k_co_tilemap, dim3(nbG), dim3(256), 0, st, tilePtr, gTiles, tileGroup, G);
+  // 5. fold every (group, slot) in fragment order
+  hipLaunchKernelGGL(k_co_reduce, dim3((unsigned)((nTiles + 3) / 4)), dim3(256), 0, st, tileGroup, tilePtr, order, runStart, idx, rs->rowPtr, gSize, groupPtr,
+                     (T1kGroupEnt *)rs->bGroupEnt.p, nTiles);
+  RS_HIP(hipStreamSynchronize(st));
+  rs->nGroups = G; rs->nEntries = N;
+  if (nGroups) *nGroups = G;
+  if (nEntries) *nEntries = N;
+  return T1K_OK;
+}
+
+int t1k_rowset_groups_download(t1k_rowset *rs, uint64_t *groupPtr, t1k_group_entry *entries, uint32_t *firstFragment) {
+  if (!rs || !rs->coalesced) return rsFail(rs, T1K_ERR_STATE, "t1k_rowset_groups_download: not coalesced");
+  RS_HIP(hipSetDevice(rs->device));
+  const uint64_t G = rs->nGroups;
+  if (groupPtr) {
+    if (G) RS_HIP(hipMemcpy(groupPtr, rs->bGroupPtr.p, (G + 1) * 8, hipMemcpyDeviceToHost));
+    else groupPtr[0] = 0;
+  }
+  if (entries && rs->nEntries) RS_HIP(hipMemcpy(entries, rs->bGroupEnt.p, rs->nEntries * sizeof(T1kGroupEnt), hipMemcpyDeviceToHost));
+  if (firstFragment && G) RS_HIP(hipMemcpy(firstFragment, rs->bGroupFirst.p, G * 4, hipMemcpyDeviceToHost));
+  return T1K_OK;
+}
+
+int t1k_rowset_assigned_download(t1k_rowset *rs, uint8_t *fragAssigned) {
+  if (!rs || !fragAssigned) return T1K_ERR_ARG;
+  RS_HIP(hipSetDevice(rs->device));
+  if (rs->nFrag) RS_HIP(hipMemcpy(fragAssigned, rs->assigned, rs->nFrag, hipMemcpyDeviceToHost));
+  return T1K_OK;
+}
+
+int t1k_rowset_rows_download(t1k_rowset *rs, uint64_t first, uint32_t count, uint32_t *rowCounts, t1k_row_entry *rows, uint64_t cap, uint64_t *total) {
+  if (!rs || !rowCounts || first + count > rs->nFrag) return rsFail(rs, T1K_ERR_ARG, "t1k_rowset_rows_download: bad arguments");
+  RS_HIP(hipSetDevice(rs->device));
+  if (total) *total = 0;
+  if (!count) return T1K_OK;
+  RS_HIP(hipMemcpy(rowCounts, rs->rowCount + first, (size_t)count * 4, hipMemcpyDeviceToHost));
+  std::vector<unsigned long long> off(count);
+  uint64_t tot = 0;
+  for (uint32_t i = 0; i < count; ++i) { off[i] = tot; tot += rowCounts[i]; }
+  if (total) *total = tot;
+  if (!rows || !tot) return T1K_OK;
+  if (cap < tot) return rsFail(rs, T1K_ERR_ARG, "t1k_rowset_rows_download: row buffer too small");
+  void *dOff = nullptr, *dOut = nullptr;
+  RS_HIP(hipMalloc(&dOff, (size_t)count * 8));
+  if (hipMalloc(&dOut, tot * sizeof(t1k_row_entry)) != hipSuccess) { (void)hipFree(dOff); return rsFail(rs, T1K_ERR_DEVICE, "t1k_rowset_rows_download: out of device memory"); }
+  hipStream_t st = rs->owner->stream;
+  hipError_t e = hipMemcpyAsync(dOff, off.data(), (size_t)count * 8, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_co_unsort, dim3((count + 3) / 4), dim3(256), 0, st, rs->rowPtr, rs->rowCount, (const unsigned long long *)dOff, (t1k_row_entry *)dOut, first, count);
+    e = hipMemcpyAsync(rows, dOut, tot * sizeof(t1k_row_entry), hipMemcpyDeviceToHost, st);
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  (void)hipFree(dOff); (void)hipFree(dOut);
+  if (e != hipSuccess) return rsFail(rs, T1K_ERR_DEVICE, hipGetErrorString(e));
+  return T1K_OK;
+}
+
+}  // extern "C"

@@ -91,6 +91,11 @@ struct T1kReadsDev {
   const uint64_t *nmask;        // [re][2][S]
   const uint16_t *len;
   const uint32_t *weight;
+  // the final overlap list of every read-end assigned since the read set was uploaded (published by t1k_assign_range, read by
+  // k_pair): device address of its first T1kOvl record and its length.  Lists live in the overlap stores of whichever context
+  // (pipeline) assigned the read-end; all contexts that alias one read set share this table.
+  unsigned long long *listPtr;  // [nReadEnds]
+  uint32_t *listCount;          // [nReadEnds]
 };
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -643,12 +648,22 @@ struct t1k_ctx {
   std::vector<T1kDevBuf> refBufs;
   // reads
   T1kReadsDev reads{};
-  T1kDevBuf bReadAscii, bReadOffs, bReadBases, bReadN, bReadLen, bReadWeight;
+  T1kDevBuf bReadAscii, bReadOffs, bReadBases, bReadN, bReadLen, bReadWeight, bListPtr, bListCount;
+  T1kDevBuf bDedupScratch, bDedupBases, bDedupN, bDedupLen, bDedupWeight;  // t1k_reads_dedupe
+  bool readsShared = false;      // the read set belongs to another context (t1k_reads_share)
   int batchMaxLen = 0;
   uint32_t rangeCount = 0;       // read-ends of the last t1k_assign_range
   // assignment arenas
   T1kDevBuf bWgHits, bWgGroups, bWgStage, bWgBig, bWgCache, bLists;
-  T1kDevBuf bCand, bExt, bCandStart, bCandCount, bOvl, bOvlStart, bOvlCount, bCounters, bSlowQueue, bSlowScratch, bSortScratch, bEqTrace, bSortTmp, bSlowKeys, bJobSort;
+  // Overlap store: the final overlap lists stay resident from the upload of a read set until the next one (mate pairing reads the
+  // lists of both mates, which identical-read-end collapse scatters over different batches).  Two slots (consecutive windows of a
+  // job overlap in time), each a list of chunks of storeChunkEntries records; a range is written contiguously into one chunk.
+  std::vector<T1kDevBuf> storeChunks[2];
+  int storeSlot = 0;
+  size_t storeChunk[2] = {0, 0};   // chunk being filled
+  uint64_t storeUsed[2] = {0, 0};  // records used in it
+  T1kOvl *ovlBase = nullptr;       // where the last t1k_assign_range wrote its lists (t1k_overlaps_download)
+  T1kDevBuf bCand, bExt, bCandStart, bCandCount, bOvlStart, bOvlCount, bCounters, bSlowQueue, bSlowScratch, bSortScratch, bEqTrace, bSortTmp, bSlowKeys, bJobSort;
   uint64_t nCand = 0, nOvl = 0;
   // pairing
   T1kDevBuf bEnd1, bEnd2, bHasN, bRows, bRowStart, bRowCount, bFragAssigned, bPairScratch;

@@ -1,5 +1,6 @@
 // t1k_amd/csrc/t1k_launch.h -- internal: kernel argument blocks and host launchers shared by the .hip files
 #pragma once
+#include <mutex>
 #include "t1k_dev.h"
 
 struct ChainArgs {
@@ -85,6 +86,33 @@ struct TruncArgs {
   int alleleBits;
   unsigned long long *counters;
 };
+
+// All fragment rows of a job on one GPU (t1k_pair_into appends, several contexts concurrently) and their coalescing into read
+// groups (t1k_coalesce.hip).  Rows live in chunks; a fragment's row is contiguous, ordered by allele index.
+struct t1k_rowset {
+  int device = 0;
+  t1k_ctx *owner = nullptr;         // its stream runs the coalescing kernels
+  uint64_t nFrag = 0;
+  T1kDevBuf bFrag;                  // rowPtr | h1 | h2 | rowCount | assigned
+  unsigned long long *rowPtr = nullptr, *h1 = nullptr, *h2 = nullptr;
+  uint32_t *rowCount = nullptr;
+  uint8_t *assigned = nullptr;
+  T1kDevBuf bCursors;               // one append cursor per chunk
+  std::vector<T1kDevBuf> chunks;
+  size_t cur = 0;
+  uint64_t chunkEntries = 0;
+  std::mutex m;
+  T1kDevBuf bWhitelist;
+  const uint8_t *whitelist = nullptr;
+  // coalescing results (device)
+  T1kDevBuf bWork, bGroupPtr, bGroupEnt, bGroupFirst;
+  uint64_t nGroups = 0, nEntries = 0, nAssigned = 0;
+  bool coalesced = false;
+  std::string err;
+};
+int t1k_rowset_chunk(t1k_rowset *rs, t1k_ctx *ctx, size_t *chunk, t1k_row_entry **rows, uint64_t *cap, unsigned long long **cursor);
+int t1k_rowset_chunk_full(t1k_rowset *rs, t1k_ctx *ctx, size_t chunk);
+int t1k_exclusive_sum64(t1k_ctx *ctx, const uint32_t *in, unsigned long long *out, uint32_t n);
 
 int t1k_launch_pack(t1k_ctx *ctx, const char *dAscii, const uint64_t *dOffs, uint32_t n, int S, uint64_t *bases, uint64_t *nmask, uint16_t *lens, int nCode);
 size_t t1k_slow_per_thread(int maxCells);

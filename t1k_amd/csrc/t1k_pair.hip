@@ -2,6 +2,11 @@
 //   k_pair: one 256-thread workgroup per fragment restates SeqSet::ReadAssignmentToFragmentAssignment
 //           (SeqSet.hpp:2310-2655) and Genotyper::SetReadAssignments / ReadAssignmentWeight (Genotyper.hpp:778-832,
 //           205-230) on the two overlap lists left in HBM by t1k_assign_batch.
+// The two overlap lists are found through the read set's list table (T1kReadsDev::listPtr / listCount): identical read-ends are
+// assigned once (t1k_reads_dedupe), so the mates of a fragment may have been assigned in different batches, by different contexts.
+// Two output forms: t1k_pair_batch keeps the rows of one call in the context (fragment order, list order inside a row);
+// t1k_pair_into appends them to a t1k_rowset -- all rows of a job resident in HBM, each row ordered by allele index with a
+// 128-bit pattern hash per fragment -- which t1k_rowset_coalesce (t1k_coalesce.hip) turns into read groups.
 // Mates are joined through a per-workgroup direct-address table (allele -> index in the mate's list, stamped with a
 // fragment epoch so it never needs clearing).  If an allele occurs twice in a list (several diagonal runs on one
 // allele -- rare) lane 0 replays the reference's sequential algorithm instead.
@@ -12,6 +17,14 @@
 #include "t1k_launch.h"
 
 #define WG 256
+#define SORT_TILE 2048
+
+// contribution of the allele at sorted position r to a fragment's pattern hash (summed over the row: order of evaluation is free)
+__device__ __forceinline__ unsigned long long t1k_pattern_mix(uint32_t allele, uint32_t r, unsigned long long k) {
+  unsigned long long x = ((unsigned long long)allele << 32 | r) * k;
+  x ^= x >> 31; x *= 0xD6E8FEB86659FD93ull; x ^= x >> 29;
+  return x;
+}
 
 struct Frag {
   uint32_t allele;
@@ -23,8 +36,8 @@ struct Frag {
 
 struct PairArgs {
   T1kRefDev ref;
-  const T1kOvl *ovl;
-  const uint32_t *ovlStart, *ovlCount;
+  const unsigned long long *listPtr;  // per read-end of the read set: address of its first overlap record
+  const uint32_t *listCount;
   const uint32_t *end1, *end2;     // end2 == NULL: single-end run
   const uint8_t *hasN;
   uint32_t nFragments;
@@ -36,6 +49,10 @@ struct PairArgs {
   Frag *frags; uint32_t fragCap;   // [wg][fragCap]
   uint32_t *keep;                  // [wg][fragCap]
   unsigned long long *counters;    // [2] error flags, [9] row total
+  const uint8_t *whitelist;        // [nAlleles] or NULL: alleles outside it are left out of the rows (Genotyper.hpp:822-823)
+  // rowset form (rsRowPtr != NULL): rows go to rsRows[*rsCursor ...), ordered by allele; per-fragment records at fragBase + f
+  unsigned long long *rsRowPtr; uint32_t *rsRowCount; unsigned long long *rsH1, *rsH2; uint8_t *rsAssigned;
+  t1k_row_entry *rsRows; uint64_t rsCap; unsigned long long *rsCursor; uint64_t fragBase;
 };
 
 __device__ __forceinline__ double ovlSim(const T1kOvl &o) {
@@ -139,19 +156,24 @@ __global__ __launch_bounds__(WG) void k_pair(PairArgs P) {
     const uint64_t epoch = (uint64_t)(P.epochBase + f + 1) << 32;
     const bool paired = P.end2 != nullptr;
     const uint32_t e1 = P.end1[f];
-    const uint32_t n1 = P.ovlCount[e1];
-    const T1kOvl *L1 = P.ovl + P.ovlStart[e1];
+    const uint32_t n1 = P.listCount[e1];
+    const T1kOvl *L1 = (const T1kOvl *)P.listPtr[e1];
     uint32_t n2 = 0;
     const T1kOvl *L2 = nullptr;
-    if (paired) { uint32_t e2 = P.end2[f]; n2 = P.ovlCount[e2]; L2 = P.ovl + P.ovlStart[e2]; }
+    if (paired) { uint32_t e2 = P.end2[f]; n2 = P.listCount[e2]; L2 = (const T1kOvl *)P.listPtr[e2]; }
     const bool hasN = P.hasN ? P.hasN[f] != 0 : false;
     if (tid == 0) { sDup = 0; sFail = 0; sBestM = -1; sBestIdx = 0x7FFFFFFF; sAnySep = 0; sNotOne = 0; sN = 0; }
     __syncthreads();
+    if (tid == 0 && n1 + n2) atomicAdd(&P.counters[22], (unsigned long long)(n1 + n2));  // statistics: overlap records read
     const bool dangling = paired && (n1 == 0 || n2 == 0);
     const bool both = paired && !dangling;
     uint32_t nFrag = 0;
     if (n1 + n2 > P.fragCap) {
-      if (tid == 0) { atomicOr(&P.counters[2], 128ull); P.rowStart[f] = 0; P.rowCount[f] = 0; P.fragAssigned[f] = 0; }
+      if (tid == 0) {
+        atomicOr(&P.counters[2], 128ull);
+        if (P.rsRowPtr) { P.rsRowCount[P.fragBase + f] = 0; P.rsAssigned[P.fragBase + f] = 0; }
+        else { P.rowStart[f] = 0; P.rowCount[f] = 0; P.fragAssigned[f] = 0; }
+      }
       __syncthreads();
       continue;
     }
@@ -360,27 +382,184 @@ __global__ __launch_bounds__(WG) void k_pair(PairArgs P) {
       __syncthreads();
       if (sAnySep) emptyRow = true;
     }
-    const uint32_t nRow = emptyRow ? 0 : nKept;
-    if (tid == 0) {
-      unsigned long long b = nRow ? atomicAdd(&P.counters[9], (unsigned long long)nRow) : 0ull;
-      if (b + nRow > P.rowCap) { atomicOr(&P.counters[2], 128ull); sBase = 0xFFFFFFFFu; P.rowStart[f] = 0; P.rowCount[f] = 0; }
-      else { sBase = (uint32_t)b; P.rowStart[f] = (uint32_t)b; P.rowCount[f] = nRow; }
-      P.fragAssigned[f] = nKept > 0 ? 1 : 0;
+    uint32_t nRow = emptyRow ? 0 : nKept;
+    const bool anyKept = nKept > 0;  // fragmentAssigned is set before the -n / separator / whitelist drops
+    if (nRow && P.whitelist) {      // order-preserving compaction of `keep`
+      uint32_t w = 0;
+      for (uint32_t q0 = 0; q0 < nRow; q0 += WG) {
+        const uint32_t q = q0 + tid;
+        const uint32_t kq = q < nRow ? keep[q] : 0;
+        const bool ok = q < nRow && P.whitelist[frags[kq].allele] != 0;
+        uint32_t tot;
+        const uint32_t off = scanExcl(ok ? 1u : 0u, warpSums, &tot);  // (its barriers separate the reads above from the writes below)
+        if (ok) keep[w + off] = kq;
+        w += tot;
+      }
+      __syncthreads();
+      nRow = w;
     }
-    __syncthreads();
-    if (nRow && sBase != 0xFFFFFFFFu) {
-      const double adjust = sNotOne ? 1.0 : 0.25;  // 804-817
+    const double adjust = sNotOne ? 1.0 : 0.25;  // 804-817
+    if (!P.rsRowPtr) {
+      if (tid == 0) {
+        unsigned long long b = nRow ? atomicAdd(&P.counters[9], (unsigned long long)nRow) : 0ull;
+        if (b + nRow > P.rowCap) { atomicOr(&P.counters[2], 128ull); sBase = 0xFFFFFFFFu; P.rowStart[f] = 0; P.rowCount[f] = 0; }
+        else { sBase = (uint32_t)b; P.rowStart[f] = (uint32_t)b; P.rowCount[f] = nRow; }
+        P.fragAssigned[f] = anyKept ? 1 : 0;
+      }
+      __syncthreads();
+      if (nRow && sBase != 0xFFFFFFFFu) {
+        for (uint32_t q = tid; q < nRow; q += WG) {
+          const Frag &fr = frags[keep[q]];
+          t1k_row_entry r;
+          r.allele_idx = (int32_t)fr.allele; r.start = fr.seqStart; r.end = fr.seqEnd;
+          r.weight = rowWeight(fr.sim, P.sim, hasN);
+          r.qual = 1.0f;
+          r.adjust_weight = (float)(adjust * r.weight);
+          P.rows[(uint64_t)sBase + q] = r;
+        }
+      }
+      __syncthreads();
+      continue;
+    }
+    // ---- rowset form: the row ordered by allele index (the order of a coalesced group's entries, Genotyper.hpp:847-853), its place
+    // in the list kept in the `qual` slot (all assignment qualities are 1), and a 128-bit hash of the allele pattern ---------------
+    __shared__ unsigned long long sRowBase;
+    __shared__ uint32_t sAllele[SORT_TILE];
+    __shared__ unsigned long long sHash[2][4];
+    if (tid == 0) {
+      unsigned long long b = nRow ? atomicAdd(P.rsCursor, (unsigned long long)nRow) : 0ull;
+      if (b + nRow > P.rsCap) { atomicOr(&P.counters[2], 128ull); sRowBase = ~0ull; }
+      else { sRowBase = b; if (nRow) atomicAdd(&P.counters[9], (unsigned long long)nRow); }
+    }
+    // rank of every entry among the row's (distinct) alleles
+    for (uint32_t q = tid; q < nRow; q += WG) frags[keep[q]].slot = 0;
+    for (uint32_t t0 = 0; t0 < nRow; t0 += SORT_TILE) {
+      const uint32_t tn = min(nRow - t0, (uint32_t)SORT_TILE);
+      __syncthreads();
+      for (uint32_t i = tid; i < tn; i += WG) sAllele[i] = frags[keep[t0 + i]].allele;
+      __syncthreads();
       for (uint32_t q = tid; q < nRow; q += WG) {
-        const Frag &fr = frags[keep[q]];
-        t1k_row_entry r;
-        r.allele_idx = (int32_t)fr.allele; r.start = fr.seqStart; r.end = fr.seqEnd;
-        r.weight = rowWeight(fr.sim, P.sim, hasN);
-        r.qual = 1.0f;
-        r.adjust_weight = (float)(adjust * r.weight);
-        P.rows[(uint64_t)sBase + q] = r;
+        Frag &fr = frags[keep[q]];
+        const uint32_t a = fr.allele;
+        int c = 0;
+        for (uint32_t i = 0; i < tn; ++i) c += sAllele[i] < a ? 1 : 0;
+        fr.slot += c;
       }
     }
     __syncthreads();
+    unsigned long long h1 = 0, h2 = 0;
+    const bool fits = sRowBase != ~0ull;
+    for (uint32_t q = tid; q < nRow; q += WG) {
+      const Frag &fr = frags[keep[q]];
+      const uint32_t r = (uint32_t)fr.slot;
+      h1 += t1k_pattern_mix(fr.allele, r, 0x9E3779B97F4A7C15ull);
+      h2 += t1k_pattern_mix(fr.allele, r, 0xC2B2AE3D27D4EB4Full);
+      if (fits) {
+        t1k_row_entry e;
+        e.allele_idx = (int32_t)fr.allele; e.start = fr.seqStart; e.end = fr.seqEnd;
+        e.weight = rowWeight(fr.sim, P.sim, hasN);
+        e.qual = __uint_as_float(q);  // position in the reference's row order (read back by t1k_rowset_rows_download)
+        e.adjust_weight = (float)(adjust * e.weight);
+        P.rsRows[sRowBase + r] = e;
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { h1 += __shfl_down(h1, o, 64); h2 += __shfl_down(h2, o, 64); }
+    if ((tid & 63) == 0) { sHash[0][tid >> 6] = h1; sHash[1][tid >> 6] = h2; }
+    __syncthreads();
+    if (tid == 0) {
+      const uint64_t g = P.fragBase + f;
+      P.rsRowPtr[g] = fits ? (unsigned long long)(P.rsRows + sRowBase) : 0ull;
+      P.rsRowCount[g] = fits ? nRow : 0;
+      P.rsH1[g] = sHash[0][0] + sHash[0][1] + sHash[0][2] + sHash[0][3] + 0x632BE59BD9B4E019ull * nRow;
+      P.rsH2[g] = sHash[1][0] + sHash[1][1] + sHash[1][2] + sHash[1][3] + 0xA0761D6478BD642Full * nRow;
+      P.rsAssigned[g] = anyKept ? 1 : 0;
+    }
+    __syncthreads();
+  }
+}
+
+// shared by t1k_pair_batch (rs == NULL) and t1k_pair_into
+static int pairLaunch(t1k_ctx *ctx, t1k_rowset *rs, const uint32_t *end1, const uint32_t *end2, const uint8_t *hasN, uint32_t nFragments, uint64_t fragBase,
+                      const uint8_t *dWhitelist) {
+  if (!ctx->ref.bases) return t1k_fail(ctx, T1K_ERR_STATE, "mate pairing: no reference");
+  if (!ctx->reads.listPtr) return t1k_fail(ctx, T1K_ERR_STATE, "mate pairing: no reads uploaded");
+  T1K_HIP(ctx, hipSetDevice(ctx->device));
+  int rc;
+  const uint32_t n = nFragments;
+  const int nWg = (int)std::min<uint32_t>(2048, std::max<uint32_t>(n, 1));  // the kernel is latency-bound: fill the wave slots
+  const uint32_t fragCap = 1u << 16;
+  const uint32_t A = ctx->ref.nAlleles;
+  if (!rs) { ctx->nFragments = n; ctx->nRows = 0; }
+  if ((rc = t1k_ensure(ctx, ctx->bEnd1, (size_t)n * 4))) return rc;
+  if ((rc = t1k_ensure(ctx, ctx->bEnd2, (size_t)n * 4))) return rc;
+  if ((rc = t1k_ensure(ctx, ctx->bHasN, (size_t)n))) return rc;
+  if (!rs) {
+    if ((rc = t1k_ensure(ctx, ctx->bRows, (size_t)ctx->prm.row_cap * sizeof(t1k_row_entry)))) return rc;
+    if ((rc = t1k_ensure(ctx, ctx->bRowStart, (size_t)n * 4))) return rc;
+    if ((rc = t1k_ensure(ctx, ctx->bRowCount, (size_t)n * 4))) return rc;
+    if ((rc = t1k_ensure(ctx, ctx->bFragAssigned, (size_t)n))) return rc;
+  }
+  size_t perWg = (size_t)A * 16 + (size_t)fragCap * (sizeof(Frag) + 4);
+  bool fresh = ctx->bPairScratch.bytes < (size_t)2048 * perWg;
+  if ((rc = t1k_ensure(ctx, ctx->bPairScratch, (size_t)2048 * perWg))) return rc;
+  if ((rc = t1k_ensure(ctx, ctx->bCounters, (size_t)T1K_COUNTER_WORDS * 8))) return rc;
+  if (n == 0) return T1K_OK;
+  T1K_HIP(ctx, hipMemcpyAsync(ctx->bEnd1.p, end1, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+  if (end2) T1K_HIP(ctx, hipMemcpyAsync(ctx->bEnd2.p, end2, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+  if (hasN) T1K_HIP(ctx, hipMemcpyAsync(ctx->bHasN.p, hasN, (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+  else T1K_HIP(ctx, hipMemsetAsync(ctx->bHasN.p, 0, (size_t)n, ctx->stream));
+  // the epoch of fragment f is epochBase + f + 1; the base moves on with every call, so the tables only need clearing when the
+  // 32-bit epoch space is about to wrap (or the scratch was just allocated)
+  if (fresh || ctx->pairEpoch > 0xFFFFFFFFull - 2ull * n - 2) {
+    T1K_HIP(ctx, hipMemsetAsync(ctx->bPairScratch.p, 0, (size_t)2048 * (size_t)A * 16, ctx->stream));
+    ctx->pairEpoch = 0;
+  }
+  PairArgs p{};
+  p.ref = ctx->ref;
+  p.listPtr = ctx->reads.listPtr; p.listCount = ctx->reads.listCount;
+  p.end1 = (const uint32_t *)ctx->bEnd1.p; p.end2 = end2 ? (const uint32_t *)ctx->bEnd2.p : nullptr; p.hasN = (const uint8_t *)ctx->bHasN.p;
+  p.nFragments = n; p.sim = ctx->prm.ref_seq_similarity; p.relax = ctx->prm.relax_intron_align; p.maxAssign = ctx->prm.max_assign_cnt;
+  p.hitLenRequired = ctx->prm.hit_len_required;
+  p.rows = (t1k_row_entry *)ctx->bRows.p; p.rowCap = (uint64_t)ctx->prm.row_cap;
+  p.rowStart = (uint32_t *)ctx->bRowStart.p; p.rowCount = (uint32_t *)ctx->bRowCount.p; p.fragAssigned = (uint8_t *)ctx->bFragAssigned.p;
+  uint8_t *sc = (uint8_t *)ctx->bPairScratch.p;
+  p.tab2 = (uint64_t *)sc;
+  p.tabSlot = (uint64_t *)(sc + (size_t)2048 * A * 8);
+  p.frags = (Frag *)(sc + (size_t)2048 * A * 16);
+  p.fragCap = fragCap;
+  p.keep = (uint32_t *)(sc + (size_t)2048 * A * 16 + (size_t)2048 * fragCap * sizeof(Frag));
+  p.counters = (unsigned long long *)ctx->bCounters.p;
+  p.whitelist = dWhitelist;
+  if (getenv("T1K_DEBUG_TRACE")) fprintf(stderr, "[t1k trace] pair %u fragments%s\n", n, rs ? " into the rowset" : "");
+  for (int attempt = 0;; ++attempt) {
+    T1K_HIP(ctx, hipMemsetAsync((char *)ctx->bCounters.p + 2 * 8, 0, 8, ctx->stream));
+    T1K_HIP(ctx, hipMemsetAsync((char *)ctx->bCounters.p + 9 * 8, 0, 8, ctx->stream));
+    T1K_HIP(ctx, hipMemsetAsync((char *)ctx->bCounters.p + 22 * 8, 0, 8, ctx->stream));
+    size_t chunk = 0;
+    if (rs) {
+      if ((rc = t1k_rowset_chunk(rs, ctx, &chunk, &p.rsRows, &p.rsCap, &p.rsCursor))) return rc;
+      p.rsRowPtr = rs->rowPtr; p.rsRowCount = rs->rowCount; p.rsH1 = rs->h1; p.rsH2 = rs->h2; p.rsAssigned = rs->assigned; p.fragBase = fragBase;
+    }
+    p.epochBase = (uint32_t)ctx->pairEpoch; ctx->pairEpoch += n;
+    T1K_HIP(ctx, hipEventRecord(ctx->ev[5], ctx->stream));
+    hipLaunchKernelGGL(k_pair, dim3(nWg), dim3(WG), 0, ctx->stream, p);
+    T1K_HIP(ctx, hipEventRecord(ctx->ev[6], ctx->stream));
+    if (!ctx->countersPinned) T1K_HIP(ctx, hipHostMalloc((void **)&ctx->countersPinned, (size_t)T1K_COUNTER_WORDS * 8, hipHostMallocDefault));
+    unsigned long long *hc = ctx->countersPinned;
+    T1K_HIP(ctx, hipMemcpyAsync(hc, ctx->bCounters.p, 64 * 8, hipMemcpyDeviceToHost, ctx->stream));
+    T1K_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    { float ms = 0; (void)hipEventElapsedTime(&ms, ctx->ev[5], ctx->ev[6]); ctx->stats.ms_pair = (attempt ? ctx->stats.ms_pair : 0) + ms; }
+    if (hc[2] && rs && attempt < 4) {
+      // the rowset's current chunk is full (or a fragment has more overlaps than the scratch holds: that repeats and fails below):
+      // close the chunk and run the call again; fragments are written by index, the first attempt's rows are simply left behind
+      if ((rc = t1k_rowset_chunk_full(rs, ctx, chunk))) return rc;
+      continue;
+    }
+    if (hc[2]) return t1k_fail(ctx, T1K_ERR_CAPACITY, "device arena overflow: row_cap / fragment scratch");
+    if (!rs) ctx->nRows = hc[9];
+    ctx->stats.rows = hc[9]; ctx->stats.pair_overlaps = hc[22];
+    return T1K_OK;
   }
 }
 
@@ -388,68 +567,14 @@ extern "C" {
 
 int t1k_pair_batch(t1k_ctx *ctx, const uint32_t *end1, const uint32_t *end2, const uint8_t *hasN, uint32_t nFragments) {
   if (!ctx || !end1) return t1k_fail(ctx, T1K_ERR_ARG, "t1k_pair_batch: bad arguments");
-  if (!ctx->ref.bases) return t1k_fail(ctx, T1K_ERR_STATE, "t1k_pair_batch: no reference");
-  T1K_HIP(ctx, hipSetDevice(ctx->device));
-  int rc;
-  const uint32_t n = nFragments;
-  const int nWg = (int)std::min<uint32_t>(2048, std::max<uint32_t>(n, 1));  // the kernel is latency-bound: fill the wave slots
-  const uint32_t fragCap = 1u << 16;
-  const uint32_t A = ctx->ref.nAlleles;
-  ctx->nFragments = n;
-  ctx->nRows = 0;
-  if ((rc = t1k_ensure(ctx, ctx->bEnd1, (size_t)n * 4))) return rc;
-  if ((rc = t1k_ensure(ctx, ctx->bEnd2, (size_t)n * 4))) return rc;
-  if ((rc = t1k_ensure(ctx, ctx->bHasN, (size_t)n))) return rc;
-  if ((rc = t1k_ensure(ctx, ctx->bRows, (size_t)ctx->prm.row_cap * sizeof(t1k_row_entry)))) return rc;
-  if ((rc = t1k_ensure(ctx, ctx->bRowStart, (size_t)n * 4))) return rc;
-  if ((rc = t1k_ensure(ctx, ctx->bRowCount, (size_t)n * 4))) return rc;
-  if ((rc = t1k_ensure(ctx, ctx->bFragAssigned, (size_t)n))) return rc;
-  size_t perWg = (size_t)A * 16 + (size_t)fragCap * (sizeof(Frag) + 4);
-  bool fresh = ctx->bPairScratch.bytes < (size_t)nWg * perWg;
-  if ((rc = t1k_ensure(ctx, ctx->bPairScratch, (size_t)nWg * perWg))) return rc;
-  if ((rc = t1k_ensure(ctx, ctx->bCounters, 64 * 8))) return rc;
-  if (fresh) T1K_HIP(ctx, hipMemsetAsync(ctx->bPairScratch.p, 0, (size_t)nWg * perWg, ctx->stream));  // epochs start at 0
-  if (n == 0) return T1K_OK;
-  double t0 = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
-  T1K_HIP(ctx, hipMemcpyAsync(ctx->bEnd1.p, end1, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
-  if (end2) T1K_HIP(ctx, hipMemcpyAsync(ctx->bEnd2.p, end2, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
-  if (hasN) T1K_HIP(ctx, hipMemcpyAsync(ctx->bHasN.p, hasN, (size_t)n, hipMemcpyHostToDevice, ctx->stream));
-  else T1K_HIP(ctx, hipMemsetAsync(ctx->bHasN.p, 0, (size_t)n, ctx->stream));
-  T1K_HIP(ctx, hipMemsetAsync((char *)ctx->bCounters.p + 2 * 8, 0, 8, ctx->stream));
-  T1K_HIP(ctx, hipMemsetAsync((char *)ctx->bCounters.p + 9 * 8, 0, 8, ctx->stream));
-  // the epoch of fragment f is epochBase + f + 1; the base moves on with every call, so the tables only need clearing when the
-  // 32-bit epoch space is about to wrap (or the scratch was just allocated)
-  if (fresh || ctx->pairEpoch > 0xFFFFFFFFull - 2ull * n - 2) {
-    T1K_HIP(ctx, hipMemsetAsync(ctx->bPairScratch.p, 0, (size_t)nWg * (size_t)A * 16, ctx->stream));
-    ctx->pairEpoch = 0;
-  }
-  PairArgs p{};
-  p.ref = ctx->ref;
-  p.ovl = (const T1kOvl *)ctx->bOvl.p; p.ovlStart = (const uint32_t *)ctx->bOvlStart.p; p.ovlCount = (const uint32_t *)ctx->bOvlCount.p;
-  p.end1 = (const uint32_t *)ctx->bEnd1.p; p.end2 = end2 ? (const uint32_t *)ctx->bEnd2.p : nullptr; p.hasN = (const uint8_t *)ctx->bHasN.p;
-  p.epochBase = (uint32_t)ctx->pairEpoch; ctx->pairEpoch += n;
-  p.nFragments = n; p.sim = ctx->prm.ref_seq_similarity; p.relax = ctx->prm.relax_intron_align; p.maxAssign = ctx->prm.max_assign_cnt;
-  p.hitLenRequired = ctx->prm.hit_len_required;
-  p.rows = (t1k_row_entry *)ctx->bRows.p; p.rowCap = (uint64_t)ctx->prm.row_cap;
-  p.rowStart = (uint32_t *)ctx->bRowStart.p; p.rowCount = (uint32_t *)ctx->bRowCount.p; p.fragAssigned = (uint8_t *)ctx->bFragAssigned.p;
-  uint8_t *sc = (uint8_t *)ctx->bPairScratch.p;
-  p.tab2 = (uint64_t *)sc;
-  p.tabSlot = (uint64_t *)(sc + (size_t)nWg * A * 8);
-  p.frags = (Frag *)(sc + (size_t)nWg * A * 16);
-  p.fragCap = fragCap;
-  p.keep = (uint32_t *)(sc + (size_t)nWg * A * 16 + (size_t)nWg * fragCap * sizeof(Frag));
-  p.counters = (unsigned long long *)ctx->bCounters.p;
-  if (getenv("T1K_DEBUG_TRACE")) fprintf(stderr, "[t1k trace] pair_batch %u fragments\n", n);
-  T1K_HIP(ctx, hipEventRecord(ctx->ev[5], ctx->stream));
-  hipLaunchKernelGGL(k_pair, dim3(nWg), dim3(WG), 0, ctx->stream, p);
-  T1K_HIP(ctx, hipEventRecord(ctx->ev[6], ctx->stream));
-  unsigned long long hc[64];
-  T1K_HIP(ctx, hipMemcpyAsync(hc, ctx->bCounters.p, 64 * 8, hipMemcpyDeviceToHost, ctx->stream));
-  T1K_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  if (hc[2]) return t1k_fail(ctx, T1K_ERR_CAPACITY, "device arena overflow: row_cap / fragment scratch");
-  ctx->nRows = hc[9];
-  { float ms = 0; (void)hipEventElapsedTime(&ms, ctx->ev[5], ctx->ev[6]); ctx->stats.ms_pair = ms; (void)t0; }
-  return T1K_OK;
+  return pairLaunch(ctx, nullptr, end1, end2, hasN, nFragments, 0, nullptr);
+}
+
+int t1k_pair_into(t1k_ctx *ctx, t1k_rowset *rs, const uint32_t *end1, const uint32_t *end2, const uint8_t *hasN, uint32_t nFragments, uint64_t fragBase) {
+  if (!ctx || !rs || !end1) return t1k_fail(ctx, T1K_ERR_ARG, "t1k_pair_into: bad arguments");
+  if (fragBase + nFragments > rs->nFrag) return t1k_fail(ctx, T1K_ERR_ARG, "t1k_pair_into: fragments outside the rowset");
+  if (rs->device != ctx->device) return t1k_fail(ctx, T1K_ERR_ARG, "t1k_pair_into: rowset lives on another device");
+  return pairLaunch(ctx, rs, end1, end2, hasN, nFragments, fragBase, rs->whitelist);
 }
 
 int t1k_rows_download(t1k_ctx *ctx, uint32_t *rowCounts, uint8_t *fragAssigned, t1k_row_entry *rows, uint64_t cap, uint64_t *total) {
