@@ -46,7 +46,7 @@ typedef struct {
   double ref_seq_similarity;    /* -s, default 0.8 */
   int32_t relax_intron_align;   /* --relaxIntronAlign */
   int32_t max_assign_cnt;       /* -n, default 2000 */
-  /* device arena sizing (0 = defaults) */
+  /* device arena sizing (0 = defaults).  The *_cap values are LIMITS: what a context allocates follows the demand of its ranges */
   int32_t max_read_len;         /* longest read accepted, default 320 */
   int32_t workgroups;           /* persistent workgroups of the per-read-end kernels, default 2048 */
   int64_t group_cap;            /* (read-end, strand, allele) hit groups per batch */
@@ -56,8 +56,8 @@ typedef struct {
   int32_t n_base_code;          /* the two bits a non-ACGT base contributes to a k-mer code (the code of a window holding one still decides
                                    whether its neighbour repeats the previous k-mer): 3 in the genotyper (nucToNum, Genotyper.cpp:37-40:
                                    -1 & 3), 0 in fastq-extractor (FastqExtractor.cpp:51-54: 'N' -> 0).  t1k_params_default sets 3. */
-  int32_t store_chunk_factor;   /* the overlap store (final overlap lists, resident until the next read upload) grows in chunks of
-                                   store_chunk_factor * ovl_cap records; default 4 */
+  int32_t store_chunk_mb;       /* the overlap store (final overlap lists, resident until the next read upload) grows in chunks of
+                                   this many MB (at least one range's worth); default 1536 */
 } t1k_params;
 
 void t1k_params_default(t1k_params *p);
@@ -98,7 +98,7 @@ typedef struct {
  * 2188-2285).  Results stay on the device; per-base coverage accumulates in the context. */
 int t1k_assign_batch(t1k_ctx *ctx);
 /* the same for the sub-range [first, first+count) of the read set.  The final overlap lists of every read-end assigned since
- * the read set was uploaded stay resident (the "overlap store", grown in chunks of store_chunk_factor * ovl_cap records) and are
+ * the read set was uploaded stay resident (the "overlap store", grown in chunks of store_chunk_mb) and are
  * published in a table shared by all contexts that alias the read set (t1k_reads_share / t1k_reads_attach): mate pairing finds
  * both mates' lists whichever call, on whichever context, produced them.  t1k_overlaps_download returns the lists of the last
  * call only (its read-end indices are relative to `first`). */

@@ -24,7 +24,7 @@ class Params(C.Structure):
     _fields_ = [("kmer_length", C.c_int32), ("radius", C.c_int32), ("hit_len_required", C.c_int32),
                 ("ref_seq_similarity", C.c_double), ("relax_intron_align", C.c_int32), ("max_assign_cnt", C.c_int32),
                 ("max_read_len", C.c_int32), ("workgroups", C.c_int32), ("group_cap", C.c_int64),
-                ("cand_cap", C.c_int64), ("ovl_cap", C.c_int64), ("row_cap", C.c_int64), ("n_base_code", C.c_int32), ("store_chunk_factor", C.c_int32)]
+                ("cand_cap", C.c_int64), ("ovl_cap", C.c_int64), ("row_cap", C.c_int64), ("n_base_code", C.c_int32), ("store_chunk_mb", C.c_int32)]
 
 
 class JobParams(C.Structure):

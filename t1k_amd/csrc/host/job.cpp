@@ -109,10 +109,12 @@ int t1k_job_create(const t1k_job_params *p, const char *refFasta, t1k_job **out)
   }
   rc = t1k_ref_upload(job->ctx, blob.data(), off.data(), ex.data(), (uint32_t)R.seqs.size());
   if (rc != T1K_OK) return jobFail(job, rc, t1k_last_error(job->ctx));
-  // Most kernels of the path are latency-bound; further independent pipelines (context, stream, arenas) on the same GPU let
-  // the hardware overlap several batches.  T1K_PIPELINES=1 turns it off.
+  // Most kernels of the path are latency-bound; a second independent pipeline (context, stream, arenas) on the same GPU lets the
+  // hardware overlap two batches and hides the host's share of a batch (counter fetches, launches).  Measured on the 1 M-pair HLA-like
+  // workload (device loop, arenas warm): 1 pipeline 840 ms, 2: 723 ms, 4: 678 ms -- and every pipeline's arenas are fresh VRAM that
+  // costs ~35 ms per GB, so two is the default.  T1K_PIPELINES overrides.
   const char *pl = getenv("T1K_PIPELINES");
-  const int nPipe = pl ? std::max(1, std::min(8, atoi(pl))) : 4;
+  const int nPipe = pl ? std::max(1, std::min(8, atoi(pl))) : 2;
   for (int i = 1; i < nPipe; ++i) {
     t1k_ctx *c = nullptr;
     rc = t1k_ctx_create(job->prm.device, &job->prm.dev, &c);

@@ -160,8 +160,7 @@ bool ReadInput::addGeneral(const std::string &path, Side &dst, std::string &err)
   if (!readSeqFile(path, recs, err)) return false;
   size_t bytes = 0;
   for (auto &r : recs) bytes += r.id.size() + r.seq.size();
-  blobs_.emplace_back();
-  Blob &b = blobs_.back();
+  Blob &b = newBlob();
   b.owned.reset(new std::vector<char>(bytes + 1));
   char *w = b.owned->data();
   for (auto &r : recs) {
@@ -191,16 +190,15 @@ bool ReadInput::addFile(const std::string &path, int threads, Side &dst, std::st
     ::close(fd);
     if (m == MAP_FAILED) { err = "cannot map " + path; return false; }
     (void)madvise(m, (size_t)st.st_size, MADV_WILLNEED);
-    blobs_.emplace_back();
-    blobs_.back().map = m; blobs_.back().len = (size_t)st.st_size;
+    Blob &b = newBlob();
+    b.map = m; b.len = (size_t)st.st_size;
     data = (const char *)m; size = (size_t)st.st_size;
   } else {
     ::close(fd);
     gzFile fp = gzopen(path.c_str(), "rb");  // also reads a plain stream (a pipe) transparently
     if (!fp) { err = "cannot open " + path; return false; }
     gzbuffer(fp, 1 << 20);
-    blobs_.emplace_back();
-    Blob &b = blobs_.back();
+    Blob &b = newBlob();
     b.owned.reset(new std::vector<char>());
     std::vector<char> &v = *b.owned;
     size_t used = 0;
@@ -253,8 +251,7 @@ void ReadInput::setMemory(const char *seq1, const uint64_t *off1, const char *se
   for (int m = 0; m < (paired ? 2 : 1); ++m) {
     const char *s = m ? seq2 : seq1;
     const uint64_t *o = m ? off2 : off1;
-    blobs_.emplace_back();
-    Blob &b = blobs_.back();
+    Blob &b = newBlob();
     b.owned.reset(new std::vector<char>(s + o[0], s + o[n]));
     const char *base = b.owned->data();
     Side &d = side[m];

@@ -3,7 +3,9 @@
 // equivalence classes, the SQUAREM control loop (the E-step runs on the GPU), allele selection, TSV writers.
 #pragma once
 #include <cstdint>
+#include <list>
 #include <map>
+#include <mutex>
 #include <memory>
 #include <string>
 #include <unordered_map>
@@ -45,7 +47,9 @@ struct ReadInput {
     size_t len = 0;
     std::unique_ptr<std::vector<char>> owned;
   };
-  std::vector<Blob> blobs_;
+  std::list<Blob> blobs_;  // the mates are read by concurrent threads: nodes never move, additions are serialised
+  std::mutex blobLock_;
+  Blob &newBlob() { std::lock_guard<std::mutex> g(blobLock_); blobs_.emplace_back(); return blobs_.back(); }
   bool addFile(const std::string &path, int threads, Side &dst, std::string &err);
   bool addBuffer(const char *p, size_t n, int threads, Side &dst, std::string &err, const std::string &what);
   bool addGeneral(const std::string &path, Side &dst, std::string &err);

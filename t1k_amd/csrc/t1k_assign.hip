@@ -920,7 +920,7 @@ void t1k_launch_align_fill_apply(t1k_ctx *ctx, const SlowArgs &a, bool eq) {
 }
 void t1k_launch_truncate(t1k_ctx *ctx, const TruncArgs &a, int nWg) {
   hipFuncSetAttribute((const void *)k_truncate<SELECT_LARGE, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, SELECT_LARGE * 8);
-  hipLaunchKernelGGL((k_truncate<SELECT_SMALL, 256>), dim3(nWg), dim3(256), SELECT_SMALL * 8, ctx->stream, a);
+  hipLaunchKernelGGL((k_truncate<SELECT_SMALL, 256>), dim3(std::min(nWg, 512)), dim3(256), SELECT_SMALL * 8, ctx->stream, a);  // (its staging area: 512 workgroups' worth)
   hipLaunchKernelGGL((k_truncate<SELECT_LARGE, 1024>), dim3(std::min(nWg, 512)), dim3(1024), SELECT_LARGE * 8, ctx->stream, a);
 }
 __global__ __launch_bounds__(WG) void k_coverage_add(int32_t *dst, int32_t *src, uint64_t n) {

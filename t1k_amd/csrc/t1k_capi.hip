@@ -69,7 +69,7 @@ void t1k_params_default(t1k_params *p) {
   p->max_read_len = 320;
   p->workgroups = 2048;
   p->n_base_code = 3;
-  p->store_chunk_factor = 4;
+  p->store_chunk_mb = 1536;
   p->group_cap = 160ll << 20;
   p->cand_cap = 128ll << 20;
   p->ovl_cap = 96ll << 20;
@@ -104,7 +104,7 @@ int t1k_ctx_create(int device, const t1k_params *params, t1k_ctx **out) {
   if (ctx->prm.cand_cap <= 0) ctx->prm.cand_cap = d.cand_cap;
   if (ctx->prm.ovl_cap <= 0) ctx->prm.ovl_cap = d.ovl_cap;
   if (ctx->prm.row_cap <= 0) ctx->prm.row_cap = d.row_cap;
-  if (ctx->prm.store_chunk_factor <= 0) ctx->prm.store_chunk_factor = d.store_chunk_factor;
+  if (ctx->prm.store_chunk_mb <= 0) ctx->prm.store_chunk_mb = d.store_chunk_mb;
   if (ctx->prm.kmer_length > 15 || ctx->prm.max_read_len > 320) { delete ctx; return T1K_ERR_ARG; }  // the hit-offset bitmask of the chain kernels spans 320 positions
   if (hipStreamCreate(&ctx->stream) != hipSuccess) { delete ctx; return T1K_ERR_DEVICE; }
   for (auto &e : ctx->ev) if (hipEventCreate(&e) != hipSuccess) { delete ctx; return T1K_ERR_DEVICE; }
@@ -126,7 +126,7 @@ void t1k_ctx_destroy(t1k_ctx *ctx) {
   T1kDevBuf *all[] = {&ctx->bReadAscii, &ctx->bReadOffs, &ctx->bReadBases, &ctx->bReadN, &ctx->bReadLen, &ctx->bReadWeight, &ctx->bWgHits, &ctx->bWgGroups,
                       &ctx->bWgStage, &ctx->bWgBig, &ctx->bWgCache, &ctx->bLists, &ctx->bCand, &ctx->bExt, &ctx->bCandStart, &ctx->bCandCount, &ctx->bListPtr, &ctx->bListCount,
                       &ctx->bDedupScratch, &ctx->bDedupBases, &ctx->bDedupN, &ctx->bDedupLen, &ctx->bDedupWeight, &ctx->bOvlStart, &ctx->bOvlCount, &ctx->bCounters, &ctx->bSlowQueue, &ctx->bSlowScratch, &ctx->bSortScratch, &ctx->bEqTrace, &ctx->bSortTmp, &ctx->bSlowKeys, &ctx->bJobSort, &ctx->bEnd1, &ctx->bEnd2,
-                      &ctx->bHasN, &ctx->bRows, &ctx->bRowStart, &ctx->bRowCount, &ctx->bFragAssigned, &ctx->bPairScratch, &ctx->bEmRowPtr, &ctx->bEmEc,
+                      &ctx->bHasN, &ctx->bRows, &ctx->bRowStart, &ctx->bRowCount, &ctx->bFragAssigned, &ctx->bPairScratch, &ctx->bPairOverflow, &ctx->bPairBig, &ctx->bEmRowPtr, &ctx->bEmEc,
                       &ctx->bEmCount, &ctx->bEmLen, &ctx->bEmX0, &ctx->bEmN, &ctx->bEmContrib, &ctx->bEmColPtr, &ctx->bEmColIdx, &ctx->bExtract};
   for (auto *b : all) freeBuf(*b);
   for (auto &slot : ctx->storeChunks)
@@ -597,7 +597,22 @@ extern "C++" int t1k_fetch_counters(t1k_ctx *ctx, unsigned long long *h) {
 }
 static int fetchCounters(t1k_ctx *ctx, unsigned long long *h) { return t1k_fetch_counters(ctx, h); }
 
+// An arena overflowed.  The cursors keep counting past their capacity, so the last fetched counter block holds the demand of the
+// stages that ran: remember it, t1k_assign_range sizes its working capacities from it and runs the range again.
 static int capacityError(t1k_ctx *ctx, unsigned long long flags) {
+  ctx->lastCapFlags = flags;
+  if (ctx->hRaw.size() >= T1K_COUNTER_WORDS) {
+    auto maxSeg = [&](int arena) {
+      unsigned long long m = 0;
+      for (int st = 0; st < T1K_NSTRIPE; ++st) m = std::max(m, ctx->hRaw[T1K_ARENA_BASE + ((size_t)arena * T1K_NSTRIPE + st) * 8]);
+      return m;
+    };
+    unsigned long long lists = 0;
+    for (int ar : {T1K_AR_SLOW, T1K_AR_RETRY, T1K_AR_FINISH, T1K_AR_GENERAL, T1K_AR_WAVE, T1K_AR_BIG, T1K_AR_EXTRETRY}) lists = std::max(lists, maxSeg(ar));
+    ctx->needGroup = std::max<uint64_t>(maxSeg(T1K_AR_GROUPS) * T1K_NSTRIPE, lists * T1K_NSTRIPE * T1K_LIST_DIV);
+    ctx->needCand = ctx->hRaw[0];
+    ctx->needOvl = ctx->hRaw[1];
+  }
   std::string m = "device arena overflow:";
   if (flags & 1) m += " hit_cap";
   if (flags & 2) m += " candidate staging";
@@ -618,10 +633,41 @@ int t1k_assign_batch(t1k_ctx *ctx) {
   return t1k_assign_range(ctx, 0, ctx->reads.nReadEnds);
 }
 
+static int assignOnce(t1k_ctx *ctx, uint64_t first, uint32_t count);
+
+// Working capacities.  t1k_params holds the LIMITS of the batch arenas; what is allocated follows the demand: the first range
+// starts from a floor per read-end, an overflow (always detected before anything of the range is committed) raises the working
+// capacity to the demand the device counted and the range runs again.  Fresh VRAM costs about 35 ms per GB on this platform
+// (hipMalloc of 12 GB: 0.3-0.6 s, measured), so a context that allocated its limits up front (40 GB) paid more for memory than
+// for kernels on a 1 M-pair job.
 int t1k_assign_range(t1k_ctx *ctx, uint64_t first, uint32_t count) {
   if (!ctx || !ctx->ref.bases) return t1k_fail(ctx, T1K_ERR_STATE, "t1k_assign_range: no reference uploaded");
   if (first + count > ctx->reads.nReadEnds) return t1k_fail(ctx, T1K_ERR_ARG, "t1k_assign_range: range outside the uploaded reads");
   T1K_HIP(ctx, hipSetDevice(ctx->device));
+  auto clampCap = [](uint64_t want, uint64_t floor, int64_t limit) { return std::min<uint64_t>((uint64_t)limit, std::max<uint64_t>(want, floor)); };
+  ctx->wGroup = clampCap(std::max<uint64_t>(ctx->wGroup, (uint64_t)count * 1024), 4u << 20, ctx->prm.group_cap);
+  ctx->wCand = clampCap(std::max<uint64_t>(ctx->wCand, (uint64_t)count * 512), 2u << 20, ctx->prm.cand_cap);
+  ctx->wOvl = clampCap(std::max<uint64_t>(ctx->wOvl, (uint64_t)count * 512), 2u << 20, ctx->prm.ovl_cap);
+  for (int attempt = 0;; ++attempt) {
+    ctx->lastCapFlags = 0; ctx->needGroup = ctx->needCand = ctx->needOvl = 0;
+    const int rc = assignOnce(ctx, first, count);
+    if (rc != T1K_ERR_CAPACITY || attempt >= 6) return rc;
+    bool grew = false;
+    auto grow = [&](uint64_t &w, uint64_t need, int64_t limit) {
+      if (w >= (uint64_t)limit) return;
+      w = std::min<uint64_t>((uint64_t)limit, std::max<uint64_t>(w + w / 2, need + need / 4));
+      grew = true;
+    };
+    if (ctx->lastCapFlags & 256) grow(ctx->wGroup, ctx->needGroup, ctx->prm.group_cap);
+    if (ctx->lastCapFlags & 4) grow(ctx->wCand, ctx->needCand, ctx->prm.cand_cap);
+    if (ctx->lastCapFlags & 16) grow(ctx->wOvl, ctx->needOvl, ctx->prm.ovl_cap);
+    if (!grew || (ctx->lastCapFlags & ~(256ull | 4ull | 16ull))) return rc;  // at the limits (or another arena): the caller splits the range
+    if (getenv("T1K_DEBUG_PHASES")) fprintf(stderr, "[t1k] range of %u read-ends again with capacities: groups %llu candidates %llu overlaps %llu\n", count,
+                                            (unsigned long long)ctx->wGroup, (unsigned long long)ctx->wCand, (unsigned long long)ctx->wOvl);
+  }
+}
+
+static int assignOnce(t1k_ctx *ctx, uint64_t first, uint32_t count) {
   const uint32_t n = count;
   T1kReadsDev rd = ctx->reads;  // view of the sub-range; read-end ids inside the batch are relative to `first`
   rd.nReadEnds = count;
@@ -633,7 +679,7 @@ int t1k_assign_range(t1k_ctx *ctx, uint64_t first, uint32_t count) {
   const int maxChunks = t1k_chain_max_chunks(ctx->ref.nAlleles), memoN = t1k_chain_memo_entries();
   const bool longReads = ctx->batchMaxLen > 160;
   const int recStride = t1k_chain_rec_stride(ctx->batchMaxLen);
-  const uint64_t groupCap = (uint64_t)ctx->prm.group_cap;
+  const uint64_t groupCap = ctx->wGroup;
   const uint32_t jobCap = 16u << 20, genCandCap = 16u << 20, genHitCap = 64u << 20, genJobCap = 4u << 20;
   const int bigBlocks = 32;
   if ((rc = t1k_ensure(ctx, ctx->bCounters, (size_t)T1K_COUNTER_WORDS * 8))) return rc;
@@ -645,31 +691,33 @@ int t1k_assign_range(t1k_ctx *ctx, uint64_t first, uint32_t count) {
   if ((rc = t1k_ensure(ctx, ctx->bWgBig, (size_t)bigBlocks * 64 * t1k_chain_big_scratch_u32() * 4))) return rc;
   // work lists: every list exists twice, as a striped arena the kernels append to and as the dense list its consumer reads
   const uint32_t groupSegCap = (uint32_t)std::min<uint64_t>(groupCap / T1K_NSTRIPE, 0xFFFFFFFFull / T1K_NSTRIPE);
-  const uint32_t listSegCap = std::max<uint32_t>(groupSegCap / 2, 1024u), jobSegCap = jobCap / T1K_NSTRIPE, genCandSegCap = genCandCap / T1K_NSTRIPE;
+  const uint32_t listSegCap = std::max<uint32_t>(groupSegCap / T1K_LIST_DIV, 1024u), jobSegCap = jobCap / T1K_NSTRIPE, genCandSegCap = genCandCap / T1K_NSTRIPE;
   const size_t listWords = (size_t)listSegCap * T1K_NSTRIPE;
   if ((rc = t1k_ensure(ctx, ctx->bLists, ((size_t)jobCap * 2 + listWords * 12 + (size_t)genCandCap * 6 + genHitCap + (size_t)genJobCap * 2) * 4 + 64))) return rc;
-  if ((rc = t1k_ensure(ctx, ctx->bCand, (size_t)ctx->prm.cand_cap * sizeof(T1kCand)))) return rc;
-  if ((rc = t1k_ensure(ctx, ctx->bExt, (size_t)ctx->prm.cand_cap * sizeof(T1kExt)))) return rc;
-  // this range's lists go to the end of the overlap store: the current chunk if a full ovl_cap still fits, else the next one
-  const uint64_t chunkEntries = (uint64_t)ctx->prm.ovl_cap * (uint64_t)std::max(1, ctx->prm.store_chunk_factor);
+  if ((rc = t1k_ensure(ctx, ctx->bCand, (size_t)ctx->wCand * sizeof(T1kCand)))) return rc;
+  if ((rc = t1k_ensure(ctx, ctx->bExt, (size_t)ctx->wCand * sizeof(T1kExt)))) return rc;
+  // this range's lists go to the end of the overlap store: the current chunk if the working overlap capacity still fits, else the next one
+  const uint64_t chunkEntries = std::max<uint64_t>(ctx->wOvl, (uint64_t)std::max(1, ctx->prm.store_chunk_mb) * ((1ull << 20) / sizeof(T1kOvl)));
   {
     const int sl = ctx->storeSlot;
-    if (ctx->storeUsed[sl] + (uint64_t)ctx->prm.ovl_cap > chunkEntries) { ++ctx->storeChunk[sl]; ctx->storeUsed[sl] = 0; }
-    if (ctx->storeChunk[sl] >= ctx->storeChunks[sl].size()) ctx->storeChunks[sl].resize(ctx->storeChunk[sl] + 1);
-    T1kDevBuf &ch = ctx->storeChunks[sl][ctx->storeChunk[sl]];
-    if (ch.bytes < chunkEntries * sizeof(T1kOvl)) {
-      if (ch.p) { (void)hipFree(ch.p); ch.p = nullptr; ch.bytes = 0; }
+    std::vector<T1kDevBuf> &chunks = ctx->storeChunks[sl];
+    for (;;) {
+      if (ctx->storeChunk[sl] >= chunks.size()) chunks.resize(ctx->storeChunk[sl] + 1);
+      T1kDevBuf &ch = chunks[ctx->storeChunk[sl]];
+      if (ch.p && ctx->storeUsed[sl] + ctx->wOvl <= ch.bytes / sizeof(T1kOvl)) break;   // fits behind what the chunk already holds
+      if (ch.p && ctx->storeUsed[sl] > 0) { ++ctx->storeChunk[sl]; ctx->storeUsed[sl] = 0; continue; }
+      if (ch.p) { (void)hipFree(ch.p); ch.p = nullptr; ch.bytes = 0; }  // an empty chunk that is too small for this range
       hipError_t e = hipMalloc(&ch.p, chunkEntries * sizeof(T1kOvl));
-      if (e != hipSuccess) { ch.p = nullptr; return t1k_fail(ctx, T1K_ERR_DEVICE, std::string("overlap store: hipMalloc of another ") + std::to_string(chunkEntries * sizeof(T1kOvl) >> 20) + " MB chunk failed (" + hipGetErrorString(e) + "); fewer read-ends per window (T1K_WINDOW) need less"); }
+      if (e != hipSuccess) { ch.p = nullptr; return t1k_fail(ctx, T1K_ERR_DEVICE, std::string("overlap store: hipMalloc of another ") + std::to_string(chunkEntries * sizeof(T1kOvl) >> 20) + " MB chunk failed (" + hipGetErrorString(e) + "); fewer fragments per window (T1K_WINDOW) need less"); }
       ch.bytes = chunkEntries * sizeof(T1kOvl);
     }
-    ctx->ovlBase = (T1kOvl *)ch.p + ctx->storeUsed[sl];
+    ctx->ovlBase = (T1kOvl *)chunks[ctx->storeChunk[sl]].p + ctx->storeUsed[sl];
   }
   if ((rc = t1k_ensure(ctx, ctx->bCandStart, (size_t)n * 4))) return rc;
   if ((rc = t1k_ensure(ctx, ctx->bCandCount, (size_t)n * 4))) return rc;
   if ((rc = t1k_ensure(ctx, ctx->bOvlStart, (size_t)n * 4))) return rc;
   if ((rc = t1k_ensure(ctx, ctx->bOvlCount, (size_t)n * 4))) return rc;
-  if ((rc = t1k_ensure(ctx, ctx->bSortScratch, (size_t)nWg * sortCap * 48))) return rc;
+  if ((rc = t1k_ensure(ctx, ctx->bSortScratch, (size_t)std::min(nWg, 512) * sortCap * 48))) return rc;  // only the kernels launched with <= 512 workgroups use it
   T1K_HIP(ctx, hipMemsetAsync(ctx->bCounters.p, 0, (size_t)T1K_COUNTER_WORDS * 8, ctx->stream));
   T1K_HIP(ctx, hipMemsetAsync(ctx->bOvlCount.p, 0, (size_t)n * 4 + 4, ctx->stream));
   T1K_HIP(ctx, hipMemsetAsync(ctx->bCandCount.p, 0, (size_t)n * 4 + 4, ctx->stream));
@@ -701,7 +749,7 @@ int t1k_assign_range(t1k_ctx *ctx, uint64_t first, uint32_t count) {
   a.genJobStr = a.genHits + genHitCap; a.genJobList = a.genJobStr + genJobCap; a.genJobSegCap = genJobCap / T1K_NSTRIPE;
   a.groupSegCap = groupSegCap; a.jobSegCap = jobSegCap; a.listSegCap = listSegCap; a.genCandSegCap = genCandSegCap;
   a.bigScratch = (uint32_t *)ctx->bWgBig.p;
-  a.cand = (T1kCand *)ctx->bCand.p; a.candCap = (uint64_t)ctx->prm.cand_cap;
+  a.cand = (T1kCand *)ctx->bCand.p; a.candCap = ctx->wCand;
   a.candStart = (uint32_t *)ctx->bCandStart.p; a.candCount = (uint32_t *)ctx->bCandCount.p;
   a.counters = (unsigned long long *)ctx->bCounters.p;
   if ((rc = t1k_run_chain(ctx, a, nWg, bigBlocks, longReads, hc))) return rc;
@@ -728,7 +776,7 @@ int t1k_assign_range(t1k_ctx *ctx, uint64_t first, uint32_t count) {
   double t2 = nowMs();
   SelectArgs s{};
   s.reads = rd; s.cand = a.cand; s.ext = e.ext; s.candStart = a.candStart; s.candCount = a.candCount;
-  s.ovl = ctx->ovlBase; s.ovlCap = (uint64_t)ctx->prm.ovl_cap;
+  s.ovl = ctx->ovlBase; s.ovlCap = ctx->wOvl;
   s.ovlStart = (uint32_t *)ctx->bOvlStart.p; s.ovlCount = (uint32_t *)ctx->bOvlCount.p;
   s.sortScratch = (uint64_t *)ctx->bSortScratch.p; s.sortCap = sortCap; s.counters = a.counters;
   s.alleleBits = 1;
@@ -745,7 +793,6 @@ int t1k_assign_range(t1k_ctx *ctx, uint64_t first, uint32_t count) {
   const uint32_t qSegCap = (uint32_t)(ctx->nOvl / T1K_NSTRIPE * 2 + 1024);
   const size_t qDense = (size_t)ctx->nOvl + 1, qStr = (size_t)qSegCap * T1K_NSTRIPE;
   if ((rc = t1k_ensure(ctx, ctx->bSlowQueue, (qDense + qStr) * 3 * 4))) return rc;
-  if ((rc = t1k_ensure(ctx, ctx->bSlowScratch, (size_t)slowBlocks * 64 * t1k_slow_per_thread(maxCells)))) return rc;
   FullArgs f{};
   f.ref = ctx->ref; f.reads = rd; f.relax = relaxFlag; f.ovl = s.ovl; f.nOvl = ctx->nOvl;
   uint32_t *qEq = (uint32_t *)ctx->bSlowQueue.p, *qBand = qEq + qDense, *qWide = qBand + qDense;
@@ -793,6 +840,7 @@ int t1k_assign_range(t1k_ctx *ctx, uint64_t first, uint32_t count) {
     if (getenv("T1K_DEBUG_PHASES")) fprintf(stderr, "[t1k] %s alignments: %u jobs in %u runs of identical windows\n", kind == 0 ? "equal-span" : "band", nJobs, nRuns);
   }
   if (hc[20]) {  // wide length difference: general DP with row arrays in HBM
+    if ((rc = t1k_ensure(ctx, ctx->bSlowScratch, (size_t)slowBlocks * 64 * t1k_slow_per_thread(maxCells)))) return rc;
     SlowArgs sl{};
     sl.ref = ctx->ref; sl.reads = rd; sl.relax = relaxFlag; sl.ovl = s.ovl; sl.slowQueue = qWide; sl.nSlow = (uint32_t)hc[20];
     sl.scratch = (uint8_t *)ctx->bSlowScratch.p; sl.perThread = t1k_slow_per_thread(maxCells); sl.maxCells = maxCells; sl.counters = a.counters;

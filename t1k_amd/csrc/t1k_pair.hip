@@ -49,6 +49,8 @@ struct PairArgs {
   Frag *frags; uint32_t fragCap;   // [wg][fragCap]
   uint32_t *keep;                  // [wg][fragCap]
   unsigned long long *counters;    // [2] error flags, [9] row total
+  const uint32_t *only; uint32_t nOnly;  // second pass: just these fragments (the ones whose lists did not fit the first pass's scratch)
+  uint32_t *overflowList;          // first pass: fragments with more than fragCap overlaps are listed here (count in counters[23]) instead of failing
   const uint8_t *whitelist;        // [nAlleles] or NULL: alleles outside it are left out of the rows (Genotyper.hpp:822-823)
   // rowset form (rsRowPtr != NULL): rows go to rsRows[*rsCursor ...), ordered by allele; per-fragment records at fragBase + f
   unsigned long long *rsRowPtr; uint32_t *rsRowCount; unsigned long long *rsH1, *rsH2; uint8_t *rsAssigned;
@@ -152,7 +154,9 @@ __global__ __launch_bounds__(WG) void k_pair(PairArgs P) {
   uint64_t *tabSlot = P.tabSlot + (uint64_t)blockIdx.x * A;
   Frag *frags = P.frags + (uint64_t)blockIdx.x * P.fragCap;
   uint32_t *keep = P.keep + (uint64_t)blockIdx.x * P.fragCap;
-  for (uint32_t f = blockIdx.x; f < P.nFragments; f += gridDim.x) {
+  const uint32_t nItems = P.only ? P.nOnly : P.nFragments;
+  for (uint32_t it = blockIdx.x; it < nItems; it += gridDim.x) {
+    const uint32_t f = P.only ? P.only[it] : it;
     const uint64_t epoch = (uint64_t)(P.epochBase + f + 1) << 32;
     const bool paired = P.end2 != nullptr;
     const uint32_t e1 = P.end1[f];
@@ -169,6 +173,11 @@ __global__ __launch_bounds__(WG) void k_pair(PairArgs P) {
     const bool both = paired && !dangling;
     uint32_t nFrag = 0;
     if (n1 + n2 > P.fragCap) {
+      if (P.overflowList) {  // rare: a second launch with a large scratch takes it
+        if (tid == 0) P.overflowList[atomicAdd(&P.counters[23], 1ull)] = f;
+        __syncthreads();
+        continue;
+      }
       if (tid == 0) {
         atomicOr(&P.counters[2], 128ull);
         if (P.rsRowPtr) { P.rsRowCount[P.fragBase + f] = 0; P.rsAssigned[P.fragBase + f] = 0; }
@@ -487,8 +496,10 @@ static int pairLaunch(t1k_ctx *ctx, t1k_rowset *rs, const uint32_t *end1, const 
   T1K_HIP(ctx, hipSetDevice(ctx->device));
   int rc;
   const uint32_t n = nFragments;
-  const int nWg = (int)std::min<uint32_t>(2048, std::max<uint32_t>(n, 1));  // the kernel is latency-bound: fill the wave slots
-  const uint32_t fragCap = 1u << 16;
+  const int maxWg = 1024;
+  const int nWg = (int)std::min<uint32_t>(maxWg, std::max<uint32_t>(n, 1));  // the kernel is latency-bound: fill the wave slots
+  const uint32_t fragCap = 8192, bigFragCap = 1u << 17;  // overlaps of both mates a workgroup's scratch holds (first pass | second pass)
+  const int bigWg = 128;
   const uint32_t A = ctx->ref.nAlleles;
   if (!rs) { ctx->nFragments = n; ctx->nRows = 0; }
   if ((rc = t1k_ensure(ctx, ctx->bEnd1, (size_t)n * 4))) return rc;
@@ -501,8 +512,9 @@ static int pairLaunch(t1k_ctx *ctx, t1k_rowset *rs, const uint32_t *end1, const 
     if ((rc = t1k_ensure(ctx, ctx->bFragAssigned, (size_t)n))) return rc;
   }
   size_t perWg = (size_t)A * 16 + (size_t)fragCap * (sizeof(Frag) + 4);
-  bool fresh = ctx->bPairScratch.bytes < (size_t)2048 * perWg;
-  if ((rc = t1k_ensure(ctx, ctx->bPairScratch, (size_t)2048 * perWg))) return rc;
+  bool fresh = ctx->bPairScratch.bytes < (size_t)maxWg * perWg;
+  if ((rc = t1k_ensure(ctx, ctx->bPairScratch, (size_t)maxWg * perWg))) return rc;
+  if ((rc = t1k_ensure(ctx, ctx->bPairOverflow, (size_t)n * 4 + 16))) return rc;
   if ((rc = t1k_ensure(ctx, ctx->bCounters, (size_t)T1K_COUNTER_WORDS * 8))) return rc;
   if (n == 0) return T1K_OK;
   T1K_HIP(ctx, hipMemcpyAsync(ctx->bEnd1.p, end1, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
@@ -512,7 +524,7 @@ static int pairLaunch(t1k_ctx *ctx, t1k_rowset *rs, const uint32_t *end1, const 
   // the epoch of fragment f is epochBase + f + 1; the base moves on with every call, so the tables only need clearing when the
   // 32-bit epoch space is about to wrap (or the scratch was just allocated)
   if (fresh || ctx->pairEpoch > 0xFFFFFFFFull - 2ull * n - 2) {
-    T1K_HIP(ctx, hipMemsetAsync(ctx->bPairScratch.p, 0, (size_t)2048 * (size_t)A * 16, ctx->stream));
+    T1K_HIP(ctx, hipMemsetAsync(ctx->bPairScratch.p, 0, (size_t)maxWg * (size_t)A * 16, ctx->stream));
     ctx->pairEpoch = 0;
   }
   PairArgs p{};
@@ -525,17 +537,18 @@ static int pairLaunch(t1k_ctx *ctx, t1k_rowset *rs, const uint32_t *end1, const 
   p.rowStart = (uint32_t *)ctx->bRowStart.p; p.rowCount = (uint32_t *)ctx->bRowCount.p; p.fragAssigned = (uint8_t *)ctx->bFragAssigned.p;
   uint8_t *sc = (uint8_t *)ctx->bPairScratch.p;
   p.tab2 = (uint64_t *)sc;
-  p.tabSlot = (uint64_t *)(sc + (size_t)2048 * A * 8);
-  p.frags = (Frag *)(sc + (size_t)2048 * A * 16);
+  p.tabSlot = (uint64_t *)(sc + (size_t)maxWg * A * 8);
+  p.frags = (Frag *)(sc + (size_t)maxWg * A * 16);
   p.fragCap = fragCap;
-  p.keep = (uint32_t *)(sc + (size_t)2048 * A * 16 + (size_t)2048 * fragCap * sizeof(Frag));
+  p.keep = (uint32_t *)(sc + (size_t)maxWg * A * 16 + (size_t)maxWg * fragCap * sizeof(Frag));
+  p.overflowList = (uint32_t *)ctx->bPairOverflow.p;
   p.counters = (unsigned long long *)ctx->bCounters.p;
   p.whitelist = dWhitelist;
   if (getenv("T1K_DEBUG_TRACE")) fprintf(stderr, "[t1k trace] pair %u fragments%s\n", n, rs ? " into the rowset" : "");
   for (int attempt = 0;; ++attempt) {
     T1K_HIP(ctx, hipMemsetAsync((char *)ctx->bCounters.p + 2 * 8, 0, 8, ctx->stream));
     T1K_HIP(ctx, hipMemsetAsync((char *)ctx->bCounters.p + 9 * 8, 0, 8, ctx->stream));
-    T1K_HIP(ctx, hipMemsetAsync((char *)ctx->bCounters.p + 22 * 8, 0, 8, ctx->stream));
+    T1K_HIP(ctx, hipMemsetAsync((char *)ctx->bCounters.p + 22 * 8, 0, 16, ctx->stream));
     size_t chunk = 0;
     if (rs) {
       if ((rc = t1k_rowset_chunk(rs, ctx, &chunk, &p.rsRows, &p.rsCap, &p.rsCursor))) return rc;
@@ -546,9 +559,24 @@ static int pairLaunch(t1k_ctx *ctx, t1k_rowset *rs, const uint32_t *end1, const 
     hipLaunchKernelGGL(k_pair, dim3(nWg), dim3(WG), 0, ctx->stream, p);
     T1K_HIP(ctx, hipEventRecord(ctx->ev[6], ctx->stream));
     if (!ctx->countersPinned) T1K_HIP(ctx, hipHostMalloc((void **)&ctx->countersPinned, (size_t)T1K_COUNTER_WORDS * 8, hipHostMallocDefault));
-    unsigned long long *hc = ctx->countersPinned;
-    T1K_HIP(ctx, hipMemcpyAsync(hc, ctx->bCounters.p, 64 * 8, hipMemcpyDeviceToHost, ctx->stream));
+    T1K_HIP(ctx, hipMemcpyAsync(ctx->countersPinned, ctx->bCounters.p, 64 * 8, hipMemcpyDeviceToHost, ctx->stream));
     T1K_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (const uint32_t nOver = (uint32_t)ctx->countersPinned[23]) {
+      // fragments whose two lists exceed the first pass's per-workgroup scratch: a few workgroups with a scratch for 2^17 overlaps each
+      const size_t perBig = (size_t)A * 16 + (size_t)bigFragCap * (sizeof(Frag) + 4);
+      if ((rc = t1k_ensure(ctx, ctx->bPairBig, (size_t)bigWg * perBig))) return rc;
+      T1K_HIP(ctx, hipMemsetAsync(ctx->bPairBig.p, 0, (size_t)bigWg * (size_t)A * 16, ctx->stream));
+      PairArgs q = p;
+      uint8_t *bs = (uint8_t *)ctx->bPairBig.p;
+      q.tab2 = (uint64_t *)bs; q.tabSlot = (uint64_t *)(bs + (size_t)bigWg * A * 8);
+      q.frags = (Frag *)(bs + (size_t)bigWg * A * 16); q.fragCap = bigFragCap;
+      q.keep = (uint32_t *)(bs + (size_t)bigWg * A * 16 + (size_t)bigWg * bigFragCap * sizeof(Frag));
+      q.only = (const uint32_t *)ctx->bPairOverflow.p; q.nOnly = nOver; q.overflowList = nullptr; q.epochBase = 0;
+      hipLaunchKernelGGL(k_pair, dim3(std::min<uint32_t>(nOver, bigWg)), dim3(WG), 0, ctx->stream, q);
+      T1K_HIP(ctx, hipMemcpyAsync(ctx->countersPinned, ctx->bCounters.p, 64 * 8, hipMemcpyDeviceToHost, ctx->stream));
+      T1K_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    unsigned long long *hc = ctx->countersPinned;
     { float ms = 0; (void)hipEventElapsedTime(&ms, ctx->ev[5], ctx->ev[6]); ctx->stats.ms_pair = (attempt ? ctx->stats.ms_pair : 0) + ms; }
     if (hc[2] && rs && attempt < 4) {
       // the rowset's current chunk is full (or a fragment has more overlaps than the scratch holds: that repeats and fails below):
