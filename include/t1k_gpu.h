@@ -207,6 +207,8 @@ typedef struct {
   double ms_load, ms_device, ms_coalesce, ms_write;
 } t1k_stats;
 int t1k_stats_get(t1k_ctx *ctx, t1k_stats *out);
+/* wall time (ms) the context has spent allocating device memory and the bytes it asked for (diagnostics) */
+double t1k_alloc_ms(t1k_ctx *ctx, uint64_t *bytes);
 
 /* ---- whole-stage job API (host C++ + the device stages above) ------------------------------------------------- */
 /* argv-compatible replacement of the reference's genotyper executable (Genotyper.cpp:194-738). Returns the exit code. */

@@ -283,6 +283,7 @@ int t1k_job_run_local(t1k_job *job) {
     sh.cv.notify_all();
   };
   double msPrep = 0;
+  const bool traceTasks = getenv("T1K_DEBUG_TASKS") != nullptr;
   // ---- window preparation ------------------------------------------------------------------------------------------
   auto prepare = [&] {
     std::vector<char> text[2];
@@ -328,6 +329,7 @@ int t1k_job_run_local(t1k_job *job) {
         }
       });
       off[ne] = total;
+      const double tText = nowMs();
       t1k_ctx *rd = job->reader[W.slot];
       int r = t1k_reads_upload(rd, tx.data(), off.data(), nullptr, ne);
       W.distinctOf.resize(ne);
@@ -335,6 +337,7 @@ int t1k_job_run_local(t1k_job *job) {
       if (r != T1K_OK) { fail(r, t1k_last_error(rd)); return; }
       W.assignBatch = assignBatch; W.nAssign = (W.nDistinct + assignBatch - 1) / assignBatch;
       W.pairBatch = pairBatch; W.nPair = (nf + pairBatch - 1) / pairBatch;
+      if (traceTasks) fprintf(stderr, "[t1k task] prep window %u: %.1f .. %.1f ms (text %.1f ms)\n", w, t0 - tStart, nowMs() - tStart, tText - t0);
       {
         std::lock_guard<std::mutex> g(sh.m);
         job->distinctReadEnds += W.nDistinct;
@@ -387,6 +390,7 @@ int t1k_job_run_local(t1k_job *job) {
       Window &W = win[w];
       int r = T1K_OK;
       std::string msg;
+      const double tTask = nowMs();
       if (attached != (int)w) {
         r = t1k_reads_attach(ctx, job->reader[W.slot], W.slot, W.touched[pi] ? 0 : 1);
         if (r != T1K_OK) msg = t1k_last_error(ctx);
@@ -410,6 +414,7 @@ int t1k_job_run_local(t1k_job *job) {
         }
       }
       if (r != T1K_OK) { fail(r, msg); return; }
+      if (traceTasks) fprintf(stderr, "[t1k task] pipe %d window %u %s %u: %.1f .. %.1f ms\n", pi, w, kind == 0 ? "assign" : "pair", item, tTask - tStart, nowMs() - tStart);
       {
         std::lock_guard<std::mutex> g(sh.m);
         if (kind == 0) ++W.doneAssign; else ++W.donePair;
@@ -475,6 +480,12 @@ int t1k_job_run_local(t1k_job *job) {
   job->rows = nullptr;
   job->msDevice = tDev - tStart; job->msCoalesce = nowMs() - tDev; job->msHost = 0;
   job->stats.ms_load = job->msLoad; job->stats.ms_device = job->msDevice; job->stats.ms_coalesce = job->msCoalesce;
+  if (getenv("T1K_DEBUG_PHASES")) {
+    double ms = 0; uint64_t by = 0, b1 = 0;
+    for (t1k_ctx *c : pipes) { ms += t1k_alloc_ms(c, &b1); by += b1; }
+    for (t1k_ctx *c : job->reader) { ms += t1k_alloc_ms(c, &b1); by += b1; }
+    fprintf(stderr, "[t1k job] device memory: %.1f GB allocated by the contexts in %.1f ms of hipMalloc (summed over threads)\n", by / 1073741824.0, ms);
+  }
   if (getenv("T1K_DEBUG_PHASES"))
     fprintf(stderr, "[t1k job] %u windows, %llu read-ends -> %llu distinct; window preparation %.1f ms (overlapped), device loop %.1f ms, coalesce + download %.1f ms (%llu groups, %llu entries)\n",
             nWin, (unsigned long long)job->readEnds, (unsigned long long)job->distinctReadEnds, msPrep, job->msDevice, job->msCoalesce, (unsigned long long)G, (unsigned long long)N);

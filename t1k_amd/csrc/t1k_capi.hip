@@ -19,9 +19,13 @@ int t1k_fail(t1k_ctx *ctx, int code, const std::string &msg) {
 int t1k_ensure(t1k_ctx *ctx, T1kDevBuf &b, size_t bytes) {
   if (bytes == 0) bytes = 16;
   if (b.bytes >= bytes) return 0;
+  // a buffer that has to grow grows by at least half (the sizes of several arenas follow the data of each range and creep up: every
+  // reallocation is fresh VRAM, which the driver zeroes at ~35 ms per GB)
+  size_t want = std::max(bytes + bytes / 8, b.p ? b.bytes + b.bytes / 2 : (size_t)0) + 256;
   if (b.p) { (void)hipFree(b.p); b.p = nullptr; b.bytes = 0; }
-  size_t want = bytes + bytes / 8 + 256;
+  const auto t0 = std::chrono::steady_clock::now();
   hipError_t e = hipMalloc(&b.p, want);
+  if (ctx) { ctx->msAlloc += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); ctx->bytesAlloc += want; }
   if (e != hipSuccess) { b.p = nullptr; return t1k_fail(ctx, T1K_ERR_DEVICE, std::string("hipMalloc(") + std::to_string(want) + "): " + hipGetErrorString(e)); }
   b.bytes = want;
   return 0;
@@ -607,9 +611,12 @@ static int capacityError(t1k_ctx *ctx, unsigned long long flags) {
       for (int st = 0; st < T1K_NSTRIPE; ++st) m = std::max(m, ctx->hRaw[T1K_ARENA_BASE + ((size_t)arena * T1K_NSTRIPE + st) * 8]);
       return m;
     };
-    unsigned long long lists = 0;
-    for (int ar : {T1K_AR_SLOW, T1K_AR_RETRY, T1K_AR_FINISH, T1K_AR_GENERAL, T1K_AR_WAVE, T1K_AR_BIG, T1K_AR_EXTRETRY}) lists = std::max(lists, maxSeg(ar));
-    ctx->needGroup = std::max<uint64_t>(maxSeg(T1K_AR_GROUPS) * T1K_NSTRIPE, lists * T1K_NSTRIPE * T1K_LIST_DIV);
+    unsigned long long lists = 0, rare = 0;
+    for (int ar : {T1K_AR_SLOW, T1K_AR_RETRY, T1K_AR_FINISH, T1K_AR_EXTRETRY}) lists = std::max(lists, maxSeg(ar));
+    for (int ar : {T1K_AR_GENERAL, T1K_AR_WAVE, T1K_AR_BIG}) rare = std::max(rare, maxSeg(ar));
+    ctx->needGroup = maxSeg(T1K_AR_GROUPS) * T1K_NSTRIPE;
+    ctx->needList = lists * T1K_NSTRIPE;
+    ctx->needRare = rare * T1K_NSTRIPE;
     ctx->needCand = ctx->hRaw[0];
     ctx->needOvl = ctx->hRaw[1];
   }
@@ -645,25 +652,44 @@ int t1k_assign_range(t1k_ctx *ctx, uint64_t first, uint32_t count) {
   if (first + count > ctx->reads.nReadEnds) return t1k_fail(ctx, T1K_ERR_ARG, "t1k_assign_range: range outside the uploaded reads");
   T1K_HIP(ctx, hipSetDevice(ctx->device));
   auto clampCap = [](uint64_t want, uint64_t floor, int64_t limit) { return std::min<uint64_t>((uint64_t)limit, std::max<uint64_t>(want, floor)); };
-  ctx->wGroup = clampCap(std::max<uint64_t>(ctx->wGroup, (uint64_t)count * 1024), 4u << 20, ctx->prm.group_cap);
-  ctx->wCand = clampCap(std::max<uint64_t>(ctx->wCand, (uint64_t)count * 512), 2u << 20, ctx->prm.cand_cap);
-  ctx->wOvl = clampCap(std::max<uint64_t>(ctx->wOvl, (uint64_t)count * 512), 2u << 20, ctx->prm.ovl_cap);
+  // floors per read-end: what a 2x150 bp read-end needs against an HLA-sized reference (about 30 000 alleles: 1 900 groups, 1 000 of
+  // them on the gap-walk list, 800 candidates, 610 overlaps), with room to spare; smaller references just leave part of it unused
+  const uint64_t perRe = std::min<uint64_t>(2400, std::max<uint64_t>(256, (uint64_t)ctx->ref.nAlleles / 12));
+  ctx->wGroup = clampCap(std::max<uint64_t>(ctx->wGroup, (uint64_t)count * perRe), 4u << 20, ctx->prm.group_cap);
+  ctx->wCand = clampCap(std::max<uint64_t>(ctx->wCand, (uint64_t)count * perRe * 5 / 12), 2u << 20, ctx->prm.cand_cap);
+  ctx->wOvl = clampCap(std::max<uint64_t>(ctx->wOvl, (uint64_t)count * perRe / 3), 2u << 20, ctx->prm.ovl_cap);
+  ctx->wList = clampCap(std::max<uint64_t>(ctx->wList, (uint64_t)count * perRe * 7 / 12), 1u << 20, ctx->prm.group_cap);
+  ctx->wRare = clampCap(std::max<uint64_t>(ctx->wRare, (uint64_t)count * perRe / 24), 1u << 18, ctx->prm.group_cap);
   for (int attempt = 0;; ++attempt) {
-    ctx->lastCapFlags = 0; ctx->needGroup = ctx->needCand = ctx->needOvl = 0;
+    ctx->lastCapFlags = 0; ctx->needGroup = ctx->needCand = ctx->needOvl = ctx->needList = ctx->needRare = 0;
     const int rc = assignOnce(ctx, first, count);
-    if (rc != T1K_ERR_CAPACITY || attempt >= 6) return rc;
+    if (rc != T1K_ERR_CAPACITY || attempt >= 10) return rc;
     bool grew = false;
-    auto grow = [&](uint64_t &w, uint64_t need, int64_t limit) {
-      if (w >= (uint64_t)limit) return;
-      w = std::min<uint64_t>((uint64_t)limit, std::max<uint64_t>(w + w / 2, need + need / 4));
+    auto grow = [&](uint64_t &w, uint64_t need, int64_t limit) {  // to the demand the device counted, with a quarter to spare
+      if (w >= (uint64_t)limit || need <= w) return;
+      w = std::min<uint64_t>((uint64_t)limit, need + need / 4);
       grew = true;
     };
-    if (ctx->lastCapFlags & 256) grow(ctx->wGroup, ctx->needGroup, ctx->prm.group_cap);
+    if (ctx->lastCapFlags & 256) {
+      const uint64_t before = ctx->wGroup;
+      grow(ctx->wGroup, ctx->needGroup, ctx->prm.group_cap);
+      if (ctx->wGroup > before && !ctx->scaledOnce) {
+        // the seeding kernel is the first to overflow and the later arenas' demand goes with the number of groups: scale them once
+        // by the same factor instead of discovering each of them with a failed pass of its own
+        const double f = std::min(4.0, (double)ctx->wGroup / (double)before);
+        ctx->wList = std::min<uint64_t>((uint64_t)ctx->prm.group_cap, (uint64_t)(ctx->wList * f));
+        ctx->wCand = std::min<uint64_t>((uint64_t)ctx->prm.cand_cap, (uint64_t)(ctx->wCand * f));
+        ctx->wOvl = std::min<uint64_t>((uint64_t)ctx->prm.ovl_cap, (uint64_t)(ctx->wOvl * f));
+        ctx->scaledOnce = true;
+      }
+      grow(ctx->wList, ctx->needList, ctx->prm.group_cap);
+      grow(ctx->wRare, ctx->needRare, ctx->prm.group_cap);
+    }
     if (ctx->lastCapFlags & 4) grow(ctx->wCand, ctx->needCand, ctx->prm.cand_cap);
     if (ctx->lastCapFlags & 16) grow(ctx->wOvl, ctx->needOvl, ctx->prm.ovl_cap);
     if (!grew || (ctx->lastCapFlags & ~(256ull | 4ull | 16ull))) return rc;  // at the limits (or another arena): the caller splits the range
-    if (getenv("T1K_DEBUG_PHASES")) fprintf(stderr, "[t1k] range of %u read-ends again with capacities: groups %llu candidates %llu overlaps %llu\n", count,
-                                            (unsigned long long)ctx->wGroup, (unsigned long long)ctx->wCand, (unsigned long long)ctx->wOvl);
+    if (getenv("T1K_DEBUG_PHASES")) fprintf(stderr, "[t1k] range of %u read-ends again with capacities: groups %llu lists %llu / %llu candidates %llu overlaps %llu\n", count,
+                                            (unsigned long long)ctx->wGroup, (unsigned long long)ctx->wList, (unsigned long long)ctx->wRare, (unsigned long long)ctx->wCand, (unsigned long long)ctx->wOvl);
   }
 }
 
@@ -691,9 +717,11 @@ static int assignOnce(t1k_ctx *ctx, uint64_t first, uint32_t count) {
   if ((rc = t1k_ensure(ctx, ctx->bWgBig, (size_t)bigBlocks * 64 * t1k_chain_big_scratch_u32() * 4))) return rc;
   // work lists: every list exists twice, as a striped arena the kernels append to and as the dense list its consumer reads
   const uint32_t groupSegCap = (uint32_t)std::min<uint64_t>(groupCap / T1K_NSTRIPE, 0xFFFFFFFFull / T1K_NSTRIPE);
-  const uint32_t listSegCap = std::max<uint32_t>(groupSegCap / T1K_LIST_DIV, 1024u), jobSegCap = jobCap / T1K_NSTRIPE, genCandSegCap = genCandCap / T1K_NSTRIPE;
-  const size_t listWords = (size_t)listSegCap * T1K_NSTRIPE;
-  if ((rc = t1k_ensure(ctx, ctx->bLists, ((size_t)jobCap * 2 + listWords * 12 + (size_t)genCandCap * 6 + genHitCap + (size_t)genJobCap * 2) * 4 + 64))) return rc;
+  // group-id lists: the frequent kinds (gap walk, retry, finish; extension retry) and the rare ones (several diagonals, wave, big scratch)
+  const uint32_t listSegCap = (uint32_t)std::max<uint64_t>(ctx->wList / T1K_NSTRIPE, 1024u), rareSegCap = (uint32_t)std::max<uint64_t>(ctx->wRare / T1K_NSTRIPE, 1024u);
+  const uint32_t jobSegCap = jobCap / T1K_NSTRIPE, genCandSegCap = genCandCap / T1K_NSTRIPE;
+  const size_t listWords = (size_t)listSegCap * T1K_NSTRIPE, rareWords = (size_t)rareSegCap * T1K_NSTRIPE;
+  if ((rc = t1k_ensure(ctx, ctx->bLists, ((size_t)jobCap * 2 + listWords * 6 + rareWords * 6 + (size_t)genCandCap * 6 + genHitCap + (size_t)genJobCap * 2) * 4 + 64))) return rc;
   if ((rc = t1k_ensure(ctx, ctx->bCand, (size_t)ctx->wCand * sizeof(T1kCand)))) return rc;
   if ((rc = t1k_ensure(ctx, ctx->bExt, (size_t)ctx->wCand * sizeof(T1kExt)))) return rc;
   // this range's lists go to the end of the overlap store: the current chunk if the working overlap capacity still fits, else the next one
@@ -707,7 +735,9 @@ static int assignOnce(t1k_ctx *ctx, uint64_t first, uint32_t count) {
       if (ch.p && ctx->storeUsed[sl] + ctx->wOvl <= ch.bytes / sizeof(T1kOvl)) break;   // fits behind what the chunk already holds
       if (ch.p && ctx->storeUsed[sl] > 0) { ++ctx->storeChunk[sl]; ctx->storeUsed[sl] = 0; continue; }
       if (ch.p) { (void)hipFree(ch.p); ch.p = nullptr; ch.bytes = 0; }  // an empty chunk that is too small for this range
+      const auto t0 = std::chrono::steady_clock::now();
       hipError_t e = hipMalloc(&ch.p, chunkEntries * sizeof(T1kOvl));
+      ctx->msAlloc += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); ctx->bytesAlloc += chunkEntries * sizeof(T1kOvl);
       if (e != hipSuccess) { ch.p = nullptr; return t1k_fail(ctx, T1K_ERR_DEVICE, std::string("overlap store: hipMalloc of another ") + std::to_string(chunkEntries * sizeof(T1kOvl) >> 20) + " MB chunk failed (" + hipGetErrorString(e) + "); fewer fragments per window (T1K_WINDOW) need less"); }
       ch.bytes = chunkEntries * sizeof(T1kOvl);
     }
@@ -740,14 +770,14 @@ static int assignOnce(t1k_ctx *ctx, uint64_t first, uint32_t count) {
   a.memo = (unsigned long long *)ctx->bWgCache.p;
   a.jobList = (uint32_t *)ctx->bLists.p; a.jobCap = jobCap;
   a.jobStr = a.jobList + jobCap;
-  a.retryList = a.jobStr + jobCap; a.generalList = a.retryList + listWords; a.bigList = a.generalList + listWords; a.finishList = a.bigList + listWords;
-  a.retryStr = a.finishList + listWords; a.generalStr = a.retryStr + listWords; a.bigStr = a.generalStr + listWords; a.finishStr = a.bigStr + listWords;
-  a.waveStr = a.finishStr + listWords; a.waveList = a.waveStr + listWords;
-  a.slowStr = a.waveList + listWords; a.slowList = a.slowStr + listWords;
-  a.genCand = a.slowList + listWords; a.genCandCap = genCandCap;
+  a.retryList = a.jobStr + jobCap; a.finishList = a.retryList + listWords; a.slowList = a.finishList + listWords;
+  a.retryStr = a.slowList + listWords; a.finishStr = a.retryStr + listWords; a.slowStr = a.finishStr + listWords;
+  a.generalList = a.slowStr + listWords; a.bigList = a.generalList + rareWords; a.waveList = a.bigList + rareWords;
+  a.generalStr = a.waveList + rareWords; a.bigStr = a.generalStr + rareWords; a.waveStr = a.bigStr + rareWords;
+  a.genCand = a.waveStr + rareWords; a.genCandCap = genCandCap;
   a.genHits = a.genCand + (size_t)genCandCap * 6; a.genHitSegCap = genHitCap / T1K_NSTRIPE;
   a.genJobStr = a.genHits + genHitCap; a.genJobList = a.genJobStr + genJobCap; a.genJobSegCap = genJobCap / T1K_NSTRIPE;
-  a.groupSegCap = groupSegCap; a.jobSegCap = jobSegCap; a.listSegCap = listSegCap; a.genCandSegCap = genCandSegCap;
+  a.groupSegCap = groupSegCap; a.jobSegCap = jobSegCap; a.listSegCap = listSegCap; a.rareSegCap = rareSegCap; a.genCandSegCap = genCandSegCap;
   a.bigScratch = (uint32_t *)ctx->bWgBig.p;
   a.cand = (T1kCand *)ctx->bCand.p; a.candCap = ctx->wCand;
   a.candStart = (uint32_t *)ctx->bCandStart.p; a.candCount = (uint32_t *)ctx->bCandCount.p;
@@ -792,14 +822,21 @@ static int assignOnce(t1k_ctx *ctx, uint64_t first, uint32_t count) {
   // alignment queues (equal spans | spans differing by <= 4 | wider): striped arenas appended to by k_fullalign, then made dense
   const uint32_t qSegCap = (uint32_t)(ctx->nOvl / T1K_NSTRIPE * 2 + 1024);
   const size_t qDense = (size_t)ctx->nOvl + 1, qStr = (size_t)qSegCap * T1K_NSTRIPE;
-  if ((rc = t1k_ensure(ctx, ctx->bSlowQueue, (qDense + qStr) * 3 * 4))) return rc;
+  // The group records, the work lists and the candidates are dead from here on: the alignment queues, their sort keys and the trace
+  // rows live in that memory when it is large enough (every arena of its own is more fresh VRAM for the driver to zero).
+  const size_t queueBytes = ((qDense + qStr) * 3 * 4 + 255) & ~(size_t)255, keyBytes = (qStr * 2 + qDense * 2) * 8 + qDense * 4;
+  char *queueMem = nullptr;
+  if (ctx->bWgGroups.bytes >= queueBytes + keyBytes) queueMem = (char *)ctx->bWgGroups.p;
+  else {
+    if ((rc = t1k_ensure(ctx, ctx->bSlowQueue, queueBytes + keyBytes))) return rc;
+    queueMem = (char *)ctx->bSlowQueue.p;
+  }
   FullArgs f{};
   f.ref = ctx->ref; f.reads = rd; f.relax = relaxFlag; f.ovl = s.ovl; f.nOvl = ctx->nOvl;
-  uint32_t *qEq = (uint32_t *)ctx->bSlowQueue.p, *qBand = qEq + qDense, *qWide = qBand + qDense;
+  uint32_t *qEq = (uint32_t *)queueMem, *qBand = qEq + qDense, *qWide = qBand + qDense;
   f.eqStr = qWide + qDense; f.bandStr = f.eqStr + qStr; f.wideStr = f.bandStr + qStr; f.segCap = qSegCap; f.counters = a.counters;
   // sort keys of the equal / band queues: striped | dense | sorted (scratch of the radix sort), and the unsorted dense gid lists
-  if ((rc = t1k_ensure(ctx, ctx->bSlowKeys, (qStr * 2 + qDense * 2) * 8 + qDense * 4))) return rc;
-  f.eqKeyStr = (unsigned long long *)ctx->bSlowKeys.p; f.bandKeyStr = f.eqKeyStr + qStr;
+  f.eqKeyStr = (unsigned long long *)(queueMem + queueBytes); f.bandKeyStr = f.eqKeyStr + qStr;
   unsigned long long *kDense = f.bandKeyStr + qStr, *kSorted = kDense + qDense;
   uint32_t *vDense = (uint32_t *)(kSorted + qDense);
   t1k_launch_fullalign(ctx, f);
@@ -834,8 +871,10 @@ static int assignOnce(t1k_ctx *ctx, uint64_t first, uint32_t count) {
     T1K_HIP(ctx, hipStreamSynchronize(ctx->stream));
     t1k_launch_align_reps(ctx, flags, runOf, rep, nJobs);
     const uint64_t stride = ((uint64_t)nRuns + 63) / 64 * 64;
-    if ((rc = t1k_ensure(ctx, ctx->bEqTrace, stride * (size_t)(ctx->batchMaxLen + 2) * 8))) return rc;
-    sl.scratch = (uint8_t *)ctx->bEqTrace.p; sl.runOf = runOf; sl.rep = rep; sl.nRuns = nRuns; sl.traceStride = stride;
+    const size_t traceBytes = stride * (size_t)(ctx->batchMaxLen + 2) * 8;
+    if (ctx->bLists.bytes >= traceBytes) sl.scratch = (uint8_t *)ctx->bLists.p;
+    else if (ctx->bCand.bytes >= traceBytes) sl.scratch = (uint8_t *)ctx->bCand.p;
+    else { if ((rc = t1k_ensure(ctx, ctx->bEqTrace, traceBytes))) return rc; sl.scratch = (uint8_t *)ctx->bEqTrace.p; } sl.runOf = runOf; sl.rep = rep; sl.nRuns = nRuns; sl.traceStride = stride;
     t1k_launch_align_fill_apply(ctx, sl, kind == 0);
     if (getenv("T1K_DEBUG_PHASES")) fprintf(stderr, "[t1k] %s alignments: %u jobs in %u runs of identical windows\n", kind == 0 ? "equal-span" : "band", nJobs, nRuns);
   }
@@ -906,6 +945,12 @@ int t1k_overlaps_download(t1k_ctx *ctx, uint32_t *counts, t1k_overlap *out, uint
     }
   }
   return T1K_OK;
+}
+
+double t1k_alloc_ms(t1k_ctx *ctx, uint64_t *bytes) {  // time this context has spent in hipMalloc, and how much it asked for
+  if (!ctx) return 0;
+  if (bytes) *bytes = ctx->bytesAlloc;
+  return ctx->msAlloc;
 }
 
 int t1k_stats_get(t1k_ctx *ctx, t1k_stats *out) {

@@ -839,7 +839,7 @@ __global__ __launch_bounds__(WG) void k_chain_fast(ChainArgs P, const uint32_t *
   // list appends: one atomic per wavefront, list and arena segment (a full segment shows in its cursor; the host fails the batch)
   if (kind == 2) { const uint32_t q = t1k_arena_append(P.counters, T1K_AR_RETRY, P.listSegCap); if (q != T1K_ARENA_FULL) P.retryStr[q] = gi; }
   if (kind == 3) { const uint32_t q = t1k_arena_append(P.counters, T1K_AR_FINISH, P.listSegCap); if (q != T1K_ARENA_FULL) P.finishStr[q] = gi; }
-  if (kind == 4) { const uint32_t q = t1k_arena_append(P.counters, T1K_AR_GENERAL, P.listSegCap); if (q != T1K_ARENA_FULL) P.generalStr[q] = gi; }
+  if (kind == 4) { const uint32_t q = t1k_arena_append(P.counters, T1K_AR_GENERAL, P.rareSegCap); if (q != T1K_ARENA_FULL) P.generalStr[q] = gi; }
   if (kind == 5) { const uint32_t q = t1k_arena_append(P.counters, T1K_AR_SLOW, P.listSegCap); if (q != T1K_ARENA_FULL) P.slowStr[q] = gi; }
   t1k_stat_add(P.counters, T1K_STAT_DP, dpLocal);
   t1k_stat_add(P.counters, T1K_STAT_FAST, fastLocal);
@@ -949,14 +949,14 @@ __global__ __launch_bounds__(WG) void k_gather_general(ChainArgs P, uint32_t nIt
     uint32_t base = 0;
     if (lane == 0) {
       if (n > WAVE_CAP) {  // k_chain_big gathers for itself
-        const uint32_t bq = t1k_arena_append(P.counters, T1K_AR_BIG, P.listSegCap);
+        const uint32_t bq = t1k_arena_append(P.counters, T1K_AR_BIG, P.rareSegCap);
         if (bq != T1K_ARENA_FULL) P.bigStr[bq] = gi;
         rec[4] = 0xFFFFFFFFu;
       } else {
         base = n ? t1k_arena_alloc(P.counters, T1K_AR_GENHITS, n, P.genHitSegCap) : 0u;
         rec[3] = base; rec[4] = n;
         if (n > GENERAL_SMALL) {  // one wavefront per group (k_chain_wave)
-          const uint32_t wq = t1k_arena_append(P.counters, T1K_AR_WAVE, P.listSegCap);
+          const uint32_t wq = t1k_arena_append(P.counters, T1K_AR_WAVE, P.rareSegCap);
           if (wq != T1K_ARENA_FULL) P.waveStr[wq] = gi;
         }
       }
@@ -1000,7 +1000,7 @@ __global__ __launch_bounds__(64) void k_chain_general(ChainArgs P, uint32_t nIte
     const GapSink sink{P.memo + (uint64_t)re * GAP_CACHE, P.genJobStr, P.counters, re * GAP_CACHE, P.genJobSegCap, T1K_AR_GENJOBS};
     LaneArr A{sArr + threadIdx.x}, B{sArr + GENERAL_SMALL * 64 + threadIdx.x}, C{sArr + 2 * GENERAL_SMALL * 64 + threadIdx.x};
     groupGeneral(hh, n, c, P.k, P.radius, P.hitLenRequired, A, B, C, nullptr, 0, out, &dpLocal, &P.counters[2], &needScratch, &sink, pass);
-    if (needScratch) { const uint32_t b = t1k_arena_append(P.counters, T1K_AR_BIG, P.listSegCap); if (b != T1K_ARENA_FULL) P.bigStr[b] = gi; }
+    if (needScratch) { const uint32_t b = t1k_arena_append(P.counters, T1K_AR_BIG, P.rareSegCap); if (b != T1K_ARENA_FULL) P.bigStr[b] = gi; }
     else {
       ++genLocal;
       uint32_t base = 0;
@@ -1097,7 +1097,7 @@ __global__ __launch_bounds__(64) void k_chain_wave(ChainArgs P, uint32_t nItems)
     }
     if (lane == 0) {
       if (out.overflow) atomicOr(&P.counters[2], (unsigned long long)ERR_BIGGROUP);
-      if (needScratch) { const uint32_t b = t1k_arena_append(P.counters, T1K_AR_BIG, P.listSegCap); if (b != T1K_ARENA_FULL) P.bigStr[b] = gi; }
+      if (needScratch) { const uint32_t b = t1k_arena_append(P.counters, T1K_AR_BIG, P.rareSegCap); if (b != T1K_ARENA_FULL) P.bigStr[b] = gi; }
       else {
         ++genLocal;
         uint32_t base = 0;
@@ -1386,14 +1386,14 @@ int t1k_run_chain(t1k_ctx *ctx, const ChainArgs &a, int nWg, int bigBlocks, bool
   if ((rc = readCounters(ctx, hc))) return rc;
   hc[6] = groups.total;
   const T1kArenaCounts jobs = t1k_arena_counts(ctx, T1K_AR_JOBS, a.jobSegCap), retry = t1k_arena_counts(ctx, T1K_AR_RETRY, a.listSegCap),
-                       fin = t1k_arena_counts(ctx, T1K_AR_FINISH, a.listSegCap), gen = t1k_arena_counts(ctx, T1K_AR_GENERAL, a.listSegCap);
+                       fin = t1k_arena_counts(ctx, T1K_AR_FINISH, a.listSegCap), gen = t1k_arena_counts(ctx, T1K_AR_GENERAL, a.rareSegCap);
   // (a full job segment is benign: the claim was released and the gap is aligned inline by the retry pass)
   if (retry.overflow || fin.overflow || gen.overflow) { hc[2] |= ERR_GROUPCAP; return 0; }
   hc[16] = jobs.total; hc[17] = retry.total; hc[18] = gen.total; hc[22] = fin.total;
   t1k_arena_compact(ctx, T1K_AR_JOBS, a.jobStr, a.jobSegCap, a.jobList, jobs.maxSeg);
   t1k_arena_compact(ctx, T1K_AR_FINISH, a.finishStr, a.listSegCap, a.finishList, fin.maxSeg);
   t1k_arena_compact(ctx, T1K_AR_RETRY, a.retryStr, a.listSegCap, a.retryList, retry.maxSeg);
-  t1k_arena_compact(ctx, T1K_AR_GENERAL, a.generalStr, a.listSegCap, a.generalList, gen.maxSeg);
+  t1k_arena_compact(ctx, T1K_AR_GENERAL, a.generalStr, a.rareSegCap, a.generalList, gen.maxSeg);
   const uint32_t nJobs = (uint32_t)jobs.total, nRetry = (uint32_t)retry.total, nGen = (uint32_t)gen.total, nFinish = (uint32_t)fin.total;
   t1k_launch_dp_dense(ctx, a, a.jobList, nJobs);
   if (nFinish) hipLaunchKernelGGL(k_chain_finish, dim3((nFinish + WG - 1) / WG), dim3(WG), 0, ctx->stream, a, nFinish);
@@ -1413,10 +1413,10 @@ int t1k_run_chain(t1k_ctx *ctx, const ChainArgs &a, int nWg, int bigBlocks, bool
     }
     hipLaunchKernelGGL(k_chain_general, dim3((nGen + 63) / 64), dim3(64), 0, ctx->stream, g, nGen);
     if ((rc = readCounters(ctx, hc))) return rc;
-    const T1kArenaCounts wv = t1k_arena_counts(ctx, T1K_AR_WAVE, a.listSegCap);
+    const T1kArenaCounts wv = t1k_arena_counts(ctx, T1K_AR_WAVE, a.rareSegCap);
     if (wv.overflow) { hc[2] |= ERR_GROUPCAP; return 0; }
     if (wv.total) {
-      t1k_arena_compact(ctx, T1K_AR_WAVE, a.waveStr, a.listSegCap, a.waveList, wv.maxSeg);
+      t1k_arena_compact(ctx, T1K_AR_WAVE, a.waveStr, a.rareSegCap, a.waveList, wv.maxSeg);
       T1K_HIP(ctx, hipFuncSetAttribute((const void *)k_chain_wave, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * WAVE_CAP * 4));
       hipLaunchKernelGGL(k_chain_wave, dim3(std::min<uint32_t>((uint32_t)wv.total, 2048u)), dim3(64), 3 * WAVE_CAP * 4, ctx->stream, a, (uint32_t)wv.total);
     }
@@ -1425,9 +1425,9 @@ int t1k_run_chain(t1k_ctx *ctx, const ChainArgs &a, int nWg, int bigBlocks, bool
     t1k_arena_compact(ctx, T1K_AR_GENJOBS, a.genJobStr, a.genJobSegCap, a.genJobList, gj.maxSeg);
     t1k_launch_dp_dense(ctx, a, a.genJobList, (uint32_t)gj.total);
     hipLaunchKernelGGL(k_general_finish, dim3((nGen + WG - 1) / WG), dim3(WG), 0, ctx->stream, a, nGen);
-    const T1kArenaCounts big = t1k_arena_counts(ctx, T1K_AR_BIG, a.listSegCap);
+    const T1kArenaCounts big = t1k_arena_counts(ctx, T1K_AR_BIG, a.rareSegCap);
     if (big.overflow) { hc[2] |= ERR_GROUPCAP; return 0; }
-    t1k_arena_compact(ctx, T1K_AR_BIG, a.bigStr, a.listSegCap, a.bigList, big.maxSeg);
+    t1k_arena_compact(ctx, T1K_AR_BIG, a.bigStr, a.rareSegCap, a.bigList, big.maxSeg);
     nBig = (uint32_t)big.total;
   }
   if (nBig) hipLaunchKernelGGL(k_chain_big, dim3(bigBlocks * 64), dim3(64), 0, ctx->stream, a, nBig);

@@ -566,7 +566,6 @@ enum { T1K_STAT_DP = 0, T1K_STAT_FAST = 1, T1K_STAT_GENERAL = 2, T1K_STAT_EXTEND
 // half the occupancy -- measured per kernel)
 #define T1K_OCC8 __attribute__((amdgpu_waves_per_eu(8)))
 #define T1K_NSTRIPE 32
-#define T1K_LIST_DIV 4   // a work list (group ids of one kind) holds up to a quarter of the group capacity
 enum { T1K_AR_GROUPS = 0, T1K_AR_JOBS, T1K_AR_RETRY, T1K_AR_FINISH, T1K_AR_GENERAL, T1K_AR_BIG, T1K_AR_GENCAND, T1K_AR_EQ, T1K_AR_BAND, T1K_AR_WIDE, T1K_AR_GENHITS, T1K_AR_GENJOBS, T1K_AR_WAVE, T1K_AR_EXTJOBS, T1K_AR_EXTRETRY, T1K_AR_SLOW, T1K_NARENA };
 #define T1K_ARENA_BASE (64 + T1K_STAT_STRIPES * 8)
 #define T1K_COUNTER_WORDS (T1K_ARENA_BASE + T1K_NARENA * T1K_NSTRIPE * 8)
@@ -666,8 +665,11 @@ struct t1k_ctx {
   T1kOvl *ovlBase = nullptr;       // where the last t1k_assign_range wrote its lists (t1k_overlaps_download)
   // working capacities of the batch arenas (t1k_assign_range grows them on demand up to the limits in prm) and the demand the last
   // overflow reported
-  uint64_t wGroup = 0, wCand = 0, wOvl = 0, needGroup = 0, needCand = 0, needOvl = 0;
+  uint64_t wGroup = 0, wList = 0, wRare = 0, wCand = 0, wOvl = 0, needGroup = 0, needList = 0, needRare = 0, needCand = 0, needOvl = 0;
   unsigned long long lastCapFlags = 0;
+  bool scaledOnce = false;
+  double msAlloc = 0;            // wall time spent in hipMalloc (fresh VRAM is zeroed by the driver: ~35 ms per GB)
+  uint64_t bytesAlloc = 0;
   T1kDevBuf bCand, bExt, bCandStart, bCandCount, bOvlStart, bOvlCount, bCounters, bSlowQueue, bSlowScratch, bSortScratch, bEqTrace, bSortTmp, bSlowKeys, bJobSort;
   uint64_t nCand = 0, nOvl = 0;
   // pairing

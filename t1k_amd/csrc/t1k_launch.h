@@ -15,7 +15,7 @@ struct ChainArgs {
   uint32_t *jobList; uint32_t jobCap;
   uint32_t *retryList, *generalList, *bigList, *finishList;  // dense lists (filled by k_arena_compact)
   uint32_t *jobStr, *retryStr, *generalStr, *bigStr, *finishStr, *waveStr, *waveList, *slowStr, *slowList;  // striped arenas the kernels append to
-  uint32_t groupSegCap, jobSegCap, listSegCap, genCandSegCap, genHitSegCap;
+  uint32_t groupSegCap, jobSegCap, listSegCap, rareSegCap, genCandSegCap, genHitSegCap;  // listSegCap: slow / retry / finish lists; rareSegCap: general / wave / big
   uint32_t maxK;  // upper bound of the k-mers of a read-end (both strands): stride of the used-list table
   uint32_t *genJobStr, *genJobList; uint32_t genJobSegCap;  // alignments registered by the multi-diagonal groups
   uint32_t *genHits;  // hit lists of the multi-diagonal groups (k_gather_general)
