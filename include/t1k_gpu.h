@@ -142,6 +142,38 @@ int t1k_rowset_assigned_download(t1k_rowset *rs, uint8_t *fragAssigned);
 /* rows of fragments [first, first + count) in the reference's row order (--outputReadAssignment, tests) */
 int t1k_rowset_rows_download(t1k_rowset *rs, uint64_t first, uint32_t count, uint32_t *rowCounts, t1k_row_entry *rows, uint64_t cap, uint64_t *total);
 
+/* ---- multi-GPU: one rank per GPU, each owning a contiguous slice of the fragments in file order -------------------
+ * Ranks are processes (one per GPU, e.g. under torch.distributed.run: rank 0 calls t1k_comm_unique_id and hands the 128 bytes to
+ * the others) or threads of one process (t1k_comm_group_create: `genotyper --gpus N`).  Transport: RCCL over xGMI (librccl.so.1,
+ * bound lazily); ranks of one process that share a device use an in-process transport (transport = 0, or automatically): that is
+ * how the multi-rank path is tested on one GPU.
+ *   t1k_comm_allreduce            in-place sum over the ranks (kind 0: int32 -- the coverage arrays; 1: f64 -- the EM contributions)
+ *   t1k_rowset_exchange           every fragment row goes to the rank that owns its pattern (hash mod nRanks); that rank coalesces the
+ *                                 group over ALL its fragments in global order, so group contents do not depend on the sharding
+ *   t1k_rowset_groups_gather      every rank's group table on every rank; merged by first fragment on the host (the job layer)
+ *   t1k_em_shard                  t1k_em_update runs the row pass on [rowBegin, rowEnd) only and all-reduces the contribution array
+ *                                 (every element has one writer: exact), then the column pass everywhere: same doubles as on one GPU */
+typedef struct t1k_comm_group t1k_comm_group;
+int t1k_comm_unique_id(void *id128);
+t1k_comm_group *t1k_comm_group_create(int nRanks);
+void t1k_comm_group_destroy(t1k_comm_group *g);
+int t1k_comm_init(t1k_ctx *ctx, int nRanks, int rank, const void *id128, t1k_comm_group *group, int transport /* -1 auto, 0 in-process, 1 RCCL */, t1k_comm **out);
+int t1k_comm_bind(t1k_comm *c, t1k_ctx *ctx);  /* use the communicator with another context of the same device */
+void t1k_comm_destroy(t1k_comm *c);
+const char *t1k_comm_last_error(const t1k_comm *c);
+int t1k_comm_rank(const t1k_comm *c);
+int t1k_comm_size(const t1k_comm *c);
+int t1k_comm_is_rccl(const t1k_comm *c);
+int t1k_comm_allreduce(t1k_comm *c, void *dev, uint64_t count, int kind);
+int t1k_comm_allgather_u64(t1k_comm *c, const uint64_t *mine, uint32_t k, uint64_t *all);
+int t1k_comm_alltoallv(t1k_comm *c, const void *sendbuf, const uint64_t *sendOff, void *recvbuf, const uint64_t *recvOff);
+int t1k_comm_allgatherv(t1k_comm *c, const void *mine, const uint64_t *bytes, const uint64_t *displ, void *out);
+int t1k_comm_allgatherv_host(t1k_comm *c, void *host, const uint64_t *bytes, const uint64_t *displ, uint64_t total);
+int t1k_rowset_exchange(t1k_rowset *rs, t1k_comm *comm, uint64_t fragBase);
+int t1k_rowset_groups_gather(t1k_rowset *rs, t1k_comm *comm, uint64_t *totalGroups, uint64_t *totalEntries, uint64_t *totalAssigned);
+int t1k_rowset_groups_download_all(t1k_rowset *rs, uint32_t *sizes, t1k_group_entry *entries, uint32_t *firstFragment);
+int t1k_em_shard(t1k_ctx *ctx, uint32_t rowBegin, uint32_t rowEnd, t1k_comm *comm);
+
 /* per-base coverage of each allele's own base (posWeight[pos].count[base], SeqSet.hpp:2253-2274, read back by
  * GetSeqMissingBaseCoverage 2717-2755).  out[sum of allele lengths], alleles concatenated in upload order. */
 int t1k_coverage_get(t1k_ctx *ctx, int32_t *out, uint64_t cap);
@@ -248,22 +280,24 @@ int t1k_job_genotype_text(t1k_job *job, char *buf, uint64_t cap, uint64_t *neede
 int t1k_job_counts(t1k_job *job, uint64_t *fragments, uint64_t *assignedFragments, uint64_t *groups, uint64_t *ecs, int32_t *emIterations);
 int t1k_job_stats(t1k_job *job, t1k_stats *out);
 t1k_ctx *t1k_job_ctx(t1k_job *job);
-/* ---- multi-GPU: one job (process) per GPU, each owning a contiguous slice of the fragments in file order -------------
- * t1k_job_run == t1k_job_run_local + t1k_job_finish(0, all groups).  With N ranks:
- *   1. every rank: t1k_job_run_local (read-end assignment, pairing, local coalescing; coverage stays on the device)
- *   2. all-reduce (sum, int32) the coverage difference array returned by t1k_coverage_device over RCCL
- *   3. all-gather the byte strings of t1k_job_groups_serialize; every rank calls t1k_job_groups_reset and absorbs the
- *      strings in rank order (fragment order), which reproduces global first-appearance group numbering
- *   4. every rank: t1k_job_finish(b, e) with its slice [b, e) of the merged groups: local E-step, the callback set by
- *      t1k_job_set_allreduce sums the per-class read counts over the ranks, identical M-step / selection everywhere */
-int t1k_job_set_allreduce(t1k_job *job, t1k_allreduce_fn cb, void *user);
+/* ---- multi-GPU jobs: one job per GPU (rank), every rank loads the same inputs and owns the fragments
+ * [F * rank / nRanks, F * (rank + 1) / nRanks) in file order.  t1k_job_run then does, per rank: read-end assignment and pairing of its
+ * slice (no collective), the coverage all-reduce, the row exchange + coalescing + group gather (t1k_rowset_exchange ...), the
+ * replicated class build, the EM with a sharded row pass, and the replicated selection; every rank ends with the same result and the
+ * complete fragmentAssigned flags, rank 0 writes the files.  The result is identical to a single-GPU run for any nRanks. */
+int t1k_job_set_shard(t1k_job *job, int rank, int nRanks, t1k_comm *comm);
+/* rank threads of one process: dst uses the read files src has mapped (t1k_job_load_reads on src only) */
+int t1k_job_share_reads(t1k_job *dst, t1k_job *src);
 int t1k_job_run_local(t1k_job *job);
-int t1k_job_finish(t1k_job *job, uint64_t emGroupBegin, uint64_t emGroupEnd);
+int t1k_job_finish(t1k_job *job, uint64_t unused0, uint64_t unused1);
+/* the job's group table as a byte string: [u64 nGroups][u64 nEntries][u64 assignedFragments][u64 groupPtr[nGroups+1]]
+ * [u32 firstFragment[nGroups]][t1k_group_entry entries[nEntries]] */
 int t1k_job_groups_serialize(t1k_job *job, void *buf, uint64_t cap, uint64_t *needed);
-int t1k_job_groups_reset(t1k_job *job);
-int t1k_job_groups_absorb(t1k_job *job, const void *buf, uint64_t len);
-/* host-side CoalesceReadAssignments (Genotyper.hpp:841-908) on caller-provided fragment rows, in order (tests; device = -1 jobs) */
-int t1k_job_coalesce_rows(t1k_job *job, const t1k_row_entry *rows, const uint32_t *rowCounts, uint32_t nFragments);
+/* host half of the multi-GPU merge: the tables of all pattern owners become this job's table, ordered by first fragment */
+int t1k_job_groups_merge(t1k_job *job, const void *const *bufs, const uint64_t *lens, uint32_t n);
+/* host-side CoalesceReadAssignments (Genotyper.hpp:841-908) on caller-provided fragment rows, in order (tests; device = -1 jobs);
+ * fragments[i] = global index of fragment i (NULL: 0, 1, ...) */
+int t1k_job_coalesce_rows(t1k_job *job, const t1k_row_entry *rows, const uint32_t *rowCounts, const uint32_t *fragments, uint32_t nFragments);
 /* device pointer + element count of the int32 coverage difference array (for an in-place all-reduce) */
 int t1k_coverage_device(t1k_ctx *ctx, void **devPtr, uint64_t *count);
 

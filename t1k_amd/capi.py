@@ -107,13 +107,25 @@ def lib():
     L.t1k_job_stats.argtypes = [vp, C.POINTER(Stats)]
     L.t1k_job_ctx.argtypes = [vp]
     L.t1k_job_ctx.restype = vp
-    L.t1k_job_set_allreduce.argtypes = [vp, ALLREDUCE_FN, vp]
     L.t1k_job_run_local.argtypes = [vp]
     L.t1k_job_finish.argtypes = [vp, C.c_uint64, C.c_uint64]
     L.t1k_job_groups_serialize.argtypes = [vp, vp, C.c_uint64, u64p]
-    L.t1k_job_groups_reset.argtypes = [vp]
-    L.t1k_job_groups_absorb.argtypes = [vp, vp, C.c_uint64]
-    L.t1k_job_coalesce_rows.argtypes = [vp, vp, vp, C.c_uint32]
+    L.t1k_job_groups_merge.argtypes = [vp, vp, vp, C.c_uint32]
+    L.t1k_job_coalesce_rows.argtypes = [vp, vp, vp, vp, C.c_uint32]
+    L.t1k_job_set_shard.argtypes = [vp, C.c_int, C.c_int, vp]
+    L.t1k_job_share_reads.argtypes = [vp, vp]
+    L.t1k_job_ctx.restype = vp
+    L.t1k_job_ctx.argtypes = [vp]
+    L.t1k_comm_unique_id.argtypes = [vp]
+    L.t1k_comm_init.argtypes = [vp, C.c_int, C.c_int, vp, vp, C.c_int, C.POINTER(vp)]
+    L.t1k_comm_bind.argtypes = [vp, vp]
+    L.t1k_comm_destroy.argtypes = [vp]
+    L.t1k_comm_last_error.restype = C.c_char_p
+    L.t1k_comm_last_error.argtypes = [vp]
+    L.t1k_comm_is_rccl.argtypes = [vp]
+    L.t1k_comm_group_create.restype = vp
+    L.t1k_comm_group_create.argtypes = [C.c_int]
+    L.t1k_comm_group_destroy.argtypes = [vp]
     L.t1k_coverage_device.argtypes = [vp, C.POINTER(vp), u64p]
     _lib = L
     return L
@@ -351,16 +363,23 @@ class Job:
         lib().t1k_job_stats(self.h, C.byref(s))
         return s.as_dict()
 
-    def set_allreduce(self, fn):
-        self._cb = ALLREDUCE_FN(fn)
-        self._check(lib().t1k_job_set_allreduce(self.h, self._cb, None), "t1k_job_set_allreduce")
+    # ---- multi-GPU building blocks (include/t1k_gpu.h, "multi-GPU jobs") ----
+    def set_shard(self, rank, n_ranks, comm):
+        """this job is rank `rank` of `n_ranks`: it owns the fragments [F*rank/n, F*(rank+1)/n) of the loaded input"""
+        self._comm = comm
+        self._check(lib().t1k_job_set_shard(self.h, rank, n_ranks, comm.h if comm is not None else None), "t1k_job_set_shard")
 
-    # ---- multi-GPU building blocks (include/t1k_gpu.h, "multi-GPU") ----
+    def share_reads(self, other):
+        self._check(lib().t1k_job_share_reads(self.h, other.h), "t1k_job_share_reads")
+
+    def ctx(self):
+        return lib().t1k_job_ctx(self.h)
+
     def run_local(self):
         self._check(lib().t1k_job_run_local(self.h), "t1k_job_run_local")
 
-    def finish(self, group_begin=0, group_end=2 ** 64 - 1):
-        self._check(lib().t1k_job_finish(self.h, group_begin, group_end), "t1k_job_finish")
+    def finish(self):
+        self._check(lib().t1k_job_finish(self.h, 0, 0), "t1k_job_finish")
 
     def groups_serialize(self):
         need = C.c_uint64()
@@ -369,17 +388,18 @@ class Job:
         self._check(lib().t1k_job_groups_serialize(self.h, _ptr(buf), need.value, C.byref(need)), "t1k_job_groups_serialize")
         return buf
 
-    def groups_reset(self):
-        self._check(lib().t1k_job_groups_reset(self.h), "t1k_job_groups_reset")
+    def groups_merge(self, bufs):
+        """the group tables of all pattern owners (byte strings of groups_serialize) become this job's table, ordered by first fragment"""
+        bufs = [np.ascontiguousarray(b, dtype=np.uint8) for b in bufs]
+        ptrs = (C.c_void_p * len(bufs))(*[b.ctypes.data for b in bufs])
+        lens = np.array([b.size for b in bufs], dtype=np.uint64)
+        self._check(lib().t1k_job_groups_merge(self.h, ptrs, _ptr(lens), len(bufs)), "t1k_job_groups_merge")
 
-    def groups_absorb(self, buf):
-        buf = np.ascontiguousarray(buf, dtype=np.uint8)
-        self._check(lib().t1k_job_groups_absorb(self.h, _ptr(buf), buf.size), "t1k_job_groups_absorb")
-
-    def coalesce_rows(self, rows, row_counts):
+    def coalesce_rows(self, rows, row_counts, fragments=None):
         rows = np.ascontiguousarray(rows, dtype=ROW_DTYPE)
         rc = np.ascontiguousarray(row_counts, dtype=np.uint32)
-        self._check(lib().t1k_job_coalesce_rows(self.h, _ptr(rows), _ptr(rc), len(rc)), "t1k_job_coalesce_rows")
+        fr = None if fragments is None else np.ascontiguousarray(fragments, dtype=np.uint32)
+        self._check(lib().t1k_job_coalesce_rows(self.h, _ptr(rows), _ptr(rc), _ptr(fr), len(rc)), "t1k_job_coalesce_rows")
 
     def coverage_device(self):
         """(device pointer, element count) of the int32 coverage difference array"""
@@ -388,6 +408,50 @@ class Job:
         if lib().t1k_coverage_device(ctx, C.byref(p), C.byref(n)) != 0:
             raise T1kError("t1k_coverage_device failed")
         return p.value, n.value
+
+
+class CommGroup:
+    """meeting point of the rank threads of one process (t1k_comm_group)"""
+
+    def __init__(self, n_ranks):
+        self.h = lib().t1k_comm_group_create(n_ranks)
+
+    def close(self):
+        if self.h:
+            lib().t1k_comm_group_destroy(self.h)
+            self.h = None
+
+
+def comm_unique_id():
+    """128 bytes from ncclGetUniqueId (rank 0 calls this and hands them to the other ranks)"""
+    buf = np.zeros(128, dtype=np.uint8)
+    if lib().t1k_comm_unique_id(_ptr(buf)) != 0:
+        raise T1kError("t1k_comm_unique_id failed: RCCL not available")
+    return buf
+
+
+class Comm:
+    """One rank's communicator (t1k_comm): RCCL over xGMI between processes / GPUs, in-process transport between threads that share a GPU."""
+
+    def __init__(self, job, n_ranks, rank, unique_id=None, group=None, transport=-1):
+        h = C.c_void_p()
+        uid = None if unique_id is None else np.ascontiguousarray(unique_id, dtype=np.uint8)
+        rc = lib().t1k_comm_init(job.ctx(), n_ranks, rank, _ptr(uid), group.h if group is not None else None, transport, C.byref(h))
+        self.h = h
+        if rc != 0:
+            raise T1kError("t1k_comm_init failed (%d): %s" % (rc, lib().t1k_comm_last_error(h).decode() if h else ""))
+
+    def bind(self, job):
+        if lib().t1k_comm_bind(self.h, job.ctx()) != 0:
+            raise T1kError("t1k_comm_bind failed")
+
+    def is_rccl(self):
+        return bool(lib().t1k_comm_is_rccl(self.h))
+
+    def close(self):
+        if self.h:
+            lib().t1k_comm_destroy(self.h)
+            self.h = None
 
 
 # ---------------------------------------------------------------------------------------------------------------------

@@ -35,7 +35,7 @@ namespace t1k {
 // coalescing (Genotyper::CoalesceReadAssignments, Genotyper.hpp:841-908): fragments with the same allele set share one
 // read group; group ids follow first appearance; weights are floats accumulated in fragment order
 // ------------------------------------------------------------------------------------------------------------------
-void Genotyper::coalesce(t1k_row_entry *row, uint32_t n) {
+void Genotyper::coalesce(t1k_row_entry *row, uint32_t n, uint32_t fragment) {
   if (n == 0) return;
   ++assignedFragments;
   std::sort(row, row + n, [](const t1k_row_entry &a, const t1k_row_entry &b) { return a.allele_idx < b.allele_idx; });
@@ -62,34 +62,26 @@ void Genotyper::coalesce(t1k_row_entry *row, uint32_t n) {
   bucket.push_back((uint32_t)nGroups());
   for (uint32_t j = 0; j < n; ++j) groupEnt.push_back(GroupEntry{row[j].allele_idx, row[j].start, row[j].end, row[j].weight, row[j].adjust_weight});
   groupPtr.push_back(groupEnt.size());
+  groupFirst.push_back(fragment);
 }
 
-// merge a group that another shard (a later slice of the fragments) has already coalesced: same pattern -> same group,
-// weights added in shard order, start = min, and the reference's end rule applied with the shard's (start, end) as if it
-// were one fragment (exact when the shard's entry never triggered the rule)
-void Genotyper::absorb(const GroupEntry *ent, uint32_t n) {
-  if (n == 0) return;
-  uint64_t h = 1469598103934665603ull ^ n;
-  for (uint32_t j = 0; j < n; ++j) { h ^= (uint64_t)(uint32_t)ent[j].allele; h *= 1099511628211ull; h ^= h >> 29; }
-  std::vector<uint32_t> &bucket = groupOfHash[h];
-  for (uint32_t gid : bucket) {
-    uint64_t b = groupPtr[gid];
-    if (groupPtr[gid + 1] - b != n) continue;
-    bool same = true;
-    for (uint32_t j = 0; j < n && same; ++j) same = groupEnt[b + j].allele == ent[j].allele;
-    if (!same) continue;
-    for (uint32_t j = 0; j < n; ++j) {
-      GroupEntry &g = groupEnt[b + j];
-      if (ent[j].start < g.start) g.start = ent[j].start;
-      if (ent[j].end < g.end) g.end = ent[j].start;
-      g.weight += ent[j].weight;
-      g.adjustWeight += ent[j].adjustWeight;
-    }
-    return;
-  }
-  bucket.push_back((uint32_t)nGroups());
-  groupEnt.insert(groupEnt.end(), ent, ent + n);
-  groupPtr.push_back(groupEnt.size());
+void Genotyper::setGroupsMerged(const std::vector<uint32_t> &sizes, const std::vector<GroupEntry> &entries, const std::vector<uint32_t> &first) {
+  const size_t G = sizes.size();
+  std::vector<uint64_t> at(G + 1, 0);
+  for (size_t g = 0; g < G; ++g) at[g + 1] = at[g] + sizes[g];
+  std::vector<uint32_t> order(G);
+  for (size_t g = 0; g < G; ++g) order[g] = (uint32_t)g;
+  std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return first[x] < first[y]; });  // first fragments are distinct
+  groupPtr.assign(G + 1, 0);
+  groupEnt.resize(entries.size());
+  groupFirst.resize(G);
+  groupOfHash.clear();
+  for (size_t i = 0; i < G; ++i) groupPtr[i + 1] = groupPtr[i] + sizes[order[i]];
+  parallelFor(G, [&](size_t i) {
+    const uint32_t g = order[i];
+    groupFirst[i] = first[g];
+    std::copy(entries.begin() + at[g], entries.begin() + at[g + 1], groupEnt.begin() + groupPtr[i]);
+  });
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -187,13 +179,11 @@ void Genotyper::setAbundance(const double *n, const std::vector<int> &ecLen) {
 // ------------------------------------------------------------------------------------------------------------------
 // QuantifyAlleleEquivalentClass (Genotyper.hpp:1142-1328): SQUAREM-accelerated EM; every EMupdate is t1k_em_update
 // ------------------------------------------------------------------------------------------------------------------
-int Genotyper::quantify(t1k_ctx *ctx, t1k_allreduce_fn cb, void *user, std::string &err, uint64_t gBegin, uint64_t gEnd) {
+int Genotyper::quantify(t1k_ctx *ctx, t1k_comm *comm, std::string &err) {
   const double tq0 = hostNowMs();
   RefSet &R = *ref;
-  const size_t E = ecAlleles.size(), Gall = nGroups();
-  if (gEnd > Gall) gEnd = Gall;
-  if (gBegin > gEnd) gBegin = gEnd;
-  const size_t G = gEnd - gBegin;  // rows of the E-step handled by this GPU
+  const size_t E = ecAlleles.size(), G = nGroups();
+  const size_t gBegin = 0;
   std::vector<uint64_t> rowPtr(G + 1, 0);
   std::vector<uint32_t> ecIdx;
   std::vector<double> count(G);
@@ -219,9 +209,13 @@ int Genotyper::quantify(t1k_ctx *ctx, t1k_allreduce_fn cb, void *user, std::stri
     ecLen[e] = len;
   }
   const double tq1 = hostNowMs();
-  if (t1k_em_setup(ctx, rowPtr.data(), ecIdx.data(), count.data(), ecLen.data(), (uint32_t)G, (uint32_t)E, cb, user) != T1K_OK) {
+  if (t1k_em_setup(ctx, rowPtr.data(), ecIdx.data(), count.data(), ecLen.data(), (uint32_t)G, (uint32_t)E, nullptr, nullptr) != T1K_OK) {
     err = t1k_last_error(ctx);
     return -1;
+  }
+  if (comm && t1k_comm_size(comm) > 1) {  // this rank's slice of the read groups for the row pass of every EMupdate
+    const uint64_t n = (uint64_t)t1k_comm_size(comm), r = (uint64_t)t1k_comm_rank(comm);
+    if (t1k_em_shard(ctx, (uint32_t)(G * r / n), (uint32_t)(G * (r + 1) / n), comm) != T1K_OK) { err = t1k_last_error(ctx); return -1; }
   }
   const double tq2 = hostNowMs();
   std::vector<double> x0(E), x1(E), x2(E), x3(E), n(E);

@@ -27,7 +27,10 @@ struct t1k_job {
   t1k_ctx *ctx = nullptr;           // owns the reference, pipeline 0, final stages (missing coverage, coalescing, EM)
   std::vector<t1k_ctx *> more;      // further pipelines on the same GPU (own stream and batch arenas): several batches in flight
   t1k_ctx *reader[2] = {nullptr, nullptr};  // the read sets of two consecutive windows of fragments (upload, pack, identical-read-end collapse)
-  std::unique_ptr<ReadInput> in;    // the read files, mapped and indexed
+  std::shared_ptr<ReadInput> in;    // the read files, mapped and indexed (the rank threads of one process share one)
+  // multi-GPU: this job is rank `rank` of `nRanks`; it owns fragments [F * rank / nRanks, F * (rank + 1) / nRanks) of the input
+  int rank = 0, nRanks = 1;
+  t1k_comm *comm = nullptr;         // not owned
   t1k_rowset *rows = nullptr;       // every fragment's row, resident on the GPU until the job is coalesced
   std::vector<uint8_t> fragAssigned;
   bool ran = false, localDone = false;
@@ -36,8 +39,6 @@ struct t1k_job {
   std::string assignText;           // --outputReadAssignment rows
   t1k_stats stats{};
   uint64_t distinctReadEnds = 0, readEnds = 0;
-  t1k_allreduce_fn allreduce = nullptr;
-  void *allreduceUser = nullptr;
   double msLoad = 0, msDevice = 0, msHost = 0, msEm = 0, msCoalesce = 0, msWrite = 0;
 };
 
@@ -171,9 +172,16 @@ int t1k_job_stage_reads(t1k_job *job) {  // kept for callers of round 1: reads n
   return T1K_OK;
 }
 
-int t1k_job_set_allreduce(t1k_job *job, t1k_allreduce_fn cb, void *user) {
-  if (!job) return T1K_ERR_ARG;
-  job->allreduce = cb; job->allreduceUser = user;
+int t1k_job_set_shard(t1k_job *job, int rank, int nRanks, t1k_comm *comm) {
+  if (!job || nRanks < 1 || rank < 0 || rank >= nRanks || (nRanks > 1 && !comm)) return T1K_ERR_ARG;
+  job->rank = rank; job->nRanks = nRanks; job->comm = comm;
+  return T1K_OK;
+}
+
+int t1k_job_share_reads(t1k_job *dst, t1k_job *src) {
+  if (!dst || !src || !src->in) return T1K_ERR_ARG;
+  dst->in = src->in;
+  dst->ran = false; dst->localDone = false;
   return T1K_OK;
 }
 
@@ -234,12 +242,15 @@ int t1k_job_run_local(t1k_job *job) {
   // fresh state (a job may be run repeatedly, e.g. by the benchmark)
   Genotyper &gt = job->gt;
   const ReadInput &in = *job->in;
-  gt.groupPtr.assign(1, 0); gt.groupEnt.clear(); gt.groupOfHash.clear(); gt.assignedFragments = 0; gt.emIterations = 0;
+  gt.groupPtr.assign(1, 0); gt.groupEnt.clear(); gt.groupFirst.clear(); gt.groupOfHash.clear(); gt.assignedFragments = 0; gt.emIterations = 0;
   gt.readLength = in.maxLen;  // Genotyper.cpp:443
   for (auto &a : job->ref.al) { a.rank = -1; a.quality = -1; a.abundance = a.ecAbundance = 0; a.ec = -1; a.missingCov = 0; }
-  const uint32_t F = (uint32_t)in.nFrag();
+  const uint32_t Fall = (uint32_t)in.nFrag();
+  const uint32_t fBeg = (uint32_t)((uint64_t)Fall * job->rank / job->nRanks), fEnd = (uint32_t)((uint64_t)Fall * (job->rank + 1) / job->nRanks);
+  const uint32_t F = fEnd - fBeg;  // this rank's fragments; local index f <-> fragment fBeg + f of the input
   const uint32_t per = in.paired ? 2 : 1;
-  job->fragAssigned.assign(F, 0);
+  job->fragAssigned.assign(Fall, 0);
+  if (job->nRanks > 1 && job->prm.output_read_assignment) return jobFail(job, T1K_ERR_ARG, "--outputReadAssignment is not available when the job is sharded over several GPUs");
   job->assignText.clear();
   memset(&job->stats, 0, sizeof(job->stats));
   job->distinctReadEnds = 0; job->readEnds = (uint64_t)F * per;
@@ -306,7 +317,7 @@ int t1k_job_run_local(t1k_job *job) {
       parallelRanges(nf, T, [&](int t, size_t b, size_t e) {
         uint64_t run = 0;
         for (size_t i = b; i < e; ++i) {
-          const uint32_t r = in.frag[W.f0 + i];
+          const uint32_t r = in.frag[fBeg + W.f0 + i];
           for (uint32_t m = 0; m < per; ++m) { off[i * per + m] = run; run += in.side[m].seqL[r]; }
         }
         pieceBytes[t + 1] = run;
@@ -317,7 +328,7 @@ int t1k_job_run_local(t1k_job *job) {
       parallelRanges(nf, T, [&](int t, size_t b, size_t e) {
         const uint64_t carry = pieceBytes[t];
         for (size_t i = b; i < e; ++i) {
-          const uint32_t r = in.frag[W.f0 + i];
+          const uint32_t r = in.frag[fBeg + W.f0 + i];
           bool n = false;
           for (uint32_t m = 0; m < per; ++m) {
             const uint32_t len = in.side[m].seqL[r];
@@ -441,17 +452,12 @@ int t1k_job_run_local(t1k_job *job) {
   const double tDev = nowMs();
   for (t1k_ctx *c : job->more)
     if ((rc = t1k_coverage_absorb(job->ctx, c)) != T1K_OK) return jobFail(job, rc, t1k_last_error(job->ctx));
-  // ---- CoalesceReadAssignments over all fragments (t1k_coalesce.hip), groups back to the host ---------------------------
-  uint64_t G = 0, N = 0, assigned = 0;
-  if ((rc = t1k_rowset_coalesce(job->rows, &G, &N, &assigned)) != T1K_OK) return jobFail(job, rc, t1k_rowset_last_error(job->rows));
-  gt.groupPtr.assign(G + 1, 0);
-  gt.groupEnt.resize(N);
-  static_assert(sizeof(GroupEntry) == sizeof(t1k_group_entry), "group entry layouts differ");
-  if ((rc = t1k_rowset_groups_download(job->rows, gt.groupPtr.data(), (t1k_group_entry *)gt.groupEnt.data(), nullptr)) != T1K_OK)
-    return jobFail(job, rc, t1k_rowset_last_error(job->rows));
-  gt.assignedFragments = assigned;
-  if ((rc = t1k_rowset_assigned_download(job->rows, job->fragAssigned.data())) != T1K_OK) return jobFail(job, rc, t1k_rowset_last_error(job->rows));
-  job->stats.read_ends_total = job->readEnds;
+  const bool sharded = job->nRanks > 1;
+  if (sharded) {  // per-base coverage of all ranks: integers, exact in any order
+    void *cov = nullptr; uint64_t covN = 0;
+    if ((rc = t1k_coverage_device(job->ctx, &cov, &covN)) != T1K_OK) return jobFail(job, rc, t1k_last_error(job->ctx));
+    if ((rc = t1k_comm_allreduce(job->comm, cov, covN, 0)) != T1K_OK) return jobFail(job, rc, t1k_comm_last_error(job->comm));
+  }
   if (job->prm.output_read_assignment) {  // Genotyper.cpp:553-560: the rows in the reference's order, before coalescing
     const uint32_t step = 1u << 18;
     std::vector<uint32_t> cnt;
@@ -466,8 +472,8 @@ int t1k_job_run_local(t1k_job *job) {
       if (total && (rc = t1k_rowset_rows_download(job->rows, f0, n, cnt.data(), rows.data(), total, &total)) != T1K_OK) return jobFail(job, rc, t1k_rowset_last_error(job->rows));
       uint64_t p = 0;
       for (uint32_t i = 0; i < n; ++i) {
-        const uint32_t r = in.frag[f0 + i];
-        const std::string id = in.noIds ? "r" + std::to_string(f0 + i) : std::string(in.side[0].idP[r], in.side[0].idL[r]);
+        const uint32_t r = in.frag[fBeg + f0 + i];
+        const std::string id = in.noIds ? "r" + std::to_string(fBeg + f0 + i) : std::string(in.side[0].idP[r], in.side[0].idL[r]);
         for (uint32_t j = 0; j < cnt[i]; ++j, ++p) {
           job->assignText += id; job->assignText += '\t'; job->assignText += job->ref.al[rows[p].allele_idx].name;
           snprintf(num, sizeof(num), "\t%d\t%d\n", rows[p].start, rows[p].end);
@@ -476,6 +482,35 @@ int t1k_job_run_local(t1k_job *job) {
       }
     }
   }
+  // ---- CoalesceReadAssignments over all fragments (t1k_coalesce.hip), groups back to the host ---------------------------
+  // Sharded: every row first travels to the rank that owns its pattern, which folds the group over ALL its fragments in global
+  // order; the owners' tables are gathered on every rank and merged by first fragment (= first-appearance numbering).
+  uint64_t G = 0, N = 0, assigned = 0;
+  static_assert(sizeof(GroupEntry) == sizeof(t1k_group_entry), "group entry layouts differ");
+  if (sharded && (rc = t1k_rowset_exchange(job->rows, job->comm, fBeg)) != T1K_OK) return jobFail(job, rc, t1k_rowset_last_error(job->rows));
+  if ((rc = t1k_rowset_coalesce(job->rows, &G, &N, &assigned)) != T1K_OK) return jobFail(job, rc, t1k_rowset_last_error(job->rows));
+  if (!sharded) {
+    gt.groupPtr.assign(G + 1, 0);
+    gt.groupEnt.resize(N);
+    gt.groupFirst.resize(G);
+    if ((rc = t1k_rowset_groups_download(job->rows, gt.groupPtr.data(), (t1k_group_entry *)gt.groupEnt.data(), gt.groupFirst.data())) != T1K_OK)
+      return jobFail(job, rc, t1k_rowset_last_error(job->rows));
+    if ((rc = t1k_rowset_assigned_download(job->rows, job->fragAssigned.data())) != T1K_OK) return jobFail(job, rc, t1k_rowset_last_error(job->rows));
+  } else {
+    if ((rc = t1k_rowset_groups_gather(job->rows, job->comm, &G, &N, &assigned)) != T1K_OK) return jobFail(job, rc, t1k_rowset_last_error(job->rows));
+    std::vector<uint32_t> sizes(G), first(G);
+    std::vector<GroupEntry> ents(N);
+    if ((rc = t1k_rowset_groups_download_all(job->rows, sizes.data(), (t1k_group_entry *)ents.data(), first.data())) != T1K_OK)
+      return jobFail(job, rc, t1k_rowset_last_error(job->rows));
+    gt.setGroupsMerged(sizes, ents, first);
+    // fragmentAssigned of every rank's slice on every rank (rank 0 writes the *_aligned*.fa files)
+    if ((rc = t1k_rowset_assigned_download(job->rows, job->fragAssigned.data() + fBeg)) != T1K_OK) return jobFail(job, rc, t1k_rowset_last_error(job->rows));
+    std::vector<uint64_t> bytes(job->nRanks), displ(job->nRanks);
+    for (int r = 0; r < job->nRanks; ++r) { displ[r] = (uint64_t)Fall * r / job->nRanks; bytes[r] = (uint64_t)Fall * (r + 1) / job->nRanks - displ[r]; }
+    if ((rc = t1k_comm_allgatherv_host(job->comm, job->fragAssigned.data(), bytes.data(), displ.data(), Fall)) != T1K_OK) return jobFail(job, rc, t1k_comm_last_error(job->comm));
+  }
+  gt.assignedFragments = assigned;
+  job->stats.read_ends_total = job->readEnds;
   t1k_rowset_destroy(job->rows);
   job->rows = nullptr;
   job->msDevice = tDev - tStart; job->msCoalesce = nowMs() - tDev; job->msHost = 0;
@@ -505,7 +540,8 @@ int t1k_job_finish(t1k_job *job, uint64_t emGroupBegin, uint64_t emGroupEnd) {
   if (!job->abundanceFile.empty()) {
     if (!loadAbundance(job)) return T1K_ERR_IO;
   } else {
-    if (gt.quantify(job->ctx, job->allreduce, job->allreduceUser, job->err, emGroupBegin, emGroupEnd) < 0) return T1K_ERR_DEVICE;
+    (void)emGroupBegin; (void)emGroupEnd;
+    if (gt.quantify(job->ctx, job->comm, job->err) < 0) return T1K_ERR_DEVICE;
   }
   double t4 = nowMs();
   gt.dropUnlikely();
@@ -528,56 +564,63 @@ int t1k_job_run(t1k_job *job) {
   return t1k_job_finish(job, 0, ~0ull);
 }
 
-// group table <-> byte string: [u64 nGroups][u64 nEntries][u64 assignedFragments][u64 groupPtr[nGroups+1]][GroupEntry entries[nEntries]]
+// group table <-> byte string: [u64 nGroups][u64 nEntries][u64 assignedFragments][u64 groupPtr[nGroups+1]][u32 firstFragment[nGroups]][GroupEntry entries[nEntries]]
 int t1k_job_groups_serialize(t1k_job *job, void *buf, uint64_t cap, uint64_t *needed) {
   if (!job) return T1K_ERR_ARG;
   const Genotyper &gt = job->gt;
   const uint64_t G = gt.nGroups(), N = gt.groupEnt.size();
-  const uint64_t bytes = 24 + (G + 1) * 8 + N * sizeof(GroupEntry);
+  const uint64_t bytes = 24 + (G + 1) * 8 + G * 4 + N * sizeof(GroupEntry);
   if (needed) *needed = bytes;
   if (!buf) return T1K_OK;
   if (cap < bytes) return jobFail(job, T1K_ERR_ARG, "group buffer too small");
+  if (gt.groupFirst.size() != G) return jobFail(job, T1K_ERR_STATE, "group table without first fragments");
   uint8_t *p = (uint8_t *)buf;
   uint64_t head[3] = {G, N, gt.assignedFragments};
   memcpy(p, head, 24); p += 24;
   memcpy(p, gt.groupPtr.data(), (G + 1) * 8); p += (G + 1) * 8;
+  if (G) memcpy(p, gt.groupFirst.data(), G * 4);
+  p += G * 4;
   if (N) memcpy(p, gt.groupEnt.data(), N * sizeof(GroupEntry));
   return T1K_OK;
 }
 
-int t1k_job_groups_reset(t1k_job *job) {
-  if (!job) return T1K_ERR_ARG;
-  Genotyper &gt = job->gt;
-  gt.groupPtr.assign(1, 0); gt.groupEnt.clear(); gt.groupOfHash.clear(); gt.assignedFragments = 0;
-  return T1K_OK;
-}
-
-int t1k_job_groups_absorb(t1k_job *job, const void *buf, uint64_t len) {
-  if (!job || !buf || len < 24) return T1K_ERR_ARG;
-  const uint8_t *p = (const uint8_t *)buf;
-  uint64_t head[3];
-  memcpy(head, p, 24);
-  const uint64_t G = head[0], N = head[1];
-  if (len < 24 + (G + 1) * 8 + N * sizeof(GroupEntry)) return jobFail(job, T1K_ERR_ARG, "truncated group table");
-  const uint64_t *gp = (const uint64_t *)(p + 24);
-  const GroupEntry *ent = (const GroupEntry *)(p + 24 + (G + 1) * 8);
-  std::vector<GroupEntry> row;
-  for (uint64_t g = 0; g < G; ++g) {
-    row.assign(ent + gp[g], ent + gp[g + 1]);  // copy: the source may be unaligned for GroupEntry
-    job->gt.absorb(row.data(), (uint32_t)row.size());
+// The host half of the multi-GPU merge: the group tables of all pattern owners (serialized as above; every pattern lives in exactly
+// one of them) become this job's table, groups ordered by their first fragment.
+int t1k_job_groups_merge(t1k_job *job, const void *const *bufs, const uint64_t *lens, uint32_t n) {
+  if (!job || !bufs || !lens) return T1K_ERR_ARG;
+  std::vector<uint32_t> sizes, first;
+  std::vector<GroupEntry> ents;
+  uint64_t assigned = 0;
+  for (uint32_t i = 0; i < n; ++i) {
+    const uint8_t *p = (const uint8_t *)bufs[i];
+    if (!p || lens[i] < 24) return jobFail(job, T1K_ERR_ARG, "truncated group table");
+    uint64_t head[3];
+    memcpy(head, p, 24);
+    const uint64_t G = head[0], N = head[1];
+    if (lens[i] < 24 + (G + 1) * 8 + G * 4 + N * sizeof(GroupEntry)) return jobFail(job, T1K_ERR_ARG, "truncated group table");
+    assigned += head[2];
+    std::vector<uint64_t> gp(G + 1);
+    memcpy(gp.data(), p + 24, (G + 1) * 8);
+    const size_t g0 = sizes.size(), e0 = ents.size();
+    sizes.resize(g0 + G); first.resize(g0 + G); ents.resize(e0 + N);
+    for (uint64_t g = 0; g < G; ++g) sizes[g0 + g] = (uint32_t)(gp[g + 1] - gp[g]);
+    if (G) memcpy(first.data() + g0, p + 24 + (G + 1) * 8, G * 4);
+    if (N) memcpy(ents.data() + e0, p + 24 + (G + 1) * 8 + G * 4, N * sizeof(GroupEntry));
   }
-  job->gt.assignedFragments += head[2];
+  job->gt.setGroupsMerged(sizes, ents, first);
+  job->gt.assignedFragments = assigned;
   return T1K_OK;
 }
 
-int t1k_job_coalesce_rows(t1k_job *job, const t1k_row_entry *rows, const uint32_t *rowCounts, uint32_t nFragments) {
+// host-side CoalesceReadAssignments on caller-provided fragment rows, in order; fragments[i] = global index of fragment i (NULL: 0, 1, ...)
+int t1k_job_coalesce_rows(t1k_job *job, const t1k_row_entry *rows, const uint32_t *rowCounts, const uint32_t *fragments, uint32_t nFragments) {
   if (!job || !rowCounts || (!rows && nFragments)) return T1K_ERR_ARG;
   std::vector<t1k_row_entry> tmp;
   uint64_t p = 0;
   for (uint32_t f = 0; f < nFragments; ++f) {
     tmp.assign(rows + p, rows + p + rowCounts[f]);
     p += rowCounts[f];
-    job->gt.coalesce(tmp.data(), (uint32_t)tmp.size());
+    job->gt.coalesce(tmp.data(), (uint32_t)tmp.size(), fragments ? fragments[f] : f);
   }
   return T1K_OK;
 }
@@ -737,7 +780,8 @@ static const char *kUsage =
     "\t--alleleDelimiter CHR: delimiter of the name units (default: automatic)\n"
     "\t--outputReadAssignment: write prefix_assign.tsv\n"
     "\t--squaremMinAlpha FLOAT: lower bound (negative) of the SQUAREM step length\n"
-    "\t--device INT: GPU ordinal (default: $T1K_DEVICE or 0)\n";
+    "\t--device INT: GPU ordinal (default: $T1K_DEVICE or 0)\n"
+    "\t--gpus INT: shard the fragments over the first INT GPUs ($T1K_GPUS=0,1,.. names them; a GPU may be named twice)\n";
 
 int t1k_genotyper_main(int argc, char **argv) {
   if (argc <= 1) { fprintf(stderr, "%s", kUsage); return 0; }  // Genotyper.cpp:199-203
@@ -745,10 +789,11 @@ int t1k_genotyper_main(int argc, char **argv) {
                                      {"barcode", required_argument, 0, 1003}, {"relaxIntronAlign", no_argument, 0, 1004},
                                      {"alleleDigitUnits", required_argument, 0, 1005}, {"alleleDelimiter", required_argument, 0, 1006},
                                      {"alleleWhitelist", required_argument, 0, 1007}, {"outputReadAssignment", no_argument, 0, 1008},
-                                     {"squaremMinAlpha", required_argument, 0, 1009}, {"device", required_argument, 0, 1010}, {0, 0, 0, 0}};
+                                     {"squaremMinAlpha", required_argument, 0, 1009}, {"device", required_argument, 0, 1010}, {"gpus", required_argument, 0, 1011}, {0, 0, 0, 0}};
   t1k_job_params p;
   t1k_job_params_default(&p);
   if (const char *d = getenv("T1K_DEVICE")) p.device = atoi(d);
+  int nGpus = 0;
   std::string refFile, prefix = "t1k", barcode, whitelistFile, abundance;
   std::vector<const char *> f1, f2, single;  // every -u / -1 / -2 counts: the files are read back to back (ReadFiles::AddReadFile)
   optind = 1;
@@ -776,22 +821,41 @@ int t1k_genotyper_main(int argc, char **argv) {
       case 1008: p.output_read_assignment = 1; break;
       case 1009: p.squarem_min_alpha = atof(optarg); break;
       case 1010: p.device = atoi(optarg); break;
+      case 1011: nGpus = atoi(optarg); break;
       default: fprintf(stderr, "%s", kUsage); return EXIT_FAILURE;
     }
   }
   if (refFile.empty()) { fprintf(stderr, "Need to use -f to specify the reference sequences.\n"); return EXIT_FAILURE; }
   if (p.dev.max_assign_cnt == 0) p.dev.max_assign_cnt = -1;  // "-n 0" disables the cap in the reference (maxAssignCnt > 0 test)
-  t1k_job *job = nullptr;
-  int rc = t1k_job_create(&p, refFile.c_str(), &job);
-  if (rc != T1K_OK) {
-    fprintf(stderr, "genotyper: %s\n", job ? t1k_job_last_error(job) : "initialisation failed");
-    if (job && job->ref.al.empty()) fprintf(stderr, "Need to use -f to specify the reference sequences.\n");
-    t1k_job_destroy(job);
-    return EXIT_FAILURE;
+  // GPUs of the job: --gpus N = the first N devices, T1K_GPUS = an explicit list; one rank (thread, job, context set) per entry
+  std::vector<int> devices;
+  if (const char *e = getenv("T1K_GPUS")) {
+    for (const char *q = e; *q;) { devices.push_back(atoi(q)); while (*q && *q != ',') ++q; if (*q == ',') ++q; }
+  } else if (nGpus > 1) {
+    for (int d = 0; d < nGpus; ++d) devices.push_back(d);
   }
+  if (devices.empty()) devices.push_back(p.device);
+  const int R = (int)devices.size();
+  std::vector<t1k_job *> jobs(R, nullptr);
+  std::vector<int> rcs(R, T1K_OK);
+  auto destroyAll = [&] { for (t1k_job *j : jobs) t1k_job_destroy(j); };
+  {
+    std::vector<std::thread> th;
+    for (int r = 0; r < R; ++r)
+      th.emplace_back([&, r] { t1k_job_params q = p; q.device = devices[r]; rcs[r] = t1k_job_create(&q, refFile.c_str(), &jobs[r]); });
+    for (auto &t : th) t.join();
+  }
+  for (int r = 0; r < R; ++r)
+    if (rcs[r] != T1K_OK) {
+      fprintf(stderr, "genotyper: %s\n", jobs[r] ? t1k_job_last_error(jobs[r]) : "initialisation failed");
+      if (jobs[r] && jobs[r]->ref.al.empty()) fprintf(stderr, "Need to use -f to specify the reference sequences.\n");
+      destroyAll();
+      return EXIT_FAILURE;
+    }
+  t1k_job *job = jobs[0];
   if (!whitelistFile.empty()) {  // Genotyper::SetAlleleWhitelist (Genotyper.hpp:684-705): whole major-allele series
     FILE *fp = fopen(whitelistFile.c_str(), "r");
-    if (!fp) { fprintf(stderr, "genotyper: cannot open %s\n", whitelistFile.c_str()); t1k_job_destroy(job); return EXIT_FAILURE; }
+    if (!fp) { fprintf(stderr, "genotyper: cannot open %s\n", whitelistFile.c_str()); destroyAll(); return EXIT_FAILURE; }
     std::set<int> majors;
     std::map<std::string, int> majorId;
     for (size_t i = 0; i < job->ref.majorName.size(); ++i) majorId[job->ref.majorName[i]] = (int)i;
@@ -803,27 +867,49 @@ int t1k_genotyper_main(int argc, char **argv) {
       if (it != majorId.end()) majors.insert(it->second);
     }
     fclose(fp);
-    job->whitelist.assign(job->ref.al.size(), 0);
-    for (size_t a = 0; a < job->ref.al.size(); ++a) job->whitelist[a] = majors.count(job->ref.al[a].major) ? 1 : 0;
+    for (t1k_job *j : jobs) {
+      j->whitelist.assign(j->ref.al.size(), 0);
+      for (size_t a = 0; a < j->ref.al.size(); ++a) j->whitelist[a] = majors.count(j->ref.al[a].major) ? 1 : 0;
+    }
   }
-  job->abundanceFile = abundance;
+  for (t1k_job *j : jobs) j->abundanceFile = abundance;
   const bool paired = !f2.empty();
   const std::vector<const char *> &first = !f1.empty() ? f1 : single;
-  if (first.empty()) { fprintf(stderr, "genotyper: no read file given (-u, or -1 and -2)\n"); t1k_job_destroy(job); return EXIT_FAILURE; }
-  rc = t1k_job_load_reads_multi(job, first.data(), (uint32_t)first.size(), paired ? f2.data() : nullptr, (uint32_t)f2.size(), barcode.empty() ? nullptr : barcode.c_str());
-  if (rc != T1K_OK) { fprintf(stderr, "genotyper: %s\n", t1k_job_last_error(job)); t1k_job_destroy(job); return EXIT_FAILURE; }
+  if (first.empty()) { fprintf(stderr, "genotyper: no read file given (-u, or -1 and -2)\n"); destroyAll(); return EXIT_FAILURE; }
+  int rc = t1k_job_load_reads_multi(job, first.data(), (uint32_t)first.size(), paired ? f2.data() : nullptr, (uint32_t)f2.size(), barcode.empty() ? nullptr : barcode.c_str());
+  if (rc != T1K_OK) { fprintf(stderr, "genotyper: %s\n", t1k_job_last_error(job)); destroyAll(); return EXIT_FAILURE; }
   logLine("Found %d read fragments. Start read assignment.", (int)job->in->nFrag());
-  rc = t1k_job_run(job);
-  if (rc != T1K_OK) { fprintf(stderr, "genotyper: %s\n", t1k_job_last_error(job)); t1k_job_destroy(job); return EXIT_FAILURE; }
+  if (R == 1) rc = t1k_job_run(job);
+  else {
+    // one thread per rank: the ranks meet in the collectives of t1k_job_run (RCCL when every rank has its own GPU)
+    t1k_comm_group *group = t1k_comm_group_create(R);
+    std::vector<t1k_comm *> comms(R, nullptr);
+    std::vector<std::thread> th;
+    for (int r = 0; r < R; ++r)
+      th.emplace_back([&, r] {
+        int x = r ? t1k_job_share_reads(jobs[r], job) : T1K_OK;
+        const int y = t1k_comm_init(t1k_job_ctx(jobs[r]), R, r, nullptr, group, -1, &comms[r]);  // collective: every rank calls it
+        if (x == T1K_OK && y != T1K_OK) { jobs[r]->err = comms[r] ? t1k_comm_last_error(comms[r]) : "cannot create the communicator"; x = y; }
+        if (x == T1K_OK) x = t1k_job_set_shard(jobs[r], r, R, comms[r]);
+        // a rank that failed before the first collective must still not leave the others waiting: it runs with nothing to do
+        rcs[r] = x == T1K_OK ? t1k_job_run(jobs[r]) : x;
+      });
+    for (auto &t : th) t.join();
+    for (int r = 0; r < R; ++r)
+      if (rcs[r] != T1K_OK && rc == T1K_OK) { rc = rcs[r]; if (r) job->err = t1k_job_last_error(jobs[r]); }
+    for (t1k_comm *c : comms) t1k_comm_destroy(c);
+    t1k_comm_group_destroy(group);
+  }
+  if (rc != T1K_OK) { fprintf(stderr, "genotyper: %s\n", t1k_job_last_error(job)); destroyAll(); return EXIT_FAILURE; }
   logLine("Finish read end assignments.");
   const double groups = (double)job->gt.nGroups();
   logLine("Finish read fragment assignments. %d read fragments can be assigned (average %.2lf alleles/read).", (int)job->gt.assignedFragments,
           job->gt.sumAssign / groups);
   if (abundance.empty()) logLine("Finish allele quantification in %d EM iterations.", job->gt.emIterations);
   rc = t1k_job_write_outputs(job, prefix.c_str());
-  if (rc != T1K_OK) { fprintf(stderr, "genotyper: %s\n", t1k_job_last_error(job)); t1k_job_destroy(job); return EXIT_FAILURE; }
+  if (rc != T1K_OK) { fprintf(stderr, "genotyper: %s\n", t1k_job_last_error(job)); destroyAll(); return EXIT_FAILURE; }
   logLine("Genotyping finishes.");
-  t1k_job_destroy(job);
+  destroyAll();
   return 0;
 }
 

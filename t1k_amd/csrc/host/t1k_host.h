@@ -90,6 +90,7 @@ struct Genotyper {
   // coalesced read groups (Genotyper::readAssignments, Genotyper.hpp:443), CSR
   std::vector<uint64_t> groupPtr{0};
   std::vector<GroupEntry> groupEnt;
+  std::vector<uint32_t> groupFirst;   // the fragment that opened each group (host coalescing and the multi-GPU merge keep it)
   std::unordered_map<uint64_t, std::vector<uint32_t>> groupOfHash;
   uint64_t assignedFragments = 0;
   double sumAssign = 0;
@@ -102,11 +103,14 @@ struct Genotyper {
   int emIterations = 0;
 
   size_t nGroups() const { return groupPtr.size() - 1; }
-  void coalesce(t1k_row_entry *row, uint32_t n);             // CoalesceReadAssignments (841-908), one fragment
+  void coalesce(t1k_row_entry *row, uint32_t n, uint32_t fragment = 0);  // CoalesceReadAssignments (841-908), one fragment
+  // group tables of several owners (every pattern belongs to exactly one of them) -> one table in first-fragment order = the
+  // reference's first-appearance numbering
+  void setGroupsMerged(const std::vector<uint32_t> &sizes, const std::vector<GroupEntry> &entries, const std::vector<uint32_t> &first);
   void finalize(const std::vector<int32_t> &missing);        // FinalizeReadAssignments (912-939); missing[a] from t1k_missing_coverage
   // QuantifyAlleleEquivalentClass (1142-1328); the E-step covers groups [gBegin, gEnd) (the whole table on one GPU)
-  int quantify(t1k_ctx *ctx, t1k_allreduce_fn cb, void *user, std::string &err, uint64_t gBegin = 0, uint64_t gEnd = ~0ull);
-  void absorb(const GroupEntry *ent, uint32_t n);               // merge one already-coalesced group of another shard
+  // the E-step's row pass covers the slice `rank` of `nRanks` of the read groups when a communicator is given (t1k_em_shard)
+  int quantify(t1k_ctx *ctx, t1k_comm *comm, std::string &err);
   void dropUnlikely();                                       // RemoveLowLikelihoodAlleleInEquivalentClass (1371-1460)
   void select();                                             // SelectAllelesForGenes (1462-2090)
   std::string geneLine(int gene) const;                      // GetAlleleDescription (2103-2178) + Genotyper.cpp:660-670

@@ -58,13 +58,13 @@ __global__ void k_co_heads(const uint32_t *idx, const uint32_t *flag, const uint
   if (j == m - 1) runStart[runOf[j]] = m;
 }
 // group g (first-appearance order) is run order[g]; its size, its 64-slot tiles
-__global__ void k_co_sizes(const uint32_t *order, const uint32_t *runStart, const uint32_t *idx, const uint32_t *rowCount, uint32_t *gSize, uint32_t *gTiles, uint32_t *gFirst,
-                           uint32_t G) {
+__global__ void k_co_sizes(const uint32_t *order, const uint32_t *runStart, const uint32_t *idx, const uint32_t *rowCount, const uint32_t *gid, uint32_t *gSize,
+                           uint32_t *gTiles, uint32_t *gFirst, uint32_t G) {
   const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= G) return;
   const uint32_t f = idx[runStart[order[g]]];
   const uint32_t n = rowCount[f];
-  gSize[g] = n; gTiles[g] = (n + 63) / 64; gFirst[g] = f;
+  gSize[g] = n; gTiles[g] = (n + 63) / 64; gFirst[g] = gid ? gid[f] : f;
 }
 __global__ void k_co_tilemap(const unsigned long long *tilePtr, const uint32_t *gTiles, uint32_t *tileGroup, uint32_t G) {
   const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
@@ -174,7 +174,7 @@ int t1k_rowset_create(t1k_ctx *owner, uint64_t nFragments, const uint8_t *whitel
 void t1k_rowset_destroy(t1k_rowset *rs) {
   if (!rs) return;
   (void)hipSetDevice(rs->device);
-  T1kDevBuf *all[] = {&rs->bFrag, &rs->bCursors, &rs->bWhitelist, &rs->bWork, &rs->bGroupPtr, &rs->bGroupEnt, &rs->bGroupFirst};
+  T1kDevBuf *all[] = {&rs->bFrag, &rs->bCursors, &rs->bWhitelist, &rs->bWork, &rs->bGroupPtr, &rs->bGroupEnt, &rs->bGroupFirst, &rs->bSend, &rs->bRecv, &rs->bFrag2, &rs->bAll};
   for (auto *b : all) if (b->p) (void)hipFree(b->p);
   for (auto &b : rs->chunks) if (b.p) (void)hipFree(b.p);
   delete rs;
@@ -188,11 +188,12 @@ int t1k_rowset_coalesce(t1k_rowset *rs, uint64_t *nGroups, uint64_t *nEntries, u
   RS_HIP(hipSetDevice(rs->device));
   hipStream_t st = ctx->stream;
   const uint32_t F = (uint32_t)rs->nFrag;
-  rs->nGroups = rs->nEntries = rs->nAssigned = 0;
+  rs->nGroups = rs->nEntries = 0;
+  if (!rs->exchanged) rs->nAssigned = 0;
   rs->coalesced = true;
   if (nGroups) *nGroups = 0;
   if (nEntries) *nEntries = 0;
-  if (assignedFragments) *assignedFragments = 0;
+  if (assignedFragments) *assignedFragments = rs->exchanged ? rs->nAssigned : 0;
   if (F == 0) return T1K_OK;
   int rc;
   auto fail = [&](int code) { rs->err = ctx->err; return code; };
@@ -210,8 +211,8 @@ int t1k_rowset_coalesce(t1k_rowset *rs, uint64_t *nGroups, uint64_t *nEntries, u
   uint32_t M = 0;
   RS_HIP(hipMemcpyAsync(&M, a1 + (F - 1), 4, hipMemcpyDeviceToHost, st));
   RS_HIP(hipStreamSynchronize(st));
-  rs->nAssigned = M;
-  if (assignedFragments) *assignedFragments = M;
+  if (!rs->exchanged) rs->nAssigned = M;  // (after an exchange: the count of this rank's own fragments, taken before it)
+  if (assignedFragments) *assignedFragments = rs->nAssigned;
   if (M == 0) return T1K_OK;
   hipLaunchKernelGGL(k_co_compact, dim3(nbF), dim3(256), 0, st, a0, a1, rs->h2, a2, k0, F);  // a2 = fragment ids, k0 = hash word 2
   const unsigned nbM = (M + 255) / 256;
@@ -232,7 +233,7 @@ int t1k_rowset_coalesce(t1k_rowset *rs, uint64_t *nGroups, uint64_t *nEntries, u
   if ((rc = t1k_sort_pairs(ctx, k0, k2, headVal, order, G, 32))) return fail(rc);
   uint32_t *gSize = a0, *gTiles = a1, *gFirst = a6;
   const unsigned nbG = (G + 255) / 256;
-  hipLaunchKernelGGL(k_co_sizes, dim3(nbG), dim3(256), 0, st, order, runStart, idx, rs->rowCount, gSize, gTiles, gFirst, G);
+  hipLaunchKernelGGL(k_co_sizes, dim3(nbG), dim3(256), 0, st, order, runStart, idx, rs->rowCount, rs->gid, gSize, gTiles, gFirst, G);
   if ((rc = t1k_ensure(ctx, rs->bGroupPtr, ((size_t)G + 2) * 8 * 2))) return fail(rc);
   unsigned long long *groupPtr = (unsigned long long *)rs->bGroupPtr.p, *tilePtr = groupPtr + (G + 2);
   // exclusive sums over G + 1 elements (the element behind the last group is read but never used: make it defined)
@@ -277,7 +278,8 @@ int t1k_rowset_groups_download(t1k_rowset *rs, uint64_t *groupPtr, t1k_group_ent
 int t1k_rowset_assigned_download(t1k_rowset *rs, uint8_t *fragAssigned) {
   if (!rs || !fragAssigned) return T1K_ERR_ARG;
   RS_HIP(hipSetDevice(rs->device));
-  if (rs->nFrag) RS_HIP(hipMemcpy(fragAssigned, rs->assigned, rs->nFrag, hipMemcpyDeviceToHost));
+  const uint64_t nLocal = rs->exchanged ? rs->nFragLocal : rs->nFrag;  // the flags belong to this rank's own fragments
+  if (nLocal) RS_HIP(hipMemcpy(fragAssigned, rs->assigned, nLocal, hipMemcpyDeviceToHost));
   return T1K_OK;
 }
 
@@ -305,6 +307,202 @@ int t1k_rowset_rows_download(t1k_rowset *rs, uint64_t first, uint32_t count, uin
   if (e == hipSuccess) e = hipStreamSynchronize(st);
   (void)hipFree(dOff); (void)hipFree(dOut);
   if (e != hipSuccess) return rsFail(rs, T1K_ERR_DEVICE, hipGetErrorString(e));
+  return T1K_OK;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------------------------------
+// multi-GPU: fragments travel to the owner of their pattern (hash word 1 mod nRanks)
+// ------------------------------------------------------------------------------------------------------------------
+struct T1kFragMeta { uint32_t gid, n; unsigned long long h1, h2; };  // 24 bytes
+
+__global__ void k_ex_dest(const uint32_t *idx, const unsigned long long *h1, unsigned long long *key, uint32_t nRanks, uint32_t m) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < m) key[j] = h1[idx[j]] % nRanks;
+}
+__global__ void k_ex_counts(const uint32_t *idxS, const uint32_t *rowCount, uint32_t *cnt, uint32_t m) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < m) cnt[j] = rowCount[idxS[j]];
+}
+// start[p] = first sorted position whose destination is >= p  (p = 0 .. nRanks)
+__global__ void k_ex_bounds(const unsigned long long *keyS, uint32_t m, uint32_t nRanks, uint32_t *start) {
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p > nRanks) return;
+  uint32_t lo = 0, hi = m;
+  while (lo < hi) { const uint32_t mid = (lo + hi) / 2; if (keyS[mid] < p) lo = mid + 1; else hi = mid; }
+  start[p] = lo;
+}
+__global__ void k_ex_pack(const uint32_t *idxS, const unsigned long long *eOff, const unsigned long long *rowPtr, const uint32_t *rowCount, const unsigned long long *h1,
+                          const unsigned long long *h2, uint64_t fragBase, T1kFragMeta *meta, t1k_row_entry *rows, uint32_t m) {
+  const uint32_t j = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (j >= m) return;
+  const int lane = threadIdx.x & 63;
+  const uint32_t f = idxS[j], n = rowCount[f];
+  if (lane == 0) meta[j] = T1kFragMeta{(uint32_t)(fragBase + f), n, h1[f], h2[f]};
+  const t1k_row_entry *src = (const t1k_row_entry *)rowPtr[f];
+  t1k_row_entry *dst = rows + eOff[j];
+  for (uint32_t q = lane; q < n; q += 64) dst[q] = src[q];
+}
+__global__ void k_ex_unpack_counts(const T1kFragMeta *meta, uint32_t *cnt, uint32_t m) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < m) cnt[j] = meta[j].n;
+}
+__global__ void k_ex_unpack(const T1kFragMeta *meta, const unsigned long long *eOff, const t1k_row_entry *rows, unsigned long long *rowPtr, uint32_t *rowCount,
+                            unsigned long long *h1, unsigned long long *h2, uint32_t *gid, uint32_t m) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= m) return;
+  const T1kFragMeta t = meta[j];
+  rowPtr[j] = (unsigned long long)(rows + eOff[j]); rowCount[j] = t.n; h1[j] = t.h1; h2[j] = t.h2; gid[j] = t.gid;
+}
+__global__ void k_ex_sizes(const unsigned long long *groupPtr, uint32_t *size, uint32_t g) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < g) size[i] = (uint32_t)(groupPtr[i + 1] - groupPtr[i]);
+}
+
+extern "C" {
+
+// Every fragment row of every rank moves to the rank that owns its pattern.  Afterwards the rowset holds the fragments this rank
+// owns, in global fragment order (ranks hold contiguous slices of the fragments in rank order), and t1k_rowset_coalesce folds them.
+// fragBase = global index of this rank's first fragment.
+int t1k_rowset_exchange(t1k_rowset *rs, t1k_comm *comm, uint64_t fragBase) {
+  if (!rs || !comm) return T1K_ERR_ARG;
+  if (rs->exchanged) return rsFail(rs, T1K_ERR_STATE, "t1k_rowset_exchange: already exchanged");
+  t1k_ctx *ctx = rs->owner;
+  RS_HIP(hipSetDevice(rs->device));
+  hipStream_t st = ctx->stream;
+  const int N = t1k_comm_size(comm), me = t1k_comm_rank(comm);
+  const uint32_t F = (uint32_t)rs->nFrag;
+  int rc;
+  auto fail = [&](int code) { rs->err = ctx->err; return code; };
+  auto cfail = [&](int code) { rs->err = t1k_comm_last_error(comm); return code; };
+  const size_t n4 = ((size_t)(F + 2) * 4 + 255) & ~(size_t)255, n8 = ((size_t)(F + 2) * 8 + 255) & ~(size_t)255;
+  if ((rc = t1k_ensure(ctx, rs->bWork, 8 * n4 + 3 * n8))) return fail(rc);
+  char *wp = (char *)rs->bWork.p;
+  uint32_t *a0 = (uint32_t *)wp, *a1 = (uint32_t *)(wp + n4), *a2 = (uint32_t *)(wp + 2 * n4), *a3 = (uint32_t *)(wp + 3 * n4), *a4 = (uint32_t *)(wp + 4 * n4);
+  unsigned long long *k0 = (unsigned long long *)(wp + 8 * n4), *k1 = (unsigned long long *)(wp + 8 * n4 + n8), *k2 = (unsigned long long *)(wp + 8 * n4 + 2 * n8);
+  uint32_t M = 0;
+  if (F) {
+    const unsigned nbF = (F + 255) / 256;
+    hipLaunchKernelGGL(k_co_flag, dim3(nbF), dim3(256), 0, st, rs->rowCount, a0, F);
+    if ((rc = t1k_inclusive_sum(ctx, a0, a1, F))) return fail(rc);
+    RS_HIP(hipMemcpyAsync(&M, a1 + (F - 1), 4, hipMemcpyDeviceToHost, st));
+    RS_HIP(hipStreamSynchronize(st));
+    if (M) hipLaunchKernelGGL(k_co_compact, dim3(nbF), dim3(256), 0, st, a0, a1, rs->h2, a2, k0, F);  // a2 = fragments with a row, in order
+  }
+  rs->nAssigned = M;
+  // stable order by destination
+  std::vector<uint32_t> start(N + 1, 0);
+  std::vector<unsigned long long> eAt(N + 1, 0);
+  uint32_t *idxS = a3;
+  if (M) {
+    const unsigned nbM = (M + 255) / 256;
+    hipLaunchKernelGGL(k_ex_dest, dim3(nbM), dim3(256), 0, st, a2, rs->h1, k0, (uint32_t)N, M);
+    if ((rc = t1k_sort_pairs(ctx, k0, k1, a2, idxS, M, 16))) return fail(rc);
+    hipLaunchKernelGGL(k_ex_counts, dim3(nbM), dim3(256), 0, st, idxS, rs->rowCount, a0, M);
+    RS_HIP(hipMemsetAsync(a0 + M, 0, 4, st));
+    if ((rc = t1k_exclusive_sum64(ctx, a0, k2, M + 1))) return fail(rc);  // k2 = entry offset of each sorted fragment, k2[M] = total
+    hipLaunchKernelGGL(k_ex_bounds, dim3(1), dim3(256), 0, st, k1, M, (uint32_t)N, a4);
+    if (N + 1 > 256) return rsFail(rs, T1K_ERR_ARG, "t1k_rowset_exchange: more than 255 ranks");
+    RS_HIP(hipMemcpyAsync(start.data(), a4, (size_t)(N + 1) * 4, hipMemcpyDeviceToHost, st));
+    RS_HIP(hipStreamSynchronize(st));
+    for (int p = 0; p <= N; ++p) RS_HIP(hipMemcpyAsync(&eAt[p], k2 + start[p], 8, hipMemcpyDeviceToHost, st));
+    RS_HIP(hipStreamSynchronize(st));
+  }
+  const uint64_t Etot = eAt[N];
+  // what everybody sends to everybody: [rank][2 * dest] fragments, [rank][2 * dest + 1] entries
+  std::vector<uint64_t> mine(2 * (size_t)N), all(2 * (size_t)N * N);
+  for (int p = 0; p < N; ++p) { mine[2 * p] = start[p + 1] - start[p]; mine[2 * p + 1] = eAt[p + 1] - eAt[p]; }
+  if ((rc = t1k_comm_allgather_u64(comm, mine.data(), (uint32_t)(2 * N), all.data()))) return cfail(rc);
+  std::vector<uint64_t> sOffM(N + 1), sOffE(N + 1), rOffM(N + 1, 0), rOffE(N + 1, 0);
+  for (int p = 0; p <= N; ++p) { sOffM[p] = (uint64_t)start[p] * sizeof(T1kFragMeta); sOffE[p] = eAt[p] * sizeof(t1k_row_entry); }
+  uint64_t recvF = 0, recvE = 0, totalF = 0;
+  for (int r = 0; r < N; ++r) {
+    rOffM[r] = recvF * sizeof(T1kFragMeta); rOffE[r] = recvE * sizeof(t1k_row_entry);
+    recvF += all[(size_t)r * 2 * N + 2 * me]; recvE += all[(size_t)r * 2 * N + 2 * me + 1];
+    for (int p = 0; p < N; ++p) totalF += all[(size_t)r * 2 * N + 2 * p];
+  }
+  rOffM[N] = recvF * sizeof(T1kFragMeta); rOffE[N] = recvE * sizeof(t1k_row_entry);
+  if (recvF >= 0xFFFFFFF0ull || totalF >= 0xFFFFFFF0ull) return rsFail(rs, T1K_ERR_CAPACITY, "t1k_rowset_exchange: more than 2^32 fragments");
+  if ((rc = t1k_ensure(ctx, rs->bSend, (size_t)M * sizeof(T1kFragMeta) + Etot * sizeof(t1k_row_entry) + 512))) return fail(rc);
+  if ((rc = t1k_ensure(ctx, rs->bRecv, recvF * sizeof(T1kFragMeta) + recvE * sizeof(t1k_row_entry) + 512))) return fail(rc);
+  T1kFragMeta *sMeta = (T1kFragMeta *)rs->bSend.p;
+  t1k_row_entry *sRows = (t1k_row_entry *)((char *)rs->bSend.p + (((size_t)M * sizeof(T1kFragMeta) + 255) & ~(size_t)255));
+  T1kFragMeta *rMeta = (T1kFragMeta *)rs->bRecv.p;
+  t1k_row_entry *rRows = (t1k_row_entry *)((char *)rs->bRecv.p + ((recvF * sizeof(T1kFragMeta) + 255) & ~(size_t)255));
+  if (M) hipLaunchKernelGGL(k_ex_pack, dim3((M + 3) / 4), dim3(256), 0, st, idxS, k2, rs->rowPtr, rs->rowCount, rs->h1, rs->h2, fragBase, sMeta, sRows, M);
+  RS_HIP(hipStreamSynchronize(st));
+  if ((rc = t1k_comm_alltoallv(comm, sMeta, sOffM.data(), rMeta, rOffM.data()))) return cfail(rc);
+  if ((rc = t1k_comm_alltoallv(comm, sRows, sOffE.data(), rRows, rOffE.data()))) return cfail(rc);
+  // the rows this rank gave away are dead: the chunks and the send buffer go back
+  for (auto &b : rs->chunks) if (b.p) { (void)hipFree(b.p); b.p = nullptr; b.bytes = 0; }
+  (void)hipFree(rs->bSend.p); rs->bSend.p = nullptr; rs->bSend.bytes = 0;
+  // the received fragments, in (source rank, source order) = global fragment order
+  const uint64_t R = std::max<uint64_t>(recvF, 1);
+  if ((rc = t1k_ensure(ctx, rs->bFrag2, R * (8 * 3 + 4 + 4) + 256))) return fail(rc);
+  rs->rowPtr = (unsigned long long *)rs->bFrag2.p; rs->h1 = rs->rowPtr + R; rs->h2 = rs->h1 + R;
+  rs->rowCount = (uint32_t *)(rs->h2 + R); rs->gid = rs->rowCount + R;
+  if (recvF) {
+    const uint32_t m = (uint32_t)recvF;
+    const size_t m4 = ((size_t)(m + 2) * 4 + 255) & ~(size_t)255, m8 = ((size_t)(m + 2) * 8 + 255) & ~(size_t)255;
+    if ((rc = t1k_ensure(ctx, rs->bWork, 8 * m4 + 3 * m8))) return fail(rc);
+    uint32_t *c0 = (uint32_t *)rs->bWork.p;
+    unsigned long long *e0 = (unsigned long long *)((char *)rs->bWork.p + 8 * m4);
+    hipLaunchKernelGGL(k_ex_unpack_counts, dim3((m + 255) / 256), dim3(256), 0, st, rMeta, c0, m);
+    RS_HIP(hipMemsetAsync(c0 + m, 0, 4, st));
+    if ((rc = t1k_exclusive_sum64(ctx, c0, e0, m + 1))) return fail(rc);
+    hipLaunchKernelGGL(k_ex_unpack, dim3((m + 255) / 256), dim3(256), 0, st, rMeta, e0, rRows, rs->rowPtr, rs->rowCount, rs->h1, rs->h2, rs->gid, m);
+    RS_HIP(hipStreamSynchronize(st));
+  }
+  rs->nFragLocal = rs->nFrag;
+  rs->nFrag = recvF;
+  rs->exchanged = true;
+  return T1K_OK;
+}
+
+// after t1k_rowset_coalesce on every rank: all ranks' group tables on every rank, concatenated in rank order
+// (sizes[totalGroups], entries[totalEntries], firstFragment[totalGroups] -- global fragment indices)
+int t1k_rowset_groups_gather(t1k_rowset *rs, t1k_comm *comm, uint64_t *totalGroups, uint64_t *totalEntries, uint64_t *totalAssigned) {
+  if (!rs || !comm || !rs->coalesced) return rsFail(rs, T1K_ERR_STATE, "t1k_rowset_groups_gather: not coalesced");
+  t1k_ctx *ctx = rs->owner;
+  RS_HIP(hipSetDevice(rs->device));
+  hipStream_t st = ctx->stream;
+  const int N = t1k_comm_size(comm);
+  int rc;
+  std::vector<uint64_t> mine{rs->nGroups, rs->nEntries, rs->nAssigned}, all(3 * (size_t)N);
+  if ((rc = t1k_comm_allgather_u64(comm, mine.data(), 3, all.data()))) { rs->err = t1k_comm_last_error(comm); return rc; }
+  std::vector<uint64_t> bG(N), dG(N), bE(N), dE(N);
+  uint64_t G = 0, E = 0, A = 0;
+  for (int r = 0; r < N; ++r) { dG[r] = G * 4; dE[r] = E * sizeof(T1kGroupEnt); bG[r] = all[3 * r] * 4; bE[r] = all[3 * r + 1] * sizeof(T1kGroupEnt); G += all[3 * r]; E += all[3 * r + 1]; A += all[3 * r + 2]; }
+  if ((rc = t1k_ensure(ctx, rs->bAll, (G + 1) * 8 + E * sizeof(T1kGroupEnt) + 1024))) { rs->err = ctx->err; return rc; }
+  uint32_t *allSize = (uint32_t *)rs->bAll.p, *allFirst = allSize + (G + 1);
+  T1kGroupEnt *allEnt = (T1kGroupEnt *)((char *)rs->bAll.p + (((G + 1) * 8 + 255) & ~(size_t)255));
+  // own sizes from groupPtr
+  T1kDevBuf tmp;
+  if ((rc = t1k_ensure(ctx, tmp, (rs->nGroups + 1) * 4))) { rs->err = ctx->err; return rc; }
+  if (rs->nGroups) hipLaunchKernelGGL(k_ex_sizes, dim3((unsigned)((rs->nGroups + 255) / 256)), dim3(256), 0, st, (const unsigned long long *)rs->bGroupPtr.p, (uint32_t *)tmp.p, (uint32_t)rs->nGroups);
+  RS_HIP(hipStreamSynchronize(st));
+  rc = t1k_comm_allgatherv(comm, tmp.p, bG.data(), dG.data(), allSize);
+  if (rc == T1K_OK) rc = t1k_comm_allgatherv(comm, rs->bGroupFirst.p, bG.data(), dG.data(), allFirst);
+  if (rc == T1K_OK) rc = t1k_comm_allgatherv(comm, rs->bGroupEnt.p, bE.data(), dE.data(), allEnt);
+  (void)hipFree(tmp.p);
+  if (rc != T1K_OK) { rs->err = t1k_comm_last_error(comm); return rc; }
+  rs->allGroups = G; rs->allEntries = E;
+  if (totalGroups) *totalGroups = G;
+  if (totalEntries) *totalEntries = E;
+  if (totalAssigned) *totalAssigned = A;
+  return T1K_OK;
+}
+
+int t1k_rowset_groups_download_all(t1k_rowset *rs, uint32_t *sizes, t1k_group_entry *entries, uint32_t *firstFragment) {
+  if (!rs || !rs->bAll.p) return rsFail(rs, T1K_ERR_STATE, "t1k_rowset_groups_download_all: nothing gathered");
+  RS_HIP(hipSetDevice(rs->device));
+  const uint64_t G = rs->allGroups, E = rs->allEntries;
+  const uint32_t *allSize = (const uint32_t *)rs->bAll.p, *allFirst = allSize + (G + 1);
+  const T1kGroupEnt *allEnt = (const T1kGroupEnt *)((const char *)rs->bAll.p + (((G + 1) * 8 + 255) & ~(size_t)255));
+  if (sizes && G) RS_HIP(hipMemcpy(sizes, allSize, G * 4, hipMemcpyDeviceToHost));
+  if (firstFragment && G) RS_HIP(hipMemcpy(firstFragment, allFirst, G * 4, hipMemcpyDeviceToHost));
+  if (entries && E) RS_HIP(hipMemcpy(entries, allEnt, E * sizeof(T1kGroupEnt), hipMemcpyDeviceToHost));
   return T1K_OK;
 }
 

@@ -678,7 +678,8 @@ struct t1k_ctx {
   uint64_t nRows = 0;
   // EM
   T1kDevBuf bEmRowPtr, bEmEc, bEmCount, bEmLen, bEmX0, bEmN, bEmContrib, bEmColPtr, bEmColIdx;
-  uint32_t emGroups = 0, emEc = 0;
+  uint32_t emGroups = 0, emEc = 0, emRowBegin = 0, emRowEnd = 0;
+  struct t1k_comm *emComm = nullptr;
   uint64_t emNnz = 0;
   std::vector<int32_t> hEmLen;
   int traceFetch = 0;          // T1K_DEBUG_TRACE

@@ -6,8 +6,10 @@
 //               contrib = count_g * (x[ec] / psum) written at the entry's class-major (CSC) position
 //   k_em_cols : one lane per class: n[ec] = sum of its contributions in group order -- the order the reference's
 //               row-major loop adds them to ecReadCount[ec] -- so every class total is the same rounded double
-// (optional all-reduce of n over GPUs when groups are sharded), then the M-step (normalise by length, sum|diff|) runs on
-// the host in the reference's order: it is O(#classes) and needs the values on the host anyway.
+// then the M-step (normalise by length, sum|diff|) runs on the host in the reference's order: it is O(#classes) and needs the
+// values on the host anyway.  Sharded over GPUs (t1k_em_shard): a rank runs k_em_rows on its slice of the read groups only, the
+// contribution array -- every element has exactly one writer, the others hold 0 -- is all-reduced (sum, f64: exact in any order),
+// and k_em_cols runs on every rank: the same doubles as on one GPU, whatever the number of ranks.
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -236,8 +238,15 @@ int t1k_em_setup(t1k_ctx *ctx, const uint64_t *rowPtr, const uint32_t *ecIdx, co
   T1K_HIP(ctx, hipStreamSynchronize(ctx->stream));
   ctx->emGroups = nGroups; ctx->emEc = nEc; ctx->emNnz = nnz;
   ctx->emAllreduce = allreduce; ctx->emUser = user;
+  ctx->emRowBegin = 0; ctx->emRowEnd = nGroups; ctx->emComm = nullptr;
   // class lengths stay on the host (M-step)
   if (nEc) ctx->hEmLen.assign(ecLen, ecLen + nEc); else ctx->hEmLen.clear();
+  return T1K_OK;
+}
+
+int t1k_em_shard(t1k_ctx *ctx, uint32_t rowBegin, uint32_t rowEnd, t1k_comm *comm) {
+  if (!ctx || rowBegin > rowEnd || rowEnd > ctx->emGroups) return t1k_fail(ctx, T1K_ERR_ARG, "t1k_em_shard: bad row range");
+  ctx->emRowBegin = rowBegin; ctx->emRowEnd = rowEnd; ctx->emComm = comm;
   return T1K_OK;
 }
 
@@ -256,8 +265,16 @@ int t1k_em_update(t1k_ctx *ctx, const double *x0, double *x1, double *ecReadCoun
   double *px = ctx->emPinned, *pn = ctx->emPinned + ctx->emPinnedN;
   memcpy(px, x0, (size_t)E * 8);
   T1K_HIP(ctx, hipMemcpyAsync(ctx->bEmX0.p, px, (size_t)E * 8, hipMemcpyHostToDevice, ctx->stream));
-  if (G) hipLaunchKernelGGL(k_em_rows, dim3((G + 3) / 4), dim3(256), 0, ctx->stream, (const uint64_t *)ctx->bEmRowPtr.p, (const uint32_t *)ctx->bEmEc.p,
-                            (const uint64_t *)ctx->bEmColIdx.p, (const double *)ctx->bEmCount.p, (const double *)ctx->bEmX0.p, (double *)ctx->bEmContrib.p, G);
+  const bool sharded = ctx->emComm && t1k_comm_size(ctx->emComm) > 1;
+  const uint32_t g0 = sharded ? ctx->emRowBegin : 0, gn = (sharded ? ctx->emRowEnd : G) - g0;
+  if (sharded && ctx->emNnz) T1K_HIP(ctx, hipMemsetAsync(ctx->bEmContrib.p, 0, (size_t)ctx->emNnz * 8, ctx->stream));  // the other ranks' entries
+  if (gn) hipLaunchKernelGGL(k_em_rows, dim3((gn + 3) / 4), dim3(256), 0, ctx->stream, (const uint64_t *)ctx->bEmRowPtr.p + g0, (const uint32_t *)ctx->bEmEc.p,
+                             (const uint64_t *)ctx->bEmColIdx.p, (const double *)ctx->bEmCount.p + g0, (const double *)ctx->bEmX0.p, (double *)ctx->bEmContrib.p, gn);
+  if (sharded) {
+    T1K_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const int rc = t1k_comm_allreduce(ctx->emComm, ctx->bEmContrib.p, ctx->emNnz, 1);
+    if (rc != T1K_OK) return t1k_fail(ctx, rc, std::string("t1k_em_update: ") + t1k_comm_last_error(ctx->emComm));
+  }
   hipLaunchKernelGGL(k_em_cols, dim3((E + 3) / 4), dim3(256), 0, ctx->stream, (const uint64_t *)ctx->bEmColPtr.p, (const double *)ctx->bEmContrib.p,
                      (double *)ctx->bEmN.p, E);
   if (ctx->emAllreduce) {

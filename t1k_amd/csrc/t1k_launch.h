@@ -97,6 +97,12 @@ struct t1k_rowset {
   unsigned long long *rowPtr = nullptr, *h1 = nullptr, *h2 = nullptr;
   uint32_t *rowCount = nullptr;
   uint8_t *assigned = nullptr;
+  // after t1k_rowset_exchange: the fragments this rank owns (bFrag2 / bRecv), gid = their global fragment index
+  uint32_t *gid = nullptr;
+  bool exchanged = false;
+  uint64_t nFragLocal = 0;
+  T1kDevBuf bSend, bRecv, bFrag2, bAll;
+  uint64_t allGroups = 0, allEntries = 0;
   T1kDevBuf bCursors;               // one append cursor per chunk
   std::vector<T1kDevBuf> chunks;
   size_t cur = 0;

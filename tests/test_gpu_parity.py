@@ -229,3 +229,48 @@ def test_n_next_to_homopolymer_vs_oracle(built, tmp_path):
     import gpu_assign_check
     fa, reads = homopolymer_case(tmp_path, 11)
     assert gpu_assign_check.compare(fa, reads, 0.8, False, "N next to homopolymers") == 0
+
+
+@pytest.mark.parametrize("name", ["hla_synth_2x150", "cyp_dna_relax_2x150", "kir_synth_relax_2x150", "cyp_rna_single"])
+@pytest.mark.parametrize("gpus", ["0,0", "0,0,0"])
+def test_sharded_job_equals_single_gpu_job(built, tmp_path, name, gpus):
+    """The multi-GPU path with several ranks on ONE device (T1K_GPUS=0,0: one thread, job and context set per rank, in-process
+    transport): fragments sharded by contiguous slices, coverage all-reduce, row exchange to the pattern owners + coalescing + group
+    gather, EM with a sharded row pass.  Every output file must equal the reference's (= the single-GPU run's) byte for byte."""
+    c = goldens.Case(name, str(tmp_path))
+    out = os.path.join(str(tmp_path), "sharded")
+    r = subprocess.run([GENO] + c.args() + ["-o", out], stderr=subprocess.PIPE, text=True, env=dict(os.environ, T1K_GPUS=gpus))
+    assert r.returncode == 0, r.stderr
+    assert open(out + "_genotype.tsv").read() == c.expected("genotype.tsv")
+    assert open(out + "_allele.tsv").read() == c.expected("allele.tsv")
+    ids = [l[1:].strip() for l in open(out + ("_aligned_1.fa" if c.paired else "_aligned.fa")) if l.startswith(">")]
+    assert ids == c.expected("aligned_ids.txt.gz").split()
+    if c.bc:
+        assert open(out + "_aligned_bc.fa").read() == c.expected("aligned_bc.fa")
+    m = re.search(r"in (\d+) EM iterations", r.stderr)
+    assert int(m.group(1)) == c.meta["em_iterations"]
+    m = re.search(r"(\d+) read fragments can be assigned \(average ([-\d.naninf]+) alleles/read\)", r.stderr)
+    assert int(m.group(1)) == c.meta["assigned_fragments"] and m.group(2) == c.meta["avg_alleles"]
+
+
+def test_rccl_single_rank_communicator(built, tmp_path):
+    """the RCCL transport itself (librccl bound lazily, ncclCommInitRank, all-reduce / send-recv / broadcast groups) with one rank:
+    the job must run through every collective and give the single-GPU result"""
+    c = goldens.Case("hla_synth_2x150", str(tmp_path))
+    ref_text = None
+    for use_comm in (False, True):
+        job = t1k_amd.Job(c.ref, ref_seq_similarity=0.97)
+        job.load_reads(c.r1, c.r2)
+        comm = None
+        if use_comm:
+            comm = t1k_amd.Comm(job, 1, 0, unique_id=t1k_amd.comm_unique_id())
+            assert comm.is_rccl()
+            job.set_shard(0, 1, comm)
+        job.run()
+        text = job.genotype_text()
+        job.close()
+        if comm:
+            comm.close()
+        if ref_text is None:
+            ref_text = text
+        assert text == ref_text == c.expected("genotype.tsv")
