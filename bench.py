@@ -10,7 +10,10 @@ kept between steps except the HIP runtime itself (the process) and the OS page c
 
 Workload at N=1: 10 M synthetic 2x150 bp pairs against the HLA-like rna reference (north_star's "10M synthetic 2x150 bp HLA reads";
 the real hlaidx_rna_seq.fa cannot be downloaded: tools/t1k_synth generates a reference of the same shape, seed 20250614);
---pairs 1000000 gives BASELINE.json configs[1].  With N ranks every rank owns --pairs fragments (weak scaling).
+--pairs 1000000 gives BASELINE.json configs[1].  With N ranks ONE sample of N x --pairs fragments is genotyped by all of them
+(weak scaling): rank r owns the r-th contiguous slice of the fragments; the exchanges (coverage all-reduce, row exchange to the
+pattern owners, group gather, the all-reduce of every EM update) run inside libt1k_gpu.so over RCCL.  torch.distributed only
+launches the ranks, hands rank 0's ncclUniqueId to the others and provides the barriers of the timing contract.
 
   python bench.py --gpus 1 --steps 3 --warmup 1            (single GPU)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
@@ -130,25 +133,40 @@ def main():
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # RCCL on ROCm
+    import numpy as np
     import t1k_amd
 
-    # inputs: rank r genotypes its own sample of --pairs fragments against the shared reference (independent samples per GPU)
+    # inputs: ONE sample of world x --pairs fragments; every rank maps the same files and owns a contiguous slice of the fragments
+    total_pairs = a.pairs * world
     if rank == 0:
-        ensure_inputs(a.workdir, a.pairs, a.genes, a.scale, seed=2)
+        ensure_inputs(a.workdir, total_pairs, a.genes, a.scale, seed=2)
     if dist is not None:
         dist.barrier()
-    ref, pfx = ensure_inputs(a.workdir, a.pairs, a.genes, a.scale, seed=2)
-    out_prefix = os.path.join(a.workdir, "out_rank%d" % rank)
+    ref, pfx = ensure_inputs(a.workdir, total_pairs, a.genes, a.scale, seed=2)
+    out_prefix = os.path.join(a.workdir, "out")
     last = {}
+    comm = anchor = None
+    if dist is not None:
+        # the job's own communicator (RCCL inside libt1k_gpu.so), created once: rank 0's ncclUniqueId travels over torch.distributed
+        uid = torch.from_numpy(t1k_amd.comm_unique_id() if rank == 0 else np.zeros(128, dtype=np.uint8)).cuda()
+        dist.broadcast(uid, 0)
+        anchor = t1k_amd.Context(device=local_rank)
+        comm = t1k_amd.Comm(anchor, world, rank, unique_id=uid.cpu().numpy())
 
     def step():
         job = t1k_amd.Job(ref, ref_seq_similarity=0.97, device=local_rank)
         job.load_reads(pfx + "_1.fq", pfx + "_2.fq")
+        if comm is not None:
+            comm.bind(job)
+            job.set_shard(rank, world, comm)
         job.run()
-        job.write_outputs(out_prefix)
+        if rank == 0:
+            job.write_outputs(out_prefix)
         last["stats"] = job.stats()
         last["counts"] = job.counts()
         last["text"] = job.genotype_text()
+        if comm is not None:
+            comm.bind(anchor)
         job.close()
 
     for _ in range(a.warmup):
@@ -167,6 +185,8 @@ def main():
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+        comm.close()
+        anchor.close()
         dist.destroy_process_group()
     st, counts, text = last["stats"], last["counts"], last["text"]
     import ctypes
@@ -179,7 +199,6 @@ def main():
         launches = max(1, st["batches"])
         achieved = kb[dom] / (ms[dom] * 1e-3) / 1e9 if ms[dom] > 0 else 0.0
         step_s = dt / a.steps
-        total_pairs = a.pairs * world
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "r02_seed_traffic.json")  # PMC passes of the same command (profiles/r02_pmc_hbm.md)
         if os.path.exists(tpath):
@@ -200,7 +219,9 @@ def main():
             "config": {"workload": "%d synthetic 2x150 bp pairs per GPU vs synthetic HLA-like rna reference (%d genes, scale %s: %d alleles), -s 0.97; "
                                    "END TO END per step: reference FASTA -> index -> FASTQ parse -> GPU -> genotype.tsv + allele.tsv + aligned_{1,2}.fa written"
                                    % (a.pairs, a.genes, a.scale, sum(1 for l in open(ref) if l.startswith(">"))),
-                       "parallelism": ("%d GPUs, one sample of %d pairs per GPU (independent genotyping jobs, no collective)" % (world, a.pairs)) if world > 1 else "1 GPU",
+                       "parallelism": ("one sample of %d pairs sharded over %d GPUs by contiguous fragment slices (%d per GPU); RCCL inside libt1k_gpu.so: int32 all-reduce of the coverage arrays, "
+                                       "all-to-all of fragment rows to their pattern owners, all-gather of group tables, f64 all-reduce of the contribution array in every EM update; "
+                                       "communicator created once outside the steps" % (total_pairs, world, a.pairs)) if world > 1 else "1 GPU",
                        "arithmetic": "2-bit packed bases in u64 words, int32 alignment scores, f32 read-group weights, f64 EM",
                        "read_ends": st["read_ends_total"], "distinct_read_ends": st["read_ends"],
                        "groups": counts["groups"], "equivalence_classes": counts["ecs"], "em_iterations": counts["em_iterations"],

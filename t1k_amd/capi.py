@@ -433,10 +433,12 @@ def comm_unique_id():
 class Comm:
     """One rank's communicator (t1k_comm): RCCL over xGMI between processes / GPUs, in-process transport between threads that share a GPU."""
 
-    def __init__(self, job, n_ranks, rank, unique_id=None, group=None, transport=-1):
+    def __init__(self, owner, n_ranks, rank, unique_id=None, group=None, transport=-1):
+        """owner: a Job or a Context on this rank's device (the communicator uses its stream until bind() moves it)"""
         h = C.c_void_p()
         uid = None if unique_id is None else np.ascontiguousarray(unique_id, dtype=np.uint8)
-        rc = lib().t1k_comm_init(job.ctx(), n_ranks, rank, _ptr(uid), group.h if group is not None else None, transport, C.byref(h))
+        ctx = owner.ctx() if hasattr(owner, "ctx") else owner.h
+        rc = lib().t1k_comm_init(ctx, n_ranks, rank, _ptr(uid), group.h if group is not None else None, transport, C.byref(h))
         self.h = h
         if rc != 0:
             raise T1kError("t1k_comm_init failed (%d): %s" % (rc, lib().t1k_comm_last_error(h).decode() if h else ""))

@@ -260,7 +260,7 @@ def test_rccl_single_rank_communicator(built, tmp_path):
     ref_text = None
     for use_comm in (False, True):
         job = t1k_amd.Job(c.ref, ref_seq_similarity=0.97)
-        job.load_reads(c.r1, c.r2)
+        job.load_reads(c.r1, c.r2, c.bc)
         comm = None
         if use_comm:
             comm = t1k_amd.Comm(job, 1, 0, unique_id=t1k_amd.comm_unique_id())
