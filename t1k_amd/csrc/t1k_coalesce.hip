@@ -95,7 +95,16 @@ __global__ __launch_bounds__(256) void k_co_reduce(const uint32_t *tileGroup, co
   const t1k_row_entry first = ((const t1k_row_entry *)rowPtr[idx[j0]])[q];
   T1kGroupEnt acc{first.allele_idx, first.start, first.end, first.weight, first.adjust_weight};
   uint32_t j = j0 + 1;
-  for (; j + 4 <= j1; j += 4) {  // four independent loads in flight, folded in fragment order
+  // A group's chain is sequential (float sums and the `end` rule in fragment order) and the largest groups hold 10^5 fragments: keep
+  // sixteen independent row loads in flight per lane (the row addresses are uniform over the wavefront), fold them in order.
+  for (; j + 16 <= j1; j += 16) {
+    t1k_row_entry e[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) e[u] = ((const t1k_row_entry *)rowPtr[idx[j + u]])[q];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) foldEntry(acc, e[u]);
+  }
+  for (; j + 4 <= j1; j += 4) {
     const t1k_row_entry *r0 = (const t1k_row_entry *)rowPtr[idx[j]], *r1 = (const t1k_row_entry *)rowPtr[idx[j + 1]],
                         *r2 = (const t1k_row_entry *)rowPtr[idx[j + 2]], *r3 = (const t1k_row_entry *)rowPtr[idx[j + 3]];
     const t1k_row_entry e0 = r0[q], e1 = r1[q], e2 = r2[q], e3 = r3[q];

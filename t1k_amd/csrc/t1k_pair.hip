@@ -18,6 +18,36 @@
 
 #define WG 256
 #define SORT_TILE 2048
+// Join table of one fragment in LDS: allele -> (index in list 1 + 1) | membership bit 15 | (index in list 2 + 1) << 16.  Open addressing,
+// 4096 slots; fragments whose two lists hold more than LJ_CAP overlaps (or a list with a repeated allele) use the per-workgroup
+// direct-address tables in HBM instead.
+#define LJ_SLOTS 4096
+#define LJ_CAP 2800
+
+__device__ __forceinline__ uint32_t ljHash(uint32_t allele) { return (allele * 2654435761u) >> 20; }  // 12 bits
+__device__ __forceinline__ uint32_t ljInsert(uint32_t *hKey, uint32_t allele) {
+  const uint32_t key = allele + 1;
+  uint32_t h = ljHash(allele);
+  for (;;) {
+    const uint32_t k = hKey[h];
+    if (k == key) return h;
+    if (k == 0) {
+      const uint32_t old = atomicCAS(&hKey[h], 0u, key);
+      if (old == 0 || old == key) return h;
+    }
+    h = (h + 1) & (LJ_SLOTS - 1);
+  }
+}
+__device__ __forceinline__ int ljFind(const uint32_t *hKey, uint32_t allele) {  // slot of an allele, -1 if absent
+  const uint32_t key = allele + 1;
+  uint32_t h = ljHash(allele);
+  for (;;) {
+    const uint32_t k = hKey[h];
+    if (k == key) return (int)h;
+    if (k == 0) return -1;
+    h = (h + 1) & (LJ_SLOTS - 1);
+  }
+}
 
 // contribution of the allele at sorted position r to a fragment's pattern hash (summed over the row: order of evaluation is free)
 __device__ __forceinline__ unsigned long long t1k_pattern_mix(uint32_t allele, uint32_t r, unsigned long long k) {
@@ -148,6 +178,7 @@ __global__ __launch_bounds__(WG) void k_pair(PairArgs P) {
   __shared__ int sDup, sFail, sBestM, sBestIdx, sAnySep, sNotOne;
   __shared__ double sBestSim;
   __shared__ uint32_t sN, sBase;
+  __shared__ uint32_t hKey[LJ_SLOTS], hVal[LJ_SLOTS];
   const int tid = threadIdx.x;
   const uint32_t A = P.ref.nAlleles;
   uint64_t *tab2 = P.tab2 + (uint64_t)blockIdx.x * A;
@@ -187,15 +218,32 @@ __global__ __launch_bounds__(WG) void k_pair(PairArgs P) {
       continue;
     }
     // ---- duplicate detection + join table --------------------------------------------------------------------------
-    for (uint32_t i = tid; i < n1; i += WG) {
-      unsigned long long old = atomicExch((unsigned long long *)&tabSlot[L1[i].allele], (unsigned long long)(epoch | i));
-      if ((old >> 32) == (epoch >> 32)) sDup = 1;
+    bool lds = n1 + n2 <= LJ_CAP;
+    if (lds) {
+      for (uint32_t q = tid; q < LJ_SLOTS; q += WG) { hKey[q] = 0; hVal[q] = 0; }
+      __syncthreads();
+      for (uint32_t i = tid; i < n1; i += WG) {
+        const uint32_t old = atomicOr(&hVal[ljInsert(hKey, L1[i].allele)], i + 1);
+        if (old & 0x7FFFu) sDup = 1;
+      }
+      for (uint32_t j = tid; j < n2; j += WG) {
+        const uint32_t old = atomicOr(&hVal[ljInsert(hKey, L2[j].allele)], (j + 1) << 16);
+        if (old >> 16) sDup = 1;
+      }
+      __syncthreads();
+      if (sDup) lds = false;  // a repeated allele: the sequential replay below works on the HBM tables
     }
-    for (uint32_t j = tid; j < n2; j += WG) {
-      unsigned long long old = atomicExch((unsigned long long *)&tab2[L2[j].allele], (unsigned long long)(epoch | j));
-      if ((old >> 32) == (epoch >> 32)) sDup = 1;
+    if (!lds) {
+      for (uint32_t i = tid; i < n1; i += WG) {
+        unsigned long long old = atomicExch((unsigned long long *)&tabSlot[L1[i].allele], (unsigned long long)(epoch | i));
+        if ((old >> 32) == (epoch >> 32)) sDup = 1;
+      }
+      for (uint32_t j = tid; j < n2; j += WG) {
+        unsigned long long old = atomicExch((unsigned long long *)&tab2[L2[j].allele], (unsigned long long)(epoch | j));
+        if ((old >> 32) == (epoch >> 32)) sDup = 1;
+      }
+      __syncthreads();
     }
-    __syncthreads();
     const bool dup = sDup != 0;
     if (!dup) {
       // ---- fast path: every allele at most once per list -> `assign` == fragment list, in list order ----------------
@@ -209,18 +257,24 @@ __global__ __launch_bounds__(WG) void k_pair(PairArgs P) {
         for (uint32_t i0 = 0; i0 < n1; i0 += WG) {
           uint32_t i = i0 + tid;
           int j = -1;
+          int slot = -1;
           if (i < n1 && s1 != s2) {
-            uint64_t e = tab2[L1[i].allele];
-            if ((e >> 32) == (epoch >> 32)) {
-              int jj = (int)(e & 0x7FFFFFFFu);
-              if ((s1 == 1 && L1[i].seqStart < L2[jj].seqStart) || (s1 == -1 && L1[i].seqStart > L2[jj].seqStart)) j = jj;  // 2369-2380
+            int jj = -1;
+            if (lds) {
+              slot = ljFind(hKey, L1[i].allele);
+              jj = (int)(hVal[slot] >> 16) - 1;
+            } else {
+              uint64_t e = tab2[L1[i].allele];
+              if ((e >> 32) == (epoch >> 32)) jj = (int)(e & 0x7FFFFFFFu);
             }
+            if (jj >= 0 && ((s1 == 1 && L1[i].seqStart < L2[jj].seqStart) || (s1 == -1 && L1[i].seqStart > L2[jj].seqStart))) j = jj;  // 2369-2380
           }
           uint32_t tot;
           uint32_t off = scanExcl(j >= 0 ? 1u : 0u, warpSums, &tot);
           if (j >= 0) {
             makeFrag(frags[nFrag + off], &L1[i], (int)i, &L2[j], j);
-            tab2[L1[i].allele] |= 0x80000000ull;  // the mate's allele has a fragment (seqIdxToOverlapIdx membership)
+            // the mate's allele has a fragment (seqIdxToOverlapIdx membership)
+            if (lds) atomicOr(&hVal[slot], 0x8000u); else tab2[L1[i].allele] |= 0x80000000ull;
           }
           nFrag += tot;
         }
@@ -357,10 +411,14 @@ __global__ __launch_bounds__(WG) void k_pair(PairArgs P) {
       for (uint32_t i = tid; i < n1; i += WG) {
         const T1kOvl &o = L1[i];
         double os = ovlSim(o);
-        bool inSlot;
-        if (!dup) { uint64_t e = tab2[o.allele]; inSlot = (e >> 32) == (epoch >> 32) && (e & 0x80000000ull); }
-        else { uint64_t e = tabSlot[o.allele]; inSlot = (e >> 32) == (epoch >> 32) && (e & 0x40000000ull); }
-        if (o.matchCnt > r1.matchCnt || ((o.matchCnt == r1.matchCnt && os > r1s) && !inSlot)) {
+        const bool tie = o.matchCnt == r1.matchCnt && os > r1s;
+        bool inSlot = false;
+        if (tie) {
+          if (lds) inSlot = (hVal[ljFind(hKey, o.allele)] & 0x8000u) != 0;
+          else if (!dup) { uint64_t e = tab2[o.allele]; inSlot = (e >> 32) == (epoch >> 32) && (e & 0x80000000ull); }
+          else { uint64_t e = tabSlot[o.allele]; inSlot = (e >> 32) == (epoch >> 32) && (e & 0x40000000ull); }
+        }
+        if (o.matchCnt > r1.matchCnt || (tie && !inSlot)) {
           if (truncatedMate(P.ref, o, r1, r2)) sFail = 1;
           else if (os > r2s + 0.1) sFail = 1;
         }
@@ -368,10 +426,14 @@ __global__ __launch_bounds__(WG) void k_pair(PairArgs P) {
       for (uint32_t j = tid; j < n2; j += WG) {
         const T1kOvl &o = L2[j];
         double os = ovlSim(o);
-        bool inSlot;
-        if (!dup) { uint64_t e = tab2[o.allele]; inSlot = (e >> 32) == (epoch >> 32) && (e & 0x80000000ull); }
-        else { uint64_t e = tabSlot[o.allele]; inSlot = (e >> 32) == (epoch >> 32) && (e & 0x40000000ull); }
-        if (o.matchCnt > r2.matchCnt || ((o.matchCnt == r2.matchCnt && os > r2s) && !inSlot)) {
+        const bool tie = o.matchCnt == r2.matchCnt && os > r2s;
+        bool inSlot = false;
+        if (tie) {
+          if (lds) inSlot = (hVal[ljFind(hKey, o.allele)] & 0x8000u) != 0;
+          else if (!dup) { uint64_t e = tab2[o.allele]; inSlot = (e >> 32) == (epoch >> 32) && (e & 0x80000000ull); }
+          else { uint64_t e = tabSlot[o.allele]; inSlot = (e >> 32) == (epoch >> 32) && (e & 0x40000000ull); }
+        }
+        if (o.matchCnt > r2.matchCnt || (tie && !inSlot)) {
           if (truncatedMate(P.ref, o, r2, r1)) sFail = 1;
           else if (os > r1s + 0.1) sFail = 1;
         }
