@@ -169,10 +169,10 @@ def test_n_next_to_homopolymers_vs_oracle(built, tmp_path):
         assert np.array_equal(good, want), (k, hl, sim, np.nonzero(good != want)[0][:10])
 
 
-@pytest.mark.skipif(not os.path.exists(util.REF_EXTRACT), reason="reference binary not built")
 def test_barcode_whitelist_vs_reference_binary(built, tmp_path):
     """--barcode / --barcodeWhitelist (BarcodeCorrector.hpp): exact, corrected, ambiguous (quality tie-break), uncorrectable and N barcodes,
     plain and with a reverse-complemented sub-range; the _bc.fa files against the reference's own fastq-extractor"""
+    util.need(util.REF_EXTRACT)  # decided when the test runs, after the `built` fixture had its chance to build oracle/_ref
     c = XCase("cyp_rna_2x100", str(tmp_path))
     rng = random.Random(21)
     rnd = lambda n: "".join(rng.choice("ACGT") for _ in range(n))

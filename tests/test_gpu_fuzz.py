@@ -157,11 +157,11 @@ def adversarial_pairs(al, rng, n):
     return pairs
 
 
-@pytest.mark.skipif(not os.path.exists(util.REF_BIN), reason="reference binary not built")
 @pytest.mark.parametrize("kind,flags,seed", [("ref-rna", ["-s", "0.8"], 7), ("ref-dna", ["-s", "0.9", "--relaxIntronAlign"], 8), ("ref-rna", ["-s", "0.97", "-n", "40"], 9)])
 def test_adversarial_pairs_executable_vs_reference_binary(built, tmp_path, kind, flags, seed):
     """mate pairing, row weights, coalescing, EM and selection on adversarial fragments: every output file of the executable (including
     the per-fragment assignment table) against the reference binary's"""
+    util.need(util.REF_BIN)  # decided when the test runs, after the `built` fixture had its chance to build oracle/_ref
     import subprocess
     ref = str(tmp_path / "ref.fa")
     util.synth_ref(kind, ref, seed=seed + SEED0, genes=5, scale=0.15)
@@ -196,10 +196,10 @@ def test_adversarial_pairs_executable_vs_reference_binary(built, tmp_path, kind,
     assert m >= 4
 
 
-@pytest.mark.skipif(not os.path.exists(util.REF_EXTRACT), reason="reference binary not built")
 @pytest.mark.parametrize("kind,flags,seed", [("ref-rna", [], 11), ("ref-dna", ["-s", "0.95"], 12), ("ref-rna", ["-s", "0.99", "-t", "4"], 13)])
 def test_adversarial_reads_extractor_vs_reference_binary(built, tmp_path, kind, flags, seed):
     """the candidate extractor on the same adversarial read-ends and mate pairs, files against the reference's fastq-extractor"""
+    util.need(util.REF_EXTRACT)  # decided when the test runs, after the `built` fixture had its chance to build oracle/_ref
     import subprocess
     ref = str(tmp_path / "ref.fa")
     util.synth_ref(kind, ref, seed=seed + SEED0, genes=5, scale=0.15)

@@ -79,8 +79,8 @@ def test_executable_vs_golden_reference_outputs(built, tmp_path, name):
     assert int(m.group(1)) == c.meta["assigned_fragments"] and m.group(2) == c.meta["avg_alleles"]
 
 
-@pytest.mark.skipif(not os.path.exists(util.REF_BIN), reason="reference-built oracle/_ref not present")
 def test_executable_vs_live_reference_binary(built):
+    util.need(util.REF_BIN)  # decided when the test runs, after the `built` fixture had its chance to build oracle/_ref
     import gpu_e2e_check
     assert gpu_e2e_check.main() == 0
 
@@ -274,3 +274,83 @@ def test_rccl_single_rank_communicator(built, tmp_path):
         if ref_text is None:
             ref_text = text
         assert text == ref_text == c.expected("genotype.tsv")
+
+
+def _golden_files_equal(c, out):
+    assert open(out + "_genotype.tsv").read() == c.expected("genotype.tsv")
+    assert open(out + "_allele.tsv").read() == c.expected("allele.tsv")
+    ids = [l[1:].strip() for l in open(out + ("_aligned_1.fa" if c.paired else "_aligned.fa")) if l.startswith(">")]
+    assert ids == c.expected("aligned_ids.txt.gz").split()
+
+
+def test_gzip_read_files(built, tmp_path):
+    """reads straight from .gz files (inflated once into memory, then indexed in place like a mapped file): the committed fixtures are
+    stored gzipped, so they are the input as they lie"""
+    c = goldens.Case("cyp_dna_relax_2x150", str(tmp_path))
+    out = os.path.join(str(tmp_path), "gz")
+    args = ["-f", c.ref, "-1", os.path.join(c.dir, "reads_1.fq.gz"), "-2", os.path.join(c.dir, "reads_2.fq.gz")] + c.flags
+    r = subprocess.run([GENO] + args + ["-o", out], stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 0, r.stderr
+    _golden_files_equal(c, out)
+
+
+def test_several_files_per_mate_and_wrapped_fasta(built, tmp_path):
+    """every -1 / -2 counts and the files are read back to back (ReadFiles::AddReadFile); the second half is given as FASTA with the
+    sequences wrapped at 60 columns and CRLF line ends, which the in-place indexer hands to the general (kseq-rule) reader"""
+    c = goldens.Case("cyp_rna_2x100", str(tmp_path))
+    parts = {}
+    for m, path in ((1, c.r1), (2, c.r2)):
+        lines = open(path).read().split("\n")
+        recs = [lines[i:i + 4] for i in range(0, len(lines) - 1, 4)]
+        half = len(recs) // 2
+        a, b = os.path.join(str(tmp_path), "a_%d.fq" % m), os.path.join(str(tmp_path), "b_%d.fa" % m)
+        with open(a, "w") as f:
+            f.write("".join("\n".join(r) + "\n" for r in recs[:half]))
+        with open(b, "w", newline="") as f:
+            for r in recs[half:]:
+                f.write(">" + r[0][1:] + "\r\n")
+                for k in range(0, len(r[1]), 60):
+                    f.write(r[1][k:k + 60] + "\r\n")
+        parts[m] = (a, b)
+    out = os.path.join(str(tmp_path), "multi")
+    args = ["-f", c.ref, "-1", parts[1][0], "-1", parts[1][1], "-2", parts[2][0], "-2", parts[2][1]] + c.flags
+    r = subprocess.run([GENO] + args + ["-o", out], stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 0, r.stderr
+    _golden_files_equal(c, out)
+
+
+def test_over_long_read_fails_before_any_output(built, tmp_path):
+    """reads longer than max_read_len (320) are not handled by this build: the run must stop with a message BEFORE an output file exists"""
+    c = goldens.Case("cyp_rna_2x100", str(tmp_path))
+    long1 = os.path.join(str(tmp_path), "long_1.fq")
+    lines = open(c.r1).read().split("\n")
+    lines[4 * 7 + 1] = lines[4 * 7 + 1] * 4          # one 400-base read in the middle of the file
+    lines[4 * 7 + 3] = lines[4 * 7 + 3] * 4
+    open(long1, "w").write("\n".join(lines))
+    out = os.path.join(str(tmp_path), "long")
+    r = subprocess.run([GENO, "-f", c.ref, "-1", long1, "-2", c.r2, "-o", out] + c.flags, stderr=subprocess.PIPE, text=True)
+    assert r.returncode != 0 and "longer than this build handles" in r.stderr
+    assert not any(f.startswith("long_") and f != "long_1.fq" for f in os.listdir(str(tmp_path)))
+
+
+@pytest.mark.parametrize("label,kind,scale,genes,pairs,flags", [
+    ("config2_hla_rna_100k", "ref-rna", 1.0, 24, 100000, ["-s", "0.97"]),                                  # BASELINE configs[1], 100 k of its pairs
+    ("config3_kir_wgs_100k", "ref-dna", 1.0, 17, 100000, ["-s", "0.9", "--relaxIntronAlign"]),           # --preset kir-wgs (run-t1k:300-304)
+])
+def test_baseline_configs_live_vs_reference_binary(built, tmp_path, label, kind, scale, genes, pairs, flags):
+    """BASELINE.json configs 2 and 3 at 100 k pairs against the reference binary run here (all host cores): every file identical"""
+    util.need(util.REF_BIN)
+    ref = os.path.join(str(tmp_path), "ref.fa")
+    util.synth_ref(kind, ref, genes=genes, scale=scale, seed=20250614)
+    pfx = os.path.join(str(tmp_path), "r")
+    util.synth_reads(ref, pfx, pairs=pairs, len=150, seed=2)
+    common = ["-f", ref, "-1", pfx + "_1.fq", "-2", pfx + "_2.fq"] + flags
+    o_ref, o_gpu = os.path.join(str(tmp_path), "ref"), os.path.join(str(tmp_path), "gpu")
+    r1 = subprocess.run([util.REF_BIN] + common + ["-t", str(min(os.cpu_count() or 8, 128)), "-o", o_ref], stderr=subprocess.PIPE, text=True)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    r2 = subprocess.run([GENO] + common + ["-o", o_gpu], stderr=subprocess.PIPE, text=True)
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    for suf in ("_genotype.tsv", "_allele.tsv", "_aligned_1.fa", "_aligned_2.fa"):
+        assert open(o_ref + suf).read() == open(o_gpu + suf).read(), suf
+    it = [re.search(r"in (\d+) EM iterations", x.stderr).group(1) for x in (r1, r2)]
+    assert it[0] == it[1]

@@ -51,9 +51,9 @@ def test_oracle_pipeline_matches_reference_outputs(built, tmp_path, name):
             assert m.group(6) == ("%.6f" % float(g[4]))
 
 
-@pytest.mark.skipif(not os.path.exists(util.REF_BIN), reason="reference-built oracle/_ref not present")
 def test_oracle_vs_live_reference_binary(built, tmp_path):
     """fresh seeded input, oracle CLI vs the reference binary built from /root/reference (oracle/_ref/genotyper)."""
+    util.need(util.REF_BIN)  # decided when the test runs, after the `built` fixture had its chance to build oracle/_ref
     tmp = str(tmp_path)
     ref = os.path.join(tmp, "ref.fa")
     util.synth_ref("ref-rna", ref, genes=3, scale=0.02, seed=77)

@@ -21,6 +21,13 @@ CYP_DNA = os.path.join(GOLDEN, "cyp2d6_dna_seq.fa.gz")
 CYP_FLAGS = ["--alleleDigitUnits", "1", "--alleleDelimiter", "."]
 
 
+def need(path):
+    """skip the calling test (at run time, not at collection time) when a reference-built binary is absent"""
+    import pytest
+    if not os.path.exists(path):
+        pytest.skip("%s not built (oracle/Makefile builds it from /root/reference where that exists)" % os.path.relpath(path, ROOT))
+
+
 def synth(*args):
     subprocess.run([SYNTH] + [str(a) for a in args], check=True)
 
