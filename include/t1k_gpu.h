@@ -133,6 +133,9 @@ typedef struct {
 } t1k_group_entry;
 int t1k_rowset_create(t1k_ctx *owner, uint64_t nFragments, const uint8_t *whitelist /* [nAlleles] or NULL */, t1k_rowset **out);
 void t1k_rowset_destroy(t1k_rowset *rs);
+/* raw != 0: t1k_pair_into stores the fragment assignment list itself (SeqSet::ReadAssignmentToFragmentAssignment's result) without the
+ * -n / separator / whitelist drops of SetReadAssignments -- what the analyzer's BarcodeSummary::AddFragment reads (BarcodeSummary.hpp:24-57) */
+int t1k_rowset_set_raw(t1k_rowset *rs, int raw);
 const char *t1k_rowset_last_error(const t1k_rowset *rs);
 int t1k_pair_into(t1k_ctx *ctx, t1k_rowset *rs, const uint32_t *end1, const uint32_t *end2, const uint8_t *hasN, uint32_t nFragments, uint64_t fragBase);
 int t1k_rowset_coalesce(t1k_rowset *rs, uint64_t *nGroups, uint64_t *nEntries, uint64_t *assignedFragments);
@@ -247,6 +250,9 @@ double t1k_alloc_ms(t1k_ctx *ctx, uint64_t *bytes);
 int t1k_genotyper_main(int argc, char **argv);
 /* argv-compatible replacement of the reference's fastq-extractor main() (FastqExtractor.cpp:260-626; run-t1k:377-403) */
 int t1k_extractor_main(int argc, char **argv);
+/* argv-compatible replacement of the reference's analyzer main() (Analyzer.cpp:236-733; run-t1k:438-449): re-assignment of the aligned reads
+ * to the selected alleles and the per-barcode expression table; novel-variant calling (VariantCaller.hpp) is not built */
+int t1k_analyzer_main(int argc, char **argv);
 
 typedef struct {
   t1k_params dev;

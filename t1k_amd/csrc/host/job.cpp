@@ -31,6 +31,7 @@ struct t1k_job {
   // multi-GPU: this job is rank `rank` of `nRanks`; it owns fragments [F * rank / nRanks, F * (rank + 1) / nRanks) of the input
   int rank = 0, nRanks = 1;
   t1k_comm *comm = nullptr;         // not owned
+  bool analyzer = false;            // analyzer mode: the rowset keeps the raw fragment assignment lists and is left alive after run_local
   t1k_rowset *rows = nullptr;       // every fragment's row, resident on the GPU until the job is coalesced
   std::vector<uint8_t> fragAssigned;
   bool ran = false, localDone = false;
@@ -84,14 +85,17 @@ void t1k_job_params_default(t1k_job_params *p) {
   p->batch_fragments = 0;
 }
 
-int t1k_job_create(const t1k_job_params *p, const char *refFasta, t1k_job **out) {
+static int jobCreate(const t1k_job_params *p, const char *refFasta, const std::set<std::string> *selected, t1k_job **out);
+int t1k_job_create(const t1k_job_params *p, const char *refFasta, t1k_job **out) { return jobCreate(p, refFasta, nullptr, out); }
+
+static int jobCreate(const t1k_job_params *p, const char *refFasta, const std::set<std::string> *selected, t1k_job **out) {
   if (!out || !refFasta) return T1K_ERR_ARG;
   *out = nullptr;
   t1k_job *job = new t1k_job();
   if (p) job->prm = *p; else t1k_job_params_default(&job->prm);
   *out = job;  // handed back even on failure so the caller can read the message
   const double t0 = nowMs();
-  if (!job->ref.load(refFasta, job->prm.allele_digit_units, job->prm.allele_delimiter, job->err)) return T1K_ERR_IO;
+  if (!job->ref.load(refFasta, job->prm.allele_digit_units, job->prm.allele_delimiter, job->err, selected)) return T1K_ERR_IO;
   job->gt.ref = &job->ref;
   job->gt.prm = job->prm;
   if (job->prm.device < 0) return T1K_OK;  // host-only job: group bookkeeping for tests / merging, no device work possible
@@ -263,6 +267,7 @@ int t1k_job_run_local(t1k_job *job) {
   {
     std::vector<uint8_t> wl(job->whitelist.begin(), job->whitelist.end());
     if ((rc = t1k_rowset_create(job->ctx, F, wl.empty() ? nullptr : wl.data(), &job->rows)) != T1K_OK) return jobFail(job, rc, t1k_last_error(job->ctx));
+    if (job->analyzer) t1k_rowset_set_raw(job->rows, 1);
   }
   const double tStart = nowMs();
   const int T = hostThreads(job);
@@ -452,6 +457,12 @@ int t1k_job_run_local(t1k_job *job) {
   const double tDev = nowMs();
   for (t1k_ctx *c : job->more)
     if ((rc = t1k_coverage_absorb(job->ctx, c)) != T1K_OK) return jobFail(job, rc, t1k_last_error(job->ctx));
+  if (job->analyzer) {  // the per-barcode summary reads the fragment assignment lists themselves (t1k_analyzer_main)
+    if ((rc = t1k_rowset_assigned_download(job->rows, job->fragAssigned.data())) != T1K_OK) return jobFail(job, rc, t1k_rowset_last_error(job->rows));
+    job->msDevice = tDev - tStart;
+    job->localDone = true;
+    return T1K_OK;
+  }
   const bool sharded = job->nRanks > 1;
   if (sharded) {  // per-base coverage of all ranks: integers, exact in any order
     void *cov = nullptr; uint64_t covN = 0;
@@ -910,6 +921,160 @@ int t1k_genotyper_main(int argc, char **argv) {
   if (rc != T1K_OK) { fprintf(stderr, "genotyper: %s\n", t1k_job_last_error(job)); destroyAll(); return EXIT_FAILURE; }
   logLine("Genotyping finishes.");
   destroyAll();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// analyzer: Analyzer.cpp:236-733 as run-t1k:438-449 starts it after the genotyper -- the aligned reads are
+// assigned again, to the alleles named in <prefix>_allele.tsv only (Genotyper::InitRefSet with selectedAlleles, Genotyper.hpp:732-757;
+// AssignRead with weight 0: no coverage is kept, Analyzer.cpp:139, 472), mates are paired, and BarcodeSummary (BarcodeSummary.hpp:24-80)
+// turns every assigned fragment's allele list into 1/n fractional and unique counts per barcode: <prefix>_barcode_expr.tsv.
+// Not built: VariantCaller (novel-variant calling, VariantCaller.hpp).  <prefix>_allele.vcf is therefore written empty -- what the
+// reference writes when it calls no variant -- and the per-barcode counts use the raw fragment assignments, which is what
+// VariantCaller::AdjustFragmentAssignment (1229-1311) returns whenever no called variant sits under a mismatch of the fragment.
+// ------------------------------------------------------------------------------------------------------------------
+static const char *kAnalyzerUsage =
+    "./analyzer [OPTIONS]:   (MI355X build of the T1K post-analysis stage: re-assignment + per-barcode summary; no variant calling)\n"
+    "Required:\n"
+    "\t-f STRING: fasta file with the allele reference sequences\n"
+    "\t-a STRING: selected alleles list file (prefix_allele.tsv)\n"
+    "\t-u STRING: single-end read file, or\n"
+    "\t-1 STRING -2 STRING: paired-end read files\n"
+    "Optional:\n"
+    "\t-t INT: host threads (default: 1)\n"
+    "\t-o STRING: output prefix (default: t1k)\n"
+    "\t-n INT: maximal number of alleles per read (default: 2000)\n"
+    "\t-s FLOAT: minimum alignment similarity (default: 0.8)\n"
+    "\t--barcode STRING: barcode file\n"
+    "\t--relaxIntronAlign: allow one more mismatch in intronic alignment\n"
+    "\t--alleleDigitUnits INT, --alleleDelimiter CHR: as in genotyper\n"
+    "\t--varMaxGroup INT: accepted and ignored (variant calling is not part of this build)\n"
+    "\t--device INT: GPU ordinal (default: $T1K_DEVICE or 0)\n";
+
+int t1k_analyzer_main(int argc, char **argv) {
+  if (argc <= 1) { fprintf(stderr, "%s", kAnalyzerUsage); return 0; }  // Analyzer.cpp:241-245
+  static struct option longOpts[] = {{"barcode", required_argument, 0, 10000}, {"relaxIntronAlign", no_argument, 0, 10004}, {"alleleDigitUnits", required_argument, 0, 10005},
+                                     {"alleleDelimiter", required_argument, 0, 10006}, {"varMaxGroup", required_argument, 0, 10007}, {"device", required_argument, 0, 10010},
+                                     {0, 0, 0, 0}};
+  t1k_job_params p;
+  t1k_job_params_default(&p);
+  if (const char *d = getenv("T1K_DEVICE")) p.device = atoi(d);
+  std::string refFile, alleleFile, prefix = "t1k", barcode;
+  std::vector<const char *> f1, f2, single;
+  optind = 1;
+  int c, idx = 0;
+  while ((c = getopt_long(argc, argv, "f:a:u:1:2:o:t:n:s:", longOpts, &idx)) != -1) {
+    switch (c) {
+      case 'f': refFile = optarg; break;
+      case 'a': alleleFile = optarg; break;
+      case 'u': single.push_back(optarg); break;
+      case '1': f1.push_back(optarg); break;
+      case '2': f2.push_back(optarg); break;
+      case 'o': prefix = optarg; break;
+      case 't': p.threads = atoi(optarg); break;
+      case 'n': p.dev.max_assign_cnt = atoi(optarg); break;
+      case 's': p.dev.ref_seq_similarity = atof(optarg); break;
+      case 10000: barcode = optarg; break;
+      case 10004: p.dev.relax_intron_align = 1; break;
+      case 10005: p.allele_digit_units = atoi(optarg); break;
+      case 10006: p.allele_delimiter = optarg[0]; break;
+      case 10007: break;
+      case 10010: p.device = atoi(optarg); break;
+      default: fprintf(stderr, "%s", kAnalyzerUsage); return EXIT_FAILURE;
+    }
+  }
+  if (refFile.empty()) { fprintf(stderr, "Need to use -f to specify the reference sequences.\n"); return EXIT_FAILURE; }
+  if (alleleFile.empty()) { fprintf(stderr, "Need to use -a to specify selected allele ids.\n"); return EXIT_FAILURE; }
+  if (p.dev.max_assign_cnt == 0) p.dev.max_assign_cnt = -1;
+  std::set<std::string> selected;
+  {
+    FILE *fp = fopen(alleleFile.c_str(), "r");  // first word of every line (Analyzer.cpp:347-356)
+    if (!fp) { fprintf(stderr, "analyzer: cannot open %s\n", alleleFile.c_str()); return EXIT_FAILURE; }
+    char line[10241], name[10241];
+    while (fgets(line, sizeof(line), fp))
+      if (sscanf(line, "%10240s", name) == 1) selected.insert(name);
+    fclose(fp);
+  }
+  t1k_job *job = nullptr;
+  int rc = jobCreate(&p, refFile.c_str(), &selected, &job);
+  if (rc != T1K_OK) {
+    fprintf(stderr, "analyzer: %s\n", job ? t1k_job_last_error(job) : "initialisation failed");
+    t1k_job_destroy(job);
+    return EXIT_FAILURE;
+  }
+  job->analyzer = true;
+  const bool paired = !f2.empty();
+  const std::vector<const char *> &first = !f1.empty() ? f1 : single;
+  if (first.empty()) { fprintf(stderr, "analyzer: no read file given (-u, or -1 and -2)\n"); t1k_job_destroy(job); return EXIT_FAILURE; }
+  rc = t1k_job_load_reads_multi(job, first.data(), (uint32_t)first.size(), paired ? f2.data() : nullptr, (uint32_t)f2.size(), barcode.empty() ? nullptr : barcode.c_str());
+  if (rc != T1K_OK) { fprintf(stderr, "analyzer: %s\n", t1k_job_last_error(job)); t1k_job_destroy(job); return EXIT_FAILURE; }
+  const ReadInput &in = *job->in;
+  const uint32_t F = (uint32_t)in.nFrag();
+  logLine("Found %d read fragments. Start read assignment.", (int)F);
+  rc = t1k_job_run_local(job);
+  if (rc != T1K_OK) { fprintf(stderr, "analyzer: %s\n", t1k_job_last_error(job)); t1k_job_destroy(job); return EXIT_FAILURE; }
+  logLine("Finish read end assignments.");
+  uint64_t nAssigned = 0;
+  for (uint32_t f = 0; f < F; ++f) nAssigned += job->fragAssigned[f] ? 1 : 0;
+  logLine("Finish read fragment assignments. %d read fragments can be assigned.", (int)nAssigned);
+  {  // no variant calling in this build: the file the reference writes when it finds none
+    FILE *fp = fopen((prefix + "_allele.vcf").c_str(), "w");
+    if (!fp) { fprintf(stderr, "analyzer: cannot write %s_allele.vcf\n", prefix.c_str()); t1k_job_destroy(job); return EXIT_FAILURE; }
+    fclose(fp);
+  }
+  if (in.hasBarcode) {
+    // barcode ids in order of first appearance over ALL loaded fragments (Analyzer.cpp:380-392), counts in fragment order
+    std::unordered_map<std::string, int> idOf;
+    std::vector<std::string> names;
+    std::vector<int> bcOf(F);
+    for (uint32_t f = 0; f < F; ++f) {
+      const uint32_t r = in.frag[f];
+      std::string s(in.bc.seqP[r], in.bc.seqL[r]);
+      auto it = idOf.find(s);
+      if (it == idOf.end()) { it = idOf.emplace(s, (int)names.size()).first; names.push_back(s); }
+      bcOf[f] = it->second;
+    }
+    const size_t A = job->ref.al.size();
+    std::map<int, std::pair<std::vector<double>, std::vector<int>>> table;  // barcode -> (fractional counts, unique counts)
+    const uint32_t step = 1u << 18;
+    std::vector<uint32_t> cnt;
+    std::vector<t1k_row_entry> rows;
+    for (uint32_t f0 = 0; f0 < F; f0 += step) {
+      const uint32_t n = std::min(step, F - f0);
+      cnt.resize(n);
+      uint64_t total = 0;
+      rc = t1k_rowset_rows_download(job->rows, f0, n, cnt.data(), nullptr, 0, &total);
+      rows.resize(total);
+      if (rc == T1K_OK && total) rc = t1k_rowset_rows_download(job->rows, f0, n, cnt.data(), rows.data(), total, &total);
+      if (rc != T1K_OK) { fprintf(stderr, "analyzer: %s\n", t1k_rowset_last_error(job->rows)); t1k_job_destroy(job); return EXIT_FAILURE; }
+      uint64_t q = 0;
+      for (uint32_t i = 0; i < n; ++i) {
+        const uint32_t k = cnt[i];
+        if (!job->fragAssigned[f0 + i]) { q += k; continue; }
+        auto &slot = table[bcOf[f0 + i]];  // BarcodeSummary::AddFragment (BarcodeSummary.hpp:24-57)
+        if (slot.first.empty()) { slot.first.assign(A, 0.0); slot.second.assign(A, 0); }
+        for (uint32_t j = 0; j < k; ++j, ++q) {
+          slot.first[rows[q].allele_idx] += 1.0 / k;
+          if (k == 1) ++slot.second[rows[q].allele_idx];
+        }
+      }
+    }
+    FILE *fp = fopen((prefix + "_barcode_expr.tsv").c_str(), "w");  // BarcodeSummary::Output (59-80)
+    if (!fp) { fprintf(stderr, "analyzer: cannot write %s_barcode_expr.tsv\n", prefix.c_str()); t1k_job_destroy(job); return EXIT_FAILURE; }
+    fprintf(fp, "#barcode");
+    for (size_t a = 0; a < A; ++a) fprintf(fp, "\t%s", job->ref.al[a].name.c_str());
+    for (size_t a = 0; a < A; ++a) fprintf(fp, "\t%s_uniq", job->ref.al[a].name.c_str());
+    fprintf(fp, "\n");
+    for (auto &kv : table) {
+      fprintf(fp, "%s", names[kv.first].c_str());
+      for (size_t a = 0; a < A; ++a) fprintf(fp, "\t%lf", kv.second.first[a]);
+      for (size_t a = 0; a < A; ++a) fprintf(fp, "\t%d", kv.second.second[a]);
+      fprintf(fp, "\n");
+    }
+    fclose(fp);
+  }
+  logLine("Post analysis finishes.");
+  t1k_job_destroy(job);
   return 0;
 }
 

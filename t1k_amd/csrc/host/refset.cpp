@@ -117,13 +117,14 @@ void kmerProfile(const std::string &s, std::unordered_map<uint64_t, int> &prof) 
 }
 }  // namespace
 
-bool RefSet::load(const std::string &fasta, int digitUnitsArg, char delimiterArg, std::string &err) {
+bool RefSet::load(const std::string &fasta, int digitUnitsArg, char delimiterArg, std::string &err, const std::set<std::string> *selected) {
   digitUnits = digitUnitsArg;
   delimiter = delimiterArg;
   std::vector<SeqRec> recs;
   if (!readSeqFile(fasta, recs, err)) return false;
   std::unordered_map<std::string, int> firstWithSeq;
   for (auto &r : recs) {
+    if (selected && !selected->count(r.id)) continue;  // Genotyper.hpp:742-743
     auto it = firstWithSeq.find(r.seq);
     if (it != firstWithSeq.end()) { al[it->second].weight += 1; continue; }  // Genotyper.hpp:718-721
     firstWithSeq.emplace(r.seq, (int)al.size());

@@ -6,6 +6,7 @@
 #include <list>
 #include <map>
 #include <mutex>
+#include <set>
 #include <memory>
 #include <string>
 #include <unordered_map>
@@ -73,7 +74,8 @@ struct RefSet {
   std::vector<std::vector<double>> geneSim;  // geneSim[i][j] = how similar gene i's k-mers are to gene j's (KmerCount.hpp:196-216)
   bool rnaData = true;
   // load + merge identical sequences + exon masks + weights + naming (Genotyper::InitRefSet, Genotyper.hpp:707-730)
-  bool load(const std::string &fasta, int digitUnits, char delimiter, std::string &err);
+  // selected != NULL: only the records named in it (Genotyper::InitRefSet(filename, selectedAlleles), Genotyper.hpp:732-757)
+  bool load(const std::string &fasta, int digitUnits, char delimiter, std::string &err, const std::set<std::string> *selected = nullptr);
   void splitName(const std::string &allele, std::string &gene, std::string &major, int fieldsType) const;
   int digitUnits = -1;
   char delimiter = 0;

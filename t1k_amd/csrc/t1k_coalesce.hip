@@ -189,6 +189,7 @@ void t1k_rowset_destroy(t1k_rowset *rs) {
   delete rs;
 }
 
+int t1k_rowset_set_raw(t1k_rowset *rs, int raw) { if (!rs) return T1K_ERR_ARG; rs->rawKept = raw != 0; return T1K_OK; }
 const char *t1k_rowset_last_error(const t1k_rowset *rs) { return rs ? rs->err.c_str() : "no rowset"; }
 
 int t1k_rowset_coalesce(t1k_rowset *rs, uint64_t *nGroups, uint64_t *nEntries, uint64_t *assignedFragments) {

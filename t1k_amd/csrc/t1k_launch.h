@@ -110,6 +110,7 @@ struct t1k_rowset {
   std::mutex m;
   T1kDevBuf bWhitelist;
   const uint8_t *whitelist = nullptr;
+  bool rawKept = false;             // rows = the raw fragment assignment lists (analyzer)
   // coalescing results (device)
   T1kDevBuf bWork, bGroupPtr, bGroupEnt, bGroupFirst;
   uint64_t nGroups = 0, nEntries = 0, nAssigned = 0;

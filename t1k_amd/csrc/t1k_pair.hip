@@ -82,6 +82,8 @@ struct PairArgs {
   const uint32_t *only; uint32_t nOnly;  // second pass: just these fragments (the ones whose lists did not fit the first pass's scratch)
   uint32_t *overflowList;          // first pass: fragments with more than fragCap overlaps are listed here (count in counters[23]) instead of failing
   const uint8_t *whitelist;        // [nAlleles] or NULL: alleles outside it are left out of the rows (Genotyper.hpp:822-823)
+  int rawKept;                     // rows = the fragment assignment list itself (what ReadAssignmentToFragmentAssignment returns), without
+                                   // the -n / separator / whitelist drops of SetReadAssignments: the analyzer's per-barcode summary reads that
   // rowset form (rsRowPtr != NULL): rows go to rsRows[*rsCursor ...), ordered by allele; per-fragment records at fragBase + f
   unsigned long long *rsRowPtr; uint32_t *rsRowCount; unsigned long long *rsH1, *rsH2; uint8_t *rsAssigned;
   t1k_row_entry *rsRows; uint64_t rsCap; unsigned long long *rsCursor; uint64_t fragBase;
@@ -443,7 +445,7 @@ __global__ __launch_bounds__(WG) void k_pair(PairArgs P) {
     }
     if (cleared) nKept = 0;
     // ---- Genotyper::SetReadAssignments (778-832) ------------------------------------------------------------------------------
-    bool emptyRow = nKept == 0 || (P.maxAssign > 0 && (int)nKept > P.maxAssign);
+    bool emptyRow = nKept == 0 || (!P.rawKept && P.maxAssign > 0 && (int)nKept > P.maxAssign);
     if (!emptyRow) {
       for (uint32_t q = tid; q < nKept; q += WG) {
         const Frag &fr = frags[keep[q]];
@@ -451,11 +453,11 @@ __global__ __launch_bounds__(WG) void k_pair(PairArgs P) {
         if (fr.sim >= 1) sNotOne = 1;  // maxSimilarity >= 1 somewhere
       }
       __syncthreads();
-      if (sAnySep) emptyRow = true;
+      if (sAnySep && !P.rawKept) emptyRow = true;
     }
     uint32_t nRow = emptyRow ? 0 : nKept;
     const bool anyKept = nKept > 0;  // fragmentAssigned is set before the -n / separator / whitelist drops
-    if (nRow && P.whitelist) {      // order-preserving compaction of `keep`
+    if (nRow && P.whitelist && !P.rawKept) {      // order-preserving compaction of `keep`
       uint32_t w = 0;
       for (uint32_t q0 = 0; q0 < nRow; q0 += WG) {
         const uint32_t q = q0 + tid;
@@ -614,6 +616,7 @@ static int pairLaunch(t1k_ctx *ctx, t1k_rowset *rs, const uint32_t *end1, const 
     size_t chunk = 0;
     if (rs) {
       if ((rc = t1k_rowset_chunk(rs, ctx, &chunk, &p.rsRows, &p.rsCap, &p.rsCursor))) return rc;
+      p.rawKept = rs->rawKept ? 1 : 0;
       p.rsRowPtr = rs->rowPtr; p.rsRowCount = rs->rowCount; p.rsH1 = rs->h1; p.rsH2 = rs->h2; p.rsAssigned = rs->assigned; p.fragBase = fragBase;
     }
     p.epochBase = (uint32_t)ctx->pairEpoch; ctx->pairEpoch += n;

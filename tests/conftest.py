@@ -18,7 +18,7 @@ def built():
     need = [os.path.join(util.ROOT, "t1k_amd", "lib", "libt1k_gpu.so"), util.ORACLE_SO, util.ORACLE_CLI, util.ORACLE_EXTRACT, util.SYNTH,
             os.path.join(util.ROOT, "t1k_amd", "bin", "genotyper"), os.path.join(util.ROOT, "t1k_amd", "bin", "fastq-extractor")]
     if os.path.exists("/root/reference/Genotyper.cpp"):  # the reference-built checkers can be (re)built here
-        need += [util.REF_BIN, util.REF_EXTRACT]
+        need += [util.REF_BIN, util.REF_EXTRACT, util.REF_ANALYZER]
     if not all(os.path.exists(p) for p in need):
         sys.path.insert(0, util.ROOT)
         import __graft_entry__

@@ -354,3 +354,46 @@ def test_baseline_configs_live_vs_reference_binary(built, tmp_path, label, kind,
         assert open(o_ref + suf).read() == open(o_gpu + suf).read(), suf
     it = [re.search(r"in (\d+) EM iterations", x.stderr).group(1) for x in (r1, r2)]
     assert it[0] == it[1]
+
+
+ANALYZER = os.path.join(util.ROOT, "t1k_amd", "bin", "analyzer")
+
+
+def test_analyzer_vs_golden_reference_outputs(built, tmp_path):
+    """genotyper -> analyzer as run-t1k:438-449 chains them; the per-barcode table must equal the file the reference's
+    analyzer wrote on the same inputs (tools/make_analyzer_goldens.py); the reference called no variant there, so its VCF is empty"""
+    c = goldens.Case("hla_synth_2x150", str(tmp_path))
+    g, a = os.path.join(str(tmp_path), "g"), os.path.join(str(tmp_path), "a")
+    r = subprocess.run([GENO] + c.args() + ["-o", g], stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([ANALYZER, "-f", c.ref, "-a", g + "_allele.tsv", "-1", g + "_aligned_1.fa", "-2", g + "_aligned_2.fa", "--barcode", g + "_aligned_bc.fa", "-o", a] + c.flags,
+                       stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 0, r.stderr
+    assert open(a + "_barcode_expr.tsv").read() == c.expected("analyzer_barcode_expr.tsv")
+    assert open(a + "_allele.vcf").read() == c.expected("analyzer_allele.vcf") == ""
+
+
+@pytest.mark.parametrize("seed,paired,flags", [(21, True, ["-s", "0.9"]), (22, False, ["-s", "0.8"]), (23, True, ["-s", "0.97", "-n", "3"])])
+def test_analyzer_live_vs_reference_binary(built, tmp_path, seed, paired, flags):
+    """the analyzer against the reference's analyzer run here, on reads with many multi-allele fragments (a lenient -s, a small -n that the
+    summary must NOT apply, single-end): _barcode_expr.tsv byte for byte, whenever the reference calls no variant (asserted)"""
+    util.need(util.REF_ANALYZER)
+    ref = os.path.join(str(tmp_path), "ref.fa")
+    util.synth_ref("ref-rna", ref, genes=5, scale=0.05, seed=seed)
+    pfx = os.path.join(str(tmp_path), "r")
+    util.synth_reads(ref, pfx, pairs=4000, len=150, seed=seed, barcodes=120, sub=0.0)
+    reads = ["-1", pfx + "_1.fq", "-2", pfx + "_2.fq"] if paired else ["-u", pfx + "_1.fq"]
+    g = os.path.join(str(tmp_path), "g")
+    r = subprocess.run([GENO, "-f", ref] + reads + ["--barcode", pfx + "_bc.fa", "-o", g] + flags, stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 0, r.stderr
+    aligned = ["-1", g + "_aligned_1.fa", "-2", g + "_aligned_2.fa"] if paired else ["-u", g + "_aligned.fa"]
+    outs = []
+    for binary, tag in ((util.REF_ANALYZER, "ref"), (ANALYZER, "gpu")):
+        o = os.path.join(str(tmp_path), tag)
+        r = subprocess.run([binary, "-f", ref, "-a", g + "_allele.tsv"] + aligned + ["--barcode", g + "_aligned_bc.fa", "-o", o, "-t", "4"] + flags, stderr=subprocess.PIPE, text=True)
+        assert r.returncode == 0, r.stderr
+        outs.append(o)
+    assert open(outs[0] + "_allele.vcf").read() == "", "the reference called a variant on this input: not a case this build covers"
+    a, b = open(outs[0] + "_barcode_expr.tsv").read(), open(outs[1] + "_barcode_expr.tsv").read()
+    assert a.count("\n") > 50
+    assert a == b

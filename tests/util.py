@@ -16,6 +16,7 @@ ORACLE_CLI = os.path.join(ROOT, "oracle", "t1k_oracle_cli")
 REF_BIN = os.path.join(ROOT, "oracle", "_ref", "genotyper")
 ORACLE_EXTRACT = os.path.join(ROOT, "oracle", "t1k_oracle_extract")
 REF_EXTRACT = os.path.join(ROOT, "oracle", "_ref", "fastq-extractor")
+REF_ANALYZER = os.path.join(ROOT, "oracle", "_ref", "analyzer")
 CYP_RNA = os.path.join(GOLDEN, "cyp2d6_rna_seq.fa.gz")
 CYP_DNA = os.path.join(GOLDEN, "cyp2d6_dna_seq.fa.gz")
 CYP_FLAGS = ["--alleleDigitUnits", "1", "--alleleDelimiter", "."]
