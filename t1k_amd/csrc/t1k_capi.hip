@@ -33,8 +33,6 @@ int t1k_ensure(t1k_ctx *ctx, T1kDevBuf &b, size_t bytes) {
 
 static double nowMs() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
-static inline int asciiCode(char c) { return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : 4; }
-
 // listPtr[i] = device address of read-end i's first overlap record, listCount[i] = its length (after k_truncate)
 __global__ void k_publish_lists(unsigned long long *listPtr, uint32_t *listCount, const T1kOvl *base, const uint32_t *ovlStart, const uint32_t *ovlCount, uint32_t n) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -45,18 +43,6 @@ __global__ void k_publish_lists(unsigned long long *listPtr, uint32_t *listCount
 static void t1k_launch_publish_lists(t1k_ctx *ctx, unsigned long long *listPtr, uint32_t *listCount, const T1kOvl *base, const uint32_t *ovlStart, const uint32_t *ovlCount,
                                      uint32_t n) {
   if (n) hipLaunchKernelGGL(k_publish_lists, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, listPtr, listCount, base, ovlStart, ovlCount, n);
-}
-
-template <typename T>
-static int uploadVec(t1k_ctx *ctx, const std::vector<T> &v, const void **dst) {
-  T1kDevBuf b;
-  int rc = t1k_ensure(ctx, b, v.size() * sizeof(T));
-  if (rc) return rc;
-  if (!v.empty()) T1K_HIP(ctx, hipMemcpyAsync(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
-  T1K_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  ctx->refBufs.push_back(b);
-  *dst = b.p;
-  return 0;
 }
 
 
@@ -144,240 +130,8 @@ void t1k_ctx_destroy(t1k_ctx *ctx) {
 const char *t1k_last_error(const t1k_ctx *ctx) { return ctx ? ctx->err.c_str() : "no context"; }
 
 // ------------------------------------------------------------------------------------------------------------------
-// reference
+// reference (t1k_ref_upload: t1k_refindex.hip)
 // ------------------------------------------------------------------------------------------------------------------
-int t1k_ref_upload(t1k_ctx *ctx, const char *seqs, const uint64_t *offsets, const uint8_t *exon, uint32_t nAlleles) {
-  if (!ctx || !seqs || !offsets || nAlleles == 0 || nAlleles >= (1u << 24)) return t1k_fail(ctx, T1K_ERR_ARG, "t1k_ref_upload: bad arguments");
-  if (offsets[nAlleles] - offsets[0] >= (1ull << 29)) return t1k_fail(ctx, T1K_ERR_ARG, "t1k_ref_upload: reference larger than 512 Mbases");
-  T1K_HIP(ctx, hipSetDevice(ctx->device));
-  for (auto &b : ctx->refBufs) freeBuf(b);
-  ctx->refBufs.clear();
-  const int k = ctx->prm.kmer_length;
-  const uint32_t nCode = (uint32_t)ctx->prm.n_base_code & 3u;
-  const bool dbgPhases = getenv("T1K_DEBUG_PHASES") != nullptr;
-  auto tLap = std::chrono::steady_clock::now();
-  auto lap = [&](const char *what) {
-    if (!dbgPhases) return;
-    const auto now = std::chrono::steady_clock::now();
-    fprintf(stderr, "[t1k] ref_upload %s: %.3f s\n", what, std::chrono::duration<double>(now - tLap).count());
-    tLap = now;
-  };
-  std::vector<uint64_t> alleleOff(nAlleles);
-  std::vector<uint32_t> alleleLen(nAlleles);
-  uint64_t total = 0;
-  for (uint32_t a = 0; a < nAlleles; ++a) {
-    uint64_t len = offsets[a + 1] - offsets[a];
-    if (len >= (1u << 20)) return t1k_fail(ctx, T1K_ERR_ARG, "allele longer than 2^20 bases");
-    alleleOff[a] = total;
-    alleleLen[a] = (uint32_t)len;
-    total += (len + 32) / 32 * 32;  // at least one spare position behind every allele: the coverage difference array writes its end marker at seqEnd + 1
-  }
-  total += 64;
-  size_t words = total / 32 + 2;
-  std::vector<uint64_t> bases(words, 0), nmask(words, 0), exonm(words, 0);
-  std::vector<uint32_t> sepStart(nAlleles + 1, 0);
-  std::vector<uint8_t> alleleHasN(nAlleles, 0);
-  std::vector<int32_t> sepPos;
-  // index, pass 1: count (KmerIndex::BuildIndexFromRead, KmerIndex.hpp:107-130).  k-mer codes are
-  // little-endian here (first base in the low bits); only equality and "== 0" are ever tested, both convention-free.
-  const size_t nKeys = (size_t)1 << (2 * k);
-  const uint32_t kmask = (uint32_t)(nKeys - 1);
-  // the bucket table has 4^k + 1 entries (1 GB at k = 14): transparent huge pages and a first touch by several threads, or the page
-  // faults of a plain zero-initialised vector cost more than the index build itself
-  const size_t kStartBytes = ((nKeys + 1) * sizeof(uint32_t) + (2u << 20) - 1) & ~(size_t)((2u << 20) - 1);
-  std::unique_ptr<uint32_t, void (*)(void *)> kStartBuf((uint32_t *)aligned_alloc(2u << 20, kStartBytes), free);
-  if (!kStartBuf) return t1k_fail(ctx, T1K_ERR_ARG, "t1k_ref_upload: out of host memory");
-  uint32_t *kStart = kStartBuf.get();
-  (void)madvise(kStart, kStartBytes, MADV_HUGEPAGE);
-  {
-    const unsigned nz = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
-    const size_t per = ((kStartBytes / nz) + 4095) & ~(size_t)4095;
-    std::vector<std::thread> th;
-    for (unsigned t = 0; t < nz; ++t)
-      th.emplace_back([&, t] { const size_t lo = std::min(kStartBytes, t * per), hi = std::min(kStartBytes, (t + 1) * per); memset((char *)kStart + lo, 0, hi - lo); });
-    for (auto &x : th) x.join();
-  }
-  // Alleles are independent here (every allele owns whole 32-base words of the packed arrays): contiguous allele ranges go to host
-  // threads, each keeping its insertions in allele order; the only shared writes are the bucket counts.
-  typedef std::vector<std::pair<uint32_t, uint32_t>> InsList;
-  const unsigned nThr = std::max(1u, std::min({16u, std::thread::hardware_concurrency(), nAlleles}));
-  std::vector<InsList> insOf(nThr);
-  std::vector<std::vector<int32_t>> sepOf(nThr);
-  std::vector<uint32_t> sepCount(nAlleles, 0), rangeBegin(nThr + 1, nAlleles);
-  {
-    const uint64_t totalBases = offsets[nAlleles] - offsets[0];
-    uint32_t a = 0;
-    for (unsigned t = 0; t < nThr; ++t) {  // split by bases, not by allele count
-      rangeBegin[t] = a;
-      const uint64_t until = offsets[0] + totalBases * (t + 1) / nThr;
-      while (a < nAlleles && (offsets[a + 1] <= until || a == rangeBegin[t])) ++a;
-    }
-    rangeBegin[nThr] = nAlleles;
-    rangeBegin[0] = 0;
-    for (unsigned t = 1; t <= nThr; ++t) rangeBegin[t] = std::max(rangeBegin[t], rangeBegin[t - 1]);
-  }
-  {
-    std::vector<std::thread> th;
-    for (unsigned t = 0; t < nThr; ++t)
-      th.emplace_back([&, t] {
-        InsList &ins = insOf[t];
-        std::vector<int32_t> &sep = sepOf[t];
-        for (uint32_t a = rangeBegin[t]; a < rangeBegin[t + 1]; ++a) {
-          const char *s = seqs + offsets[a];
-          const uint32_t len = alleleLen[a];
-          const uint64_t g = alleleOff[a];
-          uint32_t code = 0, prev = 0;
-          int invalid = -1;
-          for (uint32_t i = 0; i < len; ++i) {
-            int c = asciiCode(s[i]);
-            uint64_t pos = g + i;
-            if (c == 4) { nmask[pos >> 5] |= 1ull << ((pos & 31) * 2); sep.push_back((int32_t)i); ++sepCount[a]; alleleHasN[a] = 1; }
-            else bases[pos >> 5] |= (uint64_t)c << ((pos & 31) * 2);
-            if (exon && exon[offsets[a] + i]) exonm[pos >> 5] |= 1ull << ((pos & 31) * 2);
-            if (invalid != -1) ++invalid;
-            code = (code >> 2) | ((uint32_t)(c == 4 ? nCode : c) << (2 * (k - 1)));
-            code &= kmask;
-            if (c == 4) invalid = 0;
-            if (invalid >= k) invalid = -1;
-            if ((int)i < k - 1) continue;
-            if (invalid == -1 && ((int)i == k || code != prev)) { ins.push_back({code, i - k + 1}); __atomic_fetch_add(&kStart[code + 1], 1u, __ATOMIC_RELAXED); }
-            prev = code;
-          }
-          // remember where this allele's postings end
-          ins.push_back({0xFFFFFFFFu, a});
-        }
-      });
-    for (auto &x : th) x.join();
-  }
-  for (uint32_t a = 0; a < nAlleles; ++a) sepStart[a + 1] = sepStart[a] + sepCount[a];
-  for (unsigned t = 0; t < nThr; ++t) sepPos.insert(sepPos.end(), sepOf[t].begin(), sepOf[t].end());
-  lap("pack + k-mer codes");
-  for (size_t i = 0; i < nKeys; ++i) kStart[i + 1] += kStart[i];
-  lap("prefix");
-  std::vector<T1kPosting> post(kStart[nKeys]);
-  {
-    // kStart doubles as the placement cursor: afterwards entry c holds the end of list c, i.e. the start of list c + 1
-    uint32_t a = 0;
-    for (auto &ins : insOf)
-      for (auto &e : ins) {
-        if (e.first == 0xFFFFFFFFu) { a = e.second + 1; continue; }
-        post[kStart[e.first]++] = T1kPosting{a, e.second};
-      }
-    memmove(&kStart[1], &kStart[0], nKeys * sizeof(uint32_t));
-    kStart[0] = 0;
-  }
-  lap("placement");
-  ctx->hAlleleOff = alleleOff;
-  ctx->hAlleleLen = alleleLen;
-  T1kRefDev r{};
-  r.nAlleles = nAlleles;
-  r.totalBases = total;
-  int rc;
-  if ((rc = uploadVec(ctx, bases, (const void **)&r.bases))) return rc;
-  if ((rc = uploadVec(ctx, nmask, (const void **)&r.nmask))) return rc;
-  if ((rc = uploadVec(ctx, exonm, (const void **)&r.exon))) return rc;
-  if ((rc = uploadVec(ctx, alleleOff, (const void **)&r.alleleOff))) return rc;
-  if ((rc = uploadVec(ctx, alleleLen, (const void **)&r.alleleLen))) return rc;
-  if ((rc = uploadVec(ctx, alleleHasN, (const void **)&r.alleleHasN))) return rc;
-  if ((rc = uploadVec(ctx, sepStart, (const void **)&r.sepStart))) return rc;
-  if (sepPos.empty()) sepPos.push_back(0);
-  if ((rc = uploadVec(ctx, sepPos, (const void **)&r.sepPos))) return rc;
-  {
-    T1kDevBuf b;
-    if ((rc = t1k_ensure(ctx, b, (nKeys + 1) * sizeof(uint32_t)))) return rc;
-    T1K_HIP(ctx, hipMemcpyAsync(b.p, kStart, (nKeys + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-    T1K_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    ctx->refBufs.push_back(b);
-    r.kStart = (const uint32_t *)b.p;
-  }
-  lap("small uploads + bucket table upload");
-  {
-    // Per code, in two parallel sweeps over the bucket table (it has 4^k entries: 1 GB at the extractor's k = 14):
-    //   presence bitmaps (t1k_extract.hip): bit c of kHas = list c is not empty; bit p of kHasPre = some non-empty code c has
-    //   p as the first k - 2 bases of min(c, revcomp(c));
-    //   bit c of kMulti = list c holds a sequence more than once
-    //   chunk directory: where each multiple of T1K_SEED_CHUNK alleles begins inside a long posting list, so that the kernels find a
-    //   chunk's slice of a list with one load instead of a bisection
-    const uint32_t stride = (nAlleles + T1K_SEED_CHUNK - 1) / T1K_SEED_CHUNK + 1;
-    const int kp = std::max(1, k - 2);
-    const size_t nPre = (size_t)1 << (2 * kp);
-    std::vector<uint32_t> has((nKeys + 31) / 32, 0), multi((nKeys + 31) / 32, 0), hasPre((nPre + 31) / 32, 0);
-    std::unique_ptr<uint32_t[]> dirIdx(new uint32_t[nKeys]);
-    const unsigned T = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
-    const size_t per = ((nKeys + T - 1) / T + 31) / 32 * 32;
-    std::vector<uint32_t> rowBase(T + 1, 0);
-    auto sweep = [&](auto fn) {
-      std::vector<std::thread> th;
-      for (unsigned t = 0; t < T; ++t) th.emplace_back([&, t] { fn(t, std::min(nKeys, t * per), std::min(nKeys, (t + 1) * per)); });
-      for (auto &x : th) x.join();
-    };
-    sweep([&](unsigned t, size_t lo, size_t hi) {
-      uint32_t rows = 0;
-      for (size_t code = lo; code < hi; ++code) {
-        const uint32_t ln = kStart[code + 1] - kStart[code];
-        if (!ln) continue;
-        has[code >> 5] |= 1u << (code & 31);  // the ranges are multiples of 32 codes: no word is shared
-        const uint32_t rcode = t1k_code_revcomp((uint32_t)code, k);
-        const size_t pcode = std::min<uint32_t>((uint32_t)code, rcode) & (nPre - 1);
-        __atomic_fetch_or(&hasPre[pcode >> 5], 1u << (pcode & 31), __ATOMIC_RELAXED);
-        if (ln > T1K_DIR_MINLEN) ++rows;
-        const T1kPosting *pl = &post[kStart[code]];
-        for (uint32_t i = 1; i < ln; ++i)
-          if (pl[i].allele == pl[i - 1].allele) { multi[code >> 5] |= 1u << (code & 31); break; }
-      }
-      rowBase[t + 1] = rows;
-    });
-    for (unsigned t = 0; t < T; ++t) rowBase[t + 1] += rowBase[t];
-    std::vector<uint32_t> dir((size_t)std::max<uint32_t>(rowBase[T], 1) * stride, 0);
-    sweep([&](unsigned t, size_t lo, size_t hi) {
-      uint32_t row = rowBase[t];
-      for (size_t code = lo; code < hi; ++code) {
-        const uint32_t st = kStart[code], ln = kStart[code + 1] - st;
-        if (ln <= T1K_DIR_MINLEN) { dirIdx[code] = T1K_NO_DIR; continue; }
-        dirIdx[code] = row;
-        uint32_t *d = &dir[(size_t)row * stride];
-        uint32_t p = 0;
-        for (uint32_t cidx = 0; cidx < stride; ++cidx) {
-          const uint32_t bound = cidx * T1K_SEED_CHUNK;
-          while (p < ln && post[st + p].allele < bound) ++p;
-          d[cidx] = p;
-        }
-        ++row;
-      }
-    });
-    r.kDirStride = stride;
-    lap("bitmap + directory sweeps");
-    if ((rc = uploadVec(ctx, has, (const void **)&r.kHas))) return rc;
-    if ((rc = uploadVec(ctx, hasPre, (const void **)&r.kHasPre))) return rc;
-    if ((rc = uploadVec(ctx, multi, (const void **)&r.kMulti))) return rc;
-    if ((rc = uploadVec(ctx, dir, (const void **)&r.kDir))) return rc;
-    T1kDevBuf b;
-    if ((rc = t1k_ensure(ctx, b, nKeys * sizeof(uint32_t)))) return rc;
-    T1K_HIP(ctx, hipMemcpyAsync(b.p, dirIdx.get(), nKeys * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-    T1K_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    ctx->refBufs.push_back(b);
-    r.kDirIdx = (const uint32_t *)b.p;
-  }
-  lap("bitmap + directory uploads");
-  if (post.empty()) post.push_back(T1kPosting{0, 0});
-  if ((rc = uploadVec(ctx, post, (const void **)&r.kPost))) return rc;
-  {
-    std::vector<uint32_t> postAllele(post.size());
-    for (size_t i = 0; i < post.size(); ++i) postAllele[i] = post[i].allele;
-    if ((rc = uploadVec(ctx, postAllele, (const void **)&r.kPostAllele))) return rc;
-  }
-  T1kDevBuf cov;
-  r.covStride = total + 2;
-  if ((rc = t1k_ensure(ctx, cov, 2 * r.covStride * sizeof(int32_t)))) return rc;
-  T1K_HIP(ctx, hipMemsetAsync(cov.p, 0, 2 * r.covStride * sizeof(int32_t), ctx->stream));
-  ctx->refBufs.push_back(cov);
-  r.covDiff = (int32_t *)cov.p;
-  ctx->ref = r;
-  T1K_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  lap("postings + coverage arrays");
-  return T1K_OK;
-}
-
 int t1k_missing_coverage(t1k_ctx *ctx, int32_t *missing) {
   if (!ctx || !ctx->ref.covDiff || !missing) return t1k_fail(ctx, T1K_ERR_STATE, "no reference");
   T1K_HIP(ctx, hipSetDevice(ctx->device));

@@ -37,3 +37,24 @@ int t1k_exclusive_sum64(t1k_ctx *ctx, const uint32_t *in, unsigned long long *ou
   T1K_HIP(ctx, rocprim::exclusive_scan(ctx->bSortTmp.p, bytes, in, out, 0ull, (size_t)n, rocprim::plus<unsigned long long>(), ctx->stream));
   return T1K_OK;
 }
+
+int t1k_inclusive_sum_n(t1k_ctx *ctx, const uint32_t *in, uint32_t *out, uint64_t n) {
+  if (!n) return T1K_OK;
+  size_t bytes = 0;
+  T1K_HIP(ctx, rocprim::inclusive_scan(nullptr, bytes, in, out, (size_t)n, rocprim::plus<uint32_t>(), ctx->stream));
+  int rc = t1k_ensure(ctx, ctx->bSortTmp, bytes + 256);
+  if (rc) return rc;
+  T1K_HIP(ctx, rocprim::inclusive_scan(ctx->bSortTmp.p, bytes, in, out, (size_t)n, rocprim::plus<uint32_t>(), ctx->stream));
+  return T1K_OK;
+}
+
+// in == out is allowed (every tile is read before it is written)
+int t1k_exclusive_sum32(t1k_ctx *ctx, const uint32_t *in, uint32_t *out, uint64_t n) {
+  if (!n) return T1K_OK;
+  size_t bytes = 0;
+  T1K_HIP(ctx, rocprim::exclusive_scan(nullptr, bytes, in, out, 0u, (size_t)n, rocprim::plus<uint32_t>(), ctx->stream));
+  int rc = t1k_ensure(ctx, ctx->bSortTmp, bytes + 256);
+  if (rc) return rc;
+  T1K_HIP(ctx, rocprim::exclusive_scan(ctx->bSortTmp.p, bytes, in, out, 0u, (size_t)n, rocprim::plus<uint32_t>(), ctx->stream));
+  return T1K_OK;
+}
