@@ -500,6 +500,12 @@ extern "C" int t1k_extractor_main(int argc, char **argv) {
   fclose(fp1);
   if (fp2) fclose(fp2);
   if (fpBc) fclose(fpBc);
+  if (rc != 0) {
+    // a failed run (e.g. a read longer than this build's max_read_len) must not leave truncated candidate files behind for the next stage
+    remove((prefix + (hasMate ? "_1.fq" : ".fq")).c_str());
+    if (hasMate) remove((prefix + "_2.fq").c_str());
+    if (hasBarcode) remove((prefix + "_bc.fa").c_str());
+  }
   t1k_ctx_destroy(ctx);
   if (rc) return rc;
   if (dbg) fprintf(stderr, "[t1k] extractor: k=%d hitLenRequired=%d fragments=%llu kept=%llu\n", kmerLength, hitLenRequired, (unsigned long long)nFragments, (unsigned long long)nGood);

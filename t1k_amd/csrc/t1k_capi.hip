@@ -1,6 +1,9 @@
 // t1k_amd/csrc/t1k_capi.hip -- C ABI (include/t1k_gpu.h), device stage layer: context, reference upload + index build,
 // read upload, the AssignRead batch pipeline, downloads.  Kernels live in t1k_assign.hip / t1k_pair.hip / t1k_em.hip.
 #include <sys/mman.h>
+#include <map>
+#include <mutex>
+#include <unordered_map>
 #include <algorithm>
 #include <memory>
 #include <thread>
@@ -10,6 +13,73 @@
 #include <cstdlib>
 #include "t1k_dev.h"
 #include "t1k_launch.h"
+
+// ------------------------------------------------------------------------------------------------------------------
+// Device memory of the library goes through a process-wide pool: a freed block is kept and handed out again for a request of
+// similar size.  Fresh VRAM is zeroed by the driver at ~35 ms per GB (and memory a process gave back is zeroed again for its next
+// owner), so a process that runs job after job -- a service, the benchmark's steps -- would otherwise pay seconds per job for
+// memory it had a moment ago.  A one-job process (the executables) sees no difference.  T1K_POOL_GB bounds what is kept (default 192).
+// ------------------------------------------------------------------------------------------------------------------
+namespace {
+struct DevPool {
+  std::mutex m;
+  std::map<int, std::multimap<size_t, void *>> freeBlocks;  // per device, by size
+  std::unordered_map<void *, std::pair<size_t, int>> live;   // block -> (size, device)
+  size_t pooled = 0;
+};
+DevPool &devPool() { static DevPool *p = new DevPool(); return *p; }  // never destroyed: outlives every static destructor that frees through it
+}  // namespace
+
+hipError_t t1k_dev_malloc(void **out, size_t bytes) {
+  DevPool &P = devPool();
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (bytes == 0) bytes = 16;
+  {
+    std::lock_guard<std::mutex> g(P.m);
+    auto &fb = P.freeBlocks[dev];
+    auto it = fb.lower_bound(bytes);
+    if (it != fb.end() && it->first <= bytes + bytes / 2 + (64u << 20)) {
+      *out = it->second;
+      P.live[*out] = {it->first, dev};
+      P.pooled -= it->first;
+      fb.erase(it);
+      return hipSuccess;
+    }
+  }
+  hipError_t e = hipMalloc(out, bytes);
+  if (e != hipSuccess) {  // out of memory: give the pool back to the driver and try once more
+    (void)hipGetLastError();
+    std::vector<void *> drop;
+    {
+      std::lock_guard<std::mutex> g(P.m);
+      for (auto &kv : P.freeBlocks[dev]) drop.push_back(kv.second);
+      for (auto &kv : P.freeBlocks[dev]) P.pooled -= kv.first;
+      P.freeBlocks[dev].clear();
+    }
+    for (void *q : drop) (void)hipFree(q);
+    e = hipMalloc(out, bytes);
+  }
+  if (e == hipSuccess) { std::lock_guard<std::mutex> g(P.m); P.live[*out] = {bytes, dev}; }
+  return e;
+}
+
+hipError_t t1k_dev_free(void *p) {
+  if (!p) return hipSuccess;
+  DevPool &P = devPool();
+  static const size_t limit = [] { const char *e = getenv("T1K_POOL_GB"); return (size_t)(e ? atof(e) : 192.0) << 30; }();
+  {
+    std::lock_guard<std::mutex> g(P.m);
+    auto it = P.live.find(p);
+    if (it != P.live.end()) {
+      const size_t bytes = it->second.first;
+      const int dev = it->second.second;
+      P.live.erase(it);
+      if (P.pooled + bytes <= limit) { P.freeBlocks[dev].emplace(bytes, p); P.pooled += bytes; return hipSuccess; }
+    }
+  }
+  return hipFree(p);
+}
 
 int t1k_fail(t1k_ctx *ctx, int code, const std::string &msg) {
   if (ctx) ctx->err = msg;
@@ -22,11 +92,11 @@ int t1k_ensure(t1k_ctx *ctx, T1kDevBuf &b, size_t bytes) {
   // a buffer that has to grow grows by at least half (the sizes of several arenas follow the data of each range and creep up: every
   // reallocation is fresh VRAM, which the driver zeroes at ~35 ms per GB)
   size_t want = std::max(bytes + bytes / 8, b.p ? b.bytes + b.bytes / 2 : (size_t)0) + 256;
-  if (b.p) { (void)hipFree(b.p); b.p = nullptr; b.bytes = 0; }
+  if (b.p) { (void)t1k_dev_free(b.p); b.p = nullptr; b.bytes = 0; }
   const auto t0 = std::chrono::steady_clock::now();
-  hipError_t e = hipMalloc(&b.p, want);
+  hipError_t e = t1k_dev_malloc(&b.p, want);
   if (ctx) { ctx->msAlloc += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); ctx->bytesAlloc += want; }
-  if (e != hipSuccess) { b.p = nullptr; return t1k_fail(ctx, T1K_ERR_DEVICE, std::string("hipMalloc(") + std::to_string(want) + "): " + hipGetErrorString(e)); }
+  if (e != hipSuccess) { b.p = nullptr; return t1k_fail(ctx, T1K_ERR_DEVICE, std::string("t1k_dev_malloc(") + std::to_string(want) + "): " + hipGetErrorString(e)); }
   b.bytes = want;
   return 0;
 }
@@ -56,7 +126,7 @@ void t1k_params_default(t1k_params *p) {
   p->ref_seq_similarity = 0.8;
   p->relax_intron_align = 0;
   p->max_assign_cnt = 2000;
-  p->max_read_len = 320;
+  p->max_read_len = T1K_MAX_READ_LEN;
   p->workgroups = 2048;
   p->n_base_code = 3;
   p->store_chunk_mb = 1536;
@@ -95,7 +165,7 @@ int t1k_ctx_create(int device, const t1k_params *params, t1k_ctx **out) {
   if (ctx->prm.ovl_cap <= 0) ctx->prm.ovl_cap = d.ovl_cap;
   if (ctx->prm.row_cap <= 0) ctx->prm.row_cap = d.row_cap;
   if (ctx->prm.store_chunk_mb <= 0) ctx->prm.store_chunk_mb = d.store_chunk_mb;
-  if (ctx->prm.kmer_length > 15 || ctx->prm.max_read_len > 320) { delete ctx; return T1K_ERR_ARG; }  // the hit-offset bitmask of the chain kernels spans 320 positions
+  if (ctx->prm.kmer_length > 15 || ctx->prm.max_read_len > T1K_MAX_READ_LEN) { delete ctx; return T1K_ERR_ARG; }  // the hit-offset bitmask of the chain kernels spans 320 positions
   if (hipStreamCreate(&ctx->stream) != hipSuccess) { delete ctx; return T1K_ERR_DEVICE; }
   for (auto &e : ctx->ev) if (hipEventCreate(&e) != hipSuccess) { delete ctx; return T1K_ERR_DEVICE; }
   *out = ctx;
@@ -103,7 +173,7 @@ int t1k_ctx_create(int device, const t1k_params *params, t1k_ctx **out) {
 }
 
 static void freeBuf(T1kDevBuf &b) {
-  if (b.p) (void)hipFree(b.p);
+  if (b.p) (void)t1k_dev_free(b.p);
   b.p = nullptr; b.bytes = 0;
 }
 
@@ -488,9 +558,9 @@ static int assignOnce(t1k_ctx *ctx, uint64_t first, uint32_t count) {
       T1kDevBuf &ch = chunks[ctx->storeChunk[sl]];
       if (ch.p && ctx->storeUsed[sl] + ctx->wOvl <= ch.bytes / sizeof(T1kOvl)) break;   // fits behind what the chunk already holds
       if (ch.p && ctx->storeUsed[sl] > 0) { ++ctx->storeChunk[sl]; ctx->storeUsed[sl] = 0; continue; }
-      if (ch.p) { (void)hipFree(ch.p); ch.p = nullptr; ch.bytes = 0; }  // an empty chunk that is too small for this range
+      if (ch.p) { (void)t1k_dev_free(ch.p); ch.p = nullptr; ch.bytes = 0; }  // an empty chunk that is too small for this range
       const auto t0 = std::chrono::steady_clock::now();
-      hipError_t e = hipMalloc(&ch.p, chunkEntries * sizeof(T1kOvl));
+      hipError_t e = t1k_dev_malloc(&ch.p, chunkEntries * sizeof(T1kOvl));
       ctx->msAlloc += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); ctx->bytesAlloc += chunkEntries * sizeof(T1kOvl);
       if (e != hipSuccess) { ch.p = nullptr; return t1k_fail(ctx, T1K_ERR_DEVICE, std::string("overlap store: hipMalloc of another ") + std::to_string(chunkEntries * sizeof(T1kOvl) >> 20) + " MB chunk failed (" + hipGetErrorString(e) + "); fewer fragments per window (T1K_WINDOW) need less"); }
       ch.bytes = chunkEntries * sizeof(T1kOvl);

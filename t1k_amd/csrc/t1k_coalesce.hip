@@ -138,7 +138,7 @@ int t1k_rowset_chunk(t1k_rowset *rs, t1k_ctx *ctx, size_t *chunk, t1k_row_entry 
   if (rs->cur >= rs->chunks.size()) rs->chunks.resize(rs->cur + 1);
   T1kDevBuf &b = rs->chunks[rs->cur];
   if (!b.p) {
-    hipError_t e = hipMalloc(&b.p, rs->chunkEntries * sizeof(t1k_row_entry));
+    hipError_t e = t1k_dev_malloc(&b.p, rs->chunkEntries * sizeof(t1k_row_entry));
     if (e != hipSuccess) { b.p = nullptr; return t1k_fail(ctx, T1K_ERR_DEVICE, std::string("rowset: hipMalloc of a row chunk failed: ") + hipGetErrorString(e)); }
     b.bytes = rs->chunkEntries * sizeof(t1k_row_entry);
   }
@@ -184,8 +184,8 @@ void t1k_rowset_destroy(t1k_rowset *rs) {
   if (!rs) return;
   (void)hipSetDevice(rs->device);
   T1kDevBuf *all[] = {&rs->bFrag, &rs->bCursors, &rs->bWhitelist, &rs->bWork, &rs->bGroupPtr, &rs->bGroupEnt, &rs->bGroupFirst, &rs->bSend, &rs->bRecv, &rs->bFrag2, &rs->bAll};
-  for (auto *b : all) if (b->p) (void)hipFree(b->p);
-  for (auto &b : rs->chunks) if (b.p) (void)hipFree(b.p);
+  for (auto *b : all) if (b->p) (void)t1k_dev_free(b->p);
+  for (auto &b : rs->chunks) if (b.p) (void)t1k_dev_free(b.p);
   delete rs;
 }
 
@@ -306,8 +306,8 @@ int t1k_rowset_rows_download(t1k_rowset *rs, uint64_t first, uint32_t count, uin
   if (!rows || !tot) return T1K_OK;
   if (cap < tot) return rsFail(rs, T1K_ERR_ARG, "t1k_rowset_rows_download: row buffer too small");
   void *dOff = nullptr, *dOut = nullptr;
-  RS_HIP(hipMalloc(&dOff, (size_t)count * 8));
-  if (hipMalloc(&dOut, tot * sizeof(t1k_row_entry)) != hipSuccess) { (void)hipFree(dOff); return rsFail(rs, T1K_ERR_DEVICE, "t1k_rowset_rows_download: out of device memory"); }
+  RS_HIP(t1k_dev_malloc(&dOff, (size_t)count * 8));
+  if (t1k_dev_malloc(&dOut, tot * sizeof(t1k_row_entry)) != hipSuccess) { (void)t1k_dev_free(dOff); return rsFail(rs, T1K_ERR_DEVICE, "t1k_rowset_rows_download: out of device memory"); }
   hipStream_t st = rs->owner->stream;
   hipError_t e = hipMemcpyAsync(dOff, off.data(), (size_t)count * 8, hipMemcpyHostToDevice, st);
   if (e == hipSuccess) {
@@ -315,7 +315,7 @@ int t1k_rowset_rows_download(t1k_rowset *rs, uint64_t first, uint32_t count, uin
     e = hipMemcpyAsync(rows, dOut, tot * sizeof(t1k_row_entry), hipMemcpyDeviceToHost, st);
   }
   if (e == hipSuccess) e = hipStreamSynchronize(st);
-  (void)hipFree(dOff); (void)hipFree(dOut);
+  (void)t1k_dev_free(dOff); (void)t1k_dev_free(dOut);
   if (e != hipSuccess) return rsFail(rs, T1K_ERR_DEVICE, hipGetErrorString(e));
   return T1K_OK;
 }
@@ -445,8 +445,8 @@ int t1k_rowset_exchange(t1k_rowset *rs, t1k_comm *comm, uint64_t fragBase) {
   if ((rc = t1k_comm_alltoallv(comm, sMeta, sOffM.data(), rMeta, rOffM.data()))) return cfail(rc);
   if ((rc = t1k_comm_alltoallv(comm, sRows, sOffE.data(), rRows, rOffE.data()))) return cfail(rc);
   // the rows this rank gave away are dead: the chunks and the send buffer go back
-  for (auto &b : rs->chunks) if (b.p) { (void)hipFree(b.p); b.p = nullptr; b.bytes = 0; }
-  (void)hipFree(rs->bSend.p); rs->bSend.p = nullptr; rs->bSend.bytes = 0;
+  for (auto &b : rs->chunks) if (b.p) { (void)t1k_dev_free(b.p); b.p = nullptr; b.bytes = 0; }
+  (void)t1k_dev_free(rs->bSend.p); rs->bSend.p = nullptr; rs->bSend.bytes = 0;
   // the received fragments, in (source rank, source order) = global fragment order
   const uint64_t R = std::max<uint64_t>(recvF, 1);
   if ((rc = t1k_ensure(ctx, rs->bFrag2, R * (8 * 3 + 4 + 4) + 256))) return fail(rc);
@@ -495,7 +495,7 @@ int t1k_rowset_groups_gather(t1k_rowset *rs, t1k_comm *comm, uint64_t *totalGrou
   rc = t1k_comm_allgatherv(comm, tmp.p, bG.data(), dG.data(), allSize);
   if (rc == T1K_OK) rc = t1k_comm_allgatherv(comm, rs->bGroupFirst.p, bG.data(), dG.data(), allFirst);
   if (rc == T1K_OK) rc = t1k_comm_allgatherv(comm, rs->bGroupEnt.p, bE.data(), dE.data(), allEnt);
-  (void)hipFree(tmp.p);
+  (void)t1k_dev_free(tmp.p);
   if (rc != T1K_OK) { rs->err = t1k_comm_last_error(comm); return rc; }
   rs->allGroups = G; rs->allEntries = E;
   if (totalGroups) *totalGroups = G;

@@ -193,8 +193,8 @@ int t1k_comm_init(t1k_ctx *ctx, int nRanks, int rank, const void *id128, t1k_com
 // same device
 int t1k_comm_bind(t1k_comm *c, t1k_ctx *ctx) {
   if (!c || !ctx || (c->ctx && c->ctx->device != ctx->device)) return T1K_ERR_ARG;
-  if (c->tmp.p) { (void)hipFree(c->tmp.p); c->tmp.p = nullptr; c->tmp.bytes = 0; }
-  if (c->ptrs.p) { (void)hipFree(c->ptrs.p); c->ptrs.p = nullptr; c->ptrs.bytes = 0; }
+  if (c->tmp.p) { (void)t1k_dev_free(c->tmp.p); c->tmp.p = nullptr; c->tmp.bytes = 0; }
+  if (c->ptrs.p) { (void)t1k_dev_free(c->ptrs.p); c->ptrs.p = nullptr; c->ptrs.bytes = 0; }
   c->ctx = ctx;
   return T1K_OK;
 }
@@ -203,8 +203,8 @@ void t1k_comm_destroy(t1k_comm *c) {
   if (!c) return;
   if (c->nccl) (void)rccl()->CommDestroy(c->nccl);
   if (c->ctx) (void)hipSetDevice(c->ctx->device);
-  if (c->tmp.p) (void)hipFree(c->tmp.p);
-  if (c->ptrs.p) (void)hipFree(c->ptrs.p);
+  if (c->tmp.p) (void)t1k_dev_free(c->tmp.p);
+  if (c->ptrs.p) (void)t1k_dev_free(c->ptrs.p);
   delete c;
 }
 const char *t1k_comm_last_error(const t1k_comm *c) { return c ? c->err.c_str() : "no communicator"; }
@@ -347,14 +347,14 @@ int t1k_comm_allgatherv_host(t1k_comm *c, void *host, const uint64_t *bytes, con
   CM_HIP(hipSetDevice(ctx->device));
   T1kDevBuf all, mine;
   int rc;
-  if ((rc = t1k_ensure(ctx, all, total + 16)) || (rc = t1k_ensure(ctx, mine, bytes[c->rank] + 16))) { if (all.p) (void)hipFree(all.p); return commFail(c, rc, ctx->err); }
+  if ((rc = t1k_ensure(ctx, all, total + 16)) || (rc = t1k_ensure(ctx, mine, bytes[c->rank] + 16))) { if (all.p) (void)t1k_dev_free(all.p); return commFail(c, rc, ctx->err); }
   hipError_t e = bytes[c->rank] ? hipMemcpyAsync(mine.p, (const char *)host + displ[c->rank], bytes[c->rank], hipMemcpyHostToDevice, ctx->stream) : hipSuccess;
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
   if (e == hipSuccess) {
     rc = t1k_comm_allgatherv(c, mine.p, bytes, displ, all.p);
     if (rc == T1K_OK) e = hipMemcpy(host, all.p, total, hipMemcpyDeviceToHost);
   }
-  (void)hipFree(all.p); (void)hipFree(mine.p);
+  (void)t1k_dev_free(all.p); (void)t1k_dev_free(mine.p);
   if (e != hipSuccess) return commFail(c, T1K_ERR_DEVICE, hipGetErrorString(e));
   return rc;
 }

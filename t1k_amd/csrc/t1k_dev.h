@@ -15,6 +15,9 @@
 #include <vector>
 #include "../../include/t1k_gpu.h"
 
+// Longest read the kernels handle: the hit-offset masks of the chain kernels span 320 positions (10 words), the alignment memo
+// keys hold 9-bit lengths, k_extract_screen gives a lane five consecutive k-mers and k_extract a thread three positions of both strands.
+#define T1K_MAX_READ_LEN 320
 #define T1K_EVEN 0x5555555555555555ull
 #define T1K_NEG_BIG (-(1 << 28))
 
@@ -696,6 +699,9 @@ struct t1k_ctx {
   t1k_stats stats{};
 };
 
+// device memory through the library's process-wide pool (t1k_capi.hip)
+hipError_t t1k_dev_malloc(void **out, size_t bytes);
+hipError_t t1k_dev_free(void *p);
 int t1k_fail(t1k_ctx *ctx, int code, const std::string &msg);
 int t1k_ensure(t1k_ctx *ctx, T1kDevBuf &b, size_t bytes);
 #define T1K_HIP(ctx, call)                                                                              \

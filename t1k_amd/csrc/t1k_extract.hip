@@ -23,6 +23,11 @@
 #include <algorithm>
 #include "t1k_dev.h"
 #include "t1k_launch.h"
+
+static_assert(T1K_MAX_READ_LEN <= 5 * 64, "k_extract_screen: a lane takes five consecutive k-mer positions of a 64-lane wavefront");
+static_assert(2 * T1K_MAX_READ_LEN <= 3 * 256, "k_extract: a thread takes three k-mer positions (both strands) of a 256-thread workgroup");
+static_assert(T1K_MAX_READ_LEN <= 2 * 256, "k_extract: a thread takes two used lists");
+
 #include "t1k_group.h"
 
 #define XWG 256
