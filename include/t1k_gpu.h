@@ -30,7 +30,9 @@ typedef enum {
   T1K_ERR_CAPACITY = -3,  /* a device arena overflowed; raise the matching t1k_params cap and retry */
   T1K_ERR_IO = -4,        /* file could not be opened / parsed */
   T1K_ERR_STATE = -5,     /* call made in the wrong order */
-  T1K_ERR_INTERNAL = -6   /* an internal invariant did not hold (a bug; results of the call are void) */
+  T1K_ERR_INTERNAL = -6,  /* an internal invariant did not hold (a bug; results of the call are void) */
+  T1K_ERR_COMMITTED = -7  /* a capacity limit was hit after part of the range's per-base coverage had been added: do not retry the range on this
+                             context (its coverage is void); run again with smaller ranges */
 } t1k_status;
 
 typedef struct t1k_ctx t1k_ctx;

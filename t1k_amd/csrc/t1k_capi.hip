@@ -429,6 +429,12 @@ static int fetchCounters(t1k_ctx *ctx, unsigned long long *h) { return t1k_fetch
 // stages that ran: remember it, t1k_assign_range sizes its working capacities from it and runs the range again.
 static int capacityError(t1k_ctx *ctx, unsigned long long flags) {
   ctx->lastCapFlags = flags;
+  if (ctx->covCommitted) {
+    // k_fullalign has already added this range's ungapped alignments to the coverage arrays: running the range again (larger arenas,
+    // or split in two) would count them twice.  The context's coverage is void; the caller must not retry on it.
+    return t1k_fail(ctx, T1K_ERR_COMMITTED, "an alignment queue or sort buffer overflowed after part of the range's coverage was added (flags " + std::to_string(flags) +
+                                               "): rerun with smaller ranges (T1K_BATCH) -- this context's coverage is no longer valid");
+  }
   if (ctx->hRaw.size() >= T1K_COUNTER_WORDS) {
     auto maxSeg = [&](int arena) {
       unsigned long long m = 0;
@@ -519,6 +525,7 @@ int t1k_assign_range(t1k_ctx *ctx, uint64_t first, uint32_t count) {
 
 static int assignOnce(t1k_ctx *ctx, uint64_t first, uint32_t count) {
   const uint32_t n = count;
+  ctx->covCommitted = false;
   T1kReadsDev rd = ctx->reads;  // view of the sub-range; read-end ids inside the batch are relative to `first`
   rd.nReadEnds = count;
   rd.bases += first * 2 * rd.S; rd.nmask += first * 2 * rd.S; rd.len += first; rd.weight += first;
@@ -663,6 +670,7 @@ static int assignOnce(t1k_ctx *ctx, uint64_t first, uint32_t count) {
   f.eqKeyStr = (unsigned long long *)(queueMem + queueBytes); f.bandKeyStr = f.eqKeyStr + qStr;
   unsigned long long *kDense = f.bandKeyStr + qStr, *kSorted = kDense + qDense;
   uint32_t *vDense = (uint32_t *)(kSorted + qDense);
+  ctx->covCommitted = true;  // from here on the range's coverage is in the context's arrays
   t1k_launch_fullalign(ctx, f);
   T1K_HIP(ctx, hipEventRecord(ctx->ev[7], ctx->stream));
   if ((rc = fetchCounters(ctx, hc))) return rc;

@@ -671,6 +671,7 @@ struct t1k_ctx {
   uint64_t wGroup = 0, wList = 0, wRare = 0, wCand = 0, wOvl = 0, needGroup = 0, needList = 0, needRare = 0, needCand = 0, needOvl = 0;
   unsigned long long lastCapFlags = 0;
   bool scaledOnce = false;
+  bool covCommitted = false;     // the running range has started adding to the coverage arrays (no retry after that)
   double msAlloc = 0;            // wall time spent in hipMalloc (fresh VRAM is zeroed by the driver: ~35 ms per GB)
   uint64_t bytesAlloc = 0;
   T1kDevBuf bCand, bExt, bCandStart, bCandCount, bOvlStart, bOvlCount, bCounters, bSlowQueue, bSlowScratch, bSortScratch, bEqTrace, bSortTmp, bSlowKeys, bJobSort;
