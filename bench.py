@@ -230,7 +230,7 @@ def main():
                                      "write_outputs": st["ms_write"]}},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic,
-                         "launches_per_step": launches, "pipelines_per_gpu": int(os.environ.get("T1K_PIPELINES", "2")), "algorithmic_bytes_per_launch": kb[dom] / launches, "avg_launch_ms": ms[dom] / launches,
+                         "launches_per_step": launches, "pipelines_per_gpu": int(os.environ.get("T1K_PIPELINES", "3")), "algorithmic_bytes_per_launch": kb[dom] / launches, "avg_launch_ms": ms[dom] / launches,
                          "all_kernels_ms_per_step": ms,
                          "all_kernels_algorithmic_GBs": {k: (kb[k] / (ms[k] * 1e-3) / 1e9 if ms[k] > 0 else 0.0) for k in ms},
                          "pipeline_algorithmic_bytes_per_step": sum(kb.values()),

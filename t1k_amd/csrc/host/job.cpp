@@ -115,11 +115,11 @@ static int jobCreate(const t1k_job_params *p, const char *refFasta, const std::s
   rc = t1k_ref_upload(job->ctx, blob.data(), off.data(), ex.data(), (uint32_t)R.seqs.size());
   if (rc != T1K_OK) return jobFail(job, rc, t1k_last_error(job->ctx));
   // Most kernels of the path are latency-bound; a second independent pipeline (context, stream, arenas) on the same GPU lets the
-  // hardware overlap two batches and hides the host's share of a batch (counter fetches, launches).  Measured on the 1 M-pair HLA-like
+  // hardware overlap batches and hides the host's share of a batch (counter fetches, launches).  Measured on the 1 M-pair HLA-like
   // workload (device loop, arenas warm): 1 pipeline 840 ms, 2: 723 ms, 4: 678 ms -- and every pipeline's arenas are fresh VRAM that
-  // costs ~35 ms per GB, so two is the default.  T1K_PIPELINES overrides.
+  // costs ~35 ms per GB when the driver has to zero it.  Three is the default (10 M-pair device loop: 6.4 / 6.0 / 5.9 s with 2 / 3 / 4).  T1K_PIPELINES overrides.
   const char *pl = getenv("T1K_PIPELINES");
-  const int nPipe = pl ? std::max(1, std::min(8, atoi(pl))) : 2;
+  const int nPipe = pl ? std::max(1, std::min(8, atoi(pl))) : 3;
   for (int i = 1; i < nPipe; ++i) {
     t1k_ctx *c = nullptr;
     rc = t1k_ctx_create(job->prm.device, &job->prm.dev, &c);

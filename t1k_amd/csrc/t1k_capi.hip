@@ -47,7 +47,10 @@ hipError_t t1k_dev_malloc(void **out, size_t bytes) {
       return hipSuccess;
     }
   }
+  const auto tA = std::chrono::steady_clock::now();
   hipError_t e = hipMalloc(out, bytes);
+  if (getenv("T1K_DEBUG_ALLOC") && bytes >= (64u << 20))
+    fprintf(stderr, "[t1k alloc] hipMalloc %.2f GB: %.1f ms\n", bytes / 1073741824.0, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tA).count());
   if (e != hipSuccess) {  // out of memory: give the pool back to the driver and try once more
     (void)hipGetLastError();
     std::vector<void *> drop;

@@ -95,14 +95,22 @@ __global__ __launch_bounds__(256) void k_co_reduce(const uint32_t *tileGroup, co
   const t1k_row_entry first = ((const t1k_row_entry *)rowPtr[idx[j0]])[q];
   T1kGroupEnt acc{first.allele_idx, first.start, first.end, first.weight, first.adjust_weight};
   uint32_t j = j0 + 1;
-  // A group's chain is sequential (float sums and the `end` rule in fragment order) and the largest groups hold 10^5 fragments: keep
-  // sixteen independent row loads in flight per lane (the row addresses are uniform over the wavefront), fold them in order.
-  for (; j + 16 <= j1; j += 16) {
-    t1k_row_entry e[16];
+  // A group's chain is sequential (float sums and the `end` rule in fragment order) and the largest groups hold 10^6 fragments: keep
+  // thirty-two independent row loads in flight per lane (the row addresses are uniform over the wavefront), fold them in order.
+  for (; j + 32 <= j1; j += 32) {
+    int4 e[32];  // start, end, weight, adjust_weight: bytes 4..11 and 12..15, 20..23 of the entry
 #pragma unroll
-    for (int u = 0; u < 16; ++u) e[u] = ((const t1k_row_entry *)rowPtr[idx[j + u]])[q];
+    for (int u = 0; u < 32; ++u) {
+      const t1k_row_entry *r = (const t1k_row_entry *)rowPtr[idx[j + u]] + q;
+      e[u] = int4{r->start, r->end, __float_as_int(r->weight), __float_as_int(r->adjust_weight)};
+    }
 #pragma unroll
-    for (int u = 0; u < 16; ++u) foldEntry(acc, e[u]);
+    for (int u = 0; u < 32; ++u) {
+      if (e[u].x < acc.start) acc.start = e[u].x;
+      if (e[u].y < acc.end) acc.end = e[u].x;  // sic (Genotyper.hpp:893-894)
+      acc.weight += __int_as_float(e[u].z);
+      acc.adjustWeight += __int_as_float(e[u].w);
+    }
   }
   for (; j + 4 <= j1; j += 4) {
     const t1k_row_entry *r0 = (const t1k_row_entry *)rowPtr[idx[j]], *r1 = (const t1k_row_entry *)rowPtr[idx[j + 1]],
