@@ -106,16 +106,25 @@ int t1k_ensure(t1k_ctx *ctx, T1kDevBuf &b, size_t bytes) {
 
 static double nowMs() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
-// listPtr[i] = device address of read-end i's first overlap record, listCount[i] = its length (after k_truncate)
-__global__ void k_publish_lists(unsigned long long *listPtr, uint32_t *listCount, const T1kOvl *base, const uint32_t *ovlStart, const uint32_t *ovlCount, uint32_t n) {
+// listPtr[i] = device address of read-end i's first PACKED overlap record in the store, listCount[i] = its length (after k_truncate)
+__global__ void k_publish_lists(unsigned long long *listPtr, uint32_t *listCount, const T1kOvlP *store, const uint32_t *ovlStart, const uint32_t *ovlCount, uint32_t n) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  listPtr[i] = (unsigned long long)(base + ovlStart[i]);
+  listPtr[i] = (unsigned long long)(store + ovlStart[i]);
   listCount[i] = ovlCount[i];
 }
-static void t1k_launch_publish_lists(t1k_ctx *ctx, unsigned long long *listPtr, uint32_t *listCount, const T1kOvl *base, const uint32_t *ovlStart, const uint32_t *ovlCount,
-                                     uint32_t n) {
-  if (n) hipLaunchKernelGGL(k_publish_lists, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, listPtr, listCount, base, ovlStart, ovlCount, n);
+// the range's working records -> the store's packed form, same index (the gaps k_truncate left are copied along, harmlessly)
+__global__ void k_pack_overlaps(const T1kOvl *work, T1kOvlP *store, uint64_t nOvl, unsigned long long *counters) {
+  const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= nOvl) return;
+  T1kOvlP p;
+  if (!t1k_ovl_pack(work[g], p)) atomicOr(&counters[2], 1024ull);
+  store[g] = p;
+}
+static void t1k_launch_publish_lists(t1k_ctx *ctx, unsigned long long *listPtr, uint32_t *listCount, const T1kOvl *work, T1kOvlP *store, uint64_t nOvl,
+                                     const uint32_t *ovlStart, const uint32_t *ovlCount, uint32_t n, unsigned long long *counters) {
+  if (nOvl) hipLaunchKernelGGL(k_pack_overlaps, dim3((unsigned)((nOvl + 255) / 256)), dim3(256), 0, ctx->stream, work, store, nOvl, counters);
+  if (n) hipLaunchKernelGGL(k_publish_lists, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, listPtr, listCount, store, ovlStart, ovlCount, n);
 }
 
 
@@ -188,7 +197,7 @@ void t1k_ctx_destroy(t1k_ctx *ctx) {
   for (auto &b : ctx->refBufs) freeBuf(b);
   T1kDevBuf *all[] = {&ctx->bReadAscii, &ctx->bReadOffs, &ctx->bReadBases, &ctx->bReadN, &ctx->bReadLen, &ctx->bReadWeight, &ctx->bWgHits, &ctx->bWgGroups,
                       &ctx->bWgStage, &ctx->bWgBig, &ctx->bWgCache, &ctx->bLists, &ctx->bCand, &ctx->bExt, &ctx->bCandStart, &ctx->bCandCount, &ctx->bListPtr, &ctx->bListCount,
-                      &ctx->bDedupScratch, &ctx->bDedupBases, &ctx->bDedupN, &ctx->bDedupLen, &ctx->bDedupWeight, &ctx->bOvlStart, &ctx->bOvlCount, &ctx->bCounters, &ctx->bSlowQueue, &ctx->bSlowScratch, &ctx->bSortScratch, &ctx->bEqTrace, &ctx->bSortTmp, &ctx->bSlowKeys, &ctx->bJobSort, &ctx->bEnd1, &ctx->bEnd2,
+                      &ctx->bOvlWork, &ctx->bDedupScratch, &ctx->bDedupBases, &ctx->bDedupN, &ctx->bDedupLen, &ctx->bDedupWeight, &ctx->bOvlStart, &ctx->bOvlCount, &ctx->bCounters, &ctx->bSlowQueue, &ctx->bSlowScratch, &ctx->bSortScratch, &ctx->bEqTrace, &ctx->bSortTmp, &ctx->bSlowKeys, &ctx->bJobSort, &ctx->bEnd1, &ctx->bEnd2,
                       &ctx->bHasN, &ctx->bRows, &ctx->bRowStart, &ctx->bRowCount, &ctx->bFragAssigned, &ctx->bPairScratch, &ctx->bPairOverflow, &ctx->bPairBig, &ctx->bEmRowPtr, &ctx->bEmEc,
                       &ctx->bEmCount, &ctx->bEmLen, &ctx->bEmX0, &ctx->bEmN, &ctx->bEmContrib, &ctx->bEmColPtr, &ctx->bEmColIdx, &ctx->bExtract};
   for (auto *b : all) freeBuf(*b);
@@ -432,6 +441,8 @@ static int fetchCounters(t1k_ctx *ctx, unsigned long long *h) { return t1k_fetch
 // stages that ran: remember it, t1k_assign_range sizes its working capacities from it and runs the range again.
 static int capacityError(t1k_ctx *ctx, unsigned long long flags) {
   ctx->lastCapFlags = flags;
+  if (flags & 512) return t1k_fail(ctx, T1K_ERR_INTERNAL, "alignment memo entry left pending");
+  if (flags & 1024) return t1k_fail(ctx, T1K_ERR_INTERNAL, "an overlap record does not fit the packed form of the overlap store");
   if (ctx->covCommitted) {
     // k_fullalign has already added this range's ungapped alignments to the coverage arrays: running the range again (larger arenas,
     // or split in two) would count them twice.  The context's coverage is void; the caller must not retry on it.
@@ -450,6 +461,8 @@ static int capacityError(t1k_ctx *ctx, unsigned long long flags) {
     ctx->needGroup = maxSeg(T1K_AR_GROUPS) * T1K_NSTRIPE;
     ctx->needList = lists * T1K_NSTRIPE;
     ctx->needRare = rare * T1K_NSTRIPE;
+    ctx->needJob = std::max(maxSeg(T1K_AR_JOBS), maxSeg(T1K_AR_EXTJOBS)) * T1K_NSTRIPE;
+    ctx->needGenJob = maxSeg(T1K_AR_GENJOBS) * T1K_NSTRIPE;
     ctx->needCand = ctx->hRaw[0];
     ctx->needOvl = ctx->hRaw[1];
   }
@@ -464,6 +477,7 @@ static int capacityError(t1k_ctx *ctx, unsigned long long flags) {
   if (flags & 128) m += " row_cap";
   if (flags & 256) m += " group_cap";
   if (flags & 512) return t1k_fail(ctx, T1K_ERR_INTERNAL, "alignment memo entry left pending");
+  if (flags & 1024) return t1k_fail(ctx, T1K_ERR_INTERNAL, "an overlap record does not fit the packed form of the overlap store");
   return t1k_fail(ctx, T1K_ERR_CAPACITY, m);
 }
 
@@ -493,8 +507,14 @@ int t1k_assign_range(t1k_ctx *ctx, uint64_t first, uint32_t count) {
   ctx->wOvl = clampCap(std::max<uint64_t>(ctx->wOvl, (uint64_t)count * perRe / 3), 2u << 20, ctx->prm.ovl_cap);
   ctx->wList = clampCap(std::max<uint64_t>(ctx->wList, (uint64_t)count * perRe * 7 / 12), 1u << 20, ctx->prm.group_cap);
   ctx->wRare = clampCap(std::max<uint64_t>(ctx->wRare, (uint64_t)count * perRe / 24), 1u << 18, ctx->prm.group_cap);
+  // alignment job lists (memo slots waiting for k_dp_dense): a read-end's memo has 2048 slots, so count * 2048 is the most there can be.
+  // A list that overflows must not be survived by releasing the claim (another lane may already wait on that memo slot): the range
+  // runs again with a list that fits.
+  const int64_t jobLimit = (int64_t)count * 2048 + (1 << 20);
+  ctx->wJob = clampCap(std::max<uint64_t>(ctx->wJob, (uint64_t)count * 512), 1u << 20, std::max<int64_t>(jobLimit, (int64_t)ctx->wJob));
+  ctx->wGenJob = clampCap(std::max<uint64_t>(ctx->wGenJob, (uint64_t)count * 128), 1u << 20, std::max<int64_t>(jobLimit, (int64_t)ctx->wGenJob));
   for (int attempt = 0;; ++attempt) {
-    ctx->lastCapFlags = 0; ctx->needGroup = ctx->needCand = ctx->needOvl = ctx->needList = ctx->needRare = 0;
+    ctx->lastCapFlags = 0; ctx->needGroup = ctx->needCand = ctx->needOvl = ctx->needList = ctx->needRare = ctx->needJob = ctx->needGenJob = 0;
     const int rc = assignOnce(ctx, first, count);
     if (rc != T1K_ERR_CAPACITY || attempt >= 10) return rc;
     bool grew = false;
@@ -517,12 +537,15 @@ int t1k_assign_range(t1k_ctx *ctx, uint64_t first, uint32_t count) {
       }
       grow(ctx->wList, ctx->needList, ctx->prm.group_cap);
       grow(ctx->wRare, ctx->needRare, ctx->prm.group_cap);
+      grow(ctx->wJob, ctx->needJob, jobLimit * 2);
+      grow(ctx->wGenJob, ctx->needGenJob, jobLimit * 2);
     }
     if (ctx->lastCapFlags & 4) grow(ctx->wCand, ctx->needCand, ctx->prm.cand_cap);
     if (ctx->lastCapFlags & 16) grow(ctx->wOvl, ctx->needOvl, ctx->prm.ovl_cap);
     if (!grew || (ctx->lastCapFlags & ~(256ull | 4ull | 16ull))) return rc;  // at the limits (or another arena): the caller splits the range
-    if (getenv("T1K_DEBUG_PHASES")) fprintf(stderr, "[t1k] range of %u read-ends again with capacities: groups %llu lists %llu / %llu candidates %llu overlaps %llu\n", count,
-                                            (unsigned long long)ctx->wGroup, (unsigned long long)ctx->wList, (unsigned long long)ctx->wRare, (unsigned long long)ctx->wCand, (unsigned long long)ctx->wOvl);
+    if (getenv("T1K_DEBUG_PHASES")) fprintf(stderr, "[t1k] range of %u read-ends again with capacities: groups %llu lists %llu / %llu jobs %llu / %llu candidates %llu overlaps %llu\n", count,
+                                            (unsigned long long)ctx->wGroup, (unsigned long long)ctx->wList, (unsigned long long)ctx->wRare, (unsigned long long)ctx->wJob, (unsigned long long)ctx->wGenJob,
+                                            (unsigned long long)ctx->wCand, (unsigned long long)ctx->wOvl);
   }
 }
 
@@ -540,7 +563,7 @@ static int assignOnce(t1k_ctx *ctx, uint64_t first, uint32_t count) {
   const bool longReads = ctx->batchMaxLen > 160;
   const int recStride = t1k_chain_rec_stride(ctx->batchMaxLen);
   const uint64_t groupCap = ctx->wGroup;
-  const uint32_t jobCap = 16u << 20, genCandCap = 16u << 20, genHitCap = 64u << 20, genJobCap = 4u << 20;
+  const uint32_t jobCap = (uint32_t)ctx->wJob, genCandCap = 16u << 20, genHitCap = 64u << 20, genJobCap = (uint32_t)ctx->wGenJob;
   const int bigBlocks = 32;
   if ((rc = t1k_ensure(ctx, ctx->bCounters, (size_t)T1K_COUNTER_WORDS * 8))) return rc;
   if ((rc = t1k_ensure(ctx, ctx->bWgGroups, groupCap * recStride * 4))) return rc;                        // batch group records
@@ -559,24 +582,26 @@ static int assignOnce(t1k_ctx *ctx, uint64_t first, uint32_t count) {
   if ((rc = t1k_ensure(ctx, ctx->bCand, (size_t)ctx->wCand * sizeof(T1kCand)))) return rc;
   if ((rc = t1k_ensure(ctx, ctx->bExt, (size_t)ctx->wCand * sizeof(T1kExt)))) return rc;
   // this range's lists go to the end of the overlap store: the current chunk if the working overlap capacity still fits, else the next one
-  const uint64_t chunkEntries = std::max<uint64_t>(ctx->wOvl, (uint64_t)std::max(1, ctx->prm.store_chunk_mb) * ((1ull << 20) / sizeof(T1kOvl)));
+  const uint64_t chunkEntries = std::max<uint64_t>(ctx->wOvl, (uint64_t)std::max(1, ctx->prm.store_chunk_mb) * ((1ull << 20) / sizeof(T1kOvlP)));
   {
     const int sl = ctx->storeSlot;
     std::vector<T1kDevBuf> &chunks = ctx->storeChunks[sl];
     for (;;) {
       if (ctx->storeChunk[sl] >= chunks.size()) chunks.resize(ctx->storeChunk[sl] + 1);
       T1kDevBuf &ch = chunks[ctx->storeChunk[sl]];
-      if (ch.p && ctx->storeUsed[sl] + ctx->wOvl <= ch.bytes / sizeof(T1kOvl)) break;   // fits behind what the chunk already holds
+      if (ch.p && ctx->storeUsed[sl] + ctx->wOvl <= ch.bytes / sizeof(T1kOvlP)) break;   // fits behind what the chunk already holds
       if (ch.p && ctx->storeUsed[sl] > 0) { ++ctx->storeChunk[sl]; ctx->storeUsed[sl] = 0; continue; }
       if (ch.p) { (void)t1k_dev_free(ch.p); ch.p = nullptr; ch.bytes = 0; }  // an empty chunk that is too small for this range
       const auto t0 = std::chrono::steady_clock::now();
-      hipError_t e = t1k_dev_malloc(&ch.p, chunkEntries * sizeof(T1kOvl));
-      ctx->msAlloc += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); ctx->bytesAlloc += chunkEntries * sizeof(T1kOvl);
-      if (e != hipSuccess) { ch.p = nullptr; return t1k_fail(ctx, T1K_ERR_DEVICE, std::string("overlap store: hipMalloc of another ") + std::to_string(chunkEntries * sizeof(T1kOvl) >> 20) + " MB chunk failed (" + hipGetErrorString(e) + "); fewer fragments per window (T1K_WINDOW) need less"); }
-      ch.bytes = chunkEntries * sizeof(T1kOvl);
+      hipError_t e = t1k_dev_malloc(&ch.p, chunkEntries * sizeof(T1kOvlP));
+      ctx->msAlloc += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); ctx->bytesAlloc += chunkEntries * sizeof(T1kOvlP);
+      if (e != hipSuccess) { ch.p = nullptr; return t1k_fail(ctx, T1K_ERR_DEVICE, std::string("overlap store: hipMalloc of another ") + std::to_string(chunkEntries * sizeof(T1kOvlP) >> 20) + " MB chunk failed (" + hipGetErrorString(e) + "); fewer fragments per window (T1K_WINDOW) need less"); }
+      ch.bytes = chunkEntries * sizeof(T1kOvlP);
     }
-    ctx->ovlBase = (T1kOvl *)chunks[ctx->storeChunk[sl]].p + ctx->storeUsed[sl];
+    ctx->storeBase = (T1kOvlP *)chunks[ctx->storeChunk[sl]].p + ctx->storeUsed[sl];
   }
+  if ((rc = t1k_ensure(ctx, ctx->bOvlWork, (size_t)ctx->wOvl * sizeof(T1kOvl)))) return rc;
+  ctx->ovlBase = (T1kOvl *)ctx->bOvlWork.p;
   if ((rc = t1k_ensure(ctx, ctx->bCandStart, (size_t)n * 4))) return rc;
   if ((rc = t1k_ensure(ctx, ctx->bCandCount, (size_t)n * 4))) return rc;
   if ((rc = t1k_ensure(ctx, ctx->bOvlStart, (size_t)n * 4))) return rc;
@@ -629,7 +654,7 @@ static int assignOnce(t1k_ctx *ctx, uint64_t first, uint32_t count) {
   if ((rc = fetchCounters(ctx, hc))) return rc;
   {
     const T1kArenaCounts ej = t1k_arena_counts(ctx, T1K_AR_EXTJOBS, e.jobSegCap), er = t1k_arena_counts(ctx, T1K_AR_EXTRETRY, e.retrySegCap);
-    if (er.overflow) return capacityError(ctx, 256);
+    if (er.overflow || ej.overflow) return capacityError(ctx, 256);
     t1k_arena_compact(ctx, T1K_AR_EXTJOBS, e.jobStr, e.jobSegCap, a.jobList, ej.maxSeg);
     t1k_arena_compact(ctx, T1K_AR_EXTRETRY, e.retryStr, e.retrySegCap, a.retryList, er.maxSeg);
     t1k_launch_dp_dense(ctx, a, a.jobList, (uint32_t)ej.total);
@@ -728,7 +753,7 @@ static int assignOnce(t1k_ctx *ctx, uint64_t first, uint32_t count) {
   t1k_launch_truncate(ctx, tr, nWg);
   T1K_HIP(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
   // the lists are final: publish them in the read set's table (absolute read-end index) and keep their records in the store
-  t1k_launch_publish_lists(ctx, rd.listPtr + first, rd.listCount + first, ctx->ovlBase, s.ovlStart, s.ovlCount, n);
+  t1k_launch_publish_lists(ctx, rd.listPtr + first, rd.listCount + first, ctx->ovlBase, ctx->storeBase, ctx->nOvl, s.ovlStart, s.ovlCount, n, a.counters);
   if ((rc = fetchCounters(ctx, hc))) return rc;
   double t4 = nowMs();
   if (hc[2]) return capacityError(ctx, hc[2]);

@@ -1387,8 +1387,9 @@ int t1k_run_chain(t1k_ctx *ctx, const ChainArgs &a, int nWg, int bigBlocks, bool
   hc[6] = groups.total;
   const T1kArenaCounts jobs = t1k_arena_counts(ctx, T1K_AR_JOBS, a.jobSegCap), retry = t1k_arena_counts(ctx, T1K_AR_RETRY, a.listSegCap),
                        fin = t1k_arena_counts(ctx, T1K_AR_FINISH, a.listSegCap), gen = t1k_arena_counts(ctx, T1K_AR_GENERAL, a.rareSegCap);
-  // (a full job segment is benign: the claim was released and the gap is aligned inline by the retry pass)
-  if (retry.overflow || fin.overflow || gen.overflow) { hc[2] |= ERR_GROUPCAP; return 0; }
+  // A full job segment is NOT benign: the lane that could not list its job released the memo claim, but another lane may already be
+  // waiting on that slot (it saw the claim) and would find it empty or re-claimed at finish time.  The range runs again with a larger list.
+  if (retry.overflow || fin.overflow || gen.overflow || jobs.overflow) { hc[2] |= ERR_GROUPCAP; return 0; }
   hc[16] = jobs.total; hc[17] = retry.total; hc[18] = gen.total; hc[22] = fin.total;
   t1k_arena_compact(ctx, T1K_AR_JOBS, a.jobStr, a.jobSegCap, a.jobList, jobs.maxSeg);
   t1k_arena_compact(ctx, T1K_AR_FINISH, a.finishStr, a.listSegCap, a.finishList, fin.maxSeg);
@@ -1422,6 +1423,7 @@ int t1k_run_chain(t1k_ctx *ctx, const ChainArgs &a, int nWg, int bigBlocks, bool
     }
     if ((rc = readCounters(ctx, hc))) return rc;  // the general kernels register alignments and may hand groups over to the big-scratch kernel
     const T1kArenaCounts gj = t1k_arena_counts(ctx, T1K_AR_GENJOBS, a.genJobSegCap);
+    if (gj.overflow) { hc[2] |= ERR_GROUPCAP; return 0; }
     t1k_arena_compact(ctx, T1K_AR_GENJOBS, a.genJobStr, a.genJobSegCap, a.genJobList, gj.maxSeg);
     t1k_launch_dp_dense(ctx, a, a.genJobList, (uint32_t)gj.total);
     hipLaunchKernelGGL(k_general_finish, dim3((nGen + WG - 1) / WG), dim3(WG), 0, ctx->stream, a, nGen);

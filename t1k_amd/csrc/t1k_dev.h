@@ -57,6 +57,34 @@ struct T1kOvl {
   uint32_t flags;      // bit0 near-best, bit1 strand is '-', bit2 duplicate-allele list marker
 };
 
+// The same record as the overlap store keeps it (16 bytes: the store holds the lists of a whole window of fragments, tens of GB at
+// 32 bytes each, and mate pairing streams every list it joins):
+//   lo = allele:24 | seqStart:20 | (seqEnd - seqStart):12 | strand is '-':1        hi = readStart:10 | readEnd:10 | matchCnt:12 | relaxed:12 | leftClip:10 | rightClip:10
+// Ranges: alleles < 2^24 and allele lengths < 2^20 are enforced by t1k_ref_upload, reads are at most T1K_MAX_READ_LEN (320) long;
+// t1k_ovl_pack reports anything that does not fit (an internal error, never silent).
+struct T1kOvlP { unsigned long long lo, hi; };
+__host__ __device__ __forceinline__ bool t1k_ovl_pack(const T1kOvl &o, T1kOvlP &p) {
+  const int span = o.seqEnd - o.seqStart;
+  const bool ok = o.allele < (1u << 24) && o.seqStart >= 0 && o.seqStart < (1 << 20) && span >= 0 && span < 4096 && o.readStart < 1024 && o.readEnd < 1024 &&
+                  o.matchCnt < 4096 && o.relaxed < 4096 && o.leftClip < 1024 && o.rightClip < 1024;
+  p.lo = (unsigned long long)o.allele | ((unsigned long long)(uint32_t)o.seqStart << 24) | ((unsigned long long)(uint32_t)span << 44) | ((unsigned long long)((o.flags >> 1) & 1u) << 56);
+  p.hi = (unsigned long long)o.readStart | ((unsigned long long)o.readEnd << 10) | ((unsigned long long)o.matchCnt << 20) | ((unsigned long long)o.relaxed << 32) |
+         ((unsigned long long)o.leftClip << 44) | ((unsigned long long)o.rightClip << 54);
+  return ok;
+}
+__host__ __device__ __forceinline__ T1kOvl t1k_ovl_unpack(const T1kOvlP &p) {
+  T1kOvl o;
+  o.allele = (uint32_t)(p.lo & 0xFFFFFFu);
+  o.seqStart = (int32_t)((p.lo >> 24) & 0xFFFFFu);
+  o.seqEnd = o.seqStart + (int32_t)((p.lo >> 44) & 0xFFFu);
+  o.flags = (uint32_t)((p.lo >> 56) & 1u) << 1;
+  o.readStart = (uint16_t)(p.hi & 0x3FFu); o.readEnd = (uint16_t)((p.hi >> 10) & 0x3FFu);
+  o.matchCnt = (uint16_t)((p.hi >> 20) & 0xFFFu); o.relaxed = (uint16_t)((p.hi >> 32) & 0xFFFu);
+  o.leftClip = (uint16_t)((p.hi >> 44) & 0x3FFu); o.rightClip = (uint16_t)((p.hi >> 54) & 0x3FFu);
+  o.re = 0;
+  return o;
+}
+
 #define T1K_SEED_CHUNK 512    // alleles per seeding chunk (k_seed_groups): accumulators of one chunk live in LDS
 #define T1K_DIR_MINLEN 32     // posting lists longer than this get a chunk directory
 #define T1K_NO_DIR 0xFFFFFFFFu
@@ -665,10 +693,13 @@ struct t1k_ctx {
   int storeSlot = 0;
   size_t storeChunk[2] = {0, 0};   // chunk being filled
   uint64_t storeUsed[2] = {0, 0};  // records used in it
-  T1kOvl *ovlBase = nullptr;       // where the last t1k_assign_range wrote its lists (t1k_overlaps_download)
+  T1kOvl *ovlBase = nullptr;       // where the last t1k_assign_range wrote its lists (32-byte working records: t1k_overlaps_download)
+  T1kDevBuf bOvlWork;              // the working records of one range (the store keeps the packed form)
+  T1kOvlP *storeBase = nullptr;    // where the running range's packed lists go
   // working capacities of the batch arenas (t1k_assign_range grows them on demand up to the limits in prm) and the demand the last
   // overflow reported
-  uint64_t wGroup = 0, wList = 0, wRare = 0, wCand = 0, wOvl = 0, needGroup = 0, needList = 0, needRare = 0, needCand = 0, needOvl = 0;
+  uint64_t wGroup = 0, wList = 0, wRare = 0, wCand = 0, wOvl = 0, wJob = 0, wGenJob = 0;
+  uint64_t needGroup = 0, needList = 0, needRare = 0, needCand = 0, needOvl = 0, needJob = 0, needGenJob = 0;
   unsigned long long lastCapFlags = 0;
   bool scaledOnce = false;
   bool covCommitted = false;     // the running range has started adding to the coverage arrays (no retry after that)

@@ -89,6 +89,12 @@ struct PairArgs {
   t1k_row_entry *rsRows; uint64_t rsCap; unsigned long long *rsCursor; uint64_t fragBase;
 };
 
+// a read-end's list in the overlap store: packed records, unpacked on access
+struct OvlList {
+  const T1kOvlP *p;
+  __device__ __forceinline__ T1kOvl operator[](uint32_t i) const { return t1k_ovl_unpack(p[i]); }
+};
+
 __device__ __forceinline__ double ovlSim(const T1kOvl &o) {
   return (double)o.matchCnt / (double)(o.readEnd - o.readStart + 1 + o.seqEnd - o.seqStart + 1 + 2 * o.leftClip + 2 * o.rightClip);
 }
@@ -194,10 +200,10 @@ __global__ __launch_bounds__(WG) void k_pair(PairArgs P) {
     const bool paired = P.end2 != nullptr;
     const uint32_t e1 = P.end1[f];
     const uint32_t n1 = P.listCount[e1];
-    const T1kOvl *L1 = (const T1kOvl *)P.listPtr[e1];
+    const OvlList L1{(const T1kOvlP *)P.listPtr[e1]};
     uint32_t n2 = 0;
-    const T1kOvl *L2 = nullptr;
-    if (paired) { uint32_t e2 = P.end2[f]; n2 = P.listCount[e2]; L2 = (const T1kOvl *)P.listPtr[e2]; }
+    OvlList L2{nullptr};
+    if (paired) { uint32_t e2 = P.end2[f]; n2 = P.listCount[e2]; L2.p = (const T1kOvlP *)P.listPtr[e2]; }
     const bool hasN = P.hasN ? P.hasN[f] != 0 : false;
     if (tid == 0) { sDup = 0; sFail = 0; sBestM = -1; sBestIdx = 0x7FFFFFFF; sAnySep = 0; sNotOne = 0; sN = 0; }
     __syncthreads();
@@ -252,7 +258,7 @@ __global__ __launch_bounds__(WG) void k_pair(PairArgs P) {
       if (!both) {
         nFrag = n1 + n2;
         for (uint32_t q = tid; q < nFrag; q += WG) {
-          if (q < n1) makeFrag(frags[q], &L1[q], (int)q, nullptr, -1); else makeFrag(frags[q], nullptr, -1, &L2[q - n1], (int)(q - n1));
+          if (q < n1) { const T1kOvl o = L1[q]; makeFrag(frags[q], &o, (int)q, nullptr, -1); } else { const T1kOvl o = L2[q - n1]; makeFrag(frags[q], nullptr, -1, &o, (int)(q - n1)); }
         }
       } else {
         const int s1 = ovlStrand(L1[0]), s2 = ovlStrand(L2[0]);
@@ -274,7 +280,8 @@ __global__ __launch_bounds__(WG) void k_pair(PairArgs P) {
           uint32_t tot;
           uint32_t off = scanExcl(j >= 0 ? 1u : 0u, warpSums, &tot);
           if (j >= 0) {
-            makeFrag(frags[nFrag + off], &L1[i], (int)i, &L2[j], j);
+            const T1kOvl oa = L1[i], ob = L2[j];
+            makeFrag(frags[nFrag + off], &oa, (int)i, &ob, j);
             // the mate's allele has a fragment (seqIdxToOverlapIdx membership)
             if (lds) atomicOr(&hVal[slot], 0x8000u); else tab2[L1[i].allele] |= 0x80000000ull;
           }
@@ -300,8 +307,8 @@ __global__ __launch_bounds__(WG) void k_pair(PairArgs P) {
         };
         Frag fr;
         if (!both) {
-          for (uint32_t i = 0; i < n1; ++i) { makeFrag(fr, &L1[i], (int)i, nullptr, -1); add(fr, L1[i]); }
-          for (uint32_t j = 0; j < n2; ++j) { makeFrag(fr, nullptr, -1, &L2[j], (int)j); add(fr, L2[j]); }
+          for (uint32_t i = 0; i < n1; ++i) { const T1kOvl o = L1[i]; makeFrag(fr, &o, (int)i, nullptr, -1); add(fr, o); }
+          for (uint32_t j = 0; j < n2; ++j) { const T1kOvl o = L2[j]; makeFrag(fr, nullptr, -1, &o, (int)j); add(fr, o); }
         } else {
           for (uint32_t i = 0; i < n1; ++i) {
             uint64_t e = tab2[L1[i].allele];
@@ -311,8 +318,9 @@ __global__ __launch_bounds__(WG) void k_pair(PairArgs P) {
               int s1 = ovlStrand(L1[i]), s2 = ovlStrand(L2[j]);
               if (s1 == s2) continue;
               if ((s1 == 1 && L1[i].seqStart < L2[j].seqStart) || (s1 == -1 && L1[i].seqStart > L2[j].seqStart)) {
-                makeFrag(fr, &L1[i], (int)i, &L2[j], (int)j);
-                add(fr, L1[i]);
+                const T1kOvl oa = L1[i], ob = L2[j];
+                makeFrag(fr, &oa, (int)i, &ob, (int)j);
+                add(fr, oa);
                 tab2[L1[i].allele] |= 0x80000000ull;
               }
             }
