@@ -110,6 +110,7 @@ def lib():
     L.t1k_job_run_local.argtypes = [vp]
     L.t1k_job_finish.argtypes = [vp, C.c_uint64, C.c_uint64]
     L.t1k_job_groups_serialize.argtypes = [vp, vp, C.c_uint64, u64p]
+    L.t1k_reads_dedupe.argtypes = [vp, vp, u32p]
     L.t1k_job_groups_merge.argtypes = [vp, vp, vp, C.c_uint32]
     L.t1k_job_coalesce_rows.argtypes = [vp, vp, vp, vp, C.c_uint32]
     L.t1k_job_set_shard.argtypes = [vp, C.c_int, C.c_int, vp]
@@ -189,6 +190,14 @@ class Context:
         w = None if weights is None else np.asarray(weights, dtype=np.uint32)
         self.n_read_ends = len(seqs)
         self._check(lib().t1k_reads_upload(self.h, blob, _ptr(offs), _ptr(w), len(seqs)), "t1k_reads_upload")
+
+    def reads_dedupe(self):
+        """identical read-ends collapse (t1k_reads_dedupe): the context's read set becomes the distinct sequences; returns distinct_of[n_uploaded]"""
+        out = np.zeros(self.n_read_ends, dtype=np.uint32)
+        nd = C.c_uint32()
+        self._check(lib().t1k_reads_dedupe(self.h, _ptr(out), C.byref(nd)), "t1k_reads_dedupe")
+        self.n_uploaded, self.n_read_ends = self.n_read_ends, nd.value
+        return out
 
     def assign(self):
         self._check(lib().t1k_assign_batch(self.h), "t1k_assign_batch")

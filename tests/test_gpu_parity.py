@@ -397,3 +397,81 @@ def test_analyzer_live_vs_reference_binary(built, tmp_path, seed, paired, flags)
     a, b = open(outs[0] + "_barcode_expr.tsv").read(), open(outs[1] + "_barcode_expr.tsv").read()
     assert a.count("\n") > 50
     assert a == b
+
+
+def test_identical_read_end_collapse_stage(built, tmp_path):
+    """t1k_reads_dedupe (Genotyper.cpp:451-480): equal sequences <=> equal distinct index, one representative per distinct sequence, and
+    the assignment of the collapsed set with multiplicities gives the same lists and the same per-base coverage as assigning every
+    read-end separately (the weight only feeds the coverage, SeqSet.hpp:2253-2274)"""
+    c = goldens.Case("hla_synth_2x150", str(tmp_path))
+    rng = np.random.default_rng(5)
+    base = [s for _, _, s in t1k_amd.read_fastx(c.r1)][:150] + [s for _, _, s in t1k_amd.read_fastx(c.r2)][:150]
+    extra = ["", "A", "ACGT", "ACGTN", "N" * 40, "ACGT" * 40, "ACGT" * 40 + "A", ("ACGT" * 40)[:-1] + "N"]     # lengths / N differ where the bases agree
+    pool = base + extra
+    reads = [pool[i] for i in rng.integers(0, len(pool), size=3000)]
+    names, seqs, masks, _ = t1k_amd.load_reference_fasta(c.ref)
+    full = t1k_amd.Context(ref_seq_similarity=0.97)
+    full.ref_upload(seqs, masks)
+    full.reads_upload(reads)
+    full.assign()
+    cnt_full, ovl_full = full.overlaps()
+    cov_full = full.coverage()
+    full.close()
+    ctx = t1k_amd.Context(ref_seq_similarity=0.97)
+    ctx.ref_upload(seqs, masks)
+    ctx.reads_upload(reads)
+    d = ctx.reads_dedupe()
+    assert ctx.n_read_ends == len(set(reads))
+    first = {}
+    for i, r in enumerate(reads):
+        assert first.setdefault(r, int(d[i])) == int(d[i])
+    assert len(set(first.values())) == len(first)
+    ctx.assign()
+    cnt, ovl = ctx.overlaps()
+    start_full = np.concatenate([[0], np.cumsum(cnt_full)]).astype(np.int64)
+    start = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64)
+    for i in range(0, len(reads), 7):   # every seventh read-end: its list equals the list of its distinct representative
+        a = ovl_full[start_full[i]:start_full[i + 1]]
+        b = ovl[start[int(d[i])]:start[int(d[i]) + 1]]
+        assert len(a) == len(b)
+        for f in ("seq_idx", "read_start", "read_end", "seq_start", "seq_end", "strand", "match_cnt", "left_clip", "right_clip", "relaxed_match_cnt", "similarity"):
+            assert np.array_equal(a[f], b[f]), f
+    assert np.array_equal(ctx.coverage(), cov_full)
+    ctx.close()
+
+
+def test_device_coalescing_equals_host_restatement(built, tmp_path):
+    """t1k_rowset_coalesce (the job's read-group table) against the host restatement of CoalesceReadAssignments fed with the rows of
+    t1k_pair_batch: same groups in the same order, same start / end, float weights bit for bit"""
+    import test_distributed_gloo as tdg
+    for name in ("hla_synth_2x150", "cyp_dna_relax_2x150"):
+        c = goldens.Case(name, str(tmp_path / name))
+        kw = dict(ref_seq_similarity=float(c.flags[c.flags.index("-s") + 1]) if "-s" in c.flags else 0.8, relax_intron_align=1 if "--relaxIntronAlign" in c.flags else 0)
+        extra = dict(allele_digit_units=1, allele_delimiter=".") if "cyp" in name else {}
+        job = t1k_amd.Job(c.ref, **kw, **extra)
+        job.load_reads(c.r1, c.r2, c.bc)
+        job.run()
+        g2, a2, p2, f2, e2 = tdg.parse_table(job.groups_serialize())
+        job.close()
+        r1 = [s for _, _, s in t1k_amd.read_fastx(c.r1)]
+        r2 = [s for _, _, s in t1k_amd.read_fastx(c.r2)]
+        if c.bc:
+            keep = [i for i, (_, _, s) in enumerate(t1k_amd.read_fastx(c.bc)) if s != "missing_barcode"]
+            r1, r2 = [r1[i] for i in keep], [r2[i] for i in keep]
+        names, seqs, masks, _ = t1k_amd.load_reference_fasta(c.ref)
+        ctx = t1k_amd.Context(**kw)
+        ctx.ref_upload(seqs, masks)
+        ctx.reads_upload([s for pr in zip(r1, r2) for s in pr])
+        ctx.assign()
+        n = len(r1)
+        ctx.pair(np.arange(n) * 2, np.arange(n) * 2 + 1, [("N" in a) or ("N" in b) for a, b in zip(r1, r2)])
+        counts, assigned, rows = ctx.rows()
+        ctx.close()
+        host = t1k_amd.Job(c.ref, device=-1, **extra)
+        host.coalesce_rows(rows, counts)
+        g1, a1, p1, f1, e1 = tdg.parse_table(host.groups_serialize())
+        host.close()
+        assert (g1, a1) == (g2, a2) and np.array_equal(p1, p2) and np.array_equal(f1, f2)
+        for field in ("allele", "start", "end"):
+            assert np.array_equal(e1[field], e2[field]), field
+        assert np.array_equal(e1["w"].view(np.uint32), e2["w"].view(np.uint32)) and np.array_equal(e1["aw"].view(np.uint32), e2["aw"].view(np.uint32))
