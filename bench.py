@@ -159,6 +159,8 @@ def main():
         if comm is not None:
             comm.bind(job)
             job.set_shard(rank, world, comm)
+        if rank == 0:
+            job.set_output_prefix(out_prefix)   # as the executable does: the aligned-read files are written while the EM runs
         job.run()
         if rank == 0:
             job.write_outputs(out_prefix)

@@ -281,6 +281,9 @@ int t1k_job_set_reads(t1k_job *job, const char *seq1, const uint64_t *off1, cons
 int t1k_job_stage_reads(t1k_job *job);
 /* read-end assignment, pairing, coalescing, EC build, EM, allele selection (Genotyper.cpp:451-650) */
 int t1k_job_run(t1k_job *job);
+/* optional, before t1k_job_run: the *_aligned*.fa files (which only need the fragmentAssigned flags) are then written by background
+ * threads while the classes are built and the EM runs; t1k_job_write_outputs with the same prefix waits for them */
+int t1k_job_set_output_prefix(t1k_job *job, const char *prefix);
 /* <prefix>_genotype.tsv, _allele.tsv, _aligned*.fa, (_assign.tsv) (Genotyper.cpp:653-718) */
 int t1k_job_write_outputs(t1k_job *job, const char *prefix);
 /* results in memory: one line per gene, same text as _genotype.tsv */

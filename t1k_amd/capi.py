@@ -351,6 +351,10 @@ class Job:
     def run(self):
         self._check(lib().t1k_job_run(self.h), "t1k_job_run")
 
+    def set_output_prefix(self, prefix):
+        lib().t1k_job_set_output_prefix.argtypes = [C.c_void_p, C.c_char_p]
+        self._check(lib().t1k_job_set_output_prefix(self.h, prefix.encode()), "t1k_job_set_output_prefix")
+
     def write_outputs(self, prefix):
         self._check(lib().t1k_job_write_outputs(self.h, prefix.encode()), "t1k_job_write_outputs")
 

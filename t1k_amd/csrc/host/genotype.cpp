@@ -184,23 +184,44 @@ int Genotyper::quantify(t1k_ctx *ctx, t1k_comm *comm, std::string &err) {
   RefSet &R = *ref;
   const size_t E = ecAlleles.size(), G = nGroups();
   const size_t gBegin = 0;
+  // rows of the E-step: per read group its count (the largest weight of the row, 1155-1164) and its distinct classes in
+  // first-appearance order (1165-1189).  Groups are independent: the host threads take contiguous pieces (a piece's rows keep their order).
   std::vector<uint64_t> rowPtr(G + 1, 0);
   std::vector<uint32_t> ecIdx;
   std::vector<double> count(G);
-  std::vector<int> seen(E, 0);
-  for (size_t gl = 0; gl < G; ++gl) {
-    const size_t g = gBegin + gl;
-    float c = groupEnt[groupPtr[g]].weight;
-    for (uint64_t p = groupPtr[g] + 1; p < groupPtr[g + 1]; ++p)
-      if (groupEnt[p].weight > c) c = groupEnt[p].weight;
-    count[gl] = c;
-    for (uint64_t p = groupPtr[g]; p < groupPtr[g + 1]; ++p) {  // distinct classes of the row, first-appearance order (1165-1189)
-      uint32_t ec = (uint32_t)R.al[groupEnt[p].allele].ec;
-      if (seen[ec] == (int)gl + 1) continue;
-      seen[ec] = (int)gl + 1;
-      ecIdx.push_back(ec);
-    }
-    rowPtr[gl + 1] = ecIdx.size();
+  {
+    unsigned T = std::thread::hardware_concurrency();
+    if (T > 16) T = 16;
+    if (T < 1 || G < 8192) T = 1;
+    const size_t piece = (G + T - 1) / T;
+    std::vector<std::vector<uint32_t>> part(T);
+    parallelFor(T, [&](size_t t) {
+      const size_t g0 = t * piece, g1 = std::min(G, g0 + piece);
+      std::vector<int> seen(E, 0);
+      std::vector<uint32_t> &out = part[t];
+      if (g1 > g0) out.reserve((size_t)((groupPtr[g1] - groupPtr[g0]) / 2 + 16));
+      for (size_t gl = g0; gl < g1; ++gl) {
+        const size_t g = gBegin + gl;
+        float c = groupEnt[groupPtr[g]].weight;
+        for (uint64_t p = groupPtr[g] + 1; p < groupPtr[g + 1]; ++p)
+          if (groupEnt[p].weight > c) c = groupEnt[p].weight;
+        count[gl] = c;
+        const size_t before = out.size();
+        for (uint64_t p = groupPtr[g]; p < groupPtr[g + 1]; ++p) {
+          const uint32_t ec = (uint32_t)R.al[groupEnt[p].allele].ec;
+          if (seen[ec] == (int)(gl - g0) + 1) continue;
+          seen[ec] = (int)(gl - g0) + 1;
+          out.push_back(ec);
+        }
+        rowPtr[gl + 1] = out.size() - before;  // length for now
+      }
+    }, 1);
+    for (size_t gl = 0; gl < G; ++gl) rowPtr[gl + 1] += rowPtr[gl];
+    ecIdx.resize(rowPtr[G]);
+    parallelFor(T, [&](size_t t) {
+      const size_t g0 = t * piece;
+      if (g0 < G && !part[t].empty()) memcpy(ecIdx.data() + rowPtr[g0], part[t].data(), part[t].size() * 4);
+    }, 1);
   }
   std::vector<int> ecLen(E);
   for (size_t e = 0; e < E; ++e) {

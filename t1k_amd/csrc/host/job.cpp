@@ -31,6 +31,11 @@ struct t1k_job {
   // multi-GPU: this job is rank `rank` of `nRanks`; it owns fragments [F * rank / nRanks, F * (rank + 1) / nRanks) of the input
   int rank = 0, nRanks = 1;
   t1k_comm *comm = nullptr;         // not owned
+  // the *_aligned*.fa files only need the fragmentAssigned flags: with an output prefix registered before the run they are written by
+  // background threads while the classes are built and the EM runs
+  std::string outPrefix;
+  std::thread bgWriter;
+  bool bgStarted = false, bgOk = true;
   bool analyzer = false;            // analyzer mode: the rowset keeps the raw fragment assignment lists and is left alive after run_local
   t1k_rowset *rows = nullptr;       // every fragment's row, resident on the GPU until the job is coalesced
   std::vector<uint8_t> fragAssigned;
@@ -95,12 +100,34 @@ static int jobCreate(const t1k_job_params *p, const char *refFasta, const std::s
   if (p) job->prm = *p; else t1k_job_params_default(&job->prm);
   *out = job;  // handed back even on failure so the caller can read the message
   const double t0 = nowMs();
-  if (!job->ref.load(refFasta, job->prm.allele_digit_units, job->prm.allele_delimiter, job->err, selected)) return T1K_ERR_IO;
+  // the HIP runtime comes up and the contexts (streams, events) are created while the host parses the reference
+  const char *pl = getenv("T1K_PIPELINES");
+  const int nPipe = pl ? std::max(1, std::min(8, atoi(pl))) : 3;
+  int rcCtx = T1K_OK;
+  std::thread init;
+  if (job->prm.device >= 0)
+    init = std::thread([&] {
+      rcCtx = t1k_ctx_create(job->prm.device, &job->prm.dev, &job->ctx);
+      // Most kernels of the path are latency-bound; further independent pipelines (context, stream, arenas) on the same GPU let the
+      // hardware overlap batches and hide the host's share of a batch (counter fetches, launches).  Measured on the HLA-like
+      // workload (device loop): 1 M pairs 840 / 723 / 678 ms with 1 / 2 / 4 pipelines, 10 M pairs 6.4 / 6.0 / 5.9 s with 2 / 3 / 4;
+      // every pipeline's arenas are device memory the driver may have to zero first (~35 ms per GB).  T1K_PIPELINES overrides.
+      for (int i = 1; i < nPipe && rcCtx == T1K_OK; ++i) {
+        t1k_ctx *c = nullptr;
+        if (t1k_ctx_create(job->prm.device, &job->prm.dev, &c) != T1K_OK) { if (c) t1k_ctx_destroy(c); break; }
+        job->more.push_back(c);
+      }
+      for (int i = 0; i < 2 && rcCtx == T1K_OK; ++i)
+        if (t1k_ctx_create(job->prm.device, &job->prm.dev, &job->reader[i]) != T1K_OK) rcCtx = T1K_ERR_DEVICE;
+    });
+  const bool loaded = job->ref.load(refFasta, job->prm.allele_digit_units, job->prm.allele_delimiter, job->err, selected);
+  if (init.joinable()) init.join();
+  if (!loaded) return T1K_ERR_IO;
   job->gt.ref = &job->ref;
   job->gt.prm = job->prm;
   if (job->prm.device < 0) return T1K_OK;  // host-only job: group bookkeeping for tests / merging, no device work possible
   const double t1 = nowMs();
-  int rc = t1k_ctx_create(job->prm.device, &job->prm.dev, &job->ctx);
+  int rc = rcCtx;
   if (rc != T1K_OK) return jobFail(job, rc, "cannot create a GPU context on device " + std::to_string(job->prm.device) + " (this build has no CPU path)");
   // upload the reference
   const RefSet &R = job->ref;
@@ -114,27 +141,19 @@ static int jobCreate(const t1k_job_params *p, const char *refFasta, const std::s
   }
   rc = t1k_ref_upload(job->ctx, blob.data(), off.data(), ex.data(), (uint32_t)R.seqs.size());
   if (rc != T1K_OK) return jobFail(job, rc, t1k_last_error(job->ctx));
-  // Most kernels of the path are latency-bound; a second independent pipeline (context, stream, arenas) on the same GPU lets the
-  // hardware overlap batches and hides the host's share of a batch (counter fetches, launches).  Measured on the 1 M-pair HLA-like
-  // workload (device loop, arenas warm): 1 pipeline 840 ms, 2: 723 ms, 4: 678 ms -- and every pipeline's arenas are fresh VRAM that
-  // costs ~35 ms per GB when the driver has to zero it.  Three is the default (10 M-pair device loop: 6.4 / 6.0 / 5.9 s with 2 / 3 / 4).  T1K_PIPELINES overrides.
-  const char *pl = getenv("T1K_PIPELINES");
-  const int nPipe = pl ? std::max(1, std::min(8, atoi(pl))) : 3;
-  for (int i = 1; i < nPipe; ++i) {
-    t1k_ctx *c = nullptr;
-    rc = t1k_ctx_create(job->prm.device, &job->prm.dev, &c);
-    if (rc == T1K_OK) rc = t1k_ref_share(c, job->ctx);  // the pipelines read one copy of the reference and index
-    if (rc != T1K_OK) { if (c) t1k_ctx_destroy(c); break; }  // not enough memory: run with the pipelines we have
-    job->more.push_back(c);
-  }
-  for (int i = 0; i < 2; ++i)
-    if ((rc = t1k_ctx_create(job->prm.device, &job->prm.dev, &job->reader[i])) != T1K_OK) return jobFail(job, rc, "cannot create a read-set context");
+  for (size_t i = 0; i < job->more.size(); ++i)
+    if ((rc = t1k_ref_share(job->more[i], job->ctx)) != T1K_OK) {  // not enough memory: run with the pipelines we have
+      for (size_t j = i; j < job->more.size(); ++j) t1k_ctx_destroy(job->more[j]);
+      job->more.resize(i);
+      break;
+    }
   if (getenv("T1K_DEBUG_PHASES")) fprintf(stderr, "[t1k job] reference: parse + naming + gene similarity %.1f ms, pack + index + upload + contexts %.1f ms\n", t1 - t0, nowMs() - t1);
   return T1K_OK;
 }
 
 void t1k_job_destroy(t1k_job *job) {
   if (!job) return;
+  if (job->bgWriter.joinable()) job->bgWriter.join();
   if (job->rows) t1k_rowset_destroy(job->rows);
   for (t1k_ctx *c : job->more) t1k_ctx_destroy(c);  // before job->ctx, whose reference they alias
   for (t1k_ctx *c : job->reader) if (c) t1k_ctx_destroy(c);
@@ -539,8 +558,22 @@ int t1k_job_run_local(t1k_job *job) {
   return T1K_OK;
 }
 
+static bool writeAlignedFiles(t1k_job *job, const std::string &pfx);
+
+int t1k_job_set_output_prefix(t1k_job *job, const char *prefix) {
+  if (!job) return T1K_ERR_ARG;
+  job->outPrefix = prefix ? prefix : "";
+  return T1K_OK;
+}
+
 int t1k_job_finish(t1k_job *job, uint64_t emGroupBegin, uint64_t emGroupEnd) {
   if (!job || !job->ctx || !job->localDone) return jobFail(job, T1K_ERR_STATE, "t1k_job_finish: t1k_job_run_local has not completed");
+  if (job->bgWriter.joinable()) job->bgWriter.join();
+  job->bgStarted = false; job->bgOk = true;
+  if (!job->outPrefix.empty() && job->rank == 0 && !job->analyzer) {  // the flags are final: start on the big files now
+    job->bgStarted = true;
+    job->bgWriter = std::thread([job] { job->bgOk = writeAlignedFiles(job, job->outPrefix); });
+  }
   Genotyper &gt = job->gt;
   int rc;
   double t2 = nowMs();
@@ -725,6 +758,21 @@ static bool writeAligned(t1k_job *job, const std::string &path, int what, int T)
   return true;
 }
 
+// reads with at least one fragment assignment (Genotyper.cpp:680-718): the mates' files and the barcode file side by side
+static bool writeAlignedFiles(t1k_job *job, const std::string &pfx) {
+  const int T = hostThreads(job);
+  const bool paired = job->in->paired;
+  bool ok1 = true, ok2 = true, ok3 = true;
+  std::thread t2, t3;
+  const int per = std::max(1, T / (1 + (paired ? 1 : 0) + (job->in->hasBarcode ? 1 : 0)));
+  if (paired) t2 = std::thread([&] { ok2 = writeAligned(job, pfx + "_aligned_2.fa", 1, per); });
+  if (job->in->hasBarcode) t3 = std::thread([&] { ok3 = writeAligned(job, pfx + "_aligned_bc.fa", 2, per); });
+  ok1 = writeAligned(job, paired ? pfx + "_aligned_1.fa" : pfx + "_aligned.fa", 0, per);
+  if (t2.joinable()) t2.join();
+  if (t3.joinable()) t3.join();
+  return ok1 && ok2 && ok3;
+}
+
 int t1k_job_write_outputs(t1k_job *job, const char *prefix) {
   if (!job || !prefix || !job->ran || !job->in) return T1K_ERR_STATE;
   const double t0 = nowMs();
@@ -734,20 +782,14 @@ int t1k_job_write_outputs(t1k_job *job, const char *prefix) {
   if (!writeText(pfx + "_genotype.tsv", s, job->err)) return T1K_ERR_IO;
   if (!writeText(pfx + "_allele.tsv", job->gt.alleleLines(), job->err)) return T1K_ERR_IO;
   if (job->prm.output_read_assignment && !writeText(pfx + "_assign.tsv", job->assignText, job->err)) return T1K_ERR_IO;
-  // reads with at least one fragment assignment (Genotyper.cpp:680-718)
-  const int T = hostThreads(job);
-  const bool paired = job->in->paired;
-  bool ok1 = true, ok2 = true, ok3 = true;
-  {
-    std::thread t2, t3;
-    const int per = std::max(1, T / (1 + (paired ? 1 : 0) + (job->in->hasBarcode ? 1 : 0)));
-    if (paired) t2 = std::thread([&] { ok2 = writeAligned(job, pfx + "_aligned_2.fa", 1, per); });
-    if (job->in->hasBarcode) t3 = std::thread([&] { ok3 = writeAligned(job, pfx + "_aligned_bc.fa", 2, per); });
-    ok1 = writeAligned(job, paired ? pfx + "_aligned_1.fa" : pfx + "_aligned.fa", 0, per);
-    if (t2.joinable()) t2.join();
-    if (t3.joinable()) t3.join();
+  if (job->bgStarted && job->outPrefix == pfx) {  // already under way since the end of the device loop
+    if (job->bgWriter.joinable()) job->bgWriter.join();
+    job->bgStarted = false;
+    if (!job->bgOk) return T1K_ERR_IO;
+  } else {
+    if (job->bgWriter.joinable()) job->bgWriter.join();
+    if (!writeAlignedFiles(job, pfx)) return T1K_ERR_IO;
   }
-  if (!ok1 || !ok2 || !ok3) return T1K_ERR_IO;
   job->msWrite = nowMs() - t0;
   job->stats.ms_write = job->msWrite;
   if (getenv("T1K_DEBUG_PHASES")) fprintf(stderr, "[t1k job] outputs written in %.1f ms\n", job->msWrite);
@@ -890,6 +932,7 @@ int t1k_genotyper_main(int argc, char **argv) {
   int rc = t1k_job_load_reads_multi(job, first.data(), (uint32_t)first.size(), paired ? f2.data() : nullptr, (uint32_t)f2.size(), barcode.empty() ? nullptr : barcode.c_str());
   if (rc != T1K_OK) { fprintf(stderr, "genotyper: %s\n", t1k_job_last_error(job)); destroyAll(); return EXIT_FAILURE; }
   logLine("Found %d read fragments. Start read assignment.", (int)job->in->nFrag());
+  t1k_job_set_output_prefix(job, prefix.c_str());  // the aligned-read files are written while the EM runs
   if (R == 1) rc = t1k_job_run(job);
   else {
     // one thread per rank: the ranks meet in the collectives of t1k_job_run (RCCL when every rank has its own GPU)

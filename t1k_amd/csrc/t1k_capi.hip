@@ -95,7 +95,12 @@ int t1k_ensure(t1k_ctx *ctx, T1kDevBuf &b, size_t bytes) {
   // a buffer that has to grow grows by at least half (the sizes of several arenas follow the data of each range and creep up: every
   // reallocation is fresh VRAM, which the driver zeroes at ~35 ms per GB)
   size_t want = std::max(bytes + bytes / 8, b.p ? b.bytes + b.bytes / 2 : (size_t)0) + 256;
-  if (b.p) { (void)t1k_dev_free(b.p); b.p = nullptr; b.bytes = 0; }
+  if (b.p) {
+    // Kernels launched earlier on this context's stream may still be reading the old block, and the pool hands a freed block to the
+    // next caller (another pipeline's thread) at once -- unlike hipFree, which waits for the device: drain the stream first.
+    if (ctx && ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    (void)t1k_dev_free(b.p); b.p = nullptr; b.bytes = 0;
+  }
   const auto t0 = std::chrono::steady_clock::now();
   hipError_t e = t1k_dev_malloc(&b.p, want);
   if (ctx) { ctx->msAlloc += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); ctx->bytesAlloc += want; }
@@ -194,6 +199,7 @@ void t1k_ctx_destroy(t1k_ctx *ctx) {
   if (ctx && ctx->countersPinned) { (void)hipHostFree(ctx->countersPinned); ctx->countersPinned = nullptr; }
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);  // nothing of this context may be in flight when its blocks go back to the pool
   for (auto &b : ctx->refBufs) freeBuf(b);
   T1kDevBuf *all[] = {&ctx->bReadAscii, &ctx->bReadOffs, &ctx->bReadBases, &ctx->bReadN, &ctx->bReadLen, &ctx->bReadWeight, &ctx->bWgHits, &ctx->bWgGroups,
                       &ctx->bWgStage, &ctx->bWgBig, &ctx->bWgCache, &ctx->bLists, &ctx->bCand, &ctx->bExt, &ctx->bCandStart, &ctx->bCandCount, &ctx->bListPtr, &ctx->bListCount,

@@ -61,6 +61,20 @@ __global__ __launch_bounds__(256) void k_em_cols(const uint64_t *colPtr, const d
   if (lane == 0) n[ec] = s;
 }
 
+// t1k_em_setup: sort keys (class, entry) + class sizes
+__global__ void k_em_keys(const uint32_t *ecIdx, uint32_t nnz, uint32_t nEc, unsigned long long *key, uint32_t *val, unsigned long long *colCount, unsigned long long *bad) {
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= nnz) return;
+  const uint32_t ec = ecIdx[p];
+  if (ec >= nEc) { atomicOr(bad, 1ull); key[p] = 0; val[p] = p; return; }
+  key[p] = ec; val[p] = p;
+  atomicAdd(&colCount[ec], 1ull);
+}
+__global__ void k_em_scatter(const uint32_t *sortedEntry, uint32_t nnz, uint64_t *cscPos) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < nnz) cscPos[sortedEntry[j]] = j;
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // batched GlobalAlignment for tests
 // ------------------------------------------------------------------------------------------------------------------
@@ -213,28 +227,44 @@ int t1k_em_setup(t1k_ctx *ctx, const uint64_t *rowPtr, const uint32_t *ecIdx, co
   if (!ctx || !rowPtr || (!ecIdx && nGroups && rowPtr[nGroups]) || (!count && nGroups) || (!ecLen && nEc)) return t1k_fail(ctx, T1K_ERR_ARG, "t1k_em_setup: bad arguments");
   T1K_HIP(ctx, hipSetDevice(ctx->device));
   const uint64_t nnz = rowPtr[nGroups];
-  // class-major positions: a stable counting sort of the entries by class keeps them in group order within a class
-  std::vector<uint64_t> colPtr(nEc + 1, 0), cscPos(nnz);
-  for (uint64_t p = 0; p < nnz; ++p) {
-    if (ecIdx[p] >= nEc) return t1k_fail(ctx, T1K_ERR_ARG, "t1k_em_setup: class index out of range");
-    ++colPtr[ecIdx[p] + 1];
-  }
-  for (uint32_t i = 0; i < nEc; ++i) colPtr[i + 1] += colPtr[i];
-  {
-    std::vector<uint64_t> cur(colPtr.begin(), colPtr.end() - 1);
-    for (uint64_t p = 0; p < nnz; ++p) cscPos[p] = cur[ecIdx[p]]++;
-  }
   int rc;
   if ((rc = t1k_ensure(ctx, ctx->bEmRowPtr, (size_t)(nGroups + 1) * 8)) || (rc = t1k_ensure(ctx, ctx->bEmEc, (size_t)nnz * 4 + 16)) ||
-      (rc = t1k_ensure(ctx, ctx->bEmCount, (size_t)nGroups * 8 + 16)) || (rc = t1k_ensure(ctx, ctx->bEmColPtr, (size_t)(nEc + 1) * 8)) ||
+      (rc = t1k_ensure(ctx, ctx->bEmCount, (size_t)nGroups * 8 + 16)) || (rc = t1k_ensure(ctx, ctx->bEmColPtr, (size_t)(nEc + 2) * 8)) ||
       (rc = t1k_ensure(ctx, ctx->bEmColIdx, (size_t)nnz * 8 + 16)) || (rc = t1k_ensure(ctx, ctx->bEmContrib, (size_t)nnz * 8 + 16)) ||
       (rc = t1k_ensure(ctx, ctx->bEmX0, (size_t)nEc * 8 + 16)) || (rc = t1k_ensure(ctx, ctx->bEmN, (size_t)nEc * 8 + 16)))
     return rc;
   T1K_HIP(ctx, hipMemcpyAsync(ctx->bEmRowPtr.p, rowPtr, (size_t)(nGroups + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
   if (nnz) T1K_HIP(ctx, hipMemcpyAsync(ctx->bEmEc.p, ecIdx, (size_t)nnz * 4, hipMemcpyHostToDevice, ctx->stream));
   if (nGroups) T1K_HIP(ctx, hipMemcpyAsync(ctx->bEmCount.p, count, (size_t)nGroups * 8, hipMemcpyHostToDevice, ctx->stream));
-  T1K_HIP(ctx, hipMemcpyAsync(ctx->bEmColPtr.p, colPtr.data(), (size_t)(nEc + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-  if (nnz) T1K_HIP(ctx, hipMemcpyAsync(ctx->bEmColIdx.p, cscPos.data(), (size_t)nnz * 8, hipMemcpyHostToDevice, ctx->stream));
+  // Class-major positions: a STABLE sort of the entries by class keeps them in group order within a class (the order in which the
+  // reference's row-major loop adds them to ecReadCount[ec]).  On the device: radix sort of (class, entry), entry p lands at
+  // cscPos[p]; class starts from the sorted keys.
+  T1K_HIP(ctx, hipMemsetAsync(ctx->bEmColPtr.p, 0, (size_t)(nEc + 2) * 8, ctx->stream));
+  if (nnz) {
+    if (nnz >= 0xFFFFFFFFull) return t1k_fail(ctx, T1K_ERR_ARG, "t1k_em_setup: more than 2^32 entries");
+    T1kDevBuf tmp;
+    if ((rc = t1k_ensure(ctx, tmp, (size_t)nnz * 24 + 64))) return rc;
+    unsigned long long *k0 = (unsigned long long *)tmp.p, *k1 = k0 + nnz;
+    uint32_t *v0 = (uint32_t *)(k1 + nnz), *v1 = v0 + nnz;
+    unsigned long long *bad = (unsigned long long *)ctx->bEmN.p;  // a word that is free until the first update
+    T1K_HIP(ctx, hipMemsetAsync(bad, 0, 8, ctx->stream));
+    const unsigned nb = (unsigned)((nnz + 255) / 256);
+    hipLaunchKernelGGL(k_em_keys, dim3(nb), dim3(256), 0, ctx->stream, (const uint32_t *)ctx->bEmEc.p, (uint32_t)nnz, nEc, k0, v0, (unsigned long long *)ctx->bEmColPtr.p, bad);
+    int bits = 1;
+    while ((1ull << bits) < nEc) ++bits;
+    rc = t1k_sort_pairs(ctx, k0, k1, v0, v1, (uint32_t)nnz, bits);
+    if (rc == T1K_OK) {
+      hipLaunchKernelGGL(k_em_scatter, dim3(nb), dim3(256), 0, ctx->stream, (const uint32_t *)v1, (uint32_t)nnz, (uint64_t *)ctx->bEmColIdx.p);
+      unsigned long long isBad = 0;
+      hipError_t e = hipMemcpyAsync(&isBad, bad, 8, hipMemcpyDeviceToHost, ctx->stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+      (void)t1k_dev_free(tmp.p);
+      if (e != hipSuccess) return t1k_fail(ctx, T1K_ERR_DEVICE, hipGetErrorString(e));
+      if (isBad) return t1k_fail(ctx, T1K_ERR_ARG, "t1k_em_setup: class index out of range");
+    } else { (void)hipStreamSynchronize(ctx->stream); (void)t1k_dev_free(tmp.p); return rc; }
+  }
+  // class sizes -> class starts (colPtr[nEc] = nnz)
+  if ((rc = t1k_exclusive_sum_u64(ctx, (const unsigned long long *)ctx->bEmColPtr.p, (unsigned long long *)ctx->bEmColPtr.p, (uint64_t)nEc + 1))) return rc;
   T1K_HIP(ctx, hipStreamSynchronize(ctx->stream));
   ctx->emGroups = nGroups; ctx->emEc = nEc; ctx->emNnz = nnz;
   ctx->emAllreduce = allreduce; ctx->emUser = user;

@@ -122,6 +122,7 @@ int t1k_rowset_chunk_full(t1k_rowset *rs, t1k_ctx *ctx, size_t chunk);
 int t1k_exclusive_sum64(t1k_ctx *ctx, const uint32_t *in, unsigned long long *out, uint32_t n);
 int t1k_inclusive_sum_n(t1k_ctx *ctx, const uint32_t *in, uint32_t *out, uint64_t n);
 int t1k_exclusive_sum32(t1k_ctx *ctx, const uint32_t *in, uint32_t *out, uint64_t n);
+int t1k_exclusive_sum_u64(t1k_ctx *ctx, const unsigned long long *in, unsigned long long *out, uint64_t n);
 
 int t1k_launch_pack(t1k_ctx *ctx, const char *dAscii, const uint64_t *dOffs, uint32_t n, int S, uint64_t *bases, uint64_t *nmask, uint16_t *lens, int nCode);
 size_t t1k_slow_per_thread(int maxCells);

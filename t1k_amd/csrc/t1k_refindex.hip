@@ -144,9 +144,10 @@ extern "C" int t1k_ref_upload(t1k_ctx *ctx, const char *seqs, const uint64_t *of
   if (!ctx || !seqs || !offsets || nAlleles == 0 || nAlleles >= (1u << 24)) return t1k_fail(ctx, T1K_ERR_ARG, "t1k_ref_upload: bad arguments");
   if (offsets[nAlleles] - offsets[0] >= (1ull << 29)) return t1k_fail(ctx, T1K_ERR_ARG, "t1k_ref_upload: reference larger than 512 Mbases");
   T1K_HIP(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  (void)hipStreamSynchronize(st);
   for (auto &b : ctx->refBufs) if (b.p) (void)t1k_dev_free(b.p);
   ctx->refBufs.clear();
-  hipStream_t st = ctx->stream;
   const int k = ctx->prm.kmer_length;
   const int nCode = ctx->prm.n_base_code & 3;
   const bool dbgPhases = getenv("T1K_DEBUG_PHASES") != nullptr;
@@ -213,7 +214,7 @@ extern "C" int t1k_ref_upload(t1k_ctx *ctx, const char *seqs, const uint64_t *of
   // build-time scratch (freed at the end)
   const uint64_t textBytes = offsets[nAlleles] - offsets[0];
   T1kDevBuf bText, bExonB, bSrcOff, bWordAllele, bFlag, bPos, bCode;
-  auto freeScratch = [&] { for (T1kDevBuf *b : {&bText, &bExonB, &bSrcOff, &bWordAllele, &bFlag, &bPos, &bCode}) if (b->p) { (void)t1k_dev_free(b->p); b->p = nullptr; } };
+  auto freeScratch = [&] { (void)hipStreamSynchronize(st); for (T1kDevBuf *b : {&bText, &bExonB, &bSrcOff, &bWordAllele, &bFlag, &bPos, &bCode}) if (b->p) { (void)t1k_dev_free(b->p); b->p = nullptr; } };
   if ((rc = t1k_ensure(ctx, bText, textBytes + 16)) || (exon && (rc = t1k_ensure(ctx, bExonB, textBytes + 16))) || (rc = t1k_ensure(ctx, bSrcOff, (size_t)nAlleles * 8)) ||
       (rc = t1k_ensure(ctx, bWordAllele, nWords * 4)) || (rc = t1k_ensure(ctx, bFlag, (total + 1) * 4)) || (rc = t1k_ensure(ctx, bPos, (total + 1) * 4)) ||
       (rc = t1k_ensure(ctx, bCode, (total + 1) * 4))) { freeScratch(); return rc; }

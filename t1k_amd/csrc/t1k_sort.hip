@@ -58,3 +58,13 @@ int t1k_exclusive_sum32(t1k_ctx *ctx, const uint32_t *in, uint32_t *out, uint64_
   T1K_HIP(ctx, rocprim::exclusive_scan(ctx->bSortTmp.p, bytes, in, out, 0u, (size_t)n, rocprim::plus<uint32_t>(), ctx->stream));
   return T1K_OK;
 }
+
+int t1k_exclusive_sum_u64(t1k_ctx *ctx, const unsigned long long *in, unsigned long long *out, uint64_t n) {
+  if (!n) return T1K_OK;
+  size_t bytes = 0;
+  T1K_HIP(ctx, rocprim::exclusive_scan(nullptr, bytes, in, out, 0ull, (size_t)n, rocprim::plus<unsigned long long>(), ctx->stream));
+  int rc = t1k_ensure(ctx, ctx->bSortTmp, bytes + 256);
+  if (rc) return rc;
+  T1K_HIP(ctx, rocprim::exclusive_scan(ctx->bSortTmp.p, bytes, in, out, 0ull, (size_t)n, rocprim::plus<unsigned long long>(), ctx->stream));
+  return T1K_OK;
+}
