@@ -185,6 +185,7 @@ int t1k_comm_init(t1k_ctx *ctx, int nRanks, int rank, const void *id128, t1k_com
     if (!api->err.empty()) return commFail(c, T1K_ERR_DEVICE, api->err);
     CM_NCCL(api->CommInitRank(&c->nccl, nRanks, id, rank));
     c->useRccl = true;
+    (void)hipGetLastError();  // RCCL probes devices and peers while it initialises; its leftovers are not errors of this library
   }
   return T1K_OK;
 }
@@ -201,7 +202,7 @@ int t1k_comm_bind(t1k_comm *c, t1k_ctx *ctx) {
 
 void t1k_comm_destroy(t1k_comm *c) {
   if (!c) return;
-  if (c->nccl) (void)rccl()->CommDestroy(c->nccl);
+  if (c->nccl) { (void)rccl()->CommDestroy(c->nccl); (void)hipGetLastError(); }
   if (c->ctx) (void)hipSetDevice(c->ctx->device);
   if (c->tmp.p) (void)t1k_dev_free(c->tmp.p);
   if (c->ptrs.p) (void)t1k_dev_free(c->ptrs.p);

@@ -10,6 +10,7 @@
 
 int t1k_sort_pairs(t1k_ctx *ctx, const unsigned long long *keysIn, unsigned long long *keysOut, const uint32_t *valsIn, uint32_t *valsOut, uint32_t n, int endBit) {
   if (!n) return T1K_OK;
+  (void)hipGetLastError();  // rocPRIM reports the thread's last HIP error after its launches: a stale one (left by another library, e.g. RCCL's device probing) is not ours
   size_t bytes = 0;
   T1K_HIP(ctx, rocprim::radix_sort_pairs(nullptr, bytes, keysIn, keysOut, valsIn, valsOut, (size_t)n, 0u, (unsigned)endBit, ctx->stream));
   int rc = t1k_ensure(ctx, ctx->bSortTmp, bytes + 256);
@@ -20,6 +21,7 @@ int t1k_sort_pairs(t1k_ctx *ctx, const unsigned long long *keysIn, unsigned long
 
 int t1k_inclusive_sum(t1k_ctx *ctx, const uint32_t *in, uint32_t *out, uint32_t n) {
   if (!n) return T1K_OK;
+  (void)hipGetLastError();  // rocPRIM reports the thread's last HIP error after its launches: a stale one (left by another library, e.g. RCCL's device probing) is not ours
   size_t bytes = 0;
   T1K_HIP(ctx, rocprim::inclusive_scan(nullptr, bytes, in, out, (size_t)n, rocprim::plus<uint32_t>(), ctx->stream));
   int rc = t1k_ensure(ctx, ctx->bSortTmp, bytes + 256);
@@ -30,6 +32,7 @@ int t1k_inclusive_sum(t1k_ctx *ctx, const uint32_t *in, uint32_t *out, uint32_t 
 
 int t1k_exclusive_sum64(t1k_ctx *ctx, const uint32_t *in, unsigned long long *out, uint32_t n) {
   if (!n) return T1K_OK;
+  (void)hipGetLastError();  // rocPRIM reports the thread's last HIP error after its launches: a stale one (left by another library, e.g. RCCL's device probing) is not ours
   size_t bytes = 0;
   T1K_HIP(ctx, rocprim::exclusive_scan(nullptr, bytes, in, out, 0ull, (size_t)n, rocprim::plus<unsigned long long>(), ctx->stream));
   int rc = t1k_ensure(ctx, ctx->bSortTmp, bytes + 256);
@@ -40,6 +43,7 @@ int t1k_exclusive_sum64(t1k_ctx *ctx, const uint32_t *in, unsigned long long *ou
 
 int t1k_inclusive_sum_n(t1k_ctx *ctx, const uint32_t *in, uint32_t *out, uint64_t n) {
   if (!n) return T1K_OK;
+  (void)hipGetLastError();  // rocPRIM reports the thread's last HIP error after its launches: a stale one (left by another library, e.g. RCCL's device probing) is not ours
   size_t bytes = 0;
   T1K_HIP(ctx, rocprim::inclusive_scan(nullptr, bytes, in, out, (size_t)n, rocprim::plus<uint32_t>(), ctx->stream));
   int rc = t1k_ensure(ctx, ctx->bSortTmp, bytes + 256);
@@ -51,6 +55,7 @@ int t1k_inclusive_sum_n(t1k_ctx *ctx, const uint32_t *in, uint32_t *out, uint64_
 // in == out is allowed (every tile is read before it is written)
 int t1k_exclusive_sum32(t1k_ctx *ctx, const uint32_t *in, uint32_t *out, uint64_t n) {
   if (!n) return T1K_OK;
+  (void)hipGetLastError();  // rocPRIM reports the thread's last HIP error after its launches: a stale one (left by another library, e.g. RCCL's device probing) is not ours
   size_t bytes = 0;
   T1K_HIP(ctx, rocprim::exclusive_scan(nullptr, bytes, in, out, 0u, (size_t)n, rocprim::plus<uint32_t>(), ctx->stream));
   int rc = t1k_ensure(ctx, ctx->bSortTmp, bytes + 256);
@@ -61,6 +66,7 @@ int t1k_exclusive_sum32(t1k_ctx *ctx, const uint32_t *in, uint32_t *out, uint64_
 
 int t1k_exclusive_sum_u64(t1k_ctx *ctx, const unsigned long long *in, unsigned long long *out, uint64_t n) {
   if (!n) return T1K_OK;
+  (void)hipGetLastError();  // rocPRIM reports the thread's last HIP error after its launches: a stale one (left by another library, e.g. RCCL's device probing) is not ours
   size_t bytes = 0;
   T1K_HIP(ctx, rocprim::exclusive_scan(nullptr, bytes, in, out, 0ull, (size_t)n, rocprim::plus<unsigned long long>(), ctx->stream));
   int rc = t1k_ensure(ctx, ctx->bSortTmp, bytes + 256);
