@@ -16,6 +16,9 @@
 //      does not depend on how the fragments were batched, on the number of pipelines or (with the exchange of t1k_comm.hip) of GPUs.
 // Integer / float-add work bound by HBM latency; no MFMA.
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include "t1k_dev.h"
 #include "t1k_launch.h"
@@ -80,8 +83,19 @@ __device__ __forceinline__ void foldEntry(T1kGroupEnt &g, const t1k_row_entry &e
   g.adjustWeight += e.adjust_weight;
 }
 
+// address of every sorted fragment's row (one dependent load less in the sequential fold below)
+__global__ void k_co_ptrs(const uint32_t *idx, const unsigned long long *rowPtr, unsigned long long *ptrSorted, uint32_t m) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < m) ptrSorted[j] = rowPtr[idx[j]];
+}
+
+// One wavefront per (group, 64 slots): lane q folds slot q of the group's fragments in fragment order.  A group's chain is sequential
+// (float sums and the `end` rule), and the largest groups hold 10^6 fragments, so the loop is software-pipelined: while batch b is
+// folded, the rows of batch b + 1 are in flight and the row addresses of batch b + 2 are being fetched (they are uniform over the
+// wavefront and consecutive in memory).
+#define CO_B 16
 __global__ __launch_bounds__(256) void k_co_reduce(const uint32_t *tileGroup, const unsigned long long *tilePtr, const uint32_t *order, const uint32_t *runStart,
-                                                   const uint32_t *idx, const unsigned long long *rowPtr, const uint32_t *gSize, const unsigned long long *groupPtr,
+                                                   const unsigned long long *ptrSorted, const uint32_t *gSize, const unsigned long long *groupPtr,
                                                    T1kGroupEnt *out, uint64_t nTiles) {
   const uint64_t tile = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (tile >= nTiles) return;
@@ -92,33 +106,47 @@ __global__ __launch_bounds__(256) void k_co_reduce(const uint32_t *tileGroup, co
   const uint32_t run = order[g];
   const uint32_t j0 = runStart[run], j1 = runStart[run + 1];
   if (q >= n) return;
-  const t1k_row_entry first = ((const t1k_row_entry *)rowPtr[idx[j0]])[q];
+  const t1k_row_entry first = ((const t1k_row_entry *)ptrSorted[j0])[q];
   T1kGroupEnt acc{first.allele_idx, first.start, first.end, first.weight, first.adjust_weight};
+  auto fold = [&](const int4 &e) {  // Genotyper.hpp:887-897 (qual == 1 always): x = start, y = end, z = weight, w = adjust weight
+    if (e.x < acc.start) acc.start = e.x;
+    if (e.y < acc.end) acc.end = e.x;  // sic
+    acc.weight += __int_as_float(e.z);
+    acc.adjustWeight += __int_as_float(e.w);
+  };
+  auto rowOf = [&](unsigned long long p) {
+    const t1k_row_entry *r = (const t1k_row_entry *)p + q;
+    return int4{r->start, r->end, __float_as_int(r->weight), __float_as_int(r->adjust_weight)};
+  };
   uint32_t j = j0 + 1;
-  // A group's chain is sequential (float sums and the `end` rule in fragment order) and the largest groups hold 10^6 fragments: keep
-  // thirty-two independent row loads in flight per lane (the row addresses are uniform over the wavefront), fold them in order.
-  for (; j + 32 <= j1; j += 32) {
-    int4 e[32];  // start, end, weight, adjust_weight: bytes 4..11 and 12..15, 20..23 of the entry
+  if (j + 2 * CO_B <= j1) {
+    unsigned long long pNext[CO_B];
+    int4 eCur[CO_B];
 #pragma unroll
-    for (int u = 0; u < 32; ++u) {
-      const t1k_row_entry *r = (const t1k_row_entry *)rowPtr[idx[j + u]] + q;
-      e[u] = int4{r->start, r->end, __float_as_int(r->weight), __float_as_int(r->adjust_weight)};
+    for (int u = 0; u < CO_B; ++u) eCur[u] = rowOf(ptrSorted[j + u]);
+#pragma unroll
+    for (int u = 0; u < CO_B; ++u) pNext[u] = ptrSorted[j + CO_B + u];
+    j += CO_B;  // eCur holds batch [j - CO_B, j), pNext the addresses of [j, j + CO_B)
+    while (j + CO_B <= j1) {
+      int4 eNext[CO_B];
+#pragma unroll
+      for (int u = 0; u < CO_B; ++u) eNext[u] = rowOf(pNext[u]);
+      const bool more = j + 2 * CO_B <= j1;
+      if (more) {
+#pragma unroll
+        for (int u = 0; u < CO_B; ++u) pNext[u] = ptrSorted[j + CO_B + u];
+      }
+#pragma unroll
+      for (int u = 0; u < CO_B; ++u) fold(eCur[u]);
+#pragma unroll
+      for (int u = 0; u < CO_B; ++u) eCur[u] = eNext[u];
+      j += CO_B;
+      if (!more) break;
     }
 #pragma unroll
-    for (int u = 0; u < 32; ++u) {
-      if (e[u].x < acc.start) acc.start = e[u].x;
-      if (e[u].y < acc.end) acc.end = e[u].x;  // sic (Genotyper.hpp:893-894)
-      acc.weight += __int_as_float(e[u].z);
-      acc.adjustWeight += __int_as_float(e[u].w);
-    }
+    for (int u = 0; u < CO_B; ++u) fold(eCur[u]);  // the batch [j - CO_B, j)
   }
-  for (; j + 4 <= j1; j += 4) {
-    const t1k_row_entry *r0 = (const t1k_row_entry *)rowPtr[idx[j]], *r1 = (const t1k_row_entry *)rowPtr[idx[j + 1]],
-                        *r2 = (const t1k_row_entry *)rowPtr[idx[j + 2]], *r3 = (const t1k_row_entry *)rowPtr[idx[j + 3]];
-    const t1k_row_entry e0 = r0[q], e1 = r1[q], e2 = r2[q], e3 = r3[q];
-    foldEntry(acc, e0); foldEntry(acc, e1); foldEntry(acc, e2); foldEntry(acc, e3);
-  }
-  for (; j < j1; ++j) { const t1k_row_entry e = ((const t1k_row_entry *)rowPtr[idx[j]])[q]; foldEntry(acc, e); }
+  for (; j < j1; ++j) fold(rowOf(ptrSorted[j]));
   out[groupPtr[g] + q] = acc;
 }
 
@@ -215,6 +243,15 @@ int t1k_rowset_coalesce(t1k_rowset *rs, uint64_t *nGroups, uint64_t *nEntries, u
   if (F == 0) return T1K_OK;
   int rc;
   auto fail = [&](int code) { rs->err = ctx->err; return code; };
+  const bool dbg = getenv("T1K_DEBUG_PHASES") != nullptr;
+  auto tLap = std::chrono::steady_clock::now();
+  auto lap = [&](const char *what) {
+    if (!dbg) return;
+    (void)hipStreamSynchronize(st);
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "[t1k] coalesce %s: %.1f ms\n", what, std::chrono::duration<double, std::milli>(now - tLap).count());
+    tLap = now;
+  };
   // work area: u32 arrays a0..a5 [F+2], u64 arrays k0, k1 [F+1]
   const size_t n4 = ((size_t)(F + 2) * 4 + 255) & ~(size_t)255, n8 = ((size_t)(F + 2) * 8 + 255) & ~(size_t)255;
   if ((rc = t1k_ensure(ctx, rs->bWork, 8 * n4 + 3 * n8))) return fail(rc);
@@ -239,6 +276,7 @@ int t1k_rowset_coalesce(t1k_rowset *rs, uint64_t *nGroups, uint64_t *nEntries, u
   hipLaunchKernelGGL(k_co_gather_key, dim3(nbM), dim3(256), 0, st, a3, rs->h1, k0, M);
   if ((rc = t1k_sort_pairs(ctx, k0, k1, a3, a2, M))) return fail(rc);                       // a2 = ids ordered by (h1, h2, fragment), k1 = sorted h1
   uint32_t *idx = a2;
+  lap("compaction + two radix sorts");
   // 3. run heads
   hipLaunchKernelGGL(k_co_mark, dim3(nbM), dim3(256), 0, st, idx, k1, rs->h2, rs->rowPtr, rs->rowCount, a0, M);
   if ((rc = t1k_inclusive_sum(ctx, a0, a1, M))) return fail(rc);                            // a0 = head flags, a1 = 1-based run of each position
@@ -270,10 +308,14 @@ int t1k_rowset_coalesce(t1k_rowset *rs, uint64_t *nGroups, uint64_t *nEntries, u
   uint32_t *tileGroup = (uint32_t *)rs->bGroupFirst.p + (G + 1);
   RS_HIP(hipMemcpyAsync(rs->bGroupFirst.p, gFirst, (size_t)G * 4, hipMemcpyDeviceToDevice, st));
   hipLaunchKernelGGL(k_co_tilemap, dim3(nbG), dim3(256), 0, st, tilePtr, gTiles, tileGroup, G);
+  lap("run heads, group order, offsets");
   // 5. fold every (group, slot) in fragment order
-  hipLaunchKernelGGL(k_co_reduce, dim3((unsigned)((nTiles + 3) / 4)), dim3(256), 0, st, tileGroup, tilePtr, order, runStart, idx, rs->rowPtr, gSize, groupPtr,
+  unsigned long long *ptrSorted = k1;  // the sorted hash words are no longer needed
+  hipLaunchKernelGGL(k_co_ptrs, dim3(nbM), dim3(256), 0, st, idx, rs->rowPtr, ptrSorted, M);
+  hipLaunchKernelGGL(k_co_reduce, dim3((unsigned)((nTiles + 3) / 4)), dim3(256), 0, st, tileGroup, tilePtr, order, runStart, ptrSorted, gSize, groupPtr,
                      (T1kGroupEnt *)rs->bGroupEnt.p, nTiles);
   RS_HIP(hipStreamSynchronize(st));
+  lap("k_co_reduce");
   rs->nGroups = G; rs->nEntries = N;
   if (nGroups) *nGroups = G;
   if (nEntries) *nEntries = N;

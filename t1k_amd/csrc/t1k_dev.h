@@ -85,7 +85,9 @@ __host__ __device__ __forceinline__ T1kOvl t1k_ovl_unpack(const T1kOvlP &p) {
   return o;
 }
 
+#ifndef T1K_SEED_CHUNK
 #define T1K_SEED_CHUNK 512    // alleles per seeding chunk (k_seed_groups): accumulators of one chunk live in LDS
+#endif
 #define T1K_DIR_MINLEN 32     // posting lists longer than this get a chunk directory
 #define T1K_NO_DIR 0xFFFFFFFFu
 struct T1kRefDev {
@@ -595,7 +597,9 @@ enum { T1K_STAT_DP = 0, T1K_STAT_FAST = 1, T1K_STAT_GENERAL = 2, T1K_STAT_EXTEND
 // again by k_arena_compact before their consumer runs; group records are consumed segment by segment.
 // latency-bound kernels: let the register allocator aim for 8 wavefronts per SIMD (<= 64 VGPRs; a few spills are cheaper than
 // half the occupancy -- measured per kernel)
+#ifndef T1K_OCC8
 #define T1K_OCC8 __attribute__((amdgpu_waves_per_eu(8)))
+#endif
 #define T1K_NSTRIPE 32
 enum { T1K_AR_GROUPS = 0, T1K_AR_JOBS, T1K_AR_RETRY, T1K_AR_FINISH, T1K_AR_GENERAL, T1K_AR_BIG, T1K_AR_GENCAND, T1K_AR_EQ, T1K_AR_BAND, T1K_AR_WIDE, T1K_AR_GENHITS, T1K_AR_GENJOBS, T1K_AR_WAVE, T1K_AR_EXTJOBS, T1K_AR_EXTRETRY, T1K_AR_SLOW, T1K_NARENA };
 #define T1K_ARENA_BASE (64 + T1K_STAT_STRIPES * 8)
