@@ -155,15 +155,13 @@ def main():
 
     def step():
         job = t1k_amd.Job(ref, ref_seq_similarity=0.97, device=local_rank)
-        job.load_reads(pfx + "_1.fq", pfx + "_2.fq")
         if comm is not None:
             comm.bind(job)
-            job.set_shard(rank, world, comm)
-        if rank == 0:
-            job.set_output_prefix(out_prefix)   # as the executable does: the aligned-read files are written while the EM runs
+            job.set_shard(rank, world, comm)    # before the reads: a rank indexes only its own fragments of the files (host/reads.cpp)
+        job.load_reads(pfx + "_1.fq", pfx + "_2.fq")
+        job.set_output_prefix(out_prefix)       # as the executable does: the aligned-read files are written while the EM runs
         job.run()
-        if rank == 0:
-            job.write_outputs(out_prefix)
+        job.write_outputs(out_prefix)           # rank 0: the two tables; every rank: its own part of the aligned-read files
         last["stats"] = job.stats()
         last["counts"] = job.counts()
         last["text"] = job.genotype_text()

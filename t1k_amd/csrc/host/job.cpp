@@ -1,5 +1,6 @@
 // t1k_amd/csrc/host/job.cpp -- the whole genotyper stage as a job: the t1k_job_* C ABI and t1k_genotyper_main(), the
 // argv-compatible replacement of the reference's genotyper executable (Genotyper.cpp:194-738, invoked by run-t1k:430,434).
+#include <fcntl.h>
 #include <getopt.h>
 #include <unistd.h>
 #include <atomic>
@@ -171,9 +172,22 @@ int t1k_job_load_reads_multi(t1k_job *job, const char *const *files1, uint32_t n
   job->ran = false; job->localDone = false;
   std::vector<std::string> f1(files1, files1 + n1), f2;
   if (files2) f2.assign(files2, files2 + n2);
-  if (!job->in->open(f1, f2, barcodeFile ? barcodeFile : "", hostThreads(job), job->err)) { job->in.reset(); return T1K_ERR_IO; }
+  bool whole = true;
+  if (job->nRanks > 1 && job->comm && !(barcodeFile && *barcodeFile) && !getenv("T1K_NO_SHARDED_INPUT")) {
+    // a rank of a sharded job (t1k_job_set_shard came first): index this rank's fragments only -- collective over the communicator
+    ReadInput::ShardComm sc;
+    sc.rank = job->rank; sc.nRanks = job->nRanks;
+    t1k_comm *comm = job->comm;
+    sc.allgatherv = [comm](void *buf, const uint64_t *bytes, const uint64_t *displ, uint64_t total) { return t1k_comm_allgatherv_host(comm, buf, bytes, displ, total) == T1K_OK; };
+    const int r = job->in->openSharded(f1, f2, hostThreads(job), sc, job->err);
+    if (r < 0) { job->in.reset(); return T1K_ERR_IO; }
+    if (r > 0) whole = false;
+    else job->in.reset(new ReadInput());
+  }
+  if (whole && !job->in->open(f1, f2, barcodeFile ? barcodeFile : "", hostThreads(job), job->err)) { job->in.reset(); return T1K_ERR_IO; }
   job->msLoad = nowMs() - t0;
-  if (getenv("T1K_DEBUG_PHASES")) fprintf(stderr, "[t1k job] read files mapped + indexed: %zu fragments, %.1f ms\n", job->in->nFrag(), job->msLoad);
+  if (getenv("T1K_DEBUG_PHASES"))
+    fprintf(stderr, "[t1k job] read files mapped + indexed: %zu of %zu fragments, %.1f ms\n", job->in->nFrag(), job->in->nAll(), job->msLoad);
   return T1K_OK;
 }
 
@@ -268,9 +282,12 @@ int t1k_job_run_local(t1k_job *job) {
   gt.groupPtr.assign(1, 0); gt.groupEnt.clear(); gt.groupFirst.clear(); gt.groupOfHash.clear(); gt.assignedFragments = 0; gt.emIterations = 0;
   gt.readLength = in.maxLen;  // Genotyper.cpp:443
   for (auto &a : job->ref.al) { a.rank = -1; a.quality = -1; a.abundance = a.ecAbundance = 0; a.ec = -1; a.missingCov = 0; }
-  const uint32_t Fall = (uint32_t)in.nFrag();
+  const uint32_t Fall = (uint32_t)in.nAll();
   const uint32_t fBeg = (uint32_t)((uint64_t)Fall * job->rank / job->nRanks), fEnd = (uint32_t)((uint64_t)Fall * (job->rank + 1) / job->nRanks);
   const uint32_t F = fEnd - fBeg;  // this rank's fragments; local index f <-> fragment fBeg + f of the input
+  if (in.sharded && (in.shardRank != job->rank || in.shardRanks != job->nRanks || in.base != fBeg || in.nFrag() != F))
+    return jobFail(job, T1K_ERR_STATE, "the reads were loaded for another shard than the one this job runs as");
+  const uint32_t inBase = in.base;  // fragment f of the input = record in.frag[f - inBase] held here
   const uint32_t per = in.paired ? 2 : 1;
   job->fragAssigned.assign(Fall, 0);
   if (job->nRanks > 1 && job->prm.output_read_assignment) return jobFail(job, T1K_ERR_ARG, "--outputReadAssignment is not available when the job is sharded over several GPUs");
@@ -341,7 +358,7 @@ int t1k_job_run_local(t1k_job *job) {
       parallelRanges(nf, T, [&](int t, size_t b, size_t e) {
         uint64_t run = 0;
         for (size_t i = b; i < e; ++i) {
-          const uint32_t r = in.frag[fBeg + W.f0 + i];
+          const uint32_t r = in.frag[fBeg - inBase + W.f0 + i];
           for (uint32_t m = 0; m < per; ++m) { off[i * per + m] = run; run += in.side[m].seqL[r]; }
         }
         pieceBytes[t + 1] = run;
@@ -352,7 +369,7 @@ int t1k_job_run_local(t1k_job *job) {
       parallelRanges(nf, T, [&](int t, size_t b, size_t e) {
         const uint64_t carry = pieceBytes[t];
         for (size_t i = b; i < e; ++i) {
-          const uint32_t r = in.frag[fBeg + W.f0 + i];
+          const uint32_t r = in.frag[fBeg - inBase + W.f0 + i];
           bool n = false;
           for (uint32_t m = 0; m < per; ++m) {
             const uint32_t len = in.side[m].seqL[r];
@@ -502,7 +519,7 @@ int t1k_job_run_local(t1k_job *job) {
       if (total && (rc = t1k_rowset_rows_download(job->rows, f0, n, cnt.data(), rows.data(), total, &total)) != T1K_OK) return jobFail(job, rc, t1k_rowset_last_error(job->rows));
       uint64_t p = 0;
       for (uint32_t i = 0; i < n; ++i) {
-        const uint32_t r = in.frag[fBeg + f0 + i];
+        const uint32_t r = in.frag[fBeg - inBase + f0 + i];
         const std::string id = in.noIds ? "r" + std::to_string(fBeg + f0 + i) : std::string(in.side[0].idP[r], in.side[0].idL[r]);
         for (uint32_t j = 0; j < cnt[i]; ++j, ++p) {
           job->assignText += id; job->assignText += '\t'; job->assignText += job->ref.al[rows[p].allele_idx].name;
@@ -535,9 +552,11 @@ int t1k_job_run_local(t1k_job *job) {
     gt.setGroupsMerged(sizes, ents, first);
     // fragmentAssigned of every rank's slice on every rank (rank 0 writes the *_aligned*.fa files)
     if ((rc = t1k_rowset_assigned_download(job->rows, job->fragAssigned.data() + fBeg)) != T1K_OK) return jobFail(job, rc, t1k_rowset_last_error(job->rows));
-    std::vector<uint64_t> bytes(job->nRanks), displ(job->nRanks);
-    for (int r = 0; r < job->nRanks; ++r) { displ[r] = (uint64_t)Fall * r / job->nRanks; bytes[r] = (uint64_t)Fall * (r + 1) / job->nRanks - displ[r]; }
-    if ((rc = t1k_comm_allgatherv_host(job->comm, job->fragAssigned.data(), bytes.data(), displ.data(), Fall)) != T1K_OK) return jobFail(job, rc, t1k_comm_last_error(job->comm));
+    if (!in.sharded) {  // (ranks that indexed only their own reads write only their own part of the files)
+      std::vector<uint64_t> bytes(job->nRanks), displ(job->nRanks);
+      for (int r = 0; r < job->nRanks; ++r) { displ[r] = (uint64_t)Fall * r / job->nRanks; bytes[r] = (uint64_t)Fall * (r + 1) / job->nRanks - displ[r]; }
+      if ((rc = t1k_comm_allgatherv_host(job->comm, job->fragAssigned.data(), bytes.data(), displ.data(), Fall)) != T1K_OK) return jobFail(job, rc, t1k_comm_last_error(job->comm));
+    }
   }
   gt.assignedFragments = assigned;
   job->stats.read_ends_total = job->readEnds;
@@ -558,7 +577,122 @@ int t1k_job_run_local(t1k_job *job) {
   return T1K_OK;
 }
 
-static bool writeAlignedFiles(t1k_job *job, const std::string &pfx);
+// ">id\nSEQ\n" of every assigned fragment (Genotyper.cpp:680-718), formatted by the host threads straight from the mapped input and
+// written with pwrite at precomputed offsets; what = 0 / 1: the mate's sequence, 2: the barcode.
+// Two steps: the plan (bytes per host-thread piece; for ranks that each indexed their own reads also the rank's offset in the
+// shared file -- one small all-gather, and rank 0 creates the file before it) and the writing itself, which needs no communication
+// and so may run beside the EM.
+namespace {
+struct AlignedPlan {
+  std::string path;
+  int what = 0, T = 1;
+  std::vector<uint64_t> pieceBytes;  // exclusive prefix over the T pieces of this rank's fragments
+  uint64_t baseOffset = 0;           // of this rank's part in the file
+  bool create = true;                // this rank truncates / creates the file (done in the plan step when the job's input is sharded)
+};
+}  // namespace
+
+static bool planAligned(t1k_job *job, AlignedPlan &pl) {
+  const ReadInput &in = *job->in;
+  const uint32_t F = (uint32_t)in.nFrag(), base = in.base;
+  const int T = pl.T;
+  const ReadInput::Side &seqSide = pl.what == 2 ? in.bc : in.side[pl.what];
+  const ReadInput::Side &idSide = pl.what == 1 ? in.side[1] : in.side[0];  // the barcode file carries mate 1's name (Genotyper.cpp:709-718)
+  pl.pieceBytes.assign(T + 2, 0);
+  parallelRanges(F, T, [&](int t, size_t b, size_t e) {
+    uint64_t run = 0;
+    char tmp[32];
+    for (size_t f = b; f < e; ++f)
+      if (job->fragAssigned[base + f]) {
+        const uint32_t r = in.frag[f];
+        run += 3 + (in.noIds ? (size_t)snprintf(tmp, 32, "r%u", (uint32_t)(base + f)) : (size_t)idSide.idL[r]) + seqSide.seqL[r];
+      }
+    pl.pieceBytes[t + 1] = run;
+  });
+  for (int t = 0; t < T + 1; ++t) pl.pieceBytes[t + 1] += pl.pieceBytes[t];
+  pl.baseOffset = 0; pl.create = true;
+  if (in.sharded) {
+    pl.create = false;
+    if (job->rank == 0) {
+      FILE *fp = fopen(pl.path.c_str(), "w");
+      if (!fp) { job->err = "cannot write " + pl.path; return false; }
+      fclose(fp);
+    }
+    std::vector<uint64_t> sizes(job->nRanks, 0), bytes(job->nRanks, 8), displ(job->nRanks);
+    for (int r = 0; r < job->nRanks; ++r) displ[r] = 8 * (uint64_t)r;
+    sizes[job->rank] = pl.pieceBytes[T];
+    if (t1k_comm_allgatherv_host(job->comm, sizes.data(), bytes.data(), displ.data(), 8 * (uint64_t)job->nRanks) != T1K_OK) { job->err = t1k_comm_last_error(job->comm); return false; }
+    for (int r = 0; r < job->rank; ++r) pl.baseOffset += sizes[r];
+  }
+  return true;
+}
+
+static bool writeAligned(t1k_job *job, const AlignedPlan &pl) {
+  const ReadInput &in = *job->in;
+  const uint32_t F = (uint32_t)in.nFrag(), base = in.base;
+  const int fd = ::open(pl.path.c_str(), pl.create ? (O_WRONLY | O_CREAT | O_TRUNC) : O_WRONLY, 0644);
+  if (fd < 0) { job->err = "cannot write " + pl.path; return false; }
+  const ReadInput::Side &seqSide = pl.what == 2 ? in.bc : in.side[pl.what];
+  const ReadInput::Side &idSide = pl.what == 1 ? in.side[1] : in.side[0];
+  std::atomic<bool> ok{true};
+  parallelRanges(F, pl.T, [&](int t, size_t b, size_t e) {
+    uint64_t at = pl.baseOffset + pl.pieceBytes[t];
+    std::vector<char> buf;
+    buf.reserve(8u << 20);
+    char tmp[32];
+    auto flush = [&] {
+      size_t done = 0;
+      while (done < buf.size()) {
+        ssize_t w = pwrite(fd, buf.data() + done, buf.size() - done, (off_t)(at + done));
+        if (w <= 0) { ok = false; break; }
+        done += (size_t)w;
+      }
+      at += buf.size();
+      buf.clear();
+    };
+    for (size_t f = b; f < e; ++f) {
+      if (!job->fragAssigned[base + f]) continue;
+      const uint32_t r = in.frag[f];
+      buf.push_back('>');
+      if (in.noIds) { const int n = snprintf(tmp, 32, "r%u", (uint32_t)(base + f)); buf.insert(buf.end(), tmp, tmp + n); }
+      else buf.insert(buf.end(), idSide.idP[r], idSide.idP[r] + idSide.idL[r]);
+      buf.push_back('\n');
+      buf.insert(buf.end(), seqSide.seqP[r], seqSide.seqP[r] + seqSide.seqL[r]); buf.push_back('\n');
+      if (buf.size() > (7u << 20)) flush();
+    }
+    flush();
+  });
+  ::close(fd);
+  if (!ok) { job->err = "cannot write " + pl.path; return false; }
+  return true;
+}
+
+// reads with at least one fragment assignment (Genotyper.cpp:680-718): the mates' files and the barcode file
+static bool planAlignedFiles(t1k_job *job, const std::string &pfx, std::vector<AlignedPlan> &plans) {
+  const int T = hostThreads(job);
+  const bool paired = job->in->paired;
+  const int per = std::max(1, T / (1 + (paired ? 1 : 0) + (job->in->hasBarcode ? 1 : 0)));
+  plans.clear();
+  auto add = [&](const std::string &path, int what) { AlignedPlan pl; pl.path = path; pl.what = what; pl.T = per; plans.push_back(pl); };
+  add(paired ? pfx + "_aligned_1.fa" : pfx + "_aligned.fa", 0);
+  if (paired) add(pfx + "_aligned_2.fa", 1);
+  if (job->in->hasBarcode) add(pfx + "_aligned_bc.fa", 2);
+  for (auto &pl : plans)
+    if (!planAligned(job, pl)) return false;
+  return true;
+}
+static bool writePlannedFiles(t1k_job *job, const std::vector<AlignedPlan> &plans) {
+  std::vector<char> ok(plans.size(), 1);
+  std::vector<std::thread> th;
+  for (size_t i = 1; i < plans.size(); ++i) th.emplace_back([&, i] { ok[i] = writeAligned(job, plans[i]) ? 1 : 0; });
+  ok[0] = writeAligned(job, plans[0]) ? 1 : 0;
+  for (auto &t : th) t.join();
+  for (char o : ok) if (!o) return false;
+  return true;
+}
+// who writes: rank 0 when every rank holds the whole input; every rank its own part when each indexed only its own reads
+static bool writesAligned(const t1k_job *job) { return job->rank == 0 || (job->in && job->in->sharded); }
+
 
 int t1k_job_set_output_prefix(t1k_job *job, const char *prefix) {
   if (!job) return T1K_ERR_ARG;
@@ -570,9 +704,11 @@ int t1k_job_finish(t1k_job *job, uint64_t emGroupBegin, uint64_t emGroupEnd) {
   if (!job || !job->ctx || !job->localDone) return jobFail(job, T1K_ERR_STATE, "t1k_job_finish: t1k_job_run_local has not completed");
   if (job->bgWriter.joinable()) job->bgWriter.join();
   job->bgStarted = false; job->bgOk = true;
-  if (!job->outPrefix.empty() && job->rank == 0 && !job->analyzer) {  // the flags are final: start on the big files now
+  if (!job->outPrefix.empty() && writesAligned(job) && !job->analyzer) {  // the flags are final: start on the big files now
+    std::vector<AlignedPlan> plans;
+    if (!planAlignedFiles(job, job->outPrefix, plans)) return T1K_ERR_IO;
     job->bgStarted = true;
-    job->bgWriter = std::thread([job] { job->bgOk = writeAlignedFiles(job, job->outPrefix); });
+    job->bgWriter = std::thread([job, plans] { job->bgOk = writePlannedFiles(job, plans); });
   }
   Genotyper &gt = job->gt;
   int rc;
@@ -681,7 +817,7 @@ int t1k_job_genotype_text(t1k_job *job, char *buf, uint64_t cap, uint64_t *neede
 
 int t1k_job_counts(t1k_job *job, uint64_t *fragments, uint64_t *assignedFragments, uint64_t *groups, uint64_t *ecs, int32_t *emIterations) {
   if (!job) return T1K_ERR_ARG;
-  if (fragments) *fragments = job->in ? job->in->nFrag() : 0;
+  if (fragments) *fragments = job->in ? job->in->nAll() : 0;
   if (assignedFragments) *assignedFragments = job->gt.assignedFragments;
   if (groups) *groups = job->gt.nGroups();
   if (ecs) *ecs = job->gt.ecAlleles.size();
@@ -703,92 +839,27 @@ static bool writeText(const std::string &path, const std::string &text, std::str
   return true;
 }
 
-// ">id\nSEQ\n" of every assigned fragment (Genotyper.cpp:680-718), formatted by the host threads straight from the mapped input and
-// written with pwrite at precomputed offsets; what = 0 / 1: the mate's sequence, 2: the barcode
-static bool writeAligned(t1k_job *job, const std::string &path, int what, int T) {
-  const ReadInput &in = *job->in;
-  const uint32_t F = (uint32_t)in.nFrag();
-  FILE *fp = fopen(path.c_str(), "w");
-  if (!fp) { job->err = "cannot write " + path; return false; }
-  const int fd = fileno(fp);
-  const ReadInput::Side &seqSide = what == 2 ? in.bc : in.side[what];
-  const ReadInput::Side &idSide = what == 1 ? in.side[1] : in.side[0];  // the barcode file carries mate 1's name (Genotyper.cpp:709-718)
-  auto idOf = [&](uint32_t f, char *tmp) -> std::pair<const char *, size_t> {
-    if (in.noIds) { int n = snprintf(tmp, 32, "r%u", f); return {tmp, (size_t)n}; }
-    const uint32_t r = in.frag[f];
-    return {idSide.idP[r], idSide.idL[r]};
-  };
-  std::vector<uint64_t> pieceBytes(T + 2, 0);
-  parallelRanges(F, T, [&](int t, size_t b, size_t e) {
-    uint64_t run = 0;
-    char tmp[32];
-    for (size_t f = b; f < e; ++f)
-      if (job->fragAssigned[f]) run += 3 + idOf((uint32_t)f, tmp).second + seqSide.seqL[in.frag[f]];
-    pieceBytes[t + 1] = run;
-  });
-  for (int t = 0; t < T + 1; ++t) pieceBytes[t + 1] += pieceBytes[t];
-  std::atomic<bool> ok{true};
-  parallelRanges(F, T, [&](int t, size_t b, size_t e) {
-    uint64_t at = pieceBytes[t];
-    std::vector<char> buf;
-    buf.reserve(8u << 20);
-    char tmp[32];
-    auto flush = [&] {
-      size_t done = 0;
-      while (done < buf.size()) {
-        ssize_t w = pwrite(fd, buf.data() + done, buf.size() - done, (off_t)(at + done));
-        if (w <= 0) { ok = false; break; }
-        done += (size_t)w;
-      }
-      at += buf.size();
-      buf.clear();
-    };
-    for (size_t f = b; f < e; ++f) {
-      if (!job->fragAssigned[f]) continue;
-      const auto id = idOf((uint32_t)f, tmp);
-      const uint32_t r = in.frag[f];
-      buf.push_back('>'); buf.insert(buf.end(), id.first, id.first + id.second); buf.push_back('\n');
-      buf.insert(buf.end(), seqSide.seqP[r], seqSide.seqP[r] + seqSide.seqL[r]); buf.push_back('\n');
-      if (buf.size() > (7u << 20)) flush();
-    }
-    flush();
-  });
-  fclose(fp);
-  if (!ok) { job->err = "cannot write " + path; return false; }
-  return true;
-}
-
-// reads with at least one fragment assignment (Genotyper.cpp:680-718): the mates' files and the barcode file side by side
-static bool writeAlignedFiles(t1k_job *job, const std::string &pfx) {
-  const int T = hostThreads(job);
-  const bool paired = job->in->paired;
-  bool ok1 = true, ok2 = true, ok3 = true;
-  std::thread t2, t3;
-  const int per = std::max(1, T / (1 + (paired ? 1 : 0) + (job->in->hasBarcode ? 1 : 0)));
-  if (paired) t2 = std::thread([&] { ok2 = writeAligned(job, pfx + "_aligned_2.fa", 1, per); });
-  if (job->in->hasBarcode) t3 = std::thread([&] { ok3 = writeAligned(job, pfx + "_aligned_bc.fa", 2, per); });
-  ok1 = writeAligned(job, paired ? pfx + "_aligned_1.fa" : pfx + "_aligned.fa", 0, per);
-  if (t2.joinable()) t2.join();
-  if (t3.joinable()) t3.join();
-  return ok1 && ok2 && ok3;
-}
-
 int t1k_job_write_outputs(t1k_job *job, const char *prefix) {
   if (!job || !prefix || !job->ran || !job->in) return T1K_ERR_STATE;
   const double t0 = nowMs();
   const std::string pfx = prefix;
-  std::string s;
-  for (size_t g = 0; g < job->ref.geneName.size(); ++g) s += job->gt.geneLine((int)g);
-  if (!writeText(pfx + "_genotype.tsv", s, job->err)) return T1K_ERR_IO;
-  if (!writeText(pfx + "_allele.tsv", job->gt.alleleLines(), job->err)) return T1K_ERR_IO;
-  if (job->prm.output_read_assignment && !writeText(pfx + "_assign.tsv", job->assignText, job->err)) return T1K_ERR_IO;
+  if (job->rank == 0) {
+    std::string s;
+    for (size_t g = 0; g < job->ref.geneName.size(); ++g) s += job->gt.geneLine((int)g);
+    if (!writeText(pfx + "_genotype.tsv", s, job->err)) return T1K_ERR_IO;
+    if (!writeText(pfx + "_allele.tsv", job->gt.alleleLines(), job->err)) return T1K_ERR_IO;
+    if (job->prm.output_read_assignment && !writeText(pfx + "_assign.tsv", job->assignText, job->err)) return T1K_ERR_IO;
+  }
   if (job->bgStarted && job->outPrefix == pfx) {  // already under way since the end of the device loop
     if (job->bgWriter.joinable()) job->bgWriter.join();
     job->bgStarted = false;
     if (!job->bgOk) return T1K_ERR_IO;
   } else {
     if (job->bgWriter.joinable()) job->bgWriter.join();
-    if (!writeAlignedFiles(job, pfx)) return T1K_ERR_IO;
+    if (writesAligned(job)) {
+      std::vector<AlignedPlan> plans;
+      if (!planAlignedFiles(job, pfx, plans) || !writePlannedFiles(job, plans)) return T1K_ERR_IO;
+    }
   }
   job->msWrite = nowMs() - t0;
   job->stats.ms_write = job->msWrite;
@@ -929,10 +1000,19 @@ int t1k_genotyper_main(int argc, char **argv) {
   const bool paired = !f2.empty();
   const std::vector<const char *> &first = !f1.empty() ? f1 : single;
   if (first.empty()) { fprintf(stderr, "genotyper: no read file given (-u, or -1 and -2)\n"); destroyAll(); return EXIT_FAILURE; }
-  int rc = t1k_job_load_reads_multi(job, first.data(), (uint32_t)first.size(), paired ? f2.data() : nullptr, (uint32_t)f2.size(), barcode.empty() ? nullptr : barcode.c_str());
-  if (rc != T1K_OK) { fprintf(stderr, "genotyper: %s\n", t1k_job_last_error(job)); destroyAll(); return EXIT_FAILURE; }
-  logLine("Found %d read fragments. Start read assignment.", (int)job->in->nFrag());
-  t1k_job_set_output_prefix(job, prefix.c_str());  // the aligned-read files are written while the EM runs
+  // T1K_SHARD_INPUT=1: every rank indexes only its own fragments and writes only its own part of the *_aligned*.fa files, as ranks
+  // in separate processes do (bench.py under torchrun); by default the ranks of this process share one index built by all host threads
+  const bool shardInput = R > 1 && getenv("T1K_SHARD_INPUT") && atoi(getenv("T1K_SHARD_INPUT")) != 0;
+  auto loadInto = [&](t1k_job *j) {
+    return t1k_job_load_reads_multi(j, first.data(), (uint32_t)first.size(), paired ? f2.data() : nullptr, (uint32_t)f2.size(), barcode.empty() ? nullptr : barcode.c_str());
+  };
+  int rc = T1K_OK;
+  if (!shardInput) {
+    rc = loadInto(job);
+    if (rc != T1K_OK) { fprintf(stderr, "genotyper: %s\n", t1k_job_last_error(job)); destroyAll(); return EXIT_FAILURE; }
+    logLine("Found %d read fragments. Start read assignment.", (int)job->in->nAll());
+    t1k_job_set_output_prefix(job, prefix.c_str());  // the aligned-read files are written while the EM runs
+  }
   if (R == 1) rc = t1k_job_run(job);
   else {
     // one thread per rank: the ranks meet in the collectives of t1k_job_run (RCCL when every rank has its own GPU)
@@ -941,12 +1021,20 @@ int t1k_genotyper_main(int argc, char **argv) {
     std::vector<std::thread> th;
     for (int r = 0; r < R; ++r)
       th.emplace_back([&, r] {
-        int x = r ? t1k_job_share_reads(jobs[r], job) : T1K_OK;
+        int x = (r && !shardInput) ? t1k_job_share_reads(jobs[r], job) : T1K_OK;
         const int y = t1k_comm_init(t1k_job_ctx(jobs[r]), R, r, nullptr, group, -1, &comms[r]);  // collective: every rank calls it
         if (x == T1K_OK && y != T1K_OK) { jobs[r]->err = comms[r] ? t1k_comm_last_error(comms[r]) : "cannot create the communicator"; x = y; }
         if (x == T1K_OK) x = t1k_job_set_shard(jobs[r], r, R, comms[r]);
+        if (x == T1K_OK && shardInput) {
+          x = loadInto(jobs[r]);  // collective
+          if (x == T1K_OK) {
+            if (r == 0) logLine("Found %d read fragments. Start read assignment.", (int)jobs[r]->in->nAll());
+            t1k_job_set_output_prefix(jobs[r], prefix.c_str());
+          }
+        }
         // a rank that failed before the first collective must still not leave the others waiting: it runs with nothing to do
         rcs[r] = x == T1K_OK ? t1k_job_run(jobs[r]) : x;
+        if (rcs[r] == T1K_OK && shardInput && r) rcs[r] = t1k_job_write_outputs(jobs[r], prefix.c_str());  // its part of the read files (rank 0: below)
       });
     for (auto &t : th) t.join();
     for (int r = 0; r < R; ++r)

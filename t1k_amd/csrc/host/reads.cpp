@@ -104,36 +104,44 @@ bool ReadInput::addBuffer(const char *p, size_t n, int threads, Side &dst, std::
   if (b >= end) return true;  // empty file: no records
   const bool fastq = *b == '@';
   if (!fastq && *b != '>') { err = what + ": neither FASTA nor FASTQ"; return false; }
+  return addRange(b, end, end, fastq, threads, dst);  // false with err empty: the caller falls back to the general reader
+}
+
+// records of [b, stop) -- b a record start, stop a record start or the end of the text -- indexed in place by `threads` threads;
+// false = not the strict layout
+bool ReadInput::addRange(const char *b, const char *stop, const char *end, bool fastq, int threads, Side &dst) {
+  if (b >= stop) return true;
+  const size_t n = (size_t)(stop - b);
   const int T = (int)std::max<size_t>(1, std::min<size_t>((size_t)threads, n / (1u << 20) + 1));
-  std::vector<const char *> start(T + 1, end);
+  std::vector<const char *> start(T + 1, stop);
   start[0] = b;
   std::vector<Piece> piece(T);
   {
     std::vector<std::thread> th;
-    for (int t = 1; t < T; ++t) th.emplace_back([&, t] { start[t] = findRecord(p, b + (size_t)(end - b) / T * t, end, fastq); });
+    for (int t = 1; t < T; ++t) th.emplace_back([&, t] { start[t] = findRecord(b, b + n / T * t, stop, fastq); });
     for (auto &x : th) x.join();
     for (int t = 1; t <= T; ++t) start[t] = std::max(start[t], start[t - 1]);
-    start[T] = end;
+    start[T] = stop;
   }
   {
     std::vector<std::thread> th;
     for (int t = 0; t < T; ++t)
       th.emplace_back([&, t] {
         Piece &pc = piece[t];
-        const char *q = start[t], *stop = start[t + 1];
-        const size_t guess = (size_t)(stop - q) / 200 + 16;
+        const char *q = start[t], *pstop = start[t + 1];
+        const size_t guess = (size_t)(pstop - q) / 200 + 16;
         pc.seqP.reserve(guess); pc.seqL.reserve(guess); pc.idP.reserve(guess); pc.idL.reserve(guess);
-        while (q < stop) {
+        while (q < pstop) {
           q = strictRecord(q, end, fastq, pc);
           if (!q) { pc.ok = false; return; }
         }
-        if (q != stop) pc.ok = false;
+        if (q != pstop) pc.ok = false;
       });
     for (auto &x : th) x.join();
   }
   bool strict = true;
   for (auto &pc : piece) strict = strict && pc.ok;
-  if (!strict) return false;  // caller falls back to the general reader (err left empty)
+  if (!strict) return false;
   size_t tot = 0;
   std::vector<size_t> at(T);
   for (int t = 0; t < T; ++t) { at[t] = dst.seqP.size() + tot; tot += piece[t].seqP.size(); }
@@ -242,6 +250,172 @@ bool ReadInput::open(const std::vector<std::string> &files1, const std::vector<s
   if (hasBarcode && bc.seqP.size() != side[0].seqP.size()) { err = "barcode file and read file hold different numbers of records"; return false; }
   finish();
   return true;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// One process per GPU: a rank indexes only its own fragments.
+//
+// The fragments of a sharded job are contiguous slices of the input (rank r: [F r / N, F (r + 1) / N)), so a rank has to find
+// the bytes of records it has never seen.  In the strict layouts a record is a fixed number of lines (4: FASTQ, 2: FASTA), so
+// counting newlines is enough: the text of all files is cut into 1 MiB blocks, every rank counts the newlines of its share of
+// the blocks (1 / N of the bytes), the counts are all-gathered (4 bytes per MiB of input), and every rank then knows how many
+// records each file holds and in which block any record starts; it scans that one block for the exact byte and indexes its own
+// byte range with the same in-place indexer as the single-process path (which also verifies the layout record by record).
+// Anything else -- gz, a pipe, a barcode file, a layout that is not strict on ANY rank -- returns 0 on every rank and the caller
+// indexes everything as before.
+// ------------------------------------------------------------------------------------------------------------------
+int ReadInput::openSharded(const std::vector<std::string> &files1, const std::vector<std::string> &files2, int threads, const ShardComm &c, std::string &err) {
+  constexpr size_t BLK = 1u << 20;
+  struct View { const char *b = nullptr, *end = nullptr; bool fastq = false; size_t nBlocks = 0, firstBlock = 0; uint64_t lines = 0, records = 0; int L = 4; };
+  paired = !files2.empty();
+  hasBarcode = false;
+  std::vector<View> views[2];
+  size_t NB = 0;
+  for (int m = 0; m < (paired ? 2 : 1); ++m) {
+    for (const std::string &path : m ? files2 : files1) {
+      int fd = ::open(path.c_str(), O_RDONLY);
+      if (fd < 0) { err = "cannot open " + path; return -1; }
+      struct stat st;
+      if (fstat(fd, &st) != 0) { ::close(fd); err = "cannot stat " + path; return -1; }
+      unsigned char magic[2] = {0, 0};
+      const bool gz = st.st_size >= 2 && pread(fd, magic, 2, 0) == 2 && magic[0] == 0x1f && magic[1] == 0x8b;
+      if (gz || !S_ISREG(st.st_mode)) { ::close(fd); return 0; }
+      View v;
+      if (st.st_size > 0) {
+        void *mp = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+        if (mp == MAP_FAILED) { ::close(fd); err = "cannot map " + path; return -1; }
+        Blob &b = newBlob();
+        b.map = mp; b.len = (size_t)st.st_size;
+        v.b = (const char *)mp; v.end = v.b + st.st_size;
+        while (v.end > v.b && isBlank(v.end[-1])) --v.end;
+        while (v.b < v.end && isBlank(*v.b)) ++v.b;
+        if (v.b < v.end) {
+          v.fastq = *v.b == '@';
+          if (!v.fastq && *v.b != '>') { ::close(fd); return 0; }  // the whole-file path reports it
+          v.L = v.fastq ? 4 : 2;
+          v.nBlocks = ((size_t)(v.end - v.b) + BLK - 1) / BLK;
+        }
+      }
+      ::close(fd);
+      v.firstBlock = NB;
+      NB += v.nBlocks;
+      views[m].push_back(v);
+    }
+  }
+  // newline counts per block: this rank's share, then everybody's
+  std::vector<uint32_t> nl(NB + 1, 0);
+  const int N = c.nRanks;
+  const size_t k0 = NB * (size_t)c.rank / N, k1 = NB * ((size_t)c.rank + 1) / N;
+  auto blockText = [&](size_t k, const char *&p, const char *&e) {
+    for (int m = 0; m < 2; ++m)
+      for (const View &v : views[m])
+        if (k >= v.firstBlock && k < v.firstBlock + v.nBlocks) {
+          p = v.b + (k - v.firstBlock) * BLK;
+          e = std::min(v.end, p + BLK);
+          return;
+        }
+    p = e = nullptr;
+  };
+  {
+    std::atomic<size_t> next{k0};
+    auto work = [&] {
+      for (;;) {
+        const size_t k = next.fetch_add(1);
+        if (k >= k1) return;
+        const char *p, *e;
+        blockText(k, p, e);
+        uint32_t n = 0;
+        while (p < e) {
+          const char *q = (const char *)memchr(p, '\n', (size_t)(e - p));
+          if (!q) break;
+          ++n; p = q + 1;
+        }
+        nl[k] = n;
+      }
+    };
+    std::vector<std::thread> th;
+    const int T = (int)std::max<size_t>(1, std::min<size_t>((size_t)threads, k1 - k0));
+    for (int t = 1; t < T; ++t) th.emplace_back(work);
+    work();
+    for (auto &x : th) x.join();
+  }
+  {
+    std::vector<uint64_t> bytes(N), displ(N);
+    for (int r = 0; r < N; ++r) { displ[r] = 4 * (NB * (size_t)r / N); bytes[r] = 4 * (NB * ((size_t)r + 1) / N) - displ[r]; }
+    if (NB && !c.allgatherv(nl.data(), bytes.data(), displ.data(), 4 * NB)) { err = "read input: exchange of the line counts failed"; return -1; }
+  }
+  uint64_t total[2] = {0, 0};
+  for (int m = 0; m < (paired ? 2 : 1); ++m)
+    for (View &v : views[m]) {
+      if (v.b >= v.end) continue;
+      uint64_t n = 0;
+      for (size_t k = 0; k < v.nBlocks; ++k) n += nl[v.firstBlock + k];
+      v.lines = n + 1;  // the trimmed text does not end in a newline
+      if (v.lines % v.L) return 0;  // not the strict layout (every rank sees the same table)
+      v.records = v.lines / v.L;
+      total[m] += v.records;
+    }
+  if (paired && total[0] != total[1]) { err = "mate files hold different numbers of reads"; return -1; }
+  if (total[0] > 0xFFFFFFF0ull) { err = "too many fragments"; return -1; }
+  const uint64_t Fall = total[0];
+  const uint64_t fBeg = Fall * (uint64_t)c.rank / N, fEnd = Fall * ((uint64_t)c.rank + 1) / N;
+  // byte of the first character of line `line` (0-based) of a file
+  auto lineStart = [&](const View &v, uint64_t line) -> const char * {
+    if (line == 0) return v.b;
+    uint64_t before = 0;  // newlines in the blocks before k
+    size_t k = 0;
+    while (k < v.nBlocks && before + nl[v.firstBlock + k] < line) { before += nl[v.firstBlock + k]; ++k; }
+    if (k >= v.nBlocks) return v.end;
+    const char *p = v.b + k * BLK, *e = std::min(v.end, p + BLK);
+    for (uint64_t need = line - before; need > 0; --need) {
+      const char *q = (const char *)memchr(p, '\n', (size_t)(e - p));
+      if (!q) return v.end;  // cannot happen: the block holds that many newlines
+      p = q + 1;
+    }
+    return p;
+  };
+  bool okSide[2] = {true, true};
+  auto indexSide = [&](int m, int T) {
+    uint64_t R = 0;
+    for (const View &v : views[m]) {
+      const uint64_t lo = std::max(fBeg, R), hi = std::min(fEnd, R + v.records);
+      if (lo < hi) {
+        const char *p0 = lineStart(v, (lo - R) * v.L);
+        const char *p1 = hi - R == v.records ? v.end : lineStart(v, (hi - R) * v.L);
+        const size_t before = side[m].seqP.size();
+        if (!addRange(p0, p1, v.end, v.fastq, T, side[m]) || side[m].seqP.size() - before != hi - lo) okSide[m] = false;
+      }
+      R += v.records;
+    }
+  };
+  {
+    const int per = std::max(1, threads / (paired ? 2 : 1));
+    std::thread t2;
+    if (paired) t2 = std::thread([&] { indexSide(1, per); });
+    indexSide(0, per);
+    if (t2.joinable()) t2.join();
+  }
+  // agreement: the layout is strict everywhere (else every rank falls back); the longest read of the whole input (Genotyper.cpp:443)
+  uint64_t localMax = 0;
+  for (int m = 0; m < (paired ? 2 : 1); ++m)
+    for (uint32_t l : side[m].seqL) localMax = std::max<uint64_t>(localMax, l);
+  {
+    std::vector<uint64_t> flags(2 * (size_t)N, 0), bytes(N, 16), displ(N);
+    for (int r = 0; r < N; ++r) displ[r] = 16 * (uint64_t)r;
+    flags[2 * c.rank] = okSide[0] && okSide[1] ? 1 : 0;
+    flags[2 * c.rank + 1] = localMax;
+    if (!c.allgatherv(flags.data(), bytes.data(), displ.data(), 16 * (uint64_t)N)) { err = "read input: exchange of the layout flags failed"; return -1; }
+    maxLen = 0;
+    for (int r = 0; r < N; ++r) {
+      if (!flags[2 * r]) return 0;
+      maxLen = std::max<int>(maxLen, (int)flags[2 * r + 1]);
+    }
+  }
+  const size_t n = side[0].seqP.size();
+  frag.resize(n);
+  for (size_t i = 0; i < n; ++i) frag[i] = (uint32_t)i;
+  sharded = true; base = (uint32_t)fBeg; nAll_ = (uint32_t)Fall; shardRank = c.rank; shardRanks = N;
+  return 1;
 }
 
 void ReadInput::setMemory(const char *seq1, const uint64_t *off1, const char *seq2, const uint64_t *off2, uint32_t n) {

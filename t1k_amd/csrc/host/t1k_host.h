@@ -3,6 +3,7 @@
 // equivalence classes, the SQUAREM control loop (the E-step runs on the GPU), allele selection, TSV writers.
 #pragma once
 #include <cstdint>
+#include <functional>
 #include <list>
 #include <map>
 #include <mutex>
@@ -40,7 +41,18 @@ struct ReadInput {
   ~ReadInput();
   bool open(const std::vector<std::string> &files1, const std::vector<std::string> &files2, const std::string &barcodeFile, int threads, std::string &err);
   void setMemory(const char *seq1, const uint64_t *off1, const char *seq2, const uint64_t *off2, uint32_t n);
-  size_t nFrag() const { return frag.size(); }
+  size_t nFrag() const { return frag.size(); }   // fragments held here
+  // One process per GPU (host/reads.cpp, openSharded): only the fragments [base, base + nFrag()) of nAll() are indexed here
+  struct ShardComm {
+    int rank = 0, nRanks = 1;
+    std::function<bool(void *buf, const uint64_t *bytes, const uint64_t *displ, uint64_t total)> allgatherv;  // host buffers, in place
+  };
+  // 1 = indexed this rank's slice, 0 = not eligible (the caller opens the files whole, as a single process does), -1 = error
+  int openSharded(const std::vector<std::string> &files1, const std::vector<std::string> &files2, int threads, const ShardComm &c, std::string &err);
+  bool sharded = false;
+  uint32_t base = 0;
+  int shardRank = 0, shardRanks = 1;
+  size_t nAll() const { return sharded ? nAll_ : frag.size(); }
 
  private:
   struct Blob {
@@ -53,6 +65,8 @@ struct ReadInput {
   Blob &newBlob() { std::lock_guard<std::mutex> g(blobLock_); blobs_.emplace_back(); return blobs_.back(); }
   bool addFile(const std::string &path, int threads, Side &dst, std::string &err);
   bool addBuffer(const char *p, size_t n, int threads, Side &dst, std::string &err, const std::string &what);
+  bool addRange(const char *b, const char *stop, const char *end, bool fastq, int threads, Side &dst);
+  uint32_t nAll_ = 0;
   bool addGeneral(const std::string &path, Side &dst, std::string &err);
   void finish();
 };

@@ -71,6 +71,15 @@ def test_executable_vs_golden_reference_outputs(built, tmp_path, name):
     assert open(out + "_assign.tsv").read() == c.expected("assign.tsv.gz")
     ids = [l[1:].strip() for l in open(out + ("_aligned_1.fa" if c.paired else "_aligned.fa")) if l.startswith(">")]
     assert ids == c.expected("aligned_ids.txt.gz").split()
+    if c.paired:
+        ids2 = [l[1:].strip() for l in open(out + "_aligned_2.fa") if l.startswith(">")]
+        assert ids2 == ids
+    if "+" in gpus:  # the read files written in parts by the ranks: byte for byte those of a single-GPU run
+        one = os.path.join(str(tmp_path), "one")
+        r1 = subprocess.run([GENO] + c.args() + ["-o", one], stderr=subprocess.PIPE, text=True)
+        assert r1.returncode == 0, r1.stderr
+        for suf in (("_aligned_1.fa", "_aligned_2.fa") if c.paired else ("_aligned.fa",)):
+            assert open(out + suf, "rb").read() == open(one + suf, "rb").read(), suf
     if c.bc:
         assert open(out + "_aligned_bc.fa").read() == c.expected("aligned_bc.fa")
     m = re.search(r"in (\d+) EM iterations", r.stderr)
@@ -232,19 +241,27 @@ def test_n_next_to_homopolymer_vs_oracle(built, tmp_path):
 
 
 @pytest.mark.parametrize("name", ["hla_synth_2x150", "cyp_dna_relax_2x150", "kir_synth_relax_2x150", "cyp_rna_single"])
-@pytest.mark.parametrize("gpus", ["0,0", "0,0,0"])
+@pytest.mark.parametrize("gpus", ["0,0", "0,0,0", "0,0+own-input", "0,0,0+own-input"])
 def test_sharded_job_equals_single_gpu_job(built, tmp_path, name, gpus):
     """The multi-GPU path with several ranks on ONE device (T1K_GPUS=0,0: one thread, job and context set per rank, in-process
     transport): fragments sharded by contiguous slices, coverage all-reduce, row exchange to the pattern owners + coalescing + group
-    gather, EM with a sharded row pass.  Every output file must equal the reference's (= the single-GPU run's) byte for byte."""
+    gather, EM with a sharded row pass.  Every output file must equal the reference's (= the single-GPU run's) byte for byte.
+    "+own-input": every rank indexes only its own fragments of the read files (newline counts per MiB block exchanged, host/reads.cpp
+    openSharded) and writes only its own part of the *_aligned*.fa files -- what ranks in separate processes do."""
     c = goldens.Case(name, str(tmp_path))
     out = os.path.join(str(tmp_path), "sharded")
-    r = subprocess.run([GENO] + c.args() + ["-o", out], stderr=subprocess.PIPE, text=True, env=dict(os.environ, T1K_GPUS=gpus))
+    env = dict(os.environ, T1K_GPUS=gpus.split("+")[0])
+    if "+" in gpus:
+        env["T1K_SHARD_INPUT"] = "1"
+    r = subprocess.run([GENO] + c.args() + ["-o", out], stderr=subprocess.PIPE, text=True, env=env)
     assert r.returncode == 0, r.stderr
     assert open(out + "_genotype.tsv").read() == c.expected("genotype.tsv")
     assert open(out + "_allele.tsv").read() == c.expected("allele.tsv")
     ids = [l[1:].strip() for l in open(out + ("_aligned_1.fa" if c.paired else "_aligned.fa")) if l.startswith(">")]
     assert ids == c.expected("aligned_ids.txt.gz").split()
+    if c.paired:
+        ids2 = [l[1:].strip() for l in open(out + "_aligned_2.fa") if l.startswith(">")]
+        assert ids2 == ids
     if c.bc:
         assert open(out + "_aligned_bc.fa").read() == c.expected("aligned_bc.fa")
     m = re.search(r"in (\d+) EM iterations", r.stderr)
@@ -354,6 +371,13 @@ def test_baseline_configs_live_vs_reference_binary(built, tmp_path, label, kind,
         assert open(o_ref + suf).read() == open(o_gpu + suf).read(), suf
     it = [re.search(r"in (\d+) EM iterations", x.stderr).group(1) for x in (r1, r2)]
     assert it[0] == it[1]
+    # the same input (tens of 1 MiB blocks per file) through three ranks that each index and write only their own reads
+    o_own = os.path.join(str(tmp_path), "own")
+    r3 = subprocess.run([GENO] + common + ["-o", o_own], stderr=subprocess.PIPE, text=True, env=dict(os.environ, T1K_GPUS="0,0,0", T1K_SHARD_INPUT="1", T1K_DEBUG_PHASES="1"))
+    assert r3.returncode == 0, r3.stderr[-2000:]
+    assert re.search(r"indexed: 3333\d of 100000 fragments", r3.stderr), r3.stderr[-2000:]
+    for suf in ("_genotype.tsv", "_allele.tsv", "_aligned_1.fa", "_aligned_2.fa"):
+        assert open(o_ref + suf).read() == open(o_own + suf).read(), suf
 
 
 ANALYZER = os.path.join(util.ROOT, "t1k_amd", "bin", "analyzer")
