@@ -136,13 +136,20 @@ def main():
     import numpy as np
     import t1k_amd
 
-    # inputs: ONE sample of world x --pairs fragments; every rank maps the same files and owns a contiguous slice of the fragments
+    # inputs: ONE sample of world x --pairs fragments, given as `world` files per mate read back to back (every -1 / -2 of the
+    # executable counts, ReadFiles::AddReadFile); every rank maps the same files and owns a contiguous slice of the fragments.
+    # File i is the same for every world size (seed 2 + i), so the N = 1 input is the first file of the N = 8 input; each rank
+    # generates one of the files.
     total_pairs = a.pairs * world
     if rank == 0:
-        ensure_inputs(a.workdir, total_pairs, a.genes, a.scale, seed=2)
+        ensure_inputs(a.workdir, a.pairs, a.genes, a.scale, seed=2)   # (also writes the reference)
     if dist is not None:
         dist.barrier()
-    ref, pfx = ensure_inputs(a.workdir, total_pairs, a.genes, a.scale, seed=2)
+        ensure_inputs(a.workdir, a.pairs, a.genes, a.scale, seed=2 + rank)
+        dist.barrier()
+    parts = [ensure_inputs(a.workdir, a.pairs, a.genes, a.scale, seed=2 + i) for i in range(world)]
+    ref, pfx = parts[0]
+    files1, files2 = [p_[1] + "_1.fq" for p_ in parts], [p_[1] + "_2.fq" for p_ in parts]
     out_prefix = os.path.join(a.workdir, "out")
     last = {}
     comm = anchor = None
@@ -158,7 +165,7 @@ def main():
         if comm is not None:
             comm.bind(job)
             job.set_shard(rank, world, comm)    # before the reads: a rank indexes only its own fragments of the files (host/reads.cpp)
-        job.load_reads(pfx + "_1.fq", pfx + "_2.fq")
+        job.load_reads(files1, files2)
         job.set_output_prefix(out_prefix)       # as the executable does: the aligned-read files are written while the EM runs
         job.run()
         job.write_outputs(out_prefix)           # rank 0: the two tables; every rank: its own part of the aligned-read files

@@ -144,6 +144,9 @@ int t1k_rowset_coalesce(t1k_rowset *rs, uint64_t *nGroups, uint64_t *nEntries, u
 int t1k_rowset_groups_download(t1k_rowset *rs, uint64_t *groupPtr, t1k_group_entry *entries, uint32_t *firstFragment);
 /* fragAssigned[nFragments]: Genotyper.cpp:564-565 */
 int t1k_rowset_assigned_download(t1k_rowset *rs, uint8_t *fragAssigned);
+/* the flags of fragments [first, first + count), callable while t1k_pair_into calls for later fragments are in flight (the job's
+ * output writer follows the windows of the device loop with it) */
+int t1k_rowset_assigned_range(t1k_rowset *rs, uint64_t first, uint64_t count, uint8_t *fragAssigned);
 /* rows of fragments [first, first + count) in the reference's row order (--outputReadAssignment, tests) */
 int t1k_rowset_rows_download(t1k_rowset *rs, uint64_t first, uint32_t count, uint32_t *rowCounts, t1k_row_entry *rows, uint64_t cap, uint64_t *total);
 

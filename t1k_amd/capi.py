@@ -102,6 +102,7 @@ def lib():
     L.t1k_job_stage_reads.argtypes = [vp]
     L.t1k_job_run.argtypes = [vp]
     L.t1k_job_write_outputs.argtypes = [vp, C.c_char_p]
+    L.t1k_job_load_reads_multi.argtypes = [vp, C.POINTER(C.c_char_p), C.c_uint32, C.POINTER(C.c_char_p), C.c_uint32, C.c_char_p]
     L.t1k_job_genotype_text.argtypes = [vp, C.c_char_p, C.c_uint64, u64p]
     L.t1k_job_counts.argtypes = [vp, u64p, u64p, u64p, u64p, i32p]
     L.t1k_job_stats.argtypes = [vp, C.POINTER(Stats)]
@@ -338,7 +339,13 @@ class Job:
             pass
 
     def load_reads(self, f1, f2=None, barcode=None):
-        self._check(lib().t1k_job_load_reads(self.h, f1.encode(), f2.encode() if f2 else None, barcode.encode() if barcode else None), "t1k_job_load_reads")
+        """f1 / f2: a path, or a list of paths read back to back (every -1 / -2 of the executable).  On a rank of a sharded job
+        (set_shard came first) the call is collective and indexes this rank's fragments only."""
+        l1 = [f1] if isinstance(f1, str) else list(f1)
+        l2 = [] if not f2 else ([f2] if isinstance(f2, str) else list(f2))
+        a1 = (C.c_char_p * len(l1))(*[x.encode() for x in l1])
+        a2 = (C.c_char_p * len(l2))(*[x.encode() for x in l2]) if l2 else None
+        self._check(lib().t1k_job_load_reads_multi(self.h, a1, len(l1), a2, len(l2), barcode.encode() if barcode else None), "t1k_job_load_reads")
 
     def set_reads(self, seqs1, seqs2=None):
         b1, o1 = _concat(seqs1)

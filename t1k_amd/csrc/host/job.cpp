@@ -35,6 +35,9 @@ struct t1k_job {
   // the *_aligned*.fa files only need the fragmentAssigned flags: with an output prefix registered before the run they are written by
   // background threads while the classes are built and the EM runs
   std::string outPrefix;
+  struct StreamOut { std::string path; int what = 0, fd = -1; uint64_t offset = 0; };
+  std::vector<StreamOut> stream;   // read files being written along the device loop (single-GPU jobs)
+  uint32_t streamDone = 0;          // local fragments already appended
   std::thread bgWriter;
   bool bgStarted = false, bgOk = true;
   bool analyzer = false;            // analyzer mode: the rowset keeps the raw fragment assignment lists and is left alive after run_local
@@ -75,6 +78,10 @@ static void parallelRanges(size_t n, int T, F fn) {  // fn(t, begin, end) over c
 }
 
 extern "C" {
+
+static bool streamOpen(t1k_job *job, const std::string &pfx);
+static void streamClose(t1k_job *job, bool removeFiles);
+static bool streamAppend(t1k_job *job, uint32_t fLo, uint32_t fHi, bool besideLoop);
 
 void t1k_job_params_default(t1k_job_params *p) {
   memset(p, 0, sizeof(*p));
@@ -155,6 +162,7 @@ static int jobCreate(const t1k_job_params *p, const char *refFasta, const std::s
 void t1k_job_destroy(t1k_job *job) {
   if (!job) return;
   if (job->bgWriter.joinable()) job->bgWriter.join();
+  if (!job->stream.empty()) streamClose(job, true);  // a run that never reached t1k_job_finish
   if (job->rows) t1k_rowset_destroy(job->rows);
   for (t1k_ctx *c : job->more) t1k_ctx_destroy(c);  // before job->ctx, whose reference they alias
   for (t1k_ctx *c : job->reader) if (c) t1k_ctx_destroy(c);
@@ -315,13 +323,21 @@ int t1k_job_run_local(t1k_job *job) {
   uint32_t assignBatch = job->prm.batch_fragments > 0 ? (uint32_t)job->prm.batch_fragments * per : 32768u;
   if (const char *eb = getenv("T1K_BATCH")) assignBatch = (uint32_t)std::max(64, atoi(eb)) * per;  // tuning aid (in fragments, as in round 1)
   const uint32_t pairBatch = 1u << 16;
-  const uint32_t nWin = F ? (F + windowFrags - 1) / windowFrags : 0;
-  std::vector<Window> win(nWin);
-  for (uint32_t w = 0; w < nWin; ++w) {
-    win[w].f0 = w * windowFrags; win[w].f1 = (uint32_t)std::min<uint64_t>(F, (uint64_t)(w + 1) * windowFrags);
-    win[w].slot = (int)(w & 1);
-    win[w].touched.assign(P, 0);
+  // the first window is small, so that the GPU starts after a short preparation; the others are prepared while it works
+  std::vector<Window> win;
+  uint32_t firstWindow = std::max<uint32_t>(65536u, windowFrags / 8);
+  if (const char *e = getenv("T1K_FIRST_WINDOW")) firstWindow = (uint32_t)std::max(64, atoi(e));
+  for (uint64_t f0 = 0; f0 < F;) {
+    const uint64_t size = win.empty() ? firstWindow : windowFrags;
+    Window W;
+    W.f0 = (uint32_t)f0; W.f1 = (uint32_t)std::min<uint64_t>(F, f0 + size);
+    if (F - W.f1 < windowFrags / 16) W.f1 = F;  // no tiny tail window
+    W.slot = (int)(win.size() & 1);
+    W.touched.assign(P, 0);
+    f0 = W.f1;
+    win.push_back(std::move(W));
   }
+  const uint32_t nWin = (uint32_t)win.size();
   struct Shared {
     std::mutex m;
     std::condition_variable cv;
@@ -479,17 +495,40 @@ int t1k_job_run_local(t1k_job *job) {
       sh.cv.notify_all();
     }
   };
+  // ---- read files of a single-GPU job: written window by window behind the loop (all but the last window, which is left to the
+  // writer that runs beside the EM, t1k_job_finish) ---------------------------------------------------------------------------------
+  job->streamDone = 0;
+  const bool streaming = !job->outPrefix.empty() && job->nRanks == 1 && !in.sharded && !job->analyzer && nWin > 1 && !getenv("T1K_NO_STREAM_OUTPUT");
+  bool loopEnded = false;
+  auto follow = [&] {
+    if (!streamOpen(job, job->outPrefix)) { fail(T1K_ERR_IO, job->err); return; }  // (truncating last run's files takes a while: not on the loop's thread)
+    for (uint32_t w = 0; w + 1 < nWin; ++w) {
+      {
+        std::unique_lock<std::mutex> lk(sh.m);
+        sh.cv.wait(lk, [&] { return sh.err != T1K_OK || win[w].done || loopEnded; });
+        if (sh.err != T1K_OK || !win[w].done) return;
+      }
+      const Window &W = win[w];
+      int r = t1k_rowset_assigned_range(job->rows, W.f0, W.f1 - W.f0, job->fragAssigned.data() + fBeg + W.f0);
+      if (r != T1K_OK) { fail(r, t1k_rowset_last_error(job->rows)); return; }
+      if (!streamAppend(job, W.f0, W.f1, true)) { fail(T1K_ERR_IO, job->err); return; }
+      job->streamDone = W.f1;
+    }
+  };
   {
     std::thread prep(prepare);
+    std::thread writer;
+    if (streaming) writer = std::thread(follow);
     std::vector<std::thread> others;
     for (int i = 1; i < P; ++i) others.emplace_back(worker, i);
     worker(0);
     for (auto &t : others) t.join();
-    { std::lock_guard<std::mutex> g(sh.m); if (sh.err == T1K_OK && sh.oldest < nWin) { sh.err = T1K_ERR_INTERNAL; sh.errMsg = "window loop ended early"; } }
+    { std::lock_guard<std::mutex> g(sh.m); if (sh.err == T1K_OK && sh.oldest < nWin) { sh.err = T1K_ERR_INTERNAL; sh.errMsg = "window loop ended early"; } loopEnded = true; }
     sh.cv.notify_all();
     prep.join();
+    if (writer.joinable()) writer.join();
   }
-  if (sh.err != T1K_OK) return jobFail(job, sh.err, sh.errMsg);
+  if (sh.err != T1K_OK) { streamClose(job, true); return jobFail(job, sh.err, sh.errMsg); }
   const double tDev = nowMs();
   for (t1k_ctx *c : job->more)
     if ((rc = t1k_coverage_absorb(job->ctx, c)) != T1K_OK) return jobFail(job, rc, t1k_last_error(job->ctx));
@@ -592,24 +631,67 @@ struct AlignedPlan {
 };
 }  // namespace
 
-static bool planAligned(t1k_job *job, AlignedPlan &pl) {
+// bytes of ">id\nSEQ\n" of the assigned fragments among the local fragments [fLo, fHi), as an exclusive prefix over T pieces
+static void alignedSizes(t1k_job *job, int what, uint32_t fLo, uint32_t fHi, int T, std::vector<uint64_t> &pieceBytes) {
   const ReadInput &in = *job->in;
-  const uint32_t F = (uint32_t)in.nFrag(), base = in.base;
-  const int T = pl.T;
-  const ReadInput::Side &seqSide = pl.what == 2 ? in.bc : in.side[pl.what];
-  const ReadInput::Side &idSide = pl.what == 1 ? in.side[1] : in.side[0];  // the barcode file carries mate 1's name (Genotyper.cpp:709-718)
-  pl.pieceBytes.assign(T + 2, 0);
-  parallelRanges(F, T, [&](int t, size_t b, size_t e) {
+  const uint32_t base = in.base;
+  const ReadInput::Side &seqSide = what == 2 ? in.bc : in.side[what];
+  const ReadInput::Side &idSide = what == 1 ? in.side[1] : in.side[0];  // the barcode file carries mate 1's name (Genotyper.cpp:709-718)
+  pieceBytes.assign(T + 2, 0);
+  parallelRanges(fHi - fLo, T, [&](int t, size_t b, size_t e) {
     uint64_t run = 0;
     char tmp[32];
-    for (size_t f = b; f < e; ++f)
+    for (size_t f = fLo + b; f < fLo + e; ++f)
       if (job->fragAssigned[base + f]) {
         const uint32_t r = in.frag[f];
         run += 3 + (in.noIds ? (size_t)snprintf(tmp, 32, "r%u", (uint32_t)(base + f)) : (size_t)idSide.idL[r]) + seqSide.seqL[r];
       }
-    pl.pieceBytes[t + 1] = run;
+    pieceBytes[t + 1] = run;
   });
-  for (int t = 0; t < T + 1; ++t) pl.pieceBytes[t + 1] += pl.pieceBytes[t];
+  for (int t = 0; t < T + 1; ++t) pieceBytes[t + 1] += pieceBytes[t];
+}
+
+// ... and the records themselves, piece t at offset + pieceBytes[t]
+static bool alignedWrite(t1k_job *job, int fd, int what, uint32_t fLo, uint32_t fHi, int T, const std::vector<uint64_t> &pieceBytes, uint64_t offset) {
+  const ReadInput &in = *job->in;
+  const uint32_t base = in.base;
+  const ReadInput::Side &seqSide = what == 2 ? in.bc : in.side[what];
+  const ReadInput::Side &idSide = what == 1 ? in.side[1] : in.side[0];
+  std::atomic<bool> ok{true};
+  parallelRanges(fHi - fLo, T, [&](int t, size_t b, size_t e) {
+    uint64_t at = offset + pieceBytes[t];
+    std::vector<char> buf;
+    buf.reserve(8u << 20);
+    char tmp[32];
+    auto flush = [&] {
+      size_t done = 0;
+      while (done < buf.size()) {
+        ssize_t w = pwrite(fd, buf.data() + done, buf.size() - done, (off_t)(at + done));
+        if (w <= 0) { ok = false; break; }
+        done += (size_t)w;
+      }
+      at += buf.size();
+      buf.clear();
+    };
+    for (size_t f = fLo + b; f < fLo + e; ++f) {
+      if (!job->fragAssigned[base + f]) continue;
+      const uint32_t r = in.frag[f];
+      buf.push_back('>');
+      if (in.noIds) { const int n = snprintf(tmp, 32, "r%u", (uint32_t)(base + f)); buf.insert(buf.end(), tmp, tmp + n); }
+      else buf.insert(buf.end(), idSide.idP[r], idSide.idP[r] + idSide.idL[r]);
+      buf.push_back('\n');
+      buf.insert(buf.end(), seqSide.seqP[r], seqSide.seqP[r] + seqSide.seqL[r]); buf.push_back('\n');
+      if (buf.size() > (7u << 20)) flush();
+    }
+    flush();
+  });
+  return ok;
+}
+
+static bool planAligned(t1k_job *job, AlignedPlan &pl) {
+  const ReadInput &in = *job->in;
+  const int T = pl.T;
+  alignedSizes(job, pl.what, 0, (uint32_t)in.nFrag(), T, pl.pieceBytes);
   pl.baseOffset = 0; pl.create = true;
   if (in.sharded) {
     pl.create = false;
@@ -628,42 +710,56 @@ static bool planAligned(t1k_job *job, AlignedPlan &pl) {
 }
 
 static bool writeAligned(t1k_job *job, const AlignedPlan &pl) {
-  const ReadInput &in = *job->in;
-  const uint32_t F = (uint32_t)in.nFrag(), base = in.base;
   const int fd = ::open(pl.path.c_str(), pl.create ? (O_WRONLY | O_CREAT | O_TRUNC) : O_WRONLY, 0644);
   if (fd < 0) { job->err = "cannot write " + pl.path; return false; }
-  const ReadInput::Side &seqSide = pl.what == 2 ? in.bc : in.side[pl.what];
-  const ReadInput::Side &idSide = pl.what == 1 ? in.side[1] : in.side[0];
-  std::atomic<bool> ok{true};
-  parallelRanges(F, pl.T, [&](int t, size_t b, size_t e) {
-    uint64_t at = pl.baseOffset + pl.pieceBytes[t];
-    std::vector<char> buf;
-    buf.reserve(8u << 20);
-    char tmp[32];
-    auto flush = [&] {
-      size_t done = 0;
-      while (done < buf.size()) {
-        ssize_t w = pwrite(fd, buf.data() + done, buf.size() - done, (off_t)(at + done));
-        if (w <= 0) { ok = false; break; }
-        done += (size_t)w;
-      }
-      at += buf.size();
-      buf.clear();
-    };
-    for (size_t f = b; f < e; ++f) {
-      if (!job->fragAssigned[base + f]) continue;
-      const uint32_t r = in.frag[f];
-      buf.push_back('>');
-      if (in.noIds) { const int n = snprintf(tmp, 32, "r%u", (uint32_t)(base + f)); buf.insert(buf.end(), tmp, tmp + n); }
-      else buf.insert(buf.end(), idSide.idP[r], idSide.idP[r] + idSide.idL[r]);
-      buf.push_back('\n');
-      buf.insert(buf.end(), seqSide.seqP[r], seqSide.seqP[r] + seqSide.seqL[r]); buf.push_back('\n');
-      if (buf.size() > (7u << 20)) flush();
-    }
-    flush();
-  });
+  const bool ok = alignedWrite(job, fd, pl.what, 0, (uint32_t)job->in->nFrag(), pl.T, pl.pieceBytes, pl.baseOffset);
   ::close(fd);
   if (!ok) { job->err = "cannot write " + pl.path; return false; }
+  return true;
+}
+
+// A single-GPU job writes the read files while the device loop is still running: the writer follows the windows of the loop
+// (their fragment flags are final once the window's pairing tasks are done) and appends each window's records.
+static bool streamOpen(t1k_job *job, const std::string &pfx) {
+  const bool paired = job->in->paired;
+  job->stream.clear();
+  auto add = [&](const std::string &path, int what) {
+    t1k_job::StreamOut o; o.path = path; o.what = what;
+    o.fd = ::open(path.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+    job->stream.push_back(o);
+    return o.fd >= 0;
+  };
+  bool ok = add(paired ? pfx + "_aligned_1.fa" : pfx + "_aligned.fa", 0);
+  if (ok && paired) ok = add(pfx + "_aligned_2.fa", 1);
+  if (ok && job->in->hasBarcode) ok = add(pfx + "_aligned_bc.fa", 2);
+  if (!ok) job->err = "cannot write " + job->stream.back().path;
+  return ok;
+}
+static void streamClose(t1k_job *job, bool removeFiles) {
+  for (auto &o : job->stream) {
+    if (o.fd >= 0) ::close(o.fd);
+    if (removeFiles) ::unlink(o.path.c_str());
+  }
+  job->stream.clear();
+}
+// local fragments [fLo, fHi): flags must be in job->fragAssigned
+static bool streamAppend(t1k_job *job, uint32_t fLo, uint32_t fHi, bool besideLoop) {
+  // behind the device loop a few threads per file keep up easily (a window lasts a second); the rest of the machine feeds the GPU
+  const int T = besideLoop ? 4 : std::max(1, hostThreads(job) / (int)std::max<size_t>(1, job->stream.size()));
+  std::vector<char> ok(job->stream.size(), 1);
+  auto one = [&](size_t i) {
+    auto &o = job->stream[i];
+    std::vector<uint64_t> pieceBytes;
+    alignedSizes(job, o.what, fLo, fHi, T, pieceBytes);
+    ok[i] = alignedWrite(job, o.fd, o.what, fLo, fHi, T, pieceBytes, o.offset) ? 1 : 0;
+    o.offset += pieceBytes[T];
+  };
+  std::vector<std::thread> th;
+  for (size_t i = 1; i < job->stream.size(); ++i) th.emplace_back(one, i);
+  one(0);
+  for (auto &t : th) t.join();
+  for (size_t i = 0; i < ok.size(); ++i)
+    if (!ok[i]) { job->err = "cannot write " + job->stream[i].path; return false; }
   return true;
 }
 
@@ -704,7 +800,13 @@ int t1k_job_finish(t1k_job *job, uint64_t emGroupBegin, uint64_t emGroupEnd) {
   if (!job || !job->ctx || !job->localDone) return jobFail(job, T1K_ERR_STATE, "t1k_job_finish: t1k_job_run_local has not completed");
   if (job->bgWriter.joinable()) job->bgWriter.join();
   job->bgStarted = false; job->bgOk = true;
-  if (!job->outPrefix.empty() && writesAligned(job) && !job->analyzer) {  // the flags are final: start on the big files now
+  if (!job->stream.empty()) {  // the read files were started behind the device loop: the rest of the fragments now, beside the EM
+    job->bgStarted = true;
+    job->bgWriter = std::thread([job] {
+      job->bgOk = streamAppend(job, job->streamDone, (uint32_t)job->in->nFrag(), false);
+      streamClose(job, !job->bgOk);
+    });
+  } else if (!job->outPrefix.empty() && writesAligned(job) && !job->analyzer) {  // the flags are final: start on the big files now
     std::vector<AlignedPlan> plans;
     if (!planAlignedFiles(job, job->outPrefix, plans)) return T1K_ERR_IO;
     job->bgStarted = true;

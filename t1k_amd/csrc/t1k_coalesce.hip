@@ -222,6 +222,7 @@ void t1k_rowset_destroy(t1k_rowset *rs) {
   T1kDevBuf *all[] = {&rs->bFrag, &rs->bCursors, &rs->bWhitelist, &rs->bWork, &rs->bGroupPtr, &rs->bGroupEnt, &rs->bGroupFirst, &rs->bSend, &rs->bRecv, &rs->bFrag2, &rs->bAll};
   for (auto *b : all) if (b->p) (void)t1k_dev_free(b->p);
   for (auto &b : rs->chunks) if (b.p) (void)t1k_dev_free(b.p);
+  if (rs->copyStream) (void)hipStreamDestroy(rs->copyStream);
   delete rs;
 }
 
@@ -340,6 +341,18 @@ int t1k_rowset_assigned_download(t1k_rowset *rs, uint8_t *fragAssigned) {
   RS_HIP(hipSetDevice(rs->device));
   const uint64_t nLocal = rs->exchanged ? rs->nFragLocal : rs->nFrag;  // the flags belong to this rank's own fragments
   if (nLocal) RS_HIP(hipMemcpy(fragAssigned, rs->assigned, nLocal, hipMemcpyDeviceToHost));
+  return T1K_OK;
+}
+
+// flags of fragments [first, first + count) while the pipelines are still at work on later ones: a copy on the rowset's own
+// non-blocking stream, which neither waits for nor holds up the pipelines' streams (one caller at a time)
+int t1k_rowset_assigned_range(t1k_rowset *rs, uint64_t first, uint64_t count, uint8_t *fragAssigned) {
+  if (!rs || !fragAssigned || rs->exchanged || first + count > rs->nFrag) return rsFail(rs, T1K_ERR_ARG, "t1k_rowset_assigned_range: bad arguments");
+  RS_HIP(hipSetDevice(rs->device));
+  if (!count) return T1K_OK;
+  if (!rs->copyStream) RS_HIP(hipStreamCreateWithFlags(&rs->copyStream, hipStreamNonBlocking));
+  RS_HIP(hipMemcpyAsync(fragAssigned, rs->assigned + first, count, hipMemcpyDeviceToHost, rs->copyStream));
+  RS_HIP(hipStreamSynchronize(rs->copyStream));
   return T1K_OK;
 }
 

@@ -115,6 +115,7 @@ struct t1k_rowset {
   T1kDevBuf bWork, bGroupPtr, bGroupEnt, bGroupFirst;
   uint64_t nGroups = 0, nEntries = 0, nAssigned = 0;
   bool coalesced = false;
+  hipStream_t copyStream = nullptr; // t1k_rowset_assigned_range: copies beside the pipelines (non-blocking stream)
   std::string err;
 };
 int t1k_rowset_chunk(t1k_rowset *rs, t1k_ctx *ctx, size_t *chunk, t1k_row_entry **rows, uint64_t *cap, unsigned long long **cursor);
