@@ -256,6 +256,133 @@ __device__ inline void bitonicSort(uint64_t *key, uint32_t np2) {
   }
   __syncthreads();
 }
+// ------------------------------------------------------------------------------------------------------------------
+// Stable counting sort in LDS (replaces the bitonic network for the common case).
+//
+// The lists k_select and k_truncate order hold a few thousand entries but only a handful of distinct (matchCnt, spans) classes,
+// and k_select's input already arrives in allele order -- so ordering it is ONE stable pass over the dense rank of the class;
+// k_truncate's input needs the allele order first: two (three) more stable passes over the allele's bytes.
+//   ldsClassRanks     distinct classes of the list -> dense ranks 0 .. K - 1 in class order (LDS hash table, K <= 256)
+//   ldsCountingPass   one stable pass by an 8-bit digit: a wavefront takes a contiguous piece of the list, 64 entries a round;
+//                     lanes with the same digit find each other with ballots (their order inside the round is their lane
+//                     order), the first of them advances the piece's counter of that digit.  The counters, laid out
+//                     [digit][wavefront], are then prefix-summed: entry -> position.  Four workgroup barriers a pass.
+// Both must be called by all NT threads.  Entries stay 64-bit packed keys; the caller falls back to the bitonic network when a
+// list has more than 256 classes.
+// ------------------------------------------------------------------------------------------------------------------
+#define CS_SLOTS 512
+struct CsTables {
+  uint32_t hKey[CS_SLOTS];   // class + 1 (0 = empty)
+  uint8_t hRank[CS_SLOTS];
+  uint32_t dList[256];
+  uint32_t nDistinct, overflow;
+};
+__device__ __forceinline__ uint32_t csHash(uint32_t c) { return (c * 2654435761u) >> 23; }  // 9 bits
+__device__ __forceinline__ uint32_t csRankOf(const CsTables &T, uint32_t cls) {
+  const uint32_t want = cls + 1;
+  uint32_t h = csHash(cls);
+  while (T.hKey[h] != want) h = (h + 1) & (CS_SLOTS - 1);
+  return T.hRank[h];
+}
+template <int NT>
+__device__ inline bool ldsClassRanks(const uint64_t *key, uint32_t n, int classShift, CsTables &T) {
+  const int tid = threadIdx.x;
+  for (int q = tid; q < CS_SLOTS; q += NT) T.hKey[q] = 0;
+  if (tid == 0) { T.nDistinct = 0; T.overflow = 0; }
+  __syncthreads();
+  for (uint32_t i = tid; i < n; i += NT) {
+    const uint32_t cls = (uint32_t)(key[i] >> classShift), want = cls + 1;
+    uint32_t h = csHash(cls);
+    for (int probe = 0; probe < CS_SLOTS; ++probe) {
+      const uint32_t cur = T.hKey[h];
+      if (cur == want) break;
+      if (cur == 0) {
+        if (T.overflow) break;
+        const uint32_t old = atomicCAS(&T.hKey[h], 0u, want);
+        if (old == 0) { if (atomicAdd(&T.nDistinct, 1u) >= 256u) T.overflow = 1; break; }
+        if (old == want) break;
+      }
+      h = (h + 1) & (CS_SLOTS - 1);
+    }
+  }
+  __syncthreads();
+  if (T.overflow || T.nDistinct > 256u) { __syncthreads(); return false; }
+  if (tid == 0) T.nDistinct = 0;
+  __syncthreads();
+  for (int q = tid; q < CS_SLOTS; q += NT)
+    if (T.hKey[q]) T.dList[atomicAdd(&T.nDistinct, 1u)] = T.hKey[q];
+  __syncthreads();
+  const uint32_t K = T.nDistinct;
+  for (int q = tid; q < CS_SLOTS; q += NT) {
+    const uint32_t mine = T.hKey[q];
+    if (!mine) continue;
+    uint32_t r = 0;
+    for (uint32_t j = 0; j < K; ++j) r += T.dList[j] < mine ? 1u : 0u;
+    T.hRank[q] = (uint8_t)r;
+  }
+  __syncthreads();
+  return true;
+}
+
+// cnt: 256 * (NT / 64) u16 of LDS.  n <= 512 * (NT / 64).
+template <int NT, class DigitFn>
+__device__ inline void ldsCountingPass(uint64_t *key, uint32_t n, uint16_t *cnt, uint32_t *warpSums, DigitFn digit) {
+  constexpr int NW = NT / 64, ROUNDS = 8;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  {
+    uint32_t *c32 = (uint32_t *)cnt;  // 256 * NW / 2 words, two per thread
+    c32[2 * tid] = 0; c32[2 * tid + 1] = 0;
+  }
+  __syncthreads();
+  const uint32_t seg = (((n + NW - 1) / NW) + 63u) & ~63u;  // entries of one wavefront's piece (<= 512)
+  uint64_t kk[ROUNDS];
+  uint32_t at[ROUNDS];  // digit << 16 | position inside the piece's run of that digit (0xFFFFFFFF: no entry)
+  const uint64_t ltMask = lane ? (~0ull >> (64 - lane)) : 0ull;
+#pragma unroll
+  for (int q = 0; q < ROUNDS; ++q) {
+    kk[q] = 0; at[q] = 0xFFFFFFFFu;
+    if ((uint32_t)q * 64u < seg) {
+      const uint32_t i = (uint32_t)w * seg + (uint32_t)q * 64u + (uint32_t)lane;
+      const bool valid = i < n;
+      uint32_t r = 0;
+      if (valid) { kk[q] = key[i]; r = digit(kk[q]) & 0xFFu; }
+      uint64_t m = __ballot(valid);
+#pragma unroll
+      for (int b = 0; b < 8; ++b) {
+        const uint64_t bal = __ballot(valid && ((r >> b) & 1u));
+        m &= ((r >> b) & 1u) ? bal : ~bal;
+      }
+      // m: the valid lanes of this round that hold digit r (for a valid lane it contains the lane itself)
+      const int leader = valid ? (__ffsll((long long)m) - 1) : lane;
+      uint32_t base = 0;
+      if (valid && lane == leader) {
+        uint16_t *c = cnt + r * NW + w;
+        base = *c;
+        *c = (uint16_t)(base + (uint32_t)__popcll(m));
+      }
+      base = (uint32_t)__shfl((int)base, leader, 64);
+      if (valid) at[q] = (r << 16) | (base + (uint32_t)__popcll(m & ltMask));
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  __syncthreads();
+  {  // exclusive prefix over cnt in [digit][wavefront] order: four consecutive counters per thread
+    uint16_t *c = cnt + 4 * tid;
+    const uint32_t a0 = c[0], a1 = c[1], a2 = c[2], a3 = c[3];
+    uint32_t tot;
+    const uint32_t ex = t1k_block_scan_exclusive_n<NW>(a0 + a1 + a2 + a3, warpSums, &tot);
+    c[0] = (uint16_t)ex; c[1] = (uint16_t)(ex + a0); c[2] = (uint16_t)(ex + a0 + a1); c[3] = (uint16_t)(ex + a0 + a1 + a2);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < ROUNDS; ++q) {
+    if ((uint32_t)q * 64u < seg) {
+      if (at[q] != 0xFFFFFFFFu) key[(uint32_t)cnt[(at[q] >> 16) * NW + w] + (at[q] & 0xFFFFu)] = kk[q];
+    }
+  }
+  __syncthreads();
+}
+
 // entry layout: [0 | 2047 - matchCnt : 11 | span sum : 11 | 511 - read span : 9 | allele : aBits | index : iBits], bit 63 is the
 // emit mark of k_select.  Returns false if a field does not fit.
 __device__ __forceinline__ bool packSortKey(int m, int d, int rspan, uint32_t allele, uint32_t index, int aBits, int iBits, uint64_t *out) {
@@ -298,6 +425,8 @@ __global__ __launch_bounds__(NT) T1K_OCC8 void k_select(SelectArgs P) {
   __shared__ uint32_t warpSums[NT / 64];
   __shared__ int sLatch, sGood, sBest, sTie;
   __shared__ uint32_t sBase;
+  __shared__ CsTables sCs;
+  __shared__ uint16_t sCnt[256 * (NT / 64)];
   const int tid = threadIdx.x;
   unsigned int nbTotal = 0;
   for (uint32_t re = blockIdx.x; re < P.reads.nReadEnds; re += gridDim.x) {
@@ -306,18 +435,17 @@ __global__ __launch_bounds__(NT) T1K_OCC8 void k_select(SelectArgs P) {
       if (tid == 0 && SELECT_LDS_CAP == SELECT_SMALL) { P.ovlStart[re] = 0; P.ovlCount[re] = 0; }
       continue;
     }
-    // candidates that failed the similarity filter never reach the sort: count the survivors first
-    __shared__ uint32_t sLive;
-    if (tid == 0) sLive = 0;
-    __syncthreads();
+    // candidates that failed the similarity filter never reach the sort: count the survivors first.  Thread t looks at the
+    // candidates [t * per, (t + 1) * per) and will put its survivors at myFirst, myFirst + 1, ...: the list keeps the order in
+    // which k_collect wrote it (allele order), which the counting sort below relies on
+    const uint32_t per = (n + NT - 1) / NT;
+    const uint32_t iBeg = min(n, (uint32_t)tid * per), iEnd = min(n, iBeg + per);
+    uint32_t live, myFirst;
     {
       uint32_t mine = 0;
-      for (uint32_t i = tid; i < n; i += NT) mine += (P.ext[c0 + i].flags & T1K_F_DROP) ? 0u : 1u;
-      if (mine) atomicAdd(&sLive, mine);
+      for (uint32_t i = iBeg; i < iEnd; ++i) mine += (P.ext[c0 + i].flags & T1K_F_DROP) ? 0u : 1u;
+      myFirst = t1k_block_scan_exclusive_n<NT / 64>(mine, warpSums, &live);
     }
-    __syncthreads();
-    const uint32_t live = sLive;
-    __syncthreads();
     if ((live > SELECT_SMALL) != (SELECT_LDS_CAP == SELECT_LARGE)) continue;  // the other instantiation's read-end
     if (live == 0) {
       if (tid == 0) { P.ovlStart[re] = 0; P.ovlCount[re] = 0; }
@@ -339,10 +467,8 @@ __global__ __launch_bounds__(NT) T1K_OCC8 void k_select(SelectArgs P) {
     const int mShift = 19 + P.alleleBits + iBits + 3;  // position of the (1023 - matchCnt) field
     auto idxOf = [&](uint64_t kk) { return (uint32_t)((kk >> 3) & iMask); };
     auto seedOf = [&](uint64_t kk) { return 1023 - (int)((kk >> mShift) & 0x3FF); };
-    if (tid == 0) sLive = 0;
-    for (uint32_t i = tid; i < np2; i += NT) key[i] = ~0ull;
-    __syncthreads();
-    for (uint32_t i = tid; i < n; i += NT) {
+    for (uint32_t i = live + tid; i < np2; i += NT) key[i] = ~0ull;
+    for (uint32_t i = iBeg; i < iEnd; ++i) {
       const uint16_t fl = P.ext[c0 + i].flags;
       if (fl & T1K_F_DROP) continue;
       const T1kCand c = P.cand[c0 + i];
@@ -352,13 +478,16 @@ __global__ __launch_bounds__(NT) T1K_OCC8 void k_select(SelectArgs P) {
       const double sim = (double)m / (double)(c.seqEnd - c.seqStart + 1 + rend - rs + 1);
       const uint32_t kf = ((fl & T1K_F_SEPSEED) ? SEL_F_SEPSEED : 0u) | ((fl & T1K_F_EXTOK) ? SEL_F_EXTOK : 0u) |
                           (((fl & T1K_F_NEEDCLIP) && !(sim < 0.95)) ? SEL_F_KEEPCLIP : 0u);  // SeqSet.hpp:2170-2172
-      uint32_t slot = atomicAdd(&sLive, 1u);  // any order: the sort follows
+      const uint32_t slot = myFirst++;
       uint64_t kk;
       if (!packSelectKey(m, d, rspan, c.allele & 0x7FFFFFFFu, i, kf, P.alleleBits, iBits, &kk)) { atomicOr(&P.counters[2], (unsigned long long)ERR_SORTCAP); kk = (uint64_t)i << 3; }
       key[slot] = kk;
     }
     __syncthreads();
-    bitonicSort(key, np2);
+    // the list is in allele order: one stable pass by the (seed matchCnt, span sum, read span) class orders it; the bitonic network
+    // on the whole key takes the lists with more than 256 classes and the ones that live in HBM scratch
+    if (key != sKey || !ldsClassRanks<NT>(key, live, P.alleleBits + iBits + 3, sCs)) bitonicSort(key, np2);
+    else ldsCountingPass<NT>(key, live, sCnt, warpSums, [&](uint64_t kk) { return csRankOf(sCs, (uint32_t)(kk >> (P.alleleBits + iBits + 3))); });
     // resolve ties of the packed key with the remaining comparator fields (same allele, same spans)
     const uint32_t nAll = n;
     (void)nAll;
@@ -787,6 +916,9 @@ __global__ __launch_bounds__(NT) void k_truncate(TruncArgs P) {
   extern __shared__ uint64_t dynLds[];
   uint64_t *sKey = dynLds;
   __shared__ uint32_t sCut, sTie2;
+  __shared__ uint32_t warpSums[NT / 64];
+  __shared__ CsTables sCs;
+  __shared__ uint16_t sCnt[256 * (NT / 64)];
   const int tid = threadIdx.x;
   for (uint32_t re = blockIdx.x; re < P.reads.nReadEnds; re += gridDim.x) {
     const uint32_t n = P.ovlCount[re], o0 = P.ovlStart[re];
@@ -816,7 +948,14 @@ __global__ __launch_bounds__(NT) void k_truncate(TruncArgs P) {
       key[i] = kk;
     }
     __syncthreads();
-    bitonicSort(key, np2);
+    // the list arrives in k_select's order, not in allele order: stable passes over the allele's bytes first, then one over the
+    // class (matchCnt, span sum, read span); lists with more than 256 classes and the ones in HBM scratch: the bitonic network
+    if (key != sKey || !ldsClassRanks<NT>(key, n, P.alleleBits + iBits, sCs)) bitonicSort(key, np2);
+    else {
+      for (int sh = 0; sh < P.alleleBits; sh += 8)
+        ldsCountingPass<NT>(key, n, sCnt, warpSums, [&](uint64_t kk) { return (uint32_t)(kk >> (iBits + sh)) & (P.alleleBits - sh >= 8 ? 0xFFu : ((1u << (P.alleleBits - sh)) - 1u)); });
+      ldsCountingPass<NT>(key, n, sCnt, warpSums, [&](uint64_t kk) { return csRankOf(sCs, (uint32_t)(kk >> (P.alleleBits + iBits))); });
+    }
     if (tid == 0) { sCut = n; sTie2 = 0; }
     __syncthreads();
     for (uint32_t i = 1 + tid; i < n; i += NT)
