@@ -17,6 +17,11 @@
 #include "t1k_launch.h"
 
 #define WG 256
+#ifdef T1K_PAIR_PROFILE
+#define PP(i) do { if (tid == 0) { const uint64_t tn_ = __builtin_amdgcn_s_memtime(); tp_[i] += tn_ - tl_; tl_ = tn_; } } while (0)
+#else
+#define PP(i) do { } while (0)
+#endif
 #define SORT_TILE 2048
 // Join table of one fragment in LDS: allele -> (index in list 1 + 1) | membership bit 15 | (index in list 2 + 1) << 16.  Open addressing,
 // 4096 slots; fragments whose two lists hold more than LJ_CAP overlaps (or a list with a repeated allele) use the per-workgroup
@@ -193,6 +198,9 @@ __global__ __launch_bounds__(WG) void k_pair(PairArgs P) {
   uint64_t *tabSlot = P.tabSlot + (uint64_t)blockIdx.x * A;
   Frag *frags = P.frags + (uint64_t)blockIdx.x * P.fragCap;
   uint32_t *keep = P.keep + (uint64_t)blockIdx.x * P.fragCap;
+#ifdef T1K_PAIR_PROFILE
+  uint64_t tp_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tl_ = __builtin_amdgcn_s_memtime();
+#endif
   const uint32_t nItems = P.only ? P.nOnly : P.nFragments;
   for (uint32_t it = blockIdx.x; it < nItems; it += gridDim.x) {
     const uint32_t f = P.only ? P.only[it] : it;
@@ -253,6 +261,7 @@ __global__ __launch_bounds__(WG) void k_pair(PairArgs P) {
       __syncthreads();
     }
     const bool dup = sDup != 0;
+    PP(0);
     if (!dup) {
       // ---- fast path: every allele at most once per list -> `assign` == fragment list, in list order ----------------
       if (!both) {
@@ -331,6 +340,7 @@ __global__ __launch_bounds__(WG) void k_pair(PairArgs P) {
       __syncthreads();
       nFrag = sN;
     }
+    PP(1);
     // ---- best fragment: max matchCnt, then max similarity, first in order (2474-2487) --------------------------------
     {
       int bm = -1, bi = 0x7FFFFFFF; double bs = 0;
@@ -375,6 +385,7 @@ __global__ __launch_bounds__(WG) void k_pair(PairArgs P) {
     const int bestM = sBestM;
     const double bestSim = sBestSim;
     const int bestRelaxed = nFrag ? frags[sBestIdx].relaxed : 0;
+    PP(2);
     // ---- keep filter (2488-2545), order-preserving -----------------------------------------------------------------------
     uint32_t nKept = 0;
     for (uint32_t q0 = 0; q0 < nFrag; q0 += WG) {
@@ -396,6 +407,7 @@ __global__ __launch_bounds__(WG) void k_pair(PairArgs P) {
       nKept += tot;
     }
     __syncthreads();
+    PP(3);
     // ---- dangling-mate rule (2553-2578) ----------------------------------------------------------------------------------
     bool cleared = false;
     if (nKept > 0 && paired && !(frags[keep[0]].i >= 0 && frags[keep[0]].j >= 0)) {
@@ -451,6 +463,7 @@ __global__ __launch_bounds__(WG) void k_pair(PairArgs P) {
       __syncthreads();
       cleared = sFail != 0;
     }
+    PP(4);
     if (cleared) nKept = 0;
     // ---- Genotyper::SetReadAssignments (778-832) ------------------------------------------------------------------------------
     bool emptyRow = nKept == 0 || (!P.rawKept && P.maxAssign > 0 && (int)nKept > P.maxAssign);
@@ -502,6 +515,7 @@ __global__ __launch_bounds__(WG) void k_pair(PairArgs P) {
       __syncthreads();
       continue;
     }
+    PP(5);
     // ---- rowset form: the row ordered by allele index (the order of a coalesced group's entries, Genotyper.hpp:847-853), its place
     // in the list kept in the `qual` slot (all assignment qualities are 1), and a 128-bit hash of the allele pattern ---------------
     __shared__ unsigned long long sRowBase;
@@ -528,6 +542,7 @@ __global__ __launch_bounds__(WG) void k_pair(PairArgs P) {
       }
     }
     __syncthreads();
+    PP(6);
     unsigned long long h1 = 0, h2 = 0;
     const bool fits = sRowBase != ~0ull;
     for (uint32_t q = tid; q < nRow; q += WG) {
@@ -557,7 +572,11 @@ __global__ __launch_bounds__(WG) void k_pair(PairArgs P) {
       P.rsAssigned[g] = anyKept ? 1 : 0;
     }
     __syncthreads();
+    PP(7);
   }
+#ifdef T1K_PAIR_PROFILE
+  if (tid == 0) for (int i = 0; i < 8; ++i) atomicAdd(&P.counters[32 + i], (unsigned long long)tp_[i]);
+#endif
 }
 
 // shared by t1k_pair_batch (rs == NULL) and t1k_pair_into
@@ -660,6 +679,9 @@ static int pairLaunch(t1k_ctx *ctx, t1k_rowset *rs, const uint32_t *end1, const 
     if (hc[2]) return t1k_fail(ctx, T1K_ERR_CAPACITY, "device arena overflow: row_cap / fragment scratch");
     if (!rs) ctx->nRows = hc[9];
     ctx->stats.rows = hc[9]; ctx->stats.pair_overlaps = hc[22];
+#ifdef T1K_PAIR_PROFILE
+    fprintf(stderr, "[t1k] pair phases (ticks, thread 0 of every workgroup): tables %llu join %llu best %llu keep %llu rules %llu setreads %llu rank %llu rows+hash %llu\n", hc[32], hc[33], hc[34], hc[35], hc[36], hc[37], hc[38], hc[39]);
+#endif
     return T1K_OK;
   }
 }
