@@ -336,6 +336,42 @@ def test_several_files_per_mate_and_wrapped_fasta(built, tmp_path):
     _golden_files_equal(c, out)
 
 
+@pytest.mark.parametrize("gpus", ["0,0", "0,0,0"])
+def test_own_input_sharding_over_several_files_per_mate(built, tmp_path, gpus):
+    """ranks that index only their own reads, with the reads of each mate spread over three files of unequal size (the multi-GPU
+    benchmark gives one file per rank): the slices of the ranks start and end inside files and span file boundaries; one file ends
+    without a newline, one has CRLF line ends.  Every output file must equal the single-file golden run."""
+    c = goldens.Case("cyp_rna_2x100", str(tmp_path))
+    args = ["-f", c.ref]
+    for m, path in ((1, c.r1), (2, c.r2)):
+        lines = open(path).read().split("\n")
+        recs = [lines[i:i + 4] for i in range(0, len(lines) - 1, 4)]
+        n = len(recs)
+        cuts = [0, n // 7, n // 7 + n // 2, n]
+        for k in range(3):
+            part = os.path.join(str(tmp_path), "p%d_%d.fq" % (k, m))
+            text = "".join("\n".join(r) + "\n" for r in recs[cuts[k]:cuts[k + 1]])
+            if k == 0:
+                text = text[:-1]                       # no newline at the end of the file
+            if k == 1:
+                text = text.replace("\n", "\r\n")
+            with open(part, "w", newline="") as f:
+                f.write(text)
+            args += ["-%d" % m, part]
+    out = os.path.join(str(tmp_path), "multi_own")
+    r = subprocess.run([GENO] + args + c.flags + ["-o", out], stderr=subprocess.PIPE, text=True,
+                       env=dict(os.environ, T1K_GPUS=gpus, T1K_SHARD_INPUT="1", T1K_DEBUG_PHASES="1"))
+    assert r.returncode == 0, r.stderr
+    parts = [(int(a), int(b)) for a, b in re.findall(r"mapped \+ indexed: (\d+) of (\d+) fragments", r.stderr)]
+    assert len(parts) == len(gpus.split(",")) and all(0 < a < b for a, b in parts) and sum(a for a, _ in parts) == parts[0][1], parts
+    _golden_files_equal(c, out)
+    one = os.path.join(str(tmp_path), "one")
+    r1 = subprocess.run([GENO] + c.args() + ["-o", one], stderr=subprocess.PIPE, text=True)
+    assert r1.returncode == 0, r1.stderr
+    for suf in ("_aligned_1.fa", "_aligned_2.fa"):
+        assert open(out + suf, "rb").read() == open(one + suf, "rb").read(), suf
+
+
 def test_over_long_read_fails_before_any_output(built, tmp_path):
     """reads longer than max_read_len (320) are not handled by this build: the run must stop with a message BEFORE an output file exists"""
     c = goldens.Case("cyp_rna_2x100", str(tmp_path))
