@@ -261,6 +261,9 @@ __global__ __launch_bounds__(WG) void k_pair(PairArgs P) {
       __syncthreads();
     }
     const bool dup = sDup != 0;
+    int tbM = -1, tbI = 0x7FFFFFFF;  // best fragment seen by this lane while it built the list (paired fast path only)
+    double tbS = 0;
+    bool tracked = false;
     PP(0);
     if (!dup) {
       // ---- fast path: every allele at most once per list -> `assign` == fragment list, in list order ----------------
@@ -270,6 +273,7 @@ __global__ __launch_bounds__(WG) void k_pair(PairArgs P) {
           if (q < n1) { const T1kOvl o = L1[q]; makeFrag(frags[q], &o, (int)q, nullptr, -1); } else { const T1kOvl o = L2[q - n1]; makeFrag(frags[q], nullptr, -1, &o, (int)(q - n1)); }
         }
       } else {
+        tracked = true;
         const int s1 = ovlStrand(L1[0]), s2 = ovlStrand(L2[0]);
         for (uint32_t i0 = 0; i0 < n1; i0 += WG) {
           uint32_t i = i0 + tid;
@@ -290,7 +294,11 @@ __global__ __launch_bounds__(WG) void k_pair(PairArgs P) {
           uint32_t off = scanExcl(j >= 0 ? 1u : 0u, warpSums, &tot);
           if (j >= 0) {
             const T1kOvl oa = L1[i], ob = L2[j];
-            makeFrag(frags[nFrag + off], &oa, (int)i, &ob, j);
+            Frag fr;
+            makeFrag(fr, &oa, (int)i, &ob, j);
+            frags[nFrag + off] = fr;
+            // this lane's best fragment so far (its fragments come in list order: the first maximal one stays)
+            if (fr.matchCnt > tbM || (fr.matchCnt == tbM && fr.sim > tbS)) { tbM = fr.matchCnt; tbS = fr.sim; tbI = (int)(nFrag + off); }
             // the mate's allele has a fragment (seqIdxToOverlapIdx membership)
             if (lds) atomicOr(&hVal[slot], 0x8000u); else tab2[L1[i].allele] |= 0x80000000ull;
           }
@@ -342,45 +350,67 @@ __global__ __launch_bounds__(WG) void k_pair(PairArgs P) {
     }
     PP(1);
     // ---- best fragment: max matchCnt, then max similarity, first in order (2474-2487) --------------------------------
-    {
-      int bm = -1, bi = 0x7FFFFFFF; double bs = 0;
-      for (uint32_t q = tid; q < nFrag; q += WG) {
-        const Frag &fr = frags[q];
-        if (fr.matchCnt > bm || (fr.matchCnt == bm && fr.sim > bs)) { bm = fr.matchCnt; bs = fr.sim; bi = (int)q; }
+    if (tracked) {
+      // max matchCnt, then max similarity, then the smallest index: reduced over the lanes' own bests with shuffles
+      int m = tbM, ix = tbI; double sm = tbS;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const int om = __shfl_xor(m, o, 64), oi = __shfl_xor(ix, o, 64);
+        const double os = __shfl_xor(sm, o, 64);
+        if (om > m || (om == m && (os > sm || (os == sm && oi < ix)))) { m = om; sm = os; ix = oi; }
       }
-      atomicMax(&sBestM, bm);
+      __shared__ int sWM[4], sWI[4];
+      __shared__ double sWS[4];
+      if ((tid & 63) == 0) { sWM[tid >> 6] = m; sWS[tid >> 6] = sm; sWI[tid >> 6] = ix; }
       __syncthreads();
-      if (tid == 0) sBestSim = -1;
+      if (tid == 0) {
+        int bm = sWM[0], bi = sWI[0]; double bs = sWS[0];
+        for (int w = 1; w < 4; ++w)
+          if (sWM[w] > bm || (sWM[w] == bm && (sWS[w] > bs || (sWS[w] == bs && sWI[w] < bi)))) { bm = sWM[w]; bs = sWS[w]; bi = sWI[w]; }
+        sBestM = bm; sBestSim = bm >= 0 ? bs : -1.0; sBestIdx = bi;
+      }
       __syncthreads();
-      // among the lanes holding the best matchCnt: max similarity (serialised through a CAS-free two-step)
-      __shared__ double sSim[WG];
-      __shared__ int sIdx2[WG];
-      sSim[tid] = (bm == sBestM && bm >= 0) ? bs : -1.0;
-      sIdx2[tid] = (bm == sBestM && bm >= 0) ? bi : 0x7FFFFFFF;
-      __syncthreads();
-      for (int o = WG / 2; o > 0; o >>= 1) {
-        if (tid < o) {
-          double a = sSim[tid], b = sSim[tid + o];
-          int ia = sIdx2[tid], ib = sIdx2[tid + o];
-          if (b > a || (b == a && ib < ia)) { sSim[tid] = b; sIdx2[tid] = ib; }
+    } else {
+      {
+        int bm = -1, bi = 0x7FFFFFFF; double bs = 0;
+        for (uint32_t q = tid; q < nFrag; q += WG) {
+          const Frag &fr = frags[q];
+          if (fr.matchCnt > bm || (fr.matchCnt == bm && fr.sim > bs)) { bm = fr.matchCnt; bs = fr.sim; bi = (int)q; }
         }
+        atomicMax(&sBestM, bm);
+        __syncthreads();
+        if (tid == 0) sBestSim = -1;
+        __syncthreads();
+        // among the lanes holding the best matchCnt: max similarity (serialised through a CAS-free two-step)
+        __shared__ double sSim[WG];
+        __shared__ int sIdx2[WG];
+        sSim[tid] = (bm == sBestM && bm >= 0) ? bs : -1.0;
+        sIdx2[tid] = (bm == sBestM && bm >= 0) ? bi : 0x7FFFFFFF;
+        __syncthreads();
+        for (int o = WG / 2; o > 0; o >>= 1) {
+          if (tid < o) {
+            double a = sSim[tid], b = sSim[tid + o];
+            int ia = sIdx2[tid], ib = sIdx2[tid + o];
+            if (b > a || (b == a && ib < ia)) { sSim[tid] = b; sIdx2[tid] = ib; }
+          }
+          __syncthreads();
+        }
+        if (tid == 0) { sBestSim = sSim[0]; sBestIdx = sIdx2[0]; }
         __syncthreads();
       }
-      if (tid == 0) { sBestSim = sSim[0]; sBestIdx = sIdx2[0]; }
-      __syncthreads();
-    }
-    // a lane's local best is its first maximal element, but a later element of the same lane could tie the global best
-    // with a smaller index than another lane's: resolve "first in order" exactly
-    {
-      int mine = 0x7FFFFFFF;
-      for (uint32_t q = tid; q < nFrag; q += WG) {
-        const Frag &fr = frags[q];
-        if (fr.matchCnt == sBestM && fr.sim == sBestSim) { mine = (int)q; break; }
+      // a lane's local best is its first maximal element, but a later element of the same lane could tie the global best
+      // with a smaller index than another lane's: resolve "first in order" exactly
+      {
+        int mine = 0x7FFFFFFF;
+        for (uint32_t q = tid; q < nFrag; q += WG) {
+          const Frag &fr = frags[q];
+          if (fr.matchCnt == sBestM && fr.sim == sBestSim) { mine = (int)q; break; }
+        }
+        if (tid == 0) sBestIdx = 0x7FFFFFFF;
+        __syncthreads();
+        if (mine != 0x7FFFFFFF) atomicMin(&sBestIdx, mine);
+        __syncthreads();
       }
-      if (tid == 0) sBestIdx = 0x7FFFFFFF;
-      __syncthreads();
-      if (mine != 0x7FFFFFFF) atomicMin(&sBestIdx, mine);
-      __syncthreads();
     }
     const int bestM = sBestM;
     const double bestSim = sBestSim;
