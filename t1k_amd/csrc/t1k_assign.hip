@@ -610,7 +610,47 @@ __global__ __launch_bounds__(WG) void k_fullalign(FullArgs P) {
   // words (MATCH column, read base not N (2261-2265); an N allele base never feeds GetSeqMissingBaseCoverage's counter of the
   // allele's own base, so it is left out)
   uint64_t covw[10];  // reads are at most 320 bp
-  if (!slow) {
+  if (!slow && L <= 160) {
+    // the usual read length: the allele window (6 words) comes in with three 16-byte loads per array instead of one load pair per
+    // 32-base piece -- every lane's window is in another cache line, so the number of load instructions is what the kernel pays for --
+    // and the N mask of an allele without N is not fetched at all
+    typedef uint64_t u64x2 __attribute__((ext_vector_type(2), aligned(8)));
+    uint64_t gB[6], gN[6], rB[6], rN[6], gE[6];
+    const int64_t gpos = goff + o.seqStart;
+    const int64_t gw = gpos >> 5, rw = o.readStart >> 5;
+    const int gsh = (int)(gpos & 31) * 2, rsh = (o.readStart & 31) * 2;
+    const bool hasN = P.ref.alleleHasN[o.allele] != 0;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const u64x2 a = *(const u64x2 *)(P.ref.bases + gw + 2 * q), b = *(const u64x2 *)(rb + rw + 2 * q), c = *(const u64x2 *)(rn + rw + 2 * q);
+      gB[2 * q] = a.x; gB[2 * q + 1] = a.y; rB[2 * q] = b.x; rB[2 * q + 1] = b.y; rN[2 * q] = c.x; rN[2 * q + 1] = c.y;
+      gN[2 * q] = 0; gN[2 * q + 1] = 0; gE[2 * q] = 0; gE[2 * q + 1] = 0;
+    }
+    if (hasN) {
+#pragma unroll
+      for (int q = 0; q < 3; ++q) { const u64x2 a = *(const u64x2 *)(P.ref.nmask + gw + 2 * q); gN[2 * q] = a.x; gN[2 * q + 1] = a.y; }
+    }
+    if (P.relax) {
+#pragma unroll
+      for (int q = 0; q < 3; ++q) { const u64x2 a = *(const u64x2 *)(P.ref.exon + gw + 2 * q); gE[2 * q] = a.x; gE[2 * q + 1] = a.y; }
+    }
+    auto piece = [](const uint64_t *W, int wi, int sh) { return (W[wi] >> sh) | ((W[wi + 1] << 1) << (63 - sh)); };
+#pragma unroll
+    for (int wi = 0; wi < 10; ++wi) {
+      const int off = wi * 32;
+      covw[wi] = 0;
+      if (wi < 5 && off < L) {
+        const uint64_t lm = t1k_lowmask(L - off);
+        const uint64_t rnn = piece(rN, wi, rsh), gnn = piece(gN, wi, gsh);
+        const uint64_t xo = piece(rB, wi, rsh) ^ piece(gB, wi, gsh);
+        const uint64_t mm = (xo | (xo >> 1)) & T1K_EVEN & ~(rnn | gnn) & lm;
+        x += __popcll(mm);
+        if (P.relax) exonMis += __popcll(mm & piece(gE, wi, gsh));
+        covw[wi] = T1K_EVEN & lm & ~mm & ~rnn & ~gnn;
+      }
+    }
+    if (x > 3) slow = true;
+  } else if (!slow) {
 #pragma unroll
     for (int wi = 0; wi < 10; ++wi) {
       const int off = wi * 32;

@@ -207,7 +207,8 @@ extern "C" int t1k_ref_upload(t1k_ctx *ctx, const char *seqs, const uint64_t *of
   int rc;
   // resident arrays
   void *dBases, *dN, *dExon, *dAlleleOff, *dAlleleLen, *dHasN, *dSepStart, *dSepPos;
-  if ((rc = keep(ctx, nWords * 8, &dBases)) || (rc = keep(ctx, nWords * 8, &dN)) || (rc = keep(ctx, nWords * 8, &dExon)) || (rc = keep(ctx, (size_t)nAlleles * 8, &dAlleleOff)) ||
+  if ((rc = keep(ctx, (nWords + 8) * 8, &dBases)) || (rc = keep(ctx, (nWords + 8) * 8, &dN)) || (rc = keep(ctx, (nWords + 8) * 8, &dExon))  // (+8: kernels fetch a window as six whole words)
+      || (rc = keep(ctx, (size_t)nAlleles * 8, &dAlleleOff)) ||
       (rc = keep(ctx, (size_t)nAlleles * 4, &dAlleleLen)) || (rc = keep(ctx, nAlleles, &dHasN)) || (rc = keep(ctx, (size_t)(nAlleles + 1) * 4, &dSepStart)) ||
       (rc = keep(ctx, sepPos.size() * 4, &dSepPos)))
     return rc;
