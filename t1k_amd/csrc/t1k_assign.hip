@@ -802,8 +802,9 @@ __global__ __launch_bounds__(WG) void k_align_reps(const uint32_t *flags, const 
 template <bool EQ>
 __global__ __launch_bounds__(WG) void k_align_fill(SlowArgs P) {
   const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
-  if (u >= P.nRuns) return;
-  const uint32_t q = P.rep[u];
+  unsigned long long cells = 0;
+  if (u < P.nRuns) {
+    const uint32_t q = P.rep[u];
     const uint32_t gid = P.slowQueue[q];
     const T1kOvl o = P.ovl[gid];
     const int pass = (o.flags & 2) ? 1 : 0;
@@ -816,6 +817,12 @@ __global__ __launch_bounds__(WG) void k_align_fill(SlowArgs P) {
     uint64_t *trace = (uint64_t *)P.scratch + u;
     if (EQ) t1k_ga_equal_traced(T, Pv, lp, trace, P.traceStride);
     else t1k_ga_band<4, true>(T, lt, Pv, lp, trace, P.traceStride);
+    cells = (unsigned long long)lp * (EQ ? 11u : 9u);  // in-band cells per row: 11 in the equal-span sweep, the 9 diagonals of the +-4 band
+  }
+  // statistics: DP cells filled, one atomic per wavefront
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) cells += __shfl_xor(cells, o, 64);
+  if ((threadIdx.x & 63) == 0 && cells) atomicAdd(&P.counters[24], cells);
 }
 
 __global__ __launch_bounds__(WG) void k_align_apply_eq(SlowArgs P) {

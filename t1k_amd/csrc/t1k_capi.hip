@@ -772,7 +772,7 @@ static int assignOnce(t1k_ctx *ctx, uint64_t first, uint32_t count) {
   }
   t1k_stats &st = ctx->stats;
   st.read_ends = n; st.lookups = hc[3]; st.postings = hc[4]; st.hits = hc[5]; st.groups = hc[6]; st.candidates = hc[0]; st.extended = hc[1];
-  st.dp_calls = hc[7] + hc[14]; st.near_best = hc[10];
+  st.dp_calls = hc[7] + hc[14]; st.near_best = hc[10]; st.dp_cells = hc[24];
   float ms[4] = {0, 0, 0, 0}, msSeed = 0;  // kernel durations from HIP events on the launch stream
   for (int i = 0; i < 4; ++i) (void)hipEventElapsedTime(&ms[i], ctx->ev[i], ctx->ev[i + 1]);
   (void)hipEventElapsedTime(&msSeed, ctx->ev[0], ctx->ev[8]);

@@ -5,7 +5,7 @@
 mkdir -p gpurun_out /tmp/t1k_bench
 export TMPDIR=/tmp
 PAIRS=${1:-10000000}
-python -c "import bench; bench.ensure_inputs('/tmp/t1k_bench', $PAIRS, 24, 1.0, seed=2); bench.ensure_inputs('/tmp/t1k_bench', 1000000, 24, 1.0, seed=2)"
+cd /root/repo && python -c "import bench; bench.ensure_inputs('/tmp/t1k_bench', $PAIRS, 24, 1.0, seed=2); bench.ensure_inputs('/tmp/t1k_bench', 1000000, 24, 1.0, seed=2)"
 ( cd /tmp && rocprofv3 --kernel-trace --stats -d /tmp/prof_bench -o bench -- python /root/repo/bench.py --pairs $PAIRS --steps 2 --warmup 1 --no-cpu-baseline > /root/repo/gpurun_out/r02_bench_under_profiler.json 2> /root/repo/gpurun_out/r02_bench_under_profiler.err )
 python tools/rocpd_stats.py $(ls /tmp/prof_bench/*.db | head -1) > gpurun_out/r02_kernel_stats.csv
 for c in FETCH_SIZE WRITE_SIZE; do
