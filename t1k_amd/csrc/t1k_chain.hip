@@ -654,32 +654,48 @@ __global__ __launch_bounds__(WG) T1K_OCC8 void k_seed_groups(ChainArgs P) {
 #ifdef T1K_SEED_PROFILE
     { const uint64_t tn_ = __builtin_amdgcn_s_memtime(); tp_[5] += tn_ - tl_; tl_ = tn_; }
 #endif
-        // walk the chunk's postings (flat index -> list by binary search over the prefix), four in flight per lane
-        for (uint32_t j0 = tid; j0 < T; j0 += 4 * WG) {
-          T1kPosting pst[4];
-          int rr[4];
-#pragma unroll
-          for (int x = 0; x < 4; ++x) {
-            const uint32_t j = j0 + x * WG;
-            if (j < T) {
-              uint32_t lo = 0, hi = uCount;
-              while (hi - lo > 1) { uint32_t m = (lo + hi) >> 1; if (pre[m] <= j) lo = m; else hi = m; }
-              pst[x] = P.ref.kPost[lstStart[uBegin + lo] + sLo[lo] + (j - pre[lo])];
-              rr[x] = qOf[uBegin + lo];
-            }
+        // walk the chunk's postings.  The flat posting index [0, T) is cut into one contiguous range per wavefront; a lane finds the
+        // list of its first posting by bisection over the prefix ONCE, and from there its list index only moves forward (its
+        // positions grow by 64 a step), so the later postings cost a look at one or two prefix entries instead of a bisection each.
+        // Four postings in flight per lane; 64 consecutive postings per wavefront load.
+        {
+          const uint32_t wv = (uint32_t)tid >> 6, ln = (uint32_t)tid & 63u;
+          const uint32_t Rw = (((T + 3) >> 2) + 63u) & ~63u;
+          const uint32_t jBeg = wv * Rw, jEnd = min(T, jBeg + Rw);
+          uint32_t lo = 0;
+          if (jBeg + ln < jEnd) {
+            const uint32_t j = jBeg + ln;
+            uint32_t hi = uCount;
+            while (hi - lo > 1) { uint32_t m = (lo + hi) >> 1; if (pre[m] <= j) lo = m; else hi = m; }
           }
+#ifndef T1K_SEED_INFLIGHT
+#define T1K_SEED_INFLIGHT 4
+#endif
+          for (uint32_t j0 = jBeg + ln; j0 < jEnd; j0 += T1K_SEED_INFLIGHT * 64) {
+            T1kPosting pst[T1K_SEED_INFLIGHT];
+            int rr[T1K_SEED_INFLIGHT];
 #pragma unroll
-          for (int x = 0; x < 4; ++x) {
-            const uint32_t j = j0 + x * WG;
-            if (j < T) {
-              const int r = rr[x];
-              const int d = r - (int)pst[x].offset;
-              uint32_t *a = acc + (pst[x].allele - c0) * AW;
-              const uint32_t old = atomicCAS(&a[0], (uint32_t)DIAG_EMPTY, (uint32_t)d);
-              if (old == (uint32_t)DIAG_EMPTY || old == (uint32_t)d) atomicOr(&a[2 + (r >> 5)], 1u << (r & 31));
-              else {
-                int dd = d - (int)old; if (dd < 0) dd = -dd;
-                atomicAdd(&a[1], dd <= P.radius ? 0x10001u : 1u);
+            for (int x = 0; x < T1K_SEED_INFLIGHT; ++x) {
+              const uint32_t j = j0 + x * 64;
+              if (j < jEnd) {
+                while (pre[lo + 1] <= j) ++lo;  // pre[uCount] = T > j ends it
+                pst[x] = P.ref.kPost[lstStart[uBegin + lo] + sLo[lo] + (j - pre[lo])];
+                rr[x] = qOf[uBegin + lo];
+              }
+            }
+#pragma unroll
+            for (int x = 0; x < T1K_SEED_INFLIGHT; ++x) {
+              const uint32_t j = j0 + x * 64;
+              if (j < jEnd) {
+                const int r = rr[x];
+                const int d = r - (int)pst[x].offset;
+                uint32_t *a = acc + (pst[x].allele - c0) * AW;
+                const uint32_t old = atomicCAS(&a[0], (uint32_t)DIAG_EMPTY, (uint32_t)d);
+                if (old == (uint32_t)DIAG_EMPTY || old == (uint32_t)d) atomicOr(&a[2 + (r >> 5)], 1u << (r & 31));
+                else {
+                  int dd = d - (int)old; if (dd < 0) dd = -dd;
+                  atomicAdd(&a[1], dd <= P.radius ? 0x10001u : 1u);
+                }
               }
             }
           }
@@ -707,9 +723,9 @@ __global__ __launch_bounds__(WG) T1K_OCC8 void k_seed_groups(ChainArgs P) {
           flags |= 2u << (2 * i);  // occupied
           if (onDiag + (int)strays >= 3 && (general || onDiag >= 3)) { flags |= 1u << (2 * i); packed += 1ull << (16 * i); }
         }
-        uint32_t totLo, totHi;
+        uint32_t totLo, totHi = 0, exHi = 0;
         const uint32_t exLo = t1k_block_scan_exclusive((uint32_t)packed, warpSums, &totLo);
-        const uint32_t exHi = t1k_block_scan_exclusive((uint32_t)(packed >> 32), warpSums, &totHi);
+        exHi = t1k_block_scan_exclusive((uint32_t)(packed >> 32), warpSums, &totHi);  // (skipping it when CHUNK_A <= 512 -- the high word is empty then -- measured 4 % SLOWER)
         const uint64_t ex = (uint64_t)exLo | ((uint64_t)exHi << 32), tt = (uint64_t)totLo | ((uint64_t)totHi << 32);
         const uint32_t gTot = (uint32_t)((tt & 0xFFFF) + ((tt >> 16) & 0xFFFF) + ((tt >> 32) & 0xFFFF) + (tt >> 48));
         if (tid == 0) {
