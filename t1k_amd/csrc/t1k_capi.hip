@@ -507,7 +507,9 @@ int t1k_assign_range(t1k_ctx *ctx, uint64_t first, uint32_t count) {
   auto clampCap = [](uint64_t want, uint64_t floor, int64_t limit) { return std::min<uint64_t>((uint64_t)limit, std::max<uint64_t>(want, floor)); };
   // floors per read-end: what a 2x150 bp read-end needs against an HLA-sized reference (about 30 000 alleles: 1 900 groups, 1 000 of
   // them on the gap-walk list, 800 candidates, 610 overlaps), with room to spare; smaller references just leave part of it unused
-  const uint64_t perRe = std::min<uint64_t>(2400, std::max<uint64_t>(256, (uint64_t)ctx->ref.nAlleles / 12));
+  // (the group arena is striped: its fullest stripe decides, and it runs about 1.3 - 1.45 times the average -- 3 350 per read-end
+  // keeps the first ranges of a job from running twice)
+  const uint64_t perRe = std::min<uint64_t>(3400, std::max<uint64_t>(256, (uint64_t)ctx->ref.nAlleles * 23 / 200));
   ctx->wGroup = clampCap(std::max<uint64_t>(ctx->wGroup, (uint64_t)count * perRe), 4u << 20, ctx->prm.group_cap);
   ctx->wCand = clampCap(std::max<uint64_t>(ctx->wCand, (uint64_t)count * perRe * 5 / 12), 2u << 20, ctx->prm.cand_cap);
   ctx->wOvl = clampCap(std::max<uint64_t>(ctx->wOvl, (uint64_t)count * perRe / 3), 2u << 20, ctx->prm.ovl_cap);

@@ -13,9 +13,11 @@ tools/t1k_synth reads --ref $W/hla.fa --pairs 1000000 --len 150 --seed 2 --out $
 say "A. 1 M pairs, HLA-like rna ($(grep -c '>' $W/hla.fa) alleles), -s 0.97"
 SECONDS=0; t1k_amd/bin/genotyper -f $W/hla.fa -1 $W/h_1.fq -2 $W/h_2.fq -s 0.97 -o $W/ours 2> $W/ours.log; say "   this build, 1 GPU: $SECONDS s (rc $?)"
 SECONDS=0; T1K_GPUS=0,0 t1k_amd/bin/genotyper -f $W/hla.fa -1 $W/h_1.fq -2 $W/h_2.fq -s 0.97 -o $W/ours2 2> $W/ours2.log; say "   this build, 2 ranks on one GPU: $SECONDS s (rc $?)"
+SECONDS=0; T1K_GPUS=0,0,0 T1K_SHARD_INPUT=1 t1k_amd/bin/genotyper -f $W/hla.fa -1 $W/h_1.fq -2 $W/h_2.fq -s 0.97 -o $W/ours3 2> $W/ours3.log; say "   this build, 3 ranks on one GPU, each indexing and writing only its own reads: $SECONDS s (rc $?)"
 SECONDS=0; oracle/_ref/genotyper -f $W/hla.fa -1 $W/h_1.fq -2 $W/h_2.fq -s 0.97 -t 64 -o $W/ref 2> $W/ref.log; say "   reference -t 64: $SECONDS s"
 say "  1 GPU vs reference:"; cmpall $W/ours $W/ref
 say "  2 ranks vs reference:"; cmpall $W/ours2 $W/ref
+say "  3 ranks with their own input vs reference:"; cmpall $W/ours3 $W/ref
 say "  EM iterations: ours $(grep -o 'in [0-9]* EM' $W/ours.log) / sharded $(grep -o 'in [0-9]* EM' $W/ours2.log) / reference $(grep -o 'in [0-9]* EM' $W/ref.log)"
 tools/t1k_synth ref-dna --genes 17 --scale 1.0 --seed 20250614 > $W/kir.fa
 tools/t1k_synth reads --ref $W/kir.fa --pairs 10000000 --len 150 --seed 3 --out $W/k
