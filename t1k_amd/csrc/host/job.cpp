@@ -280,6 +280,8 @@ struct Window {
   uint32_t assignBatch = 0, nAssign = 0, nextAssign = 0, doneAssign = 0;
   uint32_t pairBatch = 0, nPair = 0, nextPair = 0, donePair = 0;
   bool ready = false, done = false;
+  std::vector<char> pairDone;       // per pairing range of the window: finished (the output writer follows these)
+  double tReady = 0, tDone = 0, msPrep = 0;
   std::vector<char> touched;        // per pipeline: has it attached to this window yet (first touch empties its store slot)
 };
 }  // namespace
@@ -322,51 +324,77 @@ int t1k_job_run_local(t1k_job *job) {
   std::vector<t1k_ctx *> pipes{job->ctx};
   pipes.insert(pipes.end(), job->more.begin(), job->more.end());
   const int P = (int)pipes.size();
-  uint32_t windowFrags = 1u << 21;
+  // Windows of fragments are cut while the job runs (by the preparation thread).  Large windows matter because identical read-ends
+  // collapse per window: error-free reads of a locus come back in every window (10 M pairs: 5.89 M distinct read-ends with 2 M-fragment
+  // windows, 5.28 M with 8 M).  But a window can only be prepared while the GPU still has the previous one to work on.  So: a small
+  // first window starts the GPU after a short preparation; a later window is as large as can be prepared in the time the GPU needs
+  // for what is already prepared -- both rates are measured on the windows before it -- up to T1K_WINDOW fragments (default 8 M: a
+  // window's overlap lists stay in the store until its fragments are paired, about 6 KB per fragment of an HLA-sized reference).
+  uint32_t windowFrags = 1u << 23;
   if (const char *e = getenv("T1K_WINDOW")) windowFrags = (uint32_t)std::max(64, atoi(e));
   uint32_t assignBatch = job->prm.batch_fragments > 0 ? (uint32_t)job->prm.batch_fragments * per : 32768u;
   if (const char *eb = getenv("T1K_BATCH")) assignBatch = (uint32_t)std::max(64, atoi(eb)) * per;  // tuning aid (in fragments, as in round 1)
   const uint32_t pairBatch = 1u << 16;
-  // the first window is small, so that the GPU starts after a short preparation; the others are prepared while it works
+  const uint32_t maxWindows = 4096;
   std::vector<Window> win;
-  uint32_t firstWindow = std::max<uint32_t>(65536u, windowFrags / 8);
+  win.reserve(maxWindows);  // windows are appended while other threads hold references: the vector never reallocates
+  uint32_t firstWindow = std::min<uint32_t>(windowFrags, std::max<uint32_t>(65536u, windowFrags / 32));
   if (const char *e = getenv("T1K_FIRST_WINDOW")) firstWindow = (uint32_t)std::max(64, atoi(e));
-  for (uint64_t f0 = 0; f0 < F;) {
-    const uint64_t size = win.empty() ? firstWindow : windowFrags;
-    Window W;
-    W.f0 = (uint32_t)f0; W.f1 = (uint32_t)std::min<uint64_t>(F, f0 + size);
-    if (F - W.f1 < windowFrags / 16) W.f1 = F;  // no tiny tail window
-    W.slot = (int)(win.size() & 1);
-    W.touched.assign(P, 0);
-    f0 = W.f1;
-    win.push_back(std::move(W));
-  }
-  const uint32_t nWin = (uint32_t)win.size();
+  double fixedGrowth = 0;  // T1K_WINDOW_GROWTH: a fixed factor instead of the measured one
+  if (const char *e = getenv("T1K_WINDOW_GROWTH")) fixedGrowth = std::max(1.0, atof(e));
   struct Shared {
     std::mutex m;
     std::condition_variable cv;
     int err = T1K_OK;
     std::string errMsg;
     uint32_t oldest = 0;  // first window that is not done
+    uint32_t created = 0; // windows cut so far
+    bool allCreated = false;
   } sh;
   auto fail = [&](int code, const std::string &msg) {
     std::lock_guard<std::mutex> g(sh.m);
     if (sh.err == T1K_OK) { sh.err = code; sh.errMsg = msg; }
     sh.cv.notify_all();
   };
+  sh.allCreated = F == 0;
   double msPrep = 0;
   const bool traceTasks = getenv("T1K_DEBUG_TASKS") != nullptr;
   // ---- window preparation ------------------------------------------------------------------------------------------
   auto prepare = [&] {
     std::vector<char> text[2];
     std::vector<uint64_t> offs[2];
-    for (uint32_t w = 0; w < nWin; ++w) {
-      Window &W = win[w];
+    uint64_t fNext = 0;
+    for (uint32_t w = 0; fNext < F; ++w) {
       {
         std::unique_lock<std::mutex> lk(sh.m);
         sh.cv.wait(lk, [&] { return sh.err != T1K_OK || w < 2 || win[w - 2].done; });  // the read-set context of window w - 2 is free again
         if (sh.err != T1K_OK) return;
+        // size of this window: what can be prepared while the GPU works off the windows that are ready but not done
+        uint64_t size = firstWindow;
+        if (w > 0) {
+          const Window &prev = win[w - 1];
+          const double tp = prev.msPrep / std::max<double>(1, prev.f1 - prev.f0);  // ms per fragment, preparation
+          double tg = 0;                                                            // ms per fragment, GPU (the last finished window)
+          for (uint32_t v = w; v-- > 0;)
+            if (win[v].done && win[v].tDone > win[v].tReady) { tg = (win[v].tDone - win[v].tReady) / std::max<double>(1, win[v].f1 - win[v].f0); break; }
+          uint64_t waiting = 0;  // fragments ready for the GPU and not done yet
+          for (uint32_t v = sh.oldest; v < w; ++v) waiting += win[v].f1 - win[v].f0;
+          double factor = fixedGrowth > 0 ? fixedGrowth : (tg > 0 && tp > 0 ? 0.85 * tg / tp : 6.0);
+          factor = std::min(16.0, std::max(1.0, factor));
+          size = (uint64_t)(factor * (double)std::max<uint64_t>(waiting, firstWindow / 2));
+          size = std::min<uint64_t>(windowFrags, std::max<uint64_t>(size, firstWindow));
+        }
+        Window N;
+        N.f0 = (uint32_t)fNext; N.f1 = (uint32_t)std::min<uint64_t>(F, fNext + size);
+        if (F - N.f1 < size / 4 || w + 1 >= maxWindows) N.f1 = F;  // no small tail window
+        N.slot = (int)(w & 1);
+        N.touched.assign(P, 0);
+        fNext = N.f1;
+        win.push_back(std::move(N));
+        sh.created = w + 1;
+        if (fNext >= F) sh.allCreated = true;
       }
+      Window &W = win[w];
       const double t0 = nowMs();
       const uint32_t nf = W.f1 - W.f0, ne = nf * per;
       std::vector<uint64_t> &off = offs[W.slot];
@@ -409,11 +437,13 @@ int t1k_job_run_local(t1k_job *job) {
       if (r != T1K_OK) { fail(r, t1k_last_error(rd)); return; }
       W.assignBatch = assignBatch; W.nAssign = (W.nDistinct + assignBatch - 1) / assignBatch;
       W.pairBatch = pairBatch; W.nPair = (nf + pairBatch - 1) / pairBatch;
+      W.pairDone.assign(W.nPair, 0);
       if (traceTasks) fprintf(stderr, "[t1k task] prep window %u: %.1f .. %.1f ms (text %.1f ms)\n", w, t0 - tStart, nowMs() - tStart, tText - t0);
       {
         std::lock_guard<std::mutex> g(sh.m);
         job->distinctReadEnds += W.nDistinct;
         msPrep += nowMs() - t0;
+        W.msPrep = nowMs() - t0; W.tReady = nowMs();
         W.ready = true;
       }
       sh.cv.notify_all();
@@ -448,8 +478,8 @@ int t1k_job_run_local(t1k_job *job) {
         std::unique_lock<std::mutex> lk(sh.m);
         for (;;) {
           if (sh.err != T1K_OK) return;
-          if (sh.oldest >= nWin) return;
-          for (w = sh.oldest; w < nWin && w < sh.oldest + 2 && win[w].ready && kind < 0; ++w) {
+          if (sh.allCreated && sh.oldest >= sh.created) return;
+          for (w = sh.oldest; w < sh.created && w < sh.oldest + 2 && win[w].ready && kind < 0; ++w) {
             Window &W = win[w];
             if (W.doneAssign == W.nAssign && W.nextPair < W.nPair) { kind = 1; item = W.nextPair++; }
             else if (W.nextAssign < W.nAssign) { kind = 0; item = W.nextAssign++; }
@@ -489,34 +519,51 @@ int t1k_job_run_local(t1k_job *job) {
       if (traceTasks) fprintf(stderr, "[t1k task] pipe %d window %u %s %u: %.1f .. %.1f ms\n", pi, w, kind == 0 ? "assign" : "pair", item, tTask - tStart, nowMs() - tStart);
       {
         std::lock_guard<std::mutex> g(sh.m);
-        if (kind == 0) ++W.doneAssign; else ++W.donePair;
+        if (kind == 0) ++W.doneAssign; else { ++W.donePair; W.pairDone[item] = 1; }
         if (W.doneAssign == W.nAssign && W.donePair == W.nPair) {
-          W.done = true;
+          W.done = true; W.tDone = nowMs();
           std::vector<uint32_t>().swap(W.distinctOf);
-          while (sh.oldest < nWin && win[sh.oldest].done) ++sh.oldest;
+          while (sh.oldest < sh.created && win[sh.oldest].done) ++sh.oldest;
         }
       }
       sh.cv.notify_all();
     }
   };
-  // ---- read files of a single-GPU job: written window by window behind the loop (all but the last window, which is left to the
-  // writer that runs beside the EM, t1k_job_finish) ---------------------------------------------------------------------------------
+  // ---- read files of a single-GPU job: written behind the loop, pairing range by pairing range (what is not written when the loop
+  // ends is left to the writer that runs beside the EM, t1k_job_finish) ----------------------------------------------------------
   job->streamDone = 0;
-  const bool streaming = !job->outPrefix.empty() && job->nRanks == 1 && !in.sharded && !job->analyzer && nWin > 1 && !getenv("T1K_NO_STREAM_OUTPUT");
+  const bool streaming = !job->outPrefix.empty() && job->nRanks == 1 && !in.sharded && !job->analyzer && F > 0 && !getenv("T1K_NO_STREAM_OUTPUT");
   bool loopEnded = false;
   auto follow = [&] {
     if (!streamOpen(job, job->outPrefix)) { fail(T1K_ERR_IO, job->err); return; }  // (truncating last run's files takes a while: not on the loop's thread)
-    for (uint32_t w = 0; w + 1 < nWin; ++w) {
+    // the writer stays right behind the pairing: a fragment's flag is final when its pairing range is done, and the ranges of a
+    // window are handed out in order, so it appends every run of finished ranges as soon as it is contiguous with what is written
+    for (uint32_t w = 0;; ++w) {
       {
         std::unique_lock<std::mutex> lk(sh.m);
-        sh.cv.wait(lk, [&] { return sh.err != T1K_OK || win[w].done || loopEnded; });
-        if (sh.err != T1K_OK || !win[w].done) return;
+        sh.cv.wait(lk, [&] { return sh.err != T1K_OK || loopEnded || w < sh.created || sh.allCreated; });
+        if (sh.err != T1K_OK || w >= sh.created) return;  // (all windows written, or the loop ended early)
       }
-      const Window &W = win[w];
-      int r = t1k_rowset_assigned_range(job->rows, W.f0, W.f1 - W.f0, job->fragAssigned.data() + fBeg + W.f0);
-      if (r != T1K_OK) { fail(r, t1k_rowset_last_error(job->rows)); return; }
-      if (!streamAppend(job, W.f0, W.f1, true)) { fail(T1K_ERR_IO, job->err); return; }
-      job->streamDone = W.f1;
+      Window &W = win[w];
+      uint32_t next = 0;  // first pairing range of this window that is not written yet
+      for (;;) {
+        uint32_t upto = next;
+        {
+          std::unique_lock<std::mutex> lk(sh.m);
+          sh.cv.wait(lk, [&] { return sh.err != T1K_OK || loopEnded || (W.ready && (next >= W.nPair || W.pairDone[next])); });
+          if (sh.err != T1K_OK) return;
+          if (!W.ready) return;  // the loop ended early
+          while (upto < W.nPair && W.pairDone[upto]) ++upto;
+          if (upto == next && next < W.nPair) return;  // loop ended with ranges open (an error elsewhere)
+        }
+        if (upto == next) break;  // window complete
+        const uint32_t fLo = W.f0 + next * W.pairBatch, fHi = (uint32_t)std::min<uint64_t>(W.f1, (uint64_t)W.f0 + (uint64_t)upto * W.pairBatch);
+        int r = t1k_rowset_assigned_range(job->rows, fLo, fHi - fLo, job->fragAssigned.data() + fBeg + fLo);
+        if (r != T1K_OK) { fail(r, t1k_rowset_last_error(job->rows)); return; }
+        if (!streamAppend(job, fLo, fHi, true)) { fail(T1K_ERR_IO, job->err); return; }
+        job->streamDone = fHi;
+        next = upto;
+      }
     }
   };
   {
@@ -527,7 +574,7 @@ int t1k_job_run_local(t1k_job *job) {
     for (int i = 1; i < P; ++i) others.emplace_back(worker, i);
     worker(0);
     for (auto &t : others) t.join();
-    { std::lock_guard<std::mutex> g(sh.m); if (sh.err == T1K_OK && sh.oldest < nWin) { sh.err = T1K_ERR_INTERNAL; sh.errMsg = "window loop ended early"; } loopEnded = true; }
+    { std::lock_guard<std::mutex> g(sh.m); if (sh.err == T1K_OK && (!sh.allCreated || sh.oldest < sh.created) && F > 0) { sh.err = T1K_ERR_INTERNAL; sh.errMsg = "window loop ended early"; } loopEnded = true; }
     sh.cv.notify_all();
     prep.join();
     if (writer.joinable()) writer.join();
@@ -615,7 +662,7 @@ int t1k_job_run_local(t1k_job *job) {
   }
   if (getenv("T1K_DEBUG_PHASES"))
     fprintf(stderr, "[t1k job] %u windows, %llu read-ends -> %llu distinct; window preparation %.1f ms (overlapped), device loop %.1f ms, coalesce + download %.1f ms (%llu groups, %llu entries)\n",
-            nWin, (unsigned long long)job->readEnds, (unsigned long long)job->distinctReadEnds, msPrep, job->msDevice, job->msCoalesce, (unsigned long long)G, (unsigned long long)N);
+            sh.created, (unsigned long long)job->readEnds, (unsigned long long)job->distinctReadEnds, msPrep, job->msDevice, job->msCoalesce, (unsigned long long)G, (unsigned long long)N);
   job->localDone = true;
   return T1K_OK;
 }
