@@ -562,6 +562,8 @@ int t1k_job_run_local(t1k_job *job) {
         if (r != T1K_OK) { fail(r, t1k_rowset_last_error(job->rows)); return; }
         if (!streamAppend(job, fLo, fHi, true)) { fail(T1K_ERR_IO, job->err); return; }
         job->streamDone = fHi;
+        // nobody reads these records' bytes again: unmap them here, beside the loop (6 GB of page-table entries cost 0.4 s at the end)
+        if (!job->prm.output_read_assignment && fHi > fLo) job->in->release(in.frag[fLo], (size_t)in.frag[fHi - 1] + 1);
         next = upto;
       }
     }

@@ -418,6 +418,30 @@ int ReadInput::openSharded(const std::vector<std::string> &files1, const std::ve
   return 1;
 }
 
+void ReadInput::release(size_t recLo, size_t recHi) {
+  if (recLo >= recHi) return;
+  const long page = sysconf(_SC_PAGESIZE);
+  Side *sides[3] = {&side[0], paired ? &side[1] : nullptr, hasBarcode ? &bc : nullptr};
+  for (Side *sd : sides) {
+    if (!sd || recHi > sd->idP.size() || !sd->idP[recLo]) continue;
+    auto blobOf = [&](const char *p) -> const Blob * {
+      for (const Blob &b : blobs_)
+        if (b.map && p >= (const char *)b.map && p < (const char *)b.map + b.len) return &b;
+      return nullptr;
+    };
+    auto drop = [&](const char *a, const char *b) {  // whole pages inside [a, b)
+      uintptr_t lo = ((uintptr_t)a + (uintptr_t)page - 1) & ~((uintptr_t)page - 1), hi = (uintptr_t)b & ~((uintptr_t)page - 1);
+      if (hi > lo) (void)madvise((void *)lo, hi - lo, MADV_DONTNEED);
+    };
+    const char *first = sd->idP[recLo], *last = sd->idP[recHi - 1];
+    const Blob *b0 = blobOf(first), *b1 = blobOf(last);
+    if (!b0 || !b1) continue;  // owned storage (gz, general reader)
+    const char *end1 = recHi < sd->idP.size() && blobOf(sd->idP[recHi]) == b1 ? sd->idP[recHi] - 1 : (const char *)b1->map + b1->len;
+    if (b0 == b1) drop(first - 1, end1);
+    else { drop(first - 1, (const char *)b0->map + b0->len); drop((const char *)b1->map, end1); }  // (files wholly inside the range wait for the unmapping)
+  }
+}
+
 void ReadInput::setMemory(const char *seq1, const uint64_t *off1, const char *seq2, const uint64_t *off2, uint32_t n) {
   paired = seq2 != nullptr;
   hasBarcode = false;

@@ -53,6 +53,9 @@ struct ReadInput {
   uint32_t base = 0;
   int shardRank = 0, shardRanks = 1;
   size_t nAll() const { return sharded ? nAll_ : frag.size(); }
+  // the mapped bytes of records [recLo, recHi) are not needed any more (their text went to the GPU and their output is written): drop
+  // the page-table entries now, piece by piece beside the device loop, instead of all at once when the job is destroyed
+  void release(size_t recLo, size_t recHi);
 
  private:
   struct Blob {

@@ -226,11 +226,14 @@ int t1k_missing_coverage(t1k_ctx *ctx, int32_t *missing) {
   const uint32_t A = ctx->ref.nAlleles;
   T1kDevBuf dScratch, dMiss;
   int rc;
+  const double t0 = nowMs();
   if ((rc = t1k_ensure(ctx, dScratch, (ctx->ref.totalBases + 2) * 4))) return rc;
   if ((rc = t1k_ensure(ctx, dMiss, (size_t)A * 4))) { freeBuf(dScratch); return rc; }
+  const double t1 = nowMs();
   t1k_launch_missing_coverage(ctx, ctx->ref, (int32_t *)dScratch.p, (int32_t *)dMiss.p);
   hipMemcpyAsync(missing, dMiss.p, (size_t)A * 4, hipMemcpyDeviceToHost, ctx->stream);
   hipError_t e = hipStreamSynchronize(ctx->stream);
+  if (getenv("T1K_DEBUG_PHASES")) fprintf(stderr, "[t1k] missing coverage: buffers %.1f ms, kernel + copy %.1f ms\n", t1 - t0, nowMs() - t1);
   freeBuf(dScratch); freeBuf(dMiss);
   if (e != hipSuccess) return t1k_fail(ctx, T1K_ERR_DEVICE, hipGetErrorString(e));
   return T1K_OK;
