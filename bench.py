@@ -248,6 +248,7 @@ def main():
         }
         if a.executable_check:
             exe = os.path.join(ROOT, "t1k_amd", "bin", "genotyper")
+            t1k_amd.pool_release()   # this process's cached device memory would otherwise be fresh (to-be-zeroed) VRAM for the other one
             t1 = time.time()
             sh([exe, "-f", ref, "-1", pfx + "_1.fq", "-2", pfx + "_2.fq", "-s", "0.97", "-o", os.path.join(a.workdir, "exe_out")], stderr=subprocess.DEVNULL)
             wall = time.time() - t1

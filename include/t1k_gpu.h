@@ -192,6 +192,9 @@ int t1k_missing_coverage(t1k_ctx *ctx, int32_t *missing);
 /* Several contexts on one GPU (pipelines of one job) can share the read-only device data of one of them: dst aliases src's
  * reference (and gets its own, zeroed coverage array) / src's packed reads.  src must outlive dst. */
 int t1k_ref_share(t1k_ctx *dst, const t1k_ctx *src);
+/* Device memory of the library is pooled per process (a freed block is reused by the next job: fresh VRAM costs ~35 ms per GB of
+ * driver zeroing; T1K_POOL_GB bounds what is kept).  This returns every cached block to the driver; result = bytes released. */
+uint64_t t1k_pool_release(void);
 int t1k_reads_share(t1k_ctx *dst, const t1k_ctx *src);
 /* the same with a choice of the overlap-store slot (0 or 1) dst writes its lists to, emptied first if resetStore != 0: a job
  * keeps two read sets (windows of fragments) in flight, so the lists of one stay valid while the next is being assigned */

@@ -102,6 +102,8 @@ def lib():
     L.t1k_job_stage_reads.argtypes = [vp]
     L.t1k_job_run.argtypes = [vp]
     L.t1k_job_write_outputs.argtypes = [vp, C.c_char_p]
+    L.t1k_pool_release.restype = C.c_uint64
+    L.t1k_pool_release.argtypes = []
     L.t1k_job_load_reads_multi.argtypes = [vp, C.POINTER(C.c_char_p), C.c_uint32, C.POINTER(C.c_char_p), C.c_uint32, C.c_char_p]
     L.t1k_job_genotype_text.argtypes = [vp, C.c_char_p, C.c_uint64, u64p]
     L.t1k_job_counts.argtypes = [vp, u64p, u64p, u64p, u64p, i32p]
@@ -440,6 +442,11 @@ class CommGroup:
         if self.h:
             lib().t1k_comm_group_destroy(self.h)
             self.h = None
+
+
+def pool_release():
+    """give the process-wide device memory pool back to the driver; returns the bytes released"""
+    return int(lib().t1k_pool_release())
 
 
 def comm_unique_id():

@@ -84,6 +84,26 @@ hipError_t t1k_dev_free(void *p) {
   return hipFree(p);
 }
 
+// gives every cached block back to the driver (a long-lived process that is done with its jobs for now)
+extern "C" uint64_t t1k_pool_release(void) {
+  DevPool &P = devPool();
+  std::vector<std::pair<int, void *>> drop;
+  uint64_t bytes = 0;
+  {
+    std::lock_guard<std::mutex> g(P.m);
+    for (auto &dev : P.freeBlocks) {
+      for (auto &kv : dev.second) { drop.push_back({dev.first, kv.second}); bytes += kv.first; }
+      dev.second.clear();
+    }
+    P.pooled = 0;
+  }
+  int cur = 0;
+  (void)hipGetDevice(&cur);
+  for (auto &d : drop) { (void)hipSetDevice(d.first); (void)hipFree(d.second); }
+  (void)hipSetDevice(cur);
+  return bytes;
+}
+
 int t1k_fail(t1k_ctx *ctx, int code, const std::string &msg) {
   if (ctx) ctx->err = msg;
   return code;
