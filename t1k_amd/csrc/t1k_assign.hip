@@ -776,6 +776,19 @@ struct T1kWinBits {
   }
 };
 
+// the same for the 2-bit base codes of a packed stream: 32 positions in a register, refilled when the walk leaves them
+struct T1kWinCodes {
+  const uint64_t *p;
+  int64_t off;
+  int base;
+  uint64_t w;
+  __device__ T1kWinCodes(const uint64_t *p_, int64_t off_) : p(p_), off(off_), base(1 << 30), w(0) {}
+  __device__ __forceinline__ int code(int pos) {
+    if (pos < base || pos >= base + 32) { base = pos > 31 ? pos - 31 : 0; w = t1k_get32(p, off + base); }
+    return (int)((w >> (2 * (pos - base))) & 3);
+  }
+};
+
 // The traced alignments run in three steps over the SORTED queue (identical jobs are neighbours):
 //   k_align_flags  marks the first job of every run of identical (read window, allele window) jobs; an inclusive scan numbers the runs
 //   k_align_fill   one lane per run: DP sweep, decision words -> trace[row * stride + run]
@@ -902,6 +915,7 @@ __global__ __launch_bounds__(WG) void k_align_apply_band(SlowArgs P) {
     T1kSeqView T{P.ref.bases, P.ref.nmask, goff + o.seqStart}, Pv{rb, rn, (int64_t)o.readStart};
     int32_t *cov = P.ref.covDiff + goff;
     T1kWinBits exW(P.ref.exon, goff), gnW(P.ref.nmask, goff), rnW(rn, 0);
+    T1kWinCodes gbW(P.ref.bases, goff), rbW(rb, 0);
     const int alleleLen = (int)P.ref.alleleLen[o.allele];
     int relaxed = 0, runLo = -1, runHi = -1;
     int ti = lp, tj = lt, mat = 0;
@@ -912,7 +926,12 @@ __global__ __launch_bounds__(WG) void k_align_apply_band(SlowArgs P) {
       else bits = (ti == 1 ? 4 : 0);
       int op, refPos;
       if (mat == 0) {
-        if (ti > 0 && tj > 0 && (bits & 1)) { op = t1k_eq(T.code(tj - 1), Pv.code(ti - 1)) ? 0 : 1; refPos = o.seqStart + tj - 1; --ti; --tj; }
+        if (ti > 0 && tj > 0 && (bits & 1)) {
+          // the two bases of the column, from 32-position register windows that follow the walk (a load pair per 32 columns, not per column)
+          const int ct = gnW.bit(o.seqStart + tj - 1) ? 4 : gbW.code(o.seqStart + tj - 1);
+          const int cp = rnW.bit(o.readStart + ti - 1) ? 4 : rbW.code(o.readStart + ti - 1);
+          op = t1k_eq(ct, cp) ? 0 : 1; refPos = o.seqStart + tj - 1; --ti; --tj;
+        }
         else { mat = (bits & 2) ? 2 : 1; continue; }
       } else if (mat == 1) {
         op = 2; refPos = o.seqStart + tj;
