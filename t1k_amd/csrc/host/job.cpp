@@ -331,15 +331,16 @@ int t1k_job_run_local(t1k_job *job) {
   // for what is already prepared -- both rates are measured on the windows before it -- up to T1K_WINDOW fragments (default 8 M: a
   // window's overlap lists stay in the store until its fragments are paired, about 6 KB per fragment of an HLA-sized reference).
   uint32_t windowFrags = 1u << 23;
-  if (const char *e = getenv("T1K_WINDOW")) windowFrags = (uint32_t)std::max(64, atoi(e));
+  if (const char *e = getenv("T1K_WINDOW")) windowFrags = (uint32_t)std::max(8, atoi(e));
   uint32_t assignBatch = job->prm.batch_fragments > 0 ? (uint32_t)job->prm.batch_fragments * per : 32768u;
-  if (const char *eb = getenv("T1K_BATCH")) assignBatch = (uint32_t)std::max(64, atoi(eb)) * per;  // tuning aid (in fragments, as in round 1)
-  const uint32_t pairBatch = 1u << 16;
+  if (const char *eb = getenv("T1K_BATCH")) assignBatch = (uint32_t)std::max(8, atoi(eb)) * per;  // tuning / test aid (in fragments, as in round 1)
+  uint32_t pairBatch = 1u << 16;
+  if (const char *eb = getenv("T1K_PAIR_BATCH")) pairBatch = (uint32_t)std::max(8, atoi(eb));  // test aid
   const uint32_t maxWindows = 4096;
   std::vector<Window> win;
   win.reserve(maxWindows);  // windows are appended while other threads hold references: the vector never reallocates
   uint32_t firstWindow = std::min<uint32_t>(windowFrags, std::max<uint32_t>(65536u, windowFrags / 32));
-  if (const char *e = getenv("T1K_FIRST_WINDOW")) firstWindow = (uint32_t)std::max(64, atoi(e));
+  if (const char *e = getenv("T1K_FIRST_WINDOW")) firstWindow = (uint32_t)std::max(8, atoi(e));
   double fixedGrowth = 0;  // T1K_WINDOW_GROWTH: a fixed factor instead of the measured one
   if (const char *e = getenv("T1K_WINDOW_GROWTH")) fixedGrowth = std::max(1.0, atof(e));
   struct Shared {

@@ -372,6 +372,33 @@ def test_own_input_sharding_over_several_files_per_mate(built, tmp_path, gpus):
         assert open(out + suf, "rb").read() == open(one + suf, "rb").read(), suf
 
 
+@pytest.mark.parametrize("name", ["hla_synth_2x150", "cyp_dna_relax_2x150", "cyp_rna_single"])
+@pytest.mark.parametrize("env", [{"T1K_FIRST_WINDOW": "8", "T1K_WINDOW": "96", "T1K_BATCH": "8", "T1K_PAIR_BATCH": "16"},
+                                 {"T1K_FIRST_WINDOW": "24", "T1K_WINDOW": "48", "T1K_WINDOW_GROWTH": "1", "T1K_BATCH": "16", "T1K_PAIR_BATCH": "8", "T1K_PIPELINES": "2"},
+                                 {"T1K_FIRST_WINDOW": "16", "T1K_WINDOW": "40", "T1K_BATCH": "8", "T1K_NO_STREAM_OUTPUT": "1"},
+                                 {"T1K_FIRST_WINDOW": "8", "T1K_WINDOW": "32", "T1K_BATCH": "8", "T1K_PAIR_BATCH": "8", "T1K_GPUS": "0,0"},
+                                 {"T1K_FIRST_WINDOW": "8", "T1K_WINDOW": "32", "T1K_BATCH": "8", "T1K_PAIR_BATCH": "8", "T1K_GPUS": "0,0,0", "T1K_SHARD_INPUT": "1"}])
+def test_many_small_windows_and_ranges(built, tmp_path, name, env):
+    """the job loop as it runs on millions of fragments, on a fixture: many windows cut at run time (a tiny first one, then sized from
+    the measured rates or by a fixed factor), several ranges per window, pipelines moving on to the next window while the last ranges
+    of the previous one are still out, the output writer following the pairing ranges and releasing the input behind it.  Every file
+    must equal the golden one byte for byte."""
+    c = goldens.Case(name, str(tmp_path))
+    out = os.path.join(str(tmp_path), "win")
+    r = subprocess.run([GENO] + c.args() + ["-o", out], stderr=subprocess.PIPE, text=True, env=dict(os.environ, T1K_DEBUG_PHASES="1", **env))
+    assert r.returncode == 0, r.stderr
+    m = re.search(r"(\d+) windows,", r.stderr)
+    assert m and int(m.group(1)) >= 3, r.stderr[-1500:]
+    _golden_files_equal(c, out)
+    if c.bc:
+        assert open(out + "_aligned_bc.fa").read() == c.expected("aligned_bc.fa")
+    one = os.path.join(str(tmp_path), "one")
+    r1 = subprocess.run([GENO] + c.args() + ["-o", one], stderr=subprocess.PIPE, text=True)
+    assert r1.returncode == 0, r1.stderr
+    for suf in (("_aligned_1.fa", "_aligned_2.fa") if c.paired else ("_aligned.fa",)):
+        assert open(out + suf, "rb").read() == open(one + suf, "rb").read(), suf
+
+
 def test_over_long_read_fails_before_any_output(built, tmp_path):
     """reads longer than max_read_len (320) are not handled by this build: the run must stop with a message BEFORE an output file exists"""
     c = goldens.Case("cyp_rna_2x100", str(tmp_path))
