@@ -1,7 +1,14 @@
 // t1k_amd/csrc/host/refset.cpp -- sequence-file input and the allele reference set of the genotyper stage.
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cstring>
+#include <thread>
 #include "t1k_host.h"
 
 namespace t1k {
@@ -68,6 +75,96 @@ bool readSeqFile(const std::string &path, std::vector<SeqRec> &out, std::string 
   return true;
 }
 
+namespace {
+// The reference FASTA (35 MB for an HLA set) read by all host threads: the file is mapped, cut at record starts, and every thread
+// parses its records with the rules of readSeqFile (name up to the first blank, "/1" "/2" stripped, the rest of the header line is
+// the comment, sequence = the following lines joined, CR dropped).  Anything that is not plain '>' records -- gz, a line starting
+// with '@' or '+' -- returns false and the caller takes the general reader.
+bool readFastaParallel(const std::string &path, std::vector<SeqRec> &out) {
+  int fd = ::open(path.c_str(), O_RDONLY);
+  if (fd < 0) return false;
+  struct stat st;
+  unsigned char magic[2] = {0, 0};
+  if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || st.st_size < 2 || pread(fd, magic, 2, 0) != 2 || (magic[0] == 0x1f && magic[1] == 0x8b)) { ::close(fd); return false; }
+  const size_t n = (size_t)st.st_size;
+  void *mp = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
+  ::close(fd);
+  if (mp == MAP_FAILED) return false;
+  const char *d = (const char *)mp, *end = d + n;
+  auto recordStart = [&](const char *from) -> const char * {  // first '>' at a line start at or after `from`
+    const char *p = from;
+    if (p == d && *p == '>') return p;
+    while (p < end) {
+      const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
+      if (!nl || nl + 1 >= end) return end;
+      if (nl[1] == '>') return nl + 1;
+      p = nl + 1;
+    }
+    return end;
+  };
+  const int T = (int)std::max<size_t>(1, std::min<size_t>(std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency())), n / (1u << 20) + 1));
+  std::vector<const char *> start(T + 1, end);
+  start[0] = recordStart(d);
+  for (int t = 1; t < T; ++t) start[t] = recordStart(d + n / T * t);
+  for (int t = 1; t <= T; ++t) start[t] = std::max(start[t], start[t - 1]);
+  start[T] = end;
+  // lines before the first record must be blank or carry no header (the general reader skips them); '@' / '+' lines: not our case
+  bool plain = true;
+  for (const char *p = d; p < start[0];) {
+    const char *nl = (const char *)memchr(p, '\n', (size_t)(start[0] - p));
+    if (*p == '@' || *p == '+') plain = false;
+    if (!nl) break;
+    p = nl + 1;
+  }
+  std::vector<std::vector<SeqRec>> part(T);
+  std::atomic<bool> ok{plain};
+  auto work = [&](int t) {
+    const char *p = start[t], *stop = start[t + 1];
+    std::vector<SeqRec> &recs = part[t];
+    while (p < stop && ok) {
+      // header line
+      const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
+      const char *le = nl ? nl : end;
+      const char *he = le;
+      if (he > p && he[-1] == '\r') --he;
+      SeqRec r;
+      const char *q = p + 1;
+      while (q < he && *q != ' ' && *q != '\t') ++q;
+      r.id.assign(p + 1, q);
+      if (q < he && q + 1 < he) { r.comment.assign(q + 1, he); r.hasComment = !r.comment.empty(); }
+      const size_t il = r.id.size();
+      if (il >= 2 && r.id[il - 2] == '/' && (r.id[il - 1] == '1' || r.id[il - 1] == '2')) r.id.resize(il - 2);
+      p = nl ? nl + 1 : end;
+      // sequence lines up to the next record
+      while (p < end && *p != '>') {
+        if (*p == '@' || *p == '+') { ok = false; return; }
+        const char *nl2 = (const char *)memchr(p, '\n', (size_t)(end - p));
+        const char *e2 = nl2 ? nl2 : end;
+        const char *se = e2;
+        if (se > p && se[-1] == '\r') --se;
+        r.seq.append(p, se);
+        p = nl2 ? nl2 + 1 : end;
+      }
+      recs.push_back(std::move(r));
+    }
+  };
+  {
+    std::vector<std::thread> th;
+    for (int t = 1; t < T; ++t) th.emplace_back(work, t);
+    work(0);
+    for (auto &x : th) x.join();
+  }
+  munmap(mp, n);
+  if (!ok) return false;
+  size_t total = 0;
+  for (auto &v : part) total += v.size();
+  out.reserve(out.size() + total);
+  for (auto &v : part)
+    for (auto &r : v) out.push_back(std::move(r));
+  return true;
+}
+}  // namespace
+
 // Genotyper::ParseAlleleName (Genotyper.hpp:63-131)
 void RefSet::splitName(const std::string &allele, std::string &gene, std::string &major, int fieldsType) const {
   int mode = 1, fields = digitUnits;
@@ -121,43 +218,78 @@ bool RefSet::load(const std::string &fasta, int digitUnitsArg, char delimiterArg
   digitUnits = digitUnitsArg;
   delimiter = delimiterArg;
   std::vector<SeqRec> recs;
-  if (!readSeqFile(fasta, recs, err)) return false;
-  std::unordered_map<std::string, int> firstWithSeq;
-  for (auto &r : recs) {
-    if (selected && !selected->count(r.id)) continue;  // Genotyper.hpp:742-743
-    auto it = firstWithSeq.find(r.seq);
-    if (it != firstWithSeq.end()) { al[it->second].weight += 1; continue; }  // Genotyper.hpp:718-721
-    firstWithSeq.emplace(r.seq, (int)al.size());
+  const auto tA = std::chrono::steady_clock::now();
+  if (!readFastaParallel(fasta, recs)) {
+    recs.clear();
+    if (!readSeqFile(fasta, recs, err)) return false;
+  }
+  const auto tB = std::chrono::steady_clock::now();
+  // per record, on the host threads: hash of the sequence, effective length, exon mask
+  struct Pre { uint64_t hash = 0; int effLen = 0; bool gap = false; std::vector<uint8_t> mask; };
+  std::vector<Pre> pre(recs.size());
+  {
+    const size_t R = recs.size();
+    const int T = (int)std::max<size_t>(1, std::min<size_t>(std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency())), R / 256 + 1));
+    std::vector<std::thread> th;
+    auto work = [&](int t) {
+      for (size_t i = R * t / T; i < R * (t + 1) / T; ++i) {
+        const SeqRec &r = recs[i];
+        if (selected && !selected->count(r.id)) continue;  // Genotyper.hpp:742-743
+        Pre &q = pre[i];
+        q.hash = std::hash<std::string>()(r.seq);
+        const int L = (int)r.seq.size();
+        for (int k = 0; k < L; ++k)  // SeqSet::ComputeEffectiveLen (747-758)
+          if (r.seq[k] != 'N' || (k > 0 && r.seq[k - 1] != 'N')) ++q.effLen;
+        // exon intervals from the header comment (SeqSet.hpp:933-976): numbers[0] ignored, then (start, end) pairs
+        std::vector<std::pair<int, int>> ex;
+        if (r.hasComment) {
+          std::vector<int> nums;
+          int v = 0;
+          for (char c : r.comment) {
+            if (c >= '0' && c <= '9') v = v * 10 + (c - '0');
+            else { nums.push_back(v); v = 0; }
+          }
+          if (v) nums.push_back(v);
+          if (!nums.empty()) {
+            for (size_t k = 1; k < nums.size(); k += 2) ex.push_back({nums[k], k + 1 < nums.size() ? nums[k + 1] : 0});
+          } else ex.push_back({0, L - 1});
+        } else ex.push_back({0, L - 1});
+        q.mask.assign(L, 0);  // SetSeqExonInfo (638-723)
+        for (auto &e : ex)
+          for (int j = std::max(e.first, 0); j <= e.second && j < L; ++j) q.mask[j] = 1;
+        for (size_t k = 1; k < ex.size(); ++k)
+          if (ex[k].first > ex[k - 1].second + 1) { q.gap = true; break; }
+      }
+    };
+    for (int t = 1; t < T; ++t) th.emplace_back(work, t);
+    work(0);
+    for (auto &x : th) x.join();
+  }
+  // identical sequences merge into the first one (Genotyper.hpp:718-721): found through the hash, confirmed by comparing
+  std::unordered_multimap<uint64_t, int> firstWithSeq;
+  firstWithSeq.reserve(recs.size() * 2);
+  for (size_t i = 0; i < recs.size(); ++i) {
+    SeqRec &r = recs[i];
+    if (selected && !selected->count(r.id)) continue;
+    Pre &q = pre[i];
+    bool merged = false;
+    auto range = firstWithSeq.equal_range(q.hash);
+    for (auto it = range.first; it != range.second; ++it)
+      if (seqs[it->second] == r.seq) { al[it->second].weight += 1; merged = true; break; }
+    if (merged) continue;
+    firstWithSeq.emplace(q.hash, (int)al.size());
     AlleleMeta m;
     m.name = r.id;
-    const int L = (int)r.seq.size();
-    m.seqLen = L;
-    for (int i = 0; i < L; ++i)  // SeqSet::ComputeEffectiveLen (747-758)
-      if (r.seq[i] != 'N' || (i > 0 && r.seq[i - 1] != 'N')) ++m.effLen;
-    // exon intervals from the header comment (SeqSet.hpp:933-976): numbers[0] ignored, then (start, end) pairs
-    std::vector<std::pair<int, int>> ex;
-    if (r.hasComment) {
-      std::vector<int> nums;
-      int v = 0;
-      for (char c : r.comment) {
-        if (c >= '0' && c <= '9') v = v * 10 + (c - '0');
-        else { nums.push_back(v); v = 0; }
-      }
-      if (v) nums.push_back(v);
-      if (!nums.empty()) {
-        for (size_t i = 1; i < nums.size(); i += 2) ex.push_back({nums[i], i + 1 < nums.size() ? nums[i + 1] : 0});
-      } else ex.push_back({0, L - 1});
-    } else ex.push_back({0, L - 1});
-    std::vector<uint8_t> mask(L, 0);  // SetSeqExonInfo (638-723)
-    for (auto &e : ex)
-      for (int j = std::max(e.first, 0); j <= e.second && j < L; ++j) mask[j] = 1;
-    for (size_t i = 1; i < ex.size(); ++i)
-      if (ex[i].first > ex[i - 1].second + 1) { rnaData = false; break; }
+    m.seqLen = (int)r.seq.size();
+    m.effLen = q.effLen;
+    if (q.gap) rnaData = false;
     al.push_back(m);
-    seqs.push_back(r.seq);
-    exon.push_back(std::move(mask));
+    seqs.push_back(std::move(r.seq));
+    exon.push_back(std::move(q.mask));
   }
   const int A = (int)al.size();
+  const auto tC = std::chrono::steady_clock::now();
+  if (getenv("T1K_DEBUG_PHASES")) fprintf(stderr, "[t1k host] reference: file parse %.1f ms, alleles %.1f ms\n", std::chrono::duration<double, std::milli>(tB - tA).count(), std::chrono::duration<double, std::milli>(tC - tB).count());
   if (A == 0) { err = "no sequences in " + fasta; return false; }
   if (!rnaData) {  // SeqSet::UpdateDnaSeqWeight (1008-1029): weight = multiplicity of the exon-only sequence
     std::unordered_map<std::string, int> w;
