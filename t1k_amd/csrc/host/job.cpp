@@ -629,13 +629,25 @@ int t1k_job_run_local(t1k_job *job) {
   static_assert(sizeof(GroupEntry) == sizeof(t1k_group_entry), "group entry layouts differ");
   if (sharded && (rc = t1k_rowset_exchange(job->rows, job->comm, fBeg)) != T1K_OK) return jobFail(job, rc, t1k_rowset_last_error(job->rows));
   if ((rc = t1k_rowset_coalesce(job->rows, &G, &N, &assigned)) != T1K_OK) return jobFail(job, rc, t1k_rowset_last_error(job->rows));
+  const double tCo = nowMs();
   if (!sharded) {
     gt.groupPtr.assign(G + 1, 0);
-    gt.groupEnt.resize(N);
+    gt.groupEnt.resize(N);  // (not zeroed: GroupVec)
     gt.groupFirst.resize(G);
+    // first touch of the table's pages by all host threads (100 k page faults on one thread were 90 ms)
+    parallelRanges(N * sizeof(GroupEntry) / 4096 + 1, T, [&](int, size_t b, size_t e) {
+      volatile char *base = (volatile char *)gt.groupEnt.data();
+      const size_t bytes = N * sizeof(GroupEntry);
+      for (size_t pg = b; pg < e; ++pg) if (pg * 4096 < bytes) base[pg * 4096] = 0;
+    });
+    const double tRes = nowMs();
     if ((rc = t1k_rowset_groups_download(job->rows, gt.groupPtr.data(), (t1k_group_entry *)gt.groupEnt.data(), gt.groupFirst.data())) != T1K_OK)
       return jobFail(job, rc, t1k_rowset_last_error(job->rows));
+    const double tDl = nowMs();
     if ((rc = t1k_rowset_assigned_download(job->rows, job->fragAssigned.data())) != T1K_OK) return jobFail(job, rc, t1k_rowset_last_error(job->rows));
+    if (getenv("T1K_DEBUG_PHASES"))
+      fprintf(stderr, "[t1k job] after the loop: coverage of the pipelines + coalescing on the device %.1f ms, host tables sized %.1f ms, groups downloaded %.1f ms, flags %.1f ms\n",
+              tCo - tDev, tRes - tCo, tDl - tRes, nowMs() - tDl);
   } else {
     if ((rc = t1k_rowset_groups_gather(job->rows, job->comm, &G, &N, &assigned)) != T1K_OK) return jobFail(job, rc, t1k_rowset_last_error(job->rows));
     std::vector<uint32_t> sizes(G), first(G);

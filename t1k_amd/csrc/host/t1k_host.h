@@ -11,6 +11,7 @@
 #include <memory>
 #include <string>
 #include <unordered_map>
+#include <utility>
 #include <vector>
 #include "../../../include/t1k_gpu.h"
 
@@ -102,13 +103,22 @@ struct GroupEntry {
   int allele, start, end;
   float weight, adjustWeight;
 };
+// the group table of a 10 M-pair job is half a gigabyte that is overwritten at once (download / merge): a vector that does not
+// zero what it is about to receive
+template <class T>
+struct NoInitAlloc : std::allocator<T> {
+  template <class U> struct rebind { using other = NoInitAlloc<U>; };
+  template <class U> void construct(U *p) noexcept { ::new ((void *)p) U; }
+  template <class U, class A0, class... A> void construct(U *p, A0 &&a0, A &&...a) { ::new ((void *)p) U(std::forward<A0>(a0), std::forward<A>(a)...); }
+};
+typedef std::vector<GroupEntry, NoInitAlloc<GroupEntry>> GroupVec;
 
 struct Genotyper {
   RefSet *ref = nullptr;
   t1k_job_params prm;
   // coalesced read groups (Genotyper::readAssignments, Genotyper.hpp:443), CSR
   std::vector<uint64_t> groupPtr{0};
-  std::vector<GroupEntry> groupEnt;
+  GroupVec groupEnt;
   std::vector<uint32_t> groupFirst;   // the fragment that opened each group (host coalescing and the multi-GPU merge keep it)
   std::unordered_map<uint64_t, std::vector<uint32_t>> groupOfHash;
   uint64_t assignedFragments = 0;
