@@ -462,15 +462,41 @@ void ReadInput::setMemory(const char *seq1, const uint64_t *off1, const char *se
 // fragments = records whose barcode is not "missing_barcode" (dropped with their mates, Genotyper.cpp:376-381)
 void ReadInput::finish() {
   const size_t n = side[0].seqP.size();
+  const unsigned T = (unsigned)std::max<size_t>(1, std::min<size_t>(std::min<unsigned>(32u, std::max(1u, std::thread::hardware_concurrency())), n / 65536 + 1));
+  auto pieces = [&](auto fn) {  // fn(t, begin, end) over contiguous pieces of [0, n)
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < T; ++t) th.emplace_back([&, t] { fn(t, n * t / T, n * (t + 1) / T); });
+    fn(0u, (size_t)0, n / T);
+    for (auto &x : th) x.join();
+  };
   frag.clear();
-  frag.reserve(n);
-  maxLen = 0;
-  for (size_t i = 0; i < n; ++i) {
-    if (hasBarcode && bc.seqL[i] == 15 && !memcmp(bc.seqP[i], "missing_barcode", 15)) continue;
-    frag.push_back((uint32_t)i);
+  if (!hasBarcode) {
+    frag.resize(n);
+    pieces([&](unsigned, size_t b, size_t e) { for (size_t i = b; i < e; ++i) frag[i] = (uint32_t)i; });
+  } else {
+    frag.reserve(n);
+    for (size_t i = 0; i < n; ++i) {
+      if (bc.seqL[i] == 15 && !memcmp(bc.seqP[i], "missing_barcode", 15)) continue;
+      frag.push_back((uint32_t)i);
+    }
   }
-  for (int m = 0; m < (paired ? 2 : 1); ++m)
-    for (uint32_t i : frag) maxLen = std::max<int>(maxLen, (int)side[m].seqL[i]);
+  // the longest read (of the fragments that are kept)
+  std::vector<int> mx(T, 0);
+  const size_t nf = frag.size();
+  {
+    std::vector<std::thread> th;
+    auto work = [&](unsigned t) {
+      int m = 0;
+      for (int s2 = 0; s2 < (paired ? 2 : 1); ++s2)
+        for (size_t i = nf * t / T; i < nf * (t + 1) / T; ++i) m = std::max<int>(m, (int)side[s2].seqL[frag[i]]);
+      mx[t] = m;
+    };
+    for (unsigned t = 1; t < T; ++t) th.emplace_back(work, t);
+    work(0);
+    for (auto &x : th) x.join();
+  }
+  maxLen = 0;
+  for (int m : mx) maxLen = std::max(maxLen, m);
 }
 
 }  // namespace t1k

@@ -24,17 +24,25 @@ struct SeqRec {
 // FASTA / FASTQ, plain or gz; id = header up to the first blank with a trailing /1 or /2 removed (ReadFiles.hpp:185-189)
 bool readSeqFile(const std::string &path, std::vector<SeqRec> &out, std::string &err);
 
+// vectors that do not zero what they are about to receive (record index of the read files, group tables: hundreds of MB each)
+template <class T>
+struct NoInitAlloc : std::allocator<T> {
+  template <class U> struct rebind { using other = NoInitAlloc<U>; };
+  template <class U> void construct(U *p) noexcept { ::new ((void *)p) U; }
+  template <class U, class A0, class... A> void construct(U *p, A0 &&a0, A &&...a) { ::new ((void *)p) U(std::forward<A0>(a0), std::forward<A>(a)...); }
+};
+
 // The read files of a job, whole in memory (mmap / inflated once) with a record index built in place by the host threads
 // (host/reads.cpp).  Record i of mate m is side[m].seqP[i][0 .. seqL[i]) with name idP[i][0 .. idL[i]); nothing is copied.
 struct ReadInput {
   struct Side {
-    std::vector<const char *> seqP, idP;
-    std::vector<uint32_t> seqL;
-    std::vector<uint16_t> idL;
+    std::vector<const char *, NoInitAlloc<const char *>> seqP, idP;
+    std::vector<uint32_t, NoInitAlloc<uint32_t>> seqL;
+    std::vector<uint16_t, NoInitAlloc<uint16_t>> idL;
   };
   Side side[2], bc;            // mates; barcode records (sequence = the barcode)
   bool paired = false, hasBarcode = false, noIds = false;
-  std::vector<uint32_t> frag;  // fragment f = record frag[f] (records with a missing barcode are dropped with their mates)
+  std::vector<uint32_t, NoInitAlloc<uint32_t>> frag;  // fragment f = record frag[f] (records with a missing barcode are dropped with their mates)
   int maxLen = 0;
   ReadInput() = default;
   ReadInput(const ReadInput &) = delete;
@@ -102,14 +110,6 @@ struct RefSet {
 struct GroupEntry {
   int allele, start, end;
   float weight, adjustWeight;
-};
-// the group table of a 10 M-pair job is half a gigabyte that is overwritten at once (download / merge): a vector that does not
-// zero what it is about to receive
-template <class T>
-struct NoInitAlloc : std::allocator<T> {
-  template <class U> struct rebind { using other = NoInitAlloc<U>; };
-  template <class U> void construct(U *p) noexcept { ::new ((void *)p) U; }
-  template <class U, class A0, class... A> void construct(U *p, A0 &&a0, A &&...a) { ::new ((void *)p) U(std::forward<A0>(a0), std::forward<A>(a)...); }
 };
 typedef std::vector<GroupEntry, NoInitAlloc<GroupEntry>> GroupVec;
 
