@@ -337,9 +337,11 @@ int t1k_rowset_groups_download(t1k_rowset *rs, uint64_t *groupPtr, t1k_group_ent
 }
 
 int t1k_rowset_assigned_download(t1k_rowset *rs, uint8_t *fragAssigned) {
-  if (!rs || !fragAssigned) return T1K_ERR_ARG;
-  RS_HIP(hipSetDevice(rs->device));
+  if (!rs) return T1K_ERR_ARG;
   const uint64_t nLocal = rs->exchanged ? rs->nFragLocal : rs->nFrag;  // the flags belong to this rank's own fragments
+  if (nLocal == 0) return T1K_OK;  // (an empty input: the caller's array is empty too)
+  if (!fragAssigned) return rsFail(rs, T1K_ERR_ARG, "t1k_rowset_assigned_download: no output array");
+  RS_HIP(hipSetDevice(rs->device));
   if (nLocal) RS_HIP(hipMemcpy(fragAssigned, rs->assigned, nLocal, hipMemcpyDeviceToHost));
   return T1K_OK;
 }

@@ -342,8 +342,9 @@ int t1k_comm_allgatherv(t1k_comm *c, const void *mine, const uint64_t *bytes, co
 
 // the same for host memory (every rank's slice of one host array of `total` bytes), staged through the device
 int t1k_comm_allgatherv_host(t1k_comm *c, void *host, const uint64_t *bytes, const uint64_t *displ, uint64_t total) {
-  if (!c || !host || !bytes || !displ) return T1K_ERR_ARG;
-  if (c->nRanks == 1 || total == 0) return T1K_OK;
+  if (!c) return T1K_ERR_ARG;
+  if (c->nRanks == 1 || total == 0) return T1K_OK;  // (an empty array may come with a null pointer)
+  if (!host || !bytes || !displ) return commFail(c, T1K_ERR_ARG, "t1k_comm_allgatherv_host: bad arguments");
   t1k_ctx *ctx = c->ctx;
   CM_HIP(hipSetDevice(ctx->device));
   T1kDevBuf all, mine;

@@ -399,6 +399,39 @@ def test_many_small_windows_and_ranges(built, tmp_path, name, env):
         assert open(out + suf, "rb").read() == open(one + suf, "rb").read(), suf
 
 
+@pytest.mark.parametrize("case", ["empty", "one_pair", "shorter_than_k", "single_end_empty"])
+@pytest.mark.parametrize("gpus", ["", "0,0", "0,0,0+own-input"])
+def test_degenerate_inputs_vs_reference_binary(built, tmp_path, case, gpus):
+    """read files with no records, with one pair, with reads shorter than a k-mer: the reference finishes and writes (empty) files;
+    so must this build, with one rank and with ranks that have nothing to do -- every file byte for byte"""
+    util.need(util.REF_BIN)
+    ref = util.gunzip_to(util.CYP_RNA, str(tmp_path / "ref.fa"))
+    c = goldens.Case("cyp_rna_2x100", str(tmp_path))
+    r1, r2 = str(tmp_path / "x_1.fq"), str(tmp_path / "x_2.fq")
+    l1, l2 = open(c.r1).read().split("\n"), open(c.r2).read().split("\n")
+    if case in ("empty", "single_end_empty"):
+        text1 = text2 = ""
+    elif case == "one_pair":
+        text1, text2 = "\n".join(l1[:4]) + "\n", "\n".join(l2[:4]) + "\n"
+    else:
+        text1, text2 = "@s\nACGTACG\n+\nIIIIIII\n@t\nACG\n+\nIII\n", "@s\nTTTTACG\n+\nIIIIIII\n@t\nN\n+\nI\n"
+    open(r1, "w").write(text1)
+    open(r2, "w").write(text2)
+    reads = ["-u", r1] if case == "single_end_empty" else ["-1", r1, "-2", r2]
+    o_ref, o_gpu = str(tmp_path / "ref"), str(tmp_path / "gpu")
+    a = subprocess.run([util.REF_BIN, "-f", ref] + reads + ["-o", o_ref], stderr=subprocess.PIPE, text=True)
+    env = dict(os.environ)
+    if gpus:
+        env["T1K_GPUS"] = gpus.split("+")[0]
+        if "+" in gpus:
+            env["T1K_SHARD_INPUT"] = "1"
+    b = subprocess.run([GENO, "-f", ref] + reads + ["-o", o_gpu], stderr=subprocess.PIPE, text=True, env=env)
+    assert a.returncode == 0 and b.returncode == 0, (a.stderr[-500:], b.stderr[-500:])
+    sufs = ["_genotype.tsv", "_allele.tsv"] + (["_aligned.fa"] if case == "single_end_empty" else ["_aligned_1.fa", "_aligned_2.fa"])
+    for suf in sufs:
+        assert open(o_ref + suf, "rb").read() == open(o_gpu + suf, "rb").read(), suf
+
+
 def test_over_long_read_fails_before_any_output(built, tmp_path):
     """reads longer than max_read_len (320) are not handled by this build: the run must stop with a message BEFORE an output file exists"""
     c = goldens.Case("cyp_rna_2x100", str(tmp_path))
