@@ -196,6 +196,48 @@ def test_adversarial_pairs_executable_vs_reference_binary(built, tmp_path, kind,
     assert m >= 4
 
 
+@pytest.mark.parametrize("option", ["--frac", "--cov", "--crossGeneRate", "--squaremMinAlpha", "--alleleWhitelist", "-a"])
+def test_selection_options_executable_vs_reference_binary(built, tmp_path, option):
+    """the options of the quantification / selection half that no other test sets (Genotyper.cpp:13-57): filter fraction and coverage,
+    cross-gene rate, SQUAREM step bound, an allele whitelist (whole major-allele series, Genotyper.hpp:684-705) and an abundance file
+    that replaces the EM (Genotyper.hpp:1016-1051) -- every output file against the reference binary's"""
+    util.need(util.REF_BIN)
+    import subprocess
+    ref = str(tmp_path / "ref.fa")
+    util.synth_ref("ref-rna", ref, seed=31 + SEED0, genes=6, scale=0.15)
+    names = [l[1:].split()[0] for l in open(ref) if l.startswith(">")]
+    pairs = adversarial_pairs(alleles(ref), random.Random(31 + SEED0), 5000 * SCALE)
+    for i, suffix in enumerate(("_1.fq", "_2.fq")):
+        with open(str(tmp_path / "p") + suffix, "w") as f:
+            for j, pr in enumerate(pairs):
+                f.write("@f%d/%d\n%s\n+\n%s\n" % (j, i + 1, pr[i], "I" * len(pr[i])))
+    flags = {"--frac": ["--frac", "0.4"], "--cov": ["--cov", "3.5"], "--crossGeneRate": ["--crossGeneRate", "0.3"],
+             "--squaremMinAlpha": ["--squaremMinAlpha", "-1.5"]}.get(option)
+    if option == "--alleleWhitelist":
+        wl = str(tmp_path / "whitelist.txt")
+        open(wl, "w").write("\n".join(names[::3]) + "\n")
+        flags = ["--alleleWhitelist", wl]
+    if option == "-a":
+        ab = str(tmp_path / "abundance.tsv")
+        rng = random.Random(5)
+        with open(ab, "w") as f:
+            f.write("allele len efflen count abundance\n")
+            for n in names[::2]:
+                f.write("%s 1000 900 %.3f %.4f\n" % (n, rng.random() * 200, rng.random()))
+        flags = ["-a", ab]
+    args = ["-f", ref, "-1", str(tmp_path / "p_1.fq"), "-2", str(tmp_path / "p_2.fq"), "-s", "0.9"] + flags
+    exe = os.path.join(util.ROOT, "t1k_amd", "bin", "genotyper")
+    a = subprocess.run([exe] + args + ["-o", str(tmp_path / "ours")], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
+    b = subprocess.run([util.REF_BIN] + args + ["-t", "16", "-o", str(tmp_path / "ref")], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
+    assert a.returncode == 0 and b.returncode == 0, (a.stderr[-800:], b.stderr[-800:])
+    n = 0
+    for fn in sorted(os.listdir(str(tmp_path))):
+        if fn.startswith("ref_"):
+            assert open(str(tmp_path / fn)).read() == open(str(tmp_path / ("ours_" + fn[4:]))).read(), fn
+            n += 1
+    assert n >= 4 and os.path.getsize(str(tmp_path / "ref_genotype.tsv")) > 100
+
+
 @pytest.mark.parametrize("kind,flags,seed", [("ref-rna", [], 11), ("ref-dna", ["-s", "0.95"], 12), ("ref-rna", ["-s", "0.99", "-t", "4"], 13)])
 def test_adversarial_reads_extractor_vs_reference_binary(built, tmp_path, kind, flags, seed):
     """the candidate extractor on the same adversarial read-ends and mate pairs, files against the reference's fastq-extractor"""
