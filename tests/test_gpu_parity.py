@@ -432,6 +432,44 @@ def test_degenerate_inputs_vs_reference_binary(built, tmp_path, case, gpus):
         assert open(o_ref + suf, "rb").read() == open(o_gpu + suf, "rb").read(), suf
 
 
+@pytest.mark.parametrize("layout", ["plain", "crlf", "no_final_newline"])
+def test_odd_but_legal_records_vs_reference_binary(built, tmp_path, layout):
+    """a fixture with odd records mixed in -- empty sequences (one mate, both mates), reads of 5 / 11 / 37 bases, all-N reads, tabs and
+    comments in the header lines -- as LF, as CRLF and without a final newline: every output file against the reference binary's"""
+    util.need(util.REF_BIN)
+    ref = util.gunzip_to(util.CYP_RNA, str(tmp_path / "ref.fa"))
+    c = goldens.Case("cyp_rna_2x100", str(tmp_path))
+    out = {}
+    for m, path in ((1, c.r1), (2, c.r2)):
+        lines = open(path).read().split("\n")
+        out[m] = [lines[i:i + 4] for i in range(0, len(lines) - 1, 4)]
+    for i, (a, b) in enumerate(zip(out[1], out[2])):
+        k = i % 9
+        if k == 1: a[1] = a[3] = ""
+        if k == 2: b[1], b[3] = b[1][:5], b[3][:5]
+        if k == 3: a[1] = "N" * len(a[1])
+        if k == 4: a[0] += "\tcomment with tab"; b[0] += " comment"
+        if k == 5: a[1], a[3], b[1], b[3] = a[1][:37], a[3][:37], b[1][:11], b[3][:11]
+        if k == 6: a[1] = a[3] = b[1] = b[3] = ""
+    files = []
+    for m in (1, 2):
+        text = "".join("\n".join(r) + "\n" for r in out[m])
+        if layout == "crlf":
+            text = text.replace("\n", "\r\n")
+        if layout == "no_final_newline":
+            text = text.rstrip("\r\n")
+        files.append(str(tmp_path / ("odd_%d.fq" % m)))
+        open(files[-1], "w", newline="").write(text)
+    args = ["-f", ref, "-1", files[0], "-2", files[1]] + util.CYP_FLAGS
+    o_ref, o_gpu = str(tmp_path / "ref"), str(tmp_path / "gpu")
+    a = subprocess.run([util.REF_BIN] + args + ["-o", o_ref], stderr=subprocess.PIPE, text=True)
+    b = subprocess.run([GENO] + args + ["-o", o_gpu], stderr=subprocess.PIPE, text=True)
+    assert a.returncode == 0 and b.returncode == 0, (a.stderr[-500:], b.stderr[-500:])
+    for suf in ("_genotype.tsv", "_allele.tsv", "_aligned_1.fa", "_aligned_2.fa"):
+        assert open(o_ref + suf, "rb").read() == open(o_gpu + suf, "rb").read(), suf
+    assert os.path.getsize(o_gpu + "_aligned_1.fa") > 1000
+
+
 def test_over_long_read_fails_before_any_output(built, tmp_path):
     """reads longer than max_read_len (320) are not handled by this build: the run must stop with a message BEFORE an output file exists"""
     c = goldens.Case("cyp_rna_2x100", str(tmp_path))
