@@ -1294,6 +1294,21 @@ int t1k_analyzer_main(int argc, char **argv) {
       if (sscanf(line, "%10240s", name) == 1) selected.insert(name);
     fclose(fp);
   }
+  if (selected.empty()) {
+    // nothing was genotyped (run-t1k starts the analyzer all the same): the reference loads no sequence, assigns no fragment and
+    // leaves an empty VCF and a per-barcode table that is only its header
+    FILE *fv = fopen((prefix + "_allele.vcf").c_str(), "w");
+    if (!fv) { fprintf(stderr, "analyzer: cannot write %s_allele.vcf\n", prefix.c_str()); return EXIT_FAILURE; }
+    fclose(fv);
+    if (!barcode.empty()) {
+      FILE *fb = fopen((prefix + "_barcode_expr.tsv").c_str(), "w");
+      if (!fb) { fprintf(stderr, "analyzer: cannot write %s_barcode_expr.tsv\n", prefix.c_str()); return EXIT_FAILURE; }
+      fprintf(fb, "#barcode\n");
+      fclose(fb);
+    }
+    logLine("Post analysis finishes.");
+    return 0;
+  }
   t1k_job *job = nullptr;
   int rc = jobCreate(&p, refFile.c_str(), &selected, &job);
   if (rc != T1K_OK) {

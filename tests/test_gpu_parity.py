@@ -470,6 +470,30 @@ def test_odd_but_legal_records_vs_reference_binary(built, tmp_path, layout):
     assert os.path.getsize(o_gpu + "_aligned_1.fa") > 1000
 
 
+@pytest.mark.parametrize("with_barcode", [False, True])
+def test_analyzer_with_nothing_genotyped_vs_reference_binary(built, tmp_path, with_barcode):
+    """run-t1k starts the analyzer after the genotyper even when no allele was reported: an empty <prefix>_allele.tsv.  The reference
+    finishes with an empty VCF (and a header-only per-barcode table); so must this build, for empty and for non-empty read files"""
+    util.need(util.REF_ANALYZER)
+    ref = util.gunzip_to(util.CYP_RNA, str(tmp_path / "ref.fa"))
+    c = goldens.Case("cyp_rna_2x100", str(tmp_path))
+    empty = str(tmp_path / "empty.fq")
+    open(empty, "w").close()
+    alleles = str(tmp_path / "none_allele.tsv")
+    open(alleles, "w").close()
+    for tag, r1, r2 in (("e", empty, empty), ("r", c.r1, c.r2)):
+        if with_barcode and tag == "r":
+            continue  # (a barcode file has to match the read file record for record)
+        extra = ["--barcode", empty] if with_barcode else []
+        outs = {}
+        for who, binary in (("ref", util.REF_ANALYZER), ("gpu", ANALYZER)):
+            o = str(tmp_path / ("%s_%s" % (who, tag)))
+            r = subprocess.run([binary, "-f", ref, "-a", alleles, "-1", r1, "-2", r2, "-o", o] + extra, stderr=subprocess.PIPE, text=True)
+            assert r.returncode == 0, (who, r.stderr[-500:])
+            outs[who] = {f[len(os.path.basename(o)):]: open(os.path.join(str(tmp_path), f), "rb").read() for f in os.listdir(str(tmp_path)) if f.startswith(os.path.basename(o) + "_")}
+        assert outs["ref"] == outs["gpu"] and "_allele.vcf" in outs["gpu"], (sorted(outs["ref"]), sorted(outs["gpu"]))
+
+
 def test_over_long_read_fails_before_any_output(built, tmp_path):
     """reads longer than max_read_len (320) are not handled by this build: the run must stop with a message BEFORE an output file exists"""
     c = goldens.Case("cyp_rna_2x100", str(tmp_path))
