@@ -494,6 +494,33 @@ def test_analyzer_with_nothing_genotyped_vs_reference_binary(built, tmp_path, wi
         assert outs["ref"] == outs["gpu"] and "_allele.vcf" in outs["gpu"], (sorted(outs["ref"]), sorted(outs["gpu"]))
 
 
+@pytest.mark.parametrize("which", ["all_missing", "first_and_last_kept", "every_7th_missing"])
+def test_missing_barcodes_vs_reference_binary(built, tmp_path, which):
+    """records whose barcode is "missing_barcode" are dropped with their mates (Genotyper.cpp:376-381): all of them, all but the first and
+    the last record, every seventh -- one GPU, two ranks, and many tiny windows with the writer (and the release of the mapped input)
+    behind them; every file against the reference binary's"""
+    util.need(util.REF_BIN)
+    ref = util.gunzip_to(util.CYP_RNA, str(tmp_path / "ref.fa"))
+    c = goldens.Case("cyp_rna_2x100", str(tmp_path))
+    names = [l[1:].split()[0].rsplit("/", 1)[0] for i, l in enumerate(open(c.r1)) if i % 4 == 0]
+    n = len(names)
+    keep = {"all_missing": lambda i: False, "first_and_last_kept": lambda i: i in (0, n - 1), "every_7th_missing": lambda i: i % 7 != 0}[which]
+    bc = str(tmp_path / "bc.fa")
+    with open(bc, "w") as f:
+        for i in range(n):
+            f.write(">%s\n%s\n" % (names[i], ("ACGTACGTAC" + "ACGT"[i % 4] * 2) if keep(i) else "missing_barcode"))
+    args = ["-f", ref, "-1", c.r1, "-2", c.r2, "--barcode", bc] + util.CYP_FLAGS
+    o_ref = str(tmp_path / "ref")
+    a = subprocess.run([util.REF_BIN] + args + ["-o", o_ref], stderr=subprocess.PIPE, text=True)
+    assert a.returncode == 0, a.stderr[-500:]
+    for tag, env in (("one", {}), ("two_ranks", {"T1K_GPUS": "0,0"}), ("tiny_windows", {"T1K_FIRST_WINDOW": "8", "T1K_WINDOW": "40", "T1K_BATCH": "8", "T1K_PAIR_BATCH": "8"})):
+        o = str(tmp_path / tag)
+        b = subprocess.run([GENO] + args + ["-o", o], stderr=subprocess.PIPE, text=True, env=dict(os.environ, **env))
+        assert b.returncode == 0, (tag, b.stderr[-500:])
+        for suf in ("_genotype.tsv", "_allele.tsv", "_aligned_1.fa", "_aligned_2.fa", "_aligned_bc.fa"):
+            assert open(o_ref + suf, "rb").read() == open(o + suf, "rb").read(), (tag, suf)
+
+
 def test_over_long_read_fails_before_any_output(built, tmp_path):
     """reads longer than max_read_len (320) are not handled by this build: the run must stop with a message BEFORE an output file exists"""
     c = goldens.Case("cyp_rna_2x100", str(tmp_path))
