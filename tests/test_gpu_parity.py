@@ -521,6 +521,28 @@ def test_missing_barcodes_vs_reference_binary(built, tmp_path, which):
             assert open(o_ref + suf, "rb").read() == open(o + suf, "rb").read(), (tag, suf)
 
 
+@pytest.mark.parametrize("kind,length,flags", [("ref-rna", 250, ["-s", "0.9"]), ("ref-dna", 300, ["-s", "0.9", "--relaxIntronAlign"]), ("ref-rna", 320, ["-s", "0.97"])])
+def test_long_reads_end_to_end_vs_reference_binary(built, tmp_path, kind, length, flags):
+    """2 x 250 / 300 / 320 bp reads (the 320-position instantiations of the seeding and chaining kernels, the general window loop of
+    k_fullalign, wider sort keys) through the whole stage: one GPU, two ranks, many small windows -- every file against the reference's"""
+    util.need(util.REF_BIN)
+    ref = str(tmp_path / "ref.fa")
+    util.synth_ref(kind, ref, genes=6, scale=0.2, seed=77)
+    pfx = str(tmp_path / "r")
+    util.synth_reads(ref, pfx, pairs=4000, len=length, seed=5, sub=0.008, fragmean=2 * length + 40)
+    args = ["-f", ref, "-1", pfx + "_1.fq", "-2", pfx + "_2.fq"] + flags
+    o_ref = str(tmp_path / "ref")
+    a = subprocess.run([util.REF_BIN] + args + ["-t", "32", "-o", o_ref], stderr=subprocess.PIPE, text=True)
+    assert a.returncode == 0, a.stderr[-500:]
+    for tag, env in (("one", {}), ("two_ranks", {"T1K_GPUS": "0,0"}), ("small_windows", {"T1K_FIRST_WINDOW": "64", "T1K_WINDOW": "1500", "T1K_BATCH": "128", "T1K_PAIR_BATCH": "256"})):
+        o = str(tmp_path / tag)
+        b = subprocess.run([GENO] + args + ["-o", o], stderr=subprocess.PIPE, text=True, env=dict(os.environ, **env))
+        assert b.returncode == 0, (tag, b.stderr[-500:])
+        for suf in ("_genotype.tsv", "_allele.tsv", "_aligned_1.fa", "_aligned_2.fa"):
+            assert open(o_ref + suf, "rb").read() == open(o + suf, "rb").read(), (tag, suf)
+        assert os.path.getsize(o + "_aligned_1.fa") > 100000
+
+
 def test_over_long_read_fails_before_any_output(built, tmp_path):
     """reads longer than max_read_len (320) are not handled by this build: the run must stop with a message BEFORE an output file exists"""
     c = goldens.Case("cyp_rna_2x100", str(tmp_path))
