@@ -549,7 +549,9 @@ __global__ __launch_bounds__(WG) void k_pair(PairArgs P) {
     // ---- rowset form: the row ordered by allele index (the order of a coalesced group's entries, Genotyper.hpp:847-853), its place
     // in the list kept in the `qual` slot (all assignment qualities are 1), and a 128-bit hash of the allele pattern ---------------
     __shared__ unsigned long long sRowBase;
-    __shared__ uint32_t sAllele[SORT_TILE];
+    uint32_t *sAllele = hKey;  // [SORT_TILE]: the join table is done with by now (the barriers of the phases above lie between); 8 KB less
+                               // LDS lets a fourth workgroup onto the CU
+    static_assert(SORT_TILE <= LJ_SLOTS, "the rank-sort tile lives in the join table's keys");
     __shared__ unsigned long long sHash[2][4];
     if (tid == 0) {
       unsigned long long b = nRow ? atomicAdd(P.rsCursor, (unsigned long long)nRow) : 0ull;
