@@ -810,8 +810,9 @@ static void streamClose(t1k_job *job, bool removeFiles) {
 }
 // local fragments [fLo, fHi): flags must be in job->fragAssigned
 static bool streamAppend(t1k_job *job, uint32_t fLo, uint32_t fHi, bool besideLoop) {
-  // behind the device loop a few threads per file keep up easily (a window lasts a second); the rest of the machine feeds the GPU
-  const int T = besideLoop ? 4 : std::max(1, hostThreads(job) / (int)std::max<size_t>(1, job->stream.size()));
+  // behind the device loop a few threads per file keep up (the pairing of a large window hands over 2 - 3 GB of records in about a
+  // second); the rest of the machine feeds the GPU
+  const int T = besideLoop ? 6 : std::max(1, hostThreads(job) / (int)std::max<size_t>(1, job->stream.size()));
   std::vector<char> ok(job->stream.size(), 1);
   auto one = [&](size_t i) {
     auto &o = job->stream[i];
