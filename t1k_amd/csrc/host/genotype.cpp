@@ -65,7 +65,7 @@ void Genotyper::coalesce(t1k_row_entry *row, uint32_t n, uint32_t fragment) {
   groupFirst.push_back(fragment);
 }
 
-void Genotyper::setGroupsMerged(const std::vector<uint32_t> &sizes, const std::vector<GroupEntry> &entries, const std::vector<uint32_t> &first) {
+void Genotyper::setGroupsMerged(const std::vector<uint32_t> &sizes, const GroupVec &entries, const std::vector<uint32_t> &first) {
   const size_t G = sizes.size();
   std::vector<uint64_t> at(G + 1, 0);
   for (size_t g = 0; g < G; ++g) at[g + 1] = at[g] + sizes[g];

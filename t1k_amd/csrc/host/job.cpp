@@ -651,7 +651,13 @@ int t1k_job_run_local(t1k_job *job) {
   } else {
     if ((rc = t1k_rowset_groups_gather(job->rows, job->comm, &G, &N, &assigned)) != T1K_OK) return jobFail(job, rc, t1k_rowset_last_error(job->rows));
     std::vector<uint32_t> sizes(G), first(G);
-    std::vector<GroupEntry> ents(N);
+    GroupVec ents;
+    ents.resize(N);  // (not zeroed; pages first touched by all host threads, as for the single-GPU table above)
+    parallelRanges(N * sizeof(GroupEntry) / 4096 + 1, T, [&](int, size_t b, size_t e) {
+      volatile char *base = (volatile char *)ents.data();
+      const size_t bytes = N * sizeof(GroupEntry);
+      for (size_t pg = b; pg < e; ++pg) if (pg * 4096 < bytes) base[pg * 4096] = 0;
+    });
     if ((rc = t1k_rowset_groups_download_all(job->rows, sizes.data(), (t1k_group_entry *)ents.data(), first.data())) != T1K_OK)
       return jobFail(job, rc, t1k_rowset_last_error(job->rows));
     gt.setGroupsMerged(sizes, ents, first);
@@ -938,7 +944,7 @@ int t1k_job_groups_serialize(t1k_job *job, void *buf, uint64_t cap, uint64_t *ne
 int t1k_job_groups_merge(t1k_job *job, const void *const *bufs, const uint64_t *lens, uint32_t n) {
   if (!job || !bufs || !lens) return T1K_ERR_ARG;
   std::vector<uint32_t> sizes, first;
-  std::vector<GroupEntry> ents;
+  GroupVec ents;
   uint64_t assigned = 0;
   for (uint32_t i = 0; i < n; ++i) {
     const uint8_t *p = (const uint8_t *)bufs[i];

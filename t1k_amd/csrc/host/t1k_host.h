@@ -135,7 +135,7 @@ struct Genotyper {
   void coalesce(t1k_row_entry *row, uint32_t n, uint32_t fragment = 0);  // CoalesceReadAssignments (841-908), one fragment
   // group tables of several owners (every pattern belongs to exactly one of them) -> one table in first-fragment order = the
   // reference's first-appearance numbering
-  void setGroupsMerged(const std::vector<uint32_t> &sizes, const std::vector<GroupEntry> &entries, const std::vector<uint32_t> &first);
+  void setGroupsMerged(const std::vector<uint32_t> &sizes, const GroupVec &entries, const std::vector<uint32_t> &first);
   void finalize(const std::vector<int32_t> &missing);        // FinalizeReadAssignments (912-939); missing[a] from t1k_missing_coverage
   // QuantifyAlleleEquivalentClass (1142-1328); the E-step covers groups [gBegin, gEnd) (the whole table on one GPU)
   // the E-step's row pass covers the slice `rank` of `nRanks` of the read groups when a communicator is given (t1k_em_shard)
