@@ -304,7 +304,6 @@ int t1k_job_run_local(t1k_job *job) {
   const uint32_t inBase = in.base;  // fragment f of the input = record in.frag[f - inBase] held here
   const uint32_t per = in.paired ? 2 : 1;
   job->fragAssigned.assign(Fall, 0);
-  if (job->nRanks > 1 && job->prm.output_read_assignment) return jobFail(job, T1K_ERR_ARG, "--outputReadAssignment is not available when the job is sharded over several GPUs");
   job->assignText.clear();
   memset(&job->stats, 0, sizeof(job->stats));
   job->distinctReadEnds = 0; job->readEnds = (uint64_t)F * per;
@@ -620,6 +619,19 @@ int t1k_job_run_local(t1k_job *job) {
           job->assignText += num;
         }
       }
+    }
+    if (job->nRanks > 1) {  // the table of all fragments = the ranks' tables in rank order (= fragment order); rank 0 writes it
+      std::vector<uint64_t> sizes(job->nRanks, 0), eight(job->nRanks, 8), at8(job->nRanks);
+      for (int r = 0; r < job->nRanks; ++r) at8[r] = 8 * (uint64_t)r;
+      sizes[job->rank] = job->assignText.size();
+      if ((rc = t1k_comm_allgatherv_host(job->comm, sizes.data(), eight.data(), at8.data(), 8 * (uint64_t)job->nRanks)) != T1K_OK) return jobFail(job, rc, t1k_comm_last_error(job->comm));
+      std::vector<uint64_t> displ(job->nRanks, 0);
+      uint64_t total = 0;
+      for (int r = 0; r < job->nRanks; ++r) { displ[r] = total; total += sizes[r]; }
+      std::string all(total, '\0');
+      if (!job->assignText.empty()) memcpy(&all[displ[job->rank]], job->assignText.data(), job->assignText.size());
+      if ((rc = t1k_comm_allgatherv_host(job->comm, total ? &all[0] : nullptr, sizes.data(), displ.data(), total)) != T1K_OK) return jobFail(job, rc, t1k_comm_last_error(job->comm));
+      job->assignText.swap(all);
     }
   }
   // ---- CoalesceReadAssignments over all fragments (t1k_coalesce.hip), groups back to the host ---------------------------

@@ -247,10 +247,11 @@ def test_sharded_job_equals_single_gpu_job(built, tmp_path, name, gpus):
     env = dict(os.environ, T1K_GPUS=gpus.split("+")[0])
     if "+" in gpus:
         env["T1K_SHARD_INPUT"] = "1"
-    r = subprocess.run([GENO] + c.args() + ["-o", out], stderr=subprocess.PIPE, text=True, env=env)
+    r = subprocess.run([GENO] + c.args() + ["-o", out, "--outputReadAssignment"], stderr=subprocess.PIPE, text=True, env=env)
     assert r.returncode == 0, r.stderr
     assert open(out + "_genotype.tsv").read() == c.expected("genotype.tsv")
     assert open(out + "_allele.tsv").read() == c.expected("allele.tsv")
+    assert open(out + "_assign.tsv").read() == c.expected("assign.tsv.gz")   # the ranks' tables, gathered in rank order
     ids = [l[1:].strip() for l in open(out + ("_aligned_1.fa" if c.paired else "_aligned.fa")) if l.startswith(">")]
     assert ids == c.expected("aligned_ids.txt.gz").split()
     if c.paired:
