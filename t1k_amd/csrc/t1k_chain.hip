@@ -1197,26 +1197,55 @@ __global__ __launch_bounds__(64) void k_chain_big(ChainArgs P, uint32_t nItems) 
 // ------------------------------------------------------------------------------------------------------------------
 
 // the similarity / low-complexity filter on a seed candidate (SeqSet.hpp:1838-1845, 1894-1908): candidates that fail it take no
-// further part (they only counted for the strand vote), so they are never copied out
-__device__ __forceinline__ bool keepCandidate(const ChainArgs &P, uint32_t re, int plus, uint32_t w0, uint32_t w1, uint32_t w2) {
+// further part (they only counted for the strand vote), so they are never copied out.  The low-complexity test (SeqSet.hpp:458-485)
+// asks for the number of A / C / G / T among the non-N bases of a read span; a workgroup works on one read-end, so it keeps prefix
+// counts of the four bases for both strands in LDS (sBaseCnt[strand][base][p] = occurrences in [0, p)) and a span costs eight reads.
+__device__ __forceinline__ bool lowComplexityFromCounts(const uint16_t (*cnt)[T1K_MAX_READ_LEN + 1], int rs, int re) {
+  const int L = re - rs + 1;
+  int low = 0, lowTotal = 0;
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    const int c = (int)cnt[b][re + 1] - (int)cnt[b][rs];
+    if (c <= 2) { ++low; lowTotal += c; }
+  }
+  if (lowTotal * 7 >= L) return false;
+  return low >= 2;
+}
+__device__ __forceinline__ bool keepCandidate(const ChainArgs &P, const uint16_t (*baseCnt)[4][T1K_MAX_READ_LEN + 1], int plus, uint32_t w0, uint32_t w1, uint32_t w2) {
   const int rs = (int)(w0 & 0xFFF), rend = (int)((w0 >> 12) & 0xFFF), ss = (int)(w1 & 0xFFFFF), se = (int)(w2 & 0xFFFFF);
   const int matchCnt = (int)(w2 >> 20);
   const double sim = (double)matchCnt / (double)(se - ss + 1 + rend - rs + 1);
   if (sim < P.sim) return false;
-  const int S = P.reads.S, pass = plus ? 0 : 1;
-  const uint64_t *rb = P.reads.bases + ((uint64_t)re * 2 + pass) * S, *rn = P.reads.nmask + ((uint64_t)re * 2 + pass) * S;
-  if (t1k_low_complexity(rb, rn, rs, rend)) return !(0.0 < P.sim);  // similarity becomes 0
+  if (lowComplexityFromCounts(baseCnt[plus ? 0 : 1], rs, rend)) return !(0.0 < P.sim);  // similarity becomes 0
   return true;
 }
 
 __global__ __launch_bounds__(WG) void k_collect(ChainArgs P) {
   __shared__ uint32_t warpSums[4];
+  __shared__ uint16_t sBaseCnt[2][4][T1K_MAX_READ_LEN + 1];
   __shared__ uint64_t sVoteHi[WG], sVoteLo[WG];
   __shared__ uint32_t sBase;
   const int tid = threadIdx.x;
   const uint32_t stride = P.recStride;
   for (uint32_t re = blockIdx.x; re < P.reads.nReadEnds; re += gridDim.x) {
     const uint32_t *cs = P.chunkStart + (uint64_t)re * P.maxChunks, *cc = P.chunkCount + (uint64_t)re * P.maxChunks;
+    {  // prefix counts of the four bases (non-N positions only) of both strands of this read-end
+      const int len = (int)P.reads.len[re], S = P.reads.S;
+      for (int idx = tid; idx < 2 * (len + 1); idx += WG) {
+        const int strand = idx / (len + 1), p = idx - strand * (len + 1);
+        const uint64_t *rb = P.reads.bases + ((uint64_t)re * 2 + strand) * S, *rn = P.reads.nmask + ((uint64_t)re * 2 + strand) * S;
+        int c[4] = {0, 0, 0, 0};
+        for (int o = 0; o < p; o += 32) {
+          const uint64_t x = rb[o >> 5], nn = rn[o >> 5];
+          const uint64_t valid = T1K_EVEN & ~nn & t1k_lowmask(p - o);
+          const uint64_t lo = x & T1K_EVEN, hi = (x >> 1) & T1K_EVEN;
+          c[0] += __popcll(~lo & ~hi & valid); c[1] += __popcll(lo & ~hi & valid); c[2] += __popcll(~lo & hi & valid); c[3] += __popcll(lo & hi & valid);
+        }
+#pragma unroll
+        for (int b = 0; b < 4; ++b) sBaseCnt[strand][b][p] = (uint16_t)c[b];
+      }
+      __syncthreads();
+    }
     VoteKey best; best.hi = ~0ull; best.lo = ~0ull;
     uint32_t nCand[2] = {0, 0};
     for (int ch = 0; ch < P.maxChunks; ++ch) {
@@ -1232,7 +1261,7 @@ __global__ __launch_bounds__(WG) void k_collect(ChainArgs P) {
           if (hd.z & 0x40000000u) { const uint32_t *g = P.genCand + ((uint64_t)hd.w + j) * 6; w0 = g[0]; w1 = g[1]; w2 = g[2]; }
           VoteKey vk = voteKey((int)(w1 >> 20), (int)(w0 & 0xFFF), (int)((w0 >> 12) & 0xFFF), hd.y, plus, (int)(w1 & 0xFFFFF), (int)(w2 & 0xFFFFF));
           if (vk < best) best = vk;
-          nCand[plus] += keepCandidate(P, re, plus, w0, w1, w2) ? 1u : 0u;
+          nCand[plus] += keepCandidate(P, sBaseCnt, plus, w0, w1, w2) ? 1u : 0u;
         }
       }
     }
@@ -1271,7 +1300,7 @@ __global__ __launch_bounds__(WG) void k_collect(ChainArgs P) {
           for (uint32_t j = 0; j < nc; ++j) {
             uint32_t w0 = hd.w, w1 = cw.x, w2 = cw.y;
             if (hd.z & 0x40000000u) { const uint32_t *g = P.genCand + ((uint64_t)hd.w + j) * 6; w0 = g[0]; w1 = g[1]; w2 = g[2]; }
-            if (keepCandidate(P, re, (int)winPlus, w0, w1, w2)) { keepMask |= 1u << j; ++nk; }
+            if (keepCandidate(P, sBaseCnt, (int)winPlus, w0, w1, w2)) { keepMask |= 1u << j; ++nk; }
           }
           uint32_t tot;
           uint32_t off = t1k_block_scan_exclusive(nk, warpSums, &tot);
