@@ -559,11 +559,11 @@ __global__ __launch_bounds__(WG) T1K_OCC8 void k_seed_groups(ChainArgs P) {
 
     // the used lists are kept for k_chain_general, which re-derives the hits of the few multi-diagonal groups
     {
-      uint32_t *uo = P.usedOut + (uint64_t)re * maxK * 3;
+      uint32_t *uo = P.usedOut + (uint64_t)re * maxK * 4;
       for (uint32_t u = tid; u < nUsedPlus + nUsedMinus; u += WG) {
         int q = usedQ[u];
         int pass = u < nUsedPlus ? 0 : 1;
-        uo[3 * u] = (uint32_t)(q - pass * nk); uo[3 * u + 1] = ukStart[q]; uo[3 * u + 2] = ukLen[q];
+        uo[4 * u] = (uint32_t)(q - pass * nk); uo[4 * u + 1] = ukStart[q]; uo[4 * u + 2] = ukLen[q]; uo[4 * u + 3] = ukDir[q];
       }
     }
     // what the chunk loop needs of the used lists moves out of the overlay, then the accumulators under it are made clean again
@@ -910,10 +910,10 @@ __device__ inline int gatherHits(const ChainArgs &P, uint32_t re, int pass, uint
   const int maxK = (int)P.maxK;
   const uint32_t nPlus = P.usedCount[2 * re], nMinus = P.usedCount[2 * re + 1];
   const uint32_t b = pass == 0 ? 0 : nPlus, e = pass == 0 ? nPlus : nPlus + nMinus;
-  const uint32_t *uo = P.usedOut + (uint64_t)re * maxK * 3;
+  const uint32_t *uo = P.usedOut + (uint64_t)re * maxK * 4;
   int n = 0;
   for (uint32_t u = b; u < e; ++u) {
-    const uint32_t rOff = uo[3 * u], st = uo[3 * u + 1], ln = uo[3 * u + 2];
+    const uint32_t rOff = uo[4 * u], st = uo[4 * u + 1], ln = uo[4 * u + 2];
     uint32_t l = 0, r = ln;
     while (l < r) { uint32_t m = (l + r) >> 1; if (P.ref.kPost[st + m].allele < allele) l = m + 1; else r = m; }
     for (; l < ln; ++l) {
@@ -943,15 +943,20 @@ __global__ __launch_bounds__(WG) void k_gather_general(ChainArgs P, uint32_t nIt
     const int pass = (rec[0] >> 31) ? 0 : 1;
     const uint32_t nPlus = P.usedCount[2 * re], nMinus = P.usedCount[2 * re + 1];
     const uint32_t b = pass == 0 ? 0 : nPlus, e = pass == 0 ? nPlus : nPlus + nMinus;
-    const uint32_t *uo = P.usedOut + (uint64_t)re * maxK * 3;
+    const uint32_t *uo = P.usedOut + (uint64_t)re * maxK * 4;
     uint32_t first[ROUNDS], cnt[ROUNDS], mine = 0;
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r) {
       const uint32_t u = b + lane + 64 * r;
       first[r] = 0; cnt[r] = 0;
       if (u < e) {
-        const uint32_t st = uo[3 * u + 1], ln = uo[3 * u + 2];
+        const uint32_t st = uo[4 * u + 1], ln = uo[4 * u + 2], dr = uo[4 * u + 3];
         uint32_t l = 0, rr = ln;
+        if (dr != T1K_NO_DIR) {  // a long list: its chunk directory narrows the search to the allele's chunk of T1K_SEED_CHUNK sequences
+          const uint32_t *dir = P.ref.kDir + (uint64_t)dr * P.ref.kDirStride;
+          const uint32_t ci = allele / T1K_SEED_CHUNK;
+          l = dir[ci]; rr = dir[ci + 1];
+        }
         while (l < rr) { uint32_t m = (l + rr) >> 1; if (P.ref.kPost[st + m].allele < allele) l = m + 1; else rr = m; }
         uint32_t c = 0;
         while (l + c < ln && P.ref.kPost[st + l + c].allele == allele) ++c;
@@ -984,7 +989,7 @@ __global__ __launch_bounds__(WG) void k_gather_general(ChainArgs P, uint32_t nIt
       for (int r = 0; r < ROUNDS; ++r) {
         const uint32_t u = b + lane + 64 * r;
         if (cnt[r]) {
-          const uint32_t rOff = uo[3 * u];
+          const uint32_t rOff = uo[4 * u];
           for (uint32_t j = 0; j < cnt[r]; ++j) P.genHits[w++] = (P.ref.kPost[first[r] + j].offset << 12) | rOff;
         }
       }
@@ -1333,7 +1338,7 @@ int t1k_chain_max_chunks(uint32_t nAlleles) { return 2 * (int)((nAlleles + CHUNK
 int t1k_chain_memo_entries() { return GAP_CACHE; }
 int t1k_chain_rec_stride(int maxLen) { return maxLen <= 160 ? 8 : 16; }  // u32 per record (32 / 64 bytes)
 int t1k_chain_max_kmers(int maxLen, int k) { return (2 * std::max(1, maxLen - k + 1) + 3) / 4 * 4; }
-int t1k_chain_used_u32(int maxK) { return maxK * 3; }
+int t1k_chain_used_u32(int maxK) { return maxK * 4; }  // per used list: read offset, list start, list length, directory row
 
 static int readCounters(t1k_ctx *ctx, unsigned long long *h) { return t1k_fetch_counters(ctx, h); }
 

@@ -10,7 +10,7 @@ struct ChainArgs {
   double sim;
   uint32_t *recs; uint32_t recStride; uint64_t groupCap;   // group records: re|strand, allele, diag, meta, M[...]
   uint32_t *chunkStart, *chunkCount; int maxChunks;        // [re][maxChunks] runs of groups per (strand, allele chunk), reference order
-  uint32_t *usedOut, *usedCount;                           // [re][maxK][3] used k-mers (readOff, listStart, listLen); [re][2] counts per strand
+  uint32_t *usedOut, *usedCount;                           // [re][maxK][4] used k-mers (readOff, listStart, listLen, directory row); [re][2] counts per strand
   unsigned long long *memo;                                // [re][GAP_CACHE] memo of gap alignments
   uint32_t *jobList; uint32_t jobCap;
   uint32_t *retryList, *generalList, *bigList, *finishList;  // dense lists (filled by k_arena_compact)
