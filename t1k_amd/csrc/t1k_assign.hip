@@ -884,6 +884,7 @@ __global__ __launch_bounds__(WG) void k_align_apply_eq(SlowArgs P) {
         const int readPos = o.readStart + ti;  // ti was already decremented: this column consumed read base ti
         if (!rnW.bit(readPos) && !gnW.bit(refPos)) {
           if (refPos == runLo - 1) runLo = refPos;
+          else if (refPos == runLo - 2 && runLo >= 0) { atomicAdd(&cov[P.ref.covStride + runLo - 1], w); runLo = refPos; }  // one uncovered position: a hole in the run (1 atomic, not 2)
           else {
             if (runLo >= 0) { atomicAdd(&cov[runLo], w); atomicAdd(&cov[runHi + 1], -w); }
             runLo = runHi = refPos;
@@ -948,6 +949,7 @@ __global__ __launch_bounds__(WG) void k_align_apply_band(SlowArgs P) {
         const int readPos = o.readStart + ti;
         if (!rnW.bit(readPos) && !gnW.bit(refPos)) {
           if (refPos == runLo - 1) runLo = refPos;
+          else if (refPos == runLo - 2 && runLo >= 0) { atomicAdd(&cov[P.ref.covStride + runLo - 1], w); runLo = refPos; }  // one uncovered position: a hole in the run (1 atomic, not 2)
           else {
             if (runLo >= 0) { atomicAdd(&cov[runLo], w); atomicAdd(&cov[runHi + 1], -w); }
             runLo = runHi = refPos;
