@@ -699,8 +699,8 @@ __global__ __launch_bounds__(WG) void k_fullalign(FullArgs P) {
   // difference array (2 atomics) and one "hole" per position of the span that is not covered (mismatch or N)
   if (w) {
     int32_t *diff = P.ref.covDiff + goff + o.seqStart, *hole = diff + P.ref.covStride;
-    atomicAdd(&diff[0], w);
-    atomicAdd(&diff[L], -w);
+    if (L == P.fullLen) atomicAdd(&diff[2 * P.ref.covStride], w);  // a run of the usual length: counted by its start (t1k_coverage_fold)
+    else { atomicAdd(&diff[0], w); atomicAdd(&diff[L], -w); }
 #pragma unroll
     for (int wi = 0; wi < 10; ++wi) {
       const int off = wi * 32;
@@ -1129,6 +1129,21 @@ void t1k_launch_truncate(t1k_ctx *ctx, const TruncArgs &a, int nWg) {
   hipFuncSetAttribute((const void *)k_truncate<SELECT_LARGE, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, SELECT_LARGE * 8);
   hipLaunchKernelGGL((k_truncate<SELECT_SMALL, 256>), dim3(std::min(nWg, 512)), dim3(256), SELECT_SMALL * 8, ctx->stream, a);  // (its staging area: 512 workgroups' worth)
   hipLaunchKernelGGL((k_truncate<SELECT_LARGE, 1024>), dim3(std::min(nWg, 512)), dim3(1024), SELECT_LARGE * 8, ctx->stream, a);
+}
+__global__ __launch_bounds__(WG) void k_coverage_fold(int32_t *diff, const int32_t *full, uint64_t n, uint64_t len) {
+  const uint64_t i = (uint64_t)blockIdx.x * WG + threadIdx.x;
+  if (i >= n) return;
+  const int32_t v = full[i] - (i >= len ? full[i - len] : 0);  // runs starting here, minus runs that ended just before
+  if (v) diff[i] += v;
+}
+int t1k_coverage_fold(t1k_ctx *ctx) {
+  if (!ctx->covFullDirty || !ctx->ref.covDiff) return T1K_OK;
+  const uint64_t n = ctx->ref.covStride;
+  int32_t *full = ctx->ref.covDiff + 2 * n;
+  hipLaunchKernelGGL(k_coverage_fold, dim3((unsigned)((n + WG - 1) / WG)), dim3(WG), 0, ctx->stream, ctx->ref.covDiff, (const int32_t *)full, n, (uint64_t)ctx->covFullLen);
+  if (hipMemsetAsync(full, 0, n * sizeof(int32_t), ctx->stream) != hipSuccess) return T1K_ERR_DEVICE;
+  ctx->covFullDirty = false;
+  return T1K_OK;
 }
 __global__ __launch_bounds__(WG) void k_coverage_add(int32_t *dst, int32_t *src, uint64_t n) {
   const uint64_t i = (uint64_t)blockIdx.x * WG + threadIdx.x;

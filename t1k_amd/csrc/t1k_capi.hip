@@ -250,6 +250,7 @@ int t1k_missing_coverage(t1k_ctx *ctx, int32_t *missing) {
   if ((rc = t1k_ensure(ctx, dScratch, (ctx->ref.totalBases + 2) * 4))) return rc;
   if ((rc = t1k_ensure(ctx, dMiss, (size_t)A * 4))) { freeBuf(dScratch); return rc; }
   const double t1 = nowMs();
+  if ((rc = t1k_coverage_fold(ctx))) { freeBuf(dScratch); freeBuf(dMiss); return rc; }
   t1k_launch_missing_coverage(ctx, ctx->ref, (int32_t *)dScratch.p, (int32_t *)dMiss.p);
   hipMemcpyAsync(missing, dMiss.p, (size_t)A * 4, hipMemcpyDeviceToHost, ctx->stream);
   hipError_t e = hipStreamSynchronize(ctx->stream);
@@ -260,6 +261,9 @@ int t1k_missing_coverage(t1k_ctx *ctx, int32_t *missing) {
 }
 int t1k_coverage_device(t1k_ctx *ctx, void **devPtr, uint64_t *count) {
   if (!ctx || !ctx->ref.covDiff || !devPtr || !count) return t1k_fail(ctx, T1K_ERR_STATE, "no reference");
+  T1K_HIP(ctx, hipSetDevice(ctx->device));
+  if (int rc = t1k_coverage_fold(ctx)) return rc;
+  T1K_HIP(ctx, hipStreamSynchronize(ctx->stream));
   *devPtr = ctx->ref.covDiff;
   *count = 2 * ctx->ref.covStride;  // difference array and hole array, contiguous: both are additive over GPUs
   return T1K_OK;
@@ -276,11 +280,12 @@ int t1k_ref_share(t1k_ctx *dst, const t1k_ctx *src) {
   dst->hAlleleLen = src->hAlleleLen;
   T1kDevBuf cov;  // the coverage difference array is per context
   int rc;
-  if ((rc = t1k_ensure(dst, cov, 2 * src->ref.covStride * sizeof(int32_t)))) return rc;
-  T1K_HIP(dst, hipMemsetAsync(cov.p, 0, 2 * src->ref.covStride * sizeof(int32_t), dst->stream));
+  if ((rc = t1k_ensure(dst, cov, 3 * src->ref.covStride * sizeof(int32_t)))) return rc;
+  T1K_HIP(dst, hipMemsetAsync(cov.p, 0, 3 * src->ref.covStride * sizeof(int32_t), dst->stream));
   T1K_HIP(dst, hipStreamSynchronize(dst->stream));
   dst->refBufs.push_back(cov);
   dst->ref.covDiff = (int32_t *)cov.p;
+  dst->covFullLen = 0; dst->covFullDirty = false;
   return T1K_OK;
 }
 int t1k_reads_attach(t1k_ctx *dst, const t1k_ctx *src, int storeSlot, int resetStore) {
@@ -299,6 +304,7 @@ int t1k_coverage_absorb(t1k_ctx *dst, t1k_ctx *src) {
   if (!dst || !src || !dst->ref.covDiff || !src->ref.covDiff || dst->device != src->device || dst->ref.totalBases != src->ref.totalBases)
     return t1k_fail(dst, T1K_ERR_ARG, "t1k_coverage_absorb: contexts do not match");
   T1K_HIP(dst, hipSetDevice(dst->device));
+  if (int rc = t1k_coverage_fold(src)) return t1k_fail(dst, rc, "t1k_coverage_absorb: fold");
   T1K_HIP(dst, hipStreamSynchronize(src->stream));
   t1k_launch_coverage_add(dst, dst->ref.covDiff, src->ref.covDiff, 2 * dst->ref.covStride);
   T1K_HIP(dst, hipStreamSynchronize(dst->stream));
@@ -307,8 +313,9 @@ int t1k_coverage_absorb(t1k_ctx *dst, t1k_ctx *src) {
 int t1k_coverage_reset(t1k_ctx *ctx) {
   if (!ctx || !ctx->ref.covDiff) return t1k_fail(ctx, T1K_ERR_STATE, "no reference");
   T1K_HIP(ctx, hipSetDevice(ctx->device));
-  T1K_HIP(ctx, hipMemsetAsync(ctx->ref.covDiff, 0, 2 * ctx->ref.covStride * sizeof(int32_t), ctx->stream));
+  T1K_HIP(ctx, hipMemsetAsync(ctx->ref.covDiff, 0, 3 * ctx->ref.covStride * sizeof(int32_t), ctx->stream));
   T1K_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->covFullDirty = false;
   return T1K_OK;
 }
 
@@ -325,6 +332,7 @@ int t1k_coverage_get(t1k_ctx *ctx, int32_t *out, uint64_t cap) {
   if ((rc = t1k_ensure(ctx, dOut, tot * 4))) return rc;
   if ((rc = t1k_ensure(ctx, dOff, A * 8))) { freeBuf(dOut); return rc; }
   hipMemcpyAsync(dOff.p, outOff.data(), A * 8, hipMemcpyHostToDevice, ctx->stream);
+  if ((rc = t1k_coverage_fold(ctx))) { freeBuf(dOut); freeBuf(dOff); return rc; }
   t1k_launch_coverage_scan(ctx, ctx->ref, (int32_t *)dOut.p, (const uint64_t *)dOff.p);
   hipMemcpyAsync(out, dOut.p, tot * 4, hipMemcpyDeviceToHost, ctx->stream);
   hipError_t e = hipStreamSynchronize(ctx->stream);
@@ -730,6 +738,8 @@ static int assignOnce(t1k_ctx *ctx, uint64_t first, uint32_t count) {
   unsigned long long *kDense = f.bandKeyStr + qStr, *kSorted = kDense + qDense;
   uint32_t *vDense = (uint32_t *)(kSorted + qDense);
   ctx->covCommitted = true;  // from here on the range's coverage is in the context's arrays
+  if (!ctx->covFullLen) ctx->covFullLen = std::max(1, ctx->batchMaxLen);
+  f.fullLen = ctx->covFullLen; ctx->covFullDirty = true;
   t1k_launch_fullalign(ctx, f);
   T1K_HIP(ctx, hipEventRecord(ctx->ev[7], ctx->stream));
   if ((rc = fetchCounters(ctx, hc))) return rc;

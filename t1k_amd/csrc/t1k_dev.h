@@ -113,7 +113,10 @@ struct T1kRefDev {
   const uint32_t *kPostAllele;  // the allele column of kPost on its own: the extractor's vote streams only this
   // per-base coverage = prefix sum of covDiff (+w where a covered run starts, -w behind its end) minus covHole (w at a position
   // inside an ungapped alignment's span that is not covered: a mismatch or an N).  covHole = covDiff + covStride.
-  int32_t *covDiff;             // [2][covStride]
+  // covFull = covDiff + 2 * covStride counts the covered runs of exactly the context's covFullLen positions by their start (one
+  // atomic instead of the +w / -w pair -- most alignments span the whole read); t1k_coverage_fold adds them into covDiff before
+  // anything reads the arrays.
+  int32_t *covDiff;             // [3][covStride]
   uint64_t covStride;           // totalBases + 2
 };
 
@@ -687,6 +690,8 @@ struct t1k_ctx {
   T1kDevBuf bDedupScratch, bDedupBases, bDedupN, bDedupLen, bDedupWeight;  // t1k_reads_dedupe
   bool readsShared = false;      // the read set belongs to another context (t1k_reads_share)
   int batchMaxLen = 0;
+  int covFullLen = 0;            // run length counted in covFull (fixed at the context's first range)
+  bool covFullDirty = false;     // covFull holds runs that are not in covDiff yet
   uint32_t rangeCount = 0;       // read-ends of the last t1k_assign_range
   // assignment arenas
   T1kDevBuf bWgHits, bWgGroups, bWgStage, bWgBig, bWgCache, bLists;

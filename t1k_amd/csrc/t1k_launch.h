@@ -57,6 +57,7 @@ struct FullArgs {
   T1kRefDev ref;
   T1kReadsDev reads;
   int relax;
+  int fullLen;             // span counted in ref.covFull
   T1kOvl *ovl;
   uint64_t nOvl;
   uint32_t *eqStr, *bandStr, *wideStr; uint32_t segCap;  // striped alignment queues
@@ -148,6 +149,7 @@ int t1k_fetch_counters(t1k_ctx *ctx, unsigned long long *h);
 struct T1kArenaCounts { uint64_t total; uint32_t maxSeg; bool overflow; };
 T1kArenaCounts t1k_arena_counts(const t1k_ctx *ctx, int arena, uint32_t segCap);  // from the last t1k_fetch_counters
 void t1k_launch_coverage_add(t1k_ctx *ctx, int32_t *dst, int32_t *src, uint64_t n);
+int t1k_coverage_fold(t1k_ctx *ctx);  // covFull -> covDiff (on the context's stream, not synchronised)
 void t1k_launch_missing_coverage(t1k_ctx *ctx, const T1kRefDev &ref, int32_t *scratch, int32_t *missing);
 void t1k_launch_extend_retry(t1k_ctx *ctx, const ExtendArgs &a, const uint32_t *list, uint32_t n);
 void t1k_launch_dp_dense(t1k_ctx *ctx, const ChainArgs &a, const uint32_t *jobs, uint32_t n);

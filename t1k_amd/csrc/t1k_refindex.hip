@@ -289,8 +289,8 @@ extern "C" int t1k_ref_upload(t1k_ctx *ctx, const char *seqs, const uint64_t *of
   // coverage arrays
   void *dCov;
   r.covStride = total + 2;
-  if ((rc = keep(ctx, 2 * r.covStride * sizeof(int32_t), &dCov))) { freeScratch2(); return rc; }
-  RU_HIP(hipMemsetAsync(dCov, 0, 2 * r.covStride * sizeof(int32_t), st));
+  if ((rc = keep(ctx, 3 * r.covStride * sizeof(int32_t), &dCov))) { freeScratch2(); return rc; }
+  RU_HIP(hipMemsetAsync(dCov, 0, 3 * r.covStride * sizeof(int32_t), st));
   RU_HIP(hipStreamSynchronize(st));
   freeScratch2();
 #undef RU_HIP
@@ -302,6 +302,7 @@ extern "C" int t1k_ref_upload(t1k_ctx *ctx, const char *seqs, const uint64_t *of
   r.kPost = (const T1kPosting *)dPost; r.kPostAllele = (const uint32_t *)dPostAllele;
   r.covDiff = (int32_t *)dCov;
   ctx->ref = r;
+  ctx->covFullLen = 0; ctx->covFullDirty = false;
   lap("bucket starts + bitmaps + directory + coverage arrays");
   return T1K_OK;
 }
