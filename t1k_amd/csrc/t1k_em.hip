@@ -21,6 +21,16 @@
 __device__ __forceinline__ double waveOrderedSum(double v, int cnt, double acc) {
   const long long bits = __double_as_longlong(v);
   const int lo = (int)(uint32_t)bits, hi = (int)(uint32_t)((unsigned long long)bits >> 32);
+  if (cnt == 64) {
+    // a full wavefront of operands (all but the last piece of a long list): no loop control between the dependent additions -- the
+    // chain of one long class is the critical path of the whole E-step
+#pragma unroll
+    for (int j = 0; j < 64; ++j) {
+      const uint32_t l = (uint32_t)__builtin_amdgcn_readlane(lo, j), h = (uint32_t)__builtin_amdgcn_readlane(hi, j);
+      acc += __longlong_as_double((long long)(((unsigned long long)h << 32) | l));
+    }
+    return acc;
+  }
   for (int j = 0; j < cnt; ++j) {
     const uint32_t l = (uint32_t)__builtin_amdgcn_readlane(lo, j), h = (uint32_t)__builtin_amdgcn_readlane(hi, j);
     acc += __longlong_as_double((long long)(((unsigned long long)h << 32) | l));
