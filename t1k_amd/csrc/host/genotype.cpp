@@ -16,7 +16,7 @@ double hostNowMs() { return std::chrono::duration<double, std::milli>(std::chron
 template <class F>
 void parallelFor(size_t n, F fn, size_t serialBelow = 256) {
   unsigned T = std::thread::hardware_concurrency();
-  if (T > 16) T = 16;
+  if (T > 32) T = 32;
   if (T < 2 || n < serialBelow || n < 2) { for (size_t i = 0; i < n; ++i) fn(i); return; }
   std::vector<std::thread> th;
   const size_t chunk = (n + T - 1) / T;
@@ -99,7 +99,7 @@ void Genotyper::finalize(const std::vector<int32_t> &missing) {
   // every piece its own range inside each allele's list, so the pieces fill in parallel and the order stays the sequential one
   {
     unsigned T = std::thread::hardware_concurrency();
-    if (T > 16) T = 16;
+    if (T > 32) T = 32;
     if (T < 1 || G < 4096) T = 1;
     const size_t piece = ((size_t)G + T - 1) / T;
     std::vector<std::vector<uint32_t>> cnt(T, std::vector<uint32_t>((size_t)A, 0));
@@ -191,7 +191,7 @@ int Genotyper::quantify(t1k_ctx *ctx, t1k_comm *comm, std::string &err) {
   std::vector<double> count(G);
   {
     unsigned T = std::thread::hardware_concurrency();
-    if (T > 16) T = 16;
+    if (T > 32) T = 32;
     if (T < 1 || G < 8192) T = 1;
     const size_t piece = (G + T - 1) / T;
     std::vector<std::vector<uint32_t>> part(T);
@@ -348,7 +348,12 @@ void Genotyper::select() {
   const double frac = prm.filter_frac;
   std::vector<char> groupCovered(G, 0);
   selected.assign(nGenes, {});
-  auto firstWeight = [&](int g) { return (double)groupEnt[groupPtr[g]].weight; };
+  const double ts0 = hostNowMs();
+  // weight of a group's first entry, gathered once: the class loop below reads it for every group of every class it looks at, and the
+  // entries themselves are hundreds of megabytes
+  std::vector<double> firstW(G);
+  parallelFor((size_t)G, [&](size_t g) { firstW[g] = (double)groupEnt[groupPtr[g]].weight; }, 4096);
+  auto firstWeight = [&](int g) { return firstW[g]; };
   auto lowAbundance = [&](int a) {  // 1568-1570 == 1656-1658
     const AlleleMeta &m = R.al[a];
     return m.ecAbundance < frac * geneMaxMajor[m.gene] &&
@@ -401,6 +406,7 @@ void Genotyper::select() {
       selected[m.gene].push_back({a, rank});
     }
   }
+  const double ts1 = hostNowMs();
   // rescue rejected alleles whose major allele did get selected (1669-1695)
   for (int a : rejected) {
     const AlleleMeta &m = R.al[a];
@@ -409,6 +415,7 @@ void Genotyper::select() {
       if (R.al[s.first].major == m.major) { rank = s.second; break; }
     if (rank != -1) selected[m.gene].push_back({a, rank});
   }
+  const double ts2 = hostNowMs();
   // genes with more than two allele types: pick the pair of types explaining the most reads (1697-1996)
   std::vector<int> groupUse(G, 0);
   auto forTopTwo = [&](int gene, std::set<int> &usedEc, int delta) {
@@ -512,6 +519,8 @@ void Genotyper::select() {
     }
     if (!changed) break;
   }
+  if (getenv("T1K_DEBUG_PHASES"))
+    fprintf(stderr, "[t1k host] select: classes by abundance %.1f ms (%zu rejected), rescue %.1f ms, type pairs %.1f ms\n", ts1 - ts0, rejected.size(), ts2 - ts1, hostNowMs() - ts2);
   // genotype quality (2010-2085)
   std::vector<double> selAbund(nGenes, 0);
   for (int g = 0; g < nGenes; ++g)

@@ -2,6 +2,7 @@
 // argv-compatible replacement of the reference's genotyper executable (Genotyper.cpp:194-738, invoked by run-t1k:430,434).
 #include <fcntl.h>
 #include <getopt.h>
+#include <sys/mman.h>
 #include <unistd.h>
 #include <atomic>
 #include <chrono>
@@ -735,12 +736,40 @@ static void alignedSizes(t1k_job *job, int what, uint32_t fLo, uint32_t fHi, int
   for (int t = 0; t < T + 1; ++t) pieceBytes[t + 1] += pieceBytes[t];
 }
 
-// ... and the records themselves, piece t at offset + pieceBytes[t]
-static bool alignedWrite(t1k_job *job, int fd, int what, uint32_t fLo, uint32_t fHi, int T, const std::vector<uint64_t> &pieceBytes, uint64_t offset) {
+// ... and the records themselves, piece t at offset + pieceBytes[t].
+// Buffered writes to one file take the inode lock one at a time, so a file fills at the speed of one copying thread however many
+// threads format records.  When this process is the file's only writer (mapped == true) the byte range is reserved with fallocate --
+// a full disk is reported here, not as a fault later -- and mapped, and the threads format straight into the page cache in parallel;
+// anything the file system refuses falls back to pwrite.
+static bool alignedWrite(t1k_job *job, int fd, int what, uint32_t fLo, uint32_t fHi, int T, const std::vector<uint64_t> &pieceBytes, uint64_t offset, bool mapped) {
   const ReadInput &in = *job->in;
   const uint32_t base = in.base;
   const ReadInput::Side &seqSide = what == 2 ? in.bc : in.side[what];
   const ReadInput::Side &idSide = what == 1 ? in.side[1] : in.side[0];
+  const uint64_t total = pieceBytes[T];
+  if (mapped && total >= (1u << 20) && fallocate(fd, 0, (off_t)offset, (off_t)total) == 0) {
+    const uint64_t pg = (uint64_t)sysconf(_SC_PAGESIZE), a0 = offset & ~(pg - 1);
+    void *m = mmap(nullptr, (size_t)(offset + total - a0), PROT_READ | PROT_WRITE, MAP_SHARED, fd, (off_t)a0);
+    if (m != MAP_FAILED) {
+      char *out = (char *)m + (offset - a0);
+      parallelRanges(fHi - fLo, T, [&](int t, size_t b, size_t e) {
+        char *at = out + pieceBytes[t];
+        char tmp[32];
+        for (size_t f = fLo + b; f < fLo + e; ++f) {
+          if (!job->fragAssigned[base + f]) continue;
+          const uint32_t r = in.frag[f];
+          *at++ = '>';
+          if (in.noIds) { const int n = snprintf(tmp, 32, "r%u", (uint32_t)(base + f)); memcpy(at, tmp, (size_t)n); at += n; }
+          else { memcpy(at, idSide.idP[r], idSide.idL[r]); at += idSide.idL[r]; }
+          *at++ = '\n';
+          memcpy(at, seqSide.seqP[r], seqSide.seqL[r]); at += seqSide.seqL[r];
+          *at++ = '\n';
+        }
+      });
+      munmap(m, (size_t)(offset + total - a0));
+      return true;
+    }
+  }
   std::atomic<bool> ok{true};
   parallelRanges(fHi - fLo, T, [&](int t, size_t b, size_t e) {
     uint64_t at = offset + pieceBytes[t];
@@ -772,6 +801,7 @@ static bool alignedWrite(t1k_job *job, int fd, int what, uint32_t fLo, uint32_t 
   return ok;
 }
 
+static bool mappedOutput() { static const bool on = getenv("T1K_NO_MMAP_OUTPUT") == nullptr; return on; }
 static bool planAligned(t1k_job *job, AlignedPlan &pl) {
   const ReadInput &in = *job->in;
   const int T = pl.T;
@@ -794,9 +824,9 @@ static bool planAligned(t1k_job *job, AlignedPlan &pl) {
 }
 
 static bool writeAligned(t1k_job *job, const AlignedPlan &pl) {
-  const int fd = ::open(pl.path.c_str(), pl.create ? (O_WRONLY | O_CREAT | O_TRUNC) : O_WRONLY, 0644);
+  const int fd = ::open(pl.path.c_str(), pl.create ? (O_RDWR | O_CREAT | O_TRUNC) : O_WRONLY, 0644);
   if (fd < 0) { job->err = "cannot write " + pl.path; return false; }
-  const bool ok = alignedWrite(job, fd, pl.what, 0, (uint32_t)job->in->nFrag(), pl.T, pl.pieceBytes, pl.baseOffset);
+  const bool ok = alignedWrite(job, fd, pl.what, 0, (uint32_t)job->in->nFrag(), pl.T, pl.pieceBytes, pl.baseOffset, pl.create && mappedOutput());
   ::close(fd);
   if (!ok) { job->err = "cannot write " + pl.path; return false; }
   return true;
@@ -809,7 +839,7 @@ static bool streamOpen(t1k_job *job, const std::string &pfx) {
   job->stream.clear();
   auto add = [&](const std::string &path, int what) {
     t1k_job::StreamOut o; o.path = path; o.what = what;
-    o.fd = ::open(path.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+    o.fd = ::open(path.c_str(), O_RDWR | O_CREAT | O_TRUNC, 0644);
     job->stream.push_back(o);
     return o.fd >= 0;
   };
@@ -836,7 +866,7 @@ static bool streamAppend(t1k_job *job, uint32_t fLo, uint32_t fHi, bool besideLo
     auto &o = job->stream[i];
     std::vector<uint64_t> pieceBytes;
     alignedSizes(job, o.what, fLo, fHi, T, pieceBytes);
-    ok[i] = alignedWrite(job, o.fd, o.what, fLo, fHi, T, pieceBytes, o.offset) ? 1 : 0;
+    ok[i] = alignedWrite(job, o.fd, o.what, fLo, fHi, T, pieceBytes, o.offset, !besideLoop && mappedOutput()) ? 1 : 0;
     o.offset += pieceBytes[T];
   };
   std::vector<std::thread> th;

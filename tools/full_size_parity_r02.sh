@@ -5,7 +5,7 @@
 #   B. BASELINE configs[2]: 10 M 2x150 pairs vs the KIR-like dna reference, --preset kir-wgs = -s 0.9 --relaxIntronAlign (run-t1k:300-304)
 cd "$(dirname "$0")/.."
 W=/tmp/t1k_fs; mkdir -p $W gpurun_out
-L=gpurun_out/r02_full_size_parity.log; : > $L
+L=gpurun_out/r02_full_size_parity${PARTS:+_$PARTS}.log; : > $L
 say() { echo "$@" | tee -a $L; }
 cmpall() { for s in _genotype.tsv _allele.tsv _aligned_1.fa _aligned_2.fa; do if cmp -s $1$s $2$s; then say "   $s IDENTICAL ($(stat -c %s $1$s) bytes)"; else say "   $s DIFFERS"; fi; done; }
 tools/t1k_synth ref-rna --genes 24 --scale 1.0 --seed 20250614 > $W/hla.fa
@@ -19,6 +19,7 @@ say "  1 GPU vs reference:"; cmpall $W/ours $W/ref
 say "  2 ranks vs reference:"; cmpall $W/ours2 $W/ref
 say "  3 ranks with their own input vs reference:"; cmpall $W/ours3 $W/ref
 say "  EM iterations: ours $(grep -o 'in [0-9]* EM' $W/ours.log) / sharded $(grep -o 'in [0-9]* EM' $W/ours2.log) / reference $(grep -o 'in [0-9]* EM' $W/ref.log)"
+[ "$PARTS" = "A" ] && exit 0
 tools/t1k_synth ref-dna --genes 17 --scale 1.0 --seed 20250614 > $W/kir.fa
 tools/t1k_synth reads --ref $W/kir.fa --pairs 10000000 --len 150 --seed 3 --out $W/k
 say "B. 10 M pairs, KIR-like dna ($(grep -c '>' $W/kir.fa) alleles), -s 0.9 --relaxIntronAlign (kir-wgs)"
