@@ -1,8 +1,9 @@
 // oracle/oracle_cli.cpp -- TEST INFRASTRUCTURE ONLY.
 // Command-line driver around the CPU restatement, following the order of operations of the reference's
-// genotyper main() (Genotyper.cpp:194-738) up to and including the EM, and dumping every intermediate the
+// genotyper main() (Genotyper.cpp:194-738) through the EM, the pruning, the selection and the two tables, and dumping every intermediate the
 // parity tests compare: <o>_assign.tsv (same format as the reference's --outputReadAssignment, Genotyper.cpp:555-562),
-// <o>_overlaps.tsv (per read-end overlap lists), <o>_groups.tsv, <o>_em.tsv, <o>_cov.tsv, <o>_stats.json.
+// <o>_overlaps.tsv (per read-end overlap lists), <o>_groups.tsv, <o>_em.tsv, <o>_cov.tsv, <o>_stats.json, and the reference's own
+// <o>_genotype.tsv / <o>_allele.tsv.
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
@@ -16,7 +17,7 @@
 using namespace t1k_oracle;
 
 int main(int argc, char **argv) {
-  std::string ref, f1, f2, out = "oracle";
+  std::string ref, f1, f2, fbc, out = "oracle";
   Oracle orc;
   bool dumpOverlaps = false, noEM = false;
   for (int i = 1; i < argc; ++i) {
@@ -34,9 +35,11 @@ int main(int argc, char **argv) {
     else if (a == "--alleleDigitUnits") orc.prm.alleleDigitUnits = atoi(next().c_str());
     else if (a == "--alleleDelimiter") orc.prm.alleleDelimiter = next()[0];
     else if (a == "--squaremMinAlpha") orc.prm.minSquaremAlpha = atof(next().c_str());
+    else if (a == "--barcode") fbc = next();
     else if (a == "--dumpOverlaps") dumpOverlaps = true;
     else if (a == "--noEM") noEM = true;
-    else if (a == "--cov" || a == "--crossGeneRate") next();
+    else if (a == "--cov") orc.prm.filterCov = atof(next().c_str());
+    else if (a == "--crossGeneRate") orc.prm.crossGeneRate = atof(next().c_str());
     else if (a == "--outputReadAssignment") {}
     else { fprintf(stderr, "unknown option %s\n", a.c_str()); return 1; }
   }
@@ -46,6 +49,18 @@ int main(int argc, char **argv) {
   if (!readAllRecords(f1, r1)) { fprintf(stderr, "cannot read %s\n", f1.c_str()); return 1; }
   bool hasMate = !f2.empty();
   if (hasMate && !readAllRecords(f2, r2)) { fprintf(stderr, "cannot read %s\n", f2.c_str()); return 1; }
+  if (!fbc.empty()) {  // fragments without a barcode are not loaded at all (Genotyper.cpp:372-381); the barcode itself plays no part in the assignment
+    std::vector<SeqRecord> bc;
+    if (!readAllRecords(fbc, bc) || bc.size() != r1.size()) { fprintf(stderr, "cannot read %s\n", fbc.c_str()); return 1; }
+    size_t kept = 0;
+    for (size_t i = 0; i < r1.size(); ++i) {
+      if (bc[i].seq == "missing_barcode") continue;
+      if (kept != i) { r1[kept] = r1[i]; if (hasMate) r2[kept] = r2[i]; }
+      ++kept;
+    }
+    r1.resize(kept);
+    if (hasMate) r2.resize(kept);
+  }
   size_t F = r1.size();
   auto t0 = std::chrono::steady_clock::now();
   // concat mates, sort by sequence, one AssignRead per distinct sequence with weight = multiplicity (Genotyper.cpp:451-480)
@@ -121,6 +136,17 @@ int main(int argc, char **argv) {
     FILE *fb = fopen((out + "_abundance.tsv").c_str(), "w");
     for (auto &a : orc.alleles) fprintf(fb, "%s\t%.17g\t%.17g\n", a.name.c_str(), a.abundance, a.ecAbundance);
     fclose(fb);
+    // pruning, selection and the two tables, as main() goes on after the EM (Genotyper.cpp:647-676)
+    for (auto &r : r1) orc.readLength = std::max(orc.readLength, (int)r.seq.size());  // maxReadLength (Genotyper.cpp:412-443)
+    for (auto &r : r2) orc.readLength = std::max(orc.readLength, (int)r.seq.size());
+    orc.removeLowLikelihoodAlleles();
+    orc.selectAllelesForGenes();
+    FILE *fgt = fopen((out + "_genotype.tsv").c_str(), "w");
+    fputs(orc.genotypeText().c_str(), fgt);
+    fclose(fgt);
+    FILE *fat = fopen((out + "_allele.tsv").c_str(), "w");
+    fputs(orc.alleleText().c_str(), fat);
+    fclose(fat);
   }
   auto t3 = std::chrono::steady_clock::now();
   auto sec = [](auto a, auto b) { return std::chrono::duration<double>(b - a).count(); };

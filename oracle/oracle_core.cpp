@@ -1054,9 +1054,406 @@ int Oracle::quantify(std::vector<double> *trajectory) {
     }
   }
   setAlleleAbundance(n, majorAbund, geneMax);
+  majorAlleleAbundance = majorAbund;
+  geneMaxMajorAlleleAbundance = geneMax;
   ecReadCountFinal = n;
   ecAbundanceFinal = x0;
   return ret;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// After the EM: likelihood pruning inside the classes, allele selection, genotype quality, the two tables
+// (SURVEY 8a rows 20-22).  Sequential restatements; read groups play the role of the reference's "reads".
+// ------------------------------------------------------------------------------------------------------------------
+
+// InitAlleleInfo, Genotyper.hpp:597-638: per gene the 31-mer profile (KmerCount.hpp:53-81: canonical codes, a window holding an N
+// is skipped) of its lexicographically smallest consensus; similarity[i][j] = share of i's k-mer occurrences whose k-mer also
+// occurs in j (KmerCount::GetCountSimilarity, KmerCount.hpp:196-216: not symmetric)
+void Oracle::computeGeneSimilarity() {
+  const int G = (int)geneNames.size(), K = 31;
+  std::vector<std::map<uint64_t, int>> profile(G);
+  for (int g = 0; g < G; ++g) {
+    int pick = -1;
+    for (int a = 0; a < (int)alleles.size(); ++a)
+      if (alleles[a].gene == g && (pick == -1 || strcmp(alleles[a].seq.c_str(), alleles[pick].seq.c_str()) < 0)) pick = a;
+    if (pick < 0) continue;
+    const std::string &q = alleles[pick].seq;
+    if ((int)q.size() < K) continue;
+    const uint64_t mask = (1ull << (2 * K)) - 1;
+    uint64_t code = 0;
+    int sinceN = K;  // positions since the last N, saturating: the window is clean when >= K
+    for (int i = 0; i < (int)q.size(); ++i) {
+      code = ((code << 2) & mask) | (uint64_t)(baseCode(q[i]) & 3);
+      sinceN = q[i] == 'N' ? 0 : std::min(sinceN + 1, K);
+      if (i < K - 1 || sinceN < K) continue;
+      uint64_t rc = 0;
+      for (int b = 0; b < K; ++b) rc = (rc << 2) | (3ull - ((code >> (2 * b)) & 3ull));  // KmerCode::GetCanonicalKmerCode
+      ++profile[g][rc < code ? rc : code];
+    }
+  }
+  geneSimilarity.assign(G, std::vector<double>(G, 0.0));
+  for (int i = 0; i < G; ++i)
+    for (int j = 0; j < G; ++j) {
+      if (i == j) { geneSimilarity[i][j] = 1.0; continue; }
+      int total = 0, shared = 0;
+      for (auto &kv : profile[i]) {
+        total += kv.second;
+        if (profile[j].count(kv.first)) shared += kv.second;
+      }
+      geneSimilarity[i][j] = (double)shared / (double)total;  // 0/0 = NaN for an empty profile, as in the reference
+    }
+}
+
+void Oracle::removeLowLikelihoodAlleles() {
+  for (auto &members : ecAlleles) {
+    const int size = (int)members.size();
+    if (size == 0) continue;
+    std::vector<int> lo(size), hi(size, -1);
+    std::map<int, int> slotOf;
+    for (int j = 0; j < size; ++j) { lo[j] = (int)alleles[members[j]].seq.size(); slotOf[members[j]] = j; }
+    // the groups of the class representative, and in each of them the entries of the class members (1398-1416)
+    for (int g : groupsInAllele[members[0]])
+      for (const RowEntry &e : groups[g]) {
+        auto it = slotOf.find(e.alleleIdx);
+        if (it == slotOf.end()) continue;
+        if (e.start < lo[it->second]) lo[it->second] = e.start;
+        if (e.end > hi[it->second]) hi[it->second] = e.end;
+      }
+    std::vector<double> ll(size);
+    double best = -1;
+    for (int j = 0; j < size; ++j) {
+      const int len = (int)alleles[members[j]].seq.size();
+      int span = hi[j] - lo[j] + 1;
+      if (span > len) span = len;
+      ll[j] = pow((double)span / len, alleles[members[j]].ecAbundance);
+      if (ll[j] > best) best = ll[j];
+    }
+    std::vector<int> kept;
+    for (int j = 0; j < size; ++j)
+      if (ll[j] / best >= 0.05 || ll[j] == best) kept.push_back(members[j]);
+    members = kept;
+  }
+}
+
+int Oracle::geneAlleleTypes(int gene) const {
+  if (selectedAlleles[gene].empty()) return 0;
+  int top = 0;
+  for (auto &s : selectedAlleles[gene]) top = std::max(top, s.second);
+  return top + 1;
+}
+
+// upper / lower tail of the standard normal distribution: Hill, Algorithm AS 66, Applied Statistics 22(3) 1973, 424-427 -- the
+// routine the reference carries as alnorm (Genotyper.hpp:252-370)
+static double normalIntegralAS66(double x, bool upper) {
+  const double ltone = 7.0, utzero = 18.66, con = 1.28;
+  bool up = upper;
+  double z = x;
+  if (z < 0.0) { up = !up; z = -z; }
+  if (ltone < z && (!up || utzero < z)) return up ? 0.0 : 1.0;
+  const double y = 0.5 * z * z;
+  double value;
+  if (z <= con)
+    value = 0.5 - z * (0.398942280444 - 0.39990348504 * y / (y + 5.75885480458 + -29.8213557807 / (y + 2.62433121679 + 48.6959930692 / (y + 5.92885724438))));
+  else
+    value = 0.398942280385 * exp(-y) /
+            (z + -0.000000038052 +
+             1.00000615302 / (z + 0.000398064794 + 1.98615381364 / (z + -0.151679116635 + 5.29330324926 / (z + 4.8385912808 + -15.1508972451 / (z + 0.742380924027 + 30.789933034 / (z + 3.99019417011))))));
+  return up ? value : 1.0 - value;
+}
+
+void Oracle::selectAllelesForGenes() {
+  const int nGenes = (int)geneNames.size(), nGroups = (int)groups.size(), nEc = (int)ecAlleles.size();
+  const double frac = prm.filterFrac;
+  if (geneSimilarity.empty()) computeGeneSimilarity();
+  for (auto &a : alleles) { a.genotypeQuality = -1; a.alleleRank = -1; }
+  selectedAlleles.assign(nGenes, {});
+  std::vector<char> covered(nGroups, 0);
+  auto optimal = [&](int allele, int r) { return groups[groupsInAllele[allele][r]][slotInAllele[allele][r]].qual == 1; };  // IsReadsInAlleleIdxOptimal (198-203)
+  auto weak = [&](int a) {  // the abundance filter of 1568-1570, applied again at 1656-1658
+    const AlleleRec &m = alleles[a];
+    return m.ecAbundance < frac * geneMaxMajorAlleleAbundance[m.gene] &&
+           (m.ecAbundance * 3 >= majorAlleleAbundance[m.majorAllele] || majorAlleleAbundance[m.majorAllele] < 3 * frac * geneMaxMajorAlleleAbundance[m.gene]);
+  };
+  // classes by abundance, descending; ties by class id (CompSortPairIntDoubleBDec)
+  std::vector<std::pair<int, double>> order;
+  for (int e = 0; e < nEc; ++e) order.push_back({e, alleles[ecAlleles[e][0]].ecAbundance});
+  std::sort(order.begin(), order.end(), [](const std::pair<int, double> &p, const std::pair<int, double> &q) { return p.second != q.second ? q.second < p.second : p.first < q.first; });
+  std::vector<int> filtered;
+  for (int i = 0; i < nEc; ++i) {
+    const std::vector<int> &members = ecAlleles[order[i].first];
+    const int lead = members[0];
+    if (alleles[lead].ecAbundance <= 1e-6) break;
+    double coveredWeight = 0, totalWeight = 0;  // of the lead's groups: first-entry weights (1529-1539)
+    const int nLead = (int)groupsInAllele[lead].size();
+    for (int r = 0; r < nLead; ++r) {
+      if (!optimal(lead, r)) continue;
+      const int g = groupsInAllele[lead][r];
+      const double w = groups[g][0].weight;
+      if (covered[g]) coveredWeight += w;
+      totalWeight += w;
+    }
+    std::vector<int> genesToAdd, toAdd;
+    for (int a : members) {
+      const AlleleRec &m = alleles[a];
+      bool filter = weak(a);
+      if (coveredWeight == totalWeight &&
+          (m.ecAbundance < 0.25 * geneMaxMajorAlleleAbundance[m.gene] || selectedAlleles[m.gene].empty() ||
+           m.ecAbundance < 0.5 * alleles[selectedAlleles[m.gene].back().first].ecAbundance))
+        filter = true;
+      if (filter) { filtered.push_back(a); continue; }
+      if (std::find(genesToAdd.begin(), genesToAdd.end(), m.gene) == genesToAdd.end()) genesToAdd.push_back(m.gene);
+      toAdd.push_back(a);
+    }
+    const int quality = genesToAdd.size() > 1 ? 0 : 60;
+    if (!genesToAdd.empty())
+      for (int r = 0; r < nLead; ++r)
+        if (optimal(lead, r)) covered[groupsInAllele[lead][r]] = 1;
+    std::map<int, int> newRankOfGene;
+    for (int a : toAdd) {
+      AlleleRec &m = alleles[a];
+      int rank = -1;
+      for (auto &s : selectedAlleles[m.gene])
+        if (alleles[s.first].majorAllele == m.majorAllele) { rank = s.second; break; }
+      if (rank == -1) {
+        auto it = newRankOfGene.find(m.gene);
+        if (it != newRankOfGene.end()) rank = it->second;
+        else { rank = geneAlleleTypes(m.gene); newRankOfGene[m.gene] = rank; }
+      }
+      m.genotypeQuality = weak(a) ? 0 : quality;
+      m.alleleRank = rank;
+      selectedAlleles[m.gene].push_back({a, rank});
+    }
+  }
+  // filtered alleles whose major allele was selected after all join it (1669-1695)
+  for (int a : filtered) {
+    const AlleleRec &m = alleles[a];
+    int rank = -1;
+    for (auto &s : selectedAlleles[m.gene])
+      if (alleles[s.first].majorAllele == m.majorAllele) { rank = s.second; break; }
+    if (rank != -1) selectedAlleles[m.gene].push_back({a, rank});
+  }
+  // genes with more than two allele types: the pair of types that explains the most groups not explained elsewhere (1697-1996)
+  std::vector<int> use(nGroups, 0);
+  auto countTopTwo = [&](int gene, std::map<int, int> &usedEc, int delta) {
+    for (auto &s : selectedAlleles[gene]) {
+      if (s.second > 1) continue;
+      if (usedEc.count(alleles[s.first].ec)) continue;
+      usedEc[alleles[s.first].ec] = 1;
+      for (int r = 0; r < (int)groupsInAllele[s.first].size(); ++r)
+        if (optimal(s.first, r)) use[groupsInAllele[s.first][r]] += delta;
+    }
+  };
+  {
+    std::map<int, int> usedEc;  // one map over all genes (1705-1729)
+    for (int g = 0; g < nGenes; ++g) countTopTwo(g, usedEc, +1);
+  }
+  std::vector<std::map<int, double>> missingWeight(nGenes);  // per gene: missing coverage -> largest type abundance with it (1733-1770)
+  for (int g = 0; g < nGenes; ++g) {
+    const int T = geneAlleleTypes(g);
+    std::vector<int> miss(T, -1);
+    std::vector<double> ab(T, 0.0);
+    for (auto &s : selectedAlleles[g]) {
+      ab[s.second] += alleles[s.first].abundance;
+      if (miss[s.second] == -1 || alleles[s.first].missingCoverage < miss[s.second]) miss[s.second] = alleles[s.first].missingCoverage;
+    }
+    for (int t = 0; t < T; ++t)
+      if (!missingWeight[g].count(miss[t]) || missingWeight[g][miss[t]] < ab[t]) missingWeight[g][miss[t]] = ab[t];
+  }
+  for (int iter = 0; iter < 1000; ++iter) {
+    int updated = 0;
+    for (int g = 0; g < nGenes; ++g) {
+      const int T = geneAlleleTypes(g);
+      if (T <= 2) continue;
+      std::vector<std::pair<int, int>> &sel = selectedAlleles[g];
+      const int S = (int)sel.size();
+      std::map<int, int> usedEc;
+      countTopTwo(g, usedEc, -1);
+      double maxCover = 0, maxCoverAbundance = 0;
+      std::vector<std::pair<int, int>> bestTypes;
+      int alleleJ = 0;
+      for (int j = 0; j < T - 1 && j <= 1; ++j) {
+        usedEc.clear();
+        std::map<int, int> fromJ;
+        for (int l = 0; l < S; ++l) {
+          if (sel[l].second != j) continue;
+          const int a = sel[l].first;
+          if (usedEc.count(alleles[a].ec)) continue;
+          usedEc[alleles[a].ec] = 1;
+          for (int r = 0; r < (int)groupsInAllele[a].size(); ++r)
+            if (use[groupsInAllele[a][r]] == 0 && optimal(a, r)) fromJ[groupsInAllele[a][r]] |= 1;
+          alleleJ = l;
+        }
+        for (int k = j + 1; k < T; ++k) {
+          std::map<int, int> cover = fromJ;
+          for (int l = 0; l < S; ++l) {  // usedEc is not cleared between the k's
+            if (sel[l].second != k) continue;
+            const int a = sel[l].first;
+            if (usedEc.count(alleles[a].ec)) continue;
+            usedEc[alleles[a].ec] = 1;
+            for (int r = 0; r < (int)groupsInAllele[a].size(); ++r)
+              if (use[groupsInAllele[a][r]] == 0 && optimal(a, r)) cover[groupsInAllele[a][r]] |= 2;
+          }
+          double abJ = 0, abK = 0;
+          int missJ = -1, missK = -1;
+          for (int l = 0; l < S; ++l) {
+            const AlleleRec &m = alleles[sel[l].first];
+            if (sel[l].second == j) { abJ += m.abundance; if (missJ == -1 || m.missingCoverage < missJ) missJ = m.missingCoverage; }
+            else if (sel[l].second == k) { abK += m.abundance; if (missK == -1 || m.missingCoverage < missK) missK = m.missingCoverage; }
+          }
+          const double product = abJ * abK;
+          double score = 0;
+          for (auto &kv : cover) score += groups[kv.first][0].adjustWeight;
+          if (T > 3 || missJ >= 10 || missK >= 10) {
+            double wJ = missingWeight[g][missJ], wK = missingWeight[g][missK];
+            if (T <= 3) {
+              if (wJ >= 1) wJ = log(wJ) / log(10.0);
+              if (wK >= 1) wK = log(wK) / log(10.0);
+            }
+            score = score - missJ * wJ * readLength / 150.0 - missK * wK * readLength / 150.0 + (alleles[sel[alleleJ].first].weight);
+          }
+          if (bestTypes.empty() || score > maxCover || (score == maxCover && product > maxCoverAbundance)) {
+            maxCover = score; maxCoverAbundance = product;
+            bestTypes.clear();
+            bestTypes.push_back({j, k});
+          } else if (score == maxCover) bestTypes.push_back({j, k});
+        }
+      }
+      const std::pair<int, int> best = bestTypes[0];
+      if (best.first != 0 || best.second != 1) {
+        ++updated;
+        for (auto &s : sel) {
+          int r;
+          if (s.second == best.first) r = 0;
+          else if (s.second == best.second) r = 1;
+          else if (s.second < best.first) r = s.second + 2;
+          else if (s.second < best.second) r = s.second + 1;
+          else continue;
+          s.second = r;
+          alleles[s.first].alleleRank = r;
+        }
+      }
+      usedEc.clear();
+      countTopTwo(g, usedEc, +1);
+    }
+    if (!updated) break;
+  }
+  // genotype quality (2010-2085)
+  std::vector<double> geneAbundance(nGenes, 0.0);
+  for (int g = 0; g < nGenes; ++g)
+    for (auto &s : selectedAlleles[g]) geneAbundance[g] += alleles[s.first].abundance;
+  const double crossAlleleRate = 0.01;
+  for (int g = 0; g < nGenes; ++g) {
+    const int T = geneAlleleTypes(g);
+    std::vector<double> rankAbundance(T, 0.0);
+    for (auto &s : selectedAlleles[g]) rankAbundance[s.second] += alleles[s.first].abundance;
+    double noise = 0;
+    for (int o = 0; o < nGenes; ++o)
+      if (o != g) noise += prm.crossGeneRate * geneSimilarity[o][g] * geneAbundance[o];
+    for (int t = 0; t < T; ++t) {
+      const double nullMean = (geneAbundance[g] - rankAbundance[t]) * crossAlleleRate + noise;
+      double score = 0;
+      if (rankAbundance[t]) score = -log(normalIntegralAS66(2 * (sqrt(rankAbundance[t]) - sqrt(nullMean)), true)) / log(double(10.0));
+      if (score > 60) score = 60;
+      if (score < 0) score = 0;
+      if (rankAbundance[t] < prm.filterCov) score = 0;
+      for (auto &s : selectedAlleles[g])
+        if (s.second == t && alleles[s.first].genotypeQuality > 0) alleles[s.first].genotypeQuality = (int)score;
+    }
+  }
+}
+
+// one line per gene: name, number of called alleles, allele 1, allele 2, further types
+std::string Oracle::genotypeText() const {
+  std::string out;
+  char num[64];
+  for (int g = 0; g < (int)geneNames.size(); ++g) {
+    std::vector<char> used(majorNames.size(), 0);
+    std::string field[3];
+    int called = 0, qualities[2] = {-1, -1};
+    const int T = std::max(2, geneAlleleTypes(g));
+    char sep = '\t';
+    for (int type = 0; type < T; ++type) {
+      std::string &buf = field[type > 1 ? 2 : type];
+      if (type > 1) sep = ';';
+      buf.clear();  // 2132: also for every type beyond the second, so the third column shows the last type only
+      double abundance = 0;
+      bool added = false;
+      int localQual = -1;
+      if (type == 1 && qualities[0] == 0) std::fill(used.begin(), used.end(), 0);
+      for (auto &s : selectedAlleles[g]) {
+        if (s.second != type) continue;
+        const AlleleRec &m = alleles[s.first];
+        abundance += m.abundance;
+        if (used[m.majorAllele]) continue;
+        localQual = m.genotypeQuality;
+        if (type <= 1) called = type + 1;
+        buf += (added ? "," : "") + majorNames[m.majorAllele];  // (the "|" branch of 2159-2160 needs a non-empty buffer: unreachable)
+        added = true;
+        used[m.majorAllele] = 1;
+      }
+      if (localQual >= 0) { snprintf(num, sizeof num, "%c%lf%c%d", sep, abundance, sep, localQual); buf += num; }
+      else if (type <= 1) buf += ".\t0\t-1";
+      if (type <= 1) qualities[type] = localQual;
+    }
+    snprintf(num, sizeof num, "\t%d", called);
+    out += geneNames[g] + num + "\t" + field[0] + "\t" + field[1] + "\t" + field[2] + "\n";
+  }
+  return out;
+}
+
+void Oracle::parseAlleleNameExon(const std::string &allele, std::string &gene, std::string &major) const {
+  // Genotyper::ParseAlleleName (Genotyper.hpp:63-131) with fieldsType = 1: five digits without a delimiter, three fields with one
+  int parseType = 1, fields = prm.alleleDigitUnits;
+  char delim = 0;
+  if (fields == -1) {
+    if (allele.find(':') != std::string::npos) { delim = ':'; parseType = 2; }
+    fields = parseType == 1 ? 5 : 3;
+  }
+  if (prm.alleleDelimiter != 0) { delim = prm.alleleDelimiter; parseType = 2; }
+  const size_t star = allele.find('*');
+  const size_t i = star == std::string::npos ? allele.size() : star;
+  gene = allele.substr(0, i);
+  if (parseType == 1) {
+    size_t j = 0;
+    while ((int)j <= fields && i + j < allele.size()) ++j;
+    major = allele.substr(0, i + j);
+  } else {
+    int k = 0;
+    size_t j = i;
+    for (; j < allele.size(); ++j)
+      if (allele[j] == delim) { ++k; if (k >= fields) break; }
+    major = allele.substr(0, j);
+  }
+}
+
+// per gene up to two representative alleles "name quality"
+std::string Oracle::alleleText() const {
+  std::string out;
+  for (int g = 0; g < (int)geneNames.size(); ++g) {
+    int rep[2] = {-1, -1};
+    for (auto &s : selectedAlleles[g]) {
+      const int tag = s.second, a = s.first;
+      if (tag > 1 || alleles[a].genotypeQuality < 1) continue;
+      if (rep[tag] == -1 || alleles[rep[tag]].ecAbundance < alleles[a].ecAbundance || (alleles[rep[tag]].ecAbundance == alleles[a].ecAbundance && rep[tag] > a)) rep[tag] = a;
+    }
+    if (rep[1] == -1 && rep[0] != -1) {  // two alleles of one major allele: the strongest other class of type 0 that differs in the exons (2200-2222)
+      double top = -1;
+      int pick = -1;
+      for (auto &s : selectedAlleles[g]) {
+        const int a = s.first;
+        if (s.second != 0 || alleles[a].ec == alleles[rep[0]].ec) continue;
+        std::string gA, xA, gB, xB;
+        parseAlleleNameExon(alleles[a].name, gA, xA);
+        parseAlleleNameExon(alleles[rep[0]].name, gB, xB);
+        if (xA == xB) continue;
+        if (alleles[a].ecAbundance > top || (alleles[a].ecAbundance == top && a < pick)) { top = alleles[a].ecAbundance; pick = a; }
+      }
+      if (top != -1) rep[1] = pick;
+    }
+    for (int j = 0; j < 2; ++j)
+      if (rep[j] != -1) out += alleles[rep[j]].name + " " + std::to_string(alleles[rep[j]].genotypeQuality) + "\n";
+  }
+  return out;
 }
 
 }  // namespace t1k_oracle

@@ -1,14 +1,16 @@
 // oracle/oracle_core.hpp
 //
-// TEST INFRASTRUCTURE ONLY.  CPU restatement of the T1K genotyper hot path,
+// TEST INFRASTRUCTURE ONLY.  CPU restatement of the T1K genotyper hot path (assignment through the EM,
+// likelihood pruning, allele selection, genotype quality and the two result tables),
 // written from the reference's behaviour, one function per reference routine, each citing the reference
 // file:line it follows (paths relative to /root/reference).  Only tests/, __graft_entry__.smoke() and
 // bench.py's cpu_baseline leg may use this code -- and only as the checker.  The product
 // (t1k_amd/csrc) never includes, links or executes anything under oracle/.
 //
-// Parity status: PINNED.  The restatement is checked (tests/test_oracle_vs_ref.py, tests/golden/) against
+// Parity status: PINNED.  The restatement is checked (tests/test_oracle_golden.py, tests/golden/) against
 // outputs of the reference itself: oracle/_ref/genotyper built by oracle/Makefile from the reference's own
-// sources (--outputReadAssignment rows, -DDEBUG EM trajectories, *_genotype.tsv), and against GlobalAlignment
+// sources (--outputReadAssignment rows, -DDEBUG EM trajectories, *_genotype.tsv and *_allele.tsv byte for byte,
+// fixtures and live runs with the selection options), and against GlobalAlignment
 // I/O vectors captured from the reference.  The reference repository has no tests of its own.
 #pragma once
 #include <cstdint>
@@ -56,6 +58,7 @@ struct AlleleRec {
   int missingCoverage = 0;
   int ec = -1;
   double abundance = 0, ecAbundance = 0;
+  int genotypeQuality = -1, alleleRank = -1;  // Genotyper.hpp:590-593
 };
 
 struct Params {
@@ -67,6 +70,7 @@ struct Params {
   int alleleDigitUnits = -1;
   char alleleDelimiter = 0;
   double minSquaremAlpha = 0;
+  double filterCov = 1.0, crossGeneRate = 0.04;  // --cov, --crossGeneRate (Genotyper.cpp:223-224)
   int nBaseCode = 3;  // bits an N contributes to a k-mer code: nucToNum['N'] & 3 = 3 in Genotyper.cpp:37-40, 0 in FastqExtractor.cpp:51-54
 };
 
@@ -104,6 +108,18 @@ class Oracle {
   int quantify(std::vector<double> *trajectory = nullptr);  // QuantifyAlleleEquivalentClass (1142-1328); returns #iterations
   std::vector<double> ecReadCountFinal, ecAbundanceFinal;
   std::vector<int> ecLength;
+  // ---- after the EM: pruning, selection, the two tables ----
+  std::vector<double> majorAlleleAbundance, geneMaxMajorAlleleAbundance;  // as SetAlleleAbundance left them (1012-1050)
+  std::vector<std::vector<double>> geneSimilarity;                        // InitAlleleInfo (597-638)
+  int readLength = 0;                                                     // SetReadLength(maxReadLength), Genotyper.cpp:443
+  std::vector<std::vector<std::pair<int, int>>> selectedAlleles;          // per gene: (allele, rank)
+  void computeGeneSimilarity();
+  void removeLowLikelihoodAlleles();  // RemoveLowLikelihoodAlleleInEquivalentClass (1371-1460)
+  void selectAllelesForGenes();       // SelectAllelesForGenes (1462-2090)
+  int geneAlleleTypes(int gene) const;  // GetGeneAlleleTypes (1053-1068)
+  std::string genotypeText() const;   // GetAlleleDescription (2103-2178) + the loop of Genotyper.cpp:660-670
+  std::string alleleText() const;     // OutputRepresentativeAlleles (2180-2229)
+  void parseAlleleNameExon(const std::string &allele, std::string &gene, std::string &major) const;  // ParseAlleleName with fieldsType = 1
 
   // ---- candidate extraction (oracle_extract.cpp) ----
   int loadReferenceFa(const std::string &fasta);   // SeqSet::InputRefFa (SeqSet.hpp:872-904): one sequence per record, no merging

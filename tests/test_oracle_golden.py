@@ -26,15 +26,17 @@ def test_global_alignment_golden_vectors(built):
 
 @pytest.mark.parametrize("name", goldens.CASES)
 def test_oracle_pipeline_matches_reference_outputs(built, tmp_path, name):
-    """read-end assignment + pairing + rows (_assign.tsv), fragmentAssigned ids, EM iteration count and the last EM
-    iteration's per-class read counts / abundances must equal what the reference printed for the same inputs."""
+    """read-end assignment + pairing + rows (_assign.tsv), fragmentAssigned ids, EM iteration count, the last EM
+    iteration's per-class read counts / abundances and the final _genotype.tsv / _allele.tsv must equal what the reference
+    printed for the same inputs."""
     c = goldens.Case(name, str(tmp_path))
     out = os.path.join(str(tmp_path), "orc")
-    flags = [f for f in c.flags]
-    r = subprocess.run([util.ORACLE_CLI] + c.args(with_barcode=False)[:2] + (["-1", c.r1, "-2", c.r2] if c.paired else ["-u", c.r1]) + flags + ["-o", out],
-                       stderr=subprocess.PIPE, text=True)
+    r = subprocess.run([util.ORACLE_CLI] + c.args() + ["-o", out], stderr=subprocess.PIPE, text=True)  # (--barcode: fragments without one are not loaded)
     assert r.returncode == 0, r.stderr
-    if c.bc is None:  # with barcodes the reference drops missing_barcode fragments first; covered by the GPU end-to-end test
+    # SURVEY 8a rows 20-22: likelihood pruning, selection, genotype quality and the writers -- the two tables, byte for byte
+    assert open(out + "_genotype.tsv").read() == c.expected("genotype.tsv")
+    assert open(out + "_allele.tsv").read() == c.expected("allele.tsv")
+    if True:
         assert open(out + "_assign.tsv").read() == c.expected("assign.tsv.gz")
         assert open(out + "_aligned_ids.txt").read().split() == c.expected("aligned_ids.txt.gz").split()
         it = int(open(out + "_em.tsv").readline().split()[1])
@@ -62,3 +64,36 @@ def test_oracle_vs_live_reference_binary(built, tmp_path):
     subprocess.run([util.REF_BIN] + args + ["-o", os.path.join(tmp, "a"), "--outputReadAssignment", "-t", "1"], check=True, stderr=subprocess.PIPE)
     subprocess.run([util.ORACLE_CLI] + args + ["-o", os.path.join(tmp, "b")], check=True, stderr=subprocess.PIPE)
     assert open(os.path.join(tmp, "a_assign.tsv")).read() == open(os.path.join(tmp, "b_assign.tsv")).read()
+
+
+LIVE_TABLE_CASES = [  # (kind, genes, scale, read sets mixed into one sample, read length, flags): mixtures give genes more than two allele types
+    ("ref-rna", 5, 0.02, 3, 150, ["-s", "0.9", "--crossGeneRate", "1.0"]),
+    ("ref-rna", 4, 0.04, 3, 100, ["-s", "0.95", "--frac", "0.3", "--crossGeneRate", "0"]),
+    ("ref-rna", 3, 0.02, 2, 150, ["-s", "0.9", "--frac", "0.05"]),
+    ("ref-dna", 4, 0.02, 2, 150, ["-s", "0.95", "--relaxIntronAlign", "--cov", "3"]),
+    ("ref-dna", 3, 0.02, 1, 75, ["-s", "0.8", "--squaremMinAlpha", "-2"]),
+    ("ref-rna", 6, 0.01, 3, 150, ["-s", "0.97", "--cov", "20", "--frac", "0.5"]),
+]
+
+
+@pytest.mark.parametrize("case", range(len(LIVE_TABLE_CASES)))
+def test_oracle_tables_vs_live_reference_binary(built, tmp_path, case):
+    """pruning + selection + quality + writers of the oracle against the reference binary on fresh inputs, options included;
+    samples mixed from several simulated individuals so that genes carry three and more allele types (the type-pair search,
+    Genotyper.hpp:1697-1996)."""
+    util.need(util.REF_BIN)
+    kind, genes, scale, parts, length, flags = LIVE_TABLE_CASES[case]
+    tmp = str(tmp_path)
+    ref = os.path.join(tmp, "ref.fa")
+    util.synth_ref(kind, ref, genes=genes, scale=scale, seed=900 + case)
+    for p in range(parts):
+        util.synth_reads(ref, os.path.join(tmp, "p%d" % p), pairs=120 + 40 * case, len=length, seed=1000 + 10 * case + p, sub=0.004)
+    for m in ("1", "2"):
+        with open(os.path.join(tmp, "r_%s.fq" % m), "w") as o:
+            for p in range(parts):
+                o.write(open(os.path.join(tmp, "p%d_%s.fq" % (p, m))).read())
+    args = ["-f", ref, "-1", os.path.join(tmp, "r_1.fq"), "-2", os.path.join(tmp, "r_2.fq")] + flags
+    subprocess.run([util.REF_BIN] + args + ["-o", os.path.join(tmp, "a"), "-t", "1"], check=True, stderr=subprocess.PIPE, stdout=subprocess.PIPE)
+    subprocess.run([util.ORACLE_CLI] + args + ["-o", os.path.join(tmp, "b")], check=True, stderr=subprocess.PIPE)
+    for what in ("_genotype.tsv", "_allele.tsv"):
+        assert open(os.path.join(tmp, "a" + what)).read() == open(os.path.join(tmp, "b" + what)).read(), what
