@@ -57,6 +57,28 @@ def ensure_inputs(workdir, pairs, genes, scale, seed):
     return ref, pfx
 
 
+def distinct_input_files(workdir, pairs, world, genes=24, scale=1.0, free_bytes=None):
+    """how many of the `world` read sets fit the scratch disk beside the output files (all of them, normally)"""
+    if world <= 1:
+        return 1
+    try:
+        per_set = pairs * (2 * (2 * READ_LEN + 32) + 48)          # two FASTQ files + the generator's truth table
+        outputs = world * pairs * 2 * (READ_LEN + 20)             # the two aligned-read FASTA files of the whole job
+        have = 0
+        for i in range(world):                                    # sets that exist already cost nothing more
+            pfx = os.path.join(workdir, "reads_g%d_s%s_p%d_seed%d" % (genes, scale, pairs, 2 + i))
+            have += os.path.exists(pfx + "_2.fq")
+        if free_bytes is None:
+            os.makedirs(workdir, exist_ok=True)
+            import shutil
+            free_bytes = shutil.disk_usage(workdir).free
+        room = free_bytes - outputs - (4 << 30)
+        k = have + max(0, int(room // per_set)) if room > 0 else have
+        return max(1, min(world, k))
+    except Exception:
+        return world
+
+
 def head_fastq(src, dst, n):
     with open(src) as f, open(dst, "w") as g:
         for i, line in enumerate(f):
@@ -141,13 +163,17 @@ def main():
     # File i is the same for every world size (seed 2 + i), so the N = 1 input is the first file of the N = 8 input; each rank
     # generates one of the files.
     total_pairs = a.pairs * world
+    # The scratch disk has to hold `world` read sets and the job's aligned-read files (80 GB at 8 x 10 M pairs).  Where it cannot,
+    # the first k read sets are given several times (rank r reads set r mod k) and the line says so in config.distinct_input_files.
+    distinct = distinct_input_files(a.workdir, a.pairs, world, a.genes, a.scale)
     if rank == 0:
         ensure_inputs(a.workdir, a.pairs, a.genes, a.scale, seed=2)   # (also writes the reference)
     if dist is not None:
         dist.barrier()
-        ensure_inputs(a.workdir, a.pairs, a.genes, a.scale, seed=2 + rank)
+        if rank < distinct:
+            ensure_inputs(a.workdir, a.pairs, a.genes, a.scale, seed=2 + rank)
         dist.barrier()
-    parts = [ensure_inputs(a.workdir, a.pairs, a.genes, a.scale, seed=2 + i) for i in range(world)]
+    parts = [ensure_inputs(a.workdir, a.pairs, a.genes, a.scale, seed=2 + i % distinct) for i in range(world)]
     ref, pfx = parts[0]
     files1, files2 = [p_[1] + "_1.fq" for p_ in parts], [p_[1] + "_2.fq" for p_ in parts]
     out_prefix = os.path.join(a.workdir, "out")
@@ -229,6 +255,7 @@ def main():
                        "parallelism": ("one sample of %d pairs sharded over %d GPUs by contiguous fragment slices (%d per GPU); RCCL inside libt1k_gpu.so: int32 all-reduce of the coverage arrays, "
                                        "all-to-all of fragment rows to their pattern owners, all-gather of group tables, f64 all-reduce of the contribution array in every EM update; "
                                        "communicator created once outside the steps" % (total_pairs, world, a.pairs)) if world > 1 else "1 GPU",
+                       "distinct_input_files": distinct,  # of n_gpus read sets; fewer only where the scratch disk cannot hold them all
                        "arithmetic": "2-bit packed bases in u64 words, int32 alignment scores, f32 read-group weights, f64 EM",
                        "read_ends": st["read_ends_total"], "distinct_read_ends": st["read_ends"],
                        "groups": counts["groups"], "equivalence_classes": counts["ecs"], "em_iterations": counts["em_iterations"],

@@ -77,3 +77,17 @@ def test_reference_loader_merges_identical_sequences(built, tmp_path):
     names, seqs, masks, w = t1k_amd.load_reference_fasta(str(p))
     assert names == ["A*01", "A*03"] and w == [2, 1]
     assert masks[0].tolist() == [1, 1, 1, 1, 0, 0, 1, 1, 1, 1] and masks[1].tolist() == [1] * 10
+
+
+def test_bench_input_plan_respects_scratch_disk(tmp_path):
+    """bench.py at N > 1: every rank gets its own read set when the scratch disk holds them beside the output files, else the
+    first k sets are reused (and the JSON line says how many were distinct); N = 1 is never touched."""
+    import bench
+    G = 1 << 30
+    d = str(tmp_path)
+    assert bench.distinct_input_files(d, 10_000_000, 1, free_bytes=1 * G) == 1
+    assert bench.distinct_input_files(d, 10_000_000, 8, free_bytes=500 * G) == 8
+    assert bench.distinct_input_files(d, 10_000_000, 4, free_bytes=71 * G) == 4
+    k = bench.distinct_input_files(d, 10_000_000, 8, free_bytes=71 * G)
+    assert 1 <= k < 8
+    assert bench.distinct_input_files(d, 10_000_000, 8, free_bytes=5 * G) == 1
