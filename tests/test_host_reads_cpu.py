@@ -1,0 +1,79 @@
+"""CPU tests of the host side's read-file index (t1k_amd/csrc/host/reads.cpp, plain C++): the index a single process builds over
+the whole input against the indexes N process ranks build over their own fragments only (ReadInput::openSharded: newline counts
+per MiB block all-gathered, every rank cuts records in its own slice).  The ranks run as threads of a small harness
+(tests/harness/reads_shard_harness.cpp, built with g++ here); the GPU suite covers the same path end to end."""
+import os
+import subprocess
+
+import pytest
+
+import util
+
+HARNESS_SRC = os.path.join(util.ROOT, "tests", "harness", "reads_shard_harness.cpp")
+HOST = os.path.join(util.ROOT, "t1k_amd", "csrc", "host")
+
+
+@pytest.fixture(scope="module")
+def harness(tmp_path_factory):
+    exe = str(tmp_path_factory.mktemp("harness") / "reads_shard_harness")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-o", exe, HARNESS_SRC, os.path.join(HOST, "reads.cpp"), os.path.join(HOST, "refset.cpp"), "-lz", "-lpthread"],
+                   check=True)
+    return exe
+
+
+@pytest.fixture(scope="module")
+def read_sets(built, tmp_path_factory):
+    d = str(tmp_path_factory.mktemp("reads"))
+    ref = os.path.join(d, "ref.fa")
+    util.synth_ref("ref-rna", ref, genes=3, scale=0.02, seed=5)
+    util.synth_reads(ref, os.path.join(d, "a"), pairs=30000, len=150, seed=7)   # 9 MB per mate: several 1 MiB blocks per rank
+    util.synth_reads(ref, os.path.join(d, "b"), pairs=12345, len=100, seed=8)
+    util.synth_reads(ref, os.path.join(d, "c"), pairs=7, len=150, seed=9)       # smaller than a block
+    for m in ("1", "2"):
+        p = os.path.join(d, "b_%s.fq" % m)
+        text = open(p, "rb").read()
+        open(p, "wb").write(text.replace(b"\n", b"\r\n"))                       # CRLF
+    p = os.path.join(d, "a_1.fq")
+    text = open(p, "rb").read()
+    open(p, "wb").write(text.rstrip(b"\n"))                                     # no final newline
+    open(os.path.join(d, "empty_1.fq"), "w").close()
+    open(os.path.join(d, "empty_2.fq"), "w").close()
+    return d
+
+
+@pytest.mark.parametrize("ranks", [1, 2, 3, 5, 8])
+@pytest.mark.parametrize("layout", ["one file", "three files + an empty one", "single-end"])
+def test_rank_slices_concatenate_to_the_whole_index(harness, read_sets, tmp_path, ranks, layout):
+    d = read_sets
+    names = {"one file": ["a"], "three files + an empty one": ["a", "empty", "b", "c"], "single-end": ["a", "b"]}[layout]
+    f1 = [os.path.join(d, n + "_1.fq") for n in names]
+    f2 = [] if layout == "single-end" else [os.path.join(d, n + "_2.fq") for n in names]
+    out = str(tmp_path / "o")
+    r = subprocess.run([harness, str(ranks), "4", out, str(len(f1))] + f1 + f2, stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 0, r.stderr
+    whole = open(out + "_whole.tsv").read()
+    assert whole.count("\n") == {"one file": 30000, "three files + an empty one": 42352, "single-end": 42345}[layout]
+    assert "\r" not in whole
+    assert open(out + "_sharded.tsv").read() == whole
+
+
+def test_more_ranks_than_blocks(harness, read_sets, tmp_path):
+    """seven fragments over five ranks: some ranks own nothing, the slices still tile the input"""
+    d = read_sets
+    out = str(tmp_path / "o")
+    r = subprocess.run([harness, "5", "2", out, "1", os.path.join(d, "c_1.fq"), os.path.join(d, "c_2.fq")], stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 0, r.stderr
+    assert open(out + "_sharded.tsv").read() == open(out + "_whole.tsv").read()
+    assert open(out + "_whole.tsv").read().count("\n") == 7
+
+
+def test_compressed_input_is_left_to_the_whole_file_reader(harness, read_sets, tmp_path):
+    """a .gz file cannot be cut by byte blocks: openSharded declines (0) and the job falls back to every rank reading everything"""
+    import gzip
+    d = read_sets
+    for m in ("1", "2"):
+        with open(os.path.join(d, "c_%s.fq" % m), "rb") as a, gzip.open(str(tmp_path / ("c_%s.fq.gz" % m)), "wb") as b:
+            b.write(a.read())
+    r = subprocess.run([harness, "2", "2", str(tmp_path / "o"), "1", str(tmp_path / "c_1.fq.gz"), str(tmp_path / "c_2.fq.gz")], stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 3, r.stderr
+    assert open(str(tmp_path / "o") + "_whole.tsv").read().count("\n") == 7
