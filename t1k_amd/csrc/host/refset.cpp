@@ -316,24 +316,53 @@ bool RefSet::load(const std::string &fasta, int digitUnitsArg, char delimiterArg
   // gene similarity from the lexicographically smallest allele sequence of each gene (598-638)
   std::vector<std::unordered_map<uint64_t, int>> prof(Gn);
   {
-    std::vector<int> pick(Gn, -1);
-    for (int a = 0; a < A; ++a) {
-      int g = al[a].gene;
-      if (pick[g] == -1 || strcmp(seqs[a].c_str(), seqs[pick[g]].c_str()) < 0) pick[g] = a;
+    // (the comparisons run over long common prefixes: the host threads each take a piece of the alleles, and the pieces' picks are
+    // combined in allele order with the same strict comparison, so the first of equal sequences still wins)
+    const int T = (int)std::max(1u, std::min(16u, std::min(std::thread::hardware_concurrency(), (unsigned)(A / 1024 + 1))));
+    std::vector<std::vector<int>> part(T, std::vector<int>(Gn, -1));
+    auto scan = [&](int t) {
+      const int a0 = (int)((int64_t)A * t / T), a1 = (int)((int64_t)A * (t + 1) / T);
+      std::vector<int> &pk = part[t];
+      for (int a = a0; a < a1; ++a) {
+        const int g = al[a].gene;
+        if (pk[g] == -1 || strcmp(seqs[a].c_str(), seqs[pk[g]].c_str()) < 0) pk[g] = a;
+      }
+    };
+    {
+      std::vector<std::thread> th;
+      for (int t = 1; t < T; ++t) th.emplace_back(scan, t);
+      scan(0);
+      for (auto &x : th) x.join();
     }
-    for (int g = 0; g < Gn; ++g) kmerProfile(seqs[pick[g]], prof[g]);
+    std::vector<int> pick(Gn, -1);
+    for (int t = 0; t < T; ++t)
+      for (int g = 0; g < Gn; ++g)
+        if (part[t][g] != -1 && (pick[g] == -1 || strcmp(seqs[part[t][g]].c_str(), seqs[pick[g]].c_str()) < 0)) pick[g] = part[t][g];
+    {
+      std::vector<std::thread> th;
+      for (int g = 1; g < Gn; ++g) th.emplace_back([&, g] { kmerProfile(seqs[pick[g]], prof[g]); });
+      if (Gn) kmerProfile(seqs[pick[0]], prof[0]);
+      for (auto &x : th) x.join();
+    }
   }
   geneSim.assign(Gn, std::vector<double>(Gn, 0));
-  for (int i = 0; i < Gn; ++i)
-    for (int j = 0; j < Gn; ++j) {
-      if (i == j) { geneSim[i][j] = 1.0; continue; }
-      int total = 0, shared = 0;
-      for (auto &kv : prof[i]) {
-        total += kv.second;
-        if (prof[j].count(kv.first)) shared += kv.second;
+  {
+    auto row = [&](int i) {
+      for (int j = 0; j < Gn; ++j) {
+        if (i == j) { geneSim[i][j] = 1.0; continue; }
+        int total = 0, shared = 0;
+        for (auto &kv : prof[i]) {
+          total += kv.second;
+          if (prof[j].count(kv.first)) shared += kv.second;
+        }
+        geneSim[i][j] = (double)shared / (double)total;
       }
-      geneSim[i][j] = (double)shared / (double)total;
-    }
+    };
+    std::vector<std::thread> th;  // one row per thread: a few dozen genes
+    for (int i = 1; i < Gn; ++i) th.emplace_back(row, i);
+    if (Gn) row(0);
+    for (auto &x : th) x.join();
+  }
   // effective-length repair (641-681): alleles > 500 shorter than their gene's modal length inherit the mode
   for (int g = 0; g < Gn; ++g) {
     std::vector<int> lens;
