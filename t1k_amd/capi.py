@@ -470,8 +470,10 @@ class Comm:
         if rc != 0:
             raise T1kError("t1k_comm_init failed (%d): %s" % (rc, lib().t1k_comm_last_error(h).decode() if h else ""))
 
-    def bind(self, job):
-        if lib().t1k_comm_bind(self.h, job.ctx()) != 0:
+    def bind(self, owner):
+        """owner: a Job or a Context, as in __init__"""
+        ctx = owner.ctx() if hasattr(owner, "ctx") else owner.h
+        if lib().t1k_comm_bind(self.h, ctx) != 0:
             raise T1kError("t1k_comm_bind failed")
 
     def is_rccl(self):
