@@ -69,6 +69,7 @@ int t1k_ctx_create(int device, const t1k_params *params, t1k_ctx **out);
 void t1k_ctx_destroy(t1k_ctx *ctx);
 const char *t1k_last_error(const t1k_ctx *ctx);
 int t1k_device_count(void);
+int t1k_device_memory(int device, uint64_t *freeBytes, uint64_t *totalBytes);
 
 /* ---- reference: SeqSet::InputRefSeq + KmerIndex::BuildIndexFromRead (SeqSet.hpp:906-982, KmerIndex.hpp:107-130) --
  * seqs: nAlleles sequences concatenated as ASCII (ACGT, anything else is treated as N); offsets[nAlleles+1] byte offsets;
@@ -167,6 +168,9 @@ t1k_comm_group *t1k_comm_group_create(int nRanks);
 void t1k_comm_group_destroy(t1k_comm_group *g);
 int t1k_comm_init(t1k_ctx *ctx, int nRanks, int rank, const void *id128, t1k_comm_group *group, int transport /* -1 auto, 0 in-process, 1 RCCL */, t1k_comm **out);
 int t1k_comm_bind(t1k_comm *c, t1k_ctx *ctx);  /* use the communicator with another context of the same device */
+/* a rank that cannot go on says so before it returns: ranks waiting for it are released and every later collective of the job fails
+ * with T1K_ERR_STATE instead of waiting (in-process transport: the meeting points; RCCL: ncclCommAbort) */
+int t1k_comm_abort(t1k_comm *c);
 void t1k_comm_destroy(t1k_comm *c);
 const char *t1k_comm_last_error(const t1k_comm *c);
 int t1k_comm_rank(const t1k_comm *c);
@@ -189,6 +193,29 @@ int t1k_coverage_reset(t1k_ctx *ctx);
 /* per allele: number of exon positions whose coverage is below max(1, 1 % of the allele's median exon coverage)
  * (SeqSet::GetSeqMissingBaseCoverage, SeqSet.hpp:2717-2755), computed on the device; missing[nAlleles] */
 int t1k_missing_coverage(t1k_ctx *ctx, int32_t *missing);
+/* ---- per-base coverage only where it is read ------------------------------------------------------------------------------------
+ * posWeight (SeqSet.hpp:2253-2274) has one reader, GetSeqMissingBaseCoverage (2717-2755) via Genotyper::FinalizeReadAssignments
+ * (Genotyper.hpp:935), and alleleInfo[].missingCoverage is consumed for the SELECTED alleles of a gene only (Genotyper.hpp:1754,
+ * 1870-1878; its use in EMupdate is overwritten by `adjust = 1`, 389-390 / 400-401).  A context in deferred mode
+ * (t1k_ctx_set_coverage_mode(ctx, 1)) therefore adds no coverage in t1k_assign_range -- without --relaxIntronAlign it skips the
+ * near-best full alignments altogether (relaxedMatchCnt = matchCnt there, SeqSet.hpp:2247-2250), with it they run for the relaxed
+ * counts alone.  The caller keeps the finished read sets instead of letting the next upload overwrite them:
+ *   t1k_readset_detach(reader)        the distinct read-ends of the reader context and the table of their final lists change owner
+ *   t1k_readset_take_store(rs, pipe)  ... and so do the overlap-store chunks of slot `slot` of every context that assigned ranges of it
+ * and, once allele selection has its candidates (Genotyper.hpp:1462-1695),
+ *   t1k_coverage_selected(ctx, rs, selected[nAlleles])  adds to ctx's coverage arrays what t1k_assign_range would have added for the
+ *                                     overlaps on the alleles with selected[a] != 0: identical per-base coverage for those alleles
+ * (integer sums), so t1k_missing_coverage returns the same numbers for them.  *nRecords = records aligned (may be NULL). */
+typedef struct t1k_readset t1k_readset;
+int t1k_ctx_set_coverage_mode(t1k_ctx *ctx, int deferred);
+int t1k_readset_detach(t1k_ctx *reader, t1k_readset **out);
+int t1k_readset_take_store(t1k_readset *rs, t1k_ctx *pipe, int slot);
+uint64_t t1k_readset_bytes(const t1k_readset *rs);   /* device memory the read set holds */
+uint32_t t1k_readset_size(const t1k_readset *rs);    /* distinct read-ends */
+const char *t1k_readset_last_error(const t1k_readset *rs);
+void t1k_readset_destroy(t1k_readset *rs);
+int t1k_coverage_selected(t1k_ctx *ctx, t1k_readset *rs, const uint8_t *selected, uint64_t *nRecords);
+
 /* Several contexts on one GPU (pipelines of one job) can share the read-only device data of one of them: dst aliases src's
  * reference (and gets its own, zeroed coverage array) / src's packed reads.  src must outlive dst. */
 int t1k_ref_share(t1k_ctx *dst, const t1k_ctx *src);

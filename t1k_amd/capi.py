@@ -131,6 +131,16 @@ def lib():
     L.t1k_comm_group_create.argtypes = [C.c_int]
     L.t1k_comm_group_destroy.argtypes = [vp]
     L.t1k_coverage_device.argtypes = [vp, C.POINTER(vp), u64p]
+    L.t1k_device_memory.argtypes = [C.c_int, u64p, u64p]
+    L.t1k_ctx_set_coverage_mode.argtypes = [vp, C.c_int]
+    L.t1k_readset_detach.argtypes = [vp, C.POINTER(vp)]
+    L.t1k_readset_take_store.argtypes = [vp, vp, C.c_int]
+    L.t1k_readset_bytes.argtypes = [vp]
+    L.t1k_readset_bytes.restype = C.c_uint64
+    L.t1k_readset_size.argtypes = [vp]
+    L.t1k_readset_size.restype = C.c_uint32
+    L.t1k_readset_destroy.argtypes = [vp]
+    L.t1k_coverage_selected.argtypes = [vp, vp, vp, u64p]
     _lib = L
     return L
 
@@ -244,6 +254,25 @@ class Context:
         self._check(lib().t1k_coverage_get(self.h, _ptr(out), tot), "t1k_coverage_get")
         return out
 
+    def set_coverage_mode(self, deferred):
+        """deferred: t1k_assign_range adds no per-base coverage (t1k_coverage_selected adds it later for the alleles that need it)"""
+        self._check(lib().t1k_ctx_set_coverage_mode(self.h, 1 if deferred else 0), "t1k_ctx_set_coverage_mode")
+
+    def detach_readset(self, slot=0):
+        """the context's read set and the final overlap lists it holds change owner (t1k_readset_detach + t1k_readset_take_store)"""
+        h = C.c_void_p()
+        self._check(lib().t1k_readset_detach(self.h, C.byref(h)), "t1k_readset_detach")
+        rs = Readset(h)
+        self._check(lib().t1k_readset_take_store(rs.h, self.h, slot), "t1k_readset_take_store")
+        return rs
+
+    def coverage_selected(self, readset, selected):
+        """adds the coverage of the read set's near-best overlaps on the alleles with selected[a] != 0; returns the records aligned"""
+        sel = np.ascontiguousarray(selected, dtype=np.uint8)
+        n = C.c_uint64()
+        self._check(lib().t1k_coverage_selected(self.h, readset.h, _ptr(sel), C.byref(n)), "t1k_coverage_selected")
+        return n.value
+
     def coverage_reset(self):
         self._check(lib().t1k_coverage_reset(self.h), "t1k_coverage_reset")
 
@@ -301,6 +330,30 @@ class Context:
         diff = C.c_double()
         self._check(lib().t1k_em_update(self.h, _ptr(x0), _ptr(x1), _ptr(n), C.byref(diff)), "t1k_em_update")
         return x1, n, diff.value
+
+
+class Readset:
+    """A finished read set kept resident (t1k_readset): distinct read-ends + their final overlap lists."""
+
+    def __init__(self, h):
+        self.h = h
+
+    def bytes(self):
+        return int(lib().t1k_readset_bytes(self.h))
+
+    def size(self):
+        return int(lib().t1k_readset_size(self.h))
+
+    def close(self):
+        if self.h:
+            lib().t1k_readset_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class Job:

@@ -348,6 +348,7 @@ void Genotyper::select() {
   const double frac = prm.filter_frac;
   std::vector<char> groupCovered(G, 0);
   selected.assign(nGenes, {});
+  hookFailed = false;
   const double ts0 = hostNowMs();
   // weight of a group's first entry, gathered once: the class loop below reads it for every group of every class it looks at, and the
   // entries themselves are hundreds of megabytes
@@ -414,6 +415,16 @@ void Genotyper::select() {
     for (auto &s : selected[m.gene])
       if (R.al[s.first].major == m.major) { rank = s.second; break; }
     if (rank != -1) selected[m.gene].push_back({a, rank});
+  }
+  if (missingCoverageHook) {
+    std::vector<int> need;
+    for (int g = 0; g < nGenes; ++g)
+      if (geneTypes(g) > 2)  // (the type-pair search below skips the other genes, and nothing else reads the value)
+        for (auto &sa : selected[g]) need.push_back(sa.first);
+    std::sort(need.begin(), need.end());
+    need.erase(std::unique(need.begin(), need.end()), need.end());
+    hookFailed = !missingCoverageHook(need);
+    if (hookFailed) return;
   }
   const double ts2 = hostNowMs();
   // genes with more than two allele types: pick the pair of types explaining the most reads (1697-1996)

@@ -43,6 +43,12 @@ struct t1k_job {
   bool bgStarted = false, bgOk = true;
   bool analyzer = false;            // analyzer mode: the rowset keeps the raw fragment assignment lists and is left alive after run_local
   t1k_rowset *rows = nullptr;       // every fragment's row, resident on the GPU until the job is coalesced
+  // Per-base coverage is only read for the alleles allele selection puts on its candidate lists (t1k_gpu.h, "per-base coverage only
+  // where it is read"): the windows' read sets (distinct read-ends + final overlap lists) stay resident and the coverage of those
+  // alleles is added inside select() (covDeferred; T1K_COVERAGE=eager restores the per-range updates for every allele)
+  bool covDeferred = false;
+  std::vector<t1k_readset *> archive;
+  uint64_t coverRecords = 0; double msCover = 0;
   std::vector<uint8_t> fragAssigned;
   bool ran = false, localDone = false;
   std::vector<char> whitelist;      // per allele, empty = everything allowed
@@ -165,6 +171,8 @@ void t1k_job_destroy(t1k_job *job) {
   if (job->bgWriter.joinable()) job->bgWriter.join();
   if (!job->stream.empty()) streamClose(job, true);  // a run that never reached t1k_job_finish
   if (job->rows) t1k_rowset_destroy(job->rows);
+  for (t1k_readset *rs : job->archive) t1k_readset_destroy(rs);
+  job->archive.clear();
   for (t1k_ctx *c : job->more) t1k_ctx_destroy(c);  // before job->ctx, whose reference they alias
   for (t1k_ctx *c : job->reader) if (c) t1k_ctx_destroy(c);
   if (job->ctx) t1k_ctx_destroy(job->ctx);
@@ -284,6 +292,7 @@ struct Window {
   std::vector<char> pairDone;       // per pairing range of the window: finished (the output writer follows these)
   double tReady = 0, tDone = 0, msPrep = 0;
   std::vector<char> touched;        // per pipeline: has it attached to this window yet (first touch empties its store slot)
+  bool deferred = false;            // its coverage is added later, for the selected alleles only: the read set is kept when the window is done
 };
 }  // namespace
 
@@ -291,6 +300,10 @@ int t1k_job_run_local(t1k_job *job) {
   if (!job || !job->ctx) return jobFail(job, T1K_ERR_STATE, "this job has no GPU context (device = -1): it cannot run");
   if (!job->in) return jobFail(job, T1K_ERR_STATE, "no reads loaded");
   int rc;
+  // a writer still formatting the last run's records reads fragAssigned and the stream files this run is about to reset
+  if (job->bgWriter.joinable()) job->bgWriter.join();
+  if (!job->stream.empty()) streamClose(job, false);
+  job->bgStarted = false;
   // fresh state (a job may be run repeatedly, e.g. by the benchmark)
   Genotyper &gt = job->gt;
   const ReadInput &in = *job->in;
@@ -318,6 +331,23 @@ int t1k_job_run_local(t1k_job *job) {
     std::vector<uint8_t> wl(job->whitelist.begin(), job->whitelist.end());
     if ((rc = t1k_rowset_create(job->ctx, F, wl.empty() ? nullptr : wl.data(), &job->rows)) != T1K_OK) return jobFail(job, rc, t1k_last_error(job->ctx));
     if (job->analyzer) t1k_rowset_set_raw(job->rows, 1);
+  }
+  for (t1k_readset *rs : job->archive) t1k_readset_destroy(rs);
+  job->archive.clear();
+  job->coverRecords = 0; job->msCover = 0;
+  {
+    const char *cm = getenv("T1K_COVERAGE");
+    job->covDeferred = !job->analyzer && !(cm && !strcmp(cm, "eager"));
+  }
+  // device memory the kept read sets may take (about 6 KB per fragment of an HLA-sized reference: 58 GB at 10 M pairs); windows beyond
+  // it fall back to the per-range coverage updates -- both kinds add up, only the selected alleles' sums are read
+  uint64_t archiveBudget = 0, archivedBytes = 0, archivedFrags = 0;
+  bool eagerFromNowOn = !job->covDeferred;
+  if (job->covDeferred) {
+    uint64_t freeB = 0, totalB = 0;
+    (void)t1k_device_memory(job->prm.device, &freeB, &totalB);
+    archiveBudget = totalB / 2;
+    if (const char *e = getenv("T1K_ARCHIVE_GB")) archiveBudget = (uint64_t)(atof(e) * 1073741824.0);
   }
   const double tStart = nowMs();
   const int T = hostThreads(job);
@@ -390,6 +420,14 @@ int t1k_job_run_local(t1k_job *job) {
         if (F - N.f1 < size / 4 || w + 1 >= maxWindows) N.f1 = F;  // no small tail window
         N.slot = (int)(w & 1);
         N.touched.assign(P, 0);
+        if (!eagerFromNowOn) {
+          const uint64_t est = archivedFrags ? (uint64_t)((double)archivedBytes / (double)archivedFrags * (double)(N.f1 - N.f0)) : 0;
+          uint64_t open = 0;  // windows cut earlier whose read sets are not kept yet
+          for (uint32_t v = sh.oldest; v < w; ++v)
+            if (win[v].deferred && !win[v].done) open += archivedFrags ? (uint64_t)((double)archivedBytes / (double)archivedFrags * (double)(win[v].f1 - win[v].f0)) : 0;
+          if (archivedBytes + open + est <= archiveBudget) N.deferred = true;
+          else eagerFromNowOn = true;
+        }
         fNext = N.f1;
         win.push_back(std::move(N));
         sh.created = w + 1;
@@ -500,6 +538,7 @@ int t1k_job_run_local(t1k_job *job) {
         W.touched[pi] = 1;
         attached = (int)w;
       }
+      if (r == T1K_OK) (void)t1k_ctx_set_coverage_mode(ctx, (W.deferred || job->analyzer) ? 1 : 0);
       if (r == T1K_OK && kind == 0) {
         const uint32_t b0 = item * W.assignBatch, nb = std::min(W.assignBatch, W.nDistinct - b0);
         r = assignRange(ctx, b0, nb, msg);
@@ -522,6 +561,17 @@ int t1k_job_run_local(t1k_job *job) {
         std::lock_guard<std::mutex> g(sh.m);
         if (kind == 0) ++W.doneAssign; else { ++W.donePair; W.pairDone[item] = 1; }
         if (W.doneAssign == W.nAssign && W.donePair == W.nPair) {
+          if (W.deferred) {
+            // every task of the window has finished (each ends with its stream drained): its read set and the lists the pipelines
+            // wrote change owner before the preparation thread may upload window w + 2 into the same context / store slot
+            t1k_readset *rs = nullptr;
+            if (t1k_readset_detach(job->reader[W.slot], &rs) == T1K_OK) {
+              for (int q = 0; q < P; ++q)
+                if (W.touched[q]) (void)t1k_readset_take_store(rs, pipes[q], W.slot);
+              archivedBytes += t1k_readset_bytes(rs); archivedFrags += W.f1 - W.f0;
+              job->archive.push_back(rs);
+            } else if (sh.err == T1K_OK) { sh.err = T1K_ERR_INTERNAL; sh.errMsg = std::string("keeping the window's read set: ") + t1k_last_error(job->reader[W.slot]); }
+          }
           W.done = true; W.tDone = nowMs();
           std::vector<uint32_t>().swap(W.distinctOf);
           while (sh.oldest < sh.created && win[sh.oldest].done) ++sh.oldest;
@@ -593,7 +643,7 @@ int t1k_job_run_local(t1k_job *job) {
     return T1K_OK;
   }
   const bool sharded = job->nRanks > 1;
-  if (sharded) {  // per-base coverage of all ranks: integers, exact in any order
+  if (sharded && !job->covDeferred) {  // per-base coverage of all ranks: integers, exact in any order (a deferred job reduces inside select())
     void *cov = nullptr; uint64_t covN = 0;
     if ((rc = t1k_coverage_device(job->ctx, &cov, &covN)) != T1K_OK) return jobFail(job, rc, t1k_last_error(job->ctx));
     if ((rc = t1k_comm_allreduce(job->comm, cov, covN, 0)) != T1K_OK) return jobFail(job, rc, t1k_comm_last_error(job->comm));
@@ -697,6 +747,8 @@ int t1k_job_run_local(t1k_job *job) {
   if (getenv("T1K_DEBUG_PHASES"))
     fprintf(stderr, "[t1k job] %u windows, %llu read-ends -> %llu distinct; window preparation %.1f ms (overlapped), device loop %.1f ms, coalesce + download %.1f ms (%llu groups, %llu entries)\n",
             sh.created, (unsigned long long)job->readEnds, (unsigned long long)job->distinctReadEnds, msPrep, job->msDevice, job->msCoalesce, (unsigned long long)G, (unsigned long long)N);
+  if (getenv("T1K_DEBUG_PHASES") && job->covDeferred)
+    fprintf(stderr, "[t1k job] coverage deferred to selection: read sets of %zu of %u windows kept (%.2f GB of device memory)\n", job->archive.size(), sh.created, archivedBytes / 1073741824.0);
   job->localDone = true;
   return T1K_OK;
 }
@@ -930,8 +982,38 @@ int t1k_job_finish(t1k_job *job, uint64_t emGroupBegin, uint64_t emGroupEnd) {
   Genotyper &gt = job->gt;
   int rc;
   double t2 = nowMs();
-  std::vector<int32_t> cov(job->ref.al.size());  // per allele: exon positions with too little coverage
-  if ((rc = t1k_missing_coverage(job->ctx, cov.data())) != T1K_OK) return jobFail(job, rc, t1k_last_error(job->ctx));
+  std::vector<int32_t> cov(job->ref.al.size(), 0);  // per allele: exon positions with too little coverage
+  gt.missingCoverageHook = nullptr;
+  int hookRc = T1K_OK;
+  if (!job->covDeferred) {
+    if ((rc = t1k_missing_coverage(job->ctx, cov.data())) != T1K_OK) return jobFail(job, rc, t1k_last_error(job->ctx));
+  } else {
+    // the value is read for the alleles on selection's candidate lists only (Genotyper.hpp:1754, 1870-1878): select() asks for them
+    gt.missingCoverageHook = [job, &hookRc](const std::vector<int> &need) {
+      if (need.empty()) return true;  // (the same on every rank: selection is replicated)
+      const double t0 = nowMs();
+      std::vector<uint8_t> sel(job->ref.al.size(), 0);
+      for (int a : need) sel[a] = 1;
+      for (t1k_readset *&rs : job->archive) {
+        uint64_t n = 0;
+        if ((hookRc = t1k_coverage_selected(job->ctx, rs, sel.data(), &n)) != T1K_OK) { job->err = t1k_last_error(job->ctx); return false; }
+        job->coverRecords += n;
+        t1k_readset_destroy(rs); rs = nullptr;
+      }
+      job->archive.clear();
+      if (job->nRanks > 1) {  // per-base coverage of all ranks: integers, exact in any order
+        void *dcov = nullptr; uint64_t covN = 0;
+        if ((hookRc = t1k_coverage_device(job->ctx, &dcov, &covN)) != T1K_OK) { job->err = t1k_last_error(job->ctx); return false; }
+        if ((hookRc = t1k_comm_allreduce(job->comm, dcov, covN, 0)) != T1K_OK) { job->err = t1k_comm_last_error(job->comm); return false; }
+      }
+      std::vector<int32_t> miss(job->ref.al.size());
+      if ((hookRc = t1k_missing_coverage(job->ctx, miss.data())) != T1K_OK) { job->err = t1k_last_error(job->ctx); return false; }
+      for (int a : need) job->ref.al[a].missingCov = miss[a];
+      job->msCover = nowMs() - t0;
+      if (getenv("T1K_DEBUG_PHASES")) fprintf(stderr, "[t1k job] coverage of the %zu alleles on selection's lists: %llu records aligned, %.1f ms\n", need.size(), (unsigned long long)job->coverRecords, job->msCover);
+      return true;
+    };
+  }
   gt.finalize(cov);
   double t3 = nowMs();
   if (!job->abundanceFile.empty()) {
@@ -944,6 +1026,8 @@ int t1k_job_finish(t1k_job *job, uint64_t emGroupBegin, uint64_t emGroupEnd) {
   gt.dropUnlikely();
   double t4b = nowMs();
   gt.select();
+  gt.missingCoverageHook = nullptr;
+  if (gt.hookFailed) return jobFail(job, hookRc != T1K_OK ? hookRc : T1K_ERR_INTERNAL, job->err);
   double t5 = nowMs();
   job->msHost += (t3 - t2) + (t5 - t4); job->msEm = t4 - t3;
   job->stats.ms_total = job->msLoad + job->msDevice + job->msCoalesce + job->msHost + job->msEm;
@@ -957,8 +1041,10 @@ int t1k_job_finish(t1k_job *job, uint64_t emGroupBegin, uint64_t emGroupEnd) {
 
 int t1k_job_run(t1k_job *job) {
   int rc = t1k_job_run_local(job);
-  if (rc != T1K_OK) return rc;
-  return t1k_job_finish(job, 0, ~0ull);
+  if (rc == T1K_OK) rc = t1k_job_finish(job, 0, ~0ull);
+  // a rank of a sharded job that fails tells the others (they would wait for it in the next exchange otherwise)
+  if (rc != T1K_OK && job && job->comm && job->nRanks > 1) (void)t1k_comm_abort(job->comm);
+  return rc;
 }
 
 // group table <-> byte string: [u64 nGroups][u64 nEntries][u64 assignedFragments][u64 groupPtr[nGroups+1]][u32 firstFragment[nGroups]][GroupEntry entries[nEntries]]
@@ -1249,13 +1335,15 @@ int t1k_genotyper_main(int argc, char **argv) {
             t1k_job_set_output_prefix(jobs[r], prefix.c_str());
           }
         }
-        // a rank that failed before the first collective must still not leave the others waiting: it runs with nothing to do
         rcs[r] = x == T1K_OK ? t1k_job_run(jobs[r]) : x;
         if (rcs[r] == T1K_OK && shardInput && r) rcs[r] = t1k_job_write_outputs(jobs[r], prefix.c_str());  // its part of the read files (rank 0: below)
+        // a rank that gives up must not leave the others waiting at the next exchange: they are released with an error of their own
+        if (rcs[r] != T1K_OK && comms[r]) (void)t1k_comm_abort(comms[r]);
       });
     for (auto &t : th) t.join();
-    for (int r = 0; r < R; ++r)
-      if (rcs[r] != T1K_OK && rc == T1K_OK) { rc = rcs[r]; if (r) job->err = t1k_job_last_error(jobs[r]); }
+    for (int pass = 0; pass < 2 && rc == T1K_OK; ++pass)  // report the rank that failed, not the ones it released (T1K_ERR_STATE)
+      for (int r = 0; r < R && rc == T1K_OK; ++r)
+        if (rcs[r] != T1K_OK && (pass == 1 || rcs[r] != T1K_ERR_STATE)) { rc = rcs[r]; if (r) job->err = t1k_job_last_error(jobs[r]); }
     for (t1k_comm *c : comms) t1k_comm_destroy(c);
     t1k_comm_group_destroy(group);
   }

@@ -212,6 +212,18 @@ void kmerProfile(const std::string &s, std::unordered_map<uint64_t, int> &prof) 
     if (invalid == -1) ++prof[fw < rv ? fw : rv];
   }
 }
+// fn(g) for every gene g on a bounded pool (a custom reference may split into thousands of "genes": one thread each could hit the
+// process thread limit, and the resulting std::system_error would end the process)
+template <class F>
+void overGenes(int Gn, F fn) {
+  const int T = std::max(1, std::min({16, (int)std::thread::hardware_concurrency(), Gn}));
+  std::atomic<int> next{0};
+  auto work = [&] { for (int g = next.fetch_add(1); g < Gn; g = next.fetch_add(1)) fn(g); };
+  std::vector<std::thread> th;
+  for (int t = 1; t < T; ++t) th.emplace_back(work);
+  work();
+  for (auto &x : th) x.join();
+}
 }  // namespace
 
 bool RefSet::load(const std::string &fasta, int digitUnitsArg, char delimiterArg, std::string &err, const std::set<std::string> *selected) {
@@ -338,12 +350,7 @@ bool RefSet::load(const std::string &fasta, int digitUnitsArg, char delimiterArg
     for (int t = 0; t < T; ++t)
       for (int g = 0; g < Gn; ++g)
         if (part[t][g] != -1 && (pick[g] == -1 || strcmp(seqs[part[t][g]].c_str(), seqs[pick[g]].c_str()) < 0)) pick[g] = part[t][g];
-    {
-      std::vector<std::thread> th;
-      for (int g = 1; g < Gn; ++g) th.emplace_back([&, g] { kmerProfile(seqs[pick[g]], prof[g]); });
-      if (Gn) kmerProfile(seqs[pick[0]], prof[0]);
-      for (auto &x : th) x.join();
-    }
+    overGenes(Gn, [&](int g) { kmerProfile(seqs[pick[g]], prof[g]); });
   }
   geneSim.assign(Gn, std::vector<double>(Gn, 0));
   {
@@ -358,10 +365,7 @@ bool RefSet::load(const std::string &fasta, int digitUnitsArg, char delimiterArg
         geneSim[i][j] = (double)shared / (double)total;
       }
     };
-    std::vector<std::thread> th;  // one row per thread: a few dozen genes
-    for (int i = 1; i < Gn; ++i) th.emplace_back(row, i);
-    if (Gn) row(0);
-    for (auto &x : th) x.join();
+    overGenes(Gn, row);
   }
   // effective-length repair (641-681): alleles > 500 shorter than their gene's modal length inherit the mode
   for (int g = 0; g < Gn; ++g) {

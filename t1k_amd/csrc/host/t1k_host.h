@@ -142,6 +142,11 @@ struct Genotyper {
   int quantify(t1k_ctx *ctx, t1k_comm *comm, std::string &err);
   void dropUnlikely();                                       // RemoveLowLikelihoodAlleleInEquivalentClass (1371-1460)
   void select();                                             // SelectAllelesForGenes (1462-2090)
+  // Optional: called once inside select(), after the per-gene candidate lists exist (1462-1695) and before the first read of an
+  // allele's missingCoverage (1733-1770, 1870-1878), with the alleles on those lists; it fills ref->al[a].missingCov for them (the only
+  // alleles whose value is ever read).  A job whose per-base coverage is deferred computes it here (t1k_coverage_selected).
+  std::function<bool(const std::vector<int> &)> missingCoverageHook;
+  bool hookFailed = false;
   std::string geneLine(int gene) const;                      // GetAlleleDescription (2103-2178) + Genotyper.cpp:660-670
   std::string alleleLines() const;                           // OutputRepresentativeAlleles (2180-2229)
   void setAbundance(const double *ecReadCount, const std::vector<int> &ecLen);  // SetAlleleAbundance (957-1014)

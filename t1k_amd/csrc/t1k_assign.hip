@@ -574,8 +574,11 @@ __global__ __launch_bounds__(NT) T1K_OCC8 void k_select(SelectArgs P) {
           T1kOvl o;
           o.allele = c.allele & 0x7FFFFFFFu;
           o.seqStart = x.seqStart; o.seqEnd = x.seqEnd; o.readStart = x.readStart; o.readEnd = x.readEnd;
-          o.matchCnt = x.matchCnt; o.relaxed = 0; o.leftClip = x.leftClip; o.rightClip = x.rightClip; o.re = re;
+          o.matchCnt = x.matchCnt; o.leftClip = x.leftClip; o.rightClip = x.rightClip; o.re = re;
           o.flags = ((int)x.matchCnt >= bestMatch - 10 ? 1u : 0u) | ((c.allele >> 31) ? 0u : 2u);  // SeqSet.hpp:2200
+          // without --relaxIntronAlign the relaxed count is the match count of a near-best overlap and 0 otherwise (SeqSet.hpp:2247-2250, 2282):
+          // known here, whether or not the full alignments run; with it the alignment kernels fill it in
+          o.relaxed = (!P.relax && (o.flags & 1)) ? x.matchCnt : (uint16_t)0;
           if (o.flags & 1) ++nbLocal;
           P.ovl[(uint64_t)sBase + written + off] = o;
         }
@@ -603,7 +606,7 @@ __global__ __launch_bounds__(WG) void k_fullalign(FullArgs P) {
   const uint64_t *rn = P.reads.nmask + ((uint64_t)o.re * 2 + pass) * S;
   const int64_t goff = (int64_t)P.ref.alleleOff[o.allele];
   const int L = o.readEnd - o.readStart + 1, Ls = o.seqEnd - o.seqStart + 1;
-  const int w = (int)P.reads.weight[o.re];
+  const int w = P.noCov ? 0 : (int)P.reads.weight[o.re];
   bool slow = (L != Ls);
   int x = 0, exonMis = 0;
   // one sweep over the windows: mismatch count, and -- kept in registers for the coverage updates below -- the covered-column
@@ -738,7 +741,7 @@ __global__ __launch_bounds__(64) void k_fullalign_slow(SlowArgs P) {
     const uint64_t *rn = P.reads.nmask + ((uint64_t)o.re * 2 + pass) * S;
     const int64_t goff = (int64_t)P.ref.alleleOff[o.allele];
     const int lp = o.readEnd - o.readStart + 1, lt = o.seqEnd - o.seqStart + 1;
-    const int w = (int)P.reads.weight[o.re];
+    const int w = P.noCov ? 0 : (int)P.reads.weight[o.re];
     if ((lp + 1) * (lt + 1) > P.maxCells || lt > GA_BIG_MAX) { atomicOr(&P.counters[2], (unsigned long long)ERR_SLOWCAP); continue; }
     T1kSeqView T{P.ref.bases, P.ref.nmask, goff + o.seqStart}, Pv{rb, rn, (int64_t)o.readStart};
     t1k_ga_general(T, lt, Pv, lp, rows, trace, nullptr);
@@ -852,7 +855,7 @@ __global__ __launch_bounds__(WG) void k_align_apply_eq(SlowArgs P) {
     const uint64_t *rn = P.reads.nmask + ((uint64_t)o.re * 2 + pass) * S;
     const int64_t goff = (int64_t)P.ref.alleleOff[o.allele];
     const int L = o.readEnd - o.readStart + 1;
-    const int w = (int)P.reads.weight[o.re];
+    const int w = P.noCov ? 0 : (int)P.reads.weight[o.re];
     int32_t *cov = P.ref.covDiff + goff;
     T1kWinBits exW(P.ref.exon, goff), gnW(P.ref.nmask, goff), rnW(rn, 0);
     const int alleleLen = (int)P.ref.alleleLen[o.allele];
@@ -912,7 +915,7 @@ __global__ __launch_bounds__(WG) void k_align_apply_band(SlowArgs P) {
     const int64_t goff = (int64_t)P.ref.alleleOff[o.allele];
     const int lp = o.readEnd - o.readStart + 1, lt = o.seqEnd - o.seqStart + 1;
     const int LB = 5 + (lp > lt ? lp - lt : 0);
-    const int w = (int)P.reads.weight[o.re];
+    const int w = P.noCov ? 0 : (int)P.reads.weight[o.re];
     T1kSeqView T{P.ref.bases, P.ref.nmask, goff + o.seqStart}, Pv{rb, rn, (int64_t)o.readStart};
     int32_t *cov = P.ref.covDiff + goff;
     T1kWinBits exW(P.ref.exon, goff), gnW(P.ref.nmask, goff), rnW(rn, 0);

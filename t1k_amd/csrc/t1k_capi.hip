@@ -518,6 +518,92 @@ static int capacityError(t1k_ctx *ctx, unsigned long long flags) {
   return t1k_fail(ctx, T1K_ERR_CAPACITY, m);
 }
 
+
+// The near-best full alignments of `nOvl` working records (relaxed match counts + per-base coverage, SeqSet.hpp:2188-2285): k_fullalign
+// (ungapped in closed form), then the queued DP alignments -- equal spans / spans differing by <= 4 sorted so that identical jobs share
+// one traced fill, wider differences through the general DP.  noCov: the coverage updates are left out.  exactQueues: every stripe of
+// the alignment queues can hold all records (no overflow possible; for callers that cannot run the records again).
+extern "C++" int t1k_fullalign_phase(t1k_ctx *ctx, const T1kReadsDev &rd, T1kOvl *ovl, uint64_t nOvl, int relaxFlag, int noCov, int maxLen, bool exactQueues,
+                                     unsigned long long *hc) {
+  int rc;
+  unsigned long long *counters = (unsigned long long *)ctx->bCounters.p;
+  const int maxCells = 340 * 340;
+  const int slowBlocks = 64;
+  // alignment queues (equal spans | spans differing by <= 4 | wider): striped arenas appended to by k_fullalign, then made dense
+  const uint32_t qSegCap = exactQueues ? (uint32_t)(nOvl + 64) : (uint32_t)(nOvl / T1K_NSTRIPE * 2 + 1024);
+  const size_t qDense = (size_t)nOvl + 1, qStr = (size_t)qSegCap * T1K_NSTRIPE;
+  // The group records, the work lists and the candidates are dead from here on: the alignment queues, their sort keys and the trace
+  // rows live in that memory when it is large enough (every arena of its own is more fresh VRAM for the driver to zero).
+  const size_t queueBytes = ((qDense + qStr) * 3 * 4 + 255) & ~(size_t)255, keyBytes = (qStr * 2 + qDense * 2) * 8 + qDense * 4;
+  char *queueMem = nullptr;
+  if (ctx->bWgGroups.bytes >= queueBytes + keyBytes) queueMem = (char *)ctx->bWgGroups.p;
+  else {
+    if ((rc = t1k_ensure(ctx, ctx->bSlowQueue, queueBytes + keyBytes))) return rc;
+    queueMem = (char *)ctx->bSlowQueue.p;
+  }
+  FullArgs f{};
+  f.ref = ctx->ref; f.reads = rd; f.relax = relaxFlag; f.noCov = noCov; f.ovl = ovl; f.nOvl = nOvl;
+  uint32_t *qEq = (uint32_t *)queueMem, *qBand = qEq + qDense, *qWide = qBand + qDense;
+  f.eqStr = qWide + qDense; f.bandStr = f.eqStr + qStr; f.wideStr = f.bandStr + qStr; f.segCap = qSegCap; f.counters = counters;
+  // sort keys of the equal / band queues: striped | dense | sorted (scratch of the radix sort), and the unsorted dense gid lists
+  f.eqKeyStr = (unsigned long long *)(queueMem + queueBytes); f.bandKeyStr = f.eqKeyStr + qStr;
+  unsigned long long *kDense = f.bandKeyStr + qStr, *kSorted = kDense + qDense;
+  uint32_t *vDense = (uint32_t *)(kSorted + qDense);
+  if (!noCov) {
+    if (!ctx->covFullLen) ctx->covFullLen = std::max(1, maxLen);
+    ctx->covFullDirty = true;
+  }
+  f.fullLen = noCov ? -1 : ctx->covFullLen;
+  t1k_launch_fullalign(ctx, f);
+  T1K_HIP(ctx, hipEventRecord(ctx->ev[7], ctx->stream));
+  if ((rc = fetchCounters(ctx, hc))) return rc;
+  if (hc[2]) return capacityError(ctx, hc[2]);
+  {
+    const T1kArenaCounts ce = t1k_arena_counts(ctx, T1K_AR_EQ, qSegCap), cb = t1k_arena_counts(ctx, T1K_AR_BAND, qSegCap), cw = t1k_arena_counts(ctx, T1K_AR_WIDE, qSegCap);
+    if (ce.overflow || cb.overflow || cw.overflow) return capacityError(ctx, 64);
+    // equal / band queues: dense, then ordered by (read-end, strand, read window, allele-window hash)
+    t1k_arena_compact(ctx, T1K_AR_EQ, f.eqStr, qSegCap, vDense, ce.maxSeg);
+    t1k_arena_compact64(ctx, T1K_AR_EQ, f.eqKeyStr, qSegCap, kDense, ce.maxSeg);
+    if ((rc = t1k_sort_pairs(ctx, kDense, kSorted, vDense, qEq, (uint32_t)ce.total))) return rc;
+    t1k_arena_compact(ctx, T1K_AR_BAND, f.bandStr, qSegCap, vDense, cb.maxSeg);
+    t1k_arena_compact64(ctx, T1K_AR_BAND, f.bandKeyStr, qSegCap, kDense, cb.maxSeg);
+    if ((rc = t1k_sort_pairs(ctx, kDense, kSorted, vDense, qBand, (uint32_t)cb.total))) return rc;
+    t1k_arena_compact(ctx, T1K_AR_WIDE, f.wideStr, qSegCap, qWide, cw.maxSeg);
+    hc[8] = ce.total; hc[15] = cb.total; hc[20] = cw.total;
+  }
+  // equal spans (register-band traced DP) and spans differing by 1..4 (wider register band): flags -> runs -> fill -> apply
+  for (int kind = 0; kind < 2; ++kind) {
+    const uint32_t nJobs = (uint32_t)(kind == 0 ? hc[8] : hc[15]);
+    if (!nJobs) continue;
+    SlowArgs sl{};
+    sl.ref = ctx->ref; sl.reads = rd; sl.relax = relaxFlag; sl.noCov = noCov; sl.ovl = ovl; sl.slowQueue = kind == 0 ? qEq : qBand; sl.nSlow = nJobs;
+    sl.perThread = 0; sl.maxCells = 0; sl.counters = counters;
+    uint32_t *flags = vDense, *runOf = (uint32_t *)kDense, *rep = (uint32_t *)kSorted;  // the sort's buffers are free again
+    t1k_launch_align_flags(ctx, sl, flags);
+    if ((rc = t1k_inclusive_sum(ctx, flags, runOf, nJobs))) return rc;
+    uint32_t nRuns = 0;
+    T1K_HIP(ctx, hipMemcpyAsync(&nRuns, runOf + (nJobs - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
+    T1K_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    t1k_launch_align_reps(ctx, flags, runOf, rep, nJobs);
+    const uint64_t stride = ((uint64_t)nRuns + 63) / 64 * 64;
+    const size_t traceBytes = stride * (size_t)(maxLen + 2) * 8;
+    if (ctx->bLists.bytes >= traceBytes) sl.scratch = (uint8_t *)ctx->bLists.p;
+    else if (ctx->bCand.bytes >= traceBytes) sl.scratch = (uint8_t *)ctx->bCand.p;
+    else { if ((rc = t1k_ensure(ctx, ctx->bEqTrace, traceBytes))) return rc; sl.scratch = (uint8_t *)ctx->bEqTrace.p; }
+    sl.runOf = runOf; sl.rep = rep; sl.nRuns = nRuns; sl.traceStride = stride;
+    t1k_launch_align_fill_apply(ctx, sl, kind == 0);
+    if (getenv("T1K_DEBUG_PHASES")) fprintf(stderr, "[t1k] %s alignments: %u jobs in %u runs of identical windows\n", kind == 0 ? "equal-span" : "band", nJobs, nRuns);
+  }
+  if (hc[20]) {  // wide length difference: general DP with row arrays in HBM
+    if ((rc = t1k_ensure(ctx, ctx->bSlowScratch, (size_t)slowBlocks * 64 * t1k_slow_per_thread(maxCells)))) return rc;
+    SlowArgs sl{};
+    sl.ref = ctx->ref; sl.reads = rd; sl.relax = relaxFlag; sl.noCov = noCov; sl.ovl = ovl; sl.slowQueue = qWide; sl.nSlow = (uint32_t)hc[20];
+    sl.scratch = (uint8_t *)ctx->bSlowScratch.p; sl.perThread = t1k_slow_per_thread(maxCells); sl.maxCells = maxCells; sl.counters = counters;
+    t1k_launch_fullalign_slow(ctx, sl, slowBlocks);
+  }
+  return T1K_OK;
+}
+
 int t1k_assign_batch(t1k_ctx *ctx) {
   if (!ctx) return T1K_ERR_ARG;
   ctx->storeChunk[ctx->storeSlot] = 0; ctx->storeUsed[ctx->storeSlot] = 0;  // every list is recomputed
@@ -707,7 +793,7 @@ static int assignOnce(t1k_ctx *ctx, uint64_t first, uint32_t count) {
   s.ovl = ctx->ovlBase; s.ovlCap = ctx->wOvl;
   s.ovlStart = (uint32_t *)ctx->bOvlStart.p; s.ovlCount = (uint32_t *)ctx->bOvlCount.p;
   s.sortScratch = (uint64_t *)ctx->bSortScratch.p; s.sortCap = sortCap; s.counters = a.counters;
-  s.alleleBits = 1;
+  s.alleleBits = 1; s.relax = relaxFlag;
   while ((1u << s.alleleBits) < ctx->ref.nAlleles) ++s.alleleBits;
   t1k_launch_select(ctx, s, nWg);
   T1K_HIP(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
@@ -715,76 +801,17 @@ static int assignOnce(t1k_ctx *ctx, uint64_t first, uint32_t count) {
   double t3 = nowMs();
   if (hc[2]) return capacityError(ctx, hc[2]);
   ctx->nOvl = hc[1];
-  const int maxCells = 340 * 340;
-  const int slowBlocks = 64;
-  // alignment queues (equal spans | spans differing by <= 4 | wider): striped arenas appended to by k_fullalign, then made dense
-  const uint32_t qSegCap = (uint32_t)(ctx->nOvl / T1K_NSTRIPE * 2 + 1024);
-  const size_t qDense = (size_t)ctx->nOvl + 1, qStr = (size_t)qSegCap * T1K_NSTRIPE;
-  // The group records, the work lists and the candidates are dead from here on: the alignment queues, their sort keys and the trace
-  // rows live in that memory when it is large enough (every arena of its own is more fresh VRAM for the driver to zero).
-  const size_t queueBytes = ((qDense + qStr) * 3 * 4 + 255) & ~(size_t)255, keyBytes = (qStr * 2 + qDense * 2) * 8 + qDense * 4;
-  char *queueMem = nullptr;
-  if (ctx->bWgGroups.bytes >= queueBytes + keyBytes) queueMem = (char *)ctx->bWgGroups.p;
-  else {
-    if ((rc = t1k_ensure(ctx, ctx->bSlowQueue, queueBytes + keyBytes))) return rc;
-    queueMem = (char *)ctx->bSlowQueue.p;
-  }
-  FullArgs f{};
-  f.ref = ctx->ref; f.reads = rd; f.relax = relaxFlag; f.ovl = s.ovl; f.nOvl = ctx->nOvl;
-  uint32_t *qEq = (uint32_t *)queueMem, *qBand = qEq + qDense, *qWide = qBand + qDense;
-  f.eqStr = qWide + qDense; f.bandStr = f.eqStr + qStr; f.wideStr = f.bandStr + qStr; f.segCap = qSegCap; f.counters = a.counters;
-  // sort keys of the equal / band queues: striped | dense | sorted (scratch of the radix sort), and the unsorted dense gid lists
-  f.eqKeyStr = (unsigned long long *)(queueMem + queueBytes); f.bandKeyStr = f.eqKeyStr + qStr;
-  unsigned long long *kDense = f.bandKeyStr + qStr, *kSorted = kDense + qDense;
-  uint32_t *vDense = (uint32_t *)(kSorted + qDense);
-  ctx->covCommitted = true;  // from here on the range's coverage is in the context's arrays
-  if (!ctx->covFullLen) ctx->covFullLen = std::max(1, ctx->batchMaxLen);
-  f.fullLen = ctx->covFullLen; ctx->covFullDirty = true;
-  t1k_launch_fullalign(ctx, f);
-  T1K_HIP(ctx, hipEventRecord(ctx->ev[7], ctx->stream));
-  if ((rc = fetchCounters(ctx, hc))) return rc;
-  if (hc[2]) return capacityError(ctx, hc[2]);
-  {
-    const T1kArenaCounts ce = t1k_arena_counts(ctx, T1K_AR_EQ, qSegCap), cb = t1k_arena_counts(ctx, T1K_AR_BAND, qSegCap), cw = t1k_arena_counts(ctx, T1K_AR_WIDE, qSegCap);
-    if (ce.overflow || cb.overflow || cw.overflow) return capacityError(ctx, 64);
-    // equal / band queues: dense, then ordered by (read-end, strand, read window, allele-window hash)
-    t1k_arena_compact(ctx, T1K_AR_EQ, f.eqStr, qSegCap, vDense, ce.maxSeg);
-    t1k_arena_compact64(ctx, T1K_AR_EQ, f.eqKeyStr, qSegCap, kDense, ce.maxSeg);
-    if ((rc = t1k_sort_pairs(ctx, kDense, kSorted, vDense, qEq, (uint32_t)ce.total))) return rc;
-    t1k_arena_compact(ctx, T1K_AR_BAND, f.bandStr, qSegCap, vDense, cb.maxSeg);
-    t1k_arena_compact64(ctx, T1K_AR_BAND, f.bandKeyStr, qSegCap, kDense, cb.maxSeg);
-    if ((rc = t1k_sort_pairs(ctx, kDense, kSorted, vDense, qBand, (uint32_t)cb.total))) return rc;
-    t1k_arena_compact(ctx, T1K_AR_WIDE, f.wideStr, qSegCap, qWide, cw.maxSeg);
-    hc[8] = ce.total; hc[15] = cb.total; hc[20] = cw.total;
-  }
-  // equal spans (register-band traced DP) and spans differing by 1..4 (wider register band): flags -> runs -> fill -> apply
-  for (int kind = 0; kind < 2; ++kind) {
-    const uint32_t nJobs = (uint32_t)(kind == 0 ? hc[8] : hc[15]);
-    if (!nJobs) continue;
-    SlowArgs sl{};
-    sl.ref = ctx->ref; sl.reads = rd; sl.relax = relaxFlag; sl.ovl = s.ovl; sl.slowQueue = kind == 0 ? qEq : qBand; sl.nSlow = nJobs;
-    sl.perThread = 0; sl.maxCells = 0; sl.counters = a.counters;
-    uint32_t *flags = vDense, *runOf = (uint32_t *)kDense, *rep = (uint32_t *)kSorted;  // the sort's buffers are free again
-    t1k_launch_align_flags(ctx, sl, flags);
-    if ((rc = t1k_inclusive_sum(ctx, flags, runOf, nJobs))) return rc;
-    uint32_t nRuns = 0;
-    T1K_HIP(ctx, hipMemcpyAsync(&nRuns, runOf + (nJobs - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
-    T1K_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    t1k_launch_align_reps(ctx, flags, runOf, rep, nJobs);
-    const uint64_t stride = ((uint64_t)nRuns + 63) / 64 * 64;
-    const size_t traceBytes = stride * (size_t)(ctx->batchMaxLen + 2) * 8;
-    if (ctx->bLists.bytes >= traceBytes) sl.scratch = (uint8_t *)ctx->bLists.p;
-    else if (ctx->bCand.bytes >= traceBytes) sl.scratch = (uint8_t *)ctx->bCand.p;
-    else { if ((rc = t1k_ensure(ctx, ctx->bEqTrace, traceBytes))) return rc; sl.scratch = (uint8_t *)ctx->bEqTrace.p; } sl.runOf = runOf; sl.rep = rep; sl.nRuns = nRuns; sl.traceStride = stride;
-    t1k_launch_align_fill_apply(ctx, sl, kind == 0);
-    if (getenv("T1K_DEBUG_PHASES")) fprintf(stderr, "[t1k] %s alignments: %u jobs in %u runs of identical windows\n", kind == 0 ? "equal-span" : "band", nJobs, nRuns);
-  }
-  if (hc[20]) {  // wide length difference: general DP with row arrays in HBM
-    if ((rc = t1k_ensure(ctx, ctx->bSlowScratch, (size_t)slowBlocks * 64 * t1k_slow_per_thread(maxCells)))) return rc;
-    SlowArgs sl{};
-    sl.ref = ctx->ref; sl.reads = rd; sl.relax = relaxFlag; sl.ovl = s.ovl; sl.slowQueue = qWide; sl.nSlow = (uint32_t)hc[20];
-    sl.scratch = (uint8_t *)ctx->bSlowScratch.p; sl.perThread = t1k_slow_per_thread(maxCells); sl.maxCells = maxCells; sl.counters = a.counters;
-    t1k_launch_fullalign_slow(ctx, sl, slowBlocks);
+  // Near-best full alignments (SeqSet.hpp:2188-2285).  Without --relaxIntronAlign they only feed the per-base coverage, so a context
+  // whose coverage is deferred (t1k_ctx_set_coverage_mode) skips them here altogether: k_select has written the relaxed counts, and
+  // t1k_coverage_selected later aligns the records of the alleles whose coverage is actually read.  With it they run for the relaxed
+  // counts, and the deferred mode only leaves the coverage updates out.
+  const bool deferCov = ctx->covMode == 1;
+  if (relaxFlag || !deferCov) {
+    if (!deferCov) ctx->covCommitted = true;  // from here on the range's coverage is in the context's arrays
+    if ((rc = t1k_fullalign_phase(ctx, rd, s.ovl, ctx->nOvl, relaxFlag, deferCov ? 1 : 0, ctx->batchMaxLen, false, hc))) return rc;
+  } else {
+    T1K_HIP(ctx, hipEventRecord(ctx->ev[7], ctx->stream));
+    hc[8] = hc[15] = hc[20] = 0;
   }
   hipEvent_t evSlow = ctx->ev[9];
   T1K_HIP(ctx, hipEventRecord(evSlow, ctx->stream));

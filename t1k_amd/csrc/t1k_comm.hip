@@ -29,6 +29,7 @@ struct RcclApi {
   ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
   ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
   ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
@@ -54,6 +55,7 @@ RcclApi *rccl() {
     api.GetUniqueId = (decltype(api.GetUniqueId))sym("ncclGetUniqueId");
     api.CommInitRank = (decltype(api.CommInitRank))sym("ncclCommInitRank");
     api.CommDestroy = (decltype(api.CommDestroy))sym("ncclCommDestroy");
+    api.CommAbort = (decltype(api.CommAbort))sym("ncclCommAbort");
     api.AllReduce = (decltype(api.AllReduce))sym("ncclAllReduce");
     api.Broadcast = (decltype(api.Broadcast))sym("ncclBroadcast");
     api.AllGather = (decltype(api.AllGather))sym("ncclAllGather");
@@ -77,11 +79,19 @@ struct Hub {
   std::vector<const uint64_t *> off;
   ncclUniqueId id;
   bool failed = false;
-  void barrier() {
+  bool aborted = false;  // a rank gave up (t1k_comm_abort): nobody waits for it any more, every collective returns an error
+  // false: the job was aborted (before or while waiting)
+  bool barrier() {
     std::unique_lock<std::mutex> lk(m);
+    if (aborted) return false;
     const uint64_t g = gen;
     if (++arrived == n) { arrived = 0; ++gen; cv.notify_all(); }
-    else cv.wait(lk, [&] { return gen != g; });
+    else cv.wait(lk, [&] { return gen != g || aborted; });
+    return !aborted;
+  }
+  void abort() {
+    { std::lock_guard<std::mutex> g(m); aborted = true; }
+    cv.notify_all();
   }
 };
 
@@ -109,6 +119,7 @@ struct t1k_comm {
   ncclComm_t nccl = nullptr;
   Hub *hub = nullptr;       // shared by the ranks of one process (owned by the t1k_comm_group)
   T1kDevBuf tmp, ptrs;
+  bool aborted = false;
   std::string err;
 };
 
@@ -116,7 +127,11 @@ struct t1k_comm_group {
   Hub hub;
 };
 
-static int commFail(t1k_comm *c, int code, const std::string &m) { if (c) c->err = m; return code; }
+// (a collective that fails on one rank leaves the others at its next meeting point: the whole job is abandoned with it)
+static int commFail(t1k_comm *c, int code, const std::string &m) {
+  if (c) { c->err = m; if (c->hub && c->nRanks > 1) c->hub->abort(); }
+  return code;
+}
 #define CM_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return commFail(c, T1K_ERR_DEVICE, std::string(#call) + ": " + hipGetErrorString(e_)); } while (0)
 #define CM_NCCL(call) do { ncclResult_t r_ = (call); if (r_ != ncclSuccess) return commFail(c, T1K_ERR_DEVICE, std::string(#call) + ": " + rccl()->GetErrorString(r_)); } while (0)
 
@@ -161,15 +176,15 @@ int t1k_comm_init(t1k_ctx *ctx, int nRanks, int rank, const void *id128, t1k_com
     // devices of all ranks: distinct -> RCCL
     static_assert(sizeof(void *) >= sizeof(int), "");
     h.ptr[rank] = (const void *)(intptr_t)(ctx->device + 1);
-    h.barrier();
+    (void)h.barrier();
     bool distinct = true;
     for (int a = 0; a < nRanks; ++a) for (int b = a + 1; b < nRanks; ++b) if (h.ptr[a] == h.ptr[b]) distinct = false;
-    h.barrier();
+    (void)h.barrier();
     if (transport < 0) wantRccl = distinct;
     if (wantRccl && !distinct) return commFail(c, T1K_ERR_ARG, "t1k_comm_init: RCCL needs one device per rank");
     if (wantRccl) {
       if (rank == 0) { if (!rccl()->err.empty() || rccl()->GetUniqueId(&h.id) != ncclSuccess) h.failed = true; }
-      h.barrier();
+      (void)h.barrier();
       if (h.failed) return commFail(c, T1K_ERR_DEVICE, "t1k_comm_init: " + (rccl()->err.empty() ? std::string("ncclGetUniqueId failed") : rccl()->err));
       id = h.id;
     }
@@ -202,7 +217,7 @@ int t1k_comm_bind(t1k_comm *c, t1k_ctx *ctx) {
 
 void t1k_comm_destroy(t1k_comm *c) {
   if (!c) return;
-  if (c->nccl) { (void)rccl()->CommDestroy(c->nccl); (void)hipGetLastError(); }
+  if (c->nccl) { (void)rccl()->CommDestroy(c->nccl); (void)hipGetLastError(); }  // (an aborted communicator is gone already)
   if (c->ctx) (void)hipSetDevice(c->ctx->device);
   if (c->tmp.p) (void)t1k_dev_free(c->tmp.p);
   if (c->ptrs.p) (void)t1k_dev_free(c->ptrs.p);
@@ -213,12 +228,24 @@ int t1k_comm_rank(const t1k_comm *c) { return c ? c->rank : 0; }
 int t1k_comm_size(const t1k_comm *c) { return c ? c->nRanks : 1; }
 int t1k_comm_is_rccl(const t1k_comm *c) { return c && c->useRccl ? 1 : 0; }
 
-void t1k_comm_barrier_local(t1k_comm *c) { if (c && c->hub) c->hub->barrier(); }
+void t1k_comm_barrier_local(t1k_comm *c) { if (c && c->hub) (void)c->hub->barrier(); }
+
+// A rank that cannot go on (a failed stage, out of memory, ...) says so before it returns: the in-process ranks waiting for it at a
+// meeting point are released, RCCL operations in flight are torn down, and every later collective of the job returns T1K_ERR_STATE
+// instead of waiting for a rank that will never come.
+int t1k_comm_abort(t1k_comm *c) {
+  if (!c) return T1K_ERR_ARG;
+  c->aborted = true;
+  if (c->hub) c->hub->abort();
+  if (c->nccl && rccl()->CommAbort) { (void)rccl()->CommAbort(c->nccl); c->nccl = nullptr; (void)hipGetLastError(); }
+  return T1K_OK;
+}
 
 // in place sum over the ranks of `count` elements at dev (kind 0: int32, 1: f64); blocking
 int t1k_comm_allreduce(t1k_comm *c, void *dev, uint64_t count, int kind) {
   if (!c || !dev) return T1K_ERR_ARG;
   if (c->nRanks == 1 || count == 0) return T1K_OK;
+  if (c->aborted) return commFail(c, T1K_ERR_STATE, "the job was aborted");
   t1k_ctx *ctx = c->ctx;
   CM_HIP(hipSetDevice(ctx->device));
   if (c->useRccl) {
@@ -232,17 +259,17 @@ int t1k_comm_allreduce(t1k_comm *c, void *dev, uint64_t count, int kind) {
   if ((rc = t1k_ensure(ctx, c->tmp, count * esz)) || (rc = t1k_ensure(ctx, c->ptrs, (size_t)c->nRanks * 8))) return commFail(c, rc, ctx->err);
   CM_HIP(hipStreamSynchronize(ctx->stream));
   h.ptr[c->rank] = dev;
-  h.barrier();
+  if (!h.barrier()) return commFail(c, T1K_ERR_STATE, "another rank of the job failed: the exchange was abandoned");
   std::vector<const void *> all(h.ptr.begin(), h.ptr.end());
   CM_HIP(hipMemcpyAsync(c->ptrs.p, all.data(), (size_t)c->nRanks * 8, hipMemcpyHostToDevice, ctx->stream));
   const unsigned nb = (unsigned)((count + 255) / 256);
   if (kind == 0) hipLaunchKernelGGL(k_sum_ranks_i32, dim3(nb), dim3(256), 0, ctx->stream, (int32_t *)c->tmp.p, (const int32_t *const *)c->ptrs.p, c->nRanks, count);
   else hipLaunchKernelGGL(k_sum_ranks_f64, dim3(nb), dim3(256), 0, ctx->stream, (double *)c->tmp.p, (const double *const *)c->ptrs.p, c->nRanks, count);
   CM_HIP(hipStreamSynchronize(ctx->stream));
-  h.barrier();  // everybody has read everybody's input
+  if (!h.barrier()) return commFail(c, T1K_ERR_STATE, "another rank of the job failed: the exchange was abandoned");  // everybody has read everybody's input
   CM_HIP(hipMemcpyAsync(dev, c->tmp.p, count * esz, hipMemcpyDeviceToDevice, ctx->stream));
   CM_HIP(hipStreamSynchronize(ctx->stream));
-  h.barrier();
+  if (!h.barrier()) return commFail(c, T1K_ERR_STATE, "another rank of the job failed: the exchange was abandoned");
   return T1K_OK;
 }
 
@@ -250,6 +277,7 @@ int t1k_comm_allreduce(t1k_comm *c, void *dev, uint64_t count, int kind) {
 int t1k_comm_allgather_u64(t1k_comm *c, const uint64_t *mine, uint32_t k, uint64_t *all) {
   if (!c || !mine || !all) return T1K_ERR_ARG;
   if (c->nRanks == 1) { memcpy(all, mine, (size_t)k * 8); return T1K_OK; }
+  if (c->aborted) return commFail(c, T1K_ERR_STATE, "the job was aborted");
   t1k_ctx *ctx = c->ctx;
   CM_HIP(hipSetDevice(ctx->device));
   if (c->useRccl) {
@@ -264,9 +292,9 @@ int t1k_comm_allgather_u64(t1k_comm *c, const uint64_t *mine, uint32_t k, uint64
   }
   Hub &h = *c->hub;
   h.off[c->rank] = mine;
-  h.barrier();
+  if (!h.barrier()) return commFail(c, T1K_ERR_STATE, "another rank of the job failed: the exchange was abandoned");
   for (int r = 0; r < c->nRanks; ++r) memcpy(all + (size_t)r * k, h.off[r], (size_t)k * 8);
-  h.barrier();
+  if (!h.barrier()) return commFail(c, T1K_ERR_STATE, "another rank of the job failed: the exchange was abandoned");
   return T1K_OK;
 }
 
@@ -274,6 +302,7 @@ int t1k_comm_allgather_u64(t1k_comm *c, const uint64_t *mine, uint32_t k, uint64
 // (recvOff[nRanks + 1] is this rank's view: what it gets from each peer; sizes must have been agreed on beforehand)
 int t1k_comm_alltoallv(t1k_comm *c, const void *sendbuf, const uint64_t *sendOff, void *recvbuf, const uint64_t *recvOff) {
   if (!c || !sendOff || !recvOff) return T1K_ERR_ARG;
+  if (c->aborted) return commFail(c, T1K_ERR_STATE, "the job was aborted");
   t1k_ctx *ctx = c->ctx;
   CM_HIP(hipSetDevice(ctx->device));
   const int N = c->nRanks;
@@ -298,20 +327,21 @@ int t1k_comm_alltoallv(t1k_comm *c, const void *sendbuf, const uint64_t *sendOff
   Hub &h = *c->hub;
   CM_HIP(hipStreamSynchronize(ctx->stream));
   h.ptr[c->rank] = sendbuf; h.off[c->rank] = sendOff;
-  h.barrier();
+  if (!h.barrier()) return commFail(c, T1K_ERR_STATE, "another rank of the job failed: the exchange was abandoned");
   for (int p = 0; p < N; ++p) {  // pull what peer p holds for this rank
     const uint64_t *po = h.off[p];
     const uint64_t b = po[c->rank + 1] - po[c->rank];
     if (b) CM_HIP(hipMemcpyAsync((char *)recvbuf + recvOff[p], (const char *)h.ptr[p] + po[c->rank], b, hipMemcpyDefault, ctx->stream));
   }
   CM_HIP(hipStreamSynchronize(ctx->stream));
-  h.barrier();
+  if (!h.barrier()) return commFail(c, T1K_ERR_STATE, "another rank of the job failed: the exchange was abandoned");
   return T1K_OK;
 }
 
 // variable-length all-gather of device bytes: rank r's `bytes[r]` bytes land at out + displ[r] on every rank
 int t1k_comm_allgatherv(t1k_comm *c, const void *mine, const uint64_t *bytes, const uint64_t *displ, void *out) {
   if (!c || !bytes || !displ) return T1K_ERR_ARG;
+  if (c->aborted) return commFail(c, T1K_ERR_STATE, "the job was aborted");
   t1k_ctx *ctx = c->ctx;
   CM_HIP(hipSetDevice(ctx->device));
   const int N = c->nRanks;
@@ -332,11 +362,11 @@ int t1k_comm_allgatherv(t1k_comm *c, const void *mine, const uint64_t *bytes, co
   Hub &h = *c->hub;
   CM_HIP(hipStreamSynchronize(ctx->stream));
   h.ptr[c->rank] = mine;
-  h.barrier();
+  if (!h.barrier()) return commFail(c, T1K_ERR_STATE, "another rank of the job failed: the exchange was abandoned");
   for (int r = 0; r < N; ++r)
     if (bytes[r]) CM_HIP(hipMemcpyAsync((char *)out + displ[r], h.ptr[r], bytes[r], hipMemcpyDefault, ctx->stream));
   CM_HIP(hipStreamSynchronize(ctx->stream));
-  h.barrier();
+  if (!h.barrier()) return commFail(c, T1K_ERR_STATE, "another rank of the job failed: the exchange was abandoned");
   return T1K_OK;
 }
 

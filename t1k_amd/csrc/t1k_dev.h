@@ -59,7 +59,7 @@ struct T1kOvl {
 
 // The same record as the overlap store keeps it (16 bytes: the store holds the lists of a whole window of fragments, tens of GB at
 // 32 bytes each, and mate pairing streams every list it joins):
-//   lo = allele:24 | seqStart:20 | (seqEnd - seqStart):12 | strand is '-':1        hi = readStart:10 | readEnd:10 | matchCnt:12 | relaxed:12 | leftClip:10 | rightClip:10
+//   lo = allele:24 | seqStart:20 | (seqEnd - seqStart):12 | strand is '-':1 | near-best:1        hi = readStart:10 | readEnd:10 | matchCnt:12 | relaxed:12 | leftClip:10 | rightClip:10
 // Ranges: alleles < 2^24 and allele lengths < 2^20 are enforced by t1k_ref_upload, reads are at most T1K_MAX_READ_LEN (320) long;
 // t1k_ovl_pack reports anything that does not fit (an internal error, never silent).
 struct T1kOvlP { unsigned long long lo, hi; };
@@ -67,7 +67,8 @@ __host__ __device__ __forceinline__ bool t1k_ovl_pack(const T1kOvl &o, T1kOvlP &
   const int span = o.seqEnd - o.seqStart;
   const bool ok = o.allele < (1u << 24) && o.seqStart >= 0 && o.seqStart < (1 << 20) && span >= 0 && span < 4096 && o.readStart < 1024 && o.readEnd < 1024 &&
                   o.matchCnt < 4096 && o.relaxed < 4096 && o.leftClip < 1024 && o.rightClip < 1024;
-  p.lo = (unsigned long long)o.allele | ((unsigned long long)(uint32_t)o.seqStart << 24) | ((unsigned long long)(uint32_t)span << 44) | ((unsigned long long)((o.flags >> 1) & 1u) << 56);
+  p.lo = (unsigned long long)o.allele | ((unsigned long long)(uint32_t)o.seqStart << 24) | ((unsigned long long)(uint32_t)span << 44) | ((unsigned long long)((o.flags >> 1) & 1u) << 56) |
+         ((unsigned long long)(o.flags & 1u) << 57);
   p.hi = (unsigned long long)o.readStart | ((unsigned long long)o.readEnd << 10) | ((unsigned long long)o.matchCnt << 20) | ((unsigned long long)o.relaxed << 32) |
          ((unsigned long long)o.leftClip << 44) | ((unsigned long long)o.rightClip << 54);
   return ok;
@@ -77,7 +78,7 @@ __host__ __device__ __forceinline__ T1kOvl t1k_ovl_unpack(const T1kOvlP &p) {
   o.allele = (uint32_t)(p.lo & 0xFFFFFFu);
   o.seqStart = (int32_t)((p.lo >> 24) & 0xFFFFFu);
   o.seqEnd = o.seqStart + (int32_t)((p.lo >> 44) & 0xFFFu);
-  o.flags = (uint32_t)((p.lo >> 56) & 1u) << 1;
+  o.flags = ((uint32_t)((p.lo >> 56) & 1u) << 1) | (uint32_t)((p.lo >> 57) & 1u);
   o.readStart = (uint16_t)(p.hi & 0x3FFu); o.readEnd = (uint16_t)((p.hi >> 10) & 0x3FFu);
   o.matchCnt = (uint16_t)((p.hi >> 20) & 0xFFFu); o.relaxed = (uint16_t)((p.hi >> 32) & 0xFFFu);
   o.leftClip = (uint16_t)((p.hi >> 44) & 0x3FFu); o.rightClip = (uint16_t)((p.hi >> 54) & 0x3FFu);
@@ -712,6 +713,8 @@ struct t1k_ctx {
   unsigned long long lastCapFlags = 0;
   bool scaledOnce = false;
   bool covCommitted = false;     // the running range has started adding to the coverage arrays (no retry after that)
+  int covMode = 0;               // t1k_ctx_set_coverage_mode: 0 = t1k_assign_range adds per-base coverage (eager), 1 = it does not (deferred to
+                                 // t1k_coverage_selected over the kept lists, or not wanted at all)
   double msAlloc = 0;            // wall time spent in hipMalloc (fresh VRAM is zeroed by the driver: ~35 ms per GB)
   uint64_t bytesAlloc = 0;
   T1kDevBuf bCand, bExt, bCandStart, bCandCount, bOvlStart, bOvlCount, bCounters, bSlowQueue, bSlowScratch, bSortScratch, bEqTrace, bSortTmp, bSlowKeys, bJobSort;

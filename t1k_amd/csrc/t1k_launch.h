@@ -50,6 +50,7 @@ struct SelectArgs {
   uint64_t *sortScratch;   // [wg][sortCap] packed keys (per-workgroup stride: sortCap * 6 words, shared with k_truncate)
   uint32_t sortCap;
   int alleleBits;          // bits of an allele index
+  int relax;               // --relaxIntronAlign: the relaxed match counts come from the full alignments (else k_select writes them)
   unsigned long long *counters;
 };
 
@@ -57,6 +58,7 @@ struct FullArgs {
   T1kRefDev ref;
   T1kReadsDev reads;
   int relax;
+  int noCov;               // the alignments only feed the relaxed counts: no per-base coverage is added (t1k_ctx_set_coverage_mode 1)
   int fullLen;             // span counted in ref.covFull
   T1kOvl *ovl;
   uint64_t nOvl;
@@ -69,6 +71,7 @@ struct SlowArgs {
   T1kRefDev ref;
   T1kReadsDev reads;
   int relax;
+  int noCov;
   T1kOvl *ovl;
   const uint32_t *slowQueue;  // (sorted) queue of overlap indices
   uint32_t nSlow;
@@ -146,6 +149,8 @@ int t1k_inclusive_sum(t1k_ctx *ctx, const uint32_t *in, uint32_t *out, uint32_t 
 void t1k_launch_truncate(t1k_ctx *ctx, const TruncArgs &a, int nWg);
 void t1k_launch_coverage_scan(t1k_ctx *ctx, const T1kRefDev &ref, int32_t *out, const uint64_t *outOff);
 int t1k_fetch_counters(t1k_ctx *ctx, unsigned long long *h);
+// near-best full alignments of nOvl working records (t1k_capi.hip): relaxed counts + (unless noCov) per-base coverage
+int t1k_fullalign_phase(t1k_ctx *ctx, const T1kReadsDev &rd, T1kOvl *ovl, uint64_t nOvl, int relaxFlag, int noCov, int maxLen, bool exactQueues, unsigned long long *hc);
 struct T1kArenaCounts { uint64_t total; uint32_t maxSeg; bool overflow; };
 T1kArenaCounts t1k_arena_counts(const t1k_ctx *ctx, int arena, uint32_t segCap);  // from the last t1k_fetch_counters
 void t1k_launch_coverage_add(t1k_ctx *ctx, int32_t *dst, int32_t *src, uint64_t n);

@@ -28,6 +28,35 @@ def test_library_exports_every_declared_symbol(built):
     t1k_amd.lib()  # argtypes binding resolves every function it names
 
 
+def test_comm_bind_accepts_a_job_and_a_context(monkeypatch):
+    """bench.py binds its communicator to each step's Job and back to the anchor Context between steps (bind(Context)
+    used to raise AttributeError on every rank): both owner kinds must reach t1k_comm_bind with their context handle"""
+    import t1k_amd.capi as capi
+    calls = []
+
+    class FakeLib:
+        def t1k_comm_bind(self, h, ctx):
+            calls.append((h, ctx))
+            return 0
+
+        def t1k_job_ctx(self, h):
+            return 1000 + h
+
+    monkeypatch.setattr(capi, "lib", lambda: FakeLib())
+    comm = capi.Comm.__new__(capi.Comm)
+    comm.h = 7
+    job = capi.Job.__new__(capi.Job)
+    job.h = 5
+    cx = capi.Context.__new__(capi.Context)
+    cx.h = 22
+    try:
+        comm.bind(job)
+        comm.bind(cx)
+        assert calls == [(7, 1005), (7, 22)]
+    finally:
+        comm.h = job.h = cx.h = None  # nothing real to destroy
+
+
 def test_defaults_match_reference(built):
     p = t1k_amd.JobParams()
     t1k_amd.lib().t1k_job_params_default(C.byref(p))

@@ -1,0 +1,124 @@
+"""GPU tests (pytest -m gpu) of the per-base coverage modes.  posWeight (SeqSet.hpp:2253-2274) is read through
+GetSeqMissingBaseCoverage (2717-2755) for the alleles on selection's candidate lists only (Genotyper.hpp:1754, 1870-1878), so a job keeps
+the windows' overlap lists and adds coverage for those alleles inside select() (t1k_coverage_selected) instead of for all alleles in
+every range.  Checked here: the stage against the eager per-range updates base by base, and the executable in every mode (deferred,
+eager, a memory budget that makes later windows fall back to eager, small batches, two ranks) against the reference binary on
+samples mixed from several individuals -- genes with more than two allele types are where missingCoverage decides the call."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import util
+import t1k_amd
+import test_oracle_golden as tog
+
+pytestmark = pytest.mark.gpu
+GENO = os.path.join(util.ROOT, "t1k_amd", "bin", "genotyper")
+
+
+def _reads(prefix):
+    return [s for _, _, s in t1k_amd.read_fastx(prefix + "_1.fq")] + [s for _, _, s in t1k_amd.read_fastx(prefix + "_2.fq")]
+
+
+@pytest.mark.parametrize("kind,sim,relax,batch", [("rna", 0.9, 0, None), ("rna", 0.97, 0, "64"), ("dna", 0.9, 1, None), ("dna", 0.8, 1, "100")])
+def test_coverage_selected_stage_equals_eager_updates(built, tmp_path, kind, sim, relax, batch):
+    """t1k_assign_range in deferred mode leaves the coverage arrays untouched and produces the same overlap lists (relaxed counts
+    included); t1k_coverage_selected then yields, for every selected allele, exactly the per-base coverage the eager mode accumulates,
+    and nothing for the others.  Weighted read-ends, indels (traced DP alignments), several gather batches."""
+    tmp = str(tmp_path)
+    ref = os.path.join(tmp, "ref.fa")
+    util.synth_ref("ref-" + kind, ref, genes=4, scale=0.04, seed=31)
+    pfx = os.path.join(tmp, "r")
+    util.synth_reads(ref, pfx, pairs=180, len=150, seed=32, sub=0.006, indel=0.004, fragmean=420 if kind == "dna" else 350)
+    reads = _reads(pfx)
+    rng = np.random.default_rng(7)
+    weights = rng.integers(1, 6, size=len(reads)).astype(np.uint32)
+    names, seqs, masks, _ = t1k_amd.load_reference_fasta(ref)
+    kw = dict(ref_seq_similarity=sim, relax_intron_align=relax)
+    eager = t1k_amd.Context(**kw)
+    eager.ref_upload(seqs, masks)
+    eager.reads_upload(reads, weights)
+    eager.assign()
+    cnt_e, ovl_e = eager.overlaps()
+    cov_e = eager.coverage()
+    assert cov_e.sum() > 0
+    lazy = t1k_amd.Context(**kw)
+    lazy.set_coverage_mode(True)
+    lazy.ref_upload(seqs, masks)
+    lazy.reads_upload(reads, weights)
+    lazy.assign()
+    cnt_d, ovl_d = lazy.overlaps()
+    assert np.array_equal(cnt_e, cnt_d) and ovl_e.tobytes() == ovl_d.tobytes()
+    assert not lazy.coverage().any()
+    rs = lazy.detach_readset()
+    assert rs.size() == len(reads) and rs.bytes() > 0
+    sel = (rng.random(len(seqs)) < 0.3).astype(np.uint8)
+    covered = [a for a in range(len(seqs)) if cov_e[sum(len(s) for s in seqs[:a]):sum(len(s) for s in seqs[:a + 1])].any()]
+    sel[covered[:3]] = 1
+    if batch:
+        os.environ["T1K_COVER_BATCH"] = batch
+    try:
+        n = lazy.coverage_selected(rs, sel)
+    finally:
+        os.environ.pop("T1K_COVER_BATCH", None)
+    assert n > 0
+    cov_d = lazy.coverage()
+    off = 0
+    for a, s in enumerate(seqs):
+        want = cov_e[off:off + len(s)] if sel[a] else np.zeros(len(s), np.int32)
+        assert np.array_equal(cov_d[off:off + len(s)], want), "allele %d (%s)" % (a, "selected" if sel[a] else "not selected")
+        off += len(s)
+    # a second call adds the same again (the arrays are sums): the read set is still intact
+    assert lazy.coverage_selected(rs, sel) == n
+    assert np.array_equal(lazy.coverage(), 2 * cov_d)
+    rs.close(); lazy.close(); eager.close()
+
+
+MODES = {
+    "deferred": {},
+    "eager": {"T1K_COVERAGE": "eager"},
+    "budget_fallback": {"T1K_FIRST_WINDOW": "16", "T1K_WINDOW": "64", "T1K_WINDOW_GROWTH": "1", "T1K_BATCH": "16", "T1K_PAIR_BATCH": "16", "T1K_ARCHIVE_GB": "0.0000001"},
+    "small_windows_small_batches": {"T1K_FIRST_WINDOW": "24", "T1K_WINDOW": "96", "T1K_BATCH": "16", "T1K_PAIR_BATCH": "32", "T1K_COVER_BATCH": "64", "T1K_PIPELINES": "2"},
+    "two_ranks": {"T1K_GPUS": "0,0"},
+    "three_ranks_small_windows": {"T1K_GPUS": "0,0,0", "T1K_FIRST_WINDOW": "16", "T1K_WINDOW": "48", "T1K_BATCH": "16"},
+}
+
+
+@pytest.mark.parametrize("case", range(len(tog.LIVE_TABLE_CASES)))
+def test_coverage_modes_on_mixed_samples_vs_reference_binary(built, tmp_path, case):
+    """every coverage mode of the job against the reference binary, on samples mixed from several simulated individuals (genes with
+    three and more allele types: Genotyper.hpp:1697-1996 reads missingCoverage there) with the selection options of the oracle's live
+    cases, --relaxIntronAlign among them: all output files byte for byte"""
+    util.need(util.REF_BIN)
+    kind, genes, scale, parts, length, flags = tog.LIVE_TABLE_CASES[case]
+    tmp = str(tmp_path)
+    ref = os.path.join(tmp, "ref.fa")
+    util.synth_ref(kind, ref, genes=genes, scale=scale, seed=900 + case)
+    for p in range(parts):
+        util.synth_reads(ref, os.path.join(tmp, "p%d" % p), pairs=120 + 40 * case, len=length, seed=1000 + 10 * case + p, sub=0.004)
+    for m in ("1", "2"):
+        with open(os.path.join(tmp, "r_%s.fq" % m), "w") as o:
+            for p in range(parts):
+                o.write(open(os.path.join(tmp, "p%d_%s.fq" % (p, m))).read())
+    args = ["-f", ref, "-1", os.path.join(tmp, "r_1.fq"), "-2", os.path.join(tmp, "r_2.fq")] + flags
+    a = os.path.join(tmp, "ref_out")
+    subprocess.run([util.REF_BIN] + args + ["-o", a, "-t", "2"], check=True, stderr=subprocess.PIPE, stdout=subprocess.PIPE)
+    asked = {}
+    for mode, env in MODES.items():
+        b = os.path.join(tmp, mode)
+        r = subprocess.run([GENO] + args + ["-o", b], stderr=subprocess.PIPE, text=True, env=dict(os.environ, T1K_DEBUG_PHASES="1", **env))
+        assert r.returncode == 0, (mode, r.stderr[-2000:])
+        for suf in ("_genotype.tsv", "_allele.tsv", "_aligned_1.fa", "_aligned_2.fa"):
+            assert open(a + suf, "rb").read() == open(b + suf, "rb").read(), (mode, suf)
+        m = re.findall(r"coverage of the (\d+) alleles on selection's lists: (\d+) records", r.stderr)
+        asked[mode] = [(int(x), int(y)) for x, y in m]
+        kept = re.findall(r"read sets of (\d+) of (\d+) windows kept", r.stderr)
+        if mode == "eager":
+            assert not m and not kept
+        if mode == "budget_fallback":
+            assert kept and all(0 < int(k) < int(w) for k, w in kept), r.stderr[-1500:]
+    if parts >= 3:  # three individuals: some gene carries more than two types, so selection asked for coverage
+        assert asked["deferred"] and asked["deferred"][0][0] > 0 and asked["deferred"][0][1] > 0, asked
