@@ -160,8 +160,10 @@ int t1k_rowset_rows_download(t1k_rowset *rs, uint64_t first, uint32_t count, uin
  *   t1k_rowset_exchange           every fragment row goes to the rank that owns its pattern (hash mod nRanks); that rank coalesces the
  *                                 group over ALL its fragments in global order, so group contents do not depend on the sharding
  *   t1k_rowset_groups_gather      every rank's group table on every rank; merged by first fragment on the host (the job layer)
- *   t1k_em_shard                  t1k_em_update runs the row pass on [rowBegin, rowEnd) only and all-reduces the contribution array
- *                                 (every element has one writer: exact), then the column pass everywhere: same doubles as on one GPU */
+ *   t1k_em_shard                  t1k_em_update runs the row pass on [rowBegin, rowEnd) only (collective: the ranks' ranges must partition the
+ *                                 read groups in rank order), all-gathers the ranks' pieces of the row-major contribution array (every
+ *                                 element has one writer: nothing is added, bytes / nRanks per rank), then the column pass everywhere in
+ *                                 group order: same doubles as on one GPU */
 typedef struct t1k_comm_group t1k_comm_group;
 int t1k_comm_unique_id(void *id128);
 t1k_comm_group *t1k_comm_group_create(int nRanks);
@@ -285,6 +287,10 @@ double t1k_alloc_ms(t1k_ctx *ctx, uint64_t *bytes);
 int t1k_genotyper_main(int argc, char **argv);
 /* argv-compatible replacement of the reference's fastq-extractor main() (FastqExtractor.cpp:260-626; run-t1k:377-403) */
 int t1k_extractor_main(int argc, char **argv);
+/* argv-compatible replacement of the reference's bam-extractor main() (BamExtractor.cpp:463-949; run-t1k:350): candidate reads from a
+ * coordinate-sorted BAM file -- reads over the gene intervals, reads on alternative contigs and unaligned reads that pass
+ * IsLowComplexity + SeqSet::HasHitInSet (t1k_extract_batch).  The BAM container is read natively (BGZF blocks inflated in parallel). */
+int t1k_bam_extractor_main(int argc, char **argv);
 /* argv-compatible replacement of the reference's analyzer main() (Analyzer.cpp:236-733; run-t1k:438-449): re-assignment of the aligned reads
  * to the selected alleles and the per-barcode expression table; novel-variant calling (VariantCaller.hpp) is not built */
 int t1k_analyzer_main(int argc, char **argv);

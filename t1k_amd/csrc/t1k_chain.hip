@@ -412,12 +412,17 @@ __global__ __launch_bounds__(WG) T1K_OCC8 void k_seed_groups(ChainArgs P) {
   uint32_t *lstLen = lstStart + maxK;               // [maxK]
   uint32_t *lstDir = lstLen + maxK;                 // [maxK]
   uint16_t *qOf = (uint16_t *)(lstDir + maxK);      // [maxK]  read offset of the used lists
+  // two bitmaps over all alleles (chunk selection, before the chunk loop of each strand): over the accumulators when they fit there
+  // (references of up to 57 344 / 106 496 sequences), else behind the list arrays (the launcher sizes the dynamic LDS for it)
+  const uint32_t A = P.ref.nAlleles;
+  const uint32_t nChunks = P.ref.kDirStride - 1;    // (the launcher refuses more than 256 chunks: sHot)
+  uint32_t *bitmaps = 2 * ((A + 31) >> 5) <= (uint32_t)(CHUNK_A * AW) ? acc : (uint32_t *)(qOf + ((maxK + 1) & ~1));
   __shared__ uint32_t warpSums[4];
-  __shared__ uint32_t sUsed[2], sGroupBase, sMin, sFallback, sPost;
+  __shared__ uint32_t sHot[8];                      // bit c: chunk c can hold an allele with three hits (this strand)
+  __shared__ uint32_t sUsed[2], sGroupBase, sFallback, sPost;
   __shared__ int sWaveMax[4];
   const int tid = threadIdx.x;
   const uint32_t kmask = (1u << (2 * k)) - 1;
-  const uint32_t A = P.ref.nAlleles;
   const uint32_t stride = P.recStride;
   for (uint32_t i = tid; i < CHUNK_A * AW; i += WG) acc[i] = (i % AW) == 0 ? (uint32_t)DIAG_EMPTY : 0u;
   __syncthreads();
@@ -592,49 +597,91 @@ __global__ __launch_bounds__(WG) T1K_OCC8 void k_seed_groups(ChainArgs P) {
       const bool has0 = (uint32_t)tid < uCount, has1 = (uint32_t)tid + WG < uCount;
       uint32_t st0 = 0, ln0 = 0, st1 = 0, ln1 = 0, cur0 = 0, cur1 = 0;
       const uint32_t *dir0 = nullptr, *dir1 = nullptr;  // chunk-directory rows of this lane's lists (long lists only)
-      if (has0) { st0 = lstStart[uBegin + tid]; ln0 = lstLen[uBegin + tid]; const uint32_t d = lstDir[uBegin + tid]; if (d != T1K_NO_DIR) dir0 = P.ref.kDir + (uint64_t)d * P.ref.kDirStride; }
-      if (has1) { st1 = lstStart[uBegin + tid + WG]; ln1 = lstLen[uBegin + tid + WG]; const uint32_t d = lstDir[uBegin + tid + WG]; if (d != T1K_NO_DIR) dir1 = P.ref.kDir + (uint64_t)d * P.ref.kDirStride; }
-      // allele of the posting under each cursor (0xFFFFFFFF: list exhausted); kept up to date by the slice search below
-      uint32_t nx0 = (has0 && ln0) ? P.ref.kPost[st0].allele : 0xFFFFFFFFu, nx1 = (has1 && ln1) ? P.ref.kPost[st1].allele : 0xFFFFFFFFu;
-      // first posting with allele >= the end of chunk ci, at or after cur: one directory load, or a bisection of a short list
-      auto sliceEnd = [&](uint32_t st, uint32_t cur, uint32_t ln, const uint32_t *dir, uint32_t ci, uint32_t c1, uint32_t &nxt) -> uint32_t {
-        uint32_t lo;
-        if (dir) lo = dir[ci + 1];
-        else {
-          lo = cur + 1;  // the posting under the cursor is known to be < c1
-          uint32_t hi = ln;
-          while (lo < hi) { uint32_t m = (lo + hi) >> 1; if (P.ref.kPost[st + m].allele < c1) lo = m + 1; else hi = m; }
+      uint32_t row0 = T1K_NO_DIR, row1 = T1K_NO_DIR;
+      if (has0) { st0 = lstStart[uBegin + tid]; ln0 = lstLen[uBegin + tid]; row0 = lstDir[uBegin + tid]; if (row0 != T1K_NO_DIR) dir0 = P.ref.kDir + (uint64_t)row0 * P.ref.kDirStride; }
+      if (has1) { st1 = lstStart[uBegin + tid + WG]; ln1 = lstLen[uBegin + tid + WG]; row1 = lstDir[uBegin + tid + WG]; if (row1 != T1K_NO_DIR) dir1 = P.ref.kDir + (uint64_t)row1 * P.ref.kDirStride; }
+      // ---- which chunks can hold a group at all.  A group needs >= 3 hits on its allele.  The k-mers of a read that are not part of
+      // a gene's conserved sequence have short lists (a handful of chance postings anywhere in the reference), and there are enough of
+      // them to put a posting or two into EVERY chunk: stepping through all chunks for them was most of this kernel's time.  So: a
+      // chunk is visited if a long list (one with a directory row: its per-chunk occupancy mask is part of the index) has a posting
+      // in it, or if some allele of it collects three postings from the short lists alone -- counted exactly with two bitmaps over
+      // all alleles (seen once / seen twice; the third sighting marks the chunk).  Every other chunk holds no allele with three hits
+      // and cannot emit a record.  mk0 / mk1: chunk occupancy of this lane's own lists (chunks < 64; beyond that: "maybe").
+      unsigned long long mk0 = 0, mk1 = 0;
+      {
+        const uint32_t BW = (A + 31) >> 5;
+        uint32_t *b1 = bitmaps, *b2 = bitmaps + BW;
+        for (uint32_t i = tid; i < 2 * BW; i += WG) bitmaps[i] = 0;
+        if (tid < 8) sHot[tid] = 0;
+        __syncthreads();
+        auto mark = [&](bool has, uint32_t st, uint32_t ln, uint32_t row, unsigned long long &mk) {
+          if (!has || !ln) return;
+          if (row != T1K_NO_DIR) {
+            const unsigned long long *m = P.ref.kDirMask + (uint64_t)row * P.ref.kDirMaskWords;
+            for (uint32_t w = 0; w < P.ref.kDirMaskWords; ++w) {
+              const unsigned long long v = m[w];
+              if (w == 0) mk = v;
+              if ((uint32_t)v) atomicOr(&sHot[2 * w], (uint32_t)v);
+              if ((uint32_t)(v >> 32)) atomicOr(&sHot[2 * w + 1], (uint32_t)(v >> 32));
+            }
+            if (P.ref.kDirMaskWords > 1) mk = ~0ull;  // (more than 64 chunks: the directory itself answers)
+          } else {
+            for (uint32_t j0 = 0; j0 < ln; j0 += 8) {  // <= T1K_DIR_MINLEN postings; eight loads in flight
+              uint32_t al[8];
+#pragma unroll
+              for (int x = 0; x < 8; ++x) al[x] = j0 + x < ln ? P.ref.kPostAllele[st + j0 + x] : 0xFFFFFFFFu;
+#pragma unroll
+              for (int x = 0; x < 8; ++x) {
+                if (al[x] == 0xFFFFFFFFu) continue;
+                const uint32_t ci = al[x] / CHUNK_A, bit = 1u << (al[x] & 31);
+                mk |= ci < 64 ? 1ull << ci : 0ull;
+                if (atomicOr(&b1[al[x] >> 5], bit) & bit)
+                  if (atomicOr(&b2[al[x] >> 5], bit) & bit) atomicOr(&sHot[ci >> 5], 1u << (ci & 31));
+              }
+            }
+            if (nChunks > 64) mk = ~0ull;
+          }
+        };
+        mark(has0, st0, ln0, row0, mk0);
+        mark(has1, st1, ln1, row1, mk1);
+        __syncthreads();
+        if (bitmaps == acc) {  // the bitmaps lay over the accumulators: make those clean again
+          for (uint32_t i = tid; i < 2 * BW; i += WG) acc[i] = (i % AW) == 0 ? (uint32_t)DIAG_EMPTY : 0u;
+          __syncthreads();
         }
-        nxt = lo < ln ? P.ref.kPost[st + lo].allele : 0xFFFFFFFFu;
+      }
+      // first posting with allele >= bound in [lo, ln) of a short list (bisection over the allele column)
+      auto lowerBound = [&](uint32_t st, uint32_t lo, uint32_t ln, uint32_t bound) -> uint32_t {
+        uint32_t hi = ln;
+        while (lo < hi) { const uint32_t m = (lo + hi) >> 1; if (P.ref.kPostAllele[st + m] < bound) lo = m + 1; else hi = m; }
         return lo;
       };
-      for (;;) {
-        // next chunk = the CHUNK_A-aligned chunk of the smallest allele any list still holds (empty chunks are skipped)
-        if (tid == 0) sMin = 0xFFFFFFFFu;
-        __syncthreads();
-        uint32_t nxt = min(nx0, nx1);
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) nxt = min(nxt, (uint32_t)__shfl_xor((int)nxt, o, 64));
-        if ((tid & 63) == 0 && nxt != 0xFFFFFFFFu) atomicMin(&sMin, nxt);
-        __syncthreads();
-
-#ifdef T1K_SEED_PROFILE
-    { const uint64_t tn_ = __builtin_amdgcn_s_memtime(); tp_[3] += tn_ - tl_; tl_ = tn_; }
-#endif
-        if (sMin == 0xFFFFFFFFu) break;
-        const uint32_t ci = sMin / CHUNK_A, c0 = ci * CHUNK_A;
+      for (uint32_t hw = 0; hw < 8; ++hw) {
+       uint32_t hotBits = sHot[hw];
+       while (hotBits) {
+        const uint32_t ci = hw * 32 + (uint32_t)__ffs((int)hotBits) - 1;
+        hotBits &= hotBits - 1;
+        const uint32_t c0 = ci * CHUNK_A;
         const uint32_t c1 = min(c0 + CHUNK_A, A);
-        // slice of every used list inside [c0, c1)
+        // slice of every used list inside [c0, c1): long lists from their directory row, short ones by bisection from their cursor
+        // (the chunks come in ascending order, so the cursor only moves forward); lists without a posting here are not touched
         uint32_t n0 = 0, n1 = 0;
+        const bool may = ci >= 64;
         if (has0) {
-          uint32_t l = cur0;
-          if (nx0 < c1) l = sliceEnd(st0, cur0, ln0, dir0, ci, c1, nx0);
-          n0 = l - cur0; sLo[tid] = cur0; cur0 = l;
+          uint32_t lo = cur0, hi = cur0;
+          if (ln0 && (may || ((mk0 >> ci) & 1ull))) {
+            if (dir0) { lo = dir0[ci]; hi = dir0[ci + 1]; }
+            else { lo = lowerBound(st0, cur0, ln0, c0); hi = lowerBound(st0, lo, ln0, c1); }
+          }
+          n0 = hi - lo; sLo[tid] = lo; cur0 = hi;
         }
         if (has1) {
-          uint32_t l = cur1;
-          if (nx1 < c1) l = sliceEnd(st1, cur1, ln1, dir1, ci, c1, nx1);
-          n1 = l - cur1; sLo[tid + WG] = cur1; cur1 = l;
+          uint32_t lo = cur1, hi = cur1;
+          if (ln1 && (may || ((mk1 >> ci) & 1ull))) {
+            if (dir1) { lo = dir1[ci]; hi = dir1[ci + 1]; }
+            else { lo = lowerBound(st1, cur1, ln1, c0); hi = lowerBound(st1, lo, ln1, c1); }
+          }
+          n1 = hi - lo; sLo[tid + WG] = lo; cur1 = hi;
         }
 
 #ifdef T1K_SEED_PROFILE
@@ -769,6 +816,7 @@ __global__ __launch_bounds__(WG) T1K_OCC8 void k_seed_groups(ChainArgs P) {
           before += (uint32_t)((tt >> (16 * i)) & 0xFFFF);
         }
         __syncthreads();
+       }
       }
     }
     if (tid == 0) statHits += hitsLocal;
@@ -1401,7 +1449,11 @@ void t1k_launch_dp_dense(t1k_ctx *ctx, const ChainArgs &a, const uint32_t *jobs,
 int t1k_run_chain(t1k_ctx *ctx, const ChainArgs &a, int nWg, int bigBlocks, bool longReads, unsigned long long *hc) {
   const int AW = longReads ? 13 : 7;
   const size_t maxK = a.maxK;
-  const size_t lds = (size_t)CHUNK_A * AW * 4 + maxK * (5 * 4 + 2) + 4 + 64;  // accumulators | sLo, pre, lstStart, lstLen, lstDir, qOf
+  size_t lds = (size_t)CHUNK_A * AW * 4 + maxK * (5 * 4 + 2) + 4 + 64;  // accumulators | sLo, pre, lstStart, lstLen, lstDir, qOf
+  const size_t bitmapWords = 2 * (((size_t)a.ref.nAlleles + 31) / 32);        // chunk selection: two bitmaps over all alleles ...
+  if (bitmapWords > (size_t)CHUNK_A * AW) lds += bitmapWords * 4 + 8;         // ... behind the list arrays when the accumulators cannot hold them
+  if (a.ref.kDirStride - 1 > 256) return t1k_fail(ctx, T1K_ERR_ARG, "the reference holds more than 131 072 distinct sequences (256 seeding chunks)");
+  if (lds > 160 * 1024) return t1k_fail(ctx, T1K_ERR_ARG, "the reference holds too many sequences for the seeding kernel's LDS bitmaps");
   // the seeding kernel keeps no per-workgroup HBM scratch: one workgroup per read-end (up to 32768) balances their uneven cost best
   const char *esw = getenv("T1K_SEED_WG");
   const int seedWg = (int)std::min<uint32_t>(a.reads.nReadEnds, esw ? (uint32_t)atoi(esw) : 32768u);

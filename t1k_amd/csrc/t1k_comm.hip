@@ -338,7 +338,8 @@ int t1k_comm_alltoallv(t1k_comm *c, const void *sendbuf, const uint64_t *sendOff
   return T1K_OK;
 }
 
-// variable-length all-gather of device bytes: rank r's `bytes[r]` bytes land at out + displ[r] on every rank
+// variable-length all-gather of device bytes: rank r's `bytes[r]` bytes land at out + displ[r] on every rank (mine == out + displ[rank]
+// is allowed: in place)
 int t1k_comm_allgatherv(t1k_comm *c, const void *mine, const uint64_t *bytes, const uint64_t *displ, void *out) {
   if (!c || !bytes || !displ) return T1K_ERR_ARG;
   if (c->aborted) return commFail(c, T1K_ERR_STATE, "the job was aborted");
@@ -364,7 +365,8 @@ int t1k_comm_allgatherv(t1k_comm *c, const void *mine, const uint64_t *bytes, co
   h.ptr[c->rank] = mine;
   if (!h.barrier()) return commFail(c, T1K_ERR_STATE, "another rank of the job failed: the exchange was abandoned");
   for (int r = 0; r < N; ++r)
-    if (bytes[r]) CM_HIP(hipMemcpyAsync((char *)out + displ[r], h.ptr[r], bytes[r], hipMemcpyDefault, ctx->stream));
+    if (bytes[r] && (const char *)h.ptr[r] != (const char *)out + displ[r])  // (in place: this rank's piece is where it belongs already)
+      CM_HIP(hipMemcpyAsync((char *)out + displ[r], h.ptr[r], bytes[r], hipMemcpyDefault, ctx->stream));
   CM_HIP(hipStreamSynchronize(ctx->stream));
   if (!h.barrier()) return commFail(c, T1K_ERR_STATE, "another rank of the job failed: the exchange was abandoned");
   return T1K_OK;

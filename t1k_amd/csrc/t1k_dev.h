@@ -110,6 +110,9 @@ struct T1kRefDev {
   const uint32_t *kDirIdx;      // [4^k]
   const uint32_t *kDir;         // [rows][kDirStride]
   uint32_t kDirStride;
+  // per directory row: bit c = the list holds a posting of chunk c (kDir[row][c + 1] > kDir[row][c]); kDirMaskWords 64-bit words a row
+  const unsigned long long *kDirMask;
+  uint32_t kDirMaskWords;
   const T1kPosting *kPost;
   const uint32_t *kPostAllele;  // the allele column of kPost on its own: the extractor's vote streams only this
   // per-base coverage = prefix sum of covDiff (+w where a covered run starts, -w behind its end) minus covHole (w at a position
@@ -724,7 +727,8 @@ struct t1k_ctx {
   uint32_t nFragments = 0;
   uint64_t nRows = 0;
   // EM
-  T1kDevBuf bEmRowPtr, bEmEc, bEmCount, bEmLen, bEmX0, bEmN, bEmContrib, bEmColPtr, bEmColIdx;
+  T1kDevBuf bEmRowPtr, bEmEc, bEmCount, bEmLen, bEmX0, bEmN, bEmContrib, bEmColPtr, bEmColIdx, bEmEntryOf;
+  std::vector<uint64_t> hEmRowPtr, emPieceBytes, emPieceDispl;  // sharded E-step: the ranks' pieces of the row-major contribution array
   uint32_t emGroups = 0, emEc = 0, emRowBegin = 0, emRowEnd = 0;
   struct t1k_comm *emComm = nullptr;
   uint64_t emNnz = 0;

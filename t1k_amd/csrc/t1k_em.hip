@@ -7,9 +7,10 @@
 //   k_em_cols : one lane per class: n[ec] = sum of its contributions in group order -- the order the reference's
 //               row-major loop adds them to ecReadCount[ec] -- so every class total is the same rounded double
 // then the M-step (normalise by length, sum|diff|) runs on the host in the reference's order: it is O(#classes) and needs the
-// values on the host anyway.  Sharded over GPUs (t1k_em_shard): a rank runs k_em_rows on its slice of the read groups only, the
-// contribution array -- every element has exactly one writer, the others hold 0 -- is all-reduced (sum, f64: exact in any order),
-// and k_em_cols runs on every rank: the same doubles as on one GPU, whatever the number of ranks.
+// values on the host anyway.  Sharded over GPUs (t1k_em_shard): a rank runs k_em_rows on its slice of the read groups only and writes
+// the contributions in ROW-major order, so its slice is one contiguous piece; the pieces are all-gathered (every element has exactly
+// one writer: no reduction, no zero-filling, bytes / N per rank) and k_em_cols, on every rank, adds each class's contributions in
+// group order through the class-major permutation: the same doubles as on one GPU, whatever the number of ranks.
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -53,11 +54,11 @@ __global__ __launch_bounds__(256) void k_em_rows(const uint64_t *rowPtr, const u
   }
   if (psum == 0) psum = 1;
   const double c = count[g];
-  for (uint64_t p = b + lane; p < e; p += 64) contrib[cscPos[p]] = c * (x[ecIdx[p]] / psum);
+  for (uint64_t p = b + lane; p < e; p += 64) contrib[cscPos ? cscPos[p] : p] = c * (x[ecIdx[p]] / psum);  // (no permutation: row-major, the sharded E-step)
 }
 
 // one wavefront per class: its contributions are added in group order
-__global__ __launch_bounds__(256) void k_em_cols(const uint64_t *colPtr, const double *contrib, double *n, uint32_t nEc) {
+__global__ __launch_bounds__(256) void k_em_cols(const uint64_t *colPtr, const double *contrib, const uint32_t *entryOf, double *n, uint32_t nEc) {
   const uint32_t ec = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int lane = threadIdx.x & 63;
   if (ec >= nEc) return;
@@ -65,7 +66,7 @@ __global__ __launch_bounds__(256) void k_em_cols(const uint64_t *colPtr, const d
   double s = 0;
   for (uint64_t base = b; base < e; base += 64) {
     const uint64_t p = base + lane;
-    const double v = p < e ? contrib[p] : 0.0;
+    const double v = p < e ? contrib[entryOf ? entryOf[p] : p] : 0.0;  // entryOf: class-major slot -> row-major entry (sharded E-step)
     s = waveOrderedSum(v, (int)(e - base < 64 ? e - base : 64), s);
   }
   if (lane == 0) n[ec] = s;
@@ -253,9 +254,9 @@ int t1k_em_setup(t1k_ctx *ctx, const uint64_t *rowPtr, const uint32_t *ecIdx, co
   if (nnz) {
     if (nnz >= 0xFFFFFFFFull) return t1k_fail(ctx, T1K_ERR_ARG, "t1k_em_setup: more than 2^32 entries");
     T1kDevBuf tmp;
-    if ((rc = t1k_ensure(ctx, tmp, (size_t)nnz * 24 + 64))) return rc;
+    if ((rc = t1k_ensure(ctx, tmp, (size_t)nnz * 20 + 64)) || (rc = t1k_ensure(ctx, ctx->bEmEntryOf, (size_t)nnz * 4 + 16))) return rc;
     unsigned long long *k0 = (unsigned long long *)tmp.p, *k1 = k0 + nnz;
-    uint32_t *v0 = (uint32_t *)(k1 + nnz), *v1 = v0 + nnz;
+    uint32_t *v0 = (uint32_t *)(k1 + nnz), *v1 = (uint32_t *)ctx->bEmEntryOf.p;  // v1[j] = the entry in class-major slot j: kept for the sharded E-step
     unsigned long long *bad = (unsigned long long *)ctx->bEmN.p;  // a word that is free until the first update
     T1K_HIP(ctx, hipMemsetAsync(bad, 0, 8, ctx->stream));
     const unsigned nb = (unsigned)((nnz + 255) / 256);
@@ -281,12 +282,29 @@ int t1k_em_setup(t1k_ctx *ctx, const uint64_t *rowPtr, const uint32_t *ecIdx, co
   ctx->emRowBegin = 0; ctx->emRowEnd = nGroups; ctx->emComm = nullptr;
   // class lengths stay on the host (M-step)
   if (nEc) ctx->hEmLen.assign(ecLen, ecLen + nEc); else ctx->hEmLen.clear();
+  ctx->hEmRowPtr.assign(rowPtr, rowPtr + nGroups + 1);  // (t1k_em_shard cuts the contribution array at the ranks' row boundaries)
   return T1K_OK;
 }
 
 int t1k_em_shard(t1k_ctx *ctx, uint32_t rowBegin, uint32_t rowEnd, t1k_comm *comm) {
   if (!ctx || rowBegin > rowEnd || rowEnd > ctx->emGroups) return t1k_fail(ctx, T1K_ERR_ARG, "t1k_em_shard: bad row range");
   ctx->emRowBegin = rowBegin; ctx->emRowEnd = rowEnd; ctx->emComm = comm;
+  // every rank's piece of the row-major contribution array: the ranks' row ranges partition [0, G) in rank order
+  ctx->emPieceBytes.clear(); ctx->emPieceDispl.clear();
+  const int N = comm ? t1k_comm_size(comm) : 1;
+  if (N > 1) {
+    std::vector<uint64_t> mine{rowBegin, rowEnd}, all((size_t)2 * N);
+    const int rc = t1k_comm_allgather_u64(comm, mine.data(), 2, all.data());
+    if (rc != T1K_OK) return t1k_fail(ctx, rc, std::string("t1k_em_shard: ") + t1k_comm_last_error(comm));
+    uint64_t next = 0;
+    for (int r = 0; r < N; ++r) {
+      if (all[2 * r] != next || all[2 * r + 1] < all[2 * r] || all[2 * r + 1] > ctx->emGroups) return t1k_fail(ctx, T1K_ERR_ARG, "t1k_em_shard: the ranks' row ranges do not partition the read groups in rank order");
+      next = all[2 * r + 1];
+      ctx->emPieceDispl.push_back(ctx->hEmRowPtr[all[2 * r]] * 8);
+      ctx->emPieceBytes.push_back((ctx->hEmRowPtr[all[2 * r + 1]] - ctx->hEmRowPtr[all[2 * r]]) * 8);
+    }
+    if (next != ctx->emGroups) return t1k_fail(ctx, T1K_ERR_ARG, "t1k_em_shard: the ranks' row ranges do not cover the read groups");
+  }
   return T1K_OK;
 }
 
@@ -307,16 +325,18 @@ int t1k_em_update(t1k_ctx *ctx, const double *x0, double *x1, double *ecReadCoun
   T1K_HIP(ctx, hipMemcpyAsync(ctx->bEmX0.p, px, (size_t)E * 8, hipMemcpyHostToDevice, ctx->stream));
   const bool sharded = ctx->emComm && t1k_comm_size(ctx->emComm) > 1;
   const uint32_t g0 = sharded ? ctx->emRowBegin : 0, gn = (sharded ? ctx->emRowEnd : G) - g0;
-  if (sharded && ctx->emNnz) T1K_HIP(ctx, hipMemsetAsync(ctx->bEmContrib.p, 0, (size_t)ctx->emNnz * 8, ctx->stream));  // the other ranks' entries
   if (gn) hipLaunchKernelGGL(k_em_rows, dim3((gn + 3) / 4), dim3(256), 0, ctx->stream, (const uint64_t *)ctx->bEmRowPtr.p + g0, (const uint32_t *)ctx->bEmEc.p,
-                             (const uint64_t *)ctx->bEmColIdx.p, (const double *)ctx->bEmCount.p + g0, (const double *)ctx->bEmX0.p, (double *)ctx->bEmContrib.p, gn);
+                             sharded ? (const uint64_t *)nullptr : (const uint64_t *)ctx->bEmColIdx.p, (const double *)ctx->bEmCount.p + g0, (const double *)ctx->bEmX0.p,
+                             (double *)ctx->bEmContrib.p, gn);
   if (sharded) {
+    // this rank's rows are one contiguous piece of the row-major array: gather everybody's piece in place
     T1K_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    const int rc = t1k_comm_allreduce(ctx->emComm, ctx->bEmContrib.p, ctx->emNnz, 1);
+    const int me = t1k_comm_rank(ctx->emComm);
+    const int rc = t1k_comm_allgatherv(ctx->emComm, (const char *)ctx->bEmContrib.p + ctx->emPieceDispl[me], ctx->emPieceBytes.data(), ctx->emPieceDispl.data(), ctx->bEmContrib.p);
     if (rc != T1K_OK) return t1k_fail(ctx, rc, std::string("t1k_em_update: ") + t1k_comm_last_error(ctx->emComm));
   }
   hipLaunchKernelGGL(k_em_cols, dim3((E + 3) / 4), dim3(256), 0, ctx->stream, (const uint64_t *)ctx->bEmColPtr.p, (const double *)ctx->bEmContrib.p,
-                     (double *)ctx->bEmN.p, E);
+                     sharded ? (const uint32_t *)ctx->bEmEntryOf.p : (const uint32_t *)nullptr, (double *)ctx->bEmN.p, E);
   if (ctx->emAllreduce) {
     T1K_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->emAllreduce(ctx->bEmN.p, E, ctx->emUser);  // RCCL all-reduce of the per-class expected read counts

@@ -127,6 +127,20 @@ __global__ void k_ref_dir(const uint32_t *rowCode, const uint32_t *kStart, const
   dir[t] = lo;
 }
 
+// mask[row][w] bit b = chunk 64 * w + b of the row's list is not empty
+__global__ void k_ref_dirmask(const uint32_t *dir, uint32_t stride, uint32_t rows, uint32_t words, unsigned long long *mask) {
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (uint64_t)rows * words) return;
+  const uint32_t row = (uint32_t)(t / words), w = (uint32_t)(t % words);
+  const uint32_t *d = dir + (uint64_t)row * stride;
+  unsigned long long m = 0;
+  for (uint32_t b = 0; b < 64; ++b) {
+    const uint32_t c = 64 * w + b;
+    if (c + 1 < stride && d[c + 1] > d[c]) m |= 1ull << b;
+  }
+  mask[t] = m;
+}
+
 static inline int asciiCode(char c) { return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : 4; }
 
 int keep(t1k_ctx *ctx, size_t bytes, void **out) {
@@ -286,6 +300,11 @@ extern "C" int t1k_ref_upload(t1k_ctx *ctx, const char *seqs, const uint64_t *of
     hipLaunchKernelGGL(k_ref_dir, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, st, (const uint32_t *)bRowCode.p, (const uint32_t *)dKStart, (const uint32_t *)dPostAllele, stride,
                        cells, (uint32_t *)dDir);
   } else RU_HIP(hipMemsetAsync(dDir, 0, (size_t)stride * 4, st));
+  const uint32_t maskWords = std::max(1u, (stride - 1 + 63) / 64);
+  void *dDirMask;
+  if ((rc = keep(ctx, (size_t)std::max(rows, 1u) * maskWords * 8, &dDirMask))) { freeScratch2(); return rc; }
+  if (rows) hipLaunchKernelGGL(k_ref_dirmask, dim3((unsigned)(((uint64_t)rows * maskWords + 255) / 256)), dim3(256), 0, st, (const uint32_t *)dDir, stride, rows, maskWords, (unsigned long long *)dDirMask);
+  else RU_HIP(hipMemsetAsync(dDirMask, 0, (size_t)maskWords * 8, st));
   // coverage arrays
   void *dCov;
   r.covStride = total + 2;
@@ -299,6 +318,7 @@ extern "C" int t1k_ref_upload(t1k_ctx *ctx, const char *seqs, const uint64_t *of
   r.sepStart = (const uint32_t *)dSepStart; r.sepPos = (const int32_t *)dSepPos;
   r.kStart = (const uint32_t *)dKStart; r.kHas = (const uint32_t *)dHas; r.kMulti = (const uint32_t *)dMulti; r.kHasPre = (const uint32_t *)dHasPre;
   r.kDirIdx = (const uint32_t *)dDirIdx; r.kDir = (const uint32_t *)dDir; r.kDirStride = stride;
+  r.kDirMask = (const unsigned long long *)dDirMask; r.kDirMaskWords = maskWords;
   r.kPost = (const T1kPosting *)dPost; r.kPostAllele = (const uint32_t *)dPostAllele;
   r.covDiff = (int32_t *)dCov;
   ctx->ref = r;

@@ -149,3 +149,4 @@ def fastx_records(path):
         else:
             i += 1
     return out
+REF_BAM_EXTRACT = os.path.join(ROOT, "oracle", "_ref", "bam-extractor")
