@@ -316,8 +316,6 @@ int t1k_job_load_reads(t1k_job *job, const char *file1, const char *file2, const
 int t1k_job_load_reads_multi(t1k_job *job, const char *const *files1, uint32_t n1, const char *const *files2, uint32_t n2, const char *barcodeFile);
 /* or hand reads over from memory: concatenated ASCII + offsets, mates parallel; ids may be NULL ("r<i>") */
 int t1k_job_set_reads(t1k_job *job, const char *seq1, const uint64_t *off1, const char *seq2, const uint64_t *off2, uint32_t nFragments);
-/* no-op kept from round 1 (reads used to be uploaded ahead of t1k_job_run; they now stream through the GPU window by window inside it) */
-int t1k_job_stage_reads(t1k_job *job);
 /* read-end assignment, pairing, coalescing, EC build, EM, allele selection (Genotyper.cpp:451-650) */
 int t1k_job_run(t1k_job *job);
 /* optional, before t1k_job_run: the *_aligned*.fa files (which only need the fragmentAssigned flags) are then written by background
@@ -339,7 +337,9 @@ int t1k_job_set_shard(t1k_job *job, int rank, int nRanks, t1k_comm *comm);
 /* rank threads of one process: dst uses the read files src has mapped (t1k_job_load_reads on src only) */
 int t1k_job_share_reads(t1k_job *dst, t1k_job *src);
 int t1k_job_run_local(t1k_job *job);
-int t1k_job_finish(t1k_job *job, uint64_t unused0, uint64_t unused1);
+/* the two halves of t1k_job_run: t1k_job_run_local = windows of fragments through the GPU up to the coalesced read groups (with the
+ * exchanges of a sharded job), t1k_job_finish = classes, EM, pruning, selection */
+int t1k_job_finish(t1k_job *job);
 /* the job's group table as a byte string: [u64 nGroups][u64 nEntries][u64 assignedFragments][u64 groupPtr[nGroups+1]]
  * [u32 firstFragment[nGroups]][t1k_group_entry entries[nEntries]] */
 int t1k_job_groups_serialize(t1k_job *job, void *buf, uint64_t cap, uint64_t *needed);

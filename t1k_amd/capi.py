@@ -99,7 +99,6 @@ def lib():
     L.t1k_job_last_error.restype = C.c_char_p
     L.t1k_job_load_reads.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_char_p]
     L.t1k_job_set_reads.argtypes = [vp, C.c_char_p, vp, C.c_char_p, vp, C.c_uint32]
-    L.t1k_job_stage_reads.argtypes = [vp]
     L.t1k_job_run.argtypes = [vp]
     L.t1k_job_write_outputs.argtypes = [vp, C.c_char_p]
     L.t1k_pool_release.restype = C.c_uint64
@@ -111,7 +110,7 @@ def lib():
     L.t1k_job_ctx.argtypes = [vp]
     L.t1k_job_ctx.restype = vp
     L.t1k_job_run_local.argtypes = [vp]
-    L.t1k_job_finish.argtypes = [vp, C.c_uint64, C.c_uint64]
+    L.t1k_job_finish.argtypes = [vp]
     L.t1k_job_groups_serialize.argtypes = [vp, vp, C.c_uint64, u64p]
     L.t1k_reads_dedupe.argtypes = [vp, vp, u32p]
     L.t1k_job_groups_merge.argtypes = [vp, vp, vp, C.c_uint32]
@@ -407,9 +406,6 @@ class Job:
         b2, o2 = _concat(seqs2) if seqs2 is not None else (None, None)
         self._check(lib().t1k_job_set_reads(self.h, b1, _ptr(o1), b2, _ptr(o2), len(seqs1)), "t1k_job_set_reads")
 
-    def stage_reads(self):
-        self._check(lib().t1k_job_stage_reads(self.h), "t1k_job_stage_reads")
-
     def run(self):
         self._check(lib().t1k_job_run(self.h), "t1k_job_run")
 
@@ -454,7 +450,7 @@ class Job:
         self._check(lib().t1k_job_run_local(self.h), "t1k_job_run_local")
 
     def finish(self):
-        self._check(lib().t1k_job_finish(self.h, 0, 0), "t1k_job_finish")
+        self._check(lib().t1k_job_finish(self.h), "t1k_job_finish")
 
     def groups_serialize(self):
         need = C.c_uint64()

@@ -225,11 +225,6 @@ int t1k_job_set_reads(t1k_job *job, const char *seq1, const uint64_t *off1, cons
   return T1K_OK;
 }
 
-int t1k_job_stage_reads(t1k_job *job) {  // kept for callers of round 1: reads now stream through the GPU window by window inside t1k_job_run
-  if (!job || !job->ctx) return T1K_ERR_STATE;
-  return T1K_OK;
-}
-
 int t1k_job_set_shard(t1k_job *job, int rank, int nRanks, t1k_comm *comm) {
   if (!job || nRanks < 1 || rank < 0 || rank >= nRanks || (nRanks > 1 && !comm)) return T1K_ERR_ARG;
   job->rank = rank; job->nRanks = nRanks; job->comm = comm;
@@ -963,7 +958,7 @@ int t1k_job_set_output_prefix(t1k_job *job, const char *prefix) {
   return T1K_OK;
 }
 
-int t1k_job_finish(t1k_job *job, uint64_t emGroupBegin, uint64_t emGroupEnd) {
+int t1k_job_finish(t1k_job *job) {
   if (!job || !job->ctx || !job->localDone) return jobFail(job, T1K_ERR_STATE, "t1k_job_finish: t1k_job_run_local has not completed");
   if (job->bgWriter.joinable()) job->bgWriter.join();
   job->bgStarted = false; job->bgOk = true;
@@ -1019,7 +1014,6 @@ int t1k_job_finish(t1k_job *job, uint64_t emGroupBegin, uint64_t emGroupEnd) {
   if (!job->abundanceFile.empty()) {
     if (!loadAbundance(job)) return T1K_ERR_IO;
   } else {
-    (void)emGroupBegin; (void)emGroupEnd;
     if (gt.quantify(job->ctx, job->comm, job->err) < 0) return T1K_ERR_DEVICE;
   }
   double t4 = nowMs();
@@ -1041,7 +1035,7 @@ int t1k_job_finish(t1k_job *job, uint64_t emGroupBegin, uint64_t emGroupEnd) {
 
 int t1k_job_run(t1k_job *job) {
   int rc = t1k_job_run_local(job);
-  if (rc == T1K_OK) rc = t1k_job_finish(job, 0, ~0ull);
+  if (rc == T1K_OK) rc = t1k_job_finish(job);
   // a rank of a sharded job that fails tells the others (they would wait for it in the next exchange otherwise)
   if (rc != T1K_OK && job && job->comm && job->nRanks > 1) (void)t1k_comm_abort(job->comm);
   return rc;
@@ -1468,10 +1462,12 @@ int t1k_analyzer_main(int argc, char **argv) {
   uint64_t nAssigned = 0;
   for (uint32_t f = 0; f < F; ++f) nAssigned += job->fragAssigned[f] ? 1 : 0;
   logLine("Finish read fragment assignments. %d read fragments can be assigned.", (int)nAssigned);
-  {  // no variant calling in this build: the file the reference writes when it finds none
+  {  // no variant calling in this build: the file the reference writes when it finds none -- said out loud, every run
     FILE *fp = fopen((prefix + "_allele.vcf").c_str(), "w");
     if (!fp) { fprintf(stderr, "analyzer: cannot write %s_allele.vcf\n", prefix.c_str()); t1k_job_destroy(job); return EXIT_FAILURE; }
     fclose(fp);
+    fprintf(stderr, "analyzer: WARNING: novel-variant calling (the reference's VariantCaller) is not part of this build: %s_allele.vcf is written empty%s\n", prefix.c_str(),
+            in.hasBarcode ? ", and the per-barcode table uses the fragment assignments as they are (the reference adjusts them where it calls a variant)" : "");
   }
   if (in.hasBarcode) {
     // barcode ids in order of first appearance over ALL loaded fragments (Analyzer.cpp:380-392), counts in fragment order

@@ -14,6 +14,8 @@
 #include <zlib.h>
 #include <algorithm>
 #include <atomic>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <thread>
 #include "t1k_host.h"
@@ -183,6 +185,66 @@ bool ReadInput::addGeneral(const std::string &path, Side &dst, std::string &err)
   return true;
 }
 
+// A .gz file written by bgzip (BGZF: independent gzip members of at most 64 KiB, each carrying its compressed size in a "BC" extra
+// field) can be inflated block-parallel; ordinary gzip is one dependent stream and goes through gzread.  False = not BGZF (or damaged):
+// the caller falls back to gzread, which reports real damage.
+bool ReadInput::bgzfInflate(int fd, size_t fileSize, int threads, Blob &blob, const char *&data, size_t &size) {
+  if (fileSize < 28) return false;
+  void *m = mmap(nullptr, fileSize, PROT_READ, MAP_PRIVATE, fd, 0);
+  if (m == MAP_FAILED) return false;
+  const uint8_t *map = (const uint8_t *)m;
+  struct Blk { size_t in, inLen, out, outLen; };
+  std::vector<Blk> blks;
+  size_t pos = 0, out = 0;
+  bool ok = true;
+  while (pos < fileSize) {
+    if (fileSize - pos < 28 || map[pos] != 31 || map[pos + 1] != 139 || map[pos + 2] != 8 || !(map[pos + 3] & 4)) { ok = false; break; }
+    const size_t xlen = map[pos + 10] | (map[pos + 11] << 8);
+    size_t bsize = 0;
+    for (size_t x = pos + 12; x + 4 <= pos + 12 + xlen && x + 6 <= fileSize;) {
+      const size_t slen = map[x + 2] | (map[x + 3] << 8);
+      if (map[x] == 'B' && map[x + 1] == 'C' && slen == 2) bsize = (size_t)(map[x + 4] | (map[x + 5] << 8)) + 1;
+      x += 4 + slen;
+    }
+    if (!bsize || pos + bsize > fileSize || bsize < xlen + 20) { ok = false; break; }
+    const uint8_t *tail = map + pos + bsize - 4;
+    const size_t isize = (size_t)tail[0] | ((size_t)tail[1] << 8) | ((size_t)tail[2] << 16) | ((size_t)tail[3] << 24);
+    blks.push_back({pos + 12 + xlen, bsize - xlen - 20, out, isize});
+    out += isize; pos += bsize;
+  }
+  if (ok && !blks.empty()) {
+    blob.owned.reset(new std::vector<char>());
+    std::vector<char> &v = *blob.owned;
+    v.resize(out);
+    std::atomic<size_t> next{0};
+    std::atomic<bool> bad{false};
+    auto work = [&] {
+      for (size_t i = next.fetch_add(16); i < blks.size(); i = next.fetch_add(16))
+        for (size_t j = i; j < std::min(blks.size(), i + 16); ++j) {
+          if (!blks[j].outLen) continue;
+          z_stream zs;
+          memset(&zs, 0, sizeof(zs));
+          if (inflateInit2(&zs, -15) != Z_OK) { bad = true; continue; }
+          zs.next_in = (Bytef *)(map + blks[j].in); zs.avail_in = (uInt)blks[j].inLen;
+          zs.next_out = (Bytef *)v.data() + blks[j].out; zs.avail_out = (uInt)blks[j].outLen;
+          if (inflate(&zs, Z_FINISH) != Z_STREAM_END || zs.avail_out != 0) bad = true;
+          inflateEnd(&zs);
+        }
+    };
+    const int T = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(1, threads), blks.size() / 16 + 1));
+    std::vector<std::thread> th;
+    for (int t = 1; t < T; ++t) th.emplace_back(work);
+    work();
+    for (auto &x : th) x.join();
+    ok = !bad;
+    if (ok && getenv("T1K_DEBUG_PHASES")) fprintf(stderr, "[t1k job] bgzip-framed read file: %zu blocks inflated by %d threads\n", blks.size(), T);
+    if (ok) { data = v.data(); size = v.size(); }
+    else blob.owned.reset();
+  } else ok = false;
+  munmap(m, fileSize);
+  return ok;
+}
+
 bool ReadInput::addFile(const std::string &path, int threads, Side &dst, std::string &err) {
   int fd = ::open(path.c_str(), O_RDONLY);
   if (fd < 0) { err = "cannot open " + path; return false; }
@@ -201,6 +263,9 @@ bool ReadInput::addFile(const std::string &path, int threads, Side &dst, std::st
     Blob &b = newBlob();
     b.map = m; b.len = (size_t)st.st_size;
     data = (const char *)m; size = (size_t)st.st_size;
+  } else if (gz && S_ISREG(st.st_mode) && bgzfInflate(fd, (size_t)st.st_size, threads, newBlob(), data, size)) {
+    // (a bgzip-framed file: its 64 KiB blocks were inflated side by side by the host threads)
+    ::close(fd);
   } else {
     ::close(fd);
     gzFile fp = gzopen(path.c_str(), "rb");  // also reads a plain stream (a pipe) transparently

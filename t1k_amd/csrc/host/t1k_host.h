@@ -76,6 +76,7 @@ struct ReadInput {
   std::mutex blobLock_;
   Blob &newBlob() { std::lock_guard<std::mutex> g(blobLock_); blobs_.emplace_back(); return blobs_.back(); }
   bool addFile(const std::string &path, int threads, Side &dst, std::string &err);
+  static bool bgzfInflate(int fd, size_t fileSize, int threads, Blob &blob, const char *&data, size_t &size);
   bool addBuffer(const char *p, size_t n, int threads, Side &dst, std::string &err, const std::string &what);
   bool addRange(const char *b, const char *stop, const char *end, bool fastq, int threads, Side &dst);
   uint32_t nAll_ = 0;

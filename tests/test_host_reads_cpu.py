@@ -77,3 +77,30 @@ def test_compressed_input_is_left_to_the_whole_file_reader(harness, read_sets, t
     r = subprocess.run([harness, "2", "2", str(tmp_path / "o"), "1", str(tmp_path / "c_1.fq.gz"), str(tmp_path / "c_2.fq.gz")], stderr=subprocess.PIPE, text=True)
     assert r.returncode == 3, r.stderr
     assert open(str(tmp_path / "o") + "_whole.tsv").read().count("\n") == 7
+
+
+def test_bgzip_framed_and_plain_gzip_input_index_like_the_plain_file(harness, read_sets, tmp_path):
+    """a .gz read file written by bgzip (independent 64 KiB gzip members) is inflated block-parallel by the host
+    threads, an ordinary .gz through one gzread stream: either way the index equals the plain file's"""
+    import gzip
+    import bamsynth
+    d = read_sets
+    out = {}
+    for kind in ("plain", "bgzf", "gzip"):
+        files = []
+        for m in ("1", "2"):
+            src = os.path.join(d, "a_%s.fq" % m)
+            if kind == "plain":
+                files.append(src)
+                continue
+            dst = str(tmp_path / ("a_%s_%s.fq.gz" % (kind, m)))
+            raw = open(src, "rb").read()
+            open(dst, "wb").write(bamsynth.bgzf(raw) if kind == "bgzf" else gzip.compress(raw, 1))
+            files.append(dst)
+        o = str(tmp_path / kind)
+        r = subprocess.run([harness, "1", "4", o, "1"] + files, stderr=subprocess.PIPE, text=True, env=dict(os.environ, T1K_DEBUG_PHASES="1"))
+        assert r.returncode in (0, 3), r.stderr
+        assert ("bgzip-framed read file" in r.stderr) == (kind == "bgzf"), r.stderr
+        out[kind] = open(o + "_whole.tsv").read()
+    assert out["plain"].count("\n") == 30000
+    assert out["bgzf"] == out["plain"] and out["gzip"] == out["plain"]
