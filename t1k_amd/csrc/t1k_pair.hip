@@ -16,7 +16,6 @@
 #include "t1k_dev.h"
 #include "t1k_launch.h"
 
-#define WG 256
 #ifdef T1K_PAIR_PROFILE
 #define PP(i) do { if (tid == 0) { const uint64_t tn_ = __builtin_amdgcn_s_memtime(); tp_[i] += tn_ - tl_; tl_ = tn_; } } while (0)
 #else
@@ -24,15 +23,14 @@
 #endif
 #define SORT_TILE 2048
 // Join table of one fragment in LDS: allele -> (index in list 1 + 1) | membership bit 15 | (index in list 2 + 1) << 16.  Open addressing,
-// 4096 slots; fragments whose two lists hold more than LJ_CAP overlaps (or a list with a repeated allele) use the per-workgroup
-// direct-address tables in HBM instead.
-#define LJ_SLOTS 4096
-#define LJ_CAP 2800
-
-__device__ __forceinline__ uint32_t ljHash(uint32_t allele) { return (allele * 2654435761u) >> 20; }  // 12 bits
+// LJ_SLOTS slots (4096 or 2048: a template parameter of the kernel); fragments whose two lists hold more than 68 % of that (or a list
+// with a repeated allele) use the per-workgroup direct-address tables in HBM instead.
+template <int LJ_SLOTS>
+__device__ __forceinline__ uint32_t ljHash(uint32_t allele) { return (allele * 2654435761u) >> (LJ_SLOTS == 4096 ? 20 : 21); }  // 12 / 11 bits
+template <int LJ_SLOTS>
 __device__ __forceinline__ uint32_t ljInsert(uint32_t *hKey, uint32_t allele) {
   const uint32_t key = allele + 1;
-  uint32_t h = ljHash(allele);
+  uint32_t h = ljHash<LJ_SLOTS>(allele);
   for (;;) {
     const uint32_t k = hKey[h];
     if (k == key) return h;
@@ -43,9 +41,10 @@ __device__ __forceinline__ uint32_t ljInsert(uint32_t *hKey, uint32_t allele) {
     h = (h + 1) & (LJ_SLOTS - 1);
   }
 }
+template <int LJ_SLOTS>
 __device__ __forceinline__ int ljFind(const uint32_t *hKey, uint32_t allele) {  // slot of an allele, -1 if absent
   const uint32_t key = allele + 1;
-  uint32_t h = ljHash(allele);
+  uint32_t h = ljHash<LJ_SLOTS>(allele);
   for (;;) {
     const uint32_t k = hKey[h];
     if (k == key) return (int)h;
@@ -168,6 +167,7 @@ __device__ __forceinline__ float rowWeight(double sim, double s, bool hasN) {  /
   return (float)ret;
 }
 
+template <int NWAVE>
 __device__ __forceinline__ uint32_t scanExcl(uint32_t v, uint32_t *warpSums, uint32_t *total) {
   int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   uint32_t x = v;
@@ -176,18 +176,26 @@ __device__ __forceinline__ uint32_t scanExcl(uint32_t v, uint32_t *warpSums, uin
     uint32_t y = __shfl_up(x, o, 64);
     if (lane >= o) x += y;
   }
+  if (NWAVE == 1) {  // one wavefront per fragment: no workgroup barrier anywhere in the scan
+    *total = __shfl(x, 63, 64);
+    return x - v;
+  }
   if (lane == 63) warpSums[wave] = x;
   __syncthreads();
-  uint32_t base = 0;
-  for (int w = 0; w < wave; ++w) base += warpSums[w];
-  uint32_t tot = warpSums[0] + warpSums[1] + warpSums[2] + warpSums[3];
+  uint32_t base = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < NWAVE; ++w) { if (w < wave) base += warpSums[w]; tot += warpSums[w]; }
   __syncthreads();
   *total = tot;
   return base + x - v;
 }
 
+// WG threads per fragment (256: four wavefronts meeting at ~20 barriers per fragment; 64: one wavefront, whose barriers cost nothing)
+template <int WG, int LJ_SLOTS>
 __global__ __launch_bounds__(WG) void k_pair(PairArgs P) {
-  __shared__ uint32_t warpSums[4];
+  constexpr int NWAVE = WG / 64;
+  constexpr uint32_t LJ_CAP = LJ_SLOTS * 17 / 25;
+  __shared__ uint32_t warpSums[NWAVE];
   __shared__ int sDup, sFail, sBestM, sBestIdx, sAnySep, sNotOne;
   __shared__ double sBestSim;
   __shared__ uint32_t sN, sBase;
@@ -239,11 +247,11 @@ __global__ __launch_bounds__(WG) void k_pair(PairArgs P) {
       for (uint32_t q = tid; q < LJ_SLOTS; q += WG) { hKey[q] = 0; hVal[q] = 0; }
       __syncthreads();
       for (uint32_t i = tid; i < n1; i += WG) {
-        const uint32_t old = atomicOr(&hVal[ljInsert(hKey, L1[i].allele)], i + 1);
+        const uint32_t old = atomicOr(&hVal[ljInsert<LJ_SLOTS>(hKey, L1[i].allele)], i + 1);
         if (old & 0x7FFFu) sDup = 1;
       }
       for (uint32_t j = tid; j < n2; j += WG) {
-        const uint32_t old = atomicOr(&hVal[ljInsert(hKey, L2[j].allele)], (j + 1) << 16);
+        const uint32_t old = atomicOr(&hVal[ljInsert<LJ_SLOTS>(hKey, L2[j].allele)], (j + 1) << 16);
         if (old >> 16) sDup = 1;
       }
       __syncthreads();
@@ -282,7 +290,7 @@ __global__ __launch_bounds__(WG) void k_pair(PairArgs P) {
           if (i < n1 && s1 != s2) {
             int jj = -1;
             if (lds) {
-              slot = ljFind(hKey, L1[i].allele);
+              slot = ljFind<LJ_SLOTS>(hKey, L1[i].allele);
               jj = (int)(hVal[slot] >> 16) - 1;
             } else {
               uint64_t e = tab2[L1[i].allele];
@@ -291,7 +299,7 @@ __global__ __launch_bounds__(WG) void k_pair(PairArgs P) {
             if (jj >= 0 && ((s1 == 1 && L1[i].seqStart < L2[jj].seqStart) || (s1 == -1 && L1[i].seqStart > L2[jj].seqStart))) j = jj;  // 2369-2380
           }
           uint32_t tot;
-          uint32_t off = scanExcl(j >= 0 ? 1u : 0u, warpSums, &tot);
+          uint32_t off = scanExcl<NWAVE>(j >= 0 ? 1u : 0u, warpSums, &tot);
           if (j >= 0) {
             const T1kOvl oa = L1[i], ob = L2[j];
             Frag fr;
@@ -359,13 +367,13 @@ __global__ __launch_bounds__(WG) void k_pair(PairArgs P) {
         const double os = __shfl_xor(sm, o, 64);
         if (om > m || (om == m && (os > sm || (os == sm && oi < ix)))) { m = om; sm = os; ix = oi; }
       }
-      __shared__ int sWM[4], sWI[4];
-      __shared__ double sWS[4];
+      __shared__ int sWM[NWAVE], sWI[NWAVE];
+      __shared__ double sWS[NWAVE];
       if ((tid & 63) == 0) { sWM[tid >> 6] = m; sWS[tid >> 6] = sm; sWI[tid >> 6] = ix; }
       __syncthreads();
       if (tid == 0) {
         int bm = sWM[0], bi = sWI[0]; double bs = sWS[0];
-        for (int w = 1; w < 4; ++w)
+        for (int w = 1; w < NWAVE; ++w)
           if (sWM[w] > bm || (sWM[w] == bm && (sWS[w] > bs || (sWS[w] == bs && sWI[w] < bi)))) { bm = sWM[w]; bs = sWS[w]; bi = sWI[w]; }
         sBestM = bm; sBestSim = bm >= 0 ? bs : -1.0; sBestIdx = bi;
       }
@@ -432,7 +440,7 @@ __global__ __launch_bounds__(WG) void k_pair(PairArgs P) {
         kp = (fr.matchCnt == bestM && fr.sim == bestSim) || (P.relax && fr.matchCnt >= bestM - relaxBy && fr.relaxed == bestRelaxed);
       }
       uint32_t tot;
-      uint32_t off = scanExcl(kp ? 1u : 0u, warpSums, &tot);
+      uint32_t off = scanExcl<NWAVE>(kp ? 1u : 0u, warpSums, &tot);
       if (kp) keep[nKept + off] = q;
       nKept += tot;
     }
@@ -466,7 +474,7 @@ __global__ __launch_bounds__(WG) void k_pair(PairArgs P) {
         const bool tie = o.matchCnt == r1.matchCnt && os > r1s;
         bool inSlot = false;
         if (tie) {
-          if (lds) inSlot = (hVal[ljFind(hKey, o.allele)] & 0x8000u) != 0;
+          if (lds) inSlot = (hVal[ljFind<LJ_SLOTS>(hKey, o.allele)] & 0x8000u) != 0;
           else if (!dup) { uint64_t e = tab2[o.allele]; inSlot = (e >> 32) == (epoch >> 32) && (e & 0x80000000ull); }
           else { uint64_t e = tabSlot[o.allele]; inSlot = (e >> 32) == (epoch >> 32) && (e & 0x40000000ull); }
         }
@@ -481,7 +489,7 @@ __global__ __launch_bounds__(WG) void k_pair(PairArgs P) {
         const bool tie = o.matchCnt == r2.matchCnt && os > r2s;
         bool inSlot = false;
         if (tie) {
-          if (lds) inSlot = (hVal[ljFind(hKey, o.allele)] & 0x8000u) != 0;
+          if (lds) inSlot = (hVal[ljFind<LJ_SLOTS>(hKey, o.allele)] & 0x8000u) != 0;
           else if (!dup) { uint64_t e = tab2[o.allele]; inSlot = (e >> 32) == (epoch >> 32) && (e & 0x80000000ull); }
           else { uint64_t e = tabSlot[o.allele]; inSlot = (e >> 32) == (epoch >> 32) && (e & 0x40000000ull); }
         }
@@ -515,7 +523,7 @@ __global__ __launch_bounds__(WG) void k_pair(PairArgs P) {
         const uint32_t kq = q < nRow ? keep[q] : 0;
         const bool ok = q < nRow && P.whitelist[frags[kq].allele] != 0;
         uint32_t tot;
-        const uint32_t off = scanExcl(ok ? 1u : 0u, warpSums, &tot);  // (its barriers separate the reads above from the writes below)
+        const uint32_t off = scanExcl<NWAVE>(ok ? 1u : 0u, warpSums, &tot);  // (its barriers separate the reads above from the writes below)
         if (ok) keep[w + off] = kq;
         w += tot;
       }
@@ -552,7 +560,7 @@ __global__ __launch_bounds__(WG) void k_pair(PairArgs P) {
     uint32_t *sAllele = hKey;  // [SORT_TILE]: the join table is done with by now (the barriers of the phases above lie between); 8 KB less
                                // LDS lets a fourth workgroup onto the CU
     static_assert(SORT_TILE <= LJ_SLOTS, "the rank-sort tile lives in the join table's keys");
-    __shared__ unsigned long long sHash[2][4];
+    __shared__ unsigned long long sHash[2][NWAVE];
     if (tid == 0) {
       unsigned long long b = nRow ? atomicAdd(P.rsCursor, (unsigned long long)nRow) : 0ull;
       if (b + nRow > P.rsCap) { atomicOr(&P.counters[2], 128ull); sRowBase = ~0ull; }
@@ -599,8 +607,11 @@ __global__ __launch_bounds__(WG) void k_pair(PairArgs P) {
       const uint64_t g = P.fragBase + f;
       P.rsRowPtr[g] = fits ? (unsigned long long)(P.rsRows + sRowBase) : 0ull;
       P.rsRowCount[g] = fits ? nRow : 0;
-      P.rsH1[g] = sHash[0][0] + sHash[0][1] + sHash[0][2] + sHash[0][3] + 0x632BE59BD9B4E019ull * nRow;
-      P.rsH2[g] = sHash[1][0] + sHash[1][1] + sHash[1][2] + sHash[1][3] + 0xA0761D6478BD642Full * nRow;
+      unsigned long long t1 = 0, t2 = 0;
+#pragma unroll
+      for (int w = 0; w < NWAVE; ++w) { t1 += sHash[0][w]; t2 += sHash[1][w]; }
+      P.rsH1[g] = t1 + 0x632BE59BD9B4E019ull * nRow;
+      P.rsH2[g] = t2 + 0xA0761D6478BD642Full * nRow;
       P.rsAssigned[g] = anyKept ? 1 : 0;
     }
     __syncthreads();
@@ -619,8 +630,27 @@ static int pairLaunch(t1k_ctx *ctx, t1k_rowset *rs, const uint32_t *end1, const 
   T1K_HIP(ctx, hipSetDevice(ctx->device));
   int rc;
   const uint32_t n = nFragments;
-  const int maxWg = 1024;
-  const int nWg = (int)std::min<uint32_t>(maxWg, std::max<uint32_t>(n, 1));  // the kernel is latency-bound: fill the wave slots
+  // threads per fragment x slots of the LDS join table (T1K_PAIR_SHAPE = 256x4096 | 128x4096 | 128x2048 | 64x2048): as many workgroups as
+  // keep the same number of wavefronts in flight (the kernel is latency-bound: fill the wave slots)
+  static const int shape = [] {
+    const char *e = getenv("T1K_PAIR_SHAPE");
+    if (!e) return 0;
+    if (!strcmp(e, "128x4096")) return 1;
+    if (!strcmp(e, "128x2048")) return 2;
+    if (!strcmp(e, "64x2048")) return 3;
+    return 0;
+  }();
+  const int wgThreads = shape == 0 ? 256 : shape == 3 ? 64 : 128;
+  const int maxWg = 1024 * 256 / wgThreads;
+  const int nWg = (int)std::min<uint32_t>(maxWg, std::max<uint32_t>(n, 1));
+  auto launch = [&](unsigned grid, const PairArgs &args) {
+    switch (shape) {
+      case 1: hipLaunchKernelGGL((k_pair<128, 4096>), dim3(grid), dim3(128), 0, ctx->stream, args); break;
+      case 2: hipLaunchKernelGGL((k_pair<128, 2048>), dim3(grid), dim3(128), 0, ctx->stream, args); break;
+      case 3: hipLaunchKernelGGL((k_pair<64, 2048>), dim3(grid), dim3(64), 0, ctx->stream, args); break;
+      default: hipLaunchKernelGGL((k_pair<256, 4096>), dim3(grid), dim3(256), 0, ctx->stream, args); break;
+    }
+  };
   const uint32_t fragCap = 8192, bigFragCap = 1u << 17;  // overlaps of both mates a workgroup's scratch holds (first pass | second pass)
   const int bigWg = 128;
   const uint32_t A = ctx->ref.nAlleles;
@@ -680,7 +710,7 @@ static int pairLaunch(t1k_ctx *ctx, t1k_rowset *rs, const uint32_t *end1, const 
     }
     p.epochBase = (uint32_t)ctx->pairEpoch; ctx->pairEpoch += n;
     T1K_HIP(ctx, hipEventRecord(ctx->ev[5], ctx->stream));
-    hipLaunchKernelGGL(k_pair, dim3(nWg), dim3(WG), 0, ctx->stream, p);
+    launch((unsigned)nWg, p);
     T1K_HIP(ctx, hipEventRecord(ctx->ev[6], ctx->stream));
     if (!ctx->countersPinned) T1K_HIP(ctx, hipHostMalloc((void **)&ctx->countersPinned, (size_t)T1K_COUNTER_WORDS * 8, hipHostMallocDefault));
     T1K_HIP(ctx, hipMemcpyAsync(ctx->countersPinned, ctx->bCounters.p, 64 * 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -696,7 +726,7 @@ static int pairLaunch(t1k_ctx *ctx, t1k_rowset *rs, const uint32_t *end1, const 
       q.frags = (Frag *)(bs + (size_t)bigWg * A * 16); q.fragCap = bigFragCap;
       q.keep = (uint32_t *)(bs + (size_t)bigWg * A * 16 + (size_t)bigWg * bigFragCap * sizeof(Frag));
       q.only = (const uint32_t *)ctx->bPairOverflow.p; q.nOnly = nOver; q.overflowList = nullptr; q.epochBase = 0;
-      hipLaunchKernelGGL(k_pair, dim3(std::min<uint32_t>(nOver, bigWg)), dim3(WG), 0, ctx->stream, q);
+      launch(std::min<uint32_t>(nOver, bigWg), q);
       T1K_HIP(ctx, hipMemcpyAsync(ctx->countersPinned, ctx->bCounters.p, 64 * 8, hipMemcpyDeviceToHost, ctx->stream));
       T1K_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
