@@ -122,3 +122,36 @@ def test_coverage_modes_on_mixed_samples_vs_reference_binary(built, tmp_path, ca
             assert kept and all(0 < int(k) < int(w) for k, w in kept), r.stderr[-1500:]
     if parts >= 3:  # three individuals: some gene carries more than two types, so selection asked for coverage
         assert asked["deferred"] and asked["deferred"][0][0] > 0 and asked["deferred"][0][1] > 0, asked
+
+
+def test_barcode_config_at_size_vs_committed_reference_hashes(built, tmp_path):
+    """BASELINE configs[4] on one GPU, at size: 1 M 2x150 bp pairs carrying ~82 k distinct 10x-style barcodes (log-uniform usage),
+    genotyper -> analyzer.  Expected = md5 of the files the REFERENCE binaries wrote for this very input on an MI355X host
+    (tools/full_size_parity_r03.sh, profiles/r03_full_size_parity.log; 103 s + 11 s there), committed as tests/golden/full_size_md5.json."""
+    import hashlib
+    import json
+    want = json.load(open(os.path.join(util.GOLDEN, "full_size_md5.json")))["barcode_1M_100k"]
+    tmp = str(tmp_path)
+    ref = os.path.join(tmp, "hla.fa")
+    util.synth_ref("ref-rna", ref, genes=24, scale=1.0, seed=20250614)
+    pfx = os.path.join(tmp, "b")
+    util.synth_reads(ref, pfx, pairs=want["pairs"], len=150, seed=want["seed"], barcodes=want["barcodes"], sub=want["sub"])
+    g = os.path.join(tmp, "g")
+    r = subprocess.run([GENO, "-f", ref, "-1", pfx + "_1.fq", "-2", pfx + "_2.fq", "--barcode", pfx + "_bc.fa", "-s", "0.97", "-o", g], stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+
+    def md5(path):
+        h = hashlib.md5()
+        with open(path, "rb") as f:
+            for blk in iter(lambda: f.read(1 << 24), b""):
+                h.update(blk)
+        return h.hexdigest()
+
+    for suf in ("_genotype.tsv", "_allele.tsv", "_aligned_1.fa", "_aligned_2.fa", "_aligned_bc.fa"):
+        assert md5(g + suf) == want[suf], suf
+    a = os.path.join(tmp, "a")
+    r = subprocess.run([os.path.join(util.ROOT, "t1k_amd", "bin", "analyzer"), "-f", ref, "-a", g + "_allele.tsv", "-1", g + "_aligned_1.fa", "-2", g + "_aligned_2.fa",
+                        "--barcode", g + "_aligned_bc.fa", "-s", "0.97", "-o", a], stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert md5(a + "_barcode_expr.tsv") == want["analyzer_barcode_expr.tsv"]
+    assert os.path.getsize(a + "_allele.vcf") == want["analyzer_vcf_bytes"] == 0
