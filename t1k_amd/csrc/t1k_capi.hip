@@ -469,7 +469,7 @@ extern "C++" int t1k_fetch_counters(t1k_ctx *ctx, unsigned long long *h) {
   static const int slot[8] = {7, 11, 12, 14, 10, 3, 4, 5};
   for (int s = 0; s < T1K_STAT_STRIPES; ++s)
     for (int k = 0; k < 8; ++k) h[slot[k]] += raw[64 + s * 8 + k];
-  if (getenv("T1K_SEED_PROFILE") && raw[48]) fprintf(stderr, "[t1k] seed phases (ticks, thread 0 of every workgroup): lookup %llu rule %llu setup %llu min %llu slice %llu scan %llu walk %llu emit-scan %llu (record writes + reset are charged to min)\n", raw[48], raw[49], raw[50], raw[51], raw[52], raw[53], raw[54], raw[55]);
+  if (getenv("T1K_SEED_PROFILE") && raw[48]) fprintf(stderr, "[t1k] seed phases (ticks, thread 0 of every workgroup): lookup %llu rule %llu setup+chunk-selection %llu [chunks visited %llu] slice %llu scan %llu walk %llu emit-scan %llu (record writes + reset are charged to slice)\n", raw[48], raw[49], raw[50], raw[51], raw[52], raw[53], raw[54], raw[55]);
   return 0;
 }
 static int fetchCounters(t1k_ctx *ctx, unsigned long long *h) { return t1k_fetch_counters(ctx, h); }

@@ -663,6 +663,9 @@ __global__ __launch_bounds__(WG) T1K_OCC8 void k_seed_groups(ChainArgs P) {
         hotBits &= hotBits - 1;
         const uint32_t c0 = ci * CHUNK_A;
         const uint32_t c1 = min(c0 + CHUNK_A, A);
+#ifdef T1K_SEED_PROFILE
+        tp_[3] += 1;  // chunks visited (not a clock)
+#endif
         // slice of every used list inside [c0, c1): long lists from their directory row, short ones by bisection from their cursor
         // (the chunks come in ascending order, so the cursor only moves forward); lists without a posting here are not touched
         uint32_t n0 = 0, n1 = 0;

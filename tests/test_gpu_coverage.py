@@ -120,7 +120,7 @@ def test_coverage_modes_on_mixed_samples_vs_reference_binary(built, tmp_path, ca
             assert not m and not kept
         if mode == "budget_fallback":
             assert kept and all(0 < int(k) < int(w) for k, w in kept), r.stderr[-1500:]
-    if parts >= 3:  # three individuals: some gene carries more than two types, so selection asked for coverage
+    if case in (0, 1):  # three individuals, permissive filters: some gene carries more than two types, so selection asked for coverage
         assert asked["deferred"] and asked["deferred"][0][0] > 0 and asked["deferred"][0][1] > 0, asked
 
 
