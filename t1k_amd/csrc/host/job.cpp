@@ -287,6 +287,7 @@ struct Window {
   std::vector<char> pairDone;       // per pairing range of the window: finished (the output writer follows these)
   double tReady = 0, tDone = 0, msPrep = 0;
   std::vector<char> touched;        // per pipeline: has it attached to this window yet (first touch empties its store slot)
+  uint64_t ovlRecords = 0;          // overlap records its ranges left in the store
   bool deferred = false;            // its coverage is added later, for the selected alleles only: the read set is kept when the window is done
 };
 }  // namespace
@@ -336,7 +337,7 @@ int t1k_job_run_local(t1k_job *job) {
   }
   // device memory the kept read sets may take (about 6 KB per fragment of an HLA-sized reference: 58 GB at 10 M pairs); windows beyond
   // it fall back to the per-range coverage updates -- both kinds add up, only the selected alleles' sums are read
-  uint64_t archiveBudget = 0, archivedBytes = 0, archivedFrags = 0;
+  uint64_t archiveBudget = 0, archivedBytes = 0, archivedFrags = 0, archivedNeed = 0;  // (Bytes: what the kept sets hold, chunk slack included; Need: their records and reads alone)
   bool eagerFromNowOn = !job->covDeferred;
   if (job->covDeferred) {
     uint64_t freeB = 0, totalB = 0;
@@ -416,11 +417,16 @@ int t1k_job_run_local(t1k_job *job) {
         N.slot = (int)(w & 1);
         N.touched.assign(P, 0);
         if (!eagerFromNowOn) {
-          const uint64_t est = archivedFrags ? (uint64_t)((double)archivedBytes / (double)archivedFrags * (double)(N.f1 - N.f0)) : 0;
+          // what a window's read set will take: its fragments x the bytes per fragment of the windows kept so far (16 B per overlap record
+          // + the packed distinct read-ends; larger windows collapse more read-ends, so this errs high), a quarter to spare, and the
+          // slack of a partly filled store chunk per pipeline
+          const double perFrag = archivedFrags ? 1.25 * (double)archivedNeed / (double)archivedFrags : 0.0;
+          const uint64_t slack = (uint64_t)P * (uint64_t)std::max(1, job->prm.dev.store_chunk_mb) << 20;
+          auto estimate = [&](const Window &X) { return archivedFrags ? (uint64_t)(perFrag * (double)(X.f1 - X.f0)) + slack : 0ull; };
           uint64_t open = 0;  // windows cut earlier whose read sets are not kept yet
           for (uint32_t v = sh.oldest; v < w; ++v)
-            if (win[v].deferred && !win[v].done) open += archivedFrags ? (uint64_t)((double)archivedBytes / (double)archivedFrags * (double)(win[v].f1 - win[v].f0)) : 0;
-          if (archivedBytes + open + est <= archiveBudget) N.deferred = true;
+            if (win[v].deferred && !win[v].done) open += estimate(win[v]);
+          if (archivedBytes + open + estimate(N) <= archiveBudget) N.deferred = true;
           else eagerFromNowOn = true;
         }
         fNext = N.f1;
@@ -485,16 +491,17 @@ int t1k_job_run_local(t1k_job *job) {
   };
   // ---- pipelines -------------------------------------------------------------------------------------------------------
   // AssignRead over distinct read-ends [b0, b0 + nb) of a window; on a capacity error of a stage before anything is committed the range is split
-  std::function<int(t1k_ctx *, uint32_t, uint32_t, std::string &)> assignRange = [&](t1k_ctx *ctx, uint32_t b0, uint32_t nb, std::string &msg) -> int {
+  std::function<int(t1k_ctx *, Window &, uint32_t, uint32_t, std::string &)> assignRange = [&](t1k_ctx *ctx, Window &Wn, uint32_t b0, uint32_t nb, std::string &msg) -> int {
     int r = t1k_assign_range(ctx, b0, nb);
     if (r == T1K_ERR_CAPACITY && nb > 64) {
-      if ((r = assignRange(ctx, b0, nb / 2, msg)) != T1K_OK) return r;
-      return assignRange(ctx, b0 + nb / 2, nb - nb / 2, msg);
+      if ((r = assignRange(ctx, Wn, b0, nb / 2, msg)) != T1K_OK) return r;
+      return assignRange(ctx, Wn, b0 + nb / 2, nb - nb / 2, msg);
     }
     if (r != T1K_OK) { msg = t1k_last_error(ctx); return r; }
     t1k_stats st;
     t1k_stats_get(ctx, &st);
     std::lock_guard<std::mutex> g(sh.m);
+    Wn.ovlRecords += st.extended;
     job->stats.read_ends += st.read_ends; job->stats.lookups += st.lookups; job->stats.postings += st.postings; job->stats.hits += st.hits;
     job->stats.groups += st.groups; job->stats.candidates += st.candidates; job->stats.extended += st.extended; job->stats.near_best += st.near_best;
     job->stats.dp_calls += st.dp_calls; job->stats.ms_chain += st.ms_chain; job->stats.ms_extend += st.ms_extend; job->stats.ms_select += st.ms_select;
@@ -536,7 +543,7 @@ int t1k_job_run_local(t1k_job *job) {
       if (r == T1K_OK) (void)t1k_ctx_set_coverage_mode(ctx, (W.deferred || job->analyzer) ? 1 : 0);
       if (r == T1K_OK && kind == 0) {
         const uint32_t b0 = item * W.assignBatch, nb = std::min(W.assignBatch, W.nDistinct - b0);
-        r = assignRange(ctx, b0, nb, msg);
+        r = assignRange(ctx, W, b0, nb, msg);
       } else if (r == T1K_OK) {
         const uint32_t q0 = item * W.pairBatch, nq = std::min(W.pairBatch, (W.f1 - W.f0) - q0);
         e1.resize(nq); e2.resize(nq);
@@ -564,6 +571,7 @@ int t1k_job_run_local(t1k_job *job) {
               for (int q = 0; q < P; ++q)
                 if (W.touched[q]) (void)t1k_readset_take_store(rs, pipes[q], W.slot);
               archivedBytes += t1k_readset_bytes(rs); archivedFrags += W.f1 - W.f0;
+              archivedNeed += W.ovlRecords * 16 + (uint64_t)W.nDistinct * 220;
               job->archive.push_back(rs);
             } else if (sh.err == T1K_OK) { sh.err = T1K_ERR_INTERNAL; sh.errMsg = std::string("keeping the window's read set: ") + t1k_last_error(job->reader[W.slot]); }
           }
