@@ -317,8 +317,42 @@ int t1k_job_run_local(t1k_job *job) {
   job->assignText.clear();
   memset(&job->stats, 0, sizeof(job->stats));
   job->distinctReadEnds = 0; job->readEnds = (uint64_t)F * per;
-  if (in.maxLen > job->prm.dev.max_read_len && job->prm.dev.max_read_len > 0)
-    return jobFail(job, T1K_ERR_ARG, "a read of " + std::to_string(in.maxLen) + " bases is longer than this build handles (" + std::to_string(job->prm.dev.max_read_len) + ")");
+  // Reads longer than the kernels' hit masks span (320 bases) stop the run before any output exists -- unless the caller asks for them
+  // to be set aside (T1K_LONG_READS=drop): their fragments then take no part (never assigned, not written to the aligned-read files,
+  // counted in a warning), which is NOT what the reference does with them; everything else is genotyped as usual.
+  const uint32_t lenLimit = job->prm.dev.max_read_len > 0 ? (uint32_t)job->prm.dev.max_read_len : 0xFFFFFFFFu;
+  bool dropLong = false;
+  if ((uint32_t)in.maxLen > lenLimit) {
+    const char *e = getenv("T1K_LONG_READS");
+    if (!(e && !strcmp(e, "drop")))
+      return jobFail(job, T1K_ERR_ARG, "a read of " + std::to_string(in.maxLen) + " bases is longer than this build handles (" + std::to_string(job->prm.dev.max_read_len) +
+                                           "); T1K_LONG_READS=drop sets the fragments of such reads aside instead of stopping");
+    dropLong = true;
+    // Genotyper.cpp:443: the longest read -- of the fragments that take part
+    uint64_t keptMax = 0;
+    {
+      std::mutex mm;
+      parallelRanges(in.nFrag(), hostThreads(job), [&](int, size_t b, size_t e) {
+        uint64_t mx = 0;
+        for (size_t i = b; i < e; ++i) {
+          const uint32_t r = in.frag[i];
+          bool skip = false;
+          uint32_t here = 0;
+          for (uint32_t m = 0; m < (in.paired ? 2u : 1u); ++m) { const uint32_t l = in.side[m].seqL[r]; skip = skip || l > lenLimit; here = std::max(here, l); }
+          if (!skip) mx = std::max<uint64_t>(mx, here);
+        }
+        std::lock_guard<std::mutex> g(mm);
+        keptMax = std::max(keptMax, mx);
+      });
+    }
+    if (job->nRanks > 1 && job->comm) {
+      std::vector<uint64_t> all((size_t)job->nRanks, 0);
+      if (t1k_comm_allgather_u64(job->comm, &keptMax, 1, all.data()) != T1K_OK) return jobFail(job, T1K_ERR_DEVICE, t1k_comm_last_error(job->comm));
+      for (uint64_t v : all) keptMax = std::max(keptMax, v);
+    }
+    gt.readLength = (int)keptMax;
+  }
+  std::atomic<uint64_t> droppedFragments{0};
   if ((rc = t1k_coverage_reset(job->ctx)) != T1K_OK) return jobFail(job, rc, t1k_last_error(job->ctx));
   for (t1k_ctx *c : job->more)
     if ((rc = t1k_coverage_reset(c)) != T1K_OK) return jobFail(job, rc, t1k_last_error(c));
@@ -443,13 +477,22 @@ int t1k_job_run_local(t1k_job *job) {
       W.hasN.resize(nf);
       // lengths -> offsets (pieces, then a carry per piece), then the text itself
       std::vector<uint64_t> pieceBytes(T + 2, 0);
+      // (a fragment with an over-long read, under T1K_LONG_READS=drop: both ends go in as empty sequences)
+      auto setAside = [&](uint32_t r) {
+        if (!dropLong) return false;
+        for (uint32_t m = 0; m < per; ++m) if (in.side[m].seqL[r] > lenLimit) return true;
+        return false;
+      };
       parallelRanges(nf, T, [&](int t, size_t b, size_t e) {
-        uint64_t run = 0;
+        uint64_t run = 0, aside = 0;
         for (size_t i = b; i < e; ++i) {
           const uint32_t r = in.frag[fBeg - inBase + W.f0 + i];
-          for (uint32_t m = 0; m < per; ++m) { off[i * per + m] = run; run += in.side[m].seqL[r]; }
+          const bool skip = setAside(r);
+          aside += skip ? 1 : 0;
+          for (uint32_t m = 0; m < per; ++m) { off[i * per + m] = run; run += skip ? 0 : in.side[m].seqL[r]; }
         }
         pieceBytes[t + 1] = run;
+        if (aside) droppedFragments += aside;
       });
       for (int t = 0; t < T; ++t) pieceBytes[t + 1] += pieceBytes[t];  // pieces the loop did not use hold 0
       const uint64_t total = pieceBytes[T];
@@ -459,8 +502,9 @@ int t1k_job_run_local(t1k_job *job) {
         for (size_t i = b; i < e; ++i) {
           const uint32_t r = in.frag[fBeg - inBase + W.f0 + i];
           bool n = false;
+          const bool skip = setAside(r);
           for (uint32_t m = 0; m < per; ++m) {
-            const uint32_t len = in.side[m].seqL[r];
+            const uint32_t len = skip ? 0 : in.side[m].seqL[r];
             const uint64_t at = (off[i * per + m] += carry);
             memcpy(tx.data() + at, in.side[m].seqP[r], len);
             n = n || memchr(in.side[m].seqP[r], 'N', len) != nullptr;  // Genotyper.cpp: hasN = strchr(seq, 'N')
@@ -636,6 +680,9 @@ int t1k_job_run_local(t1k_job *job) {
     if (writer.joinable()) writer.join();
   }
   if (sh.err != T1K_OK) { streamClose(job, true); return jobFail(job, sh.err, sh.errMsg); }
+  if (dropLong)
+    fprintf(stderr, "genotyper: WARNING: %llu fragment(s)%s hold a read longer than %u bases and were set aside (T1K_LONG_READS=drop): the reference would have genotyped them\n",
+            (unsigned long long)droppedFragments.load(), job->nRanks > 1 ? " of this rank" : "", lenLimit);
   const double tDev = nowMs();
   for (t1k_ctx *c : job->more)
     if ((rc = t1k_coverage_absorb(job->ctx, c)) != T1K_OK) return jobFail(job, rc, t1k_last_error(job->ctx));

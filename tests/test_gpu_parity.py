@@ -558,6 +558,40 @@ def test_over_long_read_fails_before_any_output(built, tmp_path):
     assert not any(f.startswith("long_") and f != "long_1.fq" for f in os.listdir(str(tmp_path)))
 
 
+@pytest.mark.parametrize("gpus", ["", "0,0"])
+def test_over_long_reads_can_be_set_aside(built, tmp_path, gpus):
+    """T1K_LONG_READS=drop: the fragments of reads beyond 320 bases take no part, the run finishes with a warning, and every output
+    file equals the run on the same files without those fragments (the reference itself would have genotyped them: an escape hatch
+    for the odd over-long read in millions, not parity)"""
+    c = goldens.Case("cyp_rna_2x100", str(tmp_path))
+    l1, l2 = open(c.r1).read().split("\n"), open(c.r2).read().split("\n")
+    long_at = (7, 40)
+    with_long, without = [list(l1), list(l2)], [[], []]
+    for k in long_at:
+        with_long[k % 2][4 * k + 1] = with_long[k % 2][4 * k + 1] * 4   # a 400-base read, once in mate 1's file and once in mate 2's
+        with_long[k % 2][4 * k + 3] = with_long[k % 2][4 * k + 3] * 4
+    for m, src in enumerate((l1, l2)):
+        for i in range(0, len(src) - 1, 4):
+            if i // 4 not in long_at:
+                without[m] += src[i:i + 4]
+    paths = {}
+    for tag, data in (("long", with_long), ("cut", without)):
+        for m in (0, 1):
+            paths[tag, m] = os.path.join(str(tmp_path), "%s_%d.fq" % (tag, m + 1))
+            open(paths[tag, m], "w").write("\n".join(data[m]) + ("\n" if tag == "cut" else ""))
+    env = dict(os.environ, T1K_LONG_READS="drop")
+    if gpus:
+        env["T1K_GPUS"] = gpus
+    a, b = os.path.join(str(tmp_path), "a"), os.path.join(str(tmp_path), "b")
+    r = subprocess.run([GENO, "-f", c.ref, "-1", paths["long", 0], "-2", paths["long", 1], "-o", a] + c.flags, stderr=subprocess.PIPE, text=True, env=env)
+    assert r.returncode == 0, r.stderr
+    assert "set aside" in r.stderr and "WARNING" in r.stderr
+    r = subprocess.run([GENO, "-f", c.ref, "-1", paths["cut", 0], "-2", paths["cut", 1], "-o", b] + c.flags, stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 0, r.stderr
+    for suf in ("_genotype.tsv", "_allele.tsv", "_aligned_1.fa", "_aligned_2.fa"):
+        assert open(a + suf, "rb").read() == open(b + suf, "rb").read(), suf
+
+
 @pytest.mark.parametrize("label,kind,scale,genes,pairs,flags", [
     ("config2_hla_rna_100k", "ref-rna", 1.0, 24, 100000, ["-s", "0.97"]),                                  # BASELINE configs[1], 100 k of its pairs
     ("config3_kir_wgs_100k", "ref-dna", 1.0, 17, 100000, ["-s", "0.9", "--relaxIntronAlign"]),           # --preset kir-wgs (run-t1k:300-304)
