@@ -340,6 +340,8 @@ def main():
         if world == 1 and not a.no_executable_check:
             exe = os.path.join(ROOT, "t1k_amd", "bin", "genotyper")
             t1k_amd.pool_release()   # this process's cached device memory would otherwise be fresh (to-be-zeroed) VRAM for the other one
+            time.sleep(10)           # ... and the driver wipes what was just returned (> 100 GB) in the background: a process started into that
+                                     # waits for the wipe (8 - 9 s measured instead of 4.8 s for the same command on an idle GPU)
             t1 = time.time()
             sh([exe, "-f", ref, "-1", pfx + "_1.fq", "-2", pfx + "_2.fq", "-s", "0.97", "-o", os.path.join(a.workdir, "exe_out")] +
                (["--barcode", barcode_file] if barcode_file else []), stderr=subprocess.DEVNULL)
