@@ -104,7 +104,7 @@ __device__ __forceinline__ bool extendOne(const ExtendArgs &P, uint64_t gid, uns
     if (bestP >= 0) { int i = ss - 1 - bestP; leftClip = lo - i; lo = i; }
   }
   unsigned int dpLocal = 0;
-  const ReadCtx rc{rb, rn, len, P.ref.bases, P.ref.nmask, goff, alleleLen};
+  const ReadCtx rc{rb, rn, len, P.ref.bases, P.ref.nmask, goff, alleleLen, P.ref.anyN != 0};
   const GapSink sink{P.memo + (uint64_t)c.re * GAP_CACHE, P.jobStr, P.counters, c.re * GAP_CACHE, P.jobSegCap, T1K_AR_EXTJOBS};
   uint32_t slot = 0;
   bool pending = false;
@@ -805,7 +805,7 @@ __global__ __launch_bounds__(WG) void k_align_flags(SlowArgs P, uint32_t *flags)
     const T1kOvl o = P.ovl[P.slowQueue[q]], p = P.ovl[P.slowQueue[q - 1]];
     const int lt = o.seqEnd - o.seqStart + 1;
     if (o.re == p.re && ((o.flags ^ p.flags) & 2) == 0 && o.readStart == p.readStart && o.readEnd == p.readEnd && lt == p.seqEnd - p.seqStart + 1 &&
-        t1k_same_window(P.ref.bases, P.ref.nmask, (int64_t)P.ref.alleleOff[p.allele] + p.seqStart, (int64_t)P.ref.alleleOff[o.allele] + o.seqStart, lt))
+        t1k_same_window(P.ref.bases, P.ref.nmask, (int64_t)P.ref.alleleOff[p.allele] + p.seqStart, (int64_t)P.ref.alleleOff[o.allele] + o.seqStart, lt, P.ref.anyN != 0))
       fl = 0;
   }
   flags[q] = fl;

@@ -763,6 +763,7 @@ static int assignOnce(t1k_ctx *ctx, uint64_t first, uint32_t count) {
   a.genJobStr = a.genHits + genHitCap; a.genJobList = a.genJobStr + genJobCap; a.genJobSegCap = genJobCap / T1K_NSTRIPE;
   a.groupSegCap = groupSegCap; a.jobSegCap = jobSegCap; a.listSegCap = listSegCap; a.rareSegCap = rareSegCap; a.genCandSegCap = genCandSegCap;
   a.bigScratch = (uint32_t *)ctx->bWgBig.p;
+  { static const int ep = getenv("T1K_NO_EARLY_PRUNE") ? 0 : 1; a.earlyPrune = ep; }
   a.cand = (T1kCand *)ctx->bCand.p; a.candCap = ctx->wCand;
   a.candStart = (uint32_t *)ctx->bCandStart.p; a.candCount = (uint32_t *)ctx->bCandCount.p;
   a.counters = (unsigned long long *)ctx->bCounters.p;
@@ -829,8 +830,8 @@ static int assignOnce(t1k_ctx *ctx, uint64_t first, uint32_t count) {
   if (getenv("T1K_DEBUG_PHASES")) {
     float a1 = 0, a2 = 0, a3 = 0;
     (void)hipEventElapsedTime(&a1, ctx->ev[3], ctx->ev[7]); (void)hipEventElapsedTime(&a2, ctx->ev[7], evSlow); (void)hipEventElapsedTime(&a3, evSlow, ctx->ev[4]);
-    fprintf(stderr, "[t1k] fullalign %.2f ms, eq-DP (%llu jobs) + general-DP (%llu jobs) %.2f ms, truncate %.2f ms; cand %llu ovl %llu dp %llu; groups %llu fast %llu general %llu big %llu; memo jobs %llu parked %llu wide-queue %llu\n",
-            a1, hc[8], hc[15], a2, a3, hc[0], hc[1], hc[7], hc[6], hc[11], hc[12], hc[13], hc[16], hc[17], hc[20]);
+    fprintf(stderr, "[t1k] fullalign %.2f ms, eq-DP (%llu jobs) + general-DP (%llu jobs) %.2f ms, truncate %.2f ms; cand %llu ovl %llu dp %llu; groups %llu (gap walk %llu) fast %llu general %llu big %llu; memo jobs %llu parked %llu wide-queue %llu\n",
+            a1, hc[8], hc[15], a2, a3, hc[0], hc[1], hc[7], hc[6], (unsigned long long)ctx->lastSlowGroups, hc[11], hc[12], hc[13], hc[16], hc[17], hc[20]);
   }
   t1k_stats &st = ctx->stats;
   st.read_ends = n; st.lookups = hc[3]; st.postings = hc[4]; st.hits = hc[5]; st.groups = hc[6]; st.candidates = hc[0]; st.extended = hc[1];

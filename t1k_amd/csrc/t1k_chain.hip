@@ -96,7 +96,7 @@ __device__ __forceinline__ void shlOr(uint64_t *C, int sft) {
 #define GROUP_MAX_REFS 4   // two 32-bit words of 16-bit memo slots in a group record
 template <int NW, bool DEFER, bool CLOSED>
 __device__ inline int groupFastPath(const uint32_t *Mw, int diag, const ReadCtx &c, bool hasN, int k, int hitLenRequired, double simThreshold, CandOut &out,
-                                    unsigned int *dpCounter, int strandBit, const GapSink &sink, uint32_t *refs, int *nRefs) {
+                                    unsigned int *dpCounter, int strandBit, const GapSink &sink, uint32_t *refs, int *nRefs, bool earlyPrune = true) {
   constexpr int MW = (NW + 1) / 2;  // 64-bit words of the read-offset bitmask
   uint64_t M[MW];
   int onDiag = 0;
@@ -174,7 +174,53 @@ __device__ inline int groupFastPath(const uint32_t *Mw, int diag, const ReadCtx 
   int matchCnt;
   int result = 1;
   if (mmT <= 3) matchCnt = 2 * (span - mmT);
-  else if (CLOSED) return 5;  // first pass: only the closed form; the gap walk runs on the compacted list of the others
+  else if (CLOSED) {
+    // first pass: the closed form ... and the groups that are certain to fail the similarity filter whatever their gaps hold.  Every gap
+    // (maximal uncovered run inside the span) with a mismatch costs at least one match -- x of them if x <= 3, one or more if x > 3 --
+    // so U' = 2 * (span - #gaps holding a mismatch) bounds the exact prune bound U of the gap walk from above; U' / (2 * span) < s
+    // means the candidate is dropped (k_collect), and like the walk's pruned candidates it leaves with the bound as its matchCnt
+    // (nothing reads the matchCnt of a dropped candidate; the strand vote reads matchCnt0 = 2 * cov).  The gaps are counted without a
+    // walk: relative to `first`, X = uncovered positions, E = mismatching positions (a subset of X: covered positions are exact
+    // k-mer hits); in X + E every run of X that holds a bit of E carries out exactly once into the covered position above it.
+    uint64_t X[MW], E[MW];
+    {
+      const int ws = first >> 6, bs = first & 63;
+#pragma unroll
+      for (int w = 0; w < MW; ++w) {
+        uint64_t lo = 0, hi = 0;
+#pragma unroll
+        for (int v = 0; v < MW; ++v) {
+          if (v == w + ws) lo = C[v];
+          if (v == w + ws + 1) hi = C[v];
+        }
+        const uint64_t crel = bs ? ((lo >> bs) | (hi << (64 - bs))) : lo;
+        const int rem = span - 64 * w;
+        X[w] = rem <= 0 ? 0ull : (~crel & (rem >= 64 ? ~0ull : ((1ull << rem) - 1ull)));
+        uint64_t e = 0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          if (2 * w + h < NW) {
+            uint64_t x = mmw[2 * w + h] & 0x5555555555555555ull;
+            x = (x | (x >> 1)) & 0x3333333333333333ull; x = (x | (x >> 2)) & 0x0F0F0F0F0F0F0F0Full; x = (x | (x >> 4)) & 0x00FF00FF00FF00FFull;
+            x = (x | (x >> 8)) & 0x0000FFFF0000FFFFull; x = (x | (x >> 16)) & 0xFFFFFFFFull;
+            e |= x << (32 * h);
+          }
+        }
+        E[w] = e & X[w];
+      }
+    }
+    int nGaps = 0;
+    uint64_t carry = 0;
+#pragma unroll
+    for (int w = 0; w < MW; ++w) {
+      const uint64_t s1 = X[w] + E[w], s2 = s1 + carry;
+      carry = (s1 < X[w]) | (s2 < s1) ? 1ull : 0ull;
+      nGaps += __popcll(s2 & ~X[w]);
+    }
+    const int bound = 2 * (span - nGaps);
+    if (!earlyPrune || !((double)bound / (double)(2 * span) < simThreshold)) return 5;  // the gap walk decides (compacted list of these groups)
+    matchCnt = bound;
+  }
   else {
     // walk the gaps (maximal uncovered runs inside the span)
     int sumSmall = 0, nBig = 0;
@@ -843,7 +889,7 @@ enum { REC_DONE = 0x80000000u };  // word 3 after chaining: REC_DONE | number of
 __device__ __forceinline__ ReadCtx makeCtx(const ChainArgs &P, uint32_t re, int pass, uint32_t allele) {
   const int S = P.reads.S;
   ReadCtx c{P.reads.bases + ((uint64_t)re * 2 + pass) * S, P.reads.nmask + ((uint64_t)re * 2 + pass) * S, (int)P.reads.len[re], P.ref.bases, P.ref.nmask,
-            (int64_t)P.ref.alleleOff[allele], (int)P.ref.alleleLen[allele]};
+            (int64_t)P.ref.alleleOff[allele], (int)P.ref.alleleLen[allele], P.ref.anyN != 0};
   return c;
 }
 
@@ -890,7 +936,7 @@ __global__ __launch_bounds__(WG) void k_chain_fast(ChainArgs P, const uint32_t *
       const GapSink sink{P.memo + (uint64_t)re * GAP_CACHE, P.jobStr, P.counters, re * GAP_CACHE, P.jobSegCap, T1K_AR_JOBS};
       uint32_t refs[2] = {0, 0};
       int nRefs = 0;
-      kind = groupFastPath<NW, DEFER, MODE == 0>(Mw, recDiag(rv[2]), c, P.ref.alleleHasN[allele] != 0, P.k, P.hitLenRequired, P.sim, out, &dpLocal, pass, sink, refs, &nRefs);
+      kind = groupFastPath<NW, DEFER, MODE == 0>(Mw, recDiag(rv[2]), c, P.ref.alleleHasN[allele] != 0, P.k, P.hitLenRequired, P.sim, out, &dpLocal, pass, sink, refs, &nRefs, P.earlyPrune != 0);
       if (kind == 3) {  // matchCnt lacks the registered alignments: k_chain_finish adds them from the memo
         // words 2..7: state (= number of memo slots to add), candidate, slots
         ((uint2 *)rec)[1] = make_uint2((uint32_t)nRefs, cbuf[0]);
@@ -923,7 +969,7 @@ __global__ __launch_bounds__(WG) void k_dp_dense(ChainArgs P, const uint32_t *jo
     const unsigned long long e = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int sb = (int)(e & 1), d = (int)((e >> 1) & 0xF) - 4, lp = (int)((e >> 5) & 0x1FF), readPos = (int)((e >> 14) & 0x7FF);
     const int S = P.reads.S;
-    ReadCtx c{P.reads.bases + ((uint64_t)re * 2 + sb) * S, P.reads.nmask + ((uint64_t)re * 2 + sb) * S, 0, P.ref.bases, P.ref.nmask, 0, 0};
+    ReadCtx c{P.reads.bases + ((uint64_t)re * 2 + sb) * S, P.reads.nmask + ((uint64_t)re * 2 + sb) * S, 0, P.ref.bases, P.ref.nmask, 0, 0, true};
     const int m = gapAlign(c, readPos, GAP_GPOS(e), lp, lp + d);
     ++dpLocal;
     __hip_atomic_store(slot, (e & ~(GAP_PENDING << 25)) | ((unsigned long long)m << 25), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1482,6 +1528,7 @@ int t1k_run_chain(t1k_ctx *ctx, const ChainArgs &a, int nWg, int bigBlocks, bool
   if ((rc = readCounters(ctx, hc))) return rc;
   const T1kArenaCounts slow = t1k_arena_counts(ctx, T1K_AR_SLOW, a.listSegCap);
   if (slow.overflow) { hc[2] |= ERR_GROUPCAP; return 0; }
+  ctx->lastSlowGroups = slow.total;
   if (slow.total) {
     t1k_arena_compact(ctx, T1K_AR_SLOW, a.slowStr, a.listSegCap, a.slowList, slow.maxSeg);
     const uint32_t nSlowGroups = (uint32_t)slow.total;

@@ -98,6 +98,7 @@ struct T1kRefDev {
   const uint64_t *alleleOff;    // [A]
   const uint32_t *alleleLen;    // [A]
   const uint8_t *alleleHasN;    // [A] 1 if the allele holds an N anywhere (its N-mask words can be skipped otherwise)
+  uint32_t anyN;                // some allele holds an N (0: nobody needs to load nmask words of the reference)
   const uint32_t *sepStart;     // [A+1] into sepPos: interior N positions only (the -1 / len sentinels are implicit)
   const int32_t *sepPos;
   const uint32_t *kStart;       // [4^k + 1]
@@ -143,11 +144,13 @@ struct T1kReadsDev {
 // ------------------------------------------------------------------------------------------------------------------
 // 32 consecutive positions starting at position pos (pos >= 0) of a 2-bit-per-position stream; the arrays carry
 // one spare word so w[wi+1] is always addressable.
+// two consecutive stream words in one 16-byte access (the streams are only 8-byte aligned; gfx950 global loads allow that)
+typedef uint64_t t1k_u64x2 __attribute__((ext_vector_type(2), aligned(8)));
 __device__ __forceinline__ uint64_t t1k_get32(const uint64_t *w, int64_t pos) {
   int64_t wi = pos >> 5;
   int sh = (int)(pos & 31) * 2;
-  uint64_t lo = w[wi], hi = w[wi + 1];  // both loads issue together; branch-free so callers can keep many windows in flight
-  return (lo >> sh) | ((hi << 1) << (63 - sh));
+  const t1k_u64x2 v = *(const t1k_u64x2 *)(w + wi);  // one 16-byte request for both words (a lane's address is its own: the request count is what these kernels pay for); branch-free
+  return (v.x >> sh) | ((v.y << 1) << (63 - sh));
 }
 // reverse complement of a k-mer code (first base in the low bits): the code of the same window read on the other strand
 __host__ __device__ __forceinline__ uint32_t t1k_code_revcomp(uint32_t code, int k) {
@@ -158,8 +161,6 @@ __host__ __device__ __forceinline__ uint32_t t1k_code_revcomp(uint32_t code, int
   x = ((x & 0xCCCCCCCCu) >> 2) | ((x & 0x33333333u) << 2);  // 2-bit groups reversed, bits inside a group kept
   return (~x) >> (32 - 2 * k);
 }
-// two consecutive stream words in one 16-byte access (the streams are only 8-byte aligned; gfx950 global loads allow that)
-typedef uint64_t t1k_u64x2 __attribute__((ext_vector_type(2), aligned(8)));
 __device__ __forceinline__ uint64_t t1k_lowmask(int nPos) {  // mask of the first nPos positions (0..32)
   return nPos >= 32 ? ~0ull : ((1ull << (2 * nPos)) - 1);
 }
@@ -207,11 +208,13 @@ __device__ inline bool t1k_low_complexity(const uint64_t *rb, const uint64_t *rn
 }
 
 // do two L-position windows of the reference hold the same bases and N marks?
-__device__ inline bool t1k_same_window(const uint64_t *gb, const uint64_t *gn, int64_t a, int64_t b, int L) {
+__device__ inline bool t1k_same_window(const uint64_t *gb, const uint64_t *gn, int64_t a, int64_t b, int L, bool anyN = true) {
   if (a == b) return true;
   for (int o = 0; o < L; o += 32) {
     uint64_t lm = t1k_lowmask(L - o);
-    if (((t1k_get32(gb, a + o) ^ t1k_get32(gb, b + o)) & lm) | ((t1k_get32(gn, a + o) ^ t1k_get32(gn, b + o)) & lm)) return false;
+    uint64_t x = t1k_get32(gb, a + o) ^ t1k_get32(gb, b + o);
+    if (anyN) x |= t1k_get32(gn, a + o) ^ t1k_get32(gn, b + o);
+    if (x & lm) return false;
   }
   return true;
 }
@@ -734,6 +737,7 @@ struct t1k_ctx {
   uint64_t emNnz = 0;
   std::vector<int32_t> hEmLen;
   int traceFetch = 0;          // T1K_DEBUG_TRACE
+  uint64_t lastSlowGroups = 0;             // groups the last range left to the gap walk (T1K_DEBUG_PHASES)
   uint64_t pairEpoch = 0;      // epochs handed out to k_pair's allele tables since they were last cleared
   unsigned long long *countersPinned = nullptr;  // page-locked landing buffer of t1k_fetch_counters
   double *emPinned = nullptr;  // page-locked staging for the per-update vectors: [x | n], emPinnedN doubles each

@@ -21,6 +21,7 @@ struct ChainArgs {
   uint32_t *genHits;  // hit lists of the multi-diagonal groups (k_gather_general)
   uint32_t *genCand; uint32_t genCandCap;                  // packed candidates of multi-diagonal groups (3 u32 each)
   uint32_t *bigScratch;
+  int earlyPrune;          // k_chain_fast<*, 0> finishes the groups that cannot pass the similarity filter (T1K_NO_EARLY_PRUNE=1: leaves them to the gap walk)
   T1kCand *cand; uint64_t candCap;
   uint32_t *candStart, *candCount;
   unsigned long long *counters;

@@ -9,6 +9,7 @@ struct ReadCtx {
   const uint64_t *gb, *gn;   // reference words
   int64_t goff;              // allele global base offset
   int alleleLen;
+  bool refN;                 // the reference holds an N somewhere (T1kRefDev::anyN): otherwise its N-mask words are all zero and not loaded here
 };
 
 
@@ -55,7 +56,7 @@ __device__ inline int gapMatchesCached(const ReadCtx &c, int readPos, int64_t gp
   uint64_t hsh = 0x9E3779B97F4A7C15ull ^ ((uint64_t)readPos << 20) ^ ((uint64_t)lp << 1) ^ ((uint64_t)(d + 4) << 40) ^ (uint64_t)strandBit;
   for (int o = 0; o < lt; o += 32) {
     uint64_t lm = t1k_lowmask(lt - o);
-    uint64_t gw = t1k_get32(c.gb, gpos + o) & lm, gnw = t1k_get32(c.gn, gpos + o) & lm;
+    uint64_t gw = t1k_get32(c.gb, gpos + o) & lm, gnw = c.refN ? t1k_get32(c.gn, gpos + o) & lm : 0;
     if (d == 0) {
       uint64_t xo = t1k_get32(c.rb, readPos + o) ^ gw;
       uint64_t mm = (xo | (xo >> 1)) & T1K_EVEN & ~(t1k_get32(c.rn, readPos + o) | gnw) & lm;
@@ -82,7 +83,7 @@ __device__ inline int gapMatchesCached(const ReadCtx &c, int readPos, int64_t gp
     const unsigned long long e = probed[probe];
     if (e != 0 && (e & GAP_ID_MASK) == idBits) {
       int64_t eg = GAP_GPOS(e);
-      if (eg == gpos || t1k_same_window(c.gb, c.gn, eg, gpos, lt)) {
+      if (eg == gpos || t1k_same_window(c.gb, c.gn, eg, gpos, lt, c.refN)) {
         const uint32_t v = GAP_VAL(e);
         if (v != GAP_PENDING) return (int)v;
         pendingSeen = true;
@@ -106,7 +107,7 @@ __device__ inline int gapMatchesCached(const ReadCtx &c, int readPos, int64_t gp
         *slotOut = slot ^ probe;
         return -1;
       }
-      if ((old & GAP_ID_MASK) == idBits && (GAP_GPOS(old) == gpos || t1k_same_window(c.gb, c.gn, GAP_GPOS(old), gpos, lt))) {
+      if ((old & GAP_ID_MASK) == idBits && (GAP_GPOS(old) == gpos || t1k_same_window(c.gb, c.gn, GAP_GPOS(old), gpos, lt, c.refN))) {
         *slotOut = slot ^ probe;
         return -1;  // somebody else just claimed it
       }

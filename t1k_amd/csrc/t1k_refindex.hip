@@ -315,6 +315,8 @@ extern "C" int t1k_ref_upload(t1k_ctx *ctx, const char *seqs, const uint64_t *of
 #undef RU_HIP
   r.bases = (const uint64_t *)dBases; r.nmask = (const uint64_t *)dN; r.exon = (const uint64_t *)dExon;
   r.alleleOff = (const uint64_t *)dAlleleOff; r.alleleLen = (const uint32_t *)dAlleleLen; r.alleleHasN = (const uint8_t *)dHasN;
+  r.anyN = 0;
+  for (uint8_t h : alleleHasN) r.anyN |= h;
   r.sepStart = (const uint32_t *)dSepStart; r.sepPos = (const int32_t *)dSepPos;
   r.kStart = (const uint32_t *)dKStart; r.kHas = (const uint32_t *)dHas; r.kMulti = (const uint32_t *)dMulti; r.kHasPre = (const uint32_t *)dHasPre;
   r.kDirIdx = (const uint32_t *)dDirIdx; r.kDir = (const uint32_t *)dDir; r.kDirStride = stride;
