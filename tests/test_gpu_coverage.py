@@ -155,3 +155,29 @@ def test_barcode_config_at_size_vs_committed_reference_hashes(built, tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     assert md5(a + "_barcode_expr.tsv") == want["analyzer_barcode_expr.tsv"]
     assert os.path.getsize(a + "_allele.vcf") == want["analyzer_vcf_bytes"] == 0
+
+
+def test_kir_wgs_config_at_size_vs_committed_reference_hashes(built, tmp_path):
+    """BASELINE configs[2] on one GPU, at size: 10 M 2x150 bp pairs against the KIR-like dna reference with the kir-wgs preset
+    (-s 0.9 --relaxIntronAlign, run-t1k:300-304): the near-best alignments run in every range for the relaxed counts and their
+    coverage is added behind selection.  Expected = md5 of the files the REFERENCE binary wrote for this very input on an MI355X host
+    (tools/kir_10M_parity_r03.sh, profiles/r03_kir_10M_parity.log: 243 s at -t 32), committed in tests/golden/full_size_md5.json."""
+    import hashlib
+    import json
+    want = json.load(open(os.path.join(util.GOLDEN, "full_size_md5.json")))["kir_10M"]
+    tmp = str(tmp_path)
+    ref = os.path.join(tmp, "kir.fa")
+    util.synth_ref("ref-dna", ref, genes=want["genes"], scale=1.0, seed=20250614)
+    pfx = os.path.join(tmp, "k")
+    util.synth_reads(ref, pfx, pairs=want["pairs"], len=150, seed=want["seed"])
+    g = os.path.join(tmp, "g")
+    r = subprocess.run([GENO, "-f", ref, "-1", pfx + "_1.fq", "-2", pfx + "_2.fq"] + want["flags"].split() + ["-o", g], stderr=subprocess.PIPE, text=True,
+                       env=dict(os.environ, T1K_DEBUG_PHASES="1"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "coverage deferred to selection" in r.stderr
+    for suf in ("_genotype.tsv", "_allele.tsv", "_aligned_1.fa", "_aligned_2.fa"):
+        h = hashlib.md5()
+        with open(g + suf, "rb") as f:
+            for blk in iter(lambda: f.read(1 << 24), b""):
+                h.update(blk)
+        assert h.hexdigest() == want[suf], suf
