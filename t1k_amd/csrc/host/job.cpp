@@ -269,9 +269,11 @@ static bool loadAbundance(t1k_job *job) {
 // Fragments stream through the GPU in windows of T1K_WINDOW fragments (file order).  A window is prepared by its own thread
 // on one of two read-set contexts -- the read-ends' text gathered from the mapped files by the host threads, uploaded, packed,
 // identical read-ends collapsed (t1k_reads_dedupe: the reference's sort + run-length loop, Genotyper.cpp:451-480) -- while the
-// pipelines work on the window before it.  Work items of a window: AssignRead over ranges of its distinct read-ends, then -- once
-// all of those are done, because a fragment's mates are scattered over the ranges -- mate pairing over ranges of its fragments
-// straight into the job's rowset.  A pipeline that finds no item left in the oldest window starts on the next one (its lists go
+// pipelines work on the window before it.  Work items of a window: AssignRead over ranges of its distinct read-ends, and mate pairing
+// over ranges of its fragments straight into the job's rowset.  The distinct read-ends are numbered in the order of their first use
+// (t1k_reads_dedupe), so the fragments of pairing range q only name distinct read-ends below pairNeed[q] x the assignment range:
+// the range is paired as soon as that prefix of the assignment ranges is done, beside the assignment of the rest (with the window
+// that holds 82 % of a 10 M-pair job paired only after its last assignment range, the loop ended in 0.4 s of pairing alone).  A pipeline that finds no item left in the oldest window starts on the next one (its lists go
 // to the other slot of the pipeline's overlap store), so the GPU does not drain at window boundaries.
 // ------------------------------------------------------------------------------------------------------------------
 namespace {
@@ -283,6 +285,9 @@ struct Window {
   std::vector<uint8_t> hasN;        // per fragment
   uint32_t assignBatch = 0, nAssign = 0, nextAssign = 0, doneAssign = 0;
   uint32_t pairBatch = 0, nPair = 0, nextPair = 0, donePair = 0;
+  std::vector<uint32_t> pairNeed;   // per pairing range: how many assignment ranges (a prefix) hold the read-ends of its fragments and of all before
+  std::vector<char> assignDone;     // per assignment range
+  uint32_t assignPrefix = 0;        // assignment ranges [0, assignPrefix) are done
   bool ready = false, done = false;
   std::vector<char> pairDone;       // per pairing range of the window: finished (the output writer follows these)
   double tReady = 0, tDone = 0, msPrep = 0;
@@ -422,8 +427,13 @@ int t1k_job_run_local(t1k_job *job) {
   const bool traceTasks = getenv("T1K_DEBUG_TASKS") != nullptr;
   // ---- window preparation ------------------------------------------------------------------------------------------
   auto prepare = [&] {
-    std::vector<char> text[2];
-    std::vector<uint64_t> offs[2];
+    // gathered text and offsets of a window, per read-set slot: plain allocations, never value-initialised (std::vector::resize would zero
+    // the 2.5 GB of the large window on this one thread before the host threads fill it: 0.3 s of a 0.7 s preparation)
+    struct Raw {
+      void *p = nullptr; size_t cap = 0;
+      ~Raw() { free(p); }
+      void *need(size_t bytes) { if (bytes > cap) { free(p); p = malloc(bytes); cap = p ? bytes : 0; } return p; }
+    } text[2], offs[2];
     uint64_t fNext = 0;
     for (uint32_t w = 0; fNext < F; ++w) {
       {
@@ -471,9 +481,8 @@ int t1k_job_run_local(t1k_job *job) {
       Window &W = win[w];
       const double t0 = nowMs();
       const uint32_t nf = W.f1 - W.f0, ne = nf * per;
-      std::vector<uint64_t> &off = offs[W.slot];
-      std::vector<char> &tx = text[W.slot];
-      off.resize((size_t)ne + 1);
+      uint64_t *off = (uint64_t *)offs[W.slot].need(((size_t)ne + 1) * 8);
+      if (!off) { fail(T1K_ERR_DEVICE, "window preparation: out of host memory"); return; }
       W.hasN.resize(nf);
       // lengths -> offsets (pieces, then a carry per piece), then the text itself
       std::vector<uint64_t> pieceBytes(T + 2, 0);
@@ -496,7 +505,8 @@ int t1k_job_run_local(t1k_job *job) {
       });
       for (int t = 0; t < T; ++t) pieceBytes[t + 1] += pieceBytes[t];  // pieces the loop did not use hold 0
       const uint64_t total = pieceBytes[T];
-      tx.resize(total + 16);
+      char *tx = (char *)text[W.slot].need(total + 16);
+      if (!tx) { fail(T1K_ERR_DEVICE, "window preparation: out of host memory"); return; }
       parallelRanges(nf, T, [&](int t, size_t b, size_t e) {
         const uint64_t carry = pieceBytes[t];
         for (size_t i = b; i < e; ++i) {
@@ -506,7 +516,7 @@ int t1k_job_run_local(t1k_job *job) {
           for (uint32_t m = 0; m < per; ++m) {
             const uint32_t len = skip ? 0 : in.side[m].seqL[r];
             const uint64_t at = (off[i * per + m] += carry);
-            memcpy(tx.data() + at, in.side[m].seqP[r], len);
+            memcpy(tx + at, in.side[m].seqP[r], len);
             n = n || memchr(in.side[m].seqP[r], 'N', len) != nullptr;  // Genotyper.cpp: hasN = strchr(seq, 'N')
           }
           W.hasN[i] = n ? 1 : 0;
@@ -515,14 +525,31 @@ int t1k_job_run_local(t1k_job *job) {
       off[ne] = total;
       const double tText = nowMs();
       t1k_ctx *rd = job->reader[W.slot];
-      int r = t1k_reads_upload(rd, tx.data(), off.data(), nullptr, ne);
+      int r = t1k_reads_upload(rd, tx, off, nullptr, ne);
+      const double tUp = nowMs();
       W.distinctOf.resize(ne);
+      const double tRes = nowMs();
       if (r == T1K_OK) r = t1k_reads_dedupe(rd, W.distinctOf.data(), &W.nDistinct);
+      const double tDd = nowMs();
       if (r != T1K_OK) { fail(r, t1k_last_error(rd)); return; }
       W.assignBatch = assignBatch; W.nAssign = (W.nDistinct + assignBatch - 1) / assignBatch;
       W.pairBatch = pairBatch; W.nPair = (nf + pairBatch - 1) / pairBatch;
       W.pairDone.assign(W.nPair, 0);
-      if (traceTasks) fprintf(stderr, "[t1k task] prep window %u: %.1f .. %.1f ms (text %.1f ms)\n", w, t0 - tStart, nowMs() - tStart, tText - t0);
+      W.assignDone.assign(W.nAssign, 0);
+      W.pairNeed.assign(W.nPair, 0);
+      {  // highest distinct read-end named by each pairing range, then the running maximum over the ranges before it
+        parallelRanges(W.nPair, T, [&](int, size_t b, size_t e) {
+          for (size_t q = b; q < e; ++q) {
+            const size_t i0 = q * (size_t)pairBatch * per, i1 = std::min<size_t>((size_t)ne, (q + 1) * (size_t)pairBatch * per);
+            uint32_t mx = 0;
+            for (size_t i = i0; i < i1; ++i) mx = std::max(mx, W.distinctOf[i]);
+            W.pairNeed[q] = mx / assignBatch + 1;
+          }
+        });
+        for (uint32_t q = 1; q < W.nPair; ++q) W.pairNeed[q] = std::max(W.pairNeed[q], W.pairNeed[q - 1]);
+        for (uint32_t q = 0; q < W.nPair; ++q) W.pairNeed[q] = std::min(W.pairNeed[q], W.nAssign);
+      }
+      if (traceTasks) fprintf(stderr, "[t1k task] prep window %u: %.1f .. %.1f ms (text %.1f ms, upload %.1f, resize %.1f, dedupe %.1f, pairing needs %.1f)\n", w, t0 - tStart, nowMs() - tStart, tText - t0, tUp - tText, tRes - tUp, tDd - tRes, nowMs() - tDd);
       {
         std::lock_guard<std::mutex> g(sh.m);
         job->distinctReadEnds += W.nDistinct;
@@ -566,7 +593,7 @@ int t1k_job_run_local(t1k_job *job) {
           if (sh.allCreated && sh.oldest >= sh.created) return;
           for (w = sh.oldest; w < sh.created && w < sh.oldest + 2 && win[w].ready && kind < 0; ++w) {
             Window &W = win[w];
-            if (W.doneAssign == W.nAssign && W.nextPair < W.nPair) { kind = 1; item = W.nextPair++; }
+            if (W.nextPair < W.nPair && W.assignPrefix >= W.pairNeed[W.nextPair]) { kind = 1; item = W.nextPair++; }
             else if (W.nextAssign < W.nAssign) { kind = 0; item = W.nextAssign++; }
             if (kind >= 0) break;
           }
@@ -605,7 +632,10 @@ int t1k_job_run_local(t1k_job *job) {
       if (traceTasks) fprintf(stderr, "[t1k task] pipe %d window %u %s %u: %.1f .. %.1f ms\n", pi, w, kind == 0 ? "assign" : "pair", item, tTask - tStart, nowMs() - tStart);
       {
         std::lock_guard<std::mutex> g(sh.m);
-        if (kind == 0) ++W.doneAssign; else { ++W.donePair; W.pairDone[item] = 1; }
+        if (kind == 0) {
+          ++W.doneAssign; W.assignDone[item] = 1;
+          while (W.assignPrefix < W.nAssign && W.assignDone[W.assignPrefix]) ++W.assignPrefix;
+        } else { ++W.donePair; W.pairDone[item] = 1; }
         if (W.doneAssign == W.nAssign && W.donePair == W.nPair) {
           if (W.deferred) {
             // every task of the window has finished (each ends with its stream drained): its read set and the lists the pipelines

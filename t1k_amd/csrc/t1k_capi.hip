@@ -368,11 +368,7 @@ int t1k_reads_upload(t1k_ctx *ctx, const char *seqs, const uint64_t *offsets, co
     T1K_HIP(ctx, hipMemcpyAsync(ctx->bReadAscii.p, seqs, bytes, hipMemcpyHostToDevice, ctx->stream));
     T1K_HIP(ctx, hipMemcpyAsync(ctx->bReadOffs.p, offsets, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
     if (weights) T1K_HIP(ctx, hipMemcpyAsync(ctx->bReadWeight.p, weights, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
-    else {
-      std::vector<uint32_t> ones(n, 1);
-      T1K_HIP(ctx, hipMemcpyAsync(ctx->bReadWeight.p, ones.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
-      T1K_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    }
+    else T1K_HIP(ctx, hipMemsetD32Async((hipDeviceptr_t)ctx->bReadWeight.p, 1, (size_t)n, ctx->stream));  // every read-end counts once
     // the spare word after each strand must be defined (funnel shifts read it)
     T1K_HIP(ctx, hipMemsetAsync(ctx->bReadBases.p, 0, (size_t)n * 2 * S * 8 + 64, ctx->stream));
     T1K_HIP(ctx, hipMemsetAsync(ctx->bReadN.p, 0, (size_t)n * 2 * S * 8 + 64, ctx->stream));

@@ -4,8 +4,12 @@
 // with weight = multiplicity; the per-base coverage is the only thing the weight feeds (SeqSet.hpp:2253-2274).  Here the
 // packed read-ends of the uploaded batch are hashed (64 bits over length + forward-strand words + N mask), ordered by a stable
 // radix sort of (hash, index), and a run of equal hashes is split wherever two neighbours differ in content, so that a hash
-// collision can only cost a missed merge, never a wrong one.  The representative of a run is its first read-end in upload order.
+// collision can only cost a missed merge, never a wrong one.  The representative of a run is its first read-end in upload order, and
+// the distinct read-ends are numbered in the upload order of their representatives: the first m fragments of a window use exactly
+// the distinct read-ends [0, D_m), so a pairing range can start as soon as a prefix of the assignment ranges is done (host/job.cpp)
+// -- (T1K_DISTINCT_ORDER=hash numbers them in hash order, as rounds 1-2 did).
 // Everything is integer / HBM-bound (a few hundred MB per window of reads); no MFMA.
+#include <cstring>
 #include "t1k_dev.h"
 #include "t1k_launch.h"
 
@@ -46,12 +50,21 @@ __global__ void k_dedupe_mark(T1kReadsDev R, const unsigned long long *keys, con
   flag[j] = f;
 }
 
-// runOf = inclusive scan of flag (1-based run of each sorted position)
-__global__ void k_dedupe_scatter(uint32_t n, const uint32_t *idx, const uint32_t *flag, const uint32_t *runOf, const uint32_t *wIn, uint32_t *distinctOf, uint32_t *repr,
-                                 uint32_t *wOut) {
+// isRep[re] = 1 for the representative of a run (idx is a permutation: every entry is written); runRep[run] = that read-end
+__global__ void k_dedupe_reps(uint32_t n, const uint32_t *idx, const uint32_t *flag, const uint32_t *runOf, uint32_t *isRep, uint32_t *runRep) {
   const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
-  const uint32_t d = runOf[j] - 1, re = idx[j];
+  isRep[idx[j]] = flag[j];
+  if (flag[j]) runRep[runOf[j] - 1] = idx[j];
+}
+// runOf = inclusive scan of flag (1-based run of each sorted position); repPos (or NULL) = inclusive scan of isRep (1-based number of a
+// representative in upload order)
+__global__ void k_dedupe_scatter(uint32_t n, const uint32_t *idx, const uint32_t *flag, const uint32_t *runOf, const uint32_t *runRep, const uint32_t *repPos,
+                                 const uint32_t *wIn, uint32_t *distinctOf, uint32_t *repr, uint32_t *wOut) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const uint32_t run = runOf[j] - 1, re = idx[j];
+  const uint32_t d = repPos ? repPos[runRep[run]] - 1 : run;
   distinctOf[re] = d;
   if (flag[j]) repr[d] = re;
   atomicAdd(&wOut[d], wIn[re]);
@@ -79,13 +92,14 @@ extern "C" int t1k_reads_dedupe(t1k_ctx *ctx, uint32_t *distinctOf, uint32_t *nD
   if (!distinctOf) return t1k_fail(ctx, T1K_ERR_ARG, "t1k_reads_dedupe: distinctOf is NULL");
   const int S = ctx->reads.S;
   int rc;
-  // scratch: keys | sorted keys | idx | sorted idx | flag | runOf | repr | distinctOf
+  // scratch: keys | sorted keys | idx | sorted idx | flag | runOf | repr | distinctOf | isRep | repPos | runRep
   const size_t n4 = ((size_t)n * 4 + 255) & ~(size_t)255, n8 = ((size_t)n * 8 + 255) & ~(size_t)255;
-  if ((rc = t1k_ensure(ctx, ctx->bDedupScratch, 2 * n8 + 6 * n4))) return rc;
+  if ((rc = t1k_ensure(ctx, ctx->bDedupScratch, 2 * n8 + 9 * n4))) return rc;
   char *sp = (char *)ctx->bDedupScratch.p;
   unsigned long long *keys = (unsigned long long *)sp, *keysSorted = (unsigned long long *)(sp + n8);
   uint32_t *idx = (uint32_t *)(sp + 2 * n8), *idxSorted = idx + n4 / 4, *flag = idxSorted + n4 / 4, *runOf = flag + n4 / 4, *repr = runOf + n4 / 4,
-           *dDistinctOf = repr + n4 / 4;
+           *dDistinctOf = repr + n4 / 4, *isRep = dDistinctOf + n4 / 4, *repPos = isRep + n4 / 4, *runRep = repPos + n4 / 4;
+  static const bool hashOrder = [] { const char *e = getenv("T1K_DISTINCT_ORDER"); return e && !strcmp(e, "hash"); }();
   const unsigned nb = (n + 255) / 256;
   hipLaunchKernelGGL(k_dedupe_hash, dim3(nb), dim3(256), 0, ctx->stream, ctx->reads, keys, idx);
   if ((rc = t1k_sort_pairs(ctx, keys, keysSorted, idx, idxSorted, n))) return rc;
@@ -100,7 +114,12 @@ extern "C" int t1k_reads_dedupe(t1k_ctx *ctx, uint32_t *distinctOf, uint32_t *nD
   if ((rc = t1k_ensure(ctx, ctx->bDedupLen, (size_t)D * 2 + 16))) return rc;
   if ((rc = t1k_ensure(ctx, ctx->bDedupWeight, (size_t)D * 4 + 16))) return rc;
   T1K_HIP(ctx, hipMemsetAsync(ctx->bDedupWeight.p, 0, (size_t)D * 4, ctx->stream));
-  hipLaunchKernelGGL(k_dedupe_scatter, dim3(nb), dim3(256), 0, ctx->stream, n, idxSorted, flag, runOf, ctx->reads.weight, dDistinctOf, repr, (uint32_t *)ctx->bDedupWeight.p);
+  if (!hashOrder) {
+    hipLaunchKernelGGL(k_dedupe_reps, dim3(nb), dim3(256), 0, ctx->stream, n, idxSorted, flag, runOf, isRep, runRep);
+    if ((rc = t1k_inclusive_sum(ctx, isRep, repPos, n))) return rc;
+  }
+  hipLaunchKernelGGL(k_dedupe_scatter, dim3(nb), dim3(256), 0, ctx->stream, n, idxSorted, flag, runOf, runRep, hashOrder ? (const uint32_t *)nullptr : repPos, ctx->reads.weight,
+                     dDistinctOf, repr, (uint32_t *)ctx->bDedupWeight.p);
   const uint64_t words = (uint64_t)D * 2 * S;
   hipLaunchKernelGGL(k_dedupe_gather, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, ctx->stream, ctx->reads, D, repr, (uint64_t *)ctx->bDedupBases.p,
                      (uint64_t *)ctx->bDedupN.p, (uint16_t *)ctx->bDedupLen.p);
