@@ -236,15 +236,22 @@ def main():
         anchor = t1k_amd.Context(device=local_rank)
         comm = t1k_amd.Comm(anchor, world, rank, unique_id=uid.cpu().numpy())
 
+    seg = {}  # wall time of the step's calls, summed over the timed steps (config.calls_ms)
+
     def step():
+        t = [time.perf_counter()]
         job = t1k_amd.Job(ref, ref_seq_similarity=0.97, device=local_rank)
         if comm is not None:
             comm.bind(job)
             job.set_shard(rank, world, comm)    # before the reads: a rank indexes only its own fragments of the files (host/reads.cpp)
+        t.append(time.perf_counter())
         job.load_reads(files1, files2, barcode=barcode_file)
         job.set_output_prefix(out_prefix)       # as the executable does: the aligned-read files are written while the EM runs
+        t.append(time.perf_counter())
         job.run()
+        t.append(time.perf_counter())
         job.write_outputs(out_prefix)           # rank 0: the two tables; every rank: its own part of the aligned-read files
+        t.append(time.perf_counter())
         last["stats"] = job.stats()
         last["counts"] = job.counts()
         last["text"] = job.genotype_text()
@@ -253,10 +260,15 @@ def main():
             hashes_ok.append(hashlib.md5(last["text"].encode()).hexdigest() == want["_genotype.tsv"] and md5_file(out_prefix + "_allele.tsv") == want["_allele.tsv"])
         if comm is not None:
             comm.bind(anchor)
+        t.append(time.perf_counter())
         job.close()
+        t.append(time.perf_counter())
+        for i, k in enumerate(("job_create_reference", "load_reads", "run", "write_outputs", "stats_text_reference_check", "job_close")):
+            seg[k] = seg.get(k, 0.0) + (t[i + 1] - t[i]) * 1e3
 
     for _ in range(a.warmup):
         step()
+    seg.clear()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -317,7 +329,8 @@ def main():
                        "groups": counts["groups"], "equivalence_classes": counts["ecs"], "em_iterations": counts["em_iterations"],
                        "assigned_fragments": counts["assigned_fragments"],
                        "phases_ms": {"read_files_map_index": st["ms_load"], "device_loop": st["ms_device"], "coalesce": st["ms_coalesce"], "em": st["ms_em"],
-                                     "write_outputs": st["ms_write"]}},
+                                     "write_outputs": st["ms_write"]},
+                       "calls_ms": {k: v / a.steps for k, v in seg.items()}},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic,
                          "launches_per_step": launches, "pipelines_per_gpu": int(os.environ.get("T1K_PIPELINES", "3")), "algorithmic_bytes_per_launch": kb[dom] / launches, "avg_launch_ms": ms[dom] / launches,

@@ -630,27 +630,13 @@ static int pairLaunch(t1k_ctx *ctx, t1k_rowset *rs, const uint32_t *end1, const 
   T1K_HIP(ctx, hipSetDevice(ctx->device));
   int rc;
   const uint32_t n = nFragments;
-  // threads per fragment x slots of the LDS join table (T1K_PAIR_SHAPE = 256x4096 | 128x4096 | 128x2048 | 64x2048): as many workgroups as
-  // keep the same number of wavefronts in flight (the kernel is latency-bound: fill the wave slots)
-  static const int shape = [] {
-    const char *e = getenv("T1K_PAIR_SHAPE");
-    if (!e) return 0;
-    if (!strcmp(e, "128x4096")) return 1;
-    if (!strcmp(e, "128x2048")) return 2;
-    if (!strcmp(e, "64x2048")) return 3;
-    return 0;
-  }();
-  const int wgThreads = shape == 0 ? 256 : shape == 3 ? 64 : 128;
+  // threads per fragment x slots of the LDS join table: 256 x 4096 (the other shapes of the template -- 128 x 4096, 128 x 2048, 64 x 2048, and
+  // 256 x 4096 / 2048 with the lists copied into LDS -- were measured in round 3 and are slower); 1024 workgroups keep
+  // the wave slots of the chip filled (the kernel is latency-bound)
+  const int wgThreads = 256;
   const int maxWg = 1024 * 256 / wgThreads;
   const int nWg = (int)std::min<uint32_t>(maxWg, std::max<uint32_t>(n, 1));
-  auto launch = [&](unsigned grid, const PairArgs &args) {
-    switch (shape) {
-      case 1: hipLaunchKernelGGL((k_pair<128, 4096>), dim3(grid), dim3(128), 0, ctx->stream, args); break;
-      case 2: hipLaunchKernelGGL((k_pair<128, 2048>), dim3(grid), dim3(128), 0, ctx->stream, args); break;
-      case 3: hipLaunchKernelGGL((k_pair<64, 2048>), dim3(grid), dim3(64), 0, ctx->stream, args); break;
-      default: hipLaunchKernelGGL((k_pair<256, 4096>), dim3(grid), dim3(256), 0, ctx->stream, args); break;
-    }
-  };
+  auto launch = [&](unsigned grid, const PairArgs &args) { hipLaunchKernelGGL((k_pair<256, 4096>), dim3(grid), dim3(256), 0, ctx->stream, args); };
   const uint32_t fragCap = 8192, bigFragCap = 1u << 17;  // overlaps of both mates a workgroup's scratch holds (first pass | second pass)
   const int bigWg = 128;
   const uint32_t A = ctx->ref.nAlleles;
