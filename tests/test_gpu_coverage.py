@@ -82,6 +82,8 @@ MODES = {
     "eager": {"T1K_COVERAGE": "eager"},
     "budget_fallback": {"T1K_FIRST_WINDOW": "16", "T1K_WINDOW": "64", "T1K_WINDOW_GROWTH": "1", "T1K_BATCH": "16", "T1K_PAIR_BATCH": "16", "T1K_ARCHIVE_GB": "0.0000001"},
     "small_windows_small_batches": {"T1K_FIRST_WINDOW": "24", "T1K_WINDOW": "96", "T1K_BATCH": "16", "T1K_PAIR_BATCH": "32", "T1K_COVER_BATCH": "64", "T1K_PIPELINES": "2"},
+    "hash_order_small_batches": {"T1K_DISTINCT_ORDER": "hash", "T1K_FIRST_WINDOW": "32", "T1K_WINDOW": "128", "T1K_BATCH": "16", "T1K_PAIR_BATCH": "16"},
+    "first_use_order_small_batches": {"T1K_FIRST_WINDOW": "32", "T1K_WINDOW": "128", "T1K_BATCH": "16", "T1K_PAIR_BATCH": "16", "T1K_PIPELINES": "4"},
     "two_ranks": {"T1K_GPUS": "0,0"},
     "three_ranks_small_windows": {"T1K_GPUS": "0,0,0", "T1K_FIRST_WINDOW": "16", "T1K_WINDOW": "48", "T1K_BATCH": "16"},
 }

@@ -693,6 +693,12 @@ def test_identical_read_end_collapse_stage(built, tmp_path):
     for i, r in enumerate(reads):
         assert first.setdefault(r, int(d[i])) == int(d[i])
     assert len(set(first.values())) == len(first)
+    # numbered in the order of first use: the first m read-ends name exactly the distinct read-ends [0, D_m) -- what lets the job pair a
+    # range of fragments as soon as a prefix of the assignment ranges is done (host/job.cpp)
+    seen = 0
+    for i in range(len(reads)):
+        assert int(d[i]) <= seen
+        seen = max(seen, int(d[i]) + 1)
     ctx.assign()
     cnt, ovl = ctx.overlaps()
     start_full = np.concatenate([[0], np.cumsum(cnt_full)]).astype(np.int64)
