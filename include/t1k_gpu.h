@@ -224,6 +224,12 @@ int t1k_ref_share(t1k_ctx *dst, const t1k_ctx *src);
 /* Device memory of the library is pooled per process (a freed block is reused by the next job: fresh VRAM costs ~35 ms per GB of
  * driver zeroing; T1K_POOL_GB bounds what is kept).  This returns every cached block to the driver; result = bytes released. */
 uint64_t t1k_pool_release(void);
+/* Page-locked host memory from a per-process cache (t1k_pool_release empties it too): what a caller should gather read text into
+ * before t1k_reads_upload -- from pageable memory a multi-GB upload is staged by the runtime on the calling thread and other
+ * streams' small copies wait behind its pieces.  NULL when the memory cannot be pinned (the caller falls back to malloc).  No
+ * counterpart in the reference (host-only program). */
+void *t1k_pinned_alloc(uint64_t bytes);
+void t1k_pinned_free(void *p);
 int t1k_reads_share(t1k_ctx *dst, const t1k_ctx *src);
 /* the same with a choice of the overlap-store slot (0 or 1) dst writes its lists to, emptied first if resetStore != 0: a job
  * keeps two read sets (windows of fragments) in flight, so the lists of one stay valid while the next is being assigned */

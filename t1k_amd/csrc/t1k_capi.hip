@@ -84,6 +84,7 @@ hipError_t t1k_dev_free(void *p) {
   return hipFree(p);
 }
 
+static uint64_t pinnedRelease();
 // gives every cached block back to the driver (a long-lived process that is done with its jobs for now)
 extern "C" uint64_t t1k_pool_release(void) {
   DevPool &P = devPool();
@@ -101,6 +102,63 @@ extern "C" uint64_t t1k_pool_release(void) {
   (void)hipGetDevice(&cur);
   for (auto &d : drop) { (void)hipSetDevice(d.first); (void)hipFree(d.second); }
   (void)hipSetDevice(cur);
+  (void)pinnedRelease();  // the cached page-locked host buffers go with it (not counted: the result is device memory)
+  return bytes;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Page-locked host buffers, cached per process like the device blocks.  A window's read text (2.5 GB at 10 M pairs) handed to
+// hipMemcpyAsync from pageable memory is staged by the runtime on the calling thread -- 0.29 s, during which the pipelines' counter
+// fetches on other streams queue behind its pieces (ranges that overlapped the upload took 80 - 100 ms instead of 48).  From a
+// pinned buffer the copy is one DMA.  Pinning costs about as much as the staged copy did, once per process.
+// ------------------------------------------------------------------------------------------------------------------
+namespace {
+struct PinPool {
+  std::mutex m;
+  std::multimap<size_t, void *> freeBlocks;
+  std::unordered_map<void *, size_t> live;
+};
+PinPool &pinPool() { static PinPool *p = new PinPool(); return *p; }
+}  // namespace
+extern "C" void *t1k_pinned_alloc(uint64_t bytes) {
+  PinPool &P = pinPool();
+  if (bytes == 0) bytes = 16;
+  {
+    std::lock_guard<std::mutex> g(P.m);
+    auto it = P.freeBlocks.lower_bound((size_t)bytes);
+    if (it != P.freeBlocks.end()) {
+      void *p = it->second;
+      P.live[p] = it->first;
+      P.freeBlocks.erase(it);
+      return p;
+    }
+  }
+  const size_t want = ((size_t)bytes + (size_t)bytes / 8 + (64u << 20)) & ~(size_t)((1u << 20) - 1);  // room to grow: the next window of this size class fits too
+  void *p = nullptr;
+  if (hipHostMalloc(&p, want, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  std::lock_guard<std::mutex> g(P.m);
+  P.live[p] = want;
+  return p;
+}
+extern "C" void t1k_pinned_free(void *p) {
+  if (!p) return;
+  PinPool &P = pinPool();
+  std::lock_guard<std::mutex> g(P.m);
+  auto it = P.live.find(p);
+  if (it == P.live.end()) return;
+  P.freeBlocks.insert({it->second, p});
+  P.live.erase(it);
+}
+static uint64_t pinnedRelease() {
+  PinPool &P = pinPool();
+  std::vector<void *> drop;
+  uint64_t bytes = 0;
+  {
+    std::lock_guard<std::mutex> g(P.m);
+    for (auto &kv : P.freeBlocks) { drop.push_back(kv.second); bytes += kv.first; }
+    P.freeBlocks.clear();
+  }
+  for (void *q : drop) (void)hipHostFree(q);
   return bytes;
 }
 
