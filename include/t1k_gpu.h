@@ -81,6 +81,16 @@ int t1k_ref_upload(t1k_ctx *ctx, const char *seqs, const uint64_t *offsets, cons
  * seqs: nReadEnds ASCII reads concatenated; offsets[nReadEnds+1]; weights[nReadEnds] = multiplicity of the read-end
  * (the run length of identical sequences, Genotyper.cpp:463-480), NULL = all 1. */
 int t1k_reads_upload(t1k_ctx *ctx, const char *seqs, const uint64_t *offsets, const uint32_t *weights, uint32_t nReadEnds);
+/* The same upload in pieces, for a caller that gathers the text through a small page-locked staging buffer (t1k_pinned_alloc) while
+ * earlier pieces are on their way: begin (read-ends, total text bytes, longest read), then pieces of the text (what = 0) and of the
+ * offset array (what = 1, nReadEnds + 1 uint64; byteOffset / bytes in bytes of that array) in any order -- each an asynchronous copy
+ * on the context's stream, tagged with the staging slot (0..3) it was sent from; t1k_reads_upload_wait(slot) returns once the last
+ * piece sent from that slot has left the host buffer, which may then be refilled -- then end (packs the reads; every read-end gets
+ * weight 1).  What Genotyper.cpp:451-480 does when it collects the read-ends of a run. */
+int t1k_reads_upload_begin(t1k_ctx *ctx, uint32_t nReadEnds, uint64_t textBytes, int maxReadLen);
+int t1k_reads_upload_piece(t1k_ctx *ctx, int what, const void *src, uint64_t byteOffset, uint64_t bytes, int slot);
+int t1k_reads_upload_wait(t1k_ctx *ctx, int slot);
+int t1k_reads_upload_end(t1k_ctx *ctx);
 
 /* Identical read-ends collapse onto one representative whose weight is the sum of theirs: the sort + run-length loop of
  * Genotyper.cpp:451-480 (AssignRead is called once per distinct sequence with weight = multiplicity; the weight only feeds the

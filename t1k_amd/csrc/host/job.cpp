@@ -427,8 +427,8 @@ int t1k_job_run_local(t1k_job *job) {
   const bool traceTasks = getenv("T1K_DEBUG_TASKS") != nullptr;
   // ---- window preparation ------------------------------------------------------------------------------------------
   auto prepare = [&] {
-    // gathered text and offsets of a window, per read-set slot: plain allocations, never value-initialised (std::vector::resize would zero
-    // the 2.5 GB of the large window on this one thread before the host threads fill it: 0.3 s of a 0.7 s preparation)
+    // offsets of a window's read-ends (per read-set slot) and the staging slots its text goes through: plain allocations, never
+    // value-initialised (round 2 gathered the text into a std::vector whose resize zeroed 2.5 GB on this one thread: 0.3 s)
     // ... and page-locked (t1k_pinned_alloc, cached per process): the upload is then one DMA instead of a copy staged on this thread
     struct Raw {
       void *p = nullptr; size_t cap = 0; bool pinned = false;
@@ -444,7 +444,7 @@ int t1k_job_run_local(t1k_job *job) {
         cap = p ? bytes : 0;
         return p;
       }
-    } text[2], offs[2];
+    } offs[2], stage;
     uint64_t fNext = 0;
     for (uint32_t w = 0; fNext < F; ++w) {
       {
@@ -495,8 +495,9 @@ int t1k_job_run_local(t1k_job *job) {
       uint64_t *off = (uint64_t *)offs[W.slot].need(((size_t)ne + 1) * 8);
       if (!off) { fail(T1K_ERR_DEVICE, "window preparation: out of host memory"); return; }
       W.hasN.resize(nf);
-      // lengths -> offsets (pieces, then a carry per piece), then the text itself
+      // lengths -> offsets (pieces, then a carry per piece)
       std::vector<uint64_t> pieceBytes(T + 2, 0);
+      std::vector<uint32_t> pieceMax(T + 1, 0);
       // (a fragment with an over-long read, under T1K_LONG_READS=drop: both ends go in as empty sequences)
       auto setAside = [&](uint32_t r) {
         if (!dropLong) return false;
@@ -505,38 +506,72 @@ int t1k_job_run_local(t1k_job *job) {
       };
       parallelRanges(nf, T, [&](int t, size_t b, size_t e) {
         uint64_t run = 0, aside = 0;
+        uint32_t mx = 0;
         for (size_t i = b; i < e; ++i) {
           const uint32_t r = in.frag[fBeg - inBase + W.f0 + i];
           const bool skip = setAside(r);
           aside += skip ? 1 : 0;
-          for (uint32_t m = 0; m < per; ++m) { off[i * per + m] = run; run += skip ? 0 : in.side[m].seqL[r]; }
+          for (uint32_t m = 0; m < per; ++m) {
+            const uint32_t len = skip ? 0 : in.side[m].seqL[r];
+            off[i * per + m] = run; run += len; mx = std::max(mx, len);
+          }
         }
-        pieceBytes[t + 1] = run;
+        pieceBytes[t + 1] = run; pieceMax[t] = mx;
         if (aside) droppedFragments += aside;
       });
       for (int t = 0; t < T; ++t) pieceBytes[t + 1] += pieceBytes[t];  // pieces the loop did not use hold 0
       const uint64_t total = pieceBytes[T];
-      char *tx = (char *)text[W.slot].need(total + 16);
-      if (!tx) { fail(T1K_ERR_DEVICE, "window preparation: out of host memory"); return; }
+      uint32_t maxLen = 0;
+      for (int t = 0; t < T; ++t) maxLen = std::max(maxLen, pieceMax[t]);
       parallelRanges(nf, T, [&](int t, size_t b, size_t e) {
         const uint64_t carry = pieceBytes[t];
-        for (size_t i = b; i < e; ++i) {
-          const uint32_t r = in.frag[fBeg - inBase + W.f0 + i];
-          bool n = false;
-          const bool skip = setAside(r);
-          for (uint32_t m = 0; m < per; ++m) {
-            const uint32_t len = skip ? 0 : in.side[m].seqL[r];
-            const uint64_t at = (off[i * per + m] += carry);
-            memcpy(tx + at, in.side[m].seqP[r], len);
-            n = n || memchr(in.side[m].seqP[r], 'N', len) != nullptr;  // Genotyper.cpp: hasN = strchr(seq, 'N')
-          }
-          W.hasN[i] = n ? 1 : 0;
-        }
+        for (size_t i = b; i < e; ++i)
+          for (uint32_t m = 0; m < per; ++m) off[i * per + m] += carry;
       });
       off[ne] = total;
-      const double tText = nowMs();
+      // the text goes to the device through three staging slots of page-locked memory: while a slot's piece is on its way (one DMA,
+      // nobody's small copies wait behind it) the host threads gather the next piece into another slot.  (Pinning the whole 2.5 GB
+      // text instead was as fast for a process that keeps the buffer -- and 0.4 s slower for the executable, which pins it once.)
+      static const size_t slotBytes = [] { const char *e = getenv("T1K_STAGE_MB"); return (size_t)std::max(1, e ? atoi(e) : 96) << 20; }();
+      const int nSlots = 3;
+      char *ring = (char *)stage.need(nSlots * slotBytes);
+      if (!ring) { fail(T1K_ERR_DEVICE, "window preparation: out of host memory"); return; }
       t1k_ctx *rd = job->reader[W.slot];
-      int r = t1k_reads_upload(rd, tx, off, nullptr, ne);
+      int r = t1k_reads_upload_begin(rd, ne, total, (int)maxLen);
+      if (r == T1K_OK) r = t1k_reads_upload_piece(rd, 1, off, 0, ((uint64_t)ne + 1) * 8, 3);
+      double msGather = 0;
+      uint32_t nPieces = 0;
+      for (size_t i0 = 0; i0 < nf && r == T1K_OK; ++nPieces) {
+        const uint64_t base = off[i0 * per];
+        size_t lo = i0 + 1, hi = nf;  // the last fragment boundary whose text still fits the slot (one fragment always does)
+        while (lo < hi) {
+          const size_t mid = lo + (hi - lo + 1) / 2;
+          if (off[mid * per] - base <= slotBytes) lo = mid; else hi = mid - 1;
+        }
+        const size_t i1 = lo;
+        const int slot = (int)(nPieces % nSlots);
+        if ((r = t1k_reads_upload_wait(rd, slot)) != T1K_OK) break;
+        char *dst = ring + (size_t)slot * slotBytes;
+        const double tg = nowMs();
+        parallelRanges(i1 - i0, T, [&](int, size_t b, size_t e) {
+          for (size_t i = i0 + b; i < i0 + e; ++i) {
+            const uint32_t rr = in.frag[fBeg - inBase + W.f0 + i];
+            bool n = false;
+            const bool skip = setAside(rr);
+            for (uint32_t m = 0; m < per; ++m) {
+              const uint32_t len = skip ? 0 : in.side[m].seqL[rr];
+              memcpy(dst + (off[i * per + m] - base), in.side[m].seqP[rr], len);
+              n = n || memchr(in.side[m].seqP[rr], 'N', len) != nullptr;  // Genotyper.cpp: hasN = strchr(seq, 'N')
+            }
+            W.hasN[i] = n ? 1 : 0;
+          }
+        });
+        msGather += nowMs() - tg;
+        r = t1k_reads_upload_piece(rd, 0, dst, base, off[i1 * per] - base, slot);
+        i0 = i1;
+      }
+      const double tText = t0 + msGather;  // (reported as "text": the gathering alone; "upload" is the rest of the pipelined loop)
+      if (r == T1K_OK) r = t1k_reads_upload_end(rd);
       const double tUp = nowMs();
       W.distinctOf.resize(ne);
       const double tRes = nowMs();

@@ -289,6 +289,7 @@ void t1k_ctx_destroy(t1k_ctx *ctx) {
     for (auto &b : slot) freeBuf(b);
   for (auto &b : ctx->bAlign) freeBuf(b);
   for (auto &e : ctx->ev) if (e) (void)hipEventDestroy(e);
+  for (auto &e : ctx->upEv) if (e) (void)hipEventDestroy(e);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -402,15 +403,13 @@ int t1k_coverage_get(t1k_ctx *ctx, int32_t *out, uint64_t cap) {
 // ------------------------------------------------------------------------------------------------------------------
 // reads
 // ------------------------------------------------------------------------------------------------------------------
-int t1k_reads_upload(t1k_ctx *ctx, const char *seqs, const uint64_t *offsets, const uint32_t *weights, uint32_t n) {
-  if (!ctx || (!seqs && n) || !offsets) return t1k_fail(ctx, T1K_ERR_ARG, "t1k_reads_upload: bad arguments");
+// The upload in three steps, so that a caller can send the text in pieces through a small page-locked staging buffer while it is
+// still gathering the rest (host/job.cpp: a window's text is 2.5 GB at 10 M pairs; t1k_reads_upload is begin + two pieces + end).
+static int readsUploadBegin(t1k_ctx *ctx, uint32_t n, uint64_t bytes, int maxLen) {
   T1K_HIP(ctx, hipSetDevice(ctx->device));
-  int maxLen = 0;
-  for (uint32_t i = 0; i < n; ++i) maxLen = std::max<int>(maxLen, (int)(offsets[i + 1] - offsets[i]));
   if (maxLen > ctx->prm.max_read_len) return t1k_fail(ctx, T1K_ERR_ARG, "read longer than max_read_len");
   int S = (maxLen + 31) / 32 + 1;
   if (S < 2) S = 2;
-  uint64_t bytes = n ? offsets[n] : 0;
   int rc;
   if ((rc = t1k_ensure(ctx, ctx->bReadAscii, bytes + 16))) return rc;
   if ((rc = t1k_ensure(ctx, ctx->bReadOffs, (size_t)(n + 1) * 8))) return rc;
@@ -422,9 +421,13 @@ int t1k_reads_upload(t1k_ctx *ctx, const char *seqs, const uint64_t *offsets, co
   if ((rc = t1k_ensure(ctx, ctx->bListCount, (size_t)n * 4 + 16))) return rc;
   T1K_HIP(ctx, hipMemsetAsync(ctx->bListCount.p, 0, (size_t)n * 4 + 16, ctx->stream));  // a read-end that was never assigned has an empty list
   T1K_HIP(ctx, hipMemsetAsync(ctx->bListPtr.p, 0, (size_t)n * 8 + 16, ctx->stream));
+  ctx->upN = n; ctx->upS = S; ctx->upMaxLen = maxLen; ctx->upBytes = bytes; ctx->upOpen = true;
+  return T1K_OK;
+}
+static int readsUploadEnd(t1k_ctx *ctx, const uint32_t *weights) {
+  const uint32_t n = ctx->upN;
+  const int S = ctx->upS;
   if (n) {
-    T1K_HIP(ctx, hipMemcpyAsync(ctx->bReadAscii.p, seqs, bytes, hipMemcpyHostToDevice, ctx->stream));
-    T1K_HIP(ctx, hipMemcpyAsync(ctx->bReadOffs.p, offsets, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
     if (weights) T1K_HIP(ctx, hipMemcpyAsync(ctx->bReadWeight.p, weights, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
     else T1K_HIP(ctx, hipMemsetD32Async((hipDeviceptr_t)ctx->bReadWeight.p, 1, (size_t)n, ctx->stream));  // every read-end counts once
     // the spare word after each strand must be defined (funnel shifts read it)
@@ -434,6 +437,7 @@ int t1k_reads_upload(t1k_ctx *ctx, const char *seqs, const uint64_t *offsets, co
                     (uint16_t *)ctx->bReadLen.p, ctx->prm.n_base_code & 3);
   }
   T1K_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->upOpen = false;
   ctx->reads.nReadEnds = n;
   ctx->reads.S = S;
   ctx->reads.bases = (const uint64_t *)ctx->bReadBases.p;
@@ -444,10 +448,50 @@ int t1k_reads_upload(t1k_ctx *ctx, const char *seqs, const uint64_t *offsets, co
   ctx->reads.listCount = (uint32_t *)ctx->bListCount.p;
   ctx->readsShared = false;
   ctx->storeSlot = 0; ctx->storeChunk[0] = 0; ctx->storeUsed[0] = 0;  // the lists of the previous read set are dead
-  ctx->batchMaxLen = maxLen;
+  ctx->batchMaxLen = ctx->upMaxLen;
   ctx->nCand = ctx->nOvl = 0;
   ctx->rangeCount = 0;
   return T1K_OK;
+}
+int t1k_reads_upload(t1k_ctx *ctx, const char *seqs, const uint64_t *offsets, const uint32_t *weights, uint32_t n) {
+  if (!ctx || (!seqs && n) || !offsets) return t1k_fail(ctx, T1K_ERR_ARG, "t1k_reads_upload: bad arguments");
+  int maxLen = 0;
+  for (uint32_t i = 0; i < n; ++i) maxLen = std::max<int>(maxLen, (int)(offsets[i + 1] - offsets[i]));
+  const uint64_t bytes = n ? offsets[n] : 0;
+  int rc;
+  if ((rc = readsUploadBegin(ctx, n, bytes, maxLen))) return rc;
+  if (n) {
+    T1K_HIP(ctx, hipMemcpyAsync(ctx->bReadAscii.p, seqs, bytes, hipMemcpyHostToDevice, ctx->stream));
+    T1K_HIP(ctx, hipMemcpyAsync(ctx->bReadOffs.p, offsets, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+  }
+  return readsUploadEnd(ctx, weights);
+}
+extern "C" int t1k_reads_upload_begin(t1k_ctx *ctx, uint32_t nReadEnds, uint64_t textBytes, int maxReadLen) {
+  if (!ctx || maxReadLen < 0) return t1k_fail(ctx, T1K_ERR_ARG, "t1k_reads_upload_begin: bad arguments");
+  return readsUploadBegin(ctx, nReadEnds, textBytes, maxReadLen);
+}
+extern "C" int t1k_reads_upload_piece(t1k_ctx *ctx, int what, const void *src, uint64_t byteOffset, uint64_t bytes, int slot) {
+  if (!ctx || !ctx->upOpen) return t1k_fail(ctx, T1K_ERR_STATE, "t1k_reads_upload_piece: no upload begun");
+  if ((what != 0 && what != 1) || slot < 0 || slot >= 4 || (!src && bytes)) return t1k_fail(ctx, T1K_ERR_ARG, "t1k_reads_upload_piece: bad arguments");
+  const uint64_t limit = what == 0 ? ctx->upBytes : ((uint64_t)ctx->upN + 1) * 8;
+  if (byteOffset + bytes > limit) return t1k_fail(ctx, T1K_ERR_ARG, "t1k_reads_upload_piece: piece outside the announced size");
+  T1K_HIP(ctx, hipSetDevice(ctx->device));
+  char *dst = (char *)(what == 0 ? ctx->bReadAscii.p : ctx->bReadOffs.p) + byteOffset;
+  if (bytes) T1K_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  if (!ctx->upEv[slot]) T1K_HIP(ctx, hipEventCreateWithFlags(&ctx->upEv[slot], hipEventDisableTiming));
+  T1K_HIP(ctx, hipEventRecord(ctx->upEv[slot], ctx->stream));
+  ctx->upEvSet[slot] = true;
+  return T1K_OK;
+}
+extern "C" int t1k_reads_upload_wait(t1k_ctx *ctx, int slot) {
+  if (!ctx || slot < 0 || slot >= 4) return t1k_fail(ctx, T1K_ERR_ARG, "t1k_reads_upload_wait: bad arguments");
+  if (ctx->upEvSet[slot]) { T1K_HIP(ctx, hipEventSynchronize(ctx->upEv[slot])); ctx->upEvSet[slot] = false; }
+  return T1K_OK;
+}
+extern "C" int t1k_reads_upload_end(t1k_ctx *ctx) {
+  if (!ctx || !ctx->upOpen) return t1k_fail(ctx, T1K_ERR_STATE, "t1k_reads_upload_end: no upload begun");
+  for (int i = 0; i < 4; ++i) ctx->upEvSet[i] = false;  // the end drains the stream
+  return readsUploadEnd(ctx, nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------------------------

@@ -737,6 +737,9 @@ struct t1k_ctx {
   uint64_t emNnz = 0;
   std::vector<int32_t> hEmLen;
   int traceFetch = 0;          // T1K_DEBUG_TRACE
+  // an upload in pieces (t1k_reads_upload_begin .. _end)
+  uint32_t upN = 0; int upS = 0, upMaxLen = 0; uint64_t upBytes = 0; bool upOpen = false;
+  hipEvent_t upEv[4] = {nullptr, nullptr, nullptr, nullptr}; bool upEvSet[4] = {false, false, false, false};
   uint64_t lastSlowGroups = 0;             // groups the last range left to the gap walk (T1K_DEBUG_PHASES)
   uint64_t pairEpoch = 0;      // epochs handed out to k_pair's allele tables since they were last cleared
   unsigned long long *countersPinned = nullptr;  // page-locked landing buffer of t1k_fetch_counters
