@@ -384,10 +384,13 @@ __device__ inline void ldsCountingPass(uint64_t *key, uint32_t n, uint16_t *cnt,
 }
 
 // entry layout: [0 | 2047 - matchCnt : 11 | span sum : 11 | 511 - read span : 9 | allele : aBits | index : iBits], bit 63 is the
-// emit mark of k_select.  Returns false if a field does not fit.
+// emit mark of k_select.  Returns false if a field does not fit.  XL (a window with reads beyond T1K_MAX_READ_LEN, up to
+// T1K_LONG_READ_LEN): the read span takes 10 bits (1023 - read span) and the key may use all 64 bits.
+template <bool XL>
 __device__ __forceinline__ bool packSortKey(int m, int d, int rspan, uint32_t allele, uint32_t index, int aBits, int iBits, uint64_t *out) {
-  if (m < 0 || m > 2047 || d < 0 || d > 2047 || rspan < 0 || rspan > 511 || 32 + aBits + iBits > 64) return false;
-  *out = (((((uint64_t)(2047 - m) << 11 | (uint64_t)d) << 9 | (uint64_t)(511 - rspan)) << aBits | (uint64_t)allele) << iBits) | (uint64_t)index;
+  constexpr int RB = XL ? 10 : 9, RMAX = (1 << RB) - 1;
+  if (m < 0 || m > 2047 || d < 0 || d > 2047 || rspan < 0 || rspan > RMAX || 32 + aBits + iBits > 64) return false;
+  *out = (((((uint64_t)(2047 - m) << 11 | (uint64_t)d) << RB | (uint64_t)(RMAX - rspan)) << aBits | (uint64_t)allele) << iBits) | (uint64_t)index;
   return true;
 }
 
@@ -397,9 +400,17 @@ __device__ __forceinline__ bool packSortKey(int m, int d, int rspan, uint32_t al
 #define SEL_F_SEPSEED 1u
 #define SEL_F_EXTOK 2u
 #define SEL_F_KEEPCLIP 4u
+// XL: 11 / 11 / 10 bits for the three class fields (seed match counts and span sums up to 2047, read spans up to 1023): the allele and
+// the index then share 28 bits (8192 candidates per read-end against a reference of 32 768 sequences; beyond: ERR_SORTCAP, loudly).
+template <bool XL> struct SelKey {
+  static constexpr int MB = XL ? 11 : 10, DB = XL ? 11 : 10, RB = XL ? 10 : 9;
+  static constexpr int MMAX = (1 << MB) - 1, DMAX = (1 << DB) - 1, RMAX = (1 << RB) - 1;
+};
+template <bool XL>
 __device__ __forceinline__ bool packSelectKey(int m, int d, int rspan, uint32_t allele, uint32_t index, uint32_t flags, int aBits, int iBits, uint64_t *out) {
-  if (m < 0 || m > 1023 || d < 0 || d > 1023 || rspan < 0 || rspan > 511 || 33 + aBits + iBits > 64) return false;
-  *out = ((((((uint64_t)(1023 - m) << 10 | (uint64_t)d) << 9 | (uint64_t)(511 - rspan)) << aBits | (uint64_t)allele) << iBits) | (uint64_t)index) << 3 | flags;
+  using K = SelKey<XL>;
+  if (m < 0 || m > K::MMAX || d < 0 || d > K::DMAX || rspan < 0 || rspan > K::RMAX || 1 + K::MB + K::DB + K::RB + 3 + aBits + iBits > 64) return false;
+  *out = ((((((uint64_t)(K::MMAX - m) << K::DB | (uint64_t)d) << K::RB | (uint64_t)(K::RMAX - rspan)) << aBits | (uint64_t)allele) << iBits) | (uint64_t)index) << 3 | flags;
   return true;
 }
 
@@ -418,7 +429,7 @@ __device__ inline bool candBeforeFull(const T1kCand &a, const T1kCand &b) {
 #define SELECT_SMALL 2048
 #define SELECT_LARGE 8192
 
-template <int SELECT_LDS_CAP, int NT>
+template <int SELECT_LDS_CAP, int NT, bool XL>
 __global__ __launch_bounds__(NT) T1K_OCC8 void k_select(SelectArgs P) {
   extern __shared__ uint64_t dynLds[];
   uint64_t *sKey = dynLds;
@@ -464,9 +475,9 @@ __global__ __launch_bounds__(NT) T1K_OCC8 void k_select(SelectArgs P) {
     int iBits = 1;
     while ((1u << iBits) < n) ++iBits;
     const uint64_t iMask = (1ull << iBits) - 1;
-    const int mShift = 19 + P.alleleBits + iBits + 3;  // position of the (1023 - matchCnt) field
+    const int mShift = SelKey<XL>::DB + SelKey<XL>::RB + P.alleleBits + iBits + 3;  // position of the (MMAX - matchCnt) field
     auto idxOf = [&](uint64_t kk) { return (uint32_t)((kk >> 3) & iMask); };
-    auto seedOf = [&](uint64_t kk) { return 1023 - (int)((kk >> mShift) & 0x3FF); };
+    auto seedOf = [&](uint64_t kk) { return SelKey<XL>::MMAX - (int)((kk >> mShift) & (uint64_t)SelKey<XL>::MMAX); };
     for (uint32_t i = live + tid; i < np2; i += NT) key[i] = ~0ull;
     for (uint32_t i = iBeg; i < iEnd; ++i) {
       const uint16_t fl = P.ext[c0 + i].flags;
@@ -480,7 +491,7 @@ __global__ __launch_bounds__(NT) T1K_OCC8 void k_select(SelectArgs P) {
                           (((fl & T1K_F_NEEDCLIP) && !(sim < 0.95)) ? SEL_F_KEEPCLIP : 0u);  // SeqSet.hpp:2170-2172
       const uint32_t slot = myFirst++;
       uint64_t kk;
-      if (!packSelectKey(m, d, rspan, c.allele & 0x7FFFFFFFu, i, kf, P.alleleBits, iBits, &kk)) { atomicOr(&P.counters[2], (unsigned long long)ERR_SORTCAP); kk = (uint64_t)i << 3; }
+      if (!packSelectKey<XL>(m, d, rspan, c.allele & 0x7FFFFFFFu, i, kf, P.alleleBits, iBits, &kk)) { atomicOr(&P.counters[2], (unsigned long long)ERR_SORTCAP); kk = (uint64_t)i << 3; }
       key[slot] = kk;
     }
     __syncthreads();
@@ -607,12 +618,12 @@ __global__ __launch_bounds__(WG) void k_fullalign(FullArgs P) {
   const int64_t goff = (int64_t)P.ref.alleleOff[o.allele];
   const int L = o.readEnd - o.readStart + 1, Ls = o.seqEnd - o.seqStart + 1;
   const int w = P.noCov ? 0 : (int)P.reads.weight[o.re];
-  bool slow = (L != Ls);
+  bool slow = (L != Ls) || L > T1K_MAX_READ_LEN;  // (the closed form below keeps 320 covered-column bits in registers; longer spans take the traced DP)
   int x = 0, exonMis = 0;
   // one sweep over the windows: mismatch count, and -- kept in registers for the coverage updates below -- the covered-column
   // words (MATCH column, read base not N (2261-2265); an N allele base never feeds GetSeqMissingBaseCoverage's counter of the
   // allele's own base, so it is left out)
-  uint64_t covw[10];  // reads are at most 320 bp
+  uint64_t covw[10];  // spans of at most T1K_MAX_READ_LEN = 320 positions
   if (!slow && L <= 160) {
     // the usual read length: the allele window (6 words) comes in with three 16-byte loads per array instead of one load pair per
     // 32-base piece -- every lane's window is in another cache line, so the number of load instructions is what the kernel pays for --
@@ -683,6 +694,8 @@ __global__ __launch_bounds__(WG) void k_fullalign(FullArgs P) {
         hsh = (hsh ^ (t1k_get32(P.ref.bases, goff + o.seqStart + off) & lm) ^ ((t1k_get32(P.ref.nmask, goff + o.seqStart + off) & lm) << 1)) * 0xD6E8FEB86659FD93ull;
         hsh ^= hsh >> 32;
       }
+      // (9-bit fields: a span or start beyond 511 -- reads longer than T1K_MAX_READ_LEN -- spills into its neighbour, which only makes
+      // the order coarser: k_align_flags compares the jobs themselves)
       key = ((unsigned long long)o.re << 44) | ((unsigned long long)pass << 43) | ((unsigned long long)o.readStart << 34) | ((unsigned long long)L << 25) |
             ((unsigned long long)(Ls - L + 4) << 21) | (hsh & 0x1FFFFFull);
     }
@@ -982,7 +995,7 @@ __device__ inline bool ovlBeforeFull(const T1kOvl &a, const T1kOvl &b) {
   return a.seqEnd < b.seqEnd;
 }
 
-template <int SELECT_LDS_CAP, int NT>
+template <int SELECT_LDS_CAP, int NT, bool XL>
 __global__ __launch_bounds__(NT) void k_truncate(TruncArgs P) {
   extern __shared__ uint64_t dynLds[];
   uint64_t *sKey = dynLds;
@@ -1013,7 +1026,7 @@ __global__ __launch_bounds__(NT) void k_truncate(TruncArgs P) {
         const T1kOvl o = P.ovl[o0 + i];
         int rspan = o.readEnd - o.readStart;
         int d = rspan + 1 + o.seqEnd - o.seqStart + 1 + 2 * o.leftClip + 2 * o.rightClip;  // similarity desc == d asc at equal matchCnt
-        if (!packSortKey((int)o.matchCnt, d, rspan, o.allele, i, P.alleleBits, iBits, &kk)) { atomicOr(&P.counters[2], (unsigned long long)ERR_SORTCAP); kk = i; }
+        if (!packSortKey<XL>((int)o.matchCnt, d, rspan, o.allele, i, P.alleleBits, iBits, &kk)) { atomicOr(&P.counters[2], (unsigned long long)ERR_SORTCAP); kk = i; }
         stage[i] = o;
       }
       key[i] = kk;
@@ -1104,9 +1117,15 @@ void t1k_launch_extend_retry(t1k_ctx *ctx, const ExtendArgs &a, const uint32_t *
   hipLaunchKernelGGL(k_extend_retry, dim3((n + WG - 1) / WG), dim3(WG), 0, ctx->stream, a, list, n);
 }
 void t1k_launch_select(t1k_ctx *ctx, const SelectArgs &a, int nWg) {
-  hipFuncSetAttribute((const void *)k_select<SELECT_LARGE, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, SELECT_LARGE * 8);
-  hipLaunchKernelGGL((k_select<SELECT_SMALL, 256>), dim3(nWg), dim3(256), SELECT_SMALL * 8, ctx->stream, a);
-  hipLaunchKernelGGL((k_select<SELECT_LARGE, 1024>), dim3(std::min(nWg, 512)), dim3(1024), SELECT_LARGE * 8, ctx->stream, a);
+  if (a.xl) {  // a window with reads beyond T1K_MAX_READ_LEN: wider key fields
+    hipFuncSetAttribute((const void *)k_select<SELECT_LARGE, 1024, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SELECT_LARGE * 8);
+    hipLaunchKernelGGL((k_select<SELECT_SMALL, 256, true>), dim3(nWg), dim3(256), SELECT_SMALL * 8, ctx->stream, a);
+    hipLaunchKernelGGL((k_select<SELECT_LARGE, 1024, true>), dim3(std::min(nWg, 512)), dim3(1024), SELECT_LARGE * 8, ctx->stream, a);
+    return;
+  }
+  hipFuncSetAttribute((const void *)k_select<SELECT_LARGE, 1024, false>, hipFuncAttributeMaxDynamicSharedMemorySize, SELECT_LARGE * 8);
+  hipLaunchKernelGGL((k_select<SELECT_SMALL, 256, false>), dim3(nWg), dim3(256), SELECT_SMALL * 8, ctx->stream, a);
+  hipLaunchKernelGGL((k_select<SELECT_LARGE, 1024, false>), dim3(std::min(nWg, 512)), dim3(1024), SELECT_LARGE * 8, ctx->stream, a);
 }
 void t1k_launch_fullalign(t1k_ctx *ctx, const FullArgs &a) {
   if (!a.nOvl) return;
@@ -1129,9 +1148,15 @@ void t1k_launch_align_fill_apply(t1k_ctx *ctx, const SlowArgs &a, bool eq) {
   }
 }
 void t1k_launch_truncate(t1k_ctx *ctx, const TruncArgs &a, int nWg) {
-  hipFuncSetAttribute((const void *)k_truncate<SELECT_LARGE, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, SELECT_LARGE * 8);
-  hipLaunchKernelGGL((k_truncate<SELECT_SMALL, 256>), dim3(std::min(nWg, 512)), dim3(256), SELECT_SMALL * 8, ctx->stream, a);  // (its staging area: 512 workgroups' worth)
-  hipLaunchKernelGGL((k_truncate<SELECT_LARGE, 1024>), dim3(std::min(nWg, 512)), dim3(1024), SELECT_LARGE * 8, ctx->stream, a);
+  if (a.xl) {
+    hipFuncSetAttribute((const void *)k_truncate<SELECT_LARGE, 1024, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SELECT_LARGE * 8);
+    hipLaunchKernelGGL((k_truncate<SELECT_SMALL, 256, true>), dim3(std::min(nWg, 512)), dim3(256), SELECT_SMALL * 8, ctx->stream, a);
+    hipLaunchKernelGGL((k_truncate<SELECT_LARGE, 1024, true>), dim3(std::min(nWg, 512)), dim3(1024), SELECT_LARGE * 8, ctx->stream, a);
+    return;
+  }
+  hipFuncSetAttribute((const void *)k_truncate<SELECT_LARGE, 1024, false>, hipFuncAttributeMaxDynamicSharedMemorySize, SELECT_LARGE * 8);
+  hipLaunchKernelGGL((k_truncate<SELECT_SMALL, 256, false>), dim3(std::min(nWg, 512)), dim3(256), SELECT_SMALL * 8, ctx->stream, a);  // (its staging area: 512 workgroups' worth)
+  hipLaunchKernelGGL((k_truncate<SELECT_LARGE, 1024, false>), dim3(std::min(nWg, 512)), dim3(1024), SELECT_LARGE * 8, ctx->stream, a);
 }
 __global__ __launch_bounds__(WG) void k_coverage_fold(int32_t *diff, const int32_t *full, uint64_t n, uint64_t len) {
   const uint64_t i = (uint64_t)blockIdx.x * WG + threadIdx.x;

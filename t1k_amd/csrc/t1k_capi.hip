@@ -221,7 +221,7 @@ void t1k_params_default(t1k_params *p) {
   p->ref_seq_similarity = 0.8;
   p->relax_intron_align = 0;
   p->max_assign_cnt = 2000;
-  p->max_read_len = T1K_MAX_READ_LEN;
+  p->max_read_len = T1K_LONG_READ_LEN;  // (candidate extraction: T1K_MAX_READ_LEN, checked by t1k_extract_batch)
   p->workgroups = 2048;
   p->n_base_code = 3;
   p->store_chunk_mb = 1536;
@@ -260,7 +260,7 @@ int t1k_ctx_create(int device, const t1k_params *params, t1k_ctx **out) {
   if (ctx->prm.ovl_cap <= 0) ctx->prm.ovl_cap = d.ovl_cap;
   if (ctx->prm.row_cap <= 0) ctx->prm.row_cap = d.row_cap;
   if (ctx->prm.store_chunk_mb <= 0) ctx->prm.store_chunk_mb = d.store_chunk_mb;
-  if (ctx->prm.kmer_length > 15 || ctx->prm.max_read_len > T1K_MAX_READ_LEN) { delete ctx; return T1K_ERR_ARG; }  // the hit-offset bitmask of the chain kernels spans 320 positions
+  if (ctx->prm.kmer_length > 15 || ctx->prm.max_read_len > T1K_LONG_READ_LEN) { delete ctx; return T1K_ERR_ARG; }  // read coordinates < 1024 in the packed overlap records (t1k_dev.h)
   if (hipStreamCreate(&ctx->stream) != hipSuccess) { delete ctx; return T1K_ERR_DEVICE; }
   for (auto &e : ctx->ev) if (hipEventCreate(&e) != hipSuccess) { delete ctx; return T1K_ERR_DEVICE; }
   *out = ctx;
@@ -505,6 +505,9 @@ int t1k_extract_batch(t1k_ctx *ctx, uint32_t endsPerFragment, uint8_t *good, uin
   const uint32_t nFrag = nEnds / endsPerFragment;
   if (stats) memset(stats, 0, 8 * sizeof(uint64_t));
   if (!nFrag) return T1K_OK;
+  if (ctx->batchMaxLen > T1K_MAX_READ_LEN)  // k_extract_screen / k_extract give a lane a fixed number of k-mer positions (t1k_extract.hip)
+    return t1k_fail(ctx, T1K_ERR_ARG, "read longer than max_read_len: candidate extraction handles reads of up to " + std::to_string(T1K_MAX_READ_LEN) + " bases (the batch holds one of " +
+                                        std::to_string(ctx->batchMaxLen) + ")");
   T1K_HIP(ctx, hipSetDevice(ctx->device));
   const size_t flagBytes = ((size_t)nFrag + 63) / 64 * 64;
   int rc;
@@ -625,7 +628,7 @@ extern "C++" int t1k_fullalign_phase(t1k_ctx *ctx, const T1kReadsDev &rd, T1kOvl
                                      unsigned long long *hc) {
   int rc;
   unsigned long long *counters = (unsigned long long *)ctx->bCounters.p;
-  const int maxCells = 340 * 340;
+  const int maxCells = std::max(340, maxLen + 24) * std::max(340, maxLen + 24);
   const int slowBlocks = 64;
   // alignment queues (equal spans | spans differing by <= 4 | wider): striped arenas appended to by k_fullalign, then made dense
   const uint32_t qSegCap = exactQueues ? (uint32_t)(nOvl + 64) : (uint32_t)(nOvl / T1K_NSTRIPE * 2 + 1024);
@@ -786,7 +789,8 @@ static int assignOnce(t1k_ctx *ctx, uint64_t first, uint32_t count) {
   const bool longReads = ctx->batchMaxLen > 160;
   const int recStride = t1k_chain_rec_stride(ctx->batchMaxLen);
   const uint64_t groupCap = ctx->wGroup;
-  const uint32_t jobCap = (uint32_t)ctx->wJob, genCandCap = 16u << 20, genHitCap = 64u << 20, genJobCap = (uint32_t)ctx->wGenJob;
+  // (a window with reads beyond T1K_MAX_READ_LEN sends every group of those read-ends through the explicit hit lists: up to ~1000 hits a group)
+  const uint32_t jobCap = (uint32_t)ctx->wJob, genCandCap = 16u << 20, genHitCap = ctx->batchMaxLen > T1K_MAX_READ_LEN ? 1024u << 20 : 64u << 20, genJobCap = (uint32_t)ctx->wGenJob;
   const int bigBlocks = 32;
   if ((rc = t1k_ensure(ctx, ctx->bCounters, (size_t)T1K_COUNTER_WORDS * 8))) return rc;
   if ((rc = t1k_ensure(ctx, ctx->bWgGroups, groupCap * recStride * 4))) return rc;                        // batch group records
@@ -849,6 +853,7 @@ static int assignOnce(t1k_ctx *ctx, uint64_t first, uint32_t count) {
   a.recs = (uint32_t *)ctx->bWgGroups.p; a.recStride = (uint32_t)recStride; a.groupCap = groupCap;
   a.chunkStart = (uint32_t *)ctx->bWgStage.p; a.chunkCount = a.chunkStart + (size_t)n * maxChunks; a.maxChunks = maxChunks;
   a.usedOut = (uint32_t *)ctx->bWgHits.p; a.usedCount = a.usedOut + (size_t)n * t1k_chain_used_u32(maxK); a.maxK = (uint32_t)maxK;
+  a.maxKFast = (uint32_t)t1k_chain_max_kmers(std::min(ctx->batchMaxLen, T1K_MAX_READ_LEN), ctx->prm.kmer_length);
   a.memo = (unsigned long long *)ctx->bWgCache.p;
   a.jobList = (uint32_t *)ctx->bLists.p; a.jobCap = jobCap;
   a.jobStr = a.jobList + jobCap;
@@ -892,7 +897,7 @@ static int assignOnce(t1k_ctx *ctx, uint64_t first, uint32_t count) {
   s.ovl = ctx->ovlBase; s.ovlCap = ctx->wOvl;
   s.ovlStart = (uint32_t *)ctx->bOvlStart.p; s.ovlCount = (uint32_t *)ctx->bOvlCount.p;
   s.sortScratch = (uint64_t *)ctx->bSortScratch.p; s.sortCap = sortCap; s.counters = a.counters;
-  s.alleleBits = 1; s.relax = relaxFlag;
+  s.alleleBits = 1; s.relax = relaxFlag; s.xl = ctx->batchMaxLen > T1K_MAX_READ_LEN ? 1 : 0;
   while ((1u << s.alleleBits) < ctx->ref.nAlleles) ++s.alleleBits;
   t1k_launch_select(ctx, s, nWg);
   T1K_HIP(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
@@ -916,7 +921,7 @@ static int assignOnce(t1k_ctx *ctx, uint64_t first, uint32_t count) {
   T1K_HIP(ctx, hipEventRecord(evSlow, ctx->stream));
   TruncArgs tr{};
   tr.reads = rd; tr.ovl = s.ovl; tr.ovlStart = s.ovlStart; tr.ovlCount = s.ovlCount; tr.sortScratch = s.sortScratch; tr.sortCap = sortCap; tr.alleleBits = s.alleleBits;
-  tr.counters = a.counters;
+  tr.counters = a.counters; tr.xl = s.xl;
   t1k_launch_truncate(ctx, tr, nWg);
   T1K_HIP(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
   // the lists are final: publish them in the read set's table (absolute read-end index) and keep their records in the store

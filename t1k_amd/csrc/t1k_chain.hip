@@ -443,7 +443,7 @@ __global__ __launch_bounds__(WG) T1K_OCC8 void k_seed_groups(ChainArgs P) {
   constexpr int AW = NW == 5 ? 7 : 13;  // u32 per accumulator: diag, meta, M[NW]; odd stride = no LDS bank conflicts
   extern __shared__ uint32_t lds[];
   const int k = P.k;
-  const int maxK = (int)P.maxK;                     // >= k-mers of a read-end, both strands
+  const int maxK = (int)P.maxKFast;                 // >= k-mers of a read-end this kernel seeds, both strands (LDS layout; the used-list table's stride is P.maxK)
   uint32_t *acc = lds;                              // [CHUNK_A][AW] per-allele accumulators of the current chunk
   // look-up phase only (overlaid on the accumulators, which are re-initialised afterwards):
   uint32_t *ukCode = acc;                           // [maxK]  code | valid << 31
@@ -483,7 +483,8 @@ __global__ __launch_bounds__(WG) T1K_OCC8 void k_seed_groups(ChainArgs P) {
     const uint64_t *rnm = P.reads.nmask + (uint64_t)re * 2 * S;
     for (int c = tid; c < P.maxChunks; c += WG) P.chunkCount[(uint64_t)re * P.maxChunks + c] = 0;
     if (tid == 0) { P.usedCount[2 * re] = 0; P.usedCount[2 * re + 1] = 0; }
-    if (len < k) { __syncthreads(); continue; }  // GetOverlapsFromRead returns -1 (SeqSet.hpp:1598-1599)
+    // (a read-end beyond the hit masks' span is seeded by k_seed_long, launched behind this kernel)
+    if (len < k || len > T1K_MAX_READ_LEN) { __syncthreads(); continue; }  // GetOverlapsFromRead returns -1 (SeqSet.hpp:1598-1599)
     const int nk = len - k + 1;
     for (int q = tid; q < 2 * nk; q += WG) {
       int pass = q / nk, p = q - pass * nk;
@@ -610,7 +611,7 @@ __global__ __launch_bounds__(WG) T1K_OCC8 void k_seed_groups(ChainArgs P) {
 
     // the used lists are kept for k_chain_general, which re-derives the hits of the few multi-diagonal groups
     {
-      uint32_t *uo = P.usedOut + (uint64_t)re * maxK * 4;
+      uint32_t *uo = P.usedOut + (uint64_t)re * P.maxK * 4;
       for (uint32_t u = tid; u < nUsedPlus + nUsedMinus; u += WG) {
         int q = usedQ[u];
         int pass = u < nUsedPlus ? 0 : 1;
@@ -880,6 +881,156 @@ __global__ __launch_bounds__(WG) T1K_OCC8 void k_seed_groups(ChainArgs P) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// K1L: seeding of the read-ends beyond the hit masks' span (T1K_MAX_READ_LEN < len <= T1K_LONG_READ_LEN), one workgroup per such
+// read-end; the others are k_seed_groups' and are skipped here.  No masks, no diagonals: the look-up rule (GetHitsFromRead,
+// SeqSet.hpp:1071-1229) is replayed sequentially by the first wavefront, the used lists are kept for gatherHits as usual, and a
+// (strand, allele) pair that collects >= 3 postings (minHitRequired, 1253 / 1314) becomes a group record flagged "several diagonals":
+// k_chain_fast<*, 0> hands such records to k_gather_general -> k_chain_general / k_chain_wave / k_chain_big, which rebuild the hit
+// list and run the reference's diagonal-run / LIS logic on it whatever the read's length.  Counts live in LDS for LONG_CH alleles at
+// a time; a pass emits its records in allele order as one entry of the read-end's chunk table ('-' strand first, as SortHits
+// 1577-1583 orders the groups).  Slow by design: such reads are the odd ones among millions.
+// ------------------------------------------------------------------------------------------------------------------
+#define LONG_CH 16384
+__global__ __launch_bounds__(WG) void k_seed_long(ChainArgs P) {
+  extern __shared__ uint32_t lds[];
+  const int k = P.k;
+  const int maxK = (int)P.maxK;
+  uint32_t *ukCode = lds;                           // [maxK]  code | valid << 31
+  uint32_t *ukStart = ukCode + maxK;                // [maxK]
+  uint32_t *ukLen = ukStart + maxK;                 // [maxK]
+  uint32_t *ukDir = ukLen + maxK;                   // [maxK]
+  uint16_t *usedQ = (uint16_t *)(ukDir + maxK);     // [maxK]  used k-mers, + strand first
+  uint32_t *cnt = (uint32_t *)(usedQ + ((maxK + 1) & ~1));  // [LONG_CH] postings per allele of the current pass
+  __shared__ uint32_t warpSums[4];
+  __shared__ uint32_t sUsed[2], sGroupBase;
+  const int tid = threadIdx.x;
+  const uint32_t kmask = (1u << (2 * k)) - 1;
+  const uint32_t stride = P.recStride;
+  const uint32_t A = P.ref.nAlleles;
+  unsigned int hitsLocal = 0;
+  for (uint32_t re = blockIdx.x; re < P.reads.nReadEnds; re += gridDim.x) {
+    const int len = P.reads.len[re];
+    if (len <= T1K_MAX_READ_LEN) continue;  // (uniform over the workgroup)
+    const int S = P.reads.S;
+    const uint64_t *rbase = P.reads.bases + (uint64_t)re * 2 * S;
+    const uint64_t *rnm = P.reads.nmask + (uint64_t)re * 2 * S;
+    const int nk = len - k + 1;
+    __syncthreads();  // the previous read-end's tables are dead
+    for (int q = tid; q < 2 * nk; q += WG) {
+      const int pass = q / nk, p = q - pass * nk;
+      const uint64_t *b = rbase + pass * S, *nm = rnm + pass * S;
+      const uint32_t code = (uint32_t)t1k_get32(b, p) & kmask;
+      const bool valid = ((uint32_t)t1k_get32(nm, p) & kmask) == 0;
+      uint32_t st = 0, ln = 0, dr = T1K_NO_DIR;
+      if (valid) { st = P.ref.kStart[code]; ln = P.ref.kStart[code + 1] - st; dr = P.ref.kDirIdx[code]; }
+      ukCode[q] = code | (valid ? 0x80000000u : 0);
+      ukStart[q] = st; ukLen[q] = ln; ukDir[q] = dr;
+    }
+    __syncthreads();
+    // the look-up rule, sequentially (SeqSet.hpp:1098-1153, 1165-1226): lane j of the first wavefront holds one k-mer's code
+    // and list length, the loop reads them with v_readlane (the same replay k_seed_groups runs for reads with short repeats)
+    if (tid < 64) {
+      uint32_t prev = 0, nUsed = 0, lookups = 0, postings = 0;
+      for (int pass = 0; pass < 2; ++pass) {
+        int skipCnt = 0;
+        const uint32_t begin = nUsed;
+        for (int seg = 0; seg < nk; seg += 64) {
+          const int pl = seg + tid;
+          const uint32_t vc = pl < nk ? (ukCode[pass * nk + pl] & 0x7FFFFFFFu) : 0u;
+          const uint32_t vl = pl < nk ? ukLen[pass * nk + pl] : 0u;
+          const int cntj = min(64, nk - seg);
+          for (int j = 0; j < cntj; ++j) {
+            const uint32_t code = (uint32_t)__builtin_amdgcn_readlane((int)vc, j);
+            const uint32_t size = (uint32_t)__builtin_amdgcn_readlane((int)vl, j);
+            const int p = seg + j;
+            if (p == 0 || code != prev) {
+              ++lookups;
+              if (size >= 100 && p != 0 && p != nk - 1 && skipCnt < k / 2) { ++skipCnt; continue; }
+              skipCnt = 0;
+              if (size) {
+                if (tid == 0) usedQ[nUsed] = (uint16_t)(pass * nk + p);
+                ++nUsed;
+                postings += size;
+              }
+            }
+            prev = code;
+          }
+        }
+        if (tid == 0) sUsed[pass] = nUsed - begin;
+      }
+      if (tid == 0) {
+        P.usedCount[2 * re] = sUsed[0]; P.usedCount[2 * re + 1] = sUsed[1];
+        unsigned long long *st = P.counters + 64 + (blockIdx.x & (T1K_STAT_STRIPES - 1)) * 8;
+        atomicAdd(&st[T1K_STAT_LOOKUPS], (unsigned long long)lookups); atomicAdd(&st[T1K_STAT_POSTINGS], (unsigned long long)postings);
+      }
+    }
+    __syncthreads();
+    const uint32_t nUsedPlus = sUsed[0], nUsedMinus = sUsed[1];
+    {
+      uint32_t *uo = P.usedOut + (uint64_t)re * maxK * 4;
+      for (uint32_t u = tid; u < nUsedPlus + nUsedMinus; u += WG) {
+        const int q = usedQ[u];
+        const int pass = u < nUsedPlus ? 0 : 1;
+        uo[4 * u] = (uint32_t)(q - pass * nk); uo[4 * u + 1] = ukStart[q]; uo[4 * u + 2] = ukLen[q]; uo[4 * u + 3] = ukDir[q];
+      }
+    }
+    int chunk = 0;
+    for (int sp = 0; sp < 2; ++sp) {  // '-' strand first
+      const int pass = sp == 0 ? 1 : 0;
+      const uint32_t uBegin = pass == 0 ? 0 : nUsedPlus;
+      const uint32_t uCount = pass == 0 ? nUsedPlus : nUsedMinus;
+      if (uCount == 0) continue;
+      for (uint32_t c0 = 0; c0 < A; c0 += LONG_CH) {
+        const uint32_t c1 = min(c0 + (uint32_t)LONG_CH, A);
+        for (uint32_t i = tid; i < LONG_CH; i += WG) cnt[i] = 0;
+        __syncthreads();
+        for (uint32_t u = tid; u < uCount; u += WG) {
+          const int q = usedQ[uBegin + u];
+          const uint32_t st = ukStart[q], ln = ukLen[q];
+          uint32_t lo = 0, hi = ln;  // first posting with allele >= c0
+          while (lo < hi) { const uint32_t m = (lo + hi) >> 1; if (P.ref.kPostAllele[st + m] < c0) lo = m + 1; else hi = m; }
+          for (uint32_t j = lo; j < ln; ++j) {
+            const uint32_t al = P.ref.kPostAllele[st + j];
+            if (al >= c1) break;
+            atomicAdd(&cnt[al - c0], 1u);
+            ++hitsLocal;
+          }
+        }
+        __syncthreads();
+        constexpr uint32_t PER = LONG_CH / WG;  // thread t looks at the alleles [c0 + t * PER, + PER): the records leave in allele order
+        uint32_t mine = 0;
+        for (uint32_t i = 0; i < PER; ++i) mine += cnt[tid * PER + i] >= 3u ? 1u : 0u;
+        uint32_t gTot;
+        const uint32_t ex = t1k_block_scan_exclusive(mine, warpSums, &gTot);
+        if (tid == 0) {
+          const uint32_t gb = gTot ? t1k_arena_alloc(P.counters, T1K_AR_GROUPS, gTot, P.groupSegCap) : 0u;
+          const bool ok = gb != T1K_ARENA_FULL && chunk < P.maxChunks;
+          if (!ok) atomicOr(&P.counters[2], (unsigned long long)ERR_GROUPCAP);
+          sGroupBase = ok ? gb : 0xFFFFFFFFu;
+          if (ok && gTot) { P.chunkStart[(uint64_t)re * P.maxChunks + chunk] = gb; P.chunkCount[(uint64_t)re * P.maxChunks + chunk] = gTot; }
+        }
+        __syncthreads();
+        const uint32_t groupBase = sGroupBase;
+        if (gTot) ++chunk;
+        if (mine && groupBase != 0xFFFFFFFFu) {
+          uint32_t slot = ex;
+          for (uint32_t i = 0; i < PER; ++i) {
+            if (cnt[tid * PER + i] < 3u) continue;
+            uint4 *rec = (uint4 *)(P.recs + (uint64_t)(groupBase + slot) * stride);
+            // words 0..2: read-end | '+' strand, allele, "several diagonals" (recIsGeneral: near count 1, diagonal 0); the rest is the chain's
+            rec[0] = make_uint4(re | (pass == 0 ? 0x80000000u : 0u), c0 + tid * PER + i, (1u << 21) | (1u << 27), 0u);
+            for (uint32_t w = 1; w < stride / 4; ++w) rec[w] = make_uint4(0u, 0u, 0u, 0u);
+            ++slot;
+          }
+        }
+        __syncthreads();
+      }
+    }
+  }
+  t1k_stat_add(P.counters, T1K_STAT_HITS, hitsLocal);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // K2 / K4: single-diagonal chain, one lane per group record
 // record words: 0 re|strand, 1 allele, 2 diagonal + stray counts, 3.. M   -> after chaining: 2 = state, 3..5 packed candidate (3 = side-arena base for
 // multi-diagonal groups), 6..7 memo slots still to be added
@@ -1028,11 +1179,13 @@ __device__ inline int gatherHits(const ChainArgs &P, uint32_t re, int pass, uint
 // K5a: hit lists of the multi-diagonal groups.  One wavefront per group: the lanes share the read-end's used posting lists,
 // each finds the allele's run in its lists (sorted by allele, then offset) and the hits are written to the hit arena;
 // record word 4 = arena offset, word 5 = hit count (0xFFFFFFFF: handed to k_chain_big)
+// ROUNDS: used lists of one strand over the 64 lanes (5: reads <= 320 bp; 16: up to T1K_LONG_READ_LEN)
+template <int ROUNDS>
 __global__ __launch_bounds__(WG) void k_gather_general(ChainArgs P, uint32_t nItems) {
   const int lane = threadIdx.x & 63;
   const uint32_t wave = (blockIdx.x * WG + threadIdx.x) >> 6, nWaves = gridDim.x * (WG / 64);
   const int maxK = (int)P.maxK;
-  constexpr int ROUNDS = 2 * GROUP_FAST_MAXLEN / 64 / 2;  // lists of one strand (<= 320) over 64 lanes
+  static_assert(ROUNDS * 64 >= GROUP_FAST_MAXLEN, "lists of one strand");
   for (uint32_t q = wave; q < nItems; q += nWaves) {
     const uint32_t gi = P.generalList[q];
     uint32_t *rec = P.recs + (uint64_t)gi * P.recStride;
@@ -1302,7 +1455,8 @@ __global__ __launch_bounds__(64) void k_chain_big(ChainArgs P, uint32_t nItems) 
 // further part (they only counted for the strand vote), so they are never copied out.  The low-complexity test (SeqSet.hpp:458-485)
 // asks for the number of A / C / G / T among the non-N bases of a read span; a workgroup works on one read-end, so it keeps prefix
 // counts of the four bases for both strands in LDS (sBaseCnt[strand][base][p] = occurrences in [0, p)) and a span costs eight reads.
-__device__ __forceinline__ bool lowComplexityFromCounts(const uint16_t (*cnt)[T1K_MAX_READ_LEN + 1], int rs, int re) {
+template <int MAXLEN>
+__device__ __forceinline__ bool lowComplexityFromCounts(const uint16_t (*cnt)[MAXLEN + 1], int rs, int re) {
   const int L = re - rs + 1;
   int low = 0, lowTotal = 0;
 #pragma unroll
@@ -1313,18 +1467,21 @@ __device__ __forceinline__ bool lowComplexityFromCounts(const uint16_t (*cnt)[T1
   if (lowTotal * 7 >= L) return false;
   return low >= 2;
 }
-__device__ __forceinline__ bool keepCandidate(const ChainArgs &P, const uint16_t (*baseCnt)[4][T1K_MAX_READ_LEN + 1], int plus, uint32_t w0, uint32_t w1, uint32_t w2) {
+template <int MAXLEN>
+__device__ __forceinline__ bool keepCandidate(const ChainArgs &P, const uint16_t (*baseCnt)[4][MAXLEN + 1], int plus, uint32_t w0, uint32_t w1, uint32_t w2) {
   const int rs = (int)(w0 & 0xFFF), rend = (int)((w0 >> 12) & 0xFFF), ss = (int)(w1 & 0xFFFFF), se = (int)(w2 & 0xFFFFF);
   const int matchCnt = (int)(w2 >> 20);
   const double sim = (double)matchCnt / (double)(se - ss + 1 + rend - rs + 1);
   if (sim < P.sim) return false;
-  if (lowComplexityFromCounts(baseCnt[plus ? 0 : 1], rs, rend)) return !(0.0 < P.sim);  // similarity becomes 0
+  if (lowComplexityFromCounts<MAXLEN>(baseCnt[plus ? 0 : 1], rs, rend)) return !(0.0 < P.sim);  // similarity becomes 0
   return true;
 }
 
+// MAXLEN: longest read of the launch (T1K_MAX_READ_LEN, or T1K_LONG_READ_LEN for a window with longer reads: 16 KB of prefix counts)
+template <int MAXLEN>
 __global__ __launch_bounds__(WG) void k_collect(ChainArgs P) {
   __shared__ uint32_t warpSums[4];
-  __shared__ uint16_t sBaseCnt[2][4][T1K_MAX_READ_LEN + 1];
+  __shared__ uint16_t sBaseCnt[2][4][MAXLEN + 1];
   __shared__ uint64_t sVoteHi[WG], sVoteLo[WG];
   __shared__ uint32_t sBase;
   const int tid = threadIdx.x;
@@ -1363,7 +1520,7 @@ __global__ __launch_bounds__(WG) void k_collect(ChainArgs P) {
           if (hd.z & 0x40000000u) { const uint32_t *g = P.genCand + ((uint64_t)hd.w + j) * 6; w0 = g[0]; w1 = g[1]; w2 = g[2]; }
           VoteKey vk = voteKey((int)(w1 >> 20), (int)(w0 & 0xFFF), (int)((w0 >> 12) & 0xFFF), hd.y, plus, (int)(w1 & 0xFFFFF), (int)(w2 & 0xFFFFF));
           if (vk < best) best = vk;
-          nCand[plus] += keepCandidate(P, sBaseCnt, plus, w0, w1, w2) ? 1u : 0u;
+          nCand[plus] += keepCandidate<MAXLEN>(P, sBaseCnt, plus, w0, w1, w2) ? 1u : 0u;
         }
       }
     }
@@ -1402,7 +1559,7 @@ __global__ __launch_bounds__(WG) void k_collect(ChainArgs P) {
           for (uint32_t j = 0; j < nc; ++j) {
             uint32_t w0 = hd.w, w1 = cw.x, w2 = cw.y;
             if (hd.z & 0x40000000u) { const uint32_t *g = P.genCand + ((uint64_t)hd.w + j) * 6; w0 = g[0]; w1 = g[1]; w2 = g[2]; }
-            if (keepCandidate(P, sBaseCnt, (int)winPlus, w0, w1, w2)) { keepMask |= 1u << j; ++nk; }
+            if (keepCandidate<MAXLEN>(P, sBaseCnt, (int)winPlus, w0, w1, w2)) { keepMask |= 1u << j; ++nk; }
           }
           uint32_t tot;
           uint32_t off = t1k_block_scan_exclusive(nk, warpSums, &tot);
@@ -1497,7 +1654,8 @@ void t1k_launch_dp_dense(t1k_ctx *ctx, const ChainArgs &a, const uint32_t *jobs,
 // runs K1..K6; on return counters[0] = number of candidates, counters[2] = error flags
 int t1k_run_chain(t1k_ctx *ctx, const ChainArgs &a, int nWg, int bigBlocks, bool longReads, unsigned long long *hc) {
   const int AW = longReads ? 13 : 7;
-  const size_t maxK = a.maxK;
+  const size_t maxK = a.maxKFast;
+  const bool xlong = a.maxK > a.maxKFast;  // the window holds read-ends beyond T1K_MAX_READ_LEN: k_seed_long takes those
   size_t lds = (size_t)CHUNK_A * AW * 4 + maxK * (5 * 4 + 2) + 4 + 64;  // accumulators | sLo, pre, lstStart, lstLen, lstDir, qOf
   const size_t bitmapWords = 2 * (((size_t)a.ref.nAlleles + 31) / 32);        // chunk selection: two bitmaps over all alleles ...
   if (bitmapWords > (size_t)CHUNK_A * AW) lds += bitmapWords * 4 + 8;         // ... behind the list arrays when the accumulators cannot hold them
@@ -1513,6 +1671,11 @@ int t1k_run_chain(t1k_ctx *ctx, const ChainArgs &a, int nWg, int bigBlocks, bool
   } else {
     T1K_HIP(ctx, hipFuncSetAttribute((const void *)k_seed_groups<5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_seed_groups<5>, dim3(seedWg), dim3(WG), lds, ctx->stream, a);
+  }
+  if (xlong) {
+    const size_t ldsLong = (size_t)a.maxK * (4 * 4 + 2) + 8 + (size_t)LONG_CH * 4;
+    T1K_HIP(ctx, hipFuncSetAttribute((const void *)k_seed_long, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsLong));
+    hipLaunchKernelGGL(k_seed_long, dim3(std::min<uint32_t>(a.reads.nReadEnds, 32768u)), dim3(WG), ldsLong, ctx->stream, a);
   }
   T1K_HIP(ctx, hipEventRecord(ctx->ev[8], ctx->stream));
   int rc = readCounters(ctx, hc);
@@ -1556,7 +1719,8 @@ int t1k_run_chain(t1k_ctx *ctx, const ChainArgs &a, int nWg, int bigBlocks, bool
   }
   uint32_t nBig = 0;
   if (nGen) {
-    hipLaunchKernelGGL(k_gather_general, dim3(std::min<uint32_t>((nGen + 3) / 4, 8192u)), dim3(WG), 0, ctx->stream, a, nGen);
+    if (xlong) hipLaunchKernelGGL(k_gather_general<(T1K_LONG_READ_LEN + 63) / 64>, dim3(std::min<uint32_t>((nGen + 3) / 4, 8192u)), dim3(WG), 0, ctx->stream, a, nGen);
+    else hipLaunchKernelGGL(k_gather_general<GROUP_FAST_MAXLEN / 64>, dim3(std::min<uint32_t>((nGen + 3) / 4, 8192u)), dim3(WG), 0, ctx->stream, a, nGen);
     ChainArgs g = a;
     if (nGen >= 4096 && t1k_ensure(ctx, ctx->bJobSort, (size_t)nGen * 20 + 64) == T1K_OK) {  // groups of similar size side by side
       unsigned long long *k0 = (unsigned long long *)ctx->bJobSort.p, *k1 = k0 + nGen;
@@ -1585,7 +1749,8 @@ int t1k_run_chain(t1k_ctx *ctx, const ChainArgs &a, int nWg, int bigBlocks, bool
     nBig = (uint32_t)big.total;
   }
   if (nBig) hipLaunchKernelGGL(k_chain_big, dim3(bigBlocks * 64), dim3(64), 0, ctx->stream, a, nBig);
-  hipLaunchKernelGGL(k_collect, dim3(nWg), dim3(WG), 0, ctx->stream, a);
+  if (xlong) hipLaunchKernelGGL(k_collect<T1K_LONG_READ_LEN>, dim3(nWg), dim3(WG), 0, ctx->stream, a);
+  else hipLaunchKernelGGL(k_collect<T1K_MAX_READ_LEN>, dim3(nWg), dim3(WG), 0, ctx->stream, a);
   T1K_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
   rc = readCounters(ctx, hc);
   hc[6] = groups.total; hc[16] = jobs.total; hc[17] = retry.total; hc[18] = gen.total; hc[19] = nBig; hc[22] = fin.total;

@@ -15,9 +15,14 @@
 #include <vector>
 #include "../../include/t1k_gpu.h"
 
-// Longest read the kernels handle: the hit-offset masks of the chain kernels span 320 positions (10 words), the alignment memo
-// keys hold 9-bit lengths, k_extract_screen gives a lane five consecutive k-mers and k_extract a thread three positions of both strands.
+// Longest read of the FAST kernels: the hit-offset masks of the chain kernels span 320 positions (10 words), k_extract_screen gives a
+// lane five consecutive k-mers and k_extract a thread three positions of both strands.  The genotyper / analyzer take reads of up to
+// T1K_LONG_READ_LEN bases: a window (upload) that holds a read beyond T1K_MAX_READ_LEN seeds those read-ends with k_seed_long (hit
+// counts instead of masks; every group takes the explicit-hit-list path of the multi-diagonal groups) and runs the selection kernels
+// with wider sort-key fields; the alignment routines themselves do not depend on the length.  1000: read coordinates < 1024 and match
+// counts < 4096 in the packed overlap record (T1kOvlP), 11-bit match counts and span sums in the sort keys.
 #define T1K_MAX_READ_LEN 320
+#define T1K_LONG_READ_LEN 1000
 #define T1K_EVEN 0x5555555555555555ull
 #define T1K_NEG_BIG (-(1 << 28))
 

@@ -17,6 +17,7 @@ struct ChainArgs {
   uint32_t *jobStr, *retryStr, *generalStr, *bigStr, *finishStr, *waveStr, *waveList, *slowStr, *slowList;  // striped arenas the kernels append to
   uint32_t groupSegCap, jobSegCap, listSegCap, rareSegCap, genCandSegCap, genHitSegCap;  // listSegCap: slow / retry / finish lists; rareSegCap: general / wave / big
   uint32_t maxK;  // upper bound of the k-mers of a read-end (both strands): stride of the used-list table
+  uint32_t maxKFast;  // the same for the read-ends k_seed_groups takes (<= T1K_MAX_READ_LEN bases): its LDS layout; < maxK in a window with longer reads
   uint32_t *genJobStr, *genJobList; uint32_t genJobSegCap;  // alignments registered by the multi-diagonal groups
   uint32_t *genHits;  // hit lists of the multi-diagonal groups (k_gather_general)
   uint32_t *genCand; uint32_t genCandCap;                  // packed candidates of multi-diagonal groups (3 u32 each)
@@ -52,6 +53,7 @@ struct SelectArgs {
   uint32_t sortCap;
   int alleleBits;          // bits of an allele index
   int relax;               // --relaxIntronAlign: the relaxed match counts come from the full alignments (else k_select writes them)
+  int xl;                  // the window holds reads beyond T1K_MAX_READ_LEN: wider sort-key fields
   unsigned long long *counters;
 };
 
@@ -89,6 +91,7 @@ struct TruncArgs {
   uint32_t *ovlCount;
   uint64_t *sortScratch; uint32_t sortCap;   // keys, then a T1kOvl staging area of sortCap records
   int alleleBits;
+  int xl;                  // as SelectArgs::xl
   unsigned long long *counters;
 };
 

@@ -544,13 +544,94 @@ def test_long_reads_end_to_end_vs_reference_binary(built, tmp_path, kind, length
         assert os.path.getsize(o + "_aligned_1.fa") > 100000
 
 
+@pytest.mark.parametrize("kind,length,flags,indel", [("ref-rna", 400, ["-s", "0.97"], 0.0005), ("ref-dna", 600, ["-s", "0.9", "--relaxIntronAlign"], 0.002),
+                                                     ("ref-rna", 1000, ["-s", "0.9"], 0.002)])
+def test_reads_beyond_the_hit_masks_vs_reference_binary(built, tmp_path, kind, length, flags, indel):
+    """2 x 400 / 600 / 1000 bp reads (beyond T1K_MAX_READ_LEN = 320: k_seed_long, every group through the explicit-hit-list kernels, the
+    wide key fields of k_select / k_truncate, full alignments of more than 320 columns through the traced DP) through the whole stage:
+    deferred and eager coverage, two ranks, small windows -- every file against the reference's"""
+    util.need(util.REF_BIN)
+    ref = str(tmp_path / "ref.fa")
+    util.synth_ref(kind, ref, genes=4, scale=0.1, seed=77)
+    pfx = str(tmp_path / "r")
+    util.synth_reads(ref, pfx, pairs=1200, len=length, seed=5, sub=0.008, indel=indel, fragmean=2 * length + 40)
+    args = ["-f", ref, "-1", pfx + "_1.fq", "-2", pfx + "_2.fq"] + flags
+    o_ref = str(tmp_path / "ref")
+    a = subprocess.run([util.REF_BIN] + args + ["-t", "32", "-o", o_ref], stderr=subprocess.PIPE, text=True)
+    assert a.returncode == 0, a.stderr[-500:]
+    for tag, env in (("one", {}), ("eager", {"T1K_COVERAGE": "eager"}), ("two_ranks", {"T1K_GPUS": "0,0"}),
+                     ("small_windows", {"T1K_FIRST_WINDOW": "64", "T1K_WINDOW": "500", "T1K_BATCH": "128", "T1K_PAIR_BATCH": "256"})):
+        o = str(tmp_path / tag)
+        b = subprocess.run([GENO] + args + ["-o", o], stderr=subprocess.PIPE, text=True, env=dict(os.environ, **env))
+        assert b.returncode == 0, (tag, b.stderr[-500:])
+        for suf in ("_genotype.tsv", "_allele.tsv", "_aligned_1.fa", "_aligned_2.fa"):
+            assert open(o_ref + suf, "rb").read() == open(o + suf, "rb").read(), (tag, suf)
+        assert os.path.getsize(o + "_aligned_1.fa") > 100000
+
+
+def test_a_few_long_reads_among_short_ones_vs_reference_binary(built, tmp_path):
+    """the case the limit used to turn into an aborted run: a 2 x 150 bp file that holds a handful of 2 x 500 bp pairs (and one end of
+    700 bases whose mate is short).  Only the windows that hold such a read take the long path; every file equals the reference's,
+    for one window, for many small ones (most of them all-short) and for two ranks"""
+    util.need(util.REF_BIN)
+    ref = str(tmp_path / "ref.fa")
+    util.synth_ref("ref-rna", ref, genes=5, scale=0.1, seed=78)
+    util.synth_reads(ref, str(tmp_path / "s"), pairs=3000, len=150, seed=6, sub=0.006)
+    util.synth_reads(ref, str(tmp_path / "l"), pairs=40, len=500, seed=7, sub=0.006, indel=0.001, fragmean=1040)
+    util.synth_reads(ref, str(tmp_path / "x"), pairs=4, len=700, seed=8, sub=0.006, fragmean=1500)
+    rec = {m: [open(str(tmp_path / ("%s_%d.fq" % (t, m)))).read().split("\n") for t in "slx"] for m in (1, 2)}
+    out = {1: [], 2: []}
+    nl, nx = 0, 0
+    for i in range(3000):
+        for m in (1, 2):
+            out[m] += rec[m][0][4 * i:4 * i + 4]
+        if i % 75 == 37:       # a long pair
+            for m in (1, 2):
+                out[m] += rec[m][1][4 * nl:4 * nl + 4]
+            nl += 1
+        if i % 750 == 400:     # one long end, its mate cut back to 150 bases
+            q = rec[1][2][4 * nx:4 * nx + 4]
+            out[1] += q
+            r2 = rec[2][2][4 * nx:4 * nx + 4]
+            out[2] += [r2[0], r2[1][:150], r2[2], r2[3][:150]]
+            nx += 1
+    for m in (1, 2):
+        open(str(tmp_path / ("mix_%d.fq" % m)), "w").write("\n".join(out[m]) + "\n")
+    args = ["-f", ref, "-1", str(tmp_path / "mix_1.fq"), "-2", str(tmp_path / "mix_2.fq"), "-s", "0.97"]
+    o_ref = str(tmp_path / "ref")
+    a = subprocess.run([util.REF_BIN] + args + ["-t", "32", "-o", o_ref], stderr=subprocess.PIPE, text=True)
+    assert a.returncode == 0, a.stderr[-500:]
+    for tag, env in (("one", {}), ("two_ranks", {"T1K_GPUS": "0,0"}), ("small_windows", {"T1K_FIRST_WINDOW": "64", "T1K_WINDOW": "400", "T1K_BATCH": "128", "T1K_PAIR_BATCH": "256"})):
+        o = str(tmp_path / tag)
+        b = subprocess.run([GENO] + args + ["-o", o], stderr=subprocess.PIPE, text=True, env=dict(os.environ, **env))
+        assert b.returncode == 0, (tag, b.stderr[-500:])
+        for suf in ("_genotype.tsv", "_allele.tsv", "_aligned_1.fa", "_aligned_2.fa"):
+            assert open(o_ref + suf, "rb").read() == open(o + suf, "rb").read(), (tag, suf)
+
+
+@pytest.mark.parametrize("fasta_gz,length,sim,relax", [("CYP_RNA", 420, 0.8, False), ("CYP_DNA", 700, 0.9, True), ("CYP_RNA", 1000, 0.8, False)])
+def test_long_read_overlap_lists_and_coverage_vs_oracle(built, tmp_path, fasta_gz, length, sim, relax):
+    """AssignRead stage on reads beyond the hit masks: every overlap list (coordinates, match counts, relaxed counts, similarity bits) and
+    the per-base coverage of every allele against the oracle's.  Includes reads that repeat themselves (hits on many diagonals 100
+    apart), the shape the old over-long-read test used"""
+    import gpu_assign_check
+    fa = util.gunzip_to(getattr(util, fasta_gz), str(tmp_path / "ref.fa"))
+    util.synth_reads(fa, str(tmp_path / "r"), pairs=40, len=length, seed=21, sub=0.006, indel=0.002, fragmean=2 * length + 40)
+    reads = [s for _, _, s in t1k_amd.read_fastx(str(tmp_path / "r_1.fq"))] + [s for _, _, s in t1k_amd.read_fastx(str(tmp_path / "r_2.fq"))]
+    util.synth_reads(fa, str(tmp_path / "q"), pairs=10, len=100, seed=22, sub=0.004)
+    short = [s for _, _, s in t1k_amd.read_fastx(str(tmp_path / "q_1.fq"))]
+    reads += short + [s * 4 for s in short[:4]] + [short[4] + short[5] + short[4]]
+    assert gpu_assign_check.compare(fa, reads, sim, relax, "long reads %s %d" % (fasta_gz, length)) == 0
+
+
 def test_over_long_read_fails_before_any_output(built, tmp_path):
-    """reads longer than max_read_len (320) are not handled by this build: the run must stop with a message BEFORE an output file exists"""
+    """reads longer than max_read_len (1000: read coordinates of the packed overlap records) are not handled by this build: the run must
+    stop with a message BEFORE an output file exists"""
     c = goldens.Case("cyp_rna_2x100", str(tmp_path))
     long1 = os.path.join(str(tmp_path), "long_1.fq")
     lines = open(c.r1).read().split("\n")
-    lines[4 * 7 + 1] = lines[4 * 7 + 1] * 4          # one 400-base read in the middle of the file
-    lines[4 * 7 + 3] = lines[4 * 7 + 3] * 4
+    lines[4 * 7 + 1] = lines[4 * 7 + 1] * 12         # one 1200-base read in the middle of the file
+    lines[4 * 7 + 3] = lines[4 * 7 + 3] * 12
     open(long1, "w").write("\n".join(lines))
     out = os.path.join(str(tmp_path), "long")
     r = subprocess.run([GENO, "-f", c.ref, "-1", long1, "-2", c.r2, "-o", out] + c.flags, stderr=subprocess.PIPE, text=True)
@@ -560,7 +641,7 @@ def test_over_long_read_fails_before_any_output(built, tmp_path):
 
 @pytest.mark.parametrize("gpus", ["", "0,0"])
 def test_over_long_reads_can_be_set_aside(built, tmp_path, gpus):
-    """T1K_LONG_READS=drop: the fragments of reads beyond 320 bases take no part, the run finishes with a warning, and every output
+    """T1K_LONG_READS=drop: the fragments of reads beyond 1000 bases take no part, the run finishes with a warning, and every output
     file equals the run on the same files without those fragments (the reference itself would have genotyped them: an escape hatch
     for the odd over-long read in millions, not parity)"""
     c = goldens.Case("cyp_rna_2x100", str(tmp_path))
@@ -568,8 +649,8 @@ def test_over_long_reads_can_be_set_aside(built, tmp_path, gpus):
     long_at = (7, 40)
     with_long, without = [list(l1), list(l2)], [[], []]
     for k in long_at:
-        with_long[k % 2][4 * k + 1] = with_long[k % 2][4 * k + 1] * 4   # a 400-base read, once in mate 1's file and once in mate 2's
-        with_long[k % 2][4 * k + 3] = with_long[k % 2][4 * k + 3] * 4
+        with_long[k % 2][4 * k + 1] = with_long[k % 2][4 * k + 1] * 12   # a 1200-base read, once in mate 1's file and once in mate 2's
+        with_long[k % 2][4 * k + 3] = with_long[k % 2][4 * k + 3] * 12
     for m, src in enumerate((l1, l2)):
         for i in range(0, len(src) - 1, 4):
             if i // 4 not in long_at:
