@@ -617,7 +617,7 @@ __global__ __launch_bounds__(WG) void k_fullalign(FullArgs P) {
   const uint64_t *rn = P.reads.nmask + ((uint64_t)o.re * 2 + pass) * S;
   const int64_t goff = (int64_t)P.ref.alleleOff[o.allele];
   const int L = o.readEnd - o.readStart + 1, Ls = o.seqEnd - o.seqStart + 1;
-  const int w = P.noCov ? 0 : (int)P.reads.weight[o.re];
+  const int w = P.noCov ? 0 : (P.undo ? -(int)P.reads.weight[o.re] : (int)P.reads.weight[o.re]);
   bool slow = (L != Ls) || L > T1K_MAX_READ_LEN;  // (the closed form below keeps 320 covered-column bits in registers; longer spans take the traced DP)
   int x = 0, exonMis = 0;
   // one sweep over the windows: mismatch count, and -- kept in registers for the coverage updates below -- the covered-column
@@ -682,6 +682,7 @@ __global__ __launch_bounds__(WG) void k_fullalign(FullArgs P) {
     if (x > 3) slow = true;
   }
   if (slow) {
+    if (P.undo) return;  // (queued alignments had not added anything yet)
     // equal spans: register-band traced DP (queue A, from the front); unequal spans: general DP (queue B, from the back)
     const int dl = L > Ls ? L - Ls : Ls - L;
     // sort key of the queue entry: alignments of one read window against identical allele windows become neighbours, and the

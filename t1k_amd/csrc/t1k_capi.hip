@@ -631,7 +631,10 @@ extern "C++" int t1k_fullalign_phase(t1k_ctx *ctx, const T1kReadsDev &rd, T1kOvl
   const int maxCells = std::max(340, maxLen + 24) * std::max(340, maxLen + 24);
   const int slowBlocks = 64;
   // alignment queues (equal spans | spans differing by <= 4 | wider): striped arenas appended to by k_fullalign, then made dense
-  const uint32_t qSegCap = exactQueues ? (uint32_t)(nOvl + 64) : (uint32_t)(nOvl / T1K_NSTRIPE * 2 + 1024);
+  // (T1K_TEST_SMALL_QUEUES: the tests' way of making a stripe overflow)
+  static const bool tinyQueues = getenv("T1K_TEST_SMALL_QUEUES") != nullptr;
+  const uint32_t qSegCap = exactQueues ? (uint32_t)(nOvl + 64)
+                                       : (uint32_t)std::min<uint64_t>(nOvl + 64, tinyQueues ? (uint64_t)8 * ctx->queueBoost : (nOvl / T1K_NSTRIPE * 2 + 1024) * ctx->queueBoost);
   const size_t qDense = (size_t)nOvl + 1, qStr = (size_t)qSegCap * T1K_NSTRIPE;
   // The group records, the work lists and the candidates are dead from here on: the alignment queues, their sort keys and the trace
   // rows live in that memory when it is large enough (every arena of its own is more fresh VRAM for the driver to zero).
@@ -661,7 +664,22 @@ extern "C++" int t1k_fullalign_phase(t1k_ctx *ctx, const T1kReadsDev &rd, T1kOvl
   if (hc[2]) return capacityError(ctx, hc[2]);
   {
     const T1kArenaCounts ce = t1k_arena_counts(ctx, T1K_AR_EQ, qSegCap), cb = t1k_arena_counts(ctx, T1K_AR_BAND, qSegCap), cw = t1k_arena_counts(ctx, T1K_AR_WIDE, qSegCap);
-    if (ce.overflow || cb.overflow || cw.overflow) return capacityError(ctx, 64);
+    if (ce.overflow || cb.overflow || cw.overflow) {
+      // A stripe of an alignment queue is full (the records are spread over the stripes by workgroup, a skewed range can put more than
+      // twice its share into one).  k_fullalign has already added the coverage of the ungapped alignments: a second pass over the same
+      // records takes exactly that back, the queued alignments had not touched the arrays yet, so nothing of the range is committed and
+      // it runs again with larger stripes (t1k_assign_range) instead of ending the job with T1K_ERR_COMMITTED.
+      if (!noCov) {
+        f.undo = 1;
+        t1k_launch_fullalign(ctx, f);
+        T1K_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->covCommitted = false;
+      }
+      ctx->queueBoost = std::min<uint32_t>(ctx->queueBoost * 4, 1u << 20);
+      if (getenv("T1K_DEBUG_PHASES")) fprintf(stderr, "[t1k] a stripe of an alignment queue is full (%llu records in stripes of %u): %s, the range runs again with stripes x%u\n",
+                                              (unsigned long long)nOvl, qSegCap, noCov ? "nothing was committed" : "the range's coverage was taken back", ctx->queueBoost);
+      return capacityError(ctx, 64);
+    }
     // equal / band queues: dense, then ordered by (read-end, strand, read window, allele-window hash)
     t1k_arena_compact(ctx, T1K_AR_EQ, f.eqStr, qSegCap, vDense, ce.maxSeg);
     t1k_arena_compact64(ctx, T1K_AR_EQ, f.eqKeyStr, qSegCap, kDense, ce.maxSeg);
@@ -768,7 +786,8 @@ int t1k_assign_range(t1k_ctx *ctx, uint64_t first, uint32_t count) {
     }
     if (ctx->lastCapFlags & 4) grow(ctx->wCand, ctx->needCand, ctx->prm.cand_cap);
     if (ctx->lastCapFlags & 16) grow(ctx->wOvl, ctx->needOvl, ctx->prm.ovl_cap);
-    if (!grew || (ctx->lastCapFlags & ~(256ull | 4ull | 16ull))) return rc;  // at the limits (or another arena): the caller splits the range
+    if (ctx->lastCapFlags & 64) grew = true;  // an alignment queue's stripe: t1k_fullalign_phase has raised queueBoost (and taken the range's coverage back)
+    if (!grew || (ctx->lastCapFlags & ~(256ull | 4ull | 16ull | 64ull))) return rc;  // at the limits (or another arena): the caller splits the range
     if (getenv("T1K_DEBUG_PHASES")) fprintf(stderr, "[t1k] range of %u read-ends again with capacities: groups %llu lists %llu / %llu jobs %llu / %llu candidates %llu overlaps %llu\n", count,
                                             (unsigned long long)ctx->wGroup, (unsigned long long)ctx->wList, (unsigned long long)ctx->wRare, (unsigned long long)ctx->wJob, (unsigned long long)ctx->wGenJob,
                                             (unsigned long long)ctx->wCand, (unsigned long long)ctx->wOvl);

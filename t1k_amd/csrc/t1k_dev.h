@@ -724,6 +724,7 @@ struct t1k_ctx {
   unsigned long long lastCapFlags = 0;
   bool scaledOnce = false;
   bool covCommitted = false;     // the running range has started adding to the coverage arrays (no retry after that)
+  uint32_t queueBoost = 1;       // capacity factor of the alignment queues' stripes (t1k_fullalign_phase): raised when a stripe overflowed
   int covMode = 0;               // t1k_ctx_set_coverage_mode: 0 = t1k_assign_range adds per-base coverage (eager), 1 = it does not (deferred to
                                  // t1k_coverage_selected over the kept lists, or not wanted at all)
   double msAlloc = 0;            // wall time spent in hipMalloc (fresh VRAM is zeroed by the driver: ~35 ms per GB)

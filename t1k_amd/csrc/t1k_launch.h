@@ -63,6 +63,8 @@ struct FullArgs {
   int relax;
   int noCov;               // the alignments only feed the relaxed counts: no per-base coverage is added (t1k_ctx_set_coverage_mode 1)
   int fullLen;             // span counted in ref.covFull
+  int undo;                // second pass over the same records after an alignment queue overflowed: the coverage the first pass added for the
+                           // ungapped alignments is taken back (weights negated, integer atomics: exact) and nothing is queued -- the range can run again
   T1kOvl *ovl;
   uint64_t nOvl;
   uint32_t *eqStr, *bandStr, *wideStr; uint32_t segCap;  // striped alignment queues

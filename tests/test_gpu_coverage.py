@@ -84,6 +84,10 @@ MODES = {
     "small_windows_small_batches": {"T1K_FIRST_WINDOW": "24", "T1K_WINDOW": "96", "T1K_BATCH": "16", "T1K_PAIR_BATCH": "32", "T1K_COVER_BATCH": "64", "T1K_PIPELINES": "2"},
     "hash_order_small_batches": {"T1K_DISTINCT_ORDER": "hash", "T1K_FIRST_WINDOW": "32", "T1K_WINDOW": "128", "T1K_BATCH": "16", "T1K_PAIR_BATCH": "16"},
     "first_use_order_small_batches": {"T1K_FIRST_WINDOW": "32", "T1K_WINDOW": "128", "T1K_BATCH": "16", "T1K_PAIR_BATCH": "16", "T1K_PIPELINES": "4"},
+    # the alignment queues' stripes start at 8 entries: they overflow AFTER k_fullalign has added the range's ungapped coverage; the phase
+    # takes that back and the range runs again with larger stripes (this used to end the job with T1K_ERR_COMMITTED)
+    "eager_queue_overflow": {"T1K_COVERAGE": "eager", "T1K_TEST_SMALL_QUEUES": "1"},
+    "deferred_queue_overflow": {"T1K_TEST_SMALL_QUEUES": "1", "T1K_COVER_BATCH": "64"},
     "two_ranks": {"T1K_GPUS": "0,0"},
     "three_ranks_small_windows": {"T1K_GPUS": "0,0,0", "T1K_FIRST_WINDOW": "16", "T1K_WINDOW": "48", "T1K_BATCH": "16"},
 }
@@ -120,6 +124,8 @@ def test_coverage_modes_on_mixed_samples_vs_reference_binary(built, tmp_path, ca
         kept = re.findall(r"read sets of (\d+) of (\d+) windows kept", r.stderr)
         if mode == "eager":
             assert not m and not kept
+        if mode == "eager_queue_overflow" and case in (0, 1, 2, 3):  # (the other cases queue too few alignments to fill a stripe)
+            assert "the range's coverage was taken back" in r.stderr and "runs again with stripes" in r.stderr, r.stderr[-1500:]
         if mode == "budget_fallback":
             assert kept and all(0 < int(k) < int(w) for k, w in kept), r.stderr[-1500:]
     if case in (0, 1):  # three individuals, permissive filters: some gene carries more than two types, so selection asked for coverage
