@@ -383,34 +383,44 @@ __device__ inline void ldsCountingPass(uint64_t *key, uint32_t n, uint16_t *cnt,
   __syncthreads();
 }
 
-// entry layout: [0 | 2047 - matchCnt : 11 | span sum : 11 | 511 - read span : 9 | allele : aBits | index : iBits], bit 63 is the
-// emit mark of k_select.  Returns false if a field does not fit.  XL (a window with reads beyond T1K_MAX_READ_LEN, up to
-// T1K_LONG_READ_LEN): the read span takes 10 bits (1023 - read span) and the key may use all 64 bits.
+// Field widths of the sort keys' class (match count, span sum, read span).  A read-end's list is sorted on its own, so the layout may
+// differ from read-end to read-end: the fast windows use fixed widths (compile-time constants: reads of at most T1K_MAX_READ_LEN bases);
+// in a window that holds longer reads (XL) the widths follow the read-end's length -- a 1000-base read needs 11 / 11 / 10 bits, which
+// leaves the allele and the index 28 bits (8192 candidates against a reference of 32 768 sequences; beyond: ERR_SORTCAP, loudly), while
+// the short read-ends of the same window keep the room they have elsewhere (a 150-base read-end of the HLA-like benchmark reference
+// can hold more than 8192 candidates).
+struct KeyW { int MB, DB, RB; };
+__device__ __forceinline__ int bitLen(uint32_t v) { return 32 - __clz((int)v); }  // v >= 1
 template <bool XL>
-__device__ __forceinline__ bool packSortKey(int m, int d, int rspan, uint32_t allele, uint32_t index, int aBits, int iBits, uint64_t *out) {
-  constexpr int RB = XL ? 10 : 9, RMAX = (1 << RB) - 1;
-  if (m < 0 || m > 2047 || d < 0 || d > 2047 || rspan < 0 || rspan > RMAX || 32 + aBits + iBits > 64) return false;
-  *out = (((((uint64_t)(2047 - m) << 11 | (uint64_t)d) << RB | (uint64_t)(RMAX - rspan)) << aBits | (uint64_t)allele) << iBits) | (uint64_t)index;
+__device__ __forceinline__ KeyW selectWidths(int len) {  // k_select: seed match counts <= 2 len, span sums <= 2 len + indel slack
+  if (!XL || len <= T1K_MAX_READ_LEN) return KeyW{10, 10, 9};  // (the fast windows' layout for every read-end they could hold)
+  return KeyW{bitLen((uint32_t)(2 * len)), bitLen((uint32_t)(2 * len + 40)), bitLen((uint32_t)len)};
+}
+template <bool XL>
+__device__ __forceinline__ KeyW truncWidths(int len) {   // k_truncate: extended match counts incl. clip credit, span sums incl. clips
+  if (!XL || len <= T1K_MAX_READ_LEN) return KeyW{11, 11, 9};
+  return KeyW{bitLen((uint32_t)(2 * len)), bitLen((uint32_t)(2 * len + 40)), bitLen((uint32_t)len)};
+}
+
+// k_truncate's entry: [0.. | MMAX - matchCnt : MB | span sum : DB | RMAX - read span : RB | allele : aBits | index : iBits] (fast windows:
+// 11 / 11 / 9 and bit 63 clear).  Returns false if a field does not fit.
+__device__ __forceinline__ bool packSortKey(const KeyW &W, int m, int d, int rspan, uint32_t allele, uint32_t index, int aBits, int iBits, uint64_t *out) {
+  const int MMAX = (1 << W.MB) - 1, DMAX = (1 << W.DB) - 1, RMAX = (1 << W.RB) - 1;
+  if (m < 0 || m > MMAX || d < 0 || d > DMAX || rspan < 0 || rspan > RMAX || 1 + W.MB + W.DB + W.RB + aBits + iBits > 64) return false;
+  *out = (((((uint64_t)(MMAX - m) << W.DB | (uint64_t)d) << W.RB | (uint64_t)(RMAX - rspan)) << aBits | (uint64_t)allele) << iBits) | (uint64_t)index;
   return true;
 }
 
-// k_select's entry: [emit mark : 1 | 1023 - seed matchCnt : 10 | span sum : 10 | 511 - read span : 9 | allele : aBits | index : iBits |
-// flags : 3]; the flags (separator in the seed, extension passed, "needs clipping and similarity >= 0.95") are all the later
-// phases need to know about a candidate, so they never go back to HBM for it.  The index is unique, so the flags never order.
+// k_select's entry: [emit mark : 1 | MMAX - seed matchCnt : MB | span sum : DB | RMAX - read span : RB | allele : aBits | index : iBits |
+// flags : 3] (fast windows: 10 / 10 / 9); the flags (separator in the seed, extension passed, "needs clipping and similarity >= 0.95")
+// are all the later phases need to know about a candidate, so they never go back to HBM for it.  The index is unique, so the flags never order.
 #define SEL_F_SEPSEED 1u
 #define SEL_F_EXTOK 2u
 #define SEL_F_KEEPCLIP 4u
-// XL: 11 / 11 / 10 bits for the three class fields (seed match counts and span sums up to 2047, read spans up to 1023): the allele and
-// the index then share 28 bits (8192 candidates per read-end against a reference of 32 768 sequences; beyond: ERR_SORTCAP, loudly).
-template <bool XL> struct SelKey {
-  static constexpr int MB = XL ? 11 : 10, DB = XL ? 11 : 10, RB = XL ? 10 : 9;
-  static constexpr int MMAX = (1 << MB) - 1, DMAX = (1 << DB) - 1, RMAX = (1 << RB) - 1;
-};
-template <bool XL>
-__device__ __forceinline__ bool packSelectKey(int m, int d, int rspan, uint32_t allele, uint32_t index, uint32_t flags, int aBits, int iBits, uint64_t *out) {
-  using K = SelKey<XL>;
-  if (m < 0 || m > K::MMAX || d < 0 || d > K::DMAX || rspan < 0 || rspan > K::RMAX || 1 + K::MB + K::DB + K::RB + 3 + aBits + iBits > 64) return false;
-  *out = ((((((uint64_t)(K::MMAX - m) << K::DB | (uint64_t)d) << K::RB | (uint64_t)(K::RMAX - rspan)) << aBits | (uint64_t)allele) << iBits) | (uint64_t)index) << 3 | flags;
+__device__ __forceinline__ bool packSelectKey(const KeyW &W, int m, int d, int rspan, uint32_t allele, uint32_t index, uint32_t flags, int aBits, int iBits, uint64_t *out) {
+  const int MMAX = (1 << W.MB) - 1, DMAX = (1 << W.DB) - 1, RMAX = (1 << W.RB) - 1;
+  if (m < 0 || m > MMAX || d < 0 || d > DMAX || rspan < 0 || rspan > RMAX || 1 + W.MB + W.DB + W.RB + 3 + aBits + iBits > 64) return false;
+  *out = ((((((uint64_t)(MMAX - m) << W.DB | (uint64_t)d) << W.RB | (uint64_t)(RMAX - rspan)) << aBits | (uint64_t)allele) << iBits) | (uint64_t)index) << 3 | flags;
   return true;
 }
 
@@ -475,9 +485,11 @@ __global__ __launch_bounds__(NT) T1K_OCC8 void k_select(SelectArgs P) {
     int iBits = 1;
     while ((1u << iBits) < n) ++iBits;
     const uint64_t iMask = (1ull << iBits) - 1;
-    const int mShift = SelKey<XL>::DB + SelKey<XL>::RB + P.alleleBits + iBits + 3;  // position of the (MMAX - matchCnt) field
+    const KeyW W = selectWidths<XL>((int)P.reads.len[re]);
+    const int mShift = W.DB + W.RB + P.alleleBits + iBits + 3;  // position of the (MMAX - matchCnt) field
+    const int mMax = (1 << W.MB) - 1;
     auto idxOf = [&](uint64_t kk) { return (uint32_t)((kk >> 3) & iMask); };
-    auto seedOf = [&](uint64_t kk) { return SelKey<XL>::MMAX - (int)((kk >> mShift) & (uint64_t)SelKey<XL>::MMAX); };
+    auto seedOf = [&](uint64_t kk) { return mMax - (int)((kk >> mShift) & (uint64_t)mMax); };
     for (uint32_t i = live + tid; i < np2; i += NT) key[i] = ~0ull;
     for (uint32_t i = iBeg; i < iEnd; ++i) {
       const uint16_t fl = P.ext[c0 + i].flags;
@@ -491,7 +503,7 @@ __global__ __launch_bounds__(NT) T1K_OCC8 void k_select(SelectArgs P) {
                           (((fl & T1K_F_NEEDCLIP) && !(sim < 0.95)) ? SEL_F_KEEPCLIP : 0u);  // SeqSet.hpp:2170-2172
       const uint32_t slot = myFirst++;
       uint64_t kk;
-      if (!packSelectKey<XL>(m, d, rspan, c.allele & 0x7FFFFFFFu, i, kf, P.alleleBits, iBits, &kk)) { atomicOr(&P.counters[2], (unsigned long long)ERR_SORTCAP); kk = (uint64_t)i << 3; }
+      if (!packSelectKey(W, m, d, rspan, c.allele & 0x7FFFFFFFu, i, kf, P.alleleBits, iBits, &kk)) { atomicOr(&P.counters[2], (unsigned long long)ERR_SORTCAP); kk = (uint64_t)i << 3; }
       key[slot] = kk;
     }
     __syncthreads();
@@ -1021,13 +1033,14 @@ __global__ __launch_bounds__(NT) void k_truncate(TruncArgs P) {
     int iBits = 1;
     while ((1u << iBits) < n) ++iBits;
     const uint64_t iMask = (1ull << iBits) - 1;
+    const KeyW W = truncWidths<XL>((int)P.reads.len[re]);
     for (uint32_t i = tid; i < np2; i += NT) {
       uint64_t kk = ~0ull;
       if (i < n) {
         const T1kOvl o = P.ovl[o0 + i];
         int rspan = o.readEnd - o.readStart;
         int d = rspan + 1 + o.seqEnd - o.seqStart + 1 + 2 * o.leftClip + 2 * o.rightClip;  // similarity desc == d asc at equal matchCnt
-        if (!packSortKey<XL>((int)o.matchCnt, d, rspan, o.allele, i, P.alleleBits, iBits, &kk)) { atomicOr(&P.counters[2], (unsigned long long)ERR_SORTCAP); kk = i; }
+        if (!packSortKey(W, (int)o.matchCnt, d, rspan, o.allele, i, P.alleleBits, iBits, &kk)) { atomicOr(&P.counters[2], (unsigned long long)ERR_SORTCAP); kk = i; }
         stage[i] = o;
       }
       key[i] = kk;

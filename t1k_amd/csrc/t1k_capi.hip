@@ -351,7 +351,7 @@ int t1k_reads_attach(t1k_ctx *dst, const t1k_ctx *src, int storeSlot, int resetS
   if (!dst || !src || dst == src || dst->device != src->device || storeSlot < 0 || storeSlot > 1) return t1k_fail(dst, T1K_ERR_ARG, "t1k_reads_attach: contexts do not match");
   dst->reads = src->reads;  // packed read-ends are read-only for the stages and the list table is shared; both are owned by src
   dst->readsShared = true;
-  dst->batchMaxLen = src->batchMaxLen;
+  dst->batchMaxLen = src->batchMaxLen; dst->batchFastMaxLen = src->batchFastMaxLen;
   dst->nCand = dst->nOvl = 0;
   dst->rangeCount = 0;
   dst->storeSlot = storeSlot;
@@ -424,9 +424,17 @@ static int readsUploadBegin(t1k_ctx *ctx, uint32_t n, uint64_t bytes, int maxLen
   ctx->upN = n; ctx->upS = S; ctx->upMaxLen = maxLen; ctx->upBytes = bytes; ctx->upOpen = true;
   return T1K_OK;
 }
+// longest read among those the fast kernels take (windows that hold a read beyond T1K_MAX_READ_LEN only)
+__global__ void k_fast_max_len(const uint16_t *lens, uint32_t n, uint32_t *out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t v = i < n && lens[i] <= T1K_MAX_READ_LEN ? lens[i] : 0u;
+  for (int o = 32; o > 0; o >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, o, 64));
+  if ((threadIdx.x & 63) == 0 && v) atomicMax(out, v);
+}
 static int readsUploadEnd(t1k_ctx *ctx, const uint32_t *weights) {
   const uint32_t n = ctx->upN;
   const int S = ctx->upS;
+  uint32_t fastMax = 0;
   if (n) {
     if (weights) T1K_HIP(ctx, hipMemcpyAsync(ctx->bReadWeight.p, weights, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
     else T1K_HIP(ctx, hipMemsetD32Async((hipDeviceptr_t)ctx->bReadWeight.p, 1, (size_t)n, ctx->stream));  // every read-end counts once
@@ -435,6 +443,12 @@ static int readsUploadEnd(t1k_ctx *ctx, const uint32_t *weights) {
     T1K_HIP(ctx, hipMemsetAsync(ctx->bReadN.p, 0, (size_t)n * 2 * S * 8 + 64, ctx->stream));
     t1k_launch_pack(ctx, (const char *)ctx->bReadAscii.p, (const uint64_t *)ctx->bReadOffs.p, n, S, (uint64_t *)ctx->bReadBases.p, (uint64_t *)ctx->bReadN.p,
                     (uint16_t *)ctx->bReadLen.p, ctx->prm.n_base_code & 3);
+    if (ctx->upMaxLen > T1K_MAX_READ_LEN) {
+      uint32_t *d = (uint32_t *)ctx->bListCount.p + n;  // (spare words behind the table)
+      T1K_HIP(ctx, hipMemsetAsync(d, 0, 4, ctx->stream));
+      hipLaunchKernelGGL(k_fast_max_len, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, (const uint16_t *)ctx->bReadLen.p, n, d);
+      T1K_HIP(ctx, hipMemcpyAsync(&fastMax, d, 4, hipMemcpyDeviceToHost, ctx->stream));
+    }
   }
   T1K_HIP(ctx, hipStreamSynchronize(ctx->stream));
   ctx->upOpen = false;
@@ -449,6 +463,7 @@ static int readsUploadEnd(t1k_ctx *ctx, const uint32_t *weights) {
   ctx->readsShared = false;
   ctx->storeSlot = 0; ctx->storeChunk[0] = 0; ctx->storeUsed[0] = 0;  // the lists of the previous read set are dead
   ctx->batchMaxLen = ctx->upMaxLen;
+  ctx->batchFastMaxLen = ctx->upMaxLen > T1K_MAX_READ_LEN ? (int)fastMax : ctx->upMaxLen;
   ctx->nCand = ctx->nOvl = 0;
   ctx->rangeCount = 0;
   return T1K_OK;
@@ -805,8 +820,8 @@ static int assignOnce(t1k_ctx *ctx, uint64_t first, uint32_t count) {
   const int nWg = (int)std::min<uint32_t>((uint32_t)ctx->prm.workgroups, std::max<uint32_t>(n, 1));
   const uint32_t sortCap = 1u << 15;
   const int maxChunks = t1k_chain_max_chunks(ctx->ref.nAlleles), memoN = t1k_chain_memo_entries();
-  const bool longReads = ctx->batchMaxLen > 160;
-  const int recStride = t1k_chain_rec_stride(ctx->batchMaxLen);
+  const bool longReads = ctx->batchFastMaxLen > 160;  // (read-ends beyond T1K_MAX_READ_LEN are k_seed_long's: they do not widen the masks)
+  const int recStride = t1k_chain_rec_stride(ctx->batchFastMaxLen);
   const uint64_t groupCap = ctx->wGroup;
   // (a window with reads beyond T1K_MAX_READ_LEN sends every group of those read-ends through the explicit hit lists: up to ~1000 hits a group)
   const uint32_t jobCap = (uint32_t)ctx->wJob, genCandCap = 16u << 20, genHitCap = ctx->batchMaxLen > T1K_MAX_READ_LEN ? 1024u << 20 : 64u << 20, genJobCap = (uint32_t)ctx->wGenJob;
@@ -872,7 +887,7 @@ static int assignOnce(t1k_ctx *ctx, uint64_t first, uint32_t count) {
   a.recs = (uint32_t *)ctx->bWgGroups.p; a.recStride = (uint32_t)recStride; a.groupCap = groupCap;
   a.chunkStart = (uint32_t *)ctx->bWgStage.p; a.chunkCount = a.chunkStart + (size_t)n * maxChunks; a.maxChunks = maxChunks;
   a.usedOut = (uint32_t *)ctx->bWgHits.p; a.usedCount = a.usedOut + (size_t)n * t1k_chain_used_u32(maxK); a.maxK = (uint32_t)maxK;
-  a.maxKFast = (uint32_t)t1k_chain_max_kmers(std::min(ctx->batchMaxLen, T1K_MAX_READ_LEN), ctx->prm.kmer_length);
+  a.maxKFast = (uint32_t)t1k_chain_max_kmers(ctx->batchFastMaxLen, ctx->prm.kmer_length);
   a.memo = (unsigned long long *)ctx->bWgCache.p;
   a.jobList = (uint32_t *)ctx->bLists.p; a.jobCap = jobCap;
   a.jobStr = a.jobList + jobCap;

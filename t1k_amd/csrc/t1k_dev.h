@@ -702,6 +702,8 @@ struct t1k_ctx {
   T1kDevBuf bDedupScratch, bDedupBases, bDedupN, bDedupLen, bDedupWeight;  // t1k_reads_dedupe
   bool readsShared = false;      // the read set belongs to another context (t1k_reads_share)
   int batchMaxLen = 0;
+  int batchFastMaxLen = 0;       // longest read among those of at most T1K_MAX_READ_LEN bases (== batchMaxLen unless the window holds longer ones):
+                                 // decides the mask width of the fast kernels, so that an odd long read does not widen them for everybody
   int covFullLen = 0;            // run length counted in covFull (fixed at the context's first range)
   bool covFullDirty = false;     // covFull holds runs that are not in covDiff yet
   uint32_t rangeCount = 0;       // read-ends of the last t1k_assign_range
