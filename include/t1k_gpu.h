@@ -49,7 +49,7 @@ typedef struct {
   int32_t relax_intron_align;   /* --relaxIntronAlign */
   int32_t max_assign_cnt;       /* -n, default 2000 */
   /* device arena sizing (0 = defaults).  The *_cap values are LIMITS: what a context allocates follows the demand of its ranges */
-  int32_t max_read_len;         /* longest read accepted, default (and most) 1000; candidate extraction (t1k_extract_batch): 320 */
+  int32_t max_read_len;         /* longest read accepted, default (and most) 1000 */
   int32_t workgroups;           /* persistent workgroups of the per-read-end kernels, default 2048 */
   int64_t group_cap;            /* (read-end, strand, allele) hit groups per batch */
   int64_t cand_cap;             /* candidate records per batch */

@@ -32,7 +32,7 @@
 #include <vector>
 #include "t1k_host.h"
 
-#define T1K_BAM_MAX_READ 320  // t1k_params_default's max_read_len: the extraction kernels' hit masks span 320 read positions
+#define T1K_BAM_MAX_READ 1000  // t1k_params_default's max_read_len (T1K_LONG_READ_LEN: a batch with reads beyond 320 bases takes the wide kernel shapes)
 
 namespace {
 

@@ -221,7 +221,7 @@ void t1k_params_default(t1k_params *p) {
   p->ref_seq_similarity = 0.8;
   p->relax_intron_align = 0;
   p->max_assign_cnt = 2000;
-  p->max_read_len = T1K_LONG_READ_LEN;  // (candidate extraction: T1K_MAX_READ_LEN, checked by t1k_extract_batch)
+  p->max_read_len = T1K_LONG_READ_LEN;
   p->workgroups = 2048;
   p->n_base_code = 3;
   p->store_chunk_mb = 1536;
@@ -520,9 +520,6 @@ int t1k_extract_batch(t1k_ctx *ctx, uint32_t endsPerFragment, uint8_t *good, uin
   const uint32_t nFrag = nEnds / endsPerFragment;
   if (stats) memset(stats, 0, 8 * sizeof(uint64_t));
   if (!nFrag) return T1K_OK;
-  if (ctx->batchMaxLen > T1K_MAX_READ_LEN)  // k_extract_screen / k_extract give a lane a fixed number of k-mer positions (t1k_extract.hip)
-    return t1k_fail(ctx, T1K_ERR_ARG, "read longer than max_read_len: candidate extraction handles reads of up to " + std::to_string(T1K_MAX_READ_LEN) + " bases (the batch holds one of " +
-                                        std::to_string(ctx->batchMaxLen) + ")");
   T1K_HIP(ctx, hipSetDevice(ctx->device));
   const size_t flagBytes = ((size_t)nFrag + 63) / 64 * 64;
   int rc;
@@ -535,6 +532,7 @@ int t1k_extract_batch(t1k_ctx *ctx, uint32_t endsPerFragment, uint8_t *good, uin
   const uint32_t maxK = (uint32_t)((2 * std::max(1, ctx->batchMaxLen - ctx->prm.kmer_length + 1) + 3) / 4 * 4);
   t1k_launch_extract(ctx, ctx->ref, ctx->reads, ctx->prm.kmer_length, ctx->prm.radius, ctx->prm.hit_len_required, 1 - ctx->prm.ref_seq_similarity, nFrag,
                      endsPerFragment, maxK, dGood, dState, dCtl, dCtl + 1, ctx->prm.workgroups * 4);
+  T1K_HIP(ctx, hipGetLastError());
   unsigned long long ctl[16];
   T1K_HIP(ctx, hipMemcpyAsync(ctl, dCtl, 128, hipMemcpyDeviceToHost, ctx->stream));
   T1K_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -545,6 +543,7 @@ int t1k_extract_batch(t1k_ctx *ctx, uint32_t endsPerFragment, uint8_t *good, uin
     T1K_HIP(ctx, hipMemsetAsync(dCtl, 0, 128, ctx->stream));
     t1k_launch_extract_big(ctx, ctx->ref, ctx->reads, ctx->prm.kmer_length, ctx->prm.radius, ctx->prm.hit_len_required, 1 - ctx->prm.ref_seq_similarity, nFrag,
                            endsPerFragment, maxK, dGood, dState, dCtl, dCtl + 1, ctx->prm.workgroups * 4);
+    T1K_HIP(ctx, hipGetLastError());
     T1K_HIP(ctx, hipMemcpyAsync(ctl, dCtl, 128, hipMemcpyDeviceToHost, ctx->stream));
   }
   T1K_HIP(ctx, hipMemcpyAsync(good, dGood, nFrag, hipMemcpyDeviceToHost, ctx->stream));
@@ -554,7 +553,7 @@ int t1k_extract_batch(t1k_ctx *ctx, uint32_t endsPerFragment, uint8_t *good, uin
     for (int i = 0; i < 7; ++i) fprintf(stderr, " %.3g", (double)ctl[8 + i]);
     fprintf(stderr, "\n");
   }
-  if (ctl[0]) return t1k_fail(ctx, T1K_ERR_CAPACITY, "t1k_extract_batch: a read has more than 8192 hits on one reference sequence");
+  if (ctl[0]) return t1k_fail(ctx, T1K_ERR_CAPACITY, "t1k_extract_batch: a read has more hits on one reference sequence than the large kernel shape holds (8192; 6144 in a batch with reads beyond 320 bases)");
   if (stats) {
     for (int i = 0; i < 5; ++i) stats[i] = ctl[1 + i];
     stats[0] = nEnds;

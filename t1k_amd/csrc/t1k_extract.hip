@@ -24,9 +24,19 @@
 #include "t1k_dev.h"
 #include "t1k_launch.h"
 
-static_assert(T1K_MAX_READ_LEN <= 5 * 64, "k_extract_screen: a lane takes five consecutive k-mer positions of a 64-lane wavefront");
-static_assert(2 * T1K_MAX_READ_LEN <= 3 * 256, "k_extract: a thread takes three k-mer positions (both strands) of a 256-thread workgroup");
-static_assert(T1K_MAX_READ_LEN <= 2 * 256, "k_extract: a thread takes two used lists");
+// Shapes.  The production kernels give a lane / thread a fixed number of k-mer positions and used lists, sized for reads of up to
+// T1K_MAX_READ_LEN bases; a batch that holds a longer read (up to T1K_LONG_READ_LEN) runs the same code with larger counts (template
+// parameters PS: positions per lane of the screen, PT: positions per thread, LT: used lists per thread) -- more registers, same results.
+#define X_PS_FAST 5
+#define X_PT_FAST 3
+#define X_LT_FAST 2
+#define X_PS_LONG 16
+#define X_PT_LONG 8
+#define X_LT_LONG 4
+static_assert(T1K_MAX_READ_LEN <= X_PS_FAST * 64 && T1K_LONG_READ_LEN <= X_PS_LONG * 64, "k_extract_screen: a lane takes PS consecutive k-mer positions of a 64-lane wavefront");
+static_assert(X_PS_LONG + 15 - 1 <= 32, "k_extract_screen: a lane cuts its codes (k <= 15) out of one 32-position window");
+static_assert(2 * T1K_MAX_READ_LEN <= X_PT_FAST * 256 && 2 * T1K_LONG_READ_LEN <= X_PT_LONG * 256, "k_extract: a thread takes PT k-mer positions (both strands) of a 256-thread workgroup");
+static_assert(T1K_MAX_READ_LEN <= X_LT_FAST * 256 && T1K_LONG_READ_LEN <= X_LT_LONG * 256, "k_extract: a thread takes LT used lists of a strand");
 
 #include "t1k_group.h"
 
@@ -37,6 +47,7 @@ static_assert(T1K_MAX_READ_LEN <= 2 * 256, "k_extract: a thread takes two used l
 // again with 32768 (128 KB, one workgroup per CU, 8192 hits).
 #define X_RANGE_SMALL 4096
 #define X_RANGE_BIG 32768
+#define X_RANGE_BIG_LONG 24576   // the large shape of a batch with reads beyond T1K_MAX_READ_LEN: its k-mer tables take 48 KB of the 160
 enum { XERR_HITCAP = 1 };
 #ifdef T1K_XPROF
 #define XP(i) { const uint64_t tn_ = __builtin_amdgcn_s_memtime(); xp_[i] += tn_ - xl_; xl_ = tn_; }
@@ -77,6 +88,7 @@ __device__ __forceinline__ bool lowComplexity(int len, int cC, int cG, int cT, i
   return (cA <= 2) + (cC <= 2) + (cG <= 2) + (cT <= 2) >= 2;
 }
 
+template <int PS>
 __global__ __launch_bounds__(XWG) void k_extract_screen(ExtractArgs P) {
   const int lane = threadIdx.x & 63;
   const uint32_t wave = blockIdx.x * (XWG / 64) + (threadIdx.x >> 6), nWaves = gridDim.x * (XWG / 64);
@@ -112,16 +124,16 @@ __global__ __launch_bounds__(XWG) void k_extract_screen(ExtractArgs P) {
       // screens both strands; only the positions it lets through ask the full bitmap, once per strand.  A lane owns `per` consecutive
       // positions and cuts their codes out of two packed words it loads once (per + k - 1 <= 32 positions).
       const uint32_t pmask = k > 2 ? (1u << (2 * (k - 2))) - 1 : kmask;
-      const int per = (nk + 63) / 64;  // <= 5 for reads up to 320 bp
+      const int per = (nk + 63) / 64;  // <= PS
       const int p0 = lane * per;
-      uint32_t code[5], rcode[5], w[5];
+      uint32_t code[PS], rcode[PS], w[PS];
       uint64_t bits = 0, nbits = 0;
       if (p0 < nk) {
         bits = t1k_get32(rbase, p0);
         if (hasN) nbits = t1k_get32(rnm, p0);
       }
 #pragma unroll
-      for (int j = 0; j < 5; ++j) {
+      for (int j = 0; j < PS; ++j) {
         code[j] = (uint32_t)(bits >> (2 * j)) & kmask;
         rcode[j] = t1k_code_revcomp(code[j], k);
         w[j] = 0;
@@ -129,7 +141,7 @@ __global__ __launch_bounds__(XWG) void k_extract_screen(ExtractArgs P) {
         if (valid) w[j] = P.ref.kHasPre[(min(code[j], rcode[j]) & pmask) >> 5];
       }
 #pragma unroll
-      for (int j = 0; j < 5; ++j) {
+      for (int j = 0; j < PS; ++j) {
         if (j >= per) break;  // uniform
         bool hit0 = false, hit1 = false;
         if ((w[j] >> (min(code[j], rcode[j]) & 31u)) & 1u) {
@@ -151,7 +163,7 @@ __global__ __launch_bounds__(XWG) void k_extract_screen(ExtractArgs P) {
   }
 }
 
-template <int X_RANGE>
+template <int X_RANGE, int PT, int LT>
 __global__ __launch_bounds__(XWG) __attribute__((amdgpu_waves_per_eu(6))) void k_extract(ExtractArgs P) {
   constexpr int X_HCAP = X_RANGE / 4;
   extern __shared__ uint32_t lds[];
@@ -234,13 +246,13 @@ __global__ __launch_bounds__(XWG) __attribute__((amdgpu_waves_per_eu(6))) void k
       // with such short repeats take the sequential replay below.
       {
         const int W1 = k / 2 + 1;
-        int lastNonBig[3];
-        uint32_t szv[3];
-        bool bigv[3], dup = false;
+        int lastNonBig[PT];
+        uint32_t szv[PT];
+        bool bigv[PT], dup = false;
         int localMax = -1;
 #pragma unroll
-        for (int x = 0; x < 3; ++x) {
-          const int q = 3 * tid + x;
+        for (int x = 0; x < PT; ++x) {
+          const int q = PT * tid + x;
           szv[x] = 0; bigv[x] = false;
           if (q < 2 * nk) {
             const int pass = q >= nk ? 1 : 0, p = q - pass * nk;
@@ -263,10 +275,10 @@ __global__ __launch_bounds__(XWG) __attribute__((amdgpu_waves_per_eu(6))) void k
         for (int w = 0; w < (tid >> 6); ++w) before = max(before, sWaveMax[w]);
         const bool fallback = sMulti != 0;
         uint32_t mine = 0, minePlus = 0, minePost = 0;
-        bool usedv[3];
+        bool usedv[PT];
 #pragma unroll
-        for (int x = 0; x < 3; ++x) {
-          const int q = 3 * tid + x;
+        for (int x = 0; x < PT; ++x) {
+          const int q = PT * tid + x;
           usedv[x] = false;
           if (!fallback && q < 2 * nk && szv[x]) usedv[x] = !bigv[x] || ((q - max(lastNonBig[x], before)) % W1 == 0);
           if (usedv[x]) { ++mine; minePost += szv[x]; if (q < nk) ++minePlus; }
@@ -274,8 +286,8 @@ __global__ __launch_bounds__(XWG) __attribute__((amdgpu_waves_per_eu(6))) void k
         uint32_t tot;
         uint32_t slot = t1k_block_scan_exclusive(mine, warpSums, &tot);
 #pragma unroll
-        for (int x = 0; x < 3; ++x)
-          if (usedv[x]) usedQ[slot++] = (uint16_t)(3 * tid + x);
+        for (int x = 0; x < PT; ++x)
+          if (usedv[x]) usedQ[slot++] = (uint16_t)(PT * tid + x);
         for (int o = 32; o > 0; o >>= 1) { minePlus += __shfl_xor(minePlus, o, 64); minePost += __shfl_xor(minePost, o, 64); }
         if ((tid & 63) == 0 && !fallback) { atomicAdd(&sUsed[0], minePlus); atomicAdd(&sPost, minePost); }
         __syncthreads();
@@ -334,8 +346,8 @@ __global__ __launch_bounds__(XWG) __attribute__((amdgpu_waves_per_eu(6))) void k
         {
           uint32_t mn = 0xFFFFFFFFu, mx = 0, tsum = 0;
 #pragma unroll
-          for (int x = 0; x < 2; ++x) {
-            const uint32_t u = 2 * tid + x;
+          for (int x = 0; x < LT; ++x) {
+            const uint32_t u = LT * tid + x;
             if (u < uCnt) {
               const int q = usedQ[uBeg + u];
               const uint32_t st = ukStart[q], ln = ukLen[q];
@@ -354,11 +366,13 @@ __global__ __launch_bounds__(XWG) __attribute__((amdgpu_waves_per_eu(6))) void k
         }
         for (uint32_t r0 = rBeg; r0 < rEnd; r0 += X_RANGE) {
           const uint32_t r1 = min(A, r0 + X_RANGE);
-          // slices of the used lists (two consecutive lists per thread keep the prefix in list order)
-          uint32_t myLen[2] = {0, 0};
+          // slices of the used lists (LT consecutive lists per thread keep the prefix in list order)
+          uint32_t myLen[LT];
 #pragma unroll
-          for (int x = 0; x < 2; ++x) {
-            const uint32_t u = 2 * tid + x;
+          for (int x = 0; x < LT; ++x) myLen[x] = 0;
+#pragma unroll
+          for (int x = 0; x < LT; ++x) {
+            const uint32_t u = LT * tid + x;
             if (u < uCnt) {
               const int q = usedQ[uBeg + u];
               const uint32_t st = ukStart[q], ln = ukLen[q];
@@ -378,10 +392,18 @@ __global__ __launch_bounds__(XWG) __attribute__((amdgpu_waves_per_eu(6))) void k
               myLen[x] = hi - lo;
             }
           }
-          uint32_t total;
-          const uint32_t base = t1k_block_scan_exclusive(myLen[0] + myLen[1], warpSums, &total);
-          if (2 * tid < (int)uCnt) pre[2 * tid] = base;
-          if (2 * tid + 1 < (int)uCnt) pre[2 * tid + 1] = base + myLen[0];
+          uint32_t total, mySum = 0;
+#pragma unroll
+          for (int x = 0; x < LT; ++x) mySum += myLen[x];
+          const uint32_t base = t1k_block_scan_exclusive(mySum, warpSums, &total);
+          {
+            uint32_t run = base;
+#pragma unroll
+            for (int x = 0; x < LT; ++x) {
+              if (LT * tid + x < (int)uCnt) pre[LT * tid + x] = run;
+              run += myLen[x];
+            }
+          }
           if (tid == 0) pre[uCnt] = total;
           // a bucket holds at most all `total` hits of this range: fewer than ceil(hitLenRequired / k) cannot pass 1959, and cannot outvote
           // a bucket that does (the vote is by count alone)
@@ -431,10 +453,12 @@ __global__ __launch_bounds__(XWG) __attribute__((amdgpu_waves_per_eu(6))) void k
       const uint32_t uBeg = bestPass == 0 ? 0 : nUsed0, uCnt = bestPass == 0 ? nUsed0 : nUsed1;
       uint32_t n;
       {
-        uint32_t myLo[2] = {0, 0}, myLen[2] = {0, 0};
+        uint32_t myLo[LT], myLen[LT], mySum = 0;
 #pragma unroll
-        for (int x = 0; x < 2; ++x) {
-          const uint32_t u = 2 * tid + x;
+        for (int x = 0; x < LT; ++x) { myLo[x] = 0; myLen[x] = 0; }
+#pragma unroll
+        for (int x = 0; x < LT; ++x) {
+          const uint32_t u = LT * tid + x;
           if (u < uCnt) {
             const int q = usedQ[uBeg + u];
             const uint32_t *pl = P.ref.kPostAllele + ukStart[q];
@@ -445,12 +469,14 @@ __global__ __launch_bounds__(XWG) __attribute__((amdgpu_waves_per_eu(6))) void k
             myLo[x] = lo; myLen[x] = hi - lo;
           }
         }
-        const uint32_t base = t1k_block_scan_exclusive(myLen[0] + myLen[1], warpSums, &n);
+#pragma unroll
+        for (int x = 0; x < LT; ++x) mySum += myLen[x];
+        const uint32_t base = t1k_block_scan_exclusive(mySum, warpSums, &n);
         if (n <= X_HCAP) {
           uint32_t w = base;
 #pragma unroll
-          for (int x = 0; x < 2; ++x) {
-            const uint32_t u = 2 * tid + x;
+          for (int x = 0; x < LT; ++x) {
+            const uint32_t u = LT * tid + x;
             if (u < uCnt) {
               const int q = usedQ[uBeg + u];
               const uint32_t a = (uint32_t)(q - bestPass * nk);
@@ -571,13 +597,17 @@ void t1k_launch_extract(t1k_ctx *ctx, const T1kRefDev &ref, const T1kReadsDev &r
                         uint32_t epf, uint32_t maxK, uint8_t *good, uint8_t *state, unsigned long long *err, unsigned long long *stats, int nWg) {
   const ExtractArgs a = extractArgs(ref, reads, k, radius, hitLenRequired, oneMinusSim, nFragments, epf, maxK, good, state, err, stats);
   const size_t ldsBytes = t1k_extract_lds_bytes((int)maxK, X_RANGE_SMALL);
-  hipFuncSetAttribute((const void *)k_extract<X_RANGE_SMALL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes);
+  const bool xl = ctx->batchMaxLen > T1K_MAX_READ_LEN;  // the batch holds a read beyond the production shape
+  if (xl) hipFuncSetAttribute((const void *)k_extract<X_RANGE_SMALL, X_PT_LONG, X_LT_LONG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes);
+  else hipFuncSetAttribute((const void *)k_extract<X_RANGE_SMALL, X_PT_FAST, X_LT_FAST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes);
   const unsigned gridS = (unsigned)std::min<uint64_t>(((uint64_t)reads.nReadEnds + 3) / 4, (uint64_t)nWg);
   (void)hipEventRecord(ctx->ev[0], ctx->stream);
-  hipLaunchKernelGGL(k_extract_screen, dim3(gridS), dim3(XWG), 0, ctx->stream, a);
+  if (xl) hipLaunchKernelGGL(k_extract_screen<X_PS_LONG>, dim3(gridS), dim3(XWG), 0, ctx->stream, a);
+  else hipLaunchKernelGGL(k_extract_screen<X_PS_FAST>, dim3(gridS), dim3(XWG), 0, ctx->stream, a);
   (void)hipEventRecord(ctx->ev[1], ctx->stream);
   const unsigned grid = (unsigned)std::min<uint64_t>(((uint64_t)nFragments + XWG - 1) / XWG, (uint64_t)nWg);
-  hipLaunchKernelGGL(k_extract<X_RANGE_SMALL>, dim3(grid), dim3(XWG), ldsBytes, ctx->stream, a);
+  if (xl) hipLaunchKernelGGL((k_extract<X_RANGE_SMALL, X_PT_LONG, X_LT_LONG>), dim3(grid), dim3(XWG), ldsBytes, ctx->stream, a);
+  else hipLaunchKernelGGL((k_extract<X_RANGE_SMALL, X_PT_FAST, X_LT_FAST>), dim3(grid), dim3(XWG), ldsBytes, ctx->stream, a);
   (void)hipEventRecord(ctx->ev[2], ctx->stream);
 }
 
@@ -585,9 +615,15 @@ void t1k_launch_extract(t1k_ctx *ctx, const T1kRefDev &ref, const T1kReadsDev &r
 void t1k_launch_extract_big(t1k_ctx *ctx, const T1kRefDev &ref, const T1kReadsDev &reads, int k, int radius, int hitLenRequired, double oneMinusSim,
                             uint32_t nFragments, uint32_t epf, uint32_t maxK, uint8_t *good, uint8_t *state, unsigned long long *err, unsigned long long *stats, int nWg) {
   const ExtractArgs a = extractArgs(ref, reads, k, radius, hitLenRequired, oneMinusSim, nFragments, epf, maxK, good, state, err, stats);
-  const size_t ldsBytes = t1k_extract_lds_bytes((int)maxK, X_RANGE_BIG);
-  hipFuncSetAttribute((const void *)k_extract<X_RANGE_BIG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes);
+  const bool xl = ctx->batchMaxLen > T1K_MAX_READ_LEN;
+  const size_t ldsBytes = t1k_extract_lds_bytes((int)maxK, xl ? X_RANGE_BIG_LONG : X_RANGE_BIG);
   const unsigned grid = (unsigned)std::min<uint64_t>(((uint64_t)nFragments + XWG - 1) / XWG, (uint64_t)nWg);
-  hipLaunchKernelGGL(k_extract<X_RANGE_BIG>, dim3(grid), dim3(XWG), ldsBytes, ctx->stream, a);
+  if (xl) {
+    hipFuncSetAttribute((const void *)k_extract<X_RANGE_BIG_LONG, X_PT_LONG, X_LT_LONG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes);
+    hipLaunchKernelGGL((k_extract<X_RANGE_BIG_LONG, X_PT_LONG, X_LT_LONG>), dim3(grid), dim3(XWG), ldsBytes, ctx->stream, a);
+  } else {
+    hipFuncSetAttribute((const void *)k_extract<X_RANGE_BIG, X_PT_FAST, X_LT_FAST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes);
+    hipLaunchKernelGGL((k_extract<X_RANGE_BIG, X_PT_FAST, X_LT_FAST>), dim3(grid), dim3(XWG), ldsBytes, ctx->stream, a);
+  }
   (void)hipEventRecord(ctx->ev[2], ctx->stream);
 }

@@ -202,8 +202,8 @@ class Scenario:
         write_bam(path, self.refs, [r[3] for r in self.records], block)
 
 
-def paired_scenario(seed, with_unaligned=True, with_alt=True, barcodes=False, suffix=False, n=60):
-    sc = Scenario(seed, paired=True, barcodes=barcodes)
+def paired_scenario(seed, with_unaligned=True, with_alt=True, barcodes=False, suffix=False, n=60, read_len=100, gene_len=900):
+    sc = Scenario(seed, paired=True, barcodes=barcodes, read_len=read_len, gene_len=gene_len)
     rng = sc.rng
     L = sc.read_len
     for _ in range(n):  # pairs over and around the genes (overlap decided by the interval walk), a few far away

@@ -87,6 +87,14 @@ def test_paired_bam_with_alt_contigs_and_unaligned_pairs_vs_reference(built, tmp
 
 
 @pytest.mark.gpu
+def test_paired_bam_with_reads_beyond_320_bases_vs_reference(built, tmp_path):
+    """2 x 450 bp records (alternative contigs, unaligned pairs): their candidate test runs in the wide kernel shapes"""
+    sc = bamsynth.paired_scenario(51, read_len=450, gene_len=2400)
+    a, b = run_both(str(tmp_path), sc, env={"T1K_EXTRACT_CHUNK": "16"})
+    assert same_files(a, b, ["_1.fq", "_2.fq"]) > 8000
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("seed,barcodes", [(31, False), (32, True)])
 def test_single_end_bam_with_alt_contigs_and_unaligned_reads_vs_reference(built, tmp_path, seed, barcodes):
     sc = bamsynth.single_scenario(seed, barcodes=barcodes)

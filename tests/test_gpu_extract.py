@@ -153,7 +153,7 @@ def test_large_bucket_takes_the_big_shape(built, tmp_path):
         del os.environ["T1K_EXTRACT_FORCE_BIG"]
     assert np.array_equal(good2, want)
     huge = [rnd(200) + "CAG" * 1500 + rnd(200)]
-    with pytest.raises(t1k_amd.T1kError, match="8192 hits"):
+    with pytest.raises(t1k_amd.T1kError, match="more hits on one reference sequence"):
         device_flags(huge, ["CAG" * 50], 1, 9, 27, 0.8)
 
 
@@ -167,6 +167,65 @@ def test_n_next_to_homopolymers_vs_oracle(built, tmp_path):
         orc.close()
         good, _ = device_flags(ref, reads, 1, k, hl, sim)
         assert np.array_equal(good, want), (k, hl, sim, np.nonzero(good != want)[0][:10])
+
+
+def test_reads_beyond_320_bases_vs_oracle_and_reference_binary(built, tmp_path):
+    """a batch that holds reads of more than 320 bases takes the wide shapes of k_extract_screen / k_extract (16 positions a lane, 8 a
+    thread, 4 lists a thread): flags against the oracle read by read -- windows of alleles of 100 .. 1000 bases with substitutions, N,
+    indels, both strands, self-repeating reads, random reads -- and the executable on a 2 x 150 bp file with 2 x 500 / 2 x 900 bp pairs
+    among them against the reference's own fastq-extractor, byte for byte"""
+    ref_fa = util.gunzip_to(util.CYP_DNA, str(tmp_path / "ref.fa"))
+    ref = ref_seqs(ref_fa)
+    rng = random.Random(11)
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A", "N": "N"}
+    rnd = lambda n: "".join(rng.choice("ACGT") for _ in range(n))
+    reads = [rnd(400), rnd(1000), "A" * 700, "ACGT" * 200]
+    for _ in range(260):
+        al = rng.choice(ref)
+        L = rng.choice([100, 150, 321, 400, 512, 640, 777, 1000])
+        p0 = rng.randrange(0, max(1, len(al) - L))
+        sq = list(al[p0:p0 + L])
+        for _ in range(rng.choice([0, 2, 8, 30, 80, 200])):
+            q = rng.randrange(len(sq))
+            sq[q] = rng.choice("ACGTN")
+        if rng.random() < 0.3 and len(sq) > 40:
+            q = rng.randrange(5, len(sq) - 20)
+            sq[q:q + rng.choice([1, 2, 7, 11])] = []
+        if rng.random() < 0.2:
+            sq = sq[:len(sq) // 2] * 2
+        if rng.random() < 0.5:
+            sq = [comp[c] for c in reversed(sq)]
+        reads.append("".join(sq)[:1000])
+    for k, hl, sim in ((12, 27, 0.8), (12, 30, 0.97), (9, 23, 0.8), (14, 40, 0.9)):
+        good, _ = device_flags(ref, reads, 1, k, hl, sim)
+        orc = util.ExtractOracle(ref_fa, similarity=sim, k=k, hit_len_required=hl)
+        want = np.array([1 if orc.good(r) else 0 for r in reads], dtype=np.uint8)
+        orc.close()
+        assert np.array_equal(good, want), (k, hl, sim, np.nonzero(good != want)[0][:10])
+        assert 0 < int(want.sum()) < len(reads)
+    good2, _ = device_flags(ref, reads[:len(reads) // 2 * 2], 2, 12, 27, 0.8)   # paired: the mate is asked when the first end fails
+    orc = util.ExtractOracle(ref_fa, similarity=0.8, k=12, hit_len_required=27)
+    want2 = np.array([1 if (orc.good(reads[2 * i]) or orc.good(reads[2 * i + 1])) else 0 for i in range(len(reads) // 2)], dtype=np.uint8)
+    orc.close()
+    assert np.array_equal(good2, want2)
+    # the executable against the reference's
+    util.need(util.REF_EXTRACT)
+    rna = util.gunzip_to(util.CYP_RNA, str(tmp_path / "rna.fa"))
+    util.synth_reads(rna, str(tmp_path / "s"), pairs=3000, len=150, seed=31, bg=0.5)
+    util.synth_reads(rna, str(tmp_path / "l"), pairs=40, len=500, seed=32, bg=0.3, fragmean=1040)
+    util.synth_reads(rna, str(tmp_path / "x"), pairs=10, len=900, seed=33, bg=0.3, fragmean=1400)
+    for m in (1, 2):
+        sh = open(str(tmp_path / ("s_%d.fq" % m))).read().split("\n")
+        lo = open(str(tmp_path / ("l_%d.fq" % m))).read().split("\n")[:160]
+        xl = open(str(tmp_path / ("x_%d.fq" % m))).read().split("\n")[:40]
+        open(str(tmp_path / ("mix_%d.fq" % m)), "w").write("\n".join(sh[:4000] + lo + sh[4000:8000] + xl + sh[8000:]))
+    args = ["-f", rna, "-1", str(tmp_path / "mix_1.fq"), "-2", str(tmp_path / "mix_2.fq"), "-t", "8"]  # (-t also decides whether /1 /2 stay in the ids)
+    subprocess.run([util.REF_EXTRACT] + args + ["-o", str(tmp_path / "r")], check=True, stderr=subprocess.DEVNULL)
+    for tag, env in (("o", {}), ("c", {"T1K_EXTRACT_CHUNK": "97"})):
+        subprocess.run([XBIN] + args + ["-o", str(tmp_path / tag)], check=True, stderr=subprocess.PIPE, env=dict(os.environ, **env))
+        for suffix in ("_1.fq", "_2.fq"):
+            assert open(str(tmp_path / "r") + suffix).read() == open(str(tmp_path / tag) + suffix).read(), (tag, suffix)
+    assert len(kept_ids(str(tmp_path / "o_1.fq"))) > 100
 
 
 def test_barcode_whitelist_vs_reference_binary(built, tmp_path):

@@ -609,6 +609,32 @@ def test_a_few_long_reads_among_short_ones_vs_reference_binary(built, tmp_path):
             assert open(o_ref + suf, "rb").read() == open(o + suf, "rb").read(), (tag, suf)
 
 
+def test_long_reads_against_the_benchmark_sized_reference(built, tmp_path):
+    """the long path next to lists of benchmark size: the HLA-like reference at full scale (29 135 alleles, 15 allele bits in the sort
+    keys; short read-ends there hold more than 8192 candidates, which the 1000-base key layout could not index -- the layout follows
+    the read-end) with 2 x 150 bp pairs and a few 2 x 500 / 2 x 900 bp pairs among them, against the reference binary"""
+    util.need(util.REF_BIN)
+    ref = str(tmp_path / "ref.fa")
+    util.synth_ref("ref-rna", ref, genes=24, scale=1.0, seed=20250614)
+    util.synth_reads(ref, str(tmp_path / "s"), pairs=5000, len=150, seed=16)
+    util.synth_reads(ref, str(tmp_path / "l"), pairs=4, len=500, seed=17, fragmean=1040)
+    util.synth_reads(ref, str(tmp_path / "x"), pairs=2, len=900, seed=18, indel=0.001, fragmean=1900)
+    for m in (1, 2):
+        sh = open(str(tmp_path / ("s_%d.fq" % m))).read().split("\n")
+        lo = open(str(tmp_path / ("l_%d.fq" % m))).read().split("\n")[:16]
+        xl = open(str(tmp_path / ("x_%d.fq" % m))).read().split("\n")[:8]
+        open(str(tmp_path / ("mix_%d.fq" % m)), "w").write("\n".join(sh[:8000] + lo + sh[8000:16000] + xl + sh[16000:]))
+    args = ["-f", ref, "-1", str(tmp_path / "mix_1.fq"), "-2", str(tmp_path / "mix_2.fq"), "-s", "0.97"]
+    o_ref = str(tmp_path / "ref")
+    a = subprocess.run([util.REF_BIN] + args + ["-t", "32", "-o", o_ref], stderr=subprocess.PIPE, text=True)
+    assert a.returncode == 0, a.stderr[-500:]
+    o = str(tmp_path / "gpu")
+    b = subprocess.run([GENO] + args + ["-o", o], stderr=subprocess.PIPE, text=True)
+    assert b.returncode == 0, b.stderr[-800:]
+    for suf in ("_genotype.tsv", "_allele.tsv", "_aligned_1.fa", "_aligned_2.fa"):
+        assert open(o_ref + suf, "rb").read() == open(o + suf, "rb").read(), suf
+
+
 @pytest.mark.parametrize("fasta_gz,length,sim,relax", [("CYP_RNA", 420, 0.8, False), ("CYP_DNA", 700, 0.9, True), ("CYP_RNA", 1000, 0.8, False)])
 def test_long_read_overlap_lists_and_coverage_vs_oracle(built, tmp_path, fasta_gz, length, sim, relax):
     """AssignRead stage on reads beyond the hit masks: every overlap list (coordinates, match counts, relaxed counts, similarity bits) and
