@@ -94,9 +94,11 @@ __global__ void k_co_ptrs(const uint32_t *idx, const unsigned long long *rowPtr,
 // folded, the rows of batch b + 1 are in flight and the row addresses of batch b + 2 are being fetched (they are uniform over the
 // wavefront and consecutive in memory).
 #define CO_B 16
+static_assert(sizeof(t1k_row_entry) == 24 && offsetof(t1k_row_entry, start) == 4 && offsetof(t1k_row_entry, weight) == 12 && offsetof(t1k_row_entry, adjust_weight) == 20, "k_co_reduce_long reads the row entries as words");
+#define CO_LONG_RUN 4096   // groups of at least this many fragments are folded by k_co_reduce_long (four wavefronts a tile)
 __global__ __launch_bounds__(256) void k_co_reduce(const uint32_t *tileGroup, const unsigned long long *tilePtr, const uint32_t *order, const uint32_t *runStart,
                                                    const unsigned long long *ptrSorted, const uint32_t *gSize, const unsigned long long *groupPtr,
-                                                   T1kGroupEnt *out, uint64_t nTiles) {
+                                                   T1kGroupEnt *out, uint64_t nTiles, uint32_t longRun) {
   const uint64_t tile = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (tile >= nTiles) return;
   const int lane = threadIdx.x & 63;
@@ -105,6 +107,7 @@ __global__ __launch_bounds__(256) void k_co_reduce(const uint32_t *tileGroup, co
   const uint32_t n = gSize[g];
   const uint32_t run = order[g];
   const uint32_t j0 = runStart[run], j1 = runStart[run + 1];
+  if (j1 - j0 >= longRun) return;  // k_co_reduce_long's
   if (q >= n) return;
   const t1k_row_entry first = ((const t1k_row_entry *)ptrSorted[j0])[q];
   T1kGroupEnt acc{first.allele_idx, first.start, first.end, first.weight, first.adjust_weight};
@@ -148,6 +151,103 @@ __global__ __launch_bounds__(256) void k_co_reduce(const uint32_t *tileGroup, co
   }
   for (; j < j1; ++j) fold(rowOf(ptrSorted[j]));
   out[groupPtr[g] + q] = acc;
+}
+
+// The same fold for the groups of many fragments (10^6 in the largest group of a 10 M-pair job: its chain IS the kernel's time, and a
+// wavefront that folds 16 rows while the next 16 are in flight spends most of a step waiting for memory: 57 ns a fragment).  Here a tile
+// (group, 64 slots) belongs to a workgroup of four wavefronts: wavefront w loads the batches w, w + 4, ... of 16 rows, and the batches
+// are folded strictly in order -- the accumulators of the 64 slots pass from wavefront to wavefront through LDS, one turn (and one
+// barrier) a batch -- so every addition still happens in fragment order, while a wavefront's next rows have the other three turns to
+// arrive: four times the rows in flight per chain.
+__global__ __launch_bounds__(256) void k_co_reduce_long(const uint32_t *tileGroup, const unsigned long long *tilePtr, const uint32_t *order, const uint32_t *runStart,
+                                                        const unsigned long long *ptrSorted, const uint32_t *gSize, const unsigned long long *groupPtr,
+                                                        T1kGroupEnt *out, uint32_t longRun) {
+  __shared__ int4 sAcc[64];
+  const uint64_t tile = blockIdx.x;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const uint32_t g = tileGroup[tile];
+  const uint32_t run = order[g];
+  const uint32_t j0 = runStart[run], j1 = runStart[run + 1];
+  if (j1 - j0 < longRun) return;  // (uniform over the workgroup) k_co_reduce's
+  const uint32_t q = (uint32_t)(tile - tilePtr[g]) * 64 + lane;
+  const uint32_t nSlots = gSize[g];
+  const bool act = q < nSlots;
+  const uint32_t qc = act ? q : nSlots - 1;  // idle lanes of the group's last tile read a valid entry and drop it: no branch around any load
+  int32_t allele = 0;
+  if (w == 0) {
+    const t1k_row_entry first = ((const t1k_row_entry *)ptrSorted[j0])[qc];
+    allele = first.allele_idx;
+    sAcc[lane] = int4{first.start, first.end, __float_as_int(first.weight), __float_as_int(first.adjust_weight)};
+  }
+  __syncthreads();
+  const uint32_t total = j1 - (j0 + 1);                   // rows to fold
+  const uint32_t nBatches = (total + CO_B - 1) / CO_B;
+  const uint32_t rounds = (nBatches + 3) / 4;
+  unsigned long long pNext[CO_B];
+  int4 e[CO_B];
+  // (indices past the run are clamped to its last row: every load is unconditional, the fold counts)
+  auto loadPtrs = [&](uint32_t b) {
+#pragma unroll
+    for (int u = 0; u < CO_B; ++u) pNext[u] = ptrSorted[min(j0 + 1 + b * CO_B + (uint32_t)u, j1 - 1)];
+  };
+  auto loadRows = [&]() {
+#pragma unroll
+    for (int u = 0; u < CO_B; ++u) {
+      // (a GLOBAL load: through a generic pointer it would be a flat load, which also counts as an LDS operation -- and the wait for the
+      // LDS write before the meeting point would then wait for the rows as well)
+      typedef const __attribute__((address_space(1))) int GInt;
+      GInt *r = (GInt *)(pNext[u] + (unsigned long long)qc * sizeof(t1k_row_entry));
+      e[u] = int4{r[1], r[2], r[3], r[5]};  // start, end, weight, adjust weight (t1k_row_entry: allele, start, end, weight, qual, adjust_weight)
+    }
+  };
+  // (the accumulators travel through LDS only, so a turn ends with "wait for the LDS write and meet" -- NOT __syncthreads(), whose fence
+  // also waits for the row loads just issued (vmcnt(0)) and puts a full memory latency back into every turn: 211 ms instead of 53.  And
+  // the loads sit in straight-line code: inside an `if (w == turn)` the compiler copies the loaded registers at the join and waits there)
+  auto meet = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+  const int ws = __builtin_amdgcn_readfirstlane(w);
+  loadPtrs(min((uint32_t)ws, nBatches - 1));
+  loadRows();
+  loadPtrs(min((uint32_t)ws + 4, nBatches - 1));
+  for (uint32_t r = 0; r < rounds; ++r) {
+    const uint32_t b = 4 * r + (uint32_t)ws;
+    for (int t = 0; t < ws; ++t) meet();  // the wavefronts before this one fold their batches
+    {
+      int4 a = sAcc[lane];
+      float wt = __int_as_float(a.z), aw = __int_as_float(a.w);
+      const int cnt = b < nBatches ? (int)min((uint32_t)CO_B, total - b * CO_B) : 0;  // (past the run: nothing to fold, the turn is still taken)
+      // Genotyper.hpp:887-897 (qual == 1 always): x = start, y = end, z = weight, w = adjust weight
+      if (cnt == CO_B) {
+#pragma unroll
+        for (int u = 0; u < CO_B; ++u) {
+          if (e[u].x < a.x) a.x = e[u].x;
+          if (e[u].y < a.y) a.y = e[u].x;  // sic
+          wt += __int_as_float(e[u].z);
+          aw += __int_as_float(e[u].w);
+        }
+      } else {
+#pragma unroll
+        for (int u = 0; u < CO_B; ++u) {
+          if (u < cnt) {
+            if (e[u].x < a.x) a.x = e[u].x;
+            if (e[u].y < a.y) a.y = e[u].x;
+            wt += __int_as_float(e[u].z);
+            aw += __int_as_float(e[u].w);
+          }
+        }
+      }
+      a.z = __float_as_int(wt); a.w = __float_as_int(aw);
+      sAcc[lane] = a;
+    }
+    // this wavefront's next batch (clamped past the run: loaded and never folded): its addresses are here, its rows have the other
+    // wavefronts' turns to arrive
+    loadRows();
+    loadPtrs(min(b + 8, nBatches - 1));
+    for (int t = ws; t < 4; ++t) meet();
+  }
+  if (w == 0 && act) {
+    const int4 a = sAcc[lane];
+    out[groupPtr[g] + q] = T1kGroupEnt{allele, a.x, a.y, __int_as_float(a.z), __int_as_float(a.w)};
+  }
 }
 
 // rows of fragments [f0, f0 + n) back in the reference's row order (the `qual` slot holds the position), one wave per fragment
@@ -313,8 +413,13 @@ int t1k_rowset_coalesce(t1k_rowset *rs, uint64_t *nGroups, uint64_t *nEntries, u
   // 5. fold every (group, slot) in fragment order
   unsigned long long *ptrSorted = k1;  // the sorted hash words are no longer needed
   hipLaunchKernelGGL(k_co_ptrs, dim3(nbM), dim3(256), 0, st, idx, rs->rowPtr, ptrSorted, M);
-  hipLaunchKernelGGL(k_co_reduce, dim3((unsigned)((nTiles + 3) / 4)), dim3(256), 0, st, tileGroup, tilePtr, order, runStart, ptrSorted, gSize, groupPtr,
-                     (T1kGroupEnt *)rs->bGroupEnt.p, nTiles);
+  {
+    static const uint32_t longRun = getenv("T1K_CO_LONG_RUN") ? (uint32_t)std::max(2 * CO_B + 2, atoi(getenv("T1K_CO_LONG_RUN"))) : (uint32_t)CO_LONG_RUN;  // (0xFFFFFFFF-like values: every group through k_co_reduce)
+    hipLaunchKernelGGL(k_co_reduce_long, dim3((unsigned)nTiles), dim3(256), 0, st, tileGroup, tilePtr, order, runStart, ptrSorted, gSize, groupPtr,
+                       (T1kGroupEnt *)rs->bGroupEnt.p, longRun);
+    hipLaunchKernelGGL(k_co_reduce, dim3((unsigned)((nTiles + 3) / 4)), dim3(256), 0, st, tileGroup, tilePtr, order, runStart, ptrSorted, gSize, groupPtr,
+                       (T1kGroupEnt *)rs->bGroupEnt.p, nTiles, longRun);
+  }
   RS_HIP(hipStreamSynchronize(st));
   lap("k_co_reduce");
   rs->nGroups = G; rs->nEntries = N;

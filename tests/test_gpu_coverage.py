@@ -88,6 +88,9 @@ MODES = {
     # takes that back and the range runs again with larger stripes (this used to end the job with T1K_ERR_COMMITTED)
     "eager_queue_overflow": {"T1K_COVERAGE": "eager", "T1K_TEST_SMALL_QUEUES": "1"},
     "deferred_queue_overflow": {"T1K_TEST_SMALL_QUEUES": "1", "T1K_COVER_BATCH": "64"},
+    # every group of at least 34 fragments through the four-wavefront fold of the large groups (k_co_reduce_long; 4096 by default)
+    "long_group_fold": {"T1K_CO_LONG_RUN": "34"},
+    "long_group_fold_two_ranks": {"T1K_CO_LONG_RUN": "40", "T1K_GPUS": "0,0"},
     "two_ranks": {"T1K_GPUS": "0,0"},
     "three_ranks_small_windows": {"T1K_GPUS": "0,0,0", "T1K_FIRST_WINDOW": "16", "T1K_WINDOW": "48", "T1K_BATCH": "16"},
 }
