@@ -203,7 +203,7 @@ __global__ __launch_bounds__(256) void k_co_reduce_long(const uint32_t *tileGrou
   // (the accumulators travel through LDS only, so a turn ends with "wait for the LDS write and meet" -- NOT __syncthreads(), whose fence
   // also waits for the row loads just issued (vmcnt(0)) and puts a full memory latency back into every turn: 211 ms instead of 53.  And
   // the loads sit in straight-line code: inside an `if (w == turn)` the compiler copies the loaded registers at the join and waits there)
-  auto meet = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+  auto meet = [] { t1k_lds_barrier(); };
   const int ws = __builtin_amdgcn_readfirstlane(w);
   loadPtrs(min((uint32_t)ws, nBatches - 1));
   loadRows();

@@ -653,8 +653,16 @@ __device__ __forceinline__ void t1k_stat_add(unsigned long long *counters, int k
   }
 }
 
-// exclusive prefix sum over a workgroup of NWAVES wavefronts; all threads must call it (warpSums: NWAVES words of LDS)
-template <int NWAVES>
+// Workgroup barrier for data that is exchanged through LDS only: it waits for this wavefront's LDS operations, not for its global
+// loads and stores.  __syncthreads() fences global memory as well -- s_waitcnt vmcnt(0) before every s_barrier, and on this ISA stores
+// count in vmcnt too -- so a barrier behind a burst of record writes, or with the next step's loads already requested, waits a full
+// memory round trip for data nobody in the workgroup reads (measured: k_co_reduce_long 211 -> 31 ms, t1k_coalesce.hip).  Only for
+// barriers with no global-memory communication between the threads of the workgroup across them.
+__device__ __forceinline__ void t1k_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// exclusive prefix sum over a workgroup of NWAVES wavefronts; all threads must call it (warpSums: NWAVES words of LDS).  LDS_ONLY: its
+// two barriers are t1k_lds_barrier()
+template <int NWAVES, bool LDS_ONLY = false>
 __device__ __forceinline__ uint32_t t1k_block_scan_exclusive_n(uint32_t v, uint32_t *warpSums, uint32_t *total) {
   int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   uint32_t x = v;
@@ -664,11 +672,11 @@ __device__ __forceinline__ uint32_t t1k_block_scan_exclusive_n(uint32_t v, uint3
     if (lane >= o) x += y;
   }
   if (lane == 63) warpSums[wave] = x;
-  __syncthreads();
+  if (LDS_ONLY) t1k_lds_barrier(); else __syncthreads();
   uint32_t base = 0, tot = 0;
 #pragma unroll
   for (int w = 0; w < NWAVES; ++w) { const uint32_t s = warpSums[w]; if (w < wave) base += s; tot += s; }
-  __syncthreads();
+  if (LDS_ONLY) t1k_lds_barrier(); else __syncthreads();
   *total = tot;
   return base + x - v;
 }
