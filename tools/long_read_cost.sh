@@ -16,6 +16,7 @@ for tag in s mix; do
     T1K_DEBUG_PHASES=1 $R/t1k_amd/bin/genotyper -f ref.fa -1 ${tag}_1.fq -2 ${tag}_2.fq -s 0.97 -o out_$tag 2> err_$tag.txt || { tail -5 err_$tag.txt; exit 1; }
     echo "$tag run $rep: $(( ($(date +%s%N) - t0) / 1000000 )) ms wall"
     grep -E "windows,|device memory" err_$tag.txt | tail -3
+    sleep 20  # (the driver zeroes the memory the process gave back: the next start would wait for it)
   done
 done
 md5sum out_s_genotype.tsv out_mix_genotype.tsv
