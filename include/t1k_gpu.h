@@ -227,6 +227,18 @@ uint32_t t1k_readset_size(const t1k_readset *rs);    /* distinct read-ends */
 const char *t1k_readset_last_error(const t1k_readset *rs);
 void t1k_readset_destroy(t1k_readset *rs);
 int t1k_coverage_selected(t1k_ctx *ctx, t1k_readset *rs, const uint8_t *selected, uint64_t *nRecords);
+/* Identical read-ends across the windows of a job (the reference sorts ALL read-ends and assigns each distinct sequence once,
+ * Genotyper.cpp:451-480; a window only sees its own).  A table of the sequences assigned in the windows whose lists stay resident:
+ *   t1k_xwin_link(x, reader, w, &n)  after t1k_reads_dedupe of window w: its read-ends found in the table are marked (t1k_assign_range
+ *                                    skips them), the others are entered; n = how many were found
+ *   t1k_xwin_resolve(x, ctx, w)      once every earlier window's assignment ranges are done: the marked read-ends' list-table entries are
+ *                                    copied from the windows that hold their lists (before any fragment of w is paired) */
+typedef struct t1k_xwin t1k_xwin;
+int t1k_xwin_create(t1k_ctx *owner, uint64_t maxReadEnds, uint32_t maxWindows, t1k_xwin **out);
+void t1k_xwin_destroy(t1k_xwin *x);
+const char *t1k_xwin_last_error(const t1k_xwin *x);
+int t1k_xwin_link(t1k_xwin *x, t1k_ctx *reader, uint32_t window, uint32_t *nExternal);
+int t1k_xwin_resolve(t1k_xwin *x, t1k_ctx *ctx, uint32_t window);
 
 /* Several contexts on one GPU (pipelines of one job) can share the read-only device data of one of them: dst aliases src's
  * reference (and gets its own, zeroed coverage array) / src's packed reads.  src must outlive dst. */

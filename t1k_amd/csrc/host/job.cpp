@@ -294,6 +294,8 @@ struct Window {
   std::vector<char> touched;        // per pipeline: has it attached to this window yet (first touch empties its store slot)
   uint64_t ovlRecords = 0;          // overlap records its ranges left in the store
   bool deferred = false;            // its coverage is added later, for the selected alleles only: the read set is kept when the window is done
+  uint32_t nExternal = 0;           // distinct read-ends whose sequence an earlier kept window assigned (t1k_xwin_link): not assigned again
+  bool linking = false, linked = false;  // their list-table entries are being / have been copied from those windows (before the first pairing range)
 };
 }  // namespace
 
@@ -386,6 +388,8 @@ int t1k_job_run_local(t1k_job *job) {
   }
   const double tStart = nowMs();
   const int T = hostThreads(job);
+  // identical read-ends across windows: only between windows whose lists stay resident (T1K_CROSS_WINDOW=0 turns it off)
+  struct XwinHolder { t1k_xwin *x = nullptr; ~XwinHolder() { t1k_xwin_destroy(x); } } xw;
   std::vector<t1k_ctx *> pipes{job->ctx};
   pipes.insert(pipes.end(), job->more.begin(), job->more.end());
   const int P = (int)pipes.size();
@@ -402,6 +406,12 @@ int t1k_job_run_local(t1k_job *job) {
   uint32_t pairBatch = 1u << 16;
   if (const char *eb = getenv("T1K_PAIR_BATCH")) pairBatch = (uint32_t)std::max(8, atoi(eb));  // test aid
   const uint32_t maxWindows = 4096;
+  {
+    const char *e = getenv("T1K_CROSS_WINDOW");
+    if (job->covDeferred && F > 0 && !(e && atoi(e) == 0)) {
+      if ((rc = t1k_xwin_create(job->ctx, (uint64_t)F * per, maxWindows, &xw.x)) != T1K_OK) return jobFail(job, rc, t1k_last_error(job->ctx));
+    }
+  }
   std::vector<Window> win;
   win.reserve(maxWindows);  // windows are appended while other threads hold references: the vector never reallocates
   uint32_t firstWindow = std::min<uint32_t>(windowFrags, std::max<uint32_t>(65536u, windowFrags / 32));
@@ -576,8 +586,12 @@ int t1k_job_run_local(t1k_job *job) {
       W.distinctOf.resize(ne);
       const double tRes = nowMs();
       if (r == T1K_OK) r = t1k_reads_dedupe(rd, W.distinctOf.data(), &W.nDistinct);
-      const double tDd = nowMs();
       if (r != T1K_OK) { fail(r, t1k_last_error(rd)); return; }
+      if (xw.x && W.deferred) {  // sequences an earlier kept window assigned are not assigned again; this window's own become known to later ones
+        if ((r = t1k_xwin_link(xw.x, rd, w, &W.nExternal)) != T1K_OK) { fail(r, t1k_xwin_last_error(xw.x)); return; }
+        W.linked = W.nExternal == 0;
+      } else W.linked = true;
+      const double tDd = nowMs();
       W.assignBatch = assignBatch; W.nAssign = (W.nDistinct + assignBatch - 1) / assignBatch;
       W.pairBatch = pairBatch; W.nPair = (nf + pairBatch - 1) / pairBatch;
       W.pairDone.assign(W.nPair, 0);
@@ -598,7 +612,8 @@ int t1k_job_run_local(t1k_job *job) {
       if (traceTasks) fprintf(stderr, "[t1k task] prep window %u: %.1f .. %.1f ms (text %.1f ms, upload %.1f, resize %.1f, dedupe %.1f, pairing needs %.1f)\n", w, t0 - tStart, nowMs() - tStart, tText - t0, tUp - tText, tRes - tUp, tDd - tRes, nowMs() - tDd);
       {
         std::lock_guard<std::mutex> g(sh.m);
-        job->distinctReadEnds += W.nDistinct;
+        job->distinctReadEnds += W.nDistinct - W.nExternal;
+        job->stats.read_ends -= W.nExternal;  // (the ranges count every read-end they were given; the linked ones were not assigned)
         msPrep += nowMs() - t0;
         W.msPrep = nowMs() - t0; W.tReady = nowMs();
         W.ready = true;
@@ -632,7 +647,7 @@ int t1k_job_run_local(t1k_job *job) {
     std::vector<uint32_t> e1, e2;
     for (;;) {
       uint32_t w = 0, item = 0;
-      int kind = -1;  // 0 assign, 1 pair
+      int kind = -1;  // 0 assign, 1 pair, 2 copy the table entries of the read-ends an earlier window assigned
       {
         std::unique_lock<std::mutex> lk(sh.m);
         for (;;) {
@@ -640,8 +655,17 @@ int t1k_job_run_local(t1k_job *job) {
           if (sh.allCreated && sh.oldest >= sh.created) return;
           for (w = sh.oldest; w < sh.created && w < sh.oldest + 2 && win[w].ready && kind < 0; ++w) {
             Window &W = win[w];
-            if (W.nextPair < W.nPair && W.assignPrefix >= W.pairNeed[W.nextPair]) { kind = 1; item = W.nextPair++; }
-            else if (W.nextAssign < W.nAssign) { kind = 0; item = W.nextAssign++; }
+            if (W.nextPair < W.nPair && W.assignPrefix >= W.pairNeed[W.nextPair]) {
+              if (W.linked) { kind = 1; item = W.nextPair++; }
+              else if (!W.linking) {
+                // its linked read-ends take their lists from earlier windows: those must have finished their assignment ranges (the windows
+                // before sh.oldest are done altogether)
+                bool srcDone = true;
+                for (uint32_t v = sh.oldest; v < w; ++v) srcDone = srcDone && win[v].ready && win[v].doneAssign == win[v].nAssign;
+                if (srcDone) { kind = 2; W.linking = true; }
+              }
+            }
+            if (kind < 0 && W.nextAssign < W.nAssign) { kind = 0; item = W.nextAssign++; }
             if (kind >= 0) break;
           }
           if (kind >= 0) break;
@@ -652,6 +676,14 @@ int t1k_job_run_local(t1k_job *job) {
       int r = T1K_OK;
       std::string msg;
       const double tTask = nowMs();
+      if (kind == 2) {
+        r = t1k_xwin_resolve(xw.x, ctx, w);
+        if (r != T1K_OK) { fail(r, t1k_xwin_last_error(xw.x)); return; }
+        if (traceTasks) fprintf(stderr, "[t1k task] pipe %d window %u: %u read-ends linked to earlier windows: %.1f .. %.1f ms\n", pi, w, W.nExternal, tTask - tStart, nowMs() - tStart);
+        { std::lock_guard<std::mutex> g(sh.m); W.linked = true; }
+        sh.cv.notify_all();
+        continue;
+      }
       if (attached != (int)w) {
         r = t1k_reads_attach(ctx, job->reader[W.slot], W.slot, W.touched[pi] ? 0 : 1);
         if (r != T1K_OK) msg = t1k_last_error(ctx);

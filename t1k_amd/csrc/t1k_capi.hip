@@ -190,9 +190,11 @@ int t1k_ensure(t1k_ctx *ctx, T1kDevBuf &b, size_t bytes) {
 static double nowMs() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 // listPtr[i] = device address of read-end i's first PACKED overlap record in the store, listCount[i] = its length (after k_truncate)
-__global__ void k_publish_lists(unsigned long long *listPtr, uint32_t *listCount, const T1kOvlP *store, const uint32_t *ovlStart, const uint32_t *ovlCount, uint32_t n) {
+__global__ void k_publish_lists(unsigned long long *listPtr, uint32_t *listCount, const T1kOvlP *store, const uint32_t *ovlStart, const uint32_t *ovlCount, uint32_t n,
+                                const uint8_t *skip) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  if (skip && skip[i]) return;  // its entry comes from an earlier window (t1k_xwin_resolve)
   listPtr[i] = (unsigned long long)(store + ovlStart[i]);
   listCount[i] = ovlCount[i];
 }
@@ -205,9 +207,9 @@ __global__ void k_pack_overlaps(const T1kOvl *work, T1kOvlP *store, uint64_t nOv
   store[g] = p;
 }
 static void t1k_launch_publish_lists(t1k_ctx *ctx, unsigned long long *listPtr, uint32_t *listCount, const T1kOvl *work, T1kOvlP *store, uint64_t nOvl,
-                                     const uint32_t *ovlStart, const uint32_t *ovlCount, uint32_t n, unsigned long long *counters) {
+                                     const uint32_t *ovlStart, const uint32_t *ovlCount, uint32_t n, unsigned long long *counters, const uint8_t *skip) {
   if (nOvl) hipLaunchKernelGGL(k_pack_overlaps, dim3((unsigned)((nOvl + 255) / 256)), dim3(256), 0, ctx->stream, work, store, nOvl, counters);
-  if (n) hipLaunchKernelGGL(k_publish_lists, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, listPtr, listCount, store, ovlStart, ovlCount, n);
+  if (n) hipLaunchKernelGGL(k_publish_lists, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, listPtr, listCount, store, ovlStart, ovlCount, n, skip);
 }
 
 
@@ -460,6 +462,7 @@ static int readsUploadEnd(t1k_ctx *ctx, const uint32_t *weights) {
   ctx->reads.weight = (const uint32_t *)ctx->bReadWeight.p;
   ctx->reads.listPtr = (unsigned long long *)ctx->bListPtr.p;
   ctx->reads.listCount = (uint32_t *)ctx->bListCount.p;
+  ctx->reads.skip = nullptr;
   ctx->readsShared = false;
   ctx->storeSlot = 0; ctx->storeChunk[0] = 0; ctx->storeUsed[0] = 0;  // the lists of the previous read set are dead
   ctx->batchMaxLen = ctx->upMaxLen;
@@ -814,6 +817,7 @@ static int assignOnce(t1k_ctx *ctx, uint64_t first, uint32_t count) {
   T1kReadsDev rd = ctx->reads;  // view of the sub-range; read-end ids inside the batch are relative to `first`
   rd.nReadEnds = count;
   rd.bases += first * 2 * rd.S; rd.nmask += first * 2 * rd.S; rd.len += first; rd.weight += first;
+  if (rd.skip) rd.skip += first;
   ctx->rangeCount = count;
   int rc;
   const int nWg = (int)std::min<uint32_t>((uint32_t)ctx->prm.workgroups, std::max<uint32_t>(n, 1));
@@ -958,7 +962,7 @@ static int assignOnce(t1k_ctx *ctx, uint64_t first, uint32_t count) {
   t1k_launch_truncate(ctx, tr, nWg);
   T1K_HIP(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
   // the lists are final: publish them in the read set's table (absolute read-end index) and keep their records in the store
-  t1k_launch_publish_lists(ctx, rd.listPtr + first, rd.listCount + first, ctx->ovlBase, ctx->storeBase, ctx->nOvl, s.ovlStart, s.ovlCount, n, a.counters);
+  t1k_launch_publish_lists(ctx, rd.listPtr + first, rd.listCount + first, ctx->ovlBase, ctx->storeBase, ctx->nOvl, s.ovlStart, s.ovlCount, n, a.counters, rd.skip);
   if ((rc = fetchCounters(ctx, hc))) return rc;
   double t4 = nowMs();
   if (hc[2]) return capacityError(ctx, hc[2]);

@@ -484,7 +484,8 @@ __global__ __launch_bounds__(WG) T1K_OCC8 void k_seed_groups(ChainArgs P) {
     for (int c = tid; c < P.maxChunks; c += WG) P.chunkCount[(uint64_t)re * P.maxChunks + c] = 0;
     if (tid == 0) { P.usedCount[2 * re] = 0; P.usedCount[2 * re + 1] = 0; }
     // (a read-end beyond the hit masks' span is seeded by k_seed_long, launched behind this kernel)
-    if (len < k || len > T1K_MAX_READ_LEN) { __syncthreads(); continue; }  // GetOverlapsFromRead returns -1 (SeqSet.hpp:1598-1599)
+    // (... and one whose lists an earlier window of the job holds is not seeded at all: t1k_xwin_link)
+    if (len < k || len > T1K_MAX_READ_LEN || (P.reads.skip && P.reads.skip[re])) { __syncthreads(); continue; }  // GetOverlapsFromRead returns -1 (SeqSet.hpp:1598-1599)
     const int nk = len - k + 1;
     for (int q = tid; q < 2 * nk; q += WG) {
       int pass = q / nk, p = q - pass * nk;
@@ -910,7 +911,7 @@ __global__ __launch_bounds__(WG) void k_seed_long(ChainArgs P) {
   unsigned int hitsLocal = 0;
   for (uint32_t re = blockIdx.x; re < P.reads.nReadEnds; re += gridDim.x) {
     const int len = P.reads.len[re];
-    if (len <= T1K_MAX_READ_LEN) continue;  // (uniform over the workgroup)
+    if (len <= T1K_MAX_READ_LEN || (P.reads.skip && P.reads.skip[re])) continue;  // (uniform over the workgroup)
     const int S = P.reads.S;
     const uint64_t *rbase = P.reads.bases + (uint64_t)re * 2 * S;
     const uint64_t *rnm = P.reads.nmask + (uint64_t)re * 2 * S;

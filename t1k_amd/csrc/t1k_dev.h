@@ -142,6 +142,9 @@ struct T1kReadsDev {
   // (pipeline) assigned the read-end; all contexts that alias one read set share this table.
   unsigned long long *listPtr;  // [nReadEnds]
   uint32_t *listCount;          // [nReadEnds]
+  // [nReadEnds] or NULL: 1 = the read-end's sequence was assigned in an earlier window of the job that is still resident; it is not
+  // seeded again and its table entry is filled from that window's (t1k_xwin_link / t1k_xwin_resolve, t1k_dedupe.hip)
+  const uint8_t *skip;
 };
 
 // ------------------------------------------------------------------------------------------------------------------
