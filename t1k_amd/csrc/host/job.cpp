@@ -592,7 +592,10 @@ int t1k_job_run_local(t1k_job *job) {
         W.linked = W.nExternal == 0;
       } else W.linked = true;
       const double tDd = nowMs();
-      W.assignBatch = assignBatch; W.nAssign = (W.nDistinct + assignBatch - 1) / assignBatch;
+      // (a range is sized by the read-ends it has to assign: the ones linked to earlier windows ride along for nothing)
+      W.assignBatch = assignBatch;
+      if (W.nExternal) W.assignBatch = (uint32_t)std::min<uint64_t>(2ull * assignBatch, ((uint64_t)assignBatch * W.nDistinct + (W.nDistinct - W.nExternal)) / std::max<uint32_t>(1u, W.nDistinct - W.nExternal));
+      W.nAssign = (W.nDistinct + W.assignBatch - 1) / W.assignBatch;
       W.pairBatch = pairBatch; W.nPair = (nf + pairBatch - 1) / pairBatch;
       W.pairDone.assign(W.nPair, 0);
       W.assignDone.assign(W.nAssign, 0);
@@ -603,7 +606,7 @@ int t1k_job_run_local(t1k_job *job) {
             const size_t i0 = q * (size_t)pairBatch * per, i1 = std::min<size_t>((size_t)ne, (q + 1) * (size_t)pairBatch * per);
             uint32_t mx = 0;
             for (size_t i = i0; i < i1; ++i) mx = std::max(mx, W.distinctOf[i]);
-            W.pairNeed[q] = mx / assignBatch + 1;
+            W.pairNeed[q] = mx / W.assignBatch + 1;
           }
         });
         for (uint32_t q = 1; q < W.nPair; ++q) W.pairNeed[q] = std::max(W.pairNeed[q], W.pairNeed[q - 1]);

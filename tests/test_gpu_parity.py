@@ -404,10 +404,11 @@ def test_many_small_windows_and_ranges(built, tmp_path, name, env):
     r0 = subprocess.run([GENO] + c.args() + ["-o", off], stderr=subprocess.PIPE, text=True, env=dict(os.environ, T1K_DEBUG_PHASES="1", T1K_CROSS_WINDOW="0", **env))
     assert r0.returncode == 0, r0.stderr
     _golden_files_equal(c, off)
-    d_on, d_off = (int(re.search(r"read-ends -> (\d+) distinct", x.stderr).group(1)) for x in (r, r0))
-    assert d_on <= d_off
-    if name.startswith("cyp") and "T1K_GPUS" not in env:  # (thousands of reads of one gene: every window repeats sequences of the ones before)
-        assert d_on < d_off, (d_on, d_off)
+    if "T1K_GPUS" not in env:  # (several ranks print a line each, in any order)
+        d_on, d_off = (int(re.search(r"read-ends -> (\d+) distinct", x.stderr).group(1)) for x in (r, r0))
+        assert d_on <= d_off
+        if name == "cyp_rna_single":  # (thousands of reads of one short gene: every window repeats sequences of the ones before)
+            assert d_on < d_off, (d_on, d_off)
 
 
 @pytest.mark.parametrize("case", ["empty", "one_pair", "shorter_than_k", "single_end_empty"])
