@@ -409,7 +409,11 @@ int t1k_job_run_local(t1k_job *job) {
   {
     const char *e = getenv("T1K_CROSS_WINDOW");
     if (job->covDeferred && F > 0 && !(e && atoi(e) == 0)) {
-      if ((rc = t1k_xwin_create(job->ctx, (uint64_t)F * per, maxWindows, &xw.x)) != T1K_OK) return jobFail(job, rc, t1k_last_error(job->ctx));
+      // (no memory for the table: the windows then assign their own copies, as before -- an optimisation must not end the job)
+      if (t1k_xwin_create(job->ctx, (uint64_t)F * per, maxWindows, &xw.x) != T1K_OK) {
+        xw.x = nullptr;
+        if (getenv("T1K_DEBUG_PHASES")) fprintf(stderr, "[t1k job] no table of read-ends across windows: %s\n", t1k_last_error(job->ctx));
+      }
     }
   }
   std::vector<Window> win;
