@@ -1177,12 +1177,14 @@ int t1k_job_finish(t1k_job *job) {
       const double t0 = nowMs();
       std::vector<uint8_t> sel(job->ref.al.size(), 0);
       for (int a : need) sel[a] = 1;
-      for (t1k_readset *&rs : job->archive) {
+      // every kept read set stays alive until ALL of them are scanned: a later window's list table holds addresses inside the overlap-store
+      // chunks of the earlier windows whose lists it shares (t1k_xwin_resolve), and those chunks belong to the earlier sets
+      for (t1k_readset *rs : job->archive) {
         uint64_t n = 0;
         if ((hookRc = t1k_coverage_selected(job->ctx, rs, sel.data(), &n)) != T1K_OK) { job->err = t1k_last_error(job->ctx); return false; }
         job->coverRecords += n;
-        t1k_readset_destroy(rs); rs = nullptr;
       }
+      for (t1k_readset *&rs : job->archive) { t1k_readset_destroy(rs); rs = nullptr; }
       job->archive.clear();
       if (job->nRanks > 1) {  // per-base coverage of all ranks: integers, exact in any order
         void *dcov = nullptr; uint64_t covN = 0;

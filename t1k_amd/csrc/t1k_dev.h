@@ -753,6 +753,7 @@ struct t1k_ctx {
   std::vector<uint64_t> hEmRowPtr, emPieceBytes, emPieceDispl;  // sharded E-step: the ranks' pieces of the row-major contribution array
   uint32_t emGroups = 0, emEc = 0, emRowBegin = 0, emRowEnd = 0;
   struct t1k_comm *emComm = nullptr;
+  bool emReduceMode = false;   // T1K_EM_COLLECTIVE=allreduce: partial class totals per rank, all-reduce of E doubles (opt-in: re-associates the sums)
   uint64_t emNnz = 0;
   std::vector<int32_t> hEmLen;
   int traceFetch = 0;          // T1K_DEBUG_TRACE
@@ -761,6 +762,7 @@ struct t1k_ctx {
   hipEvent_t upEv[4] = {nullptr, nullptr, nullptr, nullptr}; bool upEvSet[4] = {false, false, false, false};
   uint64_t lastSlowGroups = 0;             // groups the last range left to the gap walk (T1K_DEBUG_PHASES)
   uint64_t pairEpoch = 0;      // epochs handed out to k_pair's allele tables since they were last cleared
+  uint64_t pairBigCap = 0;     // entries of k_pair's big arena (scratch of the fragments whose lists exceed a workgroup's own)
   unsigned long long *countersPinned = nullptr;  // page-locked landing buffer of t1k_fetch_counters
   double *emPinned = nullptr;  // page-locked staging for the per-update vectors: [x | n], emPinnedN doubles each
   size_t emPinnedN = 0;

@@ -279,7 +279,7 @@ int t1k_em_setup(t1k_ctx *ctx, const uint64_t *rowPtr, const uint32_t *ecIdx, co
   T1K_HIP(ctx, hipStreamSynchronize(ctx->stream));
   ctx->emGroups = nGroups; ctx->emEc = nEc; ctx->emNnz = nnz;
   ctx->emAllreduce = allreduce; ctx->emUser = user;
-  ctx->emRowBegin = 0; ctx->emRowEnd = nGroups; ctx->emComm = nullptr;
+  ctx->emRowBegin = 0; ctx->emRowEnd = nGroups; ctx->emComm = nullptr; ctx->emReduceMode = false;
   // class lengths stay on the host (M-step)
   if (nEc) ctx->hEmLen.assign(ecLen, ecLen + nEc); else ctx->hEmLen.clear();
   ctx->hEmRowPtr.assign(rowPtr, rowPtr + nGroups + 1);  // (t1k_em_shard cuts the contribution array at the ranks' row boundaries)
@@ -305,6 +305,17 @@ int t1k_em_shard(t1k_ctx *ctx, uint32_t rowBegin, uint32_t rowEnd, t1k_comm *com
     }
     if (next != ctx->emGroups) return t1k_fail(ctx, T1K_ERR_ARG, "t1k_em_shard: the ranks' row ranges do not cover the read groups");
   }
+  // T1K_EM_COLLECTIVE=allreduce: the collective north_star names -- every rank adds up its OWN rows' contributions per class and the E
+  // partial sums are all-reduced (E doubles per update instead of the nnz-sized gather).  The class totals then differ from the one-GPU
+  // run's by the re-association of the sum (a few ulp), so this mode is opt-in; the default gathers the contributions and stays bit-exact.
+  // Here: the class-major contribution array is zeroed once -- the slots of the other ranks' rows are never written, and x + 0.0 == x.
+  const char *mode = getenv("T1K_EM_COLLECTIVE");
+  ctx->emReduceMode = N > 1 && mode && !strcmp(mode, "allreduce");
+  if (ctx->emReduceMode && ctx->emNnz) {
+    T1K_HIP(ctx, hipSetDevice(ctx->device));
+    T1K_HIP(ctx, hipMemsetAsync(ctx->bEmContrib.p, 0, (size_t)ctx->emNnz * 8, ctx->stream));
+    T1K_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
   return T1K_OK;
 }
 
@@ -323,8 +334,9 @@ int t1k_em_update(t1k_ctx *ctx, const double *x0, double *x1, double *ecReadCoun
   double *px = ctx->emPinned, *pn = ctx->emPinned + ctx->emPinnedN;
   memcpy(px, x0, (size_t)E * 8);
   T1K_HIP(ctx, hipMemcpyAsync(ctx->bEmX0.p, px, (size_t)E * 8, hipMemcpyHostToDevice, ctx->stream));
-  const bool sharded = ctx->emComm && t1k_comm_size(ctx->emComm) > 1;
-  const uint32_t g0 = sharded ? ctx->emRowBegin : 0, gn = (sharded ? ctx->emRowEnd : G) - g0;
+  const bool reduce = ctx->emComm && t1k_comm_size(ctx->emComm) > 1 && ctx->emReduceMode;
+  const bool sharded = ctx->emComm && t1k_comm_size(ctx->emComm) > 1 && !reduce;
+  const uint32_t g0 = (sharded || reduce) ? ctx->emRowBegin : 0, gn = ((sharded || reduce) ? ctx->emRowEnd : G) - g0;
   if (gn) hipLaunchKernelGGL(k_em_rows, dim3((gn + 3) / 4), dim3(256), 0, ctx->stream, (const uint64_t *)ctx->bEmRowPtr.p + g0, (const uint32_t *)ctx->bEmEc.p,
                              sharded ? (const uint64_t *)nullptr : (const uint64_t *)ctx->bEmColIdx.p, (const double *)ctx->bEmCount.p + g0, (const double *)ctx->bEmX0.p,
                              (double *)ctx->bEmContrib.p, gn);
@@ -337,6 +349,11 @@ int t1k_em_update(t1k_ctx *ctx, const double *x0, double *x1, double *ecReadCoun
   }
   hipLaunchKernelGGL(k_em_cols, dim3((E + 3) / 4), dim3(256), 0, ctx->stream, (const uint64_t *)ctx->bEmColPtr.p, (const double *)ctx->bEmContrib.p,
                      sharded ? (const uint32_t *)ctx->bEmEntryOf.p : (const uint32_t *)nullptr, (double *)ctx->bEmN.p, E);
+  if (reduce) {  // partial class totals of this rank's rows -> totals of all rows (E doubles over RCCL / the in-process transport)
+    T1K_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const int rc = t1k_comm_allreduce(ctx->emComm, ctx->bEmN.p, E, 1);
+    if (rc != T1K_OK) return t1k_fail(ctx, rc, std::string("t1k_em_update: ") + t1k_comm_last_error(ctx->emComm));
+  }
   if (ctx->emAllreduce) {
     T1K_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->emAllreduce(ctx->bEmN.p, E, ctx->emUser);  // RCCL all-reduce of the per-class expected read counts

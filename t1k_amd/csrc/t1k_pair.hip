@@ -83,8 +83,13 @@ struct PairArgs {
   Frag *frags; uint32_t fragCap;   // [wg][fragCap]
   uint32_t *keep;                  // [wg][fragCap]
   unsigned long long *counters;    // [2] error flags, [9] row total
-  const uint32_t *only; uint32_t nOnly;  // second pass: just these fragments (the ones whose lists did not fit the first pass's scratch)
-  uint32_t *overflowList;          // first pass: fragments with more than fragCap overlaps are listed here (count in counters[23]) instead of failing
+  // second pass (same launch sequence, no host step between the two): the fragments whose two lists did not fit the first pass's per-workgroup
+  // scratch.  `only` = {fragment, offset of its scratch in the big arena} pairs written by the first pass, their number in counters[23]
+  // (read by the device: the launch is unconditional and sized to fill the chip), the arena cursor in counters[24] (entries, counted past
+  // the capacity so that the host knows what to allocate when it has to run the call again)
+  const uint32_t *only;
+  Frag *bigFrags; uint32_t *bigKeep; uint64_t bigCap;
+  uint32_t *overflowList;          // first pass: fragments with more than fragCap overlaps are listed here instead of failing
   const uint8_t *whitelist;        // [nAlleles] or NULL: alleles outside it are left out of the rows (Genotyper.hpp:822-823)
   int rawKept;                     // rows = the fragment assignment list itself (what ReadAssignmentToFragmentAssignment returns), without
                                    // the -n / separator / whitelist drops of SetReadAssignments: the analyzer's per-barcode summary reads that
@@ -206,12 +211,13 @@ __global__ __launch_bounds__(WG) void k_pair(PairArgs P) {
   uint64_t *tabSlot = P.tabSlot + (uint64_t)blockIdx.x * A;
   Frag *frags = P.frags + (uint64_t)blockIdx.x * P.fragCap;
   uint32_t *keep = P.keep + (uint64_t)blockIdx.x * P.fragCap;
+  uint32_t fragCap = P.fragCap;
 #ifdef T1K_PAIR_PROFILE
   uint64_t tp_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tl_ = __builtin_amdgcn_s_memtime();
 #endif
-  const uint32_t nItems = P.only ? P.nOnly : P.nFragments;
+  const uint32_t nItems = P.only ? (uint32_t)P.counters[23] : P.nFragments;
   for (uint32_t it = blockIdx.x; it < nItems; it += gridDim.x) {
-    const uint32_t f = P.only ? P.only[it] : it;
+    const uint32_t f = P.only ? P.only[2 * it] : it;
     const uint64_t epoch = (uint64_t)(P.epochBase + f + 1) << 32;
     const bool paired = P.end2 != nullptr;
     const uint32_t e1 = P.end1[f];
@@ -223,24 +229,33 @@ __global__ __launch_bounds__(WG) void k_pair(PairArgs P) {
     const bool hasN = P.hasN ? P.hasN[f] != 0 : false;
     if (tid == 0) { sDup = 0; sFail = 0; sBestM = -1; sBestIdx = 0x7FFFFFFF; sAnySep = 0; sNotOne = 0; sN = 0; }
     __syncthreads();
-    if (tid == 0 && n1 + n2) atomicAdd(&P.counters[22], (unsigned long long)(n1 + n2));  // statistics: overlap records read
     const bool dangling = paired && (n1 == 0 || n2 == 0);
     const bool both = paired && !dangling;
     uint32_t nFrag = 0;
-    if (n1 + n2 > P.fragCap) {
-      if (P.overflowList) {  // rare: a second launch with a large scratch takes it
-        if (tid == 0) P.overflowList[atomicAdd(&P.counters[23], 1ull)] = f;
+    if (P.only) {  // this fragment's piece of the big arena
+      const uint64_t off = P.only[2 * it + 1];
+      fragCap = off + n1 + n2 <= P.bigCap ? n1 + n2 : 0u;
+      frags = P.bigFrags + off; keep = P.bigKeep + off;
+    }
+    if (n1 + n2 > fragCap) {
+      if (P.overflowList) {  // the second launch takes it, with a scratch of its own size
+        if (tid == 0) {
+          const unsigned long long q = atomicAdd(&P.counters[23], 1ull);
+          const unsigned long long off = atomicAdd(&P.counters[24], (unsigned long long)(n1 + n2));
+          P.overflowList[2 * q] = f; P.overflowList[2 * q + 1] = (uint32_t)min(off, 0xFFFFFFFFull);
+        }
         __syncthreads();
         continue;
       }
       if (tid == 0) {
-        atomicOr(&P.counters[2], 128ull);
+        atomicOr(&P.counters[2], P.only ? 1024ull : 128ull);  // 1024: the big arena is too small (the host grows it to counters[24] and runs the call again)
         if (P.rsRowPtr) { P.rsRowCount[P.fragBase + f] = 0; P.rsAssigned[P.fragBase + f] = 0; }
         else { P.rowStart[f] = 0; P.rowCount[f] = 0; P.fragAssigned[f] = 0; }
       }
       __syncthreads();
       continue;
     }
+    if (tid == 0 && n1 + n2) atomicAdd(&P.counters[22], (unsigned long long)(n1 + n2));  // statistics: overlap records read (by the launch that pairs the fragment)
     // ---- duplicate detection + join table --------------------------------------------------------------------------
     bool lds = n1 + n2 <= LJ_CAP;
     if (lds) {
@@ -637,8 +652,9 @@ static int pairLaunch(t1k_ctx *ctx, t1k_rowset *rs, const uint32_t *end1, const 
   const int maxWg = 1024 * 256 / wgThreads;
   const int nWg = (int)std::min<uint32_t>(maxWg, std::max<uint32_t>(n, 1));
   auto launch = [&](unsigned grid, const PairArgs &args) { hipLaunchKernelGGL((k_pair<256, 4096>), dim3(grid), dim3(256), 0, ctx->stream, args); };
-  const uint32_t fragCap = 8192, bigFragCap = 1u << 17;  // overlaps of both mates a workgroup's scratch holds (first pass | second pass)
-  const int bigWg = 128;
+  static const uint32_t envFragCap = [] { const char *e = getenv("T1K_PAIR_FRAGCAP"); return e ? (uint32_t)std::max(8, atoi(e)) : 8192u; }();  // (tests: force the second launch)
+  static const uint64_t envBigCap = [] { const char *e = getenv("T1K_PAIR_BIGCAP"); return e ? (uint64_t)std::max(64, atoi(e)) : (uint64_t)(8u << 20); }();
+  const uint32_t fragCap = envFragCap;   // overlaps of both mates a workgroup's own scratch holds; longer fragments: the second launch, scratch from the big arena
   const uint32_t A = ctx->ref.nAlleles;
   if (!rs) { ctx->nFragments = n; ctx->nRows = 0; }
   if ((rc = t1k_ensure(ctx, ctx->bEnd1, (size_t)n * 4))) return rc;
@@ -653,7 +669,10 @@ static int pairLaunch(t1k_ctx *ctx, t1k_rowset *rs, const uint32_t *end1, const 
   size_t perWg = (size_t)A * 16 + (size_t)fragCap * (sizeof(Frag) + 4);
   bool fresh = ctx->bPairScratch.bytes < (size_t)maxWg * perWg;
   if ((rc = t1k_ensure(ctx, ctx->bPairScratch, (size_t)maxWg * perWg))) return rc;
-  if ((rc = t1k_ensure(ctx, ctx->bPairOverflow, (size_t)n * 4 + 16))) return rc;
+  if ((rc = t1k_ensure(ctx, ctx->bPairOverflow, (size_t)n * 8 + 16))) return rc;
+  // the big arena: 52 bytes per overlap of the fragments that go to the second launch; starts at 8 M entries, grows to the demand the device counted
+  if (ctx->pairBigCap == 0) ctx->pairBigCap = envBigCap;
+  if ((rc = t1k_ensure(ctx, ctx->bPairBig, (size_t)ctx->pairBigCap * (sizeof(Frag) + 4)))) return rc;
   if ((rc = t1k_ensure(ctx, ctx->bCounters, (size_t)T1K_COUNTER_WORDS * 8))) return rc;
   if (n == 0) return T1K_OK;
   T1K_HIP(ctx, hipMemcpyAsync(ctx->bEnd1.p, end1, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
@@ -662,7 +681,7 @@ static int pairLaunch(t1k_ctx *ctx, t1k_rowset *rs, const uint32_t *end1, const 
   else T1K_HIP(ctx, hipMemsetAsync(ctx->bHasN.p, 0, (size_t)n, ctx->stream));
   // the epoch of fragment f is epochBase + f + 1; the base moves on with every call, so the tables only need clearing when the
   // 32-bit epoch space is about to wrap (or the scratch was just allocated)
-  if (fresh || ctx->pairEpoch > 0xFFFFFFFFull - 2ull * n - 2) {
+  if (fresh || ctx->pairEpoch > 0xFFFFFFFFull - 12ull * n - 2) {
     T1K_HIP(ctx, hipMemsetAsync(ctx->bPairScratch.p, 0, (size_t)maxWg * (size_t)A * 16, ctx->stream));
     ctx->pairEpoch = 0;
   }
@@ -687,7 +706,7 @@ static int pairLaunch(t1k_ctx *ctx, t1k_rowset *rs, const uint32_t *end1, const 
   for (int attempt = 0;; ++attempt) {
     T1K_HIP(ctx, hipMemsetAsync((char *)ctx->bCounters.p + 2 * 8, 0, 8, ctx->stream));
     T1K_HIP(ctx, hipMemsetAsync((char *)ctx->bCounters.p + 9 * 8, 0, 8, ctx->stream));
-    T1K_HIP(ctx, hipMemsetAsync((char *)ctx->bCounters.p + 22 * 8, 0, 16, ctx->stream));
+    T1K_HIP(ctx, hipMemsetAsync((char *)ctx->bCounters.p + 22 * 8, 0, 24, ctx->stream));
     size_t chunk = 0;
     if (rs) {
       if ((rc = t1k_rowset_chunk(rs, ctx, &chunk, &p.rsRows, &p.rsCap, &p.rsCursor))) return rc;
@@ -695,29 +714,33 @@ static int pairLaunch(t1k_ctx *ctx, t1k_rowset *rs, const uint32_t *end1, const 
       p.rsRowPtr = rs->rowPtr; p.rsRowCount = rs->rowCount; p.rsH1 = rs->h1; p.rsH2 = rs->h2; p.rsAssigned = rs->assigned; p.fragBase = fragBase;
     }
     p.epochBase = (uint32_t)ctx->pairEpoch; ctx->pairEpoch += n;
+    p.only = nullptr; p.overflowList = (uint32_t *)ctx->bPairOverflow.p;
     T1K_HIP(ctx, hipEventRecord(ctx->ev[5], ctx->stream));
     launch((unsigned)nWg, p);
+    {
+      // second launch, always: the fragments whose lists exceed the first pass's scratch (with 29 k alleles the large genes put whole classes
+      // of fragments here).  Their number is on the device (counters[23]); the workgroups beyond it leave at once.  Same per-workgroup
+      // allele tables as the first launch (the kernels run one after the other on this stream), fresh epochs.
+      PairArgs q = p;
+      q.only = (const uint32_t *)ctx->bPairOverflow.p; q.overflowList = nullptr;
+      q.bigFrags = (Frag *)ctx->bPairBig.p; q.bigKeep = (uint32_t *)((char *)ctx->bPairBig.p + (size_t)ctx->pairBigCap * sizeof(Frag)); q.bigCap = ctx->pairBigCap;
+      q.epochBase = (uint32_t)ctx->pairEpoch; ctx->pairEpoch += n;
+      launch((unsigned)nWg, q);
+    }
     T1K_HIP(ctx, hipEventRecord(ctx->ev[6], ctx->stream));
     if (!ctx->countersPinned) T1K_HIP(ctx, hipHostMalloc((void **)&ctx->countersPinned, (size_t)T1K_COUNTER_WORDS * 8, hipHostMallocDefault));
     T1K_HIP(ctx, hipMemcpyAsync(ctx->countersPinned, ctx->bCounters.p, 64 * 8, hipMemcpyDeviceToHost, ctx->stream));
     T1K_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (const uint32_t nOver = (uint32_t)ctx->countersPinned[23]) {
-      // fragments whose two lists exceed the first pass's per-workgroup scratch: a few workgroups with a scratch for 2^17 overlaps each
-      const size_t perBig = (size_t)A * 16 + (size_t)bigFragCap * (sizeof(Frag) + 4);
-      if ((rc = t1k_ensure(ctx, ctx->bPairBig, (size_t)bigWg * perBig))) return rc;
-      T1K_HIP(ctx, hipMemsetAsync(ctx->bPairBig.p, 0, (size_t)bigWg * (size_t)A * 16, ctx->stream));
-      PairArgs q = p;
-      uint8_t *bs = (uint8_t *)ctx->bPairBig.p;
-      q.tab2 = (uint64_t *)bs; q.tabSlot = (uint64_t *)(bs + (size_t)bigWg * A * 8);
-      q.frags = (Frag *)(bs + (size_t)bigWg * A * 16); q.fragCap = bigFragCap;
-      q.keep = (uint32_t *)(bs + (size_t)bigWg * A * 16 + (size_t)bigWg * bigFragCap * sizeof(Frag));
-      q.only = (const uint32_t *)ctx->bPairOverflow.p; q.nOnly = nOver; q.overflowList = nullptr; q.epochBase = 0;
-      launch(std::min<uint32_t>(nOver, bigWg), q);
-      T1K_HIP(ctx, hipMemcpyAsync(ctx->countersPinned, ctx->bCounters.p, 64 * 8, hipMemcpyDeviceToHost, ctx->stream));
-      T1K_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    }
     unsigned long long *hc = ctx->countersPinned;
     { float ms = 0; (void)hipEventElapsedTime(&ms, ctx->ev[5], ctx->ev[6]); ctx->stats.ms_pair = (attempt ? ctx->stats.ms_pair : 0) + ms; }
+    if ((hc[2] & 1024ull) && attempt < 4) {
+      // the big arena was too small for this call's long fragments: the device counted the demand (counters[24]); fragments are written
+      // by index, so the call simply runs again (the rows of the first attempt are left behind in the rowset's chunk)
+      ctx->pairBigCap = (uint64_t)((double)hc[24] * 1.25) + (getenv("T1K_PAIR_BIGCAP") ? 16 : (1u << 20));
+      if ((rc = t1k_ensure(ctx, ctx->bPairBig, (size_t)ctx->pairBigCap * (sizeof(Frag) + 4)))) return rc;
+      if (getenv("T1K_DEBUG_TRACE")) fprintf(stderr, "[t1k trace] pair: big arena grows to %llu entries\n", (unsigned long long)ctx->pairBigCap);
+      if (!rs || !(hc[2] & ~1024ull)) continue;
+    }
     if (hc[2] && rs && attempt < 4) {
       // the rowset's current chunk is full (or a fragment has more overlaps than the scratch holds: that repeats and fails below):
       // close the chunk and run the call again; fragments are written by index, the first attempt's rows are simply left behind

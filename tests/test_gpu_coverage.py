@@ -91,6 +91,13 @@ MODES = {
     # every group of at least 34 fragments through the four-wavefront fold of the large groups (k_co_reduce_long; 4096 by default)
     "long_group_fold": {"T1K_CO_LONG_RUN": "34"},
     "long_group_fold_two_ranks": {"T1K_CO_LONG_RUN": "40", "T1K_GPUS": "0,0"},
+    # no device-memory pool: a freed block goes back to the driver at once, so a kept window's list table that points into an EARLIER
+    # window's overlap-store chunks (identical read-ends linked across windows) faults or reads garbage if that window's read set was
+    # released before the later one is scanned (every kept set stays alive until all are scanned)
+    "no_pool_small_windows": {"T1K_POOL_GB": "0", "T1K_FIRST_WINDOW": "24", "T1K_WINDOW": "96", "T1K_BATCH": "16", "T1K_PAIR_BATCH": "32", "T1K_COVER_BATCH": "64"},
+    # k_pair: every fragment with more than 16 overlaps goes to the second launch (scratch from the big arena), whose 64 entries force the
+    # "arena grows to the demand the device counted, the call runs again" path
+    "pair_second_launch_arena_growth": {"T1K_PAIR_FRAGCAP": "16", "T1K_PAIR_BIGCAP": "64", "T1K_PAIR_BATCH": "32"},
     "two_ranks": {"T1K_GPUS": "0,0"},
     "three_ranks_small_windows": {"T1K_GPUS": "0,0,0", "T1K_FIRST_WINDOW": "16", "T1K_WINDOW": "48", "T1K_BATCH": "16"},
 }

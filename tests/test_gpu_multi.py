@@ -49,6 +49,19 @@ def test_two_gpus_over_rccl_equal_the_goldens(built, tmp_path, name, own_input):
         assert open(out + suf, "rb").read() == open(one + suf, "rb").read(), suf
 
 
+def test_two_gpus_em_allreduce_over_rccl_within_tolerance(built, tmp_path):
+    """T1K_EM_COLLECTIVE=allreduce over RCCL (ncclAllReduce of E doubles per EM update): same calls, abundances within 1e-4 relative"""
+    need_devices(2)
+    c = goldens.Case("hla_synth_2x150", str(tmp_path))
+    out = os.path.join(str(tmp_path), "two")
+    r = subprocess.run([GENO] + c.args() + ["-o", out], stderr=subprocess.PIPE, text=True, env=dict(os.environ, T1K_GPUS="0,1", T1K_EM_COLLECTIVE="allreduce"), timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    for g, w in zip(open(out + "_genotype.tsv").read().splitlines(), c.expected("genotype.tsv").splitlines()):
+        for x, y in zip(g.split("\t"), w.split("\t")):
+            if x != y:
+                assert abs(float(x) - float(y)) <= 1e-4 * max(abs(float(x)), abs(float(y))), (g, w)
+
+
 def test_communicator_is_rccl_across_devices(built):
     need_devices(2)
     import threading

@@ -271,6 +271,43 @@ def test_sharded_job_equals_single_gpu_job(built, tmp_path, name, gpus):
     assert int(m.group(1)) == c.meta["assigned_fragments"] and m.group(2) == c.meta["avg_alleles"]
 
 
+@pytest.mark.parametrize("name", ["hla_synth_2x150", "cyp_dna_relax_2x150", "kir_synth_relax_2x150"])
+@pytest.mark.parametrize("gpus", ["0,0", "0,0,0"])
+def test_em_allreduce_collective_within_tolerance_of_exact_mode(built, tmp_path, name, gpus):
+    """T1K_EM_COLLECTIVE=allreduce (opt-in): every rank sums its own read groups' contributions per class and the E partial sums are
+    all-reduced (the collective BASELINE.json's north_star names: E doubles per EM update, Genotyper.hpp:372-421) instead of the
+    bit-exact gather of the nnz-sized contribution array.  The re-associated sums may move low bits, so the stated tolerance applies:
+    identical allele calls and qualities, abundances within 1e-4 relative of the reference's (= the exact mode's) golden output,
+    the same number of EM iterations."""
+    c = goldens.Case(name, str(tmp_path))
+    out = os.path.join(str(tmp_path), "reduce")
+    env = dict(os.environ, T1K_GPUS=gpus, T1K_EM_COLLECTIVE="allreduce")
+    r = subprocess.run([GENO] + c.args() + ["-o", out], stderr=subprocess.PIPE, text=True, env=env)
+    assert r.returncode == 0, r.stderr
+
+    def close(a, b):
+        if len(a) != len(b):
+            return False
+        for x, y in zip(a, b):
+            if x == y:
+                continue
+            try:
+                fx, fy = float(x), float(y)
+            except ValueError:
+                return False
+            if abs(fx - fy) > 1e-4 * max(abs(fx), abs(fy)):   # north_star: abundances within 1e-4 relative
+                return False
+        return True
+
+    for suf, key in (("_genotype.tsv", "genotype.tsv"), ("_allele.tsv", "allele.tsv")):
+        got, want = open(out + suf).read().splitlines(), c.expected(key).splitlines()
+        assert len(got) == len(want), suf
+        for g, w in zip(got, want):
+            assert close(g.split("\t"), w.split("\t")), (suf, g, w)
+    m = re.search(r"in (\d+) EM iterations", r.stderr)
+    assert int(m.group(1)) == c.meta["em_iterations"]
+
+
 def test_rccl_single_rank_communicator(built, tmp_path):
     """the RCCL transport itself (librccl bound lazily, ncclCommInitRank, all-reduce / send-recv / broadcast groups) with one rank:
     the job must run through every collective and give the single-GPU result"""
