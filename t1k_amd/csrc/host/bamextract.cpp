@@ -54,7 +54,8 @@ const char kUsage[] =
     "\t-u: the flag or order of unaligned read-pair is not ordinary (default: not used)\n"
     "\t--barcode STRING: the barcode field in the bam file (default: not used)\n"
     "\t--UMI STRING: the UMI field in the bam file (default: not used)\n"
-    "\t--mateIdSuffixLen INT: the suffix length in read id for mate. (default: not used)\n";
+    "\t--mateIdSuffixLen INT: the suffix length in read id for mate. (default: not used)\n"
+    "(this build: reads of up to 1000 bases; a longer read on an alternative contig / unaligned is not tested and not kept, with a warning)\n";
 
 // ---- BGZF: the file is a series of gzip members of at most 64 KiB of data each, their compressed size in a "BC" extra field ----------
 struct BamFile {
@@ -94,8 +95,10 @@ struct BamFile {
       if (size - pos < 28 || map[pos] != 31 || map[pos + 1] != 139 || map[pos + 2] != 8 || !(map[pos + 3] & 4)) { err = "not a BGZF (BAM) file"; return false; }
       const size_t xlen = map[pos + 10] | (map[pos + 11] << 8);
       size_t bsize = 0;
+      if (pos + 12 + xlen > size) { err = "damaged BGZF block"; return false; }  // (the extra field itself must lie inside the file)
       for (size_t x = pos + 12; x + 4 <= pos + 12 + xlen;) {
         const size_t slen = map[x + 2] | (map[x + 3] << 8);
+        if (x + 4 + slen > pos + 12 + xlen) break;  // a subfield that runs past the extra field: damaged, no BC found -> reported below
         if (map[x] == 'B' && map[x + 1] == 'C' && slen == 2) bsize = (size_t)(map[x + 4] | (map[x + 5] << 8)) + 1;
         x += 4 + slen;
       }
@@ -258,6 +261,9 @@ bool nextRecord(BamFile &bam, Rec &r) {
   p = bam.take(n);
   if (!p) { if (bam.err.empty()) bam.err = "truncated BAM file"; return false; }
   r.d = p; r.len = n;
+  // the lengths inside the record must fit the record: name, CIGAR, 4-bit sequence and qualities are read through them
+  const int64_t lSeq = r.lSeq();
+  if (lSeq < 0 || r.lName() < 1 || 32 + (uint64_t)r.lName() + 4ull * r.nCigar() + ((uint64_t)lSeq + 1) / 2 + (uint64_t)lSeq > (uint64_t)n) { bam.err = "damaged BAM record"; return false; }
   return true;
 }
 
@@ -417,7 +423,13 @@ extern "C" int t1k_bam_extractor_main(int argc, char **argv) {
   std::unordered_set<std::string> candidates;          // paired data: template names to collect in the second pass
   std::unordered_set<std::string> usedName;            // single-end data: aligned reads already written
   uint64_t nTested = 0, nKept = 0;
-  auto addTest = [&](const std::string &s) { batchSeq += s; batchOff.push_back(batchSeq.size()); return (int)batchOff.size() - 2; };
+  // a read beyond the device stage's length limit is asked about as an EMPTY sequence (never a candidate) and counted: the run goes on
+  // (the reference has no limit and would test it; a read-length estimate above the limit was refused before the first record)
+  uint64_t nOverLong = 0;
+  auto addTest = [&](const std::string &s) {
+    if (s.size() > (size_t)T1K_BAM_MAX_READ) { ++nOverLong; batchOff.push_back(batchSeq.size()); return (int)batchOff.size() - 2; }
+    batchSeq += s; batchOff.push_back(batchSeq.size()); return (int)batchOff.size() - 2;
+  };
   auto tags = [&](const Rec &r, Event &e) {
     if (!bcField.empty()) { const char *v = r.fieldZ(bcField.c_str()); e.hasBc = v != nullptr; if (v) e.bc = v; }
     if (!umiField.empty()) { const char *v = r.fieldZ(umiField.c_str()); e.hasUmi = v != nullptr; if (v) e.umi = v; }
@@ -553,6 +565,7 @@ extern "C" int t1k_bam_extractor_main(int argc, char **argv) {
     if (!flush()) { closeAll(true); return EXIT_FAILURE; }
   }
   if (!paired) {
+    if (nOverLong) fprintf(stderr, "bam-extractor: WARNING: %llu read(s) longer than %d bases were not tested against the reference sequences and not kept (the reference bam-extractor has no such limit)\n", (unsigned long long)nOverLong, T1K_BAM_MAX_READ);
     if (getenv("T1K_DEBUG_PHASES")) fprintf(stderr, "[t1k] bam-extractor: k=%d hitLenRequired=%d reads tested on the GPU %llu, kept %llu\n", kmerLength, hitLenRequired, (unsigned long long)nTested, (unsigned long long)nKept);
     closeAll(false);
     logLine("Finish extracting reads.");
@@ -591,6 +604,7 @@ extern "C" int t1k_bam_extractor_main(int argc, char **argv) {
     }
     if (!bam.err.empty()) { fprintf(stderr, "bam-extractor: %s\n", bam.err.c_str()); closeAll(true); return EXIT_FAILURE; }
   }
+  if (nOverLong) fprintf(stderr, "bam-extractor: WARNING: %llu read(s) longer than %d bases were not tested against the reference sequences and not kept (the reference bam-extractor has no such limit)\n", (unsigned long long)nOverLong, T1K_BAM_MAX_READ);
   if (getenv("T1K_DEBUG_PHASES")) fprintf(stderr, "[t1k] bam-extractor: k=%d hitLenRequired=%d reads tested on the GPU %llu, templates kept %llu\n", kmerLength, hitLenRequired, (unsigned long long)nTested, (unsigned long long)nKept);
   closeAll(false);
   logLine("Finish extracting reads.");

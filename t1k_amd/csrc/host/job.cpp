@@ -188,7 +188,42 @@ void t1k_job_destroy(t1k_job *job) {
   // (... and not right away: unmapping hundreds of MB holds the process's memory-map lock, and a caller that creates its next job at once
   // -- the benchmark's steps, a service -- had its reference parse slowed from 55 to 130 ms by the allocations waiting for that lock; half
   // a second later the next job's host threads are waiting for the GPU)
-  std::thread([job] { std::this_thread::sleep_for(std::chrono::milliseconds(500)); delete job; }).detach();
+  // The deferred releases are known to the process: at exit the ones still waiting are dropped (the process's memory goes back to the
+  // system anyway) and one that is in the middle of its delete is waited for, so no thread frees containers while the static
+  // destructors run.
+  struct Deferred {
+    std::mutex m;
+    std::condition_variable cv;
+    int pending = 0;       // threads started and not finished
+    bool exiting = false;
+    static Deferred &get() {
+      static Deferred *d = [] {
+        Deferred *x = new Deferred();  // never destroyed: threads may outlive the static destructors' turn
+        atexit([] {
+          Deferred &q = Deferred::get();
+          std::unique_lock<std::mutex> lk(q.m);
+          q.exiting = true;
+          q.cv.notify_all();
+          q.cv.wait_for(lk, std::chrono::seconds(10), [&] { return q.pending == 0; });
+        });
+        return x;
+      }();
+      return *d;
+    }
+  };
+  Deferred &d = Deferred::get();
+  { std::lock_guard<std::mutex> g(d.m); ++d.pending; }
+  std::thread([job, &d] {
+    bool drop;
+    {
+      std::unique_lock<std::mutex> lk(d.m);
+      d.cv.wait_for(lk, std::chrono::milliseconds(500), [&] { return d.exiting; });
+      drop = d.exiting;
+    }
+    if (!drop) delete job;  // (at exit the job is left to the process teardown)
+    { std::lock_guard<std::mutex> g(d.m); --d.pending; }
+    d.cv.notify_all();
+  }).detach();
 }
 
 const char *t1k_job_last_error(const t1k_job *job) { return job ? job->err.c_str() : "no job"; }
@@ -864,7 +899,9 @@ int t1k_job_run_local(t1k_job *job) {
   // order; the owners' tables are gathered on every rank and merged by first fragment (= first-appearance numbering).
   uint64_t G = 0, N = 0, assigned = 0;
   static_assert(sizeof(GroupEntry) == sizeof(t1k_group_entry), "group entry layouts differ");
+  const double tEx0 = nowMs();
   if (sharded && (rc = t1k_rowset_exchange(job->rows, job->comm, fBeg)) != T1K_OK) return jobFail(job, rc, t1k_rowset_last_error(job->rows));
+  const double tEx1 = nowMs();
   if ((rc = t1k_rowset_coalesce(job->rows, &G, &N, &assigned)) != T1K_OK) return jobFail(job, rc, t1k_rowset_last_error(job->rows));
   const double tCo = nowMs();
   if (!sharded) {
@@ -886,6 +923,7 @@ int t1k_job_run_local(t1k_job *job) {
       fprintf(stderr, "[t1k job] after the loop: coverage of the pipelines + coalescing on the device %.1f ms, host tables sized %.1f ms, groups downloaded %.1f ms, flags %.1f ms\n",
               tCo - tDev, tRes - tCo, tDl - tRes, nowMs() - tDl);
   } else {
+    const uint64_t Gl = G, Nl = N;
     if ((rc = t1k_rowset_groups_gather(job->rows, job->comm, &G, &N, &assigned)) != T1K_OK) return jobFail(job, rc, t1k_rowset_last_error(job->rows));
     std::vector<uint32_t> sizes(G), first(G);
     GroupVec ents;
@@ -897,7 +935,13 @@ int t1k_job_run_local(t1k_job *job) {
     });
     if ((rc = t1k_rowset_groups_download_all(job->rows, sizes.data(), (t1k_group_entry *)ents.data(), first.data())) != T1K_OK)
       return jobFail(job, rc, t1k_rowset_last_error(job->rows));
+    const double tGa = nowMs();
     gt.setGroupsMerged(sizes, ents, first);
+    if (getenv("T1K_DEBUG_PHASES"))
+      fprintf(stderr, "[t1k job] rank %d of %d after the loop (waits for the slowest rank included): rows to their pattern owners %.1f ms, coalescing of the owned patterns %.1f ms "
+                      "(%llu groups, %llu entries on this rank), group tables gathered + downloaded %.1f ms (%llu groups, %llu entries in all), merged by first fragment %.1f ms\n",
+              job->rank, job->nRanks, tEx1 - tEx0, tCo - tEx1, (unsigned long long)Gl, (unsigned long long)Nl, tGa - tCo,
+              (unsigned long long)G, (unsigned long long)N, nowMs() - tGa);
     // fragmentAssigned of every rank's slice on every rank (rank 0 writes the *_aligned*.fa files)
     if ((rc = t1k_rowset_assigned_download(job->rows, job->fragAssigned.data() + fBeg)) != T1K_OK) return jobFail(job, rc, t1k_rowset_last_error(job->rows));
     if (!in.sharded) {  // (ranks that indexed only their own reads write only their own part of the files)

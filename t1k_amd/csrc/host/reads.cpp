@@ -7,6 +7,7 @@
 // indexer accepts the two layouts the pipeline produces (four-line FASTQ, two-line FASTA; LF or CRLF); anything else -- wrapped
 // sequences, blank lines -- goes through the general record reader (readSeqFile, the kseq rules) into owned storage.
 // Several files per mate are read back to back, as ReadFiles does with currentFpInd.
+#include <dlfcn.h>
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -245,6 +246,72 @@ bool ReadInput::bgzfInflate(int fd, size_t fileSize, int threads, Blob &blob, co
   return ok;
 }
 
+// An ordinary gzip file is one dependent stream: nothing inflates it block-parallel.  What can be had is a faster inflater and no
+// copies: the compressed file is mapped, the text goes straight into one reserved range of anonymous memory (only the pages that are
+// written get backed), member after member (concatenated .gz files are legal), through libdeflate's whole-buffer decoder -- 2 - 3 x
+// zlib's inflate on FASTQ text -- which this image ships as a runtime library (libdeflate.so.0, bound lazily like librccl; no header is
+// needed for three entry points).  False = not available / the text does not fit the reservation / damaged: the caller goes through
+// gzread, which also reports real damage.  (The reference reads the same files through gzopen + kseq, ReadFiles.hpp:23-282.)
+namespace {
+struct Deflate {
+  void *(*alloc)() = nullptr;
+  int (*gunzip)(void *, const void *, size_t, void *, size_t, size_t *, size_t *) = nullptr;
+  void (*release)(void *) = nullptr;
+  static const Deflate *get() {
+    static const Deflate d = [] {
+      Deflate x;
+      if (getenv("T1K_NO_LIBDEFLATE")) return x;
+      void *h = dlopen("libdeflate.so.0", RTLD_NOW | RTLD_LOCAL);
+      if (!h) return x;
+      x.alloc = (decltype(x.alloc))dlsym(h, "libdeflate_alloc_decompressor");
+      x.gunzip = (decltype(x.gunzip))dlsym(h, "libdeflate_gzip_decompress_ex");
+      x.release = (decltype(x.release))dlsym(h, "libdeflate_free_decompressor");
+      if (!x.alloc || !x.gunzip || !x.release) x = Deflate();
+      return x;
+    }();
+    return d.gunzip ? &d : nullptr;
+  }
+};
+}  // namespace
+
+bool ReadInput::gzipInflate(int fd, size_t fileSize, Blob &blob, const char *&data, size_t &size) {
+  const Deflate *z = Deflate::get();
+  if (!z || fileSize < 18) return false;
+  void *m = mmap(nullptr, fileSize, PROT_READ, MAP_PRIVATE, fd, 0);
+  if (m == MAP_FAILED) return false;
+  (void)madvise(m, fileSize, MADV_SEQUENTIAL);
+  // room for the text: 48 x the compressed size (FASTQ deflates 3 - 6 x; a file that beats 48 x takes the gzread path), address space only
+  const size_t cap = ((fileSize * 48 + (64u << 20)) + 4095) & ~(size_t)4095;
+  void *out = mmap(nullptr, cap, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+  if (out == MAP_FAILED) { munmap(m, fileSize); return false; }
+  void *d = z->alloc();
+  bool ok = d != nullptr;
+  size_t in = 0, used = 0;
+  const uint8_t *src = (const uint8_t *)m;
+  while (ok && in < fileSize) {
+    if (fileSize - in < 18 || src[in] != 0x1f || src[in + 1] != 0x8b) {  // trailing garbage after the last member: gzread decides what it means
+      bool zeros = true;
+      for (size_t i = in; i < fileSize && zeros; ++i) zeros = src[i] == 0;  // (zero padding is legal and ignored, as gzip does)
+      ok = zeros;
+      break;
+    }
+    size_t ate = 0, made = 0;
+    const int r = z->gunzip(d, src + in, fileSize - in, (char *)out + used, cap - used, &ate, &made);
+    if (r != 0 || ate == 0) { ok = false; break; }
+    in += ate; used += made;
+  }
+  if (d) z->release(d);
+  munmap(m, fileSize);
+  if (!ok) { munmap(out, cap); return false; }
+  // give the unused tail of the reservation back; the blob owns the rest like a mapped file
+  const size_t keep = std::max<size_t>(4096, (used + 4095) & ~(size_t)4095);
+  if (keep < cap) munmap((char *)out + keep, cap - keep);
+  blob.map = out; blob.len = keep; blob.anon = true;
+  data = (const char *)out; size = used;
+  if (getenv("T1K_DEBUG_PHASES")) fprintf(stderr, "[t1k job] gzip read file: %zu -> %zu bytes through libdeflate\n", fileSize, used);
+  return true;
+}
+
 bool ReadInput::addFile(const std::string &path, int threads, Side &dst, std::string &err) {
   int fd = ::open(path.c_str(), O_RDONLY);
   if (fd < 0) { err = "cannot open " + path; return false; }
@@ -265,6 +332,9 @@ bool ReadInput::addFile(const std::string &path, int threads, Side &dst, std::st
     data = (const char *)m; size = (size_t)st.st_size;
   } else if (gz && S_ISREG(st.st_mode) && bgzfInflate(fd, (size_t)st.st_size, threads, newBlob(), data, size)) {
     // (a bgzip-framed file: its 64 KiB blocks were inflated side by side by the host threads)
+    ::close(fd);
+  } else if (gz && S_ISREG(st.st_mode) && gzipInflate(fd, (size_t)st.st_size, newBlob(), data, size)) {
+    // (ordinary gzip: one stream, inflated by libdeflate straight into reserved memory)
     ::close(fd);
   } else {
     ::close(fd);
@@ -500,7 +570,7 @@ void ReadInput::release(size_t recLo, size_t recHi) {
     };
     const char *first = sd->idP[recLo], *last = sd->idP[recHi - 1];
     const Blob *b0 = blobOf(first), *b1 = blobOf(last);
-    if (!b0 || !b1) continue;  // owned storage (gz, general reader)
+    if (!b0 || !b1 || b0->anon || b1->anon) continue;  // owned storage (gz, general reader): a rerun of the job reads the text again, and dropped anonymous pages come back as zeros
     const char *end1 = recHi < sd->idP.size() && blobOf(sd->idP[recHi]) == b1 ? sd->idP[recHi] - 1 : (const char *)b1->map + b1->len;
     if (b0 == b1) drop(first - 1, end1);
     else { drop(first - 1, (const char *)b0->map + b0->len); drop((const char *)b1->map, end1); }  // (files wholly inside the range wait for the unmapping)

@@ -70,6 +70,7 @@ struct ReadInput {
   struct Blob {
     void *map = nullptr;
     size_t len = 0;
+    bool anon = false;  // map is anonymous memory (inflated text), not a file: its pages cannot be dropped and read again
     std::unique_ptr<std::vector<char>> owned;
   };
   std::list<Blob> blobs_;  // the mates are read by concurrent threads: nodes never move, additions are serialised
@@ -77,6 +78,7 @@ struct ReadInput {
   Blob &newBlob() { std::lock_guard<std::mutex> g(blobLock_); blobs_.emplace_back(); return blobs_.back(); }
   bool addFile(const std::string &path, int threads, Side &dst, std::string &err);
   static bool bgzfInflate(int fd, size_t fileSize, int threads, Blob &blob, const char *&data, size_t &size);
+  static bool gzipInflate(int fd, size_t fileSize, Blob &blob, const char *&data, size_t &size);
   bool addBuffer(const char *p, size_t n, int threads, Side &dst, std::string &err, const std::string &what);
   bool addRange(const char *b, const char *stop, const char *end, bool fastq, int threads, Side &dst);
   uint32_t nAll_ = 0;

@@ -274,6 +274,10 @@ __device__ inline int groupFastPath(const uint32_t *Mw, int diag, const ReadCtx 
       pos = ge;
     }
     const int upper = 2 * (span - sumSmall - nBig);
+#ifdef T1K_WALK_STATS
+    { const int cls = nBig == 0 ? 0 : ((double)upper / (double)(2 * span) < simThreshold) ? 1 : 2;
+      for (int c = 0; c < 3; ++c) { const unsigned long long mk = __ballot(cls == c); if (mk && (int)(threadIdx.x & 63) == __ffsll((long long)mk) - 1) atomicAdd(&sink.counters[40 + c], (unsigned long long)__popcll(mk)); } }
+#endif
     if (nBig == 0) matchCnt = upper;  // exact
     else if ((double)upper / (double)(2 * span) < simThreshold) matchCnt = upper;  // certain to be dropped; no DP needed
     else {
@@ -439,7 +443,10 @@ __device__ __forceinline__ bool recIsGeneral(uint32_t w2) { return ((w2 >> 27) &
 #define DIAG_EMPTY 0x7FFFFFFF
 
 template <int NW>
-__global__ __launch_bounds__(WG) T1K_OCC8 void k_seed_groups(ChainArgs P) {
+#ifndef T1K_SEED_WAVES
+#define T1K_SEED_WAVES 8
+#endif
+__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(T1K_SEED_WAVES, T1K_SEED_WAVES))) void k_seed_groups(ChainArgs P) {
   constexpr int AW = NW == 5 ? 7 : 13;  // u32 per accumulator: diag, meta, M[NW]; odd stride = no LDS bank conflicts
   extern __shared__ uint32_t lds[];
   const int k = P.k;
@@ -475,7 +482,8 @@ __global__ __launch_bounds__(WG) T1K_OCC8 void k_seed_groups(ChainArgs P) {
 #ifdef T1K_SEED_PROFILE
   uint64_t tp_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tl_ = __builtin_amdgcn_s_memtime();
 #endif
-  unsigned long long statLookups = 0, statPostings = 0, statHits = 0;  // thread 0 tallies, flushed once per workgroup
+  __shared__ unsigned long long sStat[3];             // lookups, postings, hits: thread 0 tallies them in LDS (three 64-bit counters in registers would be held by every lane), flushed once per workgroup
+  if (tid == 0) { sStat[0] = 0; sStat[1] = 0; sStat[2] = 0; }
   for (uint32_t re = blockIdx.x; re < P.reads.nReadEnds; re += gridDim.x) {
     const int len = P.reads.len[re];
     const int S = P.reads.S;
@@ -562,7 +570,7 @@ __global__ __launch_bounds__(WG) T1K_OCC8 void k_seed_groups(ChainArgs P) {
       __syncthreads();
       if (tid == 0) {
         sUsed[1] = tot - sUsed[0];
-        statLookups += 2 * nk; statPostings += sPost;
+        sStat[0] += 2 * nk; sStat[1] += sPost;
         P.usedCount[2 * re] = sUsed[0]; P.usedCount[2 * re + 1] = sUsed[1];
       }
     }
@@ -600,7 +608,7 @@ __global__ __launch_bounds__(WG) T1K_OCC8 void k_seed_groups(ChainArgs P) {
         if (tid == 0) sUsed[pass] = nUsed - begin;
       }
       if (tid == 0) {
-        statLookups += lookups; statPostings += postings;
+        sStat[0] += lookups; sStat[1] += postings;
         P.usedCount[2 * re] = sUsed[0]; P.usedCount[2 * re + 1] = sUsed[1];
       }
     }
@@ -635,7 +643,6 @@ __global__ __launch_bounds__(WG) T1K_OCC8 void k_seed_groups(ChainArgs P) {
     { const uint64_t tn_ = __builtin_amdgcn_s_memtime(); tp_[2] += tn_ - tl_; tl_ = tn_; }
 #endif
     int chunk = 0;
-    unsigned long long hitsLocal = 0;
     for (int sp = 0; sp < 2; ++sp) {  // '-' strand first (SortHits 1577-1583)
       const int pass = sp == 0 ? 1 : 0;
       const uint32_t uBegin = pass == 0 ? 0 : nUsedPlus;
@@ -643,11 +650,7 @@ __global__ __launch_bounds__(WG) T1K_OCC8 void k_seed_groups(ChainArgs P) {
       if (uCount == 0) continue;
       // thread t owns the lists t and t + WG (uCount <= 2 * WG: reads are at most 320 bp)
       const bool has0 = (uint32_t)tid < uCount, has1 = (uint32_t)tid + WG < uCount;
-      uint32_t st0 = 0, ln0 = 0, st1 = 0, ln1 = 0, cur0 = 0, cur1 = 0;
-      const uint32_t *dir0 = nullptr, *dir1 = nullptr;  // chunk-directory rows of this lane's lists (long lists only)
-      uint32_t row0 = T1K_NO_DIR, row1 = T1K_NO_DIR;
-      if (has0) { st0 = lstStart[uBegin + tid]; ln0 = lstLen[uBegin + tid]; row0 = lstDir[uBegin + tid]; if (row0 != T1K_NO_DIR) dir0 = P.ref.kDir + (uint64_t)row0 * P.ref.kDirStride; }
-      if (has1) { st1 = lstStart[uBegin + tid + WG]; ln1 = lstLen[uBegin + tid + WG]; row1 = lstDir[uBegin + tid + WG]; if (row1 != T1K_NO_DIR) dir1 = P.ref.kDir + (uint64_t)row1 * P.ref.kDirStride; }
+      uint32_t cur0 = 0, cur1 = 0;
       // ---- which chunks can hold a group at all.  A group needs >= 3 hits on its allele.  The k-mers of a read that are not part of
       // a gene's conserved sequence have short lists (a handful of chance postings anywhere in the reference), and there are enough of
       // them to put a posting or two into EVERY chunk: stepping through all chunks for them was most of this kernel's time.  So: a
@@ -690,8 +693,8 @@ __global__ __launch_bounds__(WG) T1K_OCC8 void k_seed_groups(ChainArgs P) {
             if (nChunks > 64) mk = ~0ull;
           }
         };
-        mark(has0, st0, ln0, row0, mk0);
-        mark(has1, st1, ln1, row1, mk1);
+        mark(has0, has0 ? lstStart[uBegin + tid] : 0u, has0 ? lstLen[uBegin + tid] : 0u, has0 ? lstDir[uBegin + tid] : T1K_NO_DIR, mk0);
+        mark(has1, has1 ? lstStart[uBegin + tid + WG] : 0u, has1 ? lstLen[uBegin + tid + WG] : 0u, has1 ? lstDir[uBegin + tid + WG] : T1K_NO_DIR, mk1);
         __syncthreads();
         if (bitmaps == acc) {  // the bitmaps lay over the accumulators: make those clean again
           for (uint32_t i = tid; i < 2 * BW; i += WG) acc[i] = (i % AW) == 0 ? (uint32_t)DIAG_EMPTY : 0u;
@@ -716,21 +719,25 @@ __global__ __launch_bounds__(WG) T1K_OCC8 void k_seed_groups(ChainArgs P) {
 #endif
         // slice of every used list inside [c0, c1): long lists from their directory row, short ones by bisection from their cursor
         // (the chunks come in ascending order, so the cursor only moves forward); lists without a posting here are not touched
+        // (a lane's list start / length / directory row are read back from LDS where they are needed: held in registers across the
+        // chunk loop they were spilled to scratch under the 64-VGPR budget)
         uint32_t n0 = 0, n1 = 0;
         const bool may = ci >= 64;
         if (has0) {
           uint32_t lo = cur0, hi = cur0;
-          if (ln0 && (may || ((mk0 >> ci) & 1ull))) {
-            if (dir0) { lo = dir0[ci]; hi = dir0[ci + 1]; }
-            else { lo = lowerBound(st0, cur0, ln0, c0); hi = lowerBound(st0, lo, ln0, c1); }
+          if (may || ((mk0 >> ci) & 1ull)) {
+            const uint32_t row = lstDir[uBegin + tid];
+            if (row != T1K_NO_DIR) { const uint32_t *dir = P.ref.kDir + (uint64_t)row * P.ref.kDirStride; lo = dir[ci]; hi = dir[ci + 1]; }
+            else { const uint32_t st = lstStart[uBegin + tid], ln = lstLen[uBegin + tid]; lo = lowerBound(st, cur0, ln, c0); hi = lowerBound(st, lo, ln, c1); }
           }
           n0 = hi - lo; sLo[tid] = lo; cur0 = hi;
         }
         if (has1) {
           uint32_t lo = cur1, hi = cur1;
-          if (ln1 && (may || ((mk1 >> ci) & 1ull))) {
-            if (dir1) { lo = dir1[ci]; hi = dir1[ci + 1]; }
-            else { lo = lowerBound(st1, cur1, ln1, c0); hi = lowerBound(st1, lo, ln1, c1); }
+          if (may || ((mk1 >> ci) & 1ull)) {
+            const uint32_t row = lstDir[uBegin + tid + WG];
+            if (row != T1K_NO_DIR) { const uint32_t *dir = P.ref.kDir + (uint64_t)row * P.ref.kDirStride; lo = dir[ci]; hi = dir[ci + 1]; }
+            else { const uint32_t st = lstStart[uBegin + tid + WG], ln = lstLen[uBegin + tid + WG]; lo = lowerBound(st, cur1, ln, c0); hi = lowerBound(st, lo, ln, c1); }
           }
           n1 = hi - lo; sLo[tid + WG] = lo; cur1 = hi;
         }
@@ -746,7 +753,7 @@ __global__ __launch_bounds__(WG) T1K_OCC8 void k_seed_groups(ChainArgs P) {
           if (has1) pre[tid + WG] = tot0 + e1;
         }
         const uint32_t T = tot0 + tot1;
-        if (tid == 0) { pre[uCount] = T; hitsLocal += T; }
+        if (tid == 0) { pre[uCount] = T; sStat[2] += T; }
         __syncthreads();
 
 #ifdef T1K_SEED_PROFILE
@@ -870,14 +877,13 @@ __global__ __launch_bounds__(WG) T1K_OCC8 void k_seed_groups(ChainArgs P) {
        }
       }
     }
-    if (tid == 0) statHits += hitsLocal;
   }
 #ifdef T1K_SEED_PROFILE
   if (tid == 0) for (int i = 0; i < 8; ++i) atomicAdd(&P.counters[48 + i], (unsigned long long)tp_[i]);
 #endif
   if (tid == 0) {  // statistics: one striped atomic per workgroup and counter
     unsigned long long *st = P.counters + 64 + (blockIdx.x & (T1K_STAT_STRIPES - 1)) * 8;
-    atomicAdd(&st[T1K_STAT_LOOKUPS], statLookups); atomicAdd(&st[T1K_STAT_POSTINGS], statPostings); atomicAdd(&st[T1K_STAT_HITS], statHits);
+    atomicAdd(&st[T1K_STAT_LOOKUPS], sStat[0]); atomicAdd(&st[T1K_STAT_POSTINGS], sStat[1]); atomicAdd(&st[T1K_STAT_HITS], sStat[2]);
   }
 }
 

@@ -16,7 +16,7 @@ HOST = os.path.join(util.ROOT, "t1k_amd", "csrc", "host")
 @pytest.fixture(scope="module")
 def harness(tmp_path_factory):
     exe = str(tmp_path_factory.mktemp("harness") / "reads_shard_harness")
-    subprocess.run(["g++", "-O2", "-std=c++17", "-o", exe, HARNESS_SRC, os.path.join(HOST, "reads.cpp"), os.path.join(HOST, "refset.cpp"), "-lz", "-lpthread"],
+    subprocess.run(["g++", "-O2", "-std=c++17", "-o", exe, HARNESS_SRC, os.path.join(HOST, "reads.cpp"), os.path.join(HOST, "refset.cpp"), "-lz", "-lpthread", "-ldl"],
                    check=True)
     return exe
 
@@ -81,12 +81,14 @@ def test_compressed_input_is_left_to_the_whole_file_reader(harness, read_sets, t
 
 def test_bgzip_framed_and_plain_gzip_input_index_like_the_plain_file(harness, read_sets, tmp_path):
     """a .gz read file written by bgzip (independent 64 KiB gzip members) is inflated block-parallel by the host
-    threads, an ordinary .gz through one gzread stream: either way the index equals the plain file's"""
+    threads; an ordinary .gz is one dependent stream and goes through libdeflate's whole-buffer decoder into reserved memory (member
+    after member: concatenated .gz files, zero padding behind the last one), or through gzread where that library is missing
+    (T1K_NO_LIBDEFLATE): every way the index equals the plain file's"""
     import gzip
     import bamsynth
     d = read_sets
     out = {}
-    for kind in ("plain", "bgzf", "gzip"):
+    for kind in ("plain", "bgzf", "gzip", "gzip_zlib", "gzip_members"):
         files = []
         for m in ("1", "2"):
             src = os.path.join(d, "a_%s.fq" % m)
@@ -95,12 +97,28 @@ def test_bgzip_framed_and_plain_gzip_input_index_like_the_plain_file(harness, re
                 continue
             dst = str(tmp_path / ("a_%s_%s.fq.gz" % (kind, m)))
             raw = open(src, "rb").read()
-            open(dst, "wb").write(bamsynth.bgzf(raw) if kind == "bgzf" else gzip.compress(raw, 1))
+            if kind == "bgzf":
+                blob = bamsynth.bgzf(raw)
+            elif kind == "gzip_members":  # three members cut at record boundaries (as `cat a.gz b.gz c.gz` gives), then zero padding
+                lines = raw.split(b"\n")
+                cut1, cut2 = 4 * 7000, 4 * 7001
+                parts = [b"\n".join(lines[:cut1]) + b"\n", b"\n".join(lines[cut1:cut2]) + b"\n", b"\n".join(lines[cut2:])]
+                blob = b"".join(gzip.compress(x, 6) for x in parts) + b"\0" * 37
+            else:
+                blob = gzip.compress(raw, 1)
+            open(dst, "wb").write(blob)
             files.append(dst)
         o = str(tmp_path / kind)
-        r = subprocess.run([harness, "1", "4", o, "1"] + files, stderr=subprocess.PIPE, text=True, env=dict(os.environ, T1K_DEBUG_PHASES="1"))
+        env = dict(os.environ, T1K_DEBUG_PHASES="1")
+        if kind == "gzip_zlib":
+            env["T1K_NO_LIBDEFLATE"] = "1"
+        r = subprocess.run([harness, "1", "4", o, "1"] + files, stderr=subprocess.PIPE, text=True, env=env)
         assert r.returncode in (0, 3), r.stderr
         assert ("bgzip-framed read file" in r.stderr) == (kind == "bgzf"), r.stderr
+        import ctypes.util
+        have = ctypes.util.find_library("deflate") is not None or os.path.exists("/usr/lib/x86_64-linux-gnu/libdeflate.so.0")
+        assert ("through libdeflate" in r.stderr) == (kind in ("gzip", "gzip_members") and have), r.stderr
         out[kind] = open(o + "_whole.tsv").read()
     assert out["plain"].count("\n") == 30000
-    assert out["bgzf"] == out["plain"] and out["gzip"] == out["plain"]
+    for kind in out:
+        assert out[kind] == out["plain"], kind
