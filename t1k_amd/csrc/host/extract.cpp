@@ -307,6 +307,227 @@ struct BarcodeCorrector {
   }
 };
 
+// ------------------------------------------------------------------------------------------------------------------
+// The fast way through ordinary read files (SURVEY 8f row 1 end to end).  The streaming loop below parses records on one thread per
+// file into owned chunks, interleaves the mates on the main thread, uploads from pageable memory and writes -- 3.4 M pairs/s whatever
+// the kernels do (they screen 300 M pairs/s).  When the input is what a sequencer / the pipeline delivers -- regular files (plain or
+// gz) in the strict four-line FASTQ / two-line FASTA layout, no barcode stream, not interleaved -- the files are mapped and indexed in
+// place by the host threads exactly as the genotyper does (ReadInput, host/reads.cpp), and batches of fragments alternate between TWO
+// device contexts that share the index: while one context's kernels test batch b, the other's worker gathers the read text of batch
+// b + 1 from the mapping into page-locked staging slots (all host threads) and sends it piece by piece.  The kept records are
+// formatted by the host threads straight from the mapping and written in batch order.  Same records, same order, same bytes as the
+// streaming loop (and the reference); anything else about the input falls back to that loop.
+// ------------------------------------------------------------------------------------------------------------------
+template <class F>
+void parallelPieces(size_t n, int T, F fn) {  // fn(t, begin, end) over contiguous pieces of [0, n)
+  T = (int)std::max<size_t>(1, std::min<size_t>((size_t)T, n / 2048 + 1));
+  if (T == 1) { fn(0, (size_t)0, n); return; }
+  std::vector<std::thread> th;
+  const size_t per = (n + T - 1) / T;
+  for (int t = 0; t < T; ++t) th.emplace_back([=] { fn(t, std::min(n, t * per), std::min(n, (t + 1) * per)); });
+  for (auto &x : th) x.join();
+}
+
+struct MappedRun {
+  int r1s = 0, r1e = -1, r2s = 0, r2e = -1, threadCnt = 1;
+  bool hasMate = false, dbg = false;
+  std::string prefix;
+};
+
+// 1 = done (rc holds the exit code), 0 = not eligible: the caller runs the streaming loop
+int extractMapped(t1k_ctx *ctx0, const t1k_params &prm, int device, const std::vector<std::string> &files1, const std::vector<std::string> &files2, const MappedRun &o, int &rc,
+                  uint64_t &nFragments, uint64_t &nGood) {
+  if (getenv("T1K_EXTRACT_STREAM")) return 0;
+  const int hw = (int)std::thread::hardware_concurrency();
+  const int T = std::max(2, std::min(hw > 0 ? hw : 2, 32));
+  uint64_t bytes = 0;
+  for (const auto *fs : {&files1, &files2})
+    for (const auto &f : *fs) {
+      FILE *fp = fopen(f.c_str(), "rb");
+      if (!fp) return 0;  // (the streaming loop reports it the reference's way)
+      if (fseeko(fp, 0, SEEK_END) == 0) bytes += (uint64_t)ftello(fp);
+      fclose(fp);
+    }
+  {  // the whole input is mapped and indexed (22 bytes of index per record): beyond this much text the streaming loop's bounded memory wins
+    const char *e = getenv("T1K_EXTRACT_MAP_GB");
+    if ((double)bytes > (e ? atof(e) : 256.0) * 1073741824.0) return 0;
+  }
+  t1k::ReadInput in;
+  std::string err;
+  if (!in.open(files1, o.hasMate ? files2 : std::vector<std::string>(), "", T, err)) {
+    if (err.find("different numbers of reads") != std::string::npos) { fprintf(stderr, "The two mate-pair read files have different number of reads.\n"); rc = 1; return 1; }
+    return 0;
+  }
+  if (!in.inPlace) return 0;  // wrapped FASTA, blank lines ...: records in owned storage without their qualities
+  const size_t F = in.nFrag();
+  const uint32_t per = o.hasMate ? 2 : 1;
+  size_t B = 1u << 20;
+  if (const char *e = getenv("T1K_EXTRACT_CHUNK")) B = (size_t)std::max(1, atoi(e));
+  const size_t nBatches = (F + B - 1) / B;
+  // two contexts on the one index
+  t1k_ctx *ctx[2] = {ctx0, nullptr};
+  if (nBatches > 1) {
+    if (t1k_ctx_create(device, &prm, &ctx[1]) != T1K_OK || t1k_ref_share(ctx[1], ctx0) != T1K_OK) { if (ctx[1]) t1k_ctx_destroy(ctx[1]); ctx[1] = nullptr; }
+  }
+  const int nWorkers = ctx[1] ? 2 : 1;
+  struct Done { std::string o1, o2; uint64_t good = 0; bool ready = false; };
+  std::vector<Done> done(nBatches);
+  std::mutex mu;
+  std::condition_variable cv;
+  bool failed = false;
+  std::string failMsg;
+  size_t written = 0;  // batches the writer has taken (a worker runs at most 3 batches ahead of it: bounded output memory)
+  const size_t slotBytes = 64u << 20;
+  auto rawNameLen = [](const char *id, size_t il) {  // the name as kseq cuts it (up to the first blank): ReadInput dropped a trailing /1 or /2
+    if (id[il] == '/' && (id[il + 1] == '1' || id[il + 1] == '2') && (id[il + 2] == ' ' || id[il + 2] == '\t' || id[il + 2] == '\r' || id[il + 2] == '\n')) return il + 2;
+    return il;
+  };
+  auto qualOf = [](const char *id, const char *seq, size_t sl) -> const char * {  // four-line FASTQ: the line after the '+' line (the indexer checked both exist); FASTA: none
+    if (id[-1] != '@') return nullptr;
+    const char *p = seq + sl;
+    if (*p == '\r') ++p;
+    ++p;  // the newline
+    if (*p != '+') return nullptr;
+    while (*p != '\n') ++p;
+    return p + 1;
+  };
+  auto worker = [&](int w) {
+    t1k_ctx *c = ctx[w];
+    char *ring = (char *)t1k_pinned_alloc(3 * slotBytes);
+    const bool pinned = ring != nullptr;
+    if (!ring) ring = (char *)malloc(3 * slotBytes);
+    std::vector<uint64_t> off;
+    std::vector<uint8_t> good;
+    const int Tw = std::max(1, T / nWorkers);
+    for (size_t b = (size_t)w; b < nBatches && ring; b += (size_t)nWorkers) {
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return failed || b < written + 4; });
+        if (failed) break;
+      }
+      const size_t f0 = b * B, nf = std::min(B, F - f0), ne = nf * per;
+      off.resize(ne + 1);
+      std::vector<uint64_t> pieceBytes((size_t)Tw + 2, 0);
+      std::vector<uint32_t> pieceMax((size_t)Tw + 1, 0);
+      parallelPieces(nf, Tw, [&](int t, size_t lo, size_t hi) {
+        uint64_t run = 0; uint32_t mx = 0;
+        for (size_t i = lo; i < hi; ++i) {
+          const uint32_t r = in.frag[f0 + i];
+          for (uint32_t m = 0; m < per; ++m) { const uint32_t len = in.side[m].seqL[r]; off[i * per + m] = run; run += len; mx = std::max(mx, len); }
+        }
+        pieceBytes[(size_t)t + 1] = run; pieceMax[(size_t)t] = mx;
+      });
+      const int usedT = (int)std::max<size_t>(1, std::min<size_t>((size_t)Tw, nf / 2048 + 1));
+      for (int t = 0; t < usedT; ++t) pieceBytes[(size_t)t + 1] += pieceBytes[(size_t)t];
+      const uint64_t total = pieceBytes[(size_t)usedT];
+      uint32_t maxLen = 0;
+      for (int t = 0; t < usedT; ++t) maxLen = std::max(maxLen, pieceMax[(size_t)t]);
+      parallelPieces(nf, Tw, [&](int t, size_t lo, size_t hi) {
+        const uint64_t carry = pieceBytes[(size_t)t];
+        for (size_t i = lo; i < hi; ++i) for (uint32_t m = 0; m < per; ++m) off[i * per + m] += carry;
+      });
+      off[ne] = total;
+      int r = t1k_reads_upload_begin(c, (uint32_t)ne, total, (int)maxLen);
+      if (r == T1K_OK) r = t1k_reads_upload_piece(c, 1, off.data(), 0, ((uint64_t)ne + 1) * 8, 3);
+      uint32_t nPieces = 0;
+      for (size_t i0 = 0; i0 < nf && r == T1K_OK; ++nPieces) {
+        const uint64_t base = off[i0 * per];
+        size_t lo = i0 + 1, hi = nf;  // the last fragment boundary whose text still fits the slot (one fragment always does)
+        while (lo < hi) { const size_t mid = lo + (hi - lo + 1) / 2; if ((mid < nf ? off[mid * per] : total) - base <= slotBytes) lo = mid; else hi = mid - 1; }
+        const size_t i1 = lo;
+        const int slot = (int)(nPieces % 3);
+        if ((r = t1k_reads_upload_wait(c, slot)) != T1K_OK) break;
+        char *dst = ring + (size_t)slot * slotBytes;
+        parallelPieces(i1 - i0, Tw, [&](int, size_t a, size_t z) {
+          for (size_t i = i0 + a; i < i0 + z; ++i) {
+            const uint32_t rr = in.frag[f0 + i];
+            for (uint32_t m = 0; m < per; ++m) memcpy(dst + (off[i * per + m] - base), in.side[m].seqP[rr], in.side[m].seqL[rr]);
+          }
+        });
+        r = t1k_reads_upload_piece(c, 0, dst, base, (i1 < nf ? off[i1 * per] : total) - base, slot);
+        i0 = i1;
+      }
+      if (r == T1K_OK) r = t1k_reads_upload_end(c);
+      good.assign(nf, 0);
+      if (r == T1K_OK) r = t1k_extract_batch(c, per, good.data(), nullptr);
+      if (r != T1K_OK) {
+        std::lock_guard<std::mutex> g(mu);
+        if (!failed) { failed = true; failMsg = t1k_last_error(c); }
+        cv.notify_all();
+        break;
+      }
+      // the kept records, formatted from the mapping by the host threads (pieces in order)
+      Done d;
+      {
+        const int Tf = (int)std::max<size_t>(1, std::min<size_t>((size_t)Tw, nf / 2048 + 1));
+        std::vector<std::string> p1((size_t)Tf), p2((size_t)Tf);
+        std::vector<uint64_t> cnt((size_t)Tf, 0);
+        parallelPieces(nf, Tw, [&](int t, size_t lo, size_t hi) {
+          std::string &a = p1[(size_t)t], &bb = p2[(size_t)t];
+          for (size_t i = lo; i < hi; ++i) {
+            if (!good[i]) continue;
+            ++cnt[(size_t)t];
+            const uint32_t rr = in.frag[f0 + i];
+            const char *nm = in.side[0].idP[rr];
+            // -t 1 prints ReadFiles::Next()'s id (a trailing /1 or /2 removed), -t > 1 the raw name (FastqExtractor.cpp:446-476 vs 529-545)
+            const size_t nl = o.threadCnt == 1 ? (size_t)in.side[0].idL[rr] : rawNameLen(nm, in.side[0].idL[rr]);
+            outputSeq(a, nm, nl, in.side[0].seqP[rr], qualOf(nm, in.side[0].seqP[rr], in.side[0].seqL[rr]), in.side[0].seqL[rr], o.r1s, o.r1e);
+            if (o.hasMate) outputSeq(bb, nm, nl, in.side[1].seqP[rr], qualOf(in.side[1].idP[rr], in.side[1].seqP[rr], in.side[1].seqL[rr]), in.side[1].seqL[rr], o.r2s, o.r2e);
+          }
+        });
+        for (int t = 0; t < Tf; ++t) { d.o1 += p1[(size_t)t]; d.o2 += p2[(size_t)t]; d.good += cnt[(size_t)t]; }
+      }
+      d.ready = true;
+      {
+        std::lock_guard<std::mutex> g(mu);
+        done[b] = std::move(d);
+      }
+      cv.notify_all();
+    }
+    if (pinned) t1k_pinned_free(ring); else free(ring);
+    if (!ring) { std::lock_guard<std::mutex> g(mu); if (!failed) { failed = true; failMsg = "out of host memory"; } cv.notify_all(); }
+  };
+  FILE *fp1 = fopen((o.prefix + (o.hasMate ? "_1.fq" : ".fq")).c_str(), "w");
+  FILE *fp2 = o.hasMate ? fopen((o.prefix + "_2.fq").c_str(), "w") : nullptr;
+  if (!fp1 || (o.hasMate && !fp2)) {
+    fprintf(stderr, "Cannot open the output files.\n");
+    if (fp1) fclose(fp1);
+    if (fp2) fclose(fp2);
+    if (ctx[1]) t1k_ctx_destroy(ctx[1]);
+    rc = EXIT_FAILURE;
+    return 1;
+  }
+  std::vector<std::thread> th;
+  for (int w = 0; w < nWorkers; ++w) th.emplace_back(worker, w);
+  for (size_t b = 0; b < nBatches; ++b) {
+    Done d;
+    {
+      std::unique_lock<std::mutex> lk(mu);
+      cv.wait(lk, [&] { return failed || done[b].ready; });
+      if (failed) break;
+      d = std::move(done[b]);
+      written = b + 1;
+    }
+    cv.notify_all();
+    fwrite(d.o1.data(), 1, d.o1.size(), fp1);
+    if (fp2) fwrite(d.o2.data(), 1, d.o2.size(), fp2);
+    nGood += d.good;
+    nFragments += std::min(B, F - b * B);
+  }
+  for (auto &t : th) t.join();
+  fclose(fp1);
+  if (fp2) fclose(fp2);
+  if (ctx[1]) t1k_ctx_destroy(ctx[1]);
+  rc = 0;
+  if (failed) {
+    fprintf(stderr, "fastq-extractor: %s\n", failMsg.c_str());
+    rc = 1;
+    remove((o.prefix + (o.hasMate ? "_1.fq" : ".fq")).c_str());  // no truncated candidate files for the next stage
+    if (o.hasMate) remove((o.prefix + "_2.fq").c_str());
+  }
+  return 1;
+}
+
 }  // namespace
 
 extern "C" int t1k_extractor_main(int argc, char **argv) {
@@ -407,10 +628,10 @@ extern "C" int t1k_extractor_main(int argc, char **argv) {
   if (t1k_device_count() <= 0) { fprintf(stderr, "fastq-extractor: no HIP device (this build has no CPU path)\n"); return EXIT_FAILURE; }
   // the readers start now and parse their first chunks while the index is built and uploaded
   if (const char *e = getenv("T1K_EXTRACT_CHUNK")) reads.chunkRecords = mates.chunkRecords = barcodes.chunkRecords = (size_t)std::max(1, atoi(e));
-  reads.start();
-  if (hasMate) mates.start();
-  if (hasBarcode) barcodes.start();
-  auto drain = [&]() { while (reads.pop()) {} if (hasMate) while (mates.pop()) {} if (hasBarcode) while (barcodes.pop()) {} };  // lets blocked readers finish
+  // (input the mapped path below can take is not parsed by the stream threads at all)
+  bool started = false;
+  if (hasBarcode || reads.mod != 1 || getenv("T1K_EXTRACT_STREAM")) { reads.start(); if (hasMate) mates.start(); if (hasBarcode) barcodes.start(); started = true; }
+  auto drain = [&]() { if (!started) return; while (reads.pop()) {} if (hasMate) while (mates.pop()) {} if (hasBarcode) while (barcodes.pop()) {} };  // lets blocked readers finish
   t1k_params prm;
   t1k_params_default(&prm);
   prm.kmer_length = kmerLength;
@@ -433,6 +654,21 @@ extern "C" int t1k_extractor_main(int argc, char **argv) {
   }
 
   lap("context + reference index upload");
+  if (!hasBarcode && reads.mod == 1 && !started) {  // ordinary files: mapped, indexed in place, two device contexts (extractMapped)
+    MappedRun mo;
+    mo.r1s = r1s; mo.r1e = r1e; mo.r2s = r2s; mo.r2e = r2e; mo.threadCnt = threadCnt; mo.hasMate = hasMate; mo.dbg = dbg; mo.prefix = prefix;
+    int rcFast = 0;
+    uint64_t nf = 0, ng = 0;
+    if (extractMapped(ctx, prm, device, reads.files, mates.files, mo, rcFast, nf, ng) == 1) {
+      lap("read loop (mapped input, two contexts: index / gather / upload / test / write)");
+      t1k_ctx_destroy(ctx);
+      if (rcFast) return rcFast;
+      if (dbg) fprintf(stderr, "[t1k] extractor: k=%d hitLenRequired=%d fragments=%llu kept=%llu\n", kmerLength, hitLenRequired, (unsigned long long)nf, (unsigned long long)ng);
+      printLog("Finish extracting reads.");
+      return 0;
+    }
+  }
+  if (!started) { reads.start(); if (hasMate) mates.start(); if (hasBarcode) barcodes.start(); started = true; }
   FILE *fp1 = fopen((prefix + (hasMate ? "_1.fq" : ".fq")).c_str(), "w");
   FILE *fp2 = hasMate ? fopen((prefix + "_2.fq").c_str(), "w") : nullptr;
   FILE *fpBc = hasBarcode ? fopen((prefix + "_bc.fa").c_str(), "w") : nullptr;

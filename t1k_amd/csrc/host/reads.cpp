@@ -168,6 +168,7 @@ bool ReadInput::addRange(const char *b, const char *stop, const char *end, bool 
 // the general reader's records, copied into owned storage
 bool ReadInput::addGeneral(const std::string &path, Side &dst, std::string &err) {
   std::vector<SeqRec> recs;
+  inPlace = false;
   if (!readSeqFile(path, recs, err)) return false;
   size_t bytes = 0;
   for (auto &r : recs) bytes += r.id.size() + r.seq.size();

@@ -42,6 +42,7 @@ struct ReadInput {
   };
   Side side[2], bc;            // mates; barcode records (sequence = the barcode)
   bool paired = false, hasBarcode = false, noIds = false;
+  bool inPlace = true;         // every file was indexed in place (strict layouts): records point into the file's own text, qualities included
   std::vector<uint32_t, NoInitAlloc<uint32_t>> frag;  // fragment f = record frag[f] (records with a missing barcode are dropped with their mates)
   int maxLen = 0;
   ReadInput() = default;

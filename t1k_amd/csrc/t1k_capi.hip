@@ -284,7 +284,7 @@ void t1k_ctx_destroy(t1k_ctx *ctx) {
   T1kDevBuf *all[] = {&ctx->bReadAscii, &ctx->bReadOffs, &ctx->bReadBases, &ctx->bReadN, &ctx->bReadLen, &ctx->bReadWeight, &ctx->bWgHits, &ctx->bWgGroups,
                       &ctx->bWgStage, &ctx->bWgBig, &ctx->bWgCache, &ctx->bLists, &ctx->bCand, &ctx->bExt, &ctx->bCandStart, &ctx->bCandCount, &ctx->bListPtr, &ctx->bListCount,
                       &ctx->bOvlWork, &ctx->bDedupScratch, &ctx->bDedupBases, &ctx->bDedupN, &ctx->bDedupLen, &ctx->bDedupWeight, &ctx->bOvlStart, &ctx->bOvlCount, &ctx->bCounters, &ctx->bSlowQueue, &ctx->bSlowScratch, &ctx->bSortScratch, &ctx->bEqTrace, &ctx->bSortTmp, &ctx->bSlowKeys, &ctx->bJobSort, &ctx->bEnd1, &ctx->bEnd2,
-                      &ctx->bHasN, &ctx->bRows, &ctx->bRowStart, &ctx->bRowCount, &ctx->bFragAssigned, &ctx->bPairScratch, &ctx->bPairOverflow, &ctx->bPairBig, &ctx->bEmRowPtr, &ctx->bEmEc,
+                      &ctx->bHasN, &ctx->bRows, &ctx->bRowStart, &ctx->bRowCount, &ctx->bFragAssigned, &ctx->bPairScratch, &ctx->bPairOverflow, &ctx->bPairBig, &ctx->bExtractHuge, &ctx->bEmRowPtr, &ctx->bEmEc,
                       &ctx->bEmCount, &ctx->bEmLen, &ctx->bEmX0, &ctx->bEmN, &ctx->bEmContrib, &ctx->bEmColPtr, &ctx->bEmColIdx, &ctx->bEmEntryOf, &ctx->bExtract};
   for (auto *b : all) freeBuf(*b);
   for (auto &slot : ctx->storeChunks)
@@ -539,8 +539,8 @@ int t1k_extract_batch(t1k_ctx *ctx, uint32_t endsPerFragment, uint8_t *good, uin
   unsigned long long ctl[16];
   T1K_HIP(ctx, hipMemcpyAsync(ctl, dCtl, 128, hipMemcpyDeviceToHost, ctx->stream));
   T1K_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  bool bigShape = false;
-  if (ctl[0] || getenv("T1K_EXTRACT_FORCE_BIG")) {
+  bool bigShape = false, hugeShape = false;
+  if (ctl[0] || getenv("T1K_EXTRACT_FORCE_BIG") || getenv("T1K_EXTRACT_FORCE_HUGE")) {
     bigShape = true;
     // some (strand, sequence) bucket holds more hits than the production kernel keeps in LDS: the whole batch again in the large shape
     T1K_HIP(ctx, hipMemsetAsync(dCtl, 0, 128, ctx->stream));
@@ -548,6 +548,20 @@ int t1k_extract_batch(t1k_ctx *ctx, uint32_t endsPerFragment, uint8_t *good, uin
                            endsPerFragment, maxK, dGood, dState, dCtl, dCtl + 1, ctx->prm.workgroups * 4);
     T1K_HIP(ctx, hipGetLastError());
     T1K_HIP(ctx, hipMemcpyAsync(ctl, dCtl, 128, hipMemcpyDeviceToHost, ctx->stream));
+    T1K_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctl[0] || getenv("T1K_EXTRACT_FORCE_HUGE")) {
+      // ... and a bucket beyond the large LDS shape too (a read inside a long tandem repeat of one sequence): third attempt with the hit
+      // arrays in HBM, 64 workgroups x 4 x 65 535 words (the LIS links are 16-bit: that many hits a bucket; more is still T1K_ERR_CAPACITY)
+      const uint32_t cap = 65535u;
+      const int hugeWg = 64;
+      if ((rc = t1k_ensure(ctx, ctx->bExtractHuge, (size_t)hugeWg * 4 * cap * 4))) return rc;
+      T1K_HIP(ctx, hipMemsetAsync(dCtl, 0, 128, ctx->stream));
+      t1k_launch_extract_huge(ctx, ctx->ref, ctx->reads, ctx->prm.kmer_length, ctx->prm.radius, ctx->prm.hit_len_required, 1 - ctx->prm.ref_seq_similarity, nFrag,
+                              endsPerFragment, maxK, dGood, dState, dCtl, dCtl + 1, hugeWg, (uint32_t *)ctx->bExtractHuge.p, cap);
+      T1K_HIP(ctx, hipGetLastError());
+      T1K_HIP(ctx, hipMemcpyAsync(ctl, dCtl, 128, hipMemcpyDeviceToHost, ctx->stream));
+      hugeShape = true;
+    }
   }
   T1K_HIP(ctx, hipMemcpyAsync(good, dGood, nFrag, hipMemcpyDeviceToHost, ctx->stream));
   T1K_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -556,14 +570,14 @@ int t1k_extract_batch(t1k_ctx *ctx, uint32_t endsPerFragment, uint8_t *good, uin
     for (int i = 0; i < 7; ++i) fprintf(stderr, " %.3g", (double)ctl[8 + i]);
     fprintf(stderr, "\n");
   }
-  if (ctl[0]) return t1k_fail(ctx, T1K_ERR_CAPACITY, "t1k_extract_batch: a read has more hits on one reference sequence than the large kernel shape holds (8192; 6144 in a batch with reads beyond 320 bases)");
+  if (ctl[0]) return t1k_fail(ctx, T1K_ERR_CAPACITY, "t1k_extract_batch: a read has more than 65 535 hits on one reference sequence");
   if (stats) {
     for (int i = 0; i < 5; ++i) stats[i] = ctl[1 + i];
     stats[0] = nEnds;
     float msScreen = 0, msMain = 0;  // HIP events on the context's stream around each launch
     (void)hipEventElapsedTime(&msScreen, ctx->ev[0], ctx->ev[1]);
     (void)hipEventElapsedTime(&msMain, ctx->ev[1], ctx->ev[2]);
-    stats[5] = (uint64_t)(msScreen * 1e6); stats[6] = (uint64_t)(msMain * 1e6); stats[7] = bigShape ? 1 : 0;
+    stats[5] = (uint64_t)(msScreen * 1e6); stats[6] = (uint64_t)(msMain * 1e6); stats[7] = hugeShape ? 2 : bigShape ? 1 : 0;
   }
   return T1K_OK;
 }

@@ -745,7 +745,7 @@ struct t1k_ctx {
   T1kDevBuf bCand, bExt, bCandStart, bCandCount, bOvlStart, bOvlCount, bCounters, bSlowQueue, bSlowScratch, bSortScratch, bEqTrace, bSortTmp, bSlowKeys, bJobSort;
   uint64_t nCand = 0, nOvl = 0;
   // pairing
-  T1kDevBuf bEnd1, bEnd2, bHasN, bRows, bRowStart, bRowCount, bFragAssigned, bPairScratch, bPairOverflow, bPairBig;
+  T1kDevBuf bEnd1, bEnd2, bHasN, bRows, bRowStart, bRowCount, bFragAssigned, bPairScratch, bPairOverflow, bPairBig, bExtractHuge;
   uint32_t nFragments = 0;
   uint64_t nRows = 0;
   // EM

@@ -65,6 +65,8 @@ struct ExtractArgs {
   uint8_t *state;             // [read-end] written by k_extract_screen: 1 = the read-end may have a hit (k_extract decides)
   unsigned long long *err;
   unsigned long long *stats;  // [0] read-ends screened, [1] look-ups, [2] postings streamed, [3] read-ends reaching the histogram, [4] reaching the chain
+  uint32_t *ghScratch;        // k_extract<..., true>: the bucket's hit arrays H | A | B | C live here, ghCap words each per workgroup (HBM instead of LDS)
+  uint32_t ghCap;
 };
 
 // slice [lo, hi) of a posting list (sorted by sequence) holding the sequences [a0, a1)
@@ -163,9 +165,11 @@ __global__ __launch_bounds__(XWG) void k_extract_screen(ExtractArgs P) {
   }
 }
 
-template <int X_RANGE, int PT, int LT>
+// GH: third attempt of a batch -- a bucket beyond the large LDS shape (tandem repeats: thousands of hits of one read on one sequence).  The hit
+// arrays move to a per-workgroup piece of HBM (up to 65 535 hits: the LIS links are 16-bit); same code, slow by design, never the common path.
+template <int X_RANGE, int PT, int LT, bool GH = false>
 __global__ __launch_bounds__(XWG) __attribute__((amdgpu_waves_per_eu(6))) void k_extract(ExtractArgs P) {
-  constexpr int X_HCAP = X_RANGE / 4;
+  const uint32_t X_HCAP = GH ? P.ghCap : (uint32_t)(X_RANGE / 4);
   extern __shared__ uint32_t lds[];
   const int maxK = (int)P.maxK;
   uint32_t *ukCode = lds;                        // [maxK] code | valid << 31, both strands
@@ -449,7 +453,7 @@ __global__ __launch_bounds__(XWG) __attribute__((amdgpu_waves_per_eu(6))) void k
       if (bestCnt < 0 || k * bestCnt < P.hitLenRequired) continue;  // 1959-1964
       ++stChain;
       // ---- 4. the bucket's hits -> H (hist is dead)
-      uint32_t *H = hist, *SA = hist + X_HCAP, *SB = hist + 2 * X_HCAP, *SC = hist + 3 * X_HCAP;
+      uint32_t *H = GH ? P.ghScratch + (size_t)blockIdx.x * 4 * X_HCAP : hist, *SA = H + X_HCAP, *SB = H + 2 * (size_t)X_HCAP, *SC = H + 3 * (size_t)X_HCAP;
       const uint32_t uBeg = bestPass == 0 ? 0 : nUsed0, uCnt = bestPass == 0 ? nUsed0 : nUsed1;
       uint32_t n;
       {
@@ -608,6 +612,25 @@ void t1k_launch_extract(t1k_ctx *ctx, const T1kRefDev &ref, const T1kReadsDev &r
   const unsigned grid = (unsigned)std::min<uint64_t>(((uint64_t)nFragments + XWG - 1) / XWG, (uint64_t)nWg);
   if (xl) hipLaunchKernelGGL((k_extract<X_RANGE_SMALL, X_PT_LONG, X_LT_LONG>), dim3(grid), dim3(XWG), ldsBytes, ctx->stream, a);
   else hipLaunchKernelGGL((k_extract<X_RANGE_SMALL, X_PT_FAST, X_LT_FAST>), dim3(grid), dim3(XWG), ldsBytes, ctx->stream, a);
+  (void)hipEventRecord(ctx->ev[2], ctx->stream);
+}
+
+// third attempt: a bucket beyond the large LDS shape; hit arrays in HBM (scratch: grid x 4 x cap words)
+void t1k_launch_extract_huge(t1k_ctx *ctx, const T1kRefDev &ref, const T1kReadsDev &reads, int k, int radius, int hitLenRequired, double oneMinusSim,
+                             uint32_t nFragments, uint32_t epf, uint32_t maxK, uint8_t *good, uint8_t *state, unsigned long long *err, unsigned long long *stats, int nWg,
+                             uint32_t *scratch, uint32_t cap) {
+  ExtractArgs a = extractArgs(ref, reads, k, radius, hitLenRequired, oneMinusSim, nFragments, epf, maxK, good, state, err, stats);
+  a.ghScratch = scratch; a.ghCap = cap;
+  const bool xl = ctx->batchMaxLen > T1K_MAX_READ_LEN;
+  const size_t ldsBytes = t1k_extract_lds_bytes((int)maxK, X_RANGE_SMALL);
+  const unsigned grid = (unsigned)std::min<uint64_t>(((uint64_t)nFragments + XWG - 1) / XWG, (uint64_t)nWg);
+  if (xl) {
+    hipFuncSetAttribute((const void *)k_extract<X_RANGE_SMALL, X_PT_LONG, X_LT_LONG, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes);
+    hipLaunchKernelGGL((k_extract<X_RANGE_SMALL, X_PT_LONG, X_LT_LONG, true>), dim3(grid), dim3(XWG), ldsBytes, ctx->stream, a);
+  } else {
+    hipFuncSetAttribute((const void *)k_extract<X_RANGE_SMALL, X_PT_FAST, X_LT_FAST, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes);
+    hipLaunchKernelGGL((k_extract<X_RANGE_SMALL, X_PT_FAST, X_LT_FAST, true>), dim3(grid), dim3(XWG), ldsBytes, ctx->stream, a);
+  }
   (void)hipEventRecord(ctx->ev[2], ctx->stream);
 }
 

@@ -72,6 +72,43 @@ def test_executable_vs_golden(built, tmp_path, name):
         assert open(o + suffix).read() == open(o + "_c" + suffix).read()
 
 
+@pytest.mark.parametrize("layout", ["fastq", "fastq_crlf_no_final_newline", "fasta", "fastq_gz", "single_end"])
+def test_mapped_input_path_equals_streaming_path(built, tmp_path, layout):
+    """ordinary read files go through the mapped input (indexed in place by the host threads, batches alternating between two device
+    contexts that share the index, kept records formatted from the mapping); the streaming loop (T1K_EXTRACT_STREAM=1: reader threads,
+    owned chunks) is what every other input takes.  Same files byte for byte -- with -t 1 (ids lose /1 /2) and -t 4 (raw names), read
+    windows, many small batches -- and, where the reference binary is here, the same as its own output."""
+    ref = str(tmp_path / "ref.fa")
+    util.synth_ref("ref-rna", ref, seed=51, genes=6, scale=0.2)
+    pfx = str(tmp_path / "r")
+    util.synth_reads(ref, pfx, seed=52, pairs=6000, len=150, bg=0.5, sub=0.04, nrate=0.01, **({"fasta": 1} if layout == "fasta" else {}))
+    ext = "fa" if layout == "fasta" else "fq"
+    f1, f2 = pfx + "_1." + ext, pfx + "_2." + ext
+    if layout == "fastq_crlf_no_final_newline":
+        for f in (f1, f2):
+            open(f, "wb").write(open(f, "rb").read().replace(b"\n", b"\r\n").rstrip(b"\r\n"))
+    if layout == "fastq_gz":
+        import gzip
+        for f in (f1, f2):
+            open(f + ".gz", "wb").write(gzip.compress(open(f, "rb").read(), 1))
+        f1, f2 = f1 + ".gz", f2 + ".gz"
+    files = ["-u", f1] if layout == "single_end" else ["-1", f1, "-2", f2]
+    for extra in (["-t", "1"], ["-t", "4", "--read1Start", "3", "--read1End", "120", "--read2Start", "0", "--read2End", "99"]):
+        outs = {}
+        for mode, env in (("mapped", {"T1K_EXTRACT_CHUNK": "700"}), ("mapped_one_batch", {}), ("stream", {"T1K_EXTRACT_STREAM": "1"})):
+            o = str(tmp_path / (mode + "_".join(extra)))
+            r = subprocess.run([XBIN, "-f", ref] + files + extra + ["-o", o], stderr=subprocess.PIPE, text=True, env=dict(os.environ, T1K_DEBUG_PHASES="1", **env))
+            assert r.returncode == 0, r.stderr[-1500:]
+            assert ("mapped input" in r.stderr) == (mode != "stream"), r.stderr[-1500:]
+            outs[mode] = [open(o + sfx, "rb").read() for sfx in ([".fq"] if layout == "single_end" else ["_1.fq", "_2.fq"])]
+            assert len(outs[mode][0]) > 1000
+        assert outs["mapped"] == outs["stream"] and outs["mapped_one_batch"] == outs["stream"]
+        if os.path.exists(util.REF_EXTRACT) and not (layout == "single_end" and "--read2End" in extra):
+            o = str(tmp_path / ("ref" + "_".join(extra)))
+            subprocess.run([util.REF_EXTRACT, "-f", ref] + files + extra + ["-o", o], check=True, stderr=subprocess.PIPE)
+            assert [open(o + sfx, "rb").read() for sfx in ([".fq"] if layout == "single_end" else ["_1.fq", "_2.fq"])] == outs["mapped"]
+
+
 def test_edge_reads_vs_oracle(built, tmp_path):
     """empty / shorter-than-k / all-N / homopolymer / repeat / exact-copy / reverse-complement / boundary-similarity reads"""
     ref_fa = util.gunzip_to(util.CYP_DNA, str(tmp_path / "ref.fa"))
@@ -132,7 +169,7 @@ def test_full_size_properties(built, tmp_path):
 
 def test_large_bucket_takes_the_big_shape(built, tmp_path):
     """a trinucleotide repeat puts thousands of hits into one (strand, sequence) bucket: more than the production LDS shape holds (1024),
-    so the batch is run again in the large shape (8192); results still equal the oracle's.  Beyond that the call fails loudly."""
+    so the batch is run again in the large shape (8192), and beyond that with the hit arrays in HBM (65 535); results still equal the oracle's."""
     rng = random.Random(11)
     rnd = lambda n: "".join(rng.choice("ACGT") for _ in range(n))
     ref = [rnd(400) + "CAG" * 300 + rnd(400), rnd(1500), rnd(300) + "CAG" * 40 + rnd(300)]
@@ -152,9 +189,26 @@ def test_large_bucket_takes_the_big_shape(built, tmp_path):
     finally:
         del os.environ["T1K_EXTRACT_FORCE_BIG"]
     assert np.array_equal(good2, want)
-    huge = [rnd(200) + "CAG" * 1500 + rnd(200)]
-    with pytest.raises(t1k_amd.T1kError, match="more hits on one reference sequence"):
-        device_flags(huge, ["CAG" * 50], 1, 9, 27, 0.8)
+    # beyond the large LDS shape (8192 hits a bucket): third attempt with the hit arrays in HBM, still the oracle's answers
+    huge = [rnd(200) + "CAG" * 900 + rnd(200), rnd(800)]
+    fa2 = tmp_path / "huge.fa"
+    fa2.write_text("".join(">s%d\n%s\n" % (i, s) for i, s in enumerate(huge)))
+    hreads = ["CAG" * 50, huge[0][150:300], huge[1][100:250], rnd(150), "CTG" * 50]
+    orc = util.ExtractOracle(str(fa2), k=9, hit_len_required=27)
+    hwant = np.array([1 if orc.good(r) else 0 for r in hreads], dtype=np.uint8)
+    orc.close()
+    hgood, hst = device_flags(huge, hreads, 1, 9, 27, 0.8)
+    assert np.array_equal(hgood, hwant), (hgood, hwant)
+    assert hst["big_shape"] == 2, hst
+    os.environ["T1K_EXTRACT_FORCE_HUGE"] = "1"
+    try:
+        good3, st3 = device_flags(ref, reads, 1, 9, 27, 0.8)
+    finally:
+        del os.environ["T1K_EXTRACT_FORCE_HUGE"]
+    assert np.array_equal(good3, want) and st3["big_shape"] == 2
+    # 65 535 hits a bucket is the end (16-bit links of the chain): loudly
+    with pytest.raises(t1k_amd.T1kError, match="more than 65 535 hits"):
+        device_flags([rnd(200) + "CAG" * 12000 + rnd(200)], ["CAG" * 50], 1, 9, 27, 0.8)
 
 
 def test_n_next_to_homopolymers_vs_oracle(built, tmp_path):
