@@ -86,7 +86,8 @@ def test_mapped_input_path_equals_streaming_path(built, tmp_path, layout):
     f1, f2 = pfx + "_1." + ext, pfx + "_2." + ext
     if layout == "fastq_crlf_no_final_newline":
         for f in (f1, f2):
-            open(f, "wb").write(open(f, "rb").read().replace(b"\n", b"\r\n").rstrip(b"\r\n"))
+            text = open(f, "rb").read()
+            open(f, "wb").write(text.replace(b"\n", b"\r\n").rstrip(b"\r\n"))
     if layout == "fastq_gz":
         import gzip
         for f in (f1, f2):
