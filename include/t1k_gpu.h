@@ -152,6 +152,10 @@ int t1k_rowset_set_raw(t1k_rowset *rs, int raw);
 const char *t1k_rowset_last_error(const t1k_rowset *rs);
 int t1k_pair_into(t1k_ctx *ctx, t1k_rowset *rs, const uint32_t *end1, const uint32_t *end2, const uint8_t *hasN, uint32_t nFragments, uint64_t fragBase);
 int t1k_rowset_coalesce(t1k_rowset *rs, uint64_t *nGroups, uint64_t *nEntries, uint64_t *assignedFragments);
+/* the same; `sized` (may be NULL) is called once with the number of groups and entries as soon as they are known -- the fold of the
+ * groups (the longest step) is then still running on the device, so a caller can size its host tables beside it.  Not called when no
+ * fragment has a row. */
+int t1k_rowset_coalesce_sized(t1k_rowset *rs, uint64_t *nGroups, uint64_t *nEntries, uint64_t *assignedFragments, void (*sized)(uint64_t nGroups, uint64_t nEntries, void *user), void *user);
 int t1k_rowset_groups_download(t1k_rowset *rs, uint64_t *groupPtr, t1k_group_entry *entries, uint32_t *firstFragment);
 /* fragAssigned[nFragments]: Genotyper.cpp:564-565 */
 int t1k_rowset_assigned_download(t1k_rowset *rs, uint8_t *fragAssigned);

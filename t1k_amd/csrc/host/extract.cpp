@@ -334,31 +334,48 @@ struct MappedRun {
   std::string prefix;
 };
 
+// The input of the mapped path, opened on its own thread while the device context and the reference index are being made (the index
+// of 4 M pairs takes the host threads 60 - 90 ms: as long as the HIP runtime needs to come up).
+struct MappedInput {
+  t1k::ReadInput in;
+  std::thread th;
+  int state = 0;  // 1 = indexed in place, 0 = not eligible (the streaming loop takes the input), -1 = the mates hold different numbers of reads
+  void start(const std::vector<std::string> &files1, const std::vector<std::string> &files2, bool hasMate) {
+    th = std::thread([this, &files1, &files2, hasMate] {
+      if (getenv("T1K_EXTRACT_STREAM")) return;
+      const int hw = (int)std::thread::hardware_concurrency();
+      const int T = std::max(2, std::min(hw > 0 ? hw : 2, 32));
+      uint64_t bytes = 0;
+      for (const auto *fs : {&files1, &files2})
+        for (const auto &f : *fs) {
+          FILE *fp = fopen(f.c_str(), "rb");
+          if (!fp) return;  // (the streaming loop reports it the reference's way)
+          if (fseeko(fp, 0, SEEK_END) == 0) bytes += (uint64_t)ftello(fp);
+          fclose(fp);
+        }
+      // the whole input is mapped and indexed (22 bytes of index per record): beyond this much text the streaming loop's bounded memory wins
+      const char *e = getenv("T1K_EXTRACT_MAP_GB");
+      if ((double)bytes > (e ? atof(e) : 256.0) * 1073741824.0) return;
+      std::string err;
+      if (!in.open(files1, hasMate ? files2 : std::vector<std::string>(), "", T, err)) {
+        if (err.find("different numbers of reads") != std::string::npos) state = -1;
+        return;
+      }
+      if (in.inPlace) state = 1;  // (wrapped FASTA, blank lines ...: records in owned storage without their qualities -> streaming loop)
+    });
+  }
+  int wait() { if (th.joinable()) th.join(); return state; }
+  ~MappedInput() { if (th.joinable()) th.join(); }
+};
+
 // 1 = done (rc holds the exit code), 0 = not eligible: the caller runs the streaming loop
-int extractMapped(t1k_ctx *ctx0, const t1k_params &prm, int device, const std::vector<std::string> &files1, const std::vector<std::string> &files2, const MappedRun &o, int &rc,
-                  uint64_t &nFragments, uint64_t &nGood) {
-  if (getenv("T1K_EXTRACT_STREAM")) return 0;
+int extractMapped(t1k_ctx *ctx0, const t1k_params &prm, int device, MappedInput &mi, const MappedRun &o, int &rc, uint64_t &nFragments, uint64_t &nGood) {
+  const int st = mi.wait();
+  if (st == 0) return 0;
+  if (st < 0) { fprintf(stderr, "The two mate-pair read files have different number of reads.\n"); rc = 1; return 1; }
+  t1k::ReadInput &in = mi.in;
   const int hw = (int)std::thread::hardware_concurrency();
   const int T = std::max(2, std::min(hw > 0 ? hw : 2, 32));
-  uint64_t bytes = 0;
-  for (const auto *fs : {&files1, &files2})
-    for (const auto &f : *fs) {
-      FILE *fp = fopen(f.c_str(), "rb");
-      if (!fp) return 0;  // (the streaming loop reports it the reference's way)
-      if (fseeko(fp, 0, SEEK_END) == 0) bytes += (uint64_t)ftello(fp);
-      fclose(fp);
-    }
-  {  // the whole input is mapped and indexed (22 bytes of index per record): beyond this much text the streaming loop's bounded memory wins
-    const char *e = getenv("T1K_EXTRACT_MAP_GB");
-    if ((double)bytes > (e ? atof(e) : 256.0) * 1073741824.0) return 0;
-  }
-  t1k::ReadInput in;
-  std::string err;
-  if (!in.open(files1, o.hasMate ? files2 : std::vector<std::string>(), "", T, err)) {
-    if (err.find("different numbers of reads") != std::string::npos) { fprintf(stderr, "The two mate-pair read files have different number of reads.\n"); rc = 1; return 1; }
-    return 0;
-  }
-  if (!in.inPlace) return 0;  // wrapped FASTA, blank lines ...: records in owned storage without their qualities
   const size_t F = in.nFrag();
   const uint32_t per = o.hasMate ? 2 : 1;
   size_t B = 1u << 20;
@@ -572,6 +589,10 @@ extern "C" int t1k_extractor_main(int argc, char **argv) {
   if (refPath.empty()) { fprintf(stderr, "Need to use -f to specify the reference sequence.\n"); return EXIT_FAILURE; }
   if (reads.files.empty()) { fprintf(stderr, "Need to use -u/-1/-2/-i to specify the read files.\n"); return EXIT_FAILURE; }
   printLog("Start to extract candidate reads from read files.");
+  // the HIP runtime comes up (0.1 s) while the reference and the first reads are parsed
+  int nDevices = 0;
+  struct Joiner { std::thread t; ~Joiner() { if (t.joinable()) t.join(); } } hipUp;
+  hipUp.t = std::thread([&nDevices] { nDevices = t1k_device_count(); });
   const bool dbg = getenv("T1K_DEBUG_PHASES") != nullptr;
   auto tStart = std::chrono::steady_clock::now();
   auto lap = [&](const char *what) {
@@ -625,11 +646,15 @@ extern "C" int t1k_extractor_main(int argc, char **argv) {
       if (seen >= 2000000) break;
     }
   }
-  if (t1k_device_count() <= 0) { fprintf(stderr, "fastq-extractor: no HIP device (this build has no CPU path)\n"); return EXIT_FAILURE; }
+  lap("parameters from the first reads");
+  hipUp.t.join();
+  if (nDevices <= 0) { fprintf(stderr, "fastq-extractor: no HIP device (this build has no CPU path)\n"); return EXIT_FAILURE; }
   // the readers start now and parse their first chunks while the index is built and uploaded
   if (const char *e = getenv("T1K_EXTRACT_CHUNK")) reads.chunkRecords = mates.chunkRecords = barcodes.chunkRecords = (size_t)std::max(1, atoi(e));
-  // (input the mapped path below can take is not parsed by the stream threads at all)
+  // (input the mapped path below can take is not parsed by the stream threads at all: it is mapped and indexed while the context comes up)
   bool started = false;
+  MappedInput mapped;
+  if (!(hasBarcode || reads.mod != 1)) mapped.start(reads.files, mates.files, hasMate);
   if (hasBarcode || reads.mod != 1 || getenv("T1K_EXTRACT_STREAM")) { reads.start(); if (hasMate) mates.start(); if (hasBarcode) barcodes.start(); started = true; }
   auto drain = [&]() { if (!started) return; while (reads.pop()) {} if (hasMate) while (mates.pop()) {} if (hasBarcode) while (barcodes.pop()) {} };  // lets blocked readers finish
   t1k_params prm;
@@ -659,9 +684,10 @@ extern "C" int t1k_extractor_main(int argc, char **argv) {
     mo.r1s = r1s; mo.r1e = r1e; mo.r2s = r2s; mo.r2e = r2e; mo.threadCnt = threadCnt; mo.hasMate = hasMate; mo.dbg = dbg; mo.prefix = prefix;
     int rcFast = 0;
     uint64_t nf = 0, ng = 0;
-    if (extractMapped(ctx, prm, device, reads.files, mates.files, mo, rcFast, nf, ng) == 1) {
+    if (extractMapped(ctx, prm, device, mapped, mo, rcFast, nf, ng) == 1) {
       lap("read loop (mapped input, two contexts: index / gather / upload / test / write)");
       t1k_ctx_destroy(ctx);
+      lap("context released");
       if (rcFast) return rcFast;
       if (dbg) fprintf(stderr, "[t1k] extractor: k=%d hitLenRequired=%d fragments=%llu kept=%llu\n", kmerLength, hitLenRequired, (unsigned long long)nf, (unsigned long long)ng);
       printLog("Finish extracting reads.");

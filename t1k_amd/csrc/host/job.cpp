@@ -902,18 +902,25 @@ int t1k_job_run_local(t1k_job *job) {
   const double tEx0 = nowMs();
   if (sharded && (rc = t1k_rowset_exchange(job->rows, job->comm, fBeg)) != T1K_OK) return jobFail(job, rc, t1k_rowset_last_error(job->rows));
   const double tEx1 = nowMs();
-  if ((rc = t1k_rowset_coalesce(job->rows, &G, &N, &assigned)) != T1K_OK) return jobFail(job, rc, t1k_rowset_last_error(job->rows));
-  const double tCo = nowMs();
-  if (!sharded) {
-    gt.groupPtr.assign(G + 1, 0);
-    gt.groupEnt.resize(N);  // (not zeroed: GroupVec)
-    gt.groupFirst.resize(G);
-    // first touch of the table's pages by all host threads (100 k page faults on one thread were 90 ms)
-    parallelRanges(N * sizeof(GroupEntry) / 4096 + 1, T, [&](int, size_t b, size_t e) {
-      volatile char *base = (volatile char *)gt.groupEnt.data();
-      const size_t bytes = N * sizeof(GroupEntry);
+  // (one GPU: the host tables of the groups are sized and their pages first touched by all host threads -- 100 k page faults on one
+  // thread were 90 ms, 27 ms on all -- while the device is still folding the groups)
+  struct Sizer { Genotyper *gt; int T; bool on; } sizer{&gt, T, !sharded};
+  auto sizeTables = [](uint64_t g, uint64_t n, void *u) {
+    Sizer &z = *(Sizer *)u;
+    if (!z.on) return;
+    z.gt->groupPtr.assign(g + 1, 0);
+    z.gt->groupEnt.resize(n);  // (not zeroed: GroupVec)
+    z.gt->groupFirst.resize(g);
+    parallelRanges(n * sizeof(GroupEntry) / 4096 + 1, z.T, [&](int, size_t b, size_t e) {
+      volatile char *base = (volatile char *)z.gt->groupEnt.data();
+      const size_t bytes = n * sizeof(GroupEntry);
       for (size_t pg = b; pg < e; ++pg) if (pg * 4096 < bytes) base[pg * 4096] = 0;
     });
+  };
+  if ((rc = t1k_rowset_coalesce_sized(job->rows, &G, &N, &assigned, sizeTables, &sizer)) != T1K_OK) return jobFail(job, rc, t1k_rowset_last_error(job->rows));
+  const double tCo = nowMs();
+  if (!sharded) {
+    if (gt.groupPtr.size() != G + 1) { gt.groupPtr.assign(G + 1, 0); gt.groupEnt.resize(N); gt.groupFirst.resize(G); }  // (no row at all: the callback was not called)
     const double tRes = nowMs();
     if ((rc = t1k_rowset_groups_download(job->rows, gt.groupPtr.data(), (t1k_group_entry *)gt.groupEnt.data(), gt.groupFirst.data())) != T1K_OK)
       return jobFail(job, rc, t1k_rowset_last_error(job->rows));

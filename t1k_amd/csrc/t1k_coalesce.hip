@@ -330,6 +330,10 @@ int t1k_rowset_set_raw(t1k_rowset *rs, int raw) { if (!rs) return T1K_ERR_ARG; r
 const char *t1k_rowset_last_error(const t1k_rowset *rs) { return rs ? rs->err.c_str() : "no rowset"; }
 
 int t1k_rowset_coalesce(t1k_rowset *rs, uint64_t *nGroups, uint64_t *nEntries, uint64_t *assignedFragments) {
+  return t1k_rowset_coalesce_sized(rs, nGroups, nEntries, assignedFragments, nullptr, nullptr);
+}
+
+int t1k_rowset_coalesce_sized(t1k_rowset *rs, uint64_t *nGroups, uint64_t *nEntries, uint64_t *assignedFragments, void (*sized)(uint64_t, uint64_t, void *), void *user) {
   if (!rs) return T1K_ERR_ARG;
   t1k_ctx *ctx = rs->owner;
   RS_HIP(hipSetDevice(rs->device));
@@ -420,6 +424,7 @@ int t1k_rowset_coalesce(t1k_rowset *rs, uint64_t *nGroups, uint64_t *nEntries, u
     hipLaunchKernelGGL(k_co_reduce, dim3((unsigned)((nTiles + 3) / 4)), dim3(256), 0, st, tileGroup, tilePtr, order, runStart, ptrSorted, gSize, groupPtr,
                        (T1kGroupEnt *)rs->bGroupEnt.p, nTiles, longRun);
   }
+  if (sized) sized(G, N, user);  // the fold is on its way: the caller sizes (and first-touches) its host tables meanwhile
   RS_HIP(hipStreamSynchronize(st));
   lap("k_co_reduce");
   rs->nGroups = G; rs->nEntries = N;
