@@ -91,6 +91,7 @@ struct PairArgs {
   Frag *bigFrags; uint32_t *bigKeep; uint64_t bigCap;
   uint32_t *overflowList;          // first pass: fragments with more than fragCap overlaps are listed here instead of failing
   const uint8_t *whitelist;        // [nAlleles] or NULL: alleles outside it are left out of the rows (Genotyper.hpp:822-823)
+  int listForm;                    // T1K_PAIR_LIST=1: the joined fragments are materialised as in round 3 (A/B and parity aid)
   int rawKept;                     // rows = the fragment assignment list itself (what ReadAssignmentToFragmentAssignment returns), without
                                    // the -n / separator / whitelist drops of SetReadAssignments: the analyzer's per-barcode summary reads that
   // rowset form (rsRowPtr != NULL): rows go to rsRows[*rsCursor ...), ordered by allele; per-fragment records at fragBase + f
@@ -288,6 +289,47 @@ __global__ __launch_bounds__(WG) void k_pair(PairArgs P) {
     double tbS = 0;
     bool tracked = false;
     PP(0);
+    // ---- both mates have a list, no allele twice in a list (nearly every fragment): NO fragment list is materialised.  Round 3 wrote a
+    // 48-byte record per joined allele into the workgroup's HBM scratch (about 700 a fragment) and read them back for the best / keep
+    // passes: 51 KB written and twice that fetched per fragment (PMC, profiles/r04_before_traffic_work) for a row of ~14 entries.  The
+    // best fragment only needs (matchCnt, similarity, position) of each joined pair -- computed from the two 16-byte records on the fly --
+    // and the keep filter is a second sweep over list 1 that joins again through the LDS table and writes the FEW kept fragments, in
+    // order, to frags[0 .. nKept).  Same decisions in the same order as the list form (SeqSet.hpp:2369-2545).
+    const bool stream = both && !dup && !P.listForm;
+    uint32_t nKeptStream = 0;
+    if (stream) {
+      tracked = true;
+      const int s1 = ovlStrand(L1[0]), s2 = ovlStrand(L2[0]);
+      auto mateOf = [&](uint32_t i, const T1kOvl &oa, int &slot) -> int {  // index in list 2 of the overlap that pairs with oa, -1 if none (2369-2380)
+        int jj = -1;
+        slot = -1;
+        if (s1 == s2) return -1;
+        if (lds) {
+          slot = ljFind<LJ_SLOTS>(hKey, oa.allele);
+          jj = (int)(hVal[slot] >> 16) - 1;
+        } else {
+          const uint64_t e = tab2[oa.allele];
+          if ((e >> 32) == (epoch >> 32)) jj = (int)(e & 0x3FFFFFFFu);
+        }
+        if (jj < 0) return -1;
+        const int ss = L2[jj].seqStart;
+        return ((s1 == 1 && oa.seqStart < ss) || (s1 == -1 && oa.seqStart > ss)) ? jj : -1;
+      };
+      uint32_t nPairs = 0;
+      for (uint32_t i = tid; i < n1; i += WG) {
+        const T1kOvl oa = L1[i];
+        int slot;
+        const int j = mateOf(i, oa, slot);
+        if (j < 0) continue;
+        const T1kOvl ob = L2[j];
+        Frag fr;
+        makeFrag(fr, &oa, (int)i, &ob, j);
+        ++nPairs;
+        if (fr.matchCnt > tbM || (fr.matchCnt == tbM && fr.sim > tbS)) { tbM = fr.matchCnt; tbS = fr.sim; tbI = (int)i; }  // (a lane's i ascend: its first maximum stays)
+        if (lds) atomicOr(&hVal[slot], 0x8000u); else tab2[oa.allele] |= 0x80000000ull;   // the mate's allele has a fragment (seqIdxToOverlapIdx membership)
+      }
+      nFrag = nPairs;  // (this lane's share: only "any at all" is asked below, through sBestM)
+    } else
     if (!dup) {
       // ---- fast path: every allele at most once per list -> `assign` == fragment list, in list order ----------------
       if (!both) {
@@ -437,10 +479,54 @@ __global__ __launch_bounds__(WG) void k_pair(PairArgs P) {
     }
     const int bestM = sBestM;
     const double bestSim = sBestSim;
-    const int bestRelaxed = nFrag ? frags[sBestIdx].relaxed : 0;
+    int bestRelaxed = 0;
+    if (stream) {
+      if (bestM >= 0) {  // the best fragment again, from its two records (every lane computes the same)
+        const T1kOvl oa = L1[sBestIdx];
+        int jj;
+        if (lds) jj = (int)(hVal[ljFind<LJ_SLOTS>(hKey, oa.allele)] >> 16) - 1; else jj = (int)(tab2[oa.allele] & 0x3FFFFFFFu);
+        bestRelaxed = oa.relaxed + L2[jj].relaxed;
+      }
+    } else bestRelaxed = nFrag ? frags[sBestIdx].relaxed : 0;
     PP(2);
     // ---- keep filter (2488-2545), order-preserving -----------------------------------------------------------------------
     uint32_t nKept = 0;
+    if (stream) {
+      if (bestM >= 0) {
+        const int s1 = ovlStrand(L1[0]), s2 = ovlStrand(L2[0]);
+        for (uint32_t i0 = 0; i0 < n1; i0 += WG) {
+          const uint32_t i = i0 + tid;
+          bool kp = false;
+          Frag fr;
+          if (i < n1 && s1 != s2) {
+            const T1kOvl oa = L1[i];
+            int jj = -1;
+            if (lds) jj = (int)((hVal[ljFind<LJ_SLOTS>(hKey, oa.allele)] >> 16) & 0xFFFFu) - 1;
+            else { const uint64_t e = tab2[oa.allele]; if ((e >> 32) == (epoch >> 32)) jj = (int)(e & 0x3FFFFFFFu); }
+            if (jj >= 0) {
+              const T1kOvl ob = L2[jj];
+              if ((s1 == 1 && oa.seqStart < ob.seqStart) || (s1 == -1 && oa.seqStart > ob.seqStart)) {
+                makeFrag(fr, &oa, (int)i, &ob, jj);
+                int relaxBy = 2;
+                if (P.relax) {
+                  const bool inter = (oa.seqStart <= ob.seqStart && oa.seqEnd >= ob.seqStart) || (ob.seqStart <= oa.seqStart && ob.seqEnd >= oa.seqStart);  // 317-324
+                  if (inter && oa.matchCnt < oa.relaxed && ob.matchCnt < ob.relaxed) relaxBy = 4;
+                }
+                kp = (fr.matchCnt == bestM && fr.sim == bestSim) || (P.relax && fr.matchCnt >= bestM - relaxBy && fr.relaxed == bestRelaxed);
+              }
+            }
+          }
+          uint32_t tot;
+          const uint32_t off = scanExcl<NWAVE>(kp ? 1u : 0u, warpSums, &tot);
+          if (kp) {
+            if (nKept + off < fragCap) { frags[nKept + off] = fr; keep[nKept + off] = nKept + off; }
+            else sFail = 2;  // (more kept fragments than the scratch holds: cannot happen -- kept <= joined <= n1 <= fragCap; guarded anyway)
+          }
+          nKept += tot;
+        }
+      }
+      nKeptStream = nKept;
+    } else
     for (uint32_t q0 = 0; q0 < nFrag; q0 += WG) {
       uint32_t q = q0 + tid;
       bool kp = false;
@@ -702,6 +788,7 @@ static int pairLaunch(t1k_ctx *ctx, t1k_rowset *rs, const uint32_t *end1, const 
   p.overflowList = (uint32_t *)ctx->bPairOverflow.p;
   p.counters = (unsigned long long *)ctx->bCounters.p;
   p.whitelist = dWhitelist;
+  { static const int lf = getenv("T1K_PAIR_LIST") ? 1 : 0; p.listForm = lf; }
   if (getenv("T1K_DEBUG_TRACE")) fprintf(stderr, "[t1k trace] pair %u fragments%s\n", n, rs ? " into the rowset" : "");
   for (int attempt = 0;; ++attempt) {
     T1K_HIP(ctx, hipMemsetAsync((char *)ctx->bCounters.p + 2 * 8, 0, 8, ctx->stream));

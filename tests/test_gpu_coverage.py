@@ -98,6 +98,8 @@ MODES = {
     # k_pair: every fragment with more than 16 overlaps goes to the second launch (scratch from the big arena), whose 64 entries force the
     # "arena grows to the demand the device counted, the call runs again" path
     "pair_second_launch_arena_growth": {"T1K_PAIR_FRAGCAP": "16", "T1K_PAIR_BIGCAP": "64", "T1K_PAIR_BATCH": "32"},
+    # k_pair with the joined fragments materialised in the workgroup's scratch (round 3's form; the default streams the join twice instead)
+    "pair_list_form": {"T1K_PAIR_LIST": "1", "T1K_PAIR_BATCH": "64"},
     "two_ranks": {"T1K_GPUS": "0,0"},
     "three_ranks_small_windows": {"T1K_GPUS": "0,0,0", "T1K_FIRST_WINDOW": "16", "T1K_WINDOW": "48", "T1K_BATCH": "16"},
 }
