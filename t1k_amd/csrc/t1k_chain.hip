@@ -96,7 +96,7 @@ __device__ __forceinline__ void shlOr(uint64_t *C, int sft) {
 #define GROUP_MAX_REFS 4   // two 32-bit words of 16-bit memo slots in a group record
 template <int NW, bool DEFER, bool CLOSED>
 __device__ inline int groupFastPath(const uint32_t *Mw, int diag, const ReadCtx &c, bool hasN, int k, int hitLenRequired, double simThreshold, CandOut &out,
-                                    unsigned int *dpCounter, int strandBit, const GapSink &sink, uint32_t *refs, int *nRefs, bool earlyPrune = true) {
+                                    unsigned int *dpCounter, int strandBit, const GapSink &sink, uint32_t *refs, int *nRefs, int earlyPrune = 1) {
   constexpr int MW = (NW + 1) / 2;  // 64-bit words of the read-offset bitmask
   uint64_t M[MW];
   int onDiag = 0;
@@ -173,6 +173,44 @@ __device__ inline int groupFastPath(const uint32_t *Mw, int diag, const ReadCtx 
   }
   int matchCnt;
   int result = 1;
+  // next uncovered / covered position >= from (lowest clear / set bit of C at or above it)
+  auto nextClear = [&](int from) -> int {
+#pragma unroll
+    for (int w = 0; w < MW; ++w) {
+      if (from < (w + 1) * 64) {
+        uint64_t inv = ~C[w];
+        if (from > w * 64) inv &= ~0ull << (from - w * 64);
+        if (inv) return w * 64 + __ffsll((long long)inv) - 1;
+      }
+    }
+    return MW * 64;
+  };
+  auto nextSet = [&](int from) -> int {
+#pragma unroll
+    for (int w = 0; w < MW; ++w) {
+      if (from < (w + 1) * 64) {
+        uint64_t v = C[w];
+        if (from > w * 64) v &= ~0ull << (from - w * 64);
+        if (v) return w * 64 + __ffsll((long long)v) - 1;
+      }
+    }
+    return MW * 64;
+  };
+  auto mmIn = [&](int gsAbs, int geAbs) -> int {  // mismatches in read positions [gsAbs, geAbs)
+    const int gs = gsAbs - first, ge = geAbs - first;
+    int x = 0;
+#pragma unroll
+    for (int q = 0; q < NW; ++q) {
+      const int p0 = q * 32;
+      if (p0 < ge && p0 + 32 > gs) {
+        uint64_t msk = ~0ull;
+        if (gs > p0) msk &= ~t1k_lowmask(gs - p0);
+        if (ge < p0 + 32) msk &= t1k_lowmask(ge - p0);
+        x += __popcll(mmw[q] & msk);
+      }
+    }
+    return x;
+  };
   if (mmT <= 3) matchCnt = 2 * (span - mmT);
   else if (CLOSED) {
     // first pass: the closed form ... and the groups that are certain to fail the similarity filter whatever their gaps hold.  Every gap
@@ -218,51 +256,33 @@ __device__ inline int groupFastPath(const uint32_t *Mw, int diag, const ReadCtx 
       nGaps += __popcll(s2 & ~X[w]);
     }
     const int bound = 2 * (span - nGaps);
-    if (!earlyPrune || !((double)bound / (double)(2 * span) < simThreshold)) return 5;  // the gap walk decides (compacted list of these groups)
-    matchCnt = bound;
+    if (earlyPrune && (double)bound / (double)(2 * span) < simThreshold) matchCnt = bound;
+    else if (earlyPrune < 2) return 5;  // the gap walk decides (compacted list of these groups)
+    else {
+      // ... unless its first pass already does: per gap the mismatch count (all in the registers this pass holds).  No gap with more than
+      // three mismatches => every gap aligns ungapped and the count is exact; or the walk's own bound U = 2 * (span - sum of the small gaps'
+      // mismatches - #big gaps) fails the similarity filter => certain to be dropped.  Round 4 counted 21 % + 39 % of the groups that used to
+      // go to k_chain_fast<*, 1> in these two kinds (profiles/r04_walk_classes.txt); only the rest needs the memo and is listed for it.
+      int sumSmall = 0, nBig = 0;
+      int pos = first;
+      while (true) {
+        int gs = nextClear(pos);
+        if (gs >= spanEnd) break;
+        int ge = nextSet(gs);
+        if (ge > spanEnd) ge = spanEnd;
+        const int x = mmIn(gs, ge);
+        if (x <= 3) sumSmall += x; else ++nBig;
+        pos = ge;
+      }
+      const int upper = 2 * (span - sumSmall - nBig);
+      if (nBig != 0 && !((double)upper / (double)(2 * span) < simThreshold)) return 5;
+      matchCnt = upper;
+    }
   }
   else {
     // walk the gaps (maximal uncovered runs inside the span)
     int sumSmall = 0, nBig = 0;
     int pos = first;
-    // next uncovered / covered position >= from (lowest clear / set bit of C at or above it)
-    auto nextClear = [&](int from) -> int {
-#pragma unroll
-      for (int w = 0; w < MW; ++w) {
-        if (from < (w + 1) * 64) {
-          uint64_t inv = ~C[w];
-          if (from > w * 64) inv &= ~0ull << (from - w * 64);
-          if (inv) return w * 64 + __ffsll((long long)inv) - 1;
-        }
-      }
-      return MW * 64;
-    };
-    auto nextSet = [&](int from) -> int {
-#pragma unroll
-      for (int w = 0; w < MW; ++w) {
-        if (from < (w + 1) * 64) {
-          uint64_t v = C[w];
-          if (from > w * 64) v &= ~0ull << (from - w * 64);
-          if (v) return w * 64 + __ffsll((long long)v) - 1;
-        }
-      }
-      return MW * 64;
-    };
-    auto mmIn = [&](int gsAbs, int geAbs) -> int {  // mismatches in read positions [gsAbs, geAbs)
-      const int gs = gsAbs - first, ge = geAbs - first;
-      int x = 0;
-#pragma unroll
-      for (int q = 0; q < NW; ++q) {
-        const int p0 = q * 32;
-        if (p0 < ge && p0 + 32 > gs) {
-          uint64_t msk = ~0ull;
-          if (gs > p0) msk &= ~t1k_lowmask(gs - p0);
-          if (ge < p0 + 32) msk &= t1k_lowmask(ge - p0);
-          x += __popcll(mmw[q] & msk);
-        }
-      }
-      return x;
-    };
     // pass 1: per-gap mismatch counts -> upper bound
     while (true) {
       int gs = nextClear(pos);
@@ -1094,7 +1114,7 @@ __global__ __launch_bounds__(WG) void k_chain_fast(ChainArgs P, const uint32_t *
       const GapSink sink{P.memo + (uint64_t)re * GAP_CACHE, P.jobStr, P.counters, re * GAP_CACHE, P.jobSegCap, T1K_AR_JOBS};
       uint32_t refs[2] = {0, 0};
       int nRefs = 0;
-      kind = groupFastPath<NW, DEFER, MODE == 0>(Mw, recDiag(rv[2]), c, P.ref.alleleHasN[allele] != 0, P.k, P.hitLenRequired, P.sim, out, &dpLocal, pass, sink, refs, &nRefs, P.earlyPrune != 0);
+      kind = groupFastPath<NW, DEFER, MODE == 0>(Mw, recDiag(rv[2]), c, P.ref.alleleHasN[allele] != 0, P.k, P.hitLenRequired, P.sim, out, &dpLocal, pass, sink, refs, &nRefs, P.earlyPrune);
       if (kind == 3) {  // matchCnt lacks the registered alignments: k_chain_finish adds them from the memo
         // words 2..7: state (= number of memo slots to add), candidate, slots
         ((uint2 *)rec)[1] = make_uint2((uint32_t)nRefs, cbuf[0]);
