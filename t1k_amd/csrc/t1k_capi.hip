@@ -847,7 +847,7 @@ static int assignOnce(t1k_ctx *ctx, uint64_t first, uint32_t count) {
   if ((rc = t1k_ensure(ctx, ctx->bWgGroups, groupCap * recStride * 4))) return rc;                        // batch group records
   if ((rc = t1k_ensure(ctx, ctx->bWgStage, (size_t)n * maxChunks * 8 + 64))) return rc;                   // chunkStart | chunkCount
   const int maxK = t1k_chain_max_kmers(ctx->batchMaxLen, ctx->prm.kmer_length);
-  if ((rc = t1k_ensure(ctx, ctx->bWgHits, (size_t)n * (t1k_chain_used_u32(maxK) + 2) * 4 + 64))) return rc;  // used k-mer lists | counts
+  if ((rc = t1k_ensure(ctx, ctx->bWgHits, (size_t)n * (t1k_chain_used_u32(maxK) + 2 + 2 * T1K_USED_MASK_WORDS) * 4 + 64))) return rc;  // used k-mer lists | counts | used-offset masks
   if ((rc = t1k_ensure(ctx, ctx->bWgCache, (size_t)n * memoN * 8 + 64))) return rc;                       // per-read-end memo
   if ((rc = t1k_ensure(ctx, ctx->bWgBig, (size_t)bigBlocks * 64 * t1k_chain_big_scratch_u32() * 4))) return rc;
   // work lists: every list exists twice, as a striped arena the kernels append to and as the dense list its consumer reads
@@ -903,7 +903,7 @@ static int assignOnce(t1k_ctx *ctx, uint64_t first, uint32_t count) {
   const int relaxFlag = ctx->prm.relax_intron_align;
   a.recs = (uint32_t *)ctx->bWgGroups.p; a.recStride = (uint32_t)recStride; a.groupCap = groupCap;
   a.chunkStart = (uint32_t *)ctx->bWgStage.p; a.chunkCount = a.chunkStart + (size_t)n * maxChunks; a.maxChunks = maxChunks;
-  a.usedOut = (uint32_t *)ctx->bWgHits.p; a.usedCount = a.usedOut + (size_t)n * t1k_chain_used_u32(maxK); a.maxK = (uint32_t)maxK;
+  a.usedOut = (uint32_t *)ctx->bWgHits.p; a.usedCount = a.usedOut + (size_t)n * t1k_chain_used_u32(maxK); a.usedMask = a.usedCount + (size_t)n * 2; a.maxK = (uint32_t)maxK;
   a.maxKFast = (uint32_t)t1k_chain_max_kmers(ctx->batchFastMaxLen, ctx->prm.kmer_length);
   a.memo = (unsigned long long *)ctx->bWgCache.p;
   a.jobList = (uint32_t *)ctx->bLists.p; a.jobCap = jobCap;

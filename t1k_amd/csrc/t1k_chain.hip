@@ -452,14 +452,18 @@ __device__ __forceinline__ VoteKey voteKey(int matchCnt0, int rs, int re, uint32
 // ------------------------------------------------------------------------------------------------------------------
 #define CHUNK_A T1K_SEED_CHUNK
 // record word 2 before chaining: reference diagonal (22 bits, biased; alleles are shorter than 2^20 bases) and the counts of hits off
-// it, far (bits 22..26, saturating at 31) and near = within `radius` (bits 27..29, saturating at 7) -- the chain only asks
-// "near > 0" and "far > 2".  Bits 30 and 31 stay clear: after chaining the word holds the state, whose REC_DONE is bit 31.
+// it: FAR = beyond `radius` diagonals (bits 22..24, saturating at 7) and NEAR = within `radius` (bits 25..29, saturating at 31) -- the
+// chain asks "near > 0" and "far > 2" (several diagonals: the general path), k_near_hits asks for "far == 0" and the exact near count
+// (31 = unknown).  Bits 30 and 31 stay clear: after chaining the word holds the state, whose REC_DONE is bit 31.
 __device__ __forceinline__ uint32_t packDiagMeta(int diag, uint32_t meta) {
-  const uint32_t strays = meta & 0xFFFFu, nearCnt = meta >> 16;
-  return (uint32_t)(diag + (1 << 21)) | (min(strays, 31u) << 22) | (min(nearCnt, 7u) << 27);
+  const uint32_t strays = meta & 0xFFFFu, nearCnt = meta >> 16;  // (strays counts every hit off the reference diagonal, near ones included)
+  return (uint32_t)(diag + (1 << 21)) | (min(strays - nearCnt, 7u) << 22) | (min(nearCnt, 31u) << 25);
 }
 __device__ __forceinline__ int recDiag(uint32_t w2) { return (int)(w2 & 0x3FFFFFu) - (1 << 21); }
-__device__ __forceinline__ bool recIsGeneral(uint32_t w2) { return ((w2 >> 27) & 7u) > 0 || ((w2 >> 22) & 31u) > 2; }
+__device__ __forceinline__ uint32_t recFar(uint32_t w2) { return (w2 >> 22) & 7u; }
+__device__ __forceinline__ uint32_t recNear(uint32_t w2) { return (w2 >> 25) & 31u; }
+__device__ __forceinline__ bool recIsGeneral(uint32_t w2) { return recNear(w2) > 0 || recFar(w2) > 2; }
+#define REC_NEAR_DONE 0x4E454152u  // record word 5 of a multi-diagonal group whose hit list k_near_hits wrote (k_gather_general leaves it alone)
 #define DIAG_EMPTY 0x7FFFFFFF
 
 template <int NW>
@@ -502,6 +506,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(T1K_SEED_WAV
 #ifdef T1K_SEED_PROFILE
   uint64_t tp_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tl_ = __builtin_amdgcn_s_memtime();
 #endif
+  __shared__ uint32_t sUMask[2 * T1K_USED_MASK_WORDS];  // read offsets whose lists are used, per strand
   __shared__ unsigned long long sStat[3];             // lookups, postings, hits: thread 0 tallies them in LDS (three 64-bit counters in registers would be held by every lane), flushed once per workgroup
   if (tid == 0) { sStat[0] = 0; sStat[1] = 0; sStat[2] = 0; }
   for (uint32_t re = blockIdx.x; re < P.reads.nReadEnds; re += gridDim.x) {
@@ -515,6 +520,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(T1K_SEED_WAV
     // (... and one whose lists an earlier window of the job holds is not seeded at all: t1k_xwin_link)
     if (len < k || len > T1K_MAX_READ_LEN || (P.reads.skip && P.reads.skip[re])) { __syncthreads(); continue; }  // GetOverlapsFromRead returns -1 (SeqSet.hpp:1598-1599)
     const int nk = len - k + 1;
+    if (tid < 2 * T1K_USED_MASK_WORDS) sUMask[tid] = 0;  // (read by the previous read-end before its chunk loop's barriers)
     for (int q = tid; q < 2 * nk; q += WG) {
       int pass = q / nk, p = q - pass * nk;
       const uint64_t *b = rbase + pass * S, *nm = rnm + pass * S;
@@ -638,17 +644,21 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(T1K_SEED_WAV
     { const uint64_t tn_ = __builtin_amdgcn_s_memtime(); tp_[1] += tn_ - tl_; tl_ = tn_; }
 #endif
 
-    // the used lists are kept for k_chain_general, which re-derives the hits of the few multi-diagonal groups
+    // the used lists are kept for k_chain_general, which re-derives the hits of the few multi-diagonal groups; which read offsets have
+    // their lists used goes out per strand as bit masks as well (k_near_hits rebuilds the hits on near diagonals from them; sUMask was
+    // cleared at the top of this read-end, before the barriers of the look-up phase)
     {
       uint32_t *uo = P.usedOut + (uint64_t)re * P.maxK * 4;
       for (uint32_t u = tid; u < nUsedPlus + nUsedMinus; u += WG) {
         int q = usedQ[u];
         int pass = u < nUsedPlus ? 0 : 1;
         uo[4 * u] = (uint32_t)(q - pass * nk); uo[4 * u + 1] = ukStart[q]; uo[4 * u + 2] = ukLen[q]; uo[4 * u + 3] = ukDir[q];
+        atomicOr(&sUMask[pass * T1K_USED_MASK_WORDS + ((q - pass * nk) >> 5)], 1u << ((q - pass * nk) & 31));
       }
     }
     // what the chunk loop needs of the used lists moves out of the overlay, then the accumulators under it are made clean again
     __syncthreads();
+    if (tid < 2 * T1K_USED_MASK_WORDS) P.usedMask[(uint64_t)re * 2 * T1K_USED_MASK_WORDS + tid] = sUMask[tid];
     for (uint32_t u = tid; u < nUsedPlus + nUsedMinus; u += WG) {
       const int q = usedQ[u];
       const int pass = u < nUsedPlus ? 0 : 1;
@@ -1045,7 +1055,7 @@ __global__ __launch_bounds__(WG) void k_seed_long(ChainArgs P) {
             if (cnt[tid * PER + i] < 3u) continue;
             uint4 *rec = (uint4 *)(P.recs + (uint64_t)(groupBase + slot) * stride);
             // words 0..2: read-end | '+' strand, allele, "several diagonals" (recIsGeneral: near count 1, diagonal 0); the rest is the chain's
-            rec[0] = make_uint4(re | (pass == 0 ? 0x80000000u : 0u), c0 + tid * PER + i, (1u << 21) | (1u << 27), 0u);
+            rec[0] = make_uint4(re | (pass == 0 ? 0x80000000u : 0u), c0 + tid * PER + i, (1u << 21) | (31u << 25), 0u);  // near = 31: "count unknown", the hits come from the used lists
             for (uint32_t w = 1; w < stride / 4; ++w) rec[w] = make_uint4(0u, 0u, 0u, 0u);
             ++slot;
           }
@@ -1207,8 +1217,134 @@ __device__ inline int gatherHits(const ChainArgs &P, uint32_t re, int pass, uint
 // each finds the allele's run in its lists (sorted by allele, then offset) and the hits are written to the hit arena;
 // record word 4 = arena offset, word 5 = hit count (0xFFFFFFFF: handed to k_chain_big)
 // ROUNDS: used lists of one strand over the 64 lanes (5: reads <= 320 bp; 16: up to T1K_LONG_READ_LEN)
+// ------------------------------------------------------------------------------------------------------------------
+// K5a': hit lists of the multi-diagonal groups WITHOUT the posting lists.  Most such groups have all their hits within `radius` diagonals
+// of the reference diagonal (a read with an indel: every one of its ~2000 groups; an allele with a small indel under the read): far == 0
+// in the record.  A hit is a posting (allele, b) of a USED list of read offset a: the read's k-mer at a equals the allele's at b, that
+// k-mer of the allele was inserted (the `posted` bitmap of the index: valid + the reference's insert rule), and a's list is used (the
+// read-end's used-offset mask).  All three are bit masks over the read offsets, per diagonal d = a - b -- so one lane rebuilds the hit
+// list of a group from the packed read, ~7 words of the allele's text and of `posted`, with shifts and ANDs, for the 2 * radius + 1
+// diagonals, instead of a wavefront bisecting ~130 posting lists (k_gather_general: 9 dependent loads a lane, 2.8 KB fetched a group).
+// Checked, not assumed: the mask of the reference diagonal must equal the record's (which came from the postings themselves), and the
+// hits on the other diagonals must number exactly the record's near count; anything else (far strays, a saturated count, windows at
+// the ends of the packed text) leaves the group to k_gather_general.  Record word 5 = REC_NEAR_DONE marks a group done here.
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t evenBits32(uint64_t x) {  // bit 2j of x -> bit j
+  x &= 0x5555555555555555ull;
+  x = (x | (x >> 1)) & 0x3333333333333333ull; x = (x | (x >> 2)) & 0x0F0F0F0F0F0F0F0Full; x = (x | (x >> 4)) & 0x00FF00FF00FF00FFull;
+  x = (x | (x >> 8)) & 0x0000FFFF0000FFFFull; x = (x | (x >> 16)) & 0xFFFFFFFFull;
+  return (uint32_t)x;
+}
+template <int NW>
+__global__ __launch_bounds__(WG) void k_near_hits(ChainArgs P, uint32_t nItems) {
+  constexpr int NQ = NW + 1;  // 64-bit words (32 positions each) of the per-position masks: one spare word for the k-mer's reach
+  const uint32_t q = blockIdx.x * WG + threadIdx.x;
+  bool toWave = false;
+  uint32_t gi = 0;
+  if (q < nItems) {
+    gi = P.generalList[q];
+    uint32_t *rec = P.recs + (uint64_t)gi * P.recStride;
+    constexpr int RW = NW == 5 ? 8 : 16;
+    uint32_t rv[RW];
+#pragma unroll
+    for (int w = 0; w < RW / 4; ++w) { const uint4 q4 = ((const uint4 *)rec)[w]; rv[4 * w] = q4.x; rv[4 * w + 1] = q4.y; rv[4 * w + 2] = q4.z; rv[4 * w + 3] = q4.w; }
+    const uint32_t re = rv[0] & 0x7FFFFFFFu, allele = rv[1];
+    const int pass = (rv[0] >> 31) ? 0 : 1;
+    const int d0 = recDiag(rv[2]), k = P.k, R = P.radius;
+    const uint32_t nearCnt = recNear(rv[2]);
+    uint32_t onDiag = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) onDiag += __popc(rv[3 + w]);
+    const int64_t goff = (int64_t)P.ref.alleleOff[allele];
+    const int alleleLen = (int)P.ref.alleleLen[allele];
+    const int64_t W0 = goff - d0 - R;  // global position under read offset 0 on the diagonal d0 + R
+    const int64_t lastWord = (W0 >> 5) + NQ + 2;
+    bool ok = recFar(rv[2]) == 0 && nearCnt > 0 && nearCnt < 31 && R <= 15 && W0 >= 0 && (uint64_t)lastWord < (P.ref.totalBases >> 5) + 7;
+    uint32_t base = T1K_ARENA_FULL;
+    const uint32_t n = onDiag + nearCnt;
+    if (ok) { base = t1k_arena_alloc(P.counters, T1K_AR_GENHITS, n, P.genHitSegCap); ok = base != T1K_ARENA_FULL; }
+    if (ok) {
+      const int S = P.reads.S;
+      const uint64_t *rb = P.reads.bases + ((uint64_t)re * 2 + pass) * S;
+      const uint32_t *um = P.usedMask + ((uint64_t)re * 2 + pass) * T1K_USED_MASK_WORDS;
+      uint64_t Rr[NQ], G[NQ + 2], PG[NQ + 2];
+#pragma unroll
+      for (int j = 0; j < NQ; ++j) Rr[j] = j < S ? rb[j] : 0ull;
+      const uint64_t *gb = P.ref.bases + (W0 >> 5), *pb = P.ref.posted + (W0 >> 5);
+#pragma unroll
+      for (int j = 0; j < NQ + 2; ++j) { G[j] = gb[j]; PG[j] = pb[j]; }
+      const int sh0 = (int)(W0 & 31);
+      uint32_t w = base, cntNear = 0;
+      bool same0 = false;
+      for (int dl = -R; dl <= R; ++dl) {
+        const int d = d0 + dl;
+        const int o = sh0 + (R - dl);          // base offset of read position 0 inside G (0 .. 31 + 2R < 64)
+        const bool up = o >= 32;
+        const int bsh = (o & 31) * 2;
+        uint64_t acc[NQ], pst[NQ];
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+          const uint64_t lo = up ? G[j + 1] : G[j], hi = up ? G[j + 2] : G[j + 1];
+          const uint64_t g = bsh ? ((lo >> bsh) | (hi << (64 - bsh))) : lo;
+          const uint64_t x = g ^ Rr[j];
+          acc[j] = ~(x | (x >> 1)) & 0x5555555555555555ull;   // bit 2p: the bases at position 32 j + p are equal
+          const uint64_t pl = up ? PG[j + 1] : PG[j], ph = up ? PG[j + 2] : PG[j + 1];
+          pst[j] = bsh ? ((pl >> bsh) | (ph << (64 - bsh))) : pl;
+        }
+        // acc(a) = AND over t < k of eq(a + t), by doubling (a shift by m positions = 2 m bits towards lower positions)
+        auto andShifted = [&](int m) {
+          const int b = 2 * m;
+#pragma unroll
+          for (int j = 0; j < NQ; ++j) { const uint64_t nx = j + 1 < NQ ? acc[j + 1] : 0ull; acc[j] &= (acc[j] >> b) | (nx << (64 - b)); }
+        };
+        {
+          int have = 1;
+          while (2 * have <= k) { andShifted(have); have *= 2; }
+          if (have < k) andShifted(k - have);
+        }
+        // hits of this diagonal: equal k-mers, posted in the index, the read offset's list used, the k-mer inside THIS allele
+        const int aLo = d > 0 ? d : 0, aHi = d + alleleLen - k;  // b = a - d in [0, alleleLen - k]
+#pragma unroll
+        for (int j = 0; j < NW; ++j) {
+          uint32_t m = evenBits32(acc[j] & pst[j]) & um[j];
+          const int p0 = 32 * j;
+          if (aLo > p0) m &= aLo - p0 >= 32 ? 0u : ~0u << (aLo - p0);
+          if (aHi < p0 + 31) m &= aHi < p0 ? 0u : ~0u >> (31 - (aHi - p0));
+          if (dl == 0) { if (j == 0) same0 = true; same0 = same0 && m == rv[3 + j]; continue; }
+          cntNear += __popc(m);
+          while (m) {
+            const int p = __ffs((int)m) - 1;
+            m &= m - 1;
+            const uint32_t a = (uint32_t)(p0 + p);
+            if (w < base + n) P.genHits[w] = ((uint32_t)((int)a - d) << 12) | a;
+            ++w;
+          }
+        }
+      }
+      ok = same0 && cntNear == nearCnt;
+      if (ok) {
+        // ... and the reference diagonal's own hits, from the record's mask
+#pragma unroll
+        for (int j = 0; j < NW; ++j) {
+          uint32_t m = rv[3 + j];
+          while (m) {
+            const int p = __ffs((int)m) - 1;
+            m &= m - 1;
+            const uint32_t a = (uint32_t)(32 * j + p);
+            P.genHits[w++] = ((uint32_t)((int)a - d0) << 12) | a;
+          }
+        }
+        rec[3] = base; rec[4] = n;
+        toWave = n > GENERAL_SMALL;
+      }
+    }
+    rec[5] = ok ? REC_NEAR_DONE : 0u;
+  }
+  if (toWave) { const uint32_t wq = t1k_arena_append(P.counters, T1K_AR_WAVE, P.rareSegCap); if (wq != T1K_ARENA_FULL) P.waveStr[wq] = gi; }
+}
+
 template <int ROUNDS>
-__global__ __launch_bounds__(WG) void k_gather_general(ChainArgs P, uint32_t nItems) {
+__global__ __launch_bounds__(WG) void k_gather_general(ChainArgs P, uint32_t nItems, int skipDone) {
   const int lane = threadIdx.x & 63;
   const uint32_t wave = (blockIdx.x * WG + threadIdx.x) >> 6, nWaves = gridDim.x * (WG / 64);
   const int maxK = (int)P.maxK;
@@ -1216,6 +1352,7 @@ __global__ __launch_bounds__(WG) void k_gather_general(ChainArgs P, uint32_t nIt
   for (uint32_t q = wave; q < nItems; q += nWaves) {
     const uint32_t gi = P.generalList[q];
     uint32_t *rec = P.recs + (uint64_t)gi * P.recStride;
+    if (skipDone && rec[5] == REC_NEAR_DONE) continue;  // k_near_hits wrote this group's hits (uniform over the wavefront)
     const uint32_t re = rec[0] & 0x7FFFFFFFu, allele = rec[1];
     const int pass = (rec[0] >> 31) ? 0 : 1;
     const uint32_t nPlus = P.usedCount[2 * re], nMinus = P.usedCount[2 * re + 1];
@@ -1746,8 +1883,14 @@ int t1k_run_chain(t1k_ctx *ctx, const ChainArgs &a, int nWg, int bigBlocks, bool
   }
   uint32_t nBig = 0;
   if (nGen) {
-    if (xlong) hipLaunchKernelGGL(k_gather_general<(T1K_LONG_READ_LEN + 63) / 64>, dim3(std::min<uint32_t>((nGen + 3) / 4, 8192u)), dim3(WG), 0, ctx->stream, a, nGen);
-    else hipLaunchKernelGGL(k_gather_general<GROUP_FAST_MAXLEN / 64>, dim3(std::min<uint32_t>((nGen + 3) / 4, 8192u)), dim3(WG), 0, ctx->stream, a, nGen);
+    static const bool nearHits = getenv("T1K_NO_NEAR_HITS") == nullptr;
+    const int skipDone = nearHits && !xlong ? 1 : 0;
+    if (skipDone) {
+      if (longReads) hipLaunchKernelGGL(k_near_hits<10>, dim3((nGen + WG - 1) / WG), dim3(WG), 0, ctx->stream, a, nGen);
+      else hipLaunchKernelGGL(k_near_hits<5>, dim3((nGen + WG - 1) / WG), dim3(WG), 0, ctx->stream, a, nGen);
+    }
+    if (xlong) hipLaunchKernelGGL(k_gather_general<(T1K_LONG_READ_LEN + 63) / 64>, dim3(std::min<uint32_t>((nGen + 3) / 4, 8192u)), dim3(WG), 0, ctx->stream, a, nGen, skipDone);
+    else hipLaunchKernelGGL(k_gather_general<GROUP_FAST_MAXLEN / 64>, dim3(std::min<uint32_t>((nGen + 3) / 4, 8192u)), dim3(WG), 0, ctx->stream, a, nGen, skipDone);
     ChainArgs g = a;
     if (nGen >= 4096 && t1k_ensure(ctx, ctx->bJobSort, (size_t)nGen * 20 + 64) == T1K_OK) {  // groups of similar size side by side
       unsigned long long *k0 = (unsigned long long *)ctx->bJobSort.p, *k1 = k0 + nGen;

@@ -100,6 +100,7 @@ struct T1kRefDev {
   uint32_t nAlleles;
   uint64_t totalBases;          // padded global base count
   const uint64_t *bases, *nmask, *exon;
+  const uint64_t *posted;       // same geometry as nmask: bit 2(i&31) of word i>>5 = the k-mer STARTING at global position i has a posting (valid + the reference's insert rule, KmerIndex.hpp:121)
   const uint64_t *alleleOff;    // [A]
   const uint32_t *alleleLen;    // [A]
   const uint8_t *alleleHasN;    // [A] 1 if the allele holds an N anywhere (its N-mask words can be skipped otherwise)

@@ -3,6 +3,7 @@
 #include <mutex>
 #include "t1k_dev.h"
 
+#define T1K_USED_MASK_WORDS 10
 struct ChainArgs {
   T1kRefDev ref;
   T1kReadsDev reads;
@@ -10,6 +11,7 @@ struct ChainArgs {
   double sim;
   uint32_t *recs; uint32_t recStride; uint64_t groupCap;   // group records: re|strand, allele, diag, meta, M[...]
   uint32_t *chunkStart, *chunkCount; int maxChunks;        // [re][maxChunks] runs of groups per (strand, allele chunk), reference order
+  uint32_t *usedMask;                                      // [re][2][T1K_USED_MASK_WORDS] bit r = the list of the k-mer at read offset r (that strand) is used (k_near_hits rebuilds hits on near diagonals from it)
   uint32_t *usedOut, *usedCount;                           // [re][maxK][4] used k-mers (readOff, listStart, listLen, directory row); [re][2] counts per strand
   unsigned long long *memo;                                // [re][GAP_CACHE] memo of gap alignments
   uint32_t *jobList; uint32_t jobCap;

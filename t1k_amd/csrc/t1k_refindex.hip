@@ -78,6 +78,17 @@ __global__ void k_ref_codes(const uint64_t *bases, const uint64_t *nmask, const 
   }
   flag[g] = f; code[g] = c;
 }
+// posted bitmap (nmask geometry) from the per-END-position insert flags: the window starting at s ends at s + k - 1
+__global__ void k_ref_posted(const uint32_t *flag, uint64_t total, int k, uint64_t nWords, uint64_t *posted) {
+  const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= nWords) return;
+  uint64_t v = 0;
+  for (int q = 0; q < 32; ++q) {
+    const uint64_t e = w * 32 + q + (uint64_t)(k - 1);
+    if (e < total && flag[e]) v |= 1ull << (2 * q);
+  }
+  posted[w] = v;
+}
 __global__ void k_ref_compact(const uint32_t *flag, const uint32_t *pos, const uint32_t *code, unsigned long long *key, uint32_t *val, uint64_t total) {
   const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g < total && flag[g]) { key[pos[g] - 1] = code[g]; val[pos[g] - 1] = (uint32_t)g; }
@@ -220,8 +231,8 @@ extern "C" int t1k_ref_upload(t1k_ctx *ctx, const char *seqs, const uint64_t *of
   r.totalBases = total;
   int rc;
   // resident arrays
-  void *dBases, *dN, *dExon, *dAlleleOff, *dAlleleLen, *dHasN, *dSepStart, *dSepPos;
-  if ((rc = keep(ctx, (nWords + 8) * 8, &dBases)) || (rc = keep(ctx, (nWords + 8) * 8, &dN)) || (rc = keep(ctx, (nWords + 8) * 8, &dExon))  // (+8: kernels fetch a window as six whole words)
+  void *dBases, *dN, *dExon, *dAlleleOff, *dAlleleLen, *dHasN, *dSepStart, *dSepPos, *dPosted;
+  if ((rc = keep(ctx, (nWords + 8) * 8, &dPosted)) || (rc = keep(ctx, (nWords + 8) * 8, &dBases)) || (rc = keep(ctx, (nWords + 8) * 8, &dN)) || (rc = keep(ctx, (nWords + 8) * 8, &dExon))  // (+8: kernels fetch a window as six whole words)
       || (rc = keep(ctx, (size_t)nAlleles * 8, &dAlleleOff)) ||
       (rc = keep(ctx, (size_t)nAlleles * 4, &dAlleleLen)) || (rc = keep(ctx, nAlleles, &dHasN)) || (rc = keep(ctx, (size_t)(nAlleles + 1) * 4, &dSepStart)) ||
       (rc = keep(ctx, sepPos.size() * 4, &dSepPos)))
@@ -250,6 +261,8 @@ extern "C" int t1k_ref_upload(t1k_ctx *ctx, const char *seqs, const uint64_t *of
   // inserted windows
   hipLaunchKernelGGL(k_ref_codes, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const uint64_t *)dBases, (const uint64_t *)dN, (const uint64_t *)dAlleleOff,
                      (const uint32_t *)dAlleleLen, (const uint32_t *)bWordAllele.p, total, k, (uint32_t *)bFlag.p, (uint32_t *)bCode.p);
+  RU_HIP(hipMemsetAsync(dPosted, 0, (nWords + 8) * 8, st));
+  hipLaunchKernelGGL(k_ref_posted, dim3((unsigned)((nWords + 255) / 256)), dim3(256), 0, st, (const uint32_t *)bFlag.p, total, k, nWords, (uint64_t *)dPosted);
   if ((rc = t1k_inclusive_sum(ctx, (const uint32_t *)bFlag.p, (uint32_t *)bPos.p, (uint32_t)total))) { freeScratch(); return rc; }
   uint32_t M = 0;
   RU_HIP(hipMemcpyAsync(&M, (uint32_t *)bPos.p + (total - 1), 4, hipMemcpyDeviceToHost, st));
@@ -313,7 +326,7 @@ extern "C" int t1k_ref_upload(t1k_ctx *ctx, const char *seqs, const uint64_t *of
   RU_HIP(hipStreamSynchronize(st));
   freeScratch2();
 #undef RU_HIP
-  r.bases = (const uint64_t *)dBases; r.nmask = (const uint64_t *)dN; r.exon = (const uint64_t *)dExon;
+  r.bases = (const uint64_t *)dBases; r.nmask = (const uint64_t *)dN; r.exon = (const uint64_t *)dExon; r.posted = (const uint64_t *)dPosted;
   r.alleleOff = (const uint64_t *)dAlleleOff; r.alleleLen = (const uint32_t *)dAlleleLen; r.alleleHasN = (const uint8_t *)dHasN;
   r.anyN = 0;
   for (uint8_t h : alleleHasN) r.anyN |= h;
