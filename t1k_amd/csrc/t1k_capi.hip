@@ -917,6 +917,7 @@ static int assignOnce(t1k_ctx *ctx, uint64_t first, uint32_t count) {
   a.genJobStr = a.genHits + genHitCap; a.genJobList = a.genJobStr + genJobCap; a.genJobSegCap = genJobCap / T1K_NSTRIPE;
   a.groupSegCap = groupSegCap; a.jobSegCap = jobSegCap; a.listSegCap = listSegCap; a.rareSegCap = rareSegCap; a.genCandSegCap = genCandSegCap;
   a.bigScratch = (uint32_t *)ctx->bWgBig.p;
+  { static const int ns = getenv("T1K_NO_SIMPLE_CHAIN") ? 0 : 1; a.nearSimple = ns; }
   { static const int ep = getenv("T1K_NO_EARLY_PRUNE") ? 0 : getenv("T1K_WALK_IN_CLOSED") ? atoi(getenv("T1K_WALK_IN_CLOSED")) + 1 : 2; a.earlyPrune = ep; }  // 0: none, 1: the closed-form pass prunes with the gap-count bound, 2: ... and runs the gap walk's first pass
   a.cand = (T1kCand *)ctx->bCand.p; a.candCap = ctx->wCand;
   a.candStart = (uint32_t *)ctx->bCandStart.p; a.candCount = (uint32_t *)ctx->bCandCount.p;

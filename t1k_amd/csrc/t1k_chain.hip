@@ -336,9 +336,9 @@ __device__ inline int groupFastPath(const uint32_t *Mw, int diag, const ReadCtx 
 // LIS over the read offsets, chain -> A[s..), hit lengths, seed-chain match count, candidate (SeqSet.hpp:352-436, 1512-1551, 1697-1833)
 template <class Arr>
 __device__ inline void chainRun(const ReadCtx &c, int k, int hitLenRequired, Arr A, Arr B, Arr C, int s, int m, int *gaScratch, int gaMax, CandOut &out,
-                                unsigned int *dpCounter, unsigned long long *errFlags, bool *needScratch, const GapSink *sink, int strandBit) {
+                                unsigned int *dpCounter, unsigned long long *errFlags, bool *needScratch, const GapSink *sink, int strandBit, bool chainReady = false) {
     int ret, lenR, lenS;
-    if (!t1k_run_lis(A, B, C, s, m, k, hitLenRequired, &ret, &lenR, &lenS)) return;
+    if (!t1k_run_lis(A, B, C, s, m, k, hitLenRequired, &ret, &lenR, &lenS, chainReady)) return;
     // seed-chain match count (1697-1833).  With a sink the alignments are registered in the read-end's memo instead of being
     // run here; the candidate then carries the memo slots (k_general_finish adds their match counts).
     uint32_t refs[3] = {0, 0, 0};
@@ -425,6 +425,19 @@ __device__ inline void groupGeneral(const uint32_t *h, int n, const ReadCtx &c, 
     chainRun(c, k, hitLenRequired, A, B, C, s, m, gaScratch, gaMax, out, dpCounter, errFlags, needScratch, sink, strandBit);
     s = e;
   }
+}
+
+// A multi-diagonal group whose hit list k_near_hits found to be a chain already (two diagonals, the hits of one entirely before the
+// other's on the read AND on the allele; written in that order): one diagonal run (the diagonals lie within `radius`), every read offset
+// occurs once so the nearest-to-dominant filter keeps everything, the order by allele offset is the order given, its read offsets ascend
+// strictly so the LIS is the whole list, no allele offset repeats.  What is left of GetOverlapsFromHits are the length tests and the
+// chain walk -- the same code as the general path runs after its sorts (SeqSet.hpp:1400-1405, 1468, 1512-1551, 1697-1833).
+template <class Arr>
+__device__ inline void groupSimple(const uint32_t *h, int n, const ReadCtx &c, int k, int hitLenRequired, Arr A, CandOut &out, unsigned int *dpCounter,
+                                   unsigned long long *errFlags, bool *needScratch, const GapSink *sink, int strandBit) {
+  for (int i = 0; i < n; ++i) A[i] = h[i];
+  if (n < 3 || n * k < hitLenRequired) return;
+  chainRun(c, k, hitLenRequired, A, A, A, 0, n, nullptr, 0, out, dpCounter, errFlags, needScratch, sink, strandBit, true);
 }
 
 // key of the strand vote: _overlap::operator< with similarity == 0 (SeqSet.hpp:103-127, 1623-1627); smaller = better
@@ -1276,6 +1289,10 @@ __global__ __launch_bounds__(WG) void k_near_hits(ChainArgs P, uint32_t nItems) 
       const int sh0 = (int)(W0 & 31);
       uint32_t w = base, cntNear = 0;
       bool same0 = false;
+      int nearDiags = 0, d1 = 0;    // near diagonals that hold hits; the first one and its mask
+      uint32_t M1[NW];
+#pragma unroll
+      for (int j = 0; j < NW; ++j) M1[j] = 0;
       for (int dl = -R; dl <= R; ++dl) {
         const int d = d0 + dl;
         const int o = sh0 + (R - dl);          // base offset of read position 0 inside G (0 .. 31 + 2R < 64)
@@ -1311,6 +1328,10 @@ __global__ __launch_bounds__(WG) void k_near_hits(ChainArgs P, uint32_t nItems) 
           if (aLo > p0) m &= aLo - p0 >= 32 ? 0u : ~0u << (aLo - p0);
           if (aHi < p0 + 31) m &= aHi < p0 ? 0u : ~0u >> (31 - (aHi - p0));
           if (dl == 0) { if (j == 0) same0 = true; same0 = same0 && m == rv[3 + j]; continue; }
+          if (m) {
+            if (nearDiags == 0 || d1 != d) { ++nearDiags; if (nearDiags == 1) d1 = d; }
+            if (nearDiags == 1) M1[j] = m;
+          }
           cntNear += __popc(m);
           while (m) {
             const int p = __ffs((int)m) - 1;
@@ -1322,7 +1343,38 @@ __global__ __launch_bounds__(WG) void k_near_hits(ChainArgs P, uint32_t nItems) 
         }
       }
       ok = same0 && cntNear == nearCnt;
-      if (ok) {
+      // two diagonals whose hits follow one another on the read and on the allele: the list IS its chain (groupSimple)
+      bool simple = false;
+      if (ok && P.nearSimple && nearDiags == 1 && n >= 3 && (int)n * k >= P.hitLenRequired) {
+        int lo0 = -1, hi0 = -1, lo1 = -1, hi1 = -1;
+#pragma unroll
+        for (int j = 0; j < NW; ++j) {
+          if (rv[3 + j]) { if (lo0 < 0) lo0 = 32 * j + __ffs((int)rv[3 + j]) - 1; hi0 = 32 * j + 31 - __clz((int)rv[3 + j]); }
+          if (M1[j]) { if (lo1 < 0) lo1 = 32 * j + __ffs((int)M1[j]) - 1; hi1 = 32 * j + 31 - __clz((int)M1[j]); }
+        }
+        const bool first0 = hi0 < lo1 && hi0 - d0 < lo1 - d1, first1 = hi1 < lo0 && hi1 - d1 < lo0 - d0;
+        if (first0 || first1) {
+          simple = true;
+          w = base;
+          for (int part = 0; part < 2; ++part) {
+            const bool zero = (part == 0) == first0;  // this part is the reference diagonal's
+            const int dd = zero ? d0 : d1;
+#pragma unroll
+            for (int j = 0; j < NW; ++j) {
+              uint32_t m = zero ? rv[3 + j] : M1[j];
+              while (m) {
+                const int p = __ffs((int)m) - 1;
+                m &= m - 1;
+                const uint32_t a = (uint32_t)(32 * j + p);
+                P.genHits[w++] = ((uint32_t)((int)a - dd) << 12) | a;
+              }
+            }
+          }
+        }
+      }
+      if (ok && simple) { rec[3] = base; rec[4] = n; rec[6] = 1u; toWave = n > 3 * GENERAL_SMALL; }
+      else if (ok) {
+        rec[6] = 0u;
         // ... and the reference diagonal's own hits, from the record's mask
 #pragma unroll
         for (int j = 0; j < NW; ++j) {
@@ -1339,6 +1391,7 @@ __global__ __launch_bounds__(WG) void k_near_hits(ChainArgs P, uint32_t nItems) 
       }
     }
     rec[5] = ok ? REC_NEAR_DONE : 0u;
+    if (!ok) rec[6] = 0u;
   }
   if (toWave) { const uint32_t wq = t1k_arena_append(P.counters, T1K_AR_WAVE, P.rareSegCap); if (wq != T1K_ARENA_FULL) P.waveStr[wq] = gi; }
 }
@@ -1414,13 +1467,20 @@ __global__ __launch_bounds__(WG) void k_gather_general(ChainArgs P, uint32_t nIt
 // K5b: multi-diagonal groups with at most GENERAL_SMALL hits, one lane per group, 64-thread workgroups; the three work arrays
 // live in LDS, interleaved over the lanes (24 KB).  Alignments go through the read-end's memo (registered now, run by
 // k_dp_dense, added by k_general_finish); groups that need an alignment wider than the register band go to k_chain_big.
-__global__ __launch_bounds__(64) void k_chain_general(ChainArgs P, uint32_t nItems) {
+// useSimple: record word 6 = 1 marks a group whose hit list k_near_hits wrote as its chain (groupSimple: no sorts, no LIS, one array -- up
+// to 3 * GENERAL_SMALL hits in the same LDS)
+__global__ __launch_bounds__(64) void k_chain_general(ChainArgs P, uint32_t nItems, int useSimple) {
   __shared__ uint32_t sArr[3 * GENERAL_SMALL * 64];
   const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
   unsigned int dpLocal = 0, genLocal = 0;
   uint32_t nHits = 0xFFFFFFFFu;
-  if (q < nItems) nHits = P.recs[(uint64_t)P.generalList[q] * P.recStride + 4];
-  if (nHits <= GENERAL_SMALL) {
+  bool simple = false;
+  if (q < nItems) {
+    const uint32_t *r0 = P.recs + (uint64_t)P.generalList[q] * P.recStride;
+    nHits = r0[4];
+    simple = useSimple && r0[5] == REC_NEAR_DONE && r0[6] == 1u;
+  }
+  if (nHits <= GENERAL_SMALL || (simple && nHits <= 3 * GENERAL_SMALL)) {
     const uint32_t gi = P.generalList[q];
     uint32_t *rec = P.recs + (uint64_t)gi * P.recStride;
     const uint32_t re = rec[0] & 0x7FFFFFFFu, allele = rec[1];
@@ -1434,7 +1494,8 @@ __global__ __launch_bounds__(64) void k_chain_general(ChainArgs P, uint32_t nIte
     CandOut out{cbuf, 0, 6, GENERAL_SMALL / 3 + 1};
     const GapSink sink{P.memo + (uint64_t)re * GAP_CACHE, P.genJobStr, P.counters, re * GAP_CACHE, P.genJobSegCap, T1K_AR_GENJOBS};
     LaneArr A{sArr + threadIdx.x}, B{sArr + GENERAL_SMALL * 64 + threadIdx.x}, C{sArr + 2 * GENERAL_SMALL * 64 + threadIdx.x};
-    groupGeneral(hh, n, c, P.k, P.radius, P.hitLenRequired, A, B, C, nullptr, 0, out, &dpLocal, &P.counters[2], &needScratch, &sink, pass);
+    if (simple) groupSimple(hh, n, c, P.k, P.hitLenRequired, A, out, &dpLocal, &P.counters[2], &needScratch, &sink, pass);
+    else groupGeneral(hh, n, c, P.k, P.radius, P.hitLenRequired, A, B, C, nullptr, 0, out, &dpLocal, &P.counters[2], &needScratch, &sink, pass);
     if (needScratch) { const uint32_t b = t1k_arena_append(P.counters, T1K_AR_BIG, P.rareSegCap); if (b != T1K_ARENA_FULL) P.bigStr[b] = gi; }
     else {
       ++genLocal;
@@ -1799,9 +1860,13 @@ __global__ __launch_bounds__(WG) void k_job_keys(const unsigned long long *memo,
 }
 // sort key of a multi-diagonal group: its hit count (record word 4 after k_gather_general), so that the lanes of k_chain_general's
 // wavefronts work on groups of similar size
-__global__ __launch_bounds__(WG) void k_group_size_keys(const uint32_t *recs, uint32_t stride, const uint32_t *list, unsigned long long *keys, uint32_t n) {
+__global__ __launch_bounds__(WG) void k_group_size_keys(const uint32_t *recs, uint32_t stride, const uint32_t *list, unsigned long long *keys, uint32_t n, int useSimple) {
   const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
-  if (q < n) keys[q] = min(recs[(uint64_t)list[q] * stride + 4], 63u);
+  if (q < n) {
+    const uint32_t *r = recs + (uint64_t)list[q] * stride;
+    const bool simple = useSimple && r[5] == REC_NEAR_DONE && r[6] == 1u;  // chains first (they skip the sorts: their own wavefronts), each kind by size
+    keys[q] = simple ? min(r[4], 127u) : 128u + min(r[4], 63u);
+  }
 }
 void t1k_launch_dp_dense(t1k_ctx *ctx, const ChainArgs &a, const uint32_t *jobs, uint32_t n) {
   if (!n) return;
@@ -1895,10 +1960,10 @@ int t1k_run_chain(t1k_ctx *ctx, const ChainArgs &a, int nWg, int bigBlocks, bool
     if (nGen >= 4096 && t1k_ensure(ctx, ctx->bJobSort, (size_t)nGen * 20 + 64) == T1K_OK) {  // groups of similar size side by side
       unsigned long long *k0 = (unsigned long long *)ctx->bJobSort.p, *k1 = k0 + nGen;
       uint32_t *sorted = (uint32_t *)(k1 + nGen);
-      hipLaunchKernelGGL(k_group_size_keys, dim3((nGen + WG - 1) / WG), dim3(WG), 0, ctx->stream, (const uint32_t *)a.recs, a.recStride, (const uint32_t *)a.generalList, k0, nGen);
-      if (t1k_sort_pairs(ctx, k0, k1, a.generalList, sorted, nGen, 6) == T1K_OK) g.generalList = sorted;
+      hipLaunchKernelGGL(k_group_size_keys, dim3((nGen + WG - 1) / WG), dim3(WG), 0, ctx->stream, (const uint32_t *)a.recs, a.recStride, (const uint32_t *)a.generalList, k0, nGen, skipDone);
+      if (t1k_sort_pairs(ctx, k0, k1, a.generalList, sorted, nGen, 8) == T1K_OK) g.generalList = sorted;
     }
-    hipLaunchKernelGGL(k_chain_general, dim3((nGen + 63) / 64), dim3(64), 0, ctx->stream, g, nGen);
+    hipLaunchKernelGGL(k_chain_general, dim3((nGen + 63) / 64), dim3(64), 0, ctx->stream, g, nGen, skipDone);
     if ((rc = readCounters(ctx, hc))) return rc;
     const T1kArenaCounts wv = t1k_arena_counts(ctx, T1K_AR_WAVE, a.rareSegCap);
     if (wv.overflow) { hc[2] |= ERR_GROUPCAP; return 0; }

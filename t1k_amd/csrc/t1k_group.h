@@ -20,9 +20,13 @@ struct LaneArr {
 // (SeqSet.hpp:352-436), chain -> A[s .. s + ret) with repeated allele offsets dropped, then the total hit length on the read and on the
 // allele (1032-1069).  Returns false if the run fails the length tests of 1468, 1512-1522.  C[m]: scratch (top | link << 16).
 template <class Arr>
-__device__ inline bool t1k_run_lis(Arr A, Arr B, Arr C, int s, int m, int k, int hitLenRequired, int *retOut, int *lenROut, int *lenSOut) {
+// chainReady: A[s .. s + m) already IS the chain (hits in ascending allele offset whose read offsets ascend strictly as well and whose
+// allele offsets are distinct: the LIS of such a run is the run itself and nothing repeats) -- only the length tests are left.
+__device__ inline bool t1k_run_lis(Arr A, Arr B, Arr C, int s, int m, int k, int hitLenRequired, int *retOut, int *lenROut, int *lenSOut, bool chainReady = false) {
     // LIS over read offsets (352-436); C[i] = top | link << 16, link 0xFFFF = none
     int ret = 1;
+    if (chainReady) ret = m;
+    else {
     C[0] = 0 | (0xFFFFu << 16);
     auto topOf = [&](int i) { return (int)(C[i] & 0xFFFF); };
     auto setTop = [&](int i, int v) { C[i] = (C[i] & 0xFFFF0000u) | (uint32_t)v; };
@@ -60,6 +64,7 @@ __device__ inline bool t1k_run_lis(Arr A, Arr B, Arr C, int s, int m, int k, int
         ++w;
       }
       ret = w;
+    }
     }
     if (ret * k < hitLenRequired) return false;
     // hit lengths on read and on allele (1032-1069)
