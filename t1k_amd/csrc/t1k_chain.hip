@@ -1709,10 +1709,16 @@ __global__ __launch_bounds__(WG) void k_collect(ChainArgs P) {
   __shared__ uint16_t sBaseCnt[2][4][MAXLEN + 1];
   __shared__ uint64_t sVoteHi[WG], sVoteLo[WG];
   __shared__ uint32_t sBase;
+  // one bit per group record of the read-end (in chunk order): "the copy-out pass has to look at this record" -- its only candidate passed
+  // the filter, or it holds several (multi-diagonal groups).  The vote pass reads every record anyway; the copy-out pass then loads the
+  // 40 % that hold something instead of all of them again (records beyond the bitmap's reach are simply looked at).
+  constexpr uint32_t KEEP_BITS = 65536;
+  __shared__ uint32_t sKeepBits[KEEP_BITS / 32];
   const int tid = threadIdx.x;
   const uint32_t stride = P.recStride;
   for (uint32_t re = blockIdx.x; re < P.reads.nReadEnds; re += gridDim.x) {
     const uint32_t *cs = P.chunkStart + (uint64_t)re * P.maxChunks, *cc = P.chunkCount + (uint64_t)re * P.maxChunks;
+    for (uint32_t i = tid; i < KEEP_BITS / 32; i += WG) sKeepBits[i] = 0;
     {  // prefix counts of the four bases (non-N positions only) of both strands of this read-end
       const int len = (int)P.reads.len[re], S = P.reads.S;
       for (int idx = tid; idx < 2 * (len + 1); idx += WG) {
@@ -1732,6 +1738,7 @@ __global__ __launch_bounds__(WG) void k_collect(ChainArgs P) {
     }
     VoteKey best; best.hi = ~0ull; best.lo = ~0ull;
     uint32_t nCand[2] = {0, 0};
+    uint32_t cbase = 0;  // records of the chunks before this one
     for (int ch = 0; ch < P.maxChunks; ++ch) {
       const uint32_t g0 = cs[ch], gn = cc[ch];
       if (gn == 0) break;  // chunks are recorded densely
@@ -1740,14 +1747,19 @@ __global__ __launch_bounds__(WG) void k_collect(ChainArgs P) {
         const uint4 hd = ((const uint4 *)rec)[0], cw = ((const uint4 *)rec)[1];  // words 0..3: re|strand, allele, state, candidate word 0 (or side-arena base); 4..5: candidate words 1, 2
         const uint32_t nc = hd.z & 0x3FFFFFFFu;
         const int plus = (int)(hd.x >> 31);
+        uint32_t kept = 0;
         for (uint32_t j = 0; j < nc; ++j) {
           uint32_t w0 = hd.w, w1 = cw.x, w2 = cw.y;
           if (hd.z & 0x40000000u) { const uint32_t *g = P.genCand + ((uint64_t)hd.w + j) * 6; w0 = g[0]; w1 = g[1]; w2 = g[2]; }
           VoteKey vk = voteKey((int)(w1 >> 20), (int)(w0 & 0xFFF), (int)((w0 >> 12) & 0xFFF), hd.y, plus, (int)(w1 & 0xFFFFF), (int)(w2 & 0xFFFFF));
           if (vk < best) best = vk;
-          nCand[plus] += keepCandidate<MAXLEN>(P, sBaseCnt, plus, w0, w1, w2) ? 1u : 0u;
+          const uint32_t kc = keepCandidate<MAXLEN>(P, sBaseCnt, plus, w0, w1, w2) ? 1u : 0u;
+          nCand[plus] += kc; kept += kc;
         }
+        const uint32_t ridx = cbase + i;
+        if (kept && ridx < KEEP_BITS) atomicOr(&sKeepBits[ridx >> 5], 1u << (ridx & 31));
       }
+      cbase += gn;
     }
     sVoteHi[tid] = best.hi; sVoteLo[tid] = best.lo;
     __syncthreads();
@@ -1770,16 +1782,20 @@ __global__ __launch_bounds__(WG) void k_collect(ChainArgs P) {
     __syncthreads();
     if (sBase != 0xFFFFFFFFu && totWin) {
       // chunks are in the reference's order ('-' strand first, alleles ascending); copy the winning strand's candidates in order
-      uint32_t written = 0;
+      uint32_t written = 0, cb2 = 0;
       for (int ch = 0; ch < P.maxChunks; ++ch) {
         const uint32_t g0 = cs[ch], gn = cc[ch];
         if (gn == 0) break;
+        const uint32_t cbaseHere = cb2;
+        cb2 += gn;
         if ((P.recs[(uint64_t)g0 * stride] >> 31) != winPlus) continue;  // a chunk holds one strand
         for (uint32_t i0 = 0; i0 < gn; i0 += WG) {
           const uint32_t i = i0 + tid;
-          const uint32_t *rec = P.recs + (uint64_t)(g0 + (i < gn ? i : 0)) * stride;
-          const uint4 hd = ((const uint4 *)rec)[0], cw = ((const uint4 *)rec)[1];
-          const uint32_t nc = i < gn ? (hd.z & 0x3FFFFFFFu) : 0;
+          const uint32_t ridx = cbaseHere + i;
+          const bool look = i < gn && (ridx >= KEEP_BITS || ((sKeepBits[ridx >> 5] >> (ridx & 31)) & 1u));
+          uint4 hd = make_uint4(0u, 0u, 0u, 0u), cw = make_uint4(0u, 0u, 0u, 0u);
+          if (look) { const uint32_t *rec = P.recs + (uint64_t)(g0 + i) * stride; hd = ((const uint4 *)rec)[0]; cw = ((const uint4 *)rec)[1]; }
+          const uint32_t nc = look ? (hd.z & 0x3FFFFFFFu) : 0;
           uint32_t keepMask = 0, nk = 0;  // a group holds at most 32 candidates
           for (uint32_t j = 0; j < nc; ++j) {
             uint32_t w0 = hd.w, w1 = cw.x, w2 = cw.y;
