@@ -459,6 +459,7 @@ __global__ __launch_bounds__(NT) T1K_OCC8 void k_select(SelectArgs P) {
     // candidates that failed the similarity filter never reach the sort: count the survivors first.  Thread t looks at the
     // candidates [t * per, (t + 1) * per) and will put its survivors at myFirst, myFirst + 1, ...: the list keeps the order in
     // which k_collect wrote it (allele order), which the counting sort below relies on
+    if (SELECT_LDS_CAP == SELECT_LARGE && n <= SELECT_SMALL) continue;  // at most n survive: the small shape's read-end, whatever the filter left (no need to count)
     const uint32_t per = (n + NT - 1) / NT;
     const uint32_t iBeg = min(n, (uint32_t)tid * per), iEnd = min(n, iBeg + per);
     uint32_t live, myFirst;

@@ -31,7 +31,7 @@ python - $PAIRS > gpurun_out/r04_traffic.json <<'PY'
 import csv, json, sys, re
 fam = [("k_seed_groups", r"k_seed_groups|k_seed_long"), ("k_pair", r"k_pair"), ("k_extend", r"k_extend"), ("k_select", r"k_select"),
        ("fullalign kernels", r"k_truncate|k_pack_overlaps|k_publish_lists|k_fullalign|k_align_"),
-       ("chain kernels", r"k_chain_|k_dp_dense|k_gather_general|k_collect|k_general_finish|k_arena_compact|k_group_size_keys|k_job_keys")]
+       ("chain kernels", r"k_chain_|k_dp_dense|k_gather_general|k_near_hits|k_collect|k_general_finish|k_arena_compact|k_group_size_keys|k_job_keys")]
 out = {n: 0.0 for n, _ in fam}; parts = {n: {"fetch_kb": 0.0, "write_kb": 0.0} for n, _ in fam}; other = 0.0
 for c, key, mul in (("FETCH_SIZE", "fetch_kb", 2.0), ("WRITE_SIZE", "write_kb", 1.0)):
     for r in csv.DictReader(open("gpurun_out/r04_pmc_%s.csv" % c)):
