@@ -1702,6 +1702,23 @@ __device__ __forceinline__ bool keepCandidate(const ChainArgs &P, const uint16_t
   return true;
 }
 
+// A single-diagonal group whose candidate still waits for registered alignments (record word 2 = their number, words 6..7 their memo
+// slots; k_dp_dense has run them): the match counts are added here, where the record is read anyway -- k_chain_finish used to fetch and
+// rewrite those records in a launch of its own (1.9 GB fetched per range for scattered 32-byte records).  Returns the candidate's word 2.
+__device__ __forceinline__ uint32_t pendingMatchWord(const ChainArgs &P, uint32_t re, uint32_t nRefs, uint32_t w2, uint32_t s0, uint32_t s1) {
+  const unsigned long long *memo = P.memo + (uint64_t)re * GAP_CACHE;
+  uint32_t sum = 0;
+  for (uint32_t i = 0; i < nRefs; ++i) {
+    const uint32_t slot = ((i >> 1 ? s1 : s0) >> (16 * (i & 1))) & 0xFFFFu;
+    const unsigned long long e = __hip_atomic_load(&memo[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t v = GAP_VAL(e);
+    if (v == GAP_PENDING) atomicOr(&P.counters[2], (unsigned long long)ERR_MEMO);  // cannot happen: every registered job is run by k_dp_dense
+    sum += v;
+  }
+  return w2 + ((2u * sum) << 20);
+}
+__device__ __forceinline__ bool recPending(uint32_t state) { return !(state & REC_DONE) && state >= 1u && state <= (uint32_t)GROUP_MAX_REFS; }
+
 // MAXLEN: longest read of the launch (T1K_MAX_READ_LEN, or T1K_LONG_READ_LEN for a window with longer reads: 16 KB of prefix counts)
 template <int MAXLEN>
 __global__ __launch_bounds__(WG) void k_collect(ChainArgs P) {
@@ -1745,11 +1762,13 @@ __global__ __launch_bounds__(WG) void k_collect(ChainArgs P) {
       for (uint32_t i = tid; i < gn; i += WG) {
         const uint32_t *rec = P.recs + (uint64_t)(g0 + i) * stride;
         const uint4 hd = ((const uint4 *)rec)[0], cw = ((const uint4 *)rec)[1];  // words 0..3: re|strand, allele, state, candidate word 0 (or side-arena base); 4..5: candidate words 1, 2
-        const uint32_t nc = hd.z & 0x3FFFFFFFu;
+        const bool pend = recPending(hd.z);
+        const uint32_t nc = pend ? 1u : (hd.z & 0x3FFFFFFFu);
+        const uint32_t w2own = pend ? pendingMatchWord(P, re, hd.z, cw.y, cw.z, cw.w) : cw.y;
         const int plus = (int)(hd.x >> 31);
         uint32_t kept = 0;
         for (uint32_t j = 0; j < nc; ++j) {
-          uint32_t w0 = hd.w, w1 = cw.x, w2 = cw.y;
+          uint32_t w0 = hd.w, w1 = cw.x, w2 = w2own;
           if (hd.z & 0x40000000u) { const uint32_t *g = P.genCand + ((uint64_t)hd.w + j) * 6; w0 = g[0]; w1 = g[1]; w2 = g[2]; }
           VoteKey vk = voteKey((int)(w1 >> 20), (int)(w0 & 0xFFF), (int)((w0 >> 12) & 0xFFF), hd.y, plus, (int)(w1 & 0xFFFFF), (int)(w2 & 0xFFFFF));
           if (vk < best) best = vk;
@@ -1795,10 +1814,12 @@ __global__ __launch_bounds__(WG) void k_collect(ChainArgs P) {
           const bool look = i < gn && (ridx >= KEEP_BITS || ((sKeepBits[ridx >> 5] >> (ridx & 31)) & 1u));
           uint4 hd = make_uint4(0u, 0u, 0u, 0u), cw = make_uint4(0u, 0u, 0u, 0u);
           if (look) { const uint32_t *rec = P.recs + (uint64_t)(g0 + i) * stride; hd = ((const uint4 *)rec)[0]; cw = ((const uint4 *)rec)[1]; }
-          const uint32_t nc = look ? (hd.z & 0x3FFFFFFFu) : 0;
+          const bool pend = look && recPending(hd.z);
+          const uint32_t nc = look ? (pend ? 1u : (hd.z & 0x3FFFFFFFu)) : 0;
+          const uint32_t w2own = pend ? pendingMatchWord(P, re, hd.z, cw.y, cw.z, cw.w) : cw.y;
           uint32_t keepMask = 0, nk = 0;  // a group holds at most 32 candidates
           for (uint32_t j = 0; j < nc; ++j) {
-            uint32_t w0 = hd.w, w1 = cw.x, w2 = cw.y;
+            uint32_t w0 = hd.w, w1 = cw.x, w2 = w2own;
             if (hd.z & 0x40000000u) { const uint32_t *g = P.genCand + ((uint64_t)hd.w + j) * 6; w0 = g[0]; w1 = g[1]; w2 = g[2]; }
             if (keepCandidate<MAXLEN>(P, sBaseCnt, (int)winPlus, w0, w1, w2)) { keepMask |= 1u << j; ++nk; }
           }
@@ -1806,7 +1827,7 @@ __global__ __launch_bounds__(WG) void k_collect(ChainArgs P) {
           uint32_t off = t1k_block_scan_exclusive(nk, warpSums, &tot);
           for (uint32_t j = 0; j < nc; ++j) {
             if (!((keepMask >> j) & 1u)) continue;
-            uint32_t w0 = hd.w, w1 = cw.x, w2 = cw.y;
+            uint32_t w0 = hd.w, w1 = cw.x, w2 = w2own;
             if (hd.z & 0x40000000u) { const uint32_t *g = P.genCand + ((uint64_t)hd.w + j) * 6; w0 = g[0]; w1 = g[1]; w2 = g[2]; }
             T1kCand cd;
             cd.allele = hd.y | (winPlus ? 0x80000000u : 0);
@@ -1957,7 +1978,9 @@ int t1k_run_chain(t1k_ctx *ctx, const ChainArgs &a, int nWg, int bigBlocks, bool
   t1k_arena_compact(ctx, T1K_AR_GENERAL, a.generalStr, a.rareSegCap, a.generalList, gen.maxSeg);
   const uint32_t nJobs = (uint32_t)jobs.total, nRetry = (uint32_t)retry.total, nGen = (uint32_t)gen.total, nFinish = (uint32_t)fin.total;
   t1k_launch_dp_dense(ctx, a, a.jobList, nJobs);
-  if (nFinish) hipLaunchKernelGGL(k_chain_finish, dim3((nFinish + WG - 1) / WG), dim3(WG), 0, ctx->stream, a, nFinish);
+  // (k_collect adds the registered alignments' match counts itself; T1K_FINISH_KERNEL=1 runs the separate pass of rounds 1-3 first)
+  static const bool finishKernel = getenv("T1K_FINISH_KERNEL") != nullptr;
+  if (nFinish && finishKernel) hipLaunchKernelGGL(k_chain_finish, dim3((nFinish + WG - 1) / WG), dim3(WG), 0, ctx->stream, a, nFinish);
   if (nRetry) {
     if (longReads) hipLaunchKernelGGL((k_chain_fast<10, 2>), dim3((nRetry + WG - 1) / WG), dim3(WG), 0, ctx->stream, a, (const uint32_t *)a.retryList, nRetry);
     else hipLaunchKernelGGL((k_chain_fast<5, 2>), dim3((nRetry + WG - 1) / WG), dim3(WG), 0, ctx->stream, a, (const uint32_t *)a.retryList, nRetry);
