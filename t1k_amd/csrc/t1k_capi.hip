@@ -987,6 +987,9 @@ static int assignOnce(t1k_ctx *ctx, uint64_t first, uint32_t count) {
     (void)hipEventElapsedTime(&a1, ctx->ev[3], ctx->ev[7]); (void)hipEventElapsedTime(&a2, ctx->ev[7], evSlow); (void)hipEventElapsedTime(&a3, evSlow, ctx->ev[4]);
     fprintf(stderr, "[t1k] fullalign %.2f ms, eq-DP (%llu jobs) + general-DP (%llu jobs) %.2f ms, truncate %.2f ms; cand %llu ovl %llu dp %llu; groups %llu (gap walk %llu) fast %llu general %llu big %llu; memo jobs %llu parked %llu wide-queue %llu\n",
             a1, hc[8], hc[15], a2, a3, hc[0], hc[1], hc[7], hc[6], (unsigned long long)ctx->lastSlowGroups, hc[11], hc[12], hc[13], hc[16], hc[17], hc[20]);
+#ifdef T1K_NEAR_STATS
+    fprintf(stderr, "[t1k] multi-diagonal groups: far strays %llu, near count saturated %llu, other fallback %llu, masks ok but not a chain (<= 32 hits) %llu, (> 32 hits) %llu, chain (<= 96) %llu, chain (> 96) %llu\n", hc[40], hc[41], hc[42], hc[43], hc[47], hc[45], hc[46]);
+#endif
 #ifdef T1K_WALK_STATS
     fprintf(stderr, "[t1k] gap walk classes: exact without a DP %llu, pruned by the per-gap bound %llu, memo / DP %llu\n", hc[40], hc[41], hc[42]);
 #endif

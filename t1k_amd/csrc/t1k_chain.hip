@@ -1392,6 +1392,13 @@ __global__ __launch_bounds__(WG) void k_near_hits(ChainArgs P, uint32_t nItems) 
     }
     rec[5] = ok ? REC_NEAR_DONE : 0u;
     if (!ok) rec[6] = 0u;
+#ifdef T1K_NEAR_STATS
+    {  // what the multi-diagonal groups are (profiles/r04_multidiag_classes.txt)
+      int cls = 42;
+      if (recFar(rv[2]) != 0) cls = 40; else if (nearCnt == 31) cls = 41; else if (ok) cls = rec[6] == 1u ? (n > 96 ? 46 : 45) : (n > 32 ? 47 : 43);
+      atomicAdd(&P.counters[cls], 1ull);
+    }
+#endif
   }
   if (toWave) { const uint32_t wq = t1k_arena_append(P.counters, T1K_AR_WAVE, P.rareSegCap); if (wq != T1K_ARENA_FULL) P.waveStr[wq] = gi; }
 }
