@@ -217,7 +217,14 @@ __global__ __launch_bounds__(WG) void k_pair(PairArgs P) {
   uint64_t tp_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tl_ = __builtin_amdgcn_s_memtime();
 #endif
   const uint32_t nItems = P.only ? (uint32_t)P.counters[23] : P.nFragments;
-  for (uint32_t it = blockIdx.x; it < nItems; it += gridDim.x) {
+  // fragments are handed out one at a time (a device counter per launch): their cost spans two orders of magnitude (0 .. 8192 and more
+  // overlaps), and with a fixed stride the kernel lasted as long as its unluckiest workgroup
+  __shared__ uint32_t sItem;
+  for (;;) {
+    if (tid == 0) { sItem = (uint32_t)atomicAdd(&P.counters[P.only ? 26 : 25], 1ull); sDup = 0; sFail = 0; sBestM = -1; sBestIdx = 0x7FFFFFFF; sAnySep = 0; sNotOne = 0; sN = 0; }
+    __syncthreads();
+    const uint32_t it = sItem;
+    if (it >= nItems) break;
     const uint32_t f = P.only ? P.only[2 * it] : it;
     const uint64_t epoch = (uint64_t)(P.epochBase + f + 1) << 32;
     const bool paired = P.end2 != nullptr;
@@ -228,8 +235,6 @@ __global__ __launch_bounds__(WG) void k_pair(PairArgs P) {
     OvlList L2{nullptr};
     if (paired) { uint32_t e2 = P.end2[f]; n2 = P.listCount[e2]; L2.p = (const T1kOvlP *)P.listPtr[e2]; }
     const bool hasN = P.hasN ? P.hasN[f] != 0 : false;
-    if (tid == 0) { sDup = 0; sFail = 0; sBestM = -1; sBestIdx = 0x7FFFFFFF; sAnySep = 0; sNotOne = 0; sN = 0; }
-    __syncthreads();
     const bool dangling = paired && (n1 == 0 || n2 == 0);
     const bool both = paired && !dangling;
     uint32_t nFrag = 0;
@@ -793,7 +798,7 @@ static int pairLaunch(t1k_ctx *ctx, t1k_rowset *rs, const uint32_t *end1, const 
   for (int attempt = 0;; ++attempt) {
     T1K_HIP(ctx, hipMemsetAsync((char *)ctx->bCounters.p + 2 * 8, 0, 8, ctx->stream));
     T1K_HIP(ctx, hipMemsetAsync((char *)ctx->bCounters.p + 9 * 8, 0, 8, ctx->stream));
-    T1K_HIP(ctx, hipMemsetAsync((char *)ctx->bCounters.p + 22 * 8, 0, 24, ctx->stream));
+    T1K_HIP(ctx, hipMemsetAsync((char *)ctx->bCounters.p + 22 * 8, 0, 40, ctx->stream));  // [22] overlaps read, [23] long fragments, [24] their arena cursor, [25] / [26] next fragment of the two launches
     size_t chunk = 0;
     if (rs) {
       if ((rc = t1k_rowset_chunk(rs, ctx, &chunk, &p.rsRows, &p.rsCap, &p.rsCursor))) return rc;
