@@ -1740,7 +1740,13 @@ __global__ __launch_bounds__(WG) void k_collect(ChainArgs P) {
   __shared__ uint32_t sKeepBits[KEEP_BITS / 32];
   const int tid = threadIdx.x;
   const uint32_t stride = P.recStride;
-  for (uint32_t re = blockIdx.x; re < P.reads.nReadEnds; re += gridDim.x) {
+  __shared__ uint32_t sNextRe;  // read-ends handed out one at a time (device counter): their group counts differ by orders of magnitude
+  for (;;) {
+    __syncthreads();
+    if (tid == 0) sNextRe = (uint32_t)atomicAdd(&P.counters[27], 1ull);
+    __syncthreads();
+    const uint32_t re = sNextRe;
+    if (re >= P.reads.nReadEnds) break;
     const uint32_t *cs = P.chunkStart + (uint64_t)re * P.maxChunks, *cc = P.chunkCount + (uint64_t)re * P.maxChunks;
     for (uint32_t i = tid; i < KEEP_BITS / 32; i += WG) sKeepBits[i] = 0;
     {  // prefix counts of the four bases (non-N positions only) of both strands of this read-end
