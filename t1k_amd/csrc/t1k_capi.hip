@@ -632,6 +632,7 @@ static int capacityError(t1k_ctx *ctx, unsigned long long flags) {
     ctx->needRare = rare * T1K_NSTRIPE;
     ctx->needJob = std::max(maxSeg(T1K_AR_JOBS), maxSeg(T1K_AR_EXTJOBS)) * T1K_NSTRIPE;
     ctx->needGenJob = maxSeg(T1K_AR_GENJOBS) * T1K_NSTRIPE;
+    ctx->needGenHit = maxSeg(T1K_AR_GENHITS) * T1K_NSTRIPE;
     ctx->needCand = ctx->hRaw[0];
     ctx->needOvl = ctx->hRaw[1];
   }
@@ -788,6 +789,11 @@ int t1k_assign_range(t1k_ctx *ctx, uint64_t first, uint32_t count) {
   const int64_t jobLimit = (int64_t)count * 2048 + (1 << 20);
   ctx->wJob = clampCap(std::max<uint64_t>(ctx->wJob, (uint64_t)count * 512), 1u << 20, std::max<int64_t>(jobLimit, (int64_t)ctx->wJob));
   ctx->wGenJob = clampCap(std::max<uint64_t>(ctx->wGenJob, (uint64_t)count * 128), 1u << 20, std::max<int64_t>(jobLimit, (int64_t)ctx->wGenJob));
+  // hit lists of the multi-diagonal groups: 64 M entries (256 MB) serve every 2 x 150 bp range; a window with reads beyond the hit masks sends
+  // every group of THOSE read-ends through explicit lists (~1000 hits a group) and grows the arena to what the device counted -- round 3
+  // reserved 1 G entries (4 GB per pipeline) as soon as one such read was in the window
+  const int64_t genHitLimit = 1024ll << 20;
+  ctx->wGenHit = clampCap(ctx->wGenHit, 64u << 20, genHitLimit);
   for (int attempt = 0;; ++attempt) {
     ctx->lastCapFlags = 0; ctx->needGroup = ctx->needCand = ctx->needOvl = ctx->needList = ctx->needRare = ctx->needJob = ctx->needGenJob = 0;
     const int rc = assignOnce(ctx, first, count);
@@ -815,10 +821,11 @@ int t1k_assign_range(t1k_ctx *ctx, uint64_t first, uint32_t count) {
       grow(ctx->wJob, ctx->needJob, jobLimit * 2);
       grow(ctx->wGenJob, ctx->needGenJob, jobLimit * 2);
     }
+    if (ctx->lastCapFlags & 2) grow(ctx->wGenHit, ctx->needGenHit, genHitLimit);  // (candidate staging of the multi-diagonal groups: only the hit arena grows)
     if (ctx->lastCapFlags & 4) grow(ctx->wCand, ctx->needCand, ctx->prm.cand_cap);
     if (ctx->lastCapFlags & 16) grow(ctx->wOvl, ctx->needOvl, ctx->prm.ovl_cap);
     if (ctx->lastCapFlags & 64) grew = true;  // an alignment queue's stripe: t1k_fullalign_phase has raised queueBoost (and taken the range's coverage back)
-    if (!grew || (ctx->lastCapFlags & ~(256ull | 4ull | 16ull | 64ull))) return rc;  // at the limits (or another arena): the caller splits the range
+    if (!grew || (ctx->lastCapFlags & ~(256ull | 4ull | 16ull | 64ull | 2ull))) return rc;  // at the limits (or another arena): the caller splits the range
     if (getenv("T1K_DEBUG_PHASES")) fprintf(stderr, "[t1k] range of %u read-ends again with capacities: groups %llu lists %llu / %llu jobs %llu / %llu candidates %llu overlaps %llu\n", count,
                                             (unsigned long long)ctx->wGroup, (unsigned long long)ctx->wList, (unsigned long long)ctx->wRare, (unsigned long long)ctx->wJob, (unsigned long long)ctx->wGenJob,
                                             (unsigned long long)ctx->wCand, (unsigned long long)ctx->wOvl);
@@ -841,7 +848,7 @@ static int assignOnce(t1k_ctx *ctx, uint64_t first, uint32_t count) {
   const int recStride = t1k_chain_rec_stride(ctx->batchFastMaxLen);
   const uint64_t groupCap = ctx->wGroup;
   // (a window with reads beyond T1K_MAX_READ_LEN sends every group of those read-ends through the explicit hit lists: up to ~1000 hits a group)
-  const uint32_t jobCap = (uint32_t)ctx->wJob, genCandCap = 16u << 20, genHitCap = ctx->batchMaxLen > T1K_MAX_READ_LEN ? 1024u << 20 : 64u << 20, genJobCap = (uint32_t)ctx->wGenJob;
+  const uint32_t jobCap = (uint32_t)ctx->wJob, genCandCap = 16u << 20, genHitCap = (uint32_t)std::min<uint64_t>(ctx->wGenHit ? ctx->wGenHit : (64u << 20), 1024u << 20), genJobCap = (uint32_t)ctx->wGenJob;
   const int bigBlocks = 32;
   if ((rc = t1k_ensure(ctx, ctx->bCounters, (size_t)T1K_COUNTER_WORDS * 8))) return rc;
   if ((rc = t1k_ensure(ctx, ctx->bWgGroups, groupCap * recStride * 4))) return rc;                        // batch group records

@@ -733,8 +733,8 @@ struct t1k_ctx {
   T1kOvlP *storeBase = nullptr;    // where the running range's packed lists go
   // working capacities of the batch arenas (t1k_assign_range grows them on demand up to the limits in prm) and the demand the last
   // overflow reported
-  uint64_t wGroup = 0, wList = 0, wRare = 0, wCand = 0, wOvl = 0, wJob = 0, wGenJob = 0;
-  uint64_t needGroup = 0, needList = 0, needRare = 0, needCand = 0, needOvl = 0, needJob = 0, needGenJob = 0;
+  uint64_t wGroup = 0, wList = 0, wRare = 0, wCand = 0, wOvl = 0, wJob = 0, wGenJob = 0, wGenHit = 0;
+  uint64_t needGroup = 0, needList = 0, needRare = 0, needCand = 0, needOvl = 0, needJob = 0, needGenJob = 0, needGenHit = 0;
   unsigned long long lastCapFlags = 0;
   bool scaledOnce = false;
   bool covCommitted = false;     // the running range has started adding to the coverage arrays (no retry after that)
