@@ -267,13 +267,27 @@ __global__ __launch_bounds__(WG) void k_pair(PairArgs P) {
     if (lds) {
       for (uint32_t q = tid; q < LJ_SLOTS; q += WG) { hKey[q] = 0; hVal[q] = 0; }
       __syncthreads();
-      for (uint32_t i = tid; i < n1; i += WG) {
-        const uint32_t old = atomicOr(&hVal[ljInsert<LJ_SLOTS>(hKey, L1[i].allele)], i + 1);
-        if (old & 0x7FFFu) sDup = 1;
+      // (this is the first touch of the two lists: four records' allele words are requested together before the dependent LDS inserts --
+      // one after the other, each insert's atomic kept the next record's load from being issued)
+      for (uint32_t i0 = tid; i0 < n1; i0 += 4 * WG) {
+        uint32_t al[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) al[r] = i0 + r * WG < n1 ? (uint32_t)(L1.p[i0 + r * WG].lo & 0xFFFFFFu) : 0u;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const uint32_t i = i0 + r * WG;
+          if (i < n1) { const uint32_t old = atomicOr(&hVal[ljInsert<LJ_SLOTS>(hKey, al[r])], i + 1); if (old & 0x7FFFu) sDup = 1; }
+        }
       }
-      for (uint32_t j = tid; j < n2; j += WG) {
-        const uint32_t old = atomicOr(&hVal[ljInsert<LJ_SLOTS>(hKey, L2[j].allele)], (j + 1) << 16);
-        if (old >> 16) sDup = 1;
+      for (uint32_t j0 = tid; j0 < n2; j0 += 4 * WG) {
+        uint32_t al[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) al[r] = j0 + r * WG < n2 ? (uint32_t)(L2.p[j0 + r * WG].lo & 0xFFFFFFu) : 0u;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const uint32_t j = j0 + r * WG;
+          if (j < n2) { const uint32_t old = atomicOr(&hVal[ljInsert<LJ_SLOTS>(hKey, al[r])], (j + 1) << 16); if (old >> 16) sDup = 1; }
+        }
       }
       __syncthreads();
       if (sDup) lds = false;  // a repeated allele: the sequential replay below works on the HBM tables
