@@ -174,10 +174,10 @@ int t1k_rowset_rows_download(t1k_rowset *rs, uint64_t first, uint32_t count, uin
  *   t1k_rowset_exchange           every fragment row goes to the rank that owns its pattern (hash mod nRanks); that rank coalesces the
  *                                 group over ALL its fragments in global order, so group contents do not depend on the sharding
  *   t1k_rowset_groups_gather      every rank's group table on every rank; merged by first fragment on the host (the job layer)
- *   t1k_em_shard                  t1k_em_update runs the row pass on [rowBegin, rowEnd) only (collective: the ranks' ranges must partition the
- *                                 read groups in rank order), all-gathers the ranks' pieces of the row-major contribution array (every
- *                                 element has one writer: nothing is added, bytes / nRanks per rank), then the column pass everywhere in
- *                                 group order: same doubles as on one GPU */
+ *   t1k_em_shard                  t1k_em_update runs the row pass (one sum per read group) on [rowBegin, rowEnd) only (collective: the
+ *                                 ranks' ranges must partition the read groups in rank order), all-gathers the ranks' pieces of the
+ *                                 per-group sums (every element has one writer: nothing is added, 8 B per read group in all), then the
+ *                                 class pass everywhere in group order: same doubles as on one GPU */
 typedef struct t1k_comm_group t1k_comm_group;
 int t1k_comm_unique_id(void *id128);
 t1k_comm_group *t1k_comm_group_create(int nRanks);

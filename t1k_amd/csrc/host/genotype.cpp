@@ -179,6 +179,7 @@ void Genotyper::setAbundance(const double *n, const std::vector<int> &ecLen) {
 // ------------------------------------------------------------------------------------------------------------------
 // QuantifyAlleleEquivalentClass (Genotyper.hpp:1142-1328): SQUAREM-accelerated EM; every EMupdate is t1k_em_update
 // ------------------------------------------------------------------------------------------------------------------
+extern "C" void t1k_em_times(const t1k_ctx *ctx, double *ms4);  // (t1k_em.hip: debug clocks of the updates)
 int Genotyper::quantify(t1k_ctx *ctx, t1k_comm *comm, std::string &err) {
   const double tq0 = hostNowMs();
   RefSet &R = *ref;
@@ -276,7 +277,12 @@ int Genotyper::quantify(t1k_ctx *ctx, t1k_comm *comm, std::string &err) {
   }
   setAbundance(n.data(), ecLen);
   emIterations = rounds;
-  if (getenv("T1K_DEBUG_PHASES")) fprintf(stderr, "[t1k host] quantify: rows %.1f ms, setup %.1f ms (nnz %zu), iterations %.1f ms\n", tq1 - tq0, tq2 - tq1, ecIdx.size(), hostNowMs() - tq2);
+  if (getenv("T1K_DEBUG_PHASES")) {
+    double u[4];
+    t1k_em_times(ctx, u);
+    fprintf(stderr, "[t1k host] quantify: rows %.1f ms, setup %.1f ms (nnz %zu), iterations %.1f ms (%.0f updates: staging + enqueue %.1f ms, waiting for the device %.1f ms, M-step %.1f ms)\n",
+            tq1 - tq0, tq2 - tq1, ecIdx.size(), hostNowMs() - tq2, u[3], u[0], u[1], u[2]);
+  }
   return rounds;
 }
 

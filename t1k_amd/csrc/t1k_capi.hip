@@ -285,7 +285,7 @@ void t1k_ctx_destroy(t1k_ctx *ctx) {
                       &ctx->bWgStage, &ctx->bWgBig, &ctx->bWgCache, &ctx->bLists, &ctx->bCand, &ctx->bExt, &ctx->bCandStart, &ctx->bCandCount, &ctx->bListPtr, &ctx->bListCount,
                       &ctx->bOvlWork, &ctx->bDedupScratch, &ctx->bDedupBases, &ctx->bDedupN, &ctx->bDedupLen, &ctx->bDedupWeight, &ctx->bOvlStart, &ctx->bOvlCount, &ctx->bCounters, &ctx->bSlowQueue, &ctx->bSlowScratch, &ctx->bSortScratch, &ctx->bEqTrace, &ctx->bSortTmp, &ctx->bSlowKeys, &ctx->bJobSort, &ctx->bEnd1, &ctx->bEnd2,
                       &ctx->bHasN, &ctx->bRows, &ctx->bRowStart, &ctx->bRowCount, &ctx->bFragAssigned, &ctx->bPairScratch, &ctx->bPairOverflow, &ctx->bPairBig, &ctx->bExtractHuge, &ctx->bEmRowPtr, &ctx->bEmEc,
-                      &ctx->bEmCount, &ctx->bEmLen, &ctx->bEmX0, &ctx->bEmN, &ctx->bEmContrib, &ctx->bEmColPtr, &ctx->bEmColIdx, &ctx->bEmEntryOf, &ctx->bExtract};
+                      &ctx->bEmCount, &ctx->bEmLen, &ctx->bEmX0, &ctx->bEmN, &ctx->bEmPsum, &ctx->bEmColPtr, &ctx->bEmRowOf, &ctx->bExtract};
   for (auto *b : all) freeBuf(*b);
   for (auto &slot : ctx->storeChunks)
     for (auto &b : slot) freeBuf(b);

@@ -750,8 +750,8 @@ struct t1k_ctx {
   uint32_t nFragments = 0;
   uint64_t nRows = 0;
   // EM
-  T1kDevBuf bEmRowPtr, bEmEc, bEmCount, bEmLen, bEmX0, bEmN, bEmContrib, bEmColPtr, bEmColIdx, bEmEntryOf;
-  std::vector<uint64_t> hEmRowPtr, emPieceBytes, emPieceDispl;  // sharded E-step: the ranks' pieces of the row-major contribution array
+  T1kDevBuf bEmRowPtr, bEmEc, bEmCount, bEmLen, bEmX0, bEmN, bEmPsum, bEmColPtr, bEmRowOf;
+  std::vector<uint64_t> emPieceBytes, emPieceDispl;  // sharded E-step: the ranks' pieces of the per-group sums (psum)
   uint32_t emGroups = 0, emEc = 0, emRowBegin = 0, emRowEnd = 0;
   struct t1k_comm *emComm = nullptr;
   bool emReduceMode = false;   // T1K_EM_COLLECTIVE=allreduce: partial class totals per rank, all-reduce of E doubles (opt-in: re-associates the sums)
@@ -767,6 +767,7 @@ struct t1k_ctx {
   unsigned long long *countersPinned = nullptr;  // page-locked landing buffer of t1k_fetch_counters
   double *emPinned = nullptr;  // page-locked staging for the per-update vectors: [x | n], emPinnedN doubles each
   size_t emPinnedN = 0;
+  double emMs[4] = {0, 0, 0, 0};  // T1K_DEBUG_PHASES: per job, time of the updates' staging + enqueue | wait for the device | M-step; [3] = updates
   t1k_allreduce_fn emAllreduce = nullptr;
   void *emUser = nullptr;
   // align batch scratch

@@ -2,72 +2,118 @@
 // and the batched AlignAlgo::GlobalAlignment entry points used by the unit tests.
 //
 // E-step, bit-identical to the reference's sequential doubles:
-//   k_em_rows : one lane per read group g: psum = sum_j x[ec_j] in row order (psum == 0 -> 1), then
-//               contrib = count_g * (x[ec] / psum) written at the entry's class-major (CSC) position
-//   k_em_cols : one lane per class: n[ec] = sum of its contributions in group order -- the order the reference's
-//               row-major loop adds them to ecReadCount[ec] -- so every class total is the same rounded double
+//   k_em_psum : one wavefront per read group g: psum[g] = sum_j x[ec_j] in row order (psum == 0 -> 1)
+//   k_em_cols : one wavefront per class: n[ec] = sum over its entries, in group order -- the order the reference's row-major loop adds
+//               them to ecReadCount[ec] -- of count_g * (x[ec] / psum[g]): the contribution is formed where it is added (the class-major
+//               list holds each entry's read group; count and psum are G doubles, cache-resident), so every class total is the same
+//               rounded double as the reference's.  Rounds 1-4 had the row pass write the nnz contributions to their class-major
+//               slots (23.8 M scattered 8-byte stores per update at 10 M pairs, 0.86 ms) for the class pass to read back.
 // then the M-step (normalise by length, sum|diff|) runs on the host in the reference's order: it is O(#classes) and needs the
-// values on the host anyway.  Sharded over GPUs (t1k_em_shard): a rank runs k_em_rows on its slice of the read groups only and writes
-// the contributions in ROW-major order, so its slice is one contiguous piece; the pieces are all-gathered (every element has exactly
-// one writer: no reduction, no zero-filling, bytes / N per rank) and k_em_cols, on every rank, adds each class's contributions in
-// group order through the class-major permutation: the same doubles as on one GPU, whatever the number of ranks.
+// values on the host anyway.  Sharded over GPUs (t1k_em_shard): a rank runs k_em_psum on its slice of the read groups only; the slices
+// of psum are all-gathered (every element has exactly one writer: no reduction, G doubles in all -- 1.8 MB at 10 M pairs, where the
+// contributions were 190 MB) and k_em_cols, on every rank, adds each class in group order: the same doubles as on one GPU, whatever
+// the number of ranks.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstring>
 #include "t1k_dev.h"
 #include "t1k_launch.h"
 
 // acc + v(lane 0) + v(lane 1) + ... + v(lane cnt-1), added strictly in that order (the floating-point sums of the EM must follow
-// the reference's order); the loop is uniform, the operands come out of the lanes with v_readlane
-__device__ __forceinline__ double waveOrderedSum(double v, int cnt, double acc) {
-  const long long bits = __double_as_longlong(v);
-  const int lo = (int)(uint32_t)bits, hi = (int)(uint32_t)((unsigned long long)bits >> 32);
+// the reference's order).  The operands go through 512 bytes of LDS that belong to the wavefront: every lane reads them back at the same
+// addresses (a broadcast, two doubles a read) and runs the same chain of additions.  Taking them out of the lanes with v_readlane, as
+// rounds 1-4 did, put two readlanes into one scalar register pair and two wait states in front of EVERY addition (14 issue cycles an
+// operand); now a dependent addition follows the previous one as soon as its result is there.
+__device__ __forceinline__ double waveOrderedSum(double v, int cnt, double acc, double *slot, int lane) {
+  slot[lane] = v;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   if (cnt == 64) {
     // a full wavefront of operands (all but the last piece of a long list): no loop control between the dependent additions -- the
     // chain of one long class is the critical path of the whole E-step
 #pragma unroll
-    for (int j = 0; j < 64; ++j) {
-      const uint32_t l = (uint32_t)__builtin_amdgcn_readlane(lo, j), h = (uint32_t)__builtin_amdgcn_readlane(hi, j);
-      acc += __longlong_as_double((long long)(((unsigned long long)h << 32) | l));
-    }
-    return acc;
+    for (int j = 0; j < 64; ++j) acc += slot[j];
+  } else {
+    for (int j = 0; j < cnt; ++j) acc += slot[j];
   }
-  for (int j = 0; j < cnt; ++j) {
-    const uint32_t l = (uint32_t)__builtin_amdgcn_readlane(lo, j), h = (uint32_t)__builtin_amdgcn_readlane(hi, j);
-    acc += __longlong_as_double((long long)(((unsigned long long)h << 32) | l));
-  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();  // the reads are done before the slot is written again
   return acc;
 }
 
 // one wavefront per read group: the lanes gather the row's class abundances together, the sum is taken in row order
-__global__ __launch_bounds__(256) void k_em_rows(const uint64_t *rowPtr, const uint32_t *ecIdx, const uint64_t *cscPos, const double *count, const double *x, double *contrib,
-                          uint32_t nGroups) {
+__global__ __launch_bounds__(256) void k_em_psum(const uint64_t *rowPtr, const uint32_t *ecIdx, const double *x, double *psumOut, uint32_t nGroups) {
   const uint32_t g = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int lane = threadIdx.x & 63;
+  __shared__ __attribute__((aligned(16))) double sOrd[4][64];
   if (g >= nGroups) return;
+  double *slot = sOrd[threadIdx.x >> 6];
   const uint64_t b = rowPtr[g], e = rowPtr[g + 1];
   double psum = 0;
   for (uint64_t base = b; base < e; base += 64) {
     const uint64_t p = base + lane;
     const double v = p < e ? x[ecIdx[p]] : 0.0;
-    psum = waveOrderedSum(v, (int)(e - base < 64 ? e - base : 64), psum);
+    psum = waveOrderedSum(v, (int)(e - base < 64 ? e - base : 64), psum, slot, lane);
   }
   if (psum == 0) psum = 1;
-  const double c = count[g];
-  for (uint64_t p = b + lane; p < e; p += 64) contrib[cscPos ? cscPos[p] : p] = c * (x[ecIdx[p]] / psum);  // (no permutation: row-major, the sharded E-step)
+  if (lane == 0) psumOut[g] = psum;
 }
 
-// one wavefront per class: its contributions are added in group order
-__global__ __launch_bounds__(256) void k_em_cols(const uint64_t *colPtr, const double *contrib, const uint32_t *entryOf, double *n, uint32_t nEc) {
+// one wavefront per class: its entries' contributions are formed and added in group order.  rowOf[j] = the read group of class-major
+// slot j; groups outside [rowLo, rowHi) contribute 0.0 (T1K_EM_COLLECTIVE=allreduce: a rank adds its own groups only; x + 0.0 == x).
+// The 64 dependent additions of a piece are the critical path of the E-step (one class holds ~10^5 entries), so nothing else may sit on
+// it: the entries are taken 512 at a time, the read groups of the piece after next and the count / psum of the next piece are requested
+// before the additions of this one start.
+__global__ __launch_bounds__(256) void k_em_cols(const uint64_t *colPtr, const uint32_t *rowOf, const double *count, const double *psum, const double *x, double *n, uint32_t nEc,
+                                                 uint32_t rowLo, uint32_t rowHi) {
+  constexpr int K = 8;
+  constexpr uint64_t S = 64 * K;
   const uint32_t ec = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int lane = threadIdx.x & 63;
+  __shared__ __attribute__((aligned(16))) double sOrd[4][64];
   if (ec >= nEc) return;
+  double *slot = sOrd[threadIdx.x >> 6];
   const uint64_t b = colPtr[ec], e = colPtr[ec + 1];
+  const double xe = x[ec];
+  uint32_t g[K];       // read groups of the piece whose values are requested next (~0u: no entry, or not this rank's group)
+  double c[K], ps[K];  // count / psum of the piece that is added next
+  bool ok[K];
+  auto rows = [&](uint64_t start) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const uint64_t p = start + 64 * k + lane;
+      const uint32_t r = p < e ? rowOf[p] : ~0u;
+      g[k] = r != ~0u && r - rowLo < rowHi - rowLo ? r : ~0u;
+    }
+  };
+  auto values = [&]() {
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      ok[k] = g[k] != ~0u;
+      const uint32_t gi = ok[k] ? g[k] : rowLo;  // (any valid index: the value is not used)
+      c[k] = ok[k] ? count[gi] : 0.0;
+      ps[k] = ok[k] ? psum[gi] : 1.0;
+    }
+  };
   double s = 0;
-  for (uint64_t base = b; base < e; base += 64) {
-    const uint64_t p = base + lane;
-    const double v = p < e ? contrib[entryOf ? entryOf[p] : p] : 0.0;  // entryOf: class-major slot -> row-major entry (sharded E-step)
-    s = waveOrderedSum(v, (int)(e - base < 64 ? e - base : 64), s);
+  if (b < e) {
+    rows(b);
+    values();
+    rows(b + S);
+  }
+  for (uint64_t base = b; base < e; base += S) {
+    double v[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) v[k] = ok[k] ? c[k] * (xe / ps[k]) : 0.0;
+    values();            // the next piece's count / psum (its read groups arrived during the previous piece's additions)
+    rows(base + 2 * S);  // the read groups of the piece after next
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const uint64_t cb = base + 64 * k;
+      if (cb < e) s = waveOrderedSum(v[k], (int)(e - cb < 64 ? e - cb : 64), s, slot, lane);
+    }
   }
   if (lane == 0) n[ec] = s;
 }
@@ -81,9 +127,16 @@ __global__ void k_em_keys(const uint32_t *ecIdx, uint32_t nnz, uint32_t nEc, uns
   key[p] = ec; val[p] = p;
   atomicAdd(&colCount[ec], 1ull);
 }
-__global__ void k_em_scatter(const uint32_t *sortedEntry, uint32_t nnz, uint64_t *cscPos) {
+// the read group of every entry (row-major), then of every class-major slot
+__global__ __launch_bounds__(256) void k_em_entry_rows(const uint64_t *rowPtr, uint32_t nGroups, uint32_t *rowOfEntry) {
+  const uint32_t g = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (g >= nGroups) return;
+  for (uint64_t p = rowPtr[g] + lane; p < rowPtr[g + 1]; p += 64) rowOfEntry[p] = g;
+}
+__global__ void k_em_slot_rows(const uint32_t *sortedEntry, const uint32_t *rowOfEntry, uint32_t nnz, uint32_t *rowOf) {
   const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j < nnz) cscPos[sortedEntry[j]] = j;
+  if (j < nnz) rowOf[j] = rowOfEntry[sortedEntry[j]];
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -241,22 +294,22 @@ int t1k_em_setup(t1k_ctx *ctx, const uint64_t *rowPtr, const uint32_t *ecIdx, co
   int rc;
   if ((rc = t1k_ensure(ctx, ctx->bEmRowPtr, (size_t)(nGroups + 1) * 8)) || (rc = t1k_ensure(ctx, ctx->bEmEc, (size_t)nnz * 4 + 16)) ||
       (rc = t1k_ensure(ctx, ctx->bEmCount, (size_t)nGroups * 8 + 16)) || (rc = t1k_ensure(ctx, ctx->bEmColPtr, (size_t)(nEc + 2) * 8)) ||
-      (rc = t1k_ensure(ctx, ctx->bEmColIdx, (size_t)nnz * 8 + 16)) || (rc = t1k_ensure(ctx, ctx->bEmContrib, (size_t)nnz * 8 + 16)) ||
+      (rc = t1k_ensure(ctx, ctx->bEmPsum, (size_t)nGroups * 8 + 16)) || (rc = t1k_ensure(ctx, ctx->bEmRowOf, (size_t)nnz * 4 + 16)) ||
       (rc = t1k_ensure(ctx, ctx->bEmX0, (size_t)nEc * 8 + 16)) || (rc = t1k_ensure(ctx, ctx->bEmN, (size_t)nEc * 8 + 16)))
     return rc;
   T1K_HIP(ctx, hipMemcpyAsync(ctx->bEmRowPtr.p, rowPtr, (size_t)(nGroups + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
   if (nnz) T1K_HIP(ctx, hipMemcpyAsync(ctx->bEmEc.p, ecIdx, (size_t)nnz * 4, hipMemcpyHostToDevice, ctx->stream));
   if (nGroups) T1K_HIP(ctx, hipMemcpyAsync(ctx->bEmCount.p, count, (size_t)nGroups * 8, hipMemcpyHostToDevice, ctx->stream));
-  // Class-major positions: a STABLE sort of the entries by class keeps them in group order within a class (the order in which the
-  // reference's row-major loop adds them to ecReadCount[ec]).  On the device: radix sort of (class, entry), entry p lands at
-  // cscPos[p]; class starts from the sorted keys.
+  // Class-major order: a STABLE sort of the entries by class keeps them in group order within a class (the order in which the
+  // reference's row-major loop adds them to ecReadCount[ec]).  On the device: radix sort of (class, entry); slot j of the sorted
+  // list keeps the read group of its entry (rowOf[j]); class starts from the sorted keys.
   T1K_HIP(ctx, hipMemsetAsync(ctx->bEmColPtr.p, 0, (size_t)(nEc + 2) * 8, ctx->stream));
   if (nnz) {
     if (nnz >= 0xFFFFFFFFull) return t1k_fail(ctx, T1K_ERR_ARG, "t1k_em_setup: more than 2^32 entries");
     T1kDevBuf tmp;
-    if ((rc = t1k_ensure(ctx, tmp, (size_t)nnz * 20 + 64)) || (rc = t1k_ensure(ctx, ctx->bEmEntryOf, (size_t)nnz * 4 + 16))) return rc;
+    if ((rc = t1k_ensure(ctx, tmp, (size_t)nnz * 28 + 64))) return rc;
     unsigned long long *k0 = (unsigned long long *)tmp.p, *k1 = k0 + nnz;
-    uint32_t *v0 = (uint32_t *)(k1 + nnz), *v1 = (uint32_t *)ctx->bEmEntryOf.p;  // v1[j] = the entry in class-major slot j: kept for the sharded E-step
+    uint32_t *v0 = (uint32_t *)(k1 + nnz), *v1 = v0 + nnz, *rowOfEntry = v1 + nnz;  // v1[j] = the entry in class-major slot j
     unsigned long long *bad = (unsigned long long *)ctx->bEmN.p;  // a word that is free until the first update
     T1K_HIP(ctx, hipMemsetAsync(bad, 0, 8, ctx->stream));
     const unsigned nb = (unsigned)((nnz + 255) / 256);
@@ -265,7 +318,8 @@ int t1k_em_setup(t1k_ctx *ctx, const uint64_t *rowPtr, const uint32_t *ecIdx, co
     while ((1ull << bits) < nEc) ++bits;
     rc = t1k_sort_pairs(ctx, k0, k1, v0, v1, (uint32_t)nnz, bits);
     if (rc == T1K_OK) {
-      hipLaunchKernelGGL(k_em_scatter, dim3(nb), dim3(256), 0, ctx->stream, (const uint32_t *)v1, (uint32_t)nnz, (uint64_t *)ctx->bEmColIdx.p);
+      hipLaunchKernelGGL(k_em_entry_rows, dim3((nGroups + 3) / 4), dim3(256), 0, ctx->stream, (const uint64_t *)ctx->bEmRowPtr.p, nGroups, rowOfEntry);
+      hipLaunchKernelGGL(k_em_slot_rows, dim3(nb), dim3(256), 0, ctx->stream, (const uint32_t *)v1, (const uint32_t *)rowOfEntry, (uint32_t)nnz, (uint32_t *)ctx->bEmRowOf.p);
       unsigned long long isBad = 0;
       hipError_t e = hipMemcpyAsync(&isBad, bad, 8, hipMemcpyDeviceToHost, ctx->stream);
       if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
@@ -282,14 +336,13 @@ int t1k_em_setup(t1k_ctx *ctx, const uint64_t *rowPtr, const uint32_t *ecIdx, co
   ctx->emRowBegin = 0; ctx->emRowEnd = nGroups; ctx->emComm = nullptr; ctx->emReduceMode = false;
   // class lengths stay on the host (M-step)
   if (nEc) ctx->hEmLen.assign(ecLen, ecLen + nEc); else ctx->hEmLen.clear();
-  ctx->hEmRowPtr.assign(rowPtr, rowPtr + nGroups + 1);  // (t1k_em_shard cuts the contribution array at the ranks' row boundaries)
   return T1K_OK;
 }
 
 int t1k_em_shard(t1k_ctx *ctx, uint32_t rowBegin, uint32_t rowEnd, t1k_comm *comm) {
   if (!ctx || rowBegin > rowEnd || rowEnd > ctx->emGroups) return t1k_fail(ctx, T1K_ERR_ARG, "t1k_em_shard: bad row range");
   ctx->emRowBegin = rowBegin; ctx->emRowEnd = rowEnd; ctx->emComm = comm;
-  // every rank's piece of the row-major contribution array: the ranks' row ranges partition [0, G) in rank order
+  // every rank's piece of the per-group sums: the ranks' row ranges partition [0, G) in rank order
   ctx->emPieceBytes.clear(); ctx->emPieceDispl.clear();
   const int N = comm ? t1k_comm_size(comm) : 1;
   if (N > 1) {
@@ -300,22 +353,16 @@ int t1k_em_shard(t1k_ctx *ctx, uint32_t rowBegin, uint32_t rowEnd, t1k_comm *com
     for (int r = 0; r < N; ++r) {
       if (all[2 * r] != next || all[2 * r + 1] < all[2 * r] || all[2 * r + 1] > ctx->emGroups) return t1k_fail(ctx, T1K_ERR_ARG, "t1k_em_shard: the ranks' row ranges do not partition the read groups in rank order");
       next = all[2 * r + 1];
-      ctx->emPieceDispl.push_back(ctx->hEmRowPtr[all[2 * r]] * 8);
-      ctx->emPieceBytes.push_back((ctx->hEmRowPtr[all[2 * r + 1]] - ctx->hEmRowPtr[all[2 * r]]) * 8);
+      ctx->emPieceDispl.push_back(all[2 * r] * 8);
+      ctx->emPieceBytes.push_back((all[2 * r + 1] - all[2 * r]) * 8);
     }
     if (next != ctx->emGroups) return t1k_fail(ctx, T1K_ERR_ARG, "t1k_em_shard: the ranks' row ranges do not cover the read groups");
   }
   // T1K_EM_COLLECTIVE=allreduce: the collective north_star names -- every rank adds up its OWN rows' contributions per class and the E
-  // partial sums are all-reduced (E doubles per update instead of the nnz-sized gather).  The class totals then differ from the one-GPU
-  // run's by the re-association of the sum (a few ulp), so this mode is opt-in; the default gathers the contributions and stays bit-exact.
-  // Here: the class-major contribution array is zeroed once -- the slots of the other ranks' rows are never written, and x + 0.0 == x.
+  // partial sums are all-reduced (E doubles per update instead of the gather of the G per-group sums).  The class totals then differ from
+  // the one-GPU run's by the re-association of the sum (a few ulp), so this mode is opt-in; the default gathers psum and stays bit-exact.
   const char *mode = getenv("T1K_EM_COLLECTIVE");
   ctx->emReduceMode = N > 1 && mode && !strcmp(mode, "allreduce");
-  if (ctx->emReduceMode && ctx->emNnz) {
-    T1K_HIP(ctx, hipSetDevice(ctx->device));
-    T1K_HIP(ctx, hipMemsetAsync(ctx->bEmContrib.p, 0, (size_t)ctx->emNnz * 8, ctx->stream));
-    T1K_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  }
   return T1K_OK;
 }
 
@@ -332,23 +379,23 @@ int t1k_em_update(t1k_ctx *ctx, const double *x0, double *x1, double *ecReadCoun
     ctx->emPinnedN = E;
   }
   double *px = ctx->emPinned, *pn = ctx->emPinned + ctx->emPinnedN;
+  const auto tu0 = std::chrono::steady_clock::now();
   memcpy(px, x0, (size_t)E * 8);
   T1K_HIP(ctx, hipMemcpyAsync(ctx->bEmX0.p, px, (size_t)E * 8, hipMemcpyHostToDevice, ctx->stream));
   const bool reduce = ctx->emComm && t1k_comm_size(ctx->emComm) > 1 && ctx->emReduceMode;
   const bool sharded = ctx->emComm && t1k_comm_size(ctx->emComm) > 1 && !reduce;
   const uint32_t g0 = (sharded || reduce) ? ctx->emRowBegin : 0, gn = ((sharded || reduce) ? ctx->emRowEnd : G) - g0;
-  if (gn) hipLaunchKernelGGL(k_em_rows, dim3((gn + 3) / 4), dim3(256), 0, ctx->stream, (const uint64_t *)ctx->bEmRowPtr.p + g0, (const uint32_t *)ctx->bEmEc.p,
-                             sharded ? (const uint64_t *)nullptr : (const uint64_t *)ctx->bEmColIdx.p, (const double *)ctx->bEmCount.p + g0, (const double *)ctx->bEmX0.p,
-                             (double *)ctx->bEmContrib.p, gn);
+  if (gn) hipLaunchKernelGGL(k_em_psum, dim3((gn + 3) / 4), dim3(256), 0, ctx->stream, (const uint64_t *)ctx->bEmRowPtr.p + g0, (const uint32_t *)ctx->bEmEc.p,
+                             (const double *)ctx->bEmX0.p, (double *)ctx->bEmPsum.p + g0, gn);
   if (sharded) {
-    // this rank's rows are one contiguous piece of the row-major array: gather everybody's piece in place
+    // this rank's groups are one contiguous piece of psum: gather everybody's piece in place (G doubles in all)
     T1K_HIP(ctx, hipStreamSynchronize(ctx->stream));
     const int me = t1k_comm_rank(ctx->emComm);
-    const int rc = t1k_comm_allgatherv(ctx->emComm, (const char *)ctx->bEmContrib.p + ctx->emPieceDispl[me], ctx->emPieceBytes.data(), ctx->emPieceDispl.data(), ctx->bEmContrib.p);
+    const int rc = t1k_comm_allgatherv(ctx->emComm, (const char *)ctx->bEmPsum.p + ctx->emPieceDispl[me], ctx->emPieceBytes.data(), ctx->emPieceDispl.data(), ctx->bEmPsum.p);
     if (rc != T1K_OK) return t1k_fail(ctx, rc, std::string("t1k_em_update: ") + t1k_comm_last_error(ctx->emComm));
   }
-  hipLaunchKernelGGL(k_em_cols, dim3((E + 3) / 4), dim3(256), 0, ctx->stream, (const uint64_t *)ctx->bEmColPtr.p, (const double *)ctx->bEmContrib.p,
-                     sharded ? (const uint32_t *)ctx->bEmEntryOf.p : (const uint32_t *)nullptr, (double *)ctx->bEmN.p, E);
+  hipLaunchKernelGGL(k_em_cols, dim3((E + 3) / 4), dim3(256), 0, ctx->stream, (const uint64_t *)ctx->bEmColPtr.p, (const uint32_t *)ctx->bEmRowOf.p, (const double *)ctx->bEmCount.p,
+                     (const double *)ctx->bEmPsum.p, (const double *)ctx->bEmX0.p, (double *)ctx->bEmN.p, E, reduce ? g0 : 0u, reduce ? g0 + gn : G);
   if (reduce) {  // partial class totals of this rank's rows -> totals of all rows (E doubles over RCCL / the in-process transport)
     T1K_HIP(ctx, hipStreamSynchronize(ctx->stream));
     const int rc = t1k_comm_allreduce(ctx->emComm, ctx->bEmN.p, E, 1);
@@ -359,7 +406,9 @@ int t1k_em_update(t1k_ctx *ctx, const double *x0, double *x1, double *ecReadCoun
     ctx->emAllreduce(ctx->bEmN.p, E, ctx->emUser);  // RCCL all-reduce of the per-class expected read counts
   }
   T1K_HIP(ctx, hipMemcpyAsync(pn, ctx->bEmN.p, (size_t)E * 8, hipMemcpyDeviceToHost, ctx->stream));
+  const auto tu1 = std::chrono::steady_clock::now();
   T1K_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  const auto tu2 = std::chrono::steady_clock::now();
   memcpy(ecReadCount, pn, (size_t)E * 8);
   // M-step (Genotyper.hpp:406-420), same summation order as the reference
   double norm = 0, d = 0;
@@ -370,7 +419,13 @@ int t1k_em_update(t1k_ctx *ctx, const double *x0, double *x1, double *ecReadCoun
     x1[i] = t;
   }
   if (diff) *diff = d;
+  const auto tu3 = std::chrono::steady_clock::now();
+  ctx->emMs[0] += std::chrono::duration<double, std::milli>(tu1 - tu0).count();
+  ctx->emMs[1] += std::chrono::duration<double, std::milli>(tu2 - tu1).count();
+  ctx->emMs[2] += std::chrono::duration<double, std::milli>(tu3 - tu2).count();
+  ctx->emMs[3] += 1;
   return T1K_OK;
 }
+void t1k_em_times(const t1k_ctx *ctx, double *ms4) { for (int i = 0; i < 4; ++i) ms4[i] = ctx ? ctx->emMs[i] : 0; }
 
 }  // extern "C"

@@ -121,11 +121,17 @@ def test_job_api_batching_and_rerun_invariance(built, tmp_path):
     assert exp == got
 
 
-def test_em_update_bit_exact(ctx):
-    """t1k_em_update vs a sequential numpy restatement of Genotyper::EMupdate (same order of double operations)."""
+@pytest.mark.parametrize("G,E,long_classes", [(3000, 257, False), (20000, 37, True)])
+def test_em_update_bit_exact(ctx, G, E, long_classes):
+    """t1k_em_update vs a sequential numpy restatement of Genotyper::EMupdate (same order of double operations).  The second shape has
+    classes of thousands of entries (the class pass takes them 512 at a time, 64 to an ordered piece), one of exactly 1024, and an empty one."""
     rng = np.random.default_rng(5)
-    G, E = 3000, 257
-    rows = [rng.choice(E, size=rng.integers(1, 40), replace=False) for _ in range(G)]
+    if long_classes:
+        rows = [rng.choice(E - 2, size=rng.integers(1, 30), replace=False) for _ in range(G)]
+        for g in range(100, 100 + 1024):
+            rows[g] = np.append(rows[g], E - 1)  # class E-1: exactly 1024 entries; class E-2: none
+    else:
+        rows = [rng.choice(E, size=rng.integers(1, 40), replace=False) for _ in range(G)]
     row_ptr = np.zeros(G + 1, np.uint64)
     row_ptr[1:] = np.cumsum([len(r) for r in rows])
     ec_idx = np.concatenate(rows).astype(np.uint32)
