@@ -17,6 +17,7 @@ extern "C" {
 int t1k_em_setup(t1k_ctx *, const uint64_t *, const uint32_t *, const double *, const int32_t *, uint32_t, uint32_t, t1k_allreduce_fn, void *) { abort(); }
 int t1k_em_update(t1k_ctx *, const double *, double *, double *, double *) { abort(); }
 int t1k_em_shard(t1k_ctx *, uint32_t, uint32_t, t1k_comm *) { abort(); }
+void t1k_em_times(const t1k_ctx *, double *) { abort(); }
 int t1k_comm_size(const t1k_comm *) { abort(); }
 int t1k_comm_rank(const t1k_comm *) { abort(); }
 const char *t1k_last_error(const t1k_ctx *) { return "no device in this harness"; }
