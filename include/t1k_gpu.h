@@ -346,6 +346,18 @@ const char *t1k_job_last_error(const t1k_job *job);
 int t1k_job_load_reads(t1k_job *job, const char *file1, const char *file2, const char *barcodeFile);
 /* several files per mate, read back to back (ReadFiles::AddReadFile, Genotyper.cpp: every -u / -1 / -2 adds one); files2 NULL = single-end */
 int t1k_job_load_reads_multi(t1k_job *job, const char *const *files1, uint32_t n1, const char *const *files2, uint32_t n2, const char *barcodeFile);
+/* The same input opened on its own, before or beside t1k_job_create (both calls block; a caller with two threads -- the genotyper
+ * executable, bench.py -- maps and indexes the read files while the reference is parsed and the contexts come up; the reference's main
+ * does the two one after the other, Genotyper.cpp:226-232 then 365-454).  `threads` as -t (0 = the default of a job).
+ * t1k_job_attach_reads hands the input to the job exactly as t1k_job_load_reads_multi would have left it and consumes the handle (also
+ * on failure); t1k_reads_close is for a handle that was never attached.  Not for a rank of a sharded job that indexes only its own
+ * fragments (t1k_job_set_shard + t1k_job_load_reads: that open is a collective). */
+typedef struct t1k_reads t1k_reads;
+int t1k_reads_open(const char *const *files1, uint32_t n1, const char *const *files2, uint32_t n2, const char *barcodeFile, int threads, t1k_reads **out);
+const char *t1k_reads_last_error(const t1k_reads *reads);
+int t1k_reads_fragments(const t1k_reads *reads, uint64_t *nFragments);
+void t1k_reads_close(t1k_reads *reads);
+int t1k_job_attach_reads(t1k_job *job, t1k_reads *reads);
 /* or hand reads over from memory: concatenated ASCII + offsets, mates parallel; ids may be NULL ("r<i>") */
 int t1k_job_set_reads(t1k_job *job, const char *seq1, const uint64_t *off1, const char *seq2, const uint64_t *off2, uint32_t nFragments);
 /* read-end assignment, pairing, coalescing, EC build, EM, allele selection (Genotyper.cpp:451-650) */

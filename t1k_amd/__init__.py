@@ -3,8 +3,8 @@
 The product is the C-ABI shared library built from t1k_amd/csrc (include/t1k_gpu.h) plus the drop-in `genotyper`
 executable; this package only holds the ctypes binding used by tests, bench.py and __graft_entry__.py.
 """
-from .capi import (Context, Job, Params, JobParams, lib, lib_path, T1kError, load_reference_fasta,
+from .capi import (Context, Job, Reads, Params, JobParams, lib, lib_path, T1kError, load_reference_fasta,
                    read_fastx, OVERLAP_DTYPE, ROW_DTYPE, Comm, CommGroup, comm_unique_id, pool_release)
 
-__all__ = ["Context", "Job", "Params", "JobParams", "lib", "lib_path", "T1kError", "load_reference_fasta",
+__all__ = ["Context", "Job", "Reads", "Params", "JobParams", "lib", "lib_path", "T1kError", "load_reference_fasta",
            "read_fastx", "OVERLAP_DTYPE", "ROW_DTYPE", "Comm", "CommGroup", "comm_unique_id", "pool_release"]

@@ -104,6 +104,13 @@ def lib():
     L.t1k_pool_release.restype = C.c_uint64
     L.t1k_pool_release.argtypes = []
     L.t1k_job_load_reads_multi.argtypes = [vp, C.POINTER(C.c_char_p), C.c_uint32, C.POINTER(C.c_char_p), C.c_uint32, C.c_char_p]
+    L.t1k_reads_open.argtypes = [C.POINTER(C.c_char_p), C.c_uint32, C.POINTER(C.c_char_p), C.c_uint32, C.c_char_p, C.c_int, C.POINTER(vp)]
+    L.t1k_reads_last_error.argtypes = [vp]
+    L.t1k_reads_last_error.restype = C.c_char_p
+    L.t1k_reads_fragments.argtypes = [vp, u64p]
+    L.t1k_reads_close.argtypes = [vp]
+    L.t1k_reads_close.restype = None
+    L.t1k_job_attach_reads.argtypes = [vp, vp]
     L.t1k_job_genotype_text.argtypes = [vp, C.c_char_p, C.c_uint64, u64p]
     L.t1k_job_counts.argtypes = [vp, u64p, u64p, u64p, u64p, i32p]
     L.t1k_job_stats.argtypes = [vp, C.POINTER(Stats)]
@@ -355,6 +362,43 @@ class Readset:
             pass
 
 
+class Reads:
+    """The read files of a job, mapped and indexed on their own (t1k_reads_open): needs no GPU and no job, so a second thread can open
+    them while Job(...) parses the reference and brings the contexts up (ctypes releases the GIL for both calls); Job.attach_reads
+    takes the input over.  f1 / f2 / barcode as in Job.load_reads."""
+
+    def __init__(self, f1, f2=None, barcode=None, threads=0):
+        l1 = [f1] if isinstance(f1, str) else list(f1)
+        l2 = [] if not f2 else ([f2] if isinstance(f2, str) else list(f2))
+        a1 = (C.c_char_p * len(l1))(*[x.encode() for x in l1])
+        a2 = (C.c_char_p * len(l2))(*[x.encode() for x in l2]) if l2 else None
+        h = C.c_void_p()
+        rc = lib().t1k_reads_open(a1, len(l1), a2, len(l2), barcode.encode() if barcode else None, threads, C.byref(h))
+        if rc != 0:
+            msg = lib().t1k_reads_last_error(h).decode() if h else "bad arguments"
+            if h:
+                lib().t1k_reads_close(h)
+            raise T1kError("t1k_reads_open failed (%d): %s" % (rc, msg))
+        self.h = h
+
+    def fragments(self):
+        n = C.c_uint64()
+        if lib().t1k_reads_fragments(self.h, C.byref(n)) != 0:
+            raise T1kError("t1k_reads_fragments failed")
+        return n.value
+
+    def close(self):
+        if self.h:
+            lib().t1k_reads_close(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Job:
     """Whole-stage job (t1k_job): host C++ around the device stages; same behaviour as the `genotyper` executable."""
 
@@ -400,6 +444,11 @@ class Job:
         a1 = (C.c_char_p * len(l1))(*[x.encode() for x in l1])
         a2 = (C.c_char_p * len(l2))(*[x.encode() for x in l2]) if l2 else None
         self._check(lib().t1k_job_load_reads_multi(self.h, a1, len(l1), a2, len(l2), barcode.encode() if barcode else None), "t1k_job_load_reads")
+
+    def attach_reads(self, reads):
+        """take over a Reads object (consumed, also on failure): the same state load_reads leaves"""
+        h, reads.h = reads.h, None
+        self._check(lib().t1k_job_attach_reads(self.h, h), "t1k_job_attach_reads")
 
     def set_reads(self, seqs1, seqs2=None):
         b1, o1 = _concat(seqs1)

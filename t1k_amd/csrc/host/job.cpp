@@ -68,11 +68,12 @@ static int jobFail(t1k_job *job, int code, const std::string &msg) {
 
 // host threads for parsing, window assembly and the output writers: -t, but never fewer than the machine offers (up to 32) --
 // the GPU path is fed by the host, and the reference's -t default of 1 would starve it
-static int hostThreads(const t1k_job *job) {
+static int hostThreadsFor(int threads) {  // threads: -t
   if (const char *e = getenv("T1K_HOST_THREADS")) return std::max(1, atoi(e));
   const int hw = (int)std::thread::hardware_concurrency();
-  return std::max(1, std::max(job->prm.threads, std::min(hw, 32)));
+  return std::max(1, std::max(threads, std::min(hw, 32)));
 }
+static int hostThreads(const t1k_job *job) { return hostThreadsFor(job->prm.threads); }
 
 template <class F>
 static void parallelRanges(size_t n, int T, F fn) {  // fn(t, begin, end) over contiguous pieces of [0, n)
@@ -252,6 +253,49 @@ int t1k_job_load_reads_multi(t1k_job *job, const char *const *files1, uint32_t n
   job->msLoad = nowMs() - t0;
   if (getenv("T1K_DEBUG_PHASES"))
     fprintf(stderr, "[t1k job] read files mapped + indexed: %zu of %zu fragments, %.1f ms\n", job->in->nFrag(), job->in->nAll(), job->msLoad);
+  return T1K_OK;
+}
+
+// the read input on its own (include/t1k_gpu.h): opened by a second thread of the caller while t1k_job_create runs
+struct t1k_reads {
+  std::unique_ptr<ReadInput> in;
+  std::string err;
+  double ms = 0;
+};
+int t1k_reads_open(const char *const *files1, uint32_t n1, const char *const *files2, uint32_t n2, const char *barcodeFile, int threads, t1k_reads **out) {
+  if (!out) return T1K_ERR_ARG;
+  *out = nullptr;
+  if (!files1 || n1 == 0) return T1K_ERR_ARG;
+  t1k_reads *r = new t1k_reads();
+  *out = r;  // handed back even on failure so the caller can read the message
+  const double t0 = nowMs();
+  r->in.reset(new ReadInput());
+  std::vector<std::string> f1(files1, files1 + n1), f2;
+  if (files2) f2.assign(files2, files2 + n2);
+  if (!r->in->open(f1, f2, barcodeFile ? barcodeFile : "", hostThreadsFor(threads), r->err)) { r->in.reset(); return T1K_ERR_IO; }
+  r->ms = nowMs() - t0;
+  return T1K_OK;
+}
+const char *t1k_reads_last_error(const t1k_reads *r) { return r ? r->err.c_str() : "no read input"; }
+int t1k_reads_fragments(const t1k_reads *r, uint64_t *nFragments) {
+  if (!r || !r->in || !nFragments) return T1K_ERR_ARG;
+  *nFragments = r->in->nAll();
+  return T1K_OK;
+}
+void t1k_reads_close(t1k_reads *r) { delete r; }
+int t1k_job_attach_reads(t1k_job *job, t1k_reads *r) {
+  if (!job || !r) { delete r; return T1K_ERR_ARG; }
+  if (!r->in) { job->err = r->err.empty() ? "t1k_job_attach_reads: the read input was not opened" : r->err; delete r; return T1K_ERR_IO; }
+  if (job->nRanks > 1 && job->comm && !getenv("T1K_NO_SHARDED_INPUT")) {  // (a rank of a sharded job opens its own share: t1k_job_load_reads)
+    delete r;
+    return jobFail(job, T1K_ERR_STATE, "t1k_job_attach_reads: a rank of a sharded job indexes its own fragments (t1k_job_set_shard, then t1k_job_load_reads)");
+  }
+  job->in = std::move(r->in);
+  job->ran = false; job->localDone = false;
+  job->msLoad = r->ms;
+  if (getenv("T1K_DEBUG_PHASES"))
+    fprintf(stderr, "[t1k job] read files mapped + indexed beside the job's creation: %zu of %zu fragments, %.1f ms\n", job->in->nFrag(), job->in->nAll(), job->msLoad);
+  delete r;
   return T1K_OK;
 }
 
@@ -1502,23 +1546,40 @@ int t1k_genotyper_main(int argc, char **argv) {
   std::vector<t1k_job *> jobs(R, nullptr);
   std::vector<int> rcs(R, T1K_OK);
   auto destroyAll = [&] { for (t1k_job *j : jobs) t1k_job_destroy(j); };
+  const bool paired = !f2.empty();
+  const std::vector<const char *> &first = !f1.empty() ? f1 : single;
+  // T1K_SHARD_INPUT=1: every rank indexes only its own fragments and writes only its own part of the *_aligned*.fa files, as ranks
+  // in separate processes do (bench.py under torchrun); by default the ranks of this process share one index built by all host threads
+  const bool shardInput = R > 1 && getenv("T1K_SHARD_INPUT") && atoi(getenv("T1K_SHARD_INPUT")) != 0;
+  // the read files are mapped and indexed while the reference is parsed and the contexts come up (the reference's main does the two
+  // one after the other, Genotyper.cpp:226-232 and 365-454; neither needs the other)
+  t1k_reads *opened = nullptr;
+  int rcOpen = T1K_OK;
+  std::thread opener;
+  if (!shardInput && !first.empty() && !getenv("T1K_SERIAL_OPEN"))
+    opener = std::thread([&] {
+      rcOpen = t1k_reads_open(first.data(), (uint32_t)first.size(), paired ? f2.data() : nullptr, (uint32_t)f2.size(), barcode.empty() ? nullptr : barcode.c_str(), p.threads, &opened);
+    });
   {
     std::vector<std::thread> th;
     for (int r = 0; r < R; ++r)
       th.emplace_back([&, r] { t1k_job_params q = p; q.device = devices[r]; rcs[r] = t1k_job_create(&q, refFile.c_str(), &jobs[r]); });
     for (auto &t : th) t.join();
   }
+  const bool openedBeside = opener.joinable();
+  if (openedBeside) opener.join();
   for (int r = 0; r < R; ++r)
     if (rcs[r] != T1K_OK) {
       fprintf(stderr, "genotyper: %s\n", jobs[r] ? t1k_job_last_error(jobs[r]) : "initialisation failed");
       if (jobs[r] && jobs[r]->ref.al.empty()) fprintf(stderr, "Need to use -f to specify the reference sequences.\n");
       destroyAll();
+      t1k_reads_close(opened);
       return EXIT_FAILURE;
     }
   t1k_job *job = jobs[0];
   if (!whitelistFile.empty()) {  // Genotyper::SetAlleleWhitelist (Genotyper.hpp:684-705): whole major-allele series
     FILE *fp = fopen(whitelistFile.c_str(), "r");
-    if (!fp) { fprintf(stderr, "genotyper: cannot open %s\n", whitelistFile.c_str()); destroyAll(); return EXIT_FAILURE; }
+    if (!fp) { fprintf(stderr, "genotyper: cannot open %s\n", whitelistFile.c_str()); destroyAll(); t1k_reads_close(opened); return EXIT_FAILURE; }
     std::set<int> majors;
     std::map<std::string, int> majorId;
     for (size_t i = 0; i < job->ref.majorName.size(); ++i) majorId[job->ref.majorName[i]] = (int)i;
@@ -1536,18 +1597,14 @@ int t1k_genotyper_main(int argc, char **argv) {
     }
   }
   for (t1k_job *j : jobs) j->abundanceFile = abundance;
-  const bool paired = !f2.empty();
-  const std::vector<const char *> &first = !f1.empty() ? f1 : single;
-  if (first.empty()) { fprintf(stderr, "genotyper: no read file given (-u, or -1 and -2)\n"); destroyAll(); return EXIT_FAILURE; }
-  // T1K_SHARD_INPUT=1: every rank indexes only its own fragments and writes only its own part of the *_aligned*.fa files, as ranks
-  // in separate processes do (bench.py under torchrun); by default the ranks of this process share one index built by all host threads
-  const bool shardInput = R > 1 && getenv("T1K_SHARD_INPUT") && atoi(getenv("T1K_SHARD_INPUT")) != 0;
+  if (first.empty()) { fprintf(stderr, "genotyper: no read file given (-u, or -1 and -2)\n"); destroyAll(); t1k_reads_close(opened); return EXIT_FAILURE; }
   auto loadInto = [&](t1k_job *j) {
     return t1k_job_load_reads_multi(j, first.data(), (uint32_t)first.size(), paired ? f2.data() : nullptr, (uint32_t)f2.size(), barcode.empty() ? nullptr : barcode.c_str());
   };
   int rc = T1K_OK;
   if (!shardInput) {
-    rc = loadInto(job);
+    if (openedBeside) { rc = t1k_job_attach_reads(job, opened); opened = nullptr; if (rc == T1K_OK) rc = rcOpen; }  // (a failed open: the handle carries the message into the job)
+    else rc = loadInto(job);
     if (rc != T1K_OK) { fprintf(stderr, "genotyper: %s\n", t1k_job_last_error(job)); destroyAll(); return EXIT_FAILURE; }
     logLine("Found %d read fragments. Start read assignment.", (int)job->in->nAll());
     t1k_job_set_output_prefix(job, prefix.c_str());  // the aligned-read files are written while the EM runs

@@ -100,6 +100,18 @@ def test_fastx_reader_conventions(built, tmp_path):
     assert recs == [("r1", "extra words", "ACGTNN"), ("r2", "", "TTTT"), ("f3", "7 0 3", "ACGT")]
 
 
+def test_read_input_opens_without_a_job(built, tmp_path):
+    """t1k_reads_open is host-only (no GPU, no job): fragment count of the mapped files, error text of a missing one"""
+    a, b = tmp_path / "a_1.fq", tmp_path / "a_2.fq"
+    a.write_text("@r1/1\nACGT\n+\nIIII\n@r2/1\nACGTA\n+\nIIIII\n")
+    b.write_text("@r1/2\nTTTT\n+\nIIII\n@r2/2\nTTTTA\n+\nIIIII\n")
+    r = t1k_amd.Reads(str(a), str(b))
+    assert r.fragments() == 2
+    r.close()
+    with pytest.raises(t1k_amd.T1kError, match="missing.fq"):
+        t1k_amd.Reads(str(tmp_path / "missing.fq"))
+
+
 def test_reference_loader_merges_identical_sequences(built, tmp_path):
     p = tmp_path / "r.fa"
     p.write_text(">A*01 2 0 3 6 9\nACGTACGTAC\n>A*02 2 0 3 6 9\nACGTACGTAC\n>A*03\nACGTTTTTAC\n")

@@ -355,6 +355,40 @@ def test_gzip_read_files(built, tmp_path):
     _golden_files_equal(c, out)
 
 
+def test_reads_opened_beside_job_creation(built, tmp_path):
+    """t1k_reads_open on a second thread while t1k_job_create runs, then t1k_job_attach_reads (what the executable and bench.py do) leaves
+    the job as t1k_job_load_reads does; the executable's serial order (T1K_SERIAL_OPEN=1) writes the same files; a failed open arrives
+    as the job's error"""
+    import threading
+    c = goldens.Case("cyp_rna_2x100", str(tmp_path))
+    texts = []
+    job = t1k_amd.Job(c.ref, ref_seq_similarity=0.97)
+    job.load_reads(c.r1, c.r2)
+    job.run()
+    texts.append((job.genotype_text(), job.counts()))
+    job.close()
+    box = {}
+    th = threading.Thread(target=lambda: box.update(reads=t1k_amd.Reads(c.r1, c.r2)))
+    th.start()
+    job = t1k_amd.Job(c.ref, ref_seq_similarity=0.97)
+    th.join()
+    assert box["reads"].fragments() == texts[0][1]["fragments"]
+    job.attach_reads(box["reads"])
+    assert box["reads"].h is None  # consumed
+    job.run()
+    texts.append((job.genotype_text(), job.counts()))
+    job.close()
+    assert texts[0] == texts[1]
+    with pytest.raises(t1k_amd.T1kError):
+        t1k_amd.Reads(os.path.join(str(tmp_path), "missing_1.fq"), c.r2)
+    out = os.path.join(str(tmp_path), "serial")
+    r = subprocess.run([GENO] + c.args() + ["-o", out], stderr=subprocess.PIPE, text=True, env=dict(os.environ, T1K_SERIAL_OPEN="1"))
+    assert r.returncode == 0, r.stderr
+    _golden_files_equal(c, out)
+    r = subprocess.run([GENO, "-f", c.ref, "-1", os.path.join(str(tmp_path), "missing_1.fq"), "-2", c.r2, "-o", out], stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 1 and "missing_1.fq" in r.stderr
+
+
 def test_several_files_per_mate_and_wrapped_fasta(built, tmp_path):
     """every -1 / -2 counts and the files are read back to back (ReadFiles::AddReadFile); the second half is given as FASTA with the
     sequences wrapped at 60 columns and CRLF line ends, which the in-place indexer hands to the general (kseq-rule) reader"""
