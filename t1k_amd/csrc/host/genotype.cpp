@@ -142,10 +142,18 @@ void Genotyper::finalize(const std::vector<int32_t> &missing) {
       if (inAllele[a][i].first != inAllele[b][i].first) return false;
     return true;
   };
-  for (int i = 0; i < A && keys[i].fp != -1; ++i) {
-    int joined = -1;
-    for (int j = i - 1; j >= 0 && keys[j].fp == keys[i].fp; --j)
-      if (sameGroups(keys[i].allele, keys[j].allele)) { joined = R.al[keys[j].allele].ec; break; }
+  // which earlier allele of the same fingerprint an allele joins (the nearest one with the same group list, Genotyper.hpp:1100-1125) does
+  // not depend on the class numbers: the list comparisons -- one walk over every allele's list, 24 M entries at 10 M pairs -- run on the
+  // host threads, the numbering below stays sequential
+  int nKeyed = 0;
+  while (nKeyed < A && keys[nKeyed].fp != -1) ++nKeyed;
+  std::vector<int> joinTo((size_t)nKeyed, -1);
+  parallelFor((size_t)nKeyed, [&](size_t i) {
+    for (int j = (int)i - 1; j >= 0 && keys[j].fp == keys[i].fp; --j)
+      if (sameGroups(keys[i].allele, keys[j].allele)) { joinTo[i] = j; break; }
+  });
+  for (int i = 0; i < nKeyed; ++i) {
+    const int joined = joinTo[i] < 0 ? -1 : R.al[keys[joinTo[i]].allele].ec;
     if (joined < 0) { R.al[keys[i].allele].ec = (int)ecAlleles.size(); ecAlleles.push_back({keys[i].allele}); }
     else { R.al[keys[i].allele].ec = joined; ecAlleles[joined].push_back(keys[i].allele); }
   }
@@ -196,6 +204,8 @@ int Genotyper::quantify(t1k_ctx *ctx, t1k_comm *comm, std::string &err) {
     if (T < 1 || G < 8192) T = 1;
     const size_t piece = (G + T - 1) / T;
     std::vector<std::vector<uint32_t>> part(T);
+    std::vector<uint32_t> ecOf(R.al.size());  // (4 bytes an allele instead of a walk through the allele records: the table stays in cache)
+    for (size_t a = 0; a < R.al.size(); ++a) ecOf[a] = (uint32_t)R.al[a].ec;
     parallelFor(T, [&](size_t t) {
       const size_t g0 = t * piece, g1 = std::min(G, g0 + piece);
       std::vector<int> seen(E, 0);
@@ -209,7 +219,7 @@ int Genotyper::quantify(t1k_ctx *ctx, t1k_comm *comm, std::string &err) {
         count[gl] = c;
         const size_t before = out.size();
         for (uint64_t p = groupPtr[g]; p < groupPtr[g + 1]; ++p) {
-          const uint32_t ec = (uint32_t)R.al[groupEnt[p].allele].ec;
+          const uint32_t ec = ecOf[groupEnt[p].allele];
           if (seen[ec] == (int)(gl - g0) + 1) continue;
           seen[ec] = (int)(gl - g0) + 1;
           out.push_back(ec);
