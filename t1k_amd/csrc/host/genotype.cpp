@@ -1,6 +1,7 @@
 // t1k_amd/csrc/host/genotype.cpp -- read-group coalescing, equivalence classes, the SQUAREM control loop around the
 // device E-step, likelihood pruning, allele selection and the TSV text of the genotyper stage.
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -25,6 +26,27 @@ void parallelFor(size_t n, F fn, size_t serialBelow = 256) {
     if (b >= e) break;
     th.emplace_back([b, e, &fn] { for (size_t i = b; i < e; ++i) fn(i); });
   }
+  for (auto &x : th) x.join();
+}
+// the same over items of very unequal cost (an allele's list holds 1 .. 10^5 entries, long ones next to each other): the threads
+// take `grain` items at a time from a shared counter
+template <class F>
+void parallelForDynamic(size_t n, size_t grain, F fn) {
+  unsigned T = std::thread::hardware_concurrency();
+  if (T > 32) T = 32;
+  if (T < 2 || n <= grain) { for (size_t i = 0; i < n; ++i) fn(i); return; }
+  std::atomic<size_t> next{0};
+  auto work = [&] {
+    for (;;) {
+      const size_t b = next.fetch_add(grain);
+      if (b >= n) break;
+      const size_t e = std::min(n, b + grain);
+      for (size_t i = b; i < e; ++i) fn(i);
+    }
+  };
+  std::vector<std::thread> th;
+  for (unsigned t = 1; t < T; ++t) th.emplace_back(work);
+  work();
   for (auto &x : th) x.join();
 }
 }  // namespace
@@ -109,7 +131,7 @@ void Genotyper::finalize(const std::vector<int32_t> &missing) {
         for (uint64_t p = groupPtr[g]; p < groupPtr[g + 1]; ++p) ++cnt[t][groupEnt[p].allele];
     }, 1);
     inAllele.assign(A, {});
-    parallelFor((size_t)A, [&](size_t a) {
+    parallelForDynamic((size_t)A, 32, [&](size_t a) {
       uint32_t run = 0;
       for (unsigned t = 0; t < T; ++t) { const uint32_t c = cnt[t][a]; cnt[t][a] = run; run += c; }
       inAllele[a].resize(run);
@@ -123,9 +145,10 @@ void Genotyper::finalize(const std::vector<int32_t> &missing) {
         }
     }, 1);
   }
+  const double tfa = hostNowMs();
   struct Key { int allele, fp; };
   std::vector<Key> keys(A);
-  parallelFor((size_t)A, [&](size_t a) {
+  parallelForDynamic((size_t)A, 32, [&](size_t a) {
     R.al[a].ec = -1;
     int fp = -1;
     if (!inAllele[a].empty()) {
@@ -135,6 +158,7 @@ void Genotyper::finalize(const std::vector<int32_t> &missing) {
     keys[a] = Key{(int)a, fp};
   });
   std::sort(keys.begin(), keys.end(), [](const Key &x, const Key &y) { return x.fp != y.fp ? y.fp < x.fp : x.allele < y.allele; });
+  const double tfb = hostNowMs();
   ecAlleles.clear();
   auto sameGroups = [&](int a, int b) {
     if (inAllele[a].size() != inAllele[b].size()) return false;
@@ -148,7 +172,7 @@ void Genotyper::finalize(const std::vector<int32_t> &missing) {
   int nKeyed = 0;
   while (nKeyed < A && keys[nKeyed].fp != -1) ++nKeyed;
   std::vector<int> joinTo((size_t)nKeyed, -1);
-  parallelFor((size_t)nKeyed, [&](size_t i) {
+  parallelForDynamic((size_t)nKeyed, 32, [&](size_t i) {
     for (int j = (int)i - 1; j >= 0 && keys[j].fp == keys[i].fp; --j)
       if (sameGroups(keys[i].allele, keys[j].allele)) { joinTo[i] = j; break; }
   });
@@ -161,7 +185,7 @@ void Genotyper::finalize(const std::vector<int32_t> &missing) {
   // share their group lists.
   const double tf1 = hostNowMs();
   for (int a = 0; a < A; ++a) R.al[a].missingCov = missing[a];  // GetSeqMissingBaseCoverage, computed on the device
-  if (getenv("T1K_DEBUG_PHASES")) fprintf(stderr, "[t1k host] finalize: group lists + classes %.1f ms, rest %.1f ms\n", tf1 - tf0, hostNowMs() - tf1);
+  if (getenv("T1K_DEBUG_PHASES")) fprintf(stderr, "[t1k host] finalize: group lists %.1f ms, fingerprints + sort %.1f ms, classes %.1f ms, rest %.1f ms\n", tfa - tf0, tfb - tfa, tf1 - tfb, hostNowMs() - tf1);
 }
 
 void Genotyper::setAbundance(const double *n, const std::vector<int> &ecLen) {
@@ -196,7 +220,7 @@ int Genotyper::quantify(t1k_ctx *ctx, t1k_comm *comm, std::string &err) {
   // rows of the E-step: per read group its count (the largest weight of the row, 1155-1164) and its distinct classes in
   // first-appearance order (1165-1189).  Groups are independent: the host threads take contiguous pieces (a piece's rows keep their order).
   std::vector<uint64_t> rowPtr(G + 1, 0);
-  std::vector<uint32_t> ecIdx;
+  std::vector<uint32_t, NoInitAlloc<uint32_t>> ecIdx;  // (95 MB at 10 M pairs: filled by the threads below, not zeroed by one first)
   std::vector<double> count(G);
   {
     unsigned T = std::thread::hardware_concurrency();
@@ -301,20 +325,43 @@ int Genotyper::quantify(t1k_ctx *ctx, t1k_comm *comm, std::string &err) {
 // ------------------------------------------------------------------------------------------------------------------
 void Genotyper::dropUnlikely() {
   RefSet &R = *ref;
+  // The reference walks the groups of the class representative and picks out the members' entries (1398-1416).  Class members share
+  // their group list by construction, so those entries are exactly each member's own entries: the covered span of EVERY allele (smallest
+  // start, largest end over its entries) comes out of one pass over the entry table in storage order -- the host threads take contiguous
+  // pieces and their minima / maxima are combined -- instead of 24 M scattered reads through the per-allele lists.
+  const size_t A = R.al.size(), G = nGroups();
+  std::vector<int> spanLo(A), spanHi(A, -1);
+  for (size_t a = 0; a < A; ++a) spanLo[a] = R.al[a].seqLen;
+  {
+    unsigned T = std::thread::hardware_concurrency();
+    if (T > 32) T = 32;
+    if (T < 1 || G < 8192) T = 1;
+    const uint64_t nEnt = G ? groupPtr[G] : 0, piece = (nEnt + T - 1) / T;
+    std::vector<std::vector<int>> lo(T), hi(T);
+    parallelFor(T, [&](size_t t) {
+      const uint64_t p0 = t * piece, p1 = std::min(nEnt, p0 + piece);
+      if (p0 >= p1) return;
+      lo[t] = spanLo;  // (seqLen: the reference's initial value)
+      hi[t].assign(A, -1);
+      for (uint64_t p = p0; p < p1; ++p) {
+        const GroupEntry &e = groupEnt[p];
+        if (e.start < lo[t][e.allele]) lo[t][e.allele] = e.start;
+        if (e.end > hi[t][e.allele]) hi[t][e.allele] = e.end;
+      }
+    }, 1);
+    for (unsigned t = 0; t < T; ++t) {
+      if (lo[t].empty()) continue;
+      for (size_t a = 0; a < A; ++a) {
+        if (lo[t][a] < spanLo[a]) spanLo[a] = lo[t][a];
+        if (hi[t][a] > spanHi[a]) spanHi[a] = hi[t][a];
+      }
+    }
+  }
   parallelFor(ecAlleles.size(), [&](size_t ci) {
     std::vector<int> &members = ecAlleles[ci];
     const int size = (int)members.size();
     std::vector<int> lo(size), hi(size, -1);
-    // The reference walks the groups of the class representative and picks out the members' entries (1398-1416).  Class
-    // members share their group list by construction, so those entries are exactly each member's own (group, slot) list.
-    for (int j = 0; j < size; ++j) {
-      lo[j] = R.al[members[j]].seqLen;
-      for (auto &gs : inAllele[members[j]]) {
-        const GroupEntry &e = groupEnt[groupPtr[gs.first] + gs.second];
-        if (e.start < lo[j]) lo[j] = e.start;
-        if (e.end > hi[j]) hi[j] = e.end;
-      }
-    }
+    for (int j = 0; j < size; ++j) { lo[j] = spanLo[members[j]]; hi[j] = spanHi[members[j]]; }
     std::vector<double> ll(size);
     double best = -1;
     for (int j = 0; j < size; ++j) {
