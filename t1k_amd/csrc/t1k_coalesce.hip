@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) void k_co_reduce(const uint32_t *tileGroup, co
 // arrive: four times the rows in flight per chain.
 __global__ __launch_bounds__(256) void k_co_reduce_long(const uint32_t *tileGroup, const unsigned long long *tilePtr, const uint32_t *order, const uint32_t *runStart,
                                                         const unsigned long long *ptrSorted, const uint32_t *gSize, const unsigned long long *groupPtr,
-                                                        T1kGroupEnt *out, uint32_t longRun) {
+                                                        T1kGroupEnt *out, uint32_t longRun, uint32_t laneStride) {
   __shared__ int4 sAcc[64];
   const uint64_t tile = blockIdx.x;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -186,9 +186,15 @@ __global__ __launch_bounds__(256) void k_co_reduce_long(const uint32_t *tileGrou
   unsigned long long pNext[CO_B];
   int4 e[CO_B];
   // (indices past the run are clamped to its last row: every load is unconditional, the fold counts)
+  // (The row addresses are the same for every lane, and a uniform load is a SCALAR load: it counts with the LDS operations, out of order,
+  // so the wait before every meeting point -- lgkmcnt(0) -- waited for the addresses just requested to come back, a memory latency on
+  // every turn.  laneStride is 0: the index only looks lane-dependent to the compiler, and the addresses come through the vector
+  // memory path, whose counter the meeting points do not wait for.)
   auto loadPtrs = [&](uint32_t b) {
+    typedef const __attribute__((address_space(1))) unsigned long long GPtr;
+    GPtr *ps = (GPtr *)ptrSorted + (uint32_t)lane * laneStride;
 #pragma unroll
-    for (int u = 0; u < CO_B; ++u) pNext[u] = ptrSorted[min(j0 + 1 + b * CO_B + (uint32_t)u, j1 - 1)];
+    for (int u = 0; u < CO_B; ++u) pNext[u] = ps[min(j0 + 1 + b * CO_B + (uint32_t)u, j1 - 1)];
   };
   auto loadRows = [&]() {
 #pragma unroll
@@ -238,11 +244,13 @@ __global__ __launch_bounds__(256) void k_co_reduce_long(const uint32_t *tileGrou
       a.z = __float_as_int(wt); a.w = __float_as_int(aw);
       sAcc[lane] = a;
     }
-    // this wavefront's next batch (clamped past the run: loaded and never folded): its addresses are here, its rows have the other
-    // wavefronts' turns to arrive
+    // The accumulators are handed over FIRST: the next wavefront folds while this one requests its next batch (clamped past the run:
+    // loaded and never folded; its addresses are here, its rows have the other wavefronts' turns to arrive).  Requesting before the
+    // hand-over, as round 3 did, put the issue of 32 loads and their addresses on every turn's critical path: it was as long as the fold.
+    meet();
     loadRows();
     loadPtrs(min(b + 8, nBatches - 1));
-    for (int t = ws; t < 4; ++t) meet();
+    for (int t = ws + 1; t < 4; ++t) meet();
   }
   if (w == 0 && act) {
     const int4 a = sAcc[lane];
@@ -420,7 +428,7 @@ int t1k_rowset_coalesce_sized(t1k_rowset *rs, uint64_t *nGroups, uint64_t *nEntr
   {
     static const uint32_t longRun = getenv("T1K_CO_LONG_RUN") ? (uint32_t)std::max(2 * CO_B + 2, atoi(getenv("T1K_CO_LONG_RUN"))) : (uint32_t)CO_LONG_RUN;  // (0xFFFFFFFF-like values: every group through k_co_reduce)
     hipLaunchKernelGGL(k_co_reduce_long, dim3((unsigned)nTiles), dim3(256), 0, st, tileGroup, tilePtr, order, runStart, ptrSorted, gSize, groupPtr,
-                       (T1kGroupEnt *)rs->bGroupEnt.p, longRun);
+                       (T1kGroupEnt *)rs->bGroupEnt.p, longRun, 0u);
     hipLaunchKernelGGL(k_co_reduce, dim3((unsigned)((nTiles + 3) / 4)), dim3(256), 0, st, tileGroup, tilePtr, order, runStart, ptrSorted, gSize, groupPtr,
                        (T1kGroupEnt *)rs->bGroupEnt.p, nTiles, longRun);
   }
