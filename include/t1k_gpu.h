@@ -149,6 +149,9 @@ void t1k_rowset_destroy(t1k_rowset *rs);
 /* raw != 0: t1k_pair_into stores the fragment assignment list itself (SeqSet::ReadAssignmentToFragmentAssignment's result) without the
  * -n / separator / whitelist drops of SetReadAssignments -- what the analyzer's BarcodeSummary::AddFragment reads (BarcodeSummary.hpp:24-57) */
 int t1k_rowset_set_raw(t1k_rowset *rs, int raw);
+/* device memory the row chunks hold so far and (rowEntries, may be NULL) the row entries written so far: the job layer projects the whole
+ * job's rows from them when it decides which windows keep their read sets */
+int t1k_rowset_device_bytes(t1k_rowset *rs, uint64_t *bytes, uint64_t *rowEntries);
 const char *t1k_rowset_last_error(const t1k_rowset *rs);
 int t1k_pair_into(t1k_ctx *ctx, t1k_rowset *rs, const uint32_t *end1, const uint32_t *end2, const uint8_t *hasN, uint32_t nFragments, uint64_t fragBase);
 int t1k_rowset_coalesce(t1k_rowset *rs, uint64_t *nGroups, uint64_t *nEntries, uint64_t *assignedFragments);

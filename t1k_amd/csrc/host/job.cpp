@@ -517,6 +517,7 @@ int t1k_job_run_local(t1k_job *job) {
     uint32_t oldest = 0;  // first window that is not done
     uint32_t created = 0; // windows cut so far
     bool allCreated = false;
+    uint64_t pairedFrags = 0;  // fragments whose rows are written (with stats.rows: the job's rows per fragment so far)
   } sh;
   auto fail = [&](int code, const std::string &msg) {
     std::lock_guard<std::mutex> g(sh.m);
@@ -582,7 +583,32 @@ int t1k_job_run_local(t1k_job *job) {
           uint64_t open = 0;  // windows cut earlier whose read sets are not kept yet
           for (uint32_t v = sh.oldest; v < w; ++v)
             if (win[v].deferred && !win[v].done) open += estimate(win[v]);
-          if (archivedBytes + open + estimate(N) <= archiveBudget) N.deferred = true;
+          bool fits = archivedBytes + open + estimate(N) <= archiveBudget;
+          // ... and beside the rows of the WHOLE job: 24 bytes per (fragment, allele) add up to more than the read sets on a large job
+          // (124 GB at 50 M pairs of the benchmark's sample, where half the device for read sets ended the job with "out of memory" in
+          // the overlap store).  The fragments paired so far give the job's rows per fragment (both counted under this lock); what is
+          // allocated now beside rows and kept sets (arenas, reference, the window in flight) stays.
+          if (fits && sh.pairedFrags >= 65536 && !getenv("T1K_ARCHIVE_GB")) {
+            uint64_t freeNow = 0, totalNow = 0, rowsNow = 0, entriesNow = 0;
+            if (t1k_device_memory(job->prm.device, &freeNow, &totalNow) == T1K_OK && t1k_rowset_device_bytes(job->rows, &rowsNow, &entriesNow) == T1K_OK && totalNow) {
+              const double projectedRows = (double)entriesNow / (double)sh.pairedFrags * (double)F * sizeof(t1k_row_entry) * 1.1 + 32.0 * (double)F + 4e9;  // (+ 10 %, the per-fragment tables, chunk slack)
+              const uint64_t usedNow = totalNow - std::min(freeNow, totalNow);
+              const uint64_t other = usedNow > archivedBytes + rowsNow ? usedNow - archivedBytes - rowsNow : 0;
+              const double coalesceWork = 48.0 * (double)F + 8e9;  // (sort keys and tables of the coalescing, the EM's arrays, a margin)
+              // (a window that is not kept still holds its read set while it is in flight, and so does the one prepared behind it: what is
+              // allocated now covers the windows in flight now, one more of full size may come on top while fragments remain)
+              const double transient = perFrag * (double)std::min<uint64_t>(windowFrags, F - N.f1);
+              fits = (double)other + (double)(archivedBytes + open + estimate(N)) + std::max(projectedRows, (double)rowsNow) + coalesceWork + transient <= (double)totalNow;
+              if (getenv("T1K_DEBUG_ARCHIVE"))
+                fprintf(stderr, "[t1k job] window %u (%u fragments): %llu row entries in the chunks, %llu fragments paired, stats.rows %llu, rows %.1f GB, kept %.1f + open %.1f + this %.1f GB, other %.1f GB, transient %.1f GB -> %s\n",
+                        w, N.f1 - N.f0, (unsigned long long)entriesNow, (unsigned long long)sh.pairedFrags, (unsigned long long)job->stats.rows, rowsNow / 1e9, archivedBytes / 1e9, open / 1e9,
+                        estimate(N) / 1e9, other / 1e9, transient / 1e9, fits ? "kept" : "not kept");
+              if (!fits && getenv("T1K_DEBUG_PHASES"))
+                fprintf(stderr, "[t1k job] window %u: read sets are not kept from here on: %.1f GB of rows projected for the job (%.1f GB so far), %.1f GB kept, %.1f GB other, device %.1f GB\n",
+                        w, projectedRows / 1e9, rowsNow / 1e9, archivedBytes / 1e9, other / 1e9, totalNow / 1e9);
+            }
+          }
+          if (fits) N.deferred = true;
           else eagerFromNowOn = true;
         }
         fNext = N.f1;
@@ -799,6 +825,7 @@ int t1k_job_run_local(t1k_job *job) {
           t1k_stats_get(ctx, &st);
           std::lock_guard<std::mutex> g(sh.m);
           job->stats.ms_pair += st.ms_pair; job->stats.pair_overlaps += st.pair_overlaps; job->stats.rows += st.rows;
+          sh.pairedFrags += nq;
         }
       }
       if (r != T1K_OK) { fail(r, msg); return; }

@@ -11,7 +11,8 @@ for P in ${1:-1000000 3000000 10000000 20000000 30000000 50000000}; do
   T1K_DEBUG_PHASES=1 t1k_amd/bin/genotyper -f $W/hla_g24_s1.0.fa -1 $W/reads_g24_s1.0_p${P}_seed2_1.fq -2 $W/reads_g24_s1.0_p${P}_seed2_2.fq -s 0.97 -o $W/sz 2> $W/sz.err; rc=$?
   ms=$(( ($(date +%s%N) - t0) / 1000000 ))
   echo "== $P pairs: rc $rc, $ms ms wall = $(( P * 1000 / ms )) pairs/s, genotype md5 $(md5sum < $W/sz_genotype.tsv | cut -c1-8)" >> $LOG
-  grep "windows,\|read sets of\|device memory\|device+download\|read files mapped" $W/sz.err | cut -c1-260 >> $LOG
+  grep "windows,\|read sets of\|read sets are not kept\|device memory\|device+download\|read files mapped\|^genotyper:" $W/sz.err | cut -c1-260 >> $LOG
+  [ $rc -ne 0 ] && grep -v "^\[t1k\] \(fullalign\|range\|band\|equal\)" $W/sz.err | tail -6 | cut -c1-400 >> $LOG
   rm -f $W/sz_aligned_1.fa $W/sz_aligned_2.fa
   [ $P -gt 10000000 ] && rm -f $W/reads_g24_s1.0_p${P}_seed2_*.fq $W/reads_g24_s1.0_p${P}_seed2_truth.tsv
   sleep 10
