@@ -584,10 +584,10 @@ int t1k_job_run_local(t1k_job *job) {
           for (uint32_t v = sh.oldest; v < w; ++v)
             if (win[v].deferred && !win[v].done) open += estimate(win[v]);
           bool fits = archivedBytes + open + estimate(N) <= archiveBudget;
-          // ... and beside the rows of the WHOLE job: 24 bytes per (fragment, allele) add up to more than the read sets on a large job
-          // (124 GB at 50 M pairs of the benchmark's sample, where half the device for read sets ended the job with "out of memory" in
-          // the overlap store).  The fragments paired so far give the job's rows per fragment (both counted under this lock); what is
-          // allocated now beside rows and kept sets (arenas, reference, the window in flight) stays.
+          // ... and beside everything else the job holds at its peak (50 M pairs of the benchmark's sample ended with "out of memory" in the
+          // overlap store under the half-the-device rule alone, 30 M ran within 20 GB of the device): what is allocated now beside rows and
+          // kept sets (arenas, reference, the windows in flight), the rows projected for the whole job (the chunk cursors over the fragments
+          // paired so far), one more full window in flight, the coalescing's work space.
           if (fits && sh.pairedFrags >= 65536 && !getenv("T1K_ARCHIVE_GB")) {
             uint64_t freeNow = 0, totalNow = 0, rowsNow = 0, entriesNow = 0;
             if (t1k_device_memory(job->prm.device, &freeNow, &totalNow) == T1K_OK && t1k_rowset_device_bytes(job->rows, &rowsNow, &entriesNow) == T1K_OK && totalNow) {
