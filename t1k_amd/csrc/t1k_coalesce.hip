@@ -476,34 +476,7 @@ int t1k_rowset_groups_download(t1k_rowset *rs, uint64_t *groupPtr, t1k_group_ent
     if (G) RS_HIP(hipMemcpy(groupPtr, rs->bGroupPtr.p, (G + 1) * 8, hipMemcpyDeviceToHost));
     else groupPtr[0] = 0;
   }
-  if (entries && rs->nEntries) {
-    // The destination is ordinary (pageable) memory: the runtime stages such a copy through page-locked buffers with a host memcpy on the
-    // calling thread, which is what bounds it (476 MB at 10 M pairs: 24.5 ms = 19 GB/s).  Large tables go as a few pieces, each staged by
-    // its own thread on its own stream (T1K_DOWNLOAD_PIECES, 1 = one hipMemcpy as before).
-    const uint64_t bytes = rs->nEntries * sizeof(T1kGroupEnt);
-    static const int want = getenv("T1K_DOWNLOAD_PIECES") ? std::max(1, std::min(16, atoi(getenv("T1K_DOWNLOAD_PIECES")))) : 4;
-    const int P = bytes >= (64ull << 20) ? want : 1;
-    if (P == 1) RS_HIP(hipMemcpy(entries, rs->bGroupEnt.p, bytes, hipMemcpyDeviceToHost));
-    else {
-      std::vector<hipError_t> res((size_t)P, hipSuccess);
-      std::vector<std::thread> th;
-      const uint64_t piece = ((bytes / P) + 4095) & ~4095ull;
-      for (int i = 0; i < P; ++i)
-        th.emplace_back([&, i] {
-          const uint64_t b = (uint64_t)i * piece, e = std::min(bytes, b + piece);
-          if (b >= e) return;
-          hipError_t r = hipSetDevice(rs->device);
-          hipStream_t s = nullptr;
-          if (r == hipSuccess) r = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
-          if (r == hipSuccess) r = hipMemcpyAsync((char *)entries + b, (const char *)rs->bGroupEnt.p + b, e - b, hipMemcpyDeviceToHost, s);
-          if (r == hipSuccess) r = hipStreamSynchronize(s);
-          if (s) (void)hipStreamDestroy(s);
-          res[(size_t)i] = r;
-        });
-      for (auto &t : th) t.join();
-      for (hipError_t r : res) RS_HIP(r);
-    }
-  }
+  if (entries && rs->nEntries) RS_HIP(hipMemcpy(entries, rs->bGroupEnt.p, rs->nEntries * sizeof(T1kGroupEnt), hipMemcpyDeviceToHost));
   if (firstFragment && G) RS_HIP(hipMemcpy(firstFragment, rs->bGroupFirst.p, G * 4, hipMemcpyDeviceToHost));
   return T1K_OK;
 }
