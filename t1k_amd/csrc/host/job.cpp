@@ -971,6 +971,12 @@ int t1k_job_run_local(t1k_job *job) {
   uint64_t G = 0, N = 0, assigned = 0;
   static_assert(sizeof(GroupEntry) == sizeof(t1k_group_entry), "group entry layouts differ");
   const double tEx0 = nowMs();
+  if (getenv("T1K_DEBUG_ARCHIVE")) {
+    uint64_t b = 0, e = 0;
+    if (t1k_rowset_device_bytes(job->rows, &b, &e) == T1K_OK)
+      fprintf(stderr, "[t1k job] after the loop: %llu row entries in the chunks (%.1f GB allocated for rows), %llu fragments paired, stats.rows %llu\n",
+              (unsigned long long)e, b / 1e9, (unsigned long long)sh.pairedFrags, (unsigned long long)job->stats.rows);
+  }
   if (sharded && (rc = t1k_rowset_exchange(job->rows, job->comm, fBeg)) != T1K_OK) return jobFail(job, rc, t1k_rowset_last_error(job->rows));
   const double tEx1 = nowMs();
   // (one GPU: the host tables of the groups are sized and their pages first touched by all host threads -- 100 k page faults on one
