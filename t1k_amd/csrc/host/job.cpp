@@ -588,9 +588,13 @@ int t1k_job_run_local(t1k_job *job) {
           // overlap store under the half-the-device rule alone, 30 M ran within 20 GB of the device): what is allocated now beside rows and
           // kept sets (arenas, reference, the windows in flight), the rows projected for the whole job (the chunk cursors over the fragments
           // paired so far), one more full window in flight, the coalescing's work space.
-          if (fits && sh.pairedFrags >= 65536 && !getenv("T1K_ARCHIVE_GB")) {
+          // (test aid T1K_TEST_ARCHIVE_HEADROOM_MB: evaluate the rule from the first paired fragment on and pretend the device ends that
+          // many MB above what is allocated now, so that a small job exercises the fallback)
+          static const char *testHeadroom = getenv("T1K_TEST_ARCHIVE_HEADROOM_MB");
+          if (fits && sh.pairedFrags >= (testHeadroom ? 1u : 65536u) && !getenv("T1K_ARCHIVE_GB")) {
             uint64_t freeNow = 0, totalNow = 0, rowsNow = 0, entriesNow = 0;
             if (t1k_device_memory(job->prm.device, &freeNow, &totalNow) == T1K_OK && t1k_rowset_device_bytes(job->rows, &rowsNow, &entriesNow) == T1K_OK && totalNow) {
+              if (testHeadroom) { const uint64_t used = totalNow - std::min(freeNow, totalNow); totalNow = used + ((uint64_t)atoll(testHeadroom) << 20); freeNow = totalNow - used; }
               const double projectedRows = (double)entriesNow / (double)sh.pairedFrags * (double)F * sizeof(t1k_row_entry) * 1.1 + 32.0 * (double)F + 4e9;  // (+ 10 %, the per-fragment tables, chunk slack)
               const uint64_t usedNow = totalNow - std::min(freeNow, totalNow);
               const uint64_t other = usedNow > archivedBytes + rowsNow ? usedNow - archivedBytes - rowsNow : 0;

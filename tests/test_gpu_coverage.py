@@ -81,6 +81,9 @@ MODES = {
     "deferred": {},
     "eager": {"T1K_COVERAGE": "eager"},
     "budget_fallback": {"T1K_FIRST_WINDOW": "16", "T1K_WINDOW": "64", "T1K_WINDOW_GROWTH": "1", "T1K_BATCH": "16", "T1K_PAIR_BATCH": "16", "T1K_ARCHIVE_GB": "0.0000001"},
+    # the rule of round 4 (a window's read set is kept only beside what is allocated, the windows in flight, the job's projected rows): the
+    # device "ends" 1 MB above what is allocated at the first decision after a paired fragment, so the later windows update coverage per range
+    "memory_rule_fallback": {"T1K_FIRST_WINDOW": "16", "T1K_WINDOW": "64", "T1K_WINDOW_GROWTH": "1", "T1K_BATCH": "16", "T1K_PAIR_BATCH": "16", "T1K_TEST_ARCHIVE_HEADROOM_MB": "1"},
     "small_windows_small_batches": {"T1K_FIRST_WINDOW": "24", "T1K_WINDOW": "96", "T1K_BATCH": "16", "T1K_PAIR_BATCH": "32", "T1K_COVER_BATCH": "64", "T1K_PIPELINES": "2"},
     "hash_order_small_batches": {"T1K_DISTINCT_ORDER": "hash", "T1K_FIRST_WINDOW": "32", "T1K_WINDOW": "128", "T1K_BATCH": "16", "T1K_PAIR_BATCH": "16"},
     "first_use_order_small_batches": {"T1K_FIRST_WINDOW": "32", "T1K_WINDOW": "128", "T1K_BATCH": "16", "T1K_PAIR_BATCH": "16", "T1K_PIPELINES": "4"},
@@ -140,6 +143,8 @@ def test_coverage_modes_on_mixed_samples_vs_reference_binary(built, tmp_path, ca
             assert "the range's coverage was taken back" in r.stderr and "runs again with stripes" in r.stderr, r.stderr[-1500:]
         if mode == "budget_fallback":
             assert kept and all(0 < int(k) < int(w) for k, w in kept), r.stderr[-1500:]
+        if mode == "memory_rule_fallback":
+            assert "read sets are not kept from here on" in r.stderr and kept and all(0 < int(k) < int(w) for k, w in kept), r.stderr[-1500:]
     if case in (0, 1):  # three individuals, permissive filters: some gene carries more than two types, so selection asked for coverage
         assert asked["deferred"] and asked["deferred"][0][0] > 0 and asked["deferred"][0][1] > 0, asked
 
