@@ -110,6 +110,11 @@ def test_read_input_opens_without_a_job(built, tmp_path):
     r.close()
     with pytest.raises(t1k_amd.T1kError, match="missing.fq"):
         t1k_amd.Reads(str(tmp_path / "missing.fq"))
+    # the committed fixtures as they lie (gzip): inflated, then indexed like a mapped file
+    d = os.path.join(util.GOLDEN, "cyp_rna_2x100")
+    r = t1k_amd.Reads(os.path.join(d, "reads_1.fq.gz"), os.path.join(d, "reads_2.fq.gz"))
+    assert r.fragments() == 300
+    r.close()
 
 
 def test_reference_loader_merges_identical_sequences(built, tmp_path):
