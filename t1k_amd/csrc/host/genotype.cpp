@@ -517,6 +517,15 @@ void Genotyper::select() {
       if (it == typeWeight[g].end() || it->second < ab[t]) typeWeight[g][miss[t]] = ab[t];
     }
   }
+  // The reference scores a pair (j, k) by building a std::map over the read groups of the two types' alleles that no other gene's
+  // top two use, and adding up the groups' adjusted weights in key order.  Here: which alleles of k enter is settled first (the
+  // equivalence-class set that survives from one k to the next, SURVEY H21, is the only thing that ties the pairs of a gene together),
+  // then every pair is scored on its own -- a bitmap over the groups, walked in ascending order (the map's order: the same sum, bit for
+  // bit) -- by the host threads when there are enough list entries to share out.
+  std::vector<double> adjW(G);
+  parallelFor((size_t)G, [&](size_t g) { adjW[g] = groupEnt[groupPtr[g]].adjustWeight; }, 4096);
+  const size_t BW = ((size_t)G + 63) / 64;
+  struct PairJob { int j, k, lastJ; const std::vector<int> *lj; std::vector<int> lk; double score, product; };
   for (int iter = 0; iter < 1000; ++iter) {
     int changed = 0;
     for (int g = 0; g < nGenes; ++g) {
@@ -526,53 +535,73 @@ void Genotyper::select() {
       const int S = (int)sel.size();
       std::set<int> usedEc;
       forTopTwo(g, usedEc, -1);
-      double bestCover = 0, bestProduct = 0;
-      std::vector<std::pair<int, int>> bestPairs;
-      int lastJ = 0, lastK = 0;
-      (void)lastK;
+      std::vector<PairJob> jobs;
+      std::vector<int> listJ[2];
+      int lastJ = 0;
+      size_t entries = 0;
       for (int j = 0; j < T - 1 && j <= 1; ++j) {
         usedEc.clear();
-        std::map<int, int> fromJ;
+        size_t entJ = 0;
         for (int l = 0; l < S; ++l) {
           if (sel[l].second != j) continue;
           if (!usedEc.insert(R.al[sel[l].first].ec).second) continue;
-          for (auto &gs : inAllele[sel[l].first])
-            if (groupUse[gs.first] == 0) fromJ[gs.first] |= 1;
+          listJ[j].push_back(sel[l].first);
+          entJ += inAllele[sel[l].first].size();
           lastJ = l;
         }
         for (int k = j + 1; k < T; ++k) {
-          std::map<int, int> cover = fromJ;
+          PairJob pj{j, k, lastJ, &listJ[j], {}, 0.0, 0.0};
+          entries += entJ;
           for (int l = 0; l < S; ++l) {  // usedEc deliberately survives from one k to the next
             if (sel[l].second != k) continue;
             if (!usedEc.insert(R.al[sel[l].first].ec).second) continue;
-            for (auto &gs : inAllele[sel[l].first])
-              if (groupUse[gs.first] == 0) cover[gs.first] |= 2;
-            lastK = l;
+            pj.lk.push_back(sel[l].first);
+            entries += inAllele[sel[l].first].size();
           }
-          double abJ = 0, abK = 0;
-          int missJ = -1, missK = -1;
-          for (int l = 0; l < S; ++l) {
-            const AlleleMeta &m = R.al[sel[l].first];
-            if (sel[l].second == j) { abJ += m.abundance; if (missJ == -1 || m.missingCov < missJ) missJ = m.missingCov; }
-            else if (sel[l].second == k) { abK += m.abundance; if (missK == -1 || m.missingCov < missK) missK = m.missingCov; }
-          }
-          const double product = abJ * abK;
-          double score = 0;
-          for (auto &kv : cover) score += groupEnt[groupPtr[kv.first]].adjustWeight;
-          if (T > 3 || missJ >= 10 || missK >= 10) {
-            double wJ = typeWeight[g][missJ], wK = typeWeight[g][missK];
-            if (T <= 3) {
-              if (wJ >= 1) wJ = log(wJ) / log(10.0);
-              if (wK >= 1) wK = log(wK) / log(10.0);
-            }
-            score = score - missJ * wJ * readLength / 150.0 - missK * wK * readLength / 150.0 + (R.al[sel[lastJ].first].weight);
-          }
-          if (bestPairs.empty() || score > bestCover || (score == bestCover && product > bestProduct)) {
-            bestCover = score; bestProduct = product;
-            bestPairs.clear();
-            bestPairs.push_back({j, k});
-          } else if (score == bestCover) bestPairs.push_back({j, k});
+          jobs.push_back(std::move(pj));
         }
+      }
+      const std::map<int, double> &tw = typeWeight[g];
+      auto scoreJob = [&](size_t q) {
+        PairJob &pj = jobs[q];
+        std::vector<uint64_t> bits(BW, 0);
+        for (const std::vector<int> *lst : {pj.lj, (const std::vector<int> *)&pj.lk})
+          for (int a : *lst)
+            for (auto &gs : inAllele[a])
+              if (groupUse[gs.first] == 0) bits[(size_t)gs.first >> 6] |= 1ull << (gs.first & 63);
+        double abJ = 0, abK = 0;
+        int missJ = -1, missK = -1;
+        for (int l = 0; l < S; ++l) {
+          const AlleleMeta &m = R.al[sel[l].first];
+          if (sel[l].second == pj.j) { abJ += m.abundance; if (missJ == -1 || m.missingCov < missJ) missJ = m.missingCov; }
+          else if (sel[l].second == pj.k) { abK += m.abundance; if (missK == -1 || m.missingCov < missK) missK = m.missingCov; }
+        }
+        double score = 0;
+        for (size_t w = 0; w < BW; ++w) {
+          uint64_t x = bits[w];
+          while (x) { score += adjW[(w << 6) + (size_t)__builtin_ctzll(x)]; x &= x - 1; }
+        }
+        if (T > 3 || missJ >= 10 || missK >= 10) {
+          auto itJ = tw.find(missJ), itK = tw.find(missK);  // (every type's smallest missing coverage is a key: typeWeight was built from the same lists)
+          double wJ = itJ != tw.end() ? itJ->second : 0.0, wK = itK != tw.end() ? itK->second : 0.0;
+          if (T <= 3) {
+            if (wJ >= 1) wJ = log(wJ) / log(10.0);
+            if (wK >= 1) wK = log(wK) / log(10.0);
+          }
+          score = score - missJ * wJ * readLength / 150.0 - missK * wK * readLength / 150.0 + (R.al[sel[pj.lastJ].first].weight);
+        }
+        pj.score = score; pj.product = abJ * abK;
+      };
+      if (entries + jobs.size() * BW > (size_t)4 << 20) parallelForDynamic(jobs.size(), 1, scoreJob);
+      else for (size_t q = 0; q < jobs.size(); ++q) scoreJob(q);
+      double bestCover = 0, bestProduct = 0;
+      std::vector<std::pair<int, int>> bestPairs;
+      for (const PairJob &pj : jobs) {
+        if (bestPairs.empty() || pj.score > bestCover || (pj.score == bestCover && pj.product > bestProduct)) {
+          bestCover = pj.score; bestProduct = pj.product;
+          bestPairs.clear();
+          bestPairs.push_back({pj.j, pj.k});
+        } else if (pj.score == bestCover) bestPairs.push_back({pj.j, pj.k});
       }
       const std::pair<int, int> win = bestPairs[0];
       if (win.first != 0 || win.second != 1) {
