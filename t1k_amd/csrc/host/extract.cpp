@@ -16,6 +16,7 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <unistd.h>
 #include <unordered_map>
 #include <vector>
 
@@ -345,17 +346,35 @@ struct MappedInput {
       if (getenv("T1K_EXTRACT_STREAM")) return;
       const int hw = (int)std::thread::hardware_concurrency();
       const int T = std::max(2, std::min(hw > 0 ? hw : 2, 32));
-      uint64_t bytes = 0;
+      // the whole input is mapped and indexed (22 bytes of index per record): beyond this much TEXT the streaming loop's bounded memory
+      // wins.  A gzip file is inflated whole into anonymous memory, so what counts for it is its uncompressed size: the ISIZE field of the
+      // last member where the file has one member (exact below 4 GB), never less than 5 x the file (FASTQ deflates 4 - 5 x; ISIZE wraps at
+      // 4 GB and names only the last member of a multi-member / bgzip file).  Inflated text is resident, unlike a mapping of the page
+      // cache: it must also fit the memory the host has free right now.
+      uint64_t bytes = 0, resident = 0;
       for (const auto *fs : {&files1, &files2})
         for (const auto &f : *fs) {
           FILE *fp = fopen(f.c_str(), "rb");
           if (!fp) return;  // (the streaming loop reports it the reference's way)
-          if (fseeko(fp, 0, SEEK_END) == 0) bytes += (uint64_t)ftello(fp);
+          uint64_t sz = 0;
+          unsigned char magic[2] = {0, 0}, tail[4] = {0, 0, 0, 0};
+          const bool gz = fread(magic, 1, 2, fp) == 2 && magic[0] == 0x1f && magic[1] == 0x8b;
+          if (fseeko(fp, 0, SEEK_END) == 0) sz = (uint64_t)ftello(fp);
+          if (gz) {
+            uint64_t text = sz * 5;
+            if (sz >= 18 && fseeko(fp, -4, SEEK_END) == 0 && fread(tail, 1, 4, fp) == 4)
+              text = std::max<uint64_t>(text, (uint64_t)tail[0] | ((uint64_t)tail[1] << 8) | ((uint64_t)tail[2] << 16) | ((uint64_t)tail[3] << 24));
+            bytes += text; resident += text;
+          } else bytes += sz;
           fclose(fp);
         }
-      // the whole input is mapped and indexed (22 bytes of index per record): beyond this much text the streaming loop's bounded memory wins
       const char *e = getenv("T1K_EXTRACT_MAP_GB");
       if ((double)bytes > (e ? atof(e) : 256.0) * 1073741824.0) return;
+      if (resident) {
+        const long pages = sysconf(_SC_AVPHYS_PAGES), psz = sysconf(_SC_PAGESIZE);
+        // inflated text + its record index (22 B per ~300 B record) must leave half of what is free to everybody else
+        if (pages > 0 && psz > 0 && (double)resident * 1.08 > 0.5 * (double)pages * (double)psz) return;
+      }
       std::string err;
       if (!in.open(files1, hasMate ? files2 : std::vector<std::string>(), "", T, err)) {
         if (err.find("different numbers of reads") != std::string::npos) state = -1;

@@ -331,10 +331,10 @@ bool ReadInput::addFile(const std::string &path, int threads, Side &dst, std::st
     Blob &b = newBlob();
     b.map = m; b.len = (size_t)st.st_size;
     data = (const char *)m; size = (size_t)st.st_size;
-  } else if (gz && S_ISREG(st.st_mode) && bgzfInflate(fd, (size_t)st.st_size, threads, newBlob(), data, size)) {
+  } else if (gz && S_ISREG(st.st_mode) && [&] { Blob &b = newBlob(); if (bgzfInflate(fd, (size_t)st.st_size, threads, b, data, size)) return true; dropBlob(b); return false; }()) {
     // (a bgzip-framed file: its 64 KiB blocks were inflated side by side by the host threads)
     ::close(fd);
-  } else if (gz && S_ISREG(st.st_mode) && gzipInflate(fd, (size_t)st.st_size, newBlob(), data, size)) {
+  } else if (gz && S_ISREG(st.st_mode) && [&] { Blob &b = newBlob(); if (gzipInflate(fd, (size_t)st.st_size, b, data, size)) return true; dropBlob(b); return false; }()) {
     // (ordinary gzip: one stream, inflated by libdeflate straight into reserved memory)
     ::close(fd);
   } else {

@@ -4,6 +4,7 @@
 #pragma once
 #include <cstdint>
 #include <functional>
+#include <atomic>
 #include <list>
 #include <map>
 #include <mutex>
@@ -42,7 +43,7 @@ struct ReadInput {
   };
   Side side[2], bc;            // mates; barcode records (sequence = the barcode)
   bool paired = false, hasBarcode = false, noIds = false;
-  bool inPlace = true;         // every file was indexed in place (strict layouts): records point into the file's own text, qualities included
+  std::atomic<bool> inPlace{true};  // every file was indexed in place (strict layouts): records point into the file's own text, qualities included
   std::vector<uint32_t, NoInitAlloc<uint32_t>> frag;  // fragment f = record frag[f] (records with a missing barcode are dropped with their mates)
   int maxLen = 0;
   ReadInput() = default;
@@ -77,6 +78,7 @@ struct ReadInput {
   std::list<Blob> blobs_;  // the mates are read by concurrent threads: nodes never move, additions are serialised
   std::mutex blobLock_;
   Blob &newBlob() { std::lock_guard<std::mutex> g(blobLock_); blobs_.emplace_back(); return blobs_.back(); }
+  void dropBlob(Blob &b) { std::lock_guard<std::mutex> g(blobLock_); for (auto it = blobs_.begin(); it != blobs_.end(); ++it) if (&*it == &b) { blobs_.erase(it); return; } }  // (a failed attempt's empty node)
   bool addFile(const std::string &path, int threads, Side &dst, std::string &err);
   static bool bgzfInflate(int fd, size_t fileSize, int threads, Blob &blob, const char *&data, size_t &size);
   static bool gzipInflate(int fd, size_t fileSize, Blob &blob, const char *&data, size_t &size);
