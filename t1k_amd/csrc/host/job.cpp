@@ -1698,9 +1698,12 @@ int t1k_genotyper_main(int argc, char **argv) {
 // assigned again, to the alleles named in <prefix>_allele.tsv only (Genotyper::InitRefSet with selectedAlleles, Genotyper.hpp:732-757;
 // AssignRead with weight 0: no coverage is kept, Analyzer.cpp:139, 472), mates are paired, and BarcodeSummary (BarcodeSummary.hpp:24-80)
 // turns every assigned fragment's allele list into 1/n fractional and unique counts per barcode: <prefix>_barcode_expr.tsv.
-// Not built: VariantCaller (novel-variant calling, VariantCaller.hpp).  <prefix>_allele.vcf is therefore written empty -- what the
-// reference writes when it calls no variant -- and the per-barcode counts use the raw fragment assignments, which is what
-// VariantCaller::AdjustFragmentAssignment (1229-1311) returns whenever no called variant sits under a mismatch of the fragment.
+// Not built: VariantCaller (novel-variant calling, VariantCaller.hpp).  The reference has a switch for exactly that: --varMaxGroup 0
+// (run-t1k --post-varMaxGroup 0) makes VariantCaller::ComputeVariant return at once (VariantCaller.hpp:980-981), <prefix>_allele.vcf is
+// written empty and AdjustFragmentAssignment (1229-1311) hands every fragment's raw assignments back -- the per-barcode table of that
+// mode is what this build computes, byte for byte.  With any other value the reference may call variants and move fragments between
+// alleles; this build cannot know whether it would have, so it REFUSES to run (exit code 2, nothing written) instead of leaving files
+// that are silently different: the caller either passes --varMaxGroup 0 or runs the reference's analyzer for this stage.
 // ------------------------------------------------------------------------------------------------------------------
 static const char *kAnalyzerUsage =
     "./analyzer [OPTIONS]:   (MI355X build of the T1K post-analysis stage: re-assignment + per-barcode summary; no variant calling)\n"
@@ -1717,7 +1720,8 @@ static const char *kAnalyzerUsage =
     "\t--barcode STRING: barcode file\n"
     "\t--relaxIntronAlign: allow one more mismatch in intronic alignment\n"
     "\t--alleleDigitUnits INT, --alleleDelimiter CHR: as in genotyper\n"
-    "\t--varMaxGroup INT: accepted and ignored (variant calling is not part of this build)\n"
+    "\t--varMaxGroup INT: must be 0 (no novel-variant calling, as in the reference with 0): the reference's VariantCaller is not part of this build and\n"
+    "\t\tany other value, the reference's default of 8 included, ends the run with exit code 2 before anything is written (run-t1k: --post-varMaxGroup 0)\n"
     "\t--device INT: GPU ordinal (default: $T1K_DEVICE or 0)\n";
 
 int t1k_analyzer_main(int argc, char **argv) {
@@ -1730,6 +1734,7 @@ int t1k_analyzer_main(int argc, char **argv) {
   if (const char *d = getenv("T1K_DEVICE")) p.device = atoi(d);
   std::string refFile, alleleFile, prefix = "t1k", barcode;
   std::vector<const char *> f1, f2, single;
+  int varMaxGroup = 8;  // Analyzer.cpp:251
   optind = 1;
   int c, idx = 0;
   while ((c = getopt_long(argc, argv, "f:a:u:1:2:o:t:n:s:", longOpts, &idx)) != -1) {
@@ -1747,13 +1752,20 @@ int t1k_analyzer_main(int argc, char **argv) {
       case 10004: p.dev.relax_intron_align = 1; break;
       case 10005: p.allele_digit_units = atoi(optarg); break;
       case 10006: p.allele_delimiter = optarg[0]; break;
-      case 10007: break;
+      case 10007: varMaxGroup = atoi(optarg); break;
       case 10010: p.device = atoi(optarg); break;
       default: fprintf(stderr, "%s", kAnalyzerUsage); return EXIT_FAILURE;
     }
   }
   if (refFile.empty()) { fprintf(stderr, "Need to use -f to specify the reference sequences.\n"); return EXIT_FAILURE; }
   if (alleleFile.empty()) { fprintf(stderr, "Need to use -a to specify selected allele ids.\n"); return EXIT_FAILURE; }
+  if (varMaxGroup != 0) {
+    fprintf(stderr, "analyzer: novel-variant calling (the reference's VariantCaller) is not part of this build, and --varMaxGroup %d asks for it: with it the reference may call variants "
+                    "(%s_allele.vcf) and move fragments between alleles (%s_barcode_expr.tsv), which this build cannot reproduce.  Nothing was written.  Run this stage with "
+                    "--varMaxGroup 0 (run-t1k: --post-varMaxGroup 0) -- the reference's own switch for \"no variant calling\", whose output this build matches byte for byte -- or with "
+                    "the reference's analyzer.\n", varMaxGroup, prefix.c_str(), prefix.c_str());
+    return 2;
+  }
   if (p.dev.max_assign_cnt == 0) p.dev.max_assign_cnt = -1;
   std::set<std::string> selected;
   {
@@ -1801,12 +1813,10 @@ int t1k_analyzer_main(int argc, char **argv) {
   uint64_t nAssigned = 0;
   for (uint32_t f = 0; f < F; ++f) nAssigned += job->fragAssigned[f] ? 1 : 0;
   logLine("Finish read fragment assignments. %d read fragments can be assigned.", (int)nAssigned);
-  {  // no variant calling in this build: the file the reference writes when it finds none -- said out loud, every run
+  {  // --varMaxGroup 0: the reference's VariantCaller returns before it looks at a read and writes an empty file (VariantCaller.hpp:980-981, 1202-1227)
     FILE *fp = fopen((prefix + "_allele.vcf").c_str(), "w");
     if (!fp) { fprintf(stderr, "analyzer: cannot write %s_allele.vcf\n", prefix.c_str()); t1k_job_destroy(job); return EXIT_FAILURE; }
     fclose(fp);
-    fprintf(stderr, "analyzer: WARNING: novel-variant calling (the reference's VariantCaller) is not part of this build: %s_allele.vcf is written empty%s\n", prefix.c_str(),
-            in.hasBarcode ? ", and the per-barcode table uses the fragment assignments as they are (the reference adjusts them where it calls a variant)" : "");
   }
   if (in.hasBarcode) {
     // barcode ids in order of first appearance over ALL loaded fragments (Analyzer.cpp:380-392), counts in fragment order

@@ -598,6 +598,7 @@ extern "C++" int t1k_fetch_counters(t1k_ctx *ctx, unsigned long long *h) {
   memcpy(h, raw.data(), 64 * 8);
   h[6] = 0;  // group records: sum of the arena's segment cursors
   for (int s = 0; s < T1K_NSTRIPE; ++s) h[6] += raw[T1K_ARENA_BASE + ((size_t)T1K_AR_GROUPS * T1K_NSTRIPE + s) * 8];
+  for (int s = 56; s < 64; ++s) h[6] += raw[s];  // ... + the groups the fused seeding kernel ended without a record
   static const int slot[8] = {7, 11, 12, 14, 10, 3, 4, 5};
   for (int s = 0; s < T1K_STAT_STRIPES; ++s)
     for (int k = 0; k < 8; ++k) h[slot[k]] += raw[64 + s * 8 + k];
@@ -795,7 +796,7 @@ int t1k_assign_range(t1k_ctx *ctx, uint64_t first, uint32_t count) {
   const int64_t genHitLimit = 1024ll << 20;
   ctx->wGenHit = clampCap(ctx->wGenHit, 64u << 20, genHitLimit);
   for (int attempt = 0;; ++attempt) {
-    ctx->lastCapFlags = 0; ctx->needGroup = ctx->needCand = ctx->needOvl = ctx->needList = ctx->needRare = ctx->needJob = ctx->needGenJob = 0;
+    ctx->lastCapFlags = 0; ctx->needGroup = ctx->needCand = ctx->needOvl = ctx->needList = ctx->needRare = ctx->needJob = ctx->needGenJob = ctx->needGenHit = 0;
     const int rc = assignOnce(ctx, first, count);
     if (rc != T1K_ERR_CAPACITY || attempt >= 10) return rc;
     bool grew = false;
@@ -925,6 +926,7 @@ static int assignOnce(t1k_ctx *ctx, uint64_t first, uint32_t count) {
   a.groupSegCap = groupSegCap; a.jobSegCap = jobSegCap; a.listSegCap = listSegCap; a.rareSegCap = rareSegCap; a.genCandSegCap = genCandSegCap;
   a.bigScratch = (uint32_t *)ctx->bWgBig.p;
   { static const int ns = getenv("T1K_NO_SIMPLE_CHAIN") ? 0 : 1; a.nearSimple = ns; }
+  { static const int fz = getenv("T1K_FUSE_SEED") ? atoi(getenv("T1K_FUSE_SEED")) : 0; a.fuse = fz; }  // measured in round 5: 20 % MORE kernel time than the two launches; opt-in
   { static const int ep = getenv("T1K_NO_EARLY_PRUNE") ? 0 : getenv("T1K_WALK_IN_CLOSED") ? atoi(getenv("T1K_WALK_IN_CLOSED")) + 1 : 2; a.earlyPrune = ep; }  // 0: none, 1: the closed-form pass prunes with the gap-count bound, 2: ... and runs the gap walk's first pass
   a.cand = (T1kCand *)ctx->bCand.p; a.candCap = ctx->wCand;
   a.candStart = (uint32_t *)ctx->bCandStart.p; a.candCount = (uint32_t *)ctx->bCandCount.p;

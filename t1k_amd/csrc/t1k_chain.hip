@@ -94,7 +94,7 @@ __device__ __forceinline__ void shlOr(uint64_t *C, int sft) {
 // return value: 5 = needs the gap walk (CLOSED only), 1 = finished (out holds 0 or 1 candidate), 2 = run again after the dense DP phase, 3 = candidate pushed with a
 // partial matchCnt, refs[] name the memo slots whose match counts are still to be added (DEFER only)
 #define GROUP_MAX_REFS 4   // two 32-bit words of 16-bit memo slots in a group record
-template <int NW, bool DEFER, bool CLOSED>
+template <int NW, bool DEFER, bool CLOSED, bool ONDEMAND = false>
 __device__ inline int groupFastPath(const uint32_t *Mw, int diag, const ReadCtx &c, bool hasN, int k, int hitLenRequired, double simThreshold, CandOut &out,
                                     unsigned int *dpCounter, int strandBit, const GapSink &sink, uint32_t *refs, int *nRefs, int earlyPrune = 1) {
   constexpr int MW = (NW + 1) / 2;  // 64-bit words of the read-offset bitmask
@@ -141,6 +141,34 @@ __device__ inline int groupFastPath(const uint32_t *Mw, int diag, const ReadCtx 
     const int rw = first >> 5;
     const int nWin = (span + 31) >> 5;
     constexpr int NP = (NW + 2) / 2;  // 16-byte pieces covering NW + 1 words
+    if (ONDEMAND) {
+      // (the seeding kernel's call: the read's words are in LDS -- c.rb / c.rn point there -- and are fetched where they are used; only the
+      // allele's words come as one burst; the allele's N-mask words, rarely needed, are loaded where they are used as well.  Half the
+      // registers of the form below, the same words)
+      uint64_t G[2 * NP];
+#pragma unroll
+      for (int j = 0; j < NP; ++j) {
+        t1k_u64x2 g = {0ull, 0ull};
+        if (2 * j <= nWin) g = *(const t1k_u64x2 *)(c.gb + gw + 2 * j);
+        G[2 * j] = g.x; G[2 * j + 1] = g.y;
+      }
+#pragma unroll
+      for (int i = 0; i < NW; ++i) {
+        mmw[i] = 0;
+        if (i < nWin) {
+          const uint64_t r0 = c.rb[rw + i], r1 = c.rb[rw + i + 1], n0 = c.rn[rw + i], n1 = c.rn[rw + i + 1];
+          const uint64_t g = (G[i] >> gsh) | ((G[i + 1] << 1) << (63 - gsh)), r = (r0 >> rsh) | ((r1 << 1) << (63 - rsh));
+          uint64_t nn = (n0 >> rsh) | ((n1 << 1) << (63 - rsh));
+          if (hasN) { const uint64_t q0 = c.gn[gw + i], q1 = c.gn[gw + i + 1]; nn |= (q0 >> gsh) | ((q1 << 1) << (63 - gsh)); }
+          const uint64_t xo = g ^ r;
+          uint64_t mm = (xo | (xo >> 1)) & T1K_EVEN & ~nn;
+          const int rem = span - 32 * i;
+          if (rem < 32) mm &= t1k_lowmask(rem);
+          mmw[i] = mm;
+          mmT += __popcll(mm);
+        }
+      }
+    } else {
     uint64_t G[2 * NP], R[2 * NP], GN[2 * NP], RN[2 * NP];
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
@@ -169,6 +197,7 @@ __device__ inline int groupFastPath(const uint32_t *Mw, int diag, const ReadCtx 
         mmw[i] = mm;
         mmT += __popcll(mm);
       }
+    }
     }
   }
   int matchCnt;
@@ -252,7 +281,7 @@ __device__ inline int groupFastPath(const uint32_t *Mw, int diag, const ReadCtx 
 #pragma unroll
     for (int w = 0; w < MW; ++w) {
       const uint64_t s1 = X[w] + E[w], s2 = s1 + carry;
-      carry = (s1 < X[w]) | (s2 < s1) ? 1ull : 0ull;
+      carry = ((s1 < X[w]) | (s2 < s1)) ? 1ull : 0ull;
       nGaps += __popcll(s2 & ~X[w]);
     }
     const int bound = 2 * (span - nGaps);
@@ -477,13 +506,48 @@ __device__ __forceinline__ uint32_t recFar(uint32_t w2) { return (w2 >> 22) & 7u
 __device__ __forceinline__ uint32_t recNear(uint32_t w2) { return (w2 >> 25) & 31u; }
 __device__ __forceinline__ bool recIsGeneral(uint32_t w2) { return recNear(w2) > 0 || recFar(w2) > 2; }
 #define REC_NEAR_DONE 0x4E454152u  // record word 5 of a multi-diagonal group whose hit list k_near_hits wrote (k_gather_general leaves it alone)
+enum { REC_DONE = 0x80000000u };  // word 3 after chaining: REC_DONE | number of candidates (general groups: candidates in the side arena)
+
+__device__ __forceinline__ ReadCtx makeCtx(const ChainArgs &P, uint32_t re, int pass, uint32_t allele) {
+  const int S = P.reads.S;
+  ReadCtx c{P.reads.bases + ((uint64_t)re * 2 + pass) * S, P.reads.nmask + ((uint64_t)re * 2 + pass) * S, (int)P.reads.len[re], P.ref.bases, P.ref.nmask,
+            (int64_t)P.ref.alleleOff[allele], (int)P.ref.alleleLen[allele], P.ref.anyN != 0};
+  return c;
+}
+
 #define DIAG_EMPTY 0x7FFFFFFF
 
+// the closed-form pass on one accumulator (fused seeding): `a` = the accumulator row in LDS (diag, meta, M[NW]); returns groupFastPath's verdict, 6 instead of
+// 1 when the group ended WITH a candidate, which is left in a[2..4]
 template <int NW>
+__device__ __forceinline__ uint32_t closedFormGroup(uint32_t *a, const uint64_t *rb, const uint64_t *rn, const uint64_t *gb, const uint64_t *gn, int64_t goff, bool anyN, bool hasN, int k,
+                                                    int hitLenRequired, double sim, int pass, int earlyPrune) {
+  uint32_t Mw[NW];
+#pragma unroll
+  for (int w = 0; w < NW; ++w) Mw[w] = a[2 + w];
+  const ReadCtx c{rb, rn, 0, gb, gn, goff, 0, anyN};
+  uint32_t cbuf[3];
+  CandOut out{cbuf, 0};
+  const GapSink sink{nullptr, nullptr, nullptr, 0u, 0u, T1K_AR_JOBS};  // (the closed-form pass registers nothing)
+  uint32_t refs[2] = {0, 0};
+  int nRefs = 0;
+  const uint32_t kind = (uint32_t)groupFastPath<NW, true, true, true>(Mw, (int)a[0], c, hasN, k, hitLenRequired, sim, out, nullptr, pass, sink, refs, &nRefs, earlyPrune);
+  if (kind == 1u && out.n) { a[2] = cbuf[0]; a[3] = cbuf[1]; a[4] = cbuf[2]; return 6u; }
+  return kind;
+}
+
 #ifndef T1K_SEED_WAVES
 #define T1K_SEED_WAVES 8
 #endif
-__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(T1K_SEED_WAVES, T1K_SEED_WAVES))) void k_seed_groups(ChainArgs P) {
+#ifndef T1K_FUSE_WAVES
+#define T1K_FUSE_WAVES 5
+#endif
+// FUSE: the closed-form pass of the chain (groupFastPath<NW, true, true>, what k_chain_fast<NW, 0> does per record) runs here, on the
+// accumulators while they are in LDS: a group that ends there leaves as a finished record (state + candidate) or -- no candidate -- not
+// at all, a group for the gap walk / the multi-diagonal path leaves as before AND is put on its work list.  No launch reads the
+// records back just to classify them.
+template <int NW, bool FUSE>
+__device__ __forceinline__ void seedGroupsBody(const ChainArgs &P) {
   constexpr int AW = NW == 5 ? 7 : 13;  // u32 per accumulator: diag, meta, M[NW]; odd stride = no LDS bank conflicts
   extern __shared__ uint32_t lds[];
   const int k = P.k;
@@ -520,8 +584,11 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(T1K_SEED_WAV
   uint64_t tp_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tl_ = __builtin_amdgcn_s_memtime();
 #endif
   __shared__ uint32_t sUMask[2 * T1K_USED_MASK_WORDS];  // read offsets whose lists are used, per strand
+  constexpr int RDW = 14;                             // >= S + 2 (S <= 11: reads of at most T1K_MAX_READ_LEN bases)
+  __shared__ uint64_t sRd[2][2][FUSE ? RDW : 1];      // [strand][bases | N mask][word] of the read-end (FUSE)
   __shared__ unsigned long long sStat[3];             // lookups, postings, hits: thread 0 tallies them in LDS (three 64-bit counters in registers would be held by every lane), flushed once per workgroup
   if (tid == 0) { sStat[0] = 0; sStat[1] = 0; sStat[2] = 0; }
+  unsigned int fastLocal = 0, groupsLocal = 0, recsLocal = 0;  // (FUSE)
   for (uint32_t re = blockIdx.x; re < P.reads.nReadEnds; re += gridDim.x) {
     const int len = P.reads.len[re];
     const int S = P.reads.S;
@@ -534,6 +601,10 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(T1K_SEED_WAV
     if (len < k || len > T1K_MAX_READ_LEN || (P.reads.skip && P.reads.skip[re])) { __syncthreads(); continue; }  // GetOverlapsFromRead returns -1 (SeqSet.hpp:1598-1599)
     const int nk = len - k + 1;
     if (tid < 2 * T1K_USED_MASK_WORDS) sUMask[tid] = 0;  // (read by the previous read-end before its chunk loop's barriers)
+    if (FUSE && tid >= 64 && tid < 64 + 2 * 2 * RDW) {  // the read's packed words for the closed-form pass (used behind the barriers of the look-up phase)
+      const int x = tid - 64, strand = x / (2 * RDW), kind = (x / RDW) & 1, w = x % RDW;
+      sRd[strand][kind][w] = w < S ? (kind ? rnm : rbase)[strand * S + w] : 0ull;
+    }
     for (int q = tid; q < 2 * nk; q += WG) {
       int pass = q / nk, p = q - pass * nk;
       const uint64_t *b = rbase + pass * S, *nm = rnm + pass * S;
@@ -857,8 +928,34 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(T1K_SEED_WAV
         // or some hit close enough to chain with it, or > 2 strays (which could form their own run).  Lane t looks at the
         // accumulators t, t + WG, ... (conflict-free with the odd accumulator stride); the records leave in allele order.
         constexpr int EPT = CHUNK_A / WG;
-        uint32_t flags = 0;
+        uint32_t flags = 0, kinds = 0;  // kinds (FUSE): 4 bits per accumulator row, groupFastPath's verdict (1 finished with a candidate, 5 gap walk) or 4 = several diagonals
         uint64_t packed = 0;  // EPT counters of 16 bits
+        if (FUSE) {
+#pragma unroll 1
+          for (int i = 0; i < EPT; ++i) {
+            uint32_t *a = acc + (i * WG + tid) * AW;
+            if (a[0] == (uint32_t)DIAG_EMPTY) continue;
+            int onDiag = 0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) onDiag += __popc(a[2 + w]);
+            const uint32_t strays = a[1] & 0xFFFFu, nearCnt = a[1] >> 16;
+            const bool general = nearCnt > 0 || strays > 2;
+            flags |= 2u << (2 * i);  // occupied
+            if (!(onDiag + (int)strays >= 3 && (general || onDiag >= 3))) continue;
+            ++groupsLocal;
+            uint32_t kind = 4;
+            if (!general) {
+              // the closed-form pass (what k_chain_fast<NW, 0> does with the record): the candidate of a group that ends here waits in the
+              // accumulator's mask words (dead now) for the record write below; a group without a candidate leaves no record
+              const uint32_t allele = c0 + i * WG + tid;
+              kind = closedFormGroup<NW>(a, &sRd[pass][0][0], &sRd[pass][1][0], P.ref.bases, P.ref.nmask, (int64_t)P.ref.alleleOff[allele], P.ref.anyN != 0, P.ref.alleleHasN[allele] != 0, k,
+                                         P.hitLenRequired, P.sim, pass, P.earlyPrune);
+              if (kind == 1u) { ++fastLocal; continue; }  // no candidate
+              if (kind == 6u) { ++fastLocal; kind = 1u; }
+            }
+            flags |= 1u << (2 * i); packed += 1ull << (16 * i); kinds |= kind << (4 * i); ++recsLocal;
+          }
+        } else {
 #pragma unroll
         for (int i = 0; i < EPT; ++i) {
           const uint32_t *a = acc + (i * WG + tid) * AW;
@@ -870,6 +967,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(T1K_SEED_WAV
           const bool general = nearCnt > 0 || strays > 2;
           flags |= 2u << (2 * i);  // occupied
           if (onDiag + (int)strays >= 3 && (general || onDiag >= 3)) { flags |= 1u << (2 * i); packed += 1ull << (16 * i); }
+        }
         }
         uint32_t totLo, totHi = 0, exHi = 0;
         const uint32_t exLo = t1k_block_scan_exclusive((uint32_t)packed, warpSums, &totLo);
@@ -900,15 +998,26 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(T1K_SEED_WAV
               uint4 *rec = (uint4 *)(P.recs + (uint64_t)(groupBase + slot) * stride);
               constexpr int RW = NW == 5 ? 8 : 16;  // record words: re|strand, allele, diagonal + stray counts, M[NW]
               uint32_t v[RW];
+              const uint32_t kind = FUSE ? (kinds >> (4 * i)) & 15u : 0u;
               v[0] = re | (pass == 0 ? 0x80000000u : 0);  // bit31: '+' strand
               v[1] = c0 + i * WG + tid;
-              v[2] = packDiagMeta((int)a[0], a[1]);
+              if (FUSE && kind == 1u) {  // finished: state, candidate (the record k_chain_fast<NW, 0> leaves behind)
+                v[2] = REC_DONE | 1u; v[3] = a[2]; v[4] = a[3]; v[5] = a[4];
 #pragma unroll
-              for (int w = 0; w < NW; ++w) v[3 + w] = a[2 + w];
+                for (int w = 6; w < RW; ++w) v[w] = 0;
+              } else {
+                v[2] = packDiagMeta((int)a[0], a[1]);
 #pragma unroll
-              for (int w = 3 + NW; w < RW; ++w) v[w] = 0;
+                for (int w = 0; w < NW; ++w) v[3 + w] = a[2 + w];
+#pragma unroll
+                for (int w = 3 + NW; w < RW; ++w) v[w] = 0;
+              }
 #pragma unroll
               for (int w = 0; w < RW / 4; ++w) rec[w] = make_uint4(v[4 * w], v[4 * w + 1], v[4 * w + 2], v[4 * w + 3]);
+              if (FUSE) {  // the work lists k_chain_fast<NW, 0> used to fill
+                if (kind == 5u) { const uint32_t q = t1k_arena_append(P.counters, T1K_AR_SLOW, P.listSegCap); if (q != T1K_ARENA_FULL) P.slowStr[q] = groupBase + slot; }
+                else if (kind == 4u) { const uint32_t q = t1k_arena_append(P.counters, T1K_AR_GENERAL, P.rareSegCap); if (q != T1K_ARENA_FULL) P.generalStr[q] = groupBase + slot; }
+              }
             }
             a[0] = (uint32_t)DIAG_EMPTY; a[1] = 0;
 #pragma unroll
@@ -928,7 +1037,19 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(T1K_SEED_WAV
     unsigned long long *st = P.counters + 64 + (blockIdx.x & (T1K_STAT_STRIPES - 1)) * 8;
     atomicAdd(&st[T1K_STAT_LOOKUPS], sStat[0]); atomicAdd(&st[T1K_STAT_POSTINGS], sStat[1]); atomicAdd(&st[T1K_STAT_HITS], sStat[2]);
   }
+  if (FUSE) {
+    t1k_stat_add(P.counters, T1K_STAT_FAST, fastLocal);
+    // groups seeded = records written + groups that ended without a candidate: the latter are counted here (control counters 56..63, striped)
+    unsigned int noRec = groupsLocal - recsLocal;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) noRec += __shfl_down(noRec, o, 64);
+    if ((tid & 63) == 0 && noRec) atomicAdd(&P.counters[56 + ((blockIdx.x * 4 + (tid >> 6)) & 7)], (unsigned long long)noRec);
+  }
 }
+template <int NW>
+__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(T1K_SEED_WAVES, T1K_SEED_WAVES))) void k_seed_groups(ChainArgs P) { seedGroupsBody<NW, false>(P); }
+template <int NW>
+__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(T1K_FUSE_WAVES, T1K_FUSE_WAVES))) void k_seed_chain(ChainArgs P) { seedGroupsBody<NW, true>(P); }
 
 // ------------------------------------------------------------------------------------------------------------------
 // K1L: seeding of the read-ends beyond the hit masks' span (T1K_MAX_READ_LEN < len <= T1K_LONG_READ_LEN), one workgroup per such
@@ -1070,6 +1191,7 @@ __global__ __launch_bounds__(WG) void k_seed_long(ChainArgs P) {
             // words 0..2: read-end | '+' strand, allele, "several diagonals" (recIsGeneral: near count 1, diagonal 0); the rest is the chain's
             rec[0] = make_uint4(re | (pass == 0 ? 0x80000000u : 0u), c0 + tid * PER + i, (1u << 21) | (31u << 25), 0u);  // near = 31: "count unknown", the hits come from the used lists
             for (uint32_t w = 1; w < stride / 4; ++w) rec[w] = make_uint4(0u, 0u, 0u, 0u);
+            if (P.fuse) { const uint32_t gq = t1k_arena_append(P.counters, T1K_AR_GENERAL, P.rareSegCap); if (gq != T1K_ARENA_FULL) P.generalStr[gq] = groupBase + slot; }  // (no k_chain_fast<*, 0> lists it)
             ++slot;
           }
         }
@@ -1085,15 +1207,6 @@ __global__ __launch_bounds__(WG) void k_seed_long(ChainArgs P) {
 // record words: 0 re|strand, 1 allele, 2 diagonal + stray counts, 3.. M   -> after chaining: 2 = state, 3..5 packed candidate (3 = side-arena base for
 // multi-diagonal groups), 6..7 memo slots still to be added
 // ------------------------------------------------------------------------------------------------------------------
-enum { REC_DONE = 0x80000000u };  // word 3 after chaining: REC_DONE | number of candidates (general groups: candidates in the side arena)
-
-__device__ __forceinline__ ReadCtx makeCtx(const ChainArgs &P, uint32_t re, int pass, uint32_t allele) {
-  const int S = P.reads.S;
-  ReadCtx c{P.reads.bases + ((uint64_t)re * 2 + pass) * S, P.reads.nmask + ((uint64_t)re * 2 + pass) * S, (int)P.reads.len[re], P.ref.bases, P.ref.nmask,
-            (int64_t)P.ref.alleleOff[allele], (int)P.ref.alleleLen[allele], P.ref.anyN != 0};
-  return c;
-}
-
 // MODE 0: all records, closed form only (the rest -> slow list; multi-diagonal groups -> general list)
 // MODE 1: slow list: gap walk, alignments registered in the memo (-> finish list / retry list)
 // MODE 2: retry list after k_dp_dense: alignments from the memo or inline
@@ -1944,7 +2057,15 @@ int t1k_run_chain(t1k_ctx *ctx, const ChainArgs &a, int nWg, int bigBlocks, bool
   const char *esw = getenv("T1K_SEED_WG");
   const int seedWg = (int)std::min<uint32_t>(a.reads.nReadEnds, esw ? (uint32_t)atoi(esw) : 32768u);
   T1K_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
-  if (longReads) {
+  if (a.fuse) {
+    if (longReads) {
+      T1K_HIP(ctx, hipFuncSetAttribute((const void *)k_seed_chain<10>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(k_seed_chain<10>, dim3(seedWg), dim3(WG), lds, ctx->stream, a);
+    } else {
+      T1K_HIP(ctx, hipFuncSetAttribute((const void *)k_seed_chain<5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(k_seed_chain<5>, dim3(seedWg), dim3(WG), lds, ctx->stream, a);
+    }
+  } else if (longReads) {
     T1K_HIP(ctx, hipFuncSetAttribute((const void *)k_seed_groups<10>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_seed_groups<10>, dim3(seedWg), dim3(WG), lds, ctx->stream, a);
   } else {
@@ -1961,13 +2082,15 @@ int t1k_run_chain(t1k_ctx *ctx, const ChainArgs &a, int nWg, int bigBlocks, bool
   if (rc) return rc;
   if (hc[2]) return 0;
   const T1kArenaCounts groups = t1k_arena_counts(ctx, T1K_AR_GROUPS, a.groupSegCap);
-  hc[6] = groups.total;
-  if (groups.maxSeg) {
-    const dim3 grid((groups.maxSeg + WG - 1) / WG, T1K_NSTRIPE);
-    if (longReads) hipLaunchKernelGGL((k_chain_fast<10, 0>), grid, dim3(WG), 0, ctx->stream, a, (const uint32_t *)nullptr, 0u);
-    else hipLaunchKernelGGL((k_chain_fast<5, 0>), grid, dim3(WG), 0, ctx->stream, a, (const uint32_t *)nullptr, 0u);
+  const unsigned long long groupsSeeded = hc[6];  // records + (fused seeding) the groups that ended without one
+  if (!a.fuse) {  // the closed-form pass as a launch of its own over all records (T1K_FUSE_SEED=0)
+    if (groups.maxSeg) {
+      const dim3 grid((groups.maxSeg + WG - 1) / WG, T1K_NSTRIPE);
+      if (longReads) hipLaunchKernelGGL((k_chain_fast<10, 0>), grid, dim3(WG), 0, ctx->stream, a, (const uint32_t *)nullptr, 0u);
+      else hipLaunchKernelGGL((k_chain_fast<5, 0>), grid, dim3(WG), 0, ctx->stream, a, (const uint32_t *)nullptr, 0u);
+    }
+    if ((rc = readCounters(ctx, hc))) return rc;
   }
-  if ((rc = readCounters(ctx, hc))) return rc;
   const T1kArenaCounts slow = t1k_arena_counts(ctx, T1K_AR_SLOW, a.listSegCap);
   if (slow.overflow) { hc[2] |= ERR_GROUPCAP; return 0; }
   ctx->lastSlowGroups = slow.total;
@@ -1978,7 +2101,7 @@ int t1k_run_chain(t1k_ctx *ctx, const ChainArgs &a, int nWg, int bigBlocks, bool
     else hipLaunchKernelGGL((k_chain_fast<5, 1>), dim3((nSlowGroups + WG - 1) / WG), dim3(WG), 0, ctx->stream, a, (const uint32_t *)a.slowList, nSlowGroups);
   }
   if ((rc = readCounters(ctx, hc))) return rc;
-  hc[6] = groups.total;
+  hc[6] = groupsSeeded;
   const T1kArenaCounts jobs = t1k_arena_counts(ctx, T1K_AR_JOBS, a.jobSegCap), retry = t1k_arena_counts(ctx, T1K_AR_RETRY, a.listSegCap),
                        fin = t1k_arena_counts(ctx, T1K_AR_FINISH, a.listSegCap), gen = t1k_arena_counts(ctx, T1K_AR_GENERAL, a.rareSegCap);
   // A full job segment is NOT benign: the lane that could not list its job released the memo claim, but another lane may already be
@@ -2040,6 +2163,6 @@ int t1k_run_chain(t1k_ctx *ctx, const ChainArgs &a, int nWg, int bigBlocks, bool
   else hipLaunchKernelGGL(k_collect<T1K_MAX_READ_LEN>, dim3(nWg), dim3(WG), 0, ctx->stream, a);
   T1K_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
   rc = readCounters(ctx, hc);
-  hc[6] = groups.total; hc[16] = jobs.total; hc[17] = retry.total; hc[18] = gen.total; hc[19] = nBig; hc[22] = fin.total;
+  hc[6] = groupsSeeded; hc[16] = jobs.total; hc[17] = retry.total; hc[18] = gen.total; hc[19] = nBig; hc[22] = fin.total;
   return rc;
 }

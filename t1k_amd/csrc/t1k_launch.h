@@ -24,6 +24,7 @@ struct ChainArgs {
   uint32_t *genHits;  // hit lists of the multi-diagonal groups (k_gather_general)
   uint32_t *genCand; uint32_t genCandCap;                  // packed candidates of multi-diagonal groups (3 u32 each)
   uint32_t *bigScratch;
+  int fuse;                // the seeding kernel runs the closed-form pass itself (k_seed_chain) and fills the gap-walk / multi-diagonal lists; 0 (T1K_FUSE_SEED=0): k_seed_groups + k_chain_fast<*, 0>
   int nearSimple;          // k_near_hits marks the two-diagonal groups whose hit list is its chain (T1K_NO_SIMPLE_CHAIN=1: leaves them to the general path)
   int earlyPrune;          // k_chain_fast<*, 0>: 0 = closed form only (T1K_NO_EARLY_PRUNE=1), 1 = + the groups that cannot pass the similarity filter by the gap-count bound
                            // (T1K_WALK_IN_CLOSED=0), 2 = + the gap walk's first pass: groups without a gap of more than three mismatches and groups its bound prunes (default)

@@ -577,7 +577,7 @@ def test_analyzer_with_nothing_genotyped_vs_reference_binary(built, tmp_path, wi
         outs = {}
         for who, binary in (("ref", util.REF_ANALYZER), ("gpu", ANALYZER)):
             o = str(tmp_path / ("%s_%s" % (who, tag)))
-            r = subprocess.run([binary, "-f", ref, "-a", alleles, "-1", r1, "-2", r2, "-o", o] + extra, stderr=subprocess.PIPE, text=True)
+            r = subprocess.run([binary, "-f", ref, "-a", alleles, "-1", r1, "-2", r2, "-o", o, "--varMaxGroup", "0"] + extra, stderr=subprocess.PIPE, text=True)
             assert r.returncode == 0, (who, r.stderr[-500:])
             outs[who] = {f[len(os.path.basename(o)):]: open(os.path.join(str(tmp_path), f), "rb").read() for f in os.listdir(str(tmp_path)) if f.startswith(os.path.basename(o) + "_")}
         assert outs["ref"] == outs["gpu"] and "_allele.vcf" in outs["gpu"], (sorted(outs["ref"]), sorted(outs["gpu"]))
@@ -827,7 +827,7 @@ def test_analyzer_vs_golden_reference_outputs(built, tmp_path):
     g, a = os.path.join(str(tmp_path), "g"), os.path.join(str(tmp_path), "a")
     r = subprocess.run([GENO] + c.args() + ["-o", g], stderr=subprocess.PIPE, text=True)
     assert r.returncode == 0, r.stderr
-    r = subprocess.run([ANALYZER, "-f", c.ref, "-a", g + "_allele.tsv", "-1", g + "_aligned_1.fa", "-2", g + "_aligned_2.fa", "--barcode", g + "_aligned_bc.fa", "-o", a] + c.flags,
+    r = subprocess.run([ANALYZER, "-f", c.ref, "-a", g + "_allele.tsv", "-1", g + "_aligned_1.fa", "-2", g + "_aligned_2.fa", "--barcode", g + "_aligned_bc.fa", "-o", a, "--varMaxGroup", "0"] + c.flags,
                        stderr=subprocess.PIPE, text=True)
     assert r.returncode == 0, r.stderr
     assert "WARNING" in r.stderr and "VariantCaller" in r.stderr  # the empty VCF is announced, not silent
@@ -838,7 +838,8 @@ def test_analyzer_vs_golden_reference_outputs(built, tmp_path):
 @pytest.mark.parametrize("seed,paired,flags", [(21, True, ["-s", "0.9"]), (22, False, ["-s", "0.8"]), (23, True, ["-s", "0.97", "-n", "3"])])
 def test_analyzer_live_vs_reference_binary(built, tmp_path, seed, paired, flags):
     """the analyzer against the reference's analyzer run here, on reads with many multi-allele fragments (a lenient -s, a small -n that the
-    summary must NOT apply, single-end): _barcode_expr.tsv byte for byte, whenever the reference calls no variant (asserted)"""
+    summary must NOT apply, single-end): _barcode_expr.tsv byte for byte, both in the reference's no-variant-calling mode (--varMaxGroup 0,
+    run-t1k --post-varMaxGroup 0: the only mode this build's analyzer runs in)"""
     util.need(util.REF_ANALYZER)
     ref = os.path.join(str(tmp_path), "ref.fa")
     util.synth_ref("ref-rna", ref, genes=5, scale=0.05, seed=seed)
@@ -852,10 +853,10 @@ def test_analyzer_live_vs_reference_binary(built, tmp_path, seed, paired, flags)
     outs = []
     for binary, tag in ((util.REF_ANALYZER, "ref"), (ANALYZER, "gpu")):
         o = os.path.join(str(tmp_path), tag)
-        r = subprocess.run([binary, "-f", ref, "-a", g + "_allele.tsv"] + aligned + ["--barcode", g + "_aligned_bc.fa", "-o", o, "-t", "4"] + flags, stderr=subprocess.PIPE, text=True)
+        r = subprocess.run([binary, "-f", ref, "-a", g + "_allele.tsv"] + aligned + ["--barcode", g + "_aligned_bc.fa", "-o", o, "-t", "4", "--varMaxGroup", "0"] + flags, stderr=subprocess.PIPE, text=True)
         assert r.returncode == 0, r.stderr
         outs.append(o)
-    assert open(outs[0] + "_allele.vcf").read() == "", "the reference called a variant on this input: not a case this build covers"
+    assert open(outs[0] + "_allele.vcf").read() == open(outs[1] + "_allele.vcf").read() == ""
     a, b = open(outs[0] + "_barcode_expr.tsv").read(), open(outs[1] + "_barcode_expr.tsv").read()
     assert a.count("\n") > 50
     assert a == b
@@ -943,3 +944,68 @@ def test_device_coalescing_equals_host_restatement(built, tmp_path):
         for field in ("allele", "start", "end"):
             assert np.array_equal(e1[field], e2[field]), field
         assert np.array_equal(e1["w"].view(np.uint32), e2["w"].view(np.uint32)) and np.array_equal(e1["aw"].view(np.uint32), e2["aw"].view(np.uint32))
+
+
+
+def novel_snp_sample(tmp, het):
+    """reads drawn from a copy of the reference in which one exonic position of gene 0 carries a base the database does not know -- in every
+    allele of the gene (a homozygous novel SNP) or in every second one (het: the two sampled alleles may differ at it) -- genotyped against
+    the ORIGINAL reference: the input on which the reference's VariantCaller does call a variant"""
+    ref = os.path.join(tmp, "ref.fa")
+    util.synth_ref("ref-rna", ref, genes=4, scale=0.05, seed=31)
+    recs = []
+    for line in open(ref):
+        if line.startswith(">"):
+            recs.append([line.rstrip("\n"), ""])
+        else:
+            recs[-1][1] += line.strip()
+    gene0 = sorted(set(r[0][1:].split("*")[0] for r in recs))[0]
+    swap = {"A": "C", "C": "G", "G": "T", "T": "A"}
+    mut = os.path.join(tmp, "ref_mut.fa")
+    with open(mut, "w") as o:
+        k = 0
+        for n, sq in recs:
+            if n[1:].split("*")[0] == gene0 and len(sq) > 400 and sq[400] in swap:
+                if not het or k % 2 == 0:
+                    sq = sq[:400] + swap[sq[400]] + sq[401:]
+                k += 1
+            o.write(n + "\n" + sq + "\n")
+    pfx = os.path.join(tmp, "r")
+    util.synth_reads(mut, pfx, pairs=3000, len=150, seed=5, barcodes=50, sub=0.0)
+    return ref, pfx
+
+
+@pytest.mark.parametrize("het", [False, True])
+def test_analyzer_on_a_sample_with_a_novel_snp(built, tmp_path, het):
+    """The hole of SURVEY 8f row 2, fenced: on a sample whose reads carry a consistent SNP absent from the database the reference's analyzer
+    (default --varMaxGroup 8) calls the variant -- asserted here, so that the case stays one where the two modes differ -- which this build
+    cannot do: without --varMaxGroup 0 it must refuse (exit code 2, no file written), and with it both analyzers must write the same
+    per-barcode table and the same (empty) VCF."""
+    util.need(util.REF_ANALYZER)
+    tmp = str(tmp_path)
+    ref, pfx = novel_snp_sample(tmp, het)
+    g = os.path.join(tmp, "g")
+    r = subprocess.run([GENO, "-f", ref, "-1", pfx + "_1.fq", "-2", pfx + "_2.fq", "--barcode", pfx + "_bc.fa", "-o", g], stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 0, r.stderr
+    common = ["-f", ref, "-a", g + "_allele.tsv", "-1", g + "_aligned_1.fa", "-2", g + "_aligned_2.fa", "--barcode", g + "_aligned_bc.fa", "-t", "4"]
+    # the reference in its default mode: it calls the SNP
+    d = os.path.join(tmp, "ref_default")
+    r = subprocess.run([util.REF_ANALYZER] + common + ["-o", d], stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 0, r.stderr
+    vcf = open(d + "_allele.vcf").read()
+    assert vcf.count("\n") >= 1 and " 401 . " in vcf, vcf
+    # this build in that mode: refuses, loudly, and leaves nothing behind
+    x = os.path.join(tmp, "gpu_default")
+    r = subprocess.run([ANALYZER] + common + ["-o", x], stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 2 and "--varMaxGroup 0" in r.stderr, (r.returncode, r.stderr[-400:])
+    assert not [f for f in os.listdir(tmp) if f.startswith("gpu_default")]
+    # both in the reference's no-variant-calling mode: the same files
+    outs = []
+    for binary, tag in ((util.REF_ANALYZER, "ref0"), (ANALYZER, "gpu0")):
+        o = os.path.join(tmp, tag)
+        r = subprocess.run([binary] + common + ["-o", o, "--varMaxGroup", "0"], stderr=subprocess.PIPE, text=True)
+        assert r.returncode == 0, r.stderr
+        outs.append(o)
+    assert open(outs[0] + "_allele.vcf").read() == open(outs[1] + "_allele.vcf").read() == ""
+    a, b = open(outs[0] + "_barcode_expr.tsv").read(), open(outs[1] + "_barcode_expr.tsv").read()
+    assert a.count("\n") > 20 and a == b
