@@ -352,9 +352,10 @@ int t1k_job_load_reads_multi(t1k_job *job, const char *const *files1, uint32_t n
 /* The same input opened on its own, before or beside t1k_job_create (both calls block; a caller with two threads -- the genotyper
  * executable, bench.py -- maps and indexes the read files while the reference is parsed and the contexts come up; the reference's main
  * does the two one after the other, Genotyper.cpp:226-232 then 365-454).  `threads` as -t (0 = the default of a job).
- * t1k_job_attach_reads hands the input to the job exactly as t1k_job_load_reads_multi would have left it and consumes the handle (also
- * on failure); t1k_reads_close is for a handle that was never attached.  Not for a rank of a sharded job that indexes only its own
- * fragments (t1k_job_set_shard + t1k_job_load_reads: that open is a collective). */
+ * t1k_job_attach_reads hands the input to an UNSHARDED job exactly as t1k_job_load_reads_multi would have left it and consumes the handle
+ * (also on failure); t1k_reads_close is for a handle that was never attached.  A rank of a sharded job (t1k_job_set_shard with a
+ * communicator) gets T1K_ERR_STATE whatever the input: its open is the collective t1k_job_load_reads, including the cases in which that
+ * call ends up indexing the whole input on every rank (a barcode file, gz, non-strict layouts). */
 typedef struct t1k_reads t1k_reads;
 int t1k_reads_open(const char *const *files1, uint32_t n1, const char *const *files2, uint32_t n2, const char *barcodeFile, int threads, t1k_reads **out);
 const char *t1k_reads_last_error(const t1k_reads *reads);

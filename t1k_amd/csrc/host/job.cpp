@@ -286,7 +286,9 @@ void t1k_reads_close(t1k_reads *r) { delete r; }
 int t1k_job_attach_reads(t1k_job *job, t1k_reads *r) {
   if (!job || !r) { delete r; return T1K_ERR_ARG; }
   if (!r->in) { job->err = r->err.empty() ? "t1k_job_attach_reads: the read input was not opened" : r->err; delete r; return T1K_ERR_IO; }
-  if (job->nRanks > 1 && job->comm && !getenv("T1K_NO_SHARDED_INPUT")) {  // (a rank of a sharded job opens its own share: t1k_job_load_reads)
+  // (a rank of a sharded job opens its own share: t1k_job_load_reads -- also where that call itself would have opened the whole input, e.g.
+  // with a barcode file: the handle cannot know, and a sharded caller has the collective open anyway)
+  if (job->nRanks > 1 && job->comm && !getenv("T1K_NO_SHARDED_INPUT")) {
     delete r;
     return jobFail(job, T1K_ERR_STATE, "t1k_job_attach_reads: a rank of a sharded job indexes its own fragments (t1k_job_set_shard, then t1k_job_load_reads)");
   }
@@ -363,6 +365,7 @@ static bool loadAbundance(t1k_job *job) {
 // that holds 82 % of a 10 M-pair job paired only after its last assignment range, the loop ended in 0.4 s of pairing alone).  A pipeline that finds no item left in the oldest window starts on the next one (its lists go
 // to the other slot of the pipeline's overlap store), so the GPU does not drain at window boundaries.
 // ------------------------------------------------------------------------------------------------------------------
+extern "C" uint64_t t1k_pool_release_mt(int threads);  // t1k_capi.hip (experiment)
 namespace {
 struct Window {
   uint32_t f0 = 0, f1 = 0;          // fragments [f0, f1)
@@ -595,10 +598,10 @@ int t1k_job_run_local(t1k_job *job) {
             uint64_t freeNow = 0, totalNow = 0, rowsNow = 0, entriesNow = 0;
             if (t1k_device_memory(job->prm.device, &freeNow, &totalNow) == T1K_OK && t1k_rowset_device_bytes(job->rows, &rowsNow, &entriesNow) == T1K_OK && totalNow) {
               if (testHeadroom) { const uint64_t used = totalNow - std::min(freeNow, totalNow); totalNow = used + ((uint64_t)atoll(testHeadroom) << 20); freeNow = totalNow - used; }
-              const double projectedRows = (double)entriesNow / (double)sh.pairedFrags * (double)F * sizeof(t1k_row_entry) * 1.1 + 32.0 * (double)F + 4e9;  // (+ 10 %, the per-fragment tables, chunk slack)
+              const double projectedRows = (double)entriesNow / (double)sh.pairedFrags * (double)F * sizeof(t1k_row_entry) * 1.1 + 32.0 * (double)F + std::min(4e9, 0.015 * (double)totalNow);  // (+ 10 %, the per-fragment tables, chunk slack: 4 GB on this part, never more than 1.5 % of a smaller device)
               const uint64_t usedNow = totalNow - std::min(freeNow, totalNow);
               const uint64_t other = usedNow > archivedBytes + rowsNow ? usedNow - archivedBytes - rowsNow : 0;
-              const double coalesceWork = 48.0 * (double)F + 8e9;  // (sort keys and tables of the coalescing, the EM's arrays, a margin)
+              const double coalesceWork = 48.0 * (double)F + std::min(8e9, 0.03 * (double)totalNow);  // (sort keys and tables of the coalescing, the EM's arrays, a margin: 8 GB here, at most 3 % of the device)
               // (a window that is not kept still holds its read set while it is in flight, and so does the one prepared behind it: what is
               // allocated now covers the windows in flight now, one more of full size may come on top while fragments remain)
               const double transient = perFrag * (double)std::min<uint64_t>(windowFrags, F - N.f1);
@@ -1690,6 +1693,13 @@ int t1k_genotyper_main(int argc, char **argv) {
   destroyAll();
   if (getenv("T1K_DEBUG_PHASES"))  // (what a stopwatch around the process sees beyond this: loading the executable and the HIP runtime before main, the exit behind it)
     fprintf(stderr, "[t1k job] main: %.1f ms from its first line to the outputs, %.1f ms to release the job\n", tOut - tMain, nowMs() - tOut);
+  if (const char *e = getenv("T1K_EXIT_FREE")) {  // experiment: the job's device memory handed back by several threads, then out without the exit handlers
+    const double t0 = nowMs();
+    const uint64_t b = t1k_pool_release_mt(atoi(e));
+    if (getenv("T1K_DEBUG_PHASES")) fprintf(stderr, "[t1k job] exit: %.1f GB of device memory freed by %d threads in %.1f ms\n", b / 1e9, atoi(e), nowMs() - t0);
+    fflush(nullptr);
+    _exit(0);
+  }
   return 0;
 }
 

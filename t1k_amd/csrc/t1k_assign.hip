@@ -465,19 +465,12 @@ __global__ __launch_bounds__(NT) T1K_OCC8 void k_select(SelectArgs P) {
       if (tid == 0 && SELECT_LDS_CAP == SELECT_SMALL) { P.ovlStart[re] = 0; P.ovlCount[re] = 0; }
       continue;
     }
-    // candidates that failed the similarity filter never reach the sort: count the survivors first.  Thread t looks at the
-    // candidates [t * per, (t + 1) * per) and will put its survivors at myFirst, myFirst + 1, ...: the list keeps the order in
-    // which k_collect wrote it (allele order), which the counting sort below relies on
-    if (SELECT_LDS_CAP == SELECT_LARGE && n <= SELECT_SMALL) continue;  // at most n survive: the small shape's read-end, whatever the filter left (no need to count)
-    const uint32_t per = (n + NT - 1) / NT;
-    const uint32_t iBeg = min(n, (uint32_t)tid * per), iEnd = min(n, iBeg + per);
-    uint32_t live, myFirst;
-    {
-      uint32_t mine = 0;
-      for (uint32_t i = iBeg; i < iEnd; ++i) mine += (P.ext[c0 + i].flags & T1K_F_DROP) ? 0u : 1u;
-      myFirst = t1k_block_scan_exclusive_n<NT / 64>(mine, warpSums, &live);
-    }
-    if ((live > SELECT_SMALL) != (SELECT_LDS_CAP == SELECT_LARGE)) continue;  // the other instantiation's read-end
+    // every candidate of the list is sorted (the ones that failed the similarity filter were left out by k_collect; until round 4 this
+    // kernel -- both instantiations -- swept the extension records once just to count survivors that all survive, each thread over its own
+    // contiguous piece).  Candidate i goes to position i: the list keeps the order in which k_collect wrote it (allele order), which the
+    // counting sort below relies on, and neighbouring lanes read neighbouring records
+    if ((n > SELECT_SMALL) != (SELECT_LDS_CAP == SELECT_LARGE)) continue;  // the other instantiation's read-end
+    const uint32_t live = n;
     if (live == 0) {
       if (tid == 0) { P.ovlStart[re] = 0; P.ovlCount[re] = 0; }
       continue;
@@ -501,9 +494,8 @@ __global__ __launch_bounds__(NT) T1K_OCC8 void k_select(SelectArgs P) {
     auto idxOf = [&](uint64_t kk) { return (uint32_t)((kk >> 3) & iMask); };
     auto seedOf = [&](uint64_t kk) { return mMax - (int)((kk >> mShift) & (uint64_t)mMax); };
     for (uint32_t i = live + tid; i < np2; i += NT) key[i] = ~0ull;
-    for (uint32_t i = iBeg; i < iEnd; ++i) {
+    for (uint32_t i = tid; i < n; i += NT) {
       const uint16_t fl = P.ext[c0 + i].flags;
-      if (fl & T1K_F_DROP) continue;
       const T1kCand c = P.cand[c0 + i];
       int rs = c.readSE & 0xFFFF, rend = c.readSE >> 16;
       int m = (int)(c.match >> 16);
@@ -511,7 +503,7 @@ __global__ __launch_bounds__(NT) T1K_OCC8 void k_select(SelectArgs P) {
       const double sim = (double)m / (double)(c.seqEnd - c.seqStart + 1 + rend - rs + 1);
       const uint32_t kf = ((fl & T1K_F_SEPSEED) ? SEL_F_SEPSEED : 0u) | ((fl & T1K_F_EXTOK) ? SEL_F_EXTOK : 0u) |
                           (((fl & T1K_F_NEEDCLIP) && !(sim < 0.95)) ? SEL_F_KEEPCLIP : 0u);  // SeqSet.hpp:2170-2172
-      const uint32_t slot = myFirst++;
+      const uint32_t slot = i;
       uint64_t kk;
       if (!packSelectKey(W, m, d, rspan, c.allele & 0x7FFFFFFFu, i, kf, P.alleleBits, iBits, &kk)) { atomicOr(&P.counters[2], (unsigned long long)ERR_SORTCAP); kk = (uint64_t)i << 3; }
       key[slot] = kk;

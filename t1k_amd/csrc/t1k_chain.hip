@@ -1251,7 +1251,7 @@ __global__ __launch_bounds__(WG) void k_chain_fast(ChainArgs P, const uint32_t *
       uint32_t refs[2] = {0, 0};
       int nRefs = 0;
       kind = groupFastPath<NW, DEFER, MODE == 0>(Mw, recDiag(rv[2]), c, P.ref.alleleHasN[allele] != 0, P.k, P.hitLenRequired, P.sim, out, &dpLocal, pass, sink, refs, &nRefs, P.earlyPrune);
-      if (kind == 3) {  // matchCnt lacks the registered alignments: k_chain_finish adds them from the memo
+      if (kind == 3) {  // matchCnt lacks the registered alignments: k_collect adds them from the memo
         // words 2..7: state (= number of memo slots to add), candidate, slots
         ((uint2 *)rec)[1] = make_uint2((uint32_t)nRefs, cbuf[0]);
         ((uint2 *)rec)[2] = make_uint2(cbuf[1], cbuf[2]);
@@ -2031,11 +2031,102 @@ __global__ __launch_bounds__(WG) void k_group_size_keys(const uint32_t *recs, ui
     keys[q] = simple ? min(r[4], 127u) : 128u + min(r[4], 63u);
   }
 }
+// ------------------------------------------------------------------------------------------------------------------
+// Counting sort of a dense work list by a small key (<= CS_BINS values), fused with the key's computation: the two in-loop orderings --
+// registered alignments by read-window length (wavefronts of k_dp_dense sweep DPs of equal height: mixed lengths ran at 40 % lane
+// utilisation), multi-diagonal groups by kind and hit count (k_chain_general) -- are 9- and 8-bit keys over ~10^6 items, for which a
+// radix-sort library call (key kernel + three to four launches + its scan state) is out of proportion.  Two launches:
+//   k_csort_count    LDS histogram per workgroup, its non-empty bins added to the global histogram
+//   k_csort_scatter  every workgroup prefix-sums the global histogram itself (512 values), then tile by tile: LDS histogram with each
+//                    item's rank inside the tile, one global atomic per non-empty bin reserves the tile's run inside the bin, items go
+//                    out.  The order inside a bin is not defined (nothing downstream depends on it: the consumers' results are per
+//                    item).  The last workgroup to finish clears the two global arrays for the next call (ticket counter).
+// scratch: [hist CS_BINS | cursor CS_BINS | ticket] u32, zero when the first call starts (allocated zeroed, re-zeroed by every call).
+// ------------------------------------------------------------------------------------------------------------------
+#define CS_BINS 512
+#define CS_TILE (WG * 8)
+struct JobLenKey {  // read-window length of a registered alignment (memo entry bits 5..13)
+  const unsigned long long *memo;
+  __device__ __forceinline__ uint32_t operator()(uint32_t item) const { return (uint32_t)((memo[item] >> 5) & 0x1FF); }
+};
+struct GroupSizeKey {  // chains first (they skip the sorts: their own wavefronts), each kind by hit count (record word 4 after k_near_hits / k_gather_general)
+  const uint32_t *recs; uint32_t stride; int useSimple;
+  __device__ __forceinline__ uint32_t operator()(uint32_t item) const {
+    const uint32_t *r = recs + (uint64_t)item * stride;
+    const bool simple = useSimple && r[5] == REC_NEAR_DONE && r[6] == 1u;
+    return simple ? min(r[4], 127u) : 128u + min(r[4], 63u);
+  }
+};
+template <class KeyFn>
+__global__ __launch_bounds__(WG) void k_csort_count(const uint32_t *list, uint32_t n, uint32_t *scratch, KeyFn key) {
+  __shared__ uint32_t h[CS_BINS];
+  for (int b = threadIdx.x; b < CS_BINS; b += WG) h[b] = 0;
+  __syncthreads();
+  for (uint32_t i = blockIdx.x * WG + threadIdx.x; i < n; i += gridDim.x * WG) atomicAdd(&h[key(list[i])], 1u);
+  __syncthreads();
+  for (int b = threadIdx.x; b < CS_BINS; b += WG)
+    if (h[b]) atomicAdd(&scratch[b], h[b]);
+}
+template <class KeyFn>
+__global__ __launch_bounds__(WG) void k_csort_scatter(const uint32_t *list, uint32_t n, uint32_t *scratch, uint32_t *out, KeyFn key) {
+  __shared__ uint32_t base[CS_BINS], h[CS_BINS], off[CS_BINS], warpSums[4];
+  __shared__ uint32_t sLast;
+  uint32_t *hist = scratch, *cursor = scratch + CS_BINS, *ticket = scratch + 2 * CS_BINS;
+  {  // exclusive prefix of the global histogram (two bins per thread)
+    const uint32_t a = hist[2 * threadIdx.x], b = hist[2 * threadIdx.x + 1];
+    uint32_t tot;
+    const uint32_t ex = t1k_block_scan_exclusive(a + b, warpSums, &tot);
+    base[2 * threadIdx.x] = ex; base[2 * threadIdx.x + 1] = ex + a;
+  }
+  for (uint32_t t0 = blockIdx.x * CS_TILE; t0 < n; t0 += gridDim.x * CS_TILE) {
+    for (int b = threadIdx.x; b < CS_BINS; b += WG) h[b] = 0;
+    __syncthreads();
+    uint32_t item[8], kk[8], rk[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const uint32_t i = t0 + j * WG + threadIdx.x;
+      kk[j] = 0xFFFFFFFFu;
+      if (i < n) { item[j] = list[i]; kk[j] = key(item[j]); rk[j] = atomicAdd(&h[kk[j]], 1u); }
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < CS_BINS; b += WG)
+      if (h[b]) off[b] = base[b] + atomicAdd(&cursor[b], h[b]);
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (kk[j] != 0xFFFFFFFFu) { const uint32_t pos = off[kk[j]] + rk[j]; if (pos < n) out[pos] = item[j]; }  // (pos < n always; the test keeps a scratch left dirty by a killed launch from writing outside the list)
+    __syncthreads();
+  }
+  // the last workgroup out clears the arrays for the next call
+  __threadfence();
+  if (threadIdx.x == 0) sLast = atomicAdd(ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
+  __syncthreads();
+  if (sLast) {
+    for (int b = threadIdx.x; b < 2 * CS_BINS; b += WG) scratch[b] = 0;
+    if (threadIdx.x == 0) *ticket = 0;
+  }
+}
+// list -> sorted (both n entries); returns `sorted`, or `list` when the scratch cannot be had
+template <class KeyFn>
+static const uint32_t *countingSort(t1k_ctx *ctx, const uint32_t *list, uint32_t n, KeyFn key) {
+  static_assert(CS_BINS == 2 * WG, "two bins per thread in the prefix");
+  const size_t head = (2 * CS_BINS + 16) * 4;
+  const bool fresh = ctx->bJobSort.bytes < head + (size_t)n * 4;
+  if (t1k_ensure(ctx, ctx->bJobSort, head + (size_t)n * 4) != T1K_OK) return list;
+  uint32_t *scratch = (uint32_t *)ctx->bJobSort.p, *sorted = scratch + 2 * CS_BINS + 16;
+  if (fresh && hipMemsetAsync(scratch, 0, head, ctx->stream) != hipSuccess) return list;  // (a new block: not zero yet; afterwards every call leaves it zero)
+  const uint32_t grid = std::min<uint32_t>((n + CS_TILE - 1) / CS_TILE, 1024u);
+  hipLaunchKernelGGL(k_csort_count<KeyFn>, dim3(grid), dim3(WG), 0, ctx->stream, list, n, scratch, key);
+  hipLaunchKernelGGL(k_csort_scatter<KeyFn>, dim3(grid), dim3(WG), 0, ctx->stream, list, n, scratch, sorted, key);
+  return sorted;
+}
 void t1k_launch_dp_dense(t1k_ctx *ctx, const ChainArgs &a, const uint32_t *jobs, uint32_t n) {
   if (!n) return;
-  // order the jobs by length first (9-bit radix sort, ~50 us): wavefronts of mixed lengths ran at 40 % lane utilisation
-  if (n >= 4096 && t1k_ensure(ctx, ctx->bJobSort, (size_t)n * 20 + 64) == T1K_OK) {
-    unsigned long long *k0 = (unsigned long long *)ctx->bJobSort.p, *k1 = k0 + n;
+  // order the jobs by length first: wavefronts of mixed lengths ran at 40 % lane utilisation (T1K_RADIX_SORTS=1: the rocPRIM radix sort of rounds 2-4)
+  static const bool radix = getenv("T1K_RADIX_SORTS") != nullptr;
+  if (n >= 4096 && !radix) jobs = countingSort(ctx, jobs, n, JobLenKey{(const unsigned long long *)a.memo});
+  else if (n >= 4096 && t1k_ensure(ctx, ctx->bSlowKeys, (size_t)n * 20 + 64) == T1K_OK) {
+    unsigned long long *k0 = (unsigned long long *)ctx->bSlowKeys.p, *k1 = k0 + n;
     uint32_t *sorted = (uint32_t *)(k1 + n);
     hipLaunchKernelGGL(k_job_keys, dim3((n + WG - 1) / WG), dim3(WG), 0, ctx->stream, (const unsigned long long *)a.memo, jobs, k0, n);
     if (t1k_sort_pairs(ctx, k0, k1, jobs, sorted, n, 9) == T1K_OK) jobs = sorted;
@@ -2132,8 +2223,11 @@ int t1k_run_chain(t1k_ctx *ctx, const ChainArgs &a, int nWg, int bigBlocks, bool
     if (xlong) hipLaunchKernelGGL(k_gather_general<(T1K_LONG_READ_LEN + 63) / 64>, dim3(std::min<uint32_t>((nGen + 3) / 4, 8192u)), dim3(WG), 0, ctx->stream, a, nGen, skipDone);
     else hipLaunchKernelGGL(k_gather_general<GROUP_FAST_MAXLEN / 64>, dim3(std::min<uint32_t>((nGen + 3) / 4, 8192u)), dim3(WG), 0, ctx->stream, a, nGen, skipDone);
     ChainArgs g = a;
-    if (nGen >= 4096 && t1k_ensure(ctx, ctx->bJobSort, (size_t)nGen * 20 + 64) == T1K_OK) {  // groups of similar size side by side
-      unsigned long long *k0 = (unsigned long long *)ctx->bJobSort.p, *k1 = k0 + nGen;
+    static const bool radix = getenv("T1K_RADIX_SORTS") != nullptr;
+    if (nGen >= 4096 && !radix)  // groups of similar size side by side
+      g.generalList = (uint32_t *)countingSort(ctx, a.generalList, nGen, GroupSizeKey{(const uint32_t *)a.recs, a.recStride, skipDone});
+    else if (nGen >= 4096 && t1k_ensure(ctx, ctx->bSlowKeys, (size_t)nGen * 20 + 64) == T1K_OK) {
+      unsigned long long *k0 = (unsigned long long *)ctx->bSlowKeys.p, *k1 = k0 + nGen;
       uint32_t *sorted = (uint32_t *)(k1 + nGen);
       hipLaunchKernelGGL(k_group_size_keys, dim3((nGen + WG - 1) / WG), dim3(WG), 0, ctx->stream, (const uint32_t *)a.recs, a.recStride, (const uint32_t *)a.generalList, k0, nGen, skipDone);
       if (t1k_sort_pairs(ctx, k0, k1, a.generalList, sorted, nGen, 8) == T1K_OK) g.generalList = sorted;

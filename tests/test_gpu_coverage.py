@@ -227,14 +227,14 @@ def test_hla_10M_per_rank_paths_of_the_sharded_config_vs_committed_reference_has
     """BASELINE configs[3] (50 M HLA pairs over 8 GPUs) cannot run here; the two code paths its ranks depend on can, on the 10 M-pair
     workload whose reference hashes are committed, so that they are compared with the REFERENCE's files and not with this build's own
     eager run: (a) windows that lose their kept read set under the memory rule and fall back to the per-range coverage updates (at 50 M
-    pairs most windows do: profiles/r04_size_curve.log) -- forced here with a 2 GB budget for the kept sets; (b) rank-local input:
+    pairs most windows do: profiles/r04_size_curve.log) -- forced here with a 2 GB budget for the kept sets and windows of 1.5 M fragments; (b) rank-local input:
     two in-process ranks on the one device, each indexing and writing only its own fragments (T1K_SHARD_INPUT), coverage all-reduce,
     row exchange, group gather and the sharded E-step through the in-process communicator (Genotyper.cpp:523-621, SeqSet.hpp:2253-2274)."""
     import hashlib
     want, ref, pfx, tmp = hla_10M_input
     env = dict(os.environ, T1K_DEBUG_PHASES="1")
     if mode == "read_sets_not_kept":
-        env["T1K_ARCHIVE_GB"] = "2"
+        env.update(T1K_ARCHIVE_GB="2", T1K_WINDOW="1500000")  # (windows of at most 1.5 M fragments: the first ones, cut before any set's size is known, are kept; the rest is not)
     else:
         env.update(T1K_GPUS="0,0", T1K_SHARD_INPUT="1")
     g = os.path.join(tmp, "g_" + mode)
