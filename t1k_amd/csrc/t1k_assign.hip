@@ -151,10 +151,14 @@ __global__ __launch_bounds__(WG) void k_extend(ExtendArgs P) {
 }
 
 // second pass over the candidates whose extension waited for registered alignments
-__global__ __launch_bounds__(WG) void k_extend_retry(ExtendArgs P, const uint32_t *list, uint32_t nItems) {
-  const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(WG) void k_extend_retry(ExtendArgs P, const uint32_t *list, uint32_t nItems, const unsigned long long *nDev) {
+  if (nDev) nItems = (uint32_t)*nDev;  // (the total word k_arena_compact left: no counter fetch between k_extend and this launch)
   unsigned int dp = 0;
-  if (q < nItems) extendOne<false>(P, list[q], dp);
+  for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < nItems; q += gridDim.x * blockDim.x) {
+    unsigned int d1 = 0;
+    extendOne<false>(P, list[q], d1);
+    dp += d1;
+  }
   t1k_stat_add(P.counters, T1K_STAT_EXTEND_DP, dp);
 }
 
@@ -1136,7 +1140,11 @@ void t1k_launch_extend(t1k_ctx *ctx, const ExtendArgs &a) {
 }
 void t1k_launch_extend_retry(t1k_ctx *ctx, const ExtendArgs &a, const uint32_t *list, uint32_t n) {
   if (!n) return;
-  hipLaunchKernelGGL(k_extend_retry, dim3((n + WG - 1) / WG), dim3(WG), 0, ctx->stream, a, list, n);
+  hipLaunchKernelGGL(k_extend_retry, dim3((n + WG - 1) / WG), dim3(WG), 0, ctx->stream, a, list, n, (const unsigned long long *)nullptr);
+}
+void t1k_launch_extend_retry_dev(t1k_ctx *ctx, const ExtendArgs &a, const uint32_t *list, int arena, uint64_t est) {
+  const unsigned long long *nDev = (const unsigned long long *)ctx->bCounters.p + T1K_TOTAL_BASE + arena;
+  hipLaunchKernelGGL(k_extend_retry, dim3((unsigned)std::max<uint64_t>(1, (est + WG - 1) / WG)), dim3(WG), 0, ctx->stream, a, list, 0u, nDev);
 }
 void t1k_launch_select(t1k_ctx *ctx, const SelectArgs &a, int nWg) {
   if (a.xl) {  // a window with reads beyond T1K_MAX_READ_LEN: wider key fields

@@ -634,6 +634,9 @@ static int fetchCounters(t1k_ctx *ctx, unsigned long long *h) { return t1k_fetch
 // An arena overflowed.  The cursors keep counting past their capacity, so the last fetched counter block holds the demand of the
 // stages that ran: remember it, t1k_assign_range sizes its working capacities from it and runs the range again.
 static int capacityError(t1k_ctx *ctx, unsigned long long flags) {
+  // (a full job list releases memo claims other lanes may already wait on; with the launches behind it no longer held back by a counter
+  // fetch, one of them can meet a slot left pending: a consequence of the overflow, cured by the rerun with lists that fit)
+  if (flags & 256) flags &= ~512ull;
   ctx->lastCapFlags = flags;
   if (flags & 512) return t1k_fail(ctx, T1K_ERR_INTERNAL, "alignment memo entry left pending");
   if (flags & 1024) return t1k_fail(ctx, T1K_ERR_INTERNAL, "an overlap record does not fit the packed form of the overlap store");
@@ -965,17 +968,27 @@ static int assignOnce(t1k_ctx *ctx, uint64_t first, uint32_t count) {
   // the extension alignments go through the memo like the chain's (the chain's work lists are dead by now: reuse their memory)
   e.memo = a.memo; e.jobStr = a.jobStr; e.jobSegCap = a.jobSegCap; e.retryStr = a.retryStr; e.retrySegCap = a.listSegCap;
   t1k_launch_extend(ctx, e);
-  if ((rc = fetchCounters(ctx, hc))) return rc;
-  {
+  const bool hostDriven = t1k_chain_host_driven();
+  if (hostDriven) {
+    if ((rc = fetchCounters(ctx, hc))) return rc;
     const T1kArenaCounts ej = t1k_arena_counts(ctx, T1K_AR_EXTJOBS, e.jobSegCap), er = t1k_arena_counts(ctx, T1K_AR_EXTRETRY, e.retrySegCap);
     if (er.overflow || ej.overflow) return capacityError(ctx, 256);
     t1k_arena_compact(ctx, T1K_AR_EXTJOBS, e.jobStr, e.jobSegCap, a.jobList, ej.maxSeg);
     t1k_arena_compact(ctx, T1K_AR_EXTRETRY, e.retryStr, e.retrySegCap, a.retryList, er.maxSeg);
     t1k_launch_dp_dense(ctx, a, a.jobList, (uint32_t)ej.total);
     t1k_launch_extend_retry(ctx, e, a.retryList, (uint32_t)er.total);
+  } else if (ctx->nCand) {
+    // the same launches without the counter fetch: item counts read on the device, grids from the previous range's counts; a full stripe
+    // raises the group-capacity flag on the device and shows in the fetch behind the selection (nothing of the range is committed before it)
+    const uint64_t jobCapAll = (uint64_t)e.jobSegCap * T1K_NSTRIPE, retryCapAll = (uint64_t)e.retrySegCap * T1K_NSTRIPE;
+    const uint64_t eJ = t1k_arena_estimate(ctx, T1K_AR_EXTJOBS, jobCapAll, n), eR = t1k_arena_estimate(ctx, T1K_AR_EXTRETRY, retryCapAll, n);
+    t1k_arena_compact_dev(ctx, T1K_AR_EXTJOBS, e.jobStr, e.jobSegCap, a.jobList, eJ);
+    t1k_arena_compact_dev(ctx, T1K_AR_EXTRETRY, e.retryStr, e.retrySegCap, a.retryList, eR);
+    t1k_launch_dp_dense_dev(ctx, a, a.jobList, T1K_AR_EXTJOBS, (uint32_t)jobCapAll, eJ);
+    t1k_launch_extend_retry_dev(ctx, e, a.retryList, T1K_AR_EXTRETRY, eR);
   }
   T1K_HIP(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
-  T1K_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (hostDriven) T1K_HIP(ctx, hipStreamSynchronize(ctx->stream));
   double t2 = nowMs();
   SelectArgs s{};
   s.reads = rd; s.cand = a.cand; s.ext = e.ext; s.candStart = a.candStart; s.candCount = a.candCount;
@@ -989,6 +1002,10 @@ static int assignOnce(t1k_ctx *ctx, uint64_t first, uint32_t count) {
   if ((rc = fetchCounters(ctx, hc))) return rc;
   double t3 = nowMs();
   if (hc[2]) return capacityError(ctx, hc[2]);
+  if (!hostDriven) {
+    t1k_arena_estimate_set(ctx, T1K_AR_EXTJOBS, t1k_arena_counts(ctx, T1K_AR_EXTJOBS, e.jobSegCap).total, n);
+    t1k_arena_estimate_set(ctx, T1K_AR_EXTRETRY, t1k_arena_counts(ctx, T1K_AR_EXTRETRY, e.retrySegCap).total, n);
+  }
   ctx->nOvl = hc[1];
   // Near-best full alignments (SeqSet.hpp:2188-2285).  Without --relaxIntronAlign they only feed the per-base coverage, so a context
   // whose coverage is deferred (t1k_ctx_set_coverage_mode) skips them here altogether: k_select has written the relaxed counts, and

@@ -1210,23 +1210,26 @@ __global__ __launch_bounds__(WG) void k_seed_long(ChainArgs P) {
 // MODE 0: all records, closed form only (the rest -> slow list; multi-diagonal groups -> general list)
 // MODE 1: slow list: gap walk, alignments registered in the memo (-> finish list / retry list)
 // MODE 2: retry list after k_dp_dense: alignments from the memo or inline
-template <int NW, int MODE>
-__global__ __launch_bounds__(WG) void k_chain_fast(ChainArgs P, const uint32_t *list, uint32_t nItems) {
+// nDev != nullptr: the list's length is read there (the total word k_arena_compact left), nItems is ignored.  The workgroups stride over the
+// items, so a grid sized from an estimate (t1k_run_chain) covers whatever the device counted.
+// LOOP = false (the host-driven launches: one item per thread, the grid covers the list) keeps the straight-line kernel: the loop costs the
+// closed-form pass 16 VGPRs and a wavefront per SIMD (78 -> 94).
+template <int NW, int MODE, bool LOOP>
+__global__ __launch_bounds__(WG) void k_chain_fast(ChainArgs P, const uint32_t *list, uint32_t nItems, const unsigned long long *nDev) {
   constexpr bool DEFER = MODE != 2;
   unsigned int dpLocal = 0, fastLocal = 0;
+  if (nDev && P.counters[2]) return;  // an arena overflowed earlier in this submission: the range runs again, nothing of this pass is kept
+  // list mode: 1-D grid over a dense list of record indices; all records: blockIdx.y = arena segment, blockIdx.x strides over the segment
+  const uint32_t limit = list ? (nDev ? (uint32_t)*nDev : nItems)
+                              : (uint32_t)min(*t1k_arena_cursor(P.counters, T1K_AR_GROUPS, blockIdx.y), (unsigned long long)P.groupSegCap);
+  const uint32_t step = gridDim.x * WG;
+#pragma unroll 1
+  for (uint32_t base = blockIdx.x * WG; base < limit; base += step) {  // (lists hold fewer than 2^32 - step entries)
   int kind = 0;
   uint32_t gi = 0;
-  bool valid;
-  if (list) {  // list mode: 1-D grid over a dense list of record indices
-    const uint64_t gid = (uint64_t)blockIdx.x * WG + threadIdx.x;
-    valid = gid < nItems;
-    if (valid) gi = list[gid];
-  } else {     // all records: blockIdx.y = arena segment, blockIdx.x = block within the segment
-    const unsigned long long cnt = *t1k_arena_cursor(P.counters, T1K_AR_GROUPS, blockIdx.y);
-    const uint32_t idx = blockIdx.x * WG + threadIdx.x;
-    valid = idx < cnt;
-    gi = blockIdx.y * P.groupSegCap + idx;
-  }
+  const uint32_t gid = base + threadIdx.x;
+  const bool valid = gid < limit;
+  if (valid) gi = list ? list[gid] : blockIdx.y * P.groupSegCap + gid;
   if (valid) {
     uint32_t *rec = P.recs + (uint64_t)gi * P.recStride;
     constexpr int RW = NW == 5 ? 8 : 16;
@@ -1268,15 +1271,17 @@ __global__ __launch_bounds__(WG) void k_chain_fast(ChainArgs P, const uint32_t *
   if (kind == 3) { const uint32_t q = t1k_arena_append(P.counters, T1K_AR_FINISH, P.listSegCap); if (q != T1K_ARENA_FULL) P.finishStr[q] = gi; }
   if (kind == 4) { const uint32_t q = t1k_arena_append(P.counters, T1K_AR_GENERAL, P.rareSegCap); if (q != T1K_ARENA_FULL) P.generalStr[q] = gi; }
   if (kind == 5) { const uint32_t q = t1k_arena_append(P.counters, T1K_AR_SLOW, P.listSegCap); if (q != T1K_ARENA_FULL) P.slowStr[q] = gi; }
+  if (!LOOP) break;
+  }
   t1k_stat_add(P.counters, T1K_STAT_DP, dpLocal);
   t1k_stat_add(P.counters, T1K_STAT_FAST, fastLocal);
 }
 
 // K3: one lane per registered alignment
-__global__ __launch_bounds__(WG) void k_dp_dense(ChainArgs P, const uint32_t *jobs, uint32_t nJobs) {
-  const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(WG) void k_dp_dense(ChainArgs P, const uint32_t *jobs, uint32_t nJobs, const unsigned long long *nDev) {
+  if (nDev) { if (P.counters[2]) return; nJobs = (uint32_t)*nDev; }
   unsigned int dpLocal = 0;
-  if (q < nJobs) {
+  for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < nJobs; q += gridDim.x * blockDim.x) {
     const uint32_t tag = jobs[q];
     const uint32_t re = tag / GAP_CACHE;
     unsigned long long *slot = P.memo + tag;
@@ -1362,9 +1367,11 @@ __device__ __forceinline__ uint32_t evenBits32(uint64_t x) {  // bit 2j of x -> 
   return (uint32_t)x;
 }
 template <int NW>
-__global__ __launch_bounds__(WG) void k_near_hits(ChainArgs P, uint32_t nItems) {
+__global__ __launch_bounds__(WG) void k_near_hits(ChainArgs P, uint32_t nItems, const unsigned long long *nDev) {
   constexpr int NQ = NW + 1;  // 64-bit words (32 positions each) of the per-position masks: one spare word for the k-mer's reach
-  const uint32_t q = blockIdx.x * WG + threadIdx.x;
+  if (nDev) { if (P.counters[2]) return; nItems = (uint32_t)*nDev; }
+  for (uint32_t qb = blockIdx.x * WG; qb < nItems; qb += gridDim.x * WG) {
+  const uint32_t q = qb + threadIdx.x;
   bool toWave = false;
   uint32_t gi = 0;
   if (q < nItems) {
@@ -1514,10 +1521,12 @@ __global__ __launch_bounds__(WG) void k_near_hits(ChainArgs P, uint32_t nItems) 
 #endif
   }
   if (toWave) { const uint32_t wq = t1k_arena_append(P.counters, T1K_AR_WAVE, P.rareSegCap); if (wq != T1K_ARENA_FULL) P.waveStr[wq] = gi; }
+  }
 }
 
 template <int ROUNDS>
-__global__ __launch_bounds__(WG) void k_gather_general(ChainArgs P, uint32_t nItems, int skipDone) {
+__global__ __launch_bounds__(WG) void k_gather_general(ChainArgs P, uint32_t nItems, int skipDone, const unsigned long long *nDev) {
+  if (nDev) { if (P.counters[2]) return; nItems = (uint32_t)*nDev; }
   const int lane = threadIdx.x & 63;
   const uint32_t wave = (blockIdx.x * WG + threadIdx.x) >> 6, nWaves = gridDim.x * (WG / 64);
   const int maxK = (int)P.maxK;
@@ -1589,10 +1598,12 @@ __global__ __launch_bounds__(WG) void k_gather_general(ChainArgs P, uint32_t nIt
 // k_dp_dense, added by k_general_finish); groups that need an alignment wider than the register band go to k_chain_big.
 // useSimple: record word 6 = 1 marks a group whose hit list k_near_hits wrote as its chain (groupSimple: no sorts, no LIS, one array -- up
 // to 3 * GENERAL_SMALL hits in the same LDS)
-__global__ __launch_bounds__(64) void k_chain_general(ChainArgs P, uint32_t nItems, int useSimple) {
+__global__ __launch_bounds__(64) void k_chain_general(ChainArgs P, uint32_t nItems, int useSimple, const unsigned long long *nDev) {
   __shared__ uint32_t sArr[3 * GENERAL_SMALL * 64];
-  const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (nDev) { if (P.counters[2]) return; nItems = (uint32_t)*nDev; }
   unsigned int dpLocal = 0, genLocal = 0;
+  for (uint32_t qb = blockIdx.x * 64; qb < nItems; qb += gridDim.x * 64) {  // (a lane's work arrays are its own: no barrier between the rounds)
+  const uint32_t q = qb + threadIdx.x;
   uint32_t nHits = 0xFFFFFFFFu;
   bool simple = false;
   if (q < nItems) {
@@ -1629,6 +1640,7 @@ __global__ __launch_bounds__(64) void k_chain_general(ChainArgs P, uint32_t nIte
       rec[2] = REC_DONE | 0x40000000u | (uint32_t)out.n;  // bit30: candidates live in the side arena
     }
   }
+  }
   t1k_stat_add(P.counters, T1K_STAT_DP, dpLocal);
   t1k_stat_add(P.counters, T1K_STAT_GENERAL, genLocal);
 }
@@ -1636,8 +1648,9 @@ __global__ __launch_bounds__(64) void k_chain_general(ChainArgs P, uint32_t nIte
 // K5b': multi-diagonal groups with GENERAL_SMALL < hits <= WAVE_CAP, one wavefront per group.  The quadratic steps of
 // GetOverlapsFromHits (sort by diagonal, nearest-to-dominant filter, sort by allele offset; SeqSet.hpp:1338-1456) are spread
 // over the lanes as rank sorts; the LIS and the chain walk of each diagonal run are done by lane 0 (chainRun).
-__global__ __launch_bounds__(64) void k_chain_wave(ChainArgs P, uint32_t nItems) {
+__global__ __launch_bounds__(64) void k_chain_wave(ChainArgs P, uint32_t nItems, const unsigned long long *nDev) {
   extern __shared__ uint32_t sW[];  // A | B | C, WAVE_CAP words each
+  if (nDev) { if (P.counters[2]) return; nItems = (uint32_t)*nDev; }
   uint32_t *A = sW, *B = sW + WAVE_CAP, *C = sW + 2 * WAVE_CAP;
   const int lane = threadIdx.x;
   unsigned int dpLocal = 0, genLocal = 0;
@@ -1732,11 +1745,11 @@ __global__ __launch_bounds__(64) void k_chain_wave(ChainArgs P, uint32_t nItems)
 }
 
 // K5c: add the memo's match counts to the candidates of the multi-diagonal groups
-__global__ __launch_bounds__(WG) void k_general_finish(ChainArgs P, uint32_t nItems) {
-  const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
-  if (q >= nItems) return;
+__global__ __launch_bounds__(WG) void k_general_finish(ChainArgs P, uint32_t nItems, const unsigned long long *nDev) {
+  if (nDev) { if (P.counters[2]) return; nItems = (uint32_t)*nDev; }
+  for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < nItems; q += gridDim.x * blockDim.x) {
   const uint32_t *rec = P.recs + (uint64_t)P.generalList[q] * P.recStride;
-  if ((rec[2] & (REC_DONE | 0x40000000u)) != (REC_DONE | 0x40000000u)) return;  // not chained yet (waits for k_chain_big)
+  if ((rec[2] & (REC_DONE | 0x40000000u)) != (REC_DONE | 0x40000000u)) continue;  // not chained yet (waits for k_chain_big)
   const uint32_t re = rec[0] & 0x7FFFFFFFu, nc = rec[2] & 0x3FFFFFFFu;
   const unsigned long long *memo = P.memo + (uint64_t)re * GAP_CACHE;
   for (uint32_t j = 0; j < nc; ++j) {
@@ -1754,13 +1767,15 @@ __global__ __launch_bounds__(WG) void k_general_finish(ChainArgs P, uint32_t nIt
     g[2] += (2u * sum) << 20;
     g[0] &= 0x00FFFFFFu;
   }
+  }
 }
 
 // what is left: groups with more than WAVE_CAP hits, or a gap whose two sides differ by more than the register band covers.
 // One working lane per 64-thread workgroup; sort arrays in HBM scratch, the rows of the general alignment in LDS.
-__global__ __launch_bounds__(64) void k_chain_big(ChainArgs P, uint32_t nItems) {
+__global__ __launch_bounds__(64) void k_chain_big(ChainArgs P, uint32_t nItems, const unsigned long long *nDev) {
   __shared__ int sGa[GA_SCRATCH_INTS];
   if (threadIdx.x != 0) return;
+  if (nDev) { if (P.counters[2]) return; nItems = (uint32_t)*nDev; }
   const uint32_t t = blockIdx.x, nT = gridDim.x;
   uint32_t *mine = P.bigScratch + (uint64_t)t * (4 * BIG_CAP);
   unsigned int dpLocal = 0;
@@ -1853,6 +1868,7 @@ __global__ __launch_bounds__(WG) void k_collect(ChainArgs P) {
   __shared__ uint32_t sKeepBits[KEEP_BITS / 32];
   const int tid = threadIdx.x;
   const uint32_t stride = P.recStride;
+  if (P.devDriven && P.counters[2]) return;  // an arena overflowed earlier in this submission: the range runs again
   __shared__ uint32_t sNextRe;  // read-ends handed out one at a time (device counter): their group counts differ by orders of magnitude
   for (;;) {
     __syncthreads();
@@ -1985,12 +2001,21 @@ int t1k_chain_used_u32(int maxK) { return maxK * 4; }  // per used list: read of
 static int readCounters(t1k_ctx *ctx, unsigned long long *h) { return t1k_fetch_counters(ctx, h); }
 
 // striped list -> dense list; grid (blocks, T1K_NSTRIPE)
+// The first workgroup also leaves the dense list's length in the arena's total word (T1K_TOTAL_BASE) for the consumers that take their item
+// count from the device, and raises `overflowFlag` in the control word when a stripe is full (the range then runs again with larger lists).
 template <class V>
-__global__ __launch_bounds__(WG) void k_arena_compact(const V *src, uint32_t segCap, const unsigned long long *cursors, V *dst) {
+__global__ __launch_bounds__(WG) void k_arena_compact(const V *src, uint32_t segCap, unsigned long long *counters, int arena, V *dst, unsigned long long overflowFlag) {
+  const unsigned long long *cursors = counters + T1K_ARENA_BASE + (size_t)arena * T1K_NSTRIPE * 8;
   const uint32_t seg = blockIdx.y;
   uint32_t prefix = 0;
   for (uint32_t s = 0; s < seg; ++s) prefix += (uint32_t)min(cursors[s * 8], (unsigned long long)segCap);
   const uint32_t cnt = (uint32_t)min(cursors[seg * 8], (unsigned long long)segCap);
+  if (blockIdx.x == 0 && seg == T1K_NSTRIPE - 1 && threadIdx.x == 0) {
+    counters[T1K_TOTAL_BASE + arena] = (unsigned long long)prefix + cnt;
+    bool over = false;
+    for (uint32_t s = 0; s < T1K_NSTRIPE; ++s) over = over || cursors[s * 8] > (unsigned long long)segCap;
+    if (over && overflowFlag) atomicOr(&counters[2], overflowFlag);
+  }
   for (uint32_t i = blockIdx.x * WG + threadIdx.x; i < cnt; i += gridDim.x * WG) dst[prefix + i] = src[(uint64_t)seg * segCap + i];
 }
 
@@ -2007,13 +2032,20 @@ T1kArenaCounts t1k_arena_counts(const t1k_ctx *ctx, int arena, uint32_t segCap) 
 
 void t1k_arena_compact(t1k_ctx *ctx, int arena, const uint32_t *src, uint32_t segCap, uint32_t *dst, uint32_t maxSeg) {
   if (!maxSeg) return;
-  const unsigned long long *cur = (const unsigned long long *)ctx->bCounters.p + T1K_ARENA_BASE + (size_t)arena * T1K_NSTRIPE * 8;
-  hipLaunchKernelGGL(k_arena_compact<uint32_t>, dim3(std::min<uint32_t>((maxSeg + WG - 1) / WG, 256u), T1K_NSTRIPE), dim3(WG), 0, ctx->stream, src, segCap, cur, dst);
+  hipLaunchKernelGGL(k_arena_compact<uint32_t>, dim3(std::min<uint32_t>((maxSeg + WG - 1) / WG, 256u), T1K_NSTRIPE), dim3(WG), 0, ctx->stream, src, segCap,
+                     (unsigned long long *)ctx->bCounters.p, arena, dst, 0ull);
 }
 void t1k_arena_compact64(t1k_ctx *ctx, int arena, const unsigned long long *src, uint32_t segCap, unsigned long long *dst, uint32_t maxSeg) {
   if (!maxSeg) return;
-  const unsigned long long *cur = (const unsigned long long *)ctx->bCounters.p + T1K_ARENA_BASE + (size_t)arena * T1K_NSTRIPE * 8;
-  hipLaunchKernelGGL(k_arena_compact<unsigned long long>, dim3(std::min<uint32_t>((maxSeg + WG - 1) / WG, 256u), T1K_NSTRIPE), dim3(WG), 0, ctx->stream, src, segCap, cur, dst);
+  hipLaunchKernelGGL(k_arena_compact<unsigned long long>, dim3(std::min<uint32_t>((maxSeg + WG - 1) / WG, 256u), T1K_NSTRIPE), dim3(WG), 0, ctx->stream, src, segCap,
+                     (unsigned long long *)ctx->bCounters.p, arena, dst, 0ull);
+}
+// the device-driven form: the grid is sized from an estimate of the fullest stripe (the kernel strides over what is there), the list's length goes to
+// the arena's total word, a full stripe raises ERR_GROUPCAP on the device
+void t1k_arena_compact_dev(t1k_ctx *ctx, int arena, const uint32_t *src, uint32_t segCap, uint32_t *dst, uint64_t estTotal) {
+  const uint32_t perSeg = (uint32_t)std::min<uint64_t>(segCap, estTotal / T1K_NSTRIPE * 2 + WG);
+  hipLaunchKernelGGL(k_arena_compact<uint32_t>, dim3(std::max(1u, std::min<uint32_t>((perSeg + WG - 1) / WG, 256u)), T1K_NSTRIPE), dim3(WG), 0, ctx->stream, src, segCap,
+                     (unsigned long long *)ctx->bCounters.p, arena, dst, (unsigned long long)ERR_GROUPCAP);
 }
 
 // sort key of a registered alignment: its read-window length, so that the lanes of a wavefront sweep DPs of equal height
@@ -2058,8 +2090,9 @@ struct GroupSizeKey {  // chains first (they skip the sorts: their own wavefront
   }
 };
 template <class KeyFn>
-__global__ __launch_bounds__(WG) void k_csort_count(const uint32_t *list, uint32_t n, uint32_t *scratch, KeyFn key) {
+__global__ __launch_bounds__(WG) void k_csort_count(const uint32_t *list, uint32_t n, uint32_t *scratch, KeyFn key, const unsigned long long *nDev) {
   __shared__ uint32_t h[CS_BINS];
+  if (nDev) n = (uint32_t)*nDev;
   for (int b = threadIdx.x; b < CS_BINS; b += WG) h[b] = 0;
   __syncthreads();
   for (uint32_t i = blockIdx.x * WG + threadIdx.x; i < n; i += gridDim.x * WG) atomicAdd(&h[key(list[i])], 1u);
@@ -2068,9 +2101,10 @@ __global__ __launch_bounds__(WG) void k_csort_count(const uint32_t *list, uint32
     if (h[b]) atomicAdd(&scratch[b], h[b]);
 }
 template <class KeyFn>
-__global__ __launch_bounds__(WG) void k_csort_scatter(const uint32_t *list, uint32_t n, uint32_t *scratch, uint32_t *out, KeyFn key) {
+__global__ __launch_bounds__(WG) void k_csort_scatter(const uint32_t *list, uint32_t n, uint32_t *scratch, uint32_t *out, KeyFn key, const unsigned long long *nDev) {
   __shared__ uint32_t base[CS_BINS], h[CS_BINS], off[CS_BINS], warpSums[4];
   __shared__ uint32_t sLast;
+  if (nDev) n = (uint32_t)*nDev;
   uint32_t *hist = scratch, *cursor = scratch + CS_BINS, *ticket = scratch + 2 * CS_BINS;
   {  // exclusive prefix of the global histogram (two bins per thread)
     const uint32_t a = hist[2 * threadIdx.x], b = hist[2 * threadIdx.x + 1];
@@ -2107,17 +2141,19 @@ __global__ __launch_bounds__(WG) void k_csort_scatter(const uint32_t *list, uint
   }
 }
 // list -> sorted (both n entries); returns `sorted`, or `list` when the scratch cannot be had
+// nDev: the list's length is read on the device (n is then the most it can be: the sorted list's room; nEst sizes the grid)
 template <class KeyFn>
-static const uint32_t *countingSort(t1k_ctx *ctx, const uint32_t *list, uint32_t n, KeyFn key) {
+static const uint32_t *countingSort(t1k_ctx *ctx, const uint32_t *list, uint32_t n, KeyFn key, const unsigned long long *nDev = nullptr, uint64_t nEst = 0) {
   static_assert(CS_BINS == 2 * WG, "two bins per thread in the prefix");
   const size_t head = (2 * CS_BINS + 16) * 4;
   const bool fresh = ctx->bJobSort.bytes < head + (size_t)n * 4;
   if (t1k_ensure(ctx, ctx->bJobSort, head + (size_t)n * 4) != T1K_OK) return list;
   uint32_t *scratch = (uint32_t *)ctx->bJobSort.p, *sorted = scratch + 2 * CS_BINS + 16;
   if (fresh && hipMemsetAsync(scratch, 0, head, ctx->stream) != hipSuccess) return list;  // (a new block: not zero yet; afterwards every call leaves it zero)
-  const uint32_t grid = std::min<uint32_t>((n + CS_TILE - 1) / CS_TILE, 1024u);
-  hipLaunchKernelGGL(k_csort_count<KeyFn>, dim3(grid), dim3(WG), 0, ctx->stream, list, n, scratch, key);
-  hipLaunchKernelGGL(k_csort_scatter<KeyFn>, dim3(grid), dim3(WG), 0, ctx->stream, list, n, scratch, sorted, key);
+  const uint64_t forGrid = nDev ? std::min<uint64_t>(n, nEst) : n;
+  const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((forGrid + CS_TILE - 1) / CS_TILE, 1024u));
+  hipLaunchKernelGGL(k_csort_count<KeyFn>, dim3(grid), dim3(WG), 0, ctx->stream, list, n, scratch, key, nDev);
+  hipLaunchKernelGGL(k_csort_scatter<KeyFn>, dim3(grid), dim3(WG), 0, ctx->stream, list, n, scratch, sorted, key, nDev);
   return sorted;
 }
 void t1k_launch_dp_dense(t1k_ctx *ctx, const ChainArgs &a, const uint32_t *jobs, uint32_t n) {
@@ -2131,7 +2167,112 @@ void t1k_launch_dp_dense(t1k_ctx *ctx, const ChainArgs &a, const uint32_t *jobs,
     hipLaunchKernelGGL(k_job_keys, dim3((n + WG - 1) / WG), dim3(WG), 0, ctx->stream, (const unsigned long long *)a.memo, jobs, k0, n);
     if (t1k_sort_pairs(ctx, k0, k1, jobs, sorted, n, 9) == T1K_OK) jobs = sorted;
   }
-  hipLaunchKernelGGL(k_dp_dense, dim3((n + WG - 1) / WG), dim3(WG), 0, ctx->stream, a, jobs, n);
+  hipLaunchKernelGGL(k_dp_dense, dim3((n + WG - 1) / WG), dim3(WG), 0, ctx->stream, a, jobs, n, (const unsigned long long *)nullptr);
+}
+// the same with the number of jobs read on the device (arena's total word); cap = the most there can be, est sizes the grids
+void t1k_launch_dp_dense_dev(t1k_ctx *ctx, const ChainArgs &a, const uint32_t *jobs, int arena, uint32_t cap, uint64_t est) {
+  const unsigned long long *nDev = (const unsigned long long *)ctx->bCounters.p + T1K_TOTAL_BASE + arena;
+  jobs = countingSort(ctx, jobs, cap, JobLenKey{(const unsigned long long *)a.memo}, nDev, est);
+  const uint32_t grid = (uint32_t)std::max<uint64_t>(1, (std::min<uint64_t>(cap, est) + WG - 1) / WG);
+  hipLaunchKernelGGL(k_dp_dense, dim3(grid), dim3(WG), 0, ctx->stream, a, jobs, cap, nDev);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// The chain of one range as ONE submission (round 5).  Rounds 1-4 fetched the counter block six times per range -- after seeding, after
+// the closed-form pass, after the gap walk, twice inside the multi-diagonal path, at the end -- because every consumer's grid and item
+// count were launch arguments.  Here every consumer reads its item count on the device (the total word k_arena_compact leaves where it
+// makes a striped list dense, or the group arena's cursors) and strides over the items, so its grid only has to be roughly right: it is
+// sized from what the context's previous range counted (per read-end; the first range of a context: from the arenas' capacities).  A full
+// stripe raises ERR_GROUPCAP on the device; the kernels behind it work on the clamped lists (their results are thrown away: the caller
+// runs the range again with the capacities the cursors ask for, as before).  One counter fetch is left, at the end.
+// ------------------------------------------------------------------------------------------------------------------
+// expected entries of an arena in a range of nRe read-ends (a quarter to spare), never more than it can hold
+uint64_t t1k_arena_estimate(const t1k_ctx *ctx, int arena, uint64_t cap, uint32_t nRe) {
+  if (!ctx->estValid || !ctx->estTotal[arena]) return cap;
+  return std::min<uint64_t>(cap, (ctx->estTotal[arena] * std::max(1u, nRe) >> 16) * 5 / 4 + 4096);
+}
+void t1k_arena_estimate_set(t1k_ctx *ctx, int arena, uint64_t total, uint32_t nRe) { ctx->estTotal[arena] = (total << 16) / std::max(1u, nRe) + 1; }
+bool t1k_chain_host_driven() { static const bool h = getenv("T1K_HOST_CHAIN") != nullptr; return h; }
+static int runChainDevice(t1k_ctx *ctx, const ChainArgs &aIn, int nWg, int bigBlocks, bool longReads, bool xlong, unsigned long long *hc) {
+  ChainArgs a = aIn;
+  a.devDriven = 1;
+  const unsigned long long *tot = (const unsigned long long *)ctx->bCounters.p + T1K_TOTAL_BASE;
+  const uint32_t nRe = std::max<uint32_t>(1u, a.reads.nReadEnds);
+  auto est = [&](int arena, uint64_t cap) -> uint64_t { return t1k_arena_estimate(ctx, arena, cap, nRe); };
+  auto blocks = [](uint64_t items, uint32_t per) { return (uint32_t)std::max<uint64_t>(1, (items + per - 1) / per); };
+  const uint64_t listCap = (uint64_t)a.listSegCap * T1K_NSTRIPE, rareCap = (uint64_t)a.rareSegCap * T1K_NSTRIPE, jobCap = (uint64_t)a.jobSegCap * T1K_NSTRIPE,
+                 genJobCap = (uint64_t)a.genJobSegCap * T1K_NSTRIPE, groupCap = (uint64_t)a.groupSegCap * T1K_NSTRIPE;
+  {  // closed-form pass over all records: blockIdx.y = stripe.  The straight-line kernel (the striding form costs it a wavefront per SIMD) over a
+     // grid that covers what a stripe CAN hold: the workgroups beyond the stripe's cursor end at once (a few hundred thousand empty
+     // workgroups are tens of microseconds of dispatch)
+    const dim3 grid(blocks(a.groupSegCap, WG), T1K_NSTRIPE);
+    (void)groupCap;
+    if (longReads) hipLaunchKernelGGL((k_chain_fast<10, 0, false>), grid, dim3(WG), 0, ctx->stream, a, (const uint32_t *)nullptr, 0u, tot);
+    else hipLaunchKernelGGL((k_chain_fast<5, 0, false>), grid, dim3(WG), 0, ctx->stream, a, (const uint32_t *)nullptr, 0u, tot);
+  }
+  {  // gap walk over the groups the closed form left
+    const uint64_t e = est(T1K_AR_SLOW, listCap);
+    t1k_arena_compact_dev(ctx, T1K_AR_SLOW, a.slowStr, a.listSegCap, a.slowList, e);
+    if (longReads) hipLaunchKernelGGL((k_chain_fast<10, 1, true>), dim3(blocks(e, WG)), dim3(WG), 0, ctx->stream, a, (const uint32_t *)a.slowList, 0u, tot + T1K_AR_SLOW);
+    else hipLaunchKernelGGL((k_chain_fast<5, 1, true>), dim3(blocks(e, WG)), dim3(WG), 0, ctx->stream, a, (const uint32_t *)a.slowList, 0u, tot + T1K_AR_SLOW);
+  }
+  const uint64_t eJobs = est(T1K_AR_JOBS, jobCap), eRetry = est(T1K_AR_RETRY, listCap), eGen = est(T1K_AR_GENERAL, rareCap);
+  t1k_arena_compact_dev(ctx, T1K_AR_JOBS, a.jobStr, a.jobSegCap, a.jobList, eJobs);
+  t1k_arena_compact_dev(ctx, T1K_AR_RETRY, a.retryStr, a.listSegCap, a.retryList, eRetry);
+  t1k_arena_compact_dev(ctx, T1K_AR_GENERAL, a.generalStr, a.rareSegCap, a.generalList, eGen);
+  // (the finish list -- groups whose candidate waits for registered alignments -- is only a count here: k_collect adds the match counts itself;
+  // a full stripe of it loses nothing, its entries are never read)
+  t1k_launch_dp_dense_dev(ctx, a, a.jobList, T1K_AR_JOBS, (uint32_t)jobCap, eJobs);
+  if (longReads) hipLaunchKernelGGL((k_chain_fast<10, 2, true>), dim3(blocks(eRetry, WG)), dim3(WG), 0, ctx->stream, a, (const uint32_t *)a.retryList, 0u, tot + T1K_AR_RETRY);
+  else hipLaunchKernelGGL((k_chain_fast<5, 2, true>), dim3(blocks(eRetry, WG)), dim3(WG), 0, ctx->stream, a, (const uint32_t *)a.retryList, 0u, tot + T1K_AR_RETRY);
+  {  // groups with hits on several diagonals
+    static const bool nearHits = getenv("T1K_NO_NEAR_HITS") == nullptr;
+    const int skipDone = nearHits && !xlong ? 1 : 0;
+    const unsigned long long *nGen = tot + T1K_AR_GENERAL;
+    if (skipDone) {
+      if (longReads) hipLaunchKernelGGL(k_near_hits<10>, dim3(blocks(eGen, WG)), dim3(WG), 0, ctx->stream, a, 0u, nGen);
+      else hipLaunchKernelGGL(k_near_hits<5>, dim3(blocks(eGen, WG)), dim3(WG), 0, ctx->stream, a, 0u, nGen);
+    }
+    const uint32_t gatherGrid = std::min<uint32_t>(blocks(eGen, 4), 8192u);
+    if (xlong) hipLaunchKernelGGL(k_gather_general<(T1K_LONG_READ_LEN + 63) / 64>, dim3(gatherGrid), dim3(WG), 0, ctx->stream, a, 0u, skipDone, nGen);
+    else hipLaunchKernelGGL(k_gather_general<GROUP_FAST_MAXLEN / 64>, dim3(gatherGrid), dim3(WG), 0, ctx->stream, a, 0u, skipDone, nGen);
+    ChainArgs g = a;
+    g.generalList = (uint32_t *)countingSort(ctx, a.generalList, (uint32_t)rareCap, GroupSizeKey{(const uint32_t *)a.recs, a.recStride, skipDone}, nGen, eGen);  // groups of similar size side by side
+    hipLaunchKernelGGL(k_chain_general, dim3(blocks(eGen, 64)), dim3(64), 0, ctx->stream, g, 0u, skipDone, nGen);
+    const uint64_t eWave = est(T1K_AR_WAVE, rareCap);
+    t1k_arena_compact_dev(ctx, T1K_AR_WAVE, a.waveStr, a.rareSegCap, a.waveList, eWave);
+    T1K_HIP(ctx, hipFuncSetAttribute((const void *)k_chain_wave, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * WAVE_CAP * 4));
+    hipLaunchKernelGGL(k_chain_wave, dim3((uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(eWave, 2048u))), dim3(64), 3 * WAVE_CAP * 4, ctx->stream, a, 0u, tot + T1K_AR_WAVE);
+    const uint64_t eGenJobs = est(T1K_AR_GENJOBS, genJobCap);
+    t1k_arena_compact_dev(ctx, T1K_AR_GENJOBS, a.genJobStr, a.genJobSegCap, a.genJobList, eGenJobs);
+    t1k_launch_dp_dense_dev(ctx, a, a.genJobList, T1K_AR_GENJOBS, (uint32_t)genJobCap, eGenJobs);
+    hipLaunchKernelGGL(k_general_finish, dim3(blocks(eGen, WG)), dim3(WG), 0, ctx->stream, a, 0u, nGen);
+    t1k_arena_compact_dev(ctx, T1K_AR_BIG, a.bigStr, a.rareSegCap, a.bigList, est(T1K_AR_BIG, rareCap));
+    hipLaunchKernelGGL(k_chain_big, dim3(bigBlocks * 64), dim3(64), 0, ctx->stream, a, 0u, tot + T1K_AR_BIG);
+  }
+  if (xlong) hipLaunchKernelGGL(k_collect<T1K_LONG_READ_LEN>, dim3(nWg), dim3(WG), 0, ctx->stream, a);
+  else hipLaunchKernelGGL(k_collect<T1K_MAX_READ_LEN>, dim3(nWg), dim3(WG), 0, ctx->stream, a);
+  T1K_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+  const int rc = readCounters(ctx, hc);
+  if (rc) return rc;
+  // what the cursors say: overflow of a list whose compaction is the only place that could have seen it, the statistics, the next range's estimates
+  const T1kArenaCounts groups = t1k_arena_counts(ctx, T1K_AR_GROUPS, a.groupSegCap), slow = t1k_arena_counts(ctx, T1K_AR_SLOW, a.listSegCap), jobs = t1k_arena_counts(ctx, T1K_AR_JOBS, a.jobSegCap),
+                       retry = t1k_arena_counts(ctx, T1K_AR_RETRY, a.listSegCap), fin = t1k_arena_counts(ctx, T1K_AR_FINISH, a.listSegCap), gen = t1k_arena_counts(ctx, T1K_AR_GENERAL, a.rareSegCap),
+                       wv = t1k_arena_counts(ctx, T1K_AR_WAVE, a.rareSegCap), gj = t1k_arena_counts(ctx, T1K_AR_GENJOBS, a.genJobSegCap), big = t1k_arena_counts(ctx, T1K_AR_BIG, a.rareSegCap);
+  if (groups.overflow || slow.overflow || jobs.overflow || retry.overflow || gen.overflow || wv.overflow || gj.overflow || big.overflow) hc[2] |= ERR_GROUPCAP;
+  // (the finish list: word 22 is a statistic; the list itself is not read -- see above -- so its overflow is not an error)
+  // A full job list means memo claims were released while other lanes already waited on them: what ran behind it may have met a slot still
+  // pending (ERR_MEMO).  That is a consequence of the overflow, not an internal error: the range runs again with lists that fit.
+  if (hc[2] & ERR_GROUPCAP) hc[2] &= ~(unsigned long long)ERR_MEMO;
+  ctx->lastSlowGroups = slow.total;
+  hc[16] = jobs.total; hc[17] = retry.total; hc[18] = gen.total; hc[19] = big.total; hc[22] = fin.total;
+  if (!hc[2]) {
+    const T1kArenaCounts *cs[] = {&groups, &slow, &jobs, &retry, &gen, &wv, &gj, &big};
+    const int ar[] = {T1K_AR_GROUPS, T1K_AR_SLOW, T1K_AR_JOBS, T1K_AR_RETRY, T1K_AR_GENERAL, T1K_AR_WAVE, T1K_AR_GENJOBS, T1K_AR_BIG};
+    for (int i = 0; i < 8; ++i) t1k_arena_estimate_set(ctx, ar[i], cs[i]->total, nRe);
+    ctx->estValid = true;
+  }
+  return 0;
 }
 
 // runs K1..K6; on return counters[0] = number of candidates, counters[2] = error flags
@@ -2169,6 +2310,9 @@ int t1k_run_chain(t1k_ctx *ctx, const ChainArgs &a, int nWg, int bigBlocks, bool
     hipLaunchKernelGGL(k_seed_long, dim3(std::min<uint32_t>(a.reads.nReadEnds, 32768u)), dim3(WG), ldsLong, ctx->stream, a);
   }
   T1K_HIP(ctx, hipEventRecord(ctx->ev[8], ctx->stream));
+  // T1K_HOST_CHAIN: the launch sequence of rounds 1-4 -- the host fetches the counters between a producer and its consumers (A/B, fallback)
+  if (!t1k_chain_host_driven() && !a.fuse) return runChainDevice(ctx, a, nWg, bigBlocks, longReads, xlong, hc);
+  const unsigned long long *NODEV = nullptr;
   int rc = readCounters(ctx, hc);
   if (rc) return rc;
   if (hc[2]) return 0;
@@ -2177,8 +2321,8 @@ int t1k_run_chain(t1k_ctx *ctx, const ChainArgs &a, int nWg, int bigBlocks, bool
   if (!a.fuse) {  // the closed-form pass as a launch of its own over all records (T1K_FUSE_SEED=0)
     if (groups.maxSeg) {
       const dim3 grid((groups.maxSeg + WG - 1) / WG, T1K_NSTRIPE);
-      if (longReads) hipLaunchKernelGGL((k_chain_fast<10, 0>), grid, dim3(WG), 0, ctx->stream, a, (const uint32_t *)nullptr, 0u);
-      else hipLaunchKernelGGL((k_chain_fast<5, 0>), grid, dim3(WG), 0, ctx->stream, a, (const uint32_t *)nullptr, 0u);
+      if (longReads) hipLaunchKernelGGL((k_chain_fast<10, 0, false>), grid, dim3(WG), 0, ctx->stream, a, (const uint32_t *)nullptr, 0u, NODEV);
+      else hipLaunchKernelGGL((k_chain_fast<5, 0, false>), grid, dim3(WG), 0, ctx->stream, a, (const uint32_t *)nullptr, 0u, NODEV);
     }
     if ((rc = readCounters(ctx, hc))) return rc;
   }
@@ -2188,8 +2332,8 @@ int t1k_run_chain(t1k_ctx *ctx, const ChainArgs &a, int nWg, int bigBlocks, bool
   if (slow.total) {
     t1k_arena_compact(ctx, T1K_AR_SLOW, a.slowStr, a.listSegCap, a.slowList, slow.maxSeg);
     const uint32_t nSlowGroups = (uint32_t)slow.total;
-    if (longReads) hipLaunchKernelGGL((k_chain_fast<10, 1>), dim3((nSlowGroups + WG - 1) / WG), dim3(WG), 0, ctx->stream, a, (const uint32_t *)a.slowList, nSlowGroups);
-    else hipLaunchKernelGGL((k_chain_fast<5, 1>), dim3((nSlowGroups + WG - 1) / WG), dim3(WG), 0, ctx->stream, a, (const uint32_t *)a.slowList, nSlowGroups);
+    if (longReads) hipLaunchKernelGGL((k_chain_fast<10, 1, false>), dim3((nSlowGroups + WG - 1) / WG), dim3(WG), 0, ctx->stream, a, (const uint32_t *)a.slowList, nSlowGroups, NODEV);
+    else hipLaunchKernelGGL((k_chain_fast<5, 1, false>), dim3((nSlowGroups + WG - 1) / WG), dim3(WG), 0, ctx->stream, a, (const uint32_t *)a.slowList, nSlowGroups, NODEV);
   }
   if ((rc = readCounters(ctx, hc))) return rc;
   hc[6] = groupsSeeded;
@@ -2209,19 +2353,19 @@ int t1k_run_chain(t1k_ctx *ctx, const ChainArgs &a, int nWg, int bigBlocks, bool
   static const bool finishKernel = getenv("T1K_FINISH_KERNEL") != nullptr;
   if (nFinish && finishKernel) hipLaunchKernelGGL(k_chain_finish, dim3((nFinish + WG - 1) / WG), dim3(WG), 0, ctx->stream, a, nFinish);
   if (nRetry) {
-    if (longReads) hipLaunchKernelGGL((k_chain_fast<10, 2>), dim3((nRetry + WG - 1) / WG), dim3(WG), 0, ctx->stream, a, (const uint32_t *)a.retryList, nRetry);
-    else hipLaunchKernelGGL((k_chain_fast<5, 2>), dim3((nRetry + WG - 1) / WG), dim3(WG), 0, ctx->stream, a, (const uint32_t *)a.retryList, nRetry);
+    if (longReads) hipLaunchKernelGGL((k_chain_fast<10, 2, false>), dim3((nRetry + WG - 1) / WG), dim3(WG), 0, ctx->stream, a, (const uint32_t *)a.retryList, nRetry, NODEV);
+    else hipLaunchKernelGGL((k_chain_fast<5, 2, false>), dim3((nRetry + WG - 1) / WG), dim3(WG), 0, ctx->stream, a, (const uint32_t *)a.retryList, nRetry, NODEV);
   }
   uint32_t nBig = 0;
   if (nGen) {
     static const bool nearHits = getenv("T1K_NO_NEAR_HITS") == nullptr;
     const int skipDone = nearHits && !xlong ? 1 : 0;
     if (skipDone) {
-      if (longReads) hipLaunchKernelGGL(k_near_hits<10>, dim3((nGen + WG - 1) / WG), dim3(WG), 0, ctx->stream, a, nGen);
-      else hipLaunchKernelGGL(k_near_hits<5>, dim3((nGen + WG - 1) / WG), dim3(WG), 0, ctx->stream, a, nGen);
+      if (longReads) hipLaunchKernelGGL(k_near_hits<10>, dim3((nGen + WG - 1) / WG), dim3(WG), 0, ctx->stream, a, nGen, NODEV);
+      else hipLaunchKernelGGL(k_near_hits<5>, dim3((nGen + WG - 1) / WG), dim3(WG), 0, ctx->stream, a, nGen, NODEV);
     }
-    if (xlong) hipLaunchKernelGGL(k_gather_general<(T1K_LONG_READ_LEN + 63) / 64>, dim3(std::min<uint32_t>((nGen + 3) / 4, 8192u)), dim3(WG), 0, ctx->stream, a, nGen, skipDone);
-    else hipLaunchKernelGGL(k_gather_general<GROUP_FAST_MAXLEN / 64>, dim3(std::min<uint32_t>((nGen + 3) / 4, 8192u)), dim3(WG), 0, ctx->stream, a, nGen, skipDone);
+    if (xlong) hipLaunchKernelGGL(k_gather_general<(T1K_LONG_READ_LEN + 63) / 64>, dim3(std::min<uint32_t>((nGen + 3) / 4, 8192u)), dim3(WG), 0, ctx->stream, a, nGen, skipDone, NODEV);
+    else hipLaunchKernelGGL(k_gather_general<GROUP_FAST_MAXLEN / 64>, dim3(std::min<uint32_t>((nGen + 3) / 4, 8192u)), dim3(WG), 0, ctx->stream, a, nGen, skipDone, NODEV);
     ChainArgs g = a;
     static const bool radix = getenv("T1K_RADIX_SORTS") != nullptr;
     if (nGen >= 4096 && !radix)  // groups of similar size side by side
@@ -2232,27 +2376,27 @@ int t1k_run_chain(t1k_ctx *ctx, const ChainArgs &a, int nWg, int bigBlocks, bool
       hipLaunchKernelGGL(k_group_size_keys, dim3((nGen + WG - 1) / WG), dim3(WG), 0, ctx->stream, (const uint32_t *)a.recs, a.recStride, (const uint32_t *)a.generalList, k0, nGen, skipDone);
       if (t1k_sort_pairs(ctx, k0, k1, a.generalList, sorted, nGen, 8) == T1K_OK) g.generalList = sorted;
     }
-    hipLaunchKernelGGL(k_chain_general, dim3((nGen + 63) / 64), dim3(64), 0, ctx->stream, g, nGen, skipDone);
+    hipLaunchKernelGGL(k_chain_general, dim3((nGen + 63) / 64), dim3(64), 0, ctx->stream, g, nGen, skipDone, NODEV);
     if ((rc = readCounters(ctx, hc))) return rc;
     const T1kArenaCounts wv = t1k_arena_counts(ctx, T1K_AR_WAVE, a.rareSegCap);
     if (wv.overflow) { hc[2] |= ERR_GROUPCAP; return 0; }
     if (wv.total) {
       t1k_arena_compact(ctx, T1K_AR_WAVE, a.waveStr, a.rareSegCap, a.waveList, wv.maxSeg);
       T1K_HIP(ctx, hipFuncSetAttribute((const void *)k_chain_wave, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * WAVE_CAP * 4));
-      hipLaunchKernelGGL(k_chain_wave, dim3(std::min<uint32_t>((uint32_t)wv.total, 2048u)), dim3(64), 3 * WAVE_CAP * 4, ctx->stream, a, (uint32_t)wv.total);
+      hipLaunchKernelGGL(k_chain_wave, dim3(std::min<uint32_t>((uint32_t)wv.total, 2048u)), dim3(64), 3 * WAVE_CAP * 4, ctx->stream, a, (uint32_t)wv.total, NODEV);
     }
     if ((rc = readCounters(ctx, hc))) return rc;  // the general kernels register alignments and may hand groups over to the big-scratch kernel
     const T1kArenaCounts gj = t1k_arena_counts(ctx, T1K_AR_GENJOBS, a.genJobSegCap);
     if (gj.overflow) { hc[2] |= ERR_GROUPCAP; return 0; }
     t1k_arena_compact(ctx, T1K_AR_GENJOBS, a.genJobStr, a.genJobSegCap, a.genJobList, gj.maxSeg);
     t1k_launch_dp_dense(ctx, a, a.genJobList, (uint32_t)gj.total);
-    hipLaunchKernelGGL(k_general_finish, dim3((nGen + WG - 1) / WG), dim3(WG), 0, ctx->stream, a, nGen);
+    hipLaunchKernelGGL(k_general_finish, dim3((nGen + WG - 1) / WG), dim3(WG), 0, ctx->stream, a, nGen, NODEV);
     const T1kArenaCounts big = t1k_arena_counts(ctx, T1K_AR_BIG, a.rareSegCap);
     if (big.overflow) { hc[2] |= ERR_GROUPCAP; return 0; }
     t1k_arena_compact(ctx, T1K_AR_BIG, a.bigStr, a.rareSegCap, a.bigList, big.maxSeg);
     nBig = (uint32_t)big.total;
   }
-  if (nBig) hipLaunchKernelGGL(k_chain_big, dim3(bigBlocks * 64), dim3(64), 0, ctx->stream, a, nBig);
+  if (nBig) hipLaunchKernelGGL(k_chain_big, dim3(bigBlocks * 64), dim3(64), 0, ctx->stream, a, nBig, NODEV);
   if (xlong) hipLaunchKernelGGL(k_collect<T1K_LONG_READ_LEN>, dim3(nWg), dim3(WG), 0, ctx->stream, a);
   else hipLaunchKernelGGL(k_collect<T1K_MAX_READ_LEN>, dim3(nWg), dim3(WG), 0, ctx->stream, a);
   T1K_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));

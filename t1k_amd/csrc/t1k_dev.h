@@ -622,7 +622,11 @@ enum { T1K_STAT_DP = 0, T1K_STAT_FAST = 1, T1K_STAT_GENERAL = 2, T1K_STAT_EXTEND
 #define T1K_NSTRIPE 32
 enum { T1K_AR_GROUPS = 0, T1K_AR_JOBS, T1K_AR_RETRY, T1K_AR_FINISH, T1K_AR_GENERAL, T1K_AR_BIG, T1K_AR_GENCAND, T1K_AR_EQ, T1K_AR_BAND, T1K_AR_WIDE, T1K_AR_GENHITS, T1K_AR_GENJOBS, T1K_AR_WAVE, T1K_AR_EXTJOBS, T1K_AR_EXTRETRY, T1K_AR_SLOW, T1K_NARENA };
 #define T1K_ARENA_BASE (64 + T1K_STAT_STRIPES * 8)
-#define T1K_COUNTER_WORDS (T1K_ARENA_BASE + T1K_NARENA * T1K_NSTRIPE * 8)
+// behind the cursors: one word per arena = the number of entries of its DENSE list (sum over the stripes of min(cursor, segCap)), written by
+// k_arena_compact where it makes the list dense -- the list's consumers read their item count there instead of from a launch argument, so
+// the host does not have to fetch the cursors between a producer and its consumers (t1k_run_chain: one counter fetch per range)
+#define T1K_TOTAL_BASE (T1K_ARENA_BASE + T1K_NARENA * T1K_NSTRIPE * 8)
+#define T1K_COUNTER_WORDS (T1K_TOTAL_BASE + ((T1K_NARENA + 7) & ~7))
 #define T1K_ARENA_FULL 0xFFFFFFFFu
 __device__ __forceinline__ unsigned long long *t1k_arena_cursor(unsigned long long *counters, int arena, uint32_t stripe) {
   return counters + T1K_ARENA_BASE + ((uint32_t)arena * T1K_NSTRIPE + stripe) * 8;
@@ -762,6 +766,8 @@ struct t1k_ctx {
   uint32_t upN = 0; int upS = 0, upMaxLen = 0; uint64_t upBytes = 0; bool upOpen = false;
   hipEvent_t upEv[4] = {nullptr, nullptr, nullptr, nullptr}; bool upEvSet[4] = {false, false, false, false};
   uint64_t lastSlowGroups = 0;             // groups the last range left to the gap walk (T1K_DEBUG_PHASES)
+  uint64_t estTotal[T1K_NARENA] = {};      // entries per arena the last range of this context ended with, per read-end x 2^16: the next range's launch grids (t1k_run_chain)
+  bool estValid = false;
   uint64_t pairEpoch = 0;      // epochs handed out to k_pair's allele tables since they were last cleared
   uint64_t pairBigCap = 0;     // entries of k_pair's big arena (scratch of the fragments whose lists exceed a workgroup's own)
   unsigned long long *countersPinned = nullptr;  // page-locked landing buffer of t1k_fetch_counters

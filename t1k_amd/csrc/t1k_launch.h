@@ -25,6 +25,7 @@ struct ChainArgs {
   uint32_t *genCand; uint32_t genCandCap;                  // packed candidates of multi-diagonal groups (3 u32 each)
   uint32_t *bigScratch;
   int fuse;                // the seeding kernel runs the closed-form pass itself (k_seed_chain) and fills the gap-walk / multi-diagonal lists; 0 (T1K_FUSE_SEED=0): k_seed_groups + k_chain_fast<*, 0>
+  int devDriven;             // this submission holds no counter fetch between its launches (runChainDevice): a launch behind an overflow ends at once
   int nearSimple;          // k_near_hits marks the two-diagonal groups whose hit list is its chain (T1K_NO_SIMPLE_CHAIN=1: leaves them to the general path)
   int earlyPrune;          // k_chain_fast<*, 0>: 0 = closed form only (T1K_NO_EARLY_PRUNE=1), 1 = + the groups that cannot pass the similarity filter by the gap-count bound
                            // (T1K_WALK_IN_CLOSED=0), 2 = + the gap walk's first pass: groups without a gap of more than three mismatches and groups its bound prunes (default)
@@ -169,6 +170,13 @@ int t1k_coverage_fold(t1k_ctx *ctx);  // covFull -> covDiff (on the context's st
 void t1k_launch_missing_coverage(t1k_ctx *ctx, const T1kRefDev &ref, int32_t *scratch, int32_t *missing);
 void t1k_launch_extend_retry(t1k_ctx *ctx, const ExtendArgs &a, const uint32_t *list, uint32_t n);
 void t1k_launch_dp_dense(t1k_ctx *ctx, const ChainArgs &a, const uint32_t *jobs, uint32_t n);
+// device-driven forms (t1k_chain.hip, runChainDevice): item counts read on the device from the arena's total word, grids from estimates
+void t1k_arena_compact_dev(t1k_ctx *ctx, int arena, const uint32_t *src, uint32_t segCap, uint32_t *dst, uint64_t estTotal);
+void t1k_launch_dp_dense_dev(t1k_ctx *ctx, const ChainArgs &a, const uint32_t *jobs, int arena, uint32_t cap, uint64_t est);
+uint64_t t1k_arena_estimate(const t1k_ctx *ctx, int arena, uint64_t cap, uint32_t nRe);
+void t1k_arena_estimate_set(t1k_ctx *ctx, int arena, uint64_t total, uint32_t nRe);
+bool t1k_chain_host_driven();
+void t1k_launch_extend_retry_dev(t1k_ctx *ctx, const ExtendArgs &a, const uint32_t *list, int arena, uint64_t est);
 void t1k_arena_compact64(t1k_ctx *ctx, int arena, const unsigned long long *src, uint32_t segCap, unsigned long long *dst, uint32_t maxSeg);
 int t1k_sort_pairs(t1k_ctx *ctx, const unsigned long long *keysIn, unsigned long long *keysOut, const uint32_t *valsIn, uint32_t *valsOut, uint32_t n, int endBit = 64);
 void t1k_arena_compact(t1k_ctx *ctx, int arena, const uint32_t *src, uint32_t segCap, uint32_t *dst, uint32_t maxSeg);

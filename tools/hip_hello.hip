@@ -1,0 +1,36 @@
+// smallest HIP process: what a fresh process pays before and after any work of its own (tools/cold_r05.sh).
+//   hip_hello [GB [free]]   allocates and touches that much device memory in 1.5 GB blocks first (and hands it back before leaving with `free`):
+//   what does the end of a process cost per GB of device memory it held?
+#include <hip/hip_runtime.h>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+__global__ void k(int *p) { *p = 1; }
+int main(int argc, char **argv) {
+  auto t0 = std::chrono::steady_clock::now();
+  int *d = nullptr;
+  (void)hipSetDevice(0);
+  (void)hipMalloc(&d, 1 << 20);
+  auto t1 = std::chrono::steady_clock::now();
+  hipLaunchKernelGGL(k, dim3(1), dim3(1), 0, 0, d);
+  (void)hipDeviceSynchronize();
+  auto t2 = std::chrono::steady_clock::now();
+  const double gb = argc > 1 ? atof(argv[1]) : 0;
+  std::vector<void *> blocks;
+  for (double have = 0; have < gb; have += 1.5) {
+    void *p = nullptr;
+    if (hipMalloc(&p, (size_t)1536 << 20) != hipSuccess) break;
+    (void)hipMemsetAsync(p, 1, (size_t)1536 << 20, 0);
+    blocks.push_back(p);
+  }
+  (void)hipDeviceSynchronize();
+  auto t3 = std::chrono::steady_clock::now();
+  if (argc > 2 && !strcmp(argv[2], "free")) for (void *p : blocks) (void)hipFree(p);
+  auto t4 = std::chrono::steady_clock::now();
+  auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+  fprintf(stderr, "hip_hello: first hipMalloc %.1f ms, first kernel %.1f ms, %.1f GB allocated + set in %.1f ms, freed in %.1f ms, main %.1f ms\n", ms(t0, t1), ms(t1, t2), blocks.size() * 1.5,
+          ms(t2, t3), ms(t3, t4), ms(t0, t4));
+  return 0;
+}
