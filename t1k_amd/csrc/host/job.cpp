@@ -1691,8 +1691,46 @@ int t1k_genotyper_main(int argc, char **argv) {
   logLine("Genotyping finishes.");
   const double tOut = nowMs();
   destroyAll();
-  if (getenv("T1K_DEBUG_PHASES"))  // (what a stopwatch around the process sees beyond this: loading the executable and the HIP runtime before main, the exit behind it)
+  if (getenv("T1K_DEBUG_PHASES")) {  // (what a stopwatch around the process sees beyond this: loading the executable and the HIP runtime before main, the exit behind it)
     fprintf(stderr, "[t1k job] main: %.1f ms from its first line to the outputs, %.1f ms to release the job\n", tOut - tMain, nowMs() - tOut);
+    // what the process still maps when it leaves (the kernel takes the address space apart before the parent sees the exit)
+    if (FILE *fp = fopen("/proc/self/smaps_rollup", "r")) {
+      char line[256];
+      std::string all;
+      while (fgets(line, sizeof line, fp))
+        if (!strncmp(line, "Rss:", 4) || !strncmp(line, "Anonymous:", 10) || !strncmp(line, "Shared_Clean:", 13) || !strncmp(line, "Shared_Dirty:", 13) || !strncmp(line, "Private_Clean:", 14) ||
+            !strncmp(line, "Private_Dirty:", 14) || !strncmp(line, "AnonHugePages:", 14) || !strncmp(line, "Locked:", 7)) {
+          std::string l(line);
+          while (!l.empty() && (l.back() == '\n' || l.back() == ' ')) l.pop_back();
+          size_t a = l.find(':');
+          size_t b = l.find_first_not_of(' ', a + 1);
+          all += l.substr(0, a + 1) + " " + (b == std::string::npos ? "" : l.substr(b)) + "; ";
+        }
+      fclose(fp);
+      fprintf(stderr, "[t1k job] address space at the end of main: %s\n", all.c_str());
+    }
+    if (getenv("T1K_DEBUG_MAPS"))  // the largest resident mappings (what the exit has to take apart page by page)
+      if (FILE *fp = fopen("/proc/self/smaps", "r")) {
+        struct Reg { std::string head; unsigned long rss = 0, anon = 0; };
+        std::vector<Reg> regs;
+        char line[512];
+        while (fgets(line, sizeof line, fp)) {
+          unsigned long a, b;
+          if (sscanf(line, "%lx-%lx ", &a, &b) == 2 && strchr(line, '-') && (strstr(line, " r") || strstr(line, " -"))) { Reg r; r.head = line; while (!r.head.empty() && r.head.back() == '\n') r.head.pop_back(); regs.push_back(r); }
+          else if (!regs.empty() && !strncmp(line, "Rss:", 4)) regs.back().rss = strtoul(line + 4, nullptr, 10);
+          else if (!regs.empty() && !strncmp(line, "Anonymous:", 10)) regs.back().anon = strtoul(line + 10, nullptr, 10);
+        }
+        fclose(fp);
+        std::sort(regs.begin(), regs.end(), [](const Reg &x, const Reg &y) { return x.rss > y.rss; });
+        for (size_t i = 0; i < regs.size() && i < 24; ++i) fprintf(stderr, "[t1k job]   rss %8lu kB (anonymous %8lu kB)  %s\n", regs[i].rss, regs[i].anon, regs[i].head.c_str());
+      }
+    if (FILE *fp = fopen("/proc/self/status", "r")) {
+      char line[256];
+      while (fgets(line, sizeof line, fp))
+        if (!strncmp(line, "Threads:", 8) || !strncmp(line, "VmPeak:", 7) || !strncmp(line, "VmHWM:", 6) || !strncmp(line, "VmPTE:", 6)) fprintf(stderr, "[t1k job]   %s", line);
+      fclose(fp);
+    }
+  }
   if (const char *e = getenv("T1K_EXIT_FREE")) {  // experiment: the job's device memory handed back by several threads, then out without the exit handlers
     const double t0 = nowMs();
     const uint64_t b = t1k_pool_release_mt(atoi(e));

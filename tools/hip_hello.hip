@@ -26,6 +26,28 @@ int main(int argc, char **argv) {
     blocks.push_back(p);
   }
   (void)hipDeviceSynchronize();
+  // HH_STREAMS=n: a kernel on n streams of its own (what does the end of a process cost per hardware queue?); HH_ANON_GB=g: g GB of host memory touched
+  // page by page (... per resident GB of its own address space?); HH_MAPS=1: the largest resident mappings at the end of main
+  if (const char *e = getenv("HH_STREAMS")) {
+    std::vector<hipStream_t> st(atoi(e));
+    for (auto &x : st) { (void)hipStreamCreate(&x); hipLaunchKernelGGL(k, dim3(1), dim3(1), 0, x, d); }
+    (void)hipDeviceSynchronize();
+  }
+  if (const char *e = getenv("HH_ANON_GB")) {
+    const size_t n = (size_t)(atof(e) * 1073741824.0);
+    char *m = (char *)malloc(n);
+    for (size_t i = 0; m && i < n; i += 4096) m[i] = 1;
+  }
+  if (getenv("HH_MAPS")) {
+    FILE *fp = fopen("/proc/self/smaps", "r");
+    char line[512], head[512] = "";
+    while (fp && fgets(line, sizeof line, fp)) {
+      unsigned long a, b;
+      if (sscanf(line, "%lx-%lx ", &a, &b) == 2) strcpy(head, line);
+      else if (!strncmp(line, "Rss:", 4) && strtoul(line + 4, nullptr, 10) >= 32768) fprintf(stderr, "  rss %s kB  %s", strtok(line + 4, " k\n"), head);
+    }
+    if (fp) fclose(fp);
+  }
   auto t3 = std::chrono::steady_clock::now();
   if (argc > 2 && !strcmp(argv[2], "free")) for (void *p : blocks) (void)hipFree(p);
   auto t4 = std::chrono::steady_clock::now();
