@@ -365,7 +365,6 @@ static bool loadAbundance(t1k_job *job) {
 // that holds 82 % of a 10 M-pair job paired only after its last assignment range, the loop ended in 0.4 s of pairing alone).  A pipeline that finds no item left in the oldest window starts on the next one (its lists go
 // to the other slot of the pipeline's overlap store), so the GPU does not drain at window boundaries.
 // ------------------------------------------------------------------------------------------------------------------
-extern "C" uint64_t t1k_pool_release_mt(int threads);  // t1k_capi.hip (experiment)
 namespace {
 struct Window {
   uint32_t f0 = 0, f1 = 0;          // fragments [f0, f1)
@@ -388,6 +387,7 @@ struct Window {
   bool linking = false, linked = false;  // their list-table entries are being / have been copied from those windows (before the first pairing range)
 };
 }  // namespace
+
 
 int t1k_job_run_local(t1k_job *job) {
   if (!job || !job->ctx) return jobFail(job, T1K_ERR_STATE, "this job has no GPU context (device = -1): it cannot run");
@@ -1730,13 +1730,6 @@ int t1k_genotyper_main(int argc, char **argv) {
         if (!strncmp(line, "Threads:", 8) || !strncmp(line, "VmPeak:", 7) || !strncmp(line, "VmHWM:", 6) || !strncmp(line, "VmPTE:", 6)) fprintf(stderr, "[t1k job]   %s", line);
       fclose(fp);
     }
-  }
-  if (const char *e = getenv("T1K_EXIT_FREE")) {  // experiment: the job's device memory handed back by several threads, then out without the exit handlers
-    const double t0 = nowMs();
-    const uint64_t b = t1k_pool_release_mt(atoi(e));
-    if (getenv("T1K_DEBUG_PHASES")) fprintf(stderr, "[t1k job] exit: %.1f GB of device memory freed by %d threads in %.1f ms\n", b / 1e9, atoi(e), nowMs() - t0);
-    fflush(nullptr);
-    _exit(0);
   }
   return 0;
 }

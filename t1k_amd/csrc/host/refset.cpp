@@ -395,3 +395,16 @@ bool RefSet::load(const std::string &fasta, int digitUnitsArg, char delimiterArg
 }
 
 }  // namespace t1k
+
+// ------------------------------------------------------------------------------------------------------------------
+// large host blocks (t1k_host.h)
+// ------------------------------------------------------------------------------------------------------------------
+namespace t1k {
+void bigBlockAdvise(void *p, size_t bytes) {
+  static const bool thp = getenv("T1K_NO_THP") == nullptr;
+  if (!thp) return;
+  const uintptr_t two = (uintptr_t)2 << 20;
+  const uintptr_t lo = ((uintptr_t)p + two - 1) & ~(two - 1), hi = ((uintptr_t)p + bytes) & ~(two - 1);
+  if (hi > lo) (void)madvise((void *)lo, hi - lo, MADV_HUGEPAGE);  // (refused on hosts without the feature: nothing is lost)
+}
+}  // namespace t1k

@@ -25,10 +25,22 @@ struct SeqRec {
 // FASTA / FASTQ, plain or gz; id = header up to the first blank with a trailing /1 or /2 removed (ReadFiles.hpp:185-189)
 bool readSeqFile(const std::string &path, std::vector<SeqRec> &out, std::string &err);
 
+// Large host blocks of a job ask for transparent huge pages (host/refset.cpp).  Measured with tools/hip_hello on the MI355X hosts (round 5): a
+// first touch costs ~150 ms per GB in 4 KB pages, and the kernel takes a process's resident pages apart at ~75 ms per GB, single-threaded,
+// before the parent sees the exit; the hosts run huge pages in `madvise` mode.  With the advice the 10 M-pair step is 2.5 % shorter (group
+// tables, record index, EM arrays: 0.9 GB) -- profiles/r05_ab_thp.log.  T1K_NO_THP=1: no advice (A/B).
+void bigBlockAdvise(void *p, size_t bytes);
+constexpr size_t kBigBlock = (size_t)4 << 20;
+
 // vectors that do not zero what they are about to receive (record index of the read files, group tables: hundreds of MB each)
 template <class T>
 struct NoInitAlloc : std::allocator<T> {
   template <class U> struct rebind { using other = NoInitAlloc<U>; };
+  T *allocate(size_t n) {
+    T *p = std::allocator<T>::allocate(n);
+    if (n * sizeof(T) >= kBigBlock) bigBlockAdvise(p, n * sizeof(T));
+    return p;
+  }
   template <class U> void construct(U *p) noexcept { ::new ((void *)p) U; }
   template <class U, class A0, class... A> void construct(U *p, A0 &&a0, A &&...a) { ::new ((void *)p) U(std::forward<A0>(a0), std::forward<A>(a)...); }
 };
@@ -88,6 +100,13 @@ struct ReadInput {
   bool addGeneral(const std::string &path, Side &dst, std::string &err);
   void finish();
 };
+
+// host/inflate.cpp: the gzip decoder that publishes how far it has got (bytes of text that are final), for readers that follow it
+struct GzProgress {
+  std::atomic<uint64_t> produced{0};
+  std::atomic<int> state{0};  // 0 running, 1 finished, -1 failed
+};
+int gzInflateAll(const uint8_t *src, size_t srcLen, uint8_t *dst, size_t cap, GzProgress *pg, size_t *outLen, uint32_t *lastCrc, size_t *members, std::string &err);
 
 struct AlleleMeta {
   std::string name;

@@ -106,30 +106,6 @@ extern "C" uint64_t t1k_pool_release(void) {
   return bytes;
 }
 
-// the same with several threads (experiment of round 5, T1K_EXIT_FREE=<threads> in the genotyper executable: does unmapping the job's device
-// memory from several threads beat leaving it to the process's exit?)
-extern "C" uint64_t t1k_pool_release_mt(int threads) {
-  DevPool &P = devPool();
-  std::vector<std::pair<int, void *>> drop;
-  uint64_t bytes = 0;
-  {
-    std::lock_guard<std::mutex> g(P.m);
-    for (auto &dev : P.freeBlocks) {
-      for (auto &kv : dev.second) { drop.push_back({dev.first, kv.second}); bytes += kv.first; }
-      dev.second.clear();
-    }
-    P.pooled = 0;
-  }
-  threads = std::max(1, std::min(threads, 64));
-  std::vector<std::thread> th;
-  for (int t = 0; t < threads; ++t)
-    th.emplace_back([&, t] {
-      for (size_t i = (size_t)t; i < drop.size(); i += (size_t)threads) { (void)hipSetDevice(drop[i].first); (void)hipFree(drop[i].second); }
-    });
-  for (auto &x : th) x.join();
-  return bytes;
-}
-
 // ------------------------------------------------------------------------------------------------------------------
 // Page-locked host buffers, cached per process like the device blocks.  A window's read text (2.5 GB at 10 M pairs) handed to
 // hipMemcpyAsync from pageable memory is staged by the runtime on the calling thread -- 0.29 s, during which the pipelines' counter

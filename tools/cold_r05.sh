@@ -7,7 +7,7 @@ python -c "import bench; bench.ensure_inputs('$W', $P, 24, 1.0, seed=2)" || exit
 LOG=gpurun_out/r05_cold.log; : > $LOG
 ms() { echo $(( ($(date +%s%N) - $1) / 1000000 )); }
 t0=$(date +%s%N); /bin/true; echo "/bin/true: $(ms $t0) ms" >> $LOG
-for a in "" "128"; do sleep 3; t0=$(date +%s%N); tools/hip_hello $a 2>> $LOG; echo "  hip_hello $a wall: $(ms $t0) ms" >> $LOG; done
+for a in ""; do sleep 3; t0=$(date +%s%N); tools/hip_hello $a 2>> $LOG; echo "  hip_hello $a wall: $(ms $t0) ms" >> $LOG; done
 t0=$(date +%s%N); t1k_amd/bin/genotyper > /dev/null 2>&1; echo "genotyper without arguments (usage), wall: $(ms $t0) ms" >> $LOG
 IFS='|' read -ra VARS <<< "${1:-|}"
 for v in "${VARS[@]}"; do

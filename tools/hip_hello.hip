@@ -7,6 +7,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+#include <thread>
+#include <sys/mman.h>
 __global__ void k(int *p) { *p = 1; }
 int main(int argc, char **argv) {
   auto t0 = std::chrono::steady_clock::now();
@@ -35,8 +37,17 @@ int main(int argc, char **argv) {
   }
   if (const char *e = getenv("HH_ANON_GB")) {
     const size_t n = (size_t)(atof(e) * 1073741824.0);
-    char *m = (char *)malloc(n);
+    volatile char *m = (volatile char *)malloc(n);
     for (size_t i = 0; m && i < n; i += 4096) m[i] = 1;
+    auto ta = std::chrono::steady_clock::now();
+    if (const char *z = getenv("HH_ZAP")) {  // hand the pages back before leaving, from several threads (MADV_DONTNEED takes the memory-map lock for reading only)
+      const int T = atoi(z) > 0 ? atoi(z) : 1;
+      std::vector<std::thread> th;
+      const size_t lo = ((size_t)m + 4095) & ~(size_t)4095, hi = ((size_t)m + n) & ~(size_t)4095, piece = ((hi - lo) / T) & ~(size_t)4095;
+      for (int t = 0; t < T; ++t) th.emplace_back([=] { (void)madvise((void *)(lo + t * piece), t == T - 1 ? hi - (lo + t * piece) : piece, MADV_DONTNEED); });
+      for (auto &x : th) x.join();
+      fprintf(stderr, "  %.1f GB handed back by %d threads in %.1f ms\n", n / 1073741824.0, T, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ta).count());
+    }
   }
   if (getenv("HH_MAPS")) {
     FILE *fp = fopen("/proc/self/smaps", "r");
