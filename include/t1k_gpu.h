@@ -145,6 +145,9 @@ typedef struct {
   float weight, adjust_weight;
 } t1k_group_entry;
 int t1k_rowset_create(t1k_ctx *owner, uint64_t nFragments, const uint8_t *whitelist /* [nAlleles] or NULL */, t1k_rowset **out);
+/* A rowset made for an upper bound of the fragment count (an input that is still being inflated when the job starts, t1k_reads_open_stream):
+ * the fragments that turned out to exist.  No counterpart in the reference, whose vectors grow (Genotyper.cpp:365-440). */
+int t1k_rowset_trim(t1k_rowset *rs, uint64_t n_fragments);
 void t1k_rowset_destroy(t1k_rowset *rs);
 /* raw != 0: t1k_pair_into stores the fragment assignment list itself (SeqSet::ReadAssignmentToFragmentAssignment's result) without the
  * -n / separator / whitelist drops of SetReadAssignments -- what the analyzer's BarcodeSummary::AddFragment reads (BarcodeSummary.hpp:24-57) */
@@ -358,6 +361,12 @@ int t1k_job_load_reads_multi(t1k_job *job, const char *const *files1, uint32_t n
  * call ends up indexing the whole input on every rank (a barcode file, gz, non-strict layouts). */
 typedef struct t1k_reads t1k_reads;
 int t1k_reads_open(const char *const *files1, uint32_t n1, const char *const *files2, uint32_t n2, const char *barcodeFile, int threads, t1k_reads **out);
+/* The same for a job of ONE rank without a barcode file, with ordinary .gz inputs not waited for: one .gz file per mate (four-line FASTQ, not
+ * bgzip-framed) is inflated by a decoder that publishes its progress while a second thread indexes the records behind it, and t1k_job_run
+ * takes the fragments as they arrive -- as the reference's record-at-a-time reader does (ReadFiles.hpp:13, 95, 155-204; kseq.h:94-150).
+ * t1k_reads_fragments / t1k_job_fragments wait for the end of the stream.  Inputs that are not eligible (plain files, several files per
+ * mate, small files, T1K_STREAM_GZ=0) are opened exactly as by t1k_reads_open. */
+int t1k_reads_open_stream(const char *const *files1, uint32_t n1, const char *const *files2, uint32_t n2, int threads, t1k_reads **out);
 const char *t1k_reads_last_error(const t1k_reads *reads);
 int t1k_reads_fragments(const t1k_reads *reads, uint64_t *nFragments);
 void t1k_reads_close(t1k_reads *reads);

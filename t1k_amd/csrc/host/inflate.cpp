@@ -354,6 +354,7 @@ int gzInflateAll(const uint8_t *src, size_t srcLen, uint8_t *dst, size_t cap, Gz
     p += 8;
     out = o;
     ++nMembers;
+    if (pg) { std::lock_guard<std::mutex> g(pg->m); pg->members.push_back({(uint64_t)(out - dst), crc}); }
   }
   if (!nMembers) return fail("empty file");
   if (outLen) *outLen = (size_t)(out - dst);

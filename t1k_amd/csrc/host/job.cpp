@@ -276,9 +276,28 @@ int t1k_reads_open(const char *const *files1, uint32_t n1, const char *const *fi
   r->ms = nowMs() - t0;
   return T1K_OK;
 }
+int t1k_reads_open_stream(const char *const *files1, uint32_t n1, const char *const *files2, uint32_t n2, int threads, t1k_reads **out) {
+  if (!out) return T1K_ERR_ARG;
+  *out = nullptr;
+  if (!files1 || n1 == 0) return T1K_ERR_ARG;
+  const char *e = getenv("T1K_STREAM_GZ");
+  if (!(e && atoi(e) == 0) && !getenv("T1K_LONG_READS")) {  // (setting reads aside needs the longest kept read before the loop)
+    t1k_reads *r = new t1k_reads();
+    const double t0 = nowMs();
+    r->in.reset(new ReadInput());
+    std::vector<std::string> f1(files1, files1 + n1), f2;
+    if (files2) f2.assign(files2, files2 + n2);
+    if (r->in->openStreaming(f1, f2, r->err)) { r->ms = nowMs() - t0; *out = r; return T1K_OK; }
+    const bool failed = !r->err.empty();
+    if (failed) { r->in.reset(); *out = r; return T1K_ERR_IO; }
+    delete r;  // not eligible: opened whole
+  }
+  return t1k_reads_open(files1, n1, files2, n2, nullptr, threads, out);
+}
 const char *t1k_reads_last_error(const t1k_reads *r) { return r ? r->err.c_str() : "no read input"; }
 int t1k_reads_fragments(const t1k_reads *r, uint64_t *nFragments) {
   if (!r || !r->in || !nFragments) return T1K_ERR_ARG;
+  if (r->in->streaming) { r->in->streamWait(~(size_t)0); *nFragments = r->in->streamAvail(); return T1K_OK; }  // (the stream's end: every record is counted)
   *nFragments = r->in->nAll();
   return T1K_OK;
 }
@@ -399,13 +418,19 @@ int t1k_job_run_local(t1k_job *job) {
   job->bgStarted = false;
   // fresh state (a job may be run repeatedly, e.g. by the benchmark)
   Genotyper &gt = job->gt;
+  // A streamed input (t1k_reads_open_stream) hands its fragments over while the loop runs: one rank, the genotyper's own loop.  Anything
+  // else waits for the end of the stream here and goes on as with a file opened whole.
+  if (job->in->streaming && (job->nRanks > 1 || job->analyzer || getenv("T1K_LONG_READS"))) {
+    if (!job->in->streamFinish(job->err)) return jobFail(job, T1K_ERR_IO, job->err);
+  }
+  const bool gzStream = job->in->streaming;
   const ReadInput &in = *job->in;
   gt.groupPtr.assign(1, 0); gt.groupEnt.clear(); gt.groupFirst.clear(); gt.groupOfHash.clear(); gt.assignedFragments = 0; gt.emIterations = 0;
   gt.readLength = in.maxLen;  // Genotyper.cpp:443
   for (auto &a : job->ref.al) { a.rank = -1; a.quality = -1; a.abundance = a.ecAbundance = 0; a.ec = -1; a.missingCov = 0; }
   const uint32_t Fall = (uint32_t)in.nAll();
   const uint32_t fBeg = (uint32_t)((uint64_t)Fall * job->rank / job->nRanks), fEnd = (uint32_t)((uint64_t)Fall * (job->rank + 1) / job->nRanks);
-  const uint32_t F = fEnd - fBeg;  // this rank's fragments; local index f <-> fragment fBeg + f of the input
+  uint32_t F = fEnd - fBeg;  // this rank's fragments; local index f <-> fragment fBeg + f of the input (a streamed input: their upper bound until the loop has ended)
   if (in.sharded && (in.shardRank != job->rank || in.shardRanks != job->nRanks || in.base != fBeg || in.nFrag() != F))
     return jobFail(job, T1K_ERR_STATE, "the reads were loaded for another shard than the one this job runs as");
   const uint32_t inBase = in.base;  // fragment f of the input = record in.frag[f - inBase] held here
@@ -550,30 +575,61 @@ int t1k_job_run_local(t1k_job *job) {
         return p;
       }
     } offs[2], stage;
+    // size of window w (sh.m held): what can be prepared while the GPU works off the windows that are ready but not done
+    auto windowSize = [&](uint32_t w) -> uint64_t {
+      uint64_t size = firstWindow;
+      if (w > 0) {
+        const Window &prev = win[w - 1];
+        const double tp = prev.msPrep / std::max<double>(1, prev.f1 - prev.f0);  // ms per fragment, preparation
+        double tg = 0;                                                            // ms per fragment, GPU (the last finished window)
+        for (uint32_t v = w; v-- > 0;)
+          if (win[v].done && win[v].tDone > win[v].tReady) { tg = (win[v].tDone - win[v].tReady) / std::max<double>(1, win[v].f1 - win[v].f0); break; }
+        uint64_t waiting = 0;  // fragments ready for the GPU and not done yet
+        for (uint32_t v = sh.oldest; v < w; ++v) waiting += win[v].f1 - win[v].f0;
+        double factor = fixedGrowth > 0 ? fixedGrowth : (tg > 0 && tp > 0 ? 0.85 * tg / tp : 6.0);
+        factor = std::min(16.0, std::max(1.0, factor));
+        size = (uint64_t)(factor * (double)std::max<uint64_t>(waiting, firstWindow / 2));
+        size = std::min<uint64_t>(windowFrags, std::max<uint64_t>(size, firstWindow));
+      }
+      return size;
+    };
     uint64_t fNext = 0;
-    for (uint32_t w = 0; fNext < F; ++w) {
+    uint64_t have = F;      // fragments that can be cut into windows (a streamed input: the records indexed so far)
+    bool ended = !gzStream; // ... and whether that is all there will be
+    for (uint32_t w = 0; gzStream ? true : fNext < F; ++w) {
+      if (gzStream) {
+        // the window the loop's own rule asks for, if the stream has got that far; what is there (a quarter of a first window at least) when
+        // the GPU has nothing left to work on; all that is left at the stream's end (and when the window table is nearly full)
+        const uint64_t least = fNext + std::max<uint32_t>(16384u, firstWindow / 4);
+        for (;;) {
+          const int st = in.streamState();
+          have = in.streamAvail();
+          if (st < 0) { std::string e; (void)job->in->streamFinish(e); fail(T1K_ERR_IO, e.empty() ? "cannot read the .gz input" : e); return; }
+          if (st == 1) { have = in.streamAvail(); ended = true; break; }
+          bool idle;
+          uint64_t want;
+          { std::lock_guard<std::mutex> g(sh.m); if (sh.err != T1K_OK) return; idle = sh.oldest >= sh.created; want = fNext + windowSize(w); }
+          if (w + 8 >= maxWindows) { std::this_thread::sleep_for(std::chrono::milliseconds(1)); continue; }  // (the rest as one window)
+          if (have >= want || (have >= least && idle)) break;
+          std::this_thread::sleep_for(std::chrono::microseconds(300));
+        }
+        if (ended && fNext >= have) {
+          std::lock_guard<std::mutex> g(sh.m);
+          sh.allCreated = true;
+          sh.cv.notify_all();
+          break;
+        }
+      }
       {
         std::unique_lock<std::mutex> lk(sh.m);
         sh.cv.wait(lk, [&] { return sh.err != T1K_OK || w < 2 || win[w - 2].done; });  // the read-set context of window w - 2 is free again
         if (sh.err != T1K_OK) return;
+        if (gzStream && !ended) { const int st = in.streamState(); have = in.streamAvail(); if (st == 1) { have = in.streamAvail(); ended = true; } }  // (what arrived while this thread waited for the slot)
         // size of this window: what can be prepared while the GPU works off the windows that are ready but not done
-        uint64_t size = firstWindow;
-        if (w > 0) {
-          const Window &prev = win[w - 1];
-          const double tp = prev.msPrep / std::max<double>(1, prev.f1 - prev.f0);  // ms per fragment, preparation
-          double tg = 0;                                                            // ms per fragment, GPU (the last finished window)
-          for (uint32_t v = w; v-- > 0;)
-            if (win[v].done && win[v].tDone > win[v].tReady) { tg = (win[v].tDone - win[v].tReady) / std::max<double>(1, win[v].f1 - win[v].f0); break; }
-          uint64_t waiting = 0;  // fragments ready for the GPU and not done yet
-          for (uint32_t v = sh.oldest; v < w; ++v) waiting += win[v].f1 - win[v].f0;
-          double factor = fixedGrowth > 0 ? fixedGrowth : (tg > 0 && tp > 0 ? 0.85 * tg / tp : 6.0);
-          factor = std::min(16.0, std::max(1.0, factor));
-          size = (uint64_t)(factor * (double)std::max<uint64_t>(waiting, firstWindow / 2));
-          size = std::min<uint64_t>(windowFrags, std::max<uint64_t>(size, firstWindow));
-        }
+        const uint64_t size = windowSize(w);
         Window N;
-        N.f0 = (uint32_t)fNext; N.f1 = (uint32_t)std::min<uint64_t>(F, fNext + size);
-        if (F - N.f1 < size / 4 || w + 1 >= maxWindows) N.f1 = F;  // no small tail window
+        N.f0 = (uint32_t)fNext; N.f1 = (uint32_t)std::min<uint64_t>(have, fNext + size);
+        if (ended && (have - N.f1 < size / 4 || w + 1 >= maxWindows)) N.f1 = (uint32_t)have;  // no small tail window
         N.slot = (int)(w & 1);
         N.touched.assign(P, 0);
         if (!eagerFromNowOn) {
@@ -621,7 +677,7 @@ int t1k_job_run_local(t1k_job *job) {
         fNext = N.f1;
         win.push_back(std::move(N));
         sh.created = w + 1;
-        if (fNext >= F) sh.allCreated = true;
+        if (ended && fNext >= have) sh.allCreated = true;
       }
       Window &W = win[w];
       const double t0 = nowMs();
@@ -657,6 +713,11 @@ int t1k_job_run_local(t1k_job *job) {
       const uint64_t total = pieceBytes[T];
       uint32_t maxLen = 0;
       for (int t = 0; t < T; ++t) maxLen = std::max(maxLen, pieceMax[t]);
+      if (gzStream && maxLen > lenLimit) {  // (a file opened whole is checked before any work; a stream meets the read when it gets there)
+        fail(T1K_ERR_ARG, "a read of " + std::to_string(maxLen) + " bases is longer than this build handles (" + std::to_string(job->prm.dev.max_read_len) +
+                              "); T1K_LONG_READS=drop sets the fragments of such reads aside instead of stopping");
+        return;
+      }
       parallelRanges(nf, T, [&](int t, size_t b, size_t e) {
         const uint64_t carry = pieceBytes[t];
         for (size_t i = b; i < e; ++i)
@@ -917,6 +978,15 @@ int t1k_job_run_local(t1k_job *job) {
     if (writer.joinable()) writer.join();
   }
   if (sh.err != T1K_OK) { streamClose(job, true); return jobFail(job, sh.err, sh.errMsg); }
+  if (gzStream) {
+    // the stream has ended and every fragment went through the loop: the tables shrink to the fragments that exist
+    if (!job->in->streamFinish(job->err)) { streamClose(job, true); return jobFail(job, T1K_ERR_IO, job->err); }
+    F = (uint32_t)in.nFrag();
+    job->readEnds = (uint64_t)F * per;
+    gt.readLength = in.maxLen;  // Genotyper.cpp:443
+    if ((rc = t1k_rowset_trim(job->rows, F)) != T1K_OK) return jobFail(job, rc, "the streamed input holds more fragments than the job's tables were sized for");
+    job->fragAssigned.resize(F);
+  }
   if (dropLong)
     fprintf(stderr, "genotyper: WARNING: %llu fragment(s)%s hold a read longer than %u bases and were set aside (T1K_LONG_READS=drop): the reference would have genotyped them\n",
             (unsigned long long)droppedFragments.load(), job->nRanks > 1 ? " of this rank" : "", lenLimit);
@@ -1439,7 +1509,10 @@ int t1k_job_genotype_text(t1k_job *job, char *buf, uint64_t cap, uint64_t *neede
 
 int t1k_job_counts(t1k_job *job, uint64_t *fragments, uint64_t *assignedFragments, uint64_t *groups, uint64_t *ecs, int32_t *emIterations) {
   if (!job) return T1K_ERR_ARG;
-  if (fragments) *fragments = job->in ? job->in->nAll() : 0;
+  if (fragments) {
+    if (job->in && job->in->streaming) { job->in->streamWait(~(size_t)0); *fragments = job->in->streamAvail(); }
+    else *fragments = job->in ? job->in->nAll() : 0;
+  }
   if (assignedFragments) *assignedFragments = job->gt.assignedFragments;
   if (groups) *groups = job->gt.nGroups();
   if (ecs) *ecs = job->gt.ecAlleles.size();
@@ -1598,7 +1671,9 @@ int t1k_genotyper_main(int argc, char **argv) {
   std::thread opener;
   if (!shardInput && !first.empty() && !getenv("T1K_SERIAL_OPEN"))
     opener = std::thread([&] {
-      rcOpen = t1k_reads_open(first.data(), (uint32_t)first.size(), paired ? f2.data() : nullptr, (uint32_t)f2.size(), barcode.empty() ? nullptr : barcode.c_str(), p.threads, &opened);
+      // (one rank, no barcode file: an ordinary .gz input is handed to the loop while it is still being inflated)
+      if (R == 1 && barcode.empty()) rcOpen = t1k_reads_open_stream(first.data(), (uint32_t)first.size(), paired ? f2.data() : nullptr, (uint32_t)f2.size(), p.threads, &opened);
+      else rcOpen = t1k_reads_open(first.data(), (uint32_t)first.size(), paired ? f2.data() : nullptr, (uint32_t)f2.size(), barcode.empty() ? nullptr : barcode.c_str(), p.threads, &opened);
     });
   {
     std::vector<std::thread> th;
@@ -1642,11 +1717,13 @@ int t1k_genotyper_main(int argc, char **argv) {
     return t1k_job_load_reads_multi(j, first.data(), (uint32_t)first.size(), paired ? f2.data() : nullptr, (uint32_t)f2.size(), barcode.empty() ? nullptr : barcode.c_str());
   };
   int rc = T1K_OK;
+  bool foundLater = false;
   if (!shardInput) {
     if (openedBeside) { rc = t1k_job_attach_reads(job, opened); opened = nullptr; if (rc == T1K_OK) rc = rcOpen; }  // (a failed open: the handle carries the message into the job)
     else rc = loadInto(job);
     if (rc != T1K_OK) { fprintf(stderr, "genotyper: %s\n", t1k_job_last_error(job)); destroyAll(); return EXIT_FAILURE; }
-    logLine("Found %d read fragments. Start read assignment.", (int)job->in->nAll());
+    foundLater = job->in->streaming;  // (a streamed input: counted when the stream has ended, i.e. behind the loop)
+    if (!foundLater) logLine("Found %d read fragments. Start read assignment.", (int)job->in->nAll());
     t1k_job_set_output_prefix(job, prefix.c_str());  // the aligned-read files are written while the EM runs
   }
   if (R == 1) rc = t1k_job_run(job);
@@ -1681,6 +1758,7 @@ int t1k_genotyper_main(int argc, char **argv) {
     t1k_comm_group_destroy(group);
   }
   if (rc != T1K_OK) { fprintf(stderr, "genotyper: %s\n", t1k_job_last_error(job)); destroyAll(); return EXIT_FAILURE; }
+  if (foundLater) logLine("Found %d read fragments. Start read assignment.", (int)job->in->nAll());
   logLine("Finish read end assignments.");
   const double groups = (double)job->gt.nGroups();
   logLine("Finish read fragment assignments. %d read fragments can be assigned (average %.2lf alleles/read).", (int)job->gt.assignedFragments,

@@ -15,6 +15,7 @@
 #include <zlib.h>
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -39,7 +40,15 @@ struct Piece {
 };
 
 // one record starting at p (a line start); returns the start of the next record, or nullptr if the layout is not the strict one
+struct RecFields { const char *id, *seq; size_t idLen, seqLen; };
+inline const char *strictRecordFields(const char *p, const char *end, bool fastq, RecFields &f);
 inline const char *strictRecord(const char *p, const char *end, bool fastq, Piece &out) {
+  RecFields f;
+  const char *next = strictRecordFields(p, end, fastq, f);
+  if (next) { out.seqP.push_back(f.seq); out.seqL.push_back((uint32_t)f.seqLen); out.idP.push_back(f.id); out.idL.push_back((uint16_t)f.idLen); }
+  return next;
+}
+inline const char *strictRecordFields(const char *p, const char *end, bool fastq, RecFields &f) {
   if (p >= end || *p != (fastq ? '@' : '>')) return nullptr;
   const char *e1 = lineEnd(p, end);
   const char *id = p + 1, *ie = id;
@@ -67,7 +76,7 @@ inline const char *strictRecord(const char *p, const char *end, bool fastq, Piec
   } else {
     if (next < end && *next != '>') return nullptr;  // wrapped sequence or a blank line: not the strict layout
   }
-  out.seqP.push_back(s); out.seqL.push_back((uint32_t)sl); out.idP.push_back(id); out.idL.push_back((uint16_t)il);
+  f.id = id; f.idLen = il; f.seq = s; f.seqLen = sl;
   return next;
 }
 
@@ -94,7 +103,41 @@ inline const char *findRecord(const char *base, const char *from, const char *en
 
 }  // namespace
 
+// ------------------------------------------------------------------------------------------------------------------
+// Streaming .gz input (ReadFiles.hpp:13, 95 and kseq.h:94-150 hand the reference its first read as soon as the file is open).
+// Per mate: the compressed file mapped, the text inflated into one reserved range of anonymous memory by host/inflate.cpp (thread 1), the
+// four-line FASTQ records indexed in place behind the decoder's published progress (thread 2), the CRC-32 of every member checked behind it
+// (thread 3; libdeflate's routine when the image has it -- 10 GB/s -- zlib's otherwise).  Tables sized to an upper bound of the record count.
+// ------------------------------------------------------------------------------------------------------------------
+struct ReadInput::Stream {
+  struct Mate {
+    void *src = nullptr; size_t srcLen = 0;
+    char *text = nullptr; size_t cap = 0;
+    GzProgress pg;
+    std::thread inflater, indexer, checker;
+    std::atomic<uint64_t> records{0};
+    std::atomic<int> state{0};  // indexer: 0 running, 1 done, -1 failed
+    std::atomic<int> crcState{0};
+    std::string err, path;
+    size_t textLen = 0;
+  } mate[2];
+  int nMates = 1;
+  size_t capRecords = 0;
+  bool joined = false;
+  ~Stream() {
+    for (int m = 0; m < nMates; ++m) {
+      Mate &M = mate[m];
+      if (M.inflater.joinable()) M.inflater.join();
+      if (M.indexer.joinable()) M.indexer.join();
+      if (M.checker.joinable()) M.checker.join();
+      if (M.src) munmap(M.src, M.srcLen);
+    }
+  }
+};
+
+ReadInput::ReadInput() {}
 ReadInput::~ReadInput() {
+  stream_.reset();  // its threads write into the blobs
   for (auto &b : blobs_)
     if (b.map) munmap(b.map, b.len);
 }
@@ -285,6 +328,7 @@ bool ReadInput::gzipInflate(int fd, size_t fileSize, Blob &blob, const char *&da
   const size_t cap = ((fileSize * 48 + (64u << 20)) + 4095) & ~(size_t)4095;
   void *out = mmap(nullptr, cap, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
   if (out == MAP_FAILED) { munmap(m, fileSize); return false; }
+  bigBlockAdvise(out, cap);
   void *d = z->alloc();
   bool ok = d != nullptr;
   size_t in = 0, used = 0;
@@ -364,6 +408,249 @@ bool ReadInput::addFile(const std::string &path, int threads, Side &dst, std::st
   if (!e2.empty()) { err = e2; return false; }
   dst.seqP.resize(before); dst.seqL.resize(before); dst.idP.resize(before); dst.idL.resize(before);
   return addGeneral(path, dst, err);
+}
+
+namespace {
+// CRC-32 of a piece of text: libdeflate's (carry-less multiplication, ~10 GB/s) when the image has the library, zlib's otherwise
+uint32_t crcStep(uint32_t crc, const void *p, size_t n) {
+  static uint32_t (*fast)(uint32_t, const void *, size_t) = [] {
+    void *h = getenv("T1K_NO_LIBDEFLATE") ? nullptr : dlopen("libdeflate.so.0", RTLD_NOW | RTLD_LOCAL);
+    return h ? (uint32_t (*)(uint32_t, const void *, size_t))dlsym(h, "libdeflate_crc32") : nullptr;
+  }();
+  if (fast) return fast(crc, p, n);
+  const unsigned char *q = (const unsigned char *)p;
+  while (n) { const size_t k = std::min<size_t>(n, 1u << 30); crc = (uint32_t)crc32(crc, q, (uInt)k); q += k; n -= k; }
+  return crc;
+}
+}  // namespace
+
+size_t ReadInput::streamAvail() const {
+  if (!stream_) return frag.size();
+  uint64_t n = stream_->mate[0].records.load(std::memory_order_acquire);
+  if (stream_->nMates > 1) n = std::min<uint64_t>(n, stream_->mate[1].records.load(std::memory_order_acquire));
+  return (size_t)n;
+}
+int ReadInput::streamState() const {
+  if (!stream_) return 1;
+  int all = 1;
+  for (int m = 0; m < stream_->nMates; ++m) {
+    const int a = stream_->mate[m].state.load(std::memory_order_acquire), c = stream_->mate[m].crcState.load(std::memory_order_acquire);
+    if (a < 0 || c < 0) return -1;
+    if (a == 0 || c == 0) all = 0;
+  }
+  return all;
+}
+void ReadInput::streamWait(size_t records) const {
+  while (streamAvail() < records && streamState() == 0) std::this_thread::sleep_for(std::chrono::microseconds(300));
+}
+
+bool ReadInput::openStreaming(const std::vector<std::string> &files1, const std::vector<std::string> &files2, std::string &err) {
+  err.clear();
+  if (files1.size() != 1 || files2.size() > 1) return false;
+  static const size_t minBytes = [] { const char *e = getenv("T1K_STREAM_GZ_MIN_MB"); return (size_t)((e ? atof(e) : 32.0) * 1048576.0); }();
+  std::unique_ptr<Stream> S(new Stream());
+  S->nMates = files2.empty() ? 1 : 2;
+  size_t minRec = ~(size_t)0, estText[2] = {0, 0};
+  for (int m = 0; m < S->nMates; ++m) {
+    Stream::Mate &M = S->mate[m];
+    M.path = m ? files2[0] : files1[0];
+    int fd = ::open(M.path.c_str(), O_RDONLY);
+    if (fd < 0) return false;  // (the whole-file path reports it)
+    struct stat st;
+    if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || (size_t)st.st_size < std::max<size_t>(minBytes, 64)) { ::close(fd); return false; }
+    M.srcLen = (size_t)st.st_size;
+    M.src = mmap(nullptr, M.srcLen, PROT_READ, MAP_PRIVATE, fd, 0);
+    ::close(fd);
+    if (M.src == MAP_FAILED) { M.src = nullptr; return false; }
+    const uint8_t *z = (const uint8_t *)M.src;
+    if (z[0] != 0x1f || z[1] != 0x8b || z[2] != 8) return false;
+    if ((z[3] & 4) && M.srcLen > 16 && z[12] == 'B' && z[13] == 'C') return false;  // bgzip: its blocks are inflated side by side (bgzfInflate)
+    (void)madvise(M.src, M.srcLen, MADV_SEQUENTIAL);
+    // a look at the head of the text: four-line FASTQ?  how short can a record be?  (decoded again by the stream: 4 MB are nothing)
+    {
+      std::vector<uint8_t> head((size_t)4 << 20);
+      GzProgress pg;
+      std::string e;
+      size_t n = 0;
+      (void)gzInflateAll(z, M.srcLen, head.data(), head.size(), &pg, &n, nullptr, nullptr, e);  // (ends with "more text than the range holds" for any real file)
+      n = (size_t)pg.produced.load();
+      const char *p = (const char *)head.data(), *end = p + n;
+      if (n < 16 || *p != '@') return false;
+      size_t recs = 0;
+      while (p < end) {
+        // a whole record has four line ends inside what was decoded
+        const char *q = p;
+        int lines = 0;
+        while (lines < 4 && q < end) { const char *nl = (const char *)memchr(q, '\n', (size_t)(end - q)); if (!nl) { q = end + 1; break; } q = nl + 1; ++lines; }
+        if (lines < 4 || q > end) break;
+        RecFields f;
+        if (strictRecordFields(p, q, true, f) != q) return false;
+        minRec = std::min(minRec, (size_t)(q - p));
+        ++recs;
+        p = q;
+      }
+      if (recs < 4) return false;
+    }
+    // the text's length: the trailer's length field when it can be the whole file's (one member below 4 GB: the usual case), else 48 x the
+    // compressed size as the whole-file path reserves
+    const uint32_t isize = (uint32_t)z[M.srcLen - 4] | ((uint32_t)z[M.srcLen - 3] << 8) | ((uint32_t)z[M.srcLen - 2] << 16) | ((uint32_t)z[M.srcLen - 1] << 24);
+    const bool plausible = (size_t)isize >= M.srcLen && (size_t)isize <= M.srcLen * 48;
+    estText[m] = plausible ? (size_t)isize : M.srcLen * 48;
+    M.cap = ((std::max<size_t>(estText[m], M.srcLen * 48) + ((size_t)64 << 20)) + 4095) & ~(size_t)4095;
+  }
+  // both files are eligible: room for the text (address space only; the pages that are written get backed)
+  for (int m = 0; m < S->nMates; ++m) {
+    Stream::Mate &M = S->mate[m];
+    void *out = mmap(nullptr, M.cap, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+    if (out == MAP_FAILED) {
+      if (m == 1) for (auto it = blobs_.begin(); it != blobs_.end(); ++it) if (it->map == (void *)S->mate[0].text) { munmap(it->map, it->len); blobs_.erase(it); break; }
+      return false;
+    }
+    bigBlockAdvise(out, M.cap);  // huge pages: 3 GB of text are 0.5 s of first touches and 0.25 s of exit in 4 KB pages (t1k_host.h)
+    M.text = (char *)out;
+    Blob &b = newBlob();
+    b.map = out; b.len = M.cap; b.anon = true;
+  }
+  // tables for twice as many records as the shortest record of the heads would make of the text
+  size_t capRecords = 0;
+  for (int m = 0; m < S->nMates; ++m) capRecords = std::max(capRecords, estText[m] / std::max<size_t>(8, minRec / 2) + 4096);
+  if (capRecords > 0xFFFFFF00ull) return false;  // (fragment numbers are 32 bits)
+  S->capRecords = capRecords;
+  paired = S->nMates == 2;
+  hasBarcode = false;
+  for (int m = 0; m < S->nMates; ++m) { side[m].seqP.resize(capRecords); side[m].idP.resize(capRecords); side[m].seqL.resize(capRecords); side[m].idL.resize(capRecords); }
+  frag.resize(capRecords);
+  maxLen = 0;
+  streaming = true;
+  Stream *sp = S.get();
+  for (int m = 0; m < S->nMates; ++m) {
+    Stream::Mate *M = &S->mate[m];
+    Side *sd = &side[m];
+    M->inflater = std::thread([M] {
+      size_t n = 0;
+      if (gzInflateAll((const uint8_t *)M->src, M->srcLen, (uint8_t *)M->text, M->cap, &M->pg, &n, nullptr, nullptr, M->err) == 0) M->textLen = n;
+      else M->err = M->path + ": " + M->err;
+    });
+    M->checker = std::thread([M] {
+      uint64_t done = 0;
+      uint32_t crc = 0;
+      size_t member = 0;
+      for (;;) {
+        const int st = M->pg.state.load(std::memory_order_acquire);
+        const uint64_t have = M->pg.produced.load(std::memory_order_acquire);
+        uint64_t end = 0;
+        uint32_t want = 0;
+        bool closes = false;
+        { std::lock_guard<std::mutex> g(M->pg.m); if (member < M->pg.members.size()) { end = M->pg.members[member].first; want = M->pg.members[member].second; closes = true; } }
+        const uint64_t upto = closes ? end : have;
+        if (upto > done) { crc = crcStep(crc, M->text + done, (size_t)(upto - done)); done = upto; }
+        if (closes) {
+          if (crc != want) { M->crcState.store(-1, std::memory_order_release); return; }
+          crc = 0; ++member;
+          continue;
+        }
+        if (st != 0 && done >= M->pg.produced.load(std::memory_order_acquire)) {
+          bool more;
+          { std::lock_guard<std::mutex> g(M->pg.m); more = member < M->pg.members.size(); }
+          if (more) continue;
+          M->crcState.store(1, std::memory_order_release);  // (a failed decoder is the indexer's to report)
+          return;
+        }
+        if (upto == done) std::this_thread::sleep_for(std::chrono::microseconds(500));
+      }
+    });
+    const bool first = m == 0;
+    M->indexer = std::thread([this, sp, M, sd, first] {
+      const size_t capR = sp->capRecords;
+      uint64_t n = 0;
+      size_t recStart = 0, scan = 0;
+      int lines = 0, mx = 0;
+      auto fail = [&](const std::string &why) { M->err = M->err.empty() ? M->path + ": " + why : M->err; M->state.store(-1, std::memory_order_release); };
+      auto emit = [&](const char *b, const char *e) -> bool {
+        RecFields f;
+        if (strictRecordFields(b, e, true, f) != e) { fail("a record is not in the four-line FASTQ layout the streaming reader follows (T1K_STREAM_GZ=0 reads the file whole)"); return false; }
+        if (n >= capR) { fail("more records than the streaming reader sized its tables for (T1K_STREAM_GZ=0 reads the file whole)"); return false; }
+        sd->seqP[n] = f.seq; sd->seqL[n] = (uint32_t)f.seqLen; sd->idP[n] = f.id; sd->idL[n] = (uint16_t)f.idLen;
+        if (first) frag[n] = (uint32_t)n;
+        mx = std::max(mx, (int)f.seqLen);
+        ++n;
+        return true;
+      };
+      for (;;) {
+        const int st = M->pg.state.load(std::memory_order_acquire);
+        const size_t have = (size_t)M->pg.produced.load(std::memory_order_acquire);
+        const uint64_t before = n;
+        while (scan < have) {
+          const char *nl = (const char *)memchr(M->text + scan, '\n', have - scan);
+          if (!nl) { scan = have; break; }
+          scan = (size_t)(nl - M->text) + 1;
+          if (++lines == 4) {
+            if (!emit(M->text + recStart, M->text + scan)) return;
+            recStart = scan; lines = 0;
+            if ((n & 4095) == 0) {
+              int old = streamMaxLen.load(std::memory_order_relaxed);
+              while (mx > old && !streamMaxLen.compare_exchange_weak(old, mx)) {}
+              M->records.store(n, std::memory_order_release);
+            }
+          }
+        }
+        if (n != before) {
+          int old = streamMaxLen.load(std::memory_order_relaxed);
+          while (mx > old && !streamMaxLen.compare_exchange_weak(old, mx)) {}
+          M->records.store(n, std::memory_order_release);
+        }
+        if (st != 0 && scan >= (size_t)M->pg.produced.load(std::memory_order_acquire)) {
+          if (st < 0) { fail("the file is damaged"); return; }
+          // what is left behind the last complete record: blank lines, or a last record whose last line has no line end
+          const char *b = M->text + recStart, *e = M->text + scan;
+          while (e > b && isBlank(e[-1])) --e;
+          if (e > b) {
+            if (!emit(b, e)) return;
+            int old = streamMaxLen.load(std::memory_order_relaxed);
+            while (mx > old && !streamMaxLen.compare_exchange_weak(old, mx)) {}
+            M->records.store(n, std::memory_order_release);
+          }
+          M->state.store(1, std::memory_order_release);
+          return;
+        }
+        if (n == before) std::this_thread::sleep_for(std::chrono::microseconds(200));
+      }
+    });
+  }
+  stream_ = std::move(S);
+  return true;
+}
+
+bool ReadInput::streamFinish(std::string &err) {
+  if (!stream_) return true;
+  Stream &S = *stream_;
+  for (int m = 0; m < S.nMates; ++m) {
+    Stream::Mate &M = S.mate[m];
+    if (M.inflater.joinable()) M.inflater.join();
+    if (M.indexer.joinable()) M.indexer.join();
+    if (M.checker.joinable()) M.checker.join();
+  }
+  streaming = false;
+  for (int m = 0; m < S.nMates; ++m) {
+    Stream::Mate &M = S.mate[m];
+    if (M.state.load() < 0 || M.pg.state.load() < 0) { err = M.err.empty() ? M.path + ": cannot read the file" : M.err; return false; }
+    if (M.crcState.load() < 0) { err = M.path + ": the file is damaged (CRC check of the inflated text failed)"; return false; }
+  }
+  const size_t n = (size_t)S.mate[0].records.load();
+  if (S.nMates == 2 && (size_t)S.mate[1].records.load() != n) { err = "mate files hold different numbers of reads"; return false; }
+  for (int m = 0; m < S.nMates; ++m) { side[m].seqP.resize(n); side[m].idP.resize(n); side[m].seqL.resize(n); side[m].idL.resize(n); }
+  frag.resize(n);
+  maxLen = streamMaxLen.load();
+  // the unused tail of the text reservations goes back (the blobs keep what holds text)
+  for (int m = 0; m < S.nMates; ++m) {
+    Stream::Mate &M = S.mate[m];
+    const size_t keep = std::max<size_t>(4096, (M.textLen + 4095) & ~(size_t)4095);
+    for (Blob &b : blobs_)
+      if (b.map == (void *)M.text && keep < b.len) { munmap((char *)b.map + keep, b.len - keep); b.len = keep; }
+  }
+  if (getenv("T1K_DEBUG_PHASES"))
+    fprintf(stderr, "[t1k job] gzip read files streamed: %zu records per mate, %zu + %zu bytes of text, tables sized for %zu records\n", n, S.mate[0].textLen, S.nMates == 2 ? S.mate[1].textLen : (size_t)0, S.capRecords);
+  return true;
 }
 
 bool ReadInput::open(const std::vector<std::string> &files1, const std::vector<std::string> &files2, const std::string &barcodeFile, int threads, std::string &err) {

@@ -58,7 +58,7 @@ struct ReadInput {
   std::atomic<bool> inPlace{true};  // every file was indexed in place (strict layouts): records point into the file's own text, qualities included
   std::vector<uint32_t, NoInitAlloc<uint32_t>> frag;  // fragment f = record frag[f] (records with a missing barcode are dropped with their mates)
   int maxLen = 0;
-  ReadInput() = default;
+  ReadInput();
   ReadInput(const ReadInput &) = delete;
   ReadInput &operator=(const ReadInput &) = delete;
   ~ReadInput();
@@ -76,6 +76,19 @@ struct ReadInput {
   uint32_t base = 0;
   int shardRank = 0, shardRanks = 1;
   size_t nAll() const { return sharded ? nAll_ : frag.size(); }
+  // Streaming open (host/reads.cpp): one ordinary .gz file per mate, four-line FASTQ.  Each file is inflated by the decoder of host/inflate.cpp on
+  // a thread of its own, a second thread indexes the records behind it and a third runs the CRC over the text; the tables are sized to an
+  // upper bound of the record count (nFrag() while the stream runs) and the job's window loop takes records as they are published
+  // (streamAvail).  streamFinish trims the tables to what was found.  false with err empty = not eligible: the caller opens the files whole.
+  bool openStreaming(const std::vector<std::string> &files1, const std::vector<std::string> &files2, std::string &err);
+  bool streaming = false;      // opened by openStreaming and not finished yet: nFrag() / nAll() are the upper bound
+  size_t streamAvail() const;  // records indexed in every mate so far (their table entries may be read)
+  int streamState() const;     // 0 running, 1 every thread finished, -1 failed
+  void streamWait(size_t records) const;  // until that many records are there or the stream has ended
+  bool streamFinish(std::string &err);    // joins the threads, checks the mates against one another and the CRCs, trims the tables
+  std::atomic<int> streamMaxLen{0};       // longest read indexed so far
+  struct Stream;
+  std::unique_ptr<Stream> stream_;
   // the mapped bytes of records [recLo, recHi) are not needed any more (their text went to the GPU and their output is written): drop
   // the page-table entries now, piece by piece beside the device loop, instead of all at once when the job is destroyed
   void release(size_t recLo, size_t recHi);
@@ -105,6 +118,9 @@ struct ReadInput {
 struct GzProgress {
   std::atomic<uint64_t> produced{0};
   std::atomic<int> state{0};  // 0 running, 1 finished, -1 failed
+  // members that are complete: (offset of the member's end in the text, CRC-32 of its trailer), for the reader that checks the text behind the decoder
+  std::mutex m;
+  std::vector<std::pair<uint64_t, uint32_t>> members;
 };
 int gzInflateAll(const uint8_t *src, size_t srcLen, uint8_t *dst, size_t cap, GzProgress *pg, size_t *outLen, uint32_t *lastCrc, size_t *members, std::string &err);
 

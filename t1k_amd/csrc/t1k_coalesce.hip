@@ -325,6 +325,14 @@ int t1k_rowset_create(t1k_ctx *owner, uint64_t nFragments, const uint8_t *whitel
   return T1K_OK;
 }
 
+// a rowset created for an upper bound of the fragment count (a streamed input): the fragments that exist.  The per-fragment arrays keep
+// their places; the stages behind the loop walk the first n entries only.
+int t1k_rowset_trim(t1k_rowset *rs, uint64_t nFragments) {
+  if (!rs || rs->exchanged || nFragments > rs->nFrag) return T1K_ERR_ARG;
+  rs->nFrag = nFragments;
+  return T1K_OK;
+}
+
 void t1k_rowset_destroy(t1k_rowset *rs) {
   if (!rs) return;
   (void)hipSetDevice(rs->device);

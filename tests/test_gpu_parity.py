@@ -355,6 +355,34 @@ def test_gzip_read_files(built, tmp_path):
     _golden_files_equal(c, out)
 
 
+@pytest.mark.parametrize("case,env", [("cyp_dna_relax_2x150", {}), ("cyp_rna_2x100", {"T1K_FIRST_WINDOW": "64", "T1K_WINDOW": "256", "T1K_BATCH": "32", "T1K_PAIR_BATCH": "64"}),
+                                      ("cyp_dna_relax_2x150", {"T1K_COVERAGE": "eager", "T1K_PIPELINES": "1"})])
+def test_gzip_read_files_streamed_under_the_loop(built, tmp_path, case, env):
+    """the .gz fixtures handed to the window loop while they are still being inflated (t1k_reads_open_stream: host/inflate.cpp publishes its
+    progress, the records are indexed behind it, windows are cut from what has arrived; ReadFiles.hpp:13,95 / kseq.h:94-150 stream through
+    zlib): every output file equals the reference's, the fragment count is logged behind the loop, and a damaged file ends the job"""
+    c = goldens.Case(case, str(tmp_path))
+    out = os.path.join(str(tmp_path), "gzs")
+    r1, r2 = os.path.join(c.dir, "reads_1.fq.gz"), os.path.join(c.dir, "reads_2.fq.gz")
+    args = ["-f", c.ref, "-1", r1, "-2", r2] + c.flags
+    e = dict(os.environ, T1K_STREAM_GZ_MIN_MB="0.0001", T1K_DEBUG_PHASES="1", **env)
+    r = subprocess.run([GENO] + args + ["-o", out], stderr=subprocess.PIPE, text=True, env=e)
+    assert r.returncode == 0, r.stderr
+    assert "gzip read files streamed" in r.stderr, r.stderr      # the streaming reader did run
+    _golden_files_equal(c, out)
+    found = [l for l in r.stderr.splitlines() if "Found " in l and "read fragments" in l]
+    whole = subprocess.run([GENO] + args + ["-o", out + "_w"], stderr=subprocess.PIPE, text=True, env=dict(os.environ, T1K_STREAM_GZ="0"))
+    assert whole.returncode == 0 and "gzip read files streamed" not in whole.stderr
+    assert [l.split("] ")[-1] for l in found] == [l.split("] ")[-1] for l in whole.stderr.splitlines() if "Found " in l and "read fragments" in l]
+    if not env:
+        blob = bytearray(open(r1, "rb").read())
+        blob[-7] ^= 0x21  # the trailer's CRC
+        bad = os.path.join(str(tmp_path), "bad_1.fq.gz")
+        open(bad, "wb").write(blob)
+        r = subprocess.run([GENO, "-f", c.ref, "-1", bad, "-2", r2] + c.flags + ["-o", out + "_bad"], stderr=subprocess.PIPE, text=True, env=e)
+        assert r.returncode != 0 and "damaged" in r.stderr, r.stderr
+
+
 def test_reads_opened_beside_job_creation(built, tmp_path):
     """t1k_reads_open on a second thread while t1k_job_create runs, then t1k_job_attach_reads (what the executable and bench.py do) leaves
     the job as t1k_job_load_reads does; the executable's serial order (T1K_SERIAL_OPEN=1) writes the same files; a failed open arrives

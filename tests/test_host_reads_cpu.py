@@ -16,8 +16,8 @@ HOST = os.path.join(util.ROOT, "t1k_amd", "csrc", "host")
 @pytest.fixture(scope="module")
 def harness(tmp_path_factory):
     exe = str(tmp_path_factory.mktemp("harness") / "reads_shard_harness")
-    subprocess.run(["g++", "-O2", "-std=c++17", "-o", exe, HARNESS_SRC, os.path.join(HOST, "reads.cpp"), os.path.join(HOST, "refset.cpp"), "-lz", "-lpthread", "-ldl"],
-                   check=True)
+    subprocess.run(["g++", "-O2", "-std=c++17", "-o", exe, HARNESS_SRC, os.path.join(HOST, "reads.cpp"), os.path.join(HOST, "refset.cpp"), os.path.join(HOST, "inflate.cpp"),
+                    "-lz", "-lpthread", "-ldl"], check=True)
     return exe
 
 
@@ -122,3 +122,87 @@ def test_bgzip_framed_and_plain_gzip_input_index_like_the_plain_file(harness, re
     assert out["plain"].count("\n") == 30000
     for kind in out:
         assert out[kind] == out["plain"], kind
+
+
+# ---- streamed .gz input (ReadInput::openStreaming + host/inflate.cpp): the index the window loop reads while the files are still being inflated ----
+STREAM_SRC = os.path.join(util.ROOT, "tests", "harness", "reads_stream_harness.cpp")
+
+
+@pytest.fixture(scope="module")
+def stream_harness(tmp_path_factory):
+    exe = str(tmp_path_factory.mktemp("harness") / "reads_stream_harness")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-o", exe, STREAM_SRC, os.path.join(HOST, "reads.cpp"), os.path.join(HOST, "refset.cpp"), os.path.join(HOST, "inflate.cpp"),
+                    "-lz", "-lpthread", "-ldl"], check=True)
+    return exe
+
+
+def _stream(exe, prefix, files, min_mb="0.0001"):
+    r = subprocess.run([exe, prefix] + files, stdout=subprocess.PIPE, text=True, env=dict(os.environ, T1K_STREAM_GZ_MIN_MB=min_mb))
+    return r.returncode, r.stdout
+
+
+def _gz(src, dst, level=6):
+    import gzip
+    with open(src, "rb") as f, gzip.open(dst, "wb", compresslevel=level) as g:
+        g.write(f.read())
+    return dst
+
+
+@pytest.mark.parametrize("sample", ["a", "b", "c"])   # a: no final newline in mate 1; b: CRLF, 100-base reads; c: seven pairs
+def test_streamed_gz_index_equals_the_index_of_the_file_opened_whole(stream_harness, read_sets, tmp_path, sample):
+    f = [_gz(os.path.join(read_sets, "%s_%s.fq" % (sample, m)), str(tmp_path / ("%s_%s.fq.gz" % (sample, m))), level) for m, level in (("1", 6), ("2", 1))]
+    rc, out = _stream(stream_harness, str(tmp_path / "p"), f)
+    assert rc == 0 and "stream:" in out and "ERROR" not in out and "not eligible" not in out, out
+    assert open(str(tmp_path / "p_whole.tsv"), "rb").read() == open(str(tmp_path / "p_stream.tsv"), "rb").read()
+    whole, stream = [l for l in out.splitlines() if l.startswith("whole:")][0], [l for l in out.splitlines() if l.startswith("stream:")][0]
+    assert whole.split("fragments")[0].split()[-1] == stream.split("fragments")[0].split()[-1]
+    assert whole.split("longest read")[1].split()[0].rstrip(",") == stream.split("longest read")[1].split()[0].rstrip(",")
+    # single-end, and reads that get shorter towards the end of the file (the tables are sized from the head of the text)
+    rc, out = _stream(stream_harness, str(tmp_path / "s"), f[:1])
+    assert rc == 0 and open(str(tmp_path / "s_whole.tsv"), "rb").read() == open(str(tmp_path / "s_stream.tsv"), "rb").read(), out
+
+
+def test_streamed_gz_trimmed_reads_and_trailing_blank_lines(stream_harness, tmp_path):
+    import random
+    rnd = random.Random(3)
+    recs = []
+    for i in range(40000):
+        n = 150 if i < 5000 else rnd.choice((31, 40, 75, 150))   # the head of the file says 150, the rest is trimmed
+        s = "".join(rnd.choice("ACGTN") for _ in range(n))
+        recs.append("@q%d extra words\n%s\n+\n%s\n" % (i, s, "".join(rnd.choice("@+FF:,") for _ in range(n))))  # quality lines that start with '@' and '+'
+    open(str(tmp_path / "t.fq"), "w").write("".join(recs) + "\n\n")
+    g = _gz(str(tmp_path / "t.fq"), str(tmp_path / "t.fq.gz"))
+    rc, out = _stream(stream_harness, str(tmp_path / "t"), [g])
+    assert rc == 0 and "ERROR" not in out and "not eligible" not in out, out
+    assert open(str(tmp_path / "t_whole.tsv"), "rb").read() == open(str(tmp_path / "t_stream.tsv"), "rb").read()
+
+
+def test_streamed_gz_refuses_what_it_cannot_follow_and_reports_damage(stream_harness, read_sets, tmp_path):
+    a1 = _gz(os.path.join(read_sets, "a_1.fq"), str(tmp_path / "a_1.fq.gz"))
+    a2 = _gz(os.path.join(read_sets, "a_2.fq"), str(tmp_path / "a_2.fq.gz"))
+    c2 = _gz(os.path.join(read_sets, "c_2.fq"), str(tmp_path / "c_2.fq.gz"))
+    # below the size from which streaming pays: opened whole (default threshold)
+    rc, out = _stream(stream_harness, str(tmp_path / "n"), [a1, a2], min_mb="32")
+    assert rc == 0 and "not eligible" in out, out
+    # a plain file, a FASTA file, two members are fine, wrapped records are not the four-line layout
+    rc, out = _stream(stream_harness, str(tmp_path / "n"), [os.path.join(read_sets, "a_1.fq")])
+    assert rc == 0 and "not eligible" in out, out
+    open(str(tmp_path / "w.fa"), "w").write("".join(">s%d\nACGTACGT\nACGT\n" % i for i in range(5000)))
+    rc, out = _stream(stream_harness, str(tmp_path / "n"), [_gz(str(tmp_path / "w.fa"), str(tmp_path / "w.fa.gz"))])
+    assert rc == 0 and "not eligible" in out, out
+    # mates of different length: an error at the end of the stream, as for files opened whole
+    rc, out = _stream(stream_harness, str(tmp_path / "m"), [a1, c2])
+    assert rc == 1 and "different numbers of reads" in out, out
+    # damage: a flipped bit in the trailer's CRC, a flipped byte in the compressed data, a truncated file
+    blob = bytearray(open(a1, "rb").read())
+    bad = bytearray(blob); bad[-6] ^= 0x10
+    open(str(tmp_path / "crc.fq.gz"), "wb").write(bad)
+    rc, out = _stream(stream_harness, str(tmp_path / "d"), [str(tmp_path / "crc.fq.gz")])
+    assert rc == 1 and "damaged" in out, out
+    bad = bytearray(blob); bad[len(bad) // 2] ^= 0x55
+    open(str(tmp_path / "mid.fq.gz"), "wb").write(bad)
+    rc, out = _stream(stream_harness, str(tmp_path / "d"), [str(tmp_path / "mid.fq.gz")])
+    assert rc == 1 and "stream: ERROR" in out, out
+    open(str(tmp_path / "cut.fq.gz"), "wb").write(blob[:len(blob) * 2 // 3])
+    rc, out = _stream(stream_harness, str(tmp_path / "d"), [str(tmp_path / "cut.fq.gz")])
+    assert rc == 1 and "stream: ERROR" in out, out
