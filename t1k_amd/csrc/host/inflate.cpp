@@ -152,7 +152,7 @@ static const uint32_t *fixedDist() {
 }
 
 // one DEFLATE stream: out .. outEnd, `base` = first byte a distance may reach back to.  Returns nullptr on error (msg set).
-static uint8_t *inflateRaw(Bits &b, uint8_t *base, uint8_t *out, uint8_t *outEnd, GzProgress *pg, uint8_t *dst0, const char *&msg) {
+static uint8_t *inflateRaw(Bits &b, uint8_t *base, uint8_t *out, uint8_t *outEnd, GzProgress *pg, uint8_t *dst0, uint64_t progressBase, const char *&msg) {
   static thread_local uint32_t litTab[LSIZE], distTab[DSIZE], clTab[1 << 7];
   for (;;) {
     b.refill();
@@ -314,7 +314,7 @@ static uint8_t *inflateRaw(Bits &b, uint8_t *base, uint8_t *out, uint8_t *outEnd
     }
   blockDone:
     if (b.cnt < 0 || b.under) { msg = "truncated stream"; return nullptr; }
-    if (pg) pg->produced.store((uint64_t)(out - dst0), std::memory_order_release);
+    if (pg) pg->produced.store(progressBase + (uint64_t)(out - dst0), std::memory_order_release);
     if (bfinal) return out;
   }
 }
@@ -322,8 +322,10 @@ static uint8_t *inflateRaw(Bits &b, uint8_t *base, uint8_t *out, uint8_t *outEnd
 }  // namespace
 
 // every member of the gzip file src[0 .. srcLen) -> dst[0 .. cap); *outLen = bytes of text.  0 = fine; otherwise err says what is wrong.
+// progressBase: what the published offsets start from (a file behind others in one text range); finishes: the progress ends with this file.
 // The trailer's CRC-32 is NOT checked here (the caller runs it over the text behind the decoder, host/reads.cpp); its length field is.
-int gzInflateAll(const uint8_t *src, size_t srcLen, uint8_t *dst, size_t cap, GzProgress *pg, size_t *outLen, uint32_t *lastCrc, size_t *members, std::string &err) {
+int gzInflateAll(const uint8_t *src, size_t srcLen, uint8_t *dst, size_t cap, GzProgress *pg, size_t *outLen, uint32_t *lastCrc, size_t *members, std::string &err, uint64_t progressBase,
+                 bool finishes) {
   const uint8_t *p = src, *end = src + srcLen;
   uint8_t *out = dst, *outEnd = dst + cap;
   size_t nMembers = 0;
@@ -342,7 +344,7 @@ int gzInflateAll(const uint8_t *src, size_t srcLen, uint8_t *dst, size_t cap, Gz
     Bits b{p, end};
     const char *msg = nullptr;
     uint8_t *memberStart = out;
-    uint8_t *o = inflateRaw(b, memberStart, out, outEnd, pg, dst, msg);
+    uint8_t *o = inflateRaw(b, memberStart, out, outEnd, pg, dst, progressBase, msg);
     if (!o) return fail(msg);
     // back to whole bytes: the bit buffer holds cnt bits that were loaded but not used
     b.drop(b.cnt & 7);
@@ -354,12 +356,12 @@ int gzInflateAll(const uint8_t *src, size_t srcLen, uint8_t *dst, size_t cap, Gz
     p += 8;
     out = o;
     ++nMembers;
-    if (pg) { std::lock_guard<std::mutex> g(pg->m); pg->members.push_back({(uint64_t)(out - dst), crc}); }
+    if (pg) { std::lock_guard<std::mutex> g(pg->m); pg->members.push_back({progressBase + (uint64_t)(out - dst), crc}); }
   }
   if (!nMembers) return fail("empty file");
   if (outLen) *outLen = (size_t)(out - dst);
   if (members) *members = nMembers;
-  if (pg) { pg->produced.store((uint64_t)(out - dst), std::memory_order_release); pg->state.store(1, std::memory_order_release); }
+  if (pg) { pg->produced.store(progressBase + (uint64_t)(out - dst), std::memory_order_release); if (finishes) pg->state.store(1, std::memory_order_release); }
   return 0;
 }
 

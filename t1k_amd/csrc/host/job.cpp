@@ -128,13 +128,26 @@ static int jobCreate(const t1k_job_params *p, const char *refFasta, const std::s
       // hardware overlap batches and hide the host's share of a batch (counter fetches, launches).  Measured on the HLA-like
       // workload (device loop): 1 M pairs 840 / 723 / 678 ms with 1 / 2 / 4 pipelines, 10 M pairs 6.4 / 6.0 / 5.9 s with 2 / 3 / 4;
       // every pipeline's arenas are device memory the driver may have to zero first (~35 ms per GB).  T1K_PIPELINES overrides.
-      for (int i = 1; i < nPipe && rcCtx == T1K_OK; ++i) {
-        t1k_ctx *c = nullptr;
-        if (t1k_ctx_create(job->prm.device, &job->prm.dev, &c) != T1K_OK) { if (c) t1k_ctx_destroy(c); break; }
-        job->more.push_back(c);
+      // (the other contexts side by side: a stream of its own is a hardware queue with a 177 MB save area that the runtime allocates and
+      // touches at creation -- ~10 ms each, on the cold path of a fresh process; T1K_SERIAL_CONTEXTS=1: one after the other)
+      if (rcCtx != T1K_OK) return;
+      std::vector<t1k_ctx *> extra((size_t)std::max(0, nPipe - 1), nullptr);
+      int rcReader[2] = {T1K_OK, T1K_OK};
+      {
+        const bool serial = getenv("T1K_SERIAL_CONTEXTS") != nullptr;
+        std::vector<std::thread> th;
+        auto run = [&](std::function<void()> f) { if (serial) f(); else th.emplace_back(f); };
+        for (size_t i = 0; i < extra.size(); ++i)
+          run([&, i] { t1k_ctx *c = nullptr; if (t1k_ctx_create(job->prm.device, &job->prm.dev, &c) != T1K_OK) { if (c) t1k_ctx_destroy(c); c = nullptr; } extra[i] = c; });
+        for (int i = 0; i < 2; ++i)
+          run([&, i] { if (t1k_ctx_create(job->prm.device, &job->prm.dev, &job->reader[i]) != T1K_OK) rcReader[i] = T1K_ERR_DEVICE; });
+        for (auto &t : th) t.join();
       }
-      for (int i = 0; i < 2 && rcCtx == T1K_OK; ++i)
-        if (t1k_ctx_create(job->prm.device, &job->prm.dev, &job->reader[i]) != T1K_OK) rcCtx = T1K_ERR_DEVICE;
+      for (size_t i = 0; i < extra.size(); ++i) {  // (a pipeline that could not be had ends the list: the job runs with the ones before it)
+        if (!extra[i]) { for (size_t j = i + 1; j < extra.size(); ++j) if (extra[j]) t1k_ctx_destroy(extra[j]); break; }
+        job->more.push_back(extra[i]);
+      }
+      if (rcReader[0] != T1K_OK || rcReader[1] != T1K_OK) rcCtx = T1K_ERR_DEVICE;
     });
   const bool loaded = job->ref.load(refFasta, job->prm.allele_digit_units, job->prm.allele_delimiter, job->err, selected);
   const double tLoaded = nowMs();

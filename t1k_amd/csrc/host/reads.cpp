@@ -110,8 +110,11 @@ inline const char *findRecord(const char *base, const char *from, const char *en
 // (thread 3; libdeflate's routine when the image has it -- 10 GB/s -- zlib's otherwise).  Tables sized to an upper bound of the record count.
 // ------------------------------------------------------------------------------------------------------------------
 struct ReadInput::Stream {
+  struct Src { void *map = nullptr; size_t len = 0; std::string path; };
   struct Mate {
-    void *src = nullptr; size_t srcLen = 0;
+    std::vector<Src> srcs;        // the mate's files, read back to back (ReadFiles::currentFpInd)
+    std::mutex m;
+    std::vector<uint64_t> fileEnds;  // offsets in the text where a file's text ends (pushed before the next file's first byte is published)
     char *text = nullptr; size_t cap = 0;
     GzProgress pg;
     std::thread inflater, indexer, checker;
@@ -130,7 +133,7 @@ struct ReadInput::Stream {
       if (M.inflater.joinable()) M.inflater.join();
       if (M.indexer.joinable()) M.indexer.join();
       if (M.checker.joinable()) M.checker.join();
-      if (M.src) munmap(M.src, M.srcLen);
+      for (Src &f : M.srcs) if (f.map) munmap(f.map, f.len);
     }
   }
 };
@@ -446,33 +449,47 @@ void ReadInput::streamWait(size_t records) const {
 
 bool ReadInput::openStreaming(const std::vector<std::string> &files1, const std::vector<std::string> &files2, std::string &err) {
   err.clear();
-  if (files1.size() != 1 || files2.size() > 1) return false;
+  if (files1.empty() || (!files2.empty() && files2.size() != files1.size())) return false;
   static const size_t minBytes = [] { const char *e = getenv("T1K_STREAM_GZ_MIN_MB"); return (size_t)((e ? atof(e) : 32.0) * 1048576.0); }();
   std::unique_ptr<Stream> S(new Stream());
   S->nMates = files2.empty() ? 1 : 2;
   size_t minRec = ~(size_t)0, estText[2] = {0, 0};
   for (int m = 0; m < S->nMates; ++m) {
     Stream::Mate &M = S->mate[m];
-    M.path = m ? files2[0] : files1[0];
-    int fd = ::open(M.path.c_str(), O_RDONLY);
-    if (fd < 0) return false;  // (the whole-file path reports it)
-    struct stat st;
-    if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || (size_t)st.st_size < std::max<size_t>(minBytes, 64)) { ::close(fd); return false; }
-    M.srcLen = (size_t)st.st_size;
-    M.src = mmap(nullptr, M.srcLen, PROT_READ, MAP_PRIVATE, fd, 0);
-    ::close(fd);
-    if (M.src == MAP_FAILED) { M.src = nullptr; return false; }
-    const uint8_t *z = (const uint8_t *)M.src;
-    if (z[0] != 0x1f || z[1] != 0x8b || z[2] != 8) return false;
-    if ((z[3] & 4) && M.srcLen > 16 && z[12] == 'B' && z[13] == 'C') return false;  // bgzip: its blocks are inflated side by side (bgzfInflate)
-    (void)madvise(M.src, M.srcLen, MADV_SEQUENTIAL);
-    // a look at the head of the text: four-line FASTQ?  how short can a record be?  (decoded again by the stream: 4 MB are nothing)
+    size_t compressed = 0;
+    for (const std::string &path : m ? files2 : files1) {
+      int fd = ::open(path.c_str(), O_RDONLY);
+      if (fd < 0) return false;  // (the whole-file path reports it)
+      struct stat st;
+      if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || st.st_size < 64) { ::close(fd); return false; }
+      Stream::Src f;
+      f.path = path; f.len = (size_t)st.st_size;
+      f.map = mmap(nullptr, f.len, PROT_READ, MAP_PRIVATE, fd, 0);
+      ::close(fd);
+      if (f.map == MAP_FAILED) return false;
+      M.srcs.push_back(f);  // (unmapped by the Stream's destructor from here on)
+      const uint8_t *z = (const uint8_t *)f.map;
+      if (z[0] != 0x1f || z[1] != 0x8b || z[2] != 8) return false;
+      if ((z[3] & 4) && f.len > 16 && z[12] == 'B' && z[13] == 'C') return false;  // bgzip: its blocks are inflated side by side (bgzfInflate)
+      (void)madvise(f.map, f.len, MADV_SEQUENTIAL);
+      compressed += f.len;
+      // the text's length: the trailer's length field when it can be the whole file's (one member below 4 GB: the usual case), else 48 x the
+      // compressed size as the whole-file path reserves
+      const uint32_t isize = (uint32_t)z[f.len - 4] | ((uint32_t)z[f.len - 3] << 8) | ((uint32_t)z[f.len - 2] << 16) | ((uint32_t)z[f.len - 1] << 24);
+      const bool plausible = (size_t)isize >= f.len && (size_t)isize <= f.len * 48;
+      estText[m] += plausible ? (size_t)isize : f.len * 48;
+      M.cap += std::max<size_t>(plausible ? (size_t)isize : 0, f.len * 48) + 4096;
+    }
+    if (compressed < minBytes) return false;
+    M.path = M.srcs[0].path;
+    // a look at the head of the first file's text: four-line FASTQ?  how short can a record be?  (decoded again by the stream: 4 MB are nothing)
     {
+      const uint8_t *z = (const uint8_t *)M.srcs[0].map;
       std::vector<uint8_t> head((size_t)4 << 20);
       GzProgress pg;
       std::string e;
       size_t n = 0;
-      (void)gzInflateAll(z, M.srcLen, head.data(), head.size(), &pg, &n, nullptr, nullptr, e);  // (ends with "more text than the range holds" for any real file)
+      (void)gzInflateAll(z, M.srcs[0].len, head.data(), head.size(), &pg, &n, nullptr, nullptr, e);  // (ends with "more text than the range holds" for any real file)
       n = (size_t)pg.produced.load();
       const char *p = (const char *)head.data(), *end = p + n;
       if (n < 16 || *p != '@') return false;
@@ -491,12 +508,7 @@ bool ReadInput::openStreaming(const std::vector<std::string> &files1, const std:
       }
       if (recs < 4) return false;
     }
-    // the text's length: the trailer's length field when it can be the whole file's (one member below 4 GB: the usual case), else 48 x the
-    // compressed size as the whole-file path reserves
-    const uint32_t isize = (uint32_t)z[M.srcLen - 4] | ((uint32_t)z[M.srcLen - 3] << 8) | ((uint32_t)z[M.srcLen - 2] << 16) | ((uint32_t)z[M.srcLen - 1] << 24);
-    const bool plausible = (size_t)isize >= M.srcLen && (size_t)isize <= M.srcLen * 48;
-    estText[m] = plausible ? (size_t)isize : M.srcLen * 48;
-    M.cap = ((std::max<size_t>(estText[m], M.srcLen * 48) + ((size_t)64 << 20)) + 4095) & ~(size_t)4095;
+    M.cap = ((M.cap + ((size_t)64 << 20)) + 4095) & ~(size_t)4095;
   }
   // both files are eligible: room for the text (address space only; the pages that are written get backed)
   for (int m = 0; m < S->nMates; ++m) {
@@ -527,9 +539,18 @@ bool ReadInput::openStreaming(const std::vector<std::string> &files1, const std:
     Stream::Mate *M = &S->mate[m];
     Side *sd = &side[m];
     M->inflater = std::thread([M] {
-      size_t n = 0;
-      if (gzInflateAll((const uint8_t *)M->src, M->srcLen, (uint8_t *)M->text, M->cap, &M->pg, &n, nullptr, nullptr, M->err) == 0) M->textLen = n;
-      else M->err = M->path + ": " + M->err;
+      size_t at = 0;
+      for (size_t i = 0; i < M->srcs.size(); ++i) {
+        size_t n = 0;
+        const bool last = i + 1 == M->srcs.size();
+        if (gzInflateAll((const uint8_t *)M->srcs[i].map, M->srcs[i].len, (uint8_t *)M->text + at, M->cap - at, &M->pg, &n, nullptr, nullptr, M->err, at, last) != 0) {
+          M->err = M->srcs[i].path + ": " + M->err;  // (the decoder has set the progress to "failed")
+          return;
+        }
+        at += n;
+        if (!last) { std::lock_guard<std::mutex> g(M->m); M->fileEnds.push_back(at); }  // before the next file's first byte is published
+      }
+      M->textLen = at;
     });
     M->checker = std::thread([M] {
       uint64_t done = 0;
@@ -576,9 +597,23 @@ bool ReadInput::openStreaming(const std::vector<std::string> &files1, const std:
         ++n;
         return true;
       };
+      size_t fileNo = 0;
+      // what is left behind the last complete record of a file: blank lines, or a last record whose last line has no line end
+      auto closeFile = [&](size_t endAt) -> bool {
+        const char *b = M->text + recStart, *e = M->text + endAt;
+        while (e > b && isBlank(e[-1])) --e;
+        while (b < e && isBlank(*b)) ++b;
+        if (e > b && !emit(b, e)) return false;
+        recStart = scan = endAt; lines = 0;
+        return true;
+      };
       for (;;) {
         const int st = M->pg.state.load(std::memory_order_acquire);
-        const size_t have = (size_t)M->pg.produced.load(std::memory_order_acquire);
+        size_t have = (size_t)M->pg.produced.load(std::memory_order_acquire);
+        // (the text of the next file is published only behind this file's end mark: read after `have`, the mark is seen whenever it matters)
+        size_t boundary = ~(size_t)0;
+        { std::lock_guard<std::mutex> g(M->m); if (fileNo < M->fileEnds.size()) boundary = (size_t)M->fileEnds[fileNo]; }
+        if (boundary != ~(size_t)0 && have > boundary) have = boundary;
         const uint64_t before = n;
         while (scan < have) {
           const char *nl = (const char *)memchr(M->text + scan, '\n', have - scan);
@@ -594,26 +629,28 @@ bool ReadInput::openStreaming(const std::vector<std::string> &files1, const std:
             }
           }
         }
+        if (boundary != ~(size_t)0 && scan >= boundary) {  // this file's text is complete: its tail, then the next file
+          if (!closeFile(boundary)) return;
+          ++fileNo;
+        }
         if (n != before) {
           int old = streamMaxLen.load(std::memory_order_relaxed);
           while (mx > old && !streamMaxLen.compare_exchange_weak(old, mx)) {}
           M->records.store(n, std::memory_order_release);
         }
-        if (st != 0 && scan >= (size_t)M->pg.produced.load(std::memory_order_acquire)) {
+        if (boundary == ~(size_t)0 && st != 0 && scan >= (size_t)M->pg.produced.load(std::memory_order_acquire)) {
+          bool more;
+          { std::lock_guard<std::mutex> g(M->m); more = fileNo < M->fileEnds.size(); }
+          if (more) continue;  // (a file's end mark arrived between the two looks)
           if (st < 0) { fail("the file is damaged"); return; }
-          // what is left behind the last complete record: blank lines, or a last record whose last line has no line end
-          const char *b = M->text + recStart, *e = M->text + scan;
-          while (e > b && isBlank(e[-1])) --e;
-          if (e > b) {
-            if (!emit(b, e)) return;
-            int old = streamMaxLen.load(std::memory_order_relaxed);
-            while (mx > old && !streamMaxLen.compare_exchange_weak(old, mx)) {}
-            M->records.store(n, std::memory_order_release);
-          }
+          if (!closeFile(scan)) return;
+          int old = streamMaxLen.load(std::memory_order_relaxed);
+          while (mx > old && !streamMaxLen.compare_exchange_weak(old, mx)) {}
+          M->records.store(n, std::memory_order_release);
           M->state.store(1, std::memory_order_release);
           return;
         }
-        if (n == before) std::this_thread::sleep_for(std::chrono::microseconds(200));
+        if (n == before && !(boundary != ~(size_t)0 && scan >= boundary)) std::this_thread::sleep_for(std::chrono::microseconds(200));
       }
     });
   }

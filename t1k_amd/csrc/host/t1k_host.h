@@ -76,7 +76,7 @@ struct ReadInput {
   uint32_t base = 0;
   int shardRank = 0, shardRanks = 1;
   size_t nAll() const { return sharded ? nAll_ : frag.size(); }
-  // Streaming open (host/reads.cpp): one ordinary .gz file per mate, four-line FASTQ.  Each file is inflated by the decoder of host/inflate.cpp on
+  // Streaming open (host/reads.cpp): ordinary .gz files (the same number for every mate, read back to back as ReadFiles does), four-line FASTQ.  Each file is inflated by the decoder of host/inflate.cpp on
   // a thread of its own, a second thread indexes the records behind it and a third runs the CRC over the text; the tables are sized to an
   // upper bound of the record count (nFrag() while the stream runs) and the job's window loop takes records as they are published
   // (streamAvail).  streamFinish trims the tables to what was found.  false with err empty = not eligible: the caller opens the files whole.
@@ -122,7 +122,8 @@ struct GzProgress {
   std::mutex m;
   std::vector<std::pair<uint64_t, uint32_t>> members;
 };
-int gzInflateAll(const uint8_t *src, size_t srcLen, uint8_t *dst, size_t cap, GzProgress *pg, size_t *outLen, uint32_t *lastCrc, size_t *members, std::string &err);
+int gzInflateAll(const uint8_t *src, size_t srcLen, uint8_t *dst, size_t cap, GzProgress *pg, size_t *outLen, uint32_t *lastCrc, size_t *members, std::string &err, uint64_t progressBase = 0,
+                 bool finishes = true);
 
 struct AlleleMeta {
   std::string name;

@@ -1,9 +1,10 @@
 // tests/harness/reads_stream_harness.cpp -- TEST INFRASTRUCTURE (CPU): the read-file index of the host side (t1k_amd/csrc/host/reads.cpp) opened
 // whole and opened as a stream (ReadInput::openStreaming: the .gz files inflated by host/inflate.cpp while the records are indexed behind
 // the decoder), consumed the way the job's window loop does: records are read as soon as they are published, in pieces.
-//   reads_stream_harness <out prefix> file1.gz [file2.gz]
+//   reads_stream_harness <out prefix> <files per mate> files of mate 1 ... [files of mate 2 ...]
 // writes <prefix>_whole.tsv and <prefix>_stream.tsv (id1, seq1[, id2, seq2] per fragment) and prints what happened.
 #include <cstdio>
+#include <cstdlib>
 #include <string>
 #include <vector>
 #include "../../t1k_amd/csrc/host/t1k_host.h"
@@ -15,10 +16,11 @@ static void line(FILE *f, const ReadInput &in, size_t i) {
   fputc('\n', f);
 }
 int main(int argc, char **argv) {
-  if (argc < 3) return 2;
+  if (argc < 4) return 2;
   const std::string out = argv[1];
-  std::vector<std::string> f1{argv[2]}, f2;
-  if (argc > 3) f2.push_back(argv[3]);
+  const int per = atoi(argv[2]);
+  std::vector<std::string> f1, f2;
+  for (int i = 3; i < argc; ++i) ((int)f1.size() < per ? f1 : f2).push_back(argv[i]);
   std::string err;
   {
     ReadInput whole;

@@ -136,8 +136,8 @@ def stream_harness(tmp_path_factory):
     return exe
 
 
-def _stream(exe, prefix, files, min_mb="0.0001"):
-    r = subprocess.run([exe, prefix] + files, stdout=subprocess.PIPE, text=True, env=dict(os.environ, T1K_STREAM_GZ_MIN_MB=min_mb))
+def _stream(exe, prefix, files, min_mb="0.0001", per_mate=1):
+    r = subprocess.run([exe, prefix, str(per_mate)] + files, stdout=subprocess.PIPE, text=True, env=dict(os.environ, T1K_STREAM_GZ_MIN_MB=min_mb))
     return r.returncode, r.stdout
 
 
@@ -160,6 +160,18 @@ def test_streamed_gz_index_equals_the_index_of_the_file_opened_whole(stream_harn
     # single-end, and reads that get shorter towards the end of the file (the tables are sized from the head of the text)
     rc, out = _stream(stream_harness, str(tmp_path / "s"), f[:1])
     assert rc == 0 and open(str(tmp_path / "s_whole.tsv"), "rb").read() == open(str(tmp_path / "s_stream.tsv"), "rb").read(), out
+
+
+def test_streamed_gz_several_files_per_mate(stream_harness, read_sets, tmp_path):
+    """lanes: the files of a mate are read back to back (ReadFiles::currentFpInd); a file may end without a line end (a_1) or with CRLF (b), and
+    the next file's first record must not be glued to it"""
+    f = [_gz(os.path.join(read_sets, "%s_%s.fq" % (smp, m)), str(tmp_path / ("%s_%s.fq.gz" % (smp, m)))) for m in ("1", "2") for smp in ("a", "b", "c", "a")]
+    rc, out = _stream(stream_harness, str(tmp_path / "l"), f, per_mate=4)
+    assert rc == 0 and "ERROR" not in out and "not eligible" not in out, out
+    assert open(str(tmp_path / "l_whole.tsv"), "rb").read() == open(str(tmp_path / "l_stream.tsv"), "rb").read()
+    assert "72352 fragments" in out.split("stream:")[1], out   # 30000 + 12345 + 7 + 30000
+    rc, out = _stream(stream_harness, str(tmp_path / "u"), f[:4] + f[4:6], per_mate=4)   # mates with different numbers of files: not this reader's case
+    assert rc == 0 and "not eligible" in out, out
 
 
 def test_streamed_gz_trimmed_reads_and_trailing_blank_lines(stream_harness, tmp_path):
