@@ -383,6 +383,28 @@ def test_gzip_read_files_streamed_under_the_loop(built, tmp_path, case, env):
         assert r.returncode != 0 and "damaged" in r.stderr, r.stderr
 
 
+def test_gzip_lanes_streamed_under_the_loop(built, tmp_path):
+    """three .gz files per mate (lanes) streamed back to back: the first ends without a line end, the second with blank lines, the third is CRLF"""
+    import gzip
+    c = goldens.Case("cyp_rna_2x100", str(tmp_path))
+    args = ["-f", c.ref]
+    for m, path in ((1, c.r1), (2, c.r2)):
+        lines = open(path).read().split("\n")
+        recs = ["\n".join(lines[i:i + 4]) + "\n" for i in range(0, len(lines) - 1, 4)]
+        cut = [0, len(recs) // 5, len(recs) * 2 // 3, len(recs)]
+        texts = ["".join(recs[cut[0]:cut[1]]).rstrip("\n"), "".join(recs[cut[1]:cut[2]]) + "\n\n", "".join(recs[cut[2]:cut[3]]).replace("\n", "\r\n")]
+        for i, t in enumerate(texts):
+            g = os.path.join(str(tmp_path), "lane%d_%d.fq.gz" % (i, m))
+            with gzip.open(g, "wb", compresslevel=(1, 6, 9)[i]) as f:
+                f.write(t.encode())
+            args += ["-%d" % m, g]
+    out = os.path.join(str(tmp_path), "lanes")
+    r = subprocess.run([GENO] + args + c.flags + ["-o", out], stderr=subprocess.PIPE, text=True, env=dict(os.environ, T1K_STREAM_GZ_MIN_MB="0.0001", T1K_DEBUG_PHASES="1"))
+    assert r.returncode == 0, r.stderr
+    assert "gzip read files streamed" in r.stderr, r.stderr
+    _golden_files_equal(c, out)
+
+
 def test_reads_opened_beside_job_creation(built, tmp_path):
     """t1k_reads_open on a second thread while t1k_job_create runs, then t1k_job_attach_reads (what the executable and bench.py do) leaves
     the job as t1k_job_load_reads does; the executable's serial order (T1K_SERIAL_OPEN=1) writes the same files; a failed open arrives
