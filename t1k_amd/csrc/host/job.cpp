@@ -1735,6 +1735,7 @@ int t1k_genotyper_main(int argc, char **argv) {
     if (openedBeside) { rc = t1k_job_attach_reads(job, opened); opened = nullptr; if (rc == T1K_OK) rc = rcOpen; }  // (a failed open: the handle carries the message into the job)
     else rc = loadInto(job);
     if (rc != T1K_OK) { fprintf(stderr, "genotyper: %s\n", t1k_job_last_error(job)); destroyAll(); return EXIT_FAILURE; }
+    job->in->dropInflatedText = R == 1 && !getenv("T1K_KEEP_TEXT");  // this process runs the job once: the text of written fragments is not needed again
     foundLater = job->in->streaming;  // (a streamed input: counted when the stream has ended, i.e. behind the loop)
     if (!foundLater) logLine("Found %d read fragments. Start read assignment.", (int)job->in->nAll());
     t1k_job_set_output_prefix(job, prefix.c_str());  // the aligned-read files are written while the EM runs

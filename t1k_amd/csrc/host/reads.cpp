@@ -121,6 +121,7 @@ struct ReadInput::Stream {
     std::atomic<uint64_t> records{0};
     std::atomic<int> state{0};  // indexer: 0 running, 1 done, -1 failed
     std::atomic<int> crcState{0};
+    std::atomic<uint64_t> crcDone{0};  // text the checker has been over (nothing beyond it may be dropped: ReadInput::release)
     std::string err, path;
     size_t textLen = 0;
   } mate[2];
@@ -564,7 +565,7 @@ bool ReadInput::openStreaming(const std::vector<std::string> &files1, const std:
         bool closes = false;
         { std::lock_guard<std::mutex> g(M->pg.m); if (member < M->pg.members.size()) { end = M->pg.members[member].first; want = M->pg.members[member].second; closes = true; } }
         const uint64_t upto = closes ? end : have;
-        if (upto > done) { crc = crcStep(crc, M->text + done, (size_t)(upto - done)); done = upto; }
+        if (upto > done) { crc = crcStep(crc, M->text + done, (size_t)(upto - done)); done = upto; M->crcDone.store(done, std::memory_order_release); }
         if (closes) {
           if (crc != want) { M->crcState.store(-1, std::memory_order_release); return; }
           crc = 0; ++member;
@@ -889,14 +890,27 @@ void ReadInput::release(size_t recLo, size_t recHi) {
         if (b.map && p >= (const char *)b.map && p < (const char *)b.map + b.len) return &b;
       return nullptr;
     };
-    auto drop = [&](const char *a, const char *b) {  // whole pages inside [a, b)
-      uintptr_t lo = ((uintptr_t)a + (uintptr_t)page - 1) & ~((uintptr_t)page - 1), hi = (uintptr_t)b & ~((uintptr_t)page - 1);
-      if (hi > lo) (void)madvise((void *)lo, hi - lo, MADV_DONTNEED);
-    };
     const char *first = sd->idP[recLo], *last = sd->idP[recHi - 1];
     const Blob *b0 = blobOf(first), *b1 = blobOf(last);
-    if (!b0 || !b1 || b0->anon || b1->anon) continue;  // owned storage (gz, general reader): a rerun of the job reads the text again, and dropped anonymous pages come back as zeros
-    const char *end1 = recHi < sd->idP.size() && blobOf(sd->idP[recHi]) == b1 ? sd->idP[recHi] - 1 : (const char *)b1->map + b1->len;
+    if (!b0 || !b1) continue;
+    const bool anon = b0->anon || b1->anon;
+    if (anon && !dropInflatedText) continue;  // owned storage (gz, general reader): a rerun of the job reads the text again, and dropped anonymous pages come back as zeros
+    // (inflated text sits in huge pages: whole 2 MB units only, or every call would split two of them)
+    const uintptr_t unit = anon ? ((uintptr_t)2 << 20) : (uintptr_t)page;
+    auto drop = [&](const char *a, const char *b) {  // whole units inside [a, b)
+      uintptr_t lo = ((uintptr_t)a + unit - 1) & ~(unit - 1), hi = (uintptr_t)b & ~(unit - 1);
+      if (hi > lo) (void)madvise((void *)lo, hi - lo, MADV_DONTNEED);
+    };
+    // (a stream's tables are sized to a bound: entries beyond what has been published are not records yet, and the text range has room behind
+    // the text that exists -- without a next record the range ends at the last record's start)
+    const size_t known = streaming ? std::min(sd->idP.size(), streamAvail()) : sd->idP.size();
+    const char *end1 = recHi < known && blobOf(sd->idP[recHi]) == b1 ? sd->idP[recHi] - 1 : (anon ? last : (const char *)b1->map + b1->len);
+    if (stream_ && anon) {  // ... and the CRC checker must have been over it (it runs far ahead of the loop; with zlib's routine it may not)
+      const int mate = sd == &side[1] ? 1 : 0;
+      const char *checked = stream_->mate[mate].text + stream_->mate[mate].crcDone.load(std::memory_order_acquire);
+      if (end1 > checked) end1 = checked;
+      if (end1 <= first) continue;
+    }
     if (b0 == b1) drop(first - 1, end1);
     else { drop(first - 1, (const char *)b0->map + b0->len); drop((const char *)b1->map, end1); }  // (files wholly inside the range wait for the unmapping)
   }

@@ -363,12 +363,9 @@ __device__ inline int groupFastPath(const uint32_t *Mw, int diag, const ReadCtx 
 // Arr: work-array accessor (plain pointer, or LaneArr = LDS arrays interleaved over the lanes of a wavefront)
 // second half of one diagonal run: B[0..m) = the run's hits nearest to the dominant diagonal, sorted by (allele offset, read offset);
 // LIS over the read offsets, chain -> A[s..), hit lengths, seed-chain match count, candidate (SeqSet.hpp:352-436, 1512-1551, 1697-1833)
-// punt != nullptr: an alignment that would have to run inline here (memo full, more than GROUP_MAX_REFS waiting) ends the group undone and sets
-// *punt instead -- the caller hands the group to a launch that carries the alignment code (k_chain_general<1> does not: half its registers)
 template <class Arr>
 __device__ inline void chainRun(const ReadCtx &c, int k, int hitLenRequired, Arr A, Arr B, Arr C, int s, int m, int *gaScratch, int gaMax, CandOut &out,
-                                unsigned int *dpCounter, unsigned long long *errFlags, bool *needScratch, const GapSink *sink, int strandBit, bool chainReady = false,
-                                bool *punt = nullptr) {
+                                unsigned int *dpCounter, unsigned long long *errFlags, bool *needScratch, const GapSink *sink, int strandBit, bool chainReady = false) {
     int ret, lenR, lenS;
     if (!t1k_run_lis(A, B, C, s, m, k, hitLenRequired, &ret, &lenR, &lenS, chainReady)) return;
     // seed-chain match count (1697-1833).  With a sink the alignments are registered in the read-end's memo instead of being
@@ -384,7 +381,6 @@ __device__ inline void chainRun(const ReadCtx &c, int k, int hitLenRequired, Arr
       const int r = gapMatchesCached<true>(c, ra, c.goff + ga, lp, lt, strandBit, *sink, dpCounter, &slot);
       if (r >= 0) return r;
       if (r == -1 && nref < GROUP_MAX_REFS) { refs[nref >> 1] |= slot << (16 * (nref & 1)); ++nref; return 0; }
-      if (punt) { *punt = true; return 0; }
       if (dpCounter) ++*dpCounter;
       return gapAlign(c, ra, c.goff + ga, lp, lt);
     };
@@ -403,7 +399,6 @@ __device__ inline void chainRun(const ReadCtx &c, int k, int hitLenRequired, Arr
         else matchCnt += 2 * k + 2 * gapM(pa + k, pb + k, qa - (pa + k), qb - (pb + k));
       }
     }
-    if (punt && *punt) return;
     int rs = (int)(A[s] & 0xFFF), ss = (int)(A[s] >> 12);
     int re = (int)(A[s + ret - 1] & 0xFFF) + k - 1, se = (int)(A[s + ret - 1] >> 12) + k - 1;
     out.push(rs, re, ss, se, 2 * lenR, matchCnt);
@@ -468,10 +463,10 @@ __device__ inline void groupGeneral(const uint32_t *h, int n, const ReadCtx &c, 
 // chain walk -- the same code as the general path runs after its sorts (SeqSet.hpp:1400-1405, 1468, 1512-1551, 1697-1833).
 template <class Arr>
 __device__ inline void groupSimple(const uint32_t *h, int n, const ReadCtx &c, int k, int hitLenRequired, Arr A, CandOut &out, unsigned int *dpCounter,
-                                   unsigned long long *errFlags, bool *needScratch, const GapSink *sink, int strandBit, bool *punt = nullptr) {
+                                   unsigned long long *errFlags, bool *needScratch, const GapSink *sink, int strandBit) {
   for (int i = 0; i < n; ++i) A[i] = h[i];
   if (n < 3 || n * k < hitLenRequired) return;
-  chainRun(c, k, hitLenRequired, A, A, A, 0, n, nullptr, 0, out, dpCounter, errFlags, needScratch, sink, strandBit, true, punt);
+  chainRun(c, k, hitLenRequired, A, A, A, 0, n, nullptr, 0, out, dpCounter, errFlags, needScratch, sink, strandBit, true);
 }
 
 // key of the strand vote: _overlap::operator< with similarity == 0 (SeqSet.hpp:103-127, 1623-1627); smaller = better
@@ -1603,29 +1598,20 @@ __global__ __launch_bounds__(WG) void k_gather_general(ChainArgs P, uint32_t nIt
 // k_dp_dense, added by k_general_finish); groups that need an alignment wider than the register band go to k_chain_big.
 // useSimple: record word 6 = 1 marks a group whose hit list k_near_hits wrote as its chain (groupSimple: no sorts, no LIS, one array -- up
 // to 3 * GENERAL_SMALL hits in the same LDS)
-// PART 0: every group of the list that fits here (rounds 2-4).  Round 5 runs the list twice: PART 1 = the chains of up to GENERAL_SMALL hits
-// (nine in ten multi-diagonal groups: the ~2 000 groups of every read with an indel) in a kernel of their own -- groupSimple needs ONE work
-// array of GENERAL_SMALL entries a lane (8 KB a wavefront instead of 24) and none of the general path's registers, so it runs at several
-// times the 1.5 wavefronts per SIMD the combined kernel's LDS allowed --, PART 2 = the rest.
-template <int PART>
 __global__ __launch_bounds__(64) void k_chain_general(ChainArgs P, uint32_t nItems, int useSimple, const unsigned long long *nDev) {
-  constexpr int ARR = PART == 1 ? GENERAL_SMALL : 3 * GENERAL_SMALL;
-  __shared__ uint32_t sArr[ARR * 64];
+  __shared__ uint32_t sArr[3 * GENERAL_SMALL * 64];
   if (nDev) { if (P.counters[2]) return; nItems = (uint32_t)*nDev; }
   unsigned int dpLocal = 0, genLocal = 0;
   for (uint32_t qb = blockIdx.x * 64; qb < nItems; qb += gridDim.x * 64) {  // (a lane's work arrays are its own: no barrier between the rounds)
   const uint32_t q = qb + threadIdx.x;
   uint32_t nHits = 0xFFFFFFFFu;
   bool simple = false;
-  bool punted = false;  // a chain PART 1 could not finish without an inline alignment (record word 6 = 3): PART 2's
   if (q < nItems) {
     const uint32_t *r0 = P.recs + (uint64_t)P.generalList[q] * P.recStride;
     nHits = r0[4];
-    punted = PART == 2 && useSimple && r0[5] == REC_NEAR_DONE && r0[6] == 3u;
-    simple = useSimple && r0[5] == REC_NEAR_DONE && (r0[6] == 1u || punted);
+    simple = useSimple && r0[5] == REC_NEAR_DONE && r0[6] == 1u;
   }
-  const bool small = simple && !punted && nHits <= GENERAL_SMALL;
-  if (PART == 1 ? small : (!(PART == 2 && small) && (nHits <= GENERAL_SMALL || (simple && nHits <= 3 * GENERAL_SMALL)))) {
+  if (nHits <= GENERAL_SMALL || (simple && nHits <= 3 * GENERAL_SMALL)) {
     const uint32_t gi = P.generalList[q];
     uint32_t *rec = P.recs + (uint64_t)gi * P.recStride;
     const uint32_t re = rec[0] & 0x7FFFFFFFu, allele = rec[1];
@@ -1635,19 +1621,13 @@ __global__ __launch_bounds__(64) void k_chain_general(ChainArgs P, uint32_t nIte
     if (rec[3] == T1K_ARENA_FULL) atomicOr(&P.counters[2], (unsigned long long)ERR_STAGECAP);
     const uint32_t *hh = P.genHits + (rec[3] == T1K_ARENA_FULL ? 0u : rec[3]);
     bool needScratch = false;
-    uint32_t cbuf[PART == 1 ? 12 : 2 * GENERAL_SMALL + 6];  // a candidate needs >= 3 hits (a chain is one candidate)
-    CandOut out{cbuf, 0, 6, PART == 1 ? 2 : GENERAL_SMALL / 3 + 1};
+    uint32_t cbuf[2 * GENERAL_SMALL + 6];  // a candidate needs >= 3 hits
+    CandOut out{cbuf, 0, 6, GENERAL_SMALL / 3 + 1};
     const GapSink sink{P.memo + (uint64_t)re * GAP_CACHE, P.genJobStr, P.counters, re * GAP_CACHE, P.genJobSegCap, T1K_AR_GENJOBS};
-    LaneArr A{sArr + threadIdx.x};
-    bool punt = false;
-    if (PART == 1) groupSimple(hh, n, c, P.k, P.hitLenRequired, A, out, &dpLocal, &P.counters[2], &needScratch, &sink, pass, &punt);
-    else if (simple) groupSimple(hh, n, c, P.k, P.hitLenRequired, A, out, &dpLocal, &P.counters[2], &needScratch, &sink, pass);
-    else {
-      LaneArr B{sArr + GENERAL_SMALL * 64 + threadIdx.x}, C{sArr + 2 * GENERAL_SMALL * 64 + threadIdx.x};
-      groupGeneral(hh, n, c, P.k, P.radius, P.hitLenRequired, A, B, C, nullptr, 0, out, &dpLocal, &P.counters[2], &needScratch, &sink, pass);
-    }
-    if (PART == 1 && punt) rec[6] = 3u;  // (its hit list stays where it is: PART 2 walks the chain again, with the alignment code)
-    else if (needScratch) { const uint32_t b = t1k_arena_append(P.counters, T1K_AR_BIG, P.rareSegCap); if (b != T1K_ARENA_FULL) P.bigStr[b] = gi; }
+    LaneArr A{sArr + threadIdx.x}, B{sArr + GENERAL_SMALL * 64 + threadIdx.x}, C{sArr + 2 * GENERAL_SMALL * 64 + threadIdx.x};
+    if (simple) groupSimple(hh, n, c, P.k, P.hitLenRequired, A, out, &dpLocal, &P.counters[2], &needScratch, &sink, pass);
+    else groupGeneral(hh, n, c, P.k, P.radius, P.hitLenRequired, A, B, C, nullptr, 0, out, &dpLocal, &P.counters[2], &needScratch, &sink, pass);
+    if (needScratch) { const uint32_t b = t1k_arena_append(P.counters, T1K_AR_BIG, P.rareSegCap); if (b != T1K_ARENA_FULL) P.bigStr[b] = gi; }
     else {
       ++genLocal;
       uint32_t base = 0;
@@ -1668,10 +1648,12 @@ __global__ __launch_bounds__(64) void k_chain_general(ChainArgs P, uint32_t nIte
 // K5b': multi-diagonal groups with GENERAL_SMALL < hits <= WAVE_CAP, one wavefront per group.  The quadratic steps of
 // GetOverlapsFromHits (sort by diagonal, nearest-to-dominant filter, sort by allele offset; SeqSet.hpp:1338-1456) are spread
 // over the lanes as rank sorts; the LIS and the chain walk of each diagonal run are done by lane 0 (chainRun).
-__global__ __launch_bounds__(64) void k_chain_wave(ChainArgs P, uint32_t nItems, const unsigned long long *nDev) {
-  extern __shared__ uint32_t sW[];  // A | B | C, WAVE_CAP words each
+// cap / above: this launch takes the groups with above < hits <= cap and has 3 * cap words of LDS (round 5: the list is run twice -- most of
+// these groups hold a few dozen hits, and with room for WAVE_CAP of them a workgroup's 48 KB left three wavefronts on a compute unit)
+__global__ __launch_bounds__(64) void k_chain_wave(ChainArgs P, uint32_t nItems, const unsigned long long *nDev, uint32_t cap, uint32_t above) {
+  extern __shared__ uint32_t sW[];  // A | B | C, cap words each
   if (nDev) { if (P.counters[2]) return; nItems = (uint32_t)*nDev; }
-  uint32_t *A = sW, *B = sW + WAVE_CAP, *C = sW + 2 * WAVE_CAP;
+  uint32_t *A = sW, *B = sW + cap, *C = sW + 2 * cap;
   const int lane = threadIdx.x;
   unsigned int dpLocal = 0, genLocal = 0;
   auto diagOf = [](uint32_t x) { return (int)(x & 0xFFF) - (int)(x >> 12); };
@@ -1681,6 +1663,7 @@ __global__ __launch_bounds__(64) void k_chain_wave(ChainArgs P, uint32_t nItems,
     const uint32_t re = rec[0] & 0x7FFFFFFFu, allele = rec[1];
     const int pass = (rec[0] >> 31) ? 0 : 1;
     const int n = (int)rec[4];
+    if ((uint32_t)n <= above || (uint32_t)n > cap) continue;  // (the other launch's; uniform over the wavefront)
     const bool lost = rec[3] == T1K_ARENA_FULL;
     if (lost && lane == 0) atomicOr(&P.counters[2], (unsigned long long)ERR_STAGECAP);
     const uint32_t *hh = P.genHits + (lost ? 0u : rec[3]);
@@ -2258,15 +2241,16 @@ static int runChainDevice(t1k_ctx *ctx, const ChainArgs &aIn, int nWg, int bigBl
     else hipLaunchKernelGGL(k_gather_general<GROUP_FAST_MAXLEN / 64>, dim3(gatherGrid), dim3(WG), 0, ctx->stream, a, 0u, skipDone, nGen);
     ChainArgs g = a;
     g.generalList = (uint32_t *)countingSort(ctx, a.generalList, (uint32_t)rareCap, GroupSizeKey{(const uint32_t *)a.recs, a.recStride, skipDone}, nGen, eGen);  // groups of similar size side by side
-    static const bool twoParts = getenv("T1K_NO_SIMPLE_KERNEL") == nullptr;
-    if (twoParts && skipDone) {
-      hipLaunchKernelGGL(k_chain_general<1>, dim3(blocks(eGen, 64)), dim3(64), 0, ctx->stream, g, 0u, skipDone, nGen);
-      hipLaunchKernelGGL(k_chain_general<2>, dim3(blocks(eGen, 64)), dim3(64), 0, ctx->stream, g, 0u, skipDone, nGen);
-    } else hipLaunchKernelGGL(k_chain_general<0>, dim3(blocks(eGen, 64)), dim3(64), 0, ctx->stream, g, 0u, skipDone, nGen);
+    hipLaunchKernelGGL(k_chain_general, dim3(blocks(eGen, 64)), dim3(64), 0, ctx->stream, g, 0u, skipDone, nGen);
     const uint64_t eWave = est(T1K_AR_WAVE, rareCap);
     t1k_arena_compact_dev(ctx, T1K_AR_WAVE, a.waveStr, a.rareSegCap, a.waveList, eWave);
     T1K_HIP(ctx, hipFuncSetAttribute((const void *)k_chain_wave, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * WAVE_CAP * 4));
-    hipLaunchKernelGGL(k_chain_wave, dim3((uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(eWave, 2048u))), dim3(64), 3 * WAVE_CAP * 4, ctx->stream, a, 0u, tot + T1K_AR_WAVE);
+    {
+      const uint32_t wgrid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(eWave, 2048u));
+      static const uint32_t smallCap = getenv("T1K_WAVE_SMALL") ? (uint32_t)atoi(getenv("T1K_WAVE_SMALL")) : 512u;  // 0: one launch as in rounds 2-4
+      if (smallCap) hipLaunchKernelGGL(k_chain_wave, dim3(wgrid), dim3(64), 3 * smallCap * 4, ctx->stream, a, 0u, tot + T1K_AR_WAVE, smallCap, 0u);
+      hipLaunchKernelGGL(k_chain_wave, dim3(wgrid), dim3(64), 3 * WAVE_CAP * 4, ctx->stream, a, 0u, tot + T1K_AR_WAVE, (uint32_t)WAVE_CAP, smallCap);
+    }
     const uint64_t eGenJobs = est(T1K_AR_GENJOBS, genJobCap);
     t1k_arena_compact_dev(ctx, T1K_AR_GENJOBS, a.genJobStr, a.genJobSegCap, a.genJobList, eGenJobs);
     t1k_launch_dp_dense_dev(ctx, a, a.genJobList, T1K_AR_GENJOBS, (uint32_t)genJobCap, eGenJobs);
@@ -2400,14 +2384,14 @@ int t1k_run_chain(t1k_ctx *ctx, const ChainArgs &a, int nWg, int bigBlocks, bool
       hipLaunchKernelGGL(k_group_size_keys, dim3((nGen + WG - 1) / WG), dim3(WG), 0, ctx->stream, (const uint32_t *)a.recs, a.recStride, (const uint32_t *)a.generalList, k0, nGen, skipDone);
       if (t1k_sort_pairs(ctx, k0, k1, a.generalList, sorted, nGen, 8) == T1K_OK) g.generalList = sorted;
     }
-    hipLaunchKernelGGL(k_chain_general<0>, dim3((nGen + 63) / 64), dim3(64), 0, ctx->stream, g, nGen, skipDone, NODEV);
+    hipLaunchKernelGGL(k_chain_general, dim3((nGen + 63) / 64), dim3(64), 0, ctx->stream, g, nGen, skipDone, NODEV);
     if ((rc = readCounters(ctx, hc))) return rc;
     const T1kArenaCounts wv = t1k_arena_counts(ctx, T1K_AR_WAVE, a.rareSegCap);
     if (wv.overflow) { hc[2] |= ERR_GROUPCAP; return 0; }
     if (wv.total) {
       t1k_arena_compact(ctx, T1K_AR_WAVE, a.waveStr, a.rareSegCap, a.waveList, wv.maxSeg);
       T1K_HIP(ctx, hipFuncSetAttribute((const void *)k_chain_wave, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * WAVE_CAP * 4));
-      hipLaunchKernelGGL(k_chain_wave, dim3(std::min<uint32_t>((uint32_t)wv.total, 2048u)), dim3(64), 3 * WAVE_CAP * 4, ctx->stream, a, (uint32_t)wv.total, NODEV);
+      hipLaunchKernelGGL(k_chain_wave, dim3(std::min<uint32_t>((uint32_t)wv.total, 2048u)), dim3(64), 3 * WAVE_CAP * 4, ctx->stream, a, (uint32_t)wv.total, NODEV, (uint32_t)WAVE_CAP, 0u);
     }
     if ((rc = readCounters(ctx, hc))) return rc;  // the general kernels register alignments and may hand groups over to the big-scratch kernel
     const T1kArenaCounts gj = t1k_arena_counts(ctx, T1K_AR_GENJOBS, a.genJobSegCap);

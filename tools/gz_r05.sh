@@ -13,7 +13,7 @@ run() {  # label, files, env...
   for i in 1 2; do
     t0=$(now)
     env "$@" T1K_DEBUG_PHASES=1 t1k_amd/bin/genotyper -f $W/hla_g24_s1.0.fa -1 $a -2 $b -s 0.97 -o $W/gz_$label 2> $W/gz_$label.err
-    echo "$label run $i: rc $?, $(( ($(now) - t0) / 1000000 )) ms wall, genotype md5 $(md5sum < $W/gz_${label}_genotype.tsv | cut -c1-8) aligned_1 md5 $(md5sum < $W/gz_${label}_aligned_1.fa | cut -c1-8); $(grep 'read files mapped' $W/gz_$label.err | cut -c1-120) $(grep 'main:' $W/gz_$label.err | cut -c11-80)" >> $LOG
+    echo "$label run $i: rc $?, $(( ($(now) - t0) / 1000000 )) ms wall, genotype md5 $(md5sum < $W/gz_${label}_genotype.tsv | cut -c1-8) aligned_1 md5 $(md5sum < $W/gz_${label}_aligned_1.fa | cut -c1-8); $(grep 'read files mapped' $W/gz_$label.err | cut -c1-120) $(grep "main:" $W/gz_$label.err | cut -c11-80) $(grep "address space" $W/gz_$label.err | cut -c11-300)" >> $LOG
     sleep 15
   done
 }
