@@ -356,7 +356,9 @@ def test_gzip_read_files(built, tmp_path):
 
 
 @pytest.mark.parametrize("case,env", [("cyp_dna_relax_2x150", {}), ("cyp_rna_2x100", {"T1K_FIRST_WINDOW": "64", "T1K_WINDOW": "256", "T1K_BATCH": "32", "T1K_PAIR_BATCH": "64"}),
-                                      ("cyp_dna_relax_2x150", {"T1K_COVERAGE": "eager", "T1K_PIPELINES": "1"})])
+                                      ("cyp_dna_relax_2x150", {"T1K_COVERAGE": "eager", "T1K_PIPELINES": "1"}),
+                                      ("cyp_rna_single", {"T1K_FIRST_WINDOW": "32", "T1K_WINDOW": "128", "T1K_BATCH": "16"}),      # single-end (-u)
+                                      ("kir_synth_relax_2x150", {"T1K_FIRST_WINDOW": "128", "T1K_WINDOW": "512", "T1K_BATCH": "64"})])
 def test_gzip_read_files_streamed_under_the_loop(built, tmp_path, case, env):
     """the .gz fixtures handed to the window loop while they are still being inflated (t1k_reads_open_stream: host/inflate.cpp publishes its
     progress, the records are indexed behind it, windows are cut from what has arrived; ReadFiles.hpp:13,95 / kseq.h:94-150 stream through
@@ -364,7 +366,7 @@ def test_gzip_read_files_streamed_under_the_loop(built, tmp_path, case, env):
     c = goldens.Case(case, str(tmp_path))
     out = os.path.join(str(tmp_path), "gzs")
     r1, r2 = os.path.join(c.dir, "reads_1.fq.gz"), os.path.join(c.dir, "reads_2.fq.gz")
-    args = ["-f", c.ref, "-1", r1, "-2", r2] + c.flags
+    args = ["-f", c.ref] + (["-1", r1, "-2", r2] if c.paired else ["-u", r1]) + c.flags
     e = dict(os.environ, T1K_STREAM_GZ_MIN_MB="0.0001", T1K_DEBUG_PHASES="1", **env)
     r = subprocess.run([GENO] + args + ["-o", out], stderr=subprocess.PIPE, text=True, env=e)
     assert r.returncode == 0, r.stderr
@@ -381,6 +383,12 @@ def test_gzip_read_files_streamed_under_the_loop(built, tmp_path, case, env):
         open(bad, "wb").write(blob)
         r = subprocess.run([GENO, "-f", c.ref, "-1", bad, "-2", r2] + c.flags + ["-o", out + "_bad"], stderr=subprocess.PIPE, text=True, env=e)
         assert r.returncode != 0 and "damaged" in r.stderr, r.stderr
+        blob = open(r1, "rb").read()
+        cut = os.path.join(str(tmp_path), "cut_1.fq.gz")
+        open(cut, "wb").write(blob[:len(blob) * 3 // 5])   # a file that ends in the middle of a block: the loop is already running when the decoder gets there
+        r = subprocess.run([GENO, "-f", c.ref, "-1", cut, "-2", r2] + c.flags + ["-o", out + "_cut"], stderr=subprocess.PIPE, text=True, env=e)
+        assert r.returncode != 0 and "genotyper:" in r.stderr and ("truncated" in r.stderr or "damaged" in r.stderr), r.stderr
+        assert not os.path.exists(out + "_cut_genotype.tsv")
 
 
 def test_gzip_lanes_streamed_under_the_loop(built, tmp_path):
