@@ -385,9 +385,9 @@ def test_gzip_read_files_streamed_under_the_loop(built, tmp_path, case, env):
         assert r.returncode != 0 and "damaged" in r.stderr, r.stderr
         blob = open(r1, "rb").read()
         cut = os.path.join(str(tmp_path), "cut_1.fq.gz")
-        open(cut, "wb").write(blob[:len(blob) * 3 // 5])   # a file that ends in the middle of a block: the loop is already running when the decoder gets there
-        r = subprocess.run([GENO, "-f", c.ref, "-1", cut, "-2", r2] + c.flags + ["-o", out + "_cut"], stderr=subprocess.PIPE, text=True, env=e)
-        assert r.returncode != 0 and "genotyper:" in r.stderr and ("truncated" in r.stderr or "damaged" in r.stderr), r.stderr
+        open(cut, "wb").write(blob[:len(blob) * 3 // 5])   # a file that ends in the middle of its (only) block: nothing of it is ever published, the
+        r = subprocess.run([GENO, "-f", c.ref, "-1", cut, "-2", r2] + c.flags + ["-o", out + "_cut"], stderr=subprocess.PIPE, text=True, env=e)  # whole-file reader reports it
+        assert r.returncode != 0 and "genotyper:" in r.stderr, r.stderr   # (a file cut behind several blocks, i.e. under the running loop: tests/test_host_reads_cpu.py)
         assert not os.path.exists(out + "_cut_genotype.tsv")
 
 
