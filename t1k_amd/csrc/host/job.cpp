@@ -674,7 +674,12 @@ int t1k_job_run_local(t1k_job *job) {
               // (a window that is not kept still holds its read set while it is in flight, and so does the one prepared behind it: what is
               // allocated now covers the windows in flight now, one more of full size may come on top while fragments remain)
               const double transient = perFrag * (double)std::min<uint64_t>(windowFrags, F - N.f1);
-              fits = (double)other + (double)(archivedBytes + open + estimate(N)) + std::max(projectedRows, (double)rowsNow) + coalesceWork + transient <= (double)totalNow;
+              // ... and a reserve the projection does not see: the arenas of the pipelines still grow with the ranges' demand, the runtime needs
+              // device memory of its own (queue scratch, code objects), and the runtime ABORTS the process when it cannot have it -- round 5 saw
+              // two 30 M-pair runs in six end that way at 290 of 309 GB (T1K_ARCHIVE_RESERVE_GB overrides; 4 % of the device, 8 GB at least)
+              static const double reserve = [] { const char *e = getenv("T1K_ARCHIVE_RESERVE_GB"); return e ? atof(e) * 1073741824.0 : -1.0; }();
+              const double keepFree = reserve >= 0 ? reserve : std::max(8e9, 0.04 * (double)totalNow);
+              fits = (double)other + (double)(archivedBytes + open + estimate(N)) + std::max(projectedRows, (double)rowsNow) + coalesceWork + transient + keepFree <= (double)totalNow;
               if (getenv("T1K_DEBUG_ARCHIVE"))
                 fprintf(stderr, "[t1k job] window %u (%u fragments): %llu row entries in the chunks, %llu fragments paired, stats.rows %llu, rows %.1f GB, kept %.1f + open %.1f + this %.1f GB, other %.1f GB, transient %.1f GB -> %s\n",
                         w, N.f1 - N.f0, (unsigned long long)entriesNow, (unsigned long long)sh.pairedFrags, (unsigned long long)job->stats.rows, rowsNow / 1e9, archivedBytes / 1e9, open / 1e9,
