@@ -289,7 +289,7 @@ int t1k_reads_open(const char *const *files1, uint32_t n1, const char *const *fi
   r->ms = nowMs() - t0;
   return T1K_OK;
 }
-int t1k_reads_open_stream(const char *const *files1, uint32_t n1, const char *const *files2, uint32_t n2, int threads, t1k_reads **out) {
+int t1k_reads_open_stream(const char *const *files1, uint32_t n1, const char *const *files2, uint32_t n2, const char *barcodeFile, int threads, t1k_reads **out) {
   if (!out) return T1K_ERR_ARG;
   *out = nullptr;
   if (!files1 || n1 == 0) return T1K_ERR_ARG;
@@ -300,12 +300,12 @@ int t1k_reads_open_stream(const char *const *files1, uint32_t n1, const char *co
     r->in.reset(new ReadInput());
     std::vector<std::string> f1(files1, files1 + n1), f2;
     if (files2) f2.assign(files2, files2 + n2);
-    if (r->in->openStreaming(f1, f2, r->err)) { r->ms = nowMs() - t0; *out = r; return T1K_OK; }
+    if (r->in->openStreaming(f1, f2, barcodeFile ? barcodeFile : "", r->err)) { r->ms = nowMs() - t0; *out = r; return T1K_OK; }
     const bool failed = !r->err.empty();
     if (failed) { r->in.reset(); *out = r; return T1K_ERR_IO; }
     delete r;  // not eligible: opened whole
   }
-  return t1k_reads_open(files1, n1, files2, n2, nullptr, threads, out);
+  return t1k_reads_open(files1, n1, files2, n2, barcodeFile, threads, out);
 }
 const char *t1k_reads_last_error(const t1k_reads *r) { return r ? r->err.c_str() : "no read input"; }
 int t1k_reads_fragments(const t1k_reads *r, uint64_t *nFragments) {
@@ -1689,8 +1689,8 @@ int t1k_genotyper_main(int argc, char **argv) {
   std::thread opener;
   if (!shardInput && !first.empty() && !getenv("T1K_SERIAL_OPEN"))
     opener = std::thread([&] {
-      // (one rank, no barcode file: an ordinary .gz input is handed to the loop while it is still being inflated)
-      if (R == 1 && barcode.empty()) rcOpen = t1k_reads_open_stream(first.data(), (uint32_t)first.size(), paired ? f2.data() : nullptr, (uint32_t)f2.size(), p.threads, &opened);
+      // (one rank: an ordinary .gz input -- the barcode file with it -- is handed to the loop while it is still being inflated)
+      if (R == 1) rcOpen = t1k_reads_open_stream(first.data(), (uint32_t)first.size(), paired ? f2.data() : nullptr, (uint32_t)f2.size(), barcode.empty() ? nullptr : barcode.c_str(), p.threads, &opened);
       else rcOpen = t1k_reads_open(first.data(), (uint32_t)first.size(), paired ? f2.data() : nullptr, (uint32_t)f2.size(), barcode.empty() ? nullptr : barcode.c_str(), p.threads, &opened);
     });
   {

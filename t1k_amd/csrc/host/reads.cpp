@@ -124,11 +124,20 @@ struct ReadInput::Stream {
     std::atomic<uint64_t> crcDone{0};  // text the checker has been over (nothing beyond it may be dropped: ReadInput::release)
     std::string err, path;
     size_t textLen = 0;
-  } mate[2];
-  int nMates = 1;
+    bool fastq = true;   // four-line FASTQ (two-line FASTA otherwise: the barcode file fastq-extractor writes)
+    Side *dst = nullptr;
+  } mate[3];             // the mates, then the barcode file (ReadInput::bc) when there is one
+  int nMates = 1;        // text streams in all
+  bool withBarcode = false;
+  // fragments = records whose barcode is not "missing_barcode" (Genotyper.cpp:376-381): with a barcode file a thread of its own follows the
+  // three indexers and numbers them (frag[] and this counter are what the window loop reads)
+  std::thread fragger;
+  std::atomic<uint64_t> fragments{0};
+  std::atomic<int> fragState{0};
   size_t capRecords = 0;
   bool joined = false;
   ~Stream() {
+    if (fragger.joinable()) fragger.join();
     for (int m = 0; m < nMates; ++m) {
       Mate &M = mate[m];
       if (M.inflater.joinable()) M.inflater.join();
@@ -430,6 +439,7 @@ uint32_t crcStep(uint32_t crc, const void *p, size_t n) {
 
 size_t ReadInput::streamAvail() const {
   if (!stream_) return frag.size();
+  if (stream_->withBarcode) return (size_t)stream_->fragments.load(std::memory_order_acquire);
   uint64_t n = stream_->mate[0].records.load(std::memory_order_acquire);
   if (stream_->nMates > 1) n = std::min<uint64_t>(n, stream_->mate[1].records.load(std::memory_order_acquire));
   return (size_t)n;
@@ -442,23 +452,29 @@ int ReadInput::streamState() const {
     if (a < 0 || c < 0) return -1;
     if (a == 0 || c == 0) all = 0;
   }
+  if (stream_->withBarcode && stream_->fragState.load(std::memory_order_acquire) == 0) all = 0;
   return all;
 }
 void ReadInput::streamWait(size_t records) const {
   while (streamAvail() < records && streamState() == 0) std::this_thread::sleep_for(std::chrono::microseconds(300));
 }
 
-bool ReadInput::openStreaming(const std::vector<std::string> &files1, const std::vector<std::string> &files2, std::string &err) {
+bool ReadInput::openStreaming(const std::vector<std::string> &files1, const std::vector<std::string> &files2, const std::string &barcodeFile, std::string &err) {
   err.clear();
   if (files1.empty() || (!files2.empty() && files2.size() != files1.size())) return false;
   static const size_t minBytes = [] { const char *e = getenv("T1K_STREAM_GZ_MIN_MB"); return (size_t)((e ? atof(e) : 32.0) * 1048576.0); }();
   std::unique_ptr<Stream> S(new Stream());
-  S->nMates = files2.empty() ? 1 : 2;
-  size_t minRec = ~(size_t)0, estText[2] = {0, 0};
+  const int nReadMates = files2.empty() ? 1 : 2;
+  S->withBarcode = !barcodeFile.empty();
+  S->nMates = nReadMates + (S->withBarcode ? 1 : 0);
+  const std::vector<std::string> bcFiles{barcodeFile};
+  size_t minRec = ~(size_t)0, estText[3] = {0, 0, 0};
   for (int m = 0; m < S->nMates; ++m) {
     Stream::Mate &M = S->mate[m];
+    const bool isBc = m >= nReadMates;
+    M.dst = isBc ? &bc : &side[m];
     size_t compressed = 0;
-    for (const std::string &path : m ? files2 : files1) {
+    for (const std::string &path : isBc ? bcFiles : (m ? files2 : files1)) {
       int fd = ::open(path.c_str(), O_RDONLY);
       if (fd < 0) return false;  // (the whole-file path reports it)
       struct stat st;
@@ -481,7 +497,7 @@ bool ReadInput::openStreaming(const std::vector<std::string> &files1, const std:
       estText[m] += plausible ? (size_t)isize : f.len * 48;
       M.cap += std::max<size_t>(plausible ? (size_t)isize : 0, f.len * 48) + 4096;
     }
-    if (compressed < minBytes) return false;
+    if (!isBc && compressed < minBytes) return false;
     M.path = M.srcs[0].path;
     // a look at the head of the first file's text: four-line FASTQ?  how short can a record be?  (decoded again by the stream: 4 MB are nothing)
     {
@@ -493,17 +509,19 @@ bool ReadInput::openStreaming(const std::vector<std::string> &files1, const std:
       (void)gzInflateAll(z, M.srcs[0].len, head.data(), head.size(), &pg, &n, nullptr, nullptr, e);  // (ends with "more text than the range holds" for any real file)
       n = (size_t)pg.produced.load();
       const char *p = (const char *)head.data(), *end = p + n;
-      if (n < 16 || *p != '@') return false;
+      if (n < 16 || (*p != '@' && !(isBc && *p == '>'))) return false;   // reads: four-line FASTQ; the barcode file may be two-line FASTA
+      M.fastq = *p == '@';
+      const int per = M.fastq ? 4 : 2;
       size_t recs = 0;
       while (p < end) {
-        // a whole record has four line ends inside what was decoded
+        // a whole record has all its line ends inside what was decoded
         const char *q = p;
         int lines = 0;
-        while (lines < 4 && q < end) { const char *nl = (const char *)memchr(q, '\n', (size_t)(end - q)); if (!nl) { q = end + 1; break; } q = nl + 1; ++lines; }
-        if (lines < 4 || q > end) break;
+        while (lines < per && q < end) { const char *nl = (const char *)memchr(q, '\n', (size_t)(end - q)); if (!nl) { q = end + 1; break; } q = nl + 1; ++lines; }
+        if (lines < per || q > end) break;
         RecFields f;
-        if (strictRecordFields(p, q, true, f) != q) return false;
-        minRec = std::min(minRec, (size_t)(q - p));
+        if (strictRecordFields(p, q, M.fastq, f) != q) return false;
+        if (!isBc) minRec = std::min(minRec, (size_t)(q - p));
         ++recs;
         p = q;
       }
@@ -516,7 +534,8 @@ bool ReadInput::openStreaming(const std::vector<std::string> &files1, const std:
     Stream::Mate &M = S->mate[m];
     void *out = mmap(nullptr, M.cap, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
     if (out == MAP_FAILED) {
-      if (m == 1) for (auto it = blobs_.begin(); it != blobs_.end(); ++it) if (it->map == (void *)S->mate[0].text) { munmap(it->map, it->len); blobs_.erase(it); break; }
+      for (int e = 0; e < m; ++e)
+        for (auto it = blobs_.begin(); it != blobs_.end(); ++it) if (it->map == (void *)S->mate[e].text) { munmap(it->map, it->len); blobs_.erase(it); break; }
       return false;
     }
     bigBlockAdvise(out, M.cap);  // huge pages: 3 GB of text are 0.5 s of first touches and 0.25 s of exit in 4 KB pages (t1k_host.h)
@@ -526,19 +545,19 @@ bool ReadInput::openStreaming(const std::vector<std::string> &files1, const std:
   }
   // tables for twice as many records as the shortest record of the heads would make of the text
   size_t capRecords = 0;
-  for (int m = 0; m < S->nMates; ++m) capRecords = std::max(capRecords, estText[m] / std::max<size_t>(8, minRec / 2) + 4096);
+  for (int m = 0; m < nReadMates; ++m) capRecords = std::max(capRecords, estText[m] / std::max<size_t>(8, minRec / 2) + 4096);
   if (capRecords > 0xFFFFFF00ull) return false;  // (fragment numbers are 32 bits)
   S->capRecords = capRecords;
-  paired = S->nMates == 2;
-  hasBarcode = false;
-  for (int m = 0; m < S->nMates; ++m) { side[m].seqP.resize(capRecords); side[m].idP.resize(capRecords); side[m].seqL.resize(capRecords); side[m].idL.resize(capRecords); }
+  paired = nReadMates == 2;
+  hasBarcode = S->withBarcode;
+  for (int m = 0; m < S->nMates; ++m) { Side &d = *S->mate[m].dst; d.seqP.resize(capRecords); d.idP.resize(capRecords); d.seqL.resize(capRecords); d.idL.resize(capRecords); }
   frag.resize(capRecords);
   maxLen = 0;
   streaming = true;
   Stream *sp = S.get();
   for (int m = 0; m < S->nMates; ++m) {
     Stream::Mate *M = &S->mate[m];
-    Side *sd = &side[m];
+    Side *sd = M->dst;
     M->inflater = std::thread([M] {
       size_t at = 0;
       for (size_t i = 0; i < M->srcs.size(); ++i) {
@@ -581,8 +600,9 @@ bool ReadInput::openStreaming(const std::vector<std::string> &files1, const std:
         if (upto == done) std::this_thread::sleep_for(std::chrono::microseconds(500));
       }
     });
-    const bool first = m == 0;
-    M->indexer = std::thread([this, sp, M, sd, first] {
+    const bool first = m == 0 && !S->withBarcode;   // (with a barcode file the fragments are numbered by the thread below)
+    const bool isRead = m < nReadMates;
+    M->indexer = std::thread([this, sp, M, sd, first, isRead] {
       const size_t capR = sp->capRecords;
       uint64_t n = 0;
       size_t recStart = 0, scan = 0;
@@ -590,11 +610,11 @@ bool ReadInput::openStreaming(const std::vector<std::string> &files1, const std:
       auto fail = [&](const std::string &why) { M->err = M->err.empty() ? M->path + ": " + why : M->err; M->state.store(-1, std::memory_order_release); };
       auto emit = [&](const char *b, const char *e) -> bool {
         RecFields f;
-        if (strictRecordFields(b, e, true, f) != e) { fail("a record is not in the four-line FASTQ layout the streaming reader follows (T1K_STREAM_GZ=0 reads the file whole)"); return false; }
+        if (strictRecordFields(b, e, M->fastq, f) != e) { fail("a record is not in the four-line FASTQ (barcodes: or two-line FASTA) layout the streaming reader follows (T1K_STREAM_GZ=0 reads the file whole)"); return false; }
         if (n >= capR) { fail("more records than the streaming reader sized its tables for (T1K_STREAM_GZ=0 reads the file whole)"); return false; }
         sd->seqP[n] = f.seq; sd->seqL[n] = (uint32_t)f.seqLen; sd->idP[n] = f.id; sd->idL[n] = (uint16_t)f.idLen;
         if (first) frag[n] = (uint32_t)n;
-        mx = std::max(mx, (int)f.seqLen);
+        if (isRead) mx = std::max(mx, (int)f.seqLen);
         ++n;
         return true;
       };
@@ -620,7 +640,7 @@ bool ReadInput::openStreaming(const std::vector<std::string> &files1, const std:
           const char *nl = (const char *)memchr(M->text + scan, '\n', have - scan);
           if (!nl) { scan = have; break; }
           scan = (size_t)(nl - M->text) + 1;
-          if (++lines == 4) {
+          if (++lines == (M->fastq ? 4 : 2)) {
             if (!emit(M->text + recStart, M->text + scan)) return;
             recStart = scan; lines = 0;
             if ((n & 4095) == 0) {
@@ -655,6 +675,31 @@ bool ReadInput::openStreaming(const std::vector<std::string> &files1, const std:
       }
     });
   }
+  if (sp->withBarcode)
+    sp->fragger = std::thread([this, sp] {
+      uint64_t done = 0, nf = 0;
+      for (;;) {
+        int st = 1;
+        uint64_t have = ~0ull;
+        for (int m = 0; m < sp->nMates; ++m) {
+          const int a = sp->mate[m].state.load(std::memory_order_acquire);  // (before the count: a finished indexer's count is final)
+          have = std::min<uint64_t>(have, sp->mate[m].records.load(std::memory_order_acquire));
+          if (a < 0) { sp->fragState.store(-1, std::memory_order_release); return; }
+          if (a == 0) st = 0;
+        }
+        const uint64_t before = nf;
+        for (; done < have; ++done)
+          if (!(bc.seqL[done] == 15 && !memcmp(bc.seqP[done], "missing_barcode", 15))) frag[nf++] = (uint32_t)done;
+        if (nf != before) sp->fragments.store(nf, std::memory_order_release);
+        if (st == 1) {
+          uint64_t all = ~0ull;
+          for (int m = 0; m < sp->nMates; ++m) all = std::min<uint64_t>(all, sp->mate[m].records.load(std::memory_order_acquire));
+          if (done >= all) { sp->fragState.store(1, std::memory_order_release); return; }
+          continue;
+        }
+        if (nf == before) std::this_thread::sleep_for(std::chrono::microseconds(200));
+      }
+    });
   stream_ = std::move(S);
   return true;
 }
@@ -674,10 +719,13 @@ bool ReadInput::streamFinish(std::string &err) {
     if (M.state.load() < 0 || M.pg.state.load() < 0) { err = M.err.empty() ? M.path + ": cannot read the file" : M.err; return false; }
     if (M.crcState.load() < 0) { err = M.path + ": the file is damaged (CRC check of the inflated text failed)"; return false; }
   }
+  if (S.fragger.joinable()) S.fragger.join();
   const size_t n = (size_t)S.mate[0].records.load();
-  if (S.nMates == 2 && (size_t)S.mate[1].records.load() != n) { err = "mate files hold different numbers of reads"; return false; }
-  for (int m = 0; m < S.nMates; ++m) { side[m].seqP.resize(n); side[m].idP.resize(n); side[m].seqL.resize(n); side[m].idL.resize(n); }
-  frag.resize(n);
+  const int nReadMates = S.nMates - (S.withBarcode ? 1 : 0);
+  if (nReadMates == 2 && (size_t)S.mate[1].records.load() != n) { err = "mate files hold different numbers of reads"; return false; }
+  if (S.withBarcode && (size_t)S.mate[S.nMates - 1].records.load() != n) { err = "barcode file and read file hold different numbers of records"; return false; }
+  for (int m = 0; m < S.nMates; ++m) { Side &d = *S.mate[m].dst; d.seqP.resize(n); d.idP.resize(n); d.seqL.resize(n); d.idL.resize(n); }
+  frag.resize(S.withBarcode ? (size_t)S.fragments.load() : n);
   maxLen = streamMaxLen.load();
   // the unused tail of the text reservations goes back (the blobs keep what holds text)
   for (int m = 0; m < S.nMates; ++m) {
@@ -687,7 +735,8 @@ bool ReadInput::streamFinish(std::string &err) {
       if (b.map == (void *)M.text && keep < b.len) { munmap((char *)b.map + keep, b.len - keep); b.len = keep; }
   }
   if (getenv("T1K_DEBUG_PHASES"))
-    fprintf(stderr, "[t1k job] gzip read files streamed: %zu records per mate, %zu + %zu bytes of text, tables sized for %zu records\n", n, S.mate[0].textLen, S.nMates == 2 ? S.mate[1].textLen : (size_t)0, S.capRecords);
+    fprintf(stderr, "[t1k job] gzip read files streamed: %zu records per mate, %zu + %zu bytes of text%s, tables sized for %zu records\n", n, S.mate[0].textLen, nReadMates == 2 ? S.mate[1].textLen : (size_t)0,
+            S.withBarcode ? " + the barcode file" : "", S.capRecords);
   return true;
 }
 
@@ -906,7 +955,8 @@ void ReadInput::release(size_t recLo, size_t recHi) {
     const size_t known = streaming ? std::min(sd->idP.size(), streamAvail()) : sd->idP.size();
     const char *end1 = recHi < known && blobOf(sd->idP[recHi]) == b1 ? sd->idP[recHi] - 1 : (anon ? last : (const char *)b1->map + b1->len);
     if (stream_ && anon) {  // ... and the CRC checker must have been over it (it runs far ahead of the loop; with zlib's routine it may not)
-      const int mate = sd == &side[1] ? 1 : 0;
+      int mate = 0;
+      for (int m = 0; m < stream_->nMates; ++m) if (stream_->mate[m].dst == sd) mate = m;
       const char *checked = stream_->mate[mate].text + stream_->mate[mate].crcDone.load(std::memory_order_acquire);
       if (end1 > checked) end1 = checked;
       if (end1 <= first) continue;

@@ -80,7 +80,7 @@ struct ReadInput {
   // a thread of its own, a second thread indexes the records behind it and a third runs the CRC over the text; the tables are sized to an
   // upper bound of the record count (nFrag() while the stream runs) and the job's window loop takes records as they are published
   // (streamAvail).  streamFinish trims the tables to what was found.  false with err empty = not eligible: the caller opens the files whole.
-  bool openStreaming(const std::vector<std::string> &files1, const std::vector<std::string> &files2, std::string &err);
+  bool openStreaming(const std::vector<std::string> &files1, const std::vector<std::string> &files2, const std::string &barcodeFile, std::string &err);
   bool streaming = false;      // opened by openStreaming and not finished yet: nFrag() / nAll() are the upper bound
   size_t streamAvail() const;  // records indexed in every mate so far (their table entries may be read)
   int streamState() const;     // 0 running, 1 every thread finished, -1 failed

@@ -13,6 +13,7 @@ static void line(FILE *f, const ReadInput &in, size_t i) {
   const uint32_t r = in.frag[i];
   fprintf(f, "%.*s\t%.*s", (int)in.side[0].idL[r], in.side[0].idP[r], (int)in.side[0].seqL[r], in.side[0].seqP[r]);
   if (in.paired) fprintf(f, "\t%.*s\t%.*s", (int)in.side[1].idL[r], in.side[1].idP[r], (int)in.side[1].seqL[r], in.side[1].seqP[r]);
+  if (in.hasBarcode) fprintf(f, "\t%.*s", (int)in.bc.seqL[r], in.bc.seqP[r]);
   fputc('\n', f);
 }
 int main(int argc, char **argv) {
@@ -24,7 +25,8 @@ int main(int argc, char **argv) {
   std::string err;
   {
     ReadInput whole;
-    if (!whole.open(f1, f2, "", 4, err)) { printf("whole: ERROR %s\n", err.c_str()); }
+    const char *bcEnv = getenv("HARNESS_BARCODE");
+    if (!whole.open(f1, f2, bcEnv ? bcEnv : "", 4, err)) { printf("whole: ERROR %s\n", err.c_str()); }
     else {
       FILE *f = fopen((out + "_whole.tsv").c_str(), "w");
       for (size_t i = 0; i < whole.nFrag(); ++i) line(f, whole, i);
@@ -34,7 +36,9 @@ int main(int argc, char **argv) {
   }
   ReadInput st;
   err.clear();
-  if (!st.openStreaming(f1, f2, err)) { printf("stream: %s\n", err.empty() ? "not eligible" : ("ERROR " + err).c_str()); return err.empty() ? 0 : 1; }
+  const char *bcEnv = getenv("HARNESS_BARCODE");
+  const std::string bcFile = bcEnv ? bcEnv : "";
+  if (!st.openStreaming(f1, f2, bcFile, err)) { printf("stream: %s\n", err.empty() ? "not eligible" : ("ERROR " + err).c_str()); return err.empty() ? 0 : 1; }
   const size_t bound = st.nFrag();
   FILE *f = fopen((out + "_stream.tsv").c_str(), "w");
   size_t done = 0, pieces = 0;

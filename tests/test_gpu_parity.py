@@ -358,7 +358,8 @@ def test_gzip_read_files(built, tmp_path):
 @pytest.mark.parametrize("case,env", [("cyp_dna_relax_2x150", {}), ("cyp_rna_2x100", {"T1K_FIRST_WINDOW": "64", "T1K_WINDOW": "256", "T1K_BATCH": "32", "T1K_PAIR_BATCH": "64"}),
                                       ("cyp_dna_relax_2x150", {"T1K_COVERAGE": "eager", "T1K_PIPELINES": "1"}),
                                       ("cyp_rna_single", {"T1K_FIRST_WINDOW": "32", "T1K_WINDOW": "128", "T1K_BATCH": "16"}),      # single-end (-u)
-                                      ("kir_synth_relax_2x150", {"T1K_FIRST_WINDOW": "128", "T1K_WINDOW": "512", "T1K_BATCH": "64"})])
+                                      ("kir_synth_relax_2x150", {"T1K_FIRST_WINDOW": "128", "T1K_WINDOW": "512", "T1K_BATCH": "64"}),
+                                      ("hla_synth_2x150", {"T1K_FIRST_WINDOW": "64", "T1K_WINDOW": "256", "T1K_BATCH": "32"})])          # with a barcode file (.fa.gz)
 def test_gzip_read_files_streamed_under_the_loop(built, tmp_path, case, env):
     """the .gz fixtures handed to the window loop while they are still being inflated (t1k_reads_open_stream: host/inflate.cpp publishes its
     progress, the records are indexed behind it, windows are cut from what has arrived; ReadFiles.hpp:13,95 / kseq.h:94-150 stream through
@@ -367,11 +368,15 @@ def test_gzip_read_files_streamed_under_the_loop(built, tmp_path, case, env):
     out = os.path.join(str(tmp_path), "gzs")
     r1, r2 = os.path.join(c.dir, "reads_1.fq.gz"), os.path.join(c.dir, "reads_2.fq.gz")
     args = ["-f", c.ref] + (["-1", r1, "-2", r2] if c.paired else ["-u", r1]) + c.flags
+    if c.bc:
+        args += ["--barcode", os.path.join(c.dir, "barcodes.fa.gz")]   # streamed beside the mates; fragments = records with a barcode
     e = dict(os.environ, T1K_STREAM_GZ_MIN_MB="0.0001", T1K_DEBUG_PHASES="1", **env)
     r = subprocess.run([GENO] + args + ["-o", out], stderr=subprocess.PIPE, text=True, env=e)
     assert r.returncode == 0, r.stderr
     assert "gzip read files streamed" in r.stderr, r.stderr      # the streaming reader did run
     _golden_files_equal(c, out)
+    if c.bc:
+        assert open(out + "_aligned_bc.fa").read() == c.expected("aligned_bc.fa")
     found = [l for l in r.stderr.splitlines() if "Found " in l and "read fragments" in l]
     whole = subprocess.run([GENO] + args + ["-o", out + "_w"], stderr=subprocess.PIPE, text=True, env=dict(os.environ, T1K_STREAM_GZ="0"))
     assert whole.returncode == 0 and "gzip read files streamed" not in whole.stderr

@@ -136,8 +136,11 @@ def stream_harness(tmp_path_factory):
     return exe
 
 
-def _stream(exe, prefix, files, min_mb="0.0001", per_mate=1):
-    r = subprocess.run([exe, prefix, str(per_mate)] + files, stdout=subprocess.PIPE, text=True, env=dict(os.environ, T1K_STREAM_GZ_MIN_MB=min_mb))
+def _stream(exe, prefix, files, min_mb="0.0001", per_mate=1, barcode=None):
+    env = dict(os.environ, T1K_STREAM_GZ_MIN_MB=min_mb)
+    if barcode:
+        env["HARNESS_BARCODE"] = barcode
+    r = subprocess.run([exe, prefix, str(per_mate)] + files, stdout=subprocess.PIPE, text=True, env=env)
     return r.returncode, r.stdout
 
 
@@ -171,6 +174,39 @@ def test_streamed_gz_several_files_per_mate(stream_harness, read_sets, tmp_path)
     assert open(str(tmp_path / "l_whole.tsv"), "rb").read() == open(str(tmp_path / "l_stream.tsv"), "rb").read()
     assert "72352 fragments" in out.split("stream:")[1], out   # 30000 + 12345 + 7 + 30000
     rc, out = _stream(stream_harness, str(tmp_path / "u"), f[:4] + f[4:6], per_mate=4)   # mates with different numbers of files: not this reader's case
+    assert rc == 0 and "not eligible" in out, out
+
+
+def test_streamed_gz_with_a_barcode_file(stream_harness, read_sets, tmp_path):
+    """a barcode file (two-line FASTA as fastq-extractor writes it, or FASTQ) streamed beside the mates: fragments are the records whose
+    barcode is not "missing_barcode" (Genotyper.cpp:376-381), numbered by a thread of their own behind the three indexers"""
+    import gzip
+    import random
+    rnd = random.Random(9)
+    n = 30000
+    lines = []
+    for i in range(n):
+        b = "missing_barcode" if rnd.random() < 0.2 else "".join(rnd.choice("ACGT") for _ in range(16))
+        lines.append(">r%d\n%s\n" % (i, b))
+    f = [_gz(os.path.join(read_sets, "a_%s.fq" % m), str(tmp_path / ("a_%s.fq.gz" % m))) for m in ("1", "2")]
+    for kind in ("fa", "fq"):
+        text = "".join(lines) if kind == "fa" else "".join(l.replace(">", "@", 1) + "+\n" + "I" * (len(l.split("\n")[1])) + "\n" for l in lines)
+        bcp = str(tmp_path / ("bc.%s.gz" % kind))
+        with gzip.open(bcp, "wb") as g:
+            g.write(text.encode())
+        rc, out = _stream(stream_harness, str(tmp_path / ("b" + kind)), f, barcode=bcp)
+        assert rc == 0 and "ERROR" not in out and "not eligible" not in out, out
+        assert open(str(tmp_path / ("b%s_whole.tsv" % kind)), "rb").read() == open(str(tmp_path / ("b%s_stream.tsv" % kind)), "rb").read()
+        kept = sum(1 for l in lines if "missing_barcode" not in l)
+        assert ("%d fragments" % kept) in out.split("stream:")[1], out
+    # a barcode file with fewer records than the mates: an error at the end of the stream, as for files opened whole
+    with gzip.open(str(tmp_path / "short.fa.gz"), "wb") as g:
+        g.write("".join(lines[:n - 5]).encode())
+    rc, out = _stream(stream_harness, str(tmp_path / "bs"), f, barcode=str(tmp_path / "short.fa.gz"))
+    assert rc == 1 and "different numbers of records" in out, out
+    # a plain (not compressed) barcode file beside .gz mates: opened whole
+    open(str(tmp_path / "plain.fa"), "w").write("".join(lines))
+    rc, out = _stream(stream_harness, str(tmp_path / "bp"), f, barcode=str(tmp_path / "plain.fa"))
     assert rc == 0 and "not eligible" in out, out
 
 
