@@ -105,6 +105,7 @@ def lib():
     L.t1k_pool_release.argtypes = []
     L.t1k_job_load_reads_multi.argtypes = [vp, C.POINTER(C.c_char_p), C.c_uint32, C.POINTER(C.c_char_p), C.c_uint32, C.c_char_p]
     L.t1k_reads_open.argtypes = [C.POINTER(C.c_char_p), C.c_uint32, C.POINTER(C.c_char_p), C.c_uint32, C.c_char_p, C.c_int, C.POINTER(vp)]
+    L.t1k_reads_open_stream.argtypes = [C.POINTER(C.c_char_p), C.c_uint32, C.POINTER(C.c_char_p), C.c_uint32, C.c_char_p, C.c_int, C.POINTER(vp)]
     L.t1k_reads_last_error.argtypes = [vp]
     L.t1k_reads_last_error.restype = C.c_char_p
     L.t1k_reads_fragments.argtypes = [vp, u64p]
@@ -367,13 +368,15 @@ class Reads:
     them while Job(...) parses the reference and brings the contexts up (ctypes releases the GIL for both calls); Job.attach_reads
     takes the input over.  f1 / f2 / barcode as in Job.load_reads."""
 
-    def __init__(self, f1, f2=None, barcode=None, threads=0):
+    def __init__(self, f1, f2=None, barcode=None, threads=0, stream=False):
+        """stream=True: t1k_reads_open_stream -- ordinary .gz files are handed to Job.run while they are still being inflated"""
         l1 = [f1] if isinstance(f1, str) else list(f1)
         l2 = [] if not f2 else ([f2] if isinstance(f2, str) else list(f2))
         a1 = (C.c_char_p * len(l1))(*[x.encode() for x in l1])
         a2 = (C.c_char_p * len(l2))(*[x.encode() for x in l2]) if l2 else None
         h = C.c_void_p()
-        rc = lib().t1k_reads_open(a1, len(l1), a2, len(l2), barcode.encode() if barcode else None, threads, C.byref(h))
+        opener = lib().t1k_reads_open_stream if stream else lib().t1k_reads_open
+        rc = opener(a1, len(l1), a2, len(l2), barcode.encode() if barcode else None, threads, C.byref(h))
         if rc != 0:
             msg = lib().t1k_reads_last_error(h).decode() if h else "bad arguments"
             if h:

@@ -418,6 +418,31 @@ def test_gzip_lanes_streamed_under_the_loop(built, tmp_path):
     _golden_files_equal(c, out)
 
 
+def test_streamed_reads_through_the_c_abi_and_a_second_run(built, tmp_path):
+    """t1k_reads_open_stream + t1k_job_attach_reads + t1k_job_run from a library caller: the same tables as the input opened whole; the caller's
+    text stays resident (only the executables drop it), so the job can run again; t1k_reads_fragments waits for the stream's end"""
+    os.environ["T1K_STREAM_GZ_MIN_MB"] = "0.0001"   # (read once, at the first streamed open of this process)
+    c = goldens.Case("cyp_rna_2x100", str(tmp_path))
+    r1, r2 = os.path.join(c.dir, "reads_1.fq.gz"), os.path.join(c.dir, "reads_2.fq.gz")
+    texts = []
+    job = t1k_amd.Job(c.ref, ref_seq_similarity=0.97)
+    job.load_reads(r1, r2)
+    job.run()
+    texts.append((job.genotype_text(), job.counts()))
+    job.close()
+    rd = t1k_amd.Reads(r1, r2, stream=True)
+    assert rd.fragments() == texts[0][1]["fragments"]      # (waits for the end of the stream)
+    rd.close()
+    job = t1k_amd.Job(c.ref, ref_seq_similarity=0.97)
+    job.attach_reads(t1k_amd.Reads(r1, r2, stream=True))
+    job.run()
+    texts.append((job.genotype_text(), job.counts()))
+    job.run()                                              # the text is still there
+    texts.append((job.genotype_text(), job.counts()))
+    job.close()
+    assert texts[0] == texts[1] == texts[2]
+
+
 def test_reads_opened_beside_job_creation(built, tmp_path):
     """t1k_reads_open on a second thread while t1k_job_create runs, then t1k_job_attach_reads (what the executable and bench.py do) leaves
     the job as t1k_job_load_reads does; the executable's serial order (T1K_SERIAL_OPEN=1) writes the same files; a failed open arrives
