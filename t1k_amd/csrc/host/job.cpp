@@ -577,17 +577,18 @@ int t1k_job_run_local(t1k_job *job) {
       void *p = nullptr; size_t cap = 0; bool pinned = false;
       ~Raw() { drop(); }
       void drop() { if (pinned) t1k_pinned_free(p); else free(p); p = nullptr; cap = 0; }
-      void *need(size_t bytes) {
+      void *need(size_t bytes, bool exact = false) {
         if (bytes <= cap) return p;
         drop();
         static const bool noPin = getenv("T1K_NO_PINNED_TEXT") != nullptr;
-        p = noPin ? nullptr : t1k_pinned_alloc(bytes);
+        p = noPin ? nullptr : (exact ? t1k_pinned_alloc_exact(bytes) : t1k_pinned_alloc(bytes));
         pinned = p != nullptr;
         if (!p) p = malloc(bytes);
         cap = p ? bytes : 0;
         return p;
       }
-    } offs[2], stage;
+    } offs[2], stage[3];  // (the three staging slots are page-locked one by one, when a window first needs them: a fresh process pays ~0.1 s per 400 MB it pins,
+                          // and its first window -- the GPU waits for it -- fills one slot)
     // size of window w (sh.m held): what can be prepared while the GPU works off the windows that are ready but not done
     auto windowSize = [&](uint32_t w) -> uint64_t {
       uint64_t size = firstWindow;
@@ -747,8 +748,6 @@ int t1k_job_run_local(t1k_job *job) {
       // text instead was as fast for a process that keeps the buffer -- and 0.4 s slower for the executable, which pins it once.)
       static const size_t slotBytes = [] { const char *e = getenv("T1K_STAGE_MB"); return (size_t)std::max(1, e ? atoi(e) : 96) << 20; }();
       const int nSlots = 3;
-      char *ring = (char *)stage.need(nSlots * slotBytes);
-      if (!ring) { fail(T1K_ERR_DEVICE, "window preparation: out of host memory"); return; }
       t1k_ctx *rd = job->reader[W.slot];
       int r = t1k_reads_upload_begin(rd, ne, total, (int)maxLen);
       if (r == T1K_OK) r = t1k_reads_upload_piece(rd, 1, off, 0, ((uint64_t)ne + 1) * 8, 3);
@@ -764,7 +763,8 @@ int t1k_job_run_local(t1k_job *job) {
         const size_t i1 = lo;
         const int slot = (int)(nPieces % nSlots);
         if ((r = t1k_reads_upload_wait(rd, slot)) != T1K_OK) break;
-        char *dst = ring + (size_t)slot * slotBytes;
+        char *dst = (char *)stage[slot].need(slotBytes, true);
+        if (!dst) { fail(T1K_ERR_DEVICE, "window preparation: out of host memory"); return; }
         const double tg = nowMs();
         parallelRanges(i1 - i0, T, [&](int, size_t b, size_t e) {
           for (size_t i = i0 + b; i < i0 + e; ++i) {
