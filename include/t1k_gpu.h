@@ -261,8 +261,6 @@ uint64_t t1k_pool_release(void);
  * streams' small copies wait behind its pieces.  NULL when the memory cannot be pinned (the caller falls back to malloc).  No
  * counterpart in the reference (host-only program). */
 void *t1k_pinned_alloc(uint64_t bytes);
-/* ... of exactly that size (t1k_pinned_alloc leaves room for the array to grow): blocks of one fixed size, e.g. staging slots */
-void *t1k_pinned_alloc_exact(uint64_t bytes);
 void t1k_pinned_free(void *p);
 int t1k_reads_share(t1k_ctx *dst, const t1k_ctx *src);
 /* the same with a choice of the overlap-store slot (0 or 1) dst writes its lists to, emptied first if resetStore != 0: a job

@@ -577,18 +577,18 @@ int t1k_job_run_local(t1k_job *job) {
       void *p = nullptr; size_t cap = 0; bool pinned = false;
       ~Raw() { drop(); }
       void drop() { if (pinned) t1k_pinned_free(p); else free(p); p = nullptr; cap = 0; }
-      void *need(size_t bytes, bool exact = false) {
+      void *need(size_t bytes) {
         if (bytes <= cap) return p;
         drop();
         static const bool noPin = getenv("T1K_NO_PINNED_TEXT") != nullptr;
-        p = noPin ? nullptr : (exact ? t1k_pinned_alloc_exact(bytes) : t1k_pinned_alloc(bytes));
+        p = noPin ? nullptr : t1k_pinned_alloc(bytes);
         pinned = p != nullptr;
         if (!p) p = malloc(bytes);
         cap = p ? bytes : 0;
         return p;
       }
-    } offs[2], stage[3];  // (the three staging slots are page-locked one by one, when a window first needs them: a fresh process pays ~0.1 s per 400 MB it pins,
-                          // and its first window -- the GPU waits for it -- fills one slot)
+    } offs[2], stage;     // (the three staging slots are ONE block, page-locked when the first window is prepared: pinning them one by one as they are first
+                          // filled -- the first window fills one -- was tried in round 5 and met a 4.5 s stall of a later window's first piece in one cold run)
     // size of window w (sh.m held): what can be prepared while the GPU works off the windows that are ready but not done
     auto windowSize = [&](uint32_t w) -> uint64_t {
       uint64_t size = firstWindow;
@@ -614,7 +614,9 @@ int t1k_job_run_local(t1k_job *job) {
       if (gzStream) {
         // the window the loop's own rule asks for, if the stream has got that far; what is there (a quarter of a first window at least) when
         // the GPU has nothing left to work on; all that is left at the stream's end (and when the window table is nearly full)
-        const uint64_t least = fNext + std::max<uint32_t>(16384u, firstWindow / 4);
+        // (the FIRST window waits for its full size: the stream has been running since before the contexts came up and is far past it by the time
+        // this thread asks; windows cut smaller than the loop's own first window put its growth rule on a path it was not tuned for)
+        const uint64_t least = fNext + (w == 0 ? firstWindow : std::max<uint32_t>(16384u, firstWindow / 4));
         for (;;) {
           const int st = in.streamState();
           have = in.streamAvail();
@@ -748,6 +750,8 @@ int t1k_job_run_local(t1k_job *job) {
       // text instead was as fast for a process that keeps the buffer -- and 0.4 s slower for the executable, which pins it once.)
       static const size_t slotBytes = [] { const char *e = getenv("T1K_STAGE_MB"); return (size_t)std::max(1, e ? atoi(e) : 96) << 20; }();
       const int nSlots = 3;
+      char *ring = (char *)stage.need(nSlots * slotBytes);
+      if (!ring) { fail(T1K_ERR_DEVICE, "window preparation: out of host memory"); return; }
       t1k_ctx *rd = job->reader[W.slot];
       int r = t1k_reads_upload_begin(rd, ne, total, (int)maxLen);
       if (r == T1K_OK) r = t1k_reads_upload_piece(rd, 1, off, 0, ((uint64_t)ne + 1) * 8, 3);
@@ -763,8 +767,7 @@ int t1k_job_run_local(t1k_job *job) {
         const size_t i1 = lo;
         const int slot = (int)(nPieces % nSlots);
         if ((r = t1k_reads_upload_wait(rd, slot)) != T1K_OK) break;
-        char *dst = (char *)stage[slot].need(slotBytes, true);
-        if (!dst) { fail(T1K_ERR_DEVICE, "window preparation: out of host memory"); return; }
+        char *dst = ring + (size_t)slot * slotBytes;
         const double tg = nowMs();
         parallelRanges(i1 - i0, T, [&](int, size_t b, size_t e) {
           for (size_t i = i0 + b; i < i0 + e; ++i) {

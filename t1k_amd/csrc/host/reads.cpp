@@ -122,7 +122,7 @@ struct ReadInput::Stream {
     std::atomic<int> state{0};  // indexer: 0 running, 1 done, -1 failed
     std::atomic<int> crcState{0};
     std::atomic<uint64_t> crcDone{0};  // text the checker has been over (nothing beyond it may be dropped: ReadInput::release)
-    std::string err, path;
+    std::string err, errIndex, path;  // (the decoder's message / the indexer's: two threads, two strings)
     size_t textLen = 0;
     bool fastq = true;   // four-line FASTQ (two-line FASTA otherwise: the barcode file fastq-extractor writes)
     Side *dst = nullptr;
@@ -607,7 +607,7 @@ bool ReadInput::openStreaming(const std::vector<std::string> &files1, const std:
       uint64_t n = 0;
       size_t recStart = 0, scan = 0;
       int lines = 0, mx = 0;
-      auto fail = [&](const std::string &why) { M->err = M->err.empty() ? M->path + ": " + why : M->err; M->state.store(-1, std::memory_order_release); };
+      auto fail = [&](const std::string &why) { M->errIndex = M->path + ": " + why; M->state.store(-1, std::memory_order_release); };
       auto emit = [&](const char *b, const char *e) -> bool {
         RecFields f;
         if (strictRecordFields(b, e, M->fastq, f) != e) { fail("a record is not in the four-line FASTQ (barcodes: or two-line FASTA) layout the streaming reader follows (T1K_STREAM_GZ=0 reads the file whole)"); return false; }
@@ -716,7 +716,10 @@ bool ReadInput::streamFinish(std::string &err) {
   streaming = false;
   for (int m = 0; m < S.nMates; ++m) {
     Stream::Mate &M = S.mate[m];
-    if (M.state.load() < 0 || M.pg.state.load() < 0) { err = M.err.empty() ? M.path + ": cannot read the file" : M.err; return false; }
+    if (M.state.load() < 0 || M.pg.state.load() < 0) {  // (every thread has been joined: the strings are at rest; the decoder's message says more than "damaged")
+      err = !M.err.empty() ? M.err : !M.errIndex.empty() ? M.errIndex : M.path + ": cannot read the file";
+      return false;
+    }
     if (M.crcState.load() < 0) { err = M.path + ": the file is damaged (CRC check of the inflated text failed)"; return false; }
   }
   if (S.fragger.joinable()) S.fragger.join();

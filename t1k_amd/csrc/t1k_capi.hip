@@ -140,27 +140,6 @@ extern "C" void *t1k_pinned_alloc(uint64_t bytes) {
   P.live[p] = want;
   return p;
 }
-// exactly `bytes` (rounded to the page): blocks of one fixed size that never grow (the staging slots of the window preparation)
-extern "C" void *t1k_pinned_alloc_exact(uint64_t bytes) {
-  PinPool &P = pinPool();
-  if (bytes == 0) bytes = 16;
-  {
-    std::lock_guard<std::mutex> g(P.m);
-    auto it = P.freeBlocks.lower_bound((size_t)bytes);
-    if (it != P.freeBlocks.end() && it->first <= (size_t)bytes + ((size_t)bytes >> 2)) {  // (not a much larger block: those serve the growing arrays)
-      void *p = it->second;
-      P.live[p] = it->first;
-      P.freeBlocks.erase(it);
-      return p;
-    }
-  }
-  const size_t want = ((size_t)bytes + 4095) & ~(size_t)4095;
-  void *p = nullptr;
-  if (hipHostMalloc(&p, want, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-  std::lock_guard<std::mutex> g(P.m);
-  P.live[p] = want;
-  return p;
-}
 extern "C" void t1k_pinned_free(void *p) {
   if (!p) return;
   PinPool &P = pinPool();
