@@ -69,7 +69,7 @@ int t1k_ctx_create(int device, const t1k_params *params, t1k_ctx **out);
 void t1k_ctx_destroy(t1k_ctx *ctx);
 const char *t1k_last_error(const t1k_ctx *ctx);
 int t1k_device_count(void);
-int t1k_device_memory(int device, uint64_t *freeBytes, uint64_t *totalBytes);
+int t1k_device_memory(int device, uint64_t *freeBytes, uint64_t *totalBytes); /* free = what the driver reports + the blocks this library keeps cached for reuse (t1k_pool_release hands those back) */
 
 /* ---- reference: SeqSet::InputRefSeq + KmerIndex::BuildIndexFromRead (SeqSet.hpp:906-982, KmerIndex.hpp:107-130) --
  * seqs: nAlleles sequences concatenated as ASCII (ACGT, anything else is treated as N); offsets[nAlleles+1] byte offsets;

@@ -939,6 +939,8 @@ int t1k_job_run_local(t1k_job *job) {
             } else if (sh.err == T1K_OK) { sh.err = T1K_ERR_INTERNAL; sh.errMsg = std::string("keeping the window's read set: ") + t1k_last_error(job->reader[W.slot]); }
           }
           W.done = true; W.tDone = nowMs();
+          if (traceTasks) fprintf(stderr, "[t1k task] window %u done: fragments %u .. %u, %u distinct read-ends (%u of them assigned by earlier windows), %u + %u ranges, ready at %.1f ms, done at %.1f ms%s\n", w, W.f0, W.f1,
+                                  W.nDistinct, W.nExternal, W.nAssign, W.nPair, W.tReady - tStart, W.tDone - tStart, W.deferred ? ", read set kept" : "");
           std::vector<uint32_t>().swap(W.distinctOf);
           while (sh.oldest < sh.created && win[sh.oldest].done) ++sh.oldest;
         }

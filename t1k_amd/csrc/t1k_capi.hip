@@ -84,6 +84,16 @@ hipError_t t1k_dev_free(void *p) {
   return hipFree(p);
 }
 
+// what the pool holds for `device` and would hand out again (or give back to the driver when a fresh allocation fails)
+uint64_t t1k_pool_cached_bytes(int device) {
+  DevPool &P = devPool();
+  std::lock_guard<std::mutex> g(P.m);
+  uint64_t bytes = 0;
+  auto it = P.freeBlocks.find(device);
+  if (it != P.freeBlocks.end()) for (auto &kv : it->second) bytes += kv.first;
+  return bytes;
+}
+
 static uint64_t pinnedRelease();
 // gives every cached block back to the driver (a long-lived process that is done with its jobs for now)
 extern "C" uint64_t t1k_pool_release(void) {

@@ -786,6 +786,7 @@ struct t1k_ctx {
 // device memory through the library's process-wide pool (t1k_capi.hip)
 hipError_t t1k_dev_malloc(void **out, size_t bytes);
 hipError_t t1k_dev_free(void *p);
+uint64_t t1k_pool_cached_bytes(int device);  // free blocks the pool keeps for `device`
 int t1k_fail(t1k_ctx *ctx, int code, const std::string &msg);
 int t1k_ensure(t1k_ctx *ctx, T1kDevBuf &b, size_t bytes);
 #define T1K_HIP(ctx, call)                                                                              \
