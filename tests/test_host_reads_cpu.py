@@ -254,3 +254,42 @@ def test_streamed_gz_refuses_what_it_cannot_follow_and_reports_damage(stream_har
     open(str(tmp_path / "cut.fq.gz"), "wb").write(blob[:len(blob) * 2 // 3])
     rc, out = _stream(stream_harness, str(tmp_path / "d"), [str(tmp_path / "cut.fq.gz")])
     assert rc == 1 and "stream: ERROR" in out, out
+
+
+def test_streamed_gz_reader_under_thread_sanitizer(read_sets, tmp_path):
+    """the streamed reader is three to seven threads around shared tables (decoder, indexer and CRC checker per file role, the fragment
+    numbering for a barcode file, the consumer): the same harness built with -fsanitize=thread must report nothing on the plain, the lane
+    and the barcode layouts, and on a damaged file (the error paths end the threads early)"""
+    import gzip
+    import random
+    exe = str(tmp_path / "reads_stream_tsan")
+    r = subprocess.run(["g++", "-O1", "-g", "-fsanitize=thread", "-std=c++17", "-o", exe, STREAM_SRC, os.path.join(HOST, "reads.cpp"), os.path.join(HOST, "refset.cpp"),
+                        os.path.join(HOST, "inflate.cpp"), "-lz", "-lpthread", "-ldl"], stderr=subprocess.PIPE, text=True)
+    if r.returncode != 0:
+        pytest.skip("no thread sanitizer runtime for g++ here: " + r.stderr[-200:])
+    env = dict(os.environ, T1K_STREAM_GZ_MIN_MB="0.0001", TSAN_OPTIONS="halt_on_error=0 exitcode=0")
+
+    def run(prefix, per_mate, files, barcode=None):
+        e = dict(env, HARNESS_BARCODE=barcode) if barcode else env
+        p = subprocess.run([exe, str(tmp_path / prefix), str(per_mate)] + files, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=e)
+        if "FATAL: ThreadSanitizer" in p.stderr:   # (the sanitizer cannot map its shadow memory in some containers)
+            pytest.skip(p.stderr[-200:])
+        assert "WARNING: ThreadSanitizer" not in p.stderr, p.stderr[:4000]
+        return p
+
+    f = [_gz(os.path.join(read_sets, "a_%s.fq" % m), str(tmp_path / ("a_%s.fq.gz" % m))) for m in ("1", "2")]
+    p = run("p", 1, f)
+    assert p.returncode == 0 and open(str(tmp_path / "p_whole.tsv"), "rb").read() == open(str(tmp_path / "p_stream.tsv"), "rb").read(), p.stdout
+    lanes = [_gz(os.path.join(read_sets, "%s_%s.fq" % (s, m)), str(tmp_path / ("%s_%s.l.fq.gz" % (s, m)))) for m in ("1", "2") for s in ("a", "b")]
+    p = run("l", 2, lanes)
+    assert p.returncode == 0 and open(str(tmp_path / "l_whole.tsv"), "rb").read() == open(str(tmp_path / "l_stream.tsv"), "rb").read(), p.stdout
+    rnd = random.Random(9)
+    with gzip.open(str(tmp_path / "bc.fa.gz"), "wb") as g:
+        g.write("".join(">r%d\n%s\n" % (i, "missing_barcode" if rnd.random() < 0.2 else "".join(rnd.choice("ACGT") for _ in range(16))) for i in range(30000)).encode())
+    p = run("b", 1, f, barcode=str(tmp_path / "bc.fa.gz"))
+    assert p.returncode == 0 and open(str(tmp_path / "b_whole.tsv"), "rb").read() == open(str(tmp_path / "b_stream.tsv"), "rb").read(), p.stdout
+    blob = bytearray(open(f[0], "rb").read())
+    blob[len(blob) // 2] ^= 0x55
+    open(str(tmp_path / "mid.fq.gz"), "wb").write(blob)
+    p = run("d", 1, [str(tmp_path / "mid.fq.gz"), f[1]])
+    assert p.returncode == 1 and "stream: ERROR" in p.stdout, p.stdout
