@@ -364,8 +364,11 @@ int t1k_reads_open(const char *const *files1, uint32_t n1, const char *const *fi
 /* The same for a job of ONE rank, with ordinary .gz inputs not waited for: the .gz files of every mate (four-line FASTQ, not bgzip-framed; the same
  * number of files for each mate, read back to back) -- and the barcode file with them when it is a .gz file too -- are inflated by a decoder that publishes its progress while a second thread indexes the records behind it, and t1k_job_run
  * takes the fragments as they arrive -- as the reference's record-at-a-time reader does (ReadFiles.hpp:13, 95, 155-204; kseq.h:94-150).
- * t1k_reads_fragments / t1k_job_fragments wait for the end of the stream.  Inputs that are not eligible (plain files, several files per
- * mate, small files, T1K_STREAM_GZ=0) are opened exactly as by t1k_reads_open. */
+ * t1k_reads_fragments / t1k_job_fragments wait for the end of the stream.  Inputs that are not eligible (plain files, mates with different
+ * numbers of files, small files, text whose first 4 MB are not strict four-line records, T1K_STREAM_GZ=0) are opened exactly as by
+ * t1k_reads_open.  Text that leaves the strict layout further on (a blank line between records, a last record without its quality line:
+ * things the whole-file reader takes as the reference's kseq does) ends the stream; t1k_job_run then opens the files whole by itself and
+ * starts over (one line on stderr says so), so the caller sees the result of t1k_reads_open at the price of the time lost. */
 int t1k_reads_open_stream(const char *const *files1, uint32_t n1, const char *const *files2, uint32_t n2, const char *barcodeFile, int threads, t1k_reads **out);
 const char *t1k_reads_last_error(const t1k_reads *reads);
 int t1k_reads_fragments(const t1k_reads *reads, uint64_t *nFragments);

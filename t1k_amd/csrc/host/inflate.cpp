@@ -154,6 +154,9 @@ static const uint32_t *fixedDist() {
 // one DEFLATE stream: out .. outEnd, `base` = first byte a distance may reach back to.  Returns nullptr on error (msg set).
 static uint8_t *inflateRaw(Bits &b, uint8_t *base, uint8_t *out, uint8_t *outEnd, GzProgress *pg, uint8_t *dst0, uint64_t progressBase, const char *&msg) {
   static thread_local uint32_t litTab[LSIZE], distTab[DSIZE], clTab[1 << 7];
+  // the output range is full in the middle of a block: what was decoded so far is text, and is published as such (the streaming reader's
+  // eligibility check decodes the head of a file into a small range and looks at what arrived)
+  auto fullAt = [&](const uint8_t *o) { if (pg) pg->produced.store(progressBase + (uint64_t)(o - dst0), std::memory_order_release); };
   for (;;) {
     b.refill();
     if (b.cnt < 3) { msg = "truncated stream"; return nullptr; }
@@ -168,7 +171,7 @@ static uint8_t *inflateRaw(Bits &b, uint8_t *base, uint8_t *out, uint8_t *outEnd
       b.in += 4;
       if ((len ^ 0xFFFFu) != nlen) { msg = "stored block: length check failed"; return nullptr; }
       if ((size_t)(b.end - b.in) < len) { msg = "truncated stored block"; return nullptr; }
-      if ((size_t)(outEnd - out) < len) { msg = "more text than the output range holds"; return nullptr; }
+      if ((size_t)(outEnd - out) < len) { msg = "more text than the output range holds"; fullAt(out); return nullptr; }
       memcpy(out, b.in, len);
       out += len; b.in += len;
     } else if (btype == 3) {
@@ -269,7 +272,7 @@ static uint8_t *inflateRaw(Bits &b, uint8_t *base, uint8_t *out, uint8_t *outEnd
         if (kind == K_LIT) {
           // up to three literals per refill (3 x 15 bits <= 56)
           if (out + 3 > outEnd) {
-            if (out >= outEnd) { msg = "more text than the output range holds"; return nullptr; }
+            if (out >= outEnd) { msg = "more text than the output range holds"; fullAt(out); return nullptr; }
             b.drop((int)(e & 255)); *out++ = (uint8_t)(e >> 16);
             continue;
           }
@@ -296,7 +299,7 @@ static uint8_t *inflateRaw(Bits &b, uint8_t *base, uint8_t *out, uint8_t *outEnd
         if (b.cnt < xd) { b.refill(); if (b.cnt < xd) { msg = "truncated stream"; return nullptr; } }
         const uint32_t distance = (d >> 16) + b.take(xd);
         if ((size_t)(out - base) < distance) { msg = "distance reaches before the stream's start"; return nullptr; }
-        if ((size_t)(outEnd - out) < len) { msg = "more text than the output range holds"; return nullptr; }
+        if ((size_t)(outEnd - out) < len) { msg = "more text than the output range holds"; fullAt(out); return nullptr; }
         const uint8_t *from = out - distance;
         if (distance >= 8 && (size_t)(outEnd - out) >= (size_t)len + 8) {
           uint8_t *o = out;

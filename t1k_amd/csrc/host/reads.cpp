@@ -462,6 +462,7 @@ void ReadInput::streamWait(size_t records) const {
 bool ReadInput::openStreaming(const std::vector<std::string> &files1, const std::vector<std::string> &files2, const std::string &barcodeFile, std::string &err) {
   err.clear();
   if (files1.empty() || (!files2.empty() && files2.size() != files1.size())) return false;
+  streamFiles1 = files1; streamFiles2 = files2; streamBarcodeFile = barcodeFile;
   static const size_t minBytes = [] { const char *e = getenv("T1K_STREAM_GZ_MIN_MB"); return (size_t)((e ? atof(e) : 32.0) * 1048576.0); }();
   std::unique_ptr<Stream> S(new Stream());
   const int nReadMates = files2.empty() ? 1 : 2;
@@ -502,7 +503,9 @@ bool ReadInput::openStreaming(const std::vector<std::string> &files1, const std:
     // a look at the head of the first file's text: four-line FASTQ?  how short can a record be?  (decoded again by the stream: 4 MB are nothing)
     {
       const uint8_t *z = (const uint8_t *)M.srcs[0].map;
-      std::vector<uint8_t> head((size_t)4 << 20);
+      const char *headEnv = getenv("T1K_STREAM_HEAD_MB");
+      const size_t headBytes = std::max<size_t>(4096, (size_t)((headEnv ? atof(headEnv) : 4.0) * 1048576.0));  // (tests put odd text right behind a small head)
+      std::vector<uint8_t> head(headBytes);
       GzProgress pg;
       std::string e;
       size_t n = 0;
@@ -610,6 +613,7 @@ bool ReadInput::openStreaming(const std::vector<std::string> &files1, const std:
       auto fail = [&](const std::string &why) { M->errIndex = M->path + ": " + why; M->state.store(-1, std::memory_order_release); };
       auto emit = [&](const char *b, const char *e) -> bool {
         RecFields f;
+        if (strictRecordFields(b, e, M->fastq, f) != e || n >= capR) streamGaveUp.store(true);  // (not damage: the whole-file reader takes such text)
         if (strictRecordFields(b, e, M->fastq, f) != e) { fail("a record is not in the four-line FASTQ (barcodes: or two-line FASTA) layout the streaming reader follows (T1K_STREAM_GZ=0 reads the file whole)"); return false; }
         if (n >= capR) { fail("more records than the streaming reader sized its tables for (T1K_STREAM_GZ=0 reads the file whole)"); return false; }
         sd->seqP[n] = f.seq; sd->seqL[n] = (uint32_t)f.seqLen; sd->idP[n] = f.id; sd->idL[n] = (uint16_t)f.idLen;

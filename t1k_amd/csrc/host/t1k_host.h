@@ -87,6 +87,8 @@ struct ReadInput {
   void streamWait(size_t records) const;  // until that many records are there or the stream has ended
   bool streamFinish(std::string &err);    // joins the threads, checks the mates against one another and the CRCs, trims the tables
   std::atomic<int> streamMaxLen{0};       // longest read indexed so far
+  std::vector<std::string> streamFiles1, streamFiles2; std::string streamBarcodeFile;  // what openStreaming was given (the job opens them whole when the stream gives up)
+  std::atomic<bool> streamGaveUp{false};  // the stream failed on text the whole-file reader takes (a record outside the strict layout behind the checked head, more records than the tables were sized for): open the files whole
   struct Stream;
   std::unique_ptr<Stream> stream_;
   // the mapped bytes of records [recLo, recHi) are not needed any more (their text went to the GPU and their output is written): drop

@@ -51,7 +51,7 @@ int main(int argc, char **argv) {
     st.streamWait(done + 1000);
   }
   fclose(f);
-  if (!st.streamFinish(err)) { printf("stream: ERROR %s\n", err.c_str()); return 1; }
+  if (!st.streamFinish(err)) { printf("stream: ERROR %s%s\n", err.c_str(), st.streamGaveUp.load() ? " [gave up: the job opens the files whole]" : ""); return 1; }
   if (st.nFrag() != done) { printf("stream: ERROR %zu records read, %zu in the trimmed tables\n", done, st.nFrag()); return 1; }
   printf("stream: %zu fragments, longest read %d, tables sized for %zu, read in %zu pieces\n", st.nFrag(), st.maxLen, bound, pieces);
   return 0;

@@ -443,6 +443,48 @@ def test_streamed_reads_through_the_c_abi_and_a_second_run(built, tmp_path):
     assert texts[0] == texts[1] == texts[2]
 
 
+def test_streamed_gzip_that_leaves_the_strict_layout_is_opened_whole(built, tmp_path):
+    """behind the head the streaming reader checks, mate 1 holds a blank line between two records and mate 2's last record has no quality
+    lines: text the whole-file reader takes as the reference's kseq does (kseq.h:94-150), and the streaming reader does not follow.  The
+    run must not end there: t1k_job_run opens the files whole and starts over -- same files as the golden run, from the executable and
+    from a library caller"""
+    import gzip
+    c = goldens.Case("cyp_rna_2x100", str(tmp_path))
+    l1, l2 = open(c.r1).read().split("\n"), open(c.r2).read().split("\n")
+    n = (len(l1) - 1) // 4
+    k = 4 * (n * 3 // 5)
+    t1 = "\n".join(l1[:k]) + "\n\n" + "\n".join(l1[k:])
+    t2 = "\n".join(l2[:4 * n - 2]) + "\n"
+    g1, g2 = os.path.join(str(tmp_path), "odd_1.fq.gz"), os.path.join(str(tmp_path), "odd_2.fq.gz")
+    for g, t in ((g1, t1), (g2, t2)):
+        with gzip.open(g, "wb") as f:
+            f.write(t.encode())
+    env = dict(os.environ, T1K_STREAM_GZ_MIN_MB="0.0001", T1K_STREAM_HEAD_MB="0.01", T1K_DEBUG_PHASES="1")
+    for tag, files in (("both", (g1, g2)), ("blank", (g1, c.r2 + ".gz")), ("tail", (c.r1 + ".gz", g2))):
+        for plain in (c.r1, c.r2):
+            if not os.path.exists(plain + ".gz"):
+                with open(plain, "rb") as f, gzip.open(plain + ".gz", "wb") as g:
+                    g.write(f.read())
+        out = os.path.join(str(tmp_path), "odd_" + tag)
+        r = subprocess.run([GENO, "-f", c.ref, "-1", files[0], "-2", files[1]] + c.flags + ["-o", out], stderr=subprocess.PIPE, text=True, env=env)
+        assert r.returncode == 0, r.stderr
+        assert "opened whole and the job starts over" in r.stderr, r.stderr
+        _golden_files_equal(c, out)
+    # a library caller (this process read T1K_STREAM_GZ_MIN_MB at its first streamed open; the head size is read here for the first time)
+    os.environ["T1K_STREAM_GZ_MIN_MB"] = "0.0001"
+    os.environ["T1K_STREAM_HEAD_MB"] = "0.01"
+    job = t1k_amd.Job(c.ref, ref_seq_similarity=0.97)
+    job.load_reads(c.r1, c.r2)
+    job.run()
+    want = (job.genotype_text(), job.counts())
+    job.close()
+    job = t1k_amd.Job(c.ref, ref_seq_similarity=0.97)
+    job.attach_reads(t1k_amd.Reads(g1, g2, stream=True))
+    job.run()
+    assert (job.genotype_text(), job.counts()) == want
+    job.close()
+
+
 def test_reads_opened_beside_job_creation(built, tmp_path):
     """t1k_reads_open on a second thread while t1k_job_create runs, then t1k_job_attach_reads (what the executable and bench.py do) leaves
     the job as t1k_job_load_reads does; the executable's serial order (T1K_SERIAL_OPEN=1) writes the same files; a failed open arrives

@@ -256,6 +256,33 @@ def test_streamed_gz_refuses_what_it_cannot_follow_and_reports_damage(stream_har
     assert rc == 1 and "stream: ERROR" in out, out
 
 
+def test_streamed_gz_gives_up_on_text_the_whole_reader_takes(stream_harness, read_sets, tmp_path):
+    """a blank line between two records / a last record without quality lines, behind the head the eligibility check looks at: the
+    stream ends with the flag that makes t1k_job_run open the files whole (the whole reader indexes both texts)"""
+    import gzip
+    lines = open(os.path.join(read_sets, "a_2.fq")).read().split("\n")
+    n = (len(lines) - 1) // 4
+    texts = {"blank": "\n".join(lines[:4 * (n // 2)]) + "\n\n" + "\n".join(lines[4 * (n // 2):]), "tail": "\n".join(lines[:4 * n - 2]) + "\n"}
+    for tag, t in texts.items():
+        p = str(tmp_path / (tag + ".fq.gz"))
+        with gzip.open(p, "wb") as g:
+            g.write(t.encode())
+        env = dict(os.environ, T1K_STREAM_GZ_MIN_MB="0.0001", T1K_STREAM_HEAD_MB="0.01")
+        r = subprocess.run([stream_harness, str(tmp_path / tag), "1", p], stdout=subprocess.PIPE, text=True, env=env)
+        assert r.returncode == 1 and "whole: %d fragments" % n in r.stdout and "gave up" in r.stdout, r.stdout
+        r = subprocess.run([stream_harness, str(tmp_path / tag), "1", p], stdout=subprocess.PIPE, text=True, env=dict(env, T1K_STREAM_HEAD_MB="64"))
+        # (a head that covers the file sees the blank line and declines at once; the short last record is not a whole record of the head)
+        assert (r.returncode == 0 and "not eligible" in r.stdout) if tag == "blank" else (r.returncode == 1 and "gave up" in r.stdout), r.stdout
+    blob = bytearray(open(str(tmp_path / "blank.fq.gz"), "rb").read())
+    blob[len(blob) // 3] ^= 0x55
+    open(str(tmp_path / "bad.fq.gz"), "wb").write(blob)
+    r = subprocess.run([stream_harness, str(tmp_path / "bad"), "1", str(tmp_path / "bad.fq.gz")], stdout=subprocess.PIPE, text=True,
+                       env=dict(os.environ, T1K_STREAM_GZ_MIN_MB="0.0001", T1K_STREAM_HEAD_MB="0.01"))
+    # (damage turns into odd text before the decoder or the CRC notice it: the stream may give up first -- the whole reader the job then
+    # opens refuses the file, which is the error the caller sees)
+    assert r.returncode == 1 and "stream: ERROR" in r.stdout and "whole: ERROR" in r.stdout, r.stdout
+
+
 def test_streamed_gz_reader_under_thread_sanitizer(read_sets, tmp_path):
     """the streamed reader is three to seven threads around shared tables (decoder, indexer and CRC checker per file role, the fragment
     numbering for a barcode file, the consumer): the same harness built with -fsanitize=thread must report nothing on the plain, the lane

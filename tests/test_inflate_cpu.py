@@ -103,3 +103,31 @@ def test_damaged_files_are_refused_not_misread(harness):
     assert rc == 1
     rc, line, _ = _inflate(harness, g, cap=len(a) - 1)  # an output range that is too small is an error, never an overrun
     assert rc == 1 and "output range" in line, line
+
+
+def test_damaged_input_under_address_and_ub_sanitizers(tmp_path):
+    """a read file is untrusted input: the decoder built with -fsanitize=address,undefined over 2 400 damaged variants (bits flipped, bytes
+    replaced, pieces cut out, ends cut off, the first block's header overwritten) of files with every block type, each in a heap block of
+    exactly its size and decoded into a block whose capacity is drawn around the true size -- it may refuse or decode, it may not reach
+    outside the two blocks (tests/harness/inflate_fuzz.cpp)"""
+    exe = str(tmp_path / "inflate_fuzz")
+    r = subprocess.run(["g++", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-std=c++17", "-o", exe,
+                        os.path.join(util.ROOT, "tests", "harness", "inflate_fuzz.cpp"), os.path.join(HOST, "inflate.cpp"), "-lpthread"], stderr=subprocess.PIPE, text=True)
+    if r.returncode != 0:
+        pytest.skip("no address sanitizer runtime for g++ here: " + r.stderr[-200:])
+    data = SAMPLES["fastq"][:400000]
+    blobs = {"level6": gzip.compress(data, 6), "level1": gzip.compress(data, 1)}
+    co = zlib.compressobj(6, zlib.DEFLATED, 31, 9, zlib.Z_FIXED)
+    blobs["fixed_codes"] = co.compress(data) + co.flush()
+    co = zlib.compressobj(0, zlib.DEFLATED, 31)
+    blobs["stored"] = co.compress(data[:100000]) + co.flush()
+    blobs["members"] = gzip.compress(data[:150000], 6) + gzip.compress(b"", 6) + gzip.compress(data[150000:], 9)
+    co = zlib.compressobj(6, zlib.DEFLATED, 31)
+    blobs["flushes"] = b"".join(co.compress(data[i:i + 50000]) + co.flush(zlib.Z_FULL_FLUSH if i % 100000 else zlib.Z_SYNC_FLUSH) for i in range(0, len(data), 50000)) + co.flush()
+    for seed, (tag, blob) in enumerate(sorted(blobs.items())):
+        p = str(tmp_path / (tag + ".gz"))
+        open(p, "wb").write(blob)
+        r = subprocess.run([exe, p, "400", str(seed + 1)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        assert r.returncode == 0 and "ERROR" not in r.stdout and "Sanitizer" not in r.stderr and "runtime error" not in r.stderr, (tag, r.stdout, r.stderr[:3000])
+        n, refused, decoded = (int(x) for x in r.stdout.split())
+        assert n == 400 and refused + decoded == 400 and refused > 200, (tag, r.stdout)
