@@ -47,6 +47,24 @@ hipError_t t1k_dev_malloc(void **out, size_t bytes) {
       return hipSuccess;
     }
   }
+  // A fresh block.  The runtime takes device memory of its own while kernels run (queue scratch) and ABORTS the process when there is none
+  // (DESIGN 9.0 item 10); what this pool holds back is invisible to it.  So when the new block would leave the driver with less than the
+  // memory rule's reserve, the cached blocks go back first (a job's stale blocks after its buffers have grown; a previous job's blocks are
+  // normally taken again by the requests above and never get here).
+  if (bytes >= ((size_t)64 << 20)) {
+    bool drop = false;
+    { std::lock_guard<std::mutex> g(P.m); drop = !P.freeBlocks[dev].empty(); }
+    size_t f = 0, t = 0;
+    if (drop && hipMemGetInfo(&f, &t) == hipSuccess && f < bytes + std::max<size_t>((size_t)8 << 30, t / 25)) {
+      std::vector<void *> back;
+      {
+        std::lock_guard<std::mutex> g(P.m);
+        for (auto &kv : P.freeBlocks[dev]) { back.push_back(kv.second); P.pooled -= kv.first; }
+        P.freeBlocks[dev].clear();
+      }
+      for (void *q : back) (void)hipFree(q);
+    }
+  }
   const auto tA = std::chrono::steady_clock::now();
   hipError_t e = hipMalloc(out, bytes);
   if (getenv("T1K_DEBUG_ALLOC") && bytes >= (64u << 20))
