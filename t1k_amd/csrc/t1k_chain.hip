@@ -1862,8 +1862,17 @@ template <int MAXLEN>
 __global__ __launch_bounds__(WG) void k_collect(ChainArgs P) {
   __shared__ uint32_t warpSums[4];
   __shared__ uint16_t sBaseCnt[2][4][MAXLEN + 1];
-  __shared__ uint64_t sVoteHi[WG], sVoteLo[WG];
+  __shared__ uint64_t sVote[2 * WG];
+  uint64_t *sVoteHi = sVote, *sVoteLo = sVote + WG;
   __shared__ uint32_t sBase;
+  // the read-end's chunk table (at most 2 x 256 + 2 chunks: the launcher refuses references with more seeding chunks): record index of
+  // each chunk's first record, prefix of the chunk lengths, the chunks' strands; the copy-out pass's own prefix lives in the vote arrays,
+  // which are dead by then
+  constexpr int MAXCH = 2 * 256 + 2;
+  __shared__ uint32_t sCs[MAXCH], sPre[MAXCH + 1], sNCh;
+  __shared__ uint8_t sChPlus[MAXCH];
+  uint32_t *sPreW = (uint32_t *)sVote;
+  static_assert(sizeof(uint64_t) * 2 * WG >= sizeof(uint32_t) * (MAXCH + 1), "the copy-out prefix does not fit the vote arrays");
   // one bit per group record of the read-end (in chunk order): "the copy-out pass has to look at this record" -- its only candidate passed
   // the filter, or it holds several (multi-diagonal groups).  The vote pass reads every record anyway; the copy-out pass then loads the
   // 40 % that hold something instead of all of them again (records beyond the bitmap's reach are simply looked at).
@@ -1898,19 +1907,65 @@ __global__ __launch_bounds__(WG) void k_collect(ChainArgs P) {
       }
       __syncthreads();
     }
+    // The chunk table of the read-end (runs of records per strand and allele chunk, recorded densely) as a prefix over ONE record index r:
+    // both passes below walk r in strides of the workgroup, so a pass issues ceil(records / 256) rounds of loads -- chunk by chunk it was
+    // one or two rounds per chunk, ten to twenty chunks a read-end, each behind a dependent load of the chunk's start and count.
+    if (tid < 64) {
+      uint32_t carry = 0, nDense = 0;
+      bool open = true;
+      if (tid == 0) sPre[0] = 0;
+      for (int base = 0; base < P.maxChunks && open; base += 64) {
+        const int ch = base + tid;
+        const uint32_t n = ch < P.maxChunks ? cc[ch] : 0u;
+        const uint32_t st = ch < P.maxChunks ? cs[ch] : 0u;  // (requested with the count: used only for the recorded chunks)
+        const unsigned long long zero = __ballot(n == 0);
+        const int live = zero ? __ffsll((long long)zero) - 1 : 64;  // chunks of this strip in front of the first empty one
+        uint32_t x = tid < live ? n : 0u;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(x, o, 64); if (tid >= o) x += y; }
+        if (tid < live) { sCs[ch] = st; sPre[ch + 1] = carry + x; }
+        carry += __shfl(x, 63, 64);
+        nDense += (uint32_t)live;
+        open = live == 64;
+      }
+      if (tid == 0) sNCh = nDense;
+    }
+    __syncthreads();
+    const int nCh = (int)sNCh;
+    const uint32_t nRec = sPre[nCh];
+    auto chunkOf = [&](uint32_t r) {  // the chunk that holds record index r: the last one that starts at or before it
+      int lo = 0, hi = nCh;
+      while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (sPre[mid] <= r) lo = mid; else hi = mid; }
+      return lo;
+    };
     VoteKey best; best.hi = ~0ull; best.lo = ~0ull;
     uint32_t nCand[2] = {0, 0};
-    uint32_t cbase = 0;  // records of the chunks before this one
-    for (int ch = 0; ch < P.maxChunks; ++ch) {
-      const uint32_t g0 = cs[ch], gn = cc[ch];
-      if (gn == 0) break;  // chunks are recorded densely
-      for (uint32_t i = tid; i < gn; i += WG) {
-        const uint32_t *rec = P.recs + (uint64_t)(g0 + i) * stride;
-        const uint4 hd = ((const uint4 *)rec)[0], cw = ((const uint4 *)rec)[1];  // words 0..3: re|strand, allele, state, candidate word 0 (or side-arena base); 4..5: candidate words 1, 2
+    for (uint32_t r0 = tid; r0 < nRec; r0 += 2 * WG) {
+      // two records per lane and round, both requested before either is looked at
+      uint4 hdv[2], cwv[2];
+      uint32_t rv[2];
+      bool first[2];
+      int chv[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        rv[u] = r0 + u * WG;
+        hdv[u] = make_uint4(0u, 0u, 0u, 0u); cwv[u] = hdv[u]; first[u] = false; chv[u] = 0;
+        if (rv[u] < nRec) {
+          chv[u] = chunkOf(rv[u]);
+          first[u] = rv[u] == sPre[chv[u]];
+          const uint32_t *rec = P.recs + (uint64_t)(sCs[chv[u]] + (rv[u] - sPre[chv[u]])) * stride;
+          hdv[u] = ((const uint4 *)rec)[0]; cwv[u] = ((const uint4 *)rec)[1];  // words 0..3: re|strand, allele, state, candidate word 0 (or side-arena base); 4..5: candidate words 1, 2
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        if (rv[u] >= nRec) continue;
+        const uint4 hd = hdv[u], cw = cwv[u];
         const bool pend = recPending(hd.z);
         const uint32_t nc = pend ? 1u : (hd.z & 0x3FFFFFFFu);
         const uint32_t w2own = pend ? pendingMatchWord(P, re, hd.z, cw.y, cw.z, cw.w) : cw.y;
         const int plus = (int)(hd.x >> 31);
+        if (first[u]) sChPlus[chv[u]] = (uint8_t)plus;  // a chunk holds one strand
         uint32_t kept = 0;
         for (uint32_t j = 0; j < nc; ++j) {
           uint32_t w0 = hd.w, w1 = cw.x, w2 = w2own;
@@ -1920,10 +1975,8 @@ __global__ __launch_bounds__(WG) void k_collect(ChainArgs P) {
           const uint32_t kc = keepCandidate<MAXLEN>(P, sBaseCnt, plus, w0, w1, w2) ? 1u : 0u;
           nCand[plus] += kc; kept += kc;
         }
-        const uint32_t ridx = cbase + i;
-        if (kept && ridx < KEEP_BITS) atomicOr(&sKeepBits[ridx >> 5], 1u << (ridx & 31));
+        if (kept && rv[u] < KEEP_BITS) atomicOr(&sKeepBits[rv[u] >> 5], 1u << (rv[u] & 31));
       }
-      cbase += gn;
     }
     sVoteHi[tid] = best.hi; sVoteLo[tid] = best.lo;
     __syncthreads();
@@ -1945,46 +1998,60 @@ __global__ __launch_bounds__(WG) void k_collect(ChainArgs P) {
     }
     __syncthreads();
     if (sBase != 0xFFFFFFFFu && totWin) {
-      // chunks are in the reference's order ('-' strand first, alleles ascending); copy the winning strand's candidates in order
-      uint32_t written = 0, cb2 = 0;
-      for (int ch = 0; ch < P.maxChunks; ++ch) {
-        const uint32_t g0 = cs[ch], gn = cc[ch];
-        if (gn == 0) break;
-        const uint32_t cbaseHere = cb2;
-        cb2 += gn;
-        if ((P.recs[(uint64_t)g0 * stride] >> 31) != winPlus) continue;  // a chunk holds one strand
-        for (uint32_t i0 = 0; i0 < gn; i0 += WG) {
-          const uint32_t i = i0 + tid;
-          const uint32_t ridx = cbaseHere + i;
-          const bool look = i < gn && (ridx >= KEEP_BITS || ((sKeepBits[ridx >> 5] >> (ridx & 31)) & 1u));
-          uint4 hd = make_uint4(0u, 0u, 0u, 0u), cw = make_uint4(0u, 0u, 0u, 0u);
-          if (look) { const uint32_t *rec = P.recs + (uint64_t)(g0 + i) * stride; hd = ((const uint4 *)rec)[0]; cw = ((const uint4 *)rec)[1]; }
-          const bool pend = look && recPending(hd.z);
-          const uint32_t nc = look ? (pend ? 1u : (hd.z & 0x3FFFFFFFu)) : 0;
-          const uint32_t w2own = pend ? pendingMatchWord(P, re, hd.z, cw.y, cw.z, cw.w) : cw.y;
-          uint32_t keepMask = 0, nk = 0;  // a group holds at most 32 candidates
-          for (uint32_t j = 0; j < nc; ++j) {
-            uint32_t w0 = hd.w, w1 = cw.x, w2 = w2own;
-            if (hd.z & 0x40000000u) { const uint32_t *g = P.genCand + ((uint64_t)hd.w + j) * 6; w0 = g[0]; w1 = g[1]; w2 = g[2]; }
-            if (keepCandidate<MAXLEN>(P, sBaseCnt, (int)winPlus, w0, w1, w2)) { keepMask |= 1u << j; ++nk; }
-          }
-          uint32_t tot;
-          uint32_t off = t1k_block_scan_exclusive(nk, warpSums, &tot);
-          for (uint32_t j = 0; j < nc; ++j) {
-            if (!((keepMask >> j) & 1u)) continue;
-            uint32_t w0 = hd.w, w1 = cw.x, w2 = w2own;
-            if (hd.z & 0x40000000u) { const uint32_t *g = P.genCand + ((uint64_t)hd.w + j) * 6; w0 = g[0]; w1 = g[1]; w2 = g[2]; }
-            T1kCand cd;
-            cd.allele = hd.y | (winPlus ? 0x80000000u : 0);
-            cd.readSE = (w0 & 0xFFF) | (((w0 >> 12) & 0xFFF) << 16);
-            cd.seqStart = (int)(w1 & 0xFFFFF); cd.seqEnd = (int)(w2 & 0xFFFFF);
-            cd.match = (w1 >> 20) | ((w2 >> 20) << 16);
-            cd.re = re;
-            P.cand[(uint64_t)sBase + written + off] = cd;
-            ++off;
-          }
-          written += tot;
+      // chunks are in the reference's order ('-' strand first, alleles ascending); copy the winning strand's candidates in order:
+      // a second prefix, over the winning strand's chunks alone (the others are empty in it), gives the pass its own dense index
+      if (tid < 64) {
+        uint32_t carry = 0;
+        if (tid == 0) sPreW[0] = 0;
+        for (int base = 0; base < nCh; base += 64) {
+          const int ch = base + tid;
+          uint32_t x = (ch < nCh && sChPlus[ch] == (uint8_t)winPlus) ? sPre[ch + 1] - sPre[ch] : 0u;
+#pragma unroll
+          for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(x, o, 64); if (tid >= o) x += y; }
+          if (ch < nCh) sPreW[ch + 1] = carry + x;
+          carry += __shfl(x, 63, 64);
         }
+      }
+      __syncthreads();
+      const uint32_t nWin = sPreW[nCh];
+      uint32_t written = 0;
+      for (uint32_t i0 = 0; i0 < nWin; i0 += WG) {
+        const uint32_t q = i0 + tid;
+        uint32_t ridx = 0, g = 0;
+        if (q < nWin) {
+          int lo = 0, hi = nCh;  // the last chunk that starts at or before q in the winning strand's index (an empty one never is the last)
+          while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (sPreW[mid] <= q) lo = mid; else hi = mid; }
+          ridx = sPre[lo] + (q - sPreW[lo]);
+          g = sCs[lo] + (q - sPreW[lo]);
+        }
+        const bool look = q < nWin && (ridx >= KEEP_BITS || ((sKeepBits[ridx >> 5] >> (ridx & 31)) & 1u));
+        uint4 hd = make_uint4(0u, 0u, 0u, 0u), cw = make_uint4(0u, 0u, 0u, 0u);
+        if (look) { const uint32_t *rec = P.recs + (uint64_t)g * stride; hd = ((const uint4 *)rec)[0]; cw = ((const uint4 *)rec)[1]; }
+        const bool pend = look && recPending(hd.z);
+        const uint32_t nc = look ? (pend ? 1u : (hd.z & 0x3FFFFFFFu)) : 0;
+        const uint32_t w2own = pend ? pendingMatchWord(P, re, hd.z, cw.y, cw.z, cw.w) : cw.y;
+        uint32_t keepMask = 0, nk = 0;  // a group holds at most 32 candidates
+        for (uint32_t j = 0; j < nc; ++j) {
+          uint32_t w0 = hd.w, w1 = cw.x, w2 = w2own;
+          if (hd.z & 0x40000000u) { const uint32_t *gc = P.genCand + ((uint64_t)hd.w + j) * 6; w0 = gc[0]; w1 = gc[1]; w2 = gc[2]; }
+          if (keepCandidate<MAXLEN>(P, sBaseCnt, (int)winPlus, w0, w1, w2)) { keepMask |= 1u << j; ++nk; }
+        }
+        uint32_t tot;
+        uint32_t off = t1k_block_scan_exclusive(nk, warpSums, &tot);
+        for (uint32_t j = 0; j < nc; ++j) {
+          if (!((keepMask >> j) & 1u)) continue;
+          uint32_t w0 = hd.w, w1 = cw.x, w2 = w2own;
+          if (hd.z & 0x40000000u) { const uint32_t *gc = P.genCand + ((uint64_t)hd.w + j) * 6; w0 = gc[0]; w1 = gc[1]; w2 = gc[2]; }
+          T1kCand cd;
+          cd.allele = hd.y | (winPlus ? 0x80000000u : 0);
+          cd.readSE = (w0 & 0xFFF) | (((w0 >> 12) & 0xFFF) << 16);
+          cd.seqStart = (int)(w1 & 0xFFFFF); cd.seqEnd = (int)(w2 & 0xFFFFF);
+          cd.match = (w1 >> 20) | ((w2 >> 20) << 16);
+          cd.re = re;
+          P.cand[(uint64_t)sBase + written + off] = cd;
+          ++off;
+        }
+        written += tot;
       }
     }
     __syncthreads();
