@@ -60,6 +60,12 @@ __device__ __forceinline__ unsigned long long t1k_pattern_mix(uint32_t allele, u
   return x;
 }
 
+#ifndef T1K_PAIR_UNROLL
+#define T1K_PAIR_UNROLL 2
+#endif
+#ifndef T1K_PAIR_WAVES
+#define T1K_PAIR_WAVES 4   // wavefronts per SIMD the register allocation of k_pair is held to (the join table's LDS admits four workgroups per compute unit)
+#endif
 struct Frag {
   uint32_t allele;
   int32_t i, j;            // index in list 1 / list 2 (-1 = none)
@@ -198,8 +204,9 @@ __device__ __forceinline__ uint32_t scanExcl(uint32_t v, uint32_t *warpSums, uin
 
 // WG threads per fragment (256: four wavefronts meeting at ~20 barriers per fragment; 64: one wavefront, whose barriers cost nothing)
 template <int WG, int LJ_SLOTS>
-__global__ __launch_bounds__(WG) void k_pair(PairArgs P) {
+__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(T1K_PAIR_WAVES, T1K_PAIR_WAVES))) void k_pair(PairArgs P) {
   constexpr int NWAVE = WG / 64;
+  constexpr int PU = T1K_PAIR_UNROLL;  // records of a list a lane requests before it looks at the first (the streamed passes)
   constexpr uint32_t LJ_CAP = LJ_SLOTS * 17 / 25;
   __shared__ uint32_t warpSums[NWAVE];
   __shared__ int sDup, sFail, sBestM, sBestIdx, sAnySep, sNotOne;
@@ -228,13 +235,15 @@ __global__ __launch_bounds__(WG) void k_pair(PairArgs P) {
     const uint32_t f = P.only ? P.only[2 * it] : it;
     const uint64_t epoch = (uint64_t)(P.epochBase + f + 1) << 32;
     const bool paired = P.end2 != nullptr;
+    // (the two read-end numbers and the flag are requested together, then the four list words: two round trips, not four)
     const uint32_t e1 = P.end1[f];
+    const uint32_t e2 = paired ? P.end2[f] : 0u;
+    const bool hasN = P.hasN ? P.hasN[f] != 0 : false;
     const uint32_t n1 = P.listCount[e1];
     const OvlList L1{(const T1kOvlP *)P.listPtr[e1]};
     uint32_t n2 = 0;
     OvlList L2{nullptr};
-    if (paired) { uint32_t e2 = P.end2[f]; n2 = P.listCount[e2]; L2.p = (const T1kOvlP *)P.listPtr[e2]; }
-    const bool hasN = P.hasN ? P.hasN[f] != 0 : false;
+    if (paired) { n2 = P.listCount[e2]; L2.p = (const T1kOvlP *)P.listPtr[e2]; }
     const bool dangling = paired && (n1 == 0 || n2 == 0);
     const bool both = paired && !dangling;
     uint32_t nFrag = 0;
@@ -319,33 +328,38 @@ __global__ __launch_bounds__(WG) void k_pair(PairArgs P) {
     if (stream) {
       tracked = true;
       const int s1 = ovlStrand(L1[0]), s2 = ovlStrand(L2[0]);
-      auto mateOf = [&](uint32_t i, const T1kOvl &oa, int &slot) -> int {  // index in list 2 of the overlap that pairs with oa, -1 if none (2369-2380)
-        int jj = -1;
-        slot = -1;
-        if (s1 == s2) return -1;
-        if (lds) {
-          slot = ljFind<LJ_SLOTS>(hKey, oa.allele);
-          jj = (int)(hVal[slot] >> 16) - 1;
-        } else {
-          const uint64_t e = tab2[oa.allele];
-          if ((e >> 32) == (epoch >> 32)) jj = (int)(e & 0x3FFFFFFFu);
-        }
-        if (jj < 0) return -1;
-        const int ss = L2[jj].seqStart;
-        return ((s1 == 1 && oa.seqStart < ss) || (s1 == -1 && oa.seqStart > ss)) ? jj : -1;
-      };
       uint32_t nPairs = 0;
-      for (uint32_t i = tid; i < n1; i += WG) {
-        const T1kOvl oa = L1[i];
-        int slot;
-        const int j = mateOf(i, oa, slot);
-        if (j < 0) continue;
-        const T1kOvl ob = L2[j];
-        Frag fr;
-        makeFrag(fr, &oa, (int)i, &ob, j);
-        ++nPairs;
-        if (fr.matchCnt > tbM || (fr.matchCnt == tbM && fr.sim > tbS)) { tbM = fr.matchCnt; tbS = fr.sim; tbI = (int)i; }  // (a lane's i ascend: its first maximum stays)
-        if (lds) atomicOr(&hVal[slot], 0x8000u); else tab2[oa.allele] |= 0x80000000ull;   // the mate's allele has a fragment (seqIdxToOverlapIdx membership)
+      // PU records of list 1 per lane and round, all requested before the first is looked at, then their mates' records likewise: a list of
+      // ~700 overlaps is one round of two dependent loads instead of three (the kernel waits for loads 85 % of its time, profiles/r05_pmc_sq.md)
+      for (uint32_t i0 = tid; i0 < n1; i0 += PU * WG) {
+        T1kOvlP pa[PU], pb[PU];
+        int jv[PU], slotv[PU];
+#pragma unroll
+        for (int u = 0; u < PU; ++u) { const uint32_t i = i0 + u * WG; pa[u] = i < n1 ? L1.p[i] : T1kOvlP{0ull, 0ull}; }
+#pragma unroll
+        for (int u = 0; u < PU; ++u) {
+          const uint32_t i = i0 + u * WG;
+          jv[u] = -1; slotv[u] = -1;
+          if (i < n1 && s1 != s2) {
+            const uint32_t al = (uint32_t)(pa[u].lo & 0xFFFFFFu);
+            if (lds) { slotv[u] = ljFind<LJ_SLOTS>(hKey, al); jv[u] = (int)(hVal[slotv[u]] >> 16) - 1; }
+            else { const uint64_t e = tab2[al]; if ((e >> 32) == (epoch >> 32)) jv[u] = (int)(e & 0x3FFFFFFFu); }
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < PU; ++u) pb[u] = jv[u] >= 0 ? L2.p[jv[u]] : T1kOvlP{0ull, 0ull};
+#pragma unroll
+        for (int u = 0; u < PU; ++u) {
+          const uint32_t i = i0 + u * WG;
+          if (jv[u] < 0) continue;
+          const T1kOvl oa = t1k_ovl_unpack(pa[u]), ob = t1k_ovl_unpack(pb[u]);
+          if (!((s1 == 1 && oa.seqStart < ob.seqStart) || (s1 == -1 && oa.seqStart > ob.seqStart))) continue;  // 2369-2380
+          Frag fr;
+          makeFrag(fr, &oa, (int)i, &ob, jv[u]);
+          ++nPairs;
+          if (fr.matchCnt > tbM || (fr.matchCnt == tbM && fr.sim > tbS)) { tbM = fr.matchCnt; tbS = fr.sim; tbI = (int)i; }  // (a lane's i ascend: its first maximum stays)
+          if (lds) atomicOr(&hVal[slotv[u]], 0x8000u); else tab2[oa.allele] |= 0x80000000ull;   // the mate's allele has a fragment (seqIdxToOverlapIdx membership)
+        }
       }
       nFrag = nPairs;  // (this lane's share: only "any at all" is asked below, through sBestM)
     } else
@@ -513,19 +527,33 @@ __global__ __launch_bounds__(WG) void k_pair(PairArgs P) {
     if (stream) {
       if (bestM >= 0) {
         const int s1 = ovlStrand(L1[0]), s2 = ovlStrand(L2[0]);
-        for (uint32_t i0 = 0; i0 < n1; i0 += WG) {
-          const uint32_t i = i0 + tid;
-          bool kp = false;
-          Frag fr;
-          if (i < n1 && s1 != s2) {
-            const T1kOvl oa = L1[i];
-            int jj = -1;
-            if (lds) jj = (int)((hVal[ljFind<LJ_SLOTS>(hKey, oa.allele)] >> 16) & 0xFFFFu) - 1;
-            else { const uint64_t e = tab2[oa.allele]; if ((e >> 32) == (epoch >> 32)) jj = (int)(e & 0x3FFFFFFFu); }
-            if (jj >= 0) {
-              const T1kOvl ob = L2[jj];
+        for (uint32_t i0 = 0; i0 < n1; i0 += PU * WG) {  // (PU rounds' loads in flight together, as in the pass above; the rounds' scans keep list order)
+          T1kOvlP pa[PU], pb[PU];
+          int jv[PU];
+#pragma unroll
+          for (int u = 0; u < PU; ++u) { const uint32_t i = i0 + u * WG + tid; pa[u] = (i < n1 && s1 != s2) ? L1.p[i] : T1kOvlP{0ull, 0ull}; }
+#pragma unroll
+          for (int u = 0; u < PU; ++u) {
+            const uint32_t i = i0 + u * WG + tid;
+            jv[u] = -1;
+            if (i < n1 && s1 != s2) {
+              const uint32_t al = (uint32_t)(pa[u].lo & 0xFFFFFFu);
+              if (lds) jv[u] = (int)((hVal[ljFind<LJ_SLOTS>(hKey, al)] >> 16) & 0xFFFFu) - 1;
+              else { const uint64_t e = tab2[al]; if ((e >> 32) == (epoch >> 32)) jv[u] = (int)(e & 0x3FFFFFFFu); }
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < PU; ++u) pb[u] = jv[u] >= 0 ? L2.p[jv[u]] : T1kOvlP{0ull, 0ull};
+#pragma unroll
+          for (int u = 0; u < PU; ++u) {
+            if (i0 + u * WG >= n1) break;  // (uniform: the round lies behind the list)
+            const uint32_t i = i0 + u * WG + tid;
+            bool kp = false;
+            Frag fr;
+            if (jv[u] >= 0) {
+              const T1kOvl oa = t1k_ovl_unpack(pa[u]), ob = t1k_ovl_unpack(pb[u]);
               if ((s1 == 1 && oa.seqStart < ob.seqStart) || (s1 == -1 && oa.seqStart > ob.seqStart)) {
-                makeFrag(fr, &oa, (int)i, &ob, jj);
+                makeFrag(fr, &oa, (int)i, &ob, jv[u]);
                 int relaxBy = 2;
                 if (P.relax) {
                   const bool inter = (oa.seqStart <= ob.seqStart && oa.seqEnd >= ob.seqStart) || (ob.seqStart <= oa.seqStart && ob.seqEnd >= oa.seqStart);  // 317-324
@@ -534,14 +562,14 @@ __global__ __launch_bounds__(WG) void k_pair(PairArgs P) {
                 kp = (fr.matchCnt == bestM && fr.sim == bestSim) || (P.relax && fr.matchCnt >= bestM - relaxBy && fr.relaxed == bestRelaxed);
               }
             }
+            uint32_t tot;
+            const uint32_t off = scanExcl<NWAVE>(kp ? 1u : 0u, warpSums, &tot);
+            if (kp) {
+              if (nKept + off < fragCap) { frags[nKept + off] = fr; keep[nKept + off] = nKept + off; }
+              else sFail = 2;  // (more kept fragments than the scratch holds: cannot happen -- kept <= joined <= n1 <= fragCap; guarded anyway)
+            }
+            nKept += tot;
           }
-          uint32_t tot;
-          const uint32_t off = scanExcl<NWAVE>(kp ? 1u : 0u, warpSums, &tot);
-          if (kp) {
-            if (nKept + off < fragCap) { frags[nKept + off] = fr; keep[nKept + off] = nKept + off; }
-            else sFail = 2;  // (more kept fragments than the scratch holds: cannot happen -- kept <= joined <= n1 <= fragCap; guarded anyway)
-          }
-          nKept += tot;
         }
       }
       nKeptStream = nKept;
@@ -588,8 +616,14 @@ __global__ __launch_bounds__(WG) void k_pair(PairArgs P) {
       const Frag rep = frags[keep[0]];
       const T1kOvl r1 = L1[rep.i], r2 = L2[rep.j];
       const double r1s = ovlSim(r1), r2s = ovlSim(r2);
-      for (uint32_t i = tid; i < n1; i += WG) {
-        const T1kOvl &o = L1[i];
+      for (uint32_t i0 = tid; i0 < n1; i0 += PU * WG) {
+       T1kOvlP pv[PU];
+#pragma unroll
+       for (int u = 0; u < PU; ++u) pv[u] = i0 + u * WG < n1 ? L1.p[i0 + u * WG] : T1kOvlP{0ull, 0ull};
+#pragma unroll
+       for (int u = 0; u < PU; ++u) {
+        if (i0 + u * WG >= n1) break;
+        const T1kOvl o = t1k_ovl_unpack(pv[u]);
         double os = ovlSim(o);
         const bool tie = o.matchCnt == r1.matchCnt && os > r1s;
         bool inSlot = false;
@@ -602,9 +636,16 @@ __global__ __launch_bounds__(WG) void k_pair(PairArgs P) {
           if (truncatedMate(P.ref, o, r1, r2)) sFail = 1;
           else if (os > r2s + 0.1) sFail = 1;
         }
+       }
       }
-      for (uint32_t j = tid; j < n2; j += WG) {
-        const T1kOvl &o = L2[j];
+      for (uint32_t j0 = tid; j0 < n2; j0 += PU * WG) {
+       T1kOvlP pv[PU];
+#pragma unroll
+       for (int u = 0; u < PU; ++u) pv[u] = j0 + u * WG < n2 ? L2.p[j0 + u * WG] : T1kOvlP{0ull, 0ull};
+#pragma unroll
+       for (int u = 0; u < PU; ++u) {
+        if (j0 + u * WG >= n2) break;
+        const T1kOvl o = t1k_ovl_unpack(pv[u]);
         double os = ovlSim(o);
         const bool tie = o.matchCnt == r2.matchCnt && os > r2s;
         bool inSlot = false;
@@ -617,6 +658,7 @@ __global__ __launch_bounds__(WG) void k_pair(PairArgs P) {
           if (truncatedMate(P.ref, o, r2, r1)) sFail = 1;
           else if (os > r1s + 0.1) sFail = 1;
         }
+       }
       }
       __syncthreads();
       cleared = sFail != 0;
