@@ -411,6 +411,41 @@ int t1k_job_coalesce_rows(t1k_job *job, const t1k_row_entry *rows, const uint32_
 /* device pointer + element count of the int32 coverage difference array (for an in-place all-reduce) */
 int t1k_coverage_device(t1k_ctx *ctx, void **devPtr, uint64_t *count);
 
+/* ---- novel-variant calling of the analyzer stage (VariantCaller.hpp:92-1311), host code ----------------------------------------------
+ * One assignment of a fragment as SeqSet::ReadAssignmentToFragmentAssignment leaves it (_fragmentOverlap, SeqSet.hpp:146-173) with the
+ * edit strings SeqSet::AddFragmentAlignmentInfo adds (SeqSet.hpp:2657-2681, 2758-2778: AlignAlgo::GlobalAlignment of the allele window
+ * [seq_start, seq_end] against the read window [read_start, read_end] of the strand-corrected read -- t1k_align_batch): ops1 / ops2 are
+ * where the strings of o1 / o2 start in the caller's `ops` bytes (0 match, 1 mismatch, 2 insert, 3 delete; no terminator). */
+typedef struct {
+  int32_t allele_idx;                 /* _fragmentOverlap::seqIdx */
+  int32_t has_mate_pair, o1_from_r2;  /* SeqSet.hpp:155-156 */
+  t1k_overlap o1, o2;                 /* o2 is read only when has_mate_pair */
+  uint64_t ops1, ops2;
+  uint32_t n_ops1, n_ops2;
+} t1k_frag_assignment;
+typedef struct {  /* _variant (VariantCaller.hpp:7-20) + the exonic coordinate OutputAlleleVCF prints */
+  int32_t allele_idx, ref_pos, exon_pos;
+  char ref, var;
+  int32_t qual, group, output_group;
+  double var_support, all_support, var_uniq_support;
+} t1k_variant;
+typedef struct t1k_variants t1k_variants;
+/* VariantCaller::SetSeqAbundance + SetMaxVarGroupToResolve + ComputeVariant (249-271, 978-1140) on the alleles of `job` (a host-only job
+ * will do: nothing here runs on the device).  abundance[nAlleles] = Genotyper::GetAlleleAbundance after the analyzer's EM
+ * (Analyzer.cpp:609, 674); fragments in file order: fragment f has assignments asg[asgPtr[f] .. asgPtr[f + 1]) in the reference's list
+ * order and reads read1[f][0 .. len1[f]) / read2[f][0 .. len2[f]) (read2 / len2 NULL: single-end).  var_max_group = --varMaxGroup.
+ * The job must outlive the result. */
+int t1k_variants_call(t1k_job *job, const double *abundance, int32_t var_max_group, uint32_t nFragments, const uint64_t *asgPtr, const t1k_frag_assignment *asg,
+                      const int8_t *ops, const char *const *read1, const uint32_t *len1, const char *const *read2, const uint32_t *len2, t1k_variants **out);
+uint32_t t1k_variants_count(const t1k_variants *v);
+int t1k_variants_get(const t1k_variants *v, t1k_variant *out /* [t1k_variants_count] */);
+/* the text of <prefix>_allele.vcf (VariantCaller::OutputAlleleVCF, 1202-1227); buf may be NULL to query the size */
+int t1k_variants_vcf(const t1k_variants *v, char *buf, uint64_t cap, uint64_t *needed);
+/* VariantCaller::AdjustFragmentAssignment (1229-1311) for one fragment: keep[i] = 1 for the assignments BarcodeSummary::AddFragment counts */
+int t1k_variants_adjust(const t1k_variants *v, const t1k_frag_assignment *asg, uint32_t n, const int8_t *ops, const char *read1, uint32_t len1, const char *read2, uint32_t len2,
+                        uint8_t *keep);
+void t1k_variants_destroy(t1k_variants *v);
+
 #ifdef __cplusplus
 }
 #endif

@@ -19,7 +19,7 @@ using namespace t1k_oracle;
 int main(int argc, char **argv) {
   std::string ref, f1, f2, fbc, out = "oracle";
   Oracle orc;
-  bool dumpOverlaps = false, noEM = false;
+  bool dumpOverlaps = false, noEM = false, fragDump = false;
   for (int i = 1; i < argc; ++i) {
     std::string a = argv[i];
     auto next = [&]() { return std::string(i + 1 < argc ? argv[++i] : ""); };
@@ -38,6 +38,7 @@ int main(int argc, char **argv) {
     else if (a == "--barcode") fbc = next();
     else if (a == "--dumpOverlaps") dumpOverlaps = true;
     else if (a == "--noEM") noEM = true;
+    else if (a == "--fragDump") fragDump = true;  // <o>_fragdump.tsv: what the reference's analyzer hands its VariantCaller (Analyzer.cpp:560-571, 611-684)
     else if (a == "--cov") orc.prm.filterCov = atof(next().c_str());
     else if (a == "--crossGeneRate") orc.prm.crossGeneRate = atof(next().c_str());
     else if (a == "--outputReadAssignment") {}
@@ -96,6 +97,17 @@ int main(int argc, char **argv) {
   std::vector<FragmentOverlap> frag;
   std::vector<RowEntry> row;
   size_t assignedFragments = 0;
+  FILE *fd = fragDump ? fopen((out + "_fragdump.tsv").c_str(), "w") : nullptr;
+  // one overlap with the edit string SeqSet::AddOverlapAlignmentInfo gives it (SeqSet.hpp:2657-2681)
+  auto dumpOverlap = [&](const Overlap &o, const std::string &read) {
+    const std::string r = o.strand == -1 ? reverseComplement(read) : read;
+    std::vector<int8_t> ops;
+    globalAlignment(orc.alleles[o.seqIdx].seq.c_str() + o.seqStart, o.seqEnd - o.seqStart + 1, r.c_str() + o.readStart, o.readEnd - o.readStart + 1, ops);
+    std::string e;
+    for (int8_t c : ops) e += (char)('0' + c);
+    fprintf(fd, "\t%d\t%d\t%d\t%d\t%d\t%d\t%.17g\t%d\t%d\t%d\t%s", o.readStart, o.readEnd, o.seqStart, o.seqEnd, o.strand, o.matchCnt, o.similarity, o.leftClip, o.rightClip,
+            o.relaxedMatchCnt, e.empty() ? "-" : e.c_str());
+  };
   for (size_t i = 0; i < F; ++i) {
     bool hasN = r1[i].seq.find('N') != std::string::npos || (hasMate && r2[i].seq.find('N') != std::string::npos);
     orc.pairFragments(lists[listOf[i]], hasMate ? &lists[listOf[F + i]] : nullptr, hasN, frag);
@@ -104,7 +116,15 @@ int main(int argc, char **argv) {
     if (!frag.empty()) fprintf(fal, "%s\n", r1[i].id.c_str());  // fragmentAssigned (Genotyper.cpp:564-565)
     if (!row.empty()) ++assignedFragments;
     orc.coalesceRow(row);
+    if (fd)
+      for (auto &fo : frag) {  // the list itself, before the -n / separator drops of SetReadAssignments (Analyzer.cpp:571)
+        fprintf(fd, "%zu\t%d\t%d\t%d", i, fo.seqIdx, fo.hasMatePair ? 1 : 0, fo.o1FromR2 ? 1 : 0);
+        dumpOverlap(fo.o1, (fo.o1FromR2 && !fo.hasMatePair) ? r2[i].seq : r1[i].seq);
+        if (fo.hasMatePair) dumpOverlap(fo.o2, r2[i].seq);
+        fprintf(fd, "\n");
+      }
   }
+  if (fd) fclose(fd);
   fclose(fa);
   fclose(fal);
   auto t2 = std::chrono::steady_clock::now();

@@ -51,6 +51,12 @@ OVERLAP_DTYPE = np.dtype([("seq_idx", "<i4"), ("read_start", "<i4"), ("read_end"
 ROW_DTYPE = np.dtype([("allele_idx", "<i4"), ("start", "<i4"), ("end", "<i4"), ("weight", "<f4"), ("qual", "<f4"),
                       ("adjust_weight", "<f4")])
 assert OVERLAP_DTYPE.itemsize == 48 and ROW_DTYPE.itemsize == 24
+# t1k_frag_assignment / t1k_variant (novel-variant calling of the analyzer stage, host code)
+FRAG_ASG_DTYPE = np.dtype([("allele_idx", "<i4"), ("has_mate_pair", "<i4"), ("o1_from_r2", "<i4"), ("_pad", "<i4"), ("o1", OVERLAP_DTYPE), ("o2", OVERLAP_DTYPE),
+                           ("ops1", "<u8"), ("ops2", "<u8"), ("n_ops1", "<u4"), ("n_ops2", "<u4")])
+VARIANT_DTYPE = np.dtype([("allele_idx", "<i4"), ("ref_pos", "<i4"), ("exon_pos", "<i4"), ("ref", "S1"), ("var", "S1"), ("_pad", "S2"), ("qual", "<i4"), ("group", "<i4"),
+                          ("output_group", "<i4"), ("_pad2", "<i4"), ("var_support", "<f8"), ("all_support", "<f8"), ("var_uniq_support", "<f8")])
+assert FRAG_ASG_DTYPE.itemsize == 136 and VARIANT_DTYPE.itemsize == 56
 
 ALLREDUCE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_uint64, C.c_void_p)
 
@@ -123,6 +129,13 @@ def lib():
     L.t1k_reads_dedupe.argtypes = [vp, vp, u32p]
     L.t1k_job_groups_merge.argtypes = [vp, vp, vp, C.c_uint32]
     L.t1k_job_coalesce_rows.argtypes = [vp, vp, vp, vp, C.c_uint32]
+    L.t1k_variants_call.argtypes = [vp, vp, C.c_int32, C.c_uint32, vp, vp, vp, vp, vp, vp, vp, C.POINTER(vp)]
+    L.t1k_variants_count.argtypes = [vp]
+    L.t1k_variants_count.restype = C.c_uint32
+    L.t1k_variants_get.argtypes = [vp, vp]
+    L.t1k_variants_vcf.argtypes = [vp, vp, C.c_uint64, u64p]
+    L.t1k_variants_adjust.argtypes = [vp, vp, C.c_uint32, vp, C.c_char_p, C.c_uint32, C.c_char_p, C.c_uint32, vp]
+    L.t1k_variants_destroy.argtypes = [vp]
     L.t1k_job_set_shard.argtypes = [vp, C.c_int, C.c_int, vp]
     L.t1k_job_share_reads.argtypes = [vp, vp]
     L.t1k_job_ctx.restype = vp
@@ -524,6 +537,24 @@ class Job:
         fr = None if fragments is None else np.ascontiguousarray(fragments, dtype=np.uint32)
         self._check(lib().t1k_job_coalesce_rows(self.h, _ptr(rows), _ptr(rc), _ptr(fr), len(rc)), "t1k_job_coalesce_rows")
 
+    def call_variants(self, abundance, var_max_group, asg_ptr, asg, ops, reads1, reads2=None):
+        """VariantCaller::ComputeVariant on this job's alleles (t1k_variants_call; host code, a device=-1 job will do): asg[asg_ptr[f] :
+        asg_ptr[f + 1]] = fragment f's assignment list (FRAG_ASG_DTYPE), ops = the edit strings its ops1 / ops2 offsets point into"""
+        ab = np.ascontiguousarray(abundance, dtype=np.float64)
+        ap = np.ascontiguousarray(asg_ptr, dtype=np.uint64)
+        asg = np.ascontiguousarray(asg, dtype=FRAG_ASG_DTYPE)
+        ops = np.ascontiguousarray(ops, dtype=np.int8)
+        n = len(ap) - 1
+
+        def side(reads):
+            b = [r.encode() if isinstance(r, str) else r for r in reads]
+            return b, (C.c_char_p * n)(*b), np.array([len(x) for x in b], dtype=np.uint32)
+        b1, p1, l1 = side(reads1)
+        b2, p2, l2 = side(reads2) if reads2 is not None else (None, None, None)
+        h = C.c_void_p()
+        self._check(lib().t1k_variants_call(self.h, _ptr(ab), var_max_group, n, _ptr(ap), _ptr(asg), _ptr(ops), p1, _ptr(l1), p2, _ptr(l2), C.byref(h)), "t1k_variants_call")
+        return Variants(h, self)
+
     def coverage_device(self):
         """(device pointer, element count) of the int32 coverage difference array"""
         p, n = C.c_void_p(), C.c_uint64()
@@ -531,6 +562,51 @@ class Job:
         if lib().t1k_coverage_device(ctx, C.byref(p), C.byref(n)) != 0:
             raise T1kError("t1k_coverage_device failed")
         return p.value, n.value
+
+
+class Variants:
+    """called variants of an analyzer run (t1k_variants): VariantCaller's finalVariants and what reads them"""
+
+    def __init__(self, h, job):
+        self.h, self.job = h, job  # (the job must outlive the result)
+
+    def close(self):
+        if self.h:
+            lib().t1k_variants_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def records(self):
+        out = np.zeros(lib().t1k_variants_count(self.h), dtype=VARIANT_DTYPE)
+        if len(out) and lib().t1k_variants_get(self.h, _ptr(out)) != 0:
+            raise T1kError("t1k_variants_get failed")
+        return out
+
+    def vcf(self):
+        """the text of <prefix>_allele.vcf"""
+        need = C.c_uint64()
+        if lib().t1k_variants_vcf(self.h, None, 0, C.byref(need)) != 0:
+            raise T1kError("t1k_variants_vcf failed")
+        buf = C.create_string_buffer(need.value + 1)
+        if lib().t1k_variants_vcf(self.h, buf, need.value + 1, C.byref(need)) != 0:
+            raise T1kError("t1k_variants_vcf failed")
+        return buf.value.decode()
+
+    def adjust(self, asg, ops, read1, read2=None):
+        """VariantCaller::AdjustFragmentAssignment for one fragment: a 0/1 flag per assignment"""
+        asg = np.ascontiguousarray(asg, dtype=FRAG_ASG_DTYPE)
+        ops = np.ascontiguousarray(ops, dtype=np.int8)
+        keep = np.zeros(len(asg), dtype=np.uint8)
+        b1 = read1.encode() if isinstance(read1, str) else read1
+        b2 = None if read2 is None else (read2.encode() if isinstance(read2, str) else read2)
+        if lib().t1k_variants_adjust(self.h, _ptr(asg), len(asg), _ptr(ops), b1, len(b1), b2, len(b2) if b2 else 0, _ptr(keep)) != 0:
+            raise T1kError("t1k_variants_adjust failed")
+        return keep
 
 
 class CommGroup:

@@ -1540,6 +1540,108 @@ int t1k_job_coalesce_rows(t1k_job *job, const t1k_row_entry *rows, const uint32_
   return T1K_OK;
 }
 
+// ---- novel-variant calling of the analyzer stage (host/variants.cpp) behind the C ABI ---------------------------------------------
+struct t1k_variants {
+  std::unique_ptr<VariantCaller> vc;
+  const RefSet *ref = nullptr;
+};
+
+static bool variantInputOk(const RefSet &ref, const t1k_frag_assignment &a, uint32_t l1, uint32_t l2, bool haveR2) {
+  // the windows must lie inside the allele and the read they name (the reference trusts its own lists; this entry point has callers)
+  if (a.allele_idx < 0 || (size_t)a.allele_idx >= ref.seqs.size()) return false;
+  const int L = (int)ref.seqs[a.allele_idx].size();
+  for (int k = 0; k < (a.has_mate_pair ? 2 : 1); ++k) {
+    const t1k_overlap &o = k ? a.o2 : a.o1;
+    const bool second = k == 1 || a.o1_from_r2;
+    if (second && !haveR2) return false;
+    const int len = (int)(second ? l2 : l1);
+    if (o.seq_idx != a.allele_idx || (o.strand != 1 && o.strand != -1)) return false;
+    if (o.seq_start < 0 || o.seq_end < o.seq_start - 1 || o.seq_end >= L) return false;
+    if (o.read_start < 0 || o.read_end < o.read_start - 1 || o.read_end >= len) return false;
+  }
+  return true;
+}
+// the edit string must spell exactly the two windows (columns that consume an allele base / a read base)
+static bool variantOpsOk(const t1k_overlap &o, const int8_t *e, uint32_t n) {
+  int64_t t = 0, p = 0;
+  for (uint32_t i = 0; i < n; ++i) {
+    if (e[i] < 0 || e[i] > 3) return false;
+    if (e[i] != 2) ++t;
+    if (e[i] != 3) ++p;
+  }
+  return t == (int64_t)o.seq_end - o.seq_start + 1 && p == (int64_t)o.read_end - o.read_start + 1;
+}
+
+int t1k_variants_call(t1k_job *job, const double *abundance, int32_t var_max_group, uint32_t nFragments, const uint64_t *asgPtr, const t1k_frag_assignment *asg,
+                      const int8_t *ops, const char *const *read1, const uint32_t *len1, const char *const *read2, const uint32_t *len2, t1k_variants **out) {
+  if (!job || !out || !abundance || (nFragments && (!asgPtr || !read1 || !len1)) || ((read2 == nullptr) != (len2 == nullptr))) return T1K_ERR_ARG;
+  *out = nullptr;
+  const RefSet &ref = job->ref;
+  std::vector<VariantCaller::Fragment> frags(nFragments);
+  for (uint32_t f = 0; f < nFragments; ++f) {
+    VariantCaller::Fragment &fr = frags[f];
+    if (asgPtr[f + 1] < asgPtr[f]) return jobFail(job, T1K_ERR_ARG, "t1k_variants_call: asgPtr is not ascending");
+    fr.asg = asg + asgPtr[f];
+    fr.n = (uint32_t)(asgPtr[f + 1] - asgPtr[f]);
+    fr.r1 = read1[f]; fr.l1 = len1[f];
+    if (read2) { fr.r2 = read2[f]; fr.l2 = len2[f]; }
+    for (uint32_t i = 0; i < fr.n; ++i) {
+      const t1k_frag_assignment &a = fr.asg[i];
+      if (!variantInputOk(ref, a, fr.l1, fr.l2, read2 != nullptr) || !ops || !variantOpsOk(a.o1, ops + a.ops1, a.n_ops1) ||
+          (a.has_mate_pair && !variantOpsOk(a.o2, ops + a.ops2, a.n_ops2)))
+        return jobFail(job, T1K_ERR_ARG, "t1k_variants_call: assignment " + std::to_string(i) + " of fragment " + std::to_string(f) +
+                                             " names a window outside its allele or read, or its edit string does not spell the two windows");
+    }
+  }
+  std::unique_ptr<t1k_variants> v(new t1k_variants);
+  v->ref = &ref;
+  v->vc.reset(new VariantCaller(ref, std::vector<double>(abundance, abundance + ref.seqs.size()), var_max_group));
+  v->vc->compute(frags, ops);
+  *out = v.release();
+  return T1K_OK;
+}
+
+uint32_t t1k_variants_count(const t1k_variants *v) { return v ? (uint32_t)v->vc->variants.size() : 0; }
+
+int t1k_variants_get(const t1k_variants *v, t1k_variant *out) {
+  if (!v || !out) return T1K_ERR_ARG;
+  for (size_t i = 0; i < v->vc->variants.size(); ++i) {
+    const VariantRec &r = v->vc->variants[i];
+    t1k_variant &o = out[i];
+    o.allele_idx = r.allele; o.ref_pos = r.refPos;
+    int e = 0;
+    for (int p = 0; p < r.refPos; ++p) e += v->ref->exon[r.allele][p] ? 1 : 0;
+    o.exon_pos = v->ref->exon[r.allele][r.refPos] ? e : -1;
+    o.ref = r.ref; o.var = r.var; o.qual = r.qual; o.group = r.group; o.output_group = r.outputGroup;
+    o.var_support = r.varSupport; o.all_support = r.allSupport; o.var_uniq_support = r.varUniqSupport;
+  }
+  return T1K_OK;
+}
+
+int t1k_variants_vcf(const t1k_variants *v, char *buf, uint64_t cap, uint64_t *needed) {
+  if (!v) return T1K_ERR_ARG;
+  const std::string s = v->vc->vcfText();
+  if (needed) *needed = s.size();
+  if (buf && cap > s.size()) { memcpy(buf, s.data(), s.size()); buf[s.size()] = 0; }
+  else if (buf) return T1K_ERR_ARG;
+  return T1K_OK;
+}
+
+int t1k_variants_adjust(const t1k_variants *v, const t1k_frag_assignment *asg, uint32_t n, const int8_t *ops, const char *read1, uint32_t len1, const char *read2, uint32_t len2,
+                        uint8_t *keep) {
+  if (!v || (n && (!asg || !keep || !ops))) return T1K_ERR_ARG;
+  for (uint32_t i = 0; i < n; ++i)
+    if (!variantInputOk(*v->ref, asg[i], len1, len2, read2 != nullptr) || !variantOpsOk(asg[i].o1, ops + asg[i].ops1, asg[i].n_ops1) ||
+        (asg[i].has_mate_pair && !variantOpsOk(asg[i].o2, ops + asg[i].ops2, asg[i].n_ops2)))
+      return T1K_ERR_ARG;
+  VariantCaller::Fragment f;
+  f.asg = asg; f.n = n; f.r1 = read1; f.l1 = len1; f.r2 = read2; f.l2 = len2;
+  v->vc->adjust(f, ops, keep);
+  return T1K_OK;
+}
+
+void t1k_variants_destroy(t1k_variants *v) { delete v; }
+
 int t1k_job_genotype_text(t1k_job *job, char *buf, uint64_t cap, uint64_t *needed) {
   if (!job || !job->ran) return jobFail(job, T1K_ERR_STATE, "the job has not run");
   std::string s;

@@ -200,4 +200,52 @@ struct Genotyper {
   int geneTypes(int gene) const;                             // GetGeneAlleleTypes (1053-1069)
 };
 
+// host/variants.cpp: novel-variant calling of the analyzer stage (VariantCaller.hpp), host code over the fragments' assignment lists and
+// the edit strings of their read-ends
+struct VariantRec {  // _variant (VariantCaller.hpp:7-20)
+  int allele = 0, refPos = 0;
+  char ref = 0, var = 0;
+  double allSupport = 0, varSupport = 0, varUniqSupport = 0;
+  int group = 0, outputGroup = 0, qual = 0;
+};
+class VariantCaller {
+ public:
+  struct Fragment {  // one fragment: its assignment list (SeqSet::ReadAssignmentToFragmentAssignment's order) and its read(s)
+    const t1k_frag_assignment *asg = nullptr;
+    uint32_t n = 0;
+    const char *r1 = nullptr, *r2 = nullptr;
+    uint32_t l1 = 0, l2 = 0;
+  };
+  // abundance[a] = Genotyper::GetAlleleAbundance(a) after the analyzer's EM (VariantCaller::SetSeqAbundance 249-265); maxGroup = --varMaxGroup
+  VariantCaller(const RefSet &ref, const std::vector<double> &abundance, int maxGroup);
+  ~VariantCaller();
+  void compute(const std::vector<Fragment> &frags, const int8_t *ops);          // ComputeVariant (978-1140)
+  std::string vcfText() const;                                                   // OutputAlleleVCF (1202-1227)
+  void adjust(const Fragment &f, const int8_t *ops, uint8_t *keep) const;        // AdjustFragmentAssignment (1229-1311)
+  std::vector<VariantRec> variants;                                              // finalVariants
+
+ private:
+  struct Cell;
+  const RefSet &ref_;
+  std::vector<double> abundance_;
+  int maxGroup_;
+  std::vector<size_t> base_;                 // allele -> first cell
+  std::unique_ptr<std::vector<Cell>> cells_; // one per allele base
+  std::vector<int> copies_;                  // seqCopy
+  std::vector<std::pair<int, int>> cand_;    // candidateVariants: (allele, position)
+  std::vector<char> root_;                   // found from the counts (rootCandidate), not by expansion
+  std::vector<int> group_;                   // candidateVariantGroupId
+  std::vector<std::vector<std::pair<int, double>>> edges_;     // candidate -> (candidate, weight)
+  std::vector<std::vector<std::pair<uint32_t, char>>> seen_;   // candidate -> (fragment, nucleotide shown)
+  std::unordered_map<size_t, std::vector<int>> calledAt_;      // cell -> called variants (finalVariantIds)
+  Cell &cell(int allele, int pos) const;
+  void bookOverlap(const char *read, uint32_t len, const t1k_overlap &o, const int8_t *ops, uint32_t nOps, double weight, bool filter);
+  void bookFragment(const Fragment &f, const int8_t *ops, bool first);
+  int newCandidate(int allele, int pos, bool root);
+  void findRoots();
+  void expandFragment(const Fragment &f, const int8_t *ops);
+  void linkFragment(const Fragment &f, uint32_t fragIdx, const int8_t *ops);
+  void solveGroup(const std::vector<int> &vars, int groupId);
+};
+
 }  // namespace t1k

@@ -1077,34 +1077,6 @@ def test_device_coalescing_equals_host_restatement(built, tmp_path):
 
 
 
-def novel_snp_sample(tmp, het):
-    """reads drawn from a copy of the reference in which one exonic position of gene 0 carries a base the database does not know -- in every
-    allele of the gene (a homozygous novel SNP) or in every second one (het: the two sampled alleles may differ at it) -- genotyped against
-    the ORIGINAL reference: the input on which the reference's VariantCaller does call a variant"""
-    ref = os.path.join(tmp, "ref.fa")
-    util.synth_ref("ref-rna", ref, genes=4, scale=0.05, seed=31)
-    recs = []
-    for line in open(ref):
-        if line.startswith(">"):
-            recs.append([line.rstrip("\n"), ""])
-        else:
-            recs[-1][1] += line.strip()
-    gene0 = sorted(set(r[0][1:].split("*")[0] for r in recs))[0]
-    swap = {"A": "C", "C": "G", "G": "T", "T": "A"}
-    mut = os.path.join(tmp, "ref_mut.fa")
-    with open(mut, "w") as o:
-        k = 0
-        for n, sq in recs:
-            if n[1:].split("*")[0] == gene0 and len(sq) > 400 and sq[400] in swap:
-                if not het or k % 2 == 0:
-                    sq = sq[:400] + swap[sq[400]] + sq[401:]
-                k += 1
-            o.write(n + "\n" + sq + "\n")
-    pfx = os.path.join(tmp, "r")
-    util.synth_reads(mut, pfx, pairs=3000, len=150, seed=5, barcodes=50, sub=0.0)
-    return ref, pfx
-
-
 @pytest.mark.parametrize("het", [False, True])
 def test_analyzer_on_a_sample_with_a_novel_snp(built, tmp_path, het):
     """The hole of SURVEY 8f row 2, fenced: on a sample whose reads carry a consistent SNP absent from the database the reference's analyzer
@@ -1113,7 +1085,7 @@ def test_analyzer_on_a_sample_with_a_novel_snp(built, tmp_path, het):
     per-barcode table and the same (empty) VCF."""
     util.need(util.REF_ANALYZER)
     tmp = str(tmp_path)
-    ref, pfx = novel_snp_sample(tmp, het)
+    ref, pfx = util.novel_snp_sample(tmp, het)
     g = os.path.join(tmp, "g")
     r = subprocess.run([GENO, "-f", ref, "-1", pfx + "_1.fq", "-2", pfx + "_2.fq", "--barcode", pfx + "_bc.fa", "-o", g], stderr=subprocess.PIPE, text=True)
     assert r.returncode == 0, r.stderr

@@ -1,0 +1,252 @@
+"""Novel-variant calling of the analyzer stage (t1k_amd/csrc/host/variants.cpp behind t1k_variants_call; host code, no GPU): against the
+REFERENCE's analyzer (oracle/_ref/analyzer, VariantCaller.hpp) on samples whose reads carry SNPs the database does not know.
+
+The reference analyzer is a whole program; what its VariantCaller is handed -- every fragment's assignment list with both read-ends'
+overlaps and their edit strings, and the allele abundances of the analyzer's EM -- is produced here by the CPU restatement
+(oracle/t1k_oracle_cli --fragDump, the checker of the assignment path), given to the product's host code through the C ABI, and the two
+files that depend on it are compared with the reference analyzer's own: <prefix>_allele.vcf byte for byte, and <prefix>_barcode_expr.tsv
+rebuilt from the adjusted assignment lists (BarcodeSummary::AddFragment, BarcodeSummary.hpp:24-57)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import util
+import t1k_amd
+
+
+@pytest.fixture(scope="module")
+def built():
+    import __graft_entry__ as g
+    if not os.path.exists(t1k_amd.lib_path()):
+        g.build()
+    return True
+
+
+def read_fa(path):
+    recs = []
+    for line in open(path):
+        if line.startswith(">"):
+            recs.append([line[1:].split()[0], line.rstrip("\n"), ""])
+        else:
+            recs[-1][2] += line.strip()
+    return recs
+
+
+def reference_run(tmp, ref, pfx, geno_flags=(), ana_flags=(), single=False):
+    """reference genotyper -> reference analyzer (default --varMaxGroup 8 unless ana_flags say otherwise)"""
+    util.need(util.REF_BIN)
+    util.need(util.REF_ANALYZER)
+    g = os.path.join(tmp, "g")
+    reads = ["-u", pfx + "_1.fq"] if single else ["-1", pfx + "_1.fq", "-2", pfx + "_2.fq"]
+    r = subprocess.run([util.REF_BIN, "-f", ref] + reads + ["--barcode", pfx + "_bc.fa", "-o", g, "-t", "4"] + list(geno_flags), stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 0, r.stderr
+    aligned = ["-u", g + "_aligned.fa"] if single else ["-1", g + "_aligned_1.fa", "-2", g + "_aligned_2.fa"]
+    a = os.path.join(tmp, "ana")
+    r = subprocess.run([util.REF_ANALYZER, "-f", ref, "-a", g + "_allele.tsv"] + aligned + ["--barcode", g + "_aligned_bc.fa", "-o", a, "-t", "4"] + list(ana_flags),
+                       stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 0, r.stderr
+    return g, a, aligned
+
+
+def oracle_dump(tmp, ref, g, aligned, flags=()):
+    """the analyzer's view of the sample from the CPU restatement: the selected alleles only (Genotyper::InitRefSet with selectedAlleles,
+    Genotyper.hpp:732-757 = the reference file without the other records), assignment lists with edit strings, abundances"""
+    selected = set(line.split()[0] for line in open(g + "_allele.tsv") if line.strip())
+    sel = os.path.join(tmp, "selected.fa")
+    with open(sel, "w") as o:
+        for name, head, seq in read_fa(ref):
+            if name in selected:
+                o.write(head + "\n" + seq + "\n")
+    out = os.path.join(tmp, "orc")
+    r = subprocess.run([util.ORACLE_CLI, "-f", sel] + aligned + ["-o", out, "--fragDump"] + list(flags), stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 0, r.stderr
+    names = [line.split("\t")[0] for line in open(out + "_abundance.tsv")]
+    abundance = [float(line.split("\t")[1]) for line in open(out + "_abundance.tsv")]
+    return sel, out, names, abundance
+
+
+def parse_dump(path, n_frag):
+    """<o>_fragdump.tsv -> (asg_ptr, asg, ops)"""
+    rows, ops = [], []
+    per = [0] * n_frag
+
+    def overlap(f, allele):
+        e = [] if f[10] == "-" else [int(c) for c in f[10]]
+        o = (allele, int(f[0]), int(f[1]), int(f[2]), int(f[3]), int(f[4]), int(f[5]), int(f[7]), int(f[8]), int(f[9]), float(f[6]))
+        at = len(ops)
+        ops.extend(e)
+        return o, at, len(e)
+    zero = (0,) * 10 + (0.0,)
+    for line in open(path):
+        f = line.rstrip("\n").split("\t")
+        frag, allele, mate, from2 = int(f[0]), int(f[1]), int(f[2]), int(f[3])
+        o1, at1, n1 = overlap(f[4:15], allele)
+        o2, at2, n2 = overlap(f[15:26], allele) if mate else (zero, 0, 0)
+        rows.append((allele, mate, from2, 0, o1, o2, at1, at2, n1, n2))
+        per[frag] += 1
+    asg = np.array(rows, dtype=t1k_amd.FRAG_ASG_DTYPE) if rows else np.zeros(0, dtype=t1k_amd.FRAG_ASG_DTYPE)
+    ptr = np.zeros(n_frag + 1, dtype=np.uint64)
+    ptr[1:] = np.cumsum(per)
+    return ptr, asg, np.array(ops, dtype=np.int8)
+
+
+def barcode_table(names, barcodes, ptr, asg, keep_of):
+    """BarcodeSummary::AddFragment / Output (BarcodeSummary.hpp:24-80) over the adjusted lists"""
+    ids = {}
+    for b in barcodes:  # ids in order of first appearance over all loaded fragments (Analyzer.cpp:380-392)
+        ids.setdefault(b, len(ids))
+    A = len(names)
+    table = {}
+    for f, b in enumerate(barcodes):
+        lo, hi = int(ptr[f]), int(ptr[f + 1])
+        if hi == lo:
+            continue  # fragmentAssigned is false (Analyzer.cpp:692-696)
+        slot = table.setdefault(ids[b], ([0.0] * A, [0] * A))
+        kept = [int(asg["allele_idx"][lo + i]) for i in range(hi - lo) if keep_of(f)[i]]
+        for a in kept:
+            slot[0][a] += 1.0 / len(kept)
+            if len(kept) == 1:
+                slot[1][a] += 1
+    by_id = {v: k for k, v in ids.items()}
+    out = "#barcode" + "".join("\t" + n for n in names) + "".join("\t%s_uniq" % n for n in names) + "\n"
+    for i in sorted(table):
+        out += by_id[i] + "".join("\t%f" % x for x in table[i][0]) + "".join("\t%d" % x for x in table[i][1]) + "\n"
+    return out
+
+
+def run_case(tmp, ref, pfx, single=False, var_max_group=8, geno_flags=(), ana_flags=(), orc_flags=(), job_kw=None):
+    g, a, aligned = reference_run(tmp, ref, pfx, geno_flags, ana_flags, single)
+    sel, out, names, abundance = oracle_dump(tmp, ref, g, aligned, orc_flags)
+    r1 = [s for _, _, s in t1k_amd.read_fastx(aligned[1])]
+    r2 = None if single else [s for _, _, s in t1k_amd.read_fastx(aligned[3])]
+    bcs = [s for _, _, s in t1k_amd.read_fastx(g + "_aligned_bc.fa")]
+    ptr, asg, ops = parse_dump(out + "_fragdump.tsv", len(r1))
+    job = t1k_amd.Job(sel, device=-1, **(job_kw or {}))
+    v = job.call_variants(abundance, var_max_group, ptr, asg, ops, r1, r2)
+    want_vcf = open(a + "_allele.vcf").read()
+    got_vcf = v.vcf()
+    cache = {}
+
+    def keep_of(f):
+        if f not in cache:
+            lo, hi = int(ptr[f]), int(ptr[f + 1])
+            cache[f] = v.adjust(asg[lo:hi], ops, r1[f], None if single else r2[f])
+        return cache[f]
+    got_table = barcode_table(names, bcs, ptr, asg, keep_of)
+    want_table = open(a + "_barcode_expr.tsv").read()
+    moved = sum(1 for f in cache if not cache[f].all())
+    recs = v.records()
+    v.close()
+    job.close()
+    return want_vcf, got_vcf, want_table, got_table, moved, recs
+
+
+@pytest.mark.parametrize("het", [False, True])
+def test_called_variants_and_adjusted_counts_vs_reference_analyzer(built, tmp_path, het):
+    """one consistent exonic SNP absent from the database (in every allele of a gene, or in every second one): the VCF line(s) the
+    reference writes, byte for byte, and its per-barcode table"""
+    util.need(util.ORACLE_CLI)
+    tmp = str(tmp_path)
+    ref, pfx = util.novel_snp_sample(tmp, het)
+    want_vcf, got_vcf, want_table, got_table, moved, recs = run_case(tmp, ref, pfx)
+    assert want_vcf.count("\n") >= 1 and " 401 . " in want_vcf, want_vcf
+    assert got_vcf == want_vcf
+    assert got_table == want_table and want_table.count("\n") > 20
+    assert len(recs) == want_vcf.count("\n") and all(r["exon_pos"] == r["ref_pos"] for r in recs)  # (an rna reference: every base is exonic)
+
+
+def several_snps_sample(tmp, seed, genes=5, every=3, positions=(150, 152, 400, 800), pairs=4000, sub=0.002, kind="ref-rna", scale=0.05):
+    """like util.novel_snp_sample with several unknown bases per gene -- two of them three bases apart, so that one read-end spans both and
+    their candidates fall into one group -- carried by two alleles in three, and sequencing errors on top"""
+    ref = os.path.join(tmp, "ref.fa")
+    util.synth_ref(kind, ref, genes=genes, scale=scale, seed=seed)
+    swap = {"A": "C", "C": "G", "G": "T", "T": "A"}
+    mut = os.path.join(tmp, "ref_mut.fa")
+    k = 0
+    with open(mut, "w") as o:
+        for name, head, sq in read_fa(ref):
+            if k % every != every - 1:
+                s = list(sq)
+                for p in positions:
+                    if p < len(s) and s[p] in swap:
+                        s[p] = swap[s[p]]
+                sq = "".join(s)
+            k += 1
+            o.write(head + "\n" + sq + "\n")
+    pfx = os.path.join(tmp, "r")
+    util.synth_reads(mut, pfx, pairs=pairs, len=150, seed=seed + 1, barcodes=40, sub=sub)
+    return ref, pfx
+
+
+@pytest.mark.parametrize("seed", [3, 17])
+def test_several_variants_per_gene_with_sequencing_errors(built, tmp_path, seed):
+    """groups of more than one candidate (two unknown bases within a read's reach), candidates expanded to the other selected alleles,
+    sequencing errors that must stay below the thresholds; also --varMaxGroup 1, which leaves the two-candidate groups unresolved"""
+    util.need(util.ORACLE_CLI)
+    tmp = str(tmp_path)
+    ref, pfx = several_snps_sample(tmp, seed)
+    want_vcf, got_vcf, want_table, got_table, moved, recs = run_case(tmp, ref, pfx)
+    assert want_vcf.count("\n") >= 2, want_vcf
+    assert got_vcf == want_vcf
+    assert got_table == want_table
+    sub = os.path.join(tmp, "g1")
+    os.makedirs(sub)
+    want1, got1, wt1, gt1, _, _ = run_case(sub, ref, pfx, var_max_group=1, ana_flags=["--varMaxGroup", "1"])
+    assert got1 == want1 and gt1 == wt1
+
+
+def test_single_end_run_and_no_variant_calling(built, tmp_path):
+    """-u input (no second read anywhere) and --varMaxGroup 0 (ComputeVariant returns at once: empty VCF, raw lists counted)"""
+    util.need(util.ORACLE_CLI)
+    tmp = str(tmp_path)
+    ref, pfx = several_snps_sample(tmp, 29, genes=3, pairs=2500)
+    want_vcf, got_vcf, want_table, got_table, moved, recs = run_case(tmp, ref, pfx, single=True)
+    assert want_vcf.count("\n") >= 1 and got_vcf == want_vcf and got_table == want_table
+    sub = os.path.join(tmp, "g0")
+    os.makedirs(sub)
+    want0, got0, wt0, gt0, moved0, _ = run_case(sub, ref, pfx, single=True, var_max_group=0, ana_flags=["--varMaxGroup", "0"])
+    assert want0 == got0 == "" and gt0 == wt0 and moved0 == 0
+
+
+def test_genomic_reference_with_introns_and_separators(built, tmp_path):
+    """a dna reference (exon coordinates in the records' comments, N separators): unknown bases inside an exon are called with their
+    exonic coordinate, the ones inside an intron are not written"""
+    util.need(util.ORACLE_CLI)
+    tmp = str(tmp_path)
+    ref, pfx = several_snps_sample(tmp, 41, genes=3, kind="ref-dna", scale=0.05, positions=tuple(range(120, 2400, 97)), pairs=6000)
+    want_vcf, got_vcf, want_table, got_table, moved, recs = run_case(tmp, ref, pfx)
+    assert got_vcf == want_vcf
+    assert got_table == want_table
+    assert want_vcf.count("\n") >= 1, "the sample calls no variant: it does not test what it is meant to"
+    assert any(r["exon_pos"] != r["ref_pos"] for r in recs)
+
+
+def test_bad_input_is_refused(built, tmp_path):
+    """an assignment whose window leaves its allele, or whose edit string does not spell its windows, is an argument error, not a crash"""
+    tmp = str(tmp_path)
+    ref = os.path.join(tmp, "ref.fa")
+    util.synth_ref("ref-rna", ref, genes=1, scale=0.05, seed=1)
+    name, head, seq = read_fa(ref)[0]
+    one = os.path.join(tmp, "one.fa")
+    open(one, "w").write(head + "\n" + seq + "\n")
+    job = t1k_amd.Job(one, device=-1)
+    read = seq[10:60]
+    o = (0, 0, 49, 10, 59, 1, 50, 0, 0, 50, 1.0)
+    zero = (0,) * 10 + (0.0,)
+    good = np.array([(0, 0, 0, 0, o, zero, 0, 0, 50, 0)], dtype=t1k_amd.FRAG_ASG_DTYPE)
+    ops = np.zeros(50, dtype=np.int8)
+    v = job.call_variants([1.0], 8, [0, 1], good, ops, [read])
+    assert v.vcf() == "" and list(v.adjust(good, ops, read)) == [1]
+    v.close()
+    for field, value in (("seq_end", len(seq)), ("read_end", 50), ("seq_start", -1), ("strand", 0), ("seq_idx", 1)):
+        bad = good.copy()
+        bad["o1"][field] = value
+        with pytest.raises(t1k_amd.T1kError):
+            job.call_variants([1.0], 8, [0, 1], bad, ops, [read])
+    short = good.copy()
+    short["n_ops1"] = 49
+    with pytest.raises(t1k_amd.T1kError):
+        job.call_variants([1.0], 8, [0, 1], short, ops, [read])
+    job.close()
