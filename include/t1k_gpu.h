@@ -423,6 +423,13 @@ typedef struct {
   uint64_t ops1, ops2;
   uint32_t n_ops1, n_ops2;
 } t1k_frag_assignment;
+/* The overlaps behind a fragment's kept assignments: for every allele of the fragment's row (alleles[nAlleles], the row's order) the choice
+ * SeqSet::ReadAssignmentToFragmentAssignment makes among the mates' overlaps on that allele (SeqSet.hpp:2310-2458: compatible pairs, or single
+ * overlaps when one list is empty / the run is single-end, ranked by _fragmentOverlap::operator<), taken from the read-ends' final overlap
+ * lists (t1k_overlaps_download).  paired = 0: a -u run (l2 ignored).  Fills allele_idx, has_mate_pair, o1_from_r2, o1, o2 of out[nAlleles]
+ * (the ops fields are left 0).  T1K_ERR_ARG: an allele has no candidate in the lists.  Host code. */
+int t1k_fragment_details(const t1k_overlap *l1, uint32_t n1, const t1k_overlap *l2, uint32_t n2, int paired, const int32_t *alleles, uint32_t nAlleles,
+                         t1k_frag_assignment *out);
 typedef struct {  /* _variant (VariantCaller.hpp:7-20) + the exonic coordinate OutputAlleleVCF prints */
   int32_t allele_idx, ref_pos, exon_pos;
   char ref, var;

@@ -130,6 +130,7 @@ def lib():
     L.t1k_job_groups_merge.argtypes = [vp, vp, vp, C.c_uint32]
     L.t1k_job_coalesce_rows.argtypes = [vp, vp, vp, vp, C.c_uint32]
     L.t1k_variants_call.argtypes = [vp, vp, C.c_int32, C.c_uint32, vp, vp, vp, vp, vp, vp, vp, C.POINTER(vp)]
+    L.t1k_fragment_details.argtypes = [vp, C.c_uint32, vp, C.c_uint32, C.c_int, vp, C.c_uint32, vp]
     L.t1k_variants_count.argtypes = [vp]
     L.t1k_variants_count.restype = C.c_uint32
     L.t1k_variants_get.argtypes = [vp, vp]
@@ -562,6 +563,18 @@ class Job:
         if lib().t1k_coverage_device(ctx, C.byref(p), C.byref(n)) != 0:
             raise T1kError("t1k_coverage_device failed")
         return p.value, n.value
+
+
+def fragment_details(l1, l2, alleles, paired=True):
+    """t1k_fragment_details: the overlaps behind a fragment's kept assignments (OVERLAP_DTYPE lists of its read-ends -> FRAG_ASG_DTYPE)"""
+    l1 = np.ascontiguousarray(l1, dtype=OVERLAP_DTYPE)
+    l2 = np.ascontiguousarray(l2 if l2 is not None else [], dtype=OVERLAP_DTYPE)
+    al = np.ascontiguousarray(alleles, dtype=np.int32)
+    out = np.zeros(len(al), dtype=FRAG_ASG_DTYPE)
+    rc = lib().t1k_fragment_details(_ptr(l1), len(l1), _ptr(l2), len(l2), 1 if paired else 0, _ptr(al), len(al), _ptr(out))
+    if rc != 0:
+        raise T1kError("t1k_fragment_details failed (%d): an allele of the row has no candidate in the lists" % rc)
+    return out
 
 
 class Variants:

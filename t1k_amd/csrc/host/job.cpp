@@ -1572,6 +1572,12 @@ static bool variantOpsOk(const t1k_overlap &o, const int8_t *e, uint32_t n) {
   return t == (int64_t)o.seq_end - o.seq_start + 1 && p == (int64_t)o.read_end - o.read_start + 1;
 }
 
+int t1k_fragment_details(const t1k_overlap *l1, uint32_t n1, const t1k_overlap *l2, uint32_t n2, int paired, const int32_t *alleles, uint32_t nAlleles,
+                         t1k_frag_assignment *out) {
+  if ((n1 && !l1) || (paired && n2 && !l2) || (nAlleles && (!alleles || !out))) return T1K_ERR_ARG;
+  return fragmentDetails(l1, n1, l2, paired ? n2 : 0, paired != 0, alleles, nAlleles, out) ? T1K_OK : T1K_ERR_ARG;
+}
+
 int t1k_variants_call(t1k_job *job, const double *abundance, int32_t var_max_group, uint32_t nFragments, const uint64_t *asgPtr, const t1k_frag_assignment *asg,
                       const int8_t *ops, const char *const *read1, const uint32_t *len1, const char *const *read2, const uint32_t *len2, t1k_variants **out) {
   if (!job || !out || !abundance || (nFragments && (!asgPtr || !read1 || !len1)) || ((read2 == nullptr) != (len2 == nullptr))) return T1K_ERR_ARG;

@@ -248,4 +248,8 @@ class VariantCaller {
   void solveGroup(const std::vector<int> &vars, int groupId);
 };
 
+// the overlaps behind the assignments a fragment kept (SeqSet::ReadAssignmentToFragmentAssignment's choice per allele, SeqSet.hpp:2310-2458) from
+// its read-ends' overlap lists; alleles = the fragment's row, in order.  false: an allele without a candidate in the lists
+bool fragmentDetails(const t1k_overlap *l1, uint32_t n1, const t1k_overlap *l2, uint32_t n2, bool paired, const int32_t *alleles, uint32_t nAlleles, t1k_frag_assignment *out);
+
 }  // namespace t1k

@@ -446,4 +446,77 @@ void VariantCaller::adjust(const Fragment &f, const int8_t *ops, uint8_t *keep) 
   for (uint32_t i = 0; i < f.n; ++i) keep[i] = score[i] == top ? 1 : 0;
 }
 
+// ---- which overlaps stand behind a fragment's assignment -----------------------------------------------------------------------------
+// The fragment rows of the device path (k_pair) keep, per assigned allele, the fragment's window and weight -- what the genotyper reads.
+// The variant caller also reads the two read-ends' own overlaps (_fragmentOverlap::overlap1 / overlap2, SeqSet.hpp:158-159), so the
+// choice SeqSet::ReadAssignmentToFragmentAssignment makes per allele (SeqSet.hpp:2310-2458) is taken again here, on the host, from the
+// read-ends' final overlap lists (t1k_overlaps_download: AssignRead's order), for the alleles the device kept and in the device's order.
+
+// _overlap::operator< (SeqSet.hpp:103-127)
+static bool overlapRanksBefore(const t1k_overlap &a, const t1k_overlap &b) {
+  if (a.match_cnt != b.match_cnt) return a.match_cnt > b.match_cnt;
+  if (a.similarity != b.similarity) return a.similarity > b.similarity;
+  if (a.read_end - a.read_start != b.read_end - b.read_start) return a.read_end - a.read_start > b.read_end - b.read_start;
+  if (a.seq_idx != b.seq_idx) return a.seq_idx < b.seq_idx;
+  if (a.strand != b.strand) return a.strand < b.strand;
+  if (a.read_start != b.read_start) return a.read_start < b.read_start;
+  if (a.read_end != b.read_end) return a.read_end < b.read_end;
+  if (a.seq_start != b.seq_start) return a.seq_start < b.seq_start;
+  return a.seq_end < b.seq_end;
+}
+
+bool fragmentDetails(const t1k_overlap *l1, uint32_t n1, const t1k_overlap *l2, uint32_t n2, bool paired, const int32_t *alleles, uint32_t nAlleles, t1k_frag_assignment *out) {
+  struct Pick { int i = -1, j = -1, matchCnt = 0; double sim = 0; };
+  for (uint32_t q = 0; q < nAlleles; ++q) {
+    const int A = alleles[q];
+    Pick best;
+    bool have = false;
+    auto offer = [&](const Pick &c) {
+      if (!have) { best = c; have = true; return; }
+      // _fragmentOverlap::operator< (SeqSet.hpp:164-171): a later candidate replaces the kept one only when it ranks strictly before it
+      const t1k_overlap &oc = c.i >= 0 ? l1[c.i] : l2[c.j], &ob = best.i >= 0 ? l1[best.i] : l2[best.j];
+      bool before;
+      if (c.matchCnt != best.matchCnt) before = c.matchCnt > best.matchCnt;
+      else if (c.sim != best.sim) before = c.sim > best.sim;
+      else before = overlapRanksBefore(oc, ob);
+      if (before) best = c;
+    };
+    if (!paired || n1 == 0 || n2 == 0) {  // single-end run, or one mate without an overlap: every overlap on its own (2321-2346)
+      for (uint32_t i = 0; i < n1; ++i)
+        if (l1[i].seq_idx == A) { Pick c; c.i = (int)i; c.matchCnt = l1[i].match_cnt; c.sim = l1[i].similarity; offer(c); }
+      if (paired)
+        for (uint32_t j = 0; j < n2; ++j)
+          if (l2[j].seq_idx == A) { Pick c; c.j = (int)j; c.matchCnt = l2[j].match_cnt; c.sim = l2[j].similarity; offer(c); }
+    } else {
+      for (uint32_t i = 0; i < n1; ++i) {
+        if (l1[i].seq_idx != A) continue;
+        const t1k_overlap &o = l1[i];
+        for (uint32_t j = 0; j < n2; ++j) {
+          const t1k_overlap &o2 = l2[j];
+          if (o2.seq_idx != A || o.strand == o2.strand) continue;  // 2364-2368
+          if (!((o.strand == 1 && o.seq_start < o2.seq_start) || (o.strand == -1 && o.seq_start > o2.seq_start))) continue;
+          Pick c;
+          c.i = (int)i; c.j = (int)j;
+          c.matchCnt = o.match_cnt + o2.match_cnt;
+          c.sim = (double)c.matchCnt / (o.read_end - o.read_start + 1 + o2.read_end - o2.read_start + 1 + o.seq_end - o.seq_start + 1 + o2.seq_end - o2.seq_start + 1 +
+                                         2 * o.left_clip + 2 * o.right_clip + 2 * o2.left_clip + 2 * o2.right_clip);  // 2411-2414
+          offer(c);
+        }
+      }
+    }
+    if (!have) return false;  // the device kept an allele the lists do not explain
+    t1k_frag_assignment &a = out[q];
+    memset(&a, 0, sizeof a);
+    a.allele_idx = A;
+    if (best.i >= 0) {
+      a.o1 = l1[best.i];
+      if (best.j >= 0) { a.has_mate_pair = 1; a.o2 = l2[best.j]; }
+    } else {
+      a.o1 = l2[best.j];
+      a.o1_from_r2 = 1;
+    }
+  }
+  return true;
+}
+
 }  // namespace t1k

@@ -60,7 +60,7 @@ def oracle_dump(tmp, ref, g, aligned, flags=()):
             if name in selected:
                 o.write(head + "\n" + seq + "\n")
     out = os.path.join(tmp, "orc")
-    r = subprocess.run([util.ORACLE_CLI, "-f", sel] + aligned + ["-o", out, "--fragDump"] + list(flags), stderr=subprocess.PIPE, text=True)
+    r = subprocess.run([util.ORACLE_CLI, "-f", sel] + aligned + ["-o", out, "--fragDump", "--dumpOverlaps"] + list(flags), stderr=subprocess.PIPE, text=True)
     assert r.returncode == 0, r.stderr
     names = [line.split("\t")[0] for line in open(out + "_abundance.tsv")]
     abundance = [float(line.split("\t")[1]) for line in open(out + "_abundance.tsv")]
@@ -90,6 +90,30 @@ def parse_dump(path, n_frag):
     ptr = np.zeros(n_frag + 1, dtype=np.uint64)
     ptr[1:] = np.cumsum(per)
     return ptr, asg, np.array(ops, dtype=np.int8)
+
+
+def check_details(out, ids, ptr, asg, single):
+    """t1k_fragment_details on the read-ends' overlap lists (<o>_overlaps.tsv: AssignRead's lists, the order t1k_overlaps_download returns)
+    must name, for every allele a fragment kept, the overlaps the restatement's pairing chose"""
+    at = {name: i for i, name in enumerate(ids)}
+    lists = {}
+    for line in open(out + "_overlaps.tsv"):
+        f = line.rstrip("\n").split("\t")
+        lists.setdefault((at[f[0]], int(f[1])), []).append((int(f[2]), int(f[3]), int(f[4]), int(f[5]), int(f[6]), int(f[7]), int(f[8]), int(f[10]), int(f[11]), int(f[12]), float(f[9])))
+    checked = dangling = 0
+    for f in range(len(ids)):
+        lo, hi = int(ptr[f]), int(ptr[f + 1])
+        if hi == lo:
+            continue
+        want = asg[lo:hi]
+        got = t1k_amd.fragment_details(lists.get((f, 1), []), None if single else lists.get((f, 2), []), want["allele_idx"], paired=not single)
+        for field in ("allele_idx", "has_mate_pair", "o1_from_r2", "o1"):
+            assert np.array_equal(got[field], want[field]), (f, field, got[field], want[field])
+        mates = want["has_mate_pair"] != 0
+        assert np.array_equal(got["o2"][mates], want["o2"][mates]), f
+        checked += hi - lo
+        dangling += int((want["o1_from_r2"] != 0).sum())
+    return checked, dangling
 
 
 def barcode_table(names, barcodes, ptr, asg, keep_of):
@@ -123,6 +147,10 @@ def run_case(tmp, ref, pfx, single=False, var_max_group=8, geno_flags=(), ana_fl
     r2 = None if single else [s for _, _, s in t1k_amd.read_fastx(aligned[3])]
     bcs = [s for _, _, s in t1k_amd.read_fastx(g + "_aligned_bc.fa")]
     ptr, asg, ops = parse_dump(out + "_fragdump.tsv", len(r1))
+    ids = [i for i, _, _ in t1k_amd.read_fastx(aligned[1])]
+    assert len(set(ids)) == len(ids)
+    checked, dangling = check_details(out, ids, ptr, asg, single)
+    assert checked == len(asg)
     job = t1k_amd.Job(sel, device=-1, **(job_kw or {}))
     v = job.call_variants(abundance, var_max_group, ptr, asg, ops, r1, r2)
     want_vcf = open(a + "_allele.vcf").read()
