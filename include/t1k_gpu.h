@@ -330,7 +330,8 @@ int t1k_extractor_main(int argc, char **argv);
  * IsLowComplexity + SeqSet::HasHitInSet (t1k_extract_batch).  The BAM container is read natively (BGZF blocks inflated in parallel). */
 int t1k_bam_extractor_main(int argc, char **argv);
 /* argv-compatible replacement of the reference's analyzer main() (Analyzer.cpp:236-733; run-t1k:438-449): re-assignment of the aligned reads
- * to the selected alleles and the per-barcode expression table; novel-variant calling (VariantCaller.hpp) is not built */
+ * to the selected alleles, novel-variant calling (VariantCaller.hpp: host code over the GPU's overlap lists and alignments, see
+ * t1k_variants_call below) and the per-barcode expression table */
 int t1k_analyzer_main(int argc, char **argv);
 
 typedef struct {

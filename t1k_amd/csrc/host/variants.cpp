@@ -9,7 +9,7 @@
 //      nucleotide's count); a second sweep adds 1 again wherever the overlap is "good" for the base (match count within 4 of the best of
 //      all four nucleotides, IsGoodAssignment 47-54) and keeps a "unique" count for fragments whose abundance share is exactly 1.
 //      The reference's walk does NOT advance its two positions when it skips a column (the `continue`s of 134-137 leave the loop body
-//      before 165-168): every later column of that overlap is booked one base early.  Kept, column for column (walkBooked below).
+//      before 165-168): every later column of that overlap is booked one base early.  Kept, column for column (bookOverlap below).
 //   2. root candidates (FindCandidateVariants 307-345): bases where a nucleotide other than the allele's own has count >= 5 and at least
 //      half the count of the allele's own.
 //   3. expansion to the other alleles a fragment is assigned to, until nothing is added (ExpandCandidateVariantsFromFragmentOverlap

@@ -1077,37 +1077,62 @@ def test_device_coalescing_equals_host_restatement(built, tmp_path):
 
 
 
+def analyzers_agree(tmp, ref, pfx, single=False, flags=(), geno_flags=(), env=None):
+    """this build's genotyper, then both analyzers on its files: <prefix>_allele.vcf and <prefix>_barcode_expr.tsv byte for byte"""
+    util.need(util.REF_ANALYZER)
+    g = os.path.join(tmp, "g")
+    reads = ["-u", pfx + "_1.fq"] if single else ["-1", pfx + "_1.fq", "-2", pfx + "_2.fq"]
+    r = subprocess.run([GENO, "-f", ref] + reads + ["--barcode", pfx + "_bc.fa", "-o", g] + list(geno_flags), stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 0, r.stderr
+    aligned = ["-u", g + "_aligned.fa"] if single else ["-1", g + "_aligned_1.fa", "-2", g + "_aligned_2.fa"]
+    common = ["-f", ref, "-a", g + "_allele.tsv"] + aligned + ["--barcode", g + "_aligned_bc.fa", "-t", "4"] + list(flags)
+    outs = []
+    for binary, tag in ((util.REF_ANALYZER, "ref"), (ANALYZER, "gpu")):
+        o = os.path.join(tmp, tag + "".join(flags).replace("-", ""))
+        r = subprocess.run([binary] + common + ["-o", o], stderr=subprocess.PIPE, text=True, env=dict(os.environ, **(env or {})))
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(o)
+    vcf = [open(o + "_allele.vcf").read() for o in outs]
+    table = [open(o + "_barcode_expr.tsv").read() for o in outs]
+    assert vcf[0] == vcf[1]
+    assert table[0] == table[1] and table[0].count("\n") > 5
+    return vcf[0], table[0]
+
+
 @pytest.mark.parametrize("het", [False, True])
 def test_analyzer_on_a_sample_with_a_novel_snp(built, tmp_path, het):
-    """The hole of SURVEY 8f row 2, fenced: on a sample whose reads carry a consistent SNP absent from the database the reference's analyzer
-    (default --varMaxGroup 8) calls the variant -- asserted here, so that the case stays one where the two modes differ -- which this build
-    cannot do: without --varMaxGroup 0 it must refuse (exit code 2, no file written), and with it both analyzers must write the same
-    per-barcode table and the same (empty) VCF."""
-    util.need(util.REF_ANALYZER)
+    """SURVEY 8f row 2 with its VariantCaller: on a sample whose reads carry a consistent SNP absent from the database the reference's
+    analyzer (default --varMaxGroup 8) calls the variant -- asserted, so that the case stays one where the stage matters -- and this
+    build's analyzer writes the same VCF line(s) and the same per-barcode table; with --varMaxGroup 0 both write an empty VCF and the
+    table of the raw assignment lists."""
     tmp = str(tmp_path)
     ref, pfx = util.novel_snp_sample(tmp, het)
-    g = os.path.join(tmp, "g")
-    r = subprocess.run([GENO, "-f", ref, "-1", pfx + "_1.fq", "-2", pfx + "_2.fq", "--barcode", pfx + "_bc.fa", "-o", g], stderr=subprocess.PIPE, text=True)
-    assert r.returncode == 0, r.stderr
-    common = ["-f", ref, "-a", g + "_allele.tsv", "-1", g + "_aligned_1.fa", "-2", g + "_aligned_2.fa", "--barcode", g + "_aligned_bc.fa", "-t", "4"]
-    # the reference in its default mode: it calls the SNP
-    d = os.path.join(tmp, "ref_default")
-    r = subprocess.run([util.REF_ANALYZER] + common + ["-o", d], stderr=subprocess.PIPE, text=True)
-    assert r.returncode == 0, r.stderr
-    vcf = open(d + "_allele.vcf").read()
+    vcf, table = analyzers_agree(tmp, ref, pfx)
     assert vcf.count("\n") >= 1 and " 401 . " in vcf, vcf
-    # this build in that mode: refuses, loudly, and leaves nothing behind
-    x = os.path.join(tmp, "gpu_default")
-    r = subprocess.run([ANALYZER] + common + ["-o", x], stderr=subprocess.PIPE, text=True)
-    assert r.returncode == 2 and "--varMaxGroup 0" in r.stderr, (r.returncode, r.stderr[-400:])
-    assert not [f for f in os.listdir(tmp) if f.startswith("gpu_default")]
-    # both in the reference's no-variant-calling mode: the same files
-    outs = []
-    for binary, tag in ((util.REF_ANALYZER, "ref0"), (ANALYZER, "gpu0")):
-        o = os.path.join(tmp, tag)
-        r = subprocess.run([binary] + common + ["-o", o, "--varMaxGroup", "0"], stderr=subprocess.PIPE, text=True)
-        assert r.returncode == 0, r.stderr
-        outs.append(o)
-    assert open(outs[0] + "_allele.vcf").read() == open(outs[1] + "_allele.vcf").read() == ""
-    a, b = open(outs[0] + "_barcode_expr.tsv").read(), open(outs[1] + "_barcode_expr.tsv").read()
-    assert a.count("\n") > 20 and a == b
+    vcf0, table0 = analyzers_agree(tmp, ref, pfx, flags=["--varMaxGroup", "0"])
+    assert vcf0 == "" and table0.count("\n") > 20
+
+
+@pytest.mark.parametrize("case", ["several_per_gene", "genomic_reference", "single_end"])
+def test_analyzer_variant_calling_vs_reference_binary(built, tmp_path, case):
+    """several unknown bases per gene on two alleles in three with sequencing errors on top (groups of two candidates, candidates expanded
+    to the other selected alleles, fragments whose assignment list the called variants shorten); the same on a genomic reference (introns,
+    exonic coordinates, ties that are written as FAIL pairs); a -u run.  --varMaxGroup 1 leaves the two-candidate groups unresolved."""
+    tmp = str(tmp_path)
+    if case == "several_per_gene":
+        ref, pfx = util.several_snps_sample(tmp, 3)
+        vcf, _ = analyzers_agree(tmp, ref, pfx)
+        assert vcf.count("\n") >= 8
+        vcf1, _ = analyzers_agree(tmp, ref, pfx, flags=["--varMaxGroup", "1"])
+        assert vcf1 != vcf
+    elif case == "genomic_reference":
+        ref, pfx = util.several_snps_sample(tmp, 41, genes=3, kind="ref-dna", scale=0.05, positions=tuple(range(120, 2400, 97)), pairs=6000)
+        vcf, _ = analyzers_agree(tmp, ref, pfx)
+        assert vcf.count("\n") >= 4 and "FAIL" in vcf
+    else:
+        ref, pfx = util.several_snps_sample(tmp, 29, genes=3, pairs=2500)
+        vcf, table = analyzers_agree(tmp, ref, pfx, single=True)
+        assert vcf.count("\n") >= 1
+        # the variant pass in several pieces (re-assignment of the read-ends, their alignments): the same files
+        vcf2, table2 = analyzers_agree(tmp, ref, pfx, single=True, flags=["-n", "1999"], env={"T1K_ANALYZER_PIECE": "600"})
+        assert (vcf2, table2) == (vcf, table)

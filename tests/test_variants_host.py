@@ -24,16 +24,6 @@ def built():
     return True
 
 
-def read_fa(path):
-    recs = []
-    for line in open(path):
-        if line.startswith(">"):
-            recs.append([line[1:].split()[0], line.rstrip("\n"), ""])
-        else:
-            recs[-1][2] += line.strip()
-    return recs
-
-
 def reference_run(tmp, ref, pfx, geno_flags=(), ana_flags=(), single=False):
     """reference genotyper -> reference analyzer (default --varMaxGroup 8 unless ana_flags say otherwise)"""
     util.need(util.REF_BIN)
@@ -56,7 +46,7 @@ def oracle_dump(tmp, ref, g, aligned, flags=()):
     selected = set(line.split()[0] for line in open(g + "_allele.tsv") if line.strip())
     sel = os.path.join(tmp, "selected.fa")
     with open(sel, "w") as o:
-        for name, head, seq in read_fa(ref):
+        for name, head, seq in util.read_fa(ref):
             if name in selected:
                 o.write(head + "\n" + seq + "\n")
     out = os.path.join(tmp, "orc")
@@ -185,36 +175,13 @@ def test_called_variants_and_adjusted_counts_vs_reference_analyzer(built, tmp_pa
     assert len(recs) == want_vcf.count("\n") and all(r["exon_pos"] == r["ref_pos"] for r in recs)  # (an rna reference: every base is exonic)
 
 
-def several_snps_sample(tmp, seed, genes=5, every=3, positions=(150, 152, 400, 800), pairs=4000, sub=0.002, kind="ref-rna", scale=0.05):
-    """like util.novel_snp_sample with several unknown bases per gene -- two of them three bases apart, so that one read-end spans both and
-    their candidates fall into one group -- carried by two alleles in three, and sequencing errors on top"""
-    ref = os.path.join(tmp, "ref.fa")
-    util.synth_ref(kind, ref, genes=genes, scale=scale, seed=seed)
-    swap = {"A": "C", "C": "G", "G": "T", "T": "A"}
-    mut = os.path.join(tmp, "ref_mut.fa")
-    k = 0
-    with open(mut, "w") as o:
-        for name, head, sq in read_fa(ref):
-            if k % every != every - 1:
-                s = list(sq)
-                for p in positions:
-                    if p < len(s) and s[p] in swap:
-                        s[p] = swap[s[p]]
-                sq = "".join(s)
-            k += 1
-            o.write(head + "\n" + sq + "\n")
-    pfx = os.path.join(tmp, "r")
-    util.synth_reads(mut, pfx, pairs=pairs, len=150, seed=seed + 1, barcodes=40, sub=sub)
-    return ref, pfx
-
-
 @pytest.mark.parametrize("seed", [3, 17])
 def test_several_variants_per_gene_with_sequencing_errors(built, tmp_path, seed):
     """groups of more than one candidate (two unknown bases within a read's reach), candidates expanded to the other selected alleles,
     sequencing errors that must stay below the thresholds; also --varMaxGroup 1, which leaves the two-candidate groups unresolved"""
     util.need(util.ORACLE_CLI)
     tmp = str(tmp_path)
-    ref, pfx = several_snps_sample(tmp, seed)
+    ref, pfx = util.several_snps_sample(tmp, seed)
     want_vcf, got_vcf, want_table, got_table, moved, recs = run_case(tmp, ref, pfx)
     assert want_vcf.count("\n") >= 2, want_vcf
     assert got_vcf == want_vcf
@@ -229,7 +196,7 @@ def test_single_end_run_and_no_variant_calling(built, tmp_path):
     """-u input (no second read anywhere) and --varMaxGroup 0 (ComputeVariant returns at once: empty VCF, raw lists counted)"""
     util.need(util.ORACLE_CLI)
     tmp = str(tmp_path)
-    ref, pfx = several_snps_sample(tmp, 29, genes=3, pairs=2500)
+    ref, pfx = util.several_snps_sample(tmp, 29, genes=3, pairs=2500)
     want_vcf, got_vcf, want_table, got_table, moved, recs = run_case(tmp, ref, pfx, single=True)
     assert want_vcf.count("\n") >= 1 and got_vcf == want_vcf and got_table == want_table
     sub = os.path.join(tmp, "g0")
@@ -243,7 +210,7 @@ def test_genomic_reference_with_introns_and_separators(built, tmp_path):
     exonic coordinate, the ones inside an intron are not written"""
     util.need(util.ORACLE_CLI)
     tmp = str(tmp_path)
-    ref, pfx = several_snps_sample(tmp, 41, genes=3, kind="ref-dna", scale=0.05, positions=tuple(range(120, 2400, 97)), pairs=6000)
+    ref, pfx = util.several_snps_sample(tmp, 41, genes=3, kind="ref-dna", scale=0.05, positions=tuple(range(120, 2400, 97)), pairs=6000)
     want_vcf, got_vcf, want_table, got_table, moved, recs = run_case(tmp, ref, pfx)
     assert got_vcf == want_vcf
     assert got_table == want_table
@@ -256,7 +223,7 @@ def test_bad_input_is_refused(built, tmp_path):
     tmp = str(tmp_path)
     ref = os.path.join(tmp, "ref.fa")
     util.synth_ref("ref-rna", ref, genes=1, scale=0.05, seed=1)
-    name, head, seq = read_fa(ref)[0]
+    name, head, seq = util.read_fa(ref)[0]
     one = os.path.join(tmp, "one.fa")
     open(one, "w").write(head + "\n" + seq + "\n")
     job = t1k_amd.Job(one, device=-1)

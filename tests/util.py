@@ -76,6 +76,39 @@ def novel_snp_sample(tmp, het):
     return ref, pfx
 
 
+def read_fa(path):
+    recs = []
+    for line in open(path):
+        if line.startswith(">"):
+            recs.append([line[1:].split()[0], line.rstrip("\n"), ""])
+        else:
+            recs[-1][2] += line.strip()
+    return recs
+
+
+def several_snps_sample(tmp, seed, genes=5, every=3, positions=(150, 152, 400, 800), pairs=4000, sub=0.002, kind="ref-rna", scale=0.05):
+    """like util.novel_snp_sample with several unknown bases per gene -- two of them three bases apart, so that one read-end spans both and
+    their candidates fall into one group -- carried by two alleles in three, and sequencing errors on top"""
+    ref = os.path.join(tmp, "ref.fa")
+    synth_ref(kind, ref, genes=genes, scale=scale, seed=seed)
+    swap = {"A": "C", "C": "G", "G": "T", "T": "A"}
+    mut = os.path.join(tmp, "ref_mut.fa")
+    k = 0
+    with open(mut, "w") as o:
+        for name, head, sq in read_fa(ref):
+            if k % every != every - 1:
+                s = list(sq)
+                for p in positions:
+                    if p < len(s) and s[p] in swap:
+                        s[p] = swap[s[p]]
+                sq = "".join(s)
+            k += 1
+            o.write(head + "\n" + sq + "\n")
+    pfx = os.path.join(tmp, "r")
+    synth_reads(mut, pfx, pairs=pairs, len=150, seed=seed + 1, barcodes=40, sub=sub)
+    return ref, pfx
+
+
 def gunzip_to(src, dst):
     import gzip
     import shutil
