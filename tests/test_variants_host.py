@@ -130,6 +130,9 @@ def barcode_table(names, barcodes, ptr, asg, keep_of):
     return out
 
 
+LAST = {}  # what the last run_case saw (tests assert that their sample holds what they are about)
+
+
 def run_case(tmp, ref, pfx, single=False, var_max_group=8, geno_flags=(), ana_flags=(), orc_flags=(), job_kw=None):
     g, a, aligned = reference_run(tmp, ref, pfx, geno_flags, ana_flags, single)
     sel, out, names, abundance = oracle_dump(tmp, ref, g, aligned, orc_flags)
@@ -141,6 +144,7 @@ def run_case(tmp, ref, pfx, single=False, var_max_group=8, geno_flags=(), ana_fl
     assert len(set(ids)) == len(ids)
     checked, dangling = check_details(out, ids, ptr, asg, single)
     assert checked == len(asg)
+    LAST.update(assignments=len(asg), from_r2=dangling, unpaired=int((asg["has_mate_pair"] == 0).sum()), zero_abundance=sum(1 for x in abundance if x == 0))
     job = t1k_amd.Job(sel, device=-1, **(job_kw or {}))
     v = job.call_variants(abundance, var_max_group, ptr, asg, ops, r1, r2)
     want_vcf = open(a + "_allele.vcf").read()
@@ -216,6 +220,55 @@ def test_genomic_reference_with_introns_and_separators(built, tmp_path):
     assert got_table == want_table
     assert want_vcf.count("\n") >= 1, "the sample calls no variant: it does not test what it is meant to"
     assert any(r["exon_pos"] != r["ref_pos"] for r in recs)
+
+
+@pytest.mark.parametrize("seed", [7, 53])
+def test_reads_with_indels_and_unknown_bases(built, tmp_path, seed):
+    """reads with insertions, deletions and N on top of the unknown SNPs: edit strings with gap columns, the reference's base walk that
+    stays where it is when it skips a column (an N in the read, an overlap that is not good for the base), overlaps of lower match counts
+    that IsGoodAssignment filters"""
+    util.need(util.ORACLE_CLI)
+    tmp = str(tmp_path)
+    ref, pfx = util.several_snps_sample(tmp, seed, genes=4, pairs=5000, sub=0.004, indel=0.004, nrate=0.004)
+    want_vcf, got_vcf, want_table, got_table, moved, recs = run_case(tmp, ref, pfx)
+    assert want_vcf.count("\n") >= 4, want_vcf
+    assert got_vcf == want_vcf
+    assert got_table == want_table
+
+
+def test_relaxed_intron_alignment_on_a_genomic_reference(built, tmp_path):
+    """--relaxIntronAlign on both stages (the analyzer's assignment keeps fragments with intronic mismatches, SeqSet.hpp:2491-2519): more
+    assignments per fragment reach the variant caller"""
+    util.need(util.ORACLE_CLI)
+    tmp = str(tmp_path)
+    ref, pfx = util.several_snps_sample(tmp, 61, genes=3, kind="ref-dna", scale=0.05, positions=tuple(range(90, 2400, 61)), pairs=6000, sub=0.003)
+    flags = ["--relaxIntronAlign"]
+    want_vcf, got_vcf, want_table, got_table, moved, recs = run_case(tmp, ref, pfx, geno_flags=flags, ana_flags=flags, orc_flags=flags)
+    assert want_vcf.count("\n") >= 1, "the sample calls no variant"
+    assert got_vcf == want_vcf
+    assert got_table == want_table
+
+
+def test_fragments_with_one_unalignable_mate(built, tmp_path):
+    """every fifth first mate and every seventh second mate replaced by random bases: fragments assigned through one read-end only
+    (SeqSet.hpp:2330-2346, 2563-2590 -- kept when that end is a perfect match at the allele's edge), among them the ones whose single
+    overlap comes from the SECOND read (o1FromR2: VariantCaller reads read 2 for overlap 1, VariantCaller.hpp:296-301, 376-380, 1241-1243)"""
+    util.need(util.ORACLE_CLI)
+    import random
+    tmp = str(tmp_path)
+    ref, pfx = util.several_snps_sample(tmp, 71, genes=4, pairs=9000, sub=0.0, indel=0.0, nrate=0.0, fragmean=230, fragsd=60)
+    rng = random.Random(5)
+    for mate, every in ((1, 5), (2, 7)):
+        path = "%s_%d.fq" % (pfx, mate)
+        lines = open(path).read().split("\n")
+        for i in range(0, len(lines) - 3, 4):
+            if (i // 4) % every == 0:
+                lines[i + 1] = "".join(rng.choice("ACGT") for _ in lines[i + 1])
+        open(path, "w").write("\n".join(lines))
+    want_vcf, got_vcf, want_table, got_table, moved, recs = run_case(tmp, ref, pfx)
+    assert LAST["from_r2"] > 0 and LAST["unpaired"] > LAST["from_r2"], LAST
+    assert got_vcf == want_vcf and want_vcf.count("\n") >= 1
+    assert got_table == want_table
 
 
 def test_bad_input_is_refused(built, tmp_path):

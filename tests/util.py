@@ -86,7 +86,7 @@ def read_fa(path):
     return recs
 
 
-def several_snps_sample(tmp, seed, genes=5, every=3, positions=(150, 152, 400, 800), pairs=4000, sub=0.002, kind="ref-rna", scale=0.05):
+def several_snps_sample(tmp, seed, genes=5, every=3, positions=(150, 152, 400, 800), pairs=4000, sub=0.002, kind="ref-rna", scale=0.05, **reads_kw):
     """like util.novel_snp_sample with several unknown bases per gene -- two of them three bases apart, so that one read-end spans both and
     their candidates fall into one group -- carried by two alleles in three, and sequencing errors on top"""
     ref = os.path.join(tmp, "ref.fa")
@@ -105,7 +105,7 @@ def several_snps_sample(tmp, seed, genes=5, every=3, positions=(150, 152, 400, 8
             k += 1
             o.write(head + "\n" + sq + "\n")
     pfx = os.path.join(tmp, "r")
-    synth_reads(mut, pfx, pairs=pairs, len=150, seed=seed + 1, barcodes=40, sub=sub)
+    synth_reads(mut, pfx, pairs=pairs, len=150, seed=seed + 1, barcodes=40, sub=sub, **reads_kw)
     return ref, pfx
 
 
