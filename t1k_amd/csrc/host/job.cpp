@@ -1991,6 +1991,9 @@ struct AnalyzerVariants {
 };
 
 static int analyzerCallVariants(t1k_job *job, int varMaxGroup, AnalyzerVariants &V) {
+  const double tv0 = nowMs();
+  double msAssign = 0, msDetails = 0, msAlign = 0;
+  uint64_t nEnds = 0, nJobs = 0;
   const ReadInput &in = *job->in;
   const RefSet &R = job->ref;
   const uint32_t F = (uint32_t)in.nFrag();
@@ -2038,6 +2041,7 @@ static int analyzerCallVariants(t1k_job *job, int varMaxGroup, AnalyzerVariants 
   }
   std::vector<double> abundance(R.al.size());
   for (size_t a = 0; a < R.al.size(); ++a) abundance[a] = R.al[a].abundance;
+  const double tv1 = nowMs();
   // (2) + (3)
   t1k_ctx *vctx = nullptr;
   if ((rc = t1k_ctx_create(job->prm.device, &job->prm.dev, &vctx)) != T1K_OK) { if (vctx) t1k_ctx_destroy(vctx); return jobFail(job, rc, "analyzer: cannot create the context of the variant pass"); }
@@ -2080,6 +2084,8 @@ static int analyzerCallVariants(t1k_job *job, int varMaxGroup, AnalyzerVariants 
       for (uint32_t e = 0; e < E; ++e) off[e + 1] = off[e] + ends[e].second;
       text.reserve(off[E]);
       for (uint32_t e = 0; e < E; ++e) text.append(ends[e].first, ends[e].second);
+      const double ta = nowMs();
+      nEnds += E;
       if ((rc = t1k_reads_upload(vctx, text.data(), off.data(), nullptr, E)) != T1K_OK) return jobFail(job, rc, t1k_last_error(vctx));
       if ((rc = t1k_assign_batch(vctx)) != T1K_OK) return jobFail(job, rc, t1k_last_error(vctx));
       std::vector<uint32_t> lc(E);
@@ -2089,6 +2095,8 @@ static int analyzerCallVariants(t1k_job *job, int varMaxGroup, AnalyzerVariants 
       if (total && (rc = t1k_overlaps_download(vctx, lc.data(), lists.data(), total, &total)) != T1K_OK) return jobFail(job, rc, t1k_last_error(vctx));
       std::vector<uint64_t> listAt(E + 1, 0);
       for (uint32_t e = 0; e < E; ++e) listAt[e + 1] = listAt[e] + lc[e];
+      const double tb = nowMs();
+      msAssign += tb - ta;
       // the overlaps behind every kept assignment
       std::vector<int32_t> alleles;
       for (uint32_t f = f0; f < f1; ++f) {
@@ -2139,6 +2147,9 @@ static int analyzerCallVariants(t1k_job *job, int varMaxGroup, AnalyzerVariants 
       if (pat.size() >= (1ull << 32)) return jobFail(job, T1K_ERR_CAPACITY, "analyzer: a piece's read text exceeds 4 GB");
       std::vector<uint64_t> opsAtOfJob(jobs.size());
       std::vector<uint32_t> nOpsOfJob(jobs.size());
+      const double tc = nowMs();
+      msDetails += tc - tb;
+      nJobs += jobs.size();
       const size_t callJobs = 1u << 18;
       for (size_t j0 = 0; j0 < jobs.size(); j0 += callJobs) {
         const uint32_t n = (uint32_t)std::min(callJobs, jobs.size() - j0);
@@ -2170,9 +2181,11 @@ static int analyzerCallVariants(t1k_job *job, int varMaxGroup, AnalyzerVariants 
         a.ops1 = opsAtOfJob[j1]; a.n_ops1 = nOpsOfJob[j1];
         if (a.has_mate_pair) { a.ops2 = opsAtOfJob[j2]; a.n_ops2 = nOpsOfJob[j2]; }
       }
+      msAlign += nowMs() - tc;
     }
     f0 = f1;
   }
+  const double tv2 = nowMs();
   // (4)
   std::vector<VariantCaller::Fragment> frags(F);
   for (uint32_t f = 0; f < F; ++f) {
@@ -2185,6 +2198,10 @@ static int analyzerCallVariants(t1k_job *job, int varMaxGroup, AnalyzerVariants 
   }
   V.vc.reset(new VariantCaller(R, abundance, varMaxGroup));
   V.vc->compute(frags, V.ops.data());
+  if (getenv("T1K_DEBUG_PHASES"))
+    fprintf(stderr, "[t1k analyzer] variant pass: rows + EM %.1f ms; %llu distinct read-ends re-assigned in %.1f ms, overlaps chosen in %.1f ms, %llu alignments in %.1f ms; "
+                    "VariantCaller %.1f ms (%zu assignments, %zu variants); %.1f ms in all\n", tv1 - tv0, (unsigned long long)nEnds, msAssign, msDetails, (unsigned long long)nJobs, msAlign,
+            nowMs() - tv2, V.asg.size(), V.vc->variants.size(), nowMs() - tv0);
   return T1K_OK;
 }
 

@@ -233,6 +233,7 @@ class VariantCaller {
   std::unique_ptr<std::vector<Cell>> cells_; // one per allele base
   std::vector<int> copies_;                  // seqCopy
   std::vector<std::pair<int, int>> cand_;    // candidateVariants: (allele, position)
+  std::vector<std::vector<int>> candAt_;     // allele -> its candidates' positions, ascending
   std::vector<char> root_;                   // found from the counts (rootCandidate), not by expansion
   std::vector<int> group_;                   // candidateVariantGroupId
   std::vector<std::vector<std::pair<int, double>>> edges_;     // candidate -> (candidate, weight)
@@ -240,11 +241,12 @@ class VariantCaller {
   std::unordered_map<size_t, std::vector<int>> calledAt_;      // cell -> called variants (finalVariantIds)
   Cell &cell(int allele, int pos) const;
   void bookOverlap(const char *read, uint32_t len, const t1k_overlap &o, const int8_t *ops, uint32_t nOps, double weight, bool filter);
-  void bookFragment(const Fragment &f, const int8_t *ops, bool first);
+  void bookFragment(const Fragment &f, const int8_t *ops, bool first, int part, int parts);
+  bool candidateIn(int allele, int from, int to) const;
   int newCandidate(int allele, int pos, bool root);
   void findRoots();
   void expandFragment(const Fragment &f, const int8_t *ops);
-  void linkFragment(const Fragment &f, uint32_t fragIdx, const int8_t *ops);
+  void linkFragment(const Fragment &f, uint32_t fragIdx, const int8_t *ops, int part, int parts);
   void solveGroup(const std::vector<int> &vars, int groupId);
 };
 

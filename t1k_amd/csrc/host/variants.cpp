@@ -27,9 +27,12 @@
 // threads linked lists through SimpleVectors; list order never reaches a result: weights are integer counts, groups are components, a
 // leaf of the enumeration only counts), the enumeration as an odometer instead of a recursion.
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
+#include <thread>
 #include <unordered_map>
 
 #include "t1k_host.h"
@@ -43,15 +46,17 @@ enum { OP_MATCH = 0, OP_MISMATCH = 1, OP_INSERT = 2, OP_DELETE = 3 };  // AlignA
 inline int nucIndex(char c) { return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : -1; }  // nucToNum, Analyzer.cpp:34-37
 const char kNuc[4] = {'A', 'C', 'G', 'T'};
 
-// SeqSet::ReverseComplement (SeqSet.hpp:2103-2114): N stays N
-std::string reverseComplement(const char *s, uint32_t n) {
-  std::string r(n, 'N');
-  for (uint32_t i = 0; i < n; ++i) {
-    const int b = nucIndex(s[n - 1 - i]);
-    if (b >= 0) r[i] = kNuc[3 - b];
+// a read as an overlap sees it: as it is, or reverse-complemented (SeqSet::ReverseComplement, SeqSet.hpp:2103-2114: what is not A/C/G/T stays N)
+struct ReadView {
+  const char *p;
+  uint32_t n;
+  bool rev;
+  char at(int i) const {
+    if (!rev) return p[i];
+    const int b = nucIndex(p[n - 1 - (uint32_t)i]);
+    return b >= 0 ? kNuc[3 - b] : 'N';
   }
-  return r;
-}
+};
 
 }  // namespace
 
@@ -59,13 +64,10 @@ struct VariantCaller::Cell {
   double count[4] = {0, 0, 0, 0};  // _baseVariant::count; unweightedCount (every statement that adds to one adds the same to the other: 142-143)
   double uniq[4] = {0, 0, 0, 0};   // uniqCount
   int bestMatch[4] = {0, 0, 0, 0}; // alignInfo[].a (the similarity beside it, alignInfo[].b, is written and never read)
+  int bestOfAll = 0;               // the largest of the four
   int cand = -1;                   // candidateId
   double depth() const { return count[0] + count[1] + count[2] + count[3]; }
-  bool good(int matchCnt) const {  // IsGoodAssignment (47-54)
-    for (int i = 0; i < 4; ++i)
-      if (matchCnt < bestMatch[i] - 4) return false;
-    return true;
-  }
+  bool good(int matchCnt) const { return matchCnt >= bestOfAll - 4; }  // IsGoodAssignment (47-54): not more than 4 below any nucleotide's best
 };
 
 VariantCaller::~VariantCaller() = default;
@@ -80,6 +82,7 @@ VariantCaller::VariantCaller(const RefSet &ref, const std::vector<double> &abund
   for (size_t a = 0; a < A; ++a) ++perGene[ref.al[a].gene];
   copies_.resize(A);
   for (size_t a = 0; a < A; ++a) copies_[a] = perGene[ref.al[a].gene];
+  candAt_.assign(A, {});
 }
 
 VariantCaller::Cell &VariantCaller::cell(int allele, int pos) const { return (*cells_)[base_[allele] + (size_t)pos]; }
@@ -91,37 +94,39 @@ static inline void endOps(const t1k_frag_assignment &a, int k, const int8_t *ops
   n = k == 1 ? a.n_ops2 : a.n_ops1;
 }
 
-// UpdateBaseVariantFromOverlap (103-173).  first: the sweep that only learns the best match counts (updateType 1: weight 0, no filter)
+// UpdateBaseVariantFromOverlap (103-173).  filter = false: the sweep that only learns the best match counts (updateType 1: weight 0)
 void VariantCaller::bookOverlap(const char *read, uint32_t len, const t1k_overlap &o, const int8_t *ops, uint32_t nOps, double weight, bool filter) {
   if (o.seq_idx == -1) return;
-  std::string rc;
-  const char *r = read;
-  if (o.strand == -1) { rc = reverseComplement(read, len); r = rc.data(); }
+  const ReadView r{read, len, o.strand == -1};
   const int L = (int)ref_.seqs[o.seq_idx].size();
+  Cell *cells = cells_->data() + base_[o.seq_idx];
   int refPos = o.seq_start, readPos = o.read_start;
   for (uint32_t k = 0; k < nOps; ++k) {
     const int op = ops[k];
     if (op == OP_MATCH || op == OP_MISMATCH) {
       if (refPos >= L || readPos >= (int)len) break;  // (cannot happen with the edit string of this overlap; the reference does not look)
-      Cell &c = cell(o.seq_idx, refPos);
+      Cell &c = cells[refPos];
       if (filter && !c.good(o.match_cnt)) continue;  // 134-135: leaves the column WITHOUT moving on (see the header)
-      const int b = nucIndex(r[readPos]);
+      const int b = nucIndex(r.at(readPos));
       if (b < 0) continue;                           // 136-137 ('N'): the same
       if (weight == 1) c.uniq[b] += weight;
       c.count[b] += 1;
-      if (o.match_cnt > c.bestMatch[b]) c.bestMatch[b] = o.match_cnt;
+      if (o.match_cnt > c.bestMatch[b]) { c.bestMatch[b] = o.match_cnt; if (o.match_cnt > c.bestOfAll) c.bestOfAll = o.match_cnt; }
     }
     if (op != OP_INSERT) ++refPos;
     if (op != OP_DELETE) ++readPos;
   }
 }
 
-// UpdateBaseVariantFromFragmentOverlap (273-305)
-void VariantCaller::bookFragment(const Fragment &f, const int8_t *ops, bool first) {
+// UpdateBaseVariantFromFragmentOverlap (273-305).  An overlap books into the cells of its own allele only, and what it reads there (good())
+// was written by overlaps on the same allele: thread `part` of `parts` takes the assignments of the alleles it owns, in fragment order, and
+// every allele's cells see exactly the sequence of updates of a single sweep.
+void VariantCaller::bookFragment(const Fragment &f, const int8_t *ops, bool first, int part, int parts) {
   double total = 0;
   for (uint32_t i = 0; i < f.n; ++i) total += abundance_[f.asg[i].allele_idx];
   for (uint32_t i = 0; i < f.n; ++i) {
     const t1k_frag_assignment &a = f.asg[i];
+    if (a.allele_idx % parts != part) continue;
     const double w = first ? 0.0 : abundance_[a.allele_idx] / total;
     if (a.has_mate_pair) {
       bookOverlap(f.r1, f.l1, a.o1, ops + a.ops1, a.n_ops1, w, !first);
@@ -131,12 +136,21 @@ void VariantCaller::bookFragment(const Fragment &f, const int8_t *ops, bool firs
   }
 }
 
+// candidates of an allele inside [from, to]?  (what the reference's accumulated counts were meant for, 182-199, 214-226)
+bool VariantCaller::candidateIn(int allele, int from, int to) const {
+  const std::vector<int> &v = candAt_[allele];
+  auto it = std::lower_bound(v.begin(), v.end(), from);
+  return it != v.end() && *it <= to;
+}
+
 int VariantCaller::newCandidate(int allele, int pos, bool root) {
   const int id = (int)cand_.size();
   cand_.push_back({allele, pos});
   root_.push_back(root ? 1 : 0);
   group_.push_back(-1);
   cell(allele, pos).cand = id;
+  std::vector<int> &v = candAt_[allele];
+  v.insert(std::upper_bound(v.begin(), v.end(), pos), pos);
   return id;
 }
 
@@ -176,6 +190,14 @@ void VariantCaller::expandFragment(const Fragment &f, const int8_t *ops) {
     for (uint32_t i = 1; i < n; ++i)
       if (readPos[i] != readPos[0]) { sameStart = false; break; }
     if (!sameStart) continue;  // 398-404
+    // The walk below stands on the bases [seq_start, seq_end + 1] of every assignment and does something only where one of them is a
+    // candidate: a read-end none of whose windows holds a candidate (as of now -- candidates are added while the fragments are swept) is done.
+    bool any = false;
+    for (uint32_t i = 0; i < n && !any; ++i) {
+      const t1k_overlap &o = endOverlap(f.asg[i], k);
+      any = candidateIn(o.seq_idx, o.seq_start, o.seq_end + 1);
+    }
+    if (!any) continue;
     std::fill(at.begin(), at.end(), 0u);
     for (uint32_t j = 0; j < len; ++j) {  // the read position is the anchor (407)
       bool onCandidate = false;
@@ -227,24 +249,21 @@ void VariantCaller::expandFragment(const Fragment &f, const int8_t *ops) {
 }
 
 // BuildFragmentCandidateVarGraph (595-687): seen_[c] = (fragment, nucleotide) pairs, each once.  Fragments arrive in order, so the pairs
-// of the current fragment are the tail of the vector.
-void VariantCaller::linkFragment(const Fragment &f, uint32_t fragIdx, const int8_t *ops) {
+// of the current fragment are the tail of the vector.  A candidate's list is written by the assignments on its allele only: thread `part` of
+// `parts` takes the alleles it owns.
+void VariantCaller::linkFragment(const Fragment &f, uint32_t fragIdx, const int8_t *ops, int part, int parts) {
   if (!f.n) return;
   for (int k = 0; k <= 1; ++k) {
     if (k == 1 && !f.asg[0].has_mate_pair) break;
     const bool second = k == 1 || f.asg[0].o1_from_r2;
     const char *read = second ? f.r2 : f.r1;
     const uint32_t len = second ? f.l2 : f.l1;
-    std::string rc;
-    bool haveRc = false;
     for (uint32_t i = 0; i < f.n; ++i) {
-      const t1k_overlap &o = endOverlap(f.asg[i], k);
-      const char *r = read;
-      if (o.strand == -1) {
-        if (!haveRc) { rc = reverseComplement(read, len); haveRc = true; }
-        r = rc.data();
-      }
       const int allele = f.asg[i].allele_idx;
+      if (allele % parts != part) continue;
+      const t1k_overlap &o = endOverlap(f.asg[i], k);
+      if (!candidateIn(allele, o.seq_start, o.seq_end + 1)) continue;  // (no column of this overlap stands on a candidate)
+      const ReadView r{read, len, o.strand == -1};
       const int L = (int)ref_.seqs[allele].size();
       const int8_t *e; uint32_t ne;
       endOps(f.asg[i], k, ops, e, ne);
@@ -252,7 +271,7 @@ void VariantCaller::linkFragment(const Fragment &f, uint32_t fragIdx, const int8
       for (uint32_t j = 0; j < ne; ++j) {  // every column, gaps included (637)
         const int c = refPos < L ? cell(allele, refPos).cand : -1;
         if (c != -1) {
-          const char nuc = readPos < (int)len ? r[readPos] : '\0';  // (behind the read's last base the reference reads its terminator)
+          const char nuc = readPos < (int)len ? r.at(readPos) : '\0';  // (behind the read's last base the reference reads its terminator)
           std::vector<std::pair<uint32_t, char>> &sv = seen_[c];
           bool have = false;
           for (size_t q = sv.size(); q > 0 && sv[q - 1].first == fragIdx; --q)
@@ -352,17 +371,33 @@ void VariantCaller::solveGroup(const std::vector<int> &vars, int groupId) {
 // ComputeVariant (978-1140)
 void VariantCaller::compute(const std::vector<Fragment> &frags, const int8_t *ops) {
   if (maxGroup_ == 0) return;  // 980-981
-  for (const Fragment &f : frags) bookFragment(f, ops, true);
-  for (const Fragment &f : frags) bookFragment(f, ops, false);
+  auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double t0 = now();
+  // the sweeps that touch one allele's cells (or one allele's candidates) per assignment run on threads that own the alleles
+  int parts = (int)std::min<size_t>({(size_t)std::max(1u, std::thread::hardware_concurrency()), (size_t)16, ref_.seqs.size()});
+  if (frags.size() < 20000) parts = 1;
+  if (const char *e = getenv("T1K_VARIANTS_THREADS")) parts = std::max(1, std::min(64, atoi(e)));  // (tests: the threaded sweeps on small inputs)
+  auto sweep = [&](auto fn) {
+    if (parts == 1) { fn(0); return; }
+    std::vector<std::thread> th;
+    for (int t = 0; t < parts; ++t) th.emplace_back([&, t] { fn(t); });
+    for (auto &x : th) x.join();
+  };
+  sweep([&](int t) { for (const Fragment &f : frags) bookFragment(f, ops, true, t, parts); });
+  sweep([&](int t) { for (const Fragment &f : frags) bookFragment(f, ops, false, t, parts); });
   findRoots();
+  const double t1 = now();
+  int rounds = 0;
   const size_t nRoot = cand_.size();
   edges_.assign(nRoot, {});
   for (;;) {  // 1049-1070: the edge weights are counted afresh in every round, over the candidates of the round before
     const size_t before = cand_.size();
     for (auto &e : edges_) e.clear();
     for (const Fragment &f : frags) expandFragment(f, ops);
+    ++rounds;
     if (cand_.size() == before) break;
   }
+  const double t2 = now();
   // groups: components reached from the root candidates, numbered in the order of their first root (1080-1088)
   int nGroups = 0;
   std::vector<int> stack;
@@ -383,12 +418,16 @@ void VariantCaller::compute(const std::vector<Fragment> &frags, const int8_t *op
     ++nGroups;
   }
   seen_.assign(cand_.size(), {});
-  for (size_t i = 0; i < frags.size(); ++i) linkFragment(frags[i], (uint32_t)i, ops);
+  sweep([&](int t) { for (size_t i = 0; i < frags.size(); ++i) linkFragment(frags[i], (uint32_t)i, ops, t, parts); });
+  const double t3 = now();
   std::vector<std::vector<int>> members(nGroups);
   for (size_t c = 0; c < cand_.size(); ++c)
     if (group_[c] != -1) members[group_[c]].push_back((int)c);
   for (int g = 0; g < nGroups; ++g) solveGroup(members[g], g);
   for (size_t v = 0; v < variants.size(); ++v) calledAt_[base_[variants[v].allele] + (size_t)variants[v].refPos].push_back((int)v);
+  if (getenv("T1K_DEBUG_PHASES"))
+    fprintf(stderr, "[t1k variants] base tables %.1f ms, %d expansion rounds %.1f ms (%zu candidates, %zu of them roots), fragment links %.1f ms, %d groups solved in %.1f ms\n", t1 - t0, rounds,
+            t2 - t1, cand_.size(), (size_t)std::count(root_.begin(), root_.end(), (char)1), t3 - t2, nGroups, now() - t3);
 }
 
 // SeqSet::GetExonicPosition (SeqSet.hpp:2808-2828) for a base inside an exon: the exonic bases in front of it (the exons of a record are
@@ -423,9 +462,7 @@ void VariantCaller::adjust(const Fragment &f, const int8_t *ops, uint8_t *keep) 
       const char *read = second ? f.r2 : f.r1;
       const uint32_t len = second ? f.l2 : f.l1;
       const t1k_overlap &o = endOverlap(a, k);
-      std::string rc;
-      const char *r = read;
-      if (o.strand == -1) { rc = reverseComplement(read, len); r = rc.data(); }
+      const ReadView r{read, len, o.strand == -1};
       const int8_t *e; uint32_t ne;
       endOps(a, k, ops, e, ne);
       int refPos = o.seq_start, readPos = o.read_start;
@@ -434,7 +471,7 @@ void VariantCaller::adjust(const Fragment &f, const int8_t *ops, uint8_t *keep) 
           auto it = calledAt_.find(base_[o.seq_idx] + (size_t)refPos);
           if (it != calledAt_.end())
             for (int v : it->second)
-              if (variants[v].var == r[readPos]) { score[i] += 1; break; }
+              if (variants[v].var == r.at(readPos)) { score[i] += 1; break; }
         }
         if (e[j] != OP_INSERT) ++refPos;
         if (e[j] != OP_DELETE) ++readPos;
