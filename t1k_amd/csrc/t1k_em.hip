@@ -223,8 +223,11 @@ int t1k_align_batch(t1k_ctx *ctx, const char *text, const uint32_t *tOff, const 
     maxCells = std::max<int>(maxCells, (int)((tLen[i] + 1) * (pLen[i] + 1)));
     if (ops) opsTotal = std::max<uint64_t>(opsTotal, (uint64_t)opsOff[i] + tLen[i] + pLen[i] + 2);
   }
-  const int blocks = 64;
   const size_t perThread = (size_t)6 * (2048 + 4) * 4 + 4224 + (size_t)maxCells + 64;
+  // one lane per alignment: 64 workgroups of one wavefront for a handful of jobs (the vectors of the tests), up to 512 when the analyzer's
+  // variant pass sends 10^5 at a time -- as long as the lanes' trace scratch stays under 4 GB
+  int blocks = (int)std::min<uint64_t>(512, std::max<uint64_t>(64, ((uint64_t)nJobs + 127) / 128));
+  blocks = (int)std::max<uint64_t>(64, std::min<uint64_t>((uint64_t)blocks, ((uint64_t)4 << 30) / (64 * perThread)));
   T1kDevBuf *B = ctx->bAlign;
   int rc;
   if ((rc = up(ctx, B[0], tb)) || (rc = up(ctx, B[1], tn)) || (rc = up(ctx, B[2], pb)) || (rc = up(ctx, B[3], pn)) || (rc = up(ctx, B[4], tp)) ||
