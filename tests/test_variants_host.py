@@ -30,7 +30,7 @@ def reference_run(tmp, ref, pfx, geno_flags=(), ana_flags=(), single=False):
     util.need(util.REF_ANALYZER)
     g = os.path.join(tmp, "g")
     reads = ["-u", pfx + "_1.fq"] if single else ["-1", pfx + "_1.fq", "-2", pfx + "_2.fq"]
-    r = subprocess.run([util.REF_BIN, "-f", ref] + reads + ["--barcode", pfx + "_bc.fa", "-o", g, "-t", "4"] + list(geno_flags), stderr=subprocess.PIPE, text=True)
+    r = subprocess.run([util.REF_BIN, "-f", ref] + reads + ["--barcode", pfx + "_bc.fa", "-o", g, "-t", "8"] + list(geno_flags), stderr=subprocess.PIPE, text=True)
     assert r.returncode == 0, r.stderr
     aligned = ["-u", g + "_aligned.fa"] if single else ["-1", g + "_aligned_1.fa", "-2", g + "_aligned_2.fa"]
     a = os.path.join(tmp, "ana")
@@ -130,10 +130,62 @@ def barcode_table(names, barcodes, ptr, asg, keep_of):
     return out
 
 
+HOST = os.path.join(util.ROOT, "t1k_amd", "csrc", "host")
+_SAN = {}
+
+
+def sanitizer_harness(tmp, kind="address,undefined"):
+    """tests/harness/variants_san.cpp + host/variants.cpp under -fsanitize=<kind> (None: no such sanitizer runtime here)"""
+    if kind not in _SAN:
+        exe = os.path.join(tmp, "variants_san_" + kind.split(",")[0])
+        r = subprocess.run(["g++", "-O1", "-g", "-fsanitize=" + kind] + (["-fno-sanitize-recover=undefined"] if "undefined" in kind else []) +
+                           ["-std=c++17", "-o", exe, os.path.join(util.ROOT, "tests", "harness", "variants_san.cpp"), os.path.join(HOST, "variants.cpp"), "-lpthread"],
+                           stderr=subprocess.PIPE, text=True)
+        _SAN[kind] = exe if r.returncode == 0 else None
+    return _SAN[kind]
+
+
+def run_under_sanitizers(tmp, sel, abundance, ptr, asg, ops, r1, r2, var_max_group, want_vcf, keep_of):
+    """the same case through the sanitizer build: same VCF text, same kept flags, no report"""
+    exes = [e for e in (sanitizer_harness(tmp), sanitizer_harness(tmp, "thread")) if e]
+    if not exes:
+        return False
+    names, seqs, masks, _ = t1k_amd.load_reference_fasta(sel)
+    genes = {}
+    path = os.path.join(tmp, "case.txt")
+
+    def ov(o, at, n):
+        e = "".join(str(int(c)) for c in ops[int(at):int(at) + int(n)]) or "-"
+        return "%d %d %d %d %d %d %d %d %d %d %.17g %s" % (o["seq_idx"], o["read_start"], o["read_end"], o["seq_start"], o["seq_end"], o["strand"], o["match_cnt"], o["left_clip"],
+                                                              o["right_clip"], o["relaxed_match_cnt"], o["similarity"], e)
+    with open(path, "w") as f:
+        f.write("%d\n" % len(names))
+        for n, sq, m, ab in zip(names, seqs, masks, abundance):
+            f.write("%s %d %.17g %s %s\n" % (n, genes.setdefault(n.split("*")[0], len(genes)), ab, sq, "".join("1" if x else "0" for x in m)))
+        f.write("%d %d\n" % (len(r1), 0 if r2 is None else 1))
+        for i in range(len(r1)):
+            lo, hi = int(ptr[i]), int(ptr[i + 1])
+            f.write("%d %s%s\n" % (hi - lo, r1[i] or "-", "" if r2 is None else " " + (r2[i] or "-")))
+            for a in asg[lo:hi]:
+                f.write("%d %d %d %s%s\n" % (a["allele_idx"], a["has_mate_pair"], a["o1_from_r2"], ov(a["o1"], a["ops1"], a["n_ops1"]),
+                                              " " + ov(a["o2"], a["ops2"], a["n_ops2"]) if a["has_mate_pair"] else ""))
+    for exe in exes:  # (the thread sanitizer: the sweeps on threads that own the alleles)
+        r = subprocess.run([exe, path, str(var_max_group)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=dict(os.environ, T1K_VARIANTS_THREADS="4"))
+        assert r.returncode == 0 and "Sanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[:3000]
+        out = r.stdout.split("\n")
+        nv = int(out[0])
+        assert "\n".join(out[1:1 + nv]) + ("\n" if nv else "") == want_vcf
+        flags = out[1 + nv:1 + nv + len(r1)]
+        for i in range(len(r1)):
+            lo, hi = int(ptr[i]), int(ptr[i + 1])
+            assert flags[i] == ("".join(str(int(k)) for k in keep_of(i)) if hi > lo else "-"), i
+    return len(exes)
+
+
 LAST = {}  # what the last run_case saw (tests assert that their sample holds what they are about)
 
 
-def run_case(tmp, ref, pfx, single=False, var_max_group=8, geno_flags=(), ana_flags=(), orc_flags=(), job_kw=None):
+def run_case(tmp, ref, pfx, single=False, var_max_group=8, geno_flags=(), ana_flags=(), orc_flags=(), job_kw=None, sanitize=False):
     g, a, aligned = reference_run(tmp, ref, pfx, geno_flags, ana_flags, single)
     sel, out, names, abundance = oracle_dump(tmp, ref, g, aligned, orc_flags)
     r1 = [s for _, _, s in t1k_amd.read_fastx(aligned[1])]
@@ -167,6 +219,7 @@ def run_case(tmp, ref, pfx, single=False, var_max_group=8, geno_flags=(), ana_fl
     got_table = barcode_table(names, bcs, ptr, asg, keep_of)
     want_table = open(a + "_barcode_expr.tsv").read()
     moved = sum(1 for f in cache if not cache[f].all())
+    LAST["sanitized"] = sanitize and got_vcf == want_vcf and run_under_sanitizers(tmp, sel, abundance, ptr, asg, ops, r1, r2, var_max_group, want_vcf, keep_of)
     recs = v.records()
     v.close()
     job.close()
@@ -223,7 +276,7 @@ def test_genomic_reference_with_introns_and_separators(built, tmp_path):
     util.need(util.ORACLE_CLI)
     tmp = str(tmp_path)
     ref, pfx = util.several_snps_sample(tmp, 41, genes=3, kind="ref-dna", scale=0.05, positions=tuple(range(120, 2400, 97)), pairs=6000)
-    want_vcf, got_vcf, want_table, got_table, moved, recs = run_case(tmp, ref, pfx)
+    want_vcf, got_vcf, want_table, got_table, moved, recs = run_case(tmp, ref, pfx, sanitize=True)
     assert got_vcf == want_vcf
     assert got_table == want_table
     assert want_vcf.count("\n") >= 1, "the sample calls no variant: it does not test what it is meant to"
@@ -238,10 +291,12 @@ def test_reads_with_indels_and_unknown_bases(built, tmp_path, seed):
     util.need(util.ORACLE_CLI)
     tmp = str(tmp_path)
     ref, pfx = util.several_snps_sample(tmp, seed, genes=4, pairs=5000, sub=0.004, indel=0.004, nrate=0.004)
-    want_vcf, got_vcf, want_table, got_table, moved, recs = run_case(tmp, ref, pfx)
+    want_vcf, got_vcf, want_table, got_table, moved, recs = run_case(tmp, ref, pfx, sanitize=seed == 7)
     assert want_vcf.count("\n") >= 4, want_vcf
     assert got_vcf == want_vcf
     assert got_table == want_table
+    if seed == 7:
+        assert LAST["sanitized"] or sanitizer_harness(tmp) is None
 
 
 def test_relaxed_intron_alignment_on_a_genomic_reference(built, tmp_path):
@@ -273,7 +328,7 @@ def test_fragments_with_one_unalignable_mate(built, tmp_path):
             if (i // 4) % every == 0:
                 lines[i + 1] = "".join(rng.choice("ACGT") for _ in lines[i + 1])
         open(path, "w").write("\n".join(lines))
-    want_vcf, got_vcf, want_table, got_table, moved, recs = run_case(tmp, ref, pfx)
+    want_vcf, got_vcf, want_table, got_table, moved, recs = run_case(tmp, ref, pfx, sanitize=True)
     assert LAST["from_r2"] > 0 and LAST["unpaired"] > LAST["from_r2"], LAST
     assert got_vcf == want_vcf and want_vcf.count("\n") >= 1
     assert got_table == want_table
