@@ -1079,7 +1079,7 @@ def test_device_coalescing_equals_host_restatement(built, tmp_path):
 
 def analyzers_agree(tmp, ref, pfx, single=False, flags=(), geno_flags=(), env=None):
     """this build's genotyper, then both analyzers on its files: <prefix>_allele.vcf and <prefix>_barcode_expr.tsv byte for byte"""
-    util.need(util.REF_ANALYZER)
+    util.need(util.REF_ANALYZER)  # (where the reference binary is absent the test is skipped; the committed fixtures are compared in test_analyzer_variant_fixtures)
     g = os.path.join(tmp, "g")
     reads = ["-u", pfx + "_1.fq"] if single else ["-1", pfx + "_1.fq", "-2", pfx + "_2.fq"]
     r = subprocess.run([GENO, "-f", ref] + reads + ["--barcode", pfx + "_bc.fa", "-o", g] + list(geno_flags), stderr=subprocess.PIPE, text=True)
@@ -1109,6 +1109,9 @@ def test_analyzer_on_a_sample_with_a_novel_snp(built, tmp_path, het):
     ref, pfx = util.novel_snp_sample(tmp, het)
     vcf, table = analyzers_agree(tmp, ref, pfx)
     assert vcf.count("\n") >= 1 and " 401 . " in vcf, vcf
+    # the files the reference's own genotyper -> analyzer chain wrote for this seeded sample (tools/make_analyzer_variant_goldens.py)
+    gold = os.path.join(util.GOLDEN, "analyzer_variants", "het" if het else "homo")
+    assert vcf == open(gold + "_allele.vcf").read() and table == open(gold + "_barcode_expr.tsv").read()
     vcf0, table0 = analyzers_agree(tmp, ref, pfx, flags=["--varMaxGroup", "0"])
     assert vcf0 == "" and table0.count("\n") > 20
 
@@ -1136,3 +1139,20 @@ def test_analyzer_variant_calling_vs_reference_binary(built, tmp_path, case):
         # the variant pass in several pieces (re-assignment of the read-ends, their alignments): the same files
         vcf2, table2 = analyzers_agree(tmp, ref, pfx, single=True, flags=["-n", "1999"], env={"T1K_ANALYZER_PIECE": "600"})
         assert (vcf2, table2) == (vcf, table)
+
+
+@pytest.mark.parametrize("het", [False, True])
+def test_analyzer_variant_fixtures(built, tmp_path, het):
+    """the same two samples without the reference binary at hand: this build's genotyper and analyzer against the committed files the
+    reference's chain wrote (tests/golden/analyzer_variants, tools/make_analyzer_variant_goldens.py)"""
+    tmp = str(tmp_path)
+    ref, pfx = util.novel_snp_sample(tmp, het)
+    g, a = os.path.join(tmp, "g"), os.path.join(tmp, "a")
+    r = subprocess.run([GENO, "-f", ref, "-1", pfx + "_1.fq", "-2", pfx + "_2.fq", "--barcode", pfx + "_bc.fa", "-o", g], stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([ANALYZER, "-f", ref, "-a", g + "_allele.tsv", "-1", g + "_aligned_1.fa", "-2", g + "_aligned_2.fa", "--barcode", g + "_aligned_bc.fa", "-o", a, "-t", "4"],
+                       stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 0, r.stderr
+    gold = os.path.join(util.GOLDEN, "analyzer_variants", "het" if het else "homo")
+    assert open(a + "_allele.vcf").read() == open(gold + "_allele.vcf").read()
+    assert open(a + "_barcode_expr.tsv").read() == open(gold + "_barcode_expr.tsv").read()
