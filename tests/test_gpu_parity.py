@@ -1116,7 +1116,7 @@ def test_analyzer_on_a_sample_with_a_novel_snp(built, tmp_path, het):
     assert vcf0 == "" and table0.count("\n") > 20
 
 
-@pytest.mark.parametrize("case", ["several_per_gene", "genomic_reference", "single_end"])
+@pytest.mark.parametrize("case", ["several_per_gene", "genomic_reference", "single_end", "real_database"])
 def test_analyzer_variant_calling_vs_reference_binary(built, tmp_path, case):
     """several unknown bases per gene on two alleles in three with sequencing errors on top (groups of two candidates, candidates expanded
     to the other selected alleles, fragments whose assignment list the called variants shorten); the same on a genomic reference (introns,
@@ -1132,6 +1132,10 @@ def test_analyzer_variant_calling_vs_reference_binary(built, tmp_path, case):
         ref, pfx = util.several_snps_sample(tmp, 41, genes=3, kind="ref-dna", scale=0.05, positions=tuple(range(120, 2400, 97)), pairs=6000)
         vcf, _ = analyzers_agree(tmp, ref, pfx)
         assert vcf.count("\n") >= 4 and "FAIL" in vcf
+    elif case == "real_database":  # the CYP2D6 genomic database of the reference's example: exon lists, its own allele-name structure, FAIL pairs
+        ref, pfx = util.several_snps_sample(tmp, 83, kind=util.CYP_DNA, positions=tuple(range(140, 9000, 53)), pairs=5000, sub=0.001)
+        vcf, _ = analyzers_agree(tmp, ref, pfx, flags=util.CYP_FLAGS, geno_flags=util.CYP_FLAGS)
+        assert vcf.count("\n") >= 10 and "FAIL" in vcf
     else:
         ref, pfx = util.several_snps_sample(tmp, 29, genes=3, pairs=2500)
         vcf, table = analyzers_agree(tmp, ref, pfx, single=True)

@@ -312,6 +312,21 @@ def test_relaxed_intron_alignment_on_a_genomic_reference(built, tmp_path):
     assert got_table == want_table
 
 
+def test_real_database_with_exon_structure(built, tmp_path):
+    """the CYP2D6 genomic database of the reference's own example (exon lists in the record comments, allele names in its own digit
+    structure): unknown bases every 53 positions in two alleles of three -- the exonic ones must come out with the coordinate
+    SeqSet::GetExonicPosition gives them, the intronic ones must not be written"""
+    util.need(util.ORACLE_CLI)
+    tmp = str(tmp_path)
+    ref, pfx = util.several_snps_sample(tmp, 83, kind=util.CYP_DNA, positions=tuple(range(140, 9000, 53)), pairs=5000, sub=0.001)
+    want_vcf, got_vcf, want_table, got_table, moved, recs = run_case(tmp, ref, pfx, geno_flags=util.CYP_FLAGS, ana_flags=util.CYP_FLAGS, orc_flags=util.CYP_FLAGS,
+                                                                       job_kw=dict(allele_digit_units=1, allele_delimiter="."))
+    assert want_vcf.count("\n") >= 3, want_vcf
+    assert got_vcf == want_vcf
+    assert got_table == want_table
+    assert any(r["exon_pos"] != r["ref_pos"] for r in recs)
+
+
 def test_fragments_with_one_unalignable_mate(built, tmp_path):
     """every fifth first mate and every seventh second mate replaced by random bases: fragments assigned through one read-end only
     (SeqSet.hpp:2330-2346, 2563-2590 -- kept when that end is a perfect match at the allele's edge), among them the ones whose single

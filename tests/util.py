@@ -90,7 +90,10 @@ def several_snps_sample(tmp, seed, genes=5, every=3, positions=(150, 152, 400, 8
     """like util.novel_snp_sample with several unknown bases per gene -- two of them three bases apart, so that one read-end spans both and
     their candidates fall into one group -- carried by two alleles in three, and sequencing errors on top"""
     ref = os.path.join(tmp, "ref.fa")
-    synth_ref(kind, ref, genes=genes, scale=scale, seed=seed)
+    if os.path.exists(kind):  # a reference file of its own (a real database) instead of a synthetic one
+        gunzip_to(kind, ref) if kind.endswith(".gz") else __import__("shutil").copy(kind, ref)
+    else:
+        synth_ref(kind, ref, genes=genes, scale=scale, seed=seed)
     swap = {"A": "C", "C": "G", "G": "T", "T": "A"}
     mut = os.path.join(tmp, "ref_mut.fa")
     k = 0
