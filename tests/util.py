@@ -50,7 +50,7 @@ def synth_reads(ref, prefix, **kw):
 
 def novel_snp_sample(tmp, het):
     """reads drawn from a copy of the reference in which one exonic position of gene 0 carries a base the database does not know -- in every
-    allele of the gene (a homozygous novel SNP) or in every second one (het: the two sampled alleles may differ at it) -- genotyped against
+    allele of the gene (a homozygous novel SNP) or in one of the two alleles the reads are drawn from (het) -- genotyped against
     the ORIGINAL reference: the input on which the reference's VariantCaller does call a variant"""
     ref = os.path.join(tmp, "ref.fa")
     synth_ref("ref-rna", ref, genes=4, scale=0.05, seed=31)
@@ -67,7 +67,7 @@ def novel_snp_sample(tmp, het):
         k = 0
         for n, sq in recs:
             if n[1:].split("*")[0] == gene0 and len(sq) > 400 and sq[400] in swap:
-                if not het or k % 2 == 0:
+                if not het or k % 8 == 2:  # (one of the two alleles the read sampler draws for this gene with this seed: the reference calls the SNP on that allele only)
                     sq = sq[:400] + swap[sq[400]] + sq[401:]
                 k += 1
             o.write(n + "\n" + sq + "\n")
