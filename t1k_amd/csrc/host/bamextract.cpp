@@ -80,6 +80,7 @@ struct BamFile {
     (void)madvise((void *)map, size, MADV_SEQUENTIAL);
     return rewind();
   }
+  ~BamFile() { close(); }
   void close() {
     if (map) munmap((void *)map, size);
     if (fd >= 0) ::close(fd);
@@ -105,6 +106,7 @@ struct BamFile {
       if (!bsize || pos + bsize > size || bsize < xlen + 20) { err = "damaged BGZF block"; return false; }
       const uint8_t *tail = map + pos + bsize - 4;
       const size_t isize = (size_t)tail[0] | ((size_t)tail[1] << 8) | ((size_t)tail[2] << 16) | ((size_t)tail[3] << 24);
+      if (isize > 65536) { err = "damaged BGZF block"; return false; }  // (a BGZF block holds at most 64 KiB of data; the field is 32 bits wide)
       blks.push_back({pos + 12 + xlen, bsize - xlen - 20, out, isize});
       out += isize; got += isize; pos += bsize;
     }
@@ -208,18 +210,20 @@ struct Rec {
     else for (int i = 0, j = n - 1; j >= 0; ++i, --j) s[i] = (char)(q[j] + 33);
   }
   // first / last reference position of the aligned segments (Alignments::Next, alignments.hpp:226-283: M, D, =, X extend a segment, N closes it)
-  void span(int &start, int &end) const {
-    int st = pos(), ln = 0, first = 0, last = -1;
+  // (64-bit sums: the 28-bit lengths of a damaged record must not overflow; a valid file's values fit an int as in the reference)
+  void span(int64_t &start, int64_t &end) const {
+    int64_t st = pos(), ln = 0, first = 0, last = -1;
     bool any = false;
     const uint8_t *c = cigar();
     for (uint32_t i = 0; i < nCigar(); ++i) {
       const uint32_t v = BamFile::u32(c + 4 * i);
-      const int op = (int)(v & 0xf), num = (int)(v >> 4);
+      const int op = (int)(v & 0xf);
+      const int64_t num = (int64_t)(v >> 4);
       if (op == 0 || op == 2 || op == 7 || op == 8) ln += num;
       else if (op == 3) { if (!any) first = st; any = true; last = st + ln - 1; st = st + ln + num; ln = 0; }
     }
     if (ln > 0) { if (!any) first = st; any = true; last = st + ln - 1; }
-    if (!any) { first = pos(); last = pos() - 1; }
+    if (!any) { first = pos(); last = (int64_t)pos() - 1; }
     start = first; end = last;
   }
   // bam_aux_get + bam_aux2Z (Alignments::GetFieldZ, alignments.hpp:490-497): the value of a Z (or H) tag, NULL if absent / of another type
@@ -232,20 +236,23 @@ struct Rec {
       if (ty == 'Z' || ty == 'H') {
         const char *s = (const char *)p;
         while (p < e && *p) ++p;
+        if (p >= e) return nullptr;  // no terminator inside the record: damaged, the tag counts as absent (never read past the record)
         ++p;
         if (hit) return s;
         continue;
       }
       if (hit) return nullptr;
-      if (ty == 'A' || ty == 'c' || ty == 'C') p += 1;
-      else if (ty == 's' || ty == 'S') p += 2;
-      else if (ty == 'i' || ty == 'I' || ty == 'f') p += 4;
-      else if (ty == 'd') p += 8;
+      const size_t left = (size_t)(e - p);
+      if (ty == 'A' || ty == 'c' || ty == 'C') p += std::min<size_t>(1, left);
+      else if (ty == 's' || ty == 'S') p += std::min<size_t>(2, left);
+      else if (ty == 'i' || ty == 'I' || ty == 'f') p += std::min<size_t>(4, left);
+      else if (ty == 'd') p += std::min<size_t>(8, left);
       else if (ty == 'B') {
         if (p + 5 > e) return nullptr;
         const char sub = (char)p[0];
         const uint32_t n = BamFile::u32(p + 1);
         const size_t w = (sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2 : 4;
+        if ((uint64_t)w * n > (uint64_t)(e - p) - 5) return nullptr;  // the array runs past the record
         p += 5 + w * n;
       } else return nullptr;
     }
@@ -257,13 +264,15 @@ bool nextRecord(BamFile &bam, Rec &r) {
   const uint8_t *p = bam.take(4);
   if (!p) return false;
   const uint32_t n = BamFile::u32(p);
-  if (n < 32) { bam.err = "damaged BAM record"; return false; }
+  if (n < 32 || n > (1u << 30)) { bam.err = "damaged BAM record"; return false; }  // (a length word of a damaged file must not make the reader buffer the rest of the file)
   p = bam.take(n);
   if (!p) { if (bam.err.empty()) bam.err = "truncated BAM file"; return false; }
   r.d = p; r.len = n;
   // the lengths inside the record must fit the record: name, CIGAR, 4-bit sequence and qualities are read through them
   const int64_t lSeq = r.lSeq();
   if (lSeq < 0 || r.lName() < 1 || 32 + (uint64_t)r.lName() + 4ull * r.nCigar() + ((uint64_t)lSeq + 1) / 2 + (uint64_t)lSeq > (uint64_t)n) { bam.err = "damaged BAM record"; return false; }
+  // the name is read as a C string and the contig number indexes the header's table
+  if (r.d[32 + r.lName() - 1] != 0 || r.tid() < -1 || r.tid() >= (int64_t)bam.refName.size()) { bam.err = "damaged BAM record"; return false; }
   return true;
 }
 
@@ -538,7 +547,7 @@ extern "C" int t1k_bam_extractor_main(int argc, char **argv) {
         continue;
       }
       if (!r.aligned()) continue;  // (paired data: this mate is unaligned, the other one is not)
-      int start, end;
+      int64_t start, end;
       r.span(start, end);
       const int chr = r.tid();
       while (tag < geneCnt && (chr > genes[tag].chr || (chr == genes[tag].chr && start > genes[tag].end))) ++tag;  // the input is sorted by coordinate

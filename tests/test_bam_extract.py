@@ -75,6 +75,33 @@ def test_bam_extractor_exit_codes_and_bad_input(built, tmp_path):
     assert r.returncode == 1
 
 
+def test_damaged_bam_under_address_and_ub_sanitizers(tmp_path):
+    """a BAM file is untrusted input: bam-extractor's host side (the BGZF / BAM reader, the tag lookup, the CIGAR spans, both passes) built
+    with -fsanitize=address,undefined over 2 400 damaged variants of a paired and a single-end file -- length words, name / CIGAR / sequence
+    lengths, contig numbers, flags, tag types, string terminators and random bytes changed inside the inflated stream, the stream cut or a
+    piece removed and wrapped in BGZF again, block headers / BC / ISIZE of the container changed (tests/harness/bam_fuzz.cpp; the device
+    stage is a stand-in there).  The program may refuse a file or write its outputs; it may not read outside its buffers.  The reader of
+    the round before failed this within the first 600 variants of every seed (contig number beyond the header's table, a name or a tag
+    string without its terminator, CIGAR lengths that overflow an int)."""
+    exe = str(tmp_path / "bam_fuzz")
+    r = subprocess.run(["g++", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-std=c++17", "-I", os.path.join(util.ROOT, "include"), "-o", exe,
+                        os.path.join(util.ROOT, "tests", "harness", "bam_fuzz.cpp")] + [os.path.join(util.ROOT, "t1k_amd", "csrc", "host", f) for f in ("reads.cpp", "refset.cpp", "inflate.cpp")] +
+                       ["-lz", "-lpthread", "-ldl"], stderr=subprocess.PIPE, text=True)
+    if r.returncode != 0:
+        pytest.skip("no address sanitizer runtime for g++ here: " + r.stderr[-200:])
+    cases = [("p", bamsynth.paired_scenario(5, barcodes=True, n=40), 3000, ["--barcode", "CB", "--UMI", "UB"], 1),
+             ("s", bamsynth.single_scenario(6, barcodes=True, n=40), 0xff00, ["--barcode", "CB"], 2),
+             ("u", bamsynth.paired_scenario(7, suffix=True, n=40), 777, ["-u", "--mateIdSuffixLen", "2"], 3)]
+    for tag, sc, block, args, seed in cases:
+        bam, fa = str(tmp_path / (tag + ".bam")), str(tmp_path / (tag + ".fa"))
+        sc.write(bam, block)
+        sc.write_fasta(fa)
+        r = subprocess.run([exe, bam, fa, str(tmp_path), "800", str(seed)] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        assert r.returncode == 0 and "ERROR" not in r.stdout and "Sanitizer" not in r.stderr and "runtime error" not in r.stderr, (tag, r.stdout, r.stderr[-3000:])
+        n, refused, accepted = (int(x) for x in r.stdout.split()[-3:])
+        assert n == 800 and refused + accepted == 800 and refused > 300 and accepted > 40, (tag, r.stdout)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("seed,barcodes,suffix,env", [(21, False, False, {}), (22, True, False, {"T1K_EXTRACT_CHUNK": "7"}), (23, False, True, {"T1K_EXTRACT_CHUNK": "64"})])
 def test_paired_bam_with_alt_contigs_and_unaligned_pairs_vs_reference(built, tmp_path, seed, barcodes, suffix, env):
