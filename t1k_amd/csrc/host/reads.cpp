@@ -60,6 +60,7 @@ inline const char *strictRecordFields(const char *p, const char *end, bool fastq
   const char *s = e1 + 1;
   const char *e2 = lineEnd(s, end);
   size_t sl = (size_t)(e2 - s);
+  if (sl == 1 && s[0] == '\r') return nullptr;  // a line of a lone CR: the reference's reader keeps that character (kseq.h:142 drops a CR only from more than one character)
   if (sl && s[sl - 1] == '\r') --sl;
   if (sl && (s[0] == '>' || s[0] == '@' || s[0] == '+')) return nullptr;
   const char *next = e2 < end ? e2 + 1 : end;
@@ -70,6 +71,7 @@ inline const char *strictRecordFields(const char *p, const char *end, bool fastq
     const char *q = e3 + 1;
     const char *e4 = lineEnd(q, end);
     size_t ql = (size_t)(e4 - q);
+    if (ql == 1 && q[0] == '\r') return nullptr;
     if (ql && q[ql - 1] == '\r') --ql;
     if (ql != sl) return nullptr;
     next = e4 < end ? e4 + 1 : end;
@@ -157,12 +159,12 @@ ReadInput::~ReadInput() {
 
 bool ReadInput::addBuffer(const char *p, size_t n, int threads, Side &dst, std::string &err, const std::string &what) {
   const char *end = p + n;
-  while (n && isBlank(end[-1])) { --end; --n; }  // trailing blank lines
+  while (n && (end[-1] == '\n' || end[-1] == '\r')) { --end; --n; }  // trailing empty lines (blanks at the end of the last line belong to that line: a quality string they make longer ends the file in the reference's reader)
   const char *b = p;
   while (b < end && isBlank(*b)) ++b;
   if (b >= end) return true;  // empty file: no records
   const bool fastq = *b == '@';
-  if (!fastq && *b != '>') { err = what + ": neither FASTA nor FASTQ"; return false; }
+  if (!fastq && *b != '>') { (void)what; return false; }  // text in front of the first header: the general reader skips it as the reference's does (kseq.h:189-193)
   return addRange(b, end, end, fastq, threads, dst);  // false with err empty: the caller falls back to the general reader
 }
 
@@ -626,7 +628,7 @@ bool ReadInput::openStreaming(const std::vector<std::string> &files1, const std:
       // what is left behind the last complete record of a file: blank lines, or a last record whose last line has no line end
       auto closeFile = [&](size_t endAt) -> bool {
         const char *b = M->text + recStart, *e = M->text + endAt;
-        while (e > b && isBlank(e[-1])) --e;
+        while (e > b && (e[-1] == '\n' || e[-1] == '\r')) --e;  // (empty lines only: see addBuffer)
         while (b < e && isBlank(*b)) ++b;
         if (e > b && !emit(b, e)) return false;
         recStart = scan = endAt; lines = 0;
@@ -804,7 +806,7 @@ int ReadInput::openSharded(const std::vector<std::string> &files1, const std::ve
         Blob &b = newBlob();
         b.map = mp; b.len = (size_t)st.st_size;
         v.b = (const char *)mp; v.end = v.b + st.st_size;
-        while (v.end > v.b && isBlank(v.end[-1])) --v.end;
+        while (v.end > v.b && (v.end[-1] == '\n' || v.end[-1] == '\r')) --v.end;  // (empty lines only: see addBuffer)
         while (v.b < v.end && isBlank(*v.b)) ++v.b;
         if (v.b < v.end) {
           v.fastq = *v.b == '@';

@@ -6,6 +6,7 @@
 #include <zlib.h>
 #include <algorithm>
 #include <atomic>
+#include <cctype>
 #include <chrono>
 #include <cstring>
 #include <thread>
@@ -14,62 +15,106 @@
 namespace t1k {
 
 namespace {
-// buffered line source over zlib (reads plain and gz files alike)
-class LineSource {
+// A record reader with the rules of the reader the reference vendors (kseq.h:185-224, driven by ReadFiles::Next, ReadFiles.hpp:155-204),
+// restated as a state machine over a byte source: what it hands out must equal the reference's reader byte for byte on ANY file -- odd
+// but legal ones (wrapped sequences, blank lines, CRLF, comments, records of both kinds in one file) and damaged ones, where the rules
+// have consequences a line-by-line reading misses:
+//   * after a FASTQ record the next record starts at the next '@' or '>' WHEREVER it stands (not only at a line start);
+//   * quality lines are joined until they are at least as long as the sequence; a different length ends the FILE (kseq_read returns -2,
+//     ReadFiles::Next goes on with the next file), and so does a '+' line with nothing behind it;
+//   * a trailing CR is dropped from a line only when what has been gathered so far is longer than one character (kseq.h:142);
+//   * the name ends at the first isspace() character, the comment is the rest of that line behind this one character.
+// The source is filled 16 384 bytes at a time through zlib, as the reference's stream is (kseq.h:234; plain files are read as they are):
+// an end of file on a buffer boundary is seen one call later there, and here.
+class RecordSource {
  public:
-  explicit LineSource(const std::string &path) : buf_(1 << 20) { fp_ = gzopen(path.c_str(), "rb"); }
-  ~LineSource() { if (fp_) gzclose(fp_); }
+  explicit RecordSource(const std::string &path) : buf_(kBuf) { fp_ = gzopen(path.c_str(), "rb"); }
+  ~RecordSource() { if (fp_) gzclose(fp_); }
   bool ok() const { return fp_ != nullptr; }
-  bool next(std::string &line) {
-    line.clear();
-    bool any = false;
-    while (true) {
-      if (pos_ == len_) {
-        int n = gzread(fp_, buf_.data(), (unsigned)buf_.size());
-        if (n <= 0) break;
-        len_ = (size_t)n; pos_ = 0;
-      }
-      any = true;
-      const char *s = buf_.data() + pos_;
-      const char *nl = (const char *)memchr(s, '\n', len_ - pos_);
-      if (nl) { line.append(s, nl - s); pos_ = (size_t)(nl - buf_.data()) + 1; goto done; }
-      line.append(s, len_ - pos_);
-      pos_ = len_;
+  // >= 0: a record (its sequence length); -1: end of the file; -2: a quality string of another length, or none -- the reader of the
+  // reference treats both as the end of this file
+  long next(std::string &name, std::string &comment, std::string &seq, std::string &qual) {
+    int c;
+    if (last_ == 0) {  // to the next header character
+      while ((c = getc()) != -1 && c != '>' && c != '@') {}
+      if (c == -1) return -1;
+      last_ = c;
     }
-    if (!any) return false;
-  done:
-    if (!line.empty() && line.back() == '\r') line.pop_back();
-    return true;
+    comment.clear(); seq.clear(); qual.clear();
+    if (until(false, name, &c, false) < 0) return -1;
+    if (c != '\n') until(true, comment, nullptr, false);
+    while ((c = getc()) != -1 && c != '>' && c != '+' && c != '@') {
+      if (c == '\n') continue;  // empty lines
+      seq.push_back((char)c);
+      until(true, seq, nullptr, true);
+    }
+    if (c == '>' || c == '@') last_ = c;  // the next record's first character is taken
+    if (c != '+') return (long)seq.size();
+    while ((c = getc()) != -1 && c != '\n') {}
+    if (c == -1) return -2;
+    while (until(true, qual, nullptr, true) >= 0 && qual.size() < seq.size()) {}
+    last_ = 0;
+    if (qual.size() != seq.size()) return -2;
+    return (long)seq.size();
   }
 
  private:
+  static constexpr size_t kBuf = 16384;
+  void fill() {
+    const int n = gzread(fp_, buf_.data(), (unsigned)kBuf);
+    begin_ = 0; end_ = n > 0 ? (size_t)n : 0;
+    if (end_ < kBuf) eof_ = true;
+  }
+  int getc() {
+    if (begin_ >= end_) {
+      if (eof_) return -1;
+      fill();
+      if (end_ == 0) return -1;
+    }
+    return (unsigned char)buf_[begin_++];
+  }
+  // gathers up to the end of the line (line) or the first isspace() character; the delimiter is consumed and reported in *delim (0: none)
+  long until(bool line, std::string &str, int *delim, bool append) {
+    if (delim) *delim = 0;
+    if (!append) str.clear();
+    if (begin_ >= end_ && eof_) return -1;
+    for (;;) {
+      if (begin_ >= end_) {
+        if (eof_) break;
+        fill();
+        if (end_ == 0) break;
+      }
+      size_t i = begin_;
+      if (line) { const char *nl = (const char *)memchr(buf_.data() + begin_, '\n', end_ - begin_); i = nl ? (size_t)(nl - buf_.data()) : end_; }
+      else while (i < end_ && !isspace((unsigned char)buf_[i])) ++i;
+      str.append(buf_.data() + begin_, i - begin_);
+      begin_ = i + 1;
+      if (i < end_) { if (delim) *delim = (unsigned char)buf_[i]; break; }
+    }
+    if (line && str.size() > 1 && str.back() == '\r') str.pop_back();
+    return (long)str.size();
+  }
   gzFile fp_ = nullptr;
   std::vector<char> buf_;
-  size_t pos_ = 0, len_ = 0;
+  size_t begin_ = 0, end_ = 0;
+  bool eof_ = false;
+  int last_ = 0;
 };
 }  // namespace
 
 bool readSeqFile(const std::string &path, std::vector<SeqRec> &out, std::string &err) {
-  LineSource in(path);
+  RecordSource in(path);
   if (!in.ok()) { err = "cannot open " + path; return false; }
-  std::string line;
-  bool have = in.next(line);
-  while (have) {
-    if (line.empty() || (line[0] != '>' && line[0] != '@')) { have = in.next(line); continue; }
-    const bool fastq = line[0] == '@';
+  std::string name, comment, seq, qual;
+  while (in.next(name, comment, seq, qual) >= 0) {  // ReadFiles::Next: any negative return ends the file
     SeqRec r;
-    size_t sp = line.find_first_of(" \t");
-    r.id = sp == std::string::npos ? line.substr(1) : line.substr(1, sp - 1);
-    if (sp != std::string::npos && sp + 1 < line.size()) { r.comment = line.substr(sp + 1); r.hasComment = !r.comment.empty(); }
+    // the reference copies name, sequence and comment as C strings (strdup, ReadFiles.hpp:183-198): a NUL byte ends them
+    r.id.assign(name.c_str());
     size_t n = r.id.size();
-    if (n >= 2 && r.id[n - 2] == '/' && (r.id[n - 1] == '1' || r.id[n - 1] == '2')) r.id.resize(n - 2);
-    have = in.next(line);
-    while (have && !(!line.empty() && (line[0] == '>' || line[0] == '@' || line[0] == '+'))) { r.seq += line; have = in.next(line); }
-    if (fastq && have && !line.empty() && line[0] == '+') {
-      size_t q = 0;
-      have = in.next(line);
-      while (have && q < r.seq.size()) { q += line.size(); have = in.next(line); }
-    }
+    if (n >= 2 && r.id[n - 2] == '/' && (r.id[n - 1] == '1' || r.id[n - 1] == '2')) r.id.resize(n - 2);  // ReadFiles.hpp:185-189
+    r.seq.assign(seq.c_str());
+    r.hasComment = !comment.empty();
+    if (r.hasComment) r.comment.assign(comment.c_str());
     out.push_back(std::move(r));
   }
   return true;
@@ -141,6 +186,7 @@ bool readFastaParallel(const std::string &path, std::vector<SeqRec> &out) {
         const char *nl2 = (const char *)memchr(p, '\n', (size_t)(end - p));
         const char *e2 = nl2 ? nl2 : end;
         const char *se = e2;
+        if (se == p + 1 && *p == '\r' && r.seq.empty()) { ok = false; return; }  // a lone CR as a sequence's first character is kept by the reference's reader (kseq.h:142): the general reader's case
         if (se > p && se[-1] == '\r') --se;
         r.seq.append(p, se);
         p = nl2 ? nl2 + 1 : end;

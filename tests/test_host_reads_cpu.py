@@ -124,6 +124,74 @@ def test_bgzip_framed_and_plain_gzip_input_index_like_the_plain_file(harness, re
         assert out[kind] == out["plain"], kind
 
 
+# ---- the index against the REFERENCE's reader on odd and damaged files (ReadFiles::Next over kseq) ----
+def _ref_records(files):
+    r = subprocess.run([util.REF_READS] + files, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr[-500:]
+    return r.stdout
+
+
+def test_index_equals_the_reference_reader_on_odd_and_damaged_files(harness, tmp_path):
+    """1 200 seeded files (tests/damaged_reads.py): what ReadInput::open indexes -- in place where the layout is the strict one, through the
+    general reader (host/refset.cpp: the rules of kseq.h:185-224 as a state machine) where it is not -- must be the records the reference's
+    own ReadFiles::Next hands out (oracle/_ref/reads_harness), ids and sequences byte for byte: a record whose quality string has another
+    length ENDS the file there, the next record after a FASTQ record starts at the next '@' or '>' wherever it stands, a CR goes only from
+    lines of more than one character, text in front of the first header is skipped.  Where the file also qualifies for rank slices (three
+    ranks as threads), their concatenation is compared as well.  Every third case reads two files back to back, the first one damaged:
+    the reader goes on with the second (ReadFiles.hpp:161-164)."""
+    import damaged_reads
+    util.need(util.REF_READS)
+    refused = sliced = 0
+    for v in range(1200):
+        data, what = damaged_reads.variant(1000003 * 7 + v)
+        files = [str(tmp_path / "v.fq")]
+        open(files[0], "wb").write(data)
+        if v % 3 == 2:
+            data2, what2 = damaged_reads.variant(1000003 * 11 + v, undamaged_share=0.7)
+            files.append(str(tmp_path / "w.fq"))
+            open(files[1], "wb").write(data2)
+        want = _ref_records(files)
+        out = str(tmp_path / "o")
+        r = subprocess.run([harness, "3", "2", out, str(len(files))] + files, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        if r.returncode == 1 and "open:" in r.stderr:
+            refused += 1
+            continue
+        assert r.returncode in (0, 3), (v, what, r.stderr[-500:])
+        assert open(out + "_whole.tsv", "rb").read() == want, (v, what)
+        if r.returncode == 0:
+            sliced += 1
+            assert open(out + "_sharded.tsv", "rb").read() == want, (v, what)
+    assert refused <= 6 and sliced >= 50, (refused, sliced)
+
+
+def test_streamed_gz_index_equals_the_reference_reader_on_damaged_text(stream_harness, tmp_path):
+    """the same files as .gz through the streamed reader: what the consumer was handed when the stream finished, and what the whole-file
+    open (the job's fallback when the stream gives up) indexes, against the reference's reader (which reads the .gz through zlib as well)"""
+    import gzip
+    import damaged_reads
+    util.need(util.REF_READS)
+    streamed = gave_up = 0
+    for v in range(300):
+        data, what = damaged_reads.variant(1000003 * 13 + v, undamaged_share=0.3)
+        p = str(tmp_path / "v.fq.gz")
+        open(p, "wb").write(gzip.compress(data, 1))
+        want = _ref_records([p])
+        out = str(tmp_path / "s")
+        for f in (out + "_whole.tsv", out + "_stream.tsv"):
+            if os.path.exists(f):
+                os.remove(f)
+        r = subprocess.run([stream_harness, out, "1", p], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=dict(os.environ, T1K_STREAM_GZ_MIN_MB="0.0001"))
+        assert "whole: ERROR" not in r.stdout, (v, what, r.stdout)
+        assert open(out + "_whole.tsv", "rb").read() == want, (v, what)
+        if r.returncode == 0 and "stream: " in r.stdout and "fragments" in r.stdout.split("stream: ")[1]:
+            streamed += 1
+            assert open(out + "_stream.tsv", "rb").read() == want, (v, what, r.stdout)
+        else:
+            gave_up += 1
+            assert "not eligible" in r.stdout or "gave up" in r.stdout, (v, what, r.stdout)
+    assert streamed >= 30 and gave_up >= 30, (streamed, gave_up)
+
+
 # ---- streamed .gz input (ReadInput::openStreaming + host/inflate.cpp): the index the window loop reads while the files are still being inflated ----
 STREAM_SRC = os.path.join(util.ROOT, "tests", "harness", "reads_stream_harness.cpp")
 

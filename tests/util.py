@@ -17,6 +17,7 @@ REF_BIN = os.path.join(ROOT, "oracle", "_ref", "genotyper")
 ORACLE_EXTRACT = os.path.join(ROOT, "oracle", "t1k_oracle_extract")
 REF_EXTRACT = os.path.join(ROOT, "oracle", "_ref", "fastq-extractor")
 REF_ANALYZER = os.path.join(ROOT, "oracle", "_ref", "analyzer")
+REF_READS = os.path.join(ROOT, "oracle", "_ref", "reads_harness")
 CYP_RNA = os.path.join(GOLDEN, "cyp2d6_rna_seq.fa.gz")
 CYP_DNA = os.path.join(GOLDEN, "cyp2d6_dna_seq.fa.gz")
 CYP_FLAGS = ["--alleleDigitUnits", "1", "--alleleDelimiter", "."]
