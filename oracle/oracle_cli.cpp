@@ -17,6 +17,16 @@
 using namespace t1k_oracle;
 
 int main(int argc, char **argv) {
+  // --dumpReads file...: "id<TAB>seq" per record of the files read back to back, nothing else (the restated reader against the
+  // reference's: tests/test_host_reads_cpu.py)
+  if (argc >= 2 && !strcmp(argv[1], "--dumpReads")) {
+    for (int i = 2; i < argc; ++i) {
+      std::vector<SeqRecord> recs;
+      if (!readAllRecords(argv[i], recs)) { fprintf(stderr, "cannot read %s\n", argv[i]); return 1; }
+      for (auto &r : recs) printf("%s\t%s\n", r.id.c_str(), r.seq.c_str());
+    }
+    return 0;
+  }
   std::string ref, f1, f2, fbc, out = "oracle";
   Oracle orc;
   bool dumpOverlaps = false, noEM = false, fragDump = false;

@@ -1,6 +1,7 @@
 // oracle/oracle_core.cpp -- TEST INFRASTRUCTURE ONLY (see oracle_core.hpp header).
 // CPU restatement of the T1K genotyper hot path; every routine cites the reference lines it follows.
 #include "oracle_core.hpp"
+#include <cctype>
 
 #include <zlib.h>
 #include <algorithm>
@@ -135,59 +136,90 @@ bool overlapBefore(const Overlap &a, const Overlap &b) {
 // ---------------------------------------------------------------------------------------------------
 // file reading (ReadFiles.hpp:155-204 + kseq.h record rules)
 // ---------------------------------------------------------------------------------------------------
+// kseq.h:185-224 (kseq_read) over kseq.h:93-141 (ks_getuntil2) and ks_getc, followed step by step: the stream is filled 16 384 bytes at
+// a time (kseq.h:234), `last` is kseq_t::last_char.  Pinned against the reference's own reader on odd and damaged files through the
+// product's reader tests (tests/test_host_reads_cpu.py, oracle/_ref/reads_harness).
 namespace {
-struct GzLines {
+struct KStream {
   gzFile fp;
   std::vector<char> buf;
-  size_t pos = 0, len = 0;
-  explicit GzLines(const std::string &path) : buf(1 << 20) { fp = gzopen(path.c_str(), "r"); }
-  ~GzLines() { if (fp) gzclose(fp); }
-  bool getline(std::string &line) {
-    line.clear();
-    bool any = false;
+  int begin = 0, end = 0;
+  bool isEof = false;
+  int last = 0;
+  explicit KStream(const std::string &path) : buf(16384) { fp = gzopen(path.c_str(), "r"); }
+  ~KStream() { if (fp) gzclose(fp); }
+  void fill() {
+    begin = 0;
+    end = gzread(fp, buf.data(), (unsigned)buf.size());
+    if (end < (int)buf.size()) isEof = true;
+    if (end < 0) end = 0;
+  }
+  int getc() {
+    if (isEof && begin >= end) return -1;
+    if (begin >= end) { fill(); if (end == 0) return -1; }
+    return (unsigned char)buf[begin++];
+  }
+  int getuntil(bool line, std::string &str, int *dret, bool append) {
+    if (dret) *dret = 0;
+    if (!append) str.clear();
+    if (begin >= end && isEof) return -1;
     for (;;) {
-      if (pos == len) {
-        int n = gzread(fp, buf.data(), (unsigned)buf.size());
-        if (n <= 0) return any;
-        len = (size_t)n; pos = 0;
+      if (begin >= end) {
+        if (isEof) break;
+        fill();
+        if (end == 0) break;
       }
-      any = true;
-      char *s = buf.data() + pos;
-      char *nl = (char *)memchr(s, '\n', len - pos);
-      if (nl) { line.append(s, nl - s); pos = (nl - buf.data()) + 1; break; }
-      line.append(s, len - pos);
-      pos = len;
+      int i = begin;
+      if (line) { while (i < end && buf[i] != '\n') ++i; }
+      else { while (i < end && !isspace((unsigned char)buf[i])) ++i; }
+      str.append(buf.data() + begin, (size_t)(i - begin));
+      begin = i + 1;
+      if (i < end) { if (dret) *dret = (unsigned char)buf[i]; break; }
     }
-    if (!line.empty() && line.back() == '\r') line.pop_back();
-    return true;
+    if (line && str.size() > 1 && str.back() == '\r') str.pop_back();
+    return (int)str.size();
+  }
+  int read(std::string &name, std::string &comment, std::string &seq, std::string &qual) {
+    int c;
+    if (last == 0) {
+      while ((c = getc()) != -1 && c != '>' && c != '@') {}
+      if (c == -1) return -1;
+      last = c;
+    }
+    comment.clear(); seq.clear(); qual.clear();
+    if (getuntil(false, name, &c, false) < 0) return -1;
+    if (c != '\n') getuntil(true, comment, nullptr, false);
+    while ((c = getc()) != -1 && c != '>' && c != '+' && c != '@') {
+      if (c == '\n') continue;
+      seq.push_back((char)c);
+      getuntil(true, seq, nullptr, true);
+    }
+    if (c == '>' || c == '@') last = c;
+    if (c != '+') return (int)seq.size();
+    while ((c = getc()) != -1 && c != '\n') {}
+    if (c == -1) return -2;
+    while (getuntil(true, qual, nullptr, true) >= 0 && qual.size() < seq.size()) {}
+    last = 0;
+    if (seq.size() != qual.size()) return -2;
+    return (int)seq.size();
   }
 };
 }  // namespace
 
 bool readAllRecords(const std::string &path, std::vector<SeqRecord> &out) {
-  GzLines in(path);
+  KStream in(path);
   if (!in.fp) return false;
-  std::string line;
-  bool have = in.getline(line);
-  while (have) {
-    if (line.empty() || (line[0] != '>' && line[0] != '@')) { have = in.getline(line); continue; }
-    bool fastq = line[0] == '@';
+  std::string name, comment, seq, qual;
+  while (in.read(name, comment, seq, qual) >= 0) {  // ReadFiles::Next (ReadFiles.hpp:161-164): a negative return ends this file
     SeqRecord r;
-    size_t sp = line.find_first_of(" \t");
-    r.id = line.substr(1, sp == std::string::npos ? std::string::npos : sp - 1);
-    if (sp != std::string::npos && sp + 1 < line.size()) { r.comment = line.substr(sp + 1); r.hasComment = !r.comment.empty(); }
+    r.id = name.c_str();  // strdup (ReadFiles.hpp:183-198)
     r.rawId = r.id;
     int n = (int)r.id.size();  // ReadFiles.hpp:185-189: strip trailing /1 or /2
     if (n >= 2 && (r.id[n - 1] == '1' || r.id[n - 1] == '2') && r.id[n - 2] == '/') r.id.resize(n - 2);
-    have = in.getline(line);
-    while (have && !(line.size() && (line[0] == '>' || line[0] == '@' || line[0] == '+'))) {
-      r.seq += line;
-      have = in.getline(line);
-    }
-    if (fastq && have && line.size() && line[0] == '+') {
-      have = in.getline(line);
-      while (have && r.qual.size() < r.seq.size()) { r.qual += line; have = in.getline(line); }
-    }
+    r.seq = seq.c_str();
+    r.qual = qual.c_str();
+    r.hasComment = !comment.empty();
+    if (r.hasComment) r.comment = comment.c_str();
     out.push_back(std::move(r));
   }
   return true;

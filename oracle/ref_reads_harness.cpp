@@ -6,9 +6,18 @@
 #include <cstdio>
 #include "ReadFiles.hpp"
 
+#include <cstring>
+
 int main(int argc, char **argv) {
   ReadFiles reads;
-  for (int i = 1; i < argc; ++i) reads.AddReadFile(argv[i], false);
-  while (reads.Next()) printf("%s\t%s\n", reads.id, reads.seq);
+  bool comments = false;  // -c: a third column, the header's comment as SeqSet::InputRefFa sees it ("" and a fourth column 0 when there is none)
+  for (int i = 1; i < argc; ++i) {
+    if (!strcmp(argv[i], "-c")) comments = true;
+    else reads.AddReadFile(argv[i], false);
+  }
+  while (reads.Next()) {
+    if (comments) printf("%s\t%s\t%s\t%d\n", reads.id, reads.seq, reads.comment ? reads.comment : "", reads.comment ? 1 : 0);
+    else printf("%s\t%s\n", reads.id, reads.seq);
+  }
   return 0;
 }

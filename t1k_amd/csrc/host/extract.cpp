@@ -24,45 +24,57 @@
 
 namespace {
 
-// FASTA/FASTQ records with kseq.h's rules (the reader behind ReadFiles.hpp): the name ends at the first blank, sequence lines are
-// joined until a line starting with '+', '>' or '@', quality lines are joined until they are as long as the sequence.
+// FASTA/FASTQ records with the rules of kseq.h:185-224 (the reader behind ReadFiles.hpp), as a state machine over this reader's own buffer
+// -- the same rules as the general reader of host/refset.cpp, here beside an in-place path for the common case: the name ends at the first
+// isspace() character; sequence lines are joined up to a line that starts with '+', '>' or '@' (empty lines skipped); behind a '+' line
+// quality lines are joined until they are at least as long as the sequence, and another length ends the FILE (kseq_read returns -2,
+// ReadFiles::Next goes on with the next file); behind a FASTQ record the next record starts at the next '@' or '>' wherever it stands; a
+// trailing CR is dropped from a line only when what has been gathered is longer than one character (kseq.h:142).
 struct RecordReader {
   gzFile fp = nullptr;
   std::vector<char> buf;
   size_t pos = 0, end = 0;
   bool eof = false;
-  std::string pending;  // a header line read ahead
-  bool havePending = false;
-  explicit RecordReader(const std::string &path) : buf(1 << 22) {
+  int last = 0;  // the header character of the next record, already taken from the buffer (0: none)
+  explicit RecordReader(const std::string &path, size_t bufBytes = (size_t)1 << 22) : buf(std::max<size_t>(bufBytes, 16)) {
     fp = gzopen(path.c_str(), "r");
     if (fp) gzbuffer(fp, 1 << 20);
   }
   ~RecordReader() { if (fp) gzclose(fp); }
-  bool getline(std::string &line) {
-    line.clear();
-    while (true) {
-      if (pos == end) {
-        if (eof) return !line.empty();
-        const int n = gzread(fp, buf.data(), (unsigned)buf.size());
-        if (n <= 0) { eof = true; return !line.empty(); }
-        pos = 0; end = (size_t)n;
-      }
-      const char *nl = (const char *)memchr(buf.data() + pos, '\n', end - pos);
-      if (nl) {
-        line.append(buf.data() + pos, nl - (buf.data() + pos));
-        pos = (size_t)(nl - buf.data()) + 1;
-        if (line.size() > 1 && line.back() == '\r') line.pop_back();
-        return true;
-      }
-      line.append(buf.data() + pos, end - pos);
+  bool fill() {  // false at the end of the file
+    if (eof) return false;
+    const int n = gzread(fp, buf.data(), (unsigned)buf.size());
+    if (n <= 0) { eof = true; pos = end = 0; return false; }
+    pos = 0; end = (size_t)n;
+    return true;
+  }
+  int getc() {
+    if (pos >= end && !fill()) return -1;
+    return (unsigned char)buf[pos++];
+  }
+  // gathers up to the end of the line (line) or the first isspace() character; the delimiter is consumed and reported in *delim (0: none);
+  // -1 = nothing left in the file
+  long until(bool line, std::string &str, int *delim, bool append) {
+    if (delim) *delim = 0;
+    if (!append) str.clear();
+    if (pos >= end && !fill()) return -1;
+    for (;;) {
+      size_t i = pos;
+      if (line) { const char *nl = (const char *)memchr(buf.data() + pos, '\n', end - pos); i = nl ? (size_t)(nl - buf.data()) : end; }
+      else while (i < end && !isspace((unsigned char)buf[i])) ++i;
+      str.append(buf.data() + pos, i - pos);
+      if (i < end) { if (delim) *delim = (unsigned char)buf[i]; pos = i + 1; break; }
       pos = end;
+      if (!fill()) break;
     }
+    if (line && str.size() > 1 && str.back() == '\r') str.pop_back();
+    return (long)str.size();
   }
   // The common case without copies: a four-line FASTQ record that lies entirely in the buffer.  The pointers stay valid until the next
-  // call.  Returns false if the record is anything else (FASTA, wrapped lines, CR line ends, a record cut by the buffer end, a header read
-  // ahead): the caller then takes next().
+  // call.  Returns false if the record is anything else (FASTA, wrapped lines, CR line ends, a record cut by the buffer end, a header
+  // character taken already): the caller then takes next().
   bool nextInPlace(const char *&name, size_t &nameLen, const char *&seq, size_t &seqLen, const char *&qual) {
-    if (havePending || pos >= end) return false;
+    if (last != 0 || pos >= end) return false;
     const char *p = buf.data() + pos, *e = buf.data() + end;
     if (*p != '@') return false;
     const char *l1 = (const char *)memchr(p, '\n', e - p);
@@ -73,7 +85,8 @@ struct RecordReader {
     if (!l3 || l3 + 1 >= e) return false;
     const char *l4 = (const char *)memchr(l3 + 1, '\n', e - (l3 + 1));
     if (!l4) return false;
-    if (l2 - l1 != l4 - l3 || l2 - l1 < 2 || l1[-1] == '\r' || l2[-1] == '\r') return false;
+    if (l2 - l1 != l4 - l3 || l2 - l1 < 2 || l1[-1] == '\r' || l2[-1] == '\r' || l4[-1] == '\r') return false;
+    if (l1[1] == '>' || l1[1] == '@' || l1[1] == '+') return false;  // (a sequence line that looks like a header: the general path's case)
     const char *sp = p + 1;
     while (sp < l1 && !isspace((unsigned char)*sp)) ++sp;
     name = p + 1; nameLen = (size_t)(sp - (p + 1));
@@ -82,31 +95,29 @@ struct RecordReader {
     pos = (size_t)(l4 - buf.data()) + 1;
     return true;
   }
-  // name (up to the first blank), sequence, quality ("" for FASTA); false at the end of the file
+  // name (up to the first blank), sequence, quality ("" for FASTA); false at the end of the file (or at a record that ends it)
   bool next(std::string &name, std::string &seq, std::string &qual) {
-    std::string line;
-    if (havePending) { line.swap(pending); havePending = false; }
-    else {
-      bool got = false;
-      while (getline(line)) if (!line.empty() && (line[0] == '>' || line[0] == '@')) { got = true; break; }
-      if (!got) return false;
+    int c;
+    if (last == 0) {
+      while ((c = getc()) != -1 && c != '>' && c != '@') {}
+      if (c == -1) return false;
+      last = c;
     }
-    size_t sp = 1;
-    while (sp < line.size() && !isspace((unsigned char)line[sp])) ++sp;
-    name.assign(line, 1, sp - 1);
     seq.clear(); qual.clear();
-    bool plus = false;
-    while (getline(line)) {
-      if (line.empty()) continue;
-      if (line[0] == '>' || line[0] == '@') { pending.swap(line); havePending = true; break; }
-      if (line[0] == '+') { plus = true; break; }
-      seq += line;
+    if (until(false, name, &c, false) < 0) return false;
+    if (c != '\n') { std::string comment; until(true, comment, nullptr, false); }
+    while ((c = getc()) != -1 && c != '>' && c != '+' && c != '@') {
+      if (c == '\n') continue;
+      seq.push_back((char)c);
+      until(true, seq, nullptr, true);
     }
-    if (plus) {
-      while (qual.size() < seq.size() && getline(line)) qual += line;
-      if (qual.size() != seq.size()) return false;  // truncated record: kseq_read returns -2, ReadFiles treats it as the end of the file
-    }
-    return true;
+    if (c == '>' || c == '@') last = c;
+    if (c != '+') return true;  // FASTA
+    while ((c = getc()) != -1 && c != '\n') {}
+    if (c == -1) return false;  // no quality string: the end of this file for ReadFiles::Next
+    while (until(true, qual, nullptr, true) >= 0 && qual.size() < seq.size()) {}
+    last = 0;
+    return qual.size() == seq.size();  // another length: kseq_read returns -2, the file ends here
   }
 };
 
@@ -127,6 +138,7 @@ struct Stream {
   std::vector<std::string> files;
   int mod = 1, rem = 0;
   size_t chunkRecords = 1 << 20;
+  size_t bufBytes = (size_t)1 << 22;  // the reader's buffer (small in tests: records cut by the buffer end)
   std::mutex mu;
   std::condition_variable cv;
   std::deque<std::unique_ptr<EndChunk>> q;
@@ -145,7 +157,7 @@ struct Stream {
     };
     std::string name, seq, qual;
     for (auto &f : files) {
-      RecordReader rd(f);
+      RecordReader rd(f, bufBytes);
       if (!rd.fp) { failed = true; break; }
       uint64_t r = 0;
       while (true) {

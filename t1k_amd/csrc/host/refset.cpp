@@ -136,6 +136,9 @@ bool readFastaParallel(const std::string &path, std::vector<SeqRec> &out) {
   ::close(fd);
   if (mp == MAP_FAILED) return false;
   const char *d = (const char *)mp, *end = d + n;
+  // two things only the general reader restates: a NUL byte (the reference copies every field as a C string) and a header character as
+  // the file's last byte (kseq.h:195: no record -- unless the stream's buffer ends there too)
+  if (memchr(d, 0, n) || (d[n - 1] == '>' && (n == 1 || d[n - 2] == '\n'))) { munmap(mp, n); return false; }
   auto recordStart = [&](const char *from) -> const char * {  // first '>' at a line start at or after `from`
     const char *p = from;
     if (p == d && *p == '>') return p;
@@ -170,13 +173,15 @@ bool readFastaParallel(const std::string &path, std::vector<SeqRec> &out) {
       // header line
       const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
       const char *le = nl ? nl : end;
-      const char *he = le;
-      if (he > p && he[-1] == '\r') --he;
       SeqRec r;
       const char *q = p + 1;
-      while (q < he && *q != ' ' && *q != '\t') ++q;
+      while (q < le && !isspace((unsigned char)*q)) ++q;  // the name ends at the first isspace() character (a CR included), kseq.h:195
       r.id.assign(p + 1, q);
-      if (q < he && q + 1 < he) { r.comment.assign(q + 1, he); r.hasComment = !r.comment.empty(); }
+      if (q < le) {  // the comment is the rest of the line behind that one character; a CR goes from more than one character (kseq.h:142, 196)
+        r.comment.assign(q + 1, le);
+        if (r.comment.size() > 1 && r.comment.back() == '\r') r.comment.pop_back();
+        r.hasComment = !r.comment.empty();
+      }
       const size_t il = r.id.size();
       if (il >= 2 && r.id[il - 2] == '/' && (r.id[il - 1] == '1' || r.id[il - 1] == '2')) r.id.resize(il - 2);
       p = nl ? nl + 1 : end;
@@ -210,6 +215,13 @@ bool readFastaParallel(const std::string &path, std::vector<SeqRec> &out) {
   return true;
 }
 }  // namespace
+
+// the records of the allele reference: plain '>' records by all host threads, anything else through the general reader
+bool readReferenceRecords(const std::string &path, std::vector<SeqRec> &out, std::string &err) {
+  if (readFastaParallel(path, out)) return true;
+  out.clear();
+  return readSeqFile(path, out, err);
+}
 
 // Genotyper::ParseAlleleName (Genotyper.hpp:63-131)
 void RefSet::splitName(const std::string &allele, std::string &gene, std::string &major, int fieldsType) const {
@@ -277,10 +289,7 @@ bool RefSet::load(const std::string &fasta, int digitUnitsArg, char delimiterArg
   delimiter = delimiterArg;
   std::vector<SeqRec> recs;
   const auto tA = std::chrono::steady_clock::now();
-  if (!readFastaParallel(fasta, recs)) {
-    recs.clear();
-    if (!readSeqFile(fasta, recs, err)) return false;
-  }
+  if (!readReferenceRecords(fasta, recs, err)) return false;
   const auto tB = std::chrono::steady_clock::now();
   // per record, on the host threads: hash of the sequence, effective length, exon mask
   struct Pre { uint64_t hash = 0; int effLen = 0; bool gap = false; std::vector<uint8_t> mask; };

@@ -24,6 +24,8 @@ struct SeqRec {
 };
 // FASTA / FASTQ, plain or gz; id = header up to the first blank with a trailing /1 or /2 removed (ReadFiles.hpp:185-189)
 bool readSeqFile(const std::string &path, std::vector<SeqRec> &out, std::string &err);
+// the allele reference's records as RefSet::load reads them (a FASTA of plain '>' records is parsed by all host threads, with the same result)
+bool readReferenceRecords(const std::string &path, std::vector<SeqRec> &out, std::string &err);
 
 // Large host blocks of a job ask for transparent huge pages (host/refset.cpp).  Measured with tools/hip_hello on the MI355X hosts (round 5): a
 // first touch costs ~150 ms per GB in 4 KB pages, and the kernel takes a process's resident pages apart at ~75 ms per GB, single-threaded,

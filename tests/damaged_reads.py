@@ -2,7 +2,7 @@
 reference's own reader (oracle/_ref/reads_harness = ReadFiles.hpp + kseq.h compiled from /root/reference by oracle/Makefile).  A variant is
 a small file of records of mixed lengths (one- and several-line sequences, /1 /2 suffixes, comments) with one to three of: a line removed,
 doubled, emptied, cut, lengthened; header characters ('@', '+', '>') put in front of a line or taken away; lower case and non-ACGT letters;
-CR at line ends, blanks in front of and behind a line, a NUL byte; a lone '@'; a very long line; then written with LF or CRLF, with or
+CR at line ends, blanks in front of and behind a line, a NUL byte, a VT / FF / CR inside a line; a lone '@'; a very long line; then written with LF or CRLF, with or
 without the last line end, with empty lines behind it, or cut at a random byte."""
 import random
 
@@ -34,7 +34,7 @@ def damage(rng, lines):
     for _ in range(rng.randint(1, 3)):
         if not lines:
             break
-        k = rng.randint(0, 17)
+        k = rng.randint(0, 18)
         kinds.append(k)
         i = rng.randrange(len(lines))
         if k == 0: del lines[i]
@@ -55,6 +55,9 @@ def damage(rng, lines):
         elif k == 15: lines[i] = "A" * rng.choice([1000, 5000, 70000])
         elif k == 16: lines.insert(i, "\t")
         elif k == 17: lines[i] = lines[i][1:]
+        elif k == 18:
+            j = rng.randint(0, len(lines[i]))
+            lines[i] = lines[i][:j] + rng.choice("\v\f\r") + lines[i][j:]
     return lines, kinds
 
 

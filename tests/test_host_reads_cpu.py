@@ -151,6 +151,8 @@ def test_index_equals_the_reference_reader_on_odd_and_damaged_files(harness, tmp
             files.append(str(tmp_path / "w.fq"))
             open(files[1], "wb").write(data2)
         want = _ref_records(files)
+        # (the restated reader of oracle/ on the same files: the checker of the GPU parity tests is pinned here as well)
+        assert subprocess.run([util.ORACLE_CLI, "--dumpReads"] + files, stdout=subprocess.PIPE, check=True).stdout == want, (v, what, "oracle")
         out = str(tmp_path / "o")
         r = subprocess.run([harness, "3", "2", out, str(len(files))] + files, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
         if r.returncode == 1 and "open:" in r.stderr:
@@ -388,3 +390,53 @@ def test_streamed_gz_reader_under_thread_sanitizer(read_sets, tmp_path):
     open(str(tmp_path / "mid.fq.gz"), "wb").write(blob)
     p = run("d", 1, [str(tmp_path / "mid.fq.gz"), f[1]])
     assert p.returncode == 1 and "stream: ERROR" in p.stdout, p.stdout
+
+
+# ---- fastq-extractor's streaming record reader (host/extract.cpp) against the reference's reader ----
+def test_extractor_record_reader_equals_the_reference_reader_on_odd_and_damaged_files(tmp_path):
+    """fastq-extractor reads its inputs as streams (host/extract.cpp: RecordReader, an in-place four-line path and the general rules of
+    kseq.h:185-224 taking turns over one buffer).  600 seeded odd / damaged files (tests/damaged_reads.py), every third case two files
+    back to back, each read with a buffer of 4 MiB, 300 and 64 bytes (records cut by the buffer end take the general path): ids and
+    sequences must be the ones the reference's ReadFiles::Next hands out (oracle/_ref/reads_harness); tests/harness/extract_reader_harness.cpp"""
+    import damaged_reads
+    util.need(util.REF_READS)
+    exe = str(tmp_path / "extract_reader_harness")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-I", os.path.join(util.ROOT, "include"), "-o", exe, os.path.join(util.ROOT, "tests", "harness", "extract_reader_harness.cpp"),
+                    os.path.join(HOST, "reads.cpp"), os.path.join(HOST, "refset.cpp"), os.path.join(HOST, "inflate.cpp"), "-lz", "-lpthread", "-ldl"], check=True)
+    for v in range(600):
+        data, what = damaged_reads.variant(1000003 * 17 + v)
+        files = [str(tmp_path / "x.fq")]
+        open(files[0], "wb").write(data)
+        if v % 3 == 2:
+            data2, what2 = damaged_reads.variant(1000003 * 19 + v, undamaged_share=0.7)
+            files.append(str(tmp_path / "y.fq"))
+            open(files[1], "wb").write(data2)
+        want = _ref_records(files)
+        for buf in ("4194304", "300", "64"):
+            r = subprocess.run([exe, buf] + files, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+            assert r.returncode == 0 and r.stdout == want, (v, buf, what)
+
+
+# ---- the allele reference's records (RefSet::load) against the reference's reader, comments included ----
+def test_reference_fasta_records_equal_the_reference_reader_on_odd_and_damaged_files(tmp_path):
+    """SeqSet::InputRefFa reads the allele FASTA through the same ReadFiles::Next (SeqSet.hpp:872-904) and takes the exon coordinates from the
+    header's comment.  900 seeded files, four in five FASTA (one-line and wrapped, comments, CRLF, damage of tests/damaged_reads.py):
+    readReferenceRecords -- plain '>' records parsed by all host threads, everything else by the general reader -- must give the
+    reference reader's ids, sequences, comments and has-a-comment flags (oracle/_ref/reads_harness -c; tests/harness/ref_records_harness.cpp)"""
+    import random
+    import damaged_reads
+    util.need(util.REF_READS)
+    exe = str(tmp_path / "ref_records_harness")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(util.ROOT, "tests", "harness", "ref_records_harness.cpp"),
+                    os.path.join(HOST, "refset.cpp"), os.path.join(HOST, "reads.cpp"), os.path.join(HOST, "inflate.cpp"), "-lz", "-lpthread", "-ldl"], check=True)
+    p = str(tmp_path / "r.fa")
+    for v in range(900):
+        rng = random.Random(1000003 * 23 + v)
+        lines = damaged_reads.base_records(rng, fasta=rng.random() < 0.8, wrap=rng.choice([0, 60, 60, 7]))
+        kinds = []
+        if rng.random() < 0.85:
+            lines, kinds = damaged_reads.damage(rng, lines)
+        open(p, "wb").write(damaged_reads.render(rng, lines))
+        want = subprocess.run([util.REF_READS, "-c", p], stdout=subprocess.PIPE, check=True).stdout
+        r = subprocess.run([exe, p], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert r.returncode == 0 and r.stdout == want, (v, kinds)
