@@ -138,7 +138,8 @@ bool readFastaParallel(const std::string &path, std::vector<SeqRec> &out) {
   const char *d = (const char *)mp, *end = d + n;
   // two things only the general reader restates: a NUL byte (the reference copies every field as a C string) and a header character as
   // the file's last byte (kseq.h:195: no record -- unless the stream's buffer ends there too)
-  if (memchr(d, 0, n) || (d[n - 1] == '>' && (n == 1 || d[n - 2] == '\n'))) { munmap(mp, n); return false; }
+  // (the NUL test runs on the threads below, each over its own piece)
+  if (d[n - 1] == '>' && (n == 1 || d[n - 2] == '\n')) { munmap(mp, n); return false; }
   auto recordStart = [&](const char *from) -> const char * {  // first '>' at a line start at or after `from`
     const char *p = from;
     if (p == d && *p == '>') return p;
@@ -168,6 +169,7 @@ bool readFastaParallel(const std::string &path, std::vector<SeqRec> &out) {
   std::atomic<bool> ok{plain};
   auto work = [&](int t) {
     const char *p = start[t], *stop = start[t + 1];
+    if (memchr(t == 0 ? d : p, 0, (size_t)(stop - (t == 0 ? d : p)))) { ok = false; return; }
     std::vector<SeqRec> &recs = part[t];
     while (p < stop && ok) {
       // header line
