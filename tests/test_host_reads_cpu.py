@@ -131,7 +131,7 @@ def _ref_records(files):
     return r.stdout
 
 
-def test_index_equals_the_reference_reader_on_odd_and_damaged_files(harness, tmp_path):
+def test_index_equals_the_reference_reader_on_odd_and_damaged_files(built, harness, tmp_path):
     """1 200 seeded files (tests/damaged_reads.py): what ReadInput::open indexes -- in place where the layout is the strict one, through the
     general reader (host/refset.cpp: the rules of kseq.h:185-224 as a state machine) where it is not -- must be the records the reference's
     own ReadFiles::Next hands out (oracle/_ref/reads_harness), ids and sequences byte for byte: a record whose quality string has another
