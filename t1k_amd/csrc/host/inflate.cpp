@@ -335,8 +335,11 @@ int gzInflateAll(const uint8_t *src, size_t srcLen, uint8_t *dst, size_t cap, Gz
   auto fail = [&](const char *m) { err = std::string("gzip: ") + m; if (pg) pg->state.store(-1, std::memory_order_release); return -1; };
   while (p < end) {
     if (nMembers && *p == 0) { ++p; continue; }  // zero padding behind the last member (tar, some writers)
-    if (end - p < 18) return fail(nMembers ? "trailing bytes are not a gzip member" : "file too short");
-    if (p[0] != 0x1f || p[1] != 0x8b) return fail(nMembers ? "trailing bytes are not a gzip member" : "not a gzip file");
+    // bytes behind a complete member that do not start another one end the data, as they do for zlib's gzread (gz_look with direct == 0:
+    // "trailing garbage is ignored"), which is what the reference reads through (ReadFiles.hpp, kseq.h) -- ADVICE round 5
+    if (nMembers && (end - p < 2 || p[0] != 0x1f || p[1] != 0x8b)) break;
+    if (end - p < 18) return fail(nMembers ? "truncated header" : "file too short");
+    if (p[0] != 0x1f || p[1] != 0x8b) return fail("not a gzip file");
     if (p[2] != 8) return fail("unknown compression method");
     const uint8_t flg = p[3];
     p += 10;

@@ -497,8 +497,13 @@ bool ReadInput::openStreaming(const std::vector<std::string> &files1, const std:
       // compressed size as the whole-file path reserves
       const uint32_t isize = (uint32_t)z[f.len - 4] | ((uint32_t)z[f.len - 3] << 8) | ((uint32_t)z[f.len - 2] << 16) | ((uint32_t)z[f.len - 1] << 24);
       const bool plausible = (size_t)isize >= f.len && (size_t)isize <= f.len * 48;
-      estText[m] += plausible ? (size_t)isize : f.len * 48;
-      M.cap += std::max<size_t>(plausible ? (size_t)isize : 0, f.len * 48) + 4096;
+      // The field is the length mod 2^32: a mate with 4.3 - 8.6 GB of text (14 - 27 M reads of 150 bp) leaves a wrapped value that still lies between
+      // the file's size and 48 x it (6.4 GB in a 1.4 GB file: 2.1 GB).  FASTQ deflates 3.5 - 5 x, so a value below 3 x the file's size gets 2^32s added
+      // until it is not (an estimate too high costs table pages nobody touches twice, one too low a restart of the job: ADVICE round 5).
+      size_t est = plausible ? (size_t)isize : f.len * 48;
+      if (plausible) while (est < f.len * 3 && est + (1ull << 32) <= f.len * 48) est += 1ull << 32;
+      estText[m] += est;
+      M.cap += std::max<size_t>(plausible ? est : 0, f.len * 48) + 4096;
     }
     if (!isBc && compressed < minBytes) return false;
     M.path = M.srcs[0].path;
@@ -615,8 +620,9 @@ bool ReadInput::openStreaming(const std::vector<std::string> &files1, const std:
       auto fail = [&](const std::string &why) { M->errIndex = M->path + ": " + why; M->state.store(-1, std::memory_order_release); };
       auto emit = [&](const char *b, const char *e) -> bool {
         RecFields f;
-        if (strictRecordFields(b, e, M->fastq, f) != e || n >= capR) streamGaveUp.store(true);  // (not damage: the whole-file reader takes such text)
-        if (strictRecordFields(b, e, M->fastq, f) != e) { fail("a record is not in the four-line FASTQ (barcodes: or two-line FASTA) layout the streaming reader follows (T1K_STREAM_GZ=0 reads the file whole)"); return false; }
+        const bool laidOut = strictRecordFields(b, e, M->fastq, f) == e;
+        if (!laidOut || n >= capR) streamGaveUp.store(true);  // (not damage: the whole-file reader takes such text)
+        if (!laidOut) { fail("a record is not in the four-line FASTQ (barcodes: or two-line FASTA) layout the streaming reader follows (T1K_STREAM_GZ=0 reads the file whole)"); return false; }
         if (n >= capR) { fail("more records than the streaming reader sized its tables for (T1K_STREAM_GZ=0 reads the file whole)"); return false; }
         sd->seqP[n] = f.seq; sd->seqL[n] = (uint32_t)f.seqLen; sd->idP[n] = f.id; sd->idL[n] = (uint16_t)f.idLen;
         if (first) frag[n] = (uint32_t)n;
@@ -966,8 +972,18 @@ void ReadInput::release(size_t recLo, size_t recHi) {
     if (stream_ && anon) {  // ... and the CRC checker must have been over it (it runs far ahead of the loop; with zlib's routine it may not)
       int mate = 0;
       for (int m = 0; m < stream_->nMates; ++m) if (stream_->mate[m].dst == sd) mate = m;
-      const char *checked = stream_->mate[mate].text + stream_->mate[mate].crcDone.load(std::memory_order_acquire);
+      Stream::Mate &SM = stream_->mate[mate];
+      const char *checked = SM.text + SM.crcDone.load(std::memory_order_acquire);
       if (end1 > checked) end1 = checked;
+      // ... and the DECODER must be done with it: a match copies from up to 32 KB behind its write position, inside the member it is decoding.  A
+      // writer that has caught up with a stalled decoder would drop a unit under that window, the decoder would copy zeros into later text and the
+      // run would end with a CRC error nobody can reproduce.  The write position is at or beyond what is published: while the
+      // decoder runs (state read first), nothing within 32 KB of the published length is dropped.
+      if (SM.pg.state.load(std::memory_order_acquire) == 0) {
+        const uint64_t produced = SM.pg.produced.load(std::memory_order_acquire);
+        const char *safe = SM.text + (produced > 32768 ? produced - 32768 : 0);
+        if (end1 > safe) end1 = safe;
+      }
       if (end1 <= first) continue;
     }
     if (b0 == b1) drop(first - 1, end1);

@@ -83,7 +83,7 @@ struct ReadInput {
   // upper bound of the record count (nFrag() while the stream runs) and the job's window loop takes records as they are published
   // (streamAvail).  streamFinish trims the tables to what was found.  false with err empty = not eligible: the caller opens the files whole.
   bool openStreaming(const std::vector<std::string> &files1, const std::vector<std::string> &files2, const std::string &barcodeFile, std::string &err);
-  bool streaming = false;      // opened by openStreaming and not finished yet: nFrag() / nAll() are the upper bound
+  std::atomic<bool> streaming{false};  // opened by openStreaming and not finished yet: nFrag() / nAll() are the upper bound
   size_t streamAvail() const;  // records indexed in every mate so far (their table entries may be read)
   int streamState() const;     // 0 running, 1 every thread finished, -1 failed
   void streamWait(size_t records) const;  // until that many records are there or the stream has ended

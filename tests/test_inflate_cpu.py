@@ -82,6 +82,18 @@ def test_members_flush_points_and_padding(harness):
     assert rc == 0 and out == b, line
 
 
+def test_bytes_behind_the_last_member_that_start_no_member_end_the_data_as_for_gzread(harness):
+    """zlib's gzread -- what the reference reads through (ReadFiles.hpp:13,95; kseq.h:94-150) -- ignores trailing garbage behind a complete member
+    (gzread.c gz_look: no magic and not in direct mode => end of file).  A member that BEGINS (magic present) and is cut short stays an error."""
+    a = SAMPLES["fastq"]
+    g = gzip.compress(a)
+    for tail in (b"garbage behind the member\n", b"\x1f", b"\0\0\0junk", b"x" * 4096):
+        rc, line, out = _inflate(harness, g + tail)
+        assert rc == 0 and out == a and line.split()[1] == "1", (tail[:8], line)
+    rc, line, _ = _inflate(harness, g + g[:12])
+    assert rc == 1 and line.startswith("ERROR"), line
+
+
 def test_damaged_files_are_refused_not_misread(harness):
     a = SAMPLES["fastq"]
     g = gzip.compress(a)
