@@ -319,6 +319,8 @@ typedef struct {
 int t1k_stats_get(t1k_ctx *ctx, t1k_stats *out);
 /* wall time (ms) the context has spent allocating device memory and the bytes it asked for (diagnostics) */
 double t1k_alloc_ms(t1k_ctx *ctx, uint64_t *bytes);
+/* the device blocks the context holds right now, in bytes; print != 0: one line on stderr naming every block of 64 MB and more (diagnostics, T1K_DEBUG_MEM) */
+uint64_t t1k_ctx_mem_report(t1k_ctx *ctx, const char *tag, int print);
 
 /* ---- whole-stage job API (host C++ + the device stages above) ------------------------------------------------- */
 /* argv-compatible replacement of the reference's genotyper executable (Genotyper.cpp:194-738). Returns the exit code. */

@@ -1014,6 +1014,15 @@ int t1k_job_run_local(t1k_job *job) {
     fprintf(stderr, "genotyper: WARNING: %llu fragment(s)%s hold a read longer than %u bases and were set aside (T1K_LONG_READS=drop): the reference would have genotyped them\n",
             (unsigned long long)droppedFragments.load(), job->nRanks > 1 ? " of this rank" : "", lenLimit);
   const double tDev = nowMs();
+  if (getenv("T1K_DEBUG_MEM")) {  // what the contexts hold at the end of the window loop (their peak: arenas only grow), the kept read sets, the driver's view
+    uint64_t sum = 0; int i = 0;
+    for (t1k_ctx *c : pipes) { char tag[32]; snprintf(tag, sizeof tag, "pipeline %d", i++); sum += t1k_ctx_mem_report(c, tag, 1); }
+    i = 0;
+    for (t1k_ctx *c : job->reader) { char tag[32]; snprintf(tag, sizeof tag, "read-set context %d", i++); sum += t1k_ctx_mem_report(c, tag, 1); }
+    uint64_t fr = 0, tt = 0;
+    (void)t1k_device_memory(job->prm.device, &fr, &tt);
+    fprintf(stderr, "[t1k mem] contexts %.1f GB; device: %.1f of %.1f GB free (cached pool blocks counted as free)\n", sum / 1073741824.0, fr / 1073741824.0, tt / 1073741824.0);
+  }
   for (t1k_ctx *c : job->more)
     if ((rc = t1k_coverage_absorb(job->ctx, c)) != T1K_OK) return jobFail(job, rc, t1k_last_error(job->ctx));
   if (job->analyzer) {  // the per-barcode summary reads the fragment assignment lists themselves (t1k_analyzer_main)

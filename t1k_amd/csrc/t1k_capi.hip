@@ -326,6 +326,28 @@ void t1k_ctx_destroy(t1k_ctx *ctx) {
 
 const char *t1k_last_error(const t1k_ctx *ctx) { return ctx ? ctx->err.c_str() : "no context"; }
 
+// T1K_DEBUG_MEM: the device blocks a context holds right now, by name (what bounds the job's device memory: VERDICT round 5 item 7)
+uint64_t t1k_ctx_mem_report(t1k_ctx *ctx, const char *tag, int print) {
+  if (!ctx) return 0;
+#define B(x) {#x, &ctx->x}
+  const struct { const char *name; T1kDevBuf *b; } all[] = {B(bReadAscii), B(bReadOffs), B(bReadBases), B(bReadN), B(bReadLen), B(bReadWeight), B(bWgHits), B(bWgGroups),
+    B(bWgStage), B(bWgBig), B(bWgCache), B(bLists), B(bCand), B(bExt), B(bCandStart), B(bCandCount), B(bListPtr), B(bListCount), B(bOvlWork), B(bDedupScratch), B(bDedupBases), B(bDedupN),
+    B(bDedupLen), B(bDedupWeight), B(bOvlStart), B(bOvlCount), B(bCounters), B(bSlowQueue), B(bSlowScratch), B(bSortScratch), B(bEqTrace), B(bSortTmp), B(bSlowKeys), B(bJobSort), B(bEnd1),
+    B(bEnd2), B(bHasN), B(bRows), B(bRowStart), B(bRowCount), B(bFragAssigned), B(bPairScratch), B(bPairOverflow), B(bPairBig), B(bExtractHuge), B(bEmRowPtr), B(bEmEc), B(bEmCount),
+    B(bEmLen), B(bEmX0), B(bEmN), B(bEmPsum), B(bEmColPtr), B(bEmRowOf), B(bExtract)};
+#undef B
+  uint64_t tot = 0, ref = 0, store = 0, align = 0;
+  std::string line;
+  for (auto &e : all) if (e.b->p) { tot += e.b->bytes; if (e.b->bytes >= (64u << 20)) { char t[96]; snprintf(t, sizeof t, " %s %.0f", e.name + 1, e.b->bytes / 1048576.0); line += t; } }
+  for (auto &b : ctx->refBufs) if (b.p) ref += b.bytes;
+  for (auto &slot : ctx->storeChunks) for (auto &b : slot) if (b.p) store += b.bytes;
+  for (auto &b : ctx->bAlign) if (b.p) align += b.bytes;
+  if (print)
+    fprintf(stderr, "[t1k mem] %s: %.2f GB in named blocks + reference %.2f + overlap store %.2f + alignment phase %.2f GB; blocks of 64 MB and more (MB):%s\n", tag ? tag : "context",
+            tot / 1073741824.0, ref / 1073741824.0, store / 1073741824.0, align / 1073741824.0, line.c_str());
+  return tot + ref + store + align;
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // reference (t1k_ref_upload: t1k_refindex.hip)
 // ------------------------------------------------------------------------------------------------------------------

@@ -222,14 +222,19 @@ def hla_10M_input(tmp_path_factory):
     return want, ref, pfx, tmp
 
 
-@pytest.mark.parametrize("mode", ["read_sets_not_kept", "two_ranks_rank_local_input"])
+@pytest.mark.parametrize("mode", ["read_sets_not_kept", "two_ranks_rank_local_input", "two_ranks_allreduce_em"])
 def test_hla_10M_per_rank_paths_of_the_sharded_config_vs_committed_reference_hashes(built, hla_10M_input, mode):
     """BASELINE configs[3] (50 M HLA pairs over 8 GPUs) cannot run here; the two code paths its ranks depend on can, on the 10 M-pair
     workload whose reference hashes are committed, so that they are compared with the REFERENCE's files and not with this build's own
     eager run: (a) windows that lose their kept read set under the memory rule and fall back to the per-range coverage updates (at 50 M
     pairs most windows do: profiles/r04_size_curve.log) -- forced here with a 2 GB budget for the kept sets and windows of 1.5 M fragments; (b) rank-local input:
     two in-process ranks on the one device, each indexing and writing only its own fragments (T1K_SHARD_INPUT), coverage all-reduce,
-    row exchange, group gather and the sharded E-step through the in-process communicator (Genotyper.cpp:523-621, SeqSet.hpp:2253-2274)."""
+    row exchange, group gather and the sharded E-step through the in-process communicator (Genotyper.cpp:523-621, SeqSet.hpp:2253-2274);
+    (c) the same two ranks with the EM collective BASELINE.json's north_star names (T1K_EM_COLLECTIVE=allreduce: every rank adds up its own
+    read groups' contributions per class, E doubles are all-reduced per EM update, Genotyper.hpp:372-421) -- the sums are re-associated, so
+    the stated tolerance applies instead of the hashes: the REFERENCE's own _genotype.tsv / _allele.tsv for this input (committed:
+    tests/golden/hla_10M_ref_genotype.tsv / _allele.tsv, md5 = full_size_md5.json's) with identical calls and qualities, abundances within
+    1e-4 relative, the same number of EM iterations; the aligned-read files still byte for byte."""
     import hashlib
     want, ref, pfx, tmp = hla_10M_input
     env = dict(os.environ, T1K_DEBUG_PHASES="1")
@@ -237,6 +242,8 @@ def test_hla_10M_per_rank_paths_of_the_sharded_config_vs_committed_reference_has
         env.update(T1K_ARCHIVE_GB="2", T1K_WINDOW="1500000")  # (windows of at most 1.5 M fragments: the first ones, cut before any set's size is known, are kept; the rest is not)
     else:
         env.update(T1K_GPUS="0,0", T1K_SHARD_INPUT="1")
+    if mode == "two_ranks_allreduce_em":
+        env.update(T1K_EM_COLLECTIVE="allreduce")
     g = os.path.join(tmp, "g_" + mode)
     r = subprocess.run([GENO, "-f", ref, "-1", pfx + "_1.fq", "-2", pfx + "_2.fq"] + want["flags"].split() + ["-o", g], stderr=subprocess.PIPE, text=True, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
@@ -244,7 +251,34 @@ def test_hla_10M_per_rank_paths_of_the_sharded_config_vs_committed_reference_has
         import re
         m = re.search(r"read sets of (\d+) of (\d+) windows kept", r.stderr)
         assert m and int(m.group(1)) * 2 <= int(m.group(2)), r.stderr[-1500:]   # most windows took the per-range coverage path
+    if mode == "two_ranks_allreduce_em":
+        import re
+
+        def close(a, b):
+            if len(a) != len(b):
+                return False
+            for x, y in zip(a, b):
+                if x == y:
+                    continue
+                try:
+                    fx, fy = float(x), float(y)
+                except ValueError:
+                    return False
+                if abs(fx - fy) > 1e-4 * max(abs(fx), abs(fy)):   # north_star: abundances within 1e-4 relative
+                    return False
+            return True
+        for suf in ("_genotype.tsv", "_allele.tsv"):
+            ref_file = os.path.join(util.GOLDEN, "hla_10M_ref" + suf)
+            assert hashlib.md5(open(ref_file, "rb").read()).hexdigest() == want[suf]   # the committed file IS the reference's
+            got, exp = open(g + suf).read().splitlines(), open(ref_file).read().splitlines()
+            assert len(got) == len(exp), suf
+            for a, b in zip(got, exp):
+                assert close(a.split("\t"), b.split("\t")), (suf, a, b)
+            os.remove(g + suf)
+        assert re.search(r"in (\d+) EM iterations", r.stderr).group(1) == str(want["reference_run"].get("em_iterations", 11))
     for suf in ("_genotype.tsv", "_allele.tsv", "_aligned_1.fa", "_aligned_2.fa"):
+        if not os.path.exists(g + suf):
+            continue
         h = hashlib.md5()
         with open(g + suf, "rb") as f:
             for blk in iter(lambda: f.read(1 << 24), b""):
