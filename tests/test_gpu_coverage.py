@@ -182,6 +182,44 @@ def test_barcode_config_at_size_vs_committed_reference_hashes(built, tmp_path):
     assert os.path.getsize(a + "_allele.vcf") == want["analyzer_vcf_bytes"] == 0
 
 
+def test_barcode_config_at_its_stated_size_vs_committed_reference_hashes(built, tmp_path):
+    """BASELINE configs[4] AT ITS SIZE on one GPU: 10 M 2x150 bp pairs carrying 100 k 10x-style barcodes (99 995 distinct in the
+    file), -s 0.97, genotyper -> analyzer in its DEFAULT mode (--varMaxGroup 8: the variant pass runs over all 10 M fragments).  Expected = md5 of the
+    files the REFERENCE binaries (oracle/_ref/genotyper -t 32: 2 234 s, 186 GB; oracle/_ref/analyzer -t 64: 113 s) wrote for this very input on an MI355X
+    host (tools/barcode_10M_r06.sh, profiles/r06_barcode_10M.log), committed as tests/golden/full_size_md5.json: barcode_10M_100k.  The input is
+    bench.py's own (`python bench.py --barcodes 100000`).  Genotyper.cpp:372-392, 709-718; BarcodeSummary.hpp:24-80; Analyzer.cpp:611-696."""
+    import hashlib
+    import json
+    want = json.load(open(os.path.join(util.GOLDEN, "full_size_md5.json")))["barcode_10M_100k"]
+    tmp = str(tmp_path)
+    ref = os.path.join(tmp, "hla.fa")
+    util.synth_ref("ref-rna", ref, genes=24, scale=1.0, seed=20250614)
+    pfx = os.path.join(tmp, "b")
+    util.synth_reads(ref, pfx, pairs=want["pairs"], len=150, seed=want["seed"], barcodes=want["barcodes"])
+    g = os.path.join(tmp, "g")
+    r = subprocess.run([GENO, "-f", ref, "-1", pfx + "_1.fq", "-2", pfx + "_2.fq", "--barcode", pfx + "_bc.fa"] + want["flags"].split() + ["-o", g], stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+
+    def md5(path):
+        h = hashlib.md5()
+        with open(path, "rb") as f:
+            for blk in iter(lambda: f.read(1 << 24), b""):
+                h.update(blk)
+        return h.hexdigest()
+
+    for suf in ("_genotype.tsv", "_allele.tsv", "_aligned_1.fa", "_aligned_2.fa", "_aligned_bc.fa"):
+        assert md5(g + suf) == want[suf], suf
+    assert open(g + "_genotype.tsv").read() == open(os.path.join(util.GOLDEN, "barcode_10M_ref_genotype.tsv")).read()   # (the reference's table itself is committed)
+    for f in (pfx + "_1.fq", pfx + "_2.fq", pfx + "_bc.fa"):
+        os.remove(f)
+    a = os.path.join(tmp, "a")
+    r = subprocess.run([os.path.join(util.ROOT, "t1k_amd", "bin", "analyzer"), "-f", ref, "-a", g + "_allele.tsv", "-1", g + "_aligned_1.fa", "-2", g + "_aligned_2.fa",
+                        "--barcode", g + "_aligned_bc.fa"] + want["flags"].split() + ["-o", a], stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert md5(a + "_barcode_expr.tsv") == want["analyzer_barcode_expr.tsv"]
+    assert md5(a + "_allele.vcf") == want["analyzer_allele.vcf"]
+
+
 def test_kir_wgs_config_at_size_vs_committed_reference_hashes(built, tmp_path):
     """BASELINE configs[2] on one GPU, at size: 10 M 2x150 bp pairs against the KIR-like dna reference with the kir-wgs preset
     (-s 0.9 --relaxIntronAlign, run-t1k:300-304): the near-best alignments run in every range for the relaxed counts and their
