@@ -33,7 +33,7 @@ struct AnalyzerVariants {
 static int analyzerCallVariants(t1k_job *job, int varMaxGroup, AnalyzerVariants &V) {
   const double tv0 = nowMs();
   double msAssign = 0, msDetails = 0, msAlign = 0;
-  uint64_t nEnds = 0, nJobs = 0;
+  uint64_t nEnds = 0, nJobs = 0, nFast = 0;
   const ReadInput &in = *job->in;
   const RefSet &R = job->ref;
   const uint32_t F = (uint32_t)in.nFrag();
@@ -190,31 +190,77 @@ static int analyzerCallVariants(t1k_job *job, int varMaxGroup, AnalyzerVariants 
       const double tc = nowMs();
       msDetails += tc - tb;
       nJobs += jobs.size();
+      // Round 6: most of these alignments never reach the device.  Text and pattern of equal length with at most two mismatches ('N' on
+      // either side matches, AlignAlgo.hpp:304-305): the ungapped alignment scores 2L - 4x >= 2L - 8, anything with a gap at most 2L - 12 (one
+      // insertion AND one deletion at least) -- the diagonal is the strict optimum at every prefix, and the reference's traceback takes the
+      // diagonal wherever it attains the cell (AlignAlgo.hpp:335-343): the edit string is MATCH / MISMATCH by position (checked against
+      // the reference's routine on 232 363 cases).  The host threads write those strings straight into the job's edit-string store; what is
+      // left (reads with an indel or three and more mismatches: a few per cent) goes through t1k_align_batch as before.  T1K_ANALYZER_NO_FAST=1:
+      // everything through the device (A/B and the test that both ways agree).
+      static const bool noFast = getenv("T1K_ANALYZER_NO_FAST") != nullptr;
+      const size_t nJ = jobs.size();
+      std::vector<uint32_t> jT(nJ), jTL(nJ), jP(nJ), jPL(nJ);
+      std::vector<uint8_t> fast(nJ, 0);
+      const int TH = hostThreads(job);
+      parallelRanges(nJ, TH, [&](int, size_t lo, size_t hi) {
+        for (size_t j = lo; j < hi; ++j) {
+          const Job &jb = jobs[j];
+          const t1k_overlap &o = lists[listAt[jb.end] + jb.idx];
+          jT[j] = (uint32_t)(refOff[o.seq_idx] + (uint64_t)o.seq_start);
+          jTL[j] = (uint32_t)(o.seq_end - o.seq_start + 1);
+          jP[j] = (uint32_t)((o.strand == -1 ? rcAt[jb.end] : off[jb.end]) + (uint64_t)o.read_start);
+          jPL[j] = (uint32_t)(o.read_end - o.read_start + 1);
+          if (noFast || jTL[j] != jPL[j]) continue;
+          const char *t = refText.data() + jT[j], *q = pat.data() + jP[j];
+          int x = 0;
+          for (uint32_t i = 0; i < jTL[j] && x <= 2; ++i) x += (t[i] != q[i] && t[i] != 'N' && q[i] != 'N') ? 1 : 0;
+          fast[j] = x <= 2;
+        }
+      });
+      // the rest: through the device, in calls of at most 2^18
+      std::vector<uint32_t> slow;
+      for (size_t j = 0; j < nJ; ++j) if (!fast[j]) slow.push_back((uint32_t)j);
+      std::vector<std::vector<int8_t>> slowBuf;
+      std::vector<uint32_t> slowOff(slow.size()), slowCall(slow.size());
       const size_t callJobs = 1u << 18;
-      for (size_t j0 = 0; j0 < jobs.size(); j0 += callJobs) {
-        const uint32_t n = (uint32_t)std::min(callJobs, jobs.size() - j0);
+      for (size_t j0 = 0; j0 < slow.size(); j0 += callJobs) {
+        const uint32_t n = (uint32_t)std::min(callJobs, slow.size() - j0);
         std::vector<uint32_t> tOff(n), tLen(n), pOff(n), pLen(n), oOff(n), nOps(n);
         uint64_t room = 0;
         for (uint32_t i = 0; i < n; ++i) {
-          const Job &jb = jobs[j0 + i];
-          const t1k_overlap &o = lists[listAt[jb.end] + jb.idx];
-          tOff[i] = (uint32_t)(refOff[o.seq_idx] + (uint64_t)o.seq_start);
-          tLen[i] = (uint32_t)(o.seq_end - o.seq_start + 1);
-          pOff[i] = (uint32_t)((o.strand == -1 ? rcAt[jb.end] : off[jb.end]) + (uint64_t)o.read_start);
-          pLen[i] = (uint32_t)(o.read_end - o.read_start + 1);
+          const uint32_t j = slow[j0 + i];
+          tOff[i] = jT[j]; tLen[i] = jTL[j]; pOff[i] = jP[j]; pLen[i] = jPL[j];
           oOff[i] = (uint32_t)room;
           room += (uint64_t)tLen[i] + pLen[i] + 2;
         }
         if (room >= (1ull << 32)) return jobFail(job, T1K_ERR_CAPACITY, "analyzer: the edit strings of one alignment call exceed 4 GB");
-        std::vector<int8_t> buf(room + 64);
-        if ((rc = t1k_align_batch(vctx, refText.data(), tOff.data(), tLen.data(), pat.data(), pOff.data(), pLen.data(), n, nullptr, nullptr, nullptr, nullptr, buf.data(), oOff.data(), nOps.data())) != T1K_OK)
+        slowBuf.emplace_back(room + 64);
+        if ((rc = t1k_align_batch(vctx, refText.data(), tOff.data(), tLen.data(), pat.data(), pOff.data(), pLen.data(), n, nullptr, nullptr, nullptr, nullptr, slowBuf.back().data(), oOff.data(), nOps.data())) != T1K_OK)
           return jobFail(job, rc, t1k_last_error(vctx));
-        for (uint32_t i = 0; i < n; ++i) {
-          opsAtOfJob[j0 + i] = V.ops.size();
-          nOpsOfJob[j0 + i] = nOps[i];
-          V.ops.insert(V.ops.end(), buf.begin() + oOff[i], buf.begin() + oOff[i] + nOps[i]);
-        }
+        for (uint32_t i = 0; i < n; ++i) { nOpsOfJob[slow[j0 + i]] = nOps[i]; slowOff[j0 + i] = oOff[i]; slowCall[j0 + i] = (uint32_t)(slowBuf.size() - 1); }
       }
+      // every job's place in the store (job order, as before), then the strings, by the host threads
+      {
+        uint64_t at = V.ops.size();
+        for (size_t j = 0; j < nJ; ++j) { if (fast[j]) nOpsOfJob[j] = jTL[j]; opsAtOfJob[j] = at; at += nOpsOfJob[j]; }
+        V.ops.resize(at);
+        std::vector<uint32_t> slowIdx(nJ, 0);
+        for (size_t i = 0; i < slow.size(); ++i) slowIdx[slow[i]] = (uint32_t)i;
+        int8_t *store = V.ops.data();
+        parallelRanges(nJ, TH, [&](int, size_t lo, size_t hi) {
+          for (size_t j = lo; j < hi; ++j) {
+            int8_t *dst = store + opsAtOfJob[j];
+            if (fast[j]) {
+              const char *t = refText.data() + jT[j], *q = pat.data() + jP[j];
+              for (uint32_t i = 0; i < jTL[j]; ++i) dst[i] = (t[i] != q[i] && t[i] != 'N' && q[i] != 'N') ? 1 : 0;   // EDIT_MISMATCH : EDIT_MATCH (AlignAlgo.hpp:7-8)
+            } else {
+              const uint32_t i = slowIdx[j];
+              memcpy(dst, slowBuf[slowCall[i]].data() + slowOff[i], nOpsOfJob[j]);
+            }
+          }
+        });
+      }
+      nFast += nJ - slow.size();
       for (uint64_t q = V.asgPtr[f0]; q < V.asgPtr[f1]; ++q) {
         t1k_frag_assignment &a = V.asg[q];
         const int64_t j1 = jobOfAsg[0][q - V.asgPtr[f0]], j2 = jobOfAsg[1][q - V.asgPtr[f0]];
@@ -239,8 +285,8 @@ static int analyzerCallVariants(t1k_job *job, int varMaxGroup, AnalyzerVariants 
   V.vc.reset(new VariantCaller(R, abundance, varMaxGroup));
   V.vc->compute(frags, V.ops.data());
   if (getenv("T1K_DEBUG_PHASES"))
-    fprintf(stderr, "[t1k analyzer] variant pass: rows + EM %.1f ms; %llu distinct read-ends re-assigned in %.1f ms, overlaps chosen in %.1f ms, %llu alignments in %.1f ms; "
-                    "VariantCaller %.1f ms (%zu assignments, %zu variants); %.1f ms in all\n", tv1 - tv0, (unsigned long long)nEnds, msAssign, msDetails, (unsigned long long)nJobs, msAlign,
+    fprintf(stderr, "[t1k analyzer] variant pass: rows + EM %.1f ms; %llu distinct read-ends re-assigned in %.1f ms, overlaps chosen in %.1f ms, %llu alignments (%llu of them on the host: equal lengths, at most two mismatches) in %.1f ms; "
+                    "VariantCaller %.1f ms (%zu assignments, %zu variants); %.1f ms in all\n", tv1 - tv0, (unsigned long long)nEnds, msAssign, msDetails, (unsigned long long)nJobs, (unsigned long long)nFast, msAlign,
             nowMs() - tv2, V.asg.size(), V.vc->variants.size(), nowMs() - tv0);
   return T1K_OK;
 }

@@ -170,11 +170,16 @@ __device__ inline int groupFastPath(const uint32_t *Mw, int diag, const ReadCtx 
       }
     } else {
     uint64_t G[2 * NP], R[2 * NP], GN[2 * NP], RN[2 * NP];
+    // (the allele's words from the transposed copy where there is one: lanes = consecutive alleles, the same word of each, one row -- see T1kRefDev::basesT)
+    const uint64_t *gt = c.gT ? c.gT + (gw - (c.goff >> 5)) * 64 : nullptr;
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
       const bool need = 2 * j <= nWin;  // the arrays carry spare words, but do not stream what is never used
       t1k_u64x2 g = {0ull, 0ull}, r = {0ull, 0ull}, rn2 = {0ull, 0ull};
-      if (need) { g = *(const t1k_u64x2 *)(c.gb + gw + 2 * j); r = *(const t1k_u64x2 *)(c.rb + rw + 2 * j); rn2 = *(const t1k_u64x2 *)(c.rn + rw + 2 * j); }
+      if (need) {
+        if (gt) { g.x = gt[(2 * j) * 64]; g.y = gt[(2 * j + 1) * 64]; } else g = *(const t1k_u64x2 *)(c.gb + gw + 2 * j);
+        r = *(const t1k_u64x2 *)(c.rb + rw + 2 * j); rn2 = *(const t1k_u64x2 *)(c.rn + rw + 2 * j);
+      }
       G[2 * j] = g.x; G[2 * j + 1] = g.y; R[2 * j] = r.x; R[2 * j + 1] = r.y; RN[2 * j] = rn2.x; RN[2 * j + 1] = rn2.y;
       GN[2 * j] = GN[2 * j + 1] = 0ull;
     }
@@ -512,6 +517,7 @@ __device__ __forceinline__ ReadCtx makeCtx(const ChainArgs &P, uint32_t re, int 
   const int S = P.reads.S;
   ReadCtx c{P.reads.bases + ((uint64_t)re * 2 + pass) * S, P.reads.nmask + ((uint64_t)re * 2 + pass) * S, (int)P.reads.len[re], P.ref.bases, P.ref.nmask,
             (int64_t)P.ref.alleleOff[allele], (int)P.ref.alleleLen[allele], P.ref.anyN != 0};
+  if (P.ref.basesT) c.gT = P.ref.basesT + (uint64_t)P.ref.blockT[allele >> 6] + (allele & 63u);
   return c;
 }
 

@@ -100,6 +100,13 @@ struct T1kRefDev {
   uint32_t nAlleles;
   uint64_t totalBases;          // padded global base count
   const uint64_t *bases, *nmask, *exon;
+  // Round 6: a second copy of `bases`, TRANSPOSED in blocks of 64 consecutive alleles: word w of allele a lives at basesT[blockT[a >> 6] + w * 64 + (a & 63)].
+  // The lanes of the closed-form pass hold consecutive alleles of a gene and read the same few words of each (the window under a read): in the
+  // linear layout every lane's 48 bytes sit in a cache line of their own (an allele is ~290 bytes on), 3 - 4 x the bytes come over the fabric
+  // and the L2 keeps lines of which a third is ever used; here a wavefront's 64 windows are six contiguous 512-byte rows.  NULL: not built
+  // (T1K_REF_TRANSPOSE=0).  Rows behind an allele's last word hold zeros (the linear layout has the next allele there: neither is ever looked at).
+  const uint64_t *basesT;
+  const uint32_t *blockT;       // [ceil(A / 64)] first word of the block in basesT
   const uint64_t *posted;       // same geometry as nmask: bit 2(i&31) of word i>>5 = the k-mer STARTING at global position i has a posting (valid + the reference's insert rule, KmerIndex.hpp:121)
   const uint64_t *alleleOff;    // [A]
   const uint32_t *alleleLen;    // [A]

@@ -10,6 +10,7 @@ struct ReadCtx {
   int64_t goff;              // allele global base offset
   int alleleLen;
   bool refN;                 // the reference holds an N somewhere (T1kRefDev::anyN): otherwise its N-mask words are all zero and not loaded here
+  const uint64_t *gT = nullptr;  // this allele's column of the transposed copy of the bases (T1kRefDev::basesT): word w of the allele at gT[w * 64]; NULL = linear only
 };
 
 

@@ -213,14 +213,6 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(T1K_PAIR_WAV
   __shared__ double sBestSim;
   __shared__ uint32_t sN, sBase;
   __shared__ uint32_t hKey[LJ_SLOTS], hVal[LJ_SLOTS];
-  // Round 6: the kept fragments of the streamed path (a row holds ~14) stay in LDS.  Every phase behind the keep filter used to read them back
-  // through two dependent global loads (keep[q], then frags[keep[q]] in the workgroup's HBM scratch) -- ten round trips per fragment in a
-  // kernel that waits for loads 85 % of its time.  KF fragments of 40 bytes: the 3 KB the reduction arrays of the (never streamed) list
-  // path's best pass take, shared with them.  More than KF kept fragments (or a whitelist, whose compaction rewrites keep[]): HBM as before.
-  constexpr uint32_t KF = 76;
-  constexpr size_t KFB = KF * sizeof(Frag) > WG * (sizeof(double) + sizeof(int)) ? KF * sizeof(Frag) : WG * (sizeof(double) + sizeof(int));
-  __shared__ __attribute__((aligned(16))) unsigned char sKFraw[KFB];
-  Frag *sKF = (Frag *)sKFraw;
   const int tid = threadIdx.x;
   const uint32_t A = P.ref.nAlleles;
   uint64_t *tab2 = P.tab2 + (uint64_t)blockIdx.x * A;
@@ -233,72 +225,30 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(T1K_PAIR_WAV
 #endif
   const uint32_t nItems = P.only ? (uint32_t)P.counters[23] : P.nFragments;
   // fragments are handed out one at a time (a device counter per launch): their cost spans two orders of magnitude (0 .. 8192 and more
-  // overlaps), and with a fixed stride the kernel lasted as long as its unluckiest workgroup.
-  // Round 6: the NEXT fragment's descriptor -- hand-out counter -> fragment -> read-end numbers -> list table words: three (second launch: four)
-  // dependent global round trips, a quarter of a fragment's time in round 5's phase profile -- is requested by thread 0 in stages WHILE the
-  // current fragment is worked on (PF_STEP at the phase boundaries below: each stage's operands were asked for a phase earlier) and handed over through
-  // LDS at the top of the loop.  A workgroup therefore holds one fragment in reserve when the counter runs out: one fragment per workgroup
-  // of tail, against 64 fragments per workgroup and launch.
-  // The stages keep one level of the descriptor in registers at a time: each boundary first retires the level that has arrived into the LDS
-  // slot of the next fragment (sD[parity ^ 1]), then asks for the level below it (at most six registers live; the kernel runs at its 128).
-  __shared__ uint32_t sD[2][8];               // it, f, off, e1, e2, hasN, n1, n2
-  __shared__ unsigned long long sDP[2][2];    // list addresses
-  const bool paired = P.end2 != nullptr;
-  uint32_t pa = 0, pb = 0, pc = 0, pd = 0;    // thread 0: the level in flight
-  unsigned long long pp1 = 0, pp2 = 0;
-  uint32_t par = 0;                           // parity of the current fragment's slot
-  bool pfLive = false;                        // the fragment being fetched exists (its number is below nItems)
-  auto pfStage = [&](int s) {
-    uint32_t *D = sD[par ^ 1];
-    if (s == 1) { pa = (uint32_t)atomicAdd(&P.counters[P.only ? 26 : 25], 1ull); return; }
-    if (s == 2) {                             // the hand-out has arrived -> (second launch: its fragment number and scratch offset come from the first launch's list)
-      D[0] = pa; pfLive = pa < nItems;
-      if (pfLive && P.only) { pb = P.only[2 * pa]; pc = P.only[2 * pa + 1]; } else { pb = pa; pc = 0; }
-      return;
-    }
-    if (!pfLive) return;
-    if (s == 3) {                             // the fragment -> its two read-end numbers and the flag, requested together
-      D[1] = pb; D[2] = pc;
-      pa = P.end1[pb]; pd = paired ? P.end2[pb] : 0u; pc = P.hasN ? (uint32_t)P.hasN[pb] : 0u;
-      return;
-    }
-    if (s == 4) {                             // the read-ends -> the four list table words
-      D[3] = pa; D[4] = pd; D[5] = pc;
-      pb = P.listCount[pa]; pp1 = P.listPtr[pa];
-      if (paired) { pc = P.listCount[pd]; pp2 = P.listPtr[pd]; } else { pc = 0; pp2 = 0; }
-      return;
-    }
-    D[6] = pb; D[7] = pc; sDP[par ^ 1][0] = pp1; sDP[par ^ 1][1] = pp2;   // s == 5: the descriptor is complete
-  };
-  // (no reserve near the end of the launch: a workgroup that sat on a fragment while it finished a long one would make the launch's tail --
-  // what undid the same idea in k_collect in round 5; the last two rounds of hand-outs fetch their descriptor at the top, as before round 6)
-  bool pfOn = false;
-#define PF_STEP(s) do { if (tid == 0 && pfOn) pfStage(s); } while (0)
-#define PF_REST(from) do { if (tid == 0 && pfOn) for (int s_ = (from); s_ <= 5; ++s_) pfStage(s_); } while (0)
+  // overlaps), and with a fixed stride the kernel lasted as long as its unluckiest workgroup
+  __shared__ uint32_t sItem;
   for (;;) {
-    if (tid == 0) { if (pfOn) pfStage(5); else for (int s_ = 1; s_ <= 5; ++s_) pfStage(s_); }  // (5: asked for at the keep filter's end; behind PF_REST: the same words again)
-    par ^= 1;
-    if (tid == 0) { sDup = 0; sFail = 0; sBestM = -1; sBestIdx = 0x7FFFFFFF; sAnySep = 0; sNotOne = 0; sN = 0; }
+    if (tid == 0) { sItem = (uint32_t)atomicAdd(&P.counters[P.only ? 26 : 25], 1ull); sDup = 0; sFail = 0; sBestM = -1; sBestIdx = 0x7FFFFFFF; sAnySep = 0; sNotOne = 0; sN = 0; }
     __syncthreads();
-    const uint32_t it = sD[par][0];
+    const uint32_t it = sItem;
     if (it >= nItems) break;
-    const uint32_t f = sD[par][1];
+    const uint32_t f = P.only ? P.only[2 * it] : it;
     const uint64_t epoch = (uint64_t)(P.epochBase + f + 1) << 32;
-    const bool hasN = sD[par][5] != 0;
-    const uint32_t n1 = sD[par][6];
-    const OvlList L1{(const T1kOvlP *)sDP[par][0]};
+    const bool paired = P.end2 != nullptr;
+    // (the two read-end numbers and the flag are requested together, then the four list words: two round trips, not four)
+    const uint32_t e1 = P.end1[f];
+    const uint32_t e2 = paired ? P.end2[f] : 0u;
+    const bool hasN = P.hasN ? P.hasN[f] != 0 : false;
+    const uint32_t n1 = P.listCount[e1];
+    const OvlList L1{(const T1kOvlP *)P.listPtr[e1]};
     uint32_t n2 = 0;
     OvlList L2{nullptr};
-    if (paired) { n2 = sD[par][7]; L2.p = (const T1kOvlP *)sDP[par][1]; }
-#ifndef T1K_PAIR_NO_PREFETCH   // (A/B aid: every descriptor fetched at the top)
-    pfOn = (uint64_t)it + 2ull * gridDim.x < (uint64_t)nItems;
-#endif
-    PF_STEP(1);
+    if (paired) { n2 = P.listCount[e2]; L2.p = (const T1kOvlP *)P.listPtr[e2]; }
     const bool dangling = paired && (n1 == 0 || n2 == 0);
     const bool both = paired && !dangling;
     uint32_t nFrag = 0;
     if (P.only) {  // this fragment's piece of the big arena
-      const uint64_t off = sD[par][2];
+      const uint64_t off = P.only[2 * it + 1];
       fragCap = off + n1 + n2 <= P.bigCap ? n1 + n2 : 0u;
       frags = P.bigFrags + off; keep = P.bigKeep + off;
     }
@@ -309,7 +259,6 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(T1K_PAIR_WAV
           const unsigned long long off = atomicAdd(&P.counters[24], (unsigned long long)(n1 + n2));
           P.overflowList[2 * q] = f; P.overflowList[2 * q + 1] = (uint32_t)min(off, 0xFFFFFFFFull);
         }
-        PF_REST(2);
         __syncthreads();
         continue;
       }
@@ -318,7 +267,6 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(T1K_PAIR_WAV
         if (P.rsRowPtr) { P.rsRowCount[P.fragBase + f] = 0; P.rsAssigned[P.fragBase + f] = 0; }
         else { P.rowStart[f] = 0; P.rowCount[f] = 0; P.fragAssigned[f] = 0; }
       }
-      PF_REST(2);
       __syncthreads();
       continue;
     }
@@ -369,7 +317,6 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(T1K_PAIR_WAV
     double tbS = 0;
     bool tracked = false;
     PP(0);
-    PF_STEP(2);
     // ---- both mates have a list, no allele twice in a list (nearly every fragment): NO fragment list is materialised.  Round 3 wrote a
     // 48-byte record per joined allele into the workgroup's HBM scratch (about 700 a fragment) and read them back for the best / keep
     // passes: 51 KB written and twice that fetched per fragment (PMC, profiles/r04_before_traffic_work) for a row of ~14 entries.  The
@@ -500,7 +447,6 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(T1K_PAIR_WAV
       nFrag = sN;
     }
     PP(1);
-    PF_STEP(3);
     // ---- best fragment: max matchCnt, then max similarity, first in order (2474-2487) --------------------------------
     if (tracked) {
       // max matchCnt, then max similarity, then the smallest index: reduced over the lanes' own bests with shuffles
@@ -534,8 +480,8 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(T1K_PAIR_WAV
         if (tid == 0) sBestSim = -1;
         __syncthreads();
         // among the lanes holding the best matchCnt: max similarity (serialised through a CAS-free two-step)
-        double *sSim = (double *)sKFraw;
-        int *sIdx2 = (int *)(sKFraw + WG * sizeof(double));
+        __shared__ double sSim[WG];
+        __shared__ int sIdx2[WG];
         sSim[tid] = (bm == sBestM && bm >= 0) ? bs : -1.0;
         sIdx2[tid] = (bm == sBestM && bm >= 0) ? bi : 0x7FFFFFFF;
         __syncthreads();
@@ -619,7 +565,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(T1K_PAIR_WAV
             uint32_t tot;
             const uint32_t off = scanExcl<NWAVE>(kp ? 1u : 0u, warpSums, &tot);
             if (kp) {
-              if (nKept + off < fragCap) { frags[nKept + off] = fr; keep[nKept + off] = nKept + off; if (nKept + off < KF) sKF[nKept + off] = fr; }
+              if (nKept + off < fragCap) { frags[nKept + off] = fr; keep[nKept + off] = nKept + off; }
               else sFail = 2;  // (more kept fragments than the scratch holds: cannot happen -- kept <= joined <= n1 <= fragCap; guarded anyway)
             }
             nKept += tot;
@@ -648,13 +594,9 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(T1K_PAIR_WAV
     }
     __syncthreads();
     PP(3);
-    PF_STEP(4);
-    const bool kl = stream && nKept <= KF && !(P.whitelist && !P.rawKept);   // the kept fragments are read from LDS (keep[q] == q on the streamed path)
-    auto keptFrag = [&](uint32_t q) -> Frag { if (kl) return sKF[q]; return frags[keep[q]]; };
     // ---- dangling-mate rule (2553-2578) ----------------------------------------------------------------------------------
     bool cleared = false;
-    const bool firstBoth = nKept > 0 && paired && (kl || (frags[keep[0]].i >= 0 && frags[keep[0]].j >= 0));  // (a streamed fragment is a joined pair)
-    if (nKept > 0 && paired && !firstBoth) {
+    if (nKept > 0 && paired && !(frags[keep[0]].i >= 0 && frags[keep[0]].j >= 0)) {
       for (uint32_t q = tid; q < nKept; q += WG) {
         const Frag &fr = frags[keep[q]];
         const T1kOvl &o1 = fr.i >= 0 ? L1[fr.i] : L2[fr.j];
@@ -670,8 +612,8 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(T1K_PAIR_WAV
       cleared = sFail != 0;
     }
     // ---- truncated-reference rule (2580-2653) -----------------------------------------------------------------------------
-    if (!cleared && firstBoth) {
-      const Frag rep = keptFrag(0);
+    if (!cleared && nKept > 0 && paired && frags[keep[0]].i >= 0 && frags[keep[0]].j >= 0) {
+      const Frag rep = frags[keep[0]];
       const T1kOvl r1 = L1[rep.i], r2 = L2[rep.j];
       const double r1s = ovlSim(r1), r2s = ovlSim(r2);
       for (uint32_t i0 = tid; i0 < n1; i0 += PU * WG) {
@@ -727,7 +669,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(T1K_PAIR_WAV
     bool emptyRow = nKept == 0 || (!P.rawKept && P.maxAssign > 0 && (int)nKept > P.maxAssign);
     if (!emptyRow) {
       for (uint32_t q = tid; q < nKept; q += WG) {
-        const Frag fr = keptFrag(q);
+        const Frag &fr = frags[keep[q]];
         if (sepInRangeP(P.ref, fr.allele, fr.seqStart, fr.seqEnd)) sAnySep = 1;
         if (fr.sim >= 1) sNotOne = 1;  // maxSimilarity >= 1 somewhere
       }
@@ -761,7 +703,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(T1K_PAIR_WAV
       __syncthreads();
       if (nRow && sBase != 0xFFFFFFFFu) {
         for (uint32_t q = tid; q < nRow; q += WG) {
-          const Frag fr = keptFrag(q);
+          const Frag &fr = frags[keep[q]];
           t1k_row_entry r;
           r.allele_idx = (int32_t)fr.allele; r.start = fr.seqStart; r.end = fr.seqEnd;
           r.weight = rowWeight(fr.sim, P.sim, hasN);
@@ -787,17 +729,18 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(T1K_PAIR_WAV
       else { sRowBase = b; if (nRow) atomicAdd(&P.counters[9], (unsigned long long)nRow); }
     }
     // rank of every entry among the row's (distinct) alleles
-    for (uint32_t q = tid; q < nRow; q += WG) { if (kl) sKF[q].slot = 0; else frags[keep[q]].slot = 0; }
+    for (uint32_t q = tid; q < nRow; q += WG) frags[keep[q]].slot = 0;
     for (uint32_t t0 = 0; t0 < nRow; t0 += SORT_TILE) {
       const uint32_t tn = min(nRow - t0, (uint32_t)SORT_TILE);
       __syncthreads();
-      for (uint32_t i = tid; i < tn; i += WG) sAllele[i] = kl ? sKF[t0 + i].allele : frags[keep[t0 + i]].allele;
+      for (uint32_t i = tid; i < tn; i += WG) sAllele[i] = frags[keep[t0 + i]].allele;
       __syncthreads();
       for (uint32_t q = tid; q < nRow; q += WG) {
-        const uint32_t a = kl ? sKF[q].allele : frags[keep[q]].allele;
+        Frag &fr = frags[keep[q]];
+        const uint32_t a = fr.allele;
         int c = 0;
         for (uint32_t i = 0; i < tn; ++i) c += sAllele[i] < a ? 1 : 0;
-        if (kl) sKF[q].slot += c; else frags[keep[q]].slot += c;
+        fr.slot += c;
       }
     }
     __syncthreads();
@@ -805,7 +748,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(T1K_PAIR_WAV
     unsigned long long h1 = 0, h2 = 0;
     const bool fits = sRowBase != ~0ull;
     for (uint32_t q = tid; q < nRow; q += WG) {
-      const Frag fr = keptFrag(q);
+      const Frag &fr = frags[keep[q]];
       const uint32_t r = (uint32_t)fr.slot;
       h1 += t1k_pattern_mix(fr.allele, r, 0x9E3779B97F4A7C15ull);
       h2 += t1k_pattern_mix(fr.allele, r, 0xC2B2AE3D27D4EB4Full);
@@ -853,7 +796,9 @@ static int pairLaunch(t1k_ctx *ctx, t1k_rowset *rs, const uint32_t *end1, const 
   // 256 x 4096 / 2048 with the lists copied into LDS -- were measured in round 3 and are slower); 1024 workgroups keep
   // the wave slots of the chip filled (the kernel is latency-bound)
   const int wgThreads = 256;
-  const int maxWg = 1024 * 256 / wgThreads;
+  // (T1K_PAIR_WGS: workgroups = fragments in flight, for A/B -- round 6 measured the kernel's fabric traffic at 127 KB per fragment for 22 KB of
+  // records: each of its four sweeps over a fragment's two lists misses the L2 that 128 fragments per XCD share)
+  static const int maxWg = [] { const char *e = getenv("T1K_PAIR_WGS"); return e ? std::max(64, std::min(4096, atoi(e))) : 1024; }();
   const int nWg = (int)std::min<uint32_t>(maxWg, std::max<uint32_t>(n, 1));
   auto launch = [&](unsigned grid, const PairArgs &args) { hipLaunchKernelGGL((k_pair<256, 4096>), dim3(grid), dim3(256), 0, ctx->stream, args); };
   static const uint32_t envFragCap = [] { const char *e = getenv("T1K_PAIR_FRAGCAP"); return e ? (uint32_t)std::max(8, atoi(e)) : 8192u; }();  // (tests: force the second launch)

@@ -49,6 +49,21 @@ __global__ void k_ref_pack(const char *ascii, const uint8_t *exon, const uint64_
   bases[w] = b; nmask[w] = n; exonm[w] = e;
 }
 
+// the transposed copy of the bases (T1kRefDev::basesT): one thread per word of the copy; block b = alleles [64 b, 64 b + 64), rows[b] rows of 64 words
+__global__ void k_ref_transpose(const uint64_t *bases, const uint64_t *alleleOff, const uint32_t *alleleLen, const uint32_t *blockT, uint32_t nBlocks, uint32_t nAlleles, uint64_t totalT,
+                                uint64_t *basesT) {
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= totalT) return;
+  uint32_t lo = 0, hi = nBlocks - 1;   // the last block whose first word is <= t
+  while (lo < hi) { const uint32_t mid = (lo + hi + 1) >> 1; if ((uint64_t)blockT[mid] <= t) lo = mid; else hi = mid - 1; }
+  const uint64_t rel = t - blockT[lo];
+  const uint32_t a = lo * 64 + (uint32_t)(rel & 63);
+  const uint64_t w = rel >> 6;
+  uint64_t v = 0;
+  if (a < nAlleles && w < ((uint64_t)alleleLen[a] + 31) / 32) v = bases[(alleleOff[a] >> 5) + w];
+  basesT[t] = v;
+}
+
 // 2k bits starting at global position p (k <= 15)
 __device__ __forceinline__ uint32_t windowBits(const uint64_t *w, uint64_t p, int k) {
   const uint64_t wi = p >> 5;
@@ -257,6 +272,29 @@ extern "C" int t1k_ref_upload(t1k_ctx *ctx, const char *seqs, const uint64_t *of
   hipLaunchKernelGGL(k_ref_pack, dim3((unsigned)((nWords + 255) / 256)), dim3(256), 0, st, (const char *)bText.p, exon ? (const uint8_t *)bExonB.p : nullptr,
                      (const uint64_t *)bSrcOff.p, (const uint64_t *)dAlleleOff, (const uint32_t *)dAlleleLen, (const uint32_t *)bWordAllele.p, nWords, (uint64_t *)dBases,
                      (uint64_t *)dN, (uint64_t *)dExon, nCode);
+  // the transposed copy of the bases for the closed-form pass of the chain (T1kRefDev::basesT): blocks of 64 consecutive alleles, as many rows as the
+  // longest of them has words + 2 (a window is fetched as whole words up to two behind its last)
+  void *dBasesT = nullptr, *dBlockT = nullptr;
+  {
+    static const bool on = [] { const char *e = getenv("T1K_REF_TRANSPOSE"); return !e || atoi(e) != 0; }();
+    const uint32_t nBlocks = (nAlleles + 63) / 64;
+    std::vector<uint32_t> blockT(nBlocks);
+    uint64_t totalT = 0;
+    for (uint32_t b = 0; b < nBlocks; ++b) {
+      uint32_t words = 0;
+      for (uint32_t a = b * 64; a < std::min(nAlleles, b * 64 + 64); ++a) words = std::max(words, (alleleLen[a] + 31) / 32);
+      blockT[b] = (uint32_t)totalT;
+      totalT += (uint64_t)(words + 2) * 64;
+    }
+    if (on && nBlocks && totalT + 512 < (1ull << 32)) {
+      if ((rc = keep(ctx, (totalT + 512) * 8, &dBasesT)) || (rc = keep(ctx, (size_t)nBlocks * 4, &dBlockT))) { freeScratch(); return rc; }
+      RU_HIP(hipMemcpyAsync(dBlockT, blockT.data(), (size_t)nBlocks * 4, hipMemcpyHostToDevice, st));
+      RU_HIP(hipMemsetAsync((char *)dBasesT + totalT * 8, 0, 512 * 8, st));
+      hipLaunchKernelGGL(k_ref_transpose, dim3((unsigned)((totalT + 255) / 256)), dim3(256), 0, st, (const uint64_t *)dBases, (const uint64_t *)dAlleleOff, (const uint32_t *)dAlleleLen,
+                         (const uint32_t *)dBlockT, nBlocks, nAlleles, totalT, (uint64_t *)dBasesT);
+      RU_HIP(hipStreamSynchronize(st));  // (blockT is a local: the copy must have left it)
+    }
+  }
   lap("text upload + pack");
   // inserted windows
   hipLaunchKernelGGL(k_ref_codes, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const uint64_t *)dBases, (const uint64_t *)dN, (const uint64_t *)dAlleleOff,
@@ -326,6 +364,7 @@ extern "C" int t1k_ref_upload(t1k_ctx *ctx, const char *seqs, const uint64_t *of
   RU_HIP(hipStreamSynchronize(st));
   freeScratch2();
 #undef RU_HIP
+  r.basesT = (const uint64_t *)dBasesT; r.blockT = (const uint32_t *)dBlockT;
   r.bases = (const uint64_t *)dBases; r.nmask = (const uint64_t *)dN; r.exon = (const uint64_t *)dExon; r.posted = (const uint64_t *)dPosted;
   r.alleleOff = (const uint64_t *)dAlleleOff; r.alleleLen = (const uint32_t *)dAlleleLen; r.alleleHasN = (const uint8_t *)dHasN;
   r.anyN = 0;
