@@ -103,8 +103,24 @@ static int analyzerCallVariants(t1k_job *job, int varMaxGroup, AnalyzerVariants 
   uint32_t f0 = 0;
   while (f0 < F) {
     // a piece: fragments [f0, f1) whose distinct read-ends fit one upload
-    std::unordered_map<std::string, uint32_t> idOf;
+    // (identical read-ends of the piece are assigned once: an open-addressing table over a 64-bit hash of the bases, membership decided by comparing
+    // the bases themselves -- the std::unordered_map<std::string, ...> of round 5 allocated a string per read-end: 0.4 s per million pairs)
     std::vector<std::pair<const char *, uint32_t>> ends;
+    size_t slots = 64;
+    while (slots < (size_t)pieceEnds * 4) slots <<= 1;
+    std::vector<uint32_t> table(slots, ~0u);
+    auto endId = [&](const char *p, uint32_t n) -> uint32_t {
+      uint64_t h = 0x9E3779B97F4A7C15ull ^ n;
+      uint32_t i = 0;
+      for (; i + 8 <= n; i += 8) { uint64_t w; memcpy(&w, p + i, 8); h = (h ^ w) * 0xD6E8FEB86659FD93ull; h ^= h >> 29; }
+      for (; i < n; ++i) { h = (h ^ (uint8_t)p[i]) * 0x100000001B3ull; }
+      h ^= h >> 32;
+      for (size_t q = (size_t)h & (slots - 1);; q = (q + 1) & (slots - 1)) {
+        const uint32_t e = table[q];
+        if (e == ~0u) { table[q] = (uint32_t)ends.size(); ends.emplace_back(p, n); return (uint32_t)ends.size() - 1; }
+        if (ends[e].second == n && memcmp(ends[e].first, p, n) == 0) return e;
+      }
+    };
     std::vector<uint32_t> endOf;  // (fragment - f0) * 2 + mate -> distinct read-end of the piece
     uint32_t f1 = f0;
     for (; f1 < F && ends.size() + 2 <= pieceEnds; ++f1) {
@@ -112,9 +128,7 @@ static int analyzerCallVariants(t1k_job *job, int varMaxGroup, AnalyzerVariants 
       if (!job->fragAssigned[f1] || !cnt[f1]) continue;
       for (int m = 0; m < (paired ? 2 : 1); ++m) {
         auto rd = readOf(f1, m);
-        auto it = idOf.emplace(std::string(rd.first, rd.second), (uint32_t)ends.size());
-        if (it.second) ends.push_back(rd);
-        endOf[(size_t)(f1 - f0) * 2 + m] = it.first->second;
+        endOf[(size_t)(f1 - f0) * 2 + m] = endId(rd.first, rd.second);
       }
     }
     const uint32_t E = (uint32_t)ends.size();

@@ -242,8 +242,8 @@ class VariantCaller {
   std::vector<std::vector<std::pair<uint32_t, char>>> seen_;   // candidate -> (fragment, nucleotide shown)
   std::unordered_map<size_t, std::vector<int>> calledAt_;      // cell -> called variants (finalVariantIds)
   Cell &cell(int allele, int pos) const;
-  void bookOverlap(const char *read, uint32_t len, const t1k_overlap &o, const int8_t *ops, uint32_t nOps, double weight, bool filter);
-  void bookFragment(const Fragment &f, const int8_t *ops, bool first, int part, int parts);
+  void bookOverlap(const char *read, uint32_t len, const t1k_overlap &o, const int8_t *ops, uint32_t nOps, double weight, bool filter, Cell *table, const Cell *best);
+  void bookFragment(const Fragment &f, const int8_t *ops, bool first, int part, int parts, Cell *table, const Cell *best);
   bool candidateIn(int allele, int from, int to) const;
   int newCandidate(int allele, int pos, bool root);
   void findRoots();

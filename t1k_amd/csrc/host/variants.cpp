@@ -95,18 +95,21 @@ static inline void endOps(const t1k_frag_assignment &a, int k, const int8_t *ops
 }
 
 // UpdateBaseVariantFromOverlap (103-173).  filter = false: the sweep that only learns the best match counts (updateType 1: weight 0)
-void VariantCaller::bookOverlap(const char *read, uint32_t len, const t1k_overlap &o, const int8_t *ops, uint32_t nOps, double weight, bool filter) {
+// table: where the counts are added; best: where good() reads the best match counts (both the job's cells, or -- the sweeps threaded over the
+// FRAGMENTS -- a thread's private table and the job's cells, whose best match counts the first sweep has made final)
+void VariantCaller::bookOverlap(const char *read, uint32_t len, const t1k_overlap &o, const int8_t *ops, uint32_t nOps, double weight, bool filter, Cell *table, const Cell *best) {
   if (o.seq_idx == -1) return;
   const ReadView r{read, len, o.strand == -1};
   const int L = (int)ref_.seqs[o.seq_idx].size();
-  Cell *cells = cells_->data() + base_[o.seq_idx];
+  Cell *cells = table + base_[o.seq_idx];
+  const Cell *bestCells = best + base_[o.seq_idx];
   int refPos = o.seq_start, readPos = o.read_start;
   for (uint32_t k = 0; k < nOps; ++k) {
     const int op = ops[k];
     if (op == OP_MATCH || op == OP_MISMATCH) {
       if (refPos >= L || readPos >= (int)len) break;  // (cannot happen with the edit string of this overlap; the reference does not look)
       Cell &c = cells[refPos];
-      if (filter && !c.good(o.match_cnt)) continue;  // 134-135: leaves the column WITHOUT moving on (see the header)
+      if (filter && !bestCells[refPos].good(o.match_cnt)) continue;  // 134-135: leaves the column WITHOUT moving on (see the header)
       const int b = nucIndex(r.at(readPos));
       if (b < 0) continue;                           // 136-137 ('N'): the same
       if (weight == 1) c.uniq[b] += weight;
@@ -121,7 +124,7 @@ void VariantCaller::bookOverlap(const char *read, uint32_t len, const t1k_overla
 // UpdateBaseVariantFromFragmentOverlap (273-305).  An overlap books into the cells of its own allele only, and what it reads there (good())
 // was written by overlaps on the same allele: thread `part` of `parts` takes the assignments of the alleles it owns, in fragment order, and
 // every allele's cells see exactly the sequence of updates of a single sweep.
-void VariantCaller::bookFragment(const Fragment &f, const int8_t *ops, bool first, int part, int parts) {
+void VariantCaller::bookFragment(const Fragment &f, const int8_t *ops, bool first, int part, int parts, Cell *table, const Cell *best) {
   double total = 0;
   for (uint32_t i = 0; i < f.n; ++i) total += abundance_[f.asg[i].allele_idx];
   for (uint32_t i = 0; i < f.n; ++i) {
@@ -129,10 +132,10 @@ void VariantCaller::bookFragment(const Fragment &f, const int8_t *ops, bool firs
     if (a.allele_idx % parts != part) continue;
     const double w = first ? 0.0 : abundance_[a.allele_idx] / total;
     if (a.has_mate_pair) {
-      bookOverlap(f.r1, f.l1, a.o1, ops + a.ops1, a.n_ops1, w, !first);
-      bookOverlap(f.r2, f.l2, a.o2, ops + a.ops2, a.n_ops2, w, !first);
-    } else if (!a.o1_from_r2) bookOverlap(f.r1, f.l1, a.o1, ops + a.ops1, a.n_ops1, w, !first);
-    else bookOverlap(f.r2, f.l2, a.o1, ops + a.ops1, a.n_ops1, w, !first);
+      bookOverlap(f.r1, f.l1, a.o1, ops + a.ops1, a.n_ops1, w, !first, table, best);
+      bookOverlap(f.r2, f.l2, a.o2, ops + a.ops2, a.n_ops2, w, !first, table, best);
+    } else if (!a.o1_from_r2) bookOverlap(f.r1, f.l1, a.o1, ops + a.ops1, a.n_ops1, w, !first, table, best);
+    else bookOverlap(f.r2, f.l2, a.o1, ops + a.ops1, a.n_ops1, w, !first, table, best);
   }
 }
 
@@ -383,8 +386,47 @@ void VariantCaller::compute(const std::vector<Fragment> &frags, const int8_t *op
     for (int t = 0; t < parts; ++t) th.emplace_back([&, t] { fn(t); });
     for (auto &x : th) x.join();
   };
-  sweep([&](int t) { for (const Fragment &f : frags) bookFragment(f, ops, true, t, parts); });
-  sweep([&](int t) { for (const Fragment &f : frags) bookFragment(f, ops, false, t, parts); });
+  // The two booking sweeps (UpdateBaseVariantFromFragmentOverlap with updateType 1, then 0).  What they add to a cell are whole numbers (count += 1,
+  // uniq += 1 for a weight of exactly 1) and maxima (best match counts), and the second sweep's filter reads best match counts the first has made
+  // final: the result does not depend on the order of the fragments.  Round 6: threads take contiguous pieces of the FRAGMENTS, each into a table of its
+  // own, and the tables are folded into the job's cells (sums of whole numbers in doubles below 2^53 and maxima: exact) -- threads that own alleles
+  // (round 5) all walk every fragment and wait for the one that owns the sample's most abundant allele.  Tables beyond 1 GB in all: ownership as before.
+  Cell *const mine = cells_->data();
+  const size_t nCells = cells_->size();
+  int bookT = (int)std::min<size_t>((size_t)std::max(1u, std::thread::hardware_concurrency()), 16);
+  if (frags.size() < 20000) bookT = 1;
+  if (const char *e = getenv("T1K_VARIANTS_THREADS")) bookT = std::max(1, std::min(64, atoi(e)));
+  if (bookT > 1 && nCells * sizeof(Cell) * (size_t)bookT <= ((size_t)1 << 30)) {
+    for (int pass = 0; pass < 2; ++pass) {
+      std::vector<std::vector<Cell>> priv((size_t)bookT);
+      std::vector<std::thread> th;
+      for (int t = 0; t < bookT; ++t)
+        th.emplace_back([&, t] {
+          priv[t].assign(nCells, Cell());
+          const size_t lo = frags.size() * (size_t)t / bookT, hi = frags.size() * (size_t)(t + 1) / bookT;
+          for (size_t i = lo; i < hi; ++i) bookFragment(frags[i], ops, pass == 0, 0, 1, priv[t].data(), mine);
+        });
+      for (auto &x : th) x.join();
+      th.clear();
+      for (int t = 0; t < bookT; ++t)   // the fold, by cell ranges
+        th.emplace_back([&, t] {
+          const size_t lo = nCells * (size_t)t / bookT, hi = nCells * (size_t)(t + 1) / bookT;
+          for (int u = 0; u < bookT; ++u) {
+            const Cell *src = priv[u].data();
+            for (size_t c = lo; c < hi; ++c) {
+              Cell &d = mine[c];
+              const Cell &q = src[c];
+              for (int b = 0; b < 4; ++b) { d.count[b] += q.count[b]; d.uniq[b] += q.uniq[b]; if (q.bestMatch[b] > d.bestMatch[b]) d.bestMatch[b] = q.bestMatch[b]; }
+              if (q.bestOfAll > d.bestOfAll) d.bestOfAll = q.bestOfAll;
+            }
+          }
+        });
+      for (auto &x : th) x.join();
+    }
+  } else {
+    sweep([&](int t) { for (const Fragment &f : frags) bookFragment(f, ops, true, t, parts, mine, mine); });
+    sweep([&](int t) { for (const Fragment &f : frags) bookFragment(f, ops, false, t, parts, mine, mine); });
+  }
   findRoots();
   const double t1 = now();
   int rounds = 0;

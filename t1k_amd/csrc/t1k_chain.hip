@@ -1254,6 +1254,9 @@ __global__ __launch_bounds__(WG) void k_chain_fast(ChainArgs P, const uint32_t *
 #pragma unroll
       for (int w = 0; w < NW; ++w) Mw[w] = rv[3 + w];
       ReadCtx c = makeCtx(P, re, pass, allele);
+      // (the transposed copy pays where the lanes hold consecutive alleles: the pass over ALL records.  The gap walk's list is a scattered 40 % of them --
+      // measured with the copy: its fabric traffic went UP by a third, six lines a lane instead of one or two; profiles/r06_callC_*.log)
+      if (MODE != 0) c.gT = nullptr;
       uint32_t cbuf[3];
       CandOut out{cbuf, 0};
       const GapSink sink{P.memo + (uint64_t)re * GAP_CACHE, P.jobStr, P.counters, re * GAP_CACHE, P.jobSegCap, T1K_AR_JOBS};
