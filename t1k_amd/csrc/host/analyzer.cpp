@@ -151,42 +151,58 @@ static int analyzerCallVariants(t1k_job *job, int varMaxGroup, AnalyzerVariants 
       for (uint32_t e = 0; e < E; ++e) listAt[e + 1] = listAt[e] + lc[e];
       const double tb = nowMs();
       msAssign += tb - ta;
-      // the overlaps behind every kept assignment
-      std::vector<int32_t> alleles;
-      for (uint32_t f = f0; f < f1; ++f) {
-        if (!job->fragAssigned[f] || !cnt[f]) continue;
-        const uint32_t k = cnt[f];
-        alleles.resize(k);
-        for (uint32_t j = 0; j < k; ++j) alleles[j] = rows[rowAt[f] + j].allele_idx;
-        const uint32_t e1 = endOf[(size_t)(f - f0) * 2], e2 = paired ? endOf[(size_t)(f - f0) * 2 + 1] : 0;
-        if (!fragmentDetails(lists.data() + listAt[e1], lc[e1], paired ? lists.data() + listAt[e2] : nullptr, paired ? lc[e2] : 0, paired, alleles.data(), k, V.asg.data() + V.asgPtr[f]))
-          return jobFail(job, T1K_ERR_INTERNAL, "analyzer: fragment " + std::to_string(f) + " is assigned to an allele its read-ends' overlap lists do not hold");
-      }
-      // one alignment per distinct (read-end, overlap) an assignment names: the overlap is found again in its list by its address
+      // the overlaps behind every kept assignment, and where each of them sits in its read-end's list (found again by its coordinates): per
+      // fragment, by the host threads (round 6); the alignment jobs -- one per distinct (read-end, overlap) -- are numbered behind them in
+      // fragment order, as before
+      const uint64_t q0 = V.asgPtr[f0], nAsg = V.asgPtr[f1] - q0;
+      std::vector<int64_t> at[2];   // assignment -> index of its overlap(s) in `lists`
+      at[0].assign(nAsg, -1); at[1].assign(nAsg, -1);
+      std::atomic<int64_t> badFrag{-1};
+      std::atomic<int> badKind{0};
+      parallelRanges((size_t)(f1 - f0), hostThreads(job), [&](int, size_t lo, size_t hi) {
+        std::vector<int32_t> alleles;
+        auto find = [&](uint32_t e, const t1k_overlap &o) -> int64_t {
+          for (uint32_t i = 0; i < lc[e]; ++i) {
+            const t1k_overlap &c = lists[listAt[e] + i];
+            if (c.seq_idx == o.seq_idx && c.read_start == o.read_start && c.read_end == o.read_end && c.seq_start == o.seq_start && c.seq_end == o.seq_end && c.strand == o.strand)
+              return (int64_t)(listAt[e] + i);
+          }
+          return -1;
+        };
+        for (size_t x = lo; x < hi; ++x) {
+          const uint32_t f = f0 + (uint32_t)x;
+          if (!job->fragAssigned[f] || !cnt[f]) continue;
+          const uint32_t k = cnt[f];
+          alleles.resize(k);
+          for (uint32_t j = 0; j < k; ++j) alleles[j] = rows[rowAt[f] + j].allele_idx;
+          const uint32_t e1 = endOf[x * 2], e2 = paired ? endOf[x * 2 + 1] : 0;
+          if (!fragmentDetails(lists.data() + listAt[e1], lc[e1], paired ? lists.data() + listAt[e2] : nullptr, paired ? lc[e2] : 0, paired, alleles.data(), k, V.asg.data() + V.asgPtr[f])) {
+            badKind = 1; badFrag = f; return;
+          }
+          for (uint64_t q = V.asgPtr[f]; q < V.asgPtr[f + 1]; ++q) {
+            const t1k_frag_assignment &a = V.asg[q];
+            const uint32_t eA = endOf[x * 2 + ((a.o1_from_r2 && !a.has_mate_pair) ? 1 : 0)];
+            if ((at[0][q - q0] = find(eA, a.o1)) < 0 || (a.has_mate_pair && (at[1][q - q0] = find(endOf[x * 2 + 1], a.o2)) < 0)) { badKind = 2; badFrag = f; return; }
+          }
+        }
+      });
+      if (badKind.load() == 1) return jobFail(job, T1K_ERR_INTERNAL, "analyzer: fragment " + std::to_string(badFrag.load()) + " is assigned to an allele its read-ends' overlap lists do not hold");
+      if (badKind.load() == 2) return jobFail(job, T1K_ERR_INTERNAL, "analyzer: an assignment's overlap is not in its read-end's list");
       std::vector<int64_t> jobOf(total, -1);
       struct Job { uint32_t end, idx; };
       std::vector<Job> jobs;
-      auto jobFor = [&](uint32_t e, const t1k_overlap &o) -> int64_t {
-        for (uint32_t i = 0; i < lc[e]; ++i) {
-          const t1k_overlap &c = lists[listAt[e] + i];
-          if (c.seq_idx == o.seq_idx && c.read_start == o.read_start && c.read_end == o.read_end && c.seq_start == o.seq_start && c.seq_end == o.seq_end && c.strand == o.strand) {
-            int64_t &slot = jobOf[listAt[e] + i];
-            if (slot < 0) { slot = (int64_t)jobs.size(); jobs.push_back({e, i}); }
-            return slot;
-          }
-        }
-        return -1;
-      };
+      std::vector<uint32_t> endOfList(total);   // list entry -> its read-end
+      for (uint32_t e = 0; e < E; ++e) for (uint64_t i = listAt[e]; i < listAt[e + 1]; ++i) endOfList[i] = e;
       std::vector<int64_t> jobOfAsg[2];
-      jobOfAsg[0].assign(V.asgPtr[f1] - V.asgPtr[f0], -1);
-      jobOfAsg[1].assign(V.asgPtr[f1] - V.asgPtr[f0], -1);
-      for (uint32_t f = f0; f < f1; ++f)
-        for (uint64_t q = V.asgPtr[f]; q < V.asgPtr[f + 1]; ++q) {
-          const t1k_frag_assignment &a = V.asg[q];
-          const uint32_t eA = endOf[(size_t)(f - f0) * 2 + ((a.o1_from_r2 && !a.has_mate_pair) ? 1 : 0)];
-          if ((jobOfAsg[0][q - V.asgPtr[f0]] = jobFor(eA, a.o1)) < 0) return jobFail(job, T1K_ERR_INTERNAL, "analyzer: an assignment's overlap is not in its read-end's list");
-          if (a.has_mate_pair && (jobOfAsg[1][q - V.asgPtr[f0]] = jobFor(endOf[(size_t)(f - f0) * 2 + 1], a.o2)) < 0)
-            return jobFail(job, T1K_ERR_INTERNAL, "analyzer: an assignment's overlap is not in its read-end's list");
+      jobOfAsg[0].assign(nAsg, -1);
+      jobOfAsg[1].assign(nAsg, -1);
+      for (uint64_t q = 0; q < nAsg; ++q)
+        for (int m = 0; m < 2; ++m) {
+          const int64_t li = at[m][q];
+          if (li < 0) continue;
+          int64_t &slot = jobOf[li];
+          if (slot < 0) { slot = (int64_t)jobs.size(); jobs.push_back({endOfList[li], (uint32_t)(li - (int64_t)listAt[endOfList[li]])}); }
+          jobOfAsg[m][q] = slot;
         }
       // patterns: the read-ends as they are and, where an overlap is on the other strand, reverse-complemented (SeqSet.hpp:2663-2668)
       std::vector<uint64_t> rcAt(E, ~0ull);

@@ -448,6 +448,7 @@ bool RefSet::load(const std::string &fasta, int digitUnitsArg, char delimiterArg
     for (int a = 0; a < A; ++a)
       if (al[a].gene == g && al[a].effLen < mode - 500) al[a].effLen = mode;
   }
+  if (getenv("T1K_DEBUG_PHASES")) fprintf(stderr, "[t1k host] reference: naming + gene similarity + effective lengths %.1f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tC).count());
   return true;
 }
 

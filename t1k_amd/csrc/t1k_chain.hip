@@ -1271,7 +1271,10 @@ __global__ __launch_bounds__(WG) void k_chain_fast(ChainArgs P, const uint32_t *
       } else if (kind == 1) {
         ++fastLocal;
         if (out.n) { ((uint2 *)rec)[1] = make_uint2(REC_DONE | 1u, cbuf[0]); ((uint2 *)rec)[2] = make_uint2(cbuf[1], cbuf[2]); }
-        else rec[2] = REC_DONE;
+        else if (MODE != 0) rec[2] = REC_DONE;
+        // (MODE 0, no candidate -- six in ten groups: the record is left as seeding wrote it.  Word 2 still holds the diagonal word: neither REC_DONE nor a
+        // pending count (it is at least 2^20), which k_collect reads as "no candidate".  Round 6: a 4-byte store into a record nobody reads again was a
+        // 32-byte write on the fabric, 0.19 TB per 10 M-pair step)
       }
     }
   }
@@ -1971,7 +1974,7 @@ __global__ __launch_bounds__(WG) void k_collect(ChainArgs P) {
         if (rv[u] >= nRec) continue;
         const uint4 hd = hdv[u], cw = cwv[u];
         const bool pend = recPending(hd.z);
-        const uint32_t nc = pend ? 1u : (hd.z & 0x3FFFFFFFu);
+        const uint32_t nc = pend ? 1u : ((hd.z & REC_DONE) ? (hd.z & 0x3FFFFFFFu) : 0u);   // (neither: a group the closed-form pass ended without a candidate, left as seeded)
         const uint32_t w2own = pend ? pendingMatchWord(P, re, hd.z, cw.y, cw.z, cw.w) : cw.y;
         const int plus = (int)(hd.x >> 31);
         if (first[u]) sChPlus[chv[u]] = (uint8_t)plus;  // a chunk holds one strand
@@ -2037,7 +2040,7 @@ __global__ __launch_bounds__(WG) void k_collect(ChainArgs P) {
         uint4 hd = make_uint4(0u, 0u, 0u, 0u), cw = make_uint4(0u, 0u, 0u, 0u);
         if (look) { const uint32_t *rec = P.recs + (uint64_t)g * stride; hd = ((const uint4 *)rec)[0]; cw = ((const uint4 *)rec)[1]; }
         const bool pend = look && recPending(hd.z);
-        const uint32_t nc = look ? (pend ? 1u : (hd.z & 0x3FFFFFFFu)) : 0;
+        const uint32_t nc = look ? (pend ? 1u : ((hd.z & REC_DONE) ? (hd.z & 0x3FFFFFFFu) : 0u)) : 0;
         const uint32_t w2own = pend ? pendingMatchWord(P, re, hd.z, cw.y, cw.z, cw.w) : cw.y;
         uint32_t keepMask = 0, nk = 0;  // a group holds at most 32 candidates
         for (uint32_t j = 0; j < nc; ++j) {
