@@ -545,6 +545,9 @@ __device__ __forceinline__ uint32_t closedFormGroup(uint32_t *a, const uint64_t 
 #ifndef T1K_SEED_WAVES
 #define T1K_SEED_WAVES 8
 #endif
+#ifndef T1K_SEED_PACK_Q
+#define T1K_SEED_PACK_Q 0
+#endif
 #ifndef T1K_FUSE_WAVES
 #define T1K_FUSE_WAVES 5
 #endif
@@ -571,12 +574,22 @@ __device__ __forceinline__ void seedGroupsBody(const ChainArgs &P) {
   uint32_t *lstStart = pre + maxK + 1;              // [maxK]  posting-list start / length of the used lists (both strands)
   uint32_t *lstLen = lstStart + maxK;               // [maxK]
   uint32_t *lstDir = lstLen + maxK;                 // [maxK]
+  // read offset of the used lists: T1K_SEED_PACK_Q (round 6) keeps it in the upper nine bits of lstLen -- a list's length is only asked for "is it
+  // empty" (lists with a directory row) or is below T1K_DIR_MINLEN (the others), so 23 bits hold all that is read -- and the 560 bytes of its own array
+  // go: 20 756 -> 20 196 bytes of LDS per workgroup for 2 x 150 bp reads, under the 20 480 at which EIGHT workgroups fit a compute unit's 160 KB
+  // (the register allocation has been held to 64 VGPRs for eight wavefronts per SIMD all along; the LDS admitted seven)
+#if T1K_SEED_PACK_Q
+  uint16_t *qOf = (uint16_t *)(lstDir + maxK);      // (no array: the pointer only marks where the bitmaps may start)
+#define LST_LEN(x) ((x) & 0x7FFFFFu)
+#else
   uint16_t *qOf = (uint16_t *)(lstDir + maxK);      // [maxK]  read offset of the used lists
+#define LST_LEN(x) (x)
+#endif
   // two bitmaps over all alleles (chunk selection, before the chunk loop of each strand): over the accumulators when they fit there
   // (references of up to 57 344 / 106 496 sequences), else behind the list arrays (the launcher sizes the dynamic LDS for it)
   const uint32_t A = P.ref.nAlleles;
   const uint32_t nChunks = P.ref.kDirStride - 1;    // (the launcher refuses more than 256 chunks: sHot)
-  uint32_t *bitmaps = 2 * ((A + 31) >> 5) <= (uint32_t)(CHUNK_A * AW) ? acc : (uint32_t *)(qOf + ((maxK + 1) & ~1));
+  uint32_t *bitmaps = 2 * ((A + 31) >> 5) <= (uint32_t)(CHUNK_A * AW) ? acc : (uint32_t *)(qOf + (T1K_SEED_PACK_Q ? 0 : ((maxK + 1) & ~1)));
   __shared__ uint32_t warpSums[4];
   __shared__ uint32_t sHot[8];                      // bit c: chunk c can hold an allele with three hits (this strand)
   __shared__ uint32_t sUsed[2], sGroupBase, sFallback, sPost;
@@ -753,7 +766,11 @@ __device__ __forceinline__ void seedGroupsBody(const ChainArgs &P) {
       const int q = usedQ[u];
       const int pass = u < nUsedPlus ? 0 : 1;
       const uint32_t st = ukStart[q], ln = ukLen[q];
+#if T1K_SEED_PACK_Q
+      lstStart[u] = st; lstLen[u] = min(ln, 0x7FFFFFu) | ((uint32_t)(q - pass * nk) << 23); lstDir[u] = ukDir[q];
+#else
       lstStart[u] = st; lstLen[u] = ln; lstDir[u] = ukDir[q]; qOf[u] = (uint16_t)(q - pass * nk);
+#endif
     }
     __syncthreads();
     for (uint32_t i = tid; i < (uint32_t)((9 * maxK + 1) / 2); i += WG) acc[i] = (i % AW) == 0 ? (uint32_t)DIAG_EMPTY : 0u;
@@ -813,8 +830,8 @@ __device__ __forceinline__ void seedGroupsBody(const ChainArgs &P) {
             if (nChunks > 64) mk = ~0ull;
           }
         };
-        mark(has0, has0 ? lstStart[uBegin + tid] : 0u, has0 ? lstLen[uBegin + tid] : 0u, has0 ? lstDir[uBegin + tid] : T1K_NO_DIR, mk0);
-        mark(has1, has1 ? lstStart[uBegin + tid + WG] : 0u, has1 ? lstLen[uBegin + tid + WG] : 0u, has1 ? lstDir[uBegin + tid + WG] : T1K_NO_DIR, mk1);
+        mark(has0, has0 ? lstStart[uBegin + tid] : 0u, has0 ? LST_LEN(lstLen[uBegin + tid]) : 0u, has0 ? lstDir[uBegin + tid] : T1K_NO_DIR, mk0);
+        mark(has1, has1 ? lstStart[uBegin + tid + WG] : 0u, has1 ? LST_LEN(lstLen[uBegin + tid + WG]) : 0u, has1 ? lstDir[uBegin + tid + WG] : T1K_NO_DIR, mk1);
         __syncthreads();
         if (bitmaps == acc) {  // the bitmaps lay over the accumulators: make those clean again
           for (uint32_t i = tid; i < 2 * BW; i += WG) acc[i] = (i % AW) == 0 ? (uint32_t)DIAG_EMPTY : 0u;
@@ -848,7 +865,7 @@ __device__ __forceinline__ void seedGroupsBody(const ChainArgs &P) {
           if (may || ((mk0 >> ci) & 1ull)) {
             const uint32_t row = lstDir[uBegin + tid];
             if (row != T1K_NO_DIR) { const uint32_t *dir = P.ref.kDir + (uint64_t)row * P.ref.kDirStride; lo = dir[ci]; hi = dir[ci + 1]; }
-            else { const uint32_t st = lstStart[uBegin + tid], ln = lstLen[uBegin + tid]; lo = lowerBound(st, cur0, ln, c0); hi = lowerBound(st, lo, ln, c1); }
+            else { const uint32_t st = lstStart[uBegin + tid], ln = LST_LEN(lstLen[uBegin + tid]); lo = lowerBound(st, cur0, ln, c0); hi = lowerBound(st, lo, ln, c1); }
           }
           n0 = hi - lo; sLo[tid] = lo; cur0 = hi;
         }
@@ -857,7 +874,7 @@ __device__ __forceinline__ void seedGroupsBody(const ChainArgs &P) {
           if (may || ((mk1 >> ci) & 1ull)) {
             const uint32_t row = lstDir[uBegin + tid + WG];
             if (row != T1K_NO_DIR) { const uint32_t *dir = P.ref.kDir + (uint64_t)row * P.ref.kDirStride; lo = dir[ci]; hi = dir[ci + 1]; }
-            else { const uint32_t st = lstStart[uBegin + tid + WG], ln = lstLen[uBegin + tid + WG]; lo = lowerBound(st, cur1, ln, c0); hi = lowerBound(st, lo, ln, c1); }
+            else { const uint32_t st = lstStart[uBegin + tid + WG], ln = LST_LEN(lstLen[uBegin + tid + WG]); lo = lowerBound(st, cur1, ln, c0); hi = lowerBound(st, lo, ln, c1); }
           }
           n1 = hi - lo; sLo[tid + WG] = lo; cur1 = hi;
         }
@@ -905,7 +922,7 @@ __device__ __forceinline__ void seedGroupsBody(const ChainArgs &P) {
               if (j < jEnd) {
                 while (pre[lo + 1] <= j) ++lo;  // pre[uCount] = T > j ends it
                 pst[x] = P.ref.kPost[lstStart[uBegin + lo] + sLo[lo] + (j - pre[lo])];
-                rr[x] = qOf[uBegin + lo];
+                rr[x] = T1K_SEED_PACK_Q ? (int)(lstLen[uBegin + lo] >> 23) : (int)qOf[uBegin + lo];
               }
             }
 #pragma unroll
@@ -2367,7 +2384,7 @@ int t1k_run_chain(t1k_ctx *ctx, const ChainArgs &a, int nWg, int bigBlocks, bool
   const int AW = longReads ? 13 : 7;
   const size_t maxK = a.maxKFast;
   const bool xlong = a.maxK > a.maxKFast;  // the window holds read-ends beyond T1K_MAX_READ_LEN: k_seed_long takes those
-  size_t lds = (size_t)CHUNK_A * AW * 4 + maxK * (5 * 4 + 2) + 4 + 64;  // accumulators | sLo, pre, lstStart, lstLen, lstDir, qOf
+  size_t lds = (size_t)CHUNK_A * AW * 4 + maxK * (5 * 4 + (T1K_SEED_PACK_Q ? 0 : 2)) + 4 + (T1K_SEED_PACK_Q ? 8 : 64);  // accumulators | sLo, pre, lstStart, lstLen, lstDir, qOf
   const size_t bitmapWords = 2 * (((size_t)a.ref.nAlleles + 31) / 32);        // chunk selection: two bitmaps over all alleles ...
   if (bitmapWords > (size_t)CHUNK_A * AW) lds += bitmapWords * 4 + 8;         // ... behind the list arrays when the accumulators cannot hold them
   if (a.ref.kDirStride - 1 > 256) return t1k_fail(ctx, T1K_ERR_ARG, "the reference holds more than 131 072 distinct sequences (256 seeding chunks)");
