@@ -543,7 +543,7 @@ __device__ __forceinline__ uint32_t closedFormGroup(uint32_t *a, const uint64_t 
 }
 
 #ifndef T1K_SEED_WAVES
-#define T1K_SEED_WAVES 8
+#define T1K_SEED_WAVES 7   // round 6: the kernel's 20.7 KB of LDS admit SEVEN workgroups a compute unit; held to 64 VGPRs for eight it spilled 41 registers for an occupancy it never had (72 VGPRs: 24 spilled; 3.11 -> 2.87 ms per range alone, profiles/r06_callE_seed_waves_suite.log)
 #endif
 #ifndef T1K_SEED_PACK_Q
 #define T1K_SEED_PACK_Q 0

@@ -63,6 +63,9 @@ __device__ __forceinline__ unsigned long long t1k_pattern_mix(uint32_t allele, u
 #ifndef T1K_PAIR_UNROLL
 #define T1K_PAIR_UNROLL 2
 #endif
+#ifndef T1K_PAIR_ABLATE
+#define T1K_PAIR_ABLATE 0   // 1 / 2 / 3: one of the kernel's sweeps over the two lists compiled out -- WRONG RESULTS, for timing a sweep's share only (tools/callF_r06.sh)
+#endif
 #ifndef T1K_PAIR_WAVES
 #define T1K_PAIR_WAVES 4   // wavefronts per SIMD the register allocation of k_pair is held to (the join table's LDS admits four workgroups per compute unit)
 #endif
@@ -278,6 +281,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(T1K_PAIR_WAV
       __syncthreads();
       // (this is the first touch of the two lists: four records' allele words are requested together before the dependent LDS inserts --
       // one after the other, each insert's atomic kept the next record's load from being issued)
+#if T1K_PAIR_ABLATE != 2   // (timing-only ablation 2: list 1 is not entered into the join table)
       for (uint32_t i0 = tid; i0 < n1; i0 += 4 * WG) {
         uint32_t al[4];
 #pragma unroll
@@ -288,6 +292,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(T1K_PAIR_WAV
           if (i < n1) { const uint32_t old = atomicOr(&hVal[ljInsert<LJ_SLOTS>(hKey, al[r])], i + 1); if (old & 0x7FFFu) sDup = 1; }
         }
       }
+#endif
       for (uint32_t j0 = tid; j0 < n2; j0 += 4 * WG) {
         uint32_t al[4];
 #pragma unroll
@@ -342,7 +347,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(T1K_PAIR_WAV
           jv[u] = -1; slotv[u] = -1;
           if (i < n1 && s1 != s2) {
             const uint32_t al = (uint32_t)(pa[u].lo & 0xFFFFFFu);
-            if (lds) { slotv[u] = ljFind<LJ_SLOTS>(hKey, al); jv[u] = (int)(hVal[slotv[u]] >> 16) - 1; }
+            if (lds) { slotv[u] = ljFind<LJ_SLOTS>(hKey, al); jv[u] = slotv[u] >= 0 ? (int)(hVal[slotv[u]] >> 16) - 1 : -1; }
             else { const uint64_t e = tab2[al]; if ((e >> 32) == (epoch >> 32)) jv[u] = (int)(e & 0x3FFFFFFFu); }
           }
         }
@@ -525,7 +530,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(T1K_PAIR_WAV
     // ---- keep filter (2488-2545), order-preserving -----------------------------------------------------------------------
     uint32_t nKept = 0;
     if (stream) {
-      if (bestM >= 0) {
+      if (bestM >= 0 && T1K_PAIR_ABLATE != 1) {   // (timing-only ablation 1: no keep sweep)
         const int s1 = ovlStrand(L1[0]), s2 = ovlStrand(L2[0]);
         for (uint32_t i0 = 0; i0 < n1; i0 += PU * WG) {  // (PU rounds' loads in flight together, as in the pass above; the rounds' scans keep list order)
           T1kOvlP pa[PU], pb[PU];
@@ -538,7 +543,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(T1K_PAIR_WAV
             jv[u] = -1;
             if (i < n1 && s1 != s2) {
               const uint32_t al = (uint32_t)(pa[u].lo & 0xFFFFFFu);
-              if (lds) jv[u] = (int)((hVal[ljFind<LJ_SLOTS>(hKey, al)] >> 16) & 0xFFFFu) - 1;
+              if (lds) { const int sl = ljFind<LJ_SLOTS>(hKey, al); jv[u] = sl >= 0 ? (int)((hVal[sl] >> 16) & 0xFFFFu) - 1 : -1; }
               else { const uint64_t e = tab2[al]; if ((e >> 32) == (epoch >> 32)) jv[u] = (int)(e & 0x3FFFFFFFu); }
             }
           }
@@ -612,7 +617,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(T1K_PAIR_WAV
       cleared = sFail != 0;
     }
     // ---- truncated-reference rule (2580-2653) -----------------------------------------------------------------------------
-    if (!cleared && nKept > 0 && paired && frags[keep[0]].i >= 0 && frags[keep[0]].j >= 0) {
+    if (!cleared && nKept > 0 && paired && frags[keep[0]].i >= 0 && frags[keep[0]].j >= 0 && T1K_PAIR_ABLATE != 3) {   // (timing-only ablation 3: no sweep of the truncated-reference rule)
       const Frag rep = frags[keep[0]];
       const T1kOvl r1 = L1[rep.i], r2 = L2[rep.j];
       const double r1s = ovlSim(r1), r2s = ovlSim(r2);
