@@ -443,8 +443,14 @@ __device__ inline bool candBeforeFull(const T1kCand &a, const T1kCand &b) {
 #define SELECT_SMALL 2048
 #define SELECT_LARGE 8192
 
+// (registers: the 1024-thread shape's 76 KB of LDS admit two workgroups a compute unit = eight wavefronts per SIMD, the 256-thread shape's 22 KB seven
+// workgroups = SEVEN wavefronts: held to eight wavefronts' worth of registers it spilled 13 of them for an occupancy its LDS does not admit -- round 6,
+// as for k_seed_groups; T1K_SELECT_SMALL_WAVES)
+#ifndef T1K_SELECT_SMALL_WAVES
+#define T1K_SELECT_SMALL_WAVES 8
+#endif
 template <int SELECT_LDS_CAP, int NT, bool XL>
-__global__ __launch_bounds__(NT) T1K_OCC8 void k_select(SelectArgs P) {
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(SELECT_LDS_CAP == SELECT_SMALL ? T1K_SELECT_SMALL_WAVES : 8))) void k_select(SelectArgs P) {
   extern __shared__ uint64_t dynLds[];
   uint64_t *sKey = dynLds;
   __shared__ uint32_t warpSums[NT / 64];

@@ -63,9 +63,6 @@ __device__ __forceinline__ unsigned long long t1k_pattern_mix(uint32_t allele, u
 #ifndef T1K_PAIR_UNROLL
 #define T1K_PAIR_UNROLL 2
 #endif
-#ifndef T1K_PAIR_ABLATE
-#define T1K_PAIR_ABLATE 0   // 1 / 2 / 3: one of the kernel's sweeps over the two lists compiled out -- WRONG RESULTS, for timing a sweep's share only (tools/callF_r06.sh)
-#endif
 #ifndef T1K_PAIR_WAVES
 #define T1K_PAIR_WAVES 4   // wavefronts per SIMD the register allocation of k_pair is held to (the join table's LDS admits four workgroups per compute unit)
 #endif
@@ -281,7 +278,6 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(T1K_PAIR_WAV
       __syncthreads();
       // (this is the first touch of the two lists: four records' allele words are requested together before the dependent LDS inserts --
       // one after the other, each insert's atomic kept the next record's load from being issued)
-#if T1K_PAIR_ABLATE != 2   // (timing-only ablation 2: list 1 is not entered into the join table)
       for (uint32_t i0 = tid; i0 < n1; i0 += 4 * WG) {
         uint32_t al[4];
 #pragma unroll
@@ -292,7 +288,6 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(T1K_PAIR_WAV
           if (i < n1) { const uint32_t old = atomicOr(&hVal[ljInsert<LJ_SLOTS>(hKey, al[r])], i + 1); if (old & 0x7FFFu) sDup = 1; }
         }
       }
-#endif
       for (uint32_t j0 = tid; j0 < n2; j0 += 4 * WG) {
         uint32_t al[4];
 #pragma unroll
@@ -530,7 +525,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(T1K_PAIR_WAV
     // ---- keep filter (2488-2545), order-preserving -----------------------------------------------------------------------
     uint32_t nKept = 0;
     if (stream) {
-      if (bestM >= 0 && T1K_PAIR_ABLATE != 1) {   // (timing-only ablation 1: no keep sweep)
+      if (bestM >= 0) {
         const int s1 = ovlStrand(L1[0]), s2 = ovlStrand(L2[0]);
         for (uint32_t i0 = 0; i0 < n1; i0 += PU * WG) {  // (PU rounds' loads in flight together, as in the pass above; the rounds' scans keep list order)
           T1kOvlP pa[PU], pb[PU];
@@ -617,7 +612,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(T1K_PAIR_WAV
       cleared = sFail != 0;
     }
     // ---- truncated-reference rule (2580-2653) -----------------------------------------------------------------------------
-    if (!cleared && nKept > 0 && paired && frags[keep[0]].i >= 0 && frags[keep[0]].j >= 0 && T1K_PAIR_ABLATE != 3) {   // (timing-only ablation 3: no sweep of the truncated-reference rule)
+    if (!cleared && nKept > 0 && paired && frags[keep[0]].i >= 0 && frags[keep[0]].j >= 0) {
       const Frag rep = frags[keep[0]];
       const T1kOvl r1 = L1[rep.i], r2 = L2[rep.j];
       const double r1s = ovlSim(r1), r2s = ovlSim(r2);
