@@ -138,7 +138,12 @@ __device__ __forceinline__ bool extendOne(const ExtendArgs &P, uint64_t gid, uns
   return true;
 }
 
-__global__ __launch_bounds__(WG) void k_extend(ExtendArgs P) {
+#if T1K_EXTEND_WAVES > 0
+#define T1K_EXTEND_ATTR T1K_WAVES_ATTR_(T1K_EXTEND_WAVES)
+#else
+#define T1K_EXTEND_ATTR
+#endif
+__global__ __launch_bounds__(WG) T1K_EXTEND_ATTR void k_extend(ExtendArgs P) {
   const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   unsigned int dp = 0;
   bool done = true;
@@ -1020,8 +1025,13 @@ __device__ inline bool ovlBeforeFull(const T1kOvl &a, const T1kOvl &b) {
   return a.seqEnd < b.seqEnd;
 }
 
+#if T1K_TRUNC_SMALL_WAVES > 0 || T1K_TRUNC_LARGE_WAVES > 0
+#define T1K_TRUNC_ATTR __attribute__((amdgpu_waves_per_eu(SELECT_LDS_CAP == SELECT_SMALL ? (T1K_TRUNC_SMALL_WAVES > 0 ? T1K_TRUNC_SMALL_WAVES : 1) : (T1K_TRUNC_LARGE_WAVES > 0 ? T1K_TRUNC_LARGE_WAVES : 1))))
+#else
+#define T1K_TRUNC_ATTR
+#endif
 template <int SELECT_LDS_CAP, int NT, bool XL>
-__global__ __launch_bounds__(NT) void k_truncate(TruncArgs P) {
+__global__ __launch_bounds__(NT) T1K_TRUNC_ATTR void k_truncate(TruncArgs P) {
   extern __shared__ uint64_t dynLds[];
   uint64_t *sKey = dynLds;
   __shared__ uint32_t sCut, sTie2;

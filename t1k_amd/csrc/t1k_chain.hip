@@ -1237,8 +1237,13 @@ __global__ __launch_bounds__(WG) void k_seed_long(ChainArgs P) {
 // items, so a grid sized from an estimate (t1k_run_chain) covers whatever the device counted.
 // LOOP = false (the host-driven launches: one item per thread, the grid covers the list) keeps the straight-line kernel: the loop costs the
 // closed-form pass 16 VGPRs and a wavefront per SIMD (78 -> 94).
+#if T1K_CF0_WAVES > 0
+#define T1K_CF_ATTR __attribute__((amdgpu_waves_per_eu(MODE == 0 && NW == 5 ? T1K_CF0_WAVES : 1)))
+#else
+#define T1K_CF_ATTR
+#endif
 template <int NW, int MODE, bool LOOP>
-__global__ __launch_bounds__(WG) void k_chain_fast(ChainArgs P, const uint32_t *list, uint32_t nItems, const unsigned long long *nDev) {
+__global__ __launch_bounds__(WG) T1K_CF_ATTR void k_chain_fast(ChainArgs P, const uint32_t *list, uint32_t nItems, const unsigned long long *nDev) {
   constexpr bool DEFER = MODE != 2;
   unsigned int dpLocal = 0, fastLocal = 0;
   if (nDev && P.counters[2]) return;  // an arena overflowed earlier in this submission: the range runs again, nothing of this pass is kept
@@ -1887,8 +1892,13 @@ __device__ __forceinline__ uint32_t pendingMatchWord(const ChainArgs &P, uint32_
 __device__ __forceinline__ bool recPending(uint32_t state) { return !(state & REC_DONE) && state >= 1u && state <= (uint32_t)GROUP_MAX_REFS; }
 
 // MAXLEN: longest read of the launch (T1K_MAX_READ_LEN, or T1K_LONG_READ_LEN for a window with longer reads: 16 KB of prefix counts)
+#if T1K_COLLECT_WAVES > 0
+#define T1K_COLLECT_ATTR T1K_WAVES_ATTR_(T1K_COLLECT_WAVES)
+#else
+#define T1K_COLLECT_ATTR
+#endif
 template <int MAXLEN>
-__global__ __launch_bounds__(WG) void k_collect(ChainArgs P) {
+__global__ __launch_bounds__(WG) T1K_COLLECT_ATTR void k_collect(ChainArgs P) {
   __shared__ uint32_t warpSums[4];
   __shared__ uint16_t sBaseCnt[2][4][MAXLEN + 1];
   __shared__ uint64_t sVote[2 * WG];

@@ -626,6 +626,23 @@ enum { T1K_STAT_DP = 0, T1K_STAT_FAST = 1, T1K_STAT_GENERAL = 2, T1K_STAT_EXTEND
 #ifndef T1K_OCC8
 #define T1K_OCC8 __attribute__((amdgpu_waves_per_eu(8)))
 #endif
+// (round 6) T1K_<KERNEL>_WAVES: the wavefronts per SIMD the register allocation of a kernel aims for; 0 = the compiler's own choice
+#define T1K_WAVES_ATTR_(n) __attribute__((amdgpu_waves_per_eu(n)))
+#ifndef T1K_COLLECT_WAVES
+#define T1K_COLLECT_WAVES 0
+#endif
+#ifndef T1K_EXTEND_WAVES
+#define T1K_EXTEND_WAVES 0
+#endif
+#ifndef T1K_CF0_WAVES
+#define T1K_CF0_WAVES 0
+#endif
+#ifndef T1K_TRUNC_SMALL_WAVES
+#define T1K_TRUNC_SMALL_WAVES 0
+#endif
+#ifndef T1K_TRUNC_LARGE_WAVES
+#define T1K_TRUNC_LARGE_WAVES 0
+#endif
 #define T1K_NSTRIPE 32
 enum { T1K_AR_GROUPS = 0, T1K_AR_JOBS, T1K_AR_RETRY, T1K_AR_FINISH, T1K_AR_GENERAL, T1K_AR_BIG, T1K_AR_GENCAND, T1K_AR_EQ, T1K_AR_BAND, T1K_AR_WIDE, T1K_AR_GENHITS, T1K_AR_GENJOBS, T1K_AR_WAVE, T1K_AR_EXTJOBS, T1K_AR_EXTRETRY, T1K_AR_SLOW, T1K_NARENA };
 #define T1K_ARENA_BASE (64 + T1K_STAT_STRIPES * 8)
