@@ -452,7 +452,7 @@ __device__ inline bool candBeforeFull(const T1kCand &a, const T1kCand &b) {
 // workgroups = SEVEN wavefronts: held to eight wavefronts' worth of registers it spilled 13 of them for an occupancy its LDS does not admit -- round 6,
 // as for k_seed_groups; T1K_SELECT_SMALL_WAVES)
 #ifndef T1K_SELECT_SMALL_WAVES
-#define T1K_SELECT_SMALL_WAVES 8
+#define T1K_SELECT_SMALL_WAVES 7
 #endif
 template <int SELECT_LDS_CAP, int NT, bool XL>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(SELECT_LDS_CAP == SELECT_SMALL ? T1K_SELECT_SMALL_WAVES : 8))) void k_select(SelectArgs P) {

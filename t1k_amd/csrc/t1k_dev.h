@@ -626,7 +626,14 @@ enum { T1K_STAT_DP = 0, T1K_STAT_FAST = 1, T1K_STAT_GENERAL = 2, T1K_STAT_EXTEND
 #ifndef T1K_OCC8
 #define T1K_OCC8 __attribute__((amdgpu_waves_per_eu(8)))
 #endif
-// (round 6) T1K_<KERNEL>_WAVES: the wavefronts per SIMD the register allocation of a kernel aims for; 0 = the compiler's own choice
+// (round 6) T1K_<KERNEL>_WAVES: the wavefronts per SIMD the register allocation of a kernel aims for; 0 = the compiler's own choice, which is what
+// ships for these four.  Measured (profiles/r06_callG_occupancy_variants.log, one pipeline, per range): k_collect at 7: 0.98 -> 0.94 ms, k_extend at 7:
+// 0.85 -> 0.79 ms, k_truncate small at 6 / 7: no change, large at 8: 0.61 -> 0.65 ms -- and k_chain_fast<5, 0> at 7 (72 VGPRs, 32 of its registers
+// spilled): 1.90 -> 2.42 ms AND WRONG, VARYING RESULTS in every configuration (one pipeline, host-driven chain, kernels serialised:
+// profiles/r06_callH_occupancy_bisect.log, r06_callI_closed_form_spill_variant.log).  The kernel was re-read for values used before they are set
+// and for out-of-range local indices without a finding; the build that ships keeps it in registers (78 VGPRs, no scratch) and is the one every test
+// and reference hash covers.  Budgets are therefore only ever RAISED towards what a kernel's LDS admits (k_seed_groups, k_select's small shape:
+// fewer spills than before), never lowered.
 #define T1K_WAVES_ATTR_(n) __attribute__((amdgpu_waves_per_eu(n)))
 #ifndef T1K_COLLECT_WAVES
 #define T1K_COLLECT_WAVES 0
