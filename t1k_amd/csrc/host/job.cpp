@@ -343,7 +343,7 @@ struct Window {
 }  // namespace
 
 
-int t1k_job_run_local(t1k_job *job) {
+static int runLocalOnce(t1k_job *job) {
   if (!job || !job->ctx) return jobFail(job, T1K_ERR_STATE, "this job has no GPU context (device = -1): it cannot run");
   if (!job->in) return jobFail(job, T1K_ERR_STATE, "no reads loaded");
   int rc;
@@ -1085,5 +1085,32 @@ int t1k_job_run_local(t1k_job *job) {
   job->localDone = true;
   return T1K_OK;
 }
+
+// A streamed .gz input whose text left the layout the streaming reader follows behind the head it checked (a blank line between two
+// records, a last record without its quality line, reads that get much shorter than the head's): the whole-file reader takes such
+// text as the reference's reader does (kseq.h:94-150), so the files are opened whole and the loop starts over -- nothing of the
+// failed run is kept (its partial read files are truncated by the new run).  Here and not in t1k_job_run: a caller
+// that drives t1k_job_run_local / t1k_job_finish itself gets the same fallback.
+int t1k_job_run_local(t1k_job *job) {
+  int rc = runLocalOnce(job);
+  if (rc != T1K_OK && job && job->in && job->in->streamGaveUp.load() && job->nRanks == 1) {
+    fprintf(stderr, "[t1k] %s -- the read files are opened whole and the job starts over\n", job->err.c_str());
+    std::unique_ptr<ReadInput> whole(new ReadInput());
+    const std::vector<std::string> f1 = job->in->streamFiles1, f2 = job->in->streamFiles2;
+    const std::string bc = job->in->streamBarcodeFile;
+    const bool drop = job->in->dropInflatedText;
+    job->in.reset();  // (its text reservations first: the whole reader inflates the files again)
+    const double t0 = nowMs();
+    std::string err;
+    if (!whole->open(f1, f2, bc, hostThreads(job), err)) return jobFail(job, T1K_ERR_IO, err);
+    whole->dropInflatedText = drop;
+    job->in = std::move(whole);
+    job->ran = false; job->localDone = false;
+    job->msLoad = nowMs() - t0;
+    rc = runLocalOnce(job);
+  }
+  return rc;
+}
+
 
 }  // extern "C"

@@ -88,26 +88,6 @@ int t1k_job_finish(t1k_job *job) {
 
 int t1k_job_run(t1k_job *job) {
   int rc = t1k_job_run_local(job);
-  // A streamed .gz input whose text left the layout the streaming reader follows behind the head it checked (a blank line between two
-  // records, a last record without its quality line, reads that get much shorter than the head's): the whole-file reader takes such
-  // text as the reference's reader does (kseq.h:94-150), so the files are opened whole and the job starts over -- nothing of the
-  // failed run is kept (its partial read files are truncated by the new run).
-  if (rc != T1K_OK && job && job->in && job->in->streamGaveUp.load() && job->nRanks == 1) {
-    fprintf(stderr, "[t1k] %s -- the read files are opened whole and the job starts over\n", job->err.c_str());
-    std::unique_ptr<ReadInput> whole(new ReadInput());
-    const std::vector<std::string> f1 = job->in->streamFiles1, f2 = job->in->streamFiles2;
-    const std::string bc = job->in->streamBarcodeFile;
-    const bool drop = job->in->dropInflatedText;
-    job->in.reset();  // (its text reservations first: the whole reader inflates the files again)
-    const double t0 = nowMs();
-    std::string err;
-    if (!whole->open(f1, f2, bc, hostThreads(job), err)) return jobFail(job, T1K_ERR_IO, err);
-    whole->dropInflatedText = drop;
-    job->in = std::move(whole);
-    job->ran = false; job->localDone = false;
-    job->msLoad = nowMs() - t0;
-    rc = t1k_job_run_local(job);
-  }
   if (rc == T1K_OK) rc = t1k_job_finish(job);
   // a rank of a sharded job that fails tells the others (they would wait for it in the next exchange otherwise)
   if (rc != T1K_OK && job && job->comm && job->nRanks > 1) (void)t1k_comm_abort(job->comm);

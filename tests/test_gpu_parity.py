@@ -82,6 +82,20 @@ def test_executable_vs_golden_reference_outputs(built, tmp_path, name):
     assert int(m.group(1)) == c.meta["assigned_fragments"] and m.group(2) == c.meta["avg_alleles"]
 
 
+@pytest.mark.parametrize("name", ["hla_synth_2x150", "cyp_dna_relax_2x150", "cyp_rna_2x100"])
+def test_linear_reference_windows_give_the_same_files(built, tmp_path, name):
+    """round 6: the closed-form pass of the chain reads the allele windows from a transposed copy of the reference (T1kRefDev::basesT); with
+    T1K_REF_TRANSPOSE=0 it reads the linear layout as every other kernel does -- both against the reference's committed files
+    (SeqSet.hpp:1697-1848 through the assignment table)"""
+    c = goldens.Case(name, str(tmp_path))
+    out = os.path.join(str(tmp_path), "lin")
+    r = subprocess.run([GENO] + c.args() + ["-o", out, "--outputReadAssignment"], stderr=subprocess.PIPE, text=True, env=dict(os.environ, T1K_REF_TRANSPOSE="0"))
+    assert r.returncode == 0, r.stderr
+    assert open(out + "_genotype.tsv").read() == c.expected("genotype.tsv")
+    assert open(out + "_allele.tsv").read() == c.expected("allele.tsv")
+    assert open(out + "_assign.tsv").read() == c.expected("assign.tsv.gz")
+
+
 def test_executable_vs_live_reference_binary(built):
     util.need(util.REF_BIN)  # decided when the test runs, after the `built` fixture had its chance to build oracle/_ref
     import gpu_e2e_check
@@ -1146,16 +1160,19 @@ def test_analyzer_variant_calling_vs_reference_binary(built, tmp_path, case):
 
 
 @pytest.mark.parametrize("het", [False, True])
-def test_analyzer_variant_fixtures(built, tmp_path, het):
+@pytest.mark.parametrize("env", [{}, {"T1K_ANALYZER_NO_FAST": "1"}, {"T1K_VARIANTS_THREADS": "5", "T1K_ANALYZER_PIECE": "64"}])
+def test_analyzer_variant_fixtures(built, tmp_path, het, env):
     """the same two samples without the reference binary at hand: this build's genotyper and analyzer against the committed files the
-    reference's chain wrote (tests/golden/analyzer_variants, tools/make_analyzer_variant_goldens.py)"""
+    reference's chain wrote (tests/golden/analyzer_variants, tools/make_analyzer_variant_goldens.py).  Round 6, three ways: as shipped (equal-length
+    alignments with at most two mismatches get their edit strings from the host threads), every alignment through the device's traced DP
+    (T1K_ANALYZER_NO_FAST), and with the booking sweeps of the variant caller threaded over five pieces of the fragments and pieces of 64 read-ends."""
     tmp = str(tmp_path)
     ref, pfx = util.novel_snp_sample(tmp, het)
     g, a = os.path.join(tmp, "g"), os.path.join(tmp, "a")
     r = subprocess.run([GENO, "-f", ref, "-1", pfx + "_1.fq", "-2", pfx + "_2.fq", "--barcode", pfx + "_bc.fa", "-o", g], stderr=subprocess.PIPE, text=True)
     assert r.returncode == 0, r.stderr
     r = subprocess.run([ANALYZER, "-f", ref, "-a", g + "_allele.tsv", "-1", g + "_aligned_1.fa", "-2", g + "_aligned_2.fa", "--barcode", g + "_aligned_bc.fa", "-o", a, "-t", "4"],
-                       stderr=subprocess.PIPE, text=True)
+                       stderr=subprocess.PIPE, text=True, env=dict(os.environ, **env))
     assert r.returncode == 0, r.stderr
     gold = os.path.join(util.GOLDEN, "analyzer_variants", "het" if het else "homo")
     assert open(a + "_allele.vcf").read() == open(gold + "_allele.vcf").read()
