@@ -469,9 +469,14 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(SELECT_LDS_C
   // for a free CU would otherwise hold up its whole fixed share of them.  (Alone the kernels are 20 - 35 % faster for it; under three
   // pipelines the step is not: what one kernel gives back the others take.  64 at a time with the counts pre-read was slower.)
   __shared__ uint32_t sNextRe;
+  uint32_t hoNext = 0, hoLeft = 0;  // thread 0: what it holds from its last hand-out
   for (;;) {
     __syncthreads();
-    if (tid == 0) sNextRe = (uint32_t)atomicAdd(&P.counters[SELECT_LDS_CAP == SELECT_SMALL ? 28 : 29], 1ull);
+    if (tid == 0) {  // (T1K_RE_HANDOUT read-ends per atomic on the hand-out word: round 6)
+      constexpr uint32_t HO = SELECT_LDS_CAP == SELECT_SMALL ? T1K_SELECT_SMALL_HANDOUT : T1K_SELECT_LARGE_HANDOUT;
+      if (hoLeft == 0) { hoNext = (uint32_t)atomicAdd(&P.counters[SELECT_LDS_CAP == SELECT_SMALL ? 28 : 29], (unsigned long long)HO); hoLeft = HO; }
+      sNextRe = hoNext++; --hoLeft;
+    }
     __syncthreads();
     const uint32_t re = sNextRe;
     if (re >= P.reads.nReadEnds) break;
@@ -1040,9 +1045,14 @@ __global__ __launch_bounds__(NT) T1K_TRUNC_ATTR void k_truncate(TruncArgs P) {
   __shared__ uint16_t sCnt[256 * (NT / 64)];
   const int tid = threadIdx.x;
   __shared__ uint32_t sNextRe;  // read-ends handed out one at a time, as in k_select
+  uint32_t hoNext = 0, hoLeft = 0;
   for (;;) {
     __syncthreads();
-    if (tid == 0) sNextRe = (uint32_t)atomicAdd(&P.counters[SELECT_LDS_CAP == SELECT_SMALL ? 30 : 31], 1ull);
+    if (tid == 0) {  // (T1K_RE_HANDOUT read-ends per atomic on the hand-out word: round 6)
+      constexpr uint32_t HO = SELECT_LDS_CAP == SELECT_SMALL ? T1K_TRUNC_SMALL_HANDOUT : T1K_TRUNC_LARGE_HANDOUT;
+      if (hoLeft == 0) { hoNext = (uint32_t)atomicAdd(&P.counters[SELECT_LDS_CAP == SELECT_SMALL ? 30 : 31], (unsigned long long)HO); hoLeft = HO; }
+      sNextRe = hoNext++; --hoLeft;
+    }
     __syncthreads();
     const uint32_t re = sNextRe;
     if (re >= P.reads.nReadEnds) break;

@@ -1921,9 +1921,13 @@ __global__ __launch_bounds__(WG) T1K_COLLECT_ATTR void k_collect(ChainArgs P) {
   const uint32_t stride = P.recStride;
   if (P.devDriven && P.counters[2]) return;  // an arena overflowed earlier in this submission: the range runs again
   __shared__ uint32_t sNextRe;  // read-ends handed out one at a time (device counter): their group counts differ by orders of magnitude
+  uint32_t hoNext = 0, hoLeft = 0;
   for (;;) {
     __syncthreads();
-    if (tid == 0) sNextRe = (uint32_t)atomicAdd(&P.counters[27], 1ull);
+    if (tid == 0) {  // (T1K_RE_HANDOUT read-ends per atomic on the hand-out word: round 6)
+      if (hoLeft == 0) { hoNext = (uint32_t)atomicAdd(&P.counters[27], (unsigned long long)T1K_COLLECT_HANDOUT); hoLeft = T1K_COLLECT_HANDOUT; }
+      sNextRe = hoNext++; --hoLeft;
+    }
     __syncthreads();
     const uint32_t re = sNextRe;
     if (re >= P.reads.nReadEnds) break;

@@ -635,6 +635,26 @@ enum { T1K_STAT_DP = 0, T1K_STAT_FAST = 1, T1K_STAT_GENERAL = 2, T1K_STAT_EXTEND
 // and reference hash covers.  Budgets are therefore only ever RAISED towards what a kernel's LDS admits (k_seed_groups, k_select's small shape:
 // fewer spills than before), never lowered.
 #define T1K_WAVES_ATTR_(n) __attribute__((amdgpu_waves_per_eu(n)))
+// read-ends a workgroup takes per atomic on its kernel's hand-out word (round 6, profiles/r06_callL_hot_word_atomics.log, one pipeline, per range of 32 768
+// read-ends).  A returning atomic on one word saturates near 88 M/s on this part: 32 768 hand-outs are 0.37 ms, which is what a kernel that SKIPS most read-ends
+// lasts -- k_truncate's 256-thread shape (lists of 1001 .. 2048 overlaps): 0.450 ms one at a time, 0.267 two, 0.223 four, 0.234 eight.  Kernels that work on
+// every read-end trade it against balance: k_select's 256-thread shape 0.509 / 0.478 / 0.503 / 0.550 ms, its 1024-thread shape 0.957 / 0.94 / 0.97 / 1.00,
+// k_truncate's 1024-thread shape 0.615 / 0.604 / 0.62 / 0.64, k_collect 0.98 / 1.19 / 1.38 / 1.56 (its read-ends' cost spans orders of magnitude).
+#ifndef T1K_COLLECT_HANDOUT
+#define T1K_COLLECT_HANDOUT 1
+#endif
+#ifndef T1K_SELECT_SMALL_HANDOUT
+#define T1K_SELECT_SMALL_HANDOUT 2
+#endif
+#ifndef T1K_SELECT_LARGE_HANDOUT
+#define T1K_SELECT_LARGE_HANDOUT 1
+#endif
+#ifndef T1K_TRUNC_SMALL_HANDOUT
+#define T1K_TRUNC_SMALL_HANDOUT 4
+#endif
+#ifndef T1K_TRUNC_LARGE_HANDOUT
+#define T1K_TRUNC_LARGE_HANDOUT 1
+#endif
 #ifndef T1K_COLLECT_WAVES
 #define T1K_COLLECT_WAVES 0
 #endif

@@ -63,6 +63,12 @@ __device__ __forceinline__ unsigned long long t1k_pattern_mix(uint32_t allele, u
 #ifndef T1K_PAIR_UNROLL
 #define T1K_PAIR_UNROLL 2
 #endif
+#ifndef T1K_PAIR_HANDOUT
+#define T1K_PAIR_HANDOUT 4   // fragments a workgroup takes per hand-out atomic (1 / 2 / 4 / 8 alone: 1.296 / 1.299 / 1.320 / 1.43 ms; under three pipelines 4 + the row reservation: -0.6 % of the step)
+#endif
+#ifndef T1K_ROW_RESERVE
+#define T1K_ROW_RESERVE 32   // row entries a workgroup reserves per atomic on the rowset's cursor (0: every row its own)
+#endif
 #ifndef T1K_PAIR_WAVES
 #define T1K_PAIR_WAVES 4   // wavefronts per SIMD the register allocation of k_pair is held to (the join table's LDS admits four workgroups per compute unit)
 #endif
@@ -226,9 +232,21 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(T1K_PAIR_WAV
   const uint32_t nItems = P.only ? (uint32_t)P.counters[23] : P.nFragments;
   // fragments are handed out one at a time (a device counter per launch): their cost spans two orders of magnitude (0 .. 8192 and more
   // overlaps), and with a fixed stride the kernel lasted as long as its unluckiest workgroup
+  // Round 6: a fragment cost FOUR atomics on three hot words of the counter block -- the hand-out and the row cursor (both returning), the
+  // "overlap records read" and "row entries" statistics -- 260 k atomics per launch of 65 536 fragments into two cache lines, on a part whose
+  // returning atomics on one word saturate near 88 M/s ("striped allocation"): at 1.4 ms a launch the kernel sat at half of that rate on
+  // each word.  The hand-out now takes T1K_PAIR_HANDOUT fragments at a time (their cost is uneven: no more than a few), the two statistics are
+  // summed per workgroup (thread 0's registers) and flushed once.
   __shared__ uint32_t sItem;
+  uint32_t hoNext = 0, hoLeft = 0;                         // thread 0: the fragments it holds from its last hand-out
+  unsigned long long statOvl = 0, statRows = 0;            // thread 0
+  unsigned long long rowNext = 0; uint32_t rowLeft = 0;    // thread 0: what is left of its last reservation in the rowset's chunk
   for (;;) {
-    if (tid == 0) { sItem = (uint32_t)atomicAdd(&P.counters[P.only ? 26 : 25], 1ull); sDup = 0; sFail = 0; sBestM = -1; sBestIdx = 0x7FFFFFFF; sAnySep = 0; sNotOne = 0; sN = 0; }
+    if (tid == 0) {
+      if (hoLeft == 0) { hoNext = (uint32_t)atomicAdd(&P.counters[P.only ? 26 : 25], (unsigned long long)T1K_PAIR_HANDOUT); hoLeft = T1K_PAIR_HANDOUT; }
+      sItem = hoNext++; --hoLeft;
+      sDup = 0; sFail = 0; sBestM = -1; sBestIdx = 0x7FFFFFFF; sAnySep = 0; sNotOne = 0; sN = 0;
+    }
     __syncthreads();
     const uint32_t it = sItem;
     if (it >= nItems) break;
@@ -270,7 +288,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(T1K_PAIR_WAV
       __syncthreads();
       continue;
     }
-    if (tid == 0 && n1 + n2) atomicAdd(&P.counters[22], (unsigned long long)(n1 + n2));  // statistics: overlap records read (by the launch that pairs the fragment)
+    if (tid == 0) statOvl += n1 + n2;  // statistics: overlap records read (by the launch that pairs the fragment)
     // ---- duplicate detection + join table --------------------------------------------------------------------------
     bool lds = n1 + n2 <= LJ_CAP;
     if (lds) {
@@ -724,9 +742,20 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(T1K_PAIR_WAV
     static_assert(SORT_TILE <= LJ_SLOTS, "the rank-sort tile lives in the join table's keys");
     __shared__ unsigned long long sHash[2][NWAVE];
     if (tid == 0) {
-      unsigned long long b = nRow ? atomicAdd(P.rsCursor, (unsigned long long)nRow) : 0ull;
-      if (b + nRow > P.rsCap) { atomicOr(&P.counters[2], 128ull); sRowBase = ~0ull; }
-      else { sRowBase = b; if (nRow) atomicAdd(&P.counters[9], (unsigned long long)nRow); }
+      // (the row cursor: T1K_ROW_RESERVE > 0 takes that many entries at a time -- a row holds ~14 -- and serves the workgroup's next rows from what is
+      // left; what a workgroup holds when the launch ends stays empty in the chunk: rows are found through rsRowPtr, never by position)
+      unsigned long long b = 0;
+      bool fitsChunk = true;
+      if (nRow) {
+        if (T1K_ROW_RESERVE > 0 && nRow <= rowLeft) { b = rowNext; rowNext += nRow; rowLeft -= nRow; }
+        else {
+          const unsigned long long take = (unsigned long long)(T1K_ROW_RESERVE > 0 && nRow < (uint32_t)T1K_ROW_RESERVE ? (uint32_t)T1K_ROW_RESERVE : nRow);
+          b = atomicAdd(P.rsCursor, take);
+          if (b + take > P.rsCap) fitsChunk = false; else { rowNext = b + nRow; rowLeft = (uint32_t)(take - nRow); }
+        }
+      }
+      if (!fitsChunk) { atomicOr(&P.counters[2], 128ull); sRowBase = ~0ull; }
+      else { sRowBase = b; statRows += nRow; }
     }
     // rank of every entry among the row's (distinct) alleles
     for (uint32_t q = tid; q < nRow; q += WG) frags[keep[q]].slot = 0;
@@ -778,6 +807,10 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(T1K_PAIR_WAV
     }
     __syncthreads();
     PP(7);
+  }
+  if (tid == 0) {  // the workgroup's statistics, once
+    if (statOvl) atomicAdd(&P.counters[22], statOvl);
+    if (statRows) atomicAdd(&P.counters[9], statRows);
   }
 #ifdef T1K_PAIR_PROFILE
   if (tid == 0) for (int i = 0; i < 8; ++i) atomicAdd(&P.counters[32 + i], (unsigned long long)tp_[i]);
