@@ -941,10 +941,13 @@ static int assignOnce(t1k_ctx *ctx, uint64_t first, uint32_t count) {
   }
   if ((rc = t1k_ensure(ctx, ctx->bOvlWork, (size_t)ctx->wOvl * sizeof(T1kOvl)))) return rc;
   ctx->ovlBase = (T1kOvl *)ctx->bOvlWork.p;
-  if ((rc = t1k_ensure(ctx, ctx->bCandStart, (size_t)n * 4))) return rc;
-  if ((rc = t1k_ensure(ctx, ctx->bCandCount, (size_t)n * 4))) return rc;
-  if ((rc = t1k_ensure(ctx, ctx->bOvlStart, (size_t)n * 4))) return rc;
-  if ((rc = t1k_ensure(ctx, ctx->bOvlCount, (size_t)n * 4))) return rc;
+  // (n + 1 entries each: the two counts are cleared one entry past the range.  Since round 1 the blocks were asked for n entries and cleared for n + 1 --
+  // inside the block's slack of an eighth + 256 bytes except when a LATER range of the context had exactly that many more read-ends than its first:
+  // 29 read-ends first, 96 later -> 386 bytes held, 388 cleared, "hipMemsetAsync: invalid argument".  Found by the fuzz file under 96-read-end ranges, round 6)
+  if ((rc = t1k_ensure(ctx, ctx->bCandStart, (size_t)(n + 1) * 4))) return rc;
+  if ((rc = t1k_ensure(ctx, ctx->bCandCount, (size_t)(n + 1) * 4))) return rc;
+  if ((rc = t1k_ensure(ctx, ctx->bOvlStart, (size_t)(n + 1) * 4))) return rc;
+  if ((rc = t1k_ensure(ctx, ctx->bOvlCount, (size_t)(n + 1) * 4))) return rc;
   if ((rc = t1k_ensure(ctx, ctx->bSortScratch, (size_t)std::min(nWg, 512) * sortCap * 48))) return rc;  // only the kernels launched with <= 512 workgroups use it
   T1K_HIP(ctx, hipMemsetAsync(ctx->bCounters.p, 0, (size_t)T1K_COUNTER_WORDS * 8, ctx->stream));
   T1K_HIP(ctx, hipMemsetAsync(ctx->bOvlCount.p, 0, (size_t)n * 4 + 4, ctx->stream));

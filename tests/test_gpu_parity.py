@@ -594,6 +594,31 @@ def test_own_input_sharding_over_several_files_per_mate(built, tmp_path, gpus):
         assert open(out + suf, "rb").read() == open(one + suf, "rb").read(), suf
 
 
+def test_later_range_one_entry_past_a_smaller_first_range(built, tmp_path):
+    """round 6 (found by tests/test_gpu_fuzz.py under 96-read-end ranges): a context's per-read-end count blocks were asked for n entries and cleared for
+    n + 1; a block keeps an eighth + 256 bytes of slack, so the clear stayed inside it unless a LATER range of the context had exactly the number of
+    read-ends at which the slack ends -- 29 read-ends first, 96 later: 386 bytes held, 388 cleared, `hipMemsetAsync: invalid argument` and a failed job.
+    Here: one pipeline, a first window of 15 fragments with 29 distinct read-ends (two of its read-ends are the same sequence), then ranges of 96; the
+    files must equal the ones of an undisturbed run."""
+    tmp = str(tmp_path)
+    ref = os.path.join(tmp, "ref.fa")
+    util.synth_ref("ref-rna", ref, genes=3, scale=0.05, seed=77)
+    util.synth_reads(ref, os.path.join(tmp, "r"), pairs=900, len=150, seed=78)
+    l1 = open(os.path.join(tmp, "r_1.fq")).read().split("\n")
+    l1[4 * 2 + 1] = l1[1]      # fragment 2's first mate = fragment 0's: 29 distinct read-ends among the first 15 fragments
+    open(os.path.join(tmp, "r_1.fq"), "w").write("\n".join(l1))
+    args = [GENO, "-f", ref, "-1", os.path.join(tmp, "r_1.fq"), "-2", os.path.join(tmp, "r_2.fq"), "-s", "0.9", "--outputReadAssignment"]
+    a, b = os.path.join(tmp, "plain"), os.path.join(tmp, "ranges")
+    r = subprocess.run(args + ["-o", a], stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 0, r.stderr[-1500:]
+    for first in ("15", "14", "16"):   # (14 / 16: neighbours of the size that hit the slack's end)
+        env = dict(os.environ, T1K_PIPELINES="1", T1K_FIRST_WINDOW=first, T1K_WINDOW="512", T1K_BATCH="48", T1K_PAIR_BATCH="96", T1K_CROSS_WINDOW="0")
+        r = subprocess.run(args + ["-o", b], stderr=subprocess.PIPE, text=True, env=env)
+        assert r.returncode == 0, (first, r.stderr[-1500:])
+        for suf in ("_genotype.tsv", "_allele.tsv", "_assign.tsv", "_aligned_1.fa", "_aligned_2.fa"):
+            assert open(a + suf).read() == open(b + suf).read(), (first, suf)
+
+
 @pytest.mark.parametrize("name", ["hla_synth_2x150", "cyp_dna_relax_2x150", "cyp_rna_single"])
 @pytest.mark.parametrize("env", [{"T1K_FIRST_WINDOW": "8", "T1K_WINDOW": "96", "T1K_BATCH": "8", "T1K_PAIR_BATCH": "16"},
                                  {"T1K_FIRST_WINDOW": "24", "T1K_WINDOW": "48", "T1K_WINDOW_GROWTH": "1", "T1K_BATCH": "16", "T1K_PAIR_BATCH": "8", "T1K_PIPELINES": "2"},
