@@ -647,7 +647,7 @@ extern "C++" int t1k_fetch_counters(t1k_ctx *ctx, unsigned long long *h) {
   memcpy(raw.data(), ctx->countersPinned, (size_t)T1K_COUNTER_WORDS * 8);
   memcpy(h, raw.data(), 64 * 8);
   h[6] = 0;  // group records: sum of the arena's segment cursors
-  for (int s = 0; s < T1K_NSTRIPE; ++s) h[6] += raw[T1K_ARENA_BASE + ((size_t)T1K_AR_GROUPS * T1K_NSTRIPE + s) * 8];
+  for (int s = 0; s < T1K_NSTRIPE; ++s) h[6] += raw[T1K_ARENA_BASE + ((size_t)T1K_AR_GROUPS * T1K_NSTRIPE + s) * T1K_STRIPE_WORDS];
   for (int s = 56; s < 64; ++s) h[6] += raw[s];  // ... + the groups the fused seeding kernel ended without a record
   static const int slot[8] = {7, 11, 12, 14, 10, 3, 4, 5};
   for (int s = 0; s < T1K_STAT_STRIPES; ++s)
@@ -675,7 +675,7 @@ static int capacityError(t1k_ctx *ctx, unsigned long long flags) {
   if (ctx->hRaw.size() >= T1K_COUNTER_WORDS) {
     auto maxSeg = [&](int arena) {
       unsigned long long m = 0;
-      for (int st = 0; st < T1K_NSTRIPE; ++st) m = std::max(m, ctx->hRaw[T1K_ARENA_BASE + ((size_t)arena * T1K_NSTRIPE + st) * 8]);
+      for (int st = 0; st < T1K_NSTRIPE; ++st) m = std::max(m, ctx->hRaw[T1K_ARENA_BASE + ((size_t)arena * T1K_NSTRIPE + st) * T1K_STRIPE_WORDS]);
       return m;
     };
     unsigned long long lists = 0, rare = 0;

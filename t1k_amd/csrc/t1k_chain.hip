@@ -2118,15 +2118,15 @@ static int readCounters(t1k_ctx *ctx, unsigned long long *h) { return t1k_fetch_
 // count from the device, and raises `overflowFlag` in the control word when a stripe is full (the range then runs again with larger lists).
 template <class V>
 __global__ __launch_bounds__(WG) void k_arena_compact(const V *src, uint32_t segCap, unsigned long long *counters, int arena, V *dst, unsigned long long overflowFlag) {
-  const unsigned long long *cursors = counters + T1K_ARENA_BASE + (size_t)arena * T1K_NSTRIPE * 8;
+  const unsigned long long *cursors = counters + T1K_ARENA_BASE + (size_t)arena * T1K_NSTRIPE * T1K_STRIPE_WORDS;
   const uint32_t seg = blockIdx.y;
   uint32_t prefix = 0;
-  for (uint32_t s = 0; s < seg; ++s) prefix += (uint32_t)min(cursors[s * 8], (unsigned long long)segCap);
-  const uint32_t cnt = (uint32_t)min(cursors[seg * 8], (unsigned long long)segCap);
+  for (uint32_t s = 0; s < seg; ++s) prefix += (uint32_t)min(cursors[s * T1K_STRIPE_WORDS], (unsigned long long)segCap);
+  const uint32_t cnt = (uint32_t)min(cursors[seg * T1K_STRIPE_WORDS], (unsigned long long)segCap);
   if (blockIdx.x == 0 && seg == T1K_NSTRIPE - 1 && threadIdx.x == 0) {
     counters[T1K_TOTAL_BASE + arena] = (unsigned long long)prefix + cnt;
     bool over = false;
-    for (uint32_t s = 0; s < T1K_NSTRIPE; ++s) over = over || cursors[s * 8] > (unsigned long long)segCap;
+    for (uint32_t s = 0; s < T1K_NSTRIPE; ++s) over = over || cursors[s * T1K_STRIPE_WORDS] > (unsigned long long)segCap;
     if (over && overflowFlag) atomicOr(&counters[2], overflowFlag);
   }
   for (uint32_t i = blockIdx.x * WG + threadIdx.x; i < cnt; i += gridDim.x * WG) dst[prefix + i] = src[(uint64_t)seg * segCap + i];
@@ -2135,7 +2135,7 @@ __global__ __launch_bounds__(WG) void k_arena_compact(const V *src, uint32_t seg
 T1kArenaCounts t1k_arena_counts(const t1k_ctx *ctx, int arena, uint32_t segCap) {
   T1kArenaCounts r{0, 0, false};
   for (int s = 0; s < T1K_NSTRIPE; ++s) {
-    unsigned long long c = ctx->hRaw[T1K_ARENA_BASE + ((size_t)arena * T1K_NSTRIPE + s) * 8];
+    unsigned long long c = ctx->hRaw[T1K_ARENA_BASE + ((size_t)arena * T1K_NSTRIPE + s) * T1K_STRIPE_WORDS];
     if (c > segCap) { r.overflow = true; c = segCap; }
     r.total += c;
     r.maxSeg = std::max<uint32_t>(r.maxSeg, (uint32_t)c);

@@ -676,11 +676,14 @@ enum { T1K_AR_GROUPS = 0, T1K_AR_JOBS, T1K_AR_RETRY, T1K_AR_FINISH, T1K_AR_GENER
 // behind the cursors: one word per arena = the number of entries of its DENSE list (sum over the stripes of min(cursor, segCap)), written by
 // k_arena_compact where it makes the list dense -- the list's consumers read their item count there instead of from a launch argument, so
 // the host does not have to fetch the cursors between a producer and its consumers (t1k_run_chain: one counter fetch per range)
-#define T1K_TOTAL_BASE (T1K_ARENA_BASE + T1K_NARENA * T1K_NSTRIPE * 8)
+#ifndef T1K_STRIPE_WORDS
+#define T1K_STRIPE_WORDS 8   // 64-bit words between the cursors of two stripes of an arena (8: 64 bytes apart; 16: a 128-byte cache line each)
+#endif
+#define T1K_TOTAL_BASE (T1K_ARENA_BASE + T1K_NARENA * T1K_NSTRIPE * T1K_STRIPE_WORDS)
 #define T1K_COUNTER_WORDS (T1K_TOTAL_BASE + ((T1K_NARENA + 7) & ~7))
 #define T1K_ARENA_FULL 0xFFFFFFFFu
 __device__ __forceinline__ unsigned long long *t1k_arena_cursor(unsigned long long *counters, int arena, uint32_t stripe) {
-  return counters + T1K_ARENA_BASE + ((uint32_t)arena * T1K_NSTRIPE + stripe) * 8;
+  return counters + T1K_ARENA_BASE + ((uint32_t)arena * T1K_NSTRIPE + stripe) * T1K_STRIPE_WORDS;
 }
 // n consecutive slots in this workgroup's segment -> global slot index (segment * segCap + offset), or T1K_ARENA_FULL.
 // The cursor keeps counting past segCap, which is how the host sees the overflow.
